@@ -1,0 +1,122 @@
+/*
+ * orc.h — CPU ORACLE for the gr_modem RX/TX DSP hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product library (libqrl_hip.so)
+ * never links, loads or calls anything in this directory.
+ *
+ * PARITY UNPINNED: the reference (qradiolink @ 2025-06-14) ships no tests, golden vectors
+ * or fixtures, and its arithmetic lives in un-vendored GNU Radio 3.10 / VOLK, which is
+ * not installable here.  This oracle restates the published
+ * GNU Radio 3.10 block semantics from the upstream algorithm descriptions; every chain
+ * function cites the reference file:line whose topology and parameters it follows.
+ * It is pinned only by (i) constants quoted from upstream (tap counts, MMSE rows, atan /
+ * tanh table endpoints) and (ii) mod -> channel -> demod loopback known-answer tests.
+ *
+ * ARITHMETIC CONTRACT (what makes GPU results bit-identical to this oracle):
+ *   - IEEE-754 binary32, round-to-nearest-even, no flush-to-zero, compiled with
+ *     -ffp-contract=off: a fused multiply-add happens only where fmaf() is written.
+ *   - FIR dot products are fmaf chains in the order documented at each function
+ *     (VOLK leaves the summation order to the SIMD ISA; we fix one).
+ *   - run-time sin/cos (NCOs of rotator, FLL, Costas) use orc_sincosf()/orc_sincos_turn(),
+ *     a fixed polynomial, so results do not depend on the libm of the machine.
+ *   - design-time constants (taps, loop gains, tables) are computed in double and
+ *     rounded once to float.
+ */
+#ifndef ORC_H
+#define ORC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float re, im; } cf32;
+
+/* ---------- deterministic math ---------- */
+void  orc_sincosf(float x, float* s, float* c);            /* |x| <= ~8 rad */
+void  orc_sincos_turn(uint64_t angle, float* s, float* c); /* angle in 2^-64 turns */
+float orc_fast_atan2f(float y, float x);                   /* gnuradio fast_atan2f */
+float orc_tanhf_lut(float x);                              /* gnuradio tanhf_lut */
+const float* orc_atan_table(void);  /* 257 entries */
+const float* orc_tanh_table(void);  /* 256 entries */
+const float* orc_mmse_table(void);  /* 129 x 8 */
+
+/* ---------- firdes (gr-filter/lib/firdes.cc, gr-fft/lib/window.cc) ---------- */
+enum { ORC_WIN_HAMMING = 0, ORC_WIN_HANN = 1, ORC_WIN_BLACKMAN = 2, ORC_WIN_RECTANGULAR = 3,
+       ORC_WIN_BLACKMAN_HARRIS = 5 };
+int orc_window(int type, int ntaps, float* w);
+int orc_compute_ntaps(double fs, double tw, int win);
+int orc_compute_ntaps_windes(double fs, double tw, double atten_db);
+/* each returns ntaps; if taps==NULL only the count is returned */
+int orc_low_pass(double gain, double fs, double fc, double tw, int win, float* taps);
+int orc_low_pass_2(double gain, double fs, double fc, double tw, double atten_db, int win, float* taps);
+int orc_complex_band_pass(double gain, double fs, double lo, double hi, double tw, int win, cf32* taps);
+int orc_root_raised_cosine(double gain, double fs, double symrate, double alpha, int ntaps, float* taps);
+int orc_gaussian(double gain, double spb, double bt, int ntaps, float* taps);
+void orc_fll_taps(float sps, float rolloff, int n, cf32* lower, cf32* upper);
+void orc_control_loop_gains(float bw, float* alpha, float* beta);
+void orc_clock_loop_gains(float loop_bw, float zeta, float ted_gain, float* alpha, float* beta);
+
+/* ---------- stream blocks (one-shot over a finite stream, zero initial state) ---------- */
+uint64_t orc_phase_inc_to_turn(double radians_per_sample);
+void   orc_rotator(const cf32* in, size_t n, uint64_t inc, uint64_t acc0, cf32* out);
+size_t orc_decim_count(size_t n, int interp, int decim);
+size_t orc_decim_fir_ccf(const cf32* in, size_t n, const float* taps, int nt, int decim, int nsplit, cf32* out);
+size_t orc_resamp_ccf(const cf32* in, size_t n, const float* taps, int nt, int interp, int decim, cf32* out);
+size_t orc_resamp_fff(const float* in, size_t n, const float* taps, int nt, int interp, int decim, float* out);
+void   orc_fir_ccf(const cf32* in, size_t n, const float* taps, int nt, cf32* out);
+void   orc_fir_ccc(const cf32* in, size_t n, const cf32* taps, int nt, cf32* out);
+void   orc_fir_fff(const float* in, size_t n, const float* taps, int nt, float* out);
+void   orc_fll_band_edge(const cf32* in, size_t n, float sps, float rolloff, int ntaps, float bw, cf32* out);
+void   orc_quad_demod(const cf32* in, size_t n, float gain, float* out);
+void   orc_agc2(const cf32* in, size_t n, float attack, float decay, float ref, float gain, float max_gain, cf32* out);
+void   orc_costas(const cf32* in, size_t n, float bw, int order, int use_snr, cf32* out);
+enum { ORC_TED_MM = 0, ORC_TED_MOD_MM = 1 };
+enum { ORC_CONST_BPSK = 0, ORC_CONST_DQPSK = 1, ORC_CONST_4LEVEL = 2 };
+size_t orc_symbol_sync_ff(const float* in, size_t n, int ted, float sps, float loop_bw, float damping,
+                          float ted_gain, float max_dev, int constellation, float* out);
+size_t orc_symbol_sync_cc(const cf32* in, size_t n, int ted, float sps, float loop_bw, float damping,
+                          float ted_gain, float max_dev, int constellation, cf32* out);
+void   orc_diff_phasor(const cf32* in, size_t n, cf32* out);
+void   orc_soft_quant(const float* in, size_t n, float mul, float add, uint8_t* out);
+size_t orc_cc_decode_k7(const uint8_t* soft, size_t n, uint8_t* bits);   /* streaming, frame 80 */
+void   orc_descramble(const uint8_t* in, size_t n, uint32_t mask, uint32_t seed, int len, uint8_t* out);
+void   orc_scramble(const uint8_t* in, size_t n, uint32_t mask, uint32_t seed, int len, uint8_t* out);
+void   orc_cc_encode_k7(const uint8_t* bits, size_t n, uint8_t* out /* 2n */);
+
+/* ---------- chains (reference hier blocks) ---------- */
+typedef struct {
+    size_t n_filtered, n_const, n_bits_a, n_bits_b;
+    cf32* filtered;     /* port 0 */
+    cf32* constellation;/* port 1 */
+    uint8_t* bits_a;    /* port 2 */
+    uint8_t* bits_b;    /* port 3 (2-branch modes) */
+} orc_demod_out;
+void orc_demod_out_free(orc_demod_out* o);
+
+/* RX front end of gr_demod_base: rotator (+ decimator when fs >= 2 Msps). Returns count. */
+size_t orc_frontend(const cf32* in, size_t n, int samp_rate, double carrier_offset_hz, cf32* out);
+int    orc_frontend_taps(int samp_rate, float* taps); /* count; 0 if no resampler */
+
+void orc_demod_2fsk(const cf32* in, size_t n, int sps, int samp_rate, int carrier_freq, int filter_width, int fm, orc_demod_out* o);
+void orc_demod_gmsk(const cf32* in, size_t n, int sps, int samp_rate, int carrier_freq, int filter_width, orc_demod_out* o);
+void orc_demod_qpsk(const cf32* in, size_t n, int sps, int samp_rate, int carrier_freq, int filter_width, orc_demod_out* o);
+
+/* modulators: packed bytes in -> cf32 @ samp_rate out; returns sample count (out may be NULL to size) */
+size_t orc_mod_2fsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, int fm, cf32* out);
+size_t orc_mod_gmsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, cf32* out);
+size_t orc_mod_qpsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, cf32* out);
+/* TX back end of gr_mod_base: interpolate 1 Msps -> fs with low_pass(I, fs, 480k, 20k, BH) */
+size_t orc_tx_interp(const cf32* in, size_t n, int samp_rate, cf32* out);
+
+/* batch drivers (OpenMP over streams) used by the cpu_baseline leg of bench.py */
+enum { ORC_MODE_2FSK_1K = 0, ORC_MODE_GMSK_10K = 1, ORC_MODE_QPSK_250K = 2 };
+double orc_batch_rx(int mode, const cf32* iq, int batch, size_t n, int samp_rate, double carrier_offset_hz,
+                    int threads, uint64_t* bit_checksum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,500 @@
+/* orc_blocks.c — stream blocks of the oracle (TEST INFRASTRUCTURE; see orc.h).
+ * Each function restates one GNU Radio 3.10 block [GR-MEM] over a finite stream with the
+ * block's zero initial state.  "exists iff" rules give the output counts of an infinite
+ * stream truncated after n inputs, which is what makes results chunk-size independent. */
+#include "orc.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * rotator_cc  [gr-blocks/lib/rotator_cc_impl.cc, volk_32fc_s32fc_x2_rotator_32fc]
+ * out[n] = in[n] * e^{j angle(n)}, angle(n) = acc0 + n*inc exact in 2^-64 turns (drift-free NCO;
+ * VOLK's float recurrence with renormalisation every 512 samples drifts, ours does not).
+ * phase(n) = T_hi(n>>9) (x) T_lo(n&511) with T_hi(b) = sincos_turn(acc0 + 512*b*inc),
+ * T_lo(r) = sincos_turn(r*inc); both complex products use the fmaf pattern below.
+ * ------------------------------------------------------------------------------------------ */
+uint64_t orc_phase_inc_to_turn(double rad)
+{
+    double t = rad / (2.0 * M_PI);
+    t -= floor(t);
+    if (t >= 1.0) t = 0.0;
+    return (uint64_t)(t * 18446744073709551616.0);
+}
+static inline cf32 cmul_fma(cf32 a, cf32 b)
+{
+    cf32 r;
+    r.re = fmaf(a.re, b.re, -(a.im * b.im));
+    r.im = fmaf(a.re, b.im, a.im * b.re);
+    return r;
+}
+void orc_rotator(const cf32* in, size_t n, uint64_t inc, uint64_t acc0, cf32* out)
+{
+    cf32 lo[512];
+    for (int r = 0; r < 512; r++) orc_sincos_turn((uint64_t)r * inc, &lo[r].im, &lo[r].re);
+    cf32 hi = {1, 0};
+    for (size_t i = 0; i < n; i++) {
+        if ((i & 511) == 0) orc_sincos_turn(acc0 + (uint64_t)i * inc, &hi.im, &hi.re);
+        cf32 ph = cmul_fma(hi, lo[i & 511]);
+        out[i] = cmul_fma(in[i], ph);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * rational_resampler_ccf / fff  [gr-filter/lib/rational_resampler_impl.cc]
+ * y[i] = sum_j h[(i*D mod I) + j*I] * x[floor(i*D/I) - j];  y[i] exists iff floor(i*D/I) <= n-1.
+ * ------------------------------------------------------------------------------------------ */
+size_t orc_decim_count(size_t n, int interp, int decim)
+{
+    if (n == 0) return 0;
+    /* largest i with floor(i*D/I) <= n-1  <=>  i*D <= (n-1)*I + I-1 */
+    return (size_t)((((uint64_t)(n - 1) * (uint64_t)interp + (uint64_t)interp - 1) / (uint64_t)decim) + 1);
+}
+
+/* Pure decimator (I = 1).  Summation order (the contract the HIP kernel follows):
+ * k = p + j*D, p in [0,D), j in [0,J).  The D phases are split into nsplit contiguous groups
+ * g: p in [floor(g*D/G), floor((g+1)*D/G)); each group is ONE fmaf chain, p ascending then
+ * j ascending, starting from +0;  y = (r0 + r1) + (r2 + r3)   (G=2: r0+r1, G=1: r0). */
+size_t orc_decim_fir_ccf(const cf32* in, size_t n, const float* taps, int nt, int D, int G, cf32* out)
+{
+    size_t nout = orc_decim_count(n, 1, D);
+    int J = (nt + D - 1) / D;
+    for (size_t m = 0; m < nout; m++) {
+        float rr[4] = {0, 0, 0, 0}, ri[4] = {0, 0, 0, 0};
+        for (int g = 0; g < G; g++) {
+            int p0 = (int)(((long)g * D) / G), p1 = (int)(((long)(g + 1) * D) / G);
+            float ar = 0.0f, ai = 0.0f;
+            for (int p = p0; p < p1; p++) {
+                for (int j = 0; j < J; j++) {
+                    int k = p + j * D;
+                    if (k >= nt) break;
+                    long long idx = (long long)(m - (size_t)0) * D - (long long)j * D - p;
+                    if (idx < 0) break;
+                    float h = taps[k];
+                    ar = fmaf(h, in[idx].re, ar);
+                    ai = fmaf(h, in[idx].im, ai);
+                }
+            }
+            rr[g] = ar; ri[g] = ai;
+        }
+        if (G == 4)      { out[m].re = (rr[0] + rr[1]) + (rr[2] + rr[3]); out[m].im = (ri[0] + ri[1]) + (ri[2] + ri[3]); }
+        else if (G == 2) { out[m].re = rr[0] + rr[1]; out[m].im = ri[0] + ri[1]; }
+        else             { out[m].re = rr[0]; out[m].im = ri[0]; }
+    }
+    return nout;
+}
+
+/* General I/D.  One fmaf chain per output, j ascending. */
+size_t orc_resamp_ccf(const cf32* in, size_t n, const float* taps, int nt, int I, int D, cf32* out)
+{
+    size_t nout = orc_decim_count(n, I, D);
+    for (size_t i = 0; i < nout; i++) {
+        uint64_t u = (uint64_t)i * (uint64_t)D;
+        int ph = (int)(u % (uint64_t)I);
+        long long c = (long long)(u / (uint64_t)I);
+        float ar = 0.0f, ai = 0.0f;
+        for (int j = 0; ph + j * I < nt; j++) {
+            long long idx = c - j;
+            if (idx < 0) break;
+            float h = taps[ph + j * I];
+            ar = fmaf(h, in[idx].re, ar);
+            ai = fmaf(h, in[idx].im, ai);
+        }
+        out[i].re = ar; out[i].im = ai;
+    }
+    return nout;
+}
+size_t orc_resamp_fff(const float* in, size_t n, const float* taps, int nt, int I, int D, float* out)
+{
+    size_t nout = orc_decim_count(n, I, D);
+    for (size_t i = 0; i < nout; i++) {
+        uint64_t u = (uint64_t)i * (uint64_t)D;
+        int ph = (int)(u % (uint64_t)I);
+        long long c = (long long)(u / (uint64_t)I);
+        float a = 0.0f;
+        for (int j = 0; ph + j * I < nt; j++) {
+            long long idx = c - j;
+            if (idx < 0) break;
+            a = fmaf(taps[ph + j * I], in[idx], a);
+        }
+        out[i] = a;
+    }
+    return nout;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * fft_filter_{ccf,ccc,fff} restated as the causal direct FIR they implement
+ * [gr-filter/lib/fft_filter.cc]: y[n] = sum_k h[k] x[n-k], one fmaf chain, k ascending.
+ * ------------------------------------------------------------------------------------------ */
+void orc_fir_ccf(const cf32* in, size_t n, const float* taps, int nt, cf32* out)
+{
+    for (size_t i = 0; i < n; i++) {
+        float ar = 0.0f, ai = 0.0f;
+        for (int k = 0; k < nt && (size_t)k <= i; k++) {
+            ar = fmaf(taps[k], in[i - k].re, ar);
+            ai = fmaf(taps[k], in[i - k].im, ai);
+        }
+        out[i].re = ar; out[i].im = ai;
+    }
+}
+/* complex taps: re += hr*xr; re += (-hi)*xi; im += hr*xi; im += hi*xr */
+void orc_fir_ccc(const cf32* in, size_t n, const cf32* taps, int nt, cf32* out)
+{
+    for (size_t i = 0; i < n; i++) {
+        float ar = 0.0f, ai = 0.0f;
+        for (int k = 0; k < nt && (size_t)k <= i; k++) {
+            cf32 h = taps[k], x = in[i - k];
+            ar = fmaf(h.re, x.re, ar);
+            ar = fmaf(-h.im, x.im, ar);
+            ai = fmaf(h.re, x.im, ai);
+            ai = fmaf(h.im, x.re, ai);
+        }
+        out[i].re = ar; out[i].im = ai;
+    }
+}
+void orc_fir_fff(const float* in, size_t n, const float* taps, int nt, float* out)
+{
+    for (size_t i = 0; i < n; i++) {
+        float a = 0.0f;
+        for (int k = 0; k < nt && (size_t)k <= i; k++) a = fmaf(taps[k], in[i - k], a);
+        out[i] = a;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * control_loop helpers [gr-blocks control_loop.h]
+ * ------------------------------------------------------------------------------------------ */
+static inline float phase_wrap(float phase)
+{
+    while (phase > (float)(2 * M_PI))  phase = (float)((double)phase - 2 * M_PI);
+    while (phase < (float)(-2 * M_PI)) phase = (float)((double)phase + 2 * M_PI);
+    return phase;
+}
+static inline float branchless_clip(float x, float clip)
+{
+    /* gr::branchless_clip: 0.5*(|x+clip| - |x-clip|) */
+    float x1 = fabsf(x + clip);
+    float x2 = fabsf(x - clip);
+    x1 -= x2;
+    return 0.5f * x1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * fll_band_edge_cc [gr-digital/lib/fll_band_edge_cc_impl.cc]
+ * history = ntaps+1 and out[i] = in[i]*nco  =>  the stream is delayed by ntaps samples.
+ * The two band-edge FIRs run on the derotated output; filter taps as stored by design_filter
+ * (reversed) and applied by fir_filter_with_buffer_ccc: f = sum_j T[j] * y[n-j] with
+ * T[j] = stored[ntaps-1-j].  Complex MAC order as orc_fir_ccc.
+ * ------------------------------------------------------------------------------------------ */
+void orc_fll_band_edge(const cf32* in, size_t n, float sps, float rolloff, int nt, float bw, cf32* out)
+{
+    cf32* lower = (cf32*)malloc(sizeof(cf32) * (size_t)nt);
+    cf32* upper = (cf32*)malloc(sizeof(cf32) * (size_t)nt);
+    cf32* dl = (cf32*)calloc((size_t)nt, sizeof(cf32)); /* dl[j] = y[n-j] */
+    orc_fll_taps(sps, rolloff, nt, lower, upper);
+    float alpha, beta;
+    orc_control_loop_gains(bw, &alpha, &beta);
+    float max_freq = (float)(2 * M_PI * (2.0 / sps)), min_freq = -max_freq;
+    float phase = 0, freq = 0;
+    for (size_t i = 0; i < n; i++) {
+        cf32 x = {0, 0};
+        if (i >= (size_t)nt) x = in[i - (size_t)nt];
+        cf32 nco; orc_sincosf(phase, &nco.im, &nco.re);
+        cf32 y;
+        y.re = x.re * nco.re - x.im * nco.im;
+        y.im = x.re * nco.im + x.im * nco.re;
+        out[i] = y;
+        memmove(dl + 1, dl, sizeof(cf32) * (size_t)(nt - 1));
+        dl[0] = y;
+        float ur = 0, ui = 0, lr = 0, li = 0;
+        for (int j = 0; j < nt; j++) {
+            cf32 hu = upper[nt - 1 - j], hl = lower[nt - 1 - j], v = dl[j];
+            ur = fmaf(hu.re, v.re, ur); ur = fmaf(-hu.im, v.im, ur);
+            ui = fmaf(hu.re, v.im, ui); ui = fmaf(hu.im, v.re, ui);
+            lr = fmaf(hl.re, v.re, lr); lr = fmaf(-hl.im, v.im, lr);
+            li = fmaf(hl.re, v.im, li); li = fmaf(hl.im, v.re, li);
+        }
+        float error = (lr * lr + li * li) - (ur * ur + ui * ui);
+        freq = freq + beta * error;
+        phase = phase + freq + alpha * error;
+        phase = phase_wrap(phase);
+        if (freq > max_freq) freq = max_freq; else if (freq < min_freq) freq = min_freq;
+    }
+    free(lower); free(upper); free(dl);
+}
+
+/* quadrature_demod_cf [gr-analog/lib/quadrature_demod_cf_impl.cc]: history 2 */
+void orc_quad_demod(const cf32* in, size_t n, float gain, float* out)
+{
+    cf32 prev = {0, 0};
+    for (size_t i = 0; i < n; i++) {
+        cf32 a = in[i];
+        float re = a.re * prev.re + a.im * prev.im;
+        float im = a.im * prev.re - a.re * prev.im;
+        out[i] = gain * orc_fast_atan2f(im, re);
+        prev = a;
+    }
+}
+
+/* agc2_cc [gr-analog include/gnuradio/analog/agc2.h] */
+void orc_agc2(const cf32* in, size_t n, float attack, float decay, float ref, float gain, float max_gain, cf32* out)
+{
+    for (size_t i = 0; i < n; i++) {
+        cf32 o; o.re = in[i].re * gain; o.im = in[i].im * gain;
+        float tmp = -ref + sqrtf(o.re * o.re + o.im * o.im);
+        float rate = decay;
+        if (tmp > gain) rate = attack;
+        gain -= tmp * rate;
+        if (gain < 0.0f) gain = 10e-5f;
+        if (max_gain > 0.0f && gain > max_gain) gain = max_gain;
+        out[i] = o;
+    }
+}
+
+/* costas_loop_cc [gr-digital/lib/costas_loop_cc_impl.cc] */
+void orc_costas(const cf32* in, size_t n, float bw, int order, int use_snr, cf32* out)
+{
+    float alpha, beta;
+    orc_control_loop_gains(bw, &alpha, &beta);
+    float phase = 0, freq = 0;
+    for (size_t i = 0; i < n; i++) {
+        cf32 nco; orc_sincosf(-phase, &nco.im, &nco.re);
+        cf32 x = in[i], o;
+        o.re = x.re * nco.re - x.im * nco.im;
+        o.im = x.re * nco.im + x.im * nco.re;
+        out[i] = o;
+        float e;
+        if (order == 2) {
+            if (use_snr) { float snr = (o.re * o.re + o.im * o.im); e = orc_tanhf_lut(snr * o.re) * o.im; }
+            else e = o.re * o.im;
+        } else {
+            if (use_snr) {
+                float snr = (o.re * o.re + o.im * o.im);
+                e = (orc_tanhf_lut(snr * o.re) * o.im) - (orc_tanhf_lut(snr * o.im) * o.re);
+            } else {
+                e = ((o.re > 0 ? 1.0f : -1.0f) * o.im - (o.im > 0 ? 1.0f : -1.0f) * o.re);
+            }
+        }
+        e = branchless_clip(e, 1.0f);
+        freq = freq + beta * e;
+        phase = phase + freq + alpha * e;
+        phase = phase_wrap(phase);
+        if (freq > 1.0f) freq = 1.0f; else if (freq < -1.0f) freq = -1.0f;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * symbol_sync_{ff,cc} [gr-digital/lib/symbol_sync_ff_impl.cc, timing_error_detector.cc,
+ * clock_tracking_loop.cc, interpolating_resampler.cc, gr-filter mmse_fir_interpolator_*]
+ * osps = 1, IR_MMSE_8TAP.  A symbol at cursor ii exists iff in[ii..ii+7] exist.
+ * interp(in, mu) = sum_{k=0..7} T[imu][7-k] * in[k], imu = rint(mu*128), one fmaf chain k ascending.
+ * ------------------------------------------------------------------------------------------ */
+static inline float slice_real(int constellation, float x)
+{
+    if (constellation == ORC_CONST_BPSK) return x > 0 ? 1.0f : -1.0f;
+    /* constellation_rect {-1.5,-0.5,0.5,1.5}: nearest point, ties to the lower index */
+    float best = -1.5f, bd = fabsf(x + 1.5f);
+    const float pts[4] = {-1.5f, -0.5f, 0.5f, 1.5f};
+    for (int i = 1; i < 4; i++) { float d = fabsf(x - pts[i]); if (d < bd) { bd = d; best = pts[i]; } }
+    return best;
+}
+
+typedef struct { float avg, inst, alpha, beta, maxp, minp; } clock_loop;
+static inline void clock_advance(clock_loop* c, float e)
+{
+    c->avg = c->avg + c->beta * e;
+    if (c->avg > c->maxp) c->avg = c->maxp; else if (c->avg < c->minp) c->avg = c->minp;
+    c->inst = c->avg + c->alpha * e;
+    if (c->inst <= 0.f) c->inst = c->avg;
+}
+
+size_t orc_symbol_sync_ff(const float* in, size_t n, int ted, float sps, float loop_bw, float damping,
+                          float ted_gain, float max_dev, int constellation, float* out)
+{
+    const float* T = orc_mmse_table();
+    clock_loop c; c.avg = sps; c.inst = sps; c.maxp = sps + max_dev; c.minp = sps - max_dev;
+    orc_clock_loop_gains(loop_bw, damping, ted_gain, &c.alpha, &c.beta);
+    float x0 = 0, x1 = 0, x2 = 0, d0 = 0, d1 = 0, d2 = 0;
+    float mu = 0; size_t ii = 0, oo = 0;
+    while (ii + 8 <= n) {
+        int imu = (int)rintf(mu * 128.0f);
+        const float* t = T + imu * 8;
+        float y = 0.0f;
+        for (int k = 0; k < 8; k++) y = fmaf(t[7 - k], in[ii + (size_t)k], y);
+        x2 = x1; x1 = x0; x0 = y;
+        d2 = d1; d1 = d0; d0 = slice_real(constellation, y);
+        float e;
+        if (ted == ORC_TED_MM) e = d1 * x0 - d0 * x1;
+        else { float u = ((x0 - x2) * d1) - ((d0 - d2) * x1); e = branchless_clip(u / 2.0f, 1.0f); }
+        clock_advance(&c, e);
+        float phase = mu + c.inst;
+        float fl = floorf(phase);
+        mu = phase - fl;
+        out[oo++] = y;
+        ii += (size_t)(int)fl;
+    }
+    return oo;
+}
+
+size_t orc_symbol_sync_cc(const cf32* in, size_t n, int ted, float sps, float loop_bw, float damping,
+                          float ted_gain, float max_dev, int constellation, cf32* out)
+{
+    const float* T = orc_mmse_table();
+    (void)constellation; /* dqpsk: (+-0.707107, +-0.707107) by sign */
+    clock_loop c; c.avg = sps; c.inst = sps; c.maxp = sps + max_dev; c.minp = sps - max_dev;
+    orc_clock_loop_gains(loop_bw, damping, ted_gain, &c.alpha, &c.beta);
+    cf32 x0 = {0, 0}, x1 = {0, 0}, x2 = {0, 0}, d0 = {0, 0}, d1 = {0, 0}, d2 = {0, 0};
+    float mu = 0; size_t ii = 0, oo = 0;
+    const float SQ = 0.707107f;
+    while (ii + 8 <= n) {
+        int imu = (int)rintf(mu * 128.0f);
+        const float* t = T + imu * 8;
+        cf32 y = {0.0f, 0.0f};
+        for (int k = 0; k < 8; k++) {
+            y.re = fmaf(t[7 - k], in[ii + (size_t)k].re, y.re);
+            y.im = fmaf(t[7 - k], in[ii + (size_t)k].im, y.im);
+        }
+        x2 = x1; x1 = x0; x0 = y;
+        d2 = d1; d1 = d0; d0.re = y.re > 0 ? SQ : -SQ; d0.im = y.im > 0 ? SQ : -SQ;
+        float e;
+        if (ted == ORC_TED_MM) {
+            e = (d1.re * x0.re - d0.re * x1.re) + (d1.im * x0.im - d0.im * x1.im);
+        } else {
+            float ar = x0.re - x2.re, ai = x0.im - x2.im;
+            float br = d0.re - d2.re, bi = d0.im - d2.im;
+            float u = (ar * d1.re + ai * d1.im) - (br * x1.re + bi * x1.im);
+            e = branchless_clip(u, 1.0f);
+        }
+        clock_advance(&c, e);
+        float phase = mu + c.inst;
+        float fl = floorf(phase);
+        mu = phase - fl;
+        out[oo++] = y;
+        ii += (size_t)(int)fl;
+    }
+    return oo;
+}
+
+void orc_diff_phasor(const cf32* in, size_t n, cf32* out)
+{
+    cf32 prev = {0, 0};
+    for (size_t i = 0; i < n; i++) {
+        cf32 a = in[i];
+        out[i].re = a.re * prev.re + a.im * prev.im;
+        out[i].im = a.im * prev.re - a.re * prev.im;
+        prev = a;
+    }
+}
+
+/* multiply_const_ff -> add_const_ff -> float_to_uchar: sat_0^255(rint(x*mul + add)) */
+void orc_soft_quant(const float* in, size_t n, float mul, float add, uint8_t* out)
+{
+    for (size_t i = 0; i < n; i++) {
+        float v = in[i] * mul;
+        v = v + add;
+        float r = rintf(v);
+        if (!(r >= 0.0f)) r = 0.0f;          /* NaN -> 0 */
+        if (r > 255.0f) r = 255.0f;
+        out[i] = (uint8_t)r;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * fec::decoder(cc_decoder(frame 80, K 7, rate 2, polys {109,79}, CC_STREAMING))
+ * [gr-fec/lib/cc_decoder_impl.cc, decoder_impl.cc; VOLK volk_8u_x4_conv_k7_r2_8u_spiral]
+ * block b exists iff soft[160b .. 160b+171] exist (160 consumed + 12 look-ahead).
+ * The metric kernel restated is the SPIRAL variant -- the one the reference says decodes
+ * correctly (docs/OPERATION.md:4): branch metric = (avg_epu8(B0^s0, B1^s1) >> 2) & 63, all
+ * path-metric adds SATURATE at 255 (_mm_adds_epu8), survivor = min with decision bit 1 on
+ * ties (cmpeq(min, m1)), renormalisation (subtract the minimum) only when metric[0] > 210.
+ * ------------------------------------------------------------------------------------------ */
+static inline int parity32(uint32_t v) { return __builtin_parity(v); }
+static inline uint8_t adds_u8(unsigned a, unsigned b) { unsigned s = a + b; return (uint8_t)(s > 255 ? 255 : s); }
+
+size_t orc_cc_decode_k7(const uint8_t* soft, size_t n, uint8_t* bits)
+{
+    static const int polys[2] = {109, 79};
+    uint8_t branchtab[64];
+    for (int s = 0; s < 32; s++)
+        for (int j = 0; j < 2; j++) branchtab[j * 32 + s] = parity32((uint32_t)(2 * s) & (uint32_t)polys[j]) ? 255 : 0;
+    uint8_t X[64], Y[64];
+    uint64_t dec[86];
+    int start = 0;
+    size_t nblk = 0;
+    while (160 * nblk + 172 <= n) {
+        const uint8_t* syms = soft + 160 * nblk;
+        for (int i = 0; i < 64; i++) X[i] = 63;
+        X[start & 63] = 0;
+        for (int s = 0; s < 86; s++) {
+            uint64_t d = 0;
+            for (int i = 0; i < 32; i++) {
+                unsigned a = (unsigned)(branchtab[i] ^ syms[2 * s]);
+                unsigned b = (unsigned)(branchtab[32 + i] ^ syms[2 * s + 1]);
+                unsigned metric = (((a + b + 1) >> 1) >> 2) & 63u;
+                uint8_t m0 = adds_u8(X[i], metric);
+                uint8_t m1 = adds_u8(X[i + 32], 63u - metric);
+                uint8_t m2 = adds_u8(X[i], 63u - metric);
+                uint8_t m3 = adds_u8(X[i + 32], metric);
+                uint8_t s0 = m1 < m0 ? m1 : m0;
+                uint8_t s1 = m3 < m2 ? m3 : m2;
+                uint64_t d0 = (s0 == m1), d1 = (s1 == m3);
+                Y[2 * i] = s0;
+                Y[2 * i + 1] = s1;
+                d |= (d0 | (d1 << 1)) << (2 * i);
+            }
+            if (Y[0] > 210) {
+                uint8_t mn = Y[0];
+                for (int i = 1; i < 64; i++) if (mn > Y[i]) mn = Y[i];
+                for (int i = 0; i < 64; i++) Y[i] = (uint8_t)(Y[i] - mn);
+            }
+            memcpy(X, Y, 64);
+            dec[s] = d;
+        }
+        /* find_endstate: first minimum */
+        int end = 0; uint8_t mn = X[0];
+        for (int i = 1; i < 64; i++) if (X[i] < mn) { mn = X[i]; end = i; }
+        /* chainback: steps 85..6 give bits 79..0; the state after 6 back-steps seeds the next block */
+        int st = end, next = 0;
+        uint8_t* out = bits + 80 * nblk;
+        for (int nb = 79; nb >= 0; nb--) {
+            int k = (int)((dec[nb + 6] >> st) & 1);
+            st = (st >> 1) | (k << 5);
+            out[nb] = (uint8_t)k;
+            if (nb == 74) next = st;
+        }
+        start = next;
+        nblk++;
+    }
+    return 80 * nblk;
+}
+
+/* lfsr [gr-digital include/gnuradio/digital/lfsr.h] */
+void orc_descramble(const uint8_t* in, size_t n, uint32_t mask, uint32_t seed, int len, uint8_t* out)
+{
+    uint32_t sr = seed;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t b = in[i] & 1u;
+        out[i] = (uint8_t)(parity32(sr & mask) ^ b);
+        sr = (sr >> 1) | (b << len);
+    }
+}
+void orc_scramble(const uint8_t* in, size_t n, uint32_t mask, uint32_t seed, int len, uint8_t* out)
+{
+    uint32_t sr = seed;
+    for (size_t i = 0; i < n; i++) {
+        uint8_t o = (uint8_t)(sr & 1u);
+        uint32_t nb = (uint32_t)parity32(sr & mask) ^ (in[i] & 1u);
+        sr = (sr >> 1) | (nb << len);
+        out[i] = o;
+    }
+}
+/* cc_encoder streaming [gr-fec/lib/cc_encoder_impl.cc] */
+void orc_cc_encode_k7(const uint8_t* bits, size_t n, uint8_t* out)
+{
+    uint32_t st = 0;
+    for (size_t i = 0; i < n; i++) {
+        st = (st << 1) | (bits[i] & 1u);
+        out[2 * i] = (uint8_t)parity32(st & 109u);
+        out[2 * i + 1] = (uint8_t)parity32(st & 79u);
+    }
+}

@@ -1,0 +1,427 @@
+/* orc_chains.c — the reference's hier-block topologies wired from oracle blocks
+ * (TEST INFRASTRUCTURE; see orc.h).  Each chain cites the reference file:line it follows. */
+#include "orc.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NEW(T, n) ((T*)calloc((size_t)(n) + 16, sizeof(T)))
+
+void orc_demod_out_free(orc_demod_out* o)
+{
+    free(o->filtered); free(o->constellation); free(o->bits_a); free(o->bits_b);
+    memset(o, 0, sizeof *o);
+}
+
+/* ---- RX front end: gr_demod_base.cpp:57,180 (rotator), :1220-1225 (phase inc = 2*pi*-off/fs),
+ *      :1330-1340 (rational_resampler_ccf(1, fs/1e6, low_pass(1, fs, 480k, 100k, BH)) when fs >= 2 Msps) */
+int orc_frontend_taps(int samp_rate, float* taps)
+{
+    if (samp_rate < 2000000) return 0;
+    return orc_low_pass(1, samp_rate, 480000, 100000, ORC_WIN_BLACKMAN_HARRIS, taps);
+}
+size_t orc_frontend(const cf32* in, size_t n, int samp_rate, double carrier_offset_hz, cf32* out)
+{
+    uint64_t inc = orc_phase_inc_to_turn(2 * M_PI * -carrier_offset_hz / samp_rate);
+    if (samp_rate < 2000000) { orc_rotator(in, n, inc, 0, out); return n; }
+    int decim = samp_rate / 1000000;
+    int nt = orc_frontend_taps(samp_rate, NULL);
+    float* taps = NEW(float, nt);
+    orc_frontend_taps(samp_rate, taps);
+    cf32* rot = NEW(cf32, n);
+    orc_rotator(in, n, inc, 0, rot);
+    size_t m = orc_decim_fir_ccf(rot, n, taps, nt, decim, 4, out);
+    free(rot); free(taps);
+    return m;
+}
+
+/* soft symbols -> {viterbi -> descrambler} on the stream and on the stream delayed by one
+ * (gr_demod_2fsk.cpp:155-164, gr_demod_gmsk.cpp:122-131) */
+static void fec_tail(const float* sym, size_t nsym, float mul, int two_branch, orc_demod_out* o)
+{
+    uint8_t* soft = NEW(uint8_t, nsym + 1);
+    orc_soft_quant(sym, nsym, mul, 128.0f, soft + 1);
+    soft[0] = 0; /* blocks::delay(1): one zero item in front */
+    uint8_t* dec = NEW(uint8_t, nsym / 2 + 80);
+    size_t nb = orc_cc_decode_k7(soft + 1, nsym, dec);
+    o->bits_a = NEW(uint8_t, nb); o->n_bits_a = nb;
+    orc_descramble(dec, nb, 0x8A, 0x7F, 7, o->bits_a);
+    if (two_branch) {
+        nb = orc_cc_decode_k7(soft, nsym + 1, dec);
+        o->bits_b = NEW(uint8_t, nb); o->n_bits_b = nb;
+        orc_descramble(dec, nb, 0x8A, 0x7F, 7, o->bits_b);
+    }
+    free(soft); free(dec);
+}
+
+/* gr_demod_2fsk.cpp:38-167 */
+void orc_demod_2fsk(const cf32* in, size_t n, int sps, int samp_rate, int carrier_freq, int filter_width, int fm, orc_demod_out* o)
+{
+    (void)carrier_freq;
+    memset(o, 0, sizeof *o);
+    int decim, interp, nfilts, target, sps_eff;
+    if (sps == 10)      { target = 20000; sps_eff = sps;     decim = 50; interp = 1; nfilts = 35 * sps_eff; }
+    else if (sps >= 5)  { target = 40000; sps_eff = sps * 2; decim = 25; interp = 1; nfilts = 35 * sps_eff; }
+    else                { target = 80000; sps_eff = 4;       decim = 25; interp = 2; nfilts = 125 * sps_eff; }
+    int spacing = fm ? 1 : 2;
+    if ((nfilts % 2) == 0) nfilts += 1;
+
+    int nt = orc_low_pass(interp, (double)interp * samp_rate, target / 2, target / 2, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* taps = NEW(float, nt);
+    orc_low_pass(interp, (double)interp * samp_rate, target / 2, target / 2, ORC_WIN_BLACKMAN_HARRIS, taps);
+    size_t n1 = orc_decim_count(n, interp, decim);
+    cf32* s1 = NEW(cf32, n1);
+    if (interp == 1) orc_decim_fir_ccf(in, n, taps, nt, decim, 4, s1);
+    else             orc_resamp_ccf(in, n, taps, nt, interp, decim, s1);
+    free(taps);
+
+    cf32* s2 = NEW(cf32, n1);
+    orc_fll_band_edge(s1, n1, (float)sps_eff, 0.1f, 16, (float)(24 * M_PI / 100), s2);
+    free(s1);
+
+    int nf = orc_low_pass(1, target, filter_width, filter_width, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* ft = NEW(float, nf);
+    orc_low_pass(1, target, filter_width, filter_width, ORC_WIN_BLACKMAN_HARRIS, ft);
+    o->filtered = NEW(cf32, n1); o->n_filtered = n1;
+    orc_fir_ccf(s2, n1, ft, nf, o->filtered);
+    free(ft); free(s2);
+
+    float* s5 = NEW(float, n1);
+    if (fm) {
+        float* dem = NEW(float, n1);
+        orc_quad_demod(o->filtered, n1, (float)(sps_eff / (spacing * M_PI / 2)), dem);
+        int nr = orc_root_raised_cosine(1, target, target / sps_eff, 0.2, nfilts, NULL);
+        float* rrc = NEW(float, nr);
+        orc_root_raised_cosine(1, target, target / sps_eff, 0.2, nfilts, rrc);
+        orc_fir_fff(dem, n1, rrc, nr, s5);
+        free(rrc); free(dem);
+    } else {
+        int nb = orc_complex_band_pass(1, target, -filter_width, 0, filter_width, ORC_WIN_BLACKMAN_HARRIS, NULL);
+        cf32* up = NEW(cf32, nb); cf32* lo = NEW(cf32, nb);
+        orc_complex_band_pass(1, target, -filter_width, 0, filter_width, ORC_WIN_BLACKMAN_HARRIS, up);
+        orc_complex_band_pass(1, target, 0, filter_width, filter_width, ORC_WIN_BLACKMAN_HARRIS, lo);
+        cf32* fu = NEW(cf32, n1); cf32* fl = NEW(cf32, n1);
+        orc_fir_ccc(o->filtered, n1, up, nb, fu);
+        orc_fir_ccc(o->filtered, n1, lo, nb, fl);
+        float* s4 = NEW(float, n1);
+        for (size_t i = 0; i < n1; i++) {
+            float mu = sqrtf(fu[i].re * fu[i].re + fu[i].im * fu[i].im);
+            float ml = sqrtf(fl[i].re * fl[i].re + fl[i].im * fl[i].im);
+            float d = mu / ml;
+            /* rail_ff(0,2); NaN (0/0 on exact-zero input) -> 0, see DESIGN.md */
+            float r = d;
+            if (!(r >= 0.0f)) r = 0.0f;
+            if (r > 2.0f) r = 2.0f;
+            s4[i] = r + (-1.0f);
+        }
+        int ns = orc_low_pass(1.0, target, target / sps_eff, target / sps_eff, ORC_WIN_HAMMING, NULL);
+        float* st = NEW(float, ns);
+        orc_low_pass(1.0, target, target / sps_eff, target / sps_eff, ORC_WIN_HAMMING, st);
+        orc_fir_fff(s4, n1, st, ns, s5);
+        free(st); free(s4); free(fu); free(fl); free(up); free(lo);
+    }
+    float symbol_rate = (float)target / (float)sps_eff;
+    float sps_dev = 200.0f / symbol_rate;
+    float* sym = NEW(float, n1 / (size_t)(sps_eff > 1 ? sps_eff - 1 : 1) + 16);
+    size_t nsym = orc_symbol_sync_ff(s5, n1, ORC_TED_MOD_MM, (float)sps_eff, (float)(2 * M_PI / (symbol_rate / 10)),
+                                     1.0f, 0.2869f, sps_dev, ORC_CONST_BPSK, sym);
+    free(s5);
+    o->constellation = NEW(cf32, nsym); o->n_const = nsym;
+    for (size_t i = 0; i < nsym; i++) { o->constellation[i].re = sym[i]; o->constellation[i].im = 0; }
+    fec_tail(sym, nsym, 128.0f, 1, o);
+    free(sym);
+}
+
+/* gr_demod_gmsk.cpp:38-135 */
+void orc_demod_gmsk(const cf32* in, size_t n, int sps, int samp_rate, int carrier_freq, int filter_width, orc_demod_out* o)
+{
+    (void)carrier_freq;
+    memset(o, 0, sizeof *o);
+    int decim, interp, target, sps_eff;
+    if (sps == 10)     { target = 20000; sps_eff = sps;     decim = 50; interp = 1; }
+    else if (sps == 5) { target = 40000; sps_eff = sps * 2; decim = 25; interp = 1; }
+    else               { target = 80000; sps_eff = 4;       decim = 25; interp = 2; }
+
+    int nt = orc_low_pass(interp, (double)interp * samp_rate, target / 2, target / 2, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* taps = NEW(float, nt);
+    orc_low_pass(interp, (double)interp * samp_rate, target / 2, target / 2, ORC_WIN_BLACKMAN_HARRIS, taps);
+    size_t n1 = orc_decim_count(n, interp, decim);
+    cf32* s1 = NEW(cf32, n1);
+    if (interp == 1) orc_decim_fir_ccf(in, n, taps, nt, decim, 4, s1);
+    else             orc_resamp_ccf(in, n, taps, nt, interp, decim, s1);
+    free(taps);
+
+    int nf = orc_low_pass(1, target, filter_width, filter_width, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* ft = NEW(float, nf);
+    orc_low_pass(1, target, filter_width, filter_width, ORC_WIN_BLACKMAN_HARRIS, ft);
+    o->filtered = NEW(cf32, n1); o->n_filtered = n1;
+    orc_fir_ccf(s1, n1, ft, nf, o->filtered);
+    free(ft); free(s1);
+
+    float* dem = NEW(float, n1);
+    orc_quad_demod(o->filtered, n1, (float)(sps_eff / (M_PI / 2)), dem);
+    int ns = orc_low_pass(1, target, target / sps_eff, target / sps_eff, ORC_WIN_HAMMING, NULL);
+    float* st = NEW(float, ns);
+    orc_low_pass(1, target, target / sps_eff, target / sps_eff, ORC_WIN_HAMMING, st);
+    float* s5 = NEW(float, n1);
+    orc_fir_fff(dem, n1, st, ns, s5);
+    free(st); free(dem);
+
+    float* sym = NEW(float, n1 / (size_t)(sps_eff - 1) + 16);
+    size_t nsym = orc_symbol_sync_ff(s5, n1, ORC_TED_MOD_MM, (float)sps_eff, (float)(2 * M_PI / 200.0f),
+                                     1.0f, 0.2869f, 0.05f, ORC_CONST_BPSK, sym);
+    free(s5);
+    o->constellation = NEW(cf32, nsym); o->n_const = nsym;
+    for (size_t i = 0; i < nsym; i++) { o->constellation[i].re = sym[i]; o->constellation[i].im = 0; }
+    fec_tail(sym, nsym, 128.0f, 1, o);
+    free(sym);
+}
+
+/* gr_demod_qpsk.cpp:38-157 */
+void orc_demod_qpsk(const cf32* in, size_t n, int sps, int samp_rate, int carrier_freq, int filter_width, orc_demod_out* o)
+{
+    (void)carrier_freq; (void)filter_width;
+    memset(o, 0, sizeof *o);
+    int decim, interp = 1, target, sps_eff;
+    float costas_bw = (float)(M_PI / 200);
+    int fll_bw = 2;
+    if (sps > 4 && sps < 125) { decim = 25;  sps_eff = sps * 4 / 25; target = 40000; }
+    else if (sps >= 125)      { decim = 100; sps_eff = sps / 25;     target = 10000; }
+    else                      { decim = 2;   sps_eff = sps;          target = 500000; costas_bw = (float)(M_PI / 400); }
+
+    int nt = orc_low_pass_2(interp, (double)samp_rate * interp, target / 2, target / 10, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* taps = NEW(float, nt);
+    orc_low_pass_2(interp, (double)samp_rate * interp, target / 2, target / 10, 60, ORC_WIN_BLACKMAN_HARRIS, taps);
+    size_t n1 = orc_decim_count(n, interp, decim);
+    cf32* s1 = NEW(cf32, n1);
+    orc_decim_fir_ccf(in, n, taps, nt, decim, 4, s1);
+    free(taps);
+    if (sps > 4) {
+        cf32* s1b = NEW(cf32, n1);
+        orc_fll_band_edge(s1, n1, (float)sps_eff, 0.35f, 32, (float)(fll_bw * M_PI / 100), s1b);
+        free(s1); s1 = s1b;
+    }
+    int nr = orc_root_raised_cosine(sps_eff, sps_eff, 1, 0.35, 11 * sps_eff, NULL);
+    float* rrc = NEW(float, nr);
+    orc_root_raised_cosine(sps_eff, sps_eff, 1, 0.35, 11 * sps_eff, rrc);
+    o->filtered = NEW(cf32, n1); o->n_filtered = n1;
+    orc_fir_ccf(s1, n1, rrc, nr, o->filtered);
+    free(rrc); free(s1);
+
+    cf32* a = NEW(cf32, n1);
+    orc_agc2(o->filtered, n1, 1.0f, 1e-1f, 1.0f, 1.0f, 65536.0f, a);
+    cf32* b = NEW(cf32, n1);
+    orc_costas(a, n1, (float)(M_PI / 200 / sps_eff), 4, 1, b);
+    free(a);
+    float symbol_rate = (float)target / (float)sps_eff;
+    float sps_dev = 200.0f / symbol_rate;
+    cf32* sy = NEW(cf32, n1 / (size_t)(sps_eff > 1 ? sps_eff - 1 : 1) + 16);
+    size_t nsym = orc_symbol_sync_cc(b, n1, ORC_TED_MOD_MM, (float)sps_eff, (float)(2 * M_PI / (symbol_rate / 10)),
+                                     1.0f, 0.2869f, sps_dev, ORC_CONST_DQPSK, sy);
+    free(b);
+    cf32* c2 = NEW(cf32, nsym);
+    orc_costas(sy, nsym, costas_bw, 4, 1, c2);
+    free(sy);
+    cf32* dp = NEW(cf32, nsym);
+    orc_diff_phasor(c2, nsym, dp);
+    free(c2);
+    float ang = (float)(-3 * M_PI / 4);
+    cf32 rot; rot.re = (float)cos((double)ang); rot.im = (float)sin((double)ang);
+    o->constellation = NEW(cf32, nsym); o->n_const = nsym;
+    float* il = NEW(float, 2 * nsym);
+    for (size_t i = 0; i < nsym; i++) {
+        cf32 v;
+        v.re = dp[i].re * rot.re - dp[i].im * rot.im;
+        v.im = dp[i].re * rot.im + dp[i].im * rot.re;
+        o->constellation[i] = v;
+        il[2 * i] = v.re; il[2 * i + 1] = v.im;
+    }
+    free(dp);
+    fec_tail(il, 2 * nsym, 48.0f, 0, o);
+    free(il);
+}
+
+/* ------------------------------- modulators (TX) --------------------------------------
+ * bytes -> unpack MSB first -> scrambler(0x8A,0x7F,7) -> cc_encoder(K7, {109,79}) -> map ->
+ * symbols -> pulse shaping / FM -> gains -> interpolator.  The oracle encodes every input bit
+ * (fec::encoder would hold back a partial 80-bit frame). */
+static size_t tx_bits(const uint8_t* bytes, size_t nbytes, uint8_t** coded)
+{
+    size_t nb = nbytes * 8;
+    uint8_t* u = NEW(uint8_t, nb);
+    for (size_t i = 0; i < nb; i++) u[i] = (bytes[i >> 3] >> (7 - (i & 7))) & 1;
+    uint8_t* s = NEW(uint8_t, nb);
+    orc_scramble(u, nb, 0x8A, 0x7F, 7, s);
+    *coded = NEW(uint8_t, 2 * nb);
+    orc_cc_encode_k7(s, nb, *coded);
+    free(u); free(s);
+    return 2 * nb;
+}
+
+/* frequency_modulator_fc [gr-analog frequency_modulator_fc_impl.cc]; sin/cos by orc_sincosf
+ * (upstream: gr::fxpt table) */
+static void fm_mod(const float* in, size_t n, float k, cf32* out)
+{
+    const float F_PI = (float)M_PI;
+    float phase = 0;
+    for (size_t i = 0; i < n; i++) {
+        phase = phase + k * in[i];
+        phase = fmodf(phase + F_PI, 2.0f * F_PI) - F_PI;
+        orc_sincosf(phase, &out[i].im, &out[i].re);
+    }
+}
+
+/* gr_mod_2fsk.cpp:30-99 */
+size_t orc_mod_2fsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, int fm, cf32* out)
+{
+    (void)carrier_freq;
+    int nfilts = 25 * sps, spacing = fm ? 1 : 2, second_interp = 10;
+    float amplif = fm ? 0.9f : 0.8f;
+    if (sps == 5) nfilts *= 5;
+    if ((nfilts % 2) == 0) nfilts += 1;
+    size_t nsym_total = nbytes * 16;
+    size_t nout = nsym_total * (size_t)sps * (size_t)second_interp;
+    if (!out) return nout;
+    uint8_t* coded; size_t nc = tx_bits(bytes, nbytes, &coded);
+    float* sym = NEW(float, nc);
+    for (size_t i = 0; i < nc; i++) sym[i] = coded[i] ? 1.0f : -1.0f;
+    free(coded);
+    size_t n1 = nc * (size_t)sps;
+    float* shaped = NEW(float, n1);
+    if (fm) {
+        int nr = orc_root_raised_cosine(sps, sps, 1, 0.2, nfilts, NULL);
+        float* rrc = NEW(float, nr);
+        orc_root_raised_cosine(sps, sps, 1, 0.2, nfilts, rrc);
+        orc_resamp_fff(sym, nc, rrc, nr, sps, 1, shaped);
+        free(rrc);
+    } else {
+        for (size_t i = 0; i < n1; i++) shaped[i] = sym[i / (size_t)sps];
+    }
+    free(sym);
+    cf32* fmv = NEW(cf32, n1);
+    fm_mod(shaped, n1, (float)((spacing * M_PI / 2) / sps), fmv);
+    free(shaped);
+    for (size_t i = 0; i < n1; i++) { fmv[i].re *= amplif; fmv[i].im *= amplif; }
+    int nt = orc_low_pass(second_interp, samp_rate, filter_width, filter_width, ORC_WIN_HAMMING, NULL);
+    float* lp = NEW(float, nt);
+    orc_low_pass(second_interp, samp_rate, filter_width, filter_width, ORC_WIN_HAMMING, lp);
+    size_t m = orc_resamp_ccf(fmv, n1, lp, nt, second_interp, 1, out);
+    free(lp); free(fmv);
+    return m;
+}
+
+/* gr_mod_gmsk.cpp:30-95 */
+size_t orc_mod_gmsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, cf32* out)
+{
+    (void)carrier_freq;
+    int nfilts = 35, second_interp = 5;
+    float amplif = 0.9f;
+    if (sps == 10) { sps = 50; second_interp = 1; nfilts = 55; }
+    if (sps == 50) nfilts = 55;
+    if (sps == 100) nfilts = 35;
+    if ((nfilts % 2) == 0) nfilts += 1;
+    size_t nout = nbytes * 16 * (size_t)sps * (size_t)second_interp;
+    if (!out) return nout;
+    uint8_t* coded; size_t nc = tx_bits(bytes, nbytes, &coded);
+    float* sym = NEW(float, nc);
+    for (size_t i = 0; i < nc; i++) sym[i] = coded[i] ? 1.0f : -1.0f;
+    free(coded);
+    size_t n1 = nc * (size_t)sps;
+    float* g = NEW(float, nfilts);
+    orc_gaussian(sps, sps, 0.3, nfilts, g);
+    float* shaped = NEW(float, n1);
+    orc_resamp_fff(sym, nc, g, nfilts, sps, 1, shaped);
+    free(g); free(sym);
+    cf32* fmv = NEW(cf32, n1);
+    fm_mod(shaped, n1, (float)((M_PI / 2) / sps), fmv);
+    free(shaped);
+    for (size_t i = 0; i < n1; i++) { fmv[i].re *= amplif; fmv[i].im *= amplif; }
+    int nt = orc_low_pass(second_interp, samp_rate, filter_width, filter_width, ORC_WIN_HAMMING, NULL);
+    float* lp = NEW(float, nt);
+    orc_low_pass(second_interp, samp_rate, filter_width, filter_width, ORC_WIN_HAMMING, lp);
+    size_t m = orc_resamp_ccf(fmv, n1, lp, nt, second_interp, 1, out);
+    free(lp); free(fmv);
+    return m;
+}
+
+/* gr_mod_qpsk.cpp:28-89 */
+size_t orc_mod_qpsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, cf32* out)
+{
+    (void)carrier_freq; (void)samp_rate; (void)filter_width;
+    int nfilts = (sps > 120) ? 11 : (sps > 10 ? 13 : 15);
+    size_t nout = nbytes * 8 * (size_t)sps;
+    if (!out) return nout;
+    uint8_t* coded; size_t nc = tx_bits(bytes, nbytes, &coded);
+    static const int map[4] = {0, 1, 3, 2};
+    static const cf32 table[4] = {{-0.707f, -0.707f}, {-0.707f, 0.707f}, {0.707f, 0.707f}, {0.707f, -0.707f}};
+    size_t ns = nc / 2;
+    cf32* sym = NEW(cf32, ns);
+    int prev = 0;
+    for (size_t i = 0; i < ns; i++) {
+        int v = (coded[2 * i] << 1) | coded[2 * i + 1];
+        v = map[v];
+        prev = (v + prev) % 4;
+        sym[i] = table[prev];
+    }
+    free(coded);
+    int nr = orc_root_raised_cosine(sps, sps, 1, 0.35, nfilts * sps, NULL);
+    float* rrc = NEW(float, nr);
+    orc_root_raised_cosine(sps, sps, 1, 0.35, nfilts * sps, rrc);
+    size_t m = orc_resamp_ccf(sym, ns, rrc, nr, sps, 1, out);
+    for (size_t i = 0; i < m; i++) { out[i].re *= 0.6f; out[i].im *= 0.6f; }
+    free(rrc); free(sym);
+    return m;
+}
+
+/* gr_mod_base.cpp:249-250: rational_resampler_ccf(fs/1e6, 1, low_pass(I, fs, 480k, 20k, BH)) */
+size_t orc_tx_interp(const cf32* in, size_t n, int samp_rate, cf32* out)
+{
+    int I = samp_rate / 1000000;
+    if (I < 2) { if (out) memcpy(out, in, n * sizeof(cf32)); return n; }
+    if (!out) return n * (size_t)I;
+    int nt = orc_low_pass(I, samp_rate, 480000, 20000, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* lp = NEW(float, nt);
+    orc_low_pass(I, samp_rate, 480000, 20000, ORC_WIN_BLACKMAN_HARRIS, lp);
+    size_t m = orc_resamp_ccf(in, n, lp, nt, I, 1, out);
+    free(lp);
+    return m;
+}
+
+/* ------------------------------- batch driver for bench.py cpu_baseline ----------------------- */
+static double now_s(void)
+{
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+double orc_batch_rx(int mode, const cf32* iq, int batch, size_t n, int samp_rate, double carrier_offset_hz,
+                    int threads, uint64_t* bit_checksum)
+{
+    uint64_t total = 0;
+    double t0 = now_s();
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic) reduction(+ : total)
+#endif
+    for (int b = 0; b < batch; b++) {
+        const cf32* x = iq + (size_t)b * n;
+        size_t n1 = (samp_rate >= 2000000) ? orc_decim_count(n, 1, samp_rate / 1000000) : n;
+        cf32* fe = NEW(cf32, n1);
+        orc_frontend(x, n, samp_rate, carrier_offset_hz, fe);
+        orc_demod_out o;
+        if (mode == ORC_MODE_2FSK_1K)       orc_demod_2fsk(fe, n1, 10, 1000000, 1700, 2000, 0, &o);
+        else if (mode == ORC_MODE_GMSK_10K) orc_demod_gmsk(fe, n1, 1, 1000000, 1700, 20000, &o);
+        else                                orc_demod_qpsk(fe, n1, 2, 1000000, 1700, 160000, &o);
+        uint64_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < o.n_bits_a; i++) h = (h ^ o.bits_a[i]) * 1099511628211ull;
+        for (size_t i = 0; i < o.n_bits_b; i++) h = (h ^ o.bits_b[i]) * 1099511628211ull;
+        total += h;
+        orc_demod_out_free(&o);
+        free(fe);
+    }
+    if (bit_checksum) *bit_checksum = total;
+    return now_s() - t0;
+}

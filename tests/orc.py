@@ -1,0 +1,277 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the
+product package."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORC_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB = os.path.join(_ORC_DIR, "liborc.so")
+
+cf32 = np.complex64
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _ORC_DIR, "liborc.so"])
+
+
+def _load():
+    if not os.path.exists(_LIB):
+        build()
+    return C.CDLL(_LIB)
+
+
+lib = _load()
+
+_p = C.c_void_p
+_sz = C.c_size_t
+
+
+class DemodOut(C.Structure):
+    _fields_ = [("n_filtered", _sz), ("n_const", _sz), ("n_bits_a", _sz), ("n_bits_b", _sz),
+                ("filtered", _p), ("constellation", _p), ("bits_a", _p), ("bits_b", _p)]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_p)
+
+
+def _sig(name, res, *args):
+    f = getattr(lib, name)
+    f.restype = res
+    f.argtypes = list(args)
+    return f
+
+
+_sig("orc_low_pass", C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _p)
+_sig("orc_low_pass_2", C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _p)
+_sig("orc_complex_band_pass", C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _p)
+_sig("orc_root_raised_cosine", C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _p)
+_sig("orc_gaussian", C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _p)
+_sig("orc_frontend_taps", C.c_int, C.c_int, _p)
+_sig("orc_mmse_table", _p)
+_sig("orc_atan_table", _p)
+_sig("orc_tanh_table", _p)
+_sig("orc_sincosf", None, C.c_float, _p, _p)
+_sig("orc_sincos_turn", None, C.c_uint64, _p, _p)
+_sig("orc_fast_atan2f", C.c_float, C.c_float, C.c_float)
+_sig("orc_phase_inc_to_turn", C.c_uint64, C.c_double)
+_sig("orc_rotator", None, _p, _sz, C.c_uint64, C.c_uint64, _p)
+_sig("orc_decim_count", _sz, _sz, C.c_int, C.c_int)
+_sig("orc_decim_fir_ccf", _sz, _p, _sz, _p, C.c_int, C.c_int, C.c_int, _p)
+_sig("orc_resamp_ccf", _sz, _p, _sz, _p, C.c_int, C.c_int, C.c_int, _p)
+_sig("orc_fir_ccf", None, _p, _sz, _p, C.c_int, _p)
+_sig("orc_fir_fff", None, _p, _sz, _p, C.c_int, _p)
+_sig("orc_quad_demod", None, _p, _sz, C.c_float, _p)
+_sig("orc_symbol_sync_ff", _sz, _p, _sz, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _p)
+_sig("orc_soft_quant", None, _p, _sz, C.c_float, C.c_float, _p)
+_sig("orc_cc_decode_k7", _sz, _p, _sz, _p)
+_sig("orc_cc_encode_k7", None, _p, _sz, _p)
+_sig("orc_descramble", None, _p, _sz, C.c_uint32, C.c_uint32, C.c_int, _p)
+_sig("orc_scramble", None, _p, _sz, C.c_uint32, C.c_uint32, C.c_int, _p)
+_sig("orc_frontend", _sz, _p, _sz, C.c_int, C.c_double, _p)
+_sig("orc_demod_2fsk", None, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p)
+_sig("orc_demod_gmsk", None, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p)
+_sig("orc_demod_qpsk", None, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p)
+_sig("orc_demod_out_free", None, _p)
+_sig("orc_mod_2fsk", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p)
+_sig("orc_mod_gmsk", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p)
+_sig("orc_mod_qpsk", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p)
+_sig("orc_tx_interp", _sz, _p, _sz, C.c_int, _p)
+_sig("orc_batch_rx", C.c_double, C.c_int, _p, C.c_int, _sz, C.c_int, C.c_double, C.c_int, _p)
+
+WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECT, WIN_BH = 0, 1, 2, 3, 5
+MODE_2FSK_1K, MODE_GMSK_10K, MODE_QPSK_250K = 0, 1, 2
+
+
+def low_pass(gain, fs, fc, tw, win=WIN_HAMMING):
+    n = lib.orc_low_pass(gain, fs, fc, tw, win, None)
+    t = np.zeros(n, np.float32)
+    lib.orc_low_pass(gain, fs, fc, tw, win, _ptr(t))
+    return t
+
+
+def low_pass_2(gain, fs, fc, tw, att, win=WIN_HAMMING):
+    n = lib.orc_low_pass_2(gain, fs, fc, tw, att, win, None)
+    t = np.zeros(n, np.float32)
+    lib.orc_low_pass_2(gain, fs, fc, tw, att, win, _ptr(t))
+    return t
+
+
+def complex_band_pass(gain, fs, lo, hi, tw, win=WIN_HAMMING):
+    n = lib.orc_complex_band_pass(gain, fs, lo, hi, tw, win, None)
+    t = np.zeros(n, cf32)
+    lib.orc_complex_band_pass(gain, fs, lo, hi, tw, win, _ptr(t))
+    return t
+
+
+def root_raised_cosine(gain, fs, sr, alpha, ntaps):
+    n = lib.orc_root_raised_cosine(gain, fs, sr, alpha, ntaps, None)
+    t = np.zeros(n, np.float32)
+    lib.orc_root_raised_cosine(gain, fs, sr, alpha, ntaps, _ptr(t))
+    return t
+
+
+def gaussian(gain, spb, bt, ntaps):
+    t = np.zeros(ntaps, np.float32)
+    lib.orc_gaussian(gain, spb, bt, ntaps, _ptr(t))
+    return t
+
+
+def frontend_taps(samp_rate):
+    n = lib.orc_frontend_taps(samp_rate, None)
+    t = np.zeros(n, np.float32)
+    if n:
+        lib.orc_frontend_taps(samp_rate, _ptr(t))
+    return t
+
+
+def table(name, n):
+    p = getattr(lib, "orc_%s_table" % name)()
+    return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n,)).copy()
+
+
+def sincosf(x):
+    s, c = C.c_float(), C.c_float()
+    lib.orc_sincosf(x, C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def sincos_turn(a):
+    s, c = C.c_float(), C.c_float()
+    lib.orc_sincos_turn(a, C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def phase_inc_to_turn(rad):
+    return lib.orc_phase_inc_to_turn(rad)
+
+
+def rotator(x, inc, acc0=0):
+    x = np.ascontiguousarray(x, cf32)
+    y = np.empty_like(x)
+    lib.orc_rotator(_ptr(x), x.size, inc, acc0, _ptr(y))
+    return y
+
+
+def decim_fir_ccf(x, taps, decim, nsplit=4):
+    x = np.ascontiguousarray(x, cf32)
+    taps = np.ascontiguousarray(taps, np.float32)
+    n = lib.orc_decim_count(x.size, 1, decim)
+    y = np.empty(n, cf32)
+    lib.orc_decim_fir_ccf(_ptr(x), x.size, _ptr(taps), taps.size, decim, nsplit, _ptr(y))
+    return y
+
+
+def resamp_ccf(x, taps, interp, decim):
+    x = np.ascontiguousarray(x, cf32)
+    taps = np.ascontiguousarray(taps, np.float32)
+    n = lib.orc_decim_count(x.size, interp, decim)
+    y = np.empty(n, cf32)
+    lib.orc_resamp_ccf(_ptr(x), x.size, _ptr(taps), taps.size, interp, decim, _ptr(y))
+    return y
+
+
+def frontend(x, samp_rate, carrier_offset_hz):
+    x = np.ascontiguousarray(x, cf32)
+    y = np.empty(x.size, cf32)
+    n = lib.orc_frontend(_ptr(x), x.size, samp_rate, float(carrier_offset_hz), _ptr(y))
+    return y[:n].copy()
+
+
+def _take(o):
+    def arr(p, n, dt):
+        if not p or n == 0:
+            return np.zeros(0, dt)
+        return np.frombuffer(C.string_at(p, n * np.dtype(dt).itemsize), dtype=dt).copy()
+    r = dict(filtered=arr(o.filtered, o.n_filtered, cf32), constellation=arr(o.constellation, o.n_const, cf32),
+             bits_a=arr(o.bits_a, o.n_bits_a, np.uint8), bits_b=arr(o.bits_b, o.n_bits_b, np.uint8))
+    lib.orc_demod_out_free(C.byref(o))
+    return r
+
+
+def demod_2fsk(x, sps=10, samp_rate=1000000, carrier_freq=1700, filter_width=2000, fm=False):
+    x = np.ascontiguousarray(x, cf32)
+    o = DemodOut()
+    lib.orc_demod_2fsk(_ptr(x), x.size, sps, samp_rate, carrier_freq, filter_width, int(fm), C.byref(o))
+    return _take(o)
+
+
+def demod_gmsk(x, sps=1, samp_rate=1000000, carrier_freq=1700, filter_width=20000):
+    x = np.ascontiguousarray(x, cf32)
+    o = DemodOut()
+    lib.orc_demod_gmsk(_ptr(x), x.size, sps, samp_rate, carrier_freq, filter_width, C.byref(o))
+    return _take(o)
+
+
+def demod_qpsk(x, sps=2, samp_rate=1000000, carrier_freq=1700, filter_width=160000):
+    x = np.ascontiguousarray(x, cf32)
+    o = DemodOut()
+    lib.orc_demod_qpsk(_ptr(x), x.size, sps, samp_rate, carrier_freq, filter_width, C.byref(o))
+    return _take(o)
+
+
+def _mod(fn, data, *args):
+    data = np.ascontiguousarray(data, np.uint8)
+    n = fn(_ptr(data), data.size, *args, None)
+    y = np.zeros(n, cf32)
+    m = fn(_ptr(data), data.size, *args, _ptr(y))
+    return y[:m]
+
+
+def mod_2fsk(data, sps=50, samp_rate=1000000, carrier_freq=1700, filter_width=2000, fm=False):
+    return _mod(lib.orc_mod_2fsk, data, sps, samp_rate, carrier_freq, filter_width, int(fm))
+
+
+def mod_gmsk(data, sps=10, samp_rate=1000000, carrier_freq=1700, filter_width=20000):
+    return _mod(lib.orc_mod_gmsk, data, sps, samp_rate, carrier_freq, filter_width)
+
+
+def mod_qpsk(data, sps=4, samp_rate=1000000, carrier_freq=1700, filter_width=160000):
+    return _mod(lib.orc_mod_qpsk, data, sps, samp_rate, carrier_freq, filter_width)
+
+
+def tx_interp(x, samp_rate):
+    x = np.ascontiguousarray(x, cf32)
+    n = lib.orc_tx_interp(_ptr(x), x.size, samp_rate, None)
+    y = np.zeros(n, cf32)
+    m = lib.orc_tx_interp(_ptr(x), x.size, samp_rate, _ptr(y))
+    return y[:m]
+
+
+def cc_decode_k7(soft):
+    soft = np.ascontiguousarray(soft, np.uint8)
+    out = np.zeros(soft.size // 2 + 80, np.uint8)
+    n = lib.orc_cc_decode_k7(_ptr(soft), soft.size, _ptr(out))
+    return out[:n].copy()
+
+
+def cc_encode_k7(bits):
+    bits = np.ascontiguousarray(bits, np.uint8)
+    out = np.zeros(2 * bits.size, np.uint8)
+    lib.orc_cc_encode_k7(_ptr(bits), bits.size, _ptr(out))
+    return out
+
+
+def scramble(bits, mask=0x8A, seed=0x7F, length=7):
+    bits = np.ascontiguousarray(bits, np.uint8)
+    out = np.zeros_like(bits)
+    lib.orc_scramble(_ptr(bits), bits.size, mask, seed, length, _ptr(out))
+    return out
+
+
+def descramble(bits, mask=0x8A, seed=0x7F, length=7):
+    bits = np.ascontiguousarray(bits, np.uint8)
+    out = np.zeros_like(bits)
+    lib.orc_descramble(_ptr(bits), bits.size, mask, seed, length, _ptr(out))
+    return out
+
+
+def batch_rx(mode, iq, samp_rate, carrier_offset_hz=0.0, threads=0):
+    iq = np.ascontiguousarray(iq, cf32)
+    batch, n = iq.shape
+    chk = C.c_uint64()
+    t = lib.orc_batch_rx(mode, _ptr(iq), batch, n, samp_rate, float(carrier_offset_hz), threads, C.byref(chk))
+    return t, chk.value
