@@ -1,0 +1,127 @@
+/*
+ * qrl_hip.h — C ABI of libqrl_hip.so, the MI355X-native drop-in for QRadioLink's gr_modem
+ * RX DSP hot path (the per-mode demod flowgraphs under src/gr/ of the reference).
+ *
+ * Nothing like this exists in the reference: there the path is a GNU Radio flowgraph
+ * (gr::top_block "demodulator", src/gr/gr_demod_base.cpp:32) whose blocks run on CPU threads.
+ * Each entry point below names the reference interface it replaces; INTEGRATION.md shows the
+ * C++ stub a maintainer would add inside gr_demod_base / a gr::sync_block to bind it.
+ *
+ * Rules: plain C types; no exceptions cross the ABI; every function returns QRL_OK (0) or a
+ * negative qrl_status; the caller owns every buffer it passes, the library owns device state.
+ * One handle is single-threaded (like one GNU Radio block: work() calls never overlap,
+ * SURVEY.md 8b); different handles may be driven concurrently on different HIP streams.
+ *
+ * Data layout: "cf32" = interleaved complex<float> (gr_complex, 8 bytes). A demodulator
+ * handle processes `batch` independent streams per call: iq[b*stride + i], i < n.
+ * All data pointers are DEVICE pointers unless the function name ends in _host.
+ */
+#ifndef QRL_HIP_H
+#define QRL_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    QRL_OK = 0,
+    QRL_ERR_ARG = -1,        /* invalid argument / unsupported mode */
+    QRL_ERR_NO_DEVICE = -2,  /* no HIP device / wrong architecture */
+    QRL_ERR_HIP = -3,        /* a HIP runtime call failed (see qrl_last_error) */
+    QRL_ERR_NOMEM = -4,
+    QRL_ERR_TOO_BIG = -5,    /* n exceeds max_chunk given at creation */
+    QRL_ERR_STATE = -6
+} qrl_status;
+
+/* values of gr_modem_types (reference src/modem_types.h:5-50) accepted by qrl_demod_create */
+enum {
+    QRL_MODEM_2FSK2KFM = 15, QRL_MODEM_2FSK1KFM = 16, QRL_MODEM_2FSK2K = 17, QRL_MODEM_2FSK1K = 18,
+    QRL_MODEM_2FSK10KFM = 19, QRL_MODEM_GMSK2K = 20, QRL_MODEM_GMSK1K = 21, QRL_MODEM_GMSK10K = 22,
+    QRL_MODEM_QPSK250K = 26
+};
+
+typedef struct qrl_ctx qrl_ctx;
+typedef struct qrl_demod qrl_demod;
+
+/* replaces: process-level GNU Radio/VOLK initialisation (gr::make_top_block, gr_demod_base.cpp:32).
+ * Fails with QRL_ERR_NO_DEVICE when no gfx950-class HIP device is usable: there is no CPU fallback. */
+int qrl_init(int device, qrl_ctx** ctx);
+void qrl_shutdown(qrl_ctx* ctx);
+const char* qrl_strerror(int status);
+const char* qrl_last_error(void);
+/* compile-time identification of the library (no GPU needed) */
+const char* qrl_version(void);
+
+/*
+ * Configuration of one RX chain = the constructor arguments the reference passes.
+ * replaces: make_gr_demod_2fsk(sps,samp_rate,carrier_freq,filter_width,fm) gr_demod_2fsk.cpp:19-37,
+ *           make_gr_demod_gmsk(...) gr_demod_gmsk.cpp:19-37, make_gr_demod_qpsk(...) gr_demod_qpsk.cpp:20-37
+ *           with the literals of gr_demod_base.cpp:203-253 when use_mode_defaults != 0;
+ *           gr_demod_base::set_samp_rate (gr_demod_base.cpp:1303-1362) via device_samp_rate;
+ *           gr_demod_base::set_carrier_offset (gr_demod_base.cpp:1220-1225) via carrier_offset_hz.
+ */
+typedef struct {
+    int modem_type;          /* gr_modem_types value */
+    int use_mode_defaults;   /* 1: take sps/filter_width/fm from the reference's table for modem_type */
+    int sps, samp_rate, carrier_freq, filter_width, fm; /* make_gr_demod_X args (samp_rate = 1000000) */
+    int device_samp_rate;    /* SDR rate; >= 2e6 inserts rotator + 1:fs/1e6 decimator, else rotator only */
+    double carrier_offset_hz;
+    int batch;               /* independent streams per call (>= 1) */
+    size_t max_chunk;        /* largest n (samples per stream) of any process call */
+    void* hip_stream;        /* hipStream_t to run on, NULL = the library creates one */
+    int enable_side_outputs; /* 1: also produce port 0 (filtered) and port 1 (constellation) */
+} qrl_demod_config;
+
+/* per-call outputs, all caller-allocated DEVICE buffers laid out [batch][cap];
+ * counts[b*4 + k] = items written for stream b on port k (0 filtered, 1 constellation, 2 bits A, 3 bits B).
+ * A NULL data pointer skips that port (its count is still reported). */
+typedef struct {
+    float* filtered;      size_t filtered_cap;      /* cf32, port 0: gr_demod_2fsk.cpp:133 */
+    float* constellation; size_t constellation_cap; /* cf32, port 1: gr_demod_2fsk.cpp:153-154 */
+    uint8_t* bits_a;      size_t bits_cap;          /* u8 one bit per byte, port 2 */
+    uint8_t* bits_b;                                /* port 3 (two-branch modes), same cap */
+    uint32_t* counts;                               /* [batch][4] */
+} qrl_demod_out;
+
+int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** out);
+void qrl_demod_destroy(qrl_demod* d);
+/* replaces: top_block lock/flush on set_mode (gr_demod_base.cpp:302-311): zero all DSP state */
+int qrl_demod_reset(qrl_demod* d);
+/* replaces: rotator_cc::set_phase_inc (gr_demod_base.cpp:1220-1225); phase-continuous retune */
+int qrl_demod_set_carrier_offset(qrl_demod* d, double carrier_offset_hz);
+/* capacities (items per stream) a call with n input samples can need */
+int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* filtered_cap, size_t* constellation_cap, size_t* bits_cap);
+
+/* replaces: one scheduler pass of the "demodulator" top_block over n new samples per stream:
+ * gr::sync_block::work()/general_work() of every block on the chain (SURVEY.md 8b block ABI).
+ * iq: device pointer, stream b at iq + 2*b*stride floats, n <= max_chunk samples each, base and
+ * stride*8 bytes 16-byte aligned.  Asynchronous on the handle's stream; results are valid after
+ * qrl_demod_sync().  Results are independent of how the stream is cut into calls. */
+int qrl_demod_process(qrl_demod* d, const float* iq, size_t stride, size_t n, const qrl_demod_out* out);
+int qrl_demod_sync(qrl_demod* d);
+void* qrl_demod_stream(qrl_demod* d); /* hipStream_t */
+
+/* host-buffer convenience used by the C++ adaptor (gr_bit_sink-style mailboxes): copies iq H2D,
+ * runs one pass, copies bits back.  bits_x_host: [batch][bits_cap]; counts_host: [batch][4]. */
+int qrl_demod_process_host(qrl_demod* d, const float* iq_host, size_t stride, size_t n,
+                           uint8_t* bits_a_host, uint8_t* bits_b_host, size_t bits_cap, uint32_t* counts_host);
+
+/* ---- filter design & tables (host side, no GPU needed): what the kernels are loaded with ----
+ * replaces: gr::filter::firdes::* calls at gr_demod_2fsk.cpp:82-97, gr_demod_gmsk.cpp:80-98,
+ * gr_demod_qpsk.cpp:92-103, gr_demod_base.cpp:1333-1336.  taps==NULL returns the count. */
+enum { QRL_WIN_HAMMING = 0, QRL_WIN_HANN = 1, QRL_WIN_BLACKMAN = 2, QRL_WIN_RECTANGULAR = 3, QRL_WIN_BLACKMAN_HARRIS = 5 };
+int qrl_firdes_low_pass(double gain, double fs, double fc, double tw, int window, float* taps);
+int qrl_firdes_low_pass_2(double gain, double fs, double fc, double tw, double atten_db, int window, float* taps);
+int qrl_firdes_complex_band_pass(double gain, double fs, double lo, double hi, double tw, int window, float* taps_cf32);
+int qrl_firdes_root_raised_cosine(double gain, double fs, double symrate, double alpha, int ntaps, float* taps);
+int qrl_table_mmse(float* t129x8);
+int qrl_table_atan(float* t257);
+int qrl_table_tanh(float* t256);
+uint64_t qrl_phase_inc_to_turn(double radians_per_sample);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,242 @@
+"""qradiolink_amd — MI355X-native drop-in for QRadioLink's gr_modem RX DSP hot path.
+
+This package is a thin ctypes binding over the C ABI of ``libqrl_hip.so`` (include/qrl_hip.h).
+The compute path is hand-written HIP for gfx950; torch is used only to own device memory and
+streams.  There is NO CPU fallback: importing works without a GPU (host-side filter design is
+usable), but creating a demodulator without the HIP library or a device raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqrl_hip.so")
+
+# gr_modem_types (reference src/modem_types.h:5-50)
+MODEM_2FSK2KFM, MODEM_2FSK1KFM, MODEM_2FSK2K, MODEM_2FSK1K, MODEM_2FSK10KFM = 15, 16, 17, 18, 19
+MODEM_GMSK2K, MODEM_GMSK1K, MODEM_GMSK10K = 20, 21, 22
+MODEM_QPSK250K = 26
+WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECTANGULAR, WIN_BLACKMAN_HARRIS = 0, 1, 2, 3, 5
+
+
+class QrlError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [("modem_type", C.c_int), ("use_mode_defaults", C.c_int), ("sps", C.c_int), ("samp_rate", C.c_int),
+                ("carrier_freq", C.c_int), ("filter_width", C.c_int), ("fm", C.c_int), ("device_samp_rate", C.c_int),
+                ("carrier_offset_hz", C.c_double), ("batch", C.c_int), ("max_chunk", C.c_size_t),
+                ("hip_stream", C.c_void_p), ("enable_side_outputs", C.c_int)]
+
+
+class _Out(C.Structure):
+    _fields_ = [("filtered", C.c_void_p), ("filtered_cap", C.c_size_t), ("constellation", C.c_void_p),
+                ("constellation_cap", C.c_size_t), ("bits_a", C.c_void_p), ("bits_cap", C.c_size_t),
+                ("bits_b", C.c_void_p), ("counts", C.c_void_p)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libqrl_hip.so (built in-tree by __graft_entry__.build()).  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QrlError("libqrl_hip.so not found at %s: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, sz = C.c_void_p, C.c_size_t
+    lib.qrl_version.restype = C.c_char_p
+    lib.qrl_last_error.restype = C.c_char_p
+    lib.qrl_strerror.restype = C.c_char_p
+    lib.qrl_strerror.argtypes = [C.c_int]
+    lib.qrl_init.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.qrl_shutdown.argtypes = [vp]
+    lib.qrl_demod_create.argtypes = [vp, C.POINTER(_Config), C.POINTER(vp)]
+    lib.qrl_demod_destroy.argtypes = [vp]
+    lib.qrl_demod_reset.argtypes = [vp]
+    lib.qrl_demod_set_carrier_offset.argtypes = [vp, C.c_double]
+    lib.qrl_demod_out_caps.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+    lib.qrl_demod_process.argtypes = [vp, vp, sz, sz, C.POINTER(_Out)]
+    lib.qrl_demod_sync.argtypes = [vp]
+    lib.qrl_demod_stream.restype = vp
+    lib.qrl_demod_stream.argtypes = [vp]
+    lib.qrl_demod_process_host.argtypes = [vp, vp, sz, sz, vp, vp, sz, vp]
+    lib.qrl_firdes_low_pass.argtypes = [C.c_double] * 4 + [C.c_int, vp]
+    lib.qrl_firdes_low_pass_2.argtypes = [C.c_double] * 5 + [C.c_int, vp]
+    lib.qrl_firdes_complex_band_pass.argtypes = [C.c_double] * 5 + [C.c_int, vp]
+    lib.qrl_firdes_root_raised_cosine.argtypes = [C.c_double] * 4 + [C.c_int, vp]
+    for n in ("mmse", "atan", "tanh"):
+        getattr(lib, "qrl_table_" + n).argtypes = [vp]
+    lib.qrl_phase_inc_to_turn.restype = C.c_uint64
+    lib.qrl_phase_inc_to_turn.argtypes = [C.c_double]
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "qrl_init", "qrl_shutdown", "qrl_strerror", "qrl_last_error", "qrl_version", "qrl_demod_create",
+    "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_out_caps",
+    "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_firdes_low_pass",
+    "qrl_firdes_low_pass_2", "qrl_firdes_complex_band_pass", "qrl_firdes_root_raised_cosine", "qrl_table_mmse",
+    "qrl_table_atan", "qrl_table_tanh", "qrl_phase_inc_to_turn",
+]
+
+
+def _check(rc, what):
+    if rc != 0:
+        lib = load_library()
+        raise QrlError("%s failed: %s (%s)" % (what, lib.qrl_strerror(rc).decode(), lib.qrl_last_error().decode()))
+
+
+# ---------------------------------------------------------------- host-side design (no GPU needed)
+def _taps(fn, count_args, dtype=np.float32, mult=1):
+    lib = load_library()
+    n = fn(*count_args, None)
+    t = np.zeros(n * mult, np.float32)
+    fn(*count_args, t.ctypes.data_as(C.c_void_p))
+    return t.view(dtype) if dtype != np.float32 else t
+
+
+def low_pass(gain, fs, fc, tw, win=WIN_HAMMING):
+    return _taps(load_library().qrl_firdes_low_pass, (gain, fs, fc, tw, win))
+
+
+def low_pass_2(gain, fs, fc, tw, att, win=WIN_HAMMING):
+    return _taps(load_library().qrl_firdes_low_pass_2, (gain, fs, fc, tw, att, win))
+
+
+def complex_band_pass(gain, fs, lo, hi, tw, win=WIN_HAMMING):
+    return _taps(load_library().qrl_firdes_complex_band_pass, (gain, fs, lo, hi, tw, win), np.complex64, 2)
+
+
+def root_raised_cosine(gain, fs, sr, alpha, ntaps):
+    return _taps(load_library().qrl_firdes_root_raised_cosine, (gain, fs, sr, alpha, ntaps))
+
+
+def table(name):
+    n = {"mmse": 129 * 8, "atan": 257, "tanh": 256}[name]
+    t = np.zeros(n, np.float32)
+    getattr(load_library(), "qrl_table_" + name)(t.ctypes.data_as(C.c_void_p))
+    return t
+
+
+# ---------------------------------------------------------------- device path
+class Context:
+    """qrl_init/qrl_shutdown wrapper (one per process and device)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        _check(self.lib.qrl_init(device, C.byref(self.h)), "qrl_init")
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.lib.qrl_shutdown(self.h)
+            self.h = C.c_void_p()
+
+
+class Demod:
+    """Batch RX demodulator: mirrors make_gr_demod_2fsk / make_gr_demod_gmsk (+ gr_demod_base front end).
+
+    process(iq) takes a torch cuda tensor complex64 [batch, n] (device-resident) and returns a dict of
+    torch tensors: filtered [B, cap] complex64, constellation [B, cap] complex64, bits_a/bits_b [B, cap]
+    uint8 and counts [B, 4] int32 (valid lengths per port).  Same ports as the reference hier blocks
+    (gr_demod_2fsk.cpp:19-37)."""
+
+    def __init__(self, ctx, modem_type, batch, max_chunk, device_samp_rate=1000000, carrier_offset_hz=0.0,
+                 side_outputs=True, stream=None, **explicit):
+        import torch
+        self.torch = torch
+        self.ctx, self.lib = ctx, ctx.lib
+        cfg = _Config()
+        cfg.modem_type = modem_type
+        cfg.use_mode_defaults = 0 if explicit else 1
+        if explicit:
+            cfg.sps = explicit["sps"]
+            cfg.samp_rate = explicit.get("samp_rate", 1000000)
+            cfg.carrier_freq = explicit.get("carrier_freq", 1700)
+            cfg.filter_width = explicit["filter_width"]
+            cfg.fm = int(explicit.get("fm", 0))
+        cfg.device_samp_rate = device_samp_rate
+        cfg.carrier_offset_hz = carrier_offset_hz
+        cfg.batch = batch
+        cfg.max_chunk = max_chunk
+        cfg.hip_stream = stream
+        cfg.enable_side_outputs = int(side_outputs)
+        self.batch, self.max_chunk, self.side = batch, max_chunk, side_outputs
+        self.h = C.c_void_p()
+        _check(self.lib.qrl_demod_create(ctx.h, C.byref(cfg), C.byref(self.h)), "qrl_demod_create")
+        f, c, b = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _check(self.lib.qrl_demod_out_caps(self.h, max_chunk, C.byref(f), C.byref(c), C.byref(b)), "qrl_demod_out_caps")
+        self.caps = (f.value, c.value, b.value)
+        dev = "cuda:%d" % ctx.device
+        self.filtered = torch.zeros((batch, f.value), dtype=torch.complex64, device=dev) if side_outputs else None
+        self.constellation = torch.zeros((batch, c.value), dtype=torch.complex64, device=dev) if side_outputs else None
+        self.bits_a = torch.zeros((batch, b.value), dtype=torch.uint8, device=dev)
+        self.bits_b = torch.zeros((batch, b.value), dtype=torch.uint8, device=dev)
+        self.counts = torch.zeros((batch, 4), dtype=torch.int32, device=dev)
+        self._out = _Out()
+        if side_outputs:
+            self._out.filtered, self._out.filtered_cap = self.filtered.data_ptr(), f.value
+            self._out.constellation, self._out.constellation_cap = self.constellation.data_ptr(), c.value
+        self._out.bits_a, self._out.bits_b, self._out.bits_cap = self.bits_a.data_ptr(), self.bits_b.data_ptr(), b.value
+        self._out.counts = self.counts.data_ptr()
+
+    def process_async(self, iq):
+        """Queue one pass over iq ([batch, n] complex64 cuda tensor) on the handle's stream."""
+        assert iq.is_cuda and iq.dtype == self.torch.complex64 and iq.dim() == 2 and iq.shape[0] == self.batch
+        assert iq.stride(1) == 1
+        _check(self.lib.qrl_demod_process(self.h, iq.data_ptr(), iq.stride(0), iq.shape[1], C.byref(self._out)),
+               "qrl_demod_process")
+
+    def sync(self):
+        _check(self.lib.qrl_demod_sync(self.h), "qrl_demod_sync")
+
+    def process(self, iq):
+        self.process_async(iq)
+        self.sync()
+        return dict(filtered=self.filtered, constellation=self.constellation, bits_a=self.bits_a, bits_b=self.bits_b,
+                    counts=self.counts)
+
+    def reset(self):
+        _check(self.lib.qrl_demod_reset(self.h), "qrl_demod_reset")
+
+    def set_carrier_offset(self, hz):
+        _check(self.lib.qrl_demod_set_carrier_offset(self.h, float(hz)), "qrl_demod_set_carrier_offset")
+
+    def close(self):
+        if self.h:
+            self.lib.qrl_demod_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def collect(dem, iq, chunk):
+    """Run a whole [B, N] device tensor through dem in calls of `chunk` samples and concatenate the
+    per-port outputs on the host: returns dict of lists (one numpy array per stream)."""
+    import torch
+    B, N = iq.shape
+    ports = {k: [[] for _ in range(B)] for k in ("filtered", "constellation", "bits_a", "bits_b")}
+    idx = {"filtered": 0, "constellation": 1, "bits_a": 2, "bits_b": 3}
+    for s in range(0, N, chunk):
+        part = iq[:, s:s + chunk]
+        if part.stride(0) % 2 or (part.data_ptr() % 16):
+            part = part.contiguous()
+            if part.stride(0) % 2:
+                pad = torch.zeros((B, part.shape[1] + 1), dtype=part.dtype, device=part.device)
+                pad[:, :part.shape[1]] = part
+                part = pad[:, :part.shape[1]]
+        out = dem.process(part)
+        cnt = out["counts"].cpu().numpy()
+        for k, j in idx.items():
+            if out[k] is None:
+                continue
+            host = out[k].cpu().numpy()
+            for b in range(B):
+                ports[k][b].append(host[b, :cnt[b, j]].copy())
+    return {k: [np.concatenate(v) if v else np.zeros(0) for v in ports[k]] for k in ports}

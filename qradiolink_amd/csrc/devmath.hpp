@@ -1,0 +1,117 @@
+// devmath.hpp — device-side deterministic math shared by the HIP kernels.
+// Compiled with -ffp-contract=off: every fused multiply-add is an explicit fmaf().
+// The polynomial NCO replaces libm sincosf in rotator_cc / fll_band_edge_cc / costas_loop_cc
+// (GNU Radio gr_expj) so that results do not depend on a math library; see DESIGN.md "Arithmetic".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qrl {
+
+__device__ __forceinline__ float poly_sin(float x)
+{
+    const float z = x * x;
+    float p = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    p = fmaf(z, p, -1.6666654611e-1f);
+    return fmaf(x * z, p, x);
+}
+__device__ __forceinline__ float poly_cos(float x)
+{
+    const float z = x * x;
+    float p = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    p = fmaf(z, p, 4.166664568298827e-2f);
+    const float q = fmaf(z, -0.5f, 1.0f);
+    return fmaf(z * z, p, q);
+}
+// returns (cos, sin)
+__device__ __forceinline__ float2 quad_fix(int q, float ps, float pc)
+{
+    switch (q & 3) {
+    case 0: return make_float2(pc, ps);
+    case 1: return make_float2(-ps, pc);
+    case 2: return make_float2(-pc, -ps);
+    default: return make_float2(ps, -pc);
+    }
+}
+// (cos x, sin x) of a float angle in radians, |x| <~ 10
+__device__ __forceinline__ float2 sincos_rad(float x)
+{
+    const float k = rintf(x * 0.636619772367581343f);
+    float r = fmaf(-k, 1.57079637050628662109375f, x);
+    r = fmaf(-k, -4.37113900018624283e-8f, r);
+    return quad_fix((int)k, poly_sin(r), poly_cos(r));
+}
+// (cos, sin) of a 2^-64-turn fixed-point angle (top 32 bits used)
+__device__ __forceinline__ float2 sincos_turn(uint64_t angle)
+{
+    const uint32_t a = (uint32_t)(angle >> 32);
+    const uint32_t q = (a + 0x20000000u) >> 30;
+    const int32_t r = (int32_t)(a - (q << 30));
+    const float x = (float)r * 1.4629180792671596e-9f;
+    return quad_fix((int)q, poly_sin(x), poly_cos(x));
+}
+// complex product with the fixed fmaf pattern of the rotator contract
+__device__ __forceinline__ float2 cmul_fma(float2 a, float2 b)
+{
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+// plain complex product (std::complex operator*: two products and one add/sub per part)
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// gnuradio fast_atan2f with its 257-entry table T
+__device__ __forceinline__ float fast_atan2f_lut(float y, float x, const float* __restrict__ T)
+{
+    const float y_abs = fabsf(y), x_abs = fabsf(x);
+    if (!((y_abs > 0.0f) || (x_abs > 0.0f))) return 0.0f;
+    const float z = (y_abs < x_abs) ? (y_abs / x_abs) : (x_abs / y_abs);
+    float base;
+    if ((double)z < 0.003921569) {
+        base = z;
+    } else {
+        float alpha = z * 255.0f;
+        const int index = ((int)alpha) & 0xff;
+        alpha -= (float)index;
+        const float d = T[index + 1] - T[index];
+        base = T[index] + d * alpha;
+    }
+    const float PI_F = 3.14159265358979323846f, PIO2_F = 1.57079632679489661923f;
+    float angle;
+    if (x_abs > y_abs) {
+        if (x >= 0.0f) angle = (y >= 0.0f) ? base : -base;
+        else           angle = (y >= 0.0f) ? (PI_F - base) : (base - PI_F);
+    } else {
+        if (y >= 0.0f) angle = (x >= 0.0f) ? (PIO2_F - base) : (PIO2_F + base);
+        else           angle = (x >= 0.0f) ? (-PIO2_F + base) : (-PIO2_F - base);
+    }
+    return angle;
+}
+
+__device__ __forceinline__ float tanhf_lut(float x, const float* __restrict__ T)
+{
+    if (x > 2.0f) return 1.0f;
+    if (x <= -2.0f) return -1.0f;
+    int index = (int)(128.0f + 64.0f * x);
+    index = index > 255 ? 255 : (index < 0 ? 0 : index);
+    return T[index];
+}
+
+__device__ __forceinline__ float branchless_clip(float x, float clip)
+{
+    float x1 = fabsf(x + clip);
+    const float x2 = fabsf(x - clip);
+    x1 -= x2;
+    return 0.5f * x1;
+}
+
+__device__ __forceinline__ float phase_wrap(float phase)
+{
+    const double TWO_PI = 6.283185307179586476925286766559;
+    while (phase > (float)TWO_PI) phase = (float)((double)phase - TWO_PI);
+    while (phase < (float)(-TWO_PI)) phase = (float)((double)phase + TWO_PI);
+    return phase;
+}
+
+}  // namespace qrl

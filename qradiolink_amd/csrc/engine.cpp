@@ -1,0 +1,536 @@
+// engine.cpp — host side of libqrl_hip.so: builds the per-mode kernel pipeline the reference builds
+// as a GNU Radio flowgraph (gr_demod_base.cpp:299-828 connects rotator -> resampler -> gr_demod_X),
+// owns all device state, and exposes it through the C ABI of include/qrl_hip.h.
+// There is NO CPU fallback: without a usable HIP device qrl_init() fails.
+#include "../../include/qrl_hip.h"
+#include "engine.hpp"
+#include "firdes.hpp"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace qrl;
+
+static thread_local std::string g_last_error;
+static int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(QRL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+struct qrl_ctx { int device; };
+
+namespace {
+
+template <class T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t count) {
+        n = count;
+        if (hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return QRL_ERR_NOMEM;
+        if (hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return QRL_ERR_HIP;
+        return QRL_OK;
+    }
+    int upload(const std::vector<T>& v) {
+        int r = alloc(v.size());
+        if (r) return r;
+        if (!v.empty() && hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
+        return QRL_OK;
+    }
+    int zero() { return hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)) == hipSuccess ? QRL_OK : QRL_ERR_HIP; }
+};
+
+uint32_t pow2_at_least(size_t v) { uint32_t c = 64; while (c < v) c <<= 1; return c; }
+uint64_t decim_count(uint64_t n, int I, int D) { return n ? ((n - 1) * (uint64_t)I + (uint64_t)I - 1) / (uint64_t)D + 1 : 0; }
+
+// polyphase layout for k_decim: taps[p*Jpad + j] = h[p + j*D]
+std::vector<float> decim_layout(const std::vector<float>& h, int D, int Jpad)
+{
+    std::vector<float> t((size_t)D * Jpad, 0.0f);
+    for (size_t k = 0; k < h.size(); ++k) t[(k % D) * Jpad + k / D] = h[k];
+    return t;
+}
+std::vector<float> resamp_layout(const std::vector<float>& h, int I, int Jp)
+{
+    std::vector<float> t((size_t)I * Jp, 0.0f);
+    for (size_t k = 0; k < h.size(); ++k) t[(k % I) * Jp + k / I] = h[k];
+    return t;
+}
+std::vector<float2> to_f2(const std::vector<std::complex<float>>& v)
+{
+    std::vector<float2> r(v.size());
+    for (size_t i = 0; i < v.size(); ++i) r[i] = make_float2(v[i].real(), v[i].imag());
+    return r;
+}
+
+struct DecimStage {
+    bool used = false;
+    int D = 1, Jpad = 0, variant = DECIM_R4_J14, nt = 0;
+    DevBuf<float> taps;
+    int plan(const std::vector<float>& h, int D_) {
+        used = true; D = D_; nt = (int)h.size();
+        const int J = (nt + D - 1) / D;
+        if (J <= 9 && decim_lds_bytes(D, 9, DECIM_R2_J9) <= 80 * 1024) { variant = DECIM_R2_J9; Jpad = 9; }
+        else {
+            Jpad = (J + 13) / 14 * 14;
+            variant = decim_lds_bytes(D, Jpad, DECIM_R4_J14) <= 80 * 1024 ? DECIM_R4_J14 : DECIM_R1_J14;
+            if (decim_lds_bytes(D, Jpad, variant) > 160 * 1024) return QRL_ERR_ARG;
+        }
+        return taps.upload(decim_layout(h, D, Jpad));
+    }
+    uint32_t lookback() const { return (uint32_t)(Jpad * D); }
+};
+
+}  // namespace
+
+struct qrl_demod {
+    qrl_ctx* ctx = nullptr;
+    qrl_demod_config cfg{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    enum Family { F_2FSK, F_GMSK } fam = F_2FSK;
+    int branches = 2;
+
+    // derived chain parameters (gr_demod_2fsk.cpp:39-63, gr_demod_gmsk.cpp:39-63)
+    int fe_decim = 1, interp = 1, decim = 1, target = 0, sps_eff = 0;
+    bool fm = false;
+
+    // stage objects
+    DecimStage fe;      // gr_demod_base resampler (device rate >= 2 Msps)
+    DecimStage first;   // per-mode _resampler when interp == 1
+    DevBuf<float> rs_taps; int rs_Jp = 0;  // per-mode _resampler when interp > 1
+    DevBuf<float> filt_taps; int filt_nt = 0;
+    DevBuf<float> symf_taps; int symf_nt = 0;
+    DevBuf<float2> disc_up, disc_lo; int disc_nt = 0;
+    DevBuf<float2> fll_lo, fll_up; float fll_alpha = 0, fll_beta = 0, fll_maxf = 0;
+    DevBuf<float> atan_tab, mmse_tab;
+    float demod_gain = 0;
+    float ss_alpha = 0, ss_beta = 0, ss_maxp = 0, ss_minp = 0;
+
+    // rotator (gr_demod_base.cpp:57,1220-1225): exact 2^-64-turn NCO
+    uint64_t rot_inc = 0, rot_acc = 0, rot_nbase = 0;
+    DevBuf<float2> rot_lo;
+
+    // rings and state
+    DevBuf<float2> hist_a, hist_b; uint32_t hist_len = 0; bool hist_flip = false;
+    DevBuf<float2> s1, s2, s2l, s2f; DevBuf<float> s2d, s3; DevBuf<uint8_t> soft;
+    uint32_t s1_mask = 0, s2_mask = 0, soft_mask = 0;
+    DevBuf<FllState> fll_st; DevBuf<SymSyncState> ss_st; DevBuf<FecState> fec_st;
+    DevBuf<uint32_t> counts_scratch;
+    uint64_t n_in = 0, n1 = 0, n2 = 0;  // items so far: device rate, 1 Msps, target rate
+
+    ~qrl_demod() { if (own_stream && stream) (void)hipStreamDestroy(stream); }
+
+    int upload_rot_table() {
+        std::vector<float2> lo(512);
+        for (int r = 0; r < 512; ++r) { float s, c; sincos_turn_host((uint64_t)r * rot_inc, s, c); lo[r] = make_float2(c, s); }
+        if (!rot_lo.p) return rot_lo.upload(lo);
+        return hipMemcpy(rot_lo.p, lo.data(), 512 * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess ? QRL_OK : QRL_ERR_HIP;
+    }
+    int init_state();
+    int build();
+    int process(const float* iq, size_t stride, size_t n, const qrl_demod_out* out);
+};
+
+int qrl_demod::init_state()
+{
+    int r;
+    for (auto* b : {&hist_a, &hist_b, &s1, &s2, &s2l, &s2f}) if (b->p && (r = b->zero())) return r;
+    for (auto* b : {&s2d, &s3}) if (b->p && (r = b->zero())) return r;
+    if ((r = soft.zero())) return r;
+    if (fll_st.p && (r = fll_st.zero())) return r;
+    std::vector<SymSyncState> ss(cfg.batch);
+    for (auto& s : ss) { std::memset(&s, 0, sizeof s); s.avg = s.inst = (float)sps_eff; }
+    if (hipMemcpy(ss_st.p, ss.data(), ss.size() * sizeof(SymSyncState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
+    std::vector<FecState> fs((size_t)cfg.batch * 2);
+    for (auto& f : fs) { f.consumed = 0; f.start_state = 0; f.last_bits = 0xFE; }  // descrambler seed 0x7F, newest bit first
+    if (hipMemcpy(fec_st.p, fs.data(), fs.size() * sizeof(FecState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
+    n_in = n1 = n2 = 0;
+    rot_acc = 0; rot_nbase = 0; hist_flip = false;
+    return QRL_OK;
+}
+
+int qrl_demod::build()
+{
+    int r;
+    const int sps = cfg.sps, samp_rate = cfg.samp_rate, fw = cfg.filter_width;
+    if (fam == F_2FSK) {
+        if (sps == 10)     { target = 20000; sps_eff = sps;     decim = 50; interp = 1; }
+        else if (sps >= 5) { target = 40000; sps_eff = sps * 2; decim = 25; interp = 1; }
+        else if (sps == 1) { target = 80000; sps_eff = 4;       decim = 25; interp = 2; }
+        else return fail(QRL_ERR_ARG, "2fsk: unsupported sps");
+    } else {
+        if (sps == 10)     { target = 20000; sps_eff = sps;     decim = 50; interp = 1; }
+        else if (sps == 5) { target = 40000; sps_eff = sps * 2; decim = 25; interp = 1; }
+        else if (sps == 1) { target = 80000; sps_eff = 4;       decim = 25; interp = 2; }
+        else return fail(QRL_ERR_ARG, "gmsk: unsupported sps");
+    }
+    fm = cfg.fm != 0;
+    const int B = cfg.batch;
+    const size_t maxn = cfg.max_chunk;
+
+    // --- front end (gr_demod_base.cpp:1317-1340)
+    fe_decim = 1;
+    if (cfg.device_samp_rate >= 2000000) {
+        fe_decim = cfg.device_samp_rate / 1000000;
+        if ((r = fe.plan(low_pass(1, cfg.device_samp_rate, 480000, 100000, WIN_BLACKMAN_HARRIS), fe_decim))) return fail(r, "front-end plan");
+    }
+    rot_inc = phase_inc_to_turn(2 * M_PI * -cfg.carrier_offset_hz / cfg.device_samp_rate);
+    if ((r = upload_rot_table())) return r;
+
+    // --- per-mode first resampler (gr_demod_2fsk.cpp:82-88, gr_demod_gmsk.cpp:80-83)
+    const std::vector<float> rtaps = low_pass(interp, (double)interp * samp_rate, target / 2, target / 2, WIN_BLACKMAN_HARRIS);
+    if (interp == 1) { if ((r = first.plan(rtaps, decim))) return fail(r, "resampler plan"); }
+    else {
+        rs_Jp = ((int)rtaps.size() + interp - 1) / interp;
+        if ((r = rs_taps.upload(resamp_layout(rtaps, interp, rs_Jp)))) return r;
+    }
+
+    // --- history of the caller's IQ kept by whichever stage reads it
+    if (fe.used) hist_len = fe.lookback();
+    else if (interp == 1) hist_len = first.lookback();
+    else hist_len = (uint32_t)(rs_Jp + decim + 2);
+    if ((r = hist_a.alloc((size_t)B * hist_len)) || (r = hist_b.alloc((size_t)B * hist_len))) return r;
+
+    // --- rings
+    const size_t max1 = fe.used ? maxn / fe_decim + 2 : 0;           // 1 Msps items per call
+    const size_t in2 = fe.used ? max1 : maxn;                        // items entering the mode resampler per call
+    const size_t max2 = in2 * interp / decim + 2;                    // target-rate items per call
+    if (fe.used) {
+        const size_t look = interp == 1 ? first.lookback() : (size_t)(rs_Jp + decim + 2);
+        s1_mask = pow2_at_least(max1 + look + 64) - 1;
+        if ((r = s1.alloc((size_t)B * (s1_mask + 1)))) return r;
+    }
+    s2_mask = pow2_at_least(max2 + 1024) - 1;   // history needs: <= 501 taps downstream
+    const size_t ring2 = (size_t)B * (s2_mask + 1);
+    if ((r = s2.alloc(ring2)) || (r = s2f.alloc(ring2)) || (r = s2d.alloc(ring2)) || (r = s3.alloc(ring2))) return r;
+    if (fam == F_2FSK && (r = s2l.alloc(ring2))) return r;
+    const size_t maxsym = max2 / (size_t)(sps_eff > 1 ? sps_eff - 1 : 1) + 8;
+    soft_mask = pow2_at_least(maxsym + 512) - 1;
+    if ((r = soft.alloc((size_t)B * (soft_mask + 1)))) return r;
+
+    // --- decimated-rate filters
+    {
+        const std::vector<float> f = low_pass(1, target, fw, fw, WIN_BLACKMAN_HARRIS);
+        filt_nt = (int)f.size();
+        if ((r = filt_taps.upload(f))) return r;
+    }
+    if ((r = atan_tab.upload(atan_table())) || (r = mmse_tab.upload(mmse_table()))) return r;
+    if (fam == F_2FSK) {
+        std::vector<std::complex<float>> lo, up;
+        fll_band_edge_taps((float)sps_eff, 0.1f, 16, lo, up);
+        if ((r = fll_lo.upload(to_f2(lo))) || (r = fll_up.upload(to_f2(up)))) return r;
+        control_loop_gains((float)(24 * M_PI / 100), fll_alpha, fll_beta);
+        fll_maxf = (float)(2 * M_PI * (2.0 / sps_eff));
+        if ((r = fll_st.alloc(B))) return r;
+        if (fm) {
+            int nfilts = (sps == 1 ? 125 : 35) * sps_eff;
+            if ((nfilts % 2) == 0) nfilts += 1;
+            const std::vector<float> rrc = root_raised_cosine(1, target, target / sps_eff, 0.2, nfilts);
+            symf_nt = (int)rrc.size();
+            if ((r = symf_taps.upload(rrc))) return r;
+            demod_gain = (float)(sps_eff / (1 * M_PI / 2));
+        } else {
+            const auto up2 = complex_band_pass(1, target, -fw, 0, fw, WIN_BLACKMAN_HARRIS);
+            const auto lo2 = complex_band_pass(1, target, 0, fw, fw, WIN_BLACKMAN_HARRIS);
+            disc_nt = (int)up2.size();
+            if ((r = disc_up.upload(to_f2(up2))) || (r = disc_lo.upload(to_f2(lo2)))) return r;
+            const std::vector<float> sf = low_pass(1.0, target, target / sps_eff, target / sps_eff, WIN_HAMMING);
+            symf_nt = (int)sf.size();
+            if ((r = symf_taps.upload(sf))) return r;
+        }
+        const float symbol_rate = (float)target / (float)sps_eff;
+        const float dev = 200.0f / symbol_rate;
+        clock_loop_gains((float)(2 * M_PI / (symbol_rate / 10)), 1.0f, 0.2869f, ss_alpha, ss_beta);
+        ss_maxp = (float)sps_eff + dev; ss_minp = (float)sps_eff - dev;
+    } else {
+        const std::vector<float> sf = low_pass(1, target, target / sps_eff, target / sps_eff, WIN_HAMMING);
+        symf_nt = (int)sf.size();
+        if ((r = symf_taps.upload(sf))) return r;
+        demod_gain = (float)(sps_eff / (M_PI / 2));
+        clock_loop_gains((float)(2 * M_PI / 200.0f), 1.0f, 0.2869f, ss_alpha, ss_beta);
+        ss_maxp = (float)sps_eff + 0.05f; ss_minp = (float)sps_eff - 0.05f;
+    }
+    if ((r = ss_st.alloc(B)) || (r = fec_st.alloc((size_t)B * 2)) || (r = counts_scratch.alloc((size_t)B * 4))) return r;
+    return init_state();
+}
+
+int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod_out* out)
+{
+    if (n > cfg.max_chunk) return fail(QRL_ERR_TOO_BIG, "n exceeds max_chunk");
+    if ((reinterpret_cast<uintptr_t>(iq) & 15u) || (stride & 1u)) return fail(QRL_ERR_ARG, "iq must be 16-byte aligned, stride even");
+    const int B = cfg.batch;
+    uint32_t* counts = (out && out->counts) ? out->counts : counts_scratch.p;
+    HIPCHK(hipMemsetAsync(counts, 0, (size_t)B * 4 * sizeof(uint32_t), stream));
+    const float2* in = reinterpret_cast<const float2*>(iq);
+    const float2* hist_old = hist_flip ? hist_b.p : hist_a.p;
+    float2* hist_new = hist_flip ? hist_a.p : hist_b.p;
+
+    const uint64_t n_in0 = n_in, n_in1 = n_in + n;
+    uint64_t n1_0 = n1, n1_1 = n1;
+    RingC r1{s1.p, s1_mask}, r2{s2.p, s2_mask}, r2l{s2l.p, s2_mask}, r2f{s2f.p, s2_mask};
+    RingF r2d{s2d.p, s2_mask}, r3{s3.p, s2_mask};
+
+    // ---- stage A: gr_demod_base front end
+    if (fe.used) {
+        n1_1 = decim_count(n_in1, 1, fe_decim);
+        DecimParams p{};
+        p.in = in; p.in_stride = stride; p.n0 = n_in0; p.n = (uint32_t)n;
+        p.hist = hist_old; p.hist_len = hist_len;
+        p.out = r1; p.m0 = n1_0; p.m_count = (uint32_t)(n1_1 - n1_0);
+        p.taps = fe.taps.p; p.D = fe.D; p.Jpad = fe.Jpad;
+        p.rot_enable = 1; p.rot_acc = rot_acc; p.rot_inc = rot_inc; p.rot_nbase = rot_nbase; p.rot_lo = rot_lo.p;
+        launch_decim(p, B, fe.variant, stream);
+    }
+    // ---- stage B: per-mode resampler
+    const uint64_t src0 = fe.used ? n1_0 : n_in0, src1 = fe.used ? n1_1 : n_in1;
+    const uint64_t n2_0 = n2, n2_1 = decim_count(src1, interp, decim);
+    if (interp == 1) {
+        DecimParams p{};
+        if (fe.used) { p.in = nullptr; p.in_ring = r1; }
+        else { p.in = in; p.in_stride = stride; p.hist = hist_old; p.hist_len = hist_len;
+               p.rot_enable = 1; p.rot_acc = rot_acc; p.rot_inc = rot_inc; p.rot_nbase = rot_nbase; p.rot_lo = rot_lo.p; }
+        p.n0 = src0; p.n = (uint32_t)(src1 - src0);
+        p.out = r2; p.m0 = n2_0; p.m_count = (uint32_t)(n2_1 - n2_0);
+        p.taps = first.taps.p; p.D = first.D; p.Jpad = first.Jpad;
+        launch_decim(p, B, first.variant, stream);
+    } else {
+        ResampParams p{};
+        if (fe.used) { p.in = nullptr; p.in_ring = r1; }
+        else { p.in = in; p.in_stride = stride; p.hist = hist_old; p.hist_len = hist_len;
+               p.rot_enable = 1; p.rot_acc = rot_acc; p.rot_inc = rot_inc; p.rot_nbase = rot_nbase; p.rot_lo = rot_lo.p; }
+        p.n0 = src0; p.n = (uint32_t)(src1 - src0);
+        p.out = r2; p.q0 = n2_0; p.q_count = (uint32_t)(n2_1 - n2_0);
+        p.taps = rs_taps.p; p.I = interp; p.D = decim; p.Jp = rs_Jp;
+        launch_resamp(p, B, stream);
+    }
+    // keep the tail of the caller's IQ (rotated) for the next call
+    {
+        HistParams h{};
+        h.in = in; h.in_stride = stride; h.n0 = n_in0; h.n = (uint32_t)n;
+        h.hist_old = hist_old; h.hist_new = hist_new; h.hist_len = hist_len;
+        h.rot_enable = 1; h.rot_acc = rot_acc; h.rot_inc = rot_inc; h.rot_nbase = rot_nbase; h.rot_lo = rot_lo.p;
+        launch_hist_save(h, B, stream);
+        hist_flip = !hist_flip;
+    }
+    // ---- stage C: decimated-rate feed-forward (+ FLL for 2FSK)
+    const uint32_t c2 = (uint32_t)(n2_1 - n2_0);
+    const bool side = cfg.enable_side_outputs && out;
+    RingC filt_in = r2;
+    if (fam == F_2FSK) {
+        FllParams f{};
+        f.in = r2; f.out = r2l; f.q0 = n2_0; f.count = c2; f.st = fll_st.p;
+        f.lower = fll_lo.p; f.upper = fll_up.p; f.nt = 16; f.alpha = fll_alpha; f.beta = fll_beta; f.max_freq = fll_maxf;
+        launch_fll(f, B, stream);
+        filt_in = r2l;
+    }
+    {
+        FirCcfParams f{};
+        f.in = filt_in; f.out = r2f; f.q0 = n2_0; f.count = c2; f.taps = filt_taps.p; f.nt = filt_nt;
+        f.port = side && out->filtered ? reinterpret_cast<float2*>(out->filtered) : nullptr;
+        f.port_cap = side ? out->filtered_cap : 0;
+        f.counts = counts;
+        launch_fir_ccf(f, B, stream);
+    }
+    if (fam == F_GMSK || fm) {
+        QuadDemodParams q{}; q.in = r2f; q.out = r2d; q.q0 = n2_0; q.count = c2; q.gain = demod_gain; q.atan_tab = atan_tab.p;
+        launch_quad_demod(q, B, stream);
+    } else {
+        Disc2fskParams d{}; d.in = r2f; d.out = r2d; d.q0 = n2_0; d.count = c2; d.up = disc_up.p; d.lo = disc_lo.p; d.nt = disc_nt;
+        launch_disc_2fsk(d, B, stream);
+    }
+    {
+        FirFffParams f{}; f.in = r2d; f.out = r3; f.q0 = n2_0; f.count = c2; f.taps = symf_taps.p; f.nt = symf_nt;
+        launch_fir_fff(f, B, stream);
+    }
+    // ---- stage D: symbol sync + FEC
+    {
+        SymSyncParams s{};
+        s.in = r3; s.avail = n2_1; s.soft = RingB{soft.p, soft_mask}; s.st = ss_st.p; s.mmse = mmse_tab.p;
+        s.alpha = ss_alpha; s.beta = ss_beta; s.maxp = ss_maxp; s.minp = ss_minp;
+        s.ted = 1; s.soft_mul = 128.0f; s.soft_add = 128.0f;
+        s.port = side && out->constellation ? reinterpret_cast<float2*>(out->constellation) : nullptr;
+        s.port_cap = side ? out->constellation_cap : 0;
+        s.counts = counts;
+        launch_symsync_ff(s, B, stream);
+        FecParams f{};
+        f.soft = RingB{soft.p, soft_mask}; f.sym = ss_st.p; f.st = fec_st.p;
+        f.bits_a = out ? out->bits_a : nullptr; f.bits_b = out ? out->bits_b : nullptr; f.bits_cap = out ? out->bits_cap : 0;
+        f.counts = counts; f.branches = branches;
+        launch_fec(f, B, stream);
+    }
+    HIPCHK(hipGetLastError());
+    n_in = n_in1; n1 = n1_1; n2 = n2_1;
+    return QRL_OK;
+}
+
+// =============================================================================== C ABI
+extern "C" {
+
+const char* qrl_version(void) { return "qrl_hip 0.1 (gfx950)"; }
+const char* qrl_last_error(void) { return g_last_error.c_str(); }
+const char* qrl_strerror(int s)
+{
+    switch (s) {
+    case QRL_OK: return "ok";
+    case QRL_ERR_ARG: return "invalid argument or unsupported mode";
+    case QRL_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case QRL_ERR_HIP: return "HIP runtime error";
+    case QRL_ERR_NOMEM: return "out of device memory";
+    case QRL_ERR_TOO_BIG: return "chunk larger than max_chunk";
+    case QRL_ERR_STATE: return "invalid handle state";
+    }
+    return "unknown";
+}
+
+int qrl_init(int device, qrl_ctx** ctx)
+{
+    if (!ctx) return QRL_ERR_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(QRL_ERR_NO_DEVICE, "hipGetDeviceCount: no device");
+    if (device < 0 || device >= count) return fail(QRL_ERR_NO_DEVICE, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && std::strncmp(prop.gcnArchName, "gfx94", 5) != 0)
+        return fail(QRL_ERR_NO_DEVICE, std::string("unsupported architecture ") + prop.gcnArchName);
+    *ctx = new (std::nothrow) qrl_ctx{device};
+    return *ctx ? QRL_OK : QRL_ERR_NOMEM;
+}
+void qrl_shutdown(qrl_ctx* ctx) { delete ctx; }
+
+int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp)
+{
+    if (!ctx || !cfg || !outp) return QRL_ERR_ARG;
+    if (cfg->batch < 1 || cfg->max_chunk < 1) return fail(QRL_ERR_ARG, "batch and max_chunk must be >= 1");
+    std::unique_ptr<qrl_demod> d(new (std::nothrow) qrl_demod);
+    if (!d) return QRL_ERR_NOMEM;
+    d->ctx = ctx;
+    d->cfg = *cfg;
+    qrl_demod_config& c = d->cfg;
+    if (c.use_mode_defaults) {  // literals of gr_demod_base.cpp:203-210
+        c.samp_rate = 1000000; c.carrier_freq = 1700;
+        switch (c.modem_type) {
+        case QRL_MODEM_2FSK2KFM:  c.sps = 5;  c.filter_width = 4000;  c.fm = 1; break;
+        case QRL_MODEM_2FSK1KFM:  c.sps = 10; c.filter_width = 2500;  c.fm = 1; break;
+        case QRL_MODEM_2FSK2K:    c.sps = 5;  c.filter_width = 4000;  c.fm = 0; break;
+        case QRL_MODEM_2FSK1K:    c.sps = 10; c.filter_width = 2000;  c.fm = 0; break;
+        case QRL_MODEM_2FSK10KFM: c.sps = 1;  c.filter_width = 25000; c.fm = 1; break;
+        case QRL_MODEM_GMSK2K:    c.sps = 5;  c.filter_width = 4000;  c.fm = 0; break;
+        case QRL_MODEM_GMSK1K:    c.sps = 10; c.filter_width = 2000;  c.fm = 0; break;
+        case QRL_MODEM_GMSK10K:   c.sps = 1;  c.filter_width = 20000; c.fm = 0; break;
+        default: return fail(QRL_ERR_ARG, "modem_type not supported by this build");
+        }
+    }
+    switch (c.modem_type) {
+    case QRL_MODEM_2FSK2KFM: case QRL_MODEM_2FSK1KFM: case QRL_MODEM_2FSK2K: case QRL_MODEM_2FSK1K: case QRL_MODEM_2FSK10KFM:
+        d->fam = qrl_demod::F_2FSK; break;
+    case QRL_MODEM_GMSK2K: case QRL_MODEM_GMSK1K: case QRL_MODEM_GMSK10K:
+        d->fam = qrl_demod::F_GMSK; break;
+    default: return fail(QRL_ERR_ARG, "modem_type not supported by this build");
+    }
+    if (c.samp_rate != 1000000) return fail(QRL_ERR_ARG, "internal samp_rate must be 1000000 (gr_demod_base.cpp:21)");
+    if (c.device_samp_rate < 1000000 || (c.device_samp_rate >= 2000000 && c.device_samp_rate % 1000000))
+        return fail(QRL_ERR_ARG, "device_samp_rate must be 1e6 or a multiple of 1e6 >= 2e6");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (c.hip_stream) d->stream = static_cast<hipStream_t>(c.hip_stream);
+    else { HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)); d->own_stream = true; }
+    int r = d->build();
+    if (r) return r;
+    *outp = d.release();
+    return QRL_OK;
+}
+void qrl_demod_destroy(qrl_demod* d) { if (d) { (void)hipStreamSynchronize(d->stream); delete d; } }
+
+int qrl_demod_reset(qrl_demod* d)
+{
+    if (!d) return QRL_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return d->init_state();
+}
+int qrl_demod_set_carrier_offset(qrl_demod* d, double hz)
+{
+    if (!d) return QRL_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(d->stream));
+    d->rot_acc += (d->n_in - d->rot_nbase) * d->rot_inc;  // phase-continuous
+    d->rot_nbase = d->n_in;
+    d->cfg.carrier_offset_hz = hz;
+    d->rot_inc = phase_inc_to_turn(2 * M_PI * -hz / d->cfg.device_samp_rate);
+    return d->upload_rot_table();
+}
+int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* fcap, size_t* ccap, size_t* bcap)
+{
+    if (!d) return QRL_ERR_ARG;
+    const size_t n1 = d->fe.used ? n / d->fe_decim + 2 : n;
+    const size_t n2 = n1 * d->interp / d->decim + 2;
+    const size_t ns = n2 / (size_t)(d->sps_eff > 1 ? d->sps_eff - 1 : 1) + 8;
+    if (fcap) *fcap = n2;
+    if (ccap) *ccap = ns;
+    if (bcap) *bcap = (ns / 2 / 80 + 2) * 80;
+    return QRL_OK;
+}
+int qrl_demod_process(qrl_demod* d, const float* iq, size_t stride, size_t n, const qrl_demod_out* out)
+{
+    if (!d || (!iq && n)) return QRL_ERR_ARG;
+    HIPCHK(hipSetDevice(d->ctx->device));
+    return d->process(iq, stride, n, out);
+}
+int qrl_demod_sync(qrl_demod* d)
+{
+    if (!d) return QRL_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return QRL_OK;
+}
+void* qrl_demod_stream(qrl_demod* d) { return d ? d->stream : nullptr; }
+
+int qrl_demod_process_host(qrl_demod* d, const float* iq_host, size_t stride, size_t n, uint8_t* bits_a_host,
+                           uint8_t* bits_b_host, size_t bits_cap, uint32_t* counts_host)
+{
+    if (!d || !iq_host || !counts_host) return QRL_ERR_ARG;
+    const size_t B = (size_t)d->cfg.batch;
+    const size_t st = (n + 1) & ~(size_t)1;
+    DevBuf<float2> iq; DevBuf<uint8_t> ba, bb; DevBuf<uint32_t> cnt;
+    int r;
+    if ((r = iq.alloc(B * st)) || (r = ba.alloc(B * bits_cap)) || (r = bb.alloc(B * bits_cap)) || (r = cnt.alloc(B * 4))) return r;
+    HIPCHK(hipMemcpy2D(iq.p, st * sizeof(float2), iq_host, stride * sizeof(float2), n * sizeof(float2), B, hipMemcpyHostToDevice));
+    qrl_demod_out o{};
+    o.bits_a = ba.p; o.bits_b = bb.p; o.bits_cap = bits_cap; o.counts = cnt.p;
+    if ((r = d->process(reinterpret_cast<const float*>(iq.p), st, n, &o))) return r;
+    HIPCHK(hipStreamSynchronize(d->stream));
+    if (bits_a_host) HIPCHK(hipMemcpy(bits_a_host, ba.p, B * bits_cap, hipMemcpyDeviceToHost));
+    if (bits_b_host) HIPCHK(hipMemcpy(bits_b_host, bb.p, B * bits_cap, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(counts_host, cnt.p, B * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return QRL_OK;
+}
+
+// ---- host-only design helpers
+static int copy_out(const std::vector<float>& v, float* dst) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(float)); return (int)v.size(); }
+int qrl_firdes_low_pass(double g, double fs, double fc, double tw, int w, float* t)
+{ return t ? copy_out(low_pass(g, fs, fc, tw, (Window)w), t) : compute_ntaps(fs, tw, (Window)w); }
+int qrl_firdes_low_pass_2(double g, double fs, double fc, double tw, double a, int w, float* t)
+{ return t ? copy_out(low_pass_2(g, fs, fc, tw, a, (Window)w), t) : compute_ntaps_windes(fs, tw, a); }
+int qrl_firdes_complex_band_pass(double g, double fs, double lo, double hi, double tw, int w, float* t)
+{
+    if (!t) return compute_ntaps(fs, tw, (Window)w);
+    const auto v = complex_band_pass(g, fs, lo, hi, tw, (Window)w);
+    std::memcpy(t, v.data(), v.size() * sizeof(std::complex<float>));
+    return (int)v.size();
+}
+int qrl_firdes_root_raised_cosine(double g, double fs, double sr, double a, int n, float* t)
+{ return t ? copy_out(root_raised_cosine(g, fs, sr, a, n), t) : (n | 1); }
+int qrl_table_mmse(float* t) { return copy_out(mmse_table(), t); }
+int qrl_table_atan(float* t) { return copy_out(atan_table(), t); }
+int qrl_table_tanh(float* t) { return copy_out(tanh_table(), t); }
+uint64_t qrl_phase_inc_to_turn(double r) { return phase_inc_to_turn(r); }
+
+}  // extern "C"

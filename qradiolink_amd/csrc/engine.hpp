@@ -1,0 +1,90 @@
+// engine.hpp — device-side parameter blocks and kernel launch entry points of the RX engine.
+// Every inter-kernel stream is a per-stream ring in HBM addressed by ABSOLUTE item index
+// (idx & mask), so FIR history, loop state and block alignment carry across process() calls
+// and results do not depend on how the caller cuts the stream into chunks.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qrl {
+
+struct RingC { float2* p; uint32_t mask; };   // complex ring, stream stride = mask+1 items
+struct RingF { float* p; uint32_t mask; };
+struct RingB { uint8_t* p; uint32_t mask; };
+
+// ---- K1: rotator + decimating FIR (rotator_cc + rational_resampler_ccf(1,D)) ----
+struct DecimParams {
+    const float2* in; size_t in_stride;  // caller IQ (or nullptr when in_ring is used)
+    RingC in_ring;                       // alternative input: an engine ring (second-stage decimators)
+    uint64_t n0; uint32_t n;             // absolute index of in[0], samples in this call
+    const float2* hist; uint32_t hist_len;  // last hist_len (rotated) samples before n0, per stream
+    RingC out;
+    uint64_t m0; uint32_t m_count;       // absolute first output, number of outputs
+    const float* taps;                   // [D][Jpad], taps[p*Jpad + j] = h[p + j*D], zero padded
+    int D, Jpad;
+    int rot_enable; uint64_t rot_acc; uint64_t rot_inc; uint64_t rot_nbase; const float2* rot_lo;
+    uint32_t tiles;                      // tiles per stream
+};
+struct HistParams {
+    const float2* in; size_t in_stride; uint64_t n0; uint32_t n;
+    const float2* hist_old; float2* hist_new; uint32_t hist_len;
+    int rot_enable; uint64_t rot_acc; uint64_t rot_inc; uint64_t rot_nbase; const float2* rot_lo;
+};
+void launch_decim(const DecimParams& p, int batch, int variant, hipStream_t s);
+void launch_hist_save(const HistParams& p, int batch, hipStream_t s);
+size_t decim_lds_bytes(int D, int Jpad, int variant);
+enum { DECIM_R4_J14 = 0, DECIM_R2_J9 = 1, DECIM_R1_J14 = 2 };
+
+// ---- K2: rational resampler I/D on a ring (optionally with rotator on a caller buffer) ----
+struct ResampParams {
+    const float2* in; size_t in_stride; uint64_t n0; uint32_t n;  // caller IQ path (rotator-only front end)
+    const float2* hist; uint32_t hist_len;
+    RingC in_ring;                        // ring path
+    RingC out;
+    uint64_t q0; uint32_t q_count;        // outputs to produce
+    const float* taps;                    // [I][Jp]: taps[ph*Jp + j] = h[ph + j*I]
+    int I, D, Jp;
+    int rot_enable; uint64_t rot_acc; uint64_t rot_inc; uint64_t rot_nbase; const float2* rot_lo;
+};
+void launch_resamp(const ResampParams& p, int batch, hipStream_t s);
+
+// ---- small feed-forward kernels at the decimated rate ----
+struct FirCcfParams { RingC in; RingC out; uint64_t q0; uint32_t count; const float* taps; int nt;
+                      float2* port; size_t port_cap; uint32_t* counts; };  // optional copy to a caller port buffer; counts[b*4+0]
+struct FirFffParams { RingF in; RingF out; uint64_t q0; uint32_t count; const float* taps; int nt; };
+struct QuadDemodParams { RingC in; RingF out; uint64_t q0; uint32_t count; float gain; const float* atan_tab; };
+struct Disc2fskParams { RingC in; RingF out; uint64_t q0; uint32_t count; const float2* up; const float2* lo; int nt; };
+void launch_fir_ccf(const FirCcfParams& p, int batch, hipStream_t s);
+void launch_fir_fff(const FirFffParams& p, int batch, hipStream_t s);
+void launch_quad_demod(const QuadDemodParams& p, int batch, hipStream_t s);
+void launch_disc_2fsk(const Disc2fskParams& p, int batch, hipStream_t s);
+
+// ---- serial loops, one lane per stream ----
+struct FllState { float phase, freq; float2 dl[32]; };
+struct FllParams { RingC in; RingC out; uint64_t q0; uint32_t count; FllState* st;
+                   const float2* lower; const float2* upper; int nt; float alpha, beta, max_freq; };
+void launch_fll(const FllParams& p, int batch, hipStream_t s);
+
+struct SymSyncState { uint64_t ii; uint64_t oo; float mu, avg, inst; float x0, x1, x2, d0, d1, d2; };
+struct SymSyncParams {
+    RingF in; uint64_t avail;              // samples available (absolute count)
+    RingB soft;                            // soft symbols out (absolute symbol index)
+    SymSyncState* st;
+    const float* mmse;                     // 129 x 8
+    float alpha, beta, maxp, minp;
+    int ted; float soft_mul, soft_add;
+    float2* port; size_t port_cap; uint32_t* counts;  // constellation port (this call), counts[b*4+1]
+};
+void launch_symsync_ff(const SymSyncParams& p, int batch, hipStream_t s);
+
+// ---- FEC tail: K=7 r=1/2 Viterbi (spiral-kernel semantics) + descrambler ----
+struct FecState { uint64_t consumed; uint32_t start_state; uint32_t last_bits; };
+struct FecParams {
+    RingB soft; const SymSyncState* sym;   // available soft symbols = sym[b].oo
+    FecState* st;                          // [batch][2]
+    uint8_t* bits_a; uint8_t* bits_b; size_t bits_cap; uint32_t* counts;  // counts[b*4+2], [b*4+3]
+    int branches;
+};
+void launch_fec(const FecParams& p, int batch, hipStream_t s);
+
+}  // namespace qrl

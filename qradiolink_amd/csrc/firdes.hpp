@@ -1,0 +1,38 @@
+// firdes.hpp — host-side filter design, loop gains and lookup tables the HIP kernels are loaded with.
+// Mirrors what the reference obtains from gr::filter::firdes / gr::fft::window / control loops of
+// GNU Radio 3.10 (call sites: gr_demod_2fsk.cpp:82-110, gr_demod_gmsk.cpp:80-98,
+// gr_demod_qpsk.cpp:92-112, gr_demod_base.cpp:1333-1336).  Design math runs in double and is
+// rounded to float where upstream stores float.
+#pragma once
+#include <complex>
+#include <cstdint>
+#include <vector>
+
+namespace qrl {
+
+enum Window { WIN_HAMMING = 0, WIN_HANN = 1, WIN_BLACKMAN = 2, WIN_RECTANGULAR = 3, WIN_BLACKMAN_HARRIS = 5 };
+
+std::vector<float> window(Window type, int ntaps);
+int compute_ntaps(double fs, double tw, Window w);
+int compute_ntaps_windes(double fs, double tw, double atten_db);
+std::vector<float> low_pass(double gain, double fs, double fc, double tw, Window w = WIN_HAMMING);
+std::vector<float> low_pass_2(double gain, double fs, double fc, double tw, double atten_db, Window w = WIN_HAMMING);
+std::vector<std::complex<float>> complex_band_pass(double gain, double fs, double lo, double hi, double tw, Window w = WIN_HAMMING);
+std::vector<float> root_raised_cosine(double gain, double fs, double symrate, double alpha, int ntaps);
+
+// fll_band_edge_cc design_filter: returns taps in the order the filter applies them,
+// T[j] multiplies y[n-j] (upstream stores them reversed and reverses again in the FIR)
+void fll_band_edge_taps(float sps, float rolloff, int n, std::vector<std::complex<float>>& lower,
+                        std::vector<std::complex<float>>& upper);
+void control_loop_gains(float bw, float& alpha, float& beta);
+void clock_loop_gains(float loop_bw, float zeta, float ted_gain, float& alpha, float& beta);
+
+std::vector<float> mmse_table();  // 129 x 8
+std::vector<float> atan_table();  // 257
+std::vector<float> tanh_table();  // 256
+
+uint64_t phase_inc_to_turn(double radians_per_sample);
+// host evaluation of the NCO polynomial (same arithmetic as the device function)
+void sincos_turn_host(uint64_t angle, float& s, float& c);
+
+}  // namespace qrl

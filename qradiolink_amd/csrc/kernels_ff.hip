@@ -1,0 +1,112 @@
+// kernels_ff.hip — feed-forward blocks at the decimated rate (<= 2 % of the input bytes).
+// One thread per output item, inputs read from the producer's ring (L2-resident), one fmaf chain
+// per output with k ascending: exactly the order of oracle/orc_blocks.c.
+//   k_fir_ccf    fft_filter_ccf  (gr_demod_2fsk.cpp:91-92, gr_demod_gmsk.cpp:84-85, gr_demod_qpsk.cpp:100-103)
+//   k_fir_fff    fft_filter_fff  (gr_demod_2fsk.cpp:104, gr_demod_gmsk.cpp:96-98)
+//   k_quad_demod quadrature_demod_cf (gr_demod_gmsk.cpp:95, gr_demod_2fsk.cpp:112)
+//   k_disc_2fsk  2x fft_filter_ccc + complex_to_mag + divide + rail(0,2) + add(-1) (gr_demod_2fsk.cpp:94-102,140-149)
+#include "devmath.hpp"
+#include "engine.hpp"
+
+namespace qrl {
+
+__device__ __forceinline__ float2 ringc_at(const RingC& r, int b, int64_t i)
+{
+    if (i < 0) return make_float2(0.f, 0.f);
+    return r.p[(size_t)b * (r.mask + 1u) + ((uint32_t)i & r.mask)];
+}
+__device__ __forceinline__ float ringf_at(const RingF& r, int b, int64_t i)
+{
+    if (i < 0) return 0.f;
+    return r.p[(size_t)b * (r.mask + 1u) + ((uint32_t)i & r.mask)];
+}
+
+__global__ __launch_bounds__(256) void k_fir_ccf(const FirCcfParams P)
+{
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.count) return;
+    if (t == 0 && P.counts) P.counts[b * 4 + 0] = P.count;
+    const int64_t n = (int64_t)(P.q0 + t);
+    float ar = 0.f, ai = 0.f;
+    for (int k = 0; k < P.nt; ++k) {
+        const float h = P.taps[k];
+        const float2 x = ringc_at(P.in, b, n - k);
+        ar = fmaf(h, x.x, ar);
+        ai = fmaf(h, x.y, ai);
+    }
+    const float2 y = make_float2(ar, ai);
+    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = y;
+    if (P.port && t < P.port_cap) P.port[(size_t)b * P.port_cap + t] = y;
+}
+void launch_fir_ccf(const FirCcfParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_fir_ccf, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
+}
+
+__global__ __launch_bounds__(256) void k_fir_fff(const FirFffParams P)
+{
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.count) return;
+    const int64_t n = (int64_t)(P.q0 + t);
+    float a = 0.f;
+    for (int k = 0; k < P.nt; ++k) a = fmaf(P.taps[k], ringf_at(P.in, b, n - k), a);
+    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = a;
+}
+void launch_fir_fff(const FirFffParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_fir_fff, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
+}
+
+__global__ __launch_bounds__(256) void k_quad_demod(const QuadDemodParams P)
+{
+    __shared__ float T[257];
+    for (int k = threadIdx.x; k < 257; k += 256) T[k] = P.atan_tab[k];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.count) return;
+    const int64_t n = (int64_t)(P.q0 + t);
+    const float2 a = ringc_at(P.in, b, n), p = ringc_at(P.in, b, n - 1);
+    const float re = a.x * p.x + a.y * p.y;
+    const float im = a.y * p.x - a.x * p.y;
+    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = P.gain * fast_atan2f_lut(im, re, T);
+}
+void launch_quad_demod(const QuadDemodParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_quad_demod, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
+}
+
+__global__ __launch_bounds__(256) void k_disc_2fsk(const Disc2fskParams P)
+{
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.count) return;
+    const int64_t n = (int64_t)(P.q0 + t);
+    float ur = 0.f, ui = 0.f, lr = 0.f, li = 0.f;
+    for (int k = 0; k < P.nt; ++k) {
+        const float2 x = ringc_at(P.in, b, n - k);
+        const float2 hu = P.up[k], hl = P.lo[k];
+        ur = fmaf(hu.x, x.x, ur); ur = fmaf(-hu.y, x.y, ur);
+        ui = fmaf(hu.x, x.y, ui); ui = fmaf(hu.y, x.x, ui);
+        lr = fmaf(hl.x, x.x, lr); lr = fmaf(-hl.y, x.y, lr);
+        li = fmaf(hl.x, x.y, li); li = fmaf(hl.y, x.x, li);
+    }
+    const float mu = sqrtf(ur * ur + ui * ui);
+    const float ml = sqrtf(lr * lr + li * li);
+    float r = mu / ml;
+    if (!(r >= 0.0f)) r = 0.0f;   // rail_ff lower bound; NaN (0/0) -> 0
+    if (r > 2.0f) r = 2.0f;
+    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = r + (-1.0f);
+}
+void launch_disc_2fsk(const Disc2fskParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_disc_2fsk, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
+}
+
+}  // namespace qrl

@@ -1,0 +1,294 @@
+// kernels_frontend.hip — the HBM-facing kernels of the RX path (gfx950 / CDNA4).
+//
+//  k_decim  : rotator_cc + rational_resampler_ccf(1, D, taps)       [gr_demod_base.cpp:57,1330-1340;
+//             gr_demod_2fsk.cpp:82-88; gr_demod_qpsk.cpp:92-96]
+//  k_resamp : rational_resampler_ccf(I, D, taps), I > 1             [gr_demod_gmsk.cpp:80-83]
+//  k_hist   : keeps the last H rotated input samples of each stream for the next call
+//
+// k_decim layout.  One workgroup = 4 waves = the 4 phase groups of the summation contract
+// (oracle/orc_blocks.c orc_decim_fir_ccf): wave g owns phases p in [gD/4, (g+1)D/4) and forms ONE
+// fmaf chain per output (p ascending, j ascending); the four partial sums meet in LDS and are
+// combined as (r0+r1)+(r2+r3).  A tile of TILE = 64*R outputs needs input blocks
+// bq in [mt-Jpad, mt+TILE): they are read from HBM once, coalesced (16 B per lane), rotated on the
+// way in (phase = T_hi[k>>9] (x) T_lo[k&511]) and stored to LDS TRANSPOSED: row o = sample index
+// mod D, column = input block.  In that layout tap (p, j) of output m sits at row (D-p)%D, column
+// m-j-(p>0): a lane that owns R consecutive outputs slides a register window of R+JC-1 columns over
+// JC taps (R*JC packed FMAs per R+JC-1 LDS reads), and the columns are de-interleaved by R
+// (pos = (col%R)*Wq + col/R) so that the 64 lanes of a wave hit consecutive 8-byte LDS words.
+// Taps are wave-uniform => scalar loads.  blockIdx -> tile mapping keeps neighbouring tiles (which
+// share the Jpad-block halo) on the same XCD/L2.
+#include "devmath.hpp"
+#include "engine.hpp"
+
+namespace qrl {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float2 rot_apply(float2 x, uint64_t k, const float2* t_hi, uint32_t kb0, const float2* t_lo)
+{
+    const float2 hi = t_hi[(uint32_t)(k >> 9) - kb0];
+    const float2 lo = t_lo[(uint32_t)k & 511u];
+    return cmul_fma(x, cmul_fma(hi, lo));
+}
+
+// fetch one input sample of stream b at absolute index i (zero outside the stream so far)
+__device__ __forceinline__ float2 decim_fetch(const DecimParams& P, int b, int64_t i, const float2* t_hi, uint32_t kb0,
+                                              const float2* t_lo)
+{
+    if (i < 0) return make_float2(0.f, 0.f);
+    const uint64_t ui = (uint64_t)i;
+    if (P.in) {
+        if (ui >= P.n0 + P.n) return make_float2(0.f, 0.f);
+        if (ui >= P.n0) {
+            float2 x = P.in[(size_t)b * P.in_stride + (size_t)(ui - P.n0)];
+            if (P.rot_enable) x = rot_apply(x, ui - P.rot_nbase, t_hi, kb0, t_lo);
+            return x;
+        }
+        const uint64_t d = P.n0 - ui;
+        if (d > P.hist_len) return make_float2(0.f, 0.f);
+        return P.hist[(size_t)b * P.hist_len + (P.hist_len - (uint32_t)d)];
+    }
+    if (ui >= P.n0 + P.n) return make_float2(0.f, 0.f);
+    return P.in_ring.p[(size_t)b * (P.in_ring.mask + 1u) + ((uint32_t)ui & P.in_ring.mask)];
+}
+
+template <int R, int JC>
+__global__ __launch_bounds__(256) void k_decim(const DecimParams P)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int TILE = 64 * R;
+    const int D = P.D, Jpad = P.Jpad;
+    const int W = TILE + Jpad;
+    const int Wp = (W + R - 1) / R * R;
+    const int Wq = Wp / R;
+    float2* t_lo = reinterpret_cast<float2*>(smem);   // 512
+    float2* t_hi = t_lo + 512;                        // 64
+    float2* part = t_hi + 64;                         // 4 * TILE
+    float2* tile = part + 4 * TILE;                   // D * Wp
+
+    const int b = blockIdx.y;
+    const uint32_t per = gridDim.x >> 3;
+    const uint32_t tix = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (tix >= P.tiles) return;
+    const int tid = threadIdx.x;
+    const uint64_t mt = P.m0 + (uint64_t)tix * TILE;
+    const int64_t bq0 = (int64_t)mt - Jpad;
+    const int64_t i_start = bq0 * D;
+    const int nsamp = W * D;
+
+    // ---- rotator tables for this tile ----
+    uint32_t kb0 = 0;
+    if (P.rot_enable) {
+        t_lo[tid] = P.rot_lo[tid];
+        t_lo[tid + 256] = P.rot_lo[tid + 256];
+        const int64_t first_new = i_start > (int64_t)P.n0 ? i_start : (int64_t)P.n0;
+        kb0 = (uint32_t)(((uint64_t)first_new - P.rot_nbase) >> 9);
+        if (tid < 64) t_hi[tid] = sincos_turn(P.rot_acc + ((uint64_t)(kb0 + tid) << 9) * P.rot_inc);
+        __syncthreads();
+    }
+
+    // ---- stage the tile: coalesced pair loads, rotate, transposed LDS store ----
+    {
+        const int a = (int)((i_start - (int64_t)P.n0) & 1);  // make (i - n0) even for 16-byte loads
+        const int npairs = (nsamp + a + 1) >> 1;
+        const int dO = 512 % D, dC = 512 / D;
+        int s0 = -a + 2 * tid;
+        int o = 0, col = 0;
+        if (s0 >= 0) { col = s0 / D; o = s0 - col * D; }
+        for (int k = tid; k < npairs; k += 256, s0 += 512) {
+            float2 x0, x1;
+            const int64_t i0 = i_start + s0;
+            const bool fast = P.in && i0 >= (int64_t)P.n0 && (uint64_t)(i0 + 1) < P.n0 + P.n;
+            if (fast) {
+                const float4 v = *reinterpret_cast<const float4*>(P.in + (size_t)b * P.in_stride + (size_t)((uint64_t)i0 - P.n0));
+                x0 = make_float2(v.x, v.y);
+                x1 = make_float2(v.z, v.w);
+                if (P.rot_enable) {
+                    const uint64_t kk = (uint64_t)i0 - P.rot_nbase;
+                    x0 = rot_apply(x0, kk, t_hi, kb0, t_lo);
+                    x1 = rot_apply(x1, kk + 1, t_hi, kb0, t_lo);
+                }
+            } else {
+                x0 = decim_fetch(P, b, i0, t_hi, kb0, t_lo);
+                x1 = decim_fetch(P, b, i0 + 1, t_hi, kb0, t_lo);
+            }
+            if (s0 >= 0) {
+                tile[o * Wp + (col % R) * Wq + col / R] = x0;
+                int o1 = o + 1, c1 = col;
+                if (o1 == D) { o1 = 0; c1++; }
+                if (s0 + 1 < nsamp) tile[o1 * Wp + (c1 % R) * Wq + c1 / R] = x1;
+                o += dO; col += dC;
+                if (o >= D) { o -= D; col++; }
+            } else {  // s0 == -1: only the second sample belongs to the tile
+                tile[0] = x1;  // o = 0, col = 0
+                const int sn = s0 + 512;
+                col = sn / D; o = sn - col * D;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- FIR: wave g = phase group g ----
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int p0 = (g * D) >> 2, p1 = ((g + 1) * D) >> 2;
+    const int nchunks = Jpad / JC;
+    v2f acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = v2f{0.f, 0.f};
+    const v2f* tl = reinterpret_cast<const v2f*>(tile);
+    for (int p = p0; p < p1; ++p) {
+        const int o = p ? D - p : 0;
+        const int shift = p ? 1 : 0;
+        const v2f* row = tl + o * Wp + lane;
+        const float* tp = P.taps + p * Jpad;
+        for (int c = 0; c < nchunks; ++c) {
+            const int cst = Jpad - shift - (c + 1) * JC + 1;
+            v2f w[R + JC - 1];
+#pragma unroll
+            for (int t = 0; t < R + JC - 1; ++t) {
+                const int cc = cst + t;
+                w[t] = row[(cc % R) * Wq + cc / R];
+            }
+#pragma unroll
+            for (int jj = 0; jj < JC; ++jj) {
+                const float h = tp[c * JC + jj];
+                const v2f hv = v2f{h, h};
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = __builtin_elementwise_fma(hv, w[r - jj + JC - 1], acc[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) part[g * TILE + R * lane + r] = make_float2(acc[r].x, acc[r].y);
+    __syncthreads();
+
+    if (tid < TILE) {
+        const uint64_t m = mt + tid;
+        if (m < P.m0 + P.m_count) {
+            const float2 r0 = part[tid], r1 = part[TILE + tid], r2 = part[2 * TILE + tid], r3 = part[3 * TILE + tid];
+            float2 y;
+            y.x = (r0.x + r1.x) + (r2.x + r3.x);
+            y.y = (r0.y + r1.y) + (r2.y + r3.y);
+            P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = y;
+        }
+    }
+}
+
+size_t decim_lds_bytes(int D, int Jpad, int variant)
+{
+    const int R = variant == DECIM_R4_J14 ? 4 : (variant == DECIM_R2_J9 ? 2 : 1);
+    const int TILE = 64 * R;
+    const int W = TILE + Jpad;
+    const int Wp = (W + R - 1) / R * R;
+    return (size_t)(512 + 64 + 4 * TILE + D * Wp) * sizeof(float2);
+}
+
+void launch_decim(const DecimParams& p, int batch, int variant, hipStream_t s)
+{
+    const int R = variant == DECIM_R4_J14 ? 4 : (variant == DECIM_R2_J9 ? 2 : 1);
+    const uint32_t tiles = (p.m_count + 64 * R - 1) / (64 * R);
+    if (tiles == 0) return;
+    DecimParams q = p;
+    q.tiles = tiles;
+    dim3 grid((tiles + 7) / 8 * 8, batch), block(256);
+    const size_t lds = decim_lds_bytes(p.D, p.Jpad, variant);
+    if (variant == DECIM_R4_J14)      hipLaunchKernelGGL((k_decim<4, 14>), grid, block, lds, s, q);
+    else if (variant == DECIM_R2_J9)  hipLaunchKernelGGL((k_decim<2, 9>), grid, block, lds, s, q);
+    else                              hipLaunchKernelGGL((k_decim<1, 14>), grid, block, lds, s, q);
+}
+
+// ---- history keeper: hist_new[k] = rotated sample at absolute index n0 + n - H + k ----
+__global__ __launch_bounds__(256) void k_hist(const HistParams P)
+{
+    const int b = blockIdx.y;
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= P.hist_len) return;
+    const int64_t i = (int64_t)(P.n0 + P.n) - (int64_t)P.hist_len + (int64_t)k;
+    float2 x = make_float2(0.f, 0.f);
+    if (i >= (int64_t)P.n0) {
+        x = P.in[(size_t)b * P.in_stride + (size_t)((uint64_t)i - P.n0)];
+        if (P.rot_enable) {
+            const uint64_t kk = (uint64_t)i - P.rot_nbase;
+            const float2 hi = sincos_turn(P.rot_acc + ((kk >> 9) << 9) * P.rot_inc);
+            x = cmul_fma(x, cmul_fma(hi, P.rot_lo[(uint32_t)kk & 511u]));
+        }
+    } else if (i >= 0) {
+        const uint64_t d = P.n0 - (uint64_t)i;  // 1..hist_len
+        if (d <= P.hist_len) x = P.hist_old[(size_t)b * P.hist_len + (P.hist_len - (uint32_t)d)];
+    }
+    P.hist_new[(size_t)b * P.hist_len + k] = x;
+}
+void launch_hist_save(const HistParams& p, int batch, hipStream_t s)
+{
+    if (p.hist_len == 0) return;
+    dim3 grid((p.hist_len + 255) / 256, batch), block(256);
+    hipLaunchKernelGGL(k_hist, grid, block, 0, s, p);
+}
+
+// ---- K2: rational resampler I/D.  One fmaf chain per output, j ascending (oracle orc_resamp_ccf).
+// Tile of 256 outputs; the input span is staged in LDS once (coalesced), taps [I][Jp] in LDS.
+__device__ __forceinline__ float2 resamp_fetch(const ResampParams& P, int b, int64_t i)
+{
+    if (i < 0) return make_float2(0.f, 0.f);
+    const uint64_t ui = (uint64_t)i;
+    if (P.in) {
+        if (ui >= P.n0 + P.n) return make_float2(0.f, 0.f);
+        if (ui >= P.n0) {
+            float2 x = P.in[(size_t)b * P.in_stride + (size_t)(ui - P.n0)];
+            if (P.rot_enable) {
+                const uint64_t kk = ui - P.rot_nbase;
+                const float2 hi = sincos_turn(P.rot_acc + ((kk >> 9) << 9) * P.rot_inc);
+                x = cmul_fma(x, cmul_fma(hi, P.rot_lo[(uint32_t)kk & 511u]));
+            }
+            return x;
+        }
+        const uint64_t d = P.n0 - ui;
+        if (d > P.hist_len) return make_float2(0.f, 0.f);
+        return P.hist[(size_t)b * P.hist_len + (P.hist_len - (uint32_t)d)];
+    }
+    if (ui >= P.n0 + P.n) return make_float2(0.f, 0.f);
+    return P.in_ring.p[(size_t)b * (P.in_ring.mask + 1u) + ((uint32_t)ui & P.in_ring.mask)];
+}
+
+__global__ __launch_bounds__(256) void k_resamp(const ResampParams P, int span)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* taps = reinterpret_cast<float*>(smem);                  // I * Jp
+    float2* xs = reinterpret_cast<float2*>(taps + ((P.I * P.Jp + 3) & ~3));  // span
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const uint64_t q_first = P.q0 + (uint64_t)blockIdx.x * 256u;
+    for (int k = tid; k < P.I * P.Jp; k += 256) taps[k] = P.taps[k];
+    // input index of output q: c(q) = floor(q*D/I); the tile needs [c(q_first) - (Jp-1), c(q_last)]
+    const int64_t c_first = (int64_t)((q_first * (uint64_t)P.D) / (uint64_t)P.I);
+    const int64_t base = c_first - (P.Jp - 1);
+    for (int k = tid; k < span; k += 256) xs[k] = resamp_fetch(P, b, base + k);
+    __syncthreads();
+    const uint64_t q = q_first + tid;
+    if (q >= P.q0 + P.q_count) return;
+    const uint64_t u = q * (uint64_t)P.D;
+    const int ph = (int)(u % (uint64_t)P.I);
+    const int c = (int)((int64_t)(u / (uint64_t)P.I) - base);  // local index of x[c(q)]
+    const float* tp = taps + ph * P.Jp;
+    float ar = 0.f, ai = 0.f;
+    for (int j = 0; j < P.Jp; ++j) {
+        const float h = tp[j];
+        const float2 x = xs[c - j];
+        ar = fmaf(h, x.x, ar);
+        ai = fmaf(h, x.y, ai);
+    }
+    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)q & P.out.mask)] = make_float2(ar, ai);
+}
+
+void launch_resamp(const ResampParams& p, int batch, hipStream_t s)
+{
+    if (p.q_count == 0) return;
+    // span of inputs for 256 outputs: ceil(255*D/I) + 1 + Jp - 1 (+1 slack)
+    const int span = (255 * p.D + p.I - 1) / p.I + p.Jp + 2;
+    const size_t lds = (size_t)((p.I * p.Jp + 3) & ~3) * sizeof(float) + (size_t)span * sizeof(float2);
+    dim3 grid((p.q_count + 255) / 256, batch), block(256);
+    hipLaunchKernelGGL(k_resamp, grid, block, lds, s, p, span);
+}
+
+}  // namespace qrl

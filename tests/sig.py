@@ -1,0 +1,74 @@
+"""Synthetic IQ for tests and bench (TEST INFRASTRUCTURE): frames built like gr_modem::frame()
+(reference src/gr_modem.cpp:904-961), modulated by the oracle's restatement of the reference
+modulators, passed through a seeded channel (CFO, fractional delay by resampling phase, AWGN) and
+optionally interpolated to the SDR rate like gr_mod_base (gr_mod_base.cpp:249-250) with the RX
+tuning offset applied, so the demodulator's rotator has work to do."""
+import numpy as np
+
+import orc
+
+MODES = {
+    # name: (modulator, kwargs, sync bytes, payload bytes, nominal cfo, snr_db at 1 Msps)
+    "2fsk1k": (orc.mod_2fsk, dict(sps=50, filter_width=2000, fm=False), bytes([0xB5]), 4, 137.0, -8.0),
+    "2fsk1kfm": (orc.mod_2fsk, dict(sps=50, filter_width=2500, fm=True), bytes([0xB5]), 4, 137.0, -8.0),
+    "gmsk10k": (orc.mod_gmsk, dict(sps=10, filter_width=20000), bytes([0xED, 0x89, 0xAA]), 47, 137.0, 4.0),
+    "gmsk1k": (orc.mod_gmsk, dict(sps=100, filter_width=2000), bytes([0xB5]), 4, 137.0, -8.0),
+    "qpsk250k": (orc.mod_qpsk, dict(sps=4, filter_width=160000), bytes([0xDE, 0x98, 0xAA]), 1516, 1300.0, 12.0),
+}
+
+
+def frames(mode, nframes, rng):
+    sync, plen = MODES[mode][2], MODES[mode][3]
+    payloads = [bytes(rng.integers(0, 256, plen, dtype=np.uint8)) for _ in range(nframes)]
+    data = bytes([0xAA] * 8) + b"".join(sync + p for p in payloads) + bytes([0xAA] * 8)
+    return np.frombuffer(data, np.uint8), payloads
+
+
+def channel(x, fs, cfo, snr_db, amp, rng, lead=0):
+    n = np.arange(x.size + lead)
+    y = np.zeros(x.size + lead, np.complex128)
+    y[lead:] = amp * x
+    y *= np.exp(2j * np.pi * cfo * n / fs)
+    p = np.mean(np.abs(amp * x) ** 2)
+    sigma = np.sqrt(p / 10 ** (snr_db / 10) / 2)
+    y += sigma * (rng.standard_normal(y.size) + 1j * rng.standard_normal(y.size))
+    return y.astype(np.complex64)
+
+
+def make_stream(mode, nframes=4, device_rate=1000000, rx_offset_hz=25000.0, seed=1, amp=0.05, lead=0):
+    """One stream at device_rate.  Returns (iq complex64, payload list)."""
+    rng = np.random.default_rng(seed)
+    mod, kw, _, _, cfo, snr = MODES[mode]
+    data, payloads = frames(mode, nframes, rng)
+    x = mod(data, **kw)
+    y = channel(x, 1e6, cfo + 13.0 * (seed % 7), snr, amp, rng, lead=lead)
+    if device_rate >= 2000000:
+        y = orc.tx_interp(y, device_rate)
+        n = np.arange(y.size)
+        # the signal sits rx_offset_hz above the tuned centre; the RX rotator (-offset) brings it back
+        y = (y * np.exp(2j * np.pi * rx_offset_hz * n / device_rate)).astype(np.complex64)
+    return y, payloads
+
+
+def make_batch(mode, batch, nframes=4, device_rate=1000000, rx_offset_hz=25000.0, seed=1, amp=0.05):
+    streams = [make_stream(mode, nframes, device_rate, rx_offset_hz, seed + 101 * b, amp, lead=37 * b)[0] for b in range(batch)]
+    n = min(s.size for s in streams) & ~1
+    return np.stack([s[:n] for s in streams]).astype(np.complex64)
+
+
+def find_frames(bits, sync, nbits):
+    """gr_modem::findSync-style shift-register search (src/gr_modem.cpp:1183-1282), returns payloads."""
+    out = []
+    nsync = 8 * len(sync)
+    want = int.from_bytes(sync, "big")
+    mask = (1 << nsync) - 1
+    sr = 0
+    i, n = 0, len(bits)
+    while i < n:
+        sr = ((sr << 1) | int(bits[i])) & mask
+        i += 1
+        if sr == want and i + nbits <= n:
+            out.append(np.packbits(bits[i:i + nbits]).tobytes())
+            i += nbits
+            sr = 0
+    return out
