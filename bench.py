@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — IQ MSamples/s through the RX demod chain on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the whole hot path (rotator + front-end decimator + per-mode resampler +
+filters + symbol sync + 2x Viterbi + descramblers) over one batch of synthetic IQ that is already
+resident in HBM.  Default workload = BASELINE.json configs[1]: GMSK 10 kbit/s RX chain on 25 Msps IQ.
+The 2FSK-1k chain the north-star target is quoted on (configs[0], 1 Msps IQ) is measured too and
+reported under "north_star_c1" in the same JSON line.
+
+Launch: python bench.py --gpus N --steps K --warmup W   (N>1: via torch.distributed.run, one rank
+per GPU; streams are sharded across ranks, there is no data-path collective => "scaling": "weak").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
+
+WORKLOADS = {
+    # name: (label, sig mode, modem type, device rate, rx offset, default batch, default samples/stream, oracle mode)
+    "c2": ("C2: GMSK-10k RX chain (gr_demod_base front end 25:1 + gr_demod_gmsk) on 25 Msps IQ",
+           "gmsk10k", 22, 25000000, 25000.0, 96, 25 * (1 << 18), 1),
+    "c1": ("C1: 2FSK-1k RX chain (rotator + gr_demod_2fsk) on 1 Msps IQ",
+           "2fsk1k", 18, 1000000, 1200.0, 8192, 1 << 18, 0),
+}
+
+
+def synth(mode, device_rate, offset, batch, nsamp, seed, torch, dev):
+    """Synthetic batch, built once (untimed): one oracle-modulated stream, then per-stream circular
+    shift + CFO + AWGN applied on the GPU (torch is plumbing here, not the product)."""
+    import sig
+    nframes = {"gmsk10k": 6, "2fsk1k": 6}[mode]
+    base, _ = sig.make_stream(mode, nframes=nframes, device_rate=device_rate, rx_offset_hz=offset, seed=seed, amp=0.05)
+    reps = -(-nsamp // base.size)
+    base = np.tile(base, reps)[:nsamp]
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    x = torch.from_numpy(base).to(dev)
+    iq = torch.empty((batch, nsamp), dtype=torch.complex64, device=dev)
+    n = torch.arange(nsamp, device=dev, dtype=torch.float64)
+    for b in range(batch):
+        shift = (7919 * b) % nsamp
+        cfo = 5.0 * ((b % 21) - 10)
+        rot = torch.exp(2j * np.pi * cfo / device_rate * n).to(torch.complex64)
+        noise = torch.randn((nsamp, 2), generator=g, device=dev, dtype=torch.float32) * 0.002
+        iq[b] = torch.roll(x, shift) * rot + torch.view_as_complex(noise)
+    return iq
+
+
+def run_workload(name, args, torch, q, ctx, dev, rank, world):
+    label, mode, modem, rate, offset, dbatch, dns, _ = WORKLOADS[name]
+    batch = args.batch if (args.batch and name == args.config) else dbatch
+    nsamp = args.nsamp if (args.nsamp and name == args.config) else dns
+    nsamp &= ~1
+    iq = synth(mode, rate, offset, batch, nsamp, 1234 + rank, torch, dev)
+    dem = q.Demod(ctx, modem, batch=batch, max_chunk=nsamp, device_samp_rate=rate, carrier_offset_hz=offset,
+                  side_outputs=True)
+    for _ in range(args.warmup):
+        dem.process_async(iq)
+    dem.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dem.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dem.process_async(iq)
+    dem.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    kms, launches, kname = dem.profile_read()
+    dem.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    counts = dem.counts.cpu().numpy()
+    dem.close()
+    del iq
+    torch.cuda.empty_cache()
+    total_samples = float(batch) * nsamp * args.steps * world
+    # dominant kernel roofline: algorithmic bytes per launch = input cf32 read once + decimated cf32 written once
+    fe_decim = rate // 1000000 if rate >= 2000000 else 50
+    bytes_per_launch = batch * nsamp * 8.0 * (1.0 + 1.0 / fe_decim)
+    ach = bytes_per_launch / (kms / max(launches, 1) * 1e-3) / 1e9 if kms > 0 else 0.0
+    return dict(label=label, batch=batch, nsamp=nsamp, rate=rate, seconds=dt, msps=total_samples / dt / 1e6,
+                ms_per_step=dt / args.steps * 1e3, kernel=kname, kernel_ms=kms / max(launches, 1), launches=launches,
+                achieved_gbps=ach, bits_per_stream=int(counts[:, 2].mean()), bytes_per_launch=bytes_per_launch)
+
+
+def cpu_baseline(name, threads):
+    """Oracle (CPU restatement of the reference flowgraph) on a bounded sample of the same workload."""
+    import orc
+    import sig
+    label, mode, modem, rate, offset, _, _, omode = WORKLOADS[name]
+    nstreams = max(threads, 1)
+    per = (1 << 21) if rate >= 2000000 else (1 << 19)
+    base, _ = sig.make_stream(mode, nframes=2, device_rate=rate, rx_offset_hz=offset, seed=99, amp=0.05)
+    base = np.tile(base, -(-per // base.size))[:per]
+    iq = np.stack([np.roll(base, 977 * b) for b in range(nstreams)]).astype(np.complex64)
+    secs, _ = orc.batch_rx(omode, iq, rate, offset, threads)
+    return dict(value=round(nstreams * per / secs / 1e6, 3), unit="MS/s", cores=threads, kind="port",
+                sample="%d streams x %d samples of the %s workload, oracle/liborc.so (C, -O3, OpenMP over streams)"
+                       % (nstreams, per, name.upper()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--nsamp", type=int, default=0)
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workload and the CPU baseline")
+    args = ap.parse_args()
+
+    import torch
+    import qradiolink_amd as q
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+    ctx = q.Context(local)
+
+    main_r = run_workload(args.config, args, torch, q, ctx, dev, rank, world)
+    extra = None
+    base = None
+    if not args.no_extra:
+        other = "c1" if args.config == "c2" else "c2"
+        extra = run_workload(other, args, torch, q, ctx, dev, rank, world)
+        if rank == 0:
+            base = cpu_baseline(args.config, min(os.cpu_count() or 1, 16))
+    if rank == 0:
+        def roof(r):
+            return dict(bound="hbm", achieved=round(r["achieved_gbps"], 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                        frac=round(r["achieved_gbps"] / HBM_PEAK_GBPS, 4), traffic=None, kernel=r["kernel"],
+                        kernel_ms=round(r["kernel_ms"], 4), launches=r["launches"],
+                        algorithmic_bytes_per_launch=r["bytes_per_launch"])
+        line = {
+            "metric": "IQ MSamples/sec through RX demod chain", "value": round(main_r["msps"], 1), "unit": "MS/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(main_r["ms_per_step"], 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": main_r["label"], "streams_per_gpu": main_r["batch"],
+                       "samples_per_stream_per_step": main_r["nsamp"], "device_samp_rate": main_r["rate"],
+                       "parallelism": "streams sharded over ranks, no collective",
+                       "decoded_bits_per_stream_last_step": main_r["bits_per_stream"]},
+            "roofline": roof(main_r),
+        }
+        if base:
+            line["cpu_baseline"] = base
+        if extra:
+            key = "north_star_c1" if args.config == "c2" else "c2"
+            line[key] = {"workload": extra["label"], "value": round(extra["msps"], 1), "unit": "MS/s",
+                         "ms_per_step": round(extra["ms_per_step"], 3), "streams_per_gpu": extra["batch"],
+                         "samples_per_stream_per_step": extra["nsamp"], "roofline": roof(extra)}
+        print(json.dumps(line))
+    ctx.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

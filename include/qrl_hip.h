@@ -103,6 +103,12 @@ int qrl_demod_process(qrl_demod* d, const float* iq, size_t stride, size_t n, co
 int qrl_demod_sync(qrl_demod* d);
 void* qrl_demod_stream(qrl_demod* d); /* hipStream_t */
 
+/* Per-kernel timing of the dominant (HBM-facing) kernel with HIP events recorded on the handle's own
+ * stream (bench.py roofline leg).  enable!=0 starts recording one event pair per process call;
+ * qrl_demod_profile_read syncs, returns the summed duration and launch count, and clears the record. */
+int qrl_demod_profile(qrl_demod* d, int enable);
+int qrl_demod_profile_read(qrl_demod* d, double* kernel_ms, uint64_t* launches, const char** kernel_name);
+
 /* host-buffer convenience used by the C++ adaptor (gr_bit_sink-style mailboxes): copies iq H2D,
  * runs one pass, copies bits back.  bits_x_host: [batch][bits_cap]; counts_host: [batch][4]. */
 int qrl_demod_process_host(qrl_demod* d, const float* iq_host, size_t stride, size_t n,

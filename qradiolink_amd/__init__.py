@@ -65,6 +65,8 @@ def load_library():
     lib.qrl_demod_sync.argtypes = [vp]
     lib.qrl_demod_stream.restype = vp
     lib.qrl_demod_stream.argtypes = [vp]
+    lib.qrl_demod_profile.argtypes = [vp, C.c_int]
+    lib.qrl_demod_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_char_p)]
     lib.qrl_demod_process_host.argtypes = [vp, vp, sz, sz, vp, vp, sz, vp]
     lib.qrl_firdes_low_pass.argtypes = [C.c_double] * 4 + [C.c_int, vp]
     lib.qrl_firdes_low_pass_2.argtypes = [C.c_double] * 5 + [C.c_int, vp]
@@ -81,7 +83,8 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "qrl_init", "qrl_shutdown", "qrl_strerror", "qrl_last_error", "qrl_version", "qrl_demod_create",
     "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_out_caps",
-    "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_firdes_low_pass",
+    "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
+    "qrl_demod_profile_read", "qrl_firdes_low_pass",
     "qrl_firdes_low_pass_2", "qrl_firdes_complex_band_pass", "qrl_firdes_root_raised_cosine", "qrl_table_mmse",
     "qrl_table_atan", "qrl_table_tanh", "qrl_phase_inc_to_turn",
 ]
@@ -203,6 +206,14 @@ class Demod:
         self.sync()
         return dict(filtered=self.filtered, constellation=self.constellation, bits_a=self.bits_a, bits_b=self.bits_b,
                     counts=self.counts)
+
+    def profile(self, enable=True):
+        _check(self.lib.qrl_demod_profile(self.h, int(enable)), "qrl_demod_profile")
+
+    def profile_read(self):
+        ms, n, name = C.c_double(), C.c_uint64(), C.c_char_p()
+        _check(self.lib.qrl_demod_profile_read(self.h, C.byref(ms), C.byref(n), C.byref(name)), "qrl_demod_profile_read")
+        return ms.value, n.value, name.value.decode()
 
     def reset(self):
         _check(self.lib.qrl_demod_reset(self.h), "qrl_demod_reset")
