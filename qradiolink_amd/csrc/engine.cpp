@@ -75,17 +75,20 @@ std::vector<float2> to_f2(const std::vector<std::complex<float>>& v)
 
 struct DecimStage {
     bool used = false;
-    int D = 1, Jpad = 0, variant = DECIM_R4_J14, nt = 0;
+    int D = 1, Jpad = 0, variant = DECIM_R4_J12, nt = 0;
     DevBuf<float> taps;
     int plan(const std::vector<float>& h, int D_) {
         used = true; D = D_; nt = (int)h.size();
         const int J = (nt + D - 1) / D;
-        if (J <= 9 && decim_lds_bytes(D, 9, DECIM_R2_J9) <= 80 * 1024) { variant = DECIM_R2_J9; Jpad = 9; }
-        else {
-            Jpad = (J + 13) / 14 * 14;
-            variant = decim_lds_bytes(D, Jpad, DECIM_R4_J14) <= 80 * 1024 ? DECIM_R4_J14 : DECIM_R1_J14;
-            if (decim_lds_bytes(D, Jpad, variant) > 160 * 1024) return QRL_ERR_ARG;
-        }
+        const size_t kLds2 = 80 * 1024;  // two workgroups per CU
+        auto pad = [&](int v) { const int jc = decim_jc(v); return (J + jc - 1) / jc * jc; };
+        variant = -1;
+        if (J <= 10 && decim_lds_bytes(D, pad(DECIM_R2_J10), DECIM_R2_J10) <= kLds2) variant = DECIM_R2_J10;
+        else if (J > 36 && J <= 44 && decim_lds_bytes(D, 44, DECIM_R4_J44) <= kLds2) variant = DECIM_R4_J44;
+        else if (decim_lds_bytes(D, pad(DECIM_R4_J12), DECIM_R4_J12) <= kLds2) variant = DECIM_R4_J12;
+        else variant = DECIM_R1_J14;
+        Jpad = pad(variant);
+        if (decim_lds_bytes(D, Jpad, variant) > 160 * 1024) return QRL_ERR_ARG;
         return taps.upload(decim_layout(h, D, Jpad));
     }
     uint32_t lookback() const { return (uint32_t)(Jpad * D); }

@@ -33,7 +33,8 @@ struct HistParams {
 void launch_decim(const DecimParams& p, int batch, int variant, hipStream_t s);
 void launch_hist_save(const HistParams& p, int batch, hipStream_t s);
 size_t decim_lds_bytes(int D, int Jpad, int variant);
-enum { DECIM_R4_J14 = 0, DECIM_R2_J9 = 1, DECIM_R1_J14 = 2 };
+enum { DECIM_R4_J44 = 0, DECIM_R4_J12 = 1, DECIM_R2_J10 = 2, DECIM_R1_J14 = 3 };
+int decim_jc(int variant);
 
 // ---- K2: rational resampler I/D on a ring (optionally with rotator on a caller buffer) ----
 struct ResampParams {

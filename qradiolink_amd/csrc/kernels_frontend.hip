@@ -30,6 +30,11 @@ __device__ __forceinline__ float2 rot_apply(float2 x, uint64_t k, const float2* 
     const float2 lo = t_lo[(uint32_t)k & 511u];
     return cmul_fma(x, cmul_fma(hi, lo));
 }
+// krel = k - (kb0 << 9) fits 32 bits inside a tile
+__device__ __forceinline__ float2 rot_apply_rel(float2 x, uint32_t krel, const float2* t_hi, const float2* t_lo)
+{
+    return cmul_fma(x, cmul_fma(t_hi[krel >> 9], t_lo[krel & 511u]));
+}
 
 // fetch one input sample of stream b at absolute index i (zero outside the stream so far)
 __device__ __forceinline__ float2 decim_fetch(const DecimParams& P, int b, int64_t i, const float2* t_hi, uint32_t kb0,
@@ -53,18 +58,19 @@ __device__ __forceinline__ float2 decim_fetch(const DecimParams& P, int b, int64
 }
 
 template <int R, int JC>
-__global__ __launch_bounds__(256) void k_decim(const DecimParams P)
+__global__ __launch_bounds__(256) void k_decim(const DecimParams P_)
 {
+    const DecimParams& P = P_;
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int TILE = 64 * R;
     const int D = P.D, Jpad = P.Jpad;
     const int W = TILE + Jpad;
-    const int Wp = (W + R - 1) / R * R;
-    const int Wq = Wp / R;
+    const int Wq = (W + R - 1) / R;
+    const int PT = (R * Wq) | 1;                      // odd row pitch: <=2-way conflicts on the transposing stores
     float2* t_lo = reinterpret_cast<float2*>(smem);   // 512
     float2* t_hi = t_lo + 512;                        // 64
     float2* part = t_hi + 64;                         // 4 * TILE
-    float2* tile = part + 4 * TILE;                   // D * Wp
+    float2* tile = part + 4 * TILE;                   // D * PT
 
     const int b = blockIdx.y;
     const uint32_t per = gridDim.x >> 3;
@@ -87,48 +93,66 @@ __global__ __launch_bounds__(256) void k_decim(const DecimParams P)
         __syncthreads();
     }
 
-    // ---- stage the tile: coalesced pair loads, rotate, transposed LDS store ----
+    // ---- stage the tile: coalesced 16-byte loads, rotate, transposed LDS store ----
+    // Stored samples: i = i_first + s, s in [0, ns), i_first = i_start + 1 (sample (o=0, bq0) is never
+    // used).  o = (s+1) % D, cb = (s+1) / D, column = cb - (o == 0): row 0 sits one column to the left so
+    // that every phase reads column m-j-1 (see the FIR loop).
     {
-        const int a = (int)((i_start - (int64_t)P.n0) & 1);  // make (i - n0) even for 16-byte loads
-        const int npairs = (nsamp + a + 1) >> 1;
-        const int dO = 512 % D, dC = 512 / D;
-        int s0 = -a + 2 * tid;
-        int o = 0, col = 0;
-        if (s0 >= 0) { col = s0 / D; o = s0 - col * D; }
-        for (int k = tid; k < npairs; k += 256, s0 += 512) {
-            float2 x0, x1;
-            const int64_t i0 = i_start + s0;
-            const bool fast = P.in && i0 >= (int64_t)P.n0 && (uint64_t)(i0 + 1) < P.n0 + P.n;
-            if (fast) {
-                const float4 v = *reinterpret_cast<const float4*>(P.in + (size_t)b * P.in_stride + (size_t)((uint64_t)i0 - P.n0));
-                x0 = make_float2(v.x, v.y);
-                x1 = make_float2(v.z, v.w);
-                if (P.rot_enable) {
-                    const uint64_t kk = (uint64_t)i0 - P.rot_nbase;
-                    x0 = rot_apply(x0, kk, t_hi, kb0, t_lo);
-                    x1 = rot_apply(x1, kk + 1, t_hi, kb0, t_lo);
-                }
-            } else {
-                x0 = decim_fetch(P, b, i0, t_hi, kb0, t_lo);
-                x1 = decim_fetch(P, b, i0 + 1, t_hi, kb0, t_lo);
+        const int64_t i_first = i_start + 1;
+        const int ns = nsamp - 1;
+        const int a = (int)((i_first - (int64_t)P.n0) & 1);  // pairs start at s = -a so that (i - n0) is even
+        // pairs k in [k_lo, k_hi): both samples inside the caller's buffer and inside the tile
+        int k_lo = 0, k_hi = 0;
+        if (P.in) {
+            int64_t lo = ((int64_t)P.n0 - i_first + a + 1) >> 1;                 // i0 >= n0
+            int64_t hi = ((int64_t)(P.n0 + P.n) - i_first + a - 1) >> 1;         // i0 + 1 < n0 + n
+            if (lo < a) lo = a;                                                  // s0 >= 0
+            if (hi > ((ns + a) >> 1)) hi = (ns + a) >> 1;                        // s0 + 1 < ns
+            if (hi < lo) hi = lo;
+            k_lo = (int)lo; k_hi = (int)hi;
+        }
+        const int s_lo = k_hi > k_lo ? 2 * k_lo - a : 0, s_hi = k_hi > k_lo ? 2 * k_hi - a : 0;
+        // checked single samples: [0, s_lo) and [s_hi, ns)
+        for (int seg = 0; seg < 2; ++seg) {
+            const int sb = seg ? s_hi : 0, se = seg ? ns : s_lo;
+            for (int sl = sb + tid; sl < se; sl += 256) {
+                const float2 x = decim_fetch(P, b, i_first + sl, t_hi, kb0, t_lo);
+                const int cb = (sl + 1) / D, o = (sl + 1) - cb * D;
+                const int c0 = cb - (o == 0 ? 1 : 0);
+                tile[o * PT + (c0 % R) * Wq + c0 / R] = x;
             }
-            if (s0 >= 0) {
-                tile[o * Wp + (col % R) * Wq + col / R] = x0;
-                int o1 = o + 1, c1 = col;
-                if (o1 == D) { o1 = 0; c1++; }
-                if (s0 + 1 < nsamp) tile[o1 * Wp + (c1 % R) * Wq + c1 / R] = x1;
-                o += dO; col += dC;
-                if (o >= D) { o -= D; col++; }
-            } else {  // s0 == -1: only the second sample belongs to the tile
-                tile[0] = x1;  // o = 0, col = 0
-                const int sn = s0 + 512;
-                col = sn / D; o = sn - col * D;
+        }
+        // fast pairs
+        if (k_lo + tid < k_hi) {
+            int k = k_lo + tid;
+            const int s0 = -a + 2 * k;
+            int cb = (s0 + 1) / D, o = (s0 + 1) - cb * D;
+            const float4* src = reinterpret_cast<const float4*>(P.in + (size_t)b * P.in_stride + (size_t)((uint64_t)(i_first + s0) - P.n0));
+            uint32_t krel = (uint32_t)((uint64_t)(i_first + s0) - P.rot_nbase - ((uint64_t)kb0 << 9));
+            const int dO = 512 % D, dC = 512 / D;
+            const bool rot = P.rot_enable != 0;
+#pragma unroll 4
+            for (; k < k_hi; k += 256, src += 256, krel += 512) {
+                const float4 v = *src;
+                float2 x0 = make_float2(v.x, v.y), x1 = make_float2(v.z, v.w);
+                if (rot) {
+                    x0 = rot_apply_rel(x0, krel, t_hi, t_lo);
+                    x1 = rot_apply_rel(x1, krel + 1, t_hi, t_lo);
+                }
+                const int c0 = cb - (o == 0 ? 1 : 0);
+                tile[o * PT + (c0 % R) * Wq + c0 / R] = x0;
+                int o1 = o + 1, c1 = cb;
+                if (o1 == D) { o1 = 0; c1 = cb; } else c1 = cb;   // (o1 == 0) => column cb+1-1 = cb
+                tile[o1 * PT + (c1 % R) * Wq + c1 / R] = x1;
+                o += dO; cb += dC;
+                if (o >= D) { o -= D; cb++; }
             }
         }
     }
     __syncthreads();
 
-    // ---- FIR: wave g = phase group g ----
+    // ---- FIR: wave g = phase group g.  Tap (p, j) of output m lives in row (D-p)%D, column m-j-1
+    //      (relative to bq0): col = R*lane + cst + t, cst = Jpad-(c+1)*JC = 0 mod R, t = r-jj+JC-1.
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int p0 = (g * D) >> 2, p1 = ((g + 1) * D) >> 2;
@@ -139,17 +163,13 @@ __global__ __launch_bounds__(256) void k_decim(const DecimParams P)
     const v2f* tl = reinterpret_cast<const v2f*>(tile);
     for (int p = p0; p < p1; ++p) {
         const int o = p ? D - p : 0;
-        const int shift = p ? 1 : 0;
-        const v2f* row = tl + o * Wp + lane;
         const float* tp = P.taps + p * Jpad;
         for (int c = 0; c < nchunks; ++c) {
-            const int cst = Jpad - shift - (c + 1) * JC + 1;
+            const int cq = (Jpad - (c + 1) * JC) / R;
+            const v2f* row = tl + o * PT + cq + lane;
             v2f w[R + JC - 1];
 #pragma unroll
-            for (int t = 0; t < R + JC - 1; ++t) {
-                const int cc = cst + t;
-                w[t] = row[(cc % R) * Wq + cc / R];
-            }
+            for (int t = 0; t < R + JC - 1; ++t) w[t] = row[(t % R) * Wq + t / R];
 #pragma unroll
             for (int jj = 0; jj < JC; ++jj) {
                 const float h = tp[c * JC + jj];
@@ -175,27 +195,44 @@ __global__ __launch_bounds__(256) void k_decim(const DecimParams P)
     }
 }
 
+static void decim_variant(int variant, int& R, int& JC)
+{
+    switch (variant) {
+    case DECIM_R4_J44: R = 4; JC = 44; break;
+    case DECIM_R4_J12: R = 4; JC = 12; break;
+    case DECIM_R2_J10: R = 2; JC = 10; break;
+    default: R = 1; JC = 14; break;
+    }
+}
+int decim_jc(int variant) { int R, JC; decim_variant(variant, R, JC); return JC; }
+
 size_t decim_lds_bytes(int D, int Jpad, int variant)
 {
-    const int R = variant == DECIM_R4_J14 ? 4 : (variant == DECIM_R2_J9 ? 2 : 1);
+    int R, JC;
+    decim_variant(variant, R, JC);
     const int TILE = 64 * R;
     const int W = TILE + Jpad;
-    const int Wp = (W + R - 1) / R * R;
-    return (size_t)(512 + 64 + 4 * TILE + D * Wp) * sizeof(float2);
+    const int Wq = (W + R - 1) / R;
+    const int PT = (R * Wq) | 1;
+    return (size_t)(512 + 64 + 4 * TILE + D * PT) * sizeof(float2);
 }
 
 void launch_decim(const DecimParams& p, int batch, int variant, hipStream_t s)
 {
-    const int R = variant == DECIM_R4_J14 ? 4 : (variant == DECIM_R2_J9 ? 2 : 1);
+    int R, JC;
+    decim_variant(variant, R, JC);
     const uint32_t tiles = (p.m_count + 64 * R - 1) / (64 * R);
     if (tiles == 0) return;
     DecimParams q = p;
     q.tiles = tiles;
     dim3 grid((tiles + 7) / 8 * 8, batch), block(256);
     const size_t lds = decim_lds_bytes(p.D, p.Jpad, variant);
-    if (variant == DECIM_R4_J14)      hipLaunchKernelGGL((k_decim<4, 14>), grid, block, lds, s, q);
-    else if (variant == DECIM_R2_J9)  hipLaunchKernelGGL((k_decim<2, 9>), grid, block, lds, s, q);
-    else                              hipLaunchKernelGGL((k_decim<1, 14>), grid, block, lds, s, q);
+    switch (variant) {
+    case DECIM_R4_J44: hipLaunchKernelGGL((k_decim<4, 44>), grid, block, lds, s, q); break;
+    case DECIM_R4_J12: hipLaunchKernelGGL((k_decim<4, 12>), grid, block, lds, s, q); break;
+    case DECIM_R2_J10: hipLaunchKernelGGL((k_decim<2, 10>), grid, block, lds, s, q); break;
+    default:           hipLaunchKernelGGL((k_decim<1, 14>), grid, block, lds, s, q); break;
+    }
 }
 
 // ---- history keeper: hist_new[k] = rotated sample at absolute index n0 + n - H + k ----

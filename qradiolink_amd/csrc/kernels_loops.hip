@@ -36,26 +36,40 @@ __global__ __launch_bounds__(64) void k_fll(const FllParams P, int batch)
         for (int j = 0; j < NT; ++j) dl[j] = make_float2(0.f, 0.f);
     }
     const int nstreams = min(64, batch - b0);
+    constexpr int KPS = (FLL_CH + 63) / 64;
     for (uint32_t c0 = 0; c0 < P.count; c0 += FLL_CH) {
         const int len = min((uint32_t)FLL_CH, P.count - c0);
         __syncthreads();
-        // stage x[n - NT] for n in [q0+c0, q0+c0+len) of every stream of this wave
-        for (int s = 0; s < nstreams; ++s) {
-            for (int k = lane; k < len; k += 64) {
-                const int64_t i = (int64_t)(P.q0 + c0 + k) - NT;
-                float2 v = make_float2(0.f, 0.f);
-                if (i >= 0) v = P.in.p[(size_t)(b0 + s) * (P.in.mask + 1u) + ((uint32_t)i & P.in.mask)];
-                win[s][k] = v;
+        // stage x[n - NT] for n in [q0+c0, q0+c0+len) of every stream of this wave; 8 streams of loads in flight
+        for (int s0 = 0; s0 < nstreams; s0 += 8) {
+            float2 v[8][KPS];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int kk = 0; kk < KPS; ++kk) {
+                    const int k = lane + 64 * kk;
+                    const int64_t i = (int64_t)(P.q0 + c0 + k) - NT;
+                    v[u][kk] = make_float2(0.f, 0.f);
+                    if (s0 + u < nstreams && k < len && i >= 0)
+                        v[u][kk] = P.in.p[(size_t)(b0 + s0 + u) * (P.in.mask + 1u) + ((uint32_t)i & P.in.mask)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int kk = 0; kk < KPS; ++kk) {
+                    const int k = lane + 64 * kk;
+                    if (s0 + u < nstreams && k < FLL_CH) win[s0 + u][k] = v[u][kk];
+                }
             }
         }
         __syncthreads();
         if (active) {
-            float2* orow = P.out.p + (size_t)b * (P.out.mask + 1u);
             for (int k = 0; k < len; ++k) {
                 const float2 x = win[lane][k];
                 const float2 nco = sincos_rad(phase);  // (cos, sin)
                 const float2 y = cmul(x, nco);
-                orow[(uint32_t)(P.q0 + c0 + k) & P.out.mask] = y;
+                win[lane][k] = y;                      // output staged in place, flushed coalesced below
 #pragma unroll
                 for (int j = NT - 1; j > 0; --j) dl[j] = dl[j - 1];
                 dl[0] = y;
@@ -73,6 +87,15 @@ __global__ __launch_bounds__(64) void k_fll(const FllParams P, int batch)
                 phase = phase + freq + P.alpha * error;
                 phase = phase_wrap(phase);
                 if (freq > P.max_freq) freq = P.max_freq; else if (freq < -P.max_freq) freq = -P.max_freq;
+            }
+        }
+        __syncthreads();
+        for (int s = 0; s < nstreams; ++s) {
+            float2* orow = P.out.p + (size_t)(b0 + s) * (P.out.mask + 1u);
+#pragma unroll
+            for (int kk = 0; kk < KPS; ++kk) {
+                const int k = lane + 64 * kk;
+                if (k < len) orow[(uint32_t)(P.q0 + c0 + k) & P.out.mask] = win[s][k];
             }
         }
     }
@@ -96,6 +119,7 @@ void launch_fll(const FllParams& p, int batch, hipStream_t s)
 constexpr int SS_WIN = 184;          // new samples per window
 constexpr int SS_LEN = SS_WIN + 8;   // + interpolator span
 constexpr int SS_PITCH = SS_LEN + 1; // odd
+constexpr int SS_OPITCH = 65;        // symbols produced per stream per window < 64 (sps >= 3.9)
 
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 {
@@ -111,6 +135,9 @@ __global__ __launch_bounds__(64) void k_symsync_ff(const SymSyncParams P, int ba
 {
     __shared__ float win[64 * SS_PITCH];
     __shared__ float mm[129 * 9];
+    __shared__ float osym[64 * SS_OPITCH];
+    __shared__ int ocnt[64];
+    __shared__ uint64_t obase[64], oo0[64];
     const int lane = threadIdx.x;
     const int b0 = blockIdx.x * 64;
     const int b = b0 + lane;
@@ -120,24 +147,41 @@ __global__ __launch_bounds__(64) void k_symsync_ff(const SymSyncParams P, int ba
     if (active) st = P.st[b];
     else { st.ii = ~0ull >> 1; st.oo = 0; st.mu = 0; st.avg = st.inst = 0; st.x0 = st.x1 = st.x2 = st.d0 = st.d1 = st.d2 = 0; }
     const uint64_t oo_start = st.oo;
+    oo0[lane] = oo_start;
     const int nstreams = min(64, batch - b0);
     const float* row = win + lane * SS_PITCH;
+    constexpr int KPS = SS_LEN / 64;
+    static_assert(SS_LEN % 64 == 0, "window must be a multiple of the wave size");
     while (true) {
         const bool can = active && (st.ii + 8 <= P.avail);
         if (!__any(can)) break;
         const uint64_t w0 = wave_min_u64(can ? st.ii : ~0ull);
         const uint64_t wend = (w0 + SS_LEN < P.avail) ? (w0 + SS_LEN) : P.avail;  // exclusive
         __syncthreads();
-        for (int s = 0; s < nstreams; ++s) {
-            const float* src = P.in.p + (size_t)(b0 + s) * (P.in.mask + 1u);
-            for (int k = lane; k < SS_LEN; k += 64) {
-                const uint64_t i = w0 + k;
-                win[s * SS_PITCH + k] = (i < P.avail) ? src[(uint32_t)i & P.in.mask] : 0.f;
+        for (int s0 = 0; s0 < nstreams; s0 += 8) {   // 8 streams x KPS coalesced loads in flight
+            float v[8][KPS];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int kk = 0; kk < KPS; ++kk) {
+                    const uint64_t i = w0 + lane + 64 * kk;
+                    v[u][kk] = 0.f;
+                    if (s0 + u < nstreams && i < P.avail)
+                        v[u][kk] = P.in.p[(size_t)(b0 + s0 + u) * (P.in.mask + 1u) + ((uint32_t)i & P.in.mask)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int kk = 0; kk < KPS; ++kk)
+                    if (s0 + u < nstreams) win[(s0 + u) * SS_PITCH + lane + 64 * kk] = v[u][kk];
             }
         }
         __syncthreads();
+        const uint64_t oo_w = st.oo;   // first symbol index of this window for this stream
+        int nsym = 0;
         if (can) {
-            while (st.ii + 8 <= wend) {
+            while (st.ii + 8 <= wend && nsym < 64) {
                 const int off = (int)(st.ii - w0);
                 const int imu = (int)rintf(st.mu * 128.0f);
                 const float* t = mm + imu * 9;
@@ -159,17 +203,29 @@ __global__ __launch_bounds__(64) void k_symsync_ff(const SymSyncParams P, int ba
                 const float ph = st.mu + st.inst;
                 const float fl = floorf(ph);
                 st.mu = ph - fl;
-                // soft symbol: multiply_const -> add_const -> float_to_uchar
+                osym[lane * SS_OPITCH + nsym] = y;
+                nsym++;
+                st.oo++;
+                st.ii += (uint64_t)(int)fl;
+            }
+        }
+        ocnt[lane] = nsym;
+        obase[lane] = oo_w;
+        __syncthreads();
+        // coalesced flush: soft symbols (multiply_const -> add_const -> float_to_uchar) and port 1
+        for (int s = 0; s < nstreams; ++s) {
+            const int cnt = ocnt[s];
+            if (lane < cnt) {
+                const float y = osym[s * SS_OPITCH + lane];
                 float v = y * P.soft_mul;
                 v = v + P.soft_add;
                 float r = rintf(v);
                 if (!(r >= 0.f)) r = 0.f;
                 if (r > 255.f) r = 255.f;
-                P.soft.p[(size_t)b * (P.soft.mask + 1u) + ((uint32_t)st.oo & P.soft.mask)] = (uint8_t)r;
-                const uint64_t k = st.oo - oo_start;
-                if (P.port && k < P.port_cap) P.port[(size_t)b * P.port_cap + k] = make_float2(y, 0.f);
-                st.oo++;
-                st.ii += (uint64_t)(int)fl;
+                const uint64_t o = obase[s] + lane;
+                P.soft.p[(size_t)(b0 + s) * (P.soft.mask + 1u) + ((uint32_t)o & P.soft.mask)] = (uint8_t)r;
+                const uint64_t k = o - oo0[s];
+                if (P.port && k < P.port_cap) P.port[(size_t)(b0 + s) * P.port_cap + k] = make_float2(y, 0.f);
             }
         }
     }
