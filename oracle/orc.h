@@ -64,6 +64,10 @@ uint64_t orc_phase_inc_to_turn(double radians_per_sample);
 void   orc_rotator(const cf32* in, size_t n, uint64_t inc, uint64_t acc0, cf32* out);
 size_t orc_decim_count(size_t n, int interp, int decim);
 size_t orc_decim_fir_ccf(const cf32* in, size_t n, const float* taps, int nt, int decim, int nsplit, cf32* out);
+size_t orc_decim_fir_ccf_m16(const cf32* in, size_t n, const float* taps, int nt, int decim, cf32* out);
+int    orc_m16_steps(int nt, int decim);
+int    orc_decim_uses_m16(int nt, int decim);
+size_t orc_decim_auto(const cf32* in, size_t n, const float* taps, int nt, int decim, cf32* out);
 size_t orc_resamp_ccf(const cf32* in, size_t n, const float* taps, int nt, int interp, int decim, cf32* out);
 size_t orc_resamp_fff(const float* in, size_t n, const float* taps, int nt, int interp, int decim, float* out);
 void   orc_fir_ccf(const cf32* in, size_t n, const float* taps, int nt, cf32* out);

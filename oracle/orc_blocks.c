@@ -84,6 +84,62 @@ size_t orc_decim_fir_ccf(const cf32* in, size_t n, const float* taps, int nt, in
     return nout;
 }
 
+/* "m16" summation contract of the wide decimators (the order an f32 MFMA 16x16x4 accumulation
+ * produces: gfx950's f32-input MFMA is bit-for-bit a k-ordered fmaf chain).
+ * Output m = 16a + b (b = m mod 16, absolute index).  With u = sample offset relative to the
+ * block origin i0 = (m - b)*D, tap k = b*D - u.  The u axis [u_min, u_min + 4S), u_min = -(nt-1),
+ * S = ceil((nt + 15 D)/4) rounded up to a multiple of 4, is cut into 4 equal quarters; quarter g is
+ * ONE fmaf chain, u ascending (oldest sample first), starting from +0;
+ * y = (r0 + r1) + (r2 + r3).  Taps outside [0, nt) and samples before the stream start are exact
+ * zeros and are skipped (fmaf(0, x, acc) == acc for finite x). */
+int orc_m16_steps(int nt, int D)
+{
+    int S = (nt + 15 * D + 3) / 4;
+    return (S + 3) / 4 * 4;
+}
+size_t orc_decim_fir_ccf_m16(const cf32* in, size_t n, const float* taps, int nt, int D, cf32* out)
+{
+    size_t nout = orc_decim_count(n, 1, D);
+    const int S = orc_m16_steps(nt, D), Sq = S / 4;
+    const long long u_min = -(long long)(nt - 1);
+    for (size_t m = 0; m < nout; m++) {
+        const int b = (int)(m & 15u);
+        const long long i0 = (long long)(m - (size_t)b) * D;
+        float rr[4], ri[4];
+        for (int g = 0; g < 4; g++) {
+            float ar = 0.0f, ai = 0.0f;
+            long long ua = u_min + 4LL * Sq * g, ub = ua + 4LL * Sq;
+            /* valid taps: 0 <= b*D - u < nt  <=>  b*D - nt < u <= b*D */
+            if (ua < (long long)b * D - (nt - 1)) ua = (long long)b * D - (nt - 1);
+            if (ub > (long long)b * D + 1) ub = (long long)b * D + 1;
+            if (ua < -i0) ua = -i0;   /* samples before the stream start are zero */
+            for (long long u = ua; u < ub; u++) {
+                const float h = taps[(long long)b * D - u];
+                const cf32 x = in[i0 + u];
+                ar = fmaf(h, x.re, ar);
+                ai = fmaf(h, x.im, ai);
+            }
+            rr[g] = ar; ri[g] = ai;
+        }
+        out[m].re = (rr[0] + rr[1]) + (rr[2] + rr[3]);
+        out[m].im = (ri[0] + ri[1]) + (ri[2] + ri[3]);
+    }
+    return nout;
+}
+/* Which contract a (nt, D) decimator uses; libqrl_hip's DecimStage::plan applies the same rule:
+ * m16 when D >= 8 and the smallest MFMA tile (8 output blocks of 16) fits the LDS budget. */
+int orc_decim_uses_m16(int nt, int D)
+{
+    if (D < 8) return 0;
+    const long long samples = 7LL * 16 * D + 4LL * orc_m16_steps(nt, D);
+    return (samples + 2 * (samples / (16LL * D)) + 64) * 8 <= 150 * 1024;
+}
+size_t orc_decim_auto(const cf32* in, size_t n, const float* taps, int nt, int D, cf32* out)
+{
+    if (orc_decim_uses_m16(nt, D)) return orc_decim_fir_ccf_m16(in, n, taps, nt, D, out);
+    return orc_decim_fir_ccf(in, n, taps, nt, D, 4, out);
+}
+
 /* General I/D.  One fmaf chain per output, j ascending. */
 size_t orc_resamp_ccf(const cf32* in, size_t n, const float* taps, int nt, int I, int D, cf32* out)
 {

@@ -34,7 +34,7 @@ size_t orc_frontend(const cf32* in, size_t n, int samp_rate, double carrier_offs
     orc_frontend_taps(samp_rate, taps);
     cf32* rot = NEW(cf32, n);
     orc_rotator(in, n, inc, 0, rot);
-    size_t m = orc_decim_fir_ccf(rot, n, taps, nt, decim, 4, out);
+    size_t m = orc_decim_auto(rot, n, taps, nt, decim, out);
     free(rot); free(taps);
     return m;
 }
@@ -75,7 +75,7 @@ void orc_demod_2fsk(const cf32* in, size_t n, int sps, int samp_rate, int carrie
     orc_low_pass(interp, (double)interp * samp_rate, target / 2, target / 2, ORC_WIN_BLACKMAN_HARRIS, taps);
     size_t n1 = orc_decim_count(n, interp, decim);
     cf32* s1 = NEW(cf32, n1);
-    if (interp == 1) orc_decim_fir_ccf(in, n, taps, nt, decim, 4, s1);
+    if (interp == 1) orc_decim_auto(in, n, taps, nt, decim, s1);
     else             orc_resamp_ccf(in, n, taps, nt, interp, decim, s1);
     free(taps);
 
@@ -151,7 +151,7 @@ void orc_demod_gmsk(const cf32* in, size_t n, int sps, int samp_rate, int carrie
     orc_low_pass(interp, (double)interp * samp_rate, target / 2, target / 2, ORC_WIN_BLACKMAN_HARRIS, taps);
     size_t n1 = orc_decim_count(n, interp, decim);
     cf32* s1 = NEW(cf32, n1);
-    if (interp == 1) orc_decim_fir_ccf(in, n, taps, nt, decim, 4, s1);
+    if (interp == 1) orc_decim_auto(in, n, taps, nt, decim, s1);
     else             orc_resamp_ccf(in, n, taps, nt, interp, decim, s1);
     free(taps);
 
@@ -198,7 +198,7 @@ void orc_demod_qpsk(const cf32* in, size_t n, int sps, int samp_rate, int carrie
     orc_low_pass_2(interp, (double)samp_rate * interp, target / 2, target / 10, 60, ORC_WIN_BLACKMAN_HARRIS, taps);
     size_t n1 = orc_decim_count(n, interp, decim);
     cf32* s1 = NEW(cf32, n1);
-    orc_decim_fir_ccf(in, n, taps, nt, decim, 4, s1);
+    orc_decim_auto(in, n, taps, nt, decim, s1);
     free(taps);
     if (sps > 4) {
         cf32* s1b = NEW(cf32, n1);

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <complex>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -74,11 +75,20 @@ std::vector<float2> to_f2(const std::vector<std::complex<float>>& v)
 }
 
 struct DecimStage {
-    bool used = false;
-    int D = 1, Jpad = 0, variant = DECIM_R4_J12, nt = 0;
+    bool used = false, mfma = false;
+    int D = 1, Jpad = 0, variant = DECIM_R4_J12, nt = 0, S = 0;
     DevBuf<float> taps;
     int plan(const std::vector<float>& h, int D_) {
         used = true; D = D_; nt = (int)h.size();
+        const char* force = std::getenv("QRL_DECIM_VALU");   // A/B timing only: changes the summation contract
+        if (decim_uses_mfma(nt, D) && !(force && force[0] == '1')) {
+            // zero-padded tap vector the MFMA A operands are read from: hp[k + (4S - nt + 1)] = h[k]
+            mfma = true;
+            S = decim_mfma_steps(nt, D);
+            std::vector<float> g((size_t)decim_mfma_hpn(nt, D), 0.0f);
+            for (int k = 0; k < nt; ++k) g[(size_t)k + (size_t)(4 * S - nt + 1)] = h[k];
+            return taps.upload(g);
+        }
         const int J = (nt + D - 1) / D;
         const size_t kLds2 = 80 * 1024;  // two workgroups per CU
         auto pad = [&](int v) { const int jc = decim_jc(v); return (J + jc - 1) / jc * jc; };
@@ -91,7 +101,7 @@ struct DecimStage {
         if (decim_lds_bytes(D, Jpad, variant) > 160 * 1024) return QRL_ERR_ARG;
         return taps.upload(decim_layout(h, D, Jpad));
     }
-    uint32_t lookback() const { return (uint32_t)(Jpad * D); }
+    uint32_t lookback() const { return mfma ? (uint32_t)(nt + D) : (uint32_t)(Jpad * D); }
 };
 
 }  // namespace
@@ -304,7 +314,8 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         p.out = r1; p.m0 = n1_0; p.m_count = (uint32_t)(n1_1 - n1_0);
         p.taps = fe.taps.p; p.D = fe.D; p.Jpad = fe.Jpad;
         p.rot_enable = 1; p.rot_acc = rot_acc; p.rot_inc = rot_inc; p.rot_nbase = rot_nbase; p.rot_lo = rot_lo.p;
-        launch_decim(p, B, fe.variant, stream);
+        if (fe.mfma) { p.gtab = fe.taps.p; p.S = fe.S; p.nt = fe.nt; launch_decim_mfma(p, B, stream); }
+        else launch_decim(p, B, fe.variant, stream);
     }
     if (profiling && fe.used) { HIPCHK(hipEventRecord(ev1, stream)); prof_events.emplace_back(ev0, ev1); }
     // ---- stage B: per-mode resampler
@@ -318,7 +329,8 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         p.n0 = src0; p.n = (uint32_t)(src1 - src0);
         p.out = r2; p.m0 = n2_0; p.m_count = (uint32_t)(n2_1 - n2_0);
         p.taps = first.taps.p; p.D = first.D; p.Jpad = first.Jpad;
-        launch_decim(p, B, first.variant, stream);
+        if (first.mfma) { p.gtab = first.taps.p; p.S = first.S; p.nt = first.nt; launch_decim_mfma(p, B, stream); }
+        else launch_decim(p, B, first.variant, stream);
     } else {
         ResampParams p{};
         if (fe.used) { p.in = nullptr; p.in_ring = r1; }
@@ -528,10 +540,16 @@ int qrl_demod_profile_read(qrl_demod* d, double* kernel_ms, uint64_t* launches, 
     }
     if (kernel_ms) *kernel_ms = total;
     if (launches) *launches = d->prof_events.size();
-    if (kernel_name) *kernel_name = (d->fe.used || d->interp == 1) ? "k_decim" : "k_resamp";
+    if (kernel_name) {
+        const DecimStage& st = d->fe.used ? d->fe : d->first;
+        *kernel_name = (d->fe.used || d->interp == 1) ? (st.mfma ? "k_decim_mfma" : "k_decim") : "k_resamp";
+    }
     d->prof_events.clear();
     return QRL_OK;
 }
+
+/* developer aid (not part of the drop-in surface): phase profile of k_decim_mfma under QRL_DBG=32 */
+void qrl_debug_decim_prof(unsigned long long* out8) { decim_mfma_prof_read(out8); }
 
 int qrl_demod_process_host(qrl_demod* d, const float* iq_host, size_t stride, size_t n, uint8_t* bits_a_host,
                            uint8_t* bits_b_host, size_t bits_cap, uint32_t* counts_host)

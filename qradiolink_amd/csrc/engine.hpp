@@ -24,6 +24,9 @@ struct DecimParams {
     int D, Jpad;
     int rot_enable; uint64_t rot_acc; uint64_t rot_inc; uint64_t rot_nbase; const float2* rot_lo;
     uint32_t tiles;                      // tiles per stream
+    // MFMA variant (kernels_decim_mfma.hip): banded-Toeplitz A operands [S steps][64 lanes], S steps of 4
+    const float* gtab; int S; int nt; uint32_t magic_blk, magic_seg;   // gtab: zero-padded taps, hp[k + 4S - nt + 1] = h[k]
+    uint32_t tpw, nchunks; int nhi; int dbg;               // consecutive tiles per workgroup; rotator coarse-table entries
 };
 struct HistParams {
     const float2* in; size_t in_stride; uint64_t n0; uint32_t n;
@@ -35,6 +38,14 @@ void launch_hist_save(const HistParams& p, int batch, hipStream_t s);
 size_t decim_lds_bytes(int D, int Jpad, int variant);
 enum { DECIM_R4_J44 = 0, DECIM_R4_J12 = 1, DECIM_R2_J10 = 2, DECIM_R1_J14 = 3 };
 int decim_jc(int variant);
+// f32-MFMA decimator (D >= 8): contract "m16" of oracle/orc_blocks.c
+bool decim_uses_mfma(int nt, int D);
+int decim_mfma_steps(int nt, int D);
+int decim_mfma_na(int nt, int D);
+int decim_mfma_hpn(int nt, int D);
+size_t decim_mfma_lds_bytes(int nt, int D);
+void launch_decim_mfma(const DecimParams& p, int batch, hipStream_t s);
+void decim_mfma_prof_read(unsigned long long* out8);
 
 // ---- K2: rational resampler I/D on a ring (optionally with rotator on a caller buffer) ----
 struct ResampParams {

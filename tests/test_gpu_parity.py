@@ -50,6 +50,8 @@ def _compare(iq, out, mode_name, device_rate, offset):
     ("2fsk1k", 18, 1000000, 1 << 21),
     ("2fsk1kfm", 16, 1000000, 1 << 21),
     ("gmsk1k", 21, 2000000, 1 << 22),
+    ("gmsk10k", 22, 25000000, 1 << 23),     # front end 25:1, 1045 taps: f32-MFMA decimator, 16-block tiles
+    ("gmsk10k", 22, 10000000, 1 << 23),     # front end 10:1, 419 taps
 ])
 def test_chain_bit_exact_single_call(qrl_ctx, mode_name, modem, rate, chunk):
     offset = 25000.0 if rate >= 2000000 else 1200.0
@@ -61,6 +63,13 @@ def test_chain_bit_exact_single_call(qrl_ctx, mode_name, modem, rate, chunk):
 def test_chunk_invariance_gmsk(qrl_ctx, chunk):
     iq, out = _run(qrl_ctx, "gmsk10k", 22, 4000000, 25000.0, B=2, chunk=chunk, nframes=2)
     _compare(iq, out, "gmsk10k", 4000000, 25000.0)
+
+
+@pytest.mark.parametrize("chunk", [1 << 20, 333334, 6400 * 3 + 2])
+def test_chunk_invariance_mfma_front_end(qrl_ctx, chunk):
+    """25 Msps front end (MFMA decimator): tiles are aligned to absolute output index, so any cut works."""
+    iq, out = _run(qrl_ctx, "gmsk10k", 22, 25000000, 25000.0, B=2, chunk=chunk, nframes=1)
+    _compare(iq, out, "gmsk10k", 25000000, 25000.0)
 
 
 @pytest.mark.parametrize("chunk", [65536, 50000])
