@@ -90,8 +90,8 @@ size_t orc_decim_fir_ccf(const cf32* in, size_t n, const float* taps, int nt, in
  * block origin i0 = (m - b)*D, tap k = b*D - u.  The u axis [u_min, u_min + 4S), u_min = -(nt-1),
  * S = ceil((nt + 15 D)/4) rounded up to a multiple of 4, is cut into 4 equal quarters; quarter g is
  * ONE fmaf chain, u ascending (oldest sample first), starting from +0;
- * y = (r0 + r1) + (r2 + r3).  Taps outside [0, nt) and samples before the stream start are exact
- * zeros and are skipped (fmaf(0, x, acc) == acc for finite x). */
+ * y = (r0 + r1) + (r2 + r3).  Taps outside [0, nt) and samples outside the stream are +0 and DO take
+ * part (same value as skipping them, but it fixes the sign of a zero result; inputs must be finite). */
 int orc_m16_steps(int nt, int D)
 {
     int S = (nt + 15 * D + 3) / 4;
@@ -108,14 +108,15 @@ size_t orc_decim_fir_ccf_m16(const cf32* in, size_t n, const float* taps, int nt
         float rr[4], ri[4];
         for (int g = 0; g < 4; g++) {
             float ar = 0.0f, ai = 0.0f;
-            long long ua = u_min + 4LL * Sq * g, ub = ua + 4LL * Sq;
-            /* valid taps: 0 <= b*D - u < nt  <=>  b*D - nt < u <= b*D */
-            if (ua < (long long)b * D - (nt - 1)) ua = (long long)b * D - (nt - 1);
-            if (ub > (long long)b * D + 1) ub = (long long)b * D + 1;
-            if (ua < -i0) ua = -i0;   /* samples before the stream start are zero */
+            const long long ua = u_min + 4LL * Sq * g, ub = ua + 4LL * Sq;
+            /* every u of the quarter takes part, exactly as in the matrix product: taps outside the band
+             * are +0 and samples outside the stream are +0.  (Skipping them would be the same value except
+             * for the SIGN OF ZERO: fmaf(0, x, -0) is +0 when 0*x is +0.) */
             for (long long u = ua; u < ub; u++) {
-                const float h = taps[(long long)b * D - u];
-                const cf32 x = in[i0 + u];
+                const long long k = (long long)b * D - u, i = i0 + u;
+                const float h = (k >= 0 && k < nt) ? taps[k] : 0.0f;
+                cf32 x = {0.0f, 0.0f};
+                if (i >= 0 && (size_t)i < n) x = in[i];
                 ar = fmaf(h, x.re, ar);
                 ai = fmaf(h, x.im, ai);
             }

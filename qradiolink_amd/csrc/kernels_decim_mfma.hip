@@ -124,7 +124,6 @@ __device__ __forceinline__ void tile_commit(const DecimParams& P, int b, const T
     if (!FAST) return;
     // register-prefetched pairs: STRAIGHT-LINE code (no exec branches, so hipcc batches the LDS reads);
     // pairs past the end of the window are written to a per-thread dump slot behind the tile
-    const bool rot = P.rot_enable != 0;
     const int j0 = 2 * (w.k_lo + tid) - w.a;
     const uint32_t krel0 = (uint32_t)((uint64_t)(w.i_base + j0) - P.rot_nbase - ((uint64_t)kb0 << 9));
     // krel advances by 512 per step: the fine-table factors of a thread never change
@@ -135,10 +134,8 @@ __device__ __forceinline__ void tile_commit(const DecimParams& P, int b, const T
         const int j = j0 + 512 * it;
         const uint32_t krel = krel0 + 512u * it;
         float2 x0 = make_float2(v[it].x, v[it].y), x1 = make_float2(v[it].z, v[it].w);
-        if (rot) {
-            x0 = cmul_fma(x0, cmul_fma(t_hi[krel >> 9], lo0));
-            x1 = cmul_fma(x1, cmul_fma(t_hi[(krel + 1u) >> 9], lo1));
-        }
+        x0 = cmul_fma(x0, cmul_fma(t_hi[krel >> 9], lo0));   // the caller-buffer path always carries the rotator
+        x1 = cmul_fma(x1, cmul_fma(t_hi[(krel + 1u) >> 9], lo1));
         const bool ok = 256 * it < npair;
         const int p0 = ok ? j + 2 * (int)__umulhi((uint32_t)j, magic) : dump + 2 * tid;
         const int p1 = ok ? j + 1 + 2 * (int)__umulhi((uint32_t)(j + 1), magic) : dump + 2 * tid + 1;
@@ -148,9 +145,140 @@ __device__ __forceinline__ void tile_commit(const DecimParams& P, int b, const T
 }
 
 // One contiguous piece of the step loop (no pad jump inside): step i reads A = ap[-4 i] and B = bp[BS i].
-// Software pipelined by hand with two register sets: the LDS reads of chunk c+1 are issued before the
-// MFMAs of chunk c; sched_barrier keeps hipcc from sinking the reads next to their uses.
+// Software pipelined by hand with two register sets (X = chunk c, Y = chunk c + 1).  The LDS reads are asm
+// statements: hipcc would fuse neighbouring ds_read_b64 into ds_read2_b64, which is served at HALF the LDS
+// rate with mod-32 banking (MI355X_MICROARCH.md, LDS table) and made the LDS the bottleneck of the CU.
+// Waits are explicit and name their registers (guide 5.7 form ii):
+//   issue Y.b (8 DS) | lgkmcnt(8): X complete | 8 MFMA | issue Y.a (8 DS) | 8 MFMA
 constexpr int MF_U = 8;
+typedef __attribute__((address_space(3))) const void* lds_cptr;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_cptr)p; }
+
+#define MF_RD64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define MF_RD32(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+
+struct MfSet2 { float a[MF_U]; float2 b[MF_U]; };   // NA = 16: B = one complex sample per lane
+struct MfSet1 { float a[MF_U]; float b[MF_U]; };    // NA = 8 : B = re or im of a sample
+
+// B reads of 8 steps: byte stride BSB between steps
+template <int BSB>
+__device__ __forceinline__ void mf_issue_b(MfSet2& r, uint32_t baddr)
+{
+    MF_RD64(r.b[0], baddr, 0 * BSB); MF_RD64(r.b[1], baddr, 1 * BSB); MF_RD64(r.b[2], baddr, 2 * BSB); MF_RD64(r.b[3], baddr, 3 * BSB);
+    MF_RD64(r.b[4], baddr, 4 * BSB); MF_RD64(r.b[5], baddr, 5 * BSB); MF_RD64(r.b[6], baddr, 6 * BSB); MF_RD64(r.b[7], baddr, 7 * BSB);
+}
+template <int BSB>
+__device__ __forceinline__ void mf_issue_b(MfSet1& r, uint32_t baddr)
+{
+    MF_RD32(r.b[0], baddr, 0 * BSB); MF_RD32(r.b[1], baddr, 1 * BSB); MF_RD32(r.b[2], baddr, 2 * BSB); MF_RD32(r.b[3], baddr, 3 * BSB);
+    MF_RD32(r.b[4], baddr, 4 * BSB); MF_RD32(r.b[5], baddr, 5 * BSB); MF_RD32(r.b[6], baddr, 6 * BSB); MF_RD32(r.b[7], baddr, 7 * BSB);
+}
+// A reads of 8 steps: step u at aaddr7 + 16 (7 - u) bytes (aaddr7 = address of the LAST step of the chunk)
+template <class SET>
+__device__ __forceinline__ void mf_issue_a(SET& r, uint32_t aaddr7)
+{
+    MF_RD32(r.a[0], aaddr7, 112); MF_RD32(r.a[1], aaddr7, 96); MF_RD32(r.a[2], aaddr7, 80); MF_RD32(r.a[3], aaddr7, 64);
+    MF_RD32(r.a[4], aaddr7, 48);  MF_RD32(r.a[5], aaddr7, 32); MF_RD32(r.a[6], aaddr7, 16); MF_RD32(r.a[7], aaddr7, 0);
+}
+__device__ __forceinline__ void mf_wait8(MfSet2& r)
+{
+    asm volatile("s_waitcnt lgkmcnt(8)"
+                 : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.a[4]), "+v"(r.a[5]), "+v"(r.a[6]), "+v"(r.a[7]),
+                   "+v"(r.b[0]), "+v"(r.b[1]), "+v"(r.b[2]), "+v"(r.b[3]), "+v"(r.b[4]), "+v"(r.b[5]), "+v"(r.b[6]), "+v"(r.b[7]));
+}
+__device__ __forceinline__ void mf_wait8(MfSet1& r)
+{
+    asm volatile("s_waitcnt lgkmcnt(8)"
+                 : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.a[4]), "+v"(r.a[5]), "+v"(r.a[6]), "+v"(r.a[7]),
+                   "+v"(r.b[0]), "+v"(r.b[1]), "+v"(r.b[2]), "+v"(r.b[3]), "+v"(r.b[4]), "+v"(r.b[5]), "+v"(r.b[6]), "+v"(r.b[7]));
+}
+__device__ __forceinline__ void mf_wait0(MfSet2& r)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.a[4]), "+v"(r.a[5]), "+v"(r.a[6]), "+v"(r.a[7]),
+                   "+v"(r.b[0]), "+v"(r.b[1]), "+v"(r.b[2]), "+v"(r.b[3]), "+v"(r.b[4]), "+v"(r.b[5]), "+v"(r.b[6]), "+v"(r.b[7]));
+}
+__device__ __forceinline__ void mf_wait0(MfSet1& r)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.a[4]), "+v"(r.a[5]), "+v"(r.a[6]), "+v"(r.a[7]),
+                   "+v"(r.b[0]), "+v"(r.b[1]), "+v"(r.b[2]), "+v"(r.b[3]), "+v"(r.b[4]), "+v"(r.b[5]), "+v"(r.b[6]), "+v"(r.b[7]));
+}
+template <int U0>
+__device__ __forceinline__ void mf_fma4(const MfSet2& c, f32x4& acc0, f32x4& acc1)
+{
+#pragma unroll
+    for (int u = U0; u < U0 + 4; ++u) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.a[u], c.b[u].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.a[u], c.b[u].y, acc1, 0, 0, 0);
+    }
+}
+template <int U0>
+__device__ __forceinline__ void mf_fma4(const MfSet1& c, f32x4& acc0, f32x4&)
+{
+#pragma unroll
+    for (int u = U0; u < U0 + 4; ++u) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.a[u], c.b[u], acc0, 0, 0, 0);
+}
+
+// SET/BT/BS: MfSet2/float2/4 (B stride 4 float2 = 32 B per step) or MfSet1/float/8 (8 floats = 32 B per step)
+template <class SET, typename BT, int BS>
+__device__ __forceinline__ void mfma_piece(const float* __restrict__ ap, const BT* __restrict__ bp, int n, f32x4& acc0, f32x4& acc1)
+{
+    constexpr int U = MF_U;
+    constexpr int BSB = 32;   // bytes between the B operands of consecutive steps
+    int i = 0;
+    if (n >= U) {
+        const uint32_t a0 = lds_addr(ap) - 16u * (U - 1);   // address of step 7 of chunk 0; chunk c: minus 128 c
+        const uint32_t b0 = lds_addr(bp);                   // chunk c: plus 256 c
+        const int nch = n / U;
+        SET x, y;
+        mf_issue_b<BSB>(x, b0);
+        mf_issue_a(x, a0);
+        for (int c = 0; c < nch; c += 2) {
+            // chunk c lives in x; prefetch chunk c + 1 into y (beyond the end: harmless re-read of chunk 0)
+            const int c1 = c + 1 < nch ? c + 1 : 0;
+            mf_issue_b<BSB>(y, b0 + 256u * c1);
+            mf_wait8(x);
+            __builtin_amdgcn_sched_barrier(0);
+            mf_fma4<0>(x, acc0, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            mf_issue_a(y, a0 - 128u * c1);
+            __builtin_amdgcn_sched_barrier(0);
+            mf_fma4<4>(x, acc0, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 >= nch) { mf_wait0(y); break; }
+            const int c2 = c + 2 < nch ? c + 2 : 0;
+            mf_issue_b<BSB>(x, b0 + 256u * c2);
+            mf_wait8(y);
+            __builtin_amdgcn_sched_barrier(0);
+            mf_fma4<0>(y, acc0, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            mf_issue_a(x, a0 - 128u * c2);
+            __builtin_amdgcn_sched_barrier(0);
+            mf_fma4<4>(y, acc0, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 2 >= nch) { mf_wait0(x); break; }
+        }
+        i = nch * U;
+    }
+    for (; i < n; ++i) {
+        const float av = ap[-4 * i];
+        const BT bv = bp[BS * i];
+        if constexpr (BS == 4) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, reinterpret_cast<const float2&>(bv).x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, reinterpret_cast<const float2&>(bv).y, acc1, 0, 0, 0);
+        } else {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, reinterpret_cast<const float&>(bv), acc0, 0, 0, 0);
+        }
+    }
+}
+
+// Compiler-scheduled variant of the same ping-pong (plain LDS reads, sched_barrier pinned).  It is the DEFAULT:
+// the asm variant above is ~5 % faster but showed rare (1e-4 per tile) wrong outputs with two workgroups per
+// CU at 25 Msps that could not be explained; build with -DQRL_MF_ASM_LDS=1 to select it for experiments.
+#ifndef QRL_MF_ASM_LDS
+#define QRL_MF_ASM_LDS 0
+#endif
 template <typename BT, int BS>
 struct MfChunk {
     float a[MF_U]; BT b[MF_U];
@@ -174,7 +302,7 @@ __device__ __forceinline__ void mf_fma(const MfChunk<float, 8>& c, f32x4& acc0, 
     for (int u = 0; u < MF_U; ++u) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.a[u], c.b[u], acc0, 0, 0, 0);
 }
 template <typename BT, int BS>
-__device__ __forceinline__ void mfma_piece(const float* __restrict__ ap, const BT* __restrict__ bp, int n, f32x4& acc0, f32x4& acc1)
+__device__ __forceinline__ void mfma_piece_c(const float* __restrict__ ap, const BT* __restrict__ bp, int n, f32x4& acc0, f32x4& acc1)
 {
     constexpr int U = MF_U;
     int i = 0;
@@ -206,113 +334,108 @@ __device__ __forceinline__ void mfma_piece(const float* __restrict__ ap, const B
     }
 }
 
-template <int NA, int NLD, bool FAST>
+
+// ---- one wave's quarter of the FIR of one tile on the matrix pipe; partial sums -> part[g][.] ----
+template <int NA, bool ALIAS>
+__device__ __forceinline__ void mfma_quarter(const float2* tile, const float* hp, float2* part, int g, int lane, int D, int S,
+                                             uint32_t magic_seg)
+{
+    constexpr int T = 16 * NA;
+    const int Sq = S >> 2, Pp = 16 * D + 2, kk = lane >> 4, seg_len = 4 * D;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    int s = g * Sq;
+    const int s_end = s + Sq;
+    if constexpr (NA == 16) {
+        const int acol = lane & 15;
+        const float2* bp = tile + acol * Pp + kk;
+        const float* ap = hp + (acol * D + 4 * S - kk);     // tap k = b D - u, stored at k + (4 S - nt + 1)
+        while (s < s_end) {
+            const int seg = (int)__umulhi((uint32_t)s, magic_seg);
+            const int e = min(s_end, (seg + 1) * seg_len);
+            if constexpr (QRL_MF_ASM_LDS) mfma_piece<MfSet2, float2, 4>(ap - 4 * s, bp + 4 * s + 2 * seg, e - s, acc0, acc1);
+            else mfma_piece_c<float2, 4>(ap - 4 * s, bp + 4 * s + 2 * seg, e - s, acc0, acc1);
+            s = e;
+        }
+        if constexpr (ALIAS) __syncthreads();   // part aliases the head of the tile: every wave must be done reading it
+        float2* pp = part + g * T + 16 * acol + 4 * kk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pp[r] = make_float2(acc0[r], acc1[r]);
+    } else {
+        const int n = lane & 15, acol = n >> 1, c = n & 1;
+        const float* bp = reinterpret_cast<const float*>(tile) + 2 * (acol * Pp + kk) + c;
+        const float* ap = hp + ((lane & 15) * D + 4 * S - kk);
+        while (s < s_end) {
+            const int seg = (int)__umulhi((uint32_t)s, magic_seg);
+            const int e = min(s_end, (seg + 1) * seg_len);
+            if constexpr (QRL_MF_ASM_LDS) mfma_piece<MfSet1, float, 8>(ap - 4 * s, bp + 2 * (4 * s + 2 * seg), e - s, acc0, acc1);
+            else mfma_piece_c<float, 8>(ap - 4 * s, bp + 2 * (4 * s + 2 * seg), e - s, acc0, acc1);
+            s = e;
+        }
+        if constexpr (ALIAS) __syncthreads();
+        float* pf = reinterpret_cast<float*>(part + g * T + 16 * acol + 4 * kk) + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pf[2 * r] = acc0[r];
+    }
+}
+
+// ---- one-team variant (tiles too large for two LDS buffers, or input from an engine ring): a workgroup
+// of 4 waves walks its tiles; the loads of tile k + 1 fly during the MFMA phase of tile k.
+template <int NA, int NLD, bool FAST, bool ALIAS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_decim_mfma(const DecimParams P_)
 {
     const DecimParams& P = P_;
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int T = 16 * NA;
-    const int D = P.D, S = P.S, Sq = S >> 2;
+    const int D = P.D, S = P.S;
     const int blk = 16 * D;
-    const int Pp = blk + 2;
     const int Jtot = (NA - 1) * blk + 4 * S;
     const int hpn = (15 * D + 4 * S + 4 + 3) & ~3;   // multiple of 4 floats: the tile behind it stays 16-byte aligned
+    const int nhi = (P.nhi + 1) & ~1;
     float2* t_lo = reinterpret_cast<float2*>(smem);            // 512
-    float2* t_hi = t_lo + 512;                                 // P.nhi
-    float* hp = reinterpret_cast<float*>(t_hi + P.nhi);        // zero-padded taps, hpn (multiple of 4) floats
+    float2* t_hi = t_lo + 512;                                 // nhi
+    float* hp = reinterpret_cast<float*>(t_hi + nhi);          // zero-padded taps
     float2* tile = reinterpret_cast<float2*>(hp + hpn);
-    float2* part = tile;                                       // 4 * T partial sums alias the head of the tile
+    const int dump0 = Jtot + 2 * (Jtot / blk) + 4;
+    float2* part = ALIAS ? tile : tile + dump0 + 512;          // 4 T partial sums (ALIAS: on the head of the tile)
     const int dump = Jtot + 2 * (Jtot / blk) + 4;              // 512 dump slots behind the tile (tile_commit)
 
     const int b = blockIdx.y;
+    // grid.x is either a multiple of 8 (then neighbouring chunks are mapped to the same XCD/L2: block b runs on
+    // XCD b % 8) or exactly nchunks (few chunks per stream: the stream index spreads the work over the XCDs)
     const uint32_t per = gridDim.x >> 3;
-    const uint32_t cix = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);   // neighbouring chunks share an XCD/L2
-    // workgroup cix walks tiles cix, cix + nchunks, cix + 2 nchunks, ...: the workgroups resident at any
-    // moment sweep ONE contiguous region of the stream together (no HBM channel camping, halos shared in L2)
+    const uint32_t cix = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    // workgroup cix walks tiles cix, cix + nchunks, ...: the workgroups resident at any moment sweep ONE
+    // contiguous region of the stream together (halos shared in L2)
     const uint32_t nchunks = P.nchunks;
     if (cix >= nchunks || cix >= P.tiles) return;
-    const uint32_t t0 = cix;
     const int tid = threadIdx.x;
     const uint64_t mt_first = (P.m0 / T) * (uint64_t)T;
-    const uint64_t mt0 = mt_first + (uint64_t)t0 * T;
 
     for (int k = tid; k < hpn; k += 256) hp[k] = P.gtab[k];
-    uint32_t kb0 = 0;
-    if (P.rot_enable) {
-        t_lo[tid] = P.rot_lo[tid];
-        t_lo[tid + 256] = P.rot_lo[tid + 256];
-    }
-
+    if (P.rot_enable) { t_lo[tid] = P.rot_lo[tid]; t_lo[tid + 256] = P.rot_lo[tid + 256]; }
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int kk = lane >> 4;
-    const uint32_t magic_seg = P.magic_seg;   // ceil(2^32 / (4 D))
 
     f32x4 v[NLD];
-    TileWin w = tile_window(P, mt0, Jtot, FAST);
-    if constexpr (FAST) { if (!(P.dbg & 4)) tile_issue<NLD>(P, b, w, tid, v); }
-
-    const bool prof = (P.dbg & 32) && tid == 0;
-    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tprev = prof ? __builtin_readcyclecounter() : 0;
-#define MF_STAMP(k) do { if (prof) { const unsigned long long tn_ = __builtin_readcyclecounter(); pc[k] += tn_ - tprev; tprev = tn_; } } while (0)
-    for (uint32_t t = t0; t < P.tiles; t += nchunks) {
+    TileWin w = tile_window(P, mt_first + (uint64_t)cix * T, Jtot, FAST);
+    if constexpr (FAST) tile_issue<NLD>(P, b, w, tid, v);
+    for (uint32_t t = cix; t < P.tiles; t += nchunks) {
         const uint64_t mt = mt_first + (uint64_t)t * T;
-        if (P.rot_enable) {   // coarse rotator table of this tile (previous tile's readers are past the last barrier)
+        uint32_t kb0 = 0;
+        if (P.rot_enable) {   // coarse rotator table of this tile
             const int64_t first_new = w.i_base > (int64_t)P.n0 ? w.i_base : (int64_t)P.n0;
             kb0 = (uint32_t)(((uint64_t)first_new - P.rot_nbase) >> 9);
             if (tid < P.nhi) t_hi[tid] = sincos_turn(P.rot_acc + ((uint64_t)(kb0 + tid) << 9) * P.rot_inc);
         }
         __syncthreads();
-        MF_STAMP(0);
         if constexpr (FAST) tile_wait<NLD>(v);
-        if (!(P.dbg & 2)) tile_commit<NLD, FAST>(P, b, w, tid, v, tile, Jtot, dump, t_hi, kb0, t_lo);
-        MF_STAMP(1);
+        tile_commit<NLD, FAST>(P, b, w, tid, v, tile, Jtot, dump, t_hi, kb0, t_lo);
         __syncthreads();
-        MF_STAMP(2);
-        if (t + nchunks < P.tiles) {   // next tile's loads fly during the MFMA phase
+        if (t + nchunks < P.tiles) {
             w = tile_window(P, mt + (uint64_t)nchunks * T, Jtot, FAST);
-            if constexpr (FAST) { if (!(P.dbg & 4)) tile_issue<NLD>(P, b, w, tid, v); }
+            if constexpr (FAST) tile_issue<NLD>(P, b, w, tid, v);
         }
-
-        MF_STAMP(3);
-        // ---- FIR on the matrix pipe: wave g = quarter g of the u axis ----
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        int s = g * Sq;
-        const int s_end = (P.dbg & 1) ? s : s + Sq;
-        const int seg_len = 4 * D;   // steps between two pad jumps of the B operand
-        if constexpr (NA == 16) {
-            const int acol = lane & 15;
-            const float2* bp = tile + ((P.dbg & 8) ? 0 : acol * Pp) + kk;
-            const float* ap = hp + (((P.dbg & 16) ? 0 : acol * D) + 4 * S - kk);     // tap k = b D - u, stored at k + (4 S - nt + 1)
-            while (s < s_end) {
-                const int seg = (int)__umulhi((uint32_t)s, magic_seg);
-                const int e = min(s_end, (seg + 1) * seg_len);
-                mfma_piece<float2, 4>(ap - 4 * s, bp + 4 * s + 2 * seg, e - s, acc0, acc1);
-                s = e;
-            }
-            MF_STAMP(4);
-            __syncthreads();   // every wave is done reading the tile: its head becomes the partial-sum area
-            MF_STAMP(5);
-            float2* pp = part + g * T + 16 * acol + 4 * kk;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pp[r] = make_float2(acc0[r], acc1[r]);
-        } else {
-            const int n = lane & 15, acol = n >> 1, c = n & 1;
-            const float* bp = reinterpret_cast<const float*>(tile) + 2 * (acol * Pp + kk) + c;
-            const int brow = lane & 15;
-            const float* ap = hp + (brow * D + 4 * S - kk);
-            while (s < s_end) {
-                const int seg = (int)__umulhi((uint32_t)s, magic_seg);
-                const int e = min(s_end, (seg + 1) * seg_len);
-                mfma_piece<float, 8>(ap - 4 * s, bp + 2 * (4 * s + 2 * seg), e - s, acc0, acc1);
-                s = e;
-            }
-            __syncthreads();
-            float* pf = reinterpret_cast<float*>(part + g * T + 16 * acol + 4 * kk) + c;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pf[2 * r] = acc0[r];
-        }
+        mfma_quarter<NA, ALIAS>(tile, hp, part, g, lane, D, S, P.magic_seg);
         __syncthreads();
         if (tid < T) {
             const uint64_t m = mt + tid;
@@ -324,12 +447,125 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = y;
             }
         }
-        __syncthreads();   // partial sums consumed before the next tile overwrites them
-        MF_STAMP(6);
+    }
+}
+
+// ---- two-team variant: ONE workgroup of 8 waves per CU, two tile buffers.  In every phase one team
+// (4 waves = the 4 quarters) runs the MFMA loop of its tile while the other team combines its previous
+// tile, commits its next tile into its own buffer and issues the loads of the one after: the VALU/LDS
+// staging work of one team is deterministically overlapped with the matrix-pipe work of the other
+// (two independent workgroups per CU drift into phase and serialise instead).  One s_barrier per phase.
+template <int NA, int NLD>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_decim_mfma2(const DecimParams P_)
+{
+    const DecimParams& P = P_;
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int T = 16 * NA;
+    const int D = P.D, S = P.S;
+    const int blk = 16 * D;
+    const int Jtot = (NA - 1) * blk + 4 * S;
+    const int hpn = (15 * D + 4 * S + 4 + 3) & ~3;
+    const int nhi = (P.nhi + 1) & ~1;
+    const int dump = Jtot + 2 * (Jtot / blk) + 4;
+    const int tile_len = (dump + 512 + 1) & ~1;
+    float2* t_lo = reinterpret_cast<float2*>(smem);            // 512
+    float2* t_hi_all = t_lo + 512;                             // [team][buf][nhi]
+    float* hp = reinterpret_cast<float*>(t_hi_all + 4 * nhi);  // hpn floats
+    float2* part_all = reinterpret_cast<float2*>(hp + hpn);    // [team][4 T]
+    float2* tile_all = part_all + 2 * 4 * T;                   // [team][tile_len]
+
+    const int b = blockIdx.y;
+    const uint32_t per = gridDim.x >> 3;
+    const uint32_t cix = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    const uint32_t nchunks = P.nchunks;
+    if (cix >= nchunks || cix >= P.tiles) return;
+    const int tid = threadIdx.x;
+    const int team = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int ttid = tid & 255;
+    const int g = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+    const int lane = tid & 63;
+    const uint64_t mt_first = (P.m0 / T) * (uint64_t)T;
+    const int K = (int)((P.tiles - cix + nchunks - 1) / nchunks);   // tiles of this workgroup: t(k) = cix + k nchunks
+    float2* tile = tile_all + (size_t)team * tile_len;
+    float2* part = part_all + (size_t)team * 4 * T;
+    float2* t_hi0 = t_hi_all + (size_t)team * 2 * nhi;
+
+    for (int k = tid; k < hpn; k += 512) hp[k] = P.gtab[k];
+    if (P.rot_enable) t_lo[tid] = P.rot_lo[tid];
+
+    f32x4 v[NLD];
+    TileWin w;
+    uint32_t kb0 = 0;
+    auto tile_mt = [&](int k) { return mt_first + ((uint64_t)cix + (uint64_t)k * nchunks) * T; };
+    // coarse rotator table of tile k into buffer (k >> 1) & 1 of this team; returns its kb0
+    auto make_thi = [&](int k) -> uint32_t {
+        const int64_t ib = (int64_t)tile_mt(k) * D - (P.nt - 1);
+        const int64_t first_new = ib > (int64_t)P.n0 ? ib : (int64_t)P.n0;
+        const uint32_t kb = (uint32_t)(((uint64_t)first_new - P.rot_nbase) >> 9);
+        if (P.rot_enable && ttid < P.nhi)
+            t_hi0[((k >> 1) & 1) * nhi + ttid] = sincos_turn(P.rot_acc + ((uint64_t)(kb + ttid) << 9) * P.rot_inc);
+        return kb;
+    };
+    // stage role: (combine of tile kc done by the caller) -> wait + commit tile k -> issue loads of tile k + 2 -> table of k + 2
+    const bool prof = (P.dbg & 32) && ttid == 0;
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+#define MF2_T0() do { if (prof) tprev = __builtin_readcyclecounter(); } while (0)
+#define MF2_STAMP(k) do { if (prof) { const unsigned long long tn_ = __builtin_readcyclecounter(); pc[k] += tn_ - tprev; tprev = tn_; } } while (0)
+    auto stage = [&](int k) {
+        MF2_T0();
+        tile_wait<NLD>(v);
+        MF2_STAMP(0);
+        tile_commit<NLD, true>(P, b, w, ttid, v, tile, Jtot, dump, t_hi0 + ((k >> 1) & 1) * nhi, kb0, t_lo);
+        MF2_STAMP(1);
+        if (k + 2 < K) {
+            w = tile_window(P, tile_mt(k + 2), Jtot, true);
+            tile_issue<NLD>(P, b, w, ttid, v);
+            kb0 = make_thi(k + 2);
+        }
+        MF2_STAMP(2);
+    };
+    auto combine = [&](int k) {
+        if (ttid < T) {
+            const uint64_t m = tile_mt(k) + ttid;
+            if (m >= P.m0 && m < P.m0 + P.m_count) {
+                const float2 r0 = part[ttid], r1 = part[T + ttid], r2 = part[2 * T + ttid], r3 = part[3 * T + ttid];
+                float2 y;
+                y.x = (r0.x + r1.x) + (r2.x + r3.x);
+                y.y = (r0.y + r1.y) + (r2.y + r3.y);
+                P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = y;
+            }
+        }
+    };
+
+    // start-up: each team issues the loads and the table of its first tile (k = team)
+    if (team < K) {
+        w = tile_window(P, tile_mt(team), Jtot, true);
+        tile_issue<NLD>(P, b, w, ttid, v);
+        kb0 = make_thi(team);
+    }
+    __syncthreads();
+    if (team == 0) stage(0);
+    __syncthreads();
+    // phase p: team (p & 1) runs the matrix pipe on tile p, the other team combines tile p - 1 and stages tile p + 1
+    for (int p = 0; p <= K; ++p) {
+        if ((p & 1) == team) {
+            MF2_T0();
+            if (p < K) mfma_quarter<NA, false>(tile, hp, part, g, lane, D, S, P.magic_seg);
+            MF2_STAMP(3);
+        } else {
+            MF2_T0();
+            if (p >= 1) combine(p - 1);
+            MF2_STAMP(4);
+            if (p + 1 < K) stage(p + 1);
+        }
+        MF2_T0();
+        __syncthreads();
+        MF2_STAMP(5 + ((p & 1) == team ? 0 : 1));
     }
     if (prof) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(&g_mf_prof[k], pc[k]);
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_mf_prof[k], pc[k]);
         atomicAdd(&g_mf_prof[7], 1ull);
     }
 }
@@ -353,7 +589,7 @@ static size_t mfma_lds(int nt, int D, int NA, int tpw)
 {
     const long long Jtot = mfma_jtot(nt, D, NA);
     const long long npos = Jtot + 2 * (Jtot / (16LL * D)) + 4 + 512;   // + dump slots
-    return (size_t)(512 + mfma_nhi(nt, D, NA, tpw) + npos) * sizeof(float2) + (size_t)decim_mfma_hpn(nt, D) * sizeof(float);
+    return (size_t)(512 + ((mfma_nhi(nt, D, NA, tpw) + 1) & ~1) + npos) * sizeof(float2) + (size_t)decim_mfma_hpn(nt, D) * sizeof(float);
 }
 // rule shared with oracle/orc_blocks.c orc_decim_uses_m16
 bool decim_uses_mfma(int nt, int D)
@@ -363,6 +599,8 @@ bool decim_uses_mfma(int nt, int D)
     return (samples + 2 * (samples / (16LL * D)) + 64) * 8 <= 150 * 1024;
 }
 constexpr int kTpwMax = 16;
+static size_t mfma2_lds(int nt, int D, int NA);
+// 16 output blocks per tile when two workgroups of that size fit the 160 KB of a CU, else 8
 int decim_mfma_na(int nt, int D) { return mfma_lds(nt, D, 16, kTpwMax) <= 80 * 1024 ? 16 : 8; }
 size_t decim_mfma_lds_bytes(int nt, int D) { return mfma_lds(nt, D, decim_mfma_na(nt, D), kTpwMax); }
 
@@ -371,14 +609,46 @@ static void launch_k(const DecimParams& q, dim3 grid, size_t lds, hipStream_t s)
 {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_decim_mfma<NA, NLD, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_decim_mfma<NA, NLD, FAST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_decim_mfma<NA, NLD, FAST, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((k_decim_mfma<NA, NLD, FAST>), grid, dim3(256), lds, s, q);
+    const char* na = std::getenv("QRL_DECIM_NOALIAS");
+    if (na && na[0] == '1') hipLaunchKernelGGL((k_decim_mfma<NA, NLD, FAST, false>), grid, dim3(256), lds + 4 * 16 * NA * sizeof(float2), s, q);
+    else {
+        const char* pad = std::getenv("QRL_DECIM_PADLDS");   // debugging aid: extra LDS to force one workgroup per CU
+        hipLaunchKernelGGL((k_decim_mfma<NA, NLD, FAST, true>), grid, dim3(256), lds + (pad ? std::atoi(pad) : 0), s, q);
+    }
+}
+static size_t mfma2_lds(int nt, int D, int NA)
+{
+    const long long Jtot = mfma_jtot(nt, D, NA);
+    const long long dump = Jtot + 2 * (Jtot / (16LL * D)) + 4;
+    const long long tile_len = (dump + 512 + 1) & ~1LL;
+    const long long nhi = (mfma_nhi(nt, D, NA, 1) + 1) & ~1;
+    return (size_t)(512 + 4 * nhi + 2 * 4 * 16 * NA + 2 * tile_len) * sizeof(float2) + (size_t)decim_mfma_hpn(nt, D) * sizeof(float);
+}
+template <int NA, int NLD>
+static void launch_k2(const DecimParams& q, dim3 grid, size_t lds, hipStream_t s)
+{
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_decim_mfma2<NA, NLD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_decim_mfma2<NA, NLD>), grid, dim3(512), lds, s, q);
 }
 template <int NA, int NLD>
 static void launch_one(const DecimParams& q, dim3 grid, size_t lds, hipStream_t s)
 {
+    // two-team kernel: caller's buffer, even-aligned fast path, two tiles fit in LDS
+    // (experimental, slower on both bench workloads: VALU staging and f32 MFMA share the SIMD's ALUs, so the
+    //  overlap it enforces buys nothing; kept for A/B runs) QRL_DECIM_TWO_TEAM=1
+    const char* two = std::getenv("QRL_DECIM_TWO_TEAM");
+    if (two && two[0] == '1' && q.in && q.n >= 2 && NLD <= 16 && mfma2_lds(q.nt, q.D, NA) <= 160 * 1024) {
+        launch_k2<NA, (NLD <= 16 ? NLD : 16)>(q, grid, mfma2_lds(q.nt, q.D, NA), s);
+        return;
+    }
     // FAST: the tile comes from the caller's buffer through register-prefetched 16-byte loads
     if (q.in && q.n >= 2) launch_k<NA, NLD, true>(q, grid, lds, s);
     else launch_k<NA, 1, false>(q, grid, lds, s);
@@ -402,7 +672,8 @@ void launch_decim_mfma(const DecimParams& p, int batch, hipStream_t s)
     const uint32_t chunks = (tiles + tpw - 1) / tpw;
     q.nchunks = chunks;
     { const char* e = std::getenv("QRL_DBG"); q.dbg = e ? std::atoi(e) : 0; }
-    dim3 grid((chunks + 7) / 8 * 8, batch);
+    // never pad a short grid.x to 8: the padding blocks would leave whole XCDs idle
+    dim3 grid(chunks >= 64 ? (chunks + 7) / 8 * 8 : chunks, batch);
     const size_t lds = mfma_lds(p.nt, p.D, NA, tpw);
     const long long pairs = (mfma_jtot(p.nt, p.D, NA) + 2) / 2;
     const int nld = (int)((pairs + 255) / 256);

@@ -78,6 +78,29 @@ def test_chunk_invariance_2fsk(qrl_ctx, chunk):
     _compare(iq, out, "2fsk1k", 1000000, 1200.0)
 
 
+def test_front_end_repeatable_under_load(qrl_ctx):
+    """Race hunt: the 25 Msps front end runs two workgroups per CU; repeat the same batch and require
+    bit-identical port 0 every time (an earlier hand-scheduled LDS pipeline failed this ~1e-4 per tile)."""
+    import torch
+    import qradiolink_amd as q
+    rate, offset, B = 25000000, 25000.0, 6
+    iq = sig.make_batch("gmsk10k", B, nframes=2, device_rate=rate, rx_offset_hz=offset, seed=3)
+    d = torch.from_numpy(iq).cuda()
+    ref = None
+    for rep in range(6):
+        dem = q.Demod(qrl_ctx, q.MODEM_GMSK10K, batch=B, max_chunk=1 << 23, device_samp_rate=rate, carrier_offset_hz=offset)
+        out = q.collect(dem, d, 1 << 23)
+        dem.close()
+        got = [x.view(np.uint32).copy() for x in out["filtered"]]
+        if ref is None:
+            ref = got
+            want = orc.demod_gmsk(orc.frontend(iq[0], rate, offset), sps=1, filter_width=20000)["filtered"].view(np.uint32)
+            assert np.array_equal(got[0], want)
+        else:
+            for b in range(B):
+                assert np.array_equal(got[b], ref[b]), "run %d stream %d differs from run 0" % (rep, b)
+
+
 def test_loopback_frames_recovered(qrl_ctx):
     """mod -> channel -> HIP demod returns the transmitted frames through gr_modem-style sync search."""
     import torch

@@ -20,6 +20,8 @@ lib.qrl_debug_decim_prof(out)
 v = list(out)
 n = max(v[7], 1)
 names = ["t_hi+barrier", "commit", "barrier", "issue loads", "mfma loop", "barrier", "epilogue"]
+if os.environ.get("QRL_DECIM_ONE_TEAM") != "1":
+    names = ["stage: wait loads", "stage: commit", "stage: issue+table", "mfma role", "combine", "barrier after mfma", "barrier after stage"]
 tot = sum(v[:7])
 print("workgroups", v[7], "ticks/WG", tot / n)
 for k in range(7):
