@@ -95,6 +95,8 @@ int qrl_demod_set_carrier_offset(qrl_demod* d, double carrier_offset_hz);
 int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* filtered_cap, size_t* constellation_cap, size_t* bits_cap);
 
 /* replaces: one scheduler pass of the "demodulator" top_block over n new samples per stream:
+ * (the serial tail of a call runs on an internal second HIP stream and overlaps the next call; only
+ * qrl_demod_sync() -- not a sync of the handle's own stream -- guarantees the outputs are complete)
  * gr::sync_block::work()/general_work() of every block on the chain (SURVEY.md 8b block ABI).
  * iq: device pointer, stream b at iq + 2*b*stride floats, n <= max_chunk samples each, base and
  * stride*8 bytes 16-byte aligned.  Asynchronous on the handle's stream; results are valid after

@@ -111,6 +111,11 @@ struct qrl_demod {
     qrl_demod_config cfg{};
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // the serial tail (symbol sync + Viterbi: a handful of waves) runs on its own stream so that it overlaps the
+    // HBM-facing kernels of the NEXT call instead of idling 250 CUs
+    hipStream_t tail = nullptr;
+    hipEvent_t ev_ff = nullptr, ev_tail = nullptr;
+    bool tail_pending = false;
     enum Family { F_2FSK, F_GMSK } fam = F_2FSK;
     int branches = 2;
 
@@ -146,6 +151,9 @@ struct qrl_demod {
 
     ~qrl_demod() {
         for (auto& e : prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        if (ev_ff) (void)hipEventDestroy(ev_ff);
+        if (ev_tail) (void)hipEventDestroy(ev_tail);
+        if (tail) (void)hipStreamDestroy(tail);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 
@@ -378,8 +386,12 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         launch_disc_2fsk(d, B, stream);
     }
     {
+        // r3 is what the previous call's tail (other stream) may still be reading
+        if (tail_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_tail, 0)); tail_pending = false; }
         FirFffParams f{}; f.in = r2d; f.out = r3; f.q0 = n2_0; f.count = c2; f.taps = symf_taps.p; f.nt = symf_nt;
         launch_fir_fff(f, B, stream);
+        HIPCHK(hipEventRecord(ev_ff, stream));
+        HIPCHK(hipStreamWaitEvent(tail, ev_ff, 0));
     }
     // ---- stage D: symbol sync + FEC
     {
@@ -390,12 +402,14 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         s.port = side && out->constellation ? reinterpret_cast<float2*>(out->constellation) : nullptr;
         s.port_cap = side ? out->constellation_cap : 0;
         s.counts = counts;
-        launch_symsync_ff(s, B, stream);
+        launch_symsync_ff(s, B, tail);
         FecParams f{};
         f.soft = RingB{soft.p, soft_mask}; f.sym = ss_st.p; f.st = fec_st.p;
         f.bits_a = out ? out->bits_a : nullptr; f.bits_b = out ? out->bits_b : nullptr; f.bits_cap = out ? out->bits_cap : 0;
         f.counts = counts; f.branches = branches;
-        launch_fec(f, B, stream);
+        launch_fec(f, B, tail);
+        HIPCHK(hipEventRecord(ev_tail, tail));
+        tail_pending = true;
     }
     HIPCHK(hipGetLastError());
     n_in = n_in1; n1 = n1_1; n2 = n2_1;
@@ -473,23 +487,28 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
     HIPCHK(hipSetDevice(ctx->device));
     if (c.hip_stream) d->stream = static_cast<hipStream_t>(c.hip_stream);
     else { HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)); d->own_stream = true; }
+    HIPCHK(hipStreamCreateWithFlags(&d->tail, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&d->ev_ff, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&d->ev_tail, hipEventDisableTiming));
     int r = d->build();
     if (r) return r;
     *outp = d.release();
     return QRL_OK;
 }
-void qrl_demod_destroy(qrl_demod* d) { if (d) { (void)hipStreamSynchronize(d->stream); delete d; } }
+void qrl_demod_destroy(qrl_demod* d) { if (d) { (void)hipStreamSynchronize(d->stream); (void)hipStreamSynchronize(d->tail); delete d; } }
 
 int qrl_demod_reset(qrl_demod* d)
 {
     if (!d) return QRL_ERR_ARG;
     HIPCHK(hipStreamSynchronize(d->stream));
+    HIPCHK(hipStreamSynchronize(d->tail));
     return d->init_state();
 }
 int qrl_demod_set_carrier_offset(qrl_demod* d, double hz)
 {
     if (!d) return QRL_ERR_ARG;
     HIPCHK(hipStreamSynchronize(d->stream));
+    HIPCHK(hipStreamSynchronize(d->tail));
     d->rot_acc += (d->n_in - d->rot_nbase) * d->rot_inc;  // phase-continuous
     d->rot_nbase = d->n_in;
     d->cfg.carrier_offset_hz = hz;
@@ -517,6 +536,7 @@ int qrl_demod_sync(qrl_demod* d)
 {
     if (!d) return QRL_ERR_ARG;
     HIPCHK(hipStreamSynchronize(d->stream));
+    HIPCHK(hipStreamSynchronize(d->tail));
     return QRL_OK;
 }
 void* qrl_demod_stream(qrl_demod* d) { return d ? d->stream : nullptr; }
@@ -531,6 +551,7 @@ int qrl_demod_profile_read(qrl_demod* d, double* kernel_ms, uint64_t* launches, 
 {
     if (!d) return QRL_ERR_ARG;
     HIPCHK(hipStreamSynchronize(d->stream));
+    HIPCHK(hipStreamSynchronize(d->tail));
     double total = 0;
     for (auto& e : d->prof_events) {
         float ms = 0;
@@ -565,6 +586,7 @@ int qrl_demod_process_host(qrl_demod* d, const float* iq_host, size_t stride, si
     o.bits_a = ba.p; o.bits_b = bb.p; o.bits_cap = bits_cap; o.counts = cnt.p;
     if ((r = d->process(reinterpret_cast<const float*>(iq.p), st, n, &o))) return r;
     HIPCHK(hipStreamSynchronize(d->stream));
+    HIPCHK(hipStreamSynchronize(d->tail));
     if (bits_a_host) HIPCHK(hipMemcpy(bits_a_host, ba.p, B * bits_cap, hipMemcpyDeviceToHost));
     if (bits_b_host) HIPCHK(hipMemcpy(bits_b_host, bb.p, B * bits_cap, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(counts_host, cnt.p, B * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -116,10 +116,18 @@ void launch_fll(const FllParams& p, int batch, hipStream_t s)
 }
 
 // ------------------------------------------------------------------ symbol_sync_ff
-constexpr int SS_WIN = 184;          // new samples per window
-constexpr int SS_LEN = SS_WIN + 8;   // + interpolator span
-constexpr int SS_PITCH = SS_LEN + 1; // odd
-constexpr int SS_OPITCH = 65;        // symbols produced per stream per window < 64 (sps >= 3.9)
+// One workgroup = 64 streams.  Wave 0 runs the recursion, one lane per stream, out of an LDS window; waves
+// 1-3 meanwhile fetch the NEXT window of all 64 streams (coalesced along the stream) and flush the symbols of
+// the PREVIOUS window, so the serial wave never waits on L2/HBM latency (that wait was > 50 % of the old
+// single-wave kernel).  Windows sit on an absolute grid: window k holds samples [k W - SS_BACK, (k+1) W + 8)
+// of every stream; a lane works while its 8-tap interpolator fits, then all lanes move on together (cursors of
+// different streams never drift apart by more than a symbol inside a call: every lane consumes all samples).
+constexpr int SS_W = 192;                    // new samples per window
+constexpr int SS_BACK = 16;                  // samples kept in front of the grid point
+constexpr int SS_COLS = SS_BACK + SS_W + 8;  // 216
+constexpr int SS_PITCH = SS_COLS + 1;        // odd pitch: lanes walk down columns conflict-free
+constexpr int SS_OMAX = 56;                  // symbols per stream per window: <= (W + 5) / 3.9 + 1 for sps >= 3.9
+constexpr int SS_OPITCH = SS_OMAX + 1;
 
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 {
@@ -131,63 +139,109 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
     return v;
 }
 
-__global__ __launch_bounds__(64) void k_symsync_ff(const SymSyncParams P, int batch)
+__global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int batch)
 {
-    __shared__ float win[64 * SS_PITCH];
-    __shared__ float mm[129 * 9];
-    __shared__ float osym[64 * SS_OPITCH];
-    __shared__ int ocnt[64];
-    __shared__ uint64_t obase[64], oo0[64];
-    const int lane = threadIdx.x;
+    extern __shared__ __align__(16) unsigned char ss_smem[];
+    float* win = reinterpret_cast<float*>(ss_smem);              // [2][64][SS_PITCH]
+    float* mm = win + 2 * 64 * SS_PITCH;                         // [129][8]
+    float* osym = mm + 129 * 8;                                  // [2][64][SS_OPITCH]
+    int* ocnt = reinterpret_cast<int*>(osym + 2 * 64 * SS_OPITCH);       // [2][64]
+    uint64_t* obase = reinterpret_cast<uint64_t*>(ocnt + 2 * 64);        // [2][64]
+    uint64_t* oo0 = obase + 2 * 64;                                      // [64]
+    long long* kfl = reinterpret_cast<long long*>(oo0 + 64);             // [2]: first / last window
+
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6, lane = tid & 63;
     const int b0 = blockIdx.x * 64;
-    const int b = b0 + lane;
-    const bool active = b < batch;
-    for (int k = lane; k < 129 * 8; k += 64) mm[(k >> 3) * 9 + (k & 7)] = P.mmse[k];
-    SymSyncState st;
-    if (active) st = P.st[b];
-    else { st.ii = ~0ull >> 1; st.oo = 0; st.mu = 0; st.avg = st.inst = 0; st.x0 = st.x1 = st.x2 = st.d0 = st.d1 = st.d2 = 0; }
-    const uint64_t oo_start = st.oo;
-    oo0[lane] = oo_start;
     const int nstreams = min(64, batch - b0);
-    const float* row = win + lane * SS_PITCH;
-    constexpr int KPS = SS_LEN / 64;
-    static_assert(SS_LEN % 64 == 0, "window must be a multiple of the wave size");
-    while (true) {
-        const bool can = active && (st.ii + 8 <= P.avail);
-        if (!__any(can)) break;
-        const uint64_t w0 = wave_min_u64(can ? st.ii : ~0ull);
-        const uint64_t wend = (w0 + SS_LEN < P.avail) ? (w0 + SS_LEN) : P.avail;  // exclusive
-        __syncthreads();
-        for (int s0 = 0; s0 < nstreams; s0 += 8) {   // 8 streams x KPS coalesced loads in flight
-            float v[8][KPS];
+    for (int k = tid; k < 129 * 8; k += 256) mm[k] = P.mmse[k];
+
+    SymSyncState st;
+    bool active = false;
+    if (wv == 0) {
+        active = b0 + lane < batch;
+        if (active) st = P.st[b0 + lane];
+        else { st.ii = ~0ull >> 1; st.oo = 0; st.mu = 0; st.avg = st.inst = 0; st.x0 = st.x1 = st.x2 = st.d0 = st.d1 = st.d2 = 0; }
+        oo0[lane] = st.oo;
+        const uint64_t lo = wave_min_u64(active ? st.ii : ~0ull);
+        if (lane == 0) {
+            // windows that can hold a symbol: ii + 8 <= avail
+            kfl[0] = (long long)(lo / SS_W);
+            kfl[1] = P.avail >= 8 ? (long long)((P.avail - 8) / SS_W) : -1;
+            if (lo + 8 > P.avail) kfl[1] = kfl[0] - 1;
+        }
+    }
+    __syncthreads();
+    const long long k_first = kfl[0], k_last = kfl[1];
+
+    // loader: window k of all streams -> win[k & 1]
+    auto load_window = [&](long long k, int t, int nthreads) {
+        float* wbuf = win + (size_t)(k & 1) * 64 * SS_PITCH;
+        const long long i0 = k * SS_W - SS_BACK;
+        constexpr int BATCH = 12;
+        const int total = nstreams * SS_COLS;
+        for (int base = t; base < total; base += nthreads * BATCH) {
+            float v[BATCH];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-#pragma unroll
-                for (int kk = 0; kk < KPS; ++kk) {
-                    const uint64_t i = w0 + lane + 64 * kk;
-                    v[u][kk] = 0.f;
-                    if (s0 + u < nstreams && i < P.avail)
-                        v[u][kk] = P.in.p[(size_t)(b0 + s0 + u) * (P.in.mask + 1u) + ((uint32_t)i & P.in.mask)];
+            for (int u = 0; u < BATCH; ++u) {
+                const int idx = base + u * nthreads;
+                v[u] = 0.f;
+                if (idx < total) {
+                    const int s = idx / SS_COLS, c = idx - s * SS_COLS;
+                    const long long i = i0 + c;
+                    if (i >= 0 && (uint64_t)i < P.avail)
+                        v[u] = P.in.p[(size_t)(b0 + s) * (P.in.mask + 1u) + ((uint32_t)i & P.in.mask)];
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-#pragma unroll
-                for (int kk = 0; kk < KPS; ++kk)
-                    if (s0 + u < nstreams) win[(s0 + u) * SS_PITCH + lane + 64 * kk] = v[u][kk];
+            for (int u = 0; u < BATCH; ++u) {
+                const int idx = base + u * nthreads;
+                if (idx < total) { const int s = idx / SS_COLS, c = idx - s * SS_COLS; wbuf[s * SS_PITCH + c] = v[u]; }
             }
         }
-        __syncthreads();
-        const uint64_t oo_w = st.oo;   // first symbol index of this window for this stream
-        int nsym = 0;
-        if (can) {
-            while (st.ii + 8 <= wend && nsym < 64) {
-                const int off = (int)(st.ii - w0);
+    };
+    // flusher: symbols of window k -> soft-symbol ring (multiply_const -> add_const -> float_to_uchar) and port 1
+    auto flush_window = [&](long long k, int t, int nthreads) {
+        const int pb = (int)(k & 1);
+        const float* ob = osym + (size_t)pb * 64 * SS_OPITCH;
+        for (int idx = t; idx < nstreams * SS_OMAX; idx += nthreads) {
+            const int s = idx / SS_OMAX, j = idx - s * SS_OMAX;
+            if (j < ocnt[pb * 64 + s]) {
+                const float y = ob[s * SS_OPITCH + j];
+                float q = y * P.soft_mul;
+                q = q + P.soft_add;
+                float r = rintf(q);
+                if (!(r >= 0.f)) r = 0.f;
+                if (r > 255.f) r = 255.f;
+                const uint64_t o = obase[pb * 64 + s] + j;
+                P.soft.p[(size_t)(b0 + s) * (P.soft.mask + 1u) + ((uint32_t)o & P.soft.mask)] = (uint8_t)r;
+                const uint64_t kk = o - oo0[s];
+                if (P.port && kk < P.port_cap) P.port[(size_t)(b0 + s) * P.port_cap + kk] = make_float2(y, 0.f);
+            }
+        }
+    };
+
+    if (k_first <= k_last) load_window(k_first, tid, 256);
+    __syncthreads();
+    for (long long k = k_first; k <= k_last; ++k) {
+        if (wv == 0) {
+            const int pb = (int)(k & 1);
+            const float* row = win + (size_t)pb * 64 * SS_PITCH + lane * SS_PITCH;
+            float* orow = osym + (size_t)pb * 64 * SS_OPITCH + lane * SS_OPITCH;
+            const long long i0 = k * SS_W - SS_BACK;
+            const uint64_t wend = min((uint64_t)((k + 1) * SS_W + 8), P.avail);   // exclusive
+            const uint64_t oo_w = st.oo;
+            int nsym = 0;
+            while (active && st.ii + 8 <= wend && nsym < SS_OMAX) {
+                const int off = (int)((long long)st.ii - i0);
                 const int imu = (int)rintf(st.mu * 128.0f);
-                const float* t = mm + imu * 9;
+                const float4 ta = *reinterpret_cast<const float4*>(mm + imu * 8);
+                const float4 tb = *reinterpret_cast<const float4*>(mm + imu * 8 + 4);
                 float y = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) y = fmaf(t[7 - k], row[off + k], y);
+                y = fmaf(tb.w, row[off + 0], y); y = fmaf(tb.z, row[off + 1], y);
+                y = fmaf(tb.y, row[off + 2], y); y = fmaf(tb.x, row[off + 3], y);
+                y = fmaf(ta.w, row[off + 4], y); y = fmaf(ta.z, row[off + 5], y);
+                y = fmaf(ta.y, row[off + 6], y); y = fmaf(ta.x, row[off + 7], y);
                 st.x2 = st.x1; st.x1 = st.x0; st.x0 = y;
                 st.d2 = st.d1; st.d1 = st.d0; st.d0 = (y > 0.f) ? 1.0f : -1.0f;
                 float e;
@@ -203,42 +257,40 @@ __global__ __launch_bounds__(64) void k_symsync_ff(const SymSyncParams P, int ba
                 const float ph = st.mu + st.inst;
                 const float fl = floorf(ph);
                 st.mu = ph - fl;
-                osym[lane * SS_OPITCH + nsym] = y;
+                orow[nsym] = y;
                 nsym++;
                 st.oo++;
                 st.ii += (uint64_t)(int)fl;
             }
+            ocnt[pb * 64 + lane] = nsym;
+            obase[pb * 64 + lane] = oo_w;
+        } else {
+            if (k + 1 <= k_last) load_window(k + 1, tid - 64, 192);
+            if (k > k_first) flush_window(k - 1, tid - 64, 192);
         }
-        ocnt[lane] = nsym;
-        obase[lane] = oo_w;
         __syncthreads();
-        // coalesced flush: soft symbols (multiply_const -> add_const -> float_to_uchar) and port 1
-        for (int s = 0; s < nstreams; ++s) {
-            const int cnt = ocnt[s];
-            if (lane < cnt) {
-                const float y = osym[s * SS_OPITCH + lane];
-                float v = y * P.soft_mul;
-                v = v + P.soft_add;
-                float r = rintf(v);
-                if (!(r >= 0.f)) r = 0.f;
-                if (r > 255.f) r = 255.f;
-                const uint64_t o = obase[s] + lane;
-                P.soft.p[(size_t)(b0 + s) * (P.soft.mask + 1u) + ((uint32_t)o & P.soft.mask)] = (uint8_t)r;
-                const uint64_t k = o - oo0[s];
-                if (P.port && k < P.port_cap) P.port[(size_t)(b0 + s) * P.port_cap + k] = make_float2(y, 0.f);
-            }
-        }
     }
-    if (active) {
-        P.st[b] = st;
-        P.counts[b * 4 + 1] = (uint32_t)(st.oo - oo_start);
+    if (k_first <= k_last) flush_window(k_last, tid, 256);
+    if (wv == 0 && active) {
+        P.st[b0 + lane] = st;
+        P.counts[(b0 + lane) * 4 + 1] = (uint32_t)(st.oo - oo0[lane]);
     }
+}
+
+size_t symsync_lds_bytes()
+{
+    return (size_t)(2 * 64 * SS_PITCH + 129 * 8 + 2 * 64 * SS_OPITCH) * sizeof(float) + 2 * 64 * sizeof(int) + (2 * 64 + 64 + 2) * sizeof(uint64_t);
 }
 
 void launch_symsync_ff(const SymSyncParams& p, int batch, hipStream_t s)
 {
-    dim3 grid((batch + 63) / 64), block(64);
-    hipLaunchKernelGGL(k_symsync_ff, grid, block, 0, s, p, batch);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_symsync_ff), hipFuncAttributeMaxDynamicSharedMemorySize, (int)symsync_lds_bytes());
+        attr = true;
+    }
+    dim3 grid((batch + 63) / 64), block(256);
+    hipLaunchKernelGGL(k_symsync_ff, grid, block, symsync_lds_bytes(), s, p, batch);
 }
 
 }  // namespace qrl
