@@ -116,7 +116,7 @@ struct qrl_demod {
     hipStream_t tail = nullptr;
     hipEvent_t ev_ff = nullptr, ev_tail = nullptr;
     bool tail_pending = false;
-    enum Family { F_2FSK, F_GMSK } fam = F_2FSK;
+    enum Family { F_2FSK, F_GMSK, F_QPSK } fam = F_2FSK;
     int branches = 2;
 
     // derived chain parameters (gr_demod_2fsk.cpp:39-63, gr_demod_gmsk.cpp:39-63)
@@ -144,6 +144,9 @@ struct qrl_demod {
     DevBuf<float2> s1, s2, s2l, s2f; DevBuf<float> s2d, s3; DevBuf<uint8_t> soft;
     uint32_t s1_mask = 0, s2_mask = 0, soft_mask = 0;
     DevBuf<FllState> fll_st; DevBuf<SymSyncState> ss_st; DevBuf<FecState> fec_st;
+    // QPSK (gr_demod_qpsk.cpp:97-126)
+    DevBuf<QpskState> qp_st; DevBuf<float> tanh_tab;
+    float c1_alpha = 0, c1_beta = 0, c2_alpha = 0, c2_beta = 0; float2 qp_rot{};
     DevBuf<uint32_t> counts_scratch;
     uint64_t n_in = 0, n1 = 0, n2 = 0;  // items so far: device rate, 1 Msps, target rate
     bool profiling = false;
@@ -175,6 +178,11 @@ int qrl_demod::init_state()
     for (auto* b : {&s2d, &s3}) if (b->p && (r = b->zero())) return r;
     if ((r = soft.zero())) return r;
     if (fll_st.p && (r = fll_st.zero())) return r;
+    if (fam == F_QPSK) {
+        std::vector<QpskState> qs(cfg.batch);
+        for (auto& q : qs) { std::memset(&q, 0, sizeof q); q.gain = 1.0f; q.avg = q.inst = (float)sps_eff; }
+        if (hipMemcpy(qp_st.p, qs.data(), qs.size() * sizeof(QpskState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
+    }
     std::vector<SymSyncState> ss(cfg.batch);
     for (auto& s : ss) { std::memset(&s, 0, sizeof s); s.avg = s.inst = (float)sps_eff; }
     if (hipMemcpy(ss_st.p, ss.data(), ss.size() * sizeof(SymSyncState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
@@ -195,11 +203,16 @@ int qrl_demod::build()
         else if (sps >= 5) { target = 40000; sps_eff = sps * 2; decim = 25; interp = 1; }
         else if (sps == 1) { target = 80000; sps_eff = 4;       decim = 25; interp = 2; }
         else return fail(QRL_ERR_ARG, "2fsk: unsupported sps");
-    } else {
+    } else if (fam == F_GMSK) {
         if (sps == 10)     { target = 20000; sps_eff = sps;     decim = 50; interp = 1; }
         else if (sps == 5) { target = 40000; sps_eff = sps * 2; decim = 25; interp = 1; }
         else if (sps == 1) { target = 80000; sps_eff = 4;       decim = 25; interp = 2; }
         else return fail(QRL_ERR_ARG, "gmsk: unsupported sps");
+    } else {
+        // gr_demod_qpsk.cpp:39-60: only the sps <= 4 geometry (QPSK250K: 1:2 decimation, no FLL) is built so far
+        if (sps > 4 || sps < 2) return fail(QRL_ERR_ARG, "qpsk: only sps 2..4 (e.g. QPSK250K) is supported by this build");
+        target = 500000; sps_eff = sps; decim = 2; interp = 1;
+        branches = 1;
     }
     fm = cfg.fm != 0;
     const int B = cfg.batch;
@@ -215,7 +228,9 @@ int qrl_demod::build()
     if ((r = upload_rot_table())) return r;
 
     // --- per-mode first resampler (gr_demod_2fsk.cpp:82-88, gr_demod_gmsk.cpp:80-83)
-    const std::vector<float> rtaps = low_pass(interp, (double)interp * samp_rate, target / 2, target / 2, WIN_BLACKMAN_HARRIS);
+    const std::vector<float> rtaps = fam == F_QPSK
+        ? low_pass_2(interp, (double)interp * samp_rate, target / 2, target / 10, 60, WIN_BLACKMAN_HARRIS)   // gr_demod_qpsk.cpp:92-96
+        : low_pass(interp, (double)interp * samp_rate, target / 2, target / 2, WIN_BLACKMAN_HARRIS);
     if (interp == 1) { if ((r = first.plan(rtaps, decim))) return fail(r, "resampler plan"); }
     else {
         rs_Jp = ((int)rtaps.size() + interp - 1) / interp;
@@ -242,12 +257,14 @@ int qrl_demod::build()
     if ((r = s2.alloc(ring2)) || (r = s2f.alloc(ring2)) || (r = s2d.alloc(ring2)) || (r = s3.alloc(ring2))) return r;
     if (fam == F_2FSK && (r = s2l.alloc(ring2))) return r;
     const size_t maxsym = max2 / (size_t)(sps_eff > 1 ? sps_eff - 1 : 1) + 8;
-    soft_mask = pow2_at_least(maxsym + 512) - 1;
+    soft_mask = pow2_at_least((fam == F_QPSK ? 2 : 1) * maxsym + 512) - 1;
     if ((r = soft.alloc((size_t)B * (soft_mask + 1)))) return r;
 
     // --- decimated-rate filters
     {
-        const std::vector<float> f = low_pass(1, target, fw, fw, WIN_BLACKMAN_HARRIS);
+        const std::vector<float> f = fam == F_QPSK
+            ? root_raised_cosine(sps_eff, sps_eff, 1, 0.35, 11 * sps_eff)      // _shaping_filter, gr_demod_qpsk.cpp:100-103
+            : low_pass(1, target, fw, fw, WIN_BLACKMAN_HARRIS);
         filt_nt = (int)f.size();
         if ((r = filt_taps.upload(f))) return r;
     }
@@ -279,6 +296,16 @@ int qrl_demod::build()
         const float dev = 200.0f / symbol_rate;
         clock_loop_gains((float)(2 * M_PI / (symbol_rate / 10)), 1.0f, 0.2869f, ss_alpha, ss_beta);
         ss_maxp = (float)sps_eff + dev; ss_minp = (float)sps_eff - dev;
+    } else if (fam == F_QPSK) {
+        if ((r = tanh_tab.upload(tanh_table())) || (r = qp_st.alloc(B))) return r;
+        control_loop_gains((float)(M_PI / 200 / sps_eff), c1_alpha, c1_beta);     // _costas_pll, gr_demod_qpsk.cpp:110
+        control_loop_gains((float)(M_PI / 400), c2_alpha, c2_beta);               // _costas_loop (sps <= 4), :112
+        const float symbol_rate = (float)target / (float)sps_eff;
+        const float dev = 200.0f / symbol_rate;
+        clock_loop_gains((float)(2 * M_PI / (symbol_rate / 10)), 1.0f, 0.2869f, ss_alpha, ss_beta);
+        ss_maxp = (float)sps_eff + dev; ss_minp = (float)sps_eff - dev;
+        const float ang = (float)(-3 * M_PI / 4);
+        qp_rot = make_float2((float)std::cos((double)ang), (float)std::sin((double)ang));
     } else {
         const std::vector<float> sf = low_pass(1, target, target / sps_eff, target / sps_eff, WIN_HAMMING);
         symf_nt = (int)sf.size();
@@ -378,14 +405,18 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         f.counts = counts;
         launch_fir_ccf(f, B, stream);
     }
-    if (fam == F_GMSK || fm) {
+    if (fam == F_QPSK) {
+        // recursive chain + Viterbi below; nothing else at the sample rate
+    } else if (fam == F_GMSK || fm) {
         QuadDemodParams q{}; q.in = r2f; q.out = r2d; q.q0 = n2_0; q.count = c2; q.gain = demod_gain; q.atan_tab = atan_tab.p;
         launch_quad_demod(q, B, stream);
     } else {
         Disc2fskParams d{}; d.in = r2f; d.out = r2d; d.q0 = n2_0; d.count = c2; d.up = disc_up.p; d.lo = disc_lo.p; d.nt = disc_nt;
         launch_disc_2fsk(d, B, stream);
     }
-    {
+    if (fam == F_QPSK) {
+        // the tail reads r2f (written by k_fir_ccf above): it runs on the handle's own stream for this family
+    } else {
         // r3 is what the previous call's tail (other stream) may still be reading
         if (tail_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_tail, 0)); tail_pending = false; }
         FirFffParams f{}; f.in = r2d; f.out = r3; f.q0 = n2_0; f.count = c2; f.taps = symf_taps.p; f.nt = symf_nt;
@@ -394,7 +425,25 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         HIPCHK(hipStreamWaitEvent(tail, ev_ff, 0));
     }
     // ---- stage D: symbol sync + FEC
-    {
+    if (fam == F_QPSK) {
+        QpskParams q{};
+        q.in = r2f; q.np0 = n2_0; q.avail = n2_1; q.soft = RingB{soft.p, soft_mask}; q.st = qp_st.p;
+        q.mmse = mmse_tab.p; q.tanh_tab = tanh_tab.p;
+        q.c1_alpha = c1_alpha; q.c1_beta = c1_beta; q.c2_alpha = c2_alpha; q.c2_beta = c2_beta;
+        q.ss_alpha = ss_alpha; q.ss_beta = ss_beta; q.ss_maxp = ss_maxp; q.ss_minp = ss_minp;
+        q.rot = qp_rot; q.soft_mul = 48.0f; q.soft_add = 128.0f;
+        q.port = side && out->constellation ? reinterpret_cast<float2*>(out->constellation) : nullptr;
+        q.port_cap = side ? out->constellation_cap : 0;
+        q.counts = counts;
+        launch_qpsk_loops(q, B, stream);
+        FecParams f{};
+        f.soft = RingB{soft.p, soft_mask};
+        f.avail = &qp_st.p[0].oo; f.avail_stride = sizeof(QpskState); f.avail_mul = 2;
+        f.st = fec_st.p;
+        f.bits_a = out ? out->bits_a : nullptr; f.bits_b = nullptr; f.bits_cap = out ? out->bits_cap : 0;
+        f.counts = counts; f.branches = 1;
+        launch_fec(f, B, stream);
+    } else {
         SymSyncParams s{};
         s.in = r3; s.avail = n2_1; s.soft = RingB{soft.p, soft_mask}; s.st = ss_st.p; s.mmse = mmse_tab.p;
         s.alpha = ss_alpha; s.beta = ss_beta; s.maxp = ss_maxp; s.minp = ss_minp;
@@ -404,7 +453,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         s.counts = counts;
         launch_symsync_ff(s, B, tail);
         FecParams f{};
-        f.soft = RingB{soft.p, soft_mask}; f.sym = ss_st.p; f.st = fec_st.p;
+        f.soft = RingB{soft.p, soft_mask}; f.avail = &ss_st.p[0].oo; f.avail_stride = sizeof(SymSyncState); f.avail_mul = 1; f.st = fec_st.p;
         f.bits_a = out ? out->bits_a : nullptr; f.bits_b = out ? out->bits_b : nullptr; f.bits_cap = out ? out->bits_cap : 0;
         f.counts = counts; f.branches = branches;
         launch_fec(f, B, tail);
@@ -471,6 +520,7 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         case QRL_MODEM_GMSK2K:    c.sps = 5;  c.filter_width = 4000;  c.fm = 0; break;
         case QRL_MODEM_GMSK1K:    c.sps = 10; c.filter_width = 2000;  c.fm = 0; break;
         case QRL_MODEM_GMSK10K:   c.sps = 1;  c.filter_width = 20000; c.fm = 0; break;
+        case QRL_MODEM_QPSK250K:  c.sps = 2;  c.filter_width = 160000; c.fm = 0; break;   // gr_demod_base.cpp:223
         default: return fail(QRL_ERR_ARG, "modem_type not supported by this build");
         }
     }
@@ -479,6 +529,8 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         d->fam = qrl_demod::F_2FSK; break;
     case QRL_MODEM_GMSK2K: case QRL_MODEM_GMSK1K: case QRL_MODEM_GMSK10K:
         d->fam = qrl_demod::F_GMSK; break;
+    case QRL_MODEM_QPSK250K:
+        d->fam = qrl_demod::F_QPSK; break;
     default: return fail(QRL_ERR_ARG, "modem_type not supported by this build");
     }
     if (c.samp_rate != 1000000) return fail(QRL_ERR_ARG, "internal samp_rate must be 1000000 (gr_demod_base.cpp:21)");
@@ -523,7 +575,7 @@ int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* fcap, size_t* ccap,
     const size_t ns = n2 / (size_t)(d->sps_eff > 1 ? d->sps_eff - 1 : 1) + 8;
     if (fcap) *fcap = n2;
     if (ccap) *ccap = ns;
-    if (bcap) *bcap = (ns / 2 / 80 + 2) * 80;
+    if (bcap) *bcap = d->fam == qrl_demod::F_QPSK ? (ns / 80 + 2) * 80 : (ns / 2 / 80 + 2) * 80;
     return QRL_OK;
 }
 int qrl_demod_process(qrl_demod* d, const float* iq, size_t stride, size_t n, const qrl_demod_out* out)

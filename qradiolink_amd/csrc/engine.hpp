@@ -89,10 +89,32 @@ struct SymSyncParams {
 };
 void launch_symsync_ff(const SymSyncParams& p, int batch, hipStream_t s);
 
+// ---- QPSK recursive chain (agc2 -> costas -> symbol_sync_cc -> costas -> diff_phasor -> rotate), one lane per stream ----
+struct QpskState {
+    uint64_t ii, oo;                 // symbol-sync read cursor (absolute sample), symbols produced
+    float gain;                      // agc2
+    float c1_phase, c1_freq;         // first Costas loop (sample rate)
+    float mu, avg, inst;             // clock tracking loop
+    float2 x0, x1, x2, d0, d1, d2;   // TED history
+    float c2_phase, c2_freq;         // second Costas loop (symbol rate)
+    float2 dprev;                    // diff_phasor
+    float2 hist[16];                 // last 16 outputs of the first Costas loop
+};
+struct QpskParams {
+    RingC in; uint64_t np0, avail;   // RRC-filtered input ring; samples processed before this call / available now
+    RingB soft; QpskState* st;
+    const float* mmse; const float* tanh_tab;
+    float c1_alpha, c1_beta, c2_alpha, c2_beta;
+    float ss_alpha, ss_beta, ss_maxp, ss_minp;
+    float2 rot; float soft_mul, soft_add;
+    float2* port; size_t port_cap; uint32_t* counts;   // constellation port (this call), counts[b*4+1]
+};
+void launch_qpsk_loops(const QpskParams& p, int batch, hipStream_t s);
+
 // ---- FEC tail: K=7 r=1/2 Viterbi (spiral-kernel semantics) + descrambler ----
 struct FecState { uint64_t consumed; uint32_t start_state; uint32_t last_bits; };
 struct FecParams {
-    RingB soft; const SymSyncState* sym;   // available soft symbols = sym[b].oo
+    RingB soft; const uint64_t* avail; size_t avail_stride; uint32_t avail_mul;   // available soft symbols of stream b = *(avail + b*stride bytes) * mul
     FecState* st;                          // [batch][2]
     uint8_t* bits_a; uint8_t* bits_b; size_t bits_cap; uint32_t* counts;  // counts[b*4+2], [b*4+3]
     int branches;

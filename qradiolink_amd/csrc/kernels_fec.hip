@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64) void k_fec(const FecParams P)
     __shared__ uint8_t dbits[96];
     const int b = blockIdx.x, br = blockIdx.y, lane = threadIdx.x;
     FecState st = P.st[b * 2 + br];
-    const uint64_t avail = P.sym[b].oo + (uint64_t)br;
+    const uint64_t avail = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(P.avail) + (size_t)b * P.avail_stride) * P.avail_mul + (uint64_t)br;
     const uint8_t* soft = P.soft.p + (size_t)b * (P.soft.mask + 1u);
     uint8_t* out = (br ? P.bits_b : P.bits_a);
     if (out) out += (size_t)b * P.bits_cap;

@@ -1,0 +1,249 @@
+// kernels_qpsk.hip — the recursive part of gr_demod_qpsk (reference src/gr/gr_demod_qpsk.cpp:97-123,141-154)
+// fused into ONE kernel, one lane per stream:
+//   agc2_cc(1, 0.1, 1, 1)  ->  costas_loop_cc(pi/200/sps, 4, use_snr)  ->  symbol_sync_cc(MOD_M&M, sps, ...,
+//   constellation_dqpsk, MMSE 8 tap)  ->  costas_loop_cc(pi/400, 4, use_snr)  ->  diff_phasor_cc  ->
+//   multiply_const_cc(e^{-j 3 pi / 4})  -> port 1 (constellation) and the interleaved soft symbols
+//   (complex_to_float, interleave, x48, +128, float_to_uchar) that feed the single K=7 Viterbi (k_fec).
+// The blocks are causal per sample, so chaining them inside one serial loop is exact.  Workgroup = 64
+// streams: wave 0 runs the recursion out of an LDS window, waves 1-3 prefetch the next window of the
+// RRC-filtered input (coalesced along the stream) and flush the previous window's symbols.  Window k holds
+// samples [k W - 16, (k+1) W): the first 16 columns are Costas OUTPUTS carried over from the window before
+// (symbol sync looks back at most 13 samples), the rest arrives raw and is overwritten in place by pass 1
+// (AGC + Costas), then pass 2 (symbol sync and everything at the symbol rate) walks the row.
+#include "devmath.hpp"
+#include "engine.hpp"
+
+namespace qrl {
+
+constexpr int QP_W = 64;
+constexpr int QP_BACK = 16;
+constexpr int QP_COLS = QP_BACK + QP_W;      // 80
+constexpr int QP_PITCH = QP_COLS + 1;        // float2 units, odd
+constexpr int QP_OMAX = 38;                  // symbols per stream per window (sps >= 1.9)
+constexpr int QP_OPITCH = QP_OMAX + 1;
+
+__device__ __forceinline__ float costas4_snr_error(float2 o, const float* __restrict__ T)
+{
+    const float snr = (o.x * o.x + o.y * o.y);
+    return (tanhf_lut(snr * o.x, T) * o.y) - (tanhf_lut(snr * o.y, T) * o.x);
+}
+
+__global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batch)
+{
+    extern __shared__ __align__(16) unsigned char qp_smem[];
+    float2* win = reinterpret_cast<float2*>(qp_smem);                    // [2][64][QP_PITCH]
+    float2* osym = win + 2 * 64 * QP_PITCH;                              // [2][64][QP_OPITCH]
+    float* mm = reinterpret_cast<float*>(osym + 2 * 64 * QP_OPITCH);     // [129][8]
+    float* th = mm + 129 * 8;                                            // [256]
+    int* ocnt = reinterpret_cast<int*>(th + 256);                        // [2][64]
+    uint64_t* obase = reinterpret_cast<uint64_t*>(ocnt + 2 * 64);        // [2][64]
+    uint64_t* oo0 = obase + 2 * 64;                                      // [64]
+
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int b0 = blockIdx.x * 64;
+    const int nstreams = min(64, batch - b0);
+    for (int k = tid; k < 129 * 8; k += 256) mm[k] = P.mmse[k];
+    th[tid] = P.tanh_tab[tid];
+
+    const uint64_t np0 = P.np0, avail = P.avail;      // samples already through AGC + Costas / available now
+    const long long k_first = (long long)(np0 / QP_W);
+    const long long k_last = avail > np0 ? (long long)((avail - 1) / QP_W) : k_first - 1;
+
+    QpskState st;
+    const bool active = wv == 0 && b0 + lane < batch;
+    if (wv == 0) {
+        if (active) {
+            st = P.st[b0 + lane];
+            // Costas outputs [np0 - 16, np0) of the previous call -> their columns of the first window
+            float2* row = win + (size_t)(k_first & 1) * 64 * QP_PITCH + lane * QP_PITCH;
+            const long long i0 = k_first * QP_W - QP_BACK;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const long long i = (long long)np0 - 16 + j;
+                const long long c = i - i0;
+                if (c >= 0 && c < QP_COLS) row[c] = st.hist[j];
+            }
+        } else {
+            st = QpskState{};
+            st.ii = ~0ull >> 1;
+        }
+        oo0[lane] = st.oo;
+    }
+
+    auto load_window = [&](long long k, int t, int nthreads) {   // raw samples [max(kW, np0), min((k+1)W, avail))
+        float2* wbuf = win + (size_t)(k & 1) * 64 * QP_PITCH;
+        const long long ia = max((long long)np0, k * QP_W), ib = min((long long)avail, (k + 1) * QP_W);
+        const int cnt = (int)(ib - ia);
+        if (cnt <= 0) return;
+        const int c0 = (int)(ia - (k * QP_W - QP_BACK));
+        constexpr int BATCH = 8;
+        const int total = nstreams * cnt;
+        for (int base = t; base < total; base += nthreads * BATCH) {
+            float2 v[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int idx = base + u * nthreads;
+                v[u] = make_float2(0.f, 0.f);
+                if (idx < total) {
+                    const int s = idx / cnt, c = idx - s * cnt;
+                    v[u] = P.in.p[(size_t)(b0 + s) * (P.in.mask + 1u) + ((uint32_t)(ia + c) & P.in.mask)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int idx = base + u * nthreads;
+                if (idx < total) { const int s = idx / cnt, c = idx - s * cnt; wbuf[s * QP_PITCH + c0 + c] = v[u]; }
+            }
+        }
+    };
+    auto flush_window = [&](long long k, int t, int nthreads) {
+        const int pb = (int)(k & 1);
+        const float2* ob = osym + (size_t)pb * 64 * QP_OPITCH;
+        for (int idx = t; idx < nstreams * QP_OMAX; idx += nthreads) {
+            const int s = idx / QP_OMAX, j = idx - s * QP_OMAX;
+            if (j < ocnt[pb * 64 + s]) {
+                const float2 v = ob[s * QP_OPITCH + j];
+                const uint64_t o = obase[pb * 64 + s] + j;
+                // complex_to_float -> interleave -> multiply_const(48) -> add_const(128) -> float_to_uchar
+                float qa = v.x * P.soft_mul; qa = qa + P.soft_add;
+                float qb = v.y * P.soft_mul; qb = qb + P.soft_add;
+                float ra = rintf(qa), rb = rintf(qb);
+                if (!(ra >= 0.f)) ra = 0.f; if (ra > 255.f) ra = 255.f;
+                if (!(rb >= 0.f)) rb = 0.f; if (rb > 255.f) rb = 255.f;
+                uint8_t* sp = P.soft.p + (size_t)(b0 + s) * (P.soft.mask + 1u);
+                sp[(uint32_t)(2 * o) & P.soft.mask] = (uint8_t)ra;
+                sp[(uint32_t)(2 * o + 1) & P.soft.mask] = (uint8_t)rb;
+                const uint64_t kk = o - oo0[s];
+                if (P.port && kk < P.port_cap) P.port[(size_t)(b0 + s) * P.port_cap + kk] = v;
+            }
+        }
+    };
+
+    __syncthreads();
+    if (k_first <= k_last) load_window(k_first, tid, 256);
+    __syncthreads();
+    const float SQ = 0.707107f;
+    for (long long k = k_first; k <= k_last; ++k) {
+        if (wv == 0) {
+            const int pb = (int)(k & 1);
+            float2* row = win + (size_t)pb * 64 * QP_PITCH + lane * QP_PITCH;
+            float2* orow = osym + (size_t)pb * 64 * QP_OPITCH + lane * QP_OPITCH;
+            const long long i0 = k * QP_W - QP_BACK;
+            if (k > k_first && active) {   // carry the last 16 Costas outputs of the previous window
+                const float2* prow = win + (size_t)(pb ^ 1) * 64 * QP_PITCH + lane * QP_PITCH;
+#pragma unroll
+                for (int j = 0; j < QP_BACK; ++j) row[j] = prow[QP_W + j];
+            }
+            // ---- pass 1: agc2_cc -> costas_loop_cc on the new samples, in place
+            const int ca = (int)(max((long long)np0, k * QP_W) - i0), cb = (int)(min((long long)avail, (k + 1) * QP_W) - i0);
+            if (active) {
+                for (int c = ca; c < cb; ++c) {
+                    const float2 x = row[c];
+                    float2 a; a.x = x.x * st.gain; a.y = x.y * st.gain;
+                    const float tmp = -1.0f + sqrtf(a.x * a.x + a.y * a.y);
+                    float rate = 0.1f;
+                    if (tmp > st.gain) rate = 1.0f;
+                    st.gain -= tmp * rate;
+                    if (st.gain < 0.0f) st.gain = 10e-5f;
+                    if (st.gain > 65536.0f) st.gain = 65536.0f;
+                    const float2 nco = sincos_rad(-st.c1_phase);   // (cos, sin)
+                    float2 o; o.x = a.x * nco.x - a.y * nco.y; o.y = a.x * nco.y + a.y * nco.x;
+                    row[c] = o;
+                    float e = costas4_snr_error(o, th);
+                    e = branchless_clip(e, 1.0f);
+                    st.c1_freq = st.c1_freq + P.c1_beta * e;
+                    st.c1_phase = st.c1_phase + st.c1_freq + P.c1_alpha * e;
+                    st.c1_phase = phase_wrap(st.c1_phase);
+                    if (st.c1_freq > 1.0f) st.c1_freq = 1.0f; else if (st.c1_freq < -1.0f) st.c1_freq = -1.0f;
+                }
+            }
+            // ---- pass 2: symbol_sync_cc and the symbol-rate blocks
+            const uint64_t wend = (uint64_t)min((long long)avail, (k + 1) * QP_W);   // exclusive
+            const uint64_t oo_w = st.oo;
+            int nsym = 0;
+            while (active && st.ii + 8 <= wend && nsym < QP_OMAX) {
+                const int off = (int)((long long)st.ii - i0);
+                const int imu = (int)rintf(st.mu * 128.0f);
+                const float* t = mm + imu * 8;
+                float2 y = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float2 xs = row[off + j];
+                    y.x = fmaf(t[7 - j], xs.x, y.x);
+                    y.y = fmaf(t[7 - j], xs.y, y.y);
+                }
+                st.x2 = st.x1; st.x1 = st.x0; st.x0 = y;
+                st.d2 = st.d1; st.d1 = st.d0;
+                st.d0.x = y.x > 0.f ? SQ : -SQ; st.d0.y = y.y > 0.f ? SQ : -SQ;
+                float e;
+                {
+                    const float ar = st.x0.x - st.x2.x, ai = st.x0.y - st.x2.y;
+                    const float br = st.d0.x - st.d2.x, bi = st.d0.y - st.d2.y;
+                    const float u = (ar * st.d1.x + ai * st.d1.y) - (br * st.x1.x + bi * st.x1.y);
+                    e = branchless_clip(u, 1.0f);
+                }
+                st.avg = st.avg + P.ss_beta * e;
+                if (st.avg > P.ss_maxp) st.avg = P.ss_maxp; else if (st.avg < P.ss_minp) st.avg = P.ss_minp;
+                st.inst = st.avg + P.ss_alpha * e;
+                if (st.inst <= 0.f) st.inst = st.avg;
+                const float ph = st.mu + st.inst;
+                const float fl = floorf(ph);
+                st.mu = ph - fl;
+                st.ii += (uint64_t)(int)fl;
+                // second Costas loop at the symbol rate
+                const float2 nco = sincos_rad(-st.c2_phase);
+                float2 o; o.x = y.x * nco.x - y.y * nco.y; o.y = y.x * nco.y + y.y * nco.x;
+                float e2 = costas4_snr_error(o, th);
+                e2 = branchless_clip(e2, 1.0f);
+                st.c2_freq = st.c2_freq + P.c2_beta * e2;
+                st.c2_phase = st.c2_phase + st.c2_freq + P.c2_alpha * e2;
+                st.c2_phase = phase_wrap(st.c2_phase);
+                if (st.c2_freq > 1.0f) st.c2_freq = 1.0f; else if (st.c2_freq < -1.0f) st.c2_freq = -1.0f;
+                // diff_phasor_cc, then multiply_const_cc(e^{-j 3 pi / 4})
+                float2 dp; dp.x = o.x * st.dprev.x + o.y * st.dprev.y; dp.y = o.y * st.dprev.x - o.x * st.dprev.y;
+                st.dprev = o;
+                float2 v; v.x = dp.x * P.rot.x - dp.y * P.rot.y; v.y = dp.x * P.rot.y + dp.y * P.rot.x;
+                orow[nsym] = v;
+                nsym++;
+                st.oo++;
+            }
+            ocnt[pb * 64 + lane] = nsym;
+            obase[pb * 64 + lane] = oo_w;
+            if (k == k_last && active) {   // keep the last 16 Costas outputs for the next call
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const long long i = (long long)avail - 16 + j;
+                    const long long c = i - i0;
+                    st.hist[j] = (c >= 0 && i >= 0) ? row[c] : make_float2(0.f, 0.f);
+                }
+            }
+        } else {
+            if (k + 1 <= k_last) load_window(k + 1, tid - 64, 192);
+            if (k > k_first) flush_window(k - 1, tid - 64, 192);
+        }
+        __syncthreads();
+    }
+    if (k_first <= k_last) flush_window(k_last, tid, 256);
+    if (active) {
+        P.st[b0 + lane] = st;
+        P.counts[(b0 + lane) * 4 + 1] = (uint32_t)(st.oo - oo0[lane]);
+    }
+}
+
+static size_t qpsk_lds_bytes()
+{
+    return (size_t)(2 * 64 * QP_PITCH + 2 * 64 * QP_OPITCH) * sizeof(float2) + (129 * 8 + 256) * sizeof(float) + 2 * 64 * sizeof(int) +
+           (2 * 64 + 64) * sizeof(uint64_t);
+}
+
+void launch_qpsk_loops(const QpskParams& p, int batch, hipStream_t s)
+{
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qpsk_loops), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qpsk_lds_bytes());
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_qpsk_loops, dim3((batch + 63) / 64), dim3(256), qpsk_lds_bytes(), s, p, batch);
+}
+
+}  // namespace qrl

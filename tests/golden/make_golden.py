@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz: small seeded inputs and the ORACLE's outputs for them.
+
+The reference (qradiolink) cannot be built or imported here and ships no vectors, so
+these fixtures are minted by oracle/liborc.so (parity unpinned).  Their job is to
+(a) freeze the oracle against silent drift and (b) give the GPU tests inputs + expected outputs that
+travel to the GPU box.  Re-run this script only when the arithmetic contract changes on purpose:
+    python tests/golden/make_golden.py
+Inputs are stored as float16-exact complex64 (quantised BEFORE the oracle runs) to keep files small."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import orc   # noqa: E402
+import sig   # noqa: E402
+
+CASES = [
+    # name, sig mode, device rate, rx offset, oracle demod kwargs
+    ("2fsk1k_1M", "2fsk1k", 1000000, 0.0, ("2fsk", dict(sps=10, filter_width=2000, fm=False))),
+    ("2fsk1kfm_1M", "2fsk1kfm", 1000000, 0.0, ("2fsk", dict(sps=10, filter_width=2500, fm=True))),
+    ("gmsk10k_1M", "gmsk10k", 1000000, 0.0, ("gmsk", dict(sps=1, filter_width=20000))),
+    ("gmsk10k_8M", "gmsk10k", 8000000, 25000.0, ("gmsk", dict(sps=1, filter_width=20000))),   # front end 8:1 = f32-MFMA decimator
+    ("qpsk250k_1M", "qpsk250k", 1000000, 0.0, ("qpsk", dict(sps=2, filter_width=160000))),
+]
+
+
+def quantise(x):
+    v = x.view(np.float32).astype(np.float16).astype(np.float32)
+    return v.view(np.complex64)
+
+
+def run_oracle(kind, kw, x, rate, offset):
+    fe = orc.frontend(x, rate, offset)
+    return {"2fsk": orc.demod_2fsk, "gmsk": orc.demod_gmsk, "qpsk": orc.demod_qpsk}[kind](fe, **kw)
+
+
+def digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    for name, mode, rate, offset, (kind, kw) in CASES:
+        nframes = 1 if rate > 1000000 else (3 if mode.startswith("2fsk") else 2)
+        y, payloads = sig.make_stream(mode, nframes=nframes, device_rate=rate, rx_offset_hz=offset, seed=77, amp=0.25)
+        y = quantise(y[: y.size & ~1])
+        r = run_oracle(kind, kw, y, rate, offset)
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"),
+            iq_f16=y.view(np.float32).astype(np.float16), rate=rate, offset=offset,
+            bits_a=np.packbits(r["bits_a"]), n_bits_a=r["bits_a"].size,
+            bits_b=np.packbits(r["bits_b"]), n_bits_b=r["bits_b"].size,
+            filtered_sha256=digest(r["filtered"]), constellation_sha256=digest(r["constellation"]),
+            n_filtered=r["filtered"].size, n_constellation=r["constellation"].size,
+            filtered_head=r["filtered"][:64], constellation_head=r["constellation"][:64],
+            payloads=np.frombuffer(b"".join(payloads), np.uint8), payload_len=len(payloads[0]))
+        print(name, y.size, "samples ->", r["bits_a"].size, "bits", os.path.getsize(os.path.join(HERE, name + ".npz")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

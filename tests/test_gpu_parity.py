@@ -28,6 +28,8 @@ def _oracle(mode_name, x, device_rate, offset):
         return orc.demod_gmsk(fe, sps=1, filter_width=20000)
     if mode_name == "gmsk1k":
         return orc.demod_gmsk(fe, sps=10, filter_width=2000)
+    if mode_name == "qpsk250k":
+        return orc.demod_qpsk(fe, sps=2, filter_width=160000)
     raise ValueError(mode_name)
 
 
@@ -35,6 +37,8 @@ def _compare(iq, out, mode_name, device_rate, offset):
     for b in range(iq.shape[0]):
         ref = _oracle(mode_name, iq[b], device_rate, offset)
         for port in ("bits_a", "bits_b"):
+            if mode_name == "qpsk250k" and port == "bits_b":
+                continue   # single-branch mode (gr_demod_qpsk.cpp:124-126): port 2 only
             assert out[port][b].size == ref[port].size, (port, b, out[port][b].size, ref[port].size)
             assert np.array_equal(out[port][b], ref[port]), "%s stream %d differs" % (port, b)
         for port in ("filtered", "constellation"):
@@ -52,6 +56,8 @@ def _compare(iq, out, mode_name, device_rate, offset):
     ("gmsk1k", 21, 2000000, 1 << 22),
     ("gmsk10k", 22, 25000000, 1 << 23),     # front end 25:1, 1045 taps: f32-MFMA decimator, 16-block tiles
     ("gmsk10k", 22, 10000000, 1 << 23),     # front end 10:1, 419 taps
+    ("qpsk250k", 26, 1000000, 1 << 20),     # C3 chain at the internal rate: agc2, 2x Costas, symbol_sync_cc, diff_phasor
+    ("qpsk250k", 26, 10000000, 1 << 23),    # C3 behind the 10:1 front end
 ])
 def test_chain_bit_exact_single_call(qrl_ctx, mode_name, modem, rate, chunk):
     offset = 25000.0 if rate >= 2000000 else 1200.0
@@ -76,6 +82,12 @@ def test_chunk_invariance_mfma_front_end(qrl_ctx, chunk):
 def test_chunk_invariance_2fsk(qrl_ctx, chunk):
     iq, out = _run(qrl_ctx, "2fsk1k", 18, 1000000, 1200.0, B=2, chunk=chunk, nframes=2)
     _compare(iq, out, "2fsk1k", 1000000, 1200.0)
+
+
+@pytest.mark.parametrize("chunk", [65536, 20002, 1000])
+def test_chunk_invariance_qpsk(qrl_ctx, chunk):
+    iq, out = _run(qrl_ctx, "qpsk250k", 26, 1000000, 1200.0, B=2, chunk=chunk, nframes=2)
+    _compare(iq, out, "qpsk250k", 1000000, 1200.0)
 
 
 def test_front_end_repeatable_under_load(qrl_ctx):
