@@ -537,9 +537,33 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
     if (c.device_samp_rate < 1000000 || (c.device_samp_rate >= 2000000 && c.device_samp_rate % 1000000))
         return fail(QRL_ERR_ARG, "device_samp_rate must be 1e6 or a multiple of 1e6 >= 2e6");
     HIPCHK(hipSetDevice(ctx->device));
-    if (c.hip_stream) d->stream = static_cast<hipStream_t>(c.hip_stream);
-    else { HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)); d->own_stream = true; }
-    HIPCHK(hipStreamCreateWithFlags(&d->tail, hipStreamNonBlocking));
+    // Streams.  Optional CU partition between the main and the tail stream (QRL_TAIL_CUS = CUs reserved for the tail).
+    int tail_cus = 0;
+    {
+        // (measured: masking costs the front end ~18 % on MI355X, so it is opt-in; by default the tail stream just
+        //  has the highest priority and its kernels are small enough to take over the slot of ONE retiring
+        //  front-end workgroup: <= 80 KB LDS, <= 256 VGPRs per lane)
+        if (const char* e = std::getenv("QRL_TAIL_CUS")) tail_cus = std::atoi(e);
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
+        if (tail_cus >= prop.multiProcessorCount / 2 || c.hip_stream) tail_cus = 0;   // a caller-owned stream cannot be masked
+        const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+        std::vector<uint32_t> m_main(words, 0), m_tail(words, 0);
+        for (int i = 0; i < ncu; ++i) {
+            // spread the reserved CUs over the XCDs (CU index modulo 8 walks the XCDs on this part)
+            const bool is_tail = tail_cus > 0 && (i % (ncu / tail_cus) == 0) && (i / (ncu / tail_cus) < tail_cus);
+            (is_tail ? m_tail : m_main)[i / 32] |= 1u << (i % 32);
+        }
+        if (c.hip_stream) d->stream = static_cast<hipStream_t>(c.hip_stream);
+        else if (tail_cus > 0) { HIPCHK(hipExtStreamCreateWithCUMask(&d->stream, (uint32_t)words, m_main.data())); d->own_stream = true; }
+        else { HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)); d->own_stream = true; }
+        if (tail_cus > 0) HIPCHK(hipExtStreamCreateWithCUMask(&d->tail, (uint32_t)words, m_tail.data()));
+        else {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            HIPCHK(hipStreamCreateWithPriority(&d->tail, hipStreamNonBlocking, hi));
+        }
+    }
     HIPCHK(hipEventCreateWithFlags(&d->ev_ff, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&d->ev_tail, hipEventDisableTiming));
     int r = d->build();

@@ -92,15 +92,16 @@ __device__ __forceinline__ void tile_issue(const DecimParams& P, int b, const Ti
 {
     // UNCONDITIONAL loads with the pair index clamped into the caller's buffer; lanes outside
     // [k_lo, k_hi) fetch some valid pair, tile_commit sends them to the dump slots.
-    const float4* src = reinterpret_cast<const float4*>(P.in + (size_t)b * P.in_stride);
-    const int64_t q0 = (w.i_base - w.a - (int64_t)P.n0) >> 1;      // pair index of k = 0 (may be negative)
-    const int64_t qmax = (int64_t)(P.n >> 1) - 1;
+    // Address = stream base (SGPR pair) + 32-bit byte offset: 3 VALU per load (the host guarantees n * 8 < 4 GiB).
+    const uint64_t base = reinterpret_cast<uint64_t>(P.in + (size_t)b * P.in_stride);
+    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    const uint64_t sbase = ((uint64_t)bhi << 32) | blo;
+    const int q0k = (int)((w.i_base - w.a - (int64_t)P.n0) >> 1) + w.k_lo + tid;   // pair index of this thread's first load
+    const int qmax = (int)(P.n >> 1) - 1;
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
-        int64_t q = q0 + w.k_lo + tid + 256 * it;
-        q = q < 0 ? 0 : (q > qmax ? qmax : q);
-        const float4* p = src + q;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(v[it]) : "v"(p) : "memory");
+        const uint32_t voff = (uint32_t)min(max(q0k + 256 * it, 0), qmax) << 4;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(v[it]) : "v"(voff), "s"(sbase) : "memory");
     }
 }
 template <int NLD>
@@ -650,7 +651,7 @@ static void launch_one(const DecimParams& q, dim3 grid, size_t lds, hipStream_t 
         return;
     }
     // FAST: the tile comes from the caller's buffer through register-prefetched 16-byte loads
-    if (q.in && q.n >= 2) launch_k<NA, NLD, true>(q, grid, lds, s);
+    if (q.in && q.n >= 2 && q.n < (1u << 28)) launch_k<NA, NLD, true>(q, grid, lds, s);
     else launch_k<NA, 1, false>(q, grid, lds, s);
 }
 

@@ -116,12 +116,14 @@ void launch_fll(const FllParams& p, int batch, hipStream_t s)
 }
 
 // ------------------------------------------------------------------ symbol_sync_ff
-// One workgroup = 64 streams.  Wave 0 runs the recursion, one lane per stream, out of an LDS window; waves
+// One workgroup = SS_NS = 32 streams.  Wave 0 runs the recursion, one lane per stream, out of an LDS window; waves
 // 1-3 meanwhile fetch the NEXT window of all 64 streams (coalesced along the stream) and flush the symbols of
 // the PREVIOUS window, so the serial wave never waits on L2/HBM latency (that wait was > 50 % of the old
 // single-wave kernel).  Windows sit on an absolute grid: window k holds samples [k W - SS_BACK, (k+1) W + 8)
 // of every stream; a lane works while its 8-tap interpolator fits, then all lanes move on together (cursors of
 // different streams never drift apart by more than a symbol inside a call: every lane consumes all samples).
+constexpr int SS_NS = 32;                    // streams per workgroup (half a wave: keeps the LDS under 80 KB so the
+                                             // kernel fits beside ONE front-end workgroup and overlaps the next call)
 constexpr int SS_W = 192;                    // new samples per window
 constexpr int SS_BACK = 16;                  // samples kept in front of the grid point
 constexpr int SS_COLS = SS_BACK + SS_W + 8;  // 216
@@ -142,27 +144,27 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int batch)
 {
     extern __shared__ __align__(16) unsigned char ss_smem[];
-    float* win = reinterpret_cast<float*>(ss_smem);              // [2][64][SS_PITCH]
-    float* mm = win + 2 * 64 * SS_PITCH;                         // [129][8]
-    float* osym = mm + 129 * 8;                                  // [2][64][SS_OPITCH]
-    int* ocnt = reinterpret_cast<int*>(osym + 2 * 64 * SS_OPITCH);       // [2][64]
+    float* win = reinterpret_cast<float*>(ss_smem);              // [2][SS_NS][SS_PITCH]
+    float* mm = win + 2 * SS_NS * SS_PITCH + 4;                         // [129][8]
+    float* osym = mm + 129 * 8;                                  // [2][SS_NS][SS_OPITCH]
+    int* ocnt = reinterpret_cast<int*>(osym + 2 * SS_NS * SS_OPITCH);       // [2][64]
     uint64_t* obase = reinterpret_cast<uint64_t*>(ocnt + 2 * 64);        // [2][64]
     uint64_t* oo0 = obase + 2 * 64;                                      // [64]
     long long* kfl = reinterpret_cast<long long*>(oo0 + 64);             // [2]: first / last window
 
     const int tid = threadIdx.x;
     const int wv = tid >> 6, lane = tid & 63;
-    const int b0 = blockIdx.x * 64;
-    const int nstreams = min(64, batch - b0);
+    const int b0 = blockIdx.x * SS_NS;
+    const int nstreams = min(SS_NS, batch - b0);
     for (int k = tid; k < 129 * 8; k += 256) mm[k] = P.mmse[k];
 
     SymSyncState st;
     bool active = false;
     if (wv == 0) {
-        active = b0 + lane < batch;
+        active = lane < SS_NS && b0 + lane < batch;
         if (active) st = P.st[b0 + lane];
         else { st.ii = ~0ull >> 1; st.oo = 0; st.mu = 0; st.avg = st.inst = 0; st.x0 = st.x1 = st.x2 = st.d0 = st.d1 = st.d2 = 0; }
-        oo0[lane] = st.oo;
+        if (lane < SS_NS) oo0[lane] = st.oo;
         const uint64_t lo = wave_min_u64(active ? st.ii : ~0ull);
         if (lane == 0) {
             // windows that can hold a symbol: ii + 8 <= avail
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
 
     // loader: window k of all streams -> win[k & 1]
     auto load_window = [&](long long k, int t, int nthreads) {
-        float* wbuf = win + (size_t)(k & 1) * 64 * SS_PITCH;
+        float* wbuf = win + (size_t)(k & 1) * SS_NS * SS_PITCH;
         const long long i0 = k * SS_W - SS_BACK;
         constexpr int BATCH = 12;
         const int total = nstreams * SS_COLS;
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
     // flusher: symbols of window k -> soft-symbol ring (multiply_const -> add_const -> float_to_uchar) and port 1
     auto flush_window = [&](long long k, int t, int nthreads) {
         const int pb = (int)(k & 1);
-        const float* ob = osym + (size_t)pb * 64 * SS_OPITCH;
+        const float* ob = osym + (size_t)pb * SS_NS * SS_OPITCH;
         for (int idx = t; idx < nstreams * SS_OMAX; idx += nthreads) {
             const int s = idx / SS_OMAX, j = idx - s * SS_OMAX;
             if (j < ocnt[pb * 64 + s]) {
@@ -226,14 +228,17 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
     for (long long k = k_first; k <= k_last; ++k) {
         if (wv == 0) {
             const int pb = (int)(k & 1);
-            const float* row = win + (size_t)pb * 64 * SS_PITCH + lane * SS_PITCH;
-            float* orow = osym + (size_t)pb * 64 * SS_OPITCH + lane * SS_OPITCH;
+            const int ln = lane & (SS_NS - 1);
+            const float* row = win + (size_t)pb * SS_NS * SS_PITCH + ln * SS_PITCH;
+            float* orow = osym + (size_t)pb * SS_NS * SS_OPITCH + ln * SS_OPITCH;
             const long long i0 = k * SS_W - SS_BACK;
             const uint64_t wend = min((uint64_t)((k + 1) * SS_W + 8), P.avail);   // exclusive
             const uint64_t oo_w = st.oo;
             int nsym = 0;
-            while (active && st.ii + 8 <= wend && nsym < SS_OMAX) {
-                const int off = (int)((long long)st.ii - i0);
+            // in-window cursor as a plain int: the 64-bit absolute cursor is rebuilt after the loop
+            int off = active ? (int)min((long long)st.ii - i0, (long long)(1 << 20)) : (1 << 20);
+            const int off_end = (int)((long long)wend - i0) - 8;   // last admissible cursor
+            while (off <= off_end && nsym < SS_OMAX) {
                 const int imu = (int)rintf(st.mu * 128.0f);
                 const float4 ta = *reinterpret_cast<const float4*>(mm + imu * 8);
                 const float4 tb = *reinterpret_cast<const float4*>(mm + imu * 8 + 4);
@@ -259,11 +264,10 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
                 st.mu = ph - fl;
                 orow[nsym] = y;
                 nsym++;
-                st.oo++;
-                st.ii += (uint64_t)(int)fl;
+                off += (int)fl;
             }
-            ocnt[pb * 64 + lane] = nsym;
-            obase[pb * 64 + lane] = oo_w;
+            if (active) { st.ii = (uint64_t)(i0 + off); st.oo += (uint64_t)nsym; }
+            if (lane < SS_NS) { ocnt[pb * 64 + lane] = nsym; obase[pb * 64 + lane] = oo_w; }
         } else {
             if (k + 1 <= k_last) load_window(k + 1, tid - 64, 192);
             if (k > k_first) flush_window(k - 1, tid - 64, 192);
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
 
 size_t symsync_lds_bytes()
 {
-    return (size_t)(2 * 64 * SS_PITCH + 129 * 8 + 2 * 64 * SS_OPITCH) * sizeof(float) + 2 * 64 * sizeof(int) + (2 * 64 + 64 + 2) * sizeof(uint64_t);
+    return (size_t)(2 * SS_NS * SS_PITCH + 4 + 129 * 8 + 2 * SS_NS * SS_OPITCH) * sizeof(float) + 2 * 64 * sizeof(int) + (2 * 64 + 64 + 2) * sizeof(uint64_t);
 }
 
 void launch_symsync_ff(const SymSyncParams& p, int batch, hipStream_t s)
@@ -289,7 +293,7 @@ void launch_symsync_ff(const SymSyncParams& p, int batch, hipStream_t s)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_symsync_ff), hipFuncAttributeMaxDynamicSharedMemorySize, (int)symsync_lds_bytes());
         attr = true;
     }
-    dim3 grid((batch + 63) / 64), block(256);
+    dim3 grid((batch + SS_NS - 1) / SS_NS), block(256);
     hipLaunchKernelGGL(k_symsync_ff, grid, block, symsync_lds_bytes(), s, p, batch);
 }
 
