@@ -29,7 +29,7 @@ WORKLOADS = {
     "c2": ("C2: GMSK-10k RX chain (gr_demod_base front end 25:1 + gr_demod_gmsk) on 25 Msps IQ",
            "gmsk10k", 22, 25000000, 25000.0, 96, 25 * (1 << 18), 1),
     "c1": ("C1: 2FSK-1k RX chain (rotator + gr_demod_2fsk) on 1 Msps IQ",
-           "2fsk1k", 18, 1000000, 1200.0, 8192, 1 << 18, 0),
+           "2fsk1k", 18, 1000000, 1200.0, 16384, 1 << 18, 0),
 }
 
 

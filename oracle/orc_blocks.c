@@ -264,7 +264,8 @@ void orc_fll_band_edge(const cf32* in, size_t n, float sps, float rolloff, int n
         memmove(dl + 1, dl, sizeof(cf32) * (size_t)(nt - 1));
         dl[0] = y;
         float ur = 0, ui = 0, lr = 0, li = 0;
-        for (int j = 0; j < nt; j++) {
+        /* one fmaf chain per accumulator, OLDEST sample first: only the last link depends on y[n] */
+        for (int j = nt - 1; j >= 0; j--) {
             cf32 hu = upper[nt - 1 - j], hl = lower[nt - 1 - j], v = dl[j];
             ur = fmaf(hu.re, v.re, ur); ur = fmaf(-hu.im, v.im, ur);
             ui = fmaf(hu.re, v.im, ui); ui = fmaf(hu.im, v.re, ui);

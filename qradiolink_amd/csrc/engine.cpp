@@ -397,32 +397,47 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         launch_fll(f, B, stream);
         filt_in = r2l;
     }
-    {
-        FirCcfParams f{};
-        f.in = filt_in; f.out = r2f; f.q0 = n2_0; f.count = c2; f.taps = filt_taps.p; f.nt = filt_nt;
+    const bool fused_2fsk = fam == F_2FSK && !fm && filt_nt <= 41 && disc_nt <= 41 && symf_nt <= 25 &&
+                            !(std::getenv("QRL_2FSK_UNFUSED") && std::getenv("QRL_2FSK_UNFUSED")[0] == '1');
+    if (fused_2fsk) {
+        if (tail_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_tail, 0)); tail_pending = false; }
+        Fsk2FfParams f{};
+        f.in = filt_in; f.out = r3; f.q0 = n2_0; f.count = c2;
+        f.tf = filt_taps.p; f.nf = filt_nt; f.up = disc_up.p; f.lo = disc_lo.p; f.nb = disc_nt; f.ts = symf_taps.p; f.ns = symf_nt;
         f.port = side && out->filtered ? reinterpret_cast<float2*>(out->filtered) : nullptr;
         f.port_cap = side ? out->filtered_cap : 0;
         f.counts = counts;
-        launch_fir_ccf(f, B, stream);
-    }
-    if (fam == F_QPSK) {
-        // recursive chain + Viterbi below; nothing else at the sample rate
-    } else if (fam == F_GMSK || fm) {
-        QuadDemodParams q{}; q.in = r2f; q.out = r2d; q.q0 = n2_0; q.count = c2; q.gain = demod_gain; q.atan_tab = atan_tab.p;
-        launch_quad_demod(q, B, stream);
-    } else {
-        Disc2fskParams d{}; d.in = r2f; d.out = r2d; d.q0 = n2_0; d.count = c2; d.up = disc_up.p; d.lo = disc_lo.p; d.nt = disc_nt;
-        launch_disc_2fsk(d, B, stream);
-    }
-    if (fam == F_QPSK) {
-        // the tail reads r2f (written by k_fir_ccf above): it runs on the handle's own stream for this family
-    } else {
-        // r3 is what the previous call's tail (other stream) may still be reading
-        if (tail_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_tail, 0)); tail_pending = false; }
-        FirFffParams f{}; f.in = r2d; f.out = r3; f.q0 = n2_0; f.count = c2; f.taps = symf_taps.p; f.nt = symf_nt;
-        launch_fir_fff(f, B, stream);
+        launch_2fsk_ff(f, B, stream);
         HIPCHK(hipEventRecord(ev_ff, stream));
         HIPCHK(hipStreamWaitEvent(tail, ev_ff, 0));
+    } else {
+        {
+            FirCcfParams f{};
+            f.in = filt_in; f.out = r2f; f.q0 = n2_0; f.count = c2; f.taps = filt_taps.p; f.nt = filt_nt;
+            f.port = side && out->filtered ? reinterpret_cast<float2*>(out->filtered) : nullptr;
+            f.port_cap = side ? out->filtered_cap : 0;
+            f.counts = counts;
+            launch_fir_ccf(f, B, stream);
+        }
+        if (fam == F_QPSK) {
+            // recursive chain + Viterbi below; nothing else at the sample rate
+        } else if (fam == F_GMSK || fm) {
+            QuadDemodParams q{}; q.in = r2f; q.out = r2d; q.q0 = n2_0; q.count = c2; q.gain = demod_gain; q.atan_tab = atan_tab.p;
+            launch_quad_demod(q, B, stream);
+        } else {
+            Disc2fskParams d{}; d.in = r2f; d.out = r2d; d.q0 = n2_0; d.count = c2; d.up = disc_up.p; d.lo = disc_lo.p; d.nt = disc_nt;
+            launch_disc_2fsk(d, B, stream);
+        }
+        if (fam == F_QPSK) {
+            // the tail reads r2f (written by k_fir_ccf above): it runs on the handle's own stream for this family
+        } else {
+            // r3 is what the previous call's tail (other stream) may still be reading
+            if (tail_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_tail, 0)); tail_pending = false; }
+            FirFffParams f{}; f.in = r2d; f.out = r3; f.q0 = n2_0; f.count = c2; f.taps = symf_taps.p; f.nt = symf_nt;
+            launch_fir_fff(f, B, stream);
+            HIPCHK(hipEventRecord(ev_ff, stream));
+            HIPCHK(hipStreamWaitEvent(tail, ev_ff, 0));
+        }
     }
     // ---- stage D: symbol sync + FEC
     if (fam == F_QPSK) {

@@ -66,6 +66,10 @@ struct FirCcfParams { RingC in; RingC out; uint64_t q0; uint32_t count; const fl
 struct FirFffParams { RingF in; RingF out; uint64_t q0; uint32_t count; const float* taps; int nt; };
 struct QuadDemodParams { RingC in; RingF out; uint64_t q0; uint32_t count; float gain; const float* atan_tab; };
 struct Disc2fskParams { RingC in; RingF out; uint64_t q0; uint32_t count; const float2* up; const float2* lo; int nt; };
+struct Fsk2FfParams { RingC in; RingF out; uint64_t q0; uint32_t count;
+                      const float* tf; int nf; const float2* up; const float2* lo; int nb; const float* ts; int ns;
+                      float2* port; size_t port_cap; uint32_t* counts; };
+void launch_2fsk_ff(const Fsk2FfParams& p, int batch, hipStream_t s);
 void launch_fir_ccf(const FirCcfParams& p, int batch, hipStream_t s);
 void launch_fir_fff(const FirFffParams& p, int batch, hipStream_t s);
 void launch_quad_demod(const QuadDemodParams& p, int batch, hipStream_t s);

@@ -109,4 +109,70 @@ void launch_disc_2fsk(const Disc2fskParams& p, int batch, hipStream_t s)
     hipLaunchKernelGGL(k_disc_2fsk, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
 }
 
+// ---- fused feed-forward part of the non-FM 2FSK chain (gr_demod_2fsk.cpp:91-104,140-152):
+//   _filter (fft_filter_ccf) -> {_upper_filter, _lower_filter} (fft_filter_ccc) -> complex_to_mag x2 -> divide ->
+//   rail(0,2) -> add_const(-1) -> _symbol_filter (fft_filter_fff)
+// One workgroup = 256 consecutive outputs of one stream; the three FIR stages run out of LDS with the
+// intermediate halos recomputed (12 % extra MACs), taps are wave-uniform (scalar loads), every output is the
+// same fmaf chain (k ascending) as the unfused kernels.  Items at negative absolute index are zero, exactly
+// as a ring read in front of the stream start returns zero.
+constexpr int FF_T = 256;
+__global__ __launch_bounds__(256) void k_2fsk_ff(const Fsk2FfParams P)
+{
+    __shared__ float2 lt[FF_T + 104 + 8];   // FLL output, abs = n0t - (nf-1) - (nb-1) - (ns-1) + i
+    __shared__ float2 ft[FF_T + 64 + 8];    // _filter output
+    __shared__ float dt[FF_T + 24 + 8];     // discriminator output
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int nf = P.nf, nb = P.nb, ns = P.ns;           // 41, 41, 25 for the 1k mode
+    const int hf = nf - 1, hb = nb - 1, hs = ns - 1;
+    const int64_t n0t = (int64_t)P.q0 + (int64_t)blockIdx.x * FF_T;
+    const int nl = FF_T + hf + hb + hs, nfo = FF_T + hb + hs, nd = FF_T + hs;
+    for (int i = tid; i < nl; i += 256) lt[i] = ringc_at(P.in, b, n0t - (hf + hb + hs) + i);
+    __syncthreads();
+    for (int j = tid; j < nfo; j += 256) {                 // f at abs = n0t - (hb + hs) + j
+        float ar = 0.f, ai = 0.f;
+        for (int k = 0; k < nf; ++k) {
+            const float h = P.tf[k];
+            const float2 x = lt[j + hf - k];
+            ar = fmaf(h, x.x, ar);
+            ai = fmaf(h, x.y, ai);
+        }
+        const bool neg = n0t - (hb + hs) + j < 0;
+        ft[j] = neg ? make_float2(0.f, 0.f) : make_float2(ar, ai);
+    }
+    __syncthreads();
+    for (int j = tid; j < nd; j += 256) {                  // d at abs = n0t - hs + j
+        float ur = 0.f, ui = 0.f, lr = 0.f, li = 0.f;
+        for (int k = 0; k < nb; ++k) {
+            const float2 x = ft[j + hb - k];
+            const float2 hu = P.up[k], hl = P.lo[k];
+            ur = fmaf(hu.x, x.x, ur); ur = fmaf(-hu.y, x.y, ur);
+            ui = fmaf(hu.x, x.y, ui); ui = fmaf(hu.y, x.x, ui);
+            lr = fmaf(hl.x, x.x, lr); lr = fmaf(-hl.y, x.y, lr);
+            li = fmaf(hl.x, x.y, li); li = fmaf(hl.y, x.x, li);
+        }
+        const float mu = sqrtf(ur * ur + ui * ui);
+        const float ml = sqrtf(lr * lr + li * li);
+        float r = mu / ml;
+        if (!(r >= 0.0f)) r = 0.0f;   // rail_ff lower bound; NaN (0/0) -> 0
+        if (r > 2.0f) r = 2.0f;
+        dt[j] = (n0t - hs + j < 0) ? 0.f : r + (-1.0f);
+    }
+    __syncthreads();
+    const uint32_t t = blockIdx.x * (uint32_t)FF_T + tid;   // output index inside this call
+    if (t < P.count) {
+        float a = 0.f;
+        for (int k = 0; k < ns; ++k) a = fmaf(P.ts[k], dt[tid + hs - k], a);
+        const int64_t n = n0t + tid;
+        P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = a;
+        if (t == 0 && P.counts) P.counts[b * 4 + 0] = P.count;
+        if (P.port && t < P.port_cap) P.port[(size_t)b * P.port_cap + t] = ft[tid + hb + hs];
+    }
+}
+void launch_2fsk_ff(const Fsk2FfParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_2fsk_ff, dim3((p.count + FF_T - 1) / FF_T, batch), dim3(256), 0, s, p);
+}
+
 }  // namespace qrl

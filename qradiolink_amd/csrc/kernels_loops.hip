@@ -12,6 +12,12 @@
 namespace qrl {
 
 // ------------------------------------------------------------------ FLL band edge
+// fll_band_edge_cc: y[n] = x[n - NT] * nco(phase);  u/l = band-edge FIRs over the last NT outputs y;
+// error = |l|^2 - |u|^2;  2nd-order loop.  Summation contract (oracle orc_fll_band_edge): each of the four
+// accumulators is ONE fmaf chain over the taps OLDEST SAMPLE FIRST, so only the last link of the chain
+// depends on the sample that was just derotated.  (A variant with the delay line in absolute-index register
+// slots and an NT-times unrolled body was tried: 20 % slower -- its 60 KB of code thrashes the instruction
+// cache and a single wave per SIMD is issue-latency bound anyway: ~5 cycles per instruction.)
 constexpr int FLL_CH = 96;   // samples per stream per LDS window
 
 template <int NT>
@@ -25,7 +31,7 @@ __global__ __launch_bounds__(64) void k_fll(const FllParams P, int batch)
     const bool active = b < batch;
     if (lane < NT) { tl[lane] = P.lower[lane]; tu[lane] = P.upper[lane]; }
     float phase = 0.f, freq = 0.f;
-    float2 dl[NT];
+    float2 dl[NT];   // dl[j] = y[n - j]
     if (active) {
         const FllState& s = P.st[b];
         phase = s.phase; freq = s.freq;
@@ -70,18 +76,26 @@ __global__ __launch_bounds__(64) void k_fll(const FllParams P, int batch)
                 const float2 nco = sincos_rad(phase);  // (cos, sin)
                 const float2 y = cmul(x, nco);
                 win[lane][k] = y;                      // output staged in place, flushed coalesced below
-#pragma unroll
-                for (int j = NT - 1; j > 0; --j) dl[j] = dl[j - 1];
-                dl[0] = y;
+                // oldest sample first: the NT-1 old links do not depend on y
                 float ur = 0.f, ui = 0.f, lr = 0.f, li = 0.f;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const float2 hu = tu[j], hl = tl[j], v = dl[j];
+                for (int j = NT - 1; j >= 1; --j) {
+                    const float2 hu = tu[j], hl = tl[j], v = dl[j - 1];   // dl[j-1] is y[n - j] before the shift
                     ur = fmaf(hu.x, v.x, ur); ur = fmaf(-hu.y, v.y, ur);
                     ui = fmaf(hu.x, v.y, ui); ui = fmaf(hu.y, v.x, ui);
                     lr = fmaf(hl.x, v.x, lr); lr = fmaf(-hl.y, v.y, lr);
                     li = fmaf(hl.x, v.y, li); li = fmaf(hl.y, v.x, li);
                 }
+                {
+                    const float2 hu = tu[0], hl = tl[0];
+                    ur = fmaf(hu.x, y.x, ur); ur = fmaf(-hu.y, y.y, ur);
+                    ui = fmaf(hu.x, y.y, ui); ui = fmaf(hu.y, y.x, ui);
+                    lr = fmaf(hl.x, y.x, lr); lr = fmaf(-hl.y, y.y, lr);
+                    li = fmaf(hl.x, y.y, li); li = fmaf(hl.y, y.x, li);
+                }
+#pragma unroll
+                for (int j = NT - 1; j > 0; --j) dl[j] = dl[j - 1];
+                dl[0] = y;
                 const float error = (lr * lr + li * li) - (ur * ur + ui * ui);
                 freq = freq + P.beta * error;
                 phase = phase + freq + P.alpha * error;
