@@ -116,6 +116,37 @@ int qrl_demod_profile_read(qrl_demod* d, double* kernel_ms, uint64_t* launches, 
 int qrl_demod_process_host(qrl_demod* d, const float* iq_host, size_t stride, size_t n,
                            uint8_t* bits_a_host, uint8_t* bits_b_host, size_t bits_cap, uint32_t* counts_host);
 
+/* ---- TX: the "modulator" top_block (reference src/gr/gr_mod_base.cpp:25) ----------------------------------
+ * One handle = make_gr_mod_qpsk(sps, samp_rate, carrier_freq, filter_width) (src/gr/gr_mod_qpsk.cpp:19-30;
+ * instance make_gr_mod_qpsk(4,1000000,1700,160000) src/gr/gr_mod_base.cpp:175) for `batch` independent streams.
+ * Only the QPSK family is built so far; gr_mod_base's rate-matching interpolator (gr_mod_base.cpp:249-258) and
+ * rotator are not part of this handle yet. */
+typedef struct qrl_mod qrl_mod;
+typedef struct {
+    int modem_type;          /* gr_modem_types value (QRL_MODEM_QPSK250K) */
+    int use_mode_defaults;   /* 1: sps/filter_width from gr_mod_base.cpp:175 */
+    int sps, samp_rate, carrier_freq, filter_width;   /* make_gr_mod_qpsk arguments */
+    int batch;               /* independent streams per call */
+    size_t max_bytes;        /* largest nbytes of any process call */
+    void* hip_stream;        /* hipStream_t, NULL = the library creates one (RX and TX handles on different streams run
+                                concurrently: full duplex, reference src/radiocontroller.cpp:2043-2078) */
+    float bb_gain;           /* gr_mod_qpsk::set_bb_gain, 0 = 1.0 */
+} qrl_mod_config;
+int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** out);
+void qrl_mod_destroy(qrl_mod* m);
+/* replaces: flush of the modulator graph on mode change (gr_mod_base.cpp:354-360): scrambler seed, encoder, filter history */
+int qrl_mod_reset(qrl_mod* m);
+/* replaces: gr_mod_qpsk::set_bb_gain (src/gr/gr_mod_qpsk.cpp:91-94) */
+int qrl_mod_set_bb_gain(qrl_mod* m, float value);
+size_t qrl_mod_samples_per_byte(const qrl_mod* m);   /* 8 * sps */
+/* replaces: gr_mod_base::set_data (src/gr/gr_mod_base.cpp:783-786) + gr_byte_source::work (src/gr/gr_byte_source.cpp:75-106)
+ * + one scheduler pass of every block of gr_mod_qpsk: bytes[b*stride + i], i < nbytes (device, packed, MSB first) ->
+ * iq[2*(b*out_stride + k)], k < nbytes*8*sps (device cf32).  State (scrambler, encoder, differential symbol, pulse-shaping
+ * history) carries across calls; asynchronous on the handle's stream. */
+int qrl_mod_process(qrl_mod* m, const uint8_t* bytes, size_t stride, size_t nbytes, float* iq, size_t out_stride);
+int qrl_mod_sync(qrl_mod* m);
+void* qrl_mod_stream(qrl_mod* m);
+
 /* ---- filter design & tables (host side, no GPU needed): what the kernels are loaded with ----
  * replaces: gr::filter::firdes::* calls at gr_demod_2fsk.cpp:82-97, gr_demod_gmsk.cpp:80-98,
  * gr_demod_qpsk.cpp:92-103, gr_demod_base.cpp:1333-1336.  taps==NULL returns the count. */

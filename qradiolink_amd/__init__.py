@@ -31,6 +31,12 @@ class _Config(C.Structure):
                 ("hip_stream", C.c_void_p), ("enable_side_outputs", C.c_int)]
 
 
+class _ModConfig(C.Structure):
+    _fields_ = [("modem_type", C.c_int), ("use_mode_defaults", C.c_int), ("sps", C.c_int), ("samp_rate", C.c_int),
+                ("carrier_freq", C.c_int), ("filter_width", C.c_int), ("batch", C.c_int), ("max_bytes", C.c_size_t),
+                ("hip_stream", C.c_void_p), ("bb_gain", C.c_float)]
+
+
 class _Out(C.Structure):
     _fields_ = [("filtered", C.c_void_p), ("filtered_cap", C.c_size_t), ("constellation", C.c_void_p),
                 ("constellation_cap", C.c_size_t), ("bits_a", C.c_void_p), ("bits_cap", C.c_size_t),
@@ -68,6 +74,16 @@ def load_library():
     lib.qrl_demod_profile.argtypes = [vp, C.c_int]
     lib.qrl_demod_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_char_p)]
     lib.qrl_demod_process_host.argtypes = [vp, vp, sz, sz, vp, vp, sz, vp]
+    lib.qrl_mod_create.argtypes = [vp, C.POINTER(_ModConfig), C.POINTER(vp)]
+    lib.qrl_mod_destroy.argtypes = [vp]
+    lib.qrl_mod_reset.argtypes = [vp]
+    lib.qrl_mod_set_bb_gain.argtypes = [vp, C.c_float]
+    lib.qrl_mod_samples_per_byte.restype = sz
+    lib.qrl_mod_samples_per_byte.argtypes = [vp]
+    lib.qrl_mod_process.argtypes = [vp, vp, sz, sz, vp, sz]
+    lib.qrl_mod_sync.argtypes = [vp]
+    lib.qrl_mod_stream.restype = vp
+    lib.qrl_mod_stream.argtypes = [vp]
     lib.qrl_firdes_low_pass.argtypes = [C.c_double] * 4 + [C.c_int, vp]
     lib.qrl_firdes_low_pass_2.argtypes = [C.c_double] * 5 + [C.c_int, vp]
     lib.qrl_firdes_complex_band_pass.argtypes = [C.c_double] * 5 + [C.c_int, vp]
@@ -84,7 +100,8 @@ EXPORTED_SYMBOLS = [
     "qrl_init", "qrl_shutdown", "qrl_strerror", "qrl_last_error", "qrl_version", "qrl_demod_create",
     "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_out_caps",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
-    "qrl_demod_profile_read", "qrl_firdes_low_pass",
+    "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain",
+    "qrl_mod_samples_per_byte", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_firdes_low_pass",
     "qrl_firdes_low_pass_2", "qrl_firdes_complex_band_pass", "qrl_firdes_root_raised_cosine", "qrl_table_mmse",
     "qrl_table_atan", "qrl_table_tanh", "qrl_phase_inc_to_turn",
 ]
@@ -224,6 +241,57 @@ class Demod:
     def close(self):
         if self.h:
             self.lib.qrl_demod_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Mod:
+    """Batch TX modulator: mirrors make_gr_mod_qpsk (reference src/gr/gr_mod_qpsk.cpp:19-30).
+    process(bytes) takes a torch cuda uint8 tensor [batch, nbytes] (packed bytes, as gr_byte_source hands them
+    out) and returns a complex64 cuda tensor [batch, nbytes * 8 * sps]."""
+
+    def __init__(self, ctx, modem_type, batch, max_bytes, stream=None, bb_gain=1.0):
+        import torch
+        self.torch = torch
+        self.ctx, self.lib = ctx, ctx.lib
+        cfg = _ModConfig()
+        cfg.modem_type = modem_type
+        cfg.use_mode_defaults = 1
+        cfg.batch = batch
+        cfg.max_bytes = max_bytes
+        cfg.hip_stream = stream
+        cfg.bb_gain = bb_gain
+        self.batch, self.max_bytes = batch, max_bytes
+        self.h = C.c_void_p()
+        _check(self.lib.qrl_mod_create(ctx.h, C.byref(cfg), C.byref(self.h)), "qrl_mod_create")
+        self.spb = self.lib.qrl_mod_samples_per_byte(self.h)
+
+    def process_async(self, data, out=None):
+        assert data.is_cuda and data.dtype == self.torch.uint8 and data.dim() == 2 and data.shape[0] == self.batch
+        assert data.stride(1) == 1
+        n = data.shape[1]
+        if out is None:
+            out = self.torch.empty((self.batch, n * self.spb), dtype=self.torch.complex64, device=data.device)
+        _check(self.lib.qrl_mod_process(self.h, data.data_ptr(), data.stride(0), n, out.data_ptr(), out.stride(0)),
+               "qrl_mod_process")
+        return out
+
+    def sync(self):
+        _check(self.lib.qrl_mod_sync(self.h), "qrl_mod_sync")
+
+    def process(self, data):
+        out = self.process_async(data)
+        self.sync()
+        return out
+
+    def reset(self):
+        _check(self.lib.qrl_mod_reset(self.h), "qrl_mod_reset")
+
+    def set_bb_gain(self, g):
+        _check(self.lib.qrl_mod_set_bb_gain(self.h, float(g)), "qrl_mod_set_bb_gain")
+
+    def close(self):
+        if self.h:
+            self.lib.qrl_mod_destroy(self.h)
             self.h = C.c_void_p()
 
 

@@ -21,6 +21,7 @@ using namespace qrl;
 
 static thread_local std::string g_last_error;
 static int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+int qrl_set_error(int code, const std::string& msg) { return fail(code, msg); }   // shared with tx.cpp
 
 #define HIPCHK(expr)                                                                              \
     do {                                                                                          \

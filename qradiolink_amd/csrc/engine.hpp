@@ -125,4 +125,19 @@ struct FecParams {
 };
 void launch_fec(const FecParams& p, int batch, hipStream_t s);
 
+// ---- TX: gr_mod_qpsk (kernels_tx.hip) ----
+struct TxState { uint32_t sr, enc, prev, pad; };   // scrambler register, last 6 scrambled bits, last differential symbol
+struct TxBitsParams {
+    const uint8_t* bytes; size_t stride; uint32_t nbytes; uint32_t L;   // L bits per lane (multiple of 32)
+    uint8_t tl_cols[8];                                                  // T^L of the zero-input scrambler, column masks
+    TxState* st; RingB sym; uint64_t s0;                                 // symbol ring, absolute index of this call's first symbol
+};
+struct TxInterpParams {
+    RingB sym; uint64_t n0; uint32_t count;      // absolute first output sample, outputs of this call
+    const float* taps; int nt; int interp; float2 table[4]; float amp, bb_gain;
+    float2* out; size_t out_stride;
+};
+void launch_tx_qpsk_bits(const TxBitsParams& p, int batch, hipStream_t s);
+void launch_tx_interp(const TxInterpParams& p, int batch, hipStream_t s);
+
 }  // namespace qrl

@@ -1,0 +1,151 @@
+// kernels_tx.hip — TX side of the path: gr_mod_qpsk (reference src/gr/gr_mod_qpsk.cpp:56-89, instance
+// make_gr_mod_qpsk(4, 1000000, 1700, 160000) src/gr/gr_mod_base.cpp:175):
+//   packed_to_unpacked_bb(1, MSB) -> scrambler_bb(0x8A, 0x7F, 7) -> cc_encoder(K=7, {109, 79}) -> pack_k_bits(2)
+//   -> map_bb{0,1,3,2} -> diff_encoder_bb(4) -> chunks_to_symbols_bc -> rational_resampler_ccf(sps, 1, RRC)
+//   -> multiply_const_cc(0.6) -> multiply_const_cc(bb_gain)
+//
+//  k_tx_qpsk_bits : ONE WAVE PER STREAM turns the bytes of a call into differential symbol indices.
+//     The additive scrambler is a GF(2)-linear recurrence, so the 64 lanes each take a contiguous slice:
+//     pass 1 runs the slice from a ZERO register (gives the slice's contribution to the final state), a
+//     63-step lane chain composes it with T^L (the L-step zero-input transition, 8 column masks from the
+//     host) to get every lane's TRUE start register, pass 2 reruns the slice for real.  The encoder is
+//     feed-forward (6-bit halo) and the differential encoder is a prefix sum mod 4 (wave scan).
+//  k_tx_interp    : polyphase interpolating FIR, one thread per output sample, one fmaf chain per output
+//     (j ascending, as oracle orc_resamp_ccf), constellation looked up from the symbol index.
+#include "devmath.hpp"
+#include "engine.hpp"
+
+namespace qrl {
+
+__device__ __forceinline__ uint32_t lfsr_step(uint32_t sr, uint32_t in)   // scrambler_bb(0x8A, seed, 7)
+{
+    const uint32_t nb = (__builtin_popcount(sr & 0x8Au) & 1u) ^ (in & 1u);
+    return (sr >> 1) | (nb << 7);
+}
+__device__ __forceinline__ uint32_t gf2_apply(const uint8_t (&cols)[8], uint32_t v)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r ^= ((v >> k) & 1u) ? cols[k] : 0u;
+    return r;
+}
+
+__global__ __launch_bounds__(64) void k_tx_qpsk_bits(const TxBitsParams P)
+{
+    extern __shared__ __align__(16) unsigned char tx_smem[];
+    uint32_t* sbits = reinterpret_cast<uint32_t*>(tx_smem);     // scrambled bits of this call, packed LSB = earliest
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const uint8_t* in = P.bytes + (size_t)b * P.stride;
+    TxState st = P.st[b];
+    const uint32_t nbits = P.nbytes * 8u;
+    const uint32_t L = P.L;                                     // bits per lane, multiple of 32
+    const uint32_t lo = min(nbits, lane * L), hi = min(nbits, (lane + 1) * L);
+    auto in_bit = [&](uint32_t i) { return (uint32_t)(in[i >> 3] >> (7u - (i & 7u))) & 1u; };   // packed_to_unpacked MSB first
+
+    // pass 1: slice from a zero register
+    uint32_t sf = 0;
+    for (uint32_t i = lo; i < hi; ++i) sf = lfsr_step(sf, in_bit(i));
+    // true start register of every lane: init[l] = T^len(l-1) init[l-1] ^ sf[l-1]; only full slices use T^L,
+    // a ragged or empty slice (lanes past the end) never feeds a later lane that has bits
+    uint8_t cols[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cols[k] = P.tl_cols[k];
+    uint32_t init = st.sr;
+    uint32_t mine = st.sr;
+    for (int l = 1; l < 64; ++l) {
+        const uint32_t sfp = __shfl(sf, l - 1, 64);
+        init = gf2_apply(cols, init) ^ sfp;
+        if (lane == l) mine = init;
+    }
+    // pass 2: the real scrambler; output bit = sr & 1 BEFORE the step
+    uint32_t sr = mine, word = 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        word |= (sr & 1u) << (i & 31u);
+        sr = lfsr_step(sr, in_bit(i));
+        if ((i & 31u) == 31u || i + 1 == hi) { sbits[i >> 5] = word; word = 0; }
+    }
+    // register after the whole call = register of the last lane that had bits
+    const uint32_t last_lane = nbits ? (nbits - 1) / L : 0;
+    const uint32_t sr_end = __shfl(sr, (int)last_lane, 64);
+    __syncthreads();
+
+    // encoder + map: one symbol per input bit.  Scrambled bit i, i < 0 comes from the previous call (st.enc).
+    auto sbit = [&](int64_t i) -> uint32_t {
+        if (i >= 0) return (sbits[i >> 5] >> (i & 31)) & 1u;
+        return (st.enc >> (uint32_t)(-i - 1)) & 1u;              // st.enc bit k = scrambled bit (-1 - k)
+    };
+    const uint32_t map4[4] = {0u, 1u, 3u, 2u};
+    uint32_t local = 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        uint32_t reg = 0;                                        // bit k = scrambled bit i - k (cc_encoder shift register)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) reg |= sbit((int64_t)i - k) << k;
+        const uint32_t c0 = __builtin_popcount(reg & 109u) & 1u, c1 = __builtin_popcount(reg & 79u) & 1u;
+        local = (local + map4[(c0 << 1) | c1]) & 3u;
+    }
+    // diff_encoder_bb(4): y[n] = (x[n] + y[n-1]) mod 4  ->  exclusive wave scan of the slice sums
+    uint32_t incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl = (incl + o) & 3u;
+    }
+    uint32_t run = (st.prev + incl - local) & 3u;                // symbol before this lane's slice
+    uint8_t* ring = P.sym.p + (size_t)b * (P.sym.mask + 1u);
+    for (uint32_t i = lo; i < hi; ++i) {
+        uint32_t reg = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) reg |= sbit((int64_t)i - k) << k;
+        const uint32_t c0 = __builtin_popcount(reg & 109u) & 1u, c1 = __builtin_popcount(reg & 79u) & 1u;
+        run = (run + map4[(c0 << 1) | c1]) & 3u;
+        ring[(uint32_t)(P.s0 + i) & P.sym.mask] = (uint8_t)run;
+    }
+    const uint32_t prev_end = __shfl(run, (int)last_lane, 64);
+    if (lane == 0 && nbits) {
+        uint32_t enc = 0;
+        for (int k = 0; k < 6; ++k) enc |= sbit((int64_t)nbits - 1 - k) << k;
+        st.sr = sr_end; st.enc = enc; st.prev = prev_end;
+        P.st[b] = st;
+    }
+}
+
+void launch_tx_qpsk_bits(const TxBitsParams& p, int batch, hipStream_t s)
+{
+    if (!p.nbytes) return;
+    const size_t lds = ((size_t)p.nbytes * 8 + 31) / 32 * 4 + 16;
+    hipLaunchKernelGGL(k_tx_qpsk_bits, dim3(batch), dim3(64), lds, s, p);
+}
+
+__global__ __launch_bounds__(256) void k_tx_interp(const TxInterpParams P)
+{
+    __shared__ float taps[256];
+    for (int k = threadIdx.x; k < 256; k += 256) taps[k] = k < P.nt ? P.taps[k] : 0.f;
+    __syncthreads();
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.count) return;
+    const uint64_t n = P.n0 + t;                       // absolute output sample
+    const int I = P.interp;
+    const uint64_t c = n / (uint64_t)I;
+    const int ph = (int)(n - c * (uint64_t)I);
+    const uint8_t* ring = P.sym.p + (size_t)b * (P.sym.mask + 1u);
+    float ar = 0.f, ai = 0.f;
+    for (int j = 0; ph + j * I < P.nt; ++j) {
+        if ((uint64_t)j > c) break;                    // symbols before the stream start are zero
+        const float h = taps[ph + j * I];
+        const float2 x = P.table[ring[(uint32_t)(c - j) & P.sym.mask] & 3u];
+        ar = fmaf(h, x.x, ar);
+        ai = fmaf(h, x.y, ai);
+    }
+    ar *= P.amp; ai *= P.amp;                          // multiply_const_cc(0.6)
+    ar *= P.bb_gain; ai *= P.bb_gain;                  // multiply_const_cc(bb_gain)
+    P.out[(size_t)b * P.out_stride + t] = make_float2(ar, ai);
+}
+
+void launch_tx_interp(const TxInterpParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_tx_interp, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
+}
+
+}  // namespace qrl
