@@ -1,0 +1,163 @@
+// gr_hip_blocks.cpp — see gr_hip_blocks.h.  Host buffers are staged through device memory with plain HIP
+// copies on the handle's stream (a GNU Radio scheduler hands out host pointers).
+#include "gr_hip_blocks.h"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+#include <string>
+
+static void chk(int rc, const char* what)
+{
+    if (rc != QRL_OK) throw std::runtime_error(std::string(what) + ": " + qrl_strerror(rc) + " (" + qrl_last_error() + ")");
+}
+static void hchk(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+qrl_runtime::qrl_runtime(int device) { chk(qrl_init(device, &d_ctx), "qrl_init"); }
+qrl_runtime::~qrl_runtime() { qrl_shutdown(d_ctx); }
+
+enum { FAM_2FSK = 0, FAM_GMSK = 1, FAM_QPSK = 2 };
+
+gr_demod_hip_sptr make_gr_demod_2fsk_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width, bool fm)
+{ return gr_demod_hip_sptr(new gr_demod_hip(rt, FAM_2FSK, sps, samp_rate, carrier_freq, filter_width, fm)); }
+gr_demod_hip_sptr make_gr_demod_gmsk_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
+{ return gr_demod_hip_sptr(new gr_demod_hip(rt, FAM_GMSK, sps, samp_rate, carrier_freq, filter_width, false)); }
+gr_demod_hip_sptr make_gr_demod_qpsk_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
+{ return gr_demod_hip_sptr(new gr_demod_hip(rt, FAM_QPSK, sps, samp_rate, carrier_freq, filter_width, false)); }
+
+gr_demod_hip::gr_demod_hip(qrl_runtime& rt, int fam, int sps, int samp_rate, int carrier_freq, int filter_width, bool fm)
+    : gr::sync_block("gr_demod_hip", gr::io_signature::make(1, 1, sizeof(gr_complex)), gr::io_signature::make(0, 0, 0)), d_rt(rt)
+{
+    // any member of the family selects the chain; the explicit factory arguments (not the mode table) configure it
+    d_cfg.modem_type = fam == FAM_2FSK ? QRL_MODEM_2FSK1K : (fam == FAM_GMSK ? QRL_MODEM_GMSK10K : QRL_MODEM_QPSK250K);
+    d_cfg.use_mode_defaults = 0;
+    d_cfg.sps = sps; d_cfg.samp_rate = samp_rate; d_cfg.carrier_freq = carrier_freq; d_cfg.filter_width = filter_width; d_cfg.fm = fm;
+    d_cfg.device_samp_rate = samp_rate; d_cfg.carrier_offset_hz = 0.0;
+    d_cfg.batch = 1; d_cfg.max_chunk = kChunk; d_cfg.enable_side_outputs = 1;
+    open();
+}
+void gr_demod_hip::open()
+{
+    if (d_h) { qrl_demod_destroy(d_h); d_h = nullptr; }
+    chk(qrl_demod_create(d_rt.ctx(), &d_cfg, &d_h), "qrl_demod_create");
+    chk(qrl_demod_out_caps(d_h, kChunk, &d_fcap, &d_ccap, &d_bcap), "qrl_demod_out_caps");
+    if (!d_iq) {
+        hchk(hipMalloc(reinterpret_cast<void**>(&d_iq), kChunk * sizeof(gr_complex)), "hipMalloc");
+        hchk(hipMalloc(reinterpret_cast<void**>(&d_cnt), 4 * sizeof(uint32_t)), "hipMalloc");
+    }
+    for (void* p : {(void*)d_const, (void*)d_a, (void*)d_b}) if (p) (void)hipFree(p);
+    hchk(hipMalloc(reinterpret_cast<void**>(&d_const), d_ccap * sizeof(gr_complex)), "hipMalloc");
+    hchk(hipMalloc(reinterpret_cast<void**>(&d_a), d_bcap), "hipMalloc");
+    hchk(hipMalloc(reinterpret_cast<void**>(&d_b), d_bcap), "hipMalloc");
+    d_ha.resize(d_bcap); d_hb.resize(d_bcap); d_hc.resize(d_ccap);
+}
+gr_demod_hip::~gr_demod_hip()
+{
+    if (d_h) qrl_demod_destroy(d_h);
+    for (void* p : {(void*)d_iq, (void*)d_const, (void*)d_a, (void*)d_b, (void*)d_cnt}) if (p) (void)hipFree(p);
+}
+void gr_demod_hip::set_device_samp_rate(int r) { d_cfg.device_samp_rate = r; open(); }
+void gr_demod_hip::set_carrier_offset(double hz) { d_cfg.carrier_offset_hz = hz; chk(qrl_demod_set_carrier_offset(d_h, hz), "qrl_demod_set_carrier_offset"); }
+void gr_demod_hip::flush()
+{
+    chk(qrl_demod_reset(d_h), "qrl_demod_reset");
+    gr::thread::scoped_lock g(d_mutex);
+    d_box1.clear(); d_box2.clear(); d_boxc.clear(); d_carry.clear();
+}
+
+void gr_demod_hip::run(const gr_complex* x, size_t n)   // n even, <= kChunk
+{
+    hipStream_t s = static_cast<hipStream_t>(qrl_demod_stream(d_h));
+    hchk(hipMemcpyAsync(d_iq, x, n * sizeof(gr_complex), hipMemcpyHostToDevice, s), "H2D");
+    qrl_demod_out o{};
+    o.constellation = d_const; o.constellation_cap = d_ccap;
+    o.bits_a = d_a; o.bits_b = d_b; o.bits_cap = d_bcap; o.counts = d_cnt;
+    chk(qrl_demod_process(d_h, d_iq, kChunk, n, &o), "qrl_demod_process");
+    chk(qrl_demod_sync(d_h), "qrl_demod_sync");
+    uint32_t cnt[4];
+    hchk(hipMemcpy(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost), "D2H");
+    if (cnt[2]) hchk(hipMemcpy(d_ha.data(), d_a, cnt[2], hipMemcpyDeviceToHost), "D2H");
+    if (cnt[3]) hchk(hipMemcpy(d_hb.data(), d_b, cnt[3], hipMemcpyDeviceToHost), "D2H");
+    if (cnt[1]) hchk(hipMemcpy(d_hc.data(), d_const, cnt[1] * sizeof(gr_complex), hipMemcpyDeviceToHost), "D2H");
+    gr::thread::scoped_lock g(d_mutex);
+    if (d_box1.size() <= 1048576) d_box1.insert(d_box1.end(), d_ha.begin(), d_ha.begin() + cnt[2]);   // drop rule of gr_bit_sink.cpp:71-76
+    if (d_box2.size() <= 1048576) d_box2.insert(d_box2.end(), d_hb.begin(), d_hb.begin() + cnt[3]);
+    d_boxc.insert(d_boxc.end(), d_hc.begin(), d_hc.begin() + cnt[1]);
+    if (d_boxc.size() > 65536) d_boxc.erase(d_boxc.begin(), d_boxc.end() - 65536);
+}
+
+int gr_demod_hip::work(int noutput_items, gr_vector_const_void_star& input_items, gr_vector_void_star&)
+{
+    const gr_complex* in = static_cast<const gr_complex*>(input_items[0]);
+    size_t done = 0, n = (size_t)noutput_items;
+    while (done < n) {
+        // the scheduler may hand out any count: keep an odd sample for the next call
+        d_buf.assign(d_carry.begin(), d_carry.end());
+        const size_t take = std::min(n - done, kChunk - d_buf.size());
+        d_buf.insert(d_buf.end(), in + done, in + done + take);
+        done += take;
+        const size_t even = d_buf.size() & ~(size_t)1;
+        d_carry.assign(d_buf.begin() + even, d_buf.end());
+        if (even) run(d_buf.data(), even);
+    }
+    return noutput_items;
+}
+std::vector<unsigned char>* gr_demod_hip::get_data(int nr)
+{
+    gr::thread::scoped_lock g(d_mutex);
+    std::vector<unsigned char>& box = nr == 1 ? d_box1 : d_box2;
+    if (box.size() < 32) return nullptr;                     // gr_bit_sink.cpp:48-52
+    std::vector<unsigned char>* v = new std::vector<unsigned char>(box);
+    box.clear();
+    return v;
+}
+std::vector<gr_complex>* gr_demod_hip::get_constellation_data()
+{
+    gr::thread::scoped_lock g(d_mutex);
+    if (d_boxc.empty()) return nullptr;
+    std::vector<gr_complex>* v = new std::vector<gr_complex>(d_boxc);
+    d_boxc.clear();
+    return v;
+}
+
+gr_mod_hip_sptr make_gr_mod_qpsk_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
+{ return gr_mod_hip_sptr(new gr_mod_hip(rt, sps, samp_rate, carrier_freq, filter_width)); }
+
+gr_mod_hip::gr_mod_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
+    : gr::sync_interpolator("gr_mod_hip", gr::io_signature::make(1, 1, sizeof(unsigned char)),
+                            gr::io_signature::make(1, 1, sizeof(gr_complex)), 8u * (unsigned)sps)
+{
+    qrl_mod_config c{};
+    c.modem_type = QRL_MODEM_QPSK250K; c.use_mode_defaults = 0;
+    c.sps = sps; c.samp_rate = samp_rate; c.carrier_freq = carrier_freq; c.filter_width = filter_width;
+    c.batch = 1; c.max_bytes = kMaxBytes; c.bb_gain = 1.0f;
+    chk(qrl_mod_create(rt.ctx(), &c, &d_h), "qrl_mod_create");
+    hchk(hipMalloc(reinterpret_cast<void**>(&d_bytes), kMaxBytes), "hipMalloc");
+    hchk(hipMalloc(reinterpret_cast<void**>(&d_iq), kMaxBytes * qrl_mod_samples_per_byte(d_h) * sizeof(gr_complex)), "hipMalloc");
+}
+gr_mod_hip::~gr_mod_hip()
+{
+    if (d_h) qrl_mod_destroy(d_h);
+    if (d_bytes) (void)hipFree(d_bytes);
+    if (d_iq) (void)hipFree(d_iq);
+}
+void gr_mod_hip::set_bb_gain(float v) { chk(qrl_mod_set_bb_gain(d_h, v), "qrl_mod_set_bb_gain"); }
+int gr_mod_hip::work(int noutput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items)
+{
+    const size_t spb = qrl_mod_samples_per_byte(d_h);
+    const unsigned char* in = static_cast<const unsigned char*>(input_items[0]);
+    gr_complex* out = static_cast<gr_complex*>(output_items[0]);
+    size_t nbytes = (size_t)noutput_items / spb, done = 0;
+    hipStream_t s = static_cast<hipStream_t>(qrl_mod_stream(d_h));
+    while (done < nbytes) {
+        const size_t take = std::min(nbytes - done, kMaxBytes);
+        hchk(hipMemcpyAsync(d_bytes, in + done, take, hipMemcpyHostToDevice, s), "H2D");
+        chk(qrl_mod_process(d_h, d_bytes, kMaxBytes, take, d_iq, kMaxBytes * spb), "qrl_mod_process");
+        hchk(hipMemcpyAsync(out + done * spb, d_iq, take * spb * sizeof(gr_complex), hipMemcpyDeviceToHost, s), "D2H");
+        chk(qrl_mod_sync(d_h), "qrl_mod_sync");
+        done += take;
+    }
+    return (int)(nbytes * spb);
+}

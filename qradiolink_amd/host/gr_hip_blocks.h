@@ -1,0 +1,77 @@
+// gr_hip_blocks.h — C++ host side above the C ABI: GNU Radio-shaped blocks that a QRadioLink maintainer drops
+// where the per-mode hier blocks sit today.  Same factory arguments as the reference factories
+// (make_gr_demod_2fsk / make_gr_demod_gmsk / make_gr_demod_qpsk / make_gr_mod_qpsk), same work() block ABI
+// (src/gr/gr_4fsk_discriminator.h:19-21), same mailbox ownership rules as gr_bit_sink::get_data
+// (src/gr/gr_bit_sink.cpp:45-59: heap vector the caller deletes, nullptr = nothing yet) and the same error
+// behaviour as device construction in the reference (std::runtime_error, src/radiocontroller.cpp:1974-1983).
+#pragma once
+#include "gr_compat.h"
+#include "qrl_hip.h"
+#include <memory>
+#include <stdexcept>
+#include <vector>
+
+class qrl_runtime {   // process-wide qrl_init / qrl_shutdown (one GNU Radio "top_block" worth of device context)
+public:
+    explicit qrl_runtime(int device = 0);
+    ~qrl_runtime();
+    qrl_ctx* ctx() const { return d_ctx; }
+private:
+    qrl_ctx* d_ctx = nullptr;
+};
+
+class gr_demod_hip;
+typedef std::shared_ptr<gr_demod_hip> gr_demod_hip_sptr;
+// replaces make_gr_demod_2fsk(sps, samp_rate, carrier_freq, filter_width, fm)   src/gr/gr_demod_2fsk.cpp:19-26
+gr_demod_hip_sptr make_gr_demod_2fsk_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 250000, int carrier_freq = 1700,
+                                         int filter_width = 8000, bool fm = false);
+// replaces make_gr_demod_gmsk(sps, samp_rate, carrier_freq, filter_width)        src/gr/gr_demod_gmsk.cpp:19-26
+gr_demod_hip_sptr make_gr_demod_gmsk_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 250000, int carrier_freq = 1700,
+                                         int filter_width = 8000);
+// replaces make_gr_demod_qpsk(sps, samp_rate, carrier_freq, filter_width)        src/gr/gr_demod_qpsk.cpp:20-27
+gr_demod_hip_sptr make_gr_demod_qpsk_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 250000, int carrier_freq = 1700,
+                                         int filter_width = 8000);
+
+class gr_demod_hip : public gr::sync_block {
+public:
+    gr_demod_hip(qrl_runtime& rt, int modem_family, int sps, int samp_rate, int carrier_freq, int filter_width, bool fm);
+    ~gr_demod_hip() override;
+    // gr_demod_base::set_samp_rate / set_carrier_offset (src/gr/gr_demod_base.cpp:1303-1362, 1220-1225)
+    void set_device_samp_rate(int device_samp_rate);
+    void set_carrier_offset(double hz);
+    // one cf32 input stream at the DEVICE rate (what feeds _rotator in the reference), no stream outputs: the
+    // ports of the hier block are mailboxes, as they end in sinks in the reference (gr_bit_sink, gr_const_sink)
+    int work(int noutput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) override;
+    std::vector<unsigned char>* get_data(int nr);          // port 2 (nr = 1) / port 3 (nr = 2); caller deletes
+    std::vector<gr_complex>* get_constellation_data();     // port 1; caller deletes
+    void flush();                                          // qrl_demod_reset + drop mailboxes
+private:
+    void open();
+    void run(const gr_complex* x, size_t n);
+    qrl_runtime& d_rt;
+    qrl_demod_config d_cfg{};
+    qrl_demod* d_h = nullptr;
+    size_t d_fcap = 0, d_ccap = 0, d_bcap = 0;
+    std::vector<gr_complex> d_carry;                        // at most one sample: the ABI takes even counts
+    std::vector<gr_complex> d_buf;
+    float *d_iq = nullptr, *d_const = nullptr; uint8_t *d_a = nullptr, *d_b = nullptr; uint32_t* d_cnt = nullptr;   // device
+    std::vector<unsigned char> d_box1, d_box2, d_ha, d_hb; std::vector<gr_complex> d_boxc, d_hc;
+    gr::thread::mutex d_mutex;
+    static constexpr size_t kChunk = 1 << 18;
+};
+
+class gr_mod_hip;
+typedef std::shared_ptr<gr_mod_hip> gr_mod_hip_sptr;
+// replaces make_gr_mod_qpsk(sps, samp_rate, carrier_freq, filter_width)          src/gr/gr_mod_qpsk.cpp:19-30
+gr_mod_hip_sptr make_gr_mod_qpsk_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 250000, int carrier_freq = 1700,
+                                     int filter_width = 8000);
+class gr_mod_hip : public gr::sync_interpolator {   // u8 packed bytes in -> cf32 out, 8*sps samples per byte
+public:
+    gr_mod_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width);
+    ~gr_mod_hip() override;
+    void set_bb_gain(float value);                  // gr_mod_qpsk::set_bb_gain
+    int work(int noutput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) override;
+private:
+    qrl_mod* d_h = nullptr; uint8_t* d_bytes = nullptr; float* d_iq = nullptr;
+    static constexpr size_t kMaxBytes = 8192;
+};

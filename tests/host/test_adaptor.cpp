@@ -1,0 +1,83 @@
+// Drives the GNU Radio-shaped adaptor blocks the way the scheduler would: work() with arbitrary item counts.
+//   test_adaptor nodevice                      -> expects std::runtime_error from construction (exit 0 if thrown)
+//   test_adaptor rx <family> <sps> <fw> <fm> <device_rate> <offset> <iq.bin> <bits_a.bin> <bits_b.bin>
+//   test_adaptor tx <bytes.bin> <iq.bin>
+#include "gr_hip_blocks.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+static std::vector<char> slurp(const char* path)
+{
+    std::ifstream f(path, std::ios::binary);
+    return std::vector<char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+static void dump(const char* path, const void* p, size_t n)
+{
+    std::ofstream f(path, std::ios::binary);
+    f.write(static_cast<const char*>(p), (std::streamsize)n);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) return 2;
+    try {
+        if (!strcmp(argv[1], "nodevice")) {
+            try { qrl_runtime rt(0); } catch (const std::runtime_error& e) { std::printf("runtime_error: %s\n", e.what()); return 0; }
+            std::printf("a device is present\n");
+            return 0;
+        }
+        qrl_runtime rt(0);
+        if (!strcmp(argv[1], "rx") && argc == 11) {
+            const std::string fam = argv[2];
+            const int sps = atoi(argv[3]), fw = atoi(argv[4]), fm = atoi(argv[5]), rate = atoi(argv[6]);
+            gr_demod_hip_sptr d = fam == "2fsk" ? make_gr_demod_2fsk_hip(rt, sps, 1000000, 1700, fw, fm != 0)
+                                : fam == "gmsk" ? make_gr_demod_gmsk_hip(rt, sps, 1000000, 1700, fw)
+                                                : make_gr_demod_qpsk_hip(rt, sps, 1000000, 1700, fw);
+            if (rate != 1000000) d->set_device_samp_rate(rate);
+            d->set_carrier_offset(atof(argv[7]));
+            std::vector<char> raw = slurp(argv[8]);
+            const gr_complex* x = reinterpret_cast<const gr_complex*>(raw.data());
+            const size_t n = raw.size() / sizeof(gr_complex);
+            std::vector<unsigned char> a, b;
+            size_t pos = 0; unsigned k = 0;
+            static const int sizes[] = {8191, 4096, 1, 33333, 7, 65536, 12345};
+            gr_vector_void_star outs;
+            while (pos < n) {
+                const size_t take = std::min<size_t>(n - pos, (size_t)sizes[k++ % 7]);
+                gr_vector_const_void_star ins(1, x + pos);
+                if (d->work((int)take, ins, outs) != (int)take) return 3;
+                pos += take;
+                for (int nr = 1; nr <= 2; ++nr)
+                    if (std::vector<unsigned char>* v = d->get_data(nr)) { (nr == 1 ? a : b).insert((nr == 1 ? a : b).end(), v->begin(), v->end()); delete v; }
+            }
+            dump(argv[9], a.data(), a.size());
+            dump(argv[10], b.data(), b.size());
+            std::printf("rx ok: %zu samples -> %zu / %zu bits\n", n, a.size(), b.size());
+            return 0;
+        }
+        if (!strcmp(argv[1], "tx") && argc == 4) {
+            gr_mod_hip_sptr m = make_gr_mod_qpsk_hip(rt, 4, 1000000, 1700, 160000);
+            std::vector<char> raw = slurp(argv[2]);
+            std::vector<gr_complex> out(raw.size() * 32);
+            size_t pos = 0; unsigned k = 0;
+            static const int nb[] = {1, 100, 9000, 17, 2048};
+            while (pos < raw.size()) {
+                const size_t take = std::min<size_t>(raw.size() - pos, (size_t)nb[k++ % 5]);
+                gr_vector_const_void_star ins(1, raw.data() + pos);
+                gr_vector_void_star outs(1, out.data() + pos * 32);
+                if (m->work((int)(take * 32), ins, outs) != (int)(take * 32)) return 3;
+                pos += take;
+            }
+            dump(argv[3], out.data(), out.size() * sizeof(gr_complex));
+            std::printf("tx ok: %zu bytes -> %zu samples\n", raw.size(), out.size());
+            return 0;
+        }
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "exception: %s\n", e.what());
+        return 1;
+    }
+    return 2;
+}
