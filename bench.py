@@ -93,7 +93,8 @@ def run_workload(name, args, torch, q, ctx, dev, rank, world):
     fe_decim = rate // 1000000 if rate >= 2000000 else 50
     bytes_per_launch = batch * nsamp * 8.0 * (1.0 + 1.0 / fe_decim)
     ach = bytes_per_launch / (kms / max(launches, 1) * 1e-3) / 1e9 if kms > 0 else 0.0
-    return dict(label=label, batch=batch, nsamp=nsamp, rate=rate, seconds=dt, msps=total_samples / dt / 1e6,
+    return dict(name=name, default_shape=(batch == dbatch and nsamp == (dns & ~1)),
+                label=label, batch=batch, nsamp=nsamp, rate=rate, seconds=dt, msps=total_samples / dt / 1e6,
                 ms_per_step=dt / args.steps * 1e3, kernel=kname, kernel_ms=kms / max(launches, 1), launches=launches,
                 achieved_gbps=ach, bits_per_stream=int(counts[:, 2].mean()), bytes_per_launch=bytes_per_launch)
 
@@ -150,8 +151,18 @@ def main():
             base = cpu_baseline(args.config, min(os.cpu_count() or 1, 16))
     if rank == 0:
         def roof(r):
+            # HBM traffic per launch of the dominant kernel: PMC numbers cannot be collected from inside this process;
+            # they come from the separate rocprofv3 --pmc passes of tools/gpu_profile_final.sh (FETCH_SIZE doubled per
+            # the gfx950 correction + WRITE_SIZE), stored in profiles/pmc_traffic.json for the DEFAULT workload shape.
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(r["name"])
+                if pmc and r["default_shape"] and r["kernel"] in pmc["kernel"]:
+                    traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
+            except (OSError, ValueError, KeyError):
+                pass
             return dict(bound="hbm", achieved=round(r["achieved_gbps"], 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                        frac=round(r["achieved_gbps"] / HBM_PEAK_GBPS, 4), traffic=None, kernel=r["kernel"],
+                        frac=round(r["achieved_gbps"] / HBM_PEAK_GBPS, 4), traffic=traffic, kernel=r["kernel"],
                         kernel_ms=round(r["kernel_ms"], 4), launches=r["launches"],
                         algorithmic_bytes_per_launch=r["bytes_per_launch"])
         line = {
