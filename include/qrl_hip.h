@@ -147,6 +147,32 @@ int qrl_mod_process(qrl_mod* m, const uint8_t* bytes, size_t stride, size_t nbyt
 int qrl_mod_sync(qrl_mod* m);
 void* qrl_mod_stream(qrl_mod* m);
 
+/* ---- multi-carrier MMDVM receiver (reference src/gr/gr_demod_mmdvm_multi2.cpp:19-38,58-135) ---------------------
+ * make_gr_demod_mmdvm_multi2(burst_timer, num_channels, channel_separation, use_tdma, sps, samp_rate, carrier_freq,
+ * filter_width): stream_to_streams + pfb_channelizer_ccf + per channel {24/25 resampler, LPF, FM discriminator,
+ * level, float_to_short}.  The reference fixes 10 branches at 250 ksps (src/config_mmdvm.h:4); here num_channels = M
+ * (2..64) at fs = 25 kHz * M.  Channel c is centred at +c*fs/M (c > M/2: negative offsets); the reference's port
+ * order {0,1,2,3,9,8,7} and the TDMA tagging / ZeroMQ framing of gr_mmdvm_sink (src/gr/gr_mmdvm_sink.cpp:66-176)
+ * stay with the caller.  channel_first/channel_count select the channels THIS handle produces: ranks of a multi-GPU job
+ * take disjoint ranges (no data-path collective). */
+typedef struct qrl_chan qrl_chan;
+typedef struct {
+    int num_channels;        /* M: PFB branches = channels on the fs/M grid */
+    int channel_first, channel_count;   /* produced range; channel_count <= 0: all */
+    int batch;               /* independent wideband inputs per call */
+    size_t max_chunk;        /* largest n (wideband samples per input) of any call */
+    void* hip_stream;
+} qrl_chan_config;
+int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** out);
+void qrl_chan_destroy(qrl_chan* c);
+int qrl_chan_reset(qrl_chan* c);
+int qrl_chan_set_level(qrl_chan* c, float level);   /* _level_control multiply_const_ff, gr_demod_mmdvm_multi2.cpp:84 */
+size_t qrl_chan_out_cap(const qrl_chan* c, size_t n);   /* int16 samples per channel a call with n inputs can produce */
+/* replaces one scheduler pass of the multi-carrier graph: iq[b*stride + i] device cf32, n a multiple of num_channels;
+ * out[(b*channel_count + c)*out_cap + k] device int16 @24 ksps, counts[b*channel_count + c] = samples written. */
+int qrl_chan_process(qrl_chan* c, const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts);
+int qrl_chan_sync(qrl_chan* c);
+
 /* ---- filter design & tables (host side, no GPU needed): what the kernels are loaded with ----
  * replaces: gr::filter::firdes::* calls at gr_demod_2fsk.cpp:82-97, gr_demod_gmsk.cpp:80-98,
  * gr_demod_qpsk.cpp:92-103, gr_demod_base.cpp:1333-1336.  taps==NULL returns the count. */

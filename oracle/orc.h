@@ -115,6 +115,11 @@ size_t orc_mod_qpsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate,
 /* TX back end of gr_mod_base: interpolate 1 Msps -> fs with low_pass(I, fs, 480k, 20k, BH) */
 size_t orc_tx_interp(const cf32* in, size_t n, int samp_rate, cf32* out);
 
+/* multi-carrier MMDVM RX (gr_demod_mmdvm_multi2): PFB channelizer + per-channel 24/25 resampler, LPF, FM discriminator, int16 */
+int    orc_chan_proto_taps(int M, float* taps);
+size_t orc_pfb_channelizer(const cf32* in, size_t n, const float* taps, int nt, int M, cf32* out);
+size_t orc_demod_mmdvm_multi(const cf32* in, size_t n, int M, int16_t* out, size_t cap);
+
 /* batch drivers (OpenMP over streams) used by the cpu_baseline leg of bench.py */
 enum { ORC_MODE_2FSK_1K = 0, ORC_MODE_GMSK_10K = 1, ORC_MODE_QPSK_250K = 2 };
 double orc_batch_rx(int mode, const cf32* iq, int batch, size_t n, int samp_rate, double carrier_offset_hz,

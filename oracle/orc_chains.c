@@ -425,3 +425,91 @@ double orc_batch_rx(int mode, const cf32* iq, int batch, size_t n, int samp_rate
     if (bit_checksum) *bit_checksum = total;
     return now_s() - t0;
 }
+
+/* ------------------------------- multi-carrier MMDVM RX (C4) ---------------------------------
+ * gr_demod_mmdvm_multi2 (reference src/gr/gr_demod_mmdvm_multi2.cpp:58-135):
+ *   stream_to_streams(M) -> pfb_channelizer_ccf(M, low_pass_2(1, fs, 5000, 2000, 60, BH), 1.0) ->
+ *   per channel: rational_resampler_ccf(24, 25, low_pass_2(1, 600k, 5000, 2000, 60, BH)) ->
+ *   fft_filter_ccf(low_pass_2(1, 24k, 5000, 2000, 60, BH)) -> quadrature_demod_cf(24000 / (2 pi 12500)) ->
+ *   multiply_const_ff(1.0) -> float_to_short(1, 32767).
+ * The reference fixes M = 10, fs = 250 ksps (src/config_mmdvm.h:4); M and fs = 25 kHz * M are parameters here
+ * so that BASELINE's 64-channel extrapolation uses the same code.  Channel c is centred at +c*fs/M
+ * (c > M/2: negative frequencies), the reference's port map {0,1,2,3,9,8,7} is the caller's business.
+ *
+ * pfb_channelizer_ccf [gr-filter/lib/pfb_channelizer_ccf_impl.cc, polyphase_filterbank.cc], oversample 1:
+ *   branch p: taps h[p + M k];  v_p[n] = sum_k h[p + M k] * x[M n - p - M k]   (one fmaf chain, k ascending)
+ *   channel c: y_c[n] = sum_{p=0}^{M-1} v_p[n] * W[(p c) mod M],  W[q] = exp(+j 2 pi q / M)  rounded to float,
+ *   each product computed as (re, im) = (fmaf(v.re, w.re, -(v.im*w.im)), fmaf(v.re, w.im, v.im*w.re)) and
+ *   accumulated p ascending with plain adds.  (Upstream runs an unnormalised backward FFTW of size M; any FFT
+ *   factorisation rounds differently, so the direct sum is the contract.) */
+int orc_chan_proto_taps(int M, float* taps)
+{
+    return orc_low_pass_2(1, 25000.0 * M, 5000, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, taps);
+}
+size_t orc_pfb_channelizer(const cf32* in, size_t n, const float* taps, int nt, int M, cf32* out /* [M][n/M] */)
+{
+    const size_t nout = n / (size_t)M;
+    cf32* W = NEW(cf32, M);
+    for (int q = 0; q < M; q++) { W[q].re = (float)cos(2 * M_PI * q / M); W[q].im = (float)sin(2 * M_PI * q / M); }
+    cf32* v = NEW(cf32, M);
+    for (size_t m = 0; m < nout; m++) {
+        for (int p = 0; p < M; p++) {
+            float ar = 0.f, ai = 0.f;
+            for (int k = 0; p + M * k < nt; k++) {
+                long long idx = (long long)m * M - p - (long long)M * k;
+                if (idx < 0) break;
+                ar = fmaf(taps[p + M * k], in[idx].re, ar);
+                ai = fmaf(taps[p + M * k], in[idx].im, ai);
+            }
+            v[p].re = ar; v[p].im = ai;
+        }
+        for (int c = 0; c < M; c++) {
+            float yr = 0.f, yi = 0.f;
+            for (int p = 0; p < M; p++) {
+                const cf32 w = W[(int)(((long long)p * c) % M)];
+                yr = yr + fmaf(v[p].re, w.re, -(v[p].im * w.im));
+                yi = yi + fmaf(v[p].re, w.im, v[p].im * w.re);
+            }
+            out[(size_t)c * nout + m].re = yr; out[(size_t)c * nout + m].im = yi;
+        }
+    }
+    free(W); free(v);
+    return nout;
+}
+/* float_to_short(1, scale): rint, saturate (gr-blocks float_array_to_int-style) */
+static int16_t f2s(float x, float scale)
+{
+    float r = rintf(x * scale);
+    if (r > 32767.0f) r = 32767.0f;
+    if (r < -32768.0f) r = -32768.0f;
+    return (int16_t)r;
+}
+/* whole C4 RX chain; out: [M][cap] int16, returns samples per channel (cap must be >= n/M*24/25 + 2) */
+size_t orc_demod_mmdvm_multi(const cf32* in, size_t n, int M, int16_t* out, size_t cap)
+{
+    int nt = orc_chan_proto_taps(M, NULL);
+    float* taps = NEW(float, nt);
+    orc_chan_proto_taps(M, taps);
+    const size_t n1 = n / (size_t)M;
+    cf32* ch = NEW(cf32, (size_t)M * n1);
+    orc_pfb_channelizer(in, n, taps, nt, M, ch);
+    free(taps);
+    int nr = orc_low_pass_2(1, 600000, 5000, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* rt = NEW(float, nr);
+    orc_low_pass_2(1, 600000, 5000, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, rt);
+    int nf = orc_low_pass_2(1, 24000, 5000, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* ft = NEW(float, nf);
+    orc_low_pass_2(1, 24000, 5000, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, ft);
+    const size_t n2 = orc_decim_count(n1, 24, 25);
+    const float gain = (float)(24000.0f / (2 * M_PI * 12500.0f));
+    cf32* a = NEW(cf32, n2); cf32* b = NEW(cf32, n2); float* d = NEW(float, n2);
+    size_t m = n2 < cap ? n2 : cap;
+    for (int c = 0; c < M; c++) {
+        orc_resamp_ccf(ch + (size_t)c * n1, n1, rt, nr, 24, 25, a);
+        orc_fir_ccf(a, n2, ft, nf, b);
+        orc_quad_demod(b, n2, gain, d);
+        for (size_t i = 0; i < m; i++) out[(size_t)c * cap + i] = f2s(d[i] * 1.0f, 32767.0f);
+    }
+    free(a); free(b); free(d); free(rt); free(ft); free(ch);
+    return m;
+}

@@ -37,6 +37,11 @@ class _ModConfig(C.Structure):
                 ("hip_stream", C.c_void_p), ("bb_gain", C.c_float)]
 
 
+class _ChanConfig(C.Structure):
+    _fields_ = [("num_channels", C.c_int), ("channel_first", C.c_int), ("channel_count", C.c_int), ("batch", C.c_int),
+                ("max_chunk", C.c_size_t), ("hip_stream", C.c_void_p)]
+
+
 class _Out(C.Structure):
     _fields_ = [("filtered", C.c_void_p), ("filtered_cap", C.c_size_t), ("constellation", C.c_void_p),
                 ("constellation_cap", C.c_size_t), ("bits_a", C.c_void_p), ("bits_cap", C.c_size_t),
@@ -84,6 +89,14 @@ def load_library():
     lib.qrl_mod_sync.argtypes = [vp]
     lib.qrl_mod_stream.restype = vp
     lib.qrl_mod_stream.argtypes = [vp]
+    lib.qrl_chan_create.argtypes = [vp, C.POINTER(_ChanConfig), C.POINTER(vp)]
+    lib.qrl_chan_destroy.argtypes = [vp]
+    lib.qrl_chan_reset.argtypes = [vp]
+    lib.qrl_chan_set_level.argtypes = [vp, C.c_float]
+    lib.qrl_chan_out_cap.restype = sz
+    lib.qrl_chan_out_cap.argtypes = [vp, sz]
+    lib.qrl_chan_process.argtypes = [vp, vp, sz, sz, vp, sz, vp]
+    lib.qrl_chan_sync.argtypes = [vp]
     lib.qrl_firdes_low_pass.argtypes = [C.c_double] * 4 + [C.c_int, vp]
     lib.qrl_firdes_low_pass_2.argtypes = [C.c_double] * 5 + [C.c_int, vp]
     lib.qrl_firdes_complex_band_pass.argtypes = [C.c_double] * 5 + [C.c_int, vp]
@@ -101,7 +114,9 @@ EXPORTED_SYMBOLS = [
     "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_out_caps",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain",
-    "qrl_mod_samples_per_byte", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_firdes_low_pass",
+    "qrl_mod_samples_per_byte", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_create",
+    "qrl_chan_destroy", "qrl_chan_reset", "qrl_chan_set_level", "qrl_chan_out_cap", "qrl_chan_process", "qrl_chan_sync",
+    "qrl_firdes_low_pass",
     "qrl_firdes_low_pass_2", "qrl_firdes_complex_band_pass", "qrl_firdes_root_raised_cosine", "qrl_table_mmse",
     "qrl_table_atan", "qrl_table_tanh", "qrl_phase_inc_to_turn",
 ]
@@ -241,6 +256,46 @@ class Demod:
     def close(self):
         if self.h:
             self.lib.qrl_demod_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Channelizer:
+    """Multi-carrier MMDVM receiver: mirrors make_gr_demod_mmdvm_multi2 (reference src/gr/gr_demod_mmdvm_multi2.cpp).
+    process(iq) takes complex64 cuda [batch, n] (n multiple of num_channels) and returns (int16 cuda
+    [batch, channel_count, cap], counts int32 [batch, channel_count])."""
+
+    def __init__(self, ctx, num_channels, batch, max_chunk, channel_first=0, channel_count=0, stream=None):
+        import torch
+        self.torch = torch
+        self.ctx, self.lib = ctx, ctx.lib
+        cfg = _ChanConfig()
+        cfg.num_channels, cfg.channel_first, cfg.channel_count = num_channels, channel_first, channel_count
+        cfg.batch, cfg.max_chunk, cfg.hip_stream = batch, max_chunk, stream
+        self.h = C.c_void_p()
+        _check(self.lib.qrl_chan_create(ctx.h, C.byref(cfg), C.byref(self.h)), "qrl_chan_create")
+        self.batch = batch
+        self.cc = channel_count if channel_count > 0 else num_channels
+        self.cap = self.lib.qrl_chan_out_cap(self.h, max_chunk)
+        dev = "cuda:%d" % ctx.device
+        self.out = torch.zeros((batch, self.cc, self.cap), dtype=torch.int16, device=dev)
+        self.counts = torch.zeros((batch, self.cc), dtype=torch.int32, device=dev)
+
+    def process_async(self, iq):
+        assert iq.is_cuda and iq.dtype == self.torch.complex64 and iq.dim() == 2 and iq.shape[0] == self.batch and iq.stride(1) == 1
+        _check(self.lib.qrl_chan_process(self.h, iq.data_ptr(), iq.stride(0), iq.shape[1], self.out.data_ptr(), self.cap,
+                                         self.counts.data_ptr()), "qrl_chan_process")
+
+    def sync(self):
+        _check(self.lib.qrl_chan_sync(self.h), "qrl_chan_sync")
+
+    def process(self, iq):
+        self.process_async(iq)
+        self.sync()
+        return self.out, self.counts
+
+    def close(self):
+        if self.h:
+            self.lib.qrl_chan_destroy(self.h)
             self.h = C.c_void_p()
 
 

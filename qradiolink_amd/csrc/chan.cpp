@@ -1,0 +1,177 @@
+// chan.cpp — host side of the multi-carrier MMDVM receiver (reference src/gr/gr_demod_mmdvm_multi2.cpp:58-135):
+// PFB channelizer -> per channel {rational_resampler_ccf(24,25), fft_filter_ccf, quadrature_demod_cf, level, float_to_short}.
+// A handle owns `batch` wideband inputs and produces the channels [channel_first, channel_first + channel_count):
+// a multi-GPU job gives every rank the same wideband samples (or its own inputs) and a different channel range.
+#include "../../include/qrl_hip.h"
+#include "engine.hpp"
+#include "firdes.hpp"
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace qrl;
+extern int qrl_set_error(int code, const std::string& msg);
+struct qrl_ctx { int device; };
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return qrl_set_error(QRL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+template <class T> struct Buf {
+    T* p = nullptr;
+    ~Buf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) {
+        if (hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return QRL_ERR_NOMEM;
+        return hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)) == hipSuccess ? QRL_OK : QRL_ERR_HIP;
+    }
+    int upload(const std::vector<T>& v) {
+        int r = alloc(v.size());
+        if (r) return r;
+        return v.empty() || hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess ? QRL_OK : QRL_ERR_HIP;
+    }
+};
+uint32_t pow2ge(size_t v) { uint32_t c = 64; while (c < v) c <<= 1; return c; }
+}  // namespace
+
+struct qrl_chan {
+    qrl_ctx* ctx = nullptr;
+    qrl_chan_config cfg{};
+    hipStream_t stream = nullptr; bool own_stream = false;
+    int M = 10, J = 0, nt = 0, rs_Jp = 0, filt_nt = 0;
+    Buf<float> taps, rs_taps, filt_taps, atan_tab; Buf<float2> twiddle;
+    Buf<float2> hist_a, hist_b; uint32_t hist_len = 0; bool flip = false;
+    Buf<float2> r1, r2, r3; Buf<float> r4; uint32_t m1 = 0, m2 = 0;
+    uint64_t n_in = 0, n1 = 0, n2 = 0;
+    float gain = 0, level = 1.0f;
+    size_t zeroed = 0;
+    ~qrl_chan() { if (own_stream && stream) (void)hipStreamDestroy(stream); }
+    int reset_state() {
+        const size_t S = (size_t)cfg.batch * cfg.channel_count;
+        if (hipMemset(hist_a.p, 0, (size_t)cfg.batch * hist_len * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
+        if (hipMemset(hist_b.p, 0, (size_t)cfg.batch * hist_len * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
+        if (hipMemset(r1.p, 0, S * (m1 + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
+        if (hipMemset(r2.p, 0, S * (m2 + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
+        if (hipMemset(r3.p, 0, S * (m2 + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
+        if (hipMemset(r4.p, 0, S * (m2 + 1) * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
+        n_in = n1 = n2 = 0; flip = false;
+        return QRL_OK;
+    }
+};
+
+extern "C" {
+
+int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
+{
+    if (!ctx || !cfg || !outp) return QRL_ERR_ARG;
+    std::unique_ptr<qrl_chan> h(new (std::nothrow) qrl_chan);
+    if (!h) return QRL_ERR_NOMEM;
+    h->ctx = ctx; h->cfg = *cfg;
+    qrl_chan_config& c = h->cfg;
+    if (c.num_channels < 2 || c.num_channels > 64) return qrl_set_error(QRL_ERR_ARG, "num_channels must be 2..64");
+    if (c.channel_count <= 0) { c.channel_first = 0; c.channel_count = c.num_channels; }
+    if (c.channel_first < 0 || c.channel_first + c.channel_count > c.num_channels) return qrl_set_error(QRL_ERR_ARG, "bad channel range");
+    if (c.batch < 1 || c.max_chunk < (size_t)c.num_channels || (size_t)c.batch * c.channel_count > 65535)
+        return qrl_set_error(QRL_ERR_ARG, "bad batch / max_chunk");
+    const int M = h->M = c.num_channels;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (c.hip_stream) h->stream = static_cast<hipStream_t>(c.hip_stream);
+    else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    int r;
+    // prototype: low_pass_2(1, fs, 5000, 2000, 60, BH), fs = 25 kHz * M (gr_demod_mmdvm_multi2.cpp:58-60; 250 ksps for M = 10)
+    const std::vector<float> proto = low_pass_2(1, 25000.0 * M, 5000, 2000, 60, WIN_BLACKMAN_HARRIS);
+    h->nt = (int)proto.size(); h->J = (h->nt + M - 1) / M;
+    if (chan_lds_bytes(M, h->J) > 160 * 1024) return qrl_set_error(QRL_ERR_ARG, "channelizer tile does not fit LDS");
+    std::vector<float> t((size_t)h->J * M, 0.0f);
+    for (int k = 0; k < h->nt; ++k) t[k] = proto[k];
+    if ((r = h->taps.upload(t))) return r;
+    std::vector<float2> W(M);
+    for (int q = 0; q < M; ++q) W[q] = make_float2((float)std::cos(2 * M_PI * q / M), (float)std::sin(2 * M_PI * q / M));
+    if ((r = h->twiddle.upload(W))) return r;
+    const std::vector<float> rt = low_pass_2(1, 600000, 5000, 2000, 60, WIN_BLACKMAN_HARRIS);   // :60-61, used as 24/25 resampler
+    h->rs_Jp = ((int)rt.size() + 23) / 24;
+    std::vector<float> rl((size_t)24 * h->rs_Jp, 0.0f);
+    for (size_t k = 0; k < rt.size(); ++k) rl[(k % 24) * h->rs_Jp + k / 24] = rt[k];
+    if ((r = h->rs_taps.upload(rl))) return r;
+    const std::vector<float> ft = low_pass_2(1, 24000, 5000, 2000, 60, WIN_BLACKMAN_HARRIS);    // :62-63
+    h->filt_nt = (int)ft.size();
+    if ((r = h->filt_taps.upload(ft)) || (r = h->atan_tab.upload(atan_table()))) return r;
+    h->gain = (float)(24000.0f / (2 * M_PI * 12500.0f));                                          // :80
+    h->hist_len = (uint32_t)(h->J * M);
+    const size_t S = (size_t)c.batch * c.channel_count;
+    const size_t max1 = c.max_chunk / M + 2, max2 = max1 * 24 / 25 + 2;
+    h->m1 = pow2ge(max1 + h->rs_Jp + 64) - 1;
+    h->m2 = pow2ge(max2 + h->filt_nt + 64) - 1;
+    if ((r = h->hist_a.alloc((size_t)c.batch * h->hist_len)) || (r = h->hist_b.alloc((size_t)c.batch * h->hist_len)) ||
+        (r = h->r1.alloc(S * (h->m1 + 1))) || (r = h->r2.alloc(S * (h->m2 + 1))) || (r = h->r3.alloc(S * (h->m2 + 1))) ||
+        (r = h->r4.alloc(S * (h->m2 + 1))))
+        return qrl_set_error(r, "channelizer buffers");
+    *outp = h.release();
+    return QRL_OK;
+}
+void qrl_chan_destroy(qrl_chan* h) { if (h) { (void)hipStreamSynchronize(h->stream); delete h; } }
+int qrl_chan_reset(qrl_chan* h)
+{
+    if (!h) return QRL_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return h->reset_state();
+}
+int qrl_chan_set_level(qrl_chan* h, float level) { if (!h) return QRL_ERR_ARG; h->level = level; return QRL_OK; }
+size_t qrl_chan_out_cap(const qrl_chan* h, size_t n) { return h ? (n / h->M + 2) * 24 / 25 + 2 : 0; }
+
+int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts)
+{
+    if (!h || (!iq && n)) return QRL_ERR_ARG;
+    if (n > h->cfg.max_chunk) return qrl_set_error(QRL_ERR_TOO_BIG, "n exceeds max_chunk");
+    if (n % (size_t)h->M) return qrl_set_error(QRL_ERR_ARG, "n must be a multiple of num_channels (stream_to_streams)");
+    if (n == 0) return QRL_OK;
+    HIPCHK(hipSetDevice(h->ctx->device));
+    const int B = h->cfg.batch, M = h->M, CC = h->cfg.channel_count, S = B * CC;
+    const float2* in = reinterpret_cast<const float2*>(iq);
+    const float2* hist_old = h->flip ? h->hist_b.p : h->hist_a.p;
+    float2* hist_new = h->flip ? h->hist_a.p : h->hist_b.p;
+    const uint64_t n1_1 = (h->n_in + n) / M;
+    ChanParams p{};
+    p.in = in; p.in_stride = stride; p.n0 = h->n_in; p.n = (uint32_t)n; p.hist = hist_old; p.hist_len = h->hist_len;
+    p.out = RingC{h->r1.p, h->m1}; p.m0 = h->n1; p.m_count = (uint32_t)(n1_1 - h->n1);
+    p.taps = h->taps.p; p.twiddle = h->twiddle.p; p.M = M; p.J = h->J; p.c_first = h->cfg.channel_first; p.c_count = CC;
+    launch_pfb_chan(p, B, h->stream);
+    HistParams hp{};
+    hp.in = in; hp.in_stride = stride; hp.n0 = h->n_in; hp.n = (uint32_t)n;
+    hp.hist_old = hist_old; hp.hist_new = hist_new; hp.hist_len = h->hist_len; hp.rot_enable = 0;
+    launch_hist_save(hp, B, h->stream);
+    h->flip = !h->flip;
+    // per channel chain on S = batch * channel_count streams
+    const uint64_t n2_1 = n1_1 ? ((n1_1 - 1) * 24 + 23) / 25 + 1 : 0;
+    const uint32_t c2 = (uint32_t)(n2_1 - h->n2);
+    ResampParams rp{};
+    rp.in = nullptr; rp.in_ring = RingC{h->r1.p, h->m1}; rp.n0 = h->n1; rp.n = (uint32_t)(n1_1 - h->n1);
+    rp.out = RingC{h->r2.p, h->m2}; rp.q0 = h->n2; rp.q_count = c2; rp.taps = h->rs_taps.p; rp.I = 24; rp.D = 25; rp.Jp = h->rs_Jp;
+    launch_resamp(rp, S, h->stream);
+    FirCcfParams fp{};
+    fp.in = RingC{h->r2.p, h->m2}; fp.out = RingC{h->r3.p, h->m2}; fp.q0 = h->n2; fp.count = c2; fp.taps = h->filt_taps.p; fp.nt = h->filt_nt;
+    launch_fir_ccf(fp, S, h->stream);
+    QuadDemodParams qp{};
+    qp.in = RingC{h->r3.p, h->m2}; qp.out = RingF{h->r4.p, h->m2}; qp.q0 = h->n2; qp.count = c2; qp.gain = h->gain; qp.atan_tab = h->atan_tab.p;
+    launch_quad_demod(qp, S, h->stream);
+    F2sParams sp{};
+    sp.in = RingF{h->r4.p, h->m2}; sp.q0 = h->n2; sp.count = c2; sp.level = h->level; sp.scale = 32767.0f;
+    sp.out = out; sp.cap = out_cap; sp.counts = counts;
+    if (out) launch_f2s(sp, S, h->stream);
+    HIPCHK(hipGetLastError());
+    h->n_in += n; h->n1 = n1_1; h->n2 = n2_1;
+    return QRL_OK;
+}
+int qrl_chan_sync(qrl_chan* h)
+{
+    if (!h) return QRL_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return QRL_OK;
+}
+
+}  // extern "C"

@@ -125,6 +125,19 @@ struct FecParams {
 };
 void launch_fec(const FecParams& p, int batch, hipStream_t s);
 
+// ---- multi-carrier MMDVM RX (kernels_chan.hip) ----
+struct ChanParams {
+    const float2* in; size_t in_stride; uint64_t n0; uint32_t n;   // wideband caller IQ of this call (n multiple of M)
+    const float2* hist; uint32_t hist_len;                         // last hist_len samples before n0
+    RingC out; uint64_t m0; uint32_t m_count;                      // channel rings [batch * c_count], output instants
+    const float* taps; const float2* twiddle;                      // taps[p + M k] zero padded to J*M; W[q] = e^{+j 2 pi q / M}
+    int M, J, c_first, c_count;
+};
+struct F2sParams { RingF in; uint64_t q0; uint32_t count; float level, scale; int16_t* out; size_t cap; uint32_t* counts; };
+void launch_pfb_chan(const ChanParams& p, int batch, hipStream_t s);
+void launch_f2s(const F2sParams& p, int batch, hipStream_t s);
+size_t chan_lds_bytes(int M, int J);
+
 // ---- TX: gr_mod_qpsk (kernels_tx.hip) ----
 struct TxState { uint32_t sr, enc, prev, pad; };   // scrambler register, last 6 scrambled bits, last differential symbol
 struct TxBitsParams {

@@ -1,0 +1,108 @@
+// kernels_chan.hip — multi-carrier front end of the MMDVM path (reference src/gr/gr_demod_mmdvm_multi2.cpp:98-101):
+//   stream_to_streams(M) + pfb_channelizer_ccf(M, taps, 1.0)  ->  M channels at fs / M, channel c centred at +c fs/M.
+//  k_pfb_chan : workgroup = TI output instants of one wideband stream.  Phase 1: the M polyphase branch FIRs
+//     v_p[n] = sum_k h[p + M k] x[M n - p - M k] (one fmaf chain per branch, k ascending) out of an LDS copy of the
+//     input tile.  Phase 2: the M-point DFT y_c = sum_p v_p W[(p c) mod M], written as the direct sum the oracle
+//     defines (upstream runs FFTW; every FFT factorisation rounds differently).  Only the channels
+//     [c_first, c_first + c_count) are produced: a rank of a channel-sharded job computes just its own bins.
+//     The input is read from HBM exactly once; the tile halo (nt - 1 samples) comes from L2 / the history buffer.
+//  k_f2s      : multiply_const_ff(level) + float_to_short(1, 32767) (gr_demod_mmdvm_multi2.cpp:84,92).
+#include "devmath.hpp"
+#include "engine.hpp"
+
+namespace qrl {
+
+constexpr int CH_TI = 64;   // output instants per workgroup
+
+__global__ __launch_bounds__(256) void k_pfb_chan(const ChanParams P)
+{
+    extern __shared__ __align__(16) unsigned char ch_smem[];
+    const int M = P.M, J = P.J;
+    float2* xs = reinterpret_cast<float2*>(ch_smem);              // (TI + J) * M input samples, xs[i] = x[first + i]
+    float2* vs = xs + (CH_TI + J) * M;                            // [TI][M + 1] branch outputs
+    float* taps = reinterpret_cast<float*>(vs + CH_TI * (M + 1)); // J * M (zero padded)
+    float2* W = reinterpret_cast<float2*>(taps + J * M);          // M twiddles
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const uint64_t m_t = P.m0 + (uint64_t)blockIdx.x * CH_TI;     // first output instant of this tile (absolute)
+    const int64_t first = (int64_t)m_t * M - (int64_t)(J * M - 1);// oldest sample any branch of the tile reads
+    const int nsamp = (CH_TI + J) * M;
+    for (int i = tid; i < J * M; i += 256) taps[i] = P.taps[i];
+    for (int i = tid; i < M; i += 256) W[i] = P.twiddle[i];
+    for (int i = tid; i < nsamp; i += 256) {
+        const int64_t a = first + i;
+        float2 x = make_float2(0.f, 0.f);
+        if (a >= 0 && (uint64_t)a < P.n0 + P.n) {
+            if ((uint64_t)a >= P.n0) x = P.in[(size_t)b * P.in_stride + (size_t)((uint64_t)a - P.n0)];
+            else {
+                const uint64_t d = P.n0 - (uint64_t)a;
+                if (d <= P.hist_len) x = P.hist[(size_t)b * P.hist_len + (P.hist_len - (uint32_t)d)];
+            }
+        }
+        xs[i] = x;
+    }
+    __syncthreads();
+    // phase 1: branch (i, p) reads x[M (m_t + i) - p - M k] = xs[(J * M - 1) + M i - p - M k]
+    for (int w = tid; w < CH_TI * M; w += 256) {
+        const int i = w / M, p = w - i * M;
+        const float2* xp = xs + (J * M - 1) + M * i - p;
+        float ar = 0.f, ai = 0.f;
+        for (int k = 0; k < J; ++k) {
+            const float h = taps[p + M * k];
+            const float2 x = xp[-M * k];
+            ar = fmaf(h, x.x, ar);
+            ai = fmaf(h, x.y, ai);
+        }
+        vs[i * (M + 1) + p] = make_float2(ar, ai);
+    }
+    __syncthreads();
+    // phase 2: DFT bins of the owned channels
+    const uint32_t count = P.m_count;
+    for (int w = tid; w < CH_TI * P.c_count; w += 256) {
+        const int cc = w / CH_TI, i = w - cc * CH_TI;             // instant fastest: coalesced ring writes
+        const int c = P.c_first + cc;
+        if (blockIdx.x * (uint32_t)CH_TI + i >= count) continue;
+        const float2* v = vs + i * (M + 1);
+        float yr = 0.f, yi = 0.f;
+        int q = 0;                                                // (p * c) mod M
+        for (int p = 0; p < M; ++p) {
+            const float2 wv = W[q];
+            yr = yr + fmaf(v[p].x, wv.x, -(v[p].y * wv.y));
+            yi = yi + fmaf(v[p].x, wv.y, v[p].y * wv.x);
+            q += c; if (q >= M) q -= M;
+        }
+        const uint64_t m = m_t + i;
+        P.out.p[((size_t)b * P.c_count + cc) * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = make_float2(yr, yi);
+    }
+}
+
+size_t chan_lds_bytes(int M, int J)
+{
+    return (size_t)((CH_TI + J) * M + CH_TI * (M + 1) + M) * sizeof(float2) + (size_t)J * M * sizeof(float);
+}
+void launch_pfb_chan(const ChanParams& p, int batch, hipStream_t s)
+{
+    if (!p.m_count) return;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pfb_chan), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_pfb_chan, dim3((p.m_count + CH_TI - 1) / CH_TI, batch), dim3(256), chan_lds_bytes(p.M, p.J), s, p);
+}
+
+__global__ __launch_bounds__(256) void k_f2s(const F2sParams P)
+{
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.count) return;
+    const float x = P.in.p[(size_t)b * (P.in.mask + 1u) + ((uint32_t)(P.q0 + t) & P.in.mask)];
+    float r = rintf((x * P.level) * P.scale);
+    if (r > 32767.0f) r = 32767.0f;
+    if (r < -32768.0f) r = -32768.0f;
+    if (t < P.cap) P.out[(size_t)b * P.cap + t] = (int16_t)r;
+    if (t == 0 && P.counts) P.counts[b] = P.count < P.cap ? P.count : (uint32_t)P.cap;
+}
+void launch_f2s(const F2sParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_f2s, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
+}
+
+}  // namespace qrl

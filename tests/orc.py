@@ -84,6 +84,9 @@ _sig("orc_mod_2fsk", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, 
 _sig("orc_mod_gmsk", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p)
 _sig("orc_mod_qpsk", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p)
 _sig("orc_tx_interp", _sz, _p, _sz, C.c_int, _p)
+_sig("orc_chan_proto_taps", C.c_int, C.c_int, _p)
+_sig("orc_pfb_channelizer", _sz, _p, _sz, _p, C.c_int, C.c_int, _p)
+_sig("orc_demod_mmdvm_multi", _sz, _p, _sz, C.c_int, _p, _sz)
 _sig("orc_batch_rx", C.c_double, C.c_int, _p, C.c_int, _sz, C.c_int, C.c_double, C.c_int, _p)
 
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECT, WIN_BH = 0, 1, 2, 3, 5
@@ -289,6 +292,29 @@ def descramble(bits, mask=0x8A, seed=0x7F, length=7):
     out = np.zeros_like(bits)
     lib.orc_descramble(_ptr(bits), bits.size, mask, seed, length, _ptr(out))
     return out
+
+
+def chan_proto_taps(M):
+    n = lib.orc_chan_proto_taps(M, None)
+    t = np.zeros(n, np.float32)
+    lib.orc_chan_proto_taps(M, _ptr(t))
+    return t
+
+
+def pfb_channelizer(x, taps, M):
+    x = np.ascontiguousarray(x, cf32)
+    taps = np.ascontiguousarray(taps, np.float32)
+    out = np.zeros((M, x.size // M), cf32)
+    lib.orc_pfb_channelizer(_ptr(x), x.size, _ptr(taps), taps.size, M, _ptr(out))
+    return out
+
+
+def demod_mmdvm_multi(x, M):
+    x = np.ascontiguousarray(x, cf32)
+    cap = (x.size // M) * 24 // 25 + 4
+    out = np.zeros((M, cap), np.int16)
+    n = lib.orc_demod_mmdvm_multi(_ptr(x), x.size, M, _ptr(out), cap)
+    return out[:, :n].copy()
 
 
 def batch_rx(mode, iq, samp_rate, carrier_offset_hz=0.0, threads=0):
