@@ -230,3 +230,32 @@ def test_two_branch_alignment_exactly_one_branch_locks():
     r = orc.demod_gmsk(y, sps=1, filter_width=20000)
     ok = [_frames_ok("gmsk10k", r[k], payloads) for k in ("bits_a", "bits_b")]
     assert sorted(ok) == [0, 3]
+
+
+# ---- multi-carrier MMDVM RX (gr_demod_mmdvm_multi2.cpp:98): channel orientation and FM scaling
+@pytest.mark.parametrize("M", [10, 64])
+def test_pfb_channelizer_single_tone_lands_in_its_channel(M):
+    """A.13: channel c is centred at +c*fs/M (c > M/2: negative offsets), consistent with the reference's port map
+    {0,1,2,3,9,8,7} = {0,+25,+50,+75,-25,-50,-75 kHz} (docs/README_MMDVM_operation.md:136-157)."""
+    fs = 25000.0 * M
+    taps = orc.chan_proto_taps(M)
+    assert taps.size == {10: 341, 64: 2181}[M]
+    t = np.arange(M * 3000)
+    for c in (0, 1, 3, M - 1, M // 2 + 1):
+        f = c * 25000.0 if c <= M // 2 else (c - M) * 25000.0
+        x = np.exp(2j * np.pi * (f + 300.0) * t / fs).astype(np.complex64)
+        p = np.mean(np.abs(orc.pfb_channelizer(x, taps, M)[:, 200:]) ** 2, axis=1)
+        assert int(np.argmax(p)) == c and abs(p[c] - 1.0) < 1e-3 and np.sort(p)[-2] < 1e-9
+
+
+def test_mmdvm_chain_fm_deviation_scaling():
+    """quadrature_demod gain 24000/(2 pi 12500) and float_to_short(32767): a +-2 kHz deviation reads +-5242 counts"""
+    M, fs = 10, 250000.0
+    t = np.arange(M * 30000)
+    dev, fm = 2000.0, 400.0
+    ph = 2 * np.pi * (2 * 25000.0) * t / fs + (dev / fm) * np.sin(2 * np.pi * fm * t / fs)
+    o = orc.demod_mmdvm_multi((0.5 * np.exp(1j * ph)).astype(np.complex64), M)
+    assert o.shape == (10, 28800)
+    peak = np.abs(o[2, 2000:].astype(np.int32)).max()
+    assert abs(peak - 32767 * dev / 12500.0) < 40
+    assert np.abs(o[5, 2000:].astype(np.int32)).max() > 20000   # an empty channel is discriminator noise, full scale
