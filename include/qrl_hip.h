@@ -39,7 +39,7 @@ typedef enum {
 enum {
     QRL_MODEM_2FSK2KFM = 15, QRL_MODEM_2FSK1KFM = 16, QRL_MODEM_2FSK2K = 17, QRL_MODEM_2FSK1K = 18,
     QRL_MODEM_2FSK10KFM = 19, QRL_MODEM_GMSK2K = 20, QRL_MODEM_GMSK1K = 21, QRL_MODEM_GMSK10K = 22,
-    QRL_MODEM_QPSK250K = 26
+    QRL_MODEM_QPSK250K = 26, QRL_MODEM_DMR = 41
 };
 
 typedef struct qrl_ctx qrl_ctx;

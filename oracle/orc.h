@@ -115,6 +115,8 @@ size_t orc_mod_qpsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate,
 /* TX back end of gr_mod_base: interpolate 1 Msps -> fs with low_pass(I, fs, 480k, 20k, BH) */
 size_t orc_tx_interp(const cf32* in, size_t n, int samp_rate, cf32* out);
 
+void orc_demod_dmr(const cf32* in, size_t n, int sps, int samp_rate, orc_demod_out* o);
+void orc_4fsk_symbols_to_bits(const float* sym, size_t nsym, cf32* constellation, uint8_t* bits);
 /* multi-carrier MMDVM RX (gr_demod_mmdvm_multi2): PFB channelizer + per-channel 24/25 resampler, LPF, FM discriminator, int16 */
 int    orc_chan_proto_taps(int M, float* taps);
 size_t orc_pfb_channelizer(const cf32* in, size_t n, const float* taps, int nt, int M, cf32* out);

@@ -513,3 +513,51 @@ size_t orc_demod_mmdvm_multi(const cf32* in, size_t n, int M, int16_t* out, size
     free(a); free(b); free(d); free(rt); free(ft); free(ch);
     return m;
 }
+
+/* ------------------------------- DMR / 4FSK symbol demodulator (a37) ---------------------------------
+ * gr_demod_dmr (reference src/gr/gr_demod_dmr.cpp:36-105, instance make_gr_demod_dmr(5, 1000000) gr_demod_base.cpp:253):
+ *   rational_resampler_ccf(3, 125, low_pass_2(3, 3e6, 5000, 2000, 60, BH)) -> [port 0] -> quadrature_demod_cf(24000/(pi/2*4800))
+ *   -> fft_filter_fff(RRC(1, 24000, 4800, 0.2, 125)) -> symbol_sync_ff(TED_MUELLER_AND_MULLER, 5, 2pi/100, 1.0, 0.2869, 0.06, 1,
+ *   constellation_rect{-1.5,-0.5,0.5,1.5}) -> multiply_const(0.9) -> phase_modulator_fc(pi/2) -> [port 1] -> complex_to_float ->
+ *   interleave -> binary_slicer_fb -> pack_k_bits(2) -> map{3,1,2,0} -> unpack_k_bits(2) -> [port 2].
+ * phase_modulator_fc's sincosf is the deterministic polynomial here (orc_sincosf). */
+void orc_4fsk_symbols_to_bits(const float* sym, size_t nsym, cf32* constellation, uint8_t* bits)
+{
+    static const int map[4] = {3, 1, 2, 0};
+    const float k = (float)(M_PI / 2);
+    for (size_t i = 0; i < nsym; i++) {
+        const float s = sym[i] * 0.9f;
+        cf32 c; orc_sincosf(k * s, &c.im, &c.re);
+        if (constellation) constellation[i] = c;
+        const int v = ((c.re >= 0.0f) << 1) | (c.im >= 0.0f);
+        const int m = map[v];
+        bits[2 * i] = (uint8_t)((m >> 1) & 1); bits[2 * i + 1] = (uint8_t)(m & 1);
+    }
+}
+void orc_demod_dmr(const cf32* in, size_t n, int sps, int samp_rate, orc_demod_out* o)
+{
+    (void)sps;
+    memset(o, 0, sizeof *o);
+    int nt = orc_low_pass_2(3, (double)samp_rate * 3, 5000, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* taps = NEW(float, nt);
+    orc_low_pass_2(3, (double)samp_rate * 3, 5000, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, taps);
+    size_t n1 = orc_decim_count(n, 3, 125);
+    o->filtered = NEW(cf32, n1); o->n_filtered = n1;
+    orc_resamp_ccf(in, n, taps, nt, 3, 125, o->filtered);
+    free(taps);
+    float* d = NEW(float, n1);
+    orc_quad_demod(o->filtered, n1, (float)(24000 / (M_PI / 2 * 4800.0f)), d);
+    int nr = orc_root_raised_cosine(1, 24000, 4800, 0.2, 125, NULL);
+    float* rrc = NEW(float, nr);
+    orc_root_raised_cosine(1, 24000, 4800, 0.2, 125, rrc);
+    float* f = NEW(float, n1);
+    orc_fir_fff(d, n1, rrc, nr, f);
+    free(rrc); free(d);
+    float* sym = NEW(float, n1 / 4 + 16);
+    size_t nsym = orc_symbol_sync_ff(f, n1, ORC_TED_MM, 5.0f, (float)(2 * M_PI / 100.0f), 1.0f, 0.2869f, 0.06f, ORC_CONST_4LEVEL, sym);
+    free(f);
+    o->constellation = NEW(cf32, nsym); o->n_const = nsym;
+    o->bits_a = NEW(uint8_t, 2 * nsym); o->n_bits_a = 2 * nsym;
+    orc_4fsk_symbols_to_bits(sym, nsym, o->constellation, o->bits_a);
+    free(sym);
+}

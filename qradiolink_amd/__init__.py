@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libqrl_hip.so")
 MODEM_2FSK2KFM, MODEM_2FSK1KFM, MODEM_2FSK2K, MODEM_2FSK1K, MODEM_2FSK10KFM = 15, 16, 17, 18, 19
 MODEM_GMSK2K, MODEM_GMSK1K, MODEM_GMSK10K = 20, 21, 22
 MODEM_QPSK250K = 26
+MODEM_DMR = 41
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECTANGULAR, WIN_BLACKMAN_HARRIS = 0, 1, 2, 3, 5
 
 

@@ -117,7 +117,7 @@ struct qrl_demod {
     hipStream_t tail = nullptr;
     hipEvent_t ev_ff = nullptr, ev_tail = nullptr;
     bool tail_pending = false;
-    enum Family { F_2FSK, F_GMSK, F_QPSK } fam = F_2FSK;
+    enum Family { F_2FSK, F_GMSK, F_QPSK, F_DMR } fam = F_2FSK;
     int branches = 2;
 
     // derived chain parameters (gr_demod_2fsk.cpp:39-63, gr_demod_gmsk.cpp:39-63)
@@ -209,6 +209,9 @@ int qrl_demod::build()
         else if (sps == 5) { target = 40000; sps_eff = sps * 2; decim = 25; interp = 1; }
         else if (sps == 1) { target = 80000; sps_eff = 4;       decim = 25; interp = 2; }
         else return fail(QRL_ERR_ARG, "gmsk: unsupported sps");
+    } else if (fam == F_DMR) {
+        // gr_demod_dmr.cpp:36-58: 3/125 resampler to 24 ksps, 5 samples per symbol
+        target = 24000; sps_eff = 5; decim = 125; interp = 3; branches = 1;
     } else {
         // gr_demod_qpsk.cpp:39-60: only the sps <= 4 geometry (QPSK250K: 1:2 decimation, no FLL) is built so far
         if (sps > 4 || sps < 2) return fail(QRL_ERR_ARG, "qpsk: only sps 2..4 (e.g. QPSK250K) is supported by this build");
@@ -229,7 +232,9 @@ int qrl_demod::build()
     if ((r = upload_rot_table())) return r;
 
     // --- per-mode first resampler (gr_demod_2fsk.cpp:82-88, gr_demod_gmsk.cpp:80-83)
-    const std::vector<float> rtaps = fam == F_QPSK
+    const std::vector<float> rtaps = fam == F_DMR
+        ? low_pass_2(3, (double)samp_rate * 3, 5000, 2000, 60, WIN_BLACKMAN_HARRIS)                          // gr_demod_dmr.cpp:55-58
+        : fam == F_QPSK
         ? low_pass_2(interp, (double)interp * samp_rate, target / 2, target / 10, 60, WIN_BLACKMAN_HARRIS)   // gr_demod_qpsk.cpp:92-96
         : low_pass(interp, (double)interp * samp_rate, target / 2, target / 2, WIN_BLACKMAN_HARRIS);
     if (interp == 1) { if ((r = first.plan(rtaps, decim))) return fail(r, "resampler plan"); }
@@ -297,6 +302,13 @@ int qrl_demod::build()
         const float dev = 200.0f / symbol_rate;
         clock_loop_gains((float)(2 * M_PI / (symbol_rate / 10)), 1.0f, 0.2869f, ss_alpha, ss_beta);
         ss_maxp = (float)sps_eff + dev; ss_minp = (float)sps_eff - dev;
+    } else if (fam == F_DMR) {
+        const std::vector<float> rrc = root_raised_cosine(1, target, target / sps_eff, 0.2, 25 * sps_eff);   // gr_demod_dmr.cpp:62-66
+        symf_nt = (int)rrc.size();
+        if ((r = symf_taps.upload(rrc))) return r;
+        demod_gain = (float)(target / (M_PI / 2 * (float)(target / sps_eff)));                               // :72
+        clock_loop_gains((float)(2 * M_PI / 100.0f), 1.0f, 0.2869f, ss_alpha, ss_beta);                      // :70-71
+        ss_maxp = (float)sps_eff + 0.06f; ss_minp = (float)sps_eff - 0.06f;
     } else if (fam == F_QPSK) {
         if ((r = tanh_tab.upload(tanh_table())) || (r = qp_st.alloc(B))) return r;
         control_loop_gains((float)(M_PI / 200 / sps_eff), c1_alpha, c1_beta);     // _costas_pll, gr_demod_qpsk.cpp:110
@@ -375,6 +387,12 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         p.n0 = src0; p.n = (uint32_t)(src1 - src0);
         p.out = r2; p.q0 = n2_0; p.q_count = (uint32_t)(n2_1 - n2_0);
         p.taps = rs_taps.p; p.I = interp; p.D = decim; p.Jp = rs_Jp;
+        if (fam == F_DMR) {   // port 0 of gr_demod_dmr is the resampler output (gr_demod_dmr.cpp:89)
+            const bool sd = cfg.enable_side_outputs && out;
+            p.port = sd && out->filtered ? reinterpret_cast<float2*>(out->filtered) : nullptr;
+            p.port_cap = sd ? out->filtered_cap : 0;
+            p.port_counts = counts;
+        }
         launch_resamp(p, B, stream);
     }
     if (profiling && !fe.used) { HIPCHK(hipEventRecord(ev1, stream)); prof_events.emplace_back(ev0, ev1); }
@@ -400,7 +418,15 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
     }
     const bool fused_2fsk = fam == F_2FSK && !fm && filt_nt <= 41 && disc_nt <= 41 && symf_nt <= 25 &&
                             !(std::getenv("QRL_2FSK_UNFUSED") && std::getenv("QRL_2FSK_UNFUSED")[0] == '1');
-    if (fused_2fsk) {
+    if (fam == F_DMR) {
+        QuadDemodParams q{}; q.in = r2; q.out = r2d; q.q0 = n2_0; q.count = c2; q.gain = demod_gain; q.atan_tab = atan_tab.p;
+        launch_quad_demod(q, B, stream);
+        if (tail_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_tail, 0)); tail_pending = false; }
+        FirFffParams f{}; f.in = r2d; f.out = r3; f.q0 = n2_0; f.count = c2; f.taps = symf_taps.p; f.nt = symf_nt;
+        launch_fir_fff(f, B, stream);
+        HIPCHK(hipEventRecord(ev_ff, stream));
+        HIPCHK(hipStreamWaitEvent(tail, ev_ff, 0));
+    } else if (fused_2fsk) {
         if (tail_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_tail, 0)); tail_pending = false; }
         Fsk2FfParams f{};
         f.in = filt_in; f.out = r3; f.q0 = n2_0; f.count = c2;
@@ -463,18 +489,23 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         SymSyncParams s{};
         s.in = r3; s.avail = n2_1; s.soft = RingB{soft.p, soft_mask}; s.st = ss_st.p; s.mmse = mmse_tab.p;
         s.alpha = ss_alpha; s.beta = ss_beta; s.maxp = ss_maxp; s.minp = ss_minp;
-        s.ted = 1; s.soft_mul = 128.0f; s.soft_add = 128.0f;
+        s.ted = fam == F_DMR ? 0 : 1; s.soft_mul = 128.0f; s.soft_add = 128.0f;
+        s.slicer = fam == F_DMR ? 1 : 0; s.tail = fam == F_DMR ? 1 : 0;
+        s.bits = out ? out->bits_a : nullptr; s.bits_cap = out ? out->bits_cap : 0;
         s.port = side && out->constellation ? reinterpret_cast<float2*>(out->constellation) : nullptr;
         s.port_cap = side ? out->constellation_cap : 0;
         s.counts = counts;
         launch_symsync_ff(s, B, tail);
+        if (fam == F_DMR) { HIPCHK(hipEventRecord(ev_tail, tail)); tail_pending = true; }
         FecParams f{};
         f.soft = RingB{soft.p, soft_mask}; f.avail = &ss_st.p[0].oo; f.avail_stride = sizeof(SymSyncState); f.avail_mul = 1; f.st = fec_st.p;
         f.bits_a = out ? out->bits_a : nullptr; f.bits_b = out ? out->bits_b : nullptr; f.bits_cap = out ? out->bits_cap : 0;
         f.counts = counts; f.branches = branches;
-        launch_fec(f, B, tail);
-        HIPCHK(hipEventRecord(ev_tail, tail));
-        tail_pending = true;
+        if (fam != F_DMR) {
+            launch_fec(f, B, tail);
+            HIPCHK(hipEventRecord(ev_tail, tail));
+            tail_pending = true;
+        }
     }
     HIPCHK(hipGetLastError());
     n_in = n_in1; n1 = n1_1; n2 = n2_1;
@@ -537,6 +568,7 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         case QRL_MODEM_GMSK1K:    c.sps = 10; c.filter_width = 2000;  c.fm = 0; break;
         case QRL_MODEM_GMSK10K:   c.sps = 1;  c.filter_width = 20000; c.fm = 0; break;
         case QRL_MODEM_QPSK250K:  c.sps = 2;  c.filter_width = 160000; c.fm = 0; break;   // gr_demod_base.cpp:223
+        case QRL_MODEM_DMR:       c.sps = 5;  c.filter_width = 5000;   c.fm = 0; break;   // make_gr_demod_dmr(5, 1000000) gr_demod_base.cpp:253
         default: return fail(QRL_ERR_ARG, "modem_type not supported by this build");
         }
     }
@@ -547,6 +579,8 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         d->fam = qrl_demod::F_GMSK; break;
     case QRL_MODEM_QPSK250K:
         d->fam = qrl_demod::F_QPSK; break;
+    case QRL_MODEM_DMR:
+        d->fam = qrl_demod::F_DMR; break;
     default: return fail(QRL_ERR_ARG, "modem_type not supported by this build");
     }
     if (c.samp_rate != 1000000) return fail(QRL_ERR_ARG, "internal samp_rate must be 1000000 (gr_demod_base.cpp:21)");
@@ -615,7 +649,7 @@ int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* fcap, size_t* ccap,
     const size_t ns = n2 / (size_t)(d->sps_eff > 1 ? d->sps_eff - 1 : 1) + 8;
     if (fcap) *fcap = n2;
     if (ccap) *ccap = ns;
-    if (bcap) *bcap = d->fam == qrl_demod::F_QPSK ? (ns / 80 + 2) * 80 : (ns / 2 / 80 + 2) * 80;
+    if (bcap) *bcap = d->fam == qrl_demod::F_DMR ? 2 * ns + 8 : d->fam == qrl_demod::F_QPSK ? (ns / 80 + 2) * 80 : (ns / 2 / 80 + 2) * 80;
     return QRL_OK;
 }
 int qrl_demod_process(qrl_demod* d, const float* iq, size_t stride, size_t n, const qrl_demod_out* out)

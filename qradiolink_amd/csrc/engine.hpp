@@ -57,6 +57,7 @@ struct ResampParams {
     const float* taps;                    // [I][Jp]: taps[ph*Jp + j] = h[ph + j*I]
     int I, D, Jp;
     int rot_enable; uint64_t rot_acc; uint64_t rot_inc; uint64_t rot_nbase; const float2* rot_lo;
+    float2* port; size_t port_cap; uint32_t* port_counts;   // optional copy of this call's outputs to a caller port (counts[b*4+0])
 };
 void launch_resamp(const ResampParams& p, int batch, hipStream_t s);
 
@@ -89,6 +90,9 @@ struct SymSyncParams {
     const float* mmse;                     // 129 x 8
     float alpha, beta, maxp, minp;
     int ted; float soft_mul, soft_add;
+    int slicer;                            // 0: bpsk sign, 1: constellation_rect{-1.5,-0.5,0.5,1.5}
+    int tail;                              // 0: soft symbols for the Viterbi; 1: DMR tail (x0.9, phase_modulator, slicer, map) -> bits port
+    uint8_t* bits; size_t bits_cap;        // tail 1: two bits per symbol, counts[b*4+2]
     float2* port; size_t port_cap; uint32_t* counts;  // constellation port (this call), counts[b*4+1]
 };
 void launch_symsync_ff(const SymSyncParams& p, int batch, hipStream_t s);

@@ -381,8 +381,8 @@ __device__ __forceinline__ void mfma_quarter(const float2* tile, const float* hp
 
 // ---- one-team variant (tiles too large for two LDS buffers, or input from an engine ring): a workgroup
 // of 4 waves walks its tiles; the loads of tile k + 1 fly during the MFMA phase of tile k.
-template <int NA, int NLD, bool FAST, bool ALIAS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_decim_mfma(const DecimParams P_)
+template <int NA, int NLD, bool FAST, bool ALIAS, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_decim_mfma(const DecimParams P_)
 {
     const DecimParams& P = P_;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -602,23 +602,27 @@ bool decim_uses_mfma(int nt, int D)
 constexpr int kTpwMax = 16;
 static size_t mfma2_lds(int nt, int D, int NA);
 // 16 output blocks per tile when two workgroups of that size fit the 160 KB of a CU, else 8
-int decim_mfma_na(int nt, int D) { return mfma_lds(nt, D, 16, kTpwMax) <= 80 * 1024 ? 16 : 8; }
+int decim_mfma_na(int nt, int D)
+{
+    if (const char* e = std::getenv("QRL_DECIM_NA")) { const int v = std::atoi(e); if (v == 8 || v == 16) return v; }   // experiments
+    return mfma_lds(nt, D, 16, kTpwMax) <= 80 * 1024 ? 16 : 8;
+}
 size_t decim_mfma_lds_bytes(int nt, int D) { return mfma_lds(nt, D, decim_mfma_na(nt, D), kTpwMax); }
 
-template <int NA, int NLD, bool FAST>
+template <int NA, int NLD, bool FAST, int WPE = 2>
 static void launch_k(const DecimParams& q, dim3 grid, size_t lds, hipStream_t s)
 {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_decim_mfma<NA, NLD, FAST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_decim_mfma<NA, NLD, FAST, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_decim_mfma<NA, NLD, FAST, true, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_decim_mfma<NA, NLD, FAST, false, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     const char* na = std::getenv("QRL_DECIM_NOALIAS");
-    if (na && na[0] == '1') hipLaunchKernelGGL((k_decim_mfma<NA, NLD, FAST, false>), grid, dim3(256), lds + 4 * 16 * NA * sizeof(float2), s, q);
+    if (na && na[0] == '1') hipLaunchKernelGGL((k_decim_mfma<NA, NLD, FAST, false, WPE>), grid, dim3(256), lds + 4 * 16 * NA * sizeof(float2), s, q);
     else {
         const char* pad = std::getenv("QRL_DECIM_PADLDS");   // debugging aid: extra LDS to force one workgroup per CU
-        hipLaunchKernelGGL((k_decim_mfma<NA, NLD, FAST, true>), grid, dim3(256), lds + (pad ? std::atoi(pad) : 0), s, q);
+        hipLaunchKernelGGL((k_decim_mfma<NA, NLD, FAST, true, WPE>), grid, dim3(256), lds + (pad ? std::atoi(pad) : 0), s, q);
     }
 }
 static size_t mfma2_lds(int nt, int D, int NA)
@@ -681,7 +685,9 @@ void launch_decim_mfma(const DecimParams& p, int batch, hipStream_t s)
     if (NA == 16) {
         if (nld <= 16) launch_one<16, 16>(q, grid, lds, s); else launch_one<16, 36>(q, grid, lds, s);
     } else {
-        if (nld <= 16) launch_one<8, 16>(q, grid, lds, s); else launch_one<8, 36>(q, grid, lds, s);
+        const char* w3 = std::getenv("QRL_DECIM_WPE3");   // experiment: three smaller workgroups per CU
+        if (w3 && w3[0] == '1' && nld <= 10 && q.in && q.n >= 2 && q.n < (1u << 28)) launch_k<8, 10, true, 3>(q, grid, lds, s);
+        else if (nld <= 16) launch_one<8, 16>(q, grid, lds, s); else launch_one<8, 36>(q, grid, lds, s);
     }
 }
 

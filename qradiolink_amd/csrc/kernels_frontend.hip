@@ -316,6 +316,9 @@ __global__ __launch_bounds__(256) void k_resamp(const ResampParams P, int span)
         ai = fmaf(h, x.y, ai);
     }
     P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)q & P.out.mask)] = make_float2(ar, ai);
+    const uint32_t t = blockIdx.x * 256u + tid;   // output index inside this call
+    if (P.port && t < P.port_cap) P.port[(size_t)b * P.port_cap + t] = make_float2(ar, ai);
+    if (t == 0 && P.port_counts) P.port_counts[b * 4 + 0] = P.q_count;
 }
 
 void launch_resamp(const ResampParams& p, int batch, hipStream_t s)
@@ -324,6 +327,8 @@ void launch_resamp(const ResampParams& p, int batch, hipStream_t s)
     // span of inputs for 256 outputs: ceil(255*D/I) + 1 + Jp - 1 (+1 slack)
     const int span = (255 * p.D + p.I - 1) / p.I + p.Jp + 2;
     const size_t lds = (size_t)((p.I * p.Jp + 3) & ~3) * sizeof(float) + (size_t)span * sizeof(float2);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_resamp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     dim3 grid((p.q_count + 255) / 256, batch), block(256);
     hipLaunchKernelGGL(k_resamp, grid, block, lds, s, p, span);
 }

@@ -224,6 +224,19 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
             const int s = idx / SS_OMAX, j = idx - s * SS_OMAX;
             if (j < ocnt[pb * 64 + s]) {
                 const float y = ob[s * SS_OPITCH + j];
+                if (P.tail == 1) {   // gr_demod_dmr.cpp:73-105: x0.9 -> phase_modulator_fc(pi/2) -> slicer -> pack -> map{3,1,2,0} -> unpack
+                    const uint64_t o = obase[pb * 64 + s] + j;
+                    const uint64_t kk = o - oo0[s];
+                    const float2 cs = sincos_rad(1.57079632679489661923f * (y * 0.9f));
+                    if (P.port && kk < P.port_cap) P.port[(size_t)(b0 + s) * P.port_cap + kk] = cs;
+                    const int v = ((cs.x >= 0.0f) ? 2 : 0) | ((cs.y >= 0.0f) ? 1 : 0);
+                    const int m = (0x27 >> (2 * v)) & 3;   // map {3,1,2,0}
+                    if (P.bits && 2 * kk + 1 < P.bits_cap) {
+                        P.bits[(size_t)(b0 + s) * P.bits_cap + 2 * kk] = (uint8_t)((m >> 1) & 1);
+                        P.bits[(size_t)(b0 + s) * P.bits_cap + 2 * kk + 1] = (uint8_t)(m & 1);
+                    }
+                    continue;
+                }
                 float q = y * P.soft_mul;
                 q = q + P.soft_add;
                 float r = rintf(q);
@@ -262,7 +275,15 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
                 y = fmaf(ta.w, row[off + 4], y); y = fmaf(ta.z, row[off + 5], y);
                 y = fmaf(ta.y, row[off + 6], y); y = fmaf(ta.x, row[off + 7], y);
                 st.x2 = st.x1; st.x1 = st.x0; st.x0 = y;
-                st.d2 = st.d1; st.d1 = st.d0; st.d0 = (y > 0.f) ? 1.0f : -1.0f;
+                st.d2 = st.d1; st.d1 = st.d0;
+                if (P.slicer == 0) st.d0 = (y > 0.f) ? 1.0f : -1.0f;
+                else {   // nearest of {-1.5, -0.5, 0.5, 1.5}, ties to the lower point (oracle slice_real)
+                    float best = -1.5f, bd = fabsf(y + 1.5f);
+                    float dd = fabsf(y - (-0.5f)); if (dd < bd) { bd = dd; best = -0.5f; }
+                    dd = fabsf(y - 0.5f); if (dd < bd) { bd = dd; best = 0.5f; }
+                    dd = fabsf(y - 1.5f); if (dd < bd) { bd = dd; best = 1.5f; }
+                    st.d0 = best;
+                }
                 float e;
                 if (P.ted == 0) e = st.d1 * st.x0 - st.d0 * st.x1;
                 else {
@@ -292,6 +313,7 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
     if (wv == 0 && active) {
         P.st[b0 + lane] = st;
         P.counts[(b0 + lane) * 4 + 1] = (uint32_t)(st.oo - oo0[lane]);
+        if (P.tail == 1) P.counts[(b0 + lane) * 4 + 2] = 2u * (uint32_t)(st.oo - oo0[lane]);
     }
 }
 

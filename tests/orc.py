@@ -84,6 +84,7 @@ _sig("orc_mod_2fsk", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, 
 _sig("orc_mod_gmsk", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p)
 _sig("orc_mod_qpsk", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p)
 _sig("orc_tx_interp", _sz, _p, _sz, C.c_int, _p)
+_sig("orc_demod_dmr", None, _p, _sz, C.c_int, C.c_int, _p)
 _sig("orc_chan_proto_taps", C.c_int, C.c_int, _p)
 _sig("orc_pfb_channelizer", _sz, _p, _sz, _p, C.c_int, C.c_int, _p)
 _sig("orc_demod_mmdvm_multi", _sz, _p, _sz, C.c_int, _p, _sz)
@@ -235,6 +236,13 @@ def demod_qpsk(x, sps=2, samp_rate=1000000, carrier_freq=1700, filter_width=1600
     x = np.ascontiguousarray(x, cf32)
     o = DemodOut()
     lib.orc_demod_qpsk(_ptr(x), x.size, sps, samp_rate, carrier_freq, filter_width, C.byref(o))
+    return _take(o)
+
+
+def demod_dmr(x, sps=5, samp_rate=1000000):
+    x = np.ascontiguousarray(x, cf32)
+    o = DemodOut()
+    lib.orc_demod_dmr(_ptr(x), x.size, sps, samp_rate, C.byref(o))
     return _take(o)
 
 

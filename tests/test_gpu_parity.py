@@ -124,3 +124,34 @@ def test_loopback_frames_recovered(qrl_ctx):
     dem.close()
     got = [sum((bytes([0xAA]) + p) in sig.find_frames(out[k][0], bytes([0xED, 0x89]), 384) for p in payloads) for k in ("bits_a", "bits_b")]
     assert max(got) == len(payloads), got
+
+
+# ---- DMR / 4FSK symbol demodulator (gr_demod_dmr, the in-tree "4FSK demod" of BASELINE config 4)
+@pytest.mark.parametrize("chunk", [1 << 20, 50000, 12502])
+def test_dmr_4fsk_bit_exact(qrl_ctx, chunk):
+    import torch
+    import qradiolink_amd as q
+    xs = [sig.make_4fsk(nsym=300, seed=s)[0] for s in (1, 2)]
+    n = min(x.size for x in xs)
+    iq = np.stack([x[:n] for x in xs])
+    dem = q.Demod(qrl_ctx, q.MODEM_DMR, batch=2, max_chunk=chunk)
+    out = q.collect(dem, torch.from_numpy(iq).cuda(), chunk)
+    dem.close()
+    for b in range(2):
+        ref = orc.demod_dmr(iq[b])
+        assert np.array_equal(out["bits_a"][b], ref["bits_a"]) and ref["bits_a"].size > 500
+        for port in ("filtered", "constellation"):
+            assert np.array_equal(out[port][b].view(np.uint32), ref[port].view(np.uint32)), port
+
+
+def test_dmr_dibits_recovered(qrl_ctx):
+    import torch
+    import qradiolink_amd as q
+    x, dib = sig.make_4fsk(nsym=500, seed=7)
+    dem = q.Demod(qrl_ctx, q.MODEM_DMR, batch=1, max_chunk=x.size)
+    out = q.collect(dem, torch.from_numpy(x[None, :]).cuda(), x.size)
+    dem.close()
+    got = out["bits_a"][0].reshape(-1, 2)
+    got = got[:, 0] * 2 + got[:, 1]
+    best = max(np.mean(got[k:k + 400] == dib[:400]) for k in range(40))
+    assert best == 1.0

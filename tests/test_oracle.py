@@ -259,3 +259,15 @@ def test_mmdvm_chain_fm_deviation_scaling():
     peak = np.abs(o[2, 2000:].astype(np.int32)).max()
     assert abs(peak - 32767 * dev / 12500.0) < 40
     assert np.abs(o[5, 2000:].astype(np.int32)).max() > 20000   # an empty channel is discriminator noise, full scale
+
+
+def test_dmr_4fsk_oracle_recovers_dibits():
+    """gr_demod_dmr chain (3/125 resampler, discriminator, RRC, M&M symbol sync on the 4-level constellation, phase
+    modulator + slicer + map{3,1,2,0}) returns the transmitted dibits of a DMR-shaped 4FSK burst."""
+    x, dib = sig.make_4fsk(nsym=500, seed=7)
+    r = orc.demod_dmr(x)
+    assert r["filtered"].size == orc.lib.orc_decim_count(x.size, 3, 125)
+    got = r["bits_a"].reshape(-1, 2)
+    got = got[:, 0] * 2 + got[:, 1]
+    assert max(np.mean(got[k:k + 400] == dib[:400]) for k in range(40)) == 1.0
+    assert np.allclose(np.abs(r["constellation"][50:]), 1.0, atol=1e-6)
