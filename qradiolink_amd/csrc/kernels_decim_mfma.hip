@@ -87,7 +87,7 @@ __device__ __forceinline__ TileWin tile_window(const DecimParams& P, uint64_t mt
 // destination tuples across the MFMA loop and drain vmcnt right after the issue.  tile_wait() is the
 // matching explicit wait; it names every destination "+a", so no compiler copy can be scheduled between a
 // load and its wait (guide 5.7 form ii; audit: no v_accvgpr_* of these registers before the wait).
-template <int NLD>
+template <int NLD, int NTH>
 __device__ __forceinline__ void tile_issue(const DecimParams& P, int b, const TileWin& w, int tid, f32x4 (&v)[NLD])
 {
     // UNCONDITIONAL loads with the pair index clamped into the caller's buffer; lanes outside
@@ -100,7 +100,7 @@ __device__ __forceinline__ void tile_issue(const DecimParams& P, int b, const Ti
     const int qmax = (int)(P.n >> 1) - 1;
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
-        const uint32_t voff = (uint32_t)min(max(q0k + 256 * it, 0), qmax) << 4;
+        const uint32_t voff = (uint32_t)min(max(q0k + NTH * it, 0), qmax) << 4;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(v[it]) : "v"(voff), "s"(sbase) : "memory");
     }
 }
@@ -111,7 +111,7 @@ __device__ __forceinline__ void tile_wait(f32x4 (&v)[NLD])
     for (int it = 0; it < NLD; ++it) asm volatile("s_waitcnt vmcnt(0)" : "+a"(v[it]) : : "memory");
 }
 
-template <int NLD, bool FAST>
+template <int NLD, bool FAST, int NTH>
 __device__ __forceinline__ void tile_commit(const DecimParams& P, int b, const TileWin& w, int tid, const f32x4 (&v)[NLD],
                                             float2* tile, int Jtot, int dump, const float2* t_hi, uint32_t kb0, const float2* t_lo)
 {
@@ -119,7 +119,7 @@ __device__ __forceinline__ void tile_commit(const DecimParams& P, int b, const T
     // samples that cannot come from the aligned-pair path (history, stream edges): rare, one at a time
     for (int seg = 0; seg < 2; ++seg) {
         const int sb = seg ? w.s_hi : 0, se = seg ? Jtot : w.s_lo;
-        for (int j = sb + tid; j < se; j += 256)
+        for (int j = sb + tid; j < se; j += NTH)
             tile[j + 2 * (int)__umulhi((uint32_t)j, magic)] = mf_fetch(P, b, w.i_base + j, t_hi, kb0, t_lo);
     }
     if (!FAST) return;
@@ -129,15 +129,15 @@ __device__ __forceinline__ void tile_commit(const DecimParams& P, int b, const T
     const uint32_t krel0 = (uint32_t)((uint64_t)(w.i_base + j0) - P.rot_nbase - ((uint64_t)kb0 << 9));
     // krel advances by 512 per step: the fine-table factors of a thread never change
     const float2 lo0 = t_lo[krel0 & 511u], lo1 = t_lo[(krel0 + 1u) & 511u];
-    const int npair = w.k_hi - w.k_lo - tid;   // this thread owns pairs it < ceil(npair / 256)
+    const int npair = w.k_hi - w.k_lo - tid;   // this thread owns pairs it < ceil(npair / NTH)
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
-        const int j = j0 + 512 * it;
-        const uint32_t krel = krel0 + 512u * it;
+        const int j = j0 + 2 * NTH * it;
+        const uint32_t krel = krel0 + 2u * NTH * it;
         float2 x0 = make_float2(v[it].x, v[it].y), x1 = make_float2(v[it].z, v[it].w);
         x0 = cmul_fma(x0, cmul_fma(t_hi[krel >> 9], lo0));   // the caller-buffer path always carries the rotator
         x1 = cmul_fma(x1, cmul_fma(t_hi[(krel + 1u) >> 9], lo1));
-        const bool ok = 256 * it < npair;
+        const bool ok = NTH * it < npair;
         const int p0 = ok ? j + 2 * (int)__umulhi((uint32_t)j, magic) : dump + 2 * tid;
         const int p1 = ok ? j + 1 + 2 * (int)__umulhi((uint32_t)(j + 1), magic) : dump + 2 * tid + 1;
         tile[p0] = x0;
@@ -362,7 +362,12 @@ __device__ __forceinline__ void mfma_quarter(const float2* tile, const float* hp
 #pragma unroll
         for (int r = 0; r < 4; ++r) pp[r] = make_float2(acc0[r], acc1[r]);
     } else {
-        const int n = lane & 15, acol = n >> 1, c = n & 1;
+        // NA = 8: columns = 8 blocks x {re, im};  NA = 4: 4 blocks x {re, im} x 2 (the odd columns duplicate the even
+        // ones and are dropped: half the matrix pipe is wasted, which is irrelevant where this variant is used --
+        // low-rate-ratio decimators whose MFMA time is a few percent -- and buys a tile small enough for 3 workgroups per CU)
+        constexpr int SH = NA == 8 ? 1 : 2;
+        const int n = lane & 15, acol = n >> SH, c = (n >> (SH - 1)) & 1;
+        const bool keep = NA == 8 || !(n & 1);
         const float* bp = reinterpret_cast<const float*>(tile) + 2 * (acol * Pp + kk) + c;
         const float* ap = hp + ((lane & 15) * D + 4 * S - kk);
         while (s < s_end) {
@@ -374,15 +379,17 @@ __device__ __forceinline__ void mfma_quarter(const float2* tile, const float* hp
         }
         if constexpr (ALIAS) __syncthreads();
         float* pf = reinterpret_cast<float*>(part + g * T + 16 * acol + 4 * kk) + c;
+        if (keep) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pf[2 * r] = acc0[r];
+            for (int r = 0; r < 4; ++r) pf[2 * r] = acc0[r];
+        }
     }
 }
 
 // ---- one-team variant (tiles too large for two LDS buffers, or input from an engine ring): a workgroup
 // of 4 waves walks its tiles; the loads of tile k + 1 fly during the MFMA phase of tile k.
-template <int NA, int NLD, bool FAST, bool ALIAS, int WPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_decim_mfma(const DecimParams P_)
+template <int NA, int NLD, bool FAST, bool ALIAS, int WPE, int NTH>
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_decim_mfma(const DecimParams P_)
 {
     const DecimParams& P = P_;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     float* hp = reinterpret_cast<float*>(t_hi + nhi);          // zero-padded taps
     float2* tile = reinterpret_cast<float2*>(hp + hpn);
     const int dump0 = Jtot + 2 * (Jtot / blk) + 4;
-    float2* part = ALIAS ? tile : tile + dump0 + 512;          // 4 T partial sums (ALIAS: on the head of the tile)
+    float2* part = ALIAS ? tile : tile + dump0 + 2 * NTH;          // 4 T partial sums (ALIAS: on the head of the tile)
     const int dump = Jtot + 2 * (Jtot / blk) + 4;              // 512 dump slots behind the tile (tile_commit)
 
     const int b = blockIdx.y;
@@ -412,14 +419,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const int tid = threadIdx.x;
     const uint64_t mt_first = (P.m0 / T) * (uint64_t)T;
 
-    for (int k = tid; k < hpn; k += 256) hp[k] = P.gtab[k];
-    if (P.rot_enable) { t_lo[tid] = P.rot_lo[tid]; t_lo[tid + 256] = P.rot_lo[tid + 256]; }
+    for (int k = tid; k < hpn; k += NTH) hp[k] = P.gtab[k];
+    if (P.rot_enable) { for (int k = tid; k < 512; k += NTH) t_lo[k] = P.rot_lo[k]; }
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
 
     f32x4 v[NLD];
     TileWin w = tile_window(P, mt_first + (uint64_t)cix * T, Jtot, FAST);
-    if constexpr (FAST) tile_issue<NLD>(P, b, w, tid, v);
+    if constexpr (FAST) tile_issue<NLD, NTH>(P, b, w, tid, v);
+    const bool prof = (P.dbg & 32) && tid == 0;
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = prof ? __builtin_readcyclecounter() : 0;
+#define MF_STAMP(k) do { if (prof) { const unsigned long long tn_ = __builtin_readcyclecounter(); pc[k] += tn_ - tprev; tprev = tn_; } } while (0)
     for (uint32_t t = cix; t < P.tiles; t += nchunks) {
         const uint64_t mt = mt_first + (uint64_t)t * T;
         uint32_t kb0 = 0;
@@ -429,14 +440,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             if (tid < P.nhi) t_hi[tid] = sincos_turn(P.rot_acc + ((uint64_t)(kb0 + tid) << 9) * P.rot_inc);
         }
         __syncthreads();
+        MF_STAMP(0);
         if constexpr (FAST) tile_wait<NLD>(v);
-        tile_commit<NLD, FAST>(P, b, w, tid, v, tile, Jtot, dump, t_hi, kb0, t_lo);
+        MF_STAMP(1);
+        tile_commit<NLD, FAST, NTH>(P, b, w, tid, v, tile, Jtot, dump, t_hi, kb0, t_lo);
+        MF_STAMP(2);
         __syncthreads();
+        MF_STAMP(3);
         if (t + nchunks < P.tiles) {
             w = tile_window(P, mt + (uint64_t)nchunks * T, Jtot, FAST);
-            if constexpr (FAST) tile_issue<NLD>(P, b, w, tid, v);
+            if constexpr (FAST) tile_issue<NLD, NTH>(P, b, w, tid, v);
         }
-        mfma_quarter<NA, ALIAS>(tile, hp, part, g, lane, D, S, P.magic_seg);
+        MF_STAMP(4);
+        // waves 0-3 = the four quarters of the contract; with 512 threads waves 4-7 only help staging (more waves per
+        // SIMD hide the LDS / dependency latency of the commit) and wait at the barriers of the quarter function
+        if (NTH == 256 || g < 4) mfma_quarter<NA, ALIAS>(tile, hp, part, g, lane, D, S, P.magic_seg);
+        else if (ALIAS) __syncthreads();
+        MF_STAMP(5);
         __syncthreads();
         if (tid < T) {
             const uint64_t m = mt + tid;
@@ -448,7 +468,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = y;
             }
         }
+        MF_STAMP(6);
     }
+    if (prof) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_mf_prof[k], pc[k]);
+        atomicAdd(&g_mf_prof[7], 1ull);
+    }
+#undef MF_STAMP
 }
 
 // ---- two-team variant: ONE workgroup of 8 waves per CU, two tile buffers.  In every phase one team
@@ -517,11 +544,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         MF2_T0();
         tile_wait<NLD>(v);
         MF2_STAMP(0);
-        tile_commit<NLD, true>(P, b, w, ttid, v, tile, Jtot, dump, t_hi0 + ((k >> 1) & 1) * nhi, kb0, t_lo);
+        tile_commit<NLD, true, 256>(P, b, w, ttid, v, tile, Jtot, dump, t_hi0 + ((k >> 1) & 1) * nhi, kb0, t_lo);
         MF2_STAMP(1);
         if (k + 2 < K) {
             w = tile_window(P, tile_mt(k + 2), Jtot, true);
-            tile_issue<NLD>(P, b, w, ttid, v);
+            tile_issue<NLD, 256>(P, b, w, ttid, v);
             kb0 = make_thi(k + 2);
         }
         MF2_STAMP(2);
@@ -542,7 +569,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // start-up: each team issues the loads and the table of its first tile (k = team)
     if (team < K) {
         w = tile_window(P, tile_mt(team), Jtot, true);
-        tile_issue<NLD>(P, b, w, ttid, v);
+        tile_issue<NLD, 256>(P, b, w, ttid, v);
         kb0 = make_thi(team);
     }
     __syncthreads();
@@ -604,25 +631,26 @@ static size_t mfma2_lds(int nt, int D, int NA);
 // 16 output blocks per tile when two workgroups of that size fit the 160 KB of a CU, else 8
 int decim_mfma_na(int nt, int D)
 {
-    if (const char* e = std::getenv("QRL_DECIM_NA")) { const int v = std::atoi(e); if (v == 8 || v == 16) return v; }   // experiments
-    return mfma_lds(nt, D, 16, kTpwMax) <= 80 * 1024 ? 16 : 8;
+    if (const char* e = std::getenv("QRL_DECIM_NA")) { const int v = std::atoi(e); if (v == 4 || v == 8 || v == 16) return v; }   // experiments
+    if (mfma_lds(nt, D, 16, kTpwMax) <= 80 * 1024) return 16;    // two (or more) workgroups per CU with the efficient tile
+    return 8;   // (4-block tiles with three workgroups per CU were measured slower: QRL_DECIM_NA=4 keeps them reachable)
 }
 size_t decim_mfma_lds_bytes(int nt, int D) { return mfma_lds(nt, D, decim_mfma_na(nt, D), kTpwMax); }
 
-template <int NA, int NLD, bool FAST, int WPE = 2>
+template <int NA, int NLD, bool FAST, int WPE = 2, int NTH = 256>
 static void launch_k(const DecimParams& q, dim3 grid, size_t lds, hipStream_t s)
 {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_decim_mfma<NA, NLD, FAST, true, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_decim_mfma<NA, NLD, FAST, false, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_decim_mfma<NA, NLD, FAST, true, WPE, NTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_decim_mfma<NA, NLD, FAST, false, WPE, NTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     const char* na = std::getenv("QRL_DECIM_NOALIAS");
-    if (na && na[0] == '1') hipLaunchKernelGGL((k_decim_mfma<NA, NLD, FAST, false, WPE>), grid, dim3(256), lds + 4 * 16 * NA * sizeof(float2), s, q);
+    if (na && na[0] == '1') hipLaunchKernelGGL((k_decim_mfma<NA, NLD, FAST, false, WPE, NTH>), grid, dim3(NTH), lds + 4 * 16 * NA * sizeof(float2) + (NTH - 256) * 2 * sizeof(float2), s, q);
     else {
         const char* pad = std::getenv("QRL_DECIM_PADLDS");   // debugging aid: extra LDS to force one workgroup per CU
-        hipLaunchKernelGGL((k_decim_mfma<NA, NLD, FAST, true, WPE>), grid, dim3(256), lds + (pad ? std::atoi(pad) : 0), s, q);
+        hipLaunchKernelGGL((k_decim_mfma<NA, NLD, FAST, true, WPE, NTH>), grid, dim3(NTH), lds + (pad ? std::atoi(pad) : 0) + (NTH - 256) * 2 * sizeof(float2), s, q);
     }
 }
 static size_t mfma2_lds(int nt, int D, int NA)
@@ -682,9 +710,17 @@ void launch_decim_mfma(const DecimParams& p, int batch, hipStream_t s)
     const size_t lds = mfma_lds(p.nt, p.D, NA, tpw);
     const long long pairs = (mfma_jtot(p.nt, p.D, NA) + 2) / 2;
     const int nld = (int)((pairs + 255) / 256);
+    const bool fast = q.in && q.n >= 2 && q.n < (1u << 28);
+    const char* w8 = std::getenv("QRL_DECIM_W8");   // 8 waves per workgroup (4 per SIMD with two workgroups per CU)
+    const bool wide = w8 && w8[0] == '1' && fast && nld <= 16;
     if (NA == 16) {
-        if (nld <= 16) launch_one<16, 16>(q, grid, lds, s); else launch_one<16, 36>(q, grid, lds, s);
+        if (wide) launch_k<16, 8, true, 4, 512>(q, grid, lds, s);
+        else if (nld <= 16) launch_one<16, 16>(q, grid, lds, s); else launch_one<16, 36>(q, grid, lds, s);
+    } else if (NA == 4) {
+        if (nld <= 8 && fast) launch_k<4, 8, true, 3>(q, grid, lds, s);
+        else if (nld <= 16) launch_one<4, 16>(q, grid, lds, s); else launch_one<4, 36>(q, grid, lds, s);
     } else {
+        if (wide) { launch_k<8, 8, true, 4, 512>(q, grid, lds, s); return; }
         const char* w3 = std::getenv("QRL_DECIM_WPE3");   // experiment: three smaller workgroups per CU
         if (w3 && w3[0] == '1' && nld <= 10 && q.in && q.n >= 2 && q.n < (1u << 28)) launch_k<8, 10, true, 3>(q, grid, lds, s);
         else if (nld <= 16) launch_one<8, 16>(q, grid, lds, s); else launch_one<8, 36>(q, grid, lds, s);

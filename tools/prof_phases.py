@@ -7,7 +7,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 if cfg == "c2":
     B, N, rate, modem = 96, 25 * (1 << 18), 25000000, 22
 else:
-    B, N, rate, modem = 8192, 1 << 18, 1000000, 18
+    B, N, rate, modem = 16384, 1 << 18, 1000000, 18
 iq = torch.randn((B, N, 2), device="cuda").mul_(0.05)
 iq = torch.view_as_complex(iq)
 dem = q.Demod(ctx, modem, batch=B, max_chunk=N, device_samp_rate=rate, carrier_offset_hz=25000.0)
@@ -19,8 +19,8 @@ dem.process_async(iq); dem.sync()
 lib.qrl_debug_decim_prof(out)
 v = list(out)
 n = max(v[7], 1)
-names = ["t_hi+barrier", "commit", "barrier", "issue loads", "mfma loop", "barrier", "epilogue"]
-if os.environ.get("QRL_DECIM_ONE_TEAM") != "1":
+names = ["t_hi + barrier", "wait loads", "commit", "barrier", "issue next loads", "mfma quarter (+alias barrier)", "barrier + combine + store"]
+if os.environ.get("QRL_DECIM_TWO_TEAM") == "1":
     names = ["stage: wait loads", "stage: commit", "stage: issue+table", "mfma role", "combine", "barrier after mfma", "barrier after stage"]
 tot = sum(v[:7])
 print("workgroups", v[7], "ticks/WG", tot / n)
