@@ -119,13 +119,14 @@ int qrl_demod_process_host(qrl_demod* d, const float* iq_host, size_t stride, si
 /* ---- TX: the "modulator" top_block (reference src/gr/gr_mod_base.cpp:25) ----------------------------------
  * One handle = make_gr_mod_qpsk(sps, samp_rate, carrier_freq, filter_width) (src/gr/gr_mod_qpsk.cpp:19-30;
  * instance make_gr_mod_qpsk(4,1000000,1700,160000) src/gr/gr_mod_base.cpp:175) for `batch` independent streams.
- * Only the QPSK family is built so far; gr_mod_base's rate-matching interpolator (gr_mod_base.cpp:249-258) and
+ * Built: QPSK (gr_mod_qpsk.cpp), 2FSK incl. FM variants (gr_mod_2fsk.cpp:19-99), GMSK (gr_mod_gmsk.cpp:19-95);
+ * gr_mod_base's rate-matching interpolator (gr_mod_base.cpp:249-258) and
  * rotator are not part of this handle yet. */
 typedef struct qrl_mod qrl_mod;
 typedef struct {
     int modem_type;          /* gr_modem_types value (QRL_MODEM_QPSK250K) */
     int use_mode_defaults;   /* 1: sps/filter_width from gr_mod_base.cpp:175 */
-    int sps, samp_rate, carrier_freq, filter_width;   /* make_gr_mod_qpsk arguments */
+    int sps, samp_rate, carrier_freq, filter_width, fm;   /* make_gr_mod_qpsk / make_gr_mod_2fsk / make_gr_mod_gmsk arguments */
     int batch;               /* independent streams per call */
     size_t max_bytes;        /* largest nbytes of any process call */
     void* hip_stream;        /* hipStream_t, NULL = the library creates one (RX and TX handles on different streams run

@@ -34,8 +34,8 @@ class _Config(C.Structure):
 
 class _ModConfig(C.Structure):
     _fields_ = [("modem_type", C.c_int), ("use_mode_defaults", C.c_int), ("sps", C.c_int), ("samp_rate", C.c_int),
-                ("carrier_freq", C.c_int), ("filter_width", C.c_int), ("batch", C.c_int), ("max_bytes", C.c_size_t),
-                ("hip_stream", C.c_void_p), ("bb_gain", C.c_float)]
+                ("carrier_freq", C.c_int), ("filter_width", C.c_int), ("fm", C.c_int), ("batch", C.c_int),
+                ("max_bytes", C.c_size_t), ("hip_stream", C.c_void_p), ("bb_gain", C.c_float)]
 
 
 class _ChanConfig(C.Structure):

@@ -147,6 +147,7 @@ struct TxState { uint32_t sr, enc, prev, pad; };   // scrambler register, last 6
 struct TxBitsParams {
     const uint8_t* bytes; size_t stride; uint32_t nbytes; uint32_t L;   // L bits per lane (multiple of 32)
     uint8_t tl_cols[8];                                                  // T^L of the zero-input scrambler, column masks
+    int mode;                                                            // 0: QPSK differential symbols, 1: coded bits (2 per input bit)
     TxState* st; RingB sym; uint64_t s0;                                 // symbol ring, absolute index of this call's first symbol
 };
 struct TxInterpParams {
@@ -154,6 +155,12 @@ struct TxInterpParams {
     const float* taps; int nt; int interp; float2 table[4]; float amp, bb_gain;
     float2* out; size_t out_stride;
 };
+struct TxShapeParams { RingB sym; RingF out; uint64_t n0; uint32_t count; int sps; const float* taps; int nt; };   // nt = 0: repeat
+struct TxFmParams { RingF in; RingC out; uint64_t n0; uint32_t count; float k, amp; float* phase; };
+struct TxInterpCParams { RingC in; uint64_t n0; uint32_t count; const float* taps; int nt; int interp; float2* out; size_t out_stride; };
+void launch_tx_shape(const TxShapeParams& p, int batch, hipStream_t s);
+void launch_tx_fm(const TxFmParams& p, int batch, hipStream_t s);
+void launch_tx_interp_c(const TxInterpCParams& p, int batch, hipStream_t s);
 void launch_tx_qpsk_bits(const TxBitsParams& p, int batch, hipStream_t s);
 void launch_tx_interp(const TxInterpParams& p, int batch, hipStream_t s);
 

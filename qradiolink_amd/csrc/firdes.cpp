@@ -93,6 +93,24 @@ std::vector<std::complex<float>> complex_band_pass(double gain, double fs, doubl
     return taps;
 }
 
+// firdes::gaussian(gain, spb, bt, ntaps) (gr_mod_gmsk.cpp:68-70)
+std::vector<float> gaussian(double gain, double spb, double bt, int ntaps)
+{
+    std::vector<float> taps((size_t)ntaps);
+    double scale = 0;
+    const double dt = 1.0 / spb;
+    const double s = 1.0 / (std::sqrt(std::log(2.0)) / (2 * M_PI * bt));
+    double t0 = -0.5 * ntaps;
+    for (int i = 0; i < ntaps; i++) {
+        t0++;
+        const double ts = s * dt * t0;
+        taps[i] = (float)std::exp(-0.5 * ts * ts);
+        scale += taps[i];
+    }
+    for (int i = 0; i < ntaps; i++) taps[i] = (float)(taps[i] / scale * gain);
+    return taps;
+}
+
 std::vector<float> root_raised_cosine(double gain, double fs, double symrate, double alpha, int ntaps)
 {
     ntaps |= 1;

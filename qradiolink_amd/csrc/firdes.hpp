@@ -19,6 +19,7 @@ std::vector<float> low_pass(double gain, double fs, double fc, double tw, Window
 std::vector<float> low_pass_2(double gain, double fs, double fc, double tw, double atten_db, Window w = WIN_HAMMING);
 std::vector<std::complex<float>> complex_band_pass(double gain, double fs, double lo, double hi, double tw, Window w = WIN_HAMMING);
 std::vector<float> root_raised_cosine(double gain, double fs, double symrate, double alpha, int ntaps);
+std::vector<float> gaussian(double gain, double spb, double bt, int ntaps);
 
 // fll_band_edge_cc design_filter: returns taps in the order the filter applies them,
 // T[j] multiplies y[n-j] (upstream stores them reversed and reverses again in the FIR)

@@ -83,6 +83,23 @@ __global__ __launch_bounds__(64) void k_tx_qpsk_bits(const TxBitsParams P)
         const uint32_t c0 = __builtin_popcount(reg & 109u) & 1u, c1 = __builtin_popcount(reg & 79u) & 1u;
         local = (local + map4[(c0 << 1) | c1]) & 3u;
     }
+    if (P.mode == 1) {   // FSK family: the two coded bits of every input bit go to the ring as they are (chunks_to_symbols later)
+        uint8_t* ring1 = P.sym.p + (size_t)b * (P.sym.mask + 1u);
+        for (uint32_t i = lo; i < hi; ++i) {
+            uint32_t reg = 0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) reg |= sbit((int64_t)i - k) << k;
+            ring1[(uint32_t)(P.s0 + 2ull * i) & P.sym.mask] = (uint8_t)(__builtin_popcount(reg & 109u) & 1u);
+            ring1[(uint32_t)(P.s0 + 2ull * i + 1) & P.sym.mask] = (uint8_t)(__builtin_popcount(reg & 79u) & 1u);
+        }
+        if (lane == 0 && nbits) {
+            uint32_t enc = 0;
+            for (int k = 0; k < 6; ++k) enc |= sbit((int64_t)nbits - 1 - k) << k;
+            st.sr = sr_end; st.enc = enc;
+            P.st[b] = st;
+        }
+        return;
+    }
     // diff_encoder_bb(4): y[n] = (x[n] + y[n-1]) mod 4  ->  exclusive wave scan of the slice sums
     uint32_t incl = local;
 #pragma unroll
@@ -146,6 +163,112 @@ void launch_tx_interp(const TxInterpParams& p, int batch, hipStream_t s)
 {
     if (!p.count) return;
     hipLaunchKernelGGL(k_tx_interp, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
+}
+
+// ---- FSK family (gr_mod_2fsk.cpp:63-99, gr_mod_gmsk.cpp:68-95):
+//   chunks_to_symbols_bf{-1, 1} -> repeat(sps) | rational_resampler_fff(sps, 1, RRC | gaussian) -> frequency_modulator_fc(k)
+//   -> multiply_const(amplif) -> rational_resampler_ccf(I2, 1, low_pass(I2, samp_rate, fw, fw))
+// k_tx_shape : thread per sample at the symbol-interpolated rate: +-1 repeated, or the polyphase shaping FIR.
+// k_tx_fm    : the FM phase accumulator wraps with fmodf after every sample, so it is a serial float recurrence per
+//              stream: one lane per stream, windows staged through LDS; (cos, sin) from the deterministic polynomial.
+// k_tx_interp_c : second interpolating FIR on the complex FM output (I2 = 1: a plain FIR).
+__global__ __launch_bounds__(256) void k_tx_shape(const TxShapeParams P)
+{
+    __shared__ float taps[1536];
+    for (int k = threadIdx.x; k < P.nt && k < 1536; k += 256) taps[k] = P.taps[k];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.count) return;
+    const uint64_t n = P.n0 + t;
+    const uint64_t c = n / (uint64_t)P.sps;
+    const int ph = (int)(n - c * (uint64_t)P.sps);
+    const uint8_t* ring = P.sym.p + (size_t)b * (P.sym.mask + 1u);
+    float a;
+    if (P.nt == 0) a = ring[(uint32_t)c & P.sym.mask] ? 1.0f : -1.0f;          // blocks::repeat
+    else {
+        a = 0.f;
+        for (int j = 0; ph + j * P.sps < P.nt; ++j) {
+            if ((uint64_t)j > c) break;
+            a = fmaf(taps[ph + j * P.sps], ring[(uint32_t)(c - j) & P.sym.mask] ? 1.0f : -1.0f, a);
+        }
+    }
+    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = a;
+}
+void launch_tx_shape(const TxShapeParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_tx_shape, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
+}
+
+constexpr int TXF_CH = 96;
+__global__ __launch_bounds__(64) void k_tx_fm(const TxFmParams P, int batch)
+{
+    __shared__ float win[64][TXF_CH + 1];
+    __shared__ float2 wout[64][TXF_CH / 2 + 1];   // flushed in two halves to stay inside 64 KB static LDS
+    const int lane = threadIdx.x, b0 = blockIdx.x * 64, b = b0 + lane;
+    const bool active = b < batch;
+    const int nstreams = min(64, batch - b0);
+    float phase = active ? P.phase[b] : 0.f;
+    const float F_PI = 3.14159265358979323846f;
+    for (uint32_t c0 = 0; c0 < P.count; c0 += TXF_CH) {
+        const int len = min((uint32_t)TXF_CH, P.count - c0);
+        __syncthreads();
+        for (int s = 0; s < nstreams; ++s)
+            for (int k = lane; k < len; k += 64)
+                win[s][k] = P.in.p[(size_t)(b0 + s) * (P.in.mask + 1u) + ((uint32_t)(P.n0 + c0 + k) & P.in.mask)];
+        __syncthreads();
+        for (int half = 0; half < 2; ++half) {
+            const int k0 = half * (TXF_CH / 2), k1 = min(len, k0 + TXF_CH / 2);
+            if (active) {
+                for (int k = k0; k < k1; ++k) {
+                    phase = phase + P.k * win[lane][k];
+                    phase = fmodf(phase + F_PI, 2.0f * F_PI) - F_PI;
+                    const float2 cs = sincos_rad(phase);
+                    wout[lane][k - k0] = make_float2(cs.x * P.amp, cs.y * P.amp);
+                }
+            }
+            __syncthreads();
+            for (int s = 0; s < nstreams; ++s)
+                for (int k = k0 + lane; k < k1; k += 64)
+                    P.out.p[(size_t)(b0 + s) * (P.out.mask + 1u) + ((uint32_t)(P.n0 + c0 + k) & P.out.mask)] = wout[s][k - k0];
+            __syncthreads();
+        }
+    }
+    if (active) P.phase[b] = phase;
+}
+void launch_tx_fm(const TxFmParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_tx_fm, dim3((batch + 63) / 64), dim3(64), 0, s, p, batch);
+}
+
+__global__ __launch_bounds__(256) void k_tx_interp_c(const TxInterpCParams P)
+{
+    __shared__ float taps[2048];
+    for (int k = threadIdx.x; k < P.nt && k < 2048; k += 256) taps[k] = P.taps[k];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.count) return;
+    const uint64_t n = P.n0 + t;
+    const uint64_t c = n / (uint64_t)P.interp;
+    const int ph = (int)(n - c * (uint64_t)P.interp);
+    const float2* ring = P.in.p + (size_t)b * (P.in.mask + 1u);
+    float ar = 0.f, ai = 0.f;
+    for (int j = 0; ph + j * P.interp < P.nt; ++j) {
+        if ((uint64_t)j > c) break;
+        const float h = taps[ph + j * P.interp];
+        const float2 x = ring[(uint32_t)(c - j) & P.in.mask];
+        ar = fmaf(h, x.x, ar);
+        ai = fmaf(h, x.y, ai);
+    }
+    P.out[(size_t)b * P.out_stride + t] = make_float2(ar, ai);
+}
+void launch_tx_interp_c(const TxInterpCParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_tx_interp_c, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
 }
 
 }  // namespace qrl

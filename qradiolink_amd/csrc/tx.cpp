@@ -26,14 +26,19 @@ struct qrl_mod {
     qrl_mod_config cfg{};
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    enum { F_QPSK, F_FSK } fam = F_QPSK;
     int sps = 4;
     float bb_gain = 1.0f;
     float* taps = nullptr; int nt = 0;
+    // FSK family (2FSK / GMSK): shaping taps (nt_shape = 0: repeat), FM constant, amplitude, second interpolator
+    float* shape_taps = nullptr; int nt_shape = 0; float fm_k = 0, amplif = 0; int interp2 = 1;
+    float* shaped = nullptr; float2* fmv = nullptr; uint32_t r1_mask = 0; float* phase = nullptr;
     TxState* st = nullptr;
     uint8_t* sym = nullptr; uint32_t sym_mask = 0;
     uint64_t nsym = 0;   // symbols (= input bits) so far
     ~qrl_mod() {
         if (taps) (void)hipFree(taps);
+        for (void* p : {(void*)shape_taps, (void*)shaped, (void*)fmv, (void*)phase}) if (p) (void)hipFree(p);
         if (st) (void)hipFree(st);
         if (sym) (void)hipFree(sym);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -43,6 +48,11 @@ struct qrl_mod {
         for (auto& x : s) { x.sr = 0x7F; x.enc = 0; x.prev = 0; x.pad = 0; }   // scrambler seed 0x7F (gr_mod_qpsk.cpp:62)
         if (hipMemcpy(st, s.data(), s.size() * sizeof(TxState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
         if (hipMemset(sym, 0, (size_t)cfg.batch * (sym_mask + 1)) != hipSuccess) return QRL_ERR_HIP;
+        if (fam == F_FSK) {
+            if (hipMemset(shaped, 0, (size_t)cfg.batch * (r1_mask + 1) * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
+            if (hipMemset(fmv, 0, (size_t)cfg.batch * (r1_mask + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
+            if (hipMemset(phase, 0, (size_t)cfg.batch * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
+        }
         nsym = 0;
         return QRL_OK;
     }
@@ -71,25 +81,85 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
     if (!m) return QRL_ERR_NOMEM;
     m->ctx = ctx; m->cfg = *cfg;
     qrl_mod_config& c = m->cfg;
-    if (c.use_mode_defaults) {
-        if (c.modem_type != QRL_MODEM_QPSK250K) return qrl_set_error(QRL_ERR_ARG, "modulator: modem_type not supported by this build");
-        c.sps = 4; c.samp_rate = 1000000; c.carrier_freq = 1700; c.filter_width = 160000;   // gr_mod_base.cpp:175
+    bool fsk = false, gmsk = false;
+    if (c.use_mode_defaults) {   // literals of gr_mod_base.cpp:154-175
+        c.samp_rate = 1000000; c.carrier_freq = 1700; c.fm = 0;
+        switch (c.modem_type) {
+        case QRL_MODEM_QPSK250K:  c.sps = 4;   c.filter_width = 160000; break;
+        case QRL_MODEM_2FSK2KFM:  c.sps = 25;  c.filter_width = 4000;  c.fm = 1; break;
+        case QRL_MODEM_2FSK1KFM:  c.sps = 50;  c.filter_width = 2500;  c.fm = 1; break;
+        case QRL_MODEM_2FSK2K:    c.sps = 25;  c.filter_width = 4000;  break;
+        case QRL_MODEM_2FSK1K:    c.sps = 50;  c.filter_width = 2000;  break;
+        case QRL_MODEM_2FSK10KFM: c.sps = 5;   c.filter_width = 25000; c.fm = 1; break;
+        case QRL_MODEM_GMSK2K:    c.sps = 50;  c.filter_width = 4000;  break;
+        case QRL_MODEM_GMSK1K:    c.sps = 100; c.filter_width = 2000;  break;
+        case QRL_MODEM_GMSK10K:   c.sps = 10;  c.filter_width = 20000; break;
+        default: return qrl_set_error(QRL_ERR_ARG, "modulator: modem_type not supported by this build");
+        }
     }
-    if (c.modem_type != QRL_MODEM_QPSK250K || c.sps < 2 || c.sps > 10)
-        return qrl_set_error(QRL_ERR_ARG, "modulator: only the QPSK sps <= 10 geometry is built");
+    switch (c.modem_type) {
+    case QRL_MODEM_QPSK250K: break;
+    case QRL_MODEM_2FSK2KFM: case QRL_MODEM_2FSK1KFM: case QRL_MODEM_2FSK2K: case QRL_MODEM_2FSK1K: case QRL_MODEM_2FSK10KFM: fsk = true; break;
+    case QRL_MODEM_GMSK2K: case QRL_MODEM_GMSK1K: case QRL_MODEM_GMSK10K: fsk = gmsk = true; break;
+    default: return qrl_set_error(QRL_ERR_ARG, "modulator: modem_type not supported by this build");
+    }
+    if (!fsk && (c.sps < 2 || c.sps > 10)) return qrl_set_error(QRL_ERR_ARG, "modulator: only the QPSK sps <= 10 geometry is built");
     m->sps = c.sps;
     m->bb_gain = c.bb_gain == 0.0f ? 1.0f : c.bb_gain;
     HIPCHK(hipSetDevice(ctx->device));
     if (c.hip_stream) m->stream = static_cast<hipStream_t>(c.hip_stream);
     else { HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
-    const std::vector<float> rrc = root_raised_cosine(m->sps, m->sps, 1, 0.35, 15 * m->sps);   // nfilts = 15 for sps <= 10
-    m->nt = (int)rrc.size();
-    if (m->nt > 256) return qrl_set_error(QRL_ERR_ARG, "modulator: pulse-shaping filter too long");
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->taps), rrc.size() * sizeof(float)));
-    HIPCHK(hipMemcpy(m->taps, rrc.data(), rrc.size() * sizeof(float), hipMemcpyHostToDevice));
+    auto upload = [](const std::vector<float>& v, float** dst) -> int {
+        if (hipMalloc(reinterpret_cast<void**>(dst), std::max<size_t>(v.size(), 1) * sizeof(float)) != hipSuccess) return QRL_ERR_NOMEM;
+        if (!v.empty() && hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
+        return QRL_OK;
+    };
+    size_t ring_items = c.max_bytes * 8 + 256;   // symbol ring: one item per input bit (QPSK) or per coded bit (FSK: x2)
+    if (!fsk) {
+        const std::vector<float> rrc = root_raised_cosine(m->sps, m->sps, 1, 0.35, 15 * m->sps);   // nfilts = 15 for sps <= 10
+        m->nt = (int)rrc.size();
+        if (m->nt > 256) return qrl_set_error(QRL_ERR_ARG, "modulator: pulse-shaping filter too long");
+        int r0 = upload(rrc, &m->taps);
+        if (r0) return r0;
+    } else {
+        m->fam = qrl_mod::F_FSK;
+        int sps = c.sps, nfilts;
+        std::vector<float> shape;
+        if (gmsk) {   // gr_mod_gmsk.cpp:40-70
+            nfilts = 35; m->interp2 = 5; m->amplif = 0.9f;
+            if (sps == 10) { sps = 50; m->interp2 = 1; nfilts = 55; }
+            if (sps == 50) nfilts = 55;
+            if (sps == 100) nfilts = 35;
+            if ((nfilts % 2) == 0) nfilts += 1;
+            shape = gaussian(sps, sps, 0.3, nfilts);
+            m->fm_k = (float)((M_PI / 2) / sps);
+        } else {      // gr_mod_2fsk.cpp:38-62
+            nfilts = 25 * sps; m->interp2 = 10; m->amplif = c.fm ? 0.9f : 0.8f;
+            if (sps == 5) nfilts *= 5;
+            if ((nfilts % 2) == 0) nfilts += 1;
+            if (c.fm) shape = root_raised_cosine(sps, sps, 1, 0.2, nfilts);
+            m->fm_k = (float)(((c.fm ? 1 : 2) * M_PI / 2) / sps);
+        }
+        m->sps = sps;
+        m->nt_shape = (int)shape.size();
+        if (m->nt_shape > 1536) return qrl_set_error(QRL_ERR_ARG, "modulator: shaping filter too long");
+        int r0 = upload(shape, &m->shape_taps);
+        if (r0) return r0;
+        const std::vector<float> lp = low_pass(m->interp2, c.samp_rate, c.filter_width, c.filter_width, WIN_HAMMING);
+        m->nt = (int)lp.size();
+        if (m->nt > 2048) return qrl_set_error(QRL_ERR_ARG, "modulator: interpolator filter too long");
+        if ((r0 = upload(lp, &m->taps))) return r0;
+        ring_items = c.max_bytes * 16 + 256;
+        uint32_t cap1 = 1024;
+        while (cap1 < c.max_bytes * 16 * (size_t)sps + (size_t)m->nt + 256) cap1 <<= 1;
+        m->r1_mask = cap1 - 1;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->shaped), (size_t)c.batch * cap1 * sizeof(float)));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->fmv), (size_t)c.batch * cap1 * sizeof(float2)));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->phase), (size_t)c.batch * sizeof(float)));
+    }
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->st), (size_t)c.batch * sizeof(TxState)));
     uint32_t cap = 1024;
-    while (cap < c.max_bytes * 8 + 256) cap <<= 1;
+    while (cap < ring_items) cap <<= 1;
     m->sym_mask = cap - 1;
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->sym), (size_t)c.batch * cap));
     int r = m->init_state();
@@ -105,7 +175,11 @@ int qrl_mod_reset(qrl_mod* m)
     return m->init_state();
 }
 int qrl_mod_set_bb_gain(qrl_mod* m, float g) { if (!m) return QRL_ERR_ARG; m->bb_gain = g; return QRL_OK; }
-size_t qrl_mod_samples_per_byte(const qrl_mod* m) { return m ? (size_t)8 * m->sps : 0; }
+size_t qrl_mod_samples_per_byte(const qrl_mod* m)
+{
+    if (!m) return 0;
+    return m->fam == qrl_mod::F_FSK ? (size_t)16 * m->sps * m->interp2 : (size_t)8 * m->sps;
+}
 
 int qrl_mod_process(qrl_mod* m, const uint8_t* bytes, size_t stride, size_t nbytes, float* iq, size_t out_stride)
 {
@@ -120,7 +194,26 @@ int qrl_mod_process(qrl_mod* m, const uint8_t* bytes, size_t stride, size_t nbyt
     p.L = ((nbits + 63) / 64 + 31) / 32 * 32;
     lfsr_power(p.L, p.tl_cols);
     p.st = m->st; p.sym = RingB{m->sym, m->sym_mask}; p.s0 = m->nsym;
+    p.mode = m->fam == qrl_mod::F_FSK ? 1 : 0;
     launch_tx_qpsk_bits(p, B, m->stream);
+    if (m->fam == qrl_mod::F_FSK) {
+        // nsym counts CODED bits here (2 per input bit); rate-1 samples = coded bits * sps
+        const uint32_t ncoded = 2 * nbits;
+        const uint64_t n1_0 = m->nsym * (uint64_t)m->sps;
+        const uint32_t c1 = ncoded * (uint32_t)m->sps;
+        TxShapeParams sp{}; sp.sym = p.sym; sp.out = RingF{m->shaped, m->r1_mask}; sp.n0 = n1_0; sp.count = c1; sp.sps = m->sps;
+        sp.taps = m->shape_taps; sp.nt = m->nt_shape;
+        launch_tx_shape(sp, B, m->stream);
+        TxFmParams fp{}; fp.in = sp.out; fp.out = RingC{m->fmv, m->r1_mask}; fp.n0 = n1_0; fp.count = c1; fp.k = m->fm_k; fp.amp = m->amplif;
+        fp.phase = m->phase;
+        launch_tx_fm(fp, B, m->stream);
+        TxInterpCParams ip{}; ip.in = fp.out; ip.n0 = n1_0 * (uint64_t)m->interp2; ip.count = c1 * (uint32_t)m->interp2;
+        ip.taps = m->taps; ip.nt = m->nt; ip.interp = m->interp2; ip.out = reinterpret_cast<float2*>(iq); ip.out_stride = out_stride;
+        launch_tx_interp_c(ip, B, m->stream);
+        HIPCHK(hipGetLastError());
+        m->nsym += ncoded;
+        return QRL_OK;
+    }
     TxInterpParams q{};
     q.sym = p.sym; q.n0 = m->nsym * (uint64_t)m->sps; q.count = nbits * (uint32_t)m->sps;
     q.taps = m->taps; q.nt = m->nt; q.interp = m->sps;

@@ -106,3 +106,70 @@ def test_full_duplex_two_streams(qrl_ctx):
         assert np.array_equal(tx[b].view(np.uint32), orc.mod_qpsk(tx_data[b]).view(np.uint32))
         ref = orc.demod_qpsk(orc.frontend(rx_iq[b, :4 * step], 1000000, 0.0))
         assert np.array_equal(np.concatenate(rx_bits[b]), ref["bits_a"])
+
+
+# ---- FSK family modulators (gr_mod_2fsk incl. FM variants, gr_mod_gmsk)
+FSK_CASES = [
+    # modem, oracle call, bytes
+    (18, lambda d: orc.mod_2fsk(d, sps=50, filter_width=2000, fm=False), 24),    # 2FSK1K   (gr_mod_base.cpp:158)
+    (16, lambda d: orc.mod_2fsk(d, sps=50, filter_width=2500, fm=True), 24),     # 2FSK1KFM (:156)
+    (17, lambda d: orc.mod_2fsk(d, sps=25, filter_width=4000, fm=False), 40),    # 2FSK2K
+    (19, lambda d: orc.mod_2fsk(d, sps=5, filter_width=25000, fm=True), 200),    # 2FSK10KFM
+    (22, lambda d: orc.mod_gmsk(d, sps=10, filter_width=20000), 300),            # GMSK10K  (:162)
+    (20, lambda d: orc.mod_gmsk(d, sps=50, filter_width=4000), 40),              # GMSK2K
+    (21, lambda d: orc.mod_gmsk(d, sps=100, filter_width=2000), 20),             # GMSK1K
+]
+
+
+@pytest.mark.parametrize("modem,oracle,nbytes", FSK_CASES, ids=[str(c[0]) for c in FSK_CASES])
+def test_mod_fsk_family_bit_exact(qrl_ctx, modem, oracle, nbytes):
+    import torch
+    import qradiolink_amd as q
+    rng = np.random.default_rng(modem)
+    data = np.stack([_payload(rng, nbytes) for _ in range(3)])
+    mod = q.Mod(qrl_ctx, modem, batch=3, max_bytes=nbytes)
+    out = mod.process(torch.from_numpy(data).cuda()).cpu().numpy()
+    mod.close()
+    for b in range(3):
+        ref = oracle(data[b])
+        assert out[b].size == ref.size, (out[b].size, ref.size)
+        assert np.array_equal(out[b].view(np.uint32), ref.view(np.uint32)), "stream %d differs" % b
+
+
+@pytest.mark.parametrize("modem,oracle", [(18, FSK_CASES[0][1]), (22, FSK_CASES[4][1])], ids=["2fsk1k", "gmsk10k"])
+def test_mod_fsk_chunk_invariance(qrl_ctx, modem, oracle):
+    import torch
+    import qradiolink_amd as q
+    rng = np.random.default_rng(77)
+    cuts = [3, 1, 17, 9]
+    data = _payload(rng, sum(cuts))[None, :]
+    mod = q.Mod(qrl_ctx, modem, batch=1, max_bytes=max(cuts))
+    d = torch.from_numpy(data).cuda()
+    parts, pos = [], 0
+    for c in cuts:
+        parts.append(mod.process(d[:, pos:pos + c].contiguous()).cpu().numpy())
+        pos += c
+    mod.close()
+    got = np.concatenate(parts, axis=1)[0]
+    assert np.array_equal(got.view(np.uint32), oracle(data[0]).view(np.uint32))
+
+
+@pytest.mark.parametrize("mode,modem,sync,nbits", [("gmsk10k", 22, bytes([0xED, 0x89]), 384), ("2fsk1k", 18, bytes([0xB5]), 32)])
+def test_fsk_tx_rx_loopback_on_gpu(qrl_ctx, mode, modem, sync, nbits):
+    import torch
+    import qradiolink_amd as q
+    rng = np.random.default_rng(13)
+    data, payloads = sig.frames(mode, 3, rng)
+    mod = q.Mod(qrl_ctx, modem, batch=1, max_bytes=data.size)
+    iq = mod.process(torch.from_numpy(data[None, :]).cuda())
+    mod.close()
+    iq = (iq * 0.2).contiguous()
+    n = iq.shape[1] & ~1
+    dem = q.Demod(qrl_ctx, modem, batch=1, max_chunk=n)
+    out = q.collect(dem, iq[:, :n], n)
+    dem.close()
+    best = 0
+    for k in ("bits_a", "bits_b"):
+        fr = sig.find_frames(out[k][0], sync, nbits)
+        best = max(best, sum(((bytes([0xAA]) + p) if mode == "gmsk10k" else p) in fr for p in payloads))
+    assert best >= len(payloads) - 1   # the last frame may sit in the decoder's look-ahead
