@@ -37,9 +37,10 @@ typedef enum {
 
 /* values of gr_modem_types (reference src/modem_types.h:5-50) accepted by qrl_demod_create */
 enum {
+    QRL_MODEM_BPSK2K = 0, QRL_MODEM_4FSK10KFM = 4, QRL_MODEM_4FSK2KFM = 5, QRL_MODEM_4FSK1KFM = 6,
     QRL_MODEM_2FSK2KFM = 15, QRL_MODEM_2FSK1KFM = 16, QRL_MODEM_2FSK2K = 17, QRL_MODEM_2FSK1K = 18,
     QRL_MODEM_2FSK10KFM = 19, QRL_MODEM_GMSK2K = 20, QRL_MODEM_GMSK1K = 21, QRL_MODEM_GMSK10K = 22,
-    QRL_MODEM_QPSK250K = 26, QRL_MODEM_DMR = 41
+    QRL_MODEM_BPSK1K = 24, QRL_MODEM_QPSK250K = 26, QRL_MODEM_4FSK100K = 27, QRL_MODEM_DMR = 41
 };
 
 typedef struct qrl_ctx qrl_ctx;
@@ -132,6 +133,10 @@ typedef struct {
     void* hip_stream;        /* hipStream_t, NULL = the library creates one (RX and TX handles on different streams run
                                 concurrently: full duplex, reference src/radiocontroller.cpp:2043-2078) */
     float bb_gain;           /* gr_mod_qpsk::set_bb_gain, 0 = 1.0 */
+    /* gr_mod_base back end (src/gr/gr_mod_base.cpp:38,215-258): modulator (1 Msps) -> rotator_cc(2 pi offset / 1e6) ->
+     * rational_resampler_ccf(fs/1e6, 1, low_pass(I, fs, 480k, 20k, BLACKMAN_HARRIS)) when fs >= 2 Msps -> SDR sink */
+    int device_samp_rate;    /* gr_mod_base::set_samp_rate: 0 / 1e6 = no resampler, else a multiple of 1e6 in [2e6, 64e6] */
+    double carrier_offset_hz;/* gr_mod_base::set_carrier_offset (rotator at 1 Msps) */
 } qrl_mod_config;
 int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** out);
 void qrl_mod_destroy(qrl_mod* m);
@@ -139,7 +144,10 @@ void qrl_mod_destroy(qrl_mod* m);
 int qrl_mod_reset(qrl_mod* m);
 /* replaces: gr_mod_qpsk::set_bb_gain (src/gr/gr_mod_qpsk.cpp:91-94) */
 int qrl_mod_set_bb_gain(qrl_mod* m, float value);
-size_t qrl_mod_samples_per_byte(const qrl_mod* m);   /* 8 * sps */
+/* replaces: gr_mod_base::set_carrier_offset -> rotator_cc::set_phase_inc (src/gr/gr_mod_base.cpp:799-805); phase-continuous.
+ * Only for handles created with the back end (device_samp_rate >= 2e6 or a non-zero initial offset). */
+int qrl_mod_set_carrier_offset(qrl_mod* m, double hz);
+size_t qrl_mod_samples_per_byte(const qrl_mod* m);   /* at the DEVICE rate: 8*sps (QPSK) or 16*sps*interp (FSK), times fs/1e6 */
 /* replaces: gr_mod_base::set_data (src/gr/gr_mod_base.cpp:783-786) + gr_byte_source::work (src/gr/gr_byte_source.cpp:75-106)
  * + one scheduler pass of every block of gr_mod_qpsk: bytes[b*stride + i], i < nbytes (device, packed, MSB first) ->
  * iq[2*(b*out_stride + k)], k < nbytes*8*sps (device cf32).  State (scrambler, encoder, differential symbol, pulse-shaping

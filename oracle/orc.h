@@ -115,6 +115,16 @@ size_t orc_mod_qpsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate,
 /* TX back end of gr_mod_base: interpolate 1 Msps -> fs with low_pass(I, fs, 480k, 20k, BH) */
 size_t orc_tx_interp(const cf32* in, size_t n, int samp_rate, cf32* out);
 
+void orc_demod_4fsk(const cf32* in, size_t n, int sps, int samp_rate, int carrier_freq, int filter_width, int fm, orc_demod_out* o);
+void orc_demod_bpsk(const cf32* in, size_t n, int sps, int samp_rate, int carrier_freq, int filter_width, orc_demod_out* o);
+size_t orc_mod_4fsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, int fm, cf32* out);
+size_t orc_mod_bpsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, cf32* out);
+size_t orc_clock_recovery_mm_cc(const cf32* in, size_t n, float omega, float gain_omega, float mu, float gain_mu,
+                                float omega_relative_limit, cf32* out);
+size_t orc_rssi_tag(const cf32* in, size_t n, float calibration, float* db);
+size_t orc_demod_mmdvm(const cf32* in, size_t n, int samp_rate, int filter_width, int16_t* out, size_t cap, float* rssi, float cal,
+                       size_t* n_rssi);
+size_t orc_demod_mmdvm_multi_rssi(const cf32* in, size_t n, int M, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal);
 void orc_demod_dmr(const cf32* in, size_t n, int sps, int samp_rate, orc_demod_out* o);
 void orc_4fsk_symbols_to_bits(const float* sym, size_t nsym, cf32* constellation, uint8_t* bits);
 /* multi-carrier MMDVM RX (gr_demod_mmdvm_multi2): PFB channelizer + per-channel 24/25 resampler, LPF, FM discriminator, int16 */

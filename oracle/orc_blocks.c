@@ -350,11 +350,13 @@ void orc_costas(const cf32* in, size_t n, float bw, int order, int use_snr, cf32
 static inline float slice_real(int constellation, float x)
 {
     if (constellation == ORC_CONST_BPSK) return x > 0 ? 1.0f : -1.0f;
-    /* constellation_rect {-1.5,-0.5,0.5,1.5}: nearest point, ties to the lower index */
-    float best = -1.5f, bd = fabsf(x + 1.5f);
-    const float pts[4] = {-1.5f, -0.5f, 0.5f, 1.5f};
-    for (int i = 1; i < 4; i++) { float d = fabsf(x - pts[i]); if (d < bd) { bd = d; best = pts[i]; } }
-    return best;
+    /* constellation_rect::make(points {-1.5,-0.5,0.5,1.5}, -, 2, 4, 1, 1.0, 1.0) [gr-digital constellation.cc:
+     * constellation_sector::decision_maker -> constellation_rect::get_sector]: real sector =
+     * (int)(re / width_real + n_real / 2.0) clamped to [0, 3] (boundaries at -1, 0, 1; a value ON a boundary, e.g. the
+     * zeros before the signal starts, goes to the upper sector); the sector's point is the one closest to its centre. */
+    int sector = (int)((double)x / 1.0 + 2.0);
+    if (sector < 0) sector = 0; else if (sector > 3) sector = 3;
+    return (float)sector - 1.5f;
 }
 
 typedef struct { float avg, inst, alpha, beta, maxp, minp; } clock_loop;
@@ -555,4 +557,63 @@ void orc_cc_encode_k7(const uint8_t* bits, size_t n, uint8_t* out)
         out[2 * i] = (uint8_t)parity32(st & 109u);
         out[2 * i + 1] = (uint8_t)parity32(st & 79u);
     }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * clock_recovery_mm_cc [gr-digital/lib/clock_recovery_mm_cc_impl.cc], as instantiated by gr_demod_bpsk.cpp:56-62
+ * (omega = sps, gain_omega = 2.5e-5, mu = 0.5, gain_mu = 0.05, omega_relative_limit = 0.001).  8-tap MMSE
+ * interpolator (same table / summation order as symbol_sync); slicer_0deg gives (re > 0, im > 0) as 0/1.
+ * A symbol at cursor ii exists iff in[ii..ii+7] exist (the block's scheduler FUDGE is not modelled).
+ * ------------------------------------------------------------------------------------------ */
+size_t orc_clock_recovery_mm_cc(const cf32* in, size_t n, float omega, float gain_omega, float mu, float gain_mu,
+                                float omega_relative_limit, cf32* out)
+{
+    const float* T = orc_mmse_table();
+    const float omega_mid = omega, omega_lim = omega_relative_limit * omega;
+    cf32 p2 = {0, 0}, p1 = {0, 0}, p0 = {0, 0}, c2 = {0, 0}, c1 = {0, 0}, c0 = {0, 0};
+    size_t ii = 0, oo = 0;
+    while (ii + 8 <= n) {
+        int imu = (int)rintf(mu * 128.0f);
+        const float* t = T + imu * 8;
+        cf32 y = {0.0f, 0.0f};
+        for (int k = 0; k < 8; k++) {
+            y.re = fmaf(t[7 - k], in[ii + (size_t)k].re, y.re);
+            y.im = fmaf(t[7 - k], in[ii + (size_t)k].im, y.im);
+        }
+        p2 = p1; p1 = p0; p0 = y;
+        c2 = c1; c1 = c0; c0.re = y.re > 0.0f ? 1.0f : 0.0f; c0.im = y.im > 0.0f ? 1.0f : 0.0f;
+        /* x = (c0 - c2) * conj(p1); y = (p0 - p2) * conj(c1); mm = Re(y - x) */
+        const float ar = c0.re - c2.re, ai = c0.im - c2.im;
+        const float xr = ar * p1.re + ai * p1.im;
+        const float br = p0.re - p2.re, bi = p0.im - p2.im;
+        const float yr = br * c1.re + bi * c1.im;
+        float mm = branchless_clip(yr - xr, 1.0f);
+        out[oo++] = y;
+        omega = omega + gain_omega * mm;
+        omega = omega_mid + branchless_clip(omega - omega_mid, omega_lim);
+        mu = mu + omega + gain_mu * mm;
+        const float fl = floorf(mu);
+        ii += (size_t)(int)fl;
+        mu = mu - fl;
+    }
+    return oo;
+}
+
+/* rssi_tag_block::work (reference src/gr/rssi_tag_block.cpp:43-68): every 300 samples one value
+ * 10*log10f(sqrt(sum(|x|^4) / 300) + 1e-20) + calibration; the sum is a serial float accumulation.  Returns the count. */
+size_t orc_rssi_tag(const cf32* in, size_t n, float calibration, float* db)
+{
+    float sum = 0.0f; int nitems = 0; size_t k = 0;
+    for (size_t i = 0; i < n; i++) {
+        const float pwr = in[i].re * in[i].re + in[i].im * in[i].im;
+        sum += pwr * pwr;
+        nitems += 1;
+        if (nitems >= 300) {
+            const float level = sqrtf(sum / (float)nitems);
+            if (db) db[k] = (float)(10.0f * log10f(level + 1.0e-20f)) + calibration;
+            k++;
+            sum = 0; nitems = 0;
+        }
+    }
+    return k;
 }

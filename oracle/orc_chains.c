@@ -391,6 +391,202 @@ size_t orc_tx_interp(const cf32* in, size_t n, int samp_rate, cf32* out)
     return m;
 }
 
+static int16_t f2s(float x, float scale);
+/* gr_demod_4fsk.cpp:28-200, FM branch (instances gr_demod_base.cpp:212-214,225: 4FSK2KFM sps 5, 4FSK1KFM sps 10, 4FSK10KFM
+ * sps 1, 4FSK100K sps 2):  rational_resampler_ccf(I, D, low_pass(I, I*fs, T/2, T/2, BH)) -> fft_filter_ccf(low_pass(1, T, fw,
+ * fw/2, BH)) [port 0] -> quadrature_demod_cf(sps/pi) -> fft_filter_fff(RRC(1.5, T, T/sps, 0.2, nfilts)) -> symbol_sync_ff(
+ * TED_MOD_MUELLER_AND_MULLER, sps, 2pi/200, 1.0, 0.2869, 0.05, 1, constellation_rect{-1.5..1.5}) -> phase_modulator_fc(pi/2)
+ * [port 1] -> complex_to_float -> interleave(4) with (imag, real) port order -> x128 +128 -> uchar -> cc_decoder -> descrambler
+ * [port 2].  blocks::interleave(itemsize 4, blocksize 1)?  No: make(4) is the ITEM SIZE (bytes of a float), blocksize defaults
+ * to 1, so the soft stream is im0, re0, im1, re1, ...  The non-FM branch (4FSK2K: four band-pass magnitudes ->
+ * gr_4fsk_discriminator -> symbol_sync_cc) is not restated yet. */
+void orc_demod_4fsk(const cf32* in, size_t n, int sps, int samp_rate, int carrier_freq, int filter_width, int fm, orc_demod_out* o)
+{
+    (void)carrier_freq;
+    memset(o, 0, sizeof *o);
+    if (!fm) return;
+    int target, sps_eff, decim, interp, nfilts;
+    if (sps == 1)       { target = 80000;  sps_eff = 8;  decim = 25;  interp = 2; nfilts = 32 * 8; }
+    else if (sps == 5)  { target = 20000;  sps_eff = 10; decim = 50;  interp = 1; nfilts = 25 * 10; }
+    else if (sps == 10) { target = 10000;  sps_eff = 10; decim = 100; interp = 1; nfilts = 25 * 10; }
+    else                { target = 500000; sps_eff = 5;  decim = 2;   interp = 1; nfilts = 50 * 5; }
+    if ((nfilts % 2) == 0) nfilts += 1;
+    int nt = orc_low_pass(interp, (double)interp * samp_rate, target / 2, target / 2, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* taps = NEW(float, nt);
+    orc_low_pass(interp, (double)interp * samp_rate, target / 2, target / 2, ORC_WIN_BLACKMAN_HARRIS, taps);
+    size_t n1 = orc_decim_count(n, interp, decim);
+    cf32* s1 = NEW(cf32, n1);
+    if (interp == 1) orc_decim_auto(in, n, taps, nt, decim, s1);
+    else             orc_resamp_ccf(in, n, taps, nt, interp, decim, s1);
+    free(taps);
+    int nf = orc_low_pass(1, target, filter_width, filter_width / 2, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* ft = NEW(float, nf);
+    orc_low_pass(1, target, filter_width, filter_width / 2, ORC_WIN_BLACKMAN_HARRIS, ft);
+    o->filtered = NEW(cf32, n1); o->n_filtered = n1;
+    orc_fir_ccf(s1, n1, ft, nf, o->filtered);
+    free(ft); free(s1);
+    float* dem = NEW(float, n1);
+    orc_quad_demod(o->filtered, n1, (float)(sps_eff / (1 * M_PI)), dem);
+    int nr = orc_root_raised_cosine(1.5, target, target / sps_eff, 0.2, nfilts, NULL);
+    float* rrc = NEW(float, nr);
+    orc_root_raised_cosine(1.5, target, target / sps_eff, 0.2, nfilts, rrc);
+    float* s5 = NEW(float, n1);
+    orc_fir_fff(dem, n1, rrc, nr, s5);
+    free(rrc); free(dem);
+    float* sym = NEW(float, n1 / (size_t)(sps_eff - 1) + 16);
+    size_t nsym = orc_symbol_sync_ff(s5, n1, ORC_TED_MOD_MM, (float)sps_eff, (float)(2 * M_PI / 200.0f), 1.0f, 0.2869f, 0.05f,
+                                     ORC_CONST_4LEVEL, sym);
+    free(s5);
+    o->constellation = NEW(cf32, nsym); o->n_const = nsym;
+    float* fl = NEW(float, 2 * nsym + 2);
+    const float k = (float)(M_PI / 2);
+    for (size_t i = 0; i < nsym; i++) {
+        cf32 c; orc_sincosf(k * sym[i], &c.im, &c.re);
+        o->constellation[i] = c;
+        fl[2 * i] = c.im; fl[2 * i + 1] = c.re;       /* interleave: port 0 <- imag, port 1 <- real (gr_demod_4fsk.cpp:182-185) */
+    }
+    free(sym);
+    uint8_t* soft = NEW(uint8_t, 2 * nsym + 2);
+    orc_soft_quant(fl, 2 * nsym, 128.0f, 128.0f, soft);
+    free(fl);
+    uint8_t* dec = NEW(uint8_t, nsym + 80);
+    size_t nb = orc_cc_decode_k7(soft, 2 * nsym, dec);
+    o->bits_a = NEW(uint8_t, nb + 1); o->n_bits_a = nb;
+    orc_descramble(dec, nb, 0x8A, 0x7F, 7, o->bits_a);
+    free(soft); free(dec);
+}
+
+/* gr_mod_4fsk.cpp:28-115 (instances gr_mod_base.cpp:163-166,177) */
+size_t orc_mod_4fsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, int fm, cf32* out)
+{
+    (void)carrier_freq;
+    int nfilts = sps * 10, second_interp = 20;
+    if (sps == 2) { sps = 5; second_interp = 2; nfilts = 256; }
+    const int spacing = fm ? 1 : 2;
+    const float amplif = fm ? 0.9f : 0.8f;
+    size_t nout = nbytes * 8 * (size_t)sps * (size_t)second_interp;
+    if (!out) return nout;
+    uint8_t* coded; size_t nc = tx_bits(bytes, nbytes, &coded);
+    static const int map[4] = {0, 1, 3, 2};
+    static const float levels[4] = {-1.5f, -0.5f, 0.5f, 1.5f};
+    size_t ns = nc / 2;
+    float* sym = NEW(float, ns);
+    for (size_t i = 0; i < ns; i++) sym[i] = levels[map[(coded[2 * i] << 1) | coded[2 * i + 1]]];
+    free(coded);
+    size_t n1 = ns * (size_t)sps;
+    float* shaped = NEW(float, n1);
+    if (fm) {
+        int nr = orc_root_raised_cosine(sps, sps, 1, 0.2, nfilts, NULL);
+        float* rrc = NEW(float, nr);
+        orc_root_raised_cosine(sps, sps, 1, 0.2, nfilts, rrc);
+        orc_resamp_fff(sym, ns, rrc, nr, sps, 1, shaped);
+        free(rrc);
+        const float sc = (float)0.66666666;
+        for (size_t i = 0; i < n1; i++) shaped[i] = shaped[i] * sc;
+    } else {
+        for (size_t i = 0; i < n1; i++) shaped[i] = sym[i / (size_t)sps];
+    }
+    free(sym);
+    cf32* fmv = NEW(cf32, n1);
+    fm_mod(shaped, n1, (float)((spacing * M_PI) / sps), fmv);
+    free(shaped);
+    for (size_t i = 0; i < n1; i++) { fmv[i].re *= amplif; fmv[i].im *= amplif; }
+    int nt = orc_low_pass(second_interp, samp_rate, filter_width, filter_width, ORC_WIN_HAMMING, NULL);
+    float* lp = NEW(float, nt);
+    orc_low_pass(second_interp, samp_rate, filter_width, filter_width, ORC_WIN_HAMMING, lp);
+    size_t m = orc_resamp_ccf(fmv, n1, lp, nt, second_interp, 1, out);
+    free(lp); free(fmv);
+    return m;
+}
+
+/* gr_mod_bpsk.cpp:28-67 (instances gr_mod_base.cpp:168-169: sps 500 / 250) */
+size_t orc_mod_bpsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, cf32* out)
+{
+    (void)carrier_freq; (void)samp_rate; (void)filter_width;
+    size_t nout = nbytes * 16 * (size_t)sps;
+    if (!out) return nout;
+    uint8_t* coded; size_t nc = tx_bits(bytes, nbytes, &coded);
+    cf32* sym = NEW(cf32, nc);
+    for (size_t i = 0; i < nc; i++) { sym[i].re = coded[i] ? 1.0f : -1.0f; sym[i].im = 0.0f; }
+    free(coded);
+    int nr = orc_root_raised_cosine(sps, sps, 1, 0.35, 11 * sps, NULL);
+    float* rrc = NEW(float, nr);
+    orc_root_raised_cosine(sps, sps, 1, 0.35, 11 * sps, rrc);
+    size_t m = orc_resamp_ccf(sym, nc, rrc, nr, sps, 1, out);
+    for (size_t i = 0; i < m; i++) { out[i].re *= 0.6f; out[i].im *= 0.6f; }
+    free(rrc); free(sym);
+    return m;
+}
+
+/* gr_demod_bpsk.cpp:36-110 (instances gr_demod_base.cpp:216-217: sps 10 / 5, both at 20 ksps):
+ * rational_resampler_ccf(1, 50, low_pass(1, fs, 10k, 10k, BH)) -> fll_band_edge_cc(sps, 0.35, 32, 8pi/100) -> fft_filter_ccf(
+ * RRC(sps, sps, 1, 0.35, 15 sps)) [port 0] -> agc2_cc(0.1, 0.1, 1, 1) -> clock_recovery_mm_cc(sps, 2.5e-5, 0.5, 0.05, 0.001)
+ * -> costas_loop_cc(2pi/200, 2) [port 1] -> complex_to_real -> x64 +128 -> uchar -> 2x {cc_decoder -> descrambler} [ports 2, 3] */
+void orc_demod_bpsk(const cf32* in, size_t n, int sps, int samp_rate, int carrier_freq, int filter_width, orc_demod_out* o)
+{
+    (void)carrier_freq; (void)filter_width;
+    memset(o, 0, sizeof *o);
+    const int target = 20000;
+    int nt = orc_low_pass(1, samp_rate, target / 2, target / 2, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* taps = NEW(float, nt);
+    orc_low_pass(1, samp_rate, target / 2, target / 2, ORC_WIN_BLACKMAN_HARRIS, taps);
+    size_t n1 = orc_decim_count(n, 1, 50);
+    cf32* s1 = NEW(cf32, n1);
+    orc_decim_auto(in, n, taps, nt, 50, s1);
+    free(taps);
+    cf32* s2 = NEW(cf32, n1);
+    orc_fll_band_edge(s1, n1, (float)sps, 0.35f, 32, (float)(8 * M_PI / 100), s2);
+    free(s1);
+    int nr = orc_root_raised_cosine(sps, sps, 1, 0.35, 15 * sps, NULL);
+    float* rrc = NEW(float, nr);
+    orc_root_raised_cosine(sps, sps, 1, 0.35, 15 * sps, rrc);
+    o->filtered = NEW(cf32, n1); o->n_filtered = n1;
+    orc_fir_ccf(s2, n1, rrc, nr, o->filtered);
+    free(rrc); free(s2);
+    cf32* s3 = NEW(cf32, n1);
+    orc_agc2(o->filtered, n1, 1e-1f, 1e-1f, 1.0f, 1.0f, 65536.0f, s3);
+    cf32* s4 = NEW(cf32, n1 / (size_t)(sps > 1 ? sps - 1 : 1) + 16);
+    const float gain_omega = 0.005f;
+    size_t nsym = orc_clock_recovery_mm_cc(s3, n1, (float)sps, gain_omega * gain_omega, 0.5f, 0.05f, 0.001f, s4);
+    free(s3);
+    o->constellation = NEW(cf32, nsym + 1); o->n_const = nsym;
+    orc_costas(s4, nsym, (float)(2 * M_PI / 200), 2, 0, o->constellation);
+    free(s4);
+    float* re = NEW(float, nsym + 1);
+    for (size_t i = 0; i < nsym; i++) re[i] = o->constellation[i].re;
+    fec_tail(re, nsym, 64.0f, 1, o);
+    free(re);
+}
+
+/* single-carrier MMDVM receiver gr_demod_mmdvm.cpp:29-61 (instance make_gr_demod_mmdvm(): header defaults sps 10,
+ * MMDVM_SAMPLE_RATE, 1700, filter_width 5000, gr_demod_mmdvm.h:35-36): rational_resampler_ccf(12, 125, low_pass_2(12, 12 fs, fw, 2000, 60, BH)) -> rssi_tag_block -> fft_filter_ccf(
+ * low_pass_2(1, 24k, fw, 2000, 60, BH)) -> quadrature_demod_cf(24000/(2 pi 10000)) -> x1.0 -> float_to_short(1, 32767).
+ * out: int16 [cap]; rssi: one dB value per 300 resampler outputs (may be NULL). Returns the sample count. */
+size_t orc_demod_mmdvm(const cf32* in, size_t n, int samp_rate, int filter_width, int16_t* out, size_t cap, float* rssi, float cal,
+                       size_t* n_rssi)
+{
+    int nt = orc_low_pass_2(12, 12.0 * samp_rate, filter_width, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* taps = NEW(float, nt);
+    orc_low_pass_2(12, 12.0 * samp_rate, filter_width, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, taps);
+    size_t n1 = orc_decim_count(n, 12, 125);
+    cf32* a = NEW(cf32, n1 + 1);
+    orc_resamp_ccf(in, n, taps, nt, 12, 125, a);
+    free(taps);
+    size_t nr = orc_rssi_tag(a, n1, cal, rssi);
+    if (n_rssi) *n_rssi = nr;
+    int nf = orc_low_pass_2(1, 24000, filter_width, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* ft = NEW(float, nf);
+    orc_low_pass_2(1, 24000, filter_width, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, ft);
+    cf32* b = NEW(cf32, n1 + 1);
+    orc_fir_ccf(a, n1, ft, nf, b);
+    float* d = NEW(float, n1 + 1);
+    orc_quad_demod(b, n1, (float)(24000.0f / (2 * M_PI * 10000.0f)), d);
+    size_t m = n1 < cap ? n1 : cap;
+    for (size_t i = 0; i < m; i++) out[i] = f2s(d[i] * 1.0f, 32767.0f);
+    free(a); free(b); free(d); free(ft);
+    return m;
+}
+
 /* ------------------------------- batch driver for bench.py cpu_baseline ----------------------- */
 static double now_s(void)
 {
@@ -487,6 +683,11 @@ static int16_t f2s(float x, float scale)
 /* whole C4 RX chain; out: [M][cap] int16, returns samples per channel (cap must be >= n/M*24/25 + 2) */
 size_t orc_demod_mmdvm_multi(const cf32* in, size_t n, int M, int16_t* out, size_t cap)
 {
+    return orc_demod_mmdvm_multi_rssi(in, n, M, out, cap, NULL, 0, 0.0f);
+}
+/* same + the rssi_tag_block between filter and discriminator (gr_demod_mmdvm_multi2.cpp:96,126-127): rssi[c*rcap + k] */
+size_t orc_demod_mmdvm_multi_rssi(const cf32* in, size_t n, int M, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal)
+{
     int nt = orc_chan_proto_taps(M, NULL);
     float* taps = NEW(float, nt);
     orc_chan_proto_taps(M, taps);
@@ -507,6 +708,12 @@ size_t orc_demod_mmdvm_multi(const cf32* in, size_t n, int M, int16_t* out, size
     for (int c = 0; c < M; c++) {
         orc_resamp_ccf(ch + (size_t)c * n1, n1, rt, nr, 24, 25, a);
         orc_fir_ccf(a, n2, ft, nf, b);
+        if (rssi) {
+            float* tmp = NEW(float, n2 / 300 + 1);
+            size_t nr = orc_rssi_tag(b, n2, cal, tmp);
+            for (size_t k = 0; k < nr && k < rcap; k++) rssi[(size_t)c * rcap + k] = tmp[k];
+            free(tmp);
+        }
         orc_quad_demod(b, n2, gain, d);
         for (size_t i = 0; i < m; i++) out[(size_t)c * cap + i] = f2s(d[i] * 1.0f, 32767.0f);
     }

@@ -17,6 +17,8 @@ LIB_PATH = os.path.join(_HERE, "libqrl_hip.so")
 MODEM_2FSK2KFM, MODEM_2FSK1KFM, MODEM_2FSK2K, MODEM_2FSK1K, MODEM_2FSK10KFM = 15, 16, 17, 18, 19
 MODEM_GMSK2K, MODEM_GMSK1K, MODEM_GMSK10K = 20, 21, 22
 MODEM_QPSK250K = 26
+MODEM_BPSK2K, MODEM_BPSK1K = 0, 24
+MODEM_4FSK10KFM, MODEM_4FSK2KFM, MODEM_4FSK1KFM, MODEM_4FSK100K = 4, 5, 6, 27
 MODEM_DMR = 41
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECTANGULAR, WIN_BLACKMAN_HARRIS = 0, 1, 2, 3, 5
 
@@ -35,7 +37,8 @@ class _Config(C.Structure):
 class _ModConfig(C.Structure):
     _fields_ = [("modem_type", C.c_int), ("use_mode_defaults", C.c_int), ("sps", C.c_int), ("samp_rate", C.c_int),
                 ("carrier_freq", C.c_int), ("filter_width", C.c_int), ("fm", C.c_int), ("batch", C.c_int),
-                ("max_bytes", C.c_size_t), ("hip_stream", C.c_void_p), ("bb_gain", C.c_float)]
+                ("max_bytes", C.c_size_t), ("hip_stream", C.c_void_p), ("bb_gain", C.c_float),
+                ("device_samp_rate", C.c_int), ("carrier_offset_hz", C.c_double)]
 
 
 class _ChanConfig(C.Structure):
@@ -84,6 +87,7 @@ def load_library():
     lib.qrl_mod_destroy.argtypes = [vp]
     lib.qrl_mod_reset.argtypes = [vp]
     lib.qrl_mod_set_bb_gain.argtypes = [vp, C.c_float]
+    lib.qrl_mod_set_carrier_offset.argtypes = [vp, C.c_double]
     lib.qrl_mod_samples_per_byte.restype = sz
     lib.qrl_mod_samples_per_byte.argtypes = [vp]
     lib.qrl_mod_process.argtypes = [vp, vp, sz, sz, vp, sz]
@@ -114,7 +118,7 @@ EXPORTED_SYMBOLS = [
     "qrl_init", "qrl_shutdown", "qrl_strerror", "qrl_last_error", "qrl_version", "qrl_demod_create",
     "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_out_caps",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
-    "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain",
+    "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
     "qrl_mod_samples_per_byte", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_create",
     "qrl_chan_destroy", "qrl_chan_reset", "qrl_chan_set_level", "qrl_chan_out_cap", "qrl_chan_process", "qrl_chan_sync",
     "qrl_firdes_low_pass",
@@ -305,7 +309,8 @@ class Mod:
     process(bytes) takes a torch cuda uint8 tensor [batch, nbytes] (packed bytes, as gr_byte_source hands them
     out) and returns a complex64 cuda tensor [batch, nbytes * 8 * sps]."""
 
-    def __init__(self, ctx, modem_type, batch, max_bytes, stream=None, bb_gain=1.0):
+    def __init__(self, ctx, modem_type, batch, max_bytes, stream=None, bb_gain=1.0, device_samp_rate=0,
+                 carrier_offset_hz=0.0):
         import torch
         self.torch = torch
         self.ctx, self.lib = ctx, ctx.lib
@@ -316,6 +321,8 @@ class Mod:
         cfg.max_bytes = max_bytes
         cfg.hip_stream = stream
         cfg.bb_gain = bb_gain
+        cfg.device_samp_rate = device_samp_rate      # gr_mod_base::set_samp_rate (back-end interpolator)
+        cfg.carrier_offset_hz = carrier_offset_hz    # gr_mod_base::set_carrier_offset (rotator at 1 Msps)
         self.batch, self.max_bytes = batch, max_bytes
         self.h = C.c_void_p()
         _check(self.lib.qrl_mod_create(ctx.h, C.byref(cfg), C.byref(self.h)), "qrl_mod_create")
@@ -344,6 +351,9 @@ class Mod:
 
     def set_bb_gain(self, g):
         _check(self.lib.qrl_mod_set_bb_gain(self.h, float(g)), "qrl_mod_set_bb_gain")
+
+    def set_carrier_offset(self, hz):
+        _check(self.lib.qrl_mod_set_carrier_offset(self.h, float(hz)), "qrl_mod_set_carrier_offset")
 
     def close(self):
         if self.h:

@@ -117,7 +117,7 @@ struct qrl_demod {
     hipStream_t tail = nullptr;
     hipEvent_t ev_ff = nullptr, ev_tail = nullptr;
     bool tail_pending = false;
-    enum Family { F_2FSK, F_GMSK, F_QPSK, F_DMR } fam = F_2FSK;
+    enum Family { F_2FSK, F_GMSK, F_QPSK, F_DMR, F_4FSK, F_BPSK } fam = F_2FSK;
     int branches = 2;
 
     // derived chain parameters (gr_demod_2fsk.cpp:39-63, gr_demod_gmsk.cpp:39-63)
@@ -179,9 +179,10 @@ int qrl_demod::init_state()
     for (auto* b : {&s2d, &s3}) if (b->p && (r = b->zero())) return r;
     if ((r = soft.zero())) return r;
     if (fll_st.p && (r = fll_st.zero())) return r;
-    if (fam == F_QPSK) {
+    if (fam == F_QPSK || fam == F_BPSK) {
         std::vector<QpskState> qs(cfg.batch);
-        for (auto& q : qs) { std::memset(&q, 0, sizeof q); q.gain = 1.0f; q.avg = q.inst = (float)sps_eff; }
+        for (auto& q : qs) { std::memset(&q, 0, sizeof q); q.gain = 1.0f; q.avg = q.inst = (float)sps_eff;
+                             if (fam == F_BPSK) q.mu = 0.5f; }   // clock_recovery_mm_cc(mu = 0.5), gr_demod_bpsk.cpp:58-60
         if (hipMemcpy(qp_st.p, qs.data(), qs.size() * sizeof(QpskState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
     }
     std::vector<SymSyncState> ss(cfg.batch);
@@ -212,6 +213,19 @@ int qrl_demod::build()
     } else if (fam == F_DMR) {
         // gr_demod_dmr.cpp:36-58: 3/125 resampler to 24 ksps, 5 samples per symbol
         target = 24000; sps_eff = 5; decim = 125; interp = 3; branches = 1;
+    } else if (fam == F_4FSK) {
+        // gr_demod_4fsk.cpp:45-82 (FM branch only; the non-FM discriminator bank of 4FSK2K is not built)
+        if (!cfg.fm) return fail(QRL_ERR_ARG, "4fsk: only the FM variants (4FSK2KFM/1KFM/10KFM/100K) are built");
+        if (sps == 1)       { target = 80000;  sps_eff = 8;  decim = 25;  interp = 2; }
+        else if (sps == 5)  { target = 20000;  sps_eff = 10; decim = 50;  interp = 1; }
+        else if (sps == 10) { target = 10000;  sps_eff = 10; decim = 100; interp = 1; }
+        else if (sps == 2)  { target = 500000; sps_eff = 5;  decim = 2;   interp = 1; }
+        else return fail(QRL_ERR_ARG, "4fsk: unsupported sps");
+        branches = 1;
+    } else if (fam == F_BPSK) {
+        // gr_demod_bpsk.cpp:40-52: 1:50 to 20 ksps, sps samples per symbol
+        if (sps != 10 && sps != 5) return fail(QRL_ERR_ARG, "bpsk: sps must be 10 (BPSK1K) or 5 (BPSK2K)");
+        target = 20000; sps_eff = sps; decim = 50; interp = 1;
     } else {
         // gr_demod_qpsk.cpp:39-60: only the sps <= 4 geometry (QPSK250K: 1:2 decimation, no FLL) is built so far
         if (sps > 4 || sps < 2) return fail(QRL_ERR_ARG, "qpsk: only sps 2..4 (e.g. QPSK250K) is supported by this build");
@@ -261,15 +275,19 @@ int qrl_demod::build()
     s2_mask = pow2_at_least(max2 + 1024) - 1;   // history needs: <= 501 taps downstream
     const size_t ring2 = (size_t)B * (s2_mask + 1);
     if ((r = s2.alloc(ring2)) || (r = s2f.alloc(ring2)) || (r = s2d.alloc(ring2)) || (r = s3.alloc(ring2))) return r;
-    if (fam == F_2FSK && (r = s2l.alloc(ring2))) return r;
+    if ((fam == F_2FSK || fam == F_BPSK) && (r = s2l.alloc(ring2))) return r;
     const size_t maxsym = max2 / (size_t)(sps_eff > 1 ? sps_eff - 1 : 1) + 8;
-    soft_mask = pow2_at_least((fam == F_QPSK ? 2 : 1) * maxsym + 512) - 1;
+    soft_mask = pow2_at_least((fam == F_QPSK || fam == F_4FSK ? 2 : 1) * maxsym + 512) - 1;
     if ((r = soft.alloc((size_t)B * (soft_mask + 1)))) return r;
 
     // --- decimated-rate filters
     {
         const std::vector<float> f = fam == F_QPSK
             ? root_raised_cosine(sps_eff, sps_eff, 1, 0.35, 11 * sps_eff)      // _shaping_filter, gr_demod_qpsk.cpp:100-103
+            : fam == F_BPSK
+            ? root_raised_cosine(sps_eff, sps_eff, 1, 0.35, 15 * sps_eff)      // _shaping_filter, gr_demod_bpsk.cpp:64-66
+            : fam == F_4FSK
+            ? low_pass(1, target, fw, fw / 2, WIN_BLACKMAN_HARRIS)             // _filter, gr_demod_4fsk.cpp:108-109
             : low_pass(1, target, fw, fw, WIN_BLACKMAN_HARRIS);
         filt_nt = (int)f.size();
         if ((r = filt_taps.upload(f))) return r;
@@ -309,6 +327,24 @@ int qrl_demod::build()
         demod_gain = (float)(target / (M_PI / 2 * (float)(target / sps_eff)));                               // :72
         clock_loop_gains((float)(2 * M_PI / 100.0f), 1.0f, 0.2869f, ss_alpha, ss_beta);                      // :70-71
         ss_maxp = (float)sps_eff + 0.06f; ss_minp = (float)sps_eff - 0.06f;
+    } else if (fam == F_4FSK) {
+        int nfilts = (sps == 1 ? 32 : sps == 2 ? 50 : 25) * sps_eff;                                         // gr_demod_4fsk.cpp:45-84
+        if ((nfilts % 2) == 0) nfilts += 1;
+        const std::vector<float> rrc = root_raised_cosine(1.5, target, target / sps_eff, 0.2, nfilts);       // :130-133
+        symf_nt = (int)rrc.size();
+        if ((r = symf_taps.upload(rrc))) return r;
+        demod_gain = (float)(sps_eff / (1 * M_PI));                                                          // :129
+        clock_loop_gains((float)(2 * M_PI / 200.0f), 1.0f, 0.2869f, ss_alpha, ss_beta);                      // :135-137
+        ss_maxp = (float)sps_eff + 0.05f; ss_minp = (float)sps_eff - 0.05f;
+    } else if (fam == F_BPSK) {
+        std::vector<std::complex<float>> lo, up;
+        fll_band_edge_taps((float)sps_eff, 0.35f, 32, lo, up);                                               // gr_demod_bpsk.cpp:63
+        if ((r = fll_lo.upload(to_f2(lo))) || (r = fll_up.upload(to_f2(up)))) return r;
+        control_loop_gains((float)(8 * M_PI / 100), fll_alpha, fll_beta);
+        fll_maxf = (float)(2 * M_PI * (2.0 / sps_eff));
+        if ((r = fll_st.alloc(B))) return r;
+        if ((r = tanh_tab.upload(tanh_table())) || (r = qp_st.alloc(B))) return r;
+        control_loop_gains((float)(2 * M_PI / 200), c2_alpha, c2_beta);                                      // _costas_loop, :61
     } else if (fam == F_QPSK) {
         if ((r = tanh_tab.upload(tanh_table())) || (r = qp_st.alloc(B))) return r;
         control_loop_gains((float)(M_PI / 200 / sps_eff), c1_alpha, c1_beta);     // _costas_pll, gr_demod_qpsk.cpp:110
@@ -409,10 +445,10 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
     const uint32_t c2 = (uint32_t)(n2_1 - n2_0);
     const bool side = cfg.enable_side_outputs && out;
     RingC filt_in = r2;
-    if (fam == F_2FSK) {
+    if (fam == F_2FSK || fam == F_BPSK) {
         FllParams f{};
         f.in = r2; f.out = r2l; f.q0 = n2_0; f.count = c2; f.st = fll_st.p;
-        f.lower = fll_lo.p; f.upper = fll_up.p; f.nt = 16; f.alpha = fll_alpha; f.beta = fll_beta; f.max_freq = fll_maxf;
+        f.lower = fll_lo.p; f.upper = fll_up.p; f.nt = fam == F_BPSK ? 32 : 16; f.alpha = fll_alpha; f.beta = fll_beta; f.max_freq = fll_maxf;
         launch_fll(f, B, stream);
         filt_in = r2l;
     }
@@ -446,17 +482,17 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
             f.counts = counts;
             launch_fir_ccf(f, B, stream);
         }
-        if (fam == F_QPSK) {
+        if (fam == F_QPSK || fam == F_BPSK) {
             // recursive chain + Viterbi below; nothing else at the sample rate
-        } else if (fam == F_GMSK || fm) {
+        } else if (fam == F_GMSK || fam == F_4FSK || fm) {
             QuadDemodParams q{}; q.in = r2f; q.out = r2d; q.q0 = n2_0; q.count = c2; q.gain = demod_gain; q.atan_tab = atan_tab.p;
             launch_quad_demod(q, B, stream);
         } else {
             Disc2fskParams d{}; d.in = r2f; d.out = r2d; d.q0 = n2_0; d.count = c2; d.up = disc_up.p; d.lo = disc_lo.p; d.nt = disc_nt;
             launch_disc_2fsk(d, B, stream);
         }
-        if (fam == F_QPSK) {
-            // the tail reads r2f (written by k_fir_ccf above): it runs on the handle's own stream for this family
+        if (fam == F_QPSK || fam == F_BPSK) {
+            // the tail reads r2f (written by k_fir_ccf above): it runs on the handle's own stream for these families
         } else {
             // r3 is what the previous call's tail (other stream) may still be reading
             if (tail_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_tail, 0)); tail_pending = false; }
@@ -467,30 +503,36 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         }
     }
     // ---- stage D: symbol sync + FEC
-    if (fam == F_QPSK) {
+    if (fam == F_QPSK || fam == F_BPSK) {
         QpskParams q{};
         q.in = r2f; q.np0 = n2_0; q.avail = n2_1; q.soft = RingB{soft.p, soft_mask}; q.st = qp_st.p;
         q.mmse = mmse_tab.p; q.tanh_tab = tanh_tab.p;
         q.c1_alpha = c1_alpha; q.c1_beta = c1_beta; q.c2_alpha = c2_alpha; q.c2_beta = c2_beta;
         q.ss_alpha = ss_alpha; q.ss_beta = ss_beta; q.ss_maxp = ss_maxp; q.ss_minp = ss_minp;
         q.rot = qp_rot; q.soft_mul = 48.0f; q.soft_add = 128.0f;
+        if (fam == F_BPSK) {   // gr_demod_bpsk.cpp:54-62,67
+            q.mode = 1; q.soft_mul = 64.0f;
+            const float gain_omega = 0.005f;
+            q.cr_gain_omega = gain_omega * gain_omega; q.cr_gain_mu = 0.05f;
+            q.cr_omega_mid = (float)sps_eff; q.cr_omega_lim = 0.001f * (float)sps_eff;
+        }
         q.port = side && out->constellation ? reinterpret_cast<float2*>(out->constellation) : nullptr;
         q.port_cap = side ? out->constellation_cap : 0;
         q.counts = counts;
         launch_qpsk_loops(q, B, stream);
         FecParams f{};
         f.soft = RingB{soft.p, soft_mask};
-        f.avail = &qp_st.p[0].oo; f.avail_stride = sizeof(QpskState); f.avail_mul = 2;
+        f.avail = &qp_st.p[0].oo; f.avail_stride = sizeof(QpskState); f.avail_mul = fam == F_BPSK ? 1 : 2;
         f.st = fec_st.p;
-        f.bits_a = out ? out->bits_a : nullptr; f.bits_b = nullptr; f.bits_cap = out ? out->bits_cap : 0;
-        f.counts = counts; f.branches = 1;
+        f.bits_a = out ? out->bits_a : nullptr; f.bits_b = fam == F_BPSK && out ? out->bits_b : nullptr; f.bits_cap = out ? out->bits_cap : 0;
+        f.counts = counts; f.branches = fam == F_BPSK ? 2 : 1;
         launch_fec(f, B, stream);
     } else {
         SymSyncParams s{};
         s.in = r3; s.avail = n2_1; s.soft = RingB{soft.p, soft_mask}; s.st = ss_st.p; s.mmse = mmse_tab.p;
         s.alpha = ss_alpha; s.beta = ss_beta; s.maxp = ss_maxp; s.minp = ss_minp;
         s.ted = fam == F_DMR ? 0 : 1; s.soft_mul = 128.0f; s.soft_add = 128.0f;
-        s.slicer = fam == F_DMR ? 1 : 0; s.tail = fam == F_DMR ? 1 : 0;
+        s.slicer = fam == F_DMR || fam == F_4FSK ? 1 : 0; s.tail = fam == F_DMR ? 1 : fam == F_4FSK ? 2 : 0;
         s.bits = out ? out->bits_a : nullptr; s.bits_cap = out ? out->bits_cap : 0;
         s.port = side && out->constellation ? reinterpret_cast<float2*>(out->constellation) : nullptr;
         s.port_cap = side ? out->constellation_cap : 0;
@@ -498,7 +540,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         launch_symsync_ff(s, B, tail);
         if (fam == F_DMR) { HIPCHK(hipEventRecord(ev_tail, tail)); tail_pending = true; }
         FecParams f{};
-        f.soft = RingB{soft.p, soft_mask}; f.avail = &ss_st.p[0].oo; f.avail_stride = sizeof(SymSyncState); f.avail_mul = 1; f.st = fec_st.p;
+        f.soft = RingB{soft.p, soft_mask}; f.avail = &ss_st.p[0].oo; f.avail_stride = sizeof(SymSyncState); f.avail_mul = fam == F_4FSK ? 2 : 1; f.st = fec_st.p;
         f.bits_a = out ? out->bits_a : nullptr; f.bits_b = out ? out->bits_b : nullptr; f.bits_cap = out ? out->bits_cap : 0;
         f.counts = counts; f.branches = branches;
         if (fam != F_DMR) {
@@ -568,6 +610,12 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         case QRL_MODEM_GMSK1K:    c.sps = 10; c.filter_width = 2000;  c.fm = 0; break;
         case QRL_MODEM_GMSK10K:   c.sps = 1;  c.filter_width = 20000; c.fm = 0; break;
         case QRL_MODEM_QPSK250K:  c.sps = 2;  c.filter_width = 160000; c.fm = 0; break;   // gr_demod_base.cpp:223
+        case QRL_MODEM_4FSK2KFM:  c.sps = 5;  c.filter_width = 3000;   c.fm = 1; break;   // gr_demod_base.cpp:212
+        case QRL_MODEM_4FSK1KFM:  c.sps = 10; c.filter_width = 2000;   c.fm = 1; break;   // :213
+        case QRL_MODEM_4FSK10KFM: c.sps = 1;  c.filter_width = 20000;  c.fm = 1; break;   // :214
+        case QRL_MODEM_4FSK100K:  c.sps = 2;  c.filter_width = 125000; c.fm = 1; break;   // :225
+        case QRL_MODEM_BPSK1K:    c.sps = 10; c.filter_width = 1300;   c.fm = 0; break;   // :216
+        case QRL_MODEM_BPSK2K:    c.sps = 5;  c.filter_width = 2400;   c.fm = 0; break;   // :217
         case QRL_MODEM_DMR:       c.sps = 5;  c.filter_width = 5000;   c.fm = 0; break;   // make_gr_demod_dmr(5, 1000000) gr_demod_base.cpp:253
         default: return fail(QRL_ERR_ARG, "modem_type not supported by this build");
         }
@@ -581,6 +629,10 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         d->fam = qrl_demod::F_QPSK; break;
     case QRL_MODEM_DMR:
         d->fam = qrl_demod::F_DMR; break;
+    case QRL_MODEM_4FSK2KFM: case QRL_MODEM_4FSK1KFM: case QRL_MODEM_4FSK10KFM: case QRL_MODEM_4FSK100K:
+        d->fam = qrl_demod::F_4FSK; break;
+    case QRL_MODEM_BPSK1K: case QRL_MODEM_BPSK2K:
+        d->fam = qrl_demod::F_BPSK; break;
     default: return fail(QRL_ERR_ARG, "modem_type not supported by this build");
     }
     if (c.samp_rate != 1000000) return fail(QRL_ERR_ARG, "internal samp_rate must be 1000000 (gr_demod_base.cpp:21)");
@@ -649,7 +701,7 @@ int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* fcap, size_t* ccap,
     const size_t ns = n2 / (size_t)(d->sps_eff > 1 ? d->sps_eff - 1 : 1) + 8;
     if (fcap) *fcap = n2;
     if (ccap) *ccap = ns;
-    if (bcap) *bcap = d->fam == qrl_demod::F_DMR ? 2 * ns + 8 : d->fam == qrl_demod::F_QPSK ? (ns / 80 + 2) * 80 : (ns / 2 / 80 + 2) * 80;
+    if (bcap) *bcap = d->fam == qrl_demod::F_DMR ? 2 * ns + 8 : d->fam == qrl_demod::F_QPSK || d->fam == qrl_demod::F_4FSK ? (ns / 80 + 2) * 80 : (ns / 2 / 80 + 2) * 80;
     return QRL_OK;
 }
 int qrl_demod_process(qrl_demod* d, const float* iq, size_t stride, size_t n, const qrl_demod_out* out)

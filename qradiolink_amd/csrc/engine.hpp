@@ -91,7 +91,8 @@ struct SymSyncParams {
     float alpha, beta, maxp, minp;
     int ted; float soft_mul, soft_add;
     int slicer;                            // 0: bpsk sign, 1: constellation_rect{-1.5,-0.5,0.5,1.5}
-    int tail;                              // 0: soft symbols for the Viterbi; 1: DMR tail (x0.9, phase_modulator, slicer, map) -> bits port
+    int tail;                              // 0: soft symbols for the Viterbi; 1: DMR tail (x0.9, phase_modulator, slicer, map) -> bits port;
+                                           // 2: native 4FSK (FM) tail: phase_modulator -> (imag, real) soft pairs for the Viterbi
     uint8_t* bits; size_t bits_cap;        // tail 1: two bits per symbol, counts[b*4+2]
     float2* port; size_t port_cap; uint32_t* counts;  // constellation port (this call), counts[b*4+1]
 };
@@ -115,6 +116,8 @@ struct QpskParams {
     float c1_alpha, c1_beta, c2_alpha, c2_beta;
     float ss_alpha, ss_beta, ss_maxp, ss_minp;
     float2 rot; float soft_mul, soft_add;
+    int mode;                        // 0: gr_demod_qpsk chain; 1: gr_demod_bpsk chain (agc2 -> clock_recovery_mm_cc -> costas order 2)
+    float cr_gain_omega, cr_gain_mu, cr_omega_mid, cr_omega_lim;   // mode 1
     float2* port; size_t port_cap; uint32_t* counts;   // constellation port (this call), counts[b*4+1]
 };
 void launch_qpsk_loops(const QpskParams& p, int batch, hipStream_t s);
@@ -155,9 +158,13 @@ struct TxInterpParams {
     const float* taps; int nt; int interp; float2 table[4]; float amp, bb_gain;
     float2* out; size_t out_stride;
 };
-struct TxShapeParams { RingB sym; RingF out; uint64_t n0; uint32_t count; int sps; const float* taps; int nt; };   // nt = 0: repeat
+struct TxShapeParams { RingB sym; RingF out; uint64_t n0; uint32_t count; int sps; const float* taps; int nt;   // nt = 0: repeat
+                       int levels; float scale; };   // levels 2 | 4; scale 0 = none
 struct TxFmParams { RingF in; RingC out; uint64_t n0; uint32_t count; float k, amp; float* phase; };
 struct TxInterpCParams { RingC in; uint64_t n0; uint32_t count; const float* taps; int nt; int interp; float2* out; size_t out_stride; };
+struct TxRotParams { const float2* in; size_t in_stride; uint64_t n0; uint32_t count; uint64_t rot_acc, rot_inc, rot_nbase; const float2* rot_lo;
+                     RingC out_ring; float2* out; size_t out_stride; };
+void launch_tx_rot(const TxRotParams& p, int batch, hipStream_t s);
 void launch_tx_shape(const TxShapeParams& p, int batch, hipStream_t s);
 void launch_tx_fm(const TxFmParams& p, int batch, hipStream_t s);
 void launch_tx_interp_c(const TxInterpCParams& p, int batch, hipStream_t s);

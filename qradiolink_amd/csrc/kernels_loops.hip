@@ -237,6 +237,21 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
                     }
                     continue;
                 }
+                if (P.tail == 2) {   // gr_demod_4fsk.cpp:140-146,165-195 (FM): phase_modulator_fc(pi/2) -> port 1; (imag, real) interleaved soft symbols
+                    const uint64_t o = obase[pb * 64 + s] + j;
+                    const uint64_t kk = o - oo0[s];
+                    const float2 cs = sincos_rad(1.57079632679489661923f * y);
+                    if (P.port && kk < P.port_cap) P.port[(size_t)(b0 + s) * P.port_cap + kk] = cs;
+                    float qa = cs.y * P.soft_mul; qa = qa + P.soft_add;
+                    float qb = cs.x * P.soft_mul; qb = qb + P.soft_add;
+                    float ra = rintf(qa), rb = rintf(qb);
+                    if (!(ra >= 0.f)) ra = 0.f; if (ra > 255.f) ra = 255.f;
+                    if (!(rb >= 0.f)) rb = 0.f; if (rb > 255.f) rb = 255.f;
+                    uint8_t* sp = P.soft.p + (size_t)(b0 + s) * (P.soft.mask + 1u);
+                    sp[(uint32_t)(2 * o) & P.soft.mask] = (uint8_t)ra;
+                    sp[(uint32_t)(2 * o + 1) & P.soft.mask] = (uint8_t)rb;
+                    continue;
+                }
                 float q = y * P.soft_mul;
                 q = q + P.soft_add;
                 float r = rintf(q);
@@ -277,12 +292,10 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
                 st.x2 = st.x1; st.x1 = st.x0; st.x0 = y;
                 st.d2 = st.d1; st.d1 = st.d0;
                 if (P.slicer == 0) st.d0 = (y > 0.f) ? 1.0f : -1.0f;
-                else {   // nearest of {-1.5, -0.5, 0.5, 1.5}, ties to the lower point (oracle slice_real)
-                    float best = -1.5f, bd = fabsf(y + 1.5f);
-                    float dd = fabsf(y - (-0.5f)); if (dd < bd) { bd = dd; best = -0.5f; }
-                    dd = fabsf(y - 0.5f); if (dd < bd) { bd = dd; best = 0.5f; }
-                    dd = fabsf(y - 1.5f); if (dd < bd) { bd = dd; best = 1.5f; }
-                    st.d0 = best;
+                else {   // constellation_rect{-1.5,-0.5,0.5,1.5}: sector (int)(re / 1.0 + 4 / 2.0) clamped to [0, 3] (oracle slice_real)
+                    int sector = (int)((double)y + 2.0);
+                    sector = sector < 0 ? 0 : (sector > 3 ? 3 : sector);
+                    st.d0 = (float)sector - 1.5f;
                 }
                 float e;
                 if (P.ted == 0) e = st.d1 * st.x0 - st.d0 * st.x1;

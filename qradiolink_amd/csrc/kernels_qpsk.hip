@@ -28,6 +28,7 @@ __device__ __forceinline__ float costas4_snr_error(float2 o, const float* __rest
     return (tanhf_lut(snr * o.x, T) * o.y) - (tanhf_lut(snr * o.y, T) * o.x);
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batch)
 {
     extern __shared__ __align__(16) unsigned char qp_smem[];
@@ -104,6 +105,15 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
             if (j < ocnt[pb * 64 + s]) {
                 const float2 v = ob[s * QP_OPITCH + j];
                 const uint64_t o = obase[pb * 64 + s] + j;
+                if (MODE == 1) {   // complex_to_real -> multiply_const(64) -> add_const(128) -> float_to_uchar (gr_demod_bpsk.cpp:96-101)
+                    float q = v.x * P.soft_mul; q = q + P.soft_add;
+                    float r = rintf(q);
+                    if (!(r >= 0.f)) r = 0.f; if (r > 255.f) r = 255.f;
+                    P.soft.p[(size_t)(b0 + s) * (P.soft.mask + 1u) + ((uint32_t)o & P.soft.mask)] = (uint8_t)r;
+                    const uint64_t kk1 = o - oo0[s];
+                    if (P.port && kk1 < P.port_cap) P.port[(size_t)(b0 + s) * P.port_cap + kk1] = v;
+                    continue;
+                }
                 // complex_to_float -> interleave -> multiply_const(48) -> add_const(128) -> float_to_uchar
                 float qa = v.x * P.soft_mul; qa = qa + P.soft_add;
                 float qb = v.y * P.soft_mul; qb = qb + P.soft_add;
@@ -142,10 +152,11 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
                     float2 a; a.x = x.x * st.gain; a.y = x.y * st.gain;
                     const float tmp = -1.0f + sqrtf(a.x * a.x + a.y * a.y);
                     float rate = 0.1f;
-                    if (tmp > st.gain) rate = 1.0f;
+                    if (MODE == 0 && tmp > st.gain) rate = 1.0f;   // agc2_cc(attack 1, decay 0.1) for QPSK, (0.1, 0.1) for BPSK
                     st.gain -= tmp * rate;
                     if (st.gain < 0.0f) st.gain = 10e-5f;
                     if (st.gain > 65536.0f) st.gain = 65536.0f;
+                    if (MODE == 1) { row[c] = a; continue; }       // gr_demod_bpsk.cpp:88-90: no Costas loop in front of the clock recovery
                     const float2 nco = sincos_rad(-st.c1_phase);   // (cos, sin)
                     float2 o; o.x = a.x * nco.x - a.y * nco.y; o.y = a.x * nco.y + a.y * nco.x;
                     row[c] = o;
@@ -161,7 +172,45 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
             const uint64_t wend = (uint64_t)min((long long)avail, (k + 1) * QP_W);   // exclusive
             const uint64_t oo_w = st.oo;
             int nsym = 0;
-            while (active && st.ii + 8 <= wend && nsym < QP_OMAX) {
+            while (MODE == 1 && active && st.ii + 8 <= wend && nsym < QP_OMAX) {
+                // clock_recovery_mm_cc(sps, 2.5e-5, 0.5, 0.05, 0.001) -> costas_loop_cc(2 pi / 200, 2) (oracle orc_clock_recovery_mm_cc)
+                const int off = (int)((long long)st.ii - i0);
+                const int imu = (int)rintf(st.mu * 128.0f);
+                const float* t = mm + imu * 8;
+                float2 y = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float2 xs = row[off + j];
+                    y.x = fmaf(t[7 - j], xs.x, y.x);
+                    y.y = fmaf(t[7 - j], xs.y, y.y);
+                }
+                st.x2 = st.x1; st.x1 = st.x0; st.x0 = y;
+                st.d2 = st.d1; st.d1 = st.d0;
+                st.d0.x = y.x > 0.f ? 1.0f : 0.0f; st.d0.y = y.y > 0.f ? 1.0f : 0.0f;     // slicer_0deg
+                const float ar = st.d0.x - st.d2.x, ai = st.d0.y - st.d2.y;
+                const float xr = ar * st.x1.x + ai * st.x1.y;
+                const float br = st.x0.x - st.x2.x, bi = st.x0.y - st.x2.y;
+                const float yr = br * st.d1.x + bi * st.d1.y;
+                const float mmv = branchless_clip(yr - xr, 1.0f);
+                st.avg = st.avg + P.cr_gain_omega * mmv;                                   // d_omega lives in st.avg
+                st.avg = P.cr_omega_mid + branchless_clip(st.avg - P.cr_omega_mid, P.cr_omega_lim);
+                const float ph = st.mu + st.avg + P.cr_gain_mu * mmv;
+                const float fl = floorf(ph);
+                st.ii += (uint64_t)(int)fl;
+                st.mu = ph - fl;
+                const float2 nco = sincos_rad(-st.c2_phase);
+                float2 o; o.x = y.x * nco.x - y.y * nco.y; o.y = y.x * nco.y + y.y * nco.x;
+                float e2 = o.x * o.y;                                                      // phase_detector_2, use_snr = false
+                e2 = branchless_clip(e2, 1.0f);
+                st.c2_freq = st.c2_freq + P.c2_beta * e2;
+                st.c2_phase = st.c2_phase + st.c2_freq + P.c2_alpha * e2;
+                st.c2_phase = phase_wrap(st.c2_phase);
+                if (st.c2_freq > 1.0f) st.c2_freq = 1.0f; else if (st.c2_freq < -1.0f) st.c2_freq = -1.0f;
+                orow[nsym] = o;
+                nsym++;
+                st.oo++;
+            }
+            while (MODE == 0 && active && st.ii + 8 <= wend && nsym < QP_OMAX) {
                 const int off = (int)((long long)st.ii - i0);
                 const int imu = (int)rintf(st.mu * 128.0f);
                 const float* t = mm + imu * 8;
@@ -240,10 +289,12 @@ void launch_qpsk_loops(const QpskParams& p, int batch, hipStream_t s)
 {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qpsk_loops), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qpsk_lds_bytes());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qpsk_loops<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qpsk_lds_bytes());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qpsk_loops<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qpsk_lds_bytes());
         attr = true;
     }
-    hipLaunchKernelGGL(k_qpsk_loops, dim3((batch + 63) / 64), dim3(256), qpsk_lds_bytes(), s, p, batch);
+    if (p.mode == 1) hipLaunchKernelGGL(k_qpsk_loops<1>, dim3((batch + 63) / 64), dim3(256), qpsk_lds_bytes(), s, p, batch);
+    else             hipLaunchKernelGGL(k_qpsk_loops<0>, dim3((batch + 63) / 64), dim3(256), qpsk_lds_bytes(), s, p, batch);
 }
 
 }  // namespace qrl

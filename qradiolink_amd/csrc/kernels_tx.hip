@@ -83,6 +83,23 @@ __global__ __launch_bounds__(64) void k_tx_qpsk_bits(const TxBitsParams P)
         const uint32_t c0 = __builtin_popcount(reg & 109u) & 1u, c1 = __builtin_popcount(reg & 79u) & 1u;
         local = (local + map4[(c0 << 1) | c1]) & 3u;
     }
+    if (P.mode == 2) {   // 4FSK (gr_mod_4fsk.cpp:96-101): pack_k_bits(2) -> map{0,1,3,2}, one symbol index per input bit, no differential coding
+        uint8_t* ring2 = P.sym.p + (size_t)b * (P.sym.mask + 1u);
+        for (uint32_t i = lo; i < hi; ++i) {
+            uint32_t reg = 0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) reg |= sbit((int64_t)i - k) << k;
+            const uint32_t c0 = __builtin_popcount(reg & 109u) & 1u, c1 = __builtin_popcount(reg & 79u) & 1u;
+            ring2[(uint32_t)(P.s0 + i) & P.sym.mask] = (uint8_t)map4[(c0 << 1) | c1];
+        }
+        if (lane == 0 && nbits) {
+            uint32_t enc = 0;
+            for (int k = 0; k < 6; ++k) enc |= sbit((int64_t)nbits - 1 - k) << k;
+            st.sr = sr_end; st.enc = enc;
+            P.st[b] = st;
+        }
+        return;
+    }
     if (P.mode == 1) {   // FSK family: the two coded bits of every input bit go to the ring as they are (chunks_to_symbols later)
         uint8_t* ring1 = P.sym.p + (size_t)b * (P.sym.mask + 1u);
         for (uint32_t i = lo; i < hi; ++i) {
@@ -135,9 +152,10 @@ void launch_tx_qpsk_bits(const TxBitsParams& p, int batch, hipStream_t s)
 
 __global__ __launch_bounds__(256) void k_tx_interp(const TxInterpParams P)
 {
-    __shared__ float taps[256];
-    for (int k = threadIdx.x; k < 256; k += 256) taps[k] = k < P.nt ? P.taps[k] : 0.f;
+    __shared__ float taps_s[256];
+    taps_s[threadIdx.x] = (int)threadIdx.x < P.nt ? P.taps[threadIdx.x] : 0.f;
     __syncthreads();
+    const float* taps = P.nt <= 256 ? taps_s : P.taps;   // BPSK: 11 x sps taps (sps = 500 / 250) stay in global memory / L2
     const int b = blockIdx.y;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= P.count) return;
@@ -184,14 +202,17 @@ __global__ __launch_bounds__(256) void k_tx_shape(const TxShapeParams P)
     const uint64_t c = n / (uint64_t)P.sps;
     const int ph = (int)(n - c * (uint64_t)P.sps);
     const uint8_t* ring = P.sym.p + (size_t)b * (P.sym.mask + 1u);
+    // chunks_to_symbols_bf: {-1, 1} (2FSK / GMSK) or {-1.5, -0.5, 0.5, 1.5} (4FSK, gr_mod_4fsk.cpp:33-38)
+    auto level = [&](uint8_t v) -> float { return P.levels == 4 ? (float)(v & 3) - 1.5f : (v ? 1.0f : -1.0f); };
     float a;
-    if (P.nt == 0) a = ring[(uint32_t)c & P.sym.mask] ? 1.0f : -1.0f;          // blocks::repeat
+    if (P.nt == 0) a = level(ring[(uint32_t)c & P.sym.mask]);                  // blocks::repeat
     else {
         a = 0.f;
         for (int j = 0; ph + j * P.sps < P.nt; ++j) {
             if ((uint64_t)j > c) break;
-            a = fmaf(taps[ph + j * P.sps], ring[(uint32_t)(c - j) & P.sym.mask] ? 1.0f : -1.0f, a);
+            a = fmaf(taps[ph + j * P.sps], level(ring[(uint32_t)(c - j) & P.sym.mask]), a);
         }
+        if (P.scale != 0.0f) a = a * P.scale;                                  // _scale_pulses (4FSK FM, gr_mod_4fsk.cpp:88)
     }
     P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = a;
 }
@@ -245,9 +266,11 @@ void launch_tx_fm(const TxFmParams& p, int batch, hipStream_t s)
 
 __global__ __launch_bounds__(256) void k_tx_interp_c(const TxInterpCParams P)
 {
-    __shared__ float taps[2048];
-    for (int k = threadIdx.x; k < P.nt && k < 2048; k += 256) taps[k] = P.taps[k];
+    __shared__ float taps_s[2048];
+    const bool in_lds = P.nt <= 2048;      // longer filters (gr_mod_base back end at high device rates) read taps through L1/L2
+    if (in_lds) for (int k = threadIdx.x; k < P.nt; k += 256) taps_s[k] = P.taps[k];
     __syncthreads();
+    const float* taps = in_lds ? taps_s : P.taps;
     const int b = blockIdx.y;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= P.count) return;
@@ -269,6 +292,27 @@ void launch_tx_interp_c(const TxInterpCParams& p, int batch, hipStream_t s)
 {
     if (!p.count) return;
     hipLaunchKernelGGL(k_tx_interp_c, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
+}
+
+// ---- gr_mod_base back end (reference src/gr/gr_mod_base.cpp:38,249-258): rotator_cc(2 pi offset / 1e6) at 1 Msps, then
+// rational_resampler_ccf(fs/1e6, 1, low_pass(I, fs, 480k, 20k, BH)) (k_tx_interp_c).  Exact 2^-64-turn NCO as on RX.
+__global__ __launch_bounds__(256) void k_tx_rot(const TxRotParams P)
+{
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.count) return;
+    const uint64_t n = P.n0 + t;
+    const float2 x = P.in[(size_t)b * P.in_stride + t];
+    const uint64_t kk = n - P.rot_nbase;
+    const float2 hi = sincos_turn(P.rot_acc + ((kk >> 9) << 9) * P.rot_inc);
+    const float2 y = cmul_fma(x, cmul_fma(hi, P.rot_lo[(uint32_t)kk & 511u]));
+    if (P.out_ring.p) P.out_ring.p[(size_t)b * (P.out_ring.mask + 1u) + ((uint32_t)n & P.out_ring.mask)] = y;
+    else P.out[(size_t)b * P.out_stride + t] = y;
+}
+void launch_tx_rot(const TxRotParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_tx_rot, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
 }
 
 }  // namespace qrl

@@ -26,7 +26,8 @@ struct qrl_mod {
     qrl_mod_config cfg{};
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    enum { F_QPSK, F_FSK } fam = F_QPSK;
+    enum { F_QPSK, F_FSK } fam = F_QPSK;   // F_QPSK: symbols -> RRC interpolator (QPSK, BPSK); F_FSK: shape -> FM -> interpolator
+    bool bpsk = false, fsk4 = false; float shape_scale = 0.0f;
     int sps = 4;
     float bb_gain = 1.0f;
     float* taps = nullptr; int nt = 0;
@@ -36,10 +37,22 @@ struct qrl_mod {
     TxState* st = nullptr;
     uint8_t* sym = nullptr; uint32_t sym_mask = 0;
     uint64_t nsym = 0;   // symbols (= input bits) so far
+    // gr_mod_base back end (gr_mod_base.cpp:38,215-258): rotator at 1 Msps, then interpolation to the device rate
+    bool backend = false; int be_interp = 1; float* be_taps = nullptr; int be_nt = 0;
+    float2* bb = nullptr; size_t bb_stride = 0;            // modulator output, linear, one call's worth
+    float2* be_ring = nullptr; uint32_t be_mask = 0;       // rotated 1 Msps signal (interpolator history)
+    float2* rot_lo = nullptr; uint64_t rot_inc = 0, rot_acc = 0, rot_nbase = 0, n_bb = 0;
+    int set_rot(double hz) {
+        rot_inc = phase_inc_to_turn(2 * M_PI * hz / 1000000.0);
+        std::vector<float2> lo(512);
+        for (int r = 0; r < 512; ++r) { float s, c; sincos_turn_host((uint64_t)r * rot_inc, s, c); lo[r] = make_float2(c, s); }
+        return hipMemcpy(rot_lo, lo.data(), 512 * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess ? QRL_OK : QRL_ERR_HIP;
+    }
     ~qrl_mod() {
         if (taps) (void)hipFree(taps);
         for (void* p : {(void*)shape_taps, (void*)shaped, (void*)fmv, (void*)phase}) if (p) (void)hipFree(p);
         if (st) (void)hipFree(st);
+        for (void* p : {(void*)be_taps, (void*)bb, (void*)be_ring, (void*)rot_lo}) if (p) (void)hipFree(p);
         if (sym) (void)hipFree(sym);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
@@ -53,7 +66,8 @@ struct qrl_mod {
             if (hipMemset(fmv, 0, (size_t)cfg.batch * (r1_mask + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
             if (hipMemset(phase, 0, (size_t)cfg.batch * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
         }
-        nsym = 0;
+        if (be_ring && hipMemset(be_ring, 0, (size_t)cfg.batch * (be_mask + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
+        nsym = 0; n_bb = 0; rot_acc = 0; rot_nbase = 0;
         return QRL_OK;
     }
 };
@@ -81,7 +95,7 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
     if (!m) return QRL_ERR_NOMEM;
     m->ctx = ctx; m->cfg = *cfg;
     qrl_mod_config& c = m->cfg;
-    bool fsk = false, gmsk = false;
+    bool fsk = false, gmsk = false, fsk4 = false, bpsk = false;
     if (c.use_mode_defaults) {   // literals of gr_mod_base.cpp:154-175
         c.samp_rate = 1000000; c.carrier_freq = 1700; c.fm = 0;
         switch (c.modem_type) {
@@ -94,6 +108,12 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
         case QRL_MODEM_GMSK2K:    c.sps = 50;  c.filter_width = 4000;  break;
         case QRL_MODEM_GMSK1K:    c.sps = 100; c.filter_width = 2000;  break;
         case QRL_MODEM_GMSK10K:   c.sps = 10;  c.filter_width = 20000; break;
+        case QRL_MODEM_4FSK2KFM:  c.sps = 25;  c.filter_width = 3500;  c.fm = 1; break;   // gr_mod_base.cpp:164
+        case QRL_MODEM_4FSK1KFM:  c.sps = 50;  c.filter_width = 2000;  c.fm = 1; break;   // :165
+        case QRL_MODEM_4FSK10KFM: c.sps = 5;   c.filter_width = 20000; c.fm = 1; break;   // :166
+        case QRL_MODEM_4FSK100K:  c.sps = 2;   c.filter_width = 125000; c.fm = 1; break;  // :177
+        case QRL_MODEM_BPSK1K:    c.sps = 500; c.filter_width = 1500;  break;             // :168
+        case QRL_MODEM_BPSK2K:    c.sps = 250; c.filter_width = 2800;  break;             // :169
         default: return qrl_set_error(QRL_ERR_ARG, "modulator: modem_type not supported by this build");
         }
     }
@@ -101,9 +121,13 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
     case QRL_MODEM_QPSK250K: break;
     case QRL_MODEM_2FSK2KFM: case QRL_MODEM_2FSK1KFM: case QRL_MODEM_2FSK2K: case QRL_MODEM_2FSK1K: case QRL_MODEM_2FSK10KFM: fsk = true; break;
     case QRL_MODEM_GMSK2K: case QRL_MODEM_GMSK1K: case QRL_MODEM_GMSK10K: fsk = gmsk = true; break;
+    case QRL_MODEM_4FSK2KFM: case QRL_MODEM_4FSK1KFM: case QRL_MODEM_4FSK10KFM: case QRL_MODEM_4FSK100K: fsk = fsk4 = true; break;
+    case QRL_MODEM_BPSK1K: case QRL_MODEM_BPSK2K: bpsk = true; break;
     default: return qrl_set_error(QRL_ERR_ARG, "modulator: modem_type not supported by this build");
     }
-    if (!fsk && (c.sps < 2 || c.sps > 10)) return qrl_set_error(QRL_ERR_ARG, "modulator: only the QPSK sps <= 10 geometry is built");
+    m->bpsk = bpsk; m->fsk4 = fsk4;
+    if (bpsk && (c.sps < 2 || c.sps > 1000)) return qrl_set_error(QRL_ERR_ARG, "modulator: bpsk sps out of range");
+    if (!fsk && !bpsk && (c.sps < 2 || c.sps > 10)) return qrl_set_error(QRL_ERR_ARG, "modulator: only the QPSK sps <= 10 geometry is built");
     m->sps = c.sps;
     m->bb_gain = c.bb_gain == 0.0f ? 1.0f : c.bb_gain;
     HIPCHK(hipSetDevice(ctx->device));
@@ -116,9 +140,11 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
     };
     size_t ring_items = c.max_bytes * 8 + 256;   // symbol ring: one item per input bit (QPSK) or per coded bit (FSK: x2)
     if (!fsk) {
-        const std::vector<float> rrc = root_raised_cosine(m->sps, m->sps, 1, 0.35, 15 * m->sps);   // nfilts = 15 for sps <= 10
+        const std::vector<float> rrc = bpsk ? root_raised_cosine(m->sps, m->sps, 1, 0.35, 11 * m->sps)   // gr_mod_bpsk.cpp:52-54
+                                            : root_raised_cosine(m->sps, m->sps, 1, 0.35, 15 * m->sps);  // nfilts = 15 for sps <= 10
         m->nt = (int)rrc.size();
-        if (m->nt > 256) return qrl_set_error(QRL_ERR_ARG, "modulator: pulse-shaping filter too long");
+        if (!bpsk && m->nt > 256) return qrl_set_error(QRL_ERR_ARG, "modulator: pulse-shaping filter too long");
+        if (bpsk) ring_items = c.max_bytes * 16 + 256;
         int r0 = upload(rrc, &m->taps);
         if (r0) return r0;
     } else {
@@ -133,6 +159,12 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
             if ((nfilts % 2) == 0) nfilts += 1;
             shape = gaussian(sps, sps, 0.3, nfilts);
             m->fm_k = (float)((M_PI / 2) / sps);
+        } else if (fsk4) {   // gr_mod_4fsk.cpp:52-92
+            nfilts = sps * 10; m->interp2 = 20;
+            if (sps == 2) { sps = 5; m->interp2 = 2; nfilts = 256; }
+            m->amplif = c.fm ? 0.9f : 0.8f;
+            if (c.fm) { shape = root_raised_cosine(sps, sps, 1, 0.2, nfilts); m->shape_scale = (float)0.66666666; }
+            m->fm_k = (float)(((c.fm ? 1 : 2) * M_PI) / sps);
         } else {      // gr_mod_2fsk.cpp:38-62
             nfilts = 25 * sps; m->interp2 = 10; m->amplif = c.fm ? 0.9f : 0.8f;
             if (sps == 5) nfilts *= 5;
@@ -157,6 +189,28 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->fmv), (size_t)c.batch * cap1 * sizeof(float2)));
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->phase), (size_t)c.batch * sizeof(float)));
     }
+    if (c.device_samp_rate != 0 && c.device_samp_rate != 1000000 &&
+        (c.device_samp_rate < 2000000 || c.device_samp_rate % 1000000 != 0 || c.device_samp_rate > 64000000))
+        return qrl_set_error(QRL_ERR_ARG, "modulator: device_samp_rate must be 1e6 or a multiple of 1e6 in [2e6, 64e6]");
+    m->be_interp = c.device_samp_rate >= 2000000 ? c.device_samp_rate / 1000000 : 1;
+    m->backend = m->be_interp > 1 || c.carrier_offset_hz != 0.0;
+    if (m->backend) {
+        const size_t spb1 = fsk4 ? (size_t)8 * m->sps * m->interp2 : fsk ? (size_t)16 * m->sps * m->interp2 : (size_t)(bpsk ? 16 : 8) * m->sps;
+        m->bb_stride = c.max_bytes * spb1;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->bb), (size_t)c.batch * m->bb_stride * sizeof(float2)));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->rot_lo), 512 * sizeof(float2)));
+        int r0 = m->set_rot(c.carrier_offset_hz);
+        if (r0) return r0;
+        if (m->be_interp > 1) {
+            const std::vector<float> lp = low_pass(m->be_interp, c.device_samp_rate, 480000, 20000, WIN_BLACKMAN_HARRIS);
+            m->be_nt = (int)lp.size();
+            if ((r0 = upload(lp, &m->be_taps))) return r0;
+            uint32_t capb = 1024;
+            while (capb < m->bb_stride + (size_t)m->be_nt / m->be_interp + 64) capb <<= 1;
+            m->be_mask = capb - 1;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->be_ring), (size_t)c.batch * capb * sizeof(float2)));
+        }
+    }
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->st), (size_t)c.batch * sizeof(TxState)));
     uint32_t cap = 1024;
     while (cap < ring_items) cap <<= 1;
@@ -174,11 +228,22 @@ int qrl_mod_reset(qrl_mod* m)
     HIPCHK(hipStreamSynchronize(m->stream));
     return m->init_state();
 }
+int qrl_mod_set_carrier_offset(qrl_mod* m, double hz)
+{
+    if (!m) return QRL_ERR_ARG;
+    if (!m->backend) return qrl_set_error(QRL_ERR_ARG, "modulator was created without the gr_mod_base back end");
+    HIPCHK(hipStreamSynchronize(m->stream));   // rot_lo is rewritten below
+    m->rot_acc += (m->n_bb - m->rot_nbase) * m->rot_inc;   // phase-continuous, like rotator_cc::set_phase_inc
+    m->rot_nbase = m->n_bb;
+    return m->set_rot(hz);
+}
 int qrl_mod_set_bb_gain(qrl_mod* m, float g) { if (!m) return QRL_ERR_ARG; m->bb_gain = g; return QRL_OK; }
 size_t qrl_mod_samples_per_byte(const qrl_mod* m)
 {
     if (!m) return 0;
-    return m->fam == qrl_mod::F_FSK ? (size_t)16 * m->sps * m->interp2 : (size_t)8 * m->sps;
+    const size_t spb1 = m->fsk4 ? (size_t)8 * m->sps * m->interp2 : m->fam == qrl_mod::F_FSK ? (size_t)16 * m->sps * m->interp2
+                                : (size_t)(m->bpsk ? 16 : 8) * m->sps;
+    return spb1 * (size_t)m->be_interp;
 }
 
 int qrl_mod_process(qrl_mod* m, const uint8_t* bytes, size_t stride, size_t nbytes, float* iq, size_t out_stride)
@@ -189,42 +254,62 @@ int qrl_mod_process(qrl_mod* m, const uint8_t* bytes, size_t stride, size_t nbyt
     HIPCHK(hipSetDevice(m->ctx->device));
     const int B = m->cfg.batch;
     const uint32_t nbits = (uint32_t)nbytes * 8;
+    float2* mod_out = m->backend ? m->bb : reinterpret_cast<float2*>(iq);
+    const size_t mod_stride = m->backend ? m->bb_stride : out_stride;
+    auto back_end = [&](uint32_t n1) {   // n1 samples per stream at 1 Msps are in bb
+        TxRotParams rp{}; rp.in = m->bb; rp.in_stride = m->bb_stride; rp.n0 = m->n_bb; rp.count = n1;
+        rp.rot_acc = m->rot_acc; rp.rot_inc = m->rot_inc; rp.rot_nbase = m->rot_nbase; rp.rot_lo = m->rot_lo;
+        if (m->be_interp > 1) rp.out_ring = RingC{m->be_ring, m->be_mask};
+        else { rp.out = reinterpret_cast<float2*>(iq); rp.out_stride = out_stride; }
+        launch_tx_rot(rp, B, m->stream);
+        if (m->be_interp > 1) {
+            TxInterpCParams bp{}; bp.in = rp.out_ring; bp.n0 = m->n_bb * (uint64_t)m->be_interp; bp.count = n1 * (uint32_t)m->be_interp;
+            bp.taps = m->be_taps; bp.nt = m->be_nt; bp.interp = m->be_interp;
+            bp.out = reinterpret_cast<float2*>(iq); bp.out_stride = out_stride;
+            launch_tx_interp_c(bp, B, m->stream);
+        }
+        m->n_bb += n1;
+    };
     TxBitsParams p{};
     p.bytes = bytes; p.stride = stride; p.nbytes = (uint32_t)nbytes;
     p.L = ((nbits + 63) / 64 + 31) / 32 * 32;
     lfsr_power(p.L, p.tl_cols);
     p.st = m->st; p.sym = RingB{m->sym, m->sym_mask}; p.s0 = m->nsym;
-    p.mode = m->fam == qrl_mod::F_FSK ? 1 : 0;
+    p.mode = m->fsk4 ? 2 : (m->fam == qrl_mod::F_FSK || m->bpsk) ? 1 : 0;
     launch_tx_qpsk_bits(p, B, m->stream);
     if (m->fam == qrl_mod::F_FSK) {
         // nsym counts CODED bits here (2 per input bit); rate-1 samples = coded bits * sps
-        const uint32_t ncoded = 2 * nbits;
+        const uint32_t ncoded = m->fsk4 ? nbits : 2 * nbits;   // ring items per call: 4-level symbols, or coded bits
         const uint64_t n1_0 = m->nsym * (uint64_t)m->sps;
         const uint32_t c1 = ncoded * (uint32_t)m->sps;
         TxShapeParams sp{}; sp.sym = p.sym; sp.out = RingF{m->shaped, m->r1_mask}; sp.n0 = n1_0; sp.count = c1; sp.sps = m->sps;
-        sp.taps = m->shape_taps; sp.nt = m->nt_shape;
+        sp.taps = m->shape_taps; sp.nt = m->nt_shape; sp.levels = m->fsk4 ? 4 : 2; sp.scale = m->shape_scale;
         launch_tx_shape(sp, B, m->stream);
         TxFmParams fp{}; fp.in = sp.out; fp.out = RingC{m->fmv, m->r1_mask}; fp.n0 = n1_0; fp.count = c1; fp.k = m->fm_k; fp.amp = m->amplif;
         fp.phase = m->phase;
         launch_tx_fm(fp, B, m->stream);
         TxInterpCParams ip{}; ip.in = fp.out; ip.n0 = n1_0 * (uint64_t)m->interp2; ip.count = c1 * (uint32_t)m->interp2;
-        ip.taps = m->taps; ip.nt = m->nt; ip.interp = m->interp2; ip.out = reinterpret_cast<float2*>(iq); ip.out_stride = out_stride;
+        ip.taps = m->taps; ip.nt = m->nt; ip.interp = m->interp2; ip.out = mod_out; ip.out_stride = mod_stride;
         launch_tx_interp_c(ip, B, m->stream);
+        if (m->backend) back_end(ip.count);
         HIPCHK(hipGetLastError());
         m->nsym += ncoded;
         return QRL_OK;
     }
     TxInterpParams q{};
-    q.sym = p.sym; q.n0 = m->nsym * (uint64_t)m->sps; q.count = nbits * (uint32_t)m->sps;
+    const uint32_t nitems = m->bpsk ? 2 * nbits : nbits;   // BPSK: one symbol per coded bit (gr_mod_bpsk.cpp:60-61)
+    q.sym = p.sym; q.n0 = m->nsym * (uint64_t)m->sps; q.count = nitems * (uint32_t)m->sps;
     q.taps = m->taps; q.nt = m->nt; q.interp = m->sps;
     // chunks_to_symbols_bc table of gr_mod_qpsk.cpp:44-54
     q.table[0] = make_float2(-0.707f, -0.707f); q.table[1] = make_float2(-0.707f, 0.707f);
     q.table[2] = make_float2(0.707f, 0.707f);   q.table[3] = make_float2(0.707f, -0.707f);
+    if (m->bpsk) { q.table[0] = make_float2(-1.0f, 0.0f); q.table[1] = make_float2(1.0f, 0.0f); }   // gr_mod_bpsk.cpp:33-35
     q.amp = 0.6f; q.bb_gain = m->bb_gain;
-    q.out = reinterpret_cast<float2*>(iq); q.out_stride = out_stride;
+    q.out = mod_out; q.out_stride = mod_stride;
     launch_tx_interp(q, B, m->stream);
+    if (m->backend) back_end(q.count);
     HIPCHK(hipGetLastError());
-    m->nsym += nbits;
+    m->nsym += nitems;
     return QRL_OK;
 }
 int qrl_mod_sync(qrl_mod* m)

@@ -88,6 +88,14 @@ _sig("orc_demod_dmr", None, _p, _sz, C.c_int, C.c_int, _p)
 _sig("orc_chan_proto_taps", C.c_int, C.c_int, _p)
 _sig("orc_pfb_channelizer", _sz, _p, _sz, _p, C.c_int, C.c_int, _p)
 _sig("orc_demod_mmdvm_multi", _sz, _p, _sz, C.c_int, _p, _sz)
+_sig("orc_demod_4fsk", None, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p)
+_sig("orc_demod_bpsk", None, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p)
+_sig("orc_mod_4fsk", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p)
+_sig("orc_mod_bpsk", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p)
+_sig("orc_clock_recovery_mm_cc", _sz, _p, _sz, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p)
+_sig("orc_rssi_tag", _sz, _p, _sz, C.c_float, _p)
+_sig("orc_demod_mmdvm", _sz, _p, _sz, C.c_int, C.c_int, _p, _sz, _p, C.c_float, _p)
+_sig("orc_demod_mmdvm_multi_rssi", _sz, _p, _sz, C.c_int, _p, _sz, _p, _sz, C.c_float)
 _sig("orc_batch_rx", C.c_double, C.c_int, _p, C.c_int, _sz, C.c_int, C.c_double, C.c_int, _p)
 
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECT, WIN_BH = 0, 1, 2, 3, 5
@@ -264,6 +272,55 @@ def mod_gmsk(data, sps=10, samp_rate=1000000, carrier_freq=1700, filter_width=20
 
 def mod_qpsk(data, sps=4, samp_rate=1000000, carrier_freq=1700, filter_width=160000):
     return _mod(lib.orc_mod_qpsk, data, sps, samp_rate, carrier_freq, filter_width)
+
+
+def demod_4fsk(x, sps=5, samp_rate=1000000, carrier_freq=1700, filter_width=3000, fm=True):
+    x = np.ascontiguousarray(x, cf32)
+    o = DemodOut()
+    lib.orc_demod_4fsk(_ptr(x), x.size, sps, samp_rate, carrier_freq, filter_width, int(fm), C.byref(o))
+    return _take(o)
+
+
+def demod_bpsk(x, sps=10, samp_rate=1000000, carrier_freq=1700, filter_width=1300):
+    x = np.ascontiguousarray(x, cf32)
+    o = DemodOut()
+    lib.orc_demod_bpsk(_ptr(x), x.size, sps, samp_rate, carrier_freq, filter_width, C.byref(o))
+    return _take(o)
+
+
+def mod_4fsk(data, sps=25, samp_rate=1000000, carrier_freq=1700, filter_width=3500, fm=True):
+    return _mod(lib.orc_mod_4fsk, data, sps, samp_rate, carrier_freq, filter_width, int(fm))
+
+
+def mod_bpsk(data, sps=500, samp_rate=1000000, carrier_freq=1700, filter_width=1500):
+    return _mod(lib.orc_mod_bpsk, data, sps, samp_rate, carrier_freq, filter_width)
+
+
+def rssi_tag(x, cal=0.0):
+    x = np.ascontiguousarray(x, cf32)
+    db = np.zeros(x.size // 300 + 1, np.float32)
+    n = lib.orc_rssi_tag(_ptr(x), x.size, cal, _ptr(db))
+    return db[:n].copy()
+
+
+def demod_mmdvm(x, samp_rate=250000, filter_width=5000, cal=0.0):
+    x = np.ascontiguousarray(x, cf32)
+    cap = x.size * 12 // 125 + 4
+    out = np.zeros(cap, np.int16)
+    rssi = np.zeros(cap // 300 + 2, np.float32)
+    nr = C.c_size_t(0)
+    n = lib.orc_demod_mmdvm(_ptr(x), x.size, samp_rate, filter_width, _ptr(out), cap, _ptr(rssi), cal, C.byref(nr))
+    return out[:n].copy(), rssi[:nr.value].copy()
+
+
+def demod_mmdvm_multi_rssi(x, M, cal=0.0):
+    x = np.ascontiguousarray(x, cf32)
+    cap = (x.size // M) * 24 // 25 + 4
+    out = np.zeros((M, cap), np.int16)
+    rcap = cap // 300 + 2
+    rssi = np.zeros((M, rcap), np.float32)
+    n = lib.orc_demod_mmdvm_multi_rssi(_ptr(x), x.size, M, _ptr(out), cap, _ptr(rssi), rcap, cal)
+    return out[:, :n].copy(), rssi[:, :n // 300].copy()
 
 
 def tx_interp(x, samp_rate):

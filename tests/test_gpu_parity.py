@@ -30,6 +30,11 @@ def _oracle(mode_name, x, device_rate, offset):
         return orc.demod_gmsk(fe, sps=10, filter_width=2000)
     if mode_name == "qpsk250k":
         return orc.demod_qpsk(fe, sps=2, filter_width=160000)
+    if mode_name.startswith("4fsk"):
+        sps, fw = {"4fsk2kfm": (5, 3000), "4fsk1kfm": (10, 2000), "4fsk10kfm": (1, 20000), "4fsk100k": (2, 125000)}[mode_name]
+        return orc.demod_4fsk(fe, sps=sps, filter_width=fw, fm=True)
+    if mode_name.startswith("bpsk"):
+        return orc.demod_bpsk(fe, sps=10 if mode_name == "bpsk1k" else 5)
     raise ValueError(mode_name)
 
 
@@ -37,7 +42,7 @@ def _compare(iq, out, mode_name, device_rate, offset):
     for b in range(iq.shape[0]):
         ref = _oracle(mode_name, iq[b], device_rate, offset)
         for port in ("bits_a", "bits_b"):
-            if mode_name == "qpsk250k" and port == "bits_b":
+            if (mode_name == "qpsk250k" or mode_name.startswith("4fsk")) and port == "bits_b":
                 continue   # single-branch mode (gr_demod_qpsk.cpp:124-126): port 2 only
             assert out[port][b].size == ref[port].size, (port, b, out[port][b].size, ref[port].size)
             assert np.array_equal(out[port][b], ref[port]), "%s stream %d differs" % (port, b)
@@ -58,6 +63,12 @@ def _compare(iq, out, mode_name, device_rate, offset):
     ("gmsk10k", 22, 10000000, 1 << 23),     # front end 10:1, 419 taps
     ("qpsk250k", 26, 1000000, 1 << 20),     # C3 chain at the internal rate: agc2, 2x Costas, symbol_sync_cc, diff_phasor
     ("qpsk250k", 26, 10000000, 1 << 23),    # C3 behind the 10:1 front end
+    ("4fsk2kfm", 5, 1000000, 1 << 21),      # gr_demod_4fsk FM branch: 4-level symbol_sync_ff, phase_modulator, (imag, real) soft pairs
+    ("4fsk1kfm", 6, 2000000, 1 << 22),
+    ("4fsk10kfm", 4, 4000000, 1 << 22),     # 2/25 resampler to 80 ksps, 8 samples per symbol
+    ("4fsk100k", 27, 1000000, 1 << 20),     # 1:2 decimation to 500 ksps, 5 samples per symbol
+    ("bpsk1k", 24, 1000000, 1 << 21),       # gr_demod_bpsk: FLL(32 taps) -> RRC -> agc2 -> clock_recovery_mm_cc -> costas(2)
+    ("bpsk2k", 0, 2000000, 1 << 22),
 ])
 def test_chain_bit_exact_single_call(qrl_ctx, mode_name, modem, rate, chunk):
     offset = 25000.0 if rate >= 2000000 else 1200.0
@@ -82,6 +93,13 @@ def test_chunk_invariance_mfma_front_end(qrl_ctx, chunk):
 def test_chunk_invariance_2fsk(qrl_ctx, chunk):
     iq, out = _run(qrl_ctx, "2fsk1k", 18, 1000000, 1200.0, B=2, chunk=chunk, nframes=2)
     _compare(iq, out, "2fsk1k", 1000000, 1200.0)
+
+
+@pytest.mark.parametrize("mode_name,modem,chunk", [("4fsk2kfm", 5, 50000), ("4fsk100k", 27, 20002), ("bpsk1k", 24, 65536),
+                                                   ("bpsk2k", 0, 30000)])
+def test_chunk_invariance_4fsk_bpsk(qrl_ctx, mode_name, modem, chunk):
+    iq, out = _run(qrl_ctx, mode_name, modem, 1000000, 700.0, B=2, chunk=chunk, nframes=2)
+    _compare(iq, out, mode_name, 1000000, 700.0)
 
 
 @pytest.mark.parametrize("chunk", [65536, 20002, 1000])

@@ -118,6 +118,12 @@ FSK_CASES = [
     (22, lambda d: orc.mod_gmsk(d, sps=10, filter_width=20000), 300),            # GMSK10K  (:162)
     (20, lambda d: orc.mod_gmsk(d, sps=50, filter_width=4000), 40),              # GMSK2K
     (21, lambda d: orc.mod_gmsk(d, sps=100, filter_width=2000), 20),             # GMSK1K
+    (5, lambda d: orc.mod_4fsk(d, sps=25, filter_width=3500, fm=True), 40),      # 4FSK2KFM (gr_mod_base.cpp:164)
+    (6, lambda d: orc.mod_4fsk(d, sps=50, filter_width=2000, fm=True), 20),      # 4FSK1KFM
+    (4, lambda d: orc.mod_4fsk(d, sps=5, filter_width=20000, fm=True), 200),     # 4FSK10KFM
+    (27, lambda d: orc.mod_4fsk(d, sps=2, filter_width=125000, fm=True), 2000),  # 4FSK100K (sps 2 -> 5 x 2)
+    (24, lambda d: orc.mod_bpsk(d, sps=500, filter_width=1500), 24),             # BPSK1K (:168): 5501-tap RRC interpolator
+    (0, lambda d: orc.mod_bpsk(d, sps=250, filter_width=2800), 40),              # BPSK2K
 ]
 
 
@@ -136,7 +142,8 @@ def test_mod_fsk_family_bit_exact(qrl_ctx, modem, oracle, nbytes):
         assert np.array_equal(out[b].view(np.uint32), ref.view(np.uint32)), "stream %d differs" % b
 
 
-@pytest.mark.parametrize("modem,oracle", [(18, FSK_CASES[0][1]), (22, FSK_CASES[4][1])], ids=["2fsk1k", "gmsk10k"])
+@pytest.mark.parametrize("modem,oracle", [(18, FSK_CASES[0][1]), (22, FSK_CASES[4][1]), (5, FSK_CASES[7][1]), (24, FSK_CASES[11][1])],
+                         ids=["2fsk1k", "gmsk10k", "4fsk2kfm", "bpsk1k"])
 def test_mod_fsk_chunk_invariance(qrl_ctx, modem, oracle):
     import torch
     import qradiolink_amd as q
@@ -173,3 +180,75 @@ def test_fsk_tx_rx_loopback_on_gpu(qrl_ctx, mode, modem, sync, nbits):
         fr = sig.find_frames(out[k][0], sync, nbits)
         best = max(best, sum(((bytes([0xAA]) + p) if mode == "gmsk10k" else p) in fr for p in payloads))
     assert best >= len(payloads) - 1   # the last frame may sit in the decoder's look-ahead
+
+
+# ---- gr_mod_base back end: rotator at 1 Msps + interpolation to the device rate (gr_mod_base.cpp:38,215-258)
+def _back_end_ref(x1, device_rate, offset_hz):
+    inc = orc.phase_inc_to_turn(2 * np.pi * offset_hz / 1000000.0)
+    return orc.tx_interp(orc.rotator(x1, inc), device_rate)
+
+
+@pytest.mark.parametrize("modem,oracle,nbytes,rate,offset", [
+    (26, lambda d: orc.mod_qpsk(d), 600, 4000000, 25000.0),
+    (26, lambda d: orc.mod_qpsk(d), 300, 1000000, -12500.0),       # rotator only
+    (22, FSK_CASES[4][1], 60, 10000000, 50000.0),                  # 2090 taps: taps read from global memory
+    (18, FSK_CASES[0][1], 4, 2000000, 0.0),                        # resampler only
+], ids=["qpsk-4M", "qpsk-1M-rot", "gmsk10k-10M", "2fsk1k-2M"])
+def test_mod_back_end_bit_exact(qrl_ctx, modem, oracle, nbytes, rate, offset):
+    import torch
+    import qradiolink_amd as q
+    rng = np.random.default_rng(nbytes)
+    data = np.stack([_payload(rng, nbytes) for _ in range(2)])
+    mod = q.Mod(qrl_ctx, modem, batch=2, max_bytes=nbytes, device_samp_rate=rate, carrier_offset_hz=offset)
+    out = mod.process(torch.from_numpy(data).cuda()).cpu().numpy()
+    mod.close()
+    for b in range(2):
+        ref = _back_end_ref(oracle(data[b]), rate, offset)
+        assert out[b].size == ref.size, (out[b].size, ref.size)
+        assert np.array_equal(out[b].view(np.uint32), ref.view(np.uint32)), "stream %d differs" % b
+
+
+def test_mod_back_end_chunks_and_retune(qrl_ctx):
+    """history of the back-end interpolator and the NCO phase carry across calls; set_carrier_offset is
+    phase-continuous like rotator_cc::set_phase_inc (gr_mod_base.cpp:799-805)"""
+    import torch
+    import qradiolink_amd as q
+    rng = np.random.default_rng(77)
+    cuts = [100, 1, 333, 66]
+    data = _payload(rng, sum(cuts))[None, :]
+    mod = q.Mod(qrl_ctx, q.MODEM_QPSK250K, batch=1, max_bytes=max(cuts), device_samp_rate=5000000, carrier_offset_hz=10000.0)
+    d = torch.from_numpy(data).cuda()
+    parts, pos = [], 0
+    for i, c in enumerate(cuts):
+        if i == 2:
+            mod.set_carrier_offset(-30000.0)
+        parts.append(mod.process(d[:, pos:pos + c].contiguous()).cpu().numpy())
+        pos += c
+    mod.close()
+    got = np.concatenate(parts, axis=1)[0]
+    x1 = orc.mod_qpsk(data[0])
+    k = (cuts[0] + cuts[1]) * 32
+    inc0 = orc.phase_inc_to_turn(2 * np.pi * 10000.0 / 1e6)
+    inc1 = orc.phase_inc_to_turn(2 * np.pi * -30000.0 / 1e6)
+    rot = np.concatenate([orc.rotator(x1[:k], inc0), orc.rotator(x1[k:], inc1, (k * inc0) & (2 ** 64 - 1))])
+    ref = orc.tx_interp(rot, 5000000)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_device_rate_tx_rx_loopback(qrl_ctx):
+    """TX at 4 Msps with +25 kHz offset -> RX at 4 Msps tuned to the same offset: frames come back."""
+    import torch
+    import qradiolink_amd as q
+    rng = np.random.default_rng(10)
+    data, payloads = _frames(2, rng)
+    data = np.concatenate([data, np.full(64, 0xAA, np.uint8)])
+    mod = q.Mod(qrl_ctx, q.MODEM_QPSK250K, batch=1, max_bytes=data.size, device_samp_rate=4000000, carrier_offset_hz=25000.0)
+    iq = mod.process(torch.from_numpy(data[None, :]).cuda())
+    mod.close()
+    iq = (iq * 0.3).contiguous()
+    n = iq.shape[1] & ~7
+    dem = q.Demod(qrl_ctx, q.MODEM_QPSK250K, batch=1, max_chunk=n, device_samp_rate=4000000, carrier_offset_hz=25000.0)
+    out = q.collect(dem, iq[:, :n], n)
+    dem.close()
+    fr = sig.find_frames(out["bits_a"][0], bytes([0xDE, 0x98, 0xAA]), 1516 * 8)
+    assert sum(p in fr for p in payloads) == len(payloads)

@@ -271,3 +271,66 @@ def test_dmr_4fsk_oracle_recovers_dibits():
     got = got[:, 0] * 2 + got[:, 1]
     assert max(np.mean(got[k:k + 400] == dib[:400]) for k in range(40)) == 1.0
     assert np.allclose(np.abs(r["constellation"][50:]), 1.0, atol=1e-6)
+
+
+# ---- native 4FSK (FM variants) and BPSK chains (gr_demod_4fsk.cpp, gr_demod_bpsk.cpp): the oracle's modulator through a
+# seeded channel into the oracle's demodulator returns the frames
+NEW_MODES = {
+    "4fsk2kfm": (bytes([0xED, 0x89, 0xAA]), 56, lambda fe: orc.demod_4fsk(fe, sps=5, filter_width=3000, fm=True)),
+    "4fsk1kfm": (bytes([0xB5]), 32, lambda fe: orc.demod_4fsk(fe, sps=10, filter_width=2000, fm=True)),
+    "4fsk10kfm": (bytes([0xED, 0x89, 0xAA]), 47 * 8, lambda fe: orc.demod_4fsk(fe, sps=1, filter_width=20000, fm=True)),
+    "4fsk100k": (bytes([0xDE, 0x98, 0xAA]), 1516 * 8, lambda fe: orc.demod_4fsk(fe, sps=2, filter_width=125000, fm=True)),
+    "bpsk1k": (bytes([0xB5]), 32, lambda fe: orc.demod_bpsk(fe, sps=10)),
+    "bpsk2k": (bytes([0xED, 0x89, 0xAA]), 56, lambda fe: orc.demod_bpsk(fe, sps=5)),
+}
+
+
+@pytest.mark.parametrize("mode", sorted(NEW_MODES))
+def test_loopback_4fsk_bpsk(mode):
+    sync, nbits, dem = NEW_MODES[mode]
+    nframes = 6 if mode.startswith("bpsk") else 3
+    y, payloads = sig.make_stream(mode, nframes=nframes, device_rate=1000000, seed=6)
+    y = np.concatenate([y, np.zeros(30000, np.complex64)])   # flush the filters and the 80-bit Viterbi frames
+    r = dem(orc.frontend(y, 1000000, 0.0))
+    got = 0
+    for k in ("bits_a", "bits_b"):
+        if r[k].size:
+            fr = sig.find_frames(r[k], sync, nbits)
+            got = max(got, sum(p in fr for p in payloads))
+            if mode.startswith("bpsk"):   # BPSK has a 180 degree ambiguity; the convolutional code + descrambler are inversion transparent
+                fr = sig.find_frames(1 - r[k], sync, nbits)
+                got = max(got, sum(p in fr for p in payloads))
+    # BPSK: agc2 (rate 0.1), FLL and Costas acquire during the first frame after the 8-byte preamble
+    assert got >= len(payloads) - (1 if mode.startswith("bpsk") else 0), (mode, got)
+    assert r["filtered"].size > 0 and r["constellation"].size > 0
+
+
+def test_4level_slicer_follows_constellation_rect_sectors():
+    """symbol_sync_ff on a constant input: the decision is the sector (int)(x + 2) clamped to [0, 3], so exact zeros
+    (the start-up transient) slice to +0.5, not -0.5"""
+    import ctypes as C
+    x = np.zeros(64, np.float32)
+    out = np.zeros(64, np.float32)
+    n = orc.lib.orc_symbol_sync_ff(x.ctypes.data_as(C.c_void_p), x.size, 1, 5.0, 0.0314, 1.0, 0.2869, 0.05, 2,
+                                   out.ctypes.data_as(C.c_void_p))
+    assert n > 5 and np.all(out[:n] == 0.0)
+
+
+def test_rssi_tag_block_levels():
+    """rssi_tag_block.cpp:43-68: one tag per 300 samples, 10 log10(sqrt(mean |x|^4)) = 20 log10(amplitude) for a constant envelope"""
+    x = (0.1 * np.exp(2j * np.pi * 0.01 * np.arange(1000))).astype(np.complex64)
+    db = orc.rssi_tag(x, cal=3.0)
+    assert db.size == 3
+    assert np.allclose(db, 20 * np.log10(0.1) + 3.0, atol=1e-3)
+
+
+def test_mmdvm_single_carrier_chain():
+    """gr_demod_mmdvm: 250 ksps -> 24 ksps, FM discriminator scaled so that +-10 kHz gives +-full scale / (2 pi) * 2 pi..."""
+    fs, dev = 250000, 2500.0
+    n = np.arange(fs // 2)
+    x = (0.2 * np.exp(2j * np.pi * dev * n / fs)).astype(np.complex64)
+    out, rssi = orc.demod_mmdvm(x)
+    assert abs(out.size - n.size * 12 // 125) <= 1
+    # quadrature_demod gain 24000 / (2 pi 10000): a constant +2.5 kHz offset reads 0.25 -> 0.25 * 32767
+    assert abs(np.median(out[2000:]) - 0.25 * 32767) < 40
+    assert rssi.size == out.size // 300 and np.allclose(rssi[5:], 20 * np.log10(0.2), atol=0.05)
