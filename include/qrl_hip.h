@@ -160,7 +160,8 @@ void* qrl_mod_stream(qrl_mod* m);
  * make_gr_demod_mmdvm_multi2(burst_timer, num_channels, channel_separation, use_tdma, sps, samp_rate, carrier_freq,
  * filter_width): stream_to_streams + pfb_channelizer_ccf + per channel {24/25 resampler, LPF, FM discriminator,
  * level, float_to_short}.  The reference fixes 10 branches at 250 ksps (src/config_mmdvm.h:4); here num_channels = M
- * (2..64) at fs = 25 kHz * M.  Channel c is centred at +c*fs/M (c > M/2: negative offsets); the reference's port
+ * (2..64) at fs = 25 kHz * M; num_channels = 1 selects the SINGLE-carrier receiver gr_demod_mmdvm (src/gr/gr_demod_mmdvm.cpp:29-61:
+ * 250 ksps in, rational_resampler_ccf(12, 125), rssi tag, 43-tap LPF, quadrature_demod_cf(24000/(2 pi 10000)), int16).  Channel c is centred at +c*fs/M (c > M/2: negative offsets); the reference's port
  * order {0,1,2,3,9,8,7} and the TDMA tagging / ZeroMQ framing of gr_mmdvm_sink (src/gr/gr_mmdvm_sink.cpp:66-176)
  * stay with the caller.  channel_first/channel_count select the channels THIS handle produces: ranks of a multi-GPU job
  * take disjoint ranges (no data-path collective). */
@@ -176,11 +177,33 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** out);
 void qrl_chan_destroy(qrl_chan* c);
 int qrl_chan_reset(qrl_chan* c);
 int qrl_chan_set_level(qrl_chan* c, float level);   /* _level_control multiply_const_ff, gr_demod_mmdvm_multi2.cpp:84 */
+/* replaces: gr_demod_mmdvm_multi2::calibrate_rssi / gr_demod_mmdvm::calibrate_rssi -> rssi_tag_block::calibrate_rssi
+ * (src/gr/gr_demod_mmdvm_multi2.cpp:138-144, src/gr/gr_demod_mmdvm.cpp:64-67) */
+int qrl_chan_calibrate_rssi(qrl_chan* c, float level);
+/* replaces: the RSSI stream tags of rssi_tag_block::work (src/gr/rssi_tag_block.cpp:43-68): one dB value per 300 samples at
+ * 24 ksps.  rssi[(b*channel_count + ch)*cap + k], k < counts[b*channel_count + ch], holds the tags completed by each
+ * following qrl_chan_process call (device pointers; NULL switches the block off). */
+int qrl_chan_set_rssi_output(qrl_chan* c, float* rssi, size_t cap, uint32_t* counts);
 size_t qrl_chan_out_cap(const qrl_chan* c, size_t n);   /* int16 samples per channel a call with n inputs can produce */
 /* replaces one scheduler pass of the multi-carrier graph: iq[b*stride + i] device cf32, n a multiple of num_channels;
  * out[(b*channel_count + c)*out_cap + k] device int16 @24 ksps, counts[b*channel_count + c] = samples written. */
 int qrl_chan_process(qrl_chan* c, const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts);
 int qrl_chan_sync(qrl_chan* c);
+
+/* ---- device deframer (reference src/gr/gr_deframer_bb.cpp:24-48,83-185; instances gr_demod_base.cpp:171-178) -----------
+ * make_gr_deframer_bb(modem_type): 1 = 2k modes (16/24-bit sync words, 64 bits per frame), 2 = 1k modes (0xB5, 32 bits),
+ * 3 = 10k modes (384 bits).  qrl_deframer_process consumes the unpacked bits of one demodulator port (bits[b*stride + i];
+ * i < n, or i < counts[b*count_stride] when counts != NULL: pass the demodulator's counts + 2 or + 3 with count_stride 4)
+ * and appends what gr_deframer_bb::work pushes into its mailbox -- the sync bits followed by the frame bits -- to
+ * out[b*out_cap + k], k < out_counts[b] (out_cap >= 2 n + 24 never overflows).  Search state carries across calls.
+ * All pointers are device pointers; asynchronous on the handle's stream (give it the demodulator's stream to chain). */
+typedef struct qrl_deframer qrl_deframer;
+int qrl_deframer_create(qrl_ctx* ctx, int deframer_type, int batch, void* hip_stream, qrl_deframer** out);
+void qrl_deframer_destroy(qrl_deframer* d);
+int qrl_deframer_reset(qrl_deframer* d);   /* gr_deframer_bb::flush (:58-65) */
+int qrl_deframer_process(qrl_deframer* d, const uint8_t* bits, size_t stride, size_t n, const uint32_t* counts, size_t count_stride,
+                         uint8_t* out, size_t out_cap, uint32_t* out_counts);
+int qrl_deframer_sync(qrl_deframer* d);
 
 /* ---- filter design & tables (host side, no GPU needed): what the kernels are loaded with ----
  * replaces: gr::filter::firdes::* calls at gr_demod_2fsk.cpp:82-97, gr_demod_gmsk.cpp:80-98,

@@ -617,3 +617,44 @@ size_t orc_rssi_tag(const cf32* in, size_t n, float calibration, float* db)
     }
     return k;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * gr_deframer_bb (reference src/gr/gr_deframer_bb.cpp:24-48, 83-185): shift-register search for the sync words
+ * (type 2: 0xB5; types 1 and 3: 0x89ED 0xED89 0x98DE 0xED77 0x8CC8, 24-bit 0x4C8A2B), then the sync bits and the next
+ * bit_buf_len (64 / 32 / 384) bits go to the mailbox and the search restarts with a cleared register.
+ * st[0] = shift register, st[1] = sync_found, st[2] = bit_buf_index carry over between calls (zero them to start).
+ * Returns the number of bits appended to out (capacity >= 2 n + 24).
+ * ------------------------------------------------------------------------------------------ */
+static int deframer_find(int type, uint32_t reg, int* nbits)
+{
+    uint32_t temp = type != 2 ? (reg & 0xFFFF) : (reg & 0xFF);
+    *nbits = type == 2 ? 8 : 16;
+    if (type == 2 && temp == 0xB5) return (int)temp;
+    if (temp == 0x89ED || temp == 0xED89 || temp == 0x98DE || temp == 0xED77 || temp == 0x8CC8) return (int)temp;
+    temp = reg & 0xFFFFFF;
+    if (temp == 0x4C8A2B) { if (type != 2) *nbits = 24; return (int)temp; }
+    return 0;
+}
+size_t orc_deframer(int type, const uint8_t* bits, size_t n, uint32_t st[3], uint8_t* out)
+{
+    const uint32_t bit_buf_len = type == 1 ? 64 : type == 2 ? 32 : 384;
+    size_t no = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!st[1]) {
+            st[0] = (st[0] << 1) | (bits[i] & 1u);
+            int nb; const int ft = deframer_find(type, st[0], &nb);
+            if (ft) {
+                st[1] = 1;
+                for (int k = 0; k < nb; k++) out[no++] = (uint8_t)((ft >> (nb - 1 - k)) & 1);
+                st[2] = 0;
+                continue;
+            }
+        }
+        if (st[1]) {
+            out[no++] = bits[i] & 1u;
+            st[2]++;
+            if (st[2] >= bit_buf_len) { st[1] = 0; st[0] = 0; st[2] = 0; }
+        }
+    }
+    return no;
+}

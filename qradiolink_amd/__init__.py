@@ -98,10 +98,17 @@ def load_library():
     lib.qrl_chan_destroy.argtypes = [vp]
     lib.qrl_chan_reset.argtypes = [vp]
     lib.qrl_chan_set_level.argtypes = [vp, C.c_float]
+    lib.qrl_chan_calibrate_rssi.argtypes = [vp, C.c_float]
+    lib.qrl_chan_set_rssi_output.argtypes = [vp, vp, sz, vp]
     lib.qrl_chan_out_cap.restype = sz
     lib.qrl_chan_out_cap.argtypes = [vp, sz]
     lib.qrl_chan_process.argtypes = [vp, vp, sz, sz, vp, sz, vp]
     lib.qrl_chan_sync.argtypes = [vp]
+    lib.qrl_deframer_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    lib.qrl_deframer_destroy.argtypes = [vp]
+    lib.qrl_deframer_reset.argtypes = [vp]
+    lib.qrl_deframer_process.argtypes = [vp, vp, sz, sz, vp, sz, vp, sz, vp]
+    lib.qrl_deframer_sync.argtypes = [vp]
     lib.qrl_firdes_low_pass.argtypes = [C.c_double] * 4 + [C.c_int, vp]
     lib.qrl_firdes_low_pass_2.argtypes = [C.c_double] * 5 + [C.c_int, vp]
     lib.qrl_firdes_complex_band_pass.argtypes = [C.c_double] * 5 + [C.c_int, vp]
@@ -120,7 +127,8 @@ EXPORTED_SYMBOLS = [
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
     "qrl_mod_samples_per_byte", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_create",
-    "qrl_chan_destroy", "qrl_chan_reset", "qrl_chan_set_level", "qrl_chan_out_cap", "qrl_chan_process", "qrl_chan_sync",
+    "qrl_chan_destroy", "qrl_chan_reset", "qrl_chan_set_level", "qrl_chan_calibrate_rssi", "qrl_chan_set_rssi_output", "qrl_chan_out_cap", "qrl_chan_process", "qrl_chan_sync",
+    "qrl_deframer_create", "qrl_deframer_destroy", "qrl_deframer_reset", "qrl_deframer_process", "qrl_deframer_sync",
     "qrl_firdes_low_pass",
     "qrl_firdes_low_pass_2", "qrl_firdes_complex_band_pass", "qrl_firdes_root_raised_cosine", "qrl_table_mmse",
     "qrl_table_atan", "qrl_table_tanh", "qrl_phase_inc_to_turn",
@@ -284,6 +292,15 @@ class Channelizer:
         dev = "cuda:%d" % ctx.device
         self.out = torch.zeros((batch, self.cc, self.cap), dtype=torch.int16, device=dev)
         self.counts = torch.zeros((batch, self.cc), dtype=torch.int32, device=dev)
+        # rssi_tag_block outputs: one dB value per 300 samples of each 24 ksps channel
+        self.rssi_cap = self.cap // 300 + 2
+        self.rssi = torch.zeros((batch, self.cc, self.rssi_cap), dtype=torch.float32, device=dev)
+        self.rssi_counts = torch.zeros((batch, self.cc), dtype=torch.int32, device=dev)
+        _check(self.lib.qrl_chan_set_rssi_output(self.h, self.rssi.data_ptr(), self.rssi_cap, self.rssi_counts.data_ptr()),
+               "qrl_chan_set_rssi_output")
+
+    def calibrate_rssi(self, level):
+        _check(self.lib.qrl_chan_calibrate_rssi(self.h, float(level)), "qrl_chan_calibrate_rssi")
 
     def process_async(self, iq):
         assert iq.is_cuda and iq.dtype == self.torch.complex64 and iq.dim() == 2 and iq.shape[0] == self.batch and iq.stride(1) == 1
@@ -301,6 +318,42 @@ class Channelizer:
     def close(self):
         if self.h:
             self.lib.qrl_chan_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Deframer:
+    """gr_deframer_bb on the device (reference src/gr/gr_deframer_bb.cpp): process(bits, counts) takes the uint8 cuda tensor
+    [batch, cap] of one demodulator port plus its per-stream valid counts (int32 cuda [batch] view or None) and returns
+    (uint8 cuda [batch, out_cap], int32 cuda [batch]) = what the block pushes into its mailbox."""
+
+    def __init__(self, ctx, deframer_type, batch, stream=None):
+        import torch
+        self.torch = torch
+        self.ctx, self.lib, self.batch = ctx, ctx.lib, batch
+        self.h = C.c_void_p()
+        _check(self.lib.qrl_deframer_create(ctx.h, deframer_type, batch, stream, C.byref(self.h)), "qrl_deframer_create")
+        self.out = None
+        self.out_counts = torch.zeros((batch,), dtype=torch.int32, device="cuda:%d" % ctx.device)
+
+    def process(self, bits, counts=None, count_stride=1, n=None):
+        t = self.torch
+        assert bits.is_cuda and bits.dtype == t.uint8 and bits.dim() == 2 and bits.shape[0] == self.batch and bits.stride(1) == 1
+        n = bits.shape[1] if n is None else n
+        cap = 2 * n + 24
+        if self.out is None or self.out.shape[1] < cap:
+            self.out = t.zeros((self.batch, cap), dtype=t.uint8, device=bits.device)
+        _check(self.lib.qrl_deframer_process(self.h, bits.data_ptr(), bits.stride(0), n, counts.data_ptr() if counts is not None else None,
+                                             count_stride, self.out.data_ptr(), self.out.shape[1], self.out_counts.data_ptr()),
+               "qrl_deframer_process")
+        _check(self.lib.qrl_deframer_sync(self.h), "qrl_deframer_sync")
+        return self.out, self.out_counts
+
+    def reset(self):
+        _check(self.lib.qrl_deframer_reset(self.h), "qrl_deframer_reset")
+
+    def close(self):
+        if self.h:
+            self.lib.qrl_deframer_destroy(self.h)
             self.h = C.c_void_p()
 
 

@@ -48,7 +48,9 @@ struct qrl_chan {
     Buf<float2> hist_a, hist_b; uint32_t hist_len = 0; bool flip = false;
     Buf<float2> r1, r2, r3; Buf<float> r4; uint32_t m1 = 0, m2 = 0;
     uint64_t n_in = 0, n1 = 0, n2 = 0;
-    float gain = 0, level = 1.0f;
+    float gain = 0, level = 1.0f, rssi_cal = 0.0f;
+    bool single = false; int rs_I = 24, rs_D = 25;   // single: gr_demod_mmdvm (one carrier at 250 ksps, 12/125 resampler, no channelizer)
+    float* rssi_out = nullptr; size_t rssi_cap = 0; uint32_t* rssi_counts = nullptr;
     size_t zeroed = 0;
     ~qrl_chan() { if (own_stream && stream) (void)hipStreamDestroy(stream); }
     int reset_state() {
@@ -73,7 +75,8 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     if (!h) return QRL_ERR_NOMEM;
     h->ctx = ctx; h->cfg = *cfg;
     qrl_chan_config& c = h->cfg;
-    if (c.num_channels < 2 || c.num_channels > 64) return qrl_set_error(QRL_ERR_ARG, "num_channels must be 2..64");
+    if (c.num_channels < 1 || c.num_channels > 64) return qrl_set_error(QRL_ERR_ARG, "num_channels must be 1..64");
+    h->single = c.num_channels == 1;
     if (c.channel_count <= 0) { c.channel_first = 0; c.channel_count = c.num_channels; }
     if (c.channel_first < 0 || c.channel_first + c.channel_count > c.num_channels) return qrl_set_error(QRL_ERR_ARG, "bad channel range");
     if (c.batch < 1 || c.max_chunk < (size_t)c.num_channels || (size_t)c.batch * c.channel_count > 65535)
@@ -93,20 +96,25 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     std::vector<float2> W(M);
     for (int q = 0; q < M; ++q) W[q] = make_float2((float)std::cos(2 * M_PI * q / M), (float)std::sin(2 * M_PI * q / M));
     if ((r = h->twiddle.upload(W))) return r;
-    const std::vector<float> rt = low_pass_2(1, 600000, 5000, 2000, 60, WIN_BLACKMAN_HARRIS);   // :60-61, used as 24/25 resampler
-    h->rs_Jp = ((int)rt.size() + 23) / 24;
-    std::vector<float> rl((size_t)24 * h->rs_Jp, 0.0f);
-    for (size_t k = 0; k < rt.size(); ++k) rl[(k % 24) * h->rs_Jp + k / 24] = rt[k];
+    // multi2: :60-61, used as 24/25 resampler.  single carrier: gr_demod_mmdvm.cpp:43-45, 12/125 from MMDVM_SAMPLE_RATE = 250 ksps
+    if (h->single) { h->rs_I = 12; h->rs_D = 125; }
+    const std::vector<float> rt = h->single ? low_pass_2(12, 12 * 250000.0, 5000, 2000, 60, WIN_BLACKMAN_HARRIS)
+                                            : low_pass_2(1, 600000, 5000, 2000, 60, WIN_BLACKMAN_HARRIS);
+    const int RI = h->rs_I;
+    h->rs_Jp = ((int)rt.size() + RI - 1) / RI;
+    std::vector<float> rl((size_t)RI * h->rs_Jp, 0.0f);
+    for (size_t k = 0; k < rt.size(); ++k) rl[(k % RI) * h->rs_Jp + k / RI] = rt[k];
     if ((r = h->rs_taps.upload(rl))) return r;
     const std::vector<float> ft = low_pass_2(1, 24000, 5000, 2000, 60, WIN_BLACKMAN_HARRIS);    // :62-63
     h->filt_nt = (int)ft.size();
     if ((r = h->filt_taps.upload(ft)) || (r = h->atan_tab.upload(atan_table()))) return r;
-    h->gain = (float)(24000.0f / (2 * M_PI * 12500.0f));                                          // :80
-    h->hist_len = (uint32_t)(h->J * M);
+    h->gain = h->single ? (float)(24000.0f / (2 * M_PI * 10000.0f))                               // gr_demod_mmdvm.cpp:41,48
+                        : (float)(24000.0f / (2 * M_PI * 12500.0f));                              // gr_demod_mmdvm_multi2.cpp:80
+    h->hist_len = h->single ? (uint32_t)(h->rs_Jp + h->rs_D + 2) : (uint32_t)(h->J * M);
     const size_t S = (size_t)c.batch * c.channel_count;
-    const size_t max1 = c.max_chunk / M + 2, max2 = max1 * 24 / 25 + 2;
-    h->m1 = pow2ge(max1 + h->rs_Jp + 64) - 1;
-    h->m2 = pow2ge(max2 + h->filt_nt + 64) - 1;
+    const size_t max1 = c.max_chunk / M + 2, max2 = max1 * h->rs_I / h->rs_D + 2;
+    h->m1 = h->single ? 63 : pow2ge(max1 + h->rs_Jp + 64) - 1;   // the single-carrier chain reads the caller's IQ directly
+    h->m2 = pow2ge(max2 + h->filt_nt + 64 + 300) - 1;   // + one rssi_tag_block window
     if ((r = h->hist_a.alloc((size_t)c.batch * h->hist_len)) || (r = h->hist_b.alloc((size_t)c.batch * h->hist_len)) ||
         (r = h->r1.alloc(S * (h->m1 + 1))) || (r = h->r2.alloc(S * (h->m2 + 1))) || (r = h->r3.alloc(S * (h->m2 + 1))) ||
         (r = h->r4.alloc(S * (h->m2 + 1))))
@@ -122,7 +130,14 @@ int qrl_chan_reset(qrl_chan* h)
     return h->reset_state();
 }
 int qrl_chan_set_level(qrl_chan* h, float level) { if (!h) return QRL_ERR_ARG; h->level = level; return QRL_OK; }
-size_t qrl_chan_out_cap(const qrl_chan* h, size_t n) { return h ? (n / h->M + 2) * 24 / 25 + 2 : 0; }
+int qrl_chan_calibrate_rssi(qrl_chan* h, float level) { if (!h) return QRL_ERR_ARG; h->rssi_cal = level; return QRL_OK; }
+int qrl_chan_set_rssi_output(qrl_chan* h, float* rssi, size_t cap, uint32_t* counts)
+{
+    if (!h) return QRL_ERR_ARG;
+    h->rssi_out = rssi; h->rssi_cap = cap; h->rssi_counts = counts;
+    return QRL_OK;
+}
+size_t qrl_chan_out_cap(const qrl_chan* h, size_t n) { return h ? (n / h->M + 2) * h->rs_I / h->rs_D + 2 : 0; }
 
 int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts)
 {
@@ -136,26 +151,37 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
     const float2* hist_old = h->flip ? h->hist_b.p : h->hist_a.p;
     float2* hist_new = h->flip ? h->hist_a.p : h->hist_b.p;
     const uint64_t n1_1 = (h->n_in + n) / M;
+    if (h->rssi_out && h->rssi_counts) HIPCHK(hipMemsetAsync(h->rssi_counts, 0, (size_t)S * sizeof(uint32_t), h->stream));
     ChanParams p{};
     p.in = in; p.in_stride = stride; p.n0 = h->n_in; p.n = (uint32_t)n; p.hist = hist_old; p.hist_len = h->hist_len;
     p.out = RingC{h->r1.p, h->m1}; p.m0 = h->n1; p.m_count = (uint32_t)(n1_1 - h->n1);
     p.taps = h->taps.p; p.twiddle = h->twiddle.p; p.M = M; p.J = h->J; p.c_first = h->cfg.channel_first; p.c_count = CC;
-    launch_pfb_chan(p, B, h->stream);
+    if (!h->single) launch_pfb_chan(p, B, h->stream);
     HistParams hp{};
     hp.in = in; hp.in_stride = stride; hp.n0 = h->n_in; hp.n = (uint32_t)n;
     hp.hist_old = hist_old; hp.hist_new = hist_new; hp.hist_len = h->hist_len; hp.rot_enable = 0;
     launch_hist_save(hp, B, h->stream);
     h->flip = !h->flip;
     // per channel chain on S = batch * channel_count streams
-    const uint64_t n2_1 = n1_1 ? ((n1_1 - 1) * 24 + 23) / 25 + 1 : 0;
+    const uint64_t RI = (uint64_t)h->rs_I, RD = (uint64_t)h->rs_D;
+    const uint64_t n2_1 = n1_1 ? ((n1_1 - 1) * RI + (RI - 1)) / RD + 1 : 0;   // outputs q with q*D/I <= n1_1 - 1
     const uint32_t c2 = (uint32_t)(n2_1 - h->n2);
     ResampParams rp{};
-    rp.in = nullptr; rp.in_ring = RingC{h->r1.p, h->m1}; rp.n0 = h->n1; rp.n = (uint32_t)(n1_1 - h->n1);
-    rp.out = RingC{h->r2.p, h->m2}; rp.q0 = h->n2; rp.q_count = c2; rp.taps = h->rs_taps.p; rp.I = 24; rp.D = 25; rp.Jp = h->rs_Jp;
+    if (h->single) { rp.in = in; rp.in_stride = stride; rp.hist = hist_old; rp.hist_len = h->hist_len; rp.n0 = h->n_in; rp.n = (uint32_t)n; }
+    else { rp.in = nullptr; rp.in_ring = RingC{h->r1.p, h->m1}; rp.n0 = h->n1; rp.n = (uint32_t)(n1_1 - h->n1); }
+    rp.out = RingC{h->r2.p, h->m2}; rp.q0 = h->n2; rp.q_count = c2; rp.taps = h->rs_taps.p; rp.I = h->rs_I; rp.D = h->rs_D; rp.Jp = h->rs_Jp;
     launch_resamp(rp, S, h->stream);
+    auto rssi = [&](float2* ring) {   // rssi_tag_block: after the filter in multi2 (:126-127), after the resampler in gr_demod_mmdvm (:53-54)
+        if (!h->rssi_out) return;
+        RssiParams r{}; r.in = RingC{ring, h->m2}; r.j0 = h->n2 / 300; r.count = (uint32_t)(n2_1 / 300 - h->n2 / 300);
+        r.calibration = h->rssi_cal; r.out = h->rssi_out; r.cap = h->rssi_cap; r.counts = h->rssi_counts;
+        launch_rssi_tag(r, S, h->stream);
+    };
+    if (h->single) rssi(h->r2.p);
     FirCcfParams fp{};
     fp.in = RingC{h->r2.p, h->m2}; fp.out = RingC{h->r3.p, h->m2}; fp.q0 = h->n2; fp.count = c2; fp.taps = h->filt_taps.p; fp.nt = h->filt_nt;
     launch_fir_ccf(fp, S, h->stream);
+    if (!h->single) rssi(h->r3.p);
     QuadDemodParams qp{};
     qp.in = RingC{h->r3.p, h->m2}; qp.out = RingF{h->r4.p, h->m2}; qp.q0 = h->n2; qp.count = c2; qp.gain = h->gain; qp.atan_tab = h->atan_tab.p;
     launch_quad_demod(qp, S, h->stream);

@@ -132,6 +132,16 @@ struct FecParams {
 };
 void launch_fec(const FecParams& p, int batch, hipStream_t s);
 
+// ---- gr_deframer_bb on the device (kernels_deframe.hip) ----
+struct DeframeState { uint32_t reg, found, idx, pad; };
+struct DeframeParams {
+    const uint8_t* bits; size_t stride; uint32_t n;          // unpacked bits [batch][stride]; n valid per stream unless counts != NULL
+    const uint32_t* counts; size_t count_stride;             // device-side valid counts: counts[b * count_stride]
+    int type; uint32_t buf_len; DeframeState* st;
+    uint8_t* out; size_t out_cap; uint32_t* out_counts;
+};
+void launch_deframe(const DeframeParams& p, int batch, hipStream_t s);
+
 // ---- multi-carrier MMDVM RX (kernels_chan.hip) ----
 struct ChanParams {
     const float2* in; size_t in_stride; uint64_t n0; uint32_t n;   // wideband caller IQ of this call (n multiple of M)
@@ -141,6 +151,8 @@ struct ChanParams {
     int M, J, c_first, c_count;
 };
 struct F2sParams { RingF in; uint64_t q0; uint32_t count; float level, scale; int16_t* out; size_t cap; uint32_t* counts; };
+struct RssiParams { RingC in; uint64_t j0; uint32_t count; float calibration; float* out; size_t cap; uint32_t* counts; };
+void launch_rssi_tag(const RssiParams& p, int batch, hipStream_t s);
 void launch_pfb_chan(const ChanParams& p, int batch, hipStream_t s);
 void launch_f2s(const F2sParams& p, int batch, hipStream_t s);
 size_t chan_lds_bytes(int M, int J);

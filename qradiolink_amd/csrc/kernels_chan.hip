@@ -105,4 +105,31 @@ void launch_f2s(const F2sParams& p, int batch, hipStream_t s)
     hipLaunchKernelGGL(k_f2s, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
 }
 
+// rssi_tag_block::work (reference src/gr/rssi_tag_block.cpp:43-68): every 300 samples one RSSI tag,
+// 10 log10f(sqrtf(sum |x|^4 / 300) + 1e-20) + calibration, the sum being a serial float accumulation.  The 300-sample
+// blocks sit on an absolute grid, so one thread per (stream, block) reproduces the serial sum exactly.
+__global__ __launch_bounds__(64) void k_rssi_tag(const RssiParams P)
+{
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    if (t >= P.count) return;
+    const uint64_t j = P.j0 + t;                       // absolute tag index
+    const float2* ring = P.in.p + (size_t)b * (P.in.mask + 1u);
+    float sum = 0.0f;
+    for (int k = 0; k < 300; ++k) {
+        const float2 x = ring[(uint32_t)(j * 300u + k) & P.in.mask];
+        const float pwr = x.x * x.x + x.y * x.y;
+        sum += pwr * pwr;
+    }
+    const float level = sqrtf(sum / 300.0f);
+    const float db = 10.0f * log10f(level + 1.0e-20f) + P.calibration;
+    if (t < P.cap) P.out[(size_t)b * P.cap + t] = db;
+    if (t == 0 && P.counts) P.counts[b] = P.count < P.cap ? P.count : (uint32_t)P.cap;
+}
+void launch_rssi_tag(const RssiParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_rssi_tag, dim3((p.count + 63) / 64, batch), dim3(64), 0, s, p);
+}
+
 }  // namespace qrl

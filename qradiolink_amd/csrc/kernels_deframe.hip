@@ -1,0 +1,71 @@
+// kernels_deframe.hip — gr_deframer_bb on the device (reference src/gr/gr_deframer_bb.cpp:83-185).
+// One wave64 per stream.  While searching, the wave looks at 64 bit positions at once: a __ballot packs the 64 input
+// bits into one word, every lane rebuilds the shift register as it would stand after ITS position (carry-in register
+// shifted up, ballot word bit-reversed and shifted down), compares it with the sync words, and a second ballot picks
+// the first match -- the position the serial loop of the reference would have stopped at.  While a frame is open the
+// lanes copy its bits in parallel.  The register is cleared at the end of every frame exactly like the block does.
+#include "devmath.hpp"
+#include "engine.hpp"
+
+namespace qrl {
+
+__device__ __forceinline__ int deframer_find(int type, uint32_t reg, int& nbits)
+{
+    uint32_t temp = type != 2 ? (reg & 0xFFFFu) : (reg & 0xFFu);
+    nbits = type == 2 ? 8 : 16;
+    if (type == 2 && temp == 0xB5u) return (int)temp;
+    if (temp == 0x89EDu || temp == 0xED89u || temp == 0x98DEu || temp == 0xED77u || temp == 0x8CC8u) return (int)temp;
+    temp = reg & 0xFFFFFFu;
+    if (temp == 0x4C8A2Bu) { if (type != 2) nbits = 24; return (int)temp; }
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void k_deframe(const DeframeParams P)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const uint32_t n = P.counts ? P.counts[(size_t)b * P.count_stride] : P.n;
+    const uint8_t* in = P.bits + (size_t)b * P.stride;
+    uint8_t* out = P.out + (size_t)b * P.out_cap;
+    DeframeState st = P.st[b];
+    uint32_t i = 0, no = 0;
+    while (i < n) {
+        if (st.found) {
+            const uint32_t take = min(n - i, P.buf_len - st.idx);
+            for (uint32_t k = lane; k < take; k += 64)
+                if (no + k < P.out_cap) out[no + k] = in[i + k] & 1u;
+            no += take; i += take; st.idx += take;
+            if (st.idx >= P.buf_len) { st.found = 0; st.reg = 0; st.idx = 0; }
+        } else {
+            const uint32_t blk = min(64u, n - i);
+            const uint32_t bit = (uint32_t)lane < blk ? (in[i + lane] & 1u) : 0u;
+            const unsigned long long m = __ballot(bit != 0);
+            const uint32_t low = (uint32_t)(__brevll(m) >> (63 - lane));
+            const uint32_t reg_l = ((lane + 1 < 32) ? (st.reg << (lane + 1)) : 0u) | low;
+            int nb = 0;
+            const int ft = (uint32_t)lane < blk ? deframer_find(P.type, reg_l, nb) : 0;
+            const unsigned long long mm = __ballot(ft != 0);
+            if (mm) {
+                const int l0 = __ffsll((long long)mm) - 1;
+                const int ft0 = __shfl(ft, l0, 64), nb0 = __shfl(nb, l0, 64);
+                if (lane < nb0 && no + lane < P.out_cap) out[no + lane] = (uint8_t)((ft0 >> (nb0 - 1 - lane)) & 1);
+                no += (uint32_t)nb0;
+                st.found = 1; st.idx = 0; st.reg = __shfl(reg_l, l0, 64);
+                i += (uint32_t)l0 + 1u;
+            } else {
+                st.reg = __shfl(reg_l, (int)blk - 1, 64);
+                i += blk;
+            }
+        }
+    }
+    if (lane == 0) {
+        P.st[b] = st;
+        P.out_counts[b] = no < P.out_cap ? no : (uint32_t)P.out_cap;
+    }
+}
+
+void launch_deframe(const DeframeParams& p, int batch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_deframe, dim3(batch), dim3(64), 0, s, p);
+}
+
+}  // namespace qrl

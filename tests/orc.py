@@ -93,6 +93,7 @@ _sig("orc_demod_bpsk", None, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p)
 _sig("orc_mod_4fsk", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p)
 _sig("orc_mod_bpsk", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p)
 _sig("orc_clock_recovery_mm_cc", _sz, _p, _sz, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p)
+_sig("orc_deframer", _sz, C.c_int, _p, _sz, _p, _p)
 _sig("orc_rssi_tag", _sz, _p, _sz, C.c_float, _p)
 _sig("orc_demod_mmdvm", _sz, _p, _sz, C.c_int, C.c_int, _p, _sz, _p, C.c_float, _p)
 _sig("orc_demod_mmdvm_multi_rssi", _sz, _p, _sz, C.c_int, _p, _sz, _p, _sz, C.c_float)
@@ -294,6 +295,15 @@ def mod_4fsk(data, sps=25, samp_rate=1000000, carrier_freq=1700, filter_width=35
 
 def mod_bpsk(data, sps=500, samp_rate=1000000, carrier_freq=1700, filter_width=1500):
     return _mod(lib.orc_mod_bpsk, data, sps, samp_rate, carrier_freq, filter_width)
+
+
+def deframer(type_, bits, state=None):
+    """gr_deframer_bb over one call; state = np.uint32[3] carried between calls (None: fresh)"""
+    bits = np.ascontiguousarray(bits, np.uint8)
+    st = np.zeros(3, np.uint32) if state is None else state
+    out = np.zeros(2 * bits.size + 32, np.uint8)
+    n = lib.orc_deframer(type_, _ptr(bits), bits.size, _ptr(st), _ptr(out))
+    return out[:n].copy()
 
 
 def rssi_tag(x, cal=0.0):

@@ -71,3 +71,62 @@ def test_channel_range_sharding(qrl_ctx):
     ref = orc.demod_mmdvm_multi(iq[0], M)
     for c in range(32):
         assert np.array_equal(lo[0][c], ref[c]) and np.array_equal(hi[0][c], ref[32 + c])
+
+
+def _run_rssi(qrl_ctx, iq, M, chunk, cal=0.0):
+    """like _run, also collecting the rssi_tag_block values"""
+    import torch
+    import qradiolink_amd as q
+    ch = q.Channelizer(qrl_ctx, M, batch=iq.shape[0], max_chunk=chunk)
+    ch.calibrate_rssi(cal)
+    d = torch.from_numpy(iq).cuda()
+    B = iq.shape[0]
+    samples = [[[] for _ in range(ch.cc)] for _ in range(B)]
+    tags = [[[] for _ in range(ch.cc)] for _ in range(B)]
+    for s in range(0, iq.shape[1], chunk):
+        out, cnt = ch.process(d[:, s:s + chunk].contiguous())
+        cnt, o = cnt.cpu().numpy(), out.cpu().numpy()
+        rc, r = ch.rssi_counts.cpu().numpy(), ch.rssi.cpu().numpy()
+        for b in range(B):
+            for c in range(ch.cc):
+                samples[b][c].append(o[b, c, :cnt[b, c]].copy())
+                tags[b][c].append(r[b, c, :rc[b, c]].copy())
+    ch.close()
+    cat = lambda L: [[np.concatenate(x) for x in row] for row in L]
+    return cat(samples), cat(tags)
+
+
+@pytest.mark.parametrize("chunk", [10 * 6000, 10 * 777])
+def test_channelizer_rssi_tags(qrl_ctx, chunk):
+    """rssi_tag_block between filter and discriminator (gr_demod_mmdvm_multi2.cpp:126-127): same 300-sample serial sums as
+    the oracle; log10f differs from libm by a few ulp at most -> 1e-4 dB tolerance"""
+    M, n = 10, 10 * 6000
+    iq = _wideband(M, n, seed=11, nstreams=2)
+    got, tags = _run_rssi(qrl_ctx, iq, M, chunk, cal=-12.5)
+    for b in range(2):
+        ref, rref = orc.demod_mmdvm_multi_rssi(iq[b], M, cal=-12.5)
+        for c in range(M):
+            assert np.array_equal(got[b][c], ref[c])
+            assert tags[b][c].size == rref[c].size == ref.shape[1] // 300
+            assert np.allclose(tags[b][c], rref[c], rtol=0, atol=1e-4), (b, c)
+
+
+@pytest.mark.parametrize("chunk", [125000, 33333, 1250])
+def test_single_carrier_mmdvm_chain(qrl_ctx, chunk):
+    """gr_demod_mmdvm (num_channels = 1): 250 ksps -> 12/125 resampler -> rssi -> LPF -> discriminator -> int16, bit-exact and
+    chunk invariant"""
+    rng = np.random.default_rng(5)
+    n, fs = 125000, 250000.0
+    t = np.arange(n)
+    iq = []
+    for s in range(2):
+        dev, fm = rng.uniform(1000, 4000), rng.uniform(200, 1500)
+        ph = (dev / fm) * np.sin(2 * np.pi * fm * t / fs + rng.uniform(0, 6)) + 2 * np.pi * rng.uniform(-500, 500) * t / fs
+        iq.append((0.2 * np.exp(1j * ph) + 0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64))
+    iq = np.stack(iq)
+    got, tags = _run_rssi(qrl_ctx, iq, 1, chunk, cal=2.0)
+    for b in range(2):
+        ref, rref = orc.demod_mmdvm(iq[b], cal=2.0)
+        assert got[b][0].size == ref.size and np.array_equal(got[b][0], ref)
+        assert tags[b][0].size == rref.size and np.allclose(tags[b][0], rref, rtol=0, atol=1e-4)
+        assert np.abs(ref).max() > 1000

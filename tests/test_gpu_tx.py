@@ -241,7 +241,7 @@ def test_device_rate_tx_rx_loopback(qrl_ctx):
     import qradiolink_amd as q
     rng = np.random.default_rng(10)
     data, payloads = _frames(2, rng)
-    data = np.concatenate([data, np.full(64, 0xAA, np.uint8)])
+    data = np.concatenate([data, np.full(400, 0xAA, np.uint8)])   # flush back-end + front-end filters and the Viterbi frames
     mod = q.Mod(qrl_ctx, q.MODEM_QPSK250K, batch=1, max_bytes=data.size, device_samp_rate=4000000, carrier_offset_hz=25000.0)
     iq = mod.process(torch.from_numpy(data[None, :]).cuda())
     mod.close()

@@ -334,3 +334,21 @@ def test_mmdvm_single_carrier_chain():
     # quadrature_demod gain 24000 / (2 pi 10000): a constant +2.5 kHz offset reads 0.25 -> 0.25 * 32767
     assert abs(np.median(out[2000:]) - 0.25 * 32767) < 40
     assert rssi.size == out.size // 300 and np.allclose(rssi[5:], 20 * np.log10(0.2), atol=0.05)
+
+
+def test_deframer_oracle_frames_and_state_carry():
+    """gr_deframer_bb: sync bits + bit_buf_len frame bits; split calls give the same output as one call"""
+    rng = np.random.default_rng(3)
+    payload = rng.integers(0, 2, 32, dtype=np.uint8)
+    b5 = np.array([(0xB5 >> (7 - k)) & 1 for k in range(8)], np.uint8)
+    bits = np.concatenate([np.zeros(11, np.uint8), b5, payload, np.zeros(9, np.uint8), b5, payload[::-1], np.zeros(5, np.uint8)])
+    out = orc.deframer(2, bits)
+    assert np.array_equal(out, np.concatenate([b5, payload, b5, payload[::-1]]))
+    st = np.zeros(3, np.uint32)
+    parts = [orc.deframer(2, bits[a:b], st) for a, b in ((0, 15), (15, 16), (16, 60), (60, bits.size))]
+    assert np.array_equal(np.concatenate(parts), out)
+    # 24-bit word on a type-1 deframer: 24 sync bits + 64 frame bits
+    w = np.array([(0x4C8A2B >> (23 - k)) & 1 for k in range(24)], np.uint8)
+    fr = rng.integers(0, 2, 64, dtype=np.uint8)
+    out = orc.deframer(1, np.concatenate([np.ones(3, np.uint8), w, fr, np.ones(10, np.uint8)]))
+    assert np.array_equal(out[:24], w) and np.array_equal(out[24:88], fr)
