@@ -18,7 +18,7 @@ static void hchk(hipError_t e, const char* what)
 qrl_runtime::qrl_runtime(int device) { chk(qrl_init(device, &d_ctx), "qrl_init"); }
 qrl_runtime::~qrl_runtime() { qrl_shutdown(d_ctx); }
 
-enum { FAM_2FSK = 0, FAM_GMSK = 1, FAM_QPSK = 2 };
+enum { FAM_2FSK = 0, FAM_GMSK = 1, FAM_QPSK = 2, FAM_4FSK = 3, FAM_BPSK = 4, FAM_DMR = 5 };
 
 gr_demod_hip_sptr make_gr_demod_2fsk_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width, bool fm)
 { return gr_demod_hip_sptr(new gr_demod_hip(rt, FAM_2FSK, sps, samp_rate, carrier_freq, filter_width, fm)); }
@@ -27,11 +27,19 @@ gr_demod_hip_sptr make_gr_demod_gmsk_hip(qrl_runtime& rt, int sps, int samp_rate
 gr_demod_hip_sptr make_gr_demod_qpsk_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
 { return gr_demod_hip_sptr(new gr_demod_hip(rt, FAM_QPSK, sps, samp_rate, carrier_freq, filter_width, false)); }
 
+gr_demod_hip_sptr make_gr_demod_4fsk_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width, bool fm)
+{ return gr_demod_hip_sptr(new gr_demod_hip(rt, FAM_4FSK, sps, samp_rate, carrier_freq, filter_width, fm)); }
+gr_demod_hip_sptr make_gr_demod_bpsk_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
+{ return gr_demod_hip_sptr(new gr_demod_hip(rt, FAM_BPSK, sps, samp_rate, carrier_freq, filter_width, false)); }
+gr_demod_hip_sptr make_gr_demod_dmr_hip(qrl_runtime& rt, int sps, int samp_rate)
+{ return gr_demod_hip_sptr(new gr_demod_hip(rt, FAM_DMR, sps, samp_rate, 1700, 5000, false)); }
+
 gr_demod_hip::gr_demod_hip(qrl_runtime& rt, int fam, int sps, int samp_rate, int carrier_freq, int filter_width, bool fm)
     : gr::sync_block("gr_demod_hip", gr::io_signature::make(1, 1, sizeof(gr_complex)), gr::io_signature::make(0, 0, 0)), d_rt(rt)
 {
     // any member of the family selects the chain; the explicit factory arguments (not the mode table) configure it
-    d_cfg.modem_type = fam == FAM_2FSK ? QRL_MODEM_2FSK1K : (fam == FAM_GMSK ? QRL_MODEM_GMSK10K : QRL_MODEM_QPSK250K);
+    static const int rep[] = {QRL_MODEM_2FSK1K, QRL_MODEM_GMSK10K, QRL_MODEM_QPSK250K, QRL_MODEM_4FSK2KFM, QRL_MODEM_BPSK1K, QRL_MODEM_DMR};
+    d_cfg.modem_type = rep[fam];
     d_cfg.use_mode_defaults = 0;
     d_cfg.sps = sps; d_cfg.samp_rate = samp_rate; d_cfg.carrier_freq = carrier_freq; d_cfg.filter_width = filter_width; d_cfg.fm = fm;
     d_cfg.device_samp_rate = samp_rate; d_cfg.carrier_offset_hz = 0.0;
@@ -56,7 +64,21 @@ void gr_demod_hip::open()
 gr_demod_hip::~gr_demod_hip()
 {
     if (d_h) qrl_demod_destroy(d_h);
-    for (void* p : {(void*)d_iq, (void*)d_const, (void*)d_a, (void*)d_b, (void*)d_cnt}) if (p) (void)hipFree(p);
+    if (d_df1) qrl_deframer_destroy(d_df1);
+    if (d_df2) qrl_deframer_destroy(d_df2);
+    for (void* p : {(void*)d_iq, (void*)d_const, (void*)d_a, (void*)d_b, (void*)d_cnt, (void*)d_fa, (void*)d_fb, (void*)d_fcnt}) if (p) (void)hipFree(p);
+}
+void gr_demod_hip::attach_deframer(int type)
+{
+    if (d_df1) { qrl_deframer_destroy(d_df1); qrl_deframer_destroy(d_df2); d_df1 = d_df2 = nullptr; }
+    chk(qrl_deframer_create(d_rt.ctx(), type, 1, nullptr, &d_df1), "qrl_deframer_create");
+    chk(qrl_deframer_create(d_rt.ctx(), type, 1, nullptr, &d_df2), "qrl_deframer_create");
+    d_dfcap = 2 * d_bcap + 24;
+    for (void* p : {(void*)d_fa, (void*)d_fb, (void*)d_fcnt}) if (p) (void)hipFree(p);
+    hchk(hipMalloc(reinterpret_cast<void**>(&d_fa), d_dfcap), "hipMalloc");
+    hchk(hipMalloc(reinterpret_cast<void**>(&d_fb), d_dfcap), "hipMalloc");
+    hchk(hipMalloc(reinterpret_cast<void**>(&d_fcnt), 2 * sizeof(uint32_t)), "hipMalloc");
+    d_ha.resize(d_dfcap); d_hb.resize(d_dfcap);
 }
 void gr_demod_hip::set_device_samp_rate(int r) { d_cfg.device_samp_rate = r; open(); }
 void gr_demod_hip::set_carrier_offset(double hz) { d_cfg.carrier_offset_hz = hz; chk(qrl_demod_set_carrier_offset(d_h, hz), "qrl_demod_set_carrier_offset"); }
@@ -78,8 +100,20 @@ void gr_demod_hip::run(const gr_complex* x, size_t n)   // n even, <= kChunk
     chk(qrl_demod_sync(d_h), "qrl_demod_sync");
     uint32_t cnt[4];
     hchk(hipMemcpy(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost), "D2H");
-    if (cnt[2]) hchk(hipMemcpy(d_ha.data(), d_a, cnt[2], hipMemcpyDeviceToHost), "D2H");
-    if (cnt[3]) hchk(hipMemcpy(d_hb.data(), d_b, cnt[3], hipMemcpyDeviceToHost), "D2H");
+    if (d_df1) {   // ports 2 / 3 -> gr_deframer_bb on the device; the mailboxes then hold sync + frame bits
+        chk(qrl_deframer_process(d_df1, d_a, d_bcap, d_bcap, d_cnt + 2, 4, d_fa, d_dfcap, d_fcnt), "qrl_deframer_process");
+        chk(qrl_deframer_process(d_df2, d_b, d_bcap, d_bcap, d_cnt + 3, 4, d_fb, d_dfcap, d_fcnt + 1), "qrl_deframer_process");
+        chk(qrl_deframer_sync(d_df1), "qrl_deframer_sync");
+        chk(qrl_deframer_sync(d_df2), "qrl_deframer_sync");
+        uint32_t fc[2];
+        hchk(hipMemcpy(fc, d_fcnt, sizeof fc, hipMemcpyDeviceToHost), "D2H");
+        cnt[2] = fc[0]; cnt[3] = fc[1];
+        if (cnt[2]) hchk(hipMemcpy(d_ha.data(), d_fa, cnt[2], hipMemcpyDeviceToHost), "D2H");
+        if (cnt[3]) hchk(hipMemcpy(d_hb.data(), d_fb, cnt[3], hipMemcpyDeviceToHost), "D2H");
+    } else {
+        if (cnt[2]) hchk(hipMemcpy(d_ha.data(), d_a, cnt[2], hipMemcpyDeviceToHost), "D2H");
+        if (cnt[3]) hchk(hipMemcpy(d_hb.data(), d_b, cnt[3], hipMemcpyDeviceToHost), "D2H");
+    }
     if (cnt[1]) hchk(hipMemcpy(d_hc.data(), d_const, cnt[1] * sizeof(gr_complex), hipMemcpyDeviceToHost), "D2H");
     gr::thread::scoped_lock g(d_mutex);
     if (d_box1.size() <= 1048576) d_box1.insert(d_box1.end(), d_ha.begin(), d_ha.begin() + cnt[2]);   // drop rule of gr_bit_sink.cpp:71-76
@@ -108,7 +142,7 @@ std::vector<unsigned char>* gr_demod_hip::get_data(int nr)
 {
     gr::thread::scoped_lock g(d_mutex);
     std::vector<unsigned char>& box = nr == 1 ? d_box1 : d_box2;
-    if (box.size() < 32) return nullptr;                     // gr_bit_sink.cpp:48-52
+    if (box.size() < (d_df1 ? 1u : 32u)) return nullptr;     // gr_bit_sink.cpp:48-52 (>= 32 bits); gr_deframer_bb::get_data: anything
     std::vector<unsigned char>* v = new std::vector<unsigned char>(box);
     box.clear();
     return v;
@@ -122,18 +156,31 @@ std::vector<gr_complex>* gr_demod_hip::get_constellation_data()
     return v;
 }
 
-gr_mod_hip_sptr make_gr_mod_qpsk_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
-{ return gr_mod_hip_sptr(new gr_mod_hip(rt, sps, samp_rate, carrier_freq, filter_width)); }
-
-gr_mod_hip::gr_mod_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
-    : gr::sync_interpolator("gr_mod_hip", gr::io_signature::make(1, 1, sizeof(unsigned char)),
-                            gr::io_signature::make(1, 1, sizeof(gr_complex)), 8u * (unsigned)sps)
+static gr_mod_hip_sptr make_mod(qrl_runtime& rt, int modem, int sps, int samp_rate, int carrier_freq, int filter_width, bool fm)
 {
     qrl_mod_config c{};
-    c.modem_type = QRL_MODEM_QPSK250K; c.use_mode_defaults = 0;
-    c.sps = sps; c.samp_rate = samp_rate; c.carrier_freq = carrier_freq; c.filter_width = filter_width;
-    c.batch = 1; c.max_bytes = kMaxBytes; c.bb_gain = 1.0f;
-    chk(qrl_mod_create(rt.ctx(), &c, &d_h), "qrl_mod_create");
+    c.modem_type = modem; c.use_mode_defaults = 0;   // any member of the family selects the chain, the arguments configure it
+    c.sps = sps; c.samp_rate = samp_rate; c.carrier_freq = carrier_freq; c.filter_width = filter_width; c.fm = fm;
+    c.batch = 1; c.max_bytes = 8192; c.bb_gain = 1.0f;
+    qrl_mod* h = nullptr;
+    chk(qrl_mod_create(rt.ctx(), &c, &h), "qrl_mod_create");
+    return gr_mod_hip_sptr(new gr_mod_hip(h));
+}
+gr_mod_hip_sptr make_gr_mod_qpsk_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
+{ return make_mod(rt, QRL_MODEM_QPSK250K, sps, samp_rate, carrier_freq, filter_width, false); }
+gr_mod_hip_sptr make_gr_mod_2fsk_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width, bool fm)
+{ return make_mod(rt, QRL_MODEM_2FSK1K, sps, samp_rate, carrier_freq, filter_width, fm); }
+gr_mod_hip_sptr make_gr_mod_gmsk_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
+{ return make_mod(rt, QRL_MODEM_GMSK10K, sps, samp_rate, carrier_freq, filter_width, false); }
+gr_mod_hip_sptr make_gr_mod_4fsk_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width, bool fm)
+{ return make_mod(rt, QRL_MODEM_4FSK2KFM, sps, samp_rate, carrier_freq, filter_width, fm); }
+gr_mod_hip_sptr make_gr_mod_bpsk_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
+{ return make_mod(rt, QRL_MODEM_BPSK1K, sps, samp_rate, carrier_freq, filter_width, false); }
+
+gr_mod_hip::gr_mod_hip(qrl_mod* handle)
+    : gr::sync_interpolator("gr_mod_hip", gr::io_signature::make(1, 1, sizeof(unsigned char)),
+                            gr::io_signature::make(1, 1, sizeof(gr_complex)), (unsigned)qrl_mod_samples_per_byte(handle)), d_h(handle)
+{
     hchk(hipMalloc(reinterpret_cast<void**>(&d_bytes), kMaxBytes), "hipMalloc");
     hchk(hipMalloc(reinterpret_cast<void**>(&d_iq), kMaxBytes * qrl_mod_samples_per_byte(d_h) * sizeof(gr_complex)), "hipMalloc");
 }

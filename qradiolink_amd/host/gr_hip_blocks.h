@@ -32,6 +32,15 @@ gr_demod_hip_sptr make_gr_demod_gmsk_hip(qrl_runtime& rt, int sps = 125, int sam
 gr_demod_hip_sptr make_gr_demod_qpsk_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 250000, int carrier_freq = 1700,
                                          int filter_width = 8000);
 
+// replaces make_gr_demod_4fsk(sps, samp_rate, carrier_freq, filter_width, fm)   src/gr/gr_demod_4fsk.cpp:19-27 (FM variants)
+gr_demod_hip_sptr make_gr_demod_4fsk_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 250000, int carrier_freq = 1700,
+                                         int filter_width = 8000, bool fm = true);
+// replaces make_gr_demod_bpsk(sps, samp_rate, carrier_freq, filter_width)        src/gr/gr_demod_bpsk.cpp:19-27
+gr_demod_hip_sptr make_gr_demod_bpsk_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 250000, int carrier_freq = 1700,
+                                         int filter_width = 8000);
+// replaces make_gr_demod_dmr(sps, samp_rate)                                      src/gr/gr_demod_dmr.cpp:19-27 (port 2 = dibits)
+gr_demod_hip_sptr make_gr_demod_dmr_hip(qrl_runtime& rt, int sps = 5, int samp_rate = 1000000);
+
 class gr_demod_hip : public gr::sync_block {
 public:
     gr_demod_hip(qrl_runtime& rt, int modem_family, int sps, int samp_rate, int carrier_freq, int filter_width, bool fm);
@@ -45,12 +54,16 @@ public:
     std::vector<unsigned char>* get_data(int nr);          // port 2 (nr = 1) / port 3 (nr = 2); caller deletes
     std::vector<gr_complex>* get_constellation_data();     // port 1; caller deletes
     void flush();                                          // qrl_demod_reset + drop mailboxes
+    // gr_demod_base connects ports 2/3 of the 1k/2k/10k modes to gr_deframer_bb(2 | 1 | 3) (src/gr/gr_demod_base.cpp:171-178,
+    // 577-603): with a deframer attached get_data(nr) hands out what gr_deframer_bb::get_data would (sync bits + frame bits)
+    void attach_deframer(int deframer_type);
 private:
     void open();
     void run(const gr_complex* x, size_t n);
     qrl_runtime& d_rt;
     qrl_demod_config d_cfg{};
     qrl_demod* d_h = nullptr;
+    qrl_deframer *d_df1 = nullptr, *d_df2 = nullptr; uint8_t *d_fa = nullptr, *d_fb = nullptr; uint32_t* d_fcnt = nullptr; size_t d_dfcap = 0;
     size_t d_fcap = 0, d_ccap = 0, d_bcap = 0;
     std::vector<gr_complex> d_carry;                        // at most one sample: the ABI takes even counts
     std::vector<gr_complex> d_buf;
@@ -65,9 +78,19 @@ typedef std::shared_ptr<gr_mod_hip> gr_mod_hip_sptr;
 // replaces make_gr_mod_qpsk(sps, samp_rate, carrier_freq, filter_width)          src/gr/gr_mod_qpsk.cpp:19-30
 gr_mod_hip_sptr make_gr_mod_qpsk_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 250000, int carrier_freq = 1700,
                                      int filter_width = 8000);
-class gr_mod_hip : public gr::sync_interpolator {   // u8 packed bytes in -> cf32 out, 8*sps samples per byte
+// replaces make_gr_mod_2fsk / make_gr_mod_gmsk / make_gr_mod_4fsk / make_gr_mod_bpsk (src/gr/gr_mod_2fsk.cpp:19-28,
+// gr_mod_gmsk.cpp:19-28, gr_mod_4fsk.cpp:19-28, gr_mod_bpsk.cpp:19-27); same argument lists
+gr_mod_hip_sptr make_gr_mod_2fsk_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 250000, int carrier_freq = 1700,
+                                     int filter_width = 8000, bool fm = false);
+gr_mod_hip_sptr make_gr_mod_gmsk_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 250000, int carrier_freq = 1700,
+                                     int filter_width = 8000);
+gr_mod_hip_sptr make_gr_mod_4fsk_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 250000, int carrier_freq = 1700,
+                                     int filter_width = 8000, bool fm = true);
+gr_mod_hip_sptr make_gr_mod_bpsk_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 250000, int carrier_freq = 1700,
+                                     int filter_width = 8000);
+class gr_mod_hip : public gr::sync_interpolator {   // u8 packed bytes in -> cf32 out, qrl_mod_samples_per_byte samples per byte
 public:
-    gr_mod_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width);
+    gr_mod_hip(qrl_mod* handle);                    // takes ownership of a handle made by one of the factories
     ~gr_mod_hip() override;
     void set_bb_gain(float value);                  // gr_mod_qpsk::set_bb_gain
     int work(int noutput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) override;

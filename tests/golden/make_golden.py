@@ -25,6 +25,9 @@ CASES = [
     ("gmsk10k_1M", "gmsk10k", 1000000, 0.0, ("gmsk", dict(sps=1, filter_width=20000))),
     ("gmsk10k_8M", "gmsk10k", 8000000, 25000.0, ("gmsk", dict(sps=1, filter_width=20000))),   # front end 8:1 = f32-MFMA decimator
     ("qpsk250k_1M", "qpsk250k", 1000000, 0.0, ("qpsk", dict(sps=2, filter_width=160000))),
+    ("4fsk2kfm_1M", "4fsk2kfm", 1000000, 0.0, ("4fsk", dict(sps=5, filter_width=3000, fm=True))),
+    ("4fsk100k_1M", "4fsk100k", 1000000, 0.0, ("4fsk", dict(sps=2, filter_width=125000, fm=True))),
+    ("bpsk2k_1M", "bpsk2k", 1000000, 0.0, ("bpsk", dict(sps=5))),
 ]
 
 
@@ -35,7 +38,8 @@ def quantise(x):
 
 def run_oracle(kind, kw, x, rate, offset):
     fe = orc.frontend(x, rate, offset)
-    return {"2fsk": orc.demod_2fsk, "gmsk": orc.demod_gmsk, "qpsk": orc.demod_qpsk}[kind](fe, **kw)
+    return {"2fsk": orc.demod_2fsk, "gmsk": orc.demod_gmsk, "qpsk": orc.demod_qpsk, "4fsk": orc.demod_4fsk,
+            "bpsk": orc.demod_bpsk}[kind](fe, **kw)
 
 
 def digest(a):
@@ -43,9 +47,14 @@ def digest(a):
 
 
 def main():
+    only = set(sys.argv[1:])   # optional: names of the fixtures to (re)generate; default = all
     for name, mode, rate, offset, (kind, kw) in CASES:
-        nframes = 1 if rate > 1000000 else (3 if mode.startswith("2fsk") else 2)
+        if only and name not in only:
+            continue
+        nframes = 1 if rate > 1000000 else (3 if mode.startswith("2fsk") else 4 if mode.startswith("bpsk") else 2)
         y, payloads = sig.make_stream(mode, nframes=nframes, device_rate=rate, rx_offset_hz=offset, seed=77, amp=0.25)
+        if mode.startswith(("4fsk", "bpsk")):
+            y = np.concatenate([y, np.zeros(20000, np.complex64)])   # flush the long RRC filters / Viterbi frames
         y = quantise(y[: y.size & ~1])
         r = run_oracle(kind, kw, y, rate, offset)
         np.savez_compressed(

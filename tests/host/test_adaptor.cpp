@@ -1,7 +1,8 @@
 // Drives the GNU Radio-shaped adaptor blocks the way the scheduler would: work() with arbitrary item counts.
 //   test_adaptor nodevice                      -> expects std::runtime_error from construction (exit 0 if thrown)
-//   test_adaptor rx <family> <sps> <fw> <fm> <device_rate> <offset> <iq.bin> <bits_a.bin> <bits_b.bin>
-//   test_adaptor tx <bytes.bin> <iq.bin>
+//   test_adaptor rx <family>[+d<type>] <sps> <fw> <fm> <device_rate> <offset> <iq.bin> <bits_a.bin> <bits_b.bin>
+//                (family 2fsk | gmsk | qpsk | 4fsk | bpsk | dmr; "+d2" attaches gr_deframer_bb(2) to ports 2/3)
+//   test_adaptor tx <bytes.bin> <iq.bin> [family sps fw fm]
 #include "gr_hip_blocks.h"
 #include <cstdio>
 #include <cstdlib>
@@ -31,11 +32,18 @@ int main(int argc, char** argv)
         }
         qrl_runtime rt(0);
         if (!strcmp(argv[1], "rx") && argc == 11) {
-            const std::string fam = argv[2];
+            std::string fam = argv[2];
+            int deframer = 0;
+            const size_t plus = fam.find("+d");
+            if (plus != std::string::npos) { deframer = atoi(fam.c_str() + plus + 2); fam = fam.substr(0, plus); }
             const int sps = atoi(argv[3]), fw = atoi(argv[4]), fm = atoi(argv[5]), rate = atoi(argv[6]);
             gr_demod_hip_sptr d = fam == "2fsk" ? make_gr_demod_2fsk_hip(rt, sps, 1000000, 1700, fw, fm != 0)
                                 : fam == "gmsk" ? make_gr_demod_gmsk_hip(rt, sps, 1000000, 1700, fw)
+                                : fam == "4fsk" ? make_gr_demod_4fsk_hip(rt, sps, 1000000, 1700, fw, fm != 0)
+                                : fam == "bpsk" ? make_gr_demod_bpsk_hip(rt, sps, 1000000, 1700, fw)
+                                : fam == "dmr"  ? make_gr_demod_dmr_hip(rt, sps, 1000000)
                                                 : make_gr_demod_qpsk_hip(rt, sps, 1000000, 1700, fw);
+            if (deframer) d->attach_deframer(deframer);
             if (rate != 1000000) d->set_device_samp_rate(rate);
             d->set_carrier_offset(atof(argv[7]));
             std::vector<char> raw = slurp(argv[8]);
@@ -58,17 +66,24 @@ int main(int argc, char** argv)
             std::printf("rx ok: %zu samples -> %zu / %zu bits\n", n, a.size(), b.size());
             return 0;
         }
-        if (!strcmp(argv[1], "tx") && argc == 4) {
-            gr_mod_hip_sptr m = make_gr_mod_qpsk_hip(rt, 4, 1000000, 1700, 160000);
+        if (!strcmp(argv[1], "tx") && (argc == 4 || argc == 8)) {
+            const std::string fam = argc == 8 ? argv[4] : "qpsk";
+            const int sps = argc == 8 ? atoi(argv[5]) : 4, fw = argc == 8 ? atoi(argv[6]) : 160000, fm = argc == 8 ? atoi(argv[7]) : 0;
+            gr_mod_hip_sptr m = fam == "2fsk" ? make_gr_mod_2fsk_hip(rt, sps, 1000000, 1700, fw, fm != 0)
+                              : fam == "gmsk" ? make_gr_mod_gmsk_hip(rt, sps, 1000000, 1700, fw)
+                              : fam == "4fsk" ? make_gr_mod_4fsk_hip(rt, sps, 1000000, 1700, fw, fm != 0)
+                              : fam == "bpsk" ? make_gr_mod_bpsk_hip(rt, sps, 1000000, 1700, fw)
+                                              : make_gr_mod_qpsk_hip(rt, sps, 1000000, 1700, fw);
+            const size_t I = m->interpolation();
             std::vector<char> raw = slurp(argv[2]);
-            std::vector<gr_complex> out(raw.size() * 32);
+            std::vector<gr_complex> out(raw.size() * I);
             size_t pos = 0; unsigned k = 0;
             static const int nb[] = {1, 100, 9000, 17, 2048};
             while (pos < raw.size()) {
                 const size_t take = std::min<size_t>(raw.size() - pos, (size_t)nb[k++ % 5]);
                 gr_vector_const_void_star ins(1, raw.data() + pos);
-                gr_vector_void_star outs(1, out.data() + pos * 32);
-                if (m->work((int)(take * 32), ins, outs) != (int)(take * 32)) return 3;
+                gr_vector_void_star outs(1, out.data() + pos * I);
+                if (m->work((int)(take * I), ins, outs) != (int)(take * I)) return 3;
                 pos += take;
             }
             dump(argv[3], out.data(), out.size() * sizeof(gr_complex));

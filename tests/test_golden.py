@@ -14,8 +14,16 @@ import sig
 HERE = os.path.dirname(os.path.abspath(__file__))
 FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
 ORACLE = {"2fsk1k": ("2fsk", dict(sps=10, filter_width=2000, fm=False)), "2fsk1kfm": ("2fsk", dict(sps=10, filter_width=2500, fm=True)),
-          "gmsk10k": ("gmsk", dict(sps=1, filter_width=20000)), "qpsk250k": ("qpsk", dict(sps=2, filter_width=160000))}
-MODEM = {"2fsk1k": 18, "2fsk1kfm": 16, "gmsk10k": 22, "qpsk250k": 26}
+          "gmsk10k": ("gmsk", dict(sps=1, filter_width=20000)), "qpsk250k": ("qpsk", dict(sps=2, filter_width=160000)),
+          "4fsk2kfm": ("4fsk", dict(sps=5, filter_width=3000, fm=True)), "4fsk100k": ("4fsk", dict(sps=2, filter_width=125000, fm=True)),
+          "bpsk2k": ("bpsk", dict(sps=5))}
+MODEM = {"2fsk1k": 18, "2fsk1kfm": 16, "gmsk10k": 22, "qpsk250k": 26, "4fsk2kfm": 5, "4fsk100k": 27, "bpsk2k": 0}
+DEMOD = {"2fsk": orc.demod_2fsk, "gmsk": orc.demod_gmsk, "qpsk": orc.demod_qpsk, "4fsk": orc.demod_4fsk, "bpsk": orc.demod_bpsk}
+# sync word, frame bits, frames that may be lost to acquisition (BPSK: agc2 + FLL + Costas settle during the first frame)
+FRAMING = {"gmsk10k": (bytes([0xED, 0x89]), 384, 0), "qpsk250k": (bytes([0xDE, 0x98, 0xAA]), 1516 * 8, 0),
+           "4fsk2kfm": (bytes([0xED, 0x89, 0xAA]), 56, 0), "4fsk100k": (bytes([0xDE, 0x98, 0xAA]), 1516 * 8, 0),
+           "bpsk2k": (bytes([0xED, 0x89, 0xAA]), 56, 1)}
+SINGLE_BRANCH = ("qpsk250k", "4fsk2kfm", "4fsk100k")
 
 
 def _load(path):
@@ -31,7 +39,7 @@ def _sha(a):
 
 
 def test_fixtures_exist():
-    assert len(FILES) >= 5
+    assert len(FILES) >= 8
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
@@ -40,18 +48,19 @@ def test_oracle_reproduces_golden(path):
     mode = os.path.basename(path).split("_")[0]
     kind, kw = ORACLE[mode]
     fe = orc.frontend(iq, int(z["rate"]), float(z["offset"]))
-    r = {"2fsk": orc.demod_2fsk, "gmsk": orc.demod_gmsk, "qpsk": orc.demod_qpsk}[kind](fe, **kw)
+    r = DEMOD[kind](fe, **kw)
     assert np.array_equal(r["bits_a"], bits_a) and np.array_equal(r["bits_b"], bits_b)
     assert _sha(r["filtered"]) == str(z["filtered_sha256"]) and _sha(r["constellation"]) == str(z["constellation_sha256"])
     # the frames that were transmitted are in the decoded bits (gr_modem::findSync-style search)
     plen = int(z["payload_len"])
     payloads = [bytes(z["payloads"][i:i + plen]) for i in range(0, z["payloads"].size, plen)]
-    sync, nbits = {"gmsk10k": (bytes([0xED, 0x89]), 384), "qpsk250k": (bytes([0xDE, 0x98, 0xAA]), 1516 * 8)}.get(mode, (bytes([0xB5]), 32))
+    sync, nbits, may_lose = FRAMING.get(mode, (bytes([0xB5]), 32, 0))
     found = 0
     for bits in (bits_a, bits_b):
-        fr = sig.find_frames(bits, sync, nbits)
-        found = max(found, sum(((bytes([0xAA]) + p) if mode == "gmsk10k" else p) in fr for p in payloads))
-    assert found == len(payloads)
+        for inv in ((0, 1) if mode.startswith("bpsk") else (0,)):   # BPSK: 180 degree ambiguity, the code is inversion transparent
+            fr = sig.find_frames(bits ^ inv, sync, nbits)
+            found = max(found, sum(((bytes([0xAA]) + p) if mode == "gmsk10k" else p) in fr for p in payloads))
+    assert found >= len(payloads) - may_lose
 
 
 @pytest.mark.gpu
@@ -68,7 +77,7 @@ def test_hip_reproduces_golden(qrl_ctx, path, chunk):
     dem.close()
     for b in range(2):
         assert np.array_equal(out["bits_a"][b], bits_a)
-        if mode != "qpsk250k":
+        if mode not in SINGLE_BRANCH:
             assert np.array_equal(out["bits_b"][b], bits_b)
         assert _sha(out["filtered"][b].astype(np.complex64)) == str(z["filtered_sha256"])
         assert _sha(out["constellation"][b].astype(np.complex64)) == str(z["constellation_sha256"])

@@ -30,7 +30,8 @@ def test_adaptor_builds_and_fails_loudly_without_device():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,fam,sps,fw,fm", [("gmsk10k_1M", "gmsk", 1, 20000, 0), ("gmsk10k_8M", "gmsk", 1, 20000, 0),
-                                                ("2fsk1k_1M", "2fsk", 10, 2000, 0), ("qpsk250k_1M", "qpsk", 2, 160000, 0)])
+                                                ("2fsk1k_1M", "2fsk", 10, 2000, 0), ("qpsk250k_1M", "qpsk", 2, 160000, 0),
+                                                ("4fsk2kfm_1M", "4fsk", 5, 3000, 1), ("bpsk2k_1M", "bpsk", 5, 2400, 0)])
 def test_rx_block_matches_golden(tmp_path, name, fam, sps, fw, fm):
     z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
     iq = z["iq_f16"].astype(np.float32)
@@ -43,7 +44,7 @@ def test_rx_block_matches_golden(tmp_path, name, fam, sps, fw, fm):
     want_a = np.unpackbits(z["bits_a"])[: int(z["n_bits_a"])]
     # the mailbox hands bits out in >= 32-bit batches (gr_bit_sink.cpp:48-52): a short tail may still be inside
     assert a.size >= want_a.size - 31 and np.array_equal(a, want_a[: a.size])
-    if fam != "qpsk":
+    if fam not in ("qpsk", "4fsk"):
         b = np.fromfile(tmp_path / "b.bin", np.uint8)
         want_b = np.unpackbits(z["bits_b"])[: int(z["n_bits_b"])]
         assert b.size >= want_b.size - 31 and np.array_equal(b, want_b[: b.size])
@@ -58,3 +59,40 @@ def test_tx_block_matches_oracle(tmp_path):
     got = np.fromfile(tmp_path / "iq.bin", np.complex64)
     ref = orc.mod_qpsk(data)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_rx_block_with_deframer_mailbox(tmp_path):
+    """attach_deframer(2): get_data(nr) hands out what gr_deframer_bb::get_data would for the 2FSK-1k mode
+    (gr_demod_base.cpp:601-602): 0xB5 + 32 frame bits per frame, identical to the oracle deframer on the golden bits"""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "2fsk1k_1M.npz"))
+    (tmp_path / "iq.bin").write_bytes(z["iq_f16"].astype(np.float32).tobytes())
+    r = subprocess.run([EXE, "rx", "2fsk+d2", "10", "2000", "0", "1000000", "0.0",
+                        str(tmp_path / "iq.bin"), str(tmp_path / "a.bin"), str(tmp_path / "b.bin")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    total = 0
+    for f, key, nk in (("a.bin", "bits_a", "n_bits_a"), ("b.bin", "bits_b", "n_bits_b")):
+        got = np.fromfile(tmp_path / f, np.uint8)
+        want = orc.deframer(2, np.unpackbits(z[key])[: int(z[nk])])
+        assert np.array_equal(got, want)
+        total += want.size
+    assert total >= 3 * 40
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fam,sps,fw,fm,oracle", [
+    ("2fsk", 50, 2000, 0, lambda d: orc.mod_2fsk(d, sps=50, filter_width=2000, fm=False)),
+    ("gmsk", 10, 20000, 0, lambda d: orc.mod_gmsk(d, sps=10, filter_width=20000)),
+    ("4fsk", 25, 3500, 1, lambda d: orc.mod_4fsk(d, sps=25, filter_width=3500, fm=True)),
+    ("bpsk", 250, 2800, 0, lambda d: orc.mod_bpsk(d, sps=250, filter_width=2800)),
+])
+def test_tx_block_families_match_oracle(tmp_path, fam, sps, fw, fm, oracle):
+    data = np.random.default_rng(4).integers(0, 256, 300, dtype=np.uint8)
+    (tmp_path / "bytes.bin").write_bytes(data.tobytes())
+    r = subprocess.run([EXE, "tx", str(tmp_path / "bytes.bin"), str(tmp_path / "iq.bin"), fam, str(sps), str(fw), str(fm)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(tmp_path / "iq.bin", np.complex64)
+    ref = oracle(data)
+    assert got.size == ref.size and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
