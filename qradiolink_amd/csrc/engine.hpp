@@ -27,6 +27,7 @@ struct DecimParams {
     // MFMA variant (kernels_decim_mfma.hip): banded-Toeplitz A operands [S steps][64 lanes], S steps of 4
     const float* gtab; int S; int nt; uint32_t magic_blk, magic_seg;   // gtab: zero-padded taps, hp[k + 4S - nt + 1] = h[k]
     uint32_t tpw, nchunks; int nhi; int dbg;               // consecutive tiles per workgroup; rotator coarse-table entries
+    int nld;                                                // 16-byte loads per thread a tile needs (<= the kernel's NLD)
 };
 struct HistParams {
     const float2* in; size_t in_stride; uint64_t n0; uint32_t n;

@@ -98,10 +98,13 @@ __device__ __forceinline__ void tile_issue(const DecimParams& P, int b, const Ti
     const uint64_t sbase = ((uint64_t)bhi << 32) | blo;
     const int q0k = (int)((w.i_base - w.a - (int64_t)P.n0) >> 1) + w.k_lo + tid;   // pair index of this thread's first load
     const int qmax = (int)(P.n >> 1) - 1;
+    const int nld = __builtin_amdgcn_readfirstlane(P.nld);
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
-        const uint32_t voff = (uint32_t)min(max(q0k + NTH * it, 0), qmax) << 4;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(v[it]) : "v"(voff), "s"(sbase) : "memory");
+        if (it < nld) {   // uniform: the tile needs nld <= NLD loads per thread
+            const uint32_t voff = (uint32_t)min(max(q0k + NTH * it, 0), qmax) << 4;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(v[it]) : "v"(voff), "s"(sbase) : "memory");
+        }
     }
 }
 template <int NLD>
@@ -123,6 +126,37 @@ __device__ __forceinline__ void tile_commit(const DecimParams& P, int b, const T
             tile[j + 2 * (int)__umulhi((uint32_t)j, magic)] = mf_fetch(P, b, w.i_base + j, t_hi, kb0, t_lo);
     }
     if (!FAST) return;
+    // Interior tiles (all of them except the first / last of a stream): every pair of the tile comes from the caller's
+    // buffer, pairs are aligned to the tile (a = 0) and to the rotator tables (even krel).  Then a thread's two samples
+    // are LDS neighbours (the 2-sample pads sit at even positions), its fine-table factors are one 16-byte LDS read, its
+    // coarse factors are t_hi[h0 + it] -- fetched up front so no LDS latency sits inside the loop -- and pairs past the
+    // end of the tile simply land in the 512-sample slack behind it: no predication, one ds_write_b128 per pair.
+    if constexpr (NTH == 256 && NLD <= 16) {
+        const uint64_t kbase = (uint64_t)w.i_base - P.rot_nbase - ((uint64_t)kb0 << 9);
+        const int nld = __builtin_amdgcn_readfirstlane(P.nld);
+        if (w.a == 0 && w.k_lo == 0 && w.k_hi == (Jtot >> 1) && !(kbase & 1u) && P.rot_enable && nld <= NLD) {
+            const int j0 = 2 * tid;
+            const uint32_t krel0 = (uint32_t)kbase + (uint32_t)j0;
+            const float4 lo01 = *reinterpret_cast<const float4*>(t_lo + (krel0 & 511u));
+            const float2 lo0 = make_float2(lo01.x, lo01.y), lo1 = make_float2(lo01.z, lo01.w);
+            const float2* hp0 = t_hi + (krel0 >> 9);
+            float2 hi[NLD];
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) hi[it] = hp0[it];
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) {
+                if (it < nld) {
+                    const int j = j0 + 512 * it;
+                    float2 x0 = make_float2(v[it].x, v[it].y), x1 = make_float2(v[it].z, v[it].w);
+                    x0 = cmul_fma(x0, cmul_fma(hi[it], lo0));
+                    x1 = cmul_fma(x1, cmul_fma(hi[it], lo1));
+                    const int p0 = j + 2 * (int)__umulhi((uint32_t)j, magic);
+                    *reinterpret_cast<float4*>(tile + p0) = make_float4(x0.x, x0.y, x1.x, x1.y);
+                }
+            }
+            return;
+        }
+    }
     // register-prefetched pairs: STRAIGHT-LINE code (no exec branches, so hipcc batches the LDS reads);
     // pairs past the end of the window are written to a per-thread dump slot behind the tile
     const int j0 = 2 * (w.k_lo + tid) - w.a;
@@ -495,7 +529,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int hpn = (15 * D + 4 * S + 4 + 3) & ~3;
     const int nhi = (P.nhi + 1) & ~1;
     const int dump = Jtot + 2 * (Jtot / blk) + 4;
-    const int tile_len = (dump + 512 + 1) & ~1;
+    const int tile_len = (dump + 512 + 16 + 1) & ~1;
     float2* t_lo = reinterpret_cast<float2*>(smem);            // 512
     float2* t_hi_all = t_lo + 512;                             // [team][buf][nhi]
     float* hp = reinterpret_cast<float*>(t_hi_all + 4 * nhi);  // hpn floats
@@ -616,7 +650,7 @@ static int mfma_nhi(int nt, int D, int NA, int) { return (int)(mfma_jtot(nt, D, 
 static size_t mfma_lds(int nt, int D, int NA, int tpw)
 {
     const long long Jtot = mfma_jtot(nt, D, NA);
-    const long long npos = Jtot + 2 * (Jtot / (16LL * D)) + 4 + 512;   // + dump slots
+    const long long npos = Jtot + 2 * (Jtot / (16LL * D)) + 4 + 512 + 16;   // + dump slots (+ pad slack of the unpredicated commit)
     return (size_t)(512 + ((mfma_nhi(nt, D, NA, tpw) + 1) & ~1) + npos) * sizeof(float2) + (size_t)decim_mfma_hpn(nt, D) * sizeof(float);
 }
 // rule shared with oracle/orc_blocks.c orc_decim_uses_m16
@@ -637,6 +671,11 @@ int decim_mfma_na(int nt, int D)
 }
 size_t decim_mfma_lds_bytes(int nt, int D) { return mfma_lds(nt, D, decim_mfma_na(nt, D), kTpwMax); }
 
+static bool w8_threads(bool fast, int nld)
+{
+    const char* w8 = std::getenv("QRL_DECIM_W8");
+    return w8 && w8[0] == '1' && fast && nld <= 16;
+}
 template <int NA, int NLD, bool FAST, int WPE = 2, int NTH = 256>
 static void launch_k(const DecimParams& q, dim3 grid, size_t lds, hipStream_t s)
 {
@@ -657,7 +696,7 @@ static size_t mfma2_lds(int nt, int D, int NA)
 {
     const long long Jtot = mfma_jtot(nt, D, NA);
     const long long dump = Jtot + 2 * (Jtot / (16LL * D)) + 4;
-    const long long tile_len = (dump + 512 + 1) & ~1LL;
+    const long long tile_len = (dump + 512 + 16 + 1) & ~1LL;
     const long long nhi = (mfma_nhi(nt, D, NA, 1) + 1) & ~1;
     return (size_t)(512 + 4 * nhi + 2 * 4 * 16 * NA + 2 * tile_len) * sizeof(float2) + (size_t)decim_mfma_hpn(nt, D) * sizeof(float);
 }
@@ -711,6 +750,7 @@ void launch_decim_mfma(const DecimParams& p, int batch, hipStream_t s)
     const long long pairs = (mfma_jtot(p.nt, p.D, NA) + 2) / 2;
     const int nld = (int)((pairs + 255) / 256);
     const bool fast = q.in && q.n >= 2 && q.n < (1u << 28);
+    q.nld = (int)((pairs + (w8_threads(fast, nld) ? 511 : 255)) / (w8_threads(fast, nld) ? 512 : 256));
     const char* w8 = std::getenv("QRL_DECIM_W8");   // 8 waves per workgroup (4 per SIMD with two workgroups per CU)
     const bool wide = w8 && w8[0] == '1' && fast && nld <= 16;
     if (NA == 16) {
