@@ -311,6 +311,9 @@ __device__ __forceinline__ void mfma_piece(const float* __restrict__ ap, const B
 // Compiler-scheduled variant of the same ping-pong (plain LDS reads, sched_barrier pinned).  It is the DEFAULT:
 // the asm variant above is ~5 % faster but showed rare (1e-4 per tile) wrong outputs with two workgroups per
 // CU at 25 Msps that could not be explained; build with -DQRL_MF_ASM_LDS=1 to select it for experiments.
+#ifndef QRL_MF_VOLATILE_LDS
+#define QRL_MF_VOLATILE_LDS 1
+#endif
 #ifndef QRL_MF_ASM_LDS
 #define QRL_MF_ASM_LDS 0
 #endif
@@ -320,7 +323,25 @@ struct MfChunk {
     __device__ __forceinline__ void load(const float* ap, const BT* bp, int i)
     {
 #pragma unroll
-        for (int u = 0; u < MF_U; ++u) { a[u] = ap[-4 * (i + u)]; b[u] = bp[BS * (i + u)]; }
+        for (int u = 0; u < MF_U; ++u) {
+#if QRL_MF_VOLATILE_LDS
+            // volatile LDS-address-space reads: hipcc must not fuse neighbours into ds_read2_b32 / ds_read2_b64, which the
+            // LDS serves at half rate (MI355X_MICROARCH.md, LDS table).  The compiler still owns the waitcnt bookkeeping
+            // (unlike the asm variant above).  Measured: front end 2.10 -> 2.02 ms (C2), 9.65 -> 9.49 ms (C1).
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            typedef const volatile __attribute__((address_space(3))) float* lds_vf;
+            typedef const volatile __attribute__((address_space(3))) f32x2_t* lds_vf2;
+            a[u] = *(lds_vf)(lds_cptr)(ap - 4 * (i + u));
+            if constexpr (sizeof(BT) == 8) {
+                const f32x2_t t = *(lds_vf2)(lds_cptr)(bp + BS * (i + u));
+                b[u] = BT{t.x, t.y};
+            } else {
+                b[u] = *(lds_vf)(lds_cptr)(bp + BS * (i + u));
+            }
+#else
+            a[u] = ap[-4 * (i + u)]; b[u] = bp[BS * (i + u)];
+#endif
+        }
     }
 };
 __device__ __forceinline__ void mf_fma(const MfChunk<float2, 4>& c, f32x4& acc0, f32x4& acc1)
