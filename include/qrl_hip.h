@@ -184,6 +184,13 @@ int qrl_chan_calibrate_rssi(qrl_chan* c, float level);
  * 24 ksps.  rssi[(b*channel_count + ch)*cap + k], k < counts[b*channel_count + ch], holds the tags completed by each
  * following qrl_chan_process call (device pointers; NULL switches the block off). */
 int qrl_chan_set_rssi_output(qrl_chan* c, float* rssi, size_t cap, uint32_t* counts);
+/* optional 4FSK symbol tail behind every produced channel (BASELINE config 4: channelizer + 4FSK demod): the chain of
+ * gr_demod_dmr after its resampler (src/gr/gr_demod_dmr.cpp:62-105: quadrature_demod_cf(24000/(pi/2*4800)) ->
+ * fft_filter_fff(RRC(1, 24k, 4.8k, 0.2, 125)) -> symbol_sync_ff(M&M, 5 sps, 4-level) -> x0.9 -> phase_modulator -> slicer ->
+ * map{3,1,2,0}) applied to the 24 ksps channel signal (after _filter[i], gr_demod_mmdvm_multi2.cpp:62-63,75).
+ * bits[s*bits_cap + k]: two bits per symbol; constellation (cf32, may be NULL); counts[s*4 + 1] = symbols, [s*4 + 2] = bits
+ * produced by each following qrl_chan_process call, s = b*channel_count + ch.  bits == NULL switches the tail off. */
+int qrl_chan_set_4fsk_output(qrl_chan* c, uint8_t* bits, size_t bits_cap, float* constellation, size_t constellation_cap, uint32_t* counts);
 size_t qrl_chan_out_cap(const qrl_chan* c, size_t n);   /* int16 samples per channel a call with n inputs can produce */
 /* replaces one scheduler pass of the multi-carrier graph: iq[b*stride + i] device cf32, n a multiple of num_channels;
  * out[(b*channel_count + c)*out_cap + k] device int16 @24 ksps, counts[b*channel_count + c] = samples written. */

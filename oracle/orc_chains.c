@@ -688,6 +688,13 @@ size_t orc_demod_mmdvm_multi(const cf32* in, size_t n, int M, int16_t* out, size
 /* same + the rssi_tag_block between filter and discriminator (gr_demod_mmdvm_multi2.cpp:96,126-127): rssi[c*rcap + k] */
 size_t orc_demod_mmdvm_multi_rssi(const cf32* in, size_t n, int M, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal)
 {
+    return orc_demod_mmdvm_multi_4fsk(in, n, M, out, cap, rssi, rcap, cal, NULL, 0, NULL);
+}
+/* same + the 4FSK symbol tail of gr_demod_dmr (gr_demod_dmr.cpp:62-105) on every channel's filtered 24 ksps signal:
+ * dibits[c*dcap + k] (two bits per symbol), ndib[c] = bits produced */
+size_t orc_demod_mmdvm_multi_4fsk(const cf32* in, size_t n, int M, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal,
+                                  uint8_t* dibits, size_t dcap, size_t* ndib)
+{
     int nt = orc_chan_proto_taps(M, NULL);
     float* taps = NEW(float, nt);
     orc_chan_proto_taps(M, taps);
@@ -713,6 +720,23 @@ size_t orc_demod_mmdvm_multi_rssi(const cf32* in, size_t n, int M, int16_t* out,
             size_t nr = orc_rssi_tag(b, n2, cal, tmp);
             for (size_t k = 0; k < nr && k < rcap; k++) rssi[(size_t)c * rcap + k] = tmp[k];
             free(tmp);
+        }
+        if (dibits) {
+            float* fd = NEW(float, n2 + 1);
+            orc_quad_demod(b, n2, (float)(24000 / (M_PI / 2 * 4800.0f)), fd);
+            int nrr = orc_root_raised_cosine(1, 24000, 4800, 0.2, 125, NULL);
+            float* rrc = NEW(float, nrr);
+            orc_root_raised_cosine(1, 24000, 4800, 0.2, 125, rrc);
+            float* ff = NEW(float, n2 + 1);
+            orc_fir_fff(fd, n2, rrc, nrr, ff);
+            float* sym = NEW(float, n2 / 4 + 16);
+            size_t nsym = orc_symbol_sync_ff(ff, n2, ORC_TED_MM, 5.0f, (float)(2 * M_PI / 100.0f), 1.0f, 0.2869f, 0.06f, ORC_CONST_4LEVEL, sym);
+            uint8_t* bits = NEW(uint8_t, 2 * nsym + 2);
+            orc_4fsk_symbols_to_bits(sym, nsym, NULL, bits);
+            size_t nb = 2 * nsym < dcap ? 2 * nsym : dcap;
+            memcpy(dibits + (size_t)c * dcap, bits, nb);
+            ndib[c] = nb;
+            free(fd); free(rrc); free(ff); free(sym); free(bits);
         }
         orc_quad_demod(b, n2, gain, d);
         for (size_t i = 0; i < m; i++) out[(size_t)c * cap + i] = f2s(d[i] * 1.0f, 32767.0f);

@@ -100,6 +100,7 @@ def load_library():
     lib.qrl_chan_set_level.argtypes = [vp, C.c_float]
     lib.qrl_chan_calibrate_rssi.argtypes = [vp, C.c_float]
     lib.qrl_chan_set_rssi_output.argtypes = [vp, vp, sz, vp]
+    lib.qrl_chan_set_4fsk_output.argtypes = [vp, vp, sz, vp, sz, vp]
     lib.qrl_chan_out_cap.restype = sz
     lib.qrl_chan_out_cap.argtypes = [vp, sz]
     lib.qrl_chan_process.argtypes = [vp, vp, sz, sz, vp, sz, vp]
@@ -127,7 +128,7 @@ EXPORTED_SYMBOLS = [
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
     "qrl_mod_samples_per_byte", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_create",
-    "qrl_chan_destroy", "qrl_chan_reset", "qrl_chan_set_level", "qrl_chan_calibrate_rssi", "qrl_chan_set_rssi_output", "qrl_chan_out_cap", "qrl_chan_process", "qrl_chan_sync",
+    "qrl_chan_destroy", "qrl_chan_reset", "qrl_chan_set_level", "qrl_chan_calibrate_rssi", "qrl_chan_set_rssi_output", "qrl_chan_set_4fsk_output", "qrl_chan_out_cap", "qrl_chan_process", "qrl_chan_sync",
     "qrl_deframer_create", "qrl_deframer_destroy", "qrl_deframer_reset", "qrl_deframer_process", "qrl_deframer_sync",
     "qrl_firdes_low_pass",
     "qrl_firdes_low_pass_2", "qrl_firdes_complex_band_pass", "qrl_firdes_root_raised_cosine", "qrl_table_mmse",
@@ -298,6 +299,17 @@ class Channelizer:
         self.rssi_counts = torch.zeros((batch, self.cc), dtype=torch.int32, device=dev)
         _check(self.lib.qrl_chan_set_rssi_output(self.h, self.rssi.data_ptr(), self.rssi_cap, self.rssi_counts.data_ptr()),
                "qrl_chan_set_rssi_output")
+
+    def enable_4fsk(self):
+        """4FSK symbol tail (gr_demod_dmr chain) behind every channel: self.dibits uint8 [batch, cc, cap], self.fsk_counts [batch, cc, 4]"""
+        t = self.torch
+        dev = self.out.device
+        self.fsk_cap = 2 * (self.cap // 4 + 16)
+        self.dibits = t.zeros((self.batch, self.cc, self.fsk_cap), dtype=t.uint8, device=dev)
+        self.fsk_const = t.zeros((self.batch, self.cc, self.fsk_cap // 2), dtype=t.complex64, device=dev)
+        self.fsk_counts = t.zeros((self.batch, self.cc, 4), dtype=t.int32, device=dev)
+        _check(self.lib.qrl_chan_set_4fsk_output(self.h, self.dibits.data_ptr(), self.fsk_cap, self.fsk_const.data_ptr(), self.fsk_cap // 2,
+                                                 self.fsk_counts.data_ptr()), "qrl_chan_set_4fsk_output")
 
     def calibrate_rssi(self, level):
         _check(self.lib.qrl_chan_calibrate_rssi(self.h, float(level)), "qrl_chan_calibrate_rssi")

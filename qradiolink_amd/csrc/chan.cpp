@@ -7,6 +7,7 @@
 #include "firdes.hpp"
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <cstring>
 #include <memory>
 #include <new>
 #include <string>
@@ -51,6 +52,14 @@ struct qrl_chan {
     float gain = 0, level = 1.0f, rssi_cal = 0.0f;
     bool single = false; int rs_I = 24, rs_D = 25;   // single: gr_demod_mmdvm (one carrier at 250 ksps, 12/125 resampler, no channelizer)
     float* rssi_out = nullptr; size_t rssi_cap = 0; uint32_t* rssi_counts = nullptr;
+    // optional 4FSK symbol tail behind every channel (gr_demod_dmr.cpp:62-105 on the 24 ksps channel signal)
+    Buf<float> r5, r6, symf_taps, mmse; Buf<SymSyncState> ss; Buf<uint8_t> soft_dummy; int symf_nt = 0; float ss_alpha = 0, ss_beta = 0;
+    uint8_t* fsk_bits = nullptr; size_t fsk_bits_cap = 0; float* fsk_const = nullptr; size_t fsk_const_cap = 0; uint32_t* fsk_counts = nullptr;
+    int init_ss() {
+        std::vector<SymSyncState> s((size_t)cfg.batch * cfg.channel_count);
+        for (auto& x : s) { std::memset(&x, 0, sizeof x); x.avg = x.inst = 5.0f; }
+        return hipMemcpy(ss.p, s.data(), s.size() * sizeof(SymSyncState), hipMemcpyHostToDevice) == hipSuccess ? QRL_OK : QRL_ERR_HIP;
+    }
     size_t zeroed = 0;
     ~qrl_chan() { if (own_stream && stream) (void)hipStreamDestroy(stream); }
     int reset_state() {
@@ -62,6 +71,10 @@ struct qrl_chan {
         if (hipMemset(r3.p, 0, S * (m2 + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
         if (hipMemset(r4.p, 0, S * (m2 + 1) * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
         n_in = n1 = n2 = 0; flip = false;
+        if (ss.p) {
+            if (hipMemset(r5.p, 0, S * (m2 + 1) * sizeof(float)) != hipSuccess || hipMemset(r6.p, 0, S * (m2 + 1) * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
+            return init_ss();
+        }
         return QRL_OK;
     }
 };
@@ -137,6 +150,26 @@ int qrl_chan_set_rssi_output(qrl_chan* h, float* rssi, size_t cap, uint32_t* cou
     h->rssi_out = rssi; h->rssi_cap = cap; h->rssi_counts = counts;
     return QRL_OK;
 }
+int qrl_chan_set_4fsk_output(qrl_chan* h, uint8_t* bits, size_t bits_cap, float* constellation, size_t constellation_cap, uint32_t* counts)
+{
+    if (!h) return QRL_ERR_ARG;
+    if (bits && !counts) return qrl_set_error(QRL_ERR_ARG, "4fsk output needs a counts array [streams][4]");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    if (bits && !h->ss.p) {   // first use: rings, tables and loop state of the symbol tail
+        const size_t S = (size_t)h->cfg.batch * h->cfg.channel_count;
+        int r;
+        const std::vector<float> rrc = root_raised_cosine(1, 24000, 4800, 0.2, 25 * 5);      // gr_demod_dmr.cpp:62-66
+        h->symf_nt = (int)rrc.size();
+        if ((r = h->symf_taps.upload(rrc)) || (r = h->mmse.upload(mmse_table())) || (r = h->r5.alloc(S * (h->m2 + 1))) ||
+            (r = h->r6.alloc(S * (h->m2 + 1))) || (r = h->ss.alloc(S)) || (r = h->soft_dummy.alloc(64)))
+            return qrl_set_error(r, "4fsk tail buffers");
+        clock_loop_gains((float)(2 * M_PI / 100.0f), 1.0f, 0.2869f, h->ss_alpha, h->ss_beta);  // :70-71
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if ((r = h->init_ss())) return r;
+    }
+    h->fsk_bits = bits; h->fsk_bits_cap = bits_cap; h->fsk_const = constellation; h->fsk_const_cap = constellation_cap; h->fsk_counts = counts;
+    return QRL_OK;
+}
 size_t qrl_chan_out_cap(const qrl_chan* h, size_t n) { return h ? (n / h->M + 2) * h->rs_I / h->rs_D + 2 : 0; }
 
 int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts)
@@ -185,6 +218,22 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
     QuadDemodParams qp{};
     qp.in = RingC{h->r3.p, h->m2}; qp.out = RingF{h->r4.p, h->m2}; qp.q0 = h->n2; qp.count = c2; qp.gain = h->gain; qp.atan_tab = h->atan_tab.p;
     launch_quad_demod(qp, S, h->stream);
+    if (h->fsk_bits) {   // gr_demod_dmr.cpp:72-105 behind the channel filter: discriminator (24000 / (pi/2 * 4800)) -> RRC -> symbol_sync_ff -> dibits
+        HIPCHK(hipMemsetAsync(h->fsk_counts, 0, (size_t)S * 4 * sizeof(uint32_t), h->stream));
+        QuadDemodParams q5{};
+        q5.in = RingC{h->r3.p, h->m2}; q5.out = RingF{h->r5.p, h->m2}; q5.q0 = h->n2; q5.count = c2;
+        q5.gain = (float)(24000 / (M_PI / 2 * (float)(24000 / 5))); q5.atan_tab = h->atan_tab.p;
+        launch_quad_demod(q5, S, h->stream);
+        FirFffParams f6{}; f6.in = q5.out; f6.out = RingF{h->r6.p, h->m2}; f6.q0 = h->n2; f6.count = c2; f6.taps = h->symf_taps.p; f6.nt = h->symf_nt;
+        launch_fir_fff(f6, S, h->stream);
+        SymSyncParams s{};
+        s.in = f6.out; s.avail = n2_1; s.soft = RingB{h->soft_dummy.p, 63}; s.st = h->ss.p; s.mmse = h->mmse.p;
+        s.alpha = h->ss_alpha; s.beta = h->ss_beta; s.maxp = 5.0f + 0.06f; s.minp = 5.0f - 0.06f;
+        s.ted = 0; s.soft_mul = 128.0f; s.soft_add = 128.0f; s.slicer = 1; s.tail = 1;
+        s.bits = h->fsk_bits; s.bits_cap = h->fsk_bits_cap;
+        s.port = reinterpret_cast<float2*>(h->fsk_const); s.port_cap = h->fsk_const ? h->fsk_const_cap : 0; s.counts = h->fsk_counts;
+        launch_symsync_ff(s, S, h->stream);
+    }
     F2sParams sp{};
     sp.in = RingF{h->r4.p, h->m2}; sp.q0 = h->n2; sp.count = c2; sp.level = h->level; sp.scale = 32767.0f;
     sp.out = out; sp.cap = out_cap; sp.counts = counts;

@@ -97,6 +97,7 @@ _sig("orc_deframer", _sz, C.c_int, _p, _sz, _p, _p)
 _sig("orc_rssi_tag", _sz, _p, _sz, C.c_float, _p)
 _sig("orc_demod_mmdvm", _sz, _p, _sz, C.c_int, C.c_int, _p, _sz, _p, C.c_float, _p)
 _sig("orc_demod_mmdvm_multi_rssi", _sz, _p, _sz, C.c_int, _p, _sz, _p, _sz, C.c_float)
+_sig("orc_demod_mmdvm_multi_4fsk", _sz, _p, _sz, C.c_int, _p, _sz, _p, _sz, C.c_float, _p, _sz, _p)
 _sig("orc_batch_rx", C.c_double, C.c_int, _p, C.c_int, _sz, C.c_int, C.c_double, C.c_int, _p)
 
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECT, WIN_BH = 0, 1, 2, 3, 5
@@ -331,6 +332,18 @@ def demod_mmdvm_multi_rssi(x, M, cal=0.0):
     rssi = np.zeros((M, rcap), np.float32)
     n = lib.orc_demod_mmdvm_multi_rssi(_ptr(x), x.size, M, _ptr(out), cap, _ptr(rssi), rcap, cal)
     return out[:, :n].copy(), rssi[:, :n // 300].copy()
+
+
+def demod_mmdvm_multi_4fsk(x, M):
+    """channelizer + per-channel FM int16 + per-channel 4FSK dibits (list of uint8 arrays)"""
+    x = np.ascontiguousarray(x, cf32)
+    cap = (x.size // M) * 24 // 25 + 4
+    out = np.zeros((M, cap), np.int16)
+    dcap = 2 * (cap // 4 + 16)
+    dib = np.zeros((M, dcap), np.uint8)
+    nd = np.zeros(M, np.uint64)
+    n = lib.orc_demod_mmdvm_multi_4fsk(_ptr(x), x.size, M, _ptr(out), cap, None, 0, 0.0, _ptr(dib), dcap, _ptr(nd))
+    return out[:, :n].copy(), [dib[c, :int(nd[c])].copy() for c in range(M)]
 
 
 def tx_interp(x, samp_rate):

@@ -81,13 +81,13 @@ def find_frames(bits, sync, nbits):
     return out
 
 
-def make_4fsk(nsym=400, seed=1, amp=0.3, noise=0.002, cfo=0.0):
+def make_4fsk(nsym=400, seed=1, amp=0.3, noise=0.002, cfo=0.0, fs=1000000.0):
     """DMR-like 4FSK at 4800 sym/s on 1 Msps IQ (RRC alpha 0.2, deviation +-1944 / +-648 Hz; dibit map of the DMR air
     interface: 01 -> +3, 00 -> +1, 10 -> -1, 11 -> -3).  Returns (iq complex64, dibits)."""
     rng = np.random.default_rng(seed)
     dib = rng.integers(0, 4, nsym)
     lev = np.array([+1, +3, -1, -3])[dib] / 3.0
-    sps = 1000000 / 4800.0
+    sps = fs / 4800.0
     n = int(nsym * sps) & ~1
     up = np.zeros(n)
     up[(np.arange(nsym) * sps).astype(int)] = lev
@@ -99,6 +99,6 @@ def make_4fsk(nsym=400, seed=1, amp=0.3, noise=0.002, cfo=0.0):
     h[np.isnan(h)] = 1 - a + 4 * a / np.pi
     h[np.isinf(h)] = 0
     f = np.convolve(up, h, mode="same")
-    ph = 2 * np.pi * np.cumsum(f * 1944.0 + cfo) / 1e6
+    ph = 2 * np.pi * np.cumsum(f * 1944.0 + cfo) / fs
     x = amp * np.exp(1j * ph) + noise * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
     return x.astype(np.complex64), dib

@@ -130,3 +130,50 @@ def test_single_carrier_mmdvm_chain(qrl_ctx, chunk):
         assert got[b][0].size == ref.size and np.array_equal(got[b][0], ref)
         assert tags[b][0].size == rref.size and np.allclose(tags[b][0], rref, rtol=0, atol=1e-4)
         assert np.abs(ref).max() > 1000
+
+
+def _run_4fsk(qrl_ctx, iq, M, chunk):
+    import torch
+    import qradiolink_amd as q
+    ch = q.Channelizer(qrl_ctx, M, batch=iq.shape[0], max_chunk=chunk)
+    ch.enable_4fsk()
+    d = torch.from_numpy(iq).cuda()
+    B = iq.shape[0]
+    dib = [[[] for _ in range(ch.cc)] for _ in range(B)]
+    for s in range(0, iq.shape[1], chunk):
+        ch.process(d[:, s:s + chunk].contiguous())
+        cnt, bits = ch.fsk_counts.cpu().numpy(), ch.dibits.cpu().numpy()
+        for b in range(B):
+            for c in range(ch.cc):
+                dib[b][c].append(bits[b, c, :cnt[b, c, 2]].copy())
+    ch.close()
+    return [[np.concatenate(x) for x in row] for row in dib]
+
+
+@pytest.mark.parametrize("chunk", [10 * 6000, 10 * 1250])
+def test_channelizer_4fsk_tail_bit_exact(qrl_ctx, chunk):
+    """BASELINE config 4: channelizer + per-channel 4FSK symbol demodulator (gr_demod_dmr chain behind the channel filter)"""
+    import sig
+    M, n = 10, 10 * 6000
+    fs = 25000.0 * M
+    iq = _wideband(M, n, seed=21, nstreams=2)
+    # plant true 4FSK carriers (4800 sym/s) on channels 2 and 8 of stream 0
+    t = np.arange(n)
+    dibs = {}
+    for c, seed in ((2, 5), (8, 6)):
+        x, d = sig.make_4fsk(nsym=int(n / fs * 4800) - 2, seed=seed, amp=0.4, noise=0.0, fs=fs)
+        f0 = c * 25000.0 if c <= M // 2 else (c - M) * 25000.0
+        m = min(n, x.size)
+        iq[0, :m] += (x[:m] * np.exp(2j * np.pi * f0 * t[:m] / fs)).astype(np.complex64)
+        dibs[c] = d
+    got = _run_4fsk(qrl_ctx, iq, M, chunk)
+    for b in range(2):
+        _, ref = orc.demod_mmdvm_multi_4fsk(iq[b], M)
+        for c in range(M):
+            assert got[b][c].size == ref[c].size and np.array_equal(got[b][c], ref[c]), (b, c)
+    # known answer: the planted dibits come back (map of gr_demod_dmr.cpp:81-86 = the DMR air-interface dibits)
+    for c, d in dibs.items():
+        g = got[0][c].reshape(-1, 2)
+        g = g[:, 0] * 2 + g[:, 1]
+        best = max(np.mean(g[k:k + 800] == d[:800]) for k in range(60))
+        assert best > 0.99, (c, best)

@@ -352,3 +352,17 @@ def test_deframer_oracle_frames_and_state_carry():
     fr = rng.integers(0, 2, 64, dtype=np.uint8)
     out = orc.deframer(1, np.concatenate([np.ones(3, np.uint8), w, fr, np.ones(10, np.uint8)]))
     assert np.array_equal(out[:24], w) and np.array_equal(out[24:88], fr)
+
+
+def test_channelizer_plus_4fsk_tail_recovers_dibits():
+    """BASELINE config 4 on the oracle: a 4FSK carrier planted on channel 2 of a 10 x 25 kHz band comes back as its dibits"""
+    M, n, fs = 10, 60000, 250000.0
+    rng = np.random.default_rng(1)
+    iq = (0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    x, d = sig.make_4fsk(nsym=int(n / fs * 4800) - 2, seed=5, amp=0.4, noise=0.0, fs=fs)
+    m = min(n, x.size)
+    iq[:m] += (x[:m] * np.exp(2j * np.pi * 2 * 25000 * np.arange(m) / fs)).astype(np.complex64)
+    out, dib = orc.demod_mmdvm_multi_4fsk(iq, M)
+    g = dib[2].reshape(-1, 2)
+    g = g[:, 0] * 2 + g[:, 1]
+    assert max(np.mean(g[k:k + 800] == d[:800]) for k in range(60)) > 0.99
