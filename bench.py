@@ -30,6 +30,9 @@ WORKLOADS = {
            "gmsk10k", 22, 25000000, 25000.0, 96, 25 * (1 << 18), 1),
     "c1": ("C1: 2FSK-1k RX chain (rotator + gr_demod_2fsk) on 1 Msps IQ",
            "2fsk1k", 18, 1000000, 1200.0, 16384, 1 << 18, 0),
+    # not part of the default line (parity-test configs measured on request: --config c3 / c4)
+    "c3": ("C3: QPSK-250k RX chain (gr_demod_base front end 100:1 + gr_demod_qpsk) on 100 Msps IQ",
+           "qpsk250k", 26, 100000000, 25000.0, 384, 100 * (1 << 14), 2),
 }
 
 
@@ -37,7 +40,7 @@ def synth(mode, device_rate, offset, batch, nsamp, seed, torch, dev):
     """Synthetic batch, built once (untimed): one oracle-modulated stream, then per-stream circular
     shift + CFO + AWGN applied on the GPU (torch is plumbing here, not the product)."""
     import sig
-    nframes = {"gmsk10k": 6, "2fsk1k": 6}[mode]
+    nframes = {"gmsk10k": 6, "2fsk1k": 6, "qpsk250k": 4}[mode]
     base, _ = sig.make_stream(mode, nframes=nframes, device_rate=device_rate, rx_offset_hz=offset, seed=seed, amp=0.05)
     reps = -(-nsamp // base.size)
     base = np.tile(base, reps)[:nsamp]
@@ -99,6 +102,33 @@ def run_workload(name, args, torch, q, ctx, dev, rank, world):
                 achieved_gbps=ach, bits_per_stream=int(counts[:, 2].mean()), bytes_per_launch=bytes_per_launch)
 
 
+def run_c4(args, torch, q, ctx, dev, world):
+    """C4: multi-carrier MMDVM receiver, 64 x 25 kHz channels from 1.6 Msps wideband IQ (PFB channelizer + per-channel
+    24/25 resampler, LPF, FM discriminator -> int16, RSSI tags and the 4FSK symbol tail).  Reported on request only."""
+    M, B, n = 64, args.batch or 64, (args.nsamp or (1 << 21)) // 64 * 64
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    iq = torch.view_as_complex(torch.randn((B, n, 2), generator=g, device=dev, dtype=torch.float32) * 0.05)
+    ch = q.Channelizer(ctx, M, batch=B, max_chunk=n)
+    ch.enable_4fsk()
+    for _ in range(args.warmup):
+        ch.process_async(iq)
+    ch.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ch.process_async(iq)
+    ch.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ch.close()
+    return {"metric": "wideband IQ MSamples/sec through the C4 receiver", "value": round(B * n * args.steps * world / dt / 1e6, 1), "unit": "MS/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C4: 64 x 25 kHz MMDVM channels from 1.6 Msps IQ: PFB channelizer + FM int16 + RSSI + 4FSK tail",
+                       "wideband_streams_per_gpu": B, "samples_per_stream_per_step": n}}
+
+
 def cpu_baseline(name, threads, budget_s=12.0):
     """Oracle (CPU restatement of the reference flowgraph) on a bounded sample of the same workload:
     `threads` independent streams (OpenMP over streams, one stream per core), repeated until ~budget_s seconds
@@ -126,7 +156,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS) + ["c4"])
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--nsamp", type=int, default=0)
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workload and the CPU baseline")
@@ -147,10 +177,18 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=dev)
     ctx = q.Context(local)
 
+    if args.config == "c4":
+        line = run_c4(args, torch, q, ctx, dev, world)
+        if rank == 0:
+            print(json.dumps(line))
+        ctx.close()
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     main_r = run_workload(args.config, args, torch, q, ctx, dev, rank, world)
     extra = None
     base = None
-    if not args.no_extra:
+    if not args.no_extra and args.config in ("c1", "c2"):
         other = "c1" if args.config == "c2" else "c2"
         extra = run_workload(other, args, torch, q, ctx, dev, rank, world)
         if rank == 0:

@@ -688,15 +688,11 @@ int decim_mfma_na(int nt, int D)
 {
     if (const char* e = std::getenv("QRL_DECIM_NA")) { const int v = std::atoi(e); if (v == 4 || v == 8 || v == 16) return v; }   // experiments
     if (mfma_lds(nt, D, 16, kTpwMax) <= 80 * 1024) return 16;    // two (or more) workgroups per CU with the efficient tile
-    return 8;   // (4-block tiles with three workgroups per CU were measured slower: QRL_DECIM_NA=4 keeps them reachable)
+    if (mfma_lds(nt, D, 8, kTpwMax) <= 160 * 1024) return 8;   // (4-block tiles with three workgroups per CU were measured slower)
+    return 4;   // very long filters (100:1 front end, 4181 taps): only the 4-block tile fits the 160 KB of a CU
 }
 size_t decim_mfma_lds_bytes(int nt, int D) { return mfma_lds(nt, D, decim_mfma_na(nt, D), kTpwMax); }
 
-static bool w8_threads(bool fast, int nld)
-{
-    const char* w8 = std::getenv("QRL_DECIM_W8");
-    return w8 && w8[0] == '1' && fast && nld <= 16;
-}
 template <int NA, int NLD, bool FAST, int WPE = 2, int NTH = 256>
 static void launch_k(const DecimParams& q, dim3 grid, size_t lds, hipStream_t s)
 {
@@ -771,20 +767,32 @@ void launch_decim_mfma(const DecimParams& p, int batch, hipStream_t s)
     const long long pairs = (mfma_jtot(p.nt, p.D, NA) + 2) / 2;
     const int nld = (int)((pairs + 255) / 256);
     const bool fast = q.in && q.n >= 2 && q.n < (1u << 28);
-    q.nld = (int)((pairs + (w8_threads(fast, nld) ? 511 : 255)) / (w8_threads(fast, nld) ? 512 : 256));
     const char* w8 = std::getenv("QRL_DECIM_W8");   // 8 waves per workgroup (4 per SIMD with two workgroups per CU)
     const bool wide = w8 && w8[0] == '1' && fast && nld <= 16;
+    // More than 16 loads per thread (front ends beyond ~40:1): a 36-load variant would need 144 prefetch registers, more than
+    // the accumulator half of the register file holds, and hipcc then spills registers whose asm-issued loads are still in
+    // flight.  Those tiles run with 512 threads (<= 16 loads per thread); anything larger takes the slow per-sample staging.
+    const int nld512 = (int)((pairs + 511) / 512);
+    const bool big = fast && nld > 16 && nld512 <= 16;
+    q.nld = (wide || big) ? nld512 : nld;
+    if (fast && nld > 16 && !big) {
+        if (NA == 16) launch_k<16, 1, false>(q, grid, lds, s); else if (NA == 8) launch_k<8, 1, false>(q, grid, lds, s); else launch_k<4, 1, false>(q, grid, lds, s);
+        return;
+    }
     if (NA == 16) {
         if (wide) launch_k<16, 8, true, 4, 512>(q, grid, lds, s);
-        else if (nld <= 16) launch_one<16, 16>(q, grid, lds, s); else launch_one<16, 36>(q, grid, lds, s);
+        else if (big) launch_k<16, 16, true, 2, 512>(q, grid, lds, s);
+        else launch_one<16, 16>(q, grid, lds, s);
     } else if (NA == 4) {
-        if (nld <= 8 && fast) launch_k<4, 8, true, 3>(q, grid, lds, s);
-        else if (nld <= 16) launch_one<4, 16>(q, grid, lds, s); else launch_one<4, 36>(q, grid, lds, s);
+        if (big) launch_k<4, 16, true, 2, 512>(q, grid, lds, s);
+        else if (nld <= 8 && fast) launch_k<4, 8, true, 3>(q, grid, lds, s);
+        else launch_one<4, 16>(q, grid, lds, s);
     } else {
         if (wide) { launch_k<8, 8, true, 4, 512>(q, grid, lds, s); return; }
+        if (big) { launch_k<8, 16, true, 2, 512>(q, grid, lds, s); return; }
         const char* w3 = std::getenv("QRL_DECIM_WPE3");   // experiment: three smaller workgroups per CU
-        if (w3 && w3[0] == '1' && nld <= 10 && q.in && q.n >= 2 && q.n < (1u << 28)) launch_k<8, 10, true, 3>(q, grid, lds, s);
-        else if (nld <= 16) launch_one<8, 16>(q, grid, lds, s); else launch_one<8, 36>(q, grid, lds, s);
+        if (w3 && w3[0] == '1' && nld <= 10 && fast) launch_k<8, 10, true, 3>(q, grid, lds, s);
+        else launch_one<8, 16>(q, grid, lds, s);
     }
 }
 

@@ -47,7 +47,9 @@ def _compare(iq, out, mode_name, device_rate, offset):
             assert out[port][b].size == ref[port].size, (port, b, out[port][b].size, ref[port].size)
             assert np.array_equal(out[port][b], ref[port]), "%s stream %d differs" % (port, b)
         for port in ("filtered", "constellation"):
-            got, want = out[port][b].view(np.float32), ref[port].view(np.float32)
+            # bit-identical up to the sign of an exact zero (x + 0.0 maps -0 to +0): products that underflow below the
+            # smallest denormal at the very first samples of a stream may come out as -0 on one side and +0 on the other
+            got, want = out[port][b].view(np.float32) + np.float32(0), ref[port].view(np.float32) + np.float32(0)
             assert got.size == want.size, (port, b, got.size, want.size)
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "%s stream %d not bit-identical" % (port, b)
         assert ref["bits_a"].size > 0
@@ -63,6 +65,8 @@ def _compare(iq, out, mode_name, device_rate, offset):
     ("gmsk10k", 22, 10000000, 1 << 23),     # front end 10:1, 419 taps
     ("qpsk250k", 26, 1000000, 1 << 20),     # C3 chain at the internal rate: agc2, 2x Costas, symbol_sync_cc, diff_phasor
     ("qpsk250k", 26, 10000000, 1 << 23),    # C3 behind the 10:1 front end
+    ("gmsk10k", 22, 64000000, 1 << 24),     # front end 64:1, 2677 taps: 8-block tile, 22 loads per thread (NLD = 36 variant)
+    ("gmsk10k", 22, 100000000, 1 << 24),    # front end 100:1, 4181 taps: only the 4-block MFMA tile fits the LDS
     ("4fsk2kfm", 5, 1000000, 1 << 21),      # gr_demod_4fsk FM branch: 4-level symbol_sync_ff, phase_modulator, (imag, real) soft pairs
     ("4fsk1kfm", 6, 2000000, 1 << 22),
     ("4fsk10kfm", 4, 4000000, 1 << 22),     # 2/25 resampler to 80 ksps, 8 samples per symbol
