@@ -117,6 +117,9 @@ struct qrl_demod {
     hipStream_t tail = nullptr;
     hipEvent_t ev_ff = nullptr, ev_tail = nullptr;
     bool tail_pending = false;
+    // overlapped mode (2FSK / GMSK / 4FSK families): everything behind the first decimated ring runs on the tail stream while
+    // the front end of the NEXT call already runs on the main stream; ring s2 holds two calls, ev_tail2 guards its reuse
+    bool overlap = false; hipEvent_t ev_tail2[2] = {nullptr, nullptr}; bool tail2_valid[2] = {false, false}; uint64_t call_no = 0;
     enum Family { F_2FSK, F_GMSK, F_QPSK, F_DMR, F_4FSK, F_BPSK } fam = F_2FSK;
     int branches = 2;
 
@@ -157,6 +160,7 @@ struct qrl_demod {
         for (auto& e : prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         if (ev_ff) (void)hipEventDestroy(ev_ff);
         if (ev_tail) (void)hipEventDestroy(ev_tail);
+        for (auto e : ev_tail2) if (e) (void)hipEventDestroy(e);
         if (tail) (void)hipStreamDestroy(tail);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
@@ -272,7 +276,15 @@ int qrl_demod::build()
         s1_mask = pow2_at_least(max1 + look + 64) - 1;
         if ((r = s1.alloc((size_t)B * (s1_mask + 1)))) return r;
     }
-    s2_mask = pow2_at_least(max2 + 1024) - 1;   // history needs: <= 501 taps downstream
+    // default: only the 2FSK family, whose FLL + discriminator kernels are a third of a call (measured, C1: 15.2 -> 12.9 ms per
+    // step); for the light GMSK / 4FSK tails the extra stream hand-over costs more than it hides (C2: 2.86 -> 3.05 ms).
+    // QRL_OVERLAP=1 forces it for all three families, QRL_NO_OVERLAP=1 switches it off.
+    {
+        const char* on = std::getenv("QRL_OVERLAP"); const char* off = std::getenv("QRL_NO_OVERLAP");
+        overlap = fam == F_2FSK || ((fam == F_GMSK || fam == F_4FSK) && on && on[0] == '1');
+        if (off && off[0] == '1') overlap = false;
+    }
+    s2_mask = pow2_at_least((overlap ? 2 : 1) * max2 + 1024) - 1;   // history needs: <= 501 taps downstream; overlapped mode: two calls
     const size_t ring2 = (size_t)B * (s2_mask + 1);
     if ((r = s2.alloc(ring2)) || (r = s2f.alloc(ring2)) || (r = s2d.alloc(ring2)) || (r = s3.alloc(ring2))) return r;
     if ((fam == F_2FSK || fam == F_BPSK) && (r = s2l.alloc(ring2))) return r;
@@ -373,7 +385,14 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
     if ((reinterpret_cast<uintptr_t>(iq) & 15u) || (stride & 1u)) return fail(QRL_ERR_ARG, "iq must be 16-byte aligned, stride even");
     const int B = cfg.batch;
     uint32_t* counts = (out && out->counts) ? out->counts : counts_scratch.p;
-    HIPCHK(hipMemsetAsync(counts, 0, (size_t)B * 4 * sizeof(uint32_t), stream));
+    hipStream_t cs = overlap ? tail : stream;   // stream of stage C (decimated-rate feed-forward kernels)
+    const int slot = (int)(call_no & 1);
+    if (overlap) {
+        // ring s2 is about to be overwritten two calls behind: the tail of call k - 2 must be through
+        if (tail2_valid[slot]) HIPCHK(hipStreamWaitEvent(stream, ev_tail2[slot], 0));
+    } else {
+        HIPCHK(hipMemsetAsync(counts, 0, (size_t)B * 4 * sizeof(uint32_t), stream));
+    }
     const float2* in = reinterpret_cast<const float2*>(iq);
     const float2* hist_old = hist_flip ? hist_b.p : hist_a.p;
     float2* hist_new = hist_flip ? hist_a.p : hist_b.p;
@@ -441,6 +460,11 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         launch_hist_save(h, B, stream);
         hist_flip = !hist_flip;
     }
+    if (overlap) {
+        HIPCHK(hipEventRecord(ev_ff, stream));
+        HIPCHK(hipStreamWaitEvent(tail, ev_ff, 0));
+        HIPCHK(hipMemsetAsync(counts, 0, (size_t)B * 4 * sizeof(uint32_t), tail));
+    }
     // ---- stage C: decimated-rate feed-forward (+ FLL for 2FSK)
     const uint32_t c2 = (uint32_t)(n2_1 - n2_0);
     const bool side = cfg.enable_side_outputs && out;
@@ -449,30 +473,28 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         FllParams f{};
         f.in = r2; f.out = r2l; f.q0 = n2_0; f.count = c2; f.st = fll_st.p;
         f.lower = fll_lo.p; f.upper = fll_up.p; f.nt = fam == F_BPSK ? 32 : 16; f.alpha = fll_alpha; f.beta = fll_beta; f.max_freq = fll_maxf;
-        launch_fll(f, B, stream);
+        launch_fll(f, B, cs);
         filt_in = r2l;
     }
     const bool fused_2fsk = fam == F_2FSK && !fm && filt_nt <= 41 && disc_nt <= 41 && symf_nt <= 25 &&
                             !(std::getenv("QRL_2FSK_UNFUSED") && std::getenv("QRL_2FSK_UNFUSED")[0] == '1');
     if (fam == F_DMR) {
         QuadDemodParams q{}; q.in = r2; q.out = r2d; q.q0 = n2_0; q.count = c2; q.gain = demod_gain; q.atan_tab = atan_tab.p;
-        launch_quad_demod(q, B, stream);
-        if (tail_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_tail, 0)); tail_pending = false; }
+        launch_quad_demod(q, B, cs);
+        if (!overlap && tail_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_tail, 0)); tail_pending = false; }
         FirFffParams f{}; f.in = r2d; f.out = r3; f.q0 = n2_0; f.count = c2; f.taps = symf_taps.p; f.nt = symf_nt;
-        launch_fir_fff(f, B, stream);
-        HIPCHK(hipEventRecord(ev_ff, stream));
-        HIPCHK(hipStreamWaitEvent(tail, ev_ff, 0));
+        launch_fir_fff(f, B, cs);
+        if (!overlap) { HIPCHK(hipEventRecord(ev_ff, stream)); HIPCHK(hipStreamWaitEvent(tail, ev_ff, 0)); }
     } else if (fused_2fsk) {
-        if (tail_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_tail, 0)); tail_pending = false; }
+        if (!overlap && tail_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_tail, 0)); tail_pending = false; }
         Fsk2FfParams f{};
         f.in = filt_in; f.out = r3; f.q0 = n2_0; f.count = c2;
         f.tf = filt_taps.p; f.nf = filt_nt; f.up = disc_up.p; f.lo = disc_lo.p; f.nb = disc_nt; f.ts = symf_taps.p; f.ns = symf_nt;
         f.port = side && out->filtered ? reinterpret_cast<float2*>(out->filtered) : nullptr;
         f.port_cap = side ? out->filtered_cap : 0;
         f.counts = counts;
-        launch_2fsk_ff(f, B, stream);
-        HIPCHK(hipEventRecord(ev_ff, stream));
-        HIPCHK(hipStreamWaitEvent(tail, ev_ff, 0));
+        launch_2fsk_ff(f, B, cs);
+        if (!overlap) { HIPCHK(hipEventRecord(ev_ff, stream)); HIPCHK(hipStreamWaitEvent(tail, ev_ff, 0)); }
     } else {
         {
             FirCcfParams f{};
@@ -480,26 +502,25 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
             f.port = side && out->filtered ? reinterpret_cast<float2*>(out->filtered) : nullptr;
             f.port_cap = side ? out->filtered_cap : 0;
             f.counts = counts;
-            launch_fir_ccf(f, B, stream);
+            launch_fir_ccf(f, B, cs);
         }
         if (fam == F_QPSK || fam == F_BPSK) {
             // recursive chain + Viterbi below; nothing else at the sample rate
         } else if (fam == F_GMSK || fam == F_4FSK || fm) {
             QuadDemodParams q{}; q.in = r2f; q.out = r2d; q.q0 = n2_0; q.count = c2; q.gain = demod_gain; q.atan_tab = atan_tab.p;
-            launch_quad_demod(q, B, stream);
+            launch_quad_demod(q, B, cs);
         } else {
             Disc2fskParams d{}; d.in = r2f; d.out = r2d; d.q0 = n2_0; d.count = c2; d.up = disc_up.p; d.lo = disc_lo.p; d.nt = disc_nt;
-            launch_disc_2fsk(d, B, stream);
+            launch_disc_2fsk(d, B, cs);
         }
         if (fam == F_QPSK || fam == F_BPSK) {
             // the tail reads r2f (written by k_fir_ccf above): it runs on the handle's own stream for these families
         } else {
             // r3 is what the previous call's tail (other stream) may still be reading
-            if (tail_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_tail, 0)); tail_pending = false; }
+            if (!overlap && tail_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_tail, 0)); tail_pending = false; }
             FirFffParams f{}; f.in = r2d; f.out = r3; f.q0 = n2_0; f.count = c2; f.taps = symf_taps.p; f.nt = symf_nt;
-            launch_fir_fff(f, B, stream);
-            HIPCHK(hipEventRecord(ev_ff, stream));
-            HIPCHK(hipStreamWaitEvent(tail, ev_ff, 0));
+            launch_fir_fff(f, B, cs);
+            if (!overlap) { HIPCHK(hipEventRecord(ev_ff, stream)); HIPCHK(hipStreamWaitEvent(tail, ev_ff, 0)); }
         }
     }
     // ---- stage D: symbol sync + FEC
@@ -548,9 +569,10 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
             HIPCHK(hipEventRecord(ev_tail, tail));
             tail_pending = true;
         }
+        if (overlap) { HIPCHK(hipEventRecord(ev_tail2[slot], tail)); tail2_valid[slot] = true; }
     }
     HIPCHK(hipGetLastError());
-    n_in = n_in1; n1 = n1_1; n2 = n2_1;
+    n_in = n_in1; n1 = n1_1; n2 = n2_1; ++call_no;
     return QRL_OK;
 }
 
@@ -668,6 +690,7 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
     }
     HIPCHK(hipEventCreateWithFlags(&d->ev_ff, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&d->ev_tail, hipEventDisableTiming));
+    for (auto& e : d->ev_tail2) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     int r = d->build();
     if (r) return r;
     *outp = d.release();
