@@ -263,15 +263,24 @@ void orc_fll_band_edge(const cf32* in, size_t n, float sps, float rolloff, int n
         out[i] = y;
         memmove(dl + 1, dl, sizeof(cf32) * (size_t)(nt - 1));
         dl[0] = y;
-        float ur = 0, ui = 0, lr = 0, li = 0;
-        /* one fmaf chain per accumulator, OLDEST sample first: only the last link depends on y[n] */
-        for (int j = nt - 1; j >= 0; j--) {
-            cf32 hu = upper[nt - 1 - j], hl = lower[nt - 1 - j], v = dl[j];
-            ur = fmaf(hu.re, v.re, ur); ur = fmaf(-hu.im, v.im, ur);
-            ui = fmaf(hu.re, v.im, ui); ui = fmaf(hu.im, v.re, ui);
-            lr = fmaf(hl.re, v.re, lr); lr = fmaf(-hl.im, v.im, lr);
-            li = fmaf(hl.re, v.im, li); li = fmaf(hl.im, v.re, li);
+        /* Summation contract (what the 4-lanes-per-stream GPU kernel does): the delay line is cut into 4 groups of nt/4
+         * consecutive samples, group g = dl[g*nt/4 .. (g+1)*nt/4 - 1]; inside a group one fmaf chain per accumulator, OLDEST
+         * sample first (only the last link of group 0 depends on y[n]); the partial sums meet as (p0 + p1) + (p2 + p3). */
+        float pur[4], pui[4], plr[4], pli[4];
+        const int gl = nt / 4;
+        for (int g = 0; g < 4; g++) {
+            float ur = 0, ui = 0, lr = 0, li = 0;
+            for (int j = (g + 1) * gl - 1; j >= g * gl; j--) {
+                cf32 hu = upper[nt - 1 - j], hl = lower[nt - 1 - j], v = dl[j];
+                ur = fmaf(hu.re, v.re, ur); ur = fmaf(-hu.im, v.im, ur);
+                ui = fmaf(hu.re, v.im, ui); ui = fmaf(hu.im, v.re, ui);
+                lr = fmaf(hl.re, v.re, lr); lr = fmaf(-hl.im, v.im, lr);
+                li = fmaf(hl.re, v.im, li); li = fmaf(hl.im, v.re, li);
+            }
+            pur[g] = ur; pui[g] = ui; plr[g] = lr; pli[g] = li;
         }
+        const float ur = (pur[0] + pur[1]) + (pur[2] + pur[3]), ui = (pui[0] + pui[1]) + (pui[2] + pui[3]);
+        const float lr = (plr[0] + plr[1]) + (plr[2] + plr[3]), li = (pli[0] + pli[1]) + (pli[2] + pli[3]);
         float error = (lr * lr + li * li) - (ur * ur + ui * ui);
         freq = freq + beta * error;
         phase = phase + freq + alpha * error;

@@ -20,82 +20,84 @@ namespace qrl {
 // cache and a single wave per SIMD is issue-latency bound anyway: ~5 cycles per instruction.)
 constexpr int FLL_CH = 96;   // samples per stream per LDS window
 
-template <int NT>
-__global__ __launch_bounds__(64) void k_fll(const FllParams P, int batch)
+template <int CTRL> __device__ __forceinline__ float dpp_quad(float v)
 {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// FOUR LANES PER STREAM.  The two NT-tap band-edge filters are the bulk of the arithmetic but only their newest link sits on
+// the recursion's critical path, so the delay line is cut into 4 groups of NT/4 samples, one per lane of a quad: every lane
+// runs the short oldest-first fmaf chains of its group, the delay line shifts through the quad with one DPP move, and the
+// partial sums meet by two DPP butterflies as (p0 + p1) + (p2 + p3) -- the summation contract of oracle orc_fll_band_edge.
+// The NCO / loop update is computed redundantly by the four lanes (bit-identical inputs, bit-identical results).  A workgroup
+// of 256 threads = 64 streams shares one LDS window; compared with the lane-per-stream kernel there are 4x more waves
+// (one per SIMD instead of one per CU at 16k streams) with ~3x shorter instruction streams.
+template <int NT>
+__global__ __launch_bounds__(256) void k_fll(const FllParams P, int batch)
+{
+    constexpr int GL = NT / 4;
     __shared__ float2 win[64][FLL_CH + 1];
     __shared__ float2 tl[NT], tu[NT];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int sl = tid >> 2, g = tid & 3;
     const int b0 = blockIdx.x * 64;
-    const int b = b0 + lane;
+    const int b = b0 + sl;
     const bool active = b < batch;
-    if (lane < NT) { tl[lane] = P.lower[lane]; tu[lane] = P.upper[lane]; }
+    if (tid < NT) { tl[tid] = P.lower[tid]; tu[tid] = P.upper[tid]; }
     float phase = 0.f, freq = 0.f;
-    float2 dl[NT];   // dl[j] = y[n - j]
+    float2 dl[GL];   // dl[t] = y[n - (g GL + t)]
     if (active) {
         const FllState& s = P.st[b];
         phase = s.phase; freq = s.freq;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) dl[j] = s.dl[j];
+        for (int t = 0; t < GL; ++t) dl[t] = s.dl[g * GL + t];
     } else {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) dl[j] = make_float2(0.f, 0.f);
+        for (int t = 0; t < GL; ++t) dl[t] = make_float2(0.f, 0.f);
     }
     const int nstreams = min(64, batch - b0);
-    constexpr int KPS = (FLL_CH + 63) / 64;
+    __syncthreads();
+    float2 hu[GL], hl[GL];   // this lane's taps: entry j of the device tables belongs to y[n - j]
+#pragma unroll
+    for (int t = 0; t < GL; ++t) { hu[t] = tu[g * GL + t]; hl[t] = tl[g * GL + t]; }
     for (uint32_t c0 = 0; c0 < P.count; c0 += FLL_CH) {
         const int len = min((uint32_t)FLL_CH, P.count - c0);
         __syncthreads();
-        // stage x[n - NT] for n in [q0+c0, q0+c0+len) of every stream of this wave; 8 streams of loads in flight
-        for (int s0 = 0; s0 < nstreams; s0 += 8) {
-            float2 v[8][KPS];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-#pragma unroll
-                for (int kk = 0; kk < KPS; ++kk) {
-                    const int k = lane + 64 * kk;
-                    const int64_t i = (int64_t)(P.q0 + c0 + k) - NT;
-                    v[u][kk] = make_float2(0.f, 0.f);
-                    if (s0 + u < nstreams && k < len && i >= 0)
-                        v[u][kk] = P.in.p[(size_t)(b0 + s0 + u) * (P.in.mask + 1u) + ((uint32_t)i & P.in.mask)];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-#pragma unroll
-                for (int kk = 0; kk < KPS; ++kk) {
-                    const int k = lane + 64 * kk;
-                    if (s0 + u < nstreams && k < FLL_CH) win[s0 + u][k] = v[u][kk];
-                }
+        // stage x[n - NT] for n in [q0 + c0, q0 + c0 + len) of every stream of this workgroup (coalesced along the stream)
+        for (int idx = tid; idx < nstreams * FLL_CH; idx += 256) {
+            const int s = idx / FLL_CH, k = idx - s * FLL_CH;
+            if (k < len) {
+                const int64_t i = (int64_t)(P.q0 + c0 + k) - NT;
+                win[s][k] = i >= 0 ? P.in.p[(size_t)(b0 + s) * (P.in.mask + 1u) + ((uint32_t)i & P.in.mask)] : make_float2(0.f, 0.f);
             }
         }
         __syncthreads();
         if (active) {
             for (int k = 0; k < len; ++k) {
-                const float2 x = win[lane][k];
+                const float2 x = win[sl][k];
                 const float2 nco = sincos_rad(phase);  // (cos, sin)
                 const float2 y = cmul(x, nco);
-                win[lane][k] = y;                      // output staged in place, flushed coalesced below
-                // oldest sample first: the NT-1 old links do not depend on y
+                if (g == 0) win[sl][k] = y;            // output staged in place, flushed coalesced below
+                // shift the delay line through the quad: lane g takes the oldest entry of lane g - 1, lane 0 takes y[n]
+                float2 carry;
+                carry.x = dpp_quad<0x90>(dl[GL - 1].x);
+                carry.y = dpp_quad<0x90>(dl[GL - 1].y);
+#pragma unroll
+                for (int t = GL - 1; t > 0; --t) dl[t] = dl[t - 1];
+                dl[0] = g == 0 ? y : carry;
                 float ur = 0.f, ui = 0.f, lr = 0.f, li = 0.f;
 #pragma unroll
-                for (int j = NT - 1; j >= 1; --j) {
-                    const float2 hu = tu[j], hl = tl[j], v = dl[j - 1];   // dl[j-1] is y[n - j] before the shift
-                    ur = fmaf(hu.x, v.x, ur); ur = fmaf(-hu.y, v.y, ur);
-                    ui = fmaf(hu.x, v.y, ui); ui = fmaf(hu.y, v.x, ui);
-                    lr = fmaf(hl.x, v.x, lr); lr = fmaf(-hl.y, v.y, lr);
-                    li = fmaf(hl.x, v.y, li); li = fmaf(hl.y, v.x, li);
+                for (int t = GL - 1; t >= 0; --t) {   // oldest first: only lane 0's last link depends on y[n]
+                    const float2 v = dl[t];
+                    ur = fmaf(hu[t].x, v.x, ur); ur = fmaf(-hu[t].y, v.y, ur);
+                    ui = fmaf(hu[t].x, v.y, ui); ui = fmaf(hu[t].y, v.x, ui);
+                    lr = fmaf(hl[t].x, v.x, lr); lr = fmaf(-hl[t].y, v.y, lr);
+                    li = fmaf(hl[t].x, v.y, li); li = fmaf(hl[t].y, v.x, li);
                 }
-                {
-                    const float2 hu = tu[0], hl = tl[0];
-                    ur = fmaf(hu.x, y.x, ur); ur = fmaf(-hu.y, y.y, ur);
-                    ui = fmaf(hu.x, y.y, ui); ui = fmaf(hu.y, y.x, ui);
-                    lr = fmaf(hl.x, y.x, lr); lr = fmaf(-hl.y, y.y, lr);
-                    li = fmaf(hl.x, y.y, li); li = fmaf(hl.y, y.x, li);
-                }
-#pragma unroll
-                for (int j = NT - 1; j > 0; --j) dl[j] = dl[j - 1];
-                dl[0] = y;
+                // (p0 + p1) + (p2 + p3): quad butterflies (lane ^ 1, then lane ^ 2); float addition commutes, so all four
+                // lanes end up with the same bits
+                ur = ur + dpp_quad<0xB1>(ur); ui = ui + dpp_quad<0xB1>(ui); lr = lr + dpp_quad<0xB1>(lr); li = li + dpp_quad<0xB1>(li);
+                ur = ur + dpp_quad<0x4E>(ur); ui = ui + dpp_quad<0x4E>(ui); lr = lr + dpp_quad<0x4E>(lr); li = li + dpp_quad<0x4E>(li);
                 const float error = (lr * lr + li * li) - (ur * ur + ui * ui);
                 freq = freq + P.beta * error;
                 phase = phase + freq + P.alpha * error;
@@ -104,27 +106,23 @@ __global__ __launch_bounds__(64) void k_fll(const FllParams P, int batch)
             }
         }
         __syncthreads();
-        for (int s = 0; s < nstreams; ++s) {
-            float2* orow = P.out.p + (size_t)(b0 + s) * (P.out.mask + 1u);
-#pragma unroll
-            for (int kk = 0; kk < KPS; ++kk) {
-                const int k = lane + 64 * kk;
-                if (k < len) orow[(uint32_t)(P.q0 + c0 + k) & P.out.mask] = win[s][k];
-            }
+        for (int idx = tid; idx < nstreams * FLL_CH; idx += 256) {
+            const int s = idx / FLL_CH, k = idx - s * FLL_CH;
+            if (k < len) P.out.p[(size_t)(b0 + s) * (P.out.mask + 1u) + ((uint32_t)(P.q0 + c0 + k) & P.out.mask)] = win[s][k];
         }
     }
     if (active) {
         FllState& s = P.st[b];
-        s.phase = phase; s.freq = freq;
+        if (g == 0) { s.phase = phase; s.freq = freq; }
 #pragma unroll
-        for (int j = 0; j < NT; ++j) s.dl[j] = dl[j];
+        for (int t = 0; t < GL; ++t) s.dl[g * GL + t] = dl[t];
     }
 }
 
 void launch_fll(const FllParams& p, int batch, hipStream_t s)
 {
     if (!p.count) return;
-    dim3 grid((batch + 63) / 64), block(64);
+    dim3 grid((batch + 63) / 64), block(256);
     if (p.nt == 16) hipLaunchKernelGGL((k_fll<16>), grid, block, 0, s, p, batch);
     else            hipLaunchKernelGGL((k_fll<32>), grid, block, 0, s, p, batch);
 }
