@@ -58,8 +58,12 @@ def synth(mode, device_rate, offset, batch, nsamp, seed, torch, dev):
     return iq
 
 
-def run_workload(name, args, torch, q, ctx, dev, rank, world):
+def run_workload(name, args, torch, q, ctx, dev, rank, world, no_overlap=False):
     label, mode, modem, rate, offset, dbatch, dns, _ = WORKLOADS[name]
+    if no_overlap:
+        os.environ["QRL_NO_OVERLAP"] = "1"   # read by qrl_demod_create: stage C back on the main stream, kernels run one at a time
+    else:
+        os.environ.pop("QRL_NO_OVERLAP", None)
     batch = args.batch if (args.batch and name == args.config) else dbatch
     nsamp = args.nsamp if (args.nsamp and name == args.config) else dns
     nsamp &= ~1
@@ -89,6 +93,7 @@ def run_workload(name, args, torch, q, ctx, dev, rank, world):
         dt = float(t.item())
     counts = dem.counts.cpu().numpy()
     dem.close()
+    os.environ.pop("QRL_NO_OVERLAP", None)
     del iq
     torch.cuda.empty_cache()
     total_samples = float(batch) * nsamp * args.steps * world
@@ -193,6 +198,12 @@ def main():
         extra = run_workload(other, args, torch, q, ctx, dev, rank, world)
         if rank == 0:
             base = cpu_baseline(args.config, min(os.cpu_count() or 1, 16))
+    # C1 (2FSK family) runs in overlapped mode: the FLL / discriminator kernels of call k share the GPU with the front end of
+    # call k + 1, which stretches the front-end kernel.  Its stand-alone duration is measured in a second short pass.
+    alone = {}
+    for r in (main_r, extra):
+        if r and r["name"] == "c1" and not args.no_extra:
+            alone["c1"] = run_workload("c1", args, torch, q, ctx, dev, rank, world, no_overlap=True)
     if rank == 0:
         def roof(r):
             # HBM traffic per launch of the dominant kernel: PMC numbers cannot be collected from inside this process;
@@ -205,10 +216,16 @@ def main():
                     traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
             except (OSError, ValueError, KeyError):
                 pass
-            return dict(bound="hbm", achieved=round(r["achieved_gbps"], 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                        frac=round(r["achieved_gbps"] / HBM_PEAK_GBPS, 4), traffic=traffic, kernel=r["kernel"],
-                        kernel_ms=round(r["kernel_ms"], 4), launches=r["launches"],
-                        algorithmic_bytes_per_launch=r["bytes_per_launch"])
+            d = dict(bound="hbm", achieved=round(r["achieved_gbps"], 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                     frac=round(r["achieved_gbps"] / HBM_PEAK_GBPS, 4), traffic=traffic, kernel=r["kernel"],
+                     kernel_ms=round(r["kernel_ms"], 4), launches=r["launches"],
+                     algorithmic_bytes_per_launch=r["bytes_per_launch"])
+            a = alone.get(r["name"])
+            if a:
+                d["without_overlap"] = dict(kernel_ms=round(a["kernel_ms"], 4), achieved=round(a["achieved_gbps"], 1),
+                                            frac=round(a["achieved_gbps"] / HBM_PEAK_GBPS, 4), ms_per_step=round(a["ms_per_step"], 3),
+                                            note="QRL_NO_OVERLAP=1: same workload with the kernels of a call run one after another")
+            return d
         line = {
             "metric": "IQ MSamples/sec through RX demod chain", "value": round(main_r["msps"], 1), "unit": "MS/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(main_r["ms_per_step"], 3),
