@@ -172,6 +172,15 @@ typedef struct {
     int batch;               /* independent wideband inputs per call */
     size_t max_chunk;        /* largest n (wideband samples per input) of any call */
     void* hip_stream;
+    /* form 1 = the legacy "freq-xlating" receiver make_gr_demod_mmdvm_multi(burst_timer, num_channels, channel_separation,
+     * use_tdma, sps, samp_rate, carrier_freq, filter_width) (src/gr/gr_demod_mmdvm_multi.cpp:19-38,58-123): per channel
+     * rotator_cc(2 pi (-channel_separation) ct / fs) -> rational_resampler_ccf(1, decimation, low_pass(1, fs, filter_width,
+     * 3500, BH)) -> fft_filter_ccf -> rssi tag -> discriminator -> int16, fs = 24 kHz * decimation (240 ksps in the
+     * reference).  The wideband input is read once per channel (compute-bound form); 0 = PFB channelizer (multi2). */
+    int form;
+    int channel_separation;  /* form 1: Hz, 0 = 25000 */
+    int decimation;          /* form 1: 0 = 10 */
+    int filter_width;        /* form 1: 0 = 8000 (header default, gr_demod_mmdvm_multi.h:37-40) */
 } qrl_chan_config;
 int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** out);
 void qrl_chan_destroy(qrl_chan* c);

@@ -745,6 +745,45 @@ size_t orc_demod_mmdvm_multi_4fsk(const cf32* in, size_t n, int M, int16_t* out,
     return m;
 }
 
+/* legacy "freq-xlating" multi-carrier receiver gr_demod_mmdvm_multi.cpp:58-123: per channel i
+ *   rotator_cc(2 pi (-separation) ct / fs), ct = i (i <= 3) | 3 - i   [more than 7 channels: i <= N/2 ? i : i - N]
+ *   -> rational_resampler_ccf(1, D, low_pass(1, fs, fw, 3500, BH)) -> fft_filter_ccf(low_pass(1, 24k, fw, 3500, BH))
+ *   -> rssi_tag_block -> quadrature_demod_cf(24000 / (2 pi 12500)) -> x1.0 -> float_to_short(1, 32767),  fs = 24 kHz * D.
+ * out[c*cap + k] int16, rssi[c*rcap + k] (may be NULL).  Returns samples per channel. */
+size_t orc_demod_mmdvm_xlating(const cf32* in, size_t n, int N, int separation, int D, int fw, int16_t* out, size_t cap,
+                               float* rssi, size_t rcap, float cal)
+{
+    const double fs = 24000.0 * D;
+    int nt = orc_low_pass(1, fs, fw, 3500, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* taps = NEW(float, nt);
+    orc_low_pass(1, fs, fw, 3500, ORC_WIN_BLACKMAN_HARRIS, taps);
+    int nf = orc_low_pass(1, 24000, fw, 3500, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* ft = NEW(float, nf);
+    orc_low_pass(1, 24000, fw, 3500, ORC_WIN_BLACKMAN_HARRIS, ft);
+    const size_t n2 = orc_decim_count(n, 1, D);
+    const float gain = (float)(24000.0f / (2 * M_PI * 12500.0f));
+    cf32* rot = NEW(cf32, n + 1); cf32* a = NEW(cf32, n2 + 1); cf32* b = NEW(cf32, n2 + 1); float* d = NEW(float, n2 + 1);
+    const size_t m = n2 < cap ? n2 : cap;
+    for (int c = 0; c < N; c++) {
+        const int ct = N <= 7 ? (c > 3 ? 3 - c : c) : (c <= N / 2 ? c : c - N);
+        const float carrier_offset = (float)(-separation);
+        const uint64_t inc = orc_phase_inc_to_turn(2 * M_PI * carrier_offset * ct / (float)fs);
+        orc_rotator(in, n, inc, 0, rot);
+        orc_decim_auto(rot, n, taps, nt, D, a);
+        orc_fir_ccf(a, n2, ft, nf, b);
+        if (rssi) {
+            float* tmp = NEW(float, n2 / 300 + 1);
+            size_t nr = orc_rssi_tag(b, n2, cal, tmp);
+            for (size_t k = 0; k < nr && k < rcap; k++) rssi[(size_t)c * rcap + k] = tmp[k];
+            free(tmp);
+        }
+        orc_quad_demod(b, n2, gain, d);
+        for (size_t i = 0; i < m; i++) out[(size_t)c * cap + i] = f2s(d[i] * 1.0f, 32767.0f);
+    }
+    free(rot); free(a); free(b); free(d); free(taps); free(ft);
+    return m;
+}
+
 /* ------------------------------- DMR / 4FSK symbol demodulator (a37) ---------------------------------
  * gr_demod_dmr (reference src/gr/gr_demod_dmr.cpp:36-105, instance make_gr_demod_dmr(5, 1000000) gr_demod_base.cpp:253):
  *   rational_resampler_ccf(3, 125, low_pass_2(3, 3e6, 5000, 2000, 60, BH)) -> [port 0] -> quadrature_demod_cf(24000/(pi/2*4800))

@@ -43,7 +43,8 @@ class _ModConfig(C.Structure):
 
 class _ChanConfig(C.Structure):
     _fields_ = [("num_channels", C.c_int), ("channel_first", C.c_int), ("channel_count", C.c_int), ("batch", C.c_int),
-                ("max_chunk", C.c_size_t), ("hip_stream", C.c_void_p)]
+                ("max_chunk", C.c_size_t), ("hip_stream", C.c_void_p), ("form", C.c_int), ("channel_separation", C.c_int),
+                ("decimation", C.c_int), ("filter_width", C.c_int)]
 
 
 class _Out(C.Structure):
@@ -278,13 +279,15 @@ class Channelizer:
     process(iq) takes complex64 cuda [batch, n] (n multiple of num_channels) and returns (int16 cuda
     [batch, channel_count, cap], counts int32 [batch, channel_count])."""
 
-    def __init__(self, ctx, num_channels, batch, max_chunk, channel_first=0, channel_count=0, stream=None):
+    def __init__(self, ctx, num_channels, batch, max_chunk, channel_first=0, channel_count=0, stream=None, form=0,
+                 channel_separation=0, decimation=0, filter_width=0):
         import torch
         self.torch = torch
         self.ctx, self.lib = ctx, ctx.lib
         cfg = _ChanConfig()
         cfg.num_channels, cfg.channel_first, cfg.channel_count = num_channels, channel_first, channel_count
         cfg.batch, cfg.max_chunk, cfg.hip_stream = batch, max_chunk, stream
+        cfg.form, cfg.channel_separation, cfg.decimation, cfg.filter_width = form, channel_separation, decimation, filter_width
         self.h = C.c_void_p()
         _check(self.lib.qrl_chan_create(ctx.h, C.byref(cfg), C.byref(self.h)), "qrl_chan_create")
         self.batch = batch

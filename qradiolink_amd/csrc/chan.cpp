@@ -50,6 +50,7 @@ struct qrl_chan {
     Buf<float2> r1, r2, r3; Buf<float> r4; uint32_t m1 = 0, m2 = 0;
     uint64_t n_in = 0, n1 = 0, n2 = 0;
     float gain = 0, level = 1.0f, rssi_cal = 0.0f;
+    bool xlat = false; int xl_D = 10, xl_nt = 0, xl_S = 0; Buf<float> xl_taps; Buf<float2> xl_rot_lo; std::vector<uint64_t> xl_inc;   // form 1
     bool single = false; int rs_I = 24, rs_D = 25;   // single: gr_demod_mmdvm (one carrier at 250 ksps, 12/125 resampler, no channelizer)
     float* rssi_out = nullptr; size_t rssi_cap = 0; uint32_t* rssi_counts = nullptr;
     // optional 4FSK symbol tail behind every channel (gr_demod_dmr.cpp:62-105 on the 24 ksps channel signal)
@@ -89,12 +90,13 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     h->ctx = ctx; h->cfg = *cfg;
     qrl_chan_config& c = h->cfg;
     if (c.num_channels < 1 || c.num_channels > 64) return qrl_set_error(QRL_ERR_ARG, "num_channels must be 1..64");
-    h->single = c.num_channels == 1;
+    h->xlat = c.form == 1;
+    h->single = c.num_channels == 1 && !h->xlat;
     if (c.channel_count <= 0) { c.channel_first = 0; c.channel_count = c.num_channels; }
     if (c.channel_first < 0 || c.channel_first + c.channel_count > c.num_channels) return qrl_set_error(QRL_ERR_ARG, "bad channel range");
     if (c.batch < 1 || c.max_chunk < (size_t)c.num_channels || (size_t)c.batch * c.channel_count > 65535)
         return qrl_set_error(QRL_ERR_ARG, "bad batch / max_chunk");
-    const int M = h->M = c.num_channels;
+    const int M = h->M = h->xlat ? 1 : c.num_channels;   // M = samples consumed per channel-rate instant of the PFB form
     HIPCHK(hipSetDevice(ctx->device));
     if (c.hip_stream) h->stream = static_cast<hipStream_t>(c.hip_stream);
     else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
@@ -118,15 +120,42 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     std::vector<float> rl((size_t)RI * h->rs_Jp, 0.0f);
     for (size_t k = 0; k < rt.size(); ++k) rl[(k % RI) * h->rs_Jp + k / RI] = rt[k];
     if ((r = h->rs_taps.upload(rl))) return r;
-    const std::vector<float> ft = low_pass_2(1, 24000, 5000, 2000, 60, WIN_BLACKMAN_HARRIS);    // :62-63
+    if (h->xlat) {
+        // legacy receiver gr_demod_mmdvm_multi.cpp:58-123: per channel rotator_cc(2 pi (-separation) ct / fs) ->
+        // rational_resampler_ccf(1, D, low_pass(1, fs, fw, 3500, BH)) at fs = 24 kHz * D (240 ksps, D = 10 in the reference)
+        h->xl_D = c.decimation > 0 ? c.decimation : 10;
+        const int fw = c.filter_width > 0 ? c.filter_width : 8000, sep = c.channel_separation > 0 ? c.channel_separation : 25000;
+        const double fs = 24000.0 * h->xl_D;
+        const std::vector<float> xt = low_pass(1, fs, fw, 3500, WIN_BLACKMAN_HARRIS);
+        h->xl_nt = (int)xt.size();
+        if (!decim_uses_mfma(h->xl_nt, h->xl_D)) return qrl_set_error(QRL_ERR_ARG, "freq-xlating form: decimation must be >= 8 and the tile must fit the LDS");
+        h->xl_S = decim_mfma_steps(h->xl_nt, h->xl_D);
+        std::vector<float> g((size_t)decim_mfma_hpn(h->xl_nt, h->xl_D), 0.0f);
+        for (int k = 0; k < h->xl_nt; ++k) g[(size_t)k + (size_t)(4 * h->xl_S - h->xl_nt + 1)] = xt[k];
+        if ((r = h->xl_taps.upload(g))) return r;
+        std::vector<float2> lo((size_t)c.channel_count * 512);
+        h->xl_inc.resize(c.channel_count);
+        for (int cl = 0; cl < c.channel_count; ++cl) {
+            const int i = c.channel_first + cl;
+            // :89-95: ct = i for i <= 3, 3 - i above (7 channels at most in the reference); more channels: i <= N/2 ? i : i - N
+            const int ct = c.num_channels <= 7 ? (i > 3 ? 3 - i : i) : (i <= c.num_channels / 2 ? i : i - c.num_channels);
+            const float carrier_offset = (float)(-sep);
+            h->xl_inc[cl] = phase_inc_to_turn(2 * M_PI * carrier_offset * ct / (float)fs);
+            for (int k = 0; k < 512; ++k) { float sn, cs; sincos_turn_host((uint64_t)k * h->xl_inc[cl], sn, cs); lo[(size_t)cl * 512 + k] = make_float2(cs, sn); }
+        }
+        if ((r = h->xl_rot_lo.upload(lo))) return r;
+        h->rs_I = 1; h->rs_D = h->xl_D;
+    }
+    const std::vector<float> ft = h->xlat ? low_pass(1, 24000, c.filter_width > 0 ? c.filter_width : 8000, 3500, WIN_BLACKMAN_HARRIS)   // legacy :70-74
+                                          : low_pass_2(1, 24000, 5000, 2000, 60, WIN_BLACKMAN_HARRIS);    // :62-63
     h->filt_nt = (int)ft.size();
     if ((r = h->filt_taps.upload(ft)) || (r = h->atan_tab.upload(atan_table()))) return r;
     h->gain = h->single ? (float)(24000.0f / (2 * M_PI * 10000.0f))                               // gr_demod_mmdvm.cpp:41,48
                         : (float)(24000.0f / (2 * M_PI * 12500.0f));                              // gr_demod_mmdvm_multi2.cpp:80
-    h->hist_len = h->single ? (uint32_t)(h->rs_Jp + h->rs_D + 2) : (uint32_t)(h->J * M);
+    h->hist_len = h->xlat ? (uint32_t)(h->xl_nt + h->xl_D) : h->single ? (uint32_t)(h->rs_Jp + h->rs_D + 2) : (uint32_t)(h->J * M);
     const size_t S = (size_t)c.batch * c.channel_count;
     const size_t max1 = c.max_chunk / M + 2, max2 = max1 * h->rs_I / h->rs_D + 2;
-    h->m1 = h->single ? 63 : pow2ge(max1 + h->rs_Jp + 64) - 1;   // the single-carrier chain reads the caller's IQ directly
+    h->m1 = (h->single || h->xlat) ? 63 : pow2ge(max1 + h->rs_Jp + 64) - 1;   // the single-carrier chain reads the caller's IQ directly
     h->m2 = pow2ge(max2 + h->filt_nt + 64 + 300) - 1;   // + one rssi_tag_block window
     if ((r = h->hist_a.alloc((size_t)c.batch * h->hist_len)) || (r = h->hist_b.alloc((size_t)c.batch * h->hist_len)) ||
         (r = h->r1.alloc(S * (h->m1 + 1))) || (r = h->r2.alloc(S * (h->m2 + 1))) || (r = h->r3.alloc(S * (h->m2 + 1))) ||
@@ -176,6 +205,7 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
 {
     if (!h || (!iq && n)) return QRL_ERR_ARG;
     if (n > h->cfg.max_chunk) return qrl_set_error(QRL_ERR_TOO_BIG, "n exceeds max_chunk");
+    if (h->xlat && (n & 1)) return qrl_set_error(QRL_ERR_ARG, "n must be even");
     if (n % (size_t)h->M) return qrl_set_error(QRL_ERR_ARG, "n must be a multiple of num_channels (stream_to_streams)");
     if (n == 0) return QRL_OK;
     HIPCHK(hipSetDevice(h->ctx->device));
@@ -189,7 +219,7 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
     p.in = in; p.in_stride = stride; p.n0 = h->n_in; p.n = (uint32_t)n; p.hist = hist_old; p.hist_len = h->hist_len;
     p.out = RingC{h->r1.p, h->m1}; p.m0 = h->n1; p.m_count = (uint32_t)(n1_1 - h->n1);
     p.taps = h->taps.p; p.twiddle = h->twiddle.p; p.M = M; p.J = h->J; p.c_first = h->cfg.channel_first; p.c_count = CC;
-    if (!h->single) launch_pfb_chan(p, B, h->stream);
+    if (!h->single && !h->xlat) launch_pfb_chan(p, B, h->stream);
     HistParams hp{};
     hp.in = in; hp.in_stride = stride; hp.n0 = h->n_in; hp.n = (uint32_t)n;
     hp.hist_old = hist_old; hp.hist_new = hist_new; hp.hist_len = h->hist_len; hp.rot_enable = 0;
@@ -199,11 +229,22 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
     const uint64_t RI = (uint64_t)h->rs_I, RD = (uint64_t)h->rs_D;
     const uint64_t n2_1 = n1_1 ? ((n1_1 - 1) * RI + (RI - 1)) / RD + 1 : 0;   // outputs q with q*D/I <= n1_1 - 1
     const uint32_t c2 = (uint32_t)(n2_1 - h->n2);
+    if (h->xlat) {   // one front-end launch per channel: same input, that channel's rotator, rows b * CC + cl of ring r2
+        for (int cl = 0; cl < CC; ++cl) {
+            DecimParams dp{};
+            dp.in = in; dp.in_stride = stride; dp.n0 = h->n_in; dp.n = (uint32_t)n; dp.hist = hist_old; dp.hist_len = h->hist_len; dp.hist_raw = 1;
+            dp.out = RingC{h->r2.p, h->m2}; dp.out_row_mul_m1 = (uint32_t)CC - 1u; dp.out_row_add = (uint32_t)cl;
+            dp.m0 = h->n2; dp.m_count = c2; dp.D = h->xl_D; dp.gtab = h->xl_taps.p; dp.taps = h->xl_taps.p; dp.S = h->xl_S; dp.nt = h->xl_nt;
+            dp.rot_enable = 1; dp.rot_acc = 0; dp.rot_inc = h->xl_inc[cl]; dp.rot_nbase = 0; dp.rot_lo = h->xl_rot_lo.p + (size_t)cl * 512;
+            launch_decim_mfma(dp, B, h->stream);
+        }
+    }
     ResampParams rp{};
-    if (h->single) { rp.in = in; rp.in_stride = stride; rp.hist = hist_old; rp.hist_len = h->hist_len; rp.n0 = h->n_in; rp.n = (uint32_t)n; }
+    if (h->xlat) {
+    } else if (h->single) { rp.in = in; rp.in_stride = stride; rp.hist = hist_old; rp.hist_len = h->hist_len; rp.n0 = h->n_in; rp.n = (uint32_t)n; }
     else { rp.in = nullptr; rp.in_ring = RingC{h->r1.p, h->m1}; rp.n0 = h->n1; rp.n = (uint32_t)(n1_1 - h->n1); }
     rp.out = RingC{h->r2.p, h->m2}; rp.q0 = h->n2; rp.q_count = c2; rp.taps = h->rs_taps.p; rp.I = h->rs_I; rp.D = h->rs_D; rp.Jp = h->rs_Jp;
-    launch_resamp(rp, S, h->stream);
+    if (!h->xlat) launch_resamp(rp, S, h->stream);
     auto rssi = [&](float2* ring) {   // rssi_tag_block: after the filter in multi2 (:126-127), after the resampler in gr_demod_mmdvm (:53-54)
         if (!h->rssi_out) return;
         RssiParams r{}; r.in = RingC{ring, h->m2}; r.j0 = h->n2 / 300; r.count = (uint32_t)(n2_1 / 300 - h->n2 / 300);

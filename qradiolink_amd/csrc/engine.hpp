@@ -28,6 +28,8 @@ struct DecimParams {
     const float* gtab; int S; int nt; uint32_t magic_blk, magic_seg;   // gtab: zero-padded taps, hp[k + 4S - nt + 1] = h[k]
     uint32_t tpw, nchunks; int nhi; int dbg;               // consecutive tiles per workgroup; rotator coarse-table entries
     int nld;                                                // 16-byte loads per thread a tile needs (<= the kernel's NLD)
+    int hist_raw;                                           // hist holds UN-rotated samples (MFMA variant only): rotate on fetch
+    uint32_t out_row_mul_m1, out_row_add;                   // output ring row of stream b = b * (mul_m1 + 1) + add (MFMA variant only)
 };
 struct HistParams {
     const float2* in; size_t in_stride; uint64_t n0; uint32_t n;

@@ -56,7 +56,13 @@ __device__ __forceinline__ float2 mf_fetch(const DecimParams& P, int b, int64_t 
         }
         const uint64_t d = P.n0 - ui;
         if (d > P.hist_len) return make_float2(0.f, 0.f);
-        return P.hist[(size_t)b * P.hist_len + (P.hist_len - (uint32_t)d)];
+        float2 hx = P.hist[(size_t)b * P.hist_len + (P.hist_len - (uint32_t)d)];
+        if (P.hist_raw && P.rot_enable) {   // un-rotated history (per-channel rotators of the freq-xlating bank): exact NCO, computed directly
+            const uint64_t kk = ui - P.rot_nbase;
+            const float2 hi = sincos_turn(P.rot_acc + ((kk >> 9) << 9) * P.rot_inc);
+            hx = cmul_fma(hx, cmul_fma(hi, P.rot_lo[(uint32_t)kk & 511u]));
+        }
+        return hx;
     }
     return P.in_ring.p[(size_t)b * (P.in_ring.mask + 1u) + ((uint32_t)ui & P.in_ring.mask)];
 }
@@ -520,7 +526,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 float2 y;
                 y.x = (r0.x + r1.x) + (r2.x + r3.x);
                 y.y = (r0.y + r1.y) + (r2.y + r3.y);
-                P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = y;
+                P.out.p[((size_t)b * (P.out_row_mul_m1 + 1u) + P.out_row_add) * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = y;
             }
         }
         MF_STAMP(6);
@@ -616,7 +622,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 float2 y;
                 y.x = (r0.x + r1.x) + (r2.x + r3.x);
                 y.y = (r0.y + r1.y) + (r2.y + r3.y);
-                P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = y;
+                P.out.p[((size_t)b * (P.out_row_mul_m1 + 1u) + P.out_row_add) * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = y;
             }
         }
     };

@@ -98,6 +98,7 @@ _sig("orc_rssi_tag", _sz, _p, _sz, C.c_float, _p)
 _sig("orc_demod_mmdvm", _sz, _p, _sz, C.c_int, C.c_int, _p, _sz, _p, C.c_float, _p)
 _sig("orc_demod_mmdvm_multi_rssi", _sz, _p, _sz, C.c_int, _p, _sz, _p, _sz, C.c_float)
 _sig("orc_demod_mmdvm_multi_4fsk", _sz, _p, _sz, C.c_int, _p, _sz, _p, _sz, C.c_float, _p, _sz, _p)
+_sig("orc_demod_mmdvm_xlating", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p, _sz, _p, _sz, C.c_float)
 _sig("orc_batch_rx", C.c_double, C.c_int, _p, C.c_int, _sz, C.c_int, C.c_double, C.c_int, _p)
 
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECT, WIN_BH = 0, 1, 2, 3, 5
@@ -344,6 +345,16 @@ def demod_mmdvm_multi_4fsk(x, M):
     nd = np.zeros(M, np.uint64)
     n = lib.orc_demod_mmdvm_multi_4fsk(_ptr(x), x.size, M, _ptr(out), cap, None, 0, 0.0, _ptr(dib), dcap, _ptr(nd))
     return out[:, :n].copy(), [dib[c, :int(nd[c])].copy() for c in range(M)]
+
+
+def demod_mmdvm_xlating(x, N, separation=25000, D=10, fw=8000, cal=0.0):
+    x = np.ascontiguousarray(x, cf32)
+    cap = x.size // D + 4
+    out = np.zeros((N, cap), np.int16)
+    rcap = cap // 300 + 2
+    rssi = np.zeros((N, rcap), np.float32)
+    n = lib.orc_demod_mmdvm_xlating(_ptr(x), x.size, N, separation, D, fw, _ptr(out), cap, _ptr(rssi), rcap, cal)
+    return out[:, :n].copy(), rssi[:, :n // 300].copy()
 
 
 def tx_interp(x, samp_rate):

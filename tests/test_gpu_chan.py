@@ -177,3 +177,54 @@ def test_channelizer_4fsk_tail_bit_exact(qrl_ctx, chunk):
         g = g[:, 0] * 2 + g[:, 1]
         best = max(np.mean(g[k:k + 800] == d[:800]) for k in range(60))
         assert best > 0.99, (c, best)
+
+
+def _wideband_xl(fs, n, seed, nstreams, offsets):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    out = []
+    for s in range(nstreams):
+        x = 0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        for f0 in offsets:
+            dev, fm = rng.uniform(1000, 4000), rng.uniform(200, 1500)
+            ph = 2 * np.pi * f0 * t / fs + (dev / fm) * np.sin(2 * np.pi * fm * t / fs + rng.uniform(0, 6))
+            x = x + rng.uniform(0.05, 0.3) * np.exp(1j * ph)
+        out.append(x.astype(np.complex64))
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("N,D,chunk", [(7, 10, 48000), (7, 10, 10002), (16, 32, 76800)])
+def test_freq_xlating_form_bit_exact(qrl_ctx, N, D, chunk):
+    """form 1 = legacy gr_demod_mmdvm_multi: per channel rotator + 1:D resampler (the front-end MFMA kernel, one launch per
+    channel with that channel's exact NCO), LPF, RSSI, discriminator -> int16; bit-exact and chunk invariant"""
+    import torch
+    import qradiolink_amd as q
+    fs = 24000.0 * D
+    n = 48000 if D == 10 else 76800 * 2
+    iq = _wideband_xl(fs, n, seed=N, nstreams=2, offsets=[0.0, 25000.0, -50000.0, 75000.0])
+    ch = q.Channelizer(qrl_ctx, N, batch=2, max_chunk=chunk, form=1, decimation=D)
+    ch.calibrate_rssi(1.5)
+    d = torch.from_numpy(iq).cuda()
+    got = [[[] for _ in range(N)] for _ in range(2)]
+    tags = [[[] for _ in range(N)] for _ in range(2)]
+    for s in range(0, n, chunk):
+        part = d[:, s:s + chunk]
+        if part.shape[1] & 1:
+            part = part[:, :-1]
+        out, cnt = ch.process(part.contiguous())
+        cnt, o = cnt.cpu().numpy(), out.cpu().numpy()
+        rc, r = ch.rssi_counts.cpu().numpy(), ch.rssi.cpu().numpy()
+        for b in range(2):
+            for c in range(N):
+                got[b][c].append(o[b, c, :cnt[b, c]].copy())
+                tags[b][c].append(r[b, c, :rc[b, c]].copy())
+    ch.close()
+    used = sum((min(chunk, n - s) & ~1) for s in range(0, n, chunk))
+    for b in range(2):
+        ref, rref = orc.demod_mmdvm_xlating(iq[b, :used], N, D=D, cal=1.5)
+        for c in range(N):
+            g = np.concatenate(got[b][c])
+            assert g.size == ref.shape[1] and np.array_equal(g, ref[c]), (b, c)
+            tg = np.concatenate(tags[b][c])
+            assert tg.size == rref[c].size and np.allclose(tg, rref[c], rtol=0, atol=1e-4)
+    assert np.abs(ref).max() > 1000

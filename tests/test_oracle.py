@@ -366,3 +366,14 @@ def test_channelizer_plus_4fsk_tail_recovers_dibits():
     g = dib[2].reshape(-1, 2)
     g = g[:, 0] * 2 + g[:, 1]
     assert max(np.mean(g[k:k + 800] == d[:800]) for k in range(60)) > 0.99
+
+
+def test_legacy_freq_xlating_bank_channel_map():
+    """gr_demod_mmdvm_multi.cpp:89-95: channel i listens at ct * separation, ct = i (i <= 3) or 3 - i; +2.5 kHz reads 0.2 full scale"""
+    fs, n = 240000.0, 48000
+    t = np.arange(n)
+    for ch, ct in ((0, 0), (2, 2), (5, -2)):
+        x = (0.3 * np.exp(2j * np.pi * (ct * 25000.0 + 2500.0) * t / fs)).astype(np.complex64)
+        out, rssi = orc.demod_mmdvm_xlating(x, 7)
+        assert abs(np.median(out[ch, 500:]) - 0.2 * 32767) < 30
+        assert abs(rssi[ch][1] - 20 * np.log10(0.3)) < 0.1
