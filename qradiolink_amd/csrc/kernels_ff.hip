@@ -39,10 +39,82 @@ __global__ __launch_bounds__(256) void k_fir_ccf(const FirCcfParams P)
     P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = y;
     if (P.port && t < P.port_cap) P.port[(size_t)b * P.port_cap + t] = y;
 }
+// LDS-tiled variants for the longer filters (RRC shaping filters of the FM / 4FSK / BPSK chains, 75 ... 501 taps): a workgroup
+// stages FT_OUT + nt - 1 input items of one stream and the taps in LDS, every thread then produces FT_R outputs 256 apart
+// (consecutive lanes -> consecutive LDS words, taps are wave-uniform broadcasts).  Same fmaf chain, k ascending.
+constexpr int FT_R = 4, FT_OUT = 256 * FT_R, FT_MAXT = 1024;
+
+__global__ __launch_bounds__(256) void k_fir_ccf_tiled(const FirCcfParams P)
+{
+    __shared__ float taps[FT_MAXT];
+    __shared__ float2 xs[FT_OUT + FT_MAXT];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const uint32_t t0 = blockIdx.x * (uint32_t)FT_OUT;
+    const int nt = P.nt;
+    for (int k = tid; k < nt; k += 256) taps[k] = P.taps[k];
+    const int64_t first = (int64_t)(P.q0 + t0) - (nt - 1);         // xs[i] = x[first + i]
+    const int span = min((uint32_t)FT_OUT, P.count - t0) + nt - 1;
+    for (int i = tid; i < span; i += 256) xs[i] = ringc_at(P.in, b, first + i);
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0 && P.counts) P.counts[b * 4 + 0] = P.count;
+    float ar[FT_R], ai[FT_R];
+#pragma unroll
+    for (int r = 0; r < FT_R; ++r) { ar[r] = 0.f; ai[r] = 0.f; }
+    const float2* xp = xs + (nt - 1) + tid;                        // output j = tid + 256 r reads xp[256 r - k]
+    for (int k = 0; k < nt; ++k) {
+        const float h = taps[k];
+#pragma unroll
+        for (int r = 0; r < FT_R; ++r) {
+            const float2 x = xp[256 * r - k];
+            ar[r] = fmaf(h, x.x, ar[r]);
+            ai[r] = fmaf(h, x.y, ai[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < FT_R; ++r) {
+        const uint32_t t = t0 + tid + 256u * r;
+        if (t < P.count) {
+            const int64_t n = (int64_t)(P.q0 + t);
+            const float2 y = make_float2(ar[r], ai[r]);
+            P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = y;
+            if (P.port && t < P.port_cap) P.port[(size_t)b * P.port_cap + t] = y;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_fir_fff_tiled(const FirFffParams P)
+{
+    __shared__ float taps[FT_MAXT];
+    __shared__ float xs[FT_OUT + FT_MAXT];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const uint32_t t0 = blockIdx.x * (uint32_t)FT_OUT;
+    const int nt = P.nt;
+    for (int k = tid; k < nt; k += 256) taps[k] = P.taps[k];
+    const int64_t first = (int64_t)(P.q0 + t0) - (nt - 1);
+    const int span = min((uint32_t)FT_OUT, P.count - t0) + nt - 1;
+    for (int i = tid; i < span; i += 256) xs[i] = ringf_at(P.in, b, first + i);
+    __syncthreads();
+    float a[FT_R];
+#pragma unroll
+    for (int r = 0; r < FT_R; ++r) a[r] = 0.f;
+    const float* xp = xs + (nt - 1) + tid;
+    for (int k = 0; k < nt; ++k) {
+        const float h = taps[k];
+#pragma unroll
+        for (int r = 0; r < FT_R; ++r) a[r] = fmaf(h, xp[256 * r - k], a[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < FT_R; ++r) {
+        const uint32_t t = t0 + tid + 256u * r;
+        if (t < P.count) P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)(P.q0 + t) & P.out.mask)] = a[r];
+    }
+}
+static bool fir_use_tiled(int nt, uint32_t count) { return nt >= 32 && nt <= FT_MAXT && count >= 512; }
+
 void launch_fir_ccf(const FirCcfParams& p, int batch, hipStream_t s)
 {
     if (!p.count) return;
-    hipLaunchKernelGGL(k_fir_ccf, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
+    if (fir_use_tiled(p.nt, p.count)) hipLaunchKernelGGL(k_fir_ccf_tiled, dim3((p.count + FT_OUT - 1) / FT_OUT, batch), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_fir_ccf, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
 }
 
 __global__ __launch_bounds__(256) void k_fir_fff(const FirFffParams P)
@@ -58,7 +130,8 @@ __global__ __launch_bounds__(256) void k_fir_fff(const FirFffParams P)
 void launch_fir_fff(const FirFffParams& p, int batch, hipStream_t s)
 {
     if (!p.count) return;
-    hipLaunchKernelGGL(k_fir_fff, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
+    if (fir_use_tiled(p.nt, p.count)) hipLaunchKernelGGL(k_fir_fff_tiled, dim3((p.count + FT_OUT - 1) / FT_OUT, batch), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_fir_fff, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
 }
 
 __global__ __launch_bounds__(256) void k_quad_demod(const QuadDemodParams P)
