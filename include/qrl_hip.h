@@ -221,6 +221,24 @@ int qrl_deframer_process(qrl_deframer* d, const uint8_t* bits, size_t stride, si
                          uint8_t* out, size_t out_cap, uint32_t* out_counts);
 int qrl_deframer_sync(qrl_deframer* d);
 
+/* ---- L1 frame synchroniser (reference gr_modem::synchronize / findSync / packBytes, src/gr_modem.cpp:1119-1282, 980-994;
+ * frame types src/layer1framing.h:8-24; mode table gr_modem::toggleRxMode :203-322) ------------------------------------------
+ * Consumes the unpacked bits of a demodulator port like qrl_deframer_process and emits, per stream, the frames the
+ * reference would pass to gr_modem::processReceivedData as records
+ *     { uint32 frame_type (FrameTypeVoice1 0xB5, FrameTypeVoice 0xED89, FrameTypeText 0x89EDAA, ...); uint32 nbytes;
+ *       nbytes payload bytes, MSB-first packed, padded to a multiple of 4 }
+ * appended to out[b*out_cap ...]; out_counts[2b] = bytes written, out_counts[2b+1] = frames.  A frame that does not fit is
+ * dropped (out_cap >= n/8 + 64 + 8 * frames never overflows for the mode's frame size).  Search state, a partial frame
+ * and the _modem_sync counter carry across calls.  M17 (its own sync words, :1186-1210) is not built. */
+typedef struct qrl_framesync qrl_framesync;
+int qrl_framesync_create(qrl_ctx* ctx, int modem_type, int batch, void* hip_stream, qrl_framesync** out);
+void qrl_framesync_destroy(qrl_framesync* f);
+int qrl_framesync_reset(qrl_framesync* f);
+int qrl_framesync_frame_bytes(const qrl_framesync* f);   /* _rx_frame_length of the mode */
+int qrl_framesync_process(qrl_framesync* f, const uint8_t* bits, size_t stride, size_t n, const uint32_t* counts, size_t count_stride,
+                          uint8_t* out, size_t out_cap, uint32_t* out_counts);
+int qrl_framesync_sync(qrl_framesync* f);
+
 /* ---- filter design & tables (host side, no GPU needed): what the kernels are loaded with ----
  * replaces: gr::filter::firdes::* calls at gr_demod_2fsk.cpp:82-97, gr_demod_gmsk.cpp:80-98,
  * gr_demod_qpsk.cpp:92-103, gr_demod_base.cpp:1333-1336.  taps==NULL returns the count. */

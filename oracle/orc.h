@@ -121,6 +121,8 @@ size_t orc_mod_4fsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate,
 size_t orc_mod_bpsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, cf32* out);
 size_t orc_clock_recovery_mm_cc(const cf32* in, size_t n, float omega, float gain_omega, float mu, float gain_mu,
                                 float omega_relative_limit, cf32* out);
+int orc_modem_sync_geometry(int modem_type, int* bit_buf_len, int* frame_length);
+size_t orc_modem_sync(int modem_type, const uint8_t* bits, size_t n, uint32_t st[5], uint8_t* bitbuf, uint8_t* out);
 size_t orc_deframer(int type, const uint8_t* bits, size_t n, uint32_t st[3], uint8_t* out);
 size_t orc_rssi_tag(const cf32* in, size_t n, float calibration, float* db);
 size_t orc_demod_mmdvm(const cf32* in, size_t n, int samp_rate, int filter_width, int16_t* out, size_t cap, float* rssi, float cal,

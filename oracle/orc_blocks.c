@@ -667,3 +667,78 @@ size_t orc_deframer(int type, const uint8_t* bits, size_t n, uint32_t st[3], uin
     }
     return no;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * gr_modem::synchronize / findSync / packBytes (reference src/gr_modem.cpp:1119-1282, 980-994; frame types
+ * src/layer1framing.h:8-24; mode table :203-322).  Per bit: search the mode's sync words in a shift register, then collect
+ * the frame's bits, pack them MSB first and hand the frame to processReceivedData.  Here a frame becomes one record
+ * { u32 frame_type, u32 nbytes, nbytes payload bytes padded to a multiple of 4 } appended to out.
+ * st[0] = shift register, st[1] = sync_found, st[2] = bit_buf_index, st[3] = current frame type, st[4] = _modem_sync;
+ * bitbuf (>= orc_modem_sync_geometry(...).bit_buf_len bytes) carries a partial frame between calls.  Returns bytes written.
+ * M17 (its own sync words) is not restated.
+ * ------------------------------------------------------------------------------------------ */
+int orc_modem_sync_geometry(int modem_type, int* bit_buf_len, int* frame_length)
+{
+    int bits = 64, len = 7, cls = 2;   /* cls 0: 1k modes (0xB5), 1: fast modes (24-bit words only), 2: the rest */
+    switch (modem_type) {
+    case 24: case 16: case 18: case 21: case 6: bits = 32; len = 4; cls = 0; break;              /* BPSK1K 2FSK1KFM 2FSK1K GMSK1K 4FSK1KFM */
+    case 1: case 4: case 19: case 22: bits = 48 * 8; len = 47; break;                             /* QPSK20K 4FSK10KFM 2FSK10KFM GMSK10K */
+    case 2: bits = 3123 * 8; len = 3122; cls = 1; break;                                          /* QPSKVideo */
+    case 26: bits = 1517 * 8; len = 1516; cls = 1; break;                                         /* QPSK250K */
+    case 27: bits = 623 * 8; len = 622; cls = 1; break;                                           /* 4FSK100K */
+    default: break;                                                                               /* 2k modes: 64 bits, 7 bytes */
+    }
+    if (bit_buf_len) *bit_buf_len = bits;
+    if (frame_length) *frame_length = len;
+    return cls;
+}
+static uint32_t modem_find_sync(int cls, uint32_t reg)
+{
+    if (cls == 0) return (reg & 0xFF) == 0xB5 ? 0xB5u : 0u;                                       /* FrameTypeVoice1 */
+    uint32_t t24 = reg & 0xFFFFFF;
+    if (cls == 2) {
+        if ((reg & 0xFFFF) == 0xED89) return 0xED89u;                                             /* FrameTypeVoice2 -> FrameTypeVoice */
+        if (t24 == 0x89EDAA || t24 == 0xED77AA || t24 == 0x98DEAA || t24 == 0x8CC8DD || t24 == 0x4C8A2B) return t24;
+        return 0;
+    }
+    if (t24 == 0xDE98AA || t24 == 0x98DEAA || t24 == 0x4C8A2B) return t24;                        /* IP, Video, End */
+    return 0;
+}
+size_t orc_modem_sync(int modem_type, const uint8_t* bits, size_t n, uint32_t st[5], uint8_t* bitbuf, uint8_t* out)
+{
+    int bit_buf_len0, frame_length0;
+    const int cls = orc_modem_sync_geometry(modem_type, &bit_buf_len0, &frame_length0);
+    size_t no = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!st[1]) {
+            st[0] = (st[0] << 1) | (bits[i] & 1u);
+            const uint32_t ft = modem_find_sync(cls, st[0]);
+            if (ft) {
+                st[1] = 1; st[3] = ft; st[2] = 0;
+                if (st[4] < 32) st[4] += 8;
+                continue;
+            }
+            if (st[4] > 0) st[4] -= 1;
+        }
+        if (st[1]) {
+            bitbuf[st[2]++] = bits[i] & 1u;
+            int frame_length = frame_length0, bit_buf_len = bit_buf_len0;
+            if (cls != 0 && st[3] == 0xED89) frame_length++;          /* reserved byte of voice frames */
+            else if (cls != 0) bit_buf_len = bit_buf_len0 - 8;
+            if ((int)st[2] >= bit_buf_len) {
+                uint32_t hdr[2] = {st[3], (uint32_t)frame_length};
+                memcpy(out + no, hdr, 8); no += 8;
+                const size_t padded = ((size_t)frame_length + 3) & ~(size_t)3;
+                memset(out + no, 0, padded);
+                for (int k = 0; k < bit_buf_len; k += 8) {
+                    int t = 0;
+                    for (int j = 0; j < 8; j++) t = (t << 1) | (bitbuf[k + j] & 1);
+                    out[no + (size_t)(k >> 3)] = (uint8_t)t;
+                }
+                no += padded;
+                st[1] = 0; st[0] = 0; st[2] = 0;
+            }
+        }
+    }
+    return no;
+}

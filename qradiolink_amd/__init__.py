@@ -111,6 +111,12 @@ def load_library():
     lib.qrl_deframer_reset.argtypes = [vp]
     lib.qrl_deframer_process.argtypes = [vp, vp, sz, sz, vp, sz, vp, sz, vp]
     lib.qrl_deframer_sync.argtypes = [vp]
+    lib.qrl_framesync_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    lib.qrl_framesync_destroy.argtypes = [vp]
+    lib.qrl_framesync_reset.argtypes = [vp]
+    lib.qrl_framesync_frame_bytes.argtypes = [vp]
+    lib.qrl_framesync_process.argtypes = [vp, vp, sz, sz, vp, sz, vp, sz, vp]
+    lib.qrl_framesync_sync.argtypes = [vp]
     lib.qrl_firdes_low_pass.argtypes = [C.c_double] * 4 + [C.c_int, vp]
     lib.qrl_firdes_low_pass_2.argtypes = [C.c_double] * 5 + [C.c_int, vp]
     lib.qrl_firdes_complex_band_pass.argtypes = [C.c_double] * 5 + [C.c_int, vp]
@@ -131,6 +137,8 @@ EXPORTED_SYMBOLS = [
     "qrl_mod_samples_per_byte", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_create",
     "qrl_chan_destroy", "qrl_chan_reset", "qrl_chan_set_level", "qrl_chan_calibrate_rssi", "qrl_chan_set_rssi_output", "qrl_chan_set_4fsk_output", "qrl_chan_out_cap", "qrl_chan_process", "qrl_chan_sync",
     "qrl_deframer_create", "qrl_deframer_destroy", "qrl_deframer_reset", "qrl_deframer_process", "qrl_deframer_sync",
+    "qrl_framesync_create", "qrl_framesync_destroy", "qrl_framesync_reset", "qrl_framesync_frame_bytes", "qrl_framesync_process",
+    "qrl_framesync_sync",
     "qrl_firdes_low_pass",
     "qrl_firdes_low_pass_2", "qrl_firdes_complex_band_pass", "qrl_firdes_root_raised_cosine", "qrl_table_mmse",
     "qrl_table_atan", "qrl_table_tanh", "qrl_phase_inc_to_turn",
@@ -369,6 +377,42 @@ class Deframer:
     def close(self):
         if self.h:
             self.lib.qrl_deframer_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class FrameSync:
+    """gr_modem::synchronize/findSync/packBytes on the device (reference src/gr_modem.cpp:1119-1282): process(bits, counts) returns
+    (uint8 cuda [batch, out_cap] records {u32 frame_type, u32 nbytes, payload padded to 4}, int32 cuda [batch, 2] = bytes, frames)."""
+
+    def __init__(self, ctx, modem_type, batch, stream=None):
+        import torch
+        self.torch = torch
+        self.ctx, self.lib, self.batch = ctx, ctx.lib, batch
+        self.h = C.c_void_p()
+        _check(self.lib.qrl_framesync_create(ctx.h, modem_type, batch, stream, C.byref(self.h)), "qrl_framesync_create")
+        self.frame_bytes = self.lib.qrl_framesync_frame_bytes(self.h)
+        self.out = None
+        self.out_counts = torch.zeros((batch, 2), dtype=torch.int32, device="cuda:%d" % ctx.device)
+
+    def process(self, bits, counts=None, count_stride=1, n=None):
+        t = self.torch
+        assert bits.is_cuda and bits.dtype == t.uint8 and bits.dim() == 2 and bits.shape[0] == self.batch and bits.stride(1) == 1
+        n = bits.shape[1] if n is None else n
+        cap = (n // 8 + 64 + 16 * (n // max(8 * self.frame_bytes, 8) + 2) + 3) & ~3
+        if self.out is None or self.out.shape[1] < cap:
+            self.out = t.zeros((self.batch, cap), dtype=t.uint8, device=bits.device)
+        _check(self.lib.qrl_framesync_process(self.h, bits.data_ptr(), bits.stride(0), n, counts.data_ptr() if counts is not None else None,
+                                              count_stride, self.out.data_ptr(), self.out.shape[1], self.out_counts.data_ptr()),
+               "qrl_framesync_process")
+        _check(self.lib.qrl_framesync_sync(self.h), "qrl_framesync_sync")
+        return self.out, self.out_counts
+
+    def reset(self):
+        _check(self.lib.qrl_framesync_reset(self.h), "qrl_framesync_reset")
+
+    def close(self):
+        if self.h:
+            self.lib.qrl_framesync_destroy(self.h)
             self.h = C.c_void_p()
 
 

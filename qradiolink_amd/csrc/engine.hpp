@@ -144,6 +144,14 @@ struct DeframeParams {
     uint8_t* out; size_t out_cap; uint32_t* out_counts;
 };
 void launch_deframe(const DeframeParams& p, int batch, hipStream_t s);
+struct FrameSyncState { uint32_t reg, found, idx, ftype, modem_sync, pad[3]; };
+struct FrameSyncParams {
+    const uint8_t* bits; size_t stride; uint32_t n; const uint32_t* counts; size_t count_stride;
+    int cls; uint32_t bit_buf_len, frame_length;           // sync-word class (0: 1k modes, 1: fast modes, 2: rest), mode table
+    FrameSyncState* st; uint8_t* bitbuf; size_t bitbuf_stride;
+    uint8_t* out; size_t out_cap; uint32_t* out_counts;    // records; out_counts[2b] = bytes, [2b + 1] = frames
+};
+void launch_framesync(const FrameSyncParams& p, int batch, hipStream_t s);
 
 // ---- multi-carrier MMDVM RX (kernels_chan.hip) ----
 struct ChanParams {

@@ -63,6 +63,92 @@ __global__ __launch_bounds__(64) void k_deframe(const DeframeParams P)
     }
 }
 
+// ---- gr_modem::synchronize / findSync / packBytes on the device (reference src/gr_modem.cpp:1119-1282, 980-994).
+// Same wave-per-stream search as k_deframe with the mode's sync-word class; the frame's bits are collected into a per-stream
+// bit buffer (a frame may span calls), then packed MSB first by all lanes into one record
+// { u32 frame_type, u32 nbytes, payload padded to a multiple of 4 } of the stream's output.
+__device__ __forceinline__ uint32_t modem_find_sync(int cls, uint32_t reg)
+{
+    if (cls == 0) return (reg & 0xFFu) == 0xB5u ? 0xB5u : 0u;
+    const uint32_t t24 = reg & 0xFFFFFFu;
+    if (cls == 2) {
+        if ((reg & 0xFFFFu) == 0xED89u) return 0xED89u;
+        if (t24 == 0x89EDAAu || t24 == 0xED77AAu || t24 == 0x98DEAAu || t24 == 0x8CC8DDu || t24 == 0x4C8A2Bu) return t24;
+        return 0u;
+    }
+    if (t24 == 0xDE98AAu || t24 == 0x98DEAAu || t24 == 0x4C8A2Bu) return t24;
+    return 0u;
+}
+
+__global__ __launch_bounds__(64) void k_framesync(const FrameSyncParams P)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const uint32_t n = P.counts ? P.counts[(size_t)b * P.count_stride] : P.n;
+    const uint8_t* in = P.bits + (size_t)b * P.stride;
+    uint8_t* out = P.out + (size_t)b * P.out_cap;
+    uint8_t* bitbuf = P.bitbuf + (size_t)b * P.bitbuf_stride;
+    FrameSyncState st = P.st[b];
+    uint32_t i = 0, no = 0, nframes = 0;
+    while (i < n) {
+        if (st.found) {
+            const bool voice = P.cls != 0 && st.ftype == 0xED89u;
+            const uint32_t need = (P.cls != 0 && !voice) ? P.bit_buf_len - 8u : P.bit_buf_len;
+            const uint32_t flen = voice ? P.frame_length + 1u : P.frame_length;
+            const uint32_t take = min(n - i, need - st.idx);
+            for (uint32_t k = lane; k < take; k += 64) bitbuf[st.idx + k] = in[i + k] & 1u;
+            i += take; st.idx += take;
+            if (st.idx >= need) {
+                __syncthreads();   // one wave per workgroup: makes the bit buffer writes visible to the packing lanes
+                const uint32_t padded = (flen + 3u) & ~3u;
+                if (no + 8u + padded <= P.out_cap) {
+                    if (lane == 0) { reinterpret_cast<uint32_t*>(out + no)[0] = st.ftype; reinterpret_cast<uint32_t*>(out + no)[1] = flen; }
+                    for (uint32_t j = lane; j < padded; j += 64) {
+                        uint32_t t = 0;
+                        if (8u * j < need) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) t = (t << 1) | (bitbuf[8u * j + k] & 1u);
+                        }
+                        out[no + 8u + j] = (uint8_t)t;
+                    }
+                    no += 8u + padded; ++nframes;
+                }
+                st.found = 0; st.reg = 0; st.idx = 0;
+                __syncthreads();
+            }
+        } else {
+            const uint32_t blk = min(64u, n - i);
+            const uint32_t bit = (uint32_t)lane < blk ? (in[i + lane] & 1u) : 0u;
+            const unsigned long long m = __ballot(bit != 0);
+            const uint32_t low = (uint32_t)(__brevll(m) >> (63 - lane));
+            const uint32_t reg_l = ((lane + 1 < 32) ? (st.reg << (lane + 1)) : 0u) | low;
+            const uint32_t ft = (uint32_t)lane < blk ? modem_find_sync(P.cls, reg_l) : 0u;
+            const unsigned long long mm = __ballot(ft != 0);
+            if (mm) {
+                const int l0 = __ffsll((long long)mm) - 1;
+                st.ftype = __shfl(ft, l0, 64);
+                st.found = 1; st.idx = 0; st.reg = __shfl(reg_l, l0, 64);
+                // _modem_sync: -1 (floor 0) for each of the l0 bits searched before the word completed, then +8 below 32
+                st.modem_sync = st.modem_sync > (uint32_t)l0 ? st.modem_sync - (uint32_t)l0 : 0u;
+                if (st.modem_sync < 32u) st.modem_sync += 8u;
+                i += (uint32_t)l0 + 1u;
+            } else {
+                st.reg = __shfl(reg_l, (int)blk - 1, 64);
+                st.modem_sync = st.modem_sync > blk ? st.modem_sync - blk : 0u;
+                i += blk;
+            }
+        }
+    }
+    if (lane == 0) {
+        P.st[b] = st;
+        P.out_counts[2 * b] = no;
+        P.out_counts[2 * b + 1] = nframes;
+    }
+}
+void launch_framesync(const FrameSyncParams& p, int batch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_framesync, dim3(batch), dim3(64), 0, s, p);
+}
+
 void launch_deframe(const DeframeParams& p, int batch, hipStream_t s)
 {
     hipLaunchKernelGGL(k_deframe, dim3(batch), dim3(64), 0, s, p);

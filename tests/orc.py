@@ -93,6 +93,8 @@ _sig("orc_demod_bpsk", None, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p)
 _sig("orc_mod_4fsk", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p)
 _sig("orc_mod_bpsk", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p)
 _sig("orc_clock_recovery_mm_cc", _sz, _p, _sz, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p)
+_sig("orc_modem_sync", _sz, C.c_int, _p, _sz, _p, _p, _p)
+_sig("orc_modem_sync_geometry", C.c_int, C.c_int, _p, _p)
 _sig("orc_deframer", _sz, C.c_int, _p, _sz, _p, _p)
 _sig("orc_rssi_tag", _sz, _p, _sz, C.c_float, _p)
 _sig("orc_demod_mmdvm", _sz, _p, _sz, C.c_int, C.c_int, _p, _sz, _p, C.c_float, _p)
@@ -297,6 +299,35 @@ def mod_4fsk(data, sps=25, samp_rate=1000000, carrier_freq=1700, filter_width=35
 
 def mod_bpsk(data, sps=500, samp_rate=1000000, carrier_freq=1700, filter_width=1500):
     return _mod(lib.orc_mod_bpsk, data, sps, samp_rate, carrier_freq, filter_width)
+
+
+class ModemSync:
+    """gr_modem::synchronize/findSync/packBytes over successive calls; feed() returns the list of (frame_type, payload bytes)"""
+
+    def __init__(self, modem_type):
+        self.modem_type = modem_type
+        self.st = np.zeros(5, np.uint32)
+        self.bitbuf = np.zeros(3123 * 8 + 8, np.uint8)
+
+    def feed_raw(self, bits):
+        bits = np.ascontiguousarray(bits, np.uint8)
+        out = np.zeros(2 * bits.size + 4096, np.uint8)
+        n = lib.orc_modem_sync(self.modem_type, _ptr(bits), bits.size, _ptr(self.st), _ptr(self.bitbuf), _ptr(out))
+        return out[:n].copy()
+
+    def feed(self, bits):
+        return parse_frames(self.feed_raw(bits))
+
+
+def parse_frames(raw):
+    """records { u32 frame_type, u32 nbytes, payload padded to 4 } -> [(frame_type, bytes)]"""
+    frames, pos = [], 0
+    raw = np.ascontiguousarray(raw, np.uint8)
+    while pos + 8 <= raw.size:
+        ft, nb = np.frombuffer(raw[pos:pos + 8].tobytes(), np.uint32)
+        frames.append((int(ft), raw[pos + 8:pos + 8 + int(nb)].tobytes()))
+        pos += 8 + ((int(nb) + 3) & ~3)
+    return frames
 
 
 def deframer(type_, bits, state=None):

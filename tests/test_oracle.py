@@ -377,3 +377,14 @@ def test_legacy_freq_xlating_bank_channel_map():
         out, rssi = orc.demod_mmdvm_xlating(x, 7)
         assert abs(np.median(out[ch, 500:]) - 0.2 * 32767) < 30
         assert abs(rssi[ch][1] - 20 * np.log10(0.3)) < 0.1
+
+
+def test_modem_sync_oracle_frames_by_class():
+    """gr_modem::synchronize: 1k modes find 0xB5 + 4 bytes; 10k modes 0xED89 + (reserved + 47) bytes; QPSK-250k 0xDE98AA + 1516"""
+    rng = np.random.default_rng(2)
+    for mode, modem, ft, off in (("2fsk1k", 18, 0xB5, 0), ("gmsk10k", 22, 0xED89, 1), ("qpsk250k", 26, 0xDE98AA, 0)):
+        data, payloads = sig.frames(mode, 3, rng)
+        bits = np.unpackbits(data)
+        ms = orc.ModemSync(modem)
+        fr = ms.feed(bits[:777]) + ms.feed(bits[777:])
+        assert [f for f, _ in fr] == [ft] * 3 and [p[off:] for _, p in fr] == payloads
