@@ -228,7 +228,8 @@ int qrl_deframer_sync(qrl_deframer* d);
  *     { uint32 frame_type (FrameTypeVoice1 0xB5, FrameTypeVoice 0xED89, FrameTypeText 0x89EDAA, ...); uint32 nbytes;
  *       nbytes payload bytes, MSB-first packed, padded to a multiple of 4 }
  * appended to out[b*out_cap ...]; out_counts[2b] = bytes written, out_counts[2b+1] = frames.  A frame that does not fit is
- * dropped (out_cap >= n/8 + 64 + 8 * frames never overflows for the mode's frame size).  Search state, a partial frame
+ * dropped (out_cap >= n/8 + qrl_framesync_frame_bytes() + 96 + 16 per frame never overflows: a frame begun in earlier calls may
+ * complete in this one).  Search state, a partial frame
  * and the _modem_sync counter carry across calls.  M17 (its own sync words, :1186-1210) is not built. */
 typedef struct qrl_framesync qrl_framesync;
 int qrl_framesync_create(qrl_ctx* ctx, int modem_type, int batch, void* hip_stream, qrl_framesync** out);

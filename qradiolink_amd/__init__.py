@@ -250,6 +250,7 @@ class Demod:
         """Queue one pass over iq ([batch, n] complex64 cuda tensor) on the handle's stream."""
         assert iq.is_cuda and iq.dtype == self.torch.complex64 and iq.dim() == 2 and iq.shape[0] == self.batch
         assert iq.stride(1) == 1
+        self.torch.cuda.current_stream().synchronize()   # the handle runs on its own HIP streams: whatever produced iq must be done
         _check(self.lib.qrl_demod_process(self.h, iq.data_ptr(), iq.stride(0), iq.shape[1], C.byref(self._out)),
                "qrl_demod_process")
 
@@ -327,6 +328,7 @@ class Channelizer:
 
     def process_async(self, iq):
         assert iq.is_cuda and iq.dtype == self.torch.complex64 and iq.dim() == 2 and iq.shape[0] == self.batch and iq.stride(1) == 1
+        self.torch.cuda.current_stream().synchronize()
         _check(self.lib.qrl_chan_process(self.h, iq.data_ptr(), iq.stride(0), iq.shape[1], self.out.data_ptr(), self.cap,
                                          self.counts.data_ptr()), "qrl_chan_process")
 
@@ -365,6 +367,7 @@ class Deframer:
         cap = 2 * n + 24
         if self.out is None or self.out.shape[1] < cap:
             self.out = t.zeros((self.batch, cap), dtype=t.uint8, device=bits.device)
+        t.cuda.current_stream().synchronize()   # the handle has its own HIP stream: the producer of `bits` must be done
         _check(self.lib.qrl_deframer_process(self.h, bits.data_ptr(), bits.stride(0), n, counts.data_ptr() if counts is not None else None,
                                              count_stride, self.out.data_ptr(), self.out.shape[1], self.out_counts.data_ptr()),
                "qrl_deframer_process")
@@ -398,9 +401,11 @@ class FrameSync:
         t = self.torch
         assert bits.is_cuda and bits.dtype == t.uint8 and bits.dim() == 2 and bits.shape[0] == self.batch and bits.stride(1) == 1
         n = bits.shape[1] if n is None else n
-        cap = (n // 8 + 64 + 16 * (n // max(8 * self.frame_bytes, 8) + 2) + 3) & ~3
+        # worst case: a frame begun in earlier calls completes now, then back-to-back frames (8-byte header + padding each)
+        cap = (n // 8 + self.frame_bytes + 80 + 16 * (n // max(8 * self.frame_bytes, 8) + 2) + 3) & ~3
         if self.out is None or self.out.shape[1] < cap:
             self.out = t.zeros((self.batch, cap), dtype=t.uint8, device=bits.device)
+        t.cuda.current_stream().synchronize()   # the handle has its own HIP stream: the producer of `bits` must be done
         _check(self.lib.qrl_framesync_process(self.h, bits.data_ptr(), bits.stride(0), n, counts.data_ptr() if counts is not None else None,
                                               count_stride, self.out.data_ptr(), self.out.shape[1], self.out_counts.data_ptr()),
                "qrl_framesync_process")
@@ -446,6 +451,7 @@ class Mod:
         n = data.shape[1]
         if out is None:
             out = self.torch.empty((self.batch, n * self.spb), dtype=self.torch.complex64, device=data.device)
+        self.torch.cuda.current_stream().synchronize()
         _check(self.lib.qrl_mod_process(self.h, data.data_ptr(), data.stride(0), n, out.data_ptr(), out.stride(0)),
                "qrl_mod_process")
         return out

@@ -89,16 +89,17 @@ __global__ __launch_bounds__(64) void k_framesync(const FrameSyncParams P)
     uint8_t* bitbuf = P.bitbuf + (size_t)b * P.bitbuf_stride;
     FrameSyncState st = P.st[b];
     uint32_t i = 0, no = 0, nframes = 0;
+    // bits of the open frame: [0, carry) sit in bitbuf (written by EARLIER launches), the rest is in[fstart ...] of this call;
+    // nothing written in this launch is read back in it (no reliance on L1 coherence between lanes)
+    uint32_t carry = st.found ? st.idx : 0u, fstart = 0u;
     while (i < n) {
         if (st.found) {
             const bool voice = P.cls != 0 && st.ftype == 0xED89u;
             const uint32_t need = (P.cls != 0 && !voice) ? P.bit_buf_len - 8u : P.bit_buf_len;
             const uint32_t flen = voice ? P.frame_length + 1u : P.frame_length;
             const uint32_t take = min(n - i, need - st.idx);
-            for (uint32_t k = lane; k < take; k += 64) bitbuf[st.idx + k] = in[i + k] & 1u;
             i += take; st.idx += take;
             if (st.idx >= need) {
-                __syncthreads();   // one wave per workgroup: makes the bit buffer writes visible to the packing lanes
                 const uint32_t padded = (flen + 3u) & ~3u;
                 if (no + 8u + padded <= P.out_cap) {
                     if (lane == 0) { reinterpret_cast<uint32_t*>(out + no)[0] = st.ftype; reinterpret_cast<uint32_t*>(out + no)[1] = flen; }
@@ -106,14 +107,17 @@ __global__ __launch_bounds__(64) void k_framesync(const FrameSyncParams P)
                         uint32_t t = 0;
                         if (8u * j < need) {
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) t = (t << 1) | (bitbuf[8u * j + k] & 1u);
+                            for (int k = 0; k < 8; ++k) {
+                                const uint32_t pb = 8u * j + k;
+                                const uint32_t v = pb < carry ? bitbuf[pb] : in[fstart + (pb - carry)];
+                                t = (t << 1) | (v & 1u);
+                            }
                         }
                         out[no + 8u + j] = (uint8_t)t;
                     }
                     no += 8u + padded; ++nframes;
                 }
-                st.found = 0; st.reg = 0; st.idx = 0;
-                __syncthreads();
+                st.found = 0; st.reg = 0; st.idx = 0; carry = 0;
             }
         } else {
             const uint32_t blk = min(64u, n - i);
@@ -131,12 +135,16 @@ __global__ __launch_bounds__(64) void k_framesync(const FrameSyncParams P)
                 st.modem_sync = st.modem_sync > (uint32_t)l0 ? st.modem_sync - (uint32_t)l0 : 0u;
                 if (st.modem_sync < 32u) st.modem_sync += 8u;
                 i += (uint32_t)l0 + 1u;
+                fstart = i; carry = 0;
             } else {
                 st.reg = __shfl(reg_l, (int)blk - 1, 64);
                 st.modem_sync = st.modem_sync > blk ? st.modem_sync - blk : 0u;
                 i += blk;
             }
         }
+    }
+    if (st.found) {   // the call ends inside a frame: keep this call's part of it for the next launch
+        for (uint32_t k = lane; fstart + k < n; k += 64) bitbuf[carry + k] = in[fstart + k] & 1u;
     }
     if (lane == 0) {
         P.st[b] = st;
