@@ -177,3 +177,34 @@ def test_dmr_dibits_recovered(qrl_ctx):
     got = got[:, 0] * 2 + got[:, 1]
     best = max(np.mean(got[k:k + 400] == dib[:400]) for k in range(40))
     assert best == 1.0
+
+
+@pytest.mark.parametrize("mode_name,modem", [("2fsk1k", 18), ("2fsk1kfm", 16), ("gmsk10k", 22)])
+def test_pipelined_calls_without_sync(qrl_ctx, mode_name, modem):
+    """Back-to-back qrl_demod_process calls with NO sync in between (how bench.py drives the handle; the 2FSK family then runs
+    its decimated-rate kernels of call k under the front end of call k + 1, ring s2 holding two calls): the outputs of the
+    last call equal those of the same sequence run with a sync after every call, and the bits equal the oracle's tail."""
+    import torch
+    import qradiolink_amd as q
+    B, chunk = 130, 40000
+    iq = sig.make_batch(mode_name, 2, nframes=2, device_rate=1000000, seed=5)
+    iq = np.concatenate([iq, iq[::-1]] * (B // 4 + 1))[:B]
+    ncalls = iq.shape[1] // chunk
+    d = torch.from_numpy(iq).cuda()
+    res = []
+    for sync_each in (True, False):
+        dem = q.Demod(qrl_ctx, modem, batch=B, max_chunk=chunk)
+        for k in range(ncalls):
+            dem.process_async(d[:, k * chunk:(k + 1) * chunk])
+            if sync_each:
+                dem.sync()
+        dem.sync()
+        res.append((dem.counts.cpu().numpy().copy(), dem.bits_a.cpu().numpy().copy(), dem.bits_b.cpu().numpy().copy()))
+        dem.close()
+    (c0, a0, b0), (c1, a1, b1) = res
+    assert np.array_equal(c0, c1)
+    for b in range(B):
+        assert np.array_equal(a0[b, :c0[b, 2]], a1[b, :c1[b, 2]]) and np.array_equal(b0[b, :c0[b, 3]], b1[b, :c1[b, 3]])
+    ref = _oracle(mode_name, iq[0, :ncalls * chunk], 1000000, 0.0)
+    n_last = int(c1[0, 2])
+    assert n_last > 0 and np.array_equal(a1[0, :n_last], ref["bits_a"][-n_last:])
