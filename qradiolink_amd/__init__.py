@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqrl_hip.so")
+LIB_PATH = os.environ.get("QRL_LIB_PATH") or os.path.join(_HERE, "libqrl_hip.so")   # QRL_LIB_PATH: timing-experiment builds only
 
 # gr_modem_types (reference src/modem_types.h:5-50)
 MODEM_2FSK2KFM, MODEM_2FSK1KFM, MODEM_2FSK2K, MODEM_2FSK1K, MODEM_2FSK10KFM = 15, 16, 17, 18, 19

@@ -29,6 +29,10 @@
 #include "devmath.hpp"
 #include "engine.hpp"
 
+#ifndef QRL_MF_EXP
+#define QRL_MF_EXP 0   // timing experiments only: 1 = no LDS operand reads in the MFMA loop, 2 = no MFMA (results are wrong)
+#endif
+
 namespace qrl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -350,8 +354,16 @@ struct MfChunk {
         }
     }
 };
+#ifndef QRL_MF_EXP
+#define QRL_MF_EXP 0
+#endif
 __device__ __forceinline__ void mf_fma(const MfChunk<float2, 4>& c, f32x4& acc0, f32x4& acc1)
 {
+#if QRL_MF_EXP == 2
+#pragma unroll
+    for (int u = 0; u < MF_U; ++u) { acc0[0] = fmaf(c.a[u], c.b[u].x, acc0[0]); acc1[0] = fmaf(c.a[u], c.b[u].y, acc1[0]); }
+    return;
+#endif
 #pragma unroll
     for (int u = 0; u < MF_U; ++u) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.a[u], c.b[u].x, acc0, 0, 0, 0);
@@ -372,11 +384,16 @@ __device__ __forceinline__ void mfma_piece_c(const float* __restrict__ ap, const
         MfChunk<BT, BS> r0, r1;
         r0.load(ap, bp, 0);
         while (i + 2 * U <= n) {
+#if QRL_MF_EXP == 1
+            if (i == 0)
+#endif
             r1.load(ap, bp, i + U);
             __builtin_amdgcn_sched_barrier(0);
             mf_fma(r0, acc0, acc1);
             __builtin_amdgcn_sched_barrier(0);
+#if QRL_MF_EXP != 1
             r0.load(ap, bp, i + 3 * U <= n ? i + 2 * U : 0);   // beyond the end: harmless re-read of chunk 0
+#endif
             __builtin_amdgcn_sched_barrier(0);
             mf_fma(r1, acc0, acc1);
             __builtin_amdgcn_sched_barrier(0);
