@@ -3,7 +3,9 @@
 
 A "step" is one pass of the whole hot path (rotator + front-end decimator + per-mode resampler +
 filters + symbol sync + 2x Viterbi + descramblers) over one batch of synthetic IQ that is already
-resident in HBM.  Default workload = BASELINE.json configs[1]: GMSK 10 kbit/s RX chain on 25 Msps IQ.
+resident in HBM.  Default workload = BASELINE.json configs[1]: GMSK 10 kbit/s RX chain on 25 Msps IQ, 384 streams x
+1.6 M samples (65 ms of signal) per step = 5 GB of IQ per step.  (The serial symbol-sync tail costs ~0.4 us per symbol and stream:
+with 96 streams x 6.5 M samples it was longer than the front end and capped the whole chain at 219 GS/s.)
 The 2FSK-1k chain the north-star target is quoted on (configs[0], 1 Msps IQ) is measured too and
 reported under "north_star_c1" in the same JSON line.
 
@@ -27,7 +29,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 WORKLOADS = {
     # name: (label, sig mode, modem type, device rate, rx offset, default batch, default samples/stream, oracle mode)
     "c2": ("C2: GMSK-10k RX chain (gr_demod_base front end 25:1 + gr_demod_gmsk) on 25 Msps IQ",
-           "gmsk10k", 22, 25000000, 25000.0, 96, 25 * (1 << 18), 1),
+           "gmsk10k", 22, 25000000, 25000.0, 384, 25 * (1 << 16), 1),
     "c1": ("C1: 2FSK-1k RX chain (rotator + gr_demod_2fsk) on 1 Msps IQ",
            "2fsk1k", 18, 1000000, 1200.0, 16384, 1 << 18, 0),
     # not part of the default line (parity-test configs measured on request: --config c3 / c4)

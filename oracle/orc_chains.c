@@ -660,13 +660,17 @@ size_t orc_pfb_channelizer(const cf32* in, size_t n, const float* taps, int nt, 
             v[p].re = ar; v[p].im = ai;
         }
         for (int c = 0; c < M; c++) {
-            float yr = 0.f, yi = 0.f;
+            /* DFT summation contract: four real fmaf chains over the branches, p ascending, combined at the end -- what four
+             * f32 MFMA accumulators (W.re*v.re, W.im*v.im, W.im*v.re, W.re*v.im) produce on the GPU */
+            float sa = 0.f, sb = 0.f, sc = 0.f, sd = 0.f;
             for (int p = 0; p < M; p++) {
                 const cf32 w = W[(int)(((long long)p * c) % M)];
-                yr = yr + fmaf(v[p].re, w.re, -(v[p].im * w.im));
-                yi = yi + fmaf(v[p].re, w.im, v[p].im * w.re);
+                sa = fmaf(w.re, v[p].re, sa);
+                sb = fmaf(w.im, v[p].im, sb);
+                sc = fmaf(w.im, v[p].re, sc);
+                sd = fmaf(w.re, v[p].im, sd);
             }
-            out[(size_t)c * nout + m].re = yr; out[(size_t)c * nout + m].im = yi;
+            out[(size_t)c * nout + m].re = sa - sb; out[(size_t)c * nout + m].im = sc + sd;
         }
     }
     free(W); free(v);

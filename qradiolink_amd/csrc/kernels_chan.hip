@@ -14,6 +14,9 @@ namespace qrl {
 
 constexpr int CH_TI = 64;   // output instants per workgroup
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int STEPS>   // STEPS = M / 4 when M is a multiple of 16 (MFMA DFT), 0 = any M (VALU DFT)
 __global__ __launch_bounds__(256) void k_pfb_chan(const ChanParams P)
 {
     extern __shared__ __align__(16) unsigned char ch_smem[];
@@ -55,23 +58,66 @@ __global__ __launch_bounds__(256) void k_pfb_chan(const ChanParams P)
         vs[i * (M + 1) + p] = make_float2(ar, ai);
     }
     __syncthreads();
-    // phase 2: DFT bins of the owned channels
+    // phase 2: DFT bins of the owned channels.  Contract (oracle orc_pfb_channelizer): four real fmaf chains over the branches,
+    // p ascending -- sa = sum W.re v.re, sb = sum W.im v.im, sc = sum W.im v.re, sd = sum W.re v.im -- y = (sa - sb, sc + sd).
     const uint32_t count = P.m_count;
-    for (int w = tid; w < CH_TI * P.c_count; w += 256) {
-        const int cc = w / CH_TI, i = w - cc * CH_TI;             // instant fastest: coalesced ring writes
-        const int c = P.c_first + cc;
-        if (blockIdx.x * (uint32_t)CH_TI + i >= count) continue;
-        const float2* v = vs + i * (M + 1);
-        float yr = 0.f, yi = 0.f;
-        int q = 0;                                                // (p * c) mod M
-        for (int p = 0; p < M; ++p) {
-            const float2 wv = W[q];
-            yr = yr + fmaf(v[p].x, wv.x, -(v[p].y * wv.y));
-            yi = yi + fmaf(v[p].x, wv.y, v[p].y * wv.x);
-            q += c; if (q >= M) q -= M;
+    if constexpr (STEPS > 0) {
+        // M = 4 STEPS is a multiple of 16: the DFT is a [bins x branches] x [branches x instants] product on the f32 matrix
+        // pipe.  One MFMA block = 16 bins x 16 instants; A operand = twiddles W[(bin p) mod M] (rebuilt per bin block, held in
+        // registers), B operand = the branch outputs of phase 1 (one ds_read_b64 feeds the .re and the .im chains); four
+        // independent accumulators per block.  f32 MFMA accumulates in k order exactly like the fmaf chains of the contract.
+        const int lane = tid & 63, wv = tid >> 6;
+        const int qb0 = P.c_first >> 4, qb1 = (P.c_first + P.c_count - 1) >> 4;
+        const int nitems = (qb1 - qb0 + 1) * (CH_TI / 16);
+        for (int it = wv; it < nitems; it += 4) {
+            const int qb = qb0 + it / (CH_TI / 16), ib = it % (CH_TI / 16);
+            const int bin_a = 16 * qb + (lane & 15), k4 = lane >> 4;
+            float are[STEPS], aim[STEPS];
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const float2 wv2 = W[(bin_a * (4 * s + k4)) % M];
+                are[s] = wv2.x; aim[s] = wv2.y;
+            }
+            const float2* vb = vs + (16 * ib + (lane & 15)) * (M + 1) + k4;
+            f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, sb = sa, sc = sa, sd = sa;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const float2 v = vb[4 * s];
+                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(are[s], v.x, sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_16x16x4f32(aim[s], v.y, sb, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(aim[s], v.x, sc, 0, 0, 0);
+                sd = __builtin_amdgcn_mfma_f32_16x16x4f32(are[s], v.y, sd, 0, 0, 0);
+            }
+            const int i = 16 * ib + (lane & 15);
+            if (blockIdx.x * (uint32_t)CH_TI + i < count) {
+                const uint64_t m = m_t + i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int bin = 16 * qb + 4 * k4 + r, cc = bin - P.c_first;
+                    if (cc >= 0 && cc < P.c_count)
+                        P.out.p[((size_t)b * P.c_count + cc) * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = make_float2(sa[r] - sb[r], sc[r] + sd[r]);
+                }
+            }
         }
-        const uint64_t m = m_t + i;
-        P.out.p[((size_t)b * P.c_count + cc) * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = make_float2(yr, yi);
+    } else {
+        for (int w = tid; w < CH_TI * P.c_count; w += 256) {
+            const int cc = w / CH_TI, i = w - cc * CH_TI;             // instant fastest: coalesced ring writes
+            const int c = P.c_first + cc;
+            if (blockIdx.x * (uint32_t)CH_TI + i >= count) continue;
+            const float2* v = vs + i * (M + 1);
+            float sa = 0.f, sb = 0.f, sc = 0.f, sd = 0.f;
+            int q = 0;                                                // (p * c) mod M
+            for (int p = 0; p < M; ++p) {
+                const float2 wv = W[q];
+                sa = fmaf(wv.x, v[p].x, sa);
+                sb = fmaf(wv.y, v[p].y, sb);
+                sc = fmaf(wv.y, v[p].x, sc);
+                sd = fmaf(wv.x, v[p].y, sd);
+                q += c; if (q >= M) q -= M;
+            }
+            const uint64_t m = m_t + i;
+            P.out.p[((size_t)b * P.c_count + cc) * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = make_float2(sa - sb, sc + sd);
+        }
     }
 }
 
@@ -83,8 +129,23 @@ void launch_pfb_chan(const ChanParams& p, int batch, hipStream_t s)
 {
     if (!p.m_count) return;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pfb_chan), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL(k_pfb_chan, dim3((p.m_count + CH_TI - 1) / CH_TI, batch), dim3(256), chan_lds_bytes(p.M, p.J), s, p);
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pfb_chan<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pfb_chan<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pfb_chan<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pfb_chan<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pfb_chan<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    const dim3 grid((p.m_count + CH_TI - 1) / CH_TI, batch);
+    const size_t lds = chan_lds_bytes(p.M, p.J);
+    switch (p.M % 16 == 0 ? p.M / 4 : 0) {
+    case 4:  hipLaunchKernelGGL(k_pfb_chan<4>, grid, dim3(256), lds, s, p); break;
+    case 8:  hipLaunchKernelGGL(k_pfb_chan<8>, grid, dim3(256), lds, s, p); break;
+    case 12: hipLaunchKernelGGL(k_pfb_chan<12>, grid, dim3(256), lds, s, p); break;
+    case 16: hipLaunchKernelGGL(k_pfb_chan<16>, grid, dim3(256), lds, s, p); break;
+    default: hipLaunchKernelGGL(k_pfb_chan<0>, grid, dim3(256), lds, s, p); break;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_f2s(const F2sParams P)

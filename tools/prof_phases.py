@@ -5,7 +5,7 @@ import torch, qradiolink_amd as q
 ctx = q.Context(0)
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 if cfg == "c2":
-    B, N, rate, modem = 96, 25 * (1 << 18), 25000000, 22
+    B, N, rate, modem = 384, 25 * (1 << 16), 25000000, 22
 else:
     B, N, rate, modem = 16384, 1 << 18, 1000000, 18
 iq = torch.randn((B, N, 2), device="cuda").mul_(0.05)
