@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("QRL_LIB_PATH") or os.path.join(_HERE, "libqrl_hip.so"
 MODEM_2FSK2KFM, MODEM_2FSK1KFM, MODEM_2FSK2K, MODEM_2FSK1K, MODEM_2FSK10KFM = 15, 16, 17, 18, 19
 MODEM_GMSK2K, MODEM_GMSK1K, MODEM_GMSK10K = 20, 21, 22
 MODEM_QPSK250K = 26
+MODEM_QPSK20K, MODEM_QPSKVIDEO, MODEM_QPSK2K = 1, 2, 7
 MODEM_BPSK2K, MODEM_BPSK1K = 0, 24
 MODEM_4FSK10KFM, MODEM_4FSK2KFM, MODEM_4FSK1KFM, MODEM_4FSK100K = 4, 5, 6, 27
 MODEM_DMR = 41

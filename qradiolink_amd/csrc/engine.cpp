@@ -119,6 +119,7 @@ struct qrl_demod {
     bool tail_pending = false;
     // overlapped mode (2FSK / GMSK / 4FSK families): everything behind the first decimated ring runs on the tail stream while
     // the front end of the NEXT call already runs on the main stream; ring s2 holds two calls, ev_tail2 guards its reuse
+    bool qpsk_fll = false;
     bool overlap = false; hipEvent_t ev_tail2[2] = {nullptr, nullptr}; bool tail2_valid[2] = {false, false}; uint64_t call_no = 0;
     enum Family { F_2FSK, F_GMSK, F_QPSK, F_DMR, F_4FSK, F_BPSK } fam = F_2FSK;
     int branches = 2;
@@ -231,10 +232,14 @@ int qrl_demod::build()
         if (sps != 10 && sps != 5) return fail(QRL_ERR_ARG, "bpsk: sps must be 10 (BPSK1K) or 5 (BPSK2K)");
         target = 20000; sps_eff = sps; decim = 50; interp = 1;
     } else {
-        // gr_demod_qpsk.cpp:39-60: only the sps <= 4 geometry (QPSK250K: 1:2 decimation, no FLL) is built so far
-        if (sps > 4 || sps < 2) return fail(QRL_ERR_ARG, "qpsk: only sps 2..4 (e.g. QPSK250K) is supported by this build");
-        target = 500000; sps_eff = sps; decim = 2; interp = 1;
-        branches = 1;
+        // gr_demod_qpsk.cpp:39-60: sps <= 4 (QPSK250K / video: 1:2, no FLL), 4 < sps < 125 (QPSK20K: 1:25 to 40 ksps),
+        // sps >= 125 (QPSK2K: 1:100 to 10 ksps); the last two run fll_band_edge_cc in front of the shaping filter (:130-138)
+        if (sps < 2) return fail(QRL_ERR_ARG, "qpsk: sps must be >= 2");
+        if (sps > 4 && sps < 125) { target = 40000; sps_eff = sps * 4 / 25; decim = 25; }
+        else if (sps >= 125)      { target = 10000; sps_eff = sps / 25;     decim = 100; }
+        else                      { target = 500000; sps_eff = sps;         decim = 2; }
+        if (sps_eff < 2 || sps_eff > 10) return fail(QRL_ERR_ARG, "qpsk: unsupported samples per symbol");
+        interp = 1; branches = 1; qpsk_fll = sps > 4;
     }
     fm = cfg.fm != 0;
     const int B = cfg.batch;
@@ -287,7 +292,7 @@ int qrl_demod::build()
     s2_mask = pow2_at_least((overlap ? 2 : 1) * max2 + 1024) - 1;   // history needs: <= 501 taps downstream; overlapped mode: two calls
     const size_t ring2 = (size_t)B * (s2_mask + 1);
     if ((r = s2.alloc(ring2)) || (r = s2f.alloc(ring2)) || (r = s2d.alloc(ring2)) || (r = s3.alloc(ring2))) return r;
-    if ((fam == F_2FSK || fam == F_BPSK) && (r = s2l.alloc(ring2))) return r;
+    if ((fam == F_2FSK || fam == F_BPSK || (fam == F_QPSK && qpsk_fll)) && (r = s2l.alloc(ring2))) return r;
     const size_t maxsym = max2 / (size_t)(sps_eff > 1 ? sps_eff - 1 : 1) + 8;
     soft_mask = pow2_at_least((fam == F_QPSK || fam == F_4FSK ? 2 : 1) * maxsym + 512) - 1;
     if ((r = soft.alloc((size_t)B * (soft_mask + 1)))) return r;
@@ -360,7 +365,15 @@ int qrl_demod::build()
     } else if (fam == F_QPSK) {
         if ((r = tanh_tab.upload(tanh_table())) || (r = qp_st.alloc(B))) return r;
         control_loop_gains((float)(M_PI / 200 / sps_eff), c1_alpha, c1_beta);     // _costas_pll, gr_demod_qpsk.cpp:110
-        control_loop_gains((float)(M_PI / 400), c2_alpha, c2_beta);               // _costas_loop (sps <= 4), :112
+        control_loop_gains((float)(qpsk_fll ? M_PI / 200 : M_PI / 400), c2_alpha, c2_beta);   // _costas_loop, :44,67,112
+        if (qpsk_fll) {   // _fll = fll_band_edge_cc(sps, 0.35, 32, 2 pi / 100), :98-99
+            std::vector<std::complex<float>> lo, up;
+            fll_band_edge_taps((float)sps_eff, 0.35f, 32, lo, up);
+            if ((r = fll_lo.upload(to_f2(lo))) || (r = fll_up.upload(to_f2(up)))) return r;
+            control_loop_gains((float)(2 * M_PI / 100), fll_alpha, fll_beta);
+            fll_maxf = (float)(2 * M_PI * (2.0 / sps_eff));
+            if ((r = fll_st.alloc(B))) return r;
+        }
         const float symbol_rate = (float)target / (float)sps_eff;
         const float dev = 200.0f / symbol_rate;
         clock_loop_gains((float)(2 * M_PI / (symbol_rate / 10)), 1.0f, 0.2869f, ss_alpha, ss_beta);
@@ -469,10 +482,10 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
     const uint32_t c2 = (uint32_t)(n2_1 - n2_0);
     const bool side = cfg.enable_side_outputs && out;
     RingC filt_in = r2;
-    if (fam == F_2FSK || fam == F_BPSK) {
+    if (fam == F_2FSK || fam == F_BPSK || (fam == F_QPSK && qpsk_fll)) {
         FllParams f{};
         f.in = r2; f.out = r2l; f.q0 = n2_0; f.count = c2; f.st = fll_st.p;
-        f.lower = fll_lo.p; f.upper = fll_up.p; f.nt = fam == F_BPSK ? 32 : 16; f.alpha = fll_alpha; f.beta = fll_beta; f.max_freq = fll_maxf;
+        f.lower = fll_lo.p; f.upper = fll_up.p; f.nt = fam == F_2FSK ? 16 : 32; f.alpha = fll_alpha; f.beta = fll_beta; f.max_freq = fll_maxf;
         launch_fll(f, B, cs);
         filt_in = r2l;
     }
@@ -632,6 +645,9 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         case QRL_MODEM_GMSK1K:    c.sps = 10; c.filter_width = 2000;  c.fm = 0; break;
         case QRL_MODEM_GMSK10K:   c.sps = 1;  c.filter_width = 20000; c.fm = 0; break;
         case QRL_MODEM_QPSK250K:  c.sps = 2;  c.filter_width = 160000; c.fm = 0; break;   // gr_demod_base.cpp:223
+        case QRL_MODEM_QPSKVIDEO: c.sps = 2;  c.filter_width = 160000; c.fm = 0; break;   // :224
+        case QRL_MODEM_QPSK2K:    c.sps = 125; c.filter_width = 1300;  c.fm = 0; break;   // :221
+        case QRL_MODEM_QPSK20K:   c.sps = 25;  c.filter_width = 6500;  c.fm = 0; break;   // :222
         case QRL_MODEM_4FSK2KFM:  c.sps = 5;  c.filter_width = 3000;   c.fm = 1; break;   // gr_demod_base.cpp:212
         case QRL_MODEM_4FSK1KFM:  c.sps = 10; c.filter_width = 2000;   c.fm = 1; break;   // :213
         case QRL_MODEM_4FSK10KFM: c.sps = 1;  c.filter_width = 20000;  c.fm = 1; break;   // :214
@@ -647,7 +663,7 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         d->fam = qrl_demod::F_2FSK; break;
     case QRL_MODEM_GMSK2K: case QRL_MODEM_GMSK1K: case QRL_MODEM_GMSK10K:
         d->fam = qrl_demod::F_GMSK; break;
-    case QRL_MODEM_QPSK250K:
+    case QRL_MODEM_QPSK250K: case QRL_MODEM_QPSKVIDEO: case QRL_MODEM_QPSK2K: case QRL_MODEM_QPSK20K:
         d->fam = qrl_demod::F_QPSK; break;
     case QRL_MODEM_DMR:
         d->fam = qrl_demod::F_DMR; break;

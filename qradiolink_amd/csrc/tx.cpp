@@ -100,6 +100,9 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
         c.samp_rate = 1000000; c.carrier_freq = 1700; c.fm = 0;
         switch (c.modem_type) {
         case QRL_MODEM_QPSK250K:  c.sps = 4;   c.filter_width = 160000; break;
+        case QRL_MODEM_QPSKVIDEO: c.sps = 4;   c.filter_width = 160000; break;            // gr_mod_base.cpp:176
+        case QRL_MODEM_QPSK2K:    c.sps = 500; c.filter_width = 1300;  break;             // :173
+        case QRL_MODEM_QPSK20K:   c.sps = 100; c.filter_width = 6500;  break;             // :174
         case QRL_MODEM_2FSK2KFM:  c.sps = 25;  c.filter_width = 4000;  c.fm = 1; break;
         case QRL_MODEM_2FSK1KFM:  c.sps = 50;  c.filter_width = 2500;  c.fm = 1; break;
         case QRL_MODEM_2FSK2K:    c.sps = 25;  c.filter_width = 4000;  break;
@@ -118,7 +121,7 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
         }
     }
     switch (c.modem_type) {
-    case QRL_MODEM_QPSK250K: break;
+    case QRL_MODEM_QPSK250K: case QRL_MODEM_QPSKVIDEO: case QRL_MODEM_QPSK2K: case QRL_MODEM_QPSK20K: break;
     case QRL_MODEM_2FSK2KFM: case QRL_MODEM_2FSK1KFM: case QRL_MODEM_2FSK2K: case QRL_MODEM_2FSK1K: case QRL_MODEM_2FSK10KFM: fsk = true; break;
     case QRL_MODEM_GMSK2K: case QRL_MODEM_GMSK1K: case QRL_MODEM_GMSK10K: fsk = gmsk = true; break;
     case QRL_MODEM_4FSK2KFM: case QRL_MODEM_4FSK1KFM: case QRL_MODEM_4FSK10KFM: case QRL_MODEM_4FSK100K: fsk = fsk4 = true; break;
@@ -127,7 +130,7 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
     }
     m->bpsk = bpsk; m->fsk4 = fsk4;
     if (bpsk && (c.sps < 2 || c.sps > 1000)) return qrl_set_error(QRL_ERR_ARG, "modulator: bpsk sps out of range");
-    if (!fsk && !bpsk && (c.sps < 2 || c.sps > 10)) return qrl_set_error(QRL_ERR_ARG, "modulator: only the QPSK sps <= 10 geometry is built");
+    if (!fsk && !bpsk && (c.sps < 2 || c.sps > 1000)) return qrl_set_error(QRL_ERR_ARG, "modulator: qpsk sps out of range");
     m->sps = c.sps;
     m->bb_gain = c.bb_gain == 0.0f ? 1.0f : c.bb_gain;
     HIPCHK(hipSetDevice(ctx->device));
@@ -141,9 +144,10 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
     size_t ring_items = c.max_bytes * 8 + 256;   // symbol ring: one item per input bit (QPSK) or per coded bit (FSK: x2)
     if (!fsk) {
         const std::vector<float> rrc = bpsk ? root_raised_cosine(m->sps, m->sps, 1, 0.35, 11 * m->sps)   // gr_mod_bpsk.cpp:52-54
-                                            : root_raised_cosine(m->sps, m->sps, 1, 0.35, 15 * m->sps);  // nfilts = 15 for sps <= 10
+                                            : root_raised_cosine(m->sps, m->sps, 1, 0.35,             // gr_mod_qpsk.cpp:46-51
+                                                                 (m->sps > 120 ? 11 : m->sps > 10 ? 13 : 15) * m->sps);
         m->nt = (int)rrc.size();
-        if (!bpsk && m->nt > 256) return qrl_set_error(QRL_ERR_ARG, "modulator: pulse-shaping filter too long");
+        if (m->nt > 16384) return qrl_set_error(QRL_ERR_ARG, "modulator: pulse-shaping filter too long");
         if (bpsk) ring_items = c.max_bytes * 16 + 256;
         int r0 = upload(rrc, &m->taps);
         if (r0) return r0;

@@ -124,6 +124,8 @@ FSK_CASES = [
     (27, lambda d: orc.mod_4fsk(d, sps=2, filter_width=125000, fm=True), 2000),  # 4FSK100K (sps 2 -> 5 x 2)
     (24, lambda d: orc.mod_bpsk(d, sps=500, filter_width=1500), 24),             # BPSK1K (:168): 5501-tap RRC interpolator
     (0, lambda d: orc.mod_bpsk(d, sps=250, filter_width=2800), 40),              # BPSK2K
+    (7, lambda d: orc.mod_qpsk(d, sps=500, filter_width=1300), 40),              # QPSK2K (gr_mod_base.cpp:173): 11 x 500 tap RRC
+    (1, lambda d: orc.mod_qpsk(d, sps=100, filter_width=6500), 100),             # QPSK20K (:174): 13 x 100 taps
 ]
 
 
