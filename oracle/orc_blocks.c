@@ -409,7 +409,7 @@ size_t orc_symbol_sync_cc(const cf32* in, size_t n, int ted, float sps, float lo
                           float ted_gain, float max_dev, int constellation, cf32* out)
 {
     const float* T = orc_mmse_table();
-    (void)constellation; /* dqpsk: (+-0.707107, +-0.707107) by sign */
+    /* dqpsk: (+-0.707107, +-0.707107) by sign; 4-level rect (gr_demod_4fsk non-FM branch): real-axis sector point, imag 0 */
     clock_loop c; c.avg = sps; c.inst = sps; c.maxp = sps + max_dev; c.minp = sps - max_dev;
     orc_clock_loop_gains(loop_bw, damping, ted_gain, &c.alpha, &c.beta);
     cf32 x0 = {0, 0}, x1 = {0, 0}, x2 = {0, 0}, d0 = {0, 0}, d1 = {0, 0}, d2 = {0, 0};
@@ -424,7 +424,9 @@ size_t orc_symbol_sync_cc(const cf32* in, size_t n, int ted, float sps, float lo
             y.im = fmaf(t[7 - k], in[ii + (size_t)k].im, y.im);
         }
         x2 = x1; x1 = x0; x0 = y;
-        d2 = d1; d1 = d0; d0.re = y.re > 0 ? SQ : -SQ; d0.im = y.im > 0 ? SQ : -SQ;
+        d2 = d1; d1 = d0;
+        if (constellation == ORC_CONST_4LEVEL) { d0.re = slice_real(ORC_CONST_4LEVEL, y.re); d0.im = 0.0f; }
+        else { d0.re = y.re > 0 ? SQ : -SQ; d0.im = y.im > 0 ? SQ : -SQ; }
         float e;
         if (ted == ORC_TED_MM) {
             e = (d1.re * x0.re - d0.re * x1.re) + (d1.im * x0.im - d0.im * x1.im);

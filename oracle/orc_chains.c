@@ -398,13 +398,11 @@ static int16_t f2s(float x, float scale);
  * TED_MOD_MUELLER_AND_MULLER, sps, 2pi/200, 1.0, 0.2869, 0.05, 1, constellation_rect{-1.5..1.5}) -> phase_modulator_fc(pi/2)
  * [port 1] -> complex_to_float -> interleave(4) with (imag, real) port order -> x128 +128 -> uchar -> cc_decoder -> descrambler
  * [port 2].  blocks::interleave(itemsize 4, blocksize 1)?  No: make(4) is the ITEM SIZE (bytes of a float), blocksize defaults
- * to 1, so the soft stream is im0, re0, im1, re1, ...  The non-FM branch (4FSK2K: four band-pass magnitudes ->
- * gr_4fsk_discriminator -> symbol_sync_cc) is not restated yet. */
+ * to 1, so the soft stream is im0, re0, im1, re1, ...  */
 void orc_demod_4fsk(const cf32* in, size_t n, int sps, int samp_rate, int carrier_freq, int filter_width, int fm, orc_demod_out* o)
 {
     (void)carrier_freq;
     memset(o, 0, sizeof *o);
-    if (!fm) return;
     int target, sps_eff, decim, interp, nfilts;
     if (sps == 1)       { target = 80000;  sps_eff = 8;  decim = 25;  interp = 2; nfilts = 32 * 8; }
     else if (sps == 5)  { target = 20000;  sps_eff = 10; decim = 50;  interp = 1; nfilts = 25 * 10; }
@@ -425,6 +423,59 @@ void orc_demod_4fsk(const cf32* in, size_t n, int sps, int samp_rate, int carrie
     o->filtered = NEW(cf32, n1); o->n_filtered = n1;
     orc_fir_ccf(s1, n1, ft, nf, o->filtered);
     free(ft); free(s1);
+    if (!fm) {
+        /* non-FM branch (ModemType4FSK2K, gr_demod_4fsk.cpp:52-60,110-127,165-181,186-189): four complex band-pass filters ->
+         * complex_to_mag -> gr_4fsk_discriminator (strict arg-max, else 0) -> fft_filter_ccf(low_pass(1, T, T/sps, T/sps/20, BH))
+         * -> symbol_sync_cc(MOD_M&M, sps, 2pi/200, 1.0, 0.2869, 0.05, 1, constellation_4fsk) [port 1] -> (re, im) interleaved */
+        const int rs = sps == 1 ? 10000 : sps == 5 ? 2000 : 1000, bw = sps == 10 ? 2000 : 4000;
+        const int fw = filter_width;
+        const int lo_[4] = {-fw, -fw + rs, 0, fw - rs}, hi_[4] = {-fw + rs, 0, fw - rs, fw};
+        int nb = orc_complex_band_pass(1, target, lo_[0], hi_[0], bw, ORC_WIN_BLACKMAN_HARRIS, NULL);
+        float* mag[4];
+        cf32* bt = NEW(cf32, nb); cf32* fo = NEW(cf32, n1);
+        for (int q = 0; q < 4; q++) {
+            orc_complex_band_pass(1, target, lo_[q], hi_[q], bw, ORC_WIN_BLACKMAN_HARRIS, bt);
+            orc_fir_ccc(o->filtered, n1, bt, nb, fo);
+            mag[q] = NEW(float, n1 + 1);
+            for (size_t i = 0; i < n1; i++) mag[q][i] = sqrtf(fo[i].re * fo[i].re + fo[i].im * fo[i].im);
+        }
+        free(bt); free(fo);
+        cf32* dsc = NEW(cf32, n1 + 1);
+        const float A = (float)0.707107;
+        for (size_t i = 0; i < n1; i++) {
+            const float m1 = mag[0][i], m2 = mag[1][i], m3 = mag[2][i], m4 = mag[3][i];
+            cf32 v = {0.0f, 0.0f};
+            if (m1 > m2 && m1 > m3 && m1 > m4) { v.re = -A; v.im = -A; }
+            else if (m2 > m1 && m2 > m3 && m2 > m4) { v.re = -A; v.im = A; }
+            else if (m3 > m2 && m3 > m1 && m3 > m4) { v.re = A; v.im = A; }
+            else if (m4 > m2 && m4 > m1 && m4 > m3) { v.re = A; v.im = -A; }
+            dsc[i] = v;
+        }
+        for (int q = 0; q < 4; q++) free(mag[q]);
+        int ns = orc_low_pass(1.0, target, target / sps_eff, target / sps_eff / 20, ORC_WIN_BLACKMAN_HARRIS, NULL);
+        float* st = NEW(float, ns);
+        orc_low_pass(1.0, target, target / sps_eff, target / sps_eff / 20, ORC_WIN_BLACKMAN_HARRIS, st);
+        cf32* sf = NEW(cf32, n1 + 1);
+        orc_fir_ccf(dsc, n1, st, ns, sf);
+        free(st); free(dsc);
+        cf32* sy = NEW(cf32, n1 / (size_t)(sps_eff - 1) + 16);
+        size_t nsym = orc_symbol_sync_cc(sf, n1, ORC_TED_MOD_MM, (float)sps_eff, (float)(2 * M_PI / 200.0f), 1.0f, 0.2869f, 0.05f,
+                                         ORC_CONST_4LEVEL, sy);
+        free(sf);
+        o->constellation = NEW(cf32, nsym + 1); o->n_const = nsym;
+        float* fl2 = NEW(float, 2 * nsym + 2);
+        for (size_t i = 0; i < nsym; i++) { o->constellation[i] = sy[i]; fl2[2 * i] = sy[i].re; fl2[2 * i + 1] = sy[i].im; }
+        free(sy);
+        uint8_t* soft2 = NEW(uint8_t, 2 * nsym + 2);
+        orc_soft_quant(fl2, 2 * nsym, 128.0f, 128.0f, soft2);
+        free(fl2);
+        uint8_t* dec2 = NEW(uint8_t, nsym + 80);
+        size_t nb2 = orc_cc_decode_k7(soft2, 2 * nsym, dec2);
+        o->bits_a = NEW(uint8_t, nb2 + 1); o->n_bits_a = nb2;
+        orc_descramble(dec2, nb2, 0x8A, 0x7F, 7, o->bits_a);
+        free(soft2); free(dec2);
+        return;
+    }
     float* dem = NEW(float, n1);
     orc_quad_demod(o->filtered, n1, (float)(sps_eff / (1 * M_PI)), dem);
     int nr = orc_root_raised_cosine(1.5, target, target / sps_eff, 0.2, nfilts, NULL);

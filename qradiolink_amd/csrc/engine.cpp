@@ -119,7 +119,8 @@ struct qrl_demod {
     bool tail_pending = false;
     // overlapped mode (2FSK / GMSK / 4FSK families): everything behind the first decimated ring runs on the tail stream while
     // the front end of the NEXT call already runs on the main stream; ring s2 holds two calls, ev_tail2 guards its reuse
-    bool qpsk_fll = false;
+    bool qpsk_fll = false, fsk4_disc = false;
+    DevBuf<float2> s2g, disc4_taps; DevBuf<float> sym4_taps; int disc4_nt = 0, sym4_nt = 0;   // 4FSK non-FM branch
     bool overlap = false; hipEvent_t ev_tail2[2] = {nullptr, nullptr}; bool tail2_valid[2] = {false, false}; uint64_t call_no = 0;
     enum Family { F_2FSK, F_GMSK, F_QPSK, F_DMR, F_4FSK, F_BPSK } fam = F_2FSK;
     int branches = 2;
@@ -184,7 +185,7 @@ int qrl_demod::init_state()
     for (auto* b : {&s2d, &s3}) if (b->p && (r = b->zero())) return r;
     if ((r = soft.zero())) return r;
     if (fll_st.p && (r = fll_st.zero())) return r;
-    if (fam == F_QPSK || fam == F_BPSK) {
+    if (fam == F_QPSK || fam == F_BPSK || fsk4_disc) {
         std::vector<QpskState> qs(cfg.batch);
         for (auto& q : qs) { std::memset(&q, 0, sizeof q); q.gain = 1.0f; q.avg = q.inst = (float)sps_eff;
                              if (fam == F_BPSK) q.mu = 0.5f; }   // clock_recovery_mm_cc(mu = 0.5), gr_demod_bpsk.cpp:58-60
@@ -220,7 +221,8 @@ int qrl_demod::build()
         target = 24000; sps_eff = 5; decim = 125; interp = 3; branches = 1;
     } else if (fam == F_4FSK) {
         // gr_demod_4fsk.cpp:45-82 (FM branch only; the non-FM discriminator bank of 4FSK2K is not built)
-        if (!cfg.fm) return fail(QRL_ERR_ARG, "4fsk: only the FM variants (4FSK2KFM/1KFM/10KFM/100K) are built");
+        fsk4_disc = !cfg.fm;   // ModemType4FSK2K: four band-pass magnitudes -> gr_4fsk_discriminator -> symbol_sync_cc (:110-127,165-181)
+        if (fsk4_disc && sps == 2) return fail(QRL_ERR_ARG, "4fsk: the sps = 2 geometry exists as FM variant only (gr_demod_4fsk.cpp:78-85 sets no rs/bw)");
         if (sps == 1)       { target = 80000;  sps_eff = 8;  decim = 25;  interp = 2; }
         else if (sps == 5)  { target = 20000;  sps_eff = 10; decim = 50;  interp = 1; }
         else if (sps == 10) { target = 10000;  sps_eff = 10; decim = 100; interp = 1; }
@@ -287,7 +289,7 @@ int qrl_demod::build()
     {
         const char* on = std::getenv("QRL_OVERLAP"); const char* off = std::getenv("QRL_NO_OVERLAP");
         overlap = fam == F_2FSK || ((fam == F_GMSK || fam == F_4FSK) && on && on[0] == '1');
-        if (off && off[0] == '1') overlap = false;
+        if ((off && off[0] == '1') || fsk4_disc) overlap = false;   // (the non-FM 4FSK tail runs on the main stream)
     }
     s2_mask = pow2_at_least((overlap ? 2 : 1) * max2 + 1024) - 1;   // history needs: <= 501 taps downstream; overlapped mode: two calls
     const size_t ring2 = (size_t)B * (s2_mask + 1);
@@ -344,6 +346,23 @@ int qrl_demod::build()
         demod_gain = (float)(target / (M_PI / 2 * (float)(target / sps_eff)));                               // :72
         clock_loop_gains((float)(2 * M_PI / 100.0f), 1.0f, 0.2869f, ss_alpha, ss_beta);                      // :70-71
         ss_maxp = (float)sps_eff + 0.06f; ss_minp = (float)sps_eff - 0.06f;
+    } else if (fam == F_4FSK && fsk4_disc) {
+        const int rs = sps == 1 ? 10000 : sps == 5 ? 2000 : 1000, bw = sps == 10 ? 2000 : 4000;           // gr_demod_4fsk.cpp:45-76
+        const int lo_[4] = {-fw, -fw + rs, 0, fw - rs}, hi_[4] = {-fw + rs, 0, fw - rs, fw};                  // _filter1..4, :112-119
+        std::vector<float2> bt;
+        for (int q = 0; q < 4; ++q) {
+            const auto t4 = complex_band_pass(1, target, lo_[q], hi_[q], bw, WIN_BLACKMAN_HARRIS);
+            disc4_nt = (int)t4.size();
+            const auto f2 = to_f2(t4);
+            bt.insert(bt.end(), f2.begin(), f2.end());
+        }
+        if ((r = disc4_taps.upload(bt))) return r;
+        const std::vector<float> st4 = low_pass(1.0, target, target / sps_eff, target / sps_eff / 20, WIN_BLACKMAN_HARRIS);   // :103-105
+        sym4_nt = (int)st4.size();
+        if ((r = sym4_taps.upload(st4)) || (r = s2g.alloc(ring2)) || (r = s2l.alloc(ring2))) return r;
+        if ((r = tanh_tab.upload(tanh_table())) || (r = qp_st.alloc(B))) return r;
+        clock_loop_gains((float)(2 * M_PI / 200.0f), 1.0f, 0.2869f, ss_alpha, ss_beta);                      // :138-140
+        ss_maxp = (float)sps_eff + 0.05f; ss_minp = (float)sps_eff - 0.05f;
     } else if (fam == F_4FSK) {
         int nfilts = (sps == 1 ? 32 : sps == 2 ? 50 : 25) * sps_eff;                                         // gr_demod_4fsk.cpp:45-84
         if ((nfilts % 2) == 0) nfilts += 1;
@@ -519,6 +538,12 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         }
         if (fam == F_QPSK || fam == F_BPSK) {
             // recursive chain + Viterbi below; nothing else at the sample rate
+        } else if (fsk4_disc) {
+            RingC r2l4{s2l.p, s2_mask}, r2g{s2g.p, s2_mask};
+            Disc4fskParams d{}; d.in = r2f; d.out = r2l4; d.q0 = n2_0; d.count = c2; d.taps = disc4_taps.p; d.nt = disc4_nt;
+            launch_disc_4fsk(d, B, cs);
+            FirCcfParams f{}; f.in = r2l4; f.out = r2g; f.q0 = n2_0; f.count = c2; f.taps = sym4_taps.p; f.nt = sym4_nt;   // _symbol_filter
+            launch_fir_ccf(f, B, cs);
         } else if (fam == F_GMSK || fam == F_4FSK || fm) {
             QuadDemodParams q{}; q.in = r2f; q.out = r2d; q.q0 = n2_0; q.count = c2; q.gain = demod_gain; q.atan_tab = atan_tab.p;
             launch_quad_demod(q, B, cs);
@@ -526,7 +551,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
             Disc2fskParams d{}; d.in = r2f; d.out = r2d; d.q0 = n2_0; d.count = c2; d.up = disc_up.p; d.lo = disc_lo.p; d.nt = disc_nt;
             launch_disc_2fsk(d, B, cs);
         }
-        if (fam == F_QPSK || fam == F_BPSK) {
+        if (fam == F_QPSK || fam == F_BPSK || fsk4_disc) {
             // the tail reads r2f (written by k_fir_ccf above): it runs on the handle's own stream for these families
         } else {
             // r3 is what the previous call's tail (other stream) may still be reading
@@ -537,13 +562,14 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         }
     }
     // ---- stage D: symbol sync + FEC
-    if (fam == F_QPSK || fam == F_BPSK) {
+    if (fam == F_QPSK || fam == F_BPSK || fsk4_disc) {
         QpskParams q{};
-        q.in = r2f; q.np0 = n2_0; q.avail = n2_1; q.soft = RingB{soft.p, soft_mask}; q.st = qp_st.p;
+        q.in = fsk4_disc ? RingC{s2g.p, s2_mask} : r2f; q.np0 = n2_0; q.avail = n2_1; q.soft = RingB{soft.p, soft_mask}; q.st = qp_st.p;
         q.mmse = mmse_tab.p; q.tanh_tab = tanh_tab.p;
         q.c1_alpha = c1_alpha; q.c1_beta = c1_beta; q.c2_alpha = c2_alpha; q.c2_beta = c2_beta;
         q.ss_alpha = ss_alpha; q.ss_beta = ss_beta; q.ss_maxp = ss_maxp; q.ss_minp = ss_minp;
         q.rot = qp_rot; q.soft_mul = 48.0f; q.soft_add = 128.0f;
+        if (fsk4_disc) { q.mode = 2; q.soft_mul = 128.0f; }   // gr_demod_4fsk.cpp:138-146,186-195
         if (fam == F_BPSK) {   // gr_demod_bpsk.cpp:54-62,67
             q.mode = 1; q.soft_mul = 64.0f;
             const float gain_omega = 0.005f;
@@ -648,6 +674,7 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         case QRL_MODEM_QPSKVIDEO: c.sps = 2;  c.filter_width = 160000; c.fm = 0; break;   // :224
         case QRL_MODEM_QPSK2K:    c.sps = 125; c.filter_width = 1300;  c.fm = 0; break;   // :221
         case QRL_MODEM_QPSK20K:   c.sps = 25;  c.filter_width = 6500;  c.fm = 0; break;   // :222
+        case QRL_MODEM_4FSK2K:    c.sps = 5;  c.filter_width = 4000;   c.fm = 0; break;   // gr_demod_base.cpp:211
         case QRL_MODEM_4FSK2KFM:  c.sps = 5;  c.filter_width = 3000;   c.fm = 1; break;   // gr_demod_base.cpp:212
         case QRL_MODEM_4FSK1KFM:  c.sps = 10; c.filter_width = 2000;   c.fm = 1; break;   // :213
         case QRL_MODEM_4FSK10KFM: c.sps = 1;  c.filter_width = 20000;  c.fm = 1; break;   // :214
@@ -667,7 +694,7 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         d->fam = qrl_demod::F_QPSK; break;
     case QRL_MODEM_DMR:
         d->fam = qrl_demod::F_DMR; break;
-    case QRL_MODEM_4FSK2KFM: case QRL_MODEM_4FSK1KFM: case QRL_MODEM_4FSK10KFM: case QRL_MODEM_4FSK100K:
+    case QRL_MODEM_4FSK2K: case QRL_MODEM_4FSK2KFM: case QRL_MODEM_4FSK1KFM: case QRL_MODEM_4FSK10KFM: case QRL_MODEM_4FSK100K:
         d->fam = qrl_demod::F_4FSK; break;
     case QRL_MODEM_BPSK1K: case QRL_MODEM_BPSK2K:
         d->fam = qrl_demod::F_BPSK; break;

@@ -70,6 +70,8 @@ struct FirCcfParams { RingC in; RingC out; uint64_t q0; uint32_t count; const fl
 struct FirFffParams { RingF in; RingF out; uint64_t q0; uint32_t count; const float* taps; int nt; };
 struct QuadDemodParams { RingC in; RingF out; uint64_t q0; uint32_t count; float gain; const float* atan_tab; };
 struct Disc2fskParams { RingC in; RingF out; uint64_t q0; uint32_t count; const float2* up; const float2* lo; int nt; };
+struct Disc4fskParams { RingC in; RingC out; uint64_t q0; uint32_t count; const float2* taps; int nt; };   // taps[4][nt]
+void launch_disc_4fsk(const Disc4fskParams& p, int batch, hipStream_t s);
 struct Fsk2FfParams { RingC in; RingF out; uint64_t q0; uint32_t count;
                       const float* tf; int nf; const float2* up; const float2* lo; int nb; const float* ts; int ns;
                       float2* port; size_t port_cap; uint32_t* counts; };
@@ -119,7 +121,8 @@ struct QpskParams {
     float c1_alpha, c1_beta, c2_alpha, c2_beta;
     float ss_alpha, ss_beta, ss_maxp, ss_minp;
     float2 rot; float soft_mul, soft_add;
-    int mode;                        // 0: gr_demod_qpsk chain; 1: gr_demod_bpsk chain (agc2 -> clock_recovery_mm_cc -> costas order 2)
+    int mode;                        // 0: gr_demod_qpsk chain; 1: gr_demod_bpsk chain (agc2 -> clock_recovery_mm_cc -> costas order 2);
+                                     // 2: symbol_sync_cc alone on the 4-level rect constellation (gr_demod_4fsk non-FM branch)
     float cr_gain_omega, cr_gain_mu, cr_omega_mid, cr_omega_lim;   // mode 1
     float2* port; size_t port_cap; uint32_t* counts;   // constellation port (this call), counts[b*4+1]
 };

@@ -176,6 +176,40 @@ __global__ __launch_bounds__(256) void k_disc_2fsk(const Disc2fskParams P)
     if (r > 2.0f) r = 2.0f;
     P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = r + (-1.0f);
 }
+// gr_demod_4fsk non-FM branch (gr_demod_4fsk.cpp:110-127,165-176 + gr_4fsk_discriminator::work, gr_4fsk_discriminator.cpp:17-44):
+// four complex band-pass filters -> complex_to_mag -> strict arg-max -> one of (+-0.707107, +-0.707107), else 0
+__global__ __launch_bounds__(256) void k_disc_4fsk(const Disc4fskParams P)
+{
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.count) return;
+    const int64_t n = (int64_t)(P.q0 + t);
+    float re[4] = {0.f, 0.f, 0.f, 0.f}, im[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < P.nt; ++k) {
+        const float2 x = ringc_at(P.in, b, n - k);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float2 h = P.taps[q * P.nt + k];
+            re[q] = fmaf(h.x, x.x, re[q]); re[q] = fmaf(-h.y, x.y, re[q]);
+            im[q] = fmaf(h.x, x.y, im[q]); im[q] = fmaf(h.y, x.x, im[q]);
+        }
+    }
+    const float m1 = sqrtf(re[0] * re[0] + im[0] * im[0]), m2 = sqrtf(re[1] * re[1] + im[1] * im[1]);
+    const float m3 = sqrtf(re[2] * re[2] + im[2] * im[2]), m4 = sqrtf(re[3] * re[3] + im[3] * im[3]);
+    const float A = 0.707107f;
+    float2 v = make_float2(0.f, 0.f);
+    if (m1 > m2 && m1 > m3 && m1 > m4) v = make_float2(-A, -A);
+    else if (m2 > m1 && m2 > m3 && m2 > m4) v = make_float2(-A, A);
+    else if (m3 > m2 && m3 > m1 && m3 > m4) v = make_float2(A, A);
+    else if (m4 > m2 && m4 > m1 && m4 > m3) v = make_float2(A, -A);
+    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = v;
+}
+void launch_disc_4fsk(const Disc4fskParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_disc_4fsk, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
+}
+
 void launch_disc_2fsk(const Disc2fskParams& p, int batch, hipStream_t s)
 {
     if (!p.count) return;

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
             const int ca = (int)(max((long long)np0, k * QP_W) - i0), cb = (int)(min((long long)avail, (k + 1) * QP_W) - i0);
             if (active) {
                 for (int c = ca; c < cb; ++c) {
+                    if (MODE == 2) break;   // symbol_sync_cc consumes the samples as they are
                     const float2 x = row[c];
                     float2 a; a.x = x.x * st.gain; a.y = x.y * st.gain;
                     const float tmp = -1.0f + sqrtf(a.x * a.x + a.y * a.y);
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
                 nsym++;
                 st.oo++;
             }
-            while (MODE == 0 && active && st.ii + 8 <= wend && nsym < QP_OMAX) {
+            while (MODE != 1 && active && st.ii + 8 <= wend && nsym < QP_OMAX) {
                 const int off = (int)((long long)st.ii - i0);
                 const int imu = (int)rintf(st.mu * 128.0f);
                 const float* t = mm + imu * 8;
@@ -223,7 +224,13 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
                 }
                 st.x2 = st.x1; st.x1 = st.x0; st.x0 = y;
                 st.d2 = st.d1; st.d1 = st.d0;
-                st.d0.x = y.x > 0.f ? SQ : -SQ; st.d0.y = y.y > 0.f ? SQ : -SQ;
+                if (MODE == 2) {   // constellation_rect{-1.5,-0.5,0.5,1.5}: real-axis sector point, imag 0 (oracle slice_real)
+                    int sector = (int)((double)y.x + 2.0);
+                    sector = sector < 0 ? 0 : (sector > 3 ? 3 : sector);
+                    st.d0.x = (float)sector - 1.5f; st.d0.y = 0.0f;
+                } else {
+                    st.d0.x = y.x > 0.f ? SQ : -SQ; st.d0.y = y.y > 0.f ? SQ : -SQ;
+                }
                 float e;
                 {
                     const float ar = st.x0.x - st.x2.x, ai = st.x0.y - st.x2.y;
@@ -239,6 +246,7 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
                 const float fl = floorf(ph);
                 st.mu = ph - fl;
                 st.ii += (uint64_t)(int)fl;
+                if (MODE == 2) { orow[nsym] = y; nsym++; st.oo++; continue; }
                 // second Costas loop at the symbol rate
                 const float2 nco = sincos_rad(-st.c2_phase);
                 float2 o; o.x = y.x * nco.x - y.y * nco.y; o.y = y.x * nco.y + y.y * nco.x;
@@ -291,9 +299,11 @@ void launch_qpsk_loops(const QpskParams& p, int batch, hipStream_t s)
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qpsk_loops<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qpsk_lds_bytes());
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qpsk_loops<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qpsk_lds_bytes());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qpsk_loops<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qpsk_lds_bytes());
         attr = true;
     }
-    if (p.mode == 1) hipLaunchKernelGGL(k_qpsk_loops<1>, dim3((batch + 63) / 64), dim3(256), qpsk_lds_bytes(), s, p, batch);
+    if (p.mode == 2) hipLaunchKernelGGL(k_qpsk_loops<2>, dim3((batch + 63) / 64), dim3(256), qpsk_lds_bytes(), s, p, batch);
+    else if (p.mode == 1) hipLaunchKernelGGL(k_qpsk_loops<1>, dim3((batch + 63) / 64), dim3(256), qpsk_lds_bytes(), s, p, batch);
     else             hipLaunchKernelGGL(k_qpsk_loops<0>, dim3((batch + 63) / 64), dim3(256), qpsk_lds_bytes(), s, p, batch);
 }
 

@@ -111,6 +111,7 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
         case QRL_MODEM_GMSK2K:    c.sps = 50;  c.filter_width = 4000;  break;
         case QRL_MODEM_GMSK1K:    c.sps = 100; c.filter_width = 2000;  break;
         case QRL_MODEM_GMSK10K:   c.sps = 10;  c.filter_width = 20000; break;
+        case QRL_MODEM_4FSK2K:    c.sps = 25;  c.filter_width = 4000;  break;             // gr_mod_base.cpp:163 (non-FM: repeat, spacing 2)
         case QRL_MODEM_4FSK2KFM:  c.sps = 25;  c.filter_width = 3500;  c.fm = 1; break;   // gr_mod_base.cpp:164
         case QRL_MODEM_4FSK1KFM:  c.sps = 50;  c.filter_width = 2000;  c.fm = 1; break;   // :165
         case QRL_MODEM_4FSK10KFM: c.sps = 5;   c.filter_width = 20000; c.fm = 1; break;   // :166
@@ -124,7 +125,7 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
     case QRL_MODEM_QPSK250K: case QRL_MODEM_QPSKVIDEO: case QRL_MODEM_QPSK2K: case QRL_MODEM_QPSK20K: break;
     case QRL_MODEM_2FSK2KFM: case QRL_MODEM_2FSK1KFM: case QRL_MODEM_2FSK2K: case QRL_MODEM_2FSK1K: case QRL_MODEM_2FSK10KFM: fsk = true; break;
     case QRL_MODEM_GMSK2K: case QRL_MODEM_GMSK1K: case QRL_MODEM_GMSK10K: fsk = gmsk = true; break;
-    case QRL_MODEM_4FSK2KFM: case QRL_MODEM_4FSK1KFM: case QRL_MODEM_4FSK10KFM: case QRL_MODEM_4FSK100K: fsk = fsk4 = true; break;
+    case QRL_MODEM_4FSK2K: case QRL_MODEM_4FSK2KFM: case QRL_MODEM_4FSK1KFM: case QRL_MODEM_4FSK10KFM: case QRL_MODEM_4FSK100K: fsk = fsk4 = true; break;
     case QRL_MODEM_BPSK1K: case QRL_MODEM_BPSK2K: bpsk = true; break;
     default: return qrl_set_error(QRL_ERR_ARG, "modulator: modem_type not supported by this build");
     }

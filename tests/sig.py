@@ -17,6 +17,7 @@ MODES = {
     "qpsk2k": (orc.mod_qpsk, dict(sps=500, filter_width=1300), bytes([0xED, 0x89, 0xAA]), 7, 5.0, -6.0),
     "qpsk20k": (orc.mod_qpsk, dict(sps=100, filter_width=6500), bytes([0xED, 0x89, 0xAA]), 47, 20.0, 2.0),
     # native 4FSK (FM variants; no FLL in gr_demod_4fsk, so only a small CFO) and BPSK
+    "4fsk2k": (orc.mod_4fsk, dict(sps=25, filter_width=4000, fm=False), bytes([0xED, 0x89, 0xAA]), 7, 15.0, 0.0),
     "4fsk2kfm": (orc.mod_4fsk, dict(sps=25, filter_width=3500, fm=True), bytes([0xED, 0x89, 0xAA]), 7, 15.0, 0.0),
     "4fsk1kfm": (orc.mod_4fsk, dict(sps=50, filter_width=2000, fm=True), bytes([0xB5]), 4, 10.0, 0.0),
     "4fsk10kfm": (orc.mod_4fsk, dict(sps=5, filter_width=20000, fm=True), bytes([0xED, 0x89, 0xAA]), 47, 40.0, 8.0),

@@ -34,6 +34,8 @@ def _oracle(mode_name, x, device_rate, offset):
         return orc.demod_qpsk(fe, sps=125, filter_width=1300)
     if mode_name == "qpsk20k":
         return orc.demod_qpsk(fe, sps=25, filter_width=6500)
+    if mode_name == "4fsk2k":
+        return orc.demod_4fsk(fe, sps=5, filter_width=4000, fm=False)
     if mode_name.startswith("4fsk"):
         sps, fw = {"4fsk2kfm": (5, 3000), "4fsk1kfm": (10, 2000), "4fsk10kfm": (1, 20000), "4fsk100k": (2, 125000)}[mode_name]
         return orc.demod_4fsk(fe, sps=sps, filter_width=fw, fm=True)
@@ -73,6 +75,7 @@ def _compare(iq, out, mode_name, device_rate, offset):
     ("gmsk10k", 22, 100000000, 1 << 24),    # front end 100:1, 4181 taps: only the 4-block MFMA tile fits the LDS
     ("qpsk2k", 7, 1000000, 1 << 21),        # gr_demod_qpsk sps >= 125: 1:100 (3621 taps), FLL(32 taps), 5 samples per symbol
     ("qpsk20k", 1, 2000000, 1 << 22),       # gr_demod_qpsk 4 < sps < 125: 1:25, FLL, 4 samples per symbol
+    ("4fsk2k", 3, 1000000, 1 << 21),        # gr_demod_4fsk non-FM branch: 4 band-pass magnitudes -> discriminator -> 837-tap LPF -> symbol_sync_cc
     ("4fsk2kfm", 5, 1000000, 1 << 21),      # gr_demod_4fsk FM branch: 4-level symbol_sync_ff, phase_modulator, (imag, real) soft pairs
     ("4fsk1kfm", 6, 2000000, 1 << 22),
     ("4fsk10kfm", 4, 4000000, 1 << 22),     # 2/25 resampler to 80 ksps, 8 samples per symbol
@@ -105,7 +108,7 @@ def test_chunk_invariance_2fsk(qrl_ctx, chunk):
     _compare(iq, out, "2fsk1k", 1000000, 1200.0)
 
 
-@pytest.mark.parametrize("mode_name,modem,chunk", [("qpsk2k", 7, 60000), ("qpsk20k", 1, 33334), ("4fsk2kfm", 5, 50000), ("4fsk100k", 27, 20002), ("bpsk1k", 24, 65536),
+@pytest.mark.parametrize("mode_name,modem,chunk", [("4fsk2k", 3, 44444), ("qpsk2k", 7, 60000), ("qpsk20k", 1, 33334), ("4fsk2kfm", 5, 50000), ("4fsk100k", 27, 20002), ("bpsk1k", 24, 65536),
                                                    ("bpsk2k", 0, 30000)])
 def test_chunk_invariance_4fsk_bpsk(qrl_ctx, mode_name, modem, chunk):
     iq, out = _run(qrl_ctx, mode_name, modem, 1000000, 700.0, B=2, chunk=chunk, nframes=2)

@@ -126,6 +126,7 @@ FSK_CASES = [
     (0, lambda d: orc.mod_bpsk(d, sps=250, filter_width=2800), 40),              # BPSK2K
     (7, lambda d: orc.mod_qpsk(d, sps=500, filter_width=1300), 40),              # QPSK2K (gr_mod_base.cpp:173): 11 x 500 tap RRC
     (1, lambda d: orc.mod_qpsk(d, sps=100, filter_width=6500), 100),             # QPSK20K (:174): 13 x 100 taps
+    (3, lambda d: orc.mod_4fsk(d, sps=25, filter_width=4000, fm=False), 40),     # 4FSK2K (:163): repeat(sps), spacing 2
 ]
 
 

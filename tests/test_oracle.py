@@ -276,6 +276,7 @@ def test_dmr_4fsk_oracle_recovers_dibits():
 # ---- native 4FSK (FM variants) and BPSK chains (gr_demod_4fsk.cpp, gr_demod_bpsk.cpp): the oracle's modulator through a
 # seeded channel into the oracle's demodulator returns the frames
 NEW_MODES = {
+    "4fsk2k": (bytes([0xED, 0x89, 0xAA]), 56, lambda fe: orc.demod_4fsk(fe, sps=5, filter_width=4000, fm=False)),
     "4fsk2kfm": (bytes([0xED, 0x89, 0xAA]), 56, lambda fe: orc.demod_4fsk(fe, sps=5, filter_width=3000, fm=True)),
     "4fsk1kfm": (bytes([0xB5]), 32, lambda fe: orc.demod_4fsk(fe, sps=10, filter_width=2000, fm=True)),
     "4fsk10kfm": (bytes([0xED, 0x89, 0xAA]), 47 * 8, lambda fe: orc.demod_4fsk(fe, sps=1, filter_width=20000, fm=True)),
