@@ -321,6 +321,9 @@ __device__ __forceinline__ void mfma_piece(const float* __restrict__ ap, const B
 // Compiler-scheduled variant of the same ping-pong (plain LDS reads, sched_barrier pinned).  It is the DEFAULT:
 // the asm variant above is ~5 % faster but showed rare (1e-4 per tile) wrong outputs with two workgroups per
 // CU at 25 Msps that could not be explained; build with -DQRL_MF_ASM_LDS=1 to select it for experiments.
+#ifndef QRL_MF_INTERLEAVE
+#define QRL_MF_INTERLEAVE 1
+#endif
 #ifndef QRL_MF_VOLATILE_LDS
 #define QRL_MF_VOLATILE_LDS 1
 #endif
@@ -388,14 +391,37 @@ __device__ __forceinline__ void mfma_piece_c(const float* __restrict__ ap, const
             if (i == 0)
 #endif
             r1.load(ap, bp, i + U);
+#if !QRL_MF_INTERLEAVE
             __builtin_amdgcn_sched_barrier(0);
+#endif
             mf_fma(r0, acc0, acc1);
+#if QRL_MF_INTERLEAVE
+            // the wave issues in order and blocks at an MFMA while the pipe is busy (32 cycles per v_mfma_f32_16x16x4_f32, one
+            // dependent chain already runs at that rate: tools/ubench/mfma_chain.hip); everything issued BETWEEN two MFMAs is
+            // free, a block of operand reads behind 16 MFMAs is not.  Interleave: one LDS read group after every MFMA.
+            {
+                constexpr int NM = BS == 4 ? 2 * U : U, RD = 2 * U / NM;   // MFMAs per chunk; operand reads per MFMA
+#pragma unroll
+                for (int k = 0; k < NM; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, RD, 0); }
+            }
             __builtin_amdgcn_sched_barrier(0);
+#else
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #if QRL_MF_EXP != 1
             r0.load(ap, bp, i + 3 * U <= n ? i + 2 * U : 0);   // beyond the end: harmless re-read of chunk 0
 #endif
+#if !QRL_MF_INTERLEAVE
             __builtin_amdgcn_sched_barrier(0);
+#endif
             mf_fma(r1, acc0, acc1);
+#if QRL_MF_INTERLEAVE
+            {
+                constexpr int NM = BS == 4 ? 2 * U : U, RD = 2 * U / NM;
+#pragma unroll
+                for (int k = 0; k < NM; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x100, RD, 1); }
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             i += 2 * U;
         }
