@@ -248,6 +248,7 @@ def main():
         print(json.dumps(line))
     ctx.close()
     if world > 1:
+        torch.distributed.barrier()   # rank 0 is behind by the CPU baseline: leave together
         torch.distributed.destroy_process_group()
 
 
