@@ -206,6 +206,31 @@ size_t qrl_chan_out_cap(const qrl_chan* c, size_t n);   /* int16 samples per cha
 int qrl_chan_process(qrl_chan* c, const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts);
 int qrl_chan_sync(qrl_chan* c);
 
+/* ---- multi-carrier MMDVM transmitter (reference src/gr/gr_mod_mmdvm_multi2.cpp:30-128) -------------------------------------
+ * make_gr_mod_mmdvm_multi2(burst_timer, num_channels, channel_separation, use_tdma, sps, samp_rate, carrier_freq,
+ * filter_width): per channel short_to_float(1, 32767) -> frequency_modulator_fc(2 pi 12500 / 24000) -> fft_filter_ccf ->
+ * x0.8 -> rational_resampler_ccf(25, 24) -> pfb_synthesizer_ccf(10, ..., false) on ports {0,1,2,3,9,8,7} -> x(1 / num_channels)
+ * -> bb gain.  in[(b*num_channels + ch)*stride + i], i < n: the int16 FM baseband gr_mmdvm_source hands out at 24 ksps
+ * (src/gr/gr_mmdvm_source.cpp:180-243; its ZeroMQ framing and the tag-driven gr_zero_idle_bursts stay with the caller);
+ * iq[2*(b*out_stride + k)]: the 250 ksps cf32 wideband signal, *produced (host) samples per stream for this call
+ * (<= qrl_synth_out_cap(n)).  State carries across calls; asynchronous on the handle's stream. */
+typedef struct qrl_synth qrl_synth;
+typedef struct {
+    int num_channels;        /* 1..7 (MAX_MMDVM_CHANNELS) */
+    int filter_width;        /* 0 = 5000 (gr_mod_mmdvm_multi2.h:38-41) */
+    int batch;               /* independent transmitters */
+    size_t max_samples;      /* largest n of any call */
+    void* hip_stream;
+    float bb_gain;           /* gr_mod_mmdvm_multi2::set_bb_gain, 0 = 1.0 */
+} qrl_synth_config;
+int qrl_synth_create(qrl_ctx* ctx, const qrl_synth_config* cfg, qrl_synth** out);
+void qrl_synth_destroy(qrl_synth* s);
+int qrl_synth_reset(qrl_synth* s);
+int qrl_synth_set_bb_gain(qrl_synth* s, float value);
+size_t qrl_synth_out_cap(const qrl_synth* s, size_t n);
+int qrl_synth_process(qrl_synth* s, const int16_t* in, size_t stride, size_t n, float* iq, size_t out_stride, size_t* produced);
+int qrl_synth_sync(qrl_synth* s);
+
 /* ---- device deframer (reference src/gr/gr_deframer_bb.cpp:24-48,83-185; instances gr_demod_base.cpp:171-178) -----------
  * make_gr_deframer_bb(modem_type): 1 = 2k modes (16/24-bit sync words, 64 bits per frame), 2 = 1k modes (0xB5, 32 bits),
  * 3 = 10k modes (384 bits).  qrl_deframer_process consumes the unpacked bits of one demodulator port (bits[b*stride + i];

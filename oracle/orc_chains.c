@@ -839,6 +839,70 @@ size_t orc_demod_mmdvm_xlating(const cf32* in, size_t n, int N, int separation, 
     return m;
 }
 
+/* multi-carrier MMDVM transmitter gr_mod_mmdvm_multi2.cpp:30-128: per channel short_to_float(1, 32767) -> x1.0 ->
+ * frequency_modulator_fc(2 pi 12500 / 24000) -> fft_filter_ccf(low_pass_2(1, 24k, fw, 2000, 60, BH)) -> x0.8 ->
+ * rational_resampler_ccf(25, 24, low_pass_2(25, 600k, fw, 2000, 60, BH)) -> [gr_zero_idle_bursts: tag driven, pass-through here]
+ * -> pfb_synthesizer_ccf(10, low_pass_2(10, 250k, fw, 2000, 60, BH), false) ports {0,1,2,3,9,8,7}, idle ports zero -> x(1/N).
+ * pfb_synthesizer_ccf [gr-filter/lib/pfb_synthesizer_ccf_impl.cc, twox = false]: per block n the M port samples go through an
+ * UNNORMALISED inverse DFT V_i[n] = sum_p x_p[n] e^{+j 2 pi i p / M} (four real fmaf chains, p ascending, like the
+ * channelizer's DFT), then branch i is filtered with the polyphase taps h[i + M j] over ITS OWN history V_i[n - j] and the M
+ * branch outputs leave in order: out[n M + i].  in: int16 [N][n]; out: 10 * n25 samples, n25 = count of the 25/24 resampler. */
+size_t orc_mod_mmdvm_multi(const int16_t* in, size_t n, int N, int filter_width, cf32* out)
+{
+    const int M = 10;
+    const size_t n25 = orc_decim_count(n, 25, 24);
+    if (!out) return n25 * (size_t)M;
+    int nf = orc_low_pass_2(1, 24000, filter_width, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* ft = NEW(float, nf);
+    orc_low_pass_2(1, 24000, filter_width, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, ft);
+    int nr = orc_low_pass_2(25, 600000, filter_width, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* rt = NEW(float, nr);
+    orc_low_pass_2(25, 600000, filter_width, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, rt);
+    int ns = orc_low_pass_2(10, 250000, filter_width, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* st = NEW(float, ns);
+    orc_low_pass_2(10, 250000, filter_width, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, st);
+    cf32* port = (cf32*)calloc((size_t)M * (n25 + 1), sizeof(cf32));   /* [M][n25], idle ports stay zero */
+    float* f = NEW(float, n + 1); cf32* a = NEW(cf32, n + 1); cf32* b = NEW(cf32, n + 1);
+    int m = 1;
+    for (int c = 0; c < N; c++) {
+        for (size_t i = 0; i < n; i++) f[i] = ((float)in[(size_t)c * n + i] / 32767.0f) * 1.0f;
+        fm_mod(f, n, (float)(2 * M_PI * 12500.0f / 24000.0f), a);
+        orc_fir_ccf(a, n, ft, nf, b);
+        for (size_t i = 0; i < n; i++) { b[i].re *= 0.8f; b[i].im *= 0.8f; }
+        const int p = c <= 3 ? c : 10 - m++;
+        orc_resamp_ccf(b, n, rt, nr, 25, 24, port + (size_t)p * n25);
+    }
+    free(f); free(a); free(b); free(ft); free(rt);
+    cf32 W[10];
+    for (int q = 0; q < M; q++) { W[q].re = (float)cos(2 * M_PI * q / M); W[q].im = (float)sin(2 * M_PI * q / M); }
+    const int J = (ns + M - 1) / M;
+    cf32* V = (cf32*)calloc((size_t)M * (n25 + 1), sizeof(cf32));       /* V[i][blk] */
+    for (size_t blk = 0; blk < n25; blk++)
+        for (int i = 0; i < M; i++) {
+            float sa = 0.f, sb = 0.f, sc = 0.f, sd = 0.f;
+            for (int p = 0; p < M; p++) {
+                const cf32 w = W[(i * p) % M], x = port[(size_t)p * n25 + blk];
+                sa = fmaf(w.re, x.re, sa); sb = fmaf(w.im, x.im, sb); sc = fmaf(w.im, x.re, sc); sd = fmaf(w.re, x.im, sd);
+            }
+            V[(size_t)i * n25 + blk].re = sa - sb; V[(size_t)i * n25 + blk].im = sc + sd;
+        }
+    const float lvl = 1.0f / (float)N;
+    for (size_t blk = 0; blk < n25; blk++)
+        for (int i = 0; i < M; i++) {
+            float ar = 0.f, ai = 0.f;
+            for (int j = 0; j < J; j++) {
+                if ((size_t)j > blk) break;
+                const int k = i + M * j;
+                const float h = k < ns ? st[k] : 0.0f;
+                const cf32 v = V[(size_t)i * n25 + (blk - (size_t)j)];
+                ar = fmaf(h, v.re, ar); ai = fmaf(h, v.im, ai);
+            }
+            out[blk * M + i].re = ar * lvl; out[blk * M + i].im = ai * lvl;
+        }
+    free(port); free(V); free(st);
+    return n25 * (size_t)M;
+}
+
 /* ------------------------------- DMR / 4FSK symbol demodulator (a37) ---------------------------------
  * gr_demod_dmr (reference src/gr/gr_demod_dmr.cpp:36-105, instance make_gr_demod_dmr(5, 1000000) gr_demod_base.cpp:253):
  *   rational_resampler_ccf(3, 125, low_pass_2(3, 3e6, 5000, 2000, 60, BH)) -> [port 0] -> quadrature_demod_cf(24000/(pi/2*4800))

@@ -48,6 +48,11 @@ class _ChanConfig(C.Structure):
                 ("decimation", C.c_int), ("filter_width", C.c_int)]
 
 
+class _SynthConfig(C.Structure):
+    _fields_ = [("num_channels", C.c_int), ("filter_width", C.c_int), ("batch", C.c_int), ("max_samples", C.c_size_t),
+                ("hip_stream", C.c_void_p), ("bb_gain", C.c_float)]
+
+
 class _Out(C.Structure):
     _fields_ = [("filtered", C.c_void_p), ("filtered_cap", C.c_size_t), ("constellation", C.c_void_p),
                 ("constellation_cap", C.c_size_t), ("bits_a", C.c_void_p), ("bits_cap", C.c_size_t),
@@ -107,6 +112,14 @@ def load_library():
     lib.qrl_chan_out_cap.argtypes = [vp, sz]
     lib.qrl_chan_process.argtypes = [vp, vp, sz, sz, vp, sz, vp]
     lib.qrl_chan_sync.argtypes = [vp]
+    lib.qrl_synth_create.argtypes = [vp, C.POINTER(_SynthConfig), C.POINTER(vp)]
+    lib.qrl_synth_destroy.argtypes = [vp]
+    lib.qrl_synth_reset.argtypes = [vp]
+    lib.qrl_synth_set_bb_gain.argtypes = [vp, C.c_float]
+    lib.qrl_synth_out_cap.restype = sz
+    lib.qrl_synth_out_cap.argtypes = [vp, sz]
+    lib.qrl_synth_process.argtypes = [vp, vp, sz, sz, vp, sz, C.POINTER(sz)]
+    lib.qrl_synth_sync.argtypes = [vp]
     lib.qrl_deframer_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     lib.qrl_deframer_destroy.argtypes = [vp]
     lib.qrl_deframer_reset.argtypes = [vp]
@@ -137,6 +150,8 @@ EXPORTED_SYMBOLS = [
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
     "qrl_mod_samples_per_byte", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_create",
     "qrl_chan_destroy", "qrl_chan_reset", "qrl_chan_set_level", "qrl_chan_calibrate_rssi", "qrl_chan_set_rssi_output", "qrl_chan_set_4fsk_output", "qrl_chan_out_cap", "qrl_chan_process", "qrl_chan_sync",
+    "qrl_synth_create", "qrl_synth_destroy", "qrl_synth_reset", "qrl_synth_set_bb_gain", "qrl_synth_out_cap", "qrl_synth_process",
+    "qrl_synth_sync",
     "qrl_deframer_create", "qrl_deframer_destroy", "qrl_deframer_reset", "qrl_deframer_process", "qrl_deframer_sync",
     "qrl_framesync_create", "qrl_framesync_destroy", "qrl_framesync_reset", "qrl_framesync_frame_bytes", "qrl_framesync_process",
     "qrl_framesync_sync",
@@ -381,6 +396,40 @@ class Deframer:
     def close(self):
         if self.h:
             self.lib.qrl_deframer_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Synth:
+    """Multi-carrier MMDVM transmitter: mirrors make_gr_mod_mmdvm_multi2 (reference src/gr/gr_mod_mmdvm_multi2.cpp).
+    process(x) takes int16 cuda [batch, num_channels, n] (24 ksps FM baseband per channel) and returns complex64 cuda
+    [batch, produced] at 250 ksps."""
+
+    def __init__(self, ctx, num_channels, batch, max_samples, filter_width=0, stream=None, bb_gain=1.0):
+        import torch
+        self.torch = torch
+        self.ctx, self.lib, self.batch, self.nch = ctx, ctx.lib, batch, num_channels
+        cfg = _SynthConfig()
+        cfg.num_channels, cfg.filter_width, cfg.batch, cfg.max_samples = num_channels, filter_width, batch, max_samples
+        cfg.hip_stream, cfg.bb_gain = stream, bb_gain
+        self.h = C.c_void_p()
+        _check(self.lib.qrl_synth_create(ctx.h, C.byref(cfg), C.byref(self.h)), "qrl_synth_create")
+
+    def process(self, x):
+        t = self.torch
+        assert x.is_cuda and x.dtype == t.int16 and x.dim() == 3 and x.shape[0] == self.batch and x.shape[1] == self.nch
+        x = x.contiguous()
+        n = x.shape[2]
+        cap = self.lib.qrl_synth_out_cap(self.h, n)
+        out = t.zeros((self.batch, cap), dtype=t.complex64, device=x.device)
+        produced = C.c_size_t(0)
+        t.cuda.current_stream().synchronize()
+        _check(self.lib.qrl_synth_process(self.h, x.data_ptr(), n, n, out.data_ptr(), cap, C.byref(produced)), "qrl_synth_process")
+        _check(self.lib.qrl_synth_sync(self.h), "qrl_synth_sync")
+        return out[:, :produced.value]
+
+    def close(self):
+        if self.h:
+            self.lib.qrl_synth_destroy(self.h)
             self.h = C.c_void_p()
 
 

@@ -170,6 +170,20 @@ void launch_rssi_tag(const RssiParams& p, int batch, hipStream_t s);
 void launch_pfb_chan(const ChanParams& p, int batch, hipStream_t s);
 void launch_f2s(const F2sParams& p, int batch, hipStream_t s);
 size_t chan_lds_bytes(int M, int J);
+// ---- multi-carrier MMDVM TX (kernels_chan.hip) ----
+struct S2fInParams { const int16_t* in; size_t in_stride; RingF out; uint64_t q0; uint32_t count; float scale, level; };
+struct SynthParams {
+    RingC in; int nch;                                   // channel rings [batch * nch] at 25 ksps
+    int port_chan[16];                                   // port p <- channel ring port_chan[p], -1 = idle port
+    uint64_t blk0; uint32_t nblk;                        // absolute first block, blocks of this call
+    const float* taps; const float2* twiddle; int M, J;  // taps[i + M j] zero padded to J*M; W[q] = e^{+j 2 pi q / M}
+    float level, bb_gain;
+    float2* out; size_t out_stride, out_cap;
+};
+void launch_s2f_in(const S2fInParams& p, int streams, hipStream_t s);
+void launch_scale_c(RingC r, uint64_t q0, uint32_t count, float k, int streams, hipStream_t s);
+void launch_pfb_synth(const SynthParams& p, int batch, hipStream_t s);
+size_t synth_lds_bytes(int M, int J);
 
 // ---- TX: gr_mod_qpsk (kernels_tx.hip) ----
 struct TxState { uint32_t sr, enc, prev, pad; };   // scrambler register, last 6 scrambled bits, last differential symbol

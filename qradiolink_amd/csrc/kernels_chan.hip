@@ -193,4 +193,100 @@ void launch_rssi_tag(const RssiParams& p, int batch, hipStream_t s)
     hipLaunchKernelGGL(k_rssi_tag, dim3((p.count + 63) / 64, batch), dim3(64), 0, s, p);
 }
 
+// ---- multi-carrier MMDVM transmitter (reference src/gr/gr_mod_mmdvm_multi2.cpp:30-128) ------------------------------------
+// k_s2f_in   : short_to_float(1, 32767) + multiply_const_ff(level) into the float ring that feeds the FM modulator (k_tx_fm)
+// k_scale_c  : multiply_const_cc(0.8) in place on the filtered ring
+// k_pfb_synth: pfb_synthesizer_ccf(M = 10, taps, twox = false): per block the M port samples (ports = channel rings through
+//              the {0,1,2,3,9,8,7} map, idle ports zero) go through the unnormalised inverse DFT (four real fmaf chains, p
+//              ascending: the channelizer's contract), branch i is then filtered over its own history with h[i + M j] and the
+//              M outputs leave in order, scaled by 1 / num_channels and the baseband gain.  A workgroup produces SY_TB blocks:
+//              the IDFTs of SY_TB + J - 1 blocks are staged in LDS (the halo is recomputed from the channel rings).
+__global__ __launch_bounds__(256) void k_s2f_in(const S2fInParams P)
+{
+    const int s = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.count) return;
+    const float v = ((float)P.in[(size_t)s * P.in_stride + t] / P.scale) * P.level;
+    P.out.p[(size_t)s * (P.out.mask + 1u) + ((uint32_t)(P.q0 + t) & P.out.mask)] = v;
+}
+void launch_s2f_in(const S2fInParams& p, int streams, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_s2f_in, dim3((p.count + 255) / 256, streams), dim3(256), 0, s, p);
+}
+__global__ __launch_bounds__(256) void k_scale_c(RingC r, uint64_t q0, uint32_t count, float k)
+{
+    const int s = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= count) return;
+    float2* p = r.p + (size_t)s * (r.mask + 1u) + ((uint32_t)(q0 + t) & r.mask);
+    float2 v = *p;
+    v.x *= k; v.y *= k;
+    *p = v;
+}
+void launch_scale_c(RingC r, uint64_t q0, uint32_t count, float k, int streams, hipStream_t s)
+{
+    if (!count) return;
+    hipLaunchKernelGGL(k_scale_c, dim3((count + 255) / 256, streams), dim3(256), 0, s, r, q0, count, k);
+}
+
+constexpr int SY_TB = 96;   // output blocks per workgroup
+__global__ __launch_bounds__(256) void k_pfb_synth(const SynthParams P)
+{
+    extern __shared__ __align__(16) unsigned char sy_smem[];
+    const int M = P.M, J = P.J;
+    float2* V = reinterpret_cast<float2*>(sy_smem);                 // [(SY_TB + J - 1)][M + 1]
+    float* taps = reinterpret_cast<float*>(V + (SY_TB + J - 1) * (M + 1));   // J * M, zero padded
+    float2* W = reinterpret_cast<float2*>(taps + J * M);            // M twiddles e^{+j 2 pi q / M}
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const uint64_t blk0 = P.blk0 + (uint64_t)blockIdx.x * SY_TB;    // first output block of this workgroup (absolute)
+    const int nb = (int)min((uint64_t)SY_TB, P.blk0 + P.nblk - blk0);
+    for (int k = tid; k < J * M; k += 256) taps[k] = P.taps[k];
+    for (int k = tid; k < M; k += 256) W[k] = P.twiddle[k];
+    __syncthreads();
+    // inverse DFT of blocks [blk0 - (J - 1), blk0 + nb): thread per (block, branch)
+    const int nv = nb + J - 1;
+    for (int w = tid; w < nv * M; w += 256) {
+        const int r = w / M, i = w - r * M;
+        const int64_t blk = (int64_t)blk0 - (J - 1) + r;
+        float sa = 0.f, sb = 0.f, sc = 0.f, sd = 0.f;
+        if (blk >= 0) {
+            int q = 0;                                               // (i * p) mod M
+            for (int p = 0; p < M; ++p) {
+                const int ch = P.port_chan[p];                       // channel ring feeding port p, -1 = idle (null_source)
+                float2 x = make_float2(0.f, 0.f);
+                if (ch >= 0) x = P.in.p[((size_t)b * P.nch + ch) * (P.in.mask + 1u) + ((uint32_t)blk & P.in.mask)];
+                const float2 wv = W[q];
+                sa = fmaf(wv.x, x.x, sa); sb = fmaf(wv.y, x.y, sb); sc = fmaf(wv.y, x.x, sc); sd = fmaf(wv.x, x.y, sd);
+                q += i; if (q >= M) q -= M;
+            }
+        }
+        V[r * (M + 1) + i] = make_float2(sa - sb, sc + sd);
+    }
+    __syncthreads();
+    // branch filters: out[(blk - P.blk0) M + i] = lvl * sum_j h[i + M j] V_i[blk - j]
+    for (int w = tid; w < nb * M; w += 256) {
+        const int r = w / M, i = w - r * M;
+        const float2* vp = V + (r + J - 1) * (M + 1) + i;
+        float ar = 0.f, ai = 0.f;
+        for (int j = 0; j < J; ++j) {
+            const float h = taps[i + M * j];
+            const float2 v = vp[-j * (M + 1)];
+            ar = fmaf(h, v.x, ar); ai = fmaf(h, v.y, ai);
+        }
+        ar *= P.level; ai *= P.level;
+        ar *= P.bb_gain; ai *= P.bb_gain;
+        const size_t o = (size_t)(blk0 - P.blk0 + r) * M + i;
+        if (o < P.out_cap) P.out[(size_t)b * P.out_stride + o] = make_float2(ar, ai);
+    }
+}
+size_t synth_lds_bytes(int M, int J) { return (size_t)((SY_TB + J - 1) * (M + 1) + M) * sizeof(float2) + (size_t)J * M * sizeof(float); }
+void launch_pfb_synth(const SynthParams& p, int batch, hipStream_t s)
+{
+    if (!p.nblk) return;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pfb_synth), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_pfb_synth, dim3((p.nblk + SY_TB - 1) / SY_TB, batch), dim3(256), synth_lds_bytes(p.M, p.J), s, p);
+}
+
 }  // namespace qrl

@@ -1,0 +1,151 @@
+// synth.cpp — host side of the multi-carrier MMDVM transmitter (reference src/gr/gr_mod_mmdvm_multi2.cpp:30-128):
+// per channel int16 -> FM modulator -> LPF -> x0.8 -> 25/24 resampler, then pfb_synthesizer_ccf(10) -> x(1/N) -> bb gain.
+#include "../../include/qrl_hip.h"
+#include "engine.hpp"
+#include "firdes.hpp"
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace qrl;
+extern int qrl_set_error(int code, const std::string& msg);
+struct qrl_ctx { int device; };
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return qrl_set_error(QRL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+template <class T> struct Buf {
+    T* p = nullptr;
+    ~Buf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) {
+        if (hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return QRL_ERR_NOMEM;
+        return hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)) == hipSuccess ? QRL_OK : QRL_ERR_HIP;
+    }
+    int upload(const std::vector<T>& v) {
+        int r = alloc(v.size());
+        if (r) return r;
+        return v.empty() || hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess ? QRL_OK : QRL_ERR_HIP;
+    }
+};
+uint32_t pow2ge(size_t v) { uint32_t c = 64; while (c < v) c <<= 1; return c; }
+}  // namespace
+
+struct qrl_synth {
+    qrl_ctx* ctx = nullptr; qrl_synth_config cfg{};
+    hipStream_t stream = nullptr; bool own_stream = false;
+    int N = 3, J = 0, filt_nt = 0, rs_Jp = 0; float bb_gain = 1.0f;
+    Buf<float> filt_taps, rs_taps, syn_taps, rA, phase; Buf<float2> twiddle, rB, rC, rD;
+    uint32_t m1 = 0, m25 = 0; uint64_t n1 = 0, n25 = 0;
+    int port_chan[16];
+    ~qrl_synth() { if (own_stream && stream) (void)hipStreamDestroy(stream); }
+    int reset_state() {
+        const size_t S = (size_t)cfg.batch * N;
+        if (hipMemset(rA.p, 0, S * (m1 + 1) * sizeof(float)) != hipSuccess || hipMemset(rB.p, 0, S * (m1 + 1) * sizeof(float2)) != hipSuccess ||
+            hipMemset(rC.p, 0, S * (m1 + 1) * sizeof(float2)) != hipSuccess || hipMemset(rD.p, 0, S * (m25 + 1) * sizeof(float2)) != hipSuccess ||
+            hipMemset(phase.p, 0, S * sizeof(float)) != hipSuccess)
+            return QRL_ERR_HIP;
+        n1 = n25 = 0;
+        return QRL_OK;
+    }
+};
+
+extern "C" {
+
+int qrl_synth_create(qrl_ctx* ctx, const qrl_synth_config* cfg, qrl_synth** outp)
+{
+    if (!ctx || !cfg || !outp) return QRL_ERR_ARG;
+    if (cfg->num_channels < 1 || cfg->num_channels > 7) return qrl_set_error(QRL_ERR_ARG, "num_channels must be 1..7 (MAX_MMDVM_CHANNELS)");
+    if (cfg->batch < 1 || cfg->max_samples < 1) return qrl_set_error(QRL_ERR_ARG, "batch and max_samples must be >= 1");
+    std::unique_ptr<qrl_synth> h(new (std::nothrow) qrl_synth);
+    if (!h) return QRL_ERR_NOMEM;
+    h->ctx = ctx; h->cfg = *cfg; h->N = cfg->num_channels;
+    h->bb_gain = cfg->bb_gain == 0.0f ? 1.0f : cfg->bb_gain;
+    const int fw = cfg->filter_width > 0 ? cfg->filter_width : 5000, M = 10;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (cfg->hip_stream) h->stream = static_cast<hipStream_t>(cfg->hip_stream);
+    else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    int r;
+    const std::vector<float> ft = low_pass_2(1, 24000, fw, 2000, 60, WIN_BLACKMAN_HARRIS);          // _filter, :52-53
+    h->filt_nt = (int)ft.size();
+    const std::vector<float> rt = low_pass_2(25, 600000, fw, 2000, 60, WIN_BLACKMAN_HARRIS);        // _resampler 25/24, :50-51
+    h->rs_Jp = ((int)rt.size() + 24) / 25;
+    std::vector<float> rl((size_t)25 * h->rs_Jp, 0.0f);
+    for (size_t k = 0; k < rt.size(); ++k) rl[(k % 25) * h->rs_Jp + k / 25] = rt[k];
+    const std::vector<float> st = low_pass_2(10, 250000, fw, 2000, 60, WIN_BLACKMAN_HARRIS);        // synthesizer prototype, :88-90
+    h->J = ((int)st.size() + M - 1) / M;
+    std::vector<float> sl((size_t)h->J * M, 0.0f);
+    for (size_t k = 0; k < st.size(); ++k) sl[k] = st[k];
+    std::vector<float2> W(M);
+    for (int q = 0; q < M; ++q) W[q] = make_float2((float)std::cos(2 * M_PI * q / M), (float)std::sin(2 * M_PI * q / M));
+    if ((r = h->filt_taps.upload(ft)) || (r = h->rs_taps.upload(rl)) || (r = h->syn_taps.upload(sl)) || (r = h->twiddle.upload(W))) return r;
+    if (synth_lds_bytes(M, h->J) > 160 * 1024) return qrl_set_error(QRL_ERR_ARG, "synthesizer tile does not fit LDS");
+    // port map of :103-118: channels 0..3 -> ports 0..3, channels 4, 5, 6 -> ports 9, 8, 7; the other ports are null sources
+    for (int p = 0; p < 16; ++p) h->port_chan[p] = -1;
+    for (int c = 0, m = 1; c < h->N; ++c) h->port_chan[c <= 3 ? c : 10 - m++] = c;
+    const size_t S = (size_t)cfg->batch * h->N;
+    const size_t max25 = cfg->max_samples * 25 / 24 + 2;
+    h->m1 = pow2ge(cfg->max_samples + h->filt_nt + h->rs_Jp + 64) - 1;
+    h->m25 = pow2ge(max25 + h->J + 64) - 1;
+    if ((r = h->rA.alloc(S * (h->m1 + 1))) || (r = h->rB.alloc(S * (h->m1 + 1))) || (r = h->rC.alloc(S * (h->m1 + 1))) ||
+        (r = h->rD.alloc(S * (h->m25 + 1))) || (r = h->phase.alloc(S)))
+        return qrl_set_error(r, "synthesizer buffers");
+    *outp = h.release();
+    return QRL_OK;
+}
+void qrl_synth_destroy(qrl_synth* h) { if (h) { (void)hipStreamSynchronize(h->stream); delete h; } }
+int qrl_synth_reset(qrl_synth* h)
+{
+    if (!h) return QRL_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return h->reset_state();
+}
+int qrl_synth_set_bb_gain(qrl_synth* h, float g) { if (!h) return QRL_ERR_ARG; h->bb_gain = g; return QRL_OK; }
+size_t qrl_synth_out_cap(const qrl_synth* h, size_t n) { return h ? (n * 25 / 24 + 2) * 10 : 0; }
+
+int qrl_synth_process(qrl_synth* h, const int16_t* in, size_t stride, size_t n, float* iq, size_t out_stride, size_t* produced)
+{
+    if (!h || (!in && n) || (!iq && n)) return QRL_ERR_ARG;
+    if (n > h->cfg.max_samples) return qrl_set_error(QRL_ERR_TOO_BIG, "n exceeds max_samples");
+    if (produced) *produced = 0;
+    if (n == 0) return QRL_OK;
+    HIPCHK(hipSetDevice(h->ctx->device));
+    const int B = h->cfg.batch, N = h->N, S = B * N;
+    const uint64_t n1_1 = h->n1 + n;
+    const uint64_t n25_1 = n1_1 ? ((n1_1 - 1) * 25 + 24) / 24 + 1 : 0;   // outputs q of the 25/24 resampler with q*24/25 <= n1_1 - 1
+    const uint32_t c1 = (uint32_t)n, c25 = (uint32_t)(n25_1 - h->n25);
+    S2fInParams sp{}; sp.in = in; sp.in_stride = stride; sp.out = RingF{h->rA.p, h->m1}; sp.q0 = h->n1; sp.count = c1; sp.scale = 32767.0f; sp.level = 1.0f;
+    launch_s2f_in(sp, S, h->stream);
+    TxFmParams fp{}; fp.in = sp.out; fp.out = RingC{h->rB.p, h->m1}; fp.n0 = h->n1; fp.count = c1;
+    fp.k = (float)(2 * M_PI * 12500.0f / 24000.0f); fp.amp = 1.0f; fp.phase = h->phase.p;            // _fm_modulator, :64-66
+    launch_tx_fm(fp, S, h->stream);
+    FirCcfParams ff{}; ff.in = fp.out; ff.out = RingC{h->rC.p, h->m1}; ff.q0 = h->n1; ff.count = c1; ff.taps = h->filt_taps.p; ff.nt = h->filt_nt;
+    launch_fir_ccf(ff, S, h->stream);
+    launch_scale_c(ff.out, h->n1, c1, 0.8f, S, h->stream);                                           // _amplify, :77-79
+    ResampParams rp{}; rp.in = nullptr; rp.in_ring = ff.out; rp.n0 = h->n1; rp.n = c1;
+    rp.out = RingC{h->rD.p, h->m25}; rp.q0 = h->n25; rp.q_count = c25; rp.taps = h->rs_taps.p; rp.I = 25; rp.D = 24; rp.Jp = h->rs_Jp;
+    launch_resamp(rp, S, h->stream);
+    SynthParams yp{}; yp.in = rp.out; yp.nch = N; for (int p = 0; p < 16; ++p) yp.port_chan[p] = h->port_chan[p];
+    yp.blk0 = h->n25; yp.nblk = c25; yp.taps = h->syn_taps.p; yp.twiddle = h->twiddle.p; yp.M = 10; yp.J = h->J;
+    yp.level = 1.0f / (float)N; yp.bb_gain = h->bb_gain;                                             // _divide_level, _bb_gain :91-95
+    yp.out = reinterpret_cast<float2*>(iq); yp.out_stride = out_stride; yp.out_cap = out_stride;
+    launch_pfb_synth(yp, B, h->stream);
+    HIPCHK(hipGetLastError());
+    h->n1 = n1_1; h->n25 = n25_1;
+    if (produced) *produced = (size_t)c25 * 10;
+    return QRL_OK;
+}
+int qrl_synth_sync(qrl_synth* h)
+{
+    if (!h) return QRL_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return QRL_OK;
+}
+
+}  // extern "C"

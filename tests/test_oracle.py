@@ -389,3 +389,19 @@ def test_modem_sync_oracle_frames_by_class():
         ms = orc.ModemSync(modem)
         fr = ms.feed(bits[:777]) + ms.feed(bits[777:])
         assert [f for f, _ in fr] == [ft] * 3 and [p[off:] for _, p in fr] == payloads
+
+
+def test_mmdvm_tx_synthesizer_loops_back_through_the_channelizer():
+    """gr_mod_mmdvm_multi2 restatement -> gr_demod_mmdvm_multi2 restatement: channel c's tone returns on port {0,1,2,3,9,8,7}[c]"""
+    N, n = 7, 24000
+    t = np.arange(n)
+    x = np.stack([(8000 * np.sin(2 * np.pi * (300 + 100 * c) * t / 24000)).astype(np.int16) for c in range(N)])
+    y = orc.mod_mmdvm_multi(x)
+    assert y.size == 250000 and 0.2 < np.sqrt(np.mean(np.abs(y) ** 2)) < 0.4
+    out = orc.demod_mmdvm_multi(y, 10)
+    for c in (0, 3, 4, 6):
+        p = c if c <= 3 else 10 - (c - 3)
+        r = out[p, 3000:3000 + 16384].astype(np.float64)
+        f = np.abs(np.fft.rfft(r * np.hanning(r.size)))
+        assert abs(np.argmax(f) * 24000 / r.size - (300 + 100 * c)) < 3.0
+        assert 0.8 * 8000 < np.percentile(np.abs(r), 99) < 1.1 * 8000
