@@ -222,6 +222,8 @@ typedef struct {
     size_t max_samples;      /* largest n of any call */
     void* hip_stream;
     float bb_gain;           /* gr_mod_mmdvm_multi2::set_bb_gain, 0 = 1.0 */
+    int single_carrier;      /* 1 (with num_channels = 1): make_gr_mod_mmdvm (src/gr/gr_mod_mmdvm.cpp:17-64): FM -> LPF -> x0.8 -> bb
+                                gain -> rational_resampler_ccf(125, 12): no synthesizer, 24 ksps -> 250 ksps */
 } qrl_synth_config;
 int qrl_synth_create(qrl_ctx* ctx, const qrl_synth_config* cfg, qrl_synth** out);
 void qrl_synth_destroy(qrl_synth* s);

@@ -127,6 +127,7 @@ size_t orc_deframer(int type, const uint8_t* bits, size_t n, uint32_t st[3], uin
 size_t orc_rssi_tag(const cf32* in, size_t n, float calibration, float* db);
 size_t orc_demod_mmdvm(const cf32* in, size_t n, int samp_rate, int filter_width, int16_t* out, size_t cap, float* rssi, float cal,
                        size_t* n_rssi);
+size_t orc_mod_mmdvm(const int16_t* in, size_t n, int filter_width, float bb_gain, cf32* out);
 size_t orc_mod_mmdvm_multi(const int16_t* in, size_t n, int N, int filter_width, cf32* out);
 size_t orc_demod_mmdvm_xlating(const cf32* in, size_t n, int N, int separation, int D, int fw, int16_t* out, size_t cap,
                                float* rssi, size_t rcap, float cal);

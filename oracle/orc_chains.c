@@ -903,6 +903,29 @@ size_t orc_mod_mmdvm_multi(const int16_t* in, size_t n, int N, int filter_width,
     return n25 * (size_t)M;
 }
 
+/* single-carrier MMDVM transmitter gr_mod_mmdvm.cpp:27-64: short_to_float(1, 32767) -> x1.0 -> frequency_modulator_fc(2 pi 12500
+ * / 24000) -> [zero idle bursts: pass-through] -> fft_filter_ccf(low_pass_2(1, 24k, fw, 2000, 60, BH)) -> x0.8 -> x bb_gain ->
+ * rational_resampler_ccf(125, 12, low_pass_2(125, 3e6, fw, 2000, 60, BH)): 24 ksps -> 250 ksps */
+size_t orc_mod_mmdvm(const int16_t* in, size_t n, int filter_width, float bb_gain, cf32* out)
+{
+    const size_t nout = orc_decim_count(n, 125, 12);
+    if (!out) return nout;
+    int nf = orc_low_pass_2(1, 24000, filter_width, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* ft = NEW(float, nf);
+    orc_low_pass_2(1, 24000, filter_width, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, ft);
+    int nr = orc_low_pass_2(125, 125 * 24000.0, filter_width, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* rt = NEW(float, nr);
+    orc_low_pass_2(125, 125 * 24000.0, filter_width, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, rt);
+    float* f = NEW(float, n + 1); cf32* a = NEW(cf32, n + 1); cf32* b = NEW(cf32, n + 1);
+    for (size_t i = 0; i < n; i++) f[i] = ((float)in[i] / 32767.0f) * 1.0f;
+    fm_mod(f, n, (float)(2 * M_PI * 12500.0f / 24000.0f), a);
+    orc_fir_ccf(a, n, ft, nf, b);
+    for (size_t i = 0; i < n; i++) { b[i].re *= 0.8f; b[i].im *= 0.8f; b[i].re *= bb_gain; b[i].im *= bb_gain; }
+    size_t m = orc_resamp_ccf(b, n, rt, nr, 125, 12, out);
+    free(f); free(a); free(b); free(ft); free(rt);
+    return m;
+}
+
 /* ------------------------------- DMR / 4FSK symbol demodulator (a37) ---------------------------------
  * gr_demod_dmr (reference src/gr/gr_demod_dmr.cpp:36-105, instance make_gr_demod_dmr(5, 1000000) gr_demod_base.cpp:253):
  *   rational_resampler_ccf(3, 125, low_pass_2(3, 3e6, 5000, 2000, 60, BH)) -> [port 0] -> quadrature_demod_cf(24000/(pi/2*4800))

@@ -50,7 +50,7 @@ class _ChanConfig(C.Structure):
 
 class _SynthConfig(C.Structure):
     _fields_ = [("num_channels", C.c_int), ("filter_width", C.c_int), ("batch", C.c_int), ("max_samples", C.c_size_t),
-                ("hip_stream", C.c_void_p), ("bb_gain", C.c_float)]
+                ("hip_stream", C.c_void_p), ("bb_gain", C.c_float), ("single_carrier", C.c_int)]
 
 
 class _Out(C.Structure):
@@ -404,11 +404,12 @@ class Synth:
     process(x) takes int16 cuda [batch, num_channels, n] (24 ksps FM baseband per channel) and returns complex64 cuda
     [batch, produced] at 250 ksps."""
 
-    def __init__(self, ctx, num_channels, batch, max_samples, filter_width=0, stream=None, bb_gain=1.0):
+    def __init__(self, ctx, num_channels, batch, max_samples, filter_width=0, stream=None, bb_gain=1.0, single_carrier=False):
         import torch
         self.torch = torch
         self.ctx, self.lib, self.batch, self.nch = ctx, ctx.lib, batch, num_channels
         cfg = _SynthConfig()
+        cfg.single_carrier = 1 if single_carrier else 0
         cfg.num_channels, cfg.filter_width, cfg.batch, cfg.max_samples = num_channels, filter_width, batch, max_samples
         cfg.hip_stream, cfg.bb_gain = stream, bb_gain
         self.h = C.c_void_p()

@@ -40,7 +40,7 @@ uint32_t pow2ge(size_t v) { uint32_t c = 64; while (c < v) c <<= 1; return c; }
 struct qrl_synth {
     qrl_ctx* ctx = nullptr; qrl_synth_config cfg{};
     hipStream_t stream = nullptr; bool own_stream = false;
-    int N = 3, J = 0, filt_nt = 0, rs_Jp = 0; float bb_gain = 1.0f;
+    int N = 3, J = 0, filt_nt = 0, rs_Jp = 0; float bb_gain = 1.0f; bool single = false; int rs_I = 25, rs_D = 24;
     Buf<float> filt_taps, rs_taps, syn_taps, rA, phase; Buf<float2> twiddle, rB, rC, rD;
     uint32_t m1 = 0, m25 = 0; uint64_t n1 = 0, n25 = 0;
     int port_chan[16];
@@ -66,6 +66,9 @@ int qrl_synth_create(qrl_ctx* ctx, const qrl_synth_config* cfg, qrl_synth** outp
     std::unique_ptr<qrl_synth> h(new (std::nothrow) qrl_synth);
     if (!h) return QRL_ERR_NOMEM;
     h->ctx = ctx; h->cfg = *cfg; h->N = cfg->num_channels;
+    h->single = cfg->single_carrier != 0;
+    if (h->single && cfg->num_channels != 1) return qrl_set_error(QRL_ERR_ARG, "single_carrier needs num_channels = 1");
+    if (h->single) { h->rs_I = 125; h->rs_D = 12; }   // gr_mod_mmdvm.cpp:43-45
     h->bb_gain = cfg->bb_gain == 0.0f ? 1.0f : cfg->bb_gain;
     const int fw = cfg->filter_width > 0 ? cfg->filter_width : 5000, M = 10;
     HIPCHK(hipSetDevice(ctx->device));
@@ -74,10 +77,12 @@ int qrl_synth_create(qrl_ctx* ctx, const qrl_synth_config* cfg, qrl_synth** outp
     int r;
     const std::vector<float> ft = low_pass_2(1, 24000, fw, 2000, 60, WIN_BLACKMAN_HARRIS);          // _filter, :52-53
     h->filt_nt = (int)ft.size();
-    const std::vector<float> rt = low_pass_2(25, 600000, fw, 2000, 60, WIN_BLACKMAN_HARRIS);        // _resampler 25/24, :50-51
-    h->rs_Jp = ((int)rt.size() + 24) / 25;
-    std::vector<float> rl((size_t)25 * h->rs_Jp, 0.0f);
-    for (size_t k = 0; k < rt.size(); ++k) rl[(k % 25) * h->rs_Jp + k / 25] = rt[k];
+    const std::vector<float> rt = h->single ? low_pass_2(125, 125 * 24000.0, fw, 2000, 60, WIN_BLACKMAN_HARRIS)   // gr_mod_mmdvm.cpp:43-44
+                                            : low_pass_2(25, 600000, fw, 2000, 60, WIN_BLACKMAN_HARRIS);          // _resampler 25/24, :50-51
+    const int RI = h->rs_I;
+    h->rs_Jp = ((int)rt.size() + RI - 1) / RI;
+    std::vector<float> rl((size_t)RI * h->rs_Jp, 0.0f);
+    for (size_t k = 0; k < rt.size(); ++k) rl[(k % RI) * h->rs_Jp + k / RI] = rt[k];
     const std::vector<float> st = low_pass_2(10, 250000, fw, 2000, 60, WIN_BLACKMAN_HARRIS);        // synthesizer prototype, :88-90
     h->J = ((int)st.size() + M - 1) / M;
     std::vector<float> sl((size_t)h->J * M, 0.0f);
@@ -90,7 +95,7 @@ int qrl_synth_create(qrl_ctx* ctx, const qrl_synth_config* cfg, qrl_synth** outp
     for (int p = 0; p < 16; ++p) h->port_chan[p] = -1;
     for (int c = 0, m = 1; c < h->N; ++c) h->port_chan[c <= 3 ? c : 10 - m++] = c;
     const size_t S = (size_t)cfg->batch * h->N;
-    const size_t max25 = cfg->max_samples * 25 / 24 + 2;
+    const size_t max25 = cfg->max_samples * h->rs_I / h->rs_D + 2;
     h->m1 = pow2ge(cfg->max_samples + h->filt_nt + h->rs_Jp + 64) - 1;
     h->m25 = pow2ge(max25 + h->J + 64) - 1;
     if ((r = h->rA.alloc(S * (h->m1 + 1))) || (r = h->rB.alloc(S * (h->m1 + 1))) || (r = h->rC.alloc(S * (h->m1 + 1))) ||
@@ -107,7 +112,7 @@ int qrl_synth_reset(qrl_synth* h)
     return h->reset_state();
 }
 int qrl_synth_set_bb_gain(qrl_synth* h, float g) { if (!h) return QRL_ERR_ARG; h->bb_gain = g; return QRL_OK; }
-size_t qrl_synth_out_cap(const qrl_synth* h, size_t n) { return h ? (n * 25 / 24 + 2) * 10 : 0; }
+size_t qrl_synth_out_cap(const qrl_synth* h, size_t n) { return h ? (n * h->rs_I / h->rs_D + 2) * (h->single ? 1 : 10) : 0; }
 
 int qrl_synth_process(qrl_synth* h, const int16_t* in, size_t stride, size_t n, float* iq, size_t out_stride, size_t* produced)
 {
@@ -118,7 +123,8 @@ int qrl_synth_process(qrl_synth* h, const int16_t* in, size_t stride, size_t n, 
     HIPCHK(hipSetDevice(h->ctx->device));
     const int B = h->cfg.batch, N = h->N, S = B * N;
     const uint64_t n1_1 = h->n1 + n;
-    const uint64_t n25_1 = n1_1 ? ((n1_1 - 1) * 25 + 24) / 24 + 1 : 0;   // outputs q of the 25/24 resampler with q*24/25 <= n1_1 - 1
+    const uint64_t RI = (uint64_t)h->rs_I, RD = (uint64_t)h->rs_D;
+    const uint64_t n25_1 = n1_1 ? ((n1_1 - 1) * RI + RI - 1) / RD + 1 : 0;   // outputs q of the resampler with q*D/I <= n1_1 - 1
     const uint32_t c1 = (uint32_t)n, c25 = (uint32_t)(n25_1 - h->n25);
     S2fInParams sp{}; sp.in = in; sp.in_stride = stride; sp.out = RingF{h->rA.p, h->m1}; sp.q0 = h->n1; sp.count = c1; sp.scale = 32767.0f; sp.level = 1.0f;
     launch_s2f_in(sp, S, h->stream);
@@ -128,9 +134,17 @@ int qrl_synth_process(qrl_synth* h, const int16_t* in, size_t stride, size_t n, 
     FirCcfParams ff{}; ff.in = fp.out; ff.out = RingC{h->rC.p, h->m1}; ff.q0 = h->n1; ff.count = c1; ff.taps = h->filt_taps.p; ff.nt = h->filt_nt;
     launch_fir_ccf(ff, S, h->stream);
     launch_scale_c(ff.out, h->n1, c1, 0.8f, S, h->stream);                                           // _amplify, :77-79
+    if (h->single) launch_scale_c(ff.out, h->n1, c1, h->bb_gain, S, h->stream);                      // gr_mod_mmdvm.cpp:59-61: bb gain BEFORE the resampler
     ResampParams rp{}; rp.in = nullptr; rp.in_ring = ff.out; rp.n0 = h->n1; rp.n = c1;
-    rp.out = RingC{h->rD.p, h->m25}; rp.q0 = h->n25; rp.q_count = c25; rp.taps = h->rs_taps.p; rp.I = 25; rp.D = 24; rp.Jp = h->rs_Jp;
+    rp.out = RingC{h->rD.p, h->m25}; rp.q0 = h->n25; rp.q_count = c25; rp.taps = h->rs_taps.p; rp.I = h->rs_I; rp.D = h->rs_D; rp.Jp = h->rs_Jp;
+    if (h->single) { rp.port = reinterpret_cast<float2*>(iq); rp.port_cap = out_stride; }           // the resampler output IS the 250 ksps signal
     launch_resamp(rp, S, h->stream);
+    if (h->single) {
+        HIPCHK(hipGetLastError());
+        h->n1 = n1_1; h->n25 = n25_1;
+        if (produced) *produced = (size_t)c25;
+        return QRL_OK;
+    }
     SynthParams yp{}; yp.in = rp.out; yp.nch = N; for (int p = 0; p < 16; ++p) yp.port_chan[p] = h->port_chan[p];
     yp.blk0 = h->n25; yp.nblk = c25; yp.taps = h->syn_taps.p; yp.twiddle = h->twiddle.p; yp.M = 10; yp.J = h->J;
     yp.level = 1.0f / (float)N; yp.bb_gain = h->bb_gain;                                             // _divide_level, _bb_gain :91-95

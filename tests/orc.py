@@ -101,6 +101,7 @@ _sig("orc_demod_mmdvm", _sz, _p, _sz, C.c_int, C.c_int, _p, _sz, _p, C.c_float, 
 _sig("orc_demod_mmdvm_multi_rssi", _sz, _p, _sz, C.c_int, _p, _sz, _p, _sz, C.c_float)
 _sig("orc_demod_mmdvm_multi_4fsk", _sz, _p, _sz, C.c_int, _p, _sz, _p, _sz, C.c_float, _p, _sz, _p)
 _sig("orc_demod_mmdvm_xlating", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p, _sz, _p, _sz, C.c_float)
+_sig("orc_mod_mmdvm", _sz, _p, _sz, C.c_int, C.c_float, _p)
 _sig("orc_mod_mmdvm_multi", _sz, _p, _sz, C.c_int, C.c_int, _p)
 _sig("orc_batch_rx", C.c_double, C.c_int, _p, C.c_int, _sz, C.c_int, C.c_double, C.c_int, _p)
 
@@ -387,6 +388,14 @@ def demod_mmdvm_xlating(x, N, separation=25000, D=10, fw=8000, cal=0.0):
     rssi = np.zeros((N, rcap), np.float32)
     n = lib.orc_demod_mmdvm_xlating(_ptr(x), x.size, N, separation, D, fw, _ptr(out), cap, _ptr(rssi), rcap, cal)
     return out[:, :n].copy(), rssi[:, :n // 300].copy()
+
+
+def mod_mmdvm(x, filter_width=5000, bb_gain=1.0):
+    x = np.ascontiguousarray(x, np.int16)
+    m = lib.orc_mod_mmdvm(_ptr(x), x.size, filter_width, bb_gain, None)
+    y = np.zeros(m, cf32)
+    lib.orc_mod_mmdvm(_ptr(x), x.size, filter_width, bb_gain, _ptr(y))
+    return y
 
 
 def mod_mmdvm_multi(x, filter_width=5000):

@@ -285,3 +285,26 @@ def test_mmdvm_tx_rx_loopback_on_gpu(qrl_ctx):
         f = np.abs(np.fft.rfft(r * np.hanning(r.size)))
         assert abs(np.argmax(f) * 24000 / r.size - (300 + 150 * c)) < 3.0
         assert 0.8 * 9000 < np.percentile(np.abs(r), 99) < 1.1 * 9000
+
+
+@pytest.mark.parametrize("cuts", [[12000], [1000, 7, 5000, 5993]])
+def test_mmdvm_tx_single_carrier_bit_exact(qrl_ctx, cuts):
+    """gr_mod_mmdvm (single_carrier): FM -> LPF -> x0.8 -> bb gain -> rational_resampler_ccf(125, 12)"""
+    import torch
+    import qradiolink_amd as q
+    n = sum(cuts)
+    x = np.stack([_audio(1, n, seed=50 + b) for b in range(2)])
+    syn = q.Synth(qrl_ctx, 1, batch=2, max_samples=max(cuts), bb_gain=0.75, single_carrier=True)
+    d = torch.from_numpy(x).cuda()
+    parts, pos = [], 0
+    for c in cuts:
+        parts.append(syn.process(d[:, :, pos:pos + c]).cpu().numpy())
+        pos += c
+    syn.close()
+    got = np.concatenate(parts, axis=1)
+    for b in range(2):
+        ref = orc.mod_mmdvm(x[b, 0], bb_gain=0.75)
+        assert got[b].size == ref.size, (got[b].size, ref.size)
+        g, w = got[b].view(np.float32) + np.float32(0), ref.view(np.float32) + np.float32(0)
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+    assert np.abs(ref).max() > 0.3
