@@ -47,6 +47,12 @@ def digest(a):
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--export-iq":   # raw cf32 inputs of the committed fixtures (for tools/gr_golden)
+        os.makedirs(sys.argv[2], exist_ok=True)
+        for name, *_ in CASES:
+            z = np.load(os.path.join(HERE, name + ".npz"))
+            z["iq_f16"].astype(np.float32).tofile(os.path.join(sys.argv[2], name + ".cf32"))
+        return
     only = set(sys.argv[1:])   # optional: names of the fixtures to (re)generate; default = all
     for name, mode, rate, offset, (kind, kw) in CASES:
         if only and name not in only:
