@@ -27,6 +27,13 @@ BH = orc.WIN_BH
     ((1, 10e6, 480e3, 100e3, BH), 419),
     ((1, 25e6, 480e3, 100e3, BH), 1045),
     ((1, 100e6, 480e3, 100e3, BH), 4181),
+    ((1, 20e3, 3000, 1500, BH), 55),        # gr_demod_4fsk.cpp:108-109 (4FSK2KFM: fw 3000, tw fw/2)
+    ((1, 500e3, 125e3, 62500, BH), 33),     # gr_demod_4fsk.cpp:108-109 (4FSK100K)
+    ((1, 1e6, 250e3, 250e3, BH), 17),       # gr_demod_4fsk.cpp:100-101 (sps 2: 1:2 resampler)
+    ((1.0, 20e3, 2000, 100, BH), 837),      # gr_demod_4fsk.cpp:103-105 _symbol_filter (non-FM branch)
+    ((1, 240e3, 8000, 3500, BH), 287),      # gr_demod_mmdvm_multi.cpp:64-65 (legacy freq-xlating receiver)
+    ((1, 24e3, 8000, 3500, BH), 29),        # gr_demod_mmdvm_multi.cpp:73-74
+    ((4, 4e6, 480e3, 20e3, BH), 837),       # gr_mod_base.cpp:249-250 @4 Msps (209 per phase)
 ])
 def test_low_pass_tap_counts(args, ntaps):
     t = orc.low_pass(*args)
@@ -41,6 +48,12 @@ def test_low_pass_tap_counts(args, ntaps):
     ((1, 600e3, 5e3, 2e3, 60, BH), 819),       # gr_demod_mmdvm_multi2.cpp:60-61
     ((1, 24e3, 5e3, 2e3, 60, BH), 33),         # gr_demod_mmdvm_multi2.cpp:62-63
     ((3, 3e6, 5e3, 2e3, 60, BH), 4091),        # gr_demod_dmr.cpp:55-58
+    ((12, 3e6, 5e3, 2e3, 60, BH), 4091),       # gr_demod_mmdvm.cpp:43-44 (12/125 resampler)
+    ((25, 600e3, 5e3, 2e3, 60, BH), 819),      # gr_mod_mmdvm_multi2.cpp:50-51 (25/24 resampler)
+    ((10, 250e3, 5e3, 2e3, 60, BH), 341),      # gr_mod_mmdvm_multi2.cpp:88-89 (synthesizer prototype)
+    ((125, 3e6, 5e3, 2e3, 60, BH), 4091),      # gr_mod_mmdvm.cpp:43-44 (125/12 resampler)
+    ((1, 1e6, 5e3, 1e3, 60, BH), 2727),        # gr_demod_qpsk.cpp:92-96 for QPSK2K (target 10 ksps)
+    ((1, 1e6, 20e3, 4e3, 60, BH), 681),        # gr_demod_qpsk.cpp:92-96 for QPSK20K (target 40 ksps)
 ])
 def test_low_pass_2_tap_counts(args, ntaps):
     # firdes::compute_ntaps_windes is fred harris' rule N = A*fs/(22*tw) made odd (the same rule as
@@ -66,6 +79,10 @@ def test_rrc_and_gaussian_normalisation():
     assert orc.root_raised_cosine(2, 2, 1, 0.35, 22).size == 23   # gr_demod_qpsk.cpp:100-103 (made odd)
     g = orc.gaussian(10, 10, 0.3, 40)
     assert abs(g.sum() - 10) < 1e-4
+    assert orc.root_raised_cosine(1.5, 20000, 2000, 0.2, 251).size == 251    # gr_demod_4fsk.cpp:130-133
+    assert orc.root_raised_cosine(10, 10, 1, 0.35, 150).size == 151          # gr_demod_bpsk.cpp:64-66 (made odd)
+    assert orc.root_raised_cosine(500, 500, 1, 0.35, 5500).size == 5501      # gr_mod_bpsk.cpp:52-54
+    assert orc.complex_band_pass(1, 20e3, -4000, -2000, 4000, BH).size == 21  # gr_demod_4fsk.cpp:112-113
 
 
 # ---- (ii) upstream table rows
@@ -405,3 +422,20 @@ def test_mmdvm_tx_synthesizer_loops_back_through_the_channelizer():
         f = np.abs(np.fft.rfft(r * np.hanning(r.size)))
         assert abs(np.argmax(f) * 24000 / r.size - (300 + 100 * c)) < 3.0
         assert 0.8 * 8000 < np.percentile(np.abs(r), 99) < 1.1 * 8000
+
+
+def test_clock_recovery_mm_locks_to_symbol_rate():
+    """clock_recovery_mm_cc(omega 10, 2.5e-5, 0.5, 0.05, 0.001) on a 10 samples/symbol BPSK waveform: one output per symbol,
+    omega stays inside +-0.1 %, outputs sit on the +-1 decision points"""
+    import ctypes as C
+    rng = np.random.default_rng(4)
+    sym = rng.integers(0, 2, 600) * 2.0 - 1.0
+    h = orc.root_raised_cosine(10, 10, 1, 0.35, 110)
+    x = np.zeros(sym.size * 10)
+    x[::10] = sym
+    x = np.convolve(np.convolve(x, h), h / 10.0).astype(np.complex64)
+    out = np.zeros(x.size // 9 + 16, np.complex64)
+    n = orc.lib.orc_clock_recovery_mm_cc(x.ctypes.data_as(C.c_void_p), x.size, 10.0, 2.5e-5, 0.5, 0.05, 0.001, out.ctypes.data_as(C.c_void_p))
+    assert abs(n - x.size / 10) <= 2
+    tail = out[100:n - 30].real
+    assert np.median(np.abs(np.abs(tail) - 1.0)) < 0.05 and abs(np.abs(tail).mean() - 1.0) < 0.05
