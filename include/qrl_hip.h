@@ -58,7 +58,9 @@ const char* qrl_version(void);
 /*
  * Configuration of one RX chain = the constructor arguments the reference passes.
  * replaces: make_gr_demod_2fsk(sps,samp_rate,carrier_freq,filter_width,fm) gr_demod_2fsk.cpp:19-37,
- *           make_gr_demod_gmsk(...) gr_demod_gmsk.cpp:19-37, make_gr_demod_qpsk(...) gr_demod_qpsk.cpp:20-37
+ *           make_gr_demod_gmsk(...) gr_demod_gmsk.cpp:19-37, make_gr_demod_qpsk(...) gr_demod_qpsk.cpp:20-37,
+ *           make_gr_demod_4fsk(..., fm) gr_demod_4fsk.cpp:19-36, make_gr_demod_bpsk(...) gr_demod_bpsk.cpp:19-35,
+ *           make_gr_demod_dmr(sps, samp_rate) gr_demod_dmr.cpp:19-35
  *           with the literals of gr_demod_base.cpp:203-253 when use_mode_defaults != 0;
  *           gr_demod_base::set_samp_rate (gr_demod_base.cpp:1303-1362) via device_samp_rate;
  *           gr_demod_base::set_carrier_offset (gr_demod_base.cpp:1220-1225) via carrier_offset_hz.
@@ -120,9 +122,9 @@ int qrl_demod_process_host(qrl_demod* d, const float* iq_host, size_t stride, si
 /* ---- TX: the "modulator" top_block (reference src/gr/gr_mod_base.cpp:25) ----------------------------------
  * One handle = make_gr_mod_qpsk(sps, samp_rate, carrier_freq, filter_width) (src/gr/gr_mod_qpsk.cpp:19-30;
  * instance make_gr_mod_qpsk(4,1000000,1700,160000) src/gr/gr_mod_base.cpp:175) for `batch` independent streams.
- * Built: QPSK (gr_mod_qpsk.cpp), 2FSK incl. FM variants (gr_mod_2fsk.cpp:19-99), GMSK (gr_mod_gmsk.cpp:19-95);
- * gr_mod_base's rate-matching interpolator (gr_mod_base.cpp:249-258) and
- * rotator are not part of this handle yet. */
+ * Built: QPSK 250k / video / 20k / 2k (gr_mod_qpsk.cpp), 2FSK incl. FM variants (gr_mod_2fsk.cpp:19-99), GMSK
+ * (gr_mod_gmsk.cpp:19-95), 4FSK incl. the non-FM 2k mode (gr_mod_4fsk.cpp:19-115), BPSK (gr_mod_bpsk.cpp:19-67), and
+ * gr_mod_base's rotator + rate-matching interpolator (device_samp_rate / carrier_offset_hz below). */
 typedef struct qrl_mod qrl_mod;
 typedef struct {
     int modem_type;          /* gr_modem_types value (QRL_MODEM_QPSK250K) */
