@@ -728,7 +728,9 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         else {
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            HIPCHK(hipStreamCreateWithPriority(&d->tail, hipStreamNonBlocking, hi));
+            int prio = hi;   // QRL_TAIL_PRIO = "low" | "normal": experiments with the tail stream's priority
+            if (const char* e = std::getenv("QRL_TAIL_PRIO")) { if (e[0] == 'l') prio = lo; else if (e[0] == 'n') prio = 0; }
+            HIPCHK(hipStreamCreateWithPriority(&d->tail, hipStreamNonBlocking, prio));
         }
     }
     HIPCHK(hipEventCreateWithFlags(&d->ev_ff, hipEventDisableTiming));
