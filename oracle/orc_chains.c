@@ -569,7 +569,7 @@ size_t orc_mod_bpsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate,
     return m;
 }
 
-/* gr_demod_bpsk.cpp:36-110 (instances gr_demod_base.cpp:216-217: sps 10 / 5, both at 20 ksps):
+/* gr_demod_bpsk.cpp:36-103 (instances gr_demod_base.cpp:216-217: sps 10 / 5, both at 20 ksps):
  * rational_resampler_ccf(1, 50, low_pass(1, fs, 10k, 10k, BH)) -> fll_band_edge_cc(sps, 0.35, 32, 8pi/100) -> fft_filter_ccf(
  * RRC(sps, sps, 1, 0.35, 15 sps)) [port 0] -> agc2_cc(0.1, 0.1, 1, 1) -> clock_recovery_mm_cc(sps, 2.5e-5, 0.5, 0.05, 0.001)
  * -> costas_loop_cc(2pi/200, 2) [port 1] -> complex_to_real -> x64 +128 -> uchar -> 2x {cc_decoder -> descrambler} [ports 2, 3] */
