@@ -136,6 +136,48 @@ def run_c4(args, torch, q, ctx, dev, world):
                        "wideband_streams_per_gpu": B, "samples_per_stream_per_step": n}}
 
 
+def run_c5(args, torch, q, ctx, dev, world):
+    """C5: full duplex -- QPSK-250k modulator and QPSK-250k demodulator handles on their own HIP streams, calls interleaved without
+    synchronisation (BASELINE config 5; reference src/radiocontroller.cpp:2043-2078 runs the two top blocks concurrently)."""
+    import sig
+    B = args.batch or 4096
+    n = (args.nsamp or (1 << 16)) & ~1
+    nbytes = n // 32                                  # the TX produces as many 1 Msps samples as the RX consumes
+    base, _ = sig.make_stream("qpsk250k", nframes=3, device_rate=1000000, seed=3, amp=0.05)
+    base = np.tile(base, -(-n // base.size))[:n]
+    iq = torch.from_numpy(base).to(dev).repeat(B, 1).contiguous()
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    data = torch.randint(0, 256, (B, nbytes), generator=g, device=dev, dtype=torch.uint8)
+    dem = q.Demod(ctx, 26, batch=B, max_chunk=n)
+    mod = q.Mod(ctx, 26, batch=B, max_bytes=nbytes)
+    tx_out = torch.empty((B, nbytes * mod.spb), dtype=torch.complex64, device=dev)
+
+    def loop(k, do_tx=True, do_rx=True):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            if do_tx:
+                mod.process_async(data, out=tx_out)
+            if do_rx:
+                dem.process_async(iq)
+        mod.sync(); dem.sync()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    loop(args.warmup)
+    dt = loop(args.steps)
+    dt_rx = loop(args.steps, do_tx=False)
+    dt_tx = loop(args.steps, do_rx=False)
+    dem.close(); mod.close()
+    tot = float(B) * n * args.steps * world
+    return {"metric": "IQ MSamples/sec through RX demod chain (with the TX chain running concurrently)", "value": round(tot / dt / 1e6, 1),
+            "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C5: full duplex QPSK-250k TX + RX at 1 Msps on two HIP streams", "streams_per_gpu": B,
+                       "samples_per_stream_per_step": n, "tx_msps_concurrent": round(tot / dt / 1e6, 1),
+                       "rx_alone_ms_per_step": round(dt_rx / args.steps * 1e3, 3), "tx_alone_ms_per_step": round(dt_tx / args.steps * 1e3, 3)}}
+
+
 def cpu_baseline(name, threads, budget_s=12.0):
     """Oracle (CPU restatement of the reference flowgraph) on a bounded sample of the same workload:
     `threads` independent streams (OpenMP over streams, one stream per core), repeated until ~budget_s seconds
@@ -163,7 +205,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS) + ["c4"])
+    ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS) + ["c4", "c5"])
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--nsamp", type=int, default=0)
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workload and the CPU baseline")
@@ -184,8 +226,8 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=dev)
     ctx = q.Context(local)
 
-    if args.config == "c4":
-        line = run_c4(args, torch, q, ctx, dev, world)
+    if args.config in ("c4", "c5"):
+        line = (run_c4 if args.config == "c4" else run_c5)(args, torch, q, ctx, dev, world)
         if rank == 0:
             print(json.dumps(line))
         ctx.close()
