@@ -701,7 +701,7 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
     default: return fail(QRL_ERR_ARG, "modem_type not supported by this build");
     }
     if (c.samp_rate != 1000000) return fail(QRL_ERR_ARG, "internal samp_rate must be 1000000 (gr_demod_base.cpp:21)");
-    if (c.device_samp_rate < 1000000 || (c.device_samp_rate >= 2000000 && c.device_samp_rate % 1000000))
+    if (c.device_samp_rate != 1000000 && (c.device_samp_rate < 2000000 || c.device_samp_rate % 1000000))
         return fail(QRL_ERR_ARG, "device_samp_rate must be 1e6 or a multiple of 1e6 >= 2e6");
     HIPCHK(hipSetDevice(ctx->device));
     // Streams.  Optional CU partition between the main and the tail stream (QRL_TAIL_CUS = CUs reserved for the tail).
