@@ -89,3 +89,33 @@ def test_mod_and_channelizer_reset(qrl_ctx):
     o2, c2 = ch.process(dx); o2, c2 = o2.cpu().numpy(), c2.cpu().numpy()
     ch.close()
     assert np.array_equal(c1, c2) and all(np.array_equal(o1[0, k, :c1[0, k]], o2[0, k, :c2[0, k]]) for k in range(10))
+
+
+def test_process_host_matches_device_path(qrl_ctx, capsys):
+    """qrl_demod_process_host (H2D copy + one pass + D2H of the bit ports, what a host-buffer caller uses) returns the same
+    bits as the device-pointer path; prints the PCIe-inclusive rate of the call for DESIGN.md"""
+    import ctypes as C
+    import time
+    import torch
+    import qradiolink_amd as q
+    B = 32
+    iq = sig.make_batch("gmsk10k", 2, nframes=2, device_rate=4000000, rx_offset_hz=25000.0, seed=12)
+    n = iq.shape[1] & ~1
+    iq = np.ascontiguousarray(np.concatenate([iq[:, :n]] * (B // 2)))
+    dem = q.Demod(qrl_ctx, q.MODEM_GMSK10K, batch=B, max_chunk=n, device_samp_rate=4000000, carrier_offset_hz=25000.0)
+    out = q.collect(dem, torch.from_numpy(iq).cuda(), n)
+    dem.reset()
+    fcap, ccap, bcap = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    assert dem.lib.qrl_demod_out_caps(dem.h, n, C.byref(fcap), C.byref(ccap), C.byref(bcap)) == 0
+    ba = np.zeros((B, bcap.value), np.uint8); bb = np.zeros((B, bcap.value), np.uint8); cnt = np.zeros((B, 4), np.uint32)
+    t0 = time.perf_counter()
+    rc = dem.lib.qrl_demod_process_host(dem.h, iq.ctypes.data_as(C.c_void_p), n, n, ba.ctypes.data_as(C.c_void_p),
+                                        bb.ctypes.data_as(C.c_void_p), bcap.value, cnt.ctypes.data_as(C.c_void_p))
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    dem.close()
+    for b in range(B):
+        assert np.array_equal(ba[b, :cnt[b, 2]], out["bits_a"][b]) and np.array_equal(bb[b, :cnt[b, 3]], out["bits_b"][b])
+    with capsys.disabled():
+        print("\n[process_host] %d x %d samples from pageable host memory: %.1f ms = %.2f GS/s (%.1f GB/s over PCIe incl. allocation)"
+              % (B, n, dt * 1e3, B * n / dt / 1e9, B * n * 8 / dt / 1e9))
