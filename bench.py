@@ -203,8 +203,8 @@ def cpu_baseline(name, threads, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS) + ["c4", "c5"])
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--nsamp", type=int, default=0)
