@@ -10,6 +10,7 @@
 // samples [k W - 16, (k+1) W): the first 16 columns are Costas OUTPUTS carried over from the window before
 // (symbol sync looks back at most 13 samples), the rest arrives raw and is overwritten in place by pass 1
 // (AGC + Costas), then pass 2 (symbol sync and everything at the symbol rate) walks the row.
+#include <cstdlib>
 #include "devmath.hpp"
 #include "engine.hpp"
 
@@ -287,6 +288,209 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
     }
 }
 
+// ---- two-wave pipeline of the QPSK chain (MODE 0; the default, QRL_QPSK_PIPE=0 selects k_qpsk_loops<0>) --------------------------
+// The serial chain costs ~1 us per 500 ksps sample and stream with both passes on one wave.  Here wave 0 runs pass 1 (agc2 +
+// first Costas loop) on window t while wave 1 runs pass 2 (symbol sync + second Costas + diff_phasor + rotate) on window t - 1
+// and waves 2-3 load window t + 1 and flush the symbols of window t - 2: three window buffers, one barrier per step.  The
+// arithmetic and its order are those of k_qpsk_loops<0>.  Measured (C5, 4096 streams x 65536 samples): 32.6 -> 22.9 ms per call.
+constexpr int QPP_W = 56;
+constexpr int QPP_COLS = QP_BACK + QPP_W;    // 72
+constexpr int QPP_PITCH = QPP_COLS + 1;      // 73
+constexpr int QPP_OMAX = 32;                 // symbols per stream per window (sps >= 1.9: 56 / 1.9 + 2)
+constexpr int QPP_OPITCH = QPP_OMAX + 1;
+
+__global__ __launch_bounds__(256) void k_qpsk_pipe(const QpskParams P, int batch)
+{
+    extern __shared__ __align__(16) unsigned char qp_smem[];
+    float2* win = reinterpret_cast<float2*>(qp_smem);                    // [3][64][QPP_PITCH]
+    float2* osym = win + 3 * 64 * QPP_PITCH;                             // [2][64][QPP_OPITCH]
+    float* mm = reinterpret_cast<float*>(osym + 2 * 64 * QPP_OPITCH);    // [129][8]
+    float* th = mm + 129 * 8;                                            // [256]
+    int* ocnt = reinterpret_cast<int*>(th + 256);                        // [2][64]
+    uint64_t* obase = reinterpret_cast<uint64_t*>(ocnt + 2 * 64);        // [2][64]
+    uint64_t* oo0 = obase + 2 * 64;                                      // [64]
+
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int b0 = blockIdx.x * 64;
+    const int nstreams = min(64, batch - b0);
+    for (int k = tid; k < 129 * 8; k += 256) mm[k] = P.mmse[k];
+    th[tid] = P.tanh_tab[tid];
+    const uint64_t np0 = P.np0, avail = P.avail;
+    const long long k_first = (long long)(np0 / QPP_W);
+    const long long k_last = avail > np0 ? (long long)((avail - 1) / QPP_W) : k_first - 1;
+    const bool active = b0 + lane < batch;
+    QpskState st;
+    if (wv < 2 && active) st = P.st[b0 + lane];
+    else { st = QpskState{}; st.ii = ~0ull >> 1; }
+    if (wv == 1) oo0[lane] = st.oo;
+    auto wbuf = [&](long long k) { return win + (size_t)(((k % 3) + 3) % 3) * 64 * QPP_PITCH; };
+
+    auto load_window = [&](long long k, int t, int nthreads) {   // raw samples [max(kW, np0), min((k+1)W, avail))
+        float2* wb = wbuf(k);
+        const long long ia = max((long long)np0, k * QPP_W), ib = min((long long)avail, (k + 1) * QPP_W);
+        const int cnt = (int)(ib - ia);
+        if (cnt <= 0) return;
+        const int c0 = (int)(ia - (k * QPP_W - QP_BACK));
+        const int total = nstreams * cnt;
+        for (int idx = t; idx < total; idx += nthreads) {
+            const int s = idx / cnt, c = idx - s * cnt;
+            wb[s * QPP_PITCH + c0 + c] = P.in.p[(size_t)(b0 + s) * (P.in.mask + 1u) + ((uint32_t)(ia + c) & P.in.mask)];
+        }
+    };
+    auto flush_window = [&](long long k, int t, int nthreads) {
+        const int pb = (int)(k & 1);
+        const float2* ob = osym + (size_t)pb * 64 * QPP_OPITCH;
+        for (int idx = t; idx < nstreams * QPP_OMAX; idx += nthreads) {
+            const int s = idx / QPP_OMAX, j = idx - s * QPP_OMAX;
+            if (j < ocnt[pb * 64 + s]) {
+                const float2 v = ob[s * QPP_OPITCH + j];
+                const uint64_t o = obase[pb * 64 + s] + j;
+                float qa = v.x * P.soft_mul; qa = qa + P.soft_add;
+                float qb = v.y * P.soft_mul; qb = qb + P.soft_add;
+                float ra = rintf(qa), rb = rintf(qb);
+                if (!(ra >= 0.f)) ra = 0.f; if (ra > 255.f) ra = 255.f;
+                if (!(rb >= 0.f)) rb = 0.f; if (rb > 255.f) rb = 255.f;
+                uint8_t* sp = P.soft.p + (size_t)(b0 + s) * (P.soft.mask + 1u);
+                sp[(uint32_t)(2 * o) & P.soft.mask] = (uint8_t)ra;
+                sp[(uint32_t)(2 * o + 1) & P.soft.mask] = (uint8_t)rb;
+                const uint64_t kk = o - oo0[s];
+                if (P.port && kk < P.port_cap) P.port[(size_t)(b0 + s) * P.port_cap + kk] = v;
+            }
+        }
+    };
+
+    __syncthreads();
+    if (k_first <= k_last) load_window(k_first, tid, 256);
+    __syncthreads();
+    const float SQ = 0.707107f;
+    for (long long t = k_first; t <= k_last + 2; ++t) {
+        if (wv == 0) {
+            if (t <= k_last && active) {      // ---- pass 1 on window t: carry, then agc2_cc -> costas_loop_cc in place
+                float2* row = wbuf(t) + lane * QPP_PITCH;
+                const long long i0 = t * QPP_W - QP_BACK;
+                if (t > k_first) {
+                    const float2* prow = wbuf(t - 1) + lane * QPP_PITCH;
+#pragma unroll
+                    for (int j = 0; j < QP_BACK; ++j) row[j] = prow[QPP_W + j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const long long c = (long long)np0 - 16 + j - i0;
+                        if (c >= 0 && c < QPP_COLS) row[c] = st.hist[j];
+                    }
+                }
+                const int ca = (int)(max((long long)np0, t * QPP_W) - i0), cb = (int)(min((long long)avail, (t + 1) * QPP_W) - i0);
+                for (int c = ca; c < cb; ++c) {
+                    const float2 x = row[c];
+                    float2 a; a.x = x.x * st.gain; a.y = x.y * st.gain;
+                    const float tmp = -1.0f + sqrtf(a.x * a.x + a.y * a.y);
+                    float rate = 0.1f;
+                    if (tmp > st.gain) rate = 1.0f;
+                    st.gain -= tmp * rate;
+                    if (st.gain < 0.0f) st.gain = 10e-5f;
+                    if (st.gain > 65536.0f) st.gain = 65536.0f;
+                    const float2 nco = sincos_rad(-st.c1_phase);
+                    float2 o; o.x = a.x * nco.x - a.y * nco.y; o.y = a.x * nco.y + a.y * nco.x;
+                    row[c] = o;
+                    float e = costas4_snr_error(o, th);
+                    e = branchless_clip(e, 1.0f);
+                    st.c1_freq = st.c1_freq + P.c1_beta * e;
+                    st.c1_phase = st.c1_phase + st.c1_freq + P.c1_alpha * e;
+                    st.c1_phase = phase_wrap(st.c1_phase);
+                    if (st.c1_freq > 1.0f) st.c1_freq = 1.0f; else if (st.c1_freq < -1.0f) st.c1_freq = -1.0f;
+                }
+                if (t == k_last) {             // keep the last 16 Costas outputs for the next call
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const long long i = (long long)avail - 16 + j;
+                        const long long c = i - i0;
+                        st.hist[j] = (c >= 0 && i >= 0) ? row[c] : make_float2(0.f, 0.f);
+                    }
+                }
+            }
+        } else if (wv == 1) {
+            const long long k = t - 1;
+            if (k >= k_first && k <= k_last) {   // ---- pass 2 on window t - 1
+                const int pb = (int)(k & 1);
+                const float2* row = wbuf(k) + lane * QPP_PITCH;
+                float2* orow = osym + (size_t)pb * 64 * QPP_OPITCH + lane * QPP_OPITCH;
+                const long long i0 = k * QPP_W - QP_BACK;
+                const uint64_t wend = (uint64_t)min((long long)avail, (k + 1) * QPP_W);
+                const uint64_t oo_w = st.oo;
+                int nsym = 0;
+                while (active && st.ii + 8 <= wend && nsym < QPP_OMAX) {
+                    const int off = (int)((long long)st.ii - i0);
+                    const int imu = (int)rintf(st.mu * 128.0f);
+                    const float* tp = mm + imu * 8;
+                    float2 y = make_float2(0.f, 0.f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float2 xs = row[off + j];
+                        y.x = fmaf(tp[7 - j], xs.x, y.x);
+                        y.y = fmaf(tp[7 - j], xs.y, y.y);
+                    }
+                    st.x2 = st.x1; st.x1 = st.x0; st.x0 = y;
+                    st.d2 = st.d1; st.d1 = st.d0;
+                    st.d0.x = y.x > 0.f ? SQ : -SQ; st.d0.y = y.y > 0.f ? SQ : -SQ;
+                    float e;
+                    {
+                        const float ar = st.x0.x - st.x2.x, ai = st.x0.y - st.x2.y;
+                        const float br = st.d0.x - st.d2.x, bi = st.d0.y - st.d2.y;
+                        const float u = (ar * st.d1.x + ai * st.d1.y) - (br * st.x1.x + bi * st.x1.y);
+                        e = branchless_clip(u, 1.0f);
+                    }
+                    st.avg = st.avg + P.ss_beta * e;
+                    if (st.avg > P.ss_maxp) st.avg = P.ss_maxp; else if (st.avg < P.ss_minp) st.avg = P.ss_minp;
+                    st.inst = st.avg + P.ss_alpha * e;
+                    if (st.inst <= 0.f) st.inst = st.avg;
+                    const float ph = st.mu + st.inst;
+                    const float fl = floorf(ph);
+                    st.mu = ph - fl;
+                    st.ii += (uint64_t)(int)fl;
+                    const float2 nco = sincos_rad(-st.c2_phase);
+                    float2 o; o.x = y.x * nco.x - y.y * nco.y; o.y = y.x * nco.y + y.y * nco.x;
+                    float e2 = costas4_snr_error(o, th);
+                    e2 = branchless_clip(e2, 1.0f);
+                    st.c2_freq = st.c2_freq + P.c2_beta * e2;
+                    st.c2_phase = st.c2_phase + st.c2_freq + P.c2_alpha * e2;
+                    st.c2_phase = phase_wrap(st.c2_phase);
+                    if (st.c2_freq > 1.0f) st.c2_freq = 1.0f; else if (st.c2_freq < -1.0f) st.c2_freq = -1.0f;
+                    float2 dp; dp.x = o.x * st.dprev.x + o.y * st.dprev.y; dp.y = o.y * st.dprev.x - o.x * st.dprev.y;
+                    st.dprev = o;
+                    float2 v; v.x = dp.x * P.rot.x - dp.y * P.rot.y; v.y = dp.x * P.rot.y + dp.y * P.rot.x;
+                    orow[nsym] = v;
+                    nsym++;
+                    st.oo++;
+                }
+                ocnt[pb * 64 + lane] = nsym;
+                obase[pb * 64 + lane] = oo_w;
+            }
+        } else {
+            if (t + 1 <= k_last) load_window(t + 1, tid - 128, 128);
+            if (t - 2 >= k_first && t - 2 <= k_last) flush_window(t - 2, tid - 128, 128);
+        }
+        __syncthreads();
+    }
+    if (active && wv == 0) {
+        QpskState& g = P.st[b0 + lane];
+        g.gain = st.gain; g.c1_phase = st.c1_phase; g.c1_freq = st.c1_freq;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) g.hist[j] = st.hist[j];
+    }
+    if (active && wv == 1) {
+        QpskState& g = P.st[b0 + lane];
+        g.ii = st.ii; g.oo = st.oo; g.mu = st.mu; g.avg = st.avg; g.inst = st.inst;
+        g.x0 = st.x0; g.x1 = st.x1; g.x2 = st.x2; g.d0 = st.d0; g.d1 = st.d1; g.d2 = st.d2;
+        g.c2_phase = st.c2_phase; g.c2_freq = st.c2_freq; g.dprev = st.dprev;
+        P.counts[(b0 + lane) * 4 + 1] = (uint32_t)(st.oo - oo0[lane]);
+    }
+}
+static size_t qpsk_pipe_lds_bytes()
+{
+    return (size_t)(3 * 64 * QPP_PITCH + 2 * 64 * QPP_OPITCH) * sizeof(float2) + (129 * 8 + 256) * sizeof(float) + 2 * 64 * sizeof(int) +
+           (2 * 64 + 64) * sizeof(uint64_t);
+}
+
 static size_t qpsk_lds_bytes()
 {
     return (size_t)(2 * 64 * QP_PITCH + 2 * 64 * QP_OPITCH) * sizeof(float2) + (129 * 8 + 256) * sizeof(float) + 2 * 64 * sizeof(int) +
@@ -301,6 +505,13 @@ void launch_qpsk_loops(const QpskParams& p, int batch, hipStream_t s)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qpsk_loops<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qpsk_lds_bytes());
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qpsk_loops<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qpsk_lds_bytes());
         attr = true;
+    }
+    static const bool pipe = [] { const char* e = std::getenv("QRL_QPSK_PIPE"); return !(e && e[0] == '0'); }();   // default on
+    if (p.mode == 0 && pipe) {
+        static bool attr2 = false;
+        if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qpsk_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qpsk_pipe_lds_bytes()); attr2 = true; }
+        hipLaunchKernelGGL(k_qpsk_pipe, dim3((batch + 63) / 64), dim3(256), qpsk_pipe_lds_bytes(), s, p, batch);
+        return;
     }
     if (p.mode == 2) hipLaunchKernelGGL(k_qpsk_loops<2>, dim3((batch + 63) / 64), dim3(256), qpsk_lds_bytes(), s, p, batch);
     else if (p.mode == 1) hipLaunchKernelGGL(k_qpsk_loops<1>, dim3((batch + 63) / 64), dim3(256), qpsk_lds_bytes(), s, p, batch);
