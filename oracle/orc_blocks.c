@@ -135,8 +135,54 @@ int orc_decim_uses_m16(int nt, int D)
     const long long samples = 7LL * 16 * D + 4LL * orc_m16_steps(nt, D);
     return (samples + 2 * (samples / (16LL * D)) + 64) * 8 <= 150 * 1024;
 }
+/* "pl" (phase-lane) summation contract of the register-resident decimator k_decim_pl.
+ * Samples are dealt to 64 lane slots: super-block length D' = R*D with R = 64/D (integer division) when
+ * D <= 32, else D' = D; a slot holds E = ceil(D'/64) consecutive samples; slot(i) = ((i - 1) mod D') / E
+ * (block c covers samples (c-1)D'+1 .. cD').  For output m every slot forms ONE chain over its own samples
+ * i (ascending = oldest first) with tap k = m*D - i in [0, nt): the first term is the plain product
+ * h*x, every later term an fmaf; a slot without samples holds +0.  Samples before the stream start are +0
+ * and take part.  The 64 slot values meet in a radix-2 tree: for h = 32,16,8,4,2,1: v[l] = v[l] + v[l+h], l < h.
+ * (k_decim_pl also runs the zero taps k >= nt of a slot's chain; that can only change the sign of an exact zero.) */
+void orc_pl_geometry(int D, int* Dp, int* E)
+{
+    const int R = D <= 32 ? 64 / D : 1;
+    *Dp = R * D;
+    *E = (*Dp + 63) / 64;
+}
+int orc_decim_uses_pl(int nt, int D)
+{
+    /* the geometries k_decim_pl is instantiated for: one sample per lane, at most 16 taps per lane */
+    return D > 32 && D <= 64 && (nt + D - 1) / D <= 16;
+}
+size_t orc_decim_fir_ccf_pl(const cf32* in, size_t n, const float* taps, int nt, int D, cf32* out)
+{
+    size_t nout = orc_decim_count(n, 1, D);
+    int Dp, E;
+    orc_pl_geometry(D, &Dp, &E);
+    for (size_t m = 0; m < nout; m++) {
+        float vr[64], vi[64];
+        int used[64];
+        for (int l = 0; l < 64; l++) { vr[l] = 0.0f; vi[l] = 0.0f; used[l] = 0; }
+        for (int k = nt - 1; k >= 0; k--) {
+            const long long i = (long long)m * D - k;
+            cf32 x = {0.0f, 0.0f};
+            if (i >= 0) x = in[i];
+            long long r = (i - 1) % Dp;
+            if (r < 0) r += Dp;
+            const int l = (int)(r / E);
+            const float h = taps[k];
+            if (!used[l]) { vr[l] = h * x.re; vi[l] = h * x.im; used[l] = 1; }
+            else { vr[l] = fmaf(h, x.re, vr[l]); vi[l] = fmaf(h, x.im, vi[l]); }
+        }
+        for (int h = 32; h >= 1; h >>= 1)
+            for (int l = 0; l < h; l++) { vr[l] = vr[l] + vr[l + h]; vi[l] = vi[l] + vi[l + h]; }
+        out[m].re = vr[0]; out[m].im = vi[0];
+    }
+    return nout;
+}
 size_t orc_decim_auto(const cf32* in, size_t n, const float* taps, int nt, int D, cf32* out)
 {
+    if (orc_decim_uses_pl(nt, D)) return orc_decim_fir_ccf_pl(in, n, taps, nt, D, out);
     if (orc_decim_uses_m16(nt, D)) return orc_decim_fir_ccf_m16(in, n, taps, nt, D, out);
     return orc_decim_fir_ccf(in, n, taps, nt, D, 4, out);
 }

@@ -76,11 +76,15 @@ std::vector<float2> to_f2(const std::vector<std::complex<float>>& v)
 }
 
 struct DecimStage {
-    bool used = false, mfma = false;
+    bool used = false, mfma = false, pl = false;
     int D = 1, Jpad = 0, variant = DECIM_R4_J12, nt = 0, S = 0;
     DevBuf<float> taps;
     int plan(const std::vector<float>& h, int D_) {
         used = true; D = D_; nt = (int)h.size();
+        if (decim_uses_pl(nt, D)) {   // register-resident phase-lane kernel (the 1:50 first stages)
+            pl = true;
+            return taps.upload(decim_pl_layout(h, D));
+        }
         const char* force = std::getenv("QRL_DECIM_VALU");   // A/B timing only: changes the summation contract
         if (decim_uses_mfma(nt, D) && !(force && force[0] == '1')) {
             // zero-padded tap vector the MFMA A operands are read from: hp[k + (4S - nt + 1)] = h[k]
@@ -102,7 +106,13 @@ struct DecimStage {
         if (decim_lds_bytes(D, Jpad, variant) > 160 * 1024) return QRL_ERR_ARG;
         return taps.upload(decim_layout(h, D, Jpad));
     }
-    uint32_t lookback() const { return mfma ? (uint32_t)(nt + D) : (uint32_t)(Jpad * D); }
+    uint32_t lookback() const { return pl ? (uint32_t)(((nt + D - 1) / D + 1) * D) : mfma ? (uint32_t)(nt + D) : (uint32_t)(Jpad * D); }
+    void launch(DecimParams& p, int B, hipStream_t s) const {
+        p.nt = nt;
+        if (pl) { p.pl_taps = taps.p; launch_decim_pl(p, B, s); }
+        else if (mfma) { p.gtab = taps.p; p.S = S; launch_decim_mfma(p, B, s); }
+        else launch_decim(p, B, variant, s);
+    }
 };
 
 }  // namespace
@@ -449,8 +459,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         p.out = r1; p.m0 = n1_0; p.m_count = (uint32_t)(n1_1 - n1_0);
         p.taps = fe.taps.p; p.D = fe.D; p.Jpad = fe.Jpad;
         p.rot_enable = 1; p.rot_acc = rot_acc; p.rot_inc = rot_inc; p.rot_nbase = rot_nbase; p.rot_lo = rot_lo.p;
-        if (fe.mfma) { p.gtab = fe.taps.p; p.S = fe.S; p.nt = fe.nt; launch_decim_mfma(p, B, stream); }
-        else launch_decim(p, B, fe.variant, stream);
+        fe.launch(p, B, stream);
     }
     if (profiling && fe.used) { HIPCHK(hipEventRecord(ev1, stream)); prof_events.emplace_back(ev0, ev1); }
     // ---- stage B: per-mode resampler
@@ -464,8 +473,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         p.n0 = src0; p.n = (uint32_t)(src1 - src0);
         p.out = r2; p.m0 = n2_0; p.m_count = (uint32_t)(n2_1 - n2_0);
         p.taps = first.taps.p; p.D = first.D; p.Jpad = first.Jpad;
-        if (first.mfma) { p.gtab = first.taps.p; p.S = first.S; p.nt = first.nt; launch_decim_mfma(p, B, stream); }
-        else launch_decim(p, B, first.variant, stream);
+        first.launch(p, B, stream);
     } else {
         ResampParams p{};
         if (fe.used) { p.in = nullptr; p.in_ring = r1; }
@@ -809,7 +817,7 @@ int qrl_demod_profile_read(qrl_demod* d, double* kernel_ms, uint64_t* launches, 
     if (launches) *launches = d->prof_events.size();
     if (kernel_name) {
         const DecimStage& st = d->fe.used ? d->fe : d->first;
-        *kernel_name = (d->fe.used || d->interp == 1) ? (st.mfma ? "k_decim_mfma" : "k_decim") : "k_resamp";
+        *kernel_name = (d->fe.used || d->interp == 1) ? (st.pl ? "k_decim_pl" : st.mfma ? "k_decim_mfma" : "k_decim") : "k_resamp";
     }
     d->prof_events.clear();
     return QRL_OK;

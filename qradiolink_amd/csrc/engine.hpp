@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace qrl {
 
@@ -29,7 +30,9 @@ struct DecimParams {
     uint32_t tpw, nchunks; int nhi; int dbg;               // consecutive tiles per workgroup; rotator coarse-table entries
     int nld;                                                // 16-byte loads per thread a tile needs (<= the kernel's NLD)
     int hist_raw;                                           // hist holds UN-rotated samples (MFMA variant only): rotate on fetch
-    uint32_t out_row_mul_m1, out_row_add;                   // output ring row of stream b = b * (mul_m1 + 1) + add (MFMA variant only)
+    uint32_t out_row_mul_m1, out_row_add;                   // output ring row of stream b = b * (mul_m1 + 1) + add (MFMA / phase-lane variants)
+    // phase-lane variant (kernels_decim_pl.hip): lane tap table [J][64]; the launcher fills the segment geometry
+    const float* pl_taps; int pl_J; uint32_t pl_S, pl_nseg, pl_batch; uint64_t pl_m_begin, pl_m_end;
 };
 struct HistParams {
     const float2* in; size_t in_stride; uint64_t n0; uint32_t n;
@@ -49,6 +52,10 @@ int decim_mfma_hpn(int nt, int D);
 size_t decim_mfma_lds_bytes(int nt, int D);
 void launch_decim_mfma(const DecimParams& p, int batch, hipStream_t s);
 void decim_mfma_prof_read(unsigned long long* out8);
+// register-resident phase-lane decimator (32 < D <= 64, <= 16 taps per phase): contract "pl" of oracle/orc_blocks.c
+bool decim_uses_pl(int nt, int D);
+std::vector<float> decim_pl_layout(const std::vector<float>& h, int D);
+void launch_decim_pl(const DecimParams& p, int batch, hipStream_t s);
 
 // ---- K2: rational resampler I/D on a ring (optionally with rotator on a caller buffer) ----
 struct ResampParams {

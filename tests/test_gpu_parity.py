@@ -73,6 +73,7 @@ def _compare(iq, out, mode_name, device_rate, offset):
     ("qpsk250k", 26, 10000000, 1 << 23),    # C3 behind the 10:1 front end
     ("gmsk10k", 22, 64000000, 1 << 24),     # front end 64:1, 2677 taps: 8-block tile, 22 loads per thread (NLD = 36 variant)
     ("gmsk10k", 22, 100000000, 1 << 24),    # front end 100:1, 4181 taps: only the 4-block MFMA tile fits the LDS
+    ("qpsk250k", 26, 100000000, 1 << 24),   # BASELINE config C3 literally: QPSK-250k behind the 100:1 front end
     ("qpsk2k", 7, 1000000, 1 << 21),        # gr_demod_qpsk sps >= 125: 1:100 (3621 taps), FLL(32 taps), 5 samples per symbol
     ("qpsk20k", 1, 2000000, 1 << 22),       # gr_demod_qpsk 4 < sps < 125: 1:25, FLL, 4 samples per symbol
     ("4fsk2k", 3, 1000000, 1 << 21),        # gr_demod_4fsk non-FM branch: 4 band-pass magnitudes -> discriminator -> 837-tap LPF -> symbol_sync_cc
@@ -217,3 +218,27 @@ def test_pipelined_calls_without_sync(qrl_ctx, mode_name, modem):
     ref = _oracle(mode_name, iq[0, :ncalls * chunk], 1000000, 0.0)
     n_last = int(c1[0, 2])
     assert n_last > 0 and np.array_equal(a1[0, :n_last], ref["bits_a"][-n_last:])
+
+
+@pytest.mark.parametrize("mode_name,modem,rate,B,nframes", [
+    ("2fsk1k", 18, 1000000, 1536, 1),       # C1 at a bench-like batch: several segments per stream, grid.x >> 8 (k_decim_pl units, FLL quads)
+    ("gmsk10k", 22, 25000000, 1024, 1),     # C2 at a bench-like batch: MFMA front end with tpw > 1 and the XCD remap of grid.x
+])
+def test_large_batch_bit_exact(qrl_ctx, mode_name, modem, rate, B, nframes):
+    """Grids, tiles-per-workgroup and stream indexing at bench-like batch sizes: B streams cycle through 6 distinct seeded
+    inputs; every one of the B outputs must equal the oracle's output for its input."""
+    import torch
+    import qradiolink_amd as q
+    offset = 25000.0 if rate >= 2000000 else 1200.0
+    base = sig.make_batch(mode_name, 6, nframes=nframes, device_rate=rate, rx_offset_hz=offset, seed=21)
+    idx = np.arange(B) % 6
+    iq = torch.from_numpy(base).cuda()[torch.from_numpy(idx).cuda()].contiguous()
+    dem = q.Demod(qrl_ctx, modem, batch=B, max_chunk=base.shape[1], device_samp_rate=rate, carrier_offset_hz=offset)
+    out = q.collect(dem, iq, base.shape[1])
+    dem.close()
+    refs = [_oracle(mode_name, base[k], rate, offset) for k in range(6)]
+    for b in range(B):
+        ref = refs[idx[b]]
+        assert np.array_equal(out["bits_a"][b], ref["bits_a"]) and np.array_equal(out["bits_b"][b], ref["bits_b"]), "bits of stream %d" % b
+        got, want = out["filtered"][b].view(np.float32) + np.float32(0), ref["filtered"].view(np.float32) + np.float32(0)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "port 0 of stream %d" % b

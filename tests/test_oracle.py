@@ -188,6 +188,50 @@ def test_decimator_matches_definition_and_chain_split():
     assert np.max(np.abs(y - want)) < 2e-6 * np.max(np.abs(want))
 
 
+def _definition_error(y, x, h, decim):
+    full = np.convolve(x.astype(np.complex128), h.astype(np.float64))[: x.size]
+    want = full[::decim]
+    assert y.size == want.size
+    rms = np.sqrt(np.mean(np.abs(want) ** 2))
+    return np.max(np.abs(y - want)) / rms
+
+
+@pytest.mark.parametrize("fs,decim", [(25000000, 25), (50000000, 50), (100000000, 100)])
+def test_m16_contract_matches_float64_definition(fs, decim):
+    """The MFMA summation order (four fmaf chains per output over zero-padded quarters) stays inside the 1e-5 of RMS the
+    north star allows against the float64 definition of the decimating FIR, for the three front-end geometries."""
+    rng = np.random.default_rng(70 + decim)
+    h = orc.low_pass(1, fs, 480e3, 100e3, BH)
+    x = (rng.standard_normal(40 * decim + h.size) + 1j * rng.standard_normal(40 * decim + h.size)).astype(np.complex64)
+    assert orc.lib.orc_decim_uses_m16(h.size, decim)
+    assert _definition_error(orc.decim_fir_ccf_m16(x, h, decim), x, h, decim) < 1e-5
+
+
+@pytest.mark.parametrize("decim,nt_scale", [(50, 1.0), (33, 1.0), (64, 0.7)])
+def test_pl_contract_matches_float64_definition(decim, nt_scale):
+    """Phase-lane order of k_decim_pl (one chain per lane slot, radix-2 tree over the 64 slots) against the float64
+    definition; also the rule that selects it and equality with the plain chain when the tree degenerates."""
+    rng = np.random.default_rng(90 + decim)
+    h = orc.low_pass(1, 1e6, 10e3 / nt_scale, 10e3 / nt_scale, BH)
+    x = (rng.standard_normal(60 * decim + h.size) + 1j * rng.standard_normal(60 * decim + h.size)).astype(np.complex64)
+    assert orc.lib.orc_decim_uses_pl(h.size, decim)
+    y = orc.decim_fir_ccf_pl(x, h, decim)
+    assert _definition_error(y, x, h, decim) < 1e-5
+    assert np.array_equal(orc.decim_auto(x, h, decim).view(np.float32), y.view(np.float32))
+
+
+def test_pl_contract_is_position_independent():
+    """Output m only depends on the samples of its window: a stream that starts later (shifted by whole blocks) gives the
+    same bits once the window is inside the stream -- the property chunked / segmented evaluation relies on."""
+    rng = np.random.default_rng(5)
+    h = orc.low_pass(1, 1e6, 10e3, 10e3, BH)
+    x = (rng.standard_normal(4000) + 1j * rng.standard_normal(4000)).astype(np.complex64)
+    y = orc.decim_fir_ccf_pl(x, h, 50)
+    y2 = orc.decim_fir_ccf_pl(x[500:], h, 50)
+    k = (h.size + 49) // 50 + 1
+    assert np.array_equal(y[10 + k:].view(np.float32), y2[k:].view(np.float32))
+
+
 def test_rational_resampler_matches_zero_stuffing_definition():
     rng = np.random.default_rng(8)
     x = (rng.standard_normal(3000) + 1j * rng.standard_normal(3000)).astype(np.complex64)
