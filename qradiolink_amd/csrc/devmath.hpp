@@ -24,14 +24,14 @@ __device__ __forceinline__ float poly_cos(float x)
     return fmaf(z * z, p, q);
 }
 // returns (cos, sin)
+// quadrant q: 0 -> (pc, ps), 1 -> (-ps, pc), 2 -> (-pc, -ps), 3 -> (ps, -pc).  Branch-free (two selects, two sign flips):
+// the recursive loops call this once per sample and a switch costs four exec-mask regions on a wave that cannot hide them.
 __device__ __forceinline__ float2 quad_fix(int q, float ps, float pc)
 {
-    switch (q & 3) {
-    case 0: return make_float2(pc, ps);
-    case 1: return make_float2(-ps, pc);
-    case 2: return make_float2(-pc, -ps);
-    default: return make_float2(ps, -pc);
-    }
+    const bool swap = q & 1;
+    const uint32_t c0 = __float_as_uint(swap ? ps : pc), s0 = __float_as_uint(swap ? pc : ps);
+    const uint32_t negc = ((uint32_t)(q + 1) & 2u) << 30, negs = ((uint32_t)q & 2u) << 30;
+    return make_float2(__uint_as_float(c0 ^ negc), __uint_as_float(s0 ^ negs));
 }
 // (cos x, sin x) of a float angle in radians, |x| <~ 10
 __device__ __forceinline__ float2 sincos_rad(float x)
@@ -109,6 +109,8 @@ __device__ __forceinline__ float branchless_clip(float x, float clip)
 __device__ __forceinline__ float phase_wrap(float phase)
 {
     const double TWO_PI = 6.283185307179586476925286766559;
+    // same loops as gr::blocks::control_loop::phase_wrap; the common case (no lane of the wave out of range) is one uniform branch
+    if (__builtin_amdgcn_ballot_w64(phase > (float)TWO_PI || phase < (float)(-TWO_PI)) == 0) return phase;
     while (phase > (float)TWO_PI) phase = (float)((double)phase - TWO_PI);
     while (phase < (float)(-TWO_PI)) phase = (float)((double)phase + TWO_PI);
     return phase;

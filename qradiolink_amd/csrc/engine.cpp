@@ -146,6 +146,7 @@ struct qrl_demod {
     DevBuf<float> filt_taps; int filt_nt = 0;
     DevBuf<float> symf_taps; int symf_nt = 0;
     DevBuf<float2> disc_up, disc_lo; int disc_nt = 0;
+    DevBuf<float> ff_tf, ff_ts; DevBuf<float2> ff_up, ff_lo;   // zero-padded copies for the fused 2FSK kernel (k_2fsk_ff)
     DevBuf<float2> fll_lo, fll_up; float fll_alpha = 0, fll_beta = 0, fll_maxf = 0;
     DevBuf<float> atan_tab, mmse_tab;
     float demod_gain = 0;
@@ -344,6 +345,12 @@ int qrl_demod::build()
             const std::vector<float> sf = low_pass(1.0, target, target / sps_eff, target / sps_eff, WIN_HAMMING);
             symf_nt = (int)sf.size();
             if ((r = symf_taps.upload(sf))) return r;
+            // zero-padded copies for the fused kernel (4 A + 1 taps, tables of 4 (A + 1) entries)
+            auto padf = [](std::vector<float> v) { v.resize((size_t)fsk2_ff_padded((int)v.size()) + 3, 0.0f); return v; };
+            auto padc = [](std::vector<float2> v) { v.resize((size_t)fsk2_ff_padded((int)v.size()) + 3, make_float2(0.f, 0.f)); return v; };
+            const std::vector<float> ftaps = low_pass(1, target, fw, fw, WIN_BLACKMAN_HARRIS);
+            if ((r = ff_tf.upload(padf(ftaps))) || (r = ff_ts.upload(padf(sf))) || (r = ff_up.upload(padc(to_f2(up2)))) ||
+                (r = ff_lo.upload(padc(to_f2(lo2))))) return r;
         }
         const float symbol_rate = (float)target / (float)sps_eff;
         const float dev = 200.0f / symbol_rate;
@@ -529,7 +536,8 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         if (!overlap && tail_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_tail, 0)); tail_pending = false; }
         Fsk2FfParams f{};
         f.in = filt_in; f.out = r3; f.q0 = n2_0; f.count = c2;
-        f.tf = filt_taps.p; f.nf = filt_nt; f.up = disc_up.p; f.lo = disc_lo.p; f.nb = disc_nt; f.ts = symf_taps.p; f.ns = symf_nt;
+        f.tf = ff_tf.p; f.nf = fsk2_ff_padded(filt_nt); f.up = ff_up.p; f.lo = ff_lo.p; f.nb = fsk2_ff_padded(disc_nt);
+        f.ts = ff_ts.p; f.ns = fsk2_ff_padded(symf_nt);
         f.port = side && out->filtered ? reinterpret_cast<float2*>(out->filtered) : nullptr;
         f.port_cap = side ? out->filtered_cap : 0;
         f.counts = counts;

@@ -82,7 +82,8 @@ void launch_disc_4fsk(const Disc4fskParams& p, int batch, hipStream_t s);
 struct Fsk2FfParams { RingC in; RingF out; uint64_t q0; uint32_t count;
                       const float* tf; int nf; const float2* up; const float2* lo; int nb; const float* ts; int ns;
                       float2* port; size_t port_cap; uint32_t* counts; };
-void launch_2fsk_ff(const Fsk2FfParams& p, int batch, hipStream_t s);
+void launch_2fsk_ff(const Fsk2FfParams& p, int batch, hipStream_t s);   // nf/nb/ns and the tables zero padded: fsk2_ff_padded()
+int fsk2_ff_padded(int n);
 void launch_fir_ccf(const FirCcfParams& p, int batch, hipStream_t s);
 void launch_fir_fff(const FirFffParams& p, int batch, hipStream_t s);
 void launch_quad_demod(const QuadDemodParams& p, int batch, hipStream_t s);

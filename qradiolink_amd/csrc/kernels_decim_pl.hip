@@ -24,6 +24,7 @@
 //
 // Summation contract "pl" (oracle/orc_blocks.c orc_decim_fir_ccf_pl): slot(i) = (i-1) mod D; per slot one chain, oldest
 // sample first, first term a plain product, then fmaf; 64 slots (unused = +0) meet as v[l] += v[l+h], h = 32,16,...,1.
+#include <cstdlib>
 #include <vector>
 #include "devmath.hpp"
 #include "engine.hpp"
@@ -32,8 +33,20 @@ namespace qrl {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-constexpr int PL_RING = 16;   // accumulator ring = unroll factor of the block loop
-constexpr int PL_PF = 8;      // blocks in flight per wave
+#ifndef QRL_PL_PF
+#define QRL_PL_PF 8
+#endif
+#ifndef QRL_PL_SCHED
+#define QRL_PL_SCHED 0
+#endif
+#ifndef QRL_PL_SCALAR
+#define QRL_PL_SCALAR 1   // plain v_fma_f32 pairs: packed f32 (v_pk_fma_f32) is no faster on gfx950 and measured 6 % slower here
+#endif
+#ifndef QRL_PL_WPE
+#define QRL_PL_WPE 0
+#endif
+constexpr int PL_RING = 16;        // accumulator ring = unroll factor of the block loop
+constexpr int PL_PF = QRL_PL_PF;   // blocks in flight per wave
 
 __device__ __forceinline__ float pl_dpp_ror8(float v)
 {
@@ -86,7 +99,11 @@ __device__ __forceinline__ int pl_out_index(int lane)
 }
 
 template <int J>
-__global__ __launch_bounds__(256) void k_decim_pl(const DecimParams P_)
+__global__ __launch_bounds__(256)
+#if QRL_PL_WPE
+__attribute__((amdgpu_waves_per_eu(QRL_PL_WPE, QRL_PL_WPE)))
+#endif
+void k_decim_pl(const DecimParams P_)
 {
     const DecimParams& P = P_;
     __shared__ float2 t_lo[512];
@@ -132,37 +149,63 @@ __global__ __launch_bounds__(256) void k_decim_pl(const DecimParams P_)
         const float2 v = ub[(size_t)t * D + lo];
         pf[q] = v2f{v.x, v.y};
     }
+#if QRL_PL_SCALAR
+    float ar[PL_RING], ai[PL_RING];
+#pragma unroll
+    for (int s = 0; s < PL_RING; ++s) ar[s] = ai[s] = 0.f;
+#else
     v2f acc[PL_RING];
 #pragma unroll
     for (int s = 0; s < PL_RING; ++s) acc[s] = v2f{0.f, 0.f};
+#endif
 
-    const int nsup = (nblk + PL_RING - 1) / PL_RING;
+    constexpr int UB = PL_PF > PL_RING ? PL_PF : PL_RING;   // blocks per loop body (multiple of both rings)
+    const int nsup = (nblk + UB - 1) / UB;
     for (int sup = 0; sup < nsup; ++sup) {
-        float dr[PL_RING], di[PL_RING];
 #pragma unroll
-        for (int i = 0; i < PL_RING; ++i) {
-            const int t = sup * PL_RING + i;
-            const v2f xr = pf[i % PL_PF];
-            {   // keep PL_PF blocks in flight (past the end of the segment: harmless re-read of its last block)
-                const int tn = t + PL_PF < nblk ? t + PL_PF : nblk - 1;
-                const float2 v = ub[(size_t)tn * D + lo];
-                pf[i % PL_PF] = v2f{v.x, v.y};
+        for (int grp = 0; grp < UB / PL_RING; ++grp) {
+            float dr[PL_RING], di[PL_RING];
+#pragma unroll
+            for (int i = 0; i < PL_RING; ++i) {
+                const int u = grp * PL_RING + i;
+                const int t = sup * UB + u;
+                const v2f xr = pf[u % PL_PF];
+                {   // keep PL_PF blocks in flight (past the end of the segment: harmless re-read of its last block)
+                    const int tn = t + PL_PF < nblk ? t + PL_PF : nblk - 1;
+                    const float2 v = ub[(size_t)tn * D + lo];
+                    pf[u % PL_PF] = v2f{v.x, v.y};
+                }
+                // rotator: phasor of sample k = T_hi[k >> 9] (x) T_lo[k & 511], byte addressed
+                const uint32_t kb8 = (k0 + (uint32_t)t * (uint32_t)D) * 8u + lo8;
+                const float2 plo = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(t_lo) + (kb8 & 4095u));
+                const float2 phi = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(t_hi) + ((kb8 >> 9) & ~7u));
+                const float2 xs = cmul_fma(make_float2(xr.x, xr.y), cmul_fma(phi, plo));
+                const v2f x = v2f{xs.x, xs.y};
+                // scatter into the ring: output m = c + j takes tap h[p + j D]; its first term (j = J - 1) is a plain product
+#if QRL_PL_SCALAR
+#pragma unroll
+                for (int j = 0; j < J - 1; ++j) {
+                    ar[(i + j) % PL_RING] = fmaf(h[j], xs.x, ar[(i + j) % PL_RING]);
+                    ai[(i + j) % PL_RING] = fmaf(h[j], xs.y, ai[(i + j) % PL_RING]);
+                }
+                ar[(i + J - 1) % PL_RING] = h[J - 1] * xs.x;
+                ai[(i + J - 1) % PL_RING] = h[J - 1] * xs.y;
+                dr[i] = ar[i]; di[i] = ai[i];
+                (void)x;
+#else
+#pragma unroll
+                for (int j = 0; j < J - 1; ++j) acc[(i + j) % PL_RING] = __builtin_elementwise_fma(v2f{h[j], h[j]}, x, acc[(i + j) % PL_RING]);
+                acc[(i + J - 1) % PL_RING] = v2f{h[J - 1], h[J - 1]} * x;
+                dr[i] = acc[i].x; di[i] = acc[i].y;
+#endif
+#if QRL_PL_SCHED
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
-            // rotator: phasor of sample k = T_hi[k >> 9] (x) T_lo[k & 511], byte addressed
-            const uint32_t kb8 = (k0 + (uint32_t)t * (uint32_t)D) * 8u + lo8;
-            const float2 plo = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(t_lo) + (kb8 & 4095u));
-            const float2 phi = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(t_hi) + ((kb8 >> 9) & ~7u));
-            const float2 xs = cmul_fma(make_float2(xr.x, xr.y), cmul_fma(phi, plo));
-            const v2f x = v2f{xs.x, xs.y};
-            // scatter into the ring: output m = c + j takes tap h[p + j D]; its first term (j = J - 1) is a plain product
-#pragma unroll
-            for (int j = 0; j < J - 1; ++j) acc[(i + j) % PL_RING] = __builtin_elementwise_fma(v2f{h[j], h[j]}, x, acc[(i + j) % PL_RING]);
-            acc[(i + J - 1) % PL_RING] = v2f{h[J - 1], h[J - 1]} * x;
-            dr[i] = acc[i].x; di[i] = acc[i].y;
+            const float yr = pl_reduce16(dr, hi8, hi4), yi = pl_reduce16(di, hi8, hi4);
+            const uint64_t m = c_first + (uint64_t)(sup * UB + grp * PL_RING + oidx);
+            if (leader && m >= ms && m < me) orow[(uint32_t)m & P.out.mask] = make_float2(yr, yi);
         }
-        const float yr = pl_reduce16(dr, hi8, hi4), yi = pl_reduce16(di, hi8, hi4);
-        const uint64_t m = c_first + (uint64_t)(sup * PL_RING + oidx);
-        if (leader && m >= ms && m < me) orow[(uint32_t)m & P.out.mask] = make_float2(yr, yi);
     }
 }
 
@@ -262,7 +305,9 @@ void launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)
     const uint64_t total = (m_end - m_main) * (uint64_t)batch;
     uint64_t S = total / (256u * 16u * 4u);
     const uint64_t s_cap = (uint64_t)((62 * 512) / D - J) / 16 * 16;
-    if (S > 512) S = 512;
+    uint64_t smax = 512;
+    if (const char* e = std::getenv("QRL_PL_SMAX")) smax = (uint64_t)std::atoi(e);   // experiments
+    if (S > smax) S = smax;
     if (S > s_cap) S = s_cap;
     S = S / 16 * 16;
     if (S < 16) S = 16;

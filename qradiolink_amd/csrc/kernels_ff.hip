@@ -219,67 +219,144 @@ void launch_disc_2fsk(const Disc2fskParams& p, int batch, hipStream_t s)
 // ---- fused feed-forward part of the non-FM 2FSK chain (gr_demod_2fsk.cpp:91-104,140-152):
 //   _filter (fft_filter_ccf) -> {_upper_filter, _lower_filter} (fft_filter_ccc) -> complex_to_mag x2 -> divide ->
 //   rail(0,2) -> add_const(-1) -> _symbol_filter (fft_filter_fff)
-// One workgroup = 256 consecutive outputs of one stream; the three FIR stages run out of LDS with the
-// intermediate halos recomputed (12 % extra MACs), taps are wave-uniform (scalar loads), every output is the
-// same fmaf chain (k ascending) as the unfused kernels.  Items at negative absolute index are zero, exactly
-// as a ring read in front of the stream start returns zero.
-constexpr int FF_T = 256;
-__global__ __launch_bounds__(256) void k_2fsk_ff(const Fsk2FfParams P)
+// One workgroup = FF_T consecutive outputs of one stream; the three FIR stages run out of LDS with the intermediate
+// halos recomputed (6 % extra MACs).  Every thread owns FOUR consecutive outputs of a stage and slides a register
+// window over the taps (one 8-byte LDS read per tap for four outputs instead of four); tiles are stored TRANSPOSED
+// by 4 (item i at row i & 3, word (i >> 2) + 1) so that the lanes of a wave read consecutive LDS words.  Taps are
+// wave-uniform (scalar loads) and zero padded to 4A + 1 entries: every output is the same fmaf chain (k ascending) as
+// the unfused kernels followed by zero taps, which leave the value untouched.  Items at negative absolute index are
+// zero, exactly as a ring read in front of the stream start returns zero.
+constexpr int FF_PL = 280, FF_PF = 264, FF_PD = 264;   // row pitches (words); 8-byte rows: pitch = 8 or 24 (mod 32)
+
+// acc[r] += sum_k taps[k] * tile[4 t + r + 4 A - k], k = 0 .. 4 nq - 1, fmaf chain k ascending (CPLX: complex taps)
+template <int PITCH, typename TapT, typename ItemT, typename Fma>
+__device__ __forceinline__ void ff_window4(const ItemT* __restrict__ tile, int w, int nq, const TapT* __restrict__ taps, Fma&& fma4)
 {
-    __shared__ float2 lt[FF_T + 104 + 8];   // FLL output, abs = n0t - (nf-1) - (nb-1) - (ns-1) + i
-    __shared__ float2 ft[FF_T + 64 + 8];    // _filter output
-    __shared__ float dt[FF_T + 24 + 8];     // discriminator output
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const int nf = P.nf, nb = P.nb, ns = P.ns;           // 41, 41, 25 for the 1k mode
-    const int hf = nf - 1, hb = nb - 1, hs = ns - 1;
-    const int64_t n0t = (int64_t)P.q0 + (int64_t)blockIdx.x * FF_T;
-    const int nl = FF_T + hf + hb + hs, nfo = FF_T + hb + hs, nd = FF_T + hs;
-    for (int i = tid; i < nl; i += 256) lt[i] = ringc_at(P.in, b, n0t - (hf + hb + hs) + i);
-    __syncthreads();
-    for (int j = tid; j < nfo; j += 256) {                 // f at abs = n0t - (hb + hs) + j
-        float ar = 0.f, ai = 0.f;
-        for (int k = 0; k < nf; ++k) {
-            const float h = P.tf[k];
-            const float2 x = lt[j + hf - k];
-            ar = fmaf(h, x.x, ar);
-            ai = fmaf(h, x.y, ai);
-        }
-        const bool neg = n0t - (hb + hs) + j < 0;
-        ft[j] = neg ? make_float2(0.f, 0.f) : make_float2(ar, ai);
-    }
-    __syncthreads();
-    for (int j = tid; j < nd; j += 256) {                  // d at abs = n0t - hs + j
-        float ur = 0.f, ui = 0.f, lr = 0.f, li = 0.f;
-        for (int k = 0; k < nb; ++k) {
-            const float2 x = ft[j + hb - k];
-            const float2 hu = P.up[k], hl = P.lo[k];
-            ur = fmaf(hu.x, x.x, ur); ur = fmaf(-hu.y, x.y, ur);
-            ui = fmaf(hu.x, x.y, ui); ui = fmaf(hu.y, x.x, ui);
-            lr = fmaf(hl.x, x.x, lr); lr = fmaf(-hl.y, x.y, lr);
-            li = fmaf(hl.x, x.y, li); li = fmaf(hl.y, x.x, li);
-        }
-        const float mu = sqrtf(ur * ur + ui * ui);
-        const float ml = sqrtf(lr * lr + li * li);
-        float r = mu / ml;
-        if (!(r >= 0.0f)) r = 0.0f;   // rail_ff lower bound; NaN (0/0) -> 0
-        if (r > 2.0f) r = 2.0f;
-        dt[j] = (n0t - hs + j < 0) ? 0.f : r + (-1.0f);
-    }
-    __syncthreads();
-    const uint32_t t = blockIdx.x * (uint32_t)FF_T + tid;   // output index inside this call
-    if (t < P.count) {
-        float a = 0.f;
-        for (int k = 0; k < ns; ++k) a = fmaf(P.ts[k], dt[tid + hs - k], a);
-        const int64_t n = n0t + tid;
-        P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = a;
-        if (t == 0 && P.counts) P.counts[b * 4 + 0] = P.count;
-        if (P.port && t < P.port_cap) P.port[(size_t)b * P.port_cap + t] = ft[tid + hb + hs];
+    ItemT cur[4], nxt[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) cur[s] = tile[s * PITCH + w];
+    for (int q = 0; q < nq; ++q) {
+        --w;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) nxt[s] = tile[s * PITCH + w];   // word w - 1: subs 1..3 are this step's u < 0 samples
+        const TapT h0 = taps[4 * q], h1 = taps[4 * q + 1], h2 = taps[4 * q + 2], h3 = taps[4 * q + 3];
+        fma4(h0, cur[0], cur[1], cur[2], cur[3]);     // e = 0: output r takes sample u = r
+        fma4(h1, nxt[3], cur[0], cur[1], cur[2]);     // e = 1: u = r - 1
+        fma4(h2, nxt[2], nxt[3], cur[0], cur[1]);     // e = 2: u = r - 2
+        fma4(h3, nxt[1], nxt[2], nxt[3], cur[0]);     // e = 3: u = r - 3
+#pragma unroll
+        for (int s = 0; s < 4; ++s) cur[s] = nxt[s];
     }
 }
+
+__global__ __launch_bounds__(256) void k_2fsk_ff(const Fsk2FfParams P)
+{
+    __shared__ float2 lt[4 * FF_PL];   // FLL output, item i <-> abs n0t - (hf + hb + hs) + i
+    __shared__ float2 ft[4 * FF_PF];   // _filter output, item j <-> abs n0t - (hb + hs) + j
+    __shared__ float dt[4 * FF_PD];    // discriminator output, item j <-> abs n0t - hs + j
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int hf = P.nf - 1, hb = P.nb - 1, hs = P.ns - 1;      // multiples of 4 (padded tap counts 4A + 1)
+    const int T = 1024 - hb - hs;                                // outputs per workgroup: stage 1 computes exactly 1024 items
+    const int64_t n0t = (int64_t)P.q0 + (int64_t)blockIdx.x * T;
+    const int nl = 1024 + hf, nd = T + hs;
+    if (tid < 4) { lt[tid * FF_PL] = make_float2(0.f, 0.f); ft[tid * FF_PF] = make_float2(0.f, 0.f); dt[tid * FF_PD] = 0.f; }
+    {   // nl <= 1064 items: five unconditional ring reads per thread in flight together (ring reads are in bounds for any index)
+        float2 v[5];
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int64_t a = n0t - (hf + hb + hs) + tid + 256 * it;
+            v[it] = P.in.p[(size_t)b * (P.in.mask + 1u) + ((uint32_t)a & P.in.mask)];
+            if (a < 0) v[it] = make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int i = tid + 256 * it;
+            if (i < nl) lt[(i & 3) * FF_PL + (i >> 2) + 1] = v[it];
+        }
+    }
+    __syncthreads();
+    {   // stage 1: f[j] = sum tf[k] l[j + hf - k], j = 4 tid + r
+        float2 a[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        ff_window4<FF_PL>(lt, tid + (hf >> 2) + 1, (hf >> 2) + 1, P.tf,
+                          [&](float h, const float2& x0, const float2& x1, const float2& x2, const float2& x3) {
+                              a[0].x = fmaf(h, x0.x, a[0].x); a[0].y = fmaf(h, x0.y, a[0].y);
+                              a[1].x = fmaf(h, x1.x, a[1].x); a[1].y = fmaf(h, x1.y, a[1].y);
+                              a[2].x = fmaf(h, x2.x, a[2].x); a[2].y = fmaf(h, x2.y, a[2].y);
+                              a[3].x = fmaf(h, x3.x, a[3].x); a[3].y = fmaf(h, x3.y, a[3].y);
+                          });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool neg = n0t - (hb + hs) + 4 * tid + r < 0;
+            ft[r * FF_PF + tid + 1] = neg ? make_float2(0.f, 0.f) : a[r];
+        }
+    }
+    __syncthreads();
+    if (4 * tid < nd) {   // stage 2: u/l[j] = sum up/lo[k] f[j + hb - k]; d = rail(|u| / |l|) - 1
+        float ur[4] = {0.f, 0.f, 0.f, 0.f}, ui[4] = {0.f, 0.f, 0.f, 0.f}, lr[4] = {0.f, 0.f, 0.f, 0.f}, li[4] = {0.f, 0.f, 0.f, 0.f};
+        const int nq = (hb >> 2) + 1;
+        int w = tid + (hb >> 2) + 1;
+        float2 cur[4], nxt[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) cur[s] = ft[s * FF_PF + w];
+        auto step = [&](const float2 hu, const float2 hl, const float2& x0, const float2& x1, const float2& x2, const float2& x3) {
+            const float2 xs[4] = {x0, x1, x2, x3};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ur[r] = fmaf(hu.x, xs[r].x, ur[r]); ur[r] = fmaf(-hu.y, xs[r].y, ur[r]);
+                ui[r] = fmaf(hu.x, xs[r].y, ui[r]); ui[r] = fmaf(hu.y, xs[r].x, ui[r]);
+                lr[r] = fmaf(hl.x, xs[r].x, lr[r]); lr[r] = fmaf(-hl.y, xs[r].y, lr[r]);
+                li[r] = fmaf(hl.x, xs[r].y, li[r]); li[r] = fmaf(hl.y, xs[r].x, li[r]);
+            }
+        };
+        for (int q = 0; q < nq; ++q) {
+            --w;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) nxt[s] = ft[s * FF_PF + w];
+            step(P.up[4 * q], P.lo[4 * q], cur[0], cur[1], cur[2], cur[3]);
+            step(P.up[4 * q + 1], P.lo[4 * q + 1], nxt[3], cur[0], cur[1], cur[2]);
+            step(P.up[4 * q + 2], P.lo[4 * q + 2], nxt[2], nxt[3], cur[0], cur[1]);
+            step(P.up[4 * q + 3], P.lo[4 * q + 3], nxt[1], nxt[2], nxt[3], cur[0]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) cur[s] = nxt[s];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float mu = sqrtf(ur[r] * ur[r] + ui[r] * ui[r]);
+            const float ml = sqrtf(lr[r] * lr[r] + li[r] * li[r]);
+            float v = mu / ml;
+            if (!(v >= 0.0f)) v = 0.0f;   // rail_ff lower bound; NaN (0/0) -> 0
+            if (v > 2.0f) v = 2.0f;
+            dt[r * FF_PD + tid + 1] = (n0t - hs + 4 * tid + r < 0) ? 0.f : v + (-1.0f);
+        }
+    }
+    __syncthreads();
+    if (4 * tid < T) {   // stage 3: y[o] = sum ts[k] d[o + hs - k]
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        ff_window4<FF_PD>(dt, tid + (hs >> 2) + 1, (hs >> 2) + 1, P.ts,
+                          [&](float h, float x0, float x1, float x2, float x3) {
+                              a[0] = fmaf(h, x0, a[0]); a[1] = fmaf(h, x1, a[1]); a[2] = fmaf(h, x2, a[2]); a[3] = fmaf(h, x3, a[3]);
+                          });
+        const uint32_t t0 = blockIdx.x * (uint32_t)T + 4u * tid;   // output index inside this call
+        if (t0 == 0 && P.counts) P.counts[b * 4 + 0] = P.count;
+        const int wf = tid + ((hb + hs) >> 2) + 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t t = t0 + r;
+            if (t < P.count) {
+                const int64_t n = n0t + 4 * tid + r;
+                P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = a[r];
+                if (P.port && t < P.port_cap) P.port[(size_t)b * P.port_cap + t] = ft[r * FF_PF + wf];
+            }
+        }
+    }
+}
+// padded tap count of the fused kernel: 4 A + 1 >= n (tables hold 4 (A + 1) entries, zero filled)
+int fsk2_ff_padded(int n) { return (n - 1 + 3) / 4 * 4 + 1; }
 void launch_2fsk_ff(const Fsk2FfParams& p, int batch, hipStream_t s)
 {
     if (!p.count) return;
-    hipLaunchKernelGGL(k_2fsk_ff, dim3((p.count + FF_T - 1) / FF_T, batch), dim3(256), 0, s, p);
+    const int T = 1024 - (p.nb - 1) - (p.ns - 1);
+    hipLaunchKernelGGL(k_2fsk_ff, dim3((p.count + T - 1) / T, batch), dim3(256), 0, s, p);
 }
 
 }  // namespace qrl

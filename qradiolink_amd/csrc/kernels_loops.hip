@@ -18,7 +18,7 @@ namespace qrl {
 // depends on the sample that was just derotated.  (A variant with the delay line in absolute-index register
 // slots and an NT-times unrolled body was tried: 20 % slower -- its 60 KB of code thrashes the instruction
 // cache and a single wave per SIMD is issue-latency bound anyway: ~5 cycles per instruction.)
-constexpr int FLL_CH = 96;   // samples per stream per LDS window
+constexpr int FLL_CH = 128;   // samples per stream per LDS window (power of two: cheap staging index math)
 
 template <int CTRL> __device__ __forceinline__ float dpp_quad(float v)
 {
@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void k_fll(const FllParams P, int batch)
     constexpr int GL = NT / 4;
     __shared__ float2 win[64][FLL_CH + 1];
     __shared__ float2 tl[NT], tu[NT];
+    __shared__ float2 dump[256];
     const int tid = threadIdx.x;
     const int sl = tid >> 2, g = tid & 3;
     const int b0 = blockIdx.x * 64;
@@ -60,39 +61,59 @@ __global__ __launch_bounds__(256) void k_fll(const FllParams P, int batch)
     float2 hu[GL], hl[GL];   // this lane's taps: entry j of the device tables belongs to y[n - j]
 #pragma unroll
     for (int t = 0; t < GL; ++t) { hu[t] = tu[g * GL + t]; hl[t] = tl[g * GL + t]; }
+    // Staging: every thread keeps the NEXT window's items in registers (NPT unconditional 8-byte loads issued before the serial
+    // loop of the current window, so their latency hides behind it; a load-wait-store loop here cost as much as the recursion).
+    constexpr int NPT = 64 * FLL_CH / 256;
+    float2 pre[NPT];
+    auto preload = [&](uint32_t c0) {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int idx = tid + 256 * i, s = min(idx / FLL_CH, nstreams - 1), k = idx % FLL_CH;
+            const int64_t a = (int64_t)(P.q0 + c0 + k) - NT;   // x[n - NT]; ring reads are in bounds for any index
+            const float2 v = P.in.p[(size_t)(b0 + s) * (P.in.mask + 1u) + ((uint32_t)a & P.in.mask)];
+            pre[i] = a >= 0 ? v : make_float2(0.f, 0.f);
+        }
+    };
+    preload(0);
     for (uint32_t c0 = 0; c0 < P.count; c0 += FLL_CH) {
         const int len = min((uint32_t)FLL_CH, P.count - c0);
+        __syncthreads();   // the flush of the previous window is through with win
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) { const int idx = tid + 256 * i; win[idx / FLL_CH][idx % FLL_CH] = pre[i]; }
         __syncthreads();
-        // stage x[n - NT] for n in [q0 + c0, q0 + c0 + len) of every stream of this workgroup (coalesced along the stream)
-        for (int idx = tid; idx < nstreams * FLL_CH; idx += 256) {
-            const int s = idx / FLL_CH, k = idx - s * FLL_CH;
-            if (k < len) {
-                const int64_t i = (int64_t)(P.q0 + c0 + k) - NT;
-                win[s][k] = i >= 0 ? P.in.p[(size_t)(b0 + s) * (P.in.mask + 1u) + ((uint32_t)i & P.in.mask)] : make_float2(0.f, 0.f);
-            }
-        }
-        __syncthreads();
+        if (c0 + FLL_CH < P.count) preload(c0 + FLL_CH);
         if (active) {
             for (int k = 0; k < len; ++k) {
                 const float2 x = win[sl][k];
+                // critical path: NCO -> derotated sample -> newest link of lane 0 -> butterflies -> loop update.  The body is ONE
+                // basic block (no lane-dependent branch: lanes 1-3 of a quad send their copy of y to a dump slot), so the scheduler
+                // can fill the dependency gaps of this chain with the independent work below.
                 const float2 nco = sincos_rad(phase);  // (cos, sin)
-                const float2 y = cmul(x, nco);
-                if (g == 0) win[sl][k] = y;            // output staged in place, flushed coalesced below
-                // shift the delay line through the quad: lane g takes the oldest entry of lane g - 1, lane 0 takes y[n]
+                // independent of this sample's NCO: shift the delay line through the quad -- lane g takes the oldest entry of lane
+                // g - 1 -- and run the oldest-first chains over everything but the newest slot
                 float2 carry;
                 carry.x = dpp_quad<0x90>(dl[GL - 1].x);
                 carry.y = dpp_quad<0x90>(dl[GL - 1].y);
 #pragma unroll
                 for (int t = GL - 1; t > 0; --t) dl[t] = dl[t - 1];
-                dl[0] = g == 0 ? y : carry;
                 float ur = 0.f, ui = 0.f, lr = 0.f, li = 0.f;
 #pragma unroll
-                for (int t = GL - 1; t >= 0; --t) {   // oldest first: only lane 0's last link depends on y[n]
+                for (int t = GL - 1; t >= 1; --t) {
                     const float2 v = dl[t];
                     ur = fmaf(hu[t].x, v.x, ur); ur = fmaf(-hu[t].y, v.y, ur);
                     ui = fmaf(hu[t].x, v.y, ui); ui = fmaf(hu[t].y, v.x, ui);
                     lr = fmaf(hl[t].x, v.x, lr); lr = fmaf(-hl[t].y, v.y, lr);
                     li = fmaf(hl[t].x, v.y, li); li = fmaf(hl[t].y, v.x, li);
+                }
+                const float2 y = cmul(x, nco);
+                *(g == 0 ? &win[sl][k] : &dump[tid]) = y;   // output staged in place (lane 0 of the quad), flushed coalesced below
+                dl[0] = g == 0 ? y : carry;
+                {
+                    const float2 v = dl[0];
+                    ur = fmaf(hu[0].x, v.x, ur); ur = fmaf(-hu[0].y, v.y, ur);
+                    ui = fmaf(hu[0].x, v.y, ui); ui = fmaf(hu[0].y, v.x, ui);
+                    lr = fmaf(hl[0].x, v.x, lr); lr = fmaf(-hl[0].y, v.y, lr);
+                    li = fmaf(hl[0].x, v.y, li); li = fmaf(hl[0].y, v.x, li);
                 }
                 // (p0 + p1) + (p2 + p3): quad butterflies (lane ^ 1, then lane ^ 2); float addition commutes, so all four
                 // lanes end up with the same bits
@@ -102,7 +123,7 @@ __global__ __launch_bounds__(256) void k_fll(const FllParams P, int batch)
                 freq = freq + P.beta * error;
                 phase = phase + freq + P.alpha * error;
                 phase = phase_wrap(phase);
-                if (freq > P.max_freq) freq = P.max_freq; else if (freq < -P.max_freq) freq = -P.max_freq;
+                freq = __builtin_fminf(__builtin_fmaxf(freq, -P.max_freq), P.max_freq);   // == the two-sided clamp for finite freq
             }
         }
         __syncthreads();

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Builds variant libraries of the phase-lane decimator (timing experiments): build/libqrl_<name>.so
+# usage: tools/pl_variants.sh name "extra hipcc flags" [name flags ...]
+set -e
+cd "$(dirname "$0")/../qradiolink_amd/csrc"
+make -s -j8
+mkdir -p ../../build
+OBJ=$(ls *.o | grep -v kernels_decim_pl.o)
+while [ $# -ge 2 ]; do
+  name=$1; flags=$2; shift 2
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950 $flags -c kernels_decim_pl.hip -o ../../build/pl_$name.o
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build/libqrl_$name.so $OBJ ../../build/pl_$name.o
+  echo built $name
+done
