@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
 """bench.py — IQ MSamples/s through the RX demod chain on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the whole hot path (rotator + front-end decimator + per-mode resampler +
-filters + symbol sync + 2x Viterbi + descramblers) over one batch of synthetic IQ that is already
-resident in HBM.  Default workload = BASELINE.json configs[1]: GMSK 10 kbit/s RX chain on 25 Msps IQ, 384 streams x
-1.6 M samples (65 ms of signal) per step = 5 GB of IQ per step.  (The serial symbol-sync tail costs ~0.4 us per symbol and stream:
-with 96 streams x 6.5 M samples it was longer than the front end and capped the whole chain at 219 GS/s.)
-The 2FSK-1k chain the north-star target is quoted on (configs[0], 1 Msps IQ) is measured too and
-reported under "north_star_c1" in the same JSON line.
+A "step" is one pass of the whole hot path (rotator + decimators + per-mode filters + carrier / timing recovery + Viterbi +
+descramblers) over one batch of synthetic IQ that is already resident in HBM.
 
-Launch: python bench.py --gpus N --steps K --warmup W   (N>1: via torch.distributed.run, one rank
-per GPU; streams are sharded across ranks, there is no data-path collective => "scaling": "weak").
+Default workload = C1, the configuration BASELINE.json's target is quoted on: 2FSK 1 kbit/s RX chain (gr_demod_2fsk behind the
+gr_demod_base rotator) on 1 Msps IQ, 16384 streams x 262144 samples = 34.4 GB of IQ per step.  The same JSON line carries
+  roofline      the HBM-facing kernel (k_decim_pl: rotator + 1:50 decimator) timed with HIP events on the handle's stream;
+                achieved = SURVEY.md 8(d) algorithmic bytes (C1 8.178 B, C2 8.033 B, C3 8.0625 B per input sample) x samples
+                per launch / average launch duration
+  cpu_baseline  oracle/liborc.so timed on the host cores (a bounded sample of the same workload)
+  parity_check  four random streams of one call AT THE BENCH SHAPE compared with the oracle (bits and port 0), untimed
+  c2            the GMSK-10k chain on 25 Msps IQ (BASELINE configs[1]) measured in the same run.
+Other configs on request: --config c2 | c3 | c4 | c5.
+
+Launch: python bench.py --gpus N --steps K --warmup W.  N > 1 re-executes itself under torch.distributed.run (one rank per GPU,
+RCCL); the driver may also launch it that way directly.  C1-C3/C5 shard independent streams over the ranks with no data-path
+collective ("scaling": "weak"); C4 shards the CHANNELS of the same wideband input, which rank 0 broadcasts over RCCL every step
+("scaling": "strong").
 """
 import argparse
 import json
@@ -27,14 +34,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 
 WORKLOADS = {
-    # name: (label, sig mode, modem type, device rate, rx offset, default batch, default samples/stream, oracle mode)
-    "c2": ("C2: GMSK-10k RX chain (gr_demod_base front end 25:1 + gr_demod_gmsk) on 25 Msps IQ",
-           "gmsk10k", 22, 25000000, 25000.0, 384, 25 * (1 << 16), 1),
+    # name: (label, sig mode, modem type, device rate, rx offset, default batch, default samples/stream, oracle mode,
+    #        algorithmic bytes per input sample: SURVEY.md 8(d))
     "c1": ("C1: 2FSK-1k RX chain (rotator + gr_demod_2fsk) on 1 Msps IQ",
-           "2fsk1k", 18, 1000000, 1200.0, 16384, 1 << 18, 0),
-    # not part of the default line (parity-test configs measured on request: --config c3 / c4)
+           "2fsk1k", 18, 1000000, 1200.0, 16384, 1 << 18, 0, 8.178),
+    "c2": ("C2: GMSK-10k RX chain (gr_demod_base front end 25:1 + gr_demod_gmsk) on 25 Msps IQ",
+           "gmsk10k", 22, 25000000, 25000.0, 384, 25 * (1 << 16), 1, 8.033),
     "c3": ("C3: QPSK-250k RX chain (gr_demod_base front end 100:1 + gr_demod_qpsk) on 100 Msps IQ",
-           "qpsk250k", 26, 100000000, 25000.0, 384, 100 * (1 << 14), 2),
+           "qpsk250k", 26, 100000000, 25000.0, 384, 100 * (1 << 14), 2, 8.0625),
 }
 
 
@@ -67,18 +74,50 @@ def synth(mode, device_rate, offset, batch, nsamp, seed, torch, dev):
     return iq
 
 
-def run_workload(name, args, torch, q, ctx, dev, rank, world, no_overlap=False):
-    label, mode, modem, rate, offset, dbatch, dns, _ = WORKLOADS[name]
-    if no_overlap:
-        os.environ["QRL_NO_OVERLAP"] = "1"   # read by qrl_demod_create: stage C back on the main stream, kernels run one at a time
-    else:
-        os.environ.pop("QRL_NO_OVERLAP", None)
+def oracle_demod(mode, x, rate, offset):
+    import orc
+    fe = orc.frontend(x, rate, offset)
+    if mode == "2fsk1k":
+        return orc.demod_2fsk(fe, sps=10, filter_width=2000, fm=False)
+    if mode == "gmsk10k":
+        return orc.demod_gmsk(fe, sps=1, filter_width=20000)
+    return orc.demod_qpsk(fe, sps=2, filter_width=160000)
+
+
+def parity_check(dem, iq, mode, rate, offset, torch, nstreams=4, seed=5):
+    """One call from a fresh state at the bench shape; `nstreams` random streams against the oracle (untimed)."""
+    dem.reset()
+    out = dem.process(iq)
+    cnt = out["counts"].cpu().numpy()
+    rng = np.random.default_rng(seed)
+    picks = sorted(int(b) for b in rng.choice(iq.shape[0], size=min(nstreams, iq.shape[0]), replace=False))
+    two_branch = mode in ("2fsk1k", "gmsk10k")
+    for b in picks:
+        ref = oracle_demod(mode, iq[b].cpu().numpy(), rate, offset)
+        got_a = out["bits_a"][b, :cnt[b, 2]].cpu().numpy()
+        ok = np.array_equal(got_a, ref["bits_a"])
+        if two_branch:
+            ok = ok and np.array_equal(out["bits_b"][b, :cnt[b, 3]].cpu().numpy(), ref["bits_b"])
+        got_f = out["filtered"][b, :cnt[b, 0]].cpu().numpy().view(np.float32) + np.float32(0)
+        want_f = ref["filtered"].view(np.float32) + np.float32(0)
+        ok = ok and got_f.size == want_f.size and np.array_equal(got_f.view(np.uint32), want_f.view(np.uint32))
+        if not ok:
+            return dict(status="FAILED", stream=b, streams=picks)
+    return dict(status="bit-exact", streams=picks, compared="bits A/B and port 0 (filtered) of one call from a fresh state",
+                bits_per_stream=int(cnt[picks[0], 2]))
+
+
+def run_workload(name, args, torch, q, ctx, dev, rank, world, no_overlap=False, check=False, steps=None):
+    label, mode, modem, rate, offset, dbatch, dns, _, abytes = WORKLOADS[name]
+    steps = steps or args.steps
     batch = args.batch if (args.batch and name == args.config) else dbatch
     nsamp = args.nsamp if (args.nsamp and name == args.config) else dns
     nsamp &= ~1
     iq = synth(mode, rate, offset, batch, nsamp, 1234 + rank, torch, dev)
     dem = q.Demod(ctx, modem, batch=batch, max_chunk=nsamp, device_samp_rate=rate, carrier_offset_hz=offset,
                   side_outputs=True)
+    if no_overlap:
+        dem.set_option(q.OPT_OVERLAP, 0)   # the kernels of a call one after another: stand-alone duration of the front end
     for _ in range(args.warmup):
         dem.process_async(iq)
     dem.sync()
@@ -87,7 +126,7 @@ def run_workload(name, args, torch, q, ctx, dev, rank, world, no_overlap=False):
         torch.distributed.barrier()
     dem.profile(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         dem.process_async(iq)
     dem.sync()
     torch.cuda.synchronize()
@@ -101,81 +140,103 @@ def run_workload(name, args, torch, q, ctx, dev, rank, world, no_overlap=False):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     counts = dem.counts.cpu().numpy()
+    parity = parity_check(dem, iq, mode, rate, offset, torch) if (check and rank == 0) else None
     dem.close()
-    os.environ.pop("QRL_NO_OVERLAP", None)
     del iq
     torch.cuda.empty_cache()
-    total_samples = float(batch) * nsamp * args.steps * world
-    # dominant kernel roofline: algorithmic bytes per launch = input cf32 read once + decimated cf32 written once
-    fe_decim = rate // 1000000 if rate >= 2000000 else 50
-    bytes_per_launch = batch * nsamp * 8.0 * (1.0 + 1.0 / fe_decim)
+    total_samples = float(batch) * nsamp * steps * world
+    bytes_per_launch = batch * nsamp * abytes          # per-sample figure x samples one launch processes
     ach = bytes_per_launch / (kms / max(launches, 1) * 1e-3) / 1e9 if kms > 0 else 0.0
-    return dict(name=name, default_shape=(batch == dbatch and nsamp == (dns & ~1)),
+    return dict(name=name, default_shape=(batch == dbatch and nsamp == (dns & ~1)), steps=steps,
                 label=label, batch=batch, nsamp=nsamp, rate=rate, seconds=dt, msps=total_samples / dt / 1e6,
-                ms_per_step=dt / args.steps * 1e3, kernel=kname, kernel_ms=kms / max(launches, 1), launches=launches,
-                achieved_gbps=ach, bits_per_stream=int(counts[:, 2].mean()), bytes_per_launch=bytes_per_launch)
+                ms_per_step=dt / steps * 1e3, kernel=kname, kernel_ms=kms / max(launches, 1), launches=launches,
+                achieved_gbps=ach, bits_per_stream=int(counts[:, 2].mean()), bytes_per_launch=bytes_per_launch,
+                bytes_per_sample=abytes, parity=parity)
 
 
-def run_c4(args, torch, q, ctx, dev, world):
-    """C4: multi-carrier MMDVM receiver, 64 x 25 kHz channels from 1.6 Msps wideband IQ (PFB channelizer + per-channel
-    24/25 resampler, LPF, FM discriminator -> int16, RSSI tags and the 4FSK symbol tail).  Reported on request only."""
-    M, B, n = 64, args.batch or 64, (args.nsamp or (1 << 21)) // 64 * 64
-    g = torch.Generator(device=dev)
-    g.manual_seed(7)
-    iq = torch.view_as_complex(torch.randn((B, n, 2), generator=g, device=dev, dtype=torch.float32) * 0.05)
-    ch = q.Channelizer(ctx, M, batch=B, max_chunk=n)
-    ch.enable_4fsk()
+def timed_loop(fn, sync, args, torch, dev, world):
+    """W warm-up + K timed steps, barrier + synchronize on both sides, MAX over ranks."""
     for _ in range(args.warmup):
-        ch.process_async(iq)
-    ch.sync()
+        fn()
+    sync()
     torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ch.process_async(iq)
-    ch.sync()
+        fn()
+    sync()
     torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def run_c4(args, torch, q, ctx, dev, rank, world):
+    """C4: multi-carrier MMDVM receiver, 64 x 25 kHz channels from 1.6 Msps wideband IQ (PFB channelizer + per-channel
+    24/25 resampler, LPF, FM discriminator -> int16, RSSI tags and the 4FSK symbol tail).  Multi-GPU: the CHANNELS of the same
+    wideband streams are sharded (rank r owns channels [r M/G, (r+1) M/G)); rank 0 holds the new wideband chunk of every step
+    and broadcasts it to the other ranks over RCCL (one ncclBroadcast per step), then every rank runs its shard."""
+    M, B, n = 64, args.batch or 64, (args.nsamp or (1 << 21)) // 64 * 64
+    if M % world:
+        raise SystemExit("c4: the number of ranks must divide 64 channels")
+    per = M // world
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    src = torch.view_as_complex(torch.randn((B, n, 2), generator=g, device=dev, dtype=torch.float32) * 0.05)   # rank 0's is THE input
+    iq = src if (world == 1 or rank == 0) else torch.empty_like(src)
+    ch = q.Channelizer(ctx, M, batch=B, max_chunk=n, channel_first=rank * per, channel_count=per)
+    ch.enable_4fsk()
+    iq_f = torch.view_as_real(iq)
+
+    def step():
+        if world > 1:
+            torch.distributed.broadcast(iq_f, src=0)   # RCCL over xGMI; enqueued on torch's stream, process_async waits for it
+        ch.process_async(iq)
+    dt = timed_loop(step, ch.sync, args, torch, dev, world)
     ch.close()
-    return {"metric": "wideband IQ MSamples/sec through the C4 receiver", "value": round(B * n * args.steps * world / dt / 1e6, 1), "unit": "MS/s",
+    return {"metric": "wideband IQ MSamples/sec through the C4 receiver", "value": round(B * n * args.steps / dt / 1e6, 1), "unit": "MS/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C4: 64 x 25 kHz MMDVM channels from 1.6 Msps IQ: PFB channelizer + FM int16 + RSSI + 4FSK tail",
-                       "wideband_streams_per_gpu": B, "samples_per_stream_per_step": n}}
+                       "wideband_streams": B, "samples_per_stream_per_step": n, "channels_per_gpu": per,
+                       "parallelism": "channels sharded over ranks; wideband input broadcast from rank 0 over RCCL every step" if world > 1 else "single GPU"}}
 
 
-def run_c5(args, torch, q, ctx, dev, world):
+def run_c5(args, torch, q, ctx, dev, rank, world):
     """C5: full duplex -- QPSK-250k modulator and QPSK-250k demodulator handles on their own HIP streams, calls interleaved without
     synchronisation (BASELINE config 5; reference src/radiocontroller.cpp:2043-2078 runs the two top blocks concurrently)."""
     import sig
     B = args.batch or 4096
     n = (args.nsamp or (1 << 16)) & ~1
     nbytes = n // 32                                  # the TX produces as many 1 Msps samples as the RX consumes
-    base, _ = sig.make_stream("qpsk250k", nframes=3, device_rate=1000000, seed=3, amp=0.05)
+    base, _ = sig.make_stream("qpsk250k", nframes=3, device_rate=1000000, seed=3 + rank, amp=0.05)
     base = np.tile(base, -(-n // base.size))[:n]
     iq = torch.from_numpy(base).to(dev).repeat(B, 1).contiguous()
     g = torch.Generator(device=dev)
-    g.manual_seed(11)
+    g.manual_seed(11 + rank)
     data = torch.randint(0, 256, (B, nbytes), generator=g, device=dev, dtype=torch.uint8)
     dem = q.Demod(ctx, 26, batch=B, max_chunk=n)
     mod = q.Mod(ctx, 26, batch=B, max_bytes=nbytes)
     tx_out = torch.empty((B, nbytes * mod.spb), dtype=torch.complex64, device=dev)
 
-    def loop(k, do_tx=True, do_rx=True):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            if do_tx:
-                mod.process_async(data, out=tx_out)
-            if do_rx:
-                dem.process_async(iq)
-        mod.sync(); dem.sync()
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0
-    loop(args.warmup)
-    dt = loop(args.steps)
-    dt_rx = loop(args.steps, do_tx=False)
-    dt_tx = loop(args.steps, do_rx=False)
-    dem.close(); mod.close()
+    def both():
+        mod.process_async(data, out=tx_out)
+        dem.process_async(iq)
+
+    def sync():
+        mod.sync()
+        dem.sync()
+    dt = timed_loop(both, sync, args, torch, dev, world)
+    dt_rx = timed_loop(lambda: dem.process_async(iq), sync, args, torch, dev, world)
+    dt_tx = timed_loop(lambda: mod.process_async(data, out=tx_out), sync, args, torch, dev, world)
+    dem.close()
+    mod.close()
     tot = float(B) * n * args.steps * world
     return {"metric": "IQ MSamples/sec through RX demod chain (with the TX chain running concurrently)", "value": round(tot / dt / 1e6, 1),
             "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -185,39 +246,65 @@ def run_c5(args, torch, q, ctx, dev, world):
                        "rx_alone_ms_per_step": round(dt_rx / args.steps * 1e3, 3), "tx_alone_ms_per_step": round(dt_tx / args.steps * 1e3, 3)}}
 
 
-def cpu_baseline(name, threads, budget_s=12.0):
-    """Oracle (CPU restatement of the reference flowgraph) on a bounded sample of the same workload:
-    `threads` independent streams (OpenMP over streams, one stream per core), repeated until ~budget_s seconds
-    of CPU wall time have been measured."""
+def cpu_baseline(name, cores, budget_s=8.0):
+    """The oracle's CPU restatement of the reference flowgraph on a bounded sample of the same workload.  Three figures:
+    value          all host cores, OpenMP over independent streams, decimators as an AVX2 dot product (VOLK-like; what a
+                   GNU Radio + VOLK build would vectorise); one stream per core like one flowgraph per core
+    single_thread  the same on ONE core (= one reference flowgraph, ignoring GNU Radio's block-per-thread overlap)
+    scalar_port    the bit-exact checker itself (scalar fmaf chains in the GPU's summation order) on all cores"""
     import orc
     import sig
-    label, mode, modem, rate, offset, _, _, omode = WORKLOADS[name]
-    nstreams = max(threads, 1)
+    label, mode, modem, rate, offset, _, _, omode, _ = WORKLOADS[name]
     per = (1 << 22) if rate >= 2000000 else (1 << 20)
     base, _ = sig.make_stream(mode, nframes=2, device_rate=rate, rx_offset_hz=offset, seed=99, amp=0.05)
     base = np.tile(base, -(-per // base.size))[:per]
-    iq = np.stack([np.roll(base, 977 * b) for b in range(nstreams)]).astype(np.complex64)
-    total, reps = 0.0, 0
-    while total < budget_s and reps < 200:
-        secs, _ = orc.batch_rx(omode, iq, rate, offset, threads)
-        total += secs
-        reps += 1
-    return dict(value=round(reps * nstreams * per / total / 1e6, 3), unit="MS/s", cores=threads, kind="port",
-                sample="%d passes over %d streams x %d samples of the %s workload (%.1f s of CPU wall time), "
-                       "oracle/liborc.so (C, -O3, OpenMP over streams)" % (reps, nstreams, per, name.upper(), total))
+
+    def timed(nstreams, threads, impl, budget):
+        iq = np.stack([np.roll(base, 977 * b) for b in range(nstreams)]).astype(np.complex64)
+        orc.lib.orc_set_decim_impl(impl)
+        total, reps = 0.0, 0
+        while total < budget and reps < 200:
+            secs, _ = orc.batch_rx(omode, iq, rate, offset, threads)
+            total += secs
+            reps += 1
+        orc.lib.orc_set_decim_impl(0)
+        return reps * nstreams * per / total / 1e6, reps, total
+    v_all, reps, tot = timed(cores, cores, 1, budget_s)
+    v_one, _, _ = timed(1, 1, 1, budget_s / 4)
+    v_port, _, _ = timed(cores, cores, 0, budget_s / 2)
+    return dict(value=round(v_all, 3), unit="MS/s", cores=cores, kind="port",
+                single_thread=round(v_one, 3), scalar_port=round(v_port, 3),
+                sample="%d passes over %d streams x %d samples of the %s workload (%.1f s of CPU wall time); oracle/liborc.so "
+                       "(C, -O3 -mavx2 -mfma, OpenMP over streams) with the decimating FIRs as AVX2 dot products "
+                       "(orc_decim_fir_ccf_simd); GNU Radio / VOLK itself is not installable here"
+                       % (reps, cores, per, name.upper(), tot))
+
+
+def respawn_under_torchrun(args):
+    """python bench.py --gpus N started without a launcher: become N ranks (one per GPU) on this node."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS) + ["c4", "c5"])
+    ap.add_argument("--config", default="c1", choices=sorted(WORKLOADS) + ["c4", "c5"])
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--nsamp", type=int, default=0)
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workload and the CPU baseline")
+    ap.add_argument("--no-extra", action="store_true", help="only the timed workload: no stand-alone pass, parity check, C2 line, CPU baseline")
     ap.add_argument("--no-overlap", action="store_true", help="developer aid: run the kernels of a call one after another")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
 
     import torch
     import qradiolink_amd as q
@@ -225,6 +312,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (args.gpus, world, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -234,53 +323,51 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=dev)
     ctx = q.Context(local)
 
-    if args.config in ("c4", "c5"):
-        line = (run_c4 if args.config == "c4" else run_c5)(args, torch, q, ctx, dev, world)
-        if rank == 0:
+    def finish(line):
+        if rank == 0 and line is not None:
             print(json.dumps(line))
         ctx.close()
         if world > 1:
+            torch.distributed.barrier()   # rank 0 may be behind by the CPU baseline: leave together
             torch.distributed.destroy_process_group()
+
+    if args.config in ("c4", "c5"):
+        finish((run_c4 if args.config == "c4" else run_c5)(args, torch, q, ctx, dev, rank, world))
         return
-    main_r = run_workload(args.config, args, torch, q, ctx, dev, rank, world, no_overlap=args.no_overlap)
-    extra = None
-    base = None
-    if not args.no_extra and args.config in ("c1", "c2"):
-        other = "c1" if args.config == "c2" else "c2"
-        extra = run_workload(other, args, torch, q, ctx, dev, rank, world)
-        if rank == 0:
-            base = cpu_baseline(args.config, min(os.cpu_count() or 1, 16))
+    extra_ok = not args.no_extra
+    main_r = run_workload(args.config, args, torch, q, ctx, dev, rank, world, no_overlap=args.no_overlap, check=extra_ok)
     # C1 (2FSK family) runs in overlapped mode: the FLL / discriminator kernels of call k share the GPU with the front end of
     # call k + 1, which stretches the front-end kernel.  Its stand-alone duration is measured in a second short pass.
-    alone = {}
-    for r in (main_r, extra):
-        if r and r["name"] == "c1" and not args.no_extra:
-            alone["c1"] = run_workload("c1", args, torch, q, ctx, dev, rank, world, no_overlap=True)
+    alone = run_workload("c1", args, torch, q, ctx, dev, rank, world, no_overlap=True, steps=min(args.steps, 20)) \
+        if (extra_ok and args.config == "c1" and not args.no_overlap) else None
+    extra = run_workload("c2", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 50)) if (extra_ok and args.config == "c1") else None
+    base = cpu_baseline(args.config, min(os.cpu_count() or 1, 16)) if (extra_ok and rank == 0) else None
+
+    line = None
     if rank == 0:
         def roof(r):
-            # HBM traffic per launch of the dominant kernel: PMC numbers cannot be collected from inside this process;
-            # they come from the separate rocprofv3 --pmc passes of tools/gpu_profile_final.sh (FETCH_SIZE doubled per
-            # the gfx950 correction + WRITE_SIZE), stored in profiles/pmc_traffic.json for the DEFAULT workload shape.
-            traffic = None
+            # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process; the number is
+            # the one measured by the separate rocprofv3 --pmc passes of tools/gpu_profile_final.sh on this same command
+            # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), kept in profiles/pmc_traffic.json per workload shape.
+            traffic, src = None, None
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(r["name"])
                 if pmc and r["default_shape"] and r["kernel"] in pmc["kernel"]:
-                    traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
+                    traffic, src = pmc["fetch_bytes"] + pmc["write_bytes"], pmc.get("source")
             except (OSError, ValueError, KeyError):
                 pass
             d = dict(bound="hbm", achieved=round(r["achieved_gbps"], 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                     frac=round(r["achieved_gbps"] / HBM_PEAK_GBPS, 4), traffic=traffic, kernel=r["kernel"],
+                     frac=round(r["achieved_gbps"] / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=src, kernel=r["kernel"],
                      kernel_ms=round(r["kernel_ms"], 4), launches=r["launches"],
-                     algorithmic_bytes_per_launch=r["bytes_per_launch"])
-            a = alone.get(r["name"])
-            if a:
-                d["without_overlap"] = dict(kernel_ms=round(a["kernel_ms"], 4), achieved=round(a["achieved_gbps"], 1),
-                                            frac=round(a["achieved_gbps"] / HBM_PEAK_GBPS, 4), ms_per_step=round(a["ms_per_step"], 3),
-                                            note="QRL_NO_OVERLAP=1: same workload with the kernels of a call run one after another")
+                     algorithmic_bytes_per_launch=r["bytes_per_launch"], algorithmic_bytes_per_sample=r["bytes_per_sample"])
+            if alone and r["name"] == "c1":
+                d["stand_alone"] = dict(kernel_ms=round(alone["kernel_ms"], 4), achieved=round(alone["achieved_gbps"], 1),
+                                        frac=round(alone["achieved_gbps"] / HBM_PEAK_GBPS, 4), ms_per_step=round(alone["ms_per_step"], 3),
+                                        note="QRL_OPT_OVERLAP = 0: same workload, the kernels of a call one after another")
             return d
         line = {
             "metric": "IQ MSamples/sec through RX demod chain", "value": round(main_r["msps"], 1), "unit": "MS/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(main_r["ms_per_step"], 3),
+            "n_gpus": world, "steps": main_r["steps"], "warmup": args.warmup, "ms_per_step": round(main_r["ms_per_step"], 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": main_r["label"], "streams_per_gpu": main_r["batch"],
                        "samples_per_stream_per_step": main_r["nsamp"], "device_samp_rate": main_r["rate"],
@@ -288,18 +375,17 @@ def main():
                        "decoded_bits_per_stream_last_step": main_r["bits_per_stream"]},
             "roofline": roof(main_r),
         }
+        if main_r["parity"]:
+            line["parity_check"] = main_r["parity"]
         if base:
             line["cpu_baseline"] = base
         if extra:
-            key = "north_star_c1" if args.config == "c2" else "c2"
-            line[key] = {"workload": extra["label"], "value": round(extra["msps"], 1), "unit": "MS/s",
-                         "ms_per_step": round(extra["ms_per_step"], 3), "streams_per_gpu": extra["batch"],
-                         "samples_per_stream_per_step": extra["nsamp"], "roofline": roof(extra)}
-        print(json.dumps(line))
-    ctx.close()
-    if world > 1:
-        torch.distributed.barrier()   # rank 0 is behind by the CPU baseline: leave together
-        torch.distributed.destroy_process_group()
+            line["c2"] = {"workload": extra["label"], "value": round(extra["msps"], 1), "unit": "MS/s", "steps": extra["steps"],
+                          "ms_per_step": round(extra["ms_per_step"], 3), "streams_per_gpu": extra["batch"],
+                          "samples_per_stream_per_step": extra["nsamp"], "roofline": roof(extra)}
+    finish(line)
+    if rank == 0 and main_r["parity"] and main_r["parity"]["status"] != "bit-exact":
+        raise SystemExit("bench.py: parity check against the oracle FAILED at the bench shape: %r" % (main_r["parity"],))
 
 
 if __name__ == "__main__":

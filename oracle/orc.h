@@ -70,6 +70,8 @@ int    orc_decim_uses_m16(int nt, int decim);
 size_t orc_decim_fir_ccf_pl(const cf32* in, size_t n, const float* taps, int nt, int decim, cf32* out);
 void   orc_pl_geometry(int decim, int* dprime, int* per_lane);
 int    orc_decim_uses_pl(int nt, int decim);
+size_t orc_decim_fir_ccf_simd(const cf32* in, size_t n, const float* taps, int nt, int decim, cf32* out);   /* CPU baseline only */
+void   orc_set_decim_impl(int impl);   /* 0: summation contracts (checker), 1: AVX2 dot product (bench.py cpu_baseline timing) */
 size_t orc_decim_auto(const cf32* in, size_t n, const float* taps, int nt, int decim, cf32* out);
 size_t orc_resamp_ccf(const cf32* in, size_t n, const float* taps, int nt, int interp, int decim, cf32* out);
 size_t orc_resamp_fff(const float* in, size_t n, const float* taps, int nt, int interp, int decim, float* out);

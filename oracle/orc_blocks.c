@@ -180,8 +180,53 @@ size_t orc_decim_fir_ccf_pl(const cf32* in, size_t n, const float* taps, int nt,
     }
     return nout;
 }
+/* CPU-BASELINE variant of the decimating FIR (bench.py cpu_baseline leg only, never the checker): the dot product as a
+ * VOLK-like AVX2 kernel (volk_32fc_32f_dot_prod_32fc: complex samples x real taps, 8 floats per fused multiply-add, four
+ * independent accumulators, horizontal sum at the end).  Same value as the contracts above to ~1e-6 of RMS, different
+ * rounding order, so it is selected explicitly with orc_set_decim_impl(1) and only timed. */
+#include <immintrin.h>
+static int g_decim_impl = 0;
+void orc_set_decim_impl(int impl) { g_decim_impl = impl; }
+size_t orc_decim_fir_ccf_simd(const cf32* in, size_t n, const float* taps, int nt, int D, cf32* out)
+{
+    size_t nout = orc_decim_count(n, 1, D);
+    /* reversed taps, each duplicated for (re, im), zero padded to a multiple of 32 floats */
+    const int nf = 2 * nt, nfp = (nf + 31) / 32 * 32;
+    float* hr = (float*)aligned_alloc(32, (size_t)nfp * sizeof(float));
+    for (int i = 0; i < nfp; i++) hr[i] = 0.0f;
+    for (int k = 0; k < nt; k++) { hr[2 * (nt - 1 - k)] = taps[k]; hr[2 * (nt - 1 - k) + 1] = taps[k]; }
+    const float* xf = (const float*)in;
+    for (size_t m = 0; m < nout; m++) {
+        const long long first = (long long)m * D - (nt - 1);        /* oldest sample of the window */
+        if (first < 0 || (size_t)(first + nfp / 2) > n) {           /* stream edges: plain loop */
+            float ar = 0.0f, ai = 0.0f;
+            for (int k = 0; k < nt; k++) {
+                const long long i = (long long)m * D - k;
+                if (i < 0) break;
+                ar = fmaf(taps[k], in[i].re, ar); ai = fmaf(taps[k], in[i].im, ai);
+            }
+            out[m].re = ar; out[m].im = ai;
+            continue;
+        }
+        const float* x = xf + 2 * first;
+        __m256 a0 = _mm256_setzero_ps(), a1 = a0, a2 = a0, a3 = a0;
+        for (int j = 0; j < nfp; j += 32) {
+            a0 = _mm256_fmadd_ps(_mm256_load_ps(hr + j), _mm256_loadu_ps(x + j), a0);
+            a1 = _mm256_fmadd_ps(_mm256_load_ps(hr + j + 8), _mm256_loadu_ps(x + j + 8), a1);
+            a2 = _mm256_fmadd_ps(_mm256_load_ps(hr + j + 16), _mm256_loadu_ps(x + j + 16), a2);
+            a3 = _mm256_fmadd_ps(_mm256_load_ps(hr + j + 24), _mm256_loadu_ps(x + j + 24), a3);
+        }
+        float v[8];
+        _mm256_storeu_ps(v, _mm256_add_ps(_mm256_add_ps(a0, a1), _mm256_add_ps(a2, a3)));
+        out[m].re = (v[0] + v[2]) + (v[4] + v[6]);
+        out[m].im = (v[1] + v[3]) + (v[5] + v[7]);
+    }
+    free(hr);
+    return nout;
+}
 size_t orc_decim_auto(const cf32* in, size_t n, const float* taps, int nt, int D, cf32* out)
 {
+    if (g_decim_impl == 1) return orc_decim_fir_ccf_simd(in, n, taps, nt, D, out);
     if (orc_decim_uses_pl(nt, D)) return orc_decim_fir_ccf_pl(in, n, taps, nt, D, out);
     if (orc_decim_uses_m16(nt, D)) return orc_decim_fir_ccf_m16(in, n, taps, nt, D, out);
     return orc_decim_fir_ccf(in, n, taps, nt, D, 4, out);

@@ -21,6 +21,7 @@ MODEM_QPSK20K, MODEM_QPSKVIDEO, MODEM_QPSK2K = 1, 2, 7
 MODEM_BPSK2K, MODEM_BPSK1K = 0, 24
 MODEM_4FSK2K, MODEM_4FSK10KFM, MODEM_4FSK2KFM, MODEM_4FSK1KFM, MODEM_4FSK100K = 3, 4, 5, 6, 27
 MODEM_DMR = 41
+OPT_OVERLAP = 1
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECTANGULAR, WIN_BLACKMAN_HARRIS = 0, 1, 2, 3, 5
 
 
@@ -82,6 +83,7 @@ def load_library():
     lib.qrl_demod_destroy.argtypes = [vp]
     lib.qrl_demod_reset.argtypes = [vp]
     lib.qrl_demod_set_carrier_offset.argtypes = [vp, C.c_double]
+    lib.qrl_demod_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.qrl_demod_out_caps.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     lib.qrl_demod_process.argtypes = [vp, vp, sz, sz, C.POINTER(_Out)]
     lib.qrl_demod_sync.argtypes = [vp]
@@ -145,7 +147,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "qrl_init", "qrl_shutdown", "qrl_strerror", "qrl_last_error", "qrl_version", "qrl_demod_create",
-    "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_out_caps",
+    "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_set_option", "qrl_demod_out_caps",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
     "qrl_mod_samples_per_byte", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_create",
@@ -289,6 +291,9 @@ class Demod:
 
     def reset(self):
         _check(self.lib.qrl_demod_reset(self.h), "qrl_demod_reset")
+
+    def set_option(self, option, value):
+        _check(self.lib.qrl_demod_set_option(self.h, int(option), int(value)), "qrl_demod_set_option")
 
     def set_carrier_offset(self, hz):
         _check(self.lib.qrl_demod_set_carrier_offset(self.h, float(hz)), "qrl_demod_set_carrier_offset")

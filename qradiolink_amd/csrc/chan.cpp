@@ -102,7 +102,9 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
     int r;
     // prototype: low_pass_2(1, fs, 5000, 2000, 60, BH), fs = 25 kHz * M (gr_demod_mmdvm_multi2.cpp:58-60; 250 ksps for M = 10)
-    const std::vector<float> proto = low_pass_2(1, 25000.0 * M, 5000, 2000, 60, WIN_BLACKMAN_HARRIS);
+    // _filter_width of the reference factories (gr_demod_mmdvm_multi2.cpp:47,58-63; gr_demod_mmdvm.cpp:40-52); 0 = their default call site value
+    const double fwp = (!h->xlat && c.filter_width > 0) ? (double)c.filter_width : 5000.0;
+    const std::vector<float> proto = low_pass_2(1, 25000.0 * M, fwp, 2000, 60, WIN_BLACKMAN_HARRIS);
     h->nt = (int)proto.size(); h->J = (h->nt + M - 1) / M;
     if (chan_lds_bytes(M, h->J) > 160 * 1024) return qrl_set_error(QRL_ERR_ARG, "channelizer tile does not fit LDS");
     std::vector<float> t((size_t)h->J * M, 0.0f);
@@ -113,8 +115,8 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     if ((r = h->twiddle.upload(W))) return r;
     // multi2: :60-61, used as 24/25 resampler.  single carrier: gr_demod_mmdvm.cpp:43-45, 12/125 from MMDVM_SAMPLE_RATE = 250 ksps
     if (h->single) { h->rs_I = 12; h->rs_D = 125; }
-    const std::vector<float> rt = h->single ? low_pass_2(12, 12 * 250000.0, 5000, 2000, 60, WIN_BLACKMAN_HARRIS)
-                                            : low_pass_2(1, 600000, 5000, 2000, 60, WIN_BLACKMAN_HARRIS);
+    const std::vector<float> rt = h->single ? low_pass_2(12, 12 * 250000.0, fwp, 2000, 60, WIN_BLACKMAN_HARRIS)
+                                            : low_pass_2(1, 600000, fwp, 2000, 60, WIN_BLACKMAN_HARRIS);
     const int RI = h->rs_I;
     h->rs_Jp = ((int)rt.size() + RI - 1) / RI;
     std::vector<float> rl((size_t)RI * h->rs_Jp, 0.0f);
@@ -147,7 +149,7 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
         h->rs_I = 1; h->rs_D = h->xl_D;
     }
     const std::vector<float> ft = h->xlat ? low_pass(1, 24000, c.filter_width > 0 ? c.filter_width : 8000, 3500, WIN_BLACKMAN_HARRIS)   // legacy :70-74
-                                          : low_pass_2(1, 24000, 5000, 2000, 60, WIN_BLACKMAN_HARRIS);    // :62-63
+                                          : low_pass_2(1, 24000, fwp, 2000, 60, WIN_BLACKMAN_HARRIS);    // :62-63
     h->filt_nt = (int)ft.size();
     if ((r = h->filt_taps.upload(ft)) || (r = h->atan_tab.upload(atan_table()))) return r;
     h->gain = h->single ? (float)(24000.0f / (2 * M_PI * 10000.0f))                               // gr_demod_mmdvm.cpp:41,48
@@ -236,7 +238,7 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
             dp.out = RingC{h->r2.p, h->m2}; dp.out_row_mul_m1 = (uint32_t)CC - 1u; dp.out_row_add = (uint32_t)cl;
             dp.m0 = h->n2; dp.m_count = c2; dp.D = h->xl_D; dp.gtab = h->xl_taps.p; dp.taps = h->xl_taps.p; dp.S = h->xl_S; dp.nt = h->xl_nt;
             dp.rot_enable = 1; dp.rot_acc = 0; dp.rot_inc = h->xl_inc[cl]; dp.rot_nbase = 0; dp.rot_lo = h->xl_rot_lo.p + (size_t)cl * 512;
-            launch_decim_mfma(dp, B, h->stream);
+            if (launch_decim_mfma(dp, B, h->stream)) return qrl_set_error(QRL_ERR_HIP, "freq-xlating front end: hipFuncSetAttribute failed");
         }
     }
     ResampParams rp{};
@@ -280,6 +282,7 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
     sp.out = out; sp.cap = out_cap; sp.counts = counts;
     if (out) launch_f2s(sp, S, h->stream);
     HIPCHK(hipGetLastError());
+    if (qrl::take_launch_error()) return QRL_ERR_HIP;
     h->n_in += n; h->n1 = n1_1; h->n2 = n2_1;
     return QRL_OK;
 }

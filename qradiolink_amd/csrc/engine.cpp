@@ -15,6 +15,8 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <mutex>
+#include <set>
 #include <vector>
 
 using namespace qrl;
@@ -22,6 +24,25 @@ using namespace qrl;
 static thread_local std::string g_last_error;
 static int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
 int qrl_set_error(int code, const std::string& msg) { return fail(code, msg); }   // shared with tx.cpp
+
+namespace qrl {
+static thread_local bool t_launch_error = false;
+hipError_t dyn_lds_limit(const void* kernel, int bytes)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(mu);
+    if (done.count({kernel, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({kernel, dev});
+    else { t_launch_error = true; qrl_set_error(QRL_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e)); }
+    return e;
+}
+bool take_launch_error() { const bool r = t_launch_error; t_launch_error = false; return r; }
+}  // namespace qrl
 
 #define HIPCHK(expr)                                                                              \
     do {                                                                                          \
@@ -85,8 +106,7 @@ struct DecimStage {
             pl = true;
             return taps.upload(decim_pl_layout(h, D));
         }
-        const char* force = std::getenv("QRL_DECIM_VALU");   // A/B timing only: changes the summation contract
-        if (decim_uses_mfma(nt, D) && !(force && force[0] == '1')) {
+        if (decim_uses_mfma(nt, D)) {
             // zero-padded tap vector the MFMA A operands are read from: hp[k + (4S - nt + 1)] = h[k]
             mfma = true;
             S = decim_mfma_steps(nt, D);
@@ -107,11 +127,12 @@ struct DecimStage {
         return taps.upload(decim_layout(h, D, Jpad));
     }
     uint32_t lookback() const { return pl ? (uint32_t)(((nt + D - 1) / D + 1) * D) : mfma ? (uint32_t)(nt + D) : (uint32_t)(Jpad * D); }
-    void launch(DecimParams& p, int B, hipStream_t s) const {
+    int launch(DecimParams& p, int B, hipStream_t s) const {
         p.nt = nt;
-        if (pl) { p.pl_taps = taps.p; launch_decim_pl(p, B, s); }
-        else if (mfma) { p.gtab = taps.p; p.S = S; launch_decim_mfma(p, B, s); }
-        else launch_decim(p, B, variant, s);
+        if (pl) { p.pl_taps = taps.p; return launch_decim_pl(p, B, s); }
+        if (mfma) { p.gtab = taps.p; p.S = S; return launch_decim_mfma(p, B, s); }
+        launch_decim(p, B, variant, s);
+        return 0;
     }
 };
 
@@ -296,12 +317,8 @@ int qrl_demod::build()
     }
     // default: only the 2FSK family, whose FLL + discriminator kernels are a third of a call (measured, C1: 15.2 -> 12.9 ms per
     // step); for the light GMSK / 4FSK tails the extra stream hand-over costs more than it hides (C2: 2.86 -> 3.05 ms).
-    // QRL_OVERLAP=1 forces it for all three families, QRL_NO_OVERLAP=1 switches it off.
-    {
-        const char* on = std::getenv("QRL_OVERLAP"); const char* off = std::getenv("QRL_NO_OVERLAP");
-        overlap = fam == F_2FSK || ((fam == F_GMSK || fam == F_4FSK) && on && on[0] == '1');
-        if ((off && off[0] == '1') || fsk4_disc) overlap = false;   // (the non-FM 4FSK tail runs on the main stream)
-    }
+    // qrl_demod_set_option(QRL_OPT_OVERLAP, 0) switches it off for a handle (measurements of single kernels).
+    overlap = fam == F_2FSK;
     s2_mask = pow2_at_least((overlap ? 2 : 1) * max2 + 1024) - 1;   // history needs: <= 501 taps downstream; overlapped mode: two calls
     const size_t ring2 = (size_t)B * (s2_mask + 1);
     if ((r = s2.alloc(ring2)) || (r = s2f.alloc(ring2)) || (r = s2d.alloc(ring2)) || (r = s3.alloc(ring2))) return r;
@@ -466,7 +483,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         p.out = r1; p.m0 = n1_0; p.m_count = (uint32_t)(n1_1 - n1_0);
         p.taps = fe.taps.p; p.D = fe.D; p.Jpad = fe.Jpad;
         p.rot_enable = 1; p.rot_acc = rot_acc; p.rot_inc = rot_inc; p.rot_nbase = rot_nbase; p.rot_lo = rot_lo.p;
-        fe.launch(p, B, stream);
+        if (fe.launch(p, B, stream)) return fail(QRL_ERR_HIP, "front-end launch: hipFuncSetAttribute failed");
     }
     if (profiling && fe.used) { HIPCHK(hipEventRecord(ev1, stream)); prof_events.emplace_back(ev0, ev1); }
     // ---- stage B: per-mode resampler
@@ -480,7 +497,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         p.n0 = src0; p.n = (uint32_t)(src1 - src0);
         p.out = r2; p.m0 = n2_0; p.m_count = (uint32_t)(n2_1 - n2_0);
         p.taps = first.taps.p; p.D = first.D; p.Jpad = first.Jpad;
-        first.launch(p, B, stream);
+        if (first.launch(p, B, stream)) return fail(QRL_ERR_HIP, "first-stage launch: hipFuncSetAttribute failed");
     } else {
         ResampParams p{};
         if (fe.used) { p.in = nullptr; p.in_ring = r1; }
@@ -523,8 +540,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         launch_fll(f, B, cs);
         filt_in = r2l;
     }
-    const bool fused_2fsk = fam == F_2FSK && !fm && filt_nt <= 41 && disc_nt <= 41 && symf_nt <= 25 &&
-                            !(std::getenv("QRL_2FSK_UNFUSED") && std::getenv("QRL_2FSK_UNFUSED")[0] == '1');
+    const bool fused_2fsk = fam == F_2FSK && !fm && filt_nt <= 41 && disc_nt <= 41 && symf_nt <= 25;
     if (fam == F_DMR) {
         QuadDemodParams q{}; q.in = r2; q.out = r2d; q.q0 = n2_0; q.count = c2; q.gain = demod_gain; q.atan_tab = atan_tab.p;
         launch_quad_demod(q, B, cs);
@@ -627,6 +643,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         if (overlap) { HIPCHK(hipEventRecord(ev_tail2[slot], tail)); tail2_valid[slot] = true; }
     }
     HIPCHK(hipGetLastError());
+    if (take_launch_error()) return QRL_ERR_HIP;   // (message already recorded by dyn_lds_limit)
     n_in = n_in1; n1 = n1_1; n2 = n2_1; ++call_no;
     return QRL_OK;
 }
@@ -720,34 +737,14 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
     if (c.device_samp_rate != 1000000 && (c.device_samp_rate < 2000000 || c.device_samp_rate % 1000000))
         return fail(QRL_ERR_ARG, "device_samp_rate must be 1e6 or a multiple of 1e6 >= 2e6");
     HIPCHK(hipSetDevice(ctx->device));
-    // Streams.  Optional CU partition between the main and the tail stream (QRL_TAIL_CUS = CUs reserved for the tail).
-    int tail_cus = 0;
+    // Streams.  The tail stream has the highest priority and its kernels are small enough to take over the slot of ONE
+    // retiring front-end workgroup.  (Reserving CUs for it with a CU mask was measured: it costs the front end ~18 %.)
     {
-        // (measured: masking costs the front end ~18 % on MI355X, so it is opt-in; by default the tail stream just
-        //  has the highest priority and its kernels are small enough to take over the slot of ONE retiring
-        //  front-end workgroup: <= 80 KB LDS, <= 256 VGPRs per lane)
-        if (const char* e = std::getenv("QRL_TAIL_CUS")) tail_cus = std::atoi(e);
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
-        if (tail_cus >= prop.multiProcessorCount / 2 || c.hip_stream) tail_cus = 0;   // a caller-owned stream cannot be masked
-        const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
-        std::vector<uint32_t> m_main(words, 0), m_tail(words, 0);
-        for (int i = 0; i < ncu; ++i) {
-            // spread the reserved CUs over the XCDs (CU index modulo 8 walks the XCDs on this part)
-            const bool is_tail = tail_cus > 0 && (i % (ncu / tail_cus) == 0) && (i / (ncu / tail_cus) < tail_cus);
-            (is_tail ? m_tail : m_main)[i / 32] |= 1u << (i % 32);
-        }
         if (c.hip_stream) d->stream = static_cast<hipStream_t>(c.hip_stream);
-        else if (tail_cus > 0) { HIPCHK(hipExtStreamCreateWithCUMask(&d->stream, (uint32_t)words, m_main.data())); d->own_stream = true; }
         else { HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)); d->own_stream = true; }
-        if (tail_cus > 0) HIPCHK(hipExtStreamCreateWithCUMask(&d->tail, (uint32_t)words, m_tail.data()));
-        else {
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            int prio = hi;   // QRL_TAIL_PRIO = "low" | "normal": experiments with the tail stream's priority
-            if (const char* e = std::getenv("QRL_TAIL_PRIO")) { if (e[0] == 'l') prio = lo; else if (e[0] == 'n') prio = 0; }
-            HIPCHK(hipStreamCreateWithPriority(&d->tail, hipStreamNonBlocking, prio));
-        }
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIPCHK(hipStreamCreateWithPriority(&d->tail, hipStreamNonBlocking, hi));
     }
     HIPCHK(hipEventCreateWithFlags(&d->ev_ff, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&d->ev_tail, hipEventDisableTiming));
@@ -776,6 +773,21 @@ int qrl_demod_set_carrier_offset(qrl_demod* d, double hz)
     d->cfg.carrier_offset_hz = hz;
     d->rot_inc = phase_inc_to_turn(2 * M_PI * -hz / d->cfg.device_samp_rate);
     return d->upload_rot_table();
+}
+int qrl_demod_set_option(qrl_demod* d, int option, int value)
+{
+    if (!d) return QRL_ERR_ARG;
+    switch (option) {
+    case QRL_OPT_OVERLAP:
+        // overlapped mode can only be switched OFF after creation (ring s2 was sized for two calls; one call fits)
+        if (value != 0 && !d->overlap) return qrl_set_error(QRL_ERR_ARG, "overlapped mode is fixed at creation (2FSK family only)");
+        HIPCHK(hipStreamSynchronize(d->stream));
+        HIPCHK(hipStreamSynchronize(d->tail));
+        if (!value) { d->overlap = false; d->tail2_valid[0] = d->tail2_valid[1] = false; }
+        return QRL_OK;
+    default:
+        return qrl_set_error(QRL_ERR_ARG, "unknown option");
+    }
 }
 int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* fcap, size_t* ccap, size_t* bcap)
 {
@@ -833,6 +845,7 @@ int qrl_demod_profile_read(qrl_demod* d, double* kernel_ms, uint64_t* launches, 
 
 /* developer aid (not part of the drop-in surface): phase profile of k_decim_mfma under QRL_DBG=32 */
 void qrl_debug_decim_prof(unsigned long long* out8) { decim_mfma_prof_read(out8); }
+void qrl_debug_decim_prof_enable(int on) { decim_mfma_prof_enable(on); }
 
 int qrl_demod_process_host(qrl_demod* d, const float* iq_host, size_t stride, size_t n, uint8_t* bits_a_host,
                            uint8_t* bits_b_host, size_t bits_cap, uint32_t* counts_host)

@@ -9,6 +9,13 @@
 
 namespace qrl {
 
+// Raises a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize).  The attribute belongs to the CURRENT
+// DEVICE: it is set once per (kernel, device), from any thread; the HIP error is returned, never swallowed.
+hipError_t dyn_lds_limit(const void* kernel, int bytes);
+// launch_* helpers that could not set the attribute skip their launch and leave a per-thread mark; every process() entry point
+// ends with take_launch_error() and turns it into QRL_ERR_HIP.
+bool take_launch_error();
+
 struct RingC { float2* p; uint32_t mask; };   // complex ring, stream stride = mask+1 items
 struct RingF { float* p; uint32_t mask; };
 struct RingB { uint8_t* p; uint32_t mask; };
@@ -50,12 +57,13 @@ int decim_mfma_steps(int nt, int D);
 int decim_mfma_na(int nt, int D);
 int decim_mfma_hpn(int nt, int D);
 size_t decim_mfma_lds_bytes(int nt, int D);
-void launch_decim_mfma(const DecimParams& p, int batch, hipStream_t s);
+int launch_decim_mfma(const DecimParams& p, int batch, hipStream_t s);   // 0, or -1 when the kernel attribute could not be set
 void decim_mfma_prof_read(unsigned long long* out8);
+void decim_mfma_prof_enable(int on);
 // register-resident phase-lane decimator (32 < D <= 64, <= 16 taps per phase): contract "pl" of oracle/orc_blocks.c
 bool decim_uses_pl(int nt, int D);
 std::vector<float> decim_pl_layout(const std::vector<float>& h, int D);
-void launch_decim_pl(const DecimParams& p, int batch, hipStream_t s);
+int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s);
 
 // ---- K2: rational resampler I/D on a ring (optionally with rotator on a caller buffer) ----
 struct ResampParams {

@@ -128,15 +128,9 @@ size_t chan_lds_bytes(int M, int J)
 void launch_pfb_chan(const ChanParams& p, int batch, hipStream_t s)
 {
     if (!p.m_count) return;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pfb_chan<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pfb_chan<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pfb_chan<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pfb_chan<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pfb_chan<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    for (const void* k : {reinterpret_cast<const void*>(k_pfb_chan<0>), reinterpret_cast<const void*>(k_pfb_chan<4>), reinterpret_cast<const void*>(k_pfb_chan<8>),
+                          reinterpret_cast<const void*>(k_pfb_chan<12>), reinterpret_cast<const void*>(k_pfb_chan<16>)})
+        if (dyn_lds_limit(k, 160 * 1024) != hipSuccess) return;
     const dim3 grid((p.m_count + CH_TI - 1) / CH_TI, batch);
     const size_t lds = chan_lds_bytes(p.M, p.J);
     switch (p.M % 16 == 0 ? p.M / 4 : 0) {
@@ -284,8 +278,7 @@ size_t synth_lds_bytes(int M, int J) { return (size_t)((SY_TB + J - 1) * (M + 1)
 void launch_pfb_synth(const SynthParams& p, int batch, hipStream_t s)
 {
     if (!p.nblk) return;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pfb_synth), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (dyn_lds_limit(reinterpret_cast<const void*>(k_pfb_synth), 160 * 1024) != hipSuccess) return;
     hipLaunchKernelGGL(k_pfb_synth, dim3((p.nblk + SY_TB - 1) / SY_TB, batch), dim3(256), synth_lds_bytes(p.M, p.J), s, p);
 }
 

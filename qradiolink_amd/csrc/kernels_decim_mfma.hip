@@ -25,20 +25,19 @@
 // LDS operands use lgkmcnt, so nothing in the MFMA phase waits on vmcnt); they are rotated and
 // written to LDS after the phase.  Staging is a straight copy, no transposition.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include "devmath.hpp"
 #include "engine.hpp"
-
-#ifndef QRL_MF_EXP
-#define QRL_MF_EXP 0   // timing experiments only: 1 = no LDS operand reads in the MFMA loop, 2 = no MFMA (results are wrong)
-#endif
 
 namespace qrl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// phase profile of k_decim_mfma (QRL_DBG & 32): shader-clock ticks summed over wave 0 of every workgroup
+// phase profile of k_decim_mfma (developer aid, decim_mfma_prof_enable): shader-clock ticks summed over wave 0 of every workgroup
 __device__ unsigned long long g_mf_prof[8];
+static std::atomic<int> g_mf_prof_on{0};
+void decim_mfma_prof_enable(int on) { g_mf_prof_on.store(on ? 32 : 0); }
 
 __device__ __forceinline__ float2 mf_rot_rel(float2 x, uint32_t krel, const float2* t_hi, const float2* t_lo)
 {
@@ -189,147 +188,13 @@ __device__ __forceinline__ void tile_commit(const DecimParams& P, int b, const T
     }
 }
 
-// One contiguous piece of the step loop (no pad jump inside): step i reads A = ap[-4 i] and B = bp[BS i].
-// Software pipelined by hand with two register sets (X = chunk c, Y = chunk c + 1).  The LDS reads are asm
-// statements: hipcc would fuse neighbouring ds_read_b64 into ds_read2_b64, which is served at HALF the LDS
-// rate with mod-32 banking (MI355X_MICROARCH.md, LDS table) and made the LDS the bottleneck of the CU.
-// Waits are explicit and name their registers (guide 5.7 form ii):
-//   issue Y.b (8 DS) | lgkmcnt(8): X complete | 8 MFMA | issue Y.a (8 DS) | 8 MFMA
 constexpr int MF_U = 8;
 typedef __attribute__((address_space(3))) const void* lds_cptr;
-__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_cptr)p; }
 
-#define MF_RD64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
-#define MF_RD32(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
-
-struct MfSet2 { float a[MF_U]; float2 b[MF_U]; };   // NA = 16: B = one complex sample per lane
-struct MfSet1 { float a[MF_U]; float b[MF_U]; };    // NA = 8 : B = re or im of a sample
-
-// B reads of 8 steps: byte stride BSB between steps
-template <int BSB>
-__device__ __forceinline__ void mf_issue_b(MfSet2& r, uint32_t baddr)
-{
-    MF_RD64(r.b[0], baddr, 0 * BSB); MF_RD64(r.b[1], baddr, 1 * BSB); MF_RD64(r.b[2], baddr, 2 * BSB); MF_RD64(r.b[3], baddr, 3 * BSB);
-    MF_RD64(r.b[4], baddr, 4 * BSB); MF_RD64(r.b[5], baddr, 5 * BSB); MF_RD64(r.b[6], baddr, 6 * BSB); MF_RD64(r.b[7], baddr, 7 * BSB);
-}
-template <int BSB>
-__device__ __forceinline__ void mf_issue_b(MfSet1& r, uint32_t baddr)
-{
-    MF_RD32(r.b[0], baddr, 0 * BSB); MF_RD32(r.b[1], baddr, 1 * BSB); MF_RD32(r.b[2], baddr, 2 * BSB); MF_RD32(r.b[3], baddr, 3 * BSB);
-    MF_RD32(r.b[4], baddr, 4 * BSB); MF_RD32(r.b[5], baddr, 5 * BSB); MF_RD32(r.b[6], baddr, 6 * BSB); MF_RD32(r.b[7], baddr, 7 * BSB);
-}
-// A reads of 8 steps: step u at aaddr7 + 16 (7 - u) bytes (aaddr7 = address of the LAST step of the chunk)
-template <class SET>
-__device__ __forceinline__ void mf_issue_a(SET& r, uint32_t aaddr7)
-{
-    MF_RD32(r.a[0], aaddr7, 112); MF_RD32(r.a[1], aaddr7, 96); MF_RD32(r.a[2], aaddr7, 80); MF_RD32(r.a[3], aaddr7, 64);
-    MF_RD32(r.a[4], aaddr7, 48);  MF_RD32(r.a[5], aaddr7, 32); MF_RD32(r.a[6], aaddr7, 16); MF_RD32(r.a[7], aaddr7, 0);
-}
-__device__ __forceinline__ void mf_wait8(MfSet2& r)
-{
-    asm volatile("s_waitcnt lgkmcnt(8)"
-                 : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.a[4]), "+v"(r.a[5]), "+v"(r.a[6]), "+v"(r.a[7]),
-                   "+v"(r.b[0]), "+v"(r.b[1]), "+v"(r.b[2]), "+v"(r.b[3]), "+v"(r.b[4]), "+v"(r.b[5]), "+v"(r.b[6]), "+v"(r.b[7]));
-}
-__device__ __forceinline__ void mf_wait8(MfSet1& r)
-{
-    asm volatile("s_waitcnt lgkmcnt(8)"
-                 : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.a[4]), "+v"(r.a[5]), "+v"(r.a[6]), "+v"(r.a[7]),
-                   "+v"(r.b[0]), "+v"(r.b[1]), "+v"(r.b[2]), "+v"(r.b[3]), "+v"(r.b[4]), "+v"(r.b[5]), "+v"(r.b[6]), "+v"(r.b[7]));
-}
-__device__ __forceinline__ void mf_wait0(MfSet2& r)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.a[4]), "+v"(r.a[5]), "+v"(r.a[6]), "+v"(r.a[7]),
-                   "+v"(r.b[0]), "+v"(r.b[1]), "+v"(r.b[2]), "+v"(r.b[3]), "+v"(r.b[4]), "+v"(r.b[5]), "+v"(r.b[6]), "+v"(r.b[7]));
-}
-__device__ __forceinline__ void mf_wait0(MfSet1& r)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.a[4]), "+v"(r.a[5]), "+v"(r.a[6]), "+v"(r.a[7]),
-                   "+v"(r.b[0]), "+v"(r.b[1]), "+v"(r.b[2]), "+v"(r.b[3]), "+v"(r.b[4]), "+v"(r.b[5]), "+v"(r.b[6]), "+v"(r.b[7]));
-}
-template <int U0>
-__device__ __forceinline__ void mf_fma4(const MfSet2& c, f32x4& acc0, f32x4& acc1)
-{
-#pragma unroll
-    for (int u = U0; u < U0 + 4; ++u) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.a[u], c.b[u].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.a[u], c.b[u].y, acc1, 0, 0, 0);
-    }
-}
-template <int U0>
-__device__ __forceinline__ void mf_fma4(const MfSet1& c, f32x4& acc0, f32x4&)
-{
-#pragma unroll
-    for (int u = U0; u < U0 + 4; ++u) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.a[u], c.b[u], acc0, 0, 0, 0);
-}
-
-// SET/BT/BS: MfSet2/float2/4 (B stride 4 float2 = 32 B per step) or MfSet1/float/8 (8 floats = 32 B per step)
-template <class SET, typename BT, int BS>
-__device__ __forceinline__ void mfma_piece(const float* __restrict__ ap, const BT* __restrict__ bp, int n, f32x4& acc0, f32x4& acc1)
-{
-    constexpr int U = MF_U;
-    constexpr int BSB = 32;   // bytes between the B operands of consecutive steps
-    int i = 0;
-    if (n >= U) {
-        const uint32_t a0 = lds_addr(ap) - 16u * (U - 1);   // address of step 7 of chunk 0; chunk c: minus 128 c
-        const uint32_t b0 = lds_addr(bp);                   // chunk c: plus 256 c
-        const int nch = n / U;
-        SET x, y;
-        mf_issue_b<BSB>(x, b0);
-        mf_issue_a(x, a0);
-        for (int c = 0; c < nch; c += 2) {
-            // chunk c lives in x; prefetch chunk c + 1 into y (beyond the end: harmless re-read of chunk 0)
-            const int c1 = c + 1 < nch ? c + 1 : 0;
-            mf_issue_b<BSB>(y, b0 + 256u * c1);
-            mf_wait8(x);
-            __builtin_amdgcn_sched_barrier(0);
-            mf_fma4<0>(x, acc0, acc1);
-            __builtin_amdgcn_sched_barrier(0);
-            mf_issue_a(y, a0 - 128u * c1);
-            __builtin_amdgcn_sched_barrier(0);
-            mf_fma4<4>(x, acc0, acc1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (c + 1 >= nch) { mf_wait0(y); break; }
-            const int c2 = c + 2 < nch ? c + 2 : 0;
-            mf_issue_b<BSB>(x, b0 + 256u * c2);
-            mf_wait8(y);
-            __builtin_amdgcn_sched_barrier(0);
-            mf_fma4<0>(y, acc0, acc1);
-            __builtin_amdgcn_sched_barrier(0);
-            mf_issue_a(x, a0 - 128u * c2);
-            __builtin_amdgcn_sched_barrier(0);
-            mf_fma4<4>(y, acc0, acc1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (c + 2 >= nch) { mf_wait0(x); break; }
-        }
-        i = nch * U;
-    }
-    for (; i < n; ++i) {
-        const float av = ap[-4 * i];
-        const BT bv = bp[BS * i];
-        if constexpr (BS == 4) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, reinterpret_cast<const float2&>(bv).x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, reinterpret_cast<const float2&>(bv).y, acc1, 0, 0, 0);
-        } else {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, reinterpret_cast<const float&>(bv), acc0, 0, 0, 0);
-        }
-    }
-}
-
-// Compiler-scheduled variant of the same ping-pong (plain LDS reads, sched_barrier pinned).  It is the DEFAULT:
-// the asm variant above is ~5 % faster but showed rare (1e-4 per tile) wrong outputs with two workgroups per
-// CU at 25 Msps that could not be explained; build with -DQRL_MF_ASM_LDS=1 to select it for experiments.
-#ifndef QRL_MF_INTERLEAVE
-#define QRL_MF_INTERLEAVE 1
-#endif
-#ifndef QRL_MF_VOLATILE_LDS
-#define QRL_MF_VOLATILE_LDS 1
-#endif
-#ifndef QRL_MF_ASM_LDS
-#define QRL_MF_ASM_LDS 0
-#endif
+// One contiguous piece of the step loop (no pad jump inside): step i reads A = ap[-4 i] and B = bp[BS i].  Ping-pong over two
+// register sets, compiler-scheduled (the compiler owns every lgkmcnt wait), sched_group_barrier pinned: one LDS read group after
+// every MFMA.  (A hand-written asm variant of this loop with explicit waits was ~5 % faster but produced rare wrong outputs with
+// two workgroups per CU that were never explained; it was removed rather than kept behind a switch.)
 template <typename BT, int BS>
 struct MfChunk {
     float a[MF_U]; BT b[MF_U];
@@ -337,10 +202,8 @@ struct MfChunk {
     {
 #pragma unroll
         for (int u = 0; u < MF_U; ++u) {
-#if QRL_MF_VOLATILE_LDS
             // volatile LDS-address-space reads: hipcc must not fuse neighbours into ds_read2_b32 / ds_read2_b64, which the
-            // LDS serves at half rate (MI355X_MICROARCH.md, LDS table).  The compiler still owns the waitcnt bookkeeping
-            // (unlike the asm variant above).  Measured: front end 2.10 -> 2.02 ms (C2), 9.65 -> 9.49 ms (C1).
+            // LDS serves at half rate (MI355X_MICROARCH.md, LDS table).  The compiler still owns the waitcnt bookkeeping.
             typedef float f32x2_t __attribute__((ext_vector_type(2)));
             typedef const volatile __attribute__((address_space(3))) float* lds_vf;
             typedef const volatile __attribute__((address_space(3))) f32x2_t* lds_vf2;
@@ -351,22 +214,11 @@ struct MfChunk {
             } else {
                 b[u] = *(lds_vf)(lds_cptr)(bp + BS * (i + u));
             }
-#else
-            a[u] = ap[-4 * (i + u)]; b[u] = bp[BS * (i + u)];
-#endif
         }
     }
 };
-#ifndef QRL_MF_EXP
-#define QRL_MF_EXP 0
-#endif
 __device__ __forceinline__ void mf_fma(const MfChunk<float2, 4>& c, f32x4& acc0, f32x4& acc1)
 {
-#if QRL_MF_EXP == 2
-#pragma unroll
-    for (int u = 0; u < MF_U; ++u) { acc0[0] = fmaf(c.a[u], c.b[u].x, acc0[0]); acc1[0] = fmaf(c.a[u], c.b[u].y, acc1[0]); }
-    return;
-#endif
 #pragma unroll
     for (int u = 0; u < MF_U; ++u) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.a[u], c.b[u].x, acc0, 0, 0, 0);
@@ -387,15 +239,8 @@ __device__ __forceinline__ void mfma_piece_c(const float* __restrict__ ap, const
         MfChunk<BT, BS> r0, r1;
         r0.load(ap, bp, 0);
         while (i + 2 * U <= n) {
-#if QRL_MF_EXP == 1
-            if (i == 0)
-#endif
             r1.load(ap, bp, i + U);
-#if !QRL_MF_INTERLEAVE
-            __builtin_amdgcn_sched_barrier(0);
-#endif
             mf_fma(r0, acc0, acc1);
-#if QRL_MF_INTERLEAVE
             // the wave issues in order and blocks at an MFMA while the pipe is busy (32 cycles per v_mfma_f32_16x16x4_f32, one
             // dependent chain already runs at that rate: tools/ubench/mfma_chain.hip); everything issued BETWEEN two MFMAs is
             // free, a block of operand reads behind 16 MFMAs is not.  Interleave: one LDS read group after every MFMA.
@@ -405,23 +250,13 @@ __device__ __forceinline__ void mfma_piece_c(const float* __restrict__ ap, const
                 for (int k = 0; k < NM; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, RD, 0); }
             }
             __builtin_amdgcn_sched_barrier(0);
-#else
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#if QRL_MF_EXP != 1
             r0.load(ap, bp, i + 3 * U <= n ? i + 2 * U : 0);   // beyond the end: harmless re-read of chunk 0
-#endif
-#if !QRL_MF_INTERLEAVE
-            __builtin_amdgcn_sched_barrier(0);
-#endif
             mf_fma(r1, acc0, acc1);
-#if QRL_MF_INTERLEAVE
             {
                 constexpr int NM = BS == 4 ? 2 * U : U, RD = 2 * U / NM;
 #pragma unroll
                 for (int k = 0; k < NM; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x100, RD, 1); }
             }
-#endif
             __builtin_amdgcn_sched_barrier(0);
             i += 2 * U;
         }
@@ -457,8 +292,7 @@ __device__ __forceinline__ void mfma_quarter(const float2* tile, const float* hp
         while (s < s_end) {
             const int seg = (int)__umulhi((uint32_t)s, magic_seg);
             const int e = min(s_end, (seg + 1) * seg_len);
-            if constexpr (QRL_MF_ASM_LDS) mfma_piece<MfSet2, float2, 4>(ap - 4 * s, bp + 4 * s + 2 * seg, e - s, acc0, acc1);
-            else mfma_piece_c<float2, 4>(ap - 4 * s, bp + 4 * s + 2 * seg, e - s, acc0, acc1);
+            mfma_piece_c<float2, 4>(ap - 4 * s, bp + 4 * s + 2 * seg, e - s, acc0, acc1);
             s = e;
         }
         if constexpr (ALIAS) __syncthreads();   // part aliases the head of the tile: every wave must be done reading it
@@ -477,8 +311,7 @@ __device__ __forceinline__ void mfma_quarter(const float2* tile, const float* hp
         while (s < s_end) {
             const int seg = (int)__umulhi((uint32_t)s, magic_seg);
             const int e = min(s_end, (seg + 1) * seg_len);
-            if constexpr (QRL_MF_ASM_LDS) mfma_piece<MfSet1, float, 8>(ap - 4 * s, bp + 2 * (4 * s + 2 * seg), e - s, acc0, acc1);
-            else mfma_piece_c<float, 8>(ap - 4 * s, bp + 2 * (4 * s + 2 * seg), e - s, acc0, acc1);
+            mfma_piece_c<float, 8>(ap - 4 * s, bp + 2 * (4 * s + 2 * seg), e - s, acc0, acc1);
             s = e;
         }
         if constexpr (ALIAS) __syncthreads();
@@ -582,126 +415,6 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #undef MF_STAMP
 }
 
-// ---- two-team variant: ONE workgroup of 8 waves per CU, two tile buffers.  In every phase one team
-// (4 waves = the 4 quarters) runs the MFMA loop of its tile while the other team combines its previous
-// tile, commits its next tile into its own buffer and issues the loads of the one after: the VALU/LDS
-// staging work of one team is deterministically overlapped with the matrix-pipe work of the other
-// (two independent workgroups per CU drift into phase and serialise instead).  One s_barrier per phase.
-template <int NA, int NLD>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_decim_mfma2(const DecimParams P_)
-{
-    const DecimParams& P = P_;
-    extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int T = 16 * NA;
-    const int D = P.D, S = P.S;
-    const int blk = 16 * D;
-    const int Jtot = (NA - 1) * blk + 4 * S;
-    const int hpn = (15 * D + 4 * S + 4 + 3) & ~3;
-    const int nhi = (P.nhi + 1) & ~1;
-    const int dump = Jtot + 2 * (Jtot / blk) + 4;
-    const int tile_len = (dump + 512 + 16 + 1) & ~1;
-    float2* t_lo = reinterpret_cast<float2*>(smem);            // 512
-    float2* t_hi_all = t_lo + 512;                             // [team][buf][nhi]
-    float* hp = reinterpret_cast<float*>(t_hi_all + 4 * nhi);  // hpn floats
-    float2* part_all = reinterpret_cast<float2*>(hp + hpn);    // [team][4 T]
-    float2* tile_all = part_all + 2 * 4 * T;                   // [team][tile_len]
-
-    const int b = blockIdx.y;
-    const uint32_t per = gridDim.x >> 3;
-    const uint32_t cix = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    const uint32_t nchunks = P.nchunks;
-    if (cix >= nchunks || cix >= P.tiles) return;
-    const int tid = threadIdx.x;
-    const int team = __builtin_amdgcn_readfirstlane(tid >> 8);
-    const int ttid = tid & 255;
-    const int g = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
-    const int lane = tid & 63;
-    const uint64_t mt_first = (P.m0 / T) * (uint64_t)T;
-    const int K = (int)((P.tiles - cix + nchunks - 1) / nchunks);   // tiles of this workgroup: t(k) = cix + k nchunks
-    float2* tile = tile_all + (size_t)team * tile_len;
-    float2* part = part_all + (size_t)team * 4 * T;
-    float2* t_hi0 = t_hi_all + (size_t)team * 2 * nhi;
-
-    for (int k = tid; k < hpn; k += 512) hp[k] = P.gtab[k];
-    if (P.rot_enable) t_lo[tid] = P.rot_lo[tid];
-
-    f32x4 v[NLD];
-    TileWin w;
-    uint32_t kb0 = 0;
-    auto tile_mt = [&](int k) { return mt_first + ((uint64_t)cix + (uint64_t)k * nchunks) * T; };
-    // coarse rotator table of tile k into buffer (k >> 1) & 1 of this team; returns its kb0
-    auto make_thi = [&](int k) -> uint32_t {
-        const int64_t ib = (int64_t)tile_mt(k) * D - (P.nt - 1);
-        const int64_t first_new = ib > (int64_t)P.n0 ? ib : (int64_t)P.n0;
-        const uint32_t kb = (uint32_t)(((uint64_t)first_new - P.rot_nbase) >> 9);
-        if (P.rot_enable && ttid < P.nhi)
-            t_hi0[((k >> 1) & 1) * nhi + ttid] = sincos_turn(P.rot_acc + ((uint64_t)(kb + ttid) << 9) * P.rot_inc);
-        return kb;
-    };
-    // stage role: (combine of tile kc done by the caller) -> wait + commit tile k -> issue loads of tile k + 2 -> table of k + 2
-    const bool prof = (P.dbg & 32) && ttid == 0;
-    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tprev = 0;
-#define MF2_T0() do { if (prof) tprev = __builtin_readcyclecounter(); } while (0)
-#define MF2_STAMP(k) do { if (prof) { const unsigned long long tn_ = __builtin_readcyclecounter(); pc[k] += tn_ - tprev; tprev = tn_; } } while (0)
-    auto stage = [&](int k) {
-        MF2_T0();
-        tile_wait<NLD>(v);
-        MF2_STAMP(0);
-        tile_commit<NLD, true, 256>(P, b, w, ttid, v, tile, Jtot, dump, t_hi0 + ((k >> 1) & 1) * nhi, kb0, t_lo);
-        MF2_STAMP(1);
-        if (k + 2 < K) {
-            w = tile_window(P, tile_mt(k + 2), Jtot, true);
-            tile_issue<NLD, 256>(P, b, w, ttid, v);
-            kb0 = make_thi(k + 2);
-        }
-        MF2_STAMP(2);
-    };
-    auto combine = [&](int k) {
-        if (ttid < T) {
-            const uint64_t m = tile_mt(k) + ttid;
-            if (m >= P.m0 && m < P.m0 + P.m_count) {
-                const float2 r0 = part[ttid], r1 = part[T + ttid], r2 = part[2 * T + ttid], r3 = part[3 * T + ttid];
-                float2 y;
-                y.x = (r0.x + r1.x) + (r2.x + r3.x);
-                y.y = (r0.y + r1.y) + (r2.y + r3.y);
-                P.out.p[((size_t)b * (P.out_row_mul_m1 + 1u) + P.out_row_add) * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = y;
-            }
-        }
-    };
-
-    // start-up: each team issues the loads and the table of its first tile (k = team)
-    if (team < K) {
-        w = tile_window(P, tile_mt(team), Jtot, true);
-        tile_issue<NLD, 256>(P, b, w, ttid, v);
-        kb0 = make_thi(team);
-    }
-    __syncthreads();
-    if (team == 0) stage(0);
-    __syncthreads();
-    // phase p: team (p & 1) runs the matrix pipe on tile p, the other team combines tile p - 1 and stages tile p + 1
-    for (int p = 0; p <= K; ++p) {
-        if ((p & 1) == team) {
-            MF2_T0();
-            if (p < K) mfma_quarter<NA, false>(tile, hp, part, g, lane, D, S, P.magic_seg);
-            MF2_STAMP(3);
-        } else {
-            MF2_T0();
-            if (p >= 1) combine(p - 1);
-            MF2_STAMP(4);
-            if (p + 1 < K) stage(p + 1);
-        }
-        MF2_T0();
-        __syncthreads();
-        MF2_STAMP(5 + ((p & 1) == team ? 0 : 1));
-    }
-    if (prof) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) atomicAdd(&g_mf_prof[k], pc[k]);
-        atomicAdd(&g_mf_prof[7], 1ull);
-    }
-}
-
 void decim_mfma_prof_read(unsigned long long* out8)
 {
     (void)hipDeviceSynchronize();
@@ -731,11 +444,9 @@ bool decim_uses_mfma(int nt, int D)
     return (samples + 2 * (samples / (16LL * D)) + 64) * 8 <= 150 * 1024;
 }
 constexpr int kTpwMax = 16;
-static size_t mfma2_lds(int nt, int D, int NA);
 // 16 output blocks per tile when two workgroups of that size fit the 160 KB of a CU, else 8
 int decim_mfma_na(int nt, int D)
 {
-    if (const char* e = std::getenv("QRL_DECIM_NA")) { const int v = std::atoi(e); if (v == 4 || v == 8 || v == 16) return v; }   // experiments
     if (mfma_lds(nt, D, 16, kTpwMax) <= 80 * 1024) return 16;    // two (or more) workgroups per CU with the efficient tile
     if (mfma_lds(nt, D, 8, kTpwMax) <= 160 * 1024) return 8;   // (4-block tiles with three workgroups per CU were measured slower)
     return 4;   // very long filters (100:1 front end, 4181 taps): only the 4-block tile fits the 160 KB of a CU
@@ -743,58 +454,25 @@ int decim_mfma_na(int nt, int D)
 size_t decim_mfma_lds_bytes(int nt, int D) { return mfma_lds(nt, D, decim_mfma_na(nt, D), kTpwMax); }
 
 template <int NA, int NLD, bool FAST, int WPE = 2, int NTH = 256>
-static void launch_k(const DecimParams& q, dim3 grid, size_t lds, hipStream_t s)
+static hipError_t launch_k(const DecimParams& q, dim3 grid, size_t lds, hipStream_t s)
 {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_decim_mfma<NA, NLD, FAST, true, WPE, NTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_decim_mfma<NA, NLD, FAST, false, WPE, NTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
-    const char* na = std::getenv("QRL_DECIM_NOALIAS");
-    if (na && na[0] == '1') hipLaunchKernelGGL((k_decim_mfma<NA, NLD, FAST, false, WPE, NTH>), grid, dim3(NTH), lds + 4 * 16 * NA * sizeof(float2) + (NTH - 256) * 2 * sizeof(float2), s, q);
-    else {
-        const char* pad = std::getenv("QRL_DECIM_PADLDS");   // debugging aid: extra LDS to force one workgroup per CU
-        hipLaunchKernelGGL((k_decim_mfma<NA, NLD, FAST, true, WPE, NTH>), grid, dim3(NTH), lds + (pad ? std::atoi(pad) : 0) + (NTH - 256) * 2 * sizeof(float2), s, q);
-    }
-}
-static size_t mfma2_lds(int nt, int D, int NA)
-{
-    const long long Jtot = mfma_jtot(nt, D, NA);
-    const long long dump = Jtot + 2 * (Jtot / (16LL * D)) + 4;
-    const long long tile_len = (dump + 512 + 16 + 1) & ~1LL;
-    const long long nhi = (mfma_nhi(nt, D, NA, 1) + 1) & ~1;
-    return (size_t)(512 + 4 * nhi + 2 * 4 * 16 * NA + 2 * tile_len) * sizeof(float2) + (size_t)decim_mfma_hpn(nt, D) * sizeof(float);
+    const auto kern = k_decim_mfma<NA, NLD, FAST, true, WPE, NTH>;
+    const hipError_t e = dyn_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, dim3(NTH), lds + (NTH - 256) * 2 * sizeof(float2), s, q);
+    return hipSuccess;
 }
 template <int NA, int NLD>
-static void launch_k2(const DecimParams& q, dim3 grid, size_t lds, hipStream_t s)
+static hipError_t launch_one(const DecimParams& q, dim3 grid, size_t lds, hipStream_t s)
 {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_decim_mfma2<NA, NLD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
-    hipLaunchKernelGGL((k_decim_mfma2<NA, NLD>), grid, dim3(512), lds, s, q);
-}
-template <int NA, int NLD>
-static void launch_one(const DecimParams& q, dim3 grid, size_t lds, hipStream_t s)
-{
-    // two-team kernel: caller's buffer, even-aligned fast path, two tiles fit in LDS
-    // (experimental, slower on both bench workloads: VALU staging and f32 MFMA share the SIMD's ALUs, so the
-    //  overlap it enforces buys nothing; kept for A/B runs) QRL_DECIM_TWO_TEAM=1
-    const char* two = std::getenv("QRL_DECIM_TWO_TEAM");
-    if (two && two[0] == '1' && q.in && q.n >= 2 && NLD <= 16 && mfma2_lds(q.nt, q.D, NA) <= 160 * 1024) {
-        launch_k2<NA, (NLD <= 16 ? NLD : 16)>(q, grid, mfma2_lds(q.nt, q.D, NA), s);
-        return;
-    }
     // FAST: the tile comes from the caller's buffer through register-prefetched 16-byte loads
-    if (q.in && q.n >= 2 && q.n < (1u << 28)) launch_k<NA, NLD, true>(q, grid, lds, s);
-    else launch_k<NA, 1, false>(q, grid, lds, s);
+    if (q.in && q.n >= 2 && q.n < (1u << 28)) return launch_k<NA, NLD, true>(q, grid, lds, s);
+    return launch_k<NA, 1, false>(q, grid, lds, s);
 }
 
-void launch_decim_mfma(const DecimParams& p, int batch, hipStream_t s)
+int launch_decim_mfma(const DecimParams& p, int batch, hipStream_t s)
 {
-    if (p.m_count == 0) return;
+    if (p.m_count == 0) return 0;
     const int NA = decim_mfma_na(p.nt, p.D);
     const uint32_t T = 16 * NA;
     const uint32_t tiles = (uint32_t)((p.m0 + p.m_count + T - 1) / T - p.m0 / T);
@@ -809,40 +487,30 @@ void launch_decim_mfma(const DecimParams& p, int batch, hipStream_t s)
     q.magic_seg = (uint32_t)((0x100000000ull + 4u * (uint32_t)p.D - 1) / (4u * (uint32_t)p.D));
     const uint32_t chunks = (tiles + tpw - 1) / tpw;
     q.nchunks = chunks;
-    { const char* e = std::getenv("QRL_DBG"); q.dbg = e ? std::atoi(e) : 0; }
+    q.dbg = g_mf_prof_on.load(std::memory_order_relaxed);
     // never pad a short grid.x to 8: the padding blocks would leave whole XCDs idle
     dim3 grid(chunks >= 64 ? (chunks + 7) / 8 * 8 : chunks, batch);
     const size_t lds = mfma_lds(p.nt, p.D, NA, tpw);
     const long long pairs = (mfma_jtot(p.nt, p.D, NA) + 2) / 2;
     const int nld = (int)((pairs + 255) / 256);
     const bool fast = q.in && q.n >= 2 && q.n < (1u << 28);
-    const char* w8 = std::getenv("QRL_DECIM_W8");   // 8 waves per workgroup (4 per SIMD with two workgroups per CU)
-    const bool wide = w8 && w8[0] == '1' && fast && nld <= 16;
     // More than 16 loads per thread (front ends beyond ~40:1): a 36-load variant would need 144 prefetch registers, more than
     // the accumulator half of the register file holds, and hipcc then spills registers whose asm-issued loads are still in
     // flight.  Those tiles run with 512 threads (<= 16 loads per thread); anything larger takes the slow per-sample staging.
     const int nld512 = (int)((pairs + 511) / 512);
     const bool big = fast && nld > 16 && nld512 <= 16;
-    q.nld = (wide || big) ? nld512 : nld;
+    q.nld = big ? nld512 : nld;
+    hipError_t e;
     if (fast && nld > 16 && !big) {
-        if (NA == 16) launch_k<16, 1, false>(q, grid, lds, s); else if (NA == 8) launch_k<8, 1, false>(q, grid, lds, s); else launch_k<4, 1, false>(q, grid, lds, s);
-        return;
-    }
-    if (NA == 16) {
-        if (wide) launch_k<16, 8, true, 4, 512>(q, grid, lds, s);
-        else if (big) launch_k<16, 16, true, 2, 512>(q, grid, lds, s);
-        else launch_one<16, 16>(q, grid, lds, s);
+        e = NA == 16 ? launch_k<16, 1, false>(q, grid, lds, s) : NA == 8 ? launch_k<8, 1, false>(q, grid, lds, s) : launch_k<4, 1, false>(q, grid, lds, s);
+    } else if (NA == 16) {
+        e = big ? launch_k<16, 16, true, 2, 512>(q, grid, lds, s) : launch_one<16, 16>(q, grid, lds, s);
     } else if (NA == 4) {
-        if (big) launch_k<4, 16, true, 2, 512>(q, grid, lds, s);
-        else if (nld <= 8 && fast) launch_k<4, 8, true, 3>(q, grid, lds, s);
-        else launch_one<4, 16>(q, grid, lds, s);
+        e = big ? launch_k<4, 16, true, 2, 512>(q, grid, lds, s) : (nld <= 8 && fast) ? launch_k<4, 8, true, 3>(q, grid, lds, s) : launch_one<4, 16>(q, grid, lds, s);
     } else {
-        if (wide) { launch_k<8, 8, true, 4, 512>(q, grid, lds, s); return; }
-        if (big) { launch_k<8, 16, true, 2, 512>(q, grid, lds, s); return; }
-        const char* w3 = std::getenv("QRL_DECIM_WPE3");   // experiment: three smaller workgroups per CU
-        if (w3 && w3[0] == '1' && nld <= 10 && fast) launch_k<8, 10, true, 3>(q, grid, lds, s);
-        else launch_one<8, 16>(q, grid, lds, s);
+        e = big ? launch_k<8, 16, true, 2, 512>(q, grid, lds, s) : launch_one<8, 16>(q, grid, lds, s);
     }
+    return e == hipSuccess ? 0 : -1;
 }
 
 }  // namespace qrl

@@ -24,7 +24,6 @@
 //
 // Summation contract "pl" (oracle/orc_blocks.c orc_decim_fir_ccf_pl): slot(i) = (i-1) mod D; per slot one chain, oldest
 // sample first, first term a plain product, then fmaf; 64 slots (unused = +0) meet as v[l] += v[l+h], h = 32,16,...,1.
-#include <cstdlib>
 #include <vector>
 #include "devmath.hpp"
 #include "engine.hpp"
@@ -280,9 +279,9 @@ static void pl_launch_main(const DecimParams& q, uint32_t units, hipStream_t s)
     hipLaunchKernelGGL((k_decim_pl<J>), dim3((units + 3) / 4), dim3(256), 0, s, q);
 }
 
-void launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)
+int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)
 {
-    if (p.m_count == 0) return;
+    if (p.m_count == 0) return 0;
     const int D = p.D, J = (p.nt + D - 1) / D;
     DecimParams q = p;
     q.pl_J = J;
@@ -299,15 +298,13 @@ void launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)
         const uint32_t cnt = (uint32_t)(m_main - p.m0);
         hipLaunchKernelGGL(k_decim_pl_gen, dim3((cnt + 3) / 4, batch), dim3(256), 0, s, q, p.m0, cnt);
     }
-    if (m_main >= m_end) return;
+    if (m_main >= m_end) return 0;
     // segment length: a multiple of 16 blocks, long enough to keep the warm-up re-reads small, short enough to spread the
     // call over >= ~16 waves per CU, and inside the 64-entry coarse rotator table of a wave (64 x 512 samples)
     const uint64_t total = (m_end - m_main) * (uint64_t)batch;
     uint64_t S = total / (256u * 16u * 4u);
     const uint64_t s_cap = (uint64_t)((62 * 512) / D - J) / 16 * 16;
-    uint64_t smax = 512;
-    if (const char* e = std::getenv("QRL_PL_SMAX")) smax = (uint64_t)std::atoi(e);   // experiments
-    if (S > smax) S = smax;
+    if (S > 512) S = 512;
     if (S > s_cap) S = s_cap;
     S = S / 16 * 16;
     if (S < 16) S = 16;

@@ -23,7 +23,8 @@ __device__ __forceinline__ int deframer_find(int type, uint32_t reg, int& nbits)
 __global__ __launch_bounds__(64) void k_deframe(const DeframeParams P)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
-    const uint32_t n = P.counts ? P.counts[(size_t)b * P.count_stride] : P.n;
+    uint32_t n = P.counts ? P.counts[(size_t)b * P.count_stride] : P.n;
+    if (n > P.stride) n = (uint32_t)P.stride;   // a device-side count never reaches past the stream's own row
     const uint8_t* in = P.bits + (size_t)b * P.stride;
     uint8_t* out = P.out + (size_t)b * P.out_cap;
     DeframeState st = P.st[b];
@@ -83,7 +84,8 @@ __device__ __forceinline__ uint32_t modem_find_sync(int cls, uint32_t reg)
 __global__ __launch_bounds__(64) void k_framesync(const FrameSyncParams P)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
-    const uint32_t n = P.counts ? P.counts[(size_t)b * P.count_stride] : P.n;
+    uint32_t n = P.counts ? P.counts[(size_t)b * P.count_stride] : P.n;
+    if (n > P.stride) n = (uint32_t)P.stride;   // a device-side count never reaches past the stream's own row
     const uint8_t* in = P.bits + (size_t)b * P.stride;
     uint8_t* out = P.out + (size_t)b * P.out_cap;
     uint8_t* bitbuf = P.bitbuf + (size_t)b * P.bitbuf_stride;

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void k_fec(const FecParams P)
     }
     if (lane == 0) {
         P.st[b * 2 + br] = st;
-        P.counts[b * 4 + 2 + br] = nout;
+        P.counts[b * 4 + 2 + br] = nout < P.bits_cap ? nout : (uint32_t)P.bits_cap;   // what was WRITTEN: consumers (deframer, frame sync) trust it
     }
 }
 

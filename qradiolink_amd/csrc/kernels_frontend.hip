@@ -327,8 +327,7 @@ void launch_resamp(const ResampParams& p, int batch, hipStream_t s)
     // span of inputs for 256 outputs: ceil(255*D/I) + 1 + Jp - 1 (+1 slack)
     const int span = (255 * p.D + p.I - 1) / p.I + p.Jp + 2;
     const size_t lds = (size_t)((p.I * p.Jp + 3) & ~3) * sizeof(float) + (size_t)span * sizeof(float2);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_resamp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (dyn_lds_limit(reinterpret_cast<const void*>(k_resamp), 160 * 1024) != hipSuccess) return;
     dim3 grid((p.q_count + 255) / 256, batch), block(256);
     hipLaunchKernelGGL(k_resamp, grid, block, lds, s, p, span);
 }

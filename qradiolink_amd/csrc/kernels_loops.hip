@@ -356,11 +356,7 @@ size_t symsync_lds_bytes()
 
 void launch_symsync_ff(const SymSyncParams& p, int batch, hipStream_t s)
 {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_symsync_ff), hipFuncAttributeMaxDynamicSharedMemorySize, (int)symsync_lds_bytes());
-        attr = true;
-    }
+    if (dyn_lds_limit(reinterpret_cast<const void*>(k_symsync_ff), (int)symsync_lds_bytes()) != hipSuccess) return;
     dim3 grid((batch + SS_NS - 1) / SS_NS), block(256);
     hipLaunchKernelGGL(k_symsync_ff, grid, block, symsync_lds_bytes(), s, p, batch);
 }

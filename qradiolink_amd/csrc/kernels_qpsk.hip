@@ -499,23 +499,15 @@ static size_t qpsk_lds_bytes()
 
 void launch_qpsk_loops(const QpskParams& p, int batch, hipStream_t s)
 {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qpsk_loops<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qpsk_lds_bytes());
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qpsk_loops<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qpsk_lds_bytes());
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qpsk_loops<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qpsk_lds_bytes());
-        attr = true;
-    }
-    static const bool pipe = [] { const char* e = std::getenv("QRL_QPSK_PIPE"); return !(e && e[0] == '0'); }();   // default on
-    if (p.mode == 0 && pipe) {
-        static bool attr2 = false;
-        if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qpsk_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qpsk_pipe_lds_bytes()); attr2 = true; }
+    if (p.mode == 0) {   // gr_demod_qpsk chain: two-wave pipeline (pass 1 / pass 2 on separate waves)
+        if (dyn_lds_limit(reinterpret_cast<const void*>(k_qpsk_pipe), (int)qpsk_pipe_lds_bytes()) != hipSuccess) return;
         hipLaunchKernelGGL(k_qpsk_pipe, dim3((batch + 63) / 64), dim3(256), qpsk_pipe_lds_bytes(), s, p, batch);
         return;
     }
+    const void* kp = p.mode == 2 ? reinterpret_cast<const void*>(k_qpsk_loops<2>) : reinterpret_cast<const void*>(k_qpsk_loops<1>);
+    if (dyn_lds_limit(kp, (int)qpsk_lds_bytes()) != hipSuccess) return;
     if (p.mode == 2) hipLaunchKernelGGL(k_qpsk_loops<2>, dim3((batch + 63) / 64), dim3(256), qpsk_lds_bytes(), s, p, batch);
-    else if (p.mode == 1) hipLaunchKernelGGL(k_qpsk_loops<1>, dim3((batch + 63) / 64), dim3(256), qpsk_lds_bytes(), s, p, batch);
-    else             hipLaunchKernelGGL(k_qpsk_loops<0>, dim3((batch + 63) / 64), dim3(256), qpsk_lds_bytes(), s, p, batch);
+    else hipLaunchKernelGGL(k_qpsk_loops<1>, dim3((batch + 63) / 64), dim3(256), qpsk_lds_bytes(), s, p, batch);
 }
 
 }  // namespace qrl

@@ -141,6 +141,7 @@ int qrl_synth_process(qrl_synth* h, const int16_t* in, size_t stride, size_t n, 
     launch_resamp(rp, S, h->stream);
     if (h->single) {
         HIPCHK(hipGetLastError());
+    if (qrl::take_launch_error()) return QRL_ERR_HIP;
         h->n1 = n1_1; h->n25 = n25_1;
         if (produced) *produced = (size_t)c25;
         return QRL_OK;
@@ -151,6 +152,7 @@ int qrl_synth_process(qrl_synth* h, const int16_t* in, size_t stride, size_t n, 
     yp.out = reinterpret_cast<float2*>(iq); yp.out_stride = out_stride; yp.out_cap = out_stride;
     launch_pfb_synth(yp, B, h->stream);
     HIPCHK(hipGetLastError());
+    if (qrl::take_launch_error()) return QRL_ERR_HIP;
     h->n1 = n1_1; h->n25 = n25_1;
     if (produced) *produced = (size_t)c25 * 10;
     return QRL_OK;

@@ -298,6 +298,7 @@ int qrl_mod_process(qrl_mod* m, const uint8_t* bytes, size_t stride, size_t nbyt
         launch_tx_interp_c(ip, B, m->stream);
         if (m->backend) back_end(ip.count);
         HIPCHK(hipGetLastError());
+    if (qrl::take_launch_error()) return QRL_ERR_HIP;
         m->nsym += ncoded;
         return QRL_OK;
     }
@@ -314,6 +315,7 @@ int qrl_mod_process(qrl_mod* m, const uint8_t* bytes, size_t stride, size_t nbyt
     launch_tx_interp(q, B, m->stream);
     if (m->backend) back_end(q.count);
     HIPCHK(hipGetLastError());
+    if (qrl::take_launch_error()) return QRL_ERR_HIP;
     m->nsym += nitems;
     return QRL_OK;
 }

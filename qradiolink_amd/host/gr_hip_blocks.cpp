@@ -60,6 +60,7 @@ void gr_demod_hip::open()
     hchk(hipMalloc(reinterpret_cast<void**>(&d_a), d_bcap), "hipMalloc");
     hchk(hipMalloc(reinterpret_cast<void**>(&d_b), d_bcap), "hipMalloc");
     d_ha.resize(d_bcap); d_hb.resize(d_bcap); d_hc.resize(d_ccap);
+    if (d_df1) attach_deframer(d_df_type);   // the deframer buffers follow the (possibly new) bit capacity
 }
 gr_demod_hip::~gr_demod_hip()
 {
@@ -71,6 +72,7 @@ gr_demod_hip::~gr_demod_hip()
 void gr_demod_hip::attach_deframer(int type)
 {
     if (d_df1) { qrl_deframer_destroy(d_df1); qrl_deframer_destroy(d_df2); d_df1 = d_df2 = nullptr; }
+    d_df_type = type;
     chk(qrl_deframer_create(d_rt.ctx(), type, 1, nullptr, &d_df1), "qrl_deframer_create");
     chk(qrl_deframer_create(d_rt.ctx(), type, 1, nullptr, &d_df2), "qrl_deframer_create");
     d_dfcap = 2 * d_bcap + 24;

@@ -64,6 +64,7 @@ private:
     qrl_demod_config d_cfg{};
     qrl_demod* d_h = nullptr;
     qrl_deframer *d_df1 = nullptr, *d_df2 = nullptr; uint8_t *d_fa = nullptr, *d_fb = nullptr; uint32_t* d_fcnt = nullptr; size_t d_dfcap = 0;
+    int d_df_type = 0;
     size_t d_fcap = 0, d_ccap = 0, d_bcap = 0;
     std::vector<gr_complex> d_carry;                        // at most one sample: the ABI takes even counts
     std::vector<gr_complex> d_buf;

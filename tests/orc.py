@@ -66,6 +66,8 @@ _sig("orc_decim_auto", _sz, _p, _sz, _p, C.c_int, C.c_int, _p)
 _sig("orc_decim_uses_m16", C.c_int, C.c_int, C.c_int)
 _sig("orc_decim_fir_ccf_pl", _sz, _p, _sz, _p, C.c_int, C.c_int, _p)
 _sig("orc_decim_uses_pl", C.c_int, C.c_int, C.c_int)
+_sig("orc_decim_fir_ccf_simd", _sz, _p, _sz, _p, C.c_int, C.c_int, _p)
+_sig("orc_set_decim_impl", None, C.c_int)
 _sig("orc_m16_steps", C.c_int, C.c_int, C.c_int)
 _sig("orc_resamp_ccf", _sz, _p, _sz, _p, C.c_int, C.c_int, C.c_int, _p)
 _sig("orc_fir_ccf", None, _p, _sz, _p, C.c_int, _p)
@@ -205,6 +207,15 @@ def decim_fir_ccf_pl(x, taps, decim):
     n = lib.orc_decim_count(x.size, 1, decim)
     y = np.empty(n, cf32)
     lib.orc_decim_fir_ccf_pl(_ptr(x), x.size, _ptr(taps), taps.size, decim, _ptr(y))
+    return y
+
+
+def decim_fir_ccf_simd(x, taps, decim):
+    x = np.ascontiguousarray(x, cf32)
+    taps = np.ascontiguousarray(taps, np.float32)
+    n = lib.orc_decim_count(x.size, 1, decim)
+    y = np.empty(n, cf32)
+    lib.orc_decim_fir_ccf_simd(_ptr(x), x.size, _ptr(taps), taps.size, decim, _ptr(y))
     return y
 
 

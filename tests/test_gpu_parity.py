@@ -145,6 +145,39 @@ def test_front_end_repeatable_under_load(qrl_ctx):
                 assert np.array_equal(got[b], ref[b]), "run %d stream %d differs from run 0" % (rep, b)
 
 
+def test_front_end_repeatable_200_runs_at_bench_like_batch(qrl_ctx):
+    """The same race hunt where it matters: 512 streams (two workgroups per CU on every CU, tiles-per-workgroup > 1, the asm-issued
+    register prefetch of tile_issue / tile_wait in flight everywhere), 200 repetitions of the same call from a fresh state; every
+    repetition must reproduce run 0 bit for bit on all four ports, and run 0 equals the oracle on a few streams.  (The ISA-level
+    proof that no instruction touches a prefetch register before its wait is tests/test_isa_audit.py.)"""
+    import torch
+    import qradiolink_amd as q
+    rate, offset, B = 25000000, 25000.0, 512
+    base = sig.make_batch("gmsk10k", 4, nframes=1, device_rate=rate, rx_offset_hz=offset, seed=13)
+    n = base.shape[1] & ~1
+    idx = np.arange(B) % 4
+    d = torch.from_numpy(base[:, :n]).cuda()[torch.from_numpy(idx).cuda()].contiguous()
+    dem = q.Demod(qrl_ctx, q.MODEM_GMSK10K, batch=B, max_chunk=n, device_samp_rate=rate, carrier_offset_hz=offset)
+    ref = None
+    for rep in range(200):
+        dem.reset()
+        out = dem.process(d)
+        cur = [out[k].clone() for k in ("filtered", "constellation", "bits_a", "bits_b", "counts")]
+        if ref is None:
+            ref = cur
+            cnt = cur[4].cpu().numpy()
+            for b in (0, 1, 2, 3, 257, 511):
+                want = _oracle("gmsk10k", base[idx[b], :n], rate, offset)
+                assert np.array_equal(cur[2][b, :cnt[b, 2]].cpu().numpy(), want["bits_a"])
+                got = cur[0][b, :cnt[b, 0]].cpu().numpy().view(np.float32) + np.float32(0)
+                assert np.array_equal(got.view(np.uint32), (want["filtered"].view(np.float32) + np.float32(0)).view(np.uint32))
+        else:
+            for k in range(5):
+                assert torch.equal(torch.view_as_real(cur[k]) if cur[k].is_complex() else cur[k],
+                                   torch.view_as_real(ref[k]) if ref[k].is_complex() else ref[k]), "run %d differs from run 0 (port %d)" % (rep, k)
+    dem.close()
+
+
 def test_loopback_frames_recovered(qrl_ctx):
     """mod -> channel -> HIP demod returns the transmitted frames through gr_modem-style sync search."""
     import torch

@@ -1,0 +1,92 @@
+"""Multi-GPU paths exercised with the HIP pipeline itself.  A one-GPU box cannot run two RCCL ranks, so
+  * stream sharding (C1-C3): two handles on one device take the two shards of sharding.shard_range; together they must equal
+    the single-handle run and the oracle;
+  * channel sharding (C4): TWO PROCESSES (gloo process group, both on cuda:0) -- rank 0 owns the wideband input and broadcasts it
+    (bench.py does the same broadcast with RCCL on device tensors), every rank runs the HIP channelizer on ITS channel range,
+    results are gathered with sharding.gather_units and compared with the oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import orc
+import sig
+from qradiolink_amd import sharding
+
+pytestmark = pytest.mark.gpu
+
+
+def test_stream_sharding_two_handles_equal_single_handle(qrl_ctx):
+    import torch
+    import qradiolink_amd as q
+    B, rate, offset = 5, 1000000, 1200.0
+    iq = sig.make_batch("2fsk1k", B, nframes=2, device_rate=rate, rx_offset_hz=offset, seed=31)
+    d = torch.from_numpy(iq).cuda()
+    outs = []
+    for rank in range(2):
+        first, count = sharding.shard_range(B, 2, rank)
+        dem = q.Demod(qrl_ctx, 18, batch=count, max_chunk=iq.shape[1], device_samp_rate=rate, carrier_offset_hz=offset)
+        o = q.collect(dem, d[first:first + count].contiguous(), iq.shape[1])
+        dem.close()
+        outs.extend(zip(o["bits_a"], o["bits_b"], o["filtered"]))
+    assert len(outs) == B
+    for b in range(B):
+        ref = orc.demod_2fsk(orc.frontend(iq[b], rate, offset), sps=10, filter_width=2000, fm=False)
+        assert np.array_equal(outs[b][0], ref["bits_a"]) and np.array_equal(outs[b][1], ref["bits_b"])
+        got, want = outs[b][2].view(np.float32) + np.float32(0), ref["filtered"].view(np.float32) + np.float32(0)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def _chan_worker(rank, world, port, iq_host, M, q_out):
+    import torch
+    import torch.distributed as dist
+    import qradiolink_amd as q
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = iq_host.shape[1]
+        buf = torch.from_numpy(iq_host.view(np.float32).copy()) if rank == 0 else torch.empty((iq_host.shape[0], 2 * n), dtype=torch.float32)
+        dist.broadcast(buf, src=0)                       # the exchange step of SURVEY 8e (RCCL broadcast in bench.py --config c4)
+        iq = torch.view_as_complex(buf.view(iq_host.shape[0], n, 2)).cuda()
+        first, count = sharding.shard_range(M, world, rank)
+        ctx = q.Context(0)
+        ch = q.Channelizer(ctx, M, batch=iq.shape[0], max_chunk=n, channel_first=first, channel_count=count)
+        out, cnt = ch.process(iq)
+        out, cnt = out.cpu().numpy(), cnt.cpu().numpy()
+        local = [out[0, c, :cnt[0, c]].copy() for c in range(count)]
+        ch.close()
+        ctx.close()
+        full = sharding.gather_units(local, M)
+        if rank == 0:
+            q_out.put([x.tobytes() for x in full])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_channel_sharding_two_processes_with_broadcast():
+    import torch.multiprocessing as mp
+    M, n = 64, 64 * 1200
+    rng = np.random.default_rng(4)
+    iq = (0.05 * (rng.standard_normal((1, n)) + 1j * rng.standard_normal((1, n)))).astype(np.complex64)
+    t = np.arange(n)
+    for c in (3, 17, 40, 61):   # a few carriers so that the channels differ
+        iq[0] += (0.2 * np.exp(2j * np.pi * (c / M + 0.0007) * t)).astype(np.complex64)
+    ref = orc.demod_mmdvm_multi(iq[0], M)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    procs = [ctx.Process(target=_chan_worker, args=(r, 2, port, iq, M, q_out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q_out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len(got) == M
+    for c in range(M):
+        assert got[c] == np.ascontiguousarray(ref[c]).tobytes(), "channel %d differs from the oracle" % c

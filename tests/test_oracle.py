@@ -220,6 +220,14 @@ def test_pl_contract_matches_float64_definition(decim, nt_scale):
     assert np.array_equal(orc.decim_auto(x, h, decim).view(np.float32), y.view(np.float32))
 
 
+def test_cpu_baseline_simd_decimator_matches_definition():
+    """The AVX2 dot-product decimator the bench times as CPU baseline (not a checker) computes the same filter."""
+    rng = np.random.default_rng(17)
+    for decim, h in ((50, orc.low_pass(1, 1e6, 10e3, 10e3, BH)), (25, orc.low_pass(1, 25e6, 480e3, 100e3, BH))):
+        x = (rng.standard_normal(30 * decim + 2 * h.size) + 1j * rng.standard_normal(30 * decim + 2 * h.size)).astype(np.complex64)
+        assert _definition_error(orc.decim_fir_ccf_simd(x, h, decim), x, h, decim) < 1e-5
+
+
 def test_pl_contract_is_position_independent():
     """Output m only depends on the samples of its window: a stream that starts later (shifted by whole blocks) gives the
     same bits once the window is inside the stream -- the property chunked / segmented evaluation relies on."""

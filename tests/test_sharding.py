@@ -1,6 +1,8 @@
 """N>1 path on CPU: world_size-2 gloo run of the stream sharding + result gather used by bench.py
 and the multi-channel path (shard by stream/channel, no data-path collective).
-The per-stream work is done here by the CPU oracle as a stand-in for the device pipeline."""
+The per-stream work is done here by the CPU oracle as a stand-in for the device pipeline (there is no GPU in the CPU test run);
+tests/test_gpu_sharding.py runs the same sharding with the HIP pipeline: two handles for stream shards, two processes + a
+broadcast of the wideband input for channel shards."""
 import os
 import socket
 import sys
