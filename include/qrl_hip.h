@@ -95,9 +95,9 @@ int qrl_demod_reset(qrl_demod* d);
 /* replaces: rotator_cc::set_phase_inc (gr_demod_base.cpp:1220-1225); phase-continuous retune */
 int qrl_demod_set_carrier_offset(qrl_demod* d, double carrier_offset_hz);
 /* capacities (items per stream) a call with n input samples can need */
-/* Per-handle run-time options (none of them changes results).  QRL_OPT_OVERLAP: the 2FSK family runs everything behind the
- * first decimated ring of call k on a second stream under the front end of call k + 1 (default on); value 0 runs the kernels
- * of a call one after another (used to time single kernels).  It cannot be switched on where it is off. */
+/* Per-handle run-time options (none of them changes results).  QRL_OPT_OVERLAP (2FSK family only, default 0): value 1 runs
+ * everything behind the first decimated ring of call k on a second stream under the front end of call k + 1; value 0 runs the
+ * kernels of a call one after another. */
 enum { QRL_OPT_OVERLAP = 1 };
 int qrl_demod_set_option(qrl_demod* d, int option, int value);
 int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* filtered_cap, size_t* constellation_cap, size_t* bits_cap);

@@ -152,7 +152,7 @@ struct qrl_demod {
     // the front end of the NEXT call already runs on the main stream; ring s2 holds two calls, ev_tail2 guards its reuse
     bool qpsk_fll = false, fsk4_disc = false;
     DevBuf<float2> s2g, disc4_taps; DevBuf<float> sym4_taps; int disc4_nt = 0, sym4_nt = 0;   // 4FSK non-FM branch
-    bool overlap = false; hipEvent_t ev_tail2[2] = {nullptr, nullptr}; bool tail2_valid[2] = {false, false}; uint64_t call_no = 0;
+    bool overlap = false, overlap_capable = false; hipEvent_t ev_tail2[2] = {nullptr, nullptr}; bool tail2_valid[2] = {false, false}; uint64_t call_no = 0;
     enum Family { F_2FSK, F_GMSK, F_QPSK, F_DMR, F_4FSK, F_BPSK } fam = F_2FSK;
     int branches = 2;
 
@@ -317,9 +317,12 @@ int qrl_demod::build()
     }
     // default: only the 2FSK family, whose FLL + discriminator kernels are a third of a call (measured, C1: 15.2 -> 12.9 ms per
     // step); for the light GMSK / 4FSK tails the extra stream hand-over costs more than it hides (C2: 2.86 -> 3.05 ms).
-    // qrl_demod_set_option(QRL_OPT_OVERLAP, 0) switches it off for a handle (measurements of single kernels).
-    overlap = fam == F_2FSK;
-    s2_mask = pow2_at_least((overlap ? 2 : 1) * max2 + 1024) - 1;   // history needs: <= 501 taps downstream; overlapped mode: two calls
+    // The rings are sized for it, but it is OFF by default (qrl_demod_set_option(QRL_OPT_OVERLAP, 1) switches it on): measured on
+    // C1 it buys 10 % of whole-chain throughput (9.4 instead of 10.4 ms per step) while the front-end kernel, sharing the GPU,
+    // stretches from 7.1 to 9.0 ms -- the recursion kernels are only placed once the front end's workgroups drain.
+    overlap_capable = fam == F_2FSK;
+    overlap = false;
+    s2_mask = pow2_at_least((overlap_capable ? 2 : 1) * max2 + 1024) - 1;   // history needs: <= 501 taps downstream; overlapped mode: two calls
     const size_t ring2 = (size_t)B * (s2_mask + 1);
     if ((r = s2.alloc(ring2)) || (r = s2f.alloc(ring2)) || (r = s2d.alloc(ring2)) || (r = s3.alloc(ring2))) return r;
     if ((fam == F_2FSK || fam == F_BPSK || (fam == F_QPSK && qpsk_fll)) && (r = s2l.alloc(ring2))) return r;
@@ -744,7 +747,7 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         else { HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)); d->own_stream = true; }
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        HIPCHK(hipStreamCreateWithPriority(&d->tail, hipStreamNonBlocking, hi));
+        HIPCHK(hipStreamCreateWithPriority(&d->tail, hipStreamNonBlocking, hi));   // (low / normal priority measured: no difference)
     }
     HIPCHK(hipEventCreateWithFlags(&d->ev_ff, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&d->ev_tail, hipEventDisableTiming));
@@ -779,11 +782,11 @@ int qrl_demod_set_option(qrl_demod* d, int option, int value)
     if (!d) return QRL_ERR_ARG;
     switch (option) {
     case QRL_OPT_OVERLAP:
-        // overlapped mode can only be switched OFF after creation (ring s2 was sized for two calls; one call fits)
-        if (value != 0 && !d->overlap) return qrl_set_error(QRL_ERR_ARG, "overlapped mode is fixed at creation (2FSK family only)");
+        if (value != 0 && !d->overlap_capable) return qrl_set_error(QRL_ERR_ARG, "overlapped mode exists for the 2FSK family only");
         HIPCHK(hipStreamSynchronize(d->stream));
         HIPCHK(hipStreamSynchronize(d->tail));
-        if (!value) { d->overlap = false; d->tail2_valid[0] = d->tail2_valid[1] = false; }
+        d->overlap = value != 0;
+        d->tail2_valid[0] = d->tail2_valid[1] = false;
         return QRL_OK;
     default:
         return qrl_set_error(QRL_ERR_ARG, "unknown option");

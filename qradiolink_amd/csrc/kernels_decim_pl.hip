@@ -323,6 +323,7 @@ int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)
     case 13: pl_launch_main<13>(q, units, s); break; case 14: pl_launch_main<14>(q, units, s); break;
     case 15: pl_launch_main<15>(q, units, s); break; default: pl_launch_main<16>(q, units, s); break;
     }
+    return 0;
 }
 
 }  // namespace qrl

@@ -18,7 +18,12 @@ namespace qrl {
 // depends on the sample that was just derotated.  (A variant with the delay line in absolute-index register
 // slots and an NT-times unrolled body was tried: 20 % slower -- its 60 KB of code thrashes the instruction
 // cache and a single wave per SIMD is issue-latency bound anyway: ~5 cycles per instruction.)
-constexpr int FLL_CH = 128;   // samples per stream per LDS window (power of two: cheap staging index math)
+// Geometry: 4 waves per workgroup (64 streams x 4 lanes, one wave per SIMD) and a 128-sample LDS window.  (Single-wave
+// workgroups with a 16-sample window and <= 96 registers were tried so that the kernel could slip in beside the front end of
+// the next call in overlapped mode: the recursion itself got slower -- 2.5 instead of 1.7 ms -- and the overlap no better.)
+constexpr int FLL_TH = 256;              // threads per workgroup
+constexpr int FLL_NS = FLL_TH / 4;       // streams per workgroup
+constexpr int FLL_CH = 128;              // samples per stream per LDS window (power of two: cheap staging index math)
 
 template <int CTRL> __device__ __forceinline__ float dpp_quad(float v)
 {
@@ -29,19 +34,19 @@ template <int CTRL> __device__ __forceinline__ float dpp_quad(float v)
 // the recursion's critical path, so the delay line is cut into 4 groups of NT/4 samples, one per lane of a quad: every lane
 // runs the short oldest-first fmaf chains of its group, the delay line shifts through the quad with one DPP move, and the
 // partial sums meet by two DPP butterflies as (p0 + p1) + (p2 + p3) -- the summation contract of oracle orc_fll_band_edge.
-// The NCO / loop update is computed redundantly by the four lanes (bit-identical inputs, bit-identical results).  A workgroup
-// of 256 threads = 64 streams shares one LDS window; compared with the lane-per-stream kernel there are 4x more waves
-// (one per SIMD instead of one per CU at 16k streams) with ~3x shorter instruction streams.
+// The NCO / loop update is computed redundantly by the four lanes (bit-identical inputs, bit-identical results).  Compared with
+// the lane-per-stream kernel there are 4x more waves (one per SIMD instead of one per CU at 16k streams) with ~3x shorter
+// instruction streams.
 template <int NT>
-__global__ __launch_bounds__(256) void k_fll(const FllParams P, int batch)
+__global__ __launch_bounds__(FLL_TH) void k_fll(const FllParams P, int batch)
 {
     constexpr int GL = NT / 4;
-    __shared__ float2 win[64][FLL_CH + 1];
+    __shared__ float2 win[FLL_NS][FLL_CH + 1];
     __shared__ float2 tl[NT], tu[NT];
-    __shared__ float2 dump[256];
+    __shared__ float2 dump[FLL_TH];
     const int tid = threadIdx.x;
     const int sl = tid >> 2, g = tid & 3;
-    const int b0 = blockIdx.x * 64;
+    const int b0 = blockIdx.x * FLL_NS;
     const int b = b0 + sl;
     const bool active = b < batch;
     if (tid < NT) { tl[tid] = P.lower[tid]; tu[tid] = P.upper[tid]; }
@@ -56,19 +61,19 @@ __global__ __launch_bounds__(256) void k_fll(const FllParams P, int batch)
 #pragma unroll
         for (int t = 0; t < GL; ++t) dl[t] = make_float2(0.f, 0.f);
     }
-    const int nstreams = min(64, batch - b0);
+    const int nstreams = min(FLL_NS, batch - b0);
     __syncthreads();
     float2 hu[GL], hl[GL];   // this lane's taps: entry j of the device tables belongs to y[n - j]
 #pragma unroll
     for (int t = 0; t < GL; ++t) { hu[t] = tu[g * GL + t]; hl[t] = tl[g * GL + t]; }
     // Staging: every thread keeps the NEXT window's items in registers (NPT unconditional 8-byte loads issued before the serial
     // loop of the current window, so their latency hides behind it; a load-wait-store loop here cost as much as the recursion).
-    constexpr int NPT = 64 * FLL_CH / 256;
+    constexpr int NPT = FLL_NS * FLL_CH / FLL_TH;
     float2 pre[NPT];
     auto preload = [&](uint32_t c0) {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
-            const int idx = tid + 256 * i, s = min(idx / FLL_CH, nstreams - 1), k = idx % FLL_CH;
+            const int idx = tid + FLL_TH * i, s = min(idx / FLL_CH, nstreams - 1), k = idx % FLL_CH;
             const int64_t a = (int64_t)(P.q0 + c0 + k) - NT;   // x[n - NT]; ring reads are in bounds for any index
             const float2 v = P.in.p[(size_t)(b0 + s) * (P.in.mask + 1u) + ((uint32_t)a & P.in.mask)];
             pre[i] = a >= 0 ? v : make_float2(0.f, 0.f);
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(256) void k_fll(const FllParams P, int batch)
         const int len = min((uint32_t)FLL_CH, P.count - c0);
         __syncthreads();   // the flush of the previous window is through with win
 #pragma unroll
-        for (int i = 0; i < NPT; ++i) { const int idx = tid + 256 * i; win[idx / FLL_CH][idx % FLL_CH] = pre[i]; }
+        for (int i = 0; i < NPT; ++i) { const int idx = tid + FLL_TH * i; win[idx / FLL_CH][idx % FLL_CH] = pre[i]; }
         __syncthreads();
         if (c0 + FLL_CH < P.count) preload(c0 + FLL_CH);
         if (active) {
@@ -127,9 +132,10 @@ __global__ __launch_bounds__(256) void k_fll(const FllParams P, int batch)
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < nstreams * FLL_CH; idx += 256) {
-            const int s = idx / FLL_CH, k = idx - s * FLL_CH;
-            if (k < len) P.out.p[(size_t)(b0 + s) * (P.out.mask + 1u) + ((uint32_t)(P.q0 + c0 + k) & P.out.mask)] = win[s][k];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int idx = tid + FLL_TH * i, s = idx / FLL_CH, k = idx % FLL_CH;
+            if (s < nstreams && k < len) P.out.p[(size_t)(b0 + s) * (P.out.mask + 1u) + ((uint32_t)(P.q0 + c0 + k) & P.out.mask)] = win[s][k];
         }
     }
     if (active) {
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(256) void k_fll(const FllParams P, int batch)
 void launch_fll(const FllParams& p, int batch, hipStream_t s)
 {
     if (!p.count) return;
-    dim3 grid((batch + 63) / 64), block(256);
+    dim3 grid((batch + FLL_NS - 1) / FLL_NS), block(FLL_TH);
     if (p.nt == 16) hipLaunchKernelGGL((k_fll<16>), grid, block, 0, s, p, batch);
     else            hipLaunchKernelGGL((k_fll<32>), grid, block, 0, s, p, batch);
 }

@@ -237,6 +237,8 @@ def test_pipelined_calls_without_sync(qrl_ctx, mode_name, modem):
     res = []
     for sync_each in (True, False):
         dem = q.Demod(qrl_ctx, modem, batch=B, max_chunk=chunk)
+        if mode_name.startswith("2fsk") and not sync_each:
+            dem.set_option(q.OPT_OVERLAP, 1)   # the opt-in overlapped mode of the 2FSK family (QRL_OPT_OVERLAP)
         for k in range(ncalls):
             dem.process_async(d[:, k * chunk:(k + 1) * chunk])
             if sync_each:
