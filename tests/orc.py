@@ -438,6 +438,50 @@ def tx_interp(x, samp_rate):
     return y[:m]
 
 
+_sig("orc_fll_band_edge", None, _p, _sz, C.c_float, C.c_float, C.c_int, C.c_float, _p)
+_sig("orc_costas", None, _p, _sz, C.c_float, C.c_int, C.c_int, _p)
+_sig("orc_agc2", None, _p, _sz, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p)
+_sig("orc_symbol_sync_ff", _sz, _p, _sz, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _p)
+_sig("orc_symbol_sync_cc", _sz, _p, _sz, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _p)
+TED_MM, TED_MOD_MM = 0, 1
+CONST_BPSK, CONST_DQPSK, CONST_4LEVEL = 0, 1, 2
+
+
+def fll_band_edge(x, sps, rolloff, ntaps, bw):
+    x = np.ascontiguousarray(x, cf32)
+    y = np.empty(x.size, cf32)
+    lib.orc_fll_band_edge(_ptr(x), x.size, sps, rolloff, ntaps, bw, _ptr(y))
+    return y
+
+
+def costas(x, bw, order, use_snr):
+    x = np.ascontiguousarray(x, cf32)
+    y = np.empty(x.size, cf32)
+    lib.orc_costas(_ptr(x), x.size, bw, order, int(use_snr), _ptr(y))
+    return y
+
+
+def agc2(x, attack, decay, ref, gain, max_gain=65536.0):
+    x = np.ascontiguousarray(x, cf32)
+    y = np.empty(x.size, cf32)
+    lib.orc_agc2(_ptr(x), x.size, attack, decay, ref, gain, max_gain, _ptr(y))
+    return y
+
+
+def symbol_sync_ff(x, ted, sps, loop_bw, damping, ted_gain, max_dev, constellation):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty(x.size, np.float32)
+    n = lib.orc_symbol_sync_ff(_ptr(x), x.size, ted, sps, loop_bw, damping, ted_gain, max_dev, constellation, _ptr(y))
+    return y[:n].copy()
+
+
+def symbol_sync_cc(x, ted, sps, loop_bw, damping, ted_gain, max_dev, constellation):
+    x = np.ascontiguousarray(x, cf32)
+    y = np.empty(x.size, cf32)
+    n = lib.orc_symbol_sync_cc(_ptr(x), x.size, ted, sps, loop_bw, damping, ted_gain, max_dev, constellation, _ptr(y))
+    return y[:n].copy()
+
+
 def cc_decode_k7(soft):
     soft = np.ascontiguousarray(soft, np.uint8)
     out = np.zeros(soft.size // 2 + 80, np.uint8)
