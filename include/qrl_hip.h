@@ -95,6 +95,15 @@ int qrl_demod_reset(qrl_demod* d);
 /* replaces: rotator_cc::set_phase_inc (gr_demod_base.cpp:1220-1225); phase-continuous retune */
 int qrl_demod_set_carrier_offset(qrl_demod* d, double carrier_offset_hz);
 /* capacities (items per stream) a call with n input samples can need */
+/* a37b, QRL_MODEM_DMR only: gr_dmr_dmo_sink (reference src/gr/gr_dmr_dmo_sink.cpp:63-357) on the device, fed from port 3 of
+ * gr_demod_dmr (RRC-filtered discriminator output, gr_demod_dmr.cpp:94).  Every following qrl_demod_process call also runs the
+ * MS-sync correlator / 4-level slicer / slot-type state machine over the call's new samples and appends the DMR bursts it cuts to
+ * frames[b * cap_frames * 40 + i * 40]: 40-byte records {frame type (DMRFrameType 0 data, 1 voice, 2 voice sync), FN, colour code,
+ * 0, 33 frame bytes, 3 pad}; counts[b] = records written by the call (device pointers; replaces gr_dmr_dmo_sink::get_data).
+ * frames == NULL switches it off.  The stream position must be the start of the stream (call it before the first process / after
+ * a reset) or the slicer starts with an empty 1440-sample history. */
+#define QRL_DMO_RECORD_BYTES 40
+int qrl_demod_set_dmo_output(qrl_demod* d, uint8_t* frames, size_t cap_frames, uint32_t* counts);
 /* Per-handle run-time options (none of them changes results).  QRL_OPT_OVERLAP (2FSK family only, default 0): value 1 runs
  * everything behind the first decimated ring of call k on a second stream under the front end of call k + 1; value 0 runs the
  * kernels of a call one after another. */

@@ -140,11 +140,25 @@ size_t orc_demod_mmdvm_multi_4fsk(const cf32* in, size_t n, int M, int16_t* out,
                                   uint8_t* dibits, size_t dcap, size_t* ndib);
 size_t orc_demod_mmdvm_multi_rssi(const cf32* in, size_t n, int M, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal);
 void orc_demod_dmr(const cf32* in, size_t n, int sps, int samp_rate, orc_demod_out* o);
+size_t orc_demod_dmr_port3(const cf32* in, size_t n, int samp_rate, float* out);
 void orc_4fsk_symbols_to_bits(const float* sym, size_t nsym, cf32* constellation, uint8_t* bits);
 /* multi-carrier MMDVM RX (gr_demod_mmdvm_multi2): PFB channelizer + per-channel 24/25 resampler, LPF, FM discriminator, int16 */
 int    orc_chan_proto_taps(int M, float* taps);
 size_t orc_pfb_channelizer(const cf32* in, size_t n, const float* taps, int nt, int M, cf32* out);
 size_t orc_demod_mmdvm_multi(const cf32* in, size_t n, int M, int16_t* out, size_t cap);
+
+/* DMR DMO correlator slicer (gr_dmr_dmo_sink), orc_dmr.c.  Frames leave as 40-byte records {type, FN, colour code, 0, 33 bytes, 3 pad}. */
+typedef struct {
+    uint32_t bitBuffer[5];
+    uint16_t bitPtr, dataPtr, syncPtr, startPtr, endPtr;
+    float maxCorr, centre[4], threshold[4];
+    uint8_t averagePtr, syncCount, state, control, n, colorCode;
+    float buffer[1440];
+} orc_dmo_state;
+void     orc_dmo_init(orc_dmo_state* s);
+size_t   orc_dmo_process(orc_dmo_state* s, const uint32_t* golay_table, const float* in, size_t n, uint8_t* out, size_t cap_frames);
+uint32_t orc_golay1987_syndrome(uint32_t pattern);
+void     orc_golay1987_table(uint32_t* table /* 2048 entries */);
 
 /* batch drivers (OpenMP over streams) used by the cpu_baseline leg of bench.py */
 enum { ORC_MODE_2FSK_1K = 0, ORC_MODE_GMSK_10K = 1, ORC_MODE_QPSK_250K = 2 };

@@ -946,6 +946,27 @@ void orc_4fsk_symbols_to_bits(const float* sym, size_t nsym, cf32* constellation
         bits[2 * i] = (uint8_t)((m >> 1) & 1); bits[2 * i + 1] = (uint8_t)(m & 1);
     }
 }
+/* port 3 of gr_demod_dmr (gr_demod_dmr.cpp:94): the RRC-filtered discriminator output at 24 ksps, what gr_dmr_dmo_sink is fed;
+ * same arithmetic as the first half of orc_demod_dmr below.  out may be NULL to size. */
+size_t orc_demod_dmr_port3(const cf32* in, size_t n, int samp_rate, float* out)
+{
+    size_t n1 = orc_decim_count(n, 3, 125);
+    if (!out) return n1;
+    int nt = orc_low_pass_2(3, (double)samp_rate * 3, 5000, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* taps = NEW(float, nt);
+    orc_low_pass_2(3, (double)samp_rate * 3, 5000, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, taps);
+    cf32* r = NEW(cf32, n1);
+    orc_resamp_ccf(in, n, taps, nt, 3, 125, r);
+    free(taps);
+    float* d = NEW(float, n1);
+    orc_quad_demod(r, n1, (float)(24000 / (M_PI / 2 * 4800.0f)), d);
+    int nr = orc_root_raised_cosine(1, 24000, 4800, 0.2, 125, NULL);
+    float* rrc = NEW(float, nr);
+    orc_root_raised_cosine(1, 24000, 4800, 0.2, 125, rrc);
+    orc_fir_fff(d, n1, rrc, nr, out);
+    free(rrc); free(d); free(r);
+    return n1;
+}
 void orc_demod_dmr(const cf32* in, size_t n, int sps, int samp_rate, orc_demod_out* o)
 {
     (void)sps;

@@ -84,6 +84,7 @@ def load_library():
     lib.qrl_demod_reset.argtypes = [vp]
     lib.qrl_demod_set_carrier_offset.argtypes = [vp, C.c_double]
     lib.qrl_demod_set_option.argtypes = [vp, C.c_int, C.c_int]
+    lib.qrl_demod_set_dmo_output.argtypes = [vp, vp, sz, vp]
     lib.qrl_demod_out_caps.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     lib.qrl_demod_process.argtypes = [vp, vp, sz, sz, C.POINTER(_Out)]
     lib.qrl_demod_sync.argtypes = [vp]
@@ -147,7 +148,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "qrl_init", "qrl_shutdown", "qrl_strerror", "qrl_last_error", "qrl_version", "qrl_demod_create",
-    "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_set_option", "qrl_demod_out_caps",
+    "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_set_option", "qrl_demod_set_dmo_output", "qrl_demod_out_caps",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
     "qrl_mod_samples_per_byte", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_create",
@@ -291,6 +292,21 @@ class Demod:
 
     def reset(self):
         _check(self.lib.qrl_demod_reset(self.h), "qrl_demod_reset")
+
+    def enable_dmo_sink(self, cap_frames=64):
+        """QRL_MODEM_DMR: gr_dmr_dmo_sink on the device; after every process() self.dmo_frames uint8 [batch, cap, 40] /
+        self.dmo_counts int32 [batch] hold the DMR bursts cut from the call's samples (qrl_demod_set_dmo_output)"""
+        t = self.torch
+        dev = self.bits_a.device
+        self.dmo_frames = t.zeros((self.batch, cap_frames, 40), dtype=t.uint8, device=dev)
+        self.dmo_counts = t.zeros((self.batch,), dtype=t.int32, device=dev)
+        _check(self.lib.qrl_demod_set_dmo_output(self.h, self.dmo_frames.data_ptr(), cap_frames, self.dmo_counts.data_ptr()),
+               "qrl_demod_set_dmo_output")
+
+    def dmo_records(self):
+        """host copy of the last call's records: per stream a list of (type, fn, colour code, 33 bytes)"""
+        f, c = self.dmo_frames.cpu().numpy(), self.dmo_counts.cpu().numpy()
+        return [[(int(f[b, i, 0]), int(f[b, i, 1]), int(f[b, i, 2]), f[b, i, 4:37].tobytes()) for i in range(c[b])] for b in range(self.batch)]
 
     def set_option(self, option, value):
         _check(self.lib.qrl_demod_set_option(self.h, int(option), int(value)), "qrl_demod_set_option")

@@ -182,6 +182,8 @@ struct qrl_demod {
     DevBuf<float2> s1, s2, s2l, s2f; DevBuf<float> s2d, s3; DevBuf<uint8_t> soft;
     uint32_t s1_mask = 0, s2_mask = 0, soft_mask = 0;
     DevBuf<FllState> fll_st; DevBuf<SymSyncState> ss_st; DevBuf<FecState> fec_st;
+    // a37b: gr_dmr_dmo_sink behind port 3 of gr_demod_dmr (qrl_demod_set_dmo_output)
+    DevBuf<DmoState> dmo_st; DevBuf<uint32_t> dmo_golay; uint8_t* dmo_out = nullptr; uint32_t dmo_cap = 0; uint32_t* dmo_counts = nullptr;
     // QPSK (gr_demod_qpsk.cpp:97-126)
     DevBuf<QpskState> qp_st; DevBuf<float> tanh_tab;
     float c1_alpha = 0, c1_beta = 0, c2_alpha = 0, c2_beta = 0; float2 qp_rot{};
@@ -222,6 +224,11 @@ int qrl_demod::init_state()
         for (auto& q : qs) { std::memset(&q, 0, sizeof q); q.gain = 1.0f; q.avg = q.inst = (float)sps_eff;
                              if (fam == F_BPSK) q.mu = 0.5f; }   // clock_recovery_mm_cc(mu = 0.5), gr_demod_bpsk.cpp:58-60
         if (hipMemcpy(qp_st.p, qs.data(), qs.size() * sizeof(QpskState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
+    }
+    if (dmo_st.p) {
+        std::vector<DmoState> ds(cfg.batch);
+        for (auto& x : ds) { std::memset(&x, 0, sizeof x); x.endPtr = 9999; }
+        if (hipMemcpy(dmo_st.p, ds.data(), ds.size() * sizeof(DmoState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
     }
     std::vector<SymSyncState> ss(cfg.batch);
     for (auto& s : ss) { std::memset(&s, 0, sizeof s); s.avg = s.inst = (float)sps_eff; }
@@ -322,7 +329,7 @@ int qrl_demod::build()
     // stretches from 7.1 to 9.0 ms -- the recursion kernels are only placed once the front end's workgroups drain.
     overlap_capable = fam == F_2FSK;
     overlap = false;
-    s2_mask = pow2_at_least((overlap_capable ? 2 : 1) * max2 + 1024) - 1;   // history needs: <= 501 taps downstream; overlapped mode: two calls
+    s2_mask = pow2_at_least((overlap_capable ? 2 : 1) * max2 + (fam == F_DMR ? 2048 : 1024)) - 1;   // DMR: the DMO slicer looks back 1440 samples   // history needs: <= 501 taps downstream; overlapped mode: two calls
     const size_t ring2 = (size_t)B * (s2_mask + 1);
     if ((r = s2.alloc(ring2)) || (r = s2f.alloc(ring2)) || (r = s2d.alloc(ring2)) || (r = s3.alloc(ring2))) return r;
     if ((fam == F_2FSK || fam == F_BPSK || (fam == F_QPSK && qpsk_fll)) && (r = s2l.alloc(ring2))) return r;
@@ -633,6 +640,11 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         s.port_cap = side ? out->constellation_cap : 0;
         s.counts = counts;
         launch_symsync_ff(s, B, tail);
+        if (fam == F_DMR && dmo_out) {   // gr_dmr_dmo_sink on port 3 (= ring r3) of this call
+            DmoParams dp{}; dp.in = r3; dp.q0 = n2_0; dp.count = (uint32_t)(n2_1 - n2_0); dp.st = dmo_st.p; dp.golay = dmo_golay.p;
+            dp.out = dmo_out; dp.cap = dmo_cap; dp.counts = dmo_counts;
+            launch_dmo_sink(dp, B, tail);
+        }
         if (fam == F_DMR) { HIPCHK(hipEventRecord(ev_tail, tail)); tail_pending = true; }
         FecParams f{};
         f.soft = RingB{soft.p, soft_mask}; f.avail = &ss_st.p[0].oo; f.avail_stride = sizeof(SymSyncState); f.avail_mul = fam == F_4FSK ? 2 : 1; f.st = fec_st.p;
@@ -776,6 +788,24 @@ int qrl_demod_set_carrier_offset(qrl_demod* d, double hz)
     d->cfg.carrier_offset_hz = hz;
     d->rot_inc = phase_inc_to_turn(2 * M_PI * -hz / d->cfg.device_samp_rate);
     return d->upload_rot_table();
+}
+int qrl_demod_set_dmo_output(qrl_demod* d, uint8_t* frames, size_t cap_frames, uint32_t* counts)
+{
+    if (!d) return QRL_ERR_ARG;
+    if (d->fam != qrl_demod::F_DMR) return qrl_set_error(QRL_ERR_ARG, "the DMO slicer sits behind port 3 of gr_demod_dmr: QRL_MODEM_DMR only");
+    HIPCHK(hipStreamSynchronize(d->stream));
+    HIPCHK(hipStreamSynchronize(d->tail));
+    if (!frames) { d->dmo_out = nullptr; return QRL_OK; }
+    if (!counts || cap_frames < 1 || cap_frames > 0xFFFFFFFFu) return QRL_ERR_ARG;
+    int r;
+    if (!d->dmo_st.p) {
+        if ((r = d->dmo_st.alloc(d->cfg.batch)) || (r = d->dmo_golay.upload(golay1987_table()))) return r;
+        std::vector<DmoState> ds(d->cfg.batch);
+        for (auto& x : ds) { std::memset(&x, 0, sizeof x); x.endPtr = 9999; }
+        if (hipMemcpy(d->dmo_st.p, ds.data(), ds.size() * sizeof(DmoState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
+    }
+    d->dmo_out = frames; d->dmo_cap = (uint32_t)cap_frames; d->dmo_counts = counts;
+    return QRL_OK;
 }
 int qrl_demod_set_option(qrl_demod* d, int option, int value)
 {

@@ -154,6 +154,17 @@ struct FecParams {
 };
 void launch_fec(const FecParams& p, int batch, hipStream_t s);
 
+// ---- gr_dmr_dmo_sink on the device (kernels_dmo.hip): correlator slicer behind port 3 of gr_demod_dmr ----
+struct DmoState {
+    uint32_t bitBuffer[5];
+    uint16_t syncPtr, startPtr, endPtr, pad0;
+    float maxCorr, centre[4], threshold[4];
+    uint8_t averagePtr, syncCount, state, control, n, colorCode, pad1[2];
+};
+struct DmoParams { RingF in; uint64_t q0; uint32_t count; DmoState* st; const uint32_t* golay; uint8_t* out; uint32_t cap; uint32_t* counts; };
+void launch_dmo_sink(const DmoParams& p, int batch, hipStream_t s);
+std::vector<uint32_t> golay1987_table();
+
 // ---- gr_deframer_bb on the device (kernels_deframe.hip) ----
 struct DeframeState { uint32_t reg, found, idx, pad; };
 struct DeframeParams {

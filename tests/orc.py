@@ -482,6 +482,46 @@ def symbol_sync_cc(x, ted, sps, loop_bw, damping, ted_gain, max_dev, constellati
     return y[:n].copy()
 
 
+_sig("orc_dmo_init", None, _p)
+_sig("orc_dmo_process", _sz, _p, _p, _p, _sz, _p, _sz)
+_sig("orc_golay1987_table", None, _p)
+_sig("orc_golay1987_syndrome", C.c_uint32, C.c_uint32)
+DMO_STATE_BYTES = 4 * 5 + 2 * 5 + 2 + 4 * 9 + 8 + 4 * 1440   # sizeof(orc_dmo_state) with natural alignment (checked below)
+
+
+def golay1987_table():
+    t = np.zeros(2048, np.uint32)
+    lib.orc_golay1987_table(_ptr(t))
+    return t
+
+
+_sig("orc_demod_dmr_port3", _sz, _p, _sz, C.c_int, _p)
+
+
+def demod_dmr_port3(x, samp_rate=1000000):
+    x = np.ascontiguousarray(x, cf32)
+    n = lib.orc_demod_dmr_port3(_ptr(x), x.size, samp_rate, None)
+    y = np.empty(n, np.float32)
+    lib.orc_demod_dmr_port3(_ptr(x), x.size, samp_rate, _ptr(y))
+    return y
+
+
+class DmoSink:
+    """gr_dmr_dmo_sink restated (oracle/orc_dmr.c): process(float samples at 24 ksps) -> list of (type, fn, colour code, 33 bytes)"""
+
+    def __init__(self):
+        self.state = np.zeros(DMO_STATE_BYTES + 64, np.uint8)
+        lib.orc_dmo_init(_ptr(self.state))
+        self.table = golay1987_table()
+
+    def process(self, x, cap=64):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros(40 * cap, np.uint8)
+        n = lib.orc_dmo_process(_ptr(self.state), _ptr(self.table), _ptr(x), x.size, _ptr(out), cap)
+        assert n <= cap
+        return [(int(out[40 * i]), int(out[40 * i + 1]), int(out[40 * i + 2]), out[40 * i + 4:40 * i + 37].tobytes()) for i in range(n)]
+
+
 def cc_decode_k7(soft):
     soft = np.ascontiguousarray(soft, np.uint8)
     out = np.zeros(soft.size // 2 + 80, np.uint8)

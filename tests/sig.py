@@ -84,12 +84,16 @@ def find_frames(bits, sync, nbits):
     return out
 
 
-def make_4fsk(nsym=400, seed=1, amp=0.3, noise=0.002, cfo=0.0, fs=1000000.0):
+def make_4fsk(nsym=400, seed=1, amp=0.3, noise=0.002, cfo=0.0, fs=1000000.0, levels=None):
     """DMR-like 4FSK at 4800 sym/s on 1 Msps IQ (RRC alpha 0.2, deviation +-1944 / +-648 Hz; dibit map of the DMR air
-    interface: 01 -> +3, 00 -> +1, 10 -> -1, 11 -> -3).  Returns (iq complex64, dibits)."""
+    interface: 01 -> +3, 00 -> +1, 10 -> -1, 11 -> -3).  Returns (iq complex64, dibits).  levels: explicit symbol levels in
+    units of the outer deviation (+-1, +-1/3, 0 = unmodulated carrier) instead of random dibits."""
     rng = np.random.default_rng(seed)
     dib = rng.integers(0, 4, nsym)
     lev = np.array([+1, +3, -1, -3])[dib] / 3.0
+    if levels is not None:
+        lev = np.asarray(levels, float)
+        nsym, dib = lev.size, None
     sps = fs / 4800.0
     n = int(nsym * sps) & ~1
     up = np.zeros(n)
@@ -105,3 +109,59 @@ def make_4fsk(nsym=400, seed=1, amp=0.3, noise=0.002, cfo=0.0, fs=1000000.0):
     ph = 2 * np.pi * np.cumsum(f * 1944.0 + cfo) / fs
     x = amp * np.exp(1j * ph) + noise * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
     return x.astype(np.complex64), dib
+
+
+# ---------------------------------------------------------------- DMR bursts for the DMO correlator slicer (a37b)
+DMR_MS_DATA_SYNC, DMR_MS_VOICE_SYNC = 0xD5D7F77FD757, 0x7F7D5DD57DFD   # reference src/DMR/constants.h:8-9
+
+
+def golay2087_encode(v):
+    """(20,8) slot-type code word of byte v as 20 bits: the (19,8) cyclic code word (generator 0xC75) + overall parity"""
+    pattern = v << 11
+    aux = 0x40000
+    p = pattern
+    while p & 0xFFFFF800:
+        while not (aux & p):
+            aux >>= 1
+        p ^= (aux // 0x800) * 0xC75
+    cw19 = pattern | p
+    return (cw19 << 1) | (bin(cw19).count("1") & 1)
+
+
+def dmr_frame(info_bits, sync=None, colour_code=1, data_type=None):
+    """264-bit DMR burst as 33 bytes: info[0:98] | slot type[0:10] | sync (48) | slot type[10:20] | info[98:196]; without
+    sync / slot type (voice frames B-F) the middle 68 bits come from `info_bits` as well (it must then hold 264 bits)."""
+    info_bits = np.asarray(info_bits, np.uint8)
+    if sync is None:
+        bits = info_bits[:264].copy()
+    else:
+        st = [(golay2087_encode(((colour_code & 15) << 4) | (data_type & 15)) >> (19 - i)) & 1 for i in range(20)] if data_type is not None \
+            else list(info_bits[196:216])
+        sy = [(sync >> (47 - i)) & 1 for i in range(48)]
+        bits = np.concatenate([info_bits[:98], st[:10], sy, st[10:], info_bits[98:196]]).astype(np.uint8)
+    return np.packbits(bits).tobytes()
+
+
+def dmr_samples(frames, gap=780, scale=0.3, sps=5, lead=300):
+    """discriminator-like float stream at 24 ksps: dibit 01 -> +3, 00 -> +1, 10 -> -1, 11 -> -3 (x scale / 3), `sps` samples per
+    symbol, `gap` silent samples between bursts (DMO: one 27.5 ms burst every 60 ms = 1440 samples)"""
+    lv = {(0, 1): 3.0, (0, 0): 1.0, (1, 0): -1.0, (1, 1): -3.0}
+    out = [np.zeros(lead, np.float32)]
+    for f in frames:
+        bits = np.unpackbits(np.frombuffer(f, np.uint8))
+        sym = np.array([lv[(int(bits[2 * i]), int(bits[2 * i + 1]))] for i in range(132)], np.float32) * (scale / 3.0)
+        out.append(np.repeat(sym, sps))
+        out.append(np.zeros(gap, np.float32))
+    return np.concatenate(out)
+
+
+def dmr_levels(frames, gap_symbols=156, lead_symbols=60):
+    """symbol levels (units of the outer deviation) of DMO bursts separated by unmodulated carrier: 132 symbols per burst, one
+    burst per 288 symbols = 60 ms"""
+    lv = {(0, 1): 1.0, (0, 0): 1.0 / 3, (1, 0): -1.0 / 3, (1, 1): -1.0}
+    out = [np.zeros(lead_symbols)]
+    for f in frames:
+        bits = np.unpackbits(np.frombuffer(f, np.uint8))
+        out.append(np.array([lv[(int(bits[2 * i]), int(bits[2 * i + 1]))] for i in range(132)]))
+        out.append(np.zeros(gap_symbols))
+    return np.concatenate(out)
