@@ -244,6 +244,13 @@ typedef struct {
 int qrl_synth_create(qrl_ctx* ctx, const qrl_synth_config* cfg, qrl_synth** out);
 void qrl_synth_destroy(qrl_synth* s);
 int qrl_synth_reset(qrl_synth* s);
+/* gr_zero_idle_bursts (reference src/gr/gr_zero_idle_bursts.cpp:45-84; gr_mod_mmdvm_multi2.cpp:88,108, gr_mod_mmdvm.cpp:51-58):
+ * the zero_samples tags gr_mmdvm_source attaches to idle slots, as absolute runs at the rate of that block's input (25 ksps behind
+ * the 25/24 resampler in the multi-carrier graph, 24 ksps behind the FM modulator in the single-carrier one; item index counted from
+ * the handle's creation / last reset).  Items start .. start + count - 1 of (stream, channel) become 0 + 0j in whichever following
+ * qrl_synth_process calls they fall into.  host/mmdvm_wire.h zero_idle_runs() turns the source's tags into these runs. */
+typedef struct { int stream; int channel; uint64_t start; uint64_t count; } qrl_zero_run;
+int qrl_synth_add_zero_runs(qrl_synth* h, const qrl_zero_run* runs, size_t n);
 int qrl_synth_set_bb_gain(qrl_synth* s, float value);
 size_t qrl_synth_out_cap(const qrl_synth* s, size_t n);
 int qrl_synth_process(qrl_synth* s, const int16_t* in, size_t stride, size_t n, float* iq, size_t out_stride, size_t* produced);

@@ -847,6 +847,18 @@ size_t orc_demod_mmdvm_xlating(const cf32* in, size_t n, int N, int separation, 
  * UNNORMALISED inverse DFT V_i[n] = sum_p x_p[n] e^{+j 2 pi i p / M} (four real fmaf chains, p ascending, like the
  * channelizer's DFT), then branch i is filtered with the polyphase taps h[i + M j] over ITS OWN history V_i[n - j] and the M
  * branch outputs leave in order: out[n M + i].  in: int16 [N][n]; out: 10 * n25 samples, n25 = count of the 25/24 resampler. */
+/* gr_zero_idle_bursts (src/gr/gr_zero_idle_bursts.cpp:45-84, delay 0) as absolute runs: zero_runs = {channel, start, count}
+ * triples at the rate of the block's input (25 ksps behind the resampler here, gr_mod_mmdvm_multi2.cpp:108; 24 ksps behind the FM
+ * modulator in gr_mod_mmdvm.cpp:57-58): items start .. start + count - 1 of that channel are replaced by 0 + 0j. */
+static void apply_zero_runs(cf32* x, size_t n, int chan, const uint64_t* runs, size_t nruns)
+{
+    for (size_t r = 0; r < nruns; r++) {
+        if ((int)runs[3 * r] != chan) continue;
+        for (uint64_t i = runs[3 * r + 1]; i < runs[3 * r + 1] + runs[3 * r + 2] && i < n; i++) { x[i].re = 0.0f; x[i].im = 0.0f; }
+    }
+}
+static const uint64_t* g_zero_runs = NULL; static size_t g_zero_nruns = 0;
+void orc_set_zero_runs(const uint64_t* runs, size_t nruns) { g_zero_runs = runs; g_zero_nruns = nruns; }   /* for the next orc_mod_mmdvm* call */
 size_t orc_mod_mmdvm_multi(const int16_t* in, size_t n, int N, int filter_width, cf32* out)
 {
     const int M = 10;
@@ -871,6 +883,7 @@ size_t orc_mod_mmdvm_multi(const int16_t* in, size_t n, int N, int filter_width,
         for (size_t i = 0; i < n; i++) { b[i].re *= 0.8f; b[i].im *= 0.8f; }
         const int p = c <= 3 ? c : 10 - m++;
         orc_resamp_ccf(b, n, rt, nr, 25, 24, port + (size_t)p * n25);
+        apply_zero_runs(port + (size_t)p * n25, n25, c, g_zero_runs, g_zero_nruns);
     }
     free(f); free(a); free(b); free(ft); free(rt);
     cf32 W[10];
@@ -919,6 +932,7 @@ size_t orc_mod_mmdvm(const int16_t* in, size_t n, int filter_width, float bb_gai
     float* f = NEW(float, n + 1); cf32* a = NEW(cf32, n + 1); cf32* b = NEW(cf32, n + 1);
     for (size_t i = 0; i < n; i++) f[i] = ((float)in[i] / 32767.0f) * 1.0f;
     fm_mod(f, n, (float)(2 * M_PI * 12500.0f / 24000.0f), a);
+    apply_zero_runs(a, n, 0, g_zero_runs, g_zero_nruns);
     orc_fir_ccf(a, n, ft, nf, b);
     for (size_t i = 0; i < n; i++) { b[i].re *= 0.8f; b[i].im *= 0.8f; b[i].re *= bb_gain; b[i].im *= bb_gain; }
     size_t m = orc_resamp_ccf(b, n, rt, nr, 125, 12, out);

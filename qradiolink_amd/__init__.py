@@ -54,6 +54,10 @@ class _SynthConfig(C.Structure):
                 ("hip_stream", C.c_void_p), ("bb_gain", C.c_float), ("single_carrier", C.c_int)]
 
 
+class _ZeroRun(C.Structure):
+    _fields_ = [("stream", C.c_int), ("channel", C.c_int), ("start", C.c_uint64), ("count", C.c_uint64)]
+
+
 class _Out(C.Structure):
     _fields_ = [("filtered", C.c_void_p), ("filtered_cap", C.c_size_t), ("constellation", C.c_void_p),
                 ("constellation_cap", C.c_size_t), ("bits_a", C.c_void_p), ("bits_cap", C.c_size_t),
@@ -119,6 +123,7 @@ def load_library():
     lib.qrl_synth_destroy.argtypes = [vp]
     lib.qrl_synth_reset.argtypes = [vp]
     lib.qrl_synth_set_bb_gain.argtypes = [vp, C.c_float]
+    lib.qrl_synth_add_zero_runs.argtypes = [vp, vp, sz]
     lib.qrl_synth_out_cap.restype = sz
     lib.qrl_synth_out_cap.argtypes = [vp, sz]
     lib.qrl_synth_process.argtypes = [vp, vp, sz, sz, vp, sz, C.POINTER(sz)]
@@ -153,7 +158,7 @@ EXPORTED_SYMBOLS = [
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
     "qrl_mod_samples_per_byte", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_create",
     "qrl_chan_destroy", "qrl_chan_reset", "qrl_chan_set_level", "qrl_chan_calibrate_rssi", "qrl_chan_set_rssi_output", "qrl_chan_set_4fsk_output", "qrl_chan_out_cap", "qrl_chan_process", "qrl_chan_sync",
-    "qrl_synth_create", "qrl_synth_destroy", "qrl_synth_reset", "qrl_synth_set_bb_gain", "qrl_synth_out_cap", "qrl_synth_process",
+    "qrl_synth_create", "qrl_synth_destroy", "qrl_synth_reset", "qrl_synth_set_bb_gain", "qrl_synth_add_zero_runs", "qrl_synth_out_cap", "qrl_synth_process",
     "qrl_synth_sync",
     "qrl_deframer_create", "qrl_deframer_destroy", "qrl_deframer_reset", "qrl_deframer_process", "qrl_deframer_sync",
     "qrl_framesync_create", "qrl_framesync_destroy", "qrl_framesync_reset", "qrl_framesync_frame_bytes", "qrl_framesync_process",
@@ -448,6 +453,11 @@ class Synth:
         _check(self.lib.qrl_synth_process(self.h, x.data_ptr(), n, n, out.data_ptr(), cap, C.byref(produced)), "qrl_synth_process")
         _check(self.lib.qrl_synth_sync(self.h), "qrl_synth_sync")
         return out[:, :produced.value]
+
+    def add_zero_runs(self, runs):
+        """gr_zero_idle_bursts: runs = [(stream, channel, start, count), ...] at the rate of that block's input (qrl_synth_add_zero_runs)"""
+        arr = (_ZeroRun * len(runs))(*[_ZeroRun(*r) for r in runs])
+        _check(self.lib.qrl_synth_add_zero_runs(self.h, arr, len(runs)), "qrl_synth_add_zero_runs")
 
     def close(self):
         if self.h:

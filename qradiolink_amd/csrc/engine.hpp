@@ -209,6 +209,8 @@ struct SynthParams {
 };
 void launch_s2f_in(const S2fInParams& p, int streams, hipStream_t s);
 void launch_scale_c(RingC r, uint64_t q0, uint32_t count, float k, int streams, hipStream_t s);
+struct ZeroRun { uint32_t row; uint32_t pad; uint64_t start, count; };   // ring row, absolute item range [start, start + count)
+void launch_zero_runs(RingC r, const ZeroRun* runs, uint32_t nruns, uint64_t lo, uint64_t hi, hipStream_t s);   // gr_zero_idle_bursts
 void launch_pfb_synth(const SynthParams& p, int batch, hipStream_t s);
 size_t synth_lds_bytes(int M, int J);
 

@@ -224,6 +224,21 @@ void launch_scale_c(RingC r, uint64_t q0, uint32_t count, float k, int streams, 
     hipLaunchKernelGGL(k_scale_c, dim3((count + 255) / 256, streams), dim3(256), 0, s, r, q0, count, k);
 }
 
+// gr_zero_idle_bursts::work (reference src/gr/gr_zero_idle_bursts.cpp:45-84, delay 0): the items of a zero_samples run that fall
+// into this call's range [lo, hi) of the ring are replaced by 0 + 0j.  One workgroup per run.
+__global__ __launch_bounds__(256) void k_zero_runs(RingC r, const ZeroRun* runs, uint64_t lo, uint64_t hi)
+{
+    const ZeroRun z = runs[blockIdx.x];
+    const uint64_t a = z.start > lo ? z.start : lo, b = z.start + z.count < hi ? z.start + z.count : hi;
+    float2* row = r.p + (size_t)z.row * (r.mask + 1u);
+    for (uint64_t i = a + threadIdx.x; i < b; i += 256) row[(uint32_t)i & r.mask] = make_float2(0.f, 0.f);
+}
+void launch_zero_runs(RingC r, const ZeroRun* runs, uint32_t nruns, uint64_t lo, uint64_t hi, hipStream_t s)
+{
+    if (!nruns || hi <= lo) return;
+    hipLaunchKernelGGL(k_zero_runs, dim3(nruns), dim3(256), 0, s, r, runs, lo, hi);
+}
+
 constexpr int SY_TB = 96;   // output blocks per workgroup
 __global__ __launch_bounds__(256) void k_pfb_synth(const SynthParams P)
 {

@@ -44,6 +44,7 @@ struct qrl_synth {
     Buf<float> filt_taps, rs_taps, syn_taps, rA, phase; Buf<float2> twiddle, rB, rC, rD;
     uint32_t m1 = 0, m25 = 0; uint64_t n1 = 0, n25 = 0;
     int port_chan[16];
+    std::vector<ZeroRun> zero_runs; Buf<ZeroRun> zero_dev; size_t zero_dev_cap = 0;   // gr_zero_idle_bursts (qrl_synth_add_zero_runs)
     ~qrl_synth() { if (own_stream && stream) (void)hipStreamDestroy(stream); }
     int reset_state() {
         const size_t S = (size_t)cfg.batch * N;
@@ -52,6 +53,27 @@ struct qrl_synth {
             hipMemset(phase.p, 0, S * sizeof(float)) != hipSuccess)
             return QRL_ERR_HIP;
         n1 = n25 = 0;
+        zero_runs.clear();
+        return QRL_OK;
+    }
+    // the runs that touch [lo, hi) go to the device and are applied to ring r; runs that end before hi are dropped afterwards
+    int apply_zero_runs(RingC r, uint64_t lo, uint64_t hi) {
+        std::vector<ZeroRun> live;
+        for (const ZeroRun& z : zero_runs) if (z.start < hi && z.start + z.count > lo) live.push_back(z);
+        if (!live.empty()) {
+            if (live.size() > zero_dev_cap) {
+                zero_dev_cap = live.size() + 16;
+                if (zero_dev.p) { (void)hipFree(zero_dev.p); zero_dev.p = nullptr; }
+                int rr = zero_dev.alloc(zero_dev_cap);
+                if (rr) return rr;
+            }
+            if (hipMemcpyAsync(zero_dev.p, live.data(), live.size() * sizeof(ZeroRun), hipMemcpyHostToDevice, stream) != hipSuccess) return QRL_ERR_HIP;
+            if (hipStreamSynchronize(stream) != hipSuccess) return QRL_ERR_HIP;   // `live` is a stack vector: the copy must be through
+            launch_zero_runs(r, zero_dev.p, (uint32_t)live.size(), lo, hi, stream);
+        }
+        std::vector<ZeroRun> keep;
+        for (const ZeroRun& z : zero_runs) if (z.start + z.count > hi) keep.push_back(z);
+        zero_runs.swap(keep);
         return QRL_OK;
     }
 };
@@ -111,6 +133,16 @@ int qrl_synth_reset(qrl_synth* h)
     HIPCHK(hipStreamSynchronize(h->stream));
     return h->reset_state();
 }
+int qrl_synth_add_zero_runs(qrl_synth* h, const qrl_zero_run* runs, size_t n)
+{
+    if (!h || (!runs && n)) return QRL_ERR_ARG;
+    for (size_t i = 0; i < n; ++i) {
+        if (runs[i].stream < 0 || runs[i].stream >= h->cfg.batch || runs[i].channel < 0 || runs[i].channel >= h->N)
+            return qrl_set_error(QRL_ERR_ARG, "zero run: stream / channel out of range");
+        h->zero_runs.push_back(ZeroRun{(uint32_t)(runs[i].stream * h->N + runs[i].channel), 0u, runs[i].start, runs[i].count});
+    }
+    return QRL_OK;
+}
 int qrl_synth_set_bb_gain(qrl_synth* h, float g) { if (!h) return QRL_ERR_ARG; h->bb_gain = g; return QRL_OK; }
 size_t qrl_synth_out_cap(const qrl_synth* h, size_t n) { return h ? (n * h->rs_I / h->rs_D + 2) * (h->single ? 1 : 10) : 0; }
 
@@ -131,6 +163,10 @@ int qrl_synth_process(qrl_synth* h, const int16_t* in, size_t stride, size_t n, 
     TxFmParams fp{}; fp.in = sp.out; fp.out = RingC{h->rB.p, h->m1}; fp.n0 = h->n1; fp.count = c1;
     fp.k = (float)(2 * M_PI * 12500.0f / 24000.0f); fp.amp = 1.0f; fp.phase = h->phase.p;            // _fm_modulator, :64-66
     launch_tx_fm(fp, S, h->stream);
+    if (h->single && !h->zero_runs.empty()) {   // gr_mod_mmdvm.cpp:57-58: zero_idle_bursts between the FM modulator and the filter (24 ksps)
+        const int zr = h->apply_zero_runs(fp.out, h->n1, n1_1);
+        if (zr) return zr;
+    }
     FirCcfParams ff{}; ff.in = fp.out; ff.out = RingC{h->rC.p, h->m1}; ff.q0 = h->n1; ff.count = c1; ff.taps = h->filt_taps.p; ff.nt = h->filt_nt;
     launch_fir_ccf(ff, S, h->stream);
     launch_scale_c(ff.out, h->n1, c1, 0.8f, S, h->stream);                                           // _amplify, :77-79
@@ -145,6 +181,10 @@ int qrl_synth_process(qrl_synth* h, const int16_t* in, size_t stride, size_t n, 
         h->n1 = n1_1; h->n25 = n25_1;
         if (produced) *produced = (size_t)c25;
         return QRL_OK;
+    }
+    if (!h->zero_runs.empty()) {   // gr_mod_mmdvm_multi2.cpp:108: zero_idle_bursts behind the 25/24 resampler (25 ksps)
+        const int zr = h->apply_zero_runs(rp.out, h->n25, n25_1);
+        if (zr) return zr;
     }
     SynthParams yp{}; yp.in = rp.out; yp.nch = N; for (int p = 0; p < 16; ++p) yp.port_chan[p] = h->port_chan[p];
     yp.blk0 = h->n25; yp.nblk = c25; yp.taps = h->syn_taps.p; yp.twiddle = h->twiddle.p; yp.M = 10; yp.J = h->J;

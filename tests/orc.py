@@ -412,6 +412,19 @@ def demod_mmdvm_xlating(x, N, separation=25000, D=10, fw=8000, cal=0.0):
     return out[:, :n].copy(), rssi[:, :n // 300].copy()
 
 
+_sig("orc_set_zero_runs", None, _p, _sz)
+
+
+def set_zero_runs(runs):
+    """gr_zero_idle_bursts runs [(channel, start, count), ...] for the NEXT mod_mmdvm / mod_mmdvm_multi call (None = off)"""
+    global _zr
+    if not runs:
+        lib.orc_set_zero_runs(None, 0)
+        return
+    _zr = np.ascontiguousarray(np.array(runs, np.uint64).reshape(-1, 3))
+    lib.orc_set_zero_runs(_ptr(_zr), _zr.shape[0])
+
+
 def mod_mmdvm(x, filter_width=5000, bb_gain=1.0):
     x = np.ascontiguousarray(x, np.int16)
     m = lib.orc_mod_mmdvm(_ptr(x), x.size, filter_width, bb_gain, None)

@@ -308,3 +308,37 @@ def test_mmdvm_tx_single_carrier_bit_exact(qrl_ctx, cuts):
         g, w = got[b].view(np.float32) + np.float32(0), ref.view(np.float32) + np.float32(0)
         assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
     assert np.abs(ref).max() > 0.3
+
+
+@pytest.mark.parametrize("single", [False, True])
+def test_mmdvm_tx_zero_idle_bursts_bit_exact(qrl_ctx, single):
+    """gr_zero_idle_bursts (a50): zero_samples runs applied on the device (behind the 25/24 resampler of the multi-carrier graph,
+    behind the FM modulator of the single-carrier one) equal the oracle's, over ragged calls and runs that cross call boundaries;
+    an idle slot (750 items from a slot boundary) really mutes that channel's carrier."""
+    import torch
+    import qradiolink_amd as q
+    N = 1 if single else 3
+    cuts = [720, 1000, 7, 5000, 4273]
+    n = sum(cuts)
+    x = np.stack([_audio(N, n, seed=70 + b) for b in range(2)])
+    runs = [(0, 0, 750, 750), (0, N - 1, 2990, 750), (1, 0, 0, 750), (1, 0, 700, 750), (0, 0, 6000, 100)]   # (stream, channel, start, count)
+    syn = q.Synth(qrl_ctx, N, batch=2, max_samples=max(cuts), bb_gain=1.0, single_carrier=single)
+    syn.add_zero_runs(runs[:3])
+    d = torch.from_numpy(x).cuda()
+    parts, pos = [], 0
+    for i, c in enumerate(cuts):
+        if i == 1:
+            syn.add_zero_runs(runs[3:])
+        parts.append(syn.process(d[:, :, pos:pos + c]).cpu().numpy())
+        pos += c
+    syn.close()
+    got = np.concatenate(parts, axis=1)
+    for b in range(2):
+        orc.set_zero_runs([(ch, st, cnt) for s, ch, st, cnt in runs if s == b])
+        ref = orc.mod_mmdvm(x[b, 0], bb_gain=1.0) if single else orc.mod_mmdvm_multi(x[b])
+        orc.set_zero_runs(None)
+        assert got[b].size == ref.size
+        g, w = got[b].view(np.float32) + np.float32(0), ref.view(np.float32) + np.float32(0)
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), "stream %d differs" % b
+    plain = orc.mod_mmdvm(x[1, 0], bb_gain=1.0) if single else orc.mod_mmdvm_multi(x[1])
+    assert not np.array_equal(plain, ref)            # the runs did something
