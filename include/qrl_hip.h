@@ -121,6 +121,10 @@ int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* filtered_cap, size_
 int qrl_demod_process(qrl_demod* d, const float* iq, size_t stride, size_t n, const qrl_demod_out* out);
 int qrl_demod_sync(qrl_demod* d);
 void* qrl_demod_stream(qrl_demod* d); /* hipStream_t */
+/* makes the caller's stream wait (on the device, without blocking the host) for everything this handle has enqueued so far on its
+ * internal streams: how a host layer chains its own asynchronous copies of the output ports behind a qrl_demod_process call
+ * (host/gr_modem_hip.cpp: double-buffered mailboxes) instead of calling qrl_demod_sync. */
+int qrl_demod_stream_wait(qrl_demod* d, void* hip_stream);
 
 /* Per-kernel timing of the dominant (HBM-facing) kernel with HIP events recorded on the handle's own
  * stream (bench.py roofline leg).  enable!=0 starts recording one event pair per process call;

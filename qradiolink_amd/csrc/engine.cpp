@@ -147,6 +147,7 @@ struct qrl_demod {
     // HBM-facing kernels of the NEXT call instead of idling 250 CUs
     hipStream_t tail = nullptr;
     hipEvent_t ev_ff = nullptr, ev_tail = nullptr;
+    hipEvent_t ev_user[2] = {nullptr, nullptr};   // qrl_demod_stream_wait
     bool tail_pending = false;
     // overlapped mode (2FSK / GMSK / 4FSK families): everything behind the first decimated ring runs on the tail stream while
     // the front end of the NEXT call already runs on the main stream; ring s2 holds two calls, ev_tail2 guards its reuse
@@ -196,6 +197,7 @@ struct qrl_demod {
         for (auto& e : prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         if (ev_ff) (void)hipEventDestroy(ev_ff);
         if (ev_tail) (void)hipEventDestroy(ev_tail);
+        for (auto e : ev_user) if (e) (void)hipEventDestroy(e);
         for (auto e : ev_tail2) if (e) (void)hipEventDestroy(e);
         if (tail) (void)hipStreamDestroy(tail);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -788,6 +790,17 @@ int qrl_demod_set_carrier_offset(qrl_demod* d, double hz)
     d->cfg.carrier_offset_hz = hz;
     d->rot_inc = phase_inc_to_turn(2 * M_PI * -hz / d->cfg.device_samp_rate);
     return d->upload_rot_table();
+}
+int qrl_demod_stream_wait(qrl_demod* d, void* hip_stream)
+{
+    if (!d) return QRL_ERR_ARG;
+    hipStream_t user = static_cast<hipStream_t>(hip_stream);
+    if (!d->ev_user[0]) for (auto& e : d->ev_user) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(d->ev_user[0], d->stream));
+    HIPCHK(hipEventRecord(d->ev_user[1], d->tail));
+    HIPCHK(hipStreamWaitEvent(user, d->ev_user[0], 0));
+    HIPCHK(hipStreamWaitEvent(user, d->ev_user[1], 0));
+    return QRL_OK;
 }
 int qrl_demod_set_dmo_output(qrl_demod* d, uint8_t* frames, size_t cap_frames, uint32_t* counts)
 {

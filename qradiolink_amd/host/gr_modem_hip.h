@@ -1,0 +1,153 @@
+// gr_modem_hip.h — Qt-free host facade shaped like the three classes radiocontroller.cpp talks to, over the C ABI:
+//   gr_demod_base_hip   gr_demod_base  [reference src/gr/gr_demod_base.h:84-116: set_mode, getData(), getData(int nr),
+//                                       get_constellation_data, set_carrier_offset, set_samp_rate, start/stop]
+//   gr_mod_base_hip     gr_mod_base    [src/gr/gr_mod_base.h:73-89: set_mode, set_data (takes ownership), set_bb_gain,
+//                                       set_carrier_offset, set_samp_rate]
+//   gr_modem_hip        gr_modem       [src/gr_modem.h:55-139; demodulate src/gr_modem.cpp:1019-1117, synchronize :1119-1181,
+//                                       findSync :1183-1282, processReceivedData :1285-1441, frame :904-961, transmit :963-978,
+//                                       sendCallsign :654-676, startTransmission :678-707, endTransmission :710-744,
+//                                       transmitDigitalAudio / TextData / BinData / VideoData / NetData :812-900,
+//                                       toggleRxMode / toggleTxMode mode tables :105-322]
+// Differences that are not behaviour: Qt signals become std::function callbacks (struct gr_modem_events), QString becomes
+// std::string, and every object serves N independent radios ("streams") from ONE device handle: every reference method gets a
+// trailing `stream` argument (default 0), getters return heap vectors the caller deletes and setters take ownership, exactly as
+// in the reference (src/gr/gr_bit_sink.cpp:45-59, src/gr/gr_byte_source.cpp:54-62).  The M17 and DMR protocol stacks
+// (M17Transmitter, DMRControl) are out of scope: in DMR mode demodulate() hands the DMO slicer's bursts to a
+// callback, the M17 sync words are recognised and their frames delivered raw.
+// The device work is asynchronous and double buffered: work(k) stages its input, queues copy-in + qrl_demod_process + copy-out
+// on the device and only then harvests the mailboxes of work(k - 1) (qrl_demod_stream_wait chains the copy-out behind the
+// handle's internal streams), so the host never waits for the call it has just issued.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "gr_hip_blocks.h"
+
+namespace qrl_host {
+
+// frame types (reference src/layer1framing.h:8-24)
+enum frame_type : uint64_t {
+    FrameTypeNone = 0x00, FrameTypeVoice = 0xED89, FrameTypeVoice2 = 0xED89, FrameTypeVoice1 = 0xB5, FrameTypeText = 0x89EDAA,
+    FrameTypeIP = 0xDE98AA, FrameTypeVideo = 0x98DEAA, FrameTypeSync = 0xCC, FrameTypeCallsign = 0x8CC8DD, FrameTypeProto = 0xED77AA,
+    FrameTypeEnd = 0x4C8A2B, FrameTypeM17Stream = 0xFF5D, FrameTypeM17LSF = 0x55F7, FrameTypeM17EOT = 0x555D555D,
+};
+int modem_rx_frame_length(int modem_type, int* bit_buf_len);   // toggleRxMode table, gr_modem.cpp:203-322 (0 = unknown mode)
+int modem_tx_frame_length(int modem_type);                     // toggleTxMode table, gr_modem.cpp:105-199
+bool modem_two_branches(int modem_type);                       // the modes whose demodulator has bits A and bits B (:1048-1066)
+
+class gr_demod_base_hip {
+public:
+    gr_demod_base_hip(qrl_runtime& rt, int streams, int device_samp_rate = 1000000, double carrier_offset_hz = 0.0, size_t max_chunk = 1 << 18);
+    ~gr_demod_base_hip();
+    void set_mode(int mode);                                   // gr_modem_types value; flushes the mailboxes like the reference's graph swap
+    void set_carrier_offset(double hz);
+    void set_samp_rate(int device_samp_rate);
+    void start() {}
+    void stop() { flush(); }
+    // one scheduler pass: n new samples (even, <= max_chunk) of every stream, iq[s] = host pointer of stream s
+    void work(const gr_complex* const* iq, size_t n);
+    void flush();                                              // waits for the call in flight and harvests it
+    std::vector<unsigned char>* getData(int stream = 0) { return getData(1, stream); }
+    std::vector<unsigned char>* getData(int nr, int stream);   // nr = 1: bits A (port 2), nr = 2: bits B (port 3); nullptr = nothing yet
+    std::vector<gr_complex>* get_constellation_data(int stream = 0);
+    std::vector<std::vector<unsigned char>> getDMRData(int stream = 0);   // DMR mode: 40-byte DMO records (QRL_DMO_RECORD_BYTES)
+    int streams() const { return d_n; }
+    int mode() const { return d_mode; }
+
+private:
+    struct slot;
+    void open();
+    void close();
+    void harvest(int which);
+    qrl_runtime& d_rt;
+    int d_n, d_rate, d_mode = -1; double d_offset; size_t d_chunk;
+    qrl_demod* d_h = nullptr;
+    void* d_copy = nullptr;                                   // hipStream_t for the copy-out
+    slot* d_slot[2] = {nullptr, nullptr};
+    int d_inflight = -1; uint64_t d_calls = 0;
+    size_t d_fcap = 0, d_ccap = 0, d_bcap = 0;
+    std::mutex d_mutex;
+    std::vector<std::vector<unsigned char>> d_box1, d_box2;
+    std::vector<std::vector<gr_complex>> d_boxc;
+    std::vector<std::vector<std::vector<unsigned char>>> d_boxd;
+};
+
+class gr_mod_base_hip {
+public:
+    gr_mod_base_hip(qrl_runtime& rt, int streams, int device_samp_rate = 1000000, double carrier_offset_hz = 0.0, size_t max_bytes = 8192);
+    ~gr_mod_base_hip();
+    void set_mode(int mode);
+    int set_data(std::vector<uint8_t>* data, int stream = 0);  // takes ownership (gr_byte_source::set_data); 1 = queued
+    void set_bb_gain(float value);
+    void set_carrier_offset(double hz);
+    // one scheduler pass: consumes up to max_bytes queued bytes of every stream (zero padded to the longest) and returns the
+    // samples per stream it produced; out[s] receives them (host, capacity >= samples_per_byte() * max_bytes)
+    size_t work(gr_complex* const* out);
+    size_t samples_per_byte() const;
+    int streams() const { return d_n; }
+
+private:
+    void open();
+    qrl_runtime& d_rt;
+    int d_n, d_rate, d_mode = -1; double d_offset; size_t d_max; float d_gain = 1.0f;
+    qrl_mod* d_h = nullptr; uint8_t* d_bytes = nullptr; float* d_iq = nullptr;
+    std::mutex d_mutex;
+    std::vector<std::vector<uint8_t>> d_queue;
+};
+
+// the Qt signals of gr_modem that the RX / TX paths emit (src/gr_modem.h:118-139); unset callbacks are skipped.  Buffers are only
+// valid during the call (the reference hands heap buffers to slots that free them).
+struct gr_modem_events {
+    std::function<void(int stream, const unsigned char* data, int size)> digitalAudio, videoData, netData;
+    std::function<void(int stream, const std::string& text, bool html)> textReceived;
+    std::function<void(int stream, const std::string& callsign)> callsignReceived;
+    std::function<void(int stream, const std::vector<unsigned char>& data)> protoReceived;
+    std::function<void(int stream)> dataFrameReceived, endAudioTransmission, receiveEnd;
+    std::function<void(int stream, uint64_t frame_type, const unsigned char* data, int size)> m17Frame;   // raw M17 frames
+    std::function<void(int stream, const std::vector<std::vector<unsigned char>>& records)> dmrFrames;     // DMO slicer bursts
+};
+
+class gr_modem_hip {
+public:
+    gr_modem_hip(gr_demod_base_hip* demod, gr_mod_base_hip* mod, gr_modem_events events);
+    void toggleRxMode(int modem_type);
+    void toggleTxMode(int modem_type);
+    bool demodulate(int stream = 0);
+    // TX (bytes are queued on the modulator; its work() turns them into samples)
+    std::vector<unsigned char>* frame(unsigned char* encoded_audio, int data_size, int frame_type);
+    void transmit(std::vector<std::vector<unsigned char>*> frames, int stream = 0);
+    void sendCallsign(const std::string& callsign, int stream = 0);
+    void startTransmission(const std::string& callsign, int stream = 0);
+    void endTransmission(const std::string& callsign, int stream = 0);
+    void transmitDigitalAudio(unsigned char* data, int size, int stream = 0);   // deletes data[] like the reference
+    void transmitVideoData(unsigned char* data, int size, int stream = 0);
+    void transmitNetData(unsigned char* data, int size, int stream = 0);
+    void transmitTextData(const std::string& text, int frame_type = FrameTypeText, int stream = 0);
+    void transmitBinData(const std::vector<unsigned char>& bin_data, int frame_type = FrameTypeProto, int stream = 0);
+    void set_burst_ip_modem(bool v) { _burst_ip_modem = v; }
+    // two-branch modes (both Viterbi alignments decoded): BranchRuleBoth (default) runs the frame synchroniser on both
+    // branches, BranchRuleReference applies gr_modem.cpp:1080-1090 literally (see demodulate())
+    enum branch_rule { BranchRuleBoth = 0, BranchRuleReference = 1 };
+    void set_branch_rule(branch_rule r) { _branch_rule = r; }
+    int modem_sync(int stream = 0) const { return std::max(_rx[2 * (size_t)stream].modem_sync, _rx[2 * (size_t)stream + 1].modem_sync); }
+
+private:
+    struct rx_state {
+        bool sync_found = false; uint64_t shift_reg = 0, current_frame_type = FrameTypeNone, last_frame_type = FrameTypeNone;
+        int bit_buf_index = 0, modem_sync = 0; std::vector<unsigned char> bit_buf;
+    };
+    bool synchronize(int v_size, std::vector<unsigned char>* data, rx_state& r, int stream);
+    uint64_t findSync(unsigned char bit, rx_state& r);
+    void processReceivedData(unsigned char* received_data, uint64_t current_frame_type, rx_state& r, int stream);
+    void handleStreamEnd(rx_state& r, int stream);
+    gr_demod_base_hip* _gr_demod_base; gr_mod_base_hip* _gr_mod_base; gr_modem_events _ev;
+    int _modem_type_rx = -1, _modem_type_tx = -1, _bit_buf_len = 0, _rx_frame_length = 0, _tx_frame_length = 0, _frame_counter = 0;
+    bool _burst_ip_modem = false; branch_rule _branch_rule = BranchRuleBoth;
+    std::vector<rx_state> _rx;   // [2 * stream + branch]
+};
+
+}  // namespace qrl_host

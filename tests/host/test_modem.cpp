@@ -1,0 +1,106 @@
+// Drives the gr_modem-shaped facade (qradiolink_amd/host/gr_modem_hip.*) the way radiocontroller.cpp drives gr_modem:
+//   test_modem loopback <modem_type> <streams> <frames> <out.txt>
+// Per stream s: startTransmission("CALL<s>"), <frames> voice frames with a known payload, a text message, endTransmission;
+// the modulator's samples (+ a little silence and a per-stream delay) go into the demodulator in ragged work() calls;
+// demodulate() is polled like the radio loop does.  Every callback is logged to <out.txt> as one line per event.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+#include "gr_modem_hip.h"
+
+using namespace qrl_host;
+
+static std::string hex(const unsigned char* d, int n)
+{
+    static const char* h = "0123456789abcdef";
+    std::string s;
+    for (int i = 0; i < n; ++i) { s.push_back(h[d[i] >> 4]); s.push_back(h[d[i] & 15]); }
+    return s;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc != 6 || strcmp(argv[1], "loopback")) { std::fprintf(stderr, "usage: test_modem loopback modem_type streams frames out.txt\n"); return 2; }
+    const int mode = atoi(argv[2]), N = atoi(argv[3]), nframes = atoi(argv[4]);
+    try {
+        qrl_runtime rt(0);
+        std::ofstream log(argv[5]);
+        gr_modem_events ev;
+        ev.digitalAudio = [&](int s, const unsigned char* d, int n) { log << s << " audio " << hex(d, n) << "\n"; };
+        ev.textReceived = [&](int s, const std::string& t, bool) { log << s << " text " << hex(reinterpret_cast<const unsigned char*>(t.data()), (int)t.size()) << "\n"; };
+        ev.callsignReceived = [&](int s, const std::string& c) { log << s << " callsign " << c << "\n"; };
+        ev.dataFrameReceived = [&](int s) { log << s << " dataframe\n"; };
+        ev.endAudioTransmission = [&](int s) { log << s << " endaudio\n"; };
+        ev.receiveEnd = [&](int s) { log << s << " receiveend\n"; };
+        const size_t chunk = 1 << 17;
+        gr_demod_base_hip demod(rt, N, 1000000, 0.0, chunk);
+        gr_mod_base_hip mod(rt, N, 1000000, 0.0, 4096);
+        gr_modem_hip modem(&demod, &mod, ev);
+        modem.toggleTxMode(mode);
+        modem.toggleRxMode(mode);
+        const int L = modem_tx_frame_length(mode);
+        for (int s = 0; s < N; ++s) {
+            modem.startTransmission("CALL" + std::to_string(s), s);
+            for (int f = 0; f < nframes; ++f) {
+                unsigned char* d = new unsigned char[L];
+                for (int i = 0; i < L; ++i) d[i] = (unsigned char)(17 * s + 31 * f + 7 * i + 1);
+                modem.transmitDigitalAudio(d, L, s);
+            }
+            modem.transmitTextData("hello from stream " + std::to_string(s), (int)FrameTypeText, s);
+            modem.endTransmission("CALL" + std::to_string(s), s);
+        }
+        // modulate everything that is queued
+        const size_t spb = mod.samples_per_byte();
+        std::vector<std::vector<gr_complex>> tx(N);
+        std::vector<std::vector<gr_complex>> part(N, std::vector<gr_complex>(spb * 4096));
+        for (;;) {
+            std::vector<gr_complex*> outp(N);
+            for (int s = 0; s < N; ++s) outp[s] = part[s].data();
+            const size_t ns = mod.work(outp.data());
+            if (!ns) break;
+            for (int s = 0; s < N; ++s) tx[s].insert(tx[s].end(), part[s].begin(), part[s].begin() + ns);
+        }
+        // channel: per-stream delay, scale, trailing silence so that the last frames leave the filters / Viterbi
+        size_t total = 0;
+        for (int s = 0; s < N; ++s) total = std::max(total, tx[s].size());
+        total += 40000 + 1000 * N;
+        total &= ~(size_t)1;
+        std::vector<std::vector<gr_complex>> rx(N, std::vector<gr_complex>(total, gr_complex(0, 0)));
+        for (int s = 0; s < N; ++s)
+            for (size_t i = 0; i < tx[s].size(); ++i) rx[s][i + 500 * s] = 0.05f * tx[s][i];   // (SDR-like level: the reference's FLL loop gain scales with the input power, there is no AGC in front of it)
+        // feed in ragged, even-sized calls and poll like the radio loop (radiocontroller.cpp:1291-1303)
+        size_t pos = 0;
+        size_t sizes[] = {65536, 10000, 131072, 2, 77778};
+        if (const char* e = getenv("QRL_TEST_CHUNK")) for (auto& v : sizes) v = (size_t)atol(e);
+        FILE* bitlog = getenv("QRL_TEST_BITS") ? std::fopen(getenv("QRL_TEST_BITS"), "wb") : nullptr;
+        for (int k = 0; pos < total; ++k) {
+            const size_t n = std::min(sizes[k % 5], total - pos) & ~(size_t)1;
+            if (!n) break;
+            std::vector<const gr_complex*> in(N);
+            for (int s = 0; s < N; ++s) in[s] = rx[s].data() + pos;
+            demod.work(in.data(), n);
+            pos += n;
+            if (getenv("QRL_TEST_DEBUG")) {
+                for (int s = 0; s < N; ++s) {
+                    auto* a = demod.getData(1, s); auto* b = demod.getData(2, s);
+                    std::fprintf(stderr, "call %d stream %d: bits A %zu, bits B %zu, tx %zu samples\n", k, s, a ? a->size() : 0, b ? b->size() : 0, tx[s].size());
+                    if (bitlog && s == 0 && a) std::fwrite(a->data(), 1, a->size(), bitlog);
+                    delete a; delete b;
+                }
+                continue;
+            }
+            for (int s = 0; s < N; ++s) while (modem.demodulate(s)) {}
+        }
+        if (bitlog) std::fclose(bitlog);
+        demod.flush();
+        for (int s = 0; s < N; ++s) while (modem.demodulate(s)) {}
+        for (int s = 0; s < N; ++s) log << s << " modem_sync " << modem.modem_sync(s) << "\n";
+        return 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "exception: %s\n", e.what());
+        return 1;
+    }
+}
