@@ -40,6 +40,7 @@ struct DecimParams {
     uint32_t out_row_mul_m1, out_row_add;                   // output ring row of stream b = b * (mul_m1 + 1) + add (MFMA / phase-lane variants)
     // phase-lane variant (kernels_decim_pl.hip): lane tap table [J][64]; the launcher fills the segment geometry
     const float* pl_taps; int pl_J; uint32_t pl_S, pl_nseg, pl_batch; uint64_t pl_m_begin, pl_m_end;
+    int pl_E, pl_R; const float* pl_hraw;                   // samples per lane and block, outputs per block; raw taps h[k] (k_decim_pl_gen)
 };
 struct HistParams {
     const float2* in; size_t in_stride; uint64_t n0; uint32_t n;

@@ -91,6 +91,30 @@ __device__ __forceinline__ float pl_reduce16(const float (&d)[16], bool hi8, boo
     f = f + pl_dpp_quad<0xb1>(f) /* quad_perm [1,0,3,2] */;
     return f;
 }
+// the levels of pl_reduce16 one by one (k_decim_plx feeds the tree as outputs finish)
+__device__ __forceinline__ float pl_level32(float d0, float d1)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(d0), __float_as_uint(d1), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float pl_level16(float b0, float b1)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(b0), __float_as_uint(b1), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float pl_level8(float c0, float c1, bool hi8)
+{
+    const float keep = hi8 ? c1 : c0, send = hi8 ? c0 : c1;
+    return keep + pl_dpp_ror8(send);
+}
+__device__ __forceinline__ float pl_level421(float e0, float e1, bool hi4)
+{
+    const float keep = hi4 ? e1 : e0, send = hi4 ? e0 : e1;
+    float f = keep + pl_dpp_xor4(send);
+    f = f + pl_dpp_quad<0x4e>(f);
+    f = f + pl_dpp_quad<0xb1>(f);
+    return f;
+}
 __device__ __forceinline__ int pl_out_index(int lane)
 {
     const int row = lane >> 4, bank = (lane >> 2) & 3;
@@ -208,6 +232,157 @@ void k_decim_pl(const DecimParams P_)
     }
 }
 
+// ---- generalised geometry: E samples per lane and block, R outputs per block ------------------------------------------------------
+//  k_decim_plx<E, R, U>: the same register-resident scheme for the front ends whose decimation is not one sample per lane:
+//    E = 2, R = 1   64 < D <= 128 (the 100:1 front end of a 100 Msps device, 4 181 taps): a block is D samples, lane l owns the
+//                   samples 2l and 2l + 1 of every block (slot(i) = ((i - 1) mod D) / 2 of the "pl" contract);
+//    E = 1, R = 2   22 <= D <= 32 (the 25:1 front end): a block is 2 D samples and completes two outputs.
+//  Block c = samples (c-1) D' + 1 .. c D' (D' = R D).  The sample r = E l + e of block c meets output m = (c-1) R + u with tap
+//  h[u D - 1 - r], u = 1 .. U = floor((nt + D' - 1) / D); the accumulators are a sliding window of 16 - R + U registers that moves
+//  down by 16 after every 16 outputs.  With 84 taps + 114 accumulators + the prefetch ring a wave needs > 256 VGPRs, so one wave
+//  runs per SIMD: a lone wave issues one VALU per ~4-5 cycles, and v_pk_fma_f32 (re and im in one instruction) is what keeps the
+//  f32 pipe busy at that rate (32 lanes per clock: two v_fma_f32 = one v_pk_fma_f32 = 4 cycles).
+constexpr int PLX_PF = 4;          // blocks in flight per wave (two waves per SIMD: 247 VGPRs at 4, 276 at 8)
+constexpr int PLX_NHI = 256;       // coarse rotator entries per wave: a segment spans <= 255 x 512 samples
+
+// cmul_fma (devmath.hpp) on register pairs: {fma(a.x, b.x, -(a.y b.y)), fma(a.x, b.y, a.y b.x)} = two packed instructions
+__device__ __forceinline__ v2f plx_cmul_fma(v2f a, v2f b)
+{
+    const v2f t = v2f{-a.y, a.y} * v2f{b.y, b.x};   // -(a.y b.y) == (-a.y) b.y exactly
+    return __builtin_elementwise_fma(v2f{a.x, a.x}, b, t);
+}
+
+// acc += {h, h} * x with h = one half of a tap pair, broadcast by op_sel.  (Written as a v2f splat the compiler hoists the
+// loop-invariant {h, h} pairs out of the loop: two registers per tap, the taps alone would not fit the VGPR file.)
+template <int HI>
+__device__ __forceinline__ void plx_fma(v2f& acc, v2f hpair, v2f x)
+{
+    if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(hpair), "v"(x));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(hpair), "v"(x));
+}
+template <int HI>
+__device__ __forceinline__ v2f plx_mul(v2f hpair, v2f x)
+{
+    v2f r;
+    if (HI) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(hpair), "v"(x));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(hpair), "v"(x));
+    return r;
+}
+
+template <int E, int R, int U>
+__global__ __launch_bounds__(256, 2) void k_decim_plx(const DecimParams P_)
+{
+    constexpr int G = 16 / R;              // blocks per group of 16 outputs
+    constexpr int WN = 16 - R + U;         // accumulator window
+    constexpr int WU = (U - 1) / R;        // warm-up blocks in front of a segment
+    static_assert(G % PLX_PF == 0 || PLX_PF % G == 0, "prefetch ring and group must nest");
+    const DecimParams& P = P_;
+    __shared__ float2 t_lo[512];
+    __shared__ float2 t_hi_all[4][PLX_NHI];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    t_lo[tid] = P.rot_lo[tid];
+    t_lo[tid + 256] = P.rot_lo[tid + 256];
+
+    const uint32_t unit = blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t B = P.pl_batch;
+    const uint32_t seg = unit / B, b = unit - seg * B;
+    const bool active = seg < P.pl_nseg;
+    const int Dp = P.D * R, NL = Dp / E;
+    const uint64_t ms = P.pl_m_begin + (uint64_t)seg * P.pl_S;        // == 1 (mod R): the launcher's choice of pl_m_begin, pl_S
+    const uint64_t me = ms + P.pl_S < P.pl_m_end ? ms + P.pl_S : P.pl_m_end;
+    const uint64_t c_first = (ms - 1) / R + 1 - (uint64_t)WU;
+    const uint64_t i_first = (c_first - 1) * (uint64_t)Dp + 1;        // >= n0 (interior outputs only)
+    const uint32_t kb0 = (uint32_t)((i_first - P.rot_nbase) >> 9);
+    float2* t_hi = t_hi_all[wave];
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < PLX_NHI / 64; ++q)
+            t_hi[lane + 64 * q] = sincos_turn(P.rot_acc + ((uint64_t)(kb0 + (uint32_t)(lane + 64 * q)) << 9) * P.rot_inc);
+    }
+    __syncthreads();
+    if (!active) return;
+
+    // taps two to a register pair: v_pk_fma_f32 broadcasts either half through op_sel, a scalar float operand would be
+    // widened to a {h, h} pair by the compiler (twice the registers)
+    constexpr int NH = (E * U + 1) / 2;
+    v2f hp[NH];
+#pragma unroll
+    for (int q = 0; q < NH; ++q) {
+        hp[q].x = P.pl_taps[(2 * q) * 64 + lane];
+        hp[q].y = 2 * q + 1 < E * U ? P.pl_taps[(2 * q + 1) * 64 + lane] : 0.f;
+    }
+    const int lo = lane < NL ? lane : NL - 1;                         // idle lanes re-read the last samples against zero taps
+    const int nblk = WU + (int)((me - ms + R - 1) / R);
+    const float2* ub = P.in + (size_t)b * P.in_stride + (size_t)(i_first - P.n0) + (size_t)(E * lo);   // lane's first sample of block 0
+    const uint32_t k0 = (uint32_t)(i_first - P.rot_nbase) - (kb0 << 9) + (uint32_t)(E * lo);           // its NCO index, relative
+    const bool hi8 = lane & 8, hi4 = lane & 4;
+    const bool leader = (lane & 3) == 0;
+    const int oidx = pl_out_index(lane);
+    float2* orow = P.out.p + ((size_t)b * (P.out_row_mul_m1 + 1u) + P.out_row_add) * (P.out.mask + 1u);
+
+    v2f pf[PLX_PF][E];
+#pragma unroll
+    for (int q = 0; q < PLX_PF; ++q) {
+        const int t = q < nblk ? q : nblk - 1;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { const float2 v = ub[(size_t)t * Dp + e]; pf[q][e] = v2f{v.x, v.y}; }
+    }
+    v2f acc[WN];
+#pragma unroll
+    for (int a = 0; a < WN; ++a) acc[a] = v2f{0.f, 0.f};
+
+    const int ngrp = (nblk + G - 1) / G;
+    for (int grp = 0; grp < ngrp; ++grp) {
+        float dr[16], di[16];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int t = grp * G + i;
+            v2f x[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) x[e] = pf[i % PLX_PF][e];
+            {   // keep PLX_PF blocks in flight (past the end of the segment: harmless re-read of its last block)
+                const int tn = t + PLX_PF < nblk ? t + PLX_PF : nblk - 1;
+#pragma unroll
+                for (int e = 0; e < E; ++e) { const float2 v = ub[(size_t)tn * Dp + e]; pf[i % PLX_PF][e] = v2f{v.x, v.y}; }
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {   // rotator: phasor of sample k = T_hi[k >> 9] (x) T_lo[k & 511]
+                const uint32_t kb8 = (k0 + (uint32_t)t * (uint32_t)Dp + (uint32_t)e) * 8u;
+                const float2 plo = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(t_lo) + (kb8 & 4095u));
+                const float2 phi = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(t_hi) + ((kb8 >> 9) & ~7u));
+                x[e] = plx_cmul_fma(x[e], plx_cmul_fma(v2f{phi.x, phi.y}, v2f{plo.x, plo.y}));
+            }
+            // output (c-1) R + u sits at window slot i R + u - 1; its chain starts (plain product) at its oldest block, u > U - R
+#pragma unroll
+            for (int u = U; u >= 1; --u) {
+                const int a = i * R + u - 1;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int qq = (u - 1) * E + e;
+                    if (u > U - R && e == 0) acc[a] = (qq & 1) ? plx_mul<1>(hp[qq >> 1], x[e]) : plx_mul<0>(hp[qq >> 1], x[e]);
+                    else if (qq & 1) plx_fma<1>(acc[a], hp[qq >> 1], x[e]);
+                    else plx_fma<0>(acc[a], hp[qq >> 1], x[e]);
+                }
+            }
+            // finished outputs enter the transposing tree at once (pl_reduce16 level by level: fewer live registers)
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int o = i * R + q;
+                dr[o] = acc[o].x; di[o] = acc[o].y;
+                if ((o & 1) == 1) { dr[o >> 1] = pl_level32(dr[o - 1], dr[o]); di[o >> 1] = pl_level32(di[o - 1], di[o]); }
+                if ((o & 3) == 3) { dr[o >> 2] = pl_level16(dr[(o >> 1) - 1], dr[o >> 1]); di[o >> 2] = pl_level16(di[(o >> 1) - 1], di[o >> 1]); }
+                if ((o & 7) == 7) { dr[o >> 3] = pl_level8(dr[(o >> 2) - 1], dr[o >> 2], hi8); di[o >> 3] = pl_level8(di[(o >> 2) - 1], di[o >> 2], hi8); }
+            }
+        }
+        const float yr = pl_level421(dr[0], dr[1], hi4), yi = pl_level421(di[0], di[1], hi4);
+        const uint64_t m = (c_first - 1) * R + 1 + (uint64_t)(grp * 16 + oidx);
+        if (leader && m >= ms && m < me) orow[(uint32_t)m & P.out.mask] = make_float2(yr, yi);
+#pragma unroll
+        for (int a = 0; a < WN - 16; ++a) acc[a] = acc[a + 16];
+    }
+}
+
 // One wave per output, checked fetches: zero in front of the stream, carried (already rotated) history in front of this
 // call's buffer, the caller's buffer with the exact NCO, or an engine ring.
 __global__ __launch_bounds__(256) void k_decim_pl_gen(const DecimParams P_, uint64_t m_first, uint32_t count)
@@ -218,34 +393,50 @@ __global__ __launch_bounds__(256) void k_decim_pl_gen(const DecimParams P_, uint
     if (o >= count) return;
     const int b = blockIdx.y;
     const uint64_t m = m_first + o;
-    const int D = P.D, J = P.pl_J;
+    const int D = P.D, E = P.pl_E, Dp = D * P.pl_R, nt = P.nt;
+    // lane l owns the samples i with ((i - 1) mod D') / E = l; oldest first (tap index k descending), first term a plain product.
+    // Sample e of the lane in the block whose e = 0 sample has tap k_b: tap k_b - e.  32-bit indices relative to this call's buffer.
     float vr = 0.f, vi = 0.f;
-    if (lane < D) {
-        for (int j = J - 1; j >= 0; --j) {
-            const int k = (D - 1 - lane) + j * D;
-            const float hk = k < P.nt ? P.pl_taps[j * 64 + lane] : 0.f;
-            const int64_t i = (int64_t)m * D - k;
-            float2 x = make_float2(0.f, 0.f);
-            if (i >= 0) {
-                const uint64_t ui = (uint64_t)i;
-                if (P.in) {
-                    if (ui >= P.n0) {
-                        x = P.in[(size_t)b * P.in_stride + (size_t)(ui - P.n0)];
-                        if (P.rot_enable) {
-                            const uint64_t kk = ui - P.rot_nbase;
-                            const float2 hi = sincos_turn(P.rot_acc + ((kk >> 9) << 9) * P.rot_inc);
-                            x = cmul_fma(x, cmul_fma(hi, P.rot_lo[(uint32_t)kk & 511u]));
+    bool first = true;
+    uint32_t hi_blk = ~0u;
+    float2 hi = make_float2(1.f, 0.f);
+    const int64_t top = (int64_t)m * D;                          // sample index of tap 0
+    const int rel_top = (int)(top - (int64_t)P.n0);              // the same, relative to in[0]
+    const int64_t n_before = -(int64_t)P.n0;                     // rel < n_before: in front of the stream (zero)
+    const uint64_t kk0 = P.n0 - P.rot_nbase;                     // NCO index of in[0]: coarse block blk0, fine offset lo0
+    const uint64_t blk0 = kk0 >> 9; const uint32_t lo0 = (uint32_t)kk0 & 511u;
+    if (E * lane < Dp) {
+        int64_t k0 = (top - 1 - (int64_t)(E * lane)) % Dp;
+        if (k0 < 0) k0 += Dp;
+        const float2* inb = P.in ? P.in + (size_t)b * P.in_stride : nullptr;
+        const float2* hb = P.hist ? P.hist + (size_t)b * P.hist_len : nullptr;
+        const float2* rb = P.in_ring.p ? P.in_ring.p + (size_t)b * (P.in_ring.mask + 1u) : nullptr;
+        for (int kb = (int)k0 + ((nt - 1 + E - 1 - (int)k0) / Dp) * Dp; kb >= 0; kb -= Dp) {
+            for (int e = 0; e < E; ++e) {
+                const int k = kb - e;
+                if (k < 0 || k >= nt || E * lane + e >= Dp) continue;
+                const float hk = P.pl_hraw[k];
+                const int rel = rel_top - k;
+                float2 x = make_float2(0.f, 0.f);
+                if ((int64_t)rel >= n_before) {
+                    if (inb) {
+                        if (rel >= 0) {
+                            x = inb[rel];
+                            if (P.rot_enable) {
+                                const uint32_t kk = lo0 + (uint32_t)rel;
+                                if ((kk >> 9) != hi_blk) { hi_blk = kk >> 9; hi = sincos_turn(P.rot_acc + ((blk0 + hi_blk) << 9) * P.rot_inc); }
+                                x = cmul_fma(x, cmul_fma(hi, P.rot_lo[kk & 511u]));
+                            }
+                        } else if ((uint32_t)(-rel) <= P.hist_len) {
+                            x = hb[(int)P.hist_len + rel];
                         }
                     } else {
-                        const uint64_t d = P.n0 - ui;
-                        if (d <= P.hist_len) x = P.hist[(size_t)b * P.hist_len + (P.hist_len - (uint32_t)d)];
+                        x = rb[(uint32_t)(P.n0 + (uint64_t)(int64_t)rel) & P.in_ring.mask];
                     }
-                } else {
-                    x = P.in_ring.p[(size_t)b * (P.in_ring.mask + 1u) + ((uint32_t)ui & P.in_ring.mask)];
                 }
+                if (first) { vr = hk * x.x; vi = hk * x.y; first = false; }
+                else { vr = fmaf(hk, x.x, vr); vi = fmaf(hk, x.y, vi); }
             }
-            if (j == J - 1) { vr = hk * x.x; vi = hk * x.y; }
-            else { vr = fmaf(hk, x.x, vr); vi = fmaf(hk, x.y, vi); }
         }
     }
 #pragma unroll
@@ -257,19 +448,40 @@ __global__ __launch_bounds__(256) void k_decim_pl_gen(const DecimParams P_, uint
         P.out.p[((size_t)b * (P.out_row_mul_m1 + 1u) + P.out_row_add) * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = make_float2(vr, vi);
 }
 
+// geometry of the "pl" contract (oracle/orc_blocks.c orc_pl_geometry) and the instantiated kernels
+struct PlGeom { int R, Dp, E, U, Upad, WU; bool ok; };
+static PlGeom pl_geom(int nt, int D)
+{
+    PlGeom g{};
+    g.R = D <= 32 ? 64 / D : 1;
+    g.Dp = g.R * D;
+    g.E = (g.Dp + 63) / 64;
+    g.U = (nt + g.Dp - 1) / D;
+    g.Upad = g.U;
+    if (g.E == 1 && g.R == 1) g.ok = g.U <= 16;
+    else if (g.E == 2 && g.R == 1) { g.ok = (D % 2) == 0 && g.U <= 48; g.Upad = g.U <= 42 ? 42 : 48; }
+    else g.ok = false;
+    g.WU = (g.Upad - 1) / g.R;
+    return g;
+}
 // rule shared with oracle/orc_blocks.c orc_decim_uses_pl
-bool decim_uses_pl(int nt, int D) { return D > 32 && D <= 64 && (nt + D - 1) / D <= 16; }
+bool decim_uses_pl(int nt, int D) { return pl_geom(nt, D).ok; }
 
-// lane tap table [J][64]: lane l holds h[(j + 1) D - 1 - l]
+// lane tap table [Upad][E][64]: lane l, sample e of a block (r = E l + e) meets output u + 1 with h[(u + 1) D - 1 - r];
+// the raw taps follow (k_decim_pl_gen reads them by index)
 std::vector<float> decim_pl_layout(const std::vector<float>& h, int D)
 {
-    const int nt = (int)h.size(), J = (nt + D - 1) / D;
-    std::vector<float> t((size_t)J * 64, 0.0f);
-    for (int j = 0; j < J; ++j)
-        for (int l = 0; l < D; ++l) {
-            const int k = (j + 1) * D - 1 - l;
-            if (k < nt) t[(size_t)j * 64 + l] = h[k];
-        }
+    const int nt = (int)h.size();
+    const PlGeom g = pl_geom(nt, D);
+    std::vector<float> t((size_t)g.Upad * g.E * 64 + (size_t)nt, 0.0f);
+    for (int u = 0; u < g.Upad; ++u)
+        for (int e = 0; e < g.E; ++e)
+            for (int l = 0; l < 64; ++l) {
+                const int r = g.E * l + e;
+                const int k = (u + 1) * D - 1 - r;
+                if (r < g.Dp && k >= 0 && k < nt) t[((size_t)u * g.E + e) * 64 + l] = h[k];
+            }
+    for (int k = 0; k < nt; ++k) t[(size_t)g.Upad * g.E * 64 + k] = h[k];
     return t;
 }
 
@@ -282,47 +494,75 @@ static void pl_launch_main(const DecimParams& q, uint32_t units, hipStream_t s)
 int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)
 {
     if (p.m_count == 0) return 0;
-    const int D = p.D, J = (p.nt + D - 1) / D;
+    const int D = p.D;
+    const PlGeom g = pl_geom(p.nt, D);
     DecimParams q = p;
-    q.pl_J = J;
+    q.pl_J = g.Upad; q.pl_E = g.E; q.pl_R = g.R;
+    q.pl_hraw = p.pl_taps + (size_t)g.Upad * g.E * 64;
     const uint64_t m_end = p.m0 + p.m_count;
-    uint64_t m_main = m_end;   // first output of the register kernel
+    uint64_t m_main = m_end, m_tail = m_end;   // [m_main, m_tail): the register kernel; the rest: one wave per output
     if (p.in && p.rot_enable) {
-        // interior outputs: every sample the lanes touch, (m - J) D + 1 .. m D, lies in this call's buffer
-        const uint64_t need = p.n0 + (uint64_t)J * D;            // m D >= n0 + J D - 1 + ... : m >= ceil((n0 - 1) / D) + J
-        m_main = (need + D - 2) / D;                              // smallest m with (m - J) D + 1 >= n0
-        if (m_main < p.m0) m_main = p.m0;
-        if (m_main > m_end) m_main = m_end;
+        // interior outputs: every sample the lanes touch lies in this call's buffer.  First block of a segment starting at output
+        // ms = (cs - 1) R + 1 is cs - WU, its first sample (cs - WU - 1) D' + 1 >= n0
+        const uint64_t qb = p.n0 > 1 ? (p.n0 - 1 + g.Dp - 1) / g.Dp : 0;
+        m_main = (qb + g.WU) * g.R + 1;
+        if (m_main < p.m0) m_main = p.m0 + (g.R - 1 - (p.m0 + g.R - 2) % g.R);   // next m == 1 (mod R)
+        // last block must end inside the buffer: c D' <= n0 + n - 1
+        const uint64_t c_max = (p.n0 + p.n - 1) / g.Dp;
+        m_tail = c_max * g.R + 1;
+        if (m_tail > m_end) m_tail = m_end;
+        if (m_main > m_tail) m_main = m_tail;
     }
     if (m_main > p.m0) {
         const uint32_t cnt = (uint32_t)(m_main - p.m0);
         hipLaunchKernelGGL(k_decim_pl_gen, dim3((cnt + 3) / 4, batch), dim3(256), 0, s, q, p.m0, cnt);
     }
-    if (m_main >= m_end) return 0;
-    // segment length: a multiple of 16 blocks, long enough to keep the warm-up re-reads small, short enough to spread the
-    // call over >= ~16 waves per CU, and inside the 64-entry coarse rotator table of a wave (64 x 512 samples)
-    const uint64_t total = (m_end - m_main) * (uint64_t)batch;
-    uint64_t S = total / (256u * 16u * 4u);
-    const uint64_t s_cap = (uint64_t)((62 * 512) / D - J) / 16 * 16;
-    if (S > 512) S = 512;
+    if (m_tail < m_end && m_tail >= m_main) {
+        const uint32_t cnt = (uint32_t)(m_end - m_tail);
+        hipLaunchKernelGGL(k_decim_pl_gen, dim3((cnt + 3) / 4, batch), dim3(256), 0, s, q, m_tail, cnt);
+    }
+    if (m_main >= m_tail) return 0;
+    const uint64_t total = (m_tail - m_main) * (uint64_t)batch;
+    q.pl_m_begin = m_main; q.pl_m_end = m_tail;
+    q.pl_batch = (uint32_t)batch;
+    if (g.E == 1 && g.R == 1) {
+        // segment length: a multiple of 16 blocks, long enough to keep the warm-up re-reads small, short enough to spread the
+        // call over >= ~16 waves per CU, and inside the 64-entry coarse rotator table of a wave (64 x 512 samples)
+        const int J = g.U;
+        uint64_t S = total / (256u * 16u * 4u);
+        const uint64_t s_cap = (uint64_t)((62 * 512) / D - J) / 16 * 16;
+        if (S > 512) S = 512;
+        if (S > s_cap) S = s_cap;
+        S = S / 16 * 16;
+        if (S < 16) S = 16;
+        q.pl_S = (uint32_t)S;
+        q.pl_nseg = (uint32_t)((m_tail - m_main + S - 1) / S);
+        const uint32_t units = q.pl_nseg * (uint32_t)batch;
+        switch (J) {
+        case 1: pl_launch_main<1>(q, units, s); break;   case 2: pl_launch_main<2>(q, units, s); break;
+        case 3: pl_launch_main<3>(q, units, s); break;   case 4: pl_launch_main<4>(q, units, s); break;
+        case 5: pl_launch_main<5>(q, units, s); break;   case 6: pl_launch_main<6>(q, units, s); break;
+        case 7: pl_launch_main<7>(q, units, s); break;   case 8: pl_launch_main<8>(q, units, s); break;
+        case 9: pl_launch_main<9>(q, units, s); break;   case 10: pl_launch_main<10>(q, units, s); break;
+        case 11: pl_launch_main<11>(q, units, s); break; case 12: pl_launch_main<12>(q, units, s); break;
+        case 13: pl_launch_main<13>(q, units, s); break; case 14: pl_launch_main<14>(q, units, s); break;
+        case 15: pl_launch_main<15>(q, units, s); break; default: pl_launch_main<16>(q, units, s); break;
+        }
+        return 0;
+    }
+    // generalised geometry: two waves per SIMD (<= 256 VGPRs), ~3 segments per wave slot of the chip; a segment stays inside
+    // the wave's coarse rotator table and is a multiple of 16 outputs
+    uint64_t S = total / (2048u * 3u);
+    const uint64_t s_cap = (uint64_t)(((PLX_NHI - 2) * 512) / g.Dp - g.WU) * g.R / 16 * 16;
+    if (S > 2048) S = 2048;
     if (S > s_cap) S = s_cap;
     S = S / 16 * 16;
     if (S < 16) S = 16;
     q.pl_S = (uint32_t)S;
-    q.pl_m_begin = m_main; q.pl_m_end = m_end;
-    q.pl_nseg = (uint32_t)((m_end - m_main + S - 1) / S);
-    q.pl_batch = (uint32_t)batch;
+    q.pl_nseg = (uint32_t)((m_tail - m_main + S - 1) / S);
     const uint32_t units = q.pl_nseg * (uint32_t)batch;
-    switch (J) {
-    case 1: pl_launch_main<1>(q, units, s); break;   case 2: pl_launch_main<2>(q, units, s); break;
-    case 3: pl_launch_main<3>(q, units, s); break;   case 4: pl_launch_main<4>(q, units, s); break;
-    case 5: pl_launch_main<5>(q, units, s); break;   case 6: pl_launch_main<6>(q, units, s); break;
-    case 7: pl_launch_main<7>(q, units, s); break;   case 8: pl_launch_main<8>(q, units, s); break;
-    case 9: pl_launch_main<9>(q, units, s); break;   case 10: pl_launch_main<10>(q, units, s); break;
-    case 11: pl_launch_main<11>(q, units, s); break; case 12: pl_launch_main<12>(q, units, s); break;
-    case 13: pl_launch_main<13>(q, units, s); break; case 14: pl_launch_main<14>(q, units, s); break;
-    case 15: pl_launch_main<15>(q, units, s); break; default: pl_launch_main<16>(q, units, s); break;
-    }
+    if (g.E == 2 && g.Upad == 42) hipLaunchKernelGGL((k_decim_plx<2, 1, 42>), dim3((units + 3) / 4), dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((k_decim_plx<2, 1, 48>), dim3((units + 3) / 4), dim3(256), 0, s, q);
     return 0;
 }
 

@@ -288,63 +288,137 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
     }
 }
 
-// ---- two-wave pipeline of the QPSK chain (MODE 0; the default, QRL_QPSK_PIPE=0 selects k_qpsk_loops<0>) --------------------------
-// The serial chain costs ~1 us per 500 ksps sample and stream with both passes on one wave.  Here wave 0 runs pass 1 (agc2 +
-// first Costas loop) on window t while wave 1 runs pass 2 (symbol sync + second Costas + diff_phasor + rotate) on window t - 1
-// and waves 2-3 load window t + 1 and flush the symbols of window t - 2: three window buffers, one barrier per step.  The
-// arithmetic and its order are those of k_qpsk_loops<0>.  Measured (C5, 4096 streams x 65536 samples): 32.6 -> 22.9 ms per call.
-constexpr int QPP_W = 56;
-constexpr int QPP_COLS = QP_BACK + QPP_W;    // 72
-constexpr int QPP_PITCH = QPP_COLS + 1;      // 73
-constexpr int QPP_OMAX = 32;                 // symbols per stream per window (sps >= 1.9: 56 / 1.9 + 2)
-constexpr int QPP_OPITCH = QPP_OMAX + 1;
+// ---- four-stage wave pipeline of the QPSK chain (MODE 0) -----------------------------------------------------------------------------
+// The chain is a serial recurrence per stream; with one lane per stream the time of a call is (samples per stream) x (instructions
+// the slowest wave issues per sample), whatever the batch.  So every recurrence gets its own wave (its own SIMD) and nothing but the
+// recurrence runs on it:
+//   wave 0  agc2_cc                          window t      (in place in the LDS ring)
+//   wave 1  costas_loop_cc #1                window t - 1  (in place)
+//   wave 2  symbol_sync_cc (MMSE + M&M TED)  window t - 2  -> interpolated symbols Y
+//   wave 3  costas_loop_cc #2, diff_phasor, rotate         window t - 3  Y -> osym
+//   waves 4-5  load window t + 1 from the RRC ring, flush the symbols of window t - 4 (soft symbols + constellation port)
+// one barrier per window.  The samples live in one LDS ring per stream (5 windows of 32 columns + an 8-column mirror of the first
+// columns so that the 8-tap interpolator never wraps); the loops are straight-line code (selects instead of branches, inputs of four
+// steps loaded ahead of the recurrence).  The arithmetic and its order are those of k_qpsk_loops<0> / the oracle (bit-exact).
+#ifndef QRL_Q4_SKIP
+#define QRL_Q4_SKIP 0
+#endif
+constexpr int Q4_W = 32, Q4_NB = 5, Q4_RC = Q4_W * Q4_NB, Q4_MIR = 8;
+constexpr int Q4_PITCH = Q4_RC + Q4_MIR + 1;   // 169 float2, odd
+constexpr int Q4_OMAX = 20;                    // symbols per stream per window (sps >= 1.9: 32 / 1.9 + 2)
+constexpr int Q4_OPITCH = Q4_OMAX + 1;
 
-__global__ __launch_bounds__(256) void k_qpsk_pipe(const QpskParams P, int batch)
+__device__ __forceinline__ float tanhf_lut_sel(float x, const float* __restrict__ T)   // tanhf_lut without branches
+{
+    int index = (int)(128.0f + 64.0f * x);
+    index = index > 255 ? 255 : (index < 0 ? 0 : index);
+    float v = T[index];
+    v = x > 2.0f ? 1.0f : v;
+    v = x <= -2.0f ? -1.0f : v;
+    return v;
+}
+__device__ __forceinline__ float costas4_snr_error_sel(float2 o, const float* __restrict__ T)
+{
+    const float snr = (o.x * o.x + o.y * o.y);
+    return (tanhf_lut_sel(snr * o.x, T) * o.y) - (tanhf_lut_sel(snr * o.y, T) * o.x);
+}
+__device__ __forceinline__ float clamp_pm1(float f)   // if (f > 1) f = 1; else if (f < -1) f = -1;
+{
+    f = f > 1.0f ? 1.0f : f;
+    return f < -1.0f ? -1.0f : f;
+}
+__device__ __forceinline__ int q4_col(long long i) { return (int)(((i % Q4_RC) + Q4_RC) % Q4_RC); }
+
+__global__ __launch_bounds__(384) void k_qpsk_pipe4(const QpskParams P, int batch)
 {
     extern __shared__ __align__(16) unsigned char qp_smem[];
-    float2* win = reinterpret_cast<float2*>(qp_smem);                    // [3][64][QPP_PITCH]
-    float2* osym = win + 3 * 64 * QPP_PITCH;                             // [2][64][QPP_OPITCH]
-    float* mm = reinterpret_cast<float*>(osym + 2 * 64 * QPP_OPITCH);    // [129][8]
+    float2* ring = reinterpret_cast<float2*>(qp_smem);                   // [64][Q4_PITCH]
+    float2* ysym = ring + 64 * Q4_PITCH;                                 // [2][64][Q4_OPITCH]
+    float2* osym = ysym + 2 * 64 * Q4_OPITCH;                            // [2][64][Q4_OPITCH]
+    float* mm = reinterpret_cast<float*>(osym + 2 * 64 * Q4_OPITCH);     // [129][8]
     float* th = mm + 129 * 8;                                            // [256]
-    int* ocnt = reinterpret_cast<int*>(th + 256);                        // [2][64]
+    int* ycnt = reinterpret_cast<int*>(th + 256);                        // [2][64]
+    int* ocnt = ycnt + 2 * 64;                                           // [2][64]
     uint64_t* obase = reinterpret_cast<uint64_t*>(ocnt + 2 * 64);        // [2][64]
     uint64_t* oo0 = obase + 2 * 64;                                      // [64]
 
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int b0 = blockIdx.x * 64;
     const int nstreams = min(64, batch - b0);
-    for (int k = tid; k < 129 * 8; k += 256) mm[k] = P.mmse[k];
-    th[tid] = P.tanh_tab[tid];
+    for (int k = tid; k < 129 * 8; k += 384) mm[k] = P.mmse[k];
+    if (tid < 256) th[tid] = P.tanh_tab[tid];
     const uint64_t np0 = P.np0, avail = P.avail;
-    const long long k_first = (long long)(np0 / QPP_W);
-    const long long k_last = avail > np0 ? (long long)((avail - 1) / QPP_W) : k_first - 1;
+    const long long k_first = (long long)(np0 / Q4_W);
+    const long long k_last = avail > np0 ? (long long)((avail - 1) / Q4_W) : k_first - 1;
     const bool active = b0 + lane < batch;
-    QpskState st;
-    if (wv < 2 && active) st = P.st[b0 + lane];
-    else { st = QpskState{}; st.ii = ~0ull >> 1; }
-    if (wv == 1) oo0[lane] = st.oo;
-    auto wbuf = [&](long long k) { return win + (size_t)(((k % 3) + 3) % 3) * 64 * QPP_PITCH; };
+    QpskState* gst = P.st + (b0 + (active ? lane : 0));
+    float2* row = ring + lane * Q4_PITCH;
+
+    // per-wave recurrence state
+    float gain = 0.f, c1_phase = 0.f, c1_freq = 0.f;
+    uint64_t ii = ~0ull >> 1, oo = 0;
+    float mu = 0.f, avg = 0.f, inst = 0.f;
+    float2 x0 = {0.f, 0.f}, x1 = x0, x2 = x0, d0 = x0, d1 = x0, d2 = x0, dprev = x0;
+    float c2_phase = 0.f, c2_freq = 0.f;
+    if (active) {
+        if (wv == 0) gain = gst->gain;
+        if (wv == 1) {
+            c1_phase = gst->c1_phase; c1_freq = gst->c1_freq;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {   // Costas outputs [np0 - 16, np0) of the previous call
+                const int c = q4_col((long long)np0 - 16 + j);
+                const float2 v = gst->hist[j];
+                row[c] = v;
+                if (c < Q4_MIR) row[Q4_RC + c] = v;
+            }
+        }
+        if (wv == 2) {
+            ii = gst->ii; mu = gst->mu; avg = gst->avg; inst = gst->inst;
+            x0 = gst->x0; x1 = gst->x1; x2 = gst->x2; d0 = gst->d0; d1 = gst->d1; d2 = gst->d2;
+        }
+        if (wv == 3) { c2_phase = gst->c2_phase; c2_freq = gst->c2_freq; dprev = gst->dprev; oo = gst->oo; oo0[lane] = oo; }
+    } else if (wv == 3) {
+        oo0[lane] = 0;
+    }
+    if (k_first > k_last) {   // nothing new
+        if (wv == 3 && active) P.counts[(b0 + lane) * 4 + 1] = 0;
+        return;
+    }
 
     auto load_window = [&](long long k, int t, int nthreads) {   // raw samples [max(kW, np0), min((k+1)W, avail))
-        float2* wb = wbuf(k);
-        const long long ia = max((long long)np0, k * QPP_W), ib = min((long long)avail, (k + 1) * QPP_W);
+        const long long ia = max((long long)np0, k * Q4_W), ib = min((long long)avail, (k + 1) * Q4_W);
         const int cnt = (int)(ib - ia);
         if (cnt <= 0) return;
-        const int c0 = (int)(ia - (k * QPP_W - QP_BACK));
+        const int c0 = (int)(k % Q4_NB) * Q4_W + (int)(ia - k * Q4_W);
         const int total = nstreams * cnt;
-        for (int idx = t; idx < total; idx += nthreads) {
-            const int s = idx / cnt, c = idx - s * cnt;
-            wb[s * QPP_PITCH + c0 + c] = P.in.p[(size_t)(b0 + s) * (P.in.mask + 1u) + ((uint32_t)(ia + c) & P.in.mask)];
+        constexpr int BATCH = 8;
+        for (int base = t; base < total; base += nthreads * BATCH) {
+            float2 v[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int idx = base + u * nthreads;
+                v[u] = make_float2(0.f, 0.f);
+                if (idx < total) {
+                    const int s = idx / cnt, c = idx - s * cnt;
+                    v[u] = P.in.p[(size_t)(b0 + s) * (P.in.mask + 1u) + ((uint32_t)(ia + c) & P.in.mask)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int idx = base + u * nthreads;
+                if (idx < total) { const int s = idx / cnt, c = idx - s * cnt; ring[s * Q4_PITCH + c0 + c] = v[u]; }
+            }
         }
     };
     auto flush_window = [&](long long k, int t, int nthreads) {
         const int pb = (int)(k & 1);
-        const float2* ob = osym + (size_t)pb * 64 * QPP_OPITCH;
-        for (int idx = t; idx < nstreams * QPP_OMAX; idx += nthreads) {
-            const int s = idx / QPP_OMAX, j = idx - s * QPP_OMAX;
+        const float2* ob = osym + (size_t)pb * 64 * Q4_OPITCH;
+        for (int idx = t; idx < nstreams * Q4_OMAX; idx += nthreads) {
+            const int s = idx / Q4_OMAX, j = idx - s * Q4_OMAX;
             if (j < ocnt[pb * 64 + s]) {
-                const float2 v = ob[s * QPP_OPITCH + j];
+                const float2 v = ob[s * Q4_OPITCH + j];
                 const uint64_t o = obase[pb * 64 + s] + j;
+                // complex_to_float -> interleave -> multiply_const(48) -> add_const(128) -> float_to_uchar
                 float qa = v.x * P.soft_mul; qa = qa + P.soft_add;
                 float qb = v.y * P.soft_mul; qb = qb + P.soft_add;
                 float ra = rintf(qa), rb = rintf(qb);
@@ -358,69 +432,79 @@ __global__ __launch_bounds__(256) void k_qpsk_pipe(const QpskParams P, int batch
             }
         }
     };
+    auto agc_step = [&](float2 x) {
+        float2 a; a.x = x.x * gain; a.y = x.y * gain;
+        const float tmp = -1.0f + sqrtf(a.x * a.x + a.y * a.y);
+        const float rate = tmp > gain ? 1.0f : 0.1f;          // agc2_cc(attack 1, decay 0.1)
+        gain -= tmp * rate;
+        gain = gain < 0.0f ? 10e-5f : gain;
+        gain = gain > 65536.0f ? 65536.0f : gain;
+        return a;
+    };
+    auto costas1_step = [&](float2 a) {
+        const float2 nco = sincos_rad(-c1_phase);             // (cos, sin)
+        float2 o; o.x = a.x * nco.x - a.y * nco.y; o.y = a.x * nco.y + a.y * nco.x;
+        float e = costas4_snr_error_sel(o, th);
+        e = branchless_clip(e, 1.0f);
+        c1_freq = c1_freq + P.c1_beta * e;
+        c1_phase = c1_phase + c1_freq + P.c1_alpha * e;
+        c1_phase = phase_wrap(c1_phase);
+        c1_freq = clamp_pm1(c1_freq);
+        return o;
+    };
 
     __syncthreads();
-    if (k_first <= k_last) load_window(k_first, tid, 256);
+    load_window(k_first, tid, 384);
     __syncthreads();
     const float SQ = 0.707107f;
-    for (long long t = k_first; t <= k_last + 2; ++t) {
+    for (long long t = k_first; t <= k_last + 4; ++t) {
         if (wv == 0) {
-            if (t <= k_last && active) {      // ---- pass 1 on window t: carry, then agc2_cc -> costas_loop_cc in place
-                float2* row = wbuf(t) + lane * QPP_PITCH;
-                const long long i0 = t * QPP_W - QP_BACK;
-                if (t > k_first) {
-                    const float2* prow = wbuf(t - 1) + lane * QPP_PITCH;
+            if (QRL_Q4_SKIP != 1 && t <= k_last && active) {                      // ---- agc2_cc on window t, in place
+                const int base = (int)(t % Q4_NB) * Q4_W;
+                const int ca = base + (int)(max((long long)np0, t * Q4_W) - t * Q4_W), cb = base + (int)(min((long long)avail, (t + 1) * Q4_W) - t * Q4_W);
+                int c = ca;
+                for (; c + 4 <= cb; c += 4) {
+                    float2 x[4];
 #pragma unroll
-                    for (int j = 0; j < QP_BACK; ++j) row[j] = prow[QPP_W + j];
-                } else {
+                    for (int u = 0; u < 4; ++u) x[u] = row[c + u];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const long long c = (long long)np0 - 16 + j - i0;
-                        if (c >= 0 && c < QPP_COLS) row[c] = st.hist[j];
-                    }
-                }
-                const int ca = (int)(max((long long)np0, t * QPP_W) - i0), cb = (int)(min((long long)avail, (t + 1) * QPP_W) - i0);
-                for (int c = ca; c < cb; ++c) {
-                    const float2 x = row[c];
-                    float2 a; a.x = x.x * st.gain; a.y = x.y * st.gain;
-                    const float tmp = -1.0f + sqrtf(a.x * a.x + a.y * a.y);
-                    float rate = 0.1f;
-                    if (tmp > st.gain) rate = 1.0f;
-                    st.gain -= tmp * rate;
-                    if (st.gain < 0.0f) st.gain = 10e-5f;
-                    if (st.gain > 65536.0f) st.gain = 65536.0f;
-                    const float2 nco = sincos_rad(-st.c1_phase);
-                    float2 o; o.x = a.x * nco.x - a.y * nco.y; o.y = a.x * nco.y + a.y * nco.x;
-                    row[c] = o;
-                    float e = costas4_snr_error(o, th);
-                    e = branchless_clip(e, 1.0f);
-                    st.c1_freq = st.c1_freq + P.c1_beta * e;
-                    st.c1_phase = st.c1_phase + st.c1_freq + P.c1_alpha * e;
-                    st.c1_phase = phase_wrap(st.c1_phase);
-                    if (st.c1_freq > 1.0f) st.c1_freq = 1.0f; else if (st.c1_freq < -1.0f) st.c1_freq = -1.0f;
-                }
-                if (t == k_last) {             // keep the last 16 Costas outputs for the next call
+                    for (int u = 0; u < 4; ++u) x[u] = agc_step(x[u]);
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const long long i = (long long)avail - 16 + j;
-                        const long long c = i - i0;
-                        st.hist[j] = (c >= 0 && i >= 0) ? row[c] : make_float2(0.f, 0.f);
-                    }
+                    for (int u = 0; u < 4; ++u) row[c + u] = x[u];
                 }
+                for (; c < cb; ++c) row[c] = agc_step(row[c]);
             }
         } else if (wv == 1) {
             const long long k = t - 1;
-            if (k >= k_first && k <= k_last) {   // ---- pass 2 on window t - 1
+            if (QRL_Q4_SKIP != 2 && k >= k_first && k <= k_last && active) {      // ---- first Costas loop on window k, in place
+                const int base = (int)(k % Q4_NB) * Q4_W;
+                const int ca = base + (int)(max((long long)np0, k * Q4_W) - k * Q4_W), cb = base + (int)(min((long long)avail, (k + 1) * Q4_W) - k * Q4_W);
+                int c = ca;
+                for (; c + 4 <= cb; c += 4) {
+                    float2 x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = row[c + u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = costas1_step(x[u]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) row[c + u] = x[u];
+                }
+                for (; c < cb; ++c) row[c] = costas1_step(row[c]);
+                if (base == 0) {
+#pragma unroll
+                    for (int j = 0; j < Q4_MIR; ++j) row[Q4_RC + j] = row[j];
+                }
+            }
+        } else if (wv == 2) {
+            const long long k = t - 2;
+            if (k >= k_first && k <= k_last) {                // ---- symbol_sync_cc over window k
                 const int pb = (int)(k & 1);
-                const float2* row = wbuf(k) + lane * QPP_PITCH;
-                float2* orow = osym + (size_t)pb * 64 * QPP_OPITCH + lane * QPP_OPITCH;
-                const long long i0 = k * QPP_W - QP_BACK;
-                const uint64_t wend = (uint64_t)min((long long)avail, (k + 1) * QPP_W);
-                const uint64_t oo_w = st.oo;
+                float2* yrow = ysym + (size_t)pb * 64 * Q4_OPITCH + lane * Q4_OPITCH;
+                const uint64_t wend = (uint64_t)min((long long)avail, (k + 1) * Q4_W);
                 int nsym = 0;
-                while (active && st.ii + 8 <= wend && nsym < QPP_OMAX) {
-                    const int off = (int)((long long)st.ii - i0);
-                    const int imu = (int)rintf(st.mu * 128.0f);
+                int off = active ? (int)(ii % Q4_RC) : 0;
+                while (active && ii + 8 <= wend && nsym < Q4_OMAX) {
+                    const int imu = (int)rintf(mu * 128.0f);
                     const float* tp = mm + imu * 8;
                     float2 y = make_float2(0.f, 0.f);
 #pragma unroll
@@ -429,65 +513,83 @@ __global__ __launch_bounds__(256) void k_qpsk_pipe(const QpskParams P, int batch
                         y.x = fmaf(tp[7 - j], xs.x, y.x);
                         y.y = fmaf(tp[7 - j], xs.y, y.y);
                     }
-                    st.x2 = st.x1; st.x1 = st.x0; st.x0 = y;
-                    st.d2 = st.d1; st.d1 = st.d0;
-                    st.d0.x = y.x > 0.f ? SQ : -SQ; st.d0.y = y.y > 0.f ? SQ : -SQ;
-                    float e;
-                    {
-                        const float ar = st.x0.x - st.x2.x, ai = st.x0.y - st.x2.y;
-                        const float br = st.d0.x - st.d2.x, bi = st.d0.y - st.d2.y;
-                        const float u = (ar * st.d1.x + ai * st.d1.y) - (br * st.x1.x + bi * st.x1.y);
-                        e = branchless_clip(u, 1.0f);
-                    }
-                    st.avg = st.avg + P.ss_beta * e;
-                    if (st.avg > P.ss_maxp) st.avg = P.ss_maxp; else if (st.avg < P.ss_minp) st.avg = P.ss_minp;
-                    st.inst = st.avg + P.ss_alpha * e;
-                    if (st.inst <= 0.f) st.inst = st.avg;
-                    const float ph = st.mu + st.inst;
+                    x2 = x1; x1 = x0; x0 = y;
+                    d2 = d1; d1 = d0;
+                    d0.x = y.x > 0.f ? SQ : -SQ; d0.y = y.y > 0.f ? SQ : -SQ;
+                    const float ar = x0.x - x2.x, ai = x0.y - x2.y;
+                    const float br = d0.x - d2.x, bi = d0.y - d2.y;
+                    const float u = (ar * d1.x + ai * d1.y) - (br * x1.x + bi * x1.y);
+                    const float e = branchless_clip(u, 1.0f);
+                    avg = avg + P.ss_beta * e;
+                    avg = avg > P.ss_maxp ? P.ss_maxp : (avg < P.ss_minp ? P.ss_minp : avg);
+                    inst = avg + P.ss_alpha * e;
+                    inst = inst <= 0.f ? avg : inst;
+                    const float ph = mu + inst;
                     const float fl = floorf(ph);
-                    st.mu = ph - fl;
-                    st.ii += (uint64_t)(int)fl;
-                    const float2 nco = sincos_rad(-st.c2_phase);
-                    float2 o; o.x = y.x * nco.x - y.y * nco.y; o.y = y.x * nco.y + y.y * nco.x;
-                    float e2 = costas4_snr_error(o, th);
-                    e2 = branchless_clip(e2, 1.0f);
-                    st.c2_freq = st.c2_freq + P.c2_beta * e2;
-                    st.c2_phase = st.c2_phase + st.c2_freq + P.c2_alpha * e2;
-                    st.c2_phase = phase_wrap(st.c2_phase);
-                    if (st.c2_freq > 1.0f) st.c2_freq = 1.0f; else if (st.c2_freq < -1.0f) st.c2_freq = -1.0f;
-                    float2 dp; dp.x = o.x * st.dprev.x + o.y * st.dprev.y; dp.y = o.y * st.dprev.x - o.x * st.dprev.y;
-                    st.dprev = o;
-                    float2 v; v.x = dp.x * P.rot.x - dp.y * P.rot.y; v.y = dp.x * P.rot.y + dp.y * P.rot.x;
-                    orow[nsym] = v;
+                    mu = ph - fl;
+                    const int adv = (int)fl;
+                    ii += (uint64_t)adv;
+                    off += adv;
+                    off = off >= Q4_RC ? off - Q4_RC : off;
+                    yrow[nsym] = y;
                     nsym++;
-                    st.oo++;
                 }
-                ocnt[pb * 64 + lane] = nsym;
-                obase[pb * 64 + lane] = oo_w;
+                ycnt[pb * 64 + lane] = nsym;
+            }
+        } else if (wv == 3) {
+            const long long k = t - 3;
+            if (k >= k_first && k <= k_last) {                // ---- second Costas loop, diff_phasor, rotation on the symbols of window k
+                const int pb = (int)(k & 1);
+                const float2* yrow = ysym + (size_t)pb * 64 * Q4_OPITCH + lane * Q4_OPITCH;
+                float2* orow = osym + (size_t)pb * 64 * Q4_OPITCH + lane * Q4_OPITCH;
+                const int n = ycnt[pb * 64 + lane];
+                obase[pb * 64 + lane] = oo;
+                ocnt[pb * 64 + lane] = n;
+                for (int j = 0; j < n; ++j) {
+                    const float2 y = yrow[j];
+                    const float2 nco = sincos_rad(-c2_phase);
+                    float2 o; o.x = y.x * nco.x - y.y * nco.y; o.y = y.x * nco.y + y.y * nco.x;
+                    float e2 = costas4_snr_error_sel(o, th);
+                    e2 = branchless_clip(e2, 1.0f);
+                    c2_freq = c2_freq + P.c2_beta * e2;
+                    c2_phase = c2_phase + c2_freq + P.c2_alpha * e2;
+                    c2_phase = phase_wrap(c2_phase);
+                    c2_freq = clamp_pm1(c2_freq);
+                    float2 dp; dp.x = o.x * dprev.x + o.y * dprev.y; dp.y = o.y * dprev.x - o.x * dprev.y;
+                    dprev = o;
+                    float2 v; v.x = dp.x * P.rot.x - dp.y * P.rot.y; v.y = dp.x * P.rot.y + dp.y * P.rot.x;
+                    orow[j] = v;
+                }
+                oo += (uint64_t)n;
             }
         } else {
-            if (t + 1 <= k_last) load_window(t + 1, tid - 128, 128);
-            if (t - 2 >= k_first && t - 2 <= k_last) flush_window(t - 2, tid - 128, 128);
+            if (t + 1 <= k_last) load_window(t + 1, tid - 256, 128);
+            if (t - 4 >= k_first && t - 4 <= k_last) flush_window(t - 4, tid - 256, 128);
         }
         __syncthreads();
     }
-    if (active && wv == 0) {
-        QpskState& g = P.st[b0 + lane];
-        g.gain = st.gain; g.c1_phase = st.c1_phase; g.c1_freq = st.c1_freq;
+    if (!active) return;
+    if (wv == 0) gst->gain = gain;
+    if (wv == 1) {
+        gst->c1_phase = c1_phase; gst->c1_freq = c1_freq;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) g.hist[j] = st.hist[j];
+        for (int j = 0; j < 16; ++j) {     // the last 16 Costas outputs for the next call
+            const long long i = (long long)avail - 16 + j;
+            gst->hist[j] = i >= 0 ? row[q4_col(i)] : make_float2(0.f, 0.f);
+        }
     }
-    if (active && wv == 1) {
-        QpskState& g = P.st[b0 + lane];
-        g.ii = st.ii; g.oo = st.oo; g.mu = st.mu; g.avg = st.avg; g.inst = st.inst;
-        g.x0 = st.x0; g.x1 = st.x1; g.x2 = st.x2; g.d0 = st.d0; g.d1 = st.d1; g.d2 = st.d2;
-        g.c2_phase = st.c2_phase; g.c2_freq = st.c2_freq; g.dprev = st.dprev;
-        P.counts[(b0 + lane) * 4 + 1] = (uint32_t)(st.oo - oo0[lane]);
+    if (wv == 2) {
+        gst->ii = ii; gst->mu = mu; gst->avg = avg; gst->inst = inst;
+        gst->x0 = x0; gst->x1 = x1; gst->x2 = x2; gst->d0 = d0; gst->d1 = d1; gst->d2 = d2;
+    }
+    if (wv == 3) {
+        gst->c2_phase = c2_phase; gst->c2_freq = c2_freq; gst->dprev = dprev; gst->oo = oo;
+        P.counts[(b0 + lane) * 4 + 1] = (uint32_t)(oo - oo0[lane]);
     }
 }
-static size_t qpsk_pipe_lds_bytes()
+static size_t qpsk_pipe4_lds_bytes()
 {
-    return (size_t)(3 * 64 * QPP_PITCH + 2 * 64 * QPP_OPITCH) * sizeof(float2) + (129 * 8 + 256) * sizeof(float) + 2 * 64 * sizeof(int) +
+    return (size_t)(64 * Q4_PITCH + 4 * 64 * Q4_OPITCH) * sizeof(float2) + (129 * 8 + 256) * sizeof(float) + 4 * 64 * sizeof(int) +
            (2 * 64 + 64) * sizeof(uint64_t);
 }
 
@@ -499,9 +601,9 @@ static size_t qpsk_lds_bytes()
 
 void launch_qpsk_loops(const QpskParams& p, int batch, hipStream_t s)
 {
-    if (p.mode == 0) {   // gr_demod_qpsk chain: two-wave pipeline (pass 1 / pass 2 on separate waves)
-        if (dyn_lds_limit(reinterpret_cast<const void*>(k_qpsk_pipe), (int)qpsk_pipe_lds_bytes()) != hipSuccess) return;
-        hipLaunchKernelGGL(k_qpsk_pipe, dim3((batch + 63) / 64), dim3(256), qpsk_pipe_lds_bytes(), s, p, batch);
+    if (p.mode == 0) {   // gr_demod_qpsk chain: four-stage wave pipeline
+        if (dyn_lds_limit(reinterpret_cast<const void*>(k_qpsk_pipe4), (int)qpsk_pipe4_lds_bytes()) != hipSuccess) return;
+        hipLaunchKernelGGL(k_qpsk_pipe4, dim3((batch + 63) / 64), dim3(384), qpsk_pipe4_lds_bytes(), s, p, batch);
         return;
     }
     const void* kp = p.mode == 2 ? reinterpret_cast<const void*>(k_qpsk_loops<2>) : reinterpret_cast<const void*>(k_qpsk_loops<1>);

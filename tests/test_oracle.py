@@ -220,6 +220,19 @@ def test_pl_contract_matches_float64_definition(decim, nt_scale):
     assert np.array_equal(orc.decim_auto(x, h, decim).view(np.float32), y.view(np.float32))
 
 
+def test_pl_contract_two_samples_per_lane_matches_float64_definition():
+    """The 100:1 front end (4 181 taps at 100 Msps): 50 lane slots of two neighbouring samples each (k_decim_plx<2, 1, 42>)."""
+    rng = np.random.default_rng(191)
+    h = orc.low_pass(1, 100e6, 480e3, 100e3, BH)
+    x = (rng.standard_normal(40 * 100 + h.size) + 1j * rng.standard_normal(40 * 100 + h.size)).astype(np.complex64)
+    assert orc.lib.orc_decim_uses_pl(h.size, 100) and (h.size + 99) // 100 == 42
+    y = orc.decim_fir_ccf_pl(x, h, 100)
+    assert _definition_error(y, x, h, 100) < 1e-5
+    assert np.array_equal(orc.decim_auto(x, h, 100).view(np.float32), y.view(np.float32))
+    # the rule leaves the other front ends where they were
+    assert not orc.lib.orc_decim_uses_pl(orc.low_pass(1, 25e6, 480e3, 100e3, BH).size, 25)
+
+
 def test_cpu_baseline_simd_decimator_matches_definition():
     """The AVX2 dot-product decimator the bench times as CPU baseline (not a checker) computes the same filter."""
     rng = np.random.default_rng(17)
