@@ -146,8 +146,14 @@ struct qrl_demod {
     // the serial tail (symbol sync + Viterbi: a handful of waves) runs on its own stream so that it overlaps the
     // HBM-facing kernels of the NEXT call instead of idling 250 CUs
     hipStream_t tail = nullptr;
+    // QPSK / BPSK / 4FSK-discriminator families: the recursive chain (k_qpsk_*: latency bound, 64 streams per workgroup) runs on
+    // `tail`, the Viterbi decoder on `fecs`: call k's decoder, call k + 1's recursion and call k + 2's front end run side by side.
+    // The rings between them hold two calls; ev_q / ev_fec guard their reuse two calls later.
+    hipStream_t fecs = nullptr;
+    hipEvent_t ev_q[2] = {nullptr, nullptr}, ev_fec[2] = {nullptr, nullptr}; bool q_valid[2] = {false, false};
+    DevBuf<uint64_t> qp_snap;   // [2][B] symbols produced up to the end of call k (slot k & 1): what that call's decoder may read
     hipEvent_t ev_ff = nullptr, ev_tail = nullptr;
-    hipEvent_t ev_user[2] = {nullptr, nullptr};   // qrl_demod_stream_wait
+    hipEvent_t ev_user[3] = {nullptr, nullptr, nullptr};   // qrl_demod_stream_wait
     bool tail_pending = false;
     // overlapped mode (2FSK / GMSK / 4FSK families): everything behind the first decimated ring runs on the tail stream while
     // the front end of the NEXT call already runs on the main stream; ring s2 holds two calls, ev_tail2 guards its reuse
@@ -199,6 +205,9 @@ struct qrl_demod {
         if (ev_tail) (void)hipEventDestroy(ev_tail);
         for (auto e : ev_user) if (e) (void)hipEventDestroy(e);
         for (auto e : ev_tail2) if (e) (void)hipEventDestroy(e);
+        for (auto e : ev_q) if (e) (void)hipEventDestroy(e);
+        for (auto e : ev_fec) if (e) (void)hipEventDestroy(e);
+        if (fecs) (void)hipStreamDestroy(fecs);
         if (tail) (void)hipStreamDestroy(tail);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
@@ -209,6 +218,13 @@ struct qrl_demod {
         if (!rot_lo.p) return rot_lo.upload(lo);
         return hipMemcpy(rot_lo.p, lo.data(), 512 * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess ? QRL_OK : QRL_ERR_HIP;
     }
+    int sync_all() {
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipStreamSynchronize(tail));
+        HIPCHK(hipStreamSynchronize(fecs));
+        return QRL_OK;
+    }
+    bool loops_family() const { return fam == F_QPSK || fam == F_BPSK || fsk4_disc; }
     int init_state();
     int build();
     int process(const float* iq, size_t stride, size_t n, const qrl_demod_out* out);
@@ -238,6 +254,8 @@ int qrl_demod::init_state()
     std::vector<FecState> fs((size_t)cfg.batch * 2);
     for (auto& f : fs) { f.consumed = 0; f.start_state = 0; f.last_bits = 0xFE; }  // descrambler seed 0x7F, newest bit first
     if (hipMemcpy(fec_st.p, fs.data(), fs.size() * sizeof(FecState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
+    if (qp_snap.p && (r = qp_snap.zero())) return r;
+    q_valid[0] = q_valid[1] = false; tail2_valid[0] = tail2_valid[1] = false; tail_pending = false; call_no = 0;
     n_in = n1 = n2 = 0;
     rot_acc = 0; rot_nbase = 0; hist_flip = false;
     return QRL_OK;
@@ -331,12 +349,12 @@ int qrl_demod::build()
     // stretches from 7.1 to 9.0 ms -- the recursion kernels are only placed once the front end's workgroups drain.
     overlap_capable = fam == F_2FSK;
     overlap = false;
-    s2_mask = pow2_at_least((overlap_capable ? 2 : 1) * max2 + (fam == F_DMR ? 2048 : 1024)) - 1;   // DMR: the DMO slicer looks back 1440 samples   // history needs: <= 501 taps downstream; overlapped mode: two calls
+    s2_mask = pow2_at_least((overlap_capable || loops_family() ? 2 : 1) * max2 + (fam == F_DMR ? 2048 : 1024)) - 1;   // DMR: the DMO slicer looks back 1440 samples   // history needs: <= 501 taps downstream; overlapped mode: two calls
     const size_t ring2 = (size_t)B * (s2_mask + 1);
     if ((r = s2.alloc(ring2)) || (r = s2f.alloc(ring2)) || (r = s2d.alloc(ring2)) || (r = s3.alloc(ring2))) return r;
     if ((fam == F_2FSK || fam == F_BPSK || (fam == F_QPSK && qpsk_fll)) && (r = s2l.alloc(ring2))) return r;
     const size_t maxsym = max2 / (size_t)(sps_eff > 1 ? sps_eff - 1 : 1) + 8;
-    soft_mask = pow2_at_least((fam == F_QPSK || fam == F_4FSK ? 2 : 1) * maxsym + 512) - 1;
+    soft_mask = pow2_at_least((loops_family() ? 2 : 1) * (fam == F_QPSK || fam == F_4FSK ? 2 : 1) * maxsym + 512) - 1;   // loops families: two calls (decoder of call k beside the recursion of call k + 1)
     if ((r = soft.alloc((size_t)B * (soft_mask + 1)))) return r;
 
     // --- decimated-rate filters
@@ -454,6 +472,7 @@ int qrl_demod::build()
         ss_maxp = (float)sps_eff + 0.05f; ss_minp = (float)sps_eff - 0.05f;
     }
     if ((r = ss_st.alloc(B)) || (r = fec_st.alloc((size_t)B * 2)) || (r = counts_scratch.alloc((size_t)B * 4))) return r;
+    if (loops_family() && (r = qp_snap.alloc((size_t)B * 2))) return r;
     return init_state();
 }
 
@@ -471,6 +490,8 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
     } else {
         HIPCHK(hipMemsetAsync(counts, 0, (size_t)B * 4 * sizeof(uint32_t), stream));
     }
+    // loops families: the rings the recursion reads hold two calls; call k - 2's recursion must be through before they are rewritten
+    if (loops_family() && q_valid[slot]) HIPCHK(hipStreamWaitEvent(stream, ev_q[slot], 0));
     const float2* in = reinterpret_cast<const float2*>(iq);
     const float2* hist_old = hist_flip ? hist_b.p : hist_a.p;
     float2* hist_new = hist_flip ? hist_a.p : hist_b.p;
@@ -623,14 +644,23 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         q.port = side && out->constellation ? reinterpret_cast<float2*>(out->constellation) : nullptr;
         q.port_cap = side ? out->constellation_cap : 0;
         q.counts = counts;
-        launch_qpsk_loops(q, B, stream);
+        q.oo_snap = qp_snap.p + (size_t)slot * B;
+        // recursion on `tail` behind this call's feed-forward kernels, decoder on `fecs` behind the recursion
+        HIPCHK(hipEventRecord(ev_ff, stream));
+        HIPCHK(hipStreamWaitEvent(tail, ev_ff, 0));
+        if (q_valid[slot]) HIPCHK(hipStreamWaitEvent(tail, ev_fec[slot], 0));   // the soft ring holds two calls: decoder of call k - 2 done
+        launch_qpsk_loops(q, B, tail);
+        HIPCHK(hipEventRecord(ev_q[slot], tail));
+        HIPCHK(hipStreamWaitEvent(fecs, ev_q[slot], 0));
         FecParams f{};
         f.soft = RingB{soft.p, soft_mask};
-        f.avail = &qp_st.p[0].oo; f.avail_stride = sizeof(QpskState); f.avail_mul = fam == F_BPSK ? 1 : 2;
+        f.avail = q.oo_snap; f.avail_stride = sizeof(uint64_t); f.avail_mul = fam == F_BPSK ? 1 : 2;
         f.st = fec_st.p;
         f.bits_a = out ? out->bits_a : nullptr; f.bits_b = fam == F_BPSK && out ? out->bits_b : nullptr; f.bits_cap = out ? out->bits_cap : 0;
         f.counts = counts; f.branches = fam == F_BPSK ? 2 : 1;
-        launch_fec(f, B, stream);
+        launch_fec(f, B, fecs);
+        HIPCHK(hipEventRecord(ev_fec[slot], fecs));
+        q_valid[slot] = true;
     } else {
         SymSyncParams s{};
         s.in = r3; s.avail = n2_1; s.soft = RingB{soft.p, soft_mask}; s.st = ss_st.p; s.mmse = mmse_tab.p;
@@ -762,29 +792,30 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         HIPCHK(hipStreamCreateWithPriority(&d->tail, hipStreamNonBlocking, hi));   // (low / normal priority measured: no difference)
+        HIPCHK(hipStreamCreateWithPriority(&d->fecs, hipStreamNonBlocking, hi));
     }
     HIPCHK(hipEventCreateWithFlags(&d->ev_ff, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&d->ev_tail, hipEventDisableTiming));
     for (auto& e : d->ev_tail2) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : d->ev_q) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : d->ev_fec) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     int r = d->build();
     if (r) return r;
     *outp = d.release();
     return QRL_OK;
 }
-void qrl_demod_destroy(qrl_demod* d) { if (d) { (void)hipStreamSynchronize(d->stream); (void)hipStreamSynchronize(d->tail); delete d; } }
+void qrl_demod_destroy(qrl_demod* d) { if (d) { (void)d->sync_all(); delete d; } }
 
 int qrl_demod_reset(qrl_demod* d)
 {
     if (!d) return QRL_ERR_ARG;
-    HIPCHK(hipStreamSynchronize(d->stream));
-    HIPCHK(hipStreamSynchronize(d->tail));
+    if (int rs = d->sync_all()) return rs;
     return d->init_state();
 }
 int qrl_demod_set_carrier_offset(qrl_demod* d, double hz)
 {
     if (!d) return QRL_ERR_ARG;
-    HIPCHK(hipStreamSynchronize(d->stream));
-    HIPCHK(hipStreamSynchronize(d->tail));
+    if (int rs = d->sync_all()) return rs;
     d->rot_acc += (d->n_in - d->rot_nbase) * d->rot_inc;  // phase-continuous
     d->rot_nbase = d->n_in;
     d->cfg.carrier_offset_hz = hz;
@@ -798,16 +829,15 @@ int qrl_demod_stream_wait(qrl_demod* d, void* hip_stream)
     if (!d->ev_user[0]) for (auto& e : d->ev_user) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventRecord(d->ev_user[0], d->stream));
     HIPCHK(hipEventRecord(d->ev_user[1], d->tail));
-    HIPCHK(hipStreamWaitEvent(user, d->ev_user[0], 0));
-    HIPCHK(hipStreamWaitEvent(user, d->ev_user[1], 0));
+    HIPCHK(hipEventRecord(d->ev_user[2], d->fecs));
+    for (auto e : d->ev_user) HIPCHK(hipStreamWaitEvent(user, e, 0));
     return QRL_OK;
 }
 int qrl_demod_set_dmo_output(qrl_demod* d, uint8_t* frames, size_t cap_frames, uint32_t* counts)
 {
     if (!d) return QRL_ERR_ARG;
     if (d->fam != qrl_demod::F_DMR) return qrl_set_error(QRL_ERR_ARG, "the DMO slicer sits behind port 3 of gr_demod_dmr: QRL_MODEM_DMR only");
-    HIPCHK(hipStreamSynchronize(d->stream));
-    HIPCHK(hipStreamSynchronize(d->tail));
+    if (int rs = d->sync_all()) return rs;
     if (!frames) { d->dmo_out = nullptr; return QRL_OK; }
     if (!counts || cap_frames < 1 || cap_frames > 0xFFFFFFFFu) return QRL_ERR_ARG;
     int r;
@@ -826,8 +856,7 @@ int qrl_demod_set_option(qrl_demod* d, int option, int value)
     switch (option) {
     case QRL_OPT_OVERLAP:
         if (value != 0 && !d->overlap_capable) return qrl_set_error(QRL_ERR_ARG, "overlapped mode exists for the 2FSK family only");
-        HIPCHK(hipStreamSynchronize(d->stream));
-        HIPCHK(hipStreamSynchronize(d->tail));
+        if (int rs = d->sync_all()) return rs;
         d->overlap = value != 0;
         d->tail2_valid[0] = d->tail2_valid[1] = false;
         return QRL_OK;
@@ -855,8 +884,7 @@ int qrl_demod_process(qrl_demod* d, const float* iq, size_t stride, size_t n, co
 int qrl_demod_sync(qrl_demod* d)
 {
     if (!d) return QRL_ERR_ARG;
-    HIPCHK(hipStreamSynchronize(d->stream));
-    HIPCHK(hipStreamSynchronize(d->tail));
+    if (int rs = d->sync_all()) return rs;
     return QRL_OK;
 }
 void* qrl_demod_stream(qrl_demod* d) { return d ? d->stream : nullptr; }
@@ -870,8 +898,7 @@ int qrl_demod_profile(qrl_demod* d, int enable)
 int qrl_demod_profile_read(qrl_demod* d, double* kernel_ms, uint64_t* launches, const char** kernel_name)
 {
     if (!d) return QRL_ERR_ARG;
-    HIPCHK(hipStreamSynchronize(d->stream));
-    HIPCHK(hipStreamSynchronize(d->tail));
+    if (int rs = d->sync_all()) return rs;
     double total = 0;
     for (auto& e : d->prof_events) {
         float ms = 0;
@@ -906,8 +933,7 @@ int qrl_demod_process_host(qrl_demod* d, const float* iq_host, size_t stride, si
     qrl_demod_out o{};
     o.bits_a = ba.p; o.bits_b = bb.p; o.bits_cap = bits_cap; o.counts = cnt.p;
     if ((r = d->process(reinterpret_cast<const float*>(iq.p), st, n, &o))) return r;
-    HIPCHK(hipStreamSynchronize(d->stream));
-    HIPCHK(hipStreamSynchronize(d->tail));
+    if (int rs = d->sync_all()) return rs;
     if (bits_a_host) HIPCHK(hipMemcpy(bits_a_host, ba.p, B * bits_cap, hipMemcpyDeviceToHost));
     if (bits_b_host) HIPCHK(hipMemcpy(bits_b_host, bb.p, B * bits_cap, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(counts_host, cnt.p, B * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));

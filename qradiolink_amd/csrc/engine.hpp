@@ -142,6 +142,7 @@ struct QpskParams {
                                      // 2: symbol_sync_cc alone on the 4-level rect constellation (gr_demod_4fsk non-FM branch)
     float cr_gain_omega, cr_gain_mu, cr_omega_mid, cr_omega_lim;   // mode 1
     float2* port; size_t port_cap; uint32_t* counts;   // constellation port (this call), counts[b*4+1]
+    uint64_t* oo_snap;               // [batch] symbols produced up to the end of this call (what this call's decoder may consume)
 };
 void launch_qpsk_loops(const QpskParams& p, int batch, hipStream_t s);
 

@@ -236,7 +236,8 @@ void k_decim_pl(const DecimParams P_)
 //  k_decim_plx<E, R, U>: the same register-resident scheme for the front ends whose decimation is not one sample per lane:
 //    E = 2, R = 1   64 < D <= 128 (the 100:1 front end of a 100 Msps device, 4 181 taps): a block is D samples, lane l owns the
 //                   samples 2l and 2l + 1 of every block (slot(i) = ((i - 1) mod D) / 2 of the "pl" contract);
-//    E = 1, R = 2   22 <= D <= 32 (the 25:1 front end): a block is 2 D samples and completes two outputs.
+//    (E = 1, R = 2, the 25:1 front end as blocks of 2 D samples, was measured too: 2.47 ms on C2 against 1.9 ms for the MFMA
+//    kernel -- one sample per lane and block pays the per-block overhead twice; the rule keeps 25:1 on the m16 contract.)
 //  Block c = samples (c-1) D' + 1 .. c D' (D' = R D).  The sample r = E l + e of block c meets output m = (c-1) R + u with tap
 //  h[u D - 1 - r], u = 1 .. U = floor((nt + D' - 1) / D); the accumulators are a sliding window of 16 - R + U registers that moves
 //  down by 16 after every 16 outputs.  With 84 taps + 114 accumulators + the prefetch ring a wave needs > 256 VGPRs, so one wave

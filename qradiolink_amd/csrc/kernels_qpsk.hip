@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
     if (active) {
         P.st[b0 + lane] = st;
         P.counts[(b0 + lane) * 4 + 1] = (uint32_t)(st.oo - oo0[lane]);
+        if (P.oo_snap) P.oo_snap[b0 + lane] = st.oo;
     }
 }
 
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(384) void k_qpsk_pipe4(const QpskParams P, int batc
         oo0[lane] = 0;
     }
     if (k_first > k_last) {   // nothing new
-        if (wv == 3 && active) P.counts[(b0 + lane) * 4 + 1] = 0;
+        if (wv == 3 && active) { P.counts[(b0 + lane) * 4 + 1] = 0; if (P.oo_snap) P.oo_snap[b0 + lane] = oo; }
         return;
     }
 
@@ -585,6 +586,7 @@ __global__ __launch_bounds__(384) void k_qpsk_pipe4(const QpskParams P, int batc
     if (wv == 3) {
         gst->c2_phase = c2_phase; gst->c2_freq = c2_freq; gst->dprev = dprev; gst->oo = oo;
         P.counts[(b0 + lane) * 4 + 1] = (uint32_t)(oo - oo0[lane]);
+        if (P.oo_snap) P.oo_snap[b0 + lane] = oo;
     }
 }
 static size_t qpsk_pipe4_lds_bytes()

@@ -229,8 +229,11 @@ def test_pl_contract_two_samples_per_lane_matches_float64_definition():
     y = orc.decim_fir_ccf_pl(x, h, 100)
     assert _definition_error(y, x, h, 100) < 1e-5
     assert np.array_equal(orc.decim_auto(x, h, 100).view(np.float32), y.view(np.float32))
-    # the rule leaves the other front ends where they were
-    assert not orc.lib.orc_decim_uses_pl(orc.low_pass(1, 25e6, 480e3, 100e3, BH).size, 25)
+
+
+def test_pl_rule_leaves_the_other_front_ends_on_m16():
+    for fs, d in ((25e6, 25), (20e6, 20), (10e6, 10), (50e6, 50)):
+        assert not orc.lib.orc_decim_uses_pl(orc.low_pass(1, fs, 480e3, 100e3, BH).size, d)
 
 
 def test_cpu_baseline_simd_decimator_matches_definition():
