@@ -212,8 +212,10 @@ def run_c5(args, torch, q, ctx, dev, rank, world):
     """C5: full duplex -- QPSK-250k modulator and QPSK-250k demodulator handles on their own HIP streams, calls interleaved without
     synchronisation (BASELINE config 5; reference src/radiocontroller.cpp:2043-2078 runs the two top blocks concurrently)."""
     import sig
-    B = args.batch or 4096
-    n = (args.nsamp or (1 << 16)) & ~1
+    # 16 384 streams x 16 384 samples per call: the recursive QPSK chain is a serial walk over a call's samples of one stream (about
+    # 0.2 us per 500 ksps sample whatever the batch), so the same number of samples as more, shorter streams is what fills the chip
+    B = args.batch or 16384
+    n = (args.nsamp or (1 << 14)) & ~1
     nbytes = n // 32                                  # the TX produces as many 1 Msps samples as the RX consumes
     base, _ = sig.make_stream("qpsk250k", nframes=3, device_rate=1000000, seed=3 + rank, amp=0.05)
     base = np.tile(base, -(-n // base.size))[:n]

@@ -177,9 +177,54 @@ __global__ __launch_bounds__(256) void k_tx_interp(const TxInterpParams P)
     P.out[(size_t)b * P.out_stride + t] = make_float2(ar, ai);
 }
 
+// Small interpolation factors (QPSK-250k: 4 samples per symbol, 61 taps): one thread per SYMBOL writes its I output samples.
+// The workgroup stages the constellation points of its 256 symbols + J - 1 predecessors and the taps in LDS once, instead of one
+// 64-bit division, ~16 byte loads and ~16 table loads per output sample (C5: 4.7 ms for 268 M samples, 0.45 TB/s of stores).
+// Same fmaf chain per output (j ascending); the zero-padded taps / the zero symbols in front of the stream add +0.
+template <int I, int J>
+__global__ __launch_bounds__(256) void k_tx_interp_sym(const TxInterpParams P)
+{
+    __shared__ float2 xs[256 + J];
+    __shared__ float taps[I * J];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int k = tid; k < I * J; k += 256) taps[k] = k < P.nt ? P.taps[k] : 0.f;
+    const uint64_t cs = P.n0 / (uint64_t)I;                       // first symbol of this call (n0 is a multiple of I)
+    const uint32_t nsym = P.count / (uint32_t)I;
+    const uint32_t s0 = blockIdx.x * 256u;
+    const uint8_t* ring = P.sym.p + (size_t)b * (P.sym.mask + 1u);
+    for (int i = tid; i < 256 + J - 1; i += 256) {                // xs[i] = symbol cs + s0 - (J - 1) + i
+        const int64_t c = (int64_t)(cs + s0) - (J - 1) + i;
+        xs[i] = c >= 0 ? P.table[ring[(uint32_t)c & P.sym.mask] & 3u] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    if (s0 + tid >= nsym) return;
+    float2* o = P.out + (size_t)b * P.out_stride + (size_t)(s0 + tid) * I;
+    float2 y[I];
+#pragma unroll
+    for (int ph = 0; ph < I; ++ph) {
+        float ar = 0.f, ai = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float h = taps[ph + j * I];
+            const float2 x = xs[J - 1 + tid - j];
+            ar = fmaf(h, x.x, ar);
+            ai = fmaf(h, x.y, ai);
+        }
+        ar *= P.amp; ai *= P.amp;                                 // multiply_const_cc(0.6)
+        ar *= P.bb_gain; ai *= P.bb_gain;                         // multiply_const_cc(bb_gain)
+        y[ph] = make_float2(ar, ai);
+    }
+#pragma unroll
+    for (int ph = 0; ph < I; ++ph) o[ph] = y[ph];
+}
+
 void launch_tx_interp(const TxInterpParams& p, int batch, hipStream_t s)
 {
     if (!p.count) return;
+    if (p.interp == 4 && p.nt <= 64 && p.n0 % 4 == 0 && p.count % 4 == 0) {
+        hipLaunchKernelGGL((k_tx_interp_sym<4, 16>), dim3((p.count / 4 + 255) / 256, batch), dim3(256), 0, s, p);
+        return;
+    }
     hipLaunchKernelGGL(k_tx_interp, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
 }
 
