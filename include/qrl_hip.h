@@ -294,6 +294,47 @@ int qrl_framesync_process(qrl_framesync* f, const uint8_t* bits, size_t stride, 
                           uint8_t* out, size_t out_cap, uint32_t* out_counts);
 int qrl_framesync_sync(qrl_framesync* f);
 
+/* ---- RSSI side output (reference src/gr/rssi_block.cpp:25-50; wired src/gr/gr_demod_base.cpp:199-200: port 0 of the current
+ * demodulator -> rssi_valve -> rssi_block -> probe_signal_f) -----------------------------------------------------------------
+ * rssi_block(level): complex_to_mag_squared -> moving_average_ff(2000, 1, 2000) -> single_pole_iir_filter_ff(0.04) -> nlog10_ff
+ * -> multiply_const_ff(10) -> add_const_ff(level).  qrl_rssi_process consumes the port-0 items of one qrl_demod_process call
+ * (filtered[b*stride + i] cf32 pairs, i < counts[b*count_stride], counts == NULL: n items for every stream; device memory) and
+ * writes one dB value per item to out[b*out_cap + i] (may be NULL) and the latest value of every stream to last[b] (what
+ * probe_signal_f::level() returns; may be NULL).  State (2000-item window, IIR) carries across calls; results do not depend on
+ * how the stream is cut into calls (the moving average restarts its running sum at every absolute multiple of 2000 items: the
+ * reference's block does so at every work() call of at most max_iter = 2000 items). */
+typedef struct qrl_rssi qrl_rssi;
+int qrl_rssi_create(qrl_ctx* ctx, int batch, float level, void* hip_stream, qrl_rssi** out);
+void qrl_rssi_destroy(qrl_rssi* r);
+int qrl_rssi_reset(qrl_rssi* r);
+int qrl_rssi_set_level(qrl_rssi* r, float level);   /* rssi_block::set_level (:47-50) */
+int qrl_rssi_process(qrl_rssi* r, const float* filtered, size_t stride, size_t n, const uint32_t* counts, size_t count_stride,
+                     float* out, size_t out_cap, float* last, uint32_t* out_counts);
+int qrl_rssi_sync(qrl_rssi* r);
+void* qrl_rssi_stream(qrl_rssi* r);
+
+/* ---- spectrum side output (reference src/gr/rx_fft.cpp:44-213, instance make_rx_fft_c(32768, WIN_BLACKMAN_HARRIS)
+ * src/gr/gr_demod_base.cpp:166,185 on the device-rate IQ) ---------------------------------------------------------------------
+ * qrl_fft_process = rx_fft_c::work on n new samples of every stream: while enabled and nobody is behind on reading (d_push == 0)
+ * the samples are multiplied by the window into the FFT buffer; when the buffer is full the next sample triggers the transform
+ * (hipFFT, batched over the streams) and volk_32fc_s32f_power_spectrum_32f (10 log10 |X / N|^2), after which the block stops
+ * taking samples until qrl_fft_get_fft_data has been called.  qrl_fft_get_fft_data = rx_fft_c::get_fft_data: the spectrum with its
+ * halves swapped (negative frequencies first) to fft_points[b*out_stride + i] (device), *fft_size = 0 when nothing is ready.
+ * wintype: gr::fft::window::win_type (0 Hamming, 1 Hann, 2 Blackman, 3 rectangular, 4 Kaiser(6.76), 5 Blackman-Harris,
+ * 6 Bartlett, 7 flat top; anything else -> Hamming, :200-203). */
+typedef struct qrl_fft qrl_fft;
+int qrl_fft_create(qrl_ctx* ctx, int batch, unsigned fftsize, int wintype, void* hip_stream, qrl_fft** out);
+void qrl_fft_destroy(qrl_fft* f);
+int qrl_fft_set_enabled(qrl_fft* f, int enabled);            /* :102-107 (a new block is disabled, :58) */
+int qrl_fft_set_fft_size(qrl_fft* f, unsigned fftsize);      /* :134-163 */
+unsigned qrl_fft_get_fft_size(const qrl_fft* f);             /* :166-169 */
+int qrl_fft_set_window_type(qrl_fft* f, int wintype);        /* :172-190 */
+int qrl_fft_get_window_type(const qrl_fft* f);               /* :193-196 */
+int qrl_fft_process(qrl_fft* f, const float* iq, size_t stride, size_t n);
+int qrl_fft_get_fft_data(qrl_fft* f, float* fft_points, size_t out_stride, unsigned* fft_size);
+int qrl_fft_sync(qrl_fft* f);
+void* qrl_fft_stream(qrl_fft* f);
+
 /* ---- filter design & tables (host side, no GPU needed): what the kernels are loaded with ----
  * replaces: gr::filter::firdes::* calls at gr_demod_2fsk.cpp:82-97, gr_demod_gmsk.cpp:80-98,
  * gr_demod_qpsk.cpp:92-103, gr_demod_base.cpp:1333-1336.  taps==NULL returns the count. */

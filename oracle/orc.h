@@ -169,4 +169,9 @@ double orc_batch_rx(int mode, const cf32* iq, int batch, size_t n, int samp_rate
 #ifdef __cplusplus
 }
 #endif
+/* side outputs of gr_demod_base (orc_side.c) */
+float orc_det_log2f(float x);
+void orc_rssi_block(const cf32* in, size_t n, float level, float* out);
+void orc_power_spectrum(const cf32* in, const float* window, size_t n, float* out);
+
 #endif

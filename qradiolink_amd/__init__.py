@@ -92,6 +92,23 @@ def load_library():
     lib.qrl_demod_out_caps.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     lib.qrl_demod_process.argtypes = [vp, vp, sz, sz, C.POINTER(_Out)]
     lib.qrl_demod_sync.argtypes = [vp]
+    lib.qrl_rssi_create.argtypes = [vp, C.c_int, C.c_float, vp, C.POINTER(vp)]
+    lib.qrl_rssi_destroy.argtypes = [vp]
+    lib.qrl_rssi_reset.argtypes = [vp]
+    lib.qrl_rssi_set_level.argtypes = [vp, C.c_float]
+    lib.qrl_rssi_process.argtypes = [vp, vp, sz, sz, vp, sz, vp, sz, vp, vp]
+    lib.qrl_rssi_sync.argtypes = [vp]
+    lib.qrl_fft_create.argtypes = [vp, C.c_int, C.c_uint, C.c_int, vp, C.POINTER(vp)]
+    lib.qrl_fft_destroy.argtypes = [vp]
+    lib.qrl_fft_set_enabled.argtypes = [vp, C.c_int]
+    lib.qrl_fft_set_fft_size.argtypes = [vp, C.c_uint]
+    lib.qrl_fft_get_fft_size.argtypes = [vp]
+    lib.qrl_fft_get_fft_size.restype = C.c_uint
+    lib.qrl_fft_set_window_type.argtypes = [vp, C.c_int]
+    lib.qrl_fft_get_window_type.argtypes = [vp]
+    lib.qrl_fft_process.argtypes = [vp, vp, sz, sz]
+    lib.qrl_fft_get_fft_data.argtypes = [vp, vp, sz, C.POINTER(C.c_uint)]
+    lib.qrl_fft_sync.argtypes = [vp]
     lib.qrl_demod_stream.restype = vp
     lib.qrl_demod_stream.argtypes = [vp]
     lib.qrl_demod_profile.argtypes = [vp, C.c_int]
@@ -160,6 +177,9 @@ EXPORTED_SYMBOLS = [
     "qrl_chan_destroy", "qrl_chan_reset", "qrl_chan_set_level", "qrl_chan_calibrate_rssi", "qrl_chan_set_rssi_output", "qrl_chan_set_4fsk_output", "qrl_chan_out_cap", "qrl_chan_process", "qrl_chan_sync",
     "qrl_synth_create", "qrl_synth_destroy", "qrl_synth_reset", "qrl_synth_set_bb_gain", "qrl_synth_add_zero_runs", "qrl_synth_out_cap", "qrl_synth_process",
     "qrl_synth_sync",
+    "qrl_rssi_create", "qrl_rssi_destroy", "qrl_rssi_reset", "qrl_rssi_set_level", "qrl_rssi_process", "qrl_rssi_sync", "qrl_rssi_stream",
+    "qrl_fft_create", "qrl_fft_destroy", "qrl_fft_set_enabled", "qrl_fft_set_fft_size", "qrl_fft_get_fft_size", "qrl_fft_set_window_type",
+    "qrl_fft_get_window_type", "qrl_fft_process", "qrl_fft_get_fft_data", "qrl_fft_sync", "qrl_fft_stream",
     "qrl_deframer_create", "qrl_deframer_destroy", "qrl_deframer_reset", "qrl_deframer_process", "qrl_deframer_sync",
     "qrl_framesync_create", "qrl_framesync_destroy", "qrl_framesync_reset", "qrl_framesync_frame_bytes", "qrl_framesync_process",
     "qrl_framesync_sync",
@@ -422,6 +442,94 @@ class Deframer:
     def close(self):
         if self.h:
             self.lib.qrl_deframer_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Rssi:
+    """rssi_block on the device (reference src/gr/rssi_block.cpp:25-50): process(filtered, counts) takes the complex64 cuda tensor
+    [batch, cap] of demodulator port 0 plus the per-stream item counts (int32 cuda view, stride in elements, or None) and returns
+    (float32 cuda [batch, cap] dB values, float32 cuda [batch] latest value = probe_signal_f::level())."""
+
+    def __init__(self, ctx, batch, level=0.0, stream=None):
+        import torch
+        self.torch = torch
+        self.ctx, self.lib, self.batch = ctx, ctx.lib, batch
+        self.h = C.c_void_p()
+        _check(self.lib.qrl_rssi_create(ctx.h, batch, level, stream, C.byref(self.h)), "qrl_rssi_create")
+        self.last = torch.zeros((batch,), dtype=torch.float32, device="cuda:%d" % ctx.device)
+        self.out_counts = torch.zeros((batch,), dtype=torch.int32, device="cuda:%d" % ctx.device)
+        self.out = None
+
+    def set_level(self, level):
+        _check(self.lib.qrl_rssi_set_level(self.h, level), "qrl_rssi_set_level")
+
+    def process(self, filtered, counts=None, count_stride=1, n=None):
+        t = self.torch
+        assert filtered.is_cuda and filtered.dtype == t.complex64 and filtered.dim() == 2 and filtered.shape[0] == self.batch and filtered.stride(1) == 1
+        n = filtered.shape[1] if n is None else n
+        if self.out is None or self.out.shape[1] < n:
+            self.out = t.zeros((self.batch, max(n, 1)), dtype=t.float32, device=filtered.device)
+        t.cuda.current_stream().synchronize()
+        _check(self.lib.qrl_rssi_process(self.h, filtered.data_ptr(), filtered.stride(0), n, counts.data_ptr() if counts is not None else None,
+                                         count_stride, self.out.data_ptr(), self.out.shape[1], self.last.data_ptr(), self.out_counts.data_ptr()),
+               "qrl_rssi_process")
+        _check(self.lib.qrl_rssi_sync(self.h), "qrl_rssi_sync")
+        return self.out, self.last
+
+    def reset(self):
+        _check(self.lib.qrl_rssi_reset(self.h), "qrl_rssi_reset")
+
+    def close(self):
+        if self.h:
+            self.lib.qrl_rssi_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Fft:
+    """rx_fft_c on the device (reference src/gr/rx_fft.cpp:44-213): work(iq) feeds complex64 cuda [batch, n]; get_fft_data()
+    returns float32 cuda [batch, fftsize] (dB, negative frequencies first) or None while no spectrum is ready."""
+
+    def __init__(self, ctx, batch, fftsize=32768, wintype=5, stream=None):
+        import torch
+        self.torch = torch
+        self.ctx, self.lib, self.batch = ctx, ctx.lib, batch
+        self.h = C.c_void_p()
+        _check(self.lib.qrl_fft_create(ctx.h, batch, fftsize, wintype, stream, C.byref(self.h)), "qrl_fft_create")
+
+    def set_enabled(self, enabled):
+        _check(self.lib.qrl_fft_set_enabled(self.h, int(bool(enabled))), "qrl_fft_set_enabled")
+
+    def set_fft_size(self, n):
+        _check(self.lib.qrl_fft_set_fft_size(self.h, n), "qrl_fft_set_fft_size")
+
+    def get_fft_size(self):
+        return int(self.lib.qrl_fft_get_fft_size(self.h))
+
+    def set_window_type(self, w):
+        _check(self.lib.qrl_fft_set_window_type(self.h, w), "qrl_fft_set_window_type")
+
+    def get_window_type(self):
+        return int(self.lib.qrl_fft_get_window_type(self.h))
+
+    def work(self, iq):
+        t = self.torch
+        assert iq.is_cuda and iq.dtype == t.complex64 and iq.dim() == 2 and iq.shape[0] == self.batch and iq.stride(1) == 1
+        t.cuda.current_stream().synchronize()
+        _check(self.lib.qrl_fft_process(self.h, iq.data_ptr(), iq.stride(0), iq.shape[1]), "qrl_fft_process")
+        _check(self.lib.qrl_fft_sync(self.h), "qrl_fft_sync")   # the handle's stream has read `iq`: the caller may free / reuse it
+
+    def get_fft_data(self):
+        t = self.torch
+        n = self.get_fft_size()
+        out = t.empty((self.batch, n), dtype=t.float32, device="cuda:%d" % self.ctx.device)
+        got = C.c_uint(0)
+        _check(self.lib.qrl_fft_get_fft_data(self.h, out.data_ptr(), out.stride(0), C.byref(got)), "qrl_fft_get_fft_data")
+        _check(self.lib.qrl_fft_sync(self.h), "qrl_fft_sync")
+        return out if got.value else None
+
+    def close(self):
+        if self.h:
+            self.lib.qrl_fft_destroy(self.h)
             self.h = C.c_void_p()
 
 

@@ -116,4 +116,32 @@ __device__ __forceinline__ float phase_wrap(float phase)
     return phase;
 }
 
+// log2 of a float, the same bits on the host (oracle/orc_blocks.c orc_det_log2f) and on the device: libm's log2f is not the same
+// function on both sides, IEEE double arithmetic in a fixed order is.  x = 2^e m, m in [sqrt(1/2), sqrt(2)), t = (m - 1) / (m + 1),
+// ln m = 2 atanh t as an odd series to t^13 (|t| <= 0.172: truncation 4e-13), rounded to float once.  Stands in for log2f in
+// nlog10_ff / volk_32fc_s32f_power_spectrum_32f (VOLK's log2f_non_ieee: +-inf becomes +-127).
+__host__ __device__ inline float det_log2f(float x)
+{
+    if (!(x > 0.0f)) return x == 0.0f ? -127.0f : __builtin_nanf("");   // log2f(0) = -inf -> -127; negative -> nan
+    if (x > 3.4028234e38f) return 127.0f;                                // log2f(inf) = inf -> 127
+    int adj = 0;
+    if (x < 1.17549435e-38f) { x *= 18446744073709551616.0f; adj = -64; }   // subnormal: scale by 2^64 (exact)
+    unsigned bits = __builtin_bit_cast(unsigned, x);
+    int e = (int)(bits >> 23) - 127 + adj;
+    float m = __builtin_bit_cast(float, (bits & 0x007fffffu) | 0x3f800000u);   // [1, 2)
+    if (m > 1.41421354f) { m *= 0.5f; e += 1; }
+    const double md = (double)m;
+    const double t = (md - 1.0) / (md + 1.0);
+    const double t2 = t * t;
+    double s = 2.0 / 13.0;
+    s = s * t2 + 2.0 / 11.0;
+    s = s * t2 + 2.0 / 9.0;
+    s = s * t2 + 2.0 / 7.0;
+    s = s * t2 + 2.0 / 5.0;
+    s = s * t2 + 2.0 / 3.0;
+    s = s * t2 + 2.0;
+    s = s * t;
+    return (float)((double)e + s * 1.4426950408889634);
+}
+
 }  // namespace qrl

@@ -242,4 +242,19 @@ void launch_tx_interp_c(const TxInterpCParams& p, int batch, hipStream_t s);
 void launch_tx_qpsk_bits(const TxBitsParams& p, int batch, hipStream_t s);
 void launch_tx_interp(const TxInterpParams& p, int batch, hipStream_t s);
 
+// ---- side outputs (kernels_side.hip): rssi_block on port 0, rx_fft_c on the device-rate IQ ----
+constexpr uint32_t RSSI_RING = 4096;   // |x|^2 look-back ring per stream (moving_average_ff(2000) reads 1999 items back)
+struct RssiState { double prev; uint64_t n; float sum, last; };
+struct RssiBlockParams {
+    const float2* in; size_t in_stride; uint32_t n;       // port-0 items of this call: in[b * in_stride + i]
+    const uint32_t* counts; size_t count_stride;         // per-stream item count (device), or nullptr: n for every stream
+    RssiState* st; float* ring; int batch;
+    float level, n_log2_10;
+    float* out; size_t out_cap; float* last; uint32_t* out_counts;
+};
+void launch_rssi(const RssiBlockParams& p, hipStream_t s);
+void launch_fft_fill(const float2* in, size_t in_stride, uint32_t i0, uint32_t count, const float* win, uint32_t counter, float2* buf, uint32_t N, int batch, hipStream_t s);
+void launch_fft_power(const float2* X, float* out, uint32_t N, int batch, hipStream_t s);
+void launch_fft_shift(const float* pts, float* out, size_t out_stride, uint32_t N, int batch, hipStream_t s);
+
 }  // namespace qrl

@@ -592,3 +592,29 @@ def batch_rx(mode, iq, samp_rate, carrier_offset_hz=0.0, threads=0):
     chk = C.c_uint64()
     t = lib.orc_batch_rx(mode, _ptr(iq), batch, n, samp_rate, float(carrier_offset_hz), threads, C.byref(chk))
     return t, chk.value
+
+
+# ---- side outputs of gr_demod_base (oracle/orc_side.c)
+_sig("orc_det_log2f", C.c_float, C.c_float)
+_sig("orc_rssi_block", None, _p, C.c_size_t, C.c_float, _p)
+_sig("orc_power_spectrum", None, _p, _p, C.c_size_t, _p)
+
+
+def det_log2f(x):
+    return float(lib.orc_det_log2f(float(x)))
+
+
+def rssi_block(x, level=0.0):
+    x = np.ascontiguousarray(x, cf32)
+    out = np.zeros(max(x.size, 1), np.float32)
+    lib.orc_rssi_block(_ptr(x), x.size, level, _ptr(out))
+    return out[:x.size].copy()
+
+
+def power_spectrum(x, window):
+    x = np.ascontiguousarray(x, cf32)
+    w = np.ascontiguousarray(window, np.float32)
+    assert x.size == w.size and x.size & (x.size - 1) == 0
+    out = np.zeros(x.size, np.float32)
+    lib.orc_power_spectrum(_ptr(x), _ptr(w), x.size, _ptr(out))
+    return out
