@@ -65,6 +65,7 @@ struct gr_demod_base_hip::slot {
     float* d_iq = nullptr;                                // device [streams][chunk] cf32
     float *d_filt = nullptr, *d_const = nullptr; uint8_t *d_a = nullptr, *d_b = nullptr, *d_dmo = nullptr; uint32_t *d_cnt = nullptr, *d_dmocnt = nullptr;
     gr_complex* h_const = nullptr; uint8_t *h_a = nullptr, *h_b = nullptr, *h_dmo = nullptr; uint32_t *h_cnt = nullptr, *h_dmocnt = nullptr;   // pinned
+    float *d_rssi = nullptr, *h_rssi = nullptr; bool rssi_valid = false;   // latest rssi_block value per stream (device / pinned)
     hipEvent_t done = nullptr;
 };
 static constexpr size_t kDmoCap = 16;
@@ -87,8 +88,13 @@ gr_demod_base_hip::~gr_demod_base_hip()
 void gr_demod_base_hip::close()
 {
     if (d_h) { qrl_demod_destroy(d_h); d_h = nullptr; }
+    if (d_rssi) { qrl_rssi_destroy(d_rssi); d_rssi = nullptr; }
+    if (d_fft) { qrl_fft_destroy(d_fft); d_fft = nullptr; }
+    if (d_fftout) { (void)hipFree(d_fftout); d_fftout = nullptr; }
     for (auto& sp : d_slot) {
         if (!sp) continue;
+        if (sp->d_rssi) (void)hipFree(sp->d_rssi);
+        if (sp->h_rssi) (void)hipHostFree(sp->h_rssi);
         for (void* p : {(void*)sp->d_iq, (void*)sp->d_filt, (void*)sp->d_const, (void*)sp->d_a, (void*)sp->d_b, (void*)sp->d_dmo, (void*)sp->d_cnt, (void*)sp->d_dmocnt})
             if (p) (void)hipFree(p);
         for (void* p : {(void*)sp->h_iq, (void*)sp->h_const, (void*)sp->h_a, (void*)sp->h_b, (void*)sp->h_dmo, (void*)sp->h_cnt, (void*)sp->h_dmocnt})
@@ -108,8 +114,15 @@ void gr_demod_base_hip::open()
     chk(qrl_demod_create(d_rt.ctx(), &c, &d_h), "qrl_demod_create");
     chk(qrl_demod_out_caps(d_h, d_chunk, &d_fcap, &d_ccap, &d_bcap), "qrl_demod_out_caps");
     const size_t N = (size_t)d_n;
+    // side outputs on the copy stream: rssi_block behind port 0, rx_fft_c on the device-rate IQ (gr_demod_base.cpp:166,185,199-200)
+    chk(qrl_rssi_create(d_rt.ctx(), d_n, d_rssi_cal, d_copy, &d_rssi), "qrl_rssi_create");
+    chk(qrl_fft_create(d_rt.ctx(), d_n, d_fftsize, 5 /* WIN_BLACKMAN_HARRIS */, d_copy, &d_fft), "qrl_fft_create");
+    chk(qrl_fft_set_enabled(d_fft, d_fft_on ? 1 : 0), "qrl_fft_set_enabled");
+    d_level.assign(N, 0.0f);
     for (auto& sp : d_slot) {
         sp = new slot;
+        hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_rssi), N * sizeof(float)), "hipMalloc");
+        hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_rssi), N * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
         hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_iq), N * d_chunk * sizeof(gr_complex), hipHostMallocDefault), "hipHostMalloc");
         hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_iq), N * d_chunk * sizeof(gr_complex)), "hipMalloc");
         hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_filt), N * d_fcap * sizeof(gr_complex)), "hipMalloc");
@@ -176,6 +189,12 @@ void gr_demod_base_hip::work(const gr_complex* const* iq, size_t n)
         hchk(hipMemcpyAsync(sl.h_dmocnt, sl.d_dmocnt, N * sizeof(uint32_t), hipMemcpyDeviceToHost, cs), "D2H");
         hchk(hipMemcpyAsync(sl.h_dmo, sl.d_dmo, N * kDmoCap * QRL_DMO_RECORD_BYTES, hipMemcpyDeviceToHost, cs), "D2H");
     }
+    sl.rssi_valid = d_rssi_on;
+    if (d_rssi_on) {   // rssi_valve open: port 0 of this call through rssi_block, the probe keeps the latest value
+        chk(qrl_rssi_process(d_rssi, sl.d_filt, d_fcap, d_fcap, sl.d_cnt, 4, nullptr, 0, sl.d_rssi, nullptr), "qrl_rssi_process");
+        hchk(hipMemcpyAsync(sl.h_rssi, sl.d_rssi, N * sizeof(float), hipMemcpyDeviceToHost, cs), "D2H");
+    }
+    if (d_fft_on) chk(qrl_fft_process(d_fft, sl.d_iq, d_chunk, n), "qrl_fft_process");
     hchk(hipEventRecord(sl.done, cs), "hipEventRecord");
     const int prev = d_inflight;
     d_inflight = cur;
@@ -189,6 +208,7 @@ void gr_demod_base_hip::harvest(int which)
     std::lock_guard<std::mutex> g(d_mutex);
     for (int s = 0; s < d_n; ++s) {
         const uint32_t* c = sl.h_cnt + 4 * (size_t)s;
+        if (sl.rssi_valid && c[0]) d_level[s] = sl.h_rssi[s];
         d_box1[s].insert(d_box1[s].end(), sl.h_a + (size_t)s * d_bcap, sl.h_a + (size_t)s * d_bcap + c[2]);
         d_box2[s].insert(d_box2[s].end(), sl.h_b + (size_t)s * d_bcap, sl.h_b + (size_t)s * d_bcap + c[3]);
         d_boxc[s].insert(d_boxc[s].end(), sl.h_const + (size_t)s * d_ccap, sl.h_const + (size_t)s * d_ccap + c[1]);
@@ -222,6 +242,43 @@ std::vector<gr_complex>* gr_demod_base_hip::get_constellation_data(int stream)
     std::vector<gr_complex>* out = new std::vector<gr_complex>;
     out->swap(d_boxc[stream]);
     return out;
+}
+float gr_demod_base_hip::get_rssi(int stream)   // gr_demod_base.cpp:1234-1237
+{
+    std::lock_guard<std::mutex> g(d_mutex);
+    return d_level[stream];
+}
+void gr_demod_base_hip::calibrate_rssi(float value)   // :1413-1418
+{
+    d_rssi_cal = value;
+    if (d_rssi) chk(qrl_rssi_set_level(d_rssi, value), "qrl_rssi_set_level");
+}
+void gr_demod_base_hip::enable_gui_fft(bool value)   // :1110-1113
+{
+    d_fft_on = value;
+    if (d_fft) chk(qrl_fft_set_enabled(d_fft, value ? 1 : 0), "qrl_fft_set_enabled");
+}
+void gr_demod_base_hip::set_fft_size(int size)   // :1227-1232
+{
+    flush();
+    d_fftsize = (unsigned)size;
+    if (d_fft) chk(qrl_fft_set_fft_size(d_fft, d_fftsize), "qrl_fft_set_fft_size");
+    if (d_fftout) { (void)hipFree(d_fftout); d_fftout = nullptr; }
+}
+void gr_demod_base_hip::get_FFT_data(float* fft_data, unsigned int& fftSize, int stream)   // :978-986 -> rx_fft_c::get_fft_data
+{
+    fftSize = 0;
+    if (!d_fft) return;
+    if (!d_fftout) hchk(hipMalloc(reinterpret_cast<void**>(&d_fftout), (size_t)d_n * d_fftsize * sizeof(float)), "hipMalloc");
+    unsigned got = 0;
+    chk(qrl_fft_get_fft_data(d_fft, d_fftout, d_fftsize, &got), "qrl_fft_get_fft_data");
+    if (!got) return;
+    hipStream_t cs = static_cast<hipStream_t>(d_copy);
+    d_fftlast.resize((size_t)d_n * got);   // every stream's spectrum of this frame: the other rows stay readable through last_FFT_data()
+    hchk(hipMemcpyAsync(d_fftlast.data(), d_fftout, d_fftlast.size() * sizeof(float), hipMemcpyDeviceToHost, cs), "D2H");
+    hchk(hipStreamSynchronize(cs), "hipStreamSynchronize");
+    std::memcpy(fft_data, d_fftlast.data() + (size_t)stream * got, (size_t)got * sizeof(float));
+    fftSize = got;
 }
 std::vector<std::vector<unsigned char>> gr_demod_base_hip::getDMRData(int stream)
 {

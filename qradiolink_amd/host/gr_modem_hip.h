@@ -55,6 +55,14 @@ public:
     std::vector<unsigned char>* getData(int nr, int stream);   // nr = 1: bits A (port 2), nr = 2: bits B (port 3); nullptr = nothing yet
     std::vector<gr_complex>* get_constellation_data(int stream = 0);
     std::vector<std::vector<unsigned char>> getDMRData(int stream = 0);   // DMR mode: 40-byte DMO records (QRL_DMO_RECORD_BYTES)
+    // side outputs (gr_demod_base.cpp:199-200, 185; :978-986, 1105-1113, 1227-1237, 1413-1418)
+    void enable_rssi(bool value) { d_rssi_on = value; }
+    float get_rssi(int stream = 0);                            // probe_signal_f::level() of the rssi_block behind port 0
+    void calibrate_rssi(float value);
+    void enable_gui_fft(bool value);
+    void set_fft_size(int size);
+    void get_FFT_data(float* fft_data, unsigned int& fftSize, int stream = 0);   // fftSize = 0: nothing new (rx_fft_c::get_fft_data)
+    const float* last_FFT_data(int stream) const { return d_fftlast.empty() ? nullptr : d_fftlast.data() + (size_t)stream * (d_fftlast.size() / (size_t)d_n); }   // the other streams of the frame get_FFT_data fetched
     int streams() const { return d_n; }
     int mode() const { return d_mode; }
 
@@ -66,6 +74,8 @@ private:
     qrl_runtime& d_rt;
     int d_n, d_rate, d_mode = -1; double d_offset; size_t d_chunk;
     qrl_demod* d_h = nullptr;
+    qrl_rssi* d_rssi = nullptr; qrl_fft* d_fft = nullptr; bool d_rssi_on = false, d_fft_on = false; float d_rssi_cal = 0.0f; unsigned d_fftsize = 32768;
+    float* d_fftout = nullptr; std::vector<float> d_level, d_fftlast;
     void* d_copy = nullptr;                                   // hipStream_t for the copy-out
     slot* d_slot[2] = {nullptr, nullptr};
     int d_inflight = -1; uint64_t d_calls = 0;

@@ -3,6 +3,7 @@
 // Per stream s: startTransmission("CALL<s>"), <frames> voice frames with a known payload, a text message, endTransmission;
 // the modulator's samples (+ a little silence and a per-stream delay) go into the demodulator in ragged work() calls;
 // demodulate() is polled like the radio loop does.  Every callback is logged to <out.txt> as one line per event.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +42,13 @@ int main(int argc, char** argv)
         gr_modem_hip modem(&demod, &mod, ev);
         modem.toggleTxMode(mode);
         modem.toggleRxMode(mode);
+        demod.enable_rssi(true);
+        demod.calibrate_rssi(-30.0f);
+        demod.set_fft_size(4096);
+        demod.enable_gui_fft(true);
+        std::vector<float> spectrum(4096);
+        int spectra = 0; float peak_db = -1000.0f; int peak_bin = -1;
+        std::vector<float> rssi_max(N, -1000.0f);
         const int L = modem_tx_frame_length(mode);
         for (int s = 0; s < N; ++s) {
             modem.startTransmission("CALL" + std::to_string(s), s);
@@ -93,11 +101,20 @@ int main(int argc, char** argv)
                 continue;
             }
             for (int s = 0; s < N; ++s) while (modem.demodulate(s)) {}
+            for (int s = 0; s < N; ++s) { const float v = demod.get_rssi(s); if (v != 0.0f) rssi_max[s] = std::max(rssi_max[s], v); }   // (0 = the probe before its first item)
+            unsigned got = 0;
+            demod.get_FFT_data(spectrum.data(), got, 0);   // the GUI timer of the reference polls like this
+            if (got == 4096) {
+                ++spectra;
+                for (int i = 0; i < 4096; ++i) if (spectrum[i] > peak_db) { peak_db = spectrum[i]; peak_bin = i; }
+            }
         }
         if (bitlog) std::fclose(bitlog);
         demod.flush();
         for (int s = 0; s < N; ++s) while (modem.demodulate(s)) {}
         for (int s = 0; s < N; ++s) log << s << " modem_sync " << modem.modem_sync(s) << "\n";
+        for (int s = 0; s < N; ++s) log << s << " rssi " << demod.get_rssi(s) << "\n" << s << " rssi_max " << rssi_max[s] << "\n";
+        log << "0 spectra " << spectra << "\n" << "0 peak_bin " << peak_bin << "\n" << "0 peak_db " << peak_db << "\n";
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "exception: %s\n", e.what());

@@ -62,3 +62,16 @@ def test_facade_loopback(tmp_path, mode, L, streams, frames):
             assert text.startswith("hello from stream %d" % s)
         assert kinds.count("receiveend") >= 1 and kinds.count("endaudio") >= 1
         assert int(dict(ev[s])["modem_sync"]) >= 0
+
+
+def test_facade_side_outputs(tmp_path):
+    """enable_rssi / calibrate_rssi / get_rssi and enable_gui_fft / set_fft_size / get_FFT_data of the facade (gr_demod_base.cpp:978-986,
+    1105-1113, 1227-1237, 1413-1418): the loopback signal (amplitude ~0.03 at 1 Msps) gives a finite RSSI per stream and spectra
+    whose peak sits in the signal's band around DC (bin N/2 after the half swap)."""
+    ev = _events(tmp_path, 22, 2, 3)
+    d0 = dict(ev[0])
+    for s in range(2):
+        # while the burst is on the air: 2000 x |0.05 x 0.6..1|^2 ~ 1..5 -> 0..7 dB, -30 dB calibration; after it the level falls
+        assert -45.0 < float(dict(ev[s])["rssi_max"]) < -15.0 and float(dict(ev[s])["rssi"]) < float(dict(ev[s])["rssi_max"]) - 20.0
+    assert int(d0["spectra"]) >= 2
+    assert abs(int(d0["peak_bin"]) - 2048) < 80 and float(d0["peak_db"]) > -70.0
