@@ -100,6 +100,12 @@ struct DecimStage {
     bool used = false, mfma = false, pl = false;
     int D = 1, Jpad = 0, variant = DECIM_R4_J12, nt = 0, S = 0;
     DevBuf<float> taps;
+    DevBuf<float2> edge; uint32_t edge_len = 0;   // phase-lane kernels: per-stream scratch for the call's edge outputs
+    int alloc_edge(int B) {
+        if (!pl) return QRL_OK;
+        edge_len = (uint32_t)decim_pl_edge_len(nt, D);
+        return edge_len ? edge.alloc((size_t)B * edge_len) : QRL_OK;
+    }
     int plan(const std::vector<float>& h, int D_) {
         used = true; D = D_; nt = (int)h.size();
         if (decim_uses_pl(nt, D)) {   // register-resident phase-lane kernel (the 1:50 first stages)
@@ -129,7 +135,7 @@ struct DecimStage {
     uint32_t lookback() const { return pl ? (uint32_t)(((nt + D - 1) / D + 1) * D) : mfma ? (uint32_t)(nt + D) : (uint32_t)(Jpad * D); }
     int launch(DecimParams& p, int B, hipStream_t s) const {
         p.nt = nt;
-        if (pl) { p.pl_taps = taps.p; return launch_decim_pl(p, B, s); }
+        if (pl) { p.pl_taps = taps.p; p.pl_edge = edge.p; p.pl_edge_stride = edge_len; p.pl_edge_cap = edge_len; return launch_decim_pl(p, B, s); }
         if (mfma) { p.gtab = taps.p; p.S = S; return launch_decim_mfma(p, B, s); }
         launch_decim(p, B, variant, s);
         return 0;
@@ -311,6 +317,7 @@ int qrl_demod::build()
     if (cfg.device_samp_rate >= 2000000) {
         fe_decim = cfg.device_samp_rate / 1000000;
         if ((r = fe.plan(low_pass(1, cfg.device_samp_rate, 480000, 100000, WIN_BLACKMAN_HARRIS), fe_decim))) return fail(r, "front-end plan");
+        if ((r = fe.alloc_edge(cfg.batch))) return fail(r, "front-end edge scratch");
     }
     rot_inc = phase_inc_to_turn(2 * M_PI * -cfg.carrier_offset_hz / cfg.device_samp_rate);
     if ((r = upload_rot_table())) return r;
@@ -321,7 +328,7 @@ int qrl_demod::build()
         : fam == F_QPSK
         ? low_pass_2(interp, (double)interp * samp_rate, target / 2, target / 10, 60, WIN_BLACKMAN_HARRIS)   // gr_demod_qpsk.cpp:92-96
         : low_pass(interp, (double)interp * samp_rate, target / 2, target / 2, WIN_BLACKMAN_HARRIS);
-    if (interp == 1) { if ((r = first.plan(rtaps, decim))) return fail(r, "resampler plan"); }
+    if (interp == 1) { if ((r = first.plan(rtaps, decim))) return fail(r, "resampler plan"); if (!fe.used && (r = first.alloc_edge(cfg.batch))) return fail(r, "resampler edge scratch"); }
     else {
         rs_Jp = ((int)rtaps.size() + interp - 1) / interp;
         if ((r = rs_taps.upload(resamp_layout(rtaps, interp, rs_Jp)))) return r;
@@ -910,7 +917,7 @@ int qrl_demod_profile_read(qrl_demod* d, double* kernel_ms, uint64_t* launches, 
     if (launches) *launches = d->prof_events.size();
     if (kernel_name) {
         const DecimStage& st = d->fe.used ? d->fe : d->first;
-        *kernel_name = (d->fe.used || d->interp == 1) ? (st.pl ? "k_decim_pl" : st.mfma ? "k_decim_mfma" : "k_decim") : "k_resamp";
+        *kernel_name = (d->fe.used || d->interp == 1) ? (st.pl ? (st.D > 64 ? "k_decim_plx" : "k_decim_pl") : st.mfma ? "k_decim_mfma" : "k_decim") : "k_resamp";
     }
     d->prof_events.clear();
     return QRL_OK;

@@ -41,6 +41,9 @@ struct DecimParams {
     // phase-lane variant (kernels_decim_pl.hip): lane tap table [J][64]; the launcher fills the segment geometry
     const float* pl_taps; int pl_J; uint32_t pl_S, pl_nseg, pl_batch; uint64_t pl_m_begin, pl_m_end;
     int pl_E, pl_R; const float* pl_hraw;                   // samples per lane and block, outputs per block; raw taps h[k] (k_decim_pl_gen)
+    // edge segment (outputs whose window starts in front of this call's buffer): per-stream scratch of ROTATED samples (carried
+    // history + head of the buffer), one extra unit per stream behind the regular ones reads it with identity phasors
+    float2* pl_edge; uint32_t pl_edge_stride, pl_edge_cap; uint64_t pl_edge_ms, pl_edge_me;
 };
 struct HistParams {
     const float2* in; size_t in_stride; uint64_t n0; uint32_t n;
@@ -63,6 +66,7 @@ void decim_mfma_prof_read(unsigned long long* out8);
 void decim_mfma_prof_enable(int on);
 // register-resident phase-lane decimator (32 < D <= 64, <= 16 taps per phase): contract "pl" of oracle/orc_blocks.c
 bool decim_uses_pl(int nt, int D);
+size_t decim_pl_edge_len(int nt, int D);   // samples of edge scratch per stream (0: geometry without the register kernel)
 std::vector<float> decim_pl_layout(const std::vector<float>& h, int D);
 int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s);
 

@@ -130,25 +130,35 @@ void k_decim_pl(const DecimParams P_)
 {
     const DecimParams& P = P_;
     __shared__ float2 t_lo[512];
+    __shared__ float2 t_one[512];
     __shared__ float2 t_hi_all[4][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     t_lo[tid] = P.rot_lo[tid];
     t_lo[tid + 256] = P.rot_lo[tid + 256];
+    t_one[tid] = make_float2(1.f, 0.f);
+    t_one[tid + 256] = make_float2(1.f, 0.f);
 
-    // unit = (segment, stream); the waves of a workgroup take neighbouring streams of the same segment
+    // unit = (segment, stream); the waves of a workgroup take neighbouring streams of the same segment.  Behind the regular units:
+    // one EDGE unit per stream (outputs pl_edge_ms .. pl_edge_me out of the staged, already rotated scratch: identity phasors)
     const uint32_t unit = blockIdx.x * 4u + (uint32_t)wave;
     const uint32_t B = P.pl_batch;
-    const uint32_t seg = unit / B, b = unit - seg * B;
-    const bool active = seg < P.pl_nseg;
+    const uint32_t nreg = P.pl_nseg * B;
+    const bool edge = unit >= nreg;
+    const uint32_t seg = edge ? 0u : unit / B, b = edge ? unit - nreg : unit - seg * B;
+    const bool active = edge ? (b < B && P.pl_edge_me > P.pl_edge_ms) : true;
     const int D = P.D;
-    const uint64_t ms = P.pl_m_begin + (uint64_t)seg * P.pl_S;
-    const uint64_t me = ms + P.pl_S < P.pl_m_end ? ms + P.pl_S : P.pl_m_end;
-    const uint64_t c_first = ms - (uint64_t)(J - 1);                 // block c = samples (c-1) D + 1 .. c D
-    const uint64_t i_first = (c_first - 1) * (uint64_t)D + 1;        // >= n0: the launcher only hands over interior outputs
-    const uint32_t kb0 = (uint32_t)((i_first - P.rot_nbase) >> 9);
+    const uint64_t ms = edge ? P.pl_edge_ms : P.pl_m_begin + (uint64_t)seg * P.pl_S;
+    const uint64_t me = edge ? P.pl_edge_me : (ms + P.pl_S < P.pl_m_end ? ms + P.pl_S : P.pl_m_end);
+    // block c = samples (c-1) D + 1 .. c D; the first block of the unit is ms - (J - 1) (edge units: may lie in front of the stream)
+    const int64_t c_first_s = (int64_t)ms - (int64_t)(J - 1);
+    const uint64_t c_first = (uint64_t)c_first_s;
+    const int64_t i_first_s = (c_first_s - 1) * (int64_t)D + 1;
+    const uint64_t i_first = (uint64_t)i_first_s;                    // regular units: >= n0 (the launcher only hands over interior outputs)
+    const uint32_t kb0 = edge ? 0u : (uint32_t)((i_first - P.rot_nbase) >> 9);
     float2* t_hi = t_hi_all[wave];
-    if (active) t_hi[lane] = sincos_turn(P.rot_acc + ((uint64_t)(kb0 + (uint32_t)lane) << 9) * P.rot_inc);
+    if (active) t_hi[lane] = edge ? make_float2(1.f, 0.f) : sincos_turn(P.rot_acc + ((uint64_t)(kb0 + (uint32_t)lane) << 9) * P.rot_inc);
+    const float2* tl = edge ? t_one : t_lo;
     __syncthreads();
     if (!active) return;
 
@@ -157,8 +167,8 @@ void k_decim_pl(const DecimParams P_)
     for (int j = 0; j < J; ++j) h[j] = P.pl_taps[j * 64 + lane];
     const int lo = lane < D ? lane : D - 1;                          // idle lanes re-read the last sample against zero taps
     const int nblk = (int)(me - ms) + J - 1;
-    const float2* ub = P.in + (size_t)b * P.in_stride + (size_t)(i_first - P.n0);   // wave-uniform
-    const uint32_t k0 = (uint32_t)(i_first - P.rot_nbase) - (kb0 << 9);            // < 512
+    const float2* ub = edge ? P.pl_edge + (size_t)b * P.pl_edge_stride : P.in + (size_t)b * P.in_stride + (size_t)(i_first - P.n0);   // wave-uniform
+    const uint32_t k0 = edge ? 0u : (uint32_t)(i_first - P.rot_nbase) - (kb0 << 9);   // < 512
     const uint32_t lo8 = (uint32_t)lo * 8u;
     const bool hi8 = lane & 8, hi4 = lane & 4;
     const bool leader = (lane & 3) == 0;
@@ -200,7 +210,7 @@ void k_decim_pl(const DecimParams P_)
                 }
                 // rotator: phasor of sample k = T_hi[k >> 9] (x) T_lo[k & 511], byte addressed
                 const uint32_t kb8 = (k0 + (uint32_t)t * (uint32_t)D) * 8u + lo8;
-                const float2 plo = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(t_lo) + (kb8 & 4095u));
+                const float2 plo = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(tl) + (kb8 & 4095u));
                 const float2 phi = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(t_hi) + ((kb8 >> 9) & ~7u));
                 const float2 xs = cmul_fma(make_float2(xr.x, xr.y), cmul_fma(phi, plo));
                 const v2f x = v2f{xs.x, xs.y};
@@ -279,28 +289,35 @@ __global__ __launch_bounds__(256, 2) void k_decim_plx(const DecimParams P_)
     static_assert(G % PLX_PF == 0 || PLX_PF % G == 0, "prefetch ring and group must nest");
     const DecimParams& P = P_;
     __shared__ float2 t_lo[512];
+    __shared__ float2 t_one[512];
     __shared__ float2 t_hi_all[4][PLX_NHI];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     t_lo[tid] = P.rot_lo[tid];
     t_lo[tid + 256] = P.rot_lo[tid + 256];
+    t_one[tid] = make_float2(1.f, 0.f);
+    t_one[tid + 256] = make_float2(1.f, 0.f);
 
     const uint32_t unit = blockIdx.x * 4u + (uint32_t)wave;
     const uint32_t B = P.pl_batch;
-    const uint32_t seg = unit / B, b = unit - seg * B;
-    const bool active = seg < P.pl_nseg;
+    const uint32_t nreg = P.pl_nseg * B;
+    const bool edge = unit >= nreg;                                    // one edge unit per stream behind the regular ones (see k_decim_pl)
+    const uint32_t seg = edge ? 0u : unit / B, b = edge ? unit - nreg : unit - seg * B;
+    const bool active = edge ? (b < B && P.pl_edge_me > P.pl_edge_ms) : true;
     const int Dp = P.D * R, NL = Dp / E;
-    const uint64_t ms = P.pl_m_begin + (uint64_t)seg * P.pl_S;        // == 1 (mod R): the launcher's choice of pl_m_begin, pl_S
-    const uint64_t me = ms + P.pl_S < P.pl_m_end ? ms + P.pl_S : P.pl_m_end;
-    const uint64_t c_first = (ms - 1) / R + 1 - (uint64_t)WU;
-    const uint64_t i_first = (c_first - 1) * (uint64_t)Dp + 1;        // >= n0 (interior outputs only)
-    const uint32_t kb0 = (uint32_t)((i_first - P.rot_nbase) >> 9);
+    const uint64_t ms = edge ? P.pl_edge_ms : P.pl_m_begin + (uint64_t)seg * P.pl_S;   // == 1 (mod R)
+    const uint64_t me = edge ? P.pl_edge_me : (ms + P.pl_S < P.pl_m_end ? ms + P.pl_S : P.pl_m_end);
+    const int64_t c_first_s = (int64_t)((ms - 1) / R) + 1 - (int64_t)WU;
+    const uint64_t c_first = (uint64_t)c_first_s;
+    const uint64_t i_first = (uint64_t)((c_first_s - 1) * (int64_t)Dp + 1);   // regular units: >= n0 (interior outputs only)
+    const uint32_t kb0 = edge ? 0u : (uint32_t)((i_first - P.rot_nbase) >> 9);
     float2* t_hi = t_hi_all[wave];
     if (active) {
 #pragma unroll
         for (int q = 0; q < PLX_NHI / 64; ++q)
-            t_hi[lane + 64 * q] = sincos_turn(P.rot_acc + ((uint64_t)(kb0 + (uint32_t)(lane + 64 * q)) << 9) * P.rot_inc);
+            t_hi[lane + 64 * q] = edge ? make_float2(1.f, 0.f) : sincos_turn(P.rot_acc + ((uint64_t)(kb0 + (uint32_t)(lane + 64 * q)) << 9) * P.rot_inc);
     }
+    const float2* tl = edge ? t_one : t_lo;
     __syncthreads();
     if (!active) return;
 
@@ -315,8 +332,8 @@ __global__ __launch_bounds__(256, 2) void k_decim_plx(const DecimParams P_)
     }
     const int lo = lane < NL ? lane : NL - 1;                         // idle lanes re-read the last samples against zero taps
     const int nblk = WU + (int)((me - ms + R - 1) / R);
-    const float2* ub = P.in + (size_t)b * P.in_stride + (size_t)(i_first - P.n0) + (size_t)(E * lo);   // lane's first sample of block 0
-    const uint32_t k0 = (uint32_t)(i_first - P.rot_nbase) - (kb0 << 9) + (uint32_t)(E * lo);           // its NCO index, relative
+    const float2* ub = (edge ? P.pl_edge + (size_t)b * P.pl_edge_stride : P.in + (size_t)b * P.in_stride + (size_t)(i_first - P.n0)) + (size_t)(E * lo);   // lane's first sample of block 0
+    const uint32_t k0 = (edge ? 0u : (uint32_t)(i_first - P.rot_nbase) - (kb0 << 9)) + (uint32_t)(E * lo);   // its NCO index, relative
     const bool hi8 = lane & 8, hi4 = lane & 4;
     const bool leader = (lane & 3) == 0;
     const int oidx = pl_out_index(lane);
@@ -350,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_decim_plx(const DecimParams P_)
 #pragma unroll
             for (int e = 0; e < E; ++e) {   // rotator: phasor of sample k = T_hi[k >> 9] (x) T_lo[k & 511]
                 const uint32_t kb8 = (k0 + (uint32_t)t * (uint32_t)Dp + (uint32_t)e) * 8u;
-                const float2 plo = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(t_lo) + (kb8 & 4095u));
+                const float2 plo = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(tl) + (kb8 & 4095u));
                 const float2 phi = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(t_hi) + ((kb8 >> 9) & ~7u));
                 x[e] = plx_cmul_fma(x[e], plx_cmul_fma(v2f{phi.x, phi.y}, v2f{plo.x, plo.y}));
             }
@@ -382,6 +399,33 @@ __global__ __launch_bounds__(256, 2) void k_decim_plx(const DecimParams P_)
 #pragma unroll
         for (int a = 0; a < WN - 16; ++a) acc[a] = acc[a + 16];
     }
+}
+
+// Edge scratch of one call: for every stream the ROTATED samples i0 .. i0 + len - 1 (absolute indices, i0 may be negative): zeros in
+// front of the stream, the carried (already rotated) history in front of this call's buffer, the buffer's head through the exact NCO
+__global__ __launch_bounds__(256) void k_pl_edge_stage(const DecimParams P_, int64_t i0, uint32_t len)
+{
+    const DecimParams& P = P_;
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= len) return;
+    const int b = blockIdx.y;
+    const int64_t i = i0 + (int64_t)j;
+    float2 x = make_float2(0.f, 0.f);
+    if (i >= 0) {
+        const uint64_t ui = (uint64_t)i;
+        if (ui >= P.n0) {
+            const uint64_t r = ui - P.n0;
+            if (r < P.n) {
+                x = P.in[(size_t)b * P.in_stride + (size_t)r];
+                const uint64_t kk = ui - P.rot_nbase;
+                x = cmul_fma(x, cmul_fma(sincos_turn(P.rot_acc + ((kk >> 9) << 9) * P.rot_inc), P.rot_lo[(uint32_t)kk & 511u]));
+            }
+        } else {
+            const uint64_t d = P.n0 - ui;
+            if (d <= P.hist_len) x = P.hist[(size_t)b * P.hist_len + (P.hist_len - (uint32_t)d)];
+        }
+    }
+    P.pl_edge[(size_t)b * P.pl_edge_stride + j] = x;
 }
 
 // One wave per output, checked fetches: zero in front of the stream, carried (already rotated) history in front of this
@@ -468,6 +512,12 @@ static PlGeom pl_geom(int nt, int D)
 // rule shared with oracle/orc_blocks.c orc_decim_uses_pl
 bool decim_uses_pl(int nt, int D) { return pl_geom(nt, D).ok; }
 
+size_t decim_pl_edge_len(int nt, int D)
+{
+    const PlGeom g = pl_geom(nt, D);
+    return g.ok ? (size_t)(2 * g.WU + 4) * g.Dp : 0;   // warm-up blocks + the blocks of <= (WU + 1) R + 1 edge outputs
+}
+
 // lane tap table [Upad][E][64]: lane l, sample e of a block (r = E l + e) meets output u + 1 with h[(u + 1) D - 1 - r];
 // the raw taps follow (k_decim_pl_gen reads them by index)
 std::vector<float> decim_pl_layout(const std::vector<float>& h, int D)
@@ -514,15 +564,27 @@ int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)
         if (m_tail > m_end) m_tail = m_end;
         if (m_main > m_tail) m_main = m_tail;
     }
+    bool edge_unit = false;
     if (m_main > p.m0) {
-        const uint32_t cnt = (uint32_t)(m_main - p.m0);
-        hipLaunchKernelGGL(k_decim_pl_gen, dim3((cnt + 3) / 4, batch), dim3(256), 0, s, q, p.m0, cnt);
+        // head edge: through the register kernel out of a staged scratch when it fits (R = 1 geometries), else one wave per output
+        const int64_t c_first = (int64_t)p.m0 - g.WU;                         // (R = 1) block of output m0 minus the warm-up blocks
+        const int64_t i0 = (c_first - 1) * (int64_t)g.Dp + 1;
+        const int64_t i_last = (int64_t)(m_main - 1) * g.Dp;                   // last sample of the last edge block
+        if (p.pl_edge && g.R == 1 && i_last - i0 + 1 <= (int64_t)p.pl_edge_cap) {
+            const uint32_t len = (uint32_t)(i_last - i0 + 1);
+            hipLaunchKernelGGL(k_pl_edge_stage, dim3((len + 255) / 256, batch), dim3(256), 0, s, q, i0, len);
+            q.pl_edge_ms = p.m0; q.pl_edge_me = m_main;
+            edge_unit = true;
+        } else {
+            const uint32_t cnt = (uint32_t)(m_main - p.m0);
+            hipLaunchKernelGGL(k_decim_pl_gen, dim3((cnt + 3) / 4, batch), dim3(256), 0, s, q, p.m0, cnt);
+        }
     }
     if (m_tail < m_end && m_tail >= m_main) {
         const uint32_t cnt = (uint32_t)(m_end - m_tail);
         hipLaunchKernelGGL(k_decim_pl_gen, dim3((cnt + 3) / 4, batch), dim3(256), 0, s, q, m_tail, cnt);
     }
-    if (m_main >= m_tail) return 0;
+    if (m_main >= m_tail && !edge_unit) return 0;
     const uint64_t total = (m_tail - m_main) * (uint64_t)batch;
     q.pl_m_begin = m_main; q.pl_m_end = m_tail;
     q.pl_batch = (uint32_t)batch;
@@ -538,7 +600,7 @@ int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)
         if (S < 16) S = 16;
         q.pl_S = (uint32_t)S;
         q.pl_nseg = (uint32_t)((m_tail - m_main + S - 1) / S);
-        const uint32_t units = q.pl_nseg * (uint32_t)batch;
+        const uint32_t units = q.pl_nseg * (uint32_t)batch + (edge_unit ? (uint32_t)batch : 0u);
         switch (J) {
         case 1: pl_launch_main<1>(q, units, s); break;   case 2: pl_launch_main<2>(q, units, s); break;
         case 3: pl_launch_main<3>(q, units, s); break;   case 4: pl_launch_main<4>(q, units, s); break;
@@ -561,7 +623,7 @@ int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)
     if (S < 16) S = 16;
     q.pl_S = (uint32_t)S;
     q.pl_nseg = (uint32_t)((m_tail - m_main + S - 1) / S);
-    const uint32_t units = q.pl_nseg * (uint32_t)batch;
+    const uint32_t units = q.pl_nseg * (uint32_t)batch + (edge_unit ? (uint32_t)batch : 0u);
     if (g.E == 2 && g.Upad == 42) hipLaunchKernelGGL((k_decim_plx<2, 1, 42>), dim3((units + 3) / 4), dim3(256), 0, s, q);
     else hipLaunchKernelGGL((k_decim_plx<2, 1, 48>), dim3((units + 3) / 4), dim3(256), 0, s, q);
     return 0;
