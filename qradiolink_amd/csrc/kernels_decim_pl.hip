@@ -570,12 +570,15 @@ int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)
         const int64_t c_first = (int64_t)p.m0 - g.WU;                         // (R = 1) block of output m0 minus the warm-up blocks
         const int64_t i0 = (c_first - 1) * (int64_t)g.Dp + 1;
         const int64_t i_last = (int64_t)(m_main - 1) * g.Dp;                   // last sample of the last edge block
+#ifndef QRL_PL_NO_EDGE   // (timing experiments: -DQRL_PL_NO_EDGE sends the edge outputs through k_decim_pl_gen)
         if (p.pl_edge && g.R == 1 && i_last - i0 + 1 <= (int64_t)p.pl_edge_cap) {
             const uint32_t len = (uint32_t)(i_last - i0 + 1);
             hipLaunchKernelGGL(k_pl_edge_stage, dim3((len + 255) / 256, batch), dim3(256), 0, s, q, i0, len);
             q.pl_edge_ms = p.m0; q.pl_edge_me = m_main;
             edge_unit = true;
-        } else {
+        } else
+#endif
+        {
             const uint32_t cnt = (uint32_t)(m_main - p.m0);
             hipLaunchKernelGGL(k_decim_pl_gen, dim3((cnt + 3) / 4, batch), dim3(256), 0, s, q, p.m0, cnt);
         }

@@ -8,6 +8,6 @@ OBJ=$(ls *.o | grep -v kernels_qpsk.o)
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950 $flags -c kernels_qpsk.hip -o ../../build/q4_$name.o
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build/libqrl_$name.so $OBJ ../../build/q4_$name.o
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build/libqrl_$name.so $OBJ ../../build/q4_$name.o -L/opt/rocm/lib -lhipfft -Wl,-rpath,/opt/rocm/lib
   echo built $name
 done
