@@ -1,5 +1,5 @@
 """Python model of the host-side MMDVM layer (TEST INFRASTRUCTURE), written from the reference sources independently of
-qradiolink_amd/host/mmdvm_wire.cpp: BurstTimer (src/bursttimer.cpp:180-299), gr_mmdvm_sink::work (src/gr/gr_mmdvm_sink.cpp:66-176),
+qradiolink_amd/host/mmdvm_wire.cpp: BurstTimer (src/bursttimer.cpp:20-280), gr_mmdvm_sink::work (src/gr/gr_mmdvm_sink.cpp:66-176),
 gr_mmdvm_source::work (src/gr/gr_mmdvm_source.cpp:65-243), gr_zero_idle_bursts::work (src/gr/gr_zero_idle_bursts.cpp:45-84)."""
 import struct
 

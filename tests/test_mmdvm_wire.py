@@ -114,7 +114,7 @@ def test_slot_mark_position_known_answer(lib):
     lib.mw_timer_set_timer(tm, 7 * 10 ** 9, 0)
     tc = C.c_int64(0)
     nsec = lib.mw_timer_allocate_slot(tm, 2, 0, C.byref(tc))
-    assert nsec == 7 * 10 ** 9 + M.BURST_DELAY     # _last_slot = elapsed (first allocation), + burst delay (bursttimer.cpp:281-296)
+    assert nsec == 7 * 10 ** 9 + M.BURST_DELAY     # _last_slot = elapsed (first allocation), + burst delay (bursttimer.cpp:240-280)
     lib.mw_sink_free(sink)
     lib.mw_timer_free(tm)
 
