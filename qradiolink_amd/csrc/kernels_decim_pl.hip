@@ -13,8 +13,8 @@
 //     global_load_dwordx2 per wave and block (D x 8 contiguous bytes straight from HBM into a VGPR pair), 8 blocks in
 //     flight per wave.
 //   * the lane's J = ceil(nt/D) taps h[p + jD] live in registers.  The sample of block c is rotated (exact NCO tables in
-//     LDS) and scattered into a ring of 16 running accumulators, acc[(c+j) & 15] += h[p+jD] * x (v_pk_fma_f32: re and im
-//     at once).  After block c the accumulator of output m = c is complete in every lane: each sample is read once, no LDS
+//     LDS) and scattered into a ring of 16 running accumulators, acc[(c+j) & 15] += h[p+jD] * x (plain v_fma_f32 pairs:
+//     this kernel is HBM bound, the packed form measured 6 % slower).  After block c the accumulator of output m = c is complete in every lane: each sample is read once, no LDS
 //     traffic for data, no barrier in the loop.
 //   * 16 finished accumulators x 64 lanes are summed over the lanes by a TRANSPOSING butterfly (v_permlane32_swap,
 //     v_permlane16_swap, DPP row rotations): every level halves the number of registers, 35 VALU per 16 outputs and
@@ -32,20 +32,8 @@ namespace qrl {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-#ifndef QRL_PL_PF
-#define QRL_PL_PF 8
-#endif
-#ifndef QRL_PL_SCHED
-#define QRL_PL_SCHED 0
-#endif
-#ifndef QRL_PL_SCALAR
-#define QRL_PL_SCALAR 1   // plain v_fma_f32 pairs: packed f32 (v_pk_fma_f32) is no faster on gfx950 and measured 6 % slower here
-#endif
-#ifndef QRL_PL_WPE
-#define QRL_PL_WPE 0
-#endif
 constexpr int PL_RING = 16;        // accumulator ring = unroll factor of the block loop
-constexpr int PL_PF = QRL_PL_PF;   // blocks in flight per wave
+constexpr int PL_PF = 8;           // blocks in flight per wave
 
 __device__ __forceinline__ float pl_dpp_ror8(float v)
 {
@@ -123,9 +111,6 @@ __device__ __forceinline__ int pl_out_index(int lane)
 
 template <int J>
 __global__ __launch_bounds__(256)
-#if QRL_PL_WPE
-__attribute__((amdgpu_waves_per_eu(QRL_PL_WPE, QRL_PL_WPE)))
-#endif
 void k_decim_pl(const DecimParams P_)
 {
     const DecimParams& P = P_;
@@ -182,15 +167,9 @@ void k_decim_pl(const DecimParams P_)
         const float2 v = ub[(size_t)t * D + lo];
         pf[q] = v2f{v.x, v.y};
     }
-#if QRL_PL_SCALAR
     float ar[PL_RING], ai[PL_RING];
 #pragma unroll
     for (int s = 0; s < PL_RING; ++s) ar[s] = ai[s] = 0.f;
-#else
-    v2f acc[PL_RING];
-#pragma unroll
-    for (int s = 0; s < PL_RING; ++s) acc[s] = v2f{0.f, 0.f};
-#endif
 
     constexpr int UB = PL_PF > PL_RING ? PL_PF : PL_RING;   // blocks per loop body (multiple of both rings)
     const int nsup = (nblk + UB - 1) / UB;
@@ -213,9 +192,7 @@ void k_decim_pl(const DecimParams P_)
                 const float2 plo = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(tl) + (kb8 & 4095u));
                 const float2 phi = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(t_hi) + ((kb8 >> 9) & ~7u));
                 const float2 xs = cmul_fma(make_float2(xr.x, xr.y), cmul_fma(phi, plo));
-                const v2f x = v2f{xs.x, xs.y};
                 // scatter into the ring: output m = c + j takes tap h[p + j D]; its first term (j = J - 1) is a plain product
-#if QRL_PL_SCALAR
 #pragma unroll
                 for (int j = 0; j < J - 1; ++j) {
                     ar[(i + j) % PL_RING] = fmaf(h[j], xs.x, ar[(i + j) % PL_RING]);
@@ -224,16 +201,6 @@ void k_decim_pl(const DecimParams P_)
                 ar[(i + J - 1) % PL_RING] = h[J - 1] * xs.x;
                 ai[(i + J - 1) % PL_RING] = h[J - 1] * xs.y;
                 dr[i] = ar[i]; di[i] = ai[i];
-                (void)x;
-#else
-#pragma unroll
-                for (int j = 0; j < J - 1; ++j) acc[(i + j) % PL_RING] = __builtin_elementwise_fma(v2f{h[j], h[j]}, x, acc[(i + j) % PL_RING]);
-                acc[(i + J - 1) % PL_RING] = v2f{h[J - 1], h[J - 1]} * x;
-                dr[i] = acc[i].x; di[i] = acc[i].y;
-#endif
-#if QRL_PL_SCHED
-                __builtin_amdgcn_sched_barrier(0);
-#endif
             }
             const float yr = pl_reduce16(dr, hi8, hi4), yi = pl_reduce16(di, hi8, hi4);
             const uint64_t m = c_first + (uint64_t)(sup * UB + grp * PL_RING + oidx);
@@ -570,15 +537,12 @@ int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)
         const int64_t c_first = (int64_t)p.m0 - g.WU;                         // (R = 1) block of output m0 minus the warm-up blocks
         const int64_t i0 = (c_first - 1) * (int64_t)g.Dp + 1;
         const int64_t i_last = (int64_t)(m_main - 1) * g.Dp;                   // last sample of the last edge block
-#ifndef QRL_PL_NO_EDGE   // (timing experiments: -DQRL_PL_NO_EDGE sends the edge outputs through k_decim_pl_gen)
         if (p.pl_edge && g.R == 1 && i_last - i0 + 1 <= (int64_t)p.pl_edge_cap) {
             const uint32_t len = (uint32_t)(i_last - i0 + 1);
             hipLaunchKernelGGL(k_pl_edge_stage, dim3((len + 255) / 256, batch), dim3(256), 0, s, q, i0, len);
             q.pl_edge_ms = p.m0; q.pl_edge_me = m_main;
             edge_unit = true;
-        } else
-#endif
-        {
+        } else {
             const uint32_t cnt = (uint32_t)(m_main - p.m0);
             hipLaunchKernelGGL(k_decim_pl_gen, dim3((cnt + 3) / 4, batch), dim3(256), 0, s, q, p.m0, cnt);
         }

@@ -1,15 +1,17 @@
-// kernels_qpsk.hip — the recursive part of gr_demod_qpsk (reference src/gr/gr_demod_qpsk.cpp:97-123,141-154)
-// fused into ONE kernel, one lane per stream:
-//   agc2_cc(1, 0.1, 1, 1)  ->  costas_loop_cc(pi/200/sps, 4, use_snr)  ->  symbol_sync_cc(MOD_M&M, sps, ...,
-//   constellation_dqpsk, MMSE 8 tap)  ->  costas_loop_cc(pi/400, 4, use_snr)  ->  diff_phasor_cc  ->
-//   multiply_const_cc(e^{-j 3 pi / 4})  -> port 1 (constellation) and the interleaved soft symbols
-//   (complex_to_float, interleave, x48, +128, float_to_uchar) that feed the single K=7 Viterbi (k_fec).
-// The blocks are causal per sample, so chaining them inside one serial loop is exact.  Workgroup = 64
-// streams: wave 0 runs the recursion out of an LDS window, waves 1-3 prefetch the next window of the
-// RRC-filtered input (coalesced along the stream) and flush the previous window's symbols.  Window k holds
-// samples [k W - 16, (k+1) W): the first 16 columns are Costas OUTPUTS carried over from the window before
-// (symbol sync looks back at most 13 samples), the rest arrives raw and is overwritten in place by pass 1
-// (AGC + Costas), then pass 2 (symbol sync and everything at the symbol rate) walks the row.
+// kernels_qpsk.hip — the recursive chains with a complex symbol synchroniser, one lane per stream (workgroup = 64 streams):
+//   k_qpsk_pipe4    gr_demod_qpsk (reference src/gr/gr_demod_qpsk.cpp:97-123,141-154): agc2_cc(1, 0.1, 1, 1) ->
+//                   costas_loop_cc(pi/200/sps, 4, use_snr) -> symbol_sync_cc(MOD_M&M, sps, ..., constellation_dqpsk, MMSE 8 tap) ->
+//                   costas_loop_cc(pi/400, 4, use_snr) -> diff_phasor_cc -> multiply_const_cc(e^{-j 3 pi / 4}) -> port 1
+//                   (constellation) and the interleaved soft symbols (x48, +128, float_to_uchar) that feed the K=7 Viterbi (k_fec);
+//                   every recurrence on its own wave (see the kernel).
+//   k_qpsk_loops<1> gr_demod_bpsk (src/gr/gr_demod_bpsk.cpp:54-101): agc2_cc(0.1, 0.1) -> clock_recovery_mm_cc ->
+//                   costas_loop_cc(2 pi / 200, 2) -> real part x64 + 128
+//   k_qpsk_loops<2> symbol_sync_cc alone on the 4-level rect constellation (gr_demod_4fsk non-FM branch, gr_demod_4fsk.cpp:138-195)
+// The blocks are causal per sample, so chaining them inside one serial loop is exact.  k_qpsk_loops: wave 0 runs the recursion out
+// of an LDS window, waves 1-3 prefetch the next window of the filtered input (coalesced along the stream) and flush the previous
+// window's symbols.  Window k holds samples [k W - 16, (k+1) W): the first 16 columns are carried over from the window before
+// (symbol sync looks back at most 13 samples), the rest arrives raw, is overwritten in place by pass 1 (AGC), then pass 2 (clock
+// recovery and everything at the symbol rate) walks the row.
 #include <cstdlib>
 #include "devmath.hpp"
 #include "engine.hpp"
@@ -22,12 +24,6 @@ constexpr int QP_COLS = QP_BACK + QP_W;      // 80
 constexpr int QP_PITCH = QP_COLS + 1;        // float2 units, odd
 constexpr int QP_OMAX = 38;                  // symbols per stream per window (sps >= 1.9)
 constexpr int QP_OPITCH = QP_OMAX + 1;
-
-__device__ __forceinline__ float costas4_snr_error(float2 o, const float* __restrict__ T)
-{
-    const float snr = (o.x * o.x + o.y * o.y);
-    return (tanhf_lut(snr * o.x, T) * o.y) - (tanhf_lut(snr * o.y, T) * o.x);
-}
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batch)
@@ -115,7 +111,7 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
                     if (P.port && kk1 < P.port_cap) P.port[(size_t)(b0 + s) * P.port_cap + kk1] = v;
                     continue;
                 }
-                // complex_to_float -> interleave -> multiply_const(48) -> add_const(128) -> float_to_uchar
+                // MODE 2: complex_to_float -> interleave -> multiply_const(128) -> add_const(128) -> float_to_uchar
                 float qa = v.x * P.soft_mul; qa = qa + P.soft_add;
                 float qb = v.y * P.soft_mul; qb = qb + P.soft_add;
                 float ra = rintf(qa), rb = rintf(qb);
@@ -133,7 +129,6 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
     __syncthreads();
     if (k_first <= k_last) load_window(k_first, tid, 256);
     __syncthreads();
-    const float SQ = 0.707107f;
     for (long long k = k_first; k <= k_last; ++k) {
         if (wv == 0) {
             const int pb = (int)(k & 1);
@@ -150,24 +145,14 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
             if (active) {
                 for (int c = ca; c < cb; ++c) {
                     if (MODE == 2) break;   // symbol_sync_cc consumes the samples as they are
+                    // MODE 1: agc2_cc(0.1, 0.1) in place (gr_demod_bpsk.cpp:88-90: no Costas loop in front of the clock recovery)
                     const float2 x = row[c];
                     float2 a; a.x = x.x * st.gain; a.y = x.y * st.gain;
                     const float tmp = -1.0f + sqrtf(a.x * a.x + a.y * a.y);
-                    float rate = 0.1f;
-                    if (MODE == 0 && tmp > st.gain) rate = 1.0f;   // agc2_cc(attack 1, decay 0.1) for QPSK, (0.1, 0.1) for BPSK
-                    st.gain -= tmp * rate;
+                    st.gain -= tmp * 0.1f;
                     if (st.gain < 0.0f) st.gain = 10e-5f;
                     if (st.gain > 65536.0f) st.gain = 65536.0f;
-                    if (MODE == 1) { row[c] = a; continue; }       // gr_demod_bpsk.cpp:88-90: no Costas loop in front of the clock recovery
-                    const float2 nco = sincos_rad(-st.c1_phase);   // (cos, sin)
-                    float2 o; o.x = a.x * nco.x - a.y * nco.y; o.y = a.x * nco.y + a.y * nco.x;
-                    row[c] = o;
-                    float e = costas4_snr_error(o, th);
-                    e = branchless_clip(e, 1.0f);
-                    st.c1_freq = st.c1_freq + P.c1_beta * e;
-                    st.c1_phase = st.c1_phase + st.c1_freq + P.c1_alpha * e;
-                    st.c1_phase = phase_wrap(st.c1_phase);
-                    if (st.c1_freq > 1.0f) st.c1_freq = 1.0f; else if (st.c1_freq < -1.0f) st.c1_freq = -1.0f;
+                    row[c] = a;
                 }
             }
             // ---- pass 2: symbol_sync_cc and the symbol-rate blocks
@@ -212,7 +197,7 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
                 nsym++;
                 st.oo++;
             }
-            while (MODE != 1 && active && st.ii + 8 <= wend && nsym < QP_OMAX) {
+            while (MODE == 2 && active && st.ii + 8 <= wend && nsym < QP_OMAX) {   // symbol_sync_cc alone (gr_demod_4fsk non-FM branch)
                 const int off = (int)((long long)st.ii - i0);
                 const int imu = (int)rintf(st.mu * 128.0f);
                 const float* t = mm + imu * 8;
@@ -225,12 +210,10 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
                 }
                 st.x2 = st.x1; st.x1 = st.x0; st.x0 = y;
                 st.d2 = st.d1; st.d1 = st.d0;
-                if (MODE == 2) {   // constellation_rect{-1.5,-0.5,0.5,1.5}: real-axis sector point, imag 0 (oracle slice_real)
+                {   // constellation_rect{-1.5,-0.5,0.5,1.5}: real-axis sector point, imag 0 (oracle slice_real)
                     int sector = (int)((double)y.x + 2.0);
                     sector = sector < 0 ? 0 : (sector > 3 ? 3 : sector);
                     st.d0.x = (float)sector - 1.5f; st.d0.y = 0.0f;
-                } else {
-                    st.d0.x = y.x > 0.f ? SQ : -SQ; st.d0.y = y.y > 0.f ? SQ : -SQ;
                 }
                 float e;
                 {
@@ -247,21 +230,7 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
                 const float fl = floorf(ph);
                 st.mu = ph - fl;
                 st.ii += (uint64_t)(int)fl;
-                if (MODE == 2) { orow[nsym] = y; nsym++; st.oo++; continue; }
-                // second Costas loop at the symbol rate
-                const float2 nco = sincos_rad(-st.c2_phase);
-                float2 o; o.x = y.x * nco.x - y.y * nco.y; o.y = y.x * nco.y + y.y * nco.x;
-                float e2 = costas4_snr_error(o, th);
-                e2 = branchless_clip(e2, 1.0f);
-                st.c2_freq = st.c2_freq + P.c2_beta * e2;
-                st.c2_phase = st.c2_phase + st.c2_freq + P.c2_alpha * e2;
-                st.c2_phase = phase_wrap(st.c2_phase);
-                if (st.c2_freq > 1.0f) st.c2_freq = 1.0f; else if (st.c2_freq < -1.0f) st.c2_freq = -1.0f;
-                // diff_phasor_cc, then multiply_const_cc(e^{-j 3 pi / 4})
-                float2 dp; dp.x = o.x * st.dprev.x + o.y * st.dprev.y; dp.y = o.y * st.dprev.x - o.x * st.dprev.y;
-                st.dprev = o;
-                float2 v; v.x = dp.x * P.rot.x - dp.y * P.rot.y; v.y = dp.x * P.rot.y + dp.y * P.rot.x;
-                orow[nsym] = v;
+                orow[nsym] = y;
                 nsym++;
                 st.oo++;
             }
@@ -301,9 +270,6 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
 // one barrier per window.  The samples live in one LDS ring per stream (5 windows of 32 columns + an 8-column mirror of the first
 // columns so that the 8-tap interpolator never wraps); the loops are straight-line code (selects instead of branches, inputs of four
 // steps loaded ahead of the recurrence).  The arithmetic and its order are those of k_qpsk_loops<0> / the oracle (bit-exact).
-#ifndef QRL_Q4_SKIP
-#define QRL_Q4_SKIP 0
-#endif
 constexpr int Q4_W = 32, Q4_NB = 5, Q4_RC = Q4_W * Q4_NB, Q4_MIR = 8;
 constexpr int Q4_PITCH = Q4_RC + Q4_MIR + 1;   // 169 float2, odd
 constexpr int Q4_OMAX = 20;                    // symbols per stream per window (sps >= 1.9: 32 / 1.9 + 2)
@@ -460,7 +426,7 @@ __global__ __launch_bounds__(384) void k_qpsk_pipe4(const QpskParams P, int batc
     const float SQ = 0.707107f;
     for (long long t = k_first; t <= k_last + 4; ++t) {
         if (wv == 0) {
-            if (QRL_Q4_SKIP != 1 && t <= k_last && active) {                      // ---- agc2_cc on window t, in place
+            if (t <= k_last && active) {                      // ---- agc2_cc on window t, in place
                 const int base = (int)(t % Q4_NB) * Q4_W;
                 const int ca = base + (int)(max((long long)np0, t * Q4_W) - t * Q4_W), cb = base + (int)(min((long long)avail, (t + 1) * Q4_W) - t * Q4_W);
                 int c = ca;
@@ -477,7 +443,7 @@ __global__ __launch_bounds__(384) void k_qpsk_pipe4(const QpskParams P, int batc
             }
         } else if (wv == 1) {
             const long long k = t - 1;
-            if (QRL_Q4_SKIP != 2 && k >= k_first && k <= k_last && active) {      // ---- first Costas loop on window k, in place
+            if (k >= k_first && k <= k_last && active) {      // ---- first Costas loop on window k, in place
                 const int base = (int)(k % Q4_NB) * Q4_W;
                 const int ca = base + (int)(max((long long)np0, k * Q4_W) - k * Q4_W), cb = base + (int)(min((long long)avail, (k + 1) * Q4_W) - k * Q4_W);
                 int c = ca;
