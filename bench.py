@@ -350,7 +350,7 @@ def main():
     if rank == 0:
         def roof(r):
             # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process; the number is
-            # the one measured by the separate rocprofv3 --pmc passes of tools/gpu_profile_final.sh on this same command
+            # the one measured by the separate rocprofv3 --pmc passes of tools/r02_profile.sh on this same command
             # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), kept in profiles/pmc_traffic.json per workload shape.
             traffic, src = None, None
             try:

@@ -277,18 +277,27 @@ class Demod:
         f, c, b = C.c_size_t(), C.c_size_t(), C.c_size_t()
         _check(self.lib.qrl_demod_out_caps(self.h, max_chunk, C.byref(f), C.byref(c), C.byref(b)), "qrl_demod_out_caps")
         self.caps = (f.value, c.value, b.value)
-        dev = "cuda:%d" % ctx.device
-        self.filtered = torch.zeros((batch, f.value), dtype=torch.complex64, device=dev) if side_outputs else None
-        self.constellation = torch.zeros((batch, c.value), dtype=torch.complex64, device=dev) if side_outputs else None
-        self.bits_a = torch.zeros((batch, b.value), dtype=torch.uint8, device=dev)
-        self.bits_b = torch.zeros((batch, b.value), dtype=torch.uint8, device=dev)
-        self.counts = torch.zeros((batch, 4), dtype=torch.int32, device=dev)
+        self.new_outputs()
+
+    def new_outputs(self):
+        """Fresh output tensors for the following calls (calls that are in flight together need their own: the serial tail of call
+        k runs beside the front end of call k + 1).  Returns them as a dict; the previous set stays valid for its calls."""
+        torch = self.torch
+        f, c, b = self.caps
+        dev = "cuda:%d" % self.ctx.device
+        self.filtered = torch.zeros((self.batch, f), dtype=torch.complex64, device=dev) if self.side else None
+        self.constellation = torch.zeros((self.batch, c), dtype=torch.complex64, device=dev) if self.side else None
+        self.bits_a = torch.zeros((self.batch, b), dtype=torch.uint8, device=dev)
+        self.bits_b = torch.zeros((self.batch, b), dtype=torch.uint8, device=dev)
+        self.counts = torch.zeros((self.batch, 4), dtype=torch.int32, device=dev)
         self._out = _Out()
-        if side_outputs:
-            self._out.filtered, self._out.filtered_cap = self.filtered.data_ptr(), f.value
-            self._out.constellation, self._out.constellation_cap = self.constellation.data_ptr(), c.value
-        self._out.bits_a, self._out.bits_b, self._out.bits_cap = self.bits_a.data_ptr(), self.bits_b.data_ptr(), b.value
+        if self.side:
+            self._out.filtered, self._out.filtered_cap = self.filtered.data_ptr(), f
+            self._out.constellation, self._out.constellation_cap = self.constellation.data_ptr(), c
+        self._out.bits_a, self._out.bits_b, self._out.bits_cap = self.bits_a.data_ptr(), self.bits_b.data_ptr(), b
         self._out.counts = self.counts.data_ptr()
+        torch.cuda.current_stream().synchronize()   # the zero fills ran on torch's stream
+        return dict(filtered=self.filtered, constellation=self.constellation, bits_a=self.bits_a, bits_b=self.bits_b, counts=self.counts)
 
     def process_async(self, iq):
         """Queue one pass over iq ([batch, n] complex64 cuda tensor) on the handle's stream."""

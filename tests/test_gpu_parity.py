@@ -222,11 +222,12 @@ def test_dmr_dibits_recovered(qrl_ctx):
     assert best == 1.0
 
 
-@pytest.mark.parametrize("mode_name,modem", [("2fsk1k", 18), ("2fsk1kfm", 16), ("gmsk10k", 22)])
+@pytest.mark.parametrize("mode_name,modem", [("2fsk1k", 18), ("2fsk1kfm", 16), ("gmsk10k", 22), ("qpsk250k", 26), ("bpsk2k", 0)])
 def test_pipelined_calls_without_sync(qrl_ctx, mode_name, modem):
     """Back-to-back qrl_demod_process calls with NO sync in between (how bench.py drives the handle; the 2FSK family then runs
-    its decimated-rate kernels of call k under the front end of call k + 1, ring s2 holding two calls): the outputs of the
-    last call equal those of the same sequence run with a sync after every call, and the bits equal the oracle's tail."""
+    its decimated-rate kernels of call k under the front end of call k + 1, ring s2 holding two calls; the QPSK / BPSK families run
+    feed-forward kernels, recursion and Viterbi decoder of three consecutive calls side by side on three streams): the outputs of
+    the last call equal those of the same sequence run with a sync after every call, and the bits equal the oracle's tail."""
     import torch
     import qradiolink_amd as q
     B, chunk = 130, 40000
@@ -253,6 +254,44 @@ def test_pipelined_calls_without_sync(qrl_ctx, mode_name, modem):
     ref = _oracle(mode_name, iq[0, :ncalls * chunk], 1000000, 0.0)
     n_last = int(c1[0, 2])
     assert n_last > 0 and np.array_equal(a1[0, :n_last], ref["bits_a"][-n_last:])
+
+
+@pytest.mark.parametrize("mode_name,modem", [("qpsk250k", 26), ("bpsk2k", 0), ("gmsk10k", 22), ("2fsk1k", 18)])
+def test_every_call_of_a_pipelined_sequence_is_deterministic(qrl_ctx, mode_name, modem):
+    """Calls in flight together (each with its own output buffers, no sync in between): EVERY call's counts, bits and port 1 equal
+    those of the same sequence run with a sync after every call -- the Viterbi decoder of call k, running beside the recursion of
+    call k + 1, must only see call k's symbols (per-call symbol-count snapshot), whatever the timing."""
+    import torch
+    import qradiolink_amd as q
+    B, chunk = 70, 30000
+    iq = sig.make_batch(mode_name, 2, nframes=2, device_rate=1000000, seed=8)
+    iq = np.concatenate([iq, iq[::-1]] * (B // 4 + 1))[:B]
+    ncalls = iq.shape[1] // chunk
+    d = torch.from_numpy(iq).cuda()
+    runs = []
+    for sync_each in (True, False):
+        dem = q.Demod(qrl_ctx, modem, batch=B, max_chunk=chunk)
+        if mode_name.startswith("2fsk") and not sync_each:
+            dem.set_option(q.OPT_OVERLAP, 1)
+        outs = []
+        for k in range(ncalls):
+            outs.append(dem.new_outputs())
+            dem.process_async(d[:, k * chunk:(k + 1) * chunk])
+            if sync_each:
+                dem.sync()
+        dem.sync()
+        runs.append([{key: v.cpu().numpy().copy() for key, v in o.items() if v is not None} for o in outs])
+        dem.close()
+    total_bits = 0
+    for k in range(ncalls):
+        r0, r1 = runs[0][k], runs[1][k]
+        assert np.array_equal(r0["counts"], r1["counts"]), "call %d" % k
+        for b in range(B):
+            c = r0["counts"][b]
+            assert np.array_equal(r0["bits_a"][b, :c[2]], r1["bits_a"][b, :c[2]]) and np.array_equal(r0["bits_b"][b, :c[3]], r1["bits_b"][b, :c[3]])
+            assert np.array_equal(r0["constellation"][b, :c[1]].view(np.uint32), r1["constellation"][b, :c[1]].view(np.uint32))
+        total_bits += int(r0["counts"][:, 2].sum())
+    assert total_bits > 0
 
 
 @pytest.mark.parametrize("mode_name,modem,rate,B,nframes", [
