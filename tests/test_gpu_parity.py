@@ -122,6 +122,43 @@ def test_chunk_invariance_qpsk(qrl_ctx, chunk):
     _compare(iq, out, "qpsk250k", 1000000, 1200.0)
 
 
+@pytest.mark.parametrize("mode_name,modem,rate", [
+    ("2fsk1k", 18, 1000000),       # k_decim_pl: the edge outputs read the history rotated with the OLD offset, the buffer head with the new one
+    ("gmsk10k", 22, 25000000),     # k_decim_mfma
+    ("qpsk250k", 26, 100000000),   # k_decim_plx
+    ("gmsk10k", 22, 4000000),      # k_decim
+])
+def test_carrier_offset_retune_is_phase_continuous(qrl_ctx, mode_name, modem, rate):
+    """qrl_demod_set_carrier_offset between calls = rotator_cc::set_phase_inc (gr_demod_base.cpp:1220-1225): the phase runs on, the
+    increment changes from the next sample, and the samples already inside the decimator's history keep their old rotation.
+    Expected: the oracle chain (offset 0) on the input rotated piecewise by the oracle's exact NCO."""
+    import torch
+    import qradiolink_amd as q
+    f1, f2 = (1200.0, -800.0) if rate < 2000000 else (25000.0, -12500.0)
+    iq = sig.make_batch(mode_name, 2, nframes=2, device_rate=rate, rx_offset_hz=f1, seed=13)
+    n1 = (iq.shape[1] // 3) & ~1
+    dem = q.Demod(qrl_ctx, modem, batch=2, max_chunk=iq.shape[1], device_samp_rate=rate, carrier_offset_hz=f1)
+    d = torch.from_numpy(iq).cuda()
+    parts = []
+    for lo, hi, f in ((0, n1, None), (n1, iq.shape[1], f2)):
+        if f is not None:
+            q._check(dem.lib.qrl_demod_set_carrier_offset(dem.h, f), "qrl_demod_set_carrier_offset")
+        o = dem.process(d[:, lo:hi].contiguous())
+        c = o["counts"].cpu().numpy()
+        parts.append({k: [o[k][b, :c[b, j]].cpu().numpy().copy() for b in range(2)] for k, j in (("filtered", 0), ("bits_a", 2))})
+    dem.close()
+    inc1 = orc.phase_inc_to_turn(2 * np.pi * -f1 / rate)
+    inc2 = orc.phase_inc_to_turn(2 * np.pi * -f2 / rate)
+    for b in range(2):
+        y = np.concatenate([orc.rotator(iq[b, :n1], inc1, 0), orc.rotator(iq[b, n1:], inc2, (n1 * inc1) & 0xFFFFFFFFFFFFFFFF)])
+        # the oracle front end with offset 0 multiplies by the exact phasor (1, 0): an identity
+        ref = _oracle(mode_name, y, rate, 0.0)
+        got_f = np.concatenate([p["filtered"][b] for p in parts]).view(np.float32) + np.float32(0)
+        got_a = np.concatenate([p["bits_a"][b] for p in parts])
+        assert np.array_equal(got_f.view(np.uint32), (ref["filtered"].view(np.float32) + np.float32(0)).view(np.uint32))
+        assert got_a.size == ref["bits_a"].size and np.array_equal(got_a, ref["bits_a"])
+
+
 def test_front_end_repeatable_under_load(qrl_ctx):
     """Race hunt: the 25 Msps front end runs two workgroups per CU; repeat the same batch and require
     bit-identical port 0 every time (an earlier hand-scheduled LDS pipeline failed this ~1e-4 per tile)."""
