@@ -947,18 +947,59 @@ size_t orc_mod_mmdvm(const int16_t* in, size_t n, int filter_width, float bb_gai
  *   constellation_rect{-1.5,-0.5,0.5,1.5}) -> multiply_const(0.9) -> phase_modulator_fc(pi/2) -> [port 1] -> complex_to_float ->
  *   interleave -> binary_slicer_fb -> pack_k_bits(2) -> map{3,1,2,0} -> unpack_k_bits(2) -> [port 2].
  * phase_modulator_fc's sincosf is the deterministic polynomial here (orc_sincosf). */
-void orc_4fsk_symbols_to_bits(const float* sym, size_t nsym, cf32* constellation, uint8_t* bits)
+static void symbols_to_bits_scaled(const float* sym, size_t nsym, float scale, cf32* constellation, uint8_t* bits)
 {
     static const int map[4] = {3, 1, 2, 0};
     const float k = (float)(M_PI / 2);
     for (size_t i = 0; i < nsym; i++) {
-        const float s = sym[i] * 0.9f;
+        const float s = sym[i] * scale;
         cf32 c; orc_sincosf(k * s, &c.im, &c.re);
         if (constellation) constellation[i] = c;
         const int v = ((c.re >= 0.0f) << 1) | (c.im >= 0.0f);
         const int m = map[v];
         bits[2 * i] = (uint8_t)((m >> 1) & 1); bits[2 * i + 1] = (uint8_t)(m & 1);
     }
+}
+void orc_4fsk_symbols_to_bits(const float* sym, size_t nsym, cf32* constellation, uint8_t* bits)
+{
+    symbols_to_bits_scaled(sym, nsym, 0.9f, constellation, bits);   /* gr_demod_dmr.cpp:73: _level_control 0.9 */
+}
+/* gr_demod_m17 (reference src/gr/gr_demod_m17.cpp:32-103, instance make_gr_demod_m17() gr_demod_base.cpp:252): the 4FSK symbol
+ * demodulator of the M17 mode.  rational_resampler_ccf(3, 125, low_pass(3, 3 fs, 12k, 12k, BH)) -> fft_filter_ccf(low_pass(1, 24k, fw,
+ * fw, BH)) [port 0] -> quadrature_demod_cf(5 / pi) -> fft_filter_fff(RRC(1.5, 24k, 4.8k, 0.5, 250)) -> symbol_sync_ff(MOD_M&M, 5,
+ * 2 pi / (4800 / 50), 1.0, 0.2869, 500 / 4800, 1, constellation_rect 4 level) -> phase_modulator_fc(pi / 2) [port 1] -> slicer ->
+ * pack(2) -> map{3,1,2,0} -> unpack(2) [port 2] */
+void orc_demod_m17(const cf32* in, size_t n, int samp_rate, int filter_width, orc_demod_out* o)
+{
+    memset(o, 0, sizeof *o);
+    int nt = orc_low_pass(3, (double)samp_rate * 3, 12000, 12000, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* taps = NEW(float, nt);
+    orc_low_pass(3, (double)samp_rate * 3, 12000, 12000, ORC_WIN_BLACKMAN_HARRIS, taps);
+    size_t n1 = orc_decim_count(n, 3, 125);
+    cf32* r = NEW(cf32, n1);
+    orc_resamp_ccf(in, n, taps, nt, 3, 125, r);
+    free(taps);
+    int nf = orc_low_pass(1, 24000, filter_width, filter_width, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* ft = NEW(float, nf);
+    orc_low_pass(1, 24000, filter_width, filter_width, ORC_WIN_BLACKMAN_HARRIS, ft);
+    o->filtered = NEW(cf32, n1); o->n_filtered = n1;
+    orc_fir_ccf(r, n1, ft, nf, o->filtered);
+    free(ft); free(r);
+    float* d = NEW(float, n1);
+    orc_quad_demod(o->filtered, n1, (float)(5 / M_PI), d);
+    int nr = orc_root_raised_cosine(1.5, 24000, 4800, 0.5, 250, NULL);
+    float* rrc = NEW(float, nr);
+    orc_root_raised_cosine(1.5, 24000, 4800, 0.5, 250, rrc);
+    float* f = NEW(float, n1);
+    orc_fir_fff(d, n1, rrc, nr, f);
+    free(rrc); free(d);
+    float* sym = NEW(float, n1 / 4 + 16);
+    size_t nsym = orc_symbol_sync_ff(f, n1, ORC_TED_MOD_MM, 5.0f, (float)(2 * M_PI / (4800.0f / 50)), 1.0f, 0.2869f, 500.0f / 4800.0f, ORC_CONST_4LEVEL, sym);
+    free(f);
+    o->constellation = NEW(cf32, nsym); o->n_const = nsym;
+    o->bits_a = NEW(uint8_t, 2 * nsym); o->n_bits_a = 2 * nsym;
+    symbols_to_bits_scaled(sym, nsym, 1.0f, o->constellation, o->bits_a);
+    free(sym);
 }
 /* port 3 of gr_demod_dmr (gr_demod_dmr.cpp:94): the RRC-filtered discriminator output at 24 ksps, what gr_dmr_dmo_sink is fed;
  * same arithmetic as the first half of orc_demod_dmr below.  out may be NULL to size. */

@@ -164,6 +164,7 @@ struct qrl_demod {
     // overlapped mode (2FSK / GMSK / 4FSK families): everything behind the first decimated ring runs on the tail stream while
     // the front end of the NEXT call already runs on the main stream; ring s2 holds two calls, ev_tail2 guards its reuse
     bool qpsk_fll = false, fsk4_disc = false;
+    bool m17 = false;   // F_DMR family, gr_demod_m17 variant: channel filter behind the resampler (port 0), mod-M&M TED, no level control
     DevBuf<float2> s2g, disc4_taps; DevBuf<float> sym4_taps; int disc4_nt = 0, sym4_nt = 0;   // 4FSK non-FM branch
     bool overlap = false, overlap_capable = false; hipEvent_t ev_tail2[2] = {nullptr, nullptr}; bool tail2_valid[2] = {false, false}; uint64_t call_no = 0;
     enum Family { F_2FSK, F_GMSK, F_QPSK, F_DMR, F_4FSK, F_BPSK } fam = F_2FSK;
@@ -282,7 +283,7 @@ int qrl_demod::build()
         else if (sps == 1) { target = 80000; sps_eff = 4;       decim = 25; interp = 2; }
         else return fail(QRL_ERR_ARG, "gmsk: unsupported sps");
     } else if (fam == F_DMR) {
-        // gr_demod_dmr.cpp:36-58: 3/125 resampler to 24 ksps, 5 samples per symbol
+        // gr_demod_dmr.cpp:36-58, gr_demod_m17.cpp:38-58: 3/125 resampler to 24 ksps, 5 samples per symbol
         target = 24000; sps_eff = 5; decim = 125; interp = 3; branches = 1;
     } else if (fam == F_4FSK) {
         // gr_demod_4fsk.cpp:45-82 (FM branch only; the non-FM discriminator bank of 4FSK2K is not built)
@@ -323,7 +324,9 @@ int qrl_demod::build()
     if ((r = upload_rot_table())) return r;
 
     // --- per-mode first resampler (gr_demod_2fsk.cpp:82-88, gr_demod_gmsk.cpp:80-83)
-    const std::vector<float> rtaps = fam == F_DMR
+    const std::vector<float> rtaps = fam == F_DMR && m17
+        ? low_pass(3, (double)samp_rate * 3, target / 2, target / 2, WIN_BLACKMAN_HARRIS)                    // gr_demod_m17.cpp:55-58
+        : fam == F_DMR
         ? low_pass_2(3, (double)samp_rate * 3, 5000, 2000, 60, WIN_BLACKMAN_HARRIS)                          // gr_demod_dmr.cpp:55-58
         : fam == F_QPSK
         ? low_pass_2(interp, (double)interp * samp_rate, target / 2, target / 10, 60, WIN_BLACKMAN_HARRIS)   // gr_demod_qpsk.cpp:92-96
@@ -410,6 +413,14 @@ int qrl_demod::build()
         const float dev = 200.0f / symbol_rate;
         clock_loop_gains((float)(2 * M_PI / (symbol_rate / 10)), 1.0f, 0.2869f, ss_alpha, ss_beta);
         ss_maxp = (float)sps_eff + dev; ss_minp = (float)sps_eff - dev;
+    } else if (fam == F_DMR && m17) {
+        const std::vector<float> rrc = root_raised_cosine(1.5, target, target / sps_eff, 0.5, 50 * sps_eff); // gr_demod_m17.cpp:64-67
+        symf_nt = (int)rrc.size();
+        if ((r = symf_taps.upload(rrc))) return r;
+        demod_gain = (float)(sps_eff / M_PI);                                                                // :63
+        const float symbol_rate = (float)target / (float)sps_eff;
+        clock_loop_gains((float)(2 * M_PI / (symbol_rate / 50)), 1.0f, 0.2869f, ss_alpha, ss_beta);          // :70-71
+        ss_maxp = (float)sps_eff + 500.0f / symbol_rate; ss_minp = (float)sps_eff - 500.0f / symbol_rate;
     } else if (fam == F_DMR) {
         const std::vector<float> rrc = root_raised_cosine(1, target, target / sps_eff, 0.2, 25 * sps_eff);   // gr_demod_dmr.cpp:62-66
         symf_nt = (int)rrc.size();
@@ -546,7 +557,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         p.n0 = src0; p.n = (uint32_t)(src1 - src0);
         p.out = r2; p.q0 = n2_0; p.q_count = (uint32_t)(n2_1 - n2_0);
         p.taps = rs_taps.p; p.I = interp; p.D = decim; p.Jp = rs_Jp;
-        if (fam == F_DMR) {   // port 0 of gr_demod_dmr is the resampler output (gr_demod_dmr.cpp:89)
+        if (fam == F_DMR && !m17) {   // port 0 of gr_demod_dmr is the resampler output (gr_demod_dmr.cpp:89)
             const bool sd = cfg.enable_side_outputs && out;
             p.port = sd && out->filtered ? reinterpret_cast<float2*>(out->filtered) : nullptr;
             p.port_cap = sd ? out->filtered_cap : 0;
@@ -582,7 +593,17 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
     }
     const bool fused_2fsk = fam == F_2FSK && !fm && filt_nt <= 41 && disc_nt <= 41 && symf_nt <= 25;
     if (fam == F_DMR) {
-        QuadDemodParams q{}; q.in = r2; q.out = r2d; q.q0 = n2_0; q.count = c2; q.gain = demod_gain; q.atan_tab = atan_tab.p;
+        RingC dem_in = r2;
+        if (m17) {   // gr_demod_m17.cpp:60-61,89-90: channel filter behind the resampler, its output is port 0
+            FirCcfParams f{};
+            f.in = r2; f.out = r2f; f.q0 = n2_0; f.count = c2; f.taps = filt_taps.p; f.nt = filt_nt;
+            f.port = side && out->filtered ? reinterpret_cast<float2*>(out->filtered) : nullptr;
+            f.port_cap = side ? out->filtered_cap : 0;
+            f.counts = counts;
+            launch_fir_ccf(f, B, cs);
+            dem_in = r2f;
+        }
+        QuadDemodParams q{}; q.in = dem_in; q.out = r2d; q.q0 = n2_0; q.count = c2; q.gain = demod_gain; q.atan_tab = atan_tab.p;
         launch_quad_demod(q, B, cs);
         if (!overlap && tail_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_tail, 0)); tail_pending = false; }
         FirFffParams f{}; f.in = r2d; f.out = r3; f.q0 = n2_0; f.count = c2; f.taps = symf_taps.p; f.nt = symf_nt;
@@ -672,14 +693,15 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         SymSyncParams s{};
         s.in = r3; s.avail = n2_1; s.soft = RingB{soft.p, soft_mask}; s.st = ss_st.p; s.mmse = mmse_tab.p;
         s.alpha = ss_alpha; s.beta = ss_beta; s.maxp = ss_maxp; s.minp = ss_minp;
-        s.ted = fam == F_DMR ? 0 : 1; s.soft_mul = 128.0f; s.soft_add = 128.0f;
+        s.ted = fam == F_DMR && !m17 ? 0 : 1; s.soft_mul = 128.0f; s.soft_add = 128.0f;
+        s.tail_scale = m17 ? 1.0f : 0.9f;
         s.slicer = fam == F_DMR || fam == F_4FSK ? 1 : 0; s.tail = fam == F_DMR ? 1 : fam == F_4FSK ? 2 : 0;
         s.bits = out ? out->bits_a : nullptr; s.bits_cap = out ? out->bits_cap : 0;
         s.port = side && out->constellation ? reinterpret_cast<float2*>(out->constellation) : nullptr;
         s.port_cap = side ? out->constellation_cap : 0;
         s.counts = counts;
         launch_symsync_ff(s, B, tail);
-        if (fam == F_DMR && dmo_out) {   // gr_dmr_dmo_sink on port 3 (= ring r3) of this call
+        if (fam == F_DMR && !m17 && dmo_out) {   // gr_dmr_dmo_sink on port 3 (= ring r3) of this call
             DmoParams dp{}; dp.in = r3; dp.q0 = n2_0; dp.count = (uint32_t)(n2_1 - n2_0); dp.st = dmo_st.p; dp.golay = dmo_golay.p;
             dp.out = dmo_out; dp.cap = dmo_cap; dp.counts = dmo_counts;
             launch_dmo_sink(dp, B, tail);
@@ -769,6 +791,7 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         case QRL_MODEM_BPSK1K:    c.sps = 10; c.filter_width = 1300;   c.fm = 0; break;   // :216
         case QRL_MODEM_BPSK2K:    c.sps = 5;  c.filter_width = 2400;   c.fm = 0; break;   // :217
         case QRL_MODEM_DMR:       c.sps = 5;  c.filter_width = 5000;   c.fm = 0; break;   // make_gr_demod_dmr(5, 1000000) gr_demod_base.cpp:253
+        case QRL_MODEM_M17:       c.sps = 125; c.filter_width = 9000;  c.fm = 0; break;   // make_gr_demod_m17() gr_demod_base.cpp:252, defaults gr_demod_m17.h:41-42
         default: return fail(QRL_ERR_ARG, "modem_type not supported by this build");
         }
     }
@@ -781,6 +804,8 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         d->fam = qrl_demod::F_QPSK; break;
     case QRL_MODEM_DMR:
         d->fam = qrl_demod::F_DMR; break;
+    case QRL_MODEM_M17:
+        d->fam = qrl_demod::F_DMR; d->m17 = true; break;
     case QRL_MODEM_4FSK2K: case QRL_MODEM_4FSK2KFM: case QRL_MODEM_4FSK1KFM: case QRL_MODEM_4FSK10KFM: case QRL_MODEM_4FSK100K:
         d->fam = qrl_demod::F_4FSK; break;
     case QRL_MODEM_BPSK1K: case QRL_MODEM_BPSK2K:
@@ -843,7 +868,7 @@ int qrl_demod_stream_wait(qrl_demod* d, void* hip_stream)
 int qrl_demod_set_dmo_output(qrl_demod* d, uint8_t* frames, size_t cap_frames, uint32_t* counts)
 {
     if (!d) return QRL_ERR_ARG;
-    if (d->fam != qrl_demod::F_DMR) return qrl_set_error(QRL_ERR_ARG, "the DMO slicer sits behind port 3 of gr_demod_dmr: QRL_MODEM_DMR only");
+    if (d->fam != qrl_demod::F_DMR || d->m17) return qrl_set_error(QRL_ERR_ARG, "the DMO slicer sits behind port 3 of gr_demod_dmr: QRL_MODEM_DMR only");
     if (int rs = d->sync_all()) return rs;
     if (!frames) { d->dmo_out = nullptr; return QRL_OK; }
     if (!counts || cap_frames < 1 || cap_frames > 0xFFFFFFFFu) return QRL_ERR_ARG;

@@ -117,7 +117,8 @@ struct SymSyncParams {
     float alpha, beta, maxp, minp;
     int ted; float soft_mul, soft_add;
     int slicer;                            // 0: bpsk sign, 1: constellation_rect{-1.5,-0.5,0.5,1.5}
-    int tail;                              // 0: soft symbols for the Viterbi; 1: DMR tail (x0.9, phase_modulator, slicer, map) -> bits port;
+    float tail_scale;                      // tail 1: _level_control in front of the phase modulator (0.9 gr_demod_dmr, 1 gr_demod_m17)
+    int tail;                              // 0: soft symbols for the Viterbi; 1: DMR / M17 tail (x scale, phase_modulator, slicer, map) -> bits port;
                                            // 2: native 4FSK (FM) tail: phase_modulator -> (imag, real) soft pairs for the Viterbi
     uint8_t* bits; size_t bits_cap;        // tail 1: two bits per symbol, counts[b*4+2]
     float2* port; size_t port_cap; uint32_t* counts;  // constellation port (this call), counts[b*4+1]

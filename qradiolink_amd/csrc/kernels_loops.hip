@@ -249,10 +249,10 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
             const int s = idx / SS_OMAX, j = idx - s * SS_OMAX;
             if (j < ocnt[pb * 64 + s]) {
                 const float y = ob[s * SS_OPITCH + j];
-                if (P.tail == 1) {   // gr_demod_dmr.cpp:73-105: x0.9 -> phase_modulator_fc(pi/2) -> slicer -> pack -> map{3,1,2,0} -> unpack
+                if (P.tail == 1) {   // gr_demod_dmr.cpp:73-105 (x0.9), gr_demod_m17.cpp:74-101 (x1): -> phase_modulator_fc(pi/2) -> slicer -> pack -> map{3,1,2,0} -> unpack
                     const uint64_t o = obase[pb * 64 + s] + j;
                     const uint64_t kk = o - oo0[s];
-                    const float2 cs = sincos_rad(1.57079632679489661923f * (y * 0.9f));
+                    const float2 cs = sincos_rad(1.57079632679489661923f * (y * P.tail_scale));
                     if (P.port && kk < P.port_cap) P.port[(size_t)(b0 + s) * P.port_cap + kk] = cs;
                     const int v = ((cs.x >= 0.0f) ? 2 : 0) | ((cs.y >= 0.0f) ? 1 : 0);
                     const int m = (0x27 >> (2 * v)) & 3;   // map {3,1,2,0}

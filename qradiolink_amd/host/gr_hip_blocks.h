@@ -40,6 +40,8 @@ gr_demod_hip_sptr make_gr_demod_bpsk_hip(qrl_runtime& rt, int sps = 125, int sam
                                          int filter_width = 8000);
 // replaces make_gr_demod_dmr(sps, samp_rate)                                      src/gr/gr_demod_dmr.cpp:19-27 (port 2 = dibits)
 gr_demod_hip_sptr make_gr_demod_dmr_hip(qrl_runtime& rt, int sps = 5, int samp_rate = 1000000);
+// replaces make_gr_demod_m17(sps, samp_rate, carrier_freq, filter_width)            src/gr/gr_demod_m17.cpp:19-27, defaults gr_demod_m17.h:41-42 (port 2 = dibits)
+gr_demod_hip_sptr make_gr_demod_m17_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 1000000, int carrier_freq = 1700, int filter_width = 9000);
 
 class gr_demod_hip : public gr::sync_block {
 public:

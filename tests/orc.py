@@ -283,6 +283,13 @@ def demod_dmr(x, sps=5, samp_rate=1000000):
     return _take(o)
 
 
+def demod_m17(x, samp_rate=1000000, filter_width=9000):
+    x = np.ascontiguousarray(x, cf32)
+    o = DemodOut()
+    lib.orc_demod_m17(_ptr(x), x.size, samp_rate, filter_width, C.byref(o))
+    return _take(o)
+
+
 def _mod(fn, data, *args):
     data = np.ascontiguousarray(data, np.uint8)
     n = fn(_ptr(data), data.size, *args, None)

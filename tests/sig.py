@@ -84,10 +84,10 @@ def find_frames(bits, sync, nbits):
     return out
 
 
-def make_4fsk(nsym=400, seed=1, amp=0.3, noise=0.002, cfo=0.0, fs=1000000.0, levels=None):
+def make_4fsk(nsym=400, seed=1, amp=0.3, noise=0.002, cfo=0.0, fs=1000000.0, levels=None, alpha=0.2, dev=1944.0):
     """DMR-like 4FSK at 4800 sym/s on 1 Msps IQ (RRC alpha 0.2, deviation +-1944 / +-648 Hz; dibit map of the DMR air
     interface: 01 -> +3, 00 -> +1, 10 -> -1, 11 -> -3).  Returns (iq complex64, dibits).  levels: explicit symbol levels in
-    units of the outer deviation (+-1, +-1/3, 0 = unmodulated carrier) instead of random dibits."""
+    units of the outer deviation (+-1, +-1/3, 0 = unmodulated carrier) instead of random dibits.  M17: alpha=0.5, dev=2400."""
     rng = np.random.default_rng(seed)
     dib = rng.integers(0, 4, nsym)
     lev = np.array([+1, +3, -1, -3])[dib] / 3.0
@@ -100,13 +100,13 @@ def make_4fsk(nsym=400, seed=1, amp=0.3, noise=0.002, cfo=0.0, fs=1000000.0, lev
     up[(np.arange(nsym) * sps).astype(int)] = lev
     L = int(8 * sps)
     tt = np.arange(-L, L + 1) / sps
-    a = 0.2
+    a = alpha
     with np.errstate(divide="ignore", invalid="ignore"):
         h = (np.sin(np.pi * tt * (1 - a)) + 4 * a * tt * np.cos(np.pi * tt * (1 + a))) / (np.pi * tt * (1 - (4 * a * tt) ** 2))
     h[np.isnan(h)] = 1 - a + 4 * a / np.pi
     h[np.isinf(h)] = 0
     f = np.convolve(up, h, mode="same")
-    ph = 2 * np.pi * np.cumsum(f * 1944.0 + cfo) / fs
+    ph = 2 * np.pi * np.cumsum(f * dev + cfo) / fs
     x = amp * np.exp(1j * ph) + noise * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
     return x.astype(np.complex64), dib
 

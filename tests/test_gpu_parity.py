@@ -259,6 +259,38 @@ def test_dmr_dibits_recovered(qrl_ctx):
     assert best == 1.0
 
 
+# ---- M17 4FSK symbol demodulator (gr_demod_m17, SURVEY 8(f) rank 4: same kernels as gr_demod_dmr + a channel filter, mod-M&M TED)
+@pytest.mark.parametrize("chunk", [1 << 20, 50000, 12502])
+def test_m17_4fsk_bit_exact(qrl_ctx, chunk):
+    import torch
+    import qradiolink_amd as q
+    xs = [sig.make_4fsk(nsym=300, seed=s, alpha=0.5, dev=2400.0)[0] for s in (4, 5)]
+    n = min(x.size for x in xs)
+    iq = np.stack([x[:n] for x in xs])
+    dem = q.Demod(qrl_ctx, q.MODEM_M17, batch=2, max_chunk=chunk)
+    out = q.collect(dem, torch.from_numpy(iq).cuda(), chunk)
+    dem.close()
+    for b in range(2):
+        ref = orc.demod_m17(iq[b])
+        assert np.array_equal(out["bits_a"][b], ref["bits_a"]) and ref["bits_a"].size > 500
+        for port in ("filtered", "constellation"):
+            assert np.array_equal(out[port][b].view(np.uint32), ref[port].view(np.uint32)), port
+
+
+def test_m17_dibits_recovered(qrl_ctx):
+    import torch
+    import qradiolink_amd as q
+    x, dib = sig.make_4fsk(nsym=500, seed=9, alpha=0.5, dev=2400.0)
+    dem = q.Demod(qrl_ctx, q.MODEM_M17, batch=1, max_chunk=x.size)
+    out = q.collect(dem, torch.from_numpy(x[None, :]).cuda(), x.size)
+    dem.close()
+    got = out["bits_a"][0].reshape(-1, 2)
+    got = got[:, 0] * 2 + got[:, 1]
+    # (the clock loop -- bandwidth 2 pi / 96, 25 x DMR's -- needs ~40 symbols to settle on a burst without preamble)
+    best = max(np.mean(got[k + 60:k + 420] == dib[60:420]) for k in range(60))
+    assert best == 1.0
+
+
 @pytest.mark.parametrize("mode_name,modem", [("2fsk1k", 18), ("2fsk1kfm", 16), ("gmsk10k", 22), ("qpsk250k", 26), ("bpsk2k", 0)])
 def test_pipelined_calls_without_sync(qrl_ctx, mode_name, modem):
     """Back-to-back qrl_demod_process calls with NO sync in between (how bench.py drives the handle; the 2FSK family then runs

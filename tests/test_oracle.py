@@ -507,3 +507,14 @@ def test_clock_recovery_mm_locks_to_symbol_rate():
     assert abs(n - x.size / 10) <= 2
     tail = out[100:n - 30].real
     assert np.median(np.abs(np.abs(tail) - 1.0)) < 0.05 and abs(np.abs(tail).mean() - 1.0) < 0.05
+
+
+def test_m17_chain_recovers_dibits():
+    """gr_demod_m17 in the oracle: an M17-shaped 4FSK burst (RRC 0.5, +-2400 / +-800 Hz) comes back as its
+    dibits once the clock loop has settled."""
+    x, dib = sig.make_4fsk(nsym=500, seed=9, alpha=0.5, dev=2400.0)
+    r = orc.demod_m17(x)
+    got = r["bits_a"].reshape(-1, 2)
+    got = got[:, 0] * 2 + got[:, 1]
+    assert max(np.mean(got[k + 60:k + 420] == dib[60:420]) for k in range(60)) == 1.0
+    assert abs(r["filtered"].size - x.size * 3 / 125) <= 1 and r["constellation"].size * 2 == r["bits_a"].size
