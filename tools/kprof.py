@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Kernel times of ONE call at a time (sync after every call: no pipelining across calls, so every kernel runs alone):
+    rocprofv3 --kernel-trace --stats -d out -o x -- python tools/kprof.py <modem> <batch> <nsamp> [device_rate] [calls]"""
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import qradiolink_amd as q
+
+modem, batch, nsamp = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+rate = int(sys.argv[4]) if len(sys.argv) > 4 else 1000000
+calls = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+ctx = q.Context(0)
+g = torch.Generator(device="cuda")
+g.manual_seed(1)
+iq = torch.view_as_complex(torch.randn((batch, nsamp, 2), generator=g, device="cuda") * 0.05)
+dem = q.Demod(ctx, modem, batch=batch, max_chunk=nsamp, device_samp_rate=rate)
+for _ in range(calls):
+    dem.process_async(iq)
+    dem.sync()
+dem.close()
+ctx.close()
