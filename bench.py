@@ -45,7 +45,7 @@ WORKLOADS = {
 }
 
 
-def synth(mode, device_rate, offset, batch, nsamp, seed, torch, dev):
+def synth(mode, device_rate, offset, batch, nsamp, seed, torch, dev, pad=0):
     """Synthetic batch, built once (untimed): one oracle-modulated stream, then per-stream circular
     shift + CFO + AWGN applied on the GPU (torch is plumbing here, not the product)."""
     import sig
@@ -56,7 +56,7 @@ def synth(mode, device_rate, offset, batch, nsamp, seed, torch, dev):
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     x = torch.from_numpy(base).to(dev)
-    iq = torch.empty((batch, nsamp), dtype=torch.complex64, device=dev)
+    iq = torch.empty((batch, nsamp + pad), dtype=torch.complex64, device=dev)[:, :nsamp]   # row pitch nsamp + pad samples
     n = torch.arange(nsamp, device=dev, dtype=torch.int64)
     # a few large batched torch ops (groups of streams) instead of one small op per stream: rocprofv3 --pmc survives it
     group = max(1, min(batch, (1 << 27) // nsamp))
@@ -113,7 +113,7 @@ def run_workload(name, args, torch, q, ctx, dev, rank, world, overlap=False, che
     batch = args.batch if (args.batch and name == args.config) else dbatch
     nsamp = args.nsamp if (args.nsamp and name == args.config) else dns
     nsamp &= ~1
-    iq = synth(mode, rate, offset, batch, nsamp, 1234 + rank, torch, dev)
+    iq = synth(mode, rate, offset, batch, nsamp, 1234 + rank, torch, dev, pad=args.pad)
     dem = q.Demod(ctx, modem, batch=batch, max_chunk=nsamp, device_samp_rate=rate, carrier_offset_hz=offset,
                   side_outputs=True)
     if overlap:
@@ -301,6 +301,7 @@ def main():
     ap.add_argument("--config", default="c1", choices=sorted(WORKLOADS) + ["c4", "c5"])
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--nsamp", type=int, default=0)
+    ap.add_argument("--pad", type=int, default=0, help="extra samples of row pitch of the input batch (even)")
     ap.add_argument("--no-extra", action="store_true", help="only the timed workload: no stand-alone pass, parity check, C2 line, CPU baseline")
     ap.add_argument("--overlap", action="store_true", help="C1 only: QRL_OPT_OVERLAP = 1 (decimated-rate kernels of call k under the front end of call k + 1)")
     ap.add_argument("--no-overlap", action="store_true", help="(default behaviour; kept for the tools/ scripts)")
