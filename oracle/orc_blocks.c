@@ -153,12 +153,12 @@ int orc_decim_uses_pl(int nt, int D)
 {
     /* the geometries the register-resident kernels are instantiated for (qradiolink_amd/csrc/kernels_decim_pl.hip pl_geom):
      * one sample per lane and block with at most 16 taps per lane (32 < D <= 64), or two samples per lane (64 < D <= 128, D even)
-     * with at most 48 outputs in flight per sample */
+     * with at most 42 outputs in flight per sample */
     int Dp, E;
     orc_pl_geometry(D, &Dp, &E);
     const int R = Dp / D, U = (nt + Dp - 1) / D;
     if (E == 1 && R == 1) return U <= 16;
-    if (E == 2 && R == 1) return (D % 2) == 0 && U <= 48;
+    if (E == 2 && R == 1) return (D % 2) == 0 && U <= 42;
     return 0;
 }
 size_t orc_decim_fir_ccf_pl(const cf32* in, size_t n, const float* taps, int nt, int D, cf32* out)

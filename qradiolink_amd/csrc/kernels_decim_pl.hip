@@ -479,7 +479,7 @@ static PlGeom pl_geom(int nt, int D)
     g.U = (nt + g.Dp - 1) / D;
     g.Upad = g.U;
     if (g.E == 1 && g.R == 1) g.ok = g.U <= 16;
-    else if (g.E == 2 && g.R == 1) { g.ok = (D % 2) == 0 && g.U <= 48; g.Upad = g.U <= 42 ? 42 : 48; }
+    else if (g.E == 2 && g.R == 1) { g.ok = (D % 2) == 0 && g.U <= 42; g.Upad = 42; }   // (the front-end filters have 41.8 D taps: U = 42 for every D)
     else g.ok = false;
     g.WU = (g.Upad - 1) / g.R;
     return g;
@@ -599,8 +599,7 @@ int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)
     q.pl_S = (uint32_t)S;
     q.pl_nseg = (uint32_t)((m_tail - m_main + S - 1) / S);
     const uint32_t units = q.pl_nseg * (uint32_t)batch + (edge_unit ? (uint32_t)batch : 0u);
-    if (g.E == 2 && g.Upad == 42) hipLaunchKernelGGL((k_decim_plx<2, 1, 42>), dim3((units + 3) / 4), dim3(256), 0, s, q);
-    else hipLaunchKernelGGL((k_decim_plx<2, 1, 48>), dim3((units + 3) / 4), dim3(256), 0, s, q);
+    hipLaunchKernelGGL((k_decim_plx<2, 1, 42>), dim3((units + 3) / 4), dim3(256), 0, s, q);
     return 0;
 }
 
