@@ -284,7 +284,8 @@ int qrl_deframer_sync(qrl_deframer* d);
  * appended to out[b*out_cap ...]; out_counts[2b] = bytes written, out_counts[2b+1] = frames.  A frame that does not fit is
  * dropped (out_cap >= n/8 + qrl_framesync_frame_bytes() + 96 + 16 per frame never overflows: a frame begun in earlier calls may
  * complete in this one).  Search state, a partial frame
- * and the _modem_sync counter carry across calls.  M17 (its own sync words, :1186-1210) is not built. */
+ * and the _modem_sync counter carry across calls.  QRL_MODEM_M17: the M17 sync words (LSF 0x55F7, stream 0xFF5D, EOT
+ * 0x555D555D, :1186-1210) and 46-byte frames (:309-313); the M17 frame decoder itself stays on the host. */
 typedef struct qrl_framesync qrl_framesync;
 int qrl_framesync_create(qrl_ctx* ctx, int modem_type, int batch, void* hip_stream, qrl_framesync** out);
 void qrl_framesync_destroy(qrl_framesync* f);

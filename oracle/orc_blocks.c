@@ -775,17 +775,18 @@ size_t orc_deframer(int type, const uint8_t* bits, size_t n, uint32_t st[3], uin
  * { u32 frame_type, u32 nbytes, nbytes payload bytes padded to a multiple of 4 } appended to out.
  * st[0] = shift register, st[1] = sync_found, st[2] = bit_buf_index, st[3] = current frame type, st[4] = _modem_sync;
  * bitbuf (>= orc_modem_sync_geometry(...).bit_buf_len bytes) carries a partial frame between calls.  Returns bytes written.
- * M17 (its own sync words) is not restated.
+ * cls 3 = M17 (gr_modem.cpp:1187-1210: 16-bit LSF / stream words first, else the 32-bit EOT word; 46-byte frames, :309-313).
  * ------------------------------------------------------------------------------------------ */
 int orc_modem_sync_geometry(int modem_type, int* bit_buf_len, int* frame_length)
 {
-    int bits = 64, len = 7, cls = 2;   /* cls 0: 1k modes (0xB5), 1: fast modes (24-bit words only), 2: the rest */
+    int bits = 64, len = 7, cls = 2;   /* cls 0: 1k modes (0xB5), 1: fast modes (24-bit words only), 2: the rest, 3: M17 */
     switch (modem_type) {
     case 24: case 16: case 18: case 21: case 6: bits = 32; len = 4; cls = 0; break;              /* BPSK1K 2FSK1KFM 2FSK1K GMSK1K 4FSK1KFM */
     case 1: case 4: case 19: case 22: bits = 48 * 8; len = 47; break;                             /* QPSK20K 4FSK10KFM 2FSK10KFM GMSK10K */
     case 2: bits = 3123 * 8; len = 3122; cls = 1; break;                                          /* QPSKVideo */
     case 26: bits = 1517 * 8; len = 1516; cls = 1; break;                                         /* QPSK250K */
     case 27: bits = 623 * 8; len = 622; cls = 1; break;                                           /* 4FSK100K */
+    case 40: bits = 46 * 8; len = 46; cls = 3; break;                                             /* M17, gr_modem.cpp:309-313 */
     default: break;                                                                               /* 2k modes: 64 bits, 7 bytes */
     }
     if (bit_buf_len) *bit_buf_len = bits;
@@ -795,6 +796,11 @@ int orc_modem_sync_geometry(int modem_type, int* bit_buf_len, int* frame_length)
 static uint32_t modem_find_sync(int cls, uint32_t reg)
 {
     if (cls == 0) return (reg & 0xFF) == 0xB5 ? 0xB5u : 0u;                                       /* FrameTypeVoice1 */
+    if (cls == 3) {                                                                               /* gr_modem.cpp:1187-1210 */
+        if ((reg & 0xFFFF) == 0x55F7) return 0x55F7u;                                             /* FrameTypeM17LSF */
+        if ((reg & 0xFFFF) == 0xFF5D) return 0xFF5Du;                                             /* FrameTypeM17Stream */
+        return reg == 0x555D555Du ? 0x555D555Du : 0u;                                             /* FrameTypeM17EOT */
+    }
     uint32_t t24 = reg & 0xFFFFFF;
     if (cls == 2) {
         if ((reg & 0xFFFF) == 0xED89) return 0xED89u;                                             /* FrameTypeVoice2 -> FrameTypeVoice */
@@ -823,8 +829,8 @@ size_t orc_modem_sync(int modem_type, const uint8_t* bits, size_t n, uint32_t st
         if (st[1]) {
             bitbuf[st[2]++] = bits[i] & 1u;
             int frame_length = frame_length0, bit_buf_len = bit_buf_len0;
-            if (cls != 0 && st[3] == 0xED89) frame_length++;          /* reserved byte of voice frames */
-            else if (cls != 0) bit_buf_len = bit_buf_len0 - 8;
+            if ((cls == 1 || cls == 2) && st[3] == 0xED89) frame_length++;          /* reserved byte of voice frames */
+            else if (cls == 1 || cls == 2) bit_buf_len = bit_buf_len0 - 8;
             if ((int)st[2] >= bit_buf_len) {
                 uint32_t hdr[2] = {st[3], (uint32_t)frame_length};
                 memcpy(out + no, hdr, 8); no += 8;

@@ -96,6 +96,7 @@ static int framesync_geometry(int modem_type, uint32_t& bits, uint32_t& len)
     case 2: bits = 3123 * 8; len = 3122; cls = 1; break;
     case QRL_MODEM_QPSK250K: bits = 1517 * 8; len = 1516; cls = 1; break;
     case QRL_MODEM_4FSK100K: bits = 623 * 8; len = 622; cls = 1; break;
+    case QRL_MODEM_M17: bits = 46 * 8; len = 46; cls = 3; break;   // gr_modem.cpp:309-313
     default: break;
     }
     return cls;
@@ -107,7 +108,6 @@ int qrl_framesync_create(qrl_ctx* ctx, int modem_type, int batch, void* hip_stre
 {
     if (!ctx || !out) return QRL_ERR_ARG;
     if (batch < 1) return qrl_set_error(QRL_ERR_ARG, "batch must be >= 1");
-    if (modem_type == 40) return qrl_set_error(QRL_ERR_ARG, "M17 framing is not built");
     std::unique_ptr<qrl_framesync> h(new (std::nothrow) qrl_framesync);
     if (!h) return QRL_ERR_NOMEM;
     h->ctx = ctx; h->batch = batch;

@@ -71,6 +71,11 @@ __global__ __launch_bounds__(64) void k_deframe(const DeframeParams P)
 __device__ __forceinline__ uint32_t modem_find_sync(int cls, uint32_t reg)
 {
     if (cls == 0) return (reg & 0xFFu) == 0xB5u ? 0xB5u : 0u;
+    if (cls == 3) {   // M17 (gr_modem.cpp:1187-1210): the 16-bit LSF / stream words first, else the 32-bit EOT word
+        if ((reg & 0xFFFFu) == 0x55F7u) return 0x55F7u;
+        if ((reg & 0xFFFFu) == 0xFF5Du) return 0xFF5Du;
+        return reg == 0x555D555Du ? 0x555D555Du : 0u;
+    }
     const uint32_t t24 = reg & 0xFFFFFFu;
     if (cls == 2) {
         if ((reg & 0xFFFFu) == 0xED89u) return 0xED89u;
@@ -96,8 +101,9 @@ __global__ __launch_bounds__(64) void k_framesync(const FrameSyncParams P)
     uint32_t carry = st.found ? st.idx : 0u, fstart = 0u;
     while (i < n) {
         if (st.found) {
-            const bool voice = P.cls != 0 && st.ftype == 0xED89u;
-            const uint32_t need = (P.cls != 0 && !voice) ? P.bit_buf_len - 8u : P.bit_buf_len;
+            const bool adj = P.cls == 1 || P.cls == 2;   // (the 1k modes and M17 take bit_buf_len / frame_length as they are, :1147-1166)
+            const bool voice = adj && st.ftype == 0xED89u;
+            const uint32_t need = (adj && !voice) ? P.bit_buf_len - 8u : P.bit_buf_len;
             const uint32_t flen = voice ? P.frame_length + 1u : P.frame_length;
             const uint32_t take = min(n - i, need - st.idx);
             i += take; st.idx += take;

@@ -97,7 +97,8 @@ def _bits_with_frames(rng, modem, nframes, noise_bits=200):
     bl, fl = ctypes.c_int(), ctypes.c_int()
     cls = orc.lib.orc_modem_sync_geometry(modem, ctypes.byref(bl), ctypes.byref(fl))
     words = {0: [(0xB5, 8)], 1: [(0xDE98AA, 24), (0x98DEAA, 24), (0x4C8A2B, 24)],
-             2: [(0xED89, 16), (0x89EDAA, 24), (0xED77AA, 24), (0x8CC8DD, 24), (0x4C8A2B, 24)]}[cls]
+             2: [(0xED89, 16), (0x89EDAA, 24), (0xED77AA, 24), (0x8CC8DD, 24), (0x4C8A2B, 24)],
+             3: [(0x55F7, 16), (0xFF5D, 16), (0x555D555D, 32)]}[cls]
     parts = []
     for _ in range(nframes):
         parts.append(rng.integers(0, 2, int(rng.integers(3, noise_bits)), dtype=np.uint8))
@@ -108,7 +109,7 @@ def _bits_with_frames(rng, modem, nframes, noise_bits=200):
     return np.concatenate(parts)
 
 
-@pytest.mark.parametrize("modem", [18, 22, 17, 26, 27, 5])
+@pytest.mark.parametrize("modem", [18, 22, 17, 26, 27, 5, 40])
 @pytest.mark.parametrize("ncuts", [1, 7])
 def test_framesync_bit_exact(qrl_ctx, modem, ncuts):
     import torch

@@ -64,8 +64,6 @@ def test_unsupported_configurations_are_refused(qrl_ctx):
         q.Synth(qrl_ctx, 8, batch=1, max_samples=100)                                             # > MAX_MMDVM_CHANNELS
     with pytest.raises(q.QrlError):
         q.Deframer(qrl_ctx, 4, 1)
-    with pytest.raises(q.QrlError):
-        q.FrameSync(qrl_ctx, 40, 1)                                                               # M17 framing
 
 
 def test_mod_and_channelizer_reset(qrl_ctx):
