@@ -476,6 +476,21 @@ def test_modem_sync_oracle_frames_by_class():
         assert [f for f, _ in fr] == [ft] * 3 and [p[off:] for _, p in fr] == payloads
 
 
+def test_modem_sync_oracle_m17_words():
+    """gr_modem::findSync for ModemTypeM17 (gr_modem.cpp:1187-1210, frame geometry :309-313): LSF 0x55F7 and stream 0xFF5D as 16-bit
+    words, EOT 0x555D555D only as the full 32-bit word; every frame is 46 bytes, nothing is adjusted per frame type."""
+    rng = np.random.default_rng(40)
+    parts, want = [], []
+    for word, nb in ((0x55F7, 16), (0xFF5D, 16), (0x555D555D, 32), (0xFF5D, 16)):
+        payload = rng.integers(0, 256, 46, dtype=np.uint8)
+        parts += [np.zeros(9, np.uint8), np.array([(word >> (nb - 1 - k)) & 1 for k in range(nb)], np.uint8), np.unpackbits(payload)]
+        want.append((word, bytes(payload)))
+    bits = np.concatenate(parts + [np.zeros(5, np.uint8)])
+    ms = orc.ModemSync(40)
+    fr = ms.feed(bits[:500]) + ms.feed(bits[500:])
+    assert fr == want
+
+
 def test_mmdvm_tx_synthesizer_loops_back_through_the_channelizer():
     """gr_mod_mmdvm_multi2 restatement -> gr_demod_mmdvm_multi2 restatement: channel c's tone returns on port {0,1,2,3,9,8,7}[c]"""
     N, n = 7, 24000
