@@ -40,7 +40,7 @@ enum {
     QRL_MODEM_BPSK2K = 0, QRL_MODEM_QPSK20K = 1, QRL_MODEM_QPSKVIDEO = 2, QRL_MODEM_4FSK2K = 3, QRL_MODEM_4FSK10KFM = 4, QRL_MODEM_4FSK2KFM = 5, QRL_MODEM_4FSK1KFM = 6, QRL_MODEM_QPSK2K = 7,
     QRL_MODEM_2FSK2KFM = 15, QRL_MODEM_2FSK1KFM = 16, QRL_MODEM_2FSK2K = 17, QRL_MODEM_2FSK1K = 18,
     QRL_MODEM_2FSK10KFM = 19, QRL_MODEM_GMSK2K = 20, QRL_MODEM_GMSK1K = 21, QRL_MODEM_GMSK10K = 22,
-    QRL_MODEM_BPSK1K = 24, QRL_MODEM_QPSK250K = 26, QRL_MODEM_4FSK100K = 27, QRL_MODEM_M17 = 40, QRL_MODEM_DMR = 41
+    QRL_MODEM_BPSK1K = 24, QRL_MODEM_BPSK8 = 25 /* DSSS, Barker 13 */, QRL_MODEM_QPSK250K = 26, QRL_MODEM_4FSK100K = 27, QRL_MODEM_M17 = 40, QRL_MODEM_DMR = 41
 };
 
 typedef struct qrl_ctx qrl_ctx;

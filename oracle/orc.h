@@ -142,6 +142,9 @@ size_t orc_demod_mmdvm_multi_4fsk(const cf32* in, size_t n, int M, int16_t* out,
 size_t orc_demod_mmdvm_multi_rssi(const cf32* in, size_t n, int M, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal);
 void orc_demod_dmr(const cf32* in, size_t n, int sps, int samp_rate, orc_demod_out* o);
 void orc_demod_m17(const cf32* in, size_t n, int samp_rate, int filter_width, orc_demod_out* o);
+int orc_dsss_taps(int sps, float* taps);
+size_t orc_dsss_decoder(const cf32* in, size_t n, int sps, cf32* out);
+void orc_demod_dsss(const cf32* in, size_t n, int sps, int samp_rate, int filter_width, orc_demod_out* o);
 size_t orc_demod_dmr_port3(const cf32* in, size_t n, int samp_rate, float* out);
 void orc_4fsk_symbols_to_bits(const float* sym, size_t nsym, cf32* constellation, uint8_t* bits);
 /* multi-carrier MMDVM RX (gr_demod_mmdvm_multi2): PFB channelizer + per-channel 24/25 resampler, LPF, FM discriminator, int16 */

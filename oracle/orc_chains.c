@@ -609,6 +609,113 @@ void orc_demod_bpsk(const cf32* in, size_t n, int sps, int samp_rate, int carrie
     free(re);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * DSSS mode "BPSK 8" (reference src/gr/gr_demod_dsss.cpp:30-111, instance make_gr_demod_dsss(25, 1000000, 1700, 150)
+ * gr_demod_base.cpp:218; src/gr/dsss_decoder_cc_impl.cc:41-107 (matched-filter taps), :128-167 (general_work)).
+ * ------------------------------------------------------------------------------------------ */
+/* matched filter of dsss_decoder_cc: the Barker-13 code, reversed, `sps` samples per chip, through the RRC(1, sps, 1, 0.35,
+ * 11 sps) pulse: taps[i] = sum_k rrc[k] cs[i + nr - 1 - k], i < 13 sps + 11 sps (fir_filter_ccf::filter over the zero-extended chip
+ * sequence; one float fmaf chain, k ascending).  Real valued (the reference stores them as complex with zero imaginary part). */
+int orc_dsss_taps(int sps, float* taps)
+{
+    static const int barker_13[13] = {1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 1, 0, 1};
+    const int rrc_ntaps = sps * 11, csz = 13 * sps, extra = rrc_ntaps, nt = csz + extra;
+    if (!taps) return nt;
+    int nr = orc_root_raised_cosine(1, sps, 1.0, 0.35, rrc_ntaps, NULL);
+    float* rrc = NEW(float, nr);
+    orc_root_raised_cosine(1, sps, 1.0, 0.35, rrc_ntaps, rrc);
+    float* cs = NEW(float, csz + 2 * extra + nr);
+    memset(cs, 0, sizeof(float) * (size_t)(csz + 2 * extra + nr));
+    for (int i = 0; i < 13; i++)
+        for (int k = 0; k < sps; k++) cs[extra + i * sps + k] = barker_13[13 - (i + 1)] == 0 ? -1.0f : 1.0f;
+    for (int i = 0; i < nt; i++) {
+        float a = 0.0f;
+        for (int k = 0; k < nr; k++) a = fmaf(rrc[k], cs[i + nr - 1 - k], a);
+        taps[i] = a;
+    }
+    free(rrc); free(cs);
+    return nt;
+}
+/* dsss_decoder_cc::general_work: output I = the matched-filter value of largest magnitude among the 13 sps evaluations
+ * j = 0 .. 13 sps - 1 over the windows x[13 sps (I - 2) + j .. + nt) (history = 13 sps items: the block looks one code period
+ * back), first maximum wins, scaled by 2 / (13 sps).  Filter value = sum_k taps[k] x[P + nt - 1 - k], one fmaf chain per
+ * component, k ascending; |v| = sqrtf(re^2 + im^2).  Output I exists once all of its windows do: n >= 13 sps (I - 1) + nt - 1.
+ * Returns the number of outputs. */
+size_t orc_dsss_decoder(const cf32* in, size_t n, int sps, cf32* out)
+{
+    const int L = 13 * sps, nt = orc_dsss_taps(sps, NULL);
+    float* taps = NEW(float, nt);
+    orc_dsss_taps(sps, taps);
+    /* last index of window j = L - 1 of output I: L (I - 2) + L - 1 + nt - 1 = L (I - 1) + nt - 2  =>  n >= L (I - 1) + nt - 1 */
+    const long long need0 = (long long)nt - 1 - L;
+    size_t nout = 0;
+    if ((long long)n >= need0) nout = (size_t)(((long long)n - need0) / L) + 1;
+    for (size_t I = 0; I < nout; I++) {
+        float max_abs = 0.0f; cf32 max_val = {0.0f, 0.0f};
+        for (int j = 0; j < L; j++) {
+            const long long P = (long long)L * ((long long)I - 2) + j;
+            float ar = 0.0f, ai = 0.0f;
+            for (int k = 0; k < nt; k++) {
+                const long long idx = P + nt - 1 - k;
+                float xr = 0.0f, xi = 0.0f;
+                if (idx >= 0) { xr = in[idx].re; xi = in[idx].im; }
+                ar = fmaf(taps[k], xr, ar);
+                ai = fmaf(taps[k], xi, ai);
+            }
+            const float a2 = ar * ar, b2 = ai * ai;
+            const float cur = sqrtf(a2 + b2);
+            if (cur > max_abs) { max_abs = cur; max_val.re = ar; max_val.im = ai; }
+        }
+        const float sc = 2.0f / (float)L;
+        out[I].re = max_val.re * sc; out[I].im = max_val.im * sc;
+    }
+    free(taps);
+    return nout;
+}
+void orc_demod_dsss(const cf32* in, size_t n, int sps, int samp_rate, int filter_width, orc_demod_out* o)
+{
+    memset(o, 0, sizeof *o);
+    int nt = orc_low_pass(1, samp_rate, 10000, 10000, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* taps = NEW(float, nt);
+    orc_low_pass(1, samp_rate, 10000, 10000, ORC_WIN_BLACKMAN_HARRIS, taps);
+    size_t n1 = orc_decim_count(n, 1, 50);
+    cf32* s1 = NEW(cf32, n1 + 1);
+    orc_decim_auto(in, n, taps, nt, 50, s1);                                   /* _resampler (1, 50) -> 20 ksps */
+    free(taps);
+    int ni = orc_low_pass(1, 20000, 2600, 2600, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* ti = NEW(float, ni);
+    orc_low_pass(1, 20000, 2600, 2600, ORC_WIN_BLACKMAN_HARRIS, ti);
+    size_t n2 = orc_decim_count(n1, 13, 50);
+    cf32* s2 = NEW(cf32, n2 + 1);
+    orc_resamp_ccf(s1, n1, ti, ni, 13, 50, s2);                                /* _resampler_if (13, 50) -> 5200 sps */
+    free(ti); free(s1);
+    cf32* s3 = NEW(cf32, n2 + 1);
+    orc_costas(s2, n2, (float)(M_PI / 200), 2, 1, s3);                         /* _costas_freq */
+    free(s2);
+    int nf = orc_low_pass(1, 5200, filter_width, 1200, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* ft = NEW(float, nf);
+    orc_low_pass(1, 5200, filter_width, 1200, ORC_WIN_BLACKMAN_HARRIS, ft);
+    o->filtered = NEW(cf32, n2 + 1); o->n_filtered = n2;
+    orc_fir_ccf(s3, n2, ft, nf, o->filtered);                                  /* _filter -> port 0 */
+    free(ft); free(s3);
+    cf32* s5 = NEW(cf32, n2 + 1);
+    orc_agc2(o->filtered, n2, 1e-1f, 1e-1f, 1.0f, 10.0f, 65536.0f, s5);        /* _agc (0.1, 0.1, 1, 10) */
+    cf32* s6 = NEW(cf32, n2 / (size_t)(13 * sps) + 4);
+    const size_t nd = orc_dsss_decoder(s5, n2, sps, s6);                       /* _dsss_decoder */
+    free(s5);
+    cf32* s7 = NEW(cf32, nd + 16);
+    const float gain_omega = 0.005f;
+    const size_t nsym = orc_clock_recovery_mm_cc(s6, nd, 1.0f, gain_omega * gain_omega, 0.5f, 0.05f, 0.005f, s7);
+    free(s6);
+    o->constellation = NEW(cf32, nsym + 1); o->n_const = nsym;
+    orc_costas(s7, nsym, (float)(2 * M_PI / 100), 2, 0, o->constellation);     /* _costas_loop -> port 1 */
+    free(s7);
+    float* re = NEW(float, nsym + 1);
+    for (size_t i = 0; i < nsym; i++) re[i] = o->constellation[i].re;
+    fec_tail(re, nsym, 64.0f, 1, o);
+    free(re);
+}
+
 /* single-carrier MMDVM receiver gr_demod_mmdvm.cpp:29-61 (instance make_gr_demod_mmdvm(): header defaults sps 10,
  * MMDVM_SAMPLE_RATE, 1700, filter_width 5000, gr_demod_mmdvm.h:35-36): rational_resampler_ccf(12, 125, low_pass_2(12, 12 fs, fw, 2000, 60, BH)) -> rssi_tag_block -> fft_filter_ccf(
  * low_pass_2(1, 24k, fw, 2000, 60, BH)) -> quadrature_demod_cf(24000/(2 pi 10000)) -> x1.0 -> float_to_short(1, 32767).

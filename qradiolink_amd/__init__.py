@@ -20,6 +20,7 @@ MODEM_QPSK250K = 26
 MODEM_QPSK20K, MODEM_QPSKVIDEO, MODEM_QPSK2K = 1, 2, 7
 MODEM_BPSK2K, MODEM_BPSK1K = 0, 24
 MODEM_4FSK2K, MODEM_4FSK10KFM, MODEM_4FSK2KFM, MODEM_4FSK1KFM, MODEM_4FSK100K = 3, 4, 5, 6, 27
+MODEM_BPSK8 = 25
 MODEM_M17 = 40
 MODEM_DMR = 41
 OPT_OVERLAP = 1

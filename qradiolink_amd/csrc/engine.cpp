@@ -167,7 +167,7 @@ struct qrl_demod {
     bool m17 = false;   // F_DMR family, gr_demod_m17 variant: channel filter behind the resampler (port 0), mod-M&M TED, no level control
     DevBuf<float2> s2g, disc4_taps; DevBuf<float> sym4_taps; int disc4_nt = 0, sym4_nt = 0;   // 4FSK non-FM branch
     bool overlap = false, overlap_capable = false; hipEvent_t ev_tail2[2] = {nullptr, nullptr}; bool tail2_valid[2] = {false, false}; uint64_t call_no = 0;
-    enum Family { F_2FSK, F_GMSK, F_QPSK, F_DMR, F_4FSK, F_BPSK } fam = F_2FSK;
+    enum Family { F_2FSK, F_GMSK, F_QPSK, F_DMR, F_4FSK, F_BPSK, F_DSSS } fam = F_2FSK;
     int branches = 2;
 
     // derived chain parameters (gr_demod_2fsk.cpp:39-63, gr_demod_gmsk.cpp:39-63)
@@ -202,6 +202,14 @@ struct qrl_demod {
     DevBuf<QpskState> qp_st; DevBuf<float> tanh_tab;
     float c1_alpha = 0, c1_beta = 0, c2_alpha = 0, c2_beta = 0; float2 qp_rot{};
     DevBuf<uint32_t> counts_scratch;
+    // DSSS mode (gr_demod_dsss.cpp:30-111): behind the 1:50 stage (ring s2, 20 ksps) a 13/50 resampler to 5 200 samples/s, Costas,
+    // channel filter, agc2, Barker-13 matched filter (16 symbols/s), clock recovery + Costas (kernels_dsss.hip)
+    DevBuf<float> ds_rs, ds_filt, ds_mf; int ds_Jp = 0, ds_nf = 0;
+    DevBuf<float2> ds_ra, ds_rb, ds_rc, ds_rd, ds_sym; uint32_t ds_mask = 0, ds_sym_mask = 0;
+    DevBuf<DsssState> ds_st; DevBuf<DsssTailState> ds_tail;
+    float ds_a1 = 0, ds_b1 = 0, ds_a2 = 0, ds_b2 = 0;
+    uint64_t n5 = 0, nsy = 0;   // items so far at 5 200 samples/s, matched-filter outputs so far
+    int dsss_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* out, uint32_t* counts, bool side);
     uint64_t n_in = 0, n1 = 0, n2 = 0;  // items so far: device rate, 1 Msps, target rate
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -262,6 +270,16 @@ int qrl_demod::init_state()
     for (auto& f : fs) { f.consumed = 0; f.start_state = 0; f.last_bits = 0xFE; }  // descrambler seed 0x7F, newest bit first
     if (hipMemcpy(fec_st.p, fs.data(), fs.size() * sizeof(FecState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
     if (qp_snap.p && (r = qp_snap.zero())) return r;
+    if (fam == F_DSSS) {
+        for (auto* b : {&ds_ra, &ds_rb, &ds_rc, &ds_rd, &ds_sym}) if ((r = b->zero())) return r;
+        std::vector<DsssState> ds(cfg.batch);
+        for (auto& x : ds) { x.phase = 0.f; x.freq = 0.f; x.gain = 10.0f; x.pad = 0.f; }   // agc2_cc(0.1, 0.1, 1, 10), gr_demod_dsss.cpp:61
+        if (hipMemcpy(ds_st.p, ds.data(), ds.size() * sizeof(DsssState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
+        std::vector<DsssTailState> dt(cfg.batch);
+        for (auto& x : dt) { std::memset(&x, 0, sizeof x); x.mu = 0.5f; x.omega = 1.0f; }   // clock_recovery_mm_cc(1, ., 0.5, ., .), :69-70
+        if (hipMemcpy(ds_tail.p, dt.data(), dt.size() * sizeof(DsssTailState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
+        n5 = nsy = 0;
+    }
     q_valid[0] = q_valid[1] = false; tail2_valid[0] = tail2_valid[1] = false; tail_pending = false; call_no = 0;
     n_in = n1 = n2 = 0;
     rot_acc = 0; rot_nbase = 0; hist_flip = false;
@@ -295,6 +313,10 @@ int qrl_demod::build()
         else if (sps == 2)  { target = 500000; sps_eff = 5;  decim = 2;   interp = 1; }
         else return fail(QRL_ERR_ARG, "4fsk: unsupported sps");
         branches = 1;
+    } else if (fam == F_DSSS) {
+        // gr_demod_dsss.cpp:37-59: 1:50 to 20 ksps (this stage), then 13/50 to 5 200 samples/s (dsss_stages); sps = samples per chip
+        if (sps != 25) return fail(QRL_ERR_ARG, "dsss: sps must be 25 (make_gr_demod_dsss(25, ...), gr_demod_base.cpp:218)");
+        target = 20000; sps_eff = 10; decim = 50; interp = 1;
     } else if (fam == F_BPSK) {
         // gr_demod_bpsk.cpp:40-52: 1:50 to 20 ksps, sps samples per symbol
         if (sps != 10 && sps != 5) return fail(QRL_ERR_ARG, "bpsk: sps must be 10 (BPSK1K) or 5 (BPSK2K)");
@@ -491,6 +513,22 @@ int qrl_demod::build()
     }
     if ((r = ss_st.alloc(B)) || (r = fec_st.alloc((size_t)B * 2)) || (r = counts_scratch.alloc((size_t)B * 4))) return r;
     if (loops_family() && (r = qp_snap.alloc((size_t)B * 2))) return r;
+    if (fam == F_DSSS) {
+        const std::vector<float> ti = low_pass(1, target, 2600, 2600, WIN_BLACKMAN_HARRIS);              // _resampler_if (13, 50), gr_demod_dsss.cpp:57-59
+        ds_Jp = ((int)ti.size() + 12) / 13;
+        const std::vector<float> tf = low_pass(1, 5200, fw, 1200, WIN_BLACKMAN_HARRIS);                 // _filter, :62-63
+        ds_nf = (int)tf.size();
+        if ((r = ds_rs.upload(resamp_layout(ti, 13, ds_Jp))) || (r = ds_filt.upload(tf)) || (r = ds_mf.upload(dsss_matched_filter(sps)))) return r;
+        if (!tanh_tab.p && (r = tanh_tab.upload(tanh_table()))) return r;
+        control_loop_gains((float)(M_PI / 200), ds_a1, ds_b1);                                          // _costas_freq, :64
+        control_loop_gains((float)(2 * M_PI / 100), ds_a2, ds_b2);                                      // _costas_loop, :63
+        const size_t max5 = max2 * 13 / 50 + 2;
+        ds_mask = pow2_at_least(max5 + 2048) - 1;                                                       // the matched filter looks 2 x 325 + 600 items back
+        ds_sym_mask = pow2_at_least(max5 / 325 + 64) - 1;
+        const size_t r5 = (size_t)B * (ds_mask + 1);
+        if ((r = ds_ra.alloc(r5)) || (r = ds_rb.alloc(r5)) || (r = ds_rc.alloc(r5)) || (r = ds_rd.alloc(r5)) ||
+            (r = ds_sym.alloc((size_t)B * (ds_sym_mask + 1))) || (r = ds_st.alloc(B)) || (r = ds_tail.alloc(B))) return r;
+    }
     return init_state();
 }
 
@@ -583,6 +621,13 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
     // ---- stage C: decimated-rate feed-forward (+ FLL for 2FSK)
     const uint32_t c2 = (uint32_t)(n2_1 - n2_0);
     const bool side = cfg.enable_side_outputs && out;
+    if (fam == F_DSSS) {
+        if (int rr = dsss_stages(n2_0, n2_1, out, counts, side)) return rr;
+        HIPCHK(hipGetLastError());
+        if (take_launch_error()) return QRL_ERR_HIP;
+        n_in = n_in1; n1 = n1_1; n2 = n2_1; ++call_no;
+        return QRL_OK;
+    }
     RingC filt_in = r2;
     if (fam == F_2FSK || fam == F_BPSK || (fam == F_QPSK && qpsk_fll)) {
         FllParams f{};
@@ -724,6 +769,64 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
     return QRL_OK;
 }
 
+// everything of gr_demod_dsss behind the 1:50 stage (gr_demod_dsss.cpp:57-111); all on the handle's main stream
+int qrl_demod::dsss_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* out, uint32_t* counts, bool side)
+{
+    const int B = cfg.batch;
+    RingC r2{s2.p, s2_mask}, ra{ds_ra.p, ds_mask}, rb{ds_rb.p, ds_mask}, rc{ds_rc.p, ds_mask}, rd{ds_rd.p, ds_mask}, rs{ds_sym.p, ds_sym_mask};
+    const uint64_t n5_0 = n5, n5_1 = decim_count(n2_1, 13, 50);
+    const uint32_t c5 = (uint32_t)(n5_1 - n5_0);
+    {   // _resampler_if: rational_resampler_ccf(13, 50)
+        ResampParams p{};
+        p.in = nullptr; p.in_ring = r2; p.n0 = n2_0; p.n = (uint32_t)(n2_1 - n2_0);
+        p.out = ra; p.q0 = n5_0; p.q_count = c5;
+        p.taps = ds_rs.p; p.I = 13; p.D = 50; p.Jp = ds_Jp;
+        launch_resamp(p, B, stream);
+    }
+    {   // _costas_freq
+        DsssLoopParams p{}; p.in = ra; p.out = rb; p.q0 = n5_0; p.count = c5; p.st = ds_st.p; p.tanh_tab = tanh_tab.p; p.alpha = ds_a1; p.beta = ds_b1;
+        launch_dsss_loop(p, 0, B, stream);
+    }
+    {   // _filter -> port 0
+        FirCcfParams f{};
+        f.in = rb; f.out = rc; f.q0 = n5_0; f.count = c5; f.taps = ds_filt.p; f.nt = ds_nf;
+        f.port = side && out->filtered ? reinterpret_cast<float2*>(out->filtered) : nullptr;
+        f.port_cap = side ? out->filtered_cap : 0;
+        f.counts = counts;
+        launch_fir_ccf(f, B, stream);
+    }
+    {   // _agc
+        DsssLoopParams p{}; p.in = rc; p.out = rd; p.q0 = n5_0; p.count = c5; p.st = ds_st.p; p.tanh_tab = tanh_tab.p;
+        launch_dsss_loop(p, 1, B, stream);
+    }
+    // _dsss_decoder: output I needs x[325 (I - 1) + 598]
+    const uint64_t nsy_1 = n5_1 >= 274 ? (n5_1 - 274) / 325 + 1 : 0;
+    {
+        DsssMfParams p{}; p.in = rd; p.out = rs; p.i0 = nsy; p.count = (uint32_t)(nsy_1 - nsy); p.taps = ds_mf.p;
+        launch_dsss_mf(p, B, stream);
+    }
+    {   // _clock_recovery -> _costas_loop (port 1) -> soft symbols
+        DsssTailParams p{};
+        p.in = rs; p.avail = nsy_1; p.soft = RingB{soft.p, soft_mask}; p.st = ds_tail.p; p.mmse = mmse_tab.p;
+        const float gain_omega = 0.005f;
+        p.gain_omega = gain_omega * gain_omega; p.gain_mu = 0.05f; p.omega_mid = 1.0f; p.omega_lim = 0.005f * 1.0f;
+        p.alpha = ds_a2; p.beta = ds_b2;
+        p.port = side && out->constellation ? reinterpret_cast<float2*>(out->constellation) : nullptr;
+        p.port_cap = side ? out->constellation_cap : 0;
+        p.counts = counts;
+        launch_dsss_tail(p, B, stream);
+    }
+    FecParams f{};
+    f.soft = RingB{soft.p, soft_mask};
+    f.avail = &ds_tail.p[0].oo; f.avail_stride = sizeof(DsssTailState); f.avail_mul = 1;
+    f.st = fec_st.p;
+    f.bits_a = out ? out->bits_a : nullptr; f.bits_b = out ? out->bits_b : nullptr; f.bits_cap = out ? out->bits_cap : 0;
+    f.counts = counts; f.branches = 2;
+    launch_fec(f, B, stream);
+    n5 = n5_1; nsy = nsy_1;
+    return QRL_OK;
+}
+
 // =============================================================================== C ABI
 extern "C" {
 
@@ -791,6 +894,7 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         case QRL_MODEM_BPSK1K:    c.sps = 10; c.filter_width = 1300;   c.fm = 0; break;   // :216
         case QRL_MODEM_BPSK2K:    c.sps = 5;  c.filter_width = 2400;   c.fm = 0; break;   // :217
         case QRL_MODEM_DMR:       c.sps = 5;  c.filter_width = 5000;   c.fm = 0; break;   // make_gr_demod_dmr(5, 1000000) gr_demod_base.cpp:253
+        case QRL_MODEM_BPSK8:     c.sps = 25;  c.filter_width = 150;   c.fm = 0; break;   // make_gr_demod_dsss(25, ., 1700, 150) gr_demod_base.cpp:218
         case QRL_MODEM_M17:       c.sps = 125; c.filter_width = 9000;  c.fm = 0; break;   // make_gr_demod_m17() gr_demod_base.cpp:252, defaults gr_demod_m17.h:41-42
         default: return fail(QRL_ERR_ARG, "modem_type not supported by this build");
         }
@@ -810,6 +914,8 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         d->fam = qrl_demod::F_4FSK; break;
     case QRL_MODEM_BPSK1K: case QRL_MODEM_BPSK2K:
         d->fam = qrl_demod::F_BPSK; break;
+    case QRL_MODEM_BPSK8:
+        d->fam = qrl_demod::F_DSSS; break;
     default: return fail(QRL_ERR_ARG, "modem_type not supported by this build");
     }
     if (c.samp_rate != 1000000) return fail(QRL_ERR_ARG, "internal samp_rate must be 1000000 (gr_demod_base.cpp:21)");

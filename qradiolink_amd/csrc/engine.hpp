@@ -247,6 +247,18 @@ void launch_tx_interp_c(const TxInterpCParams& p, int batch, hipStream_t s);
 void launch_tx_qpsk_bits(const TxBitsParams& p, int batch, hipStream_t s);
 void launch_tx_interp(const TxInterpParams& p, int batch, hipStream_t s);
 
+// ---- DSSS mode (kernels_dsss.hip) ----
+struct DsssState { float phase, freq, gain, pad; };
+struct DsssLoopParams { RingC in, out; uint64_t q0; uint32_t count; DsssState* st; const float* tanh_tab; float alpha, beta; };
+void launch_dsss_loop(const DsssLoopParams& p, int mode, int batch, hipStream_t s);   // 0: costas(order 2, snr), 1: agc2(0.1, 0.1)
+struct DsssMfParams { RingC in, out; uint64_t i0; uint32_t count; const float* taps; };
+void launch_dsss_mf(const DsssMfParams& p, int batch, hipStream_t s);
+struct DsssTailState { uint64_t ii, oo; float mu, omega, phase, freq; float2 p0, p1, p2, c0, c1, c2; };
+struct DsssTailParams { RingC in; uint64_t avail; RingB soft; DsssTailState* st; const float* mmse;
+                        float gain_omega, gain_mu, omega_mid, omega_lim, alpha, beta;
+                        float2* port; size_t port_cap; uint32_t* counts; };
+void launch_dsss_tail(const DsssTailParams& p, int batch, hipStream_t s);
+
 // ---- side outputs (kernels_side.hip): rssi_block on port 0, rx_fft_c on the device-rate IQ ----
 constexpr uint32_t RSSI_RING = 4096;   // |x|^2 look-back ring per stream (moving_average_ff(2000) reads 1999 items back)
 struct RssiState { double prev; uint64_t n; float sum, last; };

@@ -268,4 +268,21 @@ void sincos_turn_host(uint64_t angle, float& s, float& c)
     }
 }
 
+std::vector<float> dsss_matched_filter(int sps)
+{
+    static const int barker_13[13] = {1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 1, 0, 1};
+    const int rrc_ntaps = sps * 11, csz = 13 * sps, extra = rrc_ntaps, nt = csz + extra;
+    const std::vector<float> rrc = root_raised_cosine(1, sps, 1.0, 0.35, rrc_ntaps);
+    const int nr = (int)rrc.size();
+    std::vector<float> cs((size_t)(csz + 2 * extra + nr), 0.0f), taps((size_t)nt);
+    for (int i = 0; i < 13; ++i)
+        for (int k = 0; k < sps; ++k) cs[(size_t)(extra + i * sps + k)] = barker_13[13 - (i + 1)] == 0 ? -1.0f : 1.0f;
+    for (int i = 0; i < nt; ++i) {
+        float a = 0.0f;
+        for (int k = 0; k < nr; ++k) a = std::fmaf(rrc[(size_t)k], cs[(size_t)(i + nr - 1 - k)], a);
+        taps[(size_t)i] = a;
+    }
+    return taps;
+}
+
 }  // namespace qrl

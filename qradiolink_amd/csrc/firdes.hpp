@@ -16,6 +16,9 @@ std::vector<float> window(Window type, int ntaps);
 int compute_ntaps(double fs, double tw, Window w);
 int compute_ntaps_windes(double fs, double tw, double atten_db);
 std::vector<float> low_pass(double gain, double fs, double fc, double tw, Window w = WIN_HAMMING);
+// matched filter of dsss_decoder_cc (reference src/gr/dsss_decoder_cc_impl.cc:41-107): Barker-13, reversed, sps samples per chip, through
+// RRC(1, sps, 1, 0.35, 11 sps); 13 sps + 11 sps real taps (== oracle orc_dsss_taps, bit for bit)
+std::vector<float> dsss_matched_filter(int sps);
 std::vector<float> low_pass_2(double gain, double fs, double fc, double tw, double atten_db, Window w = WIN_HAMMING);
 std::vector<std::complex<float>> complex_band_pass(double gain, double fs, double lo, double hi, double tw, Window w = WIN_HAMMING);
 std::vector<float> root_raised_cosine(double gain, double fs, double symrate, double alpha, int ntaps);

@@ -42,6 +42,8 @@ gr_demod_hip_sptr make_gr_demod_bpsk_hip(qrl_runtime& rt, int sps = 125, int sam
 gr_demod_hip_sptr make_gr_demod_dmr_hip(qrl_runtime& rt, int sps = 5, int samp_rate = 1000000);
 // replaces make_gr_demod_m17(sps, samp_rate, carrier_freq, filter_width)            src/gr/gr_demod_m17.cpp:19-27, defaults gr_demod_m17.h:41-42 (port 2 = dibits)
 gr_demod_hip_sptr make_gr_demod_m17_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 1000000, int carrier_freq = 1700, int filter_width = 9000);
+// replaces make_gr_demod_dsss(sps, samp_rate, carrier_freq, filter_width)           src/gr/gr_demod_dsss.cpp:21-28, instance gr_demod_base.cpp:218 (25, 1000000, 1700, 150)
+gr_demod_hip_sptr make_gr_demod_dsss_hip(qrl_runtime& rt, int sps = 25, int samp_rate = 1000000, int carrier_freq = 1700, int filter_width = 150);
 
 class gr_demod_hip : public gr::sync_block {
 public:

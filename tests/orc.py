@@ -283,6 +283,28 @@ def demod_dmr(x, sps=5, samp_rate=1000000):
     return _take(o)
 
 
+def demod_dsss(x, sps=25, samp_rate=1000000, filter_width=150):
+    x = np.ascontiguousarray(x, cf32)
+    o = DemodOut()
+    lib.orc_demod_dsss(_ptr(x), x.size, sps, samp_rate, filter_width, C.byref(o))
+    return _take(o)
+
+
+def dsss_taps(sps=25):
+    n = lib.orc_dsss_taps(sps, None)
+    t = np.zeros(n, np.float32)
+    lib.orc_dsss_taps(sps, _ptr(t))
+    return t
+
+
+def dsss_decoder(x, sps=25):
+    x = np.ascontiguousarray(x, cf32)
+    out = np.zeros(x.size // (13 * sps) + 4, cf32)
+    lib.orc_dsss_decoder.restype = C.c_size_t
+    n = lib.orc_dsss_decoder(_ptr(x), C.c_size_t(x.size), sps, _ptr(out))
+    return out[:n].copy()
+
+
 def demod_m17(x, samp_rate=1000000, filter_width=9000):
     x = np.ascontiguousarray(x, cf32)
     o = DemodOut()

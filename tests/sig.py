@@ -165,3 +165,23 @@ def dmr_levels(frames, gap_symbols=156, lead_symbols=60):
         out.append(np.array([lv[(int(bits[2 * i]), int(bits[2 * i + 1]))] for i in range(132)]))
         out.append(np.zeros(gap_symbols))
     return np.concatenate(out)
+
+
+def make_dsss(info_bits, seed=1, amp=0.05, noise=0.0005, cfo=0.0):
+    """DSSS "BPSK 8" burst at 1 Msps, built like gr_mod_dsss (src/gr/gr_mod_dsss.cpp:33-92): scrambler -> K=7 CC -> Barker-13
+    spreading (bit 0 -> code, bit 1 -> inverted code) -> {-1, +1} -> RRC at 25 samples per chip (5200 sps) -> 0.65 -> up to
+    1 Msps (exact ratio 2500 / 13, scipy polyphase instead of the reference's two rational resamplers: a test signal)."""
+    from scipy.signal import resample_poly
+    rng = np.random.default_rng(seed)
+    enc = orc.cc_encode_k7(orc.scramble(np.asarray(info_bits, np.uint8)))
+    code = np.array([1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 1, 0, 1], np.uint8)
+    chips = np.concatenate([code if b == 0 else 1 - code for b in enc])
+    sps = 25
+    rrc = orc.root_raised_cosine(sps, sps, 1, 0.35, 11 * sps).astype(np.float64)
+    up = np.zeros(chips.size * sps)
+    up[::sps] = chips.astype(np.float64) * 2 - 1
+    x = np.convolve(up, rrc)[:up.size] * 0.65
+    y = resample_poly(x, 2500, 13)
+    n = np.arange(y.size)
+    z = amp * y * np.exp(2j * np.pi * cfo * n / 1e6) + noise * (rng.standard_normal(y.size) + 1j * rng.standard_normal(y.size))
+    return z.astype(np.complex64)

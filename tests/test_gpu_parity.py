@@ -291,6 +291,43 @@ def test_m17_dibits_recovered(qrl_ctx):
     assert best == 1.0
 
 
+# ---- DSSS "BPSK 8" (gr_demod_dsss): 1:50, 13:50 resampler, Costas, filter, AGC, Barker-13 matched-filter
+# decoder (325 evaluations of a 600-tap filter per symbol), M&M clock recovery, Costas, K=7 decoder on two branches
+@pytest.mark.parametrize("chunk", [1 << 22, 250000, 65538])
+def test_dsss_bit_exact(qrl_ctx, chunk):
+    import torch
+    import qradiolink_amd as q
+    rng = np.random.default_rng(5)
+    xs = [sig.make_dsss(rng.integers(0, 2, 60, dtype=np.uint8), seed=s, cfo=c) for s, c in ((1, 0.0), (2, 3.0))]
+    n = min(x.size for x in xs) & ~1
+    iq = np.stack([x[:n] for x in xs])
+    dem = q.Demod(qrl_ctx, q.MODEM_BPSK8, batch=2, max_chunk=min(chunk, n))
+    out = q.collect(dem, torch.from_numpy(iq).cuda(), min(chunk, n))
+    dem.close()
+    for b in range(2):
+        ref = orc.demod_dsss(iq[b])
+        for port in ("bits_a", "bits_b"):
+            assert np.array_equal(out[port][b], ref[port]), port
+        assert ref["constellation"].size > 100
+        for port in ("filtered", "constellation"):
+            got, want = out[port][b].view(np.float32) + np.float32(0), ref[port].view(np.float32) + np.float32(0)
+            assert got.size == want.size, (port, got.size, want.size)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), port
+
+
+def test_dsss_info_bits_recovered(qrl_ctx):
+    import torch
+    import qradiolink_amd as q
+    bits = np.random.default_rng(3).integers(0, 2, 120, dtype=np.uint8)
+    x = sig.make_dsss(bits)
+    x = x[:x.size & ~1]
+    dem = q.Demod(qrl_ctx, q.MODEM_BPSK8, batch=1, max_chunk=x.size)
+    out = q.collect(dem, torch.from_numpy(x[None, :]).cuda(), x.size)
+    dem.close()
+    want = "".join(map(str, bits[:60]))
+    assert any(want in "".join(map(str, out[p][0])) for p in ("bits_a", "bits_b"))
+
+
 @pytest.mark.parametrize("mode_name,modem", [("2fsk1k", 18), ("2fsk1kfm", 16), ("gmsk10k", 22), ("qpsk250k", 26), ("bpsk2k", 0)])
 def test_pipelined_calls_without_sync(qrl_ctx, mode_name, modem):
     """Back-to-back qrl_demod_process calls with NO sync in between (how bench.py drives the handle; the 2FSK family then runs

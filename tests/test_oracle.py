@@ -533,3 +533,39 @@ def test_m17_chain_recovers_dibits():
     got = got[:, 0] * 2 + got[:, 1]
     assert max(np.mean(got[k + 60:k + 420] == dib[60:420]) for k in range(60)) == 1.0
     assert abs(r["filtered"].size - x.size * 3 / 125) <= 1 and r["constellation"].size * 2 == r["bits_a"].size
+
+
+# ---- DSSS "BPSK 8" (gr_demod_dsss): definition checks of the restatement
+def test_dsss_matched_filter_taps_are_the_reversed_barker_code_through_the_rrc():
+    t = orc.dsss_taps(25)
+    assert t.size == 13 * 25 + 11 * 25
+    code = np.array([1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 1, 0, 1], np.float64)[::-1] * 2 - 1
+    cs = np.zeros(13 * 25 + 2 * 275)
+    cs[275:275 + 325] = np.repeat(code, 25)
+    rrc = orc.root_raised_cosine(1, 25, 1.0, 0.35, 275).astype(np.float64)
+    want = np.convolve(cs, rrc)[rrc.size - 1:rrc.size - 1 + 600]
+    assert np.max(np.abs(t - want)) < 1e-5
+
+
+def test_dsss_decoder_picks_the_correlation_peak_of_each_code_period():
+    rng = np.random.default_rng(2)
+    bits = rng.integers(0, 2, 40)
+    code = np.array([1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 1, 0, 1])
+    chips = np.concatenate([code if b == 0 else 1 - code for b in bits]) * 2.0 - 1
+    up = np.zeros(chips.size * 25)
+    up[::25] = chips
+    x = np.convolve(up, orc.root_raised_cosine(25, 25, 1, 0.35, 275).astype(np.float64))[:up.size]
+    y = orc.dsss_decoder((x * np.exp(0.7j)).astype(np.complex64))
+    assert y.size >= 38
+    d = np.real(y * np.exp(-0.7j))
+    # one output per code period, sign = the spread bit (bit 0 -> code -> positive correlation); the block's latency is two periods
+    got = (d[3:39] < 0).astype(int)
+    assert any(np.array_equal(got[:30], bits[k:k + 30]) for k in range(6)), (got, bits)
+    assert np.all(np.abs(d[3:39]) > 0.5 * np.abs(d[3:39]).max())
+
+
+def test_dsss_chain_recovers_the_information_bits():
+    bits = np.random.default_rng(3).integers(0, 2, 120, dtype=np.uint8)
+    r = orc.demod_dsss(sig.make_dsss(bits))
+    want = "".join(map(str, bits[:60]))
+    assert any(want in "".join(map(str, r[p])) for p in ("bits_a", "bits_b"))
