@@ -174,6 +174,16 @@ double orc_batch_rx(int mode, const cf32* iq, int batch, size_t n, int samp_rate
 }
 #endif
 /* side outputs of gr_demod_base (orc_side.c) */
+/* analogue voice receivers (orc_analog.c) */
+int    orc_complex_band_pass_2(double gain, double fs, double lo, double hi, double tw, double atten_db, int win, cf32* taps);
+void   orc_deemph_taps(int sample_rate, double tau, double a[2], double b[2]);
+void   orc_squelch_envelope(int ramp, float* env /* ramp + 1 */);
+size_t orc_pwr_squelch_cc(const cf32* in, size_t n, double db, double alpha, int ramp, int gate, cf32* out);
+void   orc_agc2_ff(const float* in, size_t n, float attack, float decay, float ref, float gain, float max_gain, float* out);
+void   orc_iir_ffd_2(const float* in, size_t n, const double ff[2], const double fb[2], int oldstyle, float* out);
+void   orc_demod_analog(const cf32* in, size_t n, int kind /* 0 NBFM, 1 AM, 2 WBFM */, int samp_rate, int filter_width,
+                        cf32** filtered, size_t* n_filtered, float** audio, size_t* n_audio);
+void   orc_free(void* p);
 float orc_det_log2f(float x);
 void orc_rssi_block(const cf32* in, size_t n, float level, float* out);
 void orc_power_spectrum(const cf32* in, const float* window, size_t n, float* out);

@@ -1,0 +1,217 @@
+/* orc_analog.c -- CPU ORACLE (TEST INFRASTRUCTURE, never shipped or linked by the product): the analogue voice receivers of
+ * QRadioLink's gr_demod_base, restated block by block.
+ *   gr_demod_nbfm   reference src/gr/gr_demod_nbfm.cpp:31-88   (instances gr_demod_base.cpp:219-220: filter width 2500 / 5000)
+ *   gr_demod_am     reference src/gr/gr_demod_am.cpp:28-79     (instance  gr_demod_base.cpp:215: filter width 5000)
+ *   gr_demod_wbfm   reference src/gr/gr_demod_wbfm.cpp:28-72   (instance  gr_demod_base.cpp:228: filter width 75000)
+ *   de-emphasis taps            src/gr/emphasis.cpp:16-43
+ * GNU Radio 3.10 block semantics restated from memory [GR-MEM] (parity unpinned):
+ *   pwr_squelch_cc / squelch_base_cc  gr-analog/lib/squelch_base_cc_impl.cc, pwr_squelch_cc_impl.cc
+ *   agc2_ff                           gr-analog/include/gnuradio/analog/agc2.h
+ *   iir_filter_ffd                    gr-filter/include/gnuradio/filter/iir_filter.h (double taps, double accumulator, float in/out)
+ *   rational_resampler_fff, fft_filter_{ccf,ccc,fff}, quadrature_demod_cf, complex_to_mag: as in orc_blocks.c */
+#include "orc.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NEW(T, n) ((T*)calloc((size_t)(n) + 16, sizeof(T)))
+
+/* firdes::complex_band_pass_2 = low_pass_2 prototype rotated to the band centre, like complex_band_pass */
+int orc_complex_band_pass_2(double gain, double fs, double lo, double hi, double tw, double atten_db, int win, cf32* taps)
+{
+    int ntaps = orc_low_pass_2(gain, fs, (hi - lo) / 2, tw, atten_db, win, NULL);
+    if (!taps) return ntaps;
+    float* lp = NEW(float, ntaps);
+    orc_low_pass_2(gain, fs, (hi - lo) / 2, tw, atten_db, win, lp);
+    float freq = (float)(M_PI * (hi + lo) / fs);
+    float phase;
+    if (ntaps & 1) phase = -freq * (float)(ntaps >> 1);
+    else           phase = (float)(-freq / 2.0 * ((1 + 2 * ntaps) >> 1));
+    for (int i = 0; i < ntaps; i++) {
+        taps[i].re = (float)(lp[i] * cos((double)phase));
+        taps[i].im = (float)(lp[i] * sin((double)phase));
+        phase += freq;
+    }
+    free(lp);
+    return ntaps;
+}
+
+/* emphasis.cpp:16-43 (tanf on a float argument, the rest in double): b = {b0, b0}, a = {1, -p1} */
+void orc_deemph_taps(int sample_rate, double tau, double a[2], double b[2])
+{
+    const double fs = (double)sample_rate;
+    const double w_c = 1.0 / tau;
+    const double w_ca = 2.0 * fs * (double)tanf((float)(w_c / (2.0 * fs)));
+    const double k = -w_ca / (2.0 * fs);
+    const double z1 = -1.0;
+    const double p1 = (1.0 + k) / (1.0 - k);
+    const double b0 = -k / (1.0 - k);
+    b[0] = b0 * 1.0; b[1] = b0 * -z1;
+    a[0] = 1.0;      a[1] = -p1;
+}
+
+/* squelch envelope while ramping: 0.5 - cos(pi k / ramp) / 2 in double, k = 0 .. ramp (used as a float factor) */
+void orc_squelch_envelope(int ramp, float* env)
+{
+    for (int k = 0; k <= ramp; k++) env[k] = (float)(0.5 - cos(M_PI * (double)k / (double)ramp) / 2.0);
+}
+
+/* pwr_squelch_cc(db, alpha, ramp, gate): states MUTED 0 / ATTACK 1 / UNMUTED 2 / DECAY 3.  Per input item: the single-pole power
+ * estimate (double) is updated, then the state machine steps, then -- unless MUTED -- the item times the envelope is emitted
+ * (a complex product with (env, 0)); a MUTED item is dropped when gating, else emitted as zero.  Returns the output count. */
+size_t orc_pwr_squelch_cc(const cf32* in, size_t n, double db, double alpha, int ramp, int gate, cf32* out)
+{
+    const double threshold = pow(10.0, db / 10);
+    double pwr = 0.0;
+    int state = 0, ramped = 0;
+    float env = ramp ? 0.0f : 1.0f;
+    float* tab = NEW(float, ramp + 1);
+    if (ramp) orc_squelch_envelope(ramp, tab);
+    size_t j = 0;
+    for (size_t i = 0; i < n; i++) {
+        const float p = in[i].re * in[i].re + in[i].im * in[i].im;
+        pwr = alpha * (double)p + (1.0 - alpha) * pwr;
+        const int mute = pwr < threshold;
+        switch (state) {
+        case 0: if (!mute) state = ramp ? 1 : 2; break;
+        case 2: if (mute) state = ramp ? 3 : 0; break;
+        case 1:
+            env = tab[++ramped];
+            if (ramped >= ramp) { state = 2; env = 1.0f; }
+            break;
+        case 3:
+            env = tab[--ramped];
+            if (ramped == 0) state = 0;
+            break;
+        }
+        if (state != 0) {
+            out[j].re = in[i].re * env - in[i].im * 0.0f;
+            out[j].im = in[i].re * 0.0f + in[i].im * env;
+            j++;
+        } else if (!gate) {
+            out[j].re = 0.0f; out[j].im = 0.0f; j++;
+        }
+    }
+    free(tab);
+    return j;
+}
+
+/* agc2_ff(attack, decay, reference, gain), max gain 65536 */
+void orc_agc2_ff(const float* in, size_t n, float attack, float decay, float ref, float gain, float max_gain, float* out)
+{
+    for (size_t i = 0; i < n; i++) {
+        const float o = in[i] * gain;
+        const float tmp = -ref + fabsf(o);
+        float rate = decay;
+        if (fabsf(tmp) > gain) rate = attack;
+        gain -= tmp * rate;
+        if (gain < 0.0f) gain = 10e-5f;
+        if (max_gain > 0.0f && gain > max_gain) gain = max_gain;
+        out[i] = o;
+    }
+}
+
+/* iir_filter_ffd with two feed-forward and two feedback taps: acc = ff0 x + ff1 x[-1] + fb1 y[-1] in double (y kept in double),
+ * output (float)acc.  oldstyle: fb taps as given; new style: negated (y = sum b x - sum a y). */
+void orc_iir_ffd_2(const float* in, size_t n, const double ff[2], const double fb[2], int oldstyle, float* out)
+{
+    const double fb1 = oldstyle ? fb[1] : -fb[1];
+    float xp = 0.0f; double yp = 0.0;
+    for (size_t i = 0; i < n; i++) {
+        double acc = ff[0] * (double)in[i];
+        acc += ff[1] * (double)xp;
+        acc += fb1 * yp;
+        yp = acc; xp = in[i];
+        out[i] = (float)acc;
+    }
+}
+
+static void scale_f(float* x, size_t n, float k) { for (size_t i = 0; i < n; i++) x[i] = x[i] * k; }
+
+/* kind: 0 NBFM, 1 AM, 2 WBFM.  filtered = port 0 (before the squelch), audio = port 1 (8 kHz). */
+void orc_demod_analog(const cf32* in, size_t n, int kind, int samp_rate, int filter_width,
+                      cf32** filtered, size_t* n_filtered, float** audio, size_t* n_audio)
+{
+    const int target = kind == 2 ? 200000 : 20000, decim = kind == 2 ? 5 : 50;
+    int nt = orc_low_pass(1, samp_rate, target / 2, target / 2, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* taps = NEW(float, nt);
+    orc_low_pass(1, samp_rate, target / 2, target / 2, ORC_WIN_BLACKMAN_HARRIS, taps);
+    const size_t n1 = orc_decim_count(n, 1, decim);
+    cf32* s1 = NEW(cf32, n1);
+    orc_decim_auto(in, n, taps, nt, decim, s1);                                     /* _resampler */
+    free(taps);
+    cf32* f = NEW(cf32, n1);
+    if (kind == 1) {                                                                /* _filter: fft_filter_ccc */
+        int nf = orc_complex_band_pass_2(1, target, -filter_width, filter_width, 200, 90, ORC_WIN_BLACKMAN_HARRIS, NULL);
+        cf32* ft = NEW(cf32, nf);
+        orc_complex_band_pass_2(1, target, -filter_width, filter_width, 200, 90, ORC_WIN_BLACKMAN_HARRIS, ft);
+        orc_fir_ccc(s1, n1, ft, nf, f);
+        free(ft);
+    } else {                                                                        /* _filter: fft_filter_ccf */
+        const double tw = kind == 0 ? 3500 : 600, att = kind == 0 ? 60 : 90;
+        int nf = orc_low_pass_2(1, target, filter_width, tw, att, ORC_WIN_BLACKMAN_HARRIS, NULL);
+        float* ft = NEW(float, nf);
+        orc_low_pass_2(1, target, filter_width, tw, att, ORC_WIN_BLACKMAN_HARRIS, ft);
+        orc_fir_ccf(s1, n1, ft, nf, f);
+        free(ft);
+    }
+    free(s1);
+    *filtered = f; *n_filtered = n1;
+    cf32* g = NEW(cf32, n1);
+    const size_t ng = orc_pwr_squelch_cc(f, n1, -140, 0.01, kind == 0 ? 320 : 0, 1, g);   /* _squelch (gating) */
+    float* d = NEW(float, ng);
+    if (kind == 1) {
+        for (size_t i = 0; i < ng; i++) d[i] = sqrtf(g[i].re * g[i].re + g[i].im * g[i].im);   /* _complex_to_mag */
+        orc_agc2_ff(d, ng, 1e-1f, 1e-1f, 1.0f, 1.0f, 65536.0f, d);                             /* _agc */
+        const double ff[2] = {1, -1}, fb[2] = {0, 0.9999};
+        orc_iir_ffd_2(d, ng, ff, fb, 1, d);                                                     /* _iir_filter (DC block) */
+        scale_f(d, ng, 0.99f);                                                                  /* _audio_gain */
+    } else {
+        const float gain = (float)(target / ((kind == 0 ? 4 : 2) * M_PI * filter_width));
+        orc_quad_demod(g, ng, gain, d);                                                         /* _fm_demod */
+    }
+    free(g);
+    double a[2], b[2];
+    float* out;
+    size_t no;
+    if (kind == 2) {
+        scale_f(d, ng, 0.9f);                                                                   /* _amplify */
+        orc_deemph_taps(8000, 50e-6, a, b);
+        orc_iir_ffd_2(d, ng, b, a, 0, d);                                                       /* _de_emph_filter (at 200 ksps) */
+        int na = orc_low_pass(1, target, 4000, 2000, ORC_WIN_BLACKMAN_HARRIS, NULL);
+        float* at = NEW(float, na);
+        orc_low_pass(1, target, 4000, 2000, ORC_WIN_BLACKMAN_HARRIS, at);
+        no = orc_decim_count(ng, 1, 25);
+        out = NEW(float, no);
+        orc_resamp_fff(d, ng, at, na, 1, 25, out);                                              /* _audio_resampler (1, 25) */
+        free(at);
+    } else {
+        int na = kind == 0 ? orc_low_pass_2(2, 2 * target, 3600, 250, 60, ORC_WIN_BLACKMAN_HARRIS, NULL)
+                           : orc_low_pass(2, 2 * target, 3600, 600, ORC_WIN_BLACKMAN_HARRIS, NULL);
+        float* at = NEW(float, na);
+        if (kind == 0) orc_low_pass_2(2, 2 * target, 3600, 250, 60, ORC_WIN_BLACKMAN_HARRIS, at);
+        else           orc_low_pass(2, 2 * target, 3600, 600, ORC_WIN_BLACKMAN_HARRIS, at);
+        no = orc_decim_count(ng, 2, 5);
+        float* r = NEW(float, no);
+        orc_resamp_fff(d, ng, at, na, 2, 5, r);                                                 /* _audio_resampler (2, 5) */
+        free(at);
+        int nf = kind == 0 ? orc_low_pass_2(1, 8000, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, NULL)
+                           : orc_low_pass(1, 8000, 3600, 300, ORC_WIN_BLACKMAN_HARRIS, NULL);
+        float* aft = NEW(float, nf);
+        if (kind == 0) orc_low_pass_2(1, 8000, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, aft);
+        else           orc_low_pass(1, 8000, 3600, 300, ORC_WIN_BLACKMAN_HARRIS, aft);
+        out = NEW(float, no);
+        orc_fir_fff(r, no, aft, nf, out);                                                       /* _audio_filter */
+        free(aft); free(r);
+        if (kind == 0) {
+            orc_deemph_taps(target, 50e-6, a, b);
+            orc_iir_ffd_2(out, no, b, a, 0, out);                                               /* _de_emph_filter */
+            scale_f(out, no, 2.0f);                                                             /* _level_control */
+        }
+    }
+    free(d);
+    *audio = out; *n_audio = no;
+}
+
+void orc_free(void* p) { free(p); }

@@ -21,6 +21,7 @@ MODEM_QPSK20K, MODEM_QPSKVIDEO, MODEM_QPSK2K = 1, 2, 7
 MODEM_BPSK2K, MODEM_BPSK1K = 0, 24
 MODEM_4FSK2K, MODEM_4FSK10KFM, MODEM_4FSK2KFM, MODEM_4FSK1KFM, MODEM_4FSK100K = 3, 4, 5, 6, 27
 MODEM_BPSK8 = 25
+MODEM_NBFM2500, MODEM_NBFM5000, MODEM_WBFM, MODEM_AM5000 = 8, 9, 10, 14
 MODEM_M17 = 40
 MODEM_DMR = 41
 OPT_OVERLAP = 1
@@ -63,7 +64,7 @@ class _ZeroRun(C.Structure):
 class _Out(C.Structure):
     _fields_ = [("filtered", C.c_void_p), ("filtered_cap", C.c_size_t), ("constellation", C.c_void_p),
                 ("constellation_cap", C.c_size_t), ("bits_a", C.c_void_p), ("bits_cap", C.c_size_t),
-                ("bits_b", C.c_void_p), ("counts", C.c_void_p)]
+                ("bits_b", C.c_void_p), ("counts", C.c_void_p), ("audio", C.c_void_p), ("audio_cap", C.c_size_t)]
 
 
 _lib = None
@@ -92,6 +93,9 @@ def load_library():
     lib.qrl_demod_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.qrl_demod_set_dmo_output.argtypes = [vp, vp, sz, vp]
     lib.qrl_demod_out_caps.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+    lib.qrl_demod_audio_cap.argtypes = [vp, sz, C.POINTER(sz)]
+    lib.qrl_demod_set_squelch.argtypes = [vp, C.c_double]
+    lib.qrl_demod_set_agc.argtypes = [vp, C.c_float, C.c_float]
     lib.qrl_demod_process.argtypes = [vp, vp, sz, sz, C.POINTER(_Out)]
     lib.qrl_demod_sync.argtypes = [vp]
     lib.qrl_rssi_create.argtypes = [vp, C.c_int, C.c_float, vp, C.POINTER(vp)]
@@ -173,6 +177,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "qrl_init", "qrl_shutdown", "qrl_strerror", "qrl_last_error", "qrl_version", "qrl_demod_create",
     "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_set_option", "qrl_demod_set_dmo_output", "qrl_demod_stream_wait", "qrl_demod_out_caps",
+    "qrl_demod_audio_cap", "qrl_demod_set_squelch", "qrl_demod_set_agc",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
     "qrl_mod_samples_per_byte", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_create",
@@ -279,6 +284,9 @@ class Demod:
         f, c, b = C.c_size_t(), C.c_size_t(), C.c_size_t()
         _check(self.lib.qrl_demod_out_caps(self.h, max_chunk, C.byref(f), C.byref(c), C.byref(b)), "qrl_demod_out_caps")
         self.caps = (f.value, c.value, b.value)
+        a = C.c_size_t()
+        _check(self.lib.qrl_demod_audio_cap(self.h, max_chunk, C.byref(a)), "qrl_demod_audio_cap")
+        self.audio_cap = a.value      # > 0 for the analogue voice receivers (port 1 = audio)
         self.new_outputs()
 
     def new_outputs(self):
@@ -298,8 +306,18 @@ class Demod:
             self._out.constellation, self._out.constellation_cap = self.constellation.data_ptr(), c
         self._out.bits_a, self._out.bits_b, self._out.bits_cap = self.bits_a.data_ptr(), self.bits_b.data_ptr(), b
         self._out.counts = self.counts.data_ptr()
+        self.audio = None
+        if self.audio_cap:
+            self.audio = torch.zeros((self.batch, self.audio_cap), dtype=torch.float32, device=dev)
+            self._out.audio, self._out.audio_cap = self.audio.data_ptr(), self.audio_cap
         torch.cuda.current_stream().synchronize()   # the zero fills ran on torch's stream
-        return dict(filtered=self.filtered, constellation=self.constellation, bits_a=self.bits_a, bits_b=self.bits_b, counts=self.counts)
+        return self._ports()
+
+    def _ports(self):
+        d = dict(filtered=self.filtered, constellation=self.constellation, bits_a=self.bits_a, bits_b=self.bits_b, counts=self.counts)
+        if self.audio is not None:
+            d["audio"] = self.audio
+        return d
 
     def process_async(self, iq):
         """Queue one pass over iq ([batch, n] complex64 cuda tensor) on the handle's stream."""
@@ -315,8 +333,13 @@ class Demod:
     def process(self, iq):
         self.process_async(iq)
         self.sync()
-        return dict(filtered=self.filtered, constellation=self.constellation, bits_a=self.bits_a, bits_b=self.bits_b,
-                    counts=self.counts)
+        return self._ports()
+
+    def set_squelch(self, db):
+        _check(self.lib.qrl_demod_set_squelch(self.h, C.c_double(db)), "qrl_demod_set_squelch")
+
+    def set_agc(self, attack, decay):
+        _check(self.lib.qrl_demod_set_agc(self.h, C.c_float(attack), C.c_float(decay)), "qrl_demod_set_agc")
 
     def profile(self, enable=True):
         _check(self.lib.qrl_demod_profile(self.h, int(enable)), "qrl_demod_profile")
@@ -687,6 +710,9 @@ def collect(dem, iq, chunk):
     B, N = iq.shape
     ports = {k: [[] for _ in range(B)] for k in ("filtered", "constellation", "bits_a", "bits_b")}
     idx = {"filtered": 0, "constellation": 1, "bits_a": 2, "bits_b": 3}
+    if getattr(dem, "audio_cap", 0):   # analogue voice receivers: port 1 carries audio
+        ports = {k: [[] for _ in range(B)] for k in ("filtered", "audio")}
+        idx = {"filtered": 0, "audio": 1}
     for s in range(0, N, chunk):
         part = iq[:, s:s + chunk]
         if part.stride(0) % 2 or (part.data_ptr() % 16):

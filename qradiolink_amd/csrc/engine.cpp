@@ -167,7 +167,7 @@ struct qrl_demod {
     bool m17 = false;   // F_DMR family, gr_demod_m17 variant: channel filter behind the resampler (port 0), mod-M&M TED, no level control
     DevBuf<float2> s2g, disc4_taps; DevBuf<float> sym4_taps; int disc4_nt = 0, sym4_nt = 0;   // 4FSK non-FM branch
     bool overlap = false, overlap_capable = false; hipEvent_t ev_tail2[2] = {nullptr, nullptr}; bool tail2_valid[2] = {false, false}; uint64_t call_no = 0;
-    enum Family { F_2FSK, F_GMSK, F_QPSK, F_DMR, F_4FSK, F_BPSK, F_DSSS } fam = F_2FSK;
+    enum Family { F_2FSK, F_GMSK, F_QPSK, F_DMR, F_4FSK, F_BPSK, F_DSSS, F_ANALOG } fam = F_2FSK;
     int branches = 2;
 
     // derived chain parameters (gr_demod_2fsk.cpp:39-63, gr_demod_gmsk.cpp:39-63)
@@ -210,6 +210,15 @@ struct qrl_demod {
     float ds_a1 = 0, ds_b1 = 0, ds_a2 = 0, ds_b2 = 0;
     uint64_t n5 = 0, nsy = 0;   // items so far at 5 200 samples/s, matched-filter outputs so far
     int dsss_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* out, uint32_t* counts, bool side);
+    // analogue voice receivers (gr_demod_nbfm / gr_demod_am / gr_demod_wbfm): kernels_analog.hip
+    int an_kind = 0;                                             // 0 NBFM, 1 AM, 2 WBFM
+    DevBuf<float2> an_filt_c; int an_nfc = 0;                    // AM channel filter (complex taps)
+    DevBuf<float> an_env, an_rtaps, an_ftaps; int an_ramp = 0, an_nr = 0, an_nf = 0, an_I = 2, an_D = 5;
+    DevBuf<float> an_f1, an_f2, an_f3; uint32_t an_m1 = 0, an_m2 = 0;
+    DevBuf<AnState> an_st;
+    double an_threshold = 1e-14, an_ff[2] = {0, 0}, an_fb1 = 0, an_de_ff[2] = {0, 0}, an_de_fb1 = 0;
+    float an_gain = 1.f, an_attack = 0.1f, an_decay = 0.1f;
+    int analog_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* out, uint32_t* counts, bool side);
     uint64_t n_in = 0, n1 = 0, n2 = 0;  // items so far: device rate, 1 Msps, target rate
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -280,6 +289,12 @@ int qrl_demod::init_state()
         if (hipMemcpy(ds_tail.p, dt.data(), dt.size() * sizeof(DsssTailState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
         n5 = nsy = 0;
     }
+    if (fam == F_ANALOG) {
+        for (auto* b : {&an_f1, &an_f2, &an_f3}) if (b->p && (r = b->zero())) return r;
+        std::vector<AnState> as(cfg.batch);
+        for (auto& x : as) { std::memset(&x, 0, sizeof x); x.env = an_ramp ? 0.0f : 1.0f; x.gain = 1.0f; }   // agc2_ff(0.1, 0.1, 1, 1), gr_demod_am.cpp:48
+        if (hipMemcpy(an_st.p, as.data(), as.size() * sizeof(AnState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
+    }
     q_valid[0] = q_valid[1] = false; tail2_valid[0] = tail2_valid[1] = false; tail_pending = false; call_no = 0;
     n_in = n1 = n2 = 0;
     rot_acc = 0; rot_nbase = 0; hist_flip = false;
@@ -317,6 +332,9 @@ int qrl_demod::build()
         // gr_demod_dsss.cpp:37-59: 1:50 to 20 ksps (this stage), then 13/50 to 5 200 samples/s (dsss_stages); sps = samples per chip
         if (sps != 25) return fail(QRL_ERR_ARG, "dsss: sps must be 25 (make_gr_demod_dsss(25, ...), gr_demod_base.cpp:218)");
         target = 20000; sps_eff = 10; decim = 50; interp = 1;
+    } else if (fam == F_ANALOG) {
+        // gr_demod_nbfm.cpp:39,50 / gr_demod_am.cpp:36,44: 1:50 to 20 ksps; gr_demod_wbfm.cpp:37,49: 1:5 to 200 ksps (sps is unused there)
+        target = an_kind == 2 ? 200000 : 20000; decim = an_kind == 2 ? 5 : 50; interp = 1; sps_eff = 10; branches = 1;
     } else if (fam == F_BPSK) {
         // gr_demod_bpsk.cpp:40-52: 1:50 to 20 ksps, sps samples per symbol
         if (sps != 10 && sps != 5) return fail(QRL_ERR_ARG, "bpsk: sps must be 10 (BPSK1K) or 5 (BPSK2K)");
@@ -381,7 +399,7 @@ int qrl_demod::build()
     // stretches from 7.1 to 9.0 ms -- the recursion kernels are only placed once the front end's workgroups drain.
     overlap_capable = fam == F_2FSK;
     overlap = false;
-    s2_mask = pow2_at_least((overlap_capable || loops_family() ? 2 : 1) * max2 + (fam == F_DMR ? 2048 : 1024)) - 1;   // DMR: the DMO slicer looks back 1440 samples   // history needs: <= 501 taps downstream; overlapped mode: two calls
+    s2_mask = pow2_at_least((overlap_capable || loops_family() ? 2 : 1) * max2 + (fam == F_DMR ? 2048 : fam == F_ANALOG ? 4096 : 1024)) - 1;   // DMR: the DMO slicer looks back 1440 samples   // history needs: <= 501 taps downstream; overlapped mode: two calls
     const size_t ring2 = (size_t)B * (s2_mask + 1);
     if ((r = s2.alloc(ring2)) || (r = s2f.alloc(ring2)) || (r = s2d.alloc(ring2)) || (r = s3.alloc(ring2))) return r;
     if ((fam == F_2FSK || fam == F_BPSK || (fam == F_QPSK && qpsk_fll)) && (r = s2l.alloc(ring2))) return r;
@@ -397,6 +415,9 @@ int qrl_demod::build()
             ? root_raised_cosine(sps_eff, sps_eff, 1, 0.35, 15 * sps_eff)      // _shaping_filter, gr_demod_bpsk.cpp:64-66
             : fam == F_4FSK
             ? low_pass(1, target, fw, fw / 2, WIN_BLACKMAN_HARRIS)             // _filter, gr_demod_4fsk.cpp:108-109
+            : fam == F_ANALOG
+            ? (an_kind == 2 ? low_pass_2(1, target, fw, 600, 90, WIN_BLACKMAN_HARRIS)      // gr_demod_wbfm.cpp:52-53
+                            : low_pass_2(1, target, fw, 3500, 60, WIN_BLACKMAN_HARRIS))    // gr_demod_nbfm.cpp:53-54 (AM: an_filt_c)
             : low_pass(1, target, fw, fw, WIN_BLACKMAN_HARRIS);
         filt_nt = (int)f.size();
         if ((r = filt_taps.upload(f))) return r;
@@ -513,6 +534,38 @@ int qrl_demod::build()
     }
     if ((r = ss_st.alloc(B)) || (r = fec_st.alloc((size_t)B * 2)) || (r = counts_scratch.alloc((size_t)B * 4))) return r;
     if (loops_family() && (r = qp_snap.alloc((size_t)B * 2))) return r;
+    if (fam == F_ANALOG) {
+        std::vector<float> rt, ft;
+        double a[2], b[2];
+        if (an_kind == 0) {          // gr_demod_nbfm.cpp:43-64
+            an_ramp = 320; an_I = 2; an_D = 5;
+            rt = low_pass_2(2, 2 * target, 3600, 250, 60, WIN_BLACKMAN_HARRIS);
+            ft = low_pass_2(1, 8000, 3500, 200, 35, WIN_BLACKMAN_HARRIS);
+            an_gain = (float)(target / (4 * M_PI * fw));
+            deemph_taps(target, 50e-6, a, b);
+            an_de_ff[0] = b[0]; an_de_ff[1] = b[1]; an_de_fb1 = -a[1];            // iir_filter_ffd(btaps, ataps, oldstyle = false)
+        } else if (an_kind == 1) {   // gr_demod_am.cpp:40-61
+            an_ramp = 0; an_I = 2; an_D = 5;
+            rt = low_pass(2, 2 * target, 3600, 600, WIN_BLACKMAN_HARRIS);
+            ft = low_pass(1, 8000, 3600, 300, WIN_BLACKMAN_HARRIS);
+            const auto fc = complex_band_pass_2(1, target, -fw, fw, 200, 90, WIN_BLACKMAN_HARRIS);
+            an_nfc = (int)fc.size();
+            if ((r = an_filt_c.upload(to_f2(fc)))) return r;
+            an_ff[0] = 1; an_ff[1] = -1; an_fb1 = 0.9999;                          // iir_filter_ffd({1, -1}, {0, 0.9999}), old style
+        } else {                     // gr_demod_wbfm.cpp:41-57
+            an_ramp = 0; an_I = 1; an_D = 25;
+            rt = low_pass(1, target, 4000, 2000, WIN_BLACKMAN_HARRIS);
+            an_gain = (float)(target / (2 * M_PI * fw));
+            deemph_taps(8000, 50e-6, a, b);
+            an_ff[0] = b[0]; an_ff[1] = b[1]; an_fb1 = -a[1];
+        }
+        an_nr = (int)rt.size(); an_nf = (int)ft.size();
+        if ((r = an_rtaps.upload(rt)) || (an_nf && (r = an_ftaps.upload(ft))) || (r = an_env.upload(squelch_envelope(an_ramp)))) return r;
+        an_m1 = pow2_at_least(max2 + 1024) - 1;                                  // the audio resampler looks <= 419 gated items back
+        an_m2 = pow2_at_least(max2 * an_I / an_D + 512) - 1;
+        if ((r = an_f1.alloc((size_t)B * (an_m1 + 1))) || (r = an_f2.alloc((size_t)B * (an_m2 + 1))) ||
+            (an_kind != 2 && (r = an_f3.alloc((size_t)B * (an_m2 + 1)))) || (r = an_st.alloc(B))) return r;
+    }
     if (fam == F_DSSS) {
         const std::vector<float> ti = low_pass(1, target, 2600, 2600, WIN_BLACKMAN_HARRIS);              // _resampler_if (13, 50), gr_demod_dsss.cpp:57-59
         ds_Jp = ((int)ti.size() + 12) / 13;
@@ -621,8 +674,8 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
     // ---- stage C: decimated-rate feed-forward (+ FLL for 2FSK)
     const uint32_t c2 = (uint32_t)(n2_1 - n2_0);
     const bool side = cfg.enable_side_outputs && out;
-    if (fam == F_DSSS) {
-        if (int rr = dsss_stages(n2_0, n2_1, out, counts, side)) return rr;
+    if (fam == F_DSSS || fam == F_ANALOG) {
+        if (int rr = fam == F_DSSS ? dsss_stages(n2_0, n2_1, out, counts, side) : analog_stages(n2_0, n2_1, out, counts, side)) return rr;
         HIPCHK(hipGetLastError());
         if (take_launch_error()) return QRL_ERR_HIP;
         n_in = n_in1; n1 = n1_1; n2 = n2_1; ++call_no;
@@ -827,6 +880,51 @@ int qrl_demod::dsss_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* ou
     return QRL_OK;
 }
 
+// everything of gr_demod_nbfm / gr_demod_am / gr_demod_wbfm behind the first resampler; all on the handle's main stream
+int qrl_demod::analog_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* out, uint32_t* counts, bool side)
+{
+    const int B = cfg.batch;
+    RingC r2{s2.p, s2_mask}, r2f{s2f.p, s2_mask};
+    const uint32_t c2 = (uint32_t)(n2_1 - n2_0);
+    float2* fport = side && out->filtered ? reinterpret_cast<float2*>(out->filtered) : nullptr;
+    const size_t fcap = side ? out->filtered_cap : 0;
+    if (an_kind == 1) {   // _filter -> port 0
+        FirCccParams f{}; f.in = r2; f.out = r2f; f.q0 = n2_0; f.count = c2; f.taps = an_filt_c.p; f.nt = an_nfc;
+        f.port = fport; f.port_cap = fcap; f.counts = counts;
+        launch_an_fir_ccc(f, B, stream);
+    } else {
+        FirCcfParams f{}; f.in = r2; f.out = r2f; f.q0 = n2_0; f.count = c2; f.taps = filt_taps.p; f.nt = filt_nt;
+        f.port = fport; f.port_cap = fcap; f.counts = counts;
+        launch_fir_ccf(f, B, stream);
+    }
+    RingF f1{an_f1.p, an_m1}, f2{an_f2.p, an_m2}, f3{an_f3.p, an_m2};
+    {   // _squelch and the recursions directly behind it
+        AnGateParams g{}; g.in = r2f; g.out = f1; g.q0 = n2_0; g.count = c2; g.st = an_st.p; g.atan_tab = atan_tab.p;
+        g.env = an_env.p; g.ramp = an_ramp; g.alpha = 0.01; g.one_minus_alpha = 1.0 - 0.01; g.threshold = an_threshold;
+        g.gain = an_gain; g.attack = an_attack; g.decay = an_decay; g.ff0 = an_ff[0]; g.ff1 = an_ff[1]; g.fb1 = an_fb1;
+        launch_an_gate(g, an_kind, B, stream);
+    }
+    float* aport = out ? out->audio : nullptr;
+    const size_t acap = out ? out->audio_cap : 0;
+    const uint32_t max_out = (uint32_t)((uint64_t)c2 * an_I / an_D + 2);
+    {   // _audio_resampler (WBFM: -> port 1)
+        AnResampParams p{}; p.in = f1; p.out = f2; p.st = an_st.p; p.taps = an_rtaps.p; p.nt = an_nr; p.I = an_I; p.D = an_D;
+        if (an_kind == 2) { p.port = aport; p.port_cap = acap; p.counts = counts; }
+        launch_an_resamp(p, max_out, B, stream);
+    }
+    if (an_kind != 2) {   // _audio_filter (AM: -> port 1)
+        AnFirParams p{}; p.in = f2; p.out = f3; p.st = an_st.p; p.taps = an_ftaps.p; p.nt = an_nf; p.I = an_I; p.D = an_D;
+        if (an_kind == 1) { p.port = aport; p.port_cap = acap; p.counts = counts; }
+        launch_an_fir(p, max_out, B, stream);
+    }
+    if (an_kind == 0) {   // _de_emph_filter, _level_control -> port 1
+        AnDeemphParams p{}; p.in = f3; p.st = an_st.p; p.I = an_I; p.D = an_D;
+        p.ff0 = an_de_ff[0]; p.ff1 = an_de_ff[1]; p.fb1 = an_de_fb1; p.port = aport; p.port_cap = acap; p.counts = counts;
+        launch_an_deemph(p, B, stream);
+    }
+    return QRL_OK;
+}
+
 // =============================================================================== C ABI
 extern "C" {
 
@@ -894,7 +992,11 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         case QRL_MODEM_BPSK1K:    c.sps = 10; c.filter_width = 1300;   c.fm = 0; break;   // :216
         case QRL_MODEM_BPSK2K:    c.sps = 5;  c.filter_width = 2400;   c.fm = 0; break;   // :217
         case QRL_MODEM_DMR:       c.sps = 5;  c.filter_width = 5000;   c.fm = 0; break;   // make_gr_demod_dmr(5, 1000000) gr_demod_base.cpp:253
-        case QRL_MODEM_BPSK8:     c.sps = 25;  c.filter_width = 150;   c.fm = 0; break;   // make_gr_demod_dsss(25, ., 1700, 150) gr_demod_base.cpp:218
+        case QRL_MODEM_BPSK8:     c.sps = 25;  c.filter_width = 150;   c.fm = 0; break;
+        case QRL_MODEM_NBFM2500:  c.sps = 125; c.filter_width = 2500;  c.fm = 0; break;   // make_gr_demod_nbfm(125, ., 1700, 2500) gr_demod_base.cpp:219
+        case QRL_MODEM_NBFM5000:  c.sps = 125; c.filter_width = 5000;  c.fm = 0; break;   // :220
+        case QRL_MODEM_WBFM:      c.sps = 125; c.filter_width = 75000; c.fm = 0; break;   // make_gr_demod_wbfm(125, ., 1700, 75000) :228
+        case QRL_MODEM_AM5000:    c.sps = 125; c.filter_width = 5000;  c.fm = 0; break;   // make_gr_demod_am(125, ., 1700, 5000) :215   // make_gr_demod_dsss(25, ., 1700, 150) gr_demod_base.cpp:218
         case QRL_MODEM_M17:       c.sps = 125; c.filter_width = 9000;  c.fm = 0; break;   // make_gr_demod_m17() gr_demod_base.cpp:252, defaults gr_demod_m17.h:41-42
         default: return fail(QRL_ERR_ARG, "modem_type not supported by this build");
         }
@@ -916,6 +1018,12 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         d->fam = qrl_demod::F_BPSK; break;
     case QRL_MODEM_BPSK8:
         d->fam = qrl_demod::F_DSSS; break;
+    case QRL_MODEM_NBFM2500: case QRL_MODEM_NBFM5000:
+        d->fam = qrl_demod::F_ANALOG; d->an_kind = 0; break;
+    case QRL_MODEM_AM5000:
+        d->fam = qrl_demod::F_ANALOG; d->an_kind = 1; break;
+    case QRL_MODEM_WBFM:
+        d->fam = qrl_demod::F_ANALOG; d->an_kind = 2; break;
     default: return fail(QRL_ERR_ARG, "modem_type not supported by this build");
     }
     if (c.samp_rate != 1000000) return fail(QRL_ERR_ARG, "internal samp_rate must be 1000000 (gr_demod_base.cpp:21)");
@@ -1011,6 +1119,27 @@ int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* fcap, size_t* ccap,
     if (fcap) *fcap = n2;
     if (ccap) *ccap = ns;
     if (bcap) *bcap = d->fam == qrl_demod::F_DMR ? 2 * ns + 8 : d->fam == qrl_demod::F_QPSK || d->fam == qrl_demod::F_4FSK ? (ns / 80 + 2) * 80 : (ns / 2 / 80 + 2) * 80;
+    return QRL_OK;
+}
+int qrl_demod_audio_cap(const qrl_demod* d, size_t n, size_t* audio_cap)
+{
+    if (!d || !audio_cap) return QRL_ERR_ARG;
+    if (d->fam != qrl_demod::F_ANALOG) { *audio_cap = 0; return QRL_OK; }
+    const size_t n1 = d->fe.used ? n / d->fe_decim + 2 : n;
+    const size_t n2 = n1 * d->interp / d->decim + 2;
+    *audio_cap = n2 * d->an_I / d->an_D + 4;
+    return QRL_OK;
+}
+int qrl_demod_set_squelch(qrl_demod* d, double db)
+{
+    if (!d || d->fam != qrl_demod::F_ANALOG) return QRL_ERR_ARG;
+    d->an_threshold = std::pow(10.0, db / 10);   // pwr_squelch_cc::set_threshold
+    return QRL_OK;
+}
+int qrl_demod_set_agc(qrl_demod* d, float attack, float decay)
+{
+    if (!d || d->fam != qrl_demod::F_ANALOG || d->an_kind != 1) return QRL_ERR_ARG;
+    d->an_attack = attack; d->an_decay = decay;
     return QRL_OK;
 }
 int qrl_demod_process(qrl_demod* d, const float* iq, size_t stride, size_t n, const qrl_demod_out* out)

@@ -77,6 +77,42 @@ std::vector<float> low_pass_2(double gain, double fs, double fc, double tw, doub
     return windowed_sinc(gain, fs, fc, compute_ntaps_windes(fs, tw, atten_db), w);
 }
 
+static std::vector<std::complex<float>> rotate_prototype(const std::vector<float>& lp, double fs, double lo, double hi)
+{
+    const int ntaps = (int)lp.size();
+    std::vector<std::complex<float>> taps(ntaps);
+    const float freq = static_cast<float>(kPi * (hi + lo) / fs);
+    float phase = (ntaps & 1) ? -freq * static_cast<float>(ntaps >> 1)
+                              : static_cast<float>(-freq / 2.0 * ((1 + 2 * ntaps) >> 1));
+    for (int i = 0; i < ntaps; ++i) {
+        taps[i] = {static_cast<float>(lp[i] * std::cos(static_cast<double>(phase))),
+                   static_cast<float>(lp[i] * std::sin(static_cast<double>(phase)))};
+        phase += freq;
+    }
+    return taps;
+}
+std::vector<std::complex<float>> complex_band_pass_2(double gain, double fs, double lo, double hi, double tw, double atten_db, Window w)
+{
+    return rotate_prototype(low_pass_2(gain, fs, (hi - lo) / 2, tw, atten_db, w), fs, lo, hi);
+}
+void deemph_taps(int sample_rate, double tau, double a[2], double b[2])
+{
+    const double fs = (double)sample_rate;
+    const double w_c = 1.0 / tau;
+    const double w_ca = 2.0 * fs * (double)tanf((float)(w_c / (2.0 * fs)));   // the reference calls tanf
+    const double k = -w_ca / (2.0 * fs);
+    const double p1 = (1.0 + k) / (1.0 - k);
+    const double b0 = -k / (1.0 - k);
+    b[0] = b0; b[1] = b0 * 1.0;
+    a[0] = 1.0; a[1] = -p1;
+}
+std::vector<float> squelch_envelope(int ramp)
+{
+    std::vector<float> e((size_t)ramp + 1, 1.0f);
+    for (int k = 0; ramp && k <= ramp; ++k) e[k] = (float)(0.5 - std::cos(kPi * (double)k / (double)ramp) / 2.0);
+    return e;
+}
+
 std::vector<std::complex<float>> complex_band_pass(double gain, double fs, double lo, double hi, double tw, Window w)
 {
     const int ntaps = compute_ntaps(fs, tw, w);

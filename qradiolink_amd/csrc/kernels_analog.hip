@@ -1,0 +1,219 @@
+// kernels_analog.hip — the analogue voice receivers behind their channel filter:
+//   gr_demod_nbfm  reference src/gr/gr_demod_nbfm.cpp:31-88   squelch -> quadrature demod -> 2:5 -> audio filter -> de-emphasis -> x2
+//   gr_demod_am    reference src/gr/gr_demod_am.cpp:28-79     squelch -> |.| -> agc2_ff -> DC block -> x0.99 -> 2:5 -> audio filter
+//   gr_demod_wbfm  reference src/gr/gr_demod_wbfm.cpp:28-72   squelch -> quadrature demod -> x0.9 -> de-emphasis -> 1:25
+// The squelch GATES (pwr_squelch_cc(-140, 0.01, ramp, true)): a muted item is dropped, so everything behind it runs on a
+// per-stream item count that only the device knows.  k_an_gate (lane per stream, serial: power estimate, state machine and the
+// recursions that sit directly behind it) compacts the unmuted items into a float ring and keeps the cumulative count; the
+// feed-forward kernels behind it (k_an_resamp, k_an_fir: thread per output) derive their output range from that count, the last
+// recursion (NBFM de-emphasis) is again a lane per stream.  Rates: 20 ksps / 200 ksps in, 8 ksps out.
+// Arithmetic = oracle/orc_analog.c, bit for bit (double-precision single-pole filters are plain IEEE mul / add, no contraction).
+#include "devmath.hpp"
+#include "engine.hpp"
+
+namespace qrl {
+
+__device__ __forceinline__ float2 an_ringc_at(const RingC& r, int b, int64_t i)
+{
+    if (i < 0) return make_float2(0.f, 0.f);
+    return r.p[(size_t)b * (r.mask + 1u) + ((uint32_t)i & r.mask)];
+}
+__device__ __forceinline__ float an_ringf_at(const RingF& r, int b, int64_t i)
+{
+    if (i < 0) return 0.f;
+    return r.p[(size_t)b * (r.mask + 1u) + ((uint32_t)i & r.mask)];
+}
+__device__ __forceinline__ uint64_t an_decim_count(uint64_t n, int I, int D)
+{
+    return n ? ((n - 1) * (uint64_t)I + (uint64_t)I - 1) / (uint64_t)D + 1 : 0;
+}
+
+// fft_filter_ccc as the direct FIR it implements (AM channel filter, 571 complex taps at 20 ksps): one fmaf chain per component,
+// k ascending, re += hr xr; re += (-hi) xi; im += hr xi; im += hi xr
+__global__ __launch_bounds__(256) void k_an_fir_ccc(const FirCccParams P)
+{
+    extern __shared__ float2 an_taps[];
+    for (int k = threadIdx.x; k < P.nt; k += 256) an_taps[k] = P.taps[k];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.count) return;
+    if (t == 0 && P.counts) P.counts[b * 4 + 0] = P.count;
+    const int64_t n = (int64_t)(P.q0 + t);
+    float ar = 0.f, ai = 0.f;
+    const int kmax = n + 1 < (int64_t)P.nt ? (int)(n + 1) : P.nt;
+    for (int k = 0; k < kmax; ++k) {
+        const float2 h = an_taps[k];
+        const float2 x = an_ringc_at(P.in, b, n - k);
+        ar = fmaf(h.x, x.x, ar);
+        ar = fmaf(-h.y, x.y, ar);
+        ai = fmaf(h.x, x.y, ai);
+        ai = fmaf(h.y, x.x, ai);
+    }
+    const float2 y = make_float2(ar, ai);
+    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = y;
+    if (P.port && t < P.port_cap) P.port[(size_t)b * P.port_cap + t] = y;
+}
+void launch_an_fir_ccc(const FirCccParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_an_fir_ccc, dim3((p.count + 255) / 256, batch), dim3(256), (size_t)p.nt * sizeof(float2), s, p);
+}
+
+// KIND 0 NBFM, 1 AM, 2 WBFM
+template <int KIND>
+__global__ __launch_bounds__(64) void k_an_gate(const AnGateParams P, int batch)
+{
+    __shared__ float T[257];
+    __shared__ float env_tab[AN_MAX_RAMP + 1];
+    for (int k = threadIdx.x; k < 257; k += 64) T[k] = P.atan_tab[k];
+    for (int k = threadIdx.x; k <= P.ramp; k += 64) env_tab[k] = P.env[k];
+    __syncthreads();
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= batch) return;
+    AnState st = P.st[b];
+    st.g_prev = st.g;
+    float* out = P.out.p + (size_t)b * (P.out.mask + 1u);
+    for (uint32_t t = 0; t < P.count; ++t) {
+        const float2 x = an_ringc_at(P.in, b, (int64_t)(P.q0 + t));
+        const float p = x.x * x.x + x.y * x.y;
+        st.pwr = P.alpha * (double)p + P.one_minus_alpha * st.pwr;
+        const bool mute = st.pwr < P.threshold;
+        switch (st.state) {
+        case 0: if (!mute) st.state = P.ramp ? 1 : 2; break;
+        case 2: if (mute) st.state = P.ramp ? 3 : 0; break;
+        case 1:
+            st.env = env_tab[++st.ramped];
+            if (st.ramped >= P.ramp) { st.state = 2; st.env = 1.0f; }
+            break;
+        case 3:
+            st.env = env_tab[--st.ramped];
+            if (st.ramped == 0) st.state = 0;
+            break;
+        }
+        if (st.state == 0) continue;   // gated
+        float2 s;
+        s.x = x.x * st.env - x.y * 0.0f;
+        s.y = x.x * 0.0f + x.y * st.env;
+        float d;
+        if (KIND == 1) {
+            const float m = sqrtf(s.x * s.x + s.y * s.y);                       // complex_to_mag
+            const float o = m * st.gain;                                        // agc2_ff(0.1, 0.1, 1, 1)
+            const float tmp = -1.0f + fabsf(o);
+            float rate = P.decay;
+            if (fabsf(tmp) > st.gain) rate = P.attack;
+            st.gain -= tmp * rate;
+            if (st.gain < 0.0f) st.gain = 10e-5f;
+            if (st.gain > 65536.0f) st.gain = 65536.0f;
+            double acc = P.ff0 * (double)o;                                     // iir_filter_ffd({1, -1}, {0, 0.9999})
+            acc += P.ff1 * (double)st.iir_x;
+            acc += P.fb1 * st.iir_y;
+            st.iir_y = acc; st.iir_x = o;
+            d = (float)acc * 0.99f;                                             // _audio_gain
+        } else {
+            const float re = s.x * st.prev.x + s.y * st.prev.y;                 // quadrature_demod_cf
+            const float im = s.y * st.prev.x - s.x * st.prev.y;
+            d = P.gain * fast_atan2f_lut(im, re, T);
+            st.prev = s;
+            if (KIND == 2) {
+                const float o = d * 0.9f;                                       // _amplify
+                double acc = P.ff0 * (double)o;                                 // _de_emph_filter at 200 ksps
+                acc += P.ff1 * (double)st.iir_x;
+                acc += P.fb1 * st.iir_y;
+                st.iir_y = acc; st.iir_x = o;
+                d = (float)acc;
+            }
+        }
+        out[(uint32_t)st.g & P.out.mask] = d;
+        ++st.g;
+    }
+    P.st[b] = st;
+}
+void launch_an_gate(const AnGateParams& p, int kind, int batch, hipStream_t s)
+{
+    const dim3 g((batch + 63) / 64), t(64);
+    if (kind == 0) hipLaunchKernelGGL(k_an_gate<0>, g, t, 0, s, p, batch);
+    else if (kind == 1) hipLaunchKernelGGL(k_an_gate<1>, g, t, 0, s, p, batch);
+    else hipLaunchKernelGGL(k_an_gate<2>, g, t, 0, s, p, batch);
+}
+
+// rational_resampler_fff(I, D) over the gated ring: output q = sum_j taps[ph + j I] x[c - j], ph = q D mod I, c = q D / I
+// (one fmaf chain, j ascending).  Outputs of this call: decim_count(g_prev) .. decim_count(g) of the stream.
+__global__ __launch_bounds__(256) void k_an_resamp(const AnResampParams P)
+{
+    extern __shared__ float an_rt[];
+    for (int k = threadIdx.x; k < P.nt; k += 256) an_rt[k] = P.taps[k];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const AnState& st = P.st[b];
+    const uint64_t q0 = an_decim_count(st.g_prev, P.I, P.D), q1 = an_decim_count(st.g, P.I, P.D);
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t == 0 && P.port && P.counts) P.counts[b * 4 + 1] = (uint32_t)(q1 - q0);
+    const uint64_t q = q0 + t;
+    if (q >= q1) return;
+    const uint64_t u = q * (uint64_t)P.D;
+    const int ph = (int)(u % (uint64_t)P.I);
+    const int64_t c = (int64_t)(u / (uint64_t)P.I);
+    float a = 0.f;
+    for (int j = 0; ph + j * P.I < P.nt; ++j) {
+        if (c - j < 0) break;
+        a = fmaf(an_rt[ph + j * P.I], an_ringf_at(P.in, b, c - j), a);
+    }
+    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)q & P.out.mask)] = a;
+    if (P.port && t < P.port_cap) P.port[(size_t)b * P.port_cap + t] = a;
+}
+void launch_an_resamp(const AnResampParams& p, uint32_t max_out, int batch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_an_resamp, dim3((max_out + 255) / 256, batch), dim3(256), (size_t)p.nt * sizeof(float), s, p);
+}
+
+// fft_filter_fff (audio filter at 8 ksps) over the resampler's outputs of this call
+__global__ __launch_bounds__(256) void k_an_fir(const AnFirParams P)
+{
+    extern __shared__ float an_ft[];
+    for (int k = threadIdx.x; k < P.nt; k += 256) an_ft[k] = P.taps[k];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const AnState& st = P.st[b];
+    const uint64_t q0 = an_decim_count(st.g_prev, P.I, P.D), q1 = an_decim_count(st.g, P.I, P.D);
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t == 0 && P.port && P.counts) P.counts[b * 4 + 1] = (uint32_t)(q1 - q0);
+    const uint64_t q = q0 + t;
+    if (q >= q1) return;
+    float a = 0.f;
+    const int kmax = q + 1 < (uint64_t)P.nt ? (int)(q + 1) : P.nt;
+    for (int k = 0; k < kmax; ++k) a = fmaf(an_ft[k], an_ringf_at(P.in, b, (int64_t)q - k), a);
+    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)q & P.out.mask)] = a;
+    if (P.port && t < P.port_cap) P.port[(size_t)b * P.port_cap + t] = a;
+}
+void launch_an_fir(const AnFirParams& p, uint32_t max_out, int batch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_an_fir, dim3((max_out + 255) / 256, batch), dim3(256), (size_t)p.nt * sizeof(float), s, p);
+}
+
+// NBFM: iir_filter_ffd(btaps, ataps, false) de-emphasis + multiply_const_ff(2.0) -> port 1
+__global__ __launch_bounds__(64) void k_an_deemph(const AnDeemphParams P, int batch)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= batch) return;
+    AnState st = P.st[b];
+    const uint64_t q0 = an_decim_count(st.g_prev, P.I, P.D), q1 = an_decim_count(st.g, P.I, P.D);
+    float x1 = st.de_x; double y1 = st.de_y;
+    for (uint64_t q = q0; q < q1; ++q) {
+        const float x = an_ringf_at(P.in, b, (int64_t)q);
+        double acc = P.ff0 * (double)x;
+        acc += P.ff1 * (double)x1;
+        acc += P.fb1 * y1;
+        y1 = acc; x1 = x;
+        const uint64_t t = q - q0;
+        if (P.port && t < P.port_cap) P.port[(size_t)b * P.port_cap + t] = (float)acc * 2.0f;
+    }
+    P.st[b].de_x = x1; P.st[b].de_y = y1;
+    if (P.port && P.counts) P.counts[b * 4 + 1] = (uint32_t)(q1 - q0);
+}
+void launch_an_deemph(const AnDeemphParams& p, int batch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_an_deemph, dim3((batch + 63) / 64), dim3(64), 0, s, p, batch);
+}
+
+}  // namespace qrl

@@ -18,7 +18,7 @@ static void hchk(hipError_t e, const char* what)
 qrl_runtime::qrl_runtime(int device) { chk(qrl_init(device, &d_ctx), "qrl_init"); }
 qrl_runtime::~qrl_runtime() { qrl_shutdown(d_ctx); }
 
-enum { FAM_2FSK = 0, FAM_GMSK = 1, FAM_QPSK = 2, FAM_4FSK = 3, FAM_BPSK = 4, FAM_DMR = 5, FAM_M17 = 6, FAM_DSSS = 7 };
+enum { FAM_2FSK = 0, FAM_GMSK = 1, FAM_QPSK = 2, FAM_4FSK = 3, FAM_BPSK = 4, FAM_DMR = 5, FAM_M17 = 6, FAM_DSSS = 7, FAM_NBFM = 8, FAM_AM = 9, FAM_WBFM = 10 };
 
 gr_demod_hip_sptr make_gr_demod_2fsk_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width, bool fm)
 { return gr_demod_hip_sptr(new gr_demod_hip(rt, FAM_2FSK, sps, samp_rate, carrier_freq, filter_width, fm)); }
@@ -39,11 +39,18 @@ gr_demod_hip_sptr make_gr_demod_m17_hip(qrl_runtime& rt, int sps, int samp_rate,
 gr_demod_hip_sptr make_gr_demod_dsss_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
 { return gr_demod_hip_sptr(new gr_demod_hip(rt, FAM_DSSS, sps, samp_rate, carrier_freq, filter_width, false)); }
 
+gr_demod_hip_sptr make_gr_demod_nbfm_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
+{ return gr_demod_hip_sptr(new gr_demod_hip(rt, FAM_NBFM, sps, samp_rate, carrier_freq, filter_width, false)); }
+gr_demod_hip_sptr make_gr_demod_am_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
+{ return gr_demod_hip_sptr(new gr_demod_hip(rt, FAM_AM, sps, samp_rate, carrier_freq, filter_width, false)); }
+gr_demod_hip_sptr make_gr_demod_wbfm_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
+{ return gr_demod_hip_sptr(new gr_demod_hip(rt, FAM_WBFM, sps, samp_rate, carrier_freq, filter_width, false)); }
+
 gr_demod_hip::gr_demod_hip(qrl_runtime& rt, int fam, int sps, int samp_rate, int carrier_freq, int filter_width, bool fm)
     : gr::sync_block("gr_demod_hip", gr::io_signature::make(1, 1, sizeof(gr_complex)), gr::io_signature::make(0, 0, 0)), d_rt(rt)
 {
     // any member of the family selects the chain; the explicit factory arguments (not the mode table) configure it
-    static const int rep[] = {QRL_MODEM_2FSK1K, QRL_MODEM_GMSK10K, QRL_MODEM_QPSK250K, QRL_MODEM_4FSK2KFM, QRL_MODEM_BPSK1K, QRL_MODEM_DMR, QRL_MODEM_M17, QRL_MODEM_BPSK8};
+    static const int rep[] = {QRL_MODEM_2FSK1K, QRL_MODEM_GMSK10K, QRL_MODEM_QPSK250K, QRL_MODEM_4FSK2KFM, QRL_MODEM_BPSK1K, QRL_MODEM_DMR, QRL_MODEM_M17, QRL_MODEM_BPSK8, QRL_MODEM_NBFM5000, QRL_MODEM_AM5000, QRL_MODEM_WBFM};
     d_cfg.modem_type = rep[fam];
     d_cfg.use_mode_defaults = 0;
     d_cfg.sps = sps; d_cfg.samp_rate = samp_rate; d_cfg.carrier_freq = carrier_freq; d_cfg.filter_width = filter_width; d_cfg.fm = fm;
@@ -65,6 +72,10 @@ void gr_demod_hip::open()
     hchk(hipMalloc(reinterpret_cast<void**>(&d_a), d_bcap), "hipMalloc");
     hchk(hipMalloc(reinterpret_cast<void**>(&d_b), d_bcap), "hipMalloc");
     d_ha.resize(d_bcap); d_hb.resize(d_bcap); d_hc.resize(d_ccap);
+    chk(qrl_demod_audio_cap(d_h, kChunk, &d_acap), "qrl_demod_audio_cap");
+    if (d_audio) { (void)hipFree(d_audio); d_audio = nullptr; }
+    if (d_acap) hchk(hipMalloc(reinterpret_cast<void**>(&d_audio), d_acap * sizeof(float)), "hipMalloc");
+    d_hau.resize(d_acap);
     if (d_df1) attach_deframer(d_df_type);   // the deframer buffers follow the (possibly new) bit capacity
 }
 gr_demod_hip::~gr_demod_hip()
@@ -72,7 +83,7 @@ gr_demod_hip::~gr_demod_hip()
     if (d_h) qrl_demod_destroy(d_h);
     if (d_df1) qrl_deframer_destroy(d_df1);
     if (d_df2) qrl_deframer_destroy(d_df2);
-    for (void* p : {(void*)d_iq, (void*)d_const, (void*)d_a, (void*)d_b, (void*)d_cnt, (void*)d_fa, (void*)d_fb, (void*)d_fcnt}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)d_iq, (void*)d_const, (void*)d_a, (void*)d_b, (void*)d_cnt, (void*)d_fa, (void*)d_fb, (void*)d_fcnt, (void*)d_audio}) if (p) (void)hipFree(p);
 }
 void gr_demod_hip::attach_deframer(int type)
 {
@@ -93,7 +104,7 @@ void gr_demod_hip::flush()
 {
     chk(qrl_demod_reset(d_h), "qrl_demod_reset");
     gr::thread::scoped_lock g(d_mutex);
-    d_box1.clear(); d_box2.clear(); d_boxc.clear(); d_carry.clear();
+    d_box1.clear(); d_box2.clear(); d_boxc.clear(); d_boxa.clear(); d_carry.clear();
 }
 
 void gr_demod_hip::run(const gr_complex* x, size_t n)   // n even, <= kChunk
@@ -103,6 +114,7 @@ void gr_demod_hip::run(const gr_complex* x, size_t n)   // n even, <= kChunk
     qrl_demod_out o{};
     o.constellation = d_const; o.constellation_cap = d_ccap;
     o.bits_a = d_a; o.bits_b = d_b; o.bits_cap = d_bcap; o.counts = d_cnt;
+    o.audio = d_audio; o.audio_cap = d_acap;
     chk(qrl_demod_process(d_h, d_iq, kChunk, n, &o), "qrl_demod_process");
     chk(qrl_demod_sync(d_h), "qrl_demod_sync");
     uint32_t cnt[4];
@@ -120,6 +132,12 @@ void gr_demod_hip::run(const gr_complex* x, size_t n)   // n even, <= kChunk
     } else {
         if (cnt[2]) hchk(hipMemcpy(d_ha.data(), d_a, cnt[2], hipMemcpyDeviceToHost), "D2H");
         if (cnt[3]) hchk(hipMemcpy(d_hb.data(), d_b, cnt[3], hipMemcpyDeviceToHost), "D2H");
+    }
+    if (d_acap) {   // analogue modes: port 1 is audio
+        if (cnt[1]) hchk(hipMemcpy(d_hau.data(), d_audio, cnt[1] * sizeof(float), hipMemcpyDeviceToHost), "D2H");
+        gr::thread::scoped_lock g(d_mutex);
+        d_boxa.insert(d_boxa.end(), d_hau.begin(), d_hau.begin() + cnt[1]);
+        return;
     }
     if (cnt[1]) hchk(hipMemcpy(d_hc.data(), d_const, cnt[1] * sizeof(gr_complex), hipMemcpyDeviceToHost), "D2H");
     gr::thread::scoped_lock g(d_mutex);
@@ -145,6 +163,16 @@ int gr_demod_hip::work(int noutput_items, gr_vector_const_void_star& input_items
     }
     return noutput_items;
 }
+std::vector<float>* gr_demod_hip::get_audio_data()
+{
+    gr::thread::scoped_lock g(d_mutex);
+    auto* v = new std::vector<float>();
+    v->swap(d_boxa);
+    return v;
+}
+void gr_demod_hip::set_squelch(int value) { chk(qrl_demod_set_squelch(d_h, (double)value), "qrl_demod_set_squelch"); }
+void gr_demod_hip::set_agc_attack(float value) { d_attack = value; chk(qrl_demod_set_agc(d_h, d_attack, d_decay), "qrl_demod_set_agc"); }
+void gr_demod_hip::set_agc_decay(float value) { d_decay = value; chk(qrl_demod_set_agc(d_h, d_attack, d_decay), "qrl_demod_set_agc"); }
 std::vector<unsigned char>* gr_demod_hip::get_data(int nr)
 {
     gr::thread::scoped_lock g(d_mutex);

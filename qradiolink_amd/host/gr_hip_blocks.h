@@ -45,6 +45,12 @@ gr_demod_hip_sptr make_gr_demod_m17_hip(qrl_runtime& rt, int sps = 125, int samp
 // replaces make_gr_demod_dsss(sps, samp_rate, carrier_freq, filter_width)           src/gr/gr_demod_dsss.cpp:21-28, instance gr_demod_base.cpp:218 (25, 1000000, 1700, 150)
 gr_demod_hip_sptr make_gr_demod_dsss_hip(qrl_runtime& rt, int sps = 25, int samp_rate = 1000000, int carrier_freq = 1700, int filter_width = 150);
 
+// replace make_gr_demod_nbfm / make_gr_demod_am / make_gr_demod_wbfm(signature, sps, samp_rate, carrier_freq, filter_width)
+// src/gr/gr_demod_nbfm.cpp:19-27, gr_demod_am.cpp:19-27, gr_demod_wbfm.cpp:19-27 (port 1 = audio at 8 ksps -> get_audio_data())
+gr_demod_hip_sptr make_gr_demod_nbfm_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 1000000, int carrier_freq = 1700, int filter_width = 5000);
+gr_demod_hip_sptr make_gr_demod_am_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 1000000, int carrier_freq = 1700, int filter_width = 5000);
+gr_demod_hip_sptr make_gr_demod_wbfm_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 1000000, int carrier_freq = 1700, int filter_width = 75000);
+
 class gr_demod_hip : public gr::sync_block {
 public:
     gr_demod_hip(qrl_runtime& rt, int modem_family, int sps, int samp_rate, int carrier_freq, int filter_width, bool fm);
@@ -57,6 +63,10 @@ public:
     int work(int noutput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) override;
     std::vector<unsigned char>* get_data(int nr);          // port 2 (nr = 1) / port 3 (nr = 2); caller deletes
     std::vector<gr_complex>* get_constellation_data();     // port 1; caller deletes
+    std::vector<float>* get_audio_data();                  // analogue modes, port 1 (gr_audio_sink::get_data, src/gr/gr_audio_sink.cpp); caller deletes
+    void set_squelch(int value);                           // gr_demod_nbfm/am/wbfm::set_squelch
+    void set_agc_attack(float value);                      // gr_demod_am::set_agc_attack / set_agc_decay
+    void set_agc_decay(float value);
     void flush();                                          // qrl_demod_reset + drop mailboxes
     // gr_demod_base connects ports 2/3 of the 1k/2k/10k modes to gr_deframer_bb(2 | 1 | 3) (src/gr/gr_demod_base.cpp:171-178,
     // 577-603): with a deframer attached get_data(nr) hands out what gr_deframer_bb::get_data would (sync bits + frame bits)
@@ -74,6 +84,7 @@ private:
     std::vector<gr_complex> d_buf;
     float *d_iq = nullptr, *d_const = nullptr; uint8_t *d_a = nullptr, *d_b = nullptr; uint32_t* d_cnt = nullptr;   // device
     std::vector<unsigned char> d_box1, d_box2, d_ha, d_hb; std::vector<gr_complex> d_boxc, d_hc;
+    float* d_audio = nullptr; size_t d_acap = 0; std::vector<float> d_boxa, d_hau; float d_attack = 0.1f, d_decay = 0.1f;
     gr::thread::mutex d_mutex;
     static constexpr size_t kChunk = 1 << 18;
 };

@@ -66,13 +66,14 @@ struct gr_demod_base_hip::slot {
     float *d_filt = nullptr, *d_const = nullptr; uint8_t *d_a = nullptr, *d_b = nullptr, *d_dmo = nullptr; uint32_t *d_cnt = nullptr, *d_dmocnt = nullptr;
     gr_complex* h_const = nullptr; uint8_t *h_a = nullptr, *h_b = nullptr, *h_dmo = nullptr; uint32_t *h_cnt = nullptr, *h_dmocnt = nullptr;   // pinned
     float *d_rssi = nullptr, *h_rssi = nullptr; bool rssi_valid = false;   // latest rssi_block value per stream (device / pinned)
+    float *d_audio = nullptr, *h_audio = nullptr;         // analogue modes: port 1 (device / pinned)
     hipEvent_t done = nullptr;
 };
 static constexpr size_t kDmoCap = 16;
 
 gr_demod_base_hip::gr_demod_base_hip(qrl_runtime& rt, int streams, int device_samp_rate, double carrier_offset_hz, size_t max_chunk)
     : d_rt(rt), d_n(streams), d_rate(device_samp_rate), d_offset(carrier_offset_hz), d_chunk(max_chunk & ~(size_t)1),
-      d_box1(streams), d_box2(streams), d_boxc(streams), d_boxd(streams)
+      d_boxa(streams), d_box1(streams), d_box2(streams), d_boxc(streams), d_boxd(streams)
 {
     if (streams < 1 || d_chunk < 2) throw std::invalid_argument("gr_demod_base_hip: streams >= 1, max_chunk >= 2");
     hipStream_t s;
@@ -95,6 +96,8 @@ void gr_demod_base_hip::close()
         if (!sp) continue;
         if (sp->d_rssi) (void)hipFree(sp->d_rssi);
         if (sp->h_rssi) (void)hipHostFree(sp->h_rssi);
+        if (sp->d_audio) (void)hipFree(sp->d_audio);
+        if (sp->h_audio) (void)hipHostFree(sp->h_audio);
         for (void* p : {(void*)sp->d_iq, (void*)sp->d_filt, (void*)sp->d_const, (void*)sp->d_a, (void*)sp->d_b, (void*)sp->d_dmo, (void*)sp->d_cnt, (void*)sp->d_dmocnt})
             if (p) (void)hipFree(p);
         for (void* p : {(void*)sp->h_iq, (void*)sp->h_const, (void*)sp->h_a, (void*)sp->h_b, (void*)sp->h_dmo, (void*)sp->h_cnt, (void*)sp->h_dmocnt})
@@ -113,6 +116,9 @@ void gr_demod_base_hip::open()
     c.batch = d_n; c.max_chunk = d_chunk; c.enable_side_outputs = 1;
     chk(qrl_demod_create(d_rt.ctx(), &c, &d_h), "qrl_demod_create");
     chk(qrl_demod_out_caps(d_h, d_chunk, &d_fcap, &d_ccap, &d_bcap), "qrl_demod_out_caps");
+    chk(qrl_demod_audio_cap(d_h, d_chunk, &d_acap), "qrl_demod_audio_cap");
+    if (d_acap) chk(qrl_demod_set_squelch(d_h, (double)d_squelch), "qrl_demod_set_squelch");
+    if (d_acap && d_mode == QRL_MODEM_AM5000) chk(qrl_demod_set_agc(d_h, d_agc_attack, d_agc_decay), "qrl_demod_set_agc");
     const size_t N = (size_t)d_n;
     // side outputs on the copy stream: rssi_block behind port 0, rx_fft_c on the device-rate IQ (gr_demod_base.cpp:166,185,199-200)
     chk(qrl_rssi_create(d_rt.ctx(), d_n, d_rssi_cal, d_copy, &d_rssi), "qrl_rssi_create");
@@ -134,6 +140,10 @@ void gr_demod_base_hip::open()
         hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_a), N * d_bcap, hipHostMallocDefault), "hipHostMalloc");
         hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_b), N * d_bcap, hipHostMallocDefault), "hipHostMalloc");
         hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_cnt), N * 4 * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
+        if (d_acap) {
+            hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_audio), N * d_acap * sizeof(float)), "hipMalloc");
+            hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_audio), N * d_acap * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
+        }
         if (d_mode == QRL_MODEM_DMR) {
             hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_dmo), N * kDmoCap * QRL_DMO_RECORD_BYTES), "hipMalloc");
             hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_dmocnt), N * sizeof(uint32_t)), "hipMalloc");
@@ -150,7 +160,7 @@ void gr_demod_base_hip::set_mode(int mode)   // gr_demod_base::set_mode (src/gr/
     d_mode = mode;
     open();
     std::lock_guard<std::mutex> g(d_mutex);
-    for (int s = 0; s < d_n; ++s) { d_box1[s].clear(); d_box2[s].clear(); d_boxc[s].clear(); d_boxd[s].clear(); }
+    for (int s = 0; s < d_n; ++s) { d_box1[s].clear(); d_box2[s].clear(); d_boxc[s].clear(); d_boxd[s].clear(); d_boxa[s].clear(); }
 }
 void gr_demod_base_hip::set_carrier_offset(double hz)   // gr_demod_base.cpp:1220-1225
 {
@@ -178,9 +188,11 @@ void gr_demod_base_hip::work(const gr_complex* const* iq, size_t n)
     qrl_demod_out o{};
     o.filtered = sl.d_filt; o.filtered_cap = d_fcap; o.constellation = sl.d_const; o.constellation_cap = d_ccap;
     o.bits_a = sl.d_a; o.bits_b = sl.d_b; o.bits_cap = d_bcap; o.counts = sl.d_cnt;
+    o.audio = sl.d_audio; o.audio_cap = d_acap;
     chk(qrl_demod_process(d_h, sl.d_iq, d_chunk, n, &o), "qrl_demod_process");
     chk(qrl_demod_stream_wait(d_h, cs), "qrl_demod_stream_wait");
     const size_t N = (size_t)d_n;
+    if (d_acap) hchk(hipMemcpyAsync(sl.h_audio, sl.d_audio, N * d_acap * sizeof(float), hipMemcpyDeviceToHost, cs), "D2H");
     hchk(hipMemcpyAsync(sl.h_cnt, sl.d_cnt, N * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, cs), "D2H");
     hchk(hipMemcpyAsync(sl.h_a, sl.d_a, N * d_bcap, hipMemcpyDeviceToHost, cs), "D2H");
     hchk(hipMemcpyAsync(sl.h_b, sl.d_b, N * d_bcap, hipMemcpyDeviceToHost, cs), "D2H");
@@ -209,6 +221,10 @@ void gr_demod_base_hip::harvest(int which)
     for (int s = 0; s < d_n; ++s) {
         const uint32_t* c = sl.h_cnt + 4 * (size_t)s;
         if (sl.rssi_valid && c[0]) d_level[s] = sl.h_rssi[s];
+        if (d_acap) {   // analogue modes: port 1 is audio (gr_audio_sink), no bit / constellation ports
+            d_boxa[s].insert(d_boxa[s].end(), sl.h_audio + (size_t)s * d_acap, sl.h_audio + (size_t)s * d_acap + c[1]);
+            continue;
+        }
         d_box1[s].insert(d_box1[s].end(), sl.h_a + (size_t)s * d_bcap, sl.h_a + (size_t)s * d_bcap + c[2]);
         d_box2[s].insert(d_box2[s].end(), sl.h_b + (size_t)s * d_bcap, sl.h_b + (size_t)s * d_bcap + c[3]);
         d_boxc[s].insert(d_boxc[s].end(), sl.h_const + (size_t)s * d_ccap, sl.h_const + (size_t)s * d_ccap + c[1]);
@@ -234,6 +250,28 @@ std::vector<unsigned char>* gr_demod_base_hip::getData(int nr, int stream)   // 
     std::vector<unsigned char>* out = new std::vector<unsigned char>;
     out->swap(box);
     return out;
+}
+std::vector<float>* gr_demod_base_hip::getAudio(int stream)   // gr_demod_base::getAudio (src/gr/gr_demod_base.cpp:968-976)
+{
+    std::lock_guard<std::mutex> g(d_mutex);
+    std::vector<float>* out = new std::vector<float>;
+    out->swap(d_boxa[stream]);
+    return out;
+}
+void gr_demod_base_hip::set_squelch(int value)   // gr_demod_base.cpp:1186-1199
+{
+    d_squelch = value;
+    if (d_h && d_acap) chk(qrl_demod_set_squelch(d_h, (double)value), "qrl_demod_set_squelch");
+}
+void gr_demod_base_hip::set_agc_attack(float value)   // :1428-1448
+{
+    d_agc_attack = value;
+    if (d_h && d_acap && d_mode == QRL_MODEM_AM5000) chk(qrl_demod_set_agc(d_h, d_agc_attack, d_agc_decay), "qrl_demod_set_agc");
+}
+void gr_demod_base_hip::set_agc_decay(float value)   // :1450-1470
+{
+    d_agc_decay = value;
+    if (d_h && d_acap && d_mode == QRL_MODEM_AM5000) chk(qrl_demod_set_agc(d_h, d_agc_attack, d_agc_decay), "qrl_demod_set_agc");
 }
 std::vector<gr_complex>* gr_demod_base_hip::get_constellation_data(int stream)
 {
@@ -374,6 +412,18 @@ void gr_modem_hip::toggleTxMode(int modem_type)   // gr_modem.cpp:105-199
     _tx_frame_length = modem_tx_frame_length(modem_type);
 }
 
+bool gr_modem_hip::demodulateAnalog(int stream)
+{
+    if (!_gr_demod_base) return false;
+    std::vector<float>* audio_data = _gr_demod_base->getAudio(stream);
+    if (audio_data == nullptr) return false;
+    if (audio_data->size() > 0) {
+        if (_ev.pcmAudio) _ev.pcmAudio(stream, audio_data); else delete audio_data;
+        return true;
+    }
+    delete audio_data;
+    return false;
+}
 bool gr_modem_hip::demodulate(int stream)   // gr_modem.cpp:1019-1117
 {
     if (!_gr_demod_base) return false;

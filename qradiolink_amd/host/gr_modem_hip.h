@@ -55,6 +55,11 @@ public:
     std::vector<unsigned char>* getData(int nr, int stream);   // nr = 1: bits A (port 2), nr = 2: bits B (port 3); nullptr = nothing yet
     std::vector<gr_complex>* get_constellation_data(int stream = 0);
     std::vector<std::vector<unsigned char>> getDMRData(int stream = 0);   // DMR mode: 40-byte DMO records (QRL_DMO_RECORD_BYTES)
+    // analogue voice modes (NBFM2500 / NBFM5000 / AM5000 / WBFM): port 1 = audio at 8 ksps (gr_demod_base::getAudio :968-976; caller deletes)
+    std::vector<float>* getAudio(int stream = 0);
+    void set_squelch(int value);                               // gr_demod_base::set_squelch, dB
+    void set_agc_attack(float value);                          // gr_demod_base::set_agc_attack / set_agc_decay (AM)
+    void set_agc_decay(float value);
     // side outputs (gr_demod_base.cpp:199-200, 185; :978-986, 1105-1113, 1227-1237, 1413-1418)
     void enable_rssi(bool value) { d_rssi_on = value; }
     float get_rssi(int stream = 0);                            // probe_signal_f::level() of the rssi_block behind port 0
@@ -79,8 +84,10 @@ private:
     void* d_copy = nullptr;                                   // hipStream_t for the copy-out
     slot* d_slot[2] = {nullptr, nullptr};
     int d_inflight = -1; uint64_t d_calls = 0;
-    size_t d_fcap = 0, d_ccap = 0, d_bcap = 0;
+    size_t d_fcap = 0, d_ccap = 0, d_bcap = 0, d_acap = 0;
+    int d_squelch = -140; float d_agc_attack = 0.1f, d_agc_decay = 0.1f;
     std::mutex d_mutex;
+    std::vector<std::vector<float>> d_boxa;
     std::vector<std::vector<unsigned char>> d_box1, d_box2;
     std::vector<std::vector<gr_complex>> d_boxc;
     std::vector<std::vector<std::vector<unsigned char>>> d_boxd;
@@ -119,6 +126,7 @@ struct gr_modem_events {
     std::function<void(int stream)> dataFrameReceived, endAudioTransmission, receiveEnd;
     std::function<void(int stream, uint64_t frame_type, const unsigned char* data, int size)> m17Frame;   // raw M17 frames
     std::function<void(int stream, const std::vector<std::vector<unsigned char>>& records)> dmrFrames;     // DMO slicer bursts
+    std::function<void(int stream, std::vector<float>* pcm)> pcmAudio;   // analogue modes (gr_modem::pcmAudio); the slot owns pcm
 };
 
 class gr_modem_hip {
@@ -127,6 +135,7 @@ public:
     void toggleRxMode(int modem_type);
     void toggleTxMode(int modem_type);
     bool demodulate(int stream = 0);
+    bool demodulateAnalog(int stream = 0);                      // gr_modem::demodulateAnalog, src/gr_modem.cpp:996-1017
     // TX (bytes are queued on the modulator; its work() turns them into samples)
     std::vector<unsigned char>* frame(unsigned char* encoded_audio, int data_size, int frame_type);
     void transmit(std::vector<std::vector<unsigned char>*> frames, int stream = 0);

@@ -2,6 +2,7 @@
 //   test_adaptor nodevice                      -> expects std::runtime_error from construction (exit 0 if thrown)
 //   test_adaptor rx <family>[+d<type>] <sps> <fw> <fm> <device_rate> <offset> <iq.bin> <bits_a.bin> <bits_b.bin>
 //                (family 2fsk | gmsk | qpsk | 4fsk | bpsk | dmr; "+d2" attaches gr_deframer_bb(2) to ports 2/3)
+//   test_adaptor rxa <nbfm | am | wbfm> <fw> <iq.bin> <audio.bin>      analogue receivers: port 1 = audio mailbox
 //   test_adaptor tx <bytes.bin> <iq.bin> [family sps fw fm]
 #include "gr_hip_blocks.h"
 #include <cstdio>
@@ -64,6 +65,30 @@ int main(int argc, char** argv)
             dump(argv[9], a.data(), a.size());
             dump(argv[10], b.data(), b.size());
             std::printf("rx ok: %zu samples -> %zu / %zu bits\n", n, a.size(), b.size());
+            return 0;
+        }
+        if (!strcmp(argv[1], "rxa") && argc == 6) {
+            const std::string fam = argv[2];
+            const int fw = atoi(argv[3]);
+            gr_demod_hip_sptr d = fam == "nbfm" ? make_gr_demod_nbfm_hip(rt, 125, 1000000, 1700, fw)
+                                : fam == "am"   ? make_gr_demod_am_hip(rt, 125, 1000000, 1700, fw)
+                                                : make_gr_demod_wbfm_hip(rt, 125, 1000000, 1700, fw);
+            std::vector<char> raw = slurp(argv[4]);
+            const gr_complex* x = reinterpret_cast<const gr_complex*>(raw.data());
+            const size_t n = raw.size() / sizeof(gr_complex);
+            std::vector<float> audio;
+            size_t pos = 0; unsigned k = 0;
+            static const int sizes[] = {8191, 4096, 1, 33333, 7, 65536, 12345};
+            gr_vector_void_star outs;
+            while (pos < n) {
+                const size_t take = std::min<size_t>(n - pos, (size_t)sizes[k++ % 7]);
+                gr_vector_const_void_star ins(1, x + pos);
+                if (d->work((int)take, ins, outs) != (int)take) return 3;
+                pos += take;
+                if (std::vector<float>* v = d->get_audio_data()) { audio.insert(audio.end(), v->begin(), v->end()); delete v; }
+            }
+            dump(argv[5], audio.data(), audio.size() * sizeof(float));
+            std::printf("rxa ok: %zu samples -> %zu audio samples\n", n, audio.size());
             return 0;
         }
         if (!strcmp(argv[1], "tx") && (argc == 4 || argc == 8)) {

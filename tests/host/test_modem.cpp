@@ -24,6 +24,44 @@ static std::string hex(const unsigned char* d, int n)
 
 int main(int argc, char** argv)
 {
+    if (argc == 6 && !strcmp(argv[1], "analog")) {
+        // test_modem analog <modem_type> <streams> <iq.bin: [streams][n] cf32> <audio prefix>: the facade's analogue path the way
+        // radiocontroller polls it (gr_modem::demodulateAnalog -> pcmAudio); stream s's audio goes to <prefix><s>.bin
+        const int mode = atoi(argv[2]), N = atoi(argv[3]);
+        try {
+            qrl_runtime rt(0);
+            std::vector<std::vector<float>> audio(N);
+            gr_modem_events ev;
+            ev.pcmAudio = [&](int s, std::vector<float>* pcm) { audio[s].insert(audio[s].end(), pcm->begin(), pcm->end()); delete pcm; };
+            const size_t chunk = 1 << 16;
+            gr_demod_base_hip demod(rt, N, 1000000, 0.0, chunk);
+            gr_modem_hip modem(&demod, nullptr, ev);
+            modem.toggleRxMode(mode);
+            std::ifstream f(argv[4], std::ios::binary);
+            std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+            const size_t n = raw.size() / sizeof(gr_complex) / (size_t)N;
+            const gr_complex* x = reinterpret_cast<const gr_complex*>(raw.data());
+            static const size_t sizes[] = {65536, 4096, 2, 33334, 20000};
+            size_t pos = 0; unsigned k = 0;
+            while (pos < n) {
+                const size_t take = std::min(n - pos, sizes[k++ % 5]) & ~(size_t)1;
+                if (!take) break;
+                std::vector<const gr_complex*> ptr(N);
+                for (int s = 0; s < N; ++s) ptr[s] = x + (size_t)s * n + pos;
+                demod.work(ptr.data(), take);
+                pos += take;
+                for (int s = 0; s < N; ++s) modem.demodulateAnalog(s);
+            }
+            demod.flush();
+            for (int s = 0; s < N; ++s) modem.demodulateAnalog(s);
+            for (int s = 0; s < N; ++s) {
+                std::ofstream o(std::string(argv[5]) + std::to_string(s) + ".bin", std::ios::binary);
+                o.write(reinterpret_cast<const char*>(audio[s].data()), (std::streamsize)(audio[s].size() * sizeof(float)));
+            }
+            std::printf("analog ok\n");
+            return 0;
+        } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+    }
     if (argc != 6 || strcmp(argv[1], "loopback")) { std::fprintf(stderr, "usage: test_modem loopback modem_type streams frames out.txt\n"); return 2; }
     const int mode = atoi(argv[2]), N = atoi(argv[3]), nframes = atoi(argv[4]);
     try {

@@ -633,6 +633,36 @@ def det_log2f(x):
     return float(lib.orc_det_log2f(float(x)))
 
 
+ANALOG_KINDS = {"nbfm": 0, "am": 1, "wbfm": 2}
+
+
+def demod_analog(x, kind, samp_rate=1000000, filter_width=5000):
+    """-> dict(filtered=cf32 port 0, audio=f32 port 1)"""
+    x = np.ascontiguousarray(x, cf32)
+    f, a = C.c_void_p(), C.c_void_p()
+    nf, na = C.c_size_t(), C.c_size_t()
+    lib.orc_demod_analog(_ptr(x), C.c_size_t(x.size), ANALOG_KINDS[kind], samp_rate, filter_width,
+                         C.byref(f), C.byref(nf), C.byref(a), C.byref(na))
+    filt = np.ctypeslib.as_array(C.cast(f, C.POINTER(C.c_float)), (2 * nf.value,)).copy().view(cf32) if nf.value else np.zeros(0, cf32)
+    aud = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_float)), (na.value,)).copy() if na.value else np.zeros(0, np.float32)
+    lib.orc_free(f); lib.orc_free(a)
+    return dict(filtered=filt, audio=aud)
+
+
+def pwr_squelch_cc(x, db=-140.0, alpha=0.01, ramp=0, gate=True):
+    x = np.ascontiguousarray(x, cf32)
+    out = np.zeros(max(x.size, 1), cf32)
+    lib.orc_pwr_squelch_cc.restype = C.c_size_t
+    n = lib.orc_pwr_squelch_cc(_ptr(x), C.c_size_t(x.size), C.c_double(db), C.c_double(alpha), ramp, int(gate), _ptr(out))
+    return out[:n].copy()
+
+
+def deemph_taps(sample_rate, tau=50e-6):
+    a, b = (C.c_double * 2)(), (C.c_double * 2)()
+    lib.orc_deemph_taps(sample_rate, C.c_double(tau), a, b)
+    return list(a), list(b)
+
+
 def rssi_block(x, level=0.0):
     x = np.ascontiguousarray(x, cf32)
     out = np.zeros(max(x.size, 1), np.float32)

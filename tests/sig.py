@@ -185,3 +185,20 @@ def make_dsss(info_bits, seed=1, amp=0.05, noise=0.0005, cfo=0.0):
     n = np.arange(y.size)
     z = amp * y * np.exp(2j * np.pi * cfo * n / 1e6) + noise * (rng.standard_normal(y.size) + 1j * rng.standard_normal(y.size))
     return z.astype(np.complex64)
+
+
+def make_analog(kind, n=400000, seed=1, amp=0.05, noise=0.0005, gap=None, fs=1000000.0):
+    """Analogue voice test signal at 1 Msps: two audio tones, FM (deviation 2.5 kHz / 50 kHz for WBFM) or AM (60 % depth) on the
+    carrier at 0 Hz, AWGN; `gap` = (start, stop) zeroes that span completely (an idle channel: the gating squelch closes)."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / fs
+    audio = 0.6 * np.sin(2 * np.pi * (700.0 + 13 * seed) * t) + 0.3 * np.sin(2 * np.pi * (1900.0 + 7 * seed) * t + 0.4)
+    if kind == "am":
+        x = (1.0 + 0.6 * audio) * np.exp(0.3j)
+    else:
+        dev = 50000.0 if kind == "wbfm" else 2500.0
+        x = np.exp(2j * np.pi * dev * np.cumsum(audio) / fs)
+    y = amp * x + noise * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    if gap:
+        y[gap[0]:gap[1]] = 0
+    return y.astype(np.complex64), audio

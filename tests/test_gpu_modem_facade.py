@@ -75,3 +75,26 @@ def test_facade_side_outputs(tmp_path):
         assert -45.0 < float(dict(ev[s])["rssi_max"]) < -15.0 and float(dict(ev[s])["rssi"]) < float(dict(ev[s])["rssi_max"]) - 20.0
     assert int(d0["spectra"]) >= 2
     assert abs(int(d0["peak_bin"]) - 2048) < 80 and float(d0["peak_db"]) > -70.0
+
+
+@pytest.mark.parametrize("mode,kind,fw", [(9, "nbfm", 5000), (14, "am", 5000), (10, "wbfm", 75000)])
+def test_facade_analog_audio(tmp_path, mode, kind, fw):
+    """toggleRxMode(NBFM / AM / WBFM) -> work() -> demodulateAnalog() -> pcmAudio, two radios on one handle; the audio every
+    stream's slot received equals the oracle chain bit for bit (gr_modem.cpp:996-1017, gr_demod_base.cpp:968-976)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import orc
+    import sig
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qradiolink_amd", "csrc"), "adaptor"])
+    n = 300000
+    xs = [sig.make_analog(kind, n=n, seed=7)[0], sig.make_analog(kind, n=n, seed=8, gap=(40000, 240000))[0]]
+    (tmp_path / "iq.bin").write_bytes(np.stack(xs).tobytes())
+    r = subprocess.run([EXE, "analog", str(mode), "2", str(tmp_path / "iq.bin"), str(tmp_path / "a")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for s in range(2):
+        got = np.fromfile(tmp_path / ("a%d.bin" % s), np.float32) + np.float32(0)
+        want = orc.demod_analog(xs[s], kind, filter_width=fw)["audio"] + np.float32(0)
+        assert got.size == want.size and got.size > 400
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

@@ -291,6 +291,62 @@ def test_m17_dibits_recovered(qrl_ctx):
     assert best == 1.0
 
 
+# ---- analogue voice receivers (gr_demod_nbfm / gr_demod_am / gr_demod_wbfm): gating squelch, so the audio
+# count is data dependent; a stretch of exact zeros (idle channel) closes the squelch in the middle of the stream
+@pytest.mark.parametrize("kind,modem,fw", [("nbfm", 9, 5000), ("nbfm", 8, 2500), ("am", 14, 5000), ("wbfm", 10, 75000)])
+@pytest.mark.parametrize("chunk", [1 << 20, 100000, 33334])
+def test_analog_bit_exact(qrl_ctx, kind, modem, fw, chunk):
+    import torch
+    import qradiolink_amd as q
+    n = 400000
+    xs = [sig.make_analog(kind, n=n, seed=1, gap=(100000, 300000))[0], sig.make_analog(kind, n=n, seed=2)[0]]
+    iq = np.stack(xs)
+    dem = q.Demod(qrl_ctx, modem, batch=2, max_chunk=min(chunk, n))
+    out = q.collect(dem, torch.from_numpy(iq).cuda(), min(chunk, n))
+    dem.close()
+    for b in range(2):
+        ref = orc.demod_analog(iq[b], kind, filter_width=fw)
+        assert ref["audio"].size > 1500
+        got, want = out["filtered"][b].view(np.float32) + np.float32(0), ref["filtered"].view(np.float32) + np.float32(0)
+        assert got.size == want.size and np.array_equal(got.view(np.uint32), want.view(np.uint32)), "filtered"
+        got, want = out["audio"][b] + np.float32(0), ref["audio"] + np.float32(0)
+        assert got.size == want.size, (got.size, want.size)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "audio"
+    # the idle stretch of stream 0 is gated away: fewer audio samples than the stream without it
+    assert out["audio"][0].size < out["audio"][1].size
+
+
+@pytest.mark.parametrize("kind,modem", [("nbfm", 9), ("am", 14), ("wbfm", 10)])
+def test_analog_audio_is_the_modulating_tone(qrl_ctx, kind, modem):
+    import torch
+    import qradiolink_amd as q
+    x, _ = sig.make_analog(kind, n=600000, seed=1)
+    dem = q.Demod(qrl_ctx, modem, batch=1, max_chunk=x.size)
+    out = q.collect(dem, torch.from_numpy(x[None, :]).cuda(), x.size)
+    dem.close()
+    a = out["audio"][0][800:4000].astype(np.float64)
+    spec = np.abs(np.fft.rfft(a * np.hanning(a.size)))
+    peak_hz = (np.argmax(spec[5:]) + 5) * 8000.0 / a.size
+    assert abs(peak_hz - 713.0) < 5.0, peak_hz
+
+
+def test_analog_squelch_threshold(qrl_ctx):
+    """set_squelch(db): a threshold above the signal's power keeps the gate shut -> no audio at all"""
+    import torch
+    import qradiolink_amd as q
+    x, _ = sig.make_analog("nbfm", n=200000, seed=3)          # power 0.05^2 = -26 dB
+    dem = q.Demod(qrl_ctx, q.MODEM_NBFM5000, batch=1, max_chunk=x.size)
+    dem.set_squelch(-10.0)
+    out = q.collect(dem, torch.from_numpy(x[None, :]).cuda(), x.size)
+    assert out["audio"][0].size == 0 and out["filtered"][0].size == 4000
+    dem.reset()
+    dem.set_squelch(-140.0)
+    out = q.collect(dem, torch.from_numpy(x[None, :]).cuda(), x.size)
+    dem.close()
+    # (the first items of the stream, where the channel filter is still filling, stay below even -140 dB)
+    assert out["audio"][0].size == orc.demod_analog(x, "nbfm", filter_width=5000)["audio"].size and 1590 <= out["audio"][0].size <= 1600
+
+
 # ---- DSSS "BPSK 8" (gr_demod_dsss, SURVEY 8(f) rank 4): 1:50, 13:50 resampler, Costas, filter, AGC, Barker-13 matched-filter
 # decoder (325 evaluations of a 600-tap filter per symbol), M&M clock recovery, Costas, K=7 decoder on two branches
 @pytest.mark.parametrize("chunk", [1 << 22, 250000, 65538])

@@ -569,3 +569,49 @@ def test_dsss_chain_recovers_the_information_bits():
     r = orc.demod_dsss(sig.make_dsss(bits))
     want = "".join(map(str, bits[:60]))
     assert any(want in "".join(map(str, r[p])) for p in ("bits_a", "bits_b"))
+
+
+# ---- analogue voice receivers (orc_analog.c): definition checks of the restated blocks
+def test_pwr_squelch_gates_and_ramps():
+    x = np.concatenate([np.ones(10), np.zeros(5000), np.ones(10)]).astype(np.complex64)
+    y = orc.pwr_squelch_cc(x, db=-140.0, alpha=0.01, ramp=4, gate=True)
+    # attack: the item that opens the gate leaves with envelope 0, then 0.5 - cos(pi k / 4) / 2
+    assert np.allclose(y[:5].real, [0.0, 0.5 - np.cos(np.pi / 4) / 2, 0.5, 0.5 + np.cos(np.pi / 4) / 2, 1.0], atol=1e-7)
+    # the single-pole power estimate (alpha 0.01) needs ln(p0 / 1e-14) / 0.01 items to fall below -140 dB; then 4 items of decay, then nothing
+    p = 0.0
+    for _ in range(10):
+        p = 0.01 * 1.0 + 0.99 * p
+    k = 0
+    while p >= 1e-14:
+        p *= 0.99
+        k += 1
+    # (the item that trips the threshold still leaves at full level, then ramp - 1 decaying items; the last one lands on envelope 0 = muted)
+    assert y.size == 10 + (k - 1) + 4 + 10
+    ungated = orc.pwr_squelch_cc(x, db=-140.0, alpha=0.01, ramp=4, gate=False)
+    assert ungated.size == x.size
+
+
+def test_deemphasis_taps_and_iir_against_scipy():
+    from scipy.signal import lfilter
+    a, b = orc.deemph_taps(20000)
+    fs, tau = 20000.0, 50e-6
+    w_ca = 2 * fs * float(np.tan(np.float32(1 / tau / (2 * fs))))
+    k = -w_ca / (2 * fs)
+    assert np.allclose(a, [1.0, -(1 + k) / (1 - k)], rtol=1e-6) and np.allclose(b, [-k / (1 - k)] * 2, rtol=1e-6)
+    assert abs(sum(b) / sum(a) - 1.0) < 1e-9          # unity gain at DC
+
+
+@pytest.mark.parametrize("kind,fw", [("nbfm", 5000), ("nbfm", 2500), ("am", 5000), ("wbfm", 75000)])
+def test_analog_chain_recovers_the_modulating_tone(kind, fw):
+    x, _ = sig.make_analog(kind, n=600000, seed=1)
+    r = orc.demod_analog(x, kind, filter_width=fw)
+    assert r["filtered"].size == (120000 if kind == "wbfm" else 12000)
+    a = r["audio"][800:4000].astype(np.float64)
+    spec = np.abs(np.fft.rfft(a * np.hanning(a.size)))
+    assert abs((np.argmax(spec[5:]) + 5) * 8000.0 / a.size - 713.0) < 5.0
+
+
+def test_analog_idle_channel_is_gated_away():
+    x, _ = sig.make_analog("nbfm", n=400000, seed=1, gap=(100000, 300000))
+    y, _ = sig.make_analog("nbfm", n=400000, seed=1)
+    assert orc.demod_analog(x, "nbfm")["audio"].size < orc.demod_analog(y, "nbfm")["audio"].size
