@@ -38,7 +38,7 @@ typedef enum {
 /* values of gr_modem_types (reference src/modem_types.h:5-50) accepted by qrl_demod_create */
 enum {
     QRL_MODEM_BPSK2K = 0, QRL_MODEM_QPSK20K = 1, QRL_MODEM_QPSKVIDEO = 2, QRL_MODEM_4FSK2K = 3, QRL_MODEM_4FSK10KFM = 4, QRL_MODEM_4FSK2KFM = 5, QRL_MODEM_4FSK1KFM = 6, QRL_MODEM_QPSK2K = 7,
-    QRL_MODEM_NBFM2500 = 8, QRL_MODEM_NBFM5000 = 9, QRL_MODEM_WBFM = 10, QRL_MODEM_AM5000 = 14,   /* analogue voice receivers: port 1 = audio */
+    QRL_MODEM_NBFM2500 = 8, QRL_MODEM_NBFM5000 = 9, QRL_MODEM_WBFM = 10, QRL_MODEM_USB2500 = 11, QRL_MODEM_LSB2500 = 12, QRL_MODEM_AM5000 = 14,   /* analogue voice receivers: port 1 = audio */
     QRL_MODEM_2FSK2KFM = 15, QRL_MODEM_2FSK1KFM = 16, QRL_MODEM_2FSK2K = 17, QRL_MODEM_2FSK1K = 18,
     QRL_MODEM_2FSK10KFM = 19, QRL_MODEM_GMSK2K = 20, QRL_MODEM_GMSK1K = 21, QRL_MODEM_GMSK10K = 22,
     QRL_MODEM_BPSK1K = 24, QRL_MODEM_BPSK8 = 25 /* DSSS, Barker 13 */, QRL_MODEM_QPSK250K = 26, QRL_MODEM_4FSK100K = 27, QRL_MODEM_M17 = 40, QRL_MODEM_DMR = 41
@@ -113,14 +113,15 @@ int qrl_demod_set_dmo_output(qrl_demod* d, uint8_t* frames, size_t cap_frames, u
 enum { QRL_OPT_OVERLAP = 1 };
 int qrl_demod_set_option(qrl_demod* d, int option, int value);
 int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* filtered_cap, size_t* constellation_cap, size_t* bits_cap);
-/* analogue voice receivers (QRL_MODEM_NBFM2500 / NBFM5000 / AM5000 / WBFM; replace make_gr_demod_nbfm / _am / _wbfm, reference
- * src/gr/gr_demod_nbfm.cpp:19-88, gr_demod_am.cpp:19-79, gr_demod_wbfm.cpp:19-72, instances gr_demod_base.cpp:215,219,220,228):
+/* analogue voice receivers (QRL_MODEM_NBFM2500 / NBFM5000 / AM5000 / WBFM / USB2500 / LSB2500; replace make_gr_demod_nbfm / _am /
+ * _wbfm / _ssb, reference src/gr/gr_demod_nbfm.cpp:19-88, gr_demod_am.cpp:19-79, gr_demod_wbfm.cpp:19-72, gr_demod_ssb.cpp:19-81
+ * (with src/gr/cessb/clipper_cc_impl.cc, stretcher_cc_impl.cc), instances gr_demod_base.cpp:215,219,220,226-228):
  * port 0 = the channel-filtered IQ, port 1 = audio.  The squelch gates (pwr_squelch_cc(-140, 0.01, ramp, true)), so the number of
  * audio samples a call returns depends on the signal; audio_cap(n) is the bound for a call of n input samples (0 for other modes). */
 int qrl_demod_audio_cap(const qrl_demod* d, size_t n, size_t* audio_cap);
 /* replaces gr_demod_nbfm/am/wbfm::set_squelch (pwr_squelch_cc::set_threshold, gr_demod_base.cpp:1186-1199): threshold in dB */
 int qrl_demod_set_squelch(qrl_demod* d, double db);
-/* replaces gr_demod_am::set_agc_attack / set_agc_decay (gr_demod_am.cpp:90-98) */
+/* replaces gr_demod_am / gr_demod_ssb::set_agc_attack / set_agc_decay (gr_demod_am.cpp:90-98, gr_demod_ssb.cpp:104-112) */
 int qrl_demod_set_agc(qrl_demod* d, float attack, float decay);
 
 /* replaces: one scheduler pass of the "demodulator" top_block over n new samples per stream:

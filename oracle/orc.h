@@ -183,6 +183,11 @@ void   orc_agc2_ff(const float* in, size_t n, float attack, float decay, float r
 void   orc_iir_ffd_2(const float* in, size_t n, const double ff[2], const double fb[2], int oldstyle, float* out);
 void   orc_demod_analog(const cf32* in, size_t n, int kind /* 0 NBFM, 1 AM, 2 WBFM */, int samp_rate, int filter_width,
                         cf32** filtered, size_t* n_filtered, float** audio, size_t* n_audio);
+int    orc_band_pass_2(double gain, double fs, double lo, double hi, double tw, double atten_db, int win, float* taps);
+void   orc_cessb_clipper(const cf32* in, size_t n, float clip, cf32* out);
+size_t orc_cessb_stretcher(const cf32* in, size_t n, cf32* out);
+void   orc_demod_ssb(const cf32* in, size_t n, int samp_rate, int filter_width, int sb /* 0 USB, 1 LSB */,
+                     cf32** filtered, size_t* n_filtered, float** audio, size_t* n_audio);
 void   orc_free(void* p);
 float orc_det_log2f(float x);
 void orc_rssi_block(const cf32* in, size_t n, float level, float* out);

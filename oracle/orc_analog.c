@@ -3,6 +3,8 @@
  *   gr_demod_nbfm   reference src/gr/gr_demod_nbfm.cpp:31-88   (instances gr_demod_base.cpp:219-220: filter width 2500 / 5000)
  *   gr_demod_am     reference src/gr/gr_demod_am.cpp:28-79     (instance  gr_demod_base.cpp:215: filter width 5000)
  *   gr_demod_wbfm   reference src/gr/gr_demod_wbfm.cpp:28-72   (instance  gr_demod_base.cpp:228: filter width 75000)
+ *   gr_demod_ssb    reference src/gr/gr_demod_ssb.cpp:28-81    (instances gr_demod_base.cpp:226-227: filter width 2700, USB / LSB)
+ *   cessb clipper / stretcher   src/gr/cessb/clipper_cc_impl.cc:66-93, stretcher_cc_impl.cc:68-106 (in the reference tree)
  *   de-emphasis taps            src/gr/emphasis.cpp:16-43
  * GNU Radio 3.10 block semantics restated from memory [GR-MEM] (parity unpinned):
  *   pwr_squelch_cc / squelch_base_cc  gr-analog/lib/squelch_base_cc_impl.cc, pwr_squelch_cc_impl.cc
@@ -212,6 +214,85 @@ void orc_demod_analog(const cf32* in, size_t n, int kind, int samp_rate, int fil
     }
     free(d);
     *audio = out; *n_audio = no;
+}
+
+/* cessb::clipper_cc(clip): polar clip, item by item (the block works in chunks of 1024, the values do not depend on them):
+ * magnitude sqrtf(re^2 + im^2), phase fast_atan2f, min(magnitude, clip), back through cos / sin.  volk_32f_cos_32f / sin_32f are
+ * restated with the oracle's own deterministic sincos (orc_sincosf): [GR-MEM] the VOLK kernels are polynomial approximations whose
+ * last bits depend on the machine's SIMD path anyway. */
+void orc_cessb_clipper(const cf32* in, size_t n, float clip, cf32* out)
+{
+    for (size_t i = 0; i < n; i++) {
+        const float mag = sqrtf(in[i].re * in[i].re + in[i].im * in[i].im);
+        const float ph = orc_fast_atan2f(in[i].im, in[i].re);
+        const float c = mag < clip ? mag : clip;
+        float sn, cs;
+        orc_sincosf(ph, &sn, &cs);
+        out[i].re = cs * c; out[i].im = sn * c;
+    }
+}
+/* cessb::stretcher_cc: output k = in[k] / h, h = (max(emax max(|in[k-2 .. k+2]|), 1) - 1) 2 + 1, emax = 1 / (sqrt(0.5) / 2) as float;
+ * items before the stream start count as 0.  The block emits whole chunks of 1024 and reads two items ahead: n input items give
+ * 1024 floor((n - 2) / 1024) outputs (returned). */
+size_t orc_cessb_stretcher(const cf32* in, size_t n, cf32* out)
+{
+    const float emax = (float)(1 / (sqrt(0.5) / 2));
+    const size_t nout = n >= 2 ? 1024 * ((n - 2) / 1024) : 0;
+    for (size_t k = 0; k < nout; k++) {
+        float e = 0.0f;
+        for (long long j = (long long)k - 2; j <= (long long)k + 2; j++) {
+            if (j < 0) continue;
+            const float m = sqrtf(in[j].re * in[j].re + in[j].im * in[j].im);
+            e = m > e ? m : e;
+        }
+        float h = e * emax;
+        h = h > 1.0f ? h : 1.0f;
+        h = h - 1.0f;
+        h = h * 2.0f;
+        h = h + 1.0f;
+        out[k].re = in[k].re / h; out[k].im = in[k].im / h;
+    }
+    return nout;
+}
+
+/* gr_demod_ssb(sps = 125, ., ., filter_width, sb): 1:125 to 8 ksps -> x0.9 -> complex band-pass (port 0) -> gating squelch ->
+ * agc2_cc(0.1, 0.1, 0.25, 1) -> clipper(0.95) -> stretcher -> real part -> x1.333 -> audio band-pass (port 1) */
+void orc_demod_ssb(const cf32* in, size_t n, int samp_rate, int filter_width, int sb,
+                   cf32** filtered, size_t* n_filtered, float** audio, size_t* n_audio)
+{
+    const int target = 8000, decim = 125;
+    int nt = orc_low_pass(1, samp_rate, target / 2, target / 2, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* taps = NEW(float, nt);
+    orc_low_pass(1, samp_rate, target / 2, target / 2, ORC_WIN_BLACKMAN_HARRIS, taps);
+    const size_t n1 = orc_decim_count(n, 1, decim);
+    cf32* s1 = NEW(cf32, n1);
+    orc_decim_auto(in, n, taps, nt, decim, s1);                                                 /* _resampler */
+    free(taps);
+    for (size_t i = 0; i < n1; i++) { s1[i].re = s1[i].re * 0.9f; s1[i].im = s1[i].im * 0.9f; } /* _if_gain */
+    const double lo = sb ? -filter_width : 200, hi = sb ? -200 : filter_width;
+    int nf = orc_complex_band_pass_2(1, target, lo, hi, 200, 90, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    cf32* ft = NEW(cf32, nf);
+    orc_complex_band_pass_2(1, target, lo, hi, 200, 90, ORC_WIN_BLACKMAN_HARRIS, ft);
+    cf32* f = NEW(cf32, n1);
+    orc_fir_ccc(s1, n1, ft, nf, f);                                                             /* _filter_usb / _filter_lsb -> port 0 */
+    free(ft); free(s1);
+    *filtered = f; *n_filtered = n1;
+    cf32* g = NEW(cf32, n1);
+    const size_t ng = orc_pwr_squelch_cc(f, n1, -140, 0.01, 0, 1, g);                           /* _squelch */
+    cf32* a = NEW(cf32, ng);
+    orc_agc2(g, ng, 1e-1f, 1e-1f, 0.25f, 1.0f, 65536.0f, a);                                    /* _agc */
+    orc_cessb_clipper(a, ng, 0.95f, g);                                                         /* _clipper */
+    const size_t ns = orc_cessb_stretcher(g, ng, a);                                            /* _stretcher */
+    float* r = NEW(float, ns);
+    for (size_t i = 0; i < ns; i++) r[i] = a[i].re * 1.333f;                                    /* _complex_to_real, _level_control */
+    free(g); free(a);
+    int na = orc_band_pass_2(1, target, 200, filter_width, 200, 90, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* at = NEW(float, na);
+    orc_band_pass_2(1, target, 200, filter_width, 200, 90, ORC_WIN_BLACKMAN_HARRIS, at);
+    float* out = NEW(float, ns);
+    orc_fir_fff(r, ns, at, na, out);                                                            /* _audio_filter -> port 1 */
+    free(at); free(r);
+    *audio = out; *n_audio = ns;
 }
 
 void orc_free(void* p) { free(p); }

@@ -83,6 +83,27 @@ int orc_low_pass_2(double gain, double fs, double fc, double tw, double atten_db
     return ntaps;
 }
 
+/* firdes::band_pass_2 [GR-MEM]: windowed difference of two sincs, unity gain at the band centre */
+int orc_band_pass_2(double gain, double fs, double lo, double hi, double tw, double atten_db, int win, float* taps)
+{
+    int ntaps = orc_compute_ntaps_windes(fs, tw, atten_db);
+    if (!taps) return ntaps;
+    float* w = (float*)malloc(sizeof(float) * (size_t)ntaps);
+    orc_window(win, ntaps, w);
+    int M = (ntaps - 1) / 2;
+    double fwT0 = 2 * M_PI * lo / fs, fwT1 = 2 * M_PI * hi / fs;
+    for (int n = -M; n <= M; n++) {
+        if (n == 0) taps[n + M] = (float)((fwT1 - fwT0) / M_PI * w[n + M]);
+        else        taps[n + M] = (float)((sin(n * fwT1) - sin(n * fwT0)) / (n * M_PI) * w[n + M]);
+    }
+    double fmax = taps[0 + M];
+    for (int n = 1; n <= M; n++) fmax += 2 * taps[n + M] * cos(n * (fwT0 + fwT1) * 0.5);
+    gain /= fmax;
+    for (int i = 0; i < ntaps; i++) taps[i] = (float)(taps[i] * gain);
+    free(w);
+    return ntaps;
+}
+
 int orc_complex_band_pass(double gain, double fs, double lo, double hi, double tw, int win, cf32* taps)
 {
     int ntaps = orc_compute_ntaps(fs, tw, win);

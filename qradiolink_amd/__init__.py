@@ -22,6 +22,7 @@ MODEM_BPSK2K, MODEM_BPSK1K = 0, 24
 MODEM_4FSK2K, MODEM_4FSK10KFM, MODEM_4FSK2KFM, MODEM_4FSK1KFM, MODEM_4FSK100K = 3, 4, 5, 6, 27
 MODEM_BPSK8 = 25
 MODEM_NBFM2500, MODEM_NBFM5000, MODEM_WBFM, MODEM_AM5000 = 8, 9, 10, 14
+MODEM_USB2500, MODEM_LSB2500 = 11, 12
 MODEM_M17 = 40
 MODEM_DMR = 41
 OPT_OVERLAP = 1

@@ -211,7 +211,8 @@ struct qrl_demod {
     uint64_t n5 = 0, nsy = 0;   // items so far at 5 200 samples/s, matched-filter outputs so far
     int dsss_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* out, uint32_t* counts, bool side);
     // analogue voice receivers (gr_demod_nbfm / gr_demod_am / gr_demod_wbfm): kernels_analog.hip
-    int an_kind = 0;                                             // 0 NBFM, 1 AM, 2 WBFM
+    int an_kind = 0; bool an_lsb = false;                        // 0 NBFM, 1 AM, 2 WBFM, 3 SSB (an_lsb: lower sideband)
+    DevBuf<float2> an_c1;                                        // SSB: clipped complex items behind the gate
     DevBuf<float2> an_filt_c; int an_nfc = 0;                    // AM channel filter (complex taps)
     DevBuf<float> an_env, an_rtaps, an_ftaps; int an_ramp = 0, an_nr = 0, an_nf = 0, an_I = 2, an_D = 5;
     DevBuf<float> an_f1, an_f2, an_f3; uint32_t an_m1 = 0, an_m2 = 0;
@@ -291,6 +292,7 @@ int qrl_demod::init_state()
     }
     if (fam == F_ANALOG) {
         for (auto* b : {&an_f1, &an_f2, &an_f3}) if (b->p && (r = b->zero())) return r;
+        if (an_c1.p && (r = an_c1.zero())) return r;
         std::vector<AnState> as(cfg.batch);
         for (auto& x : as) { std::memset(&x, 0, sizeof x); x.env = an_ramp ? 0.0f : 1.0f; x.gain = 1.0f; }   // agc2_ff(0.1, 0.1, 1, 1), gr_demod_am.cpp:48
         if (hipMemcpy(an_st.p, as.data(), as.size() * sizeof(AnState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
@@ -334,7 +336,9 @@ int qrl_demod::build()
         target = 20000; sps_eff = 10; decim = 50; interp = 1;
     } else if (fam == F_ANALOG) {
         // gr_demod_nbfm.cpp:39,50 / gr_demod_am.cpp:36,44: 1:50 to 20 ksps; gr_demod_wbfm.cpp:37,49: 1:5 to 200 ksps (sps is unused there)
-        target = an_kind == 2 ? 200000 : 20000; decim = an_kind == 2 ? 5 : 50; interp = 1; sps_eff = 10; branches = 1;
+        // gr_demod_ssb.cpp:35,41-43: 1:sps (125) to 8 ksps
+        target = an_kind == 2 ? 200000 : an_kind == 3 ? 8000 : 20000; decim = an_kind == 2 ? 5 : an_kind == 3 ? 125 : 50; interp = 1; sps_eff = 10; branches = 1;
+        if (an_kind == 3 && sps != 125) return fail(QRL_ERR_ARG, "ssb: sps must be 125 (make_gr_demod_ssb(125, ...), gr_demod_base.cpp:226-227)");
     } else if (fam == F_BPSK) {
         // gr_demod_bpsk.cpp:40-52: 1:50 to 20 ksps, sps samples per symbol
         if (sps != 10 && sps != 5) return fail(QRL_ERR_ARG, "bpsk: sps must be 10 (BPSK1K) or 5 (BPSK2K)");
@@ -552,6 +556,13 @@ int qrl_demod::build()
             an_nfc = (int)fc.size();
             if ((r = an_filt_c.upload(to_f2(fc)))) return r;
             an_ff[0] = 1; an_ff[1] = -1; an_fb1 = 0.9999;                          // iir_filter_ffd({1, -1}, {0, 0.9999}), old style
+        } else if (an_kind == 3) {   // gr_demod_ssb.cpp:41-58
+            an_ramp = 0; an_I = 0; an_D = 1;                                       // I = 0: the stretcher's chunked output count
+            ft = band_pass_2(1, target, 200, fw, 200, 90, WIN_BLACKMAN_HARRIS);
+            const auto fc = an_lsb ? complex_band_pass_2(1, target, -fw, -200, 200, 90, WIN_BLACKMAN_HARRIS)
+                                   : complex_band_pass_2(1, target, 200, fw, 200, 90, WIN_BLACKMAN_HARRIS);
+            an_nfc = (int)fc.size();
+            if ((r = an_filt_c.upload(to_f2(fc)))) return r;
         } else {                     // gr_demod_wbfm.cpp:41-57
             an_ramp = 0; an_I = 1; an_D = 25;
             rt = low_pass(1, target, 4000, 2000, WIN_BLACKMAN_HARRIS);
@@ -560,11 +571,12 @@ int qrl_demod::build()
             an_ff[0] = b[0]; an_ff[1] = b[1]; an_fb1 = -a[1];
         }
         an_nr = (int)rt.size(); an_nf = (int)ft.size();
-        if ((r = an_rtaps.upload(rt)) || (an_nf && (r = an_ftaps.upload(ft))) || (r = an_env.upload(squelch_envelope(an_ramp)))) return r;
-        an_m1 = pow2_at_least(max2 + 1024) - 1;                                  // the audio resampler looks <= 419 gated items back
-        an_m2 = pow2_at_least(max2 * an_I / an_D + 512) - 1;
-        if ((r = an_f1.alloc((size_t)B * (an_m1 + 1))) || (r = an_f2.alloc((size_t)B * (an_m2 + 1))) ||
-            (an_kind != 2 && (r = an_f3.alloc((size_t)B * (an_m2 + 1)))) || (r = an_st.alloc(B))) return r;
+        if ((an_nr && (r = an_rtaps.upload(rt))) || (an_nf && (r = an_ftaps.upload(ft))) || (r = an_env.upload(squelch_envelope(an_ramp)))) return r;
+        an_m1 = pow2_at_least(max2 + 2048) - 1;                                  // the audio resampler looks <= 419 gated items back, the stretcher <= 1025
+        an_m2 = an_kind == 3 ? an_m1 : pow2_at_least(max2 * an_I / an_D + 512) - 1;
+        if (an_kind == 3) { if ((r = an_c1.alloc((size_t)B * (an_m1 + 1)))) return r; }
+        else if ((r = an_f1.alloc((size_t)B * (an_m1 + 1)))) return r;
+        if ((r = an_f2.alloc((size_t)B * (an_m2 + 1))) || ((an_kind == 0 || an_kind == 1) && (r = an_f3.alloc((size_t)B * (an_m2 + 1)))) || (r = an_st.alloc(B))) return r;
     }
     if (fam == F_DSSS) {
         const std::vector<float> ti = low_pass(1, target, 2600, 2600, WIN_BLACKMAN_HARRIS);              // _resampler_if (13, 50), gr_demod_dsss.cpp:57-59
@@ -888,7 +900,8 @@ int qrl_demod::analog_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* 
     const uint32_t c2 = (uint32_t)(n2_1 - n2_0);
     float2* fport = side && out->filtered ? reinterpret_cast<float2*>(out->filtered) : nullptr;
     const size_t fcap = side ? out->filtered_cap : 0;
-    if (an_kind == 1) {   // _filter -> port 0
+    if (an_kind == 3) launch_scale_c(r2, n2_0, c2, 0.9f, B, stream);   // _if_gain, gr_demod_ssb.cpp:45
+    if (an_kind == 1 || an_kind == 3) {   // _filter -> port 0
         FirCccParams f{}; f.in = r2; f.out = r2f; f.q0 = n2_0; f.count = c2; f.taps = an_filt_c.p; f.nt = an_nfc;
         f.port = fport; f.port_cap = fcap; f.counts = counts;
         launch_an_fir_ccc(f, B, stream);
@@ -902,10 +915,20 @@ int qrl_demod::analog_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* 
         AnGateParams g{}; g.in = r2f; g.out = f1; g.q0 = n2_0; g.count = c2; g.st = an_st.p; g.atan_tab = atan_tab.p;
         g.env = an_env.p; g.ramp = an_ramp; g.alpha = 0.01; g.one_minus_alpha = 1.0 - 0.01; g.threshold = an_threshold;
         g.gain = an_gain; g.attack = an_attack; g.decay = an_decay; g.ff0 = an_ff[0]; g.ff1 = an_ff[1]; g.fb1 = an_fb1;
+        g.outc = RingC{an_c1.p, an_m1}; g.ref = 0.25f; g.clip = 0.95f;             // agc2_cc(0.1, 0.1, 0.25, 1), clipper_cc(0.95): gr_demod_ssb.cpp:52,58
         launch_an_gate(g, an_kind, B, stream);
     }
     float* aport = out ? out->audio : nullptr;
     const size_t acap = out ? out->audio_cap : 0;
+    if (an_kind == 3) {   // _stretcher, _complex_to_real, _level_control, _audio_filter -> port 1 (whole chunks of 1024 gated items)
+        const uint32_t max_chunked = c2 + 1024;
+        AnStretchParams sp{}; sp.in = RingC{an_c1.p, an_m1}; sp.out = f2; sp.st = an_st.p; sp.level = 1.333f;
+        launch_an_stretch(sp, max_chunked, B, stream);
+        AnFirParams p{}; p.in = f2; p.out = RingF{nullptr, 0}; p.st = an_st.p; p.taps = an_ftaps.p; p.nt = an_nf; p.I = 0; p.D = 1;
+        p.port = aport; p.port_cap = acap; p.counts = counts;
+        launch_an_fir(p, max_chunked, B, stream);
+        return QRL_OK;
+    }
     const uint32_t max_out = (uint32_t)((uint64_t)c2 * an_I / an_D + 2);
     {   // _audio_resampler (WBFM: -> port 1)
         AnResampParams p{}; p.in = f1; p.out = f2; p.st = an_st.p; p.taps = an_rtaps.p; p.nt = an_nr; p.I = an_I; p.D = an_D;
@@ -996,7 +1019,8 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         case QRL_MODEM_NBFM2500:  c.sps = 125; c.filter_width = 2500;  c.fm = 0; break;   // make_gr_demod_nbfm(125, ., 1700, 2500) gr_demod_base.cpp:219
         case QRL_MODEM_NBFM5000:  c.sps = 125; c.filter_width = 5000;  c.fm = 0; break;   // :220
         case QRL_MODEM_WBFM:      c.sps = 125; c.filter_width = 75000; c.fm = 0; break;   // make_gr_demod_wbfm(125, ., 1700, 75000) :228
-        case QRL_MODEM_AM5000:    c.sps = 125; c.filter_width = 5000;  c.fm = 0; break;   // make_gr_demod_am(125, ., 1700, 5000) :215   // make_gr_demod_dsss(25, ., 1700, 150) gr_demod_base.cpp:218
+        case QRL_MODEM_AM5000:    c.sps = 125; c.filter_width = 5000;  c.fm = 0; break;
+        case QRL_MODEM_USB2500: case QRL_MODEM_LSB2500: c.sps = 125; c.filter_width = 2700; c.fm = 0; break;   // make_gr_demod_ssb(125, ., 1700, 2700, sb) :226-227   // make_gr_demod_am(125, ., 1700, 5000) :215   // make_gr_demod_dsss(25, ., 1700, 150) gr_demod_base.cpp:218
         case QRL_MODEM_M17:       c.sps = 125; c.filter_width = 9000;  c.fm = 0; break;   // make_gr_demod_m17() gr_demod_base.cpp:252, defaults gr_demod_m17.h:41-42
         default: return fail(QRL_ERR_ARG, "modem_type not supported by this build");
         }
@@ -1024,6 +1048,8 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         d->fam = qrl_demod::F_ANALOG; d->an_kind = 1; break;
     case QRL_MODEM_WBFM:
         d->fam = qrl_demod::F_ANALOG; d->an_kind = 2; break;
+    case QRL_MODEM_USB2500: case QRL_MODEM_LSB2500:
+        d->fam = qrl_demod::F_ANALOG; d->an_kind = 3; d->an_lsb = c.modem_type == QRL_MODEM_LSB2500; break;
     default: return fail(QRL_ERR_ARG, "modem_type not supported by this build");
     }
     if (c.samp_rate != 1000000) return fail(QRL_ERR_ARG, "internal samp_rate must be 1000000 (gr_demod_base.cpp:21)");
@@ -1127,7 +1153,7 @@ int qrl_demod_audio_cap(const qrl_demod* d, size_t n, size_t* audio_cap)
     if (d->fam != qrl_demod::F_ANALOG) { *audio_cap = 0; return QRL_OK; }
     const size_t n1 = d->fe.used ? n / d->fe_decim + 2 : n;
     const size_t n2 = n1 * d->interp / d->decim + 2;
-    *audio_cap = n2 * d->an_I / d->an_D + 4;
+    *audio_cap = d->an_kind == 3 ? n2 + 1024 + 4 : n2 * d->an_I / d->an_D + 4;
     return QRL_OK;
 }
 int qrl_demod_set_squelch(qrl_demod* d, double db)
@@ -1138,7 +1164,7 @@ int qrl_demod_set_squelch(qrl_demod* d, double db)
 }
 int qrl_demod_set_agc(qrl_demod* d, float attack, float decay)
 {
-    if (!d || d->fam != qrl_demod::F_ANALOG || d->an_kind != 1) return QRL_ERR_ARG;
+    if (!d || d->fam != qrl_demod::F_ANALOG || (d->an_kind != 1 && d->an_kind != 3)) return QRL_ERR_ARG;
     d->an_attack = attack; d->an_decay = decay;
     return QRL_OK;
 }

@@ -265,15 +265,18 @@ struct FirCccParams { RingC in, out; uint64_t q0; uint32_t count; const float2* 
 void launch_an_fir_ccc(const FirCccParams& p, int batch, hipStream_t s);
 // g / g_prev: items that passed the gating squelch up to the end of this / the previous call
 struct AnState { double pwr, iir_y, de_y; uint64_t g, g_prev; float2 prev; float iir_x, de_x, gain, env; int state, ramped; };
-struct AnGateParams { RingC in; RingF out; uint64_t q0; uint32_t count; AnState* st; const float* atan_tab; const float* env; int ramp;
-                      double alpha, one_minus_alpha, threshold; float gain, attack, decay; double ff0, ff1, fb1; };
-void launch_an_gate(const AnGateParams& p, int kind, int batch, hipStream_t s);   // kind 0 NBFM, 1 AM, 2 WBFM
+struct AnGateParams { RingC in; RingF out; RingC outc; uint64_t q0; uint32_t count; AnState* st; const float* atan_tab; const float* env; int ramp;
+                      double alpha, one_minus_alpha, threshold; float gain, attack, decay, ref, clip; double ff0, ff1, fb1; };
+void launch_an_gate(const AnGateParams& p, int kind, int batch, hipStream_t s);   // kind 0 NBFM, 1 AM, 2 WBFM, 3 SSB (complex out)
 struct AnResampParams { RingF in, out; const AnState* st; const float* taps; int nt, I, D; float* port; size_t port_cap; uint32_t* counts; };
 void launch_an_resamp(const AnResampParams& p, uint32_t max_out, int batch, hipStream_t s);
 struct AnFirParams { RingF in, out; const AnState* st; const float* taps; int nt, I, D; float* port; size_t port_cap; uint32_t* counts; };
 void launch_an_fir(const AnFirParams& p, uint32_t max_out, int batch, hipStream_t s);
 struct AnDeemphParams { RingF in; AnState* st; int I, D; double ff0, ff1, fb1; float* port; size_t port_cap; uint32_t* counts; };
 void launch_an_deemph(const AnDeemphParams& p, int batch, hipStream_t s);
+// I == 0 in AnFirParams / AnStretchParams: the output range of the call is the cessb stretcher's, 1024 floor((g - 2) / 1024)
+struct AnStretchParams { RingC in; RingF out; const AnState* st; float level; };
+void launch_an_stretch(const AnStretchParams& p, uint32_t max_out, int batch, hipStream_t s);
 
 // ---- side outputs (kernels_side.hip): rssi_block on port 0, rx_fft_c on the device-rate IQ ----
 constexpr uint32_t RSSI_RING = 4096;   // |x|^2 look-back ring per stream (moving_average_ff(2000) reads 1999 items back)

@@ -77,6 +77,22 @@ std::vector<float> low_pass_2(double gain, double fs, double fc, double tw, doub
     return windowed_sinc(gain, fs, fc, compute_ntaps_windes(fs, tw, atten_db), w);
 }
 
+std::vector<float> band_pass_2(double gain, double fs, double lo, double hi, double tw, double atten_db, Window wt)
+{
+    const int ntaps = compute_ntaps_windes(fs, tw, atten_db);
+    std::vector<float> taps(ntaps);
+    const std::vector<float> w = window(wt, ntaps);
+    const int M = (ntaps - 1) / 2;
+    const double w0 = 2 * kPi * lo / fs, w1 = 2 * kPi * hi / fs;
+    for (int n = -M; n <= M; ++n)
+        taps[n + M] = n == 0 ? static_cast<float>((w1 - w0) / kPi * w[n + M])
+                             : static_cast<float>((std::sin(n * w1) - std::sin(n * w0)) / (n * kPi) * w[n + M]);
+    double centre = taps[M];                                   // unity gain at the band centre
+    for (int n = 1; n <= M; ++n) centre += 2 * taps[n + M] * std::cos(n * (w0 + w1) * 0.5);
+    const double g = gain / centre;
+    for (float& t : taps) t = static_cast<float>(t * g);
+    return taps;
+}
 static std::vector<std::complex<float>> rotate_prototype(const std::vector<float>& lp, double fs, double lo, double hi)
 {
     const int ntaps = (int)lp.size();

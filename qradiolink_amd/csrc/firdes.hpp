@@ -21,6 +21,7 @@ std::vector<float> low_pass(double gain, double fs, double fc, double tw, Window
 std::vector<float> dsss_matched_filter(int sps);
 std::vector<float> low_pass_2(double gain, double fs, double fc, double tw, double atten_db, Window w = WIN_HAMMING);
 std::vector<std::complex<float>> complex_band_pass(double gain, double fs, double lo, double hi, double tw, Window w = WIN_HAMMING);
+std::vector<float> band_pass_2(double gain, double fs, double lo, double hi, double tw, double atten_db, Window w = WIN_HAMMING);
 std::vector<std::complex<float>> complex_band_pass_2(double gain, double fs, double lo, double hi, double tw, double atten_db, Window w = WIN_HAMMING);
 // reference src/gr/emphasis.cpp:16-43 (gr-analog fm_emph.py): b = {b0, b0}, a = {1, -p1}
 void deemph_taps(int sample_rate, double tau, double a[2], double b[2]);

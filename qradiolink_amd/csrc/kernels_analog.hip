@@ -23,8 +23,11 @@ __device__ __forceinline__ float an_ringf_at(const RingF& r, int b, int64_t i)
     if (i < 0) return 0.f;
     return r.p[(size_t)b * (r.mask + 1u) + ((uint32_t)i & r.mask)];
 }
+// items the stage behind the gate has produced once g items passed it: rational resampler I:D, or (I == 0) the cessb stretcher,
+// which emits whole chunks of 1024 and reads two items ahead
 __device__ __forceinline__ uint64_t an_decim_count(uint64_t n, int I, int D)
 {
+    if (I == 0) return n >= 2 ? 1024 * ((n - 2) / 1024) : 0;
     return n ? ((n - 1) * (uint64_t)I + (uint64_t)I - 1) / (uint64_t)D + 1 : 0;
 }
 
@@ -60,7 +63,7 @@ void launch_an_fir_ccc(const FirCccParams& p, int batch, hipStream_t s)
     hipLaunchKernelGGL(k_an_fir_ccc, dim3((p.count + 255) / 256, batch), dim3(256), (size_t)p.nt * sizeof(float2), s, p);
 }
 
-// KIND 0 NBFM, 1 AM, 2 WBFM
+// KIND 0 NBFM, 1 AM, 2 WBFM, 3 SSB (gr_demod_ssb.cpp:28-81: squelch -> agc2_cc -> cessb clipper, complex items out)
 template <int KIND>
 __global__ __launch_bounds__(64) void k_an_gate(const AnGateParams P, int batch)
 {
@@ -95,6 +98,22 @@ __global__ __launch_bounds__(64) void k_an_gate(const AnGateParams P, int batch)
         float2 s;
         s.x = x.x * st.env - x.y * 0.0f;
         s.y = x.x * 0.0f + x.y * st.env;
+        if (KIND == 3) {
+            float2 o = make_float2(s.x * st.gain, s.y * st.gain);                // agc2_cc(0.1, 0.1, 0.25, 1)
+            const float tmp = -P.ref + sqrtf(o.x * o.x + o.y * o.y);
+            float rate = P.decay;
+            if (tmp > st.gain) rate = P.attack;
+            st.gain -= tmp * rate;
+            if (st.gain < 0.0f) st.gain = 10e-5f;
+            if (st.gain > 65536.0f) st.gain = 65536.0f;
+            const float mag = sqrtf(o.x * o.x + o.y * o.y);                     // cessb::clipper_cc(0.95), clipper_cc_impl.cc:74-88
+            const float ph = fast_atan2f_lut(o.y, o.x, T);
+            const float c = mag < P.clip ? mag : P.clip;
+            const float2 sc = sincos_rad(ph);
+            P.outc.p[(size_t)b * (P.outc.mask + 1u) + ((uint32_t)st.g & P.outc.mask)] = make_float2(sc.x * c, sc.y * c);
+            ++st.g;
+            continue;
+        }
         float d;
         if (KIND == 1) {
             const float m = sqrtf(s.x * s.x + s.y * s.y);                       // complex_to_mag
@@ -134,7 +153,8 @@ void launch_an_gate(const AnGateParams& p, int kind, int batch, hipStream_t s)
     const dim3 g((batch + 63) / 64), t(64);
     if (kind == 0) hipLaunchKernelGGL(k_an_gate<0>, g, t, 0, s, p, batch);
     else if (kind == 1) hipLaunchKernelGGL(k_an_gate<1>, g, t, 0, s, p, batch);
-    else hipLaunchKernelGGL(k_an_gate<2>, g, t, 0, s, p, batch);
+    else if (kind == 2) hipLaunchKernelGGL(k_an_gate<2>, g, t, 0, s, p, batch);
+    else hipLaunchKernelGGL(k_an_gate<3>, g, t, 0, s, p, batch);
 }
 
 // rational_resampler_fff(I, D) over the gated ring: output q = sum_j taps[ph + j I] x[c - j], ph = q D mod I, c = q D / I
@@ -183,12 +203,42 @@ __global__ __launch_bounds__(256) void k_an_fir(const AnFirParams P)
     float a = 0.f;
     const int kmax = q + 1 < (uint64_t)P.nt ? (int)(q + 1) : P.nt;
     for (int k = 0; k < kmax; ++k) a = fmaf(an_ft[k], an_ringf_at(P.in, b, (int64_t)q - k), a);
-    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)q & P.out.mask)] = a;
+    if (P.out.p) P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)q & P.out.mask)] = a;
     if (P.port && t < P.port_cap) P.port[(size_t)b * P.port_cap + t] = a;
 }
 void launch_an_fir(const AnFirParams& p, uint32_t max_out, int batch, hipStream_t s)
 {
     hipLaunchKernelGGL(k_an_fir, dim3((max_out + 255) / 256, batch), dim3(256), (size_t)p.nt * sizeof(float), s, p);
+}
+
+// cessb::stretcher_cc (stretcher_cc_impl.cc:68-106) + complex_to_real + multiply_const_ff(level): item k of the gated stream divided
+// by h = (max(emax max |x[k-2 .. k+2]|, 1) - 1) 2 + 1; whole chunks of 1024 only (an_decim_count with I = 0)
+__global__ __launch_bounds__(256) void k_an_stretch(const AnStretchParams P)
+{
+    const int b = blockIdx.y;
+    const AnState& st = P.st[b];
+    const uint64_t q0 = an_decim_count(st.g_prev, 0, 1), q1 = an_decim_count(st.g, 0, 1);
+    const uint64_t q = q0 + blockIdx.x * 256u + threadIdx.x;
+    if (q >= q1) return;
+    const float emax = (float)(1 / (sqrt(0.5) / 2));
+    float e = 0.0f;
+#pragma unroll
+    for (int j = -2; j <= 2; ++j) {
+        const float2 x = an_ringc_at(P.in, b, (int64_t)q + j);
+        const float m = sqrtf(x.x * x.x + x.y * x.y);
+        e = m > e ? m : e;
+    }
+    float h = e * emax;
+    h = h > 1.0f ? h : 1.0f;
+    h = h - 1.0f;
+    h = h * 2.0f;
+    h = h + 1.0f;
+    const float2 x = an_ringc_at(P.in, b, (int64_t)q);
+    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)q & P.out.mask)] = (x.x / h) * P.level;
+}
+void launch_an_stretch(const AnStretchParams& p, uint32_t max_out, int batch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_an_stretch, dim3((max_out + 255) / 256, batch), dim3(256), 0, s, p);
 }
 
 // NBFM: iir_filter_ffd(btaps, ataps, false) de-emphasis + multiply_const_ff(2.0) -> port 1

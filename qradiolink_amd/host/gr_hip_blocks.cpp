@@ -18,7 +18,7 @@ static void hchk(hipError_t e, const char* what)
 qrl_runtime::qrl_runtime(int device) { chk(qrl_init(device, &d_ctx), "qrl_init"); }
 qrl_runtime::~qrl_runtime() { qrl_shutdown(d_ctx); }
 
-enum { FAM_2FSK = 0, FAM_GMSK = 1, FAM_QPSK = 2, FAM_4FSK = 3, FAM_BPSK = 4, FAM_DMR = 5, FAM_M17 = 6, FAM_DSSS = 7, FAM_NBFM = 8, FAM_AM = 9, FAM_WBFM = 10 };
+enum { FAM_2FSK = 0, FAM_GMSK = 1, FAM_QPSK = 2, FAM_4FSK = 3, FAM_BPSK = 4, FAM_DMR = 5, FAM_M17 = 6, FAM_DSSS = 7, FAM_NBFM = 8, FAM_AM = 9, FAM_WBFM = 10, FAM_USB = 11, FAM_LSB = 12 };
 
 gr_demod_hip_sptr make_gr_demod_2fsk_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width, bool fm)
 { return gr_demod_hip_sptr(new gr_demod_hip(rt, FAM_2FSK, sps, samp_rate, carrier_freq, filter_width, fm)); }
@@ -46,11 +46,14 @@ gr_demod_hip_sptr make_gr_demod_am_hip(qrl_runtime& rt, int sps, int samp_rate, 
 gr_demod_hip_sptr make_gr_demod_wbfm_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
 { return gr_demod_hip_sptr(new gr_demod_hip(rt, FAM_WBFM, sps, samp_rate, carrier_freq, filter_width, false)); }
 
+gr_demod_hip_sptr make_gr_demod_ssb_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width, int sb)
+{ return gr_demod_hip_sptr(new gr_demod_hip(rt, sb ? FAM_LSB : FAM_USB, sps, samp_rate, carrier_freq, filter_width, false)); }
+
 gr_demod_hip::gr_demod_hip(qrl_runtime& rt, int fam, int sps, int samp_rate, int carrier_freq, int filter_width, bool fm)
     : gr::sync_block("gr_demod_hip", gr::io_signature::make(1, 1, sizeof(gr_complex)), gr::io_signature::make(0, 0, 0)), d_rt(rt)
 {
     // any member of the family selects the chain; the explicit factory arguments (not the mode table) configure it
-    static const int rep[] = {QRL_MODEM_2FSK1K, QRL_MODEM_GMSK10K, QRL_MODEM_QPSK250K, QRL_MODEM_4FSK2KFM, QRL_MODEM_BPSK1K, QRL_MODEM_DMR, QRL_MODEM_M17, QRL_MODEM_BPSK8, QRL_MODEM_NBFM5000, QRL_MODEM_AM5000, QRL_MODEM_WBFM};
+    static const int rep[] = {QRL_MODEM_2FSK1K, QRL_MODEM_GMSK10K, QRL_MODEM_QPSK250K, QRL_MODEM_4FSK2KFM, QRL_MODEM_BPSK1K, QRL_MODEM_DMR, QRL_MODEM_M17, QRL_MODEM_BPSK8, QRL_MODEM_NBFM5000, QRL_MODEM_AM5000, QRL_MODEM_WBFM, QRL_MODEM_USB2500, QRL_MODEM_LSB2500};
     d_cfg.modem_type = rep[fam];
     d_cfg.use_mode_defaults = 0;
     d_cfg.sps = sps; d_cfg.samp_rate = samp_rate; d_cfg.carrier_freq = carrier_freq; d_cfg.filter_width = filter_width; d_cfg.fm = fm;

@@ -51,6 +51,9 @@ gr_demod_hip_sptr make_gr_demod_nbfm_hip(qrl_runtime& rt, int sps = 125, int sam
 gr_demod_hip_sptr make_gr_demod_am_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 1000000, int carrier_freq = 1700, int filter_width = 5000);
 gr_demod_hip_sptr make_gr_demod_wbfm_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 1000000, int carrier_freq = 1700, int filter_width = 75000);
 
+// replaces make_gr_demod_ssb(signature, sps, samp_rate, carrier_freq, filter_width, sb)   src/gr/gr_demod_ssb.cpp:19-27 (sb 0 = USB, 1 = LSB)
+gr_demod_hip_sptr make_gr_demod_ssb_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 1000000, int carrier_freq = 1700, int filter_width = 2700, int sb = 0);
+
 class gr_demod_hip : public gr::sync_block {
 public:
     gr_demod_hip(qrl_runtime& rt, int modem_family, int sps, int samp_rate, int carrier_freq, int filter_width, bool fm);

@@ -2,7 +2,7 @@
 //   test_adaptor nodevice                      -> expects std::runtime_error from construction (exit 0 if thrown)
 //   test_adaptor rx <family>[+d<type>] <sps> <fw> <fm> <device_rate> <offset> <iq.bin> <bits_a.bin> <bits_b.bin>
 //                (family 2fsk | gmsk | qpsk | 4fsk | bpsk | dmr; "+d2" attaches gr_deframer_bb(2) to ports 2/3)
-//   test_adaptor rxa <nbfm | am | wbfm> <fw> <iq.bin> <audio.bin>      analogue receivers: port 1 = audio mailbox
+//   test_adaptor rxa <nbfm | am | wbfm | usb | lsb> <fw> <iq.bin> <audio.bin>      analogue receivers: port 1 = audio mailbox
 //   test_adaptor tx <bytes.bin> <iq.bin> [family sps fw fm]
 #include "gr_hip_blocks.h"
 #include <cstdio>
@@ -72,6 +72,8 @@ int main(int argc, char** argv)
             const int fw = atoi(argv[3]);
             gr_demod_hip_sptr d = fam == "nbfm" ? make_gr_demod_nbfm_hip(rt, 125, 1000000, 1700, fw)
                                 : fam == "am"   ? make_gr_demod_am_hip(rt, 125, 1000000, 1700, fw)
+                                : fam == "usb"  ? make_gr_demod_ssb_hip(rt, 125, 1000000, 1700, fw, 0)
+                                : fam == "lsb"  ? make_gr_demod_ssb_hip(rt, 125, 1000000, 1700, fw, 1)
                                                 : make_gr_demod_wbfm_hip(rt, 125, 1000000, 1700, fw);
             std::vector<char> raw = slurp(argv[4]);
             const gr_complex* x = reinterpret_cast<const gr_complex*>(raw.data());

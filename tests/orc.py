@@ -649,6 +649,26 @@ def demod_analog(x, kind, samp_rate=1000000, filter_width=5000):
     return dict(filtered=filt, audio=aud)
 
 
+def demod_ssb(x, sb=0, samp_rate=1000000, filter_width=2700):
+    x = np.ascontiguousarray(x, cf32)
+    f, a = C.c_void_p(), C.c_void_p()
+    nf, na = C.c_size_t(), C.c_size_t()
+    lib.orc_demod_ssb(_ptr(x), C.c_size_t(x.size), samp_rate, filter_width, sb, C.byref(f), C.byref(nf), C.byref(a), C.byref(na))
+    filt = np.ctypeslib.as_array(C.cast(f, C.POINTER(C.c_float)), (2 * nf.value,)).copy().view(cf32) if nf.value else np.zeros(0, cf32)
+    aud = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_float)), (na.value,)).copy() if na.value else np.zeros(0, np.float32)
+    lib.orc_free(f); lib.orc_free(a)
+    return dict(filtered=filt, audio=aud)
+
+
+def band_pass_2(gain, fs, lo, hi, tw, att, win=WIN_HAMMING):
+    lib.orc_band_pass_2.restype = C.c_int
+    args = (C.c_double(gain), C.c_double(fs), C.c_double(lo), C.c_double(hi), C.c_double(tw), C.c_double(att), win)
+    n = lib.orc_band_pass_2(*args, None)
+    t = np.zeros(n, np.float32)
+    lib.orc_band_pass_2(*args, _ptr(t))
+    return t
+
+
 def pwr_squelch_cc(x, db=-140.0, alpha=0.01, ramp=0, gate=True):
     x = np.ascontiguousarray(x, cf32)
     out = np.zeros(max(x.size, 1), cf32)

@@ -202,3 +202,15 @@ def make_analog(kind, n=400000, seed=1, amp=0.05, noise=0.0005, gap=None, fs=100
     if gap:
         y[gap[0]:gap[1]] = 0
     return y.astype(np.complex64), audio
+
+
+def make_ssb(n=400000, seed=1, amp=0.05, noise=0.0003, lsb=False, gap=None, fs=1000000.0):
+    """SSB test signal at 1 Msps: two audio tones as complex exponentials above (USB) or below (LSB) the suppressed carrier at 0 Hz"""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / fs
+    sgn = -1.0 if lsb else 1.0
+    x = 0.6 * np.exp(sgn * 2j * np.pi * (700.0 + 13 * seed) * t) + 0.3 * np.exp(sgn * 2j * np.pi * (1900.0 + 7 * seed) * t + 0.4j)
+    y = amp * x + noise * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    if gap:
+        y[gap[0]:gap[1]] = 0
+    return y.astype(np.complex64)

@@ -51,7 +51,7 @@ def test_oversize_call_is_refused_and_state_survives(qrl_ctx):
 
 def test_unsupported_configurations_are_refused(qrl_ctx):
     import qradiolink_amd as q
-    for modem in (11, 12, 13, 28):              # USB2500, LSB2500, CW600USB, FREEDV1600USB: not on this path
+    for modem in (13, 28, 29, 38):              # CW600USB, FREEDV1600USB, FREEDV700CUSB, MMDVM: not on this path
         with pytest.raises(q.QrlError):
             q.Demod(qrl_ctx, modem, batch=1, max_chunk=1024)
     with pytest.raises(q.QrlError):

@@ -347,6 +347,47 @@ def test_analog_squelch_threshold(qrl_ctx):
     assert out["audio"][0].size == orc.demod_analog(x, "nbfm", filter_width=5000)["audio"].size and 1590 <= out["audio"][0].size <= 1600
 
 
+@pytest.mark.parametrize("lsb,modem", [(False, 11), (True, 12)])
+@pytest.mark.parametrize("chunk", [1 << 20, 150000, 33334])
+def test_ssb_bit_exact(qrl_ctx, lsb, modem, chunk):
+    """gr_demod_ssb: 1:125, IF gain, complex band-pass, gating squelch, agc2_cc, cessb clipper + stretcher (whole chunks of 1024
+    gated items, two items of look-ahead), real part, audio band-pass"""
+    import torch
+    import qradiolink_amd as q
+    n = 1200000
+    xs = [sig.make_ssb(n=n, seed=1, lsb=lsb, gap=(300000, 900000)), sig.make_ssb(n=n, seed=2, lsb=lsb)]
+    iq = np.stack(xs)
+    dem = q.Demod(qrl_ctx, modem, batch=2, max_chunk=min(chunk, n))
+    out = q.collect(dem, torch.from_numpy(iq).cuda(), min(chunk, n))
+    dem.close()
+    for b in range(2):
+        ref = orc.demod_ssb(iq[b], sb=int(lsb))
+        assert ref["audio"].size >= 4096 and ref["audio"].size % 1024 == 0
+        got, want = out["filtered"][b].view(np.float32) + np.float32(0), ref["filtered"].view(np.float32) + np.float32(0)
+        assert got.size == want.size and np.array_equal(got.view(np.uint32), want.view(np.uint32)), "filtered"
+        got, want = out["audio"][b] + np.float32(0), ref["audio"] + np.float32(0)
+        assert got.size == want.size, (got.size, want.size)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "audio"
+    assert out["audio"][0].size < out["audio"][1].size
+
+
+def test_ssb_audio_is_the_modulating_tone_and_the_other_sideband_is_rejected(qrl_ctx):
+    import torch
+    import qradiolink_amd as q
+    x = sig.make_ssb(n=800000, seed=1, lsb=False)
+    rms = {}
+    for modem in (q.MODEM_USB2500, q.MODEM_LSB2500):
+        dem = q.Demod(qrl_ctx, modem, batch=1, max_chunk=x.size)
+        out = q.collect(dem, torch.from_numpy(x[None, :]).cuda(), x.size)
+        dem.close()
+        a = out["audio"][0][1024:5120].astype(np.float64)
+        rms[modem] = np.sqrt(np.mean(a ** 2))
+        if modem == q.MODEM_USB2500:
+            spec = np.abs(np.fft.rfft(a * np.hanning(a.size)))
+            assert abs(np.argmax(spec) * 8000.0 / a.size - 713.0) < 4.0
+    assert rms[q.MODEM_LSB2500] < 0.02 * rms[q.MODEM_USB2500]
+
+
 # ---- DSSS "BPSK 8" (gr_demod_dsss, SURVEY 8(f) rank 4): 1:50, 13:50 resampler, Costas, filter, AGC, Barker-13 matched-filter
 # decoder (325 evaluations of a 600-tap filter per symbol), M&M clock recovery, Costas, K=7 decoder on two branches
 @pytest.mark.parametrize("chunk", [1 << 22, 250000, 65538])

@@ -51,19 +51,22 @@ def test_rx_block_matches_golden(tmp_path, name, fam, sps, fw, fm):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,fw", [("nbfm", 5000), ("am", 5000), ("wbfm", 75000)])
+@pytest.mark.parametrize("kind,fw", [("nbfm", 5000), ("am", 5000), ("wbfm", 75000), ("lsb", 2700)])
 def test_analog_rx_block_audio_mailbox(tmp_path, kind, fw):
     """make_gr_demod_nbfm / _am / _wbfm shaped blocks: work() with ragged counts, audio out of the get_audio_data() mailbox
     (gr_audio_sink::get_data in the reference), bit-identical to the oracle chain"""
     import sig
-    x, _ = sig.make_analog(kind, n=300000, seed=5, gap=(60000, 220000))
+    if kind == "lsb":
+        x = sig.make_ssb(n=700000, seed=5, lsb=True)
+    else:
+        x, _ = sig.make_analog(kind, n=300000, seed=5, gap=(60000, 220000))
     x = x[: x.size & ~1]
     (tmp_path / "iq.bin").write_bytes(x.tobytes())
     r = subprocess.run([EXE, "rxa", kind, str(fw), str(tmp_path / "iq.bin"), str(tmp_path / "audio.bin")],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     got = np.fromfile(tmp_path / "audio.bin", np.float32) + np.float32(0)
-    want = orc.demod_analog(x, kind, filter_width=fw)["audio"] + np.float32(0)
+    want = (orc.demod_ssb(x, sb=1) if kind == "lsb" else orc.demod_analog(x, kind, filter_width=fw))["audio"] + np.float32(0)
     assert got.size == want.size and got.size > 500
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 

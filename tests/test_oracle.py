@@ -615,3 +615,51 @@ def test_analog_idle_channel_is_gated_away():
     x, _ = sig.make_analog("nbfm", n=400000, seed=1, gap=(100000, 300000))
     y, _ = sig.make_analog("nbfm", n=400000, seed=1)
     assert orc.demod_analog(x, "nbfm")["audio"].size < orc.demod_analog(y, "nbfm")["audio"].size
+
+
+# ---- SSB receiver: cessb clipper / stretcher definitions and the chain
+def test_cessb_clipper_limits_the_magnitude_and_keeps_the_phase():
+    lib = orc.lib
+    rng = np.random.default_rng(1)
+    x = ((rng.standard_normal(500) + 1j * rng.standard_normal(500)) * 0.8).astype(np.complex64)
+    y = np.zeros_like(x)
+    lib.orc_cessb_clipper(x.ctypes.data_as(orc.C.c_void_p), orc.C.c_size_t(x.size), orc.C.c_float(0.95), y.ctypes.data_as(orc.C.c_void_p))
+    assert np.all(np.abs(y) <= 0.95 * (1 + 1e-5))
+    small = np.abs(x) < 0.9
+    assert np.allclose(y[small], x[small], atol=2e-3)                       # (fast_atan2f is a 2e-3 rad LUT)
+    assert np.allclose(np.angle(y * np.conj(x)), 0.0, atol=2e-3)
+
+
+def test_cessb_stretcher_emits_whole_chunks_and_divides_by_the_five_point_envelope():
+    lib = orc.lib
+    lib.orc_cessb_stretcher.restype = orc.C.c_size_t
+    rng = np.random.default_rng(2)
+    x = ((rng.standard_normal(3000) + 1j * rng.standard_normal(3000)) * 0.3).astype(np.complex64)
+    y = np.zeros_like(x)
+    n = lib.orc_cessb_stretcher(x.ctypes.data_as(orc.C.c_void_p), orc.C.c_size_t(x.size), y.ctypes.data_as(orc.C.c_void_p))
+    assert n == 2048                                                        # 1024 floor((3000 - 2) / 1024)
+    assert lib.orc_cessb_stretcher(x.ctypes.data_as(orc.C.c_void_p), orc.C.c_size_t(1025), y.ctypes.data_as(orc.C.c_void_p)) == 0
+    mag = np.abs(np.concatenate([np.zeros(2, np.complex64), x]))
+    env = np.max(np.stack([mag[k:k + 2048] for k in range(5)]), axis=0)     # |x[k-2 .. k+2]|
+    h = (np.maximum(env * np.float32(1 / (np.sqrt(0.5) / 2)), 1.0) - 1.0) * 2.0 + 1.0
+    lib.orc_cessb_stretcher(x.ctypes.data_as(orc.C.c_void_p), orc.C.c_size_t(x.size), y.ctypes.data_as(orc.C.c_void_p))
+    assert np.allclose(y[:2048], x[:2048] / h, rtol=1e-5, atol=1e-7)
+
+
+def test_band_pass_2_has_unity_gain_at_the_band_centre():
+    t = orc.band_pass_2(1, 8000, 200, 2700, 200, 90, orc.WIN_BH)
+    H = np.abs(np.fft.rfft(t, 16384))
+    f = np.fft.rfftfreq(16384, 1 / 8000)
+    assert abs(H[np.argmin(abs(f - 1450))] - 1.0) < 1e-4 and H[np.argmin(abs(f - 3300))] < 1e-4 and H[0] < 2e-3
+
+
+@pytest.mark.parametrize("lsb", [False, True])
+def test_ssb_chain_recovers_the_tones_and_rejects_the_other_sideband(lsb):
+    x = sig.make_ssb(n=800000, seed=1, lsb=lsb)
+    a = orc.demod_ssb(x, sb=int(lsb))["audio"]
+    assert a.size == 6144
+    seg = a[1024:5120].astype(np.float64)
+    spec = np.abs(np.fft.rfft(seg * np.hanning(seg.size)))
+    assert abs(np.argmax(spec) * 8000.0 / seg.size - 713.0) < 4.0
+    other = orc.demod_ssb(x, sb=int(not lsb))["audio"][1024:5120]
+    assert np.sqrt(np.mean(other.astype(np.float64) ** 2)) < 0.02 * np.sqrt(np.mean(seg ** 2))
