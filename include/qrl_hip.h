@@ -362,6 +362,23 @@ int qrl_table_atan(float* t257);
 int qrl_table_tanh(float* t256);
 uint64_t qrl_phase_inc_to_turn(double radians_per_sample);
 
+/* ---- frame FEC of the DMR / M17 protocol stacks over batches of frames.  Stateless; device pointers;
+ * asynchronous on hip_stream (NULL = the default stream), the caller synchronises it.
+ * qrl_bptc19696_decode replaces CBPTC19696::decode (reference src/MMDVM/BPTC19696.cpp:47-64; users: CDMRFullLC, CDMRCSBK, CDMRDataHeader
+ * in src/MMDVM): the 196 code bits of each 33-byte DMR burst -> de-interleave -> up to 5 rounds of Hamming (13,9,3) column and
+ * (15,11,3) row correction -> the 96 payload bits as 12 bytes.  qrl_bptc19696_encode replaces CBPTC19696::encode (:67-87): payload
+ * -> row / column parities -> interleave -> written into the code-bit positions of the burst (its other bits are kept). */
+int qrl_bptc19696_decode(qrl_ctx* ctx, void* hip_stream, const uint8_t* bursts /* [n][33] */, size_t n, uint8_t* payloads /* [n][12] */);
+int qrl_bptc19696_encode(qrl_ctx* ctx, void* hip_stream, const uint8_t* payloads /* [n][12] */, size_t n, uint8_t* bursts /* [n][33] in/out */);
+/* qrl_m17_decode_frames replaces the per-frame work of M17FrameDecoder::decodeFrame (reference src/M17/M17/M17FrameDecoder.cpp:44-215:
+ * decorrelate, de-interleave, sync-word classification, punctured K = 5 Viterbi of the LSF / stream payload, Golay(24,12) of the LICH).
+ * frames: [n][48] (sync word + 46 bytes, as the frame synchroniser delivers them).  records: [n][QRL_M17_RECORD_BYTES] =
+ * {type (M17FrameType: 0 preamble, 1 link setup, 2 stream, 4 unknown), LICH ok, payload[30] (30 LSF bytes | 18 stream-frame bytes),
+ * LICH segment[6] (5 LSF bytes + segment number), 0, 0}.  The LSF reassembly from LICH segments (:130-147, per-stream state + CRC)
+ * is host work: host/m17_frame_decoder_hip. */
+#define QRL_M17_RECORD_BYTES 40
+int qrl_m17_decode_frames(qrl_ctx* ctx, void* hip_stream, const uint8_t* frames, size_t n, uint8_t* records);
+
 #ifdef __cplusplus
 }
 #endif

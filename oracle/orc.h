@@ -189,6 +189,14 @@ size_t orc_cessb_stretcher(const cf32* in, size_t n, cf32* out);
 void   orc_demod_ssb(const cf32* in, size_t n, int samp_rate, int filter_width, int sb /* 0 USB, 1 LSB */,
                      cf32** filtered, size_t* n_filtered, float** audio, size_t* n_audio);
 void   orc_free(void* p);
+/* frame FEC of the DMR / M17 stacks (orc_framefec.c; PINNED against the real reference sources through oracle/_ref) */
+void     orc_bptc19696_decode(const uint8_t* in33, uint8_t* out12);
+void     orc_bptc19696_encode(const uint8_t* in12, uint8_t* inout33);
+uint32_t orc_golay24_encode(uint16_t data);
+uint16_t orc_golay24_decode(uint32_t codeword);
+const uint8_t* orc_m17_sequence(void);   /* 46 bytes */
+void     orc_m17_decode_frame(const uint8_t frame[48], uint8_t rec[40]);
+uint16_t orc_m17_crc16(const uint8_t* p, size_t n);
 float orc_det_log2f(float x);
 void orc_rssi_block(const cf32* in, size_t n, float level, float* out);
 void orc_power_spectrum(const cf32* in, const float* window, size_t n, float* out);

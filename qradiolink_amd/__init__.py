@@ -95,6 +95,8 @@ def load_library():
     lib.qrl_demod_set_dmo_output.argtypes = [vp, vp, sz, vp]
     lib.qrl_demod_out_caps.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     lib.qrl_demod_audio_cap.argtypes = [vp, sz, C.POINTER(sz)]
+    for name in ("qrl_bptc19696_decode", "qrl_bptc19696_encode", "qrl_m17_decode_frames"):
+        getattr(lib, name).argtypes = [vp, vp, vp, sz, vp]
     lib.qrl_demod_set_squelch.argtypes = [vp, C.c_double]
     lib.qrl_demod_set_agc.argtypes = [vp, C.c_float, C.c_float]
     lib.qrl_demod_process.argtypes = [vp, vp, sz, sz, C.POINTER(_Out)]
@@ -179,6 +181,7 @@ EXPORTED_SYMBOLS = [
     "qrl_init", "qrl_shutdown", "qrl_strerror", "qrl_last_error", "qrl_version", "qrl_demod_create",
     "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_set_option", "qrl_demod_set_dmo_output", "qrl_demod_stream_wait", "qrl_demod_out_caps",
     "qrl_demod_audio_cap", "qrl_demod_set_squelch", "qrl_demod_set_agc",
+    "qrl_bptc19696_decode", "qrl_bptc19696_encode", "qrl_m17_decode_frames",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
     "qrl_mod_samples_per_byte", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_create",
@@ -702,6 +705,39 @@ class Mod:
         if self.h:
             self.lib.qrl_mod_destroy(self.h)
             self.h = C.c_void_p()
+
+
+def bptc19696_decode(ctx, bursts):
+    """[n, 33] uint8 cuda tensor of DMR bursts -> [n, 12] payloads (CBPTC19696::decode)"""
+    import torch
+    assert bursts.is_cuda and bursts.dtype == torch.uint8 and bursts.dim() == 2 and bursts.shape[1] == 33 and bursts.is_contiguous()
+    out = torch.zeros((bursts.shape[0], 12), dtype=torch.uint8, device=bursts.device)
+    torch.cuda.current_stream().synchronize()
+    _check(ctx.lib.qrl_bptc19696_decode(ctx.h, None, bursts.data_ptr(), bursts.shape[0], out.data_ptr()), "qrl_bptc19696_decode")
+    torch.cuda.synchronize()
+    return out
+
+
+def bptc19696_encode(ctx, payloads, bursts):
+    """[n, 12] payloads written into the code bits of [n, 33] bursts in place (CBPTC19696::encode); returns bursts"""
+    import torch
+    assert payloads.is_cuda and bursts.is_cuda and payloads.shape[1] == 12 and bursts.shape[1] == 33 and payloads.shape[0] == bursts.shape[0]
+    assert payloads.is_contiguous() and bursts.is_contiguous() and payloads.dtype == torch.uint8 and bursts.dtype == torch.uint8
+    torch.cuda.current_stream().synchronize()
+    _check(ctx.lib.qrl_bptc19696_encode(ctx.h, None, payloads.data_ptr(), payloads.shape[0], bursts.data_ptr()), "qrl_bptc19696_encode")
+    torch.cuda.synchronize()
+    return bursts
+
+
+def m17_decode_frames(ctx, frames):
+    """[n, 48] uint8 cuda tensor of M17 frames -> [n, 40] records (qrl_m17_decode_frames)"""
+    import torch
+    assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 2 and frames.shape[1] == 48 and frames.is_contiguous()
+    out = torch.zeros((frames.shape[0], 40), dtype=torch.uint8, device=frames.device)
+    torch.cuda.current_stream().synchronize()
+    _check(ctx.lib.qrl_m17_decode_frames(ctx.h, None, frames.data_ptr(), frames.shape[0], out.data_ptr()), "qrl_m17_decode_frames")
+    torch.cuda.synchronize()
+    return out
 
 
 def collect(dem, iq, chunk):

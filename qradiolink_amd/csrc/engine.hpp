@@ -278,6 +278,11 @@ void launch_an_deemph(const AnDeemphParams& p, int batch, hipStream_t s);
 struct AnStretchParams { RingC in; RingF out; const AnState* st; float level; };
 void launch_an_stretch(const AnStretchParams& p, uint32_t max_out, int batch, hipStream_t s);
 
+// ---- frame FEC (kernels_framefec.hip): bursts [n][33] <-> payloads [n][12]; M17 frames [n][48] -> records [n][40] ----
+void launch_bptc_decode(const uint8_t* bursts, size_t n, uint8_t* payloads, hipStream_t s);
+void launch_bptc_encode(const uint8_t* payloads, size_t n, uint8_t* bursts, hipStream_t s);
+void launch_m17_decode(const uint8_t* frames, size_t n, uint8_t* records, hipStream_t s);
+
 // ---- side outputs (kernels_side.hip): rssi_block on port 0, rx_fft_c on the device-rate IQ ----
 constexpr uint32_t RSSI_RING = 4096;   // |x|^2 look-back ring per stream (moving_average_ff(2000) reads 1999 items back)
 struct RssiState { double prev; uint64_t n; float sum, last; };

@@ -3,8 +3,11 @@
 //   test_adaptor rx <family>[+d<type>] <sps> <fw> <fm> <device_rate> <offset> <iq.bin> <bits_a.bin> <bits_b.bin>
 //                (family 2fsk | gmsk | qpsk | 4fsk | bpsk | dmr; "+d2" attaches gr_deframer_bb(2) to ports 2/3)
 //   test_adaptor rxa <nbfm | am | wbfm | usb | lsb> <fw> <iq.bin> <audio.bin>      analogue receivers: port 1 = audio mailbox
+//   test_adaptor m17seq <frames.bin: [n][48]> <out.bin>           M17FrameDecoder-shaped host class: n frames through ONE radio's
+//                decoder; out = n type bytes + the 30 LSF bytes + the 18 stream-frame bytes it holds afterwards
 //   test_adaptor tx <bytes.bin> <iq.bin> [family sps fw fm]
 #include "gr_hip_blocks.h"
+#include "m17_frame_decoder_hip.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -65,6 +68,21 @@ int main(int argc, char** argv)
             dump(argv[9], a.data(), a.size());
             dump(argv[10], b.data(), b.size());
             std::printf("rx ok: %zu samples -> %zu / %zu bits\n", n, a.size(), b.size());
+            return 0;
+        }
+        if (!strcmp(argv[1], "m17seq") && argc == 4) {
+            std::vector<char> raw = slurp(argv[2]);
+            const size_t n = raw.size() / 48;
+            qrl_host::m17_frame_decoder_hip dec(rt, 2, 4);     // (capacity 4: the batch is cut into several device calls)
+            std::vector<int> where(n, 1);
+            const auto types = dec.decodeFrames(reinterpret_cast<const uint8_t*>(raw.data()), where.data(), n);
+            std::vector<uint8_t> out;
+            for (auto t : types) out.push_back(static_cast<uint8_t>(t));
+            out.insert(out.end(), dec.getLsf(1).begin(), dec.getLsf(1).end());
+            out.insert(out.end(), dec.getStreamFrame(1).begin(), dec.getStreamFrame(1).end());
+            out.insert(out.end(), dec.getLsf(0).begin(), dec.getLsf(0).end());       // the other radio's state stays clear
+            dump(argv[3], out.data(), out.size());
+            std::printf("m17seq ok: %zu frames\n", n);
             return 0;
         }
         if (!strcmp(argv[1], "rxa") && argc == 6) {
