@@ -4,7 +4,7 @@
 //   CBPTC19696::decode / encode           /root/reference/src/MMDVM/BPTC19696.cpp (+ Hamming.cpp, Utils.cpp, Log.cpp)
 //   M17FrameDecoder::decodeFrame          /root/reference/src/M17/M17/M17FrameDecoder.cpp (+ M17Viterbi.hpp, M17Golay.cpp, ...)
 //   M17FrameEncoder::encodeLsf / encodeStreamFrame   .../M17FrameEncoder.cpp (generates the test frames)
-// Used by the tests to PIN the oracle's restatement (oracle/orc_framefec.c) and to regenerate tests/golden/framefec.npz.
+// Used by the tests to PIN the oracle's restatement (oracle/orc_framefec.c) and to regenerate tests/golden/ref/framefec.npz.
 #include <cstdint>
 #include <cstring>
 

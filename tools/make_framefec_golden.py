@@ -1,4 +1,4 @@
-"""Regenerates tests/golden/framefec.npz from the REAL reference (oracle/_ref/libqrl_ref.so = /root/reference's BPTC19696.cpp,
+"""Regenerates tests/golden/ref/framefec.npz from the REAL reference (oracle/_ref/libqrl_ref.so = /root/reference's BPTC19696.cpp,
 Hamming.cpp, M17FrameDecoder.cpp, M17FrameEncoder.cpp, M17Viterbi.hpp, M17Golay.cpp compiled where they lie: make -C oracle ref).
 Runs only in the build container (needs /root/reference); the vectors it writes travel with the repository."""
 import ctypes as C
@@ -58,7 +58,7 @@ for t in range(120):
         ty = ref.ref_m17_decode_frame(P(np.ascontiguousarray(f)), P(a), P(b))
         frames.append(f.copy()); types.append(ty); lsfs.append(a); streams.append(b)
 
-np.savez_compressed(os.path.join(ROOT, "tests", "golden", "framefec.npz"),
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref", "framefec.npz"),
                     bptc_payload=pay, bptc_base=base, bptc_encoded=enc, bptc_rx=rx, bptc_decoded=dec,
                     m17_frames=np.stack(frames), m17_type=np.array(types, np.uint8), m17_lsf=np.stack(lsfs), m17_stream=np.stack(streams),
                     m17_seq_frames=np.stack(seq_frames), m17_seq_lsf=np.stack(seq_lsf))
