@@ -1,0 +1,3 @@
+// gr_stub: see block.h
+#pragma once
+#include <gnuradio/block.h>

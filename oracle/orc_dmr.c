@@ -4,6 +4,7 @@
  * src/MMDVM/DMRDefines.h:25-28,82-93) and the slot-type decode it calls (src/MMDVM/DMRSlotType2.cpp:215-264: Golay (20,8)
  * through the (19,8) syndrome table).  The block is fed from port 3 of gr_demod_dmr (RRC-filtered discriminator output, 5
  * samples per symbol at 24 ksps, gr_demod_dmr.cpp:94).
+ * PINNED: tests/test_ref_blocks.py runs the reference's gr_dmr_dmo_sink.cpp itself (oracle/_ref) and requires identical records.
  * Differences from the reference that are NOT behaviour: the members the reference constructor leaves uninitialised (m_buffer,
  * m_bitBuffer, m_control, m_centre, m_threshold) start at zero here; frames leave as 40-byte records
  * {frame type, FN, colour code, 0, 33 frame bytes, 3 pad bytes} instead of DMRFrame objects (slot number 2, downlink false are constants). */

@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "BPTC19696.h"
+#include "src/gr/emphasis.h"
 #include <M17/M17FrameDecoder.hpp>
 #include <M17/M17FrameEncoder.hpp>
 #include <M17/M17Golay.hpp>
@@ -75,6 +76,13 @@ void ref_m17_encode(const uint8_t lsf28[28], const uint8_t* payloads /* [nstream
         e.encodeStreamFrame(p, f, i == nstream - 1);
         std::memcpy(frames + 48 * (i + 1), f.data(), 48);
     }
+}
+// gr::calculate_deemph_taps (reference src/gr/emphasis.cpp:16-43): a = {1, -p1}, b = {b0, b0}
+void ref_deemph_taps(int sample_rate, double tau, double a[2], double b[2])
+{
+    std::vector<double> at, bt;
+    gr::calculate_deemph_taps(sample_rate, tau, at, bt);
+    a[0] = at[0]; a[1] = at[1]; b[0] = bt[0]; b[1] = bt[1];
 }
 uint32_t ref_golay24_encode(uint16_t data) { return M17::golay24_encode(data); }
 uint16_t ref_golay24_decode(uint32_t cw) { return M17::golay24_decode(cw); }

@@ -1,0 +1,83 @@
+// ref_shim_gr.cpp -- TEST INFRASTRUCTURE.  extern "C" entry points into the reference's OWN GNU Radio custom blocks, compiled
+// unmodified from where they lie (make -C oracle ref) against oracle/gr_stub (a stand-in for the few GNU Radio runtime classes they
+// derive from).  Their work() functions hold the algorithms the oracle restates:
+//   gr_dmr_dmo_sink::general_work   /root/reference/src/gr/gr_dmr_dmo_sink.cpp   (DMO correlator slicer)  -> orc_dmr.c
+//   gr_deframer_bb::work            /root/reference/src/gr/gr_deframer_bb.cpp    (8(f) rank 1)                          -> orc_deframer
+//   gr_4fsk_discriminator::work     /root/reference/src/gr/gr_4fsk_discriminator.cpp                                    -> orc_demod_4fsk
+//   rssi_tag_block::work            /root/reference/src/gr/rssi_tag_block.cpp                                           -> orc_rssi_tag
+#include <cstdint>
+#include <cstring>
+
+#include "src/gr/gr_dmr_dmo_sink.h"
+#include "src/gr/gr_deframer_bb.h"
+#include "src/gr/gr_4fsk_discriminator.h"
+#include "src/gr/rssi_tag_block.h"
+
+extern "C" {
+
+// the whole float stream through one sink in calls of `chunk` items; records of 40 bytes {frame type, FN, colour code, 0, 33 frame bytes, 0 0 0}
+size_t ref_dmo_sink(const float* in, size_t n, size_t chunk, uint8_t* records, size_t cap)
+{
+    gr_dmr_dmo_sink_sptr s = make_gr_dmr_dmo_sink();
+    size_t nrec = 0;
+    for (size_t pos = 0; pos < n; pos += chunk) {
+        const size_t m = n - pos < chunk ? n - pos : chunk;
+        gr_vector_int ninput(1, (int)m);
+        gr_vector_const_void_star ins(1, in + pos);
+        gr_vector_void_star outs;
+        s->general_work((int)m, ninput, ins, outs);
+        for (DMRFrame& f : s->get_data()) {
+            if (nrec >= cap) return nrec;
+            uint8_t* r = records + 40 * nrec++;
+            std::memset(r, 0, 40);
+            r[0] = f.getFrameType(); r[1] = f.getFN(); r[2] = f.getColorCode();
+            f.getData(r + 4);
+        }
+    }
+    return nrec;
+}
+
+size_t ref_deframer(int type, const uint8_t* bits, size_t n, size_t chunk, uint8_t* out, size_t cap)
+{
+    gr_deframer_bb_sptr d = make_gr_deframer_bb(type);
+    size_t no = 0;
+    for (size_t pos = 0; pos < n; pos += chunk) {
+        const size_t m = n - pos < chunk ? n - pos : chunk;
+        gr_vector_const_void_star ins(1, bits + pos);
+        gr_vector_void_star outs;
+        d->work((int)m, ins, outs);
+        std::vector<unsigned char>* v = d->get_data();
+        if (v) {
+            for (unsigned char c : *v) if (no < cap) out[no++] = c;
+            delete v;
+        }
+    }
+    return no;
+}
+
+void ref_4fsk_discriminator(const float* a, const float* b, const float* c, const float* d, size_t n, float* out /* 2 n */)
+{
+    gr_4fsk_discriminator_sptr k = make_gr_4fsk_discriminator();
+    gr_vector_const_void_star ins{a, b, c, d};
+    gr_vector_void_star outs{out};
+    k->work((int)n, ins, outs);
+}
+
+// rssi_tag_block: returns the tags as (offset, dB) pairs; out = the pass-through copy
+size_t ref_rssi_tag(const float* in /* 2 n */, size_t n, size_t chunk, float* out, uint64_t* offsets, float* db, size_t cap)
+{
+    rssi_tag_block_sptr t = make_rssi_tag_block();
+    size_t nt = 0;
+    for (size_t pos = 0; pos < n; pos += chunk) {
+        const size_t m = n - pos < chunk ? n - pos : chunk;
+        gr_vector_const_void_star ins(1, in + 2 * pos);
+        gr_vector_void_star outs(1, out + 2 * pos);
+        t->stub_written = pos;
+        t->work((int)m, ins, outs);
+        for (const gr::tag_t& g : t->stub_tags) if (nt < cap) { offsets[nt] = g.offset; db[nt] = pmt::to_float(g.value); ++nt; }
+        t->stub_tags.clear();
+    }
+    return nt;
+}
+
+}
