@@ -3,6 +3,7 @@
 // into oracle/_ref/libqrl_ref.so: base classes that record what a block consumes / tags, nothing of GNU Radio's scheduler or DSP.
 // Written for this repository; it contains no GNU Radio or reference code.
 #pragma once
+#include <algorithm>
 #include <complex>
 #include <condition_variable>
 #include <cstdint>
@@ -33,7 +34,10 @@ public:
     static sptr makev(int, int, const std::vector<int>&) { return sptr(new io_signature); }
 };
 
-struct tag_t { uint64_t offset; pmt::pmt_t key, value; };
+struct tag_t {
+    uint64_t offset; pmt::pmt_t key, value;
+    static bool offset_compare(const tag_t& a, const tag_t& b) { return a.offset < b.offset; }
+};
 
 class block {
 public:
@@ -45,6 +49,14 @@ public:
     uint64_t nitems_written(unsigned) const { return stub_written; }
     uint64_t nitems_read(unsigned) const { return stub_read; }
     void add_item_tag(unsigned, uint64_t offset, const pmt::pmt_t& key, const pmt::pmt_t& value) { stub_tags.push_back(tag_t{offset, key, value}); }
+    // tags of the input whose offset lies in [nitems_read + start, nitems_read + end) and whose key is `key`
+    void get_tags_in_window(std::vector<tag_t>& v, unsigned, uint64_t start, uint64_t end, const pmt::pmt_t& key)
+    {
+        v.clear();
+        for (const tag_t& t : stub_in_tags)
+            if (t.offset >= stub_read + start && t.offset < stub_read + end && t.key->sym == key->sym) v.push_back(t);
+    }
+    std::vector<tag_t> stub_in_tags;
     void set_history(unsigned) {}
     void set_output_multiple(int) {}
     void set_thread_priority(int) {}

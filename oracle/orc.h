@@ -139,6 +139,7 @@ size_t orc_demod_mmdvm(const cf32* in, size_t n, int samp_rate, int filter_width
                        size_t* n_rssi);
 size_t orc_mod_mmdvm(const int16_t* in, size_t n, int filter_width, float bb_gain, cf32* out);
 size_t orc_mod_mmdvm_multi(const int16_t* in, size_t n, int N, int filter_width, cf32* out);
+void   orc_zero_idle_bursts(const cf32* in, size_t n, const uint64_t* runs, size_t nruns, cf32* out);   /* gr_zero_idle_bursts alone */
 void   orc_set_zero_runs(const uint64_t* runs /* {channel, start, count} triples */, size_t nruns);   /* gr_zero_idle_bursts for the next orc_mod_mmdvm* call */
 size_t orc_demod_mmdvm_xlating(const cf32* in, size_t n, int N, int separation, int D, int fw, int16_t* out, size_t cap,
                                float* rssi, size_t rcap, float cal);

@@ -959,10 +959,22 @@ size_t orc_demod_mmdvm_xlating(const cf32* in, size_t n, int N, int separation, 
  * modulator in gr_mod_mmdvm.cpp:57-58): items start .. start + count - 1 of that channel are replaced by 0 + 0j. */
 static void apply_zero_runs(cf32* x, size_t n, int chan, const uint64_t* runs, size_t nruns)
 {
-    for (size_t r = 0; r < nruns; r++) {
-        if ((int)runs[3 * r] != chan) continue;
-        for (uint64_t i = runs[3 * r + 1]; i < runs[3 * r + 1] + runs[3 * r + 2] && i < n; i++) { x[i].re = 0.0f; x[i].im = 0.0f; }
+    /* gr_zero_idle_bursts.cpp:53-80: one down-counter; the tag at an item's offset (re)loads it before the item is judged */
+    uint64_t counter = 0;
+    for (size_t i = 0; i < n; i++) {
+        for (size_t r = 0; r < nruns; r++)
+            if ((int)runs[3 * r] == chan && runs[3 * r + 1] == (uint64_t)i) { counter = runs[3 * r + 2]; break; }
+        if (counter > 0) { x[i].re = 0.0f; x[i].im = 0.0f; counter--; }
     }
+}
+/* the block alone (delay 0): in -> out with the tagged runs {channel (ignored), offset, count} zeroed */
+void orc_zero_idle_bursts(const cf32* in, size_t n, const uint64_t* runs, size_t nruns, cf32* out)
+{
+    memcpy(out, in, n * sizeof(cf32));
+    uint64_t* r0 = (uint64_t*)malloc(sizeof(uint64_t) * 3 * (nruns + 1));
+    for (size_t r = 0; r < nruns; r++) { r0[3 * r] = 0; r0[3 * r + 1] = runs[3 * r + 1]; r0[3 * r + 2] = runs[3 * r + 2]; }
+    apply_zero_runs(out, n, 0, r0, nruns);
+    free(r0);
 }
 static const uint64_t* g_zero_runs = NULL; static size_t g_zero_nruns = 0;
 void orc_set_zero_runs(const uint64_t* runs, size_t nruns) { g_zero_runs = runs; g_zero_nruns = nruns; }   /* for the next orc_mod_mmdvm* call */

@@ -5,6 +5,7 @@
 //   gr_deframer_bb::work            /root/reference/src/gr/gr_deframer_bb.cpp    (8(f) rank 1)                          -> orc_deframer
 //   gr_4fsk_discriminator::work     /root/reference/src/gr/gr_4fsk_discriminator.cpp                                    -> orc_demod_4fsk
 //   rssi_tag_block::work            /root/reference/src/gr/rssi_tag_block.cpp                                           -> orc_rssi_tag
+//   gr_zero_idle_bursts::work       /root/reference/src/gr/gr_zero_idle_bursts.cpp (MMDVM TX)                           -> orc_zero_idle_bursts
 #include <cstdint>
 #include <cstring>
 
@@ -12,6 +13,7 @@
 #include "src/gr/gr_deframer_bb.h"
 #include "src/gr/gr_4fsk_discriminator.h"
 #include "src/gr/rssi_tag_block.h"
+#include "src/gr/gr_zero_idle_bursts.h"
 
 extern "C" {
 
@@ -78,6 +80,20 @@ size_t ref_rssi_tag(const float* in /* 2 n */, size_t n, size_t chunk, float* ou
         t->stub_tags.clear();
     }
     return nt;
+}
+
+// gr_zero_idle_bursts (delay 0): "zero_samples" tags (offset, count) on the input stream
+void ref_zero_idle_bursts(const float* in /* 2 n */, size_t n, size_t chunk, const uint64_t* offsets, const uint64_t* counts, size_t ntags, float* out)
+{
+    gr_zero_idle_bursts_sptr z = make_gr_zero_idle_bursts(0);
+    for (size_t i = 0; i < ntags; ++i) z->stub_in_tags.push_back(gr::tag_t{offsets[i], pmt::string_to_symbol("zero_samples"), pmt::from_uint64(counts[i])});
+    for (size_t pos = 0; pos < n; pos += chunk) {
+        const size_t m = n - pos < chunk ? n - pos : chunk;
+        gr_vector_const_void_star ins(1, in + 2 * pos);
+        gr_vector_void_star outs(1, out + 2 * pos);
+        z->stub_written = pos; z->stub_read = pos;
+        z->work((int)m, ins, outs);
+    }
 }
 
 }

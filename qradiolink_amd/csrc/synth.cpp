@@ -139,7 +139,15 @@ int qrl_synth_add_zero_runs(qrl_synth* h, const qrl_zero_run* runs, size_t n)
     for (size_t i = 0; i < n; ++i) {
         if (runs[i].stream < 0 || runs[i].stream >= h->cfg.batch || runs[i].channel < 0 || runs[i].channel >= h->N)
             return qrl_set_error(QRL_ERR_ARG, "zero run: stream / channel out of range");
-        h->zero_runs.push_back(ZeroRun{(uint32_t)(runs[i].stream * h->N + runs[i].channel), 0u, runs[i].start, runs[i].count});
+        // gr_zero_idle_bursts keeps ONE counter per stream and a tag overwrites it (gr_zero_idle_bursts.cpp:62-69): a run that starts
+        // inside another one ends it there -- the zeroed set is [s_i, min(s_i + c_i, s_next)) over the tags in offset order
+        ZeroRun z{(uint32_t)(runs[i].stream * h->N + runs[i].channel), 0u, runs[i].start, runs[i].count};
+        for (ZeroRun& o : h->zero_runs) {
+            if (o.row != z.row) continue;
+            if (o.start < z.start && o.start + o.count > z.start) o.count = z.start - o.start;
+            else if (z.start < o.start && z.start + z.count > o.start) z.count = o.start - z.start;
+        }
+        h->zero_runs.push_back(z);
     }
     return QRL_OK;
 }

@@ -321,7 +321,9 @@ def test_mmdvm_tx_zero_idle_bursts_bit_exact(qrl_ctx, single):
     cuts = [720, 1000, 7, 5000, 4273]
     n = sum(cuts)
     x = np.stack([_audio(N, n, seed=70 + b) for b in range(2)])
-    runs = [(0, 0, 750, 750), (0, N - 1, 2990, 750), (1, 0, 0, 750), (1, 0, 700, 750), (0, 0, 6000, 100)]   # (stream, channel, start, count)
+    runs = [(0, 0, 750, 750), (0, N - 1, 2990, 750), (1, 0, 0, 750), (1, 0, 700, 750), (0, 0, 6000, 100), (0, 0, 6020, 10)]   # (stream, channel, start, count)
+    # (the last one starts inside its predecessor and ENDS it at 6030: one down-counter that a tag reloads, gr_zero_idle_bursts.cpp:62-69;
+    #  pinned against the reference block in test_ref_blocks.py)
     syn = q.Synth(qrl_ctx, N, batch=2, max_samples=max(cuts), bb_gain=1.0, single_carrier=single)
     syn.add_zero_runs(runs[:3])
     d = torch.from_numpy(x).cuda()

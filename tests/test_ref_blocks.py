@@ -114,3 +114,20 @@ def test_deemphasis_taps_equal_the_reference_function(ref):
         ref.ref_deemph_taps(fs, C.c_double(50e-6), a, b)
         oa, ob = orc.deemph_taps(fs, 50e-6)
         assert list(a) == oa and list(b) == ob          # bit-identical doubles
+
+
+def test_zero_idle_bursts_oracle_equals_the_reference_block(ref):
+    """one down-counter per stream, (re)loaded by the tag at an item's offset: a run that starts inside another ends it there"""
+    rng = np.random.default_rng(6)
+    n = 20000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    offs = np.array([100, 900, 1000, 5000, 5010, 7200, 7920, 15000, 19990], np.uint64)
+    cnts = np.array([720, 720, 50, 720, 0, 720, 720, 1, 100], np.uint64)         # overlapping, zero-length and clipped runs
+    runs = np.stack([np.zeros_like(offs), offs, cnts], axis=1).astype(np.uint64)
+    want = np.zeros_like(x)
+    orc.lib.orc_zero_idle_bursts(P(x), C.c_size_t(n), P(np.ascontiguousarray(runs)), C.c_size_t(offs.size), P(want))
+    for chunk in (1 << 20, 720, 333):
+        got = np.zeros_like(x)
+        ref.ref_zero_idle_bursts(P(x), C.c_size_t(n), C.c_size_t(chunk), P(offs), P(cnts), C.c_size_t(offs.size), P(got))
+        assert np.array_equal(got, want)
+    assert np.count_nonzero(want == 0) == 720 + (100 + 50) + 10 + (720 + 720) + 1 + 10   # [100,820) [900,1000)->[1000,1050) [5000,5010) ... [19990,20000)
