@@ -7,6 +7,7 @@
 #include <complex>
 #include <condition_variable>
 #include <cstdint>
+#include <iostream>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -35,7 +36,7 @@ public:
 };
 
 struct tag_t {
-    uint64_t offset; pmt::pmt_t key, value;
+    uint64_t offset; pmt::pmt_t key, value; unsigned port = 0;
     static bool offset_compare(const tag_t& a, const tag_t& b) { return a.offset < b.offset; }
 };
 
@@ -48,7 +49,7 @@ public:
     void consume(int, int n) { stub_consumed += n; }
     uint64_t nitems_written(unsigned) const { return stub_written; }
     uint64_t nitems_read(unsigned) const { return stub_read; }
-    void add_item_tag(unsigned, uint64_t offset, const pmt::pmt_t& key, const pmt::pmt_t& value) { stub_tags.push_back(tag_t{offset, key, value}); }
+    void add_item_tag(unsigned port, uint64_t offset, const pmt::pmt_t& key, const pmt::pmt_t& value) { stub_tags.push_back(tag_t{offset, key, value, port}); }
     // tags of the input whose offset lies in [nitems_read + start, nitems_read + end) and whose key is `key`
     void get_tags_in_window(std::vector<tag_t>& v, unsigned, uint64_t start, uint64_t end, const pmt::pmt_t& key)
     {
@@ -56,6 +57,15 @@ public:
         for (const tag_t& t : stub_in_tags)
             if (t.offset >= stub_read + start && t.offset < stub_read + end && t.key->sym == key->sym) v.push_back(t);
     }
+    // per-port form used by gr_mmdvm_sink: absolute range [lo, hi) on input `port`
+    void get_tags_in_range(std::vector<tag_t>& v, unsigned port, uint64_t lo, uint64_t hi, const pmt::pmt_t& key)
+    {
+        v.clear();
+        for (const tag_t& t : stub_in_tags)
+            if (t.port == port && t.offset >= lo && t.offset < hi && t.key->sym == key->sym) v.push_back(t);
+    }
+    void set_min_noutput_items(int) {}
+    void set_max_noutput_items(int) {}
     std::vector<tag_t> stub_in_tags;
     void set_history(unsigned) {}
     void set_output_multiple(int) {}
