@@ -43,8 +43,12 @@ struct tag_t {
 class block {
 public:
     enum { WORK_CALLED_PRODUCE = -2, WORK_DONE = -1 };
+    block() {}                                   // pure interface sub-classes (virtual inheritance), as in GNU Radio
     block(const std::string& name, io_signature::sptr, io_signature::sptr) : d_name(name) {}
     virtual ~block() {}
+    virtual void forecast(int, gr_vector_int&) {}
+    virtual int general_work(int, gr_vector_int&, gr_vector_const_void_star&, gr_vector_void_star&) { return 0; }
+    void set_relative_rate(double) {}
     void consume_each(int n) { stub_consumed += n; }
     void consume(int, int n) { stub_consumed += n; }
     uint64_t nitems_written(unsigned) const { return stub_written; }

@@ -621,9 +621,9 @@ int orc_dsss_taps(int sps, float* taps)
     static const int barker_13[13] = {1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 1, 0, 1};
     const int rrc_ntaps = sps * 11, csz = 13 * sps, extra = rrc_ntaps, nt = csz + extra;
     if (!taps) return nt;
-    int nr = orc_root_raised_cosine(1, sps, 1.0, 0.35, rrc_ntaps, NULL);
+    int nr = orc_root_raised_cosine(1, sps, 1.0, (double)0.350f, rrc_ntaps, NULL);
     float* rrc = NEW(float, nr);
-    orc_root_raised_cosine(1, sps, 1.0, 0.35, rrc_ntaps, rrc);
+    orc_root_raised_cosine(1, sps, 1.0, (double)0.350f, rrc_ntaps, rrc);
     float* cs = NEW(float, csz + 2 * extra + nr);
     memset(cs, 0, sizeof(float) * (size_t)(csz + 2 * extra + nr));
     for (int i = 0; i < 13; i++)
@@ -637,23 +637,23 @@ int orc_dsss_taps(int sps, float* taps)
     return nt;
 }
 /* dsss_decoder_cc::general_work: output I = the matched-filter value of largest magnitude among the 13 sps evaluations
- * j = 0 .. 13 sps - 1 over the windows x[13 sps (I - 2) + j .. + nt) (history = 13 sps items: the block looks one code period
+ * j = 0 .. 13 sps - 1 over the windows x[13 sps (I - 2) + 1 + j .. + nt) (set_history(13 sps): in[0] of a work call is the item 13 sps - 1 before the first new one, and the block reads from in + (i - 1) 13 sps + j -- pinned against the reference block itself, tests/test_ref_blocks.py; the block looks one code period
  * back), first maximum wins, scaled by 2 / (13 sps).  Filter value = sum_k taps[k] x[P + nt - 1 - k], one fmaf chain per
- * component, k ascending; |v| = sqrtf(re^2 + im^2).  Output I exists once all of its windows do: n >= 13 sps (I - 1) + nt - 1.
+ * component, k ascending; |v| = sqrtf(re^2 + im^2).  Output I exists once all of its windows do: n >= 13 sps (I - 1) + nt.
  * Returns the number of outputs. */
 size_t orc_dsss_decoder(const cf32* in, size_t n, int sps, cf32* out)
 {
     const int L = 13 * sps, nt = orc_dsss_taps(sps, NULL);
     float* taps = NEW(float, nt);
     orc_dsss_taps(sps, taps);
-    /* last index of window j = L - 1 of output I: L (I - 2) + L - 1 + nt - 1 = L (I - 1) + nt - 2  =>  n >= L (I - 1) + nt - 1 */
-    const long long need0 = (long long)nt - 1 - L;
+    /* last index of window j = L - 1 of output I: L (I - 2) + 1 + L - 1 + nt - 1 = L (I - 1) + nt - 1  =>  n >= L (I - 1) + nt */
+    const long long need0 = (long long)nt - L;
     size_t nout = 0;
     if ((long long)n >= need0) nout = (size_t)(((long long)n - need0) / L) + 1;
     for (size_t I = 0; I < nout; I++) {
         float max_abs = 0.0f; cf32 max_val = {0.0f, 0.0f};
         for (int j = 0; j < L; j++) {
-            const long long P = (long long)L * ((long long)I - 2) + j;
+            const long long P = (long long)L * ((long long)I - 2) + 1 + j;
             float ar = 0.0f, ai = 0.0f;
             for (int k = 0; k < nt; k++) {
                 const long long idx = P + nt - 1 - k;

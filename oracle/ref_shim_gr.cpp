@@ -5,6 +5,7 @@
 //   gr_deframer_bb::work            /root/reference/src/gr/gr_deframer_bb.cpp    (8(f) rank 1)                          -> orc_deframer
 //   gr_4fsk_discriminator::work     /root/reference/src/gr/gr_4fsk_discriminator.cpp                                    -> orc_demod_4fsk
 //   rssi_tag_block::work            /root/reference/src/gr/rssi_tag_block.cpp                                           -> orc_rssi_tag
+//   dsss_decoder_cc_impl::general_work  /root/reference/src/gr/dsss_decoder_cc_impl.cc (its FIR kernel / RRC design come from gr_stub)  -> orc_dsss_decoder
 //   gr_zero_idle_bursts::work       /root/reference/src/gr/gr_zero_idle_bursts.cpp (MMDVM TX)                           -> orc_zero_idle_bursts
 #include <cstdint>
 #include <cstring>
@@ -14,6 +15,7 @@
 #include "src/gr/gr_4fsk_discriminator.h"
 #include "src/gr/rssi_tag_block.h"
 #include "src/gr/gr_zero_idle_bursts.h"
+#include "src/gr/dsss_decoder_cc_impl.h"
 
 extern "C" {
 
@@ -94,6 +96,36 @@ void ref_zero_idle_bursts(const float* in /* 2 n */, size_t n, size_t chunk, con
         z->stub_written = pos; z->stub_read = pos;
         z->work((int)m, ins, outs);
     }
+}
+
+// gr::dsss::dsss_decoder_cc(Barker 13, sps): in = the whole stream; the block sees it with its history (set_history(13 sps): 13 sps - 1
+// zeros in front of the first item) and is asked for every output whose input exists.  Returns the outputs; taps optional.
+size_t ref_dsss_decoder(const float* in /* 2 n */, size_t n, int sps, size_t per_call, float* out /* 2 per output */, float* taps_out /* nt or NULL */)
+{
+    static const int barker_13[] = {1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 1, 0, 1};
+    std::vector<int> code(barker_13, barker_13 + 13);
+    gr::dsss::dsss_decoder_cc::sptr d = gr::dsss::dsss_decoder_cc::make(code, (float)sps);
+    const std::vector<gr_complex> taps = d->taps();
+    if (taps_out) for (size_t i = 0; i < taps.size(); ++i) taps_out[i] = taps[i].real();
+    const size_t L = 13 * (size_t)sps, nt = taps.size();
+    // one more code period of zeros in front: output 0 reads in - L + j, i.e. BEFORE its history (GNU Radio's zero-filled circular
+    // buffer hands out zeros there at the start of a stream)
+    std::vector<gr_complex> buf(L + L - 1 + n + nt + L, gr_complex(0, 0));
+    std::memcpy(buf.data() + L + (L - 1), in, n * sizeof(gr_complex));
+    // output I reads in + (i - 1) L + j + [0, nt) with in = item (consumed - (L - 1)): it exists once item (I - 1) L + nt - 1 does
+    const size_t total = n >= nt - L + L * 0 && n + L >= nt ? (n - (nt - L)) / L + 1 : 0;
+    size_t done = 0, consumed = 0;
+    while (done < total) {
+        const size_t m = total - done < per_call ? total - done : per_call;
+        gr_vector_int ninput(1, (int)(m * L));
+        gr_vector_const_void_star ins(1, buf.data() + L + consumed);         // = item consumed - (L - 1)
+        gr_vector_void_star outs(1, out + 2 * done);
+        d->stub_consumed = 0;
+        if (d->general_work((int)m, ninput, ins, outs) != (int)m) return 0;
+        consumed += (size_t)d->stub_consumed;
+        done += m;
+    }
+    return total;
 }
 
 }

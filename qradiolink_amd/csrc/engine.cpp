@@ -864,8 +864,8 @@ int qrl_demod::dsss_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* ou
         DsssLoopParams p{}; p.in = rc; p.out = rd; p.q0 = n5_0; p.count = c5; p.st = ds_st.p; p.tanh_tab = tanh_tab.p;
         launch_dsss_loop(p, 1, B, stream);
     }
-    // _dsss_decoder: output I needs x[325 (I - 1) + 598]
-    const uint64_t nsy_1 = n5_1 >= 274 ? (n5_1 - 274) / 325 + 1 : 0;
+    // _dsss_decoder: output I needs x[325 (I - 1) + 599]
+    const uint64_t nsy_1 = n5_1 >= 275 ? (n5_1 - 275) / 325 + 1 : 0;
     {
         DsssMfParams p{}; p.in = rd; p.out = rs; p.i0 = nsy; p.count = (uint32_t)(nsy_1 - nsy); p.taps = ds_mf.p;
         launch_dsss_mf(p, B, stream);

@@ -324,7 +324,7 @@ std::vector<float> dsss_matched_filter(int sps)
 {
     static const int barker_13[13] = {1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 1, 0, 1};
     const int rrc_ntaps = sps * 11, csz = 13 * sps, extra = rrc_ntaps, nt = csz + extra;
-    const std::vector<float> rrc = root_raised_cosine(1, sps, 1.0, 0.35, rrc_ntaps);
+    const std::vector<float> rrc = root_raised_cosine(1, sps, 1.0, (double)0.350f, rrc_ntaps);   // `float excess_bw = 0.350f` in the reference (dsss_decoder_cc_impl.cc:77)
     const int nr = (int)rrc.size();
     std::vector<float> cs((size_t)(csz + 2 * extra + nr), 0.0f), taps((size_t)nt);
     for (int i = 0; i < 13; ++i)

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64) void k_dsss_mf(const DsssMfParams P)
     const int lane = threadIdx.x, b = blockIdx.y;
     const uint64_t I = P.i0 + blockIdx.x;
     for (int k = lane; k < DS_NT; k += 64) taps[k] = P.taps[k];
-    const int64_t P0 = (int64_t)DS_L * ((int64_t)I - 2);          // window j covers x[P0 + j .. P0 + j + 600)
+    const int64_t P0 = (int64_t)DS_L * ((int64_t)I - 2) + 1;      // window j covers x[P0 + j .. P0 + j + 600): history 325 = 324 old items + the new one
     for (int i = lane; i < DS_L + DS_NT - 1; i += 64) xs[i] = ring_at(P.in, b, P0 + i);
     __syncthreads();
     float best = 0.0f; float2 bv = make_float2(0.f, 0.f); int bj = 0x7fffffff;

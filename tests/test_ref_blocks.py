@@ -131,3 +131,30 @@ def test_zero_idle_bursts_oracle_equals_the_reference_block(ref):
         ref.ref_zero_idle_bursts(P(x), C.c_size_t(n), C.c_size_t(chunk), P(offs), P(cnts), C.c_size_t(offs.size), P(got))
         assert np.array_equal(got, want)
     assert np.count_nonzero(want == 0) == 720 + (100 + 50) + 10 + (720 + 720) + 1 + 10   # [100,820) [900,1000)->[1000,1050) [5000,5010) ... [19990,20000)
+
+
+def test_dsss_decoder_oracle_equals_the_reference_block(ref):
+    """gr::dsss::dsss_decoder_cc_impl.cc itself (FIR kernel and RRC design supplied by gr_stub with the oracle's summation order):
+    matched-filter taps, window positions (set_history(325): the windows of output I start at 325 (I - 2) + 1 + j), first-maximum
+    search and scaling.  The block takes |v| with std::abs (hypotf), the oracle sqrtf(re^2 + im^2): a different pick between two
+    candidates within an ulp of each other would be legitimate; none occurs on these inputs."""
+    ref.ref_dsss_decoder.restype = C.c_size_t
+    rng = np.random.default_rng(8)
+    bits = rng.integers(0, 2, 60)
+    code = np.array([1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 1, 0, 1])
+    chips = np.concatenate([code if b == 0 else 1 - code for b in bits]) * 2.0 - 1
+    up = np.zeros(chips.size * 25)
+    up[::25] = chips
+    x = np.convolve(up, orc.root_raised_cosine(25, 25, 1, 0.35, 275).astype(np.float64))[:up.size]
+    x = (x * np.exp(0.7j) + 0.05 * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))).astype(np.complex64)
+    for n in (x.size, 5000, 600, 599, 274):
+        xs = np.ascontiguousarray(x[:n])
+        want_taps = np.zeros(600, np.float32)
+        out = np.zeros(xs.size // 325 + 8, np.complex64)
+        for per_call in (1 << 20, 1, 7):
+            m = ref.ref_dsss_decoder(P(xs), C.c_size_t(n), 25, C.c_size_t(per_call), P(out), P(want_taps))
+            got = orc.dsss_decoder(xs, 25)
+            assert m == got.size, (n, m, got.size)
+            assert np.array_equal(got.view(np.uint32), out[:m].view(np.uint32)), (n, per_call)
+        assert np.array_equal(orc.dsss_taps(25).view(np.uint32), want_taps.view(np.uint32))
+    assert orc.dsss_decoder(x, 25).size == (x.size - 275) // 325 + 1
