@@ -7,6 +7,7 @@
 #include <complex>
 #include <condition_variable>
 #include <cstdint>
+#include <cstring>
 #include <iostream>
 #include <memory>
 #include <mutex>
@@ -49,6 +50,7 @@ public:
     virtual void forecast(int, gr_vector_int&) {}
     virtual int general_work(int, gr_vector_int&, gr_vector_const_void_star&, gr_vector_void_star&) { return 0; }
     void set_relative_rate(double) {}
+    void set_alignment(int) {}
     void consume_each(int n) { stub_consumed += n; }
     void consume(int, int n) { stub_consumed += n; }
     uint64_t nitems_written(unsigned) const { return stub_written; }
@@ -84,7 +86,9 @@ private:
 };
 class sync_block : public block {
 public:
+    sync_block() {}
     using block::block;
+    virtual int work(int, gr_vector_const_void_star&, gr_vector_void_star&) { return 0; }
 };
 class sync_interpolator : public sync_block {
 public:

@@ -6,6 +6,7 @@
 //   gr_4fsk_discriminator::work     /root/reference/src/gr/gr_4fsk_discriminator.cpp                                    -> orc_demod_4fsk
 //   rssi_tag_block::work            /root/reference/src/gr/rssi_tag_block.cpp                                           -> orc_rssi_tag
 //   dsss_decoder_cc_impl::general_work  /root/reference/src/gr/dsss_decoder_cc_impl.cc (its FIR kernel / RRC design come from gr_stub)  -> orc_dsss_decoder
+//   cessb::clipper_cc / stretcher_cc    /root/reference/src/gr/cessb/*.cc (VOLK kernels from gr_stub/volk, generic forms)                 -> orc_cessb_*
 //   gr_zero_idle_bursts::work       /root/reference/src/gr/gr_zero_idle_bursts.cpp (MMDVM TX)                           -> orc_zero_idle_bursts
 #include <cstdint>
 #include <cstring>
@@ -16,6 +17,8 @@
 #include "src/gr/rssi_tag_block.h"
 #include "src/gr/gr_zero_idle_bursts.h"
 #include "src/gr/dsss_decoder_cc_impl.h"
+#include "src/gr/cessb/clipper_cc.h"
+#include "src/gr/cessb/stretcher_cc.h"
 
 extern "C" {
 
@@ -123,6 +126,32 @@ size_t ref_dsss_decoder(const float* in /* 2 n */, size_t n, int sps, size_t per
         d->stub_consumed = 0;
         if (d->general_work((int)m, ninput, ins, outs) != (int)m) return 0;
         consumed += (size_t)d->stub_consumed;
+        done += m;
+    }
+    return total;
+}
+
+// cessb::clipper_cc(clip): a sync block working in chunks of 1024 (n a multiple of 1024)
+void ref_cessb_clipper(const float* in /* 2 n */, size_t n, float clip, float* out)
+{
+    gr::cessb::clipper_cc::sptr c = gr::cessb::clipper_cc::make(clip);
+    gr_vector_const_void_star ins(1, in);
+    gr_vector_void_star outs(1, out);
+    c->work((int)n, ins, outs);
+}
+// cessb::stretcher_cc: general_work over whole chunks of 1024; the block reads two items beyond the chunk it writes (forecast), so
+// n input items give 1024 floor((n - 2) / 1024) outputs.  calls of `chunks` chunks each.
+size_t ref_cessb_stretcher(const float* in /* 2 n */, size_t n, size_t chunks, float* out)
+{
+    gr::cessb::stretcher_cc::sptr s = gr::cessb::stretcher_cc::make();
+    const size_t total = n >= 2 ? 1024 * ((n - 2) / 1024) : 0;
+    size_t done = 0;
+    while (done < total) {
+        const size_t m = total - done < 1024 * chunks ? total - done : 1024 * chunks;
+        gr_vector_int ninput(1, (int)(n - done));
+        gr_vector_const_void_star ins(1, in + 2 * done);
+        gr_vector_void_star outs(1, out + 2 * done);
+        if (s->general_work((int)m, ninput, ins, outs) != (int)m) return 0;
         done += m;
     }
     return total;

@@ -158,3 +158,26 @@ def test_dsss_decoder_oracle_equals_the_reference_block(ref):
             assert np.array_equal(got.view(np.uint32), out[:m].view(np.uint32)), (n, per_call)
         assert np.array_equal(orc.dsss_taps(25).view(np.uint32), want_taps.view(np.uint32))
     assert orc.dsss_decoder(x, 25).size == (x.size - 275) // 325 + 1
+
+
+def test_cessb_clipper_and_stretcher_oracle_equal_the_reference_blocks(ref):
+    """src/gr/cessb/clipper_cc_impl.cc and stretcher_cc_impl.cc themselves (VOLK kernels in generic form from gr_stub, cos / sin =
+    the shared deterministic polynomial): operation order of the polar clipper; the stretcher's five-point envelope window, its
+    carry of two envelope values across chunks, its two items of look-ahead and its whole-chunk output count"""
+    ref.ref_cessb_stretcher.restype = C.c_size_t
+    orc.lib.orc_cessb_stretcher.restype = C.c_size_t
+    rng = np.random.default_rng(12)
+    x = ((rng.standard_normal(5 * 1024) + 1j * rng.standard_normal(5 * 1024)) * 0.5).astype(np.complex64)
+    x[100:140] = 0                                                        # zero magnitude: atan2(0, 0), 0 / 1
+    a, b = np.zeros_like(x), np.zeros_like(x)
+    ref.ref_cessb_clipper(P(x), C.c_size_t(x.size), C.c_float(0.95), P(a))
+    orc.lib.orc_cessb_clipper(P(x), C.c_size_t(x.size), C.c_float(0.95), P(b))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for n in (5 * 1024, 4 * 1024 + 2, 4 * 1024 + 1, 1025, 1026):
+        xs = np.ascontiguousarray(a[:n])
+        want_n = orc.lib.orc_cessb_stretcher(P(xs), C.c_size_t(n), P(b))
+        for chunks in (8, 1, 2):
+            got = np.zeros(n + 8, np.complex64)
+            m = ref.ref_cessb_stretcher(P(xs), C.c_size_t(n), C.c_size_t(chunks), P(got))
+            assert m == want_n == 1024 * ((n - 2) // 1024)
+            assert np.array_equal(got[:m].view(np.uint32), b[:m].view(np.uint32)), (n, chunks)
