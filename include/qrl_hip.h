@@ -362,6 +362,28 @@ int qrl_table_atan(float* t257);
 int qrl_table_tanh(float* t256);
 uint64_t qrl_phase_inc_to_turn(double radians_per_sample);
 
+/* ---- analogue voice modulator: replaces make_gr_mod_nbfm(sps, samp_rate, carrier_freq, filter_width) (reference
+ * src/gr/gr_mod_nbfm.cpp:19-77, instances gr_mod_base.cpp:171-172) for `batch` independent radios.  audio: device f32 at 8 ksps,
+ * stream b at audio + b * stride, n samples per call (a multiple of 4, <= max_samples); iq: device cf32 at 1 Msps, stream b at
+ * iq + 2 * b * out_stride floats, n * qrl_amod_samples_per_sample() (= 125 n) samples.  Asynchronous on the handle's stream;
+ * results are independent of how the audio is cut into calls.  (AM / SSB modulators, CTCSS: not built.) */
+typedef struct qrl_amod qrl_amod;
+typedef struct qrl_amod_config {
+    int modem_type;        /* QRL_MODEM_NBFM2500 | QRL_MODEM_NBFM5000 */
+    int batch;
+    size_t max_samples;    /* audio samples per stream and call */
+    void* hip_stream;      /* hipStream_t or NULL (own stream) */
+    float bb_gain;         /* gr_mod_nbfm::set_bb_gain; 0 = 1.0 */
+} qrl_amod_config;
+int qrl_amod_create(qrl_ctx* ctx, const qrl_amod_config* cfg, qrl_amod** out);
+void qrl_amod_destroy(qrl_amod* m);
+int qrl_amod_reset(qrl_amod* m);
+int qrl_amod_set_bb_gain(qrl_amod* m, float value);
+size_t qrl_amod_samples_per_sample(const qrl_amod* m);
+int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, float* iq, size_t out_stride);
+int qrl_amod_sync(qrl_amod* m);
+void* qrl_amod_stream(qrl_amod* m);
+
 /* ---- frame FEC of the DMR / M17 protocol stacks over batches of frames.  Stateless; device pointers;
  * asynchronous on hip_stream (NULL = the default stream), the caller synchronises it.
  * qrl_bptc19696_decode replaces CBPTC19696::decode (reference src/MMDVM/BPTC19696.cpp:47-64; users: CDMRFullLC, CDMRCSBK, CDMRDataHeader

@@ -275,6 +275,72 @@ static void fm_mod(const float* in, size_t n, float k, cf32* out)
     }
 }
 
+/* gr_mod_nbfm (reference src/gr/gr_mod_nbfm.cpp:26-77, instances make_gr_mod_nbfm(20, 1000000, 1700, 2500 / 5000) gr_mod_base.cpp:171-172):
+ * audio at 8 ksps -> fft_filter_fff(low_pass_2(1, 8000, 3500, 200, 35, BH)) -> x0.99 -> iir_filter_ffd(pre-emphasis, new style) ->
+ * rational_resampler_fff(25, 4, low_pass_2(25, 200000, fw, 3500, 60, BH)) -> frequency_modulator_fc(4 pi fw / 50000) ->
+ * fft_filter_ccf(low_pass_2(1, 50000, fw, 3500, 60, BH)) -> x0.8 -> x bb_gain -> rational_resampler_ccf(sps = 20, 1,
+ * low_pass_2(20, 1e6, fw, 3500, 60, BH)).  125 samples per audio sample.  (The CTCSS tone source exists but is not connected.) */
+void orc_preemph_taps(int sample_rate, double tau, double a[2], double b[2])
+{
+    /* emphasis.cpp:44-89 (fh = 0.925 fs / 2 when not given; tanf on float arguments) */
+    const double fs = (double)sample_rate, fh = 0.925 * fs / 2.0;
+    const double w_cl = 1.0 / tau, w_ch = 2.0 * M_PI * fh;
+    const double w_cla = 2.0 * fs * (double)tanf((float)(w_cl / (2.0 * fs)));
+    const double w_cha = 2.0 * fs * (double)tanf((float)(w_ch / (2.0 * fs)));
+    const double kl = -w_cla / (2.0 * fs), kh = -w_cha / (2.0 * fs);
+    const double z1 = (1.0 + kl) / (1.0 - kl), p1 = (1.0 + kh) / (1.0 - kh), b0 = (1.0 - kl) / (1.0 - kh);
+    const double w_0dB = 2.0 * M_PI * 0.0;
+    const double g = fabs(1.0 - p1 * 1.0 * (cos(-w_0dB) + sin(-w_0dB))) / (b0 * fabs(1.0 - z1 * 1.0 * (cos(-w_0dB) + sin(-w_0dB))));
+    b[0] = g * b0 * 1.0; b[1] = g * b0 * -z1;
+    a[0] = 1.0;          a[1] = -p1;
+}
+size_t orc_mod_nbfm(const float* audio, size_t n, int sps, int samp_rate, int filter_width, float bb_gain, cf32* out)
+{
+    const size_t n50 = orc_decim_count(n, 25, 4);
+    if (!out) return n50 * (size_t)sps;
+    int na = orc_low_pass_2(1, 8000, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* at = NEW(float, na);
+    orc_low_pass_2(1, 8000, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, at);
+    float* a1 = NEW(float, n);
+    orc_fir_fff(audio, n, at, na, a1);                                           /* _audio_filter */
+    free(at);
+    double ta[2], tb[2];
+    orc_preemph_taps(8000, 50e-6, ta, tb);
+    {   /* _audio_amplify, _pre_emph_filter: acc = b0 x + b1 x[-1] - a1 y[-1] in double, y kept in double */
+        float xp = 0.0f; double yp = 0.0;
+        for (size_t i = 0; i < n; i++) {
+            const float x = a1[i] * 0.99f;
+            double acc = tb[0] * (double)x;
+            acc += tb[1] * (double)xp;
+            acc += -ta[1] * yp;
+            yp = acc; xp = x;
+            a1[i] = (float)acc;
+        }
+    }
+    int ni = orc_low_pass_2(25, 50000.0 * 4, filter_width, 3500, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* it = NEW(float, ni);
+    orc_low_pass_2(25, 50000.0 * 4, filter_width, 3500, 60, ORC_WIN_BLACKMAN_HARRIS, it);
+    float* r = NEW(float, n50);
+    orc_resamp_fff(a1, n, it, ni, 25, 4, r);                                     /* _if_resampler */
+    free(it); free(a1);
+    cf32* fmv = NEW(cf32, n50);
+    fm_mod(r, n50, (float)(4 * M_PI * filter_width / 50000.0f), fmv);            /* _fm_modulator */
+    free(r);
+    int nf = orc_low_pass_2(1, 50000, filter_width, 3500, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* ft = NEW(float, nf);
+    orc_low_pass_2(1, 50000, filter_width, 3500, 60, ORC_WIN_BLACKMAN_HARRIS, ft);
+    cf32* g = NEW(cf32, n50);
+    orc_fir_ccf(fmv, n50, ft, nf, g);                                            /* _filter */
+    free(ft); free(fmv);
+    for (size_t i = 0; i < n50; i++) { g[i].re *= 0.8f; g[i].im *= 0.8f; g[i].re *= bb_gain; g[i].im *= bb_gain; }   /* _amplify, _bb_gain */
+    int nt = orc_low_pass_2(sps, samp_rate, filter_width, 3500, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* lp = NEW(float, nt);
+    orc_low_pass_2(sps, samp_rate, filter_width, 3500, 60, ORC_WIN_BLACKMAN_HARRIS, lp);
+    const size_t m = orc_resamp_ccf(g, n50, lp, nt, sps, 1, out);                /* _resampler */
+    free(lp); free(g);
+    return m;
+}
+
 /* gr_mod_2fsk.cpp:30-99 */
 size_t orc_mod_2fsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, int fm, cf32* out)
 {

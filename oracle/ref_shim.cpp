@@ -84,6 +84,12 @@ void ref_deemph_taps(int sample_rate, double tau, double a[2], double b[2])
     gr::calculate_deemph_taps(sample_rate, tau, at, bt);
     a[0] = at[0]; a[1] = at[1]; b[0] = bt[0]; b[1] = bt[1];
 }
+void ref_preemph_taps(int sample_rate, double tau, double a[2], double b[2])
+{
+    std::vector<double> at, bt;
+    gr::calculate_preemph_taps(sample_rate, tau, at, bt);
+    a[0] = at[0]; a[1] = at[1]; b[0] = bt[0]; b[1] = bt[1];
+}
 uint32_t ref_golay24_encode(uint16_t data) { return M17::golay24_encode(data); }
 uint16_t ref_golay24_decode(uint32_t cw) { return M17::golay24_decode(cw); }
 void ref_m17_decorrelator_sequence(uint8_t out46[46])

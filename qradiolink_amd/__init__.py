@@ -62,6 +62,10 @@ class _ZeroRun(C.Structure):
     _fields_ = [("stream", C.c_int), ("channel", C.c_int), ("start", C.c_uint64), ("count", C.c_uint64)]
 
 
+class _AModConfig(C.Structure):
+    _fields_ = [("modem_type", C.c_int), ("batch", C.c_int), ("max_samples", C.c_size_t), ("hip_stream", C.c_void_p), ("bb_gain", C.c_float)]
+
+
 class _Out(C.Structure):
     _fields_ = [("filtered", C.c_void_p), ("filtered_cap", C.c_size_t), ("constellation", C.c_void_p),
                 ("constellation_cap", C.c_size_t), ("bits_a", C.c_void_p), ("bits_cap", C.c_size_t),
@@ -95,6 +99,17 @@ def load_library():
     lib.qrl_demod_set_dmo_output.argtypes = [vp, vp, sz, vp]
     lib.qrl_demod_out_caps.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     lib.qrl_demod_audio_cap.argtypes = [vp, sz, C.POINTER(sz)]
+    lib.qrl_amod_create.argtypes = [vp, vp, C.POINTER(vp)]
+    lib.qrl_amod_destroy.argtypes = [vp]
+    lib.qrl_amod_destroy.restype = None
+    lib.qrl_amod_reset.argtypes = [vp]
+    lib.qrl_amod_set_bb_gain.argtypes = [vp, C.c_float]
+    lib.qrl_amod_samples_per_sample.argtypes = [vp]
+    lib.qrl_amod_samples_per_sample.restype = sz
+    lib.qrl_amod_process.argtypes = [vp, vp, sz, sz, vp, sz]
+    lib.qrl_amod_sync.argtypes = [vp]
+    lib.qrl_amod_stream.argtypes = [vp]
+    lib.qrl_amod_stream.restype = vp
     for name in ("qrl_bptc19696_decode", "qrl_bptc19696_encode", "qrl_m17_decode_frames"):
         getattr(lib, name).argtypes = [vp, vp, vp, sz, vp]
     lib.qrl_demod_set_squelch.argtypes = [vp, C.c_double]
@@ -182,6 +197,7 @@ EXPORTED_SYMBOLS = [
     "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_set_option", "qrl_demod_set_dmo_output", "qrl_demod_stream_wait", "qrl_demod_out_caps",
     "qrl_demod_audio_cap", "qrl_demod_set_squelch", "qrl_demod_set_agc",
     "qrl_bptc19696_decode", "qrl_bptc19696_encode", "qrl_m17_decode_frames",
+    "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_samples_per_sample", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
     "qrl_mod_samples_per_byte", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_create",
@@ -705,6 +721,40 @@ class Mod:
         if self.h:
             self.lib.qrl_mod_destroy(self.h)
             self.h = C.c_void_p()
+
+
+class AMod:
+    """Batch analogue voice modulator: mirrors make_gr_mod_nbfm (src/gr/gr_mod_nbfm.cpp:19-77).  process(audio) takes a float32
+    cuda tensor [batch, n] (8 ksps, n a multiple of 4) and returns complex64 [batch, 125 n] at 1 Msps."""
+
+    def __init__(self, ctx, modem_type, batch, max_samples, bb_gain=1.0):
+        import torch
+        self.torch, self.ctx, self.lib = torch, ctx, ctx.lib
+        cfg = _AModConfig(modem_type, batch, max_samples, None, bb_gain)
+        self.h = C.c_void_p()
+        _check(self.lib.qrl_amod_create(ctx.h, C.byref(cfg), C.byref(self.h)), "qrl_amod_create")
+        self.batch, self.spa = batch, self.lib.qrl_amod_samples_per_sample(self.h)
+
+    def process(self, audio):
+        t = self.torch
+        assert audio.is_cuda and audio.dtype == t.float32 and audio.dim() == 2 and audio.shape[0] == self.batch and audio.stride(1) == 1
+        n = audio.shape[1]
+        out = t.zeros((self.batch, n * self.spa), dtype=t.complex64, device=audio.device)
+        t.cuda.current_stream().synchronize()
+        _check(self.lib.qrl_amod_process(self.h, audio.data_ptr(), audio.stride(0), n, out.data_ptr(), out.stride(0)), "qrl_amod_process")
+        _check(self.lib.qrl_amod_sync(self.h), "qrl_amod_sync")
+        return out
+
+    def set_bb_gain(self, g):
+        _check(self.lib.qrl_amod_set_bb_gain(self.h, C.c_float(g)), "qrl_amod_set_bb_gain")
+
+    def reset(self):
+        _check(self.lib.qrl_amod_reset(self.h), "qrl_amod_reset")
+
+    def close(self):
+        if self.h:
+            self.lib.qrl_amod_destroy(self.h)
+            self.h = None
 
 
 def bptc19696_decode(ctx, bursts):

@@ -1,0 +1,150 @@
+// amod.cpp — analogue voice modulator behind the C ABI: gr_mod_nbfm (reference src/gr/gr_mod_nbfm.cpp:26-77, instances
+// make_gr_mod_nbfm(20, 1000000, 1700, 2500 / 5000) src/gr/gr_mod_base.cpp:171-172) for a batch of independent radios.
+//   audio (8 ksps) -> audio filter -> x0.99 -> pre-emphasis (iir_filter_ffd, f64) -> 25:4 -> frequency modulator -> channel filter
+//   -> x0.8 -> x bb_gain -> 1:20 interpolator  = 125 IQ samples (1 Msps) per audio sample.
+// Kernels: k_am_load, k_fir_fff, k_am_iir, k_an_resamp (host-side counts), k_tx_fm, k_fir_ccf, k_scale_c, k_tx_interp_c.
+// Arithmetic = oracle/orc_chains.c orc_mod_nbfm, bit for bit, independent of how the audio is cut into calls (multiples of 4 samples:
+// the 25:4 resampler then produces whole groups of 25).
+#include "../../include/qrl_hip.h"
+#include "engine.hpp"
+#include "firdes.hpp"
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace qrl;
+extern int qrl_set_error(int code, const std::string& msg);
+struct qrl_ctx { int device; };
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return qrl_set_error(QRL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+template <class T> struct Dev {
+    T* p = nullptr; size_t n = 0;
+    ~Dev() { if (p) (void)hipFree(p); }
+    int alloc(size_t count) { n = count; return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)) == hipSuccess ? QRL_OK : QRL_ERR_HIP; }
+    int upload(const std::vector<T>& v) { if (int r = alloc(v.size())) return r; return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess ? QRL_OK : QRL_ERR_HIP; }
+    int zero() { return hipMemset(p, 0, n * sizeof(T)) == hipSuccess ? QRL_OK : QRL_ERR_HIP; }
+};
+uint32_t pow2_at_least(size_t v) { uint32_t c = 1024; while (c < v) c <<= 1; return c; }
+}  // namespace
+
+struct qrl_amod {
+    qrl_ctx* ctx = nullptr;
+    qrl_amod_config cfg{};
+    hipStream_t stream = nullptr; bool own_stream = false;
+    int sps = 20, fw = 5000;
+    float bb_gain = 1.0f, fm_k = 0.f;
+    Dev<float> t_audio, t_if, t_filt, t_interp; int n_audio = 0, n_if = 0, n_filt = 0, n_interp = 0;
+    Dev<float> a0, a1, a2, r50; uint32_t m8 = 0, m50 = 0;       // rings: audio in, filtered, pre-emphasised (8 ksps); 50 ksps
+    Dev<float2> fmv, flt;                                        // 50 ksps complex: modulator out, channel filter out
+    Dev<AmIirState> iir; Dev<float> phase;
+    double pb[2] = {0, 0}, pa[2] = {0, 0};
+    uint64_t n8 = 0, n50 = 0;
+    ~qrl_amod() { if (own_stream && stream) (void)hipStreamDestroy(stream); }
+    int init_state()
+    {
+        int r;
+        for (auto* b : {&a0, &a1, &a2, &r50, &phase}) if ((r = b->zero())) return r;
+        if ((r = fmv.zero()) || (r = flt.zero()) || (r = iir.zero())) return r;
+        n8 = n50 = 0;
+        return QRL_OK;
+    }
+};
+
+extern "C" {
+
+int qrl_amod_create(qrl_ctx* ctx, const qrl_amod_config* cfg, qrl_amod** outp)
+{
+    if (!ctx || !cfg || !outp) return QRL_ERR_ARG;
+    if (cfg->batch < 1 || cfg->max_samples < 4) return qrl_set_error(QRL_ERR_ARG, "amod: batch >= 1, max_samples >= 4");
+    std::unique_ptr<qrl_amod> m(new (std::nothrow) qrl_amod);
+    if (!m) return QRL_ERR_NOMEM;
+    m->ctx = ctx; m->cfg = *cfg; m->bb_gain = cfg->bb_gain == 0.0f ? 1.0f : cfg->bb_gain;
+    switch (cfg->modem_type) {
+    case QRL_MODEM_NBFM2500: m->fw = 2500; break;     // make_gr_mod_nbfm(20, 1000000, 1700, 2500) gr_mod_base.cpp:171
+    case QRL_MODEM_NBFM5000: m->fw = 5000; break;     // :172
+    default: return qrl_set_error(QRL_ERR_ARG, "amod: modem_type must be QRL_MODEM_NBFM2500 or QRL_MODEM_NBFM5000");
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    if (cfg->hip_stream) m->stream = static_cast<hipStream_t>(cfg->hip_stream);
+    else { HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
+    const int fw = m->fw, B = cfg->batch;
+    const std::vector<float> ta = low_pass_2(1, 8000, 3500, 200, 35, WIN_BLACKMAN_HARRIS);                 // _audio_filter, gr_mod_nbfm.cpp:43-45
+    const std::vector<float> ti = low_pass_2(25, 50000.0 * 4, fw, 3500, 60, WIN_BLACKMAN_HARRIS);          // _if_resampler (25, 4), :49-51
+    const std::vector<float> tf = low_pass_2(1, 50000, fw, 3500, 60, WIN_BLACKMAN_HARRIS);                 // _filter, :61-62
+    const std::vector<float> tr = low_pass_2(m->sps, 1000000, fw, 3500, 60, WIN_BLACKMAN_HARRIS);          // _resampler (sps, 1), :56-58
+    m->n_audio = (int)ta.size(); m->n_if = (int)ti.size(); m->n_filt = (int)tf.size(); m->n_interp = (int)tr.size();
+    if (m->n_interp > 2048) return qrl_set_error(QRL_ERR_ARG, "amod: interpolator filter too long");
+    int r;
+    if ((r = m->t_audio.upload(ta)) || (r = m->t_if.upload(ti)) || (r = m->t_filt.upload(tf)) || (r = m->t_interp.upload(tr))) return r;
+    m->fm_k = (float)(4 * M_PI * fw / 50000.0f);                                                          // frequency_modulator_fc, :41
+    preemph_taps(8000, 50e-6, m->pa, m->pb);                                                              // :39
+    const size_t max50 = cfg->max_samples * 25 / 4 + 32;
+    m->m8 = pow2_at_least(cfg->max_samples + 1024) - 1;
+    m->m50 = pow2_at_least(max50 + 2048) - 1;
+    const size_t r8 = (size_t)B * (m->m8 + 1), r5 = (size_t)B * (m->m50 + 1);
+    if ((r = m->a0.alloc(r8)) || (r = m->a1.alloc(r8)) || (r = m->a2.alloc(r8)) || (r = m->r50.alloc(r5)) || (r = m->fmv.alloc(r5)) ||
+        (r = m->flt.alloc(r5)) || (r = m->iir.alloc(B)) || (r = m->phase.alloc(B))) return r;
+    if ((r = m->init_state())) return r;
+    *outp = m.release();
+    return QRL_OK;
+}
+void qrl_amod_destroy(qrl_amod* m) { if (m) { (void)hipStreamSynchronize(m->stream); delete m; } }
+int qrl_amod_reset(qrl_amod* m)
+{
+    if (!m) return QRL_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return m->init_state();
+}
+int qrl_amod_set_bb_gain(qrl_amod* m, float g) { if (!m) return QRL_ERR_ARG; m->bb_gain = g; return QRL_OK; }
+size_t qrl_amod_samples_per_sample(const qrl_amod* m) { return m ? (size_t)25 * m->sps / 4 : 0; }
+void* qrl_amod_stream(qrl_amod* m) { return m ? m->stream : nullptr; }
+int qrl_amod_sync(qrl_amod* m) { if (!m) return QRL_ERR_ARG; HIPCHK(hipStreamSynchronize(m->stream)); return QRL_OK; }
+
+int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, float* iq, size_t out_stride)
+{
+    if (!m || (!audio && n) || (!iq && n)) return QRL_ERR_ARG;
+    if (n > m->cfg.max_samples) return qrl_set_error(QRL_ERR_TOO_BIG, "n exceeds max_samples");
+    if (n % 4) return qrl_set_error(QRL_ERR_ARG, "amod: audio samples per call must be a multiple of 4 (25:4 resampler)");
+    if (n == 0) return QRL_OK;
+    HIPCHK(hipSetDevice(m->ctx->device));
+    const int B = m->cfg.batch;
+    hipStream_t s = m->stream;
+    RingF a0{m->a0.p, m->m8}, a1{m->a1.p, m->m8}, a2{m->a2.p, m->m8}, r50{m->r50.p, m->m50};
+    RingC fmv{m->fmv.p, m->m50}, flt{m->flt.p, m->m50};
+    const uint32_t c8 = (uint32_t)n, c50 = (uint32_t)(n * 25 / 4);
+    AmLoadParams lp{}; lp.in = audio; lp.in_stride = stride; lp.out = a0; lp.n0 = m->n8; lp.count = c8;
+    launch_am_load(lp, B, s);
+    FirFffParams af{}; af.in = a0; af.out = a1; af.q0 = m->n8; af.count = c8; af.taps = m->t_audio.p; af.nt = m->n_audio;
+    launch_fir_fff(af, B, s);                                                       // _audio_filter
+    AmIirParams ip{}; ip.in = a1; ip.out = a2; ip.n0 = m->n8; ip.count = c8; ip.gain = 0.99f;   // _audio_amplify, _pre_emph_filter
+    ip.ff0 = m->pb[0]; ip.ff1 = m->pb[1]; ip.fb1 = -m->pa[1]; ip.st = m->iir.p;
+    launch_am_iir(ip, B, s);
+    AnResampParams rp{}; rp.in = a2; rp.out = r50; rp.st = nullptr; rp.taps = m->t_if.p; rp.nt = m->n_if; rp.I = 25; rp.D = 4;
+    rp.q0 = m->n50; rp.count = c50;
+    launch_an_resamp(rp, c50, B, s);                                                // _if_resampler
+    TxFmParams fp{}; fp.in = r50; fp.out = fmv; fp.n0 = m->n50; fp.count = c50; fp.k = m->fm_k; fp.amp = 1.0f; fp.phase = m->phase.p;
+    launch_tx_fm(fp, B, s);                                                         // _fm_modulator
+    FirCcfParams cf{}; cf.in = fmv; cf.out = flt; cf.q0 = m->n50; cf.count = c50; cf.taps = m->t_filt.p; cf.nt = m->n_filt;
+    launch_fir_ccf(cf, B, s);                                                       // _filter
+    launch_scale_c(flt, m->n50, c50, 0.8f, B, s);                                   // _amplify
+    launch_scale_c(flt, m->n50, c50, m->bb_gain, B, s);                             // _bb_gain
+    TxInterpCParams xp{}; xp.in = flt; xp.n0 = m->n50 * (uint64_t)m->sps; xp.count = c50 * (uint32_t)m->sps;
+    xp.taps = m->t_interp.p; xp.nt = m->n_interp; xp.interp = m->sps; xp.out = reinterpret_cast<float2*>(iq); xp.out_stride = out_stride;
+    launch_tx_interp_c(xp, B, s);                                                   // _resampler
+    HIPCHK(hipGetLastError());
+    if (qrl::take_launch_error()) return QRL_ERR_HIP;
+    m->n8 += c8; m->n50 += c50;
+    return QRL_OK;
+}
+
+}

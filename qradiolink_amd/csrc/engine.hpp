@@ -268,13 +268,20 @@ struct AnState { double pwr, iir_y, de_y; uint64_t g, g_prev; float2 prev; float
 struct AnGateParams { RingC in; RingF out; RingC outc; uint64_t q0; uint32_t count; AnState* st; const float* atan_tab; const float* env; int ramp;
                       double alpha, one_minus_alpha, threshold; float gain, attack, decay, ref, clip; double ff0, ff1, fb1; };
 void launch_an_gate(const AnGateParams& p, int kind, int batch, hipStream_t s);   // kind 0 NBFM, 1 AM, 2 WBFM, 3 SSB (complex out)
-struct AnResampParams { RingF in, out; const AnState* st; const float* taps; int nt, I, D; float* port; size_t port_cap; uint32_t* counts; };
+struct AnResampParams { RingF in, out; const AnState* st; const float* taps; int nt, I, D; float* port; size_t port_cap; uint32_t* counts;
+                        uint64_t q0; uint32_t count; };   // st == nullptr: outputs q0 .. q0 + count (host-side counts: the TX chains)
 void launch_an_resamp(const AnResampParams& p, uint32_t max_out, int batch, hipStream_t s);
 struct AnFirParams { RingF in, out; const AnState* st; const float* taps; int nt, I, D; float* port; size_t port_cap; uint32_t* counts; };
 void launch_an_fir(const AnFirParams& p, uint32_t max_out, int batch, hipStream_t s);
 struct AnDeemphParams { RingF in; AnState* st; int I, D; double ff0, ff1, fb1; float* port; size_t port_cap; uint32_t* counts; };
 void launch_an_deemph(const AnDeemphParams& p, int batch, hipStream_t s);
 // I == 0 in AnFirParams / AnStretchParams: the output range of the call is the cessb stretcher's, 1024 floor((g - 2) / 1024)
+// analogue modulators (gr_mod_nbfm): linear audio -> ring; x gain -> two-tap IIR in double (lane per stream)
+struct AmLoadParams { const float* in; size_t in_stride; RingF out; uint64_t n0; uint32_t count; };
+void launch_am_load(const AmLoadParams& p, int batch, hipStream_t s);
+struct AmIirState { double y1; float x1, pad; };
+struct AmIirParams { RingF in, out; uint64_t n0; uint32_t count; float gain; double ff0, ff1, fb1; AmIirState* st; };
+void launch_am_iir(const AmIirParams& p, int batch, hipStream_t s);
 struct AnStretchParams { RingC in; RingF out; const AnState* st; float level; };
 void launch_an_stretch(const AnStretchParams& p, uint32_t max_out, int batch, hipStream_t s);
 

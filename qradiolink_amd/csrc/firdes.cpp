@@ -122,6 +122,18 @@ void deemph_taps(int sample_rate, double tau, double a[2], double b[2])
     b[0] = b0; b[1] = b0 * 1.0;
     a[0] = 1.0; a[1] = -p1;
 }
+void preemph_taps(int sample_rate, double tau, double a[2], double b[2])
+{
+    const double fs = (double)sample_rate, fh = 0.925 * fs / 2.0;
+    const double w_cl = 1.0 / tau, w_ch = 2.0 * kPi * fh;
+    const double w_cla = 2.0 * fs * (double)tanf((float)(w_cl / (2.0 * fs)));   // (the reference calls tanf)
+    const double w_cha = 2.0 * fs * (double)tanf((float)(w_ch / (2.0 * fs)));
+    const double kl = -w_cla / (2.0 * fs), kh = -w_cha / (2.0 * fs);
+    const double z1 = (1.0 + kl) / (1.0 - kl), p1 = (1.0 + kh) / (1.0 - kh), b0 = (1.0 - kl) / (1.0 - kh);
+    const double g = std::fabs(1.0 - p1) / (b0 * std::fabs(1.0 - z1));           // unity gain at DC
+    b[0] = g * b0 * 1.0; b[1] = g * b0 * -z1;
+    a[0] = 1.0; a[1] = -p1;
+}
 std::vector<float> squelch_envelope(int ramp)
 {
     std::vector<float> e((size_t)ramp + 1, 1.0f);

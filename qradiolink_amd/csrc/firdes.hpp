@@ -25,6 +25,8 @@ std::vector<float> band_pass_2(double gain, double fs, double lo, double hi, dou
 std::vector<std::complex<float>> complex_band_pass_2(double gain, double fs, double lo, double hi, double tw, double atten_db, Window w = WIN_HAMMING);
 // reference src/gr/emphasis.cpp:16-43 (gr-analog fm_emph.py): b = {b0, b0}, a = {1, -p1}
 void deemph_taps(int sample_rate, double tau, double a[2], double b[2]);
+// reference src/gr/emphasis.cpp:44-89 with its default upper corner fh = 0.925 fs / 2: b = {g b0, -g b0 z1}, a = {1, -p1}
+void preemph_taps(int sample_rate, double tau, double a[2], double b[2]);
 // squelch_base_cc ramp envelope 0.5 - cos(pi k / ramp) / 2, k = 0 .. ramp
 std::vector<float> squelch_envelope(int ramp);
 std::vector<float> root_raised_cosine(double gain, double fs, double symrate, double alpha, int ntaps);

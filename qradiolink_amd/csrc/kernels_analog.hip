@@ -165,8 +165,8 @@ __global__ __launch_bounds__(256) void k_an_resamp(const AnResampParams P)
     for (int k = threadIdx.x; k < P.nt; k += 256) an_rt[k] = P.taps[k];
     __syncthreads();
     const int b = blockIdx.y;
-    const AnState& st = P.st[b];
-    const uint64_t q0 = an_decim_count(st.g_prev, P.I, P.D), q1 = an_decim_count(st.g, P.I, P.D);
+    uint64_t q0 = P.q0, q1 = P.q0 + P.count;
+    if (P.st) { const AnState& st = P.st[b]; q0 = an_decim_count(st.g_prev, P.I, P.D); q1 = an_decim_count(st.g, P.I, P.D); }
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t == 0 && P.port && P.counts) P.counts[b * 4 + 1] = (uint32_t)(q1 - q0);
     const uint64_t q = q0 + t;
@@ -264,6 +264,45 @@ __global__ __launch_bounds__(64) void k_an_deemph(const AnDeemphParams P, int ba
 void launch_an_deemph(const AnDeemphParams& p, int batch, hipStream_t s)
 {
     hipLaunchKernelGGL(k_an_deemph, dim3((batch + 63) / 64), dim3(64), 0, s, p, batch);
+}
+
+// ---- analogue modulators: gr_mod_nbfm (reference src/gr/gr_mod_nbfm.cpp:26-77).  The chain reuses k_fir_fff (audio filter),
+// k_an_resamp (25:4), k_tx_fm, k_fir_ccf, k_scale_c and k_tx_interp_c; new here: audio into a ring, and gain + pre-emphasis.
+__global__ __launch_bounds__(256) void k_am_load(const AmLoadParams P)
+{
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.count) return;
+    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)(P.n0 + t) & P.out.mask)] = P.in[(size_t)b * P.in_stride + t];
+}
+void launch_am_load(const AmLoadParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_am_load, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
+}
+// multiply_const_ff(gain) -> iir_filter_ffd(btaps, ataps, false): acc = b0 x + b1 x[-1] + fb1 y[-1] in double (fb1 = -a1)
+__global__ __launch_bounds__(64) void k_am_iir(const AmIirParams P, int batch)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= batch) return;
+    AmIirState st = P.st[b];
+    const float* in = P.in.p + (size_t)b * (P.in.mask + 1u);
+    float* out = P.out.p + (size_t)b * (P.out.mask + 1u);
+    for (uint32_t t = 0; t < P.count; ++t) {
+        const uint32_t n = (uint32_t)(P.n0 + t);
+        const float x = in[n & P.in.mask] * P.gain;
+        double acc = P.ff0 * (double)x;
+        acc += P.ff1 * (double)st.x1;
+        acc += P.fb1 * st.y1;
+        st.y1 = acc; st.x1 = x;
+        out[n & P.out.mask] = (float)acc;
+    }
+    P.st[b] = st;
+}
+void launch_am_iir(const AmIirParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_am_iir, dim3((batch + 63) / 64), dim3(64), 0, s, p, batch);
 }
 
 }  // namespace qrl

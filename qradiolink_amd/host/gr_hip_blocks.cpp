@@ -229,6 +229,52 @@ gr_mod_hip::~gr_mod_hip()
     if (d_iq) (void)hipFree(d_iq);
 }
 void gr_mod_hip::set_bb_gain(float v) { chk(qrl_mod_set_bb_gain(d_h, v), "qrl_mod_set_bb_gain"); }
+gr_amod_hip_sptr make_gr_mod_nbfm_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
+{
+    (void)carrier_freq;
+    if (sps != 20 || samp_rate != 1000000 || (filter_width != 2500 && filter_width != 5000))
+        throw std::invalid_argument("make_gr_mod_nbfm_hip: the instances of gr_mod_base.cpp:171-172 are (20, 1000000, ., 2500 | 5000)");
+    return gr_amod_hip_sptr(new gr_amod_hip(rt, filter_width));
+}
+gr_amod_hip::gr_amod_hip(qrl_runtime& rt, int filter_width)
+    : gr::sync_interpolator("gr_amod_hip", gr::io_signature::make(1, 1, sizeof(float)), gr::io_signature::make(1, 1, sizeof(gr_complex)), 125)
+{
+    qrl_amod_config c{};
+    c.modem_type = filter_width == 2500 ? QRL_MODEM_NBFM2500 : QRL_MODEM_NBFM5000;
+    c.batch = 1; c.max_samples = kMaxAudio; c.bb_gain = 1.0f;
+    chk(qrl_amod_create(rt.ctx(), &c, &d_h), "qrl_amod_create");
+    hchk(hipMalloc(reinterpret_cast<void**>(&d_audio), kMaxAudio * sizeof(float)), "hipMalloc");
+    hchk(hipMalloc(reinterpret_cast<void**>(&d_iq), kMaxAudio * 125 * sizeof(gr_complex)), "hipMalloc");
+}
+gr_amod_hip::~gr_amod_hip()
+{
+    if (d_h) qrl_amod_destroy(d_h);
+    if (d_audio) (void)hipFree(d_audio);
+    if (d_iq) (void)hipFree(d_iq);
+}
+void gr_amod_hip::set_bb_gain(float value) { chk(qrl_amod_set_bb_gain(d_h, value), "qrl_amod_set_bb_gain"); }
+// noutput_items = 125 x the audio items offered; audio that does not fill a group of 4 waits in d_carry (its 125 x output items are
+// handed out with the group that completes it: the block then returns fewer items than asked, as a GNU Radio block may)
+int gr_amod_hip::work(int noutput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items)
+{
+    const float* in = static_cast<const float*>(input_items[0]);
+    gr_complex* out = static_cast<gr_complex*>(output_items[0]);
+    d_carry.insert(d_carry.end(), in, in + (size_t)noutput_items / 125);
+    const size_t usable = d_carry.size() & ~(size_t)3;
+    hipStream_t s = static_cast<hipStream_t>(qrl_amod_stream(d_h));
+    size_t done = 0;
+    while (done < usable) {
+        const size_t take = std::min(usable - done, kMaxAudio);
+        hchk(hipMemcpyAsync(d_audio, d_carry.data() + done, take * sizeof(float), hipMemcpyHostToDevice, s), "H2D");
+        chk(qrl_amod_process(d_h, d_audio, kMaxAudio, take, d_iq, kMaxAudio * 125), "qrl_amod_process");
+        hchk(hipMemcpyAsync(out + done * 125, d_iq, take * 125 * sizeof(gr_complex), hipMemcpyDeviceToHost, s), "D2H");
+        chk(qrl_amod_sync(d_h), "qrl_amod_sync");
+        done += take;
+    }
+    d_carry.erase(d_carry.begin(), d_carry.begin() + (std::ptrdiff_t)usable);
+    return (int)(usable * 125);
+}
+
 int gr_mod_hip::work(int noutput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items)
 {
     const size_t spb = qrl_mod_samples_per_byte(d_h);

@@ -107,6 +107,23 @@ gr_mod_hip_sptr make_gr_mod_4fsk_hip(qrl_runtime& rt, int sps = 125, int samp_ra
                                      int filter_width = 8000, bool fm = true);
 gr_mod_hip_sptr make_gr_mod_bpsk_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 250000, int carrier_freq = 1700,
                                      int filter_width = 8000);
+// replaces make_gr_mod_nbfm(sps, samp_rate, carrier_freq, filter_width)           src/gr/gr_mod_nbfm.cpp:19-25 (f32 audio at 8 ksps in, cf32 at
+// 1 Msps out: 125 output items per input item; the scheduler hands work() whole groups, as for any sync_interpolator)
+class gr_amod_hip;
+typedef std::shared_ptr<gr_amod_hip> gr_amod_hip_sptr;
+gr_amod_hip_sptr make_gr_mod_nbfm_hip(qrl_runtime& rt, int sps = 20, int samp_rate = 1000000, int carrier_freq = 1700, int filter_width = 5000);
+class gr_amod_hip : public gr::sync_interpolator {
+public:
+    gr_amod_hip(qrl_runtime& rt, int filter_width);
+    ~gr_amod_hip() override;
+    void set_bb_gain(float value);                  // gr_mod_nbfm::set_bb_gain
+    int work(int noutput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) override;
+private:
+    qrl_amod* d_h = nullptr; float *d_audio = nullptr, *d_iq = nullptr;
+    std::vector<float> d_carry;                     // the C ABI takes multiples of 4 audio samples (25:4 resampler)
+    static constexpr size_t kMaxAudio = 4096;
+};
+
 class gr_mod_hip : public gr::sync_interpolator {   // u8 packed bytes in -> cf32 out, qrl_mod_samples_per_byte samples per byte
 public:
     gr_mod_hip(qrl_mod* handle);                    // takes ownership of a handle made by one of the factories

@@ -5,6 +5,7 @@
 //   test_adaptor rxa <nbfm | am | wbfm | usb | lsb> <fw> <iq.bin> <audio.bin>      analogue receivers: port 1 = audio mailbox
 //   test_adaptor m17seq <frames.bin: [n][48]> <out.bin>           M17FrameDecoder-shaped host class: n frames through ONE radio's
 //                decoder; out = n type bytes + the 30 LSF bytes + the 18 stream-frame bytes it holds afterwards
+//   test_adaptor txa <fw> <audio.bin: f32> <iq.bin>                 make_gr_mod_nbfm-shaped block, ragged work() calls
 //   test_adaptor tx <bytes.bin> <iq.bin> [family sps fw fm]
 #include "gr_hip_blocks.h"
 #include "m17_frame_decoder_hip.h"
@@ -83,6 +84,28 @@ int main(int argc, char** argv)
             out.insert(out.end(), dec.getLsf(0).begin(), dec.getLsf(0).end());       // the other radio's state stays clear
             dump(argv[3], out.data(), out.size());
             std::printf("m17seq ok: %zu frames\n", n);
+            return 0;
+        }
+        if (!strcmp(argv[1], "txa") && argc == 5) {
+            gr_amod_hip_sptr m = make_gr_mod_nbfm_hip(rt, 20, 1000000, 1700, atoi(argv[2]));
+            m->set_bb_gain(0.75f);
+            std::vector<char> raw = slurp(argv[3]);
+            const float* a = reinterpret_cast<const float*>(raw.data());
+            const size_t n = raw.size() / sizeof(float);
+            std::vector<gr_complex> iq, buf;
+            static const size_t sizes[] = {320, 1, 1023, 6, 2000, 5};
+            size_t pos = 0; unsigned k = 0;
+            while (pos < n) {
+                const size_t take = std::min(n - pos, sizes[k++ % 6]);
+                buf.resize((take + 3) * 125);
+                gr_vector_const_void_star ins(1, a + pos);
+                gr_vector_void_star outs(1, buf.data());
+                const int r = m->work((int)(take * 125), ins, outs);
+                iq.insert(iq.end(), buf.begin(), buf.begin() + r);
+                pos += take;
+            }
+            dump(argv[4], iq.data(), iq.size() * sizeof(gr_complex));
+            std::printf("txa ok: %zu audio samples -> %zu IQ samples\n", n, iq.size());
             return 0;
         }
         if (!strcmp(argv[1], "rxa") && argc == 6) {

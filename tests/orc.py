@@ -649,6 +649,22 @@ def demod_analog(x, kind, samp_rate=1000000, filter_width=5000):
     return dict(filtered=filt, audio=aud)
 
 
+def mod_nbfm(audio, sps=20, samp_rate=1000000, filter_width=5000, bb_gain=1.0):
+    audio = np.ascontiguousarray(audio, np.float32)
+    lib.orc_mod_nbfm.restype = C.c_size_t
+    args = (_ptr(audio), C.c_size_t(audio.size), sps, samp_rate, filter_width, C.c_float(bb_gain))
+    n = lib.orc_mod_nbfm(*args, None)
+    y = np.zeros(n, cf32)
+    m = lib.orc_mod_nbfm(*args, _ptr(y))
+    return y[:m]
+
+
+def preemph_taps(sample_rate, tau=50e-6):
+    a, b = (C.c_double * 2)(), (C.c_double * 2)()
+    lib.orc_preemph_taps(sample_rate, C.c_double(tau), a, b)
+    return list(a), list(b)
+
+
 def demod_ssb(x, sb=0, samp_rate=1000000, filter_width=2700):
     x = np.ascontiguousarray(x, cf32)
     f, a = C.c_void_p(), C.c_void_p()

@@ -256,3 +256,43 @@ def test_device_rate_tx_rx_loopback(qrl_ctx):
     dem.close()
     fr = sig.find_frames(out["bits_a"][0], bytes([0xDE, 0x98, 0xAA]), 1516 * 8)
     assert payloads[1] in fr and payloads[2] in fr
+
+
+# ---- analogue voice modulator (gr_mod_nbfm): audio in, 125 IQ samples per audio sample out
+@pytest.mark.parametrize("modem,fw", [(9, 5000), (8, 2500)])
+@pytest.mark.parametrize("chunk", [8000, 1000, 324])
+def test_nbfm_modulator_bit_exact(qrl_ctx, modem, fw, chunk):
+    import torch
+    import qradiolink_amd as q
+    n = 8000
+    t = np.arange(n) / 8000.0
+    audio = np.stack([0.5 * np.sin(2 * np.pi * 700 * t) + 0.2 * np.sin(2 * np.pi * 1900 * t),
+                      np.random.default_rng(3).uniform(-0.7, 0.7, n)]).astype(np.float32)
+    mod = q.AMod(qrl_ctx, modem, batch=2, max_samples=chunk, bb_gain=0.75)
+    parts = [mod.process(torch.from_numpy(np.ascontiguousarray(audio[:, s:s + chunk])).cuda()).cpu().numpy() for s in range(0, n, chunk)]
+    mod.close()
+    got = np.concatenate(parts, axis=1)
+    assert got.shape == (2, 125 * n)
+    for b in range(2):
+        want = orc.mod_nbfm(audio[b], filter_width=fw, bb_gain=0.75)
+        g, w = got[b].view(np.float32) + np.float32(0), want.view(np.float32) + np.float32(0)
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), "stream %d differs" % b
+
+
+def test_nbfm_voice_loopback_on_gpu(qrl_ctx):
+    """gr_mod_nbfm -> (level) -> gr_demod_nbfm, both on the device: the tone that went in comes out"""
+    import torch
+    import qradiolink_amd as q
+    n = 8000
+    audio = (0.5 * np.sin(2 * np.pi * 700 * np.arange(n) / 8000.0)).astype(np.float32)
+    mod = q.AMod(qrl_ctx, q.MODEM_NBFM5000, batch=1, max_samples=n)
+    iq = mod.process(torch.from_numpy(audio[None, :]).cuda()) * 0.05
+    mod.close()
+    dem = q.Demod(qrl_ctx, q.MODEM_NBFM5000, batch=1, max_chunk=iq.shape[1])
+    out = q.collect(dem, iq.contiguous(), iq.shape[1])
+    dem.close()
+    a = out["audio"][0][2000:7000].astype(np.float64)
+    spec = np.abs(np.fft.rfft(a * np.hanning(a.size)))
+    assert abs(np.argmax(spec) * 8000.0 / a.size - 700.0) < 3.0 and np.sqrt(np.mean(a ** 2)) > 0.3
+    with pytest.raises(q.QrlError):
+        q.AMod(qrl_ctx, q.MODEM_AM5000, batch=1, max_samples=64)          # AM / SSB modulators are not built

@@ -72,6 +72,20 @@ def test_analog_rx_block_audio_mailbox(tmp_path, kind, fw):
 
 
 @pytest.mark.gpu
+def test_nbfm_tx_block_matches_oracle(tmp_path):
+    """make_gr_mod_nbfm-shaped block: f32 audio in ragged work() calls (the odd samples wait for their group of 4), cf32 out"""
+    n = 6000
+    audio = (0.5 * np.sin(2 * np.pi * 700 * np.arange(n) / 8000.0)).astype(np.float32)
+    (tmp_path / "a.bin").write_bytes(audio.tobytes())
+    r = subprocess.run([EXE, "txa", "5000", str(tmp_path / "a.bin"), str(tmp_path / "iq.bin")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(tmp_path / "iq.bin", np.complex64)
+    want = orc.mod_nbfm(audio, filter_width=5000, bb_gain=0.75)
+    assert got.size == want.size == 125 * n
+    assert np.array_equal((got.view(np.float32) + np.float32(0)).view(np.uint32), (want.view(np.float32) + np.float32(0)).view(np.uint32))
+
+
+@pytest.mark.gpu
 def test_tx_block_matches_oracle(tmp_path):
     data = np.random.default_rng(3).integers(0, 256, 20000, dtype=np.uint8)
     (tmp_path / "bytes.bin").write_bytes(data.tobytes())

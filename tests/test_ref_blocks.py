@@ -114,6 +114,10 @@ def test_deemphasis_taps_equal_the_reference_function(ref):
         ref.ref_deemph_taps(fs, C.c_double(50e-6), a, b)
         oa, ob = orc.deemph_taps(fs, 50e-6)
         assert list(a) == oa and list(b) == ob          # bit-identical doubles
+    a, b = (C.c_double * 2)(), (C.c_double * 2)()
+    ref.ref_preemph_taps(8000, C.c_double(50e-6), a, b)      # gr_mod_nbfm's pre-emphasis (default upper corner)
+    oa, ob = orc.preemph_taps(8000, 50e-6)
+    assert list(a) == oa and list(b) == ob
 
 
 def test_zero_idle_bursts_oracle_equals_the_reference_block(ref):
