@@ -366,10 +366,10 @@ uint64_t qrl_phase_inc_to_turn(double radians_per_sample);
  * src/gr/gr_mod_nbfm.cpp:19-77, instances gr_mod_base.cpp:171-172) for `batch` independent radios.  audio: device f32 at 8 ksps,
  * stream b at audio + b * stride, n samples per call (a multiple of 4, <= max_samples); iq: device cf32 at 1 Msps, stream b at
  * iq + 2 * b * out_stride floats, n * qrl_amod_samples_per_sample() (= 125 n) samples.  Asynchronous on the handle's stream;
- * results are independent of how the audio is cut into calls.  (AM / SSB modulators, CTCSS: not built.) */
+ * results are independent of how the audio is cut into calls.  (AM modulator, CTCSS: not built.) */
 typedef struct qrl_amod qrl_amod;
 typedef struct qrl_amod_config {
-    int modem_type;        /* QRL_MODEM_NBFM2500 | QRL_MODEM_NBFM5000 */
+    int modem_type;        /* QRL_MODEM_NBFM2500 | QRL_MODEM_NBFM5000 | QRL_MODEM_USB2500 | QRL_MODEM_LSB2500 */
     int batch;
     size_t max_samples;    /* audio samples per stream and call */
     void* hip_stream;      /* hipStream_t or NULL (own stream) */
@@ -380,6 +380,12 @@ void qrl_amod_destroy(qrl_amod* m);
 int qrl_amod_reset(qrl_amod* m);
 int qrl_amod_set_bb_gain(qrl_amod* m, float value);
 size_t qrl_amod_samples_per_sample(const qrl_amod* m);
+/* SSB (replaces make_gr_mod_ssb(125, 1000000, 1700, 2700, sb), reference src/gr/gr_mod_ssb.cpp:19-82, gr_mod_base.cpp:178-179): the
+ * cessb stretcher emits whole chunks of 1024 audio-rate items and looks two items ahead, so a call returns 125 x (chunks completed
+ * by it) samples -- any n is accepted; qrl_amod_last_count = IQ samples per stream the last call wrote, qrl_amod_out_cap(n) = the
+ * bound for a call of n audio samples (what out_stride must hold).  NBFM: both are 125 n. */
+size_t qrl_amod_last_count(const qrl_amod* m);
+size_t qrl_amod_out_cap(const qrl_amod* m, size_t n);
 int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, float* iq, size_t out_stride);
 int qrl_amod_sync(qrl_amod* m);
 void* qrl_amod_stream(qrl_amod* m);

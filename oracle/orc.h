@@ -196,6 +196,7 @@ void   orc_cessb_clipper(const cf32* in, size_t n, float clip, cf32* out);
 size_t orc_cessb_stretcher(const cf32* in, size_t n, cf32* out);
 void   orc_demod_ssb(const cf32* in, size_t n, int samp_rate, int filter_width, int sb /* 0 USB, 1 LSB */,
                      cf32** filtered, size_t* n_filtered, float** audio, size_t* n_audio);
+size_t orc_mod_ssb(const float* audio, size_t n, int sps, int samp_rate, int filter_width, int sb, float bb_gain, cf32* out);   /* out NULL: count */
 void   orc_free(void* p);
 /* frame FEC of the DMR / M17 stacks (orc_framefec.c; PINNED against the real reference sources through oracle/_ref) */
 void     orc_bptc19696_decode(const uint8_t* in33, uint8_t* out12);

@@ -295,4 +295,40 @@ void orc_demod_ssb(const cf32* in, size_t n, int samp_rate, int filter_width, in
     *audio = out; *n_audio = ns;
 }
 
+/* gr_mod_ssb(sps = 125, 1000000, ., filter_width, sb) (reference src/gr/gr_mod_ssb.cpp:26-82, instances gr_mod_base.cpp:178-179):
+ * audio at 8 ksps -> fft_filter_fff(band_pass_2(1, 8000, 300, fw, 200, 90, BH)) -> float_to_complex -> cessb clipper(0.95) -> stretcher
+ * -> fft_filter_ccc(complex_band_pass_2(1, 8000, 200, fw | -fw, -200, 200, 90, BH)) -> x0.9 -> x bb_gain ->
+ * rational_resampler_ccf(125, 1, low_pass_2(125, 1e6, fw, fw, 90, BH)).  The stretcher emits whole chunks of 1024 and reads two
+ * items ahead: n audio samples give 125 * 1024 floor((n - 2) / 1024) IQ samples. */
+size_t orc_mod_ssb(const float* audio, size_t n, int sps, int samp_rate, int filter_width, int sb, float bb_gain, cf32* out)
+{
+    const size_t ns = n >= 2 ? 1024 * ((n - 2) / 1024) : 0;
+    if (!out) return ns * (size_t)sps;
+    int na = orc_band_pass_2(1, 8000, 300, filter_width, 200, 90, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* at = NEW(float, na);
+    orc_band_pass_2(1, 8000, 300, filter_width, 200, 90, ORC_WIN_BLACKMAN_HARRIS, at);
+    float* a1 = NEW(float, n);
+    orc_fir_fff(audio, n, at, na, a1);                                       /* _audio_filter */
+    free(at);
+    cf32* c = NEW(cf32, n);
+    for (size_t i = 0; i < n; i++) { c[i].re = a1[i]; c[i].im = 0.0f; }      /* _float_to_complex */
+    free(a1);
+    cf32* d = NEW(cf32, n);
+    orc_cessb_clipper(c, n, 0.95f, d);                                       /* _clipper */
+    orc_cessb_stretcher(d, n, c);                                            /* _stretcher: ns items */
+    const double lo = sb ? -filter_width : 200, hi = sb ? -200 : filter_width;
+    int nf = orc_complex_band_pass_2(1, 8000, lo, hi, 200, 90, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    cf32* ft = NEW(cf32, nf);
+    orc_complex_band_pass_2(1, 8000, lo, hi, 200, 90, ORC_WIN_BLACKMAN_HARRIS, ft);
+    orc_fir_ccc(c, ns, ft, nf, d);                                           /* _filter_usb / _filter_lsb */
+    free(ft); free(c);
+    for (size_t i = 0; i < ns; i++) { d[i].re *= 0.9f; d[i].im *= 0.9f; d[i].re *= bb_gain; d[i].im *= bb_gain; }   /* _amplify, _bb_gain */
+    int nt = orc_low_pass_2(sps, samp_rate, filter_width, filter_width, 90, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* lp = NEW(float, nt);
+    orc_low_pass_2(sps, samp_rate, filter_width, filter_width, 90, ORC_WIN_BLACKMAN_HARRIS, lp);
+    const size_t m = orc_resamp_ccf(d, ns, lp, nt, sps, 1, out);             /* _resampler */
+    free(lp); free(d);
+    return m;
+}
+
 void orc_free(void* p) { free(p); }

@@ -106,6 +106,10 @@ def load_library():
     lib.qrl_amod_set_bb_gain.argtypes = [vp, C.c_float]
     lib.qrl_amod_samples_per_sample.argtypes = [vp]
     lib.qrl_amod_samples_per_sample.restype = sz
+    lib.qrl_amod_last_count.argtypes = [vp]
+    lib.qrl_amod_last_count.restype = sz
+    lib.qrl_amod_out_cap.argtypes = [vp, sz]
+    lib.qrl_amod_out_cap.restype = sz
     lib.qrl_amod_process.argtypes = [vp, vp, sz, sz, vp, sz]
     lib.qrl_amod_sync.argtypes = [vp]
     lib.qrl_amod_stream.argtypes = [vp]
@@ -197,7 +201,7 @@ EXPORTED_SYMBOLS = [
     "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_set_option", "qrl_demod_set_dmo_output", "qrl_demod_stream_wait", "qrl_demod_out_caps",
     "qrl_demod_audio_cap", "qrl_demod_set_squelch", "qrl_demod_set_agc",
     "qrl_bptc19696_decode", "qrl_bptc19696_encode", "qrl_m17_decode_frames",
-    "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_samples_per_sample", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
+    "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
     "qrl_mod_samples_per_byte", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_create",
@@ -724,8 +728,9 @@ class Mod:
 
 
 class AMod:
-    """Batch analogue voice modulator: mirrors make_gr_mod_nbfm (src/gr/gr_mod_nbfm.cpp:19-77).  process(audio) takes a float32
-    cuda tensor [batch, n] (8 ksps, n a multiple of 4) and returns complex64 [batch, 125 n] at 1 Msps."""
+    """Batch analogue voice modulator: mirrors make_gr_mod_nbfm (src/gr/gr_mod_nbfm.cpp:19-77) and make_gr_mod_ssb (gr_mod_ssb.cpp:19-82).
+    process(audio) takes a float32 cuda tensor [batch, n] at 8 ksps (NBFM: n a multiple of 4) and returns complex64 at 1 Msps:
+    [batch, 125 n] for NBFM, 125 x the audio items of the 1024-chunks the call completed for SSB."""
 
     def __init__(self, ctx, modem_type, batch, max_samples, bb_gain=1.0):
         import torch
@@ -739,11 +744,11 @@ class AMod:
         t = self.torch
         assert audio.is_cuda and audio.dtype == t.float32 and audio.dim() == 2 and audio.shape[0] == self.batch and audio.stride(1) == 1
         n = audio.shape[1]
-        out = t.zeros((self.batch, n * self.spa), dtype=t.complex64, device=audio.device)
+        out = t.zeros((self.batch, max(self.lib.qrl_amod_out_cap(self.h, n), 1)), dtype=t.complex64, device=audio.device)
         t.cuda.current_stream().synchronize()
         _check(self.lib.qrl_amod_process(self.h, audio.data_ptr(), audio.stride(0), n, out.data_ptr(), out.stride(0)), "qrl_amod_process")
         _check(self.lib.qrl_amod_sync(self.h), "qrl_amod_sync")
-        return out
+        return out[:, :self.lib.qrl_amod_last_count(self.h)]     # SSB: whole chunks of 1024 audio items only (the cessb stretcher)
 
     def set_bb_gain(self, g):
         _check(self.lib.qrl_amod_set_bb_gain(self.h, C.c_float(g)), "qrl_amod_set_bb_gain")

@@ -1,4 +1,6 @@
-// amod.cpp — analogue voice modulator behind the C ABI: gr_mod_nbfm (reference src/gr/gr_mod_nbfm.cpp:26-77, instances
+// amod.cpp — analogue voice modulators behind the C ABI: gr_mod_nbfm, and gr_mod_ssb (reference src/gr/gr_mod_ssb.cpp:26-82, instances
+// gr_mod_base.cpp:178-179: audio filter -> float_to_complex -> cessb clipper -> stretcher -> side-band filter -> gains -> 1:125).
+// gr_mod_nbfm (reference src/gr/gr_mod_nbfm.cpp:26-77, instances
 // make_gr_mod_nbfm(20, 1000000, 1700, 2500 / 5000) src/gr/gr_mod_base.cpp:171-172) for a batch of independent radios.
 //   audio (8 ksps) -> audio filter -> x0.99 -> pre-emphasis (iir_filter_ffd, f64) -> 25:4 -> frequency modulator -> channel filter
 //   -> x0.8 -> x bb_gain -> 1:20 interpolator  = 125 IQ samples (1 Msps) per audio sample.
@@ -41,7 +43,8 @@ struct qrl_amod {
     qrl_ctx* ctx = nullptr;
     qrl_amod_config cfg{};
     hipStream_t stream = nullptr; bool own_stream = false;
-    int sps = 20, fw = 5000;
+    int sps = 20, fw = 5000; bool ssb = false, lsb = false;
+    Dev<float2> t_side, c1, c2, c3; int n_side = 0; Dev<float> atan_tab; uint64_t ns = 0; size_t last = 0;   // SSB
     float bb_gain = 1.0f, fm_k = 0.f;
     Dev<float> t_audio, t_if, t_filt, t_interp; int n_audio = 0, n_if = 0, n_filt = 0, n_interp = 0;
     Dev<float> a0, a1, a2, r50; uint32_t m8 = 0, m50 = 0;       // rings: audio in, filtered, pre-emphasised (8 ksps); 50 ksps
@@ -55,7 +58,8 @@ struct qrl_amod {
         int r;
         for (auto* b : {&a0, &a1, &a2, &r50, &phase}) if ((r = b->zero())) return r;
         if ((r = fmv.zero()) || (r = flt.zero()) || (r = iir.zero())) return r;
-        n8 = n50 = 0;
+        if (c1.p && ((r = c1.zero()) || (r = c2.zero()) || (r = c3.zero()))) return r;
+        n8 = n50 = ns = 0; last = 0;
         return QRL_OK;
     }
 };
@@ -72,12 +76,34 @@ int qrl_amod_create(qrl_ctx* ctx, const qrl_amod_config* cfg, qrl_amod** outp)
     switch (cfg->modem_type) {
     case QRL_MODEM_NBFM2500: m->fw = 2500; break;     // make_gr_mod_nbfm(20, 1000000, 1700, 2500) gr_mod_base.cpp:171
     case QRL_MODEM_NBFM5000: m->fw = 5000; break;     // :172
-    default: return qrl_set_error(QRL_ERR_ARG, "amod: modem_type must be QRL_MODEM_NBFM2500 or QRL_MODEM_NBFM5000");
+    case QRL_MODEM_USB2500: m->ssb = true; m->fw = 2700; m->sps = 125; break;              // make_gr_mod_ssb(125, 1000000, 1700, 2700, 0) :178
+    case QRL_MODEM_LSB2500: m->ssb = m->lsb = true; m->fw = 2700; m->sps = 125; break;     // :179
+    default: return qrl_set_error(QRL_ERR_ARG, "amod: modem_type must be QRL_MODEM_NBFM2500 / NBFM5000 / USB2500 / LSB2500");
     }
     HIPCHK(hipSetDevice(ctx->device));
     if (cfg->hip_stream) m->stream = static_cast<hipStream_t>(cfg->hip_stream);
     else { HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
     const int fw = m->fw, B = cfg->batch;
+    if (m->ssb) {
+        const std::vector<float> ta = band_pass_2(1, 8000, 300, fw, 200, 90, WIN_BLACKMAN_HARRIS);             // _audio_filter, gr_mod_ssb.cpp:43-45
+        const auto ts = m->lsb ? complex_band_pass_2(1, 8000, -fw, -200, 200, 90, WIN_BLACKMAN_HARRIS)           // _filter_lsb, :56-57
+                               : complex_band_pass_2(1, 8000, 200, fw, 200, 90, WIN_BLACKMAN_HARRIS);            // _filter_usb, :54-55
+        const std::vector<float> tr = low_pass_2(m->sps, 1000000, fw, fw, 90, WIN_BLACKMAN_HARRIS);            // _resampler (125, 1), :47-50
+        m->n_audio = (int)ta.size(); m->n_side = (int)ts.size(); m->n_interp = (int)tr.size();
+        if (m->n_interp > 2048) return qrl_set_error(QRL_ERR_ARG, "amod: interpolator filter too long");
+        std::vector<float2> ts2(ts.size());
+        for (size_t i = 0; i < ts.size(); ++i) ts2[i] = make_float2(ts[i].real(), ts[i].imag());
+        int r;
+        if ((r = m->t_audio.upload(ta)) || (r = m->t_side.upload(ts2)) || (r = m->t_interp.upload(tr)) || (r = m->atan_tab.upload(atan_table()))) return r;
+        m->m8 = pow2_at_least(cfg->max_samples + 2048) - 1;        // the stretcher holds back up to 1025 items
+        const size_t r8 = (size_t)B * (m->m8 + 1);
+        if ((r = m->a0.alloc(r8)) || (r = m->a1.alloc(r8)) || (r = m->c1.alloc(r8)) || (r = m->c2.alloc(r8)) || (r = m->c3.alloc(r8))) return r;
+        // (members of the FM chain stay empty)
+        if ((r = m->a2.alloc(1)) || (r = m->r50.alloc(1)) || (r = m->fmv.alloc(1)) || (r = m->flt.alloc(1)) || (r = m->iir.alloc(1)) || (r = m->phase.alloc(1))) return r;
+        if ((r = m->init_state())) return r;
+        *outp = m.release();
+        return QRL_OK;
+    }
     const std::vector<float> ta = low_pass_2(1, 8000, 3500, 200, 35, WIN_BLACKMAN_HARRIS);                 // _audio_filter, gr_mod_nbfm.cpp:43-45
     const std::vector<float> ti = low_pass_2(25, 50000.0 * 4, fw, 3500, 60, WIN_BLACKMAN_HARRIS);          // _if_resampler (25, 4), :49-51
     const std::vector<float> tf = low_pass_2(1, 50000, fw, 3500, 60, WIN_BLACKMAN_HARRIS);                 // _filter, :61-62
@@ -106,7 +132,9 @@ int qrl_amod_reset(qrl_amod* m)
     return m->init_state();
 }
 int qrl_amod_set_bb_gain(qrl_amod* m, float g) { if (!m) return QRL_ERR_ARG; m->bb_gain = g; return QRL_OK; }
-size_t qrl_amod_samples_per_sample(const qrl_amod* m) { return m ? (size_t)25 * m->sps / 4 : 0; }
+size_t qrl_amod_samples_per_sample(const qrl_amod* m) { return m ? (m->ssb ? (size_t)m->sps : (size_t)25 * m->sps / 4) : 0; }
+size_t qrl_amod_last_count(const qrl_amod* m) { return m ? m->last : 0; }
+size_t qrl_amod_out_cap(const qrl_amod* m, size_t n) { return m ? (m->ssb ? (n + 1024) * (size_t)m->sps : n * 25 / 4 * (size_t)m->sps) : 0; }
 void* qrl_amod_stream(qrl_amod* m) { return m ? m->stream : nullptr; }
 int qrl_amod_sync(qrl_amod* m) { if (!m) return QRL_ERR_ARG; HIPCHK(hipStreamSynchronize(m->stream)); return QRL_OK; }
 
@@ -114,11 +142,40 @@ int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, f
 {
     if (!m || (!audio && n) || (!iq && n)) return QRL_ERR_ARG;
     if (n > m->cfg.max_samples) return qrl_set_error(QRL_ERR_TOO_BIG, "n exceeds max_samples");
-    if (n % 4) return qrl_set_error(QRL_ERR_ARG, "amod: audio samples per call must be a multiple of 4 (25:4 resampler)");
+    if (!m->ssb && n % 4) return qrl_set_error(QRL_ERR_ARG, "amod: audio samples per call must be a multiple of 4 (25:4 resampler)");
+    m->last = 0;
     if (n == 0) return QRL_OK;
     HIPCHK(hipSetDevice(m->ctx->device));
     const int B = m->cfg.batch;
     hipStream_t s = m->stream;
+    if (m->ssb) {
+        RingF a0{m->a0.p, m->m8}, a1{m->a1.p, m->m8};
+        RingC c1{m->c1.p, m->m8}, c2{m->c2.p, m->m8}, c3{m->c3.p, m->m8};
+        const uint32_t c8 = (uint32_t)n;
+        const uint64_t n8_1 = m->n8 + n;
+        const uint64_t ns_1 = n8_1 >= 2 ? 1024 * ((n8_1 - 2) / 1024) : 0;        // stretcher: whole chunks, two items of look-ahead
+        const uint32_t cs = (uint32_t)(ns_1 - m->ns);
+        if ((size_t)cs * m->sps > out_stride && B > 1) return qrl_set_error(QRL_ERR_ARG, "amod: out_stride smaller than this call's output (qrl_amod_out_cap)");
+        AmLoadParams lp{}; lp.in = audio; lp.in_stride = stride; lp.out = a0; lp.n0 = m->n8; lp.count = c8;
+        launch_am_load(lp, B, s);
+        FirFffParams af{}; af.in = a0; af.out = a1; af.q0 = m->n8; af.count = c8; af.taps = m->t_audio.p; af.nt = m->n_audio;
+        launch_fir_fff(af, B, s);                                                   // _audio_filter
+        AmClipParams cp{}; cp.in = a1; cp.out = c1; cp.n0 = m->n8; cp.count = c8; cp.clip = 0.95f; cp.atan_tab = m->atan_tab.p;
+        launch_am_clip(cp, B, s);                                                   // _float_to_complex, _clipper
+        AmStretchParams sp{}; sp.in = c1; sp.out = c2; sp.q0 = m->ns; sp.count = cs;
+        launch_am_stretch(sp, B, s);                                                // _stretcher
+        FirCccParams ff{}; ff.in = c2; ff.out = c3; ff.q0 = m->ns; ff.count = cs; ff.taps = m->t_side.p; ff.nt = m->n_side;
+        launch_an_fir_ccc(ff, B, s);                                                // _filter_usb / _filter_lsb
+        launch_scale_c(c3, m->ns, cs, 0.9f, B, s);                                  // _amplify
+        launch_scale_c(c3, m->ns, cs, m->bb_gain, B, s);                            // _bb_gain
+        TxInterpCParams xp{}; xp.in = c3; xp.n0 = m->ns * (uint64_t)m->sps; xp.count = cs * (uint32_t)m->sps;
+        xp.taps = m->t_interp.p; xp.nt = m->n_interp; xp.interp = m->sps; xp.out = reinterpret_cast<float2*>(iq); xp.out_stride = out_stride;
+        if (xp.count) launch_tx_interp_c(xp, B, s);                                 // _resampler
+        HIPCHK(hipGetLastError());
+        if (qrl::take_launch_error()) return QRL_ERR_HIP;
+        m->n8 = n8_1; m->ns = ns_1; m->last = (size_t)cs * m->sps;
+        return QRL_OK;
+    }
     RingF a0{m->a0.p, m->m8}, a1{m->a1.p, m->m8}, a2{m->a2.p, m->m8}, r50{m->r50.p, m->m50};
     RingC fmv{m->fmv.p, m->m50}, flt{m->flt.p, m->m50};
     const uint32_t c8 = (uint32_t)n, c50 = (uint32_t)(n * 25 / 4);
@@ -143,7 +200,7 @@ int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, f
     launch_tx_interp_c(xp, B, s);                                                   // _resampler
     HIPCHK(hipGetLastError());
     if (qrl::take_launch_error()) return QRL_ERR_HIP;
-    m->n8 += c8; m->n50 += c50;
+    m->n8 += c8; m->n50 += c50; m->last = (size_t)c50 * m->sps;
     return QRL_OK;
 }
 

@@ -282,6 +282,11 @@ void launch_am_load(const AmLoadParams& p, int batch, hipStream_t s);
 struct AmIirState { double y1; float x1, pad; };
 struct AmIirParams { RingF in, out; uint64_t n0; uint32_t count; float gain; double ff0, ff1, fb1; AmIirState* st; };
 void launch_am_iir(const AmIirParams& p, int batch, hipStream_t s);
+// gr_mod_ssb: float_to_complex + cessb clipper (f32 ring -> complex ring), cessb stretcher with complex output over [q0, q0 + count)
+struct AmClipParams { RingF in; RingC out; uint64_t n0; uint32_t count; float clip; const float* atan_tab; };
+void launch_am_clip(const AmClipParams& p, int batch, hipStream_t s);
+struct AmStretchParams { RingC in, out; uint64_t q0; uint32_t count; };
+void launch_am_stretch(const AmStretchParams& p, int batch, hipStream_t s);
 struct AnStretchParams { RingC in; RingF out; const AnState* st; float level; };
 void launch_an_stretch(const AnStretchParams& p, uint32_t max_out, int batch, hipStream_t s);
 

@@ -305,4 +305,55 @@ void launch_am_iir(const AmIirParams& p, int batch, hipStream_t s)
     hipLaunchKernelGGL(k_am_iir, dim3((batch + 63) / 64), dim3(64), 0, s, p, batch);
 }
 
+// gr_mod_ssb (reference src/gr/gr_mod_ssb.cpp:26-82): float_to_complex -> cessb::clipper_cc(0.95), item by item
+__global__ __launch_bounds__(256) void k_am_clip(const AmClipParams P)
+{
+    __shared__ float T[257];
+    for (int k = threadIdx.x; k < 257; k += 256) T[k] = P.atan_tab[k];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.count) return;
+    const uint32_t n = (uint32_t)(P.n0 + t);
+    const float re = P.in.p[(size_t)b * (P.in.mask + 1u) + (n & P.in.mask)], im = 0.0f;
+    const float mag = sqrtf(re * re + im * im);
+    const float ph = fast_atan2f_lut(im, re, T);
+    const float c = mag < P.clip ? mag : P.clip;
+    const float2 sc = sincos_rad(ph);
+    P.out.p[(size_t)b * (P.out.mask + 1u) + (n & P.out.mask)] = make_float2(sc.x * c, sc.y * c);
+}
+void launch_am_clip(const AmClipParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_am_clip, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
+}
+// cessb::stretcher_cc with its complex output (TX side): item q / h, h from the five-point envelope around q
+__global__ __launch_bounds__(256) void k_am_stretch(const AmStretchParams P)
+{
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.count) return;
+    const uint64_t q = P.q0 + t;
+    const float emax = (float)(1 / (sqrt(0.5) / 2));
+    float e = 0.0f;
+#pragma unroll
+    for (int j = -2; j <= 2; ++j) {
+        const float2 x = an_ringc_at(P.in, b, (int64_t)q + j);
+        const float m = sqrtf(x.x * x.x + x.y * x.y);
+        e = m > e ? m : e;
+    }
+    float h = e * emax;
+    h = h > 1.0f ? h : 1.0f;
+    h = h - 1.0f;
+    h = h * 2.0f;
+    h = h + 1.0f;
+    const float2 x = an_ringc_at(P.in, b, (int64_t)q);
+    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)q & P.out.mask)] = make_float2(x.x / h, x.y / h);
+}
+void launch_am_stretch(const AmStretchParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_am_stretch, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
+}
+
 }  // namespace qrl

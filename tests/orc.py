@@ -659,6 +659,16 @@ def mod_nbfm(audio, sps=20, samp_rate=1000000, filter_width=5000, bb_gain=1.0):
     return y[:m]
 
 
+def mod_ssb(audio, sb=0, sps=125, samp_rate=1000000, filter_width=2700, bb_gain=1.0):
+    audio = np.ascontiguousarray(audio, np.float32)
+    lib.orc_mod_ssb.restype = C.c_size_t
+    args = (_ptr(audio), C.c_size_t(audio.size), sps, samp_rate, filter_width, sb, C.c_float(bb_gain))
+    n = lib.orc_mod_ssb(*args, None)
+    y = np.zeros(max(n, 1), cf32)
+    m = lib.orc_mod_ssb(*args, _ptr(y)) if n else 0
+    return y[:m]
+
+
 def preemph_taps(sample_rate, tau=50e-6):
     a, b = (C.c_double * 2)(), (C.c_double * 2)()
     lib.orc_preemph_taps(sample_rate, C.c_double(tau), a, b)

@@ -295,4 +295,47 @@ def test_nbfm_voice_loopback_on_gpu(qrl_ctx):
     spec = np.abs(np.fft.rfft(a * np.hanning(a.size)))
     assert abs(np.argmax(spec) * 8000.0 / a.size - 700.0) < 3.0 and np.sqrt(np.mean(a ** 2)) > 0.3
     with pytest.raises(q.QrlError):
-        q.AMod(qrl_ctx, q.MODEM_AM5000, batch=1, max_samples=64)          # AM / SSB modulators are not built
+        q.AMod(qrl_ctx, q.MODEM_AM5000, batch=1, max_samples=64)          # the AM modulator is not built
+
+
+@pytest.mark.parametrize("modem,sb", [(11, 0), (12, 1)])
+@pytest.mark.parametrize("chunk", [1 << 14, 1024, 1000, 333])
+def test_ssb_modulator_bit_exact(qrl_ctx, modem, sb, chunk):
+    """gr_mod_ssb: audio band-pass, cessb clipper + stretcher (whole 1024-chunks, two items of look-ahead), side-band filter, 1:125"""
+    import torch
+    import qradiolink_amd as q
+    n = 5 * 1024 + 700
+    t = np.arange(n) / 8000.0
+    audio = np.stack([0.9 * np.sin(2 * np.pi * 700 * t) + 0.5 * np.sin(2 * np.pi * 1500 * t),      # loud enough for the clipper to act
+                      np.random.default_rng(4).uniform(-1.2, 1.2, n)]).astype(np.float32)
+    mod = q.AMod(qrl_ctx, modem, batch=2, max_samples=min(chunk, n), bb_gain=0.8)
+    parts = [mod.process(torch.from_numpy(np.ascontiguousarray(audio[:, s:s + chunk])).cuda()).cpu().numpy() for s in range(0, n, chunk)]
+    mod.close()
+    got = np.concatenate(parts, axis=1)
+    assert got.shape == (2, 125 * 5 * 1024)
+    for b in range(2):
+        want = orc.mod_ssb(audio[b], sb=sb, bb_gain=0.8)
+        g, w = got[b].view(np.float32) + np.float32(0), want.view(np.float32) + np.float32(0)
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), "stream %d differs" % b
+
+
+def test_ssb_voice_loopback_on_gpu(qrl_ctx):
+    import torch
+    import qradiolink_amd as q
+    n = 8192 + 2
+    audio = (0.4 * np.sin(2 * np.pi * 700 * np.arange(n) / 8000.0)).astype(np.float32)
+    mod = q.AMod(qrl_ctx, q.MODEM_LSB2500, batch=1, max_samples=n)
+    iq = mod.process(torch.from_numpy(audio[None, :]).cuda()) * 0.5
+    mod.close()
+    assert iq.shape[1] == 125 * 8192
+    rms = {}
+    for modem in (q.MODEM_LSB2500, q.MODEM_USB2500):
+        dem = q.Demod(qrl_ctx, modem, batch=1, max_chunk=iq.shape[1])
+        out = q.collect(dem, iq.contiguous(), iq.shape[1])
+        dem.close()
+        a = out["audio"][0][2048:6144].astype(np.float64)
+        rms[modem] = np.sqrt(np.mean(a ** 2)) if a.size else 0.0      # (the other side band may even fall under the -140 dB gate)
+        if modem == q.MODEM_LSB2500:
+            spec = np.abs(np.fft.rfft(a * np.hanning(a.size)))
+            assert abs(np.argmax(spec) * 8000.0 / a.size - 700.0) < 3.0
+    assert rms[q.MODEM_USB2500] < 0.02 * rms[q.MODEM_LSB2500]
