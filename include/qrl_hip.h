@@ -180,7 +180,11 @@ int qrl_mod_set_bb_gain(qrl_mod* m, float value);
 /* replaces: gr_mod_base::set_carrier_offset -> rotator_cc::set_phase_inc (src/gr/gr_mod_base.cpp:799-805); phase-continuous.
  * Only for handles created with the back end (device_samp_rate >= 2e6 or a non-zero initial offset). */
 int qrl_mod_set_carrier_offset(qrl_mod* m, double hz);
-size_t qrl_mod_samples_per_byte(const qrl_mod* m);   /* at the DEVICE rate: 8*sps (QPSK) or 16*sps*interp (FSK), times fs/1e6 */
+size_t qrl_mod_samples_per_byte(const qrl_mod* m);
+/* QRL_MODEM_M17 (replaces make_gr_mod_m17(), reference src/gr/gr_mod_m17.cpp:19-81, gr_mod_base.cpp:206): its 125 / 3 output resampler
+ * makes 833 1/3 samples per byte, so calls take multiples of 3 bytes (an M17 frame is 48) and return 2500 samples per 3 bytes;
+ * qrl_mod_samples_per_byte is 0 for it.  Other modes: bytes_per_block 1, the value of qrl_mod_samples_per_byte. */
+size_t qrl_mod_samples_per_block(const qrl_mod* m, size_t* bytes_per_block);   /* at the DEVICE rate: 8*sps (QPSK) or 16*sps*interp (FSK), times fs/1e6 */
 /* replaces: gr_mod_base::set_data (src/gr/gr_mod_base.cpp:783-786) + gr_byte_source::work (src/gr/gr_byte_source.cpp:75-106)
  * + one scheduler pass of every block of gr_mod_qpsk: bytes[b*stride + i], i < nbytes (device, packed, MSB first) ->
  * iq[2*(b*out_stride + k)], k < nbytes*8*sps (device cf32).  State (scrambler, encoder, differential symbol, pulse-shaping

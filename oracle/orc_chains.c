@@ -616,6 +616,45 @@ size_t orc_mod_4fsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate,
     return m;
 }
 
+/* gr_mod_m17 (reference src/gr/gr_mod_m17.cpp:26-81, instance make_gr_mod_m17() gr_mod_base.cpp:206 with the defaults of gr_mod_m17.h:43-44:
+ * sps 125, 1 Msps, filter width 9000): bytes -> dibits (MSB first) -> map{2, 3, 1, 0} -> {-1.5, -0.5, 0.5, 1.5} ->
+ * rational_resampler_fff(5, 1, RRC(5, 5, 1, 0.5, 250)) -> x0.66666666 -> frequency_modulator_fc(pi / 5) ->
+ * fft_filter_ccf(low_pass(1, 24000, fw, fw, BH)) -> x0.9 -> x bb_gain -> rational_resampler_ccf(125, 3, low_pass(125, 3e6, 12000, 12000, BH)).
+ * 2500 samples per 3 bytes. */
+size_t orc_mod_m17(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int filter_width, float bb_gain, cf32* out)
+{
+    const size_t ns = nbytes * 4, n24 = ns * 5, nout = orc_decim_count(n24, sps, 3);
+    if (!out) return nout;
+    static const int map[4] = {2, 3, 1, 0};
+    static const float levels[4] = {-1.5f, -0.5f, 0.5f, 1.5f};
+    float* sym = NEW(float, ns);
+    for (size_t i = 0; i < ns; i++) sym[i] = levels[map[(bytes[i >> 2] >> (6 - 2 * (i & 3))) & 3]];
+    int nr = orc_root_raised_cosine(5, 5, 1, 0.5, 250, NULL);
+    float* rrc = NEW(float, nr);
+    orc_root_raised_cosine(5, 5, 1, 0.5, 250, rrc);
+    float* shaped = NEW(float, n24);
+    orc_resamp_fff(sym, ns, rrc, nr, 5, 1, shaped);                              /* _first_resampler */
+    free(rrc); free(sym);
+    const float sc = (float)0.66666666;
+    for (size_t i = 0; i < n24; i++) shaped[i] = shaped[i] * sc;                 /* _scale_pulses */
+    cf32* fmv = NEW(cf32, n24);
+    fm_mod(shaped, n24, (float)(M_PI / 5), fmv);                                 /* _fm_modulator */
+    free(shaped);
+    int nf = orc_low_pass(1, 24000, filter_width, filter_width, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* ft = NEW(float, nf);
+    orc_low_pass(1, 24000, filter_width, filter_width, ORC_WIN_BLACKMAN_HARRIS, ft);
+    cf32* g = NEW(cf32, n24);
+    orc_fir_ccf(fmv, n24, ft, nf, g);                                            /* _filter */
+    free(ft); free(fmv);
+    for (size_t i = 0; i < n24; i++) { g[i].re *= 0.9f; g[i].im *= 0.9f; g[i].re *= bb_gain; g[i].im *= bb_gain; }   /* _amplify, _bb_gain */
+    int nt = orc_low_pass(sps, (double)samp_rate * 3, 12000, 12000, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* lp = NEW(float, nt);
+    orc_low_pass(sps, (double)samp_rate * 3, 12000, 12000, ORC_WIN_BLACKMAN_HARRIS, lp);
+    const size_t m = orc_resamp_ccf(g, n24, lp, nt, sps, 3, out);                /* _resampler (125, 3) */
+    free(lp); free(g);
+    return m;
+}
+
 /* gr_mod_bpsk.cpp:28-67 (instances gr_mod_base.cpp:168-169: sps 500 / 250) */
 size_t orc_mod_bpsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, cf32* out)
 {

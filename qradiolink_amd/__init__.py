@@ -99,6 +99,8 @@ def load_library():
     lib.qrl_demod_set_dmo_output.argtypes = [vp, vp, sz, vp]
     lib.qrl_demod_out_caps.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     lib.qrl_demod_audio_cap.argtypes = [vp, sz, C.POINTER(sz)]
+    lib.qrl_mod_samples_per_block.argtypes = [vp, C.POINTER(sz)]
+    lib.qrl_mod_samples_per_block.restype = sz
     lib.qrl_amod_create.argtypes = [vp, vp, C.POINTER(vp)]
     lib.qrl_amod_destroy.argtypes = [vp]
     lib.qrl_amod_destroy.restype = None
@@ -204,7 +206,7 @@ EXPORTED_SYMBOLS = [
     "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
-    "qrl_mod_samples_per_byte", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_create",
+    "qrl_mod_samples_per_byte", "qrl_mod_samples_per_block", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_create",
     "qrl_chan_destroy", "qrl_chan_reset", "qrl_chan_set_level", "qrl_chan_calibrate_rssi", "qrl_chan_set_rssi_output", "qrl_chan_set_4fsk_output", "qrl_chan_out_cap", "qrl_chan_process", "qrl_chan_sync",
     "qrl_synth_create", "qrl_synth_destroy", "qrl_synth_reset", "qrl_synth_set_bb_gain", "qrl_synth_add_zero_runs", "qrl_synth_out_cap", "qrl_synth_process",
     "qrl_synth_sync",
@@ -692,13 +694,16 @@ class Mod:
         self.h = C.c_void_p()
         _check(self.lib.qrl_mod_create(ctx.h, C.byref(cfg), C.byref(self.h)), "qrl_mod_create")
         self.spb = self.lib.qrl_mod_samples_per_byte(self.h)
+        bpb = C.c_size_t()
+        self.spblock = self.lib.qrl_mod_samples_per_block(self.h, C.byref(bpb))   # M17: 2500 samples per 3 bytes (spb = 0)
+        self.bytes_per_block = bpb.value
 
     def process_async(self, data, out=None):
         assert data.is_cuda and data.dtype == self.torch.uint8 and data.dim() == 2 and data.shape[0] == self.batch
         assert data.stride(1) == 1
         n = data.shape[1]
         if out is None:
-            out = self.torch.empty((self.batch, n * self.spb), dtype=self.torch.complex64, device=data.device)
+            out = self.torch.empty((self.batch, n // self.bytes_per_block * self.spblock), dtype=self.torch.complex64, device=data.device)
         self.torch.cuda.current_stream().synchronize()
         _check(self.lib.qrl_mod_process(self.h, data.data_ptr(), data.stride(0), n, out.data_ptr(), out.stride(0)),
                "qrl_mod_process")

@@ -237,7 +237,9 @@ struct TxInterpParams {
 struct TxShapeParams { RingB sym; RingF out; uint64_t n0; uint32_t count; int sps; const float* taps; int nt;   // nt = 0: repeat
                        int levels; float scale; };   // levels 2 | 4; scale 0 = none
 struct TxFmParams { RingF in; RingC out; uint64_t n0; uint32_t count; float k, amp; float* phase; };
-struct TxInterpCParams { RingC in; uint64_t n0; uint32_t count; const float* taps; int nt; int interp; float2* out; size_t out_stride; };
+struct TxInterpCParams { RingC in; uint64_t n0; uint32_t count; const float* taps; int nt; int interp; float2* out; size_t out_stride;
+                         int decim; };   // decim > 1: rational_resampler_ccf(interp, decim) (gr_mod_m17: 125 / 3)
+void launch_tx_raw_dibits(const uint8_t* bytes, size_t stride, uint32_t nbytes, RingB sym, uint64_t s0, int batch, hipStream_t s);
 struct TxRotParams { const float2* in; size_t in_stride; uint64_t n0; uint32_t count; uint64_t rot_acc, rot_inc, rot_nbase; const float2* rot_lo;
                      RingC out_ring; float2* out; size_t out_stride; };
 void launch_tx_rot(const TxRotParams& p, int batch, hipStream_t s);

@@ -320,8 +320,9 @@ __global__ __launch_bounds__(256) void k_tx_interp_c(const TxInterpCParams P)
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= P.count) return;
     const uint64_t n = P.n0 + t;
-    const uint64_t c = n / (uint64_t)P.interp;
-    const int ph = (int)(n - c * (uint64_t)P.interp);
+    const uint64_t u = n * (uint64_t)(P.decim > 1 ? P.decim : 1);         // rational_resampler_ccf(interp, decim): output n sits at u / interp
+    const uint64_t c = u / (uint64_t)P.interp;
+    const int ph = (int)(u - c * (uint64_t)P.interp);
     const float2* ring = P.in.p + (size_t)b * (P.in.mask + 1u);
     float ar = 0.f, ai = 0.f;
     for (int j = 0; ph + j * P.interp < P.nt; ++j) {
@@ -332,6 +333,22 @@ __global__ __launch_bounds__(256) void k_tx_interp_c(const TxInterpCParams P)
         ai = fmaf(h, x.y, ai);
     }
     P.out[(size_t)b * P.out_stride + t] = make_float2(ar, ai);
+}
+// gr_mod_m17 (reference src/gr/gr_mod_m17.cpp:47-58,77-80): packed_to_unpacked(1, MSB) -> pack_k_bits(2) -> map{2, 3, 1, 0}: four symbol
+// indices per byte, no scrambler / FEC (the M17 frame encoder has already done that)
+__global__ __launch_bounds__(256) void k_tx_raw_dibits(const uint8_t* __restrict__ bytes, size_t stride, uint32_t nbytes, RingB sym, uint64_t s0)
+{
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= nbytes * 4u) return;
+    const uint32_t v = (bytes[(size_t)b * stride + (t >> 2)] >> (6u - 2u * (t & 3u))) & 3u;
+    const uint32_t map = (0x1Eu >> (2u * v)) & 3u;                       // {2, 3, 1, 0}
+    sym.p[(size_t)b * (sym.mask + 1u) + ((uint32_t)(s0 + t) & sym.mask)] = (uint8_t)map;
+}
+void launch_tx_raw_dibits(const uint8_t* bytes, size_t stride, uint32_t nbytes, RingB sym, uint64_t s0, int batch, hipStream_t s)
+{
+    if (!nbytes) return;
+    hipLaunchKernelGGL(k_tx_raw_dibits, dim3((nbytes * 4u + 255) / 256, batch), dim3(256), 0, s, bytes, stride, nbytes, sym, s0);
 }
 void launch_tx_interp_c(const TxInterpCParams& p, int batch, hipStream_t s)
 {

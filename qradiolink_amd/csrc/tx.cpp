@@ -28,6 +28,8 @@ struct qrl_mod {
     bool own_stream = false;
     enum { F_QPSK, F_FSK } fam = F_QPSK;   // F_QPSK: symbols -> RRC interpolator (QPSK, BPSK); F_FSK: shape -> FM -> interpolator
     bool bpsk = false, fsk4 = false; float shape_scale = 0.0f;
+    // gr_mod_m17: raw dibits -> RRC x5 -> FM -> channel filter -> gains -> 125 / 3 (2500 samples per 3 bytes)
+    bool m17 = false; float* m17_filt = nullptr; int m17_nf = 0; float2* m17_flt = nullptr;
     int sps = 4;
     float bb_gain = 1.0f;
     float* taps = nullptr; int nt = 0;
@@ -50,7 +52,7 @@ struct qrl_mod {
     }
     ~qrl_mod() {
         if (taps) (void)hipFree(taps);
-        for (void* p : {(void*)shape_taps, (void*)shaped, (void*)fmv, (void*)phase}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)shape_taps, (void*)shaped, (void*)fmv, (void*)phase, (void*)m17_filt, (void*)m17_flt}) if (p) (void)hipFree(p);
         if (st) (void)hipFree(st);
         for (void* p : {(void*)be_taps, (void*)bb, (void*)be_ring, (void*)rot_lo}) if (p) (void)hipFree(p);
         if (sym) (void)hipFree(sym);
@@ -65,6 +67,7 @@ struct qrl_mod {
             if (hipMemset(shaped, 0, (size_t)cfg.batch * (r1_mask + 1) * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
             if (hipMemset(fmv, 0, (size_t)cfg.batch * (r1_mask + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
             if (hipMemset(phase, 0, (size_t)cfg.batch * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
+            if (m17_flt && hipMemset(m17_flt, 0, (size_t)cfg.batch * (r1_mask + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
         }
         if (be_ring && hipMemset(be_ring, 0, (size_t)cfg.batch * (be_mask + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
         nsym = 0; n_bb = 0; rot_acc = 0; rot_nbase = 0;
@@ -118,6 +121,7 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
         case QRL_MODEM_4FSK100K:  c.sps = 2;   c.filter_width = 125000; c.fm = 1; break;  // :177
         case QRL_MODEM_BPSK1K:    c.sps = 500; c.filter_width = 1500;  break;             // :168
         case QRL_MODEM_BPSK2K:    c.sps = 250; c.filter_width = 2800;  break;             // :169
+        case QRL_MODEM_M17:       c.sps = 125; c.filter_width = 9000;  break;             // make_gr_mod_m17() :206, defaults gr_mod_m17.h:43-44
         default: return qrl_set_error(QRL_ERR_ARG, "modulator: modem_type not supported by this build");
         }
     }
@@ -127,9 +131,13 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
     case QRL_MODEM_GMSK2K: case QRL_MODEM_GMSK1K: case QRL_MODEM_GMSK10K: fsk = gmsk = true; break;
     case QRL_MODEM_4FSK2K: case QRL_MODEM_4FSK2KFM: case QRL_MODEM_4FSK1KFM: case QRL_MODEM_4FSK10KFM: case QRL_MODEM_4FSK100K: fsk = fsk4 = true; break;
     case QRL_MODEM_BPSK1K: case QRL_MODEM_BPSK2K: bpsk = true; break;
+    case QRL_MODEM_M17: fsk = true; m->m17 = true; break;
     default: return qrl_set_error(QRL_ERR_ARG, "modulator: modem_type not supported by this build");
     }
     m->bpsk = bpsk; m->fsk4 = fsk4;
+    if (m->m17 && c.sps != 125) return qrl_set_error(QRL_ERR_ARG, "modulator: m17 sps must be 125 (rational_resampler_ccf(sps, 3), gr_mod_m17.cpp:64-66)");
+    if (m->m17 && ((c.device_samp_rate != 0 && c.device_samp_rate != 1000000) || c.carrier_offset_hz != 0.0))
+        return qrl_set_error(QRL_ERR_ARG, "modulator: the gr_mod_base back end is not built for m17");
     if (bpsk && (c.sps < 2 || c.sps > 1000)) return qrl_set_error(QRL_ERR_ARG, "modulator: bpsk sps out of range");
     if (!fsk && !bpsk && (c.sps < 2 || c.sps > 1000)) return qrl_set_error(QRL_ERR_ARG, "modulator: qpsk sps out of range");
     m->sps = c.sps;
@@ -156,7 +164,12 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
         m->fam = qrl_mod::F_FSK;
         int sps = c.sps, nfilts;
         std::vector<float> shape;
-        if (gmsk) {   // gr_mod_gmsk.cpp:40-70
+        if (m->m17) {   // gr_mod_m17.cpp:39-70: five samples per symbol at 24 ksps
+            sps = 5; m->interp2 = 1; m->amplif = 1.0f;
+            shape = root_raised_cosine(5, 5, 1, 0.5, 250); m->shape_scale = (float)0.66666666;
+            m->fm_k = (float)(M_PI / 5);
+            m->fsk4 = true;      // four levels per ring item
+        } else if (gmsk) {   // gr_mod_gmsk.cpp:40-70
             nfilts = 35; m->interp2 = 5; m->amplif = 0.9f;
             if (sps == 10) { sps = 50; m->interp2 = 1; nfilts = 55; }
             if (sps == 50) nfilts = 55;
@@ -182,7 +195,8 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
         if (m->nt_shape > 1536) return qrl_set_error(QRL_ERR_ARG, "modulator: shaping filter too long");
         int r0 = upload(shape, &m->shape_taps);
         if (r0) return r0;
-        const std::vector<float> lp = low_pass(m->interp2, c.samp_rate, c.filter_width, c.filter_width, WIN_HAMMING);
+        const std::vector<float> lp = m->m17 ? low_pass(125, (double)c.samp_rate * 3, 12000, 12000, WIN_BLACKMAN_HARRIS)   // _resampler (125, 3), gr_mod_m17.cpp:64-66
+                                             : low_pass(m->interp2, c.samp_rate, c.filter_width, c.filter_width, WIN_HAMMING);
         m->nt = (int)lp.size();
         if (m->nt > 2048) return qrl_set_error(QRL_ERR_ARG, "modulator: interpolator filter too long");
         if ((r0 = upload(lp, &m->taps))) return r0;
@@ -193,6 +207,12 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->shaped), (size_t)c.batch * cap1 * sizeof(float)));
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->fmv), (size_t)c.batch * cap1 * sizeof(float2)));
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->phase), (size_t)c.batch * sizeof(float)));
+        if (m->m17) {
+            const std::vector<float> ft = low_pass(1, 24000, c.filter_width, c.filter_width, WIN_BLACKMAN_HARRIS);   // _filter, gr_mod_m17.cpp:69-70
+            m->m17_nf = (int)ft.size();
+            if ((r0 = upload(ft, &m->m17_filt))) return r0;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->m17_flt), (size_t)c.batch * cap1 * sizeof(float2)));
+        }
     }
     if (c.device_samp_rate != 0 && c.device_samp_rate != 1000000 &&
         (c.device_samp_rate < 2000000 || c.device_samp_rate % 1000000 != 0 || c.device_samp_rate > 64000000))
@@ -243,9 +263,17 @@ int qrl_mod_set_carrier_offset(qrl_mod* m, double hz)
     return m->set_rot(hz);
 }
 int qrl_mod_set_bb_gain(qrl_mod* m, float g) { if (!m) return QRL_ERR_ARG; m->bb_gain = g; return QRL_OK; }
+size_t qrl_mod_samples_per_block(const qrl_mod* m, size_t* bytes_per_block)
+{
+    if (!m) return 0;
+    if (m->m17) { if (bytes_per_block) *bytes_per_block = 3; return 2500; }   // 4 symbols x 5 x 125 / 3 per byte
+    if (bytes_per_block) *bytes_per_block = 1;
+    return qrl_mod_samples_per_byte(m);
+}
 size_t qrl_mod_samples_per_byte(const qrl_mod* m)
 {
     if (!m) return 0;
+    if (m->m17) return 0;   // 833 1/3: see qrl_mod_samples_per_block
     const size_t spb1 = m->fsk4 ? (size_t)8 * m->sps * m->interp2 : m->fam == qrl_mod::F_FSK ? (size_t)16 * m->sps * m->interp2
                                 : (size_t)(m->bpsk ? 16 : 8) * m->sps;
     return spb1 * (size_t)m->be_interp;
@@ -275,6 +303,31 @@ int qrl_mod_process(qrl_mod* m, const uint8_t* bytes, size_t stride, size_t nbyt
         }
         m->n_bb += n1;
     };
+    if (m->m17) {
+        if (nbytes % 3) return qrl_set_error(QRL_ERR_ARG, "modulator: m17 takes multiples of 3 bytes per call (2500 samples per 3 bytes)");
+        const uint32_t nsy = (uint32_t)nbytes * 4, c24 = nsy * 5, cout = c24 / 3 * 125;
+        RingB sym{m->sym, m->sym_mask};
+        launch_tx_raw_dibits(bytes, stride, (uint32_t)nbytes, sym, m->nsym, B, m->stream);
+        const uint64_t n24 = m->nsym * 5;
+        TxShapeParams sp{}; sp.sym = sym; sp.out = RingF{m->shaped, m->r1_mask}; sp.n0 = n24; sp.count = c24; sp.sps = 5;
+        sp.taps = m->shape_taps; sp.nt = m->nt_shape; sp.levels = 4; sp.scale = m->shape_scale;
+        launch_tx_shape(sp, B, m->stream);                                              // _chunks_to_symbols, _first_resampler, _scale_pulses
+        TxFmParams fp{}; fp.in = sp.out; fp.out = RingC{m->fmv, m->r1_mask}; fp.n0 = n24; fp.count = c24; fp.k = m->fm_k; fp.amp = 1.0f;
+        fp.phase = m->phase;
+        launch_tx_fm(fp, B, m->stream);                                                 // _fm_modulator
+        RingC flt{m->m17_flt, m->r1_mask};
+        FirCcfParams cf{}; cf.in = fp.out; cf.out = flt; cf.q0 = n24; cf.count = c24; cf.taps = m->m17_filt; cf.nt = m->m17_nf;
+        launch_fir_ccf(cf, B, m->stream);                                               // _filter
+        launch_scale_c(flt, n24, c24, 0.9f, B, m->stream);                              // _amplify
+        launch_scale_c(flt, n24, c24, m->bb_gain, B, m->stream);                        // _bb_gain
+        TxInterpCParams ip{}; ip.in = flt; ip.n0 = n24 / 3 * 125; ip.count = cout; ip.taps = m->taps; ip.nt = m->nt; ip.interp = 125; ip.decim = 3;
+        ip.out = reinterpret_cast<float2*>(iq); ip.out_stride = out_stride;
+        launch_tx_interp_c(ip, B, m->stream);                                           // _resampler (125, 3)
+        HIPCHK(hipGetLastError());
+        if (qrl::take_launch_error()) return QRL_ERR_HIP;
+        m->nsym += nsy;
+        return QRL_OK;
+    }
     TxBitsParams p{};
     p.bytes = bytes; p.stride = stride; p.nbytes = (uint32_t)nbytes;
     p.L = ((nbits + 63) / 64 + 31) / 32 * 32;

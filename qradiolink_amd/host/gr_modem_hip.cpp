@@ -347,7 +347,8 @@ void gr_mod_base_hip::open()
     c.device_samp_rate = d_rate; c.carrier_offset_hz = d_offset;
     chk(qrl_mod_create(d_rt.ctx(), &c, &d_h), "qrl_mod_create");
     hchk(hipMalloc(reinterpret_cast<void**>(&d_bytes), (size_t)d_n * d_max), "hipMalloc");
-    hchk(hipMalloc(reinterpret_cast<void**>(&d_iq), (size_t)d_n * d_max * qrl_mod_samples_per_byte(d_h) * sizeof(gr_complex)), "hipMalloc");
+    d_spblock = qrl_mod_samples_per_block(d_h, &d_bpb);     // M17: 2500 samples per 3 bytes; every other mode: samples per byte, 1
+    hchk(hipMalloc(reinterpret_cast<void**>(&d_iq), (size_t)d_n * (d_max / d_bpb + 1) * d_spblock * sizeof(gr_complex)), "hipMalloc");
 }
 void gr_mod_base_hip::set_mode(int mode)   // gr_mod_base::set_mode (src/gr/gr_mod_base.cpp:354-763): new graph, queued bytes dropped
 {
@@ -374,6 +375,7 @@ size_t gr_mod_base_hip::work(gr_complex* const* out)
     {
         std::lock_guard<std::mutex> g(d_mutex);
         for (auto& q : d_queue) nb = std::max(nb, std::min(q.size(), d_max));
+        nb -= nb % d_bpb;                 // whole blocks only (M17: 3 bytes); the rest waits for the next call
         if (nb == 0) return 0;
         for (int s = 0; s < d_n; ++s) {   // a stream with fewer bytes queued sends zero bytes, like an idle gr_byte_source feeding zeros
             const size_t k = std::min(d_queue[s].size(), nb);
@@ -383,7 +385,7 @@ size_t gr_mod_base_hip::work(gr_complex* const* out)
     }
     hipStream_t ms = static_cast<hipStream_t>(qrl_mod_stream(d_h));
     hchk(hipMemcpyAsync(d_bytes, host.data(), host.size(), hipMemcpyHostToDevice, ms), "H2D");
-    const size_t spb = qrl_mod_samples_per_byte(d_h), ns = nb * spb, stride = d_max * spb;
+    const size_t ns = nb / d_bpb * d_spblock, stride = (d_max / d_bpb + 1) * d_spblock;
     chk(qrl_mod_process(d_h, d_bytes, d_max, nb, d_iq, stride), "qrl_mod_process");
     chk(qrl_mod_sync(d_h), "qrl_mod_sync");
     for (int s = 0; s < d_n; ++s)

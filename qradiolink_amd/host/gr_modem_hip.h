@@ -112,6 +112,7 @@ private:
     qrl_runtime& d_rt;
     int d_n, d_rate, d_mode = -1; double d_offset; size_t d_max; float d_gain = 1.0f;
     qrl_mod* d_h = nullptr; uint8_t* d_bytes = nullptr; float* d_iq = nullptr;
+    size_t d_spblock = 0, d_bpb = 1;
     std::mutex d_mutex;
     std::vector<std::vector<uint8_t>> d_queue;
 };
