@@ -410,6 +410,11 @@ int qrl_bptc19696_encode(qrl_ctx* ctx, void* hip_stream, const uint8_t* payloads
  * is host work: host/m17_frame_decoder_hip. */
 #define QRL_M17_RECORD_BYTES 40
 int qrl_m17_decode_frames(qrl_ctx* ctx, void* hip_stream, const uint8_t* frames, size_t n, uint8_t* records);
+/* the inverse: replaces the per-frame work of M17FrameEncoder::encodeLsf / encodeStreamFrame (reference
+ * src/M17/M17/M17FrameEncoder.cpp:52-118): records of the same layout (type 1: the 30 LSF bytes with their CRC; type 2: the 18
+ * stream-frame bytes = frame number (EOS bit in its top bit) + 16 payload bytes, and the 6-byte LICH segment = 5 LSF bytes +
+ * segment number) -> 48-byte frames.  Frame numbering, the LICH round robin and the LSF CRC are per-stream state: host work. */
+int qrl_m17_encode_frames(qrl_ctx* ctx, void* hip_stream, const uint8_t* records, size_t n, uint8_t* frames);
 
 #ifdef __cplusplus
 }

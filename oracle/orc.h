@@ -206,6 +206,7 @@ uint32_t orc_golay24_encode(uint16_t data);
 uint16_t orc_golay24_decode(uint32_t codeword);
 const uint8_t* orc_m17_sequence(void);   /* 46 bytes */
 void     orc_m17_decode_frame(const uint8_t frame[48], uint8_t rec[40]);
+void     orc_m17_encode_frame(const uint8_t rec[40], uint8_t frame[48]);
 uint16_t orc_m17_crc16(const uint8_t* p, size_t n);
 float orc_det_log2f(float x);
 void orc_rssi_block(const cf32* in, size_t n, float level, float* out);

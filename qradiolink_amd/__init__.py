@@ -116,7 +116,7 @@ def load_library():
     lib.qrl_amod_sync.argtypes = [vp]
     lib.qrl_amod_stream.argtypes = [vp]
     lib.qrl_amod_stream.restype = vp
-    for name in ("qrl_bptc19696_decode", "qrl_bptc19696_encode", "qrl_m17_decode_frames"):
+    for name in ("qrl_bptc19696_decode", "qrl_bptc19696_encode", "qrl_m17_decode_frames", "qrl_m17_encode_frames"):
         getattr(lib, name).argtypes = [vp, vp, vp, sz, vp]
     lib.qrl_demod_set_squelch.argtypes = [vp, C.c_double]
     lib.qrl_demod_set_agc.argtypes = [vp, C.c_float, C.c_float]
@@ -202,7 +202,7 @@ EXPORTED_SYMBOLS = [
     "qrl_init", "qrl_shutdown", "qrl_strerror", "qrl_last_error", "qrl_version", "qrl_demod_create",
     "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_set_option", "qrl_demod_set_dmo_output", "qrl_demod_stream_wait", "qrl_demod_out_caps",
     "qrl_demod_audio_cap", "qrl_demod_set_squelch", "qrl_demod_set_agc",
-    "qrl_bptc19696_decode", "qrl_bptc19696_encode", "qrl_m17_decode_frames",
+    "qrl_bptc19696_decode", "qrl_bptc19696_encode", "qrl_m17_decode_frames", "qrl_m17_encode_frames",
     "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
@@ -796,6 +796,17 @@ def m17_decode_frames(ctx, frames):
     out = torch.zeros((frames.shape[0], 40), dtype=torch.uint8, device=frames.device)
     torch.cuda.current_stream().synchronize()
     _check(ctx.lib.qrl_m17_decode_frames(ctx.h, None, frames.data_ptr(), frames.shape[0], out.data_ptr()), "qrl_m17_decode_frames")
+    torch.cuda.synchronize()
+    return out
+
+
+def m17_encode_frames(ctx, records):
+    """[n, 40] uint8 cuda tensor of records (layout of m17_decode_frames) -> [n, 48] frames (qrl_m17_encode_frames)"""
+    import torch
+    assert records.is_cuda and records.dtype == torch.uint8 and records.dim() == 2 and records.shape[1] == 40 and records.is_contiguous()
+    out = torch.zeros((records.shape[0], 48), dtype=torch.uint8, device=records.device)
+    torch.cuda.current_stream().synchronize()
+    _check(ctx.lib.qrl_m17_encode_frames(ctx.h, None, records.data_ptr(), records.shape[0], out.data_ptr()), "qrl_m17_encode_frames")
     torch.cuda.synchronize()
     return out
 

@@ -296,6 +296,7 @@ void launch_an_stretch(const AnStretchParams& p, uint32_t max_out, int batch, hi
 void launch_bptc_decode(const uint8_t* bursts, size_t n, uint8_t* payloads, hipStream_t s);
 void launch_bptc_encode(const uint8_t* payloads, size_t n, uint8_t* bursts, hipStream_t s);
 void launch_m17_decode(const uint8_t* frames, size_t n, uint8_t* records, hipStream_t s);
+void launch_m17_encode(const uint8_t* records, size_t n, uint8_t* frames, hipStream_t s);
 
 // ---- side outputs (kernels_side.hip): rssi_block on port 0, rx_fft_c on the device-rate IQ ----
 constexpr uint32_t RSSI_RING = 4096;   // |x|^2 look-back ring per stream (moving_average_ff(2000) reads 1999 items back)

@@ -34,6 +34,14 @@ int qrl_bptc19696_encode(qrl_ctx* ctx, void* hip_stream, const uint8_t* payloads
     HIPCHK(hipGetLastError());
     return QRL_OK;
 }
+int qrl_m17_encode_frames(qrl_ctx* ctx, void* hip_stream, const uint8_t* records, size_t n, uint8_t* frames)
+{
+    if (!ctx || (n && (!frames || !records))) return qrl_set_error(QRL_ERR_ARG, "qrl_m17_encode_frames: null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    launch_m17_encode(records, n, frames, static_cast<hipStream_t>(hip_stream));
+    HIPCHK(hipGetLastError());
+    return QRL_OK;
+}
 int qrl_m17_decode_frames(qrl_ctx* ctx, void* hip_stream, const uint8_t* frames, size_t n, uint8_t* records)
 {
     if (!ctx || (n && (!frames || !records))) return qrl_set_error(QRL_ERR_ARG, "qrl_m17_decode_frames: null argument");

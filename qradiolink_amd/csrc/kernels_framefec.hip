@@ -286,6 +286,59 @@ __global__ __launch_bounds__(M17_TPB) void k_m17_decode(const uint8_t* __restric
     }
     for (int i = 0; i < 40; ++i) records[f * 40 + i] = rec[i];
 }
+// M17FrameEncoder::encodeLsf / encodeStreamFrame (reference src/M17/M17/M17FrameEncoder.cpp:52-118), stateless: a record as
+// k_m17_decode writes it -> K = 5 convolutional code (+ four flush bits), puncturing, Golay(24,12) of the LICH blocks, quadratic
+// interleaver, randomiser, sync word.  Thread per frame.
+__global__ __launch_bounds__(64) void k_m17_encode(const uint8_t* __restrict__ records, size_t n, uint8_t* __restrict__ frames)
+{
+    const size_t f = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (f >= n) return;
+    uint8_t rec[40], body[46], il[46];
+    for (int i = 0; i < 40; ++i) rec[i] = records[f * 40 + i];
+    for (int i = 0; i < 46; ++i) { body[i] = 0; il[i] = 0; }
+    const bool lsf = rec[0] == 1;
+    int ob = 0;
+    if (!lsf) {
+        const unsigned num = rec[37];
+        const unsigned blocks[4] = {((unsigned)rec[32] << 4) | (rec[33] >> 4), (((unsigned)rec[33] & 0xFu) << 8) | rec[34],
+                                    ((unsigned)rec[35] << 4) | (rec[36] >> 4), (((unsigned)rec[36] & 0xFu) << 8) | ((num << 5) & 0xFFu)};
+        for (int i = 0; i < 4; ++i) {
+            unsigned chk = 0;
+            for (int k = 0; k < 12; ++k) if (blocks[i] & (1u << k)) chk ^= c_gol_enc[k];
+            const unsigned cw = (blocks[i] << 12) | chk;
+            body[3 * i] = (uint8_t)(cw >> 16); body[3 * i + 1] = (uint8_t)(cw >> 8); body[3 * i + 2] = (uint8_t)cw;
+        }
+        ob = 96;
+    }
+    const int nbits = lsf ? 240 : 144, P = lsf ? 61 : 12;
+    unsigned mem = 0;
+    int pi = 0;
+    for (int i = 0; i < nbits + 4 && ob < 368; ++i) {
+        const unsigned bit = i < nbits ? (rec[2 + (i >> 3)] >> (7 - (i & 7))) & 1u : 0u;
+        mem = ((mem << 1) | bit) & 0x1Fu;
+        const unsigned c[2] = {(unsigned)__popc(mem & 0x19u) & 1u, (unsigned)__popc(mem & 0x17u) & 1u};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool keep = lsf ? (pi & 3) != 2 : pi != 11;
+            if (++pi >= P) pi = 0;
+            if (keep && ob < 368) { if (c[k]) body[ob >> 3] |= (uint8_t)(0x80u >> (ob & 7)); ++ob; }
+        }
+    }
+    for (unsigned i = 0; i < 368; ++i) {
+        if ((body[i >> 3] >> (7 - (i & 7))) & 1u) {
+            const unsigned d = (45u * i + 92u * i * i) % 368u;
+            il[d >> 3] |= (uint8_t)(0x80u >> (d & 7));
+        }
+    }
+    frames[f * 48] = lsf ? 0x55 : 0xFF;
+    frames[f * 48 + 1] = lsf ? 0xF7 : 0x5D;
+    for (int i = 0; i < 46; ++i) frames[f * 48 + 2 + i] = il[i] ^ c_m17_seq[i];
+}
+void launch_m17_encode(const uint8_t* records, size_t n, uint8_t* frames, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_m17_encode, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, records, n, frames);
+}
 void launch_m17_decode(const uint8_t* frames, size_t n, uint8_t* records, hipStream_t s)
 {
     if (!n) return;

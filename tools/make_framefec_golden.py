@@ -58,8 +58,27 @@ for t in range(120):
         ty = ref.ref_m17_decode_frame(P(np.ascontiguousarray(f)), P(a), P(b))
         frames.append(f.copy()); types.append(ty); lsfs.append(a); streams.append(b)
 
+# ---- M17 encoder: the reference's M17FrameEncoder (stateful) against stateless records {type, lich ok, payload[30], LICH segment[6], 0, 0}
+enc_rec, enc_frames = [], []
+for t in range(20):
+    lsf28 = rng.integers(0, 256, 28, dtype=np.uint8)
+    pl = rng.integers(0, 256, (9, 16), dtype=np.uint8)
+    fr = np.zeros((10, 48), np.uint8)
+    ref.ref_m17_encode(P(lsf28), P(pl), 9, P(fr))
+    a, b = np.zeros(30, np.uint8), np.zeros(18, np.uint8)
+    ref.ref_m17_decode_frame(P(np.ascontiguousarray(fr[0])), P(a), P(b))      # the LSF with the CRC the reference computed
+    rec = np.zeros(40, np.uint8); rec[0] = 1; rec[2:32] = a
+    enc_rec.append(rec); enc_frames.append(fr[0].copy())
+    for i in range(9):
+        fn = i | (0x8000 if i == 8 else 0)
+        rec = np.zeros(40, np.uint8); rec[0] = 2; rec[1] = 1; rec[2] = fn >> 8; rec[3] = fn & 0xFF; rec[4:20] = pl[i]
+        k = i % 6
+        rec[32:37] = a[5 * k:5 * k + 5]; rec[37] = k
+        enc_rec.append(rec); enc_frames.append(fr[i + 1].copy())
+
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref", "framefec.npz"),
                     bptc_payload=pay, bptc_base=base, bptc_encoded=enc, bptc_rx=rx, bptc_decoded=dec,
                     m17_frames=np.stack(frames), m17_type=np.array(types, np.uint8), m17_lsf=np.stack(lsfs), m17_stream=np.stack(streams),
-                    m17_seq_frames=np.stack(seq_frames), m17_seq_lsf=np.stack(seq_lsf))
+                    m17_seq_frames=np.stack(seq_frames), m17_seq_lsf=np.stack(seq_lsf),
+                    m17_enc_records=np.stack(enc_rec), m17_enc_frames=np.stack(enc_frames))
 print("wrote", n, "bursts,", len(frames), "M17 frames,", len(seq_frames), "LICH sequences")
