@@ -131,6 +131,7 @@ void   orc_preemph_taps(int sample_rate, double tau, double a[2], double b[2]);
 size_t orc_mod_nbfm(const float* audio, size_t n, int sps, int samp_rate, int filter_width, float bb_gain, cf32* out);   /* out NULL: count */
 size_t orc_mod_4fsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, int fm, cf32* out);
 size_t orc_mod_m17(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int filter_width, float bb_gain, cf32* out);
+size_t orc_mod_dsss(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int filter_width, float bb_gain, cf32* out);
 size_t orc_mod_bpsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, cf32* out);
 size_t orc_clock_recovery_mm_cc(const cf32* in, size_t n, float omega, float gain_omega, float mu, float gain_mu,
                                 float omega_relative_limit, cf32* out);

@@ -655,6 +655,45 @@ size_t orc_mod_m17(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, 
     return m;
 }
 
+/* gr_mod_dsss (reference src/gr/gr_mod_dsss.cpp:27-92, instance make_gr_mod_dsss(25, 1000000, 1700, 150) gr_mod_base.cpp:170;
+ * dsss_encoder_bb src/gr/dsss_encoder_bb_impl.cc:66-98): bytes -> bits -> scrambler -> K = 7 encoder -> every coded bit spread by the
+ * Barker-13 code (bit 0: the code, bit 1: its complement) -> {-1, +1} -> rational_resampler_ccf(25, 1, RRC(25, 25, 1, 0.35, 275)) ->
+ * x0.65 -> x bb_gain -> rational_resampler_ccf(50, 13, low_pass(50, 260000, fw, 5 fw)) -> rational_resampler_ccf(50, 1,
+ * low_pass(50, 1e6, fw, 5 fw)).  1 000 000 samples per byte.  (The stream is complex with a zero imaginary part up to the first
+ * resampler; it is carried as real here.) */
+size_t orc_mod_dsss(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int filter_width, float bb_gain, cf32* out)
+{
+    static const int barker_13[13] = {1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 1, 0, 1};
+    const size_t nchip = nbytes * 16 * 13, n52 = nchip * (size_t)sps, n20 = orc_decim_count(n52, 50, 13), nout = n20 * 50;
+    if (!out) return nout;
+    uint8_t* coded; size_t nc = tx_bits(bytes, nbytes, &coded);
+    float* chips = NEW(float, nchip);
+    for (size_t i = 0; i < nc; i++)
+        for (int k = 0; k < 13; k++) chips[13 * i + k] = ((coded[i] ? ~barker_13[k] : barker_13[k]) & 1) ? 1.0f : -1.0f;
+    free(coded);
+    int nr = orc_root_raised_cosine(sps, sps, 1, 0.35, 11 * sps, NULL);
+    float* rrc = NEW(float, nr);
+    orc_root_raised_cosine(sps, sps, 1, 0.35, 11 * sps, rrc);
+    float* shaped = NEW(float, n52);
+    orc_resamp_fff(chips, nchip, rrc, nr, sps, 1, shaped);                       /* _resampler (25, 1) */
+    free(rrc); free(chips);
+    cf32* a = NEW(cf32, n52);
+    for (size_t i = 0; i < n52; i++) { a[i].re = (shaped[i] * 0.65f) * bb_gain; a[i].im = 0.0f; }   /* _amplify, _bb_gain */
+    free(shaped);
+    int ni = orc_low_pass(50.0, 5200.0 * 50, filter_width, filter_width * 5, ORC_WIN_HAMMING, NULL);
+    float* ti = NEW(float, ni);
+    orc_low_pass(50.0, 5200.0 * 50, filter_width, filter_width * 5, ORC_WIN_HAMMING, ti);
+    cf32* b = NEW(cf32, n20);
+    orc_resamp_ccf(a, n52, ti, ni, 50, 13, b);                                   /* _resampler_if (50, 13) */
+    free(ti); free(a);
+    int nt = orc_low_pass(50, samp_rate, filter_width, filter_width * 5, ORC_WIN_HAMMING, NULL);
+    float* tr = NEW(float, nt);
+    orc_low_pass(50, samp_rate, filter_width, filter_width * 5, ORC_WIN_HAMMING, tr);
+    const size_t m = orc_resamp_ccf(b, n20, tr, nt, 50, 1, out);                 /* _resampler_rf (50, 1) */
+    free(tr); free(b);
+    return m;
+}
+
 /* gr_mod_bpsk.cpp:28-67 (instances gr_mod_base.cpp:168-169: sps 500 / 250) */
 size_t orc_mod_bpsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, cf32* out)
 {

@@ -239,6 +239,8 @@ struct TxShapeParams { RingB sym; RingF out; uint64_t n0; uint32_t count; int sp
 struct TxFmParams { RingF in; RingC out; uint64_t n0; uint32_t count; float k, amp; float* phase; };
 struct TxInterpCParams { RingC in; uint64_t n0; uint32_t count; const float* taps; int nt; int interp; float2* out; size_t out_stride;
                          int decim; };   // decim > 1: rational_resampler_ccf(interp, decim) (gr_mod_m17: 125 / 3)
+void launch_tx_spread(RingB coded, RingB chips, uint64_t c0, uint32_t ncoded, int batch, hipStream_t s);   // gr_mod_dsss: Barker-13 spreading
+void launch_tx_f2c(RingF in, RingC out, uint64_t n0, uint32_t count, float g, int batch, hipStream_t s);
 void launch_tx_raw_dibits(const uint8_t* bytes, size_t stride, uint32_t nbytes, RingB sym, uint64_t s0, int batch, hipStream_t s);
 struct TxRotParams { const float2* in; size_t in_stride; uint64_t n0; uint32_t count; uint64_t rot_acc, rot_inc, rot_nbase; const float2* rot_lo;
                      RingC out_ring; float2* out; size_t out_stride; };

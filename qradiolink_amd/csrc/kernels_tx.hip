@@ -350,6 +350,37 @@ void launch_tx_raw_dibits(const uint8_t* bytes, size_t stride, uint32_t nbytes, 
     if (!nbytes) return;
     hipLaunchKernelGGL(k_tx_raw_dibits, dim3((nbytes * 4u + 255) / 256, batch), dim3(256), 0, s, bytes, stride, nbytes, sym, s0);
 }
+// gr_mod_dsss (reference src/gr/gr_mod_dsss.cpp:27-92): dsss_encoder_bb (src/gr/dsss_encoder_bb_impl.cc:78-92) spreads every coded bit
+// by the Barker-13 code (bit 0: the code, bit 1: its complement), 13 chips per ring item of the coded-bit ring
+__global__ __launch_bounds__(256) void k_tx_spread(RingB coded, RingB chips, uint64_t c0, uint32_t count)
+{
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= count) return;
+    const uint64_t ch = c0 * 13ull + t;                              // absolute chip index
+    const uint32_t bit = coded.p[(size_t)b * (coded.mask + 1u) + ((uint32_t)(ch / 13ull) & coded.mask)] & 1u;
+    const uint32_t code = (0x1F35u >> (12u - (uint32_t)(ch % 13ull))) & 1u;   // 1 1 1 1 1 0 0 1 1 0 1 0 1, first chip = MSB
+    chips.p[(size_t)b * (chips.mask + 1u) + ((uint32_t)ch & chips.mask)] = (uint8_t)(bit ? code ^ 1u : code);
+}
+void launch_tx_spread(RingB coded, RingB chips, uint64_t c0, uint32_t ncoded, int batch, hipStream_t s)
+{
+    if (!ncoded) return;
+    hipLaunchKernelGGL(k_tx_spread, dim3((ncoded * 13u + 255) / 256, batch), dim3(256), 0, s, coded, chips, c0, ncoded * 13u);
+}
+// float ring -> complex ring with a gain: (x g, 0)  (multiply_const_cc on a stream whose imaginary part is zero)
+__global__ __launch_bounds__(256) void k_tx_f2c(RingF in, RingC out, uint64_t n0, uint32_t count, float g)
+{
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= count) return;
+    const uint32_t n = (uint32_t)(n0 + t);
+    out.p[(size_t)b * (out.mask + 1u) + (n & out.mask)] = make_float2(in.p[(size_t)b * (in.mask + 1u) + (n & in.mask)] * g, 0.0f);
+}
+void launch_tx_f2c(RingF in, RingC out, uint64_t n0, uint32_t count, float g, int batch, hipStream_t s)
+{
+    if (!count) return;
+    hipLaunchKernelGGL(k_tx_f2c, dim3((count + 255) / 256, batch), dim3(256), 0, s, in, out, n0, count, g);
+}
 void launch_tx_interp_c(const TxInterpCParams& p, int batch, hipStream_t s)
 {
     if (!p.count) return;

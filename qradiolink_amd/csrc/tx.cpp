@@ -30,6 +30,9 @@ struct qrl_mod {
     bool bpsk = false, fsk4 = false; float shape_scale = 0.0f;
     // gr_mod_m17: raw dibits -> RRC x5 -> FM -> channel filter -> gains -> 125 / 3 (2500 samples per 3 bytes)
     bool m17 = false; float* m17_filt = nullptr; int m17_nf = 0; float2* m17_flt = nullptr;
+    // gr_mod_dsss: coded bits -> Barker-13 chips -> RRC x25 (5200 sps) -> gains -> 50 / 13 (20 ksps) -> 1:50; 1 000 000 samples per byte
+    bool dsss = false; uint8_t* ds_chips = nullptr; uint32_t ds_chip_mask = 0; float* ds_shaped = nullptr; float2 *ds_c52 = nullptr, *ds_c20 = nullptr;
+    uint32_t ds_m52 = 0, ds_m20 = 0; float* ds_if_taps = nullptr; int ds_if_Jp = 0;
     int sps = 4;
     float bb_gain = 1.0f;
     float* taps = nullptr; int nt = 0;
@@ -52,7 +55,7 @@ struct qrl_mod {
     }
     ~qrl_mod() {
         if (taps) (void)hipFree(taps);
-        for (void* p : {(void*)shape_taps, (void*)shaped, (void*)fmv, (void*)phase, (void*)m17_filt, (void*)m17_flt}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)shape_taps, (void*)shaped, (void*)fmv, (void*)phase, (void*)m17_filt, (void*)m17_flt, (void*)ds_chips, (void*)ds_shaped, (void*)ds_c52, (void*)ds_c20, (void*)ds_if_taps}) if (p) (void)hipFree(p);
         if (st) (void)hipFree(st);
         for (void* p : {(void*)be_taps, (void*)bb, (void*)be_ring, (void*)rot_lo}) if (p) (void)hipFree(p);
         if (sym) (void)hipFree(sym);
@@ -68,6 +71,12 @@ struct qrl_mod {
             if (hipMemset(fmv, 0, (size_t)cfg.batch * (r1_mask + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
             if (hipMemset(phase, 0, (size_t)cfg.batch * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
             if (m17_flt && hipMemset(m17_flt, 0, (size_t)cfg.batch * (r1_mask + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
+        }
+        if (dsss) {
+            if (hipMemset(ds_chips, 0, (size_t)cfg.batch * (ds_chip_mask + 1)) != hipSuccess) return QRL_ERR_HIP;
+            if (hipMemset(ds_shaped, 0, (size_t)cfg.batch * (ds_m52 + 1) * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
+            if (hipMemset(ds_c52, 0, (size_t)cfg.batch * (ds_m52 + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
+            if (hipMemset(ds_c20, 0, (size_t)cfg.batch * (ds_m20 + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
         }
         if (be_ring && hipMemset(be_ring, 0, (size_t)cfg.batch * (be_mask + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
         nsym = 0; n_bb = 0; rot_acc = 0; rot_nbase = 0;
@@ -122,6 +131,7 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
         case QRL_MODEM_BPSK1K:    c.sps = 500; c.filter_width = 1500;  break;             // :168
         case QRL_MODEM_BPSK2K:    c.sps = 250; c.filter_width = 2800;  break;             // :169
         case QRL_MODEM_M17:       c.sps = 125; c.filter_width = 9000;  break;             // make_gr_mod_m17() :206, defaults gr_mod_m17.h:43-44
+        case QRL_MODEM_BPSK8:     c.sps = 25;  c.filter_width = 150;   break;             // make_gr_mod_dsss(25, 1000000, 1700, 150) :170
         default: return qrl_set_error(QRL_ERR_ARG, "modulator: modem_type not supported by this build");
         }
     }
@@ -132,12 +142,15 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
     case QRL_MODEM_4FSK2K: case QRL_MODEM_4FSK2KFM: case QRL_MODEM_4FSK1KFM: case QRL_MODEM_4FSK10KFM: case QRL_MODEM_4FSK100K: fsk = fsk4 = true; break;
     case QRL_MODEM_BPSK1K: case QRL_MODEM_BPSK2K: bpsk = true; break;
     case QRL_MODEM_M17: fsk = true; m->m17 = true; break;
+    case QRL_MODEM_BPSK8: m->dsss = true; break;
     default: return qrl_set_error(QRL_ERR_ARG, "modulator: modem_type not supported by this build");
     }
     m->bpsk = bpsk; m->fsk4 = fsk4;
     if (m->m17 && c.sps != 125) return qrl_set_error(QRL_ERR_ARG, "modulator: m17 sps must be 125 (rational_resampler_ccf(sps, 3), gr_mod_m17.cpp:64-66)");
-    if (m->m17 && ((c.device_samp_rate != 0 && c.device_samp_rate != 1000000) || c.carrier_offset_hz != 0.0))
-        return qrl_set_error(QRL_ERR_ARG, "modulator: the gr_mod_base back end is not built for m17");
+    if ((m->m17 || m->dsss) && ((c.device_samp_rate != 0 && c.device_samp_rate != 1000000) || c.carrier_offset_hz != 0.0))
+        return qrl_set_error(QRL_ERR_ARG, "modulator: the gr_mod_base back end is not built for m17 / dsss");
+    if (m->dsss && c.sps != 25) return qrl_set_error(QRL_ERR_ARG, "modulator: dsss sps must be 25");
+    if (m->dsss && c.max_bytes > 64) return qrl_set_error(QRL_ERR_TOO_BIG, "modulator: dsss makes 1 000 000 samples per byte: max_bytes <= 64");
     if (bpsk && (c.sps < 2 || c.sps > 1000)) return qrl_set_error(QRL_ERR_ARG, "modulator: bpsk sps out of range");
     if (!fsk && !bpsk && (c.sps < 2 || c.sps > 1000)) return qrl_set_error(QRL_ERR_ARG, "modulator: qpsk sps out of range");
     m->sps = c.sps;
@@ -151,7 +164,30 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
         return QRL_OK;
     };
     size_t ring_items = c.max_bytes * 8 + 256;   // symbol ring: one item per input bit (QPSK) or per coded bit (FSK: x2)
-    if (!fsk) {
+    if (m->dsss) {   // gr_mod_dsss.cpp:60-76
+        const int fw = c.filter_width;
+        const std::vector<float> rrc = root_raised_cosine(25, 25, 1, 0.35, 11 * 25);                        // _resampler (25, 1)
+        const std::vector<float> ti = low_pass(50.0, 5200.0 * 50, fw, fw * 5);                              // _resampler_if (50, 13)
+        const std::vector<float> tr = low_pass(50, c.samp_rate, fw, fw * 5);                                // _resampler_rf (50, 1)
+        m->nt_shape = (int)rrc.size(); m->nt = (int)tr.size();
+        if (m->nt_shape > 1536) return qrl_set_error(QRL_ERR_ARG, "modulator: shaping filter too long");
+        m->ds_if_Jp = ((int)ti.size() + 49) / 50;
+        std::vector<float> lay((size_t)50 * m->ds_if_Jp, 0.0f);
+        for (size_t k = 0; k < ti.size(); ++k) lay[(k % 50) * m->ds_if_Jp + k / 50] = ti[k];
+        int r0;
+        if ((r0 = upload(rrc, &m->shape_taps)) || (r0 = upload(tr, &m->taps)) || (r0 = upload(lay, &m->ds_if_taps))) return r0;
+        m->shape_scale = 0.65f;                                                                             // _amplify
+        ring_items = c.max_bytes * 16 + 256;                                                                // coded bits
+        uint32_t cc = 1024, c52 = 1024, c20 = 1024;
+        while (cc < c.max_bytes * 208 + 256) cc <<= 1;
+        while (c52 < c.max_bytes * 5200 + 1024) c52 <<= 1;
+        while (c20 < c.max_bytes * 20000 + 1024) c20 <<= 1;
+        m->ds_chip_mask = cc - 1; m->ds_m52 = c52 - 1; m->ds_m20 = c20 - 1;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->ds_chips), (size_t)c.batch * cc));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->ds_shaped), (size_t)c.batch * c52 * sizeof(float)));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->ds_c52), (size_t)c.batch * c52 * sizeof(float2)));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->ds_c20), (size_t)c.batch * c20 * sizeof(float2)));
+    } else if (!fsk) {
         const std::vector<float> rrc = bpsk ? root_raised_cosine(m->sps, m->sps, 1, 0.35, 11 * m->sps)   // gr_mod_bpsk.cpp:52-54
                                             : root_raised_cosine(m->sps, m->sps, 1, 0.35,             // gr_mod_qpsk.cpp:46-51
                                                                  (m->sps > 120 ? 11 : m->sps > 10 ? 13 : 15) * m->sps);
@@ -267,6 +303,7 @@ size_t qrl_mod_samples_per_block(const qrl_mod* m, size_t* bytes_per_block)
 {
     if (!m) return 0;
     if (m->m17) { if (bytes_per_block) *bytes_per_block = 3; return 2500; }   // 4 symbols x 5 x 125 / 3 per byte
+    if (m->dsss) { if (bytes_per_block) *bytes_per_block = 1; return 1000000; }
     if (bytes_per_block) *bytes_per_block = 1;
     return qrl_mod_samples_per_byte(m);
 }
@@ -274,6 +311,7 @@ size_t qrl_mod_samples_per_byte(const qrl_mod* m)
 {
     if (!m) return 0;
     if (m->m17) return 0;   // 833 1/3: see qrl_mod_samples_per_block
+    if (m->dsss) return 1000000;   // 16 coded bits x 13 chips x 25 x 50 / 13 x 50
     const size_t spb1 = m->fsk4 ? (size_t)8 * m->sps * m->interp2 : m->fam == qrl_mod::F_FSK ? (size_t)16 * m->sps * m->interp2
                                 : (size_t)(m->bpsk ? 16 : 8) * m->sps;
     return spb1 * (size_t)m->be_interp;
@@ -333,8 +371,29 @@ int qrl_mod_process(qrl_mod* m, const uint8_t* bytes, size_t stride, size_t nbyt
     p.L = ((nbits + 63) / 64 + 31) / 32 * 32;
     lfsr_power(p.L, p.tl_cols);
     p.st = m->st; p.sym = RingB{m->sym, m->sym_mask}; p.s0 = m->nsym;
-    p.mode = m->fsk4 ? 2 : (m->fam == qrl_mod::F_FSK || m->bpsk) ? 1 : 0;
+    p.mode = m->fsk4 ? 2 : (m->fam == qrl_mod::F_FSK || m->bpsk || m->dsss) ? 1 : 0;
     launch_tx_qpsk_bits(p, B, m->stream);
+    if (m->dsss) {
+        const uint32_t ncoded = 2 * nbits, nchips = ncoded * 13u, c52 = nchips * 25u, c20 = c52 / 13u * 50u;
+        const uint64_t chip0 = m->nsym * 13ull, n52 = chip0 * 25ull, n20 = n52 / 13ull * 50ull;
+        RingB chips{m->ds_chips, m->ds_chip_mask};
+        launch_tx_spread(p.sym, chips, m->nsym, ncoded, B, m->stream);                   // _dsss_encoder
+        TxShapeParams sp{}; sp.sym = chips; sp.out = RingF{m->ds_shaped, m->ds_m52}; sp.n0 = n52; sp.count = c52; sp.sps = 25;
+        sp.taps = m->shape_taps; sp.nt = m->nt_shape; sp.levels = 2; sp.scale = m->shape_scale;
+        launch_tx_shape(sp, B, m->stream);                                               // _chunks_to_symbols, _resampler, _amplify
+        RingC r52{m->ds_c52, m->ds_m52}, r20{m->ds_c20, m->ds_m20};
+        launch_tx_f2c(sp.out, r52, n52, c52, m->bb_gain, B, m->stream);                  // _bb_gain
+        ResampParams rp{}; rp.in = nullptr; rp.in_ring = r52; rp.n0 = n52; rp.n = c52; rp.out = r20; rp.q0 = n20; rp.q_count = c20;
+        rp.taps = m->ds_if_taps; rp.I = 50; rp.D = 13; rp.Jp = m->ds_if_Jp;
+        launch_resamp(rp, B, m->stream);                                                 // _resampler_if (50, 13)
+        TxInterpCParams ip{}; ip.in = r20; ip.n0 = n20 * 50ull; ip.count = c20 * 50u; ip.taps = m->taps; ip.nt = m->nt; ip.interp = 50;
+        ip.out = reinterpret_cast<float2*>(iq); ip.out_stride = out_stride;
+        launch_tx_interp_c(ip, B, m->stream);                                            // _resampler_rf (50, 1)
+        HIPCHK(hipGetLastError());
+        if (qrl::take_launch_error()) return QRL_ERR_HIP;
+        m->nsym += ncoded;
+        return QRL_OK;
+    }
     if (m->fam == qrl_mod::F_FSK) {
         // nsym counts CODED bits here (2 per input bit); rate-1 samples = coded bits * sps
         const uint32_t ncoded = m->fsk4 ? nbits : 2 * nbits;   // ring items per call: 4-level symbols, or coded bits

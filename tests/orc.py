@@ -659,6 +659,16 @@ def mod_nbfm(audio, sps=20, samp_rate=1000000, filter_width=5000, bb_gain=1.0):
     return y[:m]
 
 
+def mod_dsss(data, sps=25, samp_rate=1000000, filter_width=150, bb_gain=1.0):
+    data = np.ascontiguousarray(data, np.uint8)
+    lib.orc_mod_dsss.restype = C.c_size_t
+    args = (_ptr(data), C.c_size_t(data.size), sps, samp_rate, filter_width, C.c_float(bb_gain))
+    n = lib.orc_mod_dsss(*args, None)
+    y = np.zeros(max(n, 1), cf32)
+    m = lib.orc_mod_dsss(*args, _ptr(y))
+    return y[:m]
+
+
 def mod_m17(data, sps=125, samp_rate=1000000, filter_width=9000, bb_gain=1.0):
     data = np.ascontiguousarray(data, np.uint8)
     lib.orc_mod_m17.restype = C.c_size_t
