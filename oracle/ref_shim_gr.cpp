@@ -17,6 +17,7 @@
 #include "src/gr/rssi_tag_block.h"
 #include "src/gr/gr_zero_idle_bursts.h"
 #include "src/gr/dsss_decoder_cc_impl.h"
+#include "src/gr/dsss_encoder_bb_impl.h"
 #include "src/gr/cessb/clipper_cc.h"
 #include "src/gr/cessb/stretcher_cc.h"
 
@@ -155,6 +156,18 @@ size_t ref_cessb_stretcher(const float* in /* 2 n */, size_t n, size_t chunks, f
         done += m;
     }
     return total;
+}
+
+// gr::dsss::dsss_encoder_bb(Barker 13): packed bytes in, 13 chips per bit out
+size_t ref_dsss_encoder(const uint8_t* in, size_t nbytes, uint8_t* out /* 104 per byte */)
+{
+    static const int barker_13[] = {1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 1, 0, 1};
+    std::vector<int> code(barker_13, barker_13 + 13);
+    gr::dsss::dsss_encoder_bb::sptr e = gr::dsss::dsss_encoder_bb::make(code);
+    gr_vector_int ninput(1, (int)nbytes);
+    gr_vector_const_void_star ins(1, in);
+    gr_vector_void_star outs(1, out);
+    return (size_t)e->general_work((int)(nbytes * 104), ninput, ins, outs);
 }
 
 }

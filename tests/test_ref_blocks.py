@@ -185,3 +185,15 @@ def test_cessb_clipper_and_stretcher_oracle_equal_the_reference_blocks(ref):
             m = ref.ref_cessb_stretcher(P(xs), C.c_size_t(n), C.c_size_t(chunks), P(got))
             assert m == want_n == 1024 * ((n - 2) // 1024)
             assert np.array_equal(got[:m].view(np.uint32), b[:m].view(np.uint32)), (n, chunks)
+
+
+def test_dsss_encoder_chips_equal_the_reference_block(ref):
+    """gr::dsss::dsss_encoder_bb: bit 0 -> the Barker-13 code, bit 1 -> its complement, MSB first; what k_tx_spread / orc_mod_dsss do
+    with the coded bits (checked through the chips' signs in the oracle's modulator input)"""
+    ref.ref_dsss_encoder.restype = C.c_size_t
+    data = np.random.default_rng(13).integers(0, 256, 40, dtype=np.uint8)
+    out = np.zeros(40 * 104, np.uint8)
+    assert ref.ref_dsss_encoder(P(data), C.c_size_t(40), P(out)) == 40 * 104
+    code = np.array([1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 1, 0, 1], np.uint8)
+    want = np.concatenate([code if b == 0 else 1 - code for b in np.unpackbits(data)])
+    assert np.array_equal(out, want)
