@@ -69,6 +69,7 @@ __global__ __launch_bounds__(64) void k_an_gate(const AnGateParams P, int batch)
 {
     __shared__ float T[257];
     __shared__ float env_tab[AN_MAX_RAMP + 1];
+    __shared__ float2 xq[16][64];
     for (int k = threadIdx.x; k < 257; k += 64) T[k] = P.atan_tab[k];
     for (int k = threadIdx.x; k <= P.ramp; k += 64) env_tab[k] = P.env[k];
     __syncthreads();
@@ -77,8 +78,14 @@ __global__ __launch_bounds__(64) void k_an_gate(const AnGateParams P, int batch)
     AnState st = P.st[b];
     st.g_prev = st.g;
     float* out = P.out.p + (size_t)b * (P.out.mask + 1u);
-    for (uint32_t t = 0; t < P.count; ++t) {
-        const float2 x = an_ringc_at(P.in, b, (int64_t)(P.q0 + t));
+    // the loop is a chain of dependent operations per item; the loads are not: sixteen items are fetched ahead of the recursion
+    constexpr int AN_PF = 16;
+    for (uint32_t t0 = 0; t0 < P.count; t0 += AN_PF) {
+#pragma unroll
+    for (int k = 0; k < AN_PF; ++k) xq[k][threadIdx.x] = an_ringc_at(P.in, b, (int64_t)(P.q0 + t0 + k));   // (ring reads are in bounds for any index; a lane only reads back its own column)
+    for (int k = 0; k < AN_PF; ++k) {
+        if (t0 + k >= P.count) break;
+        const float2 x = xq[k][threadIdx.x];
         const float p = x.x * x.x + x.y * x.y;
         st.pwr = P.alpha * (double)p + P.one_minus_alpha * st.pwr;
         const bool mute = st.pwr < P.threshold;
@@ -145,6 +152,7 @@ __global__ __launch_bounds__(64) void k_an_gate(const AnGateParams P, int batch)
         }
         out[(uint32_t)st.g & P.out.mask] = d;
         ++st.g;
+    }
     }
     P.st[b] = st;
 }

@@ -44,10 +44,12 @@ __global__ __launch_bounds__(256) void k_fir_ccf(const FirCcfParams P)
 // (consecutive lanes -> consecutive LDS words, taps are wave-uniform broadcasts).  Same fmaf chain, k ascending.
 constexpr int FT_R = 4, FT_OUT = 256 * FT_R, FT_MAXT = 1024;
 
+template <int MAXT>   // 1024 for the digital chains; 2048 for the 1904-tap channel filter of gr_demod_wbfm (its own instance: the larger LDS
+                      // footprint would cost the short filters occupancy)
 __global__ __launch_bounds__(256) void k_fir_ccf_tiled(const FirCcfParams P)
 {
-    __shared__ float taps[FT_MAXT];
-    __shared__ float2 xs[FT_OUT + FT_MAXT];
+    __shared__ float taps[MAXT];
+    __shared__ float2 xs[FT_OUT + MAXT];
     const int b = blockIdx.y, tid = threadIdx.x;
     const uint32_t t0 = blockIdx.x * (uint32_t)FT_OUT;
     const int nt = P.nt;
@@ -115,7 +117,9 @@ static bool fir_use_tiled(int nt, uint32_t count) { return nt >= 8 && nt <= FT_M
 void launch_fir_ccf(const FirCcfParams& p, int batch, hipStream_t s)
 {
     if (!p.count) return;
-    if (fir_use_tiled(p.nt, p.count)) hipLaunchKernelGGL(k_fir_ccf_tiled, dim3((p.count + FT_OUT - 1) / FT_OUT, batch), dim3(256), 0, s, p);
+    if (fir_use_tiled(p.nt, p.count)) hipLaunchKernelGGL(k_fir_ccf_tiled<FT_MAXT>, dim3((p.count + FT_OUT - 1) / FT_OUT, batch), dim3(256), 0, s, p);
+    else if (p.nt > FT_MAXT && p.nt <= 2 * FT_MAXT && p.count >= 512)
+        hipLaunchKernelGGL(k_fir_ccf_tiled<2 * FT_MAXT>, dim3((p.count + FT_OUT - 1) / FT_OUT, batch), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(k_fir_ccf, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
 }
 
