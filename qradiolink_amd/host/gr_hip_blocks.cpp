@@ -139,7 +139,8 @@ void gr_demod_hip::run(const gr_complex* x, size_t n)   // n even, <= kChunk
     if (d_acap) {   // analogue modes: port 1 is audio
         if (cnt[1]) hchk(hipMemcpy(d_hau.data(), d_audio, cnt[1] * sizeof(float), hipMemcpyDeviceToHost), "D2H");
         gr::thread::scoped_lock g(d_mutex);
-        d_boxa.insert(d_boxa.end(), d_hau.begin(), d_hau.begin() + cnt[1]);
+        if (d_boxa.size() > 8000) d_boxa.clear();      // gr_audio_sink::work: a backlog of more than one second is dropped (gr_audio_sink.cpp:79-85)
+        else d_boxa.insert(d_boxa.end(), d_hau.begin(), d_hau.begin() + cnt[1]);
         return;
     }
     if (cnt[1]) hchk(hipMemcpy(d_hc.data(), d_const, cnt[1] * sizeof(gr_complex), hipMemcpyDeviceToHost), "D2H");
@@ -168,9 +169,10 @@ int gr_demod_hip::work(int noutput_items, gr_vector_const_void_star& input_items
 }
 std::vector<float>* gr_demod_hip::get_audio_data()
 {
-    gr::thread::scoped_lock g(d_mutex);
-    auto* v = new std::vector<float>();
-    v->swap(d_boxa);
+    gr::thread::scoped_lock g(d_mutex);      // gr_audio_sink::get_data: one packet of 640 samples, or nullptr (gr_audio_sink.cpp:51-66)
+    if (d_boxa.size() < 640) return nullptr;
+    auto* v = new std::vector<float>(d_boxa.begin(), d_boxa.begin() + 640);
+    d_boxa.erase(d_boxa.begin(), d_boxa.begin() + 640);
     return v;
 }
 void gr_demod_hip::set_squelch(int value) { chk(qrl_demod_set_squelch(d_h, (double)value), "qrl_demod_set_squelch"); }

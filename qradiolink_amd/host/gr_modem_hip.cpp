@@ -222,7 +222,9 @@ void gr_demod_base_hip::harvest(int which)
         const uint32_t* c = sl.h_cnt + 4 * (size_t)s;
         if (sl.rssi_valid && c[0]) d_level[s] = sl.h_rssi[s];
         if (d_acap) {   // analogue modes: port 1 is audio (gr_audio_sink), no bit / constellation ports
-            d_boxa[s].insert(d_boxa[s].end(), sl.h_audio + (size_t)s * d_acap, sl.h_audio + (size_t)s * d_acap + c[1]);
+            // gr_audio_sink::work (src/gr/gr_audio_sink.cpp:68-90): more than one second waiting = the reader is too slow: drop it all
+            if (d_boxa[s].size() > 8000) d_boxa[s].clear();
+            else d_boxa[s].insert(d_boxa[s].end(), sl.h_audio + (size_t)s * d_acap, sl.h_audio + (size_t)s * d_acap + c[1]);
             continue;
         }
         d_box1[s].insert(d_box1[s].end(), sl.h_a + (size_t)s * d_bcap, sl.h_a + (size_t)s * d_bcap + c[2]);
@@ -253,9 +255,12 @@ std::vector<unsigned char>* gr_demod_base_hip::getData(int nr, int stream)   // 
 }
 std::vector<float>* gr_demod_base_hip::getAudio(int stream)   // gr_demod_base::getAudio (src/gr/gr_demod_base.cpp:968-976)
 {
+    // gr_audio_sink::get_data (src/gr/gr_audio_sink.cpp:51-66): packets of 640 samples (40 ms at 8 ksps at the least), else nothing
     std::lock_guard<std::mutex> g(d_mutex);
-    std::vector<float>* out = new std::vector<float>;
-    out->swap(d_boxa[stream]);
+    std::vector<float>& box = d_boxa[stream];
+    if (box.size() < 640) return nullptr;
+    std::vector<float>* out = new std::vector<float>(box.begin(), box.begin() + 640);
+    box.erase(box.begin(), box.begin() + 640);
     return out;
 }
 void gr_demod_base_hip::set_squelch(int value)   // gr_demod_base.cpp:1186-1199

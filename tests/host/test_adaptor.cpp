@@ -128,7 +128,7 @@ int main(int argc, char** argv)
                 gr_vector_const_void_star ins(1, x + pos);
                 if (d->work((int)take, ins, outs) != (int)take) return 3;
                 pos += take;
-                if (std::vector<float>* v = d->get_audio_data()) { audio.insert(audio.end(), v->begin(), v->end()); delete v; }
+                while (std::vector<float>* v = d->get_audio_data()) { audio.insert(audio.end(), v->begin(), v->end()); delete v; }   // 640-sample packets
             }
             dump(argv[5], audio.data(), audio.size() * sizeof(float));
             std::printf("rxa ok: %zu samples -> %zu audio samples\n", n, audio.size());

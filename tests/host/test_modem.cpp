@@ -50,10 +50,10 @@ int main(int argc, char** argv)
                 for (int s = 0; s < N; ++s) ptr[s] = x + (size_t)s * n + pos;
                 demod.work(ptr.data(), take);
                 pos += take;
-                for (int s = 0; s < N; ++s) modem.demodulateAnalog(s);
+                for (int s = 0; s < N; ++s) while (modem.demodulateAnalog(s)) {}      // 640-sample packets, like radiocontroller's poll
             }
             demod.flush();
-            for (int s = 0; s < N; ++s) modem.demodulateAnalog(s);
+            for (int s = 0; s < N; ++s) while (modem.demodulateAnalog(s)) {}
             for (int s = 0; s < N; ++s) {
                 std::ofstream o(std::string(argv[5]) + std::to_string(s) + ".bin", std::ios::binary);
                 o.write(reinterpret_cast<const char*>(audio[s].data()), (std::streamsize)(audio[s].size() * sizeof(float)));

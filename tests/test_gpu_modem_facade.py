@@ -96,5 +96,6 @@ def test_facade_analog_audio(tmp_path, mode, kind, fw):
     for s in range(2):
         got = np.fromfile(tmp_path / ("a%d.bin" % s), np.float32) + np.float32(0)
         want = orc.demod_analog(xs[s], kind, filter_width=fw)["audio"] + np.float32(0)
-        assert got.size == want.size and got.size > 400
-        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        # the audio sink hands out packets of 640 samples; what is left below one packet at the end stays in the mailbox
+        assert got.size == want.size // 640 * 640 and got.size >= 640
+        assert np.array_equal(got.view(np.uint32), want[:got.size].view(np.uint32))
