@@ -147,8 +147,7 @@ void gr_demod_hip::run(const gr_complex* x, size_t n)   // n even, <= kChunk
     gr::thread::scoped_lock g(d_mutex);
     if (d_box1.size() <= 1048576) d_box1.insert(d_box1.end(), d_ha.begin(), d_ha.begin() + cnt[2]);   // drop rule of gr_bit_sink.cpp:71-76
     if (d_box2.size() <= 1048576) d_box2.insert(d_box2.end(), d_hb.begin(), d_hb.begin() + cnt[3]);
-    d_boxc.insert(d_boxc.end(), d_hc.begin(), d_hc.begin() + cnt[1]);
-    if (d_boxc.size() > 65536) d_boxc.erase(d_boxc.begin(), d_boxc.end() - 65536);
+    if (d_boxc.size() <= 256) d_boxc.insert(d_boxc.end(), d_hc.begin(), d_hc.begin() + cnt[1]);   // drop rule of gr_const_sink.cpp:75-78
 }
 
 int gr_demod_hip::work(int noutput_items, gr_vector_const_void_star& input_items, gr_vector_void_star&)
@@ -190,7 +189,7 @@ std::vector<unsigned char>* gr_demod_hip::get_data(int nr)
 std::vector<gr_complex>* gr_demod_hip::get_constellation_data()
 {
     gr::thread::scoped_lock g(d_mutex);
-    if (d_boxc.empty()) return nullptr;
+    if (d_boxc.size() < 32) return nullptr;      // gr_const_sink::get_data (src/gr/gr_const_sink.cpp:48-62)
     std::vector<gr_complex>* v = new std::vector<gr_complex>(d_boxc);
     d_boxc.clear();
     return v;

@@ -227,12 +227,11 @@ void gr_demod_base_hip::harvest(int which)
             else d_boxa[s].insert(d_boxa[s].end(), sl.h_audio + (size_t)s * d_acap, sl.h_audio + (size_t)s * d_acap + c[1]);
             continue;
         }
-        d_box1[s].insert(d_box1[s].end(), sl.h_a + (size_t)s * d_bcap, sl.h_a + (size_t)s * d_bcap + c[2]);
-        d_box2[s].insert(d_box2[s].end(), sl.h_b + (size_t)s * d_bcap, sl.h_b + (size_t)s * d_bcap + c[3]);
-        d_boxc[s].insert(d_boxc[s].end(), sl.h_const + (size_t)s * d_ccap, sl.h_const + (size_t)s * d_ccap + c[1]);
-        if (d_box1[s].size() > (1u << 20)) d_box1[s].clear();   // gr_bit_sink drops its backlog beyond 1 Mi items (src/gr/gr_bit_sink.cpp:71-76)
-        if (d_box2[s].size() > (1u << 20)) d_box2[s].clear();
-        if (d_boxc[s].size() > (1u << 20)) d_boxc[s].clear();
+        // gr_bit_sink::work (src/gr/gr_bit_sink.cpp:61-83): while more than 1 Mi items wait, new ones are not taken (nothing is cleared);
+        // gr_const_sink::work (src/gr/gr_const_sink.cpp:64-86): the same at 256 items
+        if (d_box1[s].size() <= 1048576) d_box1[s].insert(d_box1[s].end(), sl.h_a + (size_t)s * d_bcap, sl.h_a + (size_t)s * d_bcap + c[2]);
+        if (d_box2[s].size() <= 1048576) d_box2[s].insert(d_box2[s].end(), sl.h_b + (size_t)s * d_bcap, sl.h_b + (size_t)s * d_bcap + c[3]);
+        if (d_boxc[s].size() <= 256) d_boxc[s].insert(d_boxc[s].end(), sl.h_const + (size_t)s * d_ccap, sl.h_const + (size_t)s * d_ccap + c[1]);
         if (d_mode == QRL_MODEM_DMR)
             for (uint32_t i = 0; i < sl.h_dmocnt[s] && i < kDmoCap; ++i) {
                 const uint8_t* r = sl.h_dmo + ((size_t)s * kDmoCap + i) * QRL_DMO_RECORD_BYTES;
@@ -281,7 +280,7 @@ void gr_demod_base_hip::set_agc_decay(float value)   // :1450-1470
 std::vector<gr_complex>* gr_demod_base_hip::get_constellation_data(int stream)
 {
     std::lock_guard<std::mutex> g(d_mutex);
-    if (d_boxc[stream].empty()) return nullptr;
+    if (d_boxc[stream].size() < 32) return nullptr;      // gr_const_sink::get_data (src/gr/gr_const_sink.cpp:48-62)
     std::vector<gr_complex>* out = new std::vector<gr_complex>;
     out->swap(d_boxc[stream]);
     return out;
