@@ -295,12 +295,13 @@ __global__ __launch_bounds__(256) void k_resamp(const ResampParams P, int span)
     float2* xs = reinterpret_cast<float2*>(taps + ((P.I * P.Jp + 3) & ~3));  // span
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
-    const uint64_t q_first = P.q0 + (uint64_t)blockIdx.x * 256u;
-    for (int k = tid; k < P.I * P.Jp; k += 256) taps[k] = P.taps[k];
+    const uint32_t T = blockDim.x;                                  // outputs per workgroup: 256, or 64 when the input span of 256 would not leave room for a second workgroup per CU
+    const uint64_t q_first = P.q0 + (uint64_t)blockIdx.x * T;
+    for (int k = tid; k < P.I * P.Jp; k += (int)T) taps[k] = P.taps[k];
     // input index of output q: c(q) = floor(q*D/I); the tile needs [c(q_first) - (Jp-1), c(q_last)]
     const int64_t c_first = (int64_t)((q_first * (uint64_t)P.D) / (uint64_t)P.I);
     const int64_t base = c_first - (P.Jp - 1);
-    for (int k = tid; k < span; k += 256) xs[k] = resamp_fetch(P, b, base + k);
+    for (int k = tid; k < span; k += (int)T) xs[k] = resamp_fetch(P, b, base + k);
     __syncthreads();
     const uint64_t q = q_first + tid;
     if (q >= P.q0 + P.q_count) return;
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void k_resamp(const ResampParams P, int span)
         ai = fmaf(h, x.y, ai);
     }
     P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)q & P.out.mask)] = make_float2(ar, ai);
-    const uint32_t t = blockIdx.x * 256u + tid;   // output index inside this call
+    const uint32_t t = blockIdx.x * T + tid;   // output index inside this call
     if (P.port && t < P.port_cap) P.port[(size_t)b * P.port_cap + t] = make_float2(ar, ai);
     if (t == 0 && P.port_counts) P.port_counts[b * 4 + 0] = P.q_count;
 }
@@ -324,11 +325,14 @@ __global__ __launch_bounds__(256) void k_resamp(const ResampParams P, int span)
 void launch_resamp(const ResampParams& p, int batch, hipStream_t s)
 {
     if (p.q_count == 0) return;
-    // span of inputs for 256 outputs: ceil(255*D/I) + 1 + Jp - 1 (+1 slack)
-    const int span = (255 * p.D + p.I - 1) / p.I + p.Jp + 2;
+    // span of inputs for T outputs: ceil((T - 1) * D / I) + 1 + Jp - 1 (+1 slack).  Strongly decimating resamplers (3:125 of gr_demod_dmr /
+    // gr_demod_m17: 10 974 inputs = 88 KB for 256 outputs) take 64 outputs per workgroup so that several workgroups share a CU
+    int T = 256;
+    int span = ((T - 1) * p.D + p.I - 1) / p.I + p.Jp + 2;
+    if ((size_t)span * sizeof(float2) > 48 * 1024) { T = 64; span = ((T - 1) * p.D + p.I - 1) / p.I + p.Jp + 2; }
     const size_t lds = (size_t)((p.I * p.Jp + 3) & ~3) * sizeof(float) + (size_t)span * sizeof(float2);
     if (dyn_lds_limit(reinterpret_cast<const void*>(k_resamp), 160 * 1024) != hipSuccess) return;
-    dim3 grid((p.q_count + 255) / 256, batch), block(256);
+    dim3 grid((p.q_count + T - 1) / T, batch), block(T);
     hipLaunchKernelGGL(k_resamp, grid, block, lds, s, p, span);
 }
 
