@@ -15,8 +15,9 @@
  * EXCEPTION -- pinned against the real reference: what the reference implements in its OWN plain C++ is compiled from where it
  * lies (make -C oracle ref -> oracle/_ref/libqrl_ref.so, built from /root/reference sources + oracle/gr_stub) and the
  * restatement must reproduce it exactly: gr_dmr_dmo_sink (orc_dmr.c), gr_deframer_bb, gr_4fsk_discriminator, rssi_tag_block,
- * gr_zero_idle_bursts, calculate_deemph_taps, BurstTimer + gr_mmdvm_sink + gr_mmdvm_source (host/mmdvm_wire.cpp), CBPTC19696 + CHamming, M17FrameDecoder + M17Viterbi + Golay(24,12) (orc_framefec.c):
- * tests/test_ref_blocks.py, tests/test_ref_mmdvm.py, tests/test_framefec.py, tests/golden/ref/.
+ * gr_zero_idle_bursts, dsss_decoder_cc / dsss_encoder_bb, cessb clipper / stretcher, calculate_deemph_taps, gr_modem (orc_modem_sync; host/gr_modem_hip.cpp),
+ * BurstTimer + gr_mmdvm_sink + gr_mmdvm_source (host/mmdvm_wire.cpp), CBPTC19696 + CHamming, M17FrameDecoder + M17Viterbi + Golay(24,12) (orc_framefec.c):
+ * tests/test_ref_blocks.py, tests/test_ref_mmdvm.py, tests/test_ref_modem.py, tests/test_framefec.py, tests/golden/ref/.
  *
  * ARITHMETIC CONTRACT (what makes GPU results bit-identical to this oracle):
  *   - IEEE-754 binary32, round-to-nearest-even, no flush-to-zero, compiled with

@@ -42,7 +42,7 @@ bool modem_two_branches(int modem_type);                       // the modes whos
 class gr_demod_base_hip {
 public:
     gr_demod_base_hip(qrl_runtime& rt, int streams, int device_samp_rate = 1000000, double carrier_offset_hz = 0.0, size_t max_chunk = 1 << 18);
-    ~gr_demod_base_hip();
+    virtual ~gr_demod_base_hip();
     void set_mode(int mode);                                   // gr_modem_types value; flushes the mailboxes like the reference's graph swap
     void set_carrier_offset(double hz);
     void set_samp_rate(int device_samp_rate);
@@ -52,7 +52,7 @@ public:
     void work(const gr_complex* const* iq, size_t n);
     void flush();                                              // waits for the call in flight and harvests it
     std::vector<unsigned char>* getData(int stream = 0) { return getData(1, stream); }
-    std::vector<unsigned char>* getData(int nr, int stream);   // nr = 1: bits A (port 2), nr = 2: bits B (port 3); nullptr = nothing yet
+    virtual std::vector<unsigned char>* getData(int nr, int stream);   // nr = 1: bits A (port 2), nr = 2: bits B (port 3); nullptr = nothing yet (virtual: tests tap the bits)
     std::vector<gr_complex>* get_constellation_data(int stream = 0);
     std::vector<std::vector<unsigned char>> getDMRData(int stream = 0);   // DMR mode: 40-byte DMO records (QRL_DMO_RECORD_BYTES)
     // analogue voice modes (NBFM2500 / NBFM5000 / AM5000 / WBFM): port 1 = audio at 8 ksps (gr_demod_base::getAudio :968-976; caller deletes)
@@ -96,9 +96,9 @@ private:
 class gr_mod_base_hip {
 public:
     gr_mod_base_hip(qrl_runtime& rt, int streams, int device_samp_rate = 1000000, double carrier_offset_hz = 0.0, size_t max_bytes = 8192);
-    ~gr_mod_base_hip();
+    virtual ~gr_mod_base_hip();
     void set_mode(int mode);
-    int set_data(std::vector<uint8_t>* data, int stream = 0);  // takes ownership (gr_byte_source::set_data); 1 = queued
+    virtual int set_data(std::vector<uint8_t>* data, int stream = 0);  // takes ownership (gr_byte_source::set_data); 1 = queued (virtual: tests tap the bytes)
     void set_bb_gain(float value);
     void set_carrier_offset(double hz);
     // one scheduler pass: consumes up to max_bytes queued bytes of every stream (zero padded to the longest) and returns the

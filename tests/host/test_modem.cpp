@@ -24,6 +24,42 @@ static std::string hex(const unsigned char* d, int n)
 
 int main(int argc, char** argv)
 {
+    if (argc == 4 && !strcmp(argv[1], "txpin")) {
+        // test_modem txpin <modem_type> <out.bin>: a fixed script of gr_modem's TX entry points; the bytes the facade hands to the byte
+        // source (gr_mod_base::set_data) are written out and compared with what the REFERENCE's gr_modem produces for the same script
+        // (tests/test_gpu_modem_facade.py, oracle/ref_shim_modem.cpp)
+        const int mode = atoi(argv[2]);
+        try {
+            qrl_runtime rt(0);
+            struct tap_mod : gr_mod_base_hip {
+                using gr_mod_base_hip::gr_mod_base_hip;
+                std::vector<uint8_t> sent;
+                int set_data(std::vector<uint8_t>* data, int stream) override { if (stream == 0) sent.insert(sent.end(), data->begin(), data->end()); delete data; return 1; }
+            } mod(rt, 1, 1000000, 0.0, 4096);
+            gr_modem_events ev;
+            gr_modem_hip modem(nullptr, &mod, ev);
+            modem.toggleTxMode(mode);
+            const int L = modem_tx_frame_length(mode);
+            modem.startTransmission("N0CALL");
+            for (int f = 0; f < 3; ++f) {
+                unsigned char* d = new unsigned char[L];
+                for (int i = 0; i < L; ++i) d[i] = (unsigned char)(31 * f + 7 * i + 1);
+                modem.transmitDigitalAudio(d, L);
+            }
+            modem.transmitTextData("the quick brown fox jumps over the lazy dog 0123456789");
+            std::vector<unsigned char> bin(2 * L + 3);
+            for (size_t i = 0; i < bin.size(); ++i) bin[i] = (unsigned char)(200 - i);
+            modem.transmitBinData(bin);
+            { unsigned char* d = new unsigned char[L]; for (int i = 0; i < L; ++i) d[i] = (unsigned char)(i ^ 0x5A); modem.transmitVideoData(d, L); }
+            { unsigned char* d = new unsigned char[L]; for (int i = 0; i < L; ++i) d[i] = (unsigned char)(i * 3); modem.transmitNetData(d, L); }
+            modem.sendCallsign("AB1CD");
+            modem.endTransmission("N0CALL");
+            std::ofstream o(argv[3], std::ios::binary);
+            o.write(reinterpret_cast<const char*>(mod.sent.data()), (std::streamsize)mod.sent.size());
+            std::printf("txpin ok: %zu bytes\n", mod.sent.size());
+            return 0;
+        } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+    }
     if (argc == 6 && !strcmp(argv[1], "analog")) {
         // test_modem analog <modem_type> <streams> <iq.bin: [streams][n] cf32> <audio prefix>: the facade's analogue path the way
         // radiocontroller polls it (gr_modem::demodulateAnalog -> pcmAudio); stream s's audio goes to <prefix><s>.bin
@@ -74,10 +110,38 @@ int main(int argc, char** argv)
         ev.dataFrameReceived = [&](int s) { log << s << " dataframe\n"; };
         ev.endAudioTransmission = [&](int s) { log << s << " endaudio\n"; };
         ev.receiveEnd = [&](int s) { log << s << " receiveend\n"; };
+        // QRL_TEST_TAP=<file>: every bit vector demodulate() pulls out of the mailboxes ("B stream nr bits"), every demodulate() call
+        // ("D stream") and every event ("E stream text") in order: tests/test_gpu_modem_facade.py replays the bits into the REFERENCE's
+        // gr_modem and compares the events
+        FILE* tap = getenv("QRL_TEST_TAP") ? std::fopen(getenv("QRL_TEST_TAP"), "w") : nullptr;
+        if (tap) {
+            ev.digitalAudio = [&, tap](int s, const unsigned char* d, int n) { log << s << " audio " << hex(d, n) << "\n"; std::fprintf(tap, "E %d audio %s\n", s, hex(d, n).c_str()); };
+            ev.textReceived = [&, tap](int s, const std::string& t, bool h) { log << s << " text " << hex(reinterpret_cast<const unsigned char*>(t.data()), (int)t.size()) << "\n";
+                                                                          std::fprintf(tap, "E %d %s %s\n", s, h ? "html" : "text", hex(reinterpret_cast<const unsigned char*>(t.data()), (int)t.size()).c_str()); };
+            ev.callsignReceived = [&, tap](int s, const std::string& c) { log << s << " callsign " << c << "\n"; std::fprintf(tap, "E %d callsign %s\n", s, c.c_str()); };
+            ev.dataFrameReceived = [&, tap](int s) { log << s << " dataframe\n"; std::fprintf(tap, "E %d dataframe\n", s); };
+            ev.endAudioTransmission = [&, tap](int s) { log << s << " endaudio\n"; std::fprintf(tap, "E %d endaudio\n", s); };
+            ev.receiveEnd = [&, tap](int s) { log << s << " receiveend\n"; std::fprintf(tap, "E %d receiveend\n", s); };
+            ev.videoData = [tap](int s, const unsigned char* d, int n) { std::fprintf(tap, "E %d video %s\n", s, hex(d, n).c_str()); };
+            ev.netData = [tap](int s, const unsigned char* d, int n) { std::fprintf(tap, "E %d net %s\n", s, hex(d, n).c_str()); };
+            ev.protoReceived = [tap](int s, const std::vector<unsigned char>& d) { std::fprintf(tap, "E %d proto %s\n", s, hex(d.data(), (int)d.size()).c_str()); };
+        }
+        struct tap_demod : gr_demod_base_hip {
+            using gr_demod_base_hip::gr_demod_base_hip;
+            FILE* tap = nullptr;
+            std::vector<unsigned char>* getData(int nr, int stream) override
+            {
+                std::vector<unsigned char>* v = gr_demod_base_hip::getData(nr, stream);
+                if (tap && v) { std::string b(v->size(), '0'); for (size_t i = 0; i < v->size(); ++i) b[i] = (char)('0' + ((*v)[i] & 1)); std::fprintf(tap, "B %d %d %s\n", stream, nr, b.c_str()); }
+                return v;
+            }
+        };
         const size_t chunk = 1 << 17;
-        gr_demod_base_hip demod(rt, N, 1000000, 0.0, chunk);
+        tap_demod demod(rt, N, 1000000, 0.0, chunk);
+        demod.tap = tap;
         gr_mod_base_hip mod(rt, N, 1000000, 0.0, 4096);
         gr_modem_hip modem(&demod, &mod, ev);
+        if (getenv("QRL_TEST_BRANCH")) modem.set_branch_rule(gr_modem_hip::BranchRuleReference);   // the reference's literal `>=` rule (like-for-like replay)
         modem.toggleTxMode(mode);
         modem.toggleRxMode(mode);
         demod.enable_rssi(true);
@@ -138,7 +202,7 @@ int main(int argc, char** argv)
                 }
                 continue;
             }
-            for (int s = 0; s < N; ++s) while (modem.demodulate(s)) {}
+            for (int s = 0; s < N; ++s) for (;;) { if (tap) std::fprintf(tap, "D %d\n", s); if (!modem.demodulate(s)) break; }
             for (int s = 0; s < N; ++s) { const float v = demod.get_rssi(s); if (v != 0.0f) rssi_max[s] = std::max(rssi_max[s], v); }   // (0 = the probe before its first item)
             unsigned got = 0;
             demod.get_FFT_data(spectrum.data(), got, 0);   // the GUI timer of the reference polls like this
@@ -149,7 +213,8 @@ int main(int argc, char** argv)
         }
         if (bitlog) std::fclose(bitlog);
         demod.flush();
-        for (int s = 0; s < N; ++s) while (modem.demodulate(s)) {}
+        for (int s = 0; s < N; ++s) for (;;) { if (tap) std::fprintf(tap, "D %d\n", s); if (!modem.demodulate(s)) break; }
+        if (tap) std::fclose(tap);
         for (int s = 0; s < N; ++s) log << s << " modem_sync " << modem.modem_sync(s) << "\n";
         for (int s = 0; s < N; ++s) log << s << " rssi " << demod.get_rssi(s) << "\n" << s << " rssi_max " << rssi_max[s] << "\n";
         log << "0 spectra " << spectra << "\n" << "0 peak_bin " << peak_bin << "\n" << "0 peak_db " << peak_db << "\n";
