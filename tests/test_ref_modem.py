@@ -142,3 +142,46 @@ def test_frame_synchroniser_oracle_equals_the_reference_class(ref, mt):
             recs.append((ft, p, int(ms.st[4])))
     assert len(recs) >= 8
     assert got == _expected(recs, rx_len)
+
+
+def test_m17_frames_through_the_reference_gr_modem(ref):
+    """mode 40: the oracle's frame synchroniser (class 3: LSF 0x55F7, stream 0xFF5D, EOT 0x555D555D; 46-byte frames) and frame decoder
+    against the reference's gr_modem, which runs its own M17FrameDecoder on what its synchroniser cuts out: frames made by the
+    reference's M17FrameEncoder, embedded in noise bits.  Every stream frame's 16 payload bytes must come out as digitalAudio, in
+    order, and equal what orc_m17_decode_frame makes of the oracle's records; the LSF produces one m17FrameInfoReceived."""
+    import test_framefec as F
+    L = C.CDLL(REF)
+    rng = np.random.default_rng(40)
+    lsf28 = rng.integers(0, 256, 28, dtype=np.uint8)
+    lsf28[:12] = [0, 0, 0x4B, 0x13, 0xD1, 0x06, 0, 0, 0x4B, 0x13, 0xD1, 0x07]      # two ordinary base-40 call signs
+    pl = rng.integers(0, 256, (12, 16), dtype=np.uint8)
+    frames = np.zeros((13, 48), np.uint8)
+    L.ref_m17_encode(F.P(lsf28), F.P(pl), 12, F.P(frames))
+    bits = [rng.integers(0, 2, 100, dtype=np.uint8)]
+    for f in frames:
+        bits += [np.unpackbits(f), rng.integers(0, 2, int(rng.integers(0, 30)), dtype=np.uint8)]
+    bits = np.concatenate(bits)
+    m = ref.ref_modem_new()
+    ref.ref_modem_init_rx(m, 40)
+    got, pos = [], 0
+    while pos < bits.size:
+        n = int(rng.integers(32, 700))
+        part = np.ascontiguousarray(bits[pos:pos + n])
+        ref.ref_modem_push(m, 0, part.ctypes.data, part.size)
+        ref.ref_modem_demodulate(m)
+        got += _events(ref, m)
+        pos += n
+    ref.ref_modem_free(m)
+    ms = orc.ModemSync(40)
+    recs = ms.feed(bits)
+    audio = []
+    for ft, p in recs:
+        frame = np.frombuffer(ft.to_bytes(2, "big") + p[:46], np.uint8) if ft in (0x55F7, 0xFF5D) else None
+        if frame is not None:
+            rec = F.orc_m17_records(frame[None, :])[0]
+            if rec[0] == 2:
+                audio.append("audio " + bytes(rec[4:20]).hex())
+    assert [ft for ft, _ in recs].count(0xFF5D) >= 12 and [ft for ft, _ in recs].count(0x55F7) >= 1
+    assert [e for e in got if e.startswith("audio ")] == audio and len(audio) >= 12
+    assert audio[:12] == ["audio " + bytes(p).hex() for p in pl]
+    assert sum(e.startswith("m17info ") for e in got) == 1
