@@ -260,14 +260,14 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
     if (!h->single) rssi(h->r3.p);
     QuadDemodParams qp{};
     qp.in = RingC{h->r3.p, h->m2}; qp.out = RingF{h->r4.p, h->m2}; qp.q0 = h->n2; qp.count = c2; qp.gain = h->gain; qp.atan_tab = h->atan_tab.p;
+    if (h->fsk_bits) {   // the 4FSK tail's discriminator (gr_demod_dmr.cpp:72-76: 24000 / (pi/2 * 4800)) reads the same items: one pass for both
+        qp.out2 = RingF{h->r5.p, h->m2};
+        qp.gain2 = (float)(24000 / (M_PI / 2 * (float)(24000 / 5)));
+    }
     launch_quad_demod(qp, S, h->stream);
     if (h->fsk_bits) {   // gr_demod_dmr.cpp:72-105 behind the channel filter: discriminator (24000 / (pi/2 * 4800)) -> RRC -> symbol_sync_ff -> dibits
         HIPCHK(hipMemsetAsync(h->fsk_counts, 0, (size_t)S * 4 * sizeof(uint32_t), h->stream));
-        QuadDemodParams q5{};
-        q5.in = RingC{h->r3.p, h->m2}; q5.out = RingF{h->r5.p, h->m2}; q5.q0 = h->n2; q5.count = c2;
-        q5.gain = (float)(24000 / (M_PI / 2 * (float)(24000 / 5))); q5.atan_tab = h->atan_tab.p;
-        launch_quad_demod(q5, S, h->stream);
-        FirFffParams f6{}; f6.in = q5.out; f6.out = RingF{h->r6.p, h->m2}; f6.q0 = h->n2; f6.count = c2; f6.taps = h->symf_taps.p; f6.nt = h->symf_nt;
+        FirFffParams f6{}; f6.in = RingF{h->r5.p, h->m2}; f6.out = RingF{h->r6.p, h->m2}; f6.q0 = h->n2; f6.count = c2; f6.taps = h->symf_taps.p; f6.nt = h->symf_nt;
         launch_fir_fff(f6, S, h->stream);
         SymSyncParams s{};
         s.in = f6.out; s.avail = n2_1; s.soft = RingB{h->soft_dummy.p, 63}; s.st = h->ss.p; s.mmse = h->mmse.p;

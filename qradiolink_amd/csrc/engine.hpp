@@ -88,7 +88,8 @@ void launch_resamp(const ResampParams& p, int batch, hipStream_t s);
 struct FirCcfParams { RingC in; RingC out; uint64_t q0; uint32_t count; const float* taps; int nt;
                       float2* port; size_t port_cap; uint32_t* counts; };  // optional copy to a caller port buffer; counts[b*4+0]
 struct FirFffParams { RingF in; RingF out; uint64_t q0; uint32_t count; const float* taps; int nt; };
-struct QuadDemodParams { RingC in; RingF out; uint64_t q0; uint32_t count; float gain; const float* atan_tab; };
+struct QuadDemodParams { RingC in; RingF out; uint64_t q0; uint32_t count; float gain; const float* atan_tab;
+                         RingF out2; float gain2; };   // out2.p != nullptr: a second discriminator with its own gain on the same input (C4: MMDVM FM path + 4FSK tail)
 struct Disc2fskParams { RingC in; RingF out; uint64_t q0; uint32_t count; const float2* up; const float2* lo; int nt; };
 struct Disc4fskParams { RingC in; RingC out; uint64_t q0; uint32_t count; const float2* taps; int nt; };   // taps[4][nt]
 void launch_disc_4fsk(const Disc4fskParams& p, int batch, hipStream_t s);

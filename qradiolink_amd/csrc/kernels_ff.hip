@@ -152,7 +152,9 @@ __global__ __launch_bounds__(256) void k_quad_demod(const QuadDemodParams P)
     const float2 a = ringc_at(P.in, b, n), p = ringc_at(P.in, b, n - 1);
     const float re = a.x * p.x + a.y * p.y;
     const float im = a.y * p.x - a.x * p.y;
-    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = P.gain * fast_atan2f_lut(im, re, T);
+    const float ang = fast_atan2f_lut(im, re, T);
+    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = P.gain * ang;
+    if (P.out2.p) P.out2.p[(size_t)b * (P.out2.mask + 1u) + ((uint32_t)n & P.out2.mask)] = P.gain2 * ang;
 }
 void launch_quad_demod(const QuadDemodParams& p, int batch, hipStream_t s)
 {
