@@ -264,6 +264,7 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
         qp.out2 = RingF{h->r5.p, h->m2};
         qp.gain2 = (float)(24000 / (M_PI / 2 * (float)(24000 / 5)));
     }
+    if (out) { qp.s16 = out; qp.s16_cap = out_cap; qp.s16_level = h->level; qp.s16_scale = 32767.0f; qp.s16_counts = counts; }   // _level + float_to_short in the same pass
     launch_quad_demod(qp, S, h->stream);
     if (h->fsk_bits) {   // gr_demod_dmr.cpp:72-105 behind the channel filter: discriminator (24000 / (pi/2 * 4800)) -> RRC -> symbol_sync_ff -> dibits
         HIPCHK(hipMemsetAsync(h->fsk_counts, 0, (size_t)S * 4 * sizeof(uint32_t), h->stream));
@@ -277,10 +278,6 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
         s.port = reinterpret_cast<float2*>(h->fsk_const); s.port_cap = h->fsk_const ? h->fsk_const_cap : 0; s.counts = h->fsk_counts;
         launch_symsync_ff(s, S, h->stream);
     }
-    F2sParams sp{};
-    sp.in = RingF{h->r4.p, h->m2}; sp.q0 = h->n2; sp.count = c2; sp.level = h->level; sp.scale = 32767.0f;
-    sp.out = out; sp.cap = out_cap; sp.counts = counts;
-    if (out) launch_f2s(sp, S, h->stream);
     HIPCHK(hipGetLastError());
     if (qrl::take_launch_error()) return QRL_ERR_HIP;
     h->n_in += n; h->n1 = n1_1; h->n2 = n2_1;

@@ -89,7 +89,8 @@ struct FirCcfParams { RingC in; RingC out; uint64_t q0; uint32_t count; const fl
                       float2* port; size_t port_cap; uint32_t* counts; };  // optional copy to a caller port buffer; counts[b*4+0]
 struct FirFffParams { RingF in; RingF out; uint64_t q0; uint32_t count; const float* taps; int nt; };
 struct QuadDemodParams { RingC in; RingF out; uint64_t q0; uint32_t count; float gain; const float* atan_tab;
-                         RingF out2; float gain2; };   // out2.p != nullptr: a second discriminator with its own gain on the same input (C4: MMDVM FM path + 4FSK tail)
+                         RingF out2; float gain2;      // out2.p != nullptr: a second discriminator with its own gain on the same input (C4: MMDVM FM path + 4FSK tail)
+                         int16_t* s16; size_t s16_cap; float s16_level, s16_scale; uint32_t* s16_counts; };   // s16 != nullptr: + multiply_const_ff(level) + float_to_short(scale) of `out` (k_f2s fused)
 struct Disc2fskParams { RingC in; RingF out; uint64_t q0; uint32_t count; const float2* up; const float2* lo; int nt; };
 struct Disc4fskParams { RingC in; RingC out; uint64_t q0; uint32_t count; const float2* taps; int nt; };   // taps[4][nt]
 void launch_disc_4fsk(const Disc4fskParams& p, int batch, hipStream_t s);

@@ -155,6 +155,13 @@ __global__ __launch_bounds__(256) void k_quad_demod(const QuadDemodParams P)
     const float ang = fast_atan2f_lut(im, re, T);
     P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)n & P.out.mask)] = P.gain * ang;
     if (P.out2.p) P.out2.p[(size_t)b * (P.out2.mask + 1u) + ((uint32_t)n & P.out2.mask)] = P.gain2 * ang;
+    if (P.s16) {   // multiply_const_ff(level) + float_to_short(1, scale) (gr_demod_mmdvm_multi2.cpp:84,92), as k_f2s
+        float r = rintf(((P.gain * ang) * P.s16_level) * P.s16_scale);
+        if (r > 32767.0f) r = 32767.0f;
+        if (r < -32768.0f) r = -32768.0f;
+        if (t < P.s16_cap) P.s16[(size_t)b * P.s16_cap + t] = (int16_t)r;
+        if (t == 0 && P.s16_counts) P.s16_counts[b] = P.count < P.s16_cap ? P.count : (uint32_t)P.s16_cap;
+    }
 }
 void launch_quad_demod(const QuadDemodParams& p, int batch, hipStream_t s)
 {
