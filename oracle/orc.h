@@ -36,6 +36,14 @@
 
 #ifdef __cplusplus
 extern "C" {
+/* ---- construction trace (orc_trace.c): which primitives a chain calls, with which parameters; tests/test_ref_chains.py ---- */
+void orc_trace_enable(int on);            /* clears the trace; on != 0 starts recording */
+int  orc_trace_on(void);
+const char* orc_trace_get(void);          /* one "name(args)" line per primitive call */
+void orc_trace_event(const char* fmt, ...);
+void orc_trace_taps(const void* taps, size_t bytes, const char* fmt, ...);
+const char* orc_trace_name(const void* taps, size_t bytes);
+
 #endif
 
 typedef struct { float re, im; } cf32;
@@ -183,6 +191,14 @@ double orc_batch_rx(int mode, const cf32* iq, int batch, size_t n, int samp_rate
 
 #ifdef __cplusplus
 }
+/* ---- construction trace (orc_trace.c): which primitives a chain calls, with which parameters; tests/test_ref_chains.py ---- */
+void orc_trace_enable(int on);            /* clears the trace; on != 0 starts recording */
+int  orc_trace_on(void);
+const char* orc_trace_get(void);          /* one "name(args)" line per primitive call */
+void orc_trace_event(const char* fmt, ...);
+void orc_trace_taps(const void* taps, size_t bytes, const char* fmt, ...);
+const char* orc_trace_name(const void* taps, size_t bytes);
+
 #endif
 /* side outputs of gr_demod_base (orc_side.c) */
 /* analogue voice receivers (orc_analog.c) */
@@ -213,5 +229,13 @@ uint16_t orc_m17_crc16(const uint8_t* p, size_t n);
 float orc_det_log2f(float x);
 void orc_rssi_block(const cf32* in, size_t n, float level, float* out);
 void orc_power_spectrum(const cf32* in, const float* window, size_t n, float* out);
+
+/* ---- construction trace (orc_trace.c): which primitives a chain calls, with which parameters; tests/test_ref_chains.py ---- */
+void orc_trace_enable(int on);            /* clears the trace; on != 0 starts recording */
+int  orc_trace_on(void);
+const char* orc_trace_get(void);          /* one "name(args)" line per primitive call */
+void orc_trace_event(const char* fmt, ...);
+void orc_trace_taps(const void* taps, size_t bytes, const char* fmt, ...);
+const char* orc_trace_name(const void* taps, size_t bytes);
 
 #endif

@@ -36,6 +36,7 @@ int orc_complex_band_pass_2(double gain, double fs, double lo, double hi, double
         phase += freq;
     }
     free(lp);
+    orc_trace_taps(taps, sizeof(cf32) * (size_t)ntaps, "complex_band_pass_2(%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%d)", gain, fs, lo, hi, tw, atten_db, win);
     return ntaps;
 }
 
@@ -64,6 +65,7 @@ void orc_squelch_envelope(int ramp, float* env)
  * (a complex product with (env, 0)); a MUTED item is dropped when gating, else emitted as zero.  Returns the output count. */
 size_t orc_pwr_squelch_cc(const cf32* in, size_t n, double db, double alpha, int ramp, int gate, cf32* out)
 {
+    orc_trace_event("pwr_squelch_cc(%.17g,%.17g,%d,%d)", db, alpha, ramp, gate);
     const double threshold = pow(10.0, db / 10);
     double pwr = 0.0;
     int state = 0, ramped = 0;
@@ -102,6 +104,7 @@ size_t orc_pwr_squelch_cc(const cf32* in, size_t n, double db, double alpha, int
 /* agc2_ff(attack, decay, reference, gain), max gain 65536 */
 void orc_agc2_ff(const float* in, size_t n, float attack, float decay, float ref, float gain, float max_gain, float* out)
 {
+    orc_trace_event("agc2_ff(%.9g,%.9g,%.9g,%.9g,%.9g)", attack, decay, ref, gain, max_gain);
     for (size_t i = 0; i < n; i++) {
         const float o = in[i] * gain;
         const float tmp = -ref + fabsf(o);
@@ -118,6 +121,7 @@ void orc_agc2_ff(const float* in, size_t n, float attack, float decay, float ref
  * output (float)acc.  oldstyle: fb taps as given; new style: negated (y = sum b x - sum a y). */
 void orc_iir_ffd_2(const float* in, size_t n, const double ff[2], const double fb[2], int oldstyle, float* out)
 {
+    orc_trace_event("iir_ffd(%.17g,%.17g,%.17g,%.17g,%d)", ff[0], ff[1], fb[0], fb[1], oldstyle);
     const double fb1 = oldstyle ? fb[1] : -fb[1];
     float xp = 0.0f; double yp = 0.0;
     for (size_t i = 0; i < n; i++) {

@@ -233,6 +233,7 @@ size_t orc_decim_fir_ccf_simd(const cf32* in, size_t n, const float* taps, int n
 }
 size_t orc_decim_auto(const cf32* in, size_t n, const float* taps, int nt, int D, cf32* out)
 {
+    orc_trace_event("resamp_ccf(1,%d,%s)", D, orc_trace_name(taps, sizeof(float) * (size_t)nt));
     if (g_decim_impl == 1) return orc_decim_fir_ccf_simd(in, n, taps, nt, D, out);
     if (orc_decim_uses_pl(nt, D)) return orc_decim_fir_ccf_pl(in, n, taps, nt, D, out);
     if (orc_decim_uses_m16(nt, D)) return orc_decim_fir_ccf_m16(in, n, taps, nt, D, out);
@@ -242,6 +243,7 @@ size_t orc_decim_auto(const cf32* in, size_t n, const float* taps, int nt, int D
 /* General I/D.  One fmaf chain per output, j ascending. */
 size_t orc_resamp_ccf(const cf32* in, size_t n, const float* taps, int nt, int I, int D, cf32* out)
 {
+    orc_trace_event("resamp_ccf(%d,%d,%s)", I, D, orc_trace_name(taps, sizeof(float) * (size_t)nt));
     size_t nout = orc_decim_count(n, I, D);
     for (size_t i = 0; i < nout; i++) {
         uint64_t u = (uint64_t)i * (uint64_t)D;
@@ -261,6 +263,7 @@ size_t orc_resamp_ccf(const cf32* in, size_t n, const float* taps, int nt, int I
 }
 size_t orc_resamp_fff(const float* in, size_t n, const float* taps, int nt, int I, int D, float* out)
 {
+    orc_trace_event("resamp_fff(%d,%d,%s)", I, D, orc_trace_name(taps, sizeof(float) * (size_t)nt));
     size_t nout = orc_decim_count(n, I, D);
     for (size_t i = 0; i < nout; i++) {
         uint64_t u = (uint64_t)i * (uint64_t)D;
@@ -283,6 +286,7 @@ size_t orc_resamp_fff(const float* in, size_t n, const float* taps, int nt, int 
  * ------------------------------------------------------------------------------------------ */
 void orc_fir_ccf(const cf32* in, size_t n, const float* taps, int nt, cf32* out)
 {
+    orc_trace_event("fir_ccf(%s)", orc_trace_name(taps, sizeof(float) * (size_t)nt));
     for (size_t i = 0; i < n; i++) {
         float ar = 0.0f, ai = 0.0f;
         for (int k = 0; k < nt && (size_t)k <= i; k++) {
@@ -295,6 +299,7 @@ void orc_fir_ccf(const cf32* in, size_t n, const float* taps, int nt, cf32* out)
 /* complex taps: re += hr*xr; re += (-hi)*xi; im += hr*xi; im += hi*xr */
 void orc_fir_ccc(const cf32* in, size_t n, const cf32* taps, int nt, cf32* out)
 {
+    orc_trace_event("fir_ccc(%s)", orc_trace_name(taps, sizeof(cf32) * (size_t)nt));
     for (size_t i = 0; i < n; i++) {
         float ar = 0.0f, ai = 0.0f;
         for (int k = 0; k < nt && (size_t)k <= i; k++) {
@@ -309,6 +314,7 @@ void orc_fir_ccc(const cf32* in, size_t n, const cf32* taps, int nt, cf32* out)
 }
 void orc_fir_fff(const float* in, size_t n, const float* taps, int nt, float* out)
 {
+    orc_trace_event("fir_fff(%s)", orc_trace_name(taps, sizeof(float) * (size_t)nt));
     for (size_t i = 0; i < n; i++) {
         float a = 0.0f;
         for (int k = 0; k < nt && (size_t)k <= i; k++) a = fmaf(taps[k], in[i - k], a);
@@ -343,6 +349,7 @@ static inline float branchless_clip(float x, float clip)
  * ------------------------------------------------------------------------------------------ */
 void orc_fll_band_edge(const cf32* in, size_t n, float sps, float rolloff, int nt, float bw, cf32* out)
 {
+    orc_trace_event("fll_band_edge(%.9g,%.9g,%d,%.9g)", sps, rolloff, nt, bw);
     cf32* lower = (cf32*)malloc(sizeof(cf32) * (size_t)nt);
     cf32* upper = (cf32*)malloc(sizeof(cf32) * (size_t)nt);
     cf32* dl = (cf32*)calloc((size_t)nt, sizeof(cf32)); /* dl[j] = y[n-j] */
@@ -391,6 +398,7 @@ void orc_fll_band_edge(const cf32* in, size_t n, float sps, float rolloff, int n
 /* quadrature_demod_cf [gr-analog/lib/quadrature_demod_cf_impl.cc]: history 2 */
 void orc_quad_demod(const cf32* in, size_t n, float gain, float* out)
 {
+    orc_trace_event("quad_demod(%.9g)", gain);
     cf32 prev = {0, 0};
     for (size_t i = 0; i < n; i++) {
         cf32 a = in[i];
@@ -404,6 +412,7 @@ void orc_quad_demod(const cf32* in, size_t n, float gain, float* out)
 /* agc2_cc [gr-analog include/gnuradio/analog/agc2.h] */
 void orc_agc2(const cf32* in, size_t n, float attack, float decay, float ref, float gain, float max_gain, cf32* out)
 {
+    orc_trace_event("agc2_cc(%.9g,%.9g,%.9g,%.9g,%.9g)", attack, decay, ref, gain, max_gain);
     for (size_t i = 0; i < n; i++) {
         cf32 o; o.re = in[i].re * gain; o.im = in[i].im * gain;
         float tmp = -ref + sqrtf(o.re * o.re + o.im * o.im);
@@ -419,6 +428,7 @@ void orc_agc2(const cf32* in, size_t n, float attack, float decay, float ref, fl
 /* costas_loop_cc [gr-digital/lib/costas_loop_cc_impl.cc] */
 void orc_costas(const cf32* in, size_t n, float bw, int order, int use_snr, cf32* out)
 {
+    orc_trace_event("costas(%.9g,%d,%d)", bw, order, use_snr);
     float alpha, beta;
     orc_control_loop_gains(bw, &alpha, &beta);
     float phase = 0, freq = 0;
@@ -478,6 +488,7 @@ static inline void clock_advance(clock_loop* c, float e)
 size_t orc_symbol_sync_ff(const float* in, size_t n, int ted, float sps, float loop_bw, float damping,
                           float ted_gain, float max_dev, int constellation, float* out)
 {
+    orc_trace_event("symbol_sync_ff(%d,%.9g,%.9g,%.9g,%.9g,%.9g,%d)", ted, sps, loop_bw, damping, ted_gain, max_dev, constellation);
     const float* T = orc_mmse_table();
     clock_loop c; c.avg = sps; c.inst = sps; c.maxp = sps + max_dev; c.minp = sps - max_dev;
     orc_clock_loop_gains(loop_bw, damping, ted_gain, &c.alpha, &c.beta);
@@ -506,6 +517,7 @@ size_t orc_symbol_sync_ff(const float* in, size_t n, int ted, float sps, float l
 size_t orc_symbol_sync_cc(const cf32* in, size_t n, int ted, float sps, float loop_bw, float damping,
                           float ted_gain, float max_dev, int constellation, cf32* out)
 {
+    orc_trace_event("symbol_sync_cc(%d,%.9g,%.9g,%.9g,%.9g,%.9g,%d)", ted, sps, loop_bw, damping, ted_gain, max_dev, constellation);
     const float* T = orc_mmse_table();
     /* dqpsk: (+-0.707107, +-0.707107) by sign; 4-level rect (gr_demod_4fsk non-FM branch): real-axis sector point, imag 0 */
     clock_loop c; c.avg = sps; c.inst = sps; c.maxp = sps + max_dev; c.minp = sps - max_dev;
@@ -546,6 +558,7 @@ size_t orc_symbol_sync_cc(const cf32* in, size_t n, int ted, float sps, float lo
 
 void orc_diff_phasor(const cf32* in, size_t n, cf32* out)
 {
+    orc_trace_event("diff_phasor()");
     cf32 prev = {0, 0};
     for (size_t i = 0; i < n; i++) {
         cf32 a = in[i];
@@ -558,6 +571,7 @@ void orc_diff_phasor(const cf32* in, size_t n, cf32* out)
 /* multiply_const_ff -> add_const_ff -> float_to_uchar: sat_0^255(rint(x*mul + add)) */
 void orc_soft_quant(const float* in, size_t n, float mul, float add, uint8_t* out)
 {
+    orc_trace_event("soft_quant(%.9g,%.9g)", mul, add);
     for (size_t i = 0; i < n; i++) {
         float v = in[i] * mul;
         v = v + add;
@@ -582,6 +596,7 @@ static inline uint8_t adds_u8(unsigned a, unsigned b) { unsigned s = a + b; retu
 
 size_t orc_cc_decode_k7(const uint8_t* soft, size_t n, uint8_t* bits)
 {
+    orc_trace_event("cc_decode_k7()");
     static const int polys[2] = {109, 79};
     uint8_t branchtab[64];
     for (int s = 0; s < 32; s++)
@@ -640,6 +655,7 @@ size_t orc_cc_decode_k7(const uint8_t* soft, size_t n, uint8_t* bits)
 /* lfsr [gr-digital include/gnuradio/digital/lfsr.h] */
 void orc_descramble(const uint8_t* in, size_t n, uint32_t mask, uint32_t seed, int len, uint8_t* out)
 {
+    orc_trace_event("descramble(%u,%u,%d)", mask, seed, len);
     uint32_t sr = seed;
     for (size_t i = 0; i < n; i++) {
         uint32_t b = in[i] & 1u;
@@ -677,6 +693,7 @@ void orc_cc_encode_k7(const uint8_t* bits, size_t n, uint8_t* out)
 size_t orc_clock_recovery_mm_cc(const cf32* in, size_t n, float omega, float gain_omega, float mu, float gain_mu,
                                 float omega_relative_limit, cf32* out)
 {
+    orc_trace_event("clock_recovery_mm_cc(%.9g,%.9g,%.9g,%.9g,%.9g)", omega, gain_omega, mu, gain_mu, omega_relative_limit);
     const float* T = orc_mmse_table();
     const float omega_mid = omega, omega_lim = omega_relative_limit * omega;
     cf32 p2 = {0, 0}, p1 = {0, 0}, p0 = {0, 0}, c2 = {0, 0}, c1 = {0, 0}, c0 = {0, 0};

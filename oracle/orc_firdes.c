@@ -73,6 +73,7 @@ int orc_low_pass(double gain, double fs, double fc, double tw, int win, float* t
 {
     int ntaps = orc_compute_ntaps(fs, tw, win);
     if (taps) lowpass_core(gain, fs, fc, ntaps, win, taps);
+    if (taps) orc_trace_taps(taps, sizeof(float) * (size_t)ntaps, "low_pass(%.17g,%.17g,%.17g,%.17g,%d)", gain, fs, fc, tw, win);
     return ntaps;
 }
 
@@ -80,12 +81,14 @@ int orc_low_pass_2(double gain, double fs, double fc, double tw, double atten_db
 {
     int ntaps = orc_compute_ntaps_windes(fs, tw, atten_db);
     if (taps) lowpass_core(gain, fs, fc, ntaps, win, taps);
+    if (taps) orc_trace_taps(taps, sizeof(float) * (size_t)ntaps, "low_pass_2(%.17g,%.17g,%.17g,%.17g,%.17g,%d)", gain, fs, fc, tw, atten_db, win);
     return ntaps;
 }
 
 /* firdes::band_pass_2 [GR-MEM]: windowed difference of two sincs, unity gain at the band centre */
 int orc_band_pass_2(double gain, double fs, double lo, double hi, double tw, double atten_db, int win, float* taps)
 {
+    const double gain_arg = gain;
     int ntaps = orc_compute_ntaps_windes(fs, tw, atten_db);
     if (!taps) return ntaps;
     float* w = (float*)malloc(sizeof(float) * (size_t)ntaps);
@@ -101,6 +104,7 @@ int orc_band_pass_2(double gain, double fs, double lo, double hi, double tw, dou
     gain /= fmax;
     for (int i = 0; i < ntaps; i++) taps[i] = (float)(taps[i] * gain);
     free(w);
+    orc_trace_taps(taps, sizeof(float) * (size_t)ntaps, "band_pass_2(%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%d)", gain_arg, fs, lo, hi, tw, atten_db, win);
     return ntaps;
 }
 
@@ -120,11 +124,13 @@ int orc_complex_band_pass(double gain, double fs, double lo, double hi, double t
         phase += freq;
     }
     free(lp);
+    orc_trace_taps(taps, sizeof(cf32) * (size_t)ntaps, "complex_band_pass(%.17g,%.17g,%.17g,%.17g,%.17g,%d)", gain, fs, lo, hi, tw, win);
     return ntaps;
 }
 
 int orc_root_raised_cosine(double gain, double fs, double symrate, double alpha, int ntaps, float* taps)
 {
+    const int ntaps_arg = ntaps;
     ntaps |= 1;
     if (!taps) return ntaps;
     double spb = fs / symrate;
@@ -151,6 +157,7 @@ int orc_root_raised_cosine(double gain, double fs, double symrate, double alpha,
         scale += taps[i];
     }
     for (int i = 0; i < ntaps; i++) taps[i] = (float)(taps[i] * gain / scale);
+    orc_trace_taps(taps, sizeof(float) * (size_t)ntaps, "root_raised_cosine(%.17g,%.17g,%.17g,%.17g,%d)", gain, fs, symrate, alpha, ntaps_arg);
     return ntaps;
 }
 
@@ -168,6 +175,7 @@ int orc_gaussian(double gain, double spb, double bt, int ntaps, float* taps)
         scale += taps[i];
     }
     for (int i = 0; i < ntaps; i++) taps[i] = (float)(taps[i] / scale * gain);
+    orc_trace_taps(taps, sizeof(float) * (size_t)ntaps, "gaussian(%.17g,%.17g,%.17g,%d)", gain, spb, bt, ntaps);
     return ntaps;
 }
 

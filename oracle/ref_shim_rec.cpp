@@ -1,0 +1,65 @@
+// oracle/ref_shim_rec.cpp — TEST INFRASTRUCTURE, never linked into the product.
+//
+// The reference's hier-block constructors (src/gr/gr_demod_*.cpp, gr_mod_*.cpp — compiled UNMODIFIED from /root/reference by
+// `make -C oracle rec`) run here against oracle/rec_stub/, a stand-in for the stock GNU Radio headers whose ::make() factories,
+// setters, firdes designers and hier_block2::connect() only RECORD their arguments.  rr_construct() builds one block and returns
+// the construction log: the list of stock blocks with the exact parameters the reference computed for them, the firdes calls
+// behind every tap vector, and the wiring.  tests/test_ref_chains.py compares that log with the chain description this repository
+// implements (oracle/orc_chains.c / engine.cpp), which pins the PARAMETERS AND WIRING of those chains to the reference's own code.
+// The stock blocks' ARITHMETIC stays [GR-MEM] (GNU Radio itself is not in the image).
+#include <cstring>
+#include <string>
+
+#include "src/gr/gr_demod_2fsk.h"
+#include "src/gr/gr_demod_am.h"
+#include "src/gr/gr_demod_bpsk.h"
+#include "src/gr/gr_demod_gmsk.h"
+#include "src/gr/gr_demod_m17.h"
+#include "src/gr/gr_demod_nbfm.h"
+#include "src/gr/gr_demod_qpsk.h"
+#include "src/gr/gr_demod_wbfm.h"
+#include "src/gr/gr_mod_2fsk.h"
+#include "src/gr/gr_mod_4fsk.h"
+#include "src/gr/gr_mod_am.h"
+#include "src/gr/gr_mod_gmsk.h"
+#include "src/gr/gr_mod_m17.h"
+#include "src/gr/gr_mod_nbfm.h"
+#include "src/gr/gr_mod_qpsk.h"
+
+static std::string g_text;
+
+extern "C" {
+
+// Builds reference hier block `kind` with the given constructor arguments and returns its construction log (one event per line);
+// nullptr for an unknown kind.  The returned pointer is valid until the next call.
+const char* rr_construct(const char* kind, int sps, int samp_rate, int carrier_freq, int filter_width, int fm)
+{
+    gr::rec::State& s = gr::rec::st();
+    s.lines.clear();
+    s.designs.clear();
+    s.next = 1;
+    const std::string k(kind);
+    bool ok = true;
+    if (k == "demod_2fsk") { auto p = make_gr_demod_2fsk(sps, samp_rate, carrier_freq, filter_width, fm != 0); }
+    else if (k == "demod_gmsk") { auto p = make_gr_demod_gmsk(sps, samp_rate, carrier_freq, filter_width); }
+    else if (k == "demod_qpsk") { auto p = make_gr_demod_qpsk(sps, samp_rate, carrier_freq, filter_width); }
+    else if (k == "demod_bpsk") { auto p = make_gr_demod_bpsk(sps, samp_rate, carrier_freq, filter_width); }
+    else if (k == "demod_m17") { auto p = make_gr_demod_m17(sps, samp_rate, carrier_freq, filter_width); }
+    else if (k == "demod_nbfm") { auto p = make_gr_demod_nbfm(sps, samp_rate, carrier_freq, filter_width); }
+    else if (k == "demod_am") { auto p = make_gr_demod_am(sps, samp_rate, carrier_freq, filter_width); }
+    else if (k == "demod_wbfm") { auto p = make_gr_demod_wbfm(sps, samp_rate, carrier_freq, filter_width); }
+    else if (k == "mod_2fsk") { auto p = make_gr_mod_2fsk(sps, samp_rate, carrier_freq, filter_width, fm != 0); }
+    else if (k == "mod_4fsk") { auto p = make_gr_mod_4fsk(sps, samp_rate, carrier_freq, filter_width, fm != 0); }
+    else if (k == "mod_gmsk") { auto p = make_gr_mod_gmsk(sps, samp_rate, carrier_freq, filter_width); }
+    else if (k == "mod_qpsk") { auto p = make_gr_mod_qpsk(sps, samp_rate, carrier_freq, filter_width); }
+    else if (k == "mod_m17") { auto p = make_gr_mod_m17(sps, samp_rate, carrier_freq, filter_width); }
+    else if (k == "mod_nbfm") { auto p = make_gr_mod_nbfm(sps, samp_rate, carrier_freq, filter_width); }
+    else if (k == "mod_am") { auto p = make_gr_mod_am(sps, samp_rate, carrier_freq, filter_width); }
+    else ok = false;
+    if (!ok) return nullptr;
+    g_text.clear();
+    for (const std::string& l : s.lines) { g_text += l; g_text += '\n'; }
+    return g_text.c_str();
+}
+
+}  // extern "C"

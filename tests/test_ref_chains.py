@@ -1,0 +1,288 @@
+"""Construction-log pin: the PARAMETERS AND WIRING of the receive chains against the reference's own hier-block constructors.
+
+oracle/_ref/libqrl_rec.so runs the reference's gr_demod_*.cpp constructors, unmodified, against recording stand-ins of the stock GNU
+Radio factories (oracle/rec_stub/, oracle/ref_shim_rec.cpp): the log names every stock block the reference creates with the exact
+arguments it computed, the firdes call behind every tap vector, and every connect().  The oracle's chains (oracle/orc_chains.c,
+orc_analog.c — the restatement the HIP path is bit-exact against) emit the same kind of trace from their primitives
+(oracle/orc_trace.c).  For every constructor call site in the reference's mode table (src/gr/gr_demodulator.cpp / gr_modem) the two
+must agree: the same connected blocks, each with equal parameters (float parameters compared as the float the GNU Radio signature
+narrows them to; filter-design arguments as doubles), and every reference edge respected by the oracle's processing order.
+
+What this does not pin: the stock blocks' arithmetic ([GR-MEM] — GNU Radio is not in the image).  Needs /root/reference (skipped on
+the GPU box)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REC = os.path.join(HERE, "..", "oracle", "_ref", "libqrl_rec.so")
+pytestmark = pytest.mark.skipif(not os.path.exists(REC), reason="oracle/_ref/libqrl_rec.so not built (needs /root/reference)")
+
+CONST_KIND = {"digital::constellation_bpsk": 0, "digital::constellation_dqpsk": 1, "digital::constellation_rect": 2}
+
+# reference stock block -> oracle primitive; the lambda reorders/drops arguments the oracle's primitive does not take (always checked
+# to hold their only supported value)
+def _fft(name):
+    def f(a):
+        assert a[0] == "1", "fft_filter decimation"
+        return name, [a[1]]
+    return f
+
+
+def _symsync(name):
+    def f(a):
+        assert a[6] == "1", "symbol_sync osps"
+        assert len(a) == 8 or a[8:] == ["enum:0"], "symbol_sync interpolator (MMSE 8-tap)"
+        return name, a[:6] + [a[7]]
+    return f
+
+
+MAP = {
+    "filter::rational_resampler_ccf": lambda a: ("resamp_ccf", a),
+    "filter::rational_resampler_fff": lambda a: ("resamp_fff", a),
+    "filter::fft_filter_ccf": _fft("fir_ccf"),
+    "filter::fft_filter_ccc": _fft("fir_ccc"),
+    "filter::fft_filter_fff": _fft("fir_fff"),
+    "digital::fll_band_edge_cc": lambda a: ("fll_band_edge", a),
+    "analog::quadrature_demod_cf": lambda a: ("quad_demod", a),
+    "analog::agc2_cc": lambda a: ("agc2_cc", a + ["65536"] if len(a) == 4 else a),
+    "analog::agc2_ff": lambda a: ("agc2_ff", a + ["65536"] if len(a) == 4 else a),
+    "digital::costas_loop_cc": lambda a: ("costas", a),
+    "digital::symbol_sync_ff": _symsync("symbol_sync_ff"),
+    "digital::symbol_sync_cc": _symsync("symbol_sync_cc"),
+    "digital::diff_phasor_cc": lambda a: ("diff_phasor", a),
+    "digital::descrambler_bb": lambda a: ("descramble", a),
+    "digital::clock_recovery_mm_cc": lambda a: ("clock_recovery_mm_cc", a),
+    "analog::pwr_squelch_cc": lambda a: ("pwr_squelch_cc", a),
+    "fec::decoder": lambda a: ("cc_decode_k7", []),
+}
+
+# blocks the oracle's chains restate inline (no primitive of their own); their reference arguments are checked against the constants
+# the oracle hard-codes, per chain, in INLINE below
+INLINE_KINDS = {"blocks::complex_to_mag", "blocks::divide_ff", "blocks::add_const_ff", "analog::rail_ff", "blocks::float_to_complex",
+                "blocks::multiply_const_ff", "blocks::multiply_const_cc", "blocks::float_to_uchar", "blocks::delay",
+                "blocks::complex_to_float", "blocks::interleave", "blocks::complex_to_real", "blocks::complex_to_mag_squared",
+                "blocks::multiply_ff", "blocks::add_ff", "filter::iir_filter_ffd", "blocks::float_to_short"}
+
+
+def split_args(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([":
+            depth += 1
+        elif ch in ")]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur:
+        out.append(cur)
+    return out
+
+
+def parse_call(text):
+    m = re.match(r"^([\w:]+)\((.*)\)$", text)
+    assert m, text
+    return m.group(1), split_args(m.group(2))
+
+
+class RefGraph:
+    def __init__(self, log):
+        self.blocks, self.edges, self.calls = {}, [], []
+        for line in log.splitlines():
+            if line.startswith("hier "):
+                self.name = line[5:]
+            elif "->" in line:
+                a, b = line.split(" -> ")
+                pa, pb = (int(x) for x in a[1:].split(":")), (int(x) for x in b[1:].split(":"))
+                self.edges.append((tuple(pa), tuple(pb)))
+            elif re.match(r"^#\d+\.", line):
+                self.calls.append(line)
+            else:
+                m = re.match(r"^#(\d+) (.*)$", line)
+                self.blocks[int(m.group(1))] = parse_call(m.group(2))
+        self.connected = {a[0] for a, _ in self.edges} | {b[0] for _, b in self.edges}
+
+
+def ref_log(kind, *args):
+    L = C.CDLL(REC)
+    L.rr_construct.restype = C.c_char_p
+    L.rr_construct.argtypes = [C.c_char_p] + [C.c_int] * 5
+    a = list(args) + [0] * (5 - len(args))
+    r = L.rr_construct(kind.encode(), *[int(v) for v in a])
+    assert r is not None
+    return r.decode()
+
+
+def oracle_trace(fn, *a, **kw):
+    lib = orc._load()
+    lib.orc_trace_get.restype = C.c_char_p
+    lib.orc_trace_enable(1)
+    try:
+        fn(*a, **kw)
+        return [l for l in lib.orc_trace_get().decode().splitlines() if l]
+    finally:
+        lib.orc_trace_enable(0)
+
+
+def norm_value(v, g=None, as_double=False):
+    """one argument -> comparable value: numbers as float32 (block parameters) or float64 (design arguments)"""
+    v = v.strip()
+    if v.startswith("enum:"):
+        return float(v[5:])
+    if v in ("true", "false"):
+        return float(v == "true")
+    if v.startswith("#") and g is not None:
+        return float(CONST_KIND[g.blocks[int(v[1:])][0]])
+    if re.match(r"^[\w]+\(.*\)$", v):                                   # a filter design: compare its arguments as doubles
+        name, args = parse_call(v)
+        return (name,) + tuple(norm_value(x, g, True) for x in args)
+    x = float(v)
+    return x if as_double else float(np.float32(x))
+
+
+def ref_events(g):
+    """connected reference blocks -> [(block id, oracle primitive name, normalised args)], plus the inline blocks"""
+    ev, inline = [], []
+    for bid in sorted(g.connected - {0}):
+        kind, args = g.blocks[bid]
+        if kind in MAP:
+            name, a = MAP[kind](args)
+            ev.append((bid, name, tuple(norm_value(x, g) for x in a)))
+        elif kind in INLINE_KINDS:
+            inline.append((bid, kind, args))
+        else:
+            raise AssertionError("unmapped reference block %s(%s)" % (kind, ",".join(args)))
+    return ev, inline
+
+
+def fold_soft_quant(g, ev, inline):
+    """multiply_const_ff(m) -> add_const_ff(a) -> float_to_uchar is the oracle's soft_quant(m, a)"""
+    succ = {}
+    for (a, _), (b, _) in g.edges:
+        succ.setdefault(a, []).append(b)
+    kinds = {bid: (k, a) for bid, k, a in inline}
+    used = set()
+    for bid, (k, a) in list(kinds.items()):
+        if k != "blocks::multiply_const_ff":
+            continue
+        for n1 in succ.get(bid, []):
+            if kinds.get(n1, ("",))[0] == "blocks::add_const_ff":
+                for n2 in succ.get(n1, []):
+                    if kinds.get(n2, ("",))[0] == "blocks::float_to_uchar":
+                        ev.append((n2, "soft_quant", (norm_value(a[0]), norm_value(kinds[n1][1][0]))))
+                        used |= {bid, n1, n2}
+    return ev, [(b, k, a) for b, k, a in inline if b not in used]
+
+
+def oracle_events(trace):
+    out = []
+    for line in trace:
+        name, args = parse_call(line)
+        out.append((name, tuple(norm_value(x) for x in args)))
+    return out
+
+
+def compare(kind, ctor, fn, kw, inline_expect, n=6000):
+    g = RefGraph(ref_log(kind, *ctor))
+    ev, inline = ref_events(g)
+    ev, inline = fold_soft_quant(g, ev, inline)
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * 0.3
+    oev = oracle_events(oracle_trace(fn, x, **kw))
+    # 1. the same multiset of (primitive, parameters)
+    want = sorted((n_, a) for _, n_, a in ev)
+    got = sorted(oev)
+    assert want == got, "\nreference: %s\noracle:    %s" % (want, got)
+    # 2. wiring: match each reference block to an oracle event of equal text (in order of first appearance) and require every
+    #    reference edge between two mapped blocks to point forward in the oracle's processing order
+    pos, taken = {}, set()
+    order = topo_order(g)
+    for bid in order:
+        for b, n_, a in ev:
+            if b == bid:
+                for i, e in enumerate(oev):
+                    if i not in taken and e == (n_, a):
+                        pos[bid] = i
+                        taken.add(i)
+                        break
+    reach = mapped_edges(g, set(pos))
+    for a, b in reach:
+        assert pos[a] < pos[b], "edge #%d -> #%d is not respected by the oracle's order" % (a, b)
+    # 3. the inline blocks carry exactly the constants the oracle's chain hard-codes
+    got_inline = sorted("%s(%s)" % (k, ",".join(a)) for _, k, a in inline)
+    assert got_inline == sorted(inline_expect), got_inline
+    return g
+
+
+def topo_order(g):
+    succ, indeg = {}, {}
+    for (a, _), (b, _) in g.edges:
+        if b == 0 or a == 0:
+            continue
+        succ.setdefault(a, []).append(b)
+        indeg[b] = indeg.get(b, 0) + 1
+    nodes = sorted(g.connected - {0})
+    ready = [n for n in nodes if indeg.get(n, 0) == 0]
+    out = []
+    while ready:
+        n = ready.pop(0)
+        out.append(n)
+        for m in succ.get(n, []):
+            indeg[m] -= 1
+            if indeg[m] == 0:
+                ready.append(m)
+    assert len(out) == len(nodes), "cycle in the reference graph"
+    return out
+
+
+def mapped_edges(g, mapped):
+    """(a, b) for mapped blocks a, b with a path a -> ... -> b through unmapped blocks only"""
+    succ = {}
+    for (a, _), (b, _) in g.edges:
+        if a and b:
+            succ.setdefault(a, []).append(b)
+    out = set()
+    for a in mapped:
+        stack, seen = list(succ.get(a, [])), set()
+        while stack:
+            n = stack.pop()
+            if n in seen:
+                continue
+            seen.add(n)
+            if n in mapped:
+                out.add((a, n))
+            else:
+                stack.extend(succ.get(n, []))
+    return out
+
+
+FEC2 = ["blocks::delay(1,1)"]          # the second Viterbi branch's one-item delay (fec_tail)
+
+CASES_2FSK = [(1, 25000, True), (10, 2000, False), (10, 2500, True), (5, 4000, False), (5, 4000, True)]
+
+
+@pytest.mark.parametrize("sps,fw,fm", CASES_2FSK)
+def test_demod_2fsk(sps, fw, fm):
+    inline = list(FEC2) + ["blocks::float_to_complex()"]
+    if not fm:
+        inline += ["blocks::complex_to_mag()", "blocks::complex_to_mag()", "blocks::divide_ff()", "analog::rail_ff(0,2)", "blocks::add_const_ff(-1)"]
+    compare("demod_2fsk", (sps, 1000000, 1700, fw, int(fm)), orc.demod_2fsk, dict(sps=sps, filter_width=fw, fm=fm), inline)
+
+
+@pytest.mark.parametrize("sps,fw", [(1, 20000), (10, 2000), (5, 4000)])
+def test_demod_gmsk(sps, fw):
+    compare("demod_gmsk", (sps, 1000000, 1700, fw), orc.demod_gmsk, dict(sps=sps, filter_width=fw), FEC2 + ["blocks::float_to_complex()"])
+
+
+@pytest.mark.parametrize("sps,fw", [(125, 1300), (2, 160000), (25, 6500)])
+def test_demod_qpsk(sps, fw):
+    compare("demod_qpsk", (sps, 1000000, 1700, fw), orc.demod_qpsk, dict(sps=sps, filter_width=fw),
+            ["blocks::multiply_const_cc((-0.707106769,-0.707106769))", "blocks::complex_to_float()", "blocks::interleave(4)"])
