@@ -52,7 +52,8 @@ MAP = {
     "analog::quadrature_demod_cf": lambda a: ("quad_demod", a),
     "analog::agc2_cc": lambda a: ("agc2_cc", a + ["65536"] if len(a) == 4 else a),
     "analog::agc2_ff": lambda a: ("agc2_ff", a + ["65536"] if len(a) == 4 else a),
-    "digital::costas_loop_cc": lambda a: ("costas", a),
+    "digital::costas_loop_cc": lambda a: ("costas", a if len(a) == 3 else a + ["false"]),
+    "filter::iir_filter_ffd": lambda a: ("iir_ffd", split_args(a[0][1:-1]) + split_args(a[1][1:-1]) + (a[2:] or ["true"])),   # oldstyle defaults to true
     "digital::symbol_sync_ff": _symsync("symbol_sync_ff"),
     "digital::symbol_sync_cc": _symsync("symbol_sync_cc"),
     "digital::diff_phasor_cc": lambda a: ("diff_phasor", a),
@@ -67,7 +68,9 @@ MAP = {
 INLINE_KINDS = {"blocks::complex_to_mag", "blocks::divide_ff", "blocks::add_const_ff", "analog::rail_ff", "blocks::float_to_complex",
                 "blocks::multiply_const_ff", "blocks::multiply_const_cc", "blocks::float_to_uchar", "blocks::delay",
                 "blocks::complex_to_float", "blocks::interleave", "blocks::complex_to_real", "blocks::complex_to_mag_squared",
-                "blocks::multiply_ff", "blocks::add_ff", "filter::iir_filter_ffd", "blocks::float_to_short"}
+                "blocks::multiply_ff", "blocks::add_ff", "blocks::float_to_short", "analog::phase_modulator_fc",
+                "digital::binary_slicer_fb", "blocks::pack_k_bits_bb", "blocks::unpack_k_bits_bb", "digital::map_bb"}
+DOUBLE_PARAMS = {"iir_ffd", "pwr_squelch_cc"}          # primitives whose GNU Radio signature takes doubles
 
 
 def split_args(s):
@@ -155,7 +158,7 @@ def ref_events(g):
         kind, args = g.blocks[bid]
         if kind in MAP:
             name, a = MAP[kind](args)
-            ev.append((bid, name, tuple(norm_value(x, g) for x in a)))
+            ev.append((bid, name, tuple(norm_value(x, g, name in DOUBLE_PARAMS) for x in a)))
         elif kind in INLINE_KINDS:
             inline.append((bid, kind, args))
         else:
@@ -186,7 +189,7 @@ def oracle_events(trace):
     out = []
     for line in trace:
         name, args = parse_call(line)
-        out.append((name, tuple(norm_value(x) for x in args)))
+        out.append((name, tuple(norm_value(x, None, name in DOUBLE_PARAMS) for x in args)))
     return out
 
 
@@ -286,3 +289,30 @@ def test_demod_gmsk(sps, fw):
 def test_demod_qpsk(sps, fw):
     compare("demod_qpsk", (sps, 1000000, 1700, fw), orc.demod_qpsk, dict(sps=sps, filter_width=fw),
             ["blocks::multiply_const_cc((-0.707106769,-0.707106769))", "blocks::complex_to_float()", "blocks::interleave(4)"])
+
+
+@pytest.mark.parametrize("sps,fw", [(10, 1300), (5, 2400)])
+def test_demod_bpsk(sps, fw):
+    compare("demod_bpsk", (sps, 1000000, 1700, fw), orc.demod_bpsk, dict(sps=sps, filter_width=fw), FEC2 + ["blocks::complex_to_real()"])
+
+
+def test_demod_m17():
+    compare("demod_m17", (125, 1000000, 1700, 9000), orc.demod_m17, dict(),
+            ["analog::phase_modulator_fc(1.5707963267948966)", "blocks::complex_to_float()", "blocks::interleave(4)",
+             "digital::binary_slicer_fb()", "blocks::pack_k_bits_bb(2)", "digital::map_bb([3,1,2,0])", "blocks::unpack_k_bits_bb(2)"])
+
+
+@pytest.mark.parametrize("fw", [2500, 5000])
+def test_demod_nbfm(fw):
+    compare("demod_nbfm", (125, 1000000, 1700, fw), lambda x: orc.demod_analog(x, "nbfm", filter_width=fw), dict(),
+            ["blocks::multiply_const_ff(2)"])
+
+
+def test_demod_am():
+    compare("demod_am", (125, 1000000, 1700, 5000), lambda x: orc.demod_analog(x, "am", filter_width=5000), dict(),
+            ["blocks::complex_to_mag()", "blocks::multiply_const_ff(0.98999999999999999)"], n=20000)
+
+
+def test_demod_wbfm():
+    compare("demod_wbfm", (125, 1000000, 1700, 75000), lambda x: orc.demod_analog(x, "wbfm", filter_width=75000), dict(),
+            ["blocks::multiply_const_ff(0.90000000000000002)"], n=20000)
