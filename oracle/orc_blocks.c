@@ -665,6 +665,7 @@ void orc_descramble(const uint8_t* in, size_t n, uint32_t mask, uint32_t seed, i
 }
 void orc_scramble(const uint8_t* in, size_t n, uint32_t mask, uint32_t seed, int len, uint8_t* out)
 {
+    orc_trace_event("scramble(%u,%u,%d)", mask, seed, len);
     uint32_t sr = seed;
     for (size_t i = 0; i < n; i++) {
         uint8_t o = (uint8_t)(sr & 1u);
@@ -676,6 +677,7 @@ void orc_scramble(const uint8_t* in, size_t n, uint32_t mask, uint32_t seed, int
 /* cc_encoder streaming [gr-fec/lib/cc_encoder_impl.cc] */
 void orc_cc_encode_k7(const uint8_t* bits, size_t n, uint8_t* out)
 {
+    orc_trace_event("cc_encode_k7()");
     uint32_t st = 0;
     for (size_t i = 0; i < n; i++) {
         st = (st << 1) | (bits[i] & 1u);

@@ -266,6 +266,7 @@ static size_t tx_bits(const uint8_t* bytes, size_t nbytes, uint8_t** coded)
  * (upstream: gr::fxpt table) */
 static void fm_mod(const float* in, size_t n, float k, cf32* out)
 {
+    orc_trace_event("freq_mod(%.9g)", k);
     const float F_PI = (float)M_PI;
     float phase = 0;
     for (size_t i = 0; i < n; i++) {

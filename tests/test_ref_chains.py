@@ -61,6 +61,9 @@ MAP = {
     "digital::clock_recovery_mm_cc": lambda a: ("clock_recovery_mm_cc", a),
     "analog::pwr_squelch_cc": lambda a: ("pwr_squelch_cc", a),
     "fec::decoder": lambda a: ("cc_decode_k7", []),
+    "fec::encoder": lambda a: ("cc_encode_k7", []),
+    "digital::scrambler_bb": lambda a: ("scramble", a),
+    "analog::frequency_modulator_fc": lambda a: ("freq_mod", a),
 }
 
 # blocks the oracle's chains restate inline (no primitive of their own); their reference arguments are checked against the constants
@@ -69,7 +72,9 @@ INLINE_KINDS = {"blocks::complex_to_mag", "blocks::divide_ff", "blocks::add_cons
                 "blocks::multiply_const_ff", "blocks::multiply_const_cc", "blocks::float_to_uchar", "blocks::delay",
                 "blocks::complex_to_float", "blocks::interleave", "blocks::complex_to_real", "blocks::complex_to_mag_squared",
                 "blocks::multiply_ff", "blocks::add_ff", "blocks::float_to_short", "analog::phase_modulator_fc",
-                "digital::binary_slicer_fb", "blocks::pack_k_bits_bb", "blocks::unpack_k_bits_bb", "digital::map_bb"}
+                "digital::binary_slicer_fb", "blocks::pack_k_bits_bb", "blocks::unpack_k_bits_bb", "digital::map_bb",
+                "blocks::packed_to_unpacked_bb", "blocks::repeat", "digital::chunks_to_symbols_bf", "digital::chunks_to_symbols_bc",
+                "digital::diff_encoder_bb"}
 DOUBLE_PARAMS = {"iir_ffd", "pwr_squelch_cc"}          # primitives whose GNU Radio signature takes doubles
 
 
@@ -193,12 +198,13 @@ def oracle_events(trace):
     return out
 
 
-def compare(kind, ctor, fn, kw, inline_expect, n=6000):
+def compare(kind, ctor, fn, kw, inline_expect, n=6000, x=None):
     g = RefGraph(ref_log(kind, *ctor))
     ev, inline = ref_events(g)
     ev, inline = fold_soft_quant(g, ev, inline)
     rng = np.random.default_rng(1)
-    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * 0.3
+    if x is None:
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * 0.3
     oev = oracle_events(oracle_trace(fn, x, **kw))
     # 1. the same multiset of (primitive, parameters)
     want = sorted((n_, a) for _, n_, a in ev)
@@ -316,3 +322,43 @@ def test_demod_am():
 def test_demod_wbfm():
     compare("demod_wbfm", (125, 1000000, 1700, 75000), lambda x: orc.demod_analog(x, "wbfm", filter_width=75000), dict(),
             ["blocks::multiply_const_ff(0.90000000000000002)"], n=20000)
+
+
+# ---- transmit chains (src/gr/gr_mod_*.cpp; call sites gr_mod_base.cpp) ----
+TXBYTES = np.arange(64, dtype=np.uint8)
+UNPACK = "blocks::packed_to_unpacked_bb(1,enum:0)"          # MSB first
+BB1 = "blocks::multiply_const_cc(1,1)"                      # the bb_gain multiplier at its initial 1
+
+
+@pytest.mark.parametrize("sps,fw,fm", [(25, 4000, False), (25, 4000, True), (5, 25000, True), (50, 2000, False), (50, 2500, True)])
+def test_mod_2fsk(sps, fw, fm):
+    inline = [UNPACK, "digital::map_bb([0,1])", "digital::chunks_to_symbols_bf([-1,1])", BB1,
+              "blocks::multiply_const_cc(%s,1)" % ("0.899999976" if fm else "0.800000012")]
+    if not fm:
+        inline.append("blocks::repeat(4,%d)" % sps)
+    compare("mod_2fsk", (sps, 1000000, 1700, fw, int(fm)), orc.mod_2fsk, dict(sps=sps, filter_width=fw, fm=fm), inline, x=TXBYTES)
+
+
+@pytest.mark.parametrize("sps,fw,fm", [(2, 125000, True), (25, 3500, True), (25, 4000, False), (5, 20000, True), (50, 2000, True)])
+def test_mod_4fsk(sps, fw, fm):
+    inline = [UNPACK, "blocks::pack_k_bits_bb(2)", "digital::map_bb([0,1,3,2])", "digital::chunks_to_symbols_bf([-1.5,-0.5,0.5,1.5])", BB1,
+              "blocks::multiply_const_cc(%s,1)" % ("0.899999976" if fm else "0.800000012")]
+    if fm:
+        inline.append("blocks::multiply_const_ff(0.66666665999999997,1)")
+    else:
+        inline.append("blocks::repeat(4,%d)" % sps)
+    compare("mod_4fsk", (sps, 1000000, 1700, fw, int(fm)), orc.mod_4fsk, dict(sps=sps, filter_width=fw, fm=fm), inline, x=TXBYTES)
+
+
+@pytest.mark.parametrize("sps,fw", [(10, 20000), (100, 2000), (50, 4000)])
+def test_mod_gmsk(sps, fw):
+    compare("mod_gmsk", (sps, 1000000, 1700, fw), orc.mod_gmsk, dict(sps=sps, filter_width=fw),
+            [UNPACK, "digital::map_bb([0,1])", "digital::chunks_to_symbols_bf([-1,1])", BB1, "blocks::multiply_const_cc(0.899999976,1)"], x=TXBYTES)
+
+
+@pytest.mark.parametrize("sps,fw", [(100, 6500), (4, 160000), (500, 1300)])
+def test_mod_qpsk(sps, fw):
+    compare("mod_qpsk", (sps, 1000000, 1700, fw), orc.mod_qpsk, dict(sps=sps, filter_width=fw),
+            [UNPACK, "blocks::pack_k_bits_bb(2)", "digital::diff_encoder_bb(4)", "digital::map_bb([0,1,3,2])", BB1,
+             "digital::chunks_to_symbols_bc([(-0.707000017,-0.707000017),(-0.707000017,0.707000017),(0.707000017,0.707000017),(0.707000017,-0.707000017)])",
+             "blocks::multiply_const_cc(0.59999999999999998,1)"], x=TXBYTES)
