@@ -307,6 +307,7 @@ size_t orc_mod_nbfm(const float* audio, size_t n, int sps, int samp_rate, int fi
     free(at);
     double ta[2], tb[2];
     orc_preemph_taps(8000, 50e-6, ta, tb);
+    orc_trace_event("iir_ffd(%.17g,%.17g,%.17g,%.17g,0)", tb[0], tb[1], ta[0], ta[1]);   /* the new-style IIR restated inline below */
     {   /* _audio_amplify, _pre_emph_filter: acc = b0 x + b1 x[-1] - a1 y[-1] in double, y kept in double */
         float xp = 0.0f; double yp = 0.0;
         for (size_t i = 0; i < n; i++) {

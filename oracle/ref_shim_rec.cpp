@@ -21,6 +21,7 @@
 #include "src/gr/gr_mod_2fsk.h"
 #include "src/gr/gr_mod_4fsk.h"
 #include "src/gr/gr_mod_am.h"
+#include "src/gr/gr_mod_bpsk.h"
 #include "src/gr/gr_mod_gmsk.h"
 #include "src/gr/gr_mod_m17.h"
 #include "src/gr/gr_mod_nbfm.h"
@@ -54,6 +55,7 @@ const char* rr_construct(const char* kind, int sps, int samp_rate, int carrier_f
     else if (k == "mod_qpsk") { auto p = make_gr_mod_qpsk(sps, samp_rate, carrier_freq, filter_width); }
     else if (k == "mod_m17") { auto p = make_gr_mod_m17(sps, samp_rate, carrier_freq, filter_width); }
     else if (k == "mod_nbfm") { auto p = make_gr_mod_nbfm(sps, samp_rate, carrier_freq, filter_width); }
+    else if (k == "mod_bpsk") { auto p = make_gr_mod_bpsk(sps, samp_rate, carrier_freq, filter_width); }
     else if (k == "mod_am") { auto p = make_gr_mod_am(sps, samp_rate, carrier_freq, filter_width); }
     else ok = false;
     if (!ok) return nullptr;

@@ -362,3 +362,25 @@ def test_mod_qpsk(sps, fw):
             [UNPACK, "blocks::pack_k_bits_bb(2)", "digital::diff_encoder_bb(4)", "digital::map_bb([0,1,3,2])", BB1,
              "digital::chunks_to_symbols_bc([(-0.707000017,-0.707000017),(-0.707000017,0.707000017),(0.707000017,0.707000017),(0.707000017,-0.707000017)])",
              "blocks::multiply_const_cc(0.59999999999999998,1)"], x=TXBYTES)
+
+
+def test_mod_m17():
+    compare("mod_m17", (125, 1000000, 1700, 9000), orc.mod_m17, dict(),
+            [UNPACK, "blocks::pack_k_bits_bb(2)", "digital::map_bb([2,3,1,0])", "digital::chunks_to_symbols_bf([-1.5,-0.5,0.5,1.5])",
+             "blocks::multiply_const_ff(0.66666665999999997,1)", "blocks::multiply_const_cc(0.90000000000000002,1)", BB1],
+            x=np.arange(48, dtype=np.uint8))
+
+
+@pytest.mark.parametrize("fw", [2500, 5000])
+def test_mod_nbfm(fw):
+    rng = np.random.default_rng(2)
+    compare("mod_nbfm", (20, 1000000, 1700, fw), orc.mod_nbfm, dict(filter_width=fw),
+            ["blocks::multiply_const_ff(0.98999999999999999,1)", "blocks::multiply_const_cc(0.80000000000000004,1)", BB1],
+            x=(rng.standard_normal(800) * 0.1).astype(np.float32))
+
+
+@pytest.mark.parametrize("sps,fw", [(250, 2800), (500, 1500)])
+def test_mod_bpsk(sps, fw):
+    compare("mod_bpsk", (sps, 1000000, 1700, fw), orc.mod_bpsk, dict(sps=sps, filter_width=fw),
+            [UNPACK, "digital::chunks_to_symbols_bc([(-1,0),(1,0)])", "blocks::multiply_const_cc(0.59999999999999998,1)", BB1],
+            x=np.arange(16, dtype=np.uint8))
