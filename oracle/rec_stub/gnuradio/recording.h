@@ -12,8 +12,24 @@
 #include <string>
 #include <type_traits>
 #include <vector>
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <iostream>
+#include <mutex>
+
+#include <pmt/pmt.h>          // oracle/gr_stub (second on the include path)
 
 typedef std::complex<float> gr_complex;
+typedef std::vector<int> gr_vector_int;
+typedef std::vector<const void*> gr_vector_const_void_star;
+typedef std::vector<void*> gr_vector_void_star;
+namespace boost { typedef std::mutex mutex; }
+namespace gr { namespace thread {
+typedef std::mutex mutex;
+typedef std::lock_guard<std::mutex> scoped_lock;
+typedef std::condition_variable condition_variable;
+} }
 
 namespace gr {
 namespace rec {
@@ -109,9 +125,56 @@ public:
 };
 typedef std::shared_ptr<basic_block> basic_block_sptr;
 enum tag_propagation_policy_t { TPP_DONT = 0, TPP_ALL_TO_ALL = 1, TPP_ONE_TO_ONE = 2, TPP_CUSTOM = 3 };
-namespace block_ns { }
-class block : public basic_block { public: enum { TPP_DONT = 0, TPP_ALL_TO_ALL = 1, TPP_ONE_TO_ONE = 2 }; };
-class sync_block : public block {};
+// gr::block and its sync_* forms also carry the work()-side interface of oracle/gr_stub/gnuradio/block.h, so that the reference's OWN
+// custom blocks (src/gr/*.cpp) compile against this tree as well; constructed by name they record themselves as "custom::<name>"
+struct tag_t {
+    uint64_t offset; pmt::pmt_t key, value; unsigned port = 0;
+    static bool offset_compare(const tag_t& a, const tag_t& b) { return a.offset < b.offset; }
+};
+class block : public basic_block {
+public:
+    enum { WORK_CALLED_PRODUCE = -2, WORK_DONE = -1 };
+    enum { TPP_DONT = 0, TPP_ALL_TO_ALL = 1, TPP_ONE_TO_ONE = 2 };
+    block() {}
+    block(const std::string& name, io_signature::sptr, io_signature::sptr) { id = rec::add("custom::" + name); }
+    virtual ~block() {}
+    virtual void forecast(int, gr_vector_int&) {}
+    virtual int general_work(int, gr_vector_int&, gr_vector_const_void_star&, gr_vector_void_star&) { return 0; }
+    void set_relative_rate(double) {}
+    void set_alignment(int) {}
+    void consume_each(int) {}
+    void consume(int, int) {}
+    void produce(int, int) {}
+    uint64_t nitems_written(unsigned) const { return 0; }
+    uint64_t nitems_read(unsigned) const { return 0; }
+    void add_item_tag(unsigned, uint64_t, const pmt::pmt_t&, const pmt::pmt_t&) {}
+    void get_tags_in_window(std::vector<tag_t>& v, unsigned, uint64_t, uint64_t, const pmt::pmt_t&) { v.clear(); }
+    void get_tags_in_window(std::vector<tag_t>& v, unsigned, uint64_t, uint64_t) { v.clear(); }
+    void get_tags_in_range(std::vector<tag_t>& v, unsigned, uint64_t, uint64_t, const pmt::pmt_t&) { v.clear(); }
+    void get_tags_in_range(std::vector<tag_t>& v, unsigned, uint64_t, uint64_t) { v.clear(); }
+    void set_min_noutput_items(int) {}
+    void set_max_noutput_items(int) {}
+    void set_history(unsigned) {}
+    unsigned history() const { return 1; }
+    void set_output_multiple(int) {}
+    std::vector<tag_t> stub_in_tags, stub_tags;
+    long stub_consumed = 0;
+    uint64_t stub_written = 0, stub_read = 0;
+};
+class sync_block : public block {
+public:
+    sync_block() {}
+    using block::block;
+    virtual int work(int, gr_vector_const_void_star&, gr_vector_void_star&) { return 0; }
+};
+class sync_interpolator : public sync_block {
+public:
+    sync_interpolator(const std::string& name, io_signature::sptr a, io_signature::sptr b, unsigned) : sync_block(name, a, b) {}
+};
+class sync_decimator : public sync_block {
+public:
+    sync_decimator(const std::string& name, io_signature::sptr a, io_signature::sptr b, unsigned) : sync_block(name, a, b) {}
+};
 
 class hier_block2 : public basic_block {
 public:

@@ -9,6 +9,7 @@
 // The stock blocks' ARITHMETIC stays [GR-MEM] (GNU Radio itself is not in the image).
 #include <cstring>
 #include <string>
+#include <time.h>
 
 #include "src/gr/gr_demod_2fsk.h"
 #include "src/gr/gr_demod_am.h"
@@ -22,12 +23,28 @@
 #include "src/gr/gr_mod_4fsk.h"
 #include "src/gr/gr_mod_am.h"
 #include "src/gr/gr_mod_bpsk.h"
+#include "src/gr/gr_demod_4fsk.h"
+#include "src/gr/gr_demod_dmr.h"
+#include "src/gr/gr_demod_dsss.h"
+#include "src/gr/gr_demod_mmdvm.h"
+#include "src/gr/gr_demod_mmdvm_multi.h"
+#include "src/gr/gr_demod_mmdvm_multi2.h"
+#include "src/gr/gr_demod_ssb.h"
+#include "src/gr/gr_mod_dmr.h"
+#include "src/gr/gr_mod_dsss.h"
+#include "src/gr/gr_mod_mmdvm.h"
+#include "src/gr/gr_mod_mmdvm_multi.h"
+#include "src/gr/gr_mod_mmdvm_multi2.h"
+#include "src/gr/gr_mod_ssb.h"
 #include "src/gr/gr_mod_gmsk.h"
 #include "src/gr/gr_mod_m17.h"
 #include "src/gr/gr_mod_nbfm.h"
 #include "src/gr/gr_mod_qpsk.h"
 
 static std::string g_text;
+
+// the build renames nanosleep (bursttimer.cpp / gr_mmdvm_source.cpp sleep in their work loops; nothing here runs them)
+extern "C" int qrl_stub_nanosleep(const struct timespec*, struct timespec*) { return 0; }
 
 extern "C" {
 
@@ -56,6 +73,20 @@ const char* rr_construct(const char* kind, int sps, int samp_rate, int carrier_f
     else if (k == "mod_m17") { auto p = make_gr_mod_m17(sps, samp_rate, carrier_freq, filter_width); }
     else if (k == "mod_nbfm") { auto p = make_gr_mod_nbfm(sps, samp_rate, carrier_freq, filter_width); }
     else if (k == "mod_bpsk") { auto p = make_gr_mod_bpsk(sps, samp_rate, carrier_freq, filter_width); }
+    else if (k == "demod_4fsk") { auto p = make_gr_demod_4fsk(sps, samp_rate, carrier_freq, filter_width, fm != 0); }
+    else if (k == "demod_dmr") { auto p = make_gr_demod_dmr(sps, samp_rate); }
+    else if (k == "demod_dsss") { auto p = make_gr_demod_dsss(sps, samp_rate, carrier_freq, filter_width); }
+    else if (k == "demod_ssb") { auto p = make_gr_demod_ssb(sps, samp_rate, carrier_freq, filter_width, fm); }
+    else if (k == "demod_mmdvm") { auto p = make_gr_demod_mmdvm(); }
+    else if (k == "mod_mmdvm") { auto p = make_gr_mod_mmdvm(); }
+    else if (k == "mod_dmr") { auto p = make_gr_mod_dmr(); }
+    else if (k == "mod_dsss") { auto p = make_gr_mod_dsss(sps, samp_rate, carrier_freq, filter_width); }
+    else if (k == "mod_ssb") { auto p = make_gr_mod_ssb(sps, samp_rate, carrier_freq, filter_width, fm); }
+    // the multi-carrier MMDVM graphs: (num_channels, channel_separation, use_tdma) travel in the first three argument slots
+    else if (k == "demod_mmdvm_multi") { static BurstTimer bt; auto p = make_gr_demod_mmdvm_multi(&bt, sps, samp_rate, carrier_freq != 0); }
+    else if (k == "demod_mmdvm_multi2") { static BurstTimer bt; auto p = make_gr_demod_mmdvm_multi2(&bt, sps, samp_rate, carrier_freq != 0); }
+    else if (k == "mod_mmdvm_multi") { static BurstTimer bt; auto p = make_gr_mod_mmdvm_multi(&bt, sps, samp_rate, carrier_freq != 0); }
+    else if (k == "mod_mmdvm_multi2") { static BurstTimer bt; auto p = make_gr_mod_mmdvm_multi2(&bt, sps, samp_rate, carrier_freq != 0); }
     else if (k == "mod_am") { auto p = make_gr_mod_am(sps, samp_rate, carrier_freq, filter_width); }
     else ok = false;
     if (!ok) return nullptr;

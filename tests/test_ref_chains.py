@@ -164,7 +164,7 @@ def ref_events(g):
         if kind in MAP:
             name, a = MAP[kind](args)
             ev.append((bid, name, tuple(norm_value(x, g, name in DOUBLE_PARAMS) for x in a)))
-        elif kind in INLINE_KINDS:
+        elif kind in INLINE_KINDS or kind.startswith("custom::"):       # custom:: = the reference's own blocks (pinned in test_ref_blocks.py)
             inline.append((bid, kind, args))
         else:
             raise AssertionError("unmapped reference block %s(%s)" % (kind, ",".join(args)))
@@ -384,3 +384,13 @@ def test_mod_bpsk(sps, fw):
     compare("mod_bpsk", (sps, 1000000, 1700, fw), orc.mod_bpsk, dict(sps=sps, filter_width=fw),
             [UNPACK, "digital::chunks_to_symbols_bc([(-1,0),(1,0)])", "blocks::multiply_const_cc(0.59999999999999998,1)", BB1],
             x=np.arange(16, dtype=np.uint8))
+
+
+@pytest.mark.parametrize("sps,fw,fm", [(1, 20000, True), (10, 2000, True), (2, 125000, True), (5, 3000, True), (5, 4000, False)])
+def test_demod_4fsk(sps, fw, fm):
+    inline = ["blocks::complex_to_float()", "blocks::interleave(4)"]
+    if fm:
+        inline.append("analog::phase_modulator_fc(1.5707963267948966)")
+    else:
+        inline += ["blocks::complex_to_mag()"] * 4 + ["custom::gr_4fsk_discriminator()"]
+    compare("demod_4fsk", (sps, 1000000, 1700, fw, int(fm)), orc.demod_4fsk, dict(sps=sps, filter_width=fw, fm=fm), inline, n=8000)
