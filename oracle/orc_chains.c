@@ -948,6 +948,7 @@ int orc_chan_proto_taps(int M, float* taps)
 }
 size_t orc_pfb_channelizer(const cf32* in, size_t n, const float* taps, int nt, int M, cf32* out /* [M][n/M] */)
 {
+    orc_trace_event("pfb_channelizer(%d,%s,1)", M, orc_trace_name(taps, sizeof(float) * (size_t)nt));   /* critically sampled */
     const size_t nout = n / (size_t)M;
     cf32* W = NEW(cf32, M);
     for (int q = 0; q < M; q++) { W[q].re = (float)cos(2 * M_PI * q / M); W[q].im = (float)sin(2 * M_PI * q / M); }

@@ -62,6 +62,7 @@ MAP = {
     "analog::pwr_squelch_cc": lambda a: ("pwr_squelch_cc", a),
     "fec::decoder": lambda a: ("cc_decode_k7", []),
     "fec::encoder": lambda a: ("cc_encode_k7", []),
+    "filter::pfb_channelizer_ccf": lambda a: ("pfb_channelizer", a),
     "digital::scrambler_bb": lambda a: ("scramble", a),
     "analog::frequency_modulator_fc": lambda a: ("freq_mod", a),
 }
@@ -74,7 +75,8 @@ INLINE_KINDS = {"blocks::complex_to_mag", "blocks::divide_ff", "blocks::add_cons
                 "blocks::multiply_ff", "blocks::add_ff", "blocks::float_to_short", "analog::phase_modulator_fc",
                 "digital::binary_slicer_fb", "blocks::pack_k_bits_bb", "blocks::unpack_k_bits_bb", "digital::map_bb",
                 "blocks::packed_to_unpacked_bb", "blocks::repeat", "digital::chunks_to_symbols_bf", "digital::chunks_to_symbols_bc",
-                "digital::diff_encoder_bb"}
+                "digital::diff_encoder_bb", "blocks::short_to_float", "blocks::unpacked_to_packed_bb", "blocks::null_sink",
+                "blocks::stream_to_streams"}
 DOUBLE_PARAMS = {"iir_ffd", "pwr_squelch_cc"}          # primitives whose GNU Radio signature takes doubles
 
 
@@ -198,10 +200,12 @@ def oracle_events(trace):
     return out
 
 
-def compare(kind, ctor, fn, kw, inline_expect, n=6000, x=None):
+def compare(kind, ctor, fn, kw, inline_expect, n=6000, x=None, alias=None, unique=False):
     g = RefGraph(ref_log(kind, *ctor))
     ev, inline = ref_events(g)
     ev, inline = fold_soft_quant(g, ev, inline)
+    if alias:       # {(reference primitive, design name): oracle primitive} - a documented restatement choice of the oracle, see the caller
+        ev = [(b, alias.get((n_, a[-1][0] if a and isinstance(a[-1], tuple) else None), n_), a) for b, n_, a in ev]
     rng = np.random.default_rng(1)
     if x is None:
         x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * 0.3
@@ -209,6 +213,8 @@ def compare(kind, ctor, fn, kw, inline_expect, n=6000, x=None):
     # 1. the same multiset of (primitive, parameters)
     want = sorted((n_, a) for _, n_, a in ev)
     got = sorted(oev)
+    if unique:      # per-channel chains: the reference builds num_channels of them, the oracle one per channelizer output
+        want, got = sorted(set(want)), sorted(set(got))
     assert want == got, "\nreference: %s\noracle:    %s" % (want, got)
     # 2. wiring: match each reference block to an oracle event of equal text (in order of first appearance) and require every
     #    reference edge between two mapped blocks to point forward in the oracle's processing order
@@ -394,3 +400,60 @@ def test_demod_4fsk(sps, fw, fm):
     else:
         inline += ["blocks::complex_to_mag()"] * 4 + ["custom::gr_4fsk_discriminator()"]
     compare("demod_4fsk", (sps, 1000000, 1700, fw, int(fm)), orc.demod_4fsk, dict(sps=sps, filter_width=fw, fm=fm), inline, n=8000)
+
+
+def test_demod_dmr():
+    compare("demod_dmr", (5, 1000000), orc.demod_dmr, dict(),
+            ["analog::phase_modulator_fc(1.5707963267948966)", "blocks::multiply_const_ff(0.90000000000000002)", "blocks::complex_to_float()",
+             "blocks::interleave(4)", "digital::binary_slicer_fb()", "blocks::pack_k_bits_bb(2)", "blocks::unpack_k_bits_bb(2)",
+             "digital::map_bb([3,1,2,0])"], n=30000)
+
+
+def test_demod_dsss():
+    compare("demod_dsss", (25, 1000000, 1700, 150), orc.demod_dsss, dict(),
+            FEC2 + ["custom::dsss_decoder_cc()", "blocks::complex_to_real()"], n=30000)
+
+
+@pytest.mark.parametrize("sb", [0, 1])
+def test_demod_ssb(sb):
+    compare("demod_ssb", (125, 1000000, 1700, 2700, sb), orc.demod_ssb, dict(sb=sb),
+            ["blocks::multiply_const_cc(0.90000000000000002)", "blocks::complex_to_real()", "blocks::multiply_const_ff(1.333)",
+             "custom::clipper_cc()", "custom::stretcher_cc()"], n=30000)
+
+
+def test_demod_mmdvm():
+    compare("demod_mmdvm", (), orc.demod_mmdvm, dict(),
+            ["custom::rssi_tag_block()", "blocks::multiply_const_ff(1)", "blocks::float_to_short(1,32767)"], n=30000)
+
+
+def test_mod_dsss():
+    # the reference shapes the (+-1, 0) chips with a COMPLEX interpolator (real taps); the oracle runs the real interpolator on the real
+    # parts (imaginary parts are exactly zero either way) - same taps, same ratio
+    compare("mod_dsss", (25, 1000000, 1700, 200), orc.mod_dsss, dict(filter_width=200),
+            [UNPACK, "blocks::unpacked_to_packed_bb(1,enum:0)", "digital::chunks_to_symbols_bc([(-1,0),(1,0)])", "custom::dsss_encoder_bb()",
+             "blocks::multiply_const_cc(0.65000000000000002,1)", BB1],
+            x=np.arange(2, dtype=np.uint8), alias={("resamp_ccf", "root_raised_cosine"): "resamp_fff"})
+
+
+@pytest.mark.parametrize("fw,sb", [(1000, 0), (2700, 0), (2700, 1)])
+def test_mod_ssb(fw, sb):
+    rng = np.random.default_rng(3)
+    compare("mod_ssb", (125, 1000000, 1700, fw, sb), orc.mod_ssb, dict(filter_width=fw, sb=sb),
+            ["blocks::float_to_complex()", "custom::clipper_cc()", "custom::stretcher_cc()", "blocks::multiply_const_cc(0.90000000000000002,1)", BB1],
+            x=(rng.standard_normal(4096) * 0.1).astype(np.float32))
+
+
+def test_mod_mmdvm():
+    rng = np.random.default_rng(4)
+    compare("mod_mmdvm", (), orc.mod_mmdvm, dict(),
+            ["blocks::short_to_float(1,32767)", "blocks::multiply_const_ff(1,1)", "custom::gr_zero_idle_bursts()",
+             "blocks::multiply_const_cc(0.80000000000000004,1)", BB1],
+            x=(rng.standard_normal(720) * 1000).astype(np.int16))
+
+
+def test_demod_mmdvm_multi2():
+    """the multi-carrier receive graph (configs[3] of BASELINE.json): 10-port channelizer at 250 ksps, then per carrier 24/25 resampler,
+    channel filter, RSSI tagger, discriminator, x1, float_to_short into the ZMQ sink"""
+    compare("demod_mmdvm_multi2", (7, 25000, 1), lambda x: orc.demod_mmdvm_multi_rssi(x, 10), dict(),
+            ["blocks::stream_to_streams(8,10)"] + ["blocks::null_sink(8)"] * 3 + ["custom::gr_mmdvm_sink()"] +
+            ["custom::rssi_tag_block()", "blocks::multiply_const_ff(1)", "blocks::float_to_short(1,32767)"] * 7, n=30000, unique=True)
