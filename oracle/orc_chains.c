@@ -1077,6 +1077,7 @@ size_t orc_demod_mmdvm_xlating(const cf32* in, size_t n, int N, int separation, 
         const int ct = N <= 7 ? (c > 3 ? 3 - c : c) : (c <= N / 2 ? c : c - N);
         const float carrier_offset = (float)(-separation);
         const uint64_t inc = orc_phase_inc_to_turn(2 * M_PI * carrier_offset * ct / (float)fs);
+        if (ct != 0) orc_trace_event("rotator(%.17g)", 2 * M_PI * carrier_offset * ct / (float)fs);        /* the centre carrier has no rotator */
         orc_rotator(in, n, inc, 0, rot);
         orc_decim_auto(rot, n, taps, nt, D, a);
         orc_fir_ccf(a, n2, ft, nf, b);
@@ -1165,6 +1166,7 @@ size_t orc_mod_mmdvm_multi(const int16_t* in, size_t n, int N, int filter_width,
             }
             V[(size_t)i * n25 + blk].re = sa - sb; V[(size_t)i * n25 + blk].im = sc + sd;
         }
+    orc_trace_event("pfb_synthesizer(%d,%s,0)", M, orc_trace_name(st, sizeof(float) * (size_t)ns));   /* restated inline here, twox = false */
     const float lvl = 1.0f / (float)N;
     for (size_t blk = 0; blk < n25; blk++)
         for (int i = 0; i < M; i++) {

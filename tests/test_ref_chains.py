@@ -63,6 +63,8 @@ MAP = {
     "fec::decoder": lambda a: ("cc_decode_k7", []),
     "fec::encoder": lambda a: ("cc_encode_k7", []),
     "filter::pfb_channelizer_ccf": lambda a: ("pfb_channelizer", a),
+    "filter::pfb_synthesizer_ccf": lambda a: ("pfb_synthesizer", a),
+    "blocks::rotator_cc": lambda a: ("rotator", a),
     "digital::scrambler_bb": lambda a: ("scramble", a),
     "analog::frequency_modulator_fc": lambda a: ("freq_mod", a),
 }
@@ -76,8 +78,8 @@ INLINE_KINDS = {"blocks::complex_to_mag", "blocks::divide_ff", "blocks::add_cons
                 "digital::binary_slicer_fb", "blocks::pack_k_bits_bb", "blocks::unpack_k_bits_bb", "digital::map_bb",
                 "blocks::packed_to_unpacked_bb", "blocks::repeat", "digital::chunks_to_symbols_bf", "digital::chunks_to_symbols_bc",
                 "digital::diff_encoder_bb", "blocks::short_to_float", "blocks::unpacked_to_packed_bb", "blocks::null_sink",
-                "blocks::stream_to_streams"}
-DOUBLE_PARAMS = {"iir_ffd", "pwr_squelch_cc"}          # primitives whose GNU Radio signature takes doubles
+                "blocks::stream_to_streams", "blocks::null_source"}
+DOUBLE_PARAMS = {"iir_ffd", "pwr_squelch_cc", "rotator"}          # primitives whose GNU Radio signature takes doubles
 
 
 def split_args(s):
@@ -457,3 +459,25 @@ def test_demod_mmdvm_multi2():
     compare("demod_mmdvm_multi2", (7, 25000, 1), lambda x: orc.demod_mmdvm_multi_rssi(x, 10), dict(),
             ["blocks::stream_to_streams(8,10)"] + ["blocks::null_sink(8)"] * 3 + ["custom::gr_mmdvm_sink()"] +
             ["custom::rssi_tag_block()", "blocks::multiply_const_ff(1)", "blocks::float_to_short(1,32767)"] * 7, n=30000, unique=True)
+
+
+@pytest.mark.parametrize("N", [3, 7])
+def test_mod_mmdvm_multi2(N):
+    """the multi-carrier transmit graph: per carrier the gr_mod_mmdvm chain at 24 ksps -> 25/24 -> zero_idle_bursts -> 10-port synthesizer"""
+    rng = np.random.default_rng(5)
+    g = RefGraph(ref_log("mod_mmdvm_multi2", N, 25000, 1))
+    lvl = "%.9g" % np.float32(1.0 / N)
+    compare("mod_mmdvm_multi2", (N, 25000, 1), orc.mod_mmdvm_multi, dict(),
+            ["custom::gr_mmdvm_source()", "blocks::multiply_const_cc(%s)" % lvl, BB1] + ["blocks::null_source(8)"] * (10 - N) +
+            ["blocks::short_to_float(1,32767)", "blocks::multiply_const_ff(1,1)", "blocks::multiply_const_cc(0.80000000000000004,1)",
+             "custom::gr_zero_idle_bursts()"] * N,
+            x=(rng.standard_normal((N, 720)) * 1000).astype(np.int16))
+
+
+@pytest.mark.parametrize("N", [3, 7])
+def test_demod_mmdvm_multi(N):
+    """the frequency-translating multi-carrier receive graph (gr_demod_mmdvm_multi): rotator per off-centre carrier, 1:10 decimator, channel
+    filter, RSSI tagger, discriminator"""
+    compare("demod_mmdvm_multi", (N, 25000, 1), lambda x: orc.demod_mmdvm_xlating(x, N), dict(),
+            ["custom::gr_mmdvm_sink()"] + ["custom::rssi_tag_block()", "blocks::multiply_const_ff(1)", "blocks::float_to_short(1,32767)"] * N,
+            n=30000)
