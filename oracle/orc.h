@@ -18,6 +18,10 @@
  * gr_zero_idle_bursts, dsss_decoder_cc / dsss_encoder_bb, cessb clipper / stretcher, calculate_deemph_taps, gr_modem (orc_modem_sync; host/gr_modem_hip.cpp),
  * BurstTimer + gr_mmdvm_sink + gr_mmdvm_source (host/mmdvm_wire.cpp), CBPTC19696 + CHamming, M17FrameDecoder + M17Viterbi + Golay(24,12) (orc_framefec.c):
  * tests/test_ref_blocks.py, tests/test_ref_mmdvm.py, tests/test_ref_modem.py, tests/test_framefec.py, tests/golden/ref/.
+ * ALSO pinned: the CONSTRUCTION of every chain (which stock blocks, every parameter, the firdes call behind every tap vector, the
+ * wiring) -- the reference's gr_demod_*.cpp / gr_mod_*.cpp constructors run unmodified against recording stand-ins of the GNU Radio
+ * factories (oracle/rec_stub, oracle/_ref/libqrl_rec.so) and must list what the chains here trace (orc_trace.c):
+ * tests/test_ref_chains.py.  What the stock blocks COMPUTE stays unpinned.
  *
  * ARITHMETIC CONTRACT (what makes GPU results bit-identical to this oracle):
  *   - IEEE-754 binary32, round-to-nearest-even, no flush-to-zero, compiled with
