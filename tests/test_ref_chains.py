@@ -21,7 +21,10 @@ import orc
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REC = os.path.join(HERE, "..", "oracle", "_ref", "libqrl_rec.so")
-pytestmark = pytest.mark.skipif(not os.path.exists(REC), reason="oracle/_ref/libqrl_rec.so not built (needs /root/reference)")
+# the reference's logs for every case below, written by tools/make_chain_golden.py through libqrl_rec.so: lets the comparison run where
+# /root/reference (hence the library) is absent; test_fixture_is_fresh keeps it equal to the live library where that exists
+FIXTURE = os.path.join(HERE, "golden", "ref", "chains.json")
+pytestmark = pytest.mark.skipif(not os.path.exists(REC) and not os.path.exists(FIXTURE), reason="neither libqrl_rec.so nor the fixture")
 
 CONST_KIND = {"digital::constellation_bpsk": 0, "digital::constellation_dqpsk": 1, "digital::constellation_rect": 2}
 
@@ -123,7 +126,19 @@ class RefGraph:
         self.connected = {a[0] for a, _ in self.edges} | {b[0] for _, b in self.edges}
 
 
+def fixture_key(kind, args):
+    return kind + "(" + ",".join(str(int(v)) for v in args) + ")"
+
+
+_seen = {}
+
+
 def ref_log(kind, *args):
+    if not os.path.exists(REC):
+        import json
+        with open(FIXTURE) as f:
+            return json.load(f)[fixture_key(kind, args)]
+    _seen[fixture_key(kind, args)] = (kind, args)
     L = C.CDLL(REC)
     L.rr_construct.restype = C.c_char_p
     L.rr_construct.argtypes = [C.c_char_p] + [C.c_int] * 5
@@ -131,6 +146,30 @@ def ref_log(kind, *args):
     r = L.rr_construct(kind.encode(), *[int(v) for v in a])
     assert r is not None
     return r.decode()
+
+
+def all_cases():
+    """(kind, ctor args) of every parametrised case in this file, by collecting what the tests request"""
+    import inspect
+    import sys
+    mod = sys.modules[__name__]
+    out = []
+    for name, fn in inspect.getmembers(mod, inspect.isfunction):
+        if not name.startswith("test_") or name == "test_fixture_is_fresh":
+            continue
+        marks = [m for m in getattr(fn, "pytestmark", []) if m.name == "parametrize"]
+        if not marks:
+            combos = [()]
+        else:
+            combos = [v if isinstance(v, (tuple, list)) else (v,) for v in marks[0].args[1]]
+        for c in combos:
+            before = set(_seen)
+            try:
+                fn(*c)
+            except AssertionError:
+                pass
+            out += [_seen[k] for k in set(_seen) - before]
+    return out
 
 
 def oracle_trace(fn, *a, **kw):
@@ -481,3 +520,13 @@ def test_demod_mmdvm_multi(N):
     compare("demod_mmdvm_multi", (N, 25000, 1), lambda x: orc.demod_mmdvm_xlating(x, N), dict(),
             ["custom::gr_mmdvm_sink()"] + ["custom::rssi_tag_block()", "blocks::multiply_const_ff(1)", "blocks::float_to_short(1,32767)"] * N,
             n=30000)
+
+
+@pytest.mark.skipif(not os.path.exists(REC), reason="needs the live library")
+def test_fixture_is_fresh():
+    import json
+    with open(FIXTURE) as f:
+        fx = json.load(f)
+    for key, (kind, args) in sorted(_seen.items()):
+        assert fx.get(key) == ref_log(kind, *args), "stale tests/golden/ref/chains.json (%s): run tools/make_chain_golden.py" % key
+    assert len(_seen) >= 50
