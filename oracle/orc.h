@@ -101,6 +101,10 @@ void   orc_quad_demod(const cf32* in, size_t n, float gain, float* out);
 void   orc_agc2(const cf32* in, size_t n, float attack, float decay, float ref, float gain, float max_gain, cf32* out);
 void   orc_costas(const cf32* in, size_t n, float bw, int order, int use_snr, cf32* out);
 enum { ORC_TED_MM = 0, ORC_TED_MOD_MM = 1 };
+/* modified-M&M error formula: a named contract of include/qrl_contracts.h (QRL_TED_MODMM_*); < 0 restores the contract default.
+ * Process-wide; for the sensitivity test only (tests/test_ted_sensitivity.py). */
+void orc_set_ted_modmm(int ff_variant, int cc_variant);
+void orc_get_ted_modmm(int* ff_variant, int* cc_variant);
 enum { ORC_CONST_BPSK = 0, ORC_CONST_DQPSK = 1, ORC_CONST_4LEVEL = 2 };
 size_t orc_symbol_sync_ff(const float* in, size_t n, int ted, float sps, float loop_bw, float damping,
                           float ted_gain, float max_dev, int constellation, float* out);

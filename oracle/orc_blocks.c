@@ -3,6 +3,7 @@
  * block's zero initial state.  "exists iff" rules give the output counts of an infinite
  * stream truncated after n inputs, which is what makes results chunk-size independent. */
 #include "orc.h"
+#include "../include/qrl_contracts.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -464,6 +465,16 @@ void orc_costas(const cf32* in, size_t n, float bw, int order, int use_snr, cf32
  * osps = 1, IR_MMSE_8TAP.  A symbol at cursor ii exists iff in[ii..ii+7] exist.
  * interp(in, mu) = sum_{k=0..7} T[imu][7-k] * in[k], imu = rint(mu*128), one fmaf chain k ascending.
  * ------------------------------------------------------------------------------------------ */
+/* Modified M&M TED: the formula is a NAMED contract (include/qrl_contracts.h) shared with the HIP kernels.  The override exists
+ * for tests/test_ted_sensitivity.py only: it measures which hard decisions each candidate formula would move. */
+static int g_ted_ff = QRL_TED_MODMM_FF, g_ted_cc = QRL_TED_MODMM_CC;
+void orc_set_ted_modmm(int ff_variant, int cc_variant)
+{
+    g_ted_ff = ff_variant < 0 ? QRL_TED_MODMM_FF : ff_variant;
+    g_ted_cc = cc_variant < 0 ? QRL_TED_MODMM_CC : cc_variant;
+}
+void orc_get_ted_modmm(int* ff_variant, int* cc_variant) { *ff_variant = g_ted_ff; *cc_variant = g_ted_cc; }
+
 static inline float slice_real(int constellation, float x)
 {
     if (constellation == ORC_CONST_BPSK) return x > 0 ? 1.0f : -1.0f;
@@ -503,7 +514,7 @@ size_t orc_symbol_sync_ff(const float* in, size_t n, int ted, float sps, float l
         d2 = d1; d1 = d0; d0 = slice_real(constellation, y);
         float e;
         if (ted == ORC_TED_MM) e = d1 * x0 - d0 * x1;
-        else { float u = ((x0 - x2) * d1) - ((d0 - d2) * x1); e = branchless_clip(u / 2.0f, 1.0f); }
+        else { float u = ((x0 - x2) * d1) - ((d0 - d2) * x1); e = QRL_TED_MODMM_ERROR(g_ted_ff, u, branchless_clip); }
         clock_advance(&c, e);
         float phase = mu + c.inst;
         float fl = floorf(phase);
@@ -544,7 +555,7 @@ size_t orc_symbol_sync_cc(const cf32* in, size_t n, int ted, float sps, float lo
             float ar = x0.re - x2.re, ai = x0.im - x2.im;
             float br = d0.re - d2.re, bi = d0.im - d2.im;
             float u = (ar * d1.re + ai * d1.im) - (br * x1.re + bi * x1.im);
-            e = branchless_clip(u, 1.0f);
+            e = QRL_TED_MODMM_ERROR(g_ted_cc, u, branchless_clip);
         }
         clock_advance(&c, e);
         float phase = mu + c.inst;

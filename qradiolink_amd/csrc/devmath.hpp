@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/qrl_contracts.h"
 
 namespace qrl {
 

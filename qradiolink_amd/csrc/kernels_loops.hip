@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
                 if (P.ted == 0) e = st.d1 * st.x0 - st.d0 * st.x1;
                 else {
                     const float u = ((st.x0 - st.x2) * st.d1) - ((st.d0 - st.d2) * st.x1);
-                    e = branchless_clip(u / 2.0f, 1.0f);
+                    e = QRL_TED_MODMM_ERROR(QRL_TED_MODMM_FF, u, branchless_clip);   // named contract: include/qrl_contracts.h
                 }
                 st.avg = st.avg + P.beta * e;
                 if (st.avg > P.maxp) st.avg = P.maxp; else if (st.avg < P.minp) st.avg = P.minp;

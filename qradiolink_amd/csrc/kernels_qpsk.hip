@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
                     const float ar = st.x0.x - st.x2.x, ai = st.x0.y - st.x2.y;
                     const float br = st.d0.x - st.d2.x, bi = st.d0.y - st.d2.y;
                     const float u = (ar * st.d1.x + ai * st.d1.y) - (br * st.x1.x + bi * st.x1.y);
-                    e = branchless_clip(u, 1.0f);
+                    e = QRL_TED_MODMM_ERROR(QRL_TED_MODMM_CC, u, branchless_clip);   // named contract: include/qrl_contracts.h
                 }
                 st.avg = st.avg + P.ss_beta * e;
                 if (st.avg > P.ss_maxp) st.avg = P.ss_maxp; else if (st.avg < P.ss_minp) st.avg = P.ss_minp;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(384) void k_qpsk_pipe4(const QpskParams P, int batc
                     const float ar = x0.x - x2.x, ai = x0.y - x2.y;
                     const float br = d0.x - d2.x, bi = d0.y - d2.y;
                     const float u = (ar * d1.x + ai * d1.y) - (br * x1.x + bi * x1.y);
-                    const float e = branchless_clip(u, 1.0f);
+                    const float e = QRL_TED_MODMM_ERROR(QRL_TED_MODMM_CC, u, branchless_clip);   // named contract: include/qrl_contracts.h
                     avg = avg + P.ss_beta * e;
                     avg = avg > P.ss_maxp ? P.ss_maxp : (avg < P.ss_minp ? P.ss_minp : avg);
                     inst = avg + P.ss_alpha * e;

@@ -175,8 +175,16 @@ def _slice(constellation, v):
     raise ValueError(constellation)
 
 
-def symbol_sync(x, ted, sps, loop_bw, damping, ted_gain, max_dev, constellation, complex_in):
-    """ted: 'mm' | 'mod_mm'.  Returns the interpolated symbols (osps = 1, MMSE 8-tap)."""
+def _modmm(u, variant):
+    """include/qrl_contracts.h: 0 clip(u/2, 1) | 1 clip(u, 1)/2 | 2 clip(u, 1)"""
+    return _clip(u / 2.0, 1.0) if variant == 0 else (_clip(u, 1.0) / 2.0 if variant == 1 else _clip(u, 1.0))
+
+
+def symbol_sync(x, ted, sps, loop_bw, damping, ted_gain, max_dev, constellation, complex_in, modmm=None):
+    """ted: 'mm' | 'mod_mm'.  Returns the interpolated symbols (osps = 1, MMSE 8-tap).
+    modmm: candidate formula of the modified M&M error (None = the contract: 0 for real input, 2 for complex input)."""
+    if modmm is None:
+        modmm = 2 if complex_in else 0
     taps = mmse_table()
     alpha, beta = clock_loop_gains(loop_bw, damping, ted_gain)
     avg = inst = float(sps)
@@ -200,10 +208,10 @@ def symbol_sync(x, ted, sps, loop_bw, damping, ted_gain, max_dev, constellation,
         else:
             if complex_in:
                 u = (xs[0] - xs[2]) * ds[1].conjugate() - (ds[0] - ds[2]) * xs[1].conjugate()
-                e = _clip(u.real, 1.0)
+                e = _modmm(u.real, modmm)
             else:
                 u = (xs[0].real - xs[2].real) * ds[1].real - (ds[0].real - ds[2].real) * xs[1].real
-                e = _clip(u / 2.0, 1.0)
+                e = _modmm(u, modmm)
         avg += beta * e
         avg = min(max(avg, pmin), pmax)
         inst = avg + alpha * e

@@ -51,6 +51,8 @@ _sig("orc_complex_band_pass", C.c_int, C.c_double, C.c_double, C.c_double, C.c_d
 _sig("orc_root_raised_cosine", C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _p)
 _sig("orc_gaussian", C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _p)
 _sig("orc_frontend_taps", C.c_int, C.c_int, _p)
+_sig("orc_set_ted_modmm", None, C.c_int, C.c_int)
+_sig("orc_get_ted_modmm", None, _p, _p)
 _sig("orc_mmse_table", _p)
 _sig("orc_atan_table", _p)
 _sig("orc_tanh_table", _p)
