@@ -110,7 +110,9 @@ int qrl_demod_set_dmo_output(qrl_demod* d, uint8_t* frames, size_t cap_frames, u
 /* Per-handle run-time options (none of them changes results).  QRL_OPT_OVERLAP (2FSK family only, default 0): value 1 runs
  * everything behind the first decimated ring of call k on a second stream under the front end of call k + 1; value 0 runs the
  * kernels of a call one after another. */
-enum { QRL_OPT_OVERLAP = 1 };
+enum { QRL_OPT_OVERLAP = 1,
+       QRL_OPT_LEGACY_FRONTEND = 2   /* 1: the phase-lane front ends fetch with VGPR loads (round-2 kernel k_decim_pl) instead of LDS-DMA (k_decim_pl2): A/B measurements and tests */
+};
 int qrl_demod_set_option(qrl_demod* d, int option, int value);
 int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* filtered_cap, size_t* constellation_cap, size_t* bits_cap);
 /* analogue voice receivers (QRL_MODEM_NBFM2500 / NBFM5000 / AM5000 / WBFM / USB2500 / LSB2500; replace make_gr_demod_nbfm / _am /
@@ -213,7 +215,12 @@ typedef struct {
      * use_tdma, sps, samp_rate, carrier_freq, filter_width) (src/gr/gr_demod_mmdvm_multi.cpp:19-38,58-123): per channel
      * rotator_cc(2 pi (-channel_separation) ct / fs) -> rational_resampler_ccf(1, decimation, low_pass(1, fs, filter_width,
      * 3500, BH)) -> fft_filter_ccf -> rssi tag -> discriminator -> int16, fs = 24 kHz * decimation (240 ksps in the
-     * reference).  The wideband input is read once per channel (compute-bound form); 0 = PFB channelizer (multi2). */
+     * reference).  The wideband input is read once per channel (compute-bound form); 0 = PFB channelizer (multi2).
+     * form 2 = BASELINE.json configs[3] taken literally ("64x freq-xlating-FIR channelizer + 4FSK demod"): channel i
+     * = rotator_cc(2 pi (-25000) ct / fs) -> rational_resampler_ccf(1, num_channels, low_pass_2(1, fs, 5000, 2000, 60, BH)) at
+     * fs = 25 kHz * num_channels with the PFB form's channel map (ct = i, i <= N/2; i - N above), followed by the per-channel
+     * chain of form 0 (24/25 resampler, LPF, RSSI, discriminator -> int16, optional 4FSK tail).  The same channels as form 0 from
+     * num_channels separate FIRs: the compute-bound way of doing what the PFB does; it exists to be measured next to it. */
     int form;
     int channel_separation;  /* form 1: Hz, 0 = 25000 */
     int decimation;          /* form 1: 0 = 10 */
@@ -222,6 +229,11 @@ typedef struct {
 int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** out);
 void qrl_chan_destroy(qrl_chan* c);
 int qrl_chan_reset(qrl_chan* c);
+/* kernel selection for A/B measurements and tests (results are identical): QRL_CHAN_OPT_LEGACY_PFB = 1 runs the general-M
+ * channelizer kernel also for the 64-channel geometry; QRL_CHAN_OPT_LEGACY_TAIL = 1 runs the per-channel chain as separate kernels
+ * instead of the fused feed-forward kernel. */
+enum { QRL_CHAN_OPT_LEGACY_PFB = 1, QRL_CHAN_OPT_LEGACY_TAIL = 2 };
+int qrl_chan_set_option(qrl_chan* c, int option, int value);
 int qrl_chan_set_level(qrl_chan* c, float level);   /* _level_control multiply_const_ff, gr_demod_mmdvm_multi2.cpp:84 */
 /* replaces: gr_demod_mmdvm_multi2::calibrate_rssi / gr_demod_mmdvm::calibrate_rssi -> rssi_tag_block::calibrate_rssi
  * (src/gr/gr_demod_mmdvm_multi2.cpp:138-144, src/gr/gr_demod_mmdvm.cpp:64-67) */
@@ -242,6 +254,14 @@ size_t qrl_chan_out_cap(const qrl_chan* c, size_t n);   /* int16 samples per cha
  * out[(b*channel_count + c)*out_cap + k] device int16 @24 ksps, counts[b*channel_count + c] = samples written. */
 int qrl_chan_process(qrl_chan* c, const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts);
 int qrl_chan_sync(qrl_chan* c);
+/* like qrl_demod_stream_wait: the caller's stream waits, on the device, for everything this handle has enqueued so far -- how a C4
+ * caller chains its own copies / collectives (the all-to-all of a multi-GPU job) behind a call without a host synchronisation. */
+int qrl_chan_stream_wait(qrl_chan* c, void* hip_stream);
+void* qrl_chan_stream(qrl_chan* c);   /* hipStream_t the handle enqueues on */
+/* like qrl_demod_profile / qrl_demod_profile_read: HIP events on the handle's stream around the kernel(s) that read the caller's
+ * wideband IQ (k_pfb_chan; forms 1 / 2: the per-channel decimator launches of a call, summed) -- bench.py's roofline leg */
+int qrl_chan_profile(qrl_chan* c, int enable);
+int qrl_chan_profile_read(qrl_chan* c, double* kernel_ms, uint64_t* launches, const char** kernel_name);
 
 /* ---- multi-carrier MMDVM transmitter (reference src/gr/gr_mod_mmdvm_multi2.cpp:30-128) -------------------------------------
  * make_gr_mod_mmdvm_multi2(burst_timer, num_channels, channel_separation, use_tdma, sps, samp_rate, carrier_freq,
@@ -415,6 +435,10 @@ int qrl_m17_decode_frames(qrl_ctx* ctx, void* hip_stream, const uint8_t* frames,
  * stream-frame bytes = frame number (EOS bit in its top bit) + 16 payload bytes, and the 6-byte LICH segment = 5 LSF bytes +
  * segment number) -> 48-byte frames.  Frame numbering, the LICH round robin and the LSF CRC are per-stream state: host work. */
 int qrl_m17_encode_frames(qrl_ctx* ctx, void* hip_stream, const uint8_t* records, size_t n, uint8_t* frames);
+
+/* ---- developer aids (NOT part of the drop-in surface; tools/prof_phases.py): shader-clock phase profile of k_decim_mfma ---- */
+void qrl_debug_decim_prof(unsigned long long* out8);
+void qrl_debug_decim_prof_enable(int on);
 
 #ifdef __cplusplus
 }

@@ -167,6 +167,8 @@ size_t orc_demod_mmdvm_xlating(const cf32* in, size_t n, int N, int separation, 
 size_t orc_demod_mmdvm_multi_4fsk(const cf32* in, size_t n, int M, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal,
                                   uint8_t* dibits, size_t dcap, size_t* ndib);
 size_t orc_demod_mmdvm_multi_rssi(const cf32* in, size_t n, int M, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal);
+size_t orc_demod_mmdvm_xlating_bank_4fsk(const cf32* in, size_t n, int N, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal,
+                                         uint8_t* dibits, size_t dcap, size_t* ndib);   /* BASELINE configs[3] literal: N freq-xlating FIRs 1:N */
 void orc_demod_dmr(const cf32* in, size_t n, int sps, int samp_rate, orc_demod_out* o);
 void orc_demod_m17(const cf32* in, size_t n, int samp_rate, int filter_width, orc_demod_out* o);
 int orc_dsss_taps(int sps, float* taps);

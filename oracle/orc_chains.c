@@ -1001,16 +1001,11 @@ size_t orc_demod_mmdvm_multi_rssi(const cf32* in, size_t n, int M, int16_t* out,
 }
 /* same + the 4FSK symbol tail of gr_demod_dmr (gr_demod_dmr.cpp:62-105) on every channel's filtered 24 ksps signal:
  * dibits[c*dcap + k] (two bits per symbol), ndib[c] = bits produced */
-size_t orc_demod_mmdvm_multi_4fsk(const cf32* in, size_t n, int M, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal,
-                                  uint8_t* dibits, size_t dcap, size_t* ndib)
+/* the per-channel chain behind the channelizer (gr_demod_mmdvm_multi2.cpp:60-63,80-92,106-131): ch[c][n1] at 25 ksps ->
+ * rational_resampler_ccf(24, 25) -> fft_filter_ccf -> rssi_tag_block -> quadrature_demod_cf -> x1.0 -> float_to_short (+ 4FSK tail) */
+static size_t multi_tail(const cf32* ch, int M, size_t n1, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal,
+                         uint8_t* dibits, size_t dcap, size_t* ndib)
 {
-    int nt = orc_chan_proto_taps(M, NULL);
-    float* taps = NEW(float, nt);
-    orc_chan_proto_taps(M, taps);
-    const size_t n1 = n / (size_t)M;
-    cf32* ch = NEW(cf32, (size_t)M * n1);
-    orc_pfb_channelizer(in, n, taps, nt, M, ch);
-    free(taps);
     int nr = orc_low_pass_2(1, 600000, 5000, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
     float* rt = NEW(float, nr);
     orc_low_pass_2(1, 600000, 5000, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, rt);
@@ -1019,7 +1014,7 @@ size_t orc_demod_mmdvm_multi_4fsk(const cf32* in, size_t n, int M, int16_t* out,
     orc_low_pass_2(1, 24000, 5000, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, ft);
     const size_t n2 = orc_decim_count(n1, 24, 25);
     const float gain = (float)(24000.0f / (2 * M_PI * 12500.0f));
-    cf32* a = NEW(cf32, n2); cf32* b = NEW(cf32, n2); float* d = NEW(float, n2);
+    cf32* a = NEW(cf32, n2 + 1); cf32* b = NEW(cf32, n2 + 1); float* d = NEW(float, n2 + 1);
     size_t m = n2 < cap ? n2 : cap;
     for (int c = 0; c < M; c++) {
         orc_resamp_ccf(ch + (size_t)c * n1, n1, rt, nr, 24, 25, a);
@@ -1050,7 +1045,48 @@ size_t orc_demod_mmdvm_multi_4fsk(const cf32* in, size_t n, int M, int16_t* out,
         orc_quad_demod(b, n2, gain, d);
         for (size_t i = 0; i < m; i++) out[(size_t)c * cap + i] = f2s(d[i] * 1.0f, 32767.0f);
     }
-    free(a); free(b); free(d); free(rt); free(ft); free(ch);
+    free(a); free(b); free(d); free(rt); free(ft);
+    return m;
+}
+size_t orc_demod_mmdvm_multi_4fsk(const cf32* in, size_t n, int M, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal,
+                                  uint8_t* dibits, size_t dcap, size_t* ndib)
+{
+    int nt = orc_chan_proto_taps(M, NULL);
+    float* taps = NEW(float, nt);
+    orc_chan_proto_taps(M, taps);
+    const size_t n1 = n / (size_t)M;
+    cf32* ch = NEW(cf32, (size_t)M * n1 + 1);
+    orc_pfb_channelizer(in, n, taps, nt, M, ch);
+    free(taps);
+    const size_t m = multi_tail(ch, M, n1, out, cap, rssi, rcap, cal, dibits, dcap, ndib);
+    free(ch);
+    return m;
+}
+/* BASELINE.json configs[3] taken literally (SURVEY.md 8(d) "C4 freq-xlating"): N x 25 kHz channels out of ONE wideband input at
+ * fs = 25 kHz * N, each channel through its own frequency-translating decimating FIR -- rotator_cc(2 pi (-25000) ct / fs),
+ * ct = c (c <= N/2) | c - N, the channel map of the PFB form -- + rational_resampler_ccf(1, N, low_pass_2(1, fs, 5000, 2000, 60,
+ * BH)) (the reference's way of writing a freq-xlating FIR: gr_demod_mmdvm_multi.cpp:62-66,89-96,111-112; the prototype is the one
+ * gr_demod_mmdvm_multi2.cpp:58-60 designs for its channelizer), then the per-channel chain of gr_demod_mmdvm_multi2 and the 4FSK tail. */
+size_t orc_demod_mmdvm_xlating_bank_4fsk(const cf32* in, size_t n, int N, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal,
+                                         uint8_t* dibits, size_t dcap, size_t* ndib)
+{
+    const double fs = 25000.0 * N;
+    int nt = orc_chan_proto_taps(N, NULL);
+    float* taps = NEW(float, nt);
+    orc_chan_proto_taps(N, taps);
+    const size_t n1 = orc_decim_count(n, 1, N);
+    cf32* ch = NEW(cf32, (size_t)N * n1 + 1);
+    cf32* rot = NEW(cf32, n + 1);
+    for (int c = 0; c < N; c++) {
+        const int ct = c <= N / 2 ? c : c - N;
+        const float carrier_offset = -25000.0f;
+        const uint64_t inc = orc_phase_inc_to_turn(2 * M_PI * carrier_offset * ct / (float)fs);
+        orc_rotator(in, n, inc, 0, rot);
+        orc_decim_auto(rot, n, taps, nt, N, ch + (size_t)c * n1);
+    }
+    free(rot); free(taps);
+    const size_t m = multi_tail(ch, N, n1, out, cap, rssi, rcap, cal, dibits, dcap, ndib);
+    free(ch);
     return m;
 }
 

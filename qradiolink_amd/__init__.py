@@ -26,6 +26,8 @@ MODEM_USB2500, MODEM_LSB2500 = 11, 12
 MODEM_M17 = 40
 MODEM_DMR = 41
 OPT_OVERLAP = 1
+OPT_LEGACY_FRONTEND = 2
+CHAN_OPT_LEGACY_PFB, CHAN_OPT_LEGACY_TAIL = 1, 2
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECTANGULAR, WIN_BLACKMAN_HARRIS = 0, 1, 2, 3, 5
 
 
@@ -166,6 +168,12 @@ def load_library():
     lib.qrl_chan_out_cap.argtypes = [vp, sz]
     lib.qrl_chan_process.argtypes = [vp, vp, sz, sz, vp, sz, vp]
     lib.qrl_chan_sync.argtypes = [vp]
+    lib.qrl_chan_stream_wait.argtypes = [vp, vp]
+    lib.qrl_chan_stream.argtypes = [vp]
+    lib.qrl_chan_stream.restype = vp
+    lib.qrl_chan_set_option.argtypes = [vp, C.c_int, C.c_int]
+    lib.qrl_chan_profile.argtypes = [vp, C.c_int]
+    lib.qrl_chan_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_char_p)]
     lib.qrl_synth_create.argtypes = [vp, C.POINTER(_SynthConfig), C.POINTER(vp)]
     lib.qrl_synth_destroy.argtypes = [vp]
     lib.qrl_synth_reset.argtypes = [vp]
@@ -206,7 +214,7 @@ EXPORTED_SYMBOLS = [
     "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
-    "qrl_mod_samples_per_byte", "qrl_mod_samples_per_block", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_create",
+    "qrl_mod_samples_per_byte", "qrl_mod_samples_per_block", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_set_option", "qrl_chan_stream_wait", "qrl_chan_stream", "qrl_chan_profile", "qrl_chan_profile_read", "qrl_debug_decim_prof", "qrl_debug_decim_prof_enable", "qrl_chan_create",
     "qrl_chan_destroy", "qrl_chan_reset", "qrl_chan_set_level", "qrl_chan_calibrate_rssi", "qrl_chan_set_rssi_output", "qrl_chan_set_4fsk_output", "qrl_chan_out_cap", "qrl_chan_process", "qrl_chan_sync",
     "qrl_synth_create", "qrl_synth_destroy", "qrl_synth_reset", "qrl_synth_set_bb_gain", "qrl_synth_add_zero_runs", "qrl_synth_out_cap", "qrl_synth_process",
     "qrl_synth_sync",
@@ -456,6 +464,21 @@ class Channelizer:
 
     def sync(self):
         _check(self.lib.qrl_chan_sync(self.h), "qrl_chan_sync")
+
+    def set_option(self, option, value):
+        _check(self.lib.qrl_chan_set_option(self.h, int(option), int(value)), "qrl_chan_set_option")
+
+    def profile(self, enable=True):
+        _check(self.lib.qrl_chan_profile(self.h, int(enable)), "qrl_chan_profile")
+
+    def profile_read(self):
+        ms, n, name = C.c_double(), C.c_uint64(), C.c_char_p()
+        _check(self.lib.qrl_chan_profile_read(self.h, C.byref(ms), C.byref(n), C.byref(name)), "qrl_chan_profile_read")
+        return ms.value, n.value, name.value.decode()
+
+    def stream_wait(self, hip_stream):
+        """the given HIP stream (int handle, e.g. torch.cuda.current_stream().cuda_stream) waits on the device for this handle's work so far"""
+        _check(self.lib.qrl_chan_stream_wait(self.h, C.c_void_p(hip_stream)), "qrl_chan_stream_wait")
 
     def process(self, iq):
         self.process_async(iq)

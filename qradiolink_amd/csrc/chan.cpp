@@ -50,6 +50,10 @@ struct qrl_chan {
     Buf<float2> r1, r2, r3; Buf<float> r4; uint32_t m1 = 0, m2 = 0;
     uint64_t n_in = 0, n1 = 0, n2 = 0;
     float gain = 0, level = 1.0f, rssi_cal = 0.0f;
+    bool xlat2 = false;   // form 2: N freq-xlating FIR decimators 1:N with the PFB prototype in front of the multi2 per-channel chain (BASELINE configs[3])
+    hipEvent_t ev_user = nullptr;
+    int opt_legacy_pfb = 0, opt_legacy_tail = 0;   // qrl_chan_set_option
+    bool profiling = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;   // qrl_chan_profile: the HBM-facing kernel(s) of each call
     bool xlat = false; int xl_D = 10, xl_nt = 0, xl_S = 0; Buf<float> xl_taps; Buf<float2> xl_rot_lo; std::vector<uint64_t> xl_inc;   // form 1
     bool single = false; int rs_I = 24, rs_D = 25;   // single: gr_demod_mmdvm (one carrier at 250 ksps, 12/125 resampler, no channelizer)
     float* rssi_out = nullptr; size_t rssi_cap = 0; uint32_t* rssi_counts = nullptr;
@@ -62,7 +66,8 @@ struct qrl_chan {
         return hipMemcpy(ss.p, s.data(), s.size() * sizeof(SymSyncState), hipMemcpyHostToDevice) == hipSuccess ? QRL_OK : QRL_ERR_HIP;
     }
     size_t zeroed = 0;
-    ~qrl_chan() { if (own_stream && stream) (void)hipStreamDestroy(stream); }
+    ~qrl_chan() { for (auto& e : prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+                  if (ev_user) (void)hipEventDestroy(ev_user); if (own_stream && stream) (void)hipStreamDestroy(stream); }
     int reset_state() {
         const size_t S = (size_t)cfg.batch * cfg.channel_count;
         if (hipMemset(hist_a.p, 0, (size_t)cfg.batch * hist_len * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
@@ -90,13 +95,15 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     h->ctx = ctx; h->cfg = *cfg;
     qrl_chan_config& c = h->cfg;
     if (c.num_channels < 1 || c.num_channels > 64) return qrl_set_error(QRL_ERR_ARG, "num_channels must be 1..64");
+    if (c.form < 0 || c.form > 2) return qrl_set_error(QRL_ERR_ARG, "form must be 0 (PFB), 1 (legacy freq-xlating) or 2 (freq-xlating bank 1:N)");
     h->xlat = c.form == 1;
-    h->single = c.num_channels == 1 && !h->xlat;
+    h->xlat2 = c.form == 2;
+    h->single = c.num_channels == 1 && !h->xlat && !h->xlat2;
     if (c.channel_count <= 0) { c.channel_first = 0; c.channel_count = c.num_channels; }
     if (c.channel_first < 0 || c.channel_first + c.channel_count > c.num_channels) return qrl_set_error(QRL_ERR_ARG, "bad channel range");
     if (c.batch < 1 || c.max_chunk < (size_t)c.num_channels || (size_t)c.batch * c.channel_count > 65535)
         return qrl_set_error(QRL_ERR_ARG, "bad batch / max_chunk");
-    const int M = h->M = h->xlat ? 1 : c.num_channels;   // M = samples consumed per channel-rate instant of the PFB form
+    const int M = h->M = (h->xlat || h->xlat2) ? 1 : c.num_channels;   // M = samples consumed per channel-rate instant of the PFB form
     HIPCHK(hipSetDevice(ctx->device));
     if (c.hip_stream) h->stream = static_cast<hipStream_t>(c.hip_stream);
     else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
@@ -104,9 +111,9 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     // prototype: low_pass_2(1, fs, 5000, 2000, 60, BH), fs = 25 kHz * M (gr_demod_mmdvm_multi2.cpp:58-60; 250 ksps for M = 10)
     // _filter_width of the reference factories (gr_demod_mmdvm_multi2.cpp:47,58-63; gr_demod_mmdvm.cpp:40-52); 0 = their default call site value
     const double fwp = (!h->xlat && c.filter_width > 0) ? (double)c.filter_width : 5000.0;
-    const std::vector<float> proto = low_pass_2(1, 25000.0 * M, fwp, 2000, 60, WIN_BLACKMAN_HARRIS);
+    const std::vector<float> proto = low_pass_2(1, 25000.0 * (h->xlat2 ? c.num_channels : M), fwp, 2000, 60, WIN_BLACKMAN_HARRIS);
     h->nt = (int)proto.size(); h->J = (h->nt + M - 1) / M;
-    if (chan_lds_bytes(M, h->J) > 160 * 1024) return qrl_set_error(QRL_ERR_ARG, "channelizer tile does not fit LDS");
+    if (!h->xlat2 && chan_lds_bytes(M, h->J) > 160 * 1024) return qrl_set_error(QRL_ERR_ARG, "channelizer tile does not fit LDS");
     std::vector<float> t((size_t)h->J * M, 0.0f);
     for (int k = 0; k < h->nt; ++k) t[k] = proto[k];
     if ((r = h->taps.upload(t))) return r;
@@ -148,15 +155,40 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
         if ((r = h->xl_rot_lo.upload(lo))) return r;
         h->rs_I = 1; h->rs_D = h->xl_D;
     }
+    if (h->xlat2) {
+        // BASELINE configs[3] literal (SURVEY 8(d) "C4 freq-xlating"): channel i = rotator_cc(2 pi (-25000) ct / fs) ->
+        // rational_resampler_ccf(1, N, prototype), fs = 25 kHz N, ct = i (i <= N/2) | i - N: the PFB form's channel map, the
+        // reference's way of writing a frequency-translating FIR (gr_demod_mmdvm_multi.cpp:62-66,89-96,111-112).  Behind it the
+        // per-channel chain of the PFB form (24/25 resampler ... int16, 4FSK tail).
+        if (c.num_channels < 8) return qrl_set_error(QRL_ERR_ARG, "form 2: num_channels (= the decimation) must be >= 8");
+        h->xl_D = c.num_channels;
+        h->xl_nt = h->nt;
+        if (!decim_uses_mfma(h->xl_nt, h->xl_D)) return qrl_set_error(QRL_ERR_ARG, "form 2: the decimator tile does not fit the LDS");
+        h->xl_S = decim_mfma_steps(h->xl_nt, h->xl_D);
+        std::vector<float> g((size_t)decim_mfma_hpn(h->xl_nt, h->xl_D), 0.0f);
+        for (int k = 0; k < h->xl_nt; ++k) g[(size_t)k + (size_t)(4 * h->xl_S - h->xl_nt + 1)] = proto[k];
+        if ((r = h->xl_taps.upload(g))) return r;
+        const double fs = 25000.0 * c.num_channels;
+        std::vector<float2> lo((size_t)c.channel_count * 512);
+        h->xl_inc.resize(c.channel_count);
+        for (int cl = 0; cl < c.channel_count; ++cl) {
+            const int i = c.channel_first + cl;
+            const int ct = i <= c.num_channels / 2 ? i : i - c.num_channels;
+            const float carrier_offset = -25000.0f;
+            h->xl_inc[cl] = phase_inc_to_turn(2 * M_PI * carrier_offset * ct / (float)fs);
+            for (int k = 0; k < 512; ++k) { float sn, cs; sincos_turn_host((uint64_t)k * h->xl_inc[cl], sn, cs); lo[(size_t)cl * 512 + k] = make_float2(cs, sn); }
+        }
+        if ((r = h->xl_rot_lo.upload(lo))) return r;
+    }
     const std::vector<float> ft = h->xlat ? low_pass(1, 24000, c.filter_width > 0 ? c.filter_width : 8000, 3500, WIN_BLACKMAN_HARRIS)   // legacy :70-74
                                           : low_pass_2(1, 24000, fwp, 2000, 60, WIN_BLACKMAN_HARRIS);    // :62-63
     h->filt_nt = (int)ft.size();
     if ((r = h->filt_taps.upload(ft)) || (r = h->atan_tab.upload(atan_table()))) return r;
     h->gain = h->single ? (float)(24000.0f / (2 * M_PI * 10000.0f))                               // gr_demod_mmdvm.cpp:41,48
                         : (float)(24000.0f / (2 * M_PI * 12500.0f));                              // gr_demod_mmdvm_multi2.cpp:80
-    h->hist_len = h->xlat ? (uint32_t)(h->xl_nt + h->xl_D) : h->single ? (uint32_t)(h->rs_Jp + h->rs_D + 2) : (uint32_t)(h->J * M);
+    h->hist_len = (h->xlat || h->xlat2) ? (uint32_t)(h->xl_nt + h->xl_D) : h->single ? (uint32_t)(h->rs_Jp + h->rs_D + 2) : (uint32_t)(h->J * M);
     const size_t S = (size_t)c.batch * c.channel_count;
-    const size_t max1 = c.max_chunk / M + 2, max2 = max1 * h->rs_I / h->rs_D + 2;
+    const size_t max1 = c.max_chunk / (h->xlat2 ? h->xl_D : M) + 2, max2 = max1 * h->rs_I / h->rs_D + 2;
     h->m1 = (h->single || h->xlat) ? 63 : pow2ge(max1 + h->rs_Jp + 64) - 1;   // the single-carrier chain reads the caller's IQ directly
     h->m2 = pow2ge(max2 + h->filt_nt + 64 + 300) - 1;   // + one rssi_tag_block window
     if ((r = h->hist_a.alloc((size_t)c.batch * h->hist_len)) || (r = h->hist_b.alloc((size_t)c.batch * h->hist_len)) ||
@@ -172,6 +204,14 @@ int qrl_chan_reset(qrl_chan* h)
     if (!h) return QRL_ERR_ARG;
     HIPCHK(hipStreamSynchronize(h->stream));
     return h->reset_state();
+}
+int qrl_chan_set_option(qrl_chan* h, int option, int value)
+{
+    if (!h) return QRL_ERR_ARG;
+    if (option == QRL_CHAN_OPT_LEGACY_PFB) h->opt_legacy_pfb = value != 0;
+    else if (option == QRL_CHAN_OPT_LEGACY_TAIL) h->opt_legacy_tail = value != 0;
+    else return qrl_set_error(QRL_ERR_ARG, "unknown channelizer option");
+    return QRL_OK;
 }
 int qrl_chan_set_level(qrl_chan* h, float level) { if (!h) return QRL_ERR_ARG; h->level = level; return QRL_OK; }
 int qrl_chan_calibrate_rssi(qrl_chan* h, float level) { if (!h) return QRL_ERR_ARG; h->rssi_cal = level; return QRL_OK; }
@@ -201,13 +241,13 @@ int qrl_chan_set_4fsk_output(qrl_chan* h, uint8_t* bits, size_t bits_cap, float*
     h->fsk_bits = bits; h->fsk_bits_cap = bits_cap; h->fsk_const = constellation; h->fsk_const_cap = constellation_cap; h->fsk_counts = counts;
     return QRL_OK;
 }
-size_t qrl_chan_out_cap(const qrl_chan* h, size_t n) { return h ? (n / h->M + 2) * h->rs_I / h->rs_D + 2 : 0; }
+size_t qrl_chan_out_cap(const qrl_chan* h, size_t n) { return h ? (n / (h->xlat2 ? h->xl_D : h->M) + 2) * h->rs_I / h->rs_D + 2 : 0; }
 
 int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts)
 {
     if (!h || (!iq && n)) return QRL_ERR_ARG;
     if (n > h->cfg.max_chunk) return qrl_set_error(QRL_ERR_TOO_BIG, "n exceeds max_chunk");
-    if (h->xlat && (n & 1)) return qrl_set_error(QRL_ERR_ARG, "n must be even");
+    if ((h->xlat || h->xlat2) && (n & 1)) return qrl_set_error(QRL_ERR_ARG, "n must be even");
     if (n % (size_t)h->M) return qrl_set_error(QRL_ERR_ARG, "n must be a multiple of num_channels (stream_to_streams)");
     if (n == 0) return QRL_OK;
     HIPCHK(hipSetDevice(h->ctx->device));
@@ -215,13 +255,21 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
     const float2* in = reinterpret_cast<const float2*>(iq);
     const float2* hist_old = h->flip ? h->hist_b.p : h->hist_a.p;
     float2* hist_new = h->flip ? h->hist_a.p : h->hist_b.p;
-    const uint64_t n1_1 = (h->n_in + n) / M;
+    // PFB: one output instant per M inputs; form 2: rational_resampler_ccf(1, N) -- output m exists once input m N does
+    const uint64_t n1_1 = h->xlat2 ? (h->n_in + n - 1) / (uint64_t)h->xl_D + 1 : (h->n_in + n) / M;
     if (h->rssi_out && h->rssi_counts) HIPCHK(hipMemsetAsync(h->rssi_counts, 0, (size_t)S * sizeof(uint32_t), h->stream));
     ChanParams p{};
     p.in = in; p.in_stride = stride; p.n0 = h->n_in; p.n = (uint32_t)n; p.hist = hist_old; p.hist_len = h->hist_len;
     p.out = RingC{h->r1.p, h->m1}; p.m0 = h->n1; p.m_count = (uint32_t)(n1_1 - h->n1);
     p.taps = h->taps.p; p.twiddle = h->twiddle.p; p.M = M; p.J = h->J; p.c_first = h->cfg.channel_first; p.c_count = CC;
-    if (!h->single && !h->xlat) launch_pfb_chan(p, B, h->stream);
+    p.legacy = h->opt_legacy_pfb;
+    // the HBM-facing kernel(s) = whatever reads the caller's wideband IQ: the PFB, or the per-channel decimators of forms 1 / 2
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (h->profiling && !h->single) { HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1)); HIPCHK(hipEventRecord(ev0, h->stream)); }
+    if (!h->single && !h->xlat && !h->xlat2) {
+        launch_pfb_chan(p, B, h->stream);
+        if (ev1) { HIPCHK(hipEventRecord(ev1, h->stream)); h->prof_events.emplace_back(ev0, ev1); }
+    }
     HistParams hp{};
     hp.in = in; hp.in_stride = stride; hp.n0 = h->n_in; hp.n = (uint32_t)n;
     hp.hist_old = hist_old; hp.hist_new = hist_new; hp.hist_len = h->hist_len; hp.rot_enable = 0;
@@ -231,15 +279,16 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
     const uint64_t RI = (uint64_t)h->rs_I, RD = (uint64_t)h->rs_D;
     const uint64_t n2_1 = n1_1 ? ((n1_1 - 1) * RI + (RI - 1)) / RD + 1 : 0;   // outputs q with q*D/I <= n1_1 - 1
     const uint32_t c2 = (uint32_t)(n2_1 - h->n2);
-    if (h->xlat) {   // one front-end launch per channel: same input, that channel's rotator, rows b * CC + cl of ring r2
+    if (h->xlat || h->xlat2) {   // one front-end launch per channel: same input, that channel's rotator, rows b * CC + cl of ring r2 (form 2: r1)
         for (int cl = 0; cl < CC; ++cl) {
             DecimParams dp{};
             dp.in = in; dp.in_stride = stride; dp.n0 = h->n_in; dp.n = (uint32_t)n; dp.hist = hist_old; dp.hist_len = h->hist_len; dp.hist_raw = 1;
-            dp.out = RingC{h->r2.p, h->m2}; dp.out_row_mul_m1 = (uint32_t)CC - 1u; dp.out_row_add = (uint32_t)cl;
-            dp.m0 = h->n2; dp.m_count = c2; dp.D = h->xl_D; dp.gtab = h->xl_taps.p; dp.taps = h->xl_taps.p; dp.S = h->xl_S; dp.nt = h->xl_nt;
+            dp.out = h->xlat2 ? RingC{h->r1.p, h->m1} : RingC{h->r2.p, h->m2}; dp.out_row_mul_m1 = (uint32_t)CC - 1u; dp.out_row_add = (uint32_t)cl;
+            dp.m0 = h->xlat2 ? h->n1 : h->n2; dp.m_count = h->xlat2 ? (uint32_t)(n1_1 - h->n1) : c2; dp.D = h->xl_D; dp.gtab = h->xl_taps.p; dp.taps = h->xl_taps.p; dp.S = h->xl_S; dp.nt = h->xl_nt;
             dp.rot_enable = 1; dp.rot_acc = 0; dp.rot_inc = h->xl_inc[cl]; dp.rot_nbase = 0; dp.rot_lo = h->xl_rot_lo.p + (size_t)cl * 512;
             if (launch_decim_mfma(dp, B, h->stream)) return qrl_set_error(QRL_ERR_HIP, "freq-xlating front end: hipFuncSetAttribute failed");
         }
+        if (ev1) { HIPCHK(hipEventRecord(ev1, h->stream)); h->prof_events.emplace_back(ev0, ev1); }
     }
     ResampParams rp{};
     if (h->xlat) {
@@ -281,6 +330,33 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
     HIPCHK(hipGetLastError());
     if (qrl::take_launch_error()) return QRL_ERR_HIP;
     h->n_in += n; h->n1 = n1_1; h->n2 = n2_1;
+    return QRL_OK;
+}
+int qrl_chan_stream_wait(qrl_chan* h, void* hip_stream)
+{
+    if (!h) return QRL_ERR_ARG;
+    if (!h->ev_user) HIPCHK(hipEventCreateWithFlags(&h->ev_user, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->ev_user, h->stream));
+    HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), h->ev_user, 0));
+    return QRL_OK;
+}
+void* qrl_chan_stream(qrl_chan* h) { return h ? h->stream : nullptr; }
+int qrl_chan_profile(qrl_chan* h, int enable) { if (!h) return QRL_ERR_ARG; h->profiling = enable != 0; return QRL_OK; }
+int qrl_chan_profile_read(qrl_chan* h, double* kernel_ms, uint64_t* launches, const char** kernel_name)
+{
+    if (!h) return QRL_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double total = 0;
+    for (auto& e : h->prof_events) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
+        total += ms;
+        (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+    }
+    if (kernel_ms) *kernel_ms = total;
+    if (launches) *launches = h->prof_events.size();
+    if (kernel_name) *kernel_name = (h->xlat || h->xlat2) ? "k_decim_mfma (one launch per channel, summed)" : h->single ? "k_resamp" : "k_pfb_chan";
+    h->prof_events.clear();
     return QRL_OK;
 }
 int qrl_chan_sync(qrl_chan* h)

@@ -222,6 +222,7 @@ struct qrl_demod {
     int analog_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* out, uint32_t* counts, bool side);
     uint64_t n_in = 0, n1 = 0, n2 = 0;  // items so far: device rate, 1 Msps, target rate
     bool profiling = false;
+    bool legacy_fe = false;   // QRL_OPT_LEGACY_FRONTEND: phase-lane front ends with VGPR loads (k_decim_pl) instead of LDS-DMA (k_decim_pl2)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
 
     ~qrl_demod() {
@@ -637,6 +638,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         p.out = r1; p.m0 = n1_0; p.m_count = (uint32_t)(n1_1 - n1_0);
         p.taps = fe.taps.p; p.D = fe.D; p.Jpad = fe.Jpad;
         p.rot_enable = 1; p.rot_acc = rot_acc; p.rot_inc = rot_inc; p.rot_nbase = rot_nbase; p.rot_lo = rot_lo.p;
+        p.pl_legacy = legacy_fe;
         if (fe.launch(p, B, stream)) return fail(QRL_ERR_HIP, "front-end launch: hipFuncSetAttribute failed");
     }
     if (profiling && fe.used) { HIPCHK(hipEventRecord(ev1, stream)); prof_events.emplace_back(ev0, ev1); }
@@ -651,6 +653,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         p.n0 = src0; p.n = (uint32_t)(src1 - src0);
         p.out = r2; p.m0 = n2_0; p.m_count = (uint32_t)(n2_1 - n2_0);
         p.taps = first.taps.p; p.D = first.D; p.Jpad = first.Jpad;
+        p.pl_legacy = legacy_fe;
         if (first.launch(p, B, stream)) return fail(QRL_ERR_HIP, "first-stage launch: hipFuncSetAttribute failed");
     } else {
         ResampParams p{};
@@ -1131,6 +1134,9 @@ int qrl_demod_set_option(qrl_demod* d, int option, int value)
         if (int rs = d->sync_all()) return rs;
         d->overlap = value != 0;
         d->tail2_valid[0] = d->tail2_valid[1] = false;
+        return QRL_OK;
+    case QRL_OPT_LEGACY_FRONTEND:
+        d->legacy_fe = value != 0;
         return QRL_OK;
     default:
         return qrl_set_error(QRL_ERR_ARG, "unknown option");

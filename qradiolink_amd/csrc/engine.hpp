@@ -44,6 +44,7 @@ struct DecimParams {
     // edge segment (outputs whose window starts in front of this call's buffer): per-stream scratch of ROTATED samples (carried
     // history + head of the buffer), one extra unit per stream behind the regular ones reads it with identity phasors
     float2* pl_edge; uint32_t pl_edge_stride, pl_edge_cap; uint64_t pl_edge_ms, pl_edge_me;
+    int pl_legacy;                                          // 1: k_decim_pl with VGPR loads instead of the LDS-DMA kernel k_decim_pl2 (QRL_OPT_LEGACY_FRONTEND)
 };
 struct HistParams {
     const float2* in; size_t in_stride; uint64_t n0; uint32_t n;
@@ -199,6 +200,11 @@ struct ChanParams {
     RingC out; uint64_t m0; uint32_t m_count;                      // channel rings [batch * c_count], output instants
     const float* taps; const float2* twiddle;                      // taps[p + M k] zero padded to J*M; W[q] = e^{+j 2 pi q / M}
     int M, J, c_first, c_count;
+    int legacy;                 // 1: the general-M kernel also for M = 64 (qrl_chan_set_option(QRL_CHAN_OPT_LEGACY_PFB): A/B and tests)
+    // k_pfb_chan64 only.  row_cpd > 0: output rows grouped by destination rank -- row = ((cc / row_cpd) * batch + b) * row_cpd + cc % row_cpd
+    // (the send layout of an all-to-all that gives rank r the channels [r row_cpd, (r + 1) row_cpd) of every stream);
+    // out_pitch > 0: linear rows of out_pitch items, item m - m0 (a caller buffer instead of an engine ring)
+    uint32_t row_cpd; size_t out_pitch;
 };
 struct F2sParams { RingF in; uint64_t q0; uint32_t count; float level, scale; int16_t* out; size_t cap; uint32_t* counts; };
 struct RssiParams { RingC in; uint64_t j0; uint32_t count; float calibration; float* out; size_t cap; uint32_t* counts; };

@@ -213,6 +213,152 @@ void k_decim_pl(const DecimParams P_)
     }
 }
 
+// ---- k_decim_pl2: the same kernel with the input routed HBM -> LDS by LDS-DMA ------------------------------------------------------
+// k_decim_pl reads each 400-byte block with one global_load_dwordx2 per wave: 50 lanes x 8 bytes, four or five 128-byte lines touched for
+// 3.1 lines of data, partial lines requested twice.  That request stream -- not HBM -- capped it at 5.1 TB/s (tools/ubench/
+// stream_patterns: 5.27 TB/s for exactly this pattern).  Measured with tools/ubench/stream_lds.hip (round 3): a wave that streams
+// its segment as 1 KiB LDS-DMA pieces (global_load_lds_dwordx4, 64 lanes x 16 bytes, whole lines) into a PRIVATE ring of 8 KiB with
+// 4 pieces in flight, non-temporal policy, reaches 7.07 TB/s at 16-20 waves per CU -- with 20 FMAs per sample beside it.
+//   * ring = 8 pieces of 1 KiB per wave; piece q of the wave's byte stream (a0 + 1024 q, a0 = segment start rounded down to 128 bytes
+//     relative to the stream's row) lands at ring offset (1024 q) mod 8192.  No barrier anywhere: the wave that issued a piece is the
+//     only one that reads it, ordered by its own counted s_waitcnt vmcnt.
+//   * every group of 4 blocks (1600 bytes) tops the DMA queue up to need + 4 pieces, need = pieces that cover the group; then
+//     s_waitcnt vmcnt(4): at most the 4 pieces YOUNGER than the last needed one are outstanding (stores in between only make the
+//     wait stricter), so everything the group reads has landed.  The ring never holds more than 4 + 3 live pieces.
+//   * lane l reads its sample of block t with one ds_read_b64 at (o0 + 400 t + 8 l) mod 8192: lane-contiguous, conflict free.
+// Everything behind the sample fetch -- rotator, tap scatter, accumulator ring, transposing reduction -- is k_decim_pl's: the "pl"
+// summation contract is untouched, results are bit-identical.
+constexpr int PL2_RP = 8;          // ring pieces (1 KiB each) per wave
+constexpr int PL2_PD = 4;          // pieces in flight behind the last needed one
+constexpr int PL2_G = 4;           // blocks per DMA top-up / wait group (divides PL_RING)
+
+__device__ __forceinline__ void pl2_glds16(const void* gsrc, uint32_t lds_dst)
+{
+    // one LDS-DMA piece, non-temporal: 64 lanes x 16 B from per-lane global addresses to LDS[lds_dst + 16 lane].  M0 (compiler
+    // reserved) is saved and restored inside the statement (cdna_hip_programming.md 5.x "LDS-DMA recipe")
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int J>
+__global__ __launch_bounds__(256)
+void k_decim_pl2(const DecimParams P_)
+{
+    const DecimParams& P = P_;
+    // rings first (ring of wave w at byte w * 8192: the LDS address of a sample is (x & 8191) | (w << 13)), tables behind
+    __shared__ __align__(1024) unsigned char ring_all[4 * PL2_RP * 1024];
+    __shared__ float2 t_lo[512];
+    __shared__ float2 t_hi_all[4][64];
+    __shared__ float2 t_one[1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    t_lo[tid] = P.rot_lo[tid];
+    t_lo[tid + 256] = P.rot_lo[tid + 256];
+    if (tid == 0) t_one[0] = make_float2(1.f, 0.f);
+
+    const uint32_t unit = blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t B = P.pl_batch;
+    const uint32_t nreg = P.pl_nseg * B;
+    const bool edge = unit >= nreg;
+    const uint32_t nsg = P.pl_nseg ? P.pl_nseg : 1u;
+    const uint32_t b = edge ? unit - nreg : unit / nsg, seg = edge ? 0u : unit - b * nsg;
+    const bool active = edge ? (b < B && P.pl_edge_me > P.pl_edge_ms) : true;
+    const int D = P.D;
+    const uint64_t ms = edge ? P.pl_edge_ms : P.pl_m_begin + (uint64_t)seg * P.pl_S;
+    const uint64_t me = edge ? P.pl_edge_me : (ms + P.pl_S < P.pl_m_end ? ms + P.pl_S : P.pl_m_end);
+    const int64_t c_first_s = (int64_t)ms - (int64_t)(J - 1);
+    const uint64_t c_first = (uint64_t)c_first_s;
+    const int64_t i_first_s = (c_first_s - 1) * (int64_t)D + 1;
+    const uint64_t i_first = (uint64_t)i_first_s;
+    const uint32_t kb0 = edge ? 0u : (uint32_t)((i_first - P.rot_nbase) >> 9);
+    float2* t_hi = t_hi_all[wave];
+    if (active) t_hi[lane] = edge ? make_float2(1.f, 0.f) : sincos_turn(P.rot_acc + ((uint64_t)(kb0 + (uint32_t)lane) << 9) * P.rot_inc);
+    // edge units read identity phasors: the fine table collapses to its one-entry stand-in (index mask 0)
+    const float2* tl = edge ? t_one : t_lo;
+    const uint32_t tl_mask = edge ? 0u : 4095u;
+    __syncthreads();
+    if (!active) return;
+
+    float h[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) h[j] = P.pl_taps[j * 64 + lane];
+    const int lo = lane < D ? lane : D - 1;                          // idle lanes re-read the last sample against zero taps
+    const int nblk = (int)(me - ms) + J - 1;
+    // the wave's byte stream: row = the stream's buffer (or its edge scratch), first byte of block 0 at row + off0
+    const unsigned char* rowp = reinterpret_cast<const unsigned char*>(edge ? P.pl_edge + (size_t)b * P.pl_edge_stride : P.in + (size_t)b * P.in_stride);
+    const uint64_t off0 = edge ? 0ull : (uint64_t)(i_first - P.n0) * 8ull;
+    const uint64_t row_bytes = edge ? (uint64_t)P.pl_edge_stride * 8ull : (uint64_t)P.n * 8ull;   // multiples of 16 (even sample counts)
+    const uint32_t o0 = (uint32_t)(off0 & 127u);                     // offset of block 0 inside piece 0
+    const unsigned char* a0 = rowp + (off0 - o0);
+    const unsigned char* last16 = rowp + row_bytes - 16;             // lanes past the end of the row re-read its last 16 bytes (never consumed)
+    const uint32_t bytes_per_blk = (uint32_t)D * 8u;
+    const uint32_t npieces = (o0 + (uint32_t)nblk * bytes_per_blk + 1023u) >> 10;
+    const uint32_t rbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)ring_all + (uint32_t)wave * (PL2_RP * 1024);
+    const unsigned char* ring = ring_all + wave * (PL2_RP * 1024);
+    uint32_t issued = 0;
+    auto issue_upto = [&](uint32_t want) {                           // wave uniform
+        while (issued < want) {
+            const unsigned char* g = a0 + (size_t)issued * 1024 + (size_t)lane * 16;
+            g = g < last16 ? g : last16;
+            pl2_glds16(g, rbase + (issued & (PL2_RP - 1)) * 1024u);
+            ++issued;
+        }
+    };
+    const uint32_t k0 = edge ? 0u : (uint32_t)(i_first - P.rot_nbase) - (kb0 << 9);   // < 512
+    const uint32_t lo8 = (uint32_t)lo * 8u;
+    const uint32_t lane_off = o0 + lo8;
+    const bool hi8 = lane & 8, hi4 = lane & 4;
+    const bool leader = (lane & 3) == 0;
+    const int oidx = pl_out_index(lane);
+    float2* orow = P.out.p + ((size_t)b * (P.out_row_mul_m1 + 1u) + P.out_row_add) * (P.out.mask + 1u);
+
+    float ar[PL_RING], ai[PL_RING];
+#pragma unroll
+    for (int s = 0; s < PL_RING; ++s) ar[s] = ai[s] = 0.f;
+
+    const int nsup = (nblk + PL_RING - 1) / PL_RING;
+    for (int sup = 0; sup < nsup; ++sup) {
+        float dr[PL_RING], di[PL_RING];
+#pragma unroll
+        for (int grp = 0; grp < PL_RING / PL2_G; ++grp) {
+            {   // pieces that cover the blocks of this group (clamped to the segment), + PL2_PD in flight behind them
+                const uint32_t t_end = (uint32_t)(sup * PL_RING + (grp + 1) * PL2_G);
+                uint32_t need = (o0 + t_end * bytes_per_blk + 1023u) >> 10;
+                need = need < npieces ? need : npieces;
+                const uint32_t want = need + PL2_PD < npieces ? need + PL2_PD : npieces;   // never past the segment's last piece
+                issue_upto(want);
+                if (want - need == PL2_PD) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PL2_PD) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the last groups of a segment
+            }
+#pragma unroll
+            for (int ii = 0; ii < PL2_G; ++ii) {
+                const int i = grp * PL2_G + ii;
+                const int t = sup * PL_RING + i;
+                const uint32_t xo = (lane_off + (uint32_t)t * bytes_per_blk) & (PL2_RP * 1024u - 1u);
+                const float2 xr = *reinterpret_cast<const float2*>(ring + xo);
+                // rotator: phasor of sample k = T_hi[k >> 9] (x) T_lo[k & 511], byte addressed
+                const uint32_t kb8 = (k0 + (uint32_t)t * (uint32_t)D) * 8u + lo8;
+                const float2 plo = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(tl) + (kb8 & tl_mask));
+                const float2 phi = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(t_hi) + ((kb8 >> 9) & ~7u));
+                const float2 xs = cmul_fma(xr, cmul_fma(phi, plo));
+#pragma unroll
+                for (int j = 0; j < J - 1; ++j) {
+                    ar[(i + j) % PL_RING] = fmaf(h[j], xs.x, ar[(i + j) % PL_RING]);
+                    ai[(i + j) % PL_RING] = fmaf(h[j], xs.y, ai[(i + j) % PL_RING]);
+                }
+                ar[(i + J - 1) % PL_RING] = h[J - 1] * xs.x;
+                ai[(i + J - 1) % PL_RING] = h[J - 1] * xs.y;
+                dr[i] = ar[i]; di[i] = ai[i];
+            }
+        }
+        const float yr = pl_reduce16(dr, hi8, hi4), yi = pl_reduce16(di, hi8, hi4);
+        const uint64_t m = c_first + (uint64_t)(sup * PL_RING + oidx);
+        if (leader && m >= ms && m < me) orow[(uint32_t)m & P.out.mask] = make_float2(yr, yi);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be writing this wave's ring when the workgroup's LDS is handed on
+}
+
 // ---- generalised geometry: E samples per lane and block, R outputs per block ------------------------------------------------------
 //  k_decim_plx<E, R, U>: the same register-resident scheme for the front ends whose decimation is not one sample per lane:
 //    E = 2, R = 1   64 < D <= 128 (the 100:1 front end of a 100 Msps device, 4 181 taps): a block is D samples, lane l owns the
@@ -514,7 +660,12 @@ std::vector<float> decim_pl_layout(const std::vector<float>& h, int D)
 template <int J>
 static void pl_launch_main(const DecimParams& q, uint32_t units, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_decim_pl<J>), dim3((units + 3) / 4), dim3(256), 0, s, q);
+    // LDS-DMA variant whenever the byte stream of a unit can be cut into 16-byte pieces: rows 16-byte aligned with an even sample
+    // count (what qrl_demod_process demands of its callers; the edge scratch is built that way)
+    const bool dma_ok = !q.pl_legacy && q.in && (reinterpret_cast<uintptr_t>(q.in) & 15u) == 0 && (q.in_stride & 1u) == 0 && (q.n & 1u) == 0 &&
+                        (!q.pl_edge || ((reinterpret_cast<uintptr_t>(q.pl_edge) & 15u) == 0 && (q.pl_edge_stride & 1u) == 0));
+    if (dma_ok) hipLaunchKernelGGL((k_decim_pl2<J>), dim3((units + 3) / 4), dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((k_decim_pl<J>), dim3((units + 3) / 4), dim3(256), 0, s, q);
 }
 
 int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)

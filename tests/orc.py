@@ -433,6 +433,23 @@ def demod_mmdvm_multi_4fsk(x, M):
     return out[:, :n].copy(), [dib[c, :int(nd[c])].copy() for c in range(M)]
 
 
+_sig("orc_demod_mmdvm_xlating_bank_4fsk", _sz, _p, _sz, C.c_int, _p, _sz, _p, _sz, C.c_float, _p, _sz, _p)
+
+
+def demod_mmdvm_xlating_bank_4fsk(x, N, cal=0.0):
+    """BASELINE configs[3] literal: N freq-xlating FIR decimators 1:N + the multi2 per-channel chain + 4FSK dibits"""
+    x = np.ascontiguousarray(x, cf32)
+    cap = (x.size // N + 2) * 24 // 25 + 4
+    out = np.zeros((N, cap), np.int16)
+    rcap = cap // 300 + 2
+    rssi = np.zeros((N, rcap), np.float32)
+    dcap = 2 * (cap // 4 + 16)
+    dib = np.zeros((N, dcap), np.uint8)
+    nd = np.zeros(N, np.uint64)
+    n = lib.orc_demod_mmdvm_xlating_bank_4fsk(_ptr(x), x.size, N, _ptr(out), cap, _ptr(rssi), rcap, cal, _ptr(dib), dcap, _ptr(nd))
+    return out[:, :n].copy(), rssi[:, :n // 300].copy(), [dib[c, :int(nd[c])].copy() for c in range(N)]
+
+
 def demod_mmdvm_xlating(x, N, separation=25000, D=10, fw=8000, cal=0.0):
     x = np.ascontiguousarray(x, cf32)
     cap = x.size // D + 4

@@ -344,3 +344,71 @@ def test_mmdvm_tx_zero_idle_bursts_bit_exact(qrl_ctx, single):
         assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), "stream %d differs" % b
     plain = orc.mod_mmdvm(x[1, 0], bb_gain=1.0) if single else orc.mod_mmdvm_multi(x[1])
     assert not np.array_equal(plain, ref)            # the runs did something
+
+
+# ---- BASELINE.json configs[3] taken literally: 64 x freq-xlating FIR 1:64 (2181-tap prototype) + per-channel chain + 4FSK demod
+@pytest.mark.parametrize("chunk", [64 * 2500, 64 * 625 + 2])
+def test_literal_c4_freq_xlating_bank_64_channels_bit_exact(qrl_ctx, chunk):
+    """form = 2: 64 channels on the 25 kHz grid out of one 1.6 Msps input, each through its own rotator + rational_resampler_ccf(1, 64,
+    low_pass_2(1, 1.6e6, 5000, 2000, 60, BH)) (the MFMA decimator, one launch per channel), then 24/25 resampler, LPF, RSSI,
+    discriminator -> int16 and the 4FSK symbol tail -- int16, RSSI and dibits bit-exact against the oracle, in one call and cut into
+    ragged calls; planted DMR-like 4FSK carriers come back as their dibits; the PFB form (form 0) produces the same dibits from the
+    same input (the two forms are the same filter bank, summed in different orders)."""
+    import torch
+    import qradiolink_amd as q
+    import sig
+    N, n = 64, 64 * 2500
+    fs = 25000.0 * N
+    iq = _wideband(N, n, seed=64, nstreams=2)
+    t = np.arange(n)
+    dibs = {}
+    for c, seed in ((3, 5), (40, 6), (63, 7)):
+        x, d = sig.make_4fsk(nsym=int(n / fs * 4800) - 2, seed=seed, amp=0.4, noise=0.0, fs=fs)
+        f0 = c * 25000.0 if c <= N // 2 else (c - N) * 25000.0
+        m = min(n, x.size)
+        iq[0, :m] += (x[:m] * np.exp(2j * np.pi * f0 * t[:m] / fs)).astype(np.complex64)
+        dibs[c] = d
+    ch = q.Channelizer(qrl_ctx, N, batch=2, max_chunk=chunk, form=2)
+    ch.calibrate_rssi(-3.0)
+    ch.enable_4fsk()
+    d = torch.from_numpy(iq).cuda()
+    got = [[[] for _ in range(N)] for _ in range(2)]
+    tags = [[[] for _ in range(N)] for _ in range(2)]
+    dib = [[[] for _ in range(N)] for _ in range(2)]
+    for s in range(0, n, chunk):
+        part = d[:, s:s + chunk]
+        if part.shape[1] & 1:
+            part = part[:, :-1]
+        out, cnt = ch.process(part.contiguous())
+        cnt, o = cnt.cpu().numpy(), out.cpu().numpy()
+        rc, r = ch.rssi_counts.cpu().numpy(), ch.rssi.cpu().numpy()
+        fc, bits = ch.fsk_counts.cpu().numpy(), ch.dibits.cpu().numpy()
+        for b in range(2):
+            for c in range(N):
+                got[b][c].append(o[b, c, :cnt[b, c]].copy())
+                tags[b][c].append(r[b, c, :rc[b, c]].copy())
+                dib[b][c].append(bits[b, c, :fc[b, c, 2]].copy())
+    ch.close()
+    used = sum((min(chunk, n - s) & ~1) for s in range(0, n, chunk))
+    for b in range(2):
+        ref, rref, dref = orc.demod_mmdvm_xlating_bank_4fsk(iq[b, :used], N, cal=-3.0)
+        for c in range(N):
+            g = np.concatenate(got[b][c])
+            assert g.size == ref.shape[1] and np.array_equal(g, ref[c]), (b, c)
+            tg = np.concatenate(tags[b][c])
+            assert tg.size == rref[c].size and np.allclose(tg, rref[c], rtol=0, atol=1e-4)
+            dd = np.concatenate(dib[b][c])
+            assert dd.size == dref[c].size and np.array_equal(dd, dref[c]), (b, c)
+    assert np.abs(ref).max() > 1000
+    for c, dw in dibs.items():
+        g = np.concatenate(dib[0][c]).reshape(-1, 2)
+        g = g[:, 0] * 2 + g[:, 1]
+        best = max(np.mean(g[k:k + 400] == dw[:400]) for k in range(60))
+        assert best > 0.99, (c, best)
+    # the PFB form on the same input: same channels, same planted dibits
+    if chunk == n:
+        pfb = _run_4fsk(qrl_ctx, iq, N, n)
+        for c, dw in dibs.items():
+            g = pfb[0][c].reshape(-1, 2)
+            g = g[:, 0] * 2 + g[:, 1]
+            assert max(np.mean(g[k:k + 400] == dw[:400]) for k in range(60)) > 0.99

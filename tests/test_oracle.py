@@ -663,3 +663,31 @@ def test_ssb_chain_recovers_the_tones_and_rejects_the_other_sideband(lsb):
     assert abs(np.argmax(spec) * 8000.0 / seg.size - 713.0) < 4.0
     other = orc.demod_ssb(x, sb=int(not lsb))["audio"][1024:5120]
     assert np.sqrt(np.mean(other.astype(np.float64) ** 2)) < 0.02 * np.sqrt(np.mean(seg ** 2))
+
+
+def test_literal_c4_freq_xlating_bank_equals_the_pfb_form():
+    """BASELINE configs[3] literal (64 freq-xlating FIRs 1:64 with the PFB prototype, orc_demod_mmdvm_xlating_bank_4fsk) and the PFB
+    form (orc_demod_mmdvm_multi_4fsk) are the same filter bank summed in different orders: on a channel that carries a signal the
+    int16 FM outputs agree to 1 LSB and the 4FSK dibits are identical; planted dibits come back."""
+    import sig
+    N, n = 64, 64 * 2500
+    fs = 25000.0 * N
+    rng = np.random.default_rng(64)
+    iq = (0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    t = np.arange(n)
+    planted = {}
+    for c, seed in ((3, 5), (40, 6)):
+        x, d = sig.make_4fsk(nsym=int(n / fs * 4800) - 2, seed=seed, amp=0.4, noise=0.0, fs=fs)
+        f0 = c * 25000.0 if c <= N // 2 else (c - N) * 25000.0
+        m = min(n, x.size)
+        iq[:m] += (x[:m] * np.exp(2j * np.pi * f0 * t[:m] / fs)).astype(np.complex64)
+        planted[c] = d
+    a16, _, adib = orc.demod_mmdvm_xlating_bank_4fsk(iq, N)
+    p16, pdib = orc.demod_mmdvm_multi_4fsk(iq, N)
+    assert a16.shape == p16.shape
+    for c, d in planted.items():
+        assert np.abs(a16[c, 100:-5].astype(int) - p16[c, 100:-5].astype(int)).max() <= 1
+        assert np.array_equal(adib[c], pdib[c])
+        g = adib[c].reshape(-1, 2)
+        g = g[:, 0] * 2 + g[:, 1]
+        assert max(np.mean(g[k:k + 400] == d[:400]) for k in range(60)) > 0.99
