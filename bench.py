@@ -116,6 +116,8 @@ def run_workload(name, args, torch, q, ctx, dev, rank, world, overlap=False, che
     iq = synth(mode, rate, offset, batch, nsamp, 1234 + rank, torch, dev, pad=args.pad)
     dem = q.Demod(ctx, modem, batch=batch, max_chunk=nsamp, device_samp_rate=rate, carrier_offset_hz=offset,
                   side_outputs=True)
+    if args.ldsdma_frontend:
+        dem.set_option(q.OPT_LEGACY_FRONTEND, 0)   # A/B: the LDS-DMA phase-lane front end k_decim_pl2 instead of k_decim_pl
     if overlap:
         dem.set_option(q.OPT_OVERLAP, 1)   # opt-in: decimated-rate kernels of call k under the front end of call k + 1
     for _ in range(args.warmup):
@@ -192,6 +194,8 @@ def run_c4(args, torch, q, ctx, dev, rank, world):
     iq = src if (world == 1 or rank == 0) else torch.empty_like(src)
     ch = q.Channelizer(ctx, M, batch=B, max_chunk=n, channel_first=rank * per, channel_count=per)
     ch.enable_4fsk()
+    if args.legacy_pfb:
+        ch.set_option(q.CHAN_OPT_LEGACY_PFB, 1)
     iq_f = torch.view_as_real(iq)
 
     def step():
@@ -305,6 +309,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="only the timed workload: no stand-alone pass, parity check, C2 line, CPU baseline")
     ap.add_argument("--overlap", action="store_true", help="C1 only: QRL_OPT_OVERLAP = 1 (decimated-rate kernels of call k under the front end of call k + 1)")
     ap.add_argument("--no-overlap", action="store_true", help="(default behaviour; kept for the tools/ scripts)")
+    ap.add_argument("--check", action="store_true", help="with --no-extra: still run the parity check against the oracle at the bench shape")
+    ap.add_argument("--ldsdma-frontend", action="store_true", help="A/B: QRL_OPT_LEGACY_FRONTEND = 0 (phase-lane front end fed by LDS-DMA rings, k_decim_pl2)")
+    ap.add_argument("--legacy-pfb", action="store_true", help="A/B, c4: QRL_CHAN_OPT_LEGACY_PFB = 1 (general-M channelizer kernel)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -339,7 +346,7 @@ def main():
         finish((run_c4 if args.config == "c4" else run_c5)(args, torch, q, ctx, dev, rank, world))
         return
     extra_ok = not args.no_extra
-    main_r = run_workload(args.config, args, torch, q, ctx, dev, rank, world, overlap=args.overlap and args.config == "c1", check=extra_ok)
+    main_r = run_workload(args.config, args, torch, q, ctx, dev, rank, world, overlap=args.overlap and args.config == "c1", check=extra_ok or args.check)
     # C1 also has an opt-in overlapped mode (the FLL / discriminator kernels of call k share the GPU with the front end of call
     # k + 1): more whole-chain throughput, but the front-end kernel stretches.  Measured in a second short pass for the record.
     ovl = run_workload("c1", args, torch, q, ctx, dev, rank, world, overlap=True, steps=min(args.steps, 20)) \

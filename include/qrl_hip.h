@@ -111,7 +111,7 @@ int qrl_demod_set_dmo_output(qrl_demod* d, uint8_t* frames, size_t cap_frames, u
  * everything behind the first decimated ring of call k on a second stream under the front end of call k + 1; value 0 runs the
  * kernels of a call one after another. */
 enum { QRL_OPT_OVERLAP = 1,
-       QRL_OPT_LEGACY_FRONTEND = 2   /* 1: the phase-lane front ends fetch with VGPR loads (round-2 kernel k_decim_pl) instead of LDS-DMA (k_decim_pl2): A/B measurements and tests */
+       QRL_OPT_LEGACY_FRONTEND = 2   /* 1 (default): the phase-lane front ends fetch with VGPR loads (k_decim_pl); 0: through LDS-DMA rings (k_decim_pl2) -- same results, A/B measurements and tests */
 };
 int qrl_demod_set_option(qrl_demod* d, int option, int value);
 int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* filtered_cap, size_t* constellation_cap, size_t* bits_cap);

@@ -189,7 +189,8 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     h->hist_len = (h->xlat || h->xlat2) ? (uint32_t)(h->xl_nt + h->xl_D) : h->single ? (uint32_t)(h->rs_Jp + h->rs_D + 2) : (uint32_t)(h->J * M);
     const size_t S = (size_t)c.batch * c.channel_count;
     const size_t max1 = c.max_chunk / (h->xlat2 ? h->xl_D : M) + 2, max2 = max1 * h->rs_I / h->rs_D + 2;
-    h->m1 = (h->single || h->xlat) ? 63 : pow2ge(max1 + h->rs_Jp + 64) - 1;   // the single-carrier chain reads the caller's IQ directly
+    // (the fused per-channel kernel recomputes the halo of its first tile from the channel ring: chan_tail_lookback() items in front of a call)
+    h->m1 = (h->single || h->xlat) ? 63 : pow2ge(max1 + h->rs_Jp + 64 + chan_tail_lookback()) - 1;   // the single-carrier chain reads the caller's IQ directly
     h->m2 = pow2ge(max2 + h->filt_nt + 64 + 300) - 1;   // + one rssi_tag_block window
     if ((r = h->hist_a.alloc((size_t)c.batch * h->hist_len)) || (r = h->hist_b.alloc((size_t)c.batch * h->hist_len)) ||
         (r = h->r1.alloc(S * (h->m1 + 1))) || (r = h->r2.alloc(S * (h->m2 + 1))) || (r = h->r3.alloc(S * (h->m2 + 1))) ||
@@ -290,12 +291,15 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
         }
         if (ev1) { HIPCHK(hipEventRecord(ev1, h->stream)); h->prof_events.emplace_back(ev0, ev1); }
     }
+    // PFB form and form 2: the whole per-channel feed-forward chain in one kernel (kernels_chan_tail.hip)
+    const bool fused = !h->single && !h->xlat && !h->opt_legacy_tail &&
+                       chan_tail_supported(h->rs_I, h->rs_D, h->rs_Jp, h->filt_nt, h->fsk_bits ? h->symf_nt : 0);
     ResampParams rp{};
     if (h->xlat) {
     } else if (h->single) { rp.in = in; rp.in_stride = stride; rp.hist = hist_old; rp.hist_len = h->hist_len; rp.n0 = h->n_in; rp.n = (uint32_t)n; }
     else { rp.in = nullptr; rp.in_ring = RingC{h->r1.p, h->m1}; rp.n0 = h->n1; rp.n = (uint32_t)(n1_1 - h->n1); }
     rp.out = RingC{h->r2.p, h->m2}; rp.q0 = h->n2; rp.q_count = c2; rp.taps = h->rs_taps.p; rp.I = h->rs_I; rp.D = h->rs_D; rp.Jp = h->rs_Jp;
-    if (!h->xlat) launch_resamp(rp, S, h->stream);
+    if (!h->xlat && !fused) launch_resamp(rp, S, h->stream);
     auto rssi = [&](float2* ring) {   // rssi_tag_block: after the filter in multi2 (:126-127), after the resampler in gr_demod_mmdvm (:53-54)
         if (!h->rssi_out) return;
         RssiParams r{}; r.in = RingC{ring, h->m2}; r.j0 = h->n2 / 300; r.count = (uint32_t)(n2_1 / 300 - h->n2 / 300);
@@ -303,29 +307,45 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
         launch_rssi_tag(r, S, h->stream);
     };
     if (h->single) rssi(h->r2.p);
-    FirCcfParams fp{};
-    fp.in = RingC{h->r2.p, h->m2}; fp.out = RingC{h->r3.p, h->m2}; fp.q0 = h->n2; fp.count = c2; fp.taps = h->filt_taps.p; fp.nt = h->filt_nt;
-    launch_fir_ccf(fp, S, h->stream);
-    if (!h->single) rssi(h->r3.p);
-    QuadDemodParams qp{};
-    qp.in = RingC{h->r3.p, h->m2}; qp.out = RingF{h->r4.p, h->m2}; qp.q0 = h->n2; qp.count = c2; qp.gain = h->gain; qp.atan_tab = h->atan_tab.p;
-    if (h->fsk_bits) {   // the 4FSK tail's discriminator (gr_demod_dmr.cpp:72-76: 24000 / (pi/2 * 4800)) reads the same items: one pass for both
-        qp.out2 = RingF{h->r5.p, h->m2};
-        qp.gain2 = (float)(24000 / (M_PI / 2 * (float)(24000 / 5)));
+    if (fused) {
+        ChanTailParams tp{};
+        tp.in = RingC{h->r1.p, h->m1}; tp.q0 = h->n2; tp.count = c2;
+        tp.rs_taps = h->rs_taps.p; tp.filt_taps = h->filt_taps.p; tp.rrc_taps = h->symf_taps.p; tp.atan_tab = h->atan_tab.p;
+        tp.gain = h->gain; tp.gain2 = (float)(24000 / (M_PI / 2 * (float)(24000 / 5))); tp.level = h->level; tp.scale = 32767.0f;
+        tp.s16 = out; tp.s16_cap = out_cap; tp.s16_counts = counts;
+        if (h->fsk_bits) tp.out_sym = RingF{h->r6.p, h->m2};
+        if (h->rssi_out) { tp.rssi = h->rssi_out; tp.rssi_cap = h->rssi_cap; tp.rssi_counts = h->rssi_counts; tp.rssi_cal = h->rssi_cal;
+                           tp.tag0 = h->n2 / 300; tp.ntags = (uint32_t)(n2_1 / 300 - h->n2 / 300); }
+        launch_chan_tail(tp, S, h->stream);
+    } else {
+        FirCcfParams fp{};
+        fp.in = RingC{h->r2.p, h->m2}; fp.out = RingC{h->r3.p, h->m2}; fp.q0 = h->n2; fp.count = c2; fp.taps = h->filt_taps.p; fp.nt = h->filt_nt;
+        launch_fir_ccf(fp, S, h->stream);
+        if (!h->single) rssi(h->r3.p);
+        QuadDemodParams qp{};
+        qp.in = RingC{h->r3.p, h->m2}; qp.out = RingF{h->r4.p, h->m2}; qp.q0 = h->n2; qp.count = c2; qp.gain = h->gain; qp.atan_tab = h->atan_tab.p;
+        if (h->fsk_bits) {   // the 4FSK tail's discriminator (gr_demod_dmr.cpp:72-76: 24000 / (pi/2 * 4800)) reads the same items: one pass for both
+            qp.out2 = RingF{h->r5.p, h->m2};
+            qp.gain2 = (float)(24000 / (M_PI / 2 * (float)(24000 / 5)));
+        }
+        if (out) { qp.s16 = out; qp.s16_cap = out_cap; qp.s16_level = h->level; qp.s16_scale = 32767.0f; qp.s16_counts = counts; }   // _level + float_to_short in the same pass
+        launch_quad_demod(qp, S, h->stream);
+        if (h->fsk_bits) {   // gr_demod_dmr.cpp:72-76 behind the channel filter: discriminator (24000 / (pi/2 * 4800), fused above) -> RRC
+            FirFffParams f6{}; f6.in = RingF{h->r5.p, h->m2}; f6.out = RingF{h->r6.p, h->m2}; f6.q0 = h->n2; f6.count = c2; f6.taps = h->symf_taps.p; f6.nt = h->symf_nt;
+            launch_fir_fff(f6, S, h->stream);
+        }
     }
-    if (out) { qp.s16 = out; qp.s16_cap = out_cap; qp.s16_level = h->level; qp.s16_scale = 32767.0f; qp.s16_counts = counts; }   // _level + float_to_short in the same pass
-    launch_quad_demod(qp, S, h->stream);
-    if (h->fsk_bits) {   // gr_demod_dmr.cpp:72-105 behind the channel filter: discriminator (24000 / (pi/2 * 4800)) -> RRC -> symbol_sync_ff -> dibits
-        HIPCHK(hipMemsetAsync(h->fsk_counts, 0, (size_t)S * 4 * sizeof(uint32_t), h->stream));
-        FirFffParams f6{}; f6.in = RingF{h->r5.p, h->m2}; f6.out = RingF{h->r6.p, h->m2}; f6.q0 = h->n2; f6.count = c2; f6.taps = h->symf_taps.p; f6.nt = h->symf_nt;
-        launch_fir_fff(f6, S, h->stream);
-        SymSyncParams s{};
-        s.in = f6.out; s.avail = n2_1; s.soft = RingB{h->soft_dummy.p, 63}; s.st = h->ss.p; s.mmse = h->mmse.p;
-        s.alpha = h->ss_alpha; s.beta = h->ss_beta; s.maxp = 5.0f + 0.06f; s.minp = 5.0f - 0.06f;
-        s.ted = 0; s.soft_mul = 128.0f; s.soft_add = 128.0f; s.slicer = 1; s.tail = 1; s.tail_scale = 0.9f;   // gr_demod_dmr.cpp:73 _level_control
-        s.bits = h->fsk_bits; s.bits_cap = h->fsk_bits_cap;
-        s.port = reinterpret_cast<float2*>(h->fsk_const); s.port_cap = h->fsk_const ? h->fsk_const_cap : 0; s.counts = h->fsk_counts;
-        launch_symsync_ff(s, S, h->stream);
+    {
+        if (h->fsk_bits) {   // gr_demod_dmr.cpp:70-105: symbol_sync_ff -> level -> phase modulator -> slicer -> dibits, on the RRC output ring
+            HIPCHK(hipMemsetAsync(h->fsk_counts, 0, (size_t)S * 4 * sizeof(uint32_t), h->stream));
+            SymSyncParams s{};
+            s.in = RingF{h->r6.p, h->m2}; s.avail = n2_1; s.soft = RingB{h->soft_dummy.p, 63}; s.st = h->ss.p; s.mmse = h->mmse.p;
+            s.alpha = h->ss_alpha; s.beta = h->ss_beta; s.maxp = 5.0f + 0.06f; s.minp = 5.0f - 0.06f;
+            s.ted = 0; s.soft_mul = 128.0f; s.soft_add = 128.0f; s.slicer = 1; s.tail = 1; s.tail_scale = 0.9f;   // gr_demod_dmr.cpp:73 _level_control
+            s.bits = h->fsk_bits; s.bits_cap = h->fsk_bits_cap;
+            s.port = reinterpret_cast<float2*>(h->fsk_const); s.port_cap = h->fsk_const ? h->fsk_const_cap : 0; s.counts = h->fsk_counts;
+            launch_symsync_ff(s, S, h->stream);
+        }
     }
     HIPCHK(hipGetLastError());
     if (qrl::take_launch_error()) return QRL_ERR_HIP;

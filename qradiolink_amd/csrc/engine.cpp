@@ -222,7 +222,9 @@ struct qrl_demod {
     int analog_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* out, uint32_t* counts, bool side);
     uint64_t n_in = 0, n1 = 0, n2 = 0;  // items so far: device rate, 1 Msps, target rate
     bool profiling = false;
-    bool legacy_fe = false;   // QRL_OPT_LEGACY_FRONTEND: phase-lane front ends with VGPR loads (k_decim_pl) instead of LDS-DMA (k_decim_pl2)
+    // QRL_OPT_LEGACY_FRONTEND (default 1): phase-lane front ends with VGPR loads (k_decim_pl); 0 = the LDS-DMA variant k_decim_pl2.  Measured
+    // (profiles/r03_*): pl2 6.97 - 7.06 ms against 6.86 ms on C1 -- both are VALU bound (39 VALU per 50-sample block), the fetch path is not the limiter
+    bool legacy_fe = true;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
 
     ~qrl_demod() {

@@ -209,6 +209,23 @@ struct ChanParams {
 struct F2sParams { RingF in; uint64_t q0; uint32_t count; float level, scale; int16_t* out; size_t cap; uint32_t* counts; };
 struct RssiParams { RingC in; uint64_t j0; uint32_t count; float calibration; float* out; size_t cap; uint32_t* counts; };
 void launch_rssi_tag(const RssiParams& p, int batch, hipStream_t s);
+// the per-channel chain of gr_demod_mmdvm_multi2 behind the channelizer as one kernel (kernels_chan_tail.hip): 24/25 resampler,
+// channel filter, RSSI tags, FM discriminator -> int16, and the symbol demodulator's discriminator + RRC into the symbol-sync ring
+struct ChanTailParams {
+    RingC in;                               // channel ring at 25 ksps, one row per (stream, channel)
+    uint64_t q0; uint32_t count;            // outputs of this call at 24 ksps: [q0, q0 + count)
+    const float* rs_taps;                   // [24][35]: taps[ph * 35 + j] = h[ph + 24 j], zero padded
+    const float* filt_taps;                 // 33
+    const float* rrc_taps;                  // 125 (unused when out_sym.p == nullptr)
+    const float* atan_tab;                  // 257
+    float gain, gain2, level, scale;
+    int16_t* s16; size_t s16_cap; uint32_t* s16_counts;
+    RingF out_sym;                          // RRC output (symbol sync input); p == nullptr: no symbol tail
+    float* rssi; size_t rssi_cap; uint32_t* rssi_counts; float rssi_cal; uint64_t tag0; uint32_t ntags;
+};
+void launch_chan_tail(const ChanTailParams& p, int streams, hipStream_t s);
+bool chan_tail_supported(int rs_I, int rs_D, int rs_Jp, int filt_nt, int rrc_nt);
+uint32_t chan_tail_lookback();
 void launch_pfb_chan(const ChanParams& p, int batch, hipStream_t s);
 void launch_f2s(const F2sParams& p, int batch, hipStream_t s);
 size_t chan_lds_bytes(int M, int J);

@@ -1,0 +1,202 @@
+// kernels_chan_tail.hip — the per-channel chain of the multi-carrier MMDVM receiver as ONE kernel (gfx950 / CDNA4).
+//
+// Reference (src/gr/gr_demod_mmdvm_multi2.cpp:60-63,75-92,106-131), per 25 ksps channel behind the channelizer:
+//   rational_resampler_ccf(24, 25, low_pass_2(1, 600k, 5k, 2k, 60, BH))  ->  fft_filter_ccf(low_pass_2(1, 24k, 5k, 2k, 60, BH))
+//   -> rssi_tag_block -> quadrature_demod_cf(24000 / (2 pi 12500)) -> multiply_const_ff(level) -> float_to_short(1, 32767)
+// and, for BASELINE config 4, the symbol demodulator's feed-forward part behind the same channel filter
+// (src/gr/gr_demod_dmr.cpp:62-76): quadrature_demod_cf(24000 / (pi/2 4800)) -> fft_filter_fff(RRC(1, 24k, 4.8k, 0.2, 125)).
+//
+// Round 2 ran this as k_resamp, k_fir_ccf_tiled, k_rssi_tag, k_quad_demod, k_fir_fff_tiled: 4.4 ms per call of 134 M wideband samples,
+// every stage through HBM-sized rings, one LDS read of a tap and one of a sample per FMA pair.  Here a workgroup owns one channel
+// and a tile of 1200 outputs at 24 ksps (tiles on an ABSOLUTE grid, = 4 RSSI blocks of 300):
+//   stage the 25 ksps input span once -> A resampler -> B channel filter -> D discriminators (+ int16) -> E RRC, all in LDS, the
+//   serial 300-sample RSSI sums (C) on otherwise idle lanes beside E.  Halos (171 outputs in front of the tile) are recomputed
+//   from the channel ring instead of being read back from intermediate rings: every intermediate value is a pure function of the
+//   ring, so the recomputed ones are the bits the previous tile / call produced.
+// Register blocking: a thread computes 8 CONSECUTIVE outputs of a filter over a sliding register window -- one LDS read of a sample
+// per 8 FMA pairs -- and the taps are wave-uniform LDS broadcast reads out of step-major tables (step s = 7 - d, d = r - k: the 8 taps
+// h[r - d], r = 0..7, of a step are 32 contiguous bytes, zero where r - d falls outside the filter: a zero tap leaves the chain
+// untouched, fmaf(0, x, acc) = acc).  The step loops are rolled (unroll 4): fully unrolled, the compiler hoists every tap read
+// to the top of the stage (256 VGPRs or 500 scratch reloads); as scalar loads the 280 resampler taps of a wave overflow the SGPR file.  The LDS images are de-interleaved by 8 (item i at
+// (i & 7) W + (i >> 3), W = 4 mod 32) so that "thread g reads item 8 g + d" is lane-contiguous and "thread t reads item t" still
+// spreads over all banks.  The resampler (24 phases) maps lane = group of 24 outputs, wave = which 8 of them: the phase of an output
+// is then wave-uniform and c(q) = floor(25 q / 24) has no carry inside the 8 (x index 25 u + 8 w + r - j, lane stride 25 samples:
+// conflict free for ds_read_b64).
+// Every chain is the oracle's: one fmaf chain per output, tap index ascending, first term fmaf(h, x, +0) (orc_resamp_ccf,
+// orc_fir_ccf, orc_fir_fff); discriminator, quantiser and RSSI sums as in k_quad_demod / k_rssi_tag.
+#include "devmath.hpp"
+#include "engine.hpp"
+
+namespace qrl {
+
+constexpr int CT_T = 1200;          // outputs per tile (absolute grid)
+constexpr int CT_JP = 35;           // taps per phase of the 24/25 resampler (819 taps)
+constexpr int CT_NF = 33;           // channel filter
+constexpr int CT_NR = 125;          // RRC
+constexpr int CT_HA = 171;          // outputs in front of the tile the resampler produces (>= 132 + 7 + 32)
+constexpr int CT_HB = 132;          // ... the channel filter / discriminator produce (>= 124 + 7 + 1)
+constexpr int CT_W = 180;           // row pitch of the de-interleaved images: >= 24 * 59 / 8, and (l & 7) W + (l >> 3), l < 32, hits 32 different bank pairs (W = 4 x odd)
+constexpr int CT_NX = 25 * 59 + 34 + 2;   // input samples staged per tile
+constexpr int CT_SA = CT_JP + 7, CT_SB = CT_NF + 7, CT_SE = CT_NR + 7;   // window steps of the 8-output sliding filters (d = 7 .. -(nt - 1))
+
+__device__ __forceinline__ int ct_pos(int i) { return (i & 7) * CT_W + (i >> 3); }
+__device__ __forceinline__ int64_t ct_floordiv(int64_t a, int64_t b) { const int64_t q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
+
+__global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
+{
+    __shared__ __align__(16) float2 xf[CT_NX > 8 * CT_W ? CT_NX : 8 * CT_W];   // staged input x (stage A), then the channel filter output f (B .. E)
+    __shared__ __align__(16) float2 av[8 * CT_W];        // resampler output a
+    __shared__ __align__(16) float dv[8 * CT_W];         // symbol discriminator output d2
+    __shared__ float T[257];
+    __shared__ __align__(16) float tA[3 * CT_SA * 8], tB[CT_SB * 8], tE[CT_SE * 8];   // [step][r] tap tables
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = blockIdx.y;
+    const int64_t tile = (int64_t)(P.q0 / CT_T) + blockIdx.x;
+    const int64_t Q0 = tile * CT_T;
+    const int64_t ua = ct_floordiv(Q0 - CT_HA, 24), qa = ua * 24;                 // first resampler output of the tile (multiple of 24)
+    const int NU = (int)((Q0 + CT_T - qa + 23) / 24);                             // groups of 24 outputs: <= 59
+    const int64_t qb = qa + ((Q0 - CT_HB - qa) / 8) * 8;                          // first filter output (multiple of 8 behind qa)
+    const int ib0 = (int)(qb - qa);                                               // >= 32
+    const int NB = (int)(Q0 + CT_T - qb);                                         // filter outputs: 1332 .. 1339
+    const int e0 = (int)(Q0 - qb);                                                // tile start relative to qb: 132 .. 139
+    for (int k = tid; k < 257; k += 256) T[k] = P.atan_tab[k];
+    for (int k = tid; k < 3 * CT_SA * 8; k += 256) {   // tA[(w SA + s) 8 + r] = taps[(8 w + r) 35 + (r - d)], d = 7 - s
+        const int r = k & 7, st = (k >> 3) % CT_SA, w = (k >> 3) / CT_SA, j = r - (7 - st);
+        tA[k] = (j >= 0 && j < CT_JP) ? P.rs_taps[(8 * w + r) * CT_JP + j] : 0.0f;
+    }
+    for (int k = tid; k < CT_SB * 8; k += 256) { const int j = (k & 7) - (7 - (k >> 3)); tB[k] = (j >= 0 && j < CT_NF) ? P.filt_taps[j] : 0.0f; }
+    if (P.out_sym.p)
+        for (int k = tid; k < CT_SE * 8; k += 256) { const int j = (k & 7) - (7 - (k >> 3)); tE[k] = (j >= 0 && j < CT_NR) ? P.rrc_taps[j] : 0.0f; }
+    // ---- stage the input: x[xbase + i], xbase = 25 ua - 34 (zero in front of the stream)
+    const int64_t xbase = 25 * ua - (CT_JP - 1);
+    const int nx = 25 * NU + (CT_JP - 1);
+    {
+        const float2* ring = P.in.p + (size_t)row * (P.in.mask + 1u);
+        for (int i = tid; i < nx; i += 256) {
+            const int64_t a = xbase + i;
+            xf[i] = a < 0 ? make_float2(0.f, 0.f) : ring[(uint32_t)a & P.in.mask];
+        }
+    }
+    __syncthreads();
+    // ---- A: a[24 u + 8 w + r] = sum_j taps[(8 w + r) 35 + j] x[25 u + 8 w + r - j],  lane = u - ua, waves 0..2
+    if (wv < 3 && lane < NU) {
+        const float4* tp = reinterpret_cast<const float4*>(tA + wv * (CT_SA * 8));
+        const float2* xb = xf + 25 * lane + 8 * wv + (CT_JP - 1) + 7;            // x[25 u + 8 w + d] = xb[d - 7] = xb[-s]
+        float ar[8], ai[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ar[r] = ai[r] = 0.f;
+#pragma unroll 4
+        for (int st = 0; st < CT_SA; ++st) {
+            const float2 x = xb[-st];
+            const float4 h0 = tp[2 * st], h1 = tp[2 * st + 1];
+            const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { ar[r] = fmaf(h[r], x.x, ar[r]); ai[r] = fmaf(h[r], x.y, ai[r]); }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) av[r * CT_W + 3 * lane + wv] = make_float2(ar[r], ai[r]);   // item i = 24 lane + 8 w + r
+    }
+    __syncthreads();
+    // ---- B: f[q] = sum_k ft[k] a[q - k], thread g: q = qb + 8 g + r (items of a: ib0 + 8 g + r - k)
+    if (tid < (NB + 7) / 8) {
+        const float4* tp = reinterpret_cast<const float4*>(tB);
+        const float2* ab = av + (ib0 >> 3) + tid;                                  // item ib0 + 8 g + d at ab[(d & 7) W + (d >> 3)]
+        float ar[8], ai[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ar[r] = ai[r] = 0.f;
+#pragma unroll 4
+        for (int st = 0; st < CT_SB; ++st) {
+            const int d = 7 - st;                                                  // wave uniform
+            const float2 x = ab[(d & 7) * CT_W + (d >> 3)];
+            const float4 h0 = tp[2 * st], h1 = tp[2 * st + 1];
+            const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { ar[r] = fmaf(h[r], x.x, ar[r]); ai[r] = fmaf(h[r], x.y, ai[r]); }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xf[r * CT_W + tid] = make_float2(ar[r], ai[r]);   // f item i' = 8 g + r (relative to qb)
+    }
+    __syncthreads();
+    // ---- D: discriminators on f, items i' = 1 .. NB - 1 (q = qb + i'); int16 port for the outputs of this call
+    const uint64_t q_end = P.q0 + P.count;
+    for (int i = 1 + tid; i < NB; i += 256) {
+        const float2 a = xf[ct_pos(i)], p = xf[ct_pos(i - 1)];
+        const float re = a.x * p.x + a.y * p.y;
+        const float im = a.y * p.x - a.x * p.y;
+        const float ang = fast_atan2f_lut(im, re, T);
+        dv[ct_pos(i)] = P.gain2 * ang;
+        const int64_t q = qb + i;
+        if (P.s16 && q >= (int64_t)P.q0 && (uint64_t)q < q_end && i >= e0) {
+            float r = rintf(((P.gain * ang) * P.level) * P.scale);
+            if (r > 32767.0f) r = 32767.0f;
+            if (r < -32768.0f) r = -32768.0f;
+            const uint64_t t = (uint64_t)q - P.q0;
+            if (t < P.s16_cap) P.s16[(size_t)row * P.s16_cap + t] = (int16_t)r;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        if (P.s16 && P.s16_counts) P.s16_counts[row] = P.count < P.s16_cap ? P.count : (uint32_t)P.s16_cap;
+        if (P.rssi && P.rssi_counts) P.rssi_counts[row] = P.ntags < P.rssi_cap ? P.ntags : (uint32_t)P.rssi_cap;
+    }
+    __syncthreads();
+    if (wv == 3) {
+        // ---- C: rssi_tag_block, the four 300-item blocks of this tile: serial float sums, one lane per block
+        if (lane < CT_T / 300 && P.rssi) {
+            const int64_t j = tile * (CT_T / 300) + lane;                          // absolute tag index
+            if (j >= (int64_t)P.tag0 && j < (int64_t)(P.tag0 + P.ntags)) {
+                const int i0 = e0 + 300 * lane;
+                float sum = 0.0f;
+                for (int k = 0; k < 300; ++k) {
+                    const float2 x = xf[ct_pos(i0 + k)];
+                    const float pwr = x.x * x.x + x.y * x.y;
+                    sum += pwr * pwr;
+                }
+                const float level = sqrtf(sum / 300.0f);
+                const float db = 10.0f * log10f(level + 1.0e-20f) + P.rssi_cal;
+                const uint64_t t = (uint64_t)j - P.tag0;
+                if (t < P.rssi_cap) P.rssi[(size_t)row * P.rssi_cap + t] = db;
+            }
+        }
+        return;
+    }
+    // ---- E: r[q] = sum_k rrc[k] d2[q - k], thread g (waves 0..2): items i' = e8 + 8 g + r, e8 = e0 rounded down to 8
+    if (!P.out_sym.p) return;
+    const int e8 = e0 & ~7;
+    if (tid < (NB - e8 + 7) / 8) {
+        const float4* tp = reinterpret_cast<const float4*>(tE);
+        const float* db_ = dv + (e8 >> 3) + tid;
+        float acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+#pragma unroll 4
+        for (int st = 0; st < CT_SE; ++st) {
+            const int d = 7 - st;                                                  // wave uniform
+            const float x = db_[(d & 7) * CT_W + (d >> 3)];
+            const float4 h0 = tp[2 * st], h1 = tp[2 * st + 1];
+            const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = fmaf(h[r], x, acc[r]);
+        }
+        float* orow = P.out_sym.p + (size_t)row * (P.out_sym.mask + 1u);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int64_t q = qb + e8 + 8 * tid + r;
+            if (q >= (int64_t)P.q0 && (uint64_t)q < q_end && q >= Q0) orow[(uint32_t)q & P.out_sym.mask] = acc[r];
+        }
+    }
+}
+
+void launch_chan_tail(const ChanTailParams& p, int streams, hipStream_t s)
+{
+    if (!p.count) return;
+    const uint64_t t_first = p.q0 / CT_T, t_last = (p.q0 + p.count - 1) / CT_T;
+    hipLaunchKernelGGL(k_chan_tail, dim3((uint32_t)(t_last - t_first + 1), streams), dim3(256), 0, s, p);
+}
+bool chan_tail_supported(int rs_I, int rs_D, int rs_Jp, int filt_nt, int rrc_nt)
+{
+    return rs_I == 24 && rs_D == 25 && rs_Jp == CT_JP && filt_nt == CT_NF && (rrc_nt == 0 || rrc_nt == CT_NR);
+}
+uint32_t chan_tail_lookback() { return (uint32_t)((CT_T + CT_HA + 24) * 25 / 24 + CT_JP + 64); }   // channel-ring items in front of a call the tiles may re-read
+
+}  // namespace qrl

@@ -228,34 +228,50 @@ void k_decim_pl(const DecimParams P_)
 //   * lane l reads its sample of block t with one ds_read_b64 at (o0 + 400 t + 8 l) mod 8192: lane-contiguous, conflict free.
 // Everything behind the sample fetch -- rotator, tap scatter, accumulator ring, transposing reduction -- is k_decim_pl's: the "pl"
 // summation contract is untouched, results are bit-identical.
-constexpr int PL2_RP = 8;          // ring pieces (1 KiB each) per wave
-constexpr int PL2_PD = 4;          // pieces in flight behind the last needed one
-constexpr int PL2_G = 4;           // blocks per DMA top-up / wait group (divides PL_RING)
+#ifndef QRL_PL2_PD
+#define QRL_PL2_PD 6
+#endif
+#ifndef QRL_PL2_G
+#define QRL_PL2_G 2
+#endif
+#ifndef QRL_PL2_RP
+#define QRL_PL2_RP 8
+#endif
+constexpr int PL2_RP = QRL_PL2_RP;     // ring pieces (1 KiB each) per wave (power of two): the ring is aligned to its size in LDS
+constexpr int PL2_PD = QRL_PL2_PD;     // pieces in flight behind the last needed one
+constexpr int PL2_G = QRL_PL2_G;       // blocks per DMA top-up / wait group (divides PL_RING)
+// a group of G blocks of <= 512 bytes spans at most ceil((1023 + 512 G) / 1024) pieces; the ring holds them + the PD pieces in flight
+static_assert((PL2_RP & (PL2_RP - 1)) == 0 && PL_RING % PL2_G == 0 && PL2_PD + (1023 + 512 * PL2_G + 1023) / 1024 <= PL2_RP, "ring too small for the group / depth");
 
 __device__ __forceinline__ void pl2_glds16(const void* gsrc, uint32_t lds_dst)
 {
     // one LDS-DMA piece, non-temporal: 64 lanes x 16 B from per-lane global addresses to LDS[lds_dst + 16 lane].  M0 (compiler
-    // reserved) is saved and restored inside the statement (cdna_hip_programming.md 5.x "LDS-DMA recipe")
+    // reserved) is saved and restored inside the statement (cdna_hip_programming.md, "LDS-DMA recipe")
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+typedef const __attribute__((address_space(3))) v2f* pl2_lds_f2;
+__device__ __forceinline__ float2 pl2_lds(uint32_t addr)   // ds_read_b64 from a raw LDS byte address
+{
+    const v2f v = *(pl2_lds_f2)(uintptr_t)addr;
+    return make_float2(v.x, v.y);
+}
+
+__device__ __forceinline__ uint32_t pl2_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
 
 template <int J>
 __global__ __launch_bounds__(256)
 void k_decim_pl2(const DecimParams P_)
 {
     const DecimParams& P = P_;
-    // rings first (ring of wave w at byte w * 8192: the LDS address of a sample is (x & 8191) | (w << 13)), tables behind
-    __shared__ __align__(1024) unsigned char ring_all[4 * PL2_RP * 1024];
-    __shared__ float2 t_lo[512];
-    __shared__ float2 t_hi_all[4][64];
-    __shared__ float2 t_one[1];
+    __shared__ __align__(PL2_RP * 1024) unsigned char ring_all[4 * PL2_RP * 1024];   // ring of wave w at LDS byte w * ring size (+ a multiple of it)
+    __shared__ float2 t_lo[512];            // fine rotator table; entry 0 is exactly (1, 0): what edge units read through index mask 0
+    __shared__ float2 t_hi_all[4][64];      // coarse rotator table of each wave's segment
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     t_lo[tid] = P.rot_lo[tid];
     t_lo[tid + 256] = P.rot_lo[tid + 256];
-    if (tid == 0) t_one[0] = make_float2(1.f, 0.f);
 
     const uint32_t unit = blockIdx.x * 4u + (uint32_t)wave;
     const uint32_t B = P.pl_batch;
@@ -272,11 +288,7 @@ void k_decim_pl2(const DecimParams P_)
     const int64_t i_first_s = (c_first_s - 1) * (int64_t)D + 1;
     const uint64_t i_first = (uint64_t)i_first_s;
     const uint32_t kb0 = edge ? 0u : (uint32_t)((i_first - P.rot_nbase) >> 9);
-    float2* t_hi = t_hi_all[wave];
-    if (active) t_hi[lane] = edge ? make_float2(1.f, 0.f) : sincos_turn(P.rot_acc + ((uint64_t)(kb0 + (uint32_t)lane) << 9) * P.rot_inc);
-    // edge units read identity phasors: the fine table collapses to its one-entry stand-in (index mask 0)
-    const float2* tl = edge ? t_one : t_lo;
-    const uint32_t tl_mask = edge ? 0u : 4095u;
+    if (active) t_hi_all[wave][lane] = edge ? make_float2(1.f, 0.f) : sincos_turn(P.rot_acc + ((uint64_t)(kb0 + (uint32_t)lane) << 9) * P.rot_inc);
     __syncthreads();
     if (!active) return;
 
@@ -290,24 +302,31 @@ void k_decim_pl2(const DecimParams P_)
     const uint64_t off0 = edge ? 0ull : (uint64_t)(i_first - P.n0) * 8ull;
     const uint64_t row_bytes = edge ? (uint64_t)P.pl_edge_stride * 8ull : (uint64_t)P.n * 8ull;   // multiples of 16 (even sample counts)
     const uint32_t o0 = (uint32_t)(off0 & 127u);                     // offset of block 0 inside piece 0
-    const unsigned char* a0 = rowp + (off0 - o0);
-    const unsigned char* last16 = rowp + row_bytes - 16;             // lanes past the end of the row re-read its last 16 bytes (never consumed)
-    const uint32_t bytes_per_blk = (uint32_t)D * 8u;
-    const uint32_t npieces = (o0 + (uint32_t)nblk * bytes_per_blk + 1023u) >> 10;
-    const uint32_t rbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)ring_all + (uint32_t)wave * (PL2_RP * 1024);
-    const unsigned char* ring = ring_all + wave * (PL2_RP * 1024);
+    const uint64_t a_off = off0 - o0;                                // piece 0 starts here (128-byte aligned relative to the row)
+    const uint32_t bpb = (uint32_t)D * 8u;                           // bytes per block
+    const uint32_t npieces = (o0 + (uint32_t)nblk * bpb + 1023u) >> 10;
+    // pieces [0, q_safe) lie inside the row; the lanes of later pieces are clamped to the row's last 16 bytes (never consumed)
+    const uint32_t q_safe = (uint32_t)((row_bytes - a_off) >> 10);
+    const uint32_t rbase = pl2_lds_addr(ring_all) + (uint32_t)wave * (PL2_RP * 1024u);   // multiple of the ring size
+    const uint32_t tlo_base = pl2_lds_addr(t_lo);
+    const uint32_t thi_base = pl2_lds_addr(t_hi_all) + (uint32_t)wave * 512u;
+    const unsigned char* gp = rowp + a_off + (size_t)lane * 16;      // this lane's 16 bytes of the next piece
+    const unsigned char* last16 = rowp + row_bytes - 16;
     uint32_t issued = 0;
     auto issue_upto = [&](uint32_t want) {                           // wave uniform
         while (issued < want) {
-            const unsigned char* g = a0 + (size_t)issued * 1024 + (size_t)lane * 16;
-            g = g < last16 ? g : last16;
-            pl2_glds16(g, rbase + (issued & (PL2_RP - 1)) * 1024u);
+            const uint32_t dst = rbase + (issued & (PL2_RP - 1)) * 1024u;
+            if (issued < q_safe) pl2_glds16(gp, dst);
+            else pl2_glds16(gp < last16 ? gp : last16, dst);
+            gp += 1024;
             ++issued;
         }
     };
     const uint32_t k0 = edge ? 0u : (uint32_t)(i_first - P.rot_nbase) - (kb0 << 9);   // < 512
     const uint32_t lo8 = (uint32_t)lo * 8u;
-    const uint32_t lane_off = o0 + lo8;
+    const uint32_t tl_mask = edge ? 0u : 4095u;
+    uint32_t xa = rbase | ((o0 + lo8) & (PL2_RP * 1024u - 1u));     // LDS address of this lane's sample of the current block
+    uint32_t kb8 = k0 * 8u + lo8;                                    // 8 x (NCO index of that sample, relative to the coarse table)
     const bool hi8 = lane & 8, hi4 = lane & 4;
     const bool leader = (lane & 3) == 0;
     const int oidx = pl_out_index(lane);
@@ -318,15 +337,19 @@ void k_decim_pl2(const DecimParams P_)
     for (int s = 0; s < PL_RING; ++s) ar[s] = ai[s] = 0.f;
 
     const int nsup = (nblk + PL_RING - 1) / PL_RING;
+    uint32_t need_bytes = o0 + 1023u;                                // (bytes up to the end of the current group) + 1023
     for (int sup = 0; sup < nsup; ++sup) {
         float dr[PL_RING], di[PL_RING];
 #pragma unroll
         for (int grp = 0; grp < PL_RING / PL2_G; ++grp) {
             {   // pieces that cover the blocks of this group (clamped to the segment), + PL2_PD in flight behind them
-                const uint32_t t_end = (uint32_t)(sup * PL_RING + (grp + 1) * PL2_G);
-                uint32_t need = (o0 + t_end * bytes_per_blk + 1023u) >> 10;
+                need_bytes += (uint32_t)PL2_G * bpb;
+                uint32_t need = need_bytes >> 10;
                 need = need < npieces ? need : npieces;
                 const uint32_t want = need + PL2_PD < npieces ? need + PL2_PD : npieces;   // never past the segment's last piece
+                // the slots refilled now were last read a group ago: those ds_reads have been issued (program order, "memory"
+                // clobber) -- make sure they have also RETURNED before a DMA can overwrite them
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 issue_upto(want);
                 if (want - need == PL2_PD) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PL2_PD) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the last groups of a segment
@@ -334,13 +357,12 @@ void k_decim_pl2(const DecimParams P_)
 #pragma unroll
             for (int ii = 0; ii < PL2_G; ++ii) {
                 const int i = grp * PL2_G + ii;
-                const int t = sup * PL_RING + i;
-                const uint32_t xo = (lane_off + (uint32_t)t * bytes_per_blk) & (PL2_RP * 1024u - 1u);
-                const float2 xr = *reinterpret_cast<const float2*>(ring + xo);
+                const float2 xr = pl2_lds(xa);
                 // rotator: phasor of sample k = T_hi[k >> 9] (x) T_lo[k & 511], byte addressed
-                const uint32_t kb8 = (k0 + (uint32_t)t * (uint32_t)D) * 8u + lo8;
-                const float2 plo = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(tl) + (kb8 & tl_mask));
-                const float2 phi = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(t_hi) + ((kb8 >> 9) & ~7u));
+                const float2 plo = pl2_lds(tlo_base + (kb8 & tl_mask));
+                const float2 phi = pl2_lds(thi_base + ((kb8 >> 12) << 3));
+                xa = ((xa + bpb) & (PL2_RP * 1024u - 1u)) | rbase;
+                kb8 += bpb;
                 const float2 xs = cmul_fma(xr, cmul_fma(phi, plo));
 #pragma unroll
                 for (int j = 0; j < J - 1; ++j) {

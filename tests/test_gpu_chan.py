@@ -412,3 +412,65 @@ def test_literal_c4_freq_xlating_bank_64_channels_bit_exact(qrl_ctx, chunk):
             g = pfb[0][c].reshape(-1, 2)
             g = g[:, 0] * 2 + g[:, 1]
             assert max(np.mean(g[k:k + 400] == dw[:400]) for k in range(60)) > 0.99
+
+
+@pytest.mark.parametrize("chunk", [64 * 2500, 64 * 777])
+def test_channelizer_64_legacy_kernel_and_ragged_calls(qrl_ctx, chunk):
+    """M = 64 runs on k_pfb_chan64 (register-blocked branch FIRs) by default; QRL_CHAN_OPT_LEGACY_PFB = 1 keeps the general-M kernel
+    reachable for A/B runs.  Both must equal the oracle, also when the stream is cut into calls that are not a multiple of the
+    32-instant tile (history path + ragged last tile)."""
+    import torch
+    import qradiolink_amd as q
+    M, n = 64, 64 * 2500
+    iq = _wideband(M, n, seed=77, nstreams=2)
+    ref = [orc.demod_mmdvm_multi(iq[b], M) for b in range(2)]
+    for legacy in (0, 1):
+        ch = q.Channelizer(qrl_ctx, M, batch=2, max_chunk=chunk)
+        ch.set_option(q.CHAN_OPT_LEGACY_PFB, legacy)
+        d = torch.from_numpy(iq).cuda()
+        parts = []
+        for s in range(0, n, chunk):
+            out, cnt = ch.process(d[:, s:s + chunk].contiguous())
+            cnt, o = cnt.cpu().numpy(), out.cpu().numpy()
+            parts.append([[o[b, c, :cnt[b, c]].copy() for c in range(M)] for b in range(2)])
+        ch.close()
+        for b in range(2):
+            for c in range(M):
+                g = np.concatenate([p[b][c] for p in parts])
+                assert g.size == ref[b].shape[1] and np.array_equal(g, ref[b][c]), (legacy, b, c)
+
+
+@pytest.mark.parametrize("chunk", [10 * 6000, 10 * 1111])
+def test_legacy_per_channel_kernels_still_bit_exact(qrl_ctx, chunk):
+    """QRL_CHAN_OPT_LEGACY_TAIL = 1: the per-channel chain as the separate kernels of round 2 (k_resamp, k_fir_ccf, k_rssi_tag,
+    k_quad_demod, k_fir_fff) instead of the fused k_chan_tail -- int16, RSSI tags and dibits against the oracle"""
+    import torch
+    import qradiolink_amd as q
+    M, n = 10, 10 * 6000
+    iq = _wideband(M, n, seed=31, nstreams=2)
+    ch = q.Channelizer(qrl_ctx, M, batch=2, max_chunk=chunk)
+    ch.set_option(q.CHAN_OPT_LEGACY_TAIL, 1)
+    ch.calibrate_rssi(0.5)
+    ch.enable_4fsk()
+    d = torch.from_numpy(iq).cuda()
+    got = [[[] for _ in range(M)] for _ in range(2)]
+    tags = [[[] for _ in range(M)] for _ in range(2)]
+    dib = [[[] for _ in range(M)] for _ in range(2)]
+    for s in range(0, n, chunk):
+        out, cnt = ch.process(d[:, s:s + chunk].contiguous())
+        cnt, o = cnt.cpu().numpy(), out.cpu().numpy()
+        rc, r = ch.rssi_counts.cpu().numpy(), ch.rssi.cpu().numpy()
+        fc, bits = ch.fsk_counts.cpu().numpy(), ch.dibits.cpu().numpy()
+        for b in range(2):
+            for c in range(M):
+                got[b][c].append(o[b, c, :cnt[b, c]].copy())
+                tags[b][c].append(r[b, c, :rc[b, c]].copy())
+                dib[b][c].append(bits[b, c, :fc[b, c, 2]].copy())
+    ch.close()
+    for b in range(2):
+        ref, rref = orc.demod_mmdvm_multi_rssi(iq[b], M, cal=0.5)
+        _, dref = orc.demod_mmdvm_multi_4fsk(iq[b], M)
+        for c in range(M):
+            assert np.array_equal(np.concatenate(got[b][c]), ref[c]), (b, c)
+            assert np.allclose(np.concatenate(tags[b][c]), rref[c], rtol=0, atol=1e-4)
+            assert np.array_equal(np.concatenate(dib[b][c]), dref[c]), (b, c)
