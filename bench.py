@@ -179,11 +179,30 @@ def timed_loop(fn, sync, args, torch, dev, world):
     return dt
 
 
-def run_c4(args, torch, q, ctx, dev, rank, world):
+C4_BYTES = 8.0 + 64 * 24000 * 2 / 1.6e6 + 64 * 4800 * 2 / 1.6e6   # input cf32 + int16 FM samples + unpacked dibits, per wideband sample
+
+
+def roofline_obj(kernel, kms, launches, bytes_per_launch, bytes_per_sample, note=None):
+    ach = bytes_per_launch / (kms / max(launches, 1) * 1e-3) / 1e9 if kms > 0 else 0.0
+    d = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=None,
+             kernel=kernel, kernel_ms=round(kms / max(launches, 1), 4), launches=launches,
+             algorithmic_bytes_per_launch=bytes_per_launch, algorithmic_bytes_per_sample=bytes_per_sample)
+    if note:
+        d["note"] = note
+    return d
+
+
+def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True):
     """C4: multi-carrier MMDVM receiver, 64 x 25 kHz channels from 1.6 Msps wideband IQ (PFB channelizer + per-channel
     24/25 resampler, LPF, FM discriminator -> int16, RSSI tags and the 4FSK symbol tail).  Multi-GPU: the CHANNELS of the same
     wideband streams are sharded (rank r owns channels [r M/G, (r+1) M/G)); rank 0 holds the new wideband chunk of every step
-    and broadcasts it to the other ranks over RCCL (one ncclBroadcast per step), then every rank runs its shard."""
+    and broadcasts it to the other ranks over RCCL (one ncclBroadcast per step), then every rank runs its shard.
+    Also measured (single GPU): BASELINE configs[3] taken literally, form 2 = 64 frequency-translating FIRs 1:64 in front of the same
+    per-channel chain -- the compute-bound way of producing the channels the PFB produces."""
+    import copy
+    args = copy.copy(args)
+    if steps:
+        args.steps = steps
     M, B, n = 64, args.batch or 64, (args.nsamp or (1 << 21)) // 64 * 64
     if M % world:
         raise SystemExit("c4: the number of ranks must divide 64 channels")
@@ -202,17 +221,49 @@ def run_c4(args, torch, q, ctx, dev, rank, world):
         if world > 1:
             torch.distributed.broadcast(iq_f, src=0)   # RCCL over xGMI; enqueued on torch's stream, process_async waits for it
         ch.process_async(iq)
+    ch.profile(True)
     dt = timed_loop(step, ch.sync, args, torch, dev, world)
+    kms, launches, kname = ch.profile_read()
+    launches_timed = args.steps
+    kms = kms * launches_timed / max(launches, 1)          # (the warm-up calls were profiled too: same kernel, same shape)
+    ch.profile(False)
     ch.close()
-    return {"metric": "wideband IQ MSamples/sec through the C4 receiver", "value": round(B * n * args.steps / dt / 1e6, 1), "unit": "MS/s",
+    line = {"metric": "wideband IQ MSamples/sec through the C4 receiver", "value": round(B * n * args.steps / dt / 1e6, 1), "unit": "MS/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C4: 64 x 25 kHz MMDVM channels from 1.6 Msps IQ: PFB channelizer + FM int16 + RSSI + 4FSK tail",
                        "wideband_streams": B, "samples_per_stream_per_step": n, "channels_per_gpu": per,
-                       "parallelism": "channels sharded over ranks; wideband input broadcast from rank 0 over RCCL every step" if world > 1 else "single GPU"}}
+                       "parallelism": "channels sharded over ranks; wideband input broadcast from rank 0 over RCCL every step" if world > 1 else "single GPU"},
+            "roofline": roofline_obj(kname, kms, launches_timed, B * n * C4_BYTES, round(C4_BYTES, 3),
+                                     "k_pfb_chan64 reads the wideband input once and writes the 64 channel rings; whole chain: %.1f GB/s of algorithmic bytes"
+                                     % (B * n * C4_BYTES * args.steps / dt / 1e9))}
+    if world == 1 and with_form2:
+        # BASELINE configs[3] literally: 64 freq-xlating FIRs (2181 taps, 1:64) -- compute bound (34 MAC per input sample and channel)
+        B2, n2 = max(1, B // 8), n // 4
+        ch2 = q.Channelizer(ctx, M, batch=B2, max_chunk=n2, form=2)
+        ch2.enable_4fsk()
+        iq2 = src[:B2, :n2].contiguous()
+        a2 = copy.copy(args)
+        a2.steps, a2.warmup = max(2, args.steps // 5), 1
+        ch2.profile(True)
+        dt2 = timed_loop(lambda: ch2.process_async(iq2), ch2.sync, a2, torch, dev, world)
+        kms2, l2, kname2 = ch2.profile_read()
+        ch2.close()
+        flop = 2.0 * 2 * 2181 / 64 * 64            # real x complex MAC = 4 flop; taps / decimation MACs per channel, 64 channels
+        line["freq_xlating_form"] = {
+            "workload": "configs[3] literal: 64 x (rotator + rational_resampler_ccf(1, 64, 2181 taps)) + the same per-channel chain + 4FSK tail (form 2)",
+            "value": round(B2 * n2 * a2.steps / dt2 / 1e6, 1), "unit": "MS/s", "steps": a2.steps, "ms_per_step": round(dt2 / a2.steps * 1e3, 3),
+            "wideband_streams": B2, "samples_per_stream_per_step": n2,
+            "roofline": roofline_obj(kname2, kms2, l2, B2 * n2 * C4_BYTES, round(C4_BYTES, 3),
+                                     "compute bound: %.0f flop per wideband sample in the 64 decimators = %.1f TFLOP/s on the f32 matrix pipe (peak 157)"
+                                     % (flop, flop * B2 * n2 * l2 / (kms2 * 1e-3) / 1e12 if kms2 > 0 else 0.0))}
+    return line
 
 
-def run_c5(args, torch, q, ctx, dev, rank, world):
+C5_RX_BYTES = 8.0 + (500000 * 8 + 250000 * 8 + 250000) / 1e6   # C3's ports at 1 Msps: 14.25 B per RX sample; TX: 8 B written per sample
+
+
+def run_c5(args, torch, q, ctx, dev, rank, world, steps=None):
     """C5: full duplex -- QPSK-250k modulator and QPSK-250k demodulator handles on their own HIP streams, calls interleaved without
     synchronisation (BASELINE config 5; reference src/radiocontroller.cpp:2043-2078 runs the two top blocks concurrently)."""
     import sig
@@ -227,6 +278,10 @@ def run_c5(args, torch, q, ctx, dev, rank, world):
     g = torch.Generator(device=dev)
     g.manual_seed(11 + rank)
     data = torch.randint(0, 256, (B, nbytes), generator=g, device=dev, dtype=torch.uint8)
+    import copy
+    args = copy.copy(args)
+    if steps:
+        args.steps = steps
     dem = q.Demod(ctx, 26, batch=B, max_chunk=n)
     mod = q.Mod(ctx, 26, batch=B, max_bytes=nbytes)
     tx_out = torch.empty((B, nbytes * mod.spb), dtype=torch.complex64, device=dev)
@@ -239,7 +294,10 @@ def run_c5(args, torch, q, ctx, dev, rank, world):
         mod.sync()
         dem.sync()
     dt = timed_loop(both, sync, args, torch, dev, world)
+    dem.profile(True)
     dt_rx = timed_loop(lambda: dem.process_async(iq), sync, args, torch, dev, world)
+    kms, launches, kname = dem.profile_read()
+    dem.profile(False)
     dt_tx = timed_loop(lambda: mod.process_async(data, out=tx_out), sync, args, torch, dev, world)
     dem.close()
     mod.close()
@@ -249,7 +307,10 @@ def run_c5(args, torch, q, ctx, dev, rank, world):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C5: full duplex QPSK-250k TX + RX at 1 Msps on two HIP streams", "streams_per_gpu": B,
                        "samples_per_stream_per_step": n, "tx_msps_concurrent": round(tot / dt / 1e6, 1),
-                       "rx_alone_ms_per_step": round(dt_rx / args.steps * 1e3, 3), "tx_alone_ms_per_step": round(dt_tx / args.steps * 1e3, 3)}}
+                       "rx_alone_ms_per_step": round(dt_rx / args.steps * 1e3, 3), "tx_alone_ms_per_step": round(dt_tx / args.steps * 1e3, 3)},
+            "roofline": roofline_obj(kname, kms, launches, B * n * C5_RX_BYTES, C5_RX_BYTES,
+                                     "RX front end (1:2 decimator + RRC) timed in the RX-alone pass; duplex chain: %.1f GB/s of algorithmic bytes (RX %.2f + TX 8 B per sample); TX alone writes %.1f GB/s"
+                                     % (tot * (C5_RX_BYTES + 8.0) / dt / 1e9, C5_RX_BYTES, tot * 8.0 / dt_tx / 1e9))}
 
 
 def cpu_baseline(name, cores, budget_s=8.0):
@@ -352,6 +413,9 @@ def main():
     ovl = run_workload("c1", args, torch, q, ctx, dev, rank, world, overlap=True, steps=min(args.steps, 20)) \
         if (extra_ok and args.config == "c1" and not args.overlap) else None
     extra = run_workload("c2", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 50)) if (extra_ok and args.config == "c1") else None
+    extra3 = run_workload("c3", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 30)) if (extra_ok and args.config == "c1") else None
+    extra4 = run_c4(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20)) if (extra_ok and args.config == "c1" and world == 1) else None
+    extra5 = run_c5(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20)) if (extra_ok and args.config == "c1" and world == 1) else None
     base = cpu_baseline(args.config, min(os.cpu_count() or 1, 16)) if (extra_ok and rank == 0) else None
 
     line = None
@@ -391,10 +455,16 @@ def main():
             line["parity_check"] = main_r["parity"]
         if base:
             line["cpu_baseline"] = base
-        if extra:
-            line["c2"] = {"workload": extra["label"], "value": round(extra["msps"], 1), "unit": "MS/s", "steps": extra["steps"],
-                          "ms_per_step": round(extra["ms_per_step"], 3), "streams_per_gpu": extra["batch"],
-                          "samples_per_stream_per_step": extra["nsamp"], "roofline": roof(extra)}
+        for key, ex in (("c2", extra), ("c3", extra3)):
+            if ex:
+                line[key] = {"workload": ex["label"], "value": round(ex["msps"], 1), "unit": "MS/s", "steps": ex["steps"],
+                             "ms_per_step": round(ex["ms_per_step"], 3), "streams_per_gpu": ex["batch"],
+                             "samples_per_stream_per_step": ex["nsamp"], "roofline": roof(ex)}
+        for key, ex in (("c4", extra4), ("c5", extra5)):
+            if ex:
+                line[key] = {k: ex[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "roofline") if k in ex}
+                if "freq_xlating_form" in ex:
+                    line[key]["freq_xlating_form"] = ex["freq_xlating_form"]
     finish(line)
     if rank == 0 and main_r["parity"] and main_r["parity"]["status"] != "bit-exact":
         raise SystemExit("bench.py: parity check against the oracle FAILED at the bench shape: %r" % (main_r["parity"],))

@@ -132,7 +132,10 @@ int qrl_demod_set_agc(qrl_demod* d, float attack, float decay);
  * gr::sync_block::work()/general_work() of every block on the chain (SURVEY.md 8b block ABI).
  * iq: device pointer, stream b at iq + 2*b*stride floats, n <= max_chunk samples each, base and
  * stride*8 bytes 16-byte aligned.  Asynchronous on the handle's stream; results are valid after
- * qrl_demod_sync().  Results are independent of how the stream is cut into calls. */
+ * qrl_demod_sync().  Results are independent of how the stream is cut into calls.
+ * Calls in flight together need DISTINCT output buffers: for the QPSK / BPSK / 4FSK-discriminator families the recursion and the
+ * Viterbi decoder of a call run on internal streams up to two calls behind the front end, so a caller that reuses one qrl_demod_out
+ * for back-to-back calls must put qrl_demod_sync() or qrl_demod_stream_wait() between them (or alternate two buffer sets). */
 int qrl_demod_process(qrl_demod* d, const float* iq, size_t stride, size_t n, const qrl_demod_out* out);
 int qrl_demod_sync(qrl_demod* d);
 void* qrl_demod_stream(qrl_demod* d); /* hipStream_t */

@@ -46,12 +46,17 @@ struct qrl_chan {
     hipStream_t stream = nullptr; bool own_stream = false;
     int M = 10, J = 0, nt = 0, rs_Jp = 0, filt_nt = 0;
     Buf<float> taps, rs_taps, filt_taps, atan_tab; Buf<float2> twiddle;
+    Buf<float> ct_a, ct_b, ct_e;   // step-major tap tables of the fused per-channel kernel
     Buf<float2> hist_a, hist_b; uint32_t hist_len = 0; bool flip = false;
     Buf<float2> r1, r2, r3; Buf<float> r4; uint32_t m1 = 0, m2 = 0;
     uint64_t n_in = 0, n1 = 0, n2 = 0;
     float gain = 0, level = 1.0f, rssi_cal = 0.0f;
     bool xlat2 = false;   // form 2: N freq-xlating FIR decimators 1:N with the PFB prototype in front of the multi2 per-channel chain (BASELINE configs[3])
-    hipEvent_t ev_user = nullptr;
+    hipEvent_t ev_user = nullptr, ev_user2 = nullptr;
+    // the serial symbol-sync tail (64 waves for 4096 channel streams: latency bound) runs on its own stream so that it overlaps the
+    // channelizer and the fused per-channel kernel of the NEXT call; ring r6 holds two calls, ev_tail[slot] guards its reuse
+    hipStream_t tail = nullptr; hipEvent_t ev_ff = nullptr, ev_tail[2] = {nullptr, nullptr}; bool tail_valid[2] = {false, false}; uint64_t call_no = 0;
+    uint32_t m6 = 0;
     int opt_legacy_pfb = 0, opt_legacy_tail = 0;   // qrl_chan_set_option
     bool profiling = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;   // qrl_chan_profile: the HBM-facing kernel(s) of each call
     bool xlat = false; int xl_D = 10, xl_nt = 0, xl_S = 0; Buf<float> xl_taps; Buf<float2> xl_rot_lo; std::vector<uint64_t> xl_inc;   // form 1
@@ -67,6 +72,10 @@ struct qrl_chan {
     }
     size_t zeroed = 0;
     ~qrl_chan() { for (auto& e : prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+                  if (ev_user2) (void)hipEventDestroy(ev_user2);
+                  if (ev_ff) (void)hipEventDestroy(ev_ff);
+                  for (auto e : ev_tail) if (e) (void)hipEventDestroy(e);
+                  if (tail) (void)hipStreamDestroy(tail);
                   if (ev_user) (void)hipEventDestroy(ev_user); if (own_stream && stream) (void)hipStreamDestroy(stream); }
     int reset_state() {
         const size_t S = (size_t)cfg.batch * cfg.channel_count;
@@ -78,7 +87,8 @@ struct qrl_chan {
         if (hipMemset(r4.p, 0, S * (m2 + 1) * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
         n_in = n1 = n2 = 0; flip = false;
         if (ss.p) {
-            if (hipMemset(r5.p, 0, S * (m2 + 1) * sizeof(float)) != hipSuccess || hipMemset(r6.p, 0, S * (m2 + 1) * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
+            if (hipMemset(r5.p, 0, S * (m2 + 1) * sizeof(float)) != hipSuccess || hipMemset(r6.p, 0, S * (m6 + 1) * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
+            tail_valid[0] = tail_valid[1] = false; call_no = 0;
             return init_ss();
         }
         return QRL_OK;
@@ -129,6 +139,7 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     std::vector<float> rl((size_t)RI * h->rs_Jp, 0.0f);
     for (size_t k = 0; k < rt.size(); ++k) rl[(k % RI) * h->rs_Jp + k / RI] = rt[k];
     if ((r = h->rs_taps.upload(rl))) return r;
+    const bool ct_ok = !h->single && !h->xlat;
     if (h->xlat) {
         // legacy receiver gr_demod_mmdvm_multi.cpp:58-123: per channel rotator_cc(2 pi (-separation) ct / fs) ->
         // rational_resampler_ccf(1, D, low_pass(1, fs, fw, 3500, BH)) at fs = 24 kHz * D (240 ksps, D = 10 in the reference)
@@ -184,6 +195,8 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
                                           : low_pass_2(1, 24000, fwp, 2000, 60, WIN_BLACKMAN_HARRIS);    // :62-63
     h->filt_nt = (int)ft.size();
     if ((r = h->filt_taps.upload(ft)) || (r = h->atan_tab.upload(atan_table()))) return r;
+    if (ct_ok && chan_tail_supported(h->rs_I, h->rs_D, h->rs_Jp, h->filt_nt, 0) &&
+        ((r = h->ct_a.upload(chan_tail_tables(0, rl.data()))) || (r = h->ct_b.upload(chan_tail_tables(1, ft.data()))))) return r;
     h->gain = h->single ? (float)(24000.0f / (2 * M_PI * 10000.0f))                               // gr_demod_mmdvm.cpp:41,48
                         : (float)(24000.0f / (2 * M_PI * 12500.0f));                              // gr_demod_mmdvm_multi2.cpp:80
     h->hist_len = (h->xlat || h->xlat2) ? (uint32_t)(h->xl_nt + h->xl_D) : h->single ? (uint32_t)(h->rs_Jp + h->rs_D + 2) : (uint32_t)(h->J * M);
@@ -199,11 +212,12 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     *outp = h.release();
     return QRL_OK;
 }
-void qrl_chan_destroy(qrl_chan* h) { if (h) { (void)hipStreamSynchronize(h->stream); delete h; } }
+void qrl_chan_destroy(qrl_chan* h) { if (h) { (void)hipStreamSynchronize(h->stream); if (h->tail) (void)hipStreamSynchronize(h->tail); delete h; } }
 int qrl_chan_reset(qrl_chan* h)
 {
     if (!h) return QRL_ERR_ARG;
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->tail) HIPCHK(hipStreamSynchronize(h->tail));
     return h->reset_state();
 }
 int qrl_chan_set_option(qrl_chan* h, int option, int value)
@@ -232,9 +246,17 @@ int qrl_chan_set_4fsk_output(qrl_chan* h, uint8_t* bits, size_t bits_cap, float*
         int r;
         const std::vector<float> rrc = root_raised_cosine(1, 24000, 4800, 0.2, 25 * 5);      // gr_demod_dmr.cpp:62-66
         h->symf_nt = (int)rrc.size();
+        const size_t max2 = (h->cfg.max_chunk / (h->xlat2 ? h->xl_D : h->M) + 2) * h->rs_I / h->rs_D + 2;
+        h->m6 = pow2ge(2 * max2 + h->symf_nt + 64 + 300) - 1;   // two calls: the symbol sync of call k runs beside the kernels of call k + 1
+        if (chan_tail_supported(h->rs_I, h->rs_D, h->rs_Jp, h->filt_nt, h->symf_nt) && (r = h->ct_e.upload(chan_tail_tables(2, rrc.data())))) return r;
         if ((r = h->symf_taps.upload(rrc)) || (r = h->mmse.upload(mmse_table())) || (r = h->r5.alloc(S * (h->m2 + 1))) ||
-            (r = h->r6.alloc(S * (h->m2 + 1))) || (r = h->ss.alloc(S)) || (r = h->soft_dummy.alloc(64)))
+            (r = h->r6.alloc(S * (h->m6 + 1))) || (r = h->ss.alloc(S)) || (r = h->soft_dummy.alloc(64)))
             return qrl_set_error(r, "4fsk tail buffers");
+        if (!h->tail) {
+            HIPCHK(hipStreamCreateWithFlags(&h->tail, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_ff, hipEventDisableTiming));
+            for (auto& e : h->ev_tail) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
         clock_loop_gains((float)(2 * M_PI / 100.0f), 1.0f, 0.2869f, h->ss_alpha, h->ss_beta);  // :70-71
         HIPCHK(hipStreamSynchronize(h->stream));
         if ((r = h->init_ss())) return r;
@@ -252,6 +274,7 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
     if (n % (size_t)h->M) return qrl_set_error(QRL_ERR_ARG, "n must be a multiple of num_channels (stream_to_streams)");
     if (n == 0) return QRL_OK;
     HIPCHK(hipSetDevice(h->ctx->device));
+    (void)qrl::take_launch_error();
     const int B = h->cfg.batch, M = h->M, CC = h->cfg.channel_count, S = B * CC;
     const float2* in = reinterpret_cast<const float2*>(iq);
     const float2* hist_old = h->flip ? h->hist_b.p : h->hist_a.p;
@@ -259,6 +282,7 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
     // PFB: one output instant per M inputs; form 2: rational_resampler_ccf(1, N) -- output m exists once input m N does
     const uint64_t n1_1 = h->xlat2 ? (h->n_in + n - 1) / (uint64_t)h->xl_D + 1 : (h->n_in + n) / M;
     if (h->rssi_out && h->rssi_counts) HIPCHK(hipMemsetAsync(h->rssi_counts, 0, (size_t)S * sizeof(uint32_t), h->stream));
+    if (h->tail && h->tail_valid[h->call_no & 1]) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_tail[h->call_no & 1], 0));   // symbol sync of call k - 2 done: its half of ring r6 is free
     ChanParams p{};
     p.in = in; p.in_stride = stride; p.n0 = h->n_in; p.n = (uint32_t)n; p.hist = hist_old; p.hist_len = h->hist_len;
     p.out = RingC{h->r1.p, h->m1}; p.m0 = h->n1; p.m_count = (uint32_t)(n1_1 - h->n1);
@@ -292,7 +316,7 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
         if (ev1) { HIPCHK(hipEventRecord(ev1, h->stream)); h->prof_events.emplace_back(ev0, ev1); }
     }
     // PFB form and form 2: the whole per-channel feed-forward chain in one kernel (kernels_chan_tail.hip)
-    const bool fused = !h->single && !h->xlat && !h->opt_legacy_tail &&
+    const bool fused = !h->single && !h->xlat && !h->opt_legacy_tail && h->ct_a.p && (!h->fsk_bits || h->ct_e.p) &&
                        chan_tail_supported(h->rs_I, h->rs_D, h->rs_Jp, h->filt_nt, h->fsk_bits ? h->symf_nt : 0);
     ResampParams rp{};
     if (h->xlat) {
@@ -310,10 +334,10 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
     if (fused) {
         ChanTailParams tp{};
         tp.in = RingC{h->r1.p, h->m1}; tp.q0 = h->n2; tp.count = c2;
-        tp.rs_taps = h->rs_taps.p; tp.filt_taps = h->filt_taps.p; tp.rrc_taps = h->symf_taps.p; tp.atan_tab = h->atan_tab.p;
+        tp.tab_a = h->ct_a.p; tp.tab_b = h->ct_b.p; tp.tab_e = h->ct_e.p; tp.atan_tab = h->atan_tab.p;
         tp.gain = h->gain; tp.gain2 = (float)(24000 / (M_PI / 2 * (float)(24000 / 5))); tp.level = h->level; tp.scale = 32767.0f;
         tp.s16 = out; tp.s16_cap = out_cap; tp.s16_counts = counts;
-        if (h->fsk_bits) tp.out_sym = RingF{h->r6.p, h->m2};
+        if (h->fsk_bits) tp.out_sym = RingF{h->r6.p, h->m6};
         if (h->rssi_out) { tp.rssi = h->rssi_out; tp.rssi_cap = h->rssi_cap; tp.rssi_counts = h->rssi_counts; tp.rssi_cal = h->rssi_cal;
                            tp.tag0 = h->n2 / 300; tp.ntags = (uint32_t)(n2_1 / 300 - h->n2 / 300); }
         launch_chan_tail(tp, S, h->stream);
@@ -331,22 +355,29 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
         if (out) { qp.s16 = out; qp.s16_cap = out_cap; qp.s16_level = h->level; qp.s16_scale = 32767.0f; qp.s16_counts = counts; }   // _level + float_to_short in the same pass
         launch_quad_demod(qp, S, h->stream);
         if (h->fsk_bits) {   // gr_demod_dmr.cpp:72-76 behind the channel filter: discriminator (24000 / (pi/2 * 4800), fused above) -> RRC
-            FirFffParams f6{}; f6.in = RingF{h->r5.p, h->m2}; f6.out = RingF{h->r6.p, h->m2}; f6.q0 = h->n2; f6.count = c2; f6.taps = h->symf_taps.p; f6.nt = h->symf_nt;
+            FirFffParams f6{}; f6.in = RingF{h->r5.p, h->m2}; f6.out = RingF{h->r6.p, h->m6}; f6.q0 = h->n2; f6.count = c2; f6.taps = h->symf_taps.p; f6.nt = h->symf_nt;
             launch_fir_fff(f6, S, h->stream);
         }
     }
     {
         if (h->fsk_bits) {   // gr_demod_dmr.cpp:70-105: symbol_sync_ff -> level -> phase modulator -> slicer -> dibits, on the RRC output ring
-            HIPCHK(hipMemsetAsync(h->fsk_counts, 0, (size_t)S * 4 * sizeof(uint32_t), h->stream));
+            // on the tail stream, behind this call's feed-forward kernels; the ring slot it reads is rewritten two calls later
+            HIPCHK(hipEventRecord(h->ev_ff, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->tail, h->ev_ff, 0));
+            HIPCHK(hipMemsetAsync(h->fsk_counts, 0, (size_t)S * 4 * sizeof(uint32_t), h->tail));
             SymSyncParams s{};
-            s.in = RingF{h->r6.p, h->m2}; s.avail = n2_1; s.soft = RingB{h->soft_dummy.p, 63}; s.st = h->ss.p; s.mmse = h->mmse.p;
+            s.in = RingF{h->r6.p, h->m6}; s.avail = n2_1; s.soft = RingB{h->soft_dummy.p, 63}; s.st = h->ss.p; s.mmse = h->mmse.p;
             s.alpha = h->ss_alpha; s.beta = h->ss_beta; s.maxp = 5.0f + 0.06f; s.minp = 5.0f - 0.06f;
             s.ted = 0; s.soft_mul = 128.0f; s.soft_add = 128.0f; s.slicer = 1; s.tail = 1; s.tail_scale = 0.9f;   // gr_demod_dmr.cpp:73 _level_control
             s.bits = h->fsk_bits; s.bits_cap = h->fsk_bits_cap;
             s.port = reinterpret_cast<float2*>(h->fsk_const); s.port_cap = h->fsk_const ? h->fsk_const_cap : 0; s.counts = h->fsk_counts;
-            launch_symsync_ff(s, S, h->stream);
+            launch_symsync_ff(s, S, h->tail);
+            const int slot = (int)(h->call_no & 1);
+            HIPCHK(hipEventRecord(h->ev_tail[slot], h->tail));
+            h->tail_valid[slot] = true;
         }
     }
+    ++h->call_no;
     HIPCHK(hipGetLastError());
     if (qrl::take_launch_error()) return QRL_ERR_HIP;
     h->n_in += n; h->n1 = n1_1; h->n2 = n2_1;
@@ -358,6 +389,11 @@ int qrl_chan_stream_wait(qrl_chan* h, void* hip_stream)
     if (!h->ev_user) HIPCHK(hipEventCreateWithFlags(&h->ev_user, hipEventDisableTiming));
     HIPCHK(hipEventRecord(h->ev_user, h->stream));
     HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), h->ev_user, 0));
+    if (h->tail) {
+        if (!h->ev_user2) HIPCHK(hipEventCreateWithFlags(&h->ev_user2, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(h->ev_user2, h->tail));
+        HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), h->ev_user2, 0));
+    }
     return QRL_OK;
 }
 void* qrl_chan_stream(qrl_chan* h) { return h ? h->stream : nullptr; }
@@ -383,6 +419,7 @@ int qrl_chan_sync(qrl_chan* h)
 {
     if (!h) return QRL_ERR_ARG;
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->tail) HIPCHK(hipStreamSynchronize(h->tail));
     return QRL_OK;
 }
 

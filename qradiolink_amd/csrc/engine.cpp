@@ -33,7 +33,7 @@ hipError_t dyn_lds_limit(const void* kernel, int bytes)
     static std::set<std::pair<const void*, int>> done;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) { t_launch_error = true; qrl_set_error(QRL_ERR_HIP, std::string("hipGetDevice: ") + hipGetErrorString(e)); return e; }
     std::lock_guard<std::mutex> g(mu);
     if (done.count({kernel, dev})) return hipSuccess;
     e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1114,11 +1114,14 @@ int qrl_demod_set_dmo_output(qrl_demod* d, uint8_t* frames, size_t cap_frames, u
 {
     if (!d) return QRL_ERR_ARG;
     if (d->fam != qrl_demod::F_DMR || d->m17) return qrl_set_error(QRL_ERR_ARG, "the DMO slicer sits behind port 3 of gr_demod_dmr: QRL_MODEM_DMR only");
-    if (int rs = d->sync_all()) return rs;
-    if (!frames) { d->dmo_out = nullptr; return QRL_OK; }
+    // kernel parameters are captured at launch: swapping the output pointers between calls needs no synchronisation (a host layer
+    // that double-buffers its mailboxes calls this before every process).  Only the first use (state allocation) and switching
+    // the block off wait for the work in flight.
+    if (!frames) { if (int rs = d->sync_all()) return rs; d->dmo_out = nullptr; return QRL_OK; }
     if (!counts || cap_frames < 1 || cap_frames > 0xFFFFFFFFu) return QRL_ERR_ARG;
     int r;
     if (!d->dmo_st.p) {
+        if (int rs = d->sync_all()) return rs;
         if ((r = d->dmo_st.alloc(d->cfg.batch)) || (r = d->dmo_golay.upload(golay1987_table()))) return r;
         std::vector<DmoState> ds(d->cfg.batch);
         for (auto& x : ds) { std::memset(&x, 0, sizeof x); x.endPtr = 9999; }
@@ -1180,6 +1183,7 @@ int qrl_demod_process(qrl_demod* d, const float* iq, size_t stride, size_t n, co
 {
     if (!d || (!iq && n)) return QRL_ERR_ARG;
     HIPCHK(hipSetDevice(d->ctx->device));
+    (void)take_launch_error();   // a mark left on this thread by an earlier call that returned before reading it must not fail this one
     return d->process(iq, stride, n, out);
 }
 int qrl_demod_sync(qrl_demod* d)

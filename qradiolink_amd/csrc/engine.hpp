@@ -214,9 +214,7 @@ void launch_rssi_tag(const RssiParams& p, int batch, hipStream_t s);
 struct ChanTailParams {
     RingC in;                               // channel ring at 25 ksps, one row per (stream, channel)
     uint64_t q0; uint32_t count;            // outputs of this call at 24 ksps: [q0, q0 + count)
-    const float* rs_taps;                   // [24][35]: taps[ph * 35 + j] = h[ph + 24 j], zero padded
-    const float* filt_taps;                 // 33
-    const float* rrc_taps;                  // 125 (unused when out_sym.p == nullptr)
+    const float* tab_a; const float* tab_b; const float* tab_e;   // step-major tap tables (chan_tail_tables; tab_e unused when out_sym.p == nullptr)
     const float* atan_tab;                  // 257
     float gain, gain2, level, scale;
     int16_t* s16; size_t s16_cap; uint32_t* s16_counts;
@@ -225,6 +223,7 @@ struct ChanTailParams {
 };
 void launch_chan_tail(const ChanTailParams& p, int streams, hipStream_t s);
 bool chan_tail_supported(int rs_I, int rs_D, int rs_Jp, int filt_nt, int rrc_nt);
+std::vector<float> chan_tail_tables(int which, const float* taps);   // 0: resampler (phase-major taps [24][35]), 1: channel filter, 2: RRC
 uint32_t chan_tail_lookback();
 void launch_pfb_chan(const ChanParams& p, int batch, hipStream_t s);
 void launch_f2s(const F2sParams& p, int batch, hipStream_t s);

@@ -24,6 +24,7 @@
 // conflict free for ds_read_b64).
 // Every chain is the oracle's: one fmaf chain per output, tap index ascending, first term fmaf(h, x, +0) (orc_resamp_ccf,
 // orc_fir_ccf, orc_fir_fff); discriminator, quantiser and RSSI sums as in k_quad_demod / k_rssi_tag.
+#include <vector>
 #include "devmath.hpp"
 #include "engine.hpp"
 
@@ -61,13 +62,11 @@ __global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
     const int NB = (int)(Q0 + CT_T - qb);                                         // filter outputs: 1332 .. 1339
     const int e0 = (int)(Q0 - qb);                                                // tile start relative to qb: 132 .. 139
     for (int k = tid; k < 257; k += 256) T[k] = P.atan_tab[k];
-    for (int k = tid; k < 3 * CT_SA * 8; k += 256) {   // tA[(w SA + s) 8 + r] = taps[(8 w + r) 35 + (r - d)], d = 7 - s
-        const int r = k & 7, st = (k >> 3) % CT_SA, w = (k >> 3) / CT_SA, j = r - (7 - st);
-        tA[k] = (j >= 0 && j < CT_JP) ? P.rs_taps[(8 * w + r) * CT_JP + j] : 0.0f;
-    }
-    for (int k = tid; k < CT_SB * 8; k += 256) { const int j = (k & 7) - (7 - (k >> 3)); tB[k] = (j >= 0 && j < CT_NF) ? P.filt_taps[j] : 0.0f; }
+    // step-major tap tables, laid out by the host (chan_tail_tables): straight 16-byte copies
+    for (int k = tid; k < 3 * CT_SA * 2; k += 256) reinterpret_cast<float4*>(tA)[k] = reinterpret_cast<const float4*>(P.tab_a)[k];
+    if (tid < CT_SB * 2) reinterpret_cast<float4*>(tB)[tid] = reinterpret_cast<const float4*>(P.tab_b)[tid];
     if (P.out_sym.p)
-        for (int k = tid; k < CT_SE * 8; k += 256) { const int j = (k & 7) - (7 - (k >> 3)); tE[k] = (j >= 0 && j < CT_NR) ? P.rrc_taps[j] : 0.0f; }
+        for (int k = tid; k < CT_SE * 2; k += 256) reinterpret_cast<float4*>(tE)[k] = reinterpret_cast<const float4*>(P.tab_e)[k];
     // ---- stage the input: x[xbase + i], xbase = 25 ua - 34 (zero in front of the stream)
     const int64_t xbase = 25 * ua - (CT_JP - 1);
     const int nx = 25 * NU + (CT_JP - 1);
@@ -192,6 +191,29 @@ void launch_chan_tail(const ChanTailParams& p, int streams, hipStream_t s)
     if (!p.count) return;
     const uint64_t t_first = p.q0 / CT_T, t_last = (p.q0 + p.count - 1) / CT_T;
     hipLaunchKernelGGL(k_chan_tail, dim3((uint32_t)(t_last - t_first + 1), streams), dim3(256), 0, s, p);
+}
+// step-major tap tables of k_chan_tail: which = 0: resampler [3 waves][42 steps][8] from the phase-major taps[24][35];
+// 1: channel filter [40][8]; 2: RRC [132][8].  Entry (step s, r) = h[r - (7 - s)], zero outside the filter.
+std::vector<float> chan_tail_tables(int which, const float* taps)
+{
+    if (which == 0) {
+        std::vector<float> t((size_t)3 * CT_SA * 8, 0.0f);
+        for (int w = 0; w < 3; ++w)
+            for (int st = 0; st < CT_SA; ++st)
+                for (int r = 0; r < 8; ++r) {
+                    const int j = r - (7 - st);
+                    if (j >= 0 && j < CT_JP) t[((size_t)w * CT_SA + st) * 8 + r] = taps[(8 * w + r) * CT_JP + j];
+                }
+        return t;
+    }
+    const int nt = which == 1 ? CT_NF : CT_NR, ns = which == 1 ? CT_SB : CT_SE;
+    std::vector<float> t((size_t)ns * 8, 0.0f);
+    for (int st = 0; st < ns; ++st)
+        for (int r = 0; r < 8; ++r) {
+            const int j = r - (7 - st);
+            if (j >= 0 && j < nt) t[(size_t)st * 8 + r] = taps[j];
+        }
+    return t;
 }
 bool chan_tail_supported(int rs_I, int rs_D, int rs_Jp, int filt_nt, int rrc_nt)
 {

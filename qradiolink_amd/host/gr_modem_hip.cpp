@@ -156,6 +156,7 @@ void gr_demod_base_hip::open()
 }
 void gr_demod_base_hip::set_mode(int mode)   // gr_demod_base::set_mode (src/gr/gr_demod_base.cpp:460-1090): swap the graph, drop what was queued
 {
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     flush();
     d_mode = mode;
     open();
@@ -164,17 +165,20 @@ void gr_demod_base_hip::set_mode(int mode)   // gr_demod_base::set_mode (src/gr/
 }
 void gr_demod_base_hip::set_carrier_offset(double hz)   // gr_demod_base.cpp:1220-1225
 {
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     d_offset = hz;
     if (d_h) chk(qrl_demod_set_carrier_offset(d_h, hz), "qrl_demod_set_carrier_offset");
 }
 void gr_demod_base_hip::set_samp_rate(int device_samp_rate)   // gr_demod_base.cpp:1303-1362: the resampler is rebuilt
 {
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     flush();
     d_rate = device_samp_rate;
     if (d_mode >= 0) open();
 }
 void gr_demod_base_hip::work(const gr_complex* const* iq, size_t n)
 {
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     if (!d_h) throw std::runtime_error("gr_demod_base_hip::work before set_mode");
     if (n == 0) return;
     if (n > d_chunk || (n & 1)) throw std::invalid_argument("gr_demod_base_hip::work: n must be even and <= max_chunk");
@@ -241,6 +245,7 @@ void gr_demod_base_hip::harvest(int which)
 }
 void gr_demod_base_hip::flush()
 {
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     if (d_inflight >= 0) { harvest(d_inflight); d_inflight = -1; }
 }
 std::vector<unsigned char>* gr_demod_base_hip::getData(int nr, int stream)   // gr_bit_sink::get_data: >= 32 bits or nothing (src/gr/gr_bit_sink.cpp:45-59)
@@ -264,16 +269,19 @@ std::vector<float>* gr_demod_base_hip::getAudio(int stream)   // gr_demod_base::
 }
 void gr_demod_base_hip::set_squelch(int value)   // gr_demod_base.cpp:1186-1199
 {
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     d_squelch = value;
     if (d_h && d_acap) chk(qrl_demod_set_squelch(d_h, (double)value), "qrl_demod_set_squelch");
 }
 void gr_demod_base_hip::set_agc_attack(float value)   // :1428-1448
 {
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     d_agc_attack = value;
     if (d_h && d_acap && d_mode == QRL_MODEM_AM5000) chk(qrl_demod_set_agc(d_h, d_agc_attack, d_agc_decay), "qrl_demod_set_agc");
 }
 void gr_demod_base_hip::set_agc_decay(float value)   // :1450-1470
 {
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     d_agc_decay = value;
     if (d_h && d_acap && d_mode == QRL_MODEM_AM5000) chk(qrl_demod_set_agc(d_h, d_agc_attack, d_agc_decay), "qrl_demod_set_agc");
 }
@@ -292,16 +300,19 @@ float gr_demod_base_hip::get_rssi(int stream)   // gr_demod_base.cpp:1234-1237
 }
 void gr_demod_base_hip::calibrate_rssi(float value)   // :1413-1418
 {
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     d_rssi_cal = value;
     if (d_rssi) chk(qrl_rssi_set_level(d_rssi, value), "qrl_rssi_set_level");
 }
 void gr_demod_base_hip::enable_gui_fft(bool value)   // :1110-1113
 {
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     d_fft_on = value;
     if (d_fft) chk(qrl_fft_set_enabled(d_fft, value ? 1 : 0), "qrl_fft_set_enabled");
 }
 void gr_demod_base_hip::set_fft_size(int size)   // :1227-1232
 {
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     flush();
     d_fftsize = (unsigned)size;
     if (d_fft) chk(qrl_fft_set_fft_size(d_fft, d_fftsize), "qrl_fft_set_fft_size");
@@ -310,6 +321,7 @@ void gr_demod_base_hip::set_fft_size(int size)   // :1227-1232
 void gr_demod_base_hip::get_FFT_data(float* fft_data, unsigned int& fftSize, int stream)   // :978-986 -> rx_fft_c::get_fft_data
 {
     fftSize = 0;
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     if (!d_fft) return;
     if (!d_fftout) hchk(hipMalloc(reinterpret_cast<void**>(&d_fftout), (size_t)d_n * d_fftsize * sizeof(float)), "hipMalloc");
     unsigned got = 0;

@@ -86,7 +86,11 @@ private:
     int d_inflight = -1; uint64_t d_calls = 0;
     size_t d_fcap = 0, d_ccap = 0, d_bcap = 0, d_acap = 0;
     int d_squelch = -140; float d_agc_attack = 0.1f, d_agc_decay = 0.1f;
-    std::mutex d_mutex;
+    std::mutex d_mutex;                                       // the mailboxes (harvest vs the getters)
+    // the C-ABI handles (qrl_demod / qrl_rssi / qrl_fft) are single-threaded objects: work() and every setter / GUI getter that
+    // touches them takes this lock, as rx_fft_c guards work(), get_fft_data() and set_fft_size() with its own mutex
+    // (reference src/gr/rx_fft.cpp:71-100).  Lock order: d_hmutex, then d_mutex.
+    std::recursive_mutex d_hmutex;
     std::vector<std::vector<float>> d_boxa;
     std::vector<std::vector<unsigned char>> d_box1, d_box2;
     std::vector<std::vector<gr_complex>> d_boxc;

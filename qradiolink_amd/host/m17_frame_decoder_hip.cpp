@@ -58,7 +58,7 @@ std::vector<M17FrameType> m17_frame_decoder_hip::decodeFrames(const uint8_t* fra
                 if (r[1]) {
                     const uint8_t seg = r[37];
                     if (seg <= 5) std::memcpy(st.lsf_from_lich.data() + 5 * seg, r + 32, 5);
-                    st.segment_map = (uint8_t)(st.segment_map | (1u << seg));
+                    st.segment_map = (uint8_t)(st.segment_map | (1u << (seg & 7u)));   // a corrupt record byte must not shift out of range (the reference indexes a 6-entry map with the same 3-bit field)
                     if (st.segment_map == 0x3F) {
                         const uint16_t crc = crc16(st.lsf_from_lich.data(), 28);
                         if (st.lsf_from_lich[28] == (crc >> 8) && st.lsf_from_lich[29] == (crc & 0xFF)) st.lsf = st.lsf_from_lich;
