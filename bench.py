@@ -116,8 +116,6 @@ def run_workload(name, args, torch, q, ctx, dev, rank, world, overlap=False, che
     iq = synth(mode, rate, offset, batch, nsamp, 1234 + rank, torch, dev, pad=args.pad)
     dem = q.Demod(ctx, modem, batch=batch, max_chunk=nsamp, device_samp_rate=rate, carrier_offset_hz=offset,
                   side_outputs=True)
-    if args.ldsdma_frontend:
-        dem.set_option(q.OPT_LEGACY_FRONTEND, 0)   # A/B: the LDS-DMA phase-lane front end k_decim_pl2 instead of k_decim_pl
     if overlap:
         dem.set_option(q.OPT_OVERLAP, 1)   # opt-in: decimated-rate kernels of call k under the front end of call k + 1
     for _ in range(args.warmup):
@@ -371,7 +369,6 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="C1 only: QRL_OPT_OVERLAP = 1 (decimated-rate kernels of call k under the front end of call k + 1)")
     ap.add_argument("--no-overlap", action="store_true", help="(default behaviour; kept for the tools/ scripts)")
     ap.add_argument("--check", action="store_true", help="with --no-extra: still run the parity check against the oracle at the bench shape")
-    ap.add_argument("--ldsdma-frontend", action="store_true", help="A/B: QRL_OPT_LEGACY_FRONTEND = 0 (phase-lane front end fed by LDS-DMA rings, k_decim_pl2)")
     ap.add_argument("--legacy-pfb", action="store_true", help="A/B, c4: QRL_CHAN_OPT_LEGACY_PFB = 1 (general-M channelizer kernel)")
     args = ap.parse_args()
 

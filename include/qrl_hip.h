@@ -110,9 +110,7 @@ int qrl_demod_set_dmo_output(qrl_demod* d, uint8_t* frames, size_t cap_frames, u
 /* Per-handle run-time options (none of them changes results).  QRL_OPT_OVERLAP (2FSK family only, default 0): value 1 runs
  * everything behind the first decimated ring of call k on a second stream under the front end of call k + 1; value 0 runs the
  * kernels of a call one after another. */
-enum { QRL_OPT_OVERLAP = 1,
-       QRL_OPT_LEGACY_FRONTEND = 2   /* 1 (default): the phase-lane front ends fetch with VGPR loads (k_decim_pl); 0: through LDS-DMA rings (k_decim_pl2) -- same results, A/B measurements and tests */
-};
+enum { QRL_OPT_OVERLAP = 1 };
 int qrl_demod_set_option(qrl_demod* d, int option, int value);
 int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* filtered_cap, size_t* constellation_cap, size_t* bits_cap);
 /* analogue voice receivers (QRL_MODEM_NBFM2500 / NBFM5000 / AM5000 / WBFM / USB2500 / LSB2500; replace make_gr_demod_nbfm / _am /
@@ -223,7 +221,8 @@ typedef struct {
      * = rotator_cc(2 pi (-25000) ct / fs) -> rational_resampler_ccf(1, num_channels, low_pass_2(1, fs, 5000, 2000, 60, BH)) at
      * fs = 25 kHz * num_channels with the PFB form's channel map (ct = i, i <= N/2; i - N above), followed by the per-channel
      * chain of form 0 (24/25 resampler, LPF, RSSI, discriminator -> int16, optional 4FSK tail).  The same channels as form 0 from
-     * num_channels separate FIRs: the compute-bound way of doing what the PFB does; it exists to be measured next to it. */
+     * num_channels separate FIRs: the compute-bound way of doing what the PFB does; it exists to be measured next to it.
+     * form 3 = the per-channel chain alone (qrl_chan_process_channels): `batch` counts 25 ksps channel streams, max_chunk channel samples. */
     int form;
     int channel_separation;  /* form 1: Hz, 0 = 25000 */
     int decimation;          /* form 1: 0 = 10 */
@@ -257,6 +256,20 @@ size_t qrl_chan_out_cap(const qrl_chan* c, size_t n);   /* int16 samples per cha
  * out[(b*channel_count + c)*out_cap + k] device int16 @24 ksps, counts[b*channel_count + c] = samples written. */
 int qrl_chan_process(qrl_chan* c, const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts);
 int qrl_chan_sync(qrl_chan* c);
+/* ---- the two halves of qrl_chan_process for a CHANNEL-SHARDED multi-GPU job (PFB form: "channelize, then scatter the
+ * channel streams"; reference: one channelizer feeds per-channel chains, src/gr/gr_demod_mmdvm_multi2.cpp:98-135, and every channel
+ * has its own sink socket, src/gr/gr_mmdvm_sink.cpp:77-173).  Each rank channelizes ITS wideband inputs, an all-to-all moves every
+ * channel's samples to the rank that owns the channel, and that rank runs the per-channel chains:
+ *   qrl_chan_channelize        (PFB handle, form 0) stream_to_streams + pfb_channelizer_ccf only.  chan_out = device cf32,
+ *                              [groups][batch][channel_count / groups][pitch]: the rows of destination rank g are contiguous, n / M
+ *                              valid items per row.  The handle keeps the filter history; it must not be mixed with qrl_chan_process.
+ *   qrl_chan_process_channels  (form 3 handle: `batch` = number of 25 ksps channel streams, num_channels ignored) the per-channel chain
+ *                              of qrl_chan_process on chan_in[row * pitch + i], i < n1; outputs as qrl_chan_process with
+ *                              channel_count = 1 (row index = stream index).
+ *   qrl_chan_wait_for          the handle's stream waits (on the device) for what the given stream has queued so far: the collective. */
+int qrl_chan_channelize(qrl_chan* c, const float* iq, size_t stride, size_t n, float* chan_out, size_t pitch, int groups);
+int qrl_chan_process_channels(qrl_chan* c, const float* chan_in, size_t pitch, size_t n1, int16_t* out, size_t out_cap, uint32_t* counts);
+int qrl_chan_wait_for(qrl_chan* c, void* hip_stream);
 /* like qrl_demod_stream_wait: the caller's stream waits, on the device, for everything this handle has enqueued so far -- how a C4
  * caller chains its own copies / collectives (the all-to-all of a multi-GPU job) behind a call without a host synchronisation. */
 int qrl_chan_stream_wait(qrl_chan* c, void* hip_stream);

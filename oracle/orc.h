@@ -88,6 +88,8 @@ int    orc_decim_uses_m16(int nt, int decim);
 size_t orc_decim_fir_ccf_pl(const cf32* in, size_t n, const float* taps, int nt, int decim, cf32* out);
 void   orc_pl_geometry(int decim, int* dprime, int* per_lane);
 int    orc_decim_uses_pl(int nt, int decim);
+size_t orc_decim_fir_ccf_pm(const cf32* in, size_t n, const float* taps, int nt, int decim, cf32* out);   /* phase-major matrix-pipe contract, 32 < D <= 64 */
+int    orc_decim_uses_pm(int nt, int decim);
 size_t orc_decim_fir_ccf_simd(const cf32* in, size_t n, const float* taps, int nt, int decim, cf32* out);   /* CPU baseline only */
 void   orc_set_decim_impl(int impl);   /* 0: summation contracts (checker), 1: AVX2 dot product (bench.py cpu_baseline timing) */
 size_t orc_decim_auto(const cf32* in, size_t n, const float* taps, int nt, int decim, cf32* out);
@@ -167,6 +169,8 @@ size_t orc_demod_mmdvm_xlating(const cf32* in, size_t n, int N, int separation, 
 size_t orc_demod_mmdvm_multi_4fsk(const cf32* in, size_t n, int M, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal,
                                   uint8_t* dibits, size_t dcap, size_t* ndib);
 size_t orc_demod_mmdvm_multi_rssi(const cf32* in, size_t n, int M, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal);
+size_t orc_mmdvm_channel_tails(const cf32* ch, int nch, size_t n1, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal,
+                               uint8_t* dibits, size_t dcap, size_t* ndib);   /* per-channel chains only (channel-sharded jobs) */
 size_t orc_demod_mmdvm_xlating_bank_4fsk(const cf32* in, size_t n, int N, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal,
                                          uint8_t* dibits, size_t dcap, size_t* ndib);   /* BASELINE configs[3] literal: N freq-xlating FIRs 1:N */
 void orc_demod_dmr(const cf32* in, size_t n, int sps, int samp_rate, orc_demod_out* o);

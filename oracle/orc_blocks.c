@@ -158,9 +158,52 @@ int orc_decim_uses_pl(int nt, int D)
     int Dp, E;
     orc_pl_geometry(D, &Dp, &E);
     const int R = Dp / D, U = (nt + Dp - 1) / D;
-    if (E == 1 && R == 1) return U <= 16;
+    if (E == 1 && R == 1) return 0;           /* 32 < D <= 64: the phase-major matrix-pipe contract "pm" below */
     if (E == 2 && R == 1) return (D % 2) == 0 && U <= 42;
     return 0;
+}
+/* ---- contract "pm" (phase major; qradiolink_amd/csrc/kernels_decim_pl.hip k_decim_pm): 32 < D <= 52, J = ceil(nt / D) <= 16 ----------
+ * The stream is cut into BLOCKS of D samples, block c = samples (c-1) D + 1 .. c D (so output m ends at the last sample of block m).
+ * Sample p (0 .. D-1) of block c = m - j meets output m with tap H(p, j) = h[j D + D - 1 - p].
+ *   Z_j = one fmaf chain over the block's samples, p ASCENDING, from +0          (a [D x J] product on the f32 matrix pipe:
+ *                                                                                 v_mfma_f32_16x16x4_f32 accumulates k in order)
+ *   The J block terms of an output are then added with plain float adds in the order the kernel's lane layout fixes: the matrix
+ *   result holds Z_j of 16 consecutive blocks (an ABSOLUTE group: blocks 16 G .. 16 G + 15) in lane row q = j >> 2; terms whose block
+ *   lies in the output's own group (j <= m mod 16) are summed per row, j ascending, into R_q, the terms from the previous group
+ *   likewise into C_q (they were summed one group earlier); V_q = R_q + C_q; y = (V_0 + V_1) + (V_2 + V_3).
+ * The grouping is by absolute index, so the value of output m does not depend on where a call or a kernel segment starts. */
+int orc_decim_uses_pm(int nt, int D)
+{
+    return D > 32 && D <= 52 && (nt + D - 1) / D <= 16;   /* (a 16-block group of D <= 52 samples fits the 8 KiB LDS ring of a wave) */
+}
+size_t orc_decim_fir_ccf_pm(const cf32* in, size_t n, const float* taps, int nt, int D, cf32* out)
+{
+    const size_t nout = orc_decim_count(n, 1, D);
+    const int J = (nt + D - 1) / D;
+    for (size_t m = 0; m < nout; m++) {
+        float Rr[4] = {0.f, 0.f, 0.f, 0.f}, Ri[4] = {0.f, 0.f, 0.f, 0.f}, Cr[4] = {0.f, 0.f, 0.f, 0.f}, Ci[4] = {0.f, 0.f, 0.f, 0.f};
+        const int np = (int)(m & 15u);
+        for (int j = 0; j < J; j++) {
+            const long long c = (long long)m - j;
+            float zr = 0.0f, zi = 0.0f;
+            for (int p = 0; p < D; p++) {
+                const int k = j * D + D - 1 - p;
+                const long long i = (c - 1) * (long long)D + 1 + p;
+                const float h = k < nt ? taps[k] : 0.0f;
+                cf32 x = {0.0f, 0.0f};
+                if (i >= 0 && (size_t)i < n) x = in[i];
+                zr = fmaf(h, x.re, zr); zi = fmaf(h, x.im, zi);
+            }
+            const int q = j >> 2;
+            if (j <= np) { Rr[q] = Rr[q] + zr; Ri[q] = Ri[q] + zi; }
+            else         { Cr[q] = Cr[q] + zr; Ci[q] = Ci[q] + zi; }
+        }
+        float Vr[4], Vi[4];
+        for (int q = 0; q < 4; q++) { Vr[q] = Rr[q] + Cr[q]; Vi[q] = Ri[q] + Ci[q]; }
+        out[m].re = (Vr[0] + Vr[1]) + (Vr[2] + Vr[3]);
+        out[m].im = (Vi[0] + Vi[1]) + (Vi[2] + Vi[3]);
+    }
+    return nout;
 }
 size_t orc_decim_fir_ccf_pl(const cf32* in, size_t n, const float* taps, int nt, int D, cf32* out)
 {
@@ -236,6 +279,7 @@ size_t orc_decim_auto(const cf32* in, size_t n, const float* taps, int nt, int D
 {
     orc_trace_event("resamp_ccf(1,%d,%s)", D, orc_trace_name(taps, sizeof(float) * (size_t)nt));
     if (g_decim_impl == 1) return orc_decim_fir_ccf_simd(in, n, taps, nt, D, out);
+    if (orc_decim_uses_pm(nt, D)) return orc_decim_fir_ccf_pm(in, n, taps, nt, D, out);
     if (orc_decim_uses_pl(nt, D)) return orc_decim_fir_ccf_pl(in, n, taps, nt, D, out);
     if (orc_decim_uses_m16(nt, D)) return orc_decim_fir_ccf_m16(in, n, taps, nt, D, out);
     return orc_decim_fir_ccf(in, n, taps, nt, D, 4, out);

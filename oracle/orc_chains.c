@@ -1048,6 +1048,13 @@ static size_t multi_tail(const cf32* ch, int M, size_t n1, int16_t* out, size_t 
     free(a); free(b); free(d); free(rt); free(ft);
     return m;
 }
+/* the per-channel chains alone, on nch channel streams of n1 items at 25 ksps (ch[c * n1 + i]): what the owner rank of a
+ * channel-sharded multi-GPU job runs on the samples the all-to-all delivered (tests/test_sharding.py) */
+size_t orc_mmdvm_channel_tails(const cf32* ch, int nch, size_t n1, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal,
+                               uint8_t* dibits, size_t dcap, size_t* ndib)
+{
+    return multi_tail(ch, nch, n1, out, cap, rssi, rcap, cal, dibits, dcap, ndib);
+}
 size_t orc_demod_mmdvm_multi_4fsk(const cf32* in, size_t n, int M, int16_t* out, size_t cap, float* rssi, size_t rcap, float cal,
                                   uint8_t* dibits, size_t dcap, size_t* ndib)
 {

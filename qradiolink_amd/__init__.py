@@ -26,7 +26,6 @@ MODEM_USB2500, MODEM_LSB2500 = 11, 12
 MODEM_M17 = 40
 MODEM_DMR = 41
 OPT_OVERLAP = 1
-OPT_LEGACY_FRONTEND = 2
 CHAN_OPT_LEGACY_PFB, CHAN_OPT_LEGACY_TAIL = 1, 2
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECTANGULAR, WIN_BLACKMAN_HARRIS = 0, 1, 2, 3, 5
 
@@ -172,6 +171,9 @@ def load_library():
     lib.qrl_chan_stream.argtypes = [vp]
     lib.qrl_chan_stream.restype = vp
     lib.qrl_chan_set_option.argtypes = [vp, C.c_int, C.c_int]
+    lib.qrl_chan_channelize.argtypes = [vp, vp, sz, sz, vp, sz, C.c_int]
+    lib.qrl_chan_process_channels.argtypes = [vp, vp, sz, sz, vp, sz, vp]
+    lib.qrl_chan_wait_for.argtypes = [vp, vp]
     lib.qrl_chan_profile.argtypes = [vp, C.c_int]
     lib.qrl_chan_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_char_p)]
     lib.qrl_synth_create.argtypes = [vp, C.POINTER(_SynthConfig), C.POINTER(vp)]
@@ -214,7 +216,7 @@ EXPORTED_SYMBOLS = [
     "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
-    "qrl_mod_samples_per_byte", "qrl_mod_samples_per_block", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_set_option", "qrl_chan_stream_wait", "qrl_chan_stream", "qrl_chan_profile", "qrl_chan_profile_read", "qrl_debug_decim_prof", "qrl_debug_decim_prof_enable", "qrl_chan_create",
+    "qrl_mod_samples_per_byte", "qrl_mod_samples_per_block", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_set_option", "qrl_chan_channelize", "qrl_chan_process_channels", "qrl_chan_wait_for", "qrl_chan_stream_wait", "qrl_chan_stream", "qrl_chan_profile", "qrl_chan_profile_read", "qrl_debug_decim_prof", "qrl_debug_decim_prof_enable", "qrl_chan_create",
     "qrl_chan_destroy", "qrl_chan_reset", "qrl_chan_set_level", "qrl_chan_calibrate_rssi", "qrl_chan_set_rssi_output", "qrl_chan_set_4fsk_output", "qrl_chan_out_cap", "qrl_chan_process", "qrl_chan_sync",
     "qrl_synth_create", "qrl_synth_destroy", "qrl_synth_reset", "qrl_synth_set_bb_gain", "qrl_synth_add_zero_runs", "qrl_synth_out_cap", "qrl_synth_process",
     "qrl_synth_sync",
@@ -464,6 +466,24 @@ class Channelizer:
 
     def sync(self):
         _check(self.lib.qrl_chan_sync(self.h), "qrl_chan_sync")
+
+    def channelize_async(self, iq, chan_out, groups):
+        """PFB only (qrl_chan_channelize): chan_out complex64 cuda [groups, batch, channel_count // groups, pitch]"""
+        assert iq.is_cuda and iq.dtype == self.torch.complex64 and iq.dim() == 2 and iq.shape[0] == self.batch and iq.stride(1) == 1
+        assert chan_out.is_cuda and chan_out.dtype == self.torch.complex64 and chan_out.is_contiguous()
+        assert tuple(chan_out.shape[:3]) == (groups, self.batch, self.cc // groups)
+        _check(self.lib.qrl_chan_channelize(self.h, iq.data_ptr(), iq.stride(0), iq.shape[1], chan_out.data_ptr(), chan_out.shape[3], groups),
+               "qrl_chan_channelize")
+
+    def process_channels_async(self, chan_in, n1):
+        """form 3 handle: the per-channel chain on chan_in complex64 cuda [batch, pitch] (n1 valid items per row)"""
+        assert chan_in.is_cuda and chan_in.dtype == self.torch.complex64 and chan_in.dim() == 2 and chan_in.shape[0] == self.batch and chan_in.stride(1) == 1
+        _check(self.lib.qrl_chan_process_channels(self.h, chan_in.data_ptr(), chan_in.stride(0), n1, self.out.data_ptr(), self.cap,
+                                                  self.counts.data_ptr()), "qrl_chan_process_channels")
+
+    def wait_for(self, hip_stream):
+        """this handle's stream waits (on the device) for what the given HIP stream (int handle) has queued so far"""
+        _check(self.lib.qrl_chan_wait_for(self.h, C.c_void_p(hip_stream)), "qrl_chan_wait_for")
 
     def set_option(self, option, value):
         _check(self.lib.qrl_chan_set_option(self.h, int(option), int(value)), "qrl_chan_set_option")

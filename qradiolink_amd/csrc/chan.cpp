@@ -51,8 +51,9 @@ struct qrl_chan {
     Buf<float2> r1, r2, r3; Buf<float> r4; uint32_t m1 = 0, m2 = 0;
     uint64_t n_in = 0, n1 = 0, n2 = 0;
     float gain = 0, level = 1.0f, rssi_cal = 0.0f;
+    bool tail_only = false;   // form 3: only the per-channel chain; its input = 25 ksps channel streams (qrl_chan_process_channels)
     bool xlat2 = false;   // form 2: N freq-xlating FIR decimators 1:N with the PFB prototype in front of the multi2 per-channel chain (BASELINE configs[3])
-    hipEvent_t ev_user = nullptr, ev_user2 = nullptr;
+    hipEvent_t ev_user = nullptr, ev_user2 = nullptr, ev_ext = nullptr;
     // the serial symbol-sync tail (64 waves for 4096 channel streams: latency bound) runs on its own stream so that it overlaps the
     // channelizer and the fused per-channel kernel of the NEXT call; ring r6 holds two calls, ev_tail[slot] guards its reuse
     hipStream_t tail = nullptr; hipEvent_t ev_ff = nullptr, ev_tail[2] = {nullptr, nullptr}; bool tail_valid[2] = {false, false}; uint64_t call_no = 0;
@@ -73,6 +74,7 @@ struct qrl_chan {
     size_t zeroed = 0;
     ~qrl_chan() { for (auto& e : prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
                   if (ev_user2) (void)hipEventDestroy(ev_user2);
+                  if (ev_ext) (void)hipEventDestroy(ev_ext);
                   if (ev_ff) (void)hipEventDestroy(ev_ff);
                   for (auto e : ev_tail) if (e) (void)hipEventDestroy(e);
                   if (tail) (void)hipStreamDestroy(tail);
@@ -105,10 +107,12 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     h->ctx = ctx; h->cfg = *cfg;
     qrl_chan_config& c = h->cfg;
     if (c.num_channels < 1 || c.num_channels > 64) return qrl_set_error(QRL_ERR_ARG, "num_channels must be 1..64");
-    if (c.form < 0 || c.form > 2) return qrl_set_error(QRL_ERR_ARG, "form must be 0 (PFB), 1 (legacy freq-xlating) or 2 (freq-xlating bank 1:N)");
+    if (c.form < 0 || c.form > 3) return qrl_set_error(QRL_ERR_ARG, "form must be 0 (PFB), 1 (legacy freq-xlating), 2 (freq-xlating bank 1:N) or 3 (per-channel chain only)");
     h->xlat = c.form == 1;
     h->xlat2 = c.form == 2;
-    h->single = c.num_channels == 1 && !h->xlat && !h->xlat2;
+    h->tail_only = c.form == 3;
+    if (h->tail_only) { c.num_channels = 1; c.channel_first = 0; c.channel_count = 1; }
+    h->single = c.num_channels == 1 && c.form == 0;
     if (c.channel_count <= 0) { c.channel_first = 0; c.channel_count = c.num_channels; }
     if (c.channel_first < 0 || c.channel_first + c.channel_count > c.num_channels) return qrl_set_error(QRL_ERR_ARG, "bad channel range");
     if (c.batch < 1 || c.max_chunk < (size_t)c.num_channels || (size_t)c.batch * c.channel_count > 65535)
@@ -266,7 +270,29 @@ int qrl_chan_set_4fsk_output(qrl_chan* h, uint8_t* bits, size_t bits_cap, float*
 }
 size_t qrl_chan_out_cap(const qrl_chan* h, size_t n) { return h ? (n / (h->xlat2 ? h->xl_D : h->M) + 2) * h->rs_I / h->rs_D + 2 : 0; }
 
+static int chan_process_impl(qrl_chan* h, const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts,
+                             float* chan_out, size_t chan_pitch, int chan_groups);
 int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts)
+{
+    if (!h || h->tail_only) return QRL_ERR_ARG;
+    return chan_process_impl(h, iq, stride, n, out, out_cap, counts, nullptr, 0, 0);
+}
+int qrl_chan_channelize(qrl_chan* h, const float* iq, size_t stride, size_t n, float* chan_out, size_t pitch, int groups)
+{
+    if (!h || !chan_out || groups < 1) return QRL_ERR_ARG;
+    if (h->single || h->xlat || h->xlat2 || h->tail_only) return qrl_set_error(QRL_ERR_ARG, "qrl_chan_channelize: PFB form (form 0, num_channels > 1) only");
+    if (h->cfg.channel_count % groups) return qrl_set_error(QRL_ERR_ARG, "qrl_chan_channelize: groups must divide the channel count");
+    if (pitch < n / (size_t)h->M) return qrl_set_error(QRL_ERR_ARG, "qrl_chan_channelize: pitch < n / num_channels");
+    return chan_process_impl(h, iq, stride, n, nullptr, 0, nullptr, chan_out, pitch, groups);
+}
+int qrl_chan_process_channels(qrl_chan* h, const float* chan_in, size_t pitch, size_t n1, int16_t* out, size_t out_cap, uint32_t* counts)
+{
+    if (!h || (!chan_in && n1)) return QRL_ERR_ARG;
+    if (!h->tail_only) return qrl_set_error(QRL_ERR_ARG, "qrl_chan_process_channels: form 3 handles only");
+    return chan_process_impl(h, chan_in, pitch, n1, out, out_cap, counts, nullptr, 0, 0);
+}
+static int chan_process_impl(qrl_chan* h, const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts,
+                             float* chan_out, size_t chan_pitch, int chan_groups)
 {
     if (!h || (!iq && n)) return QRL_ERR_ARG;
     if (n > h->cfg.max_chunk) return qrl_set_error(QRL_ERR_TOO_BIG, "n exceeds max_chunk");
@@ -281,6 +307,10 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
     float2* hist_new = h->flip ? h->hist_a.p : h->hist_b.p;
     // PFB: one output instant per M inputs; form 2: rational_resampler_ccf(1, N) -- output m exists once input m N does
     const uint64_t n1_1 = h->xlat2 ? (h->n_in + n - 1) / (uint64_t)h->xl_D + 1 : (h->n_in + n) / M;
+    if (h->tail_only) {
+        // form 3: the call's input ARE the channel samples (rows = channel streams): into the channel ring, then the per-channel chain
+        launch_ring_load(in, stride, RingC{h->r1.p, h->m1}, h->n1, (uint32_t)n, S, h->stream);
+    }
     if (h->rssi_out && h->rssi_counts) HIPCHK(hipMemsetAsync(h->rssi_counts, 0, (size_t)S * sizeof(uint32_t), h->stream));
     if (h->tail && h->tail_valid[h->call_no & 1]) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_tail[h->call_no & 1], 0));   // symbol sync of call k - 2 done: its half of ring r6 is free
     ChanParams p{};
@@ -290,16 +320,24 @@ int qrl_chan_process(qrl_chan* h, const float* iq, size_t stride, size_t n, int1
     p.legacy = h->opt_legacy_pfb;
     // the HBM-facing kernel(s) = whatever reads the caller's wideband IQ: the PFB, or the per-channel decimators of forms 1 / 2
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (h->profiling && !h->single) { HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1)); HIPCHK(hipEventRecord(ev0, h->stream)); }
-    if (!h->single && !h->xlat && !h->xlat2) {
+    if (h->profiling && !h->single && !h->tail_only) { HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1)); HIPCHK(hipEventRecord(ev0, h->stream)); }
+    if (chan_out) {   // qrl_chan_channelize: linear rows of chan_pitch items, grouped by destination rank
+        p.out = RingC{reinterpret_cast<float2*>(chan_out), 0}; p.out_pitch = chan_pitch; p.row_cpd = (uint32_t)(CC / chan_groups);
+    }
+    if (!h->single && !h->xlat && !h->xlat2 && !h->tail_only) {
         launch_pfb_chan(p, B, h->stream);
         if (ev1) { HIPCHK(hipEventRecord(ev1, h->stream)); h->prof_events.emplace_back(ev0, ev1); }
     }
     HistParams hp{};
     hp.in = in; hp.in_stride = stride; hp.n0 = h->n_in; hp.n = (uint32_t)n;
     hp.hist_old = hist_old; hp.hist_new = hist_new; hp.hist_len = h->hist_len; hp.rot_enable = 0;
-    launch_hist_save(hp, B, h->stream);
-    h->flip = !h->flip;
+    if (!h->tail_only) { launch_hist_save(hp, B, h->stream); h->flip = !h->flip; }
+    if (chan_out) {   // channelizer only: the per-channel chain runs on the rank that owns the channel (qrl_chan_process_channels there)
+        HIPCHK(hipGetLastError());
+        if (qrl::take_launch_error()) return QRL_ERR_HIP;
+        h->n_in += n; h->n1 = n1_1;
+        return QRL_OK;
+    }
     // per channel chain on S = batch * channel_count streams
     const uint64_t RI = (uint64_t)h->rs_I, RD = (uint64_t)h->rs_D;
     const uint64_t n2_1 = n1_1 ? ((n1_1 - 1) * RI + (RI - 1)) / RD + 1 : 0;   // outputs q with q*D/I <= n1_1 - 1
@@ -394,6 +432,14 @@ int qrl_chan_stream_wait(qrl_chan* h, void* hip_stream)
         HIPCHK(hipEventRecord(h->ev_user2, h->tail));
         HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), h->ev_user2, 0));
     }
+    return QRL_OK;
+}
+int qrl_chan_wait_for(qrl_chan* h, void* hip_stream)
+{
+    if (!h) return QRL_ERR_ARG;
+    if (!h->ev_ext) HIPCHK(hipEventCreateWithFlags(&h->ev_ext, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->ev_ext, static_cast<hipStream_t>(hip_stream)));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ext, 0));
     return QRL_OK;
 }
 void* qrl_chan_stream(qrl_chan* h) { return h ? h->stream : nullptr; }

@@ -97,18 +97,22 @@ std::vector<float2> to_f2(const std::vector<std::complex<float>>& v)
 }
 
 struct DecimStage {
-    bool used = false, mfma = false, pl = false;
+    bool used = false, mfma = false, pl = false, pm = false;
     int D = 1, Jpad = 0, variant = DECIM_R4_J12, nt = 0, S = 0;
     DevBuf<float> taps;
     DevBuf<float2> edge; uint32_t edge_len = 0;   // phase-lane kernels: per-stream scratch for the call's edge outputs
     int alloc_edge(int B) {
-        if (!pl) return QRL_OK;
-        edge_len = (uint32_t)decim_pl_edge_len(nt, D);
+        if (!pl && !pm) return QRL_OK;
+        edge_len = (uint32_t)(pm ? decim_pm_edge_len(nt, D) : decim_pl_edge_len(nt, D));
         return edge_len ? edge.alloc((size_t)B * edge_len) : QRL_OK;
     }
     int plan(const std::vector<float>& h, int D_) {
         used = true; D = D_; nt = (int)h.size();
-        if (decim_uses_pl(nt, D)) {   // register-resident phase-lane kernel (the 1:50 first stages)
+        if (decim_uses_pm(nt, D)) {   // phase-major matrix-pipe kernel (the 1:50 first stages)
+            pm = true;
+            return taps.upload(decim_pm_layout(h, D));
+        }
+        if (decim_uses_pl(nt, D)) {   // register-resident phase-lane kernel (the 100:1 front end)
             pl = true;
             return taps.upload(decim_pl_layout(h, D));
         }
@@ -132,9 +136,10 @@ struct DecimStage {
         if (decim_lds_bytes(D, Jpad, variant) > 160 * 1024) return QRL_ERR_ARG;
         return taps.upload(decim_layout(h, D, Jpad));
     }
-    uint32_t lookback() const { return pl ? (uint32_t)(((nt + D - 1) / D + 1) * D) : mfma ? (uint32_t)(nt + D) : (uint32_t)(Jpad * D); }
+    uint32_t lookback() const { return pm ? decim_pm_lookback(nt, D) : pl ? (uint32_t)(((nt + D - 1) / D + 1) * D) : mfma ? (uint32_t)(nt + D) : (uint32_t)(Jpad * D); }
     int launch(DecimParams& p, int B, hipStream_t s) const {
         p.nt = nt;
+        if (pm) { p.pl_taps = taps.p; p.pl_edge = edge.p; p.pl_edge_stride = edge_len; p.pl_edge_cap = edge_len; return launch_decim_pm(p, B, s); }
         if (pl) { p.pl_taps = taps.p; p.pl_edge = edge.p; p.pl_edge_stride = edge_len; p.pl_edge_cap = edge_len; return launch_decim_pl(p, B, s); }
         if (mfma) { p.gtab = taps.p; p.S = S; return launch_decim_mfma(p, B, s); }
         launch_decim(p, B, variant, s);
@@ -222,9 +227,6 @@ struct qrl_demod {
     int analog_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* out, uint32_t* counts, bool side);
     uint64_t n_in = 0, n1 = 0, n2 = 0;  // items so far: device rate, 1 Msps, target rate
     bool profiling = false;
-    // QRL_OPT_LEGACY_FRONTEND (default 1): phase-lane front ends with VGPR loads (k_decim_pl); 0 = the LDS-DMA variant k_decim_pl2.  Measured
-    // (profiles/r03_*): pl2 6.97 - 7.06 ms against 6.86 ms on C1 -- both are VALU bound (39 VALU per 50-sample block), the fetch path is not the limiter
-    bool legacy_fe = true;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
 
     ~qrl_demod() {
@@ -640,7 +642,6 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         p.out = r1; p.m0 = n1_0; p.m_count = (uint32_t)(n1_1 - n1_0);
         p.taps = fe.taps.p; p.D = fe.D; p.Jpad = fe.Jpad;
         p.rot_enable = 1; p.rot_acc = rot_acc; p.rot_inc = rot_inc; p.rot_nbase = rot_nbase; p.rot_lo = rot_lo.p;
-        p.pl_legacy = legacy_fe;
         if (fe.launch(p, B, stream)) return fail(QRL_ERR_HIP, "front-end launch: hipFuncSetAttribute failed");
     }
     if (profiling && fe.used) { HIPCHK(hipEventRecord(ev1, stream)); prof_events.emplace_back(ev0, ev1); }
@@ -655,7 +656,6 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         p.n0 = src0; p.n = (uint32_t)(src1 - src0);
         p.out = r2; p.m0 = n2_0; p.m_count = (uint32_t)(n2_1 - n2_0);
         p.taps = first.taps.p; p.D = first.D; p.Jpad = first.Jpad;
-        p.pl_legacy = legacy_fe;
         if (first.launch(p, B, stream)) return fail(QRL_ERR_HIP, "first-stage launch: hipFuncSetAttribute failed");
     } else {
         ResampParams p{};
@@ -1140,9 +1140,6 @@ int qrl_demod_set_option(qrl_demod* d, int option, int value)
         d->overlap = value != 0;
         d->tail2_valid[0] = d->tail2_valid[1] = false;
         return QRL_OK;
-    case QRL_OPT_LEGACY_FRONTEND:
-        d->legacy_fe = value != 0;
-        return QRL_OK;
     default:
         return qrl_set_error(QRL_ERR_ARG, "unknown option");
     }
@@ -1215,7 +1212,7 @@ int qrl_demod_profile_read(qrl_demod* d, double* kernel_ms, uint64_t* launches, 
     if (launches) *launches = d->prof_events.size();
     if (kernel_name) {
         const DecimStage& st = d->fe.used ? d->fe : d->first;
-        *kernel_name = (d->fe.used || d->interp == 1) ? (st.pl ? (st.D > 64 ? "k_decim_plx" : "k_decim_pl") : st.mfma ? "k_decim_mfma" : "k_decim") : "k_resamp";
+        *kernel_name = (d->fe.used || d->interp == 1) ? (st.pm ? "k_decim_pm" : st.pl ? "k_decim_plx" : st.mfma ? "k_decim_mfma" : "k_decim") : "k_resamp";
     }
     d->prof_events.clear();
     return QRL_OK;

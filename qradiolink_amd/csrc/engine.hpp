@@ -44,7 +44,6 @@ struct DecimParams {
     // edge segment (outputs whose window starts in front of this call's buffer): per-stream scratch of ROTATED samples (carried
     // history + head of the buffer), one extra unit per stream behind the regular ones reads it with identity phasors
     float2* pl_edge; uint32_t pl_edge_stride, pl_edge_cap; uint64_t pl_edge_ms, pl_edge_me;
-    int pl_legacy;                                          // 1: k_decim_pl with VGPR loads instead of the LDS-DMA kernel k_decim_pl2 (QRL_OPT_LEGACY_FRONTEND)
 };
 struct HistParams {
     const float2* in; size_t in_stride; uint64_t n0; uint32_t n;
@@ -70,6 +69,12 @@ bool decim_uses_pl(int nt, int D);
 size_t decim_pl_edge_len(int nt, int D);   // samples of edge scratch per stream (0: geometry without the register kernel)
 std::vector<float> decim_pl_layout(const std::vector<float>& h, int D);
 int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s);
+// phase-major matrix-pipe decimator (32 < D <= 52, <= 16 taps per phase): contract "pm" of oracle/orc_blocks.c
+bool decim_uses_pm(int nt, int D);
+size_t decim_pm_edge_len(int nt, int D);
+uint32_t decim_pm_lookback(int nt, int D);
+std::vector<float> decim_pm_layout(const std::vector<float>& h, int D);
+int launch_decim_pm(const DecimParams& p, int batch, hipStream_t s);
 
 // ---- K2: rational resampler I/D on a ring (optionally with rotator on a caller buffer) ----
 struct ResampParams {
@@ -201,7 +206,7 @@ struct ChanParams {
     const float* taps; const float2* twiddle;                      // taps[p + M k] zero padded to J*M; W[q] = e^{+j 2 pi q / M}
     int M, J, c_first, c_count;
     int legacy;                 // 1: the general-M kernel also for M = 64 (qrl_chan_set_option(QRL_CHAN_OPT_LEGACY_PFB): A/B and tests)
-    // k_pfb_chan64 only.  row_cpd > 0: output rows grouped by destination rank -- row = ((cc / row_cpd) * batch + b) * row_cpd + cc % row_cpd
+    // row_cpd > 0: output rows grouped by destination rank -- row = ((cc / row_cpd) * batch + b) * row_cpd + cc % row_cpd
     // (the send layout of an all-to-all that gives rank r the channels [r row_cpd, (r + 1) row_cpd) of every stream);
     // out_pitch > 0: linear rows of out_pitch items, item m - m0 (a caller buffer instead of an engine ring)
     uint32_t row_cpd; size_t out_pitch;
@@ -226,6 +231,7 @@ bool chan_tail_supported(int rs_I, int rs_D, int rs_Jp, int filt_nt, int rrc_nt)
 std::vector<float> chan_tail_tables(int which, const float* taps);   // 0: resampler (phase-major taps [24][35]), 1: channel filter, 2: RRC
 uint32_t chan_tail_lookback();
 void launch_pfb_chan(const ChanParams& p, int batch, hipStream_t s);
+void launch_ring_load(const float2* in, size_t pitch, RingC out, uint64_t q0, uint32_t count, int rows, hipStream_t s);
 void launch_f2s(const F2sParams& p, int batch, hipStream_t s);
 size_t chan_lds_bytes(int M, int J);
 // ---- multi-carrier MMDVM TX (kernels_chan.hip) ----

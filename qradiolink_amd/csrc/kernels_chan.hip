@@ -14,6 +14,15 @@ namespace qrl {
 
 constexpr int CH_TI = 64;   // output instants per workgroup
 
+// where channel cc (relative to c_first) of stream b, output instant m goes: an engine ring row, or (out_pitch > 0) a linear caller
+// buffer; row_cpd > 0 groups the rows by destination rank for an all-to-all (engine.hpp ChanParams)
+__device__ __forceinline__ float2* chan_out_addr(const ChanParams& P, int b, int nbatch, int cc, uint64_t m)
+{
+    const size_t rowi = P.row_cpd ? ((size_t)(cc / (int)P.row_cpd) * nbatch + b) * P.row_cpd + (cc % (int)P.row_cpd) : (size_t)b * P.c_count + cc;
+    const size_t col = P.out_pitch ? (size_t)(m - P.m0) : (size_t)((uint32_t)m & P.out.mask);
+    return P.out.p + rowi * (P.out_pitch ? P.out_pitch : (size_t)P.out.mask + 1u) + col;
+}
+
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 template <int STEPS>   // STEPS = M / 4 when M is a multiple of 16 (MFMA DFT), 0 = any M (VALU DFT)
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(256) void k_pfb_chan(const ChanParams P)
                 for (int r = 0; r < 4; ++r) {
                     const int bin = 16 * qb + 4 * k4 + r, cc = bin - P.c_first;
                     if (cc >= 0 && cc < P.c_count)
-                        P.out.p[((size_t)b * P.c_count + cc) * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = make_float2(sa[r] - sb[r], sc[r] + sd[r]);
+                        *chan_out_addr(P, b, gridDim.y, cc, m) = make_float2(sa[r] - sb[r], sc[r] + sd[r]);
                 }
             }
         }
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(256) void k_pfb_chan(const ChanParams P)
                 q += c; if (q >= M) q -= M;
             }
             const uint64_t m = m_t + i;
-            P.out.p[((size_t)b * P.c_count + cc) * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = make_float2(sa - sb, sc + sd);
+            *chan_out_addr(P, b, gridDim.y, cc, m) = make_float2(sa - sb, sc + sd);
         }
     }
 }
@@ -223,15 +232,25 @@ __global__ __launch_bounds__(256, 3) void k_pfb_chan64(const ChanParams P)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int bin = 16 * qb + 4 * k4 + r, cc = bin - P.c_first;
-                    if (cc >= 0 && cc < P.c_count) {
-                        const size_t rowi = P.row_cpd ? ((size_t)(cc / P.row_cpd) * gridDim.y + b) * P.row_cpd + (cc % P.row_cpd) : (size_t)b * P.c_count + cc;
-                        const size_t col = P.out_pitch ? (size_t)(m - P.m0) : (size_t)((uint32_t)m & P.out.mask);
-                        P.out.p[rowi * (P.out_pitch ? P.out_pitch : (size_t)P.out.mask + 1u) + col] = make_float2(sa[r] - sb[r], sc[r] + sd[r]);
-                    }
+                    if (cc >= 0 && cc < P.c_count) *chan_out_addr(P, b, gridDim.y, cc, m) = make_float2(sa[r] - sb[r], sc[r] + sd[r]);
                 }
             }
         }
     }
+}
+// caller buffer [rows][pitch] -> engine ring rows at absolute items [q0, q0 + count): how the per-channel-only handle (form 3) takes
+// the channel samples an all-to-all delivered
+__global__ __launch_bounds__(256) void k_ring_load(const float2* in, size_t pitch, RingC out, uint64_t q0, uint32_t count)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= count) return;
+    const int r = blockIdx.y;
+    out.p[(size_t)r * (out.mask + 1u) + ((uint32_t)(q0 + t) & out.mask)] = in[(size_t)r * pitch + t];
+}
+void launch_ring_load(const float2* in, size_t pitch, RingC out, uint64_t q0, uint32_t count, int rows, hipStream_t s)
+{
+    if (!count) return;
+    hipLaunchKernelGGL(k_ring_load, dim3((count + 255) / 256, rows), dim3(256), 0, s, in, pitch, out, q0, count);
 }
 size_t chan64_lds_bytes(int J) { return (size_t)((C64_TI + J - 1) * 64 + 2 + C64_TI * C64_VP + 64) * sizeof(float2); }
 

@@ -31,9 +31,8 @@
 namespace qrl {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float f32x4_pm __attribute__((ext_vector_type(4)));
 
-constexpr int PL_RING = 16;        // accumulator ring = unroll factor of the block loop
-constexpr int PL_PF = 8;           // blocks in flight per wave
 
 __device__ __forceinline__ float pl_dpp_ror8(float v)
 {
@@ -109,141 +108,41 @@ __device__ __forceinline__ int pl_out_index(int lane)
     return ((row & 1) << 1 | (row >> 1)) + ((bank & 1) << 3 | (bank >> 1) << 2);
 }
 
-template <int J>
-__global__ __launch_bounds__(256)
-void k_decim_pl(const DecimParams P_)
+// =====================================================================================================================================
+// k_decim_pm — the 1:D first stages with 32 < D <= 64 (the 1:50, 419-tap stage of gr_demod_2fsk / gmsk / 4fsk / bpsk = the C1 front end)
+// as a PHASE-MAJOR product on the f32 matrix pipe.  Contract "pm" (oracle/orc_blocks.c orc_decim_fir_ccf_pm).
+//
+// Why: the phase-lane kernel of rounds 1-2 (lane = polyphase branch, taps in registers, transposing butterfly) issued 39 VALU
+// instructions per 50-sample block -- 21 of them the tap FMAs -- and measured VALU bound (SQ_INSTS_VALU x 2 cycles = 64 % of the SIMD
+// cycles at 5.1 TB/s; routing the input through LDS-DMA rings changed nothing: 6.97 - 7.06 ms against 6.86 ms).  The tap work is a matrix
+// product: with the stream cut into blocks of D samples (block c = samples (c-1) D + 1 .. c D, a ROW of the input as it lies in
+// memory), Z[c][j] = sum_p x~[c][p] H[p][j], H[p][j] = h[j D + D - 1 - p], and y[m] = sum_j Z[m - j][j].  One
+// v_mfma_f32_16x16x4_f32 per 4 phases and component produces Z for 16 blocks x 16 block lags (J <= 16): 26 matrix instructions
+// per 800 samples replace 344 VALU, and the matrix pipe runs beside the VALU (rotator) work of the other waves.
+//   A operand = H^T (rows = block lag j, k = phase): 13 registers per lane, loaded once.
+//   B operand = x~^T (k = phase, columns = 16 consecutive blocks): lane (q = lane >> 4, n = lane & 15) holds sample 4 s + q of block n:
+//       read raw from the wave's LDS-DMA ring (ds_read_b64 at block stride 8 D bytes + 8 q: conflict free), rotated in registers
+//       (exact NCO tables in LDS, as before: 14 VALU per lane and step).
+//   D = Z (rows j, columns blocks): lane (q, n) holds Z[n][4 q + r], r = 0..3.  y[m] = sum_j Z[m - j][j] is a diagonal sum: DPP
+//       row_shr:j inside a 16-lane row moves Z[.][j] to its output's lane, row_shl:(16 - j) collects what belongs to the NEXT group of
+//       16 outputs (carried in a register), one v_permlane16_swap + one v_permlane32_swap fold the four lane rows (both components
+//       at once): 44 VALU per 16 outputs instead of 70.
+// Data path = the LDS-DMA ring of round 3's experiments (tools/ubench/stream_lds.hip: 7.07 TB/s for wave-private rings, non-temporal
+// 1 KiB pieces): a wave streams its segment through a private ring of 8 KiB; a group of 16 blocks (6400 bytes at D = 50) is copied
+// to registers as soon as it has landed, which frees its slots for the next pieces -- the ring is only the landing zone, ~7 KiB per
+// wave stay in flight.  No barrier in the loop; counted s_waitcnt vmcnt orders the DMA against the wave's own reads.
+// Groups sit on an ABSOLUTE grid (blocks 16 G .. 16 G + 15), so the value of output m depends on m alone (chunk invariance).
+// acc += (v moved by a DPP row shift) in the lanes of row q only; lanes whose source falls outside the row add +0 (bound_ctrl:0),
+// the other rows keep acc.  One v_add_f32_dpp (written as asm: the compiler keeps v_mov_b32_dpp + v_add_f32 apart).  The s_nop 1 in
+// front is the gfx9 hazard "VALU writes a VGPR, DPP reads it: 2 wait states" -- the hazard recogniser does not look inside asm.
+template <int SHR, int Q>   // SHR > 0: row_shr:SHR; SHR < 0: row_shl:-SHR; SHR == 0: no move
+__device__ __forceinline__ void pm_add_dpp(float& acc, float v)
 {
-    const DecimParams& P = P_;
-    __shared__ float2 t_lo[512];
-    __shared__ float2 t_one[512];
-    __shared__ float2 t_hi_all[4][64];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    t_lo[tid] = P.rot_lo[tid];
-    t_lo[tid + 256] = P.rot_lo[tid + 256];
-    t_one[tid] = make_float2(1.f, 0.f);
-    t_one[tid + 256] = make_float2(1.f, 0.f);
-
-    // unit = (stream, segment); the waves of a workgroup take neighbouring segments of one stream.  Behind the regular units:
-    // one EDGE unit per stream (outputs pl_edge_ms .. pl_edge_me out of the staged, already rotated scratch: identity phasors)
-    const uint32_t unit = blockIdx.x * 4u + (uint32_t)wave;
-    const uint32_t B = P.pl_batch;
-    const uint32_t nreg = P.pl_nseg * B;
-    const bool edge = unit >= nreg;
-    // consecutive units = consecutive segments of ONE stream: the resident waves then sweep a contiguous ~1 GB region instead of
-    // one 200 KB piece out of each of 5000 rows 2 MB apart (measured, C1: 6.85 ms on every run against 6.9 - 8.3 ms depending on
-    // where the process's input buffer happened to be mapped)
-    const uint32_t nsg = P.pl_nseg ? P.pl_nseg : 1u;
-    const uint32_t b = edge ? unit - nreg : unit / nsg, seg = edge ? 0u : unit - b * nsg;
-    const bool active = edge ? (b < B && P.pl_edge_me > P.pl_edge_ms) : true;
-    const int D = P.D;
-    const uint64_t ms = edge ? P.pl_edge_ms : P.pl_m_begin + (uint64_t)seg * P.pl_S;
-    const uint64_t me = edge ? P.pl_edge_me : (ms + P.pl_S < P.pl_m_end ? ms + P.pl_S : P.pl_m_end);
-    // block c = samples (c-1) D + 1 .. c D; the first block of the unit is ms - (J - 1) (edge units: may lie in front of the stream)
-    const int64_t c_first_s = (int64_t)ms - (int64_t)(J - 1);
-    const uint64_t c_first = (uint64_t)c_first_s;
-    const int64_t i_first_s = (c_first_s - 1) * (int64_t)D + 1;
-    const uint64_t i_first = (uint64_t)i_first_s;                    // regular units: >= n0 (the launcher only hands over interior outputs)
-    const uint32_t kb0 = edge ? 0u : (uint32_t)((i_first - P.rot_nbase) >> 9);
-    float2* t_hi = t_hi_all[wave];
-    if (active) t_hi[lane] = edge ? make_float2(1.f, 0.f) : sincos_turn(P.rot_acc + ((uint64_t)(kb0 + (uint32_t)lane) << 9) * P.rot_inc);
-    const float2* tl = edge ? t_one : t_lo;
-    __syncthreads();
-    if (!active) return;
-
-    float h[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) h[j] = P.pl_taps[j * 64 + lane];
-    const int lo = lane < D ? lane : D - 1;                          // idle lanes re-read the last sample against zero taps
-    const int nblk = (int)(me - ms) + J - 1;
-    const float2* ub = edge ? P.pl_edge + (size_t)b * P.pl_edge_stride : P.in + (size_t)b * P.in_stride + (size_t)(i_first - P.n0);   // wave-uniform
-    const uint32_t k0 = edge ? 0u : (uint32_t)(i_first - P.rot_nbase) - (kb0 << 9);   // < 512
-    const uint32_t lo8 = (uint32_t)lo * 8u;
-    const bool hi8 = lane & 8, hi4 = lane & 4;
-    const bool leader = (lane & 3) == 0;
-    const int oidx = pl_out_index(lane);
-    float2* orow = P.out.p + ((size_t)b * (P.out_row_mul_m1 + 1u) + P.out_row_add) * (P.out.mask + 1u);
-
-    v2f pf[PL_PF];
-#pragma unroll
-    for (int q = 0; q < PL_PF; ++q) {
-        const int t = q < nblk ? q : nblk - 1;
-        const float2 v = ub[(size_t)t * D + lo];
-        pf[q] = v2f{v.x, v.y};
-    }
-    float ar[PL_RING], ai[PL_RING];
-#pragma unroll
-    for (int s = 0; s < PL_RING; ++s) ar[s] = ai[s] = 0.f;
-
-    constexpr int UB = PL_PF > PL_RING ? PL_PF : PL_RING;   // blocks per loop body (multiple of both rings)
-    const int nsup = (nblk + UB - 1) / UB;
-    for (int sup = 0; sup < nsup; ++sup) {
-#pragma unroll
-        for (int grp = 0; grp < UB / PL_RING; ++grp) {
-            float dr[PL_RING], di[PL_RING];
-#pragma unroll
-            for (int i = 0; i < PL_RING; ++i) {
-                const int u = grp * PL_RING + i;
-                const int t = sup * UB + u;
-                const v2f xr = pf[u % PL_PF];
-                {   // keep PL_PF blocks in flight (past the end of the segment: harmless re-read of its last block)
-                    const int tn = t + PL_PF < nblk ? t + PL_PF : nblk - 1;
-                    const float2 v = ub[(size_t)tn * D + lo];
-                    pf[u % PL_PF] = v2f{v.x, v.y};
-                }
-                // rotator: phasor of sample k = T_hi[k >> 9] (x) T_lo[k & 511], byte addressed
-                const uint32_t kb8 = (k0 + (uint32_t)t * (uint32_t)D) * 8u + lo8;
-                const float2 plo = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(tl) + (kb8 & 4095u));
-                const float2 phi = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(t_hi) + ((kb8 >> 9) & ~7u));
-                const float2 xs = cmul_fma(make_float2(xr.x, xr.y), cmul_fma(phi, plo));
-                // scatter into the ring: output m = c + j takes tap h[p + j D]; its first term (j = J - 1) is a plain product
-#pragma unroll
-                for (int j = 0; j < J - 1; ++j) {
-                    ar[(i + j) % PL_RING] = fmaf(h[j], xs.x, ar[(i + j) % PL_RING]);
-                    ai[(i + j) % PL_RING] = fmaf(h[j], xs.y, ai[(i + j) % PL_RING]);
-                }
-                ar[(i + J - 1) % PL_RING] = h[J - 1] * xs.x;
-                ai[(i + J - 1) % PL_RING] = h[J - 1] * xs.y;
-                dr[i] = ar[i]; di[i] = ai[i];
-            }
-            const float yr = pl_reduce16(dr, hi8, hi4), yi = pl_reduce16(di, hi8, hi4);
-            const uint64_t m = c_first + (uint64_t)(sup * UB + grp * PL_RING + oidx);
-            if (leader && m >= ms && m < me) orow[(uint32_t)m & P.out.mask] = make_float2(yr, yi);
-        }
-    }
+    if constexpr (SHR == 0) asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %0 quad_perm:[0,1,2,3] row_mask:%2 bank_mask:0xf bound_ctrl:0" : "+v"(acc) : "v"(v), "n"(1 << Q));
+    else if constexpr (SHR > 0) asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %0 row_shr:%3 row_mask:%2 bank_mask:0xf bound_ctrl:0" : "+v"(acc) : "v"(v), "n"(1 << Q), "n"(SHR));
+    else asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %0 row_shl:%3 row_mask:%2 bank_mask:0xf bound_ctrl:0" : "+v"(acc) : "v"(v), "n"(1 << Q), "n"(-SHR));
 }
-
-// ---- k_decim_pl2: the same kernel with the input routed HBM -> LDS by LDS-DMA ------------------------------------------------------
-// k_decim_pl reads each 400-byte block with one global_load_dwordx2 per wave: 50 lanes x 8 bytes, four or five 128-byte lines touched for
-// 3.1 lines of data, partial lines requested twice.  That request stream -- not HBM -- capped it at 5.1 TB/s (tools/ubench/
-// stream_patterns: 5.27 TB/s for exactly this pattern).  Measured with tools/ubench/stream_lds.hip (round 3): a wave that streams
-// its segment as 1 KiB LDS-DMA pieces (global_load_lds_dwordx4, 64 lanes x 16 bytes, whole lines) into a PRIVATE ring of 8 KiB with
-// 4 pieces in flight, non-temporal policy, reaches 7.07 TB/s at 16-20 waves per CU -- with 20 FMAs per sample beside it.
-//   * ring = 8 pieces of 1 KiB per wave; piece q of the wave's byte stream (a0 + 1024 q, a0 = segment start rounded down to 128 bytes
-//     relative to the stream's row) lands at ring offset (1024 q) mod 8192.  No barrier anywhere: the wave that issued a piece is the
-//     only one that reads it, ordered by its own counted s_waitcnt vmcnt.
-//   * every group of 4 blocks (1600 bytes) tops the DMA queue up to need + 4 pieces, need = pieces that cover the group; then
-//     s_waitcnt vmcnt(4): at most the 4 pieces YOUNGER than the last needed one are outstanding (stores in between only make the
-//     wait stricter), so everything the group reads has landed.  The ring never holds more than 4 + 3 live pieces.
-//   * lane l reads its sample of block t with one ds_read_b64 at (o0 + 400 t + 8 l) mod 8192: lane-contiguous, conflict free.
-// Everything behind the sample fetch -- rotator, tap scatter, accumulator ring, transposing reduction -- is k_decim_pl's: the "pl"
-// summation contract is untouched, results are bit-identical.
-#ifndef QRL_PL2_PD
-#define QRL_PL2_PD 6
-#endif
-#ifndef QRL_PL2_G
-#define QRL_PL2_G 2
-#endif
-#ifndef QRL_PL2_RP
-#define QRL_PL2_RP 8
-#endif
-constexpr int PL2_RP = QRL_PL2_RP;     // ring pieces (1 KiB each) per wave (power of two): the ring is aligned to its size in LDS
-constexpr int PL2_PD = QRL_PL2_PD;     // pieces in flight behind the last needed one
-constexpr int PL2_G = QRL_PL2_G;       // blocks per DMA top-up / wait group (divides PL_RING)
-// a group of G blocks of <= 512 bytes spans at most ceil((1023 + 512 G) / 1024) pieces; the ring holds them + the PD pieces in flight
-static_assert((PL2_RP & (PL2_RP - 1)) == 0 && PL_RING % PL2_G == 0 && PL2_PD + (1023 + 512 * PL2_G + 1023) / 1024 <= PL2_RP, "ring too small for the group / depth");
-
-__device__ __forceinline__ void pl2_glds16(const void* gsrc, uint32_t lds_dst)
+__device__ __forceinline__ void pm_glds16(const void* gsrc, uint32_t lds_dst)
 {
     // one LDS-DMA piece, non-temporal: 64 lanes x 16 B from per-lane global addresses to LDS[lds_dst + 16 lane].  M0 (compiler
     // reserved) is saved and restored inside the statement (cdna_hip_programming.md, "LDS-DMA recipe")
@@ -251,28 +150,68 @@ __device__ __forceinline__ void pl2_glds16(const void* gsrc, uint32_t lds_dst)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
-typedef const __attribute__((address_space(3))) v2f* pl2_lds_f2;
-__device__ __forceinline__ float2 pl2_lds(uint32_t addr)   // ds_read_b64 from a raw LDS byte address
+typedef const __attribute__((address_space(3))) v2f* pm_lds_f2;
+__device__ __forceinline__ float2 pm_lds(uint32_t addr)   // ds_read_b64 from a raw LDS byte address
 {
-    const v2f v = *(pl2_lds_f2)(uintptr_t)addr;
+    const v2f v = *(pm_lds_f2)(uintptr_t)addr;
     return make_float2(v.x, v.y);
 }
+__device__ __forceinline__ uint32_t pm_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
+template <int N> __device__ __forceinline__ void pm_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void pm_wait_vm_dyn(uint32_t allowed)   // wave uniform; at most `allowed` DMA pieces may still be in flight
+{
+    switch (allowed) {
+    case 0: pm_wait_vm<0>(); break;   case 1: pm_wait_vm<1>(); break;   case 2: pm_wait_vm<2>(); break;   case 3: pm_wait_vm<3>(); break;
+    case 4: pm_wait_vm<4>(); break;   case 5: pm_wait_vm<5>(); break;   case 6: pm_wait_vm<6>(); break;   case 7: pm_wait_vm<7>(); break;
+    case 8: pm_wait_vm<8>(); break;   case 9: pm_wait_vm<9>(); break;   case 10: pm_wait_vm<10>(); break; case 11: pm_wait_vm<11>(); break;
+    case 12: pm_wait_vm<12>(); break; case 13: pm_wait_vm<13>(); break; case 14: pm_wait_vm<14>(); break; default: pm_wait_vm<15>(); break;
+    }
+}
 
-__device__ __forceinline__ uint32_t pl2_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
+// diagonal sums of one matrix result: R += in-group terms, C += the terms that belong to the next group (both per lane row)
+template <int J, int JJ>
+__device__ __forceinline__ void pm_diag(const f32x4_pm& z, float& R, float& C)
+{
+    if constexpr (JJ < J) {
+        constexpr int q = JJ >> 2, r = JJ & 3;
+        const float zz = z[r];
+        if constexpr (JJ == 0) pm_add_dpp<0, 0>(R, zz);
+        else {
+            pm_add_dpp<JJ, q>(R, zz);             // row_shr:JJ -> the output's lane inside this group
+            pm_add_dpp<-(16 - JJ), q>(C, zz);     // row_shl:16-JJ -> the output's lane in the NEXT group
+        }
+        pm_diag<J, JJ + 1>(z, R, C);
+    }
+}
 
-template <int J>
+#ifndef QRL_PM_ABL
+#define QRL_PM_ABL 0   // developer builds only (tools/pl_variants.sh): bit 0 no output store, bit 1 no rotator, bit 2 no MFMA, bit 3 no diagonal sums (wrong results; timing ablations)
+#endif
+#ifdef QRL_PM_PROF
+// developer build (tools/pl_variants.sh -DQRL_PM_PROF): shader-clock ticks per phase of the group loop, summed over every wave
+__device__ unsigned long long g_pm_prof[8];
+#define PM_STAMP(k) do { const unsigned long long tn_ = __builtin_readcyclecounter(); pc[k] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define PM_STAMP(k) do { } while (0)
+#endif
+template <int J, int NS, int RP>
 __global__ __launch_bounds__(256)
-void k_decim_pl2(const DecimParams P_)
+void k_decim_pm(const DecimParams P_)
 {
     const DecimParams& P = P_;
-    __shared__ __align__(PL2_RP * 1024) unsigned char ring_all[4 * PL2_RP * 1024];   // ring of wave w at LDS byte w * ring size (+ a multiple of it)
-    __shared__ float2 t_lo[512];            // fine rotator table; entry 0 is exactly (1, 0): what edge units read through index mask 0
-    __shared__ float2 t_hi_all[4][64];      // coarse rotator table of each wave's segment
+    // dynamic LDS (the kernel has no static allocation, so it starts at LDS byte 0): rings first -- ring of wave w at byte w * ring
+    // size, which the address arithmetic below relies on --, then the tables
+    extern __shared__ __align__(16) unsigned char pm_smem[];
+    unsigned char* ring_all = pm_smem;
+    float2* t_lo = reinterpret_cast<float2*>(pm_smem + 4 * RP * 1024);            // fine rotator table; entry 0 is exactly (1, 0): what edge units read through index mask 0
+    float2 (*t_hi_all)[64] = reinterpret_cast<float2 (*)[64]>(t_lo + 512);        // coarse rotator table of each wave's segment
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     t_lo[tid] = P.rot_lo[tid];
     t_lo[tid + 256] = P.rot_lo[tid + 256];
 
+    // unit = (stream, segment); behind the regular units one EDGE unit per stream (outputs pl_edge_ms .. pl_edge_me out of the staged,
+    // already rotated scratch: identity phasors)
     const uint32_t unit = blockIdx.x * 4u + (uint32_t)wave;
     const uint32_t B = P.pl_batch;
     const uint32_t nreg = P.pl_nseg * B;
@@ -283,103 +222,194 @@ void k_decim_pl2(const DecimParams P_)
     const int D = P.D;
     const uint64_t ms = edge ? P.pl_edge_ms : P.pl_m_begin + (uint64_t)seg * P.pl_S;
     const uint64_t me = edge ? P.pl_edge_me : (ms + P.pl_S < P.pl_m_end ? ms + P.pl_S : P.pl_m_end);
-    const int64_t c_first_s = (int64_t)ms - (int64_t)(J - 1);
-    const uint64_t c_first = (uint64_t)c_first_s;
-    const int64_t i_first_s = (c_first_s - 1) * (int64_t)D + 1;
+    // absolute 16-block groups: the first one holds block ms - (J - 1), the oldest block output ms needs
+    const int64_t cfs = (int64_t)ms - (J - 1);
+    const int64_t G0 = cfs >= 0 ? cfs / 16 : -((-cfs + 15) / 16);
+    const int ngrp = active ? (int)((int64_t)((me - 1) / 16) - G0) + 1 : 0;
+    const int64_t i_first_s = (G0 * 16 - 1) * (int64_t)D + 1;        // first sample of block 16 G0 (regular units: >= n0; edge units: the scratch starts here)
     const uint64_t i_first = (uint64_t)i_first_s;
     const uint32_t kb0 = edge ? 0u : (uint32_t)((i_first - P.rot_nbase) >> 9);
     if (active) t_hi_all[wave][lane] = edge ? make_float2(1.f, 0.f) : sincos_turn(P.rot_acc + ((uint64_t)(kb0 + (uint32_t)lane) << 9) * P.rot_inc);
     __syncthreads();
     if (!active) return;
 
-    float h[J];
+    float a[NS];                                                     // A operand: H[p = 4 s + (lane >> 4)][j = lane & 15]
 #pragma unroll
-    for (int j = 0; j < J; ++j) h[j] = P.pl_taps[j * 64 + lane];
-    const int lo = lane < D ? lane : D - 1;                          // idle lanes re-read the last sample against zero taps
-    const int nblk = (int)(me - ms) + J - 1;
-    // the wave's byte stream: row = the stream's buffer (or its edge scratch), first byte of block 0 at row + off0
+    for (int s = 0; s < NS; ++s) a[s] = P.pl_taps[s * 64 + lane];
+    const int q = lane >> 4, nn = lane & 15;
+    // the wave's byte stream: row = the stream's buffer (or its edge scratch), first byte of block 16 G0 at row + off0
     const unsigned char* rowp = reinterpret_cast<const unsigned char*>(edge ? P.pl_edge + (size_t)b * P.pl_edge_stride : P.in + (size_t)b * P.in_stride);
     const uint64_t off0 = edge ? 0ull : (uint64_t)(i_first - P.n0) * 8ull;
     const uint64_t row_bytes = edge ? (uint64_t)P.pl_edge_stride * 8ull : (uint64_t)P.n * 8ull;   // multiples of 16 (even sample counts)
-    const uint32_t o0 = (uint32_t)(off0 & 127u);                     // offset of block 0 inside piece 0
+    const uint32_t o0 = (uint32_t)(off0 & 127u);                     // offset of the first block inside piece 0
     const uint64_t a_off = off0 - o0;                                // piece 0 starts here (128-byte aligned relative to the row)
-    const uint32_t bpb = (uint32_t)D * 8u;                           // bytes per block
-    const uint32_t npieces = (o0 + (uint32_t)nblk * bpb + 1023u) >> 10;
-    // pieces [0, q_safe) lie inside the row; the lanes of later pieces are clamped to the row's last 16 bytes (never consumed)
-    const uint32_t q_safe = (uint32_t)((row_bytes - a_off) >> 10);
-    const uint32_t rbase = pl2_lds_addr(ring_all) + (uint32_t)wave * (PL2_RP * 1024u);   // multiple of the ring size
-    const uint32_t tlo_base = pl2_lds_addr(t_lo);
-    const uint32_t thi_base = pl2_lds_addr(t_hi_all) + (uint32_t)wave * 512u;
+    const uint32_t GB = 16u * (uint32_t)D * 8u;                      // bytes per group
+    const uint32_t npieces = (o0 + (uint32_t)ngrp * GB + 1023u) >> 10;
+    const uint32_t q_safe = (uint32_t)((row_bytes - a_off) >> 10);   // pieces [0, q_safe) lie inside the row; later ones are clamped to its last 16 bytes (never consumed)
+    const uint32_t rbase = pm_lds_addr(ring_all) + (uint32_t)wave * (RP * 1024u);   // multiple of the ring size
+    const uint32_t tlo_base = pm_lds_addr(t_lo);
+    const uint32_t thi_base = pm_lds_addr(t_hi_all) + (uint32_t)wave * 512u;
     const unsigned char* gp = rowp + a_off + (size_t)lane * 16;      // this lane's 16 bytes of the next piece
     const unsigned char* last16 = rowp + row_bytes - 16;
     uint32_t issued = 0;
     auto issue_upto = [&](uint32_t want) {                           // wave uniform
         while (issued < want) {
-            const uint32_t dst = rbase + (issued & (PL2_RP - 1)) * 1024u;
-            if (issued < q_safe) pl2_glds16(gp, dst);
-            else pl2_glds16(gp < last16 ? gp : last16, dst);
+            const uint32_t dst = rbase + (issued & (RP - 1)) * 1024u;
+            if (issued < q_safe) pm_glds16(gp, dst);
+            else pm_glds16(gp < last16 ? gp : last16, dst);
             gp += 1024;
             ++issued;
         }
     };
     const uint32_t k0 = edge ? 0u : (uint32_t)(i_first - P.rot_nbase) - (kb0 << 9);   // < 512
-    const uint32_t lo8 = (uint32_t)lo * 8u;
     const uint32_t tl_mask = edge ? 0u : 4095u;
-    uint32_t xa = rbase | ((o0 + lo8) & (PL2_RP * 1024u - 1u));     // LDS address of this lane's sample of the current block
-    uint32_t kb8 = k0 * 8u + lo8;                                    // 8 x (NCO index of that sample, relative to the coarse table)
-    const bool hi8 = lane & 8, hi4 = lane & 4;
-    const bool leader = (lane & 3) == 0;
-    const int oidx = pl_out_index(lane);
+    const uint32_t lane_byte = ((uint32_t)nn * (uint32_t)D + (uint32_t)q) * 8u;      // this lane's sample of step 0 inside a group
+    const bool last_valid = 4 * (NS - 1) + q < D;                    // step NS - 1 reaches past the block for the upper lane rows
     float2* orow = P.out.p + ((size_t)b * (P.out_row_mul_m1 + 1u) + P.out_row_add) * (P.out.mask + 1u);
+    float Cr = 0.f, Ci = 0.f;                                        // carry of the previous group, per lane row
 
-    float ar[PL_RING], ai[PL_RING];
-#pragma unroll
-    for (int s = 0; s < PL_RING; ++s) ar[s] = ai[s] = 0.f;
-
-    const int nsup = (nblk + PL_RING - 1) / PL_RING;
-    uint32_t need_bytes = o0 + 1023u;                                // (bytes up to the end of the current group) + 1023
-    for (int sup = 0; sup < nsup; ++sup) {
-        float dr[PL_RING], di[PL_RING];
-#pragma unroll
-        for (int grp = 0; grp < PL_RING / PL2_G; ++grp) {
-            {   // pieces that cover the blocks of this group (clamped to the segment), + PL2_PD in flight behind them
-                need_bytes += (uint32_t)PL2_G * bpb;
-                uint32_t need = need_bytes >> 10;
-                need = need < npieces ? need : npieces;
-                const uint32_t want = need + PL2_PD < npieces ? need + PL2_PD : npieces;   // never past the segment's last piece
-                // the slots refilled now were last read a group ago: those ds_reads have been issued (program order, "memory"
-                // clobber) -- make sure they have also RETURNED before a DMA can overwrite them
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                issue_upto(want);
-                if (want - need == PL2_PD) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PL2_PD) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the last groups of a segment
-            }
-#pragma unroll
-            for (int ii = 0; ii < PL2_G; ++ii) {
-                const int i = grp * PL2_G + ii;
-                const float2 xr = pl2_lds(xa);
-                // rotator: phasor of sample k = T_hi[k >> 9] (x) T_lo[k & 511], byte addressed
-                const float2 plo = pl2_lds(tlo_base + (kb8 & tl_mask));
-                const float2 phi = pl2_lds(thi_base + ((kb8 >> 12) << 3));
-                xa = ((xa + bpb) & (PL2_RP * 1024u - 1u)) | rbase;
-                kb8 += bpb;
-                const float2 xs = cmul_fma(xr, cmul_fma(phi, plo));
-#pragma unroll
-                for (int j = 0; j < J - 1; ++j) {
-                    ar[(i + j) % PL_RING] = fmaf(h[j], xs.x, ar[(i + j) % PL_RING]);
-                    ai[(i + j) % PL_RING] = fmaf(h[j], xs.y, ai[(i + j) % PL_RING]);
-                }
-                ar[(i + J - 1) % PL_RING] = h[J - 1] * xs.x;
-                ai[(i + J - 1) % PL_RING] = h[J - 1] * xs.y;
-                dr[i] = ar[i]; di[i] = ai[i];
-            }
+#ifdef QRL_PM_PROF
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+#endif
+    issue_upto(npieces < RP ? npieces : RP);                         // (piece 0 is the first piece of group 0)
+    uint32_t gbytes = o0;                                            // byte offset of the current group in the wave's stream
+    uint32_t kb8 = (k0 * 8u) + lane_byte;                            // 8 x NCO index (relative to the coarse table) of this lane's step-0 sample
+    for (int g = 0; g < ngrp; ++g) {
+        {   // everything up to the end of this group must have landed; younger pieces may stay in flight
+            uint32_t need = (gbytes + GB + 1023u) >> 10;
+            need = need < npieces ? need : npieces;
+            pm_wait_vm_dyn(issued - need);
         }
-        const float yr = pl_reduce16(dr, hi8, hi4), yi = pl_reduce16(di, hi8, hi4);
-        const uint64_t m = c_first + (uint64_t)(sup * PL_RING + oidx);
-        if (leader && m >= ms && m < me) orow[(uint32_t)m & P.out.mask] = make_float2(yr, yi);
+        PM_STAMP(0);
+        float2 x[NS];
+        {
+            const uint32_t xb = gbytes + lane_byte;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) x[s] = pm_lds(rbase | ((xb + 32u * (uint32_t)s) & (RP * 1024u - 1u)));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the group is in registers: its ring slots are free
+        PM_STAMP(1);
+        {
+            const uint32_t first_next = (gbytes + GB) >> 10;         // first piece the next group still needs
+            const uint32_t cap = first_next + RP;
+            issue_upto(cap < npieces ? cap : npieces);
+        }
+        PM_STAMP(2);
+        f32x4_pm zr = {0.f, 0.f, 0.f, 0.f}, zi = zr;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            // rotator: phasor of sample k = T_hi[k >> 9] (x) T_lo[k & 511], byte addressed
+            const uint32_t kk = kb8 + 32u * (uint32_t)s;
+#if QRL_PM_ABL & 2
+            float2 xs = x[s]; (void)kk;
+#else
+            const float2 plo = pm_lds(tlo_base + (kk & tl_mask));
+            const float2 phi = pm_lds(thi_base + ((kk >> 12) << 3));
+            float2 xs = cmul_fma(x[s], cmul_fma(phi, plo));
+#endif
+            if (s == NS - 1 && !last_valid) xs = make_float2(0.f, 0.f);   // phases >= D: zero taps AND zero samples
+#if QRL_PM_ABL & 4
+            zr[s & 3] = fmaf(a[s], xs.x, zr[s & 3]); zi[s & 3] = fmaf(a[s], xs.y, zi[s & 3]);
+#else
+            zr = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xs.x, zr, 0, 0, 0);
+            zi = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xs.y, zi, 0, 0, 0);
+#endif
+        }
+        PM_STAMP(3);
+        // y[16 G + n'] = sum_j Z[n' - j][j]: per lane row the in-group terms (R) and the terms for the next group (C), j ascending
+        float Rr = 0.f, Ri = 0.f, Cnr = 0.f, Cni = 0.f;
+#if QRL_PM_ABL & 8
+        Rr = zr[0] + zr[1] + zr[2] + zr[3]; Ri = zi[0] + zi[1] + zi[2] + zi[3];
+#else
+        pm_diag<J, 0>(zr, Rr, Cnr);
+        pm_diag<J, 0>(zi, Ri, Cni);
+#endif
+        const float Vr = Rr + Cr, Vi = Ri + Ci;
+        Cr = Cnr; Ci = Cni;
+        // fold the four lane rows: (V_0 + V_1) + (V_2 + V_3); rows 0 / 1 of the result = real / imaginary part of the 16 outputs
+        const auto w16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(Vr), __float_as_uint(Vi), false, false);
+        const float w = __uint_as_float(w16[0]) + __uint_as_float(w16[1]);
+        const auto w32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w), __float_as_uint(w), false, false);
+        const float y = __uint_as_float(w32[0]) + __uint_as_float(w32[1]);
+        const int64_t m = (G0 + g) * 16 + nn;
+#if QRL_PM_ABL & 1
+        if (y == 12345.678f) reinterpret_cast<float*>(orow)[0] = y;
+#else
+        if (lane < 32 && m >= (int64_t)ms && m < (int64_t)me)
+            reinterpret_cast<float*>(orow + ((uint32_t)m & P.out.mask))[q] = y;
+#endif
+        gbytes += GB;
+        kb8 += GB;
+        PM_STAMP(4);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be writing this wave's ring when the workgroup's LDS is handed on
+#ifdef QRL_PM_PROF
+    if (lane == 0) { for (int k = 0; k < 5; ++k) atomicAdd(&g_pm_prof[k], pc[k]); atomicAdd(&g_pm_prof[7], (unsigned long long)ngrp); }
+#endif
+    pm_wait_vm<0>();   // no DMA may still be writing this wave's ring when the workgroup's LDS is handed on
 }
+
+// Contract "pm", one THREAD per output with checked fetches: zero in front of the stream, carried (already rotated) history in front of
+// this call's buffer, the caller's buffer with the exact NCO, or an engine ring.  Call edges that do not fit the staged scratch, the
+// outputs behind the last whole block of a call, and the second-stage form (input = an engine ring).
+__global__ __launch_bounds__(256) void k_decim_pm_gen(const DecimParams P_, uint64_t m_first, uint32_t count)
+{
+    const DecimParams& P = P_;
+    const uint32_t o = blockIdx.x * 256u + threadIdx.x;
+    if (o >= count) return;
+    const int b = blockIdx.y;
+    const uint64_t m = m_first + o;
+    const int D = P.D, nt = P.nt, J = (nt + D - 1) / D;
+    const float2* inb = P.in ? P.in + (size_t)b * P.in_stride : nullptr;
+    const float2* hb = P.hist ? P.hist + (size_t)b * P.hist_len : nullptr;
+    const float2* rb = P.in_ring.p ? P.in_ring.p + (size_t)b * (P.in_ring.mask + 1u) : nullptr;
+    const uint64_t kk0 = P.n0 - P.rot_nbase;                     // NCO index of in[0]
+    uint64_t hi_blk = ~0ull;
+    float2 hi = make_float2(1.f, 0.f);
+    float Rr[4] = {0.f, 0.f, 0.f, 0.f}, Ri[4] = {0.f, 0.f, 0.f, 0.f}, Cr[4] = {0.f, 0.f, 0.f, 0.f}, Ci[4] = {0.f, 0.f, 0.f, 0.f};
+    const int np = (int)(m & 15u);
+    for (int j = 0; j < J; ++j) {
+        const int64_t c = (int64_t)m - j;
+        float zr = 0.f, zi = 0.f;
+        for (int p = 0; p < D; ++p) {
+            const int k = j * D + D - 1 - p;
+            const int64_t i = (c - 1) * (int64_t)D + 1 + p;
+            const float h = k < nt ? P.pl_hraw[k] : 0.f;
+            float2 x = make_float2(0.f, 0.f);
+            if (i >= 0) {
+                const uint64_t ui = (uint64_t)i;
+                if (inb) {
+                    if (ui >= P.n0) {
+                        const uint64_t rel = ui - P.n0;
+                        if (rel < P.n) {
+                            x = inb[rel];
+                            if (P.rot_enable) {
+                                const uint64_t kk = kk0 + rel;
+                                if ((kk >> 9) != hi_blk) { hi_blk = kk >> 9; hi = sincos_turn(P.rot_acc + (hi_blk << 9) * P.rot_inc); }
+                                x = cmul_fma(x, cmul_fma(hi, P.rot_lo[(uint32_t)kk & 511u]));
+                            }
+                        }
+                    } else {
+                        const uint64_t d = P.n0 - ui;
+                        if (d <= P.hist_len) x = hb[P.hist_len - (uint32_t)d];
+                    }
+                } else if (ui < P.n0 + P.n) {
+                    x = rb[(uint32_t)ui & P.in_ring.mask];
+                }
+            }
+            zr = fmaf(h, x.x, zr); zi = fmaf(h, x.y, zi);
+        }
+        const int qq = j >> 2;
+        if (j <= np) { Rr[qq] = Rr[qq] + zr; Ri[qq] = Ri[qq] + zi; }
+        else         { Cr[qq] = Cr[qq] + zr; Ci[qq] = Ci[qq] + zi; }
+    }
+    float Vr[4], Vi[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) { Vr[qq] = Rr[qq] + Cr[qq]; Vi[qq] = Ri[qq] + Ci[qq]; }
+    P.out.p[((size_t)b * (P.out_row_mul_m1 + 1u) + P.out_row_add) * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] =
+        make_float2((Vr[0] + Vr[1]) + (Vr[2] + Vr[3]), (Vi[0] + Vi[1]) + (Vi[2] + Vi[3]));
+}
+
 
 // ---- generalised geometry: E samples per lane and block, R outputs per block ------------------------------------------------------
 //  k_decim_plx<E, R, U>: the same register-resident scheme for the front ends whose decimation is not one sample per lane:
@@ -646,7 +676,7 @@ static PlGeom pl_geom(int nt, int D)
     g.E = (g.Dp + 63) / 64;
     g.U = (nt + g.Dp - 1) / D;
     g.Upad = g.U;
-    if (g.E == 1 && g.R == 1) g.ok = g.U <= 16;
+    if (g.E == 1 && g.R == 1) g.ok = false;   // 32 < D <= 64: the phase-major matrix-pipe kernel (decim_uses_pm) or the generic paths
     else if (g.E == 2 && g.R == 1) { g.ok = (D % 2) == 0 && g.U <= 42; g.Upad = 42; }   // (the front-end filters have 41.8 D taps: U = 42 for every D)
     else g.ok = false;
     g.WU = (g.Upad - 1) / g.R;
@@ -677,17 +707,6 @@ std::vector<float> decim_pl_layout(const std::vector<float>& h, int D)
             }
     for (int k = 0; k < nt; ++k) t[(size_t)g.Upad * g.E * 64 + k] = h[k];
     return t;
-}
-
-template <int J>
-static void pl_launch_main(const DecimParams& q, uint32_t units, hipStream_t s)
-{
-    // LDS-DMA variant whenever the byte stream of a unit can be cut into 16-byte pieces: rows 16-byte aligned with an even sample
-    // count (what qrl_demod_process demands of its callers; the edge scratch is built that way)
-    const bool dma_ok = !q.pl_legacy && q.in && (reinterpret_cast<uintptr_t>(q.in) & 15u) == 0 && (q.in_stride & 1u) == 0 && (q.n & 1u) == 0 &&
-                        (!q.pl_edge || ((reinterpret_cast<uintptr_t>(q.pl_edge) & 15u) == 0 && (q.pl_edge_stride & 1u) == 0));
-    if (dma_ok) hipLaunchKernelGGL((k_decim_pl2<J>), dim3((units + 3) / 4), dim3(256), 0, s, q);
-    else hipLaunchKernelGGL((k_decim_pl<J>), dim3((units + 3) / 4), dim3(256), 0, s, q);
 }
 
 int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)
@@ -736,31 +755,6 @@ int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)
     const uint64_t total = (m_tail - m_main) * (uint64_t)batch;
     q.pl_m_begin = m_main; q.pl_m_end = m_tail;
     q.pl_batch = (uint32_t)batch;
-    if (g.E == 1 && g.R == 1) {
-        // segment length: a multiple of 16 blocks, long enough to keep the warm-up re-reads small, short enough to spread the
-        // call over >= ~16 waves per CU, and inside the 64-entry coarse rotator table of a wave (64 x 512 samples)
-        const int J = g.U;
-        uint64_t S = total / (256u * 16u * 4u);
-        const uint64_t s_cap = (uint64_t)((62 * 512) / D - J) / 16 * 16;
-        if (S > 512) S = 512;
-        if (S > s_cap) S = s_cap;
-        S = S / 16 * 16;
-        if (S < 16) S = 16;
-        q.pl_S = (uint32_t)S;
-        q.pl_nseg = (uint32_t)((m_tail - m_main + S - 1) / S);
-        const uint32_t units = q.pl_nseg * (uint32_t)batch + (edge_unit ? (uint32_t)batch : 0u);
-        switch (J) {
-        case 1: pl_launch_main<1>(q, units, s); break;   case 2: pl_launch_main<2>(q, units, s); break;
-        case 3: pl_launch_main<3>(q, units, s); break;   case 4: pl_launch_main<4>(q, units, s); break;
-        case 5: pl_launch_main<5>(q, units, s); break;   case 6: pl_launch_main<6>(q, units, s); break;
-        case 7: pl_launch_main<7>(q, units, s); break;   case 8: pl_launch_main<8>(q, units, s); break;
-        case 9: pl_launch_main<9>(q, units, s); break;   case 10: pl_launch_main<10>(q, units, s); break;
-        case 11: pl_launch_main<11>(q, units, s); break; case 12: pl_launch_main<12>(q, units, s); break;
-        case 13: pl_launch_main<13>(q, units, s); break; case 14: pl_launch_main<14>(q, units, s); break;
-        case 15: pl_launch_main<15>(q, units, s); break; default: pl_launch_main<16>(q, units, s); break;
-        }
-        return 0;
-    }
     // generalised geometry: two waves per SIMD (<= 256 VGPRs), ~3 segments per wave slot of the chip; a segment stays inside
     // the wave's coarse rotator table and is a multiple of 16 outputs
     uint64_t S = total / (2048u * 3u);
@@ -774,6 +768,113 @@ int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)
     const uint32_t units = q.pl_nseg * (uint32_t)batch + (edge_unit ? (uint32_t)batch : 0u);
     hipLaunchKernelGGL((k_decim_plx<2, 1, 42>), dim3((units + 3) / 4), dim3(256), 0, s, q);
     return 0;
+}
+
+#ifdef QRL_PM_PROF
+extern "C" void qrl_pm_prof_read(unsigned long long* out8)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pm_prof), 8 * sizeof(unsigned long long));
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pm_prof), z, sizeof z);
+}
+#endif
+// ---- "pm" contract: rule (shared with oracle/orc_blocks.c orc_decim_uses_pm), tables, launcher ---------------------------------------
+bool decim_uses_pm(int nt, int D) { return D > 32 && D <= 52 && (nt + D - 1) / D <= 16; }
+size_t decim_pm_edge_len(int nt, int D)
+{
+    // the edge unit of a call starts at the 16-block group of block m0 - (J - 1) and ends with the last output in front of the first
+    // aligned segment: at most 15 + (J - 1) + (J + 16) blocks
+    const int J = (nt + D - 1) / D;
+    return decim_uses_pm(nt, D) ? (size_t)(((2 * J + 32) * D + 1) & ~1) : 0;
+}
+uint32_t decim_pm_lookback(int nt, int D) { return (uint32_t)(((nt + D - 1) / D + 18) * D); }
+// A-operand table [NS][64]: lane l (j = l & 15, k = l >> 4) of step s holds H[p = 4 s + k][j] = h[j D + D - 1 - p]; the raw taps follow
+std::vector<float> decim_pm_layout(const std::vector<float>& h, int D)
+{
+    const int nt = (int)h.size(), J = (nt + D - 1) / D, NS = (D + 3) / 4;
+    std::vector<float> t((size_t)NS * 64 + (size_t)nt, 0.0f);
+    for (int s = 0; s < NS; ++s)
+        for (int l = 0; l < 64; ++l) {
+            const int j = l & 15, p = 4 * s + (l >> 4), k = j * D + D - 1 - p;
+            if (j < J && p < D && k < nt) t[(size_t)s * 64 + l] = h[k];
+        }
+    for (int k = 0; k < nt; ++k) t[(size_t)NS * 64 + k] = h[k];
+    return t;
+}
+#ifndef QRL_PM_RP
+#define QRL_PM_RP 8
+#endif
+template <int J, int NS>
+static int pm_launch_main(const DecimParams& q, uint32_t units, hipStream_t s)
+{
+    constexpr int RP = QRL_PM_RP;            // ring pieces per wave (a power of two >= 8: one 16-block group of D <= 52 samples + what is in flight)
+    const auto kern = k_decim_pm<J, NS, RP>;
+    const size_t lds = (size_t)4 * RP * 1024 + 512 * sizeof(float2) + 4 * 64 * sizeof(float2);
+    if (dyn_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024) != hipSuccess) return -1;
+    hipLaunchKernelGGL(kern, dim3((units + 3) / 4), dim3(256), lds, s, q);
+    return 0;
+}
+int launch_decim_pm(const DecimParams& p, int batch, hipStream_t s)
+{
+    if (p.m_count == 0) return 0;
+    const int D = p.D, nt = p.nt, J = (nt + D - 1) / D, NS = (D + 3) / 4;
+    DecimParams q = p;
+    q.pl_J = J; q.pl_E = 1; q.pl_R = 1;
+    q.pl_hraw = p.pl_taps + (size_t)NS * 64;
+    const uint64_t m_end = p.m0 + p.m_count;
+    auto gen = [&](uint64_t first, uint64_t last) {
+        if (last > first) hipLaunchKernelGGL(k_decim_pm_gen, dim3((uint32_t)((last - first + 255) / 256), batch), dim3(256), 0, s, q, first, (uint32_t)(last - first));
+    };
+    // the matrix kernel streams rows of the caller's buffer as 16-byte LDS-DMA pieces: rows 16-byte aligned, even sample counts
+    // (what qrl_demod_process demands; the edge scratch is built that way).  Anything else: one thread per output.
+    const bool dma_ok = p.in && p.rot_enable && (reinterpret_cast<uintptr_t>(p.in) & 15u) == 0 && (p.in_stride & 1u) == 0 && (p.n & 1u) == 0 &&
+                        p.pl_edge && (reinterpret_cast<uintptr_t>(p.pl_edge) & 15u) == 0 && (p.pl_edge_stride & 1u) == 0;
+    if (!dma_ok) { gen(p.m0, m_end); return 0; }
+    // interior segments start at outputs m == J - 1 (mod 16): their oldest block opens a 16-block group, and it lies in the buffer
+    const uint64_t qb = p.n0 > 1 ? (p.n0 - 1 + D - 1) / D : 0;             // block qb + 1 is the first one whose samples are all >= n0
+    uint64_t m_main = (qb + 1 + 15) / 16 * 16 + (uint64_t)(J - 1);
+    if (m_main < p.m0) m_main = p.m0 + (uint64_t)((((J - 1) % 16) - (int)(p.m0 % 16) + 16) % 16);
+    const uint64_t c_max = (p.n0 + p.n - 1) / D;                           // last block that ends inside the buffer
+    uint64_t m_tail = c_max + 1 < m_end ? c_max + 1 : m_end;
+    if (m_tail < p.m0) m_tail = p.m0;
+    if (m_main > m_tail) m_main = m_tail;
+    bool edge_unit = false;
+    if (m_main > p.m0) {
+        const int64_t cfs = (int64_t)p.m0 - (J - 1);
+        const int64_t G0 = cfs >= 0 ? cfs / 16 : -((-cfs + 15) / 16);
+        const int64_t i0 = (G0 * 16 - 1) * (int64_t)D + 1;
+        const int64_t i_last = (int64_t)(m_main - 1) * D;                  // last sample of the last edge output's newest block
+        const int64_t len = ((i_last - i0 + 1) + 1) & ~(int64_t)1;
+        if (len <= (int64_t)p.pl_edge_cap) {
+            hipLaunchKernelGGL(k_pl_edge_stage, dim3((uint32_t)((len + 255) / 256), batch), dim3(256), 0, s, q, i0, (uint32_t)len);
+            q.pl_edge_ms = p.m0; q.pl_edge_me = m_main;
+            edge_unit = true;
+        } else gen(p.m0, m_main);
+    }
+    gen(m_tail, m_end);
+    if (m_main >= m_tail && !edge_unit) return 0;
+    const uint64_t total = (m_tail - m_main) * (uint64_t)batch;
+    q.pl_m_begin = m_main; q.pl_m_end = m_tail;
+    q.pl_batch = (uint32_t)batch;
+    // segment length: a multiple of 16 outputs (every segment then starts on a group boundary), long enough to keep the warm-up
+    // re-reads small (J - 1 blocks per segment), short enough to spread the call over >= ~16 waves per CU, and inside the 64-entry
+    // coarse rotator table of a wave (64 x 512 samples, 16 blocks of slack for the last group)
+    uint64_t S = total / (256u * 16u * 4u);
+    const uint64_t s_cap = (uint64_t)((62 * 512) / D - J - 16) / 16 * 16;
+    if (S > 512) S = 512;
+    if (S > s_cap) S = s_cap;
+    S = S / 16 * 16;
+    if (S < 16) S = 16;
+    q.pl_S = (uint32_t)S;
+    q.pl_nseg = m_tail > m_main ? (uint32_t)((m_tail - m_main + S - 1) / S) : 0u;
+    const uint32_t units = q.pl_nseg * (uint32_t)batch + (edge_unit ? (uint32_t)batch : 0u);
+    if (J == 9 && NS == 13) return pm_launch_main<9, 13>(q, units, s);   // the 1:50, 419-tap stage
+    switch (NS) {   // other geometries: 16 block lags (the table is zero beyond J), D = 33 .. 52
+    case 9: return pm_launch_main<16, 9>(q, units, s);    case 10: return pm_launch_main<16, 10>(q, units, s);
+    case 11: return pm_launch_main<16, 11>(q, units, s);  case 12: return pm_launch_main<16, 12>(q, units, s);
+    default: return pm_launch_main<16, 13>(q, units, s);
+    }
 }
 
 }  // namespace qrl

@@ -68,6 +68,8 @@ _sig("orc_decim_auto", _sz, _p, _sz, _p, C.c_int, C.c_int, _p)
 _sig("orc_decim_uses_m16", C.c_int, C.c_int, C.c_int)
 _sig("orc_decim_fir_ccf_pl", _sz, _p, _sz, _p, C.c_int, C.c_int, _p)
 _sig("orc_decim_uses_pl", C.c_int, C.c_int, C.c_int)
+_sig("orc_decim_fir_ccf_pm", _sz, _p, _sz, _p, C.c_int, C.c_int, _p)
+_sig("orc_decim_uses_pm", C.c_int, C.c_int, C.c_int)
 _sig("orc_decim_fir_ccf_simd", _sz, _p, _sz, _p, C.c_int, C.c_int, _p)
 _sig("orc_set_decim_impl", None, C.c_int)
 _sig("orc_m16_steps", C.c_int, C.c_int, C.c_int)
@@ -209,6 +211,14 @@ def decim_fir_ccf_pl(x, taps, decim):
     n = lib.orc_decim_count(x.size, 1, decim)
     y = np.empty(n, cf32)
     lib.orc_decim_fir_ccf_pl(_ptr(x), x.size, _ptr(taps), taps.size, decim, _ptr(y))
+    return y
+
+
+def decim_fir_ccf_pm(x, taps, decim):
+    x = np.ascontiguousarray(x, cf32)
+    taps = np.ascontiguousarray(taps, np.float32)
+    y = np.empty(lib.orc_decim_count(x.size, 1, decim), cf32)
+    lib.orc_decim_fir_ccf_pm(_ptr(x), x.size, _ptr(taps), taps.size, decim, _ptr(y))
     return y
 
 
@@ -434,6 +444,23 @@ def demod_mmdvm_multi_4fsk(x, M):
 
 
 _sig("orc_demod_mmdvm_xlating_bank_4fsk", _sz, _p, _sz, C.c_int, _p, _sz, _p, _sz, C.c_float, _p, _sz, _p)
+_sig("orc_mmdvm_channel_tails", _sz, _p, C.c_int, _sz, _p, _sz, _p, _sz, C.c_float, _p, _sz, _p)
+
+
+def mmdvm_channel_tails(ch, cal=0.0):
+    """per-channel chains of gr_demod_mmdvm_multi2 on channel streams ch [nch, n1] at 25 ksps: (int16 [nch, n2], rssi, dibit list)"""
+    ch = np.ascontiguousarray(ch, cf32)
+    nch, n1 = ch.shape
+    cap = n1 * 24 // 25 + 4
+    out = np.zeros((nch, cap), np.int16)
+    rcap = cap // 300 + 2
+    rssi = np.zeros((nch, rcap), np.float32)
+    dcap = 2 * (cap // 4 + 16)
+    dib = np.zeros((nch, dcap), np.uint8)
+    nd = np.zeros(nch, np.uint64)
+    n = lib.orc_mmdvm_channel_tails(_ptr(ch), nch, n1, _ptr(out), cap, _ptr(rssi), rcap, cal, _ptr(dib), dcap, _ptr(nd))
+    return out[:, :n].copy(), rssi[:, :n // 300].copy(), [dib[c, :int(nd[c])].copy() for c in range(nch)]
+
 
 
 def demod_mmdvm_xlating_bank_4fsk(x, N, cal=0.0):

@@ -521,23 +521,9 @@ def test_large_batch_bit_exact(qrl_ctx, mode_name, modem, rate, B, nframes):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "port 0 of stream %d" % b
 
 
-@pytest.mark.parametrize("chunk", [1 << 21, 50000, 6400 * 3 + 2])
-def test_lds_dma_front_end_bit_exact(qrl_ctx, chunk):
-    """QRL_OPT_LEGACY_FRONTEND = 0: the LDS-DMA phase-lane kernel k_decim_pl2 (wave-private rings filled by global_load_lds pieces) behind
-    the same contract as the default k_decim_pl; not faster on C1 (both VALU bound), kept for A/B runs, so it stays under test."""
-    import torch
-    import qradiolink_amd as q
-    iq = sig.make_batch("2fsk1k", 3, nframes=2, device_rate=1000000, rx_offset_hz=1200.0, seed=3)
-    dem = q.Demod(qrl_ctx, 18, batch=3, max_chunk=chunk, device_samp_rate=1000000, carrier_offset_hz=1200.0)
-    dem.set_option(q.OPT_LEGACY_FRONTEND, 0)
-    out = q.collect(dem, torch.from_numpy(iq).cuda(), chunk)
-    dem.close()
-    _compare(iq, out, "2fsk1k", 1000000, 1200.0)
-
-
 @pytest.mark.parametrize("pitch_pad", [0, 6, 130])
 def test_lds_dma_front_end_with_padded_row_pitch(qrl_ctx, pitch_pad):
-    """k_decim_pl2 cuts every stream row into 16-byte LDS-DMA pieces relative to the row start and clamps the last piece at the row
+    """k_decim_pm cuts every stream row into 16-byte LDS-DMA pieces relative to the row start and clamps the last piece at the row
     end: rows whose pitch is not a multiple of 128 bytes, and the last row of the allocation, must come out the same."""
     import torch
     import qradiolink_amd as q
@@ -547,7 +533,6 @@ def test_lds_dma_front_end_with_padded_row_pitch(qrl_ctx, pitch_pad):
     buf[:, :n] = torch.from_numpy(iq).cuda()
     view = buf[:, :n]
     dem = q.Demod(qrl_ctx, 18, batch=4, max_chunk=n, device_samp_rate=1000000, carrier_offset_hz=1200.0)
-    dem.set_option(q.OPT_LEGACY_FRONTEND, 0)
     out = q.collect(dem, view, n)
     dem.close()
     _compare(iq, out, "2fsk1k", 1000000, 1200.0)

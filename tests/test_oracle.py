@@ -207,15 +207,15 @@ def test_m16_contract_matches_float64_definition(fs, decim):
     assert _definition_error(orc.decim_fir_ccf_m16(x, h, decim), x, h, decim) < 1e-5
 
 
-@pytest.mark.parametrize("decim,nt_scale", [(50, 1.0), (33, 1.0), (64, 0.7)])
-def test_pl_contract_matches_float64_definition(decim, nt_scale):
-    """Phase-lane order of k_decim_pl (one chain per lane slot, radix-2 tree over the 64 slots) against the float64
-    definition; also the rule that selects it and equality with the plain chain when the tree degenerates."""
+@pytest.mark.parametrize("decim,nt_scale", [(50, 1.0), (33, 1.0), (52, 0.9)])
+def test_pm_contract_matches_float64_definition(decim, nt_scale):
+    """Phase-major order of k_decim_pm (per block one fmaf chain over the D phases = the f32 matrix pipe's k order, then the J block
+    terms in the lane-row order of the matrix result) against the float64 definition; also the rule that selects it."""
     rng = np.random.default_rng(90 + decim)
     h = orc.low_pass(1, 1e6, 10e3 / nt_scale, 10e3 / nt_scale, BH)
     x = (rng.standard_normal(60 * decim + h.size) + 1j * rng.standard_normal(60 * decim + h.size)).astype(np.complex64)
-    assert orc.lib.orc_decim_uses_pl(h.size, decim)
-    y = orc.decim_fir_ccf_pl(x, h, decim)
+    assert orc.lib.orc_decim_uses_pm(h.size, decim) and not orc.lib.orc_decim_uses_pl(h.size, decim)
+    y = orc.decim_fir_ccf_pm(x, h, decim)
     assert _definition_error(y, x, h, decim) < 1e-5
     assert np.array_equal(orc.decim_auto(x, h, decim).view(np.float32), y.view(np.float32))
 
@@ -244,15 +244,30 @@ def test_cpu_baseline_simd_decimator_matches_definition():
         assert _definition_error(orc.decim_fir_ccf_simd(x, h, decim), x, h, decim) < 1e-5
 
 
-def test_pl_contract_is_position_independent():
-    """Output m only depends on the samples of its window: a stream that starts later (shifted by whole blocks) gives the
-    same bits once the window is inside the stream -- the property chunked / segmented evaluation relies on."""
+def test_pm_contract_depends_on_the_absolute_output_index_only():
+    """Output m only depends on the samples of its window and on m mod 16 (the absolute 16-block groups of the matrix result): a
+    stream that starts whole groups later gives the same bits once the window is inside the stream -- the property chunked /
+    segmented evaluation relies on (the engine indexes outputs absolutely).  A shift by a non-multiple of 16 blocks regroups the
+    block terms: same value to rounding, different bits."""
     rng = np.random.default_rng(5)
     h = orc.low_pass(1, 1e6, 10e3, 10e3, BH)
-    x = (rng.standard_normal(4000) + 1j * rng.standard_normal(4000)).astype(np.complex64)
-    y = orc.decim_fir_ccf_pl(x, h, 50)
-    y2 = orc.decim_fir_ccf_pl(x[500:], h, 50)
+    x = (rng.standard_normal(6000) + 1j * rng.standard_normal(6000)).astype(np.complex64)
+    y = orc.decim_fir_ccf_pm(x, h, 50)
+    y2 = orc.decim_fir_ccf_pm(x[800:], h, 50)
     k = (h.size + 49) // 50 + 1
+    assert np.array_equal(y[16 + k:].view(np.float32), y2[k:].view(np.float32))
+    y3 = orc.decim_fir_ccf_pm(x[500:], h, 50)
+    assert np.max(np.abs(y[10 + k:] - y3[k:])) < 1e-6 * np.max(np.abs(y))
+
+
+def test_pl_contract_is_position_independent():
+    """(two-samples-per-lane geometry, the 100:1 front end) Output m only depends on the samples of its window."""
+    rng = np.random.default_rng(5)
+    h = orc.low_pass(1, 100e6, 480e3, 100e3, BH)
+    x = (rng.standard_normal(12000) + 1j * rng.standard_normal(12000)).astype(np.complex64)
+    y = orc.decim_fir_ccf_pl(x, h, 100)
+    y2 = orc.decim_fir_ccf_pl(x[1000:], h, 100)
+    k = (h.size + 99) // 100 + 1
     assert np.array_equal(y[10 + k:].view(np.float32), y2[k:].view(np.float32))
 
 

@@ -84,3 +84,66 @@ def test_two_rank_gloo_shard_and_gather_matches_single_process():
         assert p.exitcode == 0
     assert total == B * iq.shape[1]
     assert got == want
+
+
+# ---- channel-sharded multi-carrier receiver (C4, SURVEY 8e PFB form): channelize locally, all-to-all the channel streams, per-channel
+# chains on the owner.  CPU stand-in: the oracle's channelizer / per-channel chains around the SAME exchange function bench.py uses.
+def _c4_worker(rank, world, port, iq, M, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B = iq.shape[0]
+        first, count = sharding.shard_range(B, world, rank)
+        assert count == B // world
+        taps = orc.chan_proto_taps(M)
+        cpr = M // world                                            # channels per rank
+        chans = np.stack([orc.pfb_channelizer(iq[b], taps, M) for b in range(first, first + count)])   # [B_local, M, n1]
+        n1 = chans.shape[2]
+        send = torch.from_numpy(np.ascontiguousarray(chans.reshape(count, world, cpr, n1).transpose(1, 0, 2, 3)))   # [dest, B_local, cpr, n1]
+        recv = sharding.exchange_channels(send).numpy()           # [src, B_local, cpr, n1] = stream-major, this rank's channels
+        mine = recv.reshape(B * cpr, n1)                           # row = stream * cpr + local channel
+        out16, rssi, dib = orc.mmdvm_channel_tails(mine, cal=1.0)
+        res = [(out16[r].tobytes(), rssi[r].tobytes(), dib[r].tobytes()) for r in range(B * cpr)]
+        box = [None] * world if rank == 0 else None
+        dist.gather_object(res, box, dst=0)
+        if rank == 0:
+            q.put((box, sharding.bytes_per_link_per_step(count, M, world, n1)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_channel_all_to_all_matches_single_process():
+    M, B, n = 10, 4, 10 * 3000
+    rng = np.random.default_rng(3)
+    t = np.arange(n)
+    iq = (0.02 * (rng.standard_normal((B, n)) + 1j * rng.standard_normal((B, n)))).astype(np.complex64)
+    for b in range(B):
+        for c in (1, 4, 8):
+            f0 = c * 25000.0 if c <= M // 2 else (c - M) * 25000.0
+            iq[b] += (0.2 * np.exp(1j * (2 * np.pi * f0 * t / (25000.0 * M) + 2.0 * np.sin(2 * np.pi * (300 + 50 * b + 10 * c) * t / (25000.0 * M))))).astype(np.complex64)
+    want = []
+    for b in range(B):
+        o, r = orc.demod_mmdvm_multi_rssi(iq[b], M, cal=1.0)
+        _, d = orc.demod_mmdvm_multi_4fsk(iq[b], M)
+        want.append([(o[c].tobytes(), r[c].tobytes(), d[c].tobytes()) for c in range(M)])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_c4_worker, args=(r, world, port, iq, M, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    box, link_bytes = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cpr = M // world
+    for r in range(world):                 # rank r owns channels [r cpr, (r + 1) cpr) of every stream
+        for b in range(B):
+            for cl in range(cpr):
+                assert box[r][b * cpr + cl] == want[b][r * cpr + cl], (r, b, cl)
+    assert link_bytes == (B // world) * cpr * (n // M) * 8

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Phase profile of k_decim_pm (build/libqrl_pmprof.so, -DQRL_PM_PROF): QRL_LIB_PATH=build/libqrl_pmprof.so python tools/pm_prof.py"""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import qradiolink_amd as q
+ctx = q.Context(0)
+B, n = 16384, 1 << 18
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+iq = torch.empty((B, n), dtype=torch.complex64, device="cuda")
+v = torch.view_as_real(iq)
+for b0 in range(0, B, 1024):
+    v[b0:b0 + 1024] = torch.randn((1024, n, 2), generator=g, device="cuda") * 0.05
+dem = q.Demod(ctx, 18, batch=B, max_chunk=n, device_samp_rate=1000000, carrier_offset_hz=1200.0, side_outputs=True)
+lib = ctx.lib
+out = (C.c_ulonglong * 8)()
+for _ in range(2): dem.process_async(iq)
+dem.sync(); lib.qrl_pm_prof_read(out)
+for _ in range(4): dem.process_async(iq)
+dem.sync(); lib.qrl_pm_prof_read(out)
+names = ["wait vmcnt (group landed)", "13 raw LDS reads + lgkmcnt(0)", "DMA issue", "rotate + 26 MFMA", "diag sums + store", "", "", "groups"]
+ng = out[7]
+tot = sum(out[k] for k in range(5))
+for k in range(5):
+    print("%-32s %8.0f cycles per group and wave  (%4.1f %%)" % (names[k], out[k] / ng, 100.0 * out[k] / tot))
+print("total %.0f cycles per group and wave; groups per call %.0f" % (tot / ng, ng / 4))

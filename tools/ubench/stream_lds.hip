@@ -142,7 +142,88 @@ __global__ __launch_bounds__(NW * 64) void w2(const unsigned char* in, size_t nt
     if (acc == 12345.678f) out[0] = acc;
 }
 
-template <class F> static double timeit(F f, int reps = 4)
+// fill with pseudo-random floats of unit scale (xorshift per element): HBM power -- and with it the sustained bandwidth -- may depend
+// on the data; the round-3 front ends all stop at 5.06 TB/s on random IQ while constant data streams at 7.07 TB/s
+__global__ __launch_bounds__(256) void fill_random(float* p, size_t n, uint32_t seed)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint32_t x = (uint32_t)i * 2654435761u + seed;
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5; x *= 0x9E3779B1u; x ^= x >> 15;
+        p[i] = ((float)(int32_t)x) * (0.05f / 2147483648.0f);
+    }
+}
+static void rep(const char* name, double ms, double useful);
+template <class F> static double timeit(F f, int reps);
+// ---- W3: the data flow of k_decim_pm: wave-private ring, consumption in GROUPS of GB bytes ---------------------------------------
+// A group is copied out of the ring (ds_read_b64 x 13 per lane) once it has landed; that frees its slots and the wave issues the
+// next pieces in a burst, then "computes" (CW dependent FMAs per lane) before it waits for the next group.  PFK > 0: every group the
+// wave also touches one dword per 128-byte line PFK KiB ahead of the DMA front (a sparse global_load whose result is dropped), so
+// that HBM requests are in flight beyond what the LDS ring can hold and the DMA pieces hit L2.
+template <int RP, int NT, int CW, int PFK, int NW>
+__global__ __launch_bounds__(NW * 64) void w3(const unsigned char* in, size_t seg_bytes, size_t nunits, float* out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr uint32_t GB = 6400;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t u = (size_t)blockIdx.x * NW + wave;
+    if (u >= nunits) return;
+    unsigned char* ring = smem + wave * (RP * 1024);
+    const uint32_t rbase = (uint32_t)(uintptr_t)(lds_ptr_t)ring;
+    const unsigned char* base = in + u * seg_bytes;
+    const unsigned char* g = base + lane * 16;
+    const uint32_t ngrp = (uint32_t)(seg_bytes / GB);
+    const uint32_t npieces = (ngrp * GB + 1023u) >> 10;
+    uint32_t issued = 0;
+    auto issue_upto = [&](uint32_t want) {
+        while (issued < want) { glds16<NT>(g + (size_t)issued * 1024, rbase + (issued & (RP - 1)) * 1024u); ++issued; }
+    };
+    float acc = 0.f, sink = 0.f;
+    issue_upto(npieces < RP ? npieces : RP);
+    uint32_t gbytes = 0;
+    const uint32_t lane_byte = ((uint32_t)(lane & 15) * 400u + (uint32_t)(lane >> 4) * 8u);
+    for (uint32_t gi = 0; gi < ngrp; ++gi) {
+        uint32_t need = (gbytes + GB + 1023u) >> 10;
+        need = need < npieces ? need : npieces;
+        switch (issued - need) {
+        case 0: wait_vm<0>(); break; case 1: wait_vm<1>(); break; case 2: wait_vm<2>(); break; case 3: wait_vm<3>(); break;
+        case 4: wait_vm<4>(); break; case 5: wait_vm<5>(); break; case 6: wait_vm<6>(); break; case 7: wait_vm<7>(); break;
+        case 8: wait_vm<8>(); break; case 9: wait_vm<9>(); break; case 10: wait_vm<10>(); break; default: wait_vm<11>(); break;
+        }
+        float2 x[13];
+#pragma unroll
+        for (int s2 = 0; s2 < 13; ++s2) x[s2] = *reinterpret_cast<const float2*>(ring + ((gbytes + lane_byte + 32u * s2) & (RP * 1024u - 1u)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint32_t cap = ((gbytes + GB) >> 10) + RP;
+        issue_upto(cap < npieces ? cap : npieces);
+        if (PFK > 0) {   // sparse touch PFK KiB ahead of the DMA front: 64 lanes x 128 B = 8 KiB of lines per instruction
+            const size_t ahead = (size_t)issued * 1024 + (size_t)PFK * 1024;
+            if (ahead + 8192 <= seg_bytes) sink += *reinterpret_cast<const volatile float*>(base + ahead + (size_t)lane * 128);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 13; ++s2) {
+#pragma unroll
+            for (int k = 0; k < CW; ++k) acc = fmaf(x[s2].x, x[s2].y, acc);
+        }
+        gbytes += GB;
+    }
+    wait_vm<0>();
+    if (acc == 12345.678f || sink == 1.2345f) out[0] = acc + sink;
+}
+template <int RP, int NT, int CW, int PFK, int NW>
+static void run_w3(const unsigned char* in, size_t bytes, int pad_kib, float* out)
+{
+    const auto kern = w3<RP, NT, CW, PFK, NW>;
+    const size_t lds = (size_t)NW * RP * 1024 + (size_t)pad_kib * 1024;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const size_t seg = 32 * 6400;   // 200 KiB
+    const size_t nunits = bytes / seg;
+    char nm[160];
+    snprintf(nm, sizeof nm, "W3 pm flow: ring %d KiB, nt %d, %d fma per sample slot, L2 touch %d KiB ahead, %d waves/WG, LDS/WG %zu KiB",
+             RP, NT, CW, PFK, NW, lds / 1024);
+    rep(nm, timeit([&] { hipLaunchKernelGGL(kern, dim3((nunits + NW - 1) / NW), dim3(NW * 64), lds, 0, in, seg, nunits, out); }, 4), (double)nunits * seg);
+}
+template <class F> static double timeit(F f, int reps)
 {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); CK(hipDeviceSynchronize());
@@ -161,7 +242,7 @@ static void run_w1(const unsigned char* in, size_t bytes, size_t seg_kib, int pa
     char nm[160];
     snprintf(nm, sizeof nm, "W1 wave ring: %d in flight, ring %d KiB, nt %d, %d fma/sample, %d waves/WG, seg %zu KiB, LDS/WG %zu KiB",
              PD, RP, NT, 2 * KF / 2, NW, seg_kib, lds / 1024);
-    rep(nm, timeit([&] { hipLaunchKernelGGL(kern, dim3((nunits + NW - 1) / NW), dim3(NW * 64), lds, 0, in, seg_kib, nunits, out); }), (double)nunits * seg_kib * 1024);
+    rep(nm, timeit([&] { hipLaunchKernelGGL(kern, dim3((nunits + NW - 1) / NW), dim3(NW * 64), lds, 0, in, seg_kib, nunits, out); }, 4), (double)nunits * seg_kib * 1024);
 }
 template <int PPT, int NB, int ND, int NT, int KF, int NW>
 static void run_w2(const unsigned char* in, size_t bytes, int grid_per_cu, int mode, int pad_kib, float* out)
@@ -175,20 +256,48 @@ static void run_w2(const unsigned char* in, size_t bytes, int grid_per_cu, int m
     char nm[160];
     snprintf(nm, sizeof nm, "W2 WG tiles: %d waves x %d KiB = %zu KiB tile, %d bufs, %d in flight, nt %d, %d fma, grid %d/CU, mode %d, LDS %zu KiB",
              NW, PPT, TILE / 1024, NB, ND, NT, KF, grid_per_cu, mode, lds / 1024);
-    rep(nm, timeit([&] { hipLaunchKernelGGL(kern, dim3(256 * grid_per_cu), dim3(NW * 64), lds, 0, in, ntiles, mode, out); }), (double)ntiles * TILE);
+    rep(nm, timeit([&] { hipLaunchKernelGGL(kern, dim3(256 * grid_per_cu), dim3(NW * 64), lds, 0, in, ntiles, mode, out); }, 4), (double)ntiles * TILE);
 }
 
 int main(int argc, char** argv)
 {
     const size_t gib = argc > 1 ? atoi(argv[1]) : 16;
+    const int fill = argc > 2 ? atoi(argv[2]) : 0;      // 0: constant bytes, 1: pseudo-random floats
+    const int quick = argc > 3 ? atoi(argv[3]) : 0;     // 1: only the headline patterns
     const size_t bytes = gib << 30;
     unsigned char* in; float* out; CK(hipMalloc(&in, bytes + (4 << 20))); CK(hipMalloc(&out, 256));
-    CK(hipMemset(in, 0x11, bytes + (4 << 20)));
-    rep("P0 contiguous sweep, dwordx4 to VGPR, grid 256*8", timeit([&] { hipLaunchKernelGGL(p0, dim3(2048), dim3(256), 0, 0, (const float4*)in, bytes / 16, out); }), bytes);
-    rep("P0 contiguous sweep, dwordx4 to VGPR, grid 256*16", timeit([&] { hipLaunchKernelGGL(p0, dim3(4096), dim3(256), 0, 0, (const float4*)in, bytes / 16, out); }), bytes);
+    if (fill == 0) CK(hipMemset(in, 0x11, bytes + (4 << 20)));
+    else { hipLaunchKernelGGL(fill_random, dim3(256 * 32), dim3(256), 0, 0, (float*)in, (bytes + (4 << 20)) / 4, 12345u); CK(hipDeviceSynchronize()); }
+    printf("# %zu GiB, fill = %s\n", gib, fill ? "pseudo-random floats" : "constant 0x11");
+    rep("P0 contiguous sweep, dwordx4 to VGPR, grid 256*8", timeit([&] { hipLaunchKernelGGL(p0, dim3(2048), dim3(256), 0, 0, (const float4*)in, bytes / 16, out); }, 4), bytes);
+    rep("P0 contiguous sweep, dwordx4 to VGPR, grid 256*16", timeit([&] { hipLaunchKernelGGL(p0, dim3(4096), dim3(256), 0, 0, (const float4*)in, bytes / 16, out); }, 4), bytes);
     {
         const size_t seg = 25600, nunits = bytes / 8 / seg;   // 512 blocks of 50 samples = 200 KiB
-        rep("P2 k_decim_pl pattern: wave-seq 50 lanes x 8 B, 8 in flight, seg 200 KB", timeit([&] { hipLaunchKernelGGL(pseq50<8>, dim3((nunits + 3) / 4), dim3(256), 0, 0, (const float2*)in, seg, nunits, out); }), (double)nunits * seg * 8);
+        rep("P2 k_decim_pl pattern: wave-seq 50 lanes x 8 B, 8 in flight, seg 200 KB", timeit([&] { hipLaunchKernelGGL(pseq50<8>, dim3((nunits + 3) / 4), dim3(256), 0, 0, (const float2*)in, seg, nunits, out); }, 4), (double)nunits * seg * 8);
+    }
+    if (quick == 2) {   // the data flow of k_decim_pm and ways to keep more bytes in flight
+        run_w3<8, 1, 1, 0, 4>(in, bytes, 6, out);      // as k_decim_pm: 4 WGs/CU x 4 waves, 38 KiB/WG
+        run_w3<8, 1, 10, 0, 4>(in, bytes, 6, out);
+        run_w3<8, 1, 30, 0, 4>(in, bytes, 6, out);
+        run_w3<8, 0, 10, 0, 4>(in, bytes, 6, out);
+        run_w3<8, 1, 10, 8, 4>(in, bytes, 6, out);     // + L2 touch 8 KiB ahead
+        run_w3<8, 1, 10, 16, 4>(in, bytes, 6, out);
+        run_w3<8, 1, 10, 32, 4>(in, bytes, 6, out);
+        run_w3<8, 1, 30, 16, 4>(in, bytes, 6, out);
+        run_w3<8, 0, 10, 16, 4>(in, bytes, 6, out);
+        run_w3<16, 1, 10, 0, 4>(in, bytes, 6, out);    // 16 KiB rings: 2 WGs/CU = 8 waves
+        run_w3<16, 1, 10, 16, 4>(in, bytes, 6, out);
+        run_w3<8, 1, 10, 0, 4>(in, bytes, 0, out);     // 32 KiB/WG: 5 WGs/CU
+        run_w3<8, 1, 10, 16, 4>(in, bytes, 0, out);
+        return 0;
+    }
+    if (quick) {
+        run_w1<4, 8, 0, 1, 4>(in, bytes, 200, 0, out);
+        run_w1<4, 8, 1, 1, 4>(in, bytes, 200, 0, out);
+        run_w1<7, 8, 1, 10, 4>(in, bytes, 200, 0, out);
+        run_w2<2, 3, 2, 1, 1, 16>(in, bytes, 1, 0, 0, out);
+        run_w2<2, 3, 2, 1, 1, 16>(in, bytes, 1, 1, 0, out);
+        return 0;
     }
     // W1: in flight / waves per CU (through LDS per WG) / segment length / nt / compute
     run_w1<2, 4, 0, 1, 4>(in, bytes, 200, 0, out);     // 16 KiB/WG: 8+ WGs/CU = 32 waves, 2 KiB in flight each
