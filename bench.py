@@ -16,8 +16,8 @@ Other configs on request: --config c2 | c3 | c4 | c5.
 
 Launch: python bench.py --gpus N --steps K --warmup W.  N > 1 re-executes itself under torch.distributed.run (one rank per GPU,
 RCCL); the driver may also launch it that way directly.  C1-C3/C5 shard independent streams over the ranks with no data-path
-collective ("scaling": "weak"); C4 shards the CHANNELS of the same wideband input, which rank 0 broadcasts over RCCL every step
-("scaling": "strong").
+collective ("scaling": "weak"); C4 shards the CHANNELS: every rank channelizes its wideband streams and one RCCL all_to_all_single
+per step hands each channel's samples to its owner ("scaling": "strong").
 """
 import argparse
 import json
@@ -192,9 +192,9 @@ def roofline_obj(kernel, kms, launches, bytes_per_launch, bytes_per_sample, note
 
 def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True):
     """C4: multi-carrier MMDVM receiver, 64 x 25 kHz channels from 1.6 Msps wideband IQ (PFB channelizer + per-channel
-    24/25 resampler, LPF, FM discriminator -> int16, RSSI tags and the 4FSK symbol tail).  Multi-GPU: the CHANNELS of the same
-    wideband streams are sharded (rank r owns channels [r M/G, (r+1) M/G)); rank 0 holds the new wideband chunk of every step
-    and broadcasts it to the other ranks over RCCL (one ncclBroadcast per step), then every rank runs its shard.
+    24/25 resampler, LPF, FM discriminator -> int16, RSSI tags and the 4FSK symbol tail).  Multi-GPU (PFB form): the CHANNELS
+    are sharded -- every rank channelizes its own B / world wideband streams, one RCCL all_to_all_single per step moves each
+    channel's 25 ksps samples to the rank that owns the channel, the per-channel chains run there ("strong" scaling: B is fixed).
     Also measured (single GPU): BASELINE configs[3] taken literally, form 2 = 64 frequency-translating FIRs 1:64 in front of the same
     per-channel chain -- the compute-bound way of producing the channels the PFB produces."""
     import copy
@@ -202,37 +202,70 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True):
     if steps:
         args.steps = steps
     M, B, n = 64, args.batch or 64, (args.nsamp or (1 << 21)) // 64 * 64
-    if M % world:
-        raise SystemExit("c4: the number of ranks must divide 64 channels")
+    if M % world or B % world:
+        raise SystemExit("c4: the number of ranks must divide 64 channels and the number of wideband streams")
     per = M // world
     g = torch.Generator(device=dev)
-    g.manual_seed(7)
-    src = torch.view_as_complex(torch.randn((B, n, 2), generator=g, device=dev, dtype=torch.float32) * 0.05)   # rank 0's is THE input
-    iq = src if (world == 1 or rank == 0) else torch.empty_like(src)
-    ch = q.Channelizer(ctx, M, batch=B, max_chunk=n, channel_first=rank * per, channel_count=per)
-    ch.enable_4fsk()
-    if args.legacy_pfb:
-        ch.set_option(q.CHAN_OPT_LEGACY_PFB, 1)
-    iq_f = torch.view_as_real(iq)
+    g.manual_seed(7 + rank)
+    from qradiolink_amd import sharding
+    link_bytes = None
+    if world == 1:
+        iq = torch.view_as_complex(torch.randn((B, n, 2), generator=g, device=dev, dtype=torch.float32) * 0.05)
+        ch = q.Channelizer(ctx, M, batch=B, max_chunk=n)
+        ch.enable_4fsk()
+        if args.legacy_pfb:
+            ch.set_option(q.CHAN_OPT_LEGACY_PFB, 1)
+        step, sync, prof = (lambda: ch.process_async(iq)), ch.sync, ch
+        handles = [ch]
+    else:
+        # SURVEY 8e, PFB form: every rank channelizes ITS B / world wideband streams (all 64 channels), one all_to_all_single
+        # (RCCL over xGMI) hands each rank the channels it owns of EVERY stream, the per-channel chains run on the owner.  Per link
+        # and step: (B / world) x (64 / world) x n / 64 cf32 items = 1 / world of a rank's input bytes.
+        Bl, n1 = B // world, n // M
+        iq = torch.view_as_complex(torch.randn((Bl, n, 2), generator=g, device=dev, dtype=torch.float32) * 0.05)   # this rank's own inputs
+        ch = q.Channelizer(ctx, M, batch=Bl, max_chunk=n)
+        tail = q.Channelizer(ctx, 1, batch=B * per, max_chunk=n1, form=3)
+        tail.enable_4fsk()
+        send = [torch.empty((world, Bl, per, n1), dtype=torch.complex64, device=dev) for _ in range(2)]
+        recv = [torch.empty((world, Bl, per, n1), dtype=torch.complex64, device=dev) for _ in range(2)]
+        ts = torch.cuda.current_stream().cuda_stream
+        link_bytes = sharding.bytes_per_link_per_step(Bl, M, world, n1)
+        k = [0]
 
-    def step():
-        if world > 1:
-            torch.distributed.broadcast(iq_f, src=0)   # RCCL over xGMI; enqueued on torch's stream, process_async waits for it
-        ch.process_async(iq)
-    ch.profile(True)
-    dt = timed_loop(step, ch.sync, args, torch, dev, world)
-    kms, launches, kname = ch.profile_read()
+        def step():
+            b = k[0] & 1
+            k[0] += 1
+            ch.wait_for(ts)                  # send[b] is free once the collectives queued so far have read it
+            ch.channelize_async(iq, send[b], world)
+            ch.stream_wait(ts)               # the collective runs behind the channelizer ...
+            tail.stream_wait(ts)             # ... and recv[b] is free once the per-channel chains queued so far have consumed it
+            torch.distributed.all_to_all_single(torch.view_as_real(recv[b]), torch.view_as_real(send[b]))
+            tail.wait_for(ts)
+            tail.process_channels_async(recv[b].view(B * per, n1), n1)
+
+        def sync():
+            ch.sync()
+            tail.sync()
+        prof, handles = ch, [ch, tail]
+    prof.profile(True)
+    dt = timed_loop(step, sync, args, torch, dev, world)
+    kms, launches, kname = prof.profile_read()
     launches_timed = args.steps
     kms = kms * launches_timed / max(launches, 1)          # (the warm-up calls were profiled too: same kernel, same shape)
-    ch.profile(False)
-    ch.close()
+    prof.profile(False)
+    for h in handles:
+        h.close()
+    b_kernel = (B // world) if world > 1 else B             # wideband streams the channelizer of THIS rank processes per launch
     line = {"metric": "wideband IQ MSamples/sec through the C4 receiver", "value": round(B * n * args.steps / dt / 1e6, 1), "unit": "MS/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C4: 64 x 25 kHz MMDVM channels from 1.6 Msps IQ: PFB channelizer + FM int16 + RSSI + 4FSK tail",
                        "wideband_streams": B, "samples_per_stream_per_step": n, "channels_per_gpu": per,
-                       "parallelism": "channels sharded over ranks; wideband input broadcast from rank 0 over RCCL every step" if world > 1 else "single GPU"},
-            "roofline": roofline_obj(kname, kms, launches_timed, B * n * C4_BYTES, round(C4_BYTES, 3),
+                       "parallelism": ("channels sharded over ranks: every rank channelizes its %d wideband streams, one RCCL all_to_all_single per step moves "
+                                       "the channel streams to their owners (%d bytes per link and step), per-channel chains on the owner" % (B // world, link_bytes))
+                                      if world > 1 else "single GPU",
+                       "bytes_per_link_per_step": link_bytes},
+            "roofline": roofline_obj(kname, kms, launches_timed, b_kernel * n * C4_BYTES, round(C4_BYTES, 3),
                                      "k_pfb_chan64 reads the wideband input once and writes the 64 channel rings; whole chain: %.1f GB/s of algorithmic bytes"
                                      % (B * n * C4_BYTES * args.steps / dt / 1e9))}
     if world == 1 and with_form2:
@@ -240,7 +273,7 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True):
         B2, n2 = max(1, B // 8), n // 4
         ch2 = q.Channelizer(ctx, M, batch=B2, max_chunk=n2, form=2)
         ch2.enable_4fsk()
-        iq2 = src[:B2, :n2].contiguous()
+        iq2 = iq[:B2, :n2].contiguous()
         a2 = copy.copy(args)
         a2.steps, a2.warmup = max(2, args.steps // 5), 1
         ch2.profile(True)

@@ -703,6 +703,9 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         FllParams f{};
         f.in = r2; f.out = r2l; f.q0 = n2_0; f.count = c2; f.st = fll_st.p;
         f.lower = fll_lo.p; f.upper = fll_up.p; f.nt = fam == F_2FSK ? 16 : 32; f.alpha = fll_alpha; f.beta = fll_beta; f.max_freq = fll_maxf;
+        // (slim single-wave FLL workgroups under an 8-wave-workgroup front end were measured in round 3: the front end alone slows from
+        //  6.57 to 7.24 ms with 8-wave workgroups and stretches to 8.4 - 9.1 ms when it shares the SIMDs; 9.47 ms per step against 9.29)
+        f.slim = 0;
         launch_fll(f, B, cs);
         filt_in = r2l;
     }

@@ -113,7 +113,8 @@ void launch_disc_2fsk(const Disc2fskParams& p, int batch, hipStream_t s);
 // ---- serial loops, one lane per stream ----
 struct FllState { float phase, freq; float2 dl[32]; };
 struct FllParams { RingC in; RingC out; uint64_t q0; uint32_t count; FllState* st;
-                   const float2* lower; const float2* upper; int nt; float alpha, beta, max_freq; };
+                   const float2* lower; const float2* upper; int nt; float alpha, beta, max_freq;
+                   int slim; };   // 1: single-wave workgroups with a 16-sample window (3 KB LDS): fits beside a CU full of front-end workgroups (overlapped mode)
 void launch_fll(const FllParams& p, int batch, hipStream_t s);
 
 struct SymSyncState { uint64_t ii; uint64_t oo; float mu, avg, inst; float x0, x1, x2, d0, d1, d2; };

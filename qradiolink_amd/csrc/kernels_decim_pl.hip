@@ -194,8 +194,8 @@ __device__ unsigned long long g_pm_prof[8];
 #else
 #define PM_STAMP(k) do { } while (0)
 #endif
-template <int J, int NS, int RP>
-__global__ __launch_bounds__(256)
+template <int J, int NS, int RP, int NW>
+__global__ __launch_bounds__(NW * 64)
 void k_decim_pm(const DecimParams P_)
 {
     const DecimParams& P = P_;
@@ -203,16 +203,15 @@ void k_decim_pm(const DecimParams P_)
     // size, which the address arithmetic below relies on --, then the tables
     extern __shared__ __align__(16) unsigned char pm_smem[];
     unsigned char* ring_all = pm_smem;
-    float2* t_lo = reinterpret_cast<float2*>(pm_smem + 4 * RP * 1024);            // fine rotator table; entry 0 is exactly (1, 0): what edge units read through index mask 0
+    float2* t_lo = reinterpret_cast<float2*>(pm_smem + NW * RP * 1024);            // fine rotator table; entry 0 is exactly (1, 0): what edge units read through index mask 0
     float2 (*t_hi_all)[64] = reinterpret_cast<float2 (*)[64]>(t_lo + 512);        // coarse rotator table of each wave's segment
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    t_lo[tid] = P.rot_lo[tid];
-    t_lo[tid + 256] = P.rot_lo[tid + 256];
+    for (int k = tid; k < 512; k += NW * 64) t_lo[k] = P.rot_lo[k];
 
     // unit = (stream, segment); behind the regular units one EDGE unit per stream (outputs pl_edge_ms .. pl_edge_me out of the staged,
     // already rotated scratch: identity phasors)
-    const uint32_t unit = blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t unit = blockIdx.x * (uint32_t)NW + (uint32_t)wave;
     const uint32_t B = P.pl_batch;
     const uint32_t nreg = P.pl_nseg * B;
     const bool edge = unit >= nreg;
@@ -805,14 +804,20 @@ std::vector<float> decim_pm_layout(const std::vector<float>& h, int D)
 #ifndef QRL_PM_RP
 #define QRL_PM_RP 8
 #endif
+#ifndef QRL_PM_NW
+#define QRL_PM_NW 4
+#endif
 template <int J, int NS>
 static int pm_launch_main(const DecimParams& q, uint32_t units, hipStream_t s)
 {
     constexpr int RP = QRL_PM_RP;            // ring pieces per wave (a power of two >= 8: one 16-block group of D <= 52 samples + what is in flight)
-    const auto kern = k_decim_pm<J, NS, RP>;
-    const size_t lds = (size_t)4 * RP * 1024 + 512 * sizeof(float2) + 4 * 64 * sizeof(float2);
+    // 4 waves per workgroup, four workgroups per CU (156 KB of LDS).  8-wave workgroups (two per CU, 144 KB: room for slim recursion
+    // kernels of the previous call beside them) were measured: 7.24 ms against 6.57 ms alone, and no gain in the overlapped mode.
+    constexpr int NW = QRL_PM_NW;
+    const auto kern = k_decim_pm<J, NS, RP, NW>;
+    const size_t lds = (size_t)NW * RP * 1024 + 512 * sizeof(float2) + NW * 64 * sizeof(float2);
     if (dyn_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024) != hipSuccess) return -1;
-    hipLaunchKernelGGL(kern, dim3((units + 3) / 4), dim3(256), lds, s, q);
+    hipLaunchKernelGGL(kern, dim3((units + NW - 1) / NW), dim3(NW * 64), lds, s, q);
     return 0;
 }
 int launch_decim_pm(const DecimParams& p, int batch, hipStream_t s)

@@ -21,9 +21,11 @@ namespace qrl {
 // Geometry: 4 waves per workgroup (64 streams x 4 lanes, one wave per SIMD) and a 128-sample LDS window.  (Single-wave
 // workgroups with a 16-sample window and <= 96 registers were tried so that the kernel could slip in beside the front end of
 // the next call in overlapped mode: the recursion itself got slower -- 2.5 instead of 1.7 ms -- and the overlap no better.)
-constexpr int FLL_TH = 256;              // threads per workgroup
-constexpr int FLL_NS = FLL_TH / 4;       // streams per workgroup
-constexpr int FLL_CH = 128;              // samples per stream per LDS window (power of two: cheap staging index math)
+// Two geometries (template parameters FLL_TH threads per workgroup, FLL_CH samples per stream and LDS window, powers of two):
+//   256 x 128  the stand-alone form: 4 waves per workgroup (64 streams x 4 lanes, one wave per SIMD), 68 KB of LDS;
+//   64 x 16    the SLIM form of the overlapped mode: single-wave workgroups with 3 KB of LDS and <= 216 VGPRs, which the dispatcher can
+//              place on a CU whose LDS and wave slots are otherwise full of front-end workgroups (k_decim_pm leaves 16 KB of LDS and
+//              224 VGPRs per SIMD): the recursion of call k then runs UNDER the front end of call k + 1 instead of behind it.
 
 template <int CTRL> __device__ __forceinline__ float dpp_quad(float v)
 {
@@ -37,9 +39,10 @@ template <int CTRL> __device__ __forceinline__ float dpp_quad(float v)
 // The NCO / loop update is computed redundantly by the four lanes (bit-identical inputs, bit-identical results).  Compared with
 // the lane-per-stream kernel there are 4x more waves (one per SIMD instead of one per CU at 16k streams) with ~3x shorter
 // instruction streams.
-template <int NT>
+template <int NT, int FLL_TH, int FLL_CH>
 __global__ __launch_bounds__(FLL_TH) void k_fll(const FllParams P, int batch)
 {
+    constexpr int FLL_NS = FLL_TH / 4;       // streams per workgroup
     constexpr int GL = NT / 4;
     __shared__ float2 win[FLL_NS][FLL_CH + 1];
     __shared__ float2 tl[NT], tu[NT];
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(FLL_TH) void k_fll(const FllParams P, int batch)
     const int b0 = blockIdx.x * FLL_NS;
     const int b = b0 + sl;
     const bool active = b < batch;
-    if (tid < NT) { tl[tid] = P.lower[tid]; tu[tid] = P.upper[tid]; }
+    for (int k = tid; k < NT; k += FLL_TH) { tl[k] = P.lower[k]; tu[k] = P.upper[k]; }
     float phase = 0.f, freq = 0.f;
     float2 dl[GL];   // dl[t] = y[n - (g GL + t)]
     if (active) {
@@ -149,9 +152,15 @@ __global__ __launch_bounds__(FLL_TH) void k_fll(const FllParams P, int batch)
 void launch_fll(const FllParams& p, int batch, hipStream_t s)
 {
     if (!p.count) return;
-    dim3 grid((batch + FLL_NS - 1) / FLL_NS), block(FLL_TH);
-    if (p.nt == 16) hipLaunchKernelGGL((k_fll<16>), grid, block, 0, s, p, batch);
-    else            hipLaunchKernelGGL((k_fll<32>), grid, block, 0, s, p, batch);
+    if (p.slim) {
+        dim3 grid((batch + 15) / 16), block(64);
+        if (p.nt == 16) hipLaunchKernelGGL((k_fll<16, 64, 16>), grid, block, 0, s, p, batch);
+        else            hipLaunchKernelGGL((k_fll<32, 64, 16>), grid, block, 0, s, p, batch);
+        return;
+    }
+    dim3 grid((batch + 63) / 64), block(256);
+    if (p.nt == 16) hipLaunchKernelGGL((k_fll<16, 256, 128>), grid, block, 0, s, p, batch);
+    else            hipLaunchKernelGGL((k_fll<32, 256, 128>), grid, block, 0, s, p, batch);
 }
 
 // ------------------------------------------------------------------ symbol_sync_ff

@@ -90,3 +90,57 @@ def test_channel_sharding_two_processes_with_broadcast():
     assert len(got) == M
     for c in range(M):
         assert got[c] == np.ascontiguousarray(ref[c]).tobytes(), "channel %d differs from the oracle" % c
+
+
+def test_channel_all_to_all_form_two_emulated_ranks_equal_the_unsharded_receiver(qrl_ctx):
+    """SURVEY 8e, PFB form, as bench.py --config c4 --gpus N runs it: every rank channelizes ITS wideband streams
+    (qrl_chan_channelize, output grouped by destination rank), an all-to-all hands each rank its channels of EVERY stream, the
+    per-channel chains run there (form-3 handles, qrl_chan_process_channels).  Two ranks emulated on one device: the exchange is the
+    same slicing all_to_all_single performs (sharding.exchange_channels; its gloo run is tests/test_sharding.py).  Two calls, so that
+    channelizer history, channel-ring history and the symbol-sync state carry.  Must equal the unsharded receiver bit for bit."""
+    import torch
+    import qradiolink_amd as q
+    import test_gpu_chan as tg
+    M, B, world, n = 64, 4, 2, 64 * 1600
+    cpr, Bl = M // world, B // world
+    iq = tg._wideband(M, n, seed=91, nstreams=B)
+    d = torch.from_numpy(iq).cuda()
+    cuts = [64 * 1000, 64 * 600]
+    # unsharded reference run
+    ref = q.Channelizer(qrl_ctx, M, batch=B, max_chunk=max(cuts))
+    ref.calibrate_rssi(0.25)
+    ref.enable_4fsk()
+    chans = [q.Channelizer(qrl_ctx, M, batch=Bl, max_chunk=max(cuts)) for _ in range(world)]
+    tails = [q.Channelizer(qrl_ctx, 1, batch=B * cpr, max_chunk=max(cuts) // M, form=3) for _ in range(world)]
+    for t in tails:
+        t.calibrate_rssi(0.25)
+        t.enable_4fsk()
+    pos = 0
+    for c in cuts:
+        part = d[:, pos:pos + c].contiguous()
+        pos += c
+        n1 = c // M
+        ro, rc = ref.process(part)
+        ro, rc = ro.cpu().numpy(), rc.cpu().numpy()
+        rr, rrc = ref.rssi.cpu().numpy(), ref.rssi_counts.cpu().numpy()
+        rd, rdc = ref.dibits.cpu().numpy(), ref.fsk_counts.cpu().numpy()
+        send = [torch.zeros((world, Bl, cpr, n1), dtype=torch.complex64, device="cuda") for _ in range(world)]
+        for r in range(world):
+            chans[r].channelize_async(part[r * Bl:(r + 1) * Bl].contiguous(), send[r], world)
+            chans[r].sync()
+        for r in range(world):
+            recv = torch.stack([send[s][r] for s in range(world)])            # what all_to_all_single delivers to rank r
+            tails[r].process_channels_async(recv.reshape(B * cpr, n1).contiguous(), n1)
+            tails[r].sync()
+            o, cn = tails[r].out.cpu().numpy(), tails[r].counts.cpu().numpy()
+            rs, rsc = tails[r].rssi.cpu().numpy(), tails[r].rssi_counts.cpu().numpy()
+            db, dbc = tails[r].dibits.cpu().numpy(), tails[r].fsk_counts.cpu().numpy()
+            for b in range(B):
+                for cl in range(cpr):
+                    row, ch_abs = b * cpr + cl, r * cpr + cl
+                    assert cn[row, 0] == rc[b, ch_abs] and np.array_equal(o[row, 0, :cn[row, 0]], ro[b, ch_abs, :rc[b, ch_abs]]), (r, b, cl)
+                    assert rsc[row, 0] == rrc[b, ch_abs] and np.array_equal(rs[row, 0, :rsc[row, 0]], rr[b, ch_abs, :rrc[b, ch_abs]])
+                    assert dbc[row, 0, 2] == rdc[b, ch_abs, 2] and np.array_equal(db[row, 0, :dbc[row, 0, 2]], rd[b, ch_abs, :rdc[b, ch_abs, 2]])
+    assert np.abs(ro).max() > 1000
+    for h in [ref] + chans + tails:
+        h.close()

@@ -210,6 +210,79 @@ __global__ __launch_bounds__(NW * 64) void w3(const unsigned char* in, size_t se
     wait_vm<0>();
     if (acc == 12345.678f || sink == 1.2345f) out[0] = acc + sink;
 }
+// ---- W4: W3's flow with a group of GB bytes, NS read-outs per lane, and per group NM f32 MFMAs (16x16x4, NA independent accumulators)
+// beside CW dependent FMAs per read-out: what a phase-major front end for the 25:1 / 100:1 filters (42 block lags = 3 lag tiles)
+// would ask of the matrix pipe and of the memory path at the same time.
+typedef float f32x4_u __attribute__((ext_vector_type(4)));
+template <int RP, int GB, int NS, int NM, int NA, int CW, int NW>
+__global__ __launch_bounds__(NW * 64) void w4(const unsigned char* in, size_t seg_bytes, size_t nunits, float* out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t u = (size_t)blockIdx.x * NW + wave;
+    if (u >= nunits) return;
+    unsigned char* ring = smem + wave * (RP * 1024);
+    const uint32_t rbase = (uint32_t)(uintptr_t)(lds_ptr_t)ring;
+    const unsigned char* g = in + u * seg_bytes + lane * 16;
+    const uint32_t ngrp = (uint32_t)(seg_bytes / GB);
+    const uint32_t npieces = (ngrp * (uint32_t)GB + 1023u) >> 10;
+    uint32_t issued = 0;
+    auto issue_upto = [&](uint32_t want) {
+        while (issued < want) { glds16<1>(g + (size_t)issued * 1024, rbase + (issued & (RP - 1)) * 1024u); ++issued; }
+    };
+    f32x4_u z[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) z[a] = f32x4_u{0.f, 0.f, 0.f, 0.f};
+    float acc = 0.f;
+    issue_upto(npieces < RP ? npieces : RP);
+    uint32_t gbytes = 0;
+    const uint32_t lane_byte = ((uint32_t)(lane & 15) * (uint32_t)(GB / 16) + (uint32_t)(lane >> 4) * 8u);
+    for (uint32_t gi = 0; gi < ngrp; ++gi) {
+        uint32_t need = (gbytes + GB + 1023u) >> 10;
+        need = need < npieces ? need : npieces;
+        switch (issued - need) {
+        case 0: wait_vm<0>(); break; case 1: wait_vm<1>(); break; case 2: wait_vm<2>(); break; case 3: wait_vm<3>(); break;
+        case 4: wait_vm<4>(); break; case 5: wait_vm<5>(); break; case 6: wait_vm<6>(); break; case 7: wait_vm<7>(); break;
+        case 8: wait_vm<8>(); break; case 9: wait_vm<9>(); break; case 10: wait_vm<10>(); break; case 11: wait_vm<11>(); break;
+        case 12: wait_vm<12>(); break; case 13: wait_vm<13>(); break; case 14: wait_vm<14>(); break; default: wait_vm<15>(); break;
+        }
+        float2 x[NS];
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) x[s2] = *reinterpret_cast<const float2*>(ring + ((gbytes + lane_byte + 32u * s2) & (RP * 1024u - 1u)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint32_t cap = ((gbytes + GB) >> 10) + RP;
+        issue_upto(cap < npieces ? cap : npieces);
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) {
+            float v = x[s2].x;
+#pragma unroll
+            for (int k = 0; k < CW; ++k) v = fmaf(v, x[s2].y, 0.25f);
+            acc += v;
+#pragma unroll
+            for (int k = 0; k < NM / NS; ++k) z[(s2 * (NM / NS) + k) % NA] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, x[s2].y, z[(s2 * (NM / NS) + k) % NA], 0, 0, 0);
+        }
+        gbytes += GB;
+    }
+    wait_vm<0>();
+    float zs = 0.f;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) zs += z[a][0] + z[a][1] + z[a][2] + z[a][3];
+    if (acc + zs == 12345.678f) out[0] = acc;
+}
+template <int RP, int GB, int NS, int NM, int NA, int CW, int NW>
+static void run_w4(const unsigned char* in, size_t bytes, int pad_kib, float* out)
+{
+    const auto kern = w4<RP, GB, NS, NM, NA, CW, NW>;
+    const size_t lds = (size_t)NW * RP * 1024 + (size_t)pad_kib * 1024;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const size_t seg = (size_t)(204800 / GB) * GB;
+    const size_t nunits = bytes / seg;
+    char nm[200];
+    snprintf(nm, sizeof nm, "W4 pm flow: group %d B, ring %d KiB, %d MFMA (%d accumulators) + %d x %d fma per group, %d waves/WG, LDS/WG %zu KiB",
+             GB, RP, NM, NA, NS, CW, NW, lds / 1024);
+    rep(nm, timeit([&] { hipLaunchKernelGGL(kern, dim3((nunits + NW - 1) / NW), dim3(NW * 64), lds, 0, in, seg, nunits, out); }, 4), (double)nunits * seg);
+}
 template <int RP, int NT, int CW, int PFK, int NW>
 static void run_w3(const unsigned char* in, size_t bytes, int pad_kib, float* out)
 {
@@ -274,6 +347,19 @@ int main(int argc, char** argv)
     {
         const size_t seg = 25600, nunits = bytes / 8 / seg;   // 512 blocks of 50 samples = 200 KiB
         rep("P2 k_decim_pl pattern: wave-seq 50 lanes x 8 B, 8 in flight, seg 200 KB", timeit([&] { hipLaunchKernelGGL(pseq50<8>, dim3((nunits + 3) / 4), dim3(256), 0, 0, (const float2*)in, seg, nunits, out); }, 4), (double)nunits * seg * 8);
+    }
+    if (quick == 3) {   // phase-major front ends for the long filters: 42 MFMA per 16 blocks of 25 samples, 150 per 16 blocks of 100
+        run_w4<8, 6400, 13, 26, 2, 8, 4>(in, bytes, 6, out);      // = k_decim_pm's shape (C1)
+        run_w4<8, 3200, 7, 42, 6, 8, 4>(in, bytes, 6, out);       // 25:1, ring holds 2.5 groups
+        run_w4<8, 3200, 7, 42, 6, 8, 4>(in, bytes, 0, out);       // 5 WGs/CU
+        run_w4<8, 3200, 7, 0, 6, 8, 4>(in, bytes, 6, out);        // no MFMA
+        run_w4<8, 3200, 7, 42, 6, 0, 4>(in, bytes, 6, out);       // no VALU work
+        run_w4<4, 3200, 7, 42, 6, 8, 4>(in, bytes, 0, out);       // 4 KiB rings: 16 KiB/WG, 8+ WGs/CU
+        run_w4<16, 12800, 25, 150, 6, 8, 4>(in, bytes, 6, out);   // 100:1: 12.8 KB groups, 16 KiB rings, 2 WGs/CU
+        run_w4<16, 12800, 25, 150, 6, 8, 2>(in, bytes, 3, out);   // 2-wave workgroups: 35 KiB/WG, 4 WGs/CU = 8 waves
+        run_w4<16, 12800, 25, 0, 6, 8, 4>(in, bytes, 6, out);
+        run_w4<8, 6400, 13, 78, 6, 8, 4>(in, bytes, 6, out);      // 50:1 front end (2091 taps): 78 MFMA per 6400 B
+        return 0;
     }
     if (quick == 2) {   // the data flow of k_decim_pm and ways to keep more bytes in flight
         run_w3<8, 1, 1, 0, 4>(in, bytes, 6, out);      // as k_decim_pm: 4 WGs/CU x 4 waves, 38 KiB/WG
