@@ -92,6 +92,7 @@ size_t orc_decim_fir_ccf_pm(const cf32* in, size_t n, const float* taps, int nt,
 int    orc_decim_uses_pm(int nt, int decim);
 size_t orc_decim_fir_ccf_simd(const cf32* in, size_t n, const float* taps, int nt, int decim, cf32* out);   /* CPU baseline only */
 void   orc_set_decim_impl(int impl);   /* 0: summation contracts (checker), 1: AVX2 dot product (bench.py cpu_baseline timing) */
+size_t orc_decim_xlating(const cf32* in, size_t n, const float* taps, int nt, int D, cf32* out);   /* multi-carrier graphs: always the m16 order */
 size_t orc_decim_auto(const cf32* in, size_t n, const float* taps, int nt, int decim, cf32* out);
 size_t orc_resamp_ccf(const cf32* in, size_t n, const float* taps, int nt, int interp, int decim, cf32* out);
 size_t orc_resamp_fff(const float* in, size_t n, const float* taps, int nt, int interp, int decim, float* out);

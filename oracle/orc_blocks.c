@@ -162,26 +162,33 @@ int orc_decim_uses_pl(int nt, int D)
     if (E == 2 && R == 1) return (D % 2) == 0 && U <= 42;
     return 0;
 }
-/* ---- contract "pm" (phase major; qradiolink_amd/csrc/kernels_decim_pl.hip k_decim_pm): 32 < D <= 52, J = ceil(nt / D) <= 16 ----------
+/* ---- contract "pm" (phase major; qradiolink_amd/csrc/kernels_decim_pl.hip k_decim_pm) ---------------------------------------------
  * The stream is cut into BLOCKS of D samples, block c = samples (c-1) D + 1 .. c D (so output m ends at the last sample of block m).
- * Sample p (0 .. D-1) of block c = m - j meets output m with tap H(p, j) = h[j D + D - 1 - p].
+ * Sample p (0 .. D-1) of block c = m - j meets output m with tap H(p, j) = h[j D + D - 1 - p], j = 0 .. J-1, J = ceil(nt / D) <= 48.
  *   Z_j = one fmaf chain over the block's samples, p ASCENDING, from +0          (a [D x J] product on the f32 matrix pipe:
  *                                                                                 v_mfma_f32_16x16x4_f32 accumulates k in order)
- *   The J block terms of an output are then added with plain float adds in the order the kernel's lane layout fixes: the matrix
- *   result holds Z_j of 16 consecutive blocks (an ABSOLUTE group: blocks 16 G .. 16 G + 15) in lane row q = j >> 2; terms whose block
- *   lies in the output's own group (j <= m mod 16) are summed per row, j ascending, into R_q, the terms from the previous group
- *   likewise into C_q (they were summed one group earlier); V_q = R_q + C_q; y = (V_0 + V_1) + (V_2 + V_3).
- * The grouping is by absolute index, so the value of output m does not depend on where a call or a kernel segment starts. */
+ *   The J block terms of an output are then added with plain float adds in the order the kernel's lane layout fixes.  Lags come in
+ *   TILES of 16 (j = 16 t + j'); one matrix result holds Z of 16 consecutive blocks (an ABSOLUTE group: blocks 16 G .. 16 G + 15) for
+ *   the 16 lags of a tile, lag j' in lane row q = j' >> 2.  A term lands in the output's group either "in row" (j' <= m mod 16) or as
+ *   a carry from the group before; per tile t and row q the in-row terms are summed j' ascending into R_t[q], the carries into C_t[q]
+ *   (both from +0).  The tiles meet through a delay line over the groups:
+ *       V[q] = R_0[q] + ((C_0[q] + R_1[q]) + ((C_1[q] + R_2[q]) + C_2[q]));      y = (V[0] + V[1]) + (V[2] + V[3]).
+ * The grouping is by absolute index, so the value of output m does not depend on where a call or a kernel segment starts.
+ * Geometries: the 1:50-class first stages (32 < D <= 52, J <= 16: one tile) and the device-rate front ends of 10 / 20 / 25 / 50 /
+ * 100 Msps (41.8 D taps: J = 42, three tiles), i.e. ceil(D / 4) in {3, 5, 7, 13, 25}: the instantiated kernels. */
 int orc_decim_uses_pm(int nt, int D)
 {
-    return D > 32 && D <= 52 && (nt + D - 1) / D <= 16;   /* (a 16-block group of D <= 52 samples fits the 8 KiB LDS ring of a wave) */
+    const int J = (nt + D - 1) / D, NS = (D + 3) / 4;
+    if (D > 32 && D <= 52 && J <= 16) return 1;
+    return J > 16 && J <= 48 && (NS == 3 || NS == 5 || NS == 7 || NS == 13 || NS == 25);
 }
 size_t orc_decim_fir_ccf_pm(const cf32* in, size_t n, const float* taps, int nt, int D, cf32* out)
 {
     const size_t nout = orc_decim_count(n, 1, D);
     const int J = (nt + D - 1) / D;
     for (size_t m = 0; m < nout; m++) {
-        float Rr[4] = {0.f, 0.f, 0.f, 0.f}, Ri[4] = {0.f, 0.f, 0.f, 0.f}, Cr[4] = {0.f, 0.f, 0.f, 0.f}, Ci[4] = {0.f, 0.f, 0.f, 0.f};
+        float Rr[3][4], Ri[3][4], Cr[3][4], Ci[3][4];
+        for (int t = 0; t < 3; t++) for (int q = 0; q < 4; q++) Rr[t][q] = Ri[t][q] = Cr[t][q] = Ci[t][q] = 0.0f;
         const int np = (int)(m & 15u);
         for (int j = 0; j < J; j++) {
             const long long c = (long long)m - j;
@@ -194,12 +201,15 @@ size_t orc_decim_fir_ccf_pm(const cf32* in, size_t n, const float* taps, int nt,
                 if (i >= 0 && (size_t)i < n) x = in[i];
                 zr = fmaf(h, x.re, zr); zi = fmaf(h, x.im, zi);
             }
-            const int q = j >> 2;
-            if (j <= np) { Rr[q] = Rr[q] + zr; Ri[q] = Ri[q] + zi; }
-            else         { Cr[q] = Cr[q] + zr; Ci[q] = Ci[q] + zi; }
+            const int t = j >> 4, jp = j & 15, q = jp >> 2;
+            if (jp <= np) { Rr[t][q] = Rr[t][q] + zr; Ri[t][q] = Ri[t][q] + zi; }
+            else          { Cr[t][q] = Cr[t][q] + zr; Ci[t][q] = Ci[t][q] + zi; }
         }
         float Vr[4], Vi[4];
-        for (int q = 0; q < 4; q++) { Vr[q] = Rr[q] + Cr[q]; Vi[q] = Ri[q] + Ci[q]; }
+        for (int q = 0; q < 4; q++) {
+            Vr[q] = Rr[0][q] + ((Cr[0][q] + Rr[1][q]) + ((Cr[1][q] + Rr[2][q]) + Cr[2][q]));
+            Vi[q] = Ri[0][q] + ((Ci[0][q] + Ri[1][q]) + ((Ci[1][q] + Ri[2][q]) + Ci[2][q]));
+        }
         out[m].re = (Vr[0] + Vr[1]) + (Vr[2] + Vr[3]);
         out[m].im = (Vi[0] + Vi[1]) + (Vi[2] + Vi[3]);
     }
@@ -274,6 +284,15 @@ size_t orc_decim_fir_ccf_simd(const cf32* in, size_t n, const float* taps, int n
     }
     free(hr);
     return nout;
+}
+/* the decimator of the frequency-translating multi-carrier graphs: the product keeps the banded-Toeplitz MFMA kernel there (chan.cpp),
+ * so the summation order is the "m16" contract whatever orc_decim_auto's rule says for the geometry */
+size_t orc_decim_xlating(const cf32* in, size_t n, const float* taps, int nt, int D, cf32* out)
+{
+    orc_trace_event("resamp_ccf(1,%d,%s)", D, orc_trace_name(taps, sizeof(float) * (size_t)nt));
+    if (g_decim_impl == 1) return orc_decim_fir_ccf_simd(in, n, taps, nt, D, out);
+    if (orc_decim_uses_m16(nt, D)) return orc_decim_fir_ccf_m16(in, n, taps, nt, D, out);
+    return orc_decim_fir_ccf(in, n, taps, nt, D, 4, out);
 }
 size_t orc_decim_auto(const cf32* in, size_t n, const float* taps, int nt, int D, cf32* out)
 {

@@ -1089,7 +1089,7 @@ size_t orc_demod_mmdvm_xlating_bank_4fsk(const cf32* in, size_t n, int N, int16_
         const float carrier_offset = -25000.0f;
         const uint64_t inc = orc_phase_inc_to_turn(2 * M_PI * carrier_offset * ct / (float)fs);
         orc_rotator(in, n, inc, 0, rot);
-        orc_decim_auto(rot, n, taps, nt, N, ch + (size_t)c * n1);
+        orc_decim_xlating(rot, n, taps, nt, N, ch + (size_t)c * n1);
     }
     free(rot); free(taps);
     const size_t m = multi_tail(ch, N, n1, out, cap, rssi, rcap, cal, dibits, dcap, ndib);
@@ -1122,7 +1122,7 @@ size_t orc_demod_mmdvm_xlating(const cf32* in, size_t n, int N, int separation, 
         const uint64_t inc = orc_phase_inc_to_turn(2 * M_PI * carrier_offset * ct / (float)fs);
         if (ct != 0) orc_trace_event("rotator(%.17g)", 2 * M_PI * carrier_offset * ct / (float)fs);        /* the centre carrier has no rotator */
         orc_rotator(in, n, inc, 0, rot);
-        orc_decim_auto(rot, n, taps, nt, D, a);
+        orc_decim_xlating(rot, n, taps, nt, D, a);
         orc_fir_ccf(a, n2, ft, nf, b);
         if (rssi) {
             float* tmp = NEW(float, n2 / 300 + 1);

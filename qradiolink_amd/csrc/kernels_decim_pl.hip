@@ -194,17 +194,24 @@ __device__ unsigned long long g_pm_prof[8];
 #else
 #define PM_STAMP(k) do { } while (0)
 #endif
-template <int J, int NS, int RP, int NW>
+// J > 16 (the device-rate front ends: 41.8 D taps = 42 block lags): the lags come in NT = ceil(J / 16) TILES, one matrix result per tile
+// (the rotated B operand is shared), and the tiles meet through a delay line over the groups -- tile t of group G contributes to the
+// outputs of groups G + t (in row) and G + t + 1 (carry):  V = R_0 + A1;  A1' = (C_0 + R_1) + A2;  A2' = (C_1 + R_2) + A3;  A3' = C_2.
+// 42 matrix instructions per 16 blocks of D samples = 0.094 per sample whatever D: the kernel is bound by the matrix pipe at about
+// 4.1 - 4.4 TB/s of input (tools/ubench/stream_lds.hip W4), against 2.5 - 2.7 TB/s for the banded-Toeplitz form of rounds 1-2 (26 % of
+// its matrix work multiplied zero taps, every tile went through LDS twice) and for the VALU phase-lane kernel at 100:1.
+template <int J, int NS, int RP, int NW, int NHI>
 __global__ __launch_bounds__(NW * 64)
 void k_decim_pm(const DecimParams P_)
 {
+    constexpr int NT = (J + 15) / 16;
     const DecimParams& P = P_;
     // dynamic LDS (the kernel has no static allocation, so it starts at LDS byte 0): rings first -- ring of wave w at byte w * ring
     // size, which the address arithmetic below relies on --, then the tables
     extern __shared__ __align__(16) unsigned char pm_smem[];
     unsigned char* ring_all = pm_smem;
     float2* t_lo = reinterpret_cast<float2*>(pm_smem + NW * RP * 1024);            // fine rotator table; entry 0 is exactly (1, 0): what edge units read through index mask 0
-    float2 (*t_hi_all)[64] = reinterpret_cast<float2 (*)[64]>(t_lo + 512);        // coarse rotator table of each wave's segment
+    float2 (*t_hi_all)[NHI] = reinterpret_cast<float2 (*)[NHI]>(t_lo + 512);      // coarse rotator table of each wave's segment (NHI x 512 samples)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int k = tid; k < 512; k += NW * 64) t_lo[k] = P.rot_lo[k];
@@ -228,13 +235,19 @@ void k_decim_pm(const DecimParams P_)
     const int64_t i_first_s = (G0 * 16 - 1) * (int64_t)D + 1;        // first sample of block 16 G0 (regular units: >= n0; edge units: the scratch starts here)
     const uint64_t i_first = (uint64_t)i_first_s;
     const uint32_t kb0 = edge ? 0u : (uint32_t)((i_first - P.rot_nbase) >> 9);
-    if (active) t_hi_all[wave][lane] = edge ? make_float2(1.f, 0.f) : sincos_turn(P.rot_acc + ((uint64_t)(kb0 + (uint32_t)lane) << 9) * P.rot_inc);
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < NHI / 64; ++e)
+            t_hi_all[wave][lane + 64 * e] = edge ? make_float2(1.f, 0.f) : sincos_turn(P.rot_acc + ((uint64_t)(kb0 + (uint32_t)(lane + 64 * e)) << 9) * P.rot_inc);
+    }
     __syncthreads();
     if (!active) return;
 
-    float a[NS];                                                     // A operand: H[p = 4 s + (lane >> 4)][j = lane & 15]
+    float a[NT][NS];                                                 // A operands: H[p = 4 s + (lane >> 4)][j = 16 t + (lane & 15)]
 #pragma unroll
-    for (int s = 0; s < NS; ++s) a[s] = P.pl_taps[s * 64 + lane];
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a[t][s] = P.pl_taps[(t * NS + s) * 64 + lane];
     const int q = lane >> 4, nn = lane & 15;
     // the wave's byte stream: row = the stream's buffer (or its edge scratch), first byte of block 16 G0 at row + off0
     const unsigned char* rowp = reinterpret_cast<const unsigned char*>(edge ? P.pl_edge + (size_t)b * P.pl_edge_stride : P.in + (size_t)b * P.in_stride);
@@ -247,7 +260,7 @@ void k_decim_pm(const DecimParams P_)
     const uint32_t q_safe = (uint32_t)((row_bytes - a_off) >> 10);   // pieces [0, q_safe) lie inside the row; later ones are clamped to its last 16 bytes (never consumed)
     const uint32_t rbase = pm_lds_addr(ring_all) + (uint32_t)wave * (RP * 1024u);   // multiple of the ring size
     const uint32_t tlo_base = pm_lds_addr(t_lo);
-    const uint32_t thi_base = pm_lds_addr(t_hi_all) + (uint32_t)wave * 512u;
+    const uint32_t thi_base = pm_lds_addr(t_hi_all) + (uint32_t)wave * (NHI * 8u);
     const unsigned char* gp = rowp + a_off + (size_t)lane * 16;      // this lane's 16 bytes of the next piece
     const unsigned char* last16 = rowp + row_bytes - 16;
     uint32_t issued = 0;
@@ -265,7 +278,7 @@ void k_decim_pm(const DecimParams P_)
     const uint32_t lane_byte = ((uint32_t)nn * (uint32_t)D + (uint32_t)q) * 8u;      // this lane's sample of step 0 inside a group
     const bool last_valid = 4 * (NS - 1) + q < D;                    // step NS - 1 reaches past the block for the upper lane rows
     float2* orow = P.out.p + ((size_t)b * (P.out_row_mul_m1 + 1u) + P.out_row_add) * (P.out.mask + 1u);
-    float Cr = 0.f, Ci = 0.f;                                        // carry of the previous group, per lane row
+    float Ar[3] = {0.f, 0.f, 0.f}, Ai[3] = {0.f, 0.f, 0.f};          // delay line over the groups (per lane row): what earlier groups owe the next three
 
 #ifdef QRL_PM_PROF
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -295,7 +308,9 @@ void k_decim_pm(const DecimParams P_)
             issue_upto(cap < npieces ? cap : npieces);
         }
         PM_STAMP(2);
-        f32x4_pm zr = {0.f, 0.f, 0.f, 0.f}, zi = zr;
+        f32x4_pm zr[NT], zi[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { zr[t] = f32x4_pm{0.f, 0.f, 0.f, 0.f}; zi[t] = zr[t]; }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             // rotator: phasor of sample k = T_hi[k >> 9] (x) T_lo[k & 511], byte addressed
@@ -308,24 +323,37 @@ void k_decim_pm(const DecimParams P_)
             float2 xs = cmul_fma(x[s], cmul_fma(phi, plo));
 #endif
             if (s == NS - 1 && !last_valid) xs = make_float2(0.f, 0.f);   // phases >= D: zero taps AND zero samples
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
 #if QRL_PM_ABL & 4
-            zr[s & 3] = fmaf(a[s], xs.x, zr[s & 3]); zi[s & 3] = fmaf(a[s], xs.y, zi[s & 3]);
+                zr[t][s & 3] = fmaf(a[t][s], xs.x, zr[t][s & 3]); zi[t][s & 3] = fmaf(a[t][s], xs.y, zi[t][s & 3]);
 #else
-            zr = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xs.x, zr, 0, 0, 0);
-            zi = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xs.y, zi, 0, 0, 0);
+                zr[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], xs.x, zr[t], 0, 0, 0);
+                zi[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], xs.y, zi[t], 0, 0, 0);
 #endif
+            }
         }
         PM_STAMP(3);
-        // y[16 G + n'] = sum_j Z[n' - j][j]: per lane row the in-group terms (R) and the terms for the next group (C), j ascending
-        float Rr = 0.f, Ri = 0.f, Cnr = 0.f, Cni = 0.f;
+        // y[16 G + n'] = sum_j Z[n' - j][j]: per tile and lane row the in-row terms (R) and the carries (C), lag ascending; then the
+        // delay line: this group's outputs take R_0 + A1, and what tiles 0..2 owe later groups moves one place down
+        float Rr[3] = {0.f, 0.f, 0.f}, Ri[3] = {0.f, 0.f, 0.f}, Cr[3] = {0.f, 0.f, 0.f}, Ci[3] = {0.f, 0.f, 0.f};
 #if QRL_PM_ABL & 8
-        Rr = zr[0] + zr[1] + zr[2] + zr[3]; Ri = zi[0] + zi[1] + zi[2] + zi[3];
+        Rr[0] = zr[0][0] + zr[0][1] + zr[0][2] + zr[0][3]; Ri[0] = zi[0][0] + zi[0][1] + zi[0][2] + zi[0][3];
 #else
-        pm_diag<J, 0>(zr, Rr, Cnr);
-        pm_diag<J, 0>(zi, Ri, Cni);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            constexpr int JL = J - 16 * (NT - 1);                    // lags of the last tile
+            if (t < NT - 1) { pm_diag<16, 0>(zr[t], Rr[t], Cr[t]); pm_diag<16, 0>(zi[t], Ri[t], Ci[t]); }
+            else            { pm_diag<JL, 0>(zr[t], Rr[t], Cr[t]); pm_diag<JL, 0>(zi[t], Ri[t], Ci[t]); }
+        }
 #endif
-        const float Vr = Rr + Cr, Vi = Ri + Ci;
-        Cr = Cnr; Ci = Cni;
+        const float Vr = Rr[0] + Ar[0], Vi = Ri[0] + Ai[0];
+        if constexpr (NT == 1) { Ar[0] = Cr[0]; Ai[0] = Ci[0]; }
+        else {
+            Ar[0] = (Cr[0] + Rr[1]) + Ar[1]; Ai[0] = (Ci[0] + Ri[1]) + Ai[1];
+            Ar[1] = (Cr[1] + Rr[2]) + Ar[2]; Ai[1] = (Ci[1] + Ri[2]) + Ai[2];
+            Ar[2] = Cr[2]; Ai[2] = Ci[2];
+        }
         // fold the four lane rows: (V_0 + V_1) + (V_2 + V_3); rows 0 / 1 of the result = real / imaginary part of the 16 outputs
         const auto w16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(Vr), __float_as_uint(Vi), false, false);
         const float w = __uint_as_float(w16[0]) + __uint_as_float(w16[1]);
@@ -365,7 +393,11 @@ __global__ __launch_bounds__(256) void k_decim_pm_gen(const DecimParams P_, uint
     const uint64_t kk0 = P.n0 - P.rot_nbase;                     // NCO index of in[0]
     uint64_t hi_blk = ~0ull;
     float2 hi = make_float2(1.f, 0.f);
-    float Rr[4] = {0.f, 0.f, 0.f, 0.f}, Ri[4] = {0.f, 0.f, 0.f, 0.f}, Cr[4] = {0.f, 0.f, 0.f, 0.f}, Ci[4] = {0.f, 0.f, 0.f, 0.f};
+    float Rr[3][4], Ri[3][4], Cr[3][4], Ci[3][4];                // [lag tile][lane row]
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) Rr[t][qq] = Ri[t][qq] = Cr[t][qq] = Ci[t][qq] = 0.f;
     const int np = (int)(m & 15u);
     for (int j = 0; j < J; ++j) {
         const int64_t c = (int64_t)m - j;
@@ -398,13 +430,23 @@ __global__ __launch_bounds__(256) void k_decim_pm_gen(const DecimParams P_, uint
             }
             zr = fmaf(h, x.x, zr); zi = fmaf(h, x.y, zi);
         }
-        const int qq = j >> 2;
-        if (j <= np) { Rr[qq] = Rr[qq] + zr; Ri[qq] = Ri[qq] + zi; }
-        else         { Cr[qq] = Cr[qq] + zr; Ci[qq] = Ci[qq] + zi; }
+        const int jp = j & 15, qq = jp >> 2;
+        // (static indexing: the tile / row selects are unrolled so the buckets stay in registers)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (t == (j >> 4) && u == qq) {
+                    if (jp <= np) { Rr[t][u] = Rr[t][u] + zr; Ri[t][u] = Ri[t][u] + zi; }
+                    else          { Cr[t][u] = Cr[t][u] + zr; Ci[t][u] = Ci[t][u] + zi; }
+                }
     }
     float Vr[4], Vi[4];
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) { Vr[qq] = Rr[qq] + Cr[qq]; Vi[qq] = Ri[qq] + Ci[qq]; }
+    for (int qq = 0; qq < 4; ++qq) {
+        Vr[qq] = Rr[0][qq] + ((Cr[0][qq] + Rr[1][qq]) + ((Cr[1][qq] + Rr[2][qq]) + Cr[2][qq]));
+        Vi[qq] = Ri[0][qq] + ((Ci[0][qq] + Ri[1][qq]) + ((Ci[1][qq] + Ri[2][qq]) + Ci[2][qq]));
+    }
     P.out.p[((size_t)b * (P.out_row_mul_m1 + 1u) + P.out_row_add) * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] =
         make_float2((Vr[0] + Vr[1]) + (Vr[2] + Vr[3]), (Vi[0] + Vi[1]) + (Vi[2] + Vi[3]));
 }
@@ -779,7 +821,13 @@ extern "C" void qrl_pm_prof_read(unsigned long long* out8)
 }
 #endif
 // ---- "pm" contract: rule (shared with oracle/orc_blocks.c orc_decim_uses_pm), tables, launcher ---------------------------------------
-bool decim_uses_pm(int nt, int D) { return D > 32 && D <= 52 && (nt + D - 1) / D <= 16; }
+bool decim_uses_pm(int nt, int D)
+{
+    const int J = (nt + D - 1) / D, NS = (D + 3) / 4;
+    if (D > 32 && D <= 52 && J <= 16) return true;                // one lag tile: the 1:50 first stages of a 1 Msps device
+    // up to three lag tiles: the device-rate front ends (41.8 D taps) at 10:1, 20:1, 25:1, 50:1, 100:1
+    return J > 16 && J <= 48 && (NS == 3 || NS == 5 || NS == 7 || NS == 13 || NS == 25);
+}
 size_t decim_pm_edge_len(int nt, int D)
 {
     // the edge unit of a call starts at the 16-block group of block m0 - (J - 1) and ends with the last output in front of the first
@@ -788,17 +836,20 @@ size_t decim_pm_edge_len(int nt, int D)
     return decim_uses_pm(nt, D) ? (size_t)(((2 * J + 32) * D + 1) & ~1) : 0;
 }
 uint32_t decim_pm_lookback(int nt, int D) { return (uint32_t)(((nt + D - 1) / D + 18) * D); }
-// A-operand table [NS][64]: lane l (j = l & 15, k = l >> 4) of step s holds H[p = 4 s + k][j] = h[j D + D - 1 - p]; the raw taps follow
+// A-operand table [NT][NS][64]: lane l (j = 16 t + (l & 15), k = l >> 4) of step s, tile t holds H[p = 4 s + k][j] = h[j D + D - 1 - p];
+// the raw taps follow
+static int pm_tiles(int J) { return J <= 16 ? 1 : 3; }
 std::vector<float> decim_pm_layout(const std::vector<float>& h, int D)
 {
-    const int nt = (int)h.size(), J = (nt + D - 1) / D, NS = (D + 3) / 4;
-    std::vector<float> t((size_t)NS * 64 + (size_t)nt, 0.0f);
-    for (int s = 0; s < NS; ++s)
-        for (int l = 0; l < 64; ++l) {
-            const int j = l & 15, p = 4 * s + (l >> 4), k = j * D + D - 1 - p;
-            if (j < J && p < D && k < nt) t[(size_t)s * 64 + l] = h[k];
-        }
-    for (int k = 0; k < nt; ++k) t[(size_t)NS * 64 + k] = h[k];
+    const int nt = (int)h.size(), J = (nt + D - 1) / D, NS = (D + 3) / 4, NT = pm_tiles(J);
+    std::vector<float> t((size_t)NT * NS * 64 + (size_t)nt, 0.0f);
+    for (int tt = 0; tt < NT; ++tt)
+        for (int s = 0; s < NS; ++s)
+            for (int l = 0; l < 64; ++l) {
+                const int j = 16 * tt + (l & 15), p = 4 * s + (l >> 4), k = j * D + D - 1 - p;
+                if (j < J && p < D && k < nt) t[((size_t)tt * NS + s) * 64 + l] = h[k];
+            }
+    for (int k = 0; k < nt; ++k) t[(size_t)NT * NS * 64 + k] = h[k];
     return t;
 }
 #ifndef QRL_PM_RP
@@ -807,15 +858,15 @@ std::vector<float> decim_pm_layout(const std::vector<float>& h, int D)
 #ifndef QRL_PM_NW
 #define QRL_PM_NW 4
 #endif
-template <int J, int NS>
+template <int J, int NS, int RP = QRL_PM_RP, int NHI = 64>
 static int pm_launch_main(const DecimParams& q, uint32_t units, hipStream_t s)
 {
-    constexpr int RP = QRL_PM_RP;            // ring pieces per wave (a power of two >= 8: one 16-block group of D <= 52 samples + what is in flight)
+    // RP = ring pieces per wave (a power of two: one 16-block group -- 128 D bytes -- + what is in flight)
     // 4 waves per workgroup, four workgroups per CU (156 KB of LDS).  8-wave workgroups (two per CU, 144 KB: room for slim recursion
     // kernels of the previous call beside them) were measured: 7.24 ms against 6.57 ms alone, and no gain in the overlapped mode.
     constexpr int NW = QRL_PM_NW;
-    const auto kern = k_decim_pm<J, NS, RP, NW>;
-    const size_t lds = (size_t)NW * RP * 1024 + 512 * sizeof(float2) + NW * 64 * sizeof(float2);
+    const auto kern = k_decim_pm<J, NS, RP, NW, NHI>;
+    const size_t lds = (size_t)NW * RP * 1024 + 512 * sizeof(float2) + NW * NHI * sizeof(float2);
     if (dyn_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024) != hipSuccess) return -1;
     hipLaunchKernelGGL(kern, dim3((units + NW - 1) / NW), dim3(NW * 64), lds, s, q);
     return 0;
@@ -826,7 +877,7 @@ int launch_decim_pm(const DecimParams& p, int batch, hipStream_t s)
     const int D = p.D, nt = p.nt, J = (nt + D - 1) / D, NS = (D + 3) / 4;
     DecimParams q = p;
     q.pl_J = J; q.pl_E = 1; q.pl_R = 1;
-    q.pl_hraw = p.pl_taps + (size_t)NS * 64;
+    q.pl_hraw = p.pl_taps + (size_t)pm_tiles(J) * NS * 64;
     const uint64_t m_end = p.m0 + p.m_count;
     auto gen = [&](uint64_t first, uint64_t last) {
         if (last > first) hipLaunchKernelGGL(k_decim_pm_gen, dim3((uint32_t)((last - first + 255) / 256), batch), dim3(256), 0, s, q, first, (uint32_t)(last - first));
@@ -865,9 +916,13 @@ int launch_decim_pm(const DecimParams& p, int batch, hipStream_t s)
     // segment length: a multiple of 16 outputs (every segment then starts on a group boundary), long enough to keep the warm-up
     // re-reads small (J - 1 blocks per segment), short enough to spread the call over >= ~16 waves per CU, and inside the 64-entry
     // coarse rotator table of a wave (64 x 512 samples, 16 blocks of slack for the last group)
-    uint64_t S = total / (256u * 16u * 4u);
-    const uint64_t s_cap = (uint64_t)((62 * 512) / D - J - 16) / 16 * 16;
-    if (S > 512) S = 512;
+    // (three-tile geometries: 41 warm-up blocks per segment, so longer segments and the 256-entry coarse table)
+    const bool multi = J > 16;
+    const int nhi = multi ? 256 : 64;
+    const uint32_t waves_cu = multi && D > 52 ? 8u : 16u;
+    uint64_t S = total / (256u * waves_cu * (multi ? 2u : 4u));
+    const uint64_t s_cap = (uint64_t)(((nhi - 2) * 512) / D - J - 16) / 16 * 16;
+    if (S > (multi ? 2048u : 512u)) S = multi ? 2048 : 512;
     if (S > s_cap) S = s_cap;
     S = S / 16 * 16;
     if (S < 16) S = 16;
@@ -875,6 +930,18 @@ int launch_decim_pm(const DecimParams& p, int batch, hipStream_t s)
     q.pl_nseg = m_tail > m_main ? (uint32_t)((m_tail - m_main + S - 1) / S) : 0u;
     const uint32_t units = q.pl_nseg * (uint32_t)batch + (edge_unit ? (uint32_t)batch : 0u);
     if (J == 9 && NS == 13) return pm_launch_main<9, 13>(q, units, s);   // the 1:50, 419-tap stage
+    if (multi) {   // device-rate front ends: 42 block lags (the table is zero beyond J; J <= 48 runs the same code)
+        if (J <= 42) switch (NS) {
+            case 3: return pm_launch_main<42, 3, 8, 256>(q, units, s);    case 5: return pm_launch_main<42, 5, 8, 256>(q, units, s);
+            case 7: return pm_launch_main<42, 7, 8, 256>(q, units, s);    case 13: return pm_launch_main<42, 13, 8, 256>(q, units, s);
+            default: return pm_launch_main<42, 25, 16, 256>(q, units, s);
+        }
+        switch (NS) {
+            case 3: return pm_launch_main<48, 3, 8, 256>(q, units, s);    case 5: return pm_launch_main<48, 5, 8, 256>(q, units, s);
+            case 7: return pm_launch_main<48, 7, 8, 256>(q, units, s);    case 13: return pm_launch_main<48, 13, 8, 256>(q, units, s);
+            default: return pm_launch_main<48, 25, 16, 256>(q, units, s);
+        }
+    }
     switch (NS) {   // other geometries: 16 block lags (the table is zero beyond J), D = 33 .. 52
     case 9: return pm_launch_main<16, 9>(q, units, s);    case 10: return pm_launch_main<16, 10>(q, units, s);
     case 11: return pm_launch_main<16, 11>(q, units, s);  case 12: return pm_launch_main<16, 12>(q, units, s);

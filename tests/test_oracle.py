@@ -221,19 +221,37 @@ def test_pm_contract_matches_float64_definition(decim, nt_scale):
 
 
 def test_pl_contract_two_samples_per_lane_matches_float64_definition():
-    """The 100:1 front end (4 181 taps at 100 Msps): 50 lane slots of two neighbouring samples each (k_decim_plx<2, 1, 42>)."""
+    """A 96:1 front end (4 013 taps at 96 Msps): 48 lane slots of two neighbouring samples each (k_decim_plx<2, 1, 42>; 100:1 itself
+    moved to the phase-major matrix kernel in round 3)."""
     rng = np.random.default_rng(191)
-    h = orc.low_pass(1, 100e6, 480e3, 100e3, BH)
-    x = (rng.standard_normal(40 * 100 + h.size) + 1j * rng.standard_normal(40 * 100 + h.size)).astype(np.complex64)
-    assert orc.lib.orc_decim_uses_pl(h.size, 100) and (h.size + 99) // 100 == 42
-    y = orc.decim_fir_ccf_pl(x, h, 100)
-    assert _definition_error(y, x, h, 100) < 1e-5
-    assert np.array_equal(orc.decim_auto(x, h, 100).view(np.float32), y.view(np.float32))
+    h = orc.low_pass(1, 96e6, 480e3, 100e3, BH)
+    x = (rng.standard_normal(40 * 96 + h.size) + 1j * rng.standard_normal(40 * 96 + h.size)).astype(np.complex64)
+    assert orc.lib.orc_decim_uses_pl(h.size, 96) and not orc.lib.orc_decim_uses_pm(h.size, 96) and (h.size + 95) // 96 == 42
+    y = orc.decim_fir_ccf_pl(x, h, 96)
+    assert _definition_error(y, x, h, 96) < 1e-5
+    assert np.array_equal(orc.decim_auto(x, h, 96).view(np.float32), y.view(np.float32))
 
 
-def test_pl_rule_leaves_the_other_front_ends_on_m16():
-    for fs, d in ((25e6, 25), (20e6, 20), (10e6, 10), (50e6, 50)):
-        assert not orc.lib.orc_decim_uses_pl(orc.low_pass(1, fs, 480e3, 100e3, BH).size, d)
+@pytest.mark.parametrize("fs,decim", [(10e6, 10), (20e6, 20), (25e6, 25), (50e6, 50), (100e6, 100)])
+def test_pm_contract_three_lag_tiles_matches_float64_definition(fs, decim):
+    """The device-rate front ends (41.8 D taps = 42 block lags = three tiles of the matrix result, delay line over the groups)."""
+    rng = np.random.default_rng(300 + decim)
+    h = orc.low_pass(1, fs, 480e3, 100e3, BH)
+    x = (rng.standard_normal(70 * decim + h.size) + 1j * rng.standard_normal(70 * decim + h.size)).astype(np.complex64)
+    assert orc.lib.orc_decim_uses_pm(h.size, decim) and (h.size + decim - 1) // decim == 42
+    y = orc.decim_fir_ccf_pm(x, h, decim)
+    assert _definition_error(y, x, h, decim) < 1e-5
+    assert np.array_equal(orc.decim_auto(x, h, decim).view(np.float32), y.view(np.float32))
+    # absolute grouping: a stream that starts 16 blocks later gives the same bits once the window is inside
+    y2 = orc.decim_fir_ccf_pm(x[16 * decim:], h, decim)
+    k = 43
+    assert np.array_equal(y[16 + k:].view(np.float32), y2[k:].view(np.float32))
+
+
+def test_rules_leave_the_other_front_ends_on_m16():
+    for fs, d in ((8e6, 8), (16e6, 16), (32e6, 32), (40e6, 40), (64e6, 64)):
+        nt = orc.low_pass(1, fs, 480e3, 100e3, BH).size
+        assert not orc.lib.orc_decim_uses_pl(nt, d) and not orc.lib.orc_decim_uses_pm(nt, d) and orc.lib.orc_decim_uses_m16(nt, d)
 
 
 def test_cpu_baseline_simd_decimator_matches_definition():
@@ -263,11 +281,11 @@ def test_pm_contract_depends_on_the_absolute_output_index_only():
 def test_pl_contract_is_position_independent():
     """(two-samples-per-lane geometry, the 100:1 front end) Output m only depends on the samples of its window."""
     rng = np.random.default_rng(5)
-    h = orc.low_pass(1, 100e6, 480e3, 100e3, BH)
+    h = orc.low_pass(1, 96e6, 480e3, 100e3, BH)
     x = (rng.standard_normal(12000) + 1j * rng.standard_normal(12000)).astype(np.complex64)
-    y = orc.decim_fir_ccf_pl(x, h, 100)
-    y2 = orc.decim_fir_ccf_pl(x[1000:], h, 100)
-    k = (h.size + 99) // 100 + 1
+    y = orc.decim_fir_ccf_pl(x, h, 96)
+    y2 = orc.decim_fir_ccf_pl(x[960:], h, 96)
+    k = (h.size + 95) // 96 + 1
     assert np.array_equal(y[10 + k:].view(np.float32), y2[k:].view(np.float32))
 
 
