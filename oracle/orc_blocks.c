@@ -165,14 +165,19 @@ int orc_decim_uses_pl(int nt, int D)
 /* ---- contract "pm" (phase major; qradiolink_amd/csrc/kernels_decim_pl.hip k_decim_pm) ---------------------------------------------
  * The stream is cut into BLOCKS of D samples, block c = samples (c-1) D + 1 .. c D (so output m ends at the last sample of block m).
  * Sample p (0 .. D-1) of block c = m - j meets output m with tap H(p, j) = h[j D + D - 1 - p], j = 0 .. J-1, J = ceil(nt / D) <= 48.
- *   Z_j = one fmaf chain over the block's samples, p ASCENDING, from +0          (a [D x J] product on the f32 matrix pipe:
- *                                                                                 v_mfma_f32_16x16x4_f32 accumulates k in order)
- *   The J block terms of an output are then added with plain float adds in the order the kernel's lane layout fixes.  Lags come in
- *   TILES of 16 (j = 16 t + j'); one matrix result holds Z of 16 consecutive blocks (an ABSOLUTE group: blocks 16 G .. 16 G + 15) for
- *   the 16 lags of a tile, lag j' in lane row q = j' >> 2.  A term lands in the output's group either "in row" (j' <= m mod 16) or as
- *   a carry from the group before; per tile t and row q the in-row terms are summed j' ascending into R_t[q], the carries into C_t[q]
- *   (both from +0).  The tiles meet through a delay line over the groups:
- *       V[q] = R_0[q] + ((C_0[q] + R_1[q]) + ((C_1[q] + R_2[q]) + C_2[q]));      y = (V[0] + V[1]) + (V[2] + V[3]).
+ * Lags come in TILES of 16, j = 16 t + j' (NT = ceil(J / 16) <= 3 tiles).  For a block c and a lag-in-tile j':
+ *   Z(c, j') = ONE fmaf chain from +0 over the tiles t = NT-1 .. 0 (the oldest data first) and, inside a tile, the D samples of block
+ *              c - 16 t with p ASCENDING -- the term of output c + j' that the lags j', 16 + j', 32 + j' contribute
+ *              (v_mfma_f32_16x16x4_f32 accumulates k in order; the accumulator of an output group walks through three consecutive
+ *              groups of blocks, one tile at a time, before it is read).
+ * One matrix result holds Z for the 16 blocks n of an ABSOLUTE group (blocks 16 G .. 16 G + 15) and the 16 lags j', lag j' = 4 q + r in
+ * lane row q, register r.  The 16 terms of an output are then added with plain float adds:
+ *   L_q[n]  = ((Z(n, 4q) + Z(n-1, 4q+1)) + Z(n-2, 4q+2)) + Z(n-3, 4q+3)          blocks of the same group, missing ones (n - r < 0) = +0
+ *   H_q[k]  = (Z(15+k, 4q+1) + Z(14+k, 4q+2)) + Z(13+k, 4q+3)                    k = 0 .. 2: what leaves the group, missing ones = +0
+ *   output 16 G + n':   R_q = L_q(G)[n' - 4q]               if n' >= 4q, else +0          (in-row terms)
+ *                       C_q = L_q(G-1)[n' + 16 - 4q]        if n' <  4q, else H_q(G-1)[n' - 4q]   (+0 for n' - 4q > 2)   (carries)
+ *                       y = ((R_0 + C_0) + (R_1 + C_1)) + ((R_2 + C_2) + (R_3 + C_3))
+ * For one tile this is the order of rounds-3a's first kernel (terms of a lane row j' ascending, in-row and carried terms separately).
  * The grouping is by absolute index, so the value of output m does not depend on where a call or a kernel segment starts.
  * Geometries: the 1:50-class first stages (32 < D <= 52, J <= 16: one tile) and the device-rate front ends of 10 / 20 / 25 / 50 /
  * 100 Msps (41.8 D taps: J = 42, three tiles), i.e. ceil(D / 4) in {3, 5, 7, 13, 25}: the instantiated kernels. */
@@ -182,33 +187,60 @@ int orc_decim_uses_pm(int nt, int D)
     if (D > 32 && D <= 52 && J <= 16) return 1;
     return J > 16 && J <= 48 && (NS == 3 || NS == 5 || NS == 7 || NS == 13 || NS == 25);
 }
+typedef struct { const cf32* in; size_t n; const float* taps; int nt, D, NT; } pm_ctx;
+/* Z(c, j') of the contract; c may be negative or beyond the data (zero samples) */
+static void pm_z(const pm_ctx* k, long long c, int jp, float* zr, float* zi)
+{
+    float ar = 0.0f, ai = 0.0f;
+    for (int t = k->NT - 1; t >= 0; t--) {
+        const int j = 16 * t + jp;
+        const long long cb = c - 16LL * t;
+        for (int p = 0; p < k->D; p++) {
+            const long long kk = (long long)j * k->D + k->D - 1 - p;
+            const long long i = (cb - 1) * (long long)k->D + 1 + p;
+            const float h = kk < k->nt ? k->taps[kk] : 0.0f;
+            cf32 x = {0.0f, 0.0f};
+            if (i >= 0 && (size_t)i < k->n) x = k->in[i];
+            ar = fmaf(h, x.re, ar); ai = fmaf(h, x.im, ai);
+        }
+    }
+    *zr = ar; *zi = ai;
+}
+static void pm_L(const pm_ctx* k, long long G, int q, int n, float* lr, float* li)
+{
+    float ar = 0.0f, ai = 0.0f;
+    for (int r = 0; r < 4; r++) {
+        float zr = 0.0f, zi = 0.0f;
+        if (n - r >= 0) pm_z(k, 16 * G + n - r, 4 * q + r, &zr, &zi);
+        if (r == 0) { ar = zr; ai = zi; } else { ar = ar + zr; ai = ai + zi; }
+    }
+    *lr = ar; *li = ai;
+}
+static void pm_H(const pm_ctx* k, long long G, int q, int kq, float* hr, float* hi)
+{
+    float ar = 0.0f, ai = 0.0f;
+    for (int r = 1; r < 4; r++) {
+        float zr = 0.0f, zi = 0.0f;
+        if (kq <= r - 1) pm_z(k, 16 * G + 16 - r + kq, 4 * q + r, &zr, &zi);
+        if (r == 1) { ar = zr; ai = zi; } else { ar = ar + zr; ai = ai + zi; }
+    }
+    *hr = ar; *hi = ai;
+}
 size_t orc_decim_fir_ccf_pm(const cf32* in, size_t n, const float* taps, int nt, int D, cf32* out)
 {
     const size_t nout = orc_decim_count(n, 1, D);
     const int J = (nt + D - 1) / D;
+    const pm_ctx k = {in, n, taps, nt, D, (J + 15) / 16};
     for (size_t m = 0; m < nout; m++) {
-        float Rr[3][4], Ri[3][4], Cr[3][4], Ci[3][4];
-        for (int t = 0; t < 3; t++) for (int q = 0; q < 4; q++) Rr[t][q] = Ri[t][q] = Cr[t][q] = Ci[t][q] = 0.0f;
+        const long long G = (long long)(m >> 4);
         const int np = (int)(m & 15u);
-        for (int j = 0; j < J; j++) {
-            const long long c = (long long)m - j;
-            float zr = 0.0f, zi = 0.0f;
-            for (int p = 0; p < D; p++) {
-                const int k = j * D + D - 1 - p;
-                const long long i = (c - 1) * (long long)D + 1 + p;
-                const float h = k < nt ? taps[k] : 0.0f;
-                cf32 x = {0.0f, 0.0f};
-                if (i >= 0 && (size_t)i < n) x = in[i];
-                zr = fmaf(h, x.re, zr); zi = fmaf(h, x.im, zi);
-            }
-            const int t = j >> 4, jp = j & 15, q = jp >> 2;
-            if (jp <= np) { Rr[t][q] = Rr[t][q] + zr; Ri[t][q] = Ri[t][q] + zi; }
-            else          { Cr[t][q] = Cr[t][q] + zr; Ci[t][q] = Ci[t][q] + zi; }
-        }
         float Vr[4], Vi[4];
         for (int q = 0; q < 4; q++) {
-            Vr[q] = Rr[0][q] + ((Cr[0][q] + Rr[1][q]) + ((Cr[1][q] + Rr[2][q]) + Cr[2][q]));
-            Vi[q] = Ri[0][q] + ((Ci[0][q] + Ri[1][q]) + ((Ci[1][q] + Ri[2][q]) + Ci[2][q]));
+            float Rr = 0.0f, Ri = 0.0f, Cr = 0.0f, Ci = 0.0f;
+            if (np >= 4 * q) pm_L(&k, G, q, np - 4 * q, &Rr, &Ri);
+            if (np < 4 * q) pm_L(&k, G - 1, q, np + 16 - 4 * q, &Cr, &Ci);
+            else if (np - 4 * q <= 2) pm_H(&k, G - 1, q, np - 4 * q, &Cr, &Ci);
+            Vr[q] = Rr + Cr; Vi[q] = Ri + Ci;
         }
         out[m].re = (Vr[0] + Vr[1]) + (Vr[2] + Vr[3]);
         out[m].im = (Vi[0] + Vi[1]) + (Vi[2] + Vi[3]);

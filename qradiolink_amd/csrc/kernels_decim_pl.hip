@@ -132,15 +132,38 @@ __device__ __forceinline__ int pl_out_index(int lane)
 // to registers as soon as it has landed, which frees its slots for the next pieces -- the ring is only the landing zone, ~7 KiB per
 // wave stay in flight.  No barrier in the loop; counted s_waitcnt vmcnt orders the DMA against the wave's own reads.
 // Groups sit on an ABSOLUTE grid (blocks 16 G .. 16 G + 15), so the value of output m depends on m alone (chunk invariance).
-// acc += (v moved by a DPP row shift) in the lanes of row q only; lanes whose source falls outside the row add +0 (bound_ctrl:0),
-// the other rows keep acc.  One v_add_f32_dpp (written as asm: the compiler keeps v_mov_b32_dpp + v_add_f32 apart).  The s_nop 1 in
-// front is the gfx9 hazard "VALU writes a VGPR, DPP reads it: 2 wait states" -- the hazard recogniser does not look inside asm.
-template <int SHR, int Q>   // SHR > 0: row_shr:SHR; SHR < 0: row_shl:-SHR; SHR == 0: no move
-__device__ __forceinline__ void pm_add_dpp(float& acc, float v)
+// Diagonal sums of one matrix result (lane (q, n) holds Z[n][4 q + r], r = 0..3), for all four lane rows at once -- 15 DPP moves /
+// adds and 2 plain moves per component instead of one masked shift-add per lag and row:
+//   1. the four lags of a row differ by 0..3 lanes whatever the row:  L[n] = ((z0[n] + z1[n-1]) + z2[n-2]) + z3[n-3]  (row_shr, +0 from
+//      outside the row), and what the shifts push out of the group  H[k] = (z1[15+k] + z2[14+k]) + z3[13+k], k = 0..2 (row_shl);
+//   2. row q then only has to move by 4 q lanes: R = row_shr:4q of L (in-row terms), C = row_shl:(16 - 4q) of L in the lanes below
+//      4 q joined with row_shr:4q of H above them (the carries into the next group): moves under a row mask, no arithmetic.
+// One asm statement: the compiler keeps v_mov_b32_dpp + v_add_f32 apart, and its hazard recogniser does not look inside asm -- the
+// leading s_nop 1 and the instruction order respect the gfx9 rule "VALU writes a VGPR, DPP reads it: 2 wait states" (H is read three
+// instructions after its last write, L four).
+__device__ __forceinline__ void pm_diag(const f32x4_pm& z, float& R, float& C)
 {
-    if constexpr (SHR == 0) asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %0 quad_perm:[0,1,2,3] row_mask:%2 bank_mask:0xf bound_ctrl:0" : "+v"(acc) : "v"(v), "n"(1 << Q));
-    else if constexpr (SHR > 0) asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %0 row_shr:%3 row_mask:%2 bank_mask:0xf bound_ctrl:0" : "+v"(acc) : "v"(v), "n"(1 << Q), "n"(SHR));
-    else asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %0 row_shl:%3 row_mask:%2 bank_mask:0xf bound_ctrl:0" : "+v"(acc) : "v"(v), "n"(1 << Q), "n"(-SHR));
+    float L, H;
+    asm("s_nop 1\n\t"
+        "v_mov_b32_dpp %[H], %[z1] row_shl:15 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_add_f32_dpp %[H], %[z2], %[H] row_shl:14 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_add_f32_dpp %[H], %[z3], %[H] row_shl:13 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_add_f32_dpp %[L], %[z1], %[z0] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_add_f32_dpp %[L], %[z2], %[L] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_add_f32_dpp %[L], %[z3], %[L] row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32 %[C], %[H]\n\t"
+        "v_mov_b32 %[R], %[L]\n\t"
+        "v_mov_b32_dpp %[C], %[H] row_shr:4 row_mask:0x2 bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %[C], %[H] row_shr:8 row_mask:0x4 bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %[C], %[H] row_shr:12 row_mask:0x8 bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %[C], %[L] row_shl:12 row_mask:0x2 bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[C], %[L] row_shl:8 row_mask:0x4 bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[C], %[L] row_shl:4 row_mask:0x8 bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[R], %[L] row_shr:4 row_mask:0x2 bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %[R], %[L] row_shr:8 row_mask:0x4 bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %[R], %[L] row_shr:12 row_mask:0x8 bank_mask:0xf bound_ctrl:0"
+        : [R] "=&v"(R), [C] "=&v"(C), [L] "=&v"(L), [H] "=&v"(H)
+        : [z0] "v"(z[0]), [z1] "v"(z[1]), [z2] "v"(z[2]), [z3] "v"(z[3]));
 }
 __device__ __forceinline__ void pm_glds16(const void* gsrc, uint32_t lds_dst)
 {
@@ -168,22 +191,12 @@ __device__ __forceinline__ void pm_wait_vm_dyn(uint32_t allowed)   // wave unifo
     }
 }
 
-// diagonal sums of one matrix result: R += in-group terms, C += the terms that belong to the next group (both per lane row)
-template <int J, int JJ>
-__device__ __forceinline__ void pm_diag(const f32x4_pm& z, float& R, float& C)
-{
-    if constexpr (JJ < J) {
-        constexpr int q = JJ >> 2, r = JJ & 3;
-        const float zz = z[r];
-        if constexpr (JJ == 0) pm_add_dpp<0, 0>(R, zz);
-        else {
-            pm_add_dpp<JJ, q>(R, zz);             // row_shr:JJ -> the output's lane inside this group
-            pm_add_dpp<-(16 - JJ), q>(C, zz);     // row_shl:16-JJ -> the output's lane in the NEXT group
-        }
-        pm_diag<J, JJ + 1>(z, R, C);
-    }
-}
-
+#ifndef QRL_PM_PRIO
+#define QRL_PM_PRIO 0   // experiment: distinct s_setprio per resident workgroup
+#endif
+#ifndef QRL_PM_SWP
+#define QRL_PM_SWP 0   // experiment: interleave the rotation of the next step with the matrix instructions (sched_barrier regions + sched_group_barrier); measured: no gain
+#endif
 #ifndef QRL_PM_ABL
 #define QRL_PM_ABL 0   // developer builds only (tools/pl_variants.sh): bit 0 no output store, bit 1 no rotator, bit 2 no MFMA, bit 3 no diagonal sums (wrong results; timing ablations)
 #endif
@@ -194,17 +207,21 @@ __device__ unsigned long long g_pm_prof[8];
 #else
 #define PM_STAMP(k) do { } while (0)
 #endif
-// J > 16 (the device-rate front ends: 41.8 D taps = 42 block lags): the lags come in NT = ceil(J / 16) TILES, one matrix result per tile
-// (the rotated B operand is shared), and the tiles meet through a delay line over the groups -- tile t of group G contributes to the
-// outputs of groups G + t (in row) and G + t + 1 (carry):  V = R_0 + A1;  A1' = (C_0 + R_1) + A2;  A2' = (C_1 + R_2) + A3;  A3' = C_2.
+// J > 16 (the device-rate front ends: 41.8 D taps = 42 block lags): the lags come in NT = 3 TILES of 16, j = 16 t + j'.  Tile t of
+// block group G and tile 0 of group G + t feed the SAME outputs (block 16 G + n, lag 16 t + j' -> output 16 (G + t) + n + j'), so the
+// accumulator of an output group is handed from tile to tile through the C operand: it starts with tile 2 of group G - 2, takes tile 1
+// of group G - 1 and is finished by tile 0 of group G -- one diagonal sum per group and component, whatever the number of tiles.
 // 42 matrix instructions per 16 blocks of D samples = 0.094 per sample whatever D: the kernel is bound by the matrix pipe at about
 // 4.1 - 4.4 TB/s of input (tools/ubench/stream_lds.hip W4), against 2.5 - 2.7 TB/s for the banded-Toeplitz form of rounds 1-2 (26 % of
 // its matrix work multiplied zero taps, every tile went through LDS twice) and for the VALU phase-lane kernel at 100:1.
-template <int J, int NS, int RP, int NW, int NHI>
+constexpr int PM_NHI = 64;   // coarse rotator entries per wave (64 x 512 samples): the wave re-bases and refills its own table as it walks
+template <int J, int NS, int RP, int NW>
 __global__ __launch_bounds__(NW * 64)
 void k_decim_pm(const DecimParams P_)
 {
+    constexpr int NHI = PM_NHI;
     constexpr int NT = (J + 15) / 16;
+    static_assert(NT == 1 || NT == 3, "one lag tile (J <= 16) or three (32 < J <= 48)");
     const DecimParams& P = P_;
     // dynamic LDS (the kernel has no static allocation, so it starts at LDS byte 0): rings first -- ring of wave w at byte w * ring
     // size, which the address arithmetic below relies on --, then the tables
@@ -214,6 +231,15 @@ void k_decim_pm(const DecimParams P_)
     float2 (*t_hi_all)[NHI] = reinterpret_cast<float2 (*)[NHI]>(t_lo + 512);      // coarse rotator table of each wave's segment (NHI x 512 samples)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if QRL_PM_PRIO
+    // The waves that share a SIMD (one per resident workgroup) all walk fetch -> LDS -> matrix pipe -> store; with equal priority they
+    // fall into step (everybody fetches, then everybody queues for the matrix pipe) and the pipe idles a third of the time.  Distinct
+    // issue priorities turn the sharing into a pipeline: the highest wave computes at full rate and goes to fetch while the others compute.
+    switch (((blockIdx.x >> 8) + blockIdx.x) & 3u) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;  case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;  default: __builtin_amdgcn_s_setprio(3); break;
+    }
+#endif
     for (int k = tid; k < 512; k += NW * 64) t_lo[k] = P.rot_lo[k];
 
     // unit = (stream, segment); behind the regular units one EDGE unit per stream (outputs pl_edge_ms .. pl_edge_me out of the staged,
@@ -234,12 +260,8 @@ void k_decim_pm(const DecimParams P_)
     const int ngrp = active ? (int)((int64_t)((me - 1) / 16) - G0) + 1 : 0;
     const int64_t i_first_s = (G0 * 16 - 1) * (int64_t)D + 1;        // first sample of block 16 G0 (regular units: >= n0; edge units: the scratch starts here)
     const uint64_t i_first = (uint64_t)i_first_s;
-    const uint32_t kb0 = edge ? 0u : (uint32_t)((i_first - P.rot_nbase) >> 9);
-    if (active) {
-#pragma unroll
-        for (int e = 0; e < NHI / 64; ++e)
-            t_hi_all[wave][lane + 64 * e] = edge ? make_float2(1.f, 0.f) : sincos_turn(P.rot_acc + ((uint64_t)(kb0 + (uint32_t)(lane + 64 * e)) << 9) * P.rot_inc);
-    }
+    uint32_t kb0 = edge ? 0u : (uint32_t)((i_first - P.rot_nbase) >> 9);          // 512-sample block of the coarse table's entry 0
+    if (active) t_hi_all[wave][lane] = edge ? make_float2(1.f, 0.f) : sincos_turn(P.rot_acc + ((uint64_t)(kb0 + (uint32_t)lane) << 9) * P.rot_inc);
     __syncthreads();
     if (!active) return;
 
@@ -278,7 +300,8 @@ void k_decim_pm(const DecimParams P_)
     const uint32_t lane_byte = ((uint32_t)nn * (uint32_t)D + (uint32_t)q) * 8u;      // this lane's sample of step 0 inside a group
     const bool last_valid = 4 * (NS - 1) + q < D;                    // step NS - 1 reaches past the block for the upper lane rows
     float2* orow = P.out.p + ((size_t)b * (P.out_row_mul_m1 + 1u) + P.out_row_add) * (P.out.mask + 1u);
-    float Ar[3] = {0.f, 0.f, 0.f}, Ai[3] = {0.f, 0.f, 0.f};          // delay line over the groups (per lane row): what earlier groups owe the next three
+    float Cpr = 0.f, Cpi = 0.f;                                      // carries of the previous group, per lane row
+    f32x4_pm nr1 = {0.f, 0.f, 0.f, 0.f}, ni1 = nr1, nr2 = nr1, ni2 = nr1;   // (three tiles) the accumulators of the next two output groups
 
 #ifdef QRL_PM_PROF
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -287,7 +310,13 @@ void k_decim_pm(const DecimParams P_)
     issue_upto(npieces < RP ? npieces : RP);                         // (piece 0 is the first piece of group 0)
     uint32_t gbytes = o0;                                            // byte offset of the current group in the wave's stream
     uint32_t kb8 = (k0 * 8u) + lane_byte;                            // 8 x NCO index (relative to the coarse table) of this lane's step-0 sample
+    uint32_t kg8 = k0 * 8u;                                          // the same for the group's first sample (wave uniform)
     for (int g = 0; g < ngrp; ++g) {
+        if (((kg8 + GB) >> 12) >= (uint32_t)(NHI - 1)) {             // the group would leave the coarse table: re-base it (wave private, no barrier)
+            const uint32_t sh = kg8 >> 12;
+            kb0 += sh; kg8 -= sh << 12; kb8 -= sh << 12;
+            t_hi_all[wave][lane] = edge ? make_float2(1.f, 0.f) : sincos_turn(P.rot_acc + ((uint64_t)(kb0 + (uint32_t)lane) << 9) * P.rot_inc);
+        }
         {   // everything up to the end of this group must have landed; younger pieces may stay in flight
             uint32_t need = (gbytes + GB + 1023u) >> 10;
             need = need < npieces ? need : npieces;
@@ -308,21 +337,41 @@ void k_decim_pm(const DecimParams P_)
             issue_upto(cap < npieces ? cap : npieces);
         }
         PM_STAMP(2);
-        f32x4_pm zr[NT], zi[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { zr[t] = f32x4_pm{0.f, 0.f, 0.f, 0.f}; zi[t] = zr[t]; }
+        f32x4_pm zr[NT], zi[NT];                                     // [t]: gets tile t now; [0] is complete after this group
+        zr[NT - 1] = f32x4_pm{0.f, 0.f, 0.f, 0.f}; zi[NT - 1] = zr[NT - 1];
+        if constexpr (NT == 3) { zr[0] = nr1; zi[0] = ni1; zr[1] = nr2; zi[1] = ni2; }
+        // rotator: phasor of sample k = T_hi[k >> 9] (x) T_lo[k & 511], byte addressed.  Software pipelined by one step: the rotation of
+        // step s + 1 is issued between the matrix instructions of step s (a 16x16x4 f32 MFMA holds the pipe for 32 cycles -- room for
+        // three VALU instructions of the same wave), (QRL_PM_SWP = 1; measured without effect: the other waves of the SIMD already fill those gaps)
+        // (the table reads run two steps ahead, so the rotation never waits for the LDS)
+        struct Ph { float2 lo, hi; };
+        auto tab = [&](int s_) -> Ph {
+            const uint32_t kk = kb8 + 32u * (uint32_t)s_;
+            return Ph{pm_lds(tlo_base + (kk & tl_mask)), pm_lds(thi_base + ((kk >> 12) << 3))};
+        };
+        auto rot = [&](int s_, const Ph& ph) -> float2 {
+#if QRL_PM_ABL & 2
+            float2 xs_ = x[s_]; (void)ph;
+#else
+            float2 xs_ = cmul_fma(x[s_], cmul_fma(ph.hi, ph.lo));
+#endif
+            if (s_ == NS - 1 && !last_valid) xs_ = make_float2(0.f, 0.f);   // phases >= D: zero taps AND zero samples
+            return xs_;
+        };
+        float2 xs = rot(0, tab(0));
+        Ph pn = tab(NS > 1 ? 1 : 0);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            // rotator: phasor of sample k = T_hi[k >> 9] (x) T_lo[k & 511], byte addressed
-            const uint32_t kk = kb8 + 32u * (uint32_t)s;
-#if QRL_PM_ABL & 2
-            float2 xs = x[s]; (void)kk;
-#else
-            const float2 plo = pm_lds(tlo_base + (kk & tl_mask));
-            const float2 phi = pm_lds(thi_base + ((kk >> 12) << 3));
-            float2 xs = cmul_fma(x[s], cmul_fma(phi, plo));
+            float2 xn = xs;
+            Ph pnn = pn;
+            // (scheduling barriers pin the order: the reads for the step after next are issued HERE, a whole step before their use --
+            // otherwise the scheduler sinks every read down to its use and the rotation waits for the LDS)
+            if (s + 2 < NS) pnn = tab(s + 2);
+#if QRL_PM_SWP
+            if constexpr (NT == 3) __builtin_amdgcn_sched_barrier(0);
 #endif
-            if (s == NS - 1 && !last_valid) xs = make_float2(0.f, 0.f);   // phases >= D: zero taps AND zero samples
+            if (s + 1 < NS) xn = rot(s + 1, pn);
+            pn = pnn;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
 #if QRL_PM_ABL & 4
@@ -332,28 +381,30 @@ void k_decim_pm(const DecimParams P_)
                 zi[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], xs.y, zi[t], 0, 0, 0);
 #endif
             }
+#if QRL_PM_SWP
+            if constexpr (NT == 3) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one matrix instruction
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // three VALU in its shadow
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+            xs = xn;
         }
         PM_STAMP(3);
-        // y[16 G + n'] = sum_j Z[n' - j][j]: per tile and lane row the in-row terms (R) and the carries (C), lag ascending; then the
-        // delay line: this group's outputs take R_0 + A1, and what tiles 0..2 owe later groups moves one place down
-        float Rr[3] = {0.f, 0.f, 0.f}, Ri[3] = {0.f, 0.f, 0.f}, Cr[3] = {0.f, 0.f, 0.f}, Ci[3] = {0.f, 0.f, 0.f};
+        if constexpr (NT == 3) { nr1 = zr[1]; ni1 = zi[1]; nr2 = zr[2]; ni2 = zi[2]; }
+        // y[16 G + n'] = sum_j' Z[n' - j'][j']: per lane row the in-row terms (R) and the carries into the next group (C)
+        float Rr, Ri, Cr, Ci;
 #if QRL_PM_ABL & 8
-        Rr[0] = zr[0][0] + zr[0][1] + zr[0][2] + zr[0][3]; Ri[0] = zi[0][0] + zi[0][1] + zi[0][2] + zi[0][3];
+        Rr = zr[0][0] + zr[0][1] + zr[0][2] + zr[0][3]; Ri = zi[0][0] + zi[0][1] + zi[0][2] + zi[0][3]; Cr = Rr; Ci = Ri;
 #else
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            constexpr int JL = J - 16 * (NT - 1);                    // lags of the last tile
-            if (t < NT - 1) { pm_diag<16, 0>(zr[t], Rr[t], Cr[t]); pm_diag<16, 0>(zi[t], Ri[t], Ci[t]); }
-            else            { pm_diag<JL, 0>(zr[t], Rr[t], Cr[t]); pm_diag<JL, 0>(zi[t], Ri[t], Ci[t]); }
-        }
+        pm_diag(zr[0], Rr, Cr);
+        pm_diag(zi[0], Ri, Ci);
 #endif
-        const float Vr = Rr[0] + Ar[0], Vi = Ri[0] + Ai[0];
-        if constexpr (NT == 1) { Ar[0] = Cr[0]; Ai[0] = Ci[0]; }
-        else {
-            Ar[0] = (Cr[0] + Rr[1]) + Ar[1]; Ai[0] = (Ci[0] + Ri[1]) + Ai[1];
-            Ar[1] = (Cr[1] + Rr[2]) + Ar[2]; Ai[1] = (Ci[1] + Ri[2]) + Ai[2];
-            Ar[2] = Cr[2]; Ai[2] = Ci[2];
-        }
+        const float Vr = Rr + Cpr, Vi = Ri + Cpi;
+        Cpr = Cr; Cpi = Ci;
         // fold the four lane rows: (V_0 + V_1) + (V_2 + V_3); rows 0 / 1 of the result = real / imaginary part of the 16 outputs
         const auto w16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(Vr), __float_as_uint(Vi), false, false);
         const float w = __uint_as_float(w16[0]) + __uint_as_float(w16[1]);
@@ -367,7 +418,7 @@ void k_decim_pm(const DecimParams P_)
             reinterpret_cast<float*>(orow + ((uint32_t)m & P.out.mask))[q] = y;
 #endif
         gbytes += GB;
-        kb8 += GB;
+        kb8 += GB; kg8 += GB;
         PM_STAMP(4);
     }
 #ifdef QRL_PM_PROF
@@ -393,59 +444,68 @@ __global__ __launch_bounds__(256) void k_decim_pm_gen(const DecimParams P_, uint
     const uint64_t kk0 = P.n0 - P.rot_nbase;                     // NCO index of in[0]
     uint64_t hi_blk = ~0ull;
     float2 hi = make_float2(1.f, 0.f);
-    float Rr[3][4], Ri[3][4], Cr[3][4], Ci[3][4];                // [lag tile][lane row]
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) Rr[t][qq] = Ri[t][qq] = Cr[t][qq] = Ci[t][qq] = 0.f;
-    const int np = (int)(m & 15u);
-    for (int j = 0; j < J; ++j) {
-        const int64_t c = (int64_t)m - j;
+    const int NT = (J + 15) / 16;
+    // Z(c, j') of the contract: one chain over the tiles t = NT-1 .. 0 and the D samples of block c - 16 t, p ascending
+    auto zval = [&](int64_t c, int jp, float& zr_, float& zi_) {
         float zr = 0.f, zi = 0.f;
-        for (int p = 0; p < D; ++p) {
-            const int k = j * D + D - 1 - p;
-            const int64_t i = (c - 1) * (int64_t)D + 1 + p;
-            const float h = k < nt ? P.pl_hraw[k] : 0.f;
-            float2 x = make_float2(0.f, 0.f);
-            if (i >= 0) {
-                const uint64_t ui = (uint64_t)i;
-                if (inb) {
-                    if (ui >= P.n0) {
-                        const uint64_t rel = ui - P.n0;
-                        if (rel < P.n) {
-                            x = inb[rel];
-                            if (P.rot_enable) {
-                                const uint64_t kk = kk0 + rel;
-                                if ((kk >> 9) != hi_blk) { hi_blk = kk >> 9; hi = sincos_turn(P.rot_acc + (hi_blk << 9) * P.rot_inc); }
-                                x = cmul_fma(x, cmul_fma(hi, P.rot_lo[(uint32_t)kk & 511u]));
+        for (int t = NT - 1; t >= 0; --t) {
+            const int j = 16 * t + jp;
+            const int64_t cb = c - 16 * (int64_t)t;
+            for (int p = 0; p < D; ++p) {
+                const int64_t k = (int64_t)j * D + D - 1 - p;
+                const int64_t i = (cb - 1) * (int64_t)D + 1 + p;
+                const float h = k < nt ? P.pl_hraw[k] : 0.f;
+                float2 x = make_float2(0.f, 0.f);
+                if (i >= 0) {
+                    const uint64_t ui = (uint64_t)i;
+                    if (inb) {
+                        if (ui >= P.n0) {
+                            const uint64_t rel = ui - P.n0;
+                            if (rel < P.n) {
+                                x = inb[rel];
+                                if (P.rot_enable) {
+                                    const uint64_t kk = kk0 + rel;
+                                    if ((kk >> 9) != hi_blk) { hi_blk = kk >> 9; hi = sincos_turn(P.rot_acc + (hi_blk << 9) * P.rot_inc); }
+                                    x = cmul_fma(x, cmul_fma(hi, P.rot_lo[(uint32_t)kk & 511u]));
+                                }
                             }
+                        } else {
+                            const uint64_t d = P.n0 - ui;
+                            if (d <= P.hist_len) x = hb[P.hist_len - (uint32_t)d];
                         }
-                    } else {
-                        const uint64_t d = P.n0 - ui;
-                        if (d <= P.hist_len) x = hb[P.hist_len - (uint32_t)d];
+                    } else if (ui < P.n0 + P.n) {
+                        x = rb[(uint32_t)ui & P.in_ring.mask];
                     }
-                } else if (ui < P.n0 + P.n) {
-                    x = rb[(uint32_t)ui & P.in_ring.mask];
                 }
+                zr = fmaf(h, x.x, zr); zi = fmaf(h, x.y, zi);
             }
-            zr = fmaf(h, x.x, zr); zi = fmaf(h, x.y, zi);
         }
-        const int jp = j & 15, qq = jp >> 2;
-        // (static indexing: the tile / row selects are unrolled so the buckets stay in registers)
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (t == (j >> 4) && u == qq) {
-                    if (jp <= np) { Rr[t][u] = Rr[t][u] + zr; Ri[t][u] = Ri[t][u] + zi; }
-                    else          { Cr[t][u] = Cr[t][u] + zr; Ci[t][u] = Ci[t][u] + zi; }
-                }
-    }
+        zr_ = zr; zi_ = zi;
+    };
+    const int64_t G = (int64_t)(m >> 4);
+    const int np = (int)(m & 15u);
     float Vr[4], Vi[4];
-#pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
-        Vr[qq] = Rr[0][qq] + ((Cr[0][qq] + Rr[1][qq]) + ((Cr[1][qq] + Rr[2][qq]) + Cr[2][qq]));
-        Vi[qq] = Ri[0][qq] + ((Ci[0][qq] + Ri[1][qq]) + ((Ci[1][qq] + Ri[2][qq]) + Ci[2][qq]));
+        float Rr = 0.f, Ri = 0.f, Cr = 0.f, Ci = 0.f;
+        // L_q(Gx)[n] = ((Z(n, 4q) + Z(n-1, 4q+1)) + Z(n-2, 4q+2)) + Z(n-3, 4q+3), blocks outside the group = +0
+        auto Lsum = [&](int64_t Gx, int n, float& lr, float& li) {
+            for (int r = 0; r < 4; ++r) {
+                float zr = 0.f, zi = 0.f;
+                if (n - r >= 0) zval(16 * Gx + n - r, 4 * qq + r, zr, zi);
+                if (r == 0) { lr = zr; li = zi; } else { lr = lr + zr; li = li + zi; }
+            }
+        };
+        if (np >= 4 * qq) Lsum(G, np - 4 * qq, Rr, Ri);
+        if (np < 4 * qq) Lsum(G - 1, np + 16 - 4 * qq, Cr, Ci);
+        else if (np - 4 * qq <= 2) {                              // H_q(G - 1)[k] = (Z(15+k, 4q+1) + Z(14+k, 4q+2)) + Z(13+k, 4q+3)
+            const int kq = np - 4 * qq;
+            for (int r = 1; r < 4; ++r) {
+                float zr = 0.f, zi = 0.f;
+                if (kq <= r - 1) zval(16 * (G - 1) + 16 - r + kq, 4 * qq + r, zr, zi);
+                if (r == 1) { Cr = zr; Ci = zi; } else { Cr = Cr + zr; Ci = Ci + zi; }
+            }
+        }
+        Vr[qq] = Rr + Cr; Vi[qq] = Ri + Ci;
     }
     P.out.p[((size_t)b * (P.out_row_mul_m1 + 1u) + P.out_row_add) * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] =
         make_float2((Vr[0] + Vr[1]) + (Vr[2] + Vr[3]), (Vi[0] + Vi[1]) + (Vi[2] + Vi[3]));
@@ -828,14 +888,22 @@ bool decim_uses_pm(int nt, int D)
     // up to three lag tiles: the device-rate front ends (41.8 D taps) at 10:1, 20:1, 25:1, 50:1, 100:1
     return J > 16 && J <= 48 && (NS == 3 || NS == 5 || NS == 7 || NS == 13 || NS == 25);
 }
+// block lags the instantiated kernel walks (its table is zero beyond the filter's own J): segment alignment, edge unit and look-back
+// are all counted in THESE lags
+static int pm_kernel_lags(int nt, int D)
+{
+    const int J = (nt + D - 1) / D, NS = (D + 3) / 4;
+    if (J <= 16) return J == 9 && NS == 13 ? 9 : 16;
+    return J <= 42 ? 42 : 48;
+}
 size_t decim_pm_edge_len(int nt, int D)
 {
     // the edge unit of a call starts at the 16-block group of block m0 - (J - 1) and ends with the last output in front of the first
     // aligned segment: at most 15 + (J - 1) + (J + 16) blocks
-    const int J = (nt + D - 1) / D;
+    const int J = pm_kernel_lags(nt, D);
     return decim_uses_pm(nt, D) ? (size_t)(((2 * J + 32) * D + 1) & ~1) : 0;
 }
-uint32_t decim_pm_lookback(int nt, int D) { return (uint32_t)(((nt + D - 1) / D + 18) * D); }
+uint32_t decim_pm_lookback(int nt, int D) { return (uint32_t)((pm_kernel_lags(nt, D) + 18) * D); }
 // A-operand table [NT][NS][64]: lane l (j = 16 t + (l & 15), k = l >> 4) of step s, tile t holds H[p = 4 s + k][j] = h[j D + D - 1 - p];
 // the raw taps follow
 static int pm_tiles(int J) { return J <= 16 ? 1 : 3; }
@@ -858,23 +926,55 @@ std::vector<float> decim_pm_layout(const std::vector<float>& h, int D)
 #ifndef QRL_PM_NW
 #define QRL_PM_NW 4
 #endif
-template <int J, int NS, int RP = QRL_PM_RP, int NHI = 64>
-static int pm_launch_main(const DecimParams& q, uint32_t units, hipStream_t s)
+#ifndef QRL_PM_RP_SMALL
+#define QRL_PM_RP_SMALL 8   // ring pieces per wave for D <= 28 (a group is <= 3.5 KiB there)
+#endif
+// Segments: a multiple of 16 outputs each (every segment then starts on a group boundary).  Every segment re-reads `warm` blocks of
+// warm-up, and the call ends when the last wave does: with `cap` waves resident on the chip the cost of a split into nseg segments per
+// stream is  ceil(nseg x batch / cap)  rounds of  S + warm + 16  blocks.  Take the cheapest split; ties go to the finer one.
+static uint32_t pm_pick_segment(uint64_t M, uint32_t batch, uint32_t cap, uint32_t warm)
 {
-    // RP = ring pieces per wave (a power of two: one 16-block group -- 128 D bytes -- + what is in flight)
-    // 4 waves per workgroup, four workgroups per CU (156 KB of LDS).  8-wave workgroups (two per CU, 144 KB: room for slim recursion
-    // kernels of the previous call beside them) were measured: 7.24 ms against 6.57 ms alone, and no gain in the overlapped mode.
+    if (M <= 16) return 16;
+    uint64_t best_cost = ~0ull; uint32_t best_S = 16;
+    const uint32_t n_lo = (uint32_t)((M + 4095) / 4096), n_hi = (uint32_t)((M + 127) / 128);
+    for (uint32_t nseg = n_lo; nseg <= n_hi; ++nseg) {
+        const uint32_t S = (uint32_t)(((M + nseg - 1) / nseg + 15) / 16 * 16);
+        const uint64_t units = ((M + S - 1) / S) * (uint64_t)batch;
+        const uint64_t cost = ((units + cap - 1) / cap) * (uint64_t)(S + warm + 16);
+        if (cost <= best_cost) { best_cost = cost; best_S = S; }
+    }
+    return best_S;
+}
+template <int J, int NS, int RP = QRL_PM_RP>
+static int pm_launch_main(DecimParams& q, uint64_t M, uint32_t batch, bool edge_unit, hipStream_t s)
+{
+    // RP = ring pieces per wave (a power of two: one 16-block group -- 128 D bytes -- + what is in flight).
+    // 4 waves per workgroup; at D = 50 four workgroups per CU (156 KB of LDS).  8-wave workgroups (two per CU, 144 KB: room for slim
+    // recursion kernels of the previous call beside them) were measured: 7.24 ms against 6.57 ms alone, and no gain in the overlapped mode.
     constexpr int NW = QRL_PM_NW;
-    const auto kern = k_decim_pm<J, NS, RP, NW, NHI>;
-    const size_t lds = (size_t)NW * RP * 1024 + 512 * sizeof(float2) + NW * NHI * sizeof(float2);
-    if (dyn_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024) != hipSuccess) return -1;
+    const auto kern = k_decim_pm<J, NS, RP, NW>;
+    const size_t lds = (size_t)NW * RP * 1024 + 512 * sizeof(float2) + NW * PM_NHI * sizeof(float2);
+    static int wg_per_cu = 0, n_cu = 0;          // (per instantiation)
+    if (!wg_per_cu) {
+        if (dyn_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024) != hipSuccess) return -1;
+        int nb = 0, dev = 0; hipDeviceProp_t pr;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NW * 64, lds) != hipSuccess || nb < 1) nb = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return -1;
+        n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+        wg_per_cu = nb;
+    }
+    const uint32_t S = pm_pick_segment(M, batch, (uint32_t)(wg_per_cu * n_cu * NW), (uint32_t)(J - 1));
+    q.pl_S = S;
+    q.pl_nseg = M ? (uint32_t)((M + S - 1) / S) : 0u;
+    const uint32_t units = q.pl_nseg * batch + (edge_unit ? batch : 0u);
     hipLaunchKernelGGL(kern, dim3((units + NW - 1) / NW), dim3(NW * 64), lds, s, q);
     return 0;
 }
 int launch_decim_pm(const DecimParams& p, int batch, hipStream_t s)
 {
     if (p.m_count == 0) return 0;
-    const int D = p.D, nt = p.nt, J = (nt + D - 1) / D, NS = (D + 3) / 4;
+    const int D = p.D, nt = p.nt, NS = (D + 3) / 4;
+    const int J = pm_kernel_lags(nt, D);
     DecimParams q = p;
     q.pl_J = J; q.pl_E = 1; q.pl_R = 1;
     q.pl_hraw = p.pl_taps + (size_t)pm_tiles(J) * NS * 64;
@@ -910,42 +1010,27 @@ int launch_decim_pm(const DecimParams& p, int batch, hipStream_t s)
     }
     gen(m_tail, m_end);
     if (m_main >= m_tail && !edge_unit) return 0;
-    const uint64_t total = (m_tail - m_main) * (uint64_t)batch;
     q.pl_m_begin = m_main; q.pl_m_end = m_tail;
     q.pl_batch = (uint32_t)batch;
-    // segment length: a multiple of 16 outputs (every segment then starts on a group boundary), long enough to keep the warm-up
-    // re-reads small (J - 1 blocks per segment), short enough to spread the call over >= ~16 waves per CU, and inside the 64-entry
-    // coarse rotator table of a wave (64 x 512 samples, 16 blocks of slack for the last group)
-    // (three-tile geometries: 41 warm-up blocks per segment, so longer segments and the 256-entry coarse table)
-    const bool multi = J > 16;
-    const int nhi = multi ? 256 : 64;
-    const uint32_t waves_cu = multi && D > 52 ? 8u : 16u;
-    uint64_t S = total / (256u * waves_cu * (multi ? 2u : 4u));
-    const uint64_t s_cap = (uint64_t)(((nhi - 2) * 512) / D - J - 16) / 16 * 16;
-    if (S > (multi ? 2048u : 512u)) S = multi ? 2048 : 512;
-    if (S > s_cap) S = s_cap;
-    S = S / 16 * 16;
-    if (S < 16) S = 16;
-    q.pl_S = (uint32_t)S;
-    q.pl_nseg = m_tail > m_main ? (uint32_t)((m_tail - m_main + S - 1) / S) : 0u;
-    const uint32_t units = q.pl_nseg * (uint32_t)batch + (edge_unit ? (uint32_t)batch : 0u);
-    if (J == 9 && NS == 13) return pm_launch_main<9, 13>(q, units, s);   // the 1:50, 419-tap stage
-    if (multi) {   // device-rate front ends: 42 block lags (the table is zero beyond J; J <= 48 runs the same code)
-        if (J <= 42) switch (NS) {
-            case 3: return pm_launch_main<42, 3, 8, 256>(q, units, s);    case 5: return pm_launch_main<42, 5, 8, 256>(q, units, s);
-            case 7: return pm_launch_main<42, 7, 8, 256>(q, units, s);    case 13: return pm_launch_main<42, 13, 8, 256>(q, units, s);
-            default: return pm_launch_main<42, 25, 16, 256>(q, units, s);
+    const uint64_t M = m_tail - m_main;
+    const uint32_t Bn = (uint32_t)batch;
+    if (J == 9) return pm_launch_main<9, 13>(q, M, Bn, edge_unit, s);   // the 1:50, 419-tap stage
+    if (J > 16) {   // device-rate front ends: 42 block lags (the table is zero beyond J; J <= 48 runs the same code)
+        if (J == 42) switch (NS) {
+            case 3: return pm_launch_main<42, 3, QRL_PM_RP_SMALL>(q, M, Bn, edge_unit, s);   case 5: return pm_launch_main<42, 5, QRL_PM_RP_SMALL>(q, M, Bn, edge_unit, s);
+            case 7: return pm_launch_main<42, 7, QRL_PM_RP_SMALL>(q, M, Bn, edge_unit, s);   case 13: return pm_launch_main<42, 13, 8>(q, M, Bn, edge_unit, s);
+            default: return pm_launch_main<42, 25, 16>(q, M, Bn, edge_unit, s);
         }
         switch (NS) {
-            case 3: return pm_launch_main<48, 3, 8, 256>(q, units, s);    case 5: return pm_launch_main<48, 5, 8, 256>(q, units, s);
-            case 7: return pm_launch_main<48, 7, 8, 256>(q, units, s);    case 13: return pm_launch_main<48, 13, 8, 256>(q, units, s);
-            default: return pm_launch_main<48, 25, 16, 256>(q, units, s);
+            case 3: return pm_launch_main<48, 3, QRL_PM_RP_SMALL>(q, M, Bn, edge_unit, s);   case 5: return pm_launch_main<48, 5, QRL_PM_RP_SMALL>(q, M, Bn, edge_unit, s);
+            case 7: return pm_launch_main<48, 7, QRL_PM_RP_SMALL>(q, M, Bn, edge_unit, s);   case 13: return pm_launch_main<48, 13, 8>(q, M, Bn, edge_unit, s);
+            default: return pm_launch_main<48, 25, 16>(q, M, Bn, edge_unit, s);
         }
     }
     switch (NS) {   // other geometries: 16 block lags (the table is zero beyond J), D = 33 .. 52
-    case 9: return pm_launch_main<16, 9>(q, units, s);    case 10: return pm_launch_main<16, 10>(q, units, s);
-    case 11: return pm_launch_main<16, 11>(q, units, s);  case 12: return pm_launch_main<16, 12>(q, units, s);
-    default: return pm_launch_main<16, 13>(q, units, s);
+    case 9: return pm_launch_main<16, 9>(q, M, Bn, edge_unit, s);    case 10: return pm_launch_main<16, 10>(q, M, Bn, edge_unit, s);
+    case 11: return pm_launch_main<16, 11>(q, M, Bn, edge_unit, s);  case 12: return pm_launch_main<16, 12>(q, M, Bn, edge_unit, s);
+    default: return pm_launch_main<16, 13>(q, M, Bn, edge_unit, s);
     }
 }
 

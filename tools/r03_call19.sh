@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 3, GPU call 19: distinct wave priorities per resident workgroup (convoy experiment), c1..c3
+set -u
+export TMPDIR=/tmp
+O=gpurun_out/r03s
+rm -rf $O; mkdir -p $O
+for v in base prio prionoswp; do
+  L=$PWD/build/libqrl_$v.so; [ $v = base ] && L=$PWD/qradiolink_amd/libqrl_hip.so
+  for c in c1 c2 c3; do
+    echo "== $c $v" >> $O/abl.log
+    QRL_LIB_PATH=$L python bench.py --config $c --steps 10 --warmup 2 --no-extra --check 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['roofline']['kernel'], d['roofline']['kernel_ms'], d.get('parity_check',{}).get('status'))" >> $O/abl.log 2>&1
+  done
+done
+cat $O/abl.log
