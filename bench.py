@@ -180,10 +180,41 @@ def timed_loop(fn, sync, args, torch, dev, world):
 C4_BYTES = 8.0 + 64 * 24000 * 2 / 1.6e6 + 64 * 4800 * 2 / 1.6e6   # input cf32 + int16 FM samples + unpacked dibits, per wideband sample
 
 
-def roofline_obj(kernel, kms, launches, bytes_per_launch, bytes_per_sample, note=None):
+def source_id():
+    """Identifies the kernel sources a measurement belongs to: sha256 over qradiolink_amd/csrc + include (sorted by name)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in ("qradiolink_amd/csrc", "include"):
+        for fn in sorted(os.listdir(os.path.join(ROOT, d))):
+            if fn.endswith((".hip", ".cpp", ".hpp", ".h")):
+                h.update(fn.encode())
+                with open(os.path.join(ROOT, d, fn), "rb") as f:
+                    h.update(f.read())
+    return h.hexdigest()[:12]
+
+
+def pmc_traffic(name, kernel, default_shape=True):
+    """HBM bytes per launch of the dominant kernel of workload `name`.  PMC counters cannot be read from inside this process; the
+    number is the one measured by the separate rocprofv3 --pmc passes of tools/r03_profile.sh on this same command (FETCH_SIZE with
+    the calibrated gfx950 factor + WRITE_SIZE), kept in profiles/pmc_traffic.json per workload shape TOGETHER WITH the id of the
+    kernel sources it was taken on: a different source id (the kernels changed since the pass) gives traffic = null."""
+    try:
+        allp = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        pmc = allp.get(name)
+        if not pmc or not default_shape or kernel.split("<")[0].split(" ")[0] not in pmc["kernel"]:
+            return None, None
+        if allp.get("_source_id") != source_id():
+            return None, "profiles/pmc_traffic.json was taken on kernel sources %s, these are %s: not reported" % (allp.get("_source_id"), source_id())
+        return pmc["fetch_bytes"] + pmc["write_bytes"], pmc.get("source")
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
+def roofline_obj(kernel, kms, launches, bytes_per_launch, bytes_per_sample, note=None, name=None, default_shape=True):
     ach = bytes_per_launch / (kms / max(launches, 1) * 1e-3) / 1e9 if kms > 0 else 0.0
-    d = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=None,
-             kernel=kernel, kernel_ms=round(kms / max(launches, 1), 4), launches=launches,
+    traffic, src = pmc_traffic(name, kernel, default_shape) if name else (None, None)
+    d = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic,
+             traffic_source=src, kernel=kernel, kernel_ms=round(kms / max(launches, 1), 4), launches=launches,
              algorithmic_bytes_per_launch=bytes_per_launch, algorithmic_bytes_per_sample=bytes_per_sample)
     if note:
         d["note"] = note
@@ -267,7 +298,7 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True):
                        "bytes_per_link_per_step": link_bytes},
             "roofline": roofline_obj(kname, kms, launches_timed, b_kernel * n * C4_BYTES, round(C4_BYTES, 3),
                                      "k_pfb_chan64 reads the wideband input once and writes the 64 channel rings; whole chain: %.1f GB/s of algorithmic bytes"
-                                     % (B * n * C4_BYTES * args.steps / dt / 1e9))}
+                                     % (B * n * C4_BYTES * args.steps / dt / 1e9), name="c4", default_shape=not (args.batch or args.nsamp))}
     if world == 1 and with_form2:
         # BASELINE configs[3] literally: 64 freq-xlating FIRs (2181 taps, 1:64) -- compute bound (34 MAC per input sample and channel)
         B2, n2 = max(1, B // 8), n // 4
@@ -341,7 +372,8 @@ def run_c5(args, torch, q, ctx, dev, rank, world, steps=None):
                        "rx_alone_ms_per_step": round(dt_rx / args.steps * 1e3, 3), "tx_alone_ms_per_step": round(dt_tx / args.steps * 1e3, 3)},
             "roofline": roofline_obj(kname, kms, launches, B * n * C5_RX_BYTES, C5_RX_BYTES,
                                      "RX front end (1:2 decimator + RRC) timed in the RX-alone pass; duplex chain: %.1f GB/s of algorithmic bytes (RX %.2f + TX 8 B per sample); TX alone writes %.1f GB/s"
-                                     % (tot * (C5_RX_BYTES + 8.0) / dt / 1e9, C5_RX_BYTES, tot * 8.0 / dt_tx / 1e9))}
+                                     % (tot * (C5_RX_BYTES + 8.0) / dt / 1e9, C5_RX_BYTES, tot * 8.0 / dt_tx / 1e9),
+                                     name="c5", default_shape=not (args.batch or args.nsamp))}
 
 
 def cpu_baseline(name, cores, budget_s=8.0):
@@ -370,8 +402,21 @@ def cpu_baseline(name, cores, budget_s=8.0):
     v_all, reps, tot = timed(cores, cores, 1, budget_s)
     v_one, _, _ = timed(1, 1, 1, budget_s / 4)
     v_port, _, _ = timed(cores, cores, 0, budget_s / 2)
+    # SURVEY 8(d) variant (ii), GNU Radio's thread-per-block scheduler: every block of the flowgraph on its own thread, streams
+    # flowing through rings.  In steady state such a pipeline moves one stream at the pace of its SLOWEST block, so the figure is
+    # derived from the measured single-thread run time of every block of one chain run (oracle/orc_trace.c block timing), best of 3:
+    # samples / max(block seconds).  It needs as many cores as the flowgraph has blocks and is an upper bound (no ring overhead).
+    orc.lib.orc_set_decim_impl(1)
+    runs = [orc.block_times(omode, base, rate, offset) for _ in range(3)]
+    orc.lib.orc_set_decim_impl(0)
+    bt = min(runs, key=lambda r: max(t for _, t in r))
+    slow = max(bt, key=lambda v: v[1])
+    tpb = dict(value=round(per / slow[1] / 1e6, 3), unit="MS/s", blocks=len(bt), slowest_block=slow[0],
+               slowest_block_share=round(slow[1] / sum(t for _, t in bt), 3),
+               note="one stream, thread-per-block pipeline bound = samples / run time of the slowest block (measured per block, "
+                    "single thread each); x streams when cores >= blocks x streams")
     return dict(value=round(v_all, 3), unit="MS/s", cores=cores, kind="port",
-                single_thread=round(v_one, 3), scalar_port=round(v_port, 3),
+                single_thread=round(v_one, 3), scalar_port=round(v_port, 3), thread_per_block_model=tpb,
                 sample="%d passes over %d streams x %d samples of the %s workload (%.1f s of CPU wall time); oracle/liborc.so "
                        "(C, -O3 -mavx2 -mfma, OpenMP over streams) with the decimating FIRs as AVX2 dot products "
                        "(orc_decim_fir_ccf_simd); GNU Radio / VOLK itself is not installable here"
@@ -447,20 +492,13 @@ def main():
     extra4 = run_c4(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20)) if (extra_ok and args.config == "c1" and world == 1) else None
     extra5 = run_c5(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20)) if (extra_ok and args.config == "c1" and world == 1) else None
     base = cpu_baseline(args.config, min(os.cpu_count() or 1, 16)) if (extra_ok and rank == 0) else None
+    base2 = cpu_baseline("c2", min(os.cpu_count() or 1, 16), budget_s=4.0) if (extra_ok and rank == 0 and args.config == "c1") else None
 
     line = None
     if rank == 0:
         def roof(r):
-            # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process; the number is
-            # the one measured by the separate rocprofv3 --pmc passes of tools/r02_profile.sh on this same command
-            # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), kept in profiles/pmc_traffic.json per workload shape.
-            traffic, src = None, None
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(r["name"])
-                if pmc and r["default_shape"] and r["kernel"] in pmc["kernel"]:
-                    traffic, src = pmc["fetch_bytes"] + pmc["write_bytes"], pmc.get("source")
-            except (OSError, ValueError, KeyError):
-                pass
+            # HBM traffic per launch of the dominant kernel: pmc_traffic() above
+            traffic, src = pmc_traffic(r["name"], r["kernel"], r["default_shape"])
             d = dict(bound="hbm", achieved=round(r["achieved_gbps"], 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                      frac=round(r["achieved_gbps"] / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=src, kernel=r["kernel"],
                      kernel_ms=round(r["kernel_ms"], 4), launches=r["launches"],
@@ -472,6 +510,7 @@ def main():
                                             note="QRL_OPT_OVERLAP = 1 (opt-in): same workload, decimated-rate kernels of call k under the front end of call k + 1")
             return d
         line = {
+            "source_id": source_id(),
             "metric": "IQ MSamples/sec through RX demod chain", "value": round(main_r["msps"], 1), "unit": "MS/s",
             "n_gpus": world, "steps": main_r["steps"], "warmup": args.warmup, "ms_per_step": round(main_r["ms_per_step"], 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -490,6 +529,8 @@ def main():
                 line[key] = {"workload": ex["label"], "value": round(ex["msps"], 1), "unit": "MS/s", "steps": ex["steps"],
                              "ms_per_step": round(ex["ms_per_step"], 3), "streams_per_gpu": ex["batch"],
                              "samples_per_stream_per_step": ex["nsamp"], "roofline": roof(ex)}
+                if key == "c2" and base2:
+                    line[key]["cpu_baseline"] = base2
         for key, ex in (("c4", extra4), ("c5", extra5)):
             if ex:
                 line[key] = {k: ex[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "roofline") if k in ex}

@@ -47,6 +47,10 @@ const char* orc_trace_get(void);          /* one "name(args)" line per primitive
 void orc_trace_event(const char* fmt, ...);
 void orc_trace_taps(const void* taps, size_t bytes, const char* fmt, ...);
 const char* orc_trace_name(const void* taps, size_t bytes);
+/* block timing for bench.py's cpu_baseline "thread_per_block_model" (orc_trace.c): run time of every primitive call of one chain run */
+void orc_block_timing_enable(int on);
+int  orc_block_timing_count(void);
+double orc_block_timing_get(int i, char* name, size_t cap);
 
 #endif
 

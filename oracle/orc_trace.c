@@ -10,9 +10,17 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "orc.h"
 
 static int g_on = 0;
+/* block timing (bench.py, cpu_baseline "thread_per_block_model"): with the trace on, the time between two primitive calls of a chain
+ * is the run time of the first one (the chains call their blocks one after the other over the whole stream) */
+#define ORC_MAX_TIMED 256
+static int g_time_on = 0, g_nblk = 0;
+static double g_tprev = 0.0, g_secs[ORC_MAX_TIMED];
+static char g_bname[ORC_MAX_TIMED][40];
+static double clock_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 static char* g_buf = NULL;
 static size_t g_len = 0, g_cap = 0;
 typedef struct { uint64_t h; char* text; } design_t;
@@ -54,6 +62,33 @@ void orc_trace_event(const char* fmt, ...)
     char line[1024];
     va_list ap; va_start(ap, fmt); vsnprintf(line, sizeof line, fmt, ap); va_end(ap);
     append(line);
+    if (g_time_on) {
+        const double t = clock_s();
+        if (g_nblk > 0) g_secs[g_nblk - 1] += t - g_tprev;
+        if (g_nblk < ORC_MAX_TIMED) {
+            size_t k = 0;
+            while (line[k] && line[k] != '(' && k + 1 < sizeof g_bname[0]) { g_bname[g_nblk][k] = line[k]; k++; }
+            g_bname[g_nblk][k] = 0;
+            g_secs[g_nblk++] = 0.0;
+        }
+        g_tprev = clock_s();
+    }
+}
+
+/* on: clear and start (also turns the construction trace on); off: close the last block */
+void orc_block_timing_enable(int on)
+{
+    if (on) {   /* what runs before the first traced primitive is gr_demod_base's rotator_cc (orc_frontend) */
+        orc_trace_enable(1); g_nblk = 1; g_secs[0] = 0.0; strcpy(g_bname[0], "rotator_cc"); g_time_on = 1; g_tprev = clock_s();
+    }
+    else if (g_time_on) { if (g_nblk > 0) g_secs[g_nblk - 1] += clock_s() - g_tprev; g_time_on = 0; g_on = 0; }
+}
+int orc_block_timing_count(void) { return g_nblk; }
+double orc_block_timing_get(int i, char* name, size_t cap)
+{
+    if (i < 0 || i >= g_nblk) return -1.0;
+    if (name && cap) { strncpy(name, g_bname[i], cap - 1); name[cap - 1] = 0; }
+    return g_secs[i];
 }
 
 void orc_trace_taps(const void* taps, size_t bytes, const char* fmt, ...)

@@ -669,6 +669,27 @@ def batch_rx(mode, iq, samp_rate, carrier_offset_hz=0.0, threads=0):
     return t, chk.value
 
 
+_sig("orc_block_timing_enable", None, C.c_int)
+_sig("orc_block_timing_count", C.c_int)
+_sig("orc_block_timing_get", C.c_double, C.c_int, C.c_char_p, C.c_size_t)
+
+
+def block_times(mode, x, samp_rate, carrier_offset_hz=0.0):
+    """Run time of every primitive call of one single-thread chain run over one stream: [(block name, seconds)] in call order."""
+    x = np.ascontiguousarray(x, cf32).reshape(1, -1)
+    lib.orc_block_timing_enable(1)
+    try:
+        batch_rx(mode, x, samp_rate, carrier_offset_hz, 1)
+    finally:
+        lib.orc_block_timing_enable(0)
+    out = []
+    buf = C.create_string_buffer(64)
+    for i in range(lib.orc_block_timing_count()):
+        secs = lib.orc_block_timing_get(i, buf, 64)
+        out.append((buf.value.decode(), float(secs)))
+    return out
+
+
 # ---- side outputs of gr_demod_base (oracle/orc_side.c)
 _sig("orc_det_log2f", C.c_float, C.c_float)
 _sig("orc_rssi_block", None, _p, C.c_size_t, C.c_float, _p)

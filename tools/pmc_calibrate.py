@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""FETCH_SIZE / WRITE_SIZE calibration (tools/r03_profile.sh): five elementwise passes (y = x + 1) over 1 GiB of float32 under rocprofv3 --pmc.
+A pass reads 2^20 KiB and writes 2^20 KiB, so counter / 2^20 is the factor the counter has to be divided by on this GPU
+(MI355X_MICROARCH.md, HBM section: FETCH_SIZE counts 64-byte requests as 32 on gfx950, i.e. reports half).
+  python tools/pmc_calibrate.py                 the workload
+  python tools/pmc_calibrate.py --summarize f   mean counter of the copy kernel in a counter_collection.csv, and its ratio to 2^20 KiB"""
+import csv
+import sys
+
+if len(sys.argv) > 2 and sys.argv[1] == "--summarize":
+    vals = {}
+    with open(sys.argv[2]) as f:
+        for r in csv.DictReader(f):
+            k = r.get("Kernel_Name", "")
+            if "elementwise" in k or "copy" in k.lower():
+                vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for c, v in vals.items():
+        big = [x for x in v if x > 1e5]          # the 1 GiB copies (skip the allocator's small fills)
+        m = sum(big) / max(len(big), 1)
+        print("copy of 1 GiB: %s = %.6g KiB (n = %d)  ratio to 2^20 KiB = %.4f" % (c, m, len(big), m / 2 ** 20))
+else:
+    import torch
+    x = torch.randn(1 << 28, device="cuda")      # 1 GiB
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+    for _ in range(5):
+        torch.add(x, 1.0, out=y)                 # one elementwise kernel: reads 1 GiB, writes 1 GiB
+    torch.cuda.synchronize()
+    print("done", float(y[12345]))

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Copies the judged summaries of tools/r03_profile.sh from gpurun_out/r03 (scratch) into profiles/ (tracked) and rebuilds
+profiles/pmc_traffic.json: HBM bytes per launch of each workload's dominant kernel = FETCH_SIZE [KiB] x 1024 / f_fetch +
+WRITE_SIZE [KiB] x 1024 / f_write, where f_* are the calibration ratios measured in the same pass on an elementwise kernel of known
+size (tools/pmc_calibrate.py; MI355X_MICROARCH.md's gfx950 correction says f_fetch = 0.5), together with the id of the kernel
+sources the pass ran on (bench.py reports traffic only for that id)."""
+import json
+import os
+import re
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC, DST = os.path.join(ROOT, "gpurun_out", "r03"), os.path.join(ROOT, "profiles")
+for name, out in (("kernel_trace_summary.md", "r03_kernel_trace_summary.md"), ("pmc_summary.txt", "r03_pmc_summary.txt")):
+    shutil.copy(os.path.join(SRC, name), os.path.join(DST, out))
+bench = {}
+for cfg in ("default", "c2", "c3", "c4", "c5", "c1_overlap"):
+    try:
+        with open(os.path.join(SRC, "bench_%s.json" % cfg)) as f:
+            lines = [l for l in f.read().splitlines() if l.startswith("{")]
+        with open(os.path.join(DST, "r03_bench_%s.json" % cfg), "w") as f:
+            f.write(lines[-1] + "\n")
+        bench[cfg] = json.loads(lines[-1])
+    except (OSError, IndexError):
+        print("missing bench line:", cfg)
+sid = open(os.path.join(SRC, "source_id.txt")).read().strip()
+
+sections, cur = {}, None
+cal = {}
+for line in open(os.path.join(SRC, "pmc_summary.txt")):
+    m = re.match(r"## (c\d|calibration) (\w+)", line)
+    if m:
+        cur = m.groups()
+        continue
+    m = re.search(r"(FETCH_SIZE|WRITE_SIZE) = [0-9.e+]+ KiB .* ratio to 2\^20 KiB = ([0-9.]+)", line)
+    if m and cur and cur[0] == "calibration":
+        cal[m.group(1)] = float(m.group(2))
+        continue
+    m = re.match(r"(qrl::\S+?)(<.*>)? .*?(FETCH_SIZE|WRITE_SIZE)=([0-9.e+]+)\(n=(\d+)\)", line)
+    if m and cur:
+        sections.setdefault(cur[0], []).append((m.group(1), m.group(2) or "", m.group(3), float(m.group(4)), int(m.group(5))))
+f_fetch, f_write = cal.get("FETCH_SIZE", 0.5), cal.get("WRITE_SIZE", 1.0)
+# round the calibration to the documented factors when it is within 3 % of them (the counters' granularity), else keep it
+f_fetch = 0.5 if abs(f_fetch - 0.5) < 0.015 else f_fetch
+f_write = 1.0 if abs(f_write - 1.0) < 0.03 else f_write
+dominant = {"c1": bench.get("default", {}).get("roofline", {}).get("kernel"), "c2": bench.get("c2", {}).get("roofline", {}).get("kernel"),
+            "c3": bench.get("c3", {}).get("roofline", {}).get("kernel"), "c4": bench.get("c4", {}).get("roofline", {}).get("kernel"),
+            "c5": bench.get("c5", {}).get("roofline", {}).get("kernel")}
+out = {"_source_id": sid, "_calibration": {"measured": cal, "applied": {"FETCH_SIZE": f_fetch, "WRITE_SIZE": f_write},
+                                           "how": "tools/pmc_calibrate.py under the same rocprofv3 --pmc passes (tools/r03_profile.sh): counter / 2^20 KiB on y = x + 1 over 1 GiB"}}
+for cfg, rows in sections.items():
+    want = (dominant.get(cfg) or "").split(" ")[0].split("<")[0]
+    want = want if want.startswith("qrl::") else "qrl::" + want
+    best = {}
+    for base, targs, cnt, val, n in rows:
+        if base != want:
+            continue
+        if cnt not in best or val > best[cnt][0]:
+            best[cnt] = (val, base + targs, n)
+    if "FETCH_SIZE" in best and "WRITE_SIZE" in best:
+        out[cfg] = {"kernel": best["FETCH_SIZE"][1], "fetch_bytes": best["FETCH_SIZE"][0] * 1024 / f_fetch,
+                    "write_bytes": best["WRITE_SIZE"][0] * 1024 / f_write, "launches_averaged": best["FETCH_SIZE"][2],
+                    "source": "profiles/r03_pmc_summary.txt",
+                    "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/r03_profile.sh) on `python bench.py --config %s "
+                            "--steps 3 --warmup 1 --no-extra`, mean over the launches of the default shape; KiB counters, divided by the calibration "
+                            "factors above" % cfg}
+    else:
+        print("no PMC rows for", cfg, want)
+with open(os.path.join(DST, "pmc_traffic.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print(json.dumps({k: round((v["fetch_bytes"] + v["write_bytes"]) / 1e9, 3) for k, v in out.items() if not k.startswith("_")}), out["_calibration"])

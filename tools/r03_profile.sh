@@ -1,0 +1,33 @@
+#!/bin/bash
+# Round-3 profile pass (run on the GPU box through gpurun): kernel-trace stats of the bench commands of c1 .. c5, HBM-traffic PMC passes of
+# their dominant kernels (separate rocprofv3 runs, kernel-trace only, as MI355X_MICROARCH.md prescribes), a FETCH_SIZE / WRITE_SIZE
+# calibration on a copy of known size, bench lines.  Everything under gpurun_out/r03/; tools/r03_collect.py turns it into profiles/r03_*.
+set -u
+export TMPDIR=/tmp
+O=gpurun_out/r03
+rm -rf $O; mkdir -p $O
+python -c "import bench; print(bench.source_id())" > $O/source_id.txt
+for cfg in c1 c2 c3 c4 c5; do
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof -o $cfg -- python bench.py --config $cfg --steps 5 --warmup 1 --no-extra > $O/prof_$cfg.log 2>&1
+done
+for f in $(find $O/prof -name '*_results.db' | sort); do python tools/prof_summary.py $f "$(basename $f _results.db): rocprofv3 --kernel-trace --stats -- python bench.py --config $(basename $f _results.db) --steps 5 --warmup 1 --no-extra"; done > $O/kernel_trace_summary.md
+pmc() { local cfg=$1 name=$2; shift 2
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $O/pmc_${cfg}_$name -o $name --output-format csv -- python bench.py --config $cfg --steps 3 --warmup 1 --no-extra > $O/pmc_${cfg}_$name.log 2>&1
+  f=$(find $O/pmc_${cfg}_$name -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && { echo "## $cfg $name"; python tools/pmc_summary.py "$f"; } >> $O/pmc_summary.txt
+}
+for cfg in c1 c2 c3 c4 c5; do
+  pmc $cfg fetch FETCH_SIZE
+  pmc $cfg write WRITE_SIZE
+done
+# calibration: a device-to-device copy of 1 GiB (reads 2^20 KiB, writes 2^20 KiB) under the same two counters
+for cnt in FETCH_SIZE WRITE_SIZE; do
+  timeout 200 rocprofv3 --kernel-trace --pmc $cnt -d $O/cal_$cnt -o cal --output-format csv -- python tools/pmc_calibrate.py > $O/cal_$cnt.log 2>&1
+  f=$(find $O/cal_$cnt -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && { echo "## calibration $cnt"; python tools/pmc_calibrate.py --summarize "$f"; } >> $O/pmc_summary.txt
+done
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+for cfg in c2 c3 c4 c5; do python bench.py --config $cfg --no-extra > $O/bench_$cfg.json 2> $O/bench_$cfg.err; done
+python bench.py --config c1 --overlap --no-extra > $O/bench_c1_overlap.json 2>/dev/null
+find $O -name '*.csv' -size +2M -delete; find $O/prof -type f -size +4M -delete; find $O -name '*.db' -size +4M -delete
+cat $O/pmc_summary.txt | cut -c1-220
