@@ -171,6 +171,7 @@ struct qrl_demod {
     bool qpsk_fll = false, fsk4_disc = false;
     bool m17 = false;   // F_DMR family, gr_demod_m17 variant: channel filter behind the resampler (port 0), mod-M&M TED, no level control
     DevBuf<float2> s2g, disc4_taps; DevBuf<float> sym4_taps; int disc4_nt = 0, sym4_nt = 0;   // 4FSK non-FM branch
+    bool d2f_capable = false, d2f = false; DevBuf<float> d2f_taps;   // 1:2 decimator + shaping filter in one kernel (k_dec2_fir)
     bool overlap = false, overlap_capable = false; hipEvent_t ev_tail2[2] = {nullptr, nullptr}; bool tail2_valid[2] = {false, false}; uint64_t call_no = 0;
     enum Family { F_2FSK, F_GMSK, F_QPSK, F_DMR, F_4FSK, F_BPSK, F_DSSS, F_ANALOG } fam = F_2FSK;
     int branches = 2;
@@ -386,9 +387,17 @@ int qrl_demod::build()
         if ((r = rs_taps.upload(resamp_layout(rtaps, interp, rs_Jp)))) return r;
     }
 
+    // QPSK-250k class (gr_demod_qpsk.cpp:92-103 with sps <= 4): 1:2 resampler and the RRC behind it run as ONE kernel
+    std::vector<float> d2f_rrc;
+    if (fam == F_QPSK && !qpsk_fll && interp == 1) {
+        d2f_rrc = root_raised_cosine(sps_eff, sps_eff, 1, 0.35, 11 * sps_eff);
+        d2f_capable = d2f = dec2_fir_supported((int)rtaps.size(), decim, (int)d2f_rrc.size());
+        if (d2f && (r = d2f_taps.upload(dec2_fir_table(rtaps, d2f_rrc)))) return r;
+    }
+    const uint32_t first_look = interp == 1 ? std::max<uint32_t>(first.lookback(), d2f ? dec2_fir_lookback() : 0u) : 0u;
     // --- history of the caller's IQ kept by whichever stage reads it
     if (fe.used) hist_len = fe.lookback();
-    else if (interp == 1) hist_len = first.lookback();
+    else if (interp == 1) hist_len = first_look;
     else hist_len = (uint32_t)(rs_Jp + decim + 2);
     if ((r = hist_a.alloc((size_t)B * hist_len)) || (r = hist_b.alloc((size_t)B * hist_len))) return r;
 
@@ -397,7 +406,7 @@ int qrl_demod::build()
     const size_t in2 = fe.used ? max1 : maxn;                        // items entering the mode resampler per call
     const size_t max2 = in2 * interp / decim + 2;                    // target-rate items per call
     if (fe.used) {
-        const size_t look = interp == 1 ? first.lookback() : (size_t)(rs_Jp + decim + 2);
+        const size_t look = interp == 1 ? first_look : (size_t)(rs_Jp + decim + 2);
         s1_mask = pow2_at_least(max1 + look + 64) - 1;
         if ((r = s1.alloc((size_t)B * (s1_mask + 1)))) return r;
     }
@@ -656,7 +665,15 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         p.n0 = src0; p.n = (uint32_t)(src1 - src0);
         p.out = r2; p.m0 = n2_0; p.m_count = (uint32_t)(n2_1 - n2_0);
         p.taps = first.taps.p; p.D = first.D; p.Jpad = first.Jpad;
-        if (first.launch(p, B, stream)) return fail(QRL_ERR_HIP, "first-stage launch: hipFuncSetAttribute failed");
+        if (d2f) {   // + _shaping_filter -> port 0 and the filtered ring, in the same kernel
+            const bool sd = cfg.enable_side_outputs && out;
+            Dec2FirParams f{};
+            f.d = p; f.taps = d2f_taps.p; f.out = RingC{s2f.p, s2_mask};
+            f.port = sd && out->filtered ? reinterpret_cast<float2*>(out->filtered) : nullptr;
+            f.port_cap = sd ? out->filtered_cap : 0;
+            f.counts = counts;
+            launch_dec2_fir(f, B, stream);
+        } else if (first.launch(p, B, stream)) return fail(QRL_ERR_HIP, "first-stage launch: hipFuncSetAttribute failed");
     } else {
         ResampParams p{};
         if (fe.used) { p.in = nullptr; p.in_ring = r1; }
@@ -739,7 +756,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         launch_2fsk_ff(f, B, cs);
         if (!overlap) { HIPCHK(hipEventRecord(ev_ff, stream)); HIPCHK(hipStreamWaitEvent(tail, ev_ff, 0)); }
     } else {
-        {
+        if (!d2f) {
             FirCcfParams f{};
             f.in = filt_in; f.out = r2f; f.q0 = n2_0; f.count = c2; f.taps = filt_taps.p; f.nt = filt_nt;
             f.port = side && out->filtered ? reinterpret_cast<float2*>(out->filtered) : nullptr;
@@ -1143,6 +1160,11 @@ int qrl_demod_set_option(qrl_demod* d, int option, int value)
         d->overlap = value != 0;
         d->tail2_valid[0] = d->tail2_valid[1] = false;
         return QRL_OK;
+    case QRL_OPT_UNFUSED_DEC2:
+        if (!d->d2f_capable) return qrl_set_error(QRL_ERR_ARG, "this chain has no fused 1:2 decimator + shaping filter");
+        if (d->n_in != 0) return qrl_set_error(QRL_ERR_STATE, "QRL_OPT_UNFUSED_DEC2 can only be set before the first sample (the two forms carry different state)");
+        d->d2f = value == 0;
+        return QRL_OK;
     default:
         return qrl_set_error(QRL_ERR_ARG, "unknown option");
     }
@@ -1215,7 +1237,8 @@ int qrl_demod_profile_read(qrl_demod* d, double* kernel_ms, uint64_t* launches, 
     if (launches) *launches = d->prof_events.size();
     if (kernel_name) {
         const DecimStage& st = d->fe.used ? d->fe : d->first;
-        *kernel_name = (d->fe.used || d->interp == 1) ? (st.pm ? "k_decim_pm" : st.pl ? "k_decim_plx" : st.mfma ? "k_decim_mfma" : "k_decim") : "k_resamp";
+        *kernel_name = (!d->fe.used && d->d2f) ? "k_dec2_fir"
+                     : (d->fe.used || d->interp == 1) ? (st.pm ? "k_decim_pm" : st.pl ? "k_decim_plx" : st.mfma ? "k_decim_mfma" : "k_decim") : "k_resamp";
     }
     d->prof_events.clear();
     return QRL_OK;

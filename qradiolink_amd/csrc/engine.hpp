@@ -51,6 +51,12 @@ struct HistParams {
     int rot_enable; uint64_t rot_acc; uint64_t rot_inc; uint64_t rot_nbase; const float2* rot_lo;
 };
 void launch_decim(const DecimParams& p, int batch, int variant, hipStream_t s);
+// 1:2 decimator + the channel FIR behind it in one kernel (kernels_frontend.hip k_dec2_fir): d = the decimator's input side (out unused)
+struct Dec2FirParams { DecimParams d; const float* taps; RingC out; float2* port; size_t port_cap; uint32_t* counts; };
+bool dec2_fir_supported(int nt1, int D, int nt2);
+uint32_t dec2_fir_lookback();
+std::vector<float> dec2_fir_table(const std::vector<float>& h1, const std::vector<float>& h2);
+void launch_dec2_fir(const Dec2FirParams& p, int batch, hipStream_t s);
 void launch_hist_save(const HistParams& p, int batch, hipStream_t s);
 size_t decim_lds_bytes(int D, int Jpad, int variant);
 enum { DECIM_R4_J44 = 0, DECIM_R4_J12 = 1, DECIM_R2_J10 = 2, DECIM_R1_J14 = 3 };

@@ -336,4 +336,178 @@ void launch_resamp(const ResampParams& p, int batch, hipStream_t s)
     hipLaunchKernelGGL(k_resamp, grid, block, lds, s, p, span);
 }
 
+
+// ---- 1:2 decimator + channel FIR in one pass (gr_demod_qpsk / gr_demod_4fsk at 250k / 100k symbols: resampler 1:2 then the RRC or
+// low-pass at 500 ksps; reference gr_demod_qpsk.cpp:62-76) ------------------------------------------------------------------------
+// Round 2 ran k_decim<4,12> (2.97 ms on C5) and k_fir_ccf_tiled (2.13 ms) with the 500 ksps stream going through HBM in between.  Here
+// a workgroup stages 4 176 input samples once, de-interleaved into even / odd samples and, inside each, into 8 IMAGES (sample m of a
+// parity lies in image m & 7 at position m >> 3), so that a thread that owns 8 CONSECUTIVE outputs reads its sliding window with
+// conflict-free ds_read_b64 (consecutive lanes = consecutive positions).  Per chunk of 8 taps a thread reads 15 samples and does
+// 64 complex x real MACs as packed fmas (v_pk_fma_f32: both components in one instruction).  The decimated samples go back into
+// the same LDS (again 8 images) and the second filter runs the same way; only its outputs leave the CU.
+// Summation order = the oracle's (orc_decim_fir_ccf with G = 4 at D = 2: one chain over the even taps, one over the odd taps, j
+// ascending, y = r_even + r_odd; orc_fir_ccf: one chain, k ascending): padding taps are zeros on finite samples, so they add +0.
+constexpr int D2_NTH = 256, D2_R = 8;
+constexpr int D2_W = 261;                        // positions per image: (40 + 2048) / 8
+constexpr int D2_HALO = 24;                      // second-filter taps, padded to a multiple of 8
+constexpr int D2_TY = D2_R * D2_NTH - D2_HALO;   // outputs a workgroup delivers
+__global__ __launch_bounds__(D2_NTH) void k_dec2_fir(const Dec2FirParams P_)
+{
+    const Dec2FirParams& P = P_;
+    const DecimParams& Q = P.d;
+    __shared__ float2 t_lo[512];
+    __shared__ float2 t_hi[16];
+    __shared__ v2f img[2 * 8 * D2_W];            // [parity][image][position]; reused as [image][position] of the decimated samples
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const uint64_t y0 = Q.m0 + (uint64_t)blockIdx.x * D2_TY;       // first output of this workgroup
+    const int64_t mb = (int64_t)y0 - D2_HALO;                       // thread t owns decimated samples mb + 8 t .. + 7
+    const int64_t mq = mb - 40;                                     // image position 0 = decimated index mq .. mq + 7
+    // ---- rotator tables (caller's buffer only: carried history is already rotated, engine rings too) ----
+    uint32_t kb0 = 0;
+    if (Q.rot_enable) {
+        t_lo[tid] = Q.rot_lo[tid];
+        t_lo[tid + 256] = Q.rot_lo[tid + 256];
+        const int64_t i_start = 2 * mq - 1;
+        const int64_t first_new = i_start > (int64_t)Q.n0 ? i_start : (int64_t)Q.n0;
+        kb0 = (uint32_t)(((uint64_t)first_new - Q.rot_nbase) >> 9);
+        if (tid < 16) t_hi[tid] = sincos_turn(Q.rot_acc + ((uint64_t)(kb0 + tid) << 9) * Q.rot_inc);
+        __syncthreads();
+    }
+    // ---- stage: local l = m - mq; even sample x[2 m] and odd sample x[2 m - 1] ----
+    // (two passes: every load of the thread is issued before the first one is used -- a fetch -> rotate -> store loop pays the memory
+    //  latency nine times per workgroup)
+    {
+        constexpr int NK = (8 * D2_W + D2_NTH - 1) / D2_NTH;         // 9 pairs per thread
+        const float2* inb = Q.in ? Q.in + (size_t)b * Q.in_stride : nullptr;
+        const float2* hb = Q.hist ? Q.hist + (size_t)b * Q.hist_len : nullptr;
+        const float2* rb = Q.in_ring.p ? Q.in_ring.p + (size_t)b * (Q.in_ring.mask + 1u) : nullptr;
+        const int64_t i_end = (int64_t)(Q.n0 + Q.n);
+        float2 v[NK][2];
+        bool fresh[NK][2];                                           // from the caller's buffer: still to be rotated
+        const int64_t i_lo = 2 * mq - 1;
+        if (inb && i_lo >= (int64_t)Q.n0 && i_lo + 2 * 8 * D2_W <= i_end) {   // the whole span lies in the caller's buffer (workgroup uniform)
+            const float2* src = inb + (size_t)(i_lo - (int64_t)Q.n0) + 2 * tid;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const bool ok = tid + D2_NTH * k < 8 * D2_W;
+                v[k][0] = ok ? src[2 * D2_NTH * k] : make_float2(0.f, 0.f);
+                v[k][1] = ok ? src[2 * D2_NTH * k + 1] : make_float2(0.f, 0.f);
+                fresh[k][0] = fresh[k][1] = Q.rot_enable != 0;
+            }
+        } else
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int l = tid + D2_NTH * k;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int64_t i = 2 * (mq + l) - 1 + e;              // e = 0: the odd sample x[2 m - 1], e = 1: the even one x[2 m]
+                const float2* src = nullptr;
+                fresh[k][e] = false;
+                if (l < 8 * D2_W && i >= 0 && i < i_end) {
+                    if (inb) {
+                        if (i >= (int64_t)Q.n0) { src = inb + (size_t)(i - (int64_t)Q.n0); fresh[k][e] = Q.rot_enable != 0; }
+                        else if ((int64_t)Q.n0 - i <= (int64_t)Q.hist_len) src = hb + (Q.hist_len - (uint32_t)((int64_t)Q.n0 - i));
+                    } else src = rb + ((uint32_t)i & Q.in_ring.mask);
+                }
+                v[k][e] = src ? *src : make_float2(0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int l = tid + D2_NTH * k;
+            if (l < 8 * D2_W) {
+                const int64_t i = 2 * (mq + l) - 1;
+                float2 xo = v[k][0], xe = v[k][1];
+                if (fresh[k][0]) xo = rot_apply(xo, (uint64_t)i - Q.rot_nbase, t_hi, kb0, t_lo);
+                if (fresh[k][1]) xe = rot_apply(xe, (uint64_t)(i + 1) - Q.rot_nbase, t_hi, kb0, t_lo);
+                const int a = (l & 7) * D2_W + (l >> 3);
+                img[a] = v2f{xe.x, xe.y};
+                img[8 * D2_W + a] = v2f{xo.x, xo.y};
+            }
+        }
+    }
+    __syncthreads();
+    // ---- first filter: 8 outputs per thread, two chains each ----
+    v2f acc[2][D2_R];
+#pragma unroll
+    for (int r = 0; r < D2_R; ++r) { acc[0][r] = v2f{0.f, 0.f}; acc[1][r] = v2f{0.f, 0.f}; }
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const v2f* im = img + par * 8 * D2_W + 5 + tid;             // position of decimated index mb + 8 t in image 0
+        const float* tp = P.taps + par * 40;
+        for (int c = 0; c < 5; ++c) {                                // taps 8 c .. 8 c + 7 of this parity's chain
+            v2f w[15];                                               // w[o + 7] = sample at offset o = r - j' from mb + 8 t - 8 c
+#pragma unroll
+            for (int o = 0; o < 8; ++o) w[7 + o] = im[o * D2_W - c];
+#pragma unroll
+            for (int o = 1; o < 8; ++o) w[7 - o] = im[(8 - o) * D2_W - c - 1];
+            float h[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = tp[8 * c + j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int r = 0; r < D2_R; ++r)
+                    acc[par][r] = __builtin_elementwise_fma(v2f{h[j], h[j]}, w[7 + r - j], acc[par][r]);
+        }
+    }
+    __syncthreads();                                                 // every thread is done with the input images
+    v2f* dimg = img;                                                 // decimated sample mb + 8 t + r -> image r, position t
+#pragma unroll
+    for (int r = 0; r < D2_R; ++r) dimg[r * D2_W + tid] = acc[0][r] + acc[1][r];
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0 && P.counts) P.counts[b * 4 + 0] = Q.m_count;
+    if (tid < D2_HALO / 8) return;                                   // these threads only supplied the halo
+    // ---- second filter ----
+    v2f y[D2_R];
+#pragma unroll
+    for (int r = 0; r < D2_R; ++r) y[r] = v2f{0.f, 0.f};
+    {
+        const v2f* im = dimg + tid;
+        const float* tp = P.taps + 80;
+        for (int c = 0; c < D2_HALO / 8; ++c) {
+            v2f w[15];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) w[7 + o] = im[o * D2_W - c];
+#pragma unroll
+            for (int o = 1; o < 8; ++o) w[7 - o] = im[(8 - o) * D2_W - c - 1];
+            float h[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = tp[8 * c + j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int r = 0; r < D2_R; ++r)
+                    y[r] = __builtin_elementwise_fma(v2f{h[j], h[j]}, w[7 + r - j], y[r]);
+        }
+    }
+    // ---- outputs: the filtered stream (engine ring) and, when asked for, the caller's port-0 buffer ----
+    const uint64_t m_end = Q.m0 + Q.m_count;
+#pragma unroll
+    for (int r = 0; r < D2_R; ++r) {
+        const uint64_t m = (uint64_t)(mb + 8 * tid + r);
+        if (m < m_end) {
+            const float2 v = make_float2(y[r].x, y[r].y);
+            P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = v;
+            const uint64_t t = m - Q.m0;
+            if (P.port && t < P.port_cap) P.port[(size_t)b * P.port_cap + t] = v;
+        }
+    }
+}
+bool dec2_fir_supported(int nt1, int D, int nt2) { return D == 2 && nt1 <= 79 && (nt1 & 1) && nt2 <= D2_HALO; }
+uint32_t dec2_fir_lookback() { return 2 * (D2_HALO + 40) + 2; }
+// table: [0..39] even taps h[2 j], [40..79] odd taps h[2 j + 1], [80..103] second filter; zero padded
+std::vector<float> dec2_fir_table(const std::vector<float>& h1, const std::vector<float>& h2)
+{
+    std::vector<float> t(80 + D2_HALO, 0.0f);
+    for (size_t k = 0; k < h1.size(); ++k) t[(k & 1) * 40 + (k >> 1)] = h1[k];
+    for (size_t k = 0; k < h2.size(); ++k) t[80 + k] = h2[k];
+    return t;
+}
+void launch_dec2_fir(const Dec2FirParams& p, int batch, hipStream_t s)
+{
+    if (p.d.m_count == 0) return;
+    hipLaunchKernelGGL(k_dec2_fir, dim3((p.d.m_count + D2_TY - 1) / D2_TY, batch), dim3(D2_NTH), 0, s, p);
+}
+
 }  // namespace qrl

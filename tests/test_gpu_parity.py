@@ -536,3 +536,35 @@ def test_lds_dma_front_end_with_padded_row_pitch(qrl_ctx, pitch_pad):
     out = q.collect(dem, view, n)
     dem.close()
     _compare(iq, out, "2fsk1k", 1000000, 1200.0)
+
+
+@pytest.mark.parametrize("chunk", [1 << 20, 4050, 7778])
+def test_qpsk250k_unfused_resampler_and_filter_agree_with_the_fused_kernel(qrl_ctx, chunk):
+    """QRL_OPT_UNFUSED_DEC2 = 1 runs the 1:2 resampler and the RRC of gr_demod_qpsk (gr_demod_qpsk.cpp:92-103) as the two kernels of
+    rounds 1-2; the fused k_dec2_fir (default) must give the same bits AND the same port-0 / port-1 floats, both equal to the oracle's.
+    Chunk sizes around the kernel's 2024-output tile (4048 input samples) exercise the halo taken from the carried history."""
+    import torch
+    import qradiolink_amd as q
+    iq = sig.make_batch("qpsk250k", 2, nframes=2, device_rate=1000000, rx_offset_hz=1200.0, seed=11)
+    outs = []
+    for unfused in (0, 1):
+        dem = q.Demod(qrl_ctx, 26, batch=2, max_chunk=chunk, device_samp_rate=1000000, carrier_offset_hz=1200.0)
+        dem.set_option(q.OPT_UNFUSED_DEC2, unfused)
+        outs.append(q.collect(dem, torch.from_numpy(iq).cuda(), chunk))
+        dem.close()
+    _compare(iq, outs[0], "qpsk250k", 1000000, 1200.0)
+    _compare(iq, outs[1], "qpsk250k", 1000000, 1200.0)
+
+
+def test_unfused_option_is_refused_mid_stream_and_on_other_chains(qrl_ctx):
+    import torch
+    import qradiolink_amd as q
+    dem = q.Demod(qrl_ctx, 18, batch=1, max_chunk=4096, device_samp_rate=1000000)
+    with pytest.raises(q.QrlError):
+        dem.set_option(q.OPT_UNFUSED_DEC2, 1)
+    dem.close()
+    dem = q.Demod(qrl_ctx, 26, batch=1, max_chunk=4096, device_samp_rate=1000000)
+    dem.process(torch.zeros((1, 4096), dtype=torch.complex64, device="cuda"))
+    with pytest.raises(q.QrlError):
+        dem.set_option(q.OPT_UNFUSED_DEC2, 1)
+    dem.close()
