@@ -15,6 +15,8 @@ g = torch.Generator(device="cuda")
 g.manual_seed(1)
 iq = torch.view_as_complex(torch.randn((batch, nsamp, 2), generator=g, device="cuda") * 0.05)
 dem = q.Demod(ctx, modem, batch=batch, max_chunk=nsamp, device_samp_rate=rate)
+if os.environ.get("QRL_KPROF_UNFUSED"):      # A/B: the 1:2 resampler and the RRC of the QPSK chain as two kernels
+    dem.set_option(q.OPT_UNFUSED_DEC2, 1)
 for _ in range(calls):
     dem.process_async(iq)
     dem.sync()

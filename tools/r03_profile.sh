@@ -11,6 +11,16 @@ for cfg in c1 c2 c3 c4 c5; do
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof -o $cfg -- python bench.py --config $cfg --steps 5 --warmup 1 --no-extra > $O/prof_$cfg.log 2>&1
 done
 for f in $(find $O/prof -name '*_results.db' | sort); do python tools/prof_summary.py $f "$(basename $f _results.db): rocprofv3 --kernel-trace --stats -- python bench.py --config $(basename $f _results.db) --steps 5 --warmup 1 --no-extra"; done > $O/kernel_trace_summary.md
+# every kernel ALONE (a sync after every call: nothing of the next call runs beside it): C1, C2, C3 chains and C5's receiver, fused and not
+kp() { local name=$1; shift
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/kprof -o $name -- python tools/kprof.py "$@" > $O/kprof_$name.log 2>&1
+}
+kp alone_c1 18 16384 262144 1000000 3
+kp alone_c2 22 384 1638400 25000000 3
+kp alone_c3 26 384 1638400 100000000 3
+kp alone_c5rx 26 16384 16384 1000000 4
+QRL_KPROF_UNFUSED=1 kp alone_c5rx_unfused 26 16384 16384 1000000 4
+for f in $(find $O/kprof -name '*_results.db' | sort); do python tools/prof_summary.py $f "$(basename $f _results.db): rocprofv3 --kernel-trace --stats -- python tools/kprof.py (one call at a time, sync after every call)"; done > $O/kernel_alone_summary.md
 pmc() { local cfg=$1 name=$2; shift 2
   timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $O/pmc_${cfg}_$name -o $name --output-format csv -- python bench.py --config $cfg --steps 3 --warmup 1 --no-extra > $O/pmc_${cfg}_$name.log 2>&1
   f=$(find $O/pmc_${cfg}_$name -name '*counter_collection.csv' | head -1)
