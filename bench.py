@@ -107,7 +107,7 @@ def parity_check(dem, iq, mode, rate, offset, torch, nstreams=4, seed=5):
                 bits_per_stream=int(cnt[picks[0], 2]))
 
 
-def run_workload(name, args, torch, q, ctx, dev, rank, world, overlap=False, check=False, steps=None):
+def run_workload(name, args, torch, q, ctx, dev, rank, world, overlap=None, check=False, steps=None):
     label, mode, modem, rate, offset, dbatch, dns, _, abytes = WORKLOADS[name]
     steps = steps or args.steps
     batch = args.batch if (args.batch and name == args.config) else dbatch
@@ -116,8 +116,10 @@ def run_workload(name, args, torch, q, ctx, dev, rank, world, overlap=False, che
     iq = synth(mode, rate, offset, batch, nsamp, 1234 + rank, torch, dev, pad=args.pad)
     dem = q.Demod(ctx, modem, batch=batch, max_chunk=nsamp, device_samp_rate=rate, carrier_offset_hz=offset,
                   side_outputs=True)
-    if overlap:
-        dem.set_option(q.OPT_OVERLAP, 1)   # opt-in: decimated-rate kernels of call k under the front end of call k + 1
+    if overlap is not None and name == "c1":
+        dem.set_option(q.OPT_OVERLAP, 1 if overlap else 0)   # library default for the 2FSK family: 1 (decimated-rate kernels of call k under the front end of call k + 1)
+    if getattr(args, "fll_slim", False):
+        dem.set_option(q.OPT_FLL_SLIM, 1)
     for _ in range(args.warmup):
         dem.process_async(iq)
     dem.sync()
@@ -444,8 +446,9 @@ def main():
     ap.add_argument("--nsamp", type=int, default=0)
     ap.add_argument("--pad", type=int, default=0, help="extra samples of row pitch of the input batch (even)")
     ap.add_argument("--no-extra", action="store_true", help="only the timed workload: no stand-alone pass, parity check, C2 line, CPU baseline")
-    ap.add_argument("--overlap", action="store_true", help="C1 only: QRL_OPT_OVERLAP = 1 (decimated-rate kernels of call k under the front end of call k + 1)")
-    ap.add_argument("--no-overlap", action="store_true", help="(default behaviour; kept for the tools/ scripts)")
+    ap.add_argument("--overlap", action="store_true", help="(the library default since round 3; kept for the tools/ scripts)")
+    ap.add_argument("--no-overlap", action="store_true", help="C1 only: QRL_OPT_OVERLAP = 0 (the kernels of a call strictly one after the other)")
+    ap.add_argument("--fll-slim", action="store_true", help="tuning, c1: QRL_OPT_FLL_SLIM = 1 (single-wave FLL workgroups)")
     ap.add_argument("--check", action="store_true", help="with --no-extra: still run the parity check against the oracle at the bench shape")
     ap.add_argument("--legacy-pfb", action="store_true", help="A/B, c4: QRL_CHAN_OPT_LEGACY_PFB = 1 (general-M channelizer kernel)")
     args = ap.parse_args()
@@ -482,11 +485,12 @@ def main():
         finish((run_c4 if args.config == "c4" else run_c5)(args, torch, q, ctx, dev, rank, world))
         return
     extra_ok = not args.no_extra
-    main_r = run_workload(args.config, args, torch, q, ctx, dev, rank, world, overlap=args.overlap and args.config == "c1", check=extra_ok or args.check)
-    # C1 also has an opt-in overlapped mode (the FLL / discriminator kernels of call k share the GPU with the front end of call
-    # k + 1): more whole-chain throughput, but the front-end kernel stretches.  Measured in a second short pass for the record.
-    ovl = run_workload("c1", args, torch, q, ctx, dev, rank, world, overlap=True, steps=min(args.steps, 20)) \
-        if (extra_ok and args.config == "c1" and not args.overlap) else None
+    main_r = run_workload(args.config, args, torch, q, ctx, dev, rank, world, overlap=False if args.no_overlap else None, check=extra_ok or args.check)
+    # C1 runs in the library's default mode (the FLL / discriminator kernels of call k share the GPU with the front end of call
+    # k + 1: more whole-chain throughput, but the front-end kernel stretches).  The serial order -- where the front-end kernel has the
+    # chip to itself -- is measured in a second short pass for the record.
+    ovl = run_workload("c1", args, torch, q, ctx, dev, rank, world, overlap=False, steps=min(args.steps, 20)) \
+        if (extra_ok and args.config == "c1" and not args.no_overlap) else None
     extra = run_workload("c2", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 50)) if (extra_ok and args.config == "c1") else None
     extra3 = run_workload("c3", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 30)) if (extra_ok and args.config == "c1") else None
     extra4 = run_c4(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20)) if (extra_ok and args.config == "c1" and world == 1) else None
@@ -504,10 +508,12 @@ def main():
                      kernel_ms=round(r["kernel_ms"], 4), launches=r["launches"],
                      algorithmic_bytes_per_launch=r["bytes_per_launch"], algorithmic_bytes_per_sample=r["bytes_per_sample"])
             if ovl and r["name"] == "c1":
-                d["overlapped_mode"] = dict(kernel_ms=round(ovl["kernel_ms"], 4), achieved=round(ovl["achieved_gbps"], 1),
-                                            frac=round(ovl["achieved_gbps"] / HBM_PEAK_GBPS, 4), ms_per_step=round(ovl["ms_per_step"], 3),
-                                            value=round(ovl["msps"], 1),
-                                            note="QRL_OPT_OVERLAP = 1 (opt-in): same workload, decimated-rate kernels of call k under the front end of call k + 1")
+                d["serial_mode"] = dict(kernel_ms=round(ovl["kernel_ms"], 4), achieved=round(ovl["achieved_gbps"], 1),
+                                        frac=round(ovl["achieved_gbps"] / HBM_PEAK_GBPS, 4), ms_per_step=round(ovl["ms_per_step"], 3),
+                                        value=round(ovl["msps"], 1),
+                                        note="QRL_OPT_OVERLAP = 0: same workload, the kernels of a call one after the other -- the front-end kernel alone on the chip")
+                d["note"] = ("default mode = QRL_OPT_OVERLAP 1: the FLL / discriminator / symbol-sync / decoder kernels of call k run beside this "
+                             "kernel of call k + 1, so its launches are longer than in serial_mode and the step is shorter")
             return d
         line = {
             "source_id": source_id(),

@@ -107,12 +107,12 @@ int qrl_demod_set_carrier_offset(qrl_demod* d, double carrier_offset_hz);
  * a reset) or the slicer starts with an empty 1440-sample history. */
 #define QRL_DMO_RECORD_BYTES 40
 int qrl_demod_set_dmo_output(qrl_demod* d, uint8_t* frames, size_t cap_frames, uint32_t* counts);
-/* Per-handle run-time options (none of them changes results).  QRL_OPT_OVERLAP (2FSK family only, default 0): value 1 runs
+/* Per-handle run-time options (none of them changes results).  QRL_OPT_OVERLAP (2FSK family only, default 1 since round 3): value 1 runs
  * everything behind the first decimated ring of call k on a second stream under the front end of call k + 1; value 0 runs the
  * kernels of a call one after another.  QRL_OPT_UNFUSED_DEC2 (QPSK chains with sps <= 4, default 0): value 1 runs the 1:2 resampler
  * and the shaping filter (gr_demod_qpsk.cpp:92-103) as the two kernels of rounds 1-2 instead of the fused one (A/B and parity checks);
  * only before the first sample of a stream. */
-enum { QRL_OPT_OVERLAP = 1, QRL_OPT_UNFUSED_DEC2 = 2 };
+enum { QRL_OPT_OVERLAP = 1, QRL_OPT_UNFUSED_DEC2 = 2, QRL_OPT_FLL_SLIM = 3 /* tuning: single-wave FLL workgroups */ };
 int qrl_demod_set_option(qrl_demod* d, int option, int value);
 int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* filtered_cap, size_t* constellation_cap, size_t* bits_cap);
 /* analogue voice receivers (QRL_MODEM_NBFM2500 / NBFM5000 / AM5000 / WBFM / USB2500 / LSB2500; replace make_gr_demod_nbfm / _am /

@@ -25,7 +25,7 @@ MODEM_NBFM2500, MODEM_NBFM5000, MODEM_WBFM, MODEM_AM5000 = 8, 9, 10, 14
 MODEM_USB2500, MODEM_LSB2500 = 11, 12
 MODEM_M17 = 40
 MODEM_DMR = 41
-OPT_OVERLAP, OPT_UNFUSED_DEC2 = 1, 2
+OPT_OVERLAP, OPT_UNFUSED_DEC2, OPT_FLL_SLIM = 1, 2, 3
 CHAN_OPT_LEGACY_PFB, CHAN_OPT_LEGACY_TAIL = 1, 2
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECTANGULAR, WIN_BLACKMAN_HARRIS = 0, 1, 2, 3, 5
 

@@ -171,6 +171,7 @@ struct qrl_demod {
     bool qpsk_fll = false, fsk4_disc = false;
     bool m17 = false;   // F_DMR family, gr_demod_m17 variant: channel filter behind the resampler (port 0), mod-M&M TED, no level control
     DevBuf<float2> s2g, disc4_taps; DevBuf<float> sym4_taps; int disc4_nt = 0, sym4_nt = 0;   // 4FSK non-FM branch
+    bool fll_slim = false;   // QRL_OPT_FLL_SLIM: single-wave FLL workgroups (3 KB of LDS) that fit beside four front-end workgroups
     bool d2f_capable = false, d2f = false; DevBuf<float> d2f_taps;   // 1:2 decimator + shaping filter in one kernel (k_dec2_fir)
     bool overlap = false, overlap_capable = false; hipEvent_t ev_tail2[2] = {nullptr, nullptr}; bool tail2_valid[2] = {false, false}; uint64_t call_no = 0;
     enum Family { F_2FSK, F_GMSK, F_QPSK, F_DMR, F_4FSK, F_BPSK, F_DSSS, F_ANALOG } fam = F_2FSK;
@@ -412,11 +413,11 @@ int qrl_demod::build()
     }
     // default: only the 2FSK family, whose FLL + discriminator kernels are a third of a call (measured, C1: 15.2 -> 12.9 ms per
     // step); for the light GMSK / 4FSK tails the extra stream hand-over costs more than it hides (C2: 2.86 -> 3.05 ms).
-    // The rings are sized for it, but it is OFF by default (qrl_demod_set_option(QRL_OPT_OVERLAP, 1) switches it on): measured on
-    // C1 it buys 10 % of whole-chain throughput (9.4 instead of 10.4 ms per step) while the front-end kernel, sharing the GPU,
-    // stretches from 7.1 to 9.0 ms -- the recursion kernels are only placed once the front end's workgroups drain.
+    // Measured on C1 (round 3, same box): 8.79 instead of 9.49 ms per step, while the front-end kernel, sharing the GPU, stretches
+    // from 6.33 to 8.04 ms -- the recursion kernels are only placed once front-end workgroups drain, and a 68 KB FLL workgroup then
+    // takes the place of two of them.
     overlap_capable = fam == F_2FSK;
-    overlap = false;
+    overlap = overlap_capable;   // round 3: ON by default for the 2FSK family (same-box A/B on C1: 8.79 against 9.49 ms per step); qrl_demod_set_option(QRL_OPT_OVERLAP, 0) gives the serial order
     s2_mask = pow2_at_least((overlap_capable || loops_family() ? 2 : 1) * max2 + (fam == F_DMR ? 2048 : fam == F_ANALOG ? 4096 : 1024)) - 1;   // DMR: the DMO slicer looks back 1440 samples   // history needs: <= 501 taps downstream; overlapped mode: two calls
     const size_t ring2 = (size_t)B * (s2_mask + 1);
     if ((r = s2.alloc(ring2)) || (r = s2f.alloc(ring2)) || (r = s2d.alloc(ring2)) || (r = s3.alloc(ring2))) return r;
@@ -722,7 +723,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         f.lower = fll_lo.p; f.upper = fll_up.p; f.nt = fam == F_2FSK ? 16 : 32; f.alpha = fll_alpha; f.beta = fll_beta; f.max_freq = fll_maxf;
         // (slim single-wave FLL workgroups under an 8-wave-workgroup front end were measured in round 3: the front end alone slows from
         //  6.57 to 7.24 ms with 8-wave workgroups and stretches to 8.4 - 9.1 ms when it shares the SIMDs; 9.47 ms per step against 9.29)
-        f.slim = 0;
+        f.slim = fll_slim ? 1 : 0;
         launch_fll(f, B, cs);
         filt_in = r2l;
     }
@@ -1159,6 +1160,10 @@ int qrl_demod_set_option(qrl_demod* d, int option, int value)
         if (int rs = d->sync_all()) return rs;
         d->overlap = value != 0;
         d->tail2_valid[0] = d->tail2_valid[1] = false;
+        return QRL_OK;
+    case QRL_OPT_FLL_SLIM:
+        if (int rs = d->sync_all()) return rs;
+        d->fll_slim = value != 0;
         return QRL_OK;
     case QRL_OPT_UNFUSED_DEC2:
         if (!d->d2f_capable) return qrl_set_error(QRL_ERR_ARG, "this chain has no fused 1:2 decimator + shaping filter");

@@ -15,7 +15,7 @@ for name, out in (("kernel_trace_summary.md", "r03_kernel_trace_summary.md"), ("
                   ("kernel_alone_summary.md", "r03_kernel_alone_summary.md")):
     shutil.copy(os.path.join(SRC, name), os.path.join(DST, out))
 bench = {}
-for cfg in ("default", "c2", "c3", "c4", "c5", "c1_overlap"):
+for cfg in ("default", "c2", "c3", "c4", "c5", "c1_serial"):
     try:
         with open(os.path.join(SRC, "bench_%s.json" % cfg)) as f:
             lines = [l for l in f.read().splitlines() if l.startswith("{")]
@@ -54,7 +54,7 @@ for cfg, rows in sections.items():
     want = want if want.startswith("qrl::") else "qrl::" + want
     best = {}
     for base, targs, cnt, val, n in rows:
-        if base != want:
+        if not base.startswith(want):
             continue
         if cnt not in best or val > best[cnt][0]:
             best[cnt] = (val, base + targs, n)

@@ -38,6 +38,6 @@ for cnt in FETCH_SIZE WRITE_SIZE; do
 done
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 for cfg in c2 c3 c4 c5; do python bench.py --config $cfg --no-extra > $O/bench_$cfg.json 2> $O/bench_$cfg.err; done
-python bench.py --config c1 --overlap --no-extra > $O/bench_c1_overlap.json 2>/dev/null
+python bench.py --config c1 --no-overlap --no-extra > $O/bench_c1_serial.json 2>/dev/null
 find $O -name '*.csv' -size +2M -delete; find $O/prof -type f -size +4M -delete; find $O -name '*.db' -size +4M -delete
 cat $O/pmc_summary.txt | cut -c1-220
