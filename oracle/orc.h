@@ -102,6 +102,7 @@ size_t orc_resamp_ccf(const cf32* in, size_t n, const float* taps, int nt, int i
 size_t orc_resamp_fff(const float* in, size_t n, const float* taps, int nt, int interp, int decim, float* out);
 void   orc_fir_ccf(const cf32* in, size_t n, const float* taps, int nt, cf32* out);
 void   orc_fir_ccc(const cf32* in, size_t n, const cf32* taps, int nt, cf32* out);
+void   orc_fir_ccc_conj_pair(const cf32* in, size_t n, const cf32* up, const cf32* lo, int nt, cf32* out_up, cf32* out_lo);   /* conjugate tap pair: shared real-tap chains */
 void   orc_fir_fff(const float* in, size_t n, const float* taps, int nt, float* out);
 void   orc_fll_band_edge(const cf32* in, size_t n, float sps, float rolloff, int ntaps, float bw, cf32* out);
 void   orc_quad_demod(const cf32* in, size_t n, float gain, float* out);

@@ -408,6 +408,33 @@ void orc_fir_ccc(const cf32* in, size_t n, const cf32* taps, int nt, cf32* out)
         out[i].re = ar; out[i].im = ai;
     }
 }
+/* The upper / lower band-edge discriminator filters of gr_demod_2fsk (complex_band_pass(-W, 0) and (0, W), gr_demod_2fsk.cpp:86-89)
+ * are a CONJUGATE pair, bit for bit (same low-pass prototype, cos(-x) = cos(x), sin(-x) = -sin(x)).  With h = a + j b:
+ *   A = sum a[k] x[i-k]   (real taps on the complex samples: two fmaf chains, k ascending)
+ *   B = sum b[k] x[i-k]
+ *   upper = (A.re - B.im, A.im + B.re),   lower = (A.re + B.im, A.im - B.re)
+ * -- half the multiplies of two independent complex-tap filters.  This is the summation contract of the product for such a pair
+ * (kernels_ff.hip k_2fsk_ff / k_disc_2fsk); a pair that is not conjugate falls back to two orc_fir_ccc. */
+void orc_fir_ccc_conj_pair(const cf32* in, size_t n, const cf32* up, const cf32* lo, int nt, cf32* out_up, cf32* out_lo)
+{
+    int conj = 1;
+    for (int k = 0; k < nt; k++) {
+        float nb = -up[k].im;
+        if (memcmp(&lo[k].re, &up[k].re, sizeof(float)) != 0 || memcmp(&lo[k].im, &nb, sizeof(float)) != 0) { conj = 0; break; }
+    }
+    if (!conj) { orc_fir_ccc(in, n, up, nt, out_up); orc_fir_ccc(in, n, lo, nt, out_lo); return; }
+    orc_trace_event("fir_ccc(%s)", orc_trace_name(up, sizeof(cf32) * (size_t)nt));
+    orc_trace_event("fir_ccc(%s)", orc_trace_name(lo, sizeof(cf32) * (size_t)nt));
+    for (size_t i = 0; i < n; i++) {
+        float ar = 0.0f, ai = 0.0f, br = 0.0f, bi = 0.0f;
+        for (int k = 0; k < nt && (size_t)k <= i; k++) {
+            ar = fmaf(up[k].re, in[i - k].re, ar); ai = fmaf(up[k].re, in[i - k].im, ai);
+            br = fmaf(up[k].im, in[i - k].re, br); bi = fmaf(up[k].im, in[i - k].im, bi);
+        }
+        out_up[i].re = ar - bi; out_up[i].im = ai + br;
+        out_lo[i].re = ar + bi; out_lo[i].im = ai - br;
+    }
+}
 void orc_fir_fff(const float* in, size_t n, const float* taps, int nt, float* out)
 {
     orc_trace_event("fir_fff(%s)", orc_trace_name(taps, sizeof(float) * (size_t)nt));

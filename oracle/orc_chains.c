@@ -105,8 +105,7 @@ void orc_demod_2fsk(const cf32* in, size_t n, int sps, int samp_rate, int carrie
         orc_complex_band_pass(1, target, -filter_width, 0, filter_width, ORC_WIN_BLACKMAN_HARRIS, up);
         orc_complex_band_pass(1, target, 0, filter_width, filter_width, ORC_WIN_BLACKMAN_HARRIS, lo);
         cf32* fu = NEW(cf32, n1); cf32* fl = NEW(cf32, n1);
-        orc_fir_ccc(o->filtered, n1, up, nb, fu);
-        orc_fir_ccc(o->filtered, n1, lo, nb, fl);
+        orc_fir_ccc_conj_pair(o->filtered, n1, up, lo, nb, fu, fl);
         float* s4 = NEW(float, n1);
         for (size_t i = 0; i < n1; i++) {
             float mu = sqrtf(fu[i].re * fu[i].re + fu[i].im * fu[i].im);

@@ -53,6 +53,9 @@ bool take_launch_error() { const bool r = t_launch_error; t_launch_error = false
 
 struct qrl_ctx { int device; };
 
+#ifndef QRL_DEV_SKIP
+#define QRL_DEV_SKIP 0   // developer builds only (tools/engine_variants.sh): bit 0 no FLL, 1 no fused 2FSK feed-forward kernel, 2 no symbol sync, 3 no decoder launch -- WRONG results, timing experiments on who stretches the front end
+#endif
 namespace {
 
 template <class T> struct DevBuf {
@@ -460,6 +463,12 @@ int qrl_demod::build()
             const auto up2 = complex_band_pass(1, target, -fw, 0, fw, WIN_BLACKMAN_HARRIS);
             const auto lo2 = complex_band_pass(1, target, 0, fw, fw, WIN_BLACKMAN_HARRIS);
             disc_nt = (int)up2.size();
+            // the discriminator kernels use the pair as what it is -- lower = conj(upper), bit for bit (same prototype, cos(-x) = cos(x),
+            // sin(-x) = -sin(x)) -- and run the shared real-tap chains once (oracle orc_fir_ccc_conj_pair)
+            for (size_t k = 0; k < up2.size(); ++k) {
+                const float ur = up2[k].real(), ui = -up2[k].imag(), lr = lo2[k].real(), li = lo2[k].imag();
+                if (std::memcmp(&ur, &lr, sizeof ur) || std::memcmp(&ui, &li, sizeof ui)) return fail(QRL_ERR_ARG, "2FSK discriminator filters are not a conjugate pair");
+            }
             if ((r = disc_up.upload(to_f2(up2))) || (r = disc_lo.upload(to_f2(lo2)))) return r;
             const std::vector<float> sf = low_pass(1.0, target, target / sps_eff, target / sps_eff, WIN_HAMMING);
             symf_nt = (int)sf.size();
@@ -724,7 +733,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         // (slim single-wave FLL workgroups under an 8-wave-workgroup front end were measured in round 3: the front end alone slows from
         //  6.57 to 7.24 ms with 8-wave workgroups and stretches to 8.4 - 9.1 ms when it shares the SIMDs; 9.47 ms per step against 9.29)
         f.slim = fll_slim ? 1 : 0;
-        launch_fll(f, B, cs);
+        if (!(QRL_DEV_SKIP & 1)) launch_fll(f, B, cs);
         filt_in = r2l;
     }
     const bool fused_2fsk = fam == F_2FSK && !fm && filt_nt <= 41 && disc_nt <= 41 && symf_nt <= 25;
@@ -754,7 +763,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         f.port = side && out->filtered ? reinterpret_cast<float2*>(out->filtered) : nullptr;
         f.port_cap = side ? out->filtered_cap : 0;
         f.counts = counts;
-        launch_2fsk_ff(f, B, cs);
+        if (!(QRL_DEV_SKIP & 2)) launch_2fsk_ff(f, B, cs);
         if (!overlap) { HIPCHK(hipEventRecord(ev_ff, stream)); HIPCHK(hipStreamWaitEvent(tail, ev_ff, 0)); }
     } else {
         if (!d2f) {
@@ -836,7 +845,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         s.port = side && out->constellation ? reinterpret_cast<float2*>(out->constellation) : nullptr;
         s.port_cap = side ? out->constellation_cap : 0;
         s.counts = counts;
-        launch_symsync_ff(s, B, tail);
+        if (!(QRL_DEV_SKIP & 4)) launch_symsync_ff(s, B, tail);
         if (fam == F_DMR && !m17 && dmo_out) {   // gr_dmr_dmo_sink on port 3 (= ring r3) of this call
             DmoParams dp{}; dp.in = r3; dp.q0 = n2_0; dp.count = (uint32_t)(n2_1 - n2_0); dp.st = dmo_st.p; dp.golay = dmo_golay.p;
             dp.out = dmo_out; dp.cap = dmo_cap; dp.counts = dmo_counts;
@@ -848,7 +857,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         f.bits_a = out ? out->bits_a : nullptr; f.bits_b = out ? out->bits_b : nullptr; f.bits_cap = out ? out->bits_cap : 0;
         f.counts = counts; f.branches = branches;
         if (fam != F_DMR) {
-            launch_fec(f, B, tail);
+            if (!(QRL_DEV_SKIP & 8)) launch_fec(f, B, tail);
             HIPCHK(hipEventRecord(ev_tail, tail));
             tail_pending = true;
         }

@@ -235,10 +235,14 @@ void k_decim_pm(const DecimParams P_)
     // The waves that share a SIMD (one per resident workgroup) all walk fetch -> LDS -> matrix pipe -> store; with equal priority they
     // fall into step (everybody fetches, then everybody queues for the matrix pipe) and the pipe idles a third of the time.  Distinct
     // issue priorities turn the sharing into a pipeline: the highest wave computes at full rate and goes to fetch while the others compute.
+#if QRL_PM_PRIO == 2
+    __builtin_amdgcn_s_setprio(3);   // every front-end wave above the waves of other kernels that share its SIMD
+#else
     switch (((blockIdx.x >> 8) + blockIdx.x) & 3u) {
     case 0: __builtin_amdgcn_s_setprio(0); break;  case 1: __builtin_amdgcn_s_setprio(1); break;
     case 2: __builtin_amdgcn_s_setprio(2); break;  default: __builtin_amdgcn_s_setprio(3); break;
     }
+#endif
 #endif
     for (int k = tid; k < 512; k += NW * 64) t_lo[k] = P.rot_lo[k];
 

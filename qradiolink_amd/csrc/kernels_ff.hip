@@ -175,15 +175,16 @@ __global__ __launch_bounds__(256) void k_disc_2fsk(const Disc2fskParams P)
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= P.count) return;
     const int64_t n = (int64_t)(P.q0 + t);
-    float ur = 0.f, ui = 0.f, lr = 0.f, li = 0.f;
+    // the two filters are a conjugate pair (the engine checks it bit for bit): h = a + j b, A = sum a x, B = sum b x (real taps, k
+    // ascending), upper = (A.re - B.im, A.im + B.re), lower = (A.re + B.im, A.im - B.re) -- oracle orc_fir_ccc_conj_pair
+    float ar = 0.f, ai = 0.f, br = 0.f, bi = 0.f;
     for (int k = 0; k < P.nt; ++k) {
         const float2 x = ringc_at(P.in, b, n - k);
-        const float2 hu = P.up[k], hl = P.lo[k];
-        ur = fmaf(hu.x, x.x, ur); ur = fmaf(-hu.y, x.y, ur);
-        ui = fmaf(hu.x, x.y, ui); ui = fmaf(hu.y, x.x, ui);
-        lr = fmaf(hl.x, x.x, lr); lr = fmaf(-hl.y, x.y, lr);
-        li = fmaf(hl.x, x.y, li); li = fmaf(hl.y, x.x, li);
+        const float2 h = P.up[k];
+        ar = fmaf(h.x, x.x, ar); ai = fmaf(h.x, x.y, ai);
+        br = fmaf(h.y, x.x, br); bi = fmaf(h.y, x.y, bi);
     }
+    const float ur = ar - bi, ui = ai + br, lr = ar + bi, li = ai - br;
     const float mu = sqrtf(ur * ur + ui * ui);
     const float ml = sqrtf(lr * lr + li * li);
     float r = mu / ml;
@@ -307,37 +308,37 @@ __global__ __launch_bounds__(256) void k_2fsk_ff(const Fsk2FfParams P)
     }
     __syncthreads();
     if (4 * tid < nd) {   // stage 2: u/l[j] = sum up/lo[k] f[j + hb - k]; d = rail(|u| / |l|) - 1
-        float ur[4] = {0.f, 0.f, 0.f, 0.f}, ui[4] = {0.f, 0.f, 0.f, 0.f}, lr[4] = {0.f, 0.f, 0.f, 0.f}, li[4] = {0.f, 0.f, 0.f, 0.f};
+        // conjugate tap pair (see k_disc_2fsk): A = sum a x, B = sum b x with the real and imaginary parts of the UPPER filter's taps
+        float ar[4] = {0.f, 0.f, 0.f, 0.f}, ai[4] = {0.f, 0.f, 0.f, 0.f}, br[4] = {0.f, 0.f, 0.f, 0.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
         const int nq = (hb >> 2) + 1;
         int w = tid + (hb >> 2) + 1;
         float2 cur[4], nxt[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) cur[s] = ft[s * FF_PF + w];
-        auto step = [&](const float2 hu, const float2 hl, const float2& x0, const float2& x1, const float2& x2, const float2& x3) {
+        auto step = [&](const float2 h, const float2& x0, const float2& x1, const float2& x2, const float2& x3) {
             const float2 xs[4] = {x0, x1, x2, x3};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                ur[r] = fmaf(hu.x, xs[r].x, ur[r]); ur[r] = fmaf(-hu.y, xs[r].y, ur[r]);
-                ui[r] = fmaf(hu.x, xs[r].y, ui[r]); ui[r] = fmaf(hu.y, xs[r].x, ui[r]);
-                lr[r] = fmaf(hl.x, xs[r].x, lr[r]); lr[r] = fmaf(-hl.y, xs[r].y, lr[r]);
-                li[r] = fmaf(hl.x, xs[r].y, li[r]); li[r] = fmaf(hl.y, xs[r].x, li[r]);
+                ar[r] = fmaf(h.x, xs[r].x, ar[r]); ai[r] = fmaf(h.x, xs[r].y, ai[r]);
+                br[r] = fmaf(h.y, xs[r].x, br[r]); bi[r] = fmaf(h.y, xs[r].y, bi[r]);
             }
         };
         for (int q = 0; q < nq; ++q) {
             --w;
 #pragma unroll
             for (int s = 0; s < 4; ++s) nxt[s] = ft[s * FF_PF + w];
-            step(P.up[4 * q], P.lo[4 * q], cur[0], cur[1], cur[2], cur[3]);
-            step(P.up[4 * q + 1], P.lo[4 * q + 1], nxt[3], cur[0], cur[1], cur[2]);
-            step(P.up[4 * q + 2], P.lo[4 * q + 2], nxt[2], nxt[3], cur[0], cur[1]);
-            step(P.up[4 * q + 3], P.lo[4 * q + 3], nxt[1], nxt[2], nxt[3], cur[0]);
+            step(P.up[4 * q], cur[0], cur[1], cur[2], cur[3]);
+            step(P.up[4 * q + 1], nxt[3], cur[0], cur[1], cur[2]);
+            step(P.up[4 * q + 2], nxt[2], nxt[3], cur[0], cur[1]);
+            step(P.up[4 * q + 3], nxt[1], nxt[2], nxt[3], cur[0]);
 #pragma unroll
             for (int s = 0; s < 4; ++s) cur[s] = nxt[s];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float mu = sqrtf(ur[r] * ur[r] + ui[r] * ui[r]);
-            const float ml = sqrtf(lr[r] * lr[r] + li[r] * li[r]);
+            const float ur = ar[r] - bi[r], ui = ai[r] + br[r], lr = ar[r] + bi[r], li = ai[r] - br[r];
+            const float mu = sqrtf(ur * ur + ui * ui);
+            const float ml = sqrtf(lr * lr + li * li);
             float v = mu / ml;
             if (!(v >= 0.0f)) v = 0.0f;   // rail_ff lower bound; NaN (0/0) -> 0
             if (v > 2.0f) v = 2.0f;

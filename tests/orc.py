@@ -76,6 +76,8 @@ _sig("orc_m16_steps", C.c_int, C.c_int, C.c_int)
 _sig("orc_resamp_ccf", _sz, _p, _sz, _p, C.c_int, C.c_int, C.c_int, _p)
 _sig("orc_fir_ccf", None, _p, _sz, _p, C.c_int, _p)
 _sig("orc_fir_fff", None, _p, _sz, _p, C.c_int, _p)
+_sig("orc_fir_ccc", None, _p, _sz, _p, C.c_int, _p)
+_sig("orc_fir_ccc_conj_pair", None, _p, _sz, _p, _p, C.c_int, _p, _p)
 _sig("orc_quad_demod", None, _p, _sz, C.c_float, _p)
 _sig("orc_symbol_sync_ff", _sz, _p, _sz, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _p)
 _sig("orc_soft_quant", None, _p, _sz, C.c_float, C.c_float, _p)
@@ -659,6 +661,21 @@ def demod_mmdvm_multi(x, M):
     out = np.zeros((M, cap), np.int16)
     n = lib.orc_demod_mmdvm_multi(_ptr(x), x.size, M, _ptr(out), cap)
     return out[:, :n].copy()
+
+
+def fir_ccc(x, taps):
+    x = np.ascontiguousarray(x, cf32); taps = np.ascontiguousarray(taps, cf32)
+    out = np.zeros(x.size, cf32)
+    lib.orc_fir_ccc(_ptr(x), x.size, _ptr(taps), taps.size, _ptr(out))
+    return out
+
+
+def fir_ccc_conj_pair(x, up, lo):
+    """-> (upper, lower) outputs of the 2FSK discriminator's filter pair (shared real-tap chains when lo == conj(up) bit for bit)"""
+    x = np.ascontiguousarray(x, cf32); up = np.ascontiguousarray(up, cf32); lo = np.ascontiguousarray(lo, cf32)
+    ou, ol = np.zeros(x.size, cf32), np.zeros(x.size, cf32)
+    lib.orc_fir_ccc_conj_pair(_ptr(x), x.size, _ptr(up), _ptr(lo), up.size, _ptr(ou), _ptr(ol))
+    return ou, ol
 
 
 def batch_rx(mode, iq, samp_rate, carrier_offset_hz=0.0, threads=0):

@@ -724,3 +724,25 @@ def test_literal_c4_freq_xlating_bank_equals_the_pfb_form():
         g = adib[c].reshape(-1, 2)
         g = g[:, 0] * 2 + g[:, 1]
         assert max(np.mean(g[k:k + 400] == d[:400]) for k in range(60)) > 0.99
+
+
+def test_conjugate_pair_contract_of_the_2fsk_discriminator_filters():
+    """gr_demod_2fsk's upper / lower band-pass filters (gr_demod_2fsk.cpp:86-89) are a conjugate pair bit for bit; the product runs the
+    shared real-tap chains once (orc_fir_ccc_conj_pair, kernels_ff.hip).  Definition test: both outputs within 1e-5 of RMS of the float64
+    filters, and within float rounding of two independent orc_fir_ccc; a pair that is NOT conjugate takes the generic path exactly."""
+    rng = np.random.default_rng(5)
+    x = ((rng.standard_normal(4000) + 1j * rng.standard_normal(4000)) * 0.3).astype(np.complex64)
+    for fs, w in ((20000, 2000), (20000, 2500), (200000, 20000)):
+        up = orc.complex_band_pass(1, fs, -w, 0, w, orc.WIN_BH)
+        lo = orc.complex_band_pass(1, fs, 0, w, w, orc.WIN_BH)
+        assert np.array_equal(lo.view(np.uint32), np.conj(up).view(np.uint32))          # the premise
+        ou, ol = orc.fir_ccc_conj_pair(x, up, lo)
+        for got, taps in ((ou, up), (ol, lo)):
+            want = np.convolve(x.astype(np.complex128), taps.astype(np.complex128))[: x.size]
+            rms = np.sqrt(np.mean(np.abs(want) ** 2))
+            assert np.max(np.abs(got - want)) < 1e-5 * rms
+            assert np.max(np.abs(got - orc.fir_ccc(x, taps))) < 4e-6 * rms
+    lo2 = lo.copy(); lo2[3] += np.float32(1e-3)
+    ou, ol = orc.fir_ccc_conj_pair(x, up, lo2)
+    assert np.array_equal(ou.view(np.uint32), orc.fir_ccc(x, up).view(np.uint32))
+    assert np.array_equal(ol.view(np.uint32), orc.fir_ccc(x, lo2).view(np.uint32))
