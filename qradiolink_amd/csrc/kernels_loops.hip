@@ -27,6 +27,9 @@ namespace qrl {
 //              place on a CU whose LDS and wave slots are otherwise full of front-end workgroups (k_decim_pm leaves 16 KB of LDS and
 //              224 VGPRs per SIMD): the recursion of call k then runs UNDER the front end of call k + 1 instead of behind it.
 
+#ifndef QRL_FLL_CH
+#define QRL_FLL_CH 128   // samples per stream and LDS window of the stand-alone geometry (64 streams x QRL_FLL_CH x 8 bytes of LDS)
+#endif
 template <int CTRL> __device__ __forceinline__ float dpp_quad(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
@@ -159,8 +162,8 @@ void launch_fll(const FllParams& p, int batch, hipStream_t s)
         return;
     }
     dim3 grid((batch + 63) / 64), block(256);
-    if (p.nt == 16) hipLaunchKernelGGL((k_fll<16, 256, 128>), grid, block, 0, s, p, batch);
-    else            hipLaunchKernelGGL((k_fll<32, 256, 128>), grid, block, 0, s, p, batch);
+    if (p.nt == 16) hipLaunchKernelGGL((k_fll<16, 256, QRL_FLL_CH>), grid, block, 0, s, p, batch);
+    else            hipLaunchKernelGGL((k_fll<32, 256, QRL_FLL_CH>), grid, block, 0, s, p, batch);
 }
 
 // ------------------------------------------------------------------ symbol_sync_ff
