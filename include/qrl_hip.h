@@ -102,7 +102,8 @@ int qrl_demod_set_carrier_offset(qrl_demod* d, double carrier_offset_hz);
  * gr_demod_dmr (RRC-filtered discriminator output, gr_demod_dmr.cpp:94).  Every following qrl_demod_process call also runs the
  * MS-sync correlator / 4-level slicer / slot-type state machine over the call's new samples and appends the DMR bursts it cuts to
  * frames[b * cap_frames * 40 + i * 40]: 40-byte records {frame type (DMRFrameType 0 data, 1 voice, 2 voice sync), FN, colour code,
- * 0, 33 frame bytes, 3 pad}; counts[b] = records written by the call (device pointers; replaces gr_dmr_dmo_sink::get_data).
+ * 0, 33 frame bytes, 3 pad}; counts[b] = bursts found by the call (device pointers; replaces gr_dmr_dmo_sink::get_data); only the first
+ * cap_frames records are written, so counts[b] > cap_frames means bursts were dropped (one burst lasts 30 ms: size cap_frames for the chunk).
  * frames == NULL switches it off.  The stream position must be the start of the stream (call it before the first process / after
  * a reset) or the slicer starts with an empty 1440-sample history. */
 #define QRL_DMO_RECORD_BYTES 40

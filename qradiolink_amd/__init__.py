@@ -401,7 +401,7 @@ class Demod:
     def dmo_records(self):
         """host copy of the last call's records: per stream a list of (type, fn, colour code, 33 bytes)"""
         f, c = self.dmo_frames.cpu().numpy(), self.dmo_counts.cpu().numpy()
-        return [[(int(f[b, i, 0]), int(f[b, i, 1]), int(f[b, i, 2]), f[b, i, 4:37].tobytes()) for i in range(c[b])] for b in range(self.batch)]
+        return [[(int(f[b, i, 0]), int(f[b, i, 1]), int(f[b, i, 2]), f[b, i, 4:37].tobytes()) for i in range(min(int(c[b]), f.shape[1]))] for b in range(self.batch)]
 
     def set_option(self, option, value):
         _check(self.lib.qrl_demod_set_option(self.h, int(option), int(value)), "qrl_demod_set_option")

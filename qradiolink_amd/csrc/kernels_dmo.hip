@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64) void k_dmo_sink(const DmoParams P, int batch)
         }
     }
     P.st[b] = s;
-    P.counts[b] = nout < P.cap ? nout : P.cap;
+    P.counts[b] = nout;   // bursts FOUND by the call; records beyond cap_frames are not written: counts[b] > cap tells the caller that bursts were dropped
 }
 
 void launch_dmo_sink(const DmoParams& p, int batch, hipStream_t s)

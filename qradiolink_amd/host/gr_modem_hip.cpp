@@ -236,11 +236,13 @@ void gr_demod_base_hip::harvest(int which)
         if (d_box1[s].size() <= 1048576) d_box1[s].insert(d_box1[s].end(), sl.h_a + (size_t)s * d_bcap, sl.h_a + (size_t)s * d_bcap + c[2]);
         if (d_box2[s].size() <= 1048576) d_box2[s].insert(d_box2[s].end(), sl.h_b + (size_t)s * d_bcap, sl.h_b + (size_t)s * d_bcap + c[3]);
         if (d_boxc[s].size() <= 256) d_boxc[s].insert(d_boxc[s].end(), sl.h_const + (size_t)s * d_ccap, sl.h_const + (size_t)s * d_ccap + c[1]);
-        if (d_mode == QRL_MODEM_DMR)
+        if (d_mode == QRL_MODEM_DMR) {
+            if (sl.h_dmocnt[s] > kDmoCap) d_dmo_dropped += sl.h_dmocnt[s] - kDmoCap;   // more bursts in one call than the record buffer holds
             for (uint32_t i = 0; i < sl.h_dmocnt[s] && i < kDmoCap; ++i) {
                 const uint8_t* r = sl.h_dmo + ((size_t)s * kDmoCap + i) * QRL_DMO_RECORD_BYTES;
                 d_boxd[s].emplace_back(r, r + QRL_DMO_RECORD_BYTES);
             }
+        }
     }
 }
 void gr_demod_base_hip::flush()

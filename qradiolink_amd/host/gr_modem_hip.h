@@ -55,6 +55,7 @@ public:
     virtual std::vector<unsigned char>* getData(int nr, int stream);   // nr = 1: bits A (port 2), nr = 2: bits B (port 3); nullptr = nothing yet (virtual: tests tap the bits)
     std::vector<gr_complex>* get_constellation_data(int stream = 0);
     std::vector<std::vector<unsigned char>> getDMRData(int stream = 0);   // DMR mode: 40-byte DMO records (QRL_DMO_RECORD_BYTES)
+    uint64_t dmr_bursts_dropped() const { return d_dmo_dropped; }        // bursts beyond the 16-per-call record buffer (a call longer than 0.48 s of signal)
     // analogue voice modes (NBFM2500 / NBFM5000 / AM5000 / WBFM): port 1 = audio at 8 ksps (gr_demod_base::getAudio :968-976; caller deletes)
     std::vector<float>* getAudio(int stream = 0);
     void set_squelch(int value);                               // gr_demod_base::set_squelch, dB
@@ -95,6 +96,7 @@ private:
     std::vector<std::vector<unsigned char>> d_box1, d_box2;
     std::vector<std::vector<gr_complex>> d_boxc;
     std::vector<std::vector<std::vector<unsigned char>>> d_boxd;
+    uint64_t d_dmo_dropped = 0;   // DMR bursts found beyond the per-call record buffer (16 per stream and call): not delivered
 };
 
 class gr_mod_base_hip {
