@@ -12,7 +12,7 @@ import shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC, DST = os.path.join(ROOT, "gpurun_out", "r03"), os.path.join(ROOT, "profiles")
 for name, out in (("kernel_trace_summary.md", "r03_kernel_trace_summary.md"), ("pmc_summary.txt", "r03_pmc_summary.txt"),
-                  ("kernel_alone_summary.md", "r03_kernel_alone_summary.md")):
+                  ("kernel_alone_summary.md", "r03_kernel_alone_summary.md"), ("sweep.jsonl", "r03_batch_sweep.jsonl")):
     shutil.copy(os.path.join(SRC, name), os.path.join(DST, out))
 bench = {}
 for cfg in ("default", "c2", "c3", "c4", "c5", "c1_serial"):
