@@ -28,9 +28,9 @@ def _random_cuts(rng, total, rate):
 
 
 @pytest.mark.parametrize("mode_name,modem,rate,seed", [
-    ("2fsk1k", 18, 1000000, 1), ("2fsk1k", 18, 1000000, 2),     # k_decim_pl + edge scratch, FLL, fused discriminator
-    ("gmsk10k", 22, 25000000, 3),                                # k_decim_mfma
-    ("qpsk250k", 26, 100000000, 4),                              # k_decim_plx + the three-stream pipeline
+    ("2fsk1k", 18, 1000000, 1), ("2fsk1k", 18, 1000000, 2),     # k_decim_pm (one lag tile) + edge scratch, FLL, fused discriminator
+    ("gmsk10k", 22, 25000000, 3),                                # k_decim_pm, three lag tiles (25:1)
+    ("qpsk250k", 26, 100000000, 4),                              # k_decim_pm at 100:1 + k_dec2_fir + the three-stream pipeline
     ("qpsk250k", 26, 1000000, 5),
     ("2fsk1k", 18, 25000000, 6),                                 # front end, then the 1:50 stage out of a ring (k_decim_pl_gen)
     ("bpsk2k", 0, 2000000, 7), ("4fsk2k", 3, 1000000, 8), ("4fsk100k", 27, 1000000, 9),

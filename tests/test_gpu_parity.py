@@ -67,7 +67,7 @@ def _compare(iq, out, mode_name, device_rate, offset):
     ("2fsk1k", 18, 1000000, 1 << 21),
     ("2fsk1kfm", 16, 1000000, 1 << 21),
     ("gmsk1k", 21, 2000000, 1 << 22),
-    ("gmsk10k", 22, 25000000, 1 << 23),     # front end 25:1, 1045 taps: f32-MFMA decimator, 16-block tiles
+    ("gmsk10k", 22, 25000000, 1 << 23),     # front end 25:1, 1045 taps: k_decim_pm with three lag tiles (rounds 1-2: banded-Toeplitz MFMA decimator)
     ("gmsk10k", 22, 10000000, 1 << 23),     # front end 10:1, 419 taps
     ("qpsk250k", 26, 1000000, 1 << 20),     # C3 chain at the internal rate: agc2, 2x Costas, symbol_sync_cc, diff_phasor
     ("qpsk250k", 26, 10000000, 1 << 23),    # C3 behind the 10:1 front end
@@ -123,9 +123,9 @@ def test_chunk_invariance_qpsk(qrl_ctx, chunk):
 
 
 @pytest.mark.parametrize("mode_name,modem,rate", [
-    ("2fsk1k", 18, 1000000),       # k_decim_pl: the edge outputs read the history rotated with the OLD offset, the buffer head with the new one
-    ("gmsk10k", 22, 25000000),     # k_decim_mfma
-    ("qpsk250k", 26, 100000000),   # k_decim_plx
+    ("2fsk1k", 18, 1000000),       # k_decim_pm: the edge outputs read the history rotated with the OLD offset, the buffer head with the new one
+    ("gmsk10k", 22, 25000000),     # k_decim_pm, 25:1
+    ("qpsk250k", 26, 100000000),   # k_decim_pm, 100:1
     ("gmsk10k", 22, 4000000),      # k_decim
 ])
 def test_carrier_offset_retune_is_phase_continuous(qrl_ctx, mode_name, modem, rate):
@@ -498,7 +498,7 @@ def test_every_call_of_a_pipelined_sequence_is_deterministic(qrl_ctx, mode_name,
 
 
 @pytest.mark.parametrize("mode_name,modem,rate,B,nframes", [
-    ("2fsk1k", 18, 1000000, 1536, 1),       # C1 at a bench-like batch: several segments per stream, grid.x >> 8 (k_decim_pl units, FLL quads)
+    ("2fsk1k", 18, 1000000, 1536, 1),       # C1 at a bench-like batch: several segments per stream, grid.x >> 8 (k_decim_pm units, FLL quads)
     ("gmsk10k", 22, 25000000, 1024, 1),     # C2 at a bench-like batch: MFMA front end with tpw > 1 and the XCD remap of grid.x
 ])
 def test_large_batch_bit_exact(qrl_ctx, mode_name, modem, rate, B, nframes):
