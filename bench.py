@@ -495,8 +495,9 @@ def main():
     extra3 = run_workload("c3", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 30)) if (extra_ok and args.config == "c1") else None
     extra4 = run_c4(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20)) if (extra_ok and args.config == "c1" and world == 1) else None
     extra5 = run_c5(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20)) if (extra_ok and args.config == "c1" and world == 1) else None
-    base = cpu_baseline(args.config, min(os.cpu_count() or 1, 16)) if (extra_ok and rank == 0) else None
-    base2 = cpu_baseline("c2", min(os.cpu_count() or 1, 16), budget_s=4.0) if (extra_ok and rank == 0 and args.config == "c1") else None
+    # (the CPU baseline is a property of the box, not of the job: rank 0 at N = 1 only, as the contract says)
+    base = cpu_baseline(args.config, min(os.cpu_count() or 1, 16)) if (extra_ok and rank == 0 and world == 1) else None
+    base2 = cpu_baseline("c2", min(os.cpu_count() or 1, 16), budget_s=4.0) if (extra_ok and rank == 0 and world == 1 and args.config == "c1") else None
 
     line = None
     if rank == 0:
