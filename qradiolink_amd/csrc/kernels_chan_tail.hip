@@ -70,12 +70,18 @@ __global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
     // ---- stage the input: x[xbase + i], xbase = 25 ua - 34 (zero in front of the stream)
     const int64_t xbase = 25 * ua - (CT_JP - 1);
     const int nx = 25 * NU + (CT_JP - 1);
-    {
+    {   // all loads of the thread are issued before the first one is used (ring reads are in bounds for any index)
         const float2* ring = P.in.p + (size_t)row * (P.in.mask + 1u);
-        for (int i = tid; i < nx; i += 256) {
-            const int64_t a = xbase + i;
-            xf[i] = a < 0 ? make_float2(0.f, 0.f) : ring[(uint32_t)a & P.in.mask];
+        constexpr int NLD = (CT_NX + 255) / 256;
+        float2 v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int64_t a = xbase + tid + 256 * k;
+            v[k] = ring[(uint32_t)a & P.in.mask];
+            if (a < 0) v[k] = make_float2(0.f, 0.f);
         }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) { const int i = tid + 256 * k; if (i < nx) xf[i] = v[k]; }
     }
     __syncthreads();
     // ---- A: a[24 u + 8 w + r] = sum_j taps[(8 w + r) 35 + j] x[25 u + 8 w + r - j],  lane = u - ua, waves 0..2
@@ -119,12 +125,17 @@ __global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
     __syncthreads();
     // ---- D: discriminators on f, items i' = 1 .. NB - 1 (q = qb + i'); int16 port for the outputs of this call
     const uint64_t q_end = P.q0 + P.count;
+    float* pv = reinterpret_cast<float*>(av);
     for (int i = 1 + tid; i < NB; i += 256) {
         const float2 a = xf[ct_pos(i)], p = xf[ct_pos(i - 1)];
         const float re = a.x * p.x + a.y * p.y;
         const float im = a.y * p.x - a.x * p.y;
         const float ang = fast_atan2f_lut(im, re, T);
         dv[ct_pos(i)] = P.gain2 * ang;
+        {   // |f|^4 of the item for the serial RSSI sums below (the resampler output `av` is dead since stage B: its memory holds them)
+            const float pwr = a.x * a.x + a.y * a.y;
+            pv[ct_pos(i)] = pwr * pwr;
+        }
         const int64_t q = qb + i;
         if (P.s16 && q >= (int64_t)P.q0 && (uint64_t)q < q_end && i >= e0) {
             float r = rintf(((P.gain * ang) * P.level) * P.scale);
@@ -145,12 +156,9 @@ __global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
             const int64_t j = tile * (CT_T / 300) + lane;                          // absolute tag index
             if (j >= (int64_t)P.tag0 && j < (int64_t)(P.tag0 + P.ntags)) {
                 const int i0 = e0 + 300 * lane;
-                float sum = 0.0f;
-                for (int k = 0; k < 300; ++k) {
-                    const float2 x = xf[ct_pos(i0 + k)];
-                    const float pwr = x.x * x.x + x.y * x.y;
-                    sum += pwr * pwr;
-                }
+                float sum = 0.0f;                                                  // the block's serial sum, item order (rssi_tag_block.cpp:52-58)
+#pragma unroll 10
+                for (int k = 0; k < 300; ++k) sum += pv[ct_pos(i0 + k)];
                 const float level = sqrtf(sum / 300.0f);
                 const float db = 10.0f * log10f(level + 1.0e-20f) + P.rssi_cal;
                 const uint64_t t = (uint64_t)j - P.tag0;

@@ -125,11 +125,14 @@ def test_channel_all_to_all_form_two_emulated_ranks_equal_the_unsharded_receiver
         rr, rrc = ref.rssi.cpu().numpy(), ref.rssi_counts.cpu().numpy()
         rd, rdc = ref.dibits.cpu().numpy(), ref.fsk_counts.cpu().numpy()
         send = [torch.zeros((world, Bl, cpr, n1), dtype=torch.complex64, device="cuda") for _ in range(world)]
+        ts = torch.cuda.current_stream().cuda_stream                          # the stream torch (and, in the real job, the collective) works on
         for r in range(world):
+            chans[r].wait_for(ts)                                             # the send buffer was zero-filled on torch's stream
             chans[r].channelize_async(part[r * Bl:(r + 1) * Bl].contiguous(), send[r], world)
             chans[r].sync()
         for r in range(world):
-            recv = torch.stack([send[s][r] for s in range(world)])            # what all_to_all_single delivers to rank r
+            recv = torch.stack([send[s][r] for s in range(world)])            # what all_to_all_single delivers to rank r ...
+            tails[r].wait_for(ts)                                             # ... on torch's stream: the handle's own stream has to wait for it
             tails[r].process_channels_async(recv.reshape(B * cpr, n1).contiguous(), n1)
             tails[r].sync()
             o, cn = tails[r].out.cpu().numpy(), tails[r].counts.cpu().numpy()
