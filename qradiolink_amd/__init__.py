@@ -468,7 +468,9 @@ class Channelizer:
         _check(self.lib.qrl_chan_sync(self.h), "qrl_chan_sync")
 
     def channelize_async(self, iq, chan_out, groups):
-        """PFB only (qrl_chan_channelize): chan_out complex64 cuda [groups, batch, channel_count // groups, pitch]"""
+        """PFB only (qrl_chan_channelize): chan_out complex64 cuda [groups, batch, channel_count // groups, pitch].
+        Unlike process_async this does NOT wait for torch's stream on the host: order the handle's stream behind whatever produced
+        iq / last read chan_out with wait_for(stream), and the consumer behind this call with stream_wait(stream)."""
         assert iq.is_cuda and iq.dtype == self.torch.complex64 and iq.dim() == 2 and iq.shape[0] == self.batch and iq.stride(1) == 1
         assert chan_out.is_cuda and chan_out.dtype == self.torch.complex64 and chan_out.is_contiguous()
         assert tuple(chan_out.shape[:3]) == (groups, self.batch, self.cc // groups)
@@ -476,7 +478,9 @@ class Channelizer:
                "qrl_chan_channelize")
 
     def process_channels_async(self, chan_in, n1):
-        """form 3 handle: the per-channel chain on chan_in complex64 cuda [batch, pitch] (n1 valid items per row)"""
+        """form 3 handle: the per-channel chain on chan_in complex64 cuda [batch, pitch] (n1 valid items per row).
+        No host synchronisation with torch's stream (see channelize_async): call wait_for(stream) first when chan_in was produced there
+        (a collective, a copy)."""
         assert chan_in.is_cuda and chan_in.dtype == self.torch.complex64 and chan_in.dim() == 2 and chan_in.shape[0] == self.batch and chan_in.stride(1) == 1
         _check(self.lib.qrl_chan_process_channels(self.h, chan_in.data_ptr(), chan_in.stride(0), n1, self.out.data_ptr(), self.cap,
                                                   self.counts.data_ptr()), "qrl_chan_process_channels")
