@@ -361,6 +361,16 @@ int main(int argc, char** argv)
         run_w4<8, 6400, 13, 78, 6, 8, 4>(in, bytes, 6, out);      // 50:1 front end (2091 taps): 78 MFMA per 6400 B
         return 0;
     }
+    if (quick == 4) {   // LDS bank conflicts of the raw read-out: block strides of 200 / 800 bytes (D = 25 / 100) against padded strides
+                        // of 208 / 816 bytes (4 x odd dwords: the 32 lanes of a half-wave hit 32 different bank pairs); compare GROUPS per second
+        run_w4<8, 3200, 7, 42, 6, 8, 4>(in, bytes, 6, out);
+        run_w4<8, 3328, 7, 42, 6, 8, 4>(in, bytes, 6, out);
+        run_w4<16, 12800, 25, 150, 6, 8, 4>(in, bytes, 6, out);
+        run_w4<16, 13056, 25, 150, 6, 8, 4>(in, bytes, 6, out);
+        run_w4<8, 3200, 7, 42, 6, 8, 4>(in, bytes, 6, out);
+        run_w4<8, 3328, 7, 42, 6, 8, 4>(in, bytes, 6, out);
+        return 0;
+    }
     if (quick == 2) {   // the data flow of k_decim_pm and ways to keep more bytes in flight
         run_w3<8, 1, 1, 0, 4>(in, bytes, 6, out);      // as k_decim_pm: 4 WGs/CU x 4 waves, 38 KiB/WG
         run_w3<8, 1, 10, 0, 4>(in, bytes, 6, out);
