@@ -1,0 +1,70 @@
+"""Measurement plumbing of bench.py that can be checked without a GPU: the PMC traffic figure is tied to the kernel sources it was taken
+on, the CPU baseline carries SURVEY 8(d)'s thread-per-block variant, and the committed traffic file belongs to the committed sources."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench   # noqa: E402
+
+
+def test_committed_pmc_traffic_belongs_to_the_committed_kernel_sources():
+    """profiles/pmc_traffic.json is only meaningful for the kernels it was measured on: its source id must be the id of
+    qradiolink_amd/csrc + include as they are committed (re-run tools/r03_profile.sh + tools/r03_collect.py after a kernel change)."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    if d["_source_id"] != bench.source_id():      # kernels changed since the pass: bench.py must then report no traffic, with the reason
+        t, why = bench.pmc_traffic("c1", "k_decim_pm")
+        assert t is None and d["_source_id"] in why
+        pytest.skip("profiles/pmc_traffic.json is stale for these kernel sources: re-run tools/r03_profile.sh + tools/r03_collect.py")
+    cal = d["_calibration"]["applied"]
+    assert cal["FETCH_SIZE"] == 0.5 and cal["WRITE_SIZE"] == 1.0      # measured in the same pass: tools/pmc_calibrate.py
+    for cfg in ("c1", "c2", "c3", "c4", "c5"):
+        assert d[cfg]["fetch_bytes"] > 0 and d[cfg]["write_bytes"] > 0 and d[cfg]["kernel"].startswith("qrl::k_")
+
+
+def test_traffic_is_reported_only_for_matching_sources(monkeypatch):
+    d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    monkeypatch.setattr(bench, "source_id", lambda: d["_source_id"])          # as if run on the sources of the pass
+    t, src = bench.pmc_traffic("c1", "k_decim_pm")
+    assert t and t > 35e9 and src == "profiles/r03_pmc_summary.txt"            # 35.1 GB of algorithmic bytes per launch
+    assert bench.pmc_traffic("c1", "k_decim_pm", default_shape=False) == (None, None)
+    assert bench.pmc_traffic("c1", "k_some_other_kernel") == (None, None)
+    monkeypatch.setattr(bench, "source_id", lambda: "000000000000")
+    t, why = bench.pmc_traffic("c1", "k_decim_pm")
+    assert t is None and "000000000000" in why
+
+
+def test_traffic_close_to_the_algorithmic_bytes_for_the_streaming_front_ends():
+    d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    alg = {"c1": 16384 * 262144 * 8.178, "c2": 384 * 1638400 * 8.033, "c3": 384 * 1638400 * 8.0625}
+    for cfg, a in alg.items():
+        ratio = (d[cfg]["fetch_bytes"] + d[cfg]["write_bytes"]) / a
+        assert 0.98 < ratio < 1.10, (cfg, ratio)
+
+
+def test_cpu_baseline_has_the_thread_per_block_variant():
+    r = bench.cpu_baseline("c1", 2, budget_s=0.4)
+    assert r["kind"] == "port" and r["cores"] == 2 and r["value"] > 0 and r["single_thread"] > 0
+    tpb = r["thread_per_block_model"]
+    assert tpb["blocks"] >= 10 and tpb["value"] > r["single_thread"] and 0 < tpb["slowest_block_share"] <= 1
+
+
+def test_source_id_changes_with_the_kernel_sources(tmp_path, monkeypatch):
+    a = bench.source_id()
+    assert len(a) == 12 and a == bench.source_id()
+    # a copy of the tree with one byte appended to a kernel file gives another id
+    import shutil
+    for d in ("qradiolink_amd/csrc", "include"):
+        dst = tmp_path / d
+        dst.mkdir(parents=True)
+        for fn in os.listdir(os.path.join(ROOT, d)):
+            if fn.endswith((".hip", ".cpp", ".hpp", ".h")):
+                shutil.copy(os.path.join(ROOT, d, fn), dst / fn)
+    with open(tmp_path / "qradiolink_amd/csrc/kernels_ff.hip", "a") as f:
+        f.write("\n")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.source_id() != a
