@@ -107,6 +107,29 @@ def parity_check(dem, iq, mode, rate, offset, torch, nstreams=4, seed=5):
                 bits_per_stream=int(cnt[picks[0], 2]))
 
 
+class StepMarks:
+    """Per-step completion times without touching the timed streams: after every queued step a side stream is made to wait (on the
+    device) for everything the handle has queued so far and an event is recorded there; the differences of consecutive events are
+    the intervals at which the steps completed.  Costs two event operations per step on the host, nothing on the handle's streams."""
+
+    def __init__(self, torch, wait):
+        self.torch, self.wait, self.side, self.ev = torch, wait, torch.cuda.Stream(), []
+
+    def mark(self):
+        self.wait(self.side.cuda_stream)
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record(self.side)
+        self.ev.append(e)
+
+    def spread(self):
+        """min / median / max of the step intervals in ms (the first interval starts at the mark before the first timed step)"""
+        d = sorted(a.elapsed_time(b) for a, b in zip(self.ev[:-1], self.ev[1:]))
+        if not d:
+            return None
+        return dict(min=round(d[0], 3), median=round(d[len(d) // 2], 3), max=round(d[-1], 3), steps=len(d),
+                    note="intervals between step completions (events on a side stream behind qrl_*_stream_wait)")
+
+
 def run_workload(name, args, torch, q, ctx, dev, rank, world, overlap=None, check=False, steps=None):
     label, mode, modem, rate, offset, dbatch, dns, _, abytes = WORKLOADS[name]
     steps = steps or args.steps
@@ -127,9 +150,12 @@ def run_workload(name, args, torch, q, ctx, dev, rank, world, overlap=None, chec
     if world > 1:
         torch.distributed.barrier()
     dem.profile(True)
+    marks = StepMarks(torch, dem.stream_wait)
+    marks.mark()
     t0 = time.perf_counter()
     for _ in range(steps):
         dem.process_async(iq)
+        marks.mark()
     dem.sync()
     torch.cuda.synchronize()
     if world > 1:
@@ -153,10 +179,10 @@ def run_workload(name, args, torch, q, ctx, dev, rank, world, overlap=None, chec
                 label=label, batch=batch, nsamp=nsamp, rate=rate, seconds=dt, msps=total_samples / dt / 1e6,
                 ms_per_step=dt / steps * 1e3, kernel=kname, kernel_ms=kms / max(launches, 1), launches=launches,
                 achieved_gbps=ach, bits_per_stream=int(counts[:, 2].mean()), bytes_per_launch=bytes_per_launch,
-                bytes_per_sample=abytes, parity=parity)
+                bytes_per_sample=abytes, parity=parity, spread=marks.spread())
 
 
-def timed_loop(fn, sync, args, torch, dev, world):
+def timed_loop(fn, sync, args, torch, dev, world, marks=None):
     """W warm-up + K timed steps, barrier + synchronize on both sides, MAX over ranks."""
     for _ in range(args.warmup):
         fn()
@@ -164,9 +190,13 @@ def timed_loop(fn, sync, args, torch, dev, world):
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
+    if marks:
+        marks.mark()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         fn()
+        if marks:
+            marks.mark()
     sync()
     torch.cuda.synchronize()
     if world > 1:
@@ -197,7 +227,7 @@ def source_id():
 
 def pmc_traffic(name, kernel, default_shape=True):
     """HBM bytes per launch of the dominant kernel of workload `name`.  PMC counters cannot be read from inside this process; the
-    number is the one measured by the separate rocprofv3 --pmc passes of tools/r03_profile.sh on this same command (FETCH_SIZE with
+    number is the one measured by the separate rocprofv3 --pmc passes of tools/profile_round.sh on this same command (FETCH_SIZE with
     the calibrated gfx950 factor + WRITE_SIZE), kept in profiles/pmc_traffic.json per workload shape TOGETHER WITH the id of the
     kernel sources it was taken on: a different source id (the kernels changed since the pass) gives traffic = null."""
     try:
@@ -223,7 +253,31 @@ def roofline_obj(kernel, kms, launches, bytes_per_launch, bytes_per_sample, note
     return d
 
 
-def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True):
+def parity_check_c4(ch, iq, torch, nstreams=2, seed=6):
+    """One call from a fresh state at the bench shape: every channel of `nstreams` random wideband streams against the oracle --
+    int16 FM samples and 4FSK dibits bit for bit, rssi_tag_block values to 1e-4 dB (log10f) -- untimed."""
+    import orc
+    M = ch.cc
+    ch.reset()
+    out, cnt = ch.process(iq)
+    rng = np.random.default_rng(seed)
+    picks = sorted(int(b) for b in rng.choice(iq.shape[0], size=min(nstreams, iq.shape[0]), replace=False))
+    for b in picks:
+        ref, rref, dref = orc.demod_mmdvm_multi_full(iq[b].cpu().numpy(), M)
+        o, c = out[b].cpu().numpy(), cnt[b].cpu().numpy()
+        r, rc = ch.rssi[b].cpu().numpy(), ch.rssi_counts[b].cpu().numpy()
+        d, dc = ch.dibits[b].cpu().numpy(), ch.fsk_counts[b].cpu().numpy()
+        for k in range(M):
+            ok = c[k] == ref.shape[1] and np.array_equal(o[k, :c[k]], ref[k])
+            ok = ok and rc[k] == rref[k].size and np.allclose(r[k, :rc[k]], rref[k], rtol=0, atol=1e-4)
+            ok = ok and dc[k, 2] == dref[k].size and np.array_equal(d[k, :dc[k, 2]], dref[k])
+            if not ok:
+                return dict(status="FAILED", stream=b, channel=k, streams=picks)
+    return dict(status="bit-exact", streams=picks, compared="int16 FM samples and 4FSK dibits of all %d channels (bit for bit), RSSI tags (1e-4 dB), one call from a fresh state" % M,
+                int16_per_channel=int(ref.shape[1]), dibit_bytes_per_channel=int(dref[0].size))
+
+
+def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, check=False):
     """C4: multi-carrier MMDVM receiver, 64 x 25 kHz channels from 1.6 Msps wideband IQ (PFB channelizer + per-channel
     24/25 resampler, LPF, FM discriminator -> int16, RSSI tags and the 4FSK symbol tail).  Multi-GPU (PFB form): the CHANNELS
     are sharded -- every rank channelizes its own B / world wideband streams, one RCCL all_to_all_single per step moves each
@@ -281,11 +335,13 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True):
             tail.sync()
         prof, handles = ch, [ch, tail]
     prof.profile(True)
-    dt = timed_loop(step, sync, args, torch, dev, world)
+    marks = StepMarks(torch, handles[-1].stream_wait)
+    dt = timed_loop(step, sync, args, torch, dev, world, marks)
     kms, launches, kname = prof.profile_read()
     launches_timed = args.steps
     kms = kms * launches_timed / max(launches, 1)          # (the warm-up calls were profiled too: same kernel, same shape)
     prof.profile(False)
+    parity = parity_check_c4(ch, iq, torch) if (check and world == 1 and rank == 0) else None
     for h in handles:
         h.close()
     b_kernel = (B // world) if world > 1 else B             # wideband streams the channelizer of THIS rank processes per launch
@@ -300,7 +356,10 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True):
                        "bytes_per_link_per_step": link_bytes},
             "roofline": roofline_obj(kname, kms, launches_timed, b_kernel * n * C4_BYTES, round(C4_BYTES, 3),
                                      "k_pfb_chan64 reads the wideband input once and writes the 64 channel rings; whole chain: %.1f GB/s of algorithmic bytes"
-                                     % (B * n * C4_BYTES * args.steps / dt / 1e9), name="c4", default_shape=not (args.batch or args.nsamp))}
+                                     % (B * n * C4_BYTES * args.steps / dt / 1e9), name="c4", default_shape=not (args.batch or args.nsamp)),
+            "step_spread_ms": marks.spread()}
+    if parity:
+        line["parity_check"] = parity
     if world == 1 and with_form2:
         # BASELINE configs[3] literally: 64 freq-xlating FIRs (2181 taps, 1:64) -- compute bound (34 MAC per input sample and channel)
         B2, n2 = max(1, B // 8), n // 4
@@ -317,17 +376,46 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True):
         line["freq_xlating_form"] = {
             "workload": "configs[3] literal: 64 x (rotator + rational_resampler_ccf(1, 64, 2181 taps)) + the same per-channel chain + 4FSK tail (form 2)",
             "value": round(B2 * n2 * a2.steps / dt2 / 1e6, 1), "unit": "MS/s", "steps": a2.steps, "ms_per_step": round(dt2 / a2.steps * 1e3, 3),
-            "wideband_streams": B2, "samples_per_stream_per_step": n2,
-            "roofline": roofline_obj(kname2, kms2, l2, B2 * n2 * C4_BYTES, round(C4_BYTES, 3),
-                                     "compute bound: %.0f flop per wideband sample in the 64 decimators = %.1f TFLOP/s on the f32 matrix pipe (peak 157)"
-                                     % (flop, flop * B2 * n2 * l2 / (kms2 * 1e-3) / 1e12 if kms2 > 0 else 0.0))}
+            "wideband_streams": B2, "samples_per_stream_per_step": n2, "kernel": kname2, "kernel_ms_per_step": round(kms2 / max(l2, 1), 3),
+            "note": "compute bound, not an HBM kernel (no hbm roofline reported): %.0f flop per wideband sample in the 64 decimators = %.1f TFLOP/s on the "
+                    "f32 matrix pipe (peak 157); 64 launches that each re-read the input -- the PFB form above is the production path"
+                    % (flop, flop * B2 * n2 * l2 / (kms2 * 1e-3) / 1e12 if kms2 > 0 else 0.0)}
     return line
 
 
 C5_RX_BYTES = 8.0 + (500000 * 8 + 250000 * 8 + 250000) / 1e6   # C3's ports at 1 Msps: 14.25 B per RX sample; TX: 8 B written per sample
 
 
-def run_c5(args, torch, q, ctx, dev, rank, world, steps=None):
+def parity_check_c5(dem, mod, iq, data, tx_out, torch, nstreams=3, seed=8):
+    """C5 at the bench shape, untimed: one RX call from a fresh state -- bits and port 0 of `nstreams` random streams against the
+    oracle's gr_demod_qpsk chain -- and one TX call from a fresh state -- the 1 Msps samples of `nstreams` streams against the
+    oracle's gr_mod_qpsk chain, float for float."""
+    import orc
+    dem.reset()
+    mod.reset()
+    out = dem.process(iq)
+    mod.process_async(data, out=tx_out)
+    mod.sync()
+    cnt = out["counts"].cpu().numpy()
+    rng = np.random.default_rng(seed)
+    picks = sorted(int(b) for b in rng.choice(iq.shape[0], size=min(nstreams, iq.shape[0]), replace=False))
+    for b in picks:
+        ref = oracle_demod("qpsk250k", iq[b].cpu().numpy(), 1000000, 0.0)
+        ok = np.array_equal(out["bits_a"][b, :cnt[b, 2]].cpu().numpy(), ref["bits_a"])
+        got_f = out["filtered"][b, :cnt[b, 0]].cpu().numpy().view(np.float32) + np.float32(0)
+        want_f = ref["filtered"].view(np.float32) + np.float32(0)
+        ok = ok and got_f.size == want_f.size and np.array_equal(got_f.view(np.uint32), want_f.view(np.uint32))
+        tx_ref = orc.mod_qpsk(data[b].cpu().numpy(), sps=4, filter_width=160000)
+        tx_got = tx_out[b].cpu().numpy()
+        g, w = tx_got.view(np.float32) + np.float32(0), tx_ref.view(np.float32) + np.float32(0)
+        ok = ok and g.size == w.size and np.array_equal(g.view(np.uint32), w.view(np.uint32))
+        if not ok:
+            return dict(status="FAILED", stream=b, streams=picks)
+    return dict(status="bit-exact", streams=picks, compared="RX: bits and port 0 (filtered); TX: every 1 Msps sample; one call each from a fresh state",
+                bits_per_stream=int(cnt[picks[0], 2]), tx_samples_per_stream=int(tx_out.shape[1]))
+
+
+def run_c5(args, torch, q, ctx, dev, rank, world, steps=None, check=False):
     """C5: full duplex -- QPSK-250k modulator and QPSK-250k demodulator handles on their own HIP streams, calls interleaved without
     synchronisation (BASELINE config 5; reference src/radiocontroller.cpp:2043-2078 runs the two top blocks concurrently)."""
     import sig
@@ -357,16 +445,18 @@ def run_c5(args, torch, q, ctx, dev, rank, world, steps=None):
     def sync():
         mod.sync()
         dem.sync()
-    dt = timed_loop(both, sync, args, torch, dev, world)
+    marks = StepMarks(torch, dem.stream_wait)
+    dt = timed_loop(both, sync, args, torch, dev, world, marks)
     dem.profile(True)
     dt_rx = timed_loop(lambda: dem.process_async(iq), sync, args, torch, dev, world)
     kms, launches, kname = dem.profile_read()
     dem.profile(False)
     dt_tx = timed_loop(lambda: mod.process_async(data, out=tx_out), sync, args, torch, dev, world)
+    parity = parity_check_c5(dem, mod, iq, data, tx_out, torch) if (check and rank == 0) else None
     dem.close()
     mod.close()
     tot = float(B) * n * args.steps * world
-    return {"metric": "IQ MSamples/sec through RX demod chain (with the TX chain running concurrently)", "value": round(tot / dt / 1e6, 1),
+    line = {"metric": "IQ MSamples/sec through RX demod chain (with the TX chain running concurrently)", "value": round(tot / dt / 1e6, 1),
             "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C5: full duplex QPSK-250k TX + RX at 1 Msps on two HIP streams", "streams_per_gpu": B,
@@ -375,7 +465,11 @@ def run_c5(args, torch, q, ctx, dev, rank, world, steps=None):
             "roofline": roofline_obj(kname, kms, launches, B * n * C5_RX_BYTES, C5_RX_BYTES,
                                      "RX front end (1:2 decimator + RRC) timed in the RX-alone pass; duplex chain: %.1f GB/s of algorithmic bytes (RX %.2f + TX 8 B per sample); TX alone writes %.1f GB/s"
                                      % (tot * (C5_RX_BYTES + 8.0) / dt / 1e9, C5_RX_BYTES, tot * 8.0 / dt_tx / 1e9),
-                                     name="c5", default_shape=not (args.batch or args.nsamp))}
+                                     name="c5", default_shape=not (args.batch or args.nsamp)),
+            "step_spread_ms": marks.spread()}
+    if parity:
+        line["parity_check"] = parity
+    return line
 
 
 def cpu_baseline(name, cores, budget_s=8.0):
@@ -423,6 +517,56 @@ def cpu_baseline(name, cores, budget_s=8.0):
                        "(C, -O3 -mavx2 -mfma, OpenMP over streams) with the decimating FIRs as AVX2 dot products "
                        "(orc_decim_fir_ccf_simd); GNU Radio / VOLK itself is not installable here"
                        % (reps, cores, per, name.upper(), tot))
+
+
+def _cpu_threads(fn, items, threads):
+    """run fn(item) for every item on `threads` host threads (the oracle's C functions release the GIL under ctypes)"""
+    from concurrent.futures import ThreadPoolExecutor
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(fn, items))
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_c4(cores, budget_s=4.0):
+    """C4 on the host: the oracle's whole multi-carrier receiver (PFB + 64 per-channel chains + 4FSK tails) on `cores` threads, one
+    wideband stream per thread (the reference runs ONE such flowgraph; GNU Radio would spread its blocks over threads)."""
+    import orc
+    n = 1 << 18
+    rng = np.random.default_rng(3)
+    xs = [(0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64) for _ in range(cores)]
+    one = _cpu_threads(lambda x: orc.demod_mmdvm_multi_full(x, 64), xs[:1], 1)
+    total, reps = 0.0, 0
+    while total < budget_s and reps < 1000:
+        total += _cpu_threads(lambda x: orc.demod_mmdvm_multi_full(x, 64), xs, cores)
+        reps += 1
+    return dict(value=round(reps * cores * n / total / 1e6, 3), unit="MS/s", cores=cores, kind="port", single_thread=round(n / one / 1e6, 3),
+                sample="%d passes over %d wideband streams x %d samples of the C4 workload (%.1f s of CPU wall time); oracle/liborc.so scalar restatement "
+                       "(direct-sum DFT as the contract defines it; upstream runs FFTW there), one stream per thread" % (reps, cores, n, total))
+
+
+def cpu_baseline_c5(cores, budget_s=4.0):
+    """C5 on the host: the oracle's QPSK-250k receiver on `cores` threads (one stream each) WHILE the same number of streams is modulated
+    on the same threads afterwards -- value = RX samples / (RX time + TX time of as many samples), i.e. both directions on the same cores."""
+    import orc
+    import sig
+    n = 1 << 18
+    base, _ = sig.make_stream("qpsk250k", nframes=3, device_rate=1000000, seed=98, amp=0.05)
+    base = np.tile(base, -(-n // base.size))[:n]
+    rng = np.random.default_rng(4)
+    xs = [np.roll(base, 911 * b).astype(np.complex64) for b in range(cores)]
+    ds = [rng.integers(0, 256, n // 32, dtype=np.uint8) for _ in range(cores)]
+    rx = lambda x: orc.demod_qpsk(orc.frontend(x, 1000000, 0.0), sps=2, filter_width=160000)
+    total_rx = total_tx = 0.0
+    reps = 0
+    while total_rx + total_tx < budget_s and reps < 1000:
+        total_rx += _cpu_threads(rx, xs, cores)
+        total_tx += _cpu_threads(orc.mod_qpsk, ds, cores)
+        reps += 1
+    return dict(value=round(reps * cores * n / (total_rx + total_tx) / 1e6, 3), unit="MS/s", cores=cores, kind="port",
+                rx_only=round(reps * cores * n / total_rx / 1e6, 3), tx_only=round(reps * cores * n / total_tx / 1e6, 3),
+                sample="%d passes over %d streams x %d samples each way of the C5 workload (%.1f s of CPU wall time); oracle/liborc.so scalar restatement, "
+                       "one stream per thread" % (reps, cores, n, total_rx + total_tx))
 
 
 def respawn_under_torchrun(args):
@@ -481,23 +625,33 @@ def main():
             torch.distributed.barrier()   # rank 0 may be behind by the CPU baseline: leave together
             torch.distributed.destroy_process_group()
 
-    if args.config in ("c4", "c5"):
-        finish((run_c4 if args.config == "c4" else run_c5)(args, torch, q, ctx, dev, rank, world))
-        return
     extra_ok = not args.no_extra
+    ncores = min(os.cpu_count() or 1, 16)
+    if args.config in ("c4", "c5"):
+        line = (run_c4 if args.config == "c4" else run_c5)(args, torch, q, ctx, dev, rank, world, check=extra_ok or args.check)
+        if extra_ok and rank == 0 and world == 1:
+            line["cpu_baseline"] = (cpu_baseline_c4 if args.config == "c4" else cpu_baseline_c5)(ncores)
+        finish(line)
+        if rank == 0 and line.get("parity_check", {}).get("status", "bit-exact") != "bit-exact":
+            raise SystemExit("bench.py: parity check against the oracle FAILED at the bench shape: %r" % (line["parity_check"],))
+        return
     main_r = run_workload(args.config, args, torch, q, ctx, dev, rank, world, overlap=False if args.no_overlap else None, check=extra_ok or args.check)
     # C1 runs in the library's default mode (the FLL / discriminator kernels of call k share the GPU with the front end of call
     # k + 1: more whole-chain throughput, but the front-end kernel stretches).  The serial order -- where the front-end kernel has the
     # chip to itself -- is measured in a second short pass for the record.
     ovl = run_workload("c1", args, torch, q, ctx, dev, rank, world, overlap=False, steps=min(args.steps, 20)) \
         if (extra_ok and args.config == "c1" and not args.no_overlap) else None
-    extra = run_workload("c2", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 50)) if (extra_ok and args.config == "c1") else None
-    extra3 = run_workload("c3", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 30)) if (extra_ok and args.config == "c1") else None
-    extra4 = run_c4(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20)) if (extra_ok and args.config == "c1" and world == 1) else None
-    extra5 = run_c5(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20)) if (extra_ok and args.config == "c1" and world == 1) else None
+    extra = run_workload("c2", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 50), check=True) if (extra_ok and args.config == "c1") else None
+    extra3 = run_workload("c3", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 30), check=True) if (extra_ok and args.config == "c1") else None
+    extra4 = run_c4(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20), check=True) if (extra_ok and args.config == "c1" and world == 1) else None
+    extra5 = run_c5(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20), check=True) if (extra_ok and args.config == "c1" and world == 1) else None
     # (the CPU baseline is a property of the box, not of the job: rank 0 at N = 1 only, as the contract says)
-    base = cpu_baseline(args.config, min(os.cpu_count() or 1, 16)) if (extra_ok and rank == 0 and world == 1) else None
-    base2 = cpu_baseline("c2", min(os.cpu_count() or 1, 16), budget_s=4.0) if (extra_ok and rank == 0 and world == 1 and args.config == "c1") else None
+    all_lines = extra_ok and rank == 0 and world == 1 and args.config == "c1"
+    base = cpu_baseline(args.config, ncores) if (extra_ok and rank == 0 and world == 1) else None
+    base2 = cpu_baseline("c2", ncores, budget_s=3.0) if all_lines else None
+    base3 = cpu_baseline("c3", ncores, budget_s=3.0) if all_lines else None
+    base4 = cpu_baseline_c4(ncores, budget_s=3.0) if all_lines else None
+    base5 = cpu_baseline_c5(ncores, budget_s=3.0) if all_lines else None
 
     line = None
     if rank == 0:
@@ -520,6 +674,7 @@ def main():
             "source_id": source_id(),
             "metric": "IQ MSamples/sec through RX demod chain", "value": round(main_r["msps"], 1), "unit": "MS/s",
             "n_gpus": world, "steps": main_r["steps"], "warmup": args.warmup, "ms_per_step": round(main_r["ms_per_step"], 3),
+            "step_spread_ms": main_r["spread"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": main_r["label"], "streams_per_gpu": main_r["batch"],
                        "samples_per_stream_per_step": main_r["nsamp"], "device_samp_rate": main_r["rate"],
@@ -531,21 +686,26 @@ def main():
             line["parity_check"] = main_r["parity"]
         if base:
             line["cpu_baseline"] = base
-        for key, ex in (("c2", extra), ("c3", extra3)):
+        for key, ex, cb in (("c2", extra, base2), ("c3", extra3, base3)):
             if ex:
                 line[key] = {"workload": ex["label"], "value": round(ex["msps"], 1), "unit": "MS/s", "steps": ex["steps"],
-                             "ms_per_step": round(ex["ms_per_step"], 3), "streams_per_gpu": ex["batch"],
+                             "ms_per_step": round(ex["ms_per_step"], 3), "step_spread_ms": ex["spread"], "streams_per_gpu": ex["batch"],
                              "samples_per_stream_per_step": ex["nsamp"], "roofline": roof(ex)}
-                if key == "c2" and base2:
-                    line[key]["cpu_baseline"] = base2
-        for key, ex in (("c4", extra4), ("c5", extra5)):
+                if ex["parity"]:
+                    line[key]["parity_check"] = ex["parity"]
+                if cb:
+                    line[key]["cpu_baseline"] = cb
+        for key, ex, cb in (("c4", extra4, base4), ("c5", extra5, base5)):
             if ex:
-                line[key] = {k: ex[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "roofline") if k in ex}
-                if "freq_xlating_form" in ex:
-                    line[key]["freq_xlating_form"] = ex["freq_xlating_form"]
+                line[key] = {k: ex[k] for k in ("value", "unit", "steps", "ms_per_step", "step_spread_ms", "config", "roofline", "parity_check", "freq_xlating_form") if k in ex}
+                if cb:
+                    line[key]["cpu_baseline"] = cb
     finish(line)
-    if rank == 0 and main_r["parity"] and main_r["parity"]["status"] != "bit-exact":
-        raise SystemExit("bench.py: parity check against the oracle FAILED at the bench shape: %r" % (main_r["parity"],))
+    if rank == 0:
+        failed = [(k, v["parity_check"]) for k, v in [("c1", line)] + [(k, line[k]) for k in ("c2", "c3", "c4", "c5") if k in line]
+                  if v.get("parity_check") and v["parity_check"]["status"] != "bit-exact"]
+        if failed:
+            raise SystemExit("bench.py: parity check against the oracle FAILED at the bench shape: %r" % (failed,))
 
 
 if __name__ == "__main__":

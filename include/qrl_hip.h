@@ -108,7 +108,7 @@ int qrl_demod_set_carrier_offset(qrl_demod* d, double carrier_offset_hz);
  * a reset) or the slicer starts with an empty 1440-sample history. */
 #define QRL_DMO_RECORD_BYTES 40
 int qrl_demod_set_dmo_output(qrl_demod* d, uint8_t* frames, size_t cap_frames, uint32_t* counts);
-/* Per-handle run-time options (none of them changes results).  QRL_OPT_OVERLAP (2FSK family only, default 1 since round 3): value 1 runs
+/* Per-handle run-time options (none of them changes results; tests/test_gpu_parity.py checks each value of each option against the oracle).  QRL_OPT_OVERLAP (2FSK family only, default 1 since round 3): value 1 runs
  * everything behind the first decimated ring of call k on a second stream under the front end of call k + 1; value 0 runs the
  * kernels of a call one after another.  QRL_OPT_UNFUSED_DEC2 (QPSK chains with sps <= 4, default 0): value 1 runs the 1:2 resampler
  * and the shaping filter (gr_demod_qpsk.cpp:92-103) as the two kernels of rounds 1-2 instead of the fused one (A/B and parity checks);
@@ -236,7 +236,8 @@ void qrl_chan_destroy(qrl_chan* c);
 int qrl_chan_reset(qrl_chan* c);
 /* kernel selection for A/B measurements and tests (results are identical): QRL_CHAN_OPT_LEGACY_PFB = 1 runs the general-M
  * channelizer kernel also for the 64-channel geometry; QRL_CHAN_OPT_LEGACY_TAIL = 1 runs the per-channel chain as separate kernels
- * instead of the fused feed-forward kernel. */
+ * instead of the fused feed-forward kernel -- only before the first samples of a stream or after qrl_chan_reset (QRL_ERR_STATE
+ * otherwise: the fused kernel does not fill the intermediate rings the separate kernels take their history from). */
 enum { QRL_CHAN_OPT_LEGACY_PFB = 1, QRL_CHAN_OPT_LEGACY_TAIL = 2 };
 int qrl_chan_set_option(qrl_chan* c, int option, int value);
 int qrl_chan_set_level(qrl_chan* c, float level);   /* _level_control multiply_const_ff, gr_demod_mmdvm_multi2.cpp:84 */
@@ -252,7 +253,10 @@ int qrl_chan_set_rssi_output(qrl_chan* c, float* rssi, size_t cap, uint32_t* cou
  * fft_filter_fff(RRC(1, 24k, 4.8k, 0.2, 125)) -> symbol_sync_ff(M&M, 5 sps, 4-level) -> x0.9 -> phase_modulator -> slicer ->
  * map{3,1,2,0}) applied to the 24 ksps channel signal (after _filter[i], gr_demod_mmdvm_multi2.cpp:62-63,75).
  * bits[s*bits_cap + k]: two bits per symbol; constellation (cf32, may be NULL); counts[s*4 + 1] = symbols, [s*4 + 2] = bits
- * produced by each following qrl_chan_process call, s = b*channel_count + ch.  bits == NULL switches the tail off. */
+ * produced by each following qrl_chan_process call, s = b*channel_count + ch.  bits == NULL switches the tail off.
+ * The symbol synchroniser runs on an internal stream of the handle (it overlaps the next call's channelizer): bits, constellation
+ * and counts of a call are valid after qrl_chan_sync() or, on the device, behind qrl_chan_stream_wait() -- synchronising only the
+ * cfg.hip_stream the caller passed in is NOT enough for these three outputs (it is for the int16 / RSSI outputs). */
 int qrl_chan_set_4fsk_output(qrl_chan* c, uint8_t* bits, size_t bits_cap, float* constellation, size_t constellation_cap, uint32_t* counts);
 size_t qrl_chan_out_cap(const qrl_chan* c, size_t n);   /* int16 samples per channel a call with n inputs can produce */
 /* replaces one scheduler pass of the multi-carrier graph: iq[b*stride + i] device cf32, n a multiple of num_channels;

@@ -140,6 +140,7 @@ def load_library():
     lib.qrl_fft_process.argtypes = [vp, vp, sz, sz]
     lib.qrl_fft_get_fft_data.argtypes = [vp, vp, sz, C.POINTER(C.c_uint)]
     lib.qrl_fft_sync.argtypes = [vp]
+    lib.qrl_demod_stream_wait.argtypes = [vp, vp]
     lib.qrl_demod_stream.restype = vp
     lib.qrl_demod_stream.argtypes = [vp]
     lib.qrl_demod_profile.argtypes = [vp, C.c_int]
@@ -377,6 +378,10 @@ class Demod:
     def set_agc(self, attack, decay):
         _check(self.lib.qrl_demod_set_agc(self.h, C.c_float(attack), C.c_float(decay)), "qrl_demod_set_agc")
 
+    def stream_wait(self, hip_stream):
+        """the given HIP stream (int handle) waits, on the device, for everything this handle has queued so far (qrl_demod_stream_wait)"""
+        _check(self.lib.qrl_demod_stream_wait(self.h, C.c_void_p(hip_stream)), "qrl_demod_stream_wait")
+
     def profile(self, enable=True):
         _check(self.lib.qrl_demod_profile(self.h, int(enable)), "qrl_demod_profile")
 
@@ -457,6 +462,10 @@ class Channelizer:
 
     def calibrate_rssi(self, level):
         _check(self.lib.qrl_chan_calibrate_rssi(self.h, float(level)), "qrl_chan_calibrate_rssi")
+
+    def reset(self):
+        """back to the state of a new handle (history, rings, symbol-sync loops): qrl_chan_reset"""
+        _check(self.lib.qrl_chan_reset(self.h), "qrl_chan_reset")
 
     def process_async(self, iq):
         assert iq.is_cuda and iq.dtype == self.torch.complex64 and iq.dim() == 2 and iq.shape[0] == self.batch and iq.stride(1) == 1

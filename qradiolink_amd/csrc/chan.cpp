@@ -228,7 +228,11 @@ int qrl_chan_set_option(qrl_chan* h, int option, int value)
 {
     if (!h) return QRL_ERR_ARG;
     if (option == QRL_CHAN_OPT_LEGACY_PFB) h->opt_legacy_pfb = value != 0;
-    else if (option == QRL_CHAN_OPT_LEGACY_TAIL) h->opt_legacy_tail = value != 0;
+    else if (option == QRL_CHAN_OPT_LEGACY_TAIL) {
+        // the fused per-channel kernel does not fill the intermediate rings the separate kernels read their history from: only before the first samples
+        if (h->n_in != 0 || h->n2 != 0) return qrl_set_error(QRL_ERR_STATE, "QRL_CHAN_OPT_LEGACY_TAIL: only before the first call (or after qrl_chan_reset)");
+        h->opt_legacy_tail = value != 0;
+    }
     else return qrl_set_error(QRL_ERR_ARG, "unknown channelizer option");
     return QRL_OK;
 }
@@ -263,6 +267,7 @@ int qrl_chan_set_4fsk_output(qrl_chan* h, uint8_t* bits, size_t bits_cap, float*
         }
         clock_loop_gains((float)(2 * M_PI / 100.0f), 1.0f, 0.2869f, h->ss_alpha, h->ss_beta);  // :70-71
         HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipStreamSynchronize(h->tail));
         if ((r = h->init_ss())) return r;
     }
     h->fsk_bits = bits; h->fsk_bits_cap = bits_cap; h->fsk_const = constellation; h->fsk_const_cap = constellation_cap; h->fsk_counts = counts;

@@ -25,6 +25,7 @@
 // Summation contract "pl" (oracle/orc_blocks.c orc_decim_fir_ccf_pl): slot(i) = (i-1) mod D; per slot one chain, oldest
 // sample first, first term a plain product, then fmaf; 64 slots (unused = +0) meet as v[l] += v[l+h], h = 32,16,...,1.
 #include <vector>
+#include <mutex>
 #include "devmath.hpp"
 #include "engine.hpp"
 
@@ -958,14 +959,23 @@ static int pm_launch_main(DecimParams& q, uint64_t M, uint32_t batch, bool edge_
     constexpr int NW = QRL_PM_NW;
     const auto kern = k_decim_pm<J, NS, RP, NW>;
     const size_t lds = (size_t)NW * RP * 1024 + 512 * sizeof(float2) + NW * PM_NHI * sizeof(float2);
-    static int wg_per_cu = 0, n_cu = 0;          // (per instantiation)
-    if (!wg_per_cu) {
-        if (dyn_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024) != hipSuccess) return -1;
-        int nb = 0, dev = 0; hipDeviceProp_t pr;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NW * 64, lds) != hipSuccess || nb < 1) nb = 1;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return -1;
-        n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-        wg_per_cu = nb;
+    // occupancy and CU count per (instantiation, device): a second device in the process gets its own LDS attribute (dyn_lds_limit
+    // de-duplicates per kernel and device) and its own geometry; first calls may race, hence the lock
+    static std::mutex mu; static int wg_cache[16], cu_cache[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -1;
+    if (dyn_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024) != hipSuccess) return -1;
+    int wg_per_cu, n_cu;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!wg_cache[dev]) {
+            int nb = 0; hipDeviceProp_t pr;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NW * 64, lds) != hipSuccess || nb < 1) nb = 1;
+            if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return -1;
+            cu_cache[dev] = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+            wg_cache[dev] = nb;
+        }
+        wg_per_cu = wg_cache[dev]; n_cu = cu_cache[dev];
     }
     const uint32_t S = pm_pick_segment(M, batch, (uint32_t)(wg_per_cu * n_cu * NW), (uint32_t)(J - 1));
     q.pl_S = S;

@@ -445,6 +445,20 @@ def demod_mmdvm_multi_4fsk(x, M):
     return out[:, :n].copy(), [dib[c, :int(nd[c])].copy() for c in range(M)]
 
 
+def demod_mmdvm_multi_full(x, M, cal=0.0):
+    """the whole C4 receiver as bench.py runs it: PFB channelizer + per-channel FM int16 + rssi_tag_block values + 4FSK dibits"""
+    x = np.ascontiguousarray(x, cf32)
+    cap = (x.size // M) * 24 // 25 + 4
+    out = np.zeros((M, cap), np.int16)
+    rcap = cap // 300 + 2
+    rssi = np.zeros((M, rcap), np.float32)
+    dcap = 2 * (cap // 4 + 16)
+    dib = np.zeros((M, dcap), np.uint8)
+    nd = np.zeros(M, np.uint64)
+    n = lib.orc_demod_mmdvm_multi_4fsk(_ptr(x), x.size, M, _ptr(out), cap, _ptr(rssi), rcap, cal, _ptr(dib), dcap, _ptr(nd))
+    return out[:, :n].copy(), rssi[:, :n // 300].copy(), [dib[c, :int(nd[c])].copy() for c in range(M)]
+
+
 _sig("orc_demod_mmdvm_xlating_bank_4fsk", _sz, _p, _sz, C.c_int, _p, _sz, _p, _sz, C.c_float, _p, _sz, _p)
 _sig("orc_mmdvm_channel_tails", _sz, _p, C.c_int, _sz, _p, _sz, _p, _sz, C.c_float, _p, _sz, _p)
 

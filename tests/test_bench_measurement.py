@@ -14,12 +14,12 @@ import bench   # noqa: E402
 
 def test_committed_pmc_traffic_belongs_to_the_committed_kernel_sources():
     """profiles/pmc_traffic.json is only meaningful for the kernels it was measured on: its source id must be the id of
-    qradiolink_amd/csrc + include as they are committed (re-run tools/r03_profile.sh + tools/r03_collect.py after a kernel change)."""
+    qradiolink_amd/csrc + include as they are committed (re-run tools/profile_round.sh + tools/collect_round.py after a kernel change)."""
     d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     if d["_source_id"] != bench.source_id():      # kernels changed since the pass: bench.py must then report no traffic, with the reason
         t, why = bench.pmc_traffic("c1", "k_decim_pm")
         assert t is None and d["_source_id"] in why
-        pytest.skip("profiles/pmc_traffic.json is stale for these kernel sources: re-run tools/r03_profile.sh + tools/r03_collect.py")
+        pytest.skip("profiles/pmc_traffic.json is stale for these kernel sources: re-run tools/profile_round.sh + tools/collect_round.py")
     cal = d["_calibration"]["applied"]
     assert cal["FETCH_SIZE"] == 0.5 and cal["WRITE_SIZE"] == 1.0      # measured in the same pass: tools/pmc_calibrate.py
     for cfg in ("c1", "c2", "c3", "c4", "c5"):

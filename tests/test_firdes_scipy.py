@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 import pytest
-import scipy.signal as ss
+ss = pytest.importorskip("scipy.signal")   # boxes without scipy skip this file instead of failing collection
 
 import orc
 import qradiolink_amd as q

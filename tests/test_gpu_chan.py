@@ -179,6 +179,62 @@ def test_channelizer_4fsk_tail_bit_exact(qrl_ctx, chunk):
         assert best > 0.99, (c, best)
 
 
+@pytest.mark.parametrize("cuts", [[64 * 2500], [64 * 777, 64 * 1723], [64 * 31, 64 * 1200, 64 * 1269]])
+def test_channelizer_64_4fsk_tail_rssi_bit_exact(qrl_ctx, cuts):
+    """The configuration bench.py times as C4 (gr_demod_mmdvm_multi2.cpp:58-135 + gr_demod_dmr.cpp:62-105): M = 64, PFB form 0,
+    enable_4fsk + RSSI tags -- int16 FM samples and dibits array_equal with the oracle, RSSI to 1e-4 dB, in one call and over ragged
+    cuts that are no multiple of the channelizer's 32-instant tile nor of the per-channel 1200-output tile; planted DMR-like 4FSK
+    carriers come back as their dibits."""
+    import torch
+    import qradiolink_amd as q
+    import sig
+    M, n = 64, sum(cuts)
+    fs = 25000.0 * M
+    iq = _wideband(M, n, seed=164, nstreams=2)
+    t = np.arange(n)
+    dibs = {}
+    for c, seed in ((1, 5), (33, 6), (62, 7)):
+        x, d = sig.make_4fsk(nsym=int(n / fs * 4800) - 2, seed=seed, amp=0.4, noise=0.0, fs=fs)
+        f0 = c * 25000.0 if c <= M // 2 else (c - M) * 25000.0
+        m = min(n, x.size)
+        iq[0, :m] += (x[:m] * np.exp(2j * np.pi * f0 * t[:m] / fs)).astype(np.complex64)
+        dibs[c] = d
+    ch = q.Channelizer(qrl_ctx, M, batch=2, max_chunk=max(cuts))
+    ch.calibrate_rssi(-7.25)
+    ch.enable_4fsk()
+    d = torch.from_numpy(iq).cuda()
+    got = [[[] for _ in range(M)] for _ in range(2)]
+    tags = [[[] for _ in range(M)] for _ in range(2)]
+    dib = [[[] for _ in range(M)] for _ in range(2)]
+    pos = 0
+    for cut in cuts:
+        out, cnt = ch.process(d[:, pos:pos + cut].contiguous())
+        pos += cut
+        cnt, o = cnt.cpu().numpy(), out.cpu().numpy()
+        rc, r = ch.rssi_counts.cpu().numpy(), ch.rssi.cpu().numpy()
+        fc, bits = ch.fsk_counts.cpu().numpy(), ch.dibits.cpu().numpy()
+        for b in range(2):
+            for c in range(M):
+                got[b][c].append(o[b, c, :cnt[b, c]].copy())
+                tags[b][c].append(r[b, c, :rc[b, c]].copy())
+                dib[b][c].append(bits[b, c, :fc[b, c, 2]].copy())
+    ch.close()
+    for b in range(2):
+        ref, rref, dref = orc.demod_mmdvm_multi_full(iq[b], M, cal=-7.25)
+        for c in range(M):
+            g = np.concatenate(got[b][c])
+            assert g.size == ref.shape[1] and np.array_equal(g, ref[c]), (b, c)
+            tg = np.concatenate(tags[b][c])
+            assert tg.size == rref[c].size == ref.shape[1] // 300 and np.allclose(tg, rref[c], rtol=0, atol=1e-4), (b, c)
+            dd = np.concatenate(dib[b][c])
+            assert dd.size == dref[c].size and np.array_equal(dd, dref[c]), (b, c)
+    assert np.abs(ref).max() > 1000
+    for c, dw in dibs.items():
+        g = np.concatenate(dib[0][c]).reshape(-1, 2)
+        g = g[:, 0] * 2 + g[:, 1]
+        assert max(np.mean(g[k:k + 400] == dw[:400]) for k in range(60)) > 0.99, c
+
+
 def _wideband_xl(fs, n, seed, nstreams, offsets):
     rng = np.random.default_rng(seed)
     t = np.arange(n)

@@ -10,11 +10,13 @@ import sig
 pytestmark = pytest.mark.gpu
 
 
-def _run(qrl_ctx, mode_name, modem, device_rate, offset, B, chunk, nframes=3, seed=3):
+def _run(qrl_ctx, mode_name, modem, device_rate, offset, B, chunk, nframes=3, seed=3, options=()):
     import torch
     import qradiolink_amd as q
     iq = sig.make_batch(mode_name, B, nframes=nframes, device_rate=device_rate, rx_offset_hz=offset, seed=seed)
     dem = q.Demod(qrl_ctx, modem, batch=B, max_chunk=chunk, device_samp_rate=device_rate, carrier_offset_hz=offset)
+    for opt, val in options:
+        dem.set_option(opt, val)
     out = q.collect(dem, torch.from_numpy(iq).cuda(), chunk)
     dem.close()
     return iq, out
@@ -88,6 +90,16 @@ def test_chain_bit_exact_single_call(qrl_ctx, mode_name, modem, rate, chunk):
     offset = 25000.0 if rate >= 2000000 else 1200.0
     iq, out = _run(qrl_ctx, mode_name, modem, rate, offset, B=3, chunk=chunk, nframes=2)
     _compare(iq, out, mode_name, rate, offset)
+
+
+@pytest.mark.parametrize("mode_name,modem,chunk", [("2fsk1k", 18, 1 << 21), ("2fsk1k", 18, 50000), ("bpsk1k", 24, 1 << 21), ("bpsk1k", 24, 65536),
+                                                   ("qpsk2k", 7, 60000)])
+def test_fll_slim_geometry_bit_exact(qrl_ctx, mode_name, modem, chunk):
+    """QRL_OPT_FLL_SLIM = 1 (k_fll<NT, 64, 16>: single-wave FLL workgroups with 16-sample windows) is declared result-neutral in
+    include/qrl_hip.h: the chains that contain an FLL, in one call and cut into calls, against the oracle with the option on."""
+    import qradiolink_amd as q
+    iq, out = _run(qrl_ctx, mode_name, modem, 1000000, 1200.0, B=3, chunk=chunk, nframes=2, options=[(q.OPT_FLL_SLIM, 1)])
+    _compare(iq, out, mode_name, 1000000, 1200.0)
 
 
 @pytest.mark.parametrize("chunk", [65536, 10007 * 2, 300002])
@@ -441,8 +453,11 @@ def test_pipelined_calls_without_sync(qrl_ctx, mode_name, modem):
     res = []
     for sync_each in (True, False):
         dem = q.Demod(qrl_ctx, modem, batch=B, max_chunk=chunk)
-        if mode_name.startswith("2fsk") and not sync_each:
-            dem.set_option(q.OPT_OVERLAP, 1)   # the opt-in overlapped mode of the 2FSK family (QRL_OPT_OVERLAP)
+        if mode_name.startswith("2fsk"):
+            # QRL_OPT_OVERLAP is the library default for this family since round 3: the synced reference run takes the SERIAL order
+            # (cs = stream, ev_tail / tail_pending waits), the unsynced run the overlapped one -- both paths are checked against each
+            # other and against the oracle
+            dem.set_option(q.OPT_OVERLAP, 0 if sync_each else 1)
         for k in range(ncalls):
             dem.process_async(d[:, k * chunk:(k + 1) * chunk])
             if sync_each:
@@ -474,8 +489,8 @@ def test_every_call_of_a_pipelined_sequence_is_deterministic(qrl_ctx, mode_name,
     runs = []
     for sync_each in (True, False):
         dem = q.Demod(qrl_ctx, modem, batch=B, max_chunk=chunk)
-        if mode_name.startswith("2fsk") and not sync_each:
-            dem.set_option(q.OPT_OVERLAP, 1)
+        if mode_name.startswith("2fsk"):
+            dem.set_option(q.OPT_OVERLAP, 0 if sync_each else 1)   # serial order in the synced run, overlapped (the default) in the other
         outs = []
         for k in range(ncalls):
             outs.append(dem.new_outputs())

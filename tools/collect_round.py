@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copies the judged summaries of tools/r03_profile.sh from gpurun_out/r03 (scratch) into profiles/ (tracked) and rebuilds
+"""Copies the judged summaries of tools/profile_round.sh from gpurun_out/<tag> (scratch; tag = argv[1], e.g. r04) into profiles/ (tracked) and rebuilds
 profiles/pmc_traffic.json: HBM bytes per launch of each workload's dominant kernel = FETCH_SIZE [KiB] x 1024 / f_fetch +
 WRITE_SIZE [KiB] x 1024 / f_write, where f_* are the calibration ratios measured in the same pass on an elementwise kernel of known
 size (tools/pmc_calibrate.py; MI355X_MICROARCH.md's gfx950 correction says f_fetch = 0.5), together with the id of the kernel
@@ -8,18 +8,20 @@ import json
 import os
 import re
 import shutil
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC, DST = os.path.join(ROOT, "gpurun_out", "r03"), os.path.join(ROOT, "profiles")
-for name, out in (("kernel_trace_summary.md", "r03_kernel_trace_summary.md"), ("pmc_summary.txt", "r03_pmc_summary.txt"),
-                  ("kernel_alone_summary.md", "r03_kernel_alone_summary.md"), ("sweep.jsonl", "r03_batch_sweep.jsonl")):
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+SRC, DST = os.path.join(ROOT, "gpurun_out", TAG), os.path.join(ROOT, "profiles")
+for name, out in (("kernel_trace_summary.md", TAG + "_kernel_trace_summary.md"), ("pmc_summary.txt", TAG + "_pmc_summary.txt"),
+                  ("kernel_alone_summary.md", TAG + "_kernel_alone_summary.md"), ("sweep.jsonl", TAG + "_batch_sweep.jsonl")):
     shutil.copy(os.path.join(SRC, name), os.path.join(DST, out))
 bench = {}
 for cfg in ("default", "c2", "c3", "c4", "c5", "c1_serial"):
     try:
         with open(os.path.join(SRC, "bench_%s.json" % cfg)) as f:
             lines = [l for l in f.read().splitlines() if l.startswith("{")]
-        with open(os.path.join(DST, "r03_bench_%s.json" % cfg), "w") as f:
+        with open(os.path.join(DST, "%s_bench_%s.json" % (TAG, cfg)), "w") as f:
             f.write(lines[-1] + "\n")
         bench[cfg] = json.loads(lines[-1])
     except (OSError, IndexError):
@@ -48,7 +50,7 @@ dominant = {"c1": bench.get("default", {}).get("roofline", {}).get("kernel"), "c
             "c3": bench.get("c3", {}).get("roofline", {}).get("kernel"), "c4": bench.get("c4", {}).get("roofline", {}).get("kernel"),
             "c5": bench.get("c5", {}).get("roofline", {}).get("kernel")}
 out = {"_source_id": sid, "_calibration": {"measured": cal, "applied": {"FETCH_SIZE": f_fetch, "WRITE_SIZE": f_write},
-                                           "how": "tools/pmc_calibrate.py under the same rocprofv3 --pmc passes (tools/r03_profile.sh): counter / 2^20 KiB on y = x + 1 over 1 GiB"}}
+                                           "how": "tools/pmc_calibrate.py under the same rocprofv3 --pmc passes (tools/profile_round.sh): counter / 2^20 KiB on y = x + 1 over 1 GiB"}}
 for cfg, rows in sections.items():
     want = (dominant.get(cfg) or "").split(" ")[0].split("<")[0]
     want = want if want.startswith("qrl::") else "qrl::" + want
@@ -61,8 +63,8 @@ for cfg, rows in sections.items():
     if "FETCH_SIZE" in best and "WRITE_SIZE" in best:
         out[cfg] = {"kernel": best["FETCH_SIZE"][1], "fetch_bytes": best["FETCH_SIZE"][0] * 1024 / f_fetch,
                     "write_bytes": best["WRITE_SIZE"][0] * 1024 / f_write, "launches_averaged": best["FETCH_SIZE"][2],
-                    "source": "profiles/r03_pmc_summary.txt",
-                    "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/r03_profile.sh) on `python bench.py --config %s "
+                    "source": "profiles/%s_pmc_summary.txt" % TAG,
+                    "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/profile_round.sh) on `python bench.py --config %s "
                             "--steps 3 --warmup 1 --no-extra`, mean over the launches of the default shape; KiB counters, divided by the calibration "
                             "factors above" % cfg}
     else:

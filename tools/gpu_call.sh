@@ -1,0 +1,69 @@
+#!/bin/bash
+# One parameterised script for every call made on the GPU box through gpurun (replaces the per-call scripts of round 3).
+# usage: tools/gpu_call.sh OUT VERB [args...]      (OUT = sub-directory of gpurun_out/, created if missing, kept between verbs)
+#   tests  <pytest args>                 pytest with the given arguments, log in OUT/pytest_<n>.log, last lines echoed
+#   bench  <cfg> [bench.py args]         python bench.py --config <cfg> ..., JSON in OUT/bench_<cfg>[_<QRL_TAG>].json, one summary line echoed
+#   prof   <cfg> [bench.py args]         rocprofv3 --kernel-trace --stats of a short bench run, per-kernel table appended to OUT/kernel_trace_summary.md
+#   ab     <cfg> <kernel regex> <variant>...   same-box A/B: every variant library (build/libqrl_<v>.so; "base" = the in-tree one) twice,
+#                                        alternating, under the profiler; matching kernels + ms_per_step appended to OUT/ab.log
+#   pmc    <cfg> <COUNTER>               one rocprofv3 --pmc pass (kernel-trace only), summary appended to OUT/pmc_summary.txt
+#   smoke                                __graft_entry__.smoke()
+# Several verbs in one gpurun call: gpurun -- 'tools/gpu_call.sh r04a tests tests/test_gpu_chan.py -x -q; tools/gpu_call.sh r04a bench c4 --no-extra'
+set -u
+export TMPDIR=/tmp
+O=gpurun_out/$1; shift
+mkdir -p $O
+verb=$1; shift
+summ() { python - "$1" <<'P'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r = d.get("roofline", {})
+    print(sys.argv[1], "ms/step", d["ms_per_step"], "value", d["value"], r.get("kernel"), r.get("kernel_ms"), "frac", r.get("frac"),
+          "parity", d.get("parity_check", {}).get("status"), d.get("step_spread_ms"))
+    for k in ("c2", "c3", "c4", "c5"):
+        if k in d:
+            e = d[k]; r = e.get("roofline", {})
+            print("  ", k, "ms/step", e["ms_per_step"], "value", e["value"], r.get("kernel_ms"), "frac", r.get("frac"), "parity", e.get("parity_check", {}).get("status"))
+except Exception as e:
+    print(sys.argv[1], "FAILED", e)
+P
+}
+clean() { find $O -name '*.csv' -size +2M -delete; find $O -name '*.db' -size +4M -delete; }
+case $verb in
+tests)
+  n=$(ls $O/pytest_*.log 2>/dev/null | wc -l)
+  timeout ${QRL_TEST_TIMEOUT:-1500} python -m pytest "$@" > $O/pytest_$n.log 2>&1; echo "pytest rc $?" >> $O/pytest_$n.log
+  tail -n ${QRL_TAIL:-8} $O/pytest_$n.log ;;
+bench)
+  cfg=$1; shift
+  f=$O/bench_$cfg${QRL_TAG:+_$QRL_TAG}.json
+  timeout ${QRL_BENCH_TIMEOUT:-600} python bench.py --config $cfg "$@" > $f 2> ${f%.json}.err; summ $f; tail -n 3 ${f%.json}.err ;;
+prof)
+  cfg=$1; shift
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof -o $cfg${QRL_TAG:+_$QRL_TAG} -- python bench.py --config $cfg --steps 5 --warmup 1 --no-extra "$@" > $O/prof_$cfg.log 2>&1
+  f=$(find $O/prof -name "$cfg${QRL_TAG:+_$QRL_TAG}_results.db" | head -1)
+  python tools/prof_summary.py $f "$cfg${QRL_TAG:+ $QRL_TAG}: rocprofv3 --kernel-trace --stats -- python bench.py --config $cfg --steps 5 --warmup 1 --no-extra $*" | tee -a $O/kernel_trace_summary.md | head -${QRL_TAIL:-14}
+  clean ;;
+ab)
+  cfg=$1; re=$2; shift 2
+  for rep in 1 2; do for v in "$@"; do
+    L=$PWD/build/libqrl_$v.so; [ $v = base ] && L=$PWD/qradiolink_amd/libqrl_hip.so
+    echo "== $cfg $v (pass $rep)" >> $O/ab.log
+    QRL_LIB_PATH=$L timeout 200 rocprofv3 --kernel-trace --stats -d $O/p_$v -o $cfg -- python bench.py --config $cfg --steps ${QRL_AB_STEPS:-6} --warmup 2 --no-extra ${QRL_AB_ARGS:-} > $O/run_$v.log 2>&1
+    f=$(find $O/p_$v -name '*_results.db' | head -1)
+    python tools/prof_summary.py $f $v 2>/dev/null | grep -E "$re" >> $O/ab.log
+    grep -o '"ms_per_step": [0-9.]*' $O/run_$v.log | head -1 >> $O/ab.log
+    rm -rf $O/p_$v
+  done; done
+  cat $O/ab.log ;;
+pmc)
+  cfg=$1; cnt=$2; shift 2
+  timeout 300 rocprofv3 --kernel-trace --pmc $cnt -d $O/pmc_${cfg}_$cnt -o $cnt --output-format csv -- python bench.py --config $cfg --steps 3 --warmup 1 --no-extra "$@" > $O/pmc_${cfg}_$cnt.log 2>&1
+  f=$(find $O/pmc_${cfg}_$cnt -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && { echo "## $cfg $cnt"; python tools/pmc_summary.py "$f"; } | tee -a $O/pmc_summary.txt | cut -c1-200
+  clean ;;
+smoke)
+  python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc $?" >> $O/smoke.log; tail -n 3 $O/smoke.log ;;
+*) echo "unknown verb $verb"; exit 2 ;;
+esac

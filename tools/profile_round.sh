@@ -1,10 +1,12 @@
 #!/bin/bash
-# Round-3 profile pass (run on the GPU box through gpurun): kernel-trace stats of the bench commands of c1 .. c5, HBM-traffic PMC passes of
+# End-of-round profile pass (run on the GPU box through gpurun): kernel-trace stats of the bench commands of c1 .. c5, HBM-traffic PMC passes of
 # their dominant kernels (separate rocprofv3 runs, kernel-trace only, as MI355X_MICROARCH.md prescribes), a FETCH_SIZE / WRITE_SIZE
-# calibration on a copy of known size, bench lines.  Everything under gpurun_out/r03/; tools/r03_collect.py turns it into profiles/r03_*.
+# calibration on a copy of known size, bench lines.  usage: tools/profile_round.sh r04 -> everything under gpurun_out/r04/;
+# tools/collect_round.py r04 turns it into profiles/r04_*.
 set -u
 export TMPDIR=/tmp
-O=gpurun_out/r03
+TAG=${1:?round tag, e.g. r04}
+O=gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
 python -c "import bench; print(bench.source_id())" > $O/source_id.txt
 for cfg in c1 c2 c3 c4 c5; do
