@@ -112,10 +112,12 @@ class StepMarks:
     device) for everything the handle has queued so far and an event is recorded there; the differences of consecutive events are
     the intervals at which the steps completed.  Costs two event operations per step on the host, nothing on the handle's streams."""
 
-    def __init__(self, torch, wait):
-        self.torch, self.wait, self.side, self.ev = torch, wait, torch.cuda.Stream(), []
+    def __init__(self, torch, wait, enabled=True):
+        self.torch, self.wait, self.side, self.ev, self.enabled = torch, wait, torch.cuda.Stream(), [], enabled
 
     def mark(self):
+        if not self.enabled:
+            return
         self.wait(self.side.cuda_stream)
         e = self.torch.cuda.Event(enable_timing=True)
         e.record(self.side)
@@ -150,7 +152,7 @@ def run_workload(name, args, torch, q, ctx, dev, rank, world, overlap=None, chec
     if world > 1:
         torch.distributed.barrier()
     dem.profile(True)
-    marks = StepMarks(torch, dem.stream_wait)
+    marks = StepMarks(torch, dem.stream_wait, enabled=not args.no_marks)
     marks.mark()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -301,7 +303,7 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, c
         ch = q.Channelizer(ctx, M, batch=B, max_chunk=n)
         ch.enable_4fsk()
         if args.legacy_pfb:
-            ch.set_option(q.CHAN_OPT_LEGACY_PFB, 1)
+            ch.set_option(q.CHAN_OPT_LEGACY_PFB, args.legacy_pfb)
         step, sync, prof = (lambda: ch.process_async(iq)), ch.sync, ch
         handles = [ch]
     else:
@@ -335,7 +337,7 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, c
             tail.sync()
         prof, handles = ch, [ch, tail]
     prof.profile(True)
-    marks = StepMarks(torch, handles[-1].stream_wait)
+    marks = StepMarks(torch, handles[-1].stream_wait, enabled=not args.no_marks)
     dt = timed_loop(step, sync, args, torch, dev, world, marks)
     kms, launches, kname = prof.profile_read()
     launches_timed = args.steps
@@ -445,7 +447,7 @@ def run_c5(args, torch, q, ctx, dev, rank, world, steps=None, check=False):
     def sync():
         mod.sync()
         dem.sync()
-    marks = StepMarks(torch, dem.stream_wait)
+    marks = StepMarks(torch, dem.stream_wait, enabled=not args.no_marks)
     dt = timed_loop(both, sync, args, torch, dev, world, marks)
     dem.profile(True)
     dt_rx = timed_loop(lambda: dem.process_async(iq), sync, args, torch, dev, world)
@@ -593,8 +595,9 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="(the library default since round 3; kept for the tools/ scripts)")
     ap.add_argument("--no-overlap", action="store_true", help="C1 only: QRL_OPT_OVERLAP = 0 (the kernels of a call strictly one after the other)")
     ap.add_argument("--fll-slim", action="store_true", help="tuning, c1: QRL_OPT_FLL_SLIM = 1 (single-wave FLL workgroups)")
+    ap.add_argument("--no-marks", action="store_true", help="no per-step completion events (step_spread_ms = null)")
     ap.add_argument("--check", action="store_true", help="with --no-extra: still run the parity check against the oracle at the bench shape")
-    ap.add_argument("--legacy-pfb", action="store_true", help="A/B, c4: QRL_CHAN_OPT_LEGACY_PFB = 1 (general-M channelizer kernel)")
+    ap.add_argument("--legacy-pfb", type=int, default=0, help="A/B, c4: QRL_CHAN_OPT_LEGACY_PFB (1 = general-M channelizer kernel, 2 = the tiled 64-channel kernel of round 3)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

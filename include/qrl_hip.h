@@ -235,7 +235,8 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** out);
 void qrl_chan_destroy(qrl_chan* c);
 int qrl_chan_reset(qrl_chan* c);
 /* kernel selection for A/B measurements and tests (results are identical): QRL_CHAN_OPT_LEGACY_PFB = 1 runs the general-M
- * channelizer kernel also for the 64-channel geometry; QRL_CHAN_OPT_LEGACY_TAIL = 1 runs the per-channel chain as separate kernels
+ * channelizer kernel also for the 64-channel geometry, = 2 the tiled 64-channel kernel of round 3 (0, the default: the streaming
+ * kernel k_pfb_stream64 when the rows are 16-byte aligned); QRL_CHAN_OPT_LEGACY_TAIL = 1 runs the per-channel chain as separate kernels
  * instead of the fused feed-forward kernel -- only before the first samples of a stream or after qrl_chan_reset (QRL_ERR_STATE
  * otherwise: the fused kernel does not fill the intermediate rings the separate kernels take their history from). */
 enum { QRL_CHAN_OPT_LEGACY_PFB = 1, QRL_CHAN_OPT_LEGACY_TAIL = 2 };

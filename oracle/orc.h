@@ -188,6 +188,7 @@ size_t orc_demod_dmr_port3(const cf32* in, size_t n, int samp_rate, float* out);
 void orc_4fsk_symbols_to_bits(const float* sym, size_t nsym, cf32* constellation, uint8_t* bits);
 /* multi-carrier MMDVM RX (gr_demod_mmdvm_multi2): PFB channelizer + per-channel 24/25 resampler, LPF, FM discriminator, int16 */
 int    orc_chan_proto_taps(int M, float* taps);
+void orc_chan_twiddles(int M, cf32* W);   /* exactly conjugate-symmetric DFT twiddles (channelizer contract) */
 size_t orc_pfb_channelizer(const cf32* in, size_t n, const float* taps, int nt, int M, cf32* out);
 size_t orc_demod_mmdvm_multi(const cf32* in, size_t n, int M, int16_t* out, size_t cap);
 

@@ -937,20 +937,29 @@ double orc_batch_rx(int mode, const cf32* iq, int batch, size_t n, int samp_rate
  *
  * pfb_channelizer_ccf [gr-filter/lib/pfb_channelizer_ccf_impl.cc, polyphase_filterbank.cc], oversample 1:
  *   branch p: taps h[p + M k];  v_p[n] = sum_k h[p + M k] * x[M n - p - M k]   (one fmaf chain, k ascending)
- *   channel c: y_c[n] = sum_{p=0}^{M-1} v_p[n] * W[(p c) mod M],  W[q] = exp(+j 2 pi q / M)  rounded to float,
- *   each product computed as (re, im) = (fmaf(v.re, w.re, -(v.im*w.im)), fmaf(v.re, w.im, v.im*w.re)) and
- *   accumulated p ascending with plain adds.  (Upstream runs an unnormalised backward FFTW of size M; any FFT
- *   factorisation rounds differently, so the direct sum is the contract.) */
+ *   channel c: y_c[n] = sum_{p=0}^{M-1} v_p[n] * W[(p c) mod M],  W = orc_chan_twiddles (exp(+j 2 pi q / M) rounded to float, exactly
+ *   conjugate symmetric), as FOUR real fmaf chains over the branches, p ascending -- sa = sum W.re v.re, sb = sum W.im v.im,
+ *   sc = sum W.im v.re, sd = sum W.re v.im -- and y = (sa - sb, sc + sd).  (Upstream runs an unnormalised backward FFTW of size M;
+ *   any FFT factorisation rounds differently, so the direct sum is the contract.) */
 int orc_chan_proto_taps(int M, float* taps)
 {
     return orc_low_pass_2(1, 25000.0 * M, 5000, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, taps);
+}
+/* DFT twiddles of the channelizer contract: W[q] = exp(+j 2 pi q / M) rounded to float for q <= M/2, with sin(pi) = 0 exactly
+ * (libm returns 1.2e-16 for the rounded argument), and W[M - q] = conj(W[q]) above: an exactly conjugate-symmetric table, as a
+ * twiddle generator that exploits the symmetry produces it.  Consequence used by the GPU kernel: the four summation chains of
+ * bin M - c equal those of bin c with sb and sc negated, bit for bit. */
+void orc_chan_twiddles(int M, cf32* W)
+{
+    for (int q = 0; q <= M / 2; q++) { W[q].re = (float)cos(2 * M_PI * q / M); W[q].im = (2 * q == M) ? 0.0f : (float)sin(2 * M_PI * q / M); }
+    for (int q = M / 2 + 1; q < M; q++) { W[q].re = W[M - q].re; W[q].im = -W[M - q].im; }
 }
 size_t orc_pfb_channelizer(const cf32* in, size_t n, const float* taps, int nt, int M, cf32* out /* [M][n/M] */)
 {
     orc_trace_event("pfb_channelizer(%d,%s,1)", M, orc_trace_name(taps, sizeof(float) * (size_t)nt));   /* critically sampled */
     const size_t nout = n / (size_t)M;
     cf32* W = NEW(cf32, M);
-    for (int q = 0; q < M; q++) { W[q].re = (float)cos(2 * M_PI * q / M); W[q].im = (float)sin(2 * M_PI * q / M); }
+    orc_chan_twiddles(M, W);
     cf32* v = NEW(cf32, M);
     for (size_t m = 0; m < nout; m++) {
         for (int p = 0; p < M; p++) {

@@ -131,8 +131,12 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     std::vector<float> t((size_t)h->J * M, 0.0f);
     for (int k = 0; k < h->nt; ++k) t[k] = proto[k];
     if ((r = h->taps.upload(t))) return r;
+    // W[q] = e^{+j 2 pi q / M} rounded to float, made EXACTLY conjugate symmetric (contract, oracle/orc_chains.c orc_chan_twiddles):
+    // entries above M/2 mirror those below, and sin(pi) is 0, not the 1.2e-16 libm returns for the rounded argument -- so that the
+    // four summation chains of bin M - c are those of bin c with two signs flipped, bit for bit (k_pfb_stream64 computes half the bins)
     std::vector<float2> W(M);
-    for (int q = 0; q < M; ++q) W[q] = make_float2((float)std::cos(2 * M_PI * q / M), (float)std::sin(2 * M_PI * q / M));
+    for (int q = 0; q <= M / 2; ++q) W[q] = make_float2((float)std::cos(2 * M_PI * q / M), (2 * q == M) ? 0.0f : (float)std::sin(2 * M_PI * q / M));
+    for (int q = M / 2 + 1; q < M; ++q) W[q] = make_float2(W[M - q].x, -W[M - q].y);
     if ((r = h->twiddle.upload(W))) return r;
     // multi2: :60-61, used as 24/25 resampler.  single carrier: gr_demod_mmdvm.cpp:43-45, 12/125 from MMDVM_SAMPLE_RATE = 250 ksps
     if (h->single) { h->rs_I = 12; h->rs_D = 125; }
@@ -227,7 +231,7 @@ int qrl_chan_reset(qrl_chan* h)
 int qrl_chan_set_option(qrl_chan* h, int option, int value)
 {
     if (!h) return QRL_ERR_ARG;
-    if (option == QRL_CHAN_OPT_LEGACY_PFB) h->opt_legacy_pfb = value != 0;
+    if (option == QRL_CHAN_OPT_LEGACY_PFB) h->opt_legacy_pfb = value < 0 || value > 2 ? 0 : value;
     else if (option == QRL_CHAN_OPT_LEGACY_TAIL) {
         // the fused per-channel kernel does not fill the intermediate rings the separate kernels read their history from: only before the first samples
         if (h->n_in != 0 || h->n2 != 0) return qrl_set_error(QRL_ERR_STATE, "QRL_CHAN_OPT_LEGACY_TAIL: only before the first call (or after qrl_chan_reset)");

@@ -193,7 +193,7 @@ def test_channelizer_64_4fsk_tail_rssi_bit_exact(qrl_ctx, cuts):
     iq = _wideband(M, n, seed=164, nstreams=2)
     t = np.arange(n)
     dibs = {}
-    for c, seed in ((1, 5), (33, 6), (62, 7)):
+    for c, seed in ((1, 5), (33, 6), (62, 7)):     # (channels 54, 7, 57, 44, 41 of stream 0 carry _wideband's FM carriers)
         x, d = sig.make_4fsk(nsym=int(n / fs * 4800) - 2, seed=seed, amp=0.4, noise=0.0, fs=fs)
         f0 = c * 25000.0 if c <= M // 2 else (c - M) * 25000.0
         m = min(n, x.size)
@@ -472,15 +472,15 @@ def test_literal_c4_freq_xlating_bank_64_channels_bit_exact(qrl_ctx, chunk):
 
 @pytest.mark.parametrize("chunk", [64 * 2500, 64 * 777])
 def test_channelizer_64_legacy_kernel_and_ragged_calls(qrl_ctx, chunk):
-    """M = 64 runs on k_pfb_chan64 (register-blocked branch FIRs) by default; QRL_CHAN_OPT_LEGACY_PFB = 1 keeps the general-M kernel
-    reachable for A/B runs.  Both must equal the oracle, also when the stream is cut into calls that are not a multiple of the
-    32-instant tile (history path + ragged last tile)."""
+    """M = 64 runs on the streaming kernel k_pfb_stream64 by default; QRL_CHAN_OPT_LEGACY_PFB = 1 keeps the general-M kernel and = 2
+    the tiled k_pfb_chan64 of round 3 reachable for A/B runs.  All three must equal the oracle, also when the stream is cut into calls
+    that are not a multiple of the 16- / 32-instant tiles (history path + ragged last tile)."""
     import torch
     import qradiolink_amd as q
     M, n = 64, 64 * 2500
     iq = _wideband(M, n, seed=77, nstreams=2)
     ref = [orc.demod_mmdvm_multi(iq[b], M) for b in range(2)]
-    for legacy in (0, 1):
+    for legacy in (0, 1, 2):
         ch = q.Channelizer(qrl_ctx, M, batch=2, max_chunk=chunk)
         ch.set_option(q.CHAN_OPT_LEGACY_PFB, legacy)
         d = torch.from_numpy(iq).cuda()
