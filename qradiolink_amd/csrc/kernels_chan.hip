@@ -245,22 +245,26 @@ __global__ __launch_bounds__(256, 3) void k_pfb_chan64(const ChanParams P)
 // input bytes), re-loaded the 35 taps of its branch and the twiddles, and spent as much matrix-pipe time on bins 33..63 as on their
 // mirror images.  Here a workgroup is PERSISTENT: it walks one segment of one wideband stream (grid = segments x streams, sized to the
 // chip: 3 workgroups per CU) in tiles of 16 output instants and
-//   * keeps the input in an LDS RING of 64 blocks of 64 samples (32 KiB): per tile only the 16 NEW blocks are fetched, with LDS-DMA
-//     (global_load_lds_dwordx4, 1 KiB pieces, issued one tile ahead: 6 pieces before the branch FIRs -- their ring slots are dead --
-//     and the 2 pieces that alias the oldest halo blocks after them); the input is read from HBM once (+ 35 blocks per segment);
+//   * keeps the input in an LDS RING of 80 blocks of 64 samples (40 KiB): per tile only the 16 NEW blocks are fetched, with LDS-DMA
+//     (global_load_lds_dwordx4, eight 1 KiB pieces issued a whole tile ahead: 51 live blocks + 16 in flight fit the ring, nothing
+//     aliases); the input is read from HBM once (+ 35 blocks per segment);
 //   * keeps the taps of the lane's branch (35 registers) and the wave's DFT operand (32 registers) for its whole life;
 //   * phase 1 (VALU): lane = branch p, wave w = instants 4 w .. 4 w + 3: v_p[m] = sum_k h[p + 64 k] x[64 (m - k) - p], one packed-fma
-//     chain per output (k ascending), every LDS sample feeding up to four chains;
+//     chain per output (k ascending), every LDS sample feeding up to four chains; the block part of an address is wave uniform
+//     (scalar ALU), one v_add per read;
 //   * phase 2 (matrix pipe): wave = (16 bins, 8 instants).  The B operand carries v.re of the 8 instants in columns 0..7 and v.im in
 //     columns 8..15, so TWO accumulators give all four chains of the contract: X = Wre * [vre | vim] = [sa | sd], Y = Wim * [vre | vim]
 //     = [sc | sb]; a DPP row rotation by 8 brings the partner column: P = X - rot(Y), Q = Y + rot(X) are (sa - sb, sc + sd) = y[bin]
 //     in the low columns and (sd - sc, sa + sb) in the high ones -- which is y[64 - bin] with re / im swapped, bit for bit: the
-//     twiddle table is exactly conjugate symmetric (engine.hpp chan_twiddles), so the chains of bin 64 - c are those of bin c with
+//     twiddle table is exactly conjugate symmetric (oracle orc_chan_twiddles), so the chains of bin 64 - c are those of bin c with
 //     sb, sc negated.  Bins 1..31 and 33..63 therefore cost 32 matrix instructions per 16 x 8 outputs instead of 128; bin 32
 //     (W = +-1, 0) is an alternating add chain on the VALU of one wave per tile.
-// Ring position of block beta = (beta - (m_lo - 48)) & 63: tile t owns positions (48 + 16 t) & 63 ...; lane p >= 1 reads block
-// m - k - 1 at offset 64 - p, lane 0 block m - k at offset 0 (= one sample further: the "& 32767" of the address).
-constexpr int S64_T = 16, S64_VP = 66;
+// Ring position of block beta = (beta - (m_lo - 64)) mod 80: tile t owns positions (64 + 16 t) mod 80 ...; lane p >= 1 reads block
+// m - k - 1 at offset 64 - p, lane 0 block m - k at offset 0 = ONE SAMPLE behind the end of block m - k - 1: positions 80, 81 mirror
+// positions 0, 1 (the piece that lands there is issued twice), so that lane 0 needs no wrap of its own.
+// Order inside a tile: issue the next tile's pieces -> FIRs -> barrier -> bin 32 and matrix phase -> wait for the pieces (and for the
+// PREVIOUS tile's stores) -> this tile's stores -> barrier: a wave never waits for the acknowledgement of stores it has just issued.
+constexpr int S64_T = 16, S64_VP = 66, S64_RB = 80;
 typedef float v2f_ch __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) v2f_ch* s64_lds_v2;
 __device__ __forceinline__ void s64_glds16(const void* gsrc, uint32_t lds_dst)
@@ -275,8 +279,8 @@ __global__ __launch_bounds__(256, 3) void k_pfb_stream64(const ChanParams P, uin
 {
     constexpr int M = 64;
     extern __shared__ __align__(16) unsigned char ch_smem[];
-    float2* xs = reinterpret_cast<float2*>(ch_smem);              // ring: 64 blocks x 64 samples
-    float2* vs = xs + 64 * 64;                                    // [16 instants][VP] branch outputs
+    float2* xs = reinterpret_cast<float2*>(ch_smem);              // ring: 80 blocks x 64 samples + 2 mirror blocks
+    float2* vs = xs + (S64_RB + 2) * 64;                          // [16 instants][VP] branch outputs
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t m_end = P.m0 + P.m_count;
@@ -286,6 +290,8 @@ __global__ __launch_bounds__(256, 3) void k_pfb_stream64(const ChanParams P, uin
     const int ntiles = (int)((m_hi - m_lo + S64_T - 1) / S64_T);
     const uint64_t nb_end = (P.n0 + P.n) >> 6;                    // blocks [n0 / 64, nb_end) lie in the caller's buffer
     const float2* row = P.in + (size_t)b * P.in_stride;
+    const uint32_t xs_base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)xs;
+    if (xs_base != 0) __builtin_trap();                          // the kernel has no static LDS: the dynamic segment (= the ring) starts at 0
     // taps of this lane's branch and the wave's DFT operand (rows = bins 16 bb + (lane & 15), k = 4 s + (lane >> 4)): registers, once
     float h[J];
 #pragma unroll
@@ -297,11 +303,11 @@ __global__ __launch_bounds__(256, 3) void k_pfb_stream64(const ChanParams P, uin
         const float2 w2 = P.twiddle[((16 * bb + n16) * (4 * s + k4)) & 63];
         are[s] = w2.x; aim[s] = w2.y;
     }
-    // prologue: halo blocks m_lo - 35 .. m_lo - 1 and the first tile's 16 blocks (ring positions 13 .. 63), checked element loads
+    // prologue: halo blocks m_lo - 35 .. m_lo - 1 and the first tile's 16 blocks (ring positions 29 .. 79), checked element loads
     {
-        const int64_t beta0 = (int64_t)m_lo - 48;
+        const int64_t beta0 = (int64_t)m_lo - 64;
         for (int i = tid; i < 51 * 64; i += 256) {
-            const int rel = 13 + (i >> 6);
+            const int rel = 29 + (i >> 6);
             const int64_t a = (beta0 + rel) * 64 + (i & 63);
             float2 x = make_float2(0.f, 0.f);
             if (a >= 0 && (uint64_t)a < P.n0 + P.n) {
@@ -314,8 +320,6 @@ __global__ __launch_bounds__(256, 3) void k_pfb_stream64(const ChanParams P, uin
             xs[rel * 64 + (i & 63)] = x;
         }
     }
-    const uint32_t xs_base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)xs;
-    if (xs_base != 0) __builtin_trap();                          // the kernel has no static LDS: the dynamic segment (= the ring) starts at 0
     const uint32_t vlane = lane == 0 ? 512u : (uint32_t)(64 - lane) * 8u;      // byte offset relative to block (m - k - 1)
     // output rows of this lane's four matrix results: low columns (n16 < 8) -> bin 16 bb + 4 k4 + r, high columns -> its mirror image 64 - bin
     // (chan_out_addr's row arithmetic, once per workgroup: per tile only the column changes)
@@ -340,26 +344,36 @@ __global__ __launch_bounds__(256, 3) void k_pfb_stream64(const ChanParams P, uin
     const bool nyq_on = P.c_first <= 32 && 32 < P.c_first + P.c_count;
     float* nyq_row = reinterpret_cast<float*>(out_row(nyq_on ? 32 - P.c_first : 0)) + (lane & 1);
     __syncthreads();
+    int rb = 64;                                                  // ring position of the tile's first block: (64 + 16 t) mod 80
     for (int t = 0; t < ntiles; ++t) {
         const uint64_t a = m_lo + (uint64_t)t * S64_T;            // first instant of the tile
-        const int rb = (48 + 16 * t) & 63;                        // its ring position
+        const int rn = rb + 16 >= S64_RB ? rb + 16 - S64_RB : rb + 16;   // position of the next tile's first block
         const bool more = t + 1 < ntiles;
         const bool dma_next = more && a + 32 <= nb_end;           // the next tile's 16 blocks lie inside the buffer
-        const unsigned char* gnext = reinterpret_cast<const unsigned char*>(row + ((a + 16) * 64 - P.n0)) + lane * 16;
-        if (dma_next) {                                           // early pieces 0..5: positions rb + 16 .. rb + 27 hold blocks a - 48 .. a - 37 (dead)
-            s64_glds16(gnext + wv * 1024, xs_base + (uint32_t)((rb + 16 + 2 * wv) & 63) * 512u);
-            if (wv < 2) s64_glds16(gnext + (4 + wv) * 1024, xs_base + (uint32_t)((rb + 24 + 2 * wv) & 63) * 512u);
+        if (dma_next) {                                           // positions rn .. rn + 15 hold blocks a - 64 .. a - 49: dead (live: a - 35 .. a + 15)
+            const unsigned char* gnext = reinterpret_cast<const unsigned char*>(row + ((a + 16) * 64 - P.n0)) + lane * 16;
+            s64_glds16(gnext + wv * 1024, (uint32_t)(rn + 2 * wv) * 512u);
+            s64_glds16(gnext + (4 + wv) * 1024, (uint32_t)(rn + 8 + 2 * wv) * 512u);
+            if (rn == 0 && wv == 0) s64_glds16(gnext, (uint32_t)S64_RB * 512u);   // mirror of positions 0, 1
+        } else if (more) {                                        // next tile reaches past the buffer (ragged end of a call): checked element loads
+            for (int i = tid; i < 16 * 64; i += 256) {
+                const uint64_t sa_ = (a + 16) * 64 + (uint64_t)i;
+                const float2 x = sa_ < P.n0 + P.n ? row[(size_t)(sa_ - P.n0)] : make_float2(0.f, 0.f);
+                xs[(rn + (i >> 6)) * 64 + (i & 63)] = x;
+                if (rn == 0 && i < 128) xs[(S64_RB + (i >> 6)) * 64 + (i & 63)] = x;
+            }
         }
         // ---- phase 1: branch FIRs of instants a + 4 wv + r
         {
             v2f_ch acc[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] = v2f_ch{0.f, 0.f};
-            const int e0 = rb + 4 * wv + 63;                      // (+ 64 - 1: block m - k - 1, kept positive)
+            const int e0 = rb + 4 * wv + (S64_RB - 1);            // (block m - k - 1 of r = k; + 80 keeps the sum positive)
 #pragma unroll
             for (int d = 3; d >= -(J - 1); --d) {
-                const uint32_t u = ((uint32_t)(e0 + d) & 63u) << 9;
-                const v2f_ch x = *(s64_lds_v2)(uintptr_t)((u + vlane) & 32767u);   // (the ring starts at LDS address 0: checked above)
+                int e = e0 + d;                                   // 45 .. 158, wave uniform
+                e = e >= S64_RB ? e - S64_RB : e;
+                const v2f_ch x = *(s64_lds_v2)(uintptr_t)((uint32_t)e * 512u + vlane);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int k = r - d;
@@ -370,59 +384,55 @@ __global__ __launch_bounds__(256, 3) void k_pfb_stream64(const ChanParams P, uin
             for (int r = 0; r < 4; ++r) vs[(4 * wv + r) * S64_VP + lane] = make_float2(acc[r].x, acc[r].y);
         }
         __syncthreads();
-        if (dma_next) {                                           // late pieces 6, 7: positions rb + 28 .. rb + 31 held blocks a - 36 .. a - 33 (read by phase 1)
-            if (wv >= 2) s64_glds16(gnext + (4 + wv) * 1024, xs_base + (uint32_t)((rb + 24 + 2 * wv) & 63) * 512u);
-        } else if (more) {                                        // next tile reaches past the buffer (ragged end of a call): checked element loads
-            for (int i = tid; i < 16 * 64; i += 256) {
-                const uint64_t sa_ = (a + 16) * 64 + (uint64_t)i;
-                xs[((rb + 16 + (i >> 6)) & 63) * 64 + (i & 63)] = sa_ < P.n0 + P.n ? row[(size_t)(sa_ - P.n0)] : make_float2(0.f, 0.f);
-            }
-        }
         // ---- bin 32: W[(32 p) & 63] = (+1, 0), (-1, 0): sa, sd are alternating add chains, sb = sc = +0 (one wave per tile)
-        if (wv == (t & 3) && nyq_on) {
-            if (lane < 32) {
-                const int inst = lane >> 1, comp = lane & 1;
-                const float* vp = vsf + inst * (2 * S64_VP) + comp;
-                float sgn = 0.f;
+        float ynyq = 0.f;
+        const bool nyq_here = wv == (t & 3) && nyq_on;
+        if (nyq_here && lane < 32) {
+            const float* vp = vsf + (lane >> 1) * (2 * S64_VP) + (lane & 1);
+            float sgn = 0.f;
 #pragma unroll 1
-                for (int p = 0; p < M; p += 8) {                  // (rolled: unrolled, the 64 LDS reads are hoisted into 64 registers)
-                    float v[8];
+            for (int p = 0; p < M; p += 8) {                      // (rolled: unrolled, the 64 LDS reads are hoisted into 64 registers)
+                float v[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = vp[2 * (p + i)];
+                for (int i = 0; i < 8; ++i) v[i] = vp[2 * (p + i)];
 #pragma unroll
-                    for (int i = 0; i < 8; i += 2) { sgn = fmaf(1.0f, v[i], sgn); sgn = fmaf(-1.0f, v[i + 1], sgn); }
-                }
-                const float zero = 0.0f;
-                const float y = comp ? zero + sgn : sgn - zero;   // (sa - sb, sc + sd)
-                const uint64_t m = a + inst;
-                if (m < m_hi) nyq_row[2 * (P.out_pitch ? (size_t)(m - P.m0) : (size_t)((uint32_t)m & P.out.mask))] = y;
+                for (int i = 0; i < 8; i += 2) { sgn = fmaf(1.0f, v[i], sgn); sgn = fmaf(-1.0f, v[i + 1], sgn); }
             }
+            const float zero = 0.0f;
+            ynyq = (lane & 1) ? zero + sgn : sgn - zero;          // (sa - sb, sc + sd)
         }
         // ---- phase 2: bins 16 bb .. 16 bb + 15 (and their mirror images) of instants a + 8 oct .. + 7
-        {
-            f32x4_t X = {0.f, 0.f, 0.f, 0.f}, Y = X;
+        f32x4_t X = {0.f, 0.f, 0.f, 0.f}, Y = X;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float v = vsf[bofs + 8 * s];
-                X = __builtin_amdgcn_mfma_f32_16x16x4f32(are[s], v, X, 0, 0, 0);
-                Y = __builtin_amdgcn_mfma_f32_16x16x4f32(aim[s], v, Y, 0, 0, 0);
-            }
+        for (int s = 0; s < 16; ++s) {
+            const float v = vsf[bofs + 8 * s];
+            X = __builtin_amdgcn_mfma_f32_16x16x4f32(are[s], v, X, 0, 0, 0);
+            Y = __builtin_amdgcn_mfma_f32_16x16x4f32(aim[s], v, Y, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next tile's pieces (this wave's) have landed; the stores waited for are the PREVIOUS tile's
+        {
             const uint64_t m = a + 8 * oct + col;
             const size_t ocol = P.out_pitch ? (size_t)(m - P.m0) : (size_t)((uint32_t)m & P.out.mask);
             const uint32_t okm = m < m_hi ? ovalid : 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float Xr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, X[r]), 0x128, 0xf, 0xf, false));   // row_ror:8
-                const float Yr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, Y[r]), 0x128, 0xf, 0xf, false));
-                const float Pv = X[r] - Yr, Qv = Y[r] + Xr;
+                // (element copies first: __builtin_bit_cast applied to a vector-element expression reads element 0 with this compiler)
+                const float xe = X[r], ye = Y[r];
+                const float Xr = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xe), 0x128, 0xf, 0xf, false));   // row_ror:8
+                const float Yr = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ye), 0x128, 0xf, 0xf, false));
+                const float Pv = xe - Yr, Qv = ye + Xr;
                 if (okm >> r & 1u) orow[r][ocol] = lo ? make_float2(Pv, Qv) : make_float2(Qv, Pv);
             }
+            if (nyq_here && lane < 32) {
+                const uint64_t mn = a + (lane >> 1);
+                if (mn < m_hi) nyq_row[2 * (P.out_pitch ? (size_t)(mn - P.m0) : (size_t)((uint32_t)mn & P.out.mask))] = ynyq;
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next tile's pieces have landed (this wave's)
-        __syncthreads();                                          // ... everybody's; vs is free again
+        __syncthreads();                                          // everybody's pieces have landed; vs is free again
+        rb = rn;
     }
 }
-size_t stream64_lds_bytes() { return (size_t)(64 * 64 + S64_T * S64_VP) * sizeof(float2); }
+size_t stream64_lds_bytes() { return (size_t)((S64_RB + 2) * 64 + S64_T * S64_VP) * sizeof(float2); }
 
 // caller buffer [rows][pitch] -> engine ring rows at absolute items [q0, q0 + count): how the per-channel-only handle (form 3) takes
 // the channel samples an all-to-all delivered
