@@ -245,9 +245,10 @@ __global__ __launch_bounds__(256, 3) void k_pfb_chan64(const ChanParams P)
 // input bytes), re-loaded the 35 taps of its branch and the twiddles, and spent as much matrix-pipe time on bins 33..63 as on their
 // mirror images.  Here a workgroup is PERSISTENT: it walks one segment of one wideband stream (grid = segments x streams, sized to the
 // chip: 3 workgroups per CU) in tiles of 16 output instants and
-//   * keeps the input in an LDS RING of 80 blocks of 64 samples (40 KiB): per tile only the 16 NEW blocks are fetched, with LDS-DMA
-//     (global_load_lds_dwordx4, eight 1 KiB pieces issued a whole tile ahead: 51 live blocks + 16 in flight fit the ring, nothing
-//     aliases); the input is read from HBM once (+ 35 blocks per segment);
+//   * keeps the input in an LDS RING of 84 blocks of 64 samples (42 KiB): per tile only the 16 NEW blocks are fetched, with LDS-DMA
+//     (global_load_lds_dwordx4, eight 1 KiB pieces issued TWO tiles ahead: 51 live blocks + 32 in flight fit the ring, nothing
+//     aliases; one tile in flight per workgroup left every tile waiting for the memory latency); the input is read from HBM once
+//     (+ 35 blocks per segment);
 //   * keeps the taps of the lane's branch (35 registers) and the wave's DFT operand (32 registers) for its whole life;
 //   * phase 1 (VALU): lane = branch p, wave w = instants 4 w .. 4 w + 3: v_p[m] = sum_k h[p + 64 k] x[64 (m - k) - p], one packed-fma
 //     chain per output (k ascending), every LDS sample feeding up to four chains; the block part of an address is wave uniform
@@ -259,12 +260,18 @@ __global__ __launch_bounds__(256, 3) void k_pfb_chan64(const ChanParams P)
 //     twiddle table is exactly conjugate symmetric (oracle orc_chan_twiddles), so the chains of bin 64 - c are those of bin c with
 //     sb, sc negated.  Bins 1..31 and 33..63 therefore cost 32 matrix instructions per 16 x 8 outputs instead of 128; bin 32
 //     (W = +-1, 0) is an alternating add chain on the VALU of one wave per tile.
-// Ring position of block beta = (beta - (m_lo - 64)) mod 80: tile t owns positions (64 + 16 t) mod 80 ...; lane p >= 1 reads block
-// m - k - 1 at offset 64 - p, lane 0 block m - k at offset 0 = ONE SAMPLE behind the end of block m - k - 1: positions 80, 81 mirror
+// Ring position of block beta = (beta - (m_lo - 64)) mod RB: tile t owns positions (64 + 16 t) mod RB ...; lane p >= 1 reads block
+// m - k - 1 at offset 64 - p, lane 0 block m - k at offset 0 = ONE SAMPLE behind the end of block m - k - 1: positions RB, RB + 1 mirror
 // positions 0, 1 (the piece that lands there is issued twice), so that lane 0 needs no wrap of its own.
-// Order inside a tile: issue the next tile's pieces -> FIRs -> barrier -> bin 32 and matrix phase -> wait for the pieces (and for the
-// PREVIOUS tile's stores) -> this tile's stores -> barrier: a wave never waits for the acknowledgement of stores it has just issued.
-constexpr int S64_T = 16, S64_VP = 66, S64_RB = 80;
+// Order inside a tile: issue the pieces of tile t + 2 -> FIRs -> barrier -> bin 32 and matrix phase -> s_waitcnt vmcnt(pieces just
+// issued): everything OLDER has completed, i.e. tile t + 1's pieces and the previous tile's stores -> this tile's stores -> barrier:
+// a wave never waits for the acknowledgement of stores it has just issued, and the count does not depend on how many stores ran.
+#ifndef QRL_S64_AHEAD
+#define QRL_S64_AHEAD 2          // tiles of input in flight per workgroup (1 or 2)
+#endif
+constexpr int S64_T = 16, S64_VP = 66;
+constexpr int S64_AHEAD = QRL_S64_AHEAD;
+constexpr int S64_RB = S64_AHEAD == 1 ? 80 : 84;                 // ring blocks: >= 51 live + 16 AHEAD in flight, a multiple of 4
 typedef float v2f_ch __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) v2f_ch* s64_lds_v2;
 __device__ __forceinline__ void s64_glds16(const void* gsrc, uint32_t lds_dst)
@@ -274,12 +281,21 @@ __device__ __forceinline__ void s64_glds16(const void* gsrc, uint32_t lds_dst)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+template <int N> __device__ __forceinline__ void s64_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+#ifdef QRL_S64_PROF
+// developer build (tools/chan_variants.sh name -DQRL_S64_PROF): shader-clock ticks per phase of the tile loop, summed over every wave
+__device__ unsigned long long g_s64_prof[8];
+#define S64_STAMP(k) do { const unsigned long long tn_ = __builtin_readcyclecounter(); pc[k] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define S64_STAMP(k) do { } while (0)
+#endif
+__device__ __forceinline__ int s64_wrap(int e) { return e >= S64_RB ? e - S64_RB : e; }
 template <int J>
 __global__ __launch_bounds__(256, 3) void k_pfb_stream64(const ChanParams P, uint32_t seg_len)
 {
     constexpr int M = 64;
     extern __shared__ __align__(16) unsigned char ch_smem[];
-    float2* xs = reinterpret_cast<float2*>(ch_smem);              // ring: 80 blocks x 64 samples + 2 mirror blocks
+    float2* xs = reinterpret_cast<float2*>(ch_smem);              // ring: RB blocks x 64 samples + 2 mirror blocks
     float2* vs = xs + (S64_RB + 2) * 64;                          // [16 instants][VP] branch outputs
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -293,9 +309,11 @@ __global__ __launch_bounds__(256, 3) void k_pfb_stream64(const ChanParams P, uin
     const uint32_t xs_base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)xs;
     if (xs_base != 0) __builtin_trap();                          // the kernel has no static LDS: the dynamic segment (= the ring) starts at 0
     // taps of this lane's branch and the wave's DFT operand (rows = bins 16 bb + (lane & 15), k = 4 s + (lane >> 4)): registers, once
-    float h[J];
+    // (as PAIRS (h[2 i], h[2 i + 1]): the packed fma broadcasts one half through op_sel; written as {h, h} vectors the compiler keeps
+    //  every tap twice, 70 registers)
+    v2f_ch hp[(J + 1) / 2];
 #pragma unroll
-    for (int k = 0; k < J; ++k) h[k] = P.taps[lane + M * k];
+    for (int k = 0; k < J; k += 2) hp[k / 2] = v2f_ch{P.taps[lane + M * k], k + 1 < J ? P.taps[lane + M * (k + 1)] : 0.f};
     const int bb = wv & 1, oct = wv >> 1, n16 = lane & 15, k4 = lane >> 4;
     float are[16], aim[16];
 #pragma unroll
@@ -303,6 +321,30 @@ __global__ __launch_bounds__(256, 3) void k_pfb_stream64(const ChanParams P, uin
         const float2 w2 = P.twiddle[((16 * bb + n16) * (4 * s + k4)) & 63];
         are[s] = w2.x; aim[s] = w2.y;
     }
+    // the 16 blocks of the tile that starts at instant a0 into ring positions r0 .. (mod RB): LDS-DMA when they lie inside the caller's
+    // buffer (returns the number of pieces THIS wave issued), checked element loads otherwise (ragged end of a call; returns 0)
+    auto fetch_tile = [&](uint64_t a0, int r0) -> int {
+        if (a0 + 16 <= nb_end) {
+            const unsigned char* g = reinterpret_cast<const unsigned char*>(row + (a0 * 64 - P.n0)) + lane * 16;
+            int nd = 0;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = wv + 4 * jj, pos = s64_wrap(r0 + 2 * j);            // even: a piece never straddles the ring's end
+                s64_glds16(g + j * 1024, (uint32_t)pos * 512u);
+                ++nd;
+                if (pos == 0) { s64_glds16(g + j * 1024, (uint32_t)S64_RB * 512u); ++nd; }   // mirror of positions 0, 1
+            }
+            return nd;
+        }
+        for (int i = tid; i < 16 * 64; i += 256) {
+            const uint64_t sa_ = a0 * 64 + (uint64_t)i;
+            const float2 x = sa_ < P.n0 + P.n ? row[(size_t)(sa_ - P.n0)] : make_float2(0.f, 0.f);
+            const int pos = s64_wrap(r0 + (i >> 6));
+            xs[pos * 64 + (i & 63)] = x;
+            if (pos < 2) xs[(S64_RB + pos) * 64 + (i & 63)] = x;
+        }
+        return 0;
+    };
     // prologue: halo blocks m_lo - 35 .. m_lo - 1 and the first tile's 16 blocks (ring positions 29 .. 79), checked element loads
     {
         const int64_t beta0 = (int64_t)m_lo - 64;
@@ -320,6 +362,7 @@ __global__ __launch_bounds__(256, 3) void k_pfb_stream64(const ChanParams P, uin
             xs[rel * 64 + (i & 63)] = x;
         }
     }
+    if (S64_AHEAD == 2 && ntiles > 1) (void)fetch_tile(m_lo + 16, s64_wrap(64 + 16));   // tile 1 (waited for at the end of tile 0)
     const uint32_t vlane = lane == 0 ? 512u : (uint32_t)(64 - lane) * 8u;      // byte offset relative to block (m - k - 1)
     // output rows of this lane's four matrix results: low columns (n16 < 8) -> bin 16 bb + 4 k4 + r, high columns -> its mirror image 64 - bin
     // (chan_out_addr's row arithmetic, once per workgroup: per tile only the column changes)
@@ -343,60 +386,85 @@ __global__ __launch_bounds__(256, 3) void k_pfb_stream64(const ChanParams P, uin
     }
     const bool nyq_on = P.c_first <= 32 && 32 < P.c_first + P.c_count;
     float* nyq_row = reinterpret_cast<float*>(out_row(nyq_on ? 32 - P.c_first : 0)) + (lane & 1);
+#ifdef QRL_S64_PROF
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+#endif
     __syncthreads();
-    int rb = 64;                                                  // ring position of the tile's first block: (64 + 16 t) mod 80
+    int rb = 64;                                                  // ring position of the tile's first block: (64 + 16 t) mod RB
     for (int t = 0; t < ntiles; ++t) {
         const uint64_t a = m_lo + (uint64_t)t * S64_T;            // first instant of the tile
-        const int rn = rb + 16 >= S64_RB ? rb + 16 - S64_RB : rb + 16;   // position of the next tile's first block
-        const bool more = t + 1 < ntiles;
-        const bool dma_next = more && a + 32 <= nb_end;           // the next tile's 16 blocks lie inside the buffer
-        if (dma_next) {                                           // positions rn .. rn + 15 hold blocks a - 64 .. a - 49: dead (live: a - 35 .. a + 15)
-            const unsigned char* gnext = reinterpret_cast<const unsigned char*>(row + ((a + 16) * 64 - P.n0)) + lane * 16;
-            s64_glds16(gnext + wv * 1024, (uint32_t)(rn + 2 * wv) * 512u);
-            s64_glds16(gnext + (4 + wv) * 1024, (uint32_t)(rn + 8 + 2 * wv) * 512u);
-            if (rn == 0 && wv == 0) s64_glds16(gnext, (uint32_t)S64_RB * 512u);   // mirror of positions 0, 1
-        } else if (more) {                                        // next tile reaches past the buffer (ragged end of a call): checked element loads
-            for (int i = tid; i < 16 * 64; i += 256) {
-                const uint64_t sa_ = (a + 16) * 64 + (uint64_t)i;
-                const float2 x = sa_ < P.n0 + P.n ? row[(size_t)(sa_ - P.n0)] : make_float2(0.f, 0.f);
-                xs[(rn + (i >> 6)) * 64 + (i & 63)] = x;
-                if (rn == 0 && i < 128) xs[(S64_RB + (i >> 6)) * 64 + (i & 63)] = x;
-            }
-        }
+        // the tile AHEAD: its positions hold blocks a + 16 AHEAD - RB ..: older than the oldest live block a - 35
+        int nd = 0;
+        if (t + S64_AHEAD < ntiles) nd = fetch_tile(a + 16 * S64_AHEAD, s64_wrap(s64_wrap(rb + 16 * S64_AHEAD)));
+        S64_STAMP(0);
         // ---- phase 1: branch FIRs of instants a + 4 wv + r
         {
             v2f_ch acc[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] = v2f_ch{0.f, 0.f};
-            const int e0 = rb + 4 * wv + (S64_RB - 1);            // (block m - k - 1 of r = k; + 80 keeps the sum positive)
+            const int e0 = rb + 4 * wv + (S64_RB - 1);            // (block m - k - 1 of r = k; + RB keeps the sum positive)
+            // the J + 3 samples the four windows share, read in groups of NBATCH that are issued one group ahead of their use (left to
+            // itself the compiler keeps two reads in flight and the phase waits for the LDS latency 19 times: 3700 of 9400 cycles per tile)
+            constexpr int NX = J + 3, NBATCH = 10, NG = (NX + NBATCH - 1) / NBATCH;
+            v2f_ch xv[NX];                                        // xv[i]: d = 3 - i
+            auto load_group = [&](int g) {
 #pragma unroll
-            for (int d = 3; d >= -(J - 1); --d) {
-                int e = e0 + d;                                   // 45 .. 158, wave uniform
-                e = e >= S64_RB ? e - S64_RB : e;
-                const v2f_ch x = *(s64_lds_v2)(uintptr_t)((uint32_t)e * 512u + vlane);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int k = r - d;
-                    if (k >= 0 && k < J) { const v2f_ch hh = {h[k], h[k]}; acc[r] = __builtin_elementwise_fma(hh, x, acc[r]); }
+                for (int i = g * NBATCH; i < (g + 1) * NBATCH && i < NX; ++i) {
+                    const int e = s64_wrap(s64_wrap(e0 + 3 - i)); // wave uniform: scalar ALU
+                    xv[i] = *(s64_lds_v2)(uintptr_t)((uint32_t)e * 512u + vlane);
                 }
+            };
+            load_group(0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) load_group(g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = g * NBATCH; i < (g + 1) * NBATCH && i < NX; ++i) {
+                    const int d = 3 - i;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = r - d;
+                        if (k >= 0 && k < J) {                    // acc[r] = fma((h[k], h[k]), x, acc[r]): one rounding per component, as fmaf
+                            if (k & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[r]) : "v"(hp[k / 2]), "v"(xv[i]));
+                            else       asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[r]) : "v"(hp[k / 2]), "v"(xv[i]));
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) vs[(4 * wv + r) * S64_VP + lane] = make_float2(acc[r].x, acc[r].y);
         }
+        S64_STAMP(1);
         __syncthreads();
+        S64_STAMP(2);
         // ---- bin 32: W[(32 p) & 63] = (+1, 0), (-1, 0): sa, sd are alternating add chains, sb = sc = +0 (one wave per tile)
         float ynyq = 0.f;
         const bool nyq_here = wv == (t & 3) && nyq_on;
         if (nyq_here && lane < 32) {
             const float* vp = vsf + (lane >> 1) * (2 * S64_VP) + (lane & 1);
             float sgn = 0.f;
-#pragma unroll 1
-            for (int p = 0; p < M; p += 8) {                      // (rolled: unrolled, the 64 LDS reads are hoisted into 64 registers)
-                float v[8];
+            // two batches of 8 reads in flight (software pipelined by hand; fully unrolled without the fences the compiler hoists all 64
+            // reads into 64 registers, rolled it waits for every batch: 8 x LDS latency on the workgroup's critical path)
+            float va[8], vb[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = vp[2 * (p + i)];
+            for (int i = 0; i < 8; ++i) va[i] = vp[2 * i];
 #pragma unroll
-                for (int i = 0; i < 8; i += 2) { sgn = fmaf(1.0f, v[i], sgn); sgn = fmaf(-1.0f, v[i + 1], sgn); }
+            for (int p = 0; p < M; p += 16) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) vb[i] = vp[2 * (p + 8 + i)];
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) { sgn = fmaf(1.0f, va[i], sgn); sgn = fmaf(-1.0f, va[i + 1], sgn); }
+                if (p + 16 < M) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) va[i] = vp[2 * (p + 16 + i)];
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) { sgn = fmaf(1.0f, vb[i], sgn); sgn = fmaf(-1.0f, vb[i + 1], sgn); }
             }
             const float zero = 0.0f;
             ynyq = (lane & 1) ? zero + sgn : sgn - zero;          // (sa - sb, sc + sd)
@@ -409,7 +477,14 @@ __global__ __launch_bounds__(256, 3) void k_pfb_stream64(const ChanParams P, uin
             X = __builtin_amdgcn_mfma_f32_16x16x4f32(are[s], v, X, 0, 0, 0);
             Y = __builtin_amdgcn_mfma_f32_16x16x4f32(aim[s], v, Y, 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next tile's pieces (this wave's) have landed; the stores waited for are the PREVIOUS tile's
+        S64_STAMP(3);
+        // everything older than the pieces issued at the top of this tile has completed: the next tile's pieces (this wave's) have landed,
+        // and the stores waited for are the PREVIOUS tile's -- a wave never waits for the acknowledgement of stores it has just issued
+        if (S64_AHEAD == 1 || nd == 0) s64_wait_vm<0>();
+        else if (nd == 2) s64_wait_vm<2>();
+        else if (nd == 3) s64_wait_vm<3>();
+        else s64_wait_vm<4>();
+        S64_STAMP(4);
         {
             const uint64_t m = a + 8 * oct + col;
             const size_t ocol = P.out_pitch ? (size_t)(m - P.m0) : (size_t)((uint32_t)m & P.out.mask);
@@ -428,10 +503,24 @@ __global__ __launch_bounds__(256, 3) void k_pfb_stream64(const ChanParams P, uin
                 if (mn < m_hi) nyq_row[2 * (P.out_pitch ? (size_t)(mn - P.m0) : (size_t)((uint32_t)mn & P.out.mask))] = ynyq;
             }
         }
+        S64_STAMP(5);
         __syncthreads();                                          // everybody's pieces have landed; vs is free again
-        rb = rn;
+        S64_STAMP(6);
+        rb = s64_wrap(rb + 16);
     }
+#ifdef QRL_S64_PROF
+    if (lane == 0) { for (int k = 0; k < 7; ++k) atomicAdd(&g_s64_prof[k], pc[k]); atomicAdd(&g_s64_prof[7], (unsigned long long)ntiles); }
+#endif
 }
+#ifdef QRL_S64_PROF
+extern "C" void qrl_s64_prof_read(unsigned long long* out8)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_s64_prof), 8 * sizeof(unsigned long long));
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_s64_prof), z, sizeof z);
+}
+#endif
 size_t stream64_lds_bytes() { return (size_t)((S64_RB + 2) * 64 + S64_T * S64_VP) * sizeof(float2); }
 
 // caller buffer [rows][pitch] -> engine ring rows at absolute items [q0, q0 + count): how the per-channel-only handle (form 3) takes
