@@ -340,7 +340,9 @@ int qrl_deframer_sync(qrl_deframer* d);
  * frame types src/layer1framing.h:8-24; mode table gr_modem::toggleRxMode :203-322) ------------------------------------------
  * Consumes the unpacked bits of a demodulator port like qrl_deframer_process and emits, per stream, the frames the
  * reference would pass to gr_modem::processReceivedData as records
- *     { uint32 frame_type (FrameTypeVoice1 0xB5, FrameTypeVoice 0xED89, FrameTypeText 0x89EDAA, ...); uint32 nbytes;
+ *     { uint32 frame_type (FrameTypeVoice1 0xB5, FrameTypeVoice 0xED89, FrameTypeText 0x89EDAA, ...);
+ *       uint32 nbytes | _modem_sync << 16  (low 16 bits: payload bytes; high 16 bits: the _modem_sync counter at the moment the frame
+ *       completed, 0..39 -- what processReceivedData's voice gate of the 1k modes tests, src/gr_modem.cpp:1376-1390);
  *       nbytes payload bytes, MSB-first packed, padded to a multiple of 4 }
  * appended to out[b*out_cap ...]; out_counts[2b] = bytes written, out_counts[2b+1] = frames.  A frame that does not fit is
  * dropped (out_cap >= n/8 + qrl_framesync_frame_bytes() + 96 + 16 per frame never overflows: a frame begun in earlier calls may

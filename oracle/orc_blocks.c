@@ -924,7 +924,8 @@ size_t orc_deframer(int type, const uint8_t* bits, size_t n, uint32_t st[3], uin
  * gr_modem::synchronize / findSync / packBytes (reference src/gr_modem.cpp:1119-1282, 980-994; frame types
  * src/layer1framing.h:8-24; mode table :203-322).  Per bit: search the mode's sync words in a shift register, then collect
  * the frame's bits, pack them MSB first and hand the frame to processReceivedData.  Here a frame becomes one record
- * { u32 frame_type, u32 nbytes, nbytes payload bytes padded to a multiple of 4 } appended to out.
+ * { u32 frame_type, u32 nbytes | _modem_sync << 16, nbytes payload bytes padded to a multiple of 4 } appended to out
+ * (_modem_sync = the counter at the moment the frame completes: what the voice gate of the 1k modes tests, :1376-1390).
  * st[0] = shift register, st[1] = sync_found, st[2] = bit_buf_index, st[3] = current frame type, st[4] = _modem_sync;
  * bitbuf (>= orc_modem_sync_geometry(...).bit_buf_len bytes) carries a partial frame between calls.  Returns bytes written.
  * cls 3 = M17 (gr_modem.cpp:1187-1210: 16-bit LSF / stream words first, else the 32-bit EOT word; 46-byte frames, :309-313).
@@ -984,7 +985,7 @@ size_t orc_modem_sync(int modem_type, const uint8_t* bits, size_t n, uint32_t st
             if ((cls == 1 || cls == 2) && st[3] == 0xED89) frame_length++;          /* reserved byte of voice frames */
             else if (cls == 1 || cls == 2) bit_buf_len = bit_buf_len0 - 8;
             if ((int)st[2] >= bit_buf_len) {
-                uint32_t hdr[2] = {st[3], (uint32_t)frame_length};
+                uint32_t hdr[2] = {st[3], (uint32_t)frame_length | (st[4] << 16)};   /* nbytes | _modem_sync << 16 */
                 memcpy(out + no, hdr, 8); no += 8;
                 const size_t padded = ((size_t)frame_length + 3) & ~(size_t)3;
                 memset(out + no, 0, padded);

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64) void k_framesync(const FrameSyncParams P)
             if (st.idx >= need) {
                 const uint32_t padded = (flen + 3u) & ~3u;
                 if (no + 8u + padded <= P.out_cap) {
-                    if (lane == 0) { reinterpret_cast<uint32_t*>(out + no)[0] = st.ftype; reinterpret_cast<uint32_t*>(out + no)[1] = flen; }
+                    if (lane == 0) { reinterpret_cast<uint32_t*>(out + no)[0] = st.ftype; reinterpret_cast<uint32_t*>(out + no)[1] = flen | (st.modem_sync << 16); }   // (_modem_sync <= 39)
                     for (uint32_t j = lane; j < padded; j += 64) {
                         uint32_t t = 0;
                         if (8u * j < need) {

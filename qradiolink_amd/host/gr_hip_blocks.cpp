@@ -69,6 +69,10 @@ void gr_demod_hip::open()
     if (!d_iq) {
         hchk(hipMalloc(reinterpret_cast<void**>(&d_iq), kChunk * sizeof(gr_complex)), "hipMalloc");
         hchk(hipMalloc(reinterpret_cast<void**>(&d_cnt), 4 * sizeof(uint32_t)), "hipMalloc");
+        hipStream_t cs;
+        hchk(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), "hipStreamCreate");
+        d_cs = cs;
+        hchk(hipHostMalloc(reinterpret_cast<void**>(&d_hcnt), 6 * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
     }
     for (void* p : {(void*)d_const, (void*)d_a, (void*)d_b}) if (p) (void)hipFree(p);
     hchk(hipMalloc(reinterpret_cast<void**>(&d_const), d_ccap * sizeof(gr_complex)), "hipMalloc");
@@ -87,13 +91,15 @@ gr_demod_hip::~gr_demod_hip()
     if (d_df1) qrl_deframer_destroy(d_df1);
     if (d_df2) qrl_deframer_destroy(d_df2);
     for (void* p : {(void*)d_iq, (void*)d_const, (void*)d_a, (void*)d_b, (void*)d_cnt, (void*)d_fa, (void*)d_fb, (void*)d_fcnt, (void*)d_audio}) if (p) (void)hipFree(p);
+    if (d_hcnt) (void)hipHostFree(d_hcnt);
+    if (d_cs) (void)hipStreamDestroy(static_cast<hipStream_t>(d_cs));
 }
 void gr_demod_hip::attach_deframer(int type)
 {
     if (d_df1) { qrl_deframer_destroy(d_df1); qrl_deframer_destroy(d_df2); d_df1 = d_df2 = nullptr; }
     d_df_type = type;
-    chk(qrl_deframer_create(d_rt.ctx(), type, 1, nullptr, &d_df1), "qrl_deframer_create");
-    chk(qrl_deframer_create(d_rt.ctx(), type, 1, nullptr, &d_df2), "qrl_deframer_create");
+    chk(qrl_deframer_create(d_rt.ctx(), type, 1, d_cs, &d_df1), "qrl_deframer_create");   // on the copy stream, behind the demodulator
+    chk(qrl_deframer_create(d_rt.ctx(), type, 1, d_cs, &d_df2), "qrl_deframer_create");
     d_dfcap = 2 * d_bcap + 24;
     for (void* p : {(void*)d_fa, (void*)d_fb, (void*)d_fcnt}) if (p) (void)hipFree(p);
     hchk(hipMalloc(reinterpret_cast<void**>(&d_fa), d_dfcap), "hipMalloc");
@@ -119,17 +125,21 @@ void gr_demod_hip::run(const gr_complex* x, size_t n)   // n even, <= kChunk
     o.bits_a = d_a; o.bits_b = d_b; o.bits_cap = d_bcap; o.counts = d_cnt;
     o.audio = d_audio; o.audio_cap = d_acap;
     chk(qrl_demod_process(d_h, d_iq, kChunk, n, &o), "qrl_demod_process");
-    chk(qrl_demod_sync(d_h), "qrl_demod_sync");
-    uint32_t cnt[4];
-    hchk(hipMemcpy(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost), "D2H");
-    if (d_df1) {   // ports 2 / 3 -> gr_deframer_bb on the device; the mailboxes then hold sync + frame bits
+    // everything behind the demodulator is chained on the copy stream with a device-side wait: the deframers (ports 2 / 3 ->
+    // gr_deframer_bb on the device; the mailboxes then hold sync + frame bits) and the copy of the counts -- ONE host synchronisation
+    // per call, after which the copies below move exactly the bytes the call produced
+    hipStream_t cs = static_cast<hipStream_t>(d_cs);
+    chk(qrl_demod_stream_wait(d_h, cs), "qrl_demod_stream_wait");
+    if (d_df1) {
         chk(qrl_deframer_process(d_df1, d_a, d_bcap, d_bcap, d_cnt + 2, 4, d_fa, d_dfcap, d_fcnt), "qrl_deframer_process");
         chk(qrl_deframer_process(d_df2, d_b, d_bcap, d_bcap, d_cnt + 3, 4, d_fb, d_dfcap, d_fcnt + 1), "qrl_deframer_process");
-        chk(qrl_deframer_sync(d_df1), "qrl_deframer_sync");
-        chk(qrl_deframer_sync(d_df2), "qrl_deframer_sync");
-        uint32_t fc[2];
-        hchk(hipMemcpy(fc, d_fcnt, sizeof fc, hipMemcpyDeviceToHost), "D2H");
-        cnt[2] = fc[0]; cnt[3] = fc[1];
+        hchk(hipMemcpyAsync(d_hcnt + 4, d_fcnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, cs), "D2H");
+    }
+    hchk(hipMemcpyAsync(d_hcnt, d_cnt, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, cs), "D2H");
+    hchk(hipStreamSynchronize(cs), "hipStreamSynchronize");
+    uint32_t cnt[4] = {d_hcnt[0], d_hcnt[1], d_hcnt[2], d_hcnt[3]};
+    if (d_df1) {
+        cnt[2] = d_hcnt[4]; cnt[3] = d_hcnt[5];
         if (cnt[2]) hchk(hipMemcpy(d_ha.data(), d_fa, cnt[2], hipMemcpyDeviceToHost), "D2H");
         if (cnt[3]) hchk(hipMemcpy(d_hb.data(), d_fb, cnt[3], hipMemcpyDeviceToHost), "D2H");
     } else {

@@ -86,6 +86,7 @@ private:
     std::vector<gr_complex> d_carry;                        // at most one sample: the ABI takes even counts
     std::vector<gr_complex> d_buf;
     float *d_iq = nullptr, *d_const = nullptr; uint8_t *d_a = nullptr, *d_b = nullptr; uint32_t* d_cnt = nullptr;   // device
+    void* d_cs = nullptr; uint32_t* d_hcnt = nullptr;       // copy stream (hipStream_t) the deframers run on behind the demodulator; pinned [6]: port counts + deframed counts
     std::vector<unsigned char> d_box1, d_box2, d_ha, d_hb; std::vector<gr_complex> d_boxc, d_hc;
     float* d_audio = nullptr; size_t d_acap = 0; std::vector<float> d_boxa, d_hau; float d_attack = 0.1f, d_decay = 0.1f;
     gr::thread::mutex d_mutex;

@@ -67,6 +67,8 @@ struct gr_demod_base_hip::slot {
     gr_complex* h_const = nullptr; uint8_t *h_a = nullptr, *h_b = nullptr, *h_dmo = nullptr; uint32_t *h_cnt = nullptr, *h_dmocnt = nullptr;   // pinned
     float *d_rssi = nullptr, *h_rssi = nullptr; bool rssi_valid = false;   // latest rssi_block value per stream (device / pinned)
     float *d_audio = nullptr, *h_audio = nullptr;         // analogue modes: port 1 (device / pinned)
+    uint8_t *d_fr[2] = {nullptr, nullptr}, *h_fr[2] = {nullptr, nullptr}; uint32_t *d_frcnt[2] = {nullptr, nullptr}, *h_frcnt[2] = {nullptr, nullptr};   // framed records of bits A / B
+    bool framed = false, bits_copied = true;
     hipEvent_t done = nullptr;
 };
 static constexpr size_t kDmoCap = 16;
@@ -75,6 +77,7 @@ gr_demod_base_hip::gr_demod_base_hip(qrl_runtime& rt, int streams, int device_sa
     : d_rt(rt), d_n(streams), d_rate(device_samp_rate), d_offset(carrier_offset_hz), d_chunk(max_chunk & ~(size_t)1),
       d_boxa(streams), d_box1(streams), d_box2(streams), d_boxc(streams), d_boxd(streams)
 {
+    d_boxf[0].resize(streams); d_boxf[1].resize(streams);
     if (streams < 1 || d_chunk < 2) throw std::invalid_argument("gr_demod_base_hip: streams >= 1, max_chunk >= 2");
     hipStream_t s;
     hchk(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
@@ -92,8 +95,15 @@ void gr_demod_base_hip::close()
     if (d_rssi) { qrl_rssi_destroy(d_rssi); d_rssi = nullptr; }
     if (d_fft) { qrl_fft_destroy(d_fft); d_fft = nullptr; }
     if (d_fftout) { (void)hipFree(d_fftout); d_fftout = nullptr; }
+    for (auto& f : d_fs) if (f) { qrl_framesync_destroy(f); f = nullptr; }
     for (auto& sp : d_slot) {
         if (!sp) continue;
+        for (int k = 0; k < 2; ++k) {
+            if (sp->d_fr[k]) (void)hipFree(sp->d_fr[k]);
+            if (sp->d_frcnt[k]) (void)hipFree(sp->d_frcnt[k]);
+            if (sp->h_fr[k]) (void)hipHostFree(sp->h_fr[k]);
+            if (sp->h_frcnt[k]) (void)hipHostFree(sp->h_frcnt[k]);
+        }
         if (sp->d_rssi) (void)hipFree(sp->d_rssi);
         if (sp->h_rssi) (void)hipHostFree(sp->h_rssi);
         if (sp->d_audio) (void)hipFree(sp->d_audio);
@@ -125,8 +135,21 @@ void gr_demod_base_hip::open()
     chk(qrl_fft_create(d_rt.ctx(), d_n, d_fftsize, 5 /* WIN_BLACKMAN_HARRIS */, d_copy, &d_fft), "qrl_fft_create");
     chk(qrl_fft_set_enabled(d_fft, d_fft_on ? 1 : 0), "qrl_fft_set_enabled");
     d_level.assign(N, 0.0f);
+    // L1 frame synchronisers on the copy stream, behind the demodulator (digital modes with gr_modem framing: not DMR, not analogue)
+    const bool fs_on = d_want_fs && !d_acap && d_mode != QRL_MODEM_DMR;
+    if (fs_on) {
+        for (auto& f : d_fs) chk(qrl_framesync_create(d_rt.ctx(), d_mode, d_n, d_copy, &f), "qrl_framesync_create");
+        const size_t fb = (size_t)qrl_framesync_frame_bytes(d_fs[0]);
+        d_frcap = (d_bcap / 8 + fb + 96 + 16 * (d_bcap / std::max<size_t>(8 * fb, 8) + 2) + 3) & ~(size_t)3;   // never overflows (include/qrl_hip.h)
+    }
     for (auto& sp : d_slot) {
         sp = new slot;
+        if (fs_on) for (int k = 0; k < 2; ++k) {
+            hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_fr[k]), N * d_frcap), "hipMalloc");
+            hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_frcnt[k]), N * 2 * sizeof(uint32_t)), "hipMalloc");
+            hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_fr[k]), N * d_frcap, hipHostMallocDefault), "hipHostMalloc");
+            hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_frcnt[k]), N * 2 * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
+        }
         hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_rssi), N * sizeof(float)), "hipMalloc");
         hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_rssi), N * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
         hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_iq), N * d_chunk * sizeof(gr_complex), hipHostMallocDefault), "hipHostMalloc");
@@ -161,7 +184,19 @@ void gr_demod_base_hip::set_mode(int mode)   // gr_demod_base::set_mode (src/gr/
     d_mode = mode;
     open();
     std::lock_guard<std::mutex> g(d_mutex);
-    for (int s = 0; s < d_n; ++s) { d_box1[s].clear(); d_box2[s].clear(); d_boxc[s].clear(); d_boxd[s].clear(); d_boxa[s].clear(); }
+    for (int s = 0; s < d_n; ++s) { d_box1[s].clear(); d_box2[s].clear(); d_boxc[s].clear(); d_boxd[s].clear(); d_boxa[s].clear(); d_boxf[0][s].clear(); d_boxf[1][s].clear(); }
+}
+void gr_demod_base_hip::enable_device_framing(bool value)
+{
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
+    d_want_fs = value;
+}
+std::vector<gr_demod_base_hip::frame_record> gr_demod_base_hip::getFrames(int nr, int stream)
+{
+    std::lock_guard<std::mutex> g(d_mutex);
+    std::vector<frame_record> out;
+    out.swap(d_boxf[nr == 2 ? 1 : 0][stream]);
+    return out;
 }
 void gr_demod_base_hip::set_carrier_offset(double hz)   // gr_demod_base.cpp:1220-1225
 {
@@ -198,8 +233,22 @@ void gr_demod_base_hip::work(const gr_complex* const* iq, size_t n)
     const size_t N = (size_t)d_n;
     if (d_acap) hchk(hipMemcpyAsync(sl.h_audio, sl.d_audio, N * d_acap * sizeof(float), hipMemcpyDeviceToHost, cs), "D2H");
     hchk(hipMemcpyAsync(sl.h_cnt, sl.d_cnt, N * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, cs), "D2H");
-    hchk(hipMemcpyAsync(sl.h_a, sl.d_a, N * d_bcap, hipMemcpyDeviceToHost, cs), "D2H");
-    hchk(hipMemcpyAsync(sl.h_b, sl.d_b, N * d_bcap, hipMemcpyDeviceToHost, cs), "D2H");
+    sl.framed = d_fs[0] != nullptr;
+    sl.bits_copied = !sl.framed || d_keep_bits;
+    if (sl.framed) {
+        // the frame synchronisers run on the copy stream behind the demodulator (no host synchronisation in between): bits A / B of
+        // this call -> records { type, nbytes | _modem_sync << 16, payload }; only those travel to the host
+        chk(qrl_framesync_process(d_fs[0], sl.d_a, d_bcap, d_bcap, sl.d_cnt + 2, 4, sl.d_fr[0], d_frcap, sl.d_frcnt[0]), "qrl_framesync_process");
+        chk(qrl_framesync_process(d_fs[1], sl.d_b, d_bcap, d_bcap, sl.d_cnt + 3, 4, sl.d_fr[1], d_frcap, sl.d_frcnt[1]), "qrl_framesync_process");
+        for (int k = 0; k < 2; ++k) {
+            hchk(hipMemcpyAsync(sl.h_frcnt[k], sl.d_frcnt[k], N * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, cs), "D2H");
+            hchk(hipMemcpyAsync(sl.h_fr[k], sl.d_fr[k], N * d_frcap, hipMemcpyDeviceToHost, cs), "D2H");
+        }
+    }
+    if (sl.bits_copied) {
+        hchk(hipMemcpyAsync(sl.h_a, sl.d_a, N * d_bcap, hipMemcpyDeviceToHost, cs), "D2H");
+        hchk(hipMemcpyAsync(sl.h_b, sl.d_b, N * d_bcap, hipMemcpyDeviceToHost, cs), "D2H");
+    }
     hchk(hipMemcpyAsync(sl.h_const, sl.d_const, N * d_ccap * sizeof(gr_complex), hipMemcpyDeviceToHost, cs), "D2H");
     if (d_mode == QRL_MODEM_DMR) {
         hchk(hipMemcpyAsync(sl.h_dmocnt, sl.d_dmocnt, N * sizeof(uint32_t), hipMemcpyDeviceToHost, cs), "D2H");
@@ -233,8 +282,26 @@ void gr_demod_base_hip::harvest(int which)
         }
         // gr_bit_sink::work (src/gr/gr_bit_sink.cpp:61-83): while more than 1 Mi items wait, new ones are not taken (nothing is cleared);
         // gr_const_sink::work (src/gr/gr_const_sink.cpp:64-86): the same at 256 items
-        if (d_box1[s].size() <= 1048576) d_box1[s].insert(d_box1[s].end(), sl.h_a + (size_t)s * d_bcap, sl.h_a + (size_t)s * d_bcap + c[2]);
-        if (d_box2[s].size() <= 1048576) d_box2[s].insert(d_box2[s].end(), sl.h_b + (size_t)s * d_bcap, sl.h_b + (size_t)s * d_bcap + c[3]);
+        if (sl.bits_copied) {
+            if (d_box1[s].size() <= 1048576) d_box1[s].insert(d_box1[s].end(), sl.h_a + (size_t)s * d_bcap, sl.h_a + (size_t)s * d_bcap + c[2]);
+            if (d_box2[s].size() <= 1048576) d_box2[s].insert(d_box2[s].end(), sl.h_b + (size_t)s * d_bcap, sl.h_b + (size_t)s * d_bcap + c[3]);
+        }
+        if (sl.framed) for (int k = 0; k < 2; ++k) {   // the records of this call, in order
+            const uint8_t* p = sl.h_fr[k] + (size_t)s * d_frcap;
+            const uint32_t nbytes = std::min<uint32_t>(sl.h_frcnt[k][2 * s], (uint32_t)d_frcap);
+            for (uint32_t pos = 0; pos + 8 <= nbytes;) {
+                uint32_t hdr[2];
+                std::memcpy(hdr, p + pos, 8);
+                const uint32_t nb = hdr[1] & 0xFFFFu, padded = (nb + 3u) & ~3u;
+                if (pos + 8 + padded > nbytes) break;
+                frame_record r;
+                r.type = hdr[0]; r.modem_sync = hdr[1] >> 16;
+                r.payload.assign(p + pos + 8, p + pos + 8 + padded);
+                r.payload.resize((size_t)padded + 4, 0);   // processReceivedData reads frame_length + 1 bytes
+                d_boxf[k][s].push_back(std::move(r));
+                pos += 8 + padded;
+            }
+        }
         if (d_boxc[s].size() <= 256) d_boxc[s].insert(d_boxc[s].end(), sl.h_const + (size_t)s * d_ccap, sl.h_const + (size_t)s * d_ccap + c[1]);
         if (d_mode == QRL_MODEM_DMR) {
             if (sl.h_dmocnt[s] > kDmoCap) d_dmo_dropped += sl.h_dmocnt[s] - kDmoCap;   // more bursts in one call than the record buffer holds
@@ -420,6 +487,7 @@ void gr_modem_hip::toggleRxMode(int modem_type)   // gr_modem.cpp:203-322
 {
     _modem_type_rx = modem_type;
     if (!_gr_demod_base) return;
+    _gr_demod_base->enable_device_framing(_device_framing);
     _gr_demod_base->set_mode(modem_type);
     _rx_frame_length = modem_rx_frame_length(modem_type, &_bit_buf_len);
     for (auto& r : _rx) { r = rx_state(); r.bit_buf.assign((size_t)std::max(_bit_buf_len, 8), 0); }
@@ -453,8 +521,27 @@ bool gr_modem_hip::demodulate(int stream)   // gr_modem.cpp:1019-1117
         if (_ev.dmrFrames) _ev.dmrFrames(stream, frames);
         return true;
     }
-    std::vector<unsigned char>*demod_data = nullptr, *demod_data2 = nullptr;
     const bool two = modem_two_branches(_modem_type_rx);
+    if (device_framing()) {
+        // the synchroniser ran on the device (qrl_framesync_process behind the demodulator): what arrives here are the frames
+        // gr_modem::synchronize would have cut out of the bit stream, with _modem_sync as it stood when each frame completed.
+        // Same dispatch as the host loop (processReceivedData, :1285-1441); two-branch modes: branch A's frames, then branch B's
+        // (BranchRuleReference: branch A only -- the `>=` rule of :1080-1090 with equal counts).
+        bool any = false;
+        for (int k = 0; k < ((two && _branch_rule == BranchRuleBoth) ? 2 : 1); ++k) {
+            std::vector<gr_demod_base_hip::frame_record> recs = _gr_demod_base->getFrames(k + 1, stream);
+            rx_state& r = _rx[2 * (size_t)stream + (size_t)k];
+            for (auto& f : recs) {
+                any = true;
+                r.modem_sync = (int)f.modem_sync;
+                r.current_frame_type = f.type;
+                processReceivedData(f.payload.data(), f.type, r, stream);
+            }
+        }
+        if (two && _branch_rule != BranchRuleBoth) (void)_gr_demod_base->getFrames(2, stream);
+        return any;
+    }
+    std::vector<unsigned char>*demod_data = nullptr, *demod_data2 = nullptr;
     if (two) {
         demod_data = _gr_demod_base->getData(1, stream);
         demod_data2 = _gr_demod_base->getData(2, stream);

@@ -54,6 +54,15 @@ public:
     std::vector<unsigned char>* getData(int stream = 0) { return getData(1, stream); }
     virtual std::vector<unsigned char>* getData(int nr, int stream);   // nr = 1: bits A (port 2), nr = 2: bits B (port 3); nullptr = nothing yet (virtual: tests tap the bits)
     std::vector<gr_complex>* get_constellation_data(int stream = 0);
+    // L1 frame synchroniser ON THE DEVICE (qrl_framesync_*, what gr_modem::synchronize / findSync / packBytes do per bit on the host,
+    // src/gr_modem.cpp:1119-1282): when enabled (gr_modem_hip does it in toggleRxMode) every work() call runs it behind the demodulator
+    // on both bit ports and only the framed records come back to the host -- no raw bits over PCIe, no per-bit host loop.
+    // keep_bits(true) still copies the raw bit ports into the getData() mailboxes (tests that replay them into the reference).
+    struct frame_record { uint32_t type = 0, modem_sync = 0; std::vector<unsigned char> payload; };
+    void enable_device_framing(bool value);                    // takes effect at the next set_mode (toggleRxMode calls it first)
+    bool device_framing() const { return d_fs[0] != nullptr; }
+    void keep_bits(bool value) { d_keep_bits = value; }
+    std::vector<frame_record> getFrames(int nr, int stream);   // nr = 1: bits A, 2: bits B; everything framed since the last call
     std::vector<std::vector<unsigned char>> getDMRData(int stream = 0);   // DMR mode: 40-byte DMO records (QRL_DMO_RECORD_BYTES)
     uint64_t dmr_bursts_dropped() const { return d_dmo_dropped; }        // bursts beyond the 16-per-call record buffer (a call longer than 0.48 s of signal)
     // analogue voice modes (NBFM2500 / NBFM5000 / AM5000 / WBFM): port 1 = audio at 8 ksps (gr_demod_base::getAudio :968-976; caller deletes)
@@ -81,6 +90,8 @@ private:
     int d_n, d_rate, d_mode = -1; double d_offset; size_t d_chunk;
     qrl_demod* d_h = nullptr;
     qrl_rssi* d_rssi = nullptr; qrl_fft* d_fft = nullptr; bool d_rssi_on = false, d_fft_on = false; float d_rssi_cal = 0.0f; unsigned d_fftsize = 32768;
+    qrl_framesync* d_fs[2] = {nullptr, nullptr}; bool d_want_fs = false, d_keep_bits = false; size_t d_frcap = 0;   // device frame synchronisers of bits A / B
+    std::vector<std::vector<frame_record>> d_boxf[2];
     float* d_fftout = nullptr; std::vector<float> d_level, d_fftlast;
     void* d_copy = nullptr;                                   // hipStream_t for the copy-out
     slot* d_slot[2] = {nullptr, nullptr};
@@ -159,6 +170,11 @@ public:
     // branches, BranchRuleReference applies gr_modem.cpp:1080-1090 literally (see demodulate())
     enum branch_rule { BranchRuleBoth = 0, BranchRuleReference = 1 };
     void set_branch_rule(branch_rule r) { _branch_rule = r; }
+    // RX framing: on the device by default (qrl_framesync_* behind the demodulator; demodulate() then only walks framed records);
+    // false keeps the reference's per-bit host loop (synchronize / findSync below) -- the checker of tests/host/test_modem.cpp.
+    // Call before toggleRxMode.
+    void set_device_framing(bool v) { _device_framing = v; }
+    bool device_framing() const { return _device_framing && _gr_demod_base && _gr_demod_base->device_framing(); }
     int modem_sync(int stream = 0) const { return std::max(_rx[2 * (size_t)stream].modem_sync, _rx[2 * (size_t)stream + 1].modem_sync); }
 
 private:
@@ -172,7 +188,7 @@ private:
     void handleStreamEnd(rx_state& r, int stream);
     gr_demod_base_hip* _gr_demod_base; gr_mod_base_hip* _gr_mod_base; gr_modem_events _ev;
     int _modem_type_rx = -1, _modem_type_tx = -1, _bit_buf_len = 0, _rx_frame_length = 0, _tx_frame_length = 0, _frame_counter = 0;
-    bool _burst_ip_modem = false; branch_rule _branch_rule = BranchRuleBoth;
+    bool _burst_ip_modem = false, _device_framing = true; branch_rule _branch_rule = BranchRuleBoth;
     std::vector<rx_state> _rx;   // [2 * stream + branch]
 };
 

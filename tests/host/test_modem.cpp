@@ -4,6 +4,7 @@
 // the modulator's samples (+ a little silence and a per-stream delay) go into the demodulator in ragged work() calls;
 // demodulate() is polled like the radio loop does.  Every callback is logged to <out.txt> as one line per event.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -98,6 +99,59 @@ int main(int argc, char** argv)
             return 0;
         } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
     }
+    if (argc == 5 && !strcmp(argv[1], "hosttime")) {
+        // test_modem hosttime <modem_type> <streams> <calls>: host CPU time of the RX boundary per work() call, with the reference's
+        // per-bit loop on the host (set_device_framing(false)) and with the frame synchroniser on the device (the default): every
+        // stream carries the same modulated frames; prints the time spent in work() and in the demodulate() polls and the factor
+        const int mode = atoi(argv[2]), N = atoi(argv[3]), calls = atoi(argv[4]);
+        try {
+            qrl_runtime rt(0);
+            const size_t chunk = 1 << 14;
+            std::vector<gr_complex> txs;
+            {
+                gr_mod_base_hip mod(rt, 1, 1000000, 0.0, 4096);
+                gr_modem_events none;
+                gr_modem_hip txm(nullptr, &mod, none);
+                txm.toggleTxMode(mode);
+                const int L = modem_tx_frame_length(mode);
+                txm.startTransmission("N0CALL");
+                while (txs.size() < chunk * (size_t)calls) {
+                    for (int f = 0; f < 8; ++f) { unsigned char* d = new unsigned char[L]; for (int i = 0; i < L; ++i) d[i] = (unsigned char)(31 * f + 7 * i + 1); txm.transmitDigitalAudio(d, L); }
+                    std::vector<gr_complex> part(mod.samples_per_byte() * 4096);
+                    for (;;) { gr_complex* o = part.data(); const size_t ns = mod.work(&o); if (!ns) break; for (size_t i = 0; i < ns; ++i) txs.push_back(0.05f * part[i]); }
+                }
+            }
+            double res[2][3] = {{0, 0, 0}, {0, 0, 0}};
+            for (int dev = 0; dev < 2; ++dev) {
+                long frames = 0;
+                gr_modem_events ev;
+                ev.digitalAudio = [&](int, const unsigned char*, int) { ++frames; };
+                ev.netData = [&](int, const unsigned char*, int) { ++frames; };
+                gr_demod_base_hip demod(rt, N, 1000000, 0.0, chunk);
+                gr_modem_hip modem(&demod, nullptr, ev);
+                modem.set_device_framing(dev == 1);
+                modem.toggleRxMode(mode);
+                std::vector<const gr_complex*> in(N);
+                double t_work = 0, t_poll = 0;
+                for (int k = 0; k < calls; ++k) {
+                    for (int s = 0; s < N; ++s) in[s] = txs.data() + (size_t)k * chunk;
+                    const auto t0 = std::chrono::steady_clock::now();
+                    demod.work(in.data(), chunk);
+                    const auto t1 = std::chrono::steady_clock::now();
+                    for (int s = 0; s < N; ++s) while (modem.demodulate(s)) {}
+                    const auto t2 = std::chrono::steady_clock::now();
+                    if (k >= 2) { t_work += std::chrono::duration<double, std::milli>(t1 - t0).count(); t_poll += std::chrono::duration<double, std::milli>(t2 - t1).count(); }
+                }
+                demod.flush();
+                for (int s = 0; s < N; ++s) while (modem.demodulate(s)) {}
+                res[dev][0] = t_work / std::max(1, calls - 2); res[dev][1] = t_poll / std::max(1, calls - 2); res[dev][2] = (double)frames;
+            }
+            std::printf("hosttime mode %d streams %d calls %d chunk %zu: host loop work %.3f ms + poll %.3f ms per call (%.0f frames); device framing work %.3f ms + poll %.3f ms per call (%.0f frames); "
+                        "poll factor %.1f, whole boundary factor %.2f\n", mode, N, calls, chunk, res[0][0], res[0][1], res[0][2], res[1][0], res[1][1], res[1][2],
+                        res[0][1] / std::max(res[1][1], 1e-6), (res[0][0] + res[0][1]) / std::max(res[1][0] + res[1][1], 1e-6));
+            return res[0][2] == res[1][2] && res[0][2] > 0 ? 0 : 3;
+        } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+    }
     if (argc != 6 || strcmp(argv[1], "loopback")) { std::fprintf(stderr, "usage: test_modem loopback modem_type streams frames out.txt\n"); return 2; }
     const int mode = atoi(argv[2]), N = atoi(argv[3]), nframes = atoi(argv[4]);
     try {
@@ -142,6 +196,20 @@ int main(int argc, char** argv)
         gr_mod_base_hip mod(rt, N, 1000000, 0.0, 4096);
         gr_modem_hip modem(&demod, &mod, ev);
         if (getenv("QRL_TEST_BRANCH")) modem.set_branch_rule(gr_modem_hip::BranchRuleReference);   // the reference's literal `>=` rule (like-for-like replay)
+        // default: the frame synchroniser runs on the device (qrl_framesync_* behind the demodulator).  QRL_TEST_HOSTLOOP=1 keeps the
+        // reference's per-bit loop on the host -- the checker.  With the tap on, the raw bit ports are still copied out so that the
+        // python side can replay them into the reference's gr_modem (the device path itself never looks at them).
+        const bool host_loop = getenv("QRL_TEST_HOSTLOOP") != nullptr;
+        modem.set_device_framing(!host_loop);
+        if (tap && !host_loop) demod.keep_bits(true);
+        const bool two = modem_two_branches(mode);
+        auto poll = [&](int s) {
+            for (;;) {
+                if (tap) std::fprintf(tap, "D %d\n", s);
+                if (tap && !host_loop) { delete demod.getData(1, s); if (two) delete demod.getData(2, s); }   // logs the "B" lines of this poll
+                if (!modem.demodulate(s)) break;
+            }
+        };
         modem.toggleTxMode(mode);
         modem.toggleRxMode(mode);
         demod.enable_rssi(true);
@@ -202,7 +270,7 @@ int main(int argc, char** argv)
                 }
                 continue;
             }
-            for (int s = 0; s < N; ++s) for (;;) { if (tap) std::fprintf(tap, "D %d\n", s); if (!modem.demodulate(s)) break; }
+            for (int s = 0; s < N; ++s) poll(s);
             for (int s = 0; s < N; ++s) { const float v = demod.get_rssi(s); if (v != 0.0f) rssi_max[s] = std::max(rssi_max[s], v); }   // (0 = the probe before its first item)
             unsigned got = 0;
             demod.get_FFT_data(spectrum.data(), got, 0);   // the GUI timer of the reference polls like this
@@ -213,8 +281,9 @@ int main(int argc, char** argv)
         }
         if (bitlog) std::fclose(bitlog);
         demod.flush();
-        for (int s = 0; s < N; ++s) for (;;) { if (tap) std::fprintf(tap, "D %d\n", s); if (!modem.demodulate(s)) break; }
+        for (int s = 0; s < N; ++s) poll(s);
         if (tap) std::fclose(tap);
+        log << "0 framing " << (modem.device_framing() ? "device" : "host") << "\n";
         for (int s = 0; s < N; ++s) log << s << " modem_sync " << modem.modem_sync(s) << "\n";
         for (int s = 0; s < N; ++s) log << s << " rssi " << demod.get_rssi(s) << "\n" << s << " rssi_max " << rssi_max[s] << "\n";
         log << "0 spectra " << spectra << "\n" << "0 peak_bin " << peak_bin << "\n" << "0 peak_db " << peak_db << "\n";

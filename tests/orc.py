@@ -386,14 +386,16 @@ class ModemSync:
         return parse_frames(self.feed_raw(bits))
 
 
-def parse_frames(raw):
-    """records { u32 frame_type, u32 nbytes, payload padded to 4 } -> [(frame_type, bytes)]"""
+def parse_frames(raw, with_sync=False):
+    """records { u32 frame_type, u32 nbytes | _modem_sync << 16, payload padded to 4 } -> [(frame_type, bytes)] (+ _modem_sync)"""
     frames, pos = [], 0
     raw = np.ascontiguousarray(raw, np.uint8)
     while pos + 8 <= raw.size:
-        ft, nb = np.frombuffer(raw[pos:pos + 8].tobytes(), np.uint32)
-        frames.append((int(ft), raw[pos + 8:pos + 8 + int(nb)].tobytes()))
-        pos += 8 + ((int(nb) + 3) & ~3)
+        ft, w = np.frombuffer(raw[pos:pos + 8].tobytes(), np.uint32)
+        nb, msync = int(w) & 0xFFFF, int(w) >> 16
+        rec = (int(ft), raw[pos + 8:pos + 8 + nb].tobytes())
+        frames.append(rec + (msync,) if with_sync else rec)
+        pos += 8 + ((nb + 3) & ~3)
     return frames
 
 

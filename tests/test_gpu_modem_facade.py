@@ -14,17 +14,54 @@ EXE = os.path.join(ROOT, "tests", "host", "test_modem")
 pytestmark = pytest.mark.gpu
 
 
-def _events(tmp_path, mode, streams, frames):
+def _events(tmp_path, mode, streams, frames, host_loop=False):
+    """host_loop = False: the default boundary (frame synchroniser on the device, demodulate() walks framed records);
+    True: the reference's per-bit loop on the host (QRL_TEST_HOSTLOOP, the checker)"""
     if not os.path.exists(EXE):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qradiolink_amd", "csrc"), "adaptor"])
-    out = tmp_path / "events.txt"
-    r = subprocess.run([EXE, "loopback", str(mode), str(streams), str(frames), str(out)], capture_output=True, text=True, timeout=300)
+    out = tmp_path / ("events_host.txt" if host_loop else "events.txt")
+    env = dict(os.environ)
+    env.pop("QRL_TEST_HOSTLOOP", None)
+    if host_loop:
+        env["QRL_TEST_HOSTLOOP"] = "1"
+    r = subprocess.run([EXE, "loopback", str(mode), str(streams), str(frames), str(out)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
     ev = {s: [] for s in range(streams)}
     for line in out.read_text().splitlines():
         s, kind, *rest = line.split(" ", 2)
         ev[int(s)].append((kind, rest[0] if rest else ""))
+    assert dict(ev[0])["framing"] == ("host" if host_loop else "device")
     return ev
+
+
+@pytest.mark.parametrize("mode,streams,frames", [(22, 3, 12), (26, 2, 3), (18, 2, 40), (7, 2, 10), (27, 2, 3)])
+def test_device_framing_equals_the_host_loop(tmp_path, mode, streams, frames):
+    """The boundary a maintainer binds: gr_modem_hip::demodulate with the L1 frame synchroniser on the device (qrl_framesync_* behind
+    the demodulator, records { type, nbytes | _modem_sync << 16, payload } over PCIe, no per-bit host loop) delivers exactly the
+    events of the same run with the reference's loop on the host (src/gr_modem.cpp:1119-1282 restated in gr_modem_hip::synchronize):
+    same kinds, same payloads, same order per stream -- including the _modem_sync >= 16 voice gate of the 1k modes, which the host
+    evaluates from the record."""
+    dev = _events(tmp_path, mode, streams, frames)
+    host = _events(tmp_path, mode, streams, frames, host_loop=True)
+    skip = {"framing", "modem_sync", "rssi", "rssi_max", "spectra", "peak_bin", "peak_db"}
+    for s in range(streams):
+        a = [e for e in dev[s] if e[0] not in skip]
+        b = [e for e in host[s] if e[0] not in skip]
+        assert a == b, s
+    assert sum(len([e for e in dev[s] if e[0] not in skip]) for s in range(streams)) >= streams
+
+
+def test_device_framing_host_time(tmp_path):
+    """host CPU time of the RX boundary per work() call at 4096 streams of QPSK-250k (16384 samples = 4096 decoded bits per stream and
+    call): the per-bit loop on the host against the frame synchroniser on the device; the factor is printed (pytest -s) and must be
+    well above 1 for the polls"""
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qradiolink_amd", "csrc"), "adaptor"])
+    r = subprocess.run([EXE, "hosttime", "26", "4096", "8"], capture_output=True, text=True, timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    f = float(r.stdout.split("poll factor ")[1].split(",")[0])
+    assert f > 2.0, r.stdout
 
 
 def _payload(s, f, L):
@@ -152,9 +189,11 @@ def test_facade_tx_framing_equals_the_reference_gr_modem(tmp_path, mode):
 
 
 @pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/libqrl_ref.so not built")
+@pytest.mark.parametrize("host_loop", [False, True])
 @pytest.mark.parametrize("mode,streams,frames", [(22, 2, 10), (26, 2, 3), (18, 2, 30), (7, 2, 10)])
-def test_facade_rx_events_equal_the_reference_gr_modem(tmp_path, mode, streams, frames):
-    """The TX -> RX loopback again, with every bit vector demodulate() pulls out of the mailboxes tapped: the same vectors go into the
+def test_facade_rx_events_equal_the_reference_gr_modem(tmp_path, mode, streams, frames, host_loop):
+    """host_loop = False: the DEVICE frame synchroniser behind the facade (the default boundary); True: the per-bit loop on the host.
+    The TX -> RX loopback again, with every bit vector of the demodulator's bit ports tapped: the same vectors go into the
     REFERENCE's gr_modem (src/gr_modem.cpp itself, oracle/_ref) call by call; its signals must be the facade's events, in order
     (synchronize / findSync / packBytes / processReceivedData).  Two-branch modes: the facade frames both Viterbi alignments with
     their own state, A then B; the reference side is therefore one gr_modem per branch, each fed its branch as
@@ -163,8 +202,12 @@ def test_facade_rx_events_equal_the_reference_gr_modem(tmp_path, mode, streams, 
     if not os.path.exists(EXE):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qradiolink_amd", "csrc"), "adaptor"])
     env = dict(os.environ, QRL_TEST_TAP=str(tmp_path / "tap.txt"))
+    env.pop("QRL_TEST_HOSTLOOP", None)
+    if host_loop:
+        env["QRL_TEST_HOSTLOOP"] = "1"
     r = subprocess.run([EXE, "loopback", str(mode), str(streams), str(frames), str(tmp_path / "ev.txt")], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
+    assert ("0 framing " + ("host" if host_loop else "device")) in (tmp_path / "ev.txt").read_text()
     L = C.CDLL(REF)
     vp = C.c_void_p
     L.ref_modem_new.restype = vp
