@@ -124,6 +124,12 @@ int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* filtered_cap, size_
 int qrl_demod_audio_cap(const qrl_demod* d, size_t n, size_t* audio_cap);
 /* replaces gr_demod_nbfm/am/wbfm::set_squelch (pwr_squelch_cc::set_threshold, gr_demod_base.cpp:1186-1199): threshold in dB */
 int qrl_demod_set_squelch(qrl_demod* d, double db);
+/* replaces gr_demod_nbfm::set_ctcss(value) (src/gr/gr_demod_nbfm.cpp:97-123): tone_hz != 0 switches analog::ctcss_squelch_ff(8000, tone,
+ * 0.01, 8000, 160, true) (:59-60) in between the audio resampler and the audio filter and the audio filter to band_pass_2(1, 8000,
+ * 300, 3500, 200, 35, BH); 0 switches it out again (the constructor's graph).  Switching it in or out restarts the chain from a
+ * fresh state (the reference re-wires the graph under lock()); a different tone while it is on re-initialises the tone detector
+ * only (ctcss_squelch_ff::set_frequency).  NBFM receivers only.  The block gates: audio leaves only while the tone is present. */
+int qrl_demod_set_ctcss(qrl_demod* d, float tone_hz);
 /* replaces gr_demod_am / gr_demod_ssb::set_agc_attack / set_agc_decay (gr_demod_am.cpp:90-98, gr_demod_ssb.cpp:104-112) */
 int qrl_demod_set_agc(qrl_demod* d, float attack, float decay);
 

@@ -229,6 +229,10 @@ void   orc_squelch_envelope(int ramp, float* env /* ramp + 1 */);
 size_t orc_pwr_squelch_cc(const cf32* in, size_t n, double db, double alpha, int ramp, int gate, cf32* out);
 void   orc_agc2_ff(const float* in, size_t n, float attack, float decay, float ref, float gain, float max_gain, float* out);
 void   orc_iir_ffd_2(const float* in, size_t n, const double ff[2], const double fb[2], int oldstyle, float* out);
+void   orc_set_ctcss(float tone_hz);   /* gr_demod_nbfm::set_ctcss for the next orc_demod_analog(kind 0) calls; 0 = off */
+size_t orc_ctcss_squelch_ff(const float* in, size_t n, int rate, float freq, double level, int len, int ramp, int gate, float* out);
+void   orc_ctcss_freqs(float freq, float* f_l, float* f_r);
+void   orc_goertzel_coeffs(int rate, float freq, float* wr, float* wi);
 void   orc_demod_analog(const cf32* in, size_t n, int kind /* 0 NBFM, 1 AM, 2 WBFM */, int samp_rate, int filter_width,
                         cf32** filtered, size_t* n_filtered, float** audio, size_t* n_audio);
 int    orc_band_pass_2(double gain, double fs, double lo, double hi, double tw, double atten_db, int win, float* taps);
@@ -237,6 +241,7 @@ size_t orc_cessb_stretcher(const cf32* in, size_t n, cf32* out);
 void   orc_demod_ssb(const cf32* in, size_t n, int samp_rate, int filter_width, int sb /* 0 USB, 1 LSB */,
                      cf32** filtered, size_t* n_filtered, float** audio, size_t* n_audio);
 size_t orc_mod_ssb(const float* audio, size_t n, int sps, int samp_rate, int filter_width, int sb, float bb_gain, cf32* out);   /* out NULL: count */
+size_t orc_mod_am(const float* audio, size_t n, int sps, int samp_rate, int filter_width, float bb_gain, cf32* out);           /* gr_mod_am; out NULL: count */
 void   orc_free(void* p);
 /* frame FEC of the DMR / M17 stacks (orc_framefec.c; PINNED against the real reference sources through oracle/_ref) */
 void     orc_bptc19696_decode(const uint8_t* in33, uint8_t* out12);

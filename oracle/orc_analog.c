@@ -101,6 +101,83 @@ size_t orc_pwr_squelch_cc(const cf32* in, size_t n, double db, double alpha, int
     return j;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * analog::ctcss_squelch_ff(rate, freq, level, len, ramp, gate)  [GR-MEM: gr-analog/lib/ctcss_squelch_ff_impl.cc, squelch_base_ff_impl.cc,
+ * gr-fft/lib/goertzel.cc] -- instance make(8000, 88.5, 0.01, 8000, 160, true) src/gr/gr_demod_nbfm.cpp:59-60, switched into the
+ * audio path by gr_demod_nbfm::set_ctcss(tone) (:97-123).
+ *   three Goertzel filters over blocks of `len` items: the tone and its neighbours in the CTCSS table (a tone not in the table or at
+ *   its ends: -2 % / +2 %); per item  y = x + wr d1 - d2 (float, left to right), d2 = d1, d1 = y,  w = (float)(2 pi f / rate),
+ *   wr = (float)(2.0 * cosf(w)), wi = sinf(w); after `len` items  out = ((0.5 wr d1 - d2) / len [in double, then float], (wi d1) / len),
+ *   |out| as sqrtf(re^2 + im^2) (std::abs of a complex<float>; hypot's last bit is libm's business), floorf(1e5 |out|) / 1e5 per
+ *   filter, mute = c < level || c < l || c < r (level compared as double); the filters restart.
+ *   squelch_base_ff: MUTED / ATTACK / UNMUTED / DECAY with the raised-cosine envelope 0.5 - cos(pi k / ramp) / 2 (double);
+ *   an unmuted item leaves as (float)((double)x * envelope), a muted one is dropped (gate) or leaves as 0.
+ * st (carried between calls): [0..5] d1, d2 of the l, c, r filters, [6] processed, [7] mute, [8] state, [9] ramped, env in *env.
+ * ------------------------------------------------------------------------------------------ */
+static const float ctcss_tones[38] = {67.0f, 71.9f, 74.4f, 77.0f, 79.7f, 82.5f, 85.4f, 88.5f, 91.5f, 94.8f, 97.4f, 100.0f, 103.5f, 107.2f, 110.9f, 114.8f,
+                                      118.8f, 123.0f, 127.3f, 131.8f, 136.5f, 141.3f, 146.2f, 151.4f, 156.7f, 162.2f, 167.9f, 173.8f, 179.9f, 186.2f, 192.8f,
+                                      203.5f, 210.7f, 218.1f, 225.7f, 233.6f, 241.8f, 250.3f};
+void orc_ctcss_freqs(float freq, float* f_l, float* f_r)
+{
+    int i = -1;
+    for (int k = 0; k < 38; k++) if (ctcss_tones[k] == freq) i = k;
+    *f_l = (i == -1 || i == 0) ? freq * 0.98f : ctcss_tones[i - 1];
+    *f_r = (i == -1 || i == 37) ? freq * 1.02f : ctcss_tones[i + 1];
+}
+void orc_goertzel_coeffs(int rate, float freq, float* wr, float* wi)
+{
+    const float w = (float)(2.0 * M_PI * freq / rate);
+    *wr = (float)(2.0 * (double)cosf(w));
+    *wi = sinf(w);
+}
+size_t orc_ctcss_squelch_ff(const float* in, size_t n, int rate, float freq, double level, int len, int ramp, int gate, float* out)
+{
+    orc_trace_event("ctcss_squelch_ff(%d,%.9g,%.17g,%d,%d,%d)", rate, freq, level, len, ramp, gate);
+    if (len == 0) len = (int)(rate / 10.0);
+    float fl, fr, wr[3], wi[3];
+    orc_ctcss_freqs(freq, &fl, &fr);
+    orc_goertzel_coeffs(rate, fl, &wr[0], &wi[0]);
+    orc_goertzel_coeffs(rate, freq, &wr[1], &wi[1]);
+    orc_goertzel_coeffs(rate, fr, &wr[2], &wi[2]);
+    float d1[3] = {0, 0, 0}, d2[3] = {0, 0, 0};
+    int processed = 0, mute = 1, state = 0, ramped = 0;
+    double env = ramp ? 0.0 : 1.0;
+    size_t j = 0;
+    for (size_t i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) {
+            float y = in[i] + wr[k] * d1[k];
+            y = y - d2[k];
+            d2[k] = d1[k]; d1[k] = y;
+        }
+        if (++processed == len) {
+            float o[3];
+            for (int k = 0; k < 3; k++) {
+                const float re = (float)((0.5 * (double)wr[k] * (double)d1[k] - (double)d2[k]) / (double)len);
+                const float im = (wi[k] * d1[k]) / (float)len;
+                o[k] = floorf(100000.0f * sqrtf(re * re + im * im)) / 100000.0f;
+                d1[k] = d2[k] = 0.0f;
+            }
+            processed = 0;
+            mute = ((double)o[1] < level) || o[1] < o[0] || o[1] < o[2];
+        }
+        switch (state) {
+        case 0: if (!mute) state = ramp ? 1 : 2; break;
+        case 2: if (mute) state = ramp ? 3 : 0; break;
+        case 1:
+            env = 0.5 - cos(M_PI * (double)(++ramped) / (double)ramp) / 2.0;
+            if (ramped >= ramp) { state = 2; env = 1.0; }
+            break;
+        case 3:
+            env = 0.5 - cos(M_PI * (double)(--ramped) / (double)ramp) / 2.0;
+            if (ramped == 0) state = 0;
+            break;
+        }
+        if (state != 0) out[j++] = (float)((double)in[i] * env);
+        else if (!gate) out[j++] = 0.0f;
+    }
+    return j;
+}
+
 /* agc2_ff(attack, decay, reference, gain), max gain 65536 */
 void orc_agc2_ff(const float* in, size_t n, float attack, float decay, float ref, float gain, float max_gain, float* out)
 {
@@ -135,6 +212,9 @@ void orc_iir_ffd_2(const float* in, size_t n, const double ff[2], const double f
 
 static void scale_f(float* x, size_t n, float k) { for (size_t i = 0; i < n; i++) x[i] = x[i] * k; }
 
+/* gr_demod_nbfm::set_ctcss(value) for the NEXT orc_demod_analog(kind 0) calls: 0 = off (the constructor's graph) */
+static float g_ctcss_tone = 0.0f;
+void orc_set_ctcss(float tone_hz) { g_ctcss_tone = tone_hz; }
 /* kind: 0 NBFM, 1 AM, 2 WBFM.  filtered = port 0 (before the squelch), audio = port 1 (8 kHz). */
 void orc_demod_analog(const cf32* in, size_t n, int kind, int samp_rate, int filter_width,
                       cf32** filtered, size_t* n_filtered, float** audio, size_t* n_audio)
@@ -202,10 +282,14 @@ void orc_demod_analog(const cf32* in, size_t n, int kind, int samp_rate, int fil
         float* r = NEW(float, no);
         orc_resamp_fff(d, ng, at, na, 2, 5, r);                                                 /* _audio_resampler (2, 5) */
         free(at);
-        int nf = kind == 0 ? orc_low_pass_2(1, 8000, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, NULL)
+        const int ctcss = kind == 0 && g_ctcss_tone != 0.0f;      /* gr_demod_nbfm::set_ctcss(tone): _ctcss between resampler and audio filter, band-pass audio filter */
+        if (ctcss) no = orc_ctcss_squelch_ff(r, no, 8000, g_ctcss_tone, 0.01, 8000, 160, 1, r);  /* (in place: j <= i) */
+        int nf = ctcss ? orc_band_pass_2(1, 8000, 300, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, NULL)
+               : kind == 0 ? orc_low_pass_2(1, 8000, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, NULL)
                            : orc_low_pass(1, 8000, 3600, 300, ORC_WIN_BLACKMAN_HARRIS, NULL);
         float* aft = NEW(float, nf);
-        if (kind == 0) orc_low_pass_2(1, 8000, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, aft);
+        if (ctcss) orc_band_pass_2(1, 8000, 300, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, aft);
+        else if (kind == 0) orc_low_pass_2(1, 8000, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, aft);
         else           orc_low_pass(1, 8000, 3600, 300, ORC_WIN_BLACKMAN_HARRIS, aft);
         out = NEW(float, no);
         orc_fir_fff(r, no, aft, nf, out);                                                       /* _audio_filter */
@@ -336,3 +420,48 @@ size_t orc_mod_ssb(const float* audio, size_t n, int sps, int samp_rate, int fil
 }
 
 void orc_free(void* p) { free(p); }
+
+
+/* ------------------------------------------------------------------------------------------
+ * gr_mod_am (reference src/gr/gr_mod_am.cpp:26-74, instance make_gr_mod_am(125, 1000000, 1700, 5000) src/gr/gr_mod_base.cpp:167):
+ *   audio (8 ksps) -> agc2_ff(1e-2, 1e-4, 1, 1), max gain 1 -> rail_ff(-0.98, 0.98) -> x0.95 -> fft_filter_fff(band_pass_2(1, 8000,
+ *   300, 3000, 200, 60, HAMMING)) -> + carrier -> float_to_complex -> rational_resampler_ccf(sps, 1, low_pass(sps, samp_rate, fw, fw))
+ *   -> x0.5 -> x bb_gain -> fft_filter_ccc(complex_band_pass_2(1, samp_rate, -fw, fw, 1200, 120, BH)).
+ * The carrier is sig_source_f(8000, GR_COS_WAVE, 0, 0.5): frequency 0, so a constant 0.5 cos(0).  [GR-MEM] upstream's sig_source_f
+ * takes the cosine from gr::fxpt's interpolated sine table; cos(0) is taken as exactly 1 here (the table's value at the quarter
+ * turn may differ from 1 in the last bit: 6e-8 relative, inside the 1e-5 bound on float samples).  _feed_forward_agc is created by
+ * the constructor but never connected (:66-77): it is not part of the graph.
+ * ------------------------------------------------------------------------------------------ */
+size_t orc_mod_am(const float* audio, size_t n, int sps, int samp_rate, int filter_width, float bb_gain, cf32* out)
+{
+    if (!out) return n * (size_t)sps;
+    float* a0 = NEW(float, n ? n : 1);
+    orc_agc2_ff(audio, n, 1e-2f, 1e-4f, 1.0f, 1.0f, 1.0f, a0);                    /* _agc, set_max_gain(1.0) */
+    for (size_t i = 0; i < n; i++) {                                              /* _rail, _audio_amplify */
+        float v = a0[i];
+        if (v < -0.98f) v = -0.98f; else if (v > 0.98f) v = 0.98f;
+        a0[i] = v * 0.95f;
+    }
+    int na = orc_band_pass_2(1, 8000, 300, 3000, 200, 60, ORC_WIN_HAMMING, NULL);
+    float* at = NEW(float, na);
+    orc_band_pass_2(1, 8000, 300, 3000, 200, 60, ORC_WIN_HAMMING, at);
+    float* a1 = NEW(float, n ? n : 1);
+    orc_fir_fff(a0, n, at, na, a1);                                               /* _audio_filter */
+    free(at); free(a0);
+    cf32* c = NEW(cf32, n ? n : 1);
+    for (size_t i = 0; i < n; i++) { c[i].re = a1[i] + 0.5f; c[i].im = 0.0f; }    /* _add (+ _signal_source), _float_to_complex */
+    free(a1);
+    int ni = orc_low_pass(sps, samp_rate, filter_width, filter_width, ORC_WIN_HAMMING, NULL);
+    float* it = NEW(float, ni);
+    orc_low_pass(sps, samp_rate, filter_width, filter_width, ORC_WIN_HAMMING, it);
+    cf32* r = NEW(cf32, n * (size_t)sps + 1);
+    const size_t m = orc_resamp_ccf(c, n, it, ni, sps, 1, r);                     /* _resampler */
+    free(it); free(c);
+    for (size_t i = 0; i < m; i++) { r[i].re *= 0.5f; r[i].im *= 0.5f; r[i].re *= bb_gain; r[i].im *= bb_gain; }   /* _amplify, _bb_gain */
+    int nf = orc_complex_band_pass_2(1, samp_rate, -filter_width, filter_width, 1200, 120, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    cf32* ft = NEW(cf32, nf);
+    orc_complex_band_pass_2(1, samp_rate, -filter_width, filter_width, 1200, 120, ORC_WIN_BLACKMAN_HARRIS, ft);
+    orc_fir_ccc(r, m, ft, nf, out);                                               /* _filter */
+    free(ft); free(r);
+    return m;
+}

@@ -141,6 +141,7 @@ def load_library():
     lib.qrl_fft_get_fft_data.argtypes = [vp, vp, sz, C.POINTER(C.c_uint)]
     lib.qrl_fft_sync.argtypes = [vp]
     lib.qrl_demod_stream_wait.argtypes = [vp, vp]
+    lib.qrl_demod_set_ctcss.argtypes = [vp, C.c_float]
     lib.qrl_demod_stream.restype = vp
     lib.qrl_demod_stream.argtypes = [vp]
     lib.qrl_demod_profile.argtypes = [vp, C.c_int]
@@ -212,7 +213,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "qrl_init", "qrl_shutdown", "qrl_strerror", "qrl_last_error", "qrl_version", "qrl_demod_create",
     "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_set_option", "qrl_demod_set_dmo_output", "qrl_demod_stream_wait", "qrl_demod_out_caps",
-    "qrl_demod_audio_cap", "qrl_demod_set_squelch", "qrl_demod_set_agc",
+    "qrl_demod_audio_cap", "qrl_demod_set_squelch", "qrl_demod_set_agc", "qrl_demod_set_ctcss",
     "qrl_bptc19696_decode", "qrl_bptc19696_encode", "qrl_m17_decode_frames", "qrl_m17_encode_frames",
     "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
@@ -374,6 +375,10 @@ class Demod:
 
     def set_squelch(self, db):
         _check(self.lib.qrl_demod_set_squelch(self.h, C.c_double(db)), "qrl_demod_set_squelch")
+
+    def set_ctcss(self, tone_hz):
+        """gr_demod_nbfm::set_ctcss: 0 = off, else the CTCSS tone that opens the audio path"""
+        _check(self.lib.qrl_demod_set_ctcss(self.h, C.c_float(tone_hz)), "qrl_demod_set_ctcss")
 
     def set_agc(self, attack, decay):
         _check(self.lib.qrl_demod_set_agc(self.h, C.c_float(attack), C.c_float(decay)), "qrl_demod_set_agc")

@@ -43,7 +43,8 @@ struct qrl_amod {
     qrl_ctx* ctx = nullptr;
     qrl_amod_config cfg{};
     hipStream_t stream = nullptr; bool own_stream = false;
-    int sps = 20, fw = 5000; bool ssb = false, lsb = false;
+    int sps = 20, fw = 5000; bool ssb = false, lsb = false, am = false;
+    Dev<float> am_gain; Dev<float2> t_chan, m1, m2; int n_chan = 0; uint32_t mm = 0; uint64_t n1m = 0;   // AM: agc gain per stream, 1 Msps rings, channel filter
     Dev<float2> t_side, c1, c2, c3; int n_side = 0; Dev<float> atan_tab; uint64_t ns = 0; size_t last = 0;   // SSB
     float bb_gain = 1.0f, fm_k = 0.f;
     Dev<float> t_audio, t_if, t_filt, t_interp; int n_audio = 0, n_if = 0, n_filt = 0, n_interp = 0;
@@ -59,6 +60,12 @@ struct qrl_amod {
         for (auto* b : {&a0, &a1, &a2, &r50, &phase}) if ((r = b->zero())) return r;
         if ((r = fmv.zero()) || (r = flt.zero()) || (r = iir.zero())) return r;
         if (c1.p && ((r = c1.zero()) || (r = c2.zero()) || (r = c3.zero()))) return r;
+        if (am) {
+            if ((r = m1.zero()) || (r = m2.zero())) return r;
+            std::vector<float> one((size_t)cfg.batch, 1.0f);                      // agc2_ff(..., gain = 1)
+            if (hipMemcpy(am_gain.p, one.data(), one.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
+            n1m = 0;
+        }
         n8 = n50 = ns = 0; last = 0;
         return QRL_OK;
     }
@@ -78,12 +85,34 @@ int qrl_amod_create(qrl_ctx* ctx, const qrl_amod_config* cfg, qrl_amod** outp)
     case QRL_MODEM_NBFM5000: m->fw = 5000; break;     // :172
     case QRL_MODEM_USB2500: m->ssb = true; m->fw = 2700; m->sps = 125; break;              // make_gr_mod_ssb(125, 1000000, 1700, 2700, 0) :178
     case QRL_MODEM_LSB2500: m->ssb = m->lsb = true; m->fw = 2700; m->sps = 125; break;     // :179
-    default: return qrl_set_error(QRL_ERR_ARG, "amod: modem_type must be QRL_MODEM_NBFM2500 / NBFM5000 / USB2500 / LSB2500");
+    case QRL_MODEM_AM5000: m->am = true; m->fw = 5000; m->sps = 125; break;                 // make_gr_mod_am(125, 1000000, 1700, 5000) gr_mod_base.cpp:167
+    default: return qrl_set_error(QRL_ERR_ARG, "amod: modem_type must be QRL_MODEM_NBFM2500 / NBFM5000 / USB2500 / LSB2500 / AM5000");
     }
     HIPCHK(hipSetDevice(ctx->device));
     if (cfg->hip_stream) m->stream = static_cast<hipStream_t>(cfg->hip_stream);
     else { HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
     const int fw = m->fw, B = cfg->batch;
+    if (m->am) {
+        // gr_mod_am.cpp:40-57: audio band-pass, interpolator low_pass(sps, samp_rate, fw, fw) (Hamming), channel filter complex_band_pass_2
+        const std::vector<float> ta = band_pass_2(1, 8000, 300, 3000, 200, 60, WIN_HAMMING);
+        const std::vector<float> tr = low_pass(m->sps, 1000000, fw, fw, WIN_HAMMING);
+        const auto tc = complex_band_pass_2(1, 1000000, -fw, fw, 1200, 120, WIN_BLACKMAN_HARRIS);
+        m->n_audio = (int)ta.size(); m->n_interp = (int)tr.size(); m->n_chan = (int)tc.size();
+        if (m->n_interp > 2048 || (size_t)m->n_chan * sizeof(float2) > 60 * 1024) return qrl_set_error(QRL_ERR_ARG, "amod: AM filters too long for the kernels' LDS tables");
+        std::vector<float2> tc2(tc.size());
+        for (size_t i = 0; i < tc.size(); ++i) tc2[i] = make_float2(tc[i].real(), tc[i].imag());
+        int r;
+        if ((r = m->t_audio.upload(ta)) || (r = m->t_interp.upload(tr)) || (r = m->t_chan.upload(tc2))) return r;
+        m->m8 = pow2_at_least(cfg->max_samples + 1024) - 1;
+        m->mm = pow2_at_least((size_t)cfg->max_samples * m->sps + (size_t)m->n_chan + 1024) - 1;
+        const size_t r8 = (size_t)B * (m->m8 + 1), r1m = (size_t)B * (m->mm + 1);
+        if ((r = m->a0.alloc(r8)) || (r = m->a1.alloc(r8)) || (r = m->a2.alloc(r8)) || (r = m->c1.alloc(r8)) || (r = m->c2.alloc(1)) || (r = m->c3.alloc(1)) ||
+            (r = m->m1.alloc(r1m)) || (r = m->m2.alloc(r1m)) || (r = m->am_gain.alloc(B))) return r;
+        if ((r = m->r50.alloc(1)) || (r = m->fmv.alloc(1)) || (r = m->flt.alloc(1)) || (r = m->iir.alloc(1)) || (r = m->phase.alloc(1))) return r;
+        if ((r = m->init_state())) return r;
+        *outp = m.release();
+        return QRL_OK;
+    }
     if (m->ssb) {
         const std::vector<float> ta = band_pass_2(1, 8000, 300, fw, 200, 90, WIN_BLACKMAN_HARRIS);             // _audio_filter, gr_mod_ssb.cpp:43-45
         const auto ts = m->lsb ? complex_band_pass_2(1, 8000, -fw, -200, 200, 90, WIN_BLACKMAN_HARRIS)           // _filter_lsb, :56-57
@@ -132,9 +161,9 @@ int qrl_amod_reset(qrl_amod* m)
     return m->init_state();
 }
 int qrl_amod_set_bb_gain(qrl_amod* m, float g) { if (!m) return QRL_ERR_ARG; m->bb_gain = g; return QRL_OK; }
-size_t qrl_amod_samples_per_sample(const qrl_amod* m) { return m ? (m->ssb ? (size_t)m->sps : (size_t)25 * m->sps / 4) : 0; }
+size_t qrl_amod_samples_per_sample(const qrl_amod* m) { return m ? ((m->ssb || m->am) ? (size_t)m->sps : (size_t)25 * m->sps / 4) : 0; }
 size_t qrl_amod_last_count(const qrl_amod* m) { return m ? m->last : 0; }
-size_t qrl_amod_out_cap(const qrl_amod* m, size_t n) { return m ? (m->ssb ? (n + 1024) * (size_t)m->sps : n * 25 / 4 * (size_t)m->sps) : 0; }
+size_t qrl_amod_out_cap(const qrl_amod* m, size_t n) { return m ? (m->am ? n * (size_t)m->sps : m->ssb ? (n + 1024) * (size_t)m->sps : n * 25 / 4 * (size_t)m->sps) : 0; }
 void* qrl_amod_stream(qrl_amod* m) { return m ? m->stream : nullptr; }
 int qrl_amod_sync(qrl_amod* m) { if (!m) return QRL_ERR_ARG; HIPCHK(hipStreamSynchronize(m->stream)); return QRL_OK; }
 
@@ -142,12 +171,38 @@ int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, f
 {
     if (!m || (!audio && n) || (!iq && n)) return QRL_ERR_ARG;
     if (n > m->cfg.max_samples) return qrl_set_error(QRL_ERR_TOO_BIG, "n exceeds max_samples");
-    if (!m->ssb && n % 4) return qrl_set_error(QRL_ERR_ARG, "amod: audio samples per call must be a multiple of 4 (25:4 resampler)");
+    if (!m->ssb && !m->am && n % 4) return qrl_set_error(QRL_ERR_ARG, "amod: audio samples per call must be a multiple of 4 (25:4 resampler)");
     m->last = 0;
     if (n == 0) return QRL_OK;
     HIPCHK(hipSetDevice(m->ctx->device));
     const int B = m->cfg.batch;
     hipStream_t s = m->stream;
+    if (m->am) {   // gr_mod_am.cpp:66-77 in connection order
+        RingF a0{m->a0.p, m->m8}, a1{m->a1.p, m->m8}, a2{m->a2.p, m->m8};
+        RingC c1{m->c1.p, m->m8}, m1{m->m1.p, m->mm}, m2{m->m2.p, m->mm};
+        const uint32_t c8 = (uint32_t)n, c1m = (uint32_t)(n * (size_t)m->sps);
+        if ((size_t)c1m > out_stride && B > 1) return qrl_set_error(QRL_ERR_ARG, "amod: out_stride smaller than this call's output (qrl_amod_out_cap)");
+        AmLoadParams lp{}; lp.in = audio; lp.in_stride = stride; lp.out = a0; lp.n0 = m->n8; lp.count = c8;
+        launch_am_load(lp, B, s);
+        AmAgcParams ap{}; ap.in = a0; ap.out = a1; ap.n0 = m->n8; ap.count = c8; ap.attack = 1e-2f; ap.decay = 1e-4f; ap.ref = 1.0f; ap.max_gain = 1.0f;
+        ap.lo = -0.98f; ap.hi = 0.98f; ap.scale = 0.95f; ap.gain = m->am_gain.p;
+        launch_am_agc_rail(ap, B, s);                                               // _agc, _rail, _audio_amplify
+        FirFffParams af{}; af.in = a1; af.out = a2; af.q0 = m->n8; af.count = c8; af.taps = m->t_audio.p; af.nt = m->n_audio;
+        launch_fir_fff(af, B, s);                                                   // _audio_filter
+        launch_am_carrier(a2, c1, m->n8, c8, 0.5f, B, s);                           // _add with _signal_source (frequency 0: a constant), _float_to_complex
+        TxInterpCParams xp{}; xp.in = c1; xp.n0 = m->n1m; xp.count = c1m; xp.taps = m->t_interp.p; xp.nt = m->n_interp; xp.interp = m->sps;
+        xp.out = nullptr; xp.out_stride = 0; xp.out_ring = m1;
+        launch_tx_interp_c(xp, B, s);                                               // _resampler
+        launch_scale_c(m1, m->n1m, c1m, 0.5f, B, s);                                // _amplify
+        launch_scale_c(m1, m->n1m, c1m, m->bb_gain, B, s);                          // _bb_gain
+        FirCccParams ff{}; ff.in = m1; ff.out = m2; ff.q0 = m->n1m; ff.count = c1m; ff.taps = m->t_chan.p; ff.nt = m->n_chan;
+        ff.port = reinterpret_cast<float2*>(iq); ff.port_cap = out_stride;
+        launch_an_fir_ccc(ff, B, s);                                                // _filter: straight into the caller's buffer
+        HIPCHK(hipGetLastError());
+        if (qrl::take_launch_error()) return QRL_ERR_HIP;
+        m->n8 += c8; m->n1m += c1m; m->last = c1m;
+        return QRL_OK;
+    }
     if (m->ssb) {
         RingF a0{m->a0.p, m->m8}, a1{m->a1.p, m->m8};
         RingC c1{m->c1.p, m->m8}, c2{m->c2.p, m->m8}, c3{m->c3.p, m->m8};

@@ -227,6 +227,9 @@ struct qrl_demod {
     DevBuf<float> an_env, an_rtaps, an_ftaps; int an_ramp = 0, an_nr = 0, an_nf = 0, an_I = 2, an_D = 5;
     DevBuf<float> an_f1, an_f2, an_f3; uint32_t an_m1 = 0, an_m2 = 0;
     DevBuf<AnState> an_st;
+    // gr_demod_nbfm::set_ctcss: ctcss_squelch_ff between audio resampler and audio filter, band-pass audio filter while it is on
+    float ctcss_tone = 0.0f; DevBuf<CtcssState> an_cs; DevBuf<float> an_f4, an_ftaps_ct; DevBuf<double> an_env_ct; int an_nf_ct = 0;
+    float ct_wr[3] = {0, 0, 0}, ct_wi[3] = {0, 0, 0};
     double an_threshold = 1e-14, an_ff[2] = {0, 0}, an_fb1 = 0, an_de_ff[2] = {0, 0}, an_de_fb1 = 0;
     float an_gain = 1.f, an_attack = 0.1f, an_decay = 0.1f;
     int analog_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* out, uint32_t* counts, bool side);
@@ -301,7 +304,12 @@ int qrl_demod::init_state()
         n5 = nsy = 0;
     }
     if (fam == F_ANALOG) {
-        for (auto* b : {&an_f1, &an_f2, &an_f3}) if (b->p && (r = b->zero())) return r;
+        for (auto* b : {&an_f1, &an_f2, &an_f3, &an_f4}) if (b->p && (r = b->zero())) return r;
+        if (an_cs.p) {   // squelch_base: muted, envelope 0 (ramp 160); the Goertzel filters empty
+            std::vector<CtcssState> cs(cfg.batch);
+            for (auto& x : cs) { std::memset(&x, 0, sizeof x); x.mute = 1; x.env = 0.0; }
+            if (hipMemcpy(an_cs.p, cs.data(), cs.size() * sizeof(CtcssState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
+        }
         if (an_c1.p && (r = an_c1.zero())) return r;
         std::vector<AnState> as(cfg.batch);
         for (auto& x : as) { std::memset(&x, 0, sizeof x); x.env = an_ramp ? 0.0f : 1.0f; x.gain = 1.0f; }   // agc2_ff(0.1, 0.1, 1, 1), gr_demod_am.cpp:48
@@ -970,13 +978,21 @@ int qrl_demod::analog_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* 
         if (an_kind == 2) { p.port = aport; p.port_cap = acap; p.counts = counts; }
         launch_an_resamp(p, max_out, B, stream);
     }
+    const bool ctcss = an_kind == 0 && ctcss_tone != 0.0f;
+    if (ctcss) {   // _ctcss (gating): audio resampler -> ring f4, item count g2 (gr_demod_nbfm.cpp:110-119)
+        CtcssParams p{}; p.in = f2; p.out = RingF{an_f4.p, an_m2}; p.st = an_st.p; p.cs = an_cs.p; p.I = an_I; p.D = an_D;
+        for (int k = 0; k < 3; ++k) { p.wr[k] = ct_wr[k]; p.wi[k] = ct_wi[k]; }
+        p.level = 0.01; p.len = 8000; p.ramp = 160; p.env = an_env_ct.p;
+        launch_an_ctcss(p, B, stream);
+    }
     if (an_kind != 2) {   // _audio_filter (AM: -> port 1)
         AnFirParams p{}; p.in = f2; p.out = f3; p.st = an_st.p; p.taps = an_ftaps.p; p.nt = an_nf; p.I = an_I; p.D = an_D;
+        if (ctcss) { p.in = RingF{an_f4.p, an_m2}; p.taps = an_ftaps_ct.p; p.nt = an_nf_ct; p.cs = an_cs.p; }   // band_pass_2(1, 8000, 300, 3500, 200, 35, BH), :112-113
         if (an_kind == 1) { p.port = aport; p.port_cap = acap; p.counts = counts; }
         launch_an_fir(p, max_out, B, stream);
     }
     if (an_kind == 0) {   // _de_emph_filter, _level_control -> port 1
-        AnDeemphParams p{}; p.in = f3; p.st = an_st.p; p.I = an_I; p.D = an_D;
+        AnDeemphParams p{}; p.in = f3; p.st = an_st.p; p.I = an_I; p.D = an_D; p.cs = ctcss ? an_cs.p : nullptr;
         p.ff0 = an_de_ff[0]; p.ff1 = an_de_ff[1]; p.fb1 = an_de_fb1; p.port = aport; p.port_cap = acap; p.counts = counts;
         launch_an_deemph(p, B, stream);
     }
@@ -1207,6 +1223,47 @@ int qrl_demod_set_squelch(qrl_demod* d, double db)
 {
     if (!d || d->fam != qrl_demod::F_ANALOG) return QRL_ERR_ARG;
     d->an_threshold = std::pow(10.0, db / 10);   // pwr_squelch_cc::set_threshold
+    return QRL_OK;
+}
+int qrl_demod_set_ctcss(qrl_demod* d, float tone_hz)
+{
+    if (!d || d->fam != qrl_demod::F_ANALOG || d->an_kind != 0) return qrl_set_error(QRL_ERR_ARG, "qrl_demod_set_ctcss: NBFM receivers only (gr_demod_nbfm::set_ctcss)");
+    if (tone_hz < 0.0f || tone_hz > 1000.0f) return QRL_ERR_ARG;
+    HIPCHK(hipSetDevice(d->ctx->device));
+    const bool was_on = d->ctcss_tone != 0.0f, on = tone_hz != 0.0f;
+    if (int rs = d->sync_all()) return rs;
+    if (on && !d->an_cs.p) {   // first use: state, the gated ring, the band-pass audio filter, the envelope of ramp 160 (double: float item x double envelope)
+        int r;
+        const std::vector<float> ft = band_pass_2(1, 8000, 300, 3500, 200, 35, WIN_BLACKMAN_HARRIS);       // gr_demod_nbfm.cpp:112-113
+        d->an_nf_ct = (int)ft.size();
+        std::vector<double> env(161);
+        for (int k = 0; k <= 160; ++k) env[k] = 0.5 - std::cos(M_PI * (double)k / 160.0) / 2.0;
+        if ((r = d->an_ftaps_ct.upload(ft)) || (r = d->an_env_ct.upload(env)) || (r = d->an_cs.alloc(d->cfg.batch)) ||
+            (r = d->an_f4.alloc((size_t)d->cfg.batch * (d->an_m2 + 1)))) return qrl_set_error(r, "ctcss buffers");
+    }
+    if (on) {   // ctcss_squelch_ff::set_frequency -> update_fft_params: the tone and its neighbours in the CTCSS table (2 % at the ends / off the table)
+        static const float tones[38] = {67.0f, 71.9f, 74.4f, 77.0f, 79.7f, 82.5f, 85.4f, 88.5f, 91.5f, 94.8f, 97.4f, 100.0f, 103.5f, 107.2f, 110.9f, 114.8f,
+                                        118.8f, 123.0f, 127.3f, 131.8f, 136.5f, 141.3f, 146.2f, 151.4f, 156.7f, 162.2f, 167.9f, 173.8f, 179.9f, 186.2f, 192.8f,
+                                        203.5f, 210.7f, 218.1f, 225.7f, 233.6f, 241.8f, 250.3f};
+        int i = -1;
+        for (int k = 0; k < 38; ++k) if (tones[k] == tone_hz) i = k;
+        const float f[3] = {(i == -1 || i == 0) ? tone_hz * 0.98f : tones[i - 1], tone_hz, (i == -1 || i == 37) ? tone_hz * 1.02f : tones[i + 1]};
+        for (int k = 0; k < 3; ++k) {
+            const float w = (float)(2.0 * M_PI * f[k] / 8000);
+            d->ct_wr[k] = (float)(2.0 * (double)cosf(w));
+            d->ct_wi[k] = sinf(w);
+        }
+    }
+    d->ctcss_tone = tone_hz;
+    // switching the block in or out re-wires the audio path (the reference disconnects / connects under lock()): the chain restarts
+    // from a fresh state, like qrl_demod_reset; a new tone while it is on re-initialises the Goertzel filters only (set_frequency)
+    if (was_on != on) return d->init_state();
+    if (on) {
+        std::vector<CtcssState> cs(d->cfg.batch);
+        if (hipMemcpy(cs.data(), d->an_cs.p, cs.size() * sizeof(CtcssState), hipMemcpyDeviceToHost) != hipSuccess) return QRL_ERR_HIP;
+        for (auto& x : cs) { for (int k = 0; k < 3; ++k) x.d1[k] = x.d2[k] = 0.0f; x.processed = 0; }
+        if (hipMemcpy(d->an_cs.p, cs.data(), cs.size() * sizeof(CtcssState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
+    }
     return QRL_OK;
 }
 int qrl_demod_set_agc(qrl_demod* d, float attack, float decay)

@@ -275,7 +275,7 @@ struct TxShapeParams { RingB sym; RingF out; uint64_t n0; uint32_t count; int sp
                        int levels; float scale; };   // levels 2 | 4; scale 0 = none
 struct TxFmParams { RingF in; RingC out; uint64_t n0; uint32_t count; float k, amp; float* phase; };
 struct TxInterpCParams { RingC in; uint64_t n0; uint32_t count; const float* taps; int nt; int interp; float2* out; size_t out_stride;
-                         int decim; };   // decim > 1: rational_resampler_ccf(interp, decim) (gr_mod_m17: 125 / 3)
+                         int decim; RingC out_ring; };   // out_ring.p != nullptr: the samples go to ring item n0 + t instead of out (gr_mod_am: a filter follows)   // decim > 1: rational_resampler_ccf(interp, decim) (gr_mod_m17: 125 / 3)
 void launch_tx_spread(RingB coded, RingB chips, uint64_t c0, uint32_t ncoded, int batch, hipStream_t s);   // gr_mod_dsss: Barker-13 spreading
 void launch_tx_f2c(RingF in, RingC out, uint64_t n0, uint32_t count, float g, int batch, hipStream_t s);
 void launch_tx_raw_dibits(const uint8_t* bytes, size_t stride, uint32_t nbytes, RingB sym, uint64_t s0, int batch, hipStream_t s);
@@ -312,12 +312,21 @@ void launch_an_gate(const AnGateParams& p, int kind, int batch, hipStream_t s); 
 struct AnResampParams { RingF in, out; const AnState* st; const float* taps; int nt, I, D; float* port; size_t port_cap; uint32_t* counts;
                         uint64_t q0; uint32_t count; };   // st == nullptr: outputs q0 .. q0 + count (host-side counts: the TX chains)
 void launch_an_resamp(const AnResampParams& p, uint32_t max_out, int batch, hipStream_t s);
-struct AnFirParams { RingF in, out; const AnState* st; const float* taps; int nt, I, D; float* port; size_t port_cap; uint32_t* counts; };
+// analog::ctcss_squelch_ff between the audio resampler and the audio filter (gr_demod_nbfm::set_ctcss, gr_demod_nbfm.cpp:59-60,97-123):
+// per stream the three Goertzel filters, the squelch_base state machine and the count of items that passed the gate (g2)
+struct CtcssState { float d1[3], d2[3]; int processed, mute, state, ramped; double env; uint64_t g2, g2_prev; };
+struct CtcssParams { RingF in, out; const AnState* st; CtcssState* cs; int I, D; float wr[3], wi[3]; double level; int len, ramp; const double* env; };
+void launch_an_ctcss(const CtcssParams& p, int batch, hipStream_t s);
+struct AnFirParams { RingF in, out; const AnState* st; const float* taps; int nt, I, D; float* port; size_t port_cap; uint32_t* counts;
+                     const CtcssState* cs; };   // cs != nullptr: the call's output range is the CTCSS gate's (g2_prev .. g2)
 void launch_an_fir(const AnFirParams& p, uint32_t max_out, int batch, hipStream_t s);
-struct AnDeemphParams { RingF in; AnState* st; int I, D; double ff0, ff1, fb1; float* port; size_t port_cap; uint32_t* counts; };
+struct AnDeemphParams { RingF in; AnState* st; int I, D; double ff0, ff1, fb1; float* port; size_t port_cap; uint32_t* counts; const CtcssState* cs; };
 void launch_an_deemph(const AnDeemphParams& p, int batch, hipStream_t s);
 // I == 0 in AnFirParams / AnStretchParams: the output range of the call is the cessb stretcher's, 1024 floor((g - 2) / 1024)
 // analogue modulators (gr_mod_nbfm): linear audio -> ring; x gain -> two-tap IIR in double (lane per stream)
+struct AmAgcParams { RingF in, out; uint64_t n0; uint32_t count; float attack, decay, ref, max_gain, lo, hi, scale; float* gain; };   // gr_mod_am: agc2_ff -> rail_ff -> multiply_const_ff
+void launch_am_agc_rail(const AmAgcParams& p, int batch, hipStream_t s);
+void launch_am_carrier(RingF in, RingC out, uint64_t n0, uint32_t count, float carrier, int batch, hipStream_t s);
 struct AmLoadParams { const float* in; size_t in_stride; RingF out; uint64_t n0; uint32_t count; };
 void launch_am_load(const AmLoadParams& p, int batch, hipStream_t s);
 struct AmIirState { double y1; float x1, pad; };

@@ -203,7 +203,8 @@ __global__ __launch_bounds__(256) void k_an_fir(const AnFirParams P)
     __syncthreads();
     const int b = blockIdx.y;
     const AnState& st = P.st[b];
-    const uint64_t q0 = an_decim_count(st.g_prev, P.I, P.D), q1 = an_decim_count(st.g, P.I, P.D);
+    uint64_t q0 = an_decim_count(st.g_prev, P.I, P.D), q1 = an_decim_count(st.g, P.I, P.D);
+    if (P.cs) { q0 = P.cs[b].g2_prev; q1 = P.cs[b].g2; }        // behind the CTCSS gate: what passed it in this call
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t == 0 && P.port && P.counts) P.counts[b * 4 + 1] = (uint32_t)(q1 - q0);
     const uint64_t q = q0 + t;
@@ -249,13 +250,68 @@ void launch_an_stretch(const AnStretchParams& p, uint32_t max_out, int batch, hi
     hipLaunchKernelGGL(k_an_stretch, dim3((max_out + 255) / 256, batch), dim3(256), 0, s, p);
 }
 
+// analog::ctcss_squelch_ff(8000, tone, 0.01, 8000, 160, true) on the audio resampler's outputs of this call (gr_demod_nbfm.cpp:59-60,
+// 97-123): lane per stream, item by item -- three Goertzel recursions, the block decision every `len` items, the squelch_base state
+// machine with its raised-cosine envelope (double table), gating: an item that passes goes to ring item g2++.  Arithmetic of
+// oracle/orc_analog.c orc_ctcss_squelch_ff.
+__global__ __launch_bounds__(64) void k_an_ctcss(const CtcssParams P, int batch)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= batch) return;
+    const AnState& st = P.st[b];
+    const uint64_t q0 = an_decim_count(st.g_prev, P.I, P.D), q1 = an_decim_count(st.g, P.I, P.D);
+    CtcssState c = P.cs[b];
+    c.g2_prev = c.g2;
+    float* out = P.out.p + (size_t)b * (P.out.mask + 1u);
+    for (uint64_t q = q0; q < q1; ++q) {
+        const float x = an_ringf_at(P.in, b, (int64_t)q);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float y = x + P.wr[k] * c.d1[k];
+            y = y - c.d2[k];
+            c.d2[k] = c.d1[k]; c.d1[k] = y;
+        }
+        if (++c.processed == P.len) {
+            float o[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float re = (float)((0.5 * (double)P.wr[k] * (double)c.d1[k] - (double)c.d2[k]) / (double)P.len);
+                const float im = (P.wi[k] * c.d1[k]) / (float)P.len;
+                o[k] = floorf(100000.0f * sqrtf(re * re + im * im)) / 100000.0f;
+                c.d1[k] = c.d2[k] = 0.0f;
+            }
+            c.processed = 0;
+            c.mute = ((double)o[1] < P.level) || o[1] < o[0] || o[1] < o[2];
+        }
+        switch (c.state) {
+        case 0: if (!c.mute) c.state = P.ramp ? 1 : 2; break;
+        case 2: if (c.mute) c.state = P.ramp ? 3 : 0; break;
+        case 1:
+            c.env = P.env[++c.ramped];
+            if (c.ramped >= P.ramp) { c.state = 2; c.env = 1.0; }
+            break;
+        case 3:
+            c.env = P.env[--c.ramped];
+            if (c.ramped == 0) c.state = 0;
+            break;
+        }
+        if (c.state != 0) { out[(uint32_t)c.g2 & P.out.mask] = (float)((double)x * c.env); ++c.g2; }
+    }
+    P.cs[b] = c;
+}
+void launch_an_ctcss(const CtcssParams& p, int batch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_an_ctcss, dim3((batch + 63) / 64), dim3(64), 0, s, p, batch);
+}
+
 // NBFM: iir_filter_ffd(btaps, ataps, false) de-emphasis + multiply_const_ff(2.0) -> port 1
 __global__ __launch_bounds__(64) void k_an_deemph(const AnDeemphParams P, int batch)
 {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= batch) return;
     AnState st = P.st[b];
-    const uint64_t q0 = an_decim_count(st.g_prev, P.I, P.D), q1 = an_decim_count(st.g, P.I, P.D);
+    uint64_t q0 = an_decim_count(st.g_prev, P.I, P.D), q1 = an_decim_count(st.g, P.I, P.D);
+    if (P.cs) { q0 = P.cs[b].g2_prev; q1 = P.cs[b].g2; }
     float x1 = st.de_x; double y1 = st.de_y;
     for (uint64_t q = q0; q < q1; ++q) {
         const float x = an_ringf_at(P.in, b, (int64_t)q);
@@ -311,6 +367,50 @@ void launch_am_iir(const AmIirParams& p, int batch, hipStream_t s)
 {
     if (!p.count) return;
     hipLaunchKernelGGL(k_am_iir, dim3((batch + 63) / 64), dim3(64), 0, s, p, batch);
+}
+
+// gr_mod_am (reference src/gr/gr_mod_am.cpp:40-45,66-70): agc2_ff(attack, decay, 1, 1) with set_max_gain(1) -> rail_ff(-0.98, 0.98) ->
+// multiply_const_ff(0.95): a serial gain recursion per stream (one lane each), arithmetic of oracle/orc_analog.c orc_agc2_ff
+__global__ __launch_bounds__(64) void k_am_agc_rail(const AmAgcParams P, int batch)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= batch) return;
+    float gain = P.gain[b];
+    const float* in = P.in.p + (size_t)b * (P.in.mask + 1u);
+    float* out = P.out.p + (size_t)b * (P.out.mask + 1u);
+    for (uint32_t t = 0; t < P.count; ++t) {
+        const uint32_t n = (uint32_t)(P.n0 + t);
+        const float o = in[n & P.in.mask] * gain;
+        const float tmp = -P.ref + fabsf(o);
+        float rate = P.decay;
+        if (fabsf(tmp) > gain) rate = P.attack;
+        gain -= tmp * rate;
+        if (gain < 0.0f) gain = 10e-5f;
+        if (P.max_gain > 0.0f && gain > P.max_gain) gain = P.max_gain;
+        float v = o;
+        if (v < P.lo) v = P.lo; else if (v > P.hi) v = P.hi;
+        out[n & P.out.mask] = v * P.scale;
+    }
+    P.gain[b] = gain;
+}
+void launch_am_agc_rail(const AmAgcParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_am_agc_rail, dim3((batch + 63) / 64), dim3(64), 0, s, p, batch);
+}
+// add_ff(audio, sig_source_f(8000, GR_COS_WAVE, 0, 0.5)) -> float_to_complex: the carrier source has frequency 0 (:40), a constant
+__global__ __launch_bounds__(256) void k_am_carrier(RingF in, RingC out, uint64_t n0, uint32_t count, float carrier)
+{
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= count) return;
+    const uint32_t n = (uint32_t)(n0 + t);
+    out.p[(size_t)b * (out.mask + 1u) + (n & out.mask)] = make_float2(in.p[(size_t)b * (in.mask + 1u) + (n & in.mask)] + carrier, 0.0f);
+}
+void launch_am_carrier(RingF in, RingC out, uint64_t n0, uint32_t count, float carrier, int batch, hipStream_t s)
+{
+    if (!count) return;
+    hipLaunchKernelGGL(k_am_carrier, dim3((count + 255) / 256, batch), dim3(256), 0, s, in, out, n0, count, carrier);
 }
 
 // gr_mod_ssb (reference src/gr/gr_mod_ssb.cpp:26-82): float_to_complex -> cessb::clipper_cc(0.95), item by item

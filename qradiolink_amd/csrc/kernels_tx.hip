@@ -332,7 +332,8 @@ __global__ __launch_bounds__(256) void k_tx_interp_c(const TxInterpCParams P)
         ar = fmaf(h, x.x, ar);
         ai = fmaf(h, x.y, ai);
     }
-    P.out[(size_t)b * P.out_stride + t] = make_float2(ar, ai);
+    if (P.out_ring.p) P.out_ring.p[(size_t)b * (P.out_ring.mask + 1u) + ((uint32_t)n & P.out_ring.mask)] = make_float2(ar, ai);
+    else P.out[(size_t)b * P.out_stride + t] = make_float2(ar, ai);
 }
 // gr_mod_m17 (reference src/gr/gr_mod_m17.cpp:47-58,77-80): packed_to_unpacked(1, MSB) -> pack_k_bits(2) -> map{2, 3, 1, 0}: four symbol
 // indices per byte, no scrambler / FEC (the M17 frame encoder has already done that)

@@ -247,11 +247,18 @@ gr_amod_hip_sptr make_gr_mod_nbfm_hip(qrl_runtime& rt, int sps, int samp_rate, i
         throw std::invalid_argument("make_gr_mod_nbfm_hip: the instances of gr_mod_base.cpp:171-172 are (20, 1000000, ., 2500 | 5000)");
     return gr_amod_hip_sptr(new gr_amod_hip(rt, filter_width));
 }
-gr_amod_hip::gr_amod_hip(qrl_runtime& rt, int filter_width)
+gr_amod_hip_sptr make_gr_mod_am_hip(qrl_runtime& rt, int sps, int samp_rate, int carrier_freq, int filter_width)
+{
+    (void)carrier_freq;
+    if (sps != 125 || samp_rate != 1000000 || filter_width != 5000)
+        throw std::invalid_argument("make_gr_mod_am_hip: the instance of gr_mod_base.cpp:167 is (125, 1000000, ., 5000)");
+    return gr_amod_hip_sptr(new gr_amod_hip(rt, filter_width, QRL_MODEM_AM5000));
+}
+gr_amod_hip::gr_amod_hip(qrl_runtime& rt, int filter_width, int modem_type)
     : gr::sync_interpolator("gr_amod_hip", gr::io_signature::make(1, 1, sizeof(float)), gr::io_signature::make(1, 1, sizeof(gr_complex)), 125)
 {
     qrl_amod_config c{};
-    c.modem_type = filter_width == 2500 ? QRL_MODEM_NBFM2500 : QRL_MODEM_NBFM5000;
+    c.modem_type = modem_type >= 0 ? modem_type : filter_width == 2500 ? QRL_MODEM_NBFM2500 : QRL_MODEM_NBFM5000;
     c.batch = 1; c.max_samples = kMaxAudio; c.bb_gain = 1.0f;
     chk(qrl_amod_create(rt.ctx(), &c, &d_h), "qrl_amod_create");
     hchk(hipMalloc(reinterpret_cast<void**>(&d_audio), kMaxAudio * sizeof(float)), "hipMalloc");

@@ -113,9 +113,11 @@ gr_mod_hip_sptr make_gr_mod_bpsk_hip(qrl_runtime& rt, int sps = 125, int samp_ra
 class gr_amod_hip;
 typedef std::shared_ptr<gr_amod_hip> gr_amod_hip_sptr;
 gr_amod_hip_sptr make_gr_mod_nbfm_hip(qrl_runtime& rt, int sps = 20, int samp_rate = 1000000, int carrier_freq = 1700, int filter_width = 5000);
+// replaces make_gr_mod_am(sps, samp_rate, carrier_freq, filter_width)             src/gr/gr_mod_am.cpp:19-24, instance gr_mod_base.cpp:167 (125, 1000000, 1700, 5000)
+gr_amod_hip_sptr make_gr_mod_am_hip(qrl_runtime& rt, int sps = 125, int samp_rate = 1000000, int carrier_freq = 1700, int filter_width = 5000);
 class gr_amod_hip : public gr::sync_interpolator {
 public:
-    gr_amod_hip(qrl_runtime& rt, int filter_width);
+    gr_amod_hip(qrl_runtime& rt, int filter_width, int modem_type = -1);   // modem_type -1: NBFM by filter width
     ~gr_amod_hip() override;
     void set_bb_gain(float value);                  // gr_mod_nbfm::set_bb_gain
     int work(int noutput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) override;

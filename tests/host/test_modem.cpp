@@ -116,7 +116,12 @@ int main(int argc, char** argv)
                 const int L = modem_tx_frame_length(mode);
                 txm.startTransmission("N0CALL");
                 while (txs.size() < chunk * (size_t)calls) {
-                    for (int f = 0; f < 8; ++f) { unsigned char* d = new unsigned char[L]; for (int i = 0; i < L; ++i) d[i] = (unsigned char)(31 * f + 7 * i + 1); txm.transmitDigitalAudio(d, L); }
+                    for (int f = 0; f < 8; ++f) {
+                        unsigned char* d = new unsigned char[L];
+                        for (int i = 0; i < L; ++i) d[i] = (unsigned char)(31 * f + 7 * i + 1);
+                        if (mode == QRL_MODEM_QPSK250K || mode == QRL_MODEM_QPSKVIDEO || mode == QRL_MODEM_4FSK100K) txm.transmitNetData(d, L);   // the fast modes frame IP / video only (gr_modem.cpp:1183-1282)
+                        else txm.transmitDigitalAudio(d, L);
+                    }
                     std::vector<gr_complex> part(mod.samples_per_byte() * 4096);
                     for (;;) { gr_complex* o = part.data(); const size_t ns = mod.work(&o); if (!ns) break; for (size_t i = 0; i < ns; ++i) txs.push_back(0.05f * part[i]); }
                 }

@@ -736,9 +736,18 @@ def det_log2f(x):
 ANALOG_KINDS = {"nbfm": 0, "am": 1, "wbfm": 2}
 
 
-def demod_analog(x, kind, samp_rate=1000000, filter_width=5000):
-    """-> dict(filtered=cf32 port 0, audio=f32 port 1)"""
+def ctcss_squelch_ff(x, rate=8000, freq=88.5, level=0.01, length=8000, ramp=160, gate=True):
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros(max(x.size, 1), np.float32)
+    lib.orc_ctcss_squelch_ff.restype = C.c_size_t
+    n = lib.orc_ctcss_squelch_ff(_ptr(x), C.c_size_t(x.size), rate, C.c_float(freq), C.c_double(level), length, ramp, int(gate), _ptr(out))
+    return out[:n].copy()
+
+
+def demod_analog(x, kind, samp_rate=1000000, filter_width=5000, ctcss=0.0):
+    """-> dict(filtered=cf32 port 0, audio=f32 port 1); ctcss != 0 (NBFM): gr_demod_nbfm::set_ctcss(tone) was called"""
     x = np.ascontiguousarray(x, cf32)
+    lib.orc_set_ctcss(C.c_float(ctcss))
     f, a = C.c_void_p(), C.c_void_p()
     nf, na = C.c_size_t(), C.c_size_t()
     lib.orc_demod_analog(_ptr(x), C.c_size_t(x.size), ANALOG_KINDS[kind], samp_rate, filter_width,
@@ -746,6 +755,7 @@ def demod_analog(x, kind, samp_rate=1000000, filter_width=5000):
     filt = np.ctypeslib.as_array(C.cast(f, C.POINTER(C.c_float)), (2 * nf.value,)).copy().view(cf32) if nf.value else np.zeros(0, cf32)
     aud = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_float)), (na.value,)).copy() if na.value else np.zeros(0, np.float32)
     lib.orc_free(f); lib.orc_free(a)
+    lib.orc_set_ctcss(C.c_float(0.0))
     return dict(filtered=filt, audio=aud)
 
 
@@ -786,6 +796,16 @@ def mod_ssb(audio, sb=0, sps=125, samp_rate=1000000, filter_width=2700, bb_gain=
     n = lib.orc_mod_ssb(*args, None)
     y = np.zeros(max(n, 1), cf32)
     m = lib.orc_mod_ssb(*args, _ptr(y)) if n else 0
+    return y[:m]
+
+
+def mod_am(audio, sps=125, samp_rate=1000000, filter_width=5000, bb_gain=1.0):
+    audio = np.ascontiguousarray(audio, np.float32)
+    lib.orc_mod_am.restype = C.c_size_t
+    args = (_ptr(audio), C.c_size_t(audio.size), sps, samp_rate, filter_width, C.c_float(bb_gain))
+    n = lib.orc_mod_am(*args, None)
+    y = np.zeros(max(n, 1), cf32)
+    m = lib.orc_mod_am(*args, _ptr(y)) if n else 0
     return y[:m]
 
 

@@ -57,7 +57,7 @@ def test_device_framing_host_time(tmp_path):
     well above 1 for the polls"""
     if not os.path.exists(EXE):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qradiolink_amd", "csrc"), "adaptor"])
-    r = subprocess.run([EXE, "hosttime", "26", "4096", "8"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([EXE, "hosttime", "26", "4096", "12"], capture_output=True, text=True, timeout=600)
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
     f = float(r.stdout.split("poll factor ")[1].split(",")[0])

@@ -102,6 +102,49 @@ def test_fll_slim_geometry_bit_exact(qrl_ctx, mode_name, modem, chunk):
     _compare(iq, out, mode_name, 1000000, 1200.0)
 
 
+def _nbfm_with_tone(n, seed, tone, fs=1000000.0, gap=None):
+    """NBFM carrier whose audio is a voice-band tone plus a sub-audible CTCSS tone (deviation ~ 15 %)"""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / fs
+    a = 0.5 * np.sin(2 * np.pi * 1000.0 * t) + (0.15 * np.sin(2 * np.pi * tone * t) if tone else 0.0)
+    ph = 2 * np.pi * 2500.0 * np.cumsum(a) / fs
+    x = 0.05 * np.exp(1j * ph) + 0.0005 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    if gap:
+        x[gap[0]:gap[1]] = 0.0005 * (rng.standard_normal(gap[1] - gap[0]) + 1j * rng.standard_normal(gap[1] - gap[0]))
+    return x.astype(np.complex64)
+
+
+@pytest.mark.parametrize("chunk", [1 << 21, 200000, 33334])
+def test_nbfm_ctcss_squelch_bit_exact(qrl_ctx, chunk):
+    """gr_demod_nbfm::set_ctcss(88.5) (src/gr/gr_demod_nbfm.cpp:59-60, 97-123): ctcss_squelch_ff(8000, 88.5, 0.01, 8000, 160, true) between
+    audio resampler and audio filter, band-pass audio filter.  Three receivers: the right tone (audio opens after the first 1 s
+    block), another tone of the table (91.5 Hz: stays shut), no tone (stays shut); audio and its COUNT equal the oracle bit for bit,
+    in one call and cut into calls; switching the block out again restores the constructor's graph."""
+    import torch
+    import qradiolink_amd as q
+    n = 2500000
+    iq = np.stack([_nbfm_with_tone(n, 1, 88.5), _nbfm_with_tone(n, 2, 91.5), _nbfm_with_tone(n, 3, 0.0)])
+    dem = q.Demod(qrl_ctx, q.MODEM_NBFM5000, batch=3, max_chunk=min(chunk, n))
+    dem.set_ctcss(88.5)
+    out = q.collect(dem, torch.from_numpy(iq).cuda(), min(chunk, n) & ~1)
+    refs = [orc.demod_analog(iq[b], "nbfm", filter_width=5000, ctcss=88.5) for b in range(3)]
+    for b in range(3):
+        got, want = out["audio"][b] + np.float32(0), refs[b]["audio"] + np.float32(0)
+        assert got.size == want.size, (b, got.size, want.size)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), b
+    assert refs[0]["audio"].size > 8000 and refs[1]["audio"].size == 0 and refs[2]["audio"].size == 0
+    a = refs[0]["audio"][2000:10000].astype(np.float64)
+    spec = np.abs(np.fft.rfft(a * np.hanning(a.size)))
+    assert abs(np.argmax(spec) * 8000.0 / a.size - 1000.0) < 3.0          # the voice tone; the 88.5 Hz tone is below the 300 Hz band-pass
+    dem.set_ctcss(0.0)                                                      # back to the constructor's graph (fresh state)
+    out2 = q.collect(dem, torch.from_numpy(iq).cuda(), min(chunk, n) & ~1)
+    dem.close()
+    for b in range(3):
+        want = orc.demod_analog(iq[b], "nbfm", filter_width=5000)["audio"] + np.float32(0)
+        got = out2["audio"][b] + np.float32(0)
+        assert got.size == want.size and np.array_equal(got.view(np.uint32), want.view(np.uint32)), b
+
+
 @pytest.mark.parametrize("chunk", [65536, 10007 * 2, 300002])
 def test_chunk_invariance_gmsk(qrl_ctx, chunk):
     iq, out = _run(qrl_ctx, "gmsk10k", 22, 4000000, 25000.0, B=2, chunk=chunk, nframes=2)

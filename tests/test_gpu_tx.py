@@ -295,7 +295,45 @@ def test_nbfm_voice_loopback_on_gpu(qrl_ctx):
     spec = np.abs(np.fft.rfft(a * np.hanning(a.size)))
     assert abs(np.argmax(spec) * 8000.0 / a.size - 700.0) < 3.0 and np.sqrt(np.mean(a ** 2)) > 0.3
     with pytest.raises(q.QrlError):
-        q.AMod(qrl_ctx, q.MODEM_AM5000, batch=1, max_samples=64)          # the AM modulator is not built
+        q.AMod(qrl_ctx, q.MODEM_WBFM, batch=1, max_samples=64)            # no WBFM transmitter in the reference's mode table either
+
+
+# ---- gr_mod_am (src/gr/gr_mod_am.cpp:26-74): agc2_ff -> rail -> band-pass -> + carrier -> 1:125 -> gains -> 4545-tap complex band-pass
+@pytest.mark.parametrize("chunk", [800, 250, 37])
+def test_am_modulator_bit_exact(qrl_ctx, chunk):
+    import torch
+    import qradiolink_amd as q
+    n = 800
+    t = np.arange(n) / 8000.0
+    audio = np.stack([0.5 * np.sin(2 * np.pi * 700 * t) + 0.2 * np.sin(2 * np.pi * 1900 * t),
+                      np.random.default_rng(4).uniform(-1.4, 1.4, n)]).astype(np.float32)      # (the second stream drives the rail and the AGC)
+    mod = q.AMod(qrl_ctx, q.MODEM_AM5000, batch=2, max_samples=chunk, bb_gain=0.75)
+    parts = [mod.process(torch.from_numpy(np.ascontiguousarray(audio[:, s:s + chunk])).cuda()).cpu().numpy()[:, :125 * min(chunk, n - s)] for s in range(0, n, chunk)]
+    mod.close()
+    got = np.concatenate(parts, axis=1)
+    assert got.shape == (2, 125 * n)
+    for b in range(2):
+        want = orc.mod_am(audio[b], bb_gain=0.75)
+        g, w = got[b].view(np.float32) + np.float32(0), want.view(np.float32) + np.float32(0)
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), "stream %d differs" % b
+    assert 0.15 < np.abs(got[0, 60000:]).mean() < 0.22          # carrier 0.5 x 0.5 x 0.75
+
+
+def test_am_voice_loopback_on_gpu(qrl_ctx):
+    """gr_mod_am -> (level) -> gr_demod_am, both on the device: the tone that went in comes out"""
+    import torch
+    import qradiolink_amd as q
+    n = 4000
+    audio = (0.5 * np.sin(2 * np.pi * 700 * np.arange(n) / 8000.0)).astype(np.float32)
+    mod = q.AMod(qrl_ctx, q.MODEM_AM5000, batch=1, max_samples=n)
+    iq = mod.process(torch.from_numpy(audio[None, :]).cuda()) * 0.2
+    mod.close()
+    dem = q.Demod(qrl_ctx, q.MODEM_AM5000, batch=1, max_chunk=iq.shape[1])
+    out = q.collect(dem, iq.contiguous(), iq.shape[1])
+    dem.close()
+    a = out["audio"][0][1500:3500].astype(np.float64)
+    spec = np.abs(np.fft.rfft((a - a.mean()) * np.hanning(a.size)))
+    assert abs(np.argmax(spec) * 8000.0 / a.size - 700.0) < 6.0 and np.std(a) > 0.02
 
 
 @pytest.mark.parametrize("modem,sb", [(11, 0), (12, 1)])

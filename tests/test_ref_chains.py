@@ -74,7 +74,7 @@ MAP = {
 
 # blocks the oracle's chains restate inline (no primitive of their own); their reference arguments are checked against the constants
 # the oracle hard-codes, per chain, in INLINE below
-INLINE_KINDS = {"blocks::complex_to_mag", "blocks::divide_ff", "blocks::add_const_ff", "analog::rail_ff", "blocks::float_to_complex",
+INLINE_KINDS = {"analog::sig_source_f", "blocks::complex_to_mag", "blocks::divide_ff", "blocks::add_const_ff", "analog::rail_ff", "blocks::float_to_complex",
                 "blocks::multiply_const_ff", "blocks::multiply_const_cc", "blocks::float_to_uchar", "blocks::delay",
                 "blocks::complex_to_float", "blocks::interleave", "blocks::complex_to_real", "blocks::complex_to_mag_squared",
                 "blocks::multiply_ff", "blocks::add_ff", "blocks::float_to_short", "analog::phase_modulator_fc",
@@ -206,6 +206,11 @@ def ref_events(g):
         kind, args = g.blocks[bid]
         if kind in MAP:
             name, a = MAP[kind](args)
+            if name in ("agc2_ff", "agc2_cc"):          # a set_max_gain() call after make() replaces the default of 65536
+                for c in g.calls:
+                    m = re.match(r"^#%d\.set_max_gain\((.*)\)$" % bid, c)
+                    if m:
+                        a = a[:4] + [m.group(1)]
             ev.append((bid, name, tuple(norm_value(x, g, name in DOUBLE_PARAMS) for x in a)))
         elif kind in INLINE_KINDS or kind.startswith("custom::"):       # custom:: = the reference's own blocks (pinned in test_ref_blocks.py)
             inline.append((bid, kind, args))
@@ -361,6 +366,28 @@ def test_demod_nbfm(fw):
             ["blocks::multiply_const_ff(2)"])
 
 
+def test_demod_nbfm_ctcss_block():
+    """gr_demod_nbfm creates _ctcss = ctcss_squelch_ff(8000, 88.5, 0.01, 8000, 160, true) (:59-60) but leaves it unconnected until
+    set_ctcss(tone) (:97-123, not a constructor path): the block's constructor parameters equal the ones the oracle's NBFM chain uses
+    when the tone is switched on, and the audio filter it swaps in is the band_pass_2 of :112-113 (checked against the source text)."""
+    g = RefGraph(ref_log("demod_nbfm", 125, 1000000, 1700, 5000))
+    blk = [(b, a) for b, (k, a) in g.blocks.items() if k == "analog::ctcss_squelch_ff"]
+    assert len(blk) == 1 and blk[0][0] not in g.connected
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal(60000) + 1j * rng.standard_normal(60000)).astype(np.complex64) * 0.3
+    tr = [parse_call(l) for l in oracle_trace(lambda v: orc.demod_analog(v, "nbfm", filter_width=5000, ctcss=88.5), x)]
+    ct = [a for n_, a in tr if n_ == "ctcss_squelch_ff"]
+    assert len(ct) == 1
+    assert [norm_value(v) for v in blk[0][1]] == [norm_value(v) for v in ct[0]]
+    fir = [a for n_, a in tr if n_ == "fir_fff"]
+    assert any("band_pass_2(1,8000,300,3500,200,35," in a[0] for a in fir)
+    src = os.path.join("/root/reference/src/gr/gr_demod_nbfm.cpp")
+    if os.path.exists(src):
+        text = open(src).read().replace(" ", "").replace("\n", "")
+        assert "band_pass_2(1,8000,300,3500,200,35,gr::fft::window::WIN_BLACKMAN_HARRIS)" in text
+        assert "connect(_audio_resampler,0,_ctcss,0);connect(_ctcss,0,_audio_filter,0);" in text
+
+
 def test_demod_am():
     compare("demod_am", (125, 1000000, 1700, 5000), lambda x: orc.demod_analog(x, "am", filter_width=5000), dict(),
             ["blocks::complex_to_mag()", "blocks::multiply_const_ff(0.98999999999999999)"], n=20000)
@@ -424,6 +451,19 @@ def test_mod_nbfm(fw):
     compare("mod_nbfm", (20, 1000000, 1700, fw), orc.mod_nbfm, dict(filter_width=fw),
             ["blocks::multiply_const_ff(0.98999999999999999,1)", "blocks::multiply_const_cc(0.80000000000000004,1)", BB1],
             x=(rng.standard_normal(800) * 0.1).astype(np.float32))
+
+
+def test_mod_am():
+    """gr_mod_am (src/gr/gr_mod_am.cpp:26-74, instance gr_mod_base.cpp:167): agc2_ff with set_max_gain(1), rail, audio band-pass, the
+    frequency-0 carrier source added to the audio, 1:125 resampler, gains, the 4545-tap complex band-pass; the feedforward_agc_cc the
+    constructor creates is NOT connected and therefore not part of the compared graph"""
+    rng = np.random.default_rng(3)
+    g = compare("mod_am", (125, 1000000, 1700, 5000), orc.mod_am, dict(),
+                ["analog::sig_source_f(8000,enum:102,0,0.5)", "analog::rail_ff(-0.97999999999999998,0.97999999999999998)", "blocks::add_ff()",
+                 "blocks::multiply_const_ff(0.94999999999999996,1)", "blocks::float_to_complex()", "blocks::multiply_const_cc(0.5,1)", BB1],
+                x=(rng.standard_normal(200) * 0.1).astype(np.float32))
+    ffagc = [b for b, (k, _) in g.blocks.items() if k == "analog::feedforward_agc_cc"]
+    assert len(ffagc) == 1 and ffagc[0] not in g.connected
 
 
 @pytest.mark.parametrize("sps,fw", [(250, 2800), (500, 1500)])
