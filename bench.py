@@ -298,7 +298,7 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, c
     g.manual_seed(7 + rank)
     from qradiolink_amd import sharding
     link_bytes = None
-    if world == 1:
+    if world == 1 and not args.cluster:
         iq = torch.view_as_complex(torch.randn((B, n, 2), generator=g, device=dev, dtype=torch.float32) * 0.05)
         ch = q.Channelizer(ctx, M, batch=B, max_chunk=n)
         ch.enable_4fsk()
@@ -307,35 +307,26 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, c
         step, sync, prof = (lambda: ch.process_async(iq)), ch.sync, ch
         handles = [ch]
     else:
-        # SURVEY 8e, PFB form: every rank channelizes ITS B / world wideband streams (all 64 channels), one all_to_all_single
-        # (RCCL over xGMI) hands each rank the channels it owns of EVERY stream, the per-channel chains run on the owner.  Per link
-        # and step: (B / world) x (64 / world) x n / 64 cf32 items = 1 / world of a rank's input bytes.
+        # SURVEY 8e, PFB form, driven through the C++ host class qrl_host::chan_cluster (qradiolink_amd/host/chan_cluster.*, libqrl_cluster.so):
+        # every rank channelizes ITS B / world wideband streams (all 64 channels), ONE all-to-all per step (chan_exchange::all_to_all:
+        # ncclAllToAll over xGMI on its own communicator) hands each rank the channels it owns of EVERY stream, the per-channel chains run
+        # on the owner; ordering on the device (qrl_chan_stream_wait / qrl_chan_wait_for), no host synchronisation.  Per link and step:
+        # (B / world) x (64 / world) x n / 64 cf32 items = 1 / world of a rank's input bytes.  (--cluster at N = 1: the same object
+        # with a one-rank RCCL communicator -- what a one-GPU box can run of this path.)
         Bl, n1 = B // world, n // M
         iq = torch.view_as_complex(torch.randn((Bl, n, 2), generator=g, device=dev, dtype=torch.float32) * 0.05)   # this rank's own inputs
-        ch = q.Channelizer(ctx, M, batch=Bl, max_chunk=n)
-        tail = q.Channelizer(ctx, 1, batch=B * per, max_chunk=n1, form=3)
-        tail.enable_4fsk()
-        send = [torch.empty((world, Bl, per, n1), dtype=torch.complex64, device=dev) for _ in range(2)]
-        recv = [torch.empty((world, Bl, per, n1), dtype=torch.complex64, device=dev) for _ in range(2)]
-        ts = torch.cuda.current_stream().cuda_stream
+        ex = sharding.Exchange.rccl(torch.distributed if world > 1 else None)
+        cl = sharding.Cluster(ctx, ex, M, Bl, n)
+        cl.tail.enable_4fsk()
         link_bytes = sharding.bytes_per_link_per_step(Bl, M, world, n1)
-        k = [0]
+        ch = cl.front
 
         def step():
-            b = k[0] & 1
-            k[0] += 1
-            ch.wait_for(ts)                  # send[b] is free once the collectives queued so far have read it
-            ch.channelize_async(iq, send[b], world)
-            ch.stream_wait(ts)               # the collective runs behind the channelizer ...
-            tail.stream_wait(ts)             # ... and recv[b] is free once the per-channel chains queued so far have consumed it
-            torch.distributed.all_to_all_single(torch.view_as_real(recv[b]), torch.view_as_real(send[b]))
-            tail.wait_for(ts)
-            tail.process_channels_async(recv[b].view(B * per, n1), n1)
+            cl.step_async(iq)
 
         def sync():
-            ch.sync()
-            tail.sync()
-        prof, handles = ch, [ch, tail]
+            cl.sync()
+        prof, handles = cl.front, [cl.front, cl.tail]
     prof.profile(True)
     marks = StepMarks(torch, handles[-1].stream_wait, enabled=not args.no_marks)
     dt = timed_loop(step, sync, args, torch, dev, world, marks)
@@ -343,9 +334,13 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, c
     launches_timed = args.steps
     kms = kms * launches_timed / max(launches, 1)          # (the warm-up calls were profiled too: same kernel, same shape)
     prof.profile(False)
-    parity = parity_check_c4(ch, iq, torch) if (check and world == 1 and rank == 0) else None
-    for h in handles:
-        h.close()
+    parity = parity_check_c4(ch, iq, torch) if (check and world == 1 and rank == 0 and not args.cluster) else None
+    if world == 1 and not args.cluster:
+        for h in handles:
+            h.close()
+    else:
+        cl.close()
+        ex.close()
     b_kernel = (B // world) if world > 1 else B             # wideband streams the channelizer of THIS rank processes per launch
     line = {"metric": "wideband IQ MSamples/sec through the C4 receiver", "value": round(B * n * args.steps / dt / 1e6, 1), "unit": "MS/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -354,7 +349,7 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, c
                        "wideband_streams": B, "samples_per_stream_per_step": n, "channels_per_gpu": per,
                        "parallelism": ("channels sharded over ranks: every rank channelizes its %d wideband streams, one RCCL all_to_all_single per step moves "
                                        "the channel streams to their owners (%d bytes per link and step), per-channel chains on the owner" % (B // world, link_bytes))
-                                      if world > 1 else "single GPU",
+                                      if (world > 1 or args.cluster) else "single GPU",
                        "bytes_per_link_per_step": link_bytes},
             "roofline": roofline_obj(kname, kms, launches_timed, b_kernel * n * C4_BYTES, round(C4_BYTES, 3),
                                      "k_pfb_chan64 reads the wideband input once and writes the 64 channel rings; whole chain: %.1f GB/s of algorithmic bytes"
@@ -362,7 +357,7 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, c
             "step_spread_ms": marks.spread()}
     if parity:
         line["parity_check"] = parity
-    if world == 1 and with_form2:
+    if world == 1 and with_form2 and not args.cluster:
         # BASELINE configs[3] literally: 64 freq-xlating FIRs (2181 taps, 1:64) -- compute bound (34 MAC per input sample and channel)
         B2, n2 = max(1, B // 8), n // 4
         ch2 = q.Channelizer(ctx, M, batch=B2, max_chunk=n2, form=2)
@@ -595,6 +590,7 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="(the library default since round 3; kept for the tools/ scripts)")
     ap.add_argument("--no-overlap", action="store_true", help="C1 only: QRL_OPT_OVERLAP = 0 (the kernels of a call strictly one after the other)")
     ap.add_argument("--fll-slim", action="store_true", help="tuning, c1: QRL_OPT_FLL_SLIM = 1 (single-wave FLL workgroups)")
+    ap.add_argument("--cluster", action="store_true", help="c4: drive the channel-sharded path (qrl_host::chan_cluster + RCCL all-to-all) also at N = 1")
     ap.add_argument("--no-marks", action="store_true", help="no per-step completion events (step_spread_ms = null)")
     ap.add_argument("--check", action="store_true", help="with --no-extra: still run the parity check against the oracle at the bench shape")
     ap.add_argument("--legacy-pfb", type=int, default=0, help="A/B, c4: QRL_CHAN_OPT_LEGACY_PFB (1 = general-M channelizer kernel, 2 = the tiled 64-channel kernel of round 3)")

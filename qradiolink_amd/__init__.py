@@ -431,16 +431,20 @@ class Channelizer:
     [batch, channel_count, cap], counts int32 [batch, channel_count])."""
 
     def __init__(self, ctx, num_channels, batch, max_chunk, channel_first=0, channel_count=0, stream=None, form=0,
-                 channel_separation=0, decimation=0, filter_width=0):
+                 channel_separation=0, decimation=0, filter_width=0, _handle=None):
         import torch
         self.torch = torch
         self.ctx, self.lib = ctx, ctx.lib
-        cfg = _ChanConfig()
-        cfg.num_channels, cfg.channel_first, cfg.channel_count = num_channels, channel_first, channel_count
-        cfg.batch, cfg.max_chunk, cfg.hip_stream = batch, max_chunk, stream
-        cfg.form, cfg.channel_separation, cfg.decimation, cfg.filter_width = form, channel_separation, decimation, filter_width
-        self.h = C.c_void_p()
-        _check(self.lib.qrl_chan_create(ctx.h, C.byref(cfg), C.byref(self.h)), "qrl_chan_create")
+        self.owns = _handle is None        # _handle: a qrl_chan owned by someone else (qradiolink_amd.sharding.Cluster's handles)
+        if _handle is None:
+            cfg = _ChanConfig()
+            cfg.num_channels, cfg.channel_first, cfg.channel_count = num_channels, channel_first, channel_count
+            cfg.batch, cfg.max_chunk, cfg.hip_stream = batch, max_chunk, stream
+            cfg.form, cfg.channel_separation, cfg.decimation, cfg.filter_width = form, channel_separation, decimation, filter_width
+            self.h = C.c_void_p()
+            _check(self.lib.qrl_chan_create(ctx.h, C.byref(cfg), C.byref(self.h)), "qrl_chan_create")
+        else:
+            self.h = C.c_void_p(_handle)
         self.batch = batch
         self.cc = channel_count if channel_count > 0 else num_channels
         self.cap = self.lib.qrl_chan_out_cap(self.h, max_chunk)
@@ -525,7 +529,8 @@ class Channelizer:
 
     def close(self):
         if self.h:
-            self.lib.qrl_chan_destroy(self.h)
+            if self.owns:
+                self.lib.qrl_chan_destroy(self.h)
             self.h = C.c_void_p()
 
 

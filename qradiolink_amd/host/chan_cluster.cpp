@@ -1,0 +1,177 @@
+// chan_cluster.cpp — see chan_cluster.h.  Host C++ only: the device work is behind the C ABI (qrl_chan_*), the collective is RCCL.
+#include "chan_cluster.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <stdexcept>
+
+namespace qrl_host {
+
+namespace {
+void chk(int status, const char* what)
+{
+    if (status != QRL_OK) throw std::runtime_error(std::string(what) + ": " + qrl_strerror(status) + " (" + qrl_last_error() + ")");
+}
+void hchk(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+void nchk(ncclResult_t r, const char* what)
+{
+    if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r));
+}
+}  // namespace
+
+void self_exchange::all_to_all(const void* send, void* recv, size_t bytes_per_peer, void* stream)
+{
+    hchk(hipMemcpyAsync(recv, send, bytes_per_peer, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)), "self_exchange: hipMemcpyAsync");
+}
+
+void rccl_exchange::unique_id(unsigned char out[kIdBytes])
+{
+    static_assert(sizeof(ncclUniqueId) <= kIdBytes, "ncclUniqueId larger than the id buffer");
+    ncclUniqueId id;
+    nchk(ncclGetUniqueId(&id), "ncclGetUniqueId");
+    std::memset(out, 0, kIdBytes);
+    std::memcpy(out, &id, sizeof id);
+}
+rccl_exchange::rccl_exchange(int world, int rank, const unsigned char id[kIdBytes]) : d_world(world), d_rank(rank)
+{
+    if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("rccl_exchange: bad world / rank");
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof uid);
+    ncclComm_t comm = nullptr;
+    nchk(ncclCommInitRank(&comm, world, uid, rank), "ncclCommInitRank");
+    d_comm = comm;
+}
+rccl_exchange::~rccl_exchange()
+{
+    if (d_comm) (void)ncclCommDestroy(static_cast<ncclComm_t>(d_comm));
+}
+void rccl_exchange::all_to_all(const void* send, void* recv, size_t bytes_per_peer, void* stream)
+{
+    // equal blocks to and from every peer: one ncclAllToAll (xGMI is point-to-point: world - 1 links carry bytes_per_peer each)
+    if (bytes_per_peer % 4) throw std::invalid_argument("rccl_exchange: blocks are cf32 items");
+    nchk(ncclAllToAll(send, recv, bytes_per_peer / 4, ncclFloat32, static_cast<ncclComm_t>(d_comm), static_cast<hipStream_t>(stream)), "ncclAllToAll");
+}
+
+void callback_exchange::all_to_all(const void* send, void* recv, size_t bytes_per_peer, void* stream)
+{
+    if (!d_fn || d_fn(d_user, send, recv, bytes_per_peer, stream) != 0) throw std::runtime_error("callback_exchange: the transport callback failed");
+}
+
+chan_cluster::chan_cluster(qrl_ctx* ctx, chan_exchange& ex, int num_channels, int streams_local, size_t max_chunk)
+    : d_ex(ex), d_M(num_channels), d_bl(streams_local), d_per(num_channels / (ex.world() > 0 ? ex.world() : 1)), d_n1max(max_chunk / (size_t)num_channels)
+{
+    const int W = ex.world();
+    if (W < 1 || num_channels < 2 || num_channels % W || streams_local < 1 || d_n1max < 1)
+        throw std::invalid_argument("chan_cluster: the number of ranks must divide the channels; streams_local >= 1; max_chunk >= num_channels");
+    qrl_chan_config c{};
+    c.num_channels = num_channels; c.batch = streams_local; c.max_chunk = max_chunk; c.form = 0;
+    chk(qrl_chan_create(ctx, &c, &d_front), "qrl_chan_create (channelizer)");
+    qrl_chan_config t{};
+    t.num_channels = 1; t.batch = streams_local * W * d_per; t.max_chunk = d_n1max; t.form = 3;
+    chk(qrl_chan_create(ctx, &t, &d_tail), "qrl_chan_create (per-channel chains)");
+    const size_t items = (size_t)W * d_bl * d_per * d_n1max;
+    for (int k = 0; k < 2; ++k) {
+        hchk(hipMalloc(reinterpret_cast<void**>(&d_send[k]), items * 2 * sizeof(float)), "hipMalloc");
+        hchk(hipMalloc(reinterpret_cast<void**>(&d_recv[k]), items * 2 * sizeof(float)), "hipMalloc");
+    }
+    hipStream_t xs;
+    hchk(hipStreamCreateWithFlags(&xs, hipStreamNonBlocking), "hipStreamCreate");
+    d_xs = xs;
+}
+chan_cluster::~chan_cluster()
+{
+    if (d_front) qrl_chan_destroy(d_front);
+    if (d_tail) qrl_chan_destroy(d_tail);
+    if (d_xs) { (void)hipStreamSynchronize(static_cast<hipStream_t>(d_xs)); (void)hipStreamDestroy(static_cast<hipStream_t>(d_xs)); }
+    for (int k = 0; k < 2; ++k) { if (d_send[k]) (void)hipFree(d_send[k]); if (d_recv[k]) (void)hipFree(d_recv[k]); }
+}
+void chan_cluster::channelize(const float* iq, size_t stride, size_t n)
+{
+    if (n % (size_t)d_M || n / (size_t)d_M > d_n1max) throw std::invalid_argument("chan_cluster: n must be a multiple of num_channels and <= max_chunk");
+    d_cur = (int)(d_k++ & 1u);
+    d_n1 = n / (size_t)d_M;
+    chk(qrl_chan_wait_for(d_front, d_xs), "qrl_chan_wait_for");          // send[cur] is free once the exchanges queued so far have read it
+    chk(qrl_chan_channelize(d_front, iq, stride, n, d_send[d_cur], d_n1max, d_ex.world()), "qrl_chan_channelize");
+}
+void chan_cluster::exchange()
+{
+    chk(qrl_chan_stream_wait(d_front, d_xs), "qrl_chan_stream_wait");    // the collective runs behind the channelizer ...
+    chk(qrl_chan_stream_wait(d_tail, d_xs), "qrl_chan_stream_wait");     // ... and recv[cur] is free once the per-channel chains queued so far have consumed it
+    d_ex.all_to_all(d_send[d_cur], d_recv[d_cur], (size_t)d_bl * d_per * d_n1max * 2 * sizeof(float), d_xs);
+}
+void chan_cluster::process_channels(int16_t* out, size_t out_cap, uint32_t* counts)
+{
+    chk(qrl_chan_wait_for(d_tail, d_xs), "qrl_chan_wait_for");           // the per-channel chains run behind the collective
+    chk(qrl_chan_process_channels(d_tail, d_recv[d_cur], d_n1max, d_n1, out, out_cap, counts), "qrl_chan_process_channels");
+}
+void chan_cluster::step(const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts)
+{
+    channelize(iq, stride, n);
+    exchange();
+    process_channels(out, out_cap, counts);
+}
+void chan_cluster::sync()
+{
+    chk(qrl_chan_sync(d_front), "qrl_chan_sync");
+    hchk(hipStreamSynchronize(static_cast<hipStream_t>(d_xs)), "hipStreamSynchronize");
+    chk(qrl_chan_sync(d_tail), "qrl_chan_sync");
+}
+
+}  // namespace qrl_host
+
+// ---- C ABI ------------------------------------------------------------------------------------------------------------------------
+struct qrl_exchange { qrl_host::chan_exchange* ex; };
+struct qrl_cluster { qrl_host::chan_cluster* cl; };
+static thread_local std::string g_cluster_error;
+template <class F> static int guarded(F&& f)
+{
+    try { f(); return QRL_OK; }
+    catch (const std::invalid_argument& e) { g_cluster_error = e.what(); return QRL_ERR_ARG; }
+    catch (const std::exception& e) { g_cluster_error = e.what(); return QRL_ERR_HIP; }
+}
+extern "C" {
+const char* qrl_cluster_last_error(void) { return g_cluster_error.c_str(); }
+int qrl_exchange_unique_id(unsigned char* out128) { return out128 ? guarded([&] { qrl_host::rccl_exchange::unique_id(out128); }) : QRL_ERR_ARG; }
+int qrl_exchange_create_rccl(int world, int rank, const unsigned char* id128, qrl_exchange** out)
+{
+    if (!id128 || !out) return QRL_ERR_ARG;
+    return guarded([&] { *out = new qrl_exchange{new qrl_host::rccl_exchange(world, rank, id128)}; });
+}
+int qrl_exchange_create_self(qrl_exchange** out) { return out ? guarded([&] { *out = new qrl_exchange{new qrl_host::self_exchange}; }) : QRL_ERR_ARG; }
+int qrl_exchange_create_callback(int world, int rank, qrl_host::chan_exchange_fn fn, void* user, qrl_exchange** out)
+{
+    if (!fn || !out || world < 1 || rank < 0 || rank >= world) return QRL_ERR_ARG;
+    return guarded([&] { *out = new qrl_exchange{new qrl_host::callback_exchange(world, rank, fn, user)}; });
+}
+int qrl_exchange_all_to_all(qrl_exchange* ex, const void* send, void* recv, size_t bytes_per_peer, void* hip_stream)
+{
+    if (!ex || !send || !recv) return QRL_ERR_ARG;
+    return guarded([&] { ex->ex->all_to_all(send, recv, bytes_per_peer, hip_stream); });
+}
+void qrl_exchange_destroy(qrl_exchange* ex) { if (ex) { delete ex->ex; delete ex; } }
+int qrl_cluster_create(qrl_ctx* ctx, qrl_exchange* ex, int num_channels, int streams_local, size_t max_chunk, qrl_cluster** out)
+{
+    if (!ctx || !ex || !out) return QRL_ERR_ARG;
+    return guarded([&] { *out = new qrl_cluster{new qrl_host::chan_cluster(ctx, *ex->ex, num_channels, streams_local, max_chunk)}; });
+}
+void qrl_cluster_destroy(qrl_cluster* c) { if (c) { delete c->cl; delete c; } }
+qrl_chan* qrl_cluster_front(qrl_cluster* c) { return c ? c->cl->front() : nullptr; }
+qrl_chan* qrl_cluster_tail(qrl_cluster* c) { return c ? c->cl->tail() : nullptr; }
+int qrl_cluster_rows(qrl_cluster* c) { return c ? c->cl->rows() : 0; }
+int qrl_cluster_step(qrl_cluster* c, const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts)
+{
+    return c ? guarded([&] { c->cl->step(iq, stride, n, out, out_cap, counts); }) : QRL_ERR_ARG;
+}
+int qrl_cluster_channelize(qrl_cluster* c, const float* iq, size_t stride, size_t n) { return c ? guarded([&] { c->cl->channelize(iq, stride, n); }) : QRL_ERR_ARG; }
+int qrl_cluster_exchange(qrl_cluster* c) { return c ? guarded([&] { c->cl->exchange(); }) : QRL_ERR_ARG; }
+int qrl_cluster_process_channels(qrl_cluster* c, int16_t* out, size_t out_cap, uint32_t* counts)
+{
+    return c ? guarded([&] { c->cl->process_channels(out, out_cap, counts); }) : QRL_ERR_ARG;
+}
+int qrl_cluster_sync(qrl_cluster* c) { return c ? guarded([&] { c->cl->sync(); }) : QRL_ERR_ARG; }
+}

@@ -60,20 +60,193 @@ def gather_units(local_items, n_units, dist=None):
     return out
 
 
-def exchange_channels(send, dist=None):
-    """All-to-all of channelizer output.  send: tensor [world, B_local, C // world, n1] (any device; complex64 viewed as float32 pairs is
-    done here) whose slice [d] holds this rank's streams x the channels rank d owns.  Returns recv of the same shape with
-    recv[s] = the slice rank s sent here, i.e. this rank's channels of every stream, stream-major by source rank."""
+# ---- the exchange itself lives in C++ (qradiolink_amd/host/chan_cluster.*, libqrl_cluster.so): chan_exchange::all_to_all with the
+# transports rccl (production, N GPUs), self (one rank) and callback (a function: torch.distributed / gloo in the CPU tests, a
+# permutation copy in the single-device emulation).  bench.py --config c4 --gpus N, tests/test_sharding.py and
+# tests/test_gpu_sharding.py all call Exchange.all_to_all / Cluster.step below: one code path.
+import ctypes as _C
+import os as _os
+
+_EXCHANGE_FN = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t, _C.c_void_p)
+_cluster_lib = None
+
+
+def cluster_library():
+    global _cluster_lib
+    if _cluster_lib is None:
+        path = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libqrl_cluster.so")
+        if not _os.path.exists(path):
+            raise RuntimeError("libqrl_cluster.so is not built: make -C qradiolink_amd/csrc cluster")
+        L = _C.CDLL(path)
+        vp, sz = _C.c_void_p, _C.c_size_t
+        L.qrl_cluster_last_error.restype = _C.c_char_p
+        L.qrl_exchange_unique_id.argtypes = [vp]
+        L.qrl_exchange_create_rccl.argtypes = [_C.c_int, _C.c_int, vp, _C.POINTER(vp)]
+        L.qrl_exchange_create_self.argtypes = [_C.POINTER(vp)]
+        L.qrl_exchange_create_callback.argtypes = [_C.c_int, _C.c_int, _EXCHANGE_FN, vp, _C.POINTER(vp)]
+        L.qrl_exchange_all_to_all.argtypes = [vp, vp, vp, sz, vp]
+        L.qrl_exchange_destroy.argtypes = [vp]
+        L.qrl_cluster_create.argtypes = [vp, vp, _C.c_int, _C.c_int, sz, _C.POINTER(vp)]
+        L.qrl_cluster_destroy.argtypes = [vp]
+        for n in ("qrl_cluster_front", "qrl_cluster_tail"):
+            getattr(L, n).restype = vp
+            getattr(L, n).argtypes = [vp]
+        L.qrl_cluster_rows.argtypes = [vp]
+        L.qrl_cluster_step.argtypes = [vp, vp, sz, sz, vp, sz, vp]
+        L.qrl_cluster_channelize.argtypes = [vp, vp, sz, sz]
+        L.qrl_cluster_exchange.argtypes = [vp]
+        L.qrl_cluster_process_channels.argtypes = [vp, vp, sz, vp]
+        L.qrl_cluster_sync.argtypes = [vp]
+        _cluster_lib = L
+    return _cluster_lib
+
+
+def _ck(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, cluster_library().qrl_cluster_last_error().decode()))
+
+
+class Exchange:
+    """qrl_host::chan_exchange behind its C ABI.  Exchange.rccl(dist): ncclAllToAll on a communicator of this job's ranks (the unique id
+    travels through the given torch.distributed group); Exchange.torch(dist): the callback transport around
+    torch.distributed.all_to_all_single (gloo on CPU tensors in the tests); Exchange.callback(world, rank, fn): any function
+    fn(send_ptr, recv_ptr, bytes_per_peer, stream) -> None; Exchange.self_(): one rank, a device copy."""
+
+    def __init__(self, handle, world, rank, keep=None):
+        self.h, self.world, self.rank, self._keep = handle, world, rank, keep
+        self.tensors = {}
+
+    @classmethod
+    def self_(cls):
+        h = _C.c_void_p()
+        _ck(cluster_library().qrl_exchange_create_self(_C.byref(h)), "qrl_exchange_create_self")
+        return cls(h, 1, 0)
+
+    @classmethod
+    def callback(cls, world, rank, fn):
+        def thunk(user, send, recv, nbytes, stream):
+            try:
+                fn(send, recv, nbytes, stream)
+                return 0
+            except Exception as e:          # a Python exception must not unwind through the C++ frames
+                import sys
+                print("exchange callback failed: %r" % (e,), file=sys.stderr)
+                return 1
+        cfn = _EXCHANGE_FN(thunk)
+        h = _C.c_void_p()
+        _ck(cluster_library().qrl_exchange_create_callback(world, rank, cfn, None, _C.byref(h)), "qrl_exchange_create_callback")
+        return cls(h, world, rank, keep=cfn)
+
+    @classmethod
+    def torch(cls, dist=None):
+        """all_to_all_single of the process group, on the tensors registered for the pointers the C++ side passes down"""
+        if dist is None:
+            import torch.distributed as dist
+        world, rank = dist.get_world_size(), dist.get_rank()
+        ex = None
+
+        def fn(send, recv, nbytes, stream):
+            s, r = ex.tensors[send], ex.tensors[recv]
+            dist.all_to_all_single(r, s)
+        ex = cls.callback(world, rank, fn)
+        return ex
+
+    @classmethod
+    def rccl(cls, dist=None):
+        """the production transport: an RCCL communicator of this job's ranks (one per GPU); the 128-byte unique id is made by rank 0
+        and broadcast through the existing torch.distributed group"""
+        L = cluster_library()
+        single = dist is None or not (dist.is_available() and dist.is_initialized())     # no process group: a communicator of one rank
+        world, rank = (1, 0) if single else (dist.get_world_size(), dist.get_rank())
+        buf = (_C.c_ubyte * 128)()
+        if rank == 0:
+            _ck(L.qrl_exchange_unique_id(buf), "qrl_exchange_unique_id")
+        box = [bytes(buf)]
+        if not single:
+            dist.broadcast_object_list(box, src=0)
+        ident = (_C.c_ubyte * 128).from_buffer_copy(box[0])
+        h = _C.c_void_p()
+        _ck(L.qrl_exchange_create_rccl(world, rank, ident, _C.byref(h)), "qrl_exchange_create_rccl")
+        return cls(h, world, rank)
+
+    def register(self, *tensors):
+        """the callback transports look their tensors up by data pointer"""
+        for t in tensors:
+            self.tensors[t.data_ptr()] = t
+
+    def all_to_all(self, send, recv, stream=0):
+        """send / recv: contiguous tensors of `world` equal blocks (block d goes to rank d, block s came from rank s)"""
+        assert send.is_contiguous() and recv.is_contiguous() and send.numel() == recv.numel() and send.shape[0] == self.world
+        self.register(send, recv)
+        nbytes = send.numel() * send.element_size() // self.world
+        _ck(cluster_library().qrl_exchange_all_to_all(self.h, send.data_ptr(), recv.data_ptr(), nbytes, _C.c_void_p(stream)), "qrl_exchange_all_to_all")
+        del self.tensors[send.data_ptr()], self.tensors[recv.data_ptr()]
+
+    def close(self):
+        if self.h:
+            cluster_library().qrl_exchange_destroy(self.h)
+            self.h = _C.c_void_p()
+
+
+class Cluster:
+    """qrl_host::chan_cluster: one rank of the channel-sharded C4 receiver (channelize own streams -> one all-to-all -> per-channel
+    chains of the owned channels).  .front / .tail are Channelizer views of its two handles (profiling on .front; the int16 / RSSI /
+    4FSK outputs live on .tail, rows = (source rank * streams_local + stream) * channels_per_rank + local channel)."""
+
+    def __init__(self, ctx, exchange, num_channels, streams_local, max_chunk):
+        import qradiolink_amd as q
+        self.L, self.ex, self.ctx = cluster_library(), exchange, ctx
+        self.h = _C.c_void_p()
+        _ck(self.L.qrl_cluster_create(ctx.h, exchange.h, num_channels, streams_local, max_chunk, _C.byref(self.h)), "qrl_cluster_create")
+        self.rows = self.L.qrl_cluster_rows(self.h)
+        self.per = num_channels // exchange.world
+        self.front = q.Channelizer(ctx, num_channels, batch=streams_local, max_chunk=max_chunk, _handle=self.L.qrl_cluster_front(self.h))
+        self.tail = q.Channelizer(ctx, 1, batch=self.rows, max_chunk=max_chunk // num_channels, form=3, _handle=self.L.qrl_cluster_tail(self.h))
+
+    def step_async(self, iq):
+        t = self.tail
+        _ck(self.L.qrl_cluster_step(self.h, iq.data_ptr(), iq.stride(0), iq.shape[1], t.out.data_ptr(), t.cap, t.counts.data_ptr()), "qrl_cluster_step")
+
+    def channelize(self, iq):
+        _ck(self.L.qrl_cluster_channelize(self.h, iq.data_ptr(), iq.stride(0), iq.shape[1]), "qrl_cluster_channelize")
+
+    def exchange(self):
+        _ck(self.L.qrl_cluster_exchange(self.h), "qrl_cluster_exchange")
+
+    def process_channels(self):
+        t = self.tail
+        _ck(self.L.qrl_cluster_process_channels(self.h, t.out.data_ptr(), t.cap, t.counts.data_ptr()), "qrl_cluster_process_channels")
+
+    def sync(self):
+        _ck(self.L.qrl_cluster_sync(self.h), "qrl_cluster_sync")
+
+    def close(self):
+        if self.h:
+            self.front.close()
+            self.tail.close()
+            self.L.qrl_cluster_destroy(self.h)
+            self.h = _C.c_void_p()
+
+
+def exchange_channels(send, dist=None, exchange=None):
+    """All-to-all of channelizer output through the C++ exchange (chan_exchange::all_to_all).  send: tensor [world, B_local, C // world,
+    n1] (any device) whose slice [d] holds this rank's streams x the channels rank d owns.  Returns recv of the same shape with
+    recv[s] = the slice rank s sent here, i.e. this rank's channels of every stream, stream-major by source rank.
+    exchange: an Exchange to use (default: Exchange.torch(dist), the callback transport around the process group)."""
     import torch
     if dist is None:
         import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if exchange is None and (not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1):
         return send.clone()
-    if send.shape[0] != dist.get_world_size():
+    own = exchange is None
+    ex = Exchange.torch(dist) if own else exchange
+    if send.shape[0] != ex.world:
         raise ValueError("exchange_channels: leading dimension must be the world size")
-    sv = torch.view_as_real(send) if send.is_complex() else send
+    sv = (torch.view_as_real(send) if send.is_complex() else send).contiguous()
     recv = torch.empty_like(sv)
-    dist.all_to_all_single(recv, sv.contiguous())
+    ex.all_to_all(sv, recv)
+    if own:
+        ex.close()
     return torch.view_as_complex(recv) if send.is_complex() else recv
 
 

@@ -92,58 +92,116 @@ def test_channel_sharding_two_processes_with_broadcast():
         assert got[c] == np.ascontiguousarray(ref[c]).tobytes(), "channel %d differs from the oracle" % c
 
 
-def test_channel_all_to_all_form_two_emulated_ranks_equal_the_unsharded_receiver(qrl_ctx):
-    """SURVEY 8e, PFB form, as bench.py --config c4 --gpus N runs it: every rank channelizes ITS wideband streams
-    (qrl_chan_channelize, output grouped by destination rank), an all-to-all hands each rank its channels of EVERY stream, the
-    per-channel chains run there (form-3 handles, qrl_chan_process_channels).  Two ranks emulated on one device: the exchange is the
-    same slicing all_to_all_single performs (sharding.exchange_channels; its gloo run is tests/test_sharding.py).  Two calls, so that
-    channelizer history, channel-ring history and the symbol-sync state carry.  Must equal the unsharded receiver bit for bit."""
-    import torch
+def _unsharded(qrl_ctx, d, M, cuts, cal):
+    """the unsharded receiver over the same calls: per call (int16, counts, rssi, rssi counts, dibits, 4fsk counts)"""
     import qradiolink_amd as q
+    ref = q.Channelizer(qrl_ctx, M, batch=d.shape[0], max_chunk=max(cuts))
+    ref.calibrate_rssi(cal)
+    ref.enable_4fsk()
+    out, pos = [], 0
+    for c in cuts:
+        ro, rc = ref.process(d[:, pos:pos + c].contiguous())
+        pos += c
+        out.append((ro.cpu().numpy().copy(), rc.cpu().numpy().copy(), ref.rssi.cpu().numpy().copy(), ref.rssi_counts.cpu().numpy().copy(),
+                    ref.dibits.cpu().numpy().copy(), ref.fsk_counts.cpu().numpy().copy()))
+    ref.close()
+    return out
+
+
+def _compare_rank(tail, ref_call, r, world, B, cpr):
+    """rows of rank r's per-channel handle against the unsharded receiver: row = (source rank * Bl + stream) * cpr + local channel"""
+    ro, rc, rr, rrc, rd, rdc = ref_call
+    o, cn = tail.out.cpu().numpy(), tail.counts.cpu().numpy()
+    rs, rsc = tail.rssi.cpu().numpy(), tail.rssi_counts.cpu().numpy()
+    db, dbc = tail.dibits.cpu().numpy(), tail.fsk_counts.cpu().numpy()
+    for b in range(B):                       # global stream index = source rank * Bl + local stream: rows are in that order
+        for cl in range(cpr):
+            row, ch_abs = b * cpr + cl, r * cpr + cl
+            assert cn[row, 0] == rc[b, ch_abs] and np.array_equal(o[row, 0, :cn[row, 0]], ro[b, ch_abs, :rc[b, ch_abs]]), (r, b, cl)
+            assert rsc[row, 0] == rrc[b, ch_abs] and np.array_equal(rs[row, 0, :rsc[row, 0]], rr[b, ch_abs, :rrc[b, ch_abs]])
+            assert dbc[row, 0, 2] == rdc[b, ch_abs, 2] and np.array_equal(db[row, 0, :dbc[row, 0, 2]], rd[b, ch_abs, :rdc[b, ch_abs, 2]])
+
+
+def test_channel_all_to_all_form_two_emulated_ranks_equal_the_unsharded_receiver(qrl_ctx):
+    """SURVEY 8e, PFB form, through the SAME C++ object bench.py --config c4 --gpus N drives (qrl_host::chan_cluster, libqrl_cluster.so):
+    every rank channelizes ITS wideband streams, chan_exchange::all_to_all hands each rank its channels of EVERY stream, the
+    per-channel chains run there.  Two ranks emulated on one device: two clusters whose callback transport records the send / receive
+    buffers; the test then performs the permutation an all-to-all performs (block r of rank s's send buffer -> block s of rank r's
+    receive buffer) on each rank's exchange stream.  Two calls, so that channelizer history, channel-ring history and the symbol-sync
+    state carry.  Must equal the unsharded receiver bit for bit."""
+    import ctypes as C
+    import torch
     import test_gpu_chan as tg
     M, B, world, n = 64, 4, 2, 64 * 1600
     cpr, Bl = M // world, B // world
     iq = tg._wideband(M, n, seed=91, nstreams=B)
     d = torch.from_numpy(iq).cuda()
     cuts = [64 * 1000, 64 * 600]
-    # unsharded reference run
-    ref = q.Channelizer(qrl_ctx, M, batch=B, max_chunk=max(cuts))
-    ref.calibrate_rssi(0.25)
-    ref.enable_4fsk()
-    chans = [q.Channelizer(qrl_ctx, M, batch=Bl, max_chunk=max(cuts)) for _ in range(world)]
-    tails = [q.Channelizer(qrl_ctx, 1, batch=B * cpr, max_chunk=max(cuts) // M, form=3) for _ in range(world)]
-    for t in tails:
-        t.calibrate_rssi(0.25)
-        t.enable_4fsk()
+    ref = _unsharded(qrl_ctx, d, M, cuts, 0.25)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    pending = {}
+    exs = [sharding.Exchange.callback(world, r, (lambda r: lambda send, recv, nbytes, stream: pending.__setitem__(r, (send, recv, nbytes, stream)))(r))
+           for r in range(world)]
+    cls = [sharding.Cluster(qrl_ctx, exs[r], M, Bl, max(cuts)) for r in range(world)]
+    for c in cls:
+        c.tail.calibrate_rssi(0.25)
+        c.tail.enable_4fsk()
     pos = 0
-    for c in cuts:
+    for k, c in enumerate(cuts):
         part = d[:, pos:pos + c].contiguous()
         pos += c
-        n1 = c // M
-        ro, rc = ref.process(part)
-        ro, rc = ro.cpu().numpy(), rc.cpu().numpy()
-        rr, rrc = ref.rssi.cpu().numpy(), ref.rssi_counts.cpu().numpy()
-        rd, rdc = ref.dibits.cpu().numpy(), ref.fsk_counts.cpu().numpy()
-        send = [torch.zeros((world, Bl, cpr, n1), dtype=torch.complex64, device="cuda") for _ in range(world)]
-        ts = torch.cuda.current_stream().cuda_stream                          # the stream torch (and, in the real job, the collective) works on
         for r in range(world):
-            chans[r].wait_for(ts)                                             # the send buffer was zero-filled on torch's stream
-            chans[r].channelize_async(part[r * Bl:(r + 1) * Bl].contiguous(), send[r], world)
-            chans[r].sync()
+            cls[r].channelize(part[r * Bl:(r + 1) * Bl].contiguous())
         for r in range(world):
-            recv = torch.stack([send[s][r] for s in range(world)])            # what all_to_all_single delivers to rank r ...
-            tails[r].wait_for(ts)                                             # ... on torch's stream: the handle's own stream has to wait for it
-            tails[r].process_channels_async(recv.reshape(B * cpr, n1).contiguous(), n1)
-            tails[r].sync()
-            o, cn = tails[r].out.cpu().numpy(), tails[r].counts.cpu().numpy()
-            rs, rsc = tails[r].rssi.cpu().numpy(), tails[r].rssi_counts.cpu().numpy()
-            db, dbc = tails[r].dibits.cpu().numpy(), tails[r].fsk_counts.cpu().numpy()
-            for b in range(B):
-                for cl in range(cpr):
-                    row, ch_abs = b * cpr + cl, r * cpr + cl
-                    assert cn[row, 0] == rc[b, ch_abs] and np.array_equal(o[row, 0, :cn[row, 0]], ro[b, ch_abs, :rc[b, ch_abs]]), (r, b, cl)
-                    assert rsc[row, 0] == rrc[b, ch_abs] and np.array_equal(rs[row, 0, :rsc[row, 0]], rr[b, ch_abs, :rrc[b, ch_abs]])
-                    assert dbc[row, 0, 2] == rdc[b, ch_abs, 2] and np.array_equal(db[row, 0, :dbc[row, 0, 2]], rd[b, ch_abs, :rdc[b, ch_abs, 2]])
-    assert np.abs(ro).max() > 1000
-    for h in [ref] + chans + tails:
-        h.close()
+            cls[r].exchange()                                               # the callbacks fill `pending`
+        for r in range(world):
+            cls[r].front.sync()                                             # (the emulation copies across ranks: every channelizer must be through)
+        for r in range(world):
+            _, recv, nbytes, stream = pending[r]
+            for s_ in range(world):
+                assert hip.hipMemcpyAsync(recv + s_ * nbytes, pending[s_][0] + r * nbytes, nbytes, 3, stream) == 0   # hipMemcpyDeviceToDevice
+        for r in range(world):
+            cls[r].process_channels()
+            cls[r].sync()
+            _compare_rank(cls[r].tail, ref[k], r, world, B, cpr)
+    assert np.abs(ref[-1][0]).max() > 1000
+    for c in cls:
+        c.close()
+    for e in exs:
+        e.close()
+
+
+def test_cluster_with_the_rccl_transport_on_one_rank_equals_the_plain_receiver(qrl_ctx):
+    """the production transport on what one GPU allows: an RCCL communicator of ONE rank (ncclCommInitRank(1, id, 0)), chan_cluster::step
+    = channelize -> ncclAllToAll (to itself) -> per-channel chains, two pipelined steps without a host synchronisation in between;
+    rows equal the unsharded receiver's channels bit for bit.  Also the self transport (a device copy)."""
+    import ctypes as C
+    import torch
+    import test_gpu_chan as tg
+    M, B, n = 64, 3, 64 * 1200
+    iq = tg._wideband(M, n, seed=92, nstreams=B)
+    d = torch.from_numpy(iq).cuda()
+    cuts = [64 * 700, 64 * 500]
+    ref = _unsharded(qrl_ctx, d, M, cuts, -1.5)
+    L = sharding.cluster_library()
+    for kind in ("rccl", "self"):
+        if kind == "rccl":
+            ident = (C.c_ubyte * 128)()
+            assert L.qrl_exchange_unique_id(ident) == 0, L.qrl_cluster_last_error()
+            h = C.c_void_p()
+            assert L.qrl_exchange_create_rccl(1, 0, ident, C.byref(h)) == 0, L.qrl_cluster_last_error()
+            ex = sharding.Exchange(h, 1, 0)
+        else:
+            ex = sharding.Exchange.self_()
+        cl = sharding.Cluster(qrl_ctx, ex, M, B, max(cuts))
+        cl.tail.calibrate_rssi(-1.5)
+        cl.tail.enable_4fsk()
+        pos = 0
+        for k, c in enumerate(cuts):
+            cl.step_async(d[:, pos:pos + c].contiguous())
+            pos += c
+            cl.sync()
+            _compare_rank(cl.tail, ref[k], 0, 1, B, M)
+        cl.close()
+        ex.close()

@@ -87,7 +87,9 @@ def test_two_rank_gloo_shard_and_gather_matches_single_process():
 
 
 # ---- channel-sharded multi-carrier receiver (C4, SURVEY 8e PFB form): channelize locally, all-to-all the channel streams, per-channel
-# chains on the owner.  CPU stand-in: the oracle's channelizer / per-channel chains around the SAME exchange function bench.py uses.
+# chains on the owner.  CPU stand-in: the oracle's channelizer / per-channel chains around the SAME exchange bench.py uses: the C++
+# chan_exchange::all_to_all of qradiolink_amd/host/chan_cluster.cpp (libqrl_cluster.so), here with its callback transport around gloo
+# (sharding.exchange_channels -> Exchange.torch); bench.py --config c4 --gpus N drives the same object with the RCCL transport.
 def _c4_worker(rank, world, port, iq, M, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
