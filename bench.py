@@ -618,7 +618,15 @@ def main():
 
     def finish(line):
         if rank == 0 and line is not None:
-            print(json.dumps(line))
+            # (RCCL writes its version banner through C stdio, which is fully buffered when stdout is a file: flush it first so that
+            #  the JSON line is the LAST line of the output)
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except OSError:
+                pass
+            sys.stdout.flush()
+            print(json.dumps(line), flush=True)
         ctx.close()
         if world > 1:
             torch.distributed.barrier()   # rank 0 may be behind by the CPU baseline: leave together
