@@ -137,6 +137,7 @@ struct SymSyncParams {
                                            // 2: native 4FSK (FM) tail: phase_modulator -> (imag, real) soft pairs for the Viterbi
     uint8_t* bits; size_t bits_cap;        // tail 1: two bits per symbol, counts[b*4+2]
     float2* port; size_t port_cap; uint32_t* counts;  // constellation port (this call), counts[b*4+1]
+    int slim;                              // 1: the <16 streams, 96-sample window> geometry, 25 KB of LDS (multi-carrier receiver)
 };
 void launch_symsync_ff(const SymSyncParams& p, int batch, hipStream_t s);
 

@@ -31,6 +31,7 @@
 namespace qrl {
 
 constexpr int CT_T = 1200;          // outputs per tile (absolute grid)
+constexpr int CT_TPW = 1;           // consecutive tiles of a row one workgroup walks (3 was measured in round 4: staging the 10.5 KB of tables once per three tiles changes nothing, 1859 against 1867 us)
 constexpr int CT_JP = 35;           // taps per phase of the 24/25 resampler (819 taps)
 constexpr int CT_NF = 33;           // channel filter
 constexpr int CT_NR = 125;          // RRC
@@ -41,6 +42,18 @@ constexpr int CT_NX = 25 * 59 + 34 + 2;   // input samples staged per tile
 constexpr int CT_SA = CT_JP + 7, CT_SB = CT_NF + 7, CT_SE = CT_NR + 7;   // window steps of the 8-output sliding filters (d = 7 .. -(nt - 1))
 
 __device__ __forceinline__ int ct_pos(int i) { return (i & 7) * CT_W + (i >> 3); }
+// Packed fmas (v_pk_fma_f32: two IEEE fmas per instruction, the rounding of fmaf): complex accumulator += real tap x complex sample with
+// the tap broadcast from one half of a register PAIR through op_sel -- the eight taps of a step arrive as two float4 = four pairs, so no
+// register is spent on duplicating them.  Halves the issue count of the three filter stages (they are VALU-issue bound).
+typedef float v2f_ct __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ct_fma_lo(v2f_ct& acc, v2f_ct hp, v2f_ct x) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(hp), "v"(x)); }
+__device__ __forceinline__ void ct_fma_hi(v2f_ct& acc, v2f_ct hp, v2f_ct x) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(hp), "v"(x)); }
+__device__ __forceinline__ void ct_step8(v2f_ct (&acc)[8], float4 h0, float4 h1, float2 xs)
+{
+    const v2f_ct x = {xs.x, xs.y}, p0 = {h0.x, h0.y}, p1 = {h0.z, h0.w}, p2 = {h1.x, h1.y}, p3 = {h1.z, h1.w};
+    ct_fma_lo(acc[0], p0, x); ct_fma_hi(acc[1], p0, x); ct_fma_lo(acc[2], p1, x); ct_fma_hi(acc[3], p1, x);
+    ct_fma_lo(acc[4], p2, x); ct_fma_hi(acc[5], p2, x); ct_fma_lo(acc[6], p3, x); ct_fma_hi(acc[7], p3, x);
+}
 __device__ __forceinline__ int64_t ct_floordiv(int64_t a, int64_t b) { const int64_t q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
 
 __global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
@@ -53,20 +66,24 @@ __global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = blockIdx.y;
-    const int64_t tile = (int64_t)(P.q0 / CT_T) + blockIdx.x;
-    const int64_t Q0 = tile * CT_T;
-    const int64_t ua = ct_floordiv(Q0 - CT_HA, 24), qa = ua * 24;                 // first resampler output of the tile (multiple of 24)
-    const int NU = (int)((Q0 + CT_T - qa + 23) / 24);                             // groups of 24 outputs: <= 59
-    const int64_t qb = qa + ((Q0 - CT_HB - qa) / 8) * 8;                          // first filter output (multiple of 8 behind qa)
-    const int ib0 = (int)(qb - qa);                                               // >= 32
-    const int NB = (int)(Q0 + CT_T - qb);                                         // filter outputs: 1332 .. 1339
-    const int e0 = (int)(Q0 - qb);                                                // tile start relative to qb: 132 .. 139
+    const int64_t tile_first = (int64_t)(P.q0 / CT_T) + (int64_t)blockIdx.x * CT_TPW, tile_last = (int64_t)((P.q0 + P.count - 1) / CT_T);
+    const int ntile = (int)(tile_last - tile_first + 1 < CT_TPW ? tile_last - tile_first + 1 : CT_TPW);
     for (int k = tid; k < 257; k += 256) T[k] = P.atan_tab[k];
     // step-major tap tables, laid out by the host (chan_tail_tables): straight 16-byte copies
     for (int k = tid; k < 3 * CT_SA * 2; k += 256) reinterpret_cast<float4*>(tA)[k] = reinterpret_cast<const float4*>(P.tab_a)[k];
     if (tid < CT_SB * 2) reinterpret_cast<float4*>(tB)[tid] = reinterpret_cast<const float4*>(P.tab_b)[tid];
     if (P.out_sym.p)
         for (int k = tid; k < CT_SE * 2; k += 256) reinterpret_cast<float4*>(tE)[k] = reinterpret_cast<const float4*>(P.tab_e)[k];
+    for (int tt = 0; tt < ntile; ++tt) {
+    const int64_t tile = tile_first + tt;
+    const int64_t Q0 = tile * CT_T;
+    if (tt) __syncthreads();                                                      // the previous tile's readers of xf / av / dv are through
+    const int64_t ua = ct_floordiv(Q0 - CT_HA, 24), qa = ua * 24;                 // first resampler output of the tile (multiple of 24)
+    const int NU = (int)((Q0 + CT_T - qa + 23) / 24);                             // groups of 24 outputs: <= 59
+    const int64_t qb = qa + ((Q0 - CT_HB - qa) / 8) * 8;                          // first filter output (multiple of 8 behind qa)
+    const int ib0 = (int)(qb - qa);                                               // >= 32
+    const int NB = (int)(Q0 + CT_T - qb);                                         // filter outputs: 1332 .. 1339
+    const int e0 = (int)(Q0 - qb);                                                // tile start relative to qb: 132 .. 139
     // ---- stage the input: x[xbase + i], xbase = 25 ua - 34 (zero in front of the stream)
     const int64_t xbase = 25 * ua - (CT_JP - 1);
     const int nx = 25 * NU + (CT_JP - 1);
@@ -88,39 +105,29 @@ __global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
     if (wv < 3 && lane < NU) {
         const float4* tp = reinterpret_cast<const float4*>(tA + wv * (CT_SA * 8));
         const float2* xb = xf + 25 * lane + 8 * wv + (CT_JP - 1) + 7;            // x[25 u + 8 w + d] = xb[d - 7] = xb[-s]
-        float ar[8], ai[8];
+        v2f_ct acc[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) ar[r] = ai[r] = 0.f;
+        for (int r = 0; r < 8; ++r) acc[r] = v2f_ct{0.f, 0.f};
 #pragma unroll 4
-        for (int st = 0; st < CT_SA; ++st) {
-            const float2 x = xb[-st];
-            const float4 h0 = tp[2 * st], h1 = tp[2 * st + 1];
-            const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        for (int st = 0; st < CT_SA; ++st) ct_step8(acc, tp[2 * st], tp[2 * st + 1], xb[-st]);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) { ar[r] = fmaf(h[r], x.x, ar[r]); ai[r] = fmaf(h[r], x.y, ai[r]); }
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) av[r * CT_W + 3 * lane + wv] = make_float2(ar[r], ai[r]);   // item i = 24 lane + 8 w + r
+        for (int r = 0; r < 8; ++r) av[r * CT_W + 3 * lane + wv] = make_float2(acc[r].x, acc[r].y);   // item i = 24 lane + 8 w + r
     }
     __syncthreads();
     // ---- B: f[q] = sum_k ft[k] a[q - k], thread g: q = qb + 8 g + r (items of a: ib0 + 8 g + r - k)
     if (tid < (NB + 7) / 8) {
         const float4* tp = reinterpret_cast<const float4*>(tB);
         const float2* ab = av + (ib0 >> 3) + tid;                                  // item ib0 + 8 g + d at ab[(d & 7) W + (d >> 3)]
-        float ar[8], ai[8];
+        v2f_ct acc[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) ar[r] = ai[r] = 0.f;
+        for (int r = 0; r < 8; ++r) acc[r] = v2f_ct{0.f, 0.f};
 #pragma unroll 4
         for (int st = 0; st < CT_SB; ++st) {
             const int d = 7 - st;                                                  // wave uniform
-            const float2 x = ab[(d & 7) * CT_W + (d >> 3)];
-            const float4 h0 = tp[2 * st], h1 = tp[2 * st + 1];
-            const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { ar[r] = fmaf(h[r], x.x, ar[r]); ai[r] = fmaf(h[r], x.y, ai[r]); }
+            ct_step8(acc, tp[2 * st], tp[2 * st + 1], ab[(d & 7) * CT_W + (d >> 3)]);
         }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) xf[r * CT_W + tid] = make_float2(ar[r], ai[r]);   // f item i' = 8 g + r (relative to qb)
+        for (int r = 0; r < 8; ++r) xf[r * CT_W + tid] = make_float2(acc[r].x, acc[r].y);   // f item i' = 8 g + r (relative to qb)
     }
     __syncthreads();
     // ---- D: discriminators on f, items i' = 1 .. NB - 1 (q = qb + i'); int16 port for the outputs of this call
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
             if (t < P.s16_cap) P.s16[(size_t)row * P.s16_cap + t] = (int16_t)r;
         }
     }
-    if (blockIdx.x == 0 && tid == 0) {
+    if (blockIdx.x == 0 && tt == 0 && tid == 0) {
         if (P.s16 && P.s16_counts) P.s16_counts[row] = P.count < P.s16_cap ? P.count : (uint32_t)P.s16_cap;
         if (P.rssi && P.rssi_counts) P.rssi_counts[row] = P.ntags < P.rssi_cap ? P.ntags : (uint32_t)P.rssi_cap;
     }
@@ -165,26 +172,28 @@ __global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
                 if (t < P.rssi_cap) P.rssi[(size_t)row * P.rssi_cap + t] = db;
             }
         }
-        return;
-    }
+    } else if (P.out_sym.p) {
     // ---- E: r[q] = sum_k rrc[k] d2[q - k], thread g (waves 0..2): items i' = e8 + 8 g + r, e8 = e0 rounded down to 8
-    if (!P.out_sym.p) return;
     const int e8 = e0 & ~7;
     if (tid < (NB - e8 + 7) / 8) {
         const float4* tp = reinterpret_cast<const float4*>(tE);
         const float* db_ = dv + (e8 >> 3) + tid;
-        float acc[8];
+        // real data: the packed fma carries two OUTPUTS (r, r + 1) -- their taps are a natural register pair, the sample is duplicated
+        v2f_ct a2[4];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+        for (int j = 0; j < 4; ++j) a2[j] = v2f_ct{0.f, 0.f};
 #pragma unroll 4
         for (int st = 0; st < CT_SE; ++st) {
             const int d = 7 - st;                                                  // wave uniform
             const float x = db_[(d & 7) * CT_W + (d >> 3)];
+            const v2f_ct xx = {x, x};
             const float4 h0 = tp[2 * st], h1 = tp[2 * st + 1];
-            const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-#pragma unroll
-            for (int r = 0; r < 8; ++r) acc[r] = fmaf(h[r], x, acc[r]);
+            a2[0] = __builtin_elementwise_fma(v2f_ct{h0.x, h0.y}, xx, a2[0]);
+            a2[1] = __builtin_elementwise_fma(v2f_ct{h0.z, h0.w}, xx, a2[1]);
+            a2[2] = __builtin_elementwise_fma(v2f_ct{h1.x, h1.y}, xx, a2[2]);
+            a2[3] = __builtin_elementwise_fma(v2f_ct{h1.z, h1.w}, xx, a2[3]);
         }
+        const float acc[8] = {a2[0].x, a2[0].y, a2[1].x, a2[1].y, a2[2].x, a2[2].y, a2[3].x, a2[3].y};
         float* orow = P.out_sym.p + (size_t)row * (P.out_sym.mask + 1u);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -192,13 +201,15 @@ __global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
             if (q >= (int64_t)P.q0 && (uint64_t)q < q_end && q >= Q0) orow[(uint32_t)q & P.out_sym.mask] = acc[r];
         }
     }
+    }
+    }   // tiles of this workgroup
 }
 
 void launch_chan_tail(const ChanTailParams& p, int streams, hipStream_t s)
 {
     if (!p.count) return;
     const uint64_t t_first = p.q0 / CT_T, t_last = (p.q0 + p.count - 1) / CT_T;
-    hipLaunchKernelGGL(k_chan_tail, dim3((uint32_t)(t_last - t_first + 1), streams), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_chan_tail, dim3((uint32_t)((t_last - t_first + CT_TPW) / CT_TPW), streams), dim3(256), 0, s, p);
 }
 // step-major tap tables of k_chan_tail: which = 0: resampler [3 waves][42 steps][8] from the phase-major taps[24][35];
 // 1: channel filter [40][8]; 2: RRC [132][8].  Entry (step s, r) = h[r - (7 - s)], zero outside the filter.

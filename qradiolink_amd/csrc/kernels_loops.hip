@@ -173,14 +173,18 @@ void launch_fll(const FllParams& p, int batch, hipStream_t s)
 // single-wave kernel).  Windows sit on an absolute grid: window k holds samples [k W - SS_BACK, (k+1) W + 8)
 // of every stream; a lane works while its 8-tap interpolator fits, then all lanes move on together (cursors of
 // different streams never drift apart by more than a symbol inside a call: every lane consumes all samples).
-constexpr int SS_NS = 32;                    // streams per workgroup (half a wave: keeps the LDS under 80 KB so the
-                                             // kernel fits beside ONE front-end workgroup and overlaps the next call)
-constexpr int SS_W = 192;                    // new samples per window
-constexpr int SS_BACK = 16;                  // samples kept in front of the grid point
-constexpr int SS_COLS = SS_BACK + SS_W + 8;  // 216
-constexpr int SS_PITCH = SS_COLS + 1;        // odd pitch: lanes walk down columns conflict-free
-constexpr int SS_OMAX = 56;                  // symbols per stream per window: <= (W + 5) / 3.9 + 1 for sps >= 3.9
-constexpr int SS_OPITCH = SS_OMAX + 1;
+// Geometry <NS streams per workgroup, W new samples per window>: <32, 192> everywhere (half a wave of streams keeps the LDS under 80 KB,
+// so that the kernel fits beside ONE front-end workgroup and overlaps the next call); <16, 96> = 25 KB for the multi-carrier receiver,
+// whose symbol synchroniser has to slip in beside the four 39 KB workgroups per CU of the NEXT call's per-channel kernel (a 75 KB
+// workgroup waits until two of those retire on the same CU at once: 0.56 of its 1.38 ms stayed exposed per C4 step).
+template <int NS, int W> struct SsGeo {
+    static constexpr int BACK = 16;                   // samples kept in front of the grid point
+    static constexpr int COLS = BACK + W + 8;
+    static constexpr int PITCH = COLS + 1;            // odd pitch: lanes walk down columns conflict-free
+    static constexpr int OMAX = W == 192 ? 56 : (W + 5) * 10 / 39 + 3;   // symbols per stream per window: <= (W + 5) / 3.9 + 1 for sps >= 3.9
+    static constexpr int OPITCH = OMAX + 1;
+    static constexpr size_t lds_bytes() { return (size_t)(2 * NS * PITCH + 4 + 129 * 8 + 2 * NS * OPITCH) * sizeof(float) + 2 * 64 * sizeof(int) + (2 * 64 + 64 + 2) * sizeof(uint64_t); }
+};
 
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 {
@@ -192,8 +196,11 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
     return v;
 }
 
+template <int SS_NS, int SS_W>
 __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int batch)
 {
+    using G = SsGeo<SS_NS, SS_W>;
+    constexpr int SS_BACK = G::BACK, SS_COLS = G::COLS, SS_PITCH = G::PITCH, SS_OMAX = G::OMAX, SS_OPITCH = G::OPITCH;
     extern __shared__ __align__(16) unsigned char ss_smem[];
     float* win = reinterpret_cast<float*>(ss_smem);              // [2][SS_NS][SS_PITCH]
     float* mm = win + 2 * SS_NS * SS_PITCH + 4;                         // [129][8]
@@ -367,16 +374,20 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
     }
 }
 
-size_t symsync_lds_bytes()
-{
-    return (size_t)(2 * SS_NS * SS_PITCH + 4 + 129 * 8 + 2 * SS_NS * SS_OPITCH) * sizeof(float) + 2 * 64 * sizeof(int) + (2 * 64 + 64 + 2) * sizeof(uint64_t);
-}
+size_t symsync_lds_bytes() { return SsGeo<32, 192>::lds_bytes(); }
 
 void launch_symsync_ff(const SymSyncParams& p, int batch, hipStream_t s)
 {
-    if (dyn_lds_limit(reinterpret_cast<const void*>(k_symsync_ff), (int)symsync_lds_bytes()) != hipSuccess) return;
-    dim3 grid((batch + SS_NS - 1) / SS_NS), block(256);
-    hipLaunchKernelGGL(k_symsync_ff, grid, block, symsync_lds_bytes(), s, p, batch);
+    if (p.slim) {   // the multi-carrier receiver's geometry (see SsGeo)
+        const auto k = k_symsync_ff<16, 96>;
+        const size_t lds = SsGeo<16, 96>::lds_bytes();
+        if (dyn_lds_limit(reinterpret_cast<const void*>(k), (int)lds) != hipSuccess) return;
+        hipLaunchKernelGGL(k, dim3((batch + 15) / 16), dim3(256), lds, s, p, batch);
+        return;
+    }
+    const auto k = k_symsync_ff<32, 192>;
+    if (dyn_lds_limit(reinterpret_cast<const void*>(k), (int)symsync_lds_bytes()) != hipSuccess) return;
+    hipLaunchKernelGGL(k, dim3((batch + 31) / 32), dim3(256), symsync_lds_bytes(), s, p, batch);
 }
 
 }  // namespace qrl
