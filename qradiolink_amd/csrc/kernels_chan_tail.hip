@@ -24,6 +24,7 @@
 // conflict free for ds_read_b64).
 // Every chain is the oracle's: one fmaf chain per output, tap index ascending, first term fmaf(h, x, +0) (orc_resamp_ccf,
 // orc_fir_ccf, orc_fir_fff); discriminator, quantiser and RSSI sums as in k_quad_demod / k_rssi_tag.
+#include <cstring>
 #include <vector>
 #include "devmath.hpp"
 #include "engine.hpp"
@@ -31,7 +32,10 @@
 namespace qrl {
 
 constexpr int CT_T = 1200;          // outputs per tile (absolute grid)
-constexpr int CT_TPW = 1;           // consecutive tiles of a row one workgroup walks (3 was measured in round 4: staging the 10.5 KB of tables once per three tiles changes nothing, 1859 against 1867 us)
+#ifndef QRL_CT_TPW
+#define QRL_CT_TPW 1
+#endif
+constexpr int CT_TPW = QRL_CT_TPW;           // consecutive tiles of a row one workgroup walks (3 was measured in round 4: staging the 10.5 KB of tables once per three tiles changes nothing, 1859 against 1867 us)
 constexpr int CT_JP = 35;           // taps per phase of the 24/25 resampler (819 taps)
 constexpr int CT_NF = 33;           // channel filter
 constexpr int CT_NR = 125;          // RRC
@@ -41,6 +45,13 @@ constexpr int CT_W = 180;           // row pitch of the de-interleaved images: >
 constexpr int CT_NX = 25 * 59 + 34 + 2;   // input samples staged per tile
 constexpr int CT_SA = CT_JP + 7, CT_SB = CT_NF + 7, CT_SE = CT_NR + 7;   // window steps of the 8-output sliding filters (d = 7 .. -(nt - 1))
 
+#ifdef QRL_CT_PROF
+// developer build (tools/chan_tail_variants.sh name -DQRL_CT_PROF): shader-clock ticks per phase, summed over every wave
+__device__ unsigned long long g_ct_prof[4096][16];   // spread over 4096 slots: one shared set of counters serialises 2 M waves on a few cache lines
+#define CT_STAMP(k) do { const unsigned long long tn_ = __builtin_readcyclecounter(); pc[k] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define CT_STAMP(k) do { } while (0)
+#endif
 __device__ __forceinline__ int ct_pos(int i) { return (i & 7) * CT_W + (i >> 3); }
 // Packed fmas (v_pk_fma_f32: two IEEE fmas per instruction, the rounding of fmaf): complex accumulator += real tap x complex sample with
 // the tap broadcast from one half of a register PAIR through op_sel -- the eight taps of a step arrive as two float4 = four pairs, so no
@@ -56,7 +67,7 @@ __device__ __forceinline__ void ct_step8(v2f_ct (&acc)[8], float4 h0, float4 h1,
 }
 __device__ __forceinline__ int64_t ct_floordiv(int64_t a, int64_t b) { const int64_t q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
 
-__global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
+__global__ __launch_bounds__(256, 4) void k_chan_tail(const ChanTailParams P)
 {
     __shared__ __align__(16) float2 xf[CT_NX > 8 * CT_W ? CT_NX : 8 * CT_W];   // staged input x (stage A), then the channel filter output f (B .. E)
     __shared__ __align__(16) float2 av[8 * CT_W];        // resampler output a
@@ -66,6 +77,10 @@ __global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = blockIdx.y;
+#ifdef QRL_CT_PROF
+    unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+#endif
     const int64_t tile_first = (int64_t)(P.q0 / CT_T) + (int64_t)blockIdx.x * CT_TPW, tile_last = (int64_t)((P.q0 + P.count - 1) / CT_T);
     const int ntile = (int)(tile_last - tile_first + 1 < CT_TPW ? tile_last - tile_first + 1 : CT_TPW);
     for (int k = tid; k < 257; k += 256) T[k] = P.atan_tab[k];
@@ -74,6 +89,7 @@ __global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
     if (tid < CT_SB * 2) reinterpret_cast<float4*>(tB)[tid] = reinterpret_cast<const float4*>(P.tab_b)[tid];
     if (P.out_sym.p)
         for (int k = tid; k < CT_SE * 2; k += 256) reinterpret_cast<float4*>(tE)[k] = reinterpret_cast<const float4*>(P.tab_e)[k];
+    CT_STAMP(0);
     for (int tt = 0; tt < ntile; ++tt) {
     const int64_t tile = tile_first + tt;
     const int64_t Q0 = tile * CT_T;
@@ -98,9 +114,13 @@ __global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
             if (a < 0) v[k] = make_float2(0.f, 0.f);
         }
 #pragma unroll
+        CT_STAMP(1);
+#pragma unroll
         for (int k = 0; k < NLD; ++k) { const int i = tid + 256 * k; if (i < nx) xf[i] = v[k]; }
     }
+    CT_STAMP(2);
     __syncthreads();
+    CT_STAMP(3);
     // ---- A: a[24 u + 8 w + r] = sum_j taps[(8 w + r) 35 + j] x[25 u + 8 w + r - j],  lane = u - ua, waves 0..2
     if (wv < 3 && lane < NU) {
         const float4* tp = reinterpret_cast<const float4*>(tA + wv * (CT_SA * 8));
@@ -113,59 +133,100 @@ __global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
 #pragma unroll
         for (int r = 0; r < 8; ++r) av[r * CT_W + 3 * lane + wv] = make_float2(acc[r].x, acc[r].y);   // item i = 24 lane + 8 w + r
     }
+    CT_STAMP(4);
     __syncthreads();
+    CT_STAMP(5);
     // ---- B: f[q] = sum_k ft[k] a[q - k], thread g: q = qb + 8 g + r (items of a: ib0 + 8 g + r - k)
+    // The kernel is LDS bound (two 16-byte tap reads + one sample read per step against 8 packed fmas: halving the fma count
+    // changed nothing), and this stage is the largest: here the 33 taps live in REGISTERS (17 pairs, read once per tile out of rows
+    // 7, 15, 23, 31, 39 of the step-major table: row 8 i + 7 holds h[8 i .. 8 i + 7]), the 40 steps are unrolled with compile-time
+    // tap indices -- one LDS read (the sample) per step, and the taps that are zero padding are not multiplied at all.
     if (tid < (NB + 7) / 8) {
         const float4* tp = reinterpret_cast<const float4*>(tB);
+        v2f_ct hb[20];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const float4 h0 = tp[2 * (8 * i + 7)], h1 = tp[2 * (8 * i + 7) + 1];
+            hb[4 * i] = v2f_ct{h0.x, h0.y}; hb[4 * i + 1] = v2f_ct{h0.z, h0.w}; hb[4 * i + 2] = v2f_ct{h1.x, h1.y}; hb[4 * i + 3] = v2f_ct{h1.z, h1.w};
+        }
         const float2* ab = av + (ib0 >> 3) + tid;                                  // item ib0 + 8 g + d at ab[(d & 7) W + (d >> 3)]
         v2f_ct acc[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) acc[r] = v2f_ct{0.f, 0.f};
-#pragma unroll 4
+#pragma unroll
         for (int st = 0; st < CT_SB; ++st) {
-            const int d = 7 - st;                                                  // wave uniform
-            ct_step8(acc, tp[2 * st], tp[2 * st + 1], ab[(d & 7) * CT_W + (d >> 3)]);
+            const int d = 7 - st;                                                  // compile time
+            const float2 xs = ab[(d & 7) * CT_W + (d >> 3)];
+            const v2f_ct x = {xs.x, xs.y};
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int t = st - 7 + r;                                          // tap index of output r at this step (ascending with the steps)
+                if (t >= 0 && t < CT_NF) { if (t & 1) ct_fma_hi(acc[r], hb[t >> 1], x); else ct_fma_lo(acc[r], hb[t >> 1], x); }
+            }
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) xf[r * CT_W + tid] = make_float2(acc[r].x, acc[r].y);   // f item i' = 8 g + r (relative to qb)
     }
+    CT_STAMP(6);
     __syncthreads();
+    CT_STAMP(7);
     // ---- D: discriminators on f, items i' = 1 .. NB - 1 (q = qb + i'); int16 port for the outputs of this call
     const uint64_t q_end = P.q0 + P.count;
     float* pv = reinterpret_cast<float*>(av);
-    for (int i = 1 + tid; i < NB; i += 256) {
-        const float2 a = xf[ct_pos(i)], p = xf[ct_pos(i - 1)];
-        const float re = a.x * p.x + a.y * p.y;
-        const float im = a.y * p.x - a.x * p.y;
-        const float ang = fast_atan2f_lut(im, re, T);
-        dv[ct_pos(i)] = P.gain2 * ang;
-        {   // |f|^4 of the item for the serial RSSI sums below (the resampler output `av` is dead since stage B: its memory holds them)
-            const float pwr = a.x * a.x + a.y * a.y;
-            pv[ct_pos(i)] = pwr * pwr;
+    {   // a thread's (at most six) items as ONE straight-line block: all LDS reads first, then six independent discriminator chains the
+        // scheduler can interleave (as a loop over i the stage waited for the LDS and the divide of every item in turn: 6.5 k cycles)
+        constexpr int ND = (CT_T + CT_HB + 8 + 255) / 256;                         // NB <= 1339
+        float2 aa[ND], pp[ND];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int i = 1 + tid + 256 * j, ic = i < NB ? i : 1;
+            aa[j] = xf[ct_pos(ic)]; pp[j] = xf[ct_pos(ic - 1)];
         }
-        const int64_t q = qb + i;
-        if (P.s16 && q >= (int64_t)P.q0 && (uint64_t)q < q_end && i >= e0) {
-            float r = rintf(((P.gain * ang) * P.level) * P.scale);
-            if (r > 32767.0f) r = 32767.0f;
-            if (r < -32768.0f) r = -32768.0f;
-            const uint64_t t = (uint64_t)q - P.q0;
-            if (t < P.s16_cap) P.s16[(size_t)row * P.s16_cap + t] = (int16_t)r;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int i = 1 + tid + 256 * j;
+            const float2 a = aa[j], p = pp[j];
+            const float re = a.x * p.x + a.y * p.y;
+            const float im = a.y * p.x - a.x * p.y;
+            const float ang = fast_atan2f_lut(im, re, T);
+            if (i < NB) dv[ct_pos(i)] = P.gain2 * ang;
+            if (i < NB && i >= e0) {   // |f|^4 of the tile's own items for the serial RSSI sums below, in item order (the resampler output `av` is dead since stage B: its memory holds them)
+                const float pwr = a.x * a.x + a.y * a.y;
+                pv[i - e0] = pwr * pwr;
+            }
+            const int64_t q = qb + i;
+            if (i < NB && P.s16 && q >= (int64_t)P.q0 && (uint64_t)q < q_end && i >= e0) {
+                float r = rintf(((P.gain * ang) * P.level) * P.scale);
+                if (r > 32767.0f) r = 32767.0f;
+                if (r < -32768.0f) r = -32768.0f;
+                const uint64_t t = (uint64_t)q - P.q0;
+                if (t < P.s16_cap) P.s16[(size_t)row * P.s16_cap + t] = (int16_t)r;
+            }
         }
     }
     if (blockIdx.x == 0 && tt == 0 && tid == 0) {
         if (P.s16 && P.s16_counts) P.s16_counts[row] = P.count < P.s16_cap ? P.count : (uint32_t)P.s16_cap;
         if (P.rssi && P.rssi_counts) P.rssi_counts[row] = P.ntags < P.rssi_cap ? P.ntags : (uint32_t)P.rssi_cap;
     }
+    CT_STAMP(8);
     __syncthreads();
+    CT_STAMP(9);
     if (wv == 3) {
         // ---- C: rssi_tag_block, the four 300-item blocks of this tile: serial float sums, one lane per block
         if (lane < CT_T / 300 && P.rssi) {
             const int64_t j = tile * (CT_T / 300) + lane;                          // absolute tag index
             if (j >= (int64_t)P.tag0 && j < (int64_t)(P.tag0 + P.ntags)) {
-                const int i0 = e0 + 300 * lane;
+                // (16-byte reads of the block's 300 values, eight in flight: one 4-byte LDS read per add made this wave the longest of the
+                //  tile -- 28.7 k of 54 k cycles, profiles/r04_c4_chan_tail_phase_profile_before.log)
+                const float4* p4 = reinterpret_cast<const float4*>(pv + 300 * lane);
                 float sum = 0.0f;                                                  // the block's serial sum, item order (rssi_tag_block.cpp:52-58)
-#pragma unroll 10
-                for (int k = 0; k < 300; ++k) sum += pv[ct_pos(i0 + k)];
+                for (int k0 = 0; k0 < 75; k0 += 5) {
+                    float4 v[5];
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) v[u] = p4[k0 + u];
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) { sum += v[u].x; sum += v[u].y; sum += v[u].z; sum += v[u].w; }
+                }
                 const float level = sqrtf(sum / 300.0f);
                 const float db = 10.0f * log10f(level + 1.0e-20f) + P.rssi_cal;
                 const uint64_t t = (uint64_t)j - P.tag0;
@@ -178,22 +239,32 @@ __global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
     if (tid < (NB - e8 + 7) / 8) {
         const float4* tp = reinterpret_cast<const float4*>(tE);
         const float* db_ = dv + (e8 >> 3) + tid;
-        // real data: the packed fma carries two OUTPUTS (r, r + 1) -- their taps are a natural register pair, the sample is duplicated
-        v2f_ct a2[4];
+        // Sliding TAP window: output r at step s multiplies h[s - 7 + r], i.e. the eight taps of a step are the previous step's shifted
+        // by one -- a window of 16 registers (the previous block's eight taps + this block's eight, read as two 16-byte broadcasts out of
+        // row 8 b + 7 of the step-major table = h[8 b .. 8 b + 7]) serves eight steps.  LDS traffic per step: 4 + 4 bytes instead of
+        // 4 + 32 (the stage was bound by the LDS, 131 cycles per step); the arithmetic is the scalar fmaf chain it always was.
+        float acc[8], hw[16];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a2[j] = v2f_ct{0.f, 0.f};
-#pragma unroll 4
-        for (int st = 0; st < CT_SE; ++st) {
-            const int d = 7 - st;                                                  // wave uniform
-            const float x = db_[(d & 7) * CT_W + (d >> 3)];
-            const v2f_ct xx = {x, x};
-            const float4 h0 = tp[2 * st], h1 = tp[2 * st + 1];
-            a2[0] = __builtin_elementwise_fma(v2f_ct{h0.x, h0.y}, xx, a2[0]);
-            a2[1] = __builtin_elementwise_fma(v2f_ct{h0.z, h0.w}, xx, a2[1]);
-            a2[2] = __builtin_elementwise_fma(v2f_ct{h1.x, h1.y}, xx, a2[2]);
-            a2[3] = __builtin_elementwise_fma(v2f_ct{h1.z, h1.w}, xx, a2[3]);
-        }
-        const float acc[8] = {a2[0].x, a2[0].y, a2[1].x, a2[1].y, a2[2].x, a2[2].y, a2[3].x, a2[3].y};
+        for (int r = 0; r < 8; ++r) { acc[r] = 0.f; hw[r] = 0.f; }
+        auto block = [&](int b, int nsteps, bool have) {
+            float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f), h1 = h0;
+            if (have) { h0 = tp[2 * (8 * b + 7)]; h1 = tp[2 * (8 * b + 7) + 1]; }
+            hw[8] = h0.x; hw[9] = h0.y; hw[10] = h0.z; hw[11] = h0.w; hw[12] = h1.x; hw[13] = h1.y; hw[14] = h1.z; hw[15] = h1.w;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u < nsteps) {
+                    const int d = 7 - (8 * b + u);
+                    const float x = db_[(d & 7) * CT_W + (d >> 3)];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) acc[r] = fmaf(hw[u + r + 1], x, acc[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) hw[r] = hw[8 + r];
+        };
+#pragma unroll 1
+        for (int b = 0; b < CT_SE / 8; ++b) block(b, 8, true);
+        if (CT_SE % 8) block(CT_SE / 8, CT_SE % 8, 8 * (CT_SE / 8) + 7 < CT_SE);
         float* orow = P.out_sym.p + (size_t)row * (P.out_sym.mask + 1u);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -202,8 +273,27 @@ __global__ __launch_bounds__(256) void k_chan_tail(const ChanTailParams P)
         }
     }
     }
+    CT_STAMP(10);
     }   // tiles of this workgroup
+#ifdef QRL_CT_PROF
+    if (lane == 0) {
+        unsigned long long* slot = g_ct_prof[(blockIdx.x * 61u + blockIdx.y * 7u + (unsigned)wv) & 4095u];
+        for (int k = 0; k < 11; ++k) atomicAdd(&slot[k], pc[k]);
+        atomicAdd(&slot[11 + (wv == 3)], pc[10]); atomicAdd(&slot[15], 1ull);
+    }
+#endif
 }
+#ifdef QRL_CT_PROF
+extern "C" void qrl_ct_prof_read(unsigned long long* out16)
+{
+    (void)hipDeviceSynchronize();
+    static unsigned long long host[4096][16];
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ct_prof), sizeof host);
+    for (int k = 0; k < 16; ++k) { out16[k] = 0; for (int i = 0; i < 4096; ++i) out16[k] += host[i][k]; }
+    std::memset(host, 0, sizeof host);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ct_prof), host, sizeof host);
+}
+#endif
 
 void launch_chan_tail(const ChanTailParams& p, int streams, hipStream_t s)
 {
