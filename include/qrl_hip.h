@@ -124,6 +124,15 @@ int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* filtered_cap, size_
 int qrl_demod_audio_cap(const qrl_demod* d, size_t n, size_t* audio_cap);
 /* replaces gr_demod_nbfm/am/wbfm::set_squelch (pwr_squelch_cc::set_threshold, gr_demod_base.cpp:1186-1199): threshold in dB */
 int qrl_demod_set_squelch(qrl_demod* d, double db);
+/* replaces the time-domain scope tap of gr_demod_base: enable_time_domain (src/gr/gr_demod_base.cpp:1115-1147) connects _demod_valve ->
+ * rational_resampler_ccf(1, 10, low_pass(1, 1e6, 50000, 25000, HAMMING)) (:62-63) -> gr_sample_sink (src/gr/gr_sample_sink.cpp), read
+ * through get_sample_data (:988-1013).  samples != NULL switches the tap on: every following qrl_demod_process also decimates the
+ * 1 Msps signal behind the front end (the caller's rotated IQ when the device runs at 1 Msps) 1:10 and writes the call's new
+ * 100 ksps items to samples[b*cap + k] (cf32 pairs, device memory), counts[b] = items written; NULL switches it off.
+ * qrl_demod_time_domain_cap: the bound for a call of n input samples.  The sink's mailbox rules (window, drop threshold) are host
+ * logic: qrl_host::gr_demod_base_hip::get_sample_data. */
+int qrl_demod_time_domain_cap(const qrl_demod* d, size_t n, size_t* cap);
+int qrl_demod_set_time_domain_output(qrl_demod* d, float* samples, size_t cap, uint32_t* counts);
 /* replaces gr_demod_nbfm::set_ctcss(value) (src/gr/gr_demod_nbfm.cpp:97-123): tone_hz != 0 switches analog::ctcss_squelch_ff(8000, tone,
  * 0.01, 8000, 160, true) (:59-60) in between the audio resampler and the audio filter and the audio filter to band_pass_2(1, 8000,
  * 300, 3500, 200, 35, BH); 0 switches it out again (the constructor's graph).  Switching it in or out restarts the chain from a

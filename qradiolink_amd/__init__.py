@@ -142,6 +142,8 @@ def load_library():
     lib.qrl_fft_sync.argtypes = [vp]
     lib.qrl_demod_stream_wait.argtypes = [vp, vp]
     lib.qrl_demod_set_ctcss.argtypes = [vp, C.c_float]
+    lib.qrl_demod_time_domain_cap.argtypes = [vp, sz, C.POINTER(sz)]
+    lib.qrl_demod_set_time_domain_output.argtypes = [vp, vp, sz, vp]
     lib.qrl_demod_stream.restype = vp
     lib.qrl_demod_stream.argtypes = [vp]
     lib.qrl_demod_profile.argtypes = [vp, C.c_int]
@@ -213,7 +215,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "qrl_init", "qrl_shutdown", "qrl_strerror", "qrl_last_error", "qrl_version", "qrl_demod_create",
     "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_set_option", "qrl_demod_set_dmo_output", "qrl_demod_stream_wait", "qrl_demod_out_caps",
-    "qrl_demod_audio_cap", "qrl_demod_set_squelch", "qrl_demod_set_agc", "qrl_demod_set_ctcss",
+    "qrl_demod_audio_cap", "qrl_demod_set_squelch", "qrl_demod_set_agc", "qrl_demod_set_ctcss", "qrl_demod_time_domain_cap", "qrl_demod_set_time_domain_output",
     "qrl_bptc19696_decode", "qrl_bptc19696_encode", "qrl_m17_decode_frames", "qrl_m17_encode_frames",
     "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
@@ -375,6 +377,18 @@ class Demod:
 
     def set_squelch(self, db):
         _check(self.lib.qrl_demod_set_squelch(self.h, C.c_double(db)), "qrl_demod_set_squelch")
+
+    def enable_time_domain(self):
+        """gr_demod_base::enable_time_domain(true): self.scope complex64 [batch, cap] / self.scope_counts int32 [batch] receive the 100 ksps
+        scope items of every following call (qrl_demod_set_time_domain_output)"""
+        t = self.torch
+        cap = C.c_size_t()
+        _check(self.lib.qrl_demod_time_domain_cap(self.h, self.max_chunk, C.byref(cap)), "qrl_demod_time_domain_cap")
+        dev = self.bits_a.device
+        self.scope = t.zeros((self.batch, cap.value), dtype=t.complex64, device=dev)
+        self.scope_counts = t.zeros((self.batch,), dtype=t.int32, device=dev)
+        t.cuda.current_stream().synchronize()
+        _check(self.lib.qrl_demod_set_time_domain_output(self.h, self.scope.data_ptr(), cap.value, self.scope_counts.data_ptr()), "qrl_demod_set_time_domain_output")
 
     def set_ctcss(self, tone_hz):
         """gr_demod_nbfm::set_ctcss: 0 = off, else the CTCSS tone that opens the audio path"""

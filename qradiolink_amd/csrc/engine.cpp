@@ -187,6 +187,10 @@ struct qrl_demod {
     // stage objects
     DecimStage fe;      // gr_demod_base resampler (device rate >= 2 Msps)
     DecimStage first;   // per-mode _resampler when interp == 1
+    // time-domain scope tap (gr_demod_base.cpp:62-63, 1115-1147, 988-1018): _demod_valve -> rational_resampler_ccf(1, 10, low_pass(1, 1e6,
+    // 50000, 25000, HAMMING)) -> gr_sample_sink; off until qrl_demod_set_time_domain_output gives it a buffer
+    DecimStage scope; DevBuf<float2> s_scope; uint32_t scope_mask = 0; uint64_t n_scope = 0;
+    float2* scope_out = nullptr; size_t scope_cap = 0; uint32_t* scope_counts = nullptr;
     DevBuf<float> rs_taps; int rs_Jp = 0;  // per-mode _resampler when interp > 1
     DevBuf<float> filt_taps; int filt_nt = 0;
     DevBuf<float> symf_taps; int symf_nt = 0;
@@ -273,6 +277,8 @@ int qrl_demod::init_state()
     int r;
     for (auto* b : {&hist_a, &hist_b, &s1, &s2, &s2l, &s2f}) if (b->p && (r = b->zero())) return r;
     for (auto* b : {&s2d, &s3}) if (b->p && (r = b->zero())) return r;
+    if (s_scope.p && (r = s_scope.zero())) return r;
+    n_scope = 0;
     if ((r = soft.zero())) return r;
     if (fll_st.p && (r = fll_st.zero())) return r;
     if (fam == F_QPSK || fam == F_BPSK || fsk4_disc) {
@@ -407,10 +413,13 @@ int qrl_demod::build()
         if (d2f && (r = d2f_taps.upload(dec2_fir_table(rtaps, d2f_rrc)))) return r;
     }
     const uint32_t first_look = interp == 1 ? std::max<uint32_t>(first.lookback(), d2f ? dec2_fir_lookback() : 0u) : 0u;
+    // --- the scope tap's 1:10 decimator on the 1 Msps signal (planned here so that the history below covers it; its ring is allocated on first use)
+    if ((r = scope.plan(low_pass(1, 1000000, 50000, 25000, WIN_HAMMING), 10))) return fail(r, "scope plan");
+    if (!fe.used && (r = scope.alloc_edge(cfg.batch))) return fail(r, "scope edge scratch");
     // --- history of the caller's IQ kept by whichever stage reads it
     if (fe.used) hist_len = fe.lookback();
-    else if (interp == 1) hist_len = first_look;
-    else hist_len = (uint32_t)(rs_Jp + decim + 2);
+    else if (interp == 1) hist_len = std::max(first_look, scope.lookback());
+    else hist_len = std::max((uint32_t)(rs_Jp + decim + 2), scope.lookback());
     if ((r = hist_a.alloc((size_t)B * hist_len)) || (r = hist_b.alloc((size_t)B * hist_len))) return r;
 
     // --- rings
@@ -418,7 +427,7 @@ int qrl_demod::build()
     const size_t in2 = fe.used ? max1 : maxn;                        // items entering the mode resampler per call
     const size_t max2 = in2 * interp / decim + 2;                    // target-rate items per call
     if (fe.used) {
-        const size_t look = interp == 1 ? first_look : (size_t)(rs_Jp + decim + 2);
+        const size_t look = std::max<size_t>(interp == 1 ? first_look : (size_t)(rs_Jp + decim + 2), scope.lookback());
         s1_mask = pow2_at_least(max1 + look + 64) - 1;
         if ((r = s1.alloc((size_t)B * (s1_mask + 1)))) return r;
     }
@@ -709,6 +718,20 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         launch_resamp(p, B, stream);
     }
     if (profiling && !fe.used) { HIPCHK(hipEventRecord(ev1, stream)); prof_events.emplace_back(ev0, ev1); }
+    // ---- time-domain scope tap: the 1 Msps signal behind the front end (the caller's rotated IQ when the device runs at 1 Msps) -> 1:10
+    if (scope_out) {
+        const uint64_t ns_1 = decim_count(src1, 1, 10);
+        DecimParams p{};
+        if (fe.used) { p.in = nullptr; p.in_ring = r1; }
+        else { p.in = in; p.in_stride = stride; p.hist = hist_old; p.hist_len = hist_len;
+               p.rot_enable = 1; p.rot_acc = rot_acc; p.rot_inc = rot_inc; p.rot_nbase = rot_nbase; p.rot_lo = rot_lo.p; }
+        p.n0 = src0; p.n = (uint32_t)(src1 - src0);
+        p.out = RingC{s_scope.p, scope_mask}; p.m0 = n_scope; p.m_count = (uint32_t)(ns_1 - n_scope);
+        p.taps = scope.taps.p; p.D = scope.D; p.Jpad = scope.Jpad;
+        if (scope.launch(p, B, stream)) return fail(QRL_ERR_HIP, "scope launch: hipFuncSetAttribute failed");
+        launch_ring_store(RingC{s_scope.p, scope_mask}, n_scope, (uint32_t)(ns_1 - n_scope), scope_out, scope_cap, scope_counts, B, stream);
+        n_scope = ns_1;
+    }
     // keep the tail of the caller's IQ (rotated) for the next call
     {
         HistParams h{};
@@ -1223,6 +1246,30 @@ int qrl_demod_set_squelch(qrl_demod* d, double db)
 {
     if (!d || d->fam != qrl_demod::F_ANALOG) return QRL_ERR_ARG;
     d->an_threshold = std::pow(10.0, db / 10);   // pwr_squelch_cc::set_threshold
+    return QRL_OK;
+}
+int qrl_demod_time_domain_cap(const qrl_demod* d, size_t n, size_t* cap)
+{
+    if (!d || !cap) return QRL_ERR_ARG;
+    const size_t n1 = d->fe.used ? n / d->fe_decim + 2 : n;
+    *cap = n1 / 10 + 2;
+    return QRL_OK;
+}
+int qrl_demod_set_time_domain_output(qrl_demod* d, float* samples, size_t cap, uint32_t* counts)
+{
+    if (!d) return QRL_ERR_ARG;
+    if (samples && !counts) return qrl_set_error(QRL_ERR_ARG, "qrl_demod_set_time_domain_output: counts [batch] required");
+    HIPCHK(hipSetDevice(d->ctx->device));
+    if (samples && !d->s_scope.p) {   // first use: the ring of the 100 ksps scope signal (one call + the stages' block granularity)
+        if (int rs = d->sync_all()) return rs;
+        const size_t max1 = d->fe.used ? d->cfg.max_chunk / d->fe_decim + 2 : d->cfg.max_chunk;
+        d->scope_mask = pow2_at_least(max1 / 10 + 256) - 1;
+        if (int r = d->s_scope.alloc((size_t)d->cfg.batch * (d->scope_mask + 1))) return qrl_set_error(r, "scope ring");
+        // the tap starts with the samples of the next call: outputs are indexed from the stream's 1 Msps position
+        d->n_scope = decim_count(d->fe.used ? d->n1 : d->n_in, 1, 10);
+    }
+    if (samples && !d->scope_out) d->n_scope = decim_count(d->fe.used ? d->n1 : d->n_in, 1, 10);   // (re-)enabled: skip what was not tapped
+    d->scope_out = reinterpret_cast<float2*>(samples); d->scope_cap = cap; d->scope_counts = counts;
     return QRL_OK;
 }
 int qrl_demod_set_ctcss(qrl_demod* d, float tone_hz)

@@ -239,6 +239,7 @@ bool chan_tail_supported(int rs_I, int rs_D, int rs_Jp, int filt_nt, int rrc_nt)
 std::vector<float> chan_tail_tables(int which, const float* taps);   // 0: resampler (phase-major taps [24][35]), 1: channel filter, 2: RRC
 uint32_t chan_tail_lookback();
 void launch_pfb_chan(const ChanParams& p, int batch, hipStream_t s);
+void launch_ring_store(RingC in, uint64_t q0, uint32_t count, float2* out, size_t cap, uint32_t* counts, int rows, hipStream_t s);
 void launch_ring_load(const float2* in, size_t pitch, RingC out, uint64_t q0, uint32_t count, int rows, hipStream_t s);
 void launch_f2s(const F2sParams& p, int batch, hipStream_t s);
 size_t chan_lds_bytes(int M, int J);

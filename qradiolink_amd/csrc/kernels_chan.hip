@@ -532,6 +532,19 @@ __global__ __launch_bounds__(256) void k_ring_load(const float2* in, size_t pitc
     const int r = blockIdx.y;
     out.p[(size_t)r * (out.mask + 1u) + ((uint32_t)(q0 + t) & out.mask)] = in[(size_t)r * pitch + t];
 }
+// engine ring rows, absolute items [q0, q0 + count) -> caller buffer [rows][cap] (+ counts[row]): the scope tap's mailbox copy
+__global__ __launch_bounds__(256) void k_ring_store(RingC in, uint64_t q0, uint32_t count, float2* out, size_t cap, uint32_t* counts)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const int r = blockIdx.y;
+    if (t == 0 && counts) counts[r] = count < cap ? count : (uint32_t)cap;
+    if (t >= count || t >= cap) return;
+    out[(size_t)r * cap + t] = in.p[(size_t)r * (in.mask + 1u) + ((uint32_t)(q0 + t) & in.mask)];
+}
+void launch_ring_store(RingC in, uint64_t q0, uint32_t count, float2* out, size_t cap, uint32_t* counts, int rows, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_ring_store, dim3(count ? (count + 255) / 256 : 1, rows), dim3(256), 0, s, in, q0, count, out, cap, counts);
+}
 void launch_ring_load(const float2* in, size_t pitch, RingC out, uint64_t q0, uint32_t count, int rows, hipStream_t s)
 {
     if (!count) return;

@@ -67,6 +67,7 @@ struct gr_demod_base_hip::slot {
     gr_complex* h_const = nullptr; uint8_t *h_a = nullptr, *h_b = nullptr, *h_dmo = nullptr; uint32_t *h_cnt = nullptr, *h_dmocnt = nullptr;   // pinned
     float *d_rssi = nullptr, *h_rssi = nullptr; bool rssi_valid = false;   // latest rssi_block value per stream (device / pinned)
     float *d_audio = nullptr, *h_audio = nullptr;         // analogue modes: port 1 (device / pinned)
+    float *d_scope = nullptr; gr_complex* h_scope = nullptr; uint32_t *d_scnt = nullptr, *h_scnt = nullptr; bool scoped = false;   // time-domain scope items of the call
     uint8_t *d_fr[2] = {nullptr, nullptr}, *h_fr[2] = {nullptr, nullptr}; uint32_t *d_frcnt[2] = {nullptr, nullptr}, *h_frcnt[2] = {nullptr, nullptr};   // framed records of bits A / B
     bool framed = false, bits_copied = true;
     hipEvent_t done = nullptr;
@@ -77,7 +78,7 @@ gr_demod_base_hip::gr_demod_base_hip(qrl_runtime& rt, int streams, int device_sa
     : d_rt(rt), d_n(streams), d_rate(device_samp_rate), d_offset(carrier_offset_hz), d_chunk(max_chunk & ~(size_t)1),
       d_boxa(streams), d_box1(streams), d_box2(streams), d_boxc(streams), d_boxd(streams)
 {
-    d_boxf[0].resize(streams); d_boxf[1].resize(streams);
+    d_boxf[0].resize(streams); d_boxf[1].resize(streams); d_boxs.resize(streams);
     if (streams < 1 || d_chunk < 2) throw std::invalid_argument("gr_demod_base_hip: streams >= 1, max_chunk >= 2");
     hipStream_t s;
     hchk(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
@@ -98,6 +99,10 @@ void gr_demod_base_hip::close()
     for (auto& f : d_fs) if (f) { qrl_framesync_destroy(f); f = nullptr; }
     for (auto& sp : d_slot) {
         if (!sp) continue;
+        if (sp->d_scope) (void)hipFree(sp->d_scope);
+        if (sp->d_scnt) (void)hipFree(sp->d_scnt);
+        if (sp->h_scope) (void)hipHostFree(sp->h_scope);
+        if (sp->h_scnt) (void)hipHostFree(sp->h_scnt);
         for (int k = 0; k < 2; ++k) {
             if (sp->d_fr[k]) (void)hipFree(sp->d_fr[k]);
             if (sp->d_frcnt[k]) (void)hipFree(sp->d_frcnt[k]);
@@ -142,8 +147,13 @@ void gr_demod_base_hip::open()
         const size_t fb = (size_t)qrl_framesync_frame_bytes(d_fs[0]);
         d_frcap = (d_bcap / 8 + fb + 96 + 16 * (d_bcap / std::max<size_t>(8 * fb, 8) + 2) + 3) & ~(size_t)3;   // never overflows (include/qrl_hip.h)
     }
+    chk(qrl_demod_time_domain_cap(d_h, d_chunk, &d_scap), "qrl_demod_time_domain_cap");
     for (auto& sp : d_slot) {
         sp = new slot;
+        hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_scope), N * d_scap * sizeof(gr_complex)), "hipMalloc");
+        hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_scnt), N * sizeof(uint32_t)), "hipMalloc");
+        hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_scope), N * d_scap * sizeof(gr_complex), hipHostMallocDefault), "hipHostMalloc");
+        hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_scnt), N * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
         if (fs_on) for (int k = 0; k < 2; ++k) {
             hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_fr[k]), N * d_frcap), "hipMalloc");
             hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_frcnt[k]), N * 2 * sizeof(uint32_t)), "hipMalloc");
@@ -184,7 +194,7 @@ void gr_demod_base_hip::set_mode(int mode)   // gr_demod_base::set_mode (src/gr/
     d_mode = mode;
     open();
     std::lock_guard<std::mutex> g(d_mutex);
-    for (int s = 0; s < d_n; ++s) { d_box1[s].clear(); d_box2[s].clear(); d_boxc[s].clear(); d_boxd[s].clear(); d_boxa[s].clear(); d_boxf[0][s].clear(); d_boxf[1][s].clear(); }
+    for (int s = 0; s < d_n; ++s) { d_box1[s].clear(); d_box2[s].clear(); d_boxc[s].clear(); d_boxd[s].clear(); d_boxa[s].clear(); d_boxf[0][s].clear(); d_boxf[1][s].clear(); d_boxs[s].clear(); }
 }
 void gr_demod_base_hip::enable_device_framing(bool value)
 {
@@ -224,6 +234,8 @@ void gr_demod_base_hip::work(const gr_complex* const* iq, size_t n)
     hipStream_t hs = static_cast<hipStream_t>(qrl_demod_stream(d_h)), cs = static_cast<hipStream_t>(d_copy);
     hchk(hipMemcpyAsync(sl.d_iq, sl.h_iq, (size_t)d_n * d_chunk * sizeof(gr_complex), hipMemcpyHostToDevice, hs), "H2D");
     if (d_mode == QRL_MODEM_DMR) chk(qrl_demod_set_dmo_output(d_h, sl.d_dmo, kDmoCap, sl.d_dmocnt), "qrl_demod_set_dmo_output");
+    sl.scoped = d_scope_on;
+    chk(qrl_demod_set_time_domain_output(d_h, d_scope_on ? sl.d_scope : nullptr, d_scap, d_scope_on ? sl.d_scnt : nullptr), "qrl_demod_set_time_domain_output");
     qrl_demod_out o{};
     o.filtered = sl.d_filt; o.filtered_cap = d_fcap; o.constellation = sl.d_const; o.constellation_cap = d_ccap;
     o.bits_a = sl.d_a; o.bits_b = sl.d_b; o.bits_cap = d_bcap; o.counts = sl.d_cnt;
@@ -233,6 +245,10 @@ void gr_demod_base_hip::work(const gr_complex* const* iq, size_t n)
     const size_t N = (size_t)d_n;
     if (d_acap) hchk(hipMemcpyAsync(sl.h_audio, sl.d_audio, N * d_acap * sizeof(float), hipMemcpyDeviceToHost, cs), "D2H");
     hchk(hipMemcpyAsync(sl.h_cnt, sl.d_cnt, N * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, cs), "D2H");
+    if (sl.scoped) {
+        hchk(hipMemcpyAsync(sl.h_scnt, sl.d_scnt, N * sizeof(uint32_t), hipMemcpyDeviceToHost, cs), "D2H");
+        hchk(hipMemcpyAsync(sl.h_scope, sl.d_scope, N * d_scap * sizeof(gr_complex), hipMemcpyDeviceToHost, cs), "D2H");
+    }
     sl.framed = d_fs[0] != nullptr;
     sl.bits_copied = !sl.framed || d_keep_bits;
     if (sl.framed) {
@@ -274,6 +290,11 @@ void gr_demod_base_hip::harvest(int which)
     for (int s = 0; s < d_n; ++s) {
         const uint32_t* c = sl.h_cnt + 4 * (size_t)s;
         if (sl.rssi_valid && c[0]) d_level[s] = sl.h_rssi[s];
+        // gr_sample_sink::work (src/gr/gr_sample_sink.cpp:74-96): while more than 524288 items wait, the new ones are dropped
+        if (sl.scoped && d_boxs[s].size() <= 524288) {
+            const gr_complex* p = sl.h_scope + (size_t)s * d_scap;
+            d_boxs[s].insert(d_boxs[s].end(), p, p + std::min<size_t>(sl.h_scnt[s], d_scap));
+        }
         if (d_acap) {   // analogue modes: port 1 is audio (gr_audio_sink), no bit / constellation ports
             // gr_audio_sink::work (src/gr/gr_audio_sink.cpp:68-90): more than one second waiting = the reader is too slow: drop it all
             if (d_boxa[s].size() > 8000) d_boxa[s].clear();
@@ -372,6 +393,31 @@ void gr_demod_base_hip::calibrate_rssi(float value)   // :1413-1418
     std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     d_rssi_cal = value;
     if (d_rssi) chk(qrl_rssi_set_level(d_rssi, value), "qrl_rssi_set_level");
+}
+void gr_demod_base_hip::enable_time_domain(bool value)   // gr_demod_base.cpp:1115-1147 (+ gr_sample_sink::set_enabled)
+{
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
+    d_scope_on = value;
+}
+void gr_demod_base_hip::set_sample_window(unsigned int size)   // gr_sample_sink::set_sample_window (:35-41): odd sizes go up by one
+{
+    std::lock_guard<std::mutex> g(d_mutex);
+    if (size % 2 != 0) size = size + 1;
+    d_window = size;
+}
+void gr_demod_base_hip::get_sample_data(float* sample_data, unsigned int& size, int stream)   // :988-1013 over gr_sample_sink::get_data (:49-66)
+{
+    std::lock_guard<std::mutex> g(d_mutex);
+    std::vector<gr_complex>& box = d_boxs[stream];
+    size = 0;
+    if (box.size() < 2) return;
+    unsigned int n = (unsigned int)std::min<size_t>(box.size(), d_window);
+    if (n % 2 != 0) n = n - 1;
+    // the reference writes the reals to [0, n) and the imaginaries to [n + 1, 2 n + 1) -- one slot is skipped (i + j + 1 with i == n, :1004-1009)
+    for (unsigned int i = 0; i < n; i++) sample_data[i] = box[i].real();
+    for (unsigned int j = 0; j < n; j++) sample_data[n + j + 1] = box[j].imag();
+    size = n * 2;
+    box.erase(box.begin(), box.begin() + n);
 }
 void gr_demod_base_hip::enable_gui_fft(bool value)   // :1110-1113
 {

@@ -75,6 +75,12 @@ public:
     float get_rssi(int stream = 0);                            // probe_signal_f::level() of the rssi_block behind port 0
     void calibrate_rssi(float value);
     void enable_gui_fft(bool value);
+    // time-domain scope tap: gr_demod_base::enable_time_domain / get_sample_data / set_sample_window (src/gr/gr_demod_base.cpp:988-1018,
+    // 1115-1147) with gr_sample_sink's mailbox rules (src/gr/gr_sample_sink.cpp:35-96): window 8096 items (made even), nothing is
+    // taken while more than 524288 items wait, get_data hands out min(waiting, window) items (an even count) or nothing below 2
+    void enable_time_domain(bool value);
+    void set_sample_window(unsigned int size);
+    void get_sample_data(float* sample_data, unsigned int& size, int stream = 0);   // reals, then imaginaries from index n + 1 on, size = 2 n (:1001-1010)
     void set_fft_size(int size);
     void get_FFT_data(float* fft_data, unsigned int& fftSize, int stream = 0);   // fftSize = 0: nothing new (rx_fft_c::get_fft_data)
     const float* last_FFT_data(int stream) const { return d_fftlast.empty() ? nullptr : d_fftlast.data() + (size_t)stream * (d_fftlast.size() / (size_t)d_n); }   // the other streams of the frame get_FFT_data fetched
@@ -90,6 +96,7 @@ private:
     int d_n, d_rate, d_mode = -1; double d_offset; size_t d_chunk;
     qrl_demod* d_h = nullptr;
     qrl_rssi* d_rssi = nullptr; qrl_fft* d_fft = nullptr; bool d_rssi_on = false, d_fft_on = false; float d_rssi_cal = 0.0f; unsigned d_fftsize = 32768;
+    bool d_scope_on = false; size_t d_scap = 0; unsigned d_window = 8096; std::vector<std::vector<gr_complex>> d_boxs;   // scope tap mailboxes
     qrl_framesync* d_fs[2] = {nullptr, nullptr}; bool d_want_fs = false, d_keep_bits = false; size_t d_frcap = 0;   // device frame synchronisers of bits A / B
     std::vector<std::vector<frame_record>> d_boxf[2];
     float* d_fftout = nullptr; std::vector<float> d_level, d_fftlast;

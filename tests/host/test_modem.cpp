@@ -221,6 +221,10 @@ int main(int argc, char** argv)
         demod.calibrate_rssi(-30.0f);
         demod.set_fft_size(4096);
         demod.enable_gui_fft(true);
+        demod.enable_time_domain(true);           // the scope tap (gr_demod_base::enable_time_domain)
+        demod.set_sample_window(4001);            // odd: the sink makes it 4002
+        std::vector<float> scope(2 * 4002 + 2);
+        size_t scope_items = 0, scope_reads = 0; double scope_power = 0.0; unsigned scope_max = 0;
         std::vector<float> spectrum(4096);
         int spectra = 0; float peak_db = -1000.0f; int peak_bin = -1;
         std::vector<float> rssi_max(N, -1000.0f);
@@ -277,6 +281,13 @@ int main(int argc, char** argv)
             }
             for (int s = 0; s < N; ++s) poll(s);
             for (int s = 0; s < N; ++s) { const float v = demod.get_rssi(s); if (v != 0.0f) rssi_max[s] = std::max(rssi_max[s], v); }   // (0 = the probe before its first item)
+            for (;;) {                                      // the GUI timer drains the sample sink window by window
+                unsigned ns = 0;
+                demod.get_sample_data(scope.data(), ns, 0);
+                if (!ns) break;
+                ++scope_reads; scope_items += ns / 2; scope_max = std::max(scope_max, ns);
+                for (unsigned i = 0; i < ns / 2; ++i) scope_power += (double)scope[i] * scope[i] + (double)scope[ns / 2 + i + 1] * scope[ns / 2 + i + 1];
+            }
             unsigned got = 0;
             demod.get_FFT_data(spectrum.data(), got, 0);   // the GUI timer of the reference polls like this
             if (got == 4096) {
@@ -292,6 +303,8 @@ int main(int argc, char** argv)
         for (int s = 0; s < N; ++s) log << s << " modem_sync " << modem.modem_sync(s) << "\n";
         for (int s = 0; s < N; ++s) log << s << " rssi " << demod.get_rssi(s) << "\n" << s << " rssi_max " << rssi_max[s] << "\n";
         log << "0 spectra " << spectra << "\n" << "0 peak_bin " << peak_bin << "\n" << "0 peak_db " << peak_db << "\n";
+        log << "0 scope_items " << scope_items << "\n" << "0 scope_reads " << scope_reads << "\n" << "0 scope_max " << scope_max << "\n"
+            << "0 scope_power " << (scope_items ? scope_power / (double)scope_items : 0.0) << "\n" << "0 samples_in " << total << "\n";
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "exception: %s\n", e.what());

@@ -43,7 +43,7 @@ def test_device_framing_equals_the_host_loop(tmp_path, mode, streams, frames):
     evaluates from the record."""
     dev = _events(tmp_path, mode, streams, frames)
     host = _events(tmp_path, mode, streams, frames, host_loop=True)
-    skip = {"framing", "modem_sync", "rssi", "rssi_max", "spectra", "peak_bin", "peak_db"}
+    skip = {"framing", "modem_sync", "rssi", "rssi_max", "spectra", "peak_bin", "peak_db", "scope_items", "scope_reads", "scope_max", "scope_power", "samples_in"}
     for s in range(streams):
         a = [e for e in dev[s] if e[0] not in skip]
         b = [e for e in host[s] if e[0] not in skip]
@@ -112,6 +112,12 @@ def test_facade_side_outputs(tmp_path):
         assert -45.0 < float(dict(ev[s])["rssi_max"]) < -15.0 and float(dict(ev[s])["rssi"]) < float(dict(ev[s])["rssi_max"]) - 20.0
     assert int(d0["spectra"]) >= 2
     assert abs(int(d0["peak_bin"]) - 2048) < 80 and float(d0["peak_db"]) > -70.0
+    # the time-domain scope tap (enable_time_domain / set_sample_window / get_sample_data, gr_demod_base.cpp:988-1018, 1115-1147): one
+    # 100 ksps item per ten input samples (the last call's items were still waiting when the loop ended), windows of at most 4002
+    # items (4001 made even), the burst's power in them (|0.05 x 0.6..1|^2 while it is on the air, ~0 in the silence)
+    n_in, items = int(d0["samples_in"]), int(d0["scope_items"])
+    assert n_in // 10 - 14000 <= items <= n_in // 10 + 1 and int(d0["scope_max"]) <= 2 * 4002 and int(d0["scope_max"]) % 4 == 0
+    assert 1e-5 < float(d0["scope_power"]) < 3e-3
 
 
 @pytest.mark.parametrize("mode,kind,fw", [(9, "nbfm", 5000), (14, "am", 5000), (10, "wbfm", 75000)])

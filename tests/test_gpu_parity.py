@@ -102,6 +102,44 @@ def test_fll_slim_geometry_bit_exact(qrl_ctx, mode_name, modem, chunk):
     _compare(iq, out, mode_name, 1000000, 1200.0)
 
 
+@pytest.mark.parametrize("mode_name,modem,rate,chunk", [("2fsk1k", 18, 1000000, 1 << 21), ("2fsk1k", 18, 1000000, 50000), ("gmsk10k", 22, 4000000, 1 << 22),
+                                                        ("gmsk10k", 22, 4000000, 100002), ("qpsk250k", 26, 1000000, 33334), ("qpsk250k", 26, 25000000, 1 << 23)])
+def test_time_domain_scope_tap_bit_exact(qrl_ctx, mode_name, modem, rate, chunk):
+    """gr_demod_base::enable_time_domain (src/gr/gr_demod_base.cpp:62-63, 1115-1147): _demod_valve -> rational_resampler_ccf(1, 10,
+    low_pass(1, 1e6, 50000, 25000, HAMMING)) -> gr_sample_sink.  The 100 ksps scope items of every call equal the oracle's decimator on
+    the oracle's 1 Msps front-end signal bit for bit, whether the tap reads the caller's rotated IQ (1 Msps device) or the front-end
+    ring (4 / 25 Msps), in one call and cut into calls; the demodulator's own outputs are unchanged by the tap."""
+    import torch
+    import qradiolink_amd as q
+    offset = 25000.0 if rate >= 2000000 else 1200.0
+    iq = sig.make_batch(mode_name, 2, nframes=1, device_rate=rate, rx_offset_hz=offset, seed=41)
+    n = iq.shape[1] & ~1
+    dem = q.Demod(qrl_ctx, modem, batch=2, max_chunk=min(chunk, n), device_samp_rate=rate, carrier_offset_hz=offset)
+    dem.enable_time_domain()
+    d = torch.from_numpy(iq).cuda()
+    parts, bits = [[], []], [[], []]
+    for s0 in range(0, n, chunk):
+        part = d[:, s0:min(s0 + chunk, n)]
+        if part.shape[1] & 1:
+            part = part[:, :-1]
+        out = dem.process(part.contiguous())
+        cnt, sc = dem.scope_counts.cpu().numpy(), dem.scope.cpu().numpy()
+        c4 = out["counts"].cpu().numpy()
+        for b in range(2):
+            parts[b].append(sc[b, :cnt[b]].copy())
+            bits[b].append(out["bits_a"][b, :c4[b, 2]].cpu().numpy().copy())
+    dem.close()
+    used = sum((min(chunk, n - s0) & ~1) for s0 in range(0, n, chunk))
+    taps = orc.low_pass(1, 1000000, 50000, 25000)
+    for b in range(2):
+        fe = orc.frontend(iq[b, :used], rate, offset)
+        want = orc.decim_auto(fe, taps, 10).view(np.float32) + np.float32(0)
+        got = np.concatenate(parts[b]).view(np.float32) + np.float32(0)
+        assert got.size == want.size and got.size > 1000, (got.size, want.size)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "stream %d" % b
+        assert np.array_equal(np.concatenate(bits[b]), _oracle(mode_name, iq[b, :used], rate, offset)["bits_a"])
+
+
 def _nbfm_with_tone(n, seed, tone, fs=1000000.0, gap=None):
     """NBFM carrier whose audio is a voice-band tone plus a sub-audible CTCSS tone (deviation ~ 15 %)"""
     rng = np.random.default_rng(seed)
