@@ -255,6 +255,36 @@ def roofline_obj(kernel, kms, launches, bytes_per_launch, bytes_per_sample, note
     return d
 
 
+VALU_ISSUE_PEAK_G = 256 * 4 * 2.4 / 4      # 1024 SIMDs, one wave64 VALU instruction per 4 cycles each, 2.4 GHz (MI355X_MICROARCH.md): 614.4 G wave-instr/s
+
+
+def issue_roofline(name, rx_seconds_per_call, default_shape=True):
+    """The issue-side bound of a receiver call (C3, C5: the recursive per-stream chain makes the call VALU-issue / latency bound, not
+    HBM bound): wave instructions of one RX call, counted by the SQ_INSTS_* PMC pass of tools/profile_round.sh on this same command
+    (profiles/pmc_traffic.json, valid for the kernel sources it was taken on), over the RX-alone time of a call measured here,
+    against 1024 SIMDs x one wave64 VALU instruction per 4 cycles."""
+    try:
+        allp = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        rec = allp.get(name + "_issue")
+        if not rec or not default_shape:
+            return None
+        if allp.get("_source_id") != source_id():
+            return dict(bound="issue", achieved=None, peak=VALU_ISSUE_PEAK_G, unit="G wave-instr/s", frac=None,
+                        note="profiles/pmc_traffic.json was taken on kernel sources %s, these are %s: not reported" % (allp.get("_source_id"), source_id()))
+        pc = rec["per_rx_call"]
+        valu = pc.get("SQ_INSTS_VALU", 0.0)
+        every = sum(pc.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH"))
+        ach = valu / rx_seconds_per_call / 1e9
+        return dict(bound="issue", achieved=round(ach, 1), peak=VALU_ISSUE_PEAK_G, unit="G wave-instr/s", frac=round(ach / VALU_ISSUE_PEAK_G, 4),
+                    valu_wave_instr_per_rx_call=valu, all_wave_instr_per_rx_call=every, waves_per_rx_call=pc.get("SQ_WAVES"),
+                    all_classes_frac=round(every / rx_seconds_per_call / 1e9 / VALU_ISSUE_PEAK_G, 4),
+                    by_kernel={k: round(v.get("SQ_INSTS_VALU", 0.0)) for k, v in rec["by_kernel"].items()}, source=rec.get("source"),
+                    note="VALU wave instructions of one receiver call (PMC) / RX-alone time of a call (measured here); all_classes_frac "
+                         "adds SALU, LDS, VMEM, SMEM and branch instructions, which issue from other ports in the same cycle")
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def parity_check_c4(ch, iq, torch, nstreams=2, seed=6):
     """One call from a fresh state at the bench shape: every channel of `nstreams` random wideband streams against the oracle --
     int16 FM samples and 4FSK dibits bit for bit, rssi_tag_block values to 1e-4 dB (log10f) -- untimed."""
@@ -464,6 +494,9 @@ def run_c5(args, torch, q, ctx, dev, rank, world, steps=None, check=False):
                                      % (tot * (C5_RX_BYTES + 8.0) / dt / 1e9, C5_RX_BYTES, tot * 8.0 / dt_tx / 1e9),
                                      name="c5", default_shape=not (args.batch or args.nsamp)),
             "step_spread_ms": marks.spread()}
+    issue = issue_roofline("c5", dt_rx / args.steps, default_shape=not (args.batch or args.nsamp))
+    if issue:
+        line["roofline"]["issue"] = issue
     if parity:
         line["parity_check"] = parity
     return line
@@ -676,6 +709,10 @@ def main():
                                         note="QRL_OPT_OVERLAP = 0: same workload, the kernels of a call one after the other -- the front-end kernel alone on the chip")
                 d["note"] = ("default mode = QRL_OPT_OVERLAP 1: the FLL / discriminator / symbol-sync / decoder kernels of call k run beside this "
                              "kernel of call k + 1, so its launches are longer than in serial_mode and the step is shorter")
+            if r["name"] == "c3":
+                issue = issue_roofline("c3", r["ms_per_step"] * 1e-3, r["default_shape"])
+                if issue:
+                    d["issue"] = issue
             return d
         line = {
             "source_id": source_id(),

@@ -30,6 +30,7 @@ sid = open(os.path.join(SRC, "source_id.txt")).read().strip()
 
 sections, cur = {}, None
 cal = {}
+insts = {}
 for line in open(os.path.join(SRC, "pmc_summary.txt")):
     m = re.match(r"## (c\d|calibration) (\w+)", line)
     if m:
@@ -38,6 +39,10 @@ for line in open(os.path.join(SRC, "pmc_summary.txt")):
     m = re.search(r"(FETCH_SIZE|WRITE_SIZE) = [0-9.e+]+ KiB .* ratio to 2\^20 KiB = ([0-9.]+)", line)
     if m and cur and cur[0] == "calibration":
         cal[m.group(1)] = float(m.group(2))
+        continue
+    if cur and cur[1] == "insts" and line.startswith("qrl::"):
+        kname = line.split(" SQ_")[0].split(" GRBM_")[0].strip()
+        insts.setdefault(cur[0], {})[kname] = {c: (float(v), int(n)) for c, v, n in re.findall(r"(\w+)=([0-9.e+]+)\(n=(\d+)\)", line)}
         continue
     m = re.match(r"(qrl::\S+?)(<.*>)? .*?(FETCH_SIZE|WRITE_SIZE)=([0-9.e+]+)\(n=(\d+)\)", line)
     if m and cur:
@@ -69,6 +74,25 @@ for cfg, rows in sections.items():
                             "factors above" % cfg}
     else:
         print("no PMC rows for", cfg, want)
+# issue side (C3, C5): wave instructions of ONE receiver call = sum over the RX kernels of (mean per launch x launches) / RX calls, where the
+# number of RX calls of the profiled command = launches of the workload's dominant (front-end) kernel
+for cfg, ks in insts.items():
+    want = (dominant.get(cfg) or "").split(" ")[0].split("<")[0].replace("qrl::", "")
+    calls = max([v["SQ_WAVES"][1] for k, v in ks.items() if want and want in k] or [0])
+    if not calls:
+        print("no instruction counters for", cfg, want)
+        continue
+    per_call, by_kernel = {}, {}
+    for k, v in ks.items():
+        if "k_tx_" in k:                       # C5's modulator kernels: not part of a receiver call
+            continue
+        by_kernel[k] = {c: val * n / calls for c, (val, n) in v.items()}
+        for c, x in by_kernel[k].items():
+            per_call[c] = per_call.get(c, 0.0) + x
+    out[cfg + "_issue"] = {"per_rx_call": per_call, "by_kernel": by_kernel, "rx_calls_profiled": calls, "source": "profiles/%s_pmc_summary.txt" % TAG,
+                           "note": "rocprofv3 --kernel-trace --pmc SQ_INSTS_* SQ_WAVES SQ_BUSY_CYCLES (one pass, tools/profile_round.sh) on `python bench.py --config %s "
+                                   "--steps 3 --warmup 1 --no-extra`; counters are sums over the 8 XCDs" % cfg}
 with open(os.path.join(DST, "pmc_traffic.json"), "w") as f:
     json.dump(out, f, indent=1)
-print(json.dumps({k: round((v["fetch_bytes"] + v["write_bytes"]) / 1e9, 3) for k, v in out.items() if not k.startswith("_")}), out["_calibration"])
+print(json.dumps({k: round((v["fetch_bytes"] + v["write_bytes"]) / 1e9, 3) for k, v in out.items() if not k.startswith("_") and "fetch_bytes" in v}), out["_calibration"])
+print({k: {c: "%.3g" % x for c, x in v["per_rx_call"].items()} for k, v in out.items() if k.endswith("_issue")})

@@ -32,6 +32,11 @@ for cfg in c1 c2 c3 c4 c5; do
   pmc $cfg fetch FETCH_SIZE
   pmc $cfg write WRITE_SIZE
 done
+# issue-side counters of the two workloads the serial per-stream chain bounds (C3, C5): wave instructions by class, for bench.py's
+# roofline.issue (VALU wave-instructions of one RX call / RX-alone time against 1024 SIMDs x one wave64 VALU instruction per 4 cycles)
+for cfg in c3 c5; do
+  pmc $cfg insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVES SQ_BUSY_CYCLES
+done
 # calibration: a device-to-device copy of 1 GiB (reads 2^20 KiB, writes 2^20 KiB) under the same two counters
 for cnt in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --kernel-trace --pmc $cnt -d $O/cal_$cnt -o cal --output-format csv -- python tools/pmc_calibrate.py > $O/cal_$cnt.log 2>&1
