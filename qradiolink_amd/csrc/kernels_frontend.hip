@@ -431,6 +431,10 @@ __global__ __launch_bounds__(D2_NTH) void k_dec2_fir(const Dec2FirParams P_)
     v2f acc[2][D2_R];
 #pragma unroll
     for (int r = 0; r < D2_R; ++r) { acc[0][r] = v2f{0.f, 0.f}; acc[1][r] = v2f{0.f, 0.f}; }
+    // a wave whose first decimated sample lies at or behind the end of this call's outputs feeds nobody (the second filter is causal)
+    // and stores nothing: it skips both filters.  The last workgroup of a stream is mostly such waves (8 192 outputs = 4 x 2 024 + 96).
+    const bool idle_wave = mb + 8 * (int64_t)(tid & ~63) >= (int64_t)(Q.m0 + Q.m_count);
+    if (!idle_wave)
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
         const v2f* im = img + par * 8 * D2_W + 5 + tid;             // position of decimated index mb + 8 t in image 0
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(D2_NTH) void k_dec2_fir(const Dec2FirParams P_)
     for (int r = 0; r < D2_R; ++r) dimg[r * D2_W + tid] = acc[0][r] + acc[1][r];
     __syncthreads();
     if (blockIdx.x == 0 && tid == 0 && P.counts) P.counts[b * 4 + 0] = Q.m_count;
-    if (tid < D2_HALO / 8) return;                                   // these threads only supplied the halo
+    if (tid < D2_HALO / 8 || idle_wave) return;                      // these threads only supplied the halo
     // ---- second filter ----
     v2f y[D2_R];
 #pragma unroll

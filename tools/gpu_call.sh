@@ -7,6 +7,8 @@
 #   ab     <cfg> <kernel regex> <variant>...   same-box A/B: every variant library (build/libqrl_<v>.so; "base" = the in-tree one) twice,
 #                                        alternating, under the profiler; matching kernels + ms_per_step appended to OUT/ab.log
 #   pmc    <cfg> <COUNTER>               one rocprofv3 --pmc pass (kernel-trace only), summary appended to OUT/pmc_summary.txt
+#   alone  <name> <kprof.py args>        rocprofv3 --kernel-trace --stats of tools/kprof.py (one call at a time, a sync after every call: every kernel alone on
+#                                        the chip), per-kernel table appended to OUT/kernel_alone_summary.md
 #   smoke                                __graft_entry__.smoke()
 # Several verbs in one gpurun call: gpurun -- 'tools/gpu_call.sh r04a tests tests/test_gpu_chan.py -x -q; tools/gpu_call.sh r04a bench c4 --no-extra'
 set -u
@@ -62,6 +64,12 @@ pmc)
   timeout 300 rocprofv3 --kernel-trace --pmc $cnt -d $O/pmc_${cfg}_$cnt -o $cnt --output-format csv -- python bench.py --config $cfg --steps 3 --warmup 1 --no-extra "$@" > $O/pmc_${cfg}_$cnt.log 2>&1
   f=$(find $O/pmc_${cfg}_$cnt -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && { echo "## $cfg $cnt"; python tools/pmc_summary.py "$f"; } | tee -a $O/pmc_summary.txt | cut -c1-200
+  clean ;;
+alone)
+  name=$1; shift
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/kprof -o $name -- python tools/kprof.py "$@" > $O/kprof_$name.log 2>&1
+  f=$(find $O/kprof -name "${name}_results.db" | head -1)
+  python tools/prof_summary.py $f "$name: rocprofv3 --kernel-trace --stats -- python tools/kprof.py $* (one call at a time, sync after every call)" | tee -a $O/kernel_alone_summary.md | head -${QRL_TAIL:-12}
   clean ;;
 smoke)
   python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc $?" >> $O/smoke.log; tail -n 3 $O/smoke.log ;;
