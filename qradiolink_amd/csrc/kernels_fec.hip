@@ -139,8 +139,13 @@ __global__ __launch_bounds__(64, 8) void k_fec(const FecParams P, int nunits)
 #pragma unroll
             for (int j = 0; j < FEC_HALF; ++j) {
                 const uint2 add = Tl[8 * j];
+#if defined(QRL_FEC_ABL) && QRL_FEC_ABL == 1   // developer ablation (wrong results): the two predecessor fetches as DPP moves instead of ds_bpermute
+                const uint32_t xi = (uint32_t)__builtin_amdgcn_update_dpp((int)X, (int)X, 0x121, 0xf, 0xf, false);
+                const uint32_t xj = (uint32_t)__builtin_amdgcn_update_dpp((int)X, (int)X, 0x122, 0xf, 0xf, false);
+#else
                 const uint32_t xi = (uint32_t)__shfl((int)X, i, 64);
                 const uint32_t xj = (uint32_t)__shfl((int)X, i + 32, 64);
+#endif
                 const uint32_t ma = pk_min_u16(xi + add.x, 0x00ff00ffu);   // saturating u8 adds
                 const uint32_t mb = pk_min_u16(xj + add.y, 0x00ff00ffu);
                 X = pk_min_u16(mb, ma);

@@ -385,6 +385,12 @@ __global__ __launch_bounds__(D2_NTH) void k_dec2_fir(const Dec2FirParams P_)
         float2 v[NK][2];
         bool fresh[NK][2];                                           // from the caller's buffer: still to be rotated
         const int64_t i_lo = 2 * mq - 1;
+#if defined(QRL_D2_ABL) && QRL_D2_ABL == 2      // developer ablation: no global loads (filters run on whatever the LDS holds)
+        if (true) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) { v[k][0] = v[k][1] = make_float2((float)tid, 1.0f); fresh[k][0] = fresh[k][1] = false; }
+        } else
+#endif
         if (inb && i_lo >= (int64_t)Q.n0 && i_lo + 2 * 8 * D2_W <= i_end) {   // the whole span lies in the caller's buffer (workgroup uniform)
             const float2* src = inb + (size_t)(i_lo - (int64_t)Q.n0) + 2 * tid;
 #pragma unroll
@@ -434,7 +440,11 @@ __global__ __launch_bounds__(D2_NTH) void k_dec2_fir(const Dec2FirParams P_)
     // a wave whose first decimated sample lies at or behind the end of this call's outputs feeds nobody (the second filter is causal)
     // and stores nothing: it skips both filters.  The last workgroup of a stream is mostly such waves (8 192 outputs = 4 x 2 024 + 96).
     const bool idle_wave = mb + 8 * (int64_t)(tid & ~63) >= (int64_t)(Q.m0 + Q.m_count);
+#if defined(QRL_D2_ABL) && QRL_D2_ABL == 1      // developer ablation: no filters (staging, barriers and stores only)
+    if (false)
+#else
     if (!idle_wave)
+#endif
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
         const v2f* im = img + par * 8 * D2_W + 5 + tid;             // position of decimated index mb + 8 t in image 0
@@ -461,15 +471,19 @@ __global__ __launch_bounds__(D2_NTH) void k_dec2_fir(const Dec2FirParams P_)
     for (int r = 0; r < D2_R; ++r) dimg[r * D2_W + tid] = acc[0][r] + acc[1][r];
     __syncthreads();
     if (blockIdx.x == 0 && tid == 0 && P.counts) P.counts[b * 4 + 0] = Q.m_count;
-    if (tid < D2_HALO / 8 || idle_wave) return;                      // these threads only supplied the halo
+    const bool live = !(tid < D2_HALO / 8 || idle_wave);             // the first three threads only supplied the halo
     // ---- second filter ----
     v2f y[D2_R];
 #pragma unroll
     for (int r = 0; r < D2_R; ++r) y[r] = v2f{0.f, 0.f};
-    {
+    if (live) {
         const v2f* im = dimg + tid;
         const float* tp = P.taps + 80;
+#if defined(QRL_D2_ABL) && QRL_D2_ABL == 1
+        for (int c = 0; c < 0; ++c) {
+#else
         for (int c = 0; c < D2_HALO / 8; ++c) {
+#endif
             v2f w[15];
 #pragma unroll
             for (int o = 0; o < 8; ++o) w[7 + o] = im[o * D2_W - c];
@@ -485,16 +499,28 @@ __global__ __launch_bounds__(D2_NTH) void k_dec2_fir(const Dec2FirParams P_)
                     y[r] = __builtin_elementwise_fma(v2f{h[j], h[j]}, w[7 + r - j], y[r]);
         }
     }
-    // ---- outputs: the filtered stream (engine ring) and, when asked for, the caller's port-0 buffer ----
-    const uint64_t m_end = Q.m0 + Q.m_count;
+    // ---- outputs: the filtered stream (engine ring) and, when asked for, the caller's port-0 buffer.  A thread owns 8 CONSECUTIVE
+    // outputs, so a store straight from its registers would scatter 8-byte pieces at a 64-byte stride (every line written eight
+    // times by eight instructions).  The outputs go back through the LDS images instead (the decimated samples are dead now) and
+    // leave in order: lane = consecutive output, 512 contiguous bytes per store instruction. ----
+    v2f* oimg = img + 8 * D2_W;                                      // output mb + 8 t + r -> image r, position t; the upper half (odd input samples) has been dead since the first filter: no barrier against dimg's readers
+    if (live)
 #pragma unroll
-    for (int r = 0; r < D2_R; ++r) {
-        const uint64_t m = (uint64_t)(mb + 8 * tid + r);
-        if (m < m_end) {
-            const float2 v = make_float2(y[r].x, y[r].y);
-            P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)m & P.out.mask)] = v;
+        for (int r = 0; r < D2_R; ++r) oimg[r * D2_W + tid] = y[r];
+    __syncthreads();
+    const uint64_t m_end = Q.m0 + Q.m_count;
+    float2* orow = P.out.p + (size_t)b * (P.out.mask + 1u);
+    float2* prow = P.port ? P.port + (size_t)b * P.port_cap : nullptr;
+#pragma unroll
+    for (int k = 0; k < D2_R; ++k) {
+        const int o = tid + D2_NTH * k;                              // output y0 + o = decimated index mb + D2_HALO + o
+        const uint64_t m = y0 + (uint64_t)o;
+        if (o < D2_TY && m < m_end) {
+            const v2f v = oimg[(o & 7) * D2_W + (o >> 3) + D2_HALO / 8];
+            const float2 f = make_float2(v.x, v.y);
+            orow[(uint32_t)m & P.out.mask] = f;
             const uint64_t t = m - Q.m0;
-            if (P.port && t < P.port_cap) P.port[(size_t)b * P.port_cap + t] = v;
+            if (prow && t < P.port_cap) prow[t] = f;
         }
     }
 }

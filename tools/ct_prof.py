@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase profile of k_chan_tail (developer build -DQRL_CT_PROF, tools/chan_tail_variants.sh):
+"""Phase profile of k_chan_tail (developer build -DQRL_CT_PROF, tools/kernel_variants.sh kernels_chan_tail.hip):
 QRL_LIB_PATH=build/libqrl_<name>.so python tools/ct_prof.py  -- shader-clock ticks per phase, wave and tile (C4 bench shape)."""
 import ctypes as C
 import os

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase profile of k_pfb_stream64 (developer build -DQRL_S64_PROF, tools/chan_variants.sh):
+"""Phase profile of k_pfb_stream64 (developer build -DQRL_S64_PROF, tools/kernel_variants.sh kernels_chan.hip):
 QRL_LIB_PATH=build/libqrl_<name>.so python tools/s64_prof.py [streams [samples]]   -- shader-clock ticks per phase, wave and tile."""
 import ctypes as C
 import os
