@@ -112,8 +112,8 @@ class StepMarks:
     device) for everything the handle has queued so far and an event is recorded there; the differences of consecutive events are
     the intervals at which the steps completed.  Costs two event operations per step on the host, nothing on the handle's streams."""
 
-    def __init__(self, torch, wait, enabled=True):
-        self.torch, self.wait, self.side, self.ev, self.enabled = torch, wait, torch.cuda.Stream(), [], enabled
+    def __init__(self, torch, wait, enabled=True, note="intervals between step completions (events on a side stream behind qrl_*_stream_wait)"):
+        self.torch, self.wait, self.side, self.ev, self.enabled, self.note = torch, wait, torch.cuda.Stream(), [], enabled, note
 
     def mark(self):
         if not self.enabled:
@@ -125,11 +125,14 @@ class StepMarks:
 
     def spread(self):
         """min / median / max of the step intervals in ms (the first interval starts at the mark before the first timed step)"""
-        d = sorted(a.elapsed_time(b) for a, b in zip(self.ev[:-1], self.ev[1:]))
+        series = [a.elapsed_time(b) for a, b in zip(self.ev[:-1], self.ev[1:])]
+        d = sorted(series)
         if not d:
             return None
-        return dict(min=round(d[0], 3), median=round(d[len(d) // 2], 3), max=round(d[-1], 3), steps=len(d),
-                    note="intervals between step completions (events on a side stream behind qrl_*_stream_wait)")
+        if os.environ.get("QRL_BENCH_DUMP_STEPS"):
+            sys.stderr.write("step intervals [ms]: " + " ".join("%.2f" % x for x in series) + "\n")
+        return dict(min=round(d[0], 3), p10=round(d[len(d) // 10], 3), median=round(d[len(d) // 2], 3), p90=round(d[(9 * len(d)) // 10], 3), max=round(d[-1], 3), steps=len(d),
+                    note=self.note)
 
 
 def run_workload(name, args, torch, q, ctx, dev, rank, world, overlap=None, check=False, steps=None):
@@ -462,17 +465,38 @@ def run_c5(args, torch, q, ctx, dev, rank, world, steps=None, check=False):
     if steps:
         args.steps = steps
     dem = q.Demod(ctx, 26, batch=B, max_chunk=n)
-    mod = q.Mod(ctx, 26, batch=B, max_bytes=nbytes)
+    if getattr(args, "no_grouped", False):
+        dem.set_option(q.OPT_GROUPED, 0)
+    tx_stream = torch.cuda.Stream()                  # the modulator handle runs on a stream this script can order
+    mod = q.Mod(ctx, 26, batch=B, max_bytes=nbytes, stream=tx_stream.cuda_stream)
     tx_out = torch.empty((B, nbytes * mod.spb), dtype=torch.complex64, device=dev)
+    main_stream = torch.cuda.ExternalStream(dem.stream)
+    lockstep = not getattr(args, "free_tx", False)
 
     def both():
-        mod.process_async(data, out=tx_out)
+        # one TX chunk per RX chunk, as two flowgraphs clocked by the same 1 Msps hardware are: TX call k is ordered (on the device, an
+        # event; the host never waits) behind the receiver's front end of call k, so it shares the chip with the recursion / decoder
+        # phase.  Unordered (--free-tx) the modulator stream runs ~ 60 calls ahead of the receiver -- samples a radio could not have
+        # sent yet -- and its tens of thousands of small workgroups keep the recursion kernel's 137 KB workgroups waiting for a CU.
         dem.process_async(iq)
+        if lockstep:
+            e = torch.cuda.Event()
+            e.record(main_stream)
+            tx_stream.wait_event(e)
+        mod.process_async(data, out=tx_out)
 
     def sync():
         mod.sync()
         dem.sync()
-    marks = StepMarks(torch, dem.stream_wait, enabled=not args.no_marks)
+    # step marks behind the receiver's FRONT END (an event on the handle's main stream), not behind qrl_demod_stream_wait: that call
+    # waits for results, so it launches the decoder the grouped order holds back for the next call (QRL_OPT_GROUPED) -- a mark per step
+    # would put every step in the free-running order.  In steady state the front ends complete at the step period.
+    def front_end_wait(side_ptr):
+        e = torch.cuda.Event()
+        e.record(main_stream)
+        torch.cuda.ExternalStream(side_ptr).wait_event(e)
+    marks = StepMarks(torch, front_end_wait, enabled=not args.no_marks,
+                      note="intervals between the completions of the receiver's front end (events behind the handle's main stream: qrl_demod_stream_wait would launch the decoder the grouped order defers)")
     dt = timed_loop(both, sync, args, torch, dev, world, marks)
     dem.profile(True)
     dt_rx = timed_loop(lambda: dem.process_async(iq), sync, args, torch, dev, world)
@@ -622,6 +646,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="only the timed workload: no stand-alone pass, parity check, C2 line, CPU baseline")
     ap.add_argument("--overlap", action="store_true", help="(the library default since round 3; kept for the tools/ scripts)")
     ap.add_argument("--no-overlap", action="store_true", help="C1 only: QRL_OPT_OVERLAP = 0 (the kernels of a call strictly one after the other)")
+    ap.add_argument("--free-tx", action="store_true", help="C5 only: the modulator stream not ordered behind the receiver's front end (it then runs tens of calls ahead)")
+    ap.add_argument("--no-grouped", action="store_true", help="C5 only: QRL_OPT_GROUPED = 0 (three free-running streams instead of front end -> recursion || decoder)")
     ap.add_argument("--fll-slim", action="store_true", help="tuning, c1: QRL_OPT_FLL_SLIM = 1 (single-wave FLL workgroups)")
     ap.add_argument("--cluster", action="store_true", help="c4: drive the channel-sharded path (qrl_host::chan_cluster + RCCL all-to-all) also at N = 1")
     ap.add_argument("--no-marks", action="store_true", help="no per-step completion events (step_spread_ms = null)")

@@ -112,8 +112,11 @@ int qrl_demod_set_dmo_output(qrl_demod* d, uint8_t* frames, size_t cap_frames, u
  * everything behind the first decimated ring of call k on a second stream under the front end of call k + 1; value 0 runs the
  * kernels of a call one after another.  QRL_OPT_UNFUSED_DEC2 (QPSK chains with sps <= 4, default 0): value 1 runs the 1:2 resampler
  * and the shaping filter (gr_demod_qpsk.cpp:92-103) as the two kernels of rounds 1-2 instead of the fused one (A/B and parity checks);
- * only before the first sample of a stream. */
-enum { QRL_OPT_OVERLAP = 1, QRL_OPT_UNFUSED_DEC2 = 2, QRL_OPT_FLL_SLIM = 3 /* tuning: single-wave FLL workgroups */ };
+ * only before the first sample of a stream.  QRL_OPT_GROUPED (gr_demod_qpsk chain; default: 1 when the batch gives the recursion kernel a
+ * workgroup for at least every second CU, else 0): the order in which a call's three kernels are put on the device -- value 1: front
+ * end of call k + 1 behind the recursion of call k, the decoder of call k - 1 launched with the recursion of call k (flushed by every
+ * function that waits for results); value 0: three free-running streams. */
+enum { QRL_OPT_OVERLAP = 1, QRL_OPT_UNFUSED_DEC2 = 2, QRL_OPT_FLL_SLIM = 3 /* tuning: single-wave FLL workgroups */, QRL_OPT_GROUPED = 4 };
 int qrl_demod_set_option(qrl_demod* d, int option, int value);
 int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* filtered_cap, size_t* constellation_cap, size_t* bits_cap);
 /* analogue voice receivers (QRL_MODEM_NBFM2500 / NBFM5000 / AM5000 / WBFM / USB2500 / LSB2500; replace make_gr_demod_nbfm / _am /

@@ -25,7 +25,7 @@ MODEM_NBFM2500, MODEM_NBFM5000, MODEM_WBFM, MODEM_AM5000 = 8, 9, 10, 14
 MODEM_USB2500, MODEM_LSB2500 = 11, 12
 MODEM_M17 = 40
 MODEM_DMR = 41
-OPT_OVERLAP, OPT_UNFUSED_DEC2, OPT_FLL_SLIM = 1, 2, 3
+OPT_OVERLAP, OPT_UNFUSED_DEC2, OPT_FLL_SLIM, OPT_GROUPED = 1, 2, 3, 4
 CHAN_OPT_LEGACY_PFB, CHAN_OPT_LEGACY_TAIL = 1, 2
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECTANGULAR, WIN_BLACKMAN_HARRIS = 0, 1, 2, 3, 5
 
@@ -400,6 +400,11 @@ class Demod:
     def stream_wait(self, hip_stream):
         """the given HIP stream (int handle) waits, on the device, for everything this handle has queued so far (qrl_demod_stream_wait)"""
         _check(self.lib.qrl_demod_stream_wait(self.h, C.c_void_p(hip_stream)), "qrl_demod_stream_wait")
+
+    @property
+    def stream(self):
+        """the handle's main HIP stream (int): the one the front end of a call is launched on (qrl_demod_stream)"""
+        return int(self.lib.qrl_demod_stream(self.h) or 0)
 
     def profile(self, enable=True):
         _check(self.lib.qrl_demod_profile(self.h, int(enable)), "qrl_demod_profile")

@@ -165,6 +165,15 @@ struct qrl_demod {
     // The rings between them hold two calls; ev_q / ev_fec guard their reuse two calls later.
     hipStream_t fecs = nullptr;
     hipEvent_t ev_q[2] = {nullptr, nullptr}, ev_fec[2] = {nullptr, nullptr}; bool q_valid[2] = {false, false};
+    // GROUPED ORDER (gr_demod_qpsk chain whose recursion kernel has a workgroup for at least every second CU): k_qpsk_pipe4 is a serial
+    // walk, one workgroup of 6 waves and 137 KB of LDS per 64 streams.  Left to the three streams, the front end of call k + 1 (tens of
+    // thousands of small workgroups) and the decoder of call k - 1 (a wave per two trellises, for its whole run) take every LDS byte
+    // and wave slot the moment they free up, and the recursion of call k is only placed once both have drained: (front end || decoder)
+    // 2.6 ms, then the recursion alone 1.9 ms (profiles/r04_c5_rx_timeline.log).  Grouped: the front end of call k + 1 waits for the
+    // recursion of call k, and the decoder of call k - 1 is LAUNCHED with the recursion of call k (behind the same front-end event),
+    // which leaves front end alone -> recursion || decoder.  The deferred launch is flushed by everything that waits for results
+    // (qrl_demod_sync, qrl_demod_stream_wait, reset, destroy), so a caller never sees the difference.
+    bool grouped = false, grouped_capable = false, fec_deferred = false; FecParams fec_pending{}; int fec_pending_slot = 0;
     DevBuf<uint64_t> qp_snap;   // [2][B] symbols produced up to the end of call k (slot k & 1): what that call's decoder may read
     hipEvent_t ev_ff = nullptr, ev_tail = nullptr;
     hipEvent_t ev_user[3] = {nullptr, nullptr, nullptr};   // qrl_demod_stream_wait
@@ -260,7 +269,21 @@ struct qrl_demod {
         if (!rot_lo.p) return rot_lo.upload(lo);
         return hipMemcpy(rot_lo.p, lo.data(), 512 * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess ? QRL_OK : QRL_ERR_HIP;
     }
+    int flush_fec(bool behind_front_end) {
+        if (!fec_deferred) return QRL_OK;
+        fec_deferred = false;
+        HIPCHK(hipStreamWaitEvent(fecs, ev_q[fec_pending_slot], 0));
+        if (behind_front_end) {   // starts with the recursion of the next call, not beside its front end -- and a moment AFTER it (k_fec_gate)
+            HIPCHK(hipStreamWaitEvent(fecs, ev_ff, 0));
+            static const unsigned gate_us = getenv("QRL_FEC_GATE_US") ? (unsigned)atoi(getenv("QRL_FEC_GATE_US")) : 30u;
+            if (gate_us) launch_fec_gate(gate_us, fecs);
+        }
+        launch_fec(fec_pending, cfg.batch, fecs);
+        HIPCHK(hipEventRecord(ev_fec[fec_pending_slot], fecs));
+        return QRL_OK;
+    }
     int sync_all() {
+        if (int r = flush_fec(false)) return r;
         HIPCHK(hipStreamSynchronize(stream));
         HIPCHK(hipStreamSynchronize(tail));
         HIPCHK(hipStreamSynchronize(fecs));
@@ -322,6 +345,7 @@ int qrl_demod::init_state()
         if (hipMemcpy(an_st.p, as.data(), as.size() * sizeof(AnState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
     }
     q_valid[0] = q_valid[1] = false; tail2_valid[0] = tail2_valid[1] = false; tail_pending = false; call_no = 0;
+    fec_deferred = false;
     n_in = n1 = n2 = 0;
     rot_acc = 0; rot_nbase = 0; hist_flip = false;
     return QRL_OK;
@@ -437,6 +461,12 @@ int qrl_demod::build()
     // from 6.33 to 8.04 ms -- the recursion kernels are only placed once front-end workgroups drain, and a 68 KB FLL workgroup then
     // takes the place of two of them.
     overlap_capable = fam == F_2FSK;
+    grouped_capable = fam == F_QPSK && !fsk4_disc;   // the chain whose recursion is k_qpsk_pipe4
+    {
+        int dev = 0, cus = 256; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+        grouped = grouped_capable && 2 * ((B + 63) / 64) >= cus;   // (below that the recursion's workgroups leave CUs free: the front end of the next call belongs beside it -- C3)
+    }
     overlap = overlap_capable;   // round 3: ON by default for the 2FSK family (same-box A/B on C1: 8.79 against 9.49 ms per step); qrl_demod_set_option(QRL_OPT_OVERLAP, 0) gives the serial order
     s2_mask = pow2_at_least((overlap_capable || loops_family() ? 2 : 1) * max2 + (fam == F_DMR ? 2048 : fam == F_ANALOG ? 4096 : 1024)) - 1;   // DMR: the DMO slicer looks back 1440 samples   // history needs: <= 501 taps downstream; overlapped mode: two calls
     const size_t ring2 = (size_t)B * (s2_mask + 1);
@@ -654,6 +684,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
     }
     // loops families: the rings the recursion reads hold two calls; call k - 2's recursion must be through before they are rewritten
     if (loops_family() && q_valid[slot]) HIPCHK(hipStreamWaitEvent(stream, ev_q[slot], 0));
+    if (grouped && q_valid[slot ^ 1]) HIPCHK(hipStreamWaitEvent(stream, ev_q[slot ^ 1], 0));   // grouped order: this front end behind the recursion of the call before
     const float2* in = reinterpret_cast<const float2*>(iq);
     const float2* hist_old = hist_flip ? hist_b.p : hist_a.p;
     float2* hist_new = hist_flip ? hist_a.p : hist_b.p;
@@ -855,15 +886,19 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         if (q_valid[slot]) HIPCHK(hipStreamWaitEvent(tail, ev_fec[slot], 0));   // the soft ring holds two calls: decoder of call k - 2 done
         launch_qpsk_loops(q, B, tail);
         HIPCHK(hipEventRecord(ev_q[slot], tail));
-        HIPCHK(hipStreamWaitEvent(fecs, ev_q[slot], 0));
+        if (int rf = flush_fec(true)) return rf;                    // grouped order: the decoder of the call before goes with this recursion
+        if (!grouped) HIPCHK(hipStreamWaitEvent(fecs, ev_q[slot], 0));
         FecParams f{};
         f.soft = RingB{soft.p, soft_mask};
         f.avail = q.oo_snap; f.avail_stride = sizeof(uint64_t); f.avail_mul = fam == F_BPSK ? 1 : 2;
         f.st = fec_st.p;
         f.bits_a = out ? out->bits_a : nullptr; f.bits_b = fam == F_BPSK && out ? out->bits_b : nullptr; f.bits_cap = out ? out->bits_cap : 0;
         f.counts = counts; f.branches = fam == F_BPSK ? 2 : 1;
-        launch_fec(f, B, fecs);
-        HIPCHK(hipEventRecord(ev_fec[slot], fecs));
+        if (grouped) { fec_pending = f; fec_pending_slot = slot; fec_deferred = true; }
+        else {
+            launch_fec(f, B, fecs);
+            HIPCHK(hipEventRecord(ev_fec[slot], fecs));
+        }
         q_valid[slot] = true;
     } else {
         SymSyncParams s{};
@@ -1171,6 +1206,7 @@ int qrl_demod_set_carrier_offset(qrl_demod* d, double hz)
 int qrl_demod_stream_wait(qrl_demod* d, void* hip_stream)
 {
     if (!d) return QRL_ERR_ARG;
+    if (int rf = d->flush_fec(false)) return rf;
     hipStream_t user = static_cast<hipStream_t>(hip_stream);
     if (!d->ev_user[0]) for (auto& e : d->ev_user) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventRecord(d->ev_user[0], d->stream));
@@ -1212,6 +1248,11 @@ int qrl_demod_set_option(qrl_demod* d, int option, int value)
     case QRL_OPT_FLL_SLIM:
         if (int rs = d->sync_all()) return rs;
         d->fll_slim = value != 0;
+        return QRL_OK;
+    case QRL_OPT_GROUPED:
+        if (value != 0 && !d->grouped_capable) return qrl_set_error(QRL_ERR_ARG, "the grouped order exists for the gr_demod_qpsk chain only");
+        if (int rs = d->sync_all()) return rs;
+        d->grouped = value != 0;
         return QRL_OK;
     case QRL_OPT_UNFUSED_DEC2:
         if (!d->d2f_capable) return qrl_set_error(QRL_ERR_ARG, "this chain has no fused 1:2 decimator + shaping filter");

@@ -176,6 +176,7 @@ struct FecParams {
     int branches;
 };
 void launch_fec(const FecParams& p, int batch, hipStream_t s);
+void launch_fec_gate(unsigned us, hipStream_t s);
 
 // ---- gr_dmr_dmo_sink on the device (kernels_dmo.hip): correlator slicer behind port 3 of gr_demod_dmr ----
 struct DmoState {

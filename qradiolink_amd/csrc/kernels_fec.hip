@@ -56,14 +56,14 @@ __device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, r);
 }
 
-// LANE = TRELLIS STATE, and two trellises share a register: the 8-bit path metrics of unit 2k live in the low and those of unit
-// 2k + 1 in the high 16 bits of one VGPR, so one ds_bpermute pair and one v_pk_* add / min serve both.  Unit = (stream, alignment
+// LANE = TRELLIS STATE, and two trellises share a register: the 8-bit path metrics of unit 2w live in the low and those of unit
+// 2w + 1 in the high 16 bits of one VGPR, so one ds_bpermute pair and one v_pk_* add / min serve both.  Unit = (stream, alignment
 // branch): with two branches a register pair is branch A and B of one stream, with one branch two neighbouring streams.  The
-// arithmetic per trellis is the one stated at the top of the file.  How the kernel got here (profiles/r04_k_fec_*):
+// arithmetic per trellis is the one stated at the top of the file.  How the kernel got here (profiles/r04_k_fec_rebuild.log):
 //   * round 3 ran at the VALU issue rate (71 % of the port) with 21 VALU instructions per step.  Three changes took that to 9:
 //     BRANCH METRICS FROM A TABLE -- a state's two addends depend on the step's two soft symbols (wave uniform) and on three bits of
 //     the state (the branch-table bits of state >> 1, the state's parity): a pre-pass computes {addend for the lower, for the upper
-//     predecessor} of the 8 variants of 48 steps into LDS (6 x 7 VALU instructions per 43 steps), a step reads its pair with one
+//     predecessor} of the 8 variants of 8 steps into LDS (7 VALU instructions per 8 steps), a step reads its pair with one
 //     ds_read_b64 (8 distinct addresses, a broadcast).  DECISIONS STAY IN THE LANE -- the decision bit of (state, step) is the sign
 //     of (lower sum - upper sum); it is shifted into a per-lane history register (no ballot, no SGPR -> VGPR moves, no LDS write,
 //     no exec masking).  CHAINBACK ON THE SCALAR UNIT -- the survivor state is wave uniform: a 64-bit scalar shift register whose
@@ -71,10 +71,14 @@ __device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b)
 //     trellis, and what it shifts out are the decoded bits in order; the descrambler is shifts and xors on those words.
 //   * after that four extra VALU or SALU instructions per step cost 1 - 3 %: the step is bound by the LDS pipe (per pair and step
 //     two ds_bpermute and one ds_read_b64, 32 waves per CU: ~ 12 LDS cycles x 32 = 384 of the ~ 400 ticks a step takes), with the
-//     VALU port (9 - 10 instructions x 8 waves x 4 cycles) close behind -- trading one for the other (byte-packed fetches, a 4-variant
-//     table) gains nothing.  The predecessor fetch of step j + 1 is issued BEFORE the renormalisation test of step j (the rare
-//     renormalisation hands its per-trellis constant to the next step's adds); NP = 2 register pairs per wave exists as a
-//     developer build and is slower (see launch_fec).
+//     VALU port (9 - 10 instructions x 8 waves x 4 cycles) close behind -- trading one for the other gains nothing.  The
+//     predecessor fetch of step j + 1 is issued BEFORE the renormalisation test of step j (the rare renormalisation hands its
+//     per-trellis constant to the next step's adds).
+//   * 512 BYTES OF LDS PER WAVE.  In the QPSK receiver this kernel runs beside k_qpsk_pipe4, whose one workgroup per CU holds 137 of
+//     the CU's 160 KB for 2 ms.  With the table covering half a block and the block's symbols in LDS (3.8 KB per wave) five waves
+//     fit beside it and the decoder starved.  Now the block's 172 symbols stay in three registers (lane t of register r = symbol
+//     64 r + t; the pre-pass fetches its two with ds_bpermute, which allocates nothing) and the table covers ONE pass of 8 steps:
+//     32 waves = 16 KB.
 #ifdef QRL_FEC_PROF
 // developer build (tools/kernel_variants.sh kernels_fec.hip name -DQRL_FEC_PROF): shader-clock ticks per phase, summed over every wave
 __device__ unsigned long long g_fec_prof[4096][8];
@@ -82,30 +86,25 @@ __device__ unsigned long long g_fec_prof[4096][8];
 #else
 #define FEC_STAMP(k) do { } while (0)
 #endif
-constexpr int FEC_HALF = 43;      // trellis steps per table pass (86 per block)
-constexpr int FEC_TSTEPS = 48;    // steps the pre-pass covers (6 iterations of 8 steps)
-template <int NP>
-__global__ __launch_bounds__(64, NP == 2 ? 4 : 8) void k_fec(const FecParams P, int nunits)
+__global__ __launch_bounds__(64, 8) void k_fec(const FecParams P, int nunits)
 {
-    constexpr int NU = 2 * NP;
-    __shared__ uint2 symp2[NP][96];              // soft symbol pair of step s: .x = symbol 2 s, .y = symbol 2 s + 1 (odd unit << 16 | even unit); 86 used, the pre-pass reads up to 91
-    __shared__ uint2 T[NP][FEC_TSTEPS * 8];      // [step in half][variant] {addend of the lower predecessor's metric, of the upper one's}
+    __shared__ uint2 T[64];                      // [step in pass][variant] {addend of the lower predecessor's metric, of the upper one's}
     const int lane = threadIdx.x;
     const int i = lane >> 1, odd = lane & 1;
     // variant of this state: bit 2 = branch-table bit of polynomial 109, bit 1 = of 79 (state >> 1), bit 0 = parity of the state
     const int var = ((__builtin_popcount((2 * i) & 109) & 1) << 2) | ((__builtin_popcount((2 * i) & 79) & 1) << 1) | odd;
-    // pre-pass: lane l fills entry l + 64 j = (step (l >> 3) + 8 j, variant l & 7)
+    // pre-pass: lane l fills entry l = (step l >> 3 of the pass, variant l & 7)
     const uint32_t pbt0 = (lane & 4) ? 0x00ff00ffu : 0u, pbt1 = (lane & 2) ? 0x00ff00ffu : 0u, podd = (lane & 1) ? 0x003f003fu : 0u;
-    FecState st[NU];
-    uint64_t avail[NU];
-    const uint8_t* soft[NU];
-    uint8_t* out[NU];
-    int ub[NU], ubr[NU];
-    bool valid[NU];
-    uint32_t nout[NU];
+    FecState st[2];
+    uint64_t avail[2];
+    const uint8_t* soft[2];
+    uint8_t* out[2];
+    int ub[2], ubr[2];
+    bool valid[2];
+    uint32_t nout[2] = {0, 0};
 #pragma unroll
-    for (int q = 0; q < NU; ++q) {
-        const int u = blockIdx.x * NU + q;
+    for (int q = 0; q < 2; ++q) {
+        const int u = blockIdx.x * 2 + q;
         valid[q] = u < nunits;
         const int uu = valid[q] ? u : 0;
         ub[q] = P.branches == 2 ? uu >> 1 : uu;
@@ -115,137 +114,111 @@ __global__ __launch_bounds__(64, NP == 2 ? 4 : 8) void k_fec(const FecParams P, 
         soft[q] = P.soft.p + (size_t)ub[q] * (P.soft.mask + 1u);
         out[q] = ubr[q] ? P.bits_b : P.bits_a;
         if (out[q]) out[q] += (size_t)ub[q] * P.bits_cap;
-        nout[q] = 0;
     }
 #ifdef QRL_FEC_PROF
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_readcyclecounter();
 #endif
-#pragma unroll
-    for (int p = 0; p < NP; ++p)
-        if (lane < 10) symp2[p][86 + lane] = make_uint2(0u, 0u);   // read by the pre-pass of the second half beyond the block's 172 symbols, never used
     for (;;) {
-        bool go[NU], any = false;
+        const bool go0 = valid[0] && st[0].consumed + 172 <= avail[0];
+        const bool go1 = valid[1] && st[1].consumed + 172 <= avail[1];
+        if (!go0 && !go1) break;
+        // the block's soft symbols: lane t of sreg[r] = symbol 64 r + t (unit 1 << 16 | unit 0), zero behind the 172nd
+        uint32_t sreg[3];
 #pragma unroll
-        for (int q = 0; q < NU; ++q) { go[q] = valid[q] && st[q].consumed + 172 <= avail[q]; any = any || go[q]; }
-        if (!any) break;
-        __syncthreads();
-        uint32_t X[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            uint32_t* symp = reinterpret_cast<uint32_t*>(symp2[p]);
-            for (int t = lane; t < 172; t += 64) {
-                const int64_t v0 = (int64_t)(st[2 * p].consumed + t) - ubr[2 * p], v1 = (int64_t)(st[2 * p + 1].consumed + t) - ubr[2 * p + 1];
-                const uint32_t s0 = (go[2 * p] && v0 >= 0) ? soft[2 * p][(uint32_t)v0 & P.soft.mask] : 0u;
-                const uint32_t s1 = (go[2 * p + 1] && v1 >= 0) ? soft[2 * p + 1][(uint32_t)v1 & P.soft.mask] : 0u;
-                symp[t] = s0 | (s1 << 16);
-            }
-            X[p] = ((lane == (int)(st[2 * p].start_state & 63u)) ? 0u : 63u) | (((lane == (int)(st[2 * p + 1].start_state & 63u)) ? 0u : 63u) << 16);
+        for (int r = 0; r < 3; ++r) {
+            const int t = lane + 64 * r;
+            const int64_t v0 = (int64_t)(st[0].consumed + t) - ubr[0], v1 = (int64_t)(st[1].consumed + t) - ubr[1];
+            const uint32_t s0 = (go0 && t < 172 && v0 >= 0) ? soft[0][(uint32_t)v0 & P.soft.mask] : 0u;
+            const uint32_t s1 = (go1 && t < 172 && v1 >= 0) ? soft[1][(uint32_t)v1 & P.soft.mask] : 0u;
+            sreg[r] = s0 | (s1 << 16);
         }
+        uint32_t X = ((lane == (int)(st[0].start_state & 63u)) ? 0u : 63u) | (((lane == (int)(st[1].start_state & 63u)) ? 0u : 63u) << 16);
         FEC_STAMP(0);
-        // decision histories [pair]: h* = the half being walked (0 = even unit, 1 = odd unit; a = steps 0..31 of the half, b = steps
-        // 32..42), g* = the first half of the block
-        uint32_t h0a[NP], h0b[NP], h1a[NP], h1b[NP], g0a[NP], g0b[NP], g1a[NP], g1b[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) h0a[p] = h0b[p] = h1a[p] = h1b[p] = g0a[p] = g0b[p] = g1a[p] = g1b[p] = 0u;
+        // decision histories, one register per trellis and third of the block (steps 0..31, 32..63, 64..85): bit (last step of the
+        // third - step) = "the lower predecessor won"
+        uint32_t h0 = 0, h1 = 0, hA0 = 0, hA1 = 0, hB0 = 0, hB1 = 0;
+        uint32_t nsub = 0;                       // minus what the renormalisation of the step before subtracted (per-trellis constants, wave uniform)
+        uint32_t xi = (uint32_t)__shfl((int)X, i, 64), xj = (uint32_t)__shfl((int)X, i + 32, 64);
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            __syncthreads();
+        for (int third = 0; third < 3; ++third) {
+            const uint32_t sr = third == 0 ? sreg[0] : third == 1 ? sreg[1] : sreg[2];   // steps 32 third .. + 31 = symbols 64 third .. + 63
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const uint2* sp = symp2[p] + half * FEC_HALF + (lane >> 3);
-#pragma unroll
-                for (int j = 0; j < FEC_TSTEPS / 8; ++j) {
-                    const uint2 sy = sp[8 * j];
-                    const uint32_t a = pbt0 ^ sy.x, c = pbt1 ^ sy.y;
+            for (int pass = 0; pass < 4; ++pass) {
+                if (third == 2 && pass == 3) break;                                       // steps 64..85: two passes of 8 and one of 6
+                __syncthreads();
+                {
+                    const int sl = 16 * pass + 2 * (lane >> 3);                           // lane of the pass' step (lane >> 3), first symbol
+                    const uint32_t sx = (uint32_t)__shfl((int)sr, sl, 64), sy = (uint32_t)__shfl((int)sr, sl + 1, 64);
+                    const uint32_t a = pbt0 ^ sx, c = pbt1 ^ sy;
                     const uint32_t metric = ((a + c + 0x00010001u) >> 3) & 0x003f003fu;   // per half ((a + c + 1) >> 1) >> 2, & 63
                     const uint32_t lo = metric ^ podd;                                     // odd states: 63 - metric from the lower predecessor
-                    T[p][lane + 64 * j] = make_uint2(lo, lo ^ 0x003f003fu);
+                    T[lane] = make_uint2(lo, lo ^ 0x003f003fu);
                 }
-            }
-            __syncthreads();
-            FEC_STAMP(1);
-            uint32_t xi[NP], xj[NP], nsub[NP];   // nsub: minus what the renormalisation of the step before subtracted (per-trellis constants, wave uniform)
+                __syncthreads();
 #pragma unroll
-            for (int p = 0; p < NP; ++p) { xi[p] = (uint32_t)__shfl((int)X[p], i, 64); xj[p] = (uint32_t)__shfl((int)X[p], i + 32, 64); nsub[p] = 0u; }
-#pragma unroll
-            for (int j = 0; j < FEC_HALF; ++j) {
-                uint32_t x0[NP], hot = 0;
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    const uint2 add = T[p][8 * j + var];
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int j = 8 * pass + jj;                                          // step 32 third + j
+                    if (third == 2 && j == 22) break;
+                    const uint2 add = T[8 * jj + var];
                     // VOLK: ma = sat255(xi + a), mb = sat255(xj + b), survivor = min(ma, mb), the upper predecessor wins unless ma < mb.
                     // With ua = xi + a left unsaturated: min(ua, mb) = min(ma, mb), and ua < mb <=> ma < mb (mb <= 255) -- one v_pk_min less.
                     // xi / xj were fetched from the metrics BEFORE the renormalisation of the step before: + nsub puts that right (the
                     // halves never borrow: a trellis' minimum is subtracted from its own metrics).
-                    const uint32_t ua = xi[p] + add.x + nsub[p];
-                    const uint32_t mb = pk_min_u16(xj[p] + add.y + nsub[p], 0x00ff00ffu);
-                    X[p] = pk_min_u16(mb, ua);
-                    if (j + 1 < FEC_HALF) { xi[p] = (uint32_t)__shfl((int)X[p], i, 64); xj[p] = (uint32_t)__shfl((int)X[p], i + 32, 64); }   // next step's predecessors, ahead of the test below
+                    const uint32_t ua = xi + add.x + nsub;
+                    const uint32_t mb = pk_min_u16(xj + add.y + nsub, 0x00ff00ffu);
+                    X = pk_min_u16(mb, ua);
+                    xi = (uint32_t)__shfl((int)X, i, 64); xj = (uint32_t)__shfl((int)X, i + 32, 64);   // next step's predecessors, ahead of the test below
                     const uint32_t z = pk_sub_u16(ua, mb);                 // sign of a half: the LOWER predecessor wins (ties go to the upper one)
-                    // (the empty asm pins the update to its step: left alone, the compiler sinks all 43 behind the loop and keeps every ua / mb alive)
-                    if (j < 32) { h1a[p] = __builtin_amdgcn_alignbit(h1a[p], z, 31); h0a[p] = __builtin_amdgcn_alignbit(h0a[p], z << 16, 31); asm volatile("" : "+v"(h1a[p]), "+v"(h0a[p])); }
-                    else        { h1b[p] = __builtin_amdgcn_alignbit(h1b[p], z, 31); h0b[p] = __builtin_amdgcn_alignbit(h0b[p], z << 16, 31); asm volatile("" : "+v"(h1b[p]), "+v"(h0b[p])); }
-                    x0[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)X[p]);
-                    hot |= (x0[p] + 0x7f2d7f2du) & 0x80008000u;           // metric[0] > 210 in one of the two trellises
-                    nsub[p] = 0u;
-                }
-                if (hot) {
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        // renormalise the trellis whose metric[0] > 210: subtract its minimum.  The metrics themselves are only read
-                        // again through the fetch above (already issued) -- the next step adds nsub instead -- and at the end of the half.
-                        const uint32_t mn = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_pk_u16(X[p]));
-                        const uint32_t sub = ((x0[p] & 0xffffu) > 210u ? mn & 0xffffu : 0u) | ((x0[p] >> 16) > 210u ? mn & 0xffff0000u : 0u);
-                        if (j + 1 < FEC_HALF) nsub[p] = 0u - sub; else X[p] -= sub;
+                    // (the empty asm pins the update to its step: left alone, the compiler sinks them behind the loop and keeps every ua / mb alive)
+                    h1 = __builtin_amdgcn_alignbit(h1, z, 31); h0 = __builtin_amdgcn_alignbit(h0, z << 16, 31); asm volatile("" : "+v"(h1), "+v"(h0));
+                    const uint32_t x0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)X);
+                    nsub = 0u;
+                    if ((x0 + 0x7f2d7f2du) & 0x80008000u) {   // metric[0] > 210 in one of the trellises: renormalise that one (subtract its minimum).
+                        // The metrics themselves are only read again through the fetch above (already issued; the next step adds nsub
+                        // instead) and by the end-state search, hence the subtraction from X as well.
+                        const uint32_t mn = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_pk_u16(X));
+                        const uint32_t sub = ((x0 & 0xffffu) > 210u ? mn & 0xffffu : 0u) | ((x0 >> 16) > 210u ? mn & 0xffff0000u : 0u);
+                        nsub = 0u - sub;
+                        X -= sub;
                     }
                 }
             }
-            if (half == 0) {
-#pragma unroll
-                for (int p = 0; p < NP; ++p) { g0a[p] = h0a[p]; g0b[p] = h0b[p]; g1a[p] = h1a[p]; g1b[p] = h1b[p]; }
-            }
+            if (third == 0) { hA0 = h0; hA1 = h1; } else if (third == 1) { hB0 = h0; hB1 = h1; }
             FEC_STAMP(2);
         }
         // histories hold "lower predecessor wins"; the chainback wants the decision bit (upper wins)
-        uint64_t SV[NU];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            g0a[p] = ~g0a[p]; g0b[p] = ~g0b[p]; g1a[p] = ~g1a[p]; g1b[p] = ~g1b[p]; h0a[p] = ~h0a[p]; h0b[p] = ~h0b[p]; h1a[p] = ~h1a[p]; h1b[p] = ~h1b[p];
-            asm volatile("" : "+v"(g0a[p]), "+v"(g0b[p]), "+v"(g1a[p]), "+v"(g1b[p]), "+v"(h0a[p]), "+v"(h0b[p]), "+v"(h1a[p]), "+v"(h1b[p]));   // (8 v_not here, not 160 s_not behind the v_readlanes)
-            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32_uniform(((X[p] & 0xffffu) << 6) | (uint32_t)lane)) & 63u;
-            const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32_uniform(((X[p] >> 16) << 6) | (uint32_t)lane)) & 63u;
-            SV[2 * p] = (uint64_t)e0 << 58; SV[2 * p + 1] = (uint64_t)e1 << 58;
-        }
-        FEC_STAMP(3);
+        hA0 = ~hA0; hA1 = ~hA1; hB0 = ~hB0; hB1 = ~hB1; h0 = ~h0; h1 = ~h1;
+        asm volatile("" : "+v"(hA0), "+v"(hA1), "+v"(hB0), "+v"(hB1), "+v"(h0), "+v"(h1));   // (6 v_not here, not 160 s_not behind the v_readlanes)
+        const uint32_t end0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32_uniform(((X & 0xffffu) << 6) | (uint32_t)lane)) & 63u;
+        const uint32_t end1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32_uniform(((X >> 16) << 6) | (uint32_t)lane)) & 63u;
         // chainback on the scalar unit: a 64-bit shift register per trellis whose top six bits are the survivor state (wave uniform);
         // after the step of bit nb, bit 63 - j = decoded bit nb + j.  (64 bits wide on purpose: the 32-bit form of this update is a funnel
         // shift, which the compiler can only select as v_alignbit -- VALU -- and then pays a v_readfirstlane per step for the lane index)
-        uint32_t SA[NU], next[NU];
-#pragma unroll
-        for (int q = 0; q < NU; ++q) { SA[q] = 0; next[q] = 0; }
+        uint64_t SV0 = (uint64_t)end0 << 58, SV1 = (uint64_t)end1 << 58;
+        FEC_STAMP(3);
+        uint32_t A0 = 0, A1 = 0, next0 = 0, next1 = 0;
 #pragma unroll
         for (int nb = 79; nb >= 0; --nb) {
-            const int s = nb + 6, hf = s >= FEC_HALF ? 1 : 0, j = s - FEC_HALF * hf;
-            const int pos = j < 32 ? 31 - j : FEC_HALF - 1 - j;
-#pragma unroll
-            for (int q = 0; q < NU; ++q) {
-                const int p = q >> 1;
-                const uint32_t r = (q & 1) ? (hf ? (j < 32 ? h1a[p] : h1b[p]) : (j < 32 ? g1a[p] : g1b[p]))
-                                           : (hf ? (j < 32 ? h0a[p] : h0b[p]) : (j < 32 ? g0a[p] : g0b[p]));
-                const uint32_t k = ((uint32_t)__builtin_amdgcn_readlane((int)r, (int)(uint32_t)(SV[q] >> 58)) >> pos) & 1u;
-                SV[q] = (SV[q] >> 1) | ((uint64_t)k << 63);
-                if (nb == 74) next[q] = (uint32_t)(SV[q] >> 58);
-                if (nb == 48) SA[q] = (uint32_t)(SV[q] >> 32);             // bit 31 - j = decoded bit 48 + j
-            }
+            const int s = nb + 6, th = s >> 5, j = s & 31;
+            const int pos = th < 2 ? 31 - j : 21 - j;
+            const uint32_t r0 = th == 0 ? hA0 : th == 1 ? hB0 : h0;
+            const uint32_t r1 = th == 0 ? hA1 : th == 1 ? hB1 : h1;
+            const uint32_t k0 = ((uint32_t)__builtin_amdgcn_readlane((int)r0, (int)(uint32_t)(SV0 >> 58)) >> pos) & 1u;
+            const uint32_t k1 = ((uint32_t)__builtin_amdgcn_readlane((int)r1, (int)(uint32_t)(SV1 >> 58)) >> pos) & 1u;
+            SV0 = (SV0 >> 1) | ((uint64_t)k0 << 63);
+            SV1 = (SV1 >> 1) | ((uint64_t)k1 << 63);
+            if (nb == 74) { next0 = (uint32_t)(SV0 >> 58); next1 = (uint32_t)(SV1 >> 58); }
+            if (nb == 48) { A0 = (uint32_t)(SV0 >> 32); A1 = (uint32_t)(SV1 >> 32); }   // bit 31 - j = decoded bit 48 + j
         }
         FEC_STAMP(4);
 #pragma unroll
-        for (int q = 0; q < NU; ++q) {
-            if (!go[q]) continue;
-            // SV[q]: bit 63 - j = decoded bit j
-            const uint32_t D0 = __builtin_bitreverse32((uint32_t)(SV[q] >> 32)), D1 = __builtin_bitreverse32((uint32_t)SV[q]);   // decoded bits 0..31, 32..63
-            const uint32_t D2 = __builtin_bitreverse32(SA[q]) >> 16;                                                              // 64..79
+        for (int q = 0; q < 2; ++q) {
+            if (!(q ? go1 : go0)) continue;
+            const uint64_t SV = q ? SV1 : SV0;                       // bit 63 - j = decoded bit j
+            const uint32_t SA = q ? A1 : A0;
+            const uint32_t D0 = __builtin_bitreverse32((uint32_t)(SV >> 32)), D1 = __builtin_bitreverse32((uint32_t)SV);   // decoded bits 0..31, 32..63
+            const uint32_t D2 = __builtin_bitreverse32(SA) >> 16;                                                           // 64..79
             // F: bit k + 8 = decoded bit k, bits 0..7 = the last 8 bits of the block before (last_bits bit t = d[-1 - t])
             const uint32_t prev8 = __builtin_bitreverse32(st[q].last_bits) >> 24;
             const uint64_t FL = (uint64_t)prev8 | ((uint64_t)D0 << 8) | ((uint64_t)D1 << 40);
@@ -259,8 +232,8 @@ __global__ __launch_bounds__(64, NP == 2 ? 4 : 8) void k_fec(const FecParams P, 
                 if (nout[q] + lane < P.bits_cap) out[q][nout[q] + lane] = (uint8_t)((EL >> lane) & 1ull);
                 if (lane < 16 && nout[q] + 64 + lane < P.bits_cap) out[q][nout[q] + 64 + lane] = (uint8_t)((EH >> lane) & 1u);
             }
-            st[q].last_bits = SA[q] & 0xffu;                        // bit t = d[79 - t]
-            st[q].start_state = next[q];
+            st[q].last_bits = SA & 0xffu;                           // bit t = d[79 - t]
+            st[q].start_state = q ? next1 : next0;
             st[q].consumed += 160;
             nout[q] += 80;
         }
@@ -277,7 +250,7 @@ __global__ __launch_bounds__(64, NP == 2 ? 4 : 8) void k_fec(const FecParams P, 
 #endif
     if (lane == 0) {
 #pragma unroll
-        for (int q = 0; q < NU; ++q) {
+        for (int q = 0; q < 2; ++q) {
             if (!valid[q]) continue;
             P.st[ub[q] * 2 + ubr[q]] = st[q];
             P.counts[ub[q] * 4 + 2 + ubr[q]] = nout[q] < P.bits_cap ? nout[q] : (uint32_t)P.bits_cap;   // what was WRITTEN: consumers (deframer, frame sync) trust it
@@ -296,18 +269,22 @@ extern "C" void qrl_fec_prof_read(unsigned long long* out8)
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fec_prof), zero, sizeof zero);
 }
 #endif
+// One wave that does nothing for `us` microseconds (constant 100 MHz counter): put in front of the decoder on its stream in the
+// grouped order, so that the recursion kernel released by the same event has its workgroups placed before the decoder's waves take
+// every wave slot of the chip (they keep them for the decoder's whole run).
+__global__ __launch_bounds__(64) void k_fec_gate(unsigned us)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < 100ull * us) __builtin_amdgcn_s_sleep(32);
+}
+void launch_fec_gate(unsigned us, hipStream_t s) { hipLaunchKernelGGL(k_fec_gate, dim3(1), dim3(64), 0, s, us); }
+
 void launch_fec(const FecParams& p, int batch, hipStream_t s)
 {
     const int nunits = batch * p.branches;
-    // NP = 1 (two trellises per wave, 8 waves per SIMD) is what ships.  NP = 2 (four per wave, the two register pairs' chains
-    // interleaved) was built on the theory that a step is latency bound; measured on C5's receiver (16 384 units) it is SLOWER, 2 264
-    // against 1 801 us: the step is bound by the LDS pipe (two ds_bpermute + one ds_read_b64 per pair and step, 32 waves per CU) with
-    // the VALU port close behind, and fewer waves hide less of it (profiles/r04_k_fec_rebuild.log).  -DQRL_FEC_NP=2 builds it.
-#if defined(QRL_FEC_NP) && QRL_FEC_NP == 2
-    hipLaunchKernelGGL(k_fec<2>, dim3((nunits + 3) / 4), dim3(64), 0, s, p, nunits);
-#else
-    hipLaunchKernelGGL(k_fec<1>, dim3((nunits + 1) / 2), dim3(64), 0, s, p, nunits);
-#endif
+    // (a build with two register pairs -- four trellises -- per wave, their chains interleaved, was measured on C5's receiver: 2 264
+    // against 1 801 us.  The same LDS-pipe work with half the waves to hide it: profiles/r04_k_fec_rebuild.log.)
+    hipLaunchKernelGGL(k_fec, dim3((nunits + 1) / 2), dim3(64), 0, s, p, nunits);
 }
 
 }  // namespace qrl

@@ -270,9 +270,16 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
 // one barrier per window.  The samples live in one LDS ring per stream (5 windows of 32 columns + an 8-column mirror of the first
 // columns so that the 8-tap interpolator never wraps); the loops are straight-line code (selects instead of branches, inputs of four
 // steps loaded ahead of the recurrence).  The arithmetic and its order are those of k_qpsk_loops<0> / the oracle (bit-exact).
-constexpr int Q4_W = 32, Q4_NB = 5, Q4_RC = Q4_W * Q4_NB, Q4_MIR = 8;
+#ifndef QRL_Q4_W
+#define QRL_Q4_W 32
+#endif
+// Window = 32 columns: the workgroup holds 137 KB of LDS -- at C5's batch one workgroup on EVERY CU for the kernel's whole 2 ms, so what
+// runs beside it must fit 23 KB (k_fec was rebuilt to 0.5 KB per wave for that reason; a k_dec2_fir workgroup, 37 KB, cannot).  A
+// 16-column window (77 KB, -DQRL_Q4_W=16) was measured: the per-window overhead makes this kernel 23 % slower alone (2 401 against
+// 1 950 us) and C3, which is this kernel's latency, 38 % slower -- rejected (profiles/r04_c5_pipe4_lds_footprint.log).
+constexpr int Q4_W = QRL_Q4_W, Q4_NB = 5, Q4_RC = Q4_W * Q4_NB, Q4_MIR = 8;
 constexpr int Q4_PITCH = Q4_RC + Q4_MIR + 1;   // 169 float2, odd
-constexpr int Q4_OMAX = 20;                    // symbols per stream per window (sps >= 1.9: 32 / 1.9 + 2)
+constexpr int Q4_OMAX = Q4_W == 32 ? 20 : 11;  // symbols per stream per window (sps >= 1.9: W / 1.9 + 2)
 constexpr int Q4_OPITCH = Q4_OMAX + 1;
 
 __device__ __forceinline__ float tanhf_lut_sel(float x, const float* __restrict__ T)   // tanhf_lut without branches

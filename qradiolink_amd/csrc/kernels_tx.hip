@@ -178,16 +178,16 @@ __global__ __launch_bounds__(256) void k_tx_interp(const TxInterpParams P)
 }
 
 // Small interpolation factors (QPSK-250k: 4 samples per symbol, 61 taps): one thread per SYMBOL writes its I output samples.
-// The workgroup stages the constellation points of its 256 symbols + J - 1 predecessors and the taps in LDS once, instead of one
-// 64-bit division, ~16 byte loads and ~16 table loads per output sample (C5: 4.7 ms for 268 M samples, 0.45 TB/s of stores).
+// The workgroup stages the constellation points of its 256 symbols + J - 1 predecessors in LDS once, instead of one 64-bit division,
+// ~16 byte loads and ~16 table loads per output sample (C5: 4.7 ms for 268 M samples, 0.45 TB/s of stores); the taps are scalar
+// operands (round 4: they were LDS broadcasts, 64 ds_reads per thread beside 64 packed fmas).
 // Same fmaf chain per output (j ascending); the zero-padded taps / the zero symbols in front of the stream add +0.
 template <int I, int J>
 __global__ __launch_bounds__(256) void k_tx_interp_sym(const TxInterpParams P)
 {
     __shared__ float2 xs[256 + J];
-    __shared__ float taps[I * J];
+    const float* taps = P.taps;                                   // wave uniform, compile-time offsets: scalar loads, SGPR operands of the fmas (the table is followed by 64 zeros, tx.cpp upload)
     const int b = blockIdx.y, tid = threadIdx.x;
-    for (int k = tid; k < I * J; k += 256) taps[k] = k < P.nt ? P.taps[k] : 0.f;
     const uint64_t cs = P.n0 / (uint64_t)I;                       // first symbol of this call (n0 is a multiple of I)
     const uint32_t nsym = P.count / (uint32_t)I;
     const uint32_t s0 = blockIdx.x * 256u;
@@ -197,25 +197,35 @@ __global__ __launch_bounds__(256) void k_tx_interp_sym(const TxInterpParams P)
         xs[i] = c >= 0 ? P.table[ring[(uint32_t)c & P.sym.mask] & 3u] : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    if (s0 + tid >= nsym) return;
-    float2* o = P.out + (size_t)b * P.out_stride + (size_t)(s0 + tid) * I;
-    float2 y[I];
+    __shared__ float2 ys[I][256 + 8];                             // outputs of the workgroup, [phase][symbol] (row pitch 264: the four rows start 16 banks apart)
+    if (s0 + tid < nsym) {
+        float2 xv[J];                                             // the J symbols under the filter, read once for the I phases
 #pragma unroll
-    for (int ph = 0; ph < I; ++ph) {
-        float ar = 0.f, ai = 0.f;
+        for (int j = 0; j < J; ++j) xv[j] = xs[J - 1 + tid - j];
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const float h = taps[ph + j * I];
-            const float2 x = xs[J - 1 + tid - j];
-            ar = fmaf(h, x.x, ar);
-            ai = fmaf(h, x.y, ai);
+        for (int ph = 0; ph < I; ++ph) {
+            float ar = 0.f, ai = 0.f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const float h = taps[ph + j * I];
+                ar = fmaf(h, xv[j].x, ar);
+                ai = fmaf(h, xv[j].y, ai);
+            }
+            ar *= P.amp; ai *= P.amp;                             // multiply_const_cc(0.6)
+            ar *= P.bb_gain; ai *= P.bb_gain;                     // multiply_const_cc(bb_gain)
+            ys[ph][tid] = make_float2(ar, ai);
         }
-        ar *= P.amp; ai *= P.amp;                                 // multiply_const_cc(0.6)
-        ar *= P.bb_gain; ai *= P.bb_gain;                         // multiply_const_cc(bb_gain)
-        y[ph] = make_float2(ar, ai);
     }
+    __syncthreads();
+    // a thread owns I consecutive output samples: stored from its registers, every instruction would scatter 8-byte pieces at a
+    // 32-byte stride.  Through the LDS they leave in order, 512 contiguous bytes per store instruction (k_dec2_fir: same finding).
+    float2* o = P.out + (size_t)b * P.out_stride + (size_t)s0 * I;
+    const uint32_t nout = (nsym > s0 ? (nsym - s0 < 256u ? nsym - s0 : 256u) : 0u) * (uint32_t)I;
 #pragma unroll
-    for (int ph = 0; ph < I; ++ph) o[ph] = y[ph];
+    for (int k = 0; k < I; ++k) {
+        const uint32_t idx = (uint32_t)tid + 256u * k;            // output s0 * I + idx = (symbol idx / I, phase idx % I)
+        if (idx < nout) o[idx] = ys[idx % I][idx / I];
+    }
 }
 
 void launch_tx_interp(const TxInterpParams& p, int batch, hipStream_t s)

@@ -158,8 +158,10 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
     HIPCHK(hipSetDevice(ctx->device));
     if (c.hip_stream) m->stream = static_cast<hipStream_t>(c.hip_stream);
     else { HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
-    auto upload = [](const std::vector<float>& v, float** dst) -> int {
-        if (hipMalloc(reinterpret_cast<void**>(dst), std::max<size_t>(v.size(), 1) * sizeof(float)) != hipSuccess) return QRL_ERR_NOMEM;
+    auto upload = [](const std::vector<float>& v, float** dst) -> int {   // followed by 64 zeros: k_tx_interp_sym reads its I x J = 64 taps unguarded
+        const size_t bytes = (v.size() + 64) * sizeof(float);
+        if (hipMalloc(reinterpret_cast<void**>(dst), bytes) != hipSuccess) return QRL_ERR_NOMEM;
+        if (hipMemset(*dst, 0, bytes) != hipSuccess) return QRL_ERR_HIP;
         if (!v.empty() && hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
         return QRL_OK;
     };

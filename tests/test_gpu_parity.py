@@ -539,6 +539,10 @@ def test_pipelined_calls_without_sync(qrl_ctx, mode_name, modem):
             # (cs = stream, ev_tail / tail_pending waits), the unsynced run the overlapped one -- both paths are checked against each
             # other and against the oracle
             dem.set_option(q.OPT_OVERLAP, 0 if sync_each else 1)
+        if mode_name == "qpsk250k":
+            # QRL_OPT_GROUPED (round 4; the default at chip-filling batches): the decoder of call k is launched with the recursion of
+            # call k + 1 (or by the next function that waits for results) -- forced on in the unsynced run, off in the synced one
+            dem.set_option(q.OPT_GROUPED, 0 if sync_each else 1)
         for k in range(ncalls):
             dem.process_async(d[:, k * chunk:(k + 1) * chunk])
             if sync_each:
@@ -572,6 +576,8 @@ def test_every_call_of_a_pipelined_sequence_is_deterministic(qrl_ctx, mode_name,
         dem = q.Demod(qrl_ctx, modem, batch=B, max_chunk=chunk)
         if mode_name.startswith("2fsk"):
             dem.set_option(q.OPT_OVERLAP, 0 if sync_each else 1)   # serial order in the synced run, overlapped (the default) in the other
+        if mode_name == "qpsk250k":
+            dem.set_option(q.OPT_GROUPED, 0 if sync_each else 1)   # deferred decoder launches in the unsynced run: every call still gets ITS bits
         outs = []
         for k in range(ncalls):
             outs.append(dem.new_outputs())

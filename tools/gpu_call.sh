@@ -9,6 +9,7 @@
 #   pmc    <cfg> <COUNTER>               one rocprofv3 --pmc pass (kernel-trace only), summary appended to OUT/pmc_summary.txt
 #   alone  <name> <kprof.py args>        rocprofv3 --kernel-trace --stats of tools/kprof.py (one call at a time, a sync after every call: every kernel alone on
 #                                        the chip), per-kernel table appended to OUT/kernel_alone_summary.md
+#   timeline <name> <rows> <kprof.py args>   the same calls queued back to back (QRL_KPROF_PIPELINED=1); start / duration / queue of the last <rows> kernels
 #   smoke                                __graft_entry__.smoke()
 # Several verbs in one gpurun call: gpurun -- 'tools/gpu_call.sh r04a tests tests/test_gpu_chan.py -x -q; tools/gpu_call.sh r04a bench c4 --no-extra'
 set -u
@@ -70,6 +71,12 @@ alone)
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/kprof -o $name -- python tools/kprof.py "$@" > $O/kprof_$name.log 2>&1
   f=$(find $O/kprof -name "${name}_results.db" | head -1)
   python tools/prof_summary.py $f "$name: rocprofv3 --kernel-trace --stats -- python tools/kprof.py $* (one call at a time, sync after every call)" | tee -a $O/kernel_alone_summary.md | head -${QRL_TAIL:-12}
+  clean ;;
+timeline)
+  name=$1; rows=$2; shift 2
+  QRL_KPROF_PIPELINED=1 timeout 300 rocprofv3 --kernel-trace -d $O/tl -o $name -- python tools/kprof.py "$@" > $O/tl_$name.log 2>&1
+  f=$(find $O/tl -name "${name}_results.db" | head -1)
+  { echo "## $name: rocprofv3 --kernel-trace -- QRL_KPROF_PIPELINED=1 python tools/kprof.py $*"; python tools/prof_timeline.py $f $rows; } | tee $O/timeline_$name.log | tail -${QRL_TAIL:-40}
   clean ;;
 smoke)
   python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc $?" >> $O/smoke.log; tail -n 3 $O/smoke.log ;;

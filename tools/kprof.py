@@ -17,8 +17,12 @@ iq = torch.view_as_complex(torch.randn((batch, nsamp, 2), generator=g, device="c
 dem = q.Demod(ctx, modem, batch=batch, max_chunk=nsamp, device_samp_rate=rate)
 if os.environ.get("QRL_KPROF_UNFUSED"):      # A/B: the 1:2 resampler and the RRC of the QPSK chain as two kernels
     dem.set_option(q.OPT_UNFUSED_DEC2, 1)
+if os.environ.get("QRL_KPROF_GROUPED"):
+    dem.set_option(q.OPT_GROUPED, int(os.environ["QRL_KPROF_GROUPED"]))
 for _ in range(calls):
     dem.process_async(iq)
-    dem.sync()
+    if not os.environ.get("QRL_KPROF_PIPELINED"):   # QRL_KPROF_PIPELINED=1: the calls queued back to back, as the bench does (tools/prof_timeline.py shows how they overlap)
+        dem.sync()
+dem.sync()
 dem.close()
 ctx.close()
