@@ -53,6 +53,9 @@ bool take_launch_error() { const bool r = t_launch_error; t_launch_error = false
 
 struct qrl_ctx { int device; };
 
+#ifndef QRL_FEC_GATE_US
+#define QRL_FEC_GATE_US 30u   // grouped order: head start of the recursion kernel over the decoder (profiles/r04_c5_rx_timeline.log: without it the decoder takes every wave slot first)
+#endif
 #ifndef QRL_DEV_SKIP
 #define QRL_DEV_SKIP 0   // developer builds only (tools/engine_variants.sh): bit 0 no FLL, 1 no fused 2FSK feed-forward kernel, 2 no symbol sync, 3 no decoder launch -- WRONG results, timing experiments on who stretches the front end
 #endif
@@ -275,8 +278,7 @@ struct qrl_demod {
         HIPCHK(hipStreamWaitEvent(fecs, ev_q[fec_pending_slot], 0));
         if (behind_front_end) {   // starts with the recursion of the next call, not beside its front end -- and a moment AFTER it (k_fec_gate)
             HIPCHK(hipStreamWaitEvent(fecs, ev_ff, 0));
-            static const unsigned gate_us = getenv("QRL_FEC_GATE_US") ? (unsigned)atoi(getenv("QRL_FEC_GATE_US")) : 30u;
-            if (gate_us) launch_fec_gate(gate_us, fecs);
+            launch_fec_gate(QRL_FEC_GATE_US, fecs);
         }
         launch_fec(fec_pending, cfg.batch, fecs);
         HIPCHK(hipEventRecord(ev_fec[fec_pending_slot], fecs));

@@ -944,7 +944,6 @@ static uint32_t pm_pick_segment(uint64_t M, uint32_t batch, uint32_t cap, uint32
     uint64_t best_cost = ~0ull; uint32_t best_S = 16;
     uint32_t n_lo = (uint32_t)((M + 4095) / 4096);
     const uint32_t n_hi = (uint32_t)((M + 127) / 128);
-    if (const char* e = getenv("QRL_PM_MIN_NSEG")) { const uint32_t v = (uint32_t)atoi(e); if (v > n_lo) n_lo = v < n_hi ? v : n_hi; }   // developer experiment: finer units
     for (uint32_t nseg = n_lo; nseg <= n_hi; ++nseg) {
         const uint32_t S = (uint32_t)(((M + nseg - 1) / nseg + 15) / 16 * 16);
         const uint64_t units = ((M + S - 1) / S) * (uint64_t)batch;
