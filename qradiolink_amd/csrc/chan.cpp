@@ -416,7 +416,7 @@ static int chan_process_impl(qrl_chan* h, const float* iq, size_t stride, size_t
             SymSyncParams s{};
             s.in = RingF{h->r6.p, h->m6}; s.avail = n2_1; s.soft = RingB{h->soft_dummy.p, 63}; s.st = h->ss.p; s.mmse = h->mmse.p;
             s.alpha = h->ss_alpha; s.beta = h->ss_beta; s.maxp = 5.0f + 0.06f; s.minp = 5.0f - 0.06f;
-            s.ted = 0; s.soft_mul = 128.0f; s.soft_add = 128.0f; s.slicer = 1; s.tail = 1; s.tail_scale = 0.9f; s.slim = 1;   // 16-sample windows, 96-thread workgroups (k_symsync_ff<16, 96>): the channels' 4.8 ksym/s streams are short
+            s.ted = 0; s.soft_mul = 128.0f; s.soft_add = 128.0f; s.slicer = 1; s.tail = 1; s.tail_scale = 0.9f; s.slim = 1;   // gr_demod_dmr.cpp:73 _level_control (tail_scale); slim = 16-sample windows, 96-thread workgroups (k_symsync_ff<16, 96>)
             s.bits = h->fsk_bits; s.bits_cap = h->fsk_bits_cap;
             s.port = reinterpret_cast<float2*>(h->fsk_const); s.port_cap = h->fsk_const ? h->fsk_const_cap : 0; s.counts = h->fsk_counts;
             launch_symsync_ff(s, S, h->tail);

@@ -908,6 +908,10 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         s.alpha = ss_alpha; s.beta = ss_beta; s.maxp = ss_maxp; s.minp = ss_minp;
         s.ted = fam == F_DMR && !m17 ? 0 : 1; s.soft_mul = 128.0f; s.soft_add = 128.0f;
         s.tail_scale = m17 ? 1.0f : 0.9f;
+        // overlapped order: the 25 KB geometry (k_symsync_ff<16, 96>), whose workgroups fit beside two front-end workgroups on a CU.  The
+        // 74 KB one was placed only as the front end of the next call drained -- 4.1 ms instead of 0.25, the decoder behind it, and the
+        // front end after next waiting 0.5 ms per step for the ring this tail frees (profiles/r04_c1_timeline.log).
+        s.slim = overlap ? 1 : 0;
         s.slicer = fam == F_DMR || fam == F_4FSK ? 1 : 0; s.tail = fam == F_DMR ? 1 : fam == F_4FSK ? 2 : 0;
         s.bits = out ? out->bits_a : nullptr; s.bits_cap = out ? out->bits_cap : 0;
         s.port = side && out->constellation ? reinterpret_cast<float2*>(out->constellation) : nullptr;

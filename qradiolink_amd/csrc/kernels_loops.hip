@@ -181,7 +181,7 @@ template <int NS, int W> struct SsGeo {
     static constexpr int BACK = 16;                   // samples kept in front of the grid point
     static constexpr int COLS = BACK + W + 8;
     static constexpr int PITCH = COLS + 1;            // odd pitch: lanes walk down columns conflict-free
-    static constexpr int OMAX = W == 192 ? 56 : (W + 5) * 10 / 39 + 3;   // symbols per stream per window: <= (W + 5) / 3.9 + 1 for sps >= 3.9
+    static constexpr int OMAX = W == 192 ? 56 : (W + 5) * 2 / 7 + 1;     // symbols per stream per window: room for (W + 5) / 3.5 (56 at W = 192, 29 at W = 96)
     static constexpr int OPITCH = OMAX + 1;
     static constexpr size_t lds_bytes() { return (size_t)(2 * NS * PITCH + 4 + 129 * 8 + 2 * NS * OPITCH) * sizeof(float) + 2 * 64 * sizeof(int) + (2 * 64 + 64 + 2) * sizeof(uint64_t); }
 };
