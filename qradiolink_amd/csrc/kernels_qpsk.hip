@@ -319,6 +319,11 @@ __global__ __launch_bounds__(384) void k_qpsk_pipe4(const QpskParams P, int batc
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int b0 = blockIdx.x * 64;
     const int nstreams = min(64, batch - b0);
+#ifndef QRL_Q4_NOPRIO
+    // a serial walk whose run time IS the receiver's step (C3) shares its SIMDs with throughput kernels of the neighbouring calls: its
+    // few instructions go first
+    __builtin_amdgcn_s_setprio(3);
+#endif
     for (int k = tid; k < 129 * 8; k += 384) mm[k] = P.mmse[k];
     if (tid < 256) th[tid] = P.tanh_tab[tid];
     const uint64_t np0 = P.np0, avail = P.avail;
