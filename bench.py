@@ -705,12 +705,19 @@ def main():
     # C1 runs in the library's default mode (the FLL / discriminator kernels of call k share the GPU with the front end of call
     # k + 1: more whole-chain throughput, but the front-end kernel stretches).  The serial order -- where the front-end kernel has the
     # chip to itself -- is measured in a second short pass for the record.
+    def settle():
+        # The sub-lines run in this same process right behind other workloads.  Measured (tools/experiments/r04_subline_order.py): C4 --
+        # a compute-bound chain -- takes 4.5 ms per step when it starts right behind C1 or C2 (HBM-bound) and 3.1 ms fresh or after a 2 s
+        # pause: the power management needs about that long to give the shader clock back.  Outside every timed region.
+        torch.cuda.synchronize()
+        time.sleep(2.0)
+        return True
     ovl = run_workload("c1", args, torch, q, ctx, dev, rank, world, overlap=False, steps=min(args.steps, 20)) \
         if (extra_ok and args.config == "c1" and not args.no_overlap) else None
-    extra = run_workload("c2", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 50), check=True) if (extra_ok and args.config == "c1") else None
-    extra3 = run_workload("c3", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 30), check=True) if (extra_ok and args.config == "c1") else None
-    extra4 = run_c4(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20), check=True) if (extra_ok and args.config == "c1" and world == 1) else None
-    extra5 = run_c5(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20), check=True) if (extra_ok and args.config == "c1" and world == 1) else None
+    extra = settle() and run_workload("c2", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 50), check=True) if (extra_ok and args.config == "c1") else None
+    extra3 = settle() and run_workload("c3", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 30), check=True) if (extra_ok and args.config == "c1") else None
+    extra4 = settle() and run_c4(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20), check=True) if (extra_ok and args.config == "c1" and world == 1) else None
+    extra5 = settle() and run_c5(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20), check=True) if (extra_ok and args.config == "c1" and world == 1) else None
     # (the CPU baseline is a property of the box, not of the job: rank 0 at N = 1 only, as the contract says)
     all_lines = extra_ok and rank == 0 and world == 1 and args.config == "c1"
     base = cpu_baseline(args.config, ncores) if (extra_ok and rank == 0 and world == 1) else None

@@ -467,7 +467,7 @@ int qrl_chan_profile_read(qrl_chan* h, double* kernel_ms, uint64_t* launches, co
     }
     if (kernel_ms) *kernel_ms = total;
     if (launches) *launches = h->prof_events.size();
-    if (kernel_name) *kernel_name = (h->xlat || h->xlat2) ? "k_decim_mfma (one launch per channel, summed)" : h->single ? "k_resamp" : "k_pfb_chan";
+    if (kernel_name) *kernel_name = (h->xlat || h->xlat2) ? "k_decim_mfma (one launch per channel, summed)" : h->single ? "k_resamp" : (h->opt_legacy_pfb == 0 && h->M == 64) ? "k_pfb_stream64" : h->opt_legacy_pfb == 2 ? "k_pfb_chan64" : "k_pfb_chan";
     h->prof_events.clear();
     return QRL_OK;
 }

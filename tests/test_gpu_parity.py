@@ -559,6 +559,44 @@ def test_pipelined_calls_without_sync(qrl_ctx, mode_name, modem):
     assert n_last > 0 and np.array_equal(a1[0, :n_last], ref["bits_a"][-n_last:])
 
 
+def test_grouped_order_at_a_chip_filling_batch(qrl_ctx):
+    """The QPSK receiver at a batch that gives k_qpsk_pipe4 a workgroup for every second CU (QRL_OPT_GROUPED's default there): calls queued
+    back to back run front end -> recursion || decoder of the call before (the decoder launched one call late, behind k_fec_gate); the
+    same sequence with a sync after every call flushes every decoder at once.  Every stream's counts and bits must agree, and two
+    streams equal the oracle."""
+    import torch
+    import qradiolink_amd as q
+    B, chunk, ncalls = 8200, 6000, 3
+    base = sig.make_batch("qpsk250k", 2, nframes=2, device_rate=1000000, seed=12)[:, :chunk * ncalls]
+    d = torch.from_numpy(base).cuda()
+    d = torch.cat([d, torch.flip(d, [0])]).repeat(B // 4 + 1, 1)[:B].contiguous()
+    res = []
+    for sync_each in (True, False):
+        dem = q.Demod(qrl_ctx, 26, batch=B, max_chunk=chunk)
+        outs = []
+        for k in range(ncalls):
+            outs.append(dem.new_outputs())
+            dem.process_async(d[:, k * chunk:(k + 1) * chunk])
+            if sync_each:
+                dem.sync()
+        dem.sync()
+        res.append([(o["counts"].cpu().numpy().copy(), o["bits_a"].cpu().numpy().copy()) for o in outs])
+        dem.close()
+    total = 0
+    for k in range(ncalls):
+        (c0, a0), (c1, a1) = res[0][k], res[1][k]
+        assert np.array_equal(c0, c1), "call %d" % k
+        n = int(c0[:, 2].max())
+        mask = np.arange(n)[None, :] < c0[:, 2:3]
+        assert np.array_equal(a0[:, :n][mask], a1[:, :n][mask]), "call %d" % k
+        total += int(c0[:, 2].sum())
+    assert total > 0
+    for b in (0, 1):
+        ref = _oracle("qpsk250k", base[b], 1000000, 0.0)
+        got = np.concatenate([res[1][k][1][b, :res[1][k][0][b, 2]] for k in range(ncalls)])
+        assert np.array_equal(got, ref["bits_a"][:got.size]) and got.size > 0
+
+
 @pytest.mark.parametrize("mode_name,modem", [("qpsk250k", 26), ("bpsk2k", 0), ("gmsk10k", 22), ("2fsk1k", 18)])
 def test_every_call_of_a_pipelined_sequence_is_deterministic(qrl_ctx, mode_name, modem):
     """Calls in flight together (each with its own output buffers, no sync in between): EVERY call's counts, bits and port 1 equal
