@@ -303,6 +303,18 @@ __device__ __forceinline__ float clamp_pm1(float f)   // if (f > 1) f = 1; else 
 }
 __device__ __forceinline__ int q4_col(long long i) { return (int)(((i % Q4_RC) + Q4_RC) % Q4_RC); }
 
+#ifdef QRL_Q4_PROF
+// developer build (tools/kernel_variants.sh kernels_qpsk.hip q4prof -DQRL_Q4_PROF): per wave (= pipeline stage) the ticks between two
+// barriers that the wave spent working, and the ticks of the whole loop: which stage sets the pace of the serial walk
+__device__ unsigned long long g_q4_prof[6][3];
+extern "C" void qrl_q4_prof_read(unsigned long long* out18)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out18, HIP_SYMBOL(g_q4_prof), sizeof(unsigned long long) * 18);
+    static unsigned long long zero[18];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_q4_prof), zero, sizeof zero);
+}
+#endif
 __global__ __launch_bounds__(384) void k_qpsk_pipe4(const QpskParams P, int batch)
 {
     extern __shared__ __align__(16) unsigned char qp_smem[];
@@ -436,7 +448,13 @@ __global__ __launch_bounds__(384) void k_qpsk_pipe4(const QpskParams P, int batc
     load_window(k_first, tid, 384);
     __syncthreads();
     const float SQ = 0.707107f;
+#ifdef QRL_Q4_PROF
+    unsigned long long busy = 0, total0 = __builtin_readcyclecounter();
+#endif
     for (long long t = k_first; t <= k_last + 4; ++t) {
+#ifdef QRL_Q4_PROF
+        const unsigned long long tb0 = __builtin_readcyclecounter();
+#endif
         if (wv == 0) {
             if (t <= k_last && active) {                      // ---- agc2_cc on window t, in place
                 const int base = (int)(t % Q4_NB) * Q4_W;
@@ -545,8 +563,14 @@ __global__ __launch_bounds__(384) void k_qpsk_pipe4(const QpskParams P, int batc
             if (t + 1 <= k_last) load_window(t + 1, tid - 256, 128);
             if (t - 4 >= k_first && t - 4 <= k_last) flush_window(t - 4, tid - 256, 128);
         }
+#ifdef QRL_Q4_PROF
+        busy += __builtin_readcyclecounter() - tb0;
+#endif
         __syncthreads();
     }
+#ifdef QRL_Q4_PROF
+    if (lane == 0) { atomicAdd(&g_q4_prof[wv][0], busy); atomicAdd(&g_q4_prof[wv][1], __builtin_readcyclecounter() - total0); atomicAdd(&g_q4_prof[wv][2], 1ull); }
+#endif
     if (!active) return;
     if (wv == 0) gst->gain = gain;
     if (wv == 1) {
