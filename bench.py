@@ -108,27 +108,36 @@ def parity_check(dem, iq, mode, rate, offset, torch, nstreams=4, seed=5):
 
 
 class StepMarks:
-    """Per-step completion times without touching the timed streams: after every queued step a side stream is made to wait (on the
-    device) for everything the handle has queued so far and an event is recorded there; the differences of consecutive events are
-    the intervals at which the steps completed.  Costs two event operations per step on the host, nothing on the handle's streams."""
+    """Per-step completion times that order NOTHING: after every queued step one event is recorded on each of the streams the step's
+    kernels run on (qrl_*_internal_streams); a step is complete when the last of its events has fired, the differences of consecutive
+    completion times are the intervals.  (Round 4 first took the marks on a side stream behind qrl_*_stream_wait.  Streams of one
+    priority share a few hardware queues, and when the side stream landed on the queue of one of the handle's streams its wait -- for
+    the whole step -- sat in front of the next step's kernel there: the steps ran strictly one after the other, C4 at 4.5 instead of
+    3.05 ms.  Whether that happened depended on how many streams the process had created before: it hit the sub-lines of the default
+    run, not the stand-alone runs.  tools/experiments/r04_subline_order*.py)"""
 
-    def __init__(self, torch, wait, enabled=True, note="intervals between step completions (events on a side stream behind qrl_*_stream_wait)"):
-        self.torch, self.wait, self.side, self.ev, self.enabled, self.note = torch, wait, torch.cuda.Stream(), [], enabled, note
+    def __init__(self, torch, streams, enabled=True, note="intervals between step completions (the last of the events recorded, per step, on the handle's internal streams)"):
+        self.torch, self.enabled, self.note, self.ev = torch, enabled, note, []
+        self.streams = [torch.cuda.ExternalStream(s) for s in streams] if enabled else []
 
     def mark(self):
         if not self.enabled:
             return
-        self.wait(self.side.cuda_stream)
-        e = self.torch.cuda.Event(enable_timing=True)
-        e.record(self.side)
-        self.ev.append(e)
+        evs = []
+        for s in self.streams:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record(s)
+            evs.append(e)
+        self.ev.append(evs)
 
     def spread(self):
-        """min / median / max of the step intervals in ms (the first interval starts at the mark before the first timed step)"""
-        series = [a.elapsed_time(b) for a, b in zip(self.ev[:-1], self.ev[1:])]
-        d = sorted(series)
-        if not d:
+        """min / p10 / median / p90 / max of the step intervals in ms (the first interval starts at the mark before the first timed step)"""
+        if len(self.ev) < 2:
             return None
+        base = self.ev[0][0]
+        done = [max(base.elapsed_time(e) for e in evs) for evs in self.ev]
+        series = [b - a for a, b in zip(done[:-1], done[1:])]
+        d = sorted(series)
         if os.environ.get("QRL_BENCH_DUMP_STEPS"):
             sys.stderr.write("step intervals [ms]: " + " ".join("%.2f" % x for x in series) + "\n")
         return dict(min=round(d[0], 3), p10=round(d[len(d) // 10], 3), median=round(d[len(d) // 2], 3), p90=round(d[(9 * len(d)) // 10], 3), max=round(d[-1], 3), steps=len(d),
@@ -155,7 +164,7 @@ def run_workload(name, args, torch, q, ctx, dev, rank, world, overlap=None, chec
     if world > 1:
         torch.distributed.barrier()
     dem.profile(True)
-    marks = StepMarks(torch, dem.stream_wait, enabled=not args.no_marks)
+    marks = StepMarks(torch, dem.internal_streams, enabled=not args.no_marks)
     marks.mark()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -361,7 +370,7 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, c
             cl.sync()
         prof, handles = cl.front, [cl.front, cl.tail]
     prof.profile(True)
-    marks = StepMarks(torch, handles[-1].stream_wait, enabled=not args.no_marks)
+    marks = StepMarks(torch, [x for hnd in handles for x in hnd.internal_streams], enabled=not args.no_marks)
     dt = timed_loop(step, sync, args, torch, dev, world, marks)
     kms, launches, kname = prof.profile_read()
     launches_timed = args.steps
@@ -488,15 +497,9 @@ def run_c5(args, torch, q, ctx, dev, rank, world, steps=None, check=False):
     def sync():
         mod.sync()
         dem.sync()
-    # step marks behind the receiver's FRONT END (an event on the handle's main stream), not behind qrl_demod_stream_wait: that call
-    # waits for results, so it launches the decoder the grouped order holds back for the next call (QRL_OPT_GROUPED) -- a mark per step
-    # would put every step in the free-running order.  In steady state the front ends complete at the step period.
-    def front_end_wait(side_ptr):
-        e = torch.cuda.Event()
-        e.record(main_stream)
-        torch.cuda.ExternalStream(side_ptr).wait_event(e)
-    marks = StepMarks(torch, front_end_wait, enabled=not args.no_marks,
-                      note="intervals between the completions of the receiver's front end (events behind the handle's main stream: qrl_demod_stream_wait would launch the decoder the grouped order defers)")
+    # step marks on the receiver's streams only (events order nothing; the decoder of a call is launched one call late in the grouped
+    # order, so its stream's mark belongs to the call before -- in steady state the intervals are the step period all the same)
+    marks = StepMarks(torch, dem.internal_streams, enabled=not args.no_marks)
     dt = timed_loop(both, sync, args, torch, dev, world, marks)
     dem.profile(True)
     dt_rx = timed_loop(lambda: dem.process_async(iq), sync, args, torch, dev, world)
@@ -705,19 +708,12 @@ def main():
     # C1 runs in the library's default mode (the FLL / discriminator kernels of call k share the GPU with the front end of call
     # k + 1: more whole-chain throughput, but the front-end kernel stretches).  The serial order -- where the front-end kernel has the
     # chip to itself -- is measured in a second short pass for the record.
-    def settle():
-        # The sub-lines run in this same process right behind other workloads.  Measured (tools/experiments/r04_subline_order.py): C4 --
-        # a compute-bound chain -- takes 4.5 ms per step when it starts right behind C1 or C2 (HBM-bound) and 3.1 ms fresh or after a 2 s
-        # pause: the power management needs about that long to give the shader clock back.  Outside every timed region.
-        torch.cuda.synchronize()
-        time.sleep(2.0)
-        return True
     ovl = run_workload("c1", args, torch, q, ctx, dev, rank, world, overlap=False, steps=min(args.steps, 20)) \
         if (extra_ok and args.config == "c1" and not args.no_overlap) else None
-    extra = settle() and run_workload("c2", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 50), check=True) if (extra_ok and args.config == "c1") else None
-    extra3 = settle() and run_workload("c3", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 30), check=True) if (extra_ok and args.config == "c1") else None
-    extra4 = settle() and run_c4(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20), check=True) if (extra_ok and args.config == "c1" and world == 1) else None
-    extra5 = settle() and run_c5(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20), check=True) if (extra_ok and args.config == "c1" and world == 1) else None
+    extra = run_workload("c2", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 50), check=True) if (extra_ok and args.config == "c1") else None
+    extra3 = run_workload("c3", args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 30), check=True) if (extra_ok and args.config == "c1") else None
+    extra4 = run_c4(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20), check=True) if (extra_ok and args.config == "c1" and world == 1) else None
+    extra5 = run_c5(args, torch, q, ctx, dev, rank, world, steps=min(args.steps, 20), check=True) if (extra_ok and args.config == "c1" and world == 1) else None
     # (the CPU baseline is a property of the box, not of the job: rank 0 at N = 1 only, as the contract says)
     all_lines = extra_ok and rank == 0 and world == 1 and args.config == "c1"
     base = cpu_baseline(args.config, ncores) if (extra_ok and rank == 0 and world == 1) else None

@@ -158,6 +158,11 @@ int qrl_demod_set_agc(qrl_demod* d, float attack, float decay);
 int qrl_demod_process(qrl_demod* d, const float* iq, size_t stride, size_t n, const qrl_demod_out* out);
 int qrl_demod_sync(qrl_demod* d);
 void* qrl_demod_stream(qrl_demod* d); /* hipStream_t */
+/* Profiling aid: the HIP streams a call's stages are launched on -- out[0] the handle's stream (front end), out[1] the stream of the
+ * decimated-rate / recursion kernels, out[2] the decoder's.  An event recorded on one of them orders nothing (unlike
+ * qrl_demod_stream_wait, whose wait on the caller's stream sits in a hardware queue that stream may share with this handle's);
+ * bench.py takes its per-step completion times this way.  Not a synchronisation interface: use qrl_demod_sync / _stream_wait. */
+int qrl_demod_internal_streams(qrl_demod* d, void* out[3]);
 /* makes the caller's stream wait (on the device, without blocking the host) for everything this handle has enqueued so far on its
  * internal streams: how a host layer chains its own asynchronous copies of the output ports behind a qrl_demod_process call
  * (host/gr_modem_hip.cpp: double-buffered mailboxes) instead of calling qrl_demod_sync. */
@@ -300,6 +305,7 @@ int qrl_chan_wait_for(qrl_chan* c, void* hip_stream);
  * caller chains its own copies / collectives (the all-to-all of a multi-GPU job) behind a call without a host synchronisation. */
 int qrl_chan_stream_wait(qrl_chan* c, void* hip_stream);
 void* qrl_chan_stream(qrl_chan* c);   /* hipStream_t the handle enqueues on */
+int qrl_chan_internal_streams(qrl_chan* c, void* out[2]);   /* profiling aid, as qrl_demod_internal_streams: out[0] the handle's stream, out[1] the symbol-sync stream (or NULL) */
 /* like qrl_demod_profile / qrl_demod_profile_read: HIP events on the handle's stream around the kernel(s) that read the caller's
  * wideband IQ (k_pfb_chan; forms 1 / 2: the per-channel decimator launches of a call, summed) -- bench.py's roofline leg */
 int qrl_chan_profile(qrl_chan* c, int enable);

@@ -146,6 +146,8 @@ def load_library():
     lib.qrl_demod_set_time_domain_output.argtypes = [vp, vp, sz, vp]
     lib.qrl_demod_stream.restype = vp
     lib.qrl_demod_stream.argtypes = [vp]
+    lib.qrl_demod_internal_streams.argtypes = [vp, C.POINTER(vp)]
+    lib.qrl_chan_internal_streams.argtypes = [vp, C.POINTER(vp)]
     lib.qrl_demod_profile.argtypes = [vp, C.c_int]
     lib.qrl_demod_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_char_p)]
     lib.qrl_demod_process_host.argtypes = [vp, vp, sz, sz, vp, vp, sz, vp]
@@ -218,7 +220,7 @@ EXPORTED_SYMBOLS = [
     "qrl_demod_audio_cap", "qrl_demod_set_squelch", "qrl_demod_set_agc", "qrl_demod_set_ctcss", "qrl_demod_time_domain_cap", "qrl_demod_set_time_domain_output",
     "qrl_bptc19696_decode", "qrl_bptc19696_encode", "qrl_m17_decode_frames", "qrl_m17_encode_frames",
     "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
-    "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_process_host", "qrl_demod_profile",
+    "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_internal_streams", "qrl_chan_internal_streams", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
     "qrl_mod_samples_per_byte", "qrl_mod_samples_per_block", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_set_option", "qrl_chan_channelize", "qrl_chan_process_channels", "qrl_chan_wait_for", "qrl_chan_stream_wait", "qrl_chan_stream", "qrl_chan_profile", "qrl_chan_profile_read", "qrl_debug_decim_prof", "qrl_debug_decim_prof_enable", "qrl_chan_create",
     "qrl_chan_destroy", "qrl_chan_reset", "qrl_chan_set_level", "qrl_chan_calibrate_rssi", "qrl_chan_set_rssi_output", "qrl_chan_set_4fsk_output", "qrl_chan_out_cap", "qrl_chan_process", "qrl_chan_sync",
@@ -406,6 +408,13 @@ class Demod:
         """the handle's main HIP stream (int): the one the front end of a call is launched on (qrl_demod_stream)"""
         return int(self.lib.qrl_demod_stream(self.h) or 0)
 
+    @property
+    def internal_streams(self):
+        """the HIP streams (ints, without duplicates / NULLs) a call's stages are launched on: profiling aid (qrl_demod_internal_streams)"""
+        arr = (C.c_void_p * 3)()
+        _check(self.lib.qrl_demod_internal_streams(self.h, arr), "qrl_demod_internal_streams")
+        return list(dict.fromkeys(int(x) for x in arr if x))
+
     def profile(self, enable=True):
         _check(self.lib.qrl_demod_profile(self.h, int(enable)), "qrl_demod_profile")
 
@@ -540,6 +549,13 @@ class Channelizer:
     def stream_wait(self, hip_stream):
         """the given HIP stream (int handle, e.g. torch.cuda.current_stream().cuda_stream) waits on the device for this handle's work so far"""
         _check(self.lib.qrl_chan_stream_wait(self.h, C.c_void_p(hip_stream)), "qrl_chan_stream_wait")
+
+    @property
+    def internal_streams(self):
+        """the HIP streams (ints) a call's stages are launched on: profiling aid (qrl_chan_internal_streams)"""
+        arr = (C.c_void_p * 2)()
+        _check(self.lib.qrl_chan_internal_streams(self.h, arr), "qrl_chan_internal_streams")
+        return list(dict.fromkeys(int(x) for x in arr if x))
 
     def process(self, iq):
         self.process_async(iq)

@@ -266,7 +266,9 @@ int qrl_chan_set_4fsk_output(qrl_chan* h, uint8_t* bits, size_t bits_cap, float*
             (r = h->r6.alloc(S * (h->m6 + 1))) || (r = h->ss.alloc(S)) || (r = h->soft_dummy.alloc(64)))
             return qrl_set_error(r, "4fsk tail buffers");
         if (!h->tail) {
-            HIPCHK(hipStreamCreateWithFlags(&h->tail, hipStreamNonBlocking));
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            HIPCHK(hipStreamCreateWithPriority(&h->tail, hipStreamNonBlocking, hi));   // a priority of its own: never the hardware queue of the main stream (engine.cpp, stream creation)
             HIPCHK(hipEventCreateWithFlags(&h->ev_ff, hipEventDisableTiming));
             for (auto& e : h->ev_tail) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
@@ -453,6 +455,12 @@ int qrl_chan_wait_for(qrl_chan* h, void* hip_stream)
     return QRL_OK;
 }
 void* qrl_chan_stream(qrl_chan* h) { return h ? h->stream : nullptr; }
+int qrl_chan_internal_streams(qrl_chan* h, void* out[2])
+{
+    if (!h || !out) return QRL_ERR_ARG;
+    out[0] = h->stream; out[1] = h->tail;
+    return QRL_OK;
+}
 int qrl_chan_profile(qrl_chan* h, int enable) { if (!h) return QRL_ERR_ARG; h->profiling = enable != 0; return QRL_OK; }
 int qrl_chan_profile_read(qrl_chan* h, double* kernel_ms, uint64_t* launches, const char** kernel_name)
 {

@@ -1178,8 +1178,13 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         else { HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)); d->own_stream = true; }
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        HIPCHK(hipStreamCreateWithPriority(&d->tail, hipStreamNonBlocking, hi));   // (low / normal priority measured: no difference)
-        HIPCHK(hipStreamCreateWithPriority(&d->fecs, hipStreamNonBlocking, hi));
+        // THREE DIFFERENT PRIORITIES, and not for the scheduling: the runtime multiplexes the streams of one priority onto a few hardware
+        // queues (least-used first), and two streams of a handle that land on the same queue run their kernels one after the other --
+        // the overlapped and grouped orders then silently degrade to the serial one (seen as C4 4.5 instead of 3.05 ms and C2 2.2 instead
+        // of 1.78 ms per step in the sub-lines of a long bench process, depending on how many streams the process had created and
+        // destroyed before: tools/experiments/r04_subline_order*.py).  Queues of different priorities are never shared.
+        HIPCHK(hipStreamCreateWithPriority(&d->tail, hipStreamNonBlocking, hi));
+        HIPCHK(hipStreamCreateWithPriority(&d->fecs, hipStreamNonBlocking, lo));
     }
     HIPCHK(hipEventCreateWithFlags(&d->ev_ff, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&d->ev_tail, hipEventDisableTiming));
@@ -1380,6 +1385,12 @@ int qrl_demod_sync(qrl_demod* d)
     return QRL_OK;
 }
 void* qrl_demod_stream(qrl_demod* d) { return d ? d->stream : nullptr; }
+int qrl_demod_internal_streams(qrl_demod* d, void* out[3])
+{
+    if (!d || !out) return QRL_ERR_ARG;
+    out[0] = d->stream; out[1] = d->tail; out[2] = d->fecs;
+    return QRL_OK;
+}
 
 int qrl_demod_profile(qrl_demod* d, int enable)
 {

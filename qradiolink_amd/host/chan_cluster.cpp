@@ -80,7 +80,11 @@ chan_cluster::chan_cluster(qrl_ctx* ctx, chan_exchange& ex, int num_channels, in
         hchk(hipMalloc(reinterpret_cast<void**>(&d_recv[k]), items * 2 * sizeof(float)), "hipMalloc");
     }
     hipStream_t xs;
-    hchk(hipStreamCreateWithFlags(&xs, hipStreamNonBlocking), "hipStreamCreate");
+    // lowest priority -- not for the scheduling: streams of one priority share a few hardware queues, and a wait queued on this
+    // stream would otherwise hold back the kernels of a handle stream that happens to sit on the same queue (csrc/engine.cpp, stream creation)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    hchk(hipStreamCreateWithPriority(&xs, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
     d_xs = xs;
 }
 chan_cluster::~chan_cluster()

@@ -70,7 +70,11 @@ void gr_demod_hip::open()
         hchk(hipMalloc(reinterpret_cast<void**>(&d_iq), kChunk * sizeof(gr_complex)), "hipMalloc");
         hchk(hipMalloc(reinterpret_cast<void**>(&d_cnt), 4 * sizeof(uint32_t)), "hipMalloc");
         hipStream_t cs;
-        hchk(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), "hipStreamCreate");
+        // lowest priority -- not for the scheduling: streams of one priority share a few hardware queues, and a wait queued on this
+        // stream would otherwise hold back the kernels of a handle stream that happens to sit on the same queue (csrc/engine.cpp, stream creation)
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        hchk(hipStreamCreateWithPriority(&cs, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
         d_cs = cs;
         hchk(hipHostMalloc(reinterpret_cast<void**>(&d_hcnt), 6 * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
     }

@@ -81,7 +81,11 @@ gr_demod_base_hip::gr_demod_base_hip(qrl_runtime& rt, int streams, int device_sa
     d_boxf[0].resize(streams); d_boxf[1].resize(streams); d_boxs.resize(streams);
     if (streams < 1 || d_chunk < 2) throw std::invalid_argument("gr_demod_base_hip: streams >= 1, max_chunk >= 2");
     hipStream_t s;
-    hchk(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    // lowest priority -- not for the scheduling: streams of one priority share a few hardware queues, and a wait queued on this
+    // stream would otherwise hold back the kernels of a handle stream that happens to sit on the same queue (csrc/engine.cpp, stream creation)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    hchk(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
     d_copy = s;
 }
 gr_demod_base_hip::~gr_demod_base_hip()
