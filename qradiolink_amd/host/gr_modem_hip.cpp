@@ -294,7 +294,7 @@ void gr_demod_base_hip::harvest(int which)
     for (int s = 0; s < d_n; ++s) {
         const uint32_t* c = sl.h_cnt + 4 * (size_t)s;
         if (sl.rssi_valid && c[0]) d_level[s] = sl.h_rssi[s];
-        // gr_sample_sink::work (src/gr/gr_sample_sink.cpp:74-96): while more than 524288 items wait, the new ones are dropped
+        // gr_sample_sink::work (src/gr/gr_sample_sink.cpp:66-89): while more than 524288 items wait, the new ones are dropped
         if (sl.scoped && d_boxs[s].size() <= 524288) {
             const gr_complex* p = sl.h_scope + (size_t)s * d_scap;
             d_boxs[s].insert(d_boxs[s].end(), p, p + std::min<size_t>(sl.h_scnt[s], d_scap));

@@ -76,7 +76,7 @@ public:
     void calibrate_rssi(float value);
     void enable_gui_fft(bool value);
     // time-domain scope tap: gr_demod_base::enable_time_domain / get_sample_data / set_sample_window (src/gr/gr_demod_base.cpp:988-1018,
-    // 1115-1147) with gr_sample_sink's mailbox rules (src/gr/gr_sample_sink.cpp:35-96): window 8096 items (made even), nothing is
+    // 1115-1147) with gr_sample_sink's mailbox rules (src/gr/gr_sample_sink.cpp:28-89): window 8096 items (made even), nothing is
     // taken while more than 524288 items wait, get_data hands out min(waiting, window) items (an even count) or nothing below 2
     void enable_time_domain(bool value);
     void set_sample_window(unsigned int size);
