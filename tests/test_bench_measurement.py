@@ -30,7 +30,8 @@ def test_traffic_is_reported_only_for_matching_sources(monkeypatch):
     d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     monkeypatch.setattr(bench, "source_id", lambda: d["_source_id"])          # as if run on the sources of the pass
     t, src = bench.pmc_traffic("c1", "k_decim_pm")
-    assert t and t > 35e9 and src == "profiles/r03_pmc_summary.txt"            # 35.1 GB of algorithmic bytes per launch
+    import re
+    assert t and t > 35e9 and re.fullmatch(r"profiles/r\d\d_pmc_summary\.txt", src)   # 35.1 GB of algorithmic bytes per launch
     assert bench.pmc_traffic("c1", "k_decim_pm", default_shape=False) == (None, None)
     assert bench.pmc_traffic("c1", "k_some_other_kernel") == (None, None)
     monkeypatch.setattr(bench, "source_id", lambda: "000000000000")
@@ -38,9 +39,26 @@ def test_traffic_is_reported_only_for_matching_sources(monkeypatch):
     assert t is None and "000000000000" in why
 
 
+def test_issue_bound_of_the_qpsk_receivers(monkeypatch):
+    """round 4: C3 and C5 carry roofline.issue -- VALU wave instructions of one receiver call from the SQ_INSTS_* pass of the same round,
+    tied to the same source id, over the RX-alone time measured in the bench."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    monkeypatch.setattr(bench, "source_id", lambda: d["_source_id"])
+    for cfg, secs in (("c3", 1.93e-3), ("c5", 3.4e-3)):
+        r = bench.issue_roofline(cfg, secs)
+        assert r["bound"] == "issue" and r["peak"] == bench.VALU_ISSUE_PEAK_G and 0.05 < r["frac"] < 1.0
+        assert r["valu_wave_instr_per_rx_call"] > 1e8 and r["all_classes_frac"] > r["frac"]
+        assert any("k_fec" in k for k in r["by_kernel"]) and any("k_qpsk_pipe4" in k for k in r["by_kernel"])
+        assert not any("k_tx_" in k for k in r["by_kernel"])          # the modulator's kernels are not part of a receiver call
+    assert bench.issue_roofline("c5", 3.4e-3, default_shape=False) is None
+    monkeypatch.setattr(bench, "source_id", lambda: "000000000000")
+    assert bench.issue_roofline("c5", 3.4e-3)["frac"] is None
+
+
 def test_traffic_close_to_the_algorithmic_bytes_for_the_streaming_front_ends():
     d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-    alg = {"c1": 16384 * 262144 * 8.178, "c2": 384 * 1638400 * 8.033, "c3": 384 * 1638400 * 8.0625}
+    alg = {"c1": 16384 * 262144 * 8.178, "c2": 384 * 1638400 * 8.033, "c3": 384 * 1638400 * 8.0625,
+           "c4": 64 * (1 << 21) * 16.0}   # round 4: the streaming channelizer reads the wideband input once and writes the 64 channel rings once (8 + 8 B per sample)
     for cfg, a in alg.items():
         ratio = (d[cfg]["fetch_bytes"] + d[cfg]["write_bytes"]) / a
         assert 0.98 < ratio < 1.10, (cfg, ratio)
