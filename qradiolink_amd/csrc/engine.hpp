@@ -265,7 +265,7 @@ size_t synth_lds_bytes(int M, int J);
 struct TxState { uint32_t sr, enc, prev, pad; };   // scrambler register, last 6 scrambled bits, last differential symbol
 struct TxBitsParams {
     const uint8_t* bytes; size_t stride; uint32_t nbytes; uint32_t L;   // L bits per lane (multiple of 32)
-    uint8_t tl_cols[8];                                                  // T^L of the zero-input scrambler, column masks
+    uint8_t tl_pow[6][8];                                                // T^(L 2^d), d = 0..5, of the zero-input scrambler: column masks
     int mode;                                                            // 0: QPSK differential symbols, 1: coded bits (2 per input bit)
     TxState* st; RingB sym; uint64_t s0;                                 // symbol ring, absolute index of this call's first symbol
 };

@@ -22,7 +22,7 @@ __device__ __forceinline__ uint32_t lfsr_step(uint32_t sr, uint32_t in)   // scr
     const uint32_t nb = (__builtin_popcount(sr & 0x8Au) & 1u) ^ (in & 1u);
     return (sr >> 1) | (nb << 7);
 }
-__device__ __forceinline__ uint32_t gf2_apply(const uint8_t (&cols)[8], uint32_t v)
+__device__ __forceinline__ uint32_t gf2_apply(const uint8_t* cols, uint32_t v)
 {
     uint32_t r = 0;
 #pragma unroll
@@ -30,123 +30,157 @@ __device__ __forceinline__ uint32_t gf2_apply(const uint8_t (&cols)[8], uint32_t
     return r;
 }
 
+// Round 4: word-parallel where the algebra allows it.  The lane's slice of L input bits is held as 32-bit words (bit j of word w =
+// input bit lane L + 32 w + j, i.e. the bytes bit-reversed); the true start register of every lane comes from a log-step scan over the
+// lanes (the slice maps are affine over GF(2): after step d a lane holds the composition of its 2^(d+1) predecessors, combined with the
+// zero-input transition T^(L 2^d) -- six 8 x 8 column-mask matrices from the host) instead of a 63-step chain; the two coded bits of
+// 32 consecutive input bits are XORs of shifted copies of the scrambled word (c0 = s ^ s>>2 ^ s>>3 ^ s>>5 ^ s>>6 for 109, c1 = s ^ s>>1 ^
+// s>>2 ^ s>>3 ^ s>>6 for 79, on the 38-bit window prev6 | word), map{0,1,3,2}[2 c0 + c1] = 2 c0 + (c0 ^ c1), and a slice's symbol sum is
+// two popcounts.  What stays bit-serial: the scrambler itself (a recursion with input feedback: two register-only passes per slice)
+// and the running differential symbol.  Symbols leave four to a dword.  (tools: the lane algorithm was checked against a serial model
+// in Python before it was written here; tests/test_gpu_tx.py has the bit-exact and chunk-invariance cases, sizes 1 .. 8192 bytes.)
 __global__ __launch_bounds__(64) void k_tx_qpsk_bits(const TxBitsParams P)
 {
     extern __shared__ __align__(16) unsigned char tx_smem[];
-    uint32_t* sbits = reinterpret_cast<uint32_t*>(tx_smem);     // scrambled bits of this call, packed LSB = earliest
+    uint32_t* sbits = reinterpret_cast<uint32_t*>(tx_smem);     // scrambled bits, word lane * nw + w, LSB = earliest
     const int b = blockIdx.x, lane = threadIdx.x;
     const uint8_t* in = P.bytes + (size_t)b * P.stride;
     TxState st = P.st[b];
     const uint32_t nbits = P.nbytes * 8u;
-    const uint32_t L = P.L;                                     // bits per lane, multiple of 32
-    const uint32_t lo = min(nbits, lane * L), hi = min(nbits, (lane + 1) * L);
-    auto in_bit = [&](uint32_t i) { return (uint32_t)(in[i >> 3] >> (7u - (i & 7u))) & 1u; };   // packed_to_unpacked MSB first
+    const uint32_t L = P.L, nw = L >> 5;                        // bits / words per lane
+    const uint32_t hi = min(nbits, (uint32_t)(lane + 1) * L);                  // this lane's slice = input bits [lane L, hi)
+    const bool aligned4 = (reinterpret_cast<uintptr_t>(in) & 3u) == 0;
+    auto in_word = [&](uint32_t w) -> uint32_t {                 // bit j = input bit lane L + 32 w + j (packed_to_unpacked MSB first), 0 behind the end
+        const uint32_t byte0 = ((uint32_t)lane * L >> 3) + 4u * w;
+        if (byte0 >= P.nbytes) return 0u;
+        uint32_t d = 0;
+        if (aligned4 && byte0 + 4u <= P.nbytes) d = *reinterpret_cast<const uint32_t*>(in + byte0);
+        else
+            for (uint32_t k = 0; k < 4u; ++k) if (byte0 + k < P.nbytes) d |= (uint32_t)in[byte0 + k] << (8u * k);
+        return __builtin_bswap32(__builtin_bitreverse32(d));
+    };
+    auto valid_bits = [&](uint32_t w) -> uint32_t {              // how many bits of word w lie inside [lo, hi)
+        const uint32_t i0 = (uint32_t)lane * L + 32u * w;
+        return hi > i0 ? min(32u, hi - i0) : 0u;
+    };
 
-    // pass 1: slice from a zero register
+    // pass 1: the slice from a ZERO register = its contribution to the register behind it
     uint32_t sf = 0;
-    for (uint32_t i = lo; i < hi; ++i) sf = lfsr_step(sf, in_bit(i));
-    // true start register of every lane: init[l] = T^len(l-1) init[l-1] ^ sf[l-1]; only full slices use T^L,
-    // a ragged or empty slice (lanes past the end) never feeds a later lane that has bits
-    uint8_t cols[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) cols[k] = P.tl_cols[k];
-    uint32_t init = st.sr;
-    uint32_t mine = st.sr;
-    for (int l = 1; l < 64; ++l) {
-        const uint32_t sfp = __shfl(sf, l - 1, 64);
-        init = gf2_apply(cols, init) ^ sfp;
-        if (lane == l) mine = init;
+    for (uint32_t w = 0; w < nw; ++w) {
+        const uint32_t x = in_word(w), nv = valid_bits(w);
+        for (uint32_t j = 0; j < nv; ++j) sf = lfsr_step(sf, x >> j);
     }
+    // registers behind every lane's slice by an inclusive scan: c[l] = T^L c[l-1] ^ sf[l], c[-1] = st.sr.  Only FULL slices feed later
+    // lanes that have bits (L = the slice length of every lane but the last one with bits), so T^(L 2^d) is the right power throughout.
+    uint32_t c = sf;
+    if (lane == 0) c ^= gf2_apply(P.tl_pow[0], st.sr);
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+        const uint32_t t = __shfl_up(c, 1u << d, 64);
+        if (lane >= (1 << d)) c ^= gf2_apply(P.tl_pow[d], t);
+    }
+    const uint32_t before = __shfl_up(c, 1, 64);
     // pass 2: the real scrambler; output bit = sr & 1 BEFORE the step
-    uint32_t sr = mine, word = 0;
-    for (uint32_t i = lo; i < hi; ++i) {
-        word |= (sr & 1u) << (i & 31u);
-        sr = lfsr_step(sr, in_bit(i));
-        if ((i & 31u) == 31u || i + 1 == hi) { sbits[i >> 5] = word; word = 0; }
+    uint32_t sr = lane == 0 ? st.sr : before;
+    for (uint32_t w = 0; w < nw; ++w) {
+        const uint32_t x = in_word(w), nv = valid_bits(w);
+        uint32_t word = 0;
+        for (uint32_t j = 0; j < nv; ++j) {
+            word |= (sr & 1u) << j;
+            sr = lfsr_step(sr, x >> j);
+        }
+        sbits[(uint32_t)lane * nw + w] = word;
     }
     // register after the whole call = register of the last lane that had bits
     const uint32_t last_lane = nbits ? (nbits - 1) / L : 0;
     const uint32_t sr_end = __shfl(sr, (int)last_lane, 64);
     __syncthreads();
 
-    // encoder + map: one symbol per input bit.  Scrambled bit i, i < 0 comes from the previous call (st.enc).
-    auto sbit = [&](int64_t i) -> uint32_t {
-        if (i >= 0) return (sbits[i >> 5] >> (i & 31)) & 1u;
-        return (st.enc >> (uint32_t)(-i - 1)) & 1u;              // st.enc bit k = scrambled bit (-1 - k)
+    // coded bits of word w of this lane: c0 / c1 bit t belong to input bit lane L + 32 w + t
+    auto coded = [&](uint32_t w, uint32_t& c0, uint32_t& c1) {
+        const uint32_t gi = (uint32_t)lane * nw + w;
+        // the 6 scrambled bits in front of the word, bit j = scrambled bit (first bit of the word) - 6 + j; in front of the call: st.enc
+        // (bit k = scrambled bit -1 - k)
+        const uint32_t prev6 = gi == 0 ? (__builtin_bitreverse32(st.enc & 63u) >> 26) : (sbits[gi - 1] >> 26);
+        const uint64_t T = ((uint64_t)sbits[gi] << 6) | prev6;
+        c0 = (uint32_t)((T >> 6) ^ (T >> 4) ^ (T >> 3) ^ (T >> 1) ^ T);      // taps of 109: reg bits 0, 2, 3, 5, 6 (bit k = scrambled bit i - k)
+        c1 = (uint32_t)((T >> 6) ^ (T >> 5) ^ (T >> 4) ^ (T >> 3) ^ T);      // taps of 79:  reg bits 0, 1, 2, 3, 6
     };
-    const uint32_t map4[4] = {0u, 1u, 3u, 2u};
-    uint32_t local = 0;
-    for (uint32_t i = lo; i < hi; ++i) {
-        uint32_t reg = 0;                                        // bit k = scrambled bit i - k (cc_encoder shift register)
+    uint8_t* ring = P.sym.p + (size_t)b * (P.sym.mask + 1u);
+    auto enc_state = [&]() -> uint32_t {                          // bit k = scrambled bit nbits - 1 - k (nbits >= 8: all of this call)
+        uint32_t enc = 0;
+        for (int k = 0; k < 6; ++k) { const uint32_t i = nbits - 1u - (uint32_t)k; enc |= ((sbits[i >> 5] >> (i & 31u)) & 1u) << k; }
+        return enc;
+    };
+    if (P.mode == 2 || P.mode == 1) {
+        // 4FSK (gr_mod_4fsk.cpp:96-101): pack_k_bits(2) -> map{0,1,3,2}, one symbol index per input bit, no differential coding;
+        // FSK family: the two coded bits of every input bit go to the ring as they are (chunks_to_symbols later)
+        for (uint32_t w = 0; w < nw; ++w) {
+            const uint32_t nv = valid_bits(w);
+            if (!nv) break;
+            uint32_t c0, c1;
+            coded(w, c0, c1);
+            const uint32_t g = c0 ^ c1, i0 = (uint32_t)lane * L + 32u * w;
+            if (P.mode == 2) {
+                for (uint32_t t = 0; t < nv; t += 4) {            // (nv is a multiple of 8: whole bytes)
+                    uint32_t pk = 0;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) reg |= sbit((int64_t)i - k) << k;
-        const uint32_t c0 = __builtin_popcount(reg & 109u) & 1u, c1 = __builtin_popcount(reg & 79u) & 1u;
-        local = (local + map4[(c0 << 1) | c1]) & 3u;
-    }
-    if (P.mode == 2) {   // 4FSK (gr_mod_4fsk.cpp:96-101): pack_k_bits(2) -> map{0,1,3,2}, one symbol index per input bit, no differential coding
-        uint8_t* ring2 = P.sym.p + (size_t)b * (P.sym.mask + 1u);
-        for (uint32_t i = lo; i < hi; ++i) {
-            uint32_t reg = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) reg |= sbit((int64_t)i - k) << k;
-            const uint32_t c0 = __builtin_popcount(reg & 109u) & 1u, c1 = __builtin_popcount(reg & 79u) & 1u;
-            ring2[(uint32_t)(P.s0 + i) & P.sym.mask] = (uint8_t)map4[(c0 << 1) | c1];
+                    for (uint32_t u = 0; u < 4; ++u) pk |= ((((c0 >> (t + u)) & 1u) << 1) | ((g >> (t + u)) & 1u)) << (8u * u);
+                    *reinterpret_cast<uint32_t*>(ring + ((uint32_t)(P.s0 + i0 + t) & P.sym.mask)) = pk;
+                }
+            } else {
+                for (uint32_t t = 0; t < nv; t += 2) {
+                    const uint32_t pk = ((c0 >> t) & 1u) | (((c1 >> t) & 1u) << 8) | (((c0 >> (t + 1)) & 1u) << 16) | (((c1 >> (t + 1)) & 1u) << 24);
+                    *reinterpret_cast<uint32_t*>(ring + ((uint32_t)(P.s0 + 2ull * (i0 + t)) & P.sym.mask)) = pk;
+                }
+            }
         }
-        if (lane == 0 && nbits) {
-            uint32_t enc = 0;
-            for (int k = 0; k < 6; ++k) enc |= sbit((int64_t)nbits - 1 - k) << k;
-            st.sr = sr_end; st.enc = enc;
-            P.st[b] = st;
-        }
+        if (lane == 0 && nbits) { st.sr = sr_end; st.enc = enc_state(); P.st[b] = st; }
         return;
     }
-    if (P.mode == 1) {   // FSK family: the two coded bits of every input bit go to the ring as they are (chunks_to_symbols later)
-        uint8_t* ring1 = P.sym.p + (size_t)b * (P.sym.mask + 1u);
-        for (uint32_t i = lo; i < hi; ++i) {
-            uint32_t reg = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) reg |= sbit((int64_t)i - k) << k;
-            ring1[(uint32_t)(P.s0 + 2ull * i) & P.sym.mask] = (uint8_t)(__builtin_popcount(reg & 109u) & 1u);
-            ring1[(uint32_t)(P.s0 + 2ull * i + 1) & P.sym.mask] = (uint8_t)(__builtin_popcount(reg & 79u) & 1u);
-        }
-        if (lane == 0 && nbits) {
-            uint32_t enc = 0;
-            for (int k = 0; k < 6; ++k) enc |= sbit((int64_t)nbits - 1 - k) << k;
-            st.sr = sr_end; st.enc = enc;
-            P.st[b] = st;
-        }
-        return;
+    // QPSK: diff_encoder_bb(4): y[n] = (x[n] + y[n-1]) mod 4, x = map{0,1,3,2}[2 c0 + c1] = 2 c0 + (c0 ^ c1)
+    uint32_t local = 0;                                          // sum of the slice's symbols
+    for (uint32_t w = 0; w < nw; ++w) {
+        const uint32_t nv = valid_bits(w);
+        if (!nv) break;
+        uint32_t c0, c1;
+        coded(w, c0, c1);
+        const uint32_t vm = nv >= 32u ? 0xffffffffu : ((1u << nv) - 1u);
+        local += 2u * (uint32_t)__builtin_popcount(c0 & vm) + (uint32_t)__builtin_popcount((c0 ^ c1) & vm);
     }
-    // diff_encoder_bb(4): y[n] = (x[n] + y[n-1]) mod 4  ->  exclusive wave scan of the slice sums
-    uint32_t incl = local;
+    local &= 3u;
+    uint32_t incl = local;                                       // exclusive wave scan of the slice sums
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = __shfl_up(incl, off, 64);
         if (lane >= off) incl = (incl + o) & 3u;
     }
     uint32_t run = (st.prev + incl - local) & 3u;                // symbol before this lane's slice
-    uint8_t* ring = P.sym.p + (size_t)b * (P.sym.mask + 1u);
-    for (uint32_t i = lo; i < hi; ++i) {
-        uint32_t reg = 0;
+    for (uint32_t w = 0; w < nw; ++w) {
+        const uint32_t nv = valid_bits(w);
+        if (!nv) break;
+        uint32_t c0, c1;
+        coded(w, c0, c1);
+        const uint32_t g = c0 ^ c1, i0 = (uint32_t)lane * L + 32u * w;
+        for (uint32_t t = 0; t < nv; t += 4) {
+            uint32_t pk = 0;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) reg |= sbit((int64_t)i - k) << k;
-        const uint32_t c0 = __builtin_popcount(reg & 109u) & 1u, c1 = __builtin_popcount(reg & 79u) & 1u;
-        run = (run + map4[(c0 << 1) | c1]) & 3u;
-        ring[(uint32_t)(P.s0 + i) & P.sym.mask] = (uint8_t)run;
+            for (uint32_t u = 0; u < 4; ++u) {
+                run = (run + ((((c0 >> (t + u)) & 1u) << 1) | ((g >> (t + u)) & 1u))) & 3u;
+                pk |= run << (8u * u);
+            }
+            *reinterpret_cast<uint32_t*>(ring + ((uint32_t)(P.s0 + i0 + t) & P.sym.mask)) = pk;
+        }
     }
     const uint32_t prev_end = __shfl(run, (int)last_lane, 64);
-    if (lane == 0 && nbits) {
-        uint32_t enc = 0;
-        for (int k = 0; k < 6; ++k) enc |= sbit((int64_t)nbits - 1 - k) << k;
-        st.sr = sr_end; st.enc = enc; st.prev = prev_end;
-        P.st[b] = st;
-    }
+    if (lane == 0 && nbits) { st.sr = sr_end; st.enc = enc_state(); st.prev = prev_end; P.st[b] = st; }
 }
 
 void launch_tx_qpsk_bits(const TxBitsParams& p, int batch, hipStream_t s)
 {
     if (!p.nbytes) return;
-    const size_t lds = ((size_t)p.nbytes * 8 + 31) / 32 * 4 + 16;
+    const size_t lds = (size_t)64 * (p.L >> 5) * 4 + 16;
+    if (lds > 64 * 1024 && dyn_lds_limit(reinterpret_cast<const void*>(k_tx_qpsk_bits), (int)lds) != hipSuccess) return;
     hipLaunchKernelGGL(k_tx_qpsk_bits, dim3(batch), dim3(64), lds, s, p);
 }
 

@@ -84,8 +84,8 @@ struct qrl_mod {
     }
 };
 
-// zero-input transition of scrambler_bb(0x8A, -, 7) applied L times, as 8 column masks
-static void lfsr_power(uint32_t L, uint8_t cols[8])
+// zero-input transition of scrambler_bb(0x8A, -, 7) applied L, 2 L, 4 L .. 32 L times, as 8 column masks each (the powers by squaring)
+static void lfsr_powers(uint32_t L, uint8_t pow[6][8])
 {
     for (int k = 0; k < 8; ++k) {
         uint32_t sr = 1u << k;
@@ -93,8 +93,14 @@ static void lfsr_power(uint32_t L, uint8_t cols[8])
             const uint32_t nb = (uint32_t)__builtin_parity(sr & 0x8Au);
             sr = (sr >> 1) | (nb << 7);
         }
-        cols[k] = (uint8_t)sr;
+        pow[0][k] = (uint8_t)sr;
     }
+    for (int d = 1; d < 6; ++d)
+        for (int k = 0; k < 8; ++k) {                  // column k of A^2 = A applied to column k of A
+            uint32_t r = 0;
+            for (int j = 0; j < 8; ++j) if ((pow[d - 1][k] >> j) & 1u) r ^= pow[d - 1][j];
+            pow[d][k] = (uint8_t)r;
+        }
 }
 
 extern "C" {
@@ -371,7 +377,7 @@ int qrl_mod_process(qrl_mod* m, const uint8_t* bytes, size_t stride, size_t nbyt
     TxBitsParams p{};
     p.bytes = bytes; p.stride = stride; p.nbytes = (uint32_t)nbytes;
     p.L = ((nbits + 63) / 64 + 31) / 32 * 32;
-    lfsr_power(p.L, p.tl_cols);
+    lfsr_powers(p.L, p.tl_pow);
     p.st = m->st; p.sym = RingB{m->sym, m->sym_mask}; p.s0 = m->nsym;
     p.mode = m->fsk4 ? 2 : (m->fam == qrl_mod::F_FSK || m->bpsk || m->dsss) ? 1 : 0;
     launch_tx_qpsk_bits(p, B, m->stream);
