@@ -22,13 +22,16 @@ namespace qrl {
 // workgroups with a 16-sample window and <= 96 registers were tried so that the kernel could slip in beside the front end of
 // the next call in overlapped mode: the recursion itself got slower -- 2.5 instead of 1.7 ms -- and the overlap no better.)
 // Two geometries (template parameters FLL_TH threads per workgroup, FLL_CH samples per stream and LDS window, powers of two):
-//   256 x 128  the stand-alone form: 4 waves per workgroup (64 streams x 4 lanes, one wave per SIMD), 68 KB of LDS;
+//   256 x 32   the default form: 4 waves per workgroup (64 streams x 4 lanes, one wave per SIMD), 17 KB of LDS (68 KB with the 128-sample
+//              window of rounds 2-3);
 //   64 x 16    the SLIM form of the overlapped mode: single-wave workgroups with 3 KB of LDS and <= 216 VGPRs, which the dispatcher can
 //              place on a CU whose LDS and wave slots are otherwise full of front-end workgroups (k_decim_pm leaves 16 KB of LDS and
 //              224 VGPRs per SIMD): the recursion of call k then runs UNDER the front end of call k + 1 instead of behind it.
 
 #ifndef QRL_FLL_CH
-#define QRL_FLL_CH 128   // samples per stream and LDS window of the stand-alone geometry (64 streams x QRL_FLL_CH x 8 bytes of LDS)
+#define QRL_FLL_CH 32    // samples per stream and LDS window of the 4-wave geometry (64 streams x QRL_FLL_CH x 8 bytes of LDS).  128 until round 4;
+                         // with the symbol synchroniser no longer starved (r04) the 17 KB window is worth 1.1 % of a C1 step, same-box A/B x 2:
+                         // 8.15 against 8.24 ms (16 samples: 8.24).  Results do not depend on it.
 #endif
 template <int CTRL> __device__ __forceinline__ float dpp_quad(float v)
 {
