@@ -92,6 +92,7 @@ chan_cluster::~chan_cluster()
     if (d_front) qrl_chan_destroy(d_front);
     if (d_tail) qrl_chan_destroy(d_tail);
     if (d_xs) { (void)hipStreamSynchronize(static_cast<hipStream_t>(d_xs)); (void)hipStreamDestroy(static_cast<hipStream_t>(d_xs)); }
+    if (d_ev) (void)hipEventDestroy(static_cast<hipEvent_t>(d_ev));
     for (int k = 0; k < 2; ++k) { if (d_send[k]) (void)hipFree(d_send[k]); if (d_recv[k]) (void)hipFree(d_recv[k]); }
 }
 void chan_cluster::channelize(const float* iq, size_t stride, size_t n)
@@ -105,7 +106,13 @@ void chan_cluster::channelize(const float* iq, size_t stride, size_t n)
 void chan_cluster::exchange()
 {
     chk(qrl_chan_stream_wait(d_front, d_xs), "qrl_chan_stream_wait");    // the collective runs behind the channelizer ...
-    chk(qrl_chan_stream_wait(d_tail, d_xs), "qrl_chan_stream_wait");     // ... and recv[cur] is free once the per-channel chains queued so far have consumed it
+    // ... and recv[cur] is free once the per-channel handle has COPIED it into its rings: that is the first kernel process_channels puts
+    // on that handle's own stream, so an event there is enough.  (qrl_chan_stream_wait on the handle also waits for its symbol-sync
+    // stream: the exchange of step k then started behind the symbol synchroniser of step k - 1 and the whole step ran serially,
+    // 5.7 instead of 3.x ms at one rank -- round 4, tools/prof_timeline.py on bench.py --config c4 --cluster.)
+    if (!d_ev) { hipEvent_t e; hchk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); d_ev = e; }
+    hchk(hipEventRecord(static_cast<hipEvent_t>(d_ev), static_cast<hipStream_t>(qrl_chan_stream(d_tail))), "hipEventRecord");
+    hchk(hipStreamWaitEvent(static_cast<hipStream_t>(d_xs), static_cast<hipEvent_t>(d_ev), 0), "hipStreamWaitEvent");
     d_ex.all_to_all(d_send[d_cur], d_recv[d_cur], (size_t)d_bl * d_per * d_n1max * 2 * sizeof(float), d_xs);
 }
 void chan_cluster::process_channels(int16_t* out, size_t out_cap, uint32_t* counts)

@@ -91,6 +91,7 @@ private:
     int d_M, d_bl, d_per; size_t d_n1max, d_n1 = 0;
     float *d_send[2] = {nullptr, nullptr}, *d_recv[2] = {nullptr, nullptr};
     void* d_xs = nullptr;                           // hipStream_t of the exchange
+    void* d_ev = nullptr;                           // hipEvent_t: the per-channel handle's own stream at the time of an exchange
     unsigned d_k = 0; int d_cur = 0;
 };
 
