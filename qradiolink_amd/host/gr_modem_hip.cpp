@@ -138,6 +138,7 @@ void gr_demod_base_hip::open()
     chk(qrl_demod_audio_cap(d_h, d_chunk, &d_acap), "qrl_demod_audio_cap");
     if (d_acap) chk(qrl_demod_set_squelch(d_h, (double)d_squelch), "qrl_demod_set_squelch");
     if (d_acap && d_mode == QRL_MODEM_AM5000) chk(qrl_demod_set_agc(d_h, d_agc_attack, d_agc_decay), "qrl_demod_set_agc");
+    if (d_acap && d_ctcss != 0.0f && (d_mode == QRL_MODEM_NBFM2500 || d_mode == QRL_MODEM_NBFM5000)) chk(qrl_demod_set_ctcss(d_h, d_ctcss), "qrl_demod_set_ctcss");   // the reference's instances keep their tone across mode changes
     const size_t N = (size_t)d_n;
     // side outputs on the copy stream: rssi_block behind port 0, rx_fft_c on the device-rate IQ (gr_demod_base.cpp:166,185,199-200)
     chk(qrl_rssi_create(d_rt.ctx(), d_n, d_rssi_cal, d_copy, &d_rssi), "qrl_rssi_create");
@@ -366,6 +367,12 @@ void gr_demod_base_hip::set_squelch(int value)   // gr_demod_base.cpp:1186-1199
     std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     d_squelch = value;
     if (d_h && d_acap) chk(qrl_demod_set_squelch(d_h, (double)value), "qrl_demod_set_squelch");
+}
+void gr_demod_base_hip::set_ctcss(float value)   // gr_demod_base.cpp:1212-1218 -> gr_demod_nbfm::set_ctcss on both NBFM instances (gr_demod_nbfm.cpp:97-123)
+{
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
+    d_ctcss = value;
+    if (d_h && d_acap && (d_mode == QRL_MODEM_NBFM2500 || d_mode == QRL_MODEM_NBFM5000)) chk(qrl_demod_set_ctcss(d_h, value), "qrl_demod_set_ctcss");
 }
 void gr_demod_base_hip::set_agc_attack(float value)   // :1428-1448
 {

@@ -68,6 +68,7 @@ public:
     // analogue voice modes (NBFM2500 / NBFM5000 / AM5000 / WBFM): port 1 = audio at 8 ksps (gr_demod_base::getAudio :968-976; caller deletes)
     std::vector<float>* getAudio(int stream = 0);
     void set_squelch(int value);                               // gr_demod_base::set_squelch, dB
+    void set_ctcss(float value);                               // gr_demod_base::set_ctcss (src/gr/gr_demod_base.cpp:1212-1218): the NBFM chains' tone squelch, 0 = off
     void set_agc_attack(float value);                          // gr_demod_base::set_agc_attack / set_agc_decay (AM)
     void set_agc_decay(float value);
     // side outputs (gr_demod_base.cpp:199-200, 185; :978-986, 1105-1113, 1227-1237, 1413-1418)
@@ -96,6 +97,7 @@ private:
     int d_n, d_rate, d_mode = -1; double d_offset; size_t d_chunk;
     qrl_demod* d_h = nullptr;
     qrl_rssi* d_rssi = nullptr; qrl_fft* d_fft = nullptr; bool d_rssi_on = false, d_fft_on = false; float d_rssi_cal = 0.0f; unsigned d_fftsize = 32768;
+    float d_ctcss = 0.0f;
     bool d_scope_on = false; size_t d_scap = 0; unsigned d_window = 8096; std::vector<std::vector<gr_complex>> d_boxs;   // scope tap mailboxes
     qrl_framesync* d_fs[2] = {nullptr, nullptr}; bool d_want_fs = false, d_keep_bits = false; size_t d_frcap = 0;   // device frame synchronisers of bits A / B
     std::vector<std::vector<frame_record>> d_boxf[2];
