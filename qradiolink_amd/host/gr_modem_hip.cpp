@@ -63,6 +63,7 @@ bool modem_two_branches(int m)   // gr_modem.cpp:1048-1058
 struct gr_demod_base_hip::slot {
     gr_complex* h_iq = nullptr;                           // pinned [streams][chunk]
     float* d_iq = nullptr;                                // device [streams][chunk] cf32
+    bool const_copied = true;
     float *d_filt = nullptr, *d_const = nullptr; uint8_t *d_a = nullptr, *d_b = nullptr, *d_dmo = nullptr; uint32_t *d_cnt = nullptr, *d_dmocnt = nullptr;
     gr_complex* h_const = nullptr; uint8_t *h_a = nullptr, *h_b = nullptr, *h_dmo = nullptr; uint32_t *h_cnt = nullptr, *h_dmocnt = nullptr;   // pinned
     float *d_rssi = nullptr, *h_rssi = nullptr; bool rssi_valid = false;   // latest rssi_block value per stream (device / pinned)
@@ -232,12 +233,18 @@ void gr_demod_base_hip::work(const gr_complex* const* iq, size_t n)
     if (!d_h) throw std::runtime_error("gr_demod_base_hip::work before set_mode");
     if (n == 0) return;
     if (n > d_chunk || (n & 1)) throw std::invalid_argument("gr_demod_base_hip::work: n must be even and <= max_chunk");
+    if (!d_demod_on && !d_fft_on) return;                        // _demod_valve closed and nobody else listens: the samples are dropped
     const int cur = (int)(d_calls & 1);
     slot& sl = *d_slot[cur];
     // slot `cur` was last used by call k - 2, which work(k - 1) has harvested: its buffers are free
     for (int s = 0; s < d_n; ++s) std::memcpy(sl.h_iq + (size_t)s * d_chunk, iq[s], n * sizeof(gr_complex));
     hipStream_t hs = static_cast<hipStream_t>(qrl_demod_stream(d_h)), cs = static_cast<hipStream_t>(d_copy);
     hchk(hipMemcpyAsync(sl.d_iq, sl.h_iq, (size_t)d_n * d_chunk * sizeof(gr_complex), hipMemcpyHostToDevice, hs), "H2D");
+    if (!d_demod_on) {                                           // _demod_valve closed (gr_demod_base.cpp:1150-1153): only the spectrum tap, which sits in front of it
+        chk(qrl_fft_process(d_fft, sl.d_iq, d_chunk, n), "qrl_fft_process");
+        hchk(hipStreamSynchronize(hs), "hipStreamSynchronize");  // (the slot's host buffer is reused by the call after next; no harvest belongs to this call)
+        return;
+    }
     if (d_mode == QRL_MODEM_DMR) chk(qrl_demod_set_dmo_output(d_h, sl.d_dmo, kDmoCap, sl.d_dmocnt), "qrl_demod_set_dmo_output");
     sl.scoped = d_scope_on;
     chk(qrl_demod_set_time_domain_output(d_h, d_scope_on ? sl.d_scope : nullptr, d_scap, d_scope_on ? sl.d_scnt : nullptr), "qrl_demod_set_time_domain_output");
@@ -270,7 +277,8 @@ void gr_demod_base_hip::work(const gr_complex* const* iq, size_t n)
         hchk(hipMemcpyAsync(sl.h_a, sl.d_a, N * d_bcap, hipMemcpyDeviceToHost, cs), "D2H");
         hchk(hipMemcpyAsync(sl.h_b, sl.d_b, N * d_bcap, hipMemcpyDeviceToHost, cs), "D2H");
     }
-    hchk(hipMemcpyAsync(sl.h_const, sl.d_const, N * d_ccap * sizeof(gr_complex), hipMemcpyDeviceToHost, cs), "D2H");
+    sl.const_copied = d_const_on;
+    if (d_const_on) hchk(hipMemcpyAsync(sl.h_const, sl.d_const, N * d_ccap * sizeof(gr_complex), hipMemcpyDeviceToHost, cs), "D2H");
     if (d_mode == QRL_MODEM_DMR) {
         hchk(hipMemcpyAsync(sl.h_dmocnt, sl.d_dmocnt, N * sizeof(uint32_t), hipMemcpyDeviceToHost, cs), "D2H");
         hchk(hipMemcpyAsync(sl.h_dmo, sl.d_dmo, N * kDmoCap * QRL_DMO_RECORD_BYTES, hipMemcpyDeviceToHost, cs), "D2H");
@@ -328,7 +336,7 @@ void gr_demod_base_hip::harvest(int which)
                 pos += 8 + padded;
             }
         }
-        if (d_boxc[s].size() <= 256) d_boxc[s].insert(d_boxc[s].end(), sl.h_const + (size_t)s * d_ccap, sl.h_const + (size_t)s * d_ccap + c[1]);
+        if (sl.const_copied && d_boxc[s].size() <= 256) d_boxc[s].insert(d_boxc[s].end(), sl.h_const + (size_t)s * d_ccap, sl.h_const + (size_t)s * d_ccap + c[1]);
         if (d_mode == QRL_MODEM_DMR) {
             if (sl.h_dmocnt[s] > kDmoCap) d_dmo_dropped += sl.h_dmocnt[s] - kDmoCap;   // more bursts in one call than the record buffer holds
             for (uint32_t i = 0; i < sl.h_dmocnt[s] && i < kDmoCap; ++i) {

@@ -68,6 +68,10 @@ public:
     // analogue voice modes (NBFM2500 / NBFM5000 / AM5000 / WBFM): port 1 = audio at 8 ksps (gr_demod_base::getAudio :968-976; caller deletes)
     std::vector<float>* getAudio(int stream = 0);
     void set_squelch(int value);                               // gr_demod_base::set_squelch, dB
+    // the two valves in front of / behind the demodulator (gr::blocks::copy with set_enabled, gr_demod_base.cpp:50-53,1100-1103,1150-1153).
+    // Here the constellation valve starts OPEN (the reference's GUI opens it before it reads; a closed valve saves the device-to-host copy of port 1).
+    void enable_gui_const(bool value) { std::lock_guard<std::recursive_mutex> hg(d_hmutex); d_const_on = value; }
+    void enable_demodulator(bool value) { std::lock_guard<std::recursive_mutex> hg(d_hmutex); d_demod_on = value; }   // closed: samples are dropped in front of the demodulator (its state does not advance); the spectrum tap still sees them
     void set_ctcss(float value);                               // gr_demod_base::set_ctcss (src/gr/gr_demod_base.cpp:1212-1218): the NBFM chains' tone squelch, 0 = off
     void set_agc_attack(float value);                          // gr_demod_base::set_agc_attack / set_agc_decay (AM)
     void set_agc_decay(float value);
@@ -97,7 +101,7 @@ private:
     int d_n, d_rate, d_mode = -1; double d_offset; size_t d_chunk;
     qrl_demod* d_h = nullptr;
     qrl_rssi* d_rssi = nullptr; qrl_fft* d_fft = nullptr; bool d_rssi_on = false, d_fft_on = false; float d_rssi_cal = 0.0f; unsigned d_fftsize = 32768;
-    float d_ctcss = 0.0f;
+    float d_ctcss = 0.0f; bool d_const_on = true, d_demod_on = true;
     bool d_scope_on = false; size_t d_scap = 0; unsigned d_window = 8096; std::vector<std::vector<gr_complex>> d_boxs;   // scope tap mailboxes
     qrl_framesync* d_fs[2] = {nullptr, nullptr}; bool d_want_fs = false, d_keep_bits = false; size_t d_frcap = 0;   // device frame synchronisers of bits A / B
     std::vector<std::vector<frame_record>> d_boxf[2];
