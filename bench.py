@@ -224,6 +224,13 @@ def timed_loop(fn, sync, args, torch, dev, world, marks=None):
 
 
 C4_BYTES = 8.0 + 64 * 24000 * 2 / 1.6e6 + 64 * 4800 * 2 / 1.6e6   # input cf32 + int16 FM samples + unpacked dibits, per wideband sample
+F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector (packed) = f32 matrix peak
+# algorithmic flop of the C4 contract per WIDEBAND sample (a real x complex MAC = 4 flop, a real MAC = 2):
+#   channelizer: 35-tap branch FIR 140 + the 64-point DFT as the contract's direct sum with the conjugate-mirrored twiddle table 256
+#   per 24 ksps channel sample (x 64 channels x 24000 / 1.6e6 = 0.96 per wideband sample): 24/25 resampler 35 taps 140, channel filter 33 taps
+#   132, RRC 125 real taps 250, two discriminators + quantiser + |f|^4 sums ~ 40
+C4_FLOP_PFB = 140.0 + 256.0
+C4_FLOP_TAIL = (140.0 + 132.0 + 250.0 + 40.0) * 64 * 24000 / 1.6e6
 
 
 def source_id():
@@ -256,12 +263,22 @@ def pmc_traffic(name, kernel, default_shape=True):
         return None, None
 
 
-def roofline_obj(kernel, kms, launches, bytes_per_launch, bytes_per_sample, note=None, name=None, default_shape=True):
+def whole_step_obj(bytes_per_step, ms_per_step):
+    """The same algorithmic bytes over the WHOLE step (every kernel of the chain, as timed by the bench loop) instead of the dominant
+    kernel's own duration: printed beside `frac` on every line (hygiene)."""
+    ach = bytes_per_step / (ms_per_step * 1e-3) / 1e9 if ms_per_step > 0 else 0.0
+    return dict(achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBPS, 4), ms_per_step=round(ms_per_step, 3),
+                note="algorithmic bytes of one step / ms_per_step / 8 TB/s: the whole chain, not the dominant kernel alone")
+
+
+def roofline_obj(kernel, kms, launches, bytes_per_launch, bytes_per_sample, note=None, name=None, default_shape=True, ms_per_step=None):
     ach = bytes_per_launch / (kms / max(launches, 1) * 1e-3) / 1e9 if kms > 0 else 0.0
     traffic, src = pmc_traffic(name, kernel, default_shape) if name else (None, None)
     d = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic,
              traffic_source=src, kernel=kernel, kernel_ms=round(kms / max(launches, 1), 4), launches=launches,
              algorithmic_bytes_per_launch=bytes_per_launch, algorithmic_bytes_per_sample=bytes_per_sample)
+    if ms_per_step:
+        d["whole_step"] = whole_step_obj(bytes_per_launch, ms_per_step)
     if note:
         d["note"] = note
     return d
@@ -372,7 +389,15 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, c
     prof.profile(True)
     marks = StepMarks(torch, [x for hnd in handles for x in hnd.internal_streams], enabled=not args.no_marks)
     dt = timed_loop(step, sync, args, torch, dev, world, marks)
-    kms, launches, kname = prof.profile_read()
+    per_kernel = None
+    if world == 1 and not args.cluster:
+        # every kernel of the call, HIP events on the stream it runs on (the warm-up calls are profiled too: same kernels, same shape)
+        pk = prof.profile_read_kernels()
+        _, _, kname = prof.profile_read()
+        per_kernel = {(kname if k == "channelizer" else k): round(ms / max(cnt, 1), 4) for k, ms, cnt in pk if cnt}
+        kms, launches = pk[0][1], pk[0][2]
+    else:
+        kms, launches, kname = prof.profile_read()
     launches_timed = args.steps
     kms = kms * launches_timed / max(launches, 1)          # (the warm-up calls were profiled too: same kernel, same shape)
     prof.profile(False)
@@ -393,10 +418,36 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, c
                                        "the channel streams to their owners (%d bytes per link and step), per-channel chains on the owner" % (B // world, link_bytes))
                                       if (world > 1 or args.cluster) else "single GPU",
                        "bytes_per_link_per_step": link_bytes},
-            "roofline": roofline_obj(kname, kms, launches_timed, b_kernel * n * C4_BYTES, round(C4_BYTES, 3),
-                                     "k_pfb_chan64 reads the wideband input once and writes the 64 channel rings; whole chain: %.1f GB/s of algorithmic bytes"
-                                     % (B * n * C4_BYTES * args.steps / dt / 1e9), name="c4", default_shape=not (args.batch or args.nsamp)),
             "step_spread_ms": marks.spread()}
+    ms_step = dt / args.steps * 1e3
+    if per_kernel:
+        # the dominant kernel = the longest of the call (k_chan_tail since round 4); `frac` = the WHOLE chain's algorithmic bytes over the whole step
+        # (VERDICT r4 #1a), the per-kernel figures beside it; C4 is bound by f32 instructions, not by HBM: the flop roofline says how far from THAT roof
+        dom = max((k for k in per_kernel if not k.startswith("k_symsync")), key=lambda k: per_kernel[k])
+        abytes = b_kernel * n * C4_BYTES
+        ws = whole_step_obj(abytes, ms_step)
+        traffic, src = pmc_traffic("c4", dom, not (args.batch or args.nsamp))
+        flop = (C4_FLOP_PFB + C4_FLOP_TAIL) * b_kernel * n
+        line["roofline"] = dict(
+            bound="f32 instruction issue (VALU + matrix pipe); hbm figures for reference", achieved=ws["achieved"], peak=HBM_PEAK_GBPS, unit="GB/s", frac=ws["frac"],
+            traffic=traffic, traffic_source=src, kernel=dom, kernel_ms=per_kernel[dom], launches=launches_timed,
+            algorithmic_bytes_per_launch=abytes, algorithmic_bytes_per_sample=round(C4_BYTES, 3),
+            kernels_ms=per_kernel,
+            kernel_fracs={k: round(abytes / (v * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) for k, v in per_kernel.items() if v > 0},
+            whole_step=ws,
+            flops=dict(bound="f32", achieved=round(flop / (ms_step * 1e-3) / 1e12, 2), peak=F32_PEAK_TFLOPS, unit="TFLOP/s",
+                       frac=round(flop / (ms_step * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4),
+                       algorithmic_flop_per_wideband_sample=round(C4_FLOP_PFB + C4_FLOP_TAIL, 1),
+                       channelizer_flop_per_sample=C4_FLOP_PFB, per_channel_chain_flop_per_sample=round(C4_FLOP_TAIL, 1),
+                       by_kernel={k: round((C4_FLOP_PFB if "pfb" in k else C4_FLOP_TAIL) * b_kernel * n / (v * 1e-3) / 1e12, 2)
+                                  for k, v in per_kernel.items() if v > 0 and not k.startswith("k_symsync")},
+                       note="flop of the arithmetic contract (oracle) per wideband sample x samples / step time / 157.3 TFLOP/s; by_kernel: that kernel's flop / its own duration"),
+            note="frac = whole chain over the whole step (the kernels of consecutive calls overlap on three streams); kernel = the longest kernel of a call, "
+                 "kernel_fracs = the chain's algorithmic bytes over each kernel's own duration (HIP events on its stream, beside whatever shares the chip)")
+    else:
+        line["roofline"] = roofline_obj(kname, kms, launches_timed, b_kernel * n * C4_BYTES, round(C4_BYTES, 3),
+                                        "the channelizer reads the wideband input once and writes the 64 channel rings; whole chain: %.1f GB/s of algorithmic bytes"
+                                        % (B * n * C4_BYTES * args.steps / dt / 1e9), name="c4", default_shape=not (args.batch or args.nsamp), ms_per_step=ms_step)
     if parity:
         line["parity_check"] = parity
     if world == 1 and with_form2 and not args.cluster:
@@ -697,7 +748,8 @@ def main():
     extra_ok = not args.no_extra
     ncores = min(os.cpu_count() or 1, 16)
     if args.config in ("c4", "c5"):
-        line = (run_c4 if args.config == "c4" else run_c5)(args, torch, q, ctx, dev, rank, world, check=extra_ok or args.check)
+        kw = dict(with_form2=extra_ok) if args.config == "c4" else {}
+        line = (run_c4 if args.config == "c4" else run_c5)(args, torch, q, ctx, dev, rank, world, check=extra_ok or args.check, **kw)
         if extra_ok and rank == 0 and world == 1:
             line["cpu_baseline"] = (cpu_baseline_c4 if args.config == "c4" else cpu_baseline_c5)(ncores)
         finish(line)
@@ -730,7 +782,8 @@ def main():
             d = dict(bound="hbm", achieved=round(r["achieved_gbps"], 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                      frac=round(r["achieved_gbps"] / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=src, kernel=r["kernel"],
                      kernel_ms=round(r["kernel_ms"], 4), launches=r["launches"],
-                     algorithmic_bytes_per_launch=r["bytes_per_launch"], algorithmic_bytes_per_sample=r["bytes_per_sample"])
+                     algorithmic_bytes_per_launch=r["bytes_per_launch"], algorithmic_bytes_per_sample=r["bytes_per_sample"],
+                     whole_step=whole_step_obj(r["bytes_per_launch"], r["ms_per_step"]))
             if ovl and r["name"] == "c1":
                 d["serial_mode"] = dict(kernel_ms=round(ovl["kernel_ms"], 4), achieved=round(ovl["achieved_gbps"], 1),
                                         frac=round(ovl["achieved_gbps"] / HBM_PEAK_GBPS, 4), ms_per_step=round(ovl["ms_per_step"], 3),

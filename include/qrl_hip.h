@@ -261,8 +261,13 @@ int qrl_chan_reset(qrl_chan* c);
  * channelizer kernel also for the 64-channel geometry, = 2 the tiled 64-channel kernel of round 3 (0, the default: the streaming
  * kernel k_pfb_stream64 when the rows are 16-byte aligned); QRL_CHAN_OPT_LEGACY_TAIL = 1 runs the per-channel chain as separate kernels
  * instead of the fused feed-forward kernel -- only before the first samples of a stream or after qrl_chan_reset (QRL_ERR_STATE
- * otherwise: the fused kernel does not fill the intermediate rings the separate kernels take their history from). */
-enum { QRL_CHAN_OPT_LEGACY_PFB = 1, QRL_CHAN_OPT_LEGACY_TAIL = 2 };
+ * otherwise: the fused kernel does not fill the intermediate rings the separate kernels take their history from).
+ * QRL_CHAN_OPT_SERIAL_TAIL = 1 keeps the per-channel kernel of a call on the handle's stream, behind its channelizer and in front of the
+ * next one (rounds 1-4); 0, the default for a PFB-form handle that owns its stream: it runs on an internal stream BESIDE the channelizer
+ * of the next call (the channel ring holds two calls) -- int16 / RSSI outputs are then valid after qrl_chan_sync() or behind
+ * qrl_chan_stream_wait(), like the 4FSK outputs.  A handle created on the caller's hip_stream always runs the serial order.
+ * (environment: QRL_CHAN_SERIAL_TAIL=1 at qrl_chan_create, for A/B runs of unmodified callers) */
+enum { QRL_CHAN_OPT_LEGACY_PFB = 1, QRL_CHAN_OPT_LEGACY_TAIL = 2, QRL_CHAN_OPT_SERIAL_TAIL = 3 };
 int qrl_chan_set_option(qrl_chan* c, int option, int value);
 int qrl_chan_set_level(qrl_chan* c, float level);   /* _level_control multiply_const_ff, gr_demod_mmdvm_multi2.cpp:84 */
 /* replaces: gr_demod_mmdvm_multi2::calibrate_rssi / gr_demod_mmdvm::calibrate_rssi -> rssi_tag_block::calibrate_rssi
@@ -280,7 +285,7 @@ int qrl_chan_set_rssi_output(qrl_chan* c, float* rssi, size_t cap, uint32_t* cou
  * produced by each following qrl_chan_process call, s = b*channel_count + ch.  bits == NULL switches the tail off.
  * The symbol synchroniser runs on an internal stream of the handle (it overlaps the next call's channelizer): bits, constellation
  * and counts of a call are valid after qrl_chan_sync() or, on the device, behind qrl_chan_stream_wait() -- synchronising only the
- * cfg.hip_stream the caller passed in is NOT enough for these three outputs (it is for the int16 / RSSI outputs). */
+ * cfg.hip_stream the caller passed in is NOT enough for these three outputs (it is for the int16 / RSSI outputs of such a handle). */
 int qrl_chan_set_4fsk_output(qrl_chan* c, uint8_t* bits, size_t bits_cap, float* constellation, size_t constellation_cap, uint32_t* counts);
 size_t qrl_chan_out_cap(const qrl_chan* c, size_t n);   /* int16 samples per channel a call with n inputs can produce */
 /* replaces one scheduler pass of the multi-carrier graph: iq[b*stride + i] device cf32, n a multiple of num_channels;
@@ -305,11 +310,15 @@ int qrl_chan_wait_for(qrl_chan* c, void* hip_stream);
  * caller chains its own copies / collectives (the all-to-all of a multi-GPU job) behind a call without a host synchronisation. */
 int qrl_chan_stream_wait(qrl_chan* c, void* hip_stream);
 void* qrl_chan_stream(qrl_chan* c);   /* hipStream_t the handle enqueues on */
-int qrl_chan_internal_streams(qrl_chan* c, void* out[2]);   /* profiling aid, as qrl_demod_internal_streams: out[0] the handle's stream, out[1] the symbol-sync stream (or NULL) */
+int qrl_chan_internal_streams(qrl_chan* c, void* out[3]);   /* profiling aid, as qrl_demod_internal_streams: out[0] the handle's stream, out[1] the symbol-sync stream (or NULL), out[2] the per-channel kernel's stream (or NULL) */
 /* like qrl_demod_profile / qrl_demod_profile_read: HIP events on the handle's stream around the kernel(s) that read the caller's
  * wideband IQ (k_pfb_chan; forms 1 / 2: the per-channel decimator launches of a call, summed) -- bench.py's roofline leg */
 int qrl_chan_profile(qrl_chan* c, int enable);
 int qrl_chan_profile_read(qrl_chan* c, double* kernel_ms, uint64_t* launches, const char** kernel_name);
+/* the same for the three kernels of a C4 call, each timed with HIP events on the stream it is launched on: ms[0] / launches[0] the
+ * kernel(s) qrl_chan_profile_read reports (channelizer), [1] the fused per-channel kernel k_chan_tail, [2] the symbol synchroniser
+ * k_symsync_ff (sums over the profiled calls; a duration includes the time a kernel shares the chip with the others of the step) */
+int qrl_chan_profile_read_kernels(qrl_chan* c, double ms[3], uint64_t launches[3]);
 
 /* ---- multi-carrier MMDVM transmitter (reference src/gr/gr_mod_mmdvm_multi2.cpp:30-128) -------------------------------------
  * make_gr_mod_mmdvm_multi2(burst_timer, num_channels, channel_separation, use_tdma, sps, samp_rate, carrier_freq,

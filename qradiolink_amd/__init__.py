@@ -26,7 +26,7 @@ MODEM_USB2500, MODEM_LSB2500 = 11, 12
 MODEM_M17 = 40
 MODEM_DMR = 41
 OPT_OVERLAP, OPT_UNFUSED_DEC2, OPT_FLL_SLIM, OPT_GROUPED = 1, 2, 3, 4
-CHAN_OPT_LEGACY_PFB, CHAN_OPT_LEGACY_TAIL = 1, 2
+CHAN_OPT_LEGACY_PFB, CHAN_OPT_LEGACY_TAIL, CHAN_OPT_SERIAL_TAIL = 1, 2, 3
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECTANGULAR, WIN_BLACKMAN_HARRIS = 0, 1, 2, 3, 5
 
 
@@ -182,6 +182,7 @@ def load_library():
     lib.qrl_chan_wait_for.argtypes = [vp, vp]
     lib.qrl_chan_profile.argtypes = [vp, C.c_int]
     lib.qrl_chan_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_char_p)]
+    lib.qrl_chan_profile_read_kernels.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.qrl_synth_create.argtypes = [vp, C.POINTER(_SynthConfig), C.POINTER(vp)]
     lib.qrl_synth_destroy.argtypes = [vp]
     lib.qrl_synth_reset.argtypes = [vp]
@@ -222,7 +223,7 @@ EXPORTED_SYMBOLS = [
     "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_internal_streams", "qrl_chan_internal_streams", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
-    "qrl_mod_samples_per_byte", "qrl_mod_samples_per_block", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_set_option", "qrl_chan_channelize", "qrl_chan_process_channels", "qrl_chan_wait_for", "qrl_chan_stream_wait", "qrl_chan_stream", "qrl_chan_profile", "qrl_chan_profile_read", "qrl_debug_decim_prof", "qrl_debug_decim_prof_enable", "qrl_chan_create",
+    "qrl_mod_samples_per_byte", "qrl_mod_samples_per_block", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_set_option", "qrl_chan_channelize", "qrl_chan_process_channels", "qrl_chan_wait_for", "qrl_chan_stream_wait", "qrl_chan_stream", "qrl_chan_profile", "qrl_chan_profile_read", "qrl_chan_profile_read_kernels", "qrl_debug_decim_prof", "qrl_debug_decim_prof_enable", "qrl_chan_create",
     "qrl_chan_destroy", "qrl_chan_reset", "qrl_chan_set_level", "qrl_chan_calibrate_rssi", "qrl_chan_set_rssi_output", "qrl_chan_set_4fsk_output", "qrl_chan_out_cap", "qrl_chan_process", "qrl_chan_sync",
     "qrl_synth_create", "qrl_synth_destroy", "qrl_synth_reset", "qrl_synth_set_bb_gain", "qrl_synth_add_zero_runs", "qrl_synth_out_cap", "qrl_synth_process",
     "qrl_synth_sync",
@@ -546,6 +547,12 @@ class Channelizer:
         _check(self.lib.qrl_chan_profile_read(self.h, C.byref(ms), C.byref(n), C.byref(name)), "qrl_chan_profile_read")
         return ms.value, n.value, name.value.decode()
 
+    def profile_read_kernels(self):
+        """[(kernel, total ms, launches)] of the channelizer, the fused per-channel kernel and the symbol synchroniser (qrl_chan_profile_read_kernels)"""
+        ms, n = (C.c_double * 3)(), (C.c_uint64 * 3)()
+        _check(self.lib.qrl_chan_profile_read_kernels(self.h, ms, n), "qrl_chan_profile_read_kernels")
+        return [(k, ms[i], n[i]) for i, k in enumerate(("channelizer", "k_chan_tail", "k_symsync_ff"))]
+
     def stream_wait(self, hip_stream):
         """the given HIP stream (int handle, e.g. torch.cuda.current_stream().cuda_stream) waits on the device for this handle's work so far"""
         _check(self.lib.qrl_chan_stream_wait(self.h, C.c_void_p(hip_stream)), "qrl_chan_stream_wait")
@@ -553,7 +560,7 @@ class Channelizer:
     @property
     def internal_streams(self):
         """the HIP streams (ints) a call's stages are launched on: profiling aid (qrl_chan_internal_streams)"""
-        arr = (C.c_void_p * 2)()
+        arr = (C.c_void_p * 3)()
         _check(self.lib.qrl_chan_internal_streams(self.h, arr), "qrl_chan_internal_streams")
         return list(dict.fromkeys(int(x) for x in arr if x))
 

@@ -59,8 +59,15 @@ struct qrl_chan {
     // channelizer and the fused per-channel kernel of the NEXT call; ring r6 holds two calls, ev_tail[slot] guards its reuse
     hipStream_t tail = nullptr; hipEvent_t ev_ff = nullptr, ev_tail[2] = {nullptr, nullptr}; bool tail_valid[2] = {false, false}; uint64_t call_no = 0;
     uint32_t m6 = 0;
+    // round 5: the fused per-channel kernel of call k runs on its own stream (`mid`) BESIDE the channelizer of call k + 1 (the PFB form on a
+    // handle-owned stream only: with a caller's stream the int16 / RSSI outputs stay ordered on that stream).  The channel ring r1 holds two
+    // calls + the tail's look-back; ev_pfb orders the tail behind its channelizer, ev_mid[slot] the channelizer of call k + 2 behind the tail
+    // of call k (the last reader of the ring items it overwrites).
+    hipStream_t mid = nullptr; hipEvent_t ev_pfb = nullptr, ev_mid[2] = {nullptr, nullptr}, ev_user3 = nullptr; bool mid_valid[2] = {false, false};
+    bool opt_serial_tail = false;
     int opt_legacy_pfb = 0, opt_legacy_tail = 0;   // qrl_chan_set_option
     bool profiling = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;   // qrl_chan_profile: the HBM-facing kernel(s) of each call
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_tail, prof_ss;                      // ... the fused per-channel kernel and the symbol synchroniser (qrl_chan_profile_read_kernels)
     bool xlat = false; int xl_D = 10, xl_nt = 0, xl_S = 0; Buf<float> xl_taps; Buf<float2> xl_rot_lo; std::vector<uint64_t> xl_inc;   // form 1
     bool single = false; int rs_I = 24, rs_D = 25;   // single: gr_demod_mmdvm (one carrier at 250 ksps, 12/125 resampler, no channelizer)
     float* rssi_out = nullptr; size_t rssi_cap = 0; uint32_t* rssi_counts = nullptr;
@@ -73,11 +80,15 @@ struct qrl_chan {
         return hipMemcpy(ss.p, s.data(), s.size() * sizeof(SymSyncState), hipMemcpyHostToDevice) == hipSuccess ? QRL_OK : QRL_ERR_HIP;
     }
     size_t zeroed = 0;
-    ~qrl_chan() { for (auto& e : prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    ~qrl_chan() { for (auto* v : {&prof_events, &prof_tail, &prof_ss}) for (auto& e : *v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
                   if (ev_user2) (void)hipEventDestroy(ev_user2);
                   if (ev_ext) (void)hipEventDestroy(ev_ext);
                   if (ev_ff) (void)hipEventDestroy(ev_ff);
                   for (auto e : ev_tail) if (e) (void)hipEventDestroy(e);
+                  for (auto e : ev_mid) if (e) (void)hipEventDestroy(e);
+                  if (ev_pfb) (void)hipEventDestroy(ev_pfb);
+                  if (ev_user3) (void)hipEventDestroy(ev_user3);
+                  if (mid) (void)hipStreamDestroy(mid);
                   if (tail) (void)hipStreamDestroy(tail);
                   if (ev_user) (void)hipEventDestroy(ev_user); if (own_stream && stream) (void)hipStreamDestroy(stream); }
     int reset_state() {
@@ -89,6 +100,8 @@ struct qrl_chan {
         if (hipMemset(r3.p, 0, S * (m2 + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
         if (hipMemset(r4.p, 0, S * (m2 + 1) * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
         n_in = n1 = n2 = 0; flip = false;
+        mid_valid[0] = mid_valid[1] = false;
+        if (!ss.p) call_no = 0;
         if (ss.p) {
             if (hipMemset(r5.p, 0, S * (m2 + 1) * sizeof(float)) != hipSuccess || hipMemset(r6.p, 0, S * (m6 + 1) * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
             tail_valid[0] = tail_valid[1] = false; call_no = 0;
@@ -212,20 +225,33 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     const size_t S = (size_t)c.batch * c.channel_count;
     const size_t max1 = c.max_chunk / (h->xlat2 ? h->xl_D : M) + 2, max2 = max1 * h->rs_I / h->rs_D + 2;
     // (the fused per-channel kernel recomputes the halo of its first tile from the channel ring: chan_tail_lookback() items in front of a call)
-    h->m1 = (h->single || h->xlat) ? 63 : pow2ge(max1 + h->rs_Jp + 64 + chan_tail_lookback()) - 1;   // the single-carrier chain reads the caller's IQ directly
+    // (PFB form on a handle-owned stream: TWO calls, the channelizer of call k + 1 writes while the per-channel kernel of call k still reads)
+    const bool can_overlap = h->own_stream && !h->single && !h->xlat && !h->xlat2 && !h->tail_only && ct_ok;
+    h->m1 = (h->single || h->xlat) ? 63 : pow2ge((can_overlap ? 2 : 1) * max1 + h->rs_Jp + 64 + chan_tail_lookback()) - 1;   // the single-carrier chain reads the caller's IQ directly
     h->m2 = pow2ge(max2 + h->filt_nt + 64 + 300) - 1;   // + one rssi_tag_block window
     if ((r = h->hist_a.alloc((size_t)c.batch * h->hist_len)) || (r = h->hist_b.alloc((size_t)c.batch * h->hist_len)) ||
         (r = h->r1.alloc(S * (h->m1 + 1))) || (r = h->r2.alloc(S * (h->m2 + 1))) || (r = h->r3.alloc(S * (h->m2 + 1))) ||
         (r = h->r4.alloc(S * (h->m2 + 1))))
         return qrl_set_error(r, "channelizer buffers");
+    if (can_overlap) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIPCHK(hipStreamCreateWithPriority(&h->mid, hipStreamNonBlocking, lo));   // a priority of its own (never the hardware queue of the main or the symbol-sync stream), and BELOW the channelizer's:
+                                                                                  // the persistent channelizer workgroups of call k + 1 are placed as the tail of call k drains
+        HIPCHK(hipEventCreateWithFlags(&h->ev_pfb, hipEventDisableTiming));
+        for (auto& e : h->ev_mid) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        const char* env = std::getenv("QRL_CHAN_SERIAL_TAIL");
+        h->opt_serial_tail = env && env[0] == '1';
+    }
     *outp = h.release();
     return QRL_OK;
 }
-void qrl_chan_destroy(qrl_chan* h) { if (h) { (void)hipStreamSynchronize(h->stream); if (h->tail) (void)hipStreamSynchronize(h->tail); delete h; } }
+void qrl_chan_destroy(qrl_chan* h) { if (h) { (void)hipStreamSynchronize(h->stream); if (h->mid) (void)hipStreamSynchronize(h->mid); if (h->tail) (void)hipStreamSynchronize(h->tail); delete h; } }
 int qrl_chan_reset(qrl_chan* h)
 {
     if (!h) return QRL_ERR_ARG;
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->mid) HIPCHK(hipStreamSynchronize(h->mid));
     if (h->tail) HIPCHK(hipStreamSynchronize(h->tail));
     return h->reset_state();
 }
@@ -237,6 +263,14 @@ int qrl_chan_set_option(qrl_chan* h, int option, int value)
         // the fused per-channel kernel does not fill the intermediate rings the separate kernels read their history from: only before the first samples
         if (h->n_in != 0 || h->n2 != 0) return qrl_set_error(QRL_ERR_STATE, "QRL_CHAN_OPT_LEGACY_TAIL: only before the first call (or after qrl_chan_reset)");
         h->opt_legacy_tail = value != 0;
+    }
+    else if (option == QRL_CHAN_OPT_SERIAL_TAIL) {
+        // every stream drained: the switch needs no ordering between the two forms
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->mid) HIPCHK(hipStreamSynchronize(h->mid));
+        if (h->tail) HIPCHK(hipStreamSynchronize(h->tail));
+        h->mid_valid[0] = h->mid_valid[1] = false;
+        h->opt_serial_tail = value != 0;
     }
     else return qrl_set_error(QRL_ERR_ARG, "unknown channelizer option");
     return QRL_OK;
@@ -274,6 +308,7 @@ int qrl_chan_set_4fsk_output(qrl_chan* h, uint8_t* bits, size_t bits_cap, float*
         }
         clock_loop_gains((float)(2 * M_PI / 100.0f), 1.0f, 0.2869f, h->ss_alpha, h->ss_beta);  // :70-71
         HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->mid) HIPCHK(hipStreamSynchronize(h->mid));
         HIPCHK(hipStreamSynchronize(h->tail));
         if ((r = h->init_ss())) return r;
     }
@@ -323,8 +358,16 @@ static int chan_process_impl(qrl_chan* h, const float* iq, size_t stride, size_t
         // form 3: the call's input ARE the channel samples (rows = channel streams): into the channel ring, then the per-channel chain
         launch_ring_load(in, stride, RingC{h->r1.p, h->m1}, h->n1, (uint32_t)n, S, h->stream);
     }
-    if (h->rssi_out && h->rssi_counts) HIPCHK(hipMemsetAsync(h->rssi_counts, 0, (size_t)S * sizeof(uint32_t), h->stream));
-    if (h->tail && h->tail_valid[h->call_no & 1]) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_tail[h->call_no & 1], 0));   // symbol sync of call k - 2 done: its half of ring r6 is free
+    // PFB form and form 2: the whole per-channel feed-forward chain in one kernel (kernels_chan_tail.hip)
+    const bool fused = !h->single && !h->xlat && !h->opt_legacy_tail && h->ct_a.p && (!h->fsk_bits || h->ct_e.p) &&
+                       chan_tail_supported(h->rs_I, h->rs_D, h->rs_Jp, h->filt_nt, h->fsk_bits ? h->symf_nt : 0);
+    // ts = the stream of the per-channel kernels: `mid` when they overlap the next call's channelizer, the handle's stream otherwise
+    const bool use_mid = h->mid && !h->opt_serial_tail && fused && !chan_out && !h->xlat2 && !h->tail_only;
+    const hipStream_t ts = use_mid ? h->mid : h->stream;
+    const int slot2 = (int)(h->call_no & 1);
+    if (use_mid && h->mid_valid[slot2]) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_mid[slot2], 0));   // per-channel kernel of call k - 2 done: the ring items this call's channelizer overwrites are free
+    if (h->rssi_out && h->rssi_counts) HIPCHK(hipMemsetAsync(h->rssi_counts, 0, (size_t)S * sizeof(uint32_t), ts));
+    if (h->tail && h->tail_valid[slot2]) HIPCHK(hipStreamWaitEvent(ts, h->ev_tail[slot2], 0));   // symbol sync of call k - 2 done: its half of ring r6 is free
     ChanParams p{};
     p.in = in; p.in_stride = stride; p.n0 = h->n_in; p.n = (uint32_t)n; p.hist = hist_old; p.hist_len = h->hist_len;
     p.out = RingC{h->r1.p, h->m1}; p.m0 = h->n1; p.m_count = (uint32_t)(n1_1 - h->n1);
@@ -365,9 +408,7 @@ static int chan_process_impl(qrl_chan* h, const float* iq, size_t stride, size_t
         }
         if (ev1) { HIPCHK(hipEventRecord(ev1, h->stream)); h->prof_events.emplace_back(ev0, ev1); }
     }
-    // PFB form and form 2: the whole per-channel feed-forward chain in one kernel (kernels_chan_tail.hip)
-    const bool fused = !h->single && !h->xlat && !h->opt_legacy_tail && h->ct_a.p && (!h->fsk_bits || h->ct_e.p) &&
-                       chan_tail_supported(h->rs_I, h->rs_D, h->rs_Jp, h->filt_nt, h->fsk_bits ? h->symf_nt : 0);
+    if (use_mid) { HIPCHK(hipEventRecord(h->ev_pfb, h->stream)); HIPCHK(hipStreamWaitEvent(ts, h->ev_pfb, 0)); }
     ResampParams rp{};
     if (h->xlat) {
     } else if (h->single) { rp.in = in; rp.in_stride = stride; rp.hist = hist_old; rp.hist_len = h->hist_len; rp.n0 = h->n_in; rp.n = (uint32_t)n; }
@@ -390,7 +431,11 @@ static int chan_process_impl(qrl_chan* h, const float* iq, size_t stride, size_t
         if (h->fsk_bits) tp.out_sym = RingF{h->r6.p, h->m6};
         if (h->rssi_out) { tp.rssi = h->rssi_out; tp.rssi_cap = h->rssi_cap; tp.rssi_counts = h->rssi_counts; tp.rssi_cal = h->rssi_cal;
                            tp.tag0 = h->n2 / 300; tp.ntags = (uint32_t)(n2_1 / 300 - h->n2 / 300); }
-        launch_chan_tail(tp, S, h->stream);
+        hipEvent_t et0 = nullptr, et1 = nullptr;
+        if (h->profiling) { HIPCHK(hipEventCreate(&et0)); HIPCHK(hipEventCreate(&et1)); HIPCHK(hipEventRecord(et0, ts)); }
+        launch_chan_tail(tp, S, ts);
+        if (et1) { HIPCHK(hipEventRecord(et1, ts)); h->prof_tail.emplace_back(et0, et1); }
+        if (use_mid) { HIPCHK(hipEventRecord(h->ev_mid[slot2], ts)); h->mid_valid[slot2] = true; }
     } else {
         FirCcfParams fp{};
         fp.in = RingC{h->r2.p, h->m2}; fp.out = RingC{h->r3.p, h->m2}; fp.q0 = h->n2; fp.count = c2; fp.taps = h->filt_taps.p; fp.nt = h->filt_nt;
@@ -412,16 +457,19 @@ static int chan_process_impl(qrl_chan* h, const float* iq, size_t stride, size_t
     {
         if (h->fsk_bits) {   // gr_demod_dmr.cpp:70-105: symbol_sync_ff -> level -> phase modulator -> slicer -> dibits, on the RRC output ring
             // on the tail stream, behind this call's feed-forward kernels; the ring slot it reads is rewritten two calls later
-            HIPCHK(hipEventRecord(h->ev_ff, h->stream));
+            HIPCHK(hipEventRecord(h->ev_ff, ts));
             HIPCHK(hipStreamWaitEvent(h->tail, h->ev_ff, 0));
             HIPCHK(hipMemsetAsync(h->fsk_counts, 0, (size_t)S * 4 * sizeof(uint32_t), h->tail));
             SymSyncParams s{};
             s.in = RingF{h->r6.p, h->m6}; s.avail = n2_1; s.soft = RingB{h->soft_dummy.p, 63}; s.st = h->ss.p; s.mmse = h->mmse.p;
             s.alpha = h->ss_alpha; s.beta = h->ss_beta; s.maxp = 5.0f + 0.06f; s.minp = 5.0f - 0.06f;
-            s.ted = 0; s.soft_mul = 128.0f; s.soft_add = 128.0f; s.slicer = 1; s.tail = 1; s.tail_scale = 0.9f; s.slim = 1;   // gr_demod_dmr.cpp:73 _level_control (tail_scale); slim = 16-sample windows, 96-thread workgroups (k_symsync_ff<16, 96>)
+            s.ted = 0; s.soft_mul = 128.0f; s.soft_add = 128.0f; s.slicer = 1; s.tail = 1; s.tail_scale = 0.9f; s.slim = 2;   // gr_demod_dmr.cpp:73 _level_control (tail_scale); slim = 16-sample windows, 96-thread workgroups (k_symsync_ff<16, 96>)
             s.bits = h->fsk_bits; s.bits_cap = h->fsk_bits_cap;
             s.port = reinterpret_cast<float2*>(h->fsk_const); s.port_cap = h->fsk_const ? h->fsk_const_cap : 0; s.counts = h->fsk_counts;
+            hipEvent_t es0 = nullptr, es1 = nullptr;
+            if (h->profiling) { HIPCHK(hipEventCreate(&es0)); HIPCHK(hipEventCreate(&es1)); HIPCHK(hipEventRecord(es0, h->tail)); }
             launch_symsync_ff(s, S, h->tail);
+            if (es1) { HIPCHK(hipEventRecord(es1, h->tail)); h->prof_ss.emplace_back(es0, es1); }
             const int slot = (int)(h->call_no & 1);
             HIPCHK(hipEventRecord(h->ev_tail[slot], h->tail));
             h->tail_valid[slot] = true;
@@ -444,6 +492,11 @@ int qrl_chan_stream_wait(qrl_chan* h, void* hip_stream)
         HIPCHK(hipEventRecord(h->ev_user2, h->tail));
         HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), h->ev_user2, 0));
     }
+    if (h->mid) {
+        if (!h->ev_user3) HIPCHK(hipEventCreateWithFlags(&h->ev_user3, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(h->ev_user3, h->mid));
+        HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), h->ev_user3, 0));
+    }
     return QRL_OK;
 }
 int qrl_chan_wait_for(qrl_chan* h, void* hip_stream)
@@ -452,13 +505,14 @@ int qrl_chan_wait_for(qrl_chan* h, void* hip_stream)
     if (!h->ev_ext) HIPCHK(hipEventCreateWithFlags(&h->ev_ext, hipEventDisableTiming));
     HIPCHK(hipEventRecord(h->ev_ext, static_cast<hipStream_t>(hip_stream)));
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ext, 0));
+    if (h->mid) HIPCHK(hipStreamWaitEvent(h->mid, h->ev_ext, 0));   // (the int16 / RSSI outputs are written on this stream)
     return QRL_OK;
 }
 void* qrl_chan_stream(qrl_chan* h) { return h ? h->stream : nullptr; }
-int qrl_chan_internal_streams(qrl_chan* h, void* out[2])
+int qrl_chan_internal_streams(qrl_chan* h, void* out[3])
 {
     if (!h || !out) return QRL_ERR_ARG;
-    out[0] = h->stream; out[1] = h->tail;
+    out[0] = h->stream; out[1] = h->tail; out[2] = h->mid;
     return QRL_OK;
 }
 int qrl_chan_profile(qrl_chan* h, int enable) { if (!h) return QRL_ERR_ARG; h->profiling = enable != 0; return QRL_OK; }
@@ -477,12 +531,34 @@ int qrl_chan_profile_read(qrl_chan* h, double* kernel_ms, uint64_t* launches, co
     if (launches) *launches = h->prof_events.size();
     if (kernel_name) *kernel_name = (h->xlat || h->xlat2) ? "k_decim_mfma (one launch per channel, summed)" : h->single ? "k_resamp" : (h->opt_legacy_pfb == 0 && h->M == 64) ? "k_pfb_stream64" : h->opt_legacy_pfb == 2 ? "k_pfb_chan64" : "k_pfb_chan";
     h->prof_events.clear();
+    for (auto* v : {&h->prof_tail, &h->prof_ss}) { for (auto& e : *v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } v->clear(); }
+    return QRL_OK;
+}
+int qrl_chan_profile_read_kernels(qrl_chan* h, double ms[3], uint64_t launches[3])
+{
+    if (!h || !ms || !launches) return QRL_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->mid) HIPCHK(hipStreamSynchronize(h->mid));
+    if (h->tail) HIPCHK(hipStreamSynchronize(h->tail));
+    std::vector<std::pair<hipEvent_t, hipEvent_t>>* sets[3] = {&h->prof_events, &h->prof_tail, &h->prof_ss};
+    for (int k = 0; k < 3; ++k) {
+        double total = 0;
+        for (auto& e : *sets[k]) {
+            float t = 0;
+            HIPCHK(hipEventElapsedTime(&t, e.first, e.second));
+            total += t;
+            (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+        }
+        ms[k] = total; launches[k] = sets[k]->size();
+        sets[k]->clear();
+    }
     return QRL_OK;
 }
 int qrl_chan_sync(qrl_chan* h)
 {
     if (!h) return QRL_ERR_ARG;
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->mid) HIPCHK(hipStreamSynchronize(h->mid));
     if (h->tail) HIPCHK(hipStreamSynchronize(h->tail));
     return QRL_OK;
 }

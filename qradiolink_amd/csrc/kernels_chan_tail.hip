@@ -43,7 +43,15 @@ constexpr int CT_HA = 171;          // outputs in front of the tile the resample
 constexpr int CT_HB = 132;          // ... the channel filter / discriminator produce (>= 124 + 7 + 1)
 constexpr int CT_W = 180;           // row pitch of the de-interleaved images: >= 24 * 59 / 8, and (l & 7) W + (l >> 3), l < 32, hits 32 different bank pairs (W = 4 x odd)
 constexpr int CT_NX = 25 * 59 + 34 + 2;   // input samples staged per tile
-constexpr int CT_SA = CT_JP + 7, CT_SB = CT_NF + 7, CT_SE = CT_NR + 7;   // window steps of the 8-output sliding filters (d = 7 .. -(nt - 1))
+constexpr int CT_SA = CT_JP + 7, CT_SB = CT_NF + 7;   // window steps of the 8-output sliding filters (d = 7 .. -(nt - 1))
+// stage E on the matrix pipe (round 5): the RRC as a Toeplitz product, v_mfma_f32_16x16x4_f32 = rows: 16 consecutive outputs, columns: 16 blocks
+// of 16 outputs, K: 4 sample offsets d (see the stage).  CT_EM matrix instructions cover d = 15 .. -(CT_NR - 1); the discriminator image is stored
+// item i at (i & 15) CT_DP + (i >> 4) so that "lane (kk, n) reads item 16 n + c - kk" spreads over the banks (CT_DP = 17 mod 32).
+constexpr int CT_EM = (CT_NR + 15 + 3) / 4;            // 35
+constexpr int CT_DP = 113;                             // >= (139 + 16 * 79 + 15) / 16 + 1 = 89 columns
+constexpr int CT_HE = 160;                             // padded tap table: hpad[j] = rrc[j - 15], j < 15 + 3 + 4 CT_EM
+typedef float f32x4_ct __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int ct_dpos(int i) { return (i & 15) * CT_DP + (i >> 4); }
 
 #ifdef QRL_CT_PROF
 // developer build (tools/chan_tail_variants.sh name -DQRL_CT_PROF): shader-clock ticks per phase, summed over every wave
@@ -71,10 +79,17 @@ __global__ __launch_bounds__(256, 4) void k_chan_tail(const ChanTailParams P)
 {
     __shared__ __align__(16) float2 xf[CT_NX > 8 * CT_W ? CT_NX : 8 * CT_W];   // staged input x (stage A), then the channel filter output f (B .. E)
     __shared__ __align__(16) float2 av[8 * CT_W];        // resampler output a
-    __shared__ __align__(16) float dv[8 * CT_W];         // symbol discriminator output d2
+    __shared__ __align__(16) float dv[16 * CT_DP];       // symbol discriminator output d2 (ct_dpos)
     __shared__ float T[257];
-    __shared__ __align__(16) float tA[3 * CT_SA * 8], tB[CT_SB * 8], tE[CT_SE * 8];   // [step][r] tap tables
+    __shared__ __align__(16) float tA[3 * CT_SA * 8], tB[CT_SB * 8];   // [step][r] tap tables
+    __shared__ __align__(16) float tE[CT_HE];            // RRC taps, 15 zeros in front (stage E)
+#ifdef QRL_CT_ROT
+    // wave ROLES rotate with the workgroup: stages A / B / E leave the last wave idle (and give it the RSSI sums) -- if wave i of every workgroup
+    // sits on SIMD i, a fixed role assignment idles one SIMD of the CU during those stages
+    const int tid = (int)((((threadIdx.x >> 6) + blockIdx.x + blockIdx.y) & 3u) << 6 | (threadIdx.x & 63u)), lane = tid & 63;
+#else
     const int tid = threadIdx.x, lane = tid & 63;
+#endif
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = blockIdx.y;
 #ifdef QRL_CT_PROF
@@ -87,8 +102,7 @@ __global__ __launch_bounds__(256, 4) void k_chan_tail(const ChanTailParams P)
     // step-major tap tables, laid out by the host (chan_tail_tables): straight 16-byte copies
     for (int k = tid; k < 3 * CT_SA * 2; k += 256) reinterpret_cast<float4*>(tA)[k] = reinterpret_cast<const float4*>(P.tab_a)[k];
     if (tid < CT_SB * 2) reinterpret_cast<float4*>(tB)[tid] = reinterpret_cast<const float4*>(P.tab_b)[tid];
-    if (P.out_sym.p)
-        for (int k = tid; k < CT_SE * 2; k += 256) reinterpret_cast<float4*>(tE)[k] = reinterpret_cast<const float4*>(P.tab_e)[k];
+    if (P.out_sym.p && tid < CT_HE) tE[tid] = P.tab_e[tid];
     CT_STAMP(0);
     for (int tt = 0; tt < ntile; ++tt) {
     const int64_t tile = tile_first + tt;
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(256, 4) void k_chan_tail(const ChanTailParams P)
             const float re = a.x * p.x + a.y * p.y;
             const float im = a.y * p.x - a.x * p.y;
             const float ang = fast_atan2f_lut(im, re, T);
-            if (i < NB) dv[ct_pos(i)] = P.gain2 * ang;
+            if (i < NB) dv[ct_dpos(i)] = P.gain2 * ang;
             if (i < NB && i >= e0) {   // |f|^4 of the tile's own items for the serial RSSI sums below, in item order (the resampler output `av` is dead since stage B: its memory holds them)
                 const float pwr = a.x * a.x + a.y * a.y;
                 pv[i - e0] = pwr * pwr;
@@ -211,6 +225,43 @@ __global__ __launch_bounds__(256, 4) void k_chan_tail(const ChanTailParams P)
     CT_STAMP(8);
     __syncthreads();
     CT_STAMP(9);
+    // ---- E: r[q] = sum_k rrc[k] d2[q - k] on the MATRIX pipe.  Output o = 16 n + i of the tile (item e0 + o of the d2 image): a Toeplitz product
+    //   Y[i][n] = sum_d A[i][d] B[d][n],  A[i][d] = rrc[i - d] (0 outside the filter),  B[d][n] = d2[e0 + 16 n + d],  d = 15 .. -124,
+    // four d per v_mfma_f32_16x16x4_f32 in DESCENDING order (slot kk of instruction m: d = 15 - 4 m - kk, tap index i - 15 + 4 m + kk): the
+    // instruction adds its four products to the accumulator one after the other with one rounding each (the pm contract of the front ends,
+    // DESIGN 2), so an output is the oracle's chain -- fmaf(rrc[k], d2[q - k], acc), k ascending from +0 -- bit for bit: a zero tap leaves the
+    // chain untouched.  One chain = 16 x 16 outputs x 125 taps in CT_EM = 35 matrix instructions (89 % of their MACs are taps); the 75 blocks of a
+    // tile are 5 chains: waves 0..2 take one each and waves 0 / 1 a second one, wave 3 the serial RSSI sums.  Per instruction two 4-byte LDS
+    // reads with immediate offsets (A: tE[i + kk + 4 m]; B: the item walks down by 4 = one row of four, a column every fourth step) and no VALU
+    // work -- the scalar-fma form of round 4 issued 1056 fmas per thread for 8 outputs and was 48 % of the kernel's VALU instructions.
+    auto e_chain = [&](int cg) {
+        const int n = 16 * cg + (lane & 15), kk = lane >> 4;
+        const int it0 = e0 + 16 * n + 15 - kk;                                    // item of instruction m = 0
+        int ob[4];                                                                // LDS index of item it0 - 4 j, minus the 8 columns the walk can go back
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ob[j] = ct_dpos(it0 - 4 * j) - 8;
+        const float* hp = tE + (lane & 15) + kk;
+        f32x4_ct acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < CT_EM; ++m) {
+            const float a = hp[4 * m];
+            const float b = dv[ob[m & 3] + 8 - (m >> 2)];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+        if (n < CT_T / 16) {
+            float* orow = P.out_sym.p + (size_t)row * (P.out_sym.mask + 1u);
+            const int64_t q4 = Q0 + 16 * n + 4 * kk;                              // lane holds outputs q4 .. q4 + 3 (rows 4 kk + r of column n)
+            if (q4 >= (int64_t)P.q0 && (uint64_t)(q4 + 3) < q_end)
+                *reinterpret_cast<float4*>(orow + ((uint32_t)q4 & P.out_sym.mask)) = make_float4(acc[0], acc[1], acc[2], acc[3]);   // q4 = 0 mod 4: inside one ring row
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t q = q4 + r;
+                    if (q >= (int64_t)P.q0 && (uint64_t)q < q_end) orow[(uint32_t)q & P.out_sym.mask] = acc[r];
+                }
+            }
+        }
+    };
     if (wv == 3) {
         // ---- C: rssi_tag_block, the four 300-item blocks of this tile: serial float sums, one lane per block
         if (lane < CT_T / 300 && P.rssi) {
@@ -233,45 +284,15 @@ __global__ __launch_bounds__(256, 4) void k_chan_tail(const ChanTailParams P)
                 if (t < P.rssi_cap) P.rssi[(size_t)row * P.rssi_cap + t] = db;
             }
         }
-    } else if (P.out_sym.p) {
-    // ---- E: r[q] = sum_k rrc[k] d2[q - k], thread g (waves 0..2): items i' = e8 + 8 g + r, e8 = e0 rounded down to 8
-    const int e8 = e0 & ~7;
-    if (tid < (NB - e8 + 7) / 8) {
-        const float4* tp = reinterpret_cast<const float4*>(tE);
-        const float* db_ = dv + (e8 >> 3) + tid;
-        // Sliding TAP window: output r at step s multiplies h[s - 7 + r], i.e. the eight taps of a step are the previous step's shifted
-        // by one -- a window of 16 registers (the previous block's eight taps + this block's eight, read as two 16-byte broadcasts out of
-        // row 8 b + 7 of the step-major table = h[8 b .. 8 b + 7]) serves eight steps.  LDS traffic per step: 4 + 4 bytes instead of
-        // 4 + 32 (the stage was bound by the LDS, 131 cycles per step); the arithmetic is the scalar fmaf chain it always was.
-        float acc[8], hw[16];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { acc[r] = 0.f; hw[r] = 0.f; }
-        auto block = [&](int b, int nsteps, bool have) {
-            float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f), h1 = h0;
-            if (have) { h0 = tp[2 * (8 * b + 7)]; h1 = tp[2 * (8 * b + 7) + 1]; }
-            hw[8] = h0.x; hw[9] = h0.y; hw[10] = h0.z; hw[11] = h0.w; hw[12] = h1.x; hw[13] = h1.y; hw[14] = h1.z; hw[15] = h1.w;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (u < nsteps) {
-                    const int d = 7 - (8 * b + u);
-                    const float x = db_[(d & 7) * CT_W + (d >> 3)];
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) acc[r] = fmaf(hw[u + r + 1], x, acc[r]);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) hw[r] = hw[8 + r];
-        };
-#pragma unroll 1
-        for (int b = 0; b < CT_SE / 8; ++b) block(b, 8, true);
-        if (CT_SE % 8) block(CT_SE / 8, CT_SE % 8, 8 * (CT_SE / 8) + 7 < CT_SE);
-        float* orow = P.out_sym.p + (size_t)row * (P.out_sym.mask + 1u);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int64_t q = qb + e8 + 8 * tid + r;
-            if (q >= (int64_t)P.q0 && (uint64_t)q < q_end && q >= Q0) orow[(uint32_t)q & P.out_sym.mask] = acc[r];
-        }
     }
+    if (P.out_sym.p) {
+        // chains of this wave: its own (wave 3 only when it has no RSSI sums to do), then chain 3 (wave 0, when wave 3 is busy) / chain 4 (wave 1)
+        const int first = (wv < 3 || !P.rssi) ? wv : 5, second = (wv == 0 && P.rssi) ? 3 : (wv == 1 ? 4 : 5);
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c) {
+            const int cg = c ? second : first;
+            if (cg < 5) e_chain(cg);
+        }
     }
     CT_STAMP(10);
     }   // tiles of this workgroup
@@ -302,7 +323,7 @@ void launch_chan_tail(const ChanTailParams& p, int streams, hipStream_t s)
     hipLaunchKernelGGL(k_chan_tail, dim3((uint32_t)((t_last - t_first + CT_TPW) / CT_TPW), streams), dim3(256), 0, s, p);
 }
 // step-major tap tables of k_chan_tail: which = 0: resampler [3 waves][42 steps][8] from the phase-major taps[24][35];
-// 1: channel filter [40][8]; 2: RRC [132][8].  Entry (step s, r) = h[r - (7 - s)], zero outside the filter.
+// 1: channel filter [40][8]; entry (step s, r) = h[r - (7 - s)], zero outside the filter.  2: RRC for stage E, hpad[160] (15 zeros, the taps, zeros).
 std::vector<float> chan_tail_tables(int which, const float* taps)
 {
     if (which == 0) {
@@ -315,7 +336,12 @@ std::vector<float> chan_tail_tables(int which, const float* taps)
                 }
         return t;
     }
-    const int nt = which == 1 ? CT_NF : CT_NR, ns = which == 1 ? CT_SB : CT_SE;
+    if (which == 2) {   // stage E (matrix pipe): hpad[j] = rrc[j - 15]
+        std::vector<float> t((size_t)CT_HE, 0.0f);
+        for (int k = 0; k < CT_NR; ++k) t[15 + k] = taps[k];
+        return t;
+    }
+    const int nt = CT_NF, ns = CT_SB;
     std::vector<float> t((size_t)ns * 8, 0.0f);
     for (int st = 0; st < ns; ++st)
         for (int r = 0; r < 8; ++r) {

@@ -33,6 +33,9 @@ namespace qrl {
                          // with the symbol synchroniser no longer starved (r04) the 17 KB window is worth 1.1 % of a C1 step, same-box A/B x 2:
                          // 8.15 against 8.24 ms (16 samples: 8.24).  Results do not depend on it.
 #endif
+#ifndef QRL_FLL_TH
+#define QRL_FLL_TH 256   // threads per workgroup of the default geometry (4 lanes per stream): 256 = one wave per SIMD and CU at 16 k streams
+#endif
 template <int CTRL> __device__ __forceinline__ float dpp_quad(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
@@ -164,9 +167,10 @@ void launch_fll(const FllParams& p, int batch, hipStream_t s)
         else            hipLaunchKernelGGL((k_fll<32, 64, 16>), grid, block, 0, s, p, batch);
         return;
     }
-    dim3 grid((batch + 63) / 64), block(256);
-    if (p.nt == 16) hipLaunchKernelGGL((k_fll<16, 256, QRL_FLL_CH>), grid, block, 0, s, p, batch);
-    else            hipLaunchKernelGGL((k_fll<32, 256, QRL_FLL_CH>), grid, block, 0, s, p, batch);
+    constexpr int TH = QRL_FLL_TH;
+    dim3 grid((batch + TH / 4 - 1) / (TH / 4)), block(TH);
+    if (p.nt == 16) hipLaunchKernelGGL((k_fll<16, TH, QRL_FLL_CH>), grid, block, 0, s, p, batch);
+    else            hipLaunchKernelGGL((k_fll<32, TH, QRL_FLL_CH>), grid, block, 0, s, p, batch);
 }
 
 // ------------------------------------------------------------------ symbol_sync_ff
@@ -379,8 +383,19 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
 
 size_t symsync_lds_bytes() { return SsGeo<32, 192>::lds_bytes(); }
 
+#ifndef QRL_CHAN_SS_NS
+#define QRL_CHAN_SS_NS 16
+#define QRL_CHAN_SS_W 96
+#endif
 void launch_symsync_ff(const SymSyncParams& p, int batch, hipStream_t s)
 {
+    if (p.slim == 2 && (QRL_CHAN_SS_NS != 16 || QRL_CHAN_SS_W != 96)) {   // the multi-carrier receiver's own geometry (QRL_CHAN_SS_NS streams per workgroup, QRL_CHAN_SS_W samples per window)
+        const auto k = k_symsync_ff<QRL_CHAN_SS_NS, QRL_CHAN_SS_W>;
+        const size_t lds = SsGeo<QRL_CHAN_SS_NS, QRL_CHAN_SS_W>::lds_bytes();
+        if (dyn_lds_limit(reinterpret_cast<const void*>(k), (int)lds) != hipSuccess) return;
+        hipLaunchKernelGGL(k, dim3((batch + QRL_CHAN_SS_NS - 1) / QRL_CHAN_SS_NS), dim3(256), lds, s, p, batch);
+        return;
+    }
     if (p.slim) {   // the multi-carrier receiver's geometry (see SsGeo)
         const auto k = k_symsync_ff<16, 96>;
         const size_t lds = SsGeo<16, 96>::lds_bytes();

@@ -530,3 +530,60 @@ def test_legacy_per_channel_kernels_still_bit_exact(qrl_ctx, chunk):
             assert np.array_equal(np.concatenate(got[b][c]), ref[c]), (b, c)
             assert np.allclose(np.concatenate(tags[b][c]), rref[c], rtol=0, atol=1e-4)
             assert np.array_equal(np.concatenate(dib[b][c]), dref[c]), (b, c)
+
+
+@pytest.mark.parametrize("serial", [0, 1])
+def test_channelizer_64_calls_queued_back_to_back_bit_exact(qrl_ctx, serial):
+    """Round 5: the per-channel kernel of call k runs on an internal stream beside the channelizer of call k + 1 (the channel ring
+    holds two calls).  Five calls are QUEUED without a synchronisation in between, every call with its own output buffers (through the
+    C ABI directly: the pointers are kernel arguments of the call that was given them), one qrl_chan_sync at the end -- int16, dibits
+    and RSSI tags of the concatenation must equal the oracle's; QRL_CHAN_OPT_SERIAL_TAIL = 1 (the order of rounds 1-4) as well."""
+    import ctypes as C
+    import torch
+    import qradiolink_amd as q
+    M = 64
+    cuts = [64 * 1500, 64 * 1500, 64 * 777, 64 * 1500, 64 * 1223]
+    n = sum(cuts)
+    iq = _wideband(M, n, seed=501, nstreams=2)
+    ch = q.Channelizer(qrl_ctx, M, batch=2, max_chunk=max(cuts))
+    ch.calibrate_rssi(1.5)
+    ch.enable_4fsk()
+    ch.set_option(q.CHAN_OPT_SERIAL_TAIL, serial)
+    assert len(ch.internal_streams) == 3
+    d = torch.from_numpy(iq).cuda()
+    lib = ch.lib
+    bufs = []
+    pos = 0
+    torch.cuda.synchronize()
+    for cut in cuts:
+        o = torch.zeros_like(ch.out); cn = torch.zeros_like(ch.counts)
+        r = torch.zeros_like(ch.rssi); rc = torch.zeros_like(ch.rssi_counts)
+        db = torch.zeros_like(ch.dibits); fc = torch.zeros_like(ch.fsk_counts)
+        torch.cuda.synchronize()
+        bufs.append((o, cn, r, rc, db, fc))
+    for cut, (o, cn, r, rc, db, fc) in zip(cuts, bufs):
+        assert lib.qrl_chan_set_rssi_output(ch.h, C.c_void_p(r.data_ptr()), ch.rssi_cap, C.c_void_p(rc.data_ptr())) == 0
+        assert lib.qrl_chan_set_4fsk_output(ch.h, C.c_void_p(db.data_ptr()), ch.fsk_cap, None, 0, C.c_void_p(fc.data_ptr())) == 0
+        x = d[:, pos:pos + cut]
+        assert lib.qrl_chan_process(ch.h, C.c_void_p(x.data_ptr()), x.stride(0), cut, C.c_void_p(o.data_ptr()), ch.cap, C.c_void_p(cn.data_ptr())) == 0
+        pos += cut
+    ch.sync()
+    got = [[[] for _ in range(M)] for _ in range(2)]
+    tags = [[[] for _ in range(M)] for _ in range(2)]
+    dib = [[[] for _ in range(M)] for _ in range(2)]
+    for (o, cn, r, rc, db, fc) in bufs:
+        o, cn, r, rc, db, fc = (t.cpu().numpy() for t in (o, cn, r, rc, db, fc))
+        for b in range(2):
+            for c in range(M):
+                got[b][c].append(o[b, c, :cn[b, c]].copy())
+                tags[b][c].append(r[b, c, :rc[b, c]].copy())
+                dib[b][c].append(db[b, c, :fc[b, c, 2]].copy())
+    ch.close()
+    for b in range(2):
+        ref, rref, dref = orc.demod_mmdvm_multi_full(iq[b], M, cal=1.5)
+        for c in range(M):
+            g = np.concatenate(got[b][c])
+            assert g.size == ref.shape[1] and np.array_equal(g, ref[c]), (serial, b, c)
+            tg = np.concatenate(tags[b][c])
+            assert tg.size == rref[c].size and np.allclose(tg, rref[c], rtol=0, atol=1e-4), (serial, b, c)
+            assert np.array_equal(np.concatenate(dib[b][c]), dref[c]), (serial, b, c)

@@ -6,6 +6,7 @@
 #   prof   <cfg> [bench.py args]         rocprofv3 --kernel-trace --stats of a short bench run, per-kernel table appended to OUT/kernel_trace_summary.md
 #   ab     <cfg> <kernel regex> <variant>...   same-box A/B: every variant library (build/libqrl_<v>.so; "base" = the in-tree one) twice,
 #                                        alternating, under the profiler; matching kernels + ms_per_step appended to OUT/ab.log
+#   abx    <cfg> <lib[,ENV=VAL...]>...   same-box A/B without the profiler: library variants and / or environment settings, twice, alternating -> OUT/abx.log
 #   pmc    <cfg> <COUNTER>               one rocprofv3 --pmc pass (kernel-trace only), summary appended to OUT/pmc_summary.txt
 #   alone  <name> <kprof.py args>        rocprofv3 --kernel-trace --stats of tools/kprof.py (one call at a time, a sync after every call: every kernel alone on
 #                                        the chip), per-kernel table appended to OUT/kernel_alone_summary.md
@@ -60,6 +61,25 @@ ab)
     rm -rf $O/p_$v
   done; done
   cat $O/ab.log ;;
+abx)
+  # same-box A/B WITHOUT the profiler: variant spec = lib[,ENV=VAL,...] (lib = base or build/libqrl_<lib>.so); ms_per_step + median step of every run
+  cfg=$1; shift
+  for rep in 1 2 ${QRL_AB_REPS:-}; do for spec in "$@"; do
+    v=${spec%%,*}; envs=$(echo "$spec" | tr ',' '\n' | tail -n +2 | tr '\n' ' ')
+    L=$PWD/build/libqrl_$v.so; [ $v = base ] && L=$PWD/qradiolink_amd/libqrl_hip.so
+    env QRL_LIB_PATH=$L $envs timeout 200 python bench.py --config $cfg --steps ${QRL_AB_STEPS:-20} --warmup 3 --no-extra ${QRL_AB_ARGS:-} > $O/runx.log 2>$O/runx.err
+    python - "$spec" $rep $O/runx.log >> $O/abx.log <<'P'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+    sp = d.get("step_spread_ms") or {}
+    r = d.get("roofline", {})
+    print("%-40s pass %s  ms/step %.3f  median %s  kernel %s %.3f ms" % (sys.argv[1], sys.argv[2], d["ms_per_step"], sp.get("median"), r.get("kernel"), r.get("kernel_ms") or 0))
+except Exception as e:
+    print(sys.argv[1], "FAILED", e)
+P
+  done; done
+  cat $O/abx.log ;;
 pmc)
   cfg=$1; cnt=$2; shift 2
   timeout 300 rocprofv3 --kernel-trace --pmc $cnt -d $O/pmc_${cfg}_$cnt -o $cnt --output-format csv -- python bench.py --config $cfg --steps 3 --warmup 1 --no-extra "$@" > $O/pmc_${cfg}_$cnt.log 2>&1
