@@ -372,6 +372,8 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, c
         # on the owner; ordering on the device (qrl_chan_stream_wait / qrl_chan_wait_for), no host synchronisation.  Per link and step:
         # (B / world) x (64 / world) x n / 64 cf32 items = 1 / world of a rank's input bytes.  (--cluster at N = 1: the same object
         # with a one-rank RCCL communicator -- what a one-GPU box can run of this path.)
+        if getattr(args, "cluster_copy", False):
+            os.environ["QRL_CLUSTER_COPY_AT_ONE_RANK"] = "1"
         Bl, n1 = B // world, n // M
         iq = torch.view_as_complex(torch.randn((Bl, n, 2), generator=g, device=dev, dtype=torch.float32) * 0.05)   # this rank's own inputs
         ex = sharding.Exchange.rccl(torch.distributed if world > 1 else None)
@@ -704,6 +706,7 @@ def main():
     ap.add_argument("--no-grouped", action="store_true", help="C5 only: QRL_OPT_GROUPED = 0 (three free-running streams instead of front end -> recursion || decoder)")
     ap.add_argument("--fll-slim", action="store_true", help="tuning, c1: QRL_OPT_FLL_SLIM = 1 (single-wave FLL workgroups)")
     ap.add_argument("--cluster", action="store_true", help="c4: drive the channel-sharded path (qrl_host::chan_cluster + RCCL all-to-all) also at N = 1")
+    ap.add_argument("--cluster-copy", action="store_true", help="c4 --cluster at N = 1: keep the one-rank ncclAllToAll (a 1 GB device copy per step that moves nothing; by default one rank reads the channelizer's output in place)")
     ap.add_argument("--no-marks", action="store_true", help="no per-step completion events (step_spread_ms = null)")
     ap.add_argument("--check", action="store_true", help="with --no-extra: still run the parity check against the oracle at the bench shape")
     ap.add_argument("--legacy-pfb", type=int, default=0, help="A/B, c4: QRL_CHAN_OPT_LEGACY_PFB (1 = general-M channelizer kernel, 2 = the tiled 64-channel kernel of round 3)")

@@ -301,7 +301,10 @@ int qrl_chan_sync(qrl_chan* c);
  *                              valid items per row.  The handle keeps the filter history; it must not be mixed with qrl_chan_process.
  *   qrl_chan_process_channels  (form 3 handle: `batch` = number of 25 ksps channel streams, num_channels ignored) the per-channel chain
  *                              of qrl_chan_process on chan_in[row * pitch + i], i < n1; outputs as qrl_chan_process with
- *                              channel_count = 1 (row index = stream index).
+ *                              channel_count = 1 (row index = stream index).  The per-channel kernel reads chan_in IN PLACE (no copy
+ *                              into the handle's rings; the handle keeps the ~1.6 k samples per row it needs of it for the next call):
+ *                              the buffer must stay untouched until the handle's stream has passed this call (an event recorded on
+ *                              qrl_chan_stream() after the call, or qrl_chan_sync).
  *   qrl_chan_wait_for          the handle's stream waits (on the device) for what the given stream has queued so far: the collective. */
 int qrl_chan_channelize(qrl_chan* c, const float* iq, size_t stride, size_t n, float* chan_out, size_t pitch, int groups);
 int qrl_chan_process_channels(qrl_chan* c, const float* chan_in, size_t pitch, size_t n1, int16_t* out, size_t out_cap, uint32_t* counts);

@@ -63,8 +63,10 @@ struct qrl_chan {
     // handle-owned stream only: with a caller's stream the int16 / RSSI outputs stay ordered on that stream).  The channel ring r1 holds two
     // calls + the tail's look-back; ev_pfb orders the tail behind its channelizer, ev_mid[slot] the channelizer of call k + 2 behind the tail
     // of call k (the last reader of the ring items it overwrites).
-    hipStream_t mid = nullptr; hipEvent_t ev_pfb = nullptr, ev_mid[2] = {nullptr, nullptr}, ev_user3 = nullptr; bool mid_valid[2] = {false, false};
+    hipStream_t mid = nullptr; hipEvent_t ev_pfb = nullptr, ev_mid[3] = {nullptr, nullptr, nullptr}, ev_user3 = nullptr; bool mid_valid[3] = {false, false, false};
+    int ring_calls = 3;   // calls the channel ring holds: the channelizer may run this many calls minus one ahead of the per-channel kernel
     bool opt_serial_tail = false;
+    bool mid_used = false, tail_used = false;   // anything ever enqueued there: qrl_chan_stream_wait leaves idle internal streams alone (a marker on an idle low-priority queue held the waiter back ~0.5 ms)
     int opt_legacy_pfb = 0, opt_legacy_tail = 0;   // qrl_chan_set_option
     bool profiling = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;   // qrl_chan_profile: the HBM-facing kernel(s) of each call
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_tail, prof_ss;                      // ... the fused per-channel kernel and the symbol synchroniser (qrl_chan_profile_read_kernels)
@@ -100,7 +102,7 @@ struct qrl_chan {
         if (hipMemset(r3.p, 0, S * (m2 + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
         if (hipMemset(r4.p, 0, S * (m2 + 1) * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
         n_in = n1 = n2 = 0; flip = false;
-        mid_valid[0] = mid_valid[1] = false;
+        mid_valid[0] = mid_valid[1] = mid_valid[2] = false;
         if (!ss.p) call_no = 0;
         if (ss.p) {
             if (hipMemset(r5.p, 0, S * (m2 + 1) * sizeof(float)) != hipSuccess || hipMemset(r6.p, 0, S * (m6 + 1) * sizeof(float)) != hipSuccess) return QRL_ERR_HIP;
@@ -222,12 +224,15 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     h->gain = h->single ? (float)(24000.0f / (2 * M_PI * 10000.0f))                               // gr_demod_mmdvm.cpp:41,48
                         : (float)(24000.0f / (2 * M_PI * 12500.0f));                              // gr_demod_mmdvm_multi2.cpp:80
     h->hist_len = (h->xlat || h->xlat2) ? (uint32_t)(h->xl_nt + h->xl_D) : h->single ? (uint32_t)(h->rs_Jp + h->rs_D + 2) : (uint32_t)(h->J * M);
+    // form 3: the history rows hold the channel samples the fused per-channel kernel re-reads in front of a call (its halo), one row per channel stream
+    if (h->tail_only) h->hist_len = (chan_tail_lookback() + 1u) & ~1u;
     const size_t S = (size_t)c.batch * c.channel_count;
     const size_t max1 = c.max_chunk / (h->xlat2 ? h->xl_D : M) + 2, max2 = max1 * h->rs_I / h->rs_D + 2;
     // (the fused per-channel kernel recomputes the halo of its first tile from the channel ring: chan_tail_lookback() items in front of a call)
     // (PFB form on a handle-owned stream: TWO calls, the channelizer of call k + 1 writes while the per-channel kernel of call k still reads)
     const bool can_overlap = h->own_stream && !h->single && !h->xlat && !h->xlat2 && !h->tail_only && ct_ok;
-    h->m1 = (h->single || h->xlat) ? 63 : pow2ge((can_overlap ? 2 : 1) * max1 + h->rs_Jp + 64 + chan_tail_lookback()) - 1;   // the single-carrier chain reads the caller's IQ directly
+    if (const char* e = std::getenv("QRL_CHAN_RING_CALLS")) { const int v = std::atoi(e); if (v == 2 || v == 3) h->ring_calls = v; }
+    h->m1 = (h->single || h->xlat) ? 63 : pow2ge((can_overlap ? h->ring_calls : 1) * max1 + h->rs_Jp + 64 + chan_tail_lookback()) - 1;   // the single-carrier chain reads the caller's IQ directly
     h->m2 = pow2ge(max2 + h->filt_nt + 64 + 300) - 1;   // + one rssi_tag_block window
     if ((r = h->hist_a.alloc((size_t)c.batch * h->hist_len)) || (r = h->hist_b.alloc((size_t)c.batch * h->hist_len)) ||
         (r = h->r1.alloc(S * (h->m1 + 1))) || (r = h->r2.alloc(S * (h->m2 + 1))) || (r = h->r3.alloc(S * (h->m2 + 1))) ||
@@ -269,7 +274,7 @@ int qrl_chan_set_option(qrl_chan* h, int option, int value)
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->mid) HIPCHK(hipStreamSynchronize(h->mid));
         if (h->tail) HIPCHK(hipStreamSynchronize(h->tail));
-        h->mid_valid[0] = h->mid_valid[1] = false;
+        h->mid_valid[0] = h->mid_valid[1] = h->mid_valid[2] = false;
         h->opt_serial_tail = value != 0;
     }
     else return qrl_set_error(QRL_ERR_ARG, "unknown channelizer option");
@@ -354,19 +359,22 @@ static int chan_process_impl(qrl_chan* h, const float* iq, size_t stride, size_t
     float2* hist_new = h->flip ? h->hist_a.p : h->hist_b.p;
     // PFB: one output instant per M inputs; form 2: rational_resampler_ccf(1, N) -- output m exists once input m N does
     const uint64_t n1_1 = h->xlat2 ? (h->n_in + n - 1) / (uint64_t)h->xl_D + 1 : (h->n_in + n) / M;
-    if (h->tail_only) {
-        // form 3: the call's input ARE the channel samples (rows = channel streams): into the channel ring, then the per-channel chain
-        launch_ring_load(in, stride, RingC{h->r1.p, h->m1}, h->n1, (uint32_t)n, S, h->stream);
-    }
     // PFB form and form 2: the whole per-channel feed-forward chain in one kernel (kernels_chan_tail.hip)
     const bool fused = !h->single && !h->xlat && !h->opt_legacy_tail && h->ct_a.p && (!h->fsk_bits || h->ct_e.p) &&
                        chan_tail_supported(h->rs_I, h->rs_D, h->rs_Jp, h->filt_nt, h->fsk_bits ? h->symf_nt : 0);
     // ts = the stream of the per-channel kernels: `mid` when they overlap the next call's channelizer, the handle's stream otherwise
     const bool use_mid = h->mid && !h->opt_serial_tail && fused && !chan_out && !h->xlat2 && !h->tail_only;
     const hipStream_t ts = use_mid ? h->mid : h->stream;
-    const int slot2 = (int)(h->call_no & 1);
-    if (use_mid && h->mid_valid[slot2]) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_mid[slot2], 0));   // per-channel kernel of call k - 2 done: the ring items this call's channelizer overwrites are free
-    if (h->rssi_out && h->rssi_counts) HIPCHK(hipMemsetAsync(h->rssi_counts, 0, (size_t)S * sizeof(uint32_t), ts));
+    // form 3: the call's input ARE the channel samples (rows = channel streams).  The fused kernel reads them where they are (round 5: the copy
+    // into the channel ring was 0.86 of the 3.9 ms of a one-rank cluster step); only the separate kernels of QRL_CHAN_OPT_LEGACY_TAIL need the ring
+    if (h->tail_only && !fused) launch_ring_load(in, stride, RingC{h->r1.p, h->m1}, h->n1, (uint32_t)n, S, h->stream);
+    const int slot2 = (int)(h->call_no & 1), slotr = (int)(h->call_no % (uint64_t)h->ring_calls);
+    if (use_mid) h->mid_used = true;
+    if (use_mid && h->mid_valid[slotr]) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_mid[slotr], 0));   // per-channel kernel of call k - ring_calls done: the ring items this call's channelizer overwrites are free
+    // rssi counts: the fused kernel writes every row's count itself; a fill kernel in front of it sat on the critical path of every step
+    // (0.5 ms in the one-rank cluster order: it is dispatched behind the persistent channelizer workgroups of the next call)
+    const bool tail_runs = fused && !chan_out && n1_1 > 0 && ((n1_1 - 1) * (uint64_t)h->rs_I + ((uint64_t)h->rs_I - 1)) / (uint64_t)h->rs_D + 1 > h->n2;   // the fused kernel has outputs to produce
+    if (h->rssi_out && h->rssi_counts && !tail_runs) HIPCHK(hipMemsetAsync(h->rssi_counts, 0, (size_t)S * sizeof(uint32_t), ts));
     if (h->tail && h->tail_valid[slot2]) HIPCHK(hipStreamWaitEvent(ts, h->ev_tail[slot2], 0));   // symbol sync of call k - 2 done: its half of ring r6 is free
     ChanParams p{};
     p.in = in; p.in_stride = stride; p.n0 = h->n_in; p.n = (uint32_t)n; p.hist = hist_old; p.hist_len = h->hist_len;
@@ -425,17 +433,26 @@ static int chan_process_impl(qrl_chan* h, const float* iq, size_t stride, size_t
     if (fused) {
         ChanTailParams tp{};
         tp.in = RingC{h->r1.p, h->m1}; tp.q0 = h->n2; tp.count = c2;
+        if (h->tail_only) { tp.lin = in; tp.lin_pitch = stride; tp.lin_base = h->n1; tp.lin_n = (uint32_t)n; tp.hist = hist_old; tp.hist_len = h->hist_len; }
         tp.tab_a = h->ct_a.p; tp.tab_b = h->ct_b.p; tp.tab_e = h->ct_e.p; tp.atan_tab = h->atan_tab.p;
         tp.gain = h->gain; tp.gain2 = (float)(24000 / (M_PI / 2 * (float)(24000 / 5))); tp.level = h->level; tp.scale = 32767.0f;
         tp.s16 = out; tp.s16_cap = out_cap; tp.s16_counts = counts;
         if (h->fsk_bits) tp.out_sym = RingF{h->r6.p, h->m6};
         if (h->rssi_out) { tp.rssi = h->rssi_out; tp.rssi_cap = h->rssi_cap; tp.rssi_counts = h->rssi_counts; tp.rssi_cal = h->rssi_cal;
                            tp.tag0 = h->n2 / 300; tp.ntags = (uint32_t)(n2_1 / 300 - h->n2 / 300); }
+        if (h->tail_only) {   // the last hist_len channel samples of every row for the next call (k_hist, as for the wideband input of the other forms);
+                              // IN FRONT of the per-channel kernel (it writes the other history buffer), so that nothing sits between two of those
+            HistParams th{};
+            th.in = in; th.in_stride = stride; th.n0 = h->n1; th.n = (uint32_t)n;
+            th.hist_old = hist_old; th.hist_new = hist_new; th.hist_len = h->hist_len; th.rot_enable = 0;
+            launch_hist_save(th, S, h->stream); h->flip = !h->flip;
+        }
         hipEvent_t et0 = nullptr, et1 = nullptr;
         if (h->profiling) { HIPCHK(hipEventCreate(&et0)); HIPCHK(hipEventCreate(&et1)); HIPCHK(hipEventRecord(et0, ts)); }
         launch_chan_tail(tp, S, ts);
         if (et1) { HIPCHK(hipEventRecord(et1, ts)); h->prof_tail.emplace_back(et0, et1); }
-        if (use_mid) { HIPCHK(hipEventRecord(h->ev_mid[slot2], ts)); h->mid_valid[slot2] = true; }
+        if (use_mid) { HIPCHK(hipEventRecord(h->ev_mid[slotr], ts)); h->mid_valid[slotr] = true; }
+
     } else {
         FirCcfParams fp{};
         fp.in = RingC{h->r2.p, h->m2}; fp.out = RingC{h->r3.p, h->m2}; fp.q0 = h->n2; fp.count = c2; fp.taps = h->filt_taps.p; fp.nt = h->filt_nt;
@@ -457,9 +474,10 @@ static int chan_process_impl(qrl_chan* h, const float* iq, size_t stride, size_t
     {
         if (h->fsk_bits) {   // gr_demod_dmr.cpp:70-105: symbol_sync_ff -> level -> phase modulator -> slicer -> dibits, on the RRC output ring
             // on the tail stream, behind this call's feed-forward kernels; the ring slot it reads is rewritten two calls later
+            h->tail_used = true;
             HIPCHK(hipEventRecord(h->ev_ff, ts));
             HIPCHK(hipStreamWaitEvent(h->tail, h->ev_ff, 0));
-            HIPCHK(hipMemsetAsync(h->fsk_counts, 0, (size_t)S * 4 * sizeof(uint32_t), h->tail));
+            // (counts[s*4 + 1] and [s*4 + 2] are written for every stream by the kernel; [0] and [3] are not touched: no fill kernel per call)
             SymSyncParams s{};
             s.in = RingF{h->r6.p, h->m6}; s.avail = n2_1; s.soft = RingB{h->soft_dummy.p, 63}; s.st = h->ss.p; s.mmse = h->mmse.p;
             s.alpha = h->ss_alpha; s.beta = h->ss_beta; s.maxp = 5.0f + 0.06f; s.minp = 5.0f - 0.06f;
@@ -487,12 +505,12 @@ int qrl_chan_stream_wait(qrl_chan* h, void* hip_stream)
     if (!h->ev_user) HIPCHK(hipEventCreateWithFlags(&h->ev_user, hipEventDisableTiming));
     HIPCHK(hipEventRecord(h->ev_user, h->stream));
     HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), h->ev_user, 0));
-    if (h->tail) {
+    if (h->tail && h->tail_used) {
         if (!h->ev_user2) HIPCHK(hipEventCreateWithFlags(&h->ev_user2, hipEventDisableTiming));
         HIPCHK(hipEventRecord(h->ev_user2, h->tail));
         HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), h->ev_user2, 0));
     }
-    if (h->mid) {
+    if (h->mid && h->mid_used) {
         if (!h->ev_user3) HIPCHK(hipEventCreateWithFlags(&h->ev_user3, hipEventDisableTiming));
         HIPCHK(hipEventRecord(h->ev_user3, h->mid));
         HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), h->ev_user3, 0));
@@ -505,7 +523,7 @@ int qrl_chan_wait_for(qrl_chan* h, void* hip_stream)
     if (!h->ev_ext) HIPCHK(hipEventCreateWithFlags(&h->ev_ext, hipEventDisableTiming));
     HIPCHK(hipEventRecord(h->ev_ext, static_cast<hipStream_t>(hip_stream)));
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ext, 0));
-    if (h->mid) HIPCHK(hipStreamWaitEvent(h->mid, h->ev_ext, 0));   // (the int16 / RSSI outputs are written on this stream)
+    if (h->mid && h->mid_used) HIPCHK(hipStreamWaitEvent(h->mid, h->ev_ext, 0));   // (the int16 / RSSI outputs are written on this stream)
     return QRL_OK;
 }
 void* qrl_chan_stream(qrl_chan* h) { return h ? h->stream : nullptr; }

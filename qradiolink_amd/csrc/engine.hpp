@@ -227,6 +227,10 @@ void launch_rssi_tag(const RssiParams& p, int batch, hipStream_t s);
 // channel filter, RSSI tags, FM discriminator -> int16, and the symbol demodulator's discriminator + RRC into the symbol-sync ring
 struct ChanTailParams {
     RingC in;                               // channel ring at 25 ksps, one row per (stream, channel)
+    // form 3 (round 5): the call's channel samples where the exchange put them, lin[row * lin_pitch + (a - lin_base)] for absolute items
+    // a in [lin_base, lin_base + lin_n), and the hist_len items in front of them in hist[row * hist_len + ...] (k_hist keeps them from call to
+    // call) -- no copy into a ring.  lin == nullptr: the ring.
+    const float2* lin; size_t lin_pitch; uint64_t lin_base; uint32_t lin_n; const float2* hist; uint32_t hist_len;
     uint64_t q0; uint32_t count;            // outputs of this call at 24 ksps: [q0, q0 + count)
     const float* tab_a; const float* tab_b; const float* tab_e;   // step-major tap tables (chan_tail_tables; tab_e unused when out_sym.p == nullptr)
     const float* atan_tab;                  // 257

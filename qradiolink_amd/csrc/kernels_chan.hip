@@ -9,6 +9,7 @@
 //  k_f2s      : multiply_const_ff(level) + float_to_short(1, 32767) (gr_demod_mmdvm_multi2.cpp:84,92).
 #include <algorithm>
 #include <mutex>
+#include <cstdlib>
 #include "devmath.hpp"
 #include "engine.hpp"
 
@@ -577,6 +578,7 @@ void launch_pfb_chan(const ChanParams& p, int batch, hipStream_t s)
             if (!slots_cache[dev]) {
                 int nb = 0; hipDeviceProp_t pr;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, stream64_lds_bytes()) != hipSuccess || nb < 1) nb = 1;
+                if (const char* e = std::getenv("QRL_PFB_WG_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v < nb) nb = v; }   // experiment: fewer persistent workgroups per CU (room for the per-channel kernel beside them)
                 slots_cache[dev] = nb * (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256);
             }
             slots = slots_cache[dev];

@@ -75,14 +75,22 @@ __device__ __forceinline__ void ct_step8(v2f_ct (&acc)[8], float4 h0, float4 h1,
 }
 __device__ __forceinline__ int64_t ct_floordiv(int64_t a, int64_t b) { const int64_t q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
 
-__global__ __launch_bounds__(256, 4) void k_chan_tail(const ChanTailParams P)
+#ifndef QRL_CT_WPE
+#define QRL_CT_WPE 4     // waves per SIMD the register allocation aims at.  5 (96 VGPRs, a few loop-invariant values in scratch: a SIMD then holds four waves of
+                         // this kernel AND one of the previous call's symbol synchroniser, and the LDS -- 32.5 KB -- allows it) was measured in round 5:
+                         // slower, 2.98 - 3.03 against 2.86 - 2.92 ms per C4 step (profiles/r05_c4_tail_experiments.log)
+#endif
+__global__ __launch_bounds__(256, QRL_CT_WPE) void k_chan_tail(const ChanTailParams P)
 {
     __shared__ __align__(16) float2 xf[CT_NX > 8 * CT_W ? CT_NX : 8 * CT_W];   // staged input x (stage A), then the channel filter output f (B .. E)
     __shared__ __align__(16) float2 av[8 * CT_W];        // resampler output a
-    __shared__ __align__(16) float dv[16 * CT_DP];       // symbol discriminator output d2 (ct_dpos)
+    __shared__ __align__(16) float dv[16 * CT_DP];       // symbol discriminator output d2 (ct_dpos); stages A / B: their tap tables
     __shared__ float T[257];
-    __shared__ __align__(16) float tA[3 * CT_SA * 8], tB[CT_SB * 8];   // [step][r] tap tables
     __shared__ __align__(16) float tE[CT_HE];            // RRC taps, 15 zeros in front (stage E)
+    // [step][r] tap tables of stages A and B live where stage D will put the discriminator image (round 5: 32.5 KB instead of 39.9 KB per
+    // workgroup, so that FIVE workgroups' worth of LDS is there: four of this kernel + the symbol synchroniser of the previous call)
+    float* const tA = dv; float* const tB = dv + 3 * CT_SA * 8;
+    static_assert(3 * CT_SA * 8 + CT_SB * 8 <= 16 * CT_DP, "tap tables do not fit the discriminator image");
 #ifdef QRL_CT_ROT
     // wave ROLES rotate with the workgroup: stages A / B / E leave the last wave idle (and give it the RSSI sums) -- if wave i of every workgroup
     // sits on SIMD i, a fixed role assignment idles one SIMD of the CU during those stages
@@ -99,15 +107,15 @@ __global__ __launch_bounds__(256, 4) void k_chan_tail(const ChanTailParams P)
     const int64_t tile_first = (int64_t)(P.q0 / CT_T) + (int64_t)blockIdx.x * CT_TPW, tile_last = (int64_t)((P.q0 + P.count - 1) / CT_T);
     const int ntile = (int)(tile_last - tile_first + 1 < CT_TPW ? tile_last - tile_first + 1 : CT_TPW);
     for (int k = tid; k < 257; k += 256) T[k] = P.atan_tab[k];
-    // step-major tap tables, laid out by the host (chan_tail_tables): straight 16-byte copies
-    for (int k = tid; k < 3 * CT_SA * 2; k += 256) reinterpret_cast<float4*>(tA)[k] = reinterpret_cast<const float4*>(P.tab_a)[k];
-    if (tid < CT_SB * 2) reinterpret_cast<float4*>(tB)[tid] = reinterpret_cast<const float4*>(P.tab_b)[tid];
     if (P.out_sym.p && tid < CT_HE) tE[tid] = P.tab_e[tid];
-    CT_STAMP(0);
     for (int tt = 0; tt < ntile; ++tt) {
     const int64_t tile = tile_first + tt;
     const int64_t Q0 = tile * CT_T;
     if (tt) __syncthreads();                                                      // the previous tile's readers of xf / av / dv are through
+    // step-major tap tables, laid out by the host (chan_tail_tables): straight 16-byte copies (per tile: stage D overwrites them)
+    for (int k = tid; k < 3 * CT_SA * 2; k += 256) reinterpret_cast<float4*>(tA)[k] = reinterpret_cast<const float4*>(P.tab_a)[k];
+    if (tid < CT_SB * 2) reinterpret_cast<float4*>(tB)[tid] = reinterpret_cast<const float4*>(P.tab_b)[tid];
+    CT_STAMP(0);
     const int64_t ua = ct_floordiv(Q0 - CT_HA, 24), qa = ua * 24;                 // first resampler output of the tile (multiple of 24)
     const int NU = (int)((Q0 + CT_T - qa + 23) / 24);                             // groups of 24 outputs: <= 59
     const int64_t qb = qa + ((Q0 - CT_HB - qa) / 8) * 8;                          // first filter output (multiple of 8 behind qa)
@@ -121,11 +129,34 @@ __global__ __launch_bounds__(256, 4) void k_chan_tail(const ChanTailParams P)
         const float2* ring = P.in.p + (size_t)row * (P.in.mask + 1u);
         constexpr int NLD = (CT_NX + 255) / 256;
         float2 v[NLD];
+        if (P.lin) {
+            // form 3: items of this call straight from the caller's rows, older ones from the history rows (reads behind the call's last item are
+            // clamped: they only feed outputs that do not exist yet)
+            const float2* lrow = P.lin + (size_t)row * P.lin_pitch;
+            const float2* hrow = P.hist + (size_t)row * P.hist_len;
+            const int64_t rel0 = xbase - (int64_t)P.lin_base;
+            if (rel0 >= 0 && rel0 + CT_NX + 256 <= (int64_t)P.lin_n) {                 // the whole span lies in this call's rows: every tile but a call's first and last
+#pragma unroll
+                for (int k = 0; k < NLD; ++k) v[k] = lrow[(size_t)rel0 + tid + 256 * k];
+            } else
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int64_t a = xbase + tid + 256 * k;
+                const int64_t rel = a - (int64_t)P.lin_base;
+                const uint32_t rl = rel < 0 ? 0u : ((uint64_t)rel < P.lin_n ? (uint32_t)rel : P.lin_n - 1u);
+                const int64_t hi = rel + (int64_t)P.hist_len;
+                const uint32_t hl = hi < 0 ? 0u : (hi < (int64_t)P.hist_len ? (uint32_t)hi : P.hist_len - 1u);
+                const float2* src = rel >= 0 ? lrow + rl : hrow + hl;              // ONE load per item (a select of two loaded values doubled the kernel's global loads)
+                v[k] = *src;
+                if (a < 0 || hi < 0) v[k] = make_float2(0.f, 0.f);
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             const int64_t a = xbase + tid + 256 * k;
             v[k] = ring[(uint32_t)a & P.in.mask];
             if (a < 0) v[k] = make_float2(0.f, 0.f);
+        }
         }
 #pragma unroll
         CT_STAMP(1);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -68,57 +69,91 @@ chan_cluster::chan_cluster(qrl_ctx* ctx, chan_exchange& ex, int num_channels, in
     const int W = ex.world();
     if (W < 1 || num_channels < 2 || num_channels % W || streams_local < 1 || d_n1max < 1)
         throw std::invalid_argument("chan_cluster: the number of ranks must divide the channels; streams_local >= 1; max_chunk >= num_channels");
-    qrl_chan_config c{};
-    c.num_channels = num_channels; c.batch = streams_local; c.max_chunk = max_chunk; c.form = 0;
-    chk(qrl_chan_create(ctx, &c, &d_front), "qrl_chan_create (channelizer)");
-    qrl_chan_config t{};
-    t.num_channels = 1; t.batch = streams_local * W * d_per; t.max_chunk = d_n1max; t.form = 3;
-    chk(qrl_chan_create(ctx, &t, &d_tail), "qrl_chan_create (per-channel chains)");
-    const size_t items = (size_t)W * d_bl * d_per * d_n1max;
-    for (int k = 0; k < 2; ++k) {
-        hchk(hipMalloc(reinterpret_cast<void**>(&d_send[k]), items * 2 * sizeof(float)), "hipMalloc");
-        hchk(hipMalloc(reinterpret_cast<void**>(&d_recv[k]), items * 2 * sizeof(float)), "hipMalloc");
+    const char* keep = std::getenv("QRL_CLUSTER_COPY_AT_ONE_RANK");
+    d_inplace = W == 1 && !(keep && keep[0] == '1');
+    try {
+        qrl_chan_config c{};
+        c.num_channels = num_channels; c.batch = streams_local; c.max_chunk = max_chunk; c.form = 0;
+        chk(qrl_chan_create(ctx, &c, &d_front), "qrl_chan_create (channelizer)");
+        qrl_chan_config t{};
+        t.num_channels = 1; t.batch = streams_local * W * d_per; t.max_chunk = d_n1max; t.form = 3;
+        chk(qrl_chan_create(ctx, &t, &d_tail), "qrl_chan_create (per-channel chains)");
+        const size_t items = (size_t)W * d_bl * d_per * d_n1max;
+        for (int k = 0; k < kSlots; ++k) {
+            hchk(hipMalloc(reinterpret_cast<void**>(&d_send[k]), items * 2 * sizeof(float)), "hipMalloc");
+            if (!d_inplace) hchk(hipMalloc(reinterpret_cast<void**>(&d_recv[k]), items * 2 * sizeof(float)), "hipMalloc");
+        }
+        hipStream_t xs;
+        // lowest priority -- not for the scheduling: streams of one priority share a few hardware queues, and a wait queued on this
+        // stream would otherwise hold back the kernels of a handle stream that happens to sit on the same queue (csrc/engine.cpp, stream creation)
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        hchk(hipStreamCreateWithPriority(&xs, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
+        d_xs = xs;
+        for (int k = 0; k < kSlots; ++k) {
+            hipEvent_t e;
+            hchk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); d_ev_sent[k] = e;
+            hchk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); d_ev_read[k] = e;
+        }
+    } catch (...) {
+        release();   // a constructor that throws has no destructor run
+        throw;
     }
-    hipStream_t xs;
-    // lowest priority -- not for the scheduling: streams of one priority share a few hardware queues, and a wait queued on this
-    // stream would otherwise hold back the kernels of a handle stream that happens to sit on the same queue (csrc/engine.cpp, stream creation)
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    hchk(hipStreamCreateWithPriority(&xs, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
-    d_xs = xs;
 }
-chan_cluster::~chan_cluster()
+void chan_cluster::release()
 {
     if (d_front) qrl_chan_destroy(d_front);
     if (d_tail) qrl_chan_destroy(d_tail);
-    if (d_xs) { (void)hipStreamSynchronize(static_cast<hipStream_t>(d_xs)); (void)hipStreamDestroy(static_cast<hipStream_t>(d_xs)); }
-    if (d_ev) (void)hipEventDestroy(static_cast<hipEvent_t>(d_ev));
-    for (int k = 0; k < 2; ++k) { if (d_send[k]) (void)hipFree(d_send[k]); if (d_recv[k]) (void)hipFree(d_recv[k]); }
+    d_front = d_tail = nullptr;
+    if (d_xs) { (void)hipStreamSynchronize(static_cast<hipStream_t>(d_xs)); (void)hipStreamDestroy(static_cast<hipStream_t>(d_xs)); d_xs = nullptr; }
+    for (int k = 0; k < kSlots; ++k) {
+        if (d_ev_sent[k]) (void)hipEventDestroy(static_cast<hipEvent_t>(d_ev_sent[k]));
+        if (d_ev_read[k]) (void)hipEventDestroy(static_cast<hipEvent_t>(d_ev_read[k]));
+        d_ev_sent[k] = d_ev_read[k] = nullptr;
+        if (d_send[k]) (void)hipFree(d_send[k]);
+        if (d_recv[k]) (void)hipFree(d_recv[k]);
+        d_send[k] = d_recv[k] = nullptr;
+    }
 }
+chan_cluster::~chan_cluster() { release(); }
+// Ordering of step k (slot = k mod 3), all on the device:
+//   channelizer k   waits for exchange k - 3 (ev_sent[slot]: the last reader of send[slot])            -- NOT for exchanges k - 1, k - 2: it runs under them
+//   exchange k      waits for channelizer k (qrl_chan_stream_wait) and for the per-channel kernels of step k - 3 (ev_read[slot]: since round 5
+//                   they read recv[slot] in place -- there is no copy into a ring any more -- so they are its last readers)
+//   per-channel k   waits for exchange k (qrl_chan_wait_for)
 void chan_cluster::channelize(const float* iq, size_t stride, size_t n)
 {
     if (n % (size_t)d_M || n / (size_t)d_M > d_n1max) throw std::invalid_argument("chan_cluster: n must be a multiple of num_channels and <= max_chunk");
-    d_cur = (int)(d_k++ & 1u);
+    d_cur = (int)(d_k++ % (unsigned)kSlots);
     d_n1 = n / (size_t)d_M;
-    chk(qrl_chan_wait_for(d_front, d_xs), "qrl_chan_wait_for");          // send[cur] is free once the exchanges queued so far have read it
+    if (d_inplace) {   // one rank: the per-channel kernels of step k - 3 were the readers of send[cur]
+        if (d_read_valid[d_cur])
+            hchk(hipStreamWaitEvent(static_cast<hipStream_t>(qrl_chan_stream(d_front)), static_cast<hipEvent_t>(d_ev_read[d_cur]), 0), "hipStreamWaitEvent");
+    } else if (d_sent_valid[d_cur])
+        hchk(hipStreamWaitEvent(static_cast<hipStream_t>(qrl_chan_stream(d_front)), static_cast<hipEvent_t>(d_ev_sent[d_cur]), 0), "hipStreamWaitEvent");
     chk(qrl_chan_channelize(d_front, iq, stride, n, d_send[d_cur], d_n1max, d_ex.world()), "qrl_chan_channelize");
 }
 void chan_cluster::exchange()
 {
+    // ONE RANK: every channel is this rank's own, the by-destination layout the channelizer wrote IS what the per-channel handle reads -- the
+    // all-to-all of one rank would be a 1 GB device copy per step (0.96 ms as rcclGenericKernel at the bench shape) that moves nothing anywhere.
+    // QRL_CLUSTER_COPY_AT_ONE_RANK=1 keeps the collective (what a one-GPU box can exercise of the RCCL transport; bench.py --cluster-copy).
+    if (d_inplace) return;
     chk(qrl_chan_stream_wait(d_front, d_xs), "qrl_chan_stream_wait");    // the collective runs behind the channelizer ...
-    // ... and recv[cur] is free once the per-channel handle has COPIED it into its rings: that is the first kernel process_channels puts
-    // on that handle's own stream, so an event there is enough.  (qrl_chan_stream_wait on the handle also waits for its symbol-sync
-    // stream: the exchange of step k then started behind the symbol synchroniser of step k - 1 and the whole step ran serially,
-    // 5.7 instead of 3.x ms at one rank -- round 4, tools/prof_timeline.py on bench.py --config c4 --cluster.)
-    if (!d_ev) { hipEvent_t e; hchk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); d_ev = e; }
-    hchk(hipEventRecord(static_cast<hipEvent_t>(d_ev), static_cast<hipStream_t>(qrl_chan_stream(d_tail))), "hipEventRecord");
-    hchk(hipStreamWaitEvent(static_cast<hipStream_t>(d_xs), static_cast<hipEvent_t>(d_ev), 0), "hipStreamWaitEvent");
+    if (d_read_valid[d_cur])                                              // ... and behind the last readers of recv[cur]
+        hchk(hipStreamWaitEvent(static_cast<hipStream_t>(d_xs), static_cast<hipEvent_t>(d_ev_read[d_cur]), 0), "hipStreamWaitEvent");
     d_ex.all_to_all(d_send[d_cur], d_recv[d_cur], (size_t)d_bl * d_per * d_n1max * 2 * sizeof(float), d_xs);
+    hchk(hipEventRecord(static_cast<hipEvent_t>(d_ev_sent[d_cur]), static_cast<hipStream_t>(d_xs)), "hipEventRecord");
+    d_sent_valid[d_cur] = true;
 }
 void chan_cluster::process_channels(int16_t* out, size_t out_cap, uint32_t* counts)
 {
-    chk(qrl_chan_wait_for(d_tail, d_xs), "qrl_chan_wait_for");           // the per-channel chains run behind the collective
-    chk(qrl_chan_process_channels(d_tail, d_recv[d_cur], d_n1max, d_n1, out, out_cap, counts), "qrl_chan_process_channels");
+    if (d_inplace) chk(qrl_chan_stream_wait(d_front, qrl_chan_stream(d_tail)), "qrl_chan_stream_wait");   // behind the channelizer
+    else chk(qrl_chan_wait_for(d_tail, d_xs), "qrl_chan_wait_for");      // the per-channel chains run behind the collective
+    chk(qrl_chan_process_channels(d_tail, d_inplace ? d_send[d_cur] : d_recv[d_cur], d_n1max, d_n1, out, out_cap, counts), "qrl_chan_process_channels");
+    // (the handle's own stream: the kernels that read recv[cur]; its symbol-sync stream reads the handle's rings only)
+    hchk(hipEventRecord(static_cast<hipEvent_t>(d_ev_read[d_cur]), static_cast<hipStream_t>(qrl_chan_stream(d_tail))), "hipEventRecord");
+    d_read_valid[d_cur] = true;
 }
 void chan_cluster::step(const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts)
 {

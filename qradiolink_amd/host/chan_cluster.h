@@ -5,8 +5,9 @@
 //     every rank channelizes ITS B / N wideband streams            qrl_chan_channelize   (all 64 channels, rows grouped by destination)
 //     ONE all-to-all per step moves each channel's 25 ksps samples to the rank that owns the channel      chan_exchange::all_to_all
 //     the owner runs the per-channel chains of its 64 / N channels of EVERY stream                        qrl_chan_process_channels
-// ordered on the device (qrl_chan_stream_wait / qrl_chan_wait_for around the exchange stream), two send / receive buffer sets so that
-// step k + 1's channelizer runs while step k's collective and per-channel chains are still in flight.  No host synchronisation.
+// ordered on the device (events per buffer slot + qrl_chan_stream_wait / qrl_chan_wait_for around the exchange stream), three send / receive
+// buffer sets so that the channelizers of steps k + 1 and k + 2 run while step k's collective and per-channel chains are still in flight; the per-channel
+// kernel reads the receive buffer in place (round 5: no copy into the handle's rings).  No host synchronisation.
 //
 // The transport is an interface: rccl_exchange (ncclAllToAll over xGMI, the production transport), self_exchange (one rank: a device
 // copy), callback_exchange (a C function: the CPU tests run torch.distributed / gloo behind it, the single-device emulation a
@@ -89,10 +90,15 @@ private:
     chan_exchange& d_ex;
     qrl_chan *d_front = nullptr, *d_tail = nullptr;
     int d_M, d_bl, d_per; size_t d_n1max, d_n1 = 0;
-    float *d_send[2] = {nullptr, nullptr}, *d_recv[2] = {nullptr, nullptr};
+    static constexpr int kSlots = 3;                // buffer sets: the channelizer may run two steps ahead of the per-channel kernels
+    float *d_send[kSlots] = {nullptr, nullptr, nullptr}, *d_recv[kSlots] = {nullptr, nullptr, nullptr};
     void* d_xs = nullptr;                           // hipStream_t of the exchange
-    void* d_ev = nullptr;                           // hipEvent_t: the per-channel handle's own stream at the time of an exchange
+    // hipEvent_t per buffer slot: exchange k done (send[slot] read, recv[slot] written); the per-channel kernels of step k queued so far done (recv[slot] read)
+    void* d_ev_sent[kSlots] = {nullptr, nullptr, nullptr}; void* d_ev_read[kSlots] = {nullptr, nullptr, nullptr};
+    bool d_sent_valid[kSlots] = {false, false, false}, d_read_valid[kSlots] = {false, false, false};
     unsigned d_k = 0; int d_cur = 0;
+    bool d_inplace = false;                         // one rank: no exchange, the per-channel handle reads send[] in place
+    void release();
 };
 
 }  // namespace qrl_host

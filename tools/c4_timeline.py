@@ -10,7 +10,9 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
 rows = db.execute("select name, start, end, %s from kernels order by start" % q).fetchall()
-rows = [(n.split("(")[0].replace("void ", "").replace("qrl::", ""), s, e, qq) for n, s, e, qq in rows if "qrl::" in n]
+import os
+every = bool(os.environ.get("QRL_TL_ALL"))   # QRL_TL_ALL=1: the runtime's own kernels too (fills, device-to-device copies)
+rows = [(n.split("(")[0].replace("void ", "").replace("qrl::", ""), s, e, qq) for n, s, e, qq in rows if "qrl::" in n or (every and "at::" not in n and "elementwise" not in n)]
 cut = next((i for i, r in enumerate(rows) if r[0].startswith("k_decim_mfma")), len(rows))
 rows = rows[:cut]
 last = [i for i, r in enumerate(rows) if r[0].startswith("k_pfb")][-steps:]

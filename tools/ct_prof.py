@@ -17,7 +17,10 @@ lib = ctx.lib
 out = (C.c_ulonglong * 16)()
 for _ in range(2): ch.process_async(iq)
 ch.sync(); lib.qrl_ct_prof_read(out)
-for _ in range(4): ch.process_async(iq)
+for _ in range(4):
+    ch.process_async(iq)
+    if os.environ.get("QRL_CT_PROF_SYNC"):   # every call alone on the chip (no channelizer / symbol synchroniser of a neighbouring call beside the kernel)
+        ch.sync()
 ch.sync(); lib.qrl_ct_prof_read(out)
 names = ["tables issue", "input loads issue", "input -> LDS (waits for the loads)", "barrier", "A resampler", "barrier", "B channel filter", "barrier",
          "D discriminators + int16", "barrier", "(all waves) E / C", "waves 0-2: E RRC (same ticks as previous row, split)", "wave 3: C RSSI sums"]
