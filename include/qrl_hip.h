@@ -210,6 +210,17 @@ int qrl_mod_set_bb_gain(qrl_mod* m, float value);
  * Only for handles created with the back end (device_samp_rate >= 2e6 or a non-zero initial offset). */
 int qrl_mod_set_carrier_offset(qrl_mod* m, double hz);
 size_t qrl_mod_samples_per_byte(const qrl_mod* m);
+typedef struct { int stream; int channel; uint64_t start; uint64_t count; } qrl_zero_run;
+/* QRL_MODEM_DMR (replaces make_gr_mod_dmr(), reference src/gr/gr_mod_dmr.cpp:19-90, instance gr_mod_base.cpp:207, fed by gr_mod_base::setDMRData
+ * :788 -> gr_dmr_source): raw dibits -> map{2,3,1,0} -> 4 levels -> RRC(5, 24000, 4800, 0.2, 125) x5 -> x0.66666666 -> frequency_modulator_fc
+ * (pi 4800 0.85 / 24000) -> gr_zero_idle_bursts(62) -> x0.9 -> bb gain -> rational_resampler_ccf(125, 3, low_pass_2(125, 3e6, 5000, 2000, 60, BH)):
+ * 2500 samples per 3 bytes, like QRL_MODEM_M17.  The zero-idle block is restated as ONE work() call over the stream sees it: its history of
+ * 2 x 720 items delays the signal by 1439 items at 24 ksps, and a "zero_samples" tag {offset T, count} zeroes the block's OUTPUT items
+ * T - 62 ... T - 62 + count - 1 (a later tag ends an earlier run).  qrl_mod_add_zero_runs hands over those tags (T in the block's 24 ksps
+ * input coordinates = 20 x the byte offset gr_dmr_source put the tag on; `channel` ignored); they apply to the following qrl_mod_process calls.
+ * (Across scheduler calls the reference only matches tags inside a call's own window, so it misses tags within the first 62 items of a window:
+ * not restated.)  The DMR frame / CACH / slot-timing layer that produces bytes and tags (gr_dmr_source, src/DMR/) stays with the caller. */
+int qrl_mod_add_zero_runs(qrl_mod* m, const qrl_zero_run* runs, size_t n);
 /* QRL_MODEM_M17 (replaces make_gr_mod_m17(), reference src/gr/gr_mod_m17.cpp:19-81, gr_mod_base.cpp:206): its 125 / 3 output resampler
  * makes 833 1/3 samples per byte, so calls take multiples of 3 bytes (an M17 frame is 48) and return 2500 samples per 3 bytes;
  * qrl_mod_samples_per_byte is 0 for it.  Other modes: bytes_per_block 1, the value of qrl_mod_samples_per_byte. */
@@ -350,7 +361,7 @@ int qrl_synth_reset(qrl_synth* s);
  * the 25/24 resampler in the multi-carrier graph, 24 ksps behind the FM modulator in the single-carrier one; item index counted from
  * the handle's creation / last reset).  Items start .. start + count - 1 of (stream, channel) become 0 + 0j in whichever following
  * qrl_synth_process calls they fall into.  host/mmdvm_wire.h zero_idle_runs() turns the source's tags into these runs. */
-typedef struct { int stream; int channel; uint64_t start; uint64_t count; } qrl_zero_run;
+/* (qrl_zero_run is declared with qrl_mod_add_zero_runs above) */
 int qrl_synth_add_zero_runs(qrl_synth* h, const qrl_zero_run* runs, size_t n);
 int qrl_synth_set_bb_gain(qrl_synth* s, float value);
 size_t qrl_synth_out_cap(const qrl_synth* s, size_t n);

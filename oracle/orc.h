@@ -156,6 +156,9 @@ void   orc_preemph_taps(int sample_rate, double tau, double a[2], double b[2]);
 size_t orc_mod_nbfm(const float* audio, size_t n, int sps, int samp_rate, int filter_width, float bb_gain, cf32* out);   /* out NULL: count */
 size_t orc_mod_4fsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, int fm, cf32* out);
 size_t orc_mod_m17(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int filter_width, float bb_gain, cf32* out);
+/* gr_mod_dmr (src/gr/gr_mod_dmr.cpp:26-90); zero_runs = {ignored, T, count} triples at the zero-idle block's 24 ksps input (NULL / 0: none) */
+size_t orc_mod_dmr(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int filter_width, float bb_gain, const uint64_t* zero_runs, size_t nruns, cf32* out);
+void   orc_zero_idle_bursts_delay(const cf32* in, size_t n, unsigned delay, const uint64_t* runs, size_t nruns, cf32* out);   /* gr_zero_idle_bursts(delay > 0): history shift + tags matched `delay` items early, one work() call */
 size_t orc_mod_dsss(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int filter_width, float bb_gain, cf32* out);
 size_t orc_mod_bpsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int carrier_freq, int filter_width, cf32* out);
 size_t orc_clock_recovery_mm_cc(const cf32* in, size_t n, float omega, float gain_omega, float mu, float gain_mu,

@@ -656,6 +656,66 @@ size_t orc_mod_m17(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, 
     return m;
 }
 
+/* gr_zero_idle_bursts with delay > 0 (src/gr/gr_zero_idle_bursts.cpp:27-84), as ONE work() call over the whole stream sees it:
+ *   - set_history(2 * SAMPLES_PER_SLOT) (:34-37; SAMPLES_PER_SLOT = 720, src/bursttimer.h:30) and work() copies in[i], the OLDEST item of
+ *     the window: the stream leaves delayed by 2 * 720 - 1 = 1439 items (zeros first);
+ *   - a tag {offset T, count} (re)loads the down-counter at OUTPUT item T - delay (`tag.offset == nitems + i + _delay`, :62-69): items
+ *     T - delay .. T - delay + count - 1 leave as 0 + 0j; a later tag overwrites the counter.
+ * (Across several work() calls the reference only looks at the tags inside the call's own window, :57, so a tag within the first `delay`
+ *  items of a window is never matched: that part of its behaviour depends on how the scheduler cuts the stream and is not restated.)
+ * runs = {ignored, T, count} triples, as orc_zero_idle_bursts takes them. */
+void orc_zero_idle_bursts_delay(const cf32* in, size_t n, unsigned delay, const uint64_t* runs, size_t nruns, cf32* out)
+{
+    const size_t H1 = delay > 0 ? 2 * 720 - 1 : 0;
+    uint64_t counter = 0;
+    for (size_t i = 0; i < n; i++) {
+        for (size_t r = 0; r < nruns; r++)
+            if (runs[3 * r + 1] == (uint64_t)i + delay) { counter = runs[3 * r + 2]; break; }
+        if (counter > 0) { out[i].re = 0.0f; out[i].im = 0.0f; counter--; }
+        else if (i >= H1) out[i] = in[i - H1];
+        else { out[i].re = 0.0f; out[i].im = 0.0f; }
+    }
+}
+
+/* gr_mod_dmr (reference src/gr/gr_mod_dmr.cpp:26-90, instance make_gr_mod_dmr() gr_mod_base.cpp:207 with the defaults of gr_mod_dmr.h:38-39:
+ * sps 125, 1 Msps, filter width 5000): bytes -> dibits (MSB first) -> map{2, 3, 1, 0} -> {-1.5, -0.5, 0.5, 1.5} ->
+ * rational_resampler_fff(5, 1, RRC(5, 24000, 4800, 0.2, 125)) -> x0.66666666 -> frequency_modulator_fc(pi 4800 0.85 / 24000) ->
+ * gr_zero_idle_bursts(delay = (125 - 1) / 2 = 62) -> x0.9 -> x bb_gain -> rational_resampler_ccf(125, 3, low_pass_2(125, 3e6, fw, 2000, 60, BH)).
+ * (The fft_filter_ccf the constructor also creates, :74-75, is not connected.)  2500 samples per 3 bytes; zero_runs = {ignored, T, count}
+ * triples in the zero-idle block's 24 ksps input coordinates (the "zero_samples" tags of gr_dmr_source once GNU Radio has scaled their
+ * offsets through the chain), NULL / 0: none. */
+size_t orc_mod_dmr(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate, int filter_width, float bb_gain, const uint64_t* zero_runs, size_t nruns, cf32* out)
+{
+    const size_t ns = nbytes * 4, n24 = ns * 5, nout = orc_decim_count(n24, sps, 3);
+    if (!out) return nout;
+    static const int map[4] = {2, 3, 1, 0};
+    static const float levels[4] = {-1.5f, -0.5f, 0.5f, 1.5f};
+    float* sym = NEW(float, ns + 1);
+    for (size_t i = 0; i < ns; i++) sym[i] = levels[map[(bytes[i >> 2] >> (6 - 2 * (i & 3))) & 3]];
+    int nr = orc_root_raised_cosine(5, 24000, 4800, 0.2, 125, NULL);
+    float* rrc = NEW(float, nr);
+    orc_root_raised_cosine(5, 24000, 4800, 0.2, 125, rrc);
+    float* shaped = NEW(float, n24 + 1);
+    orc_resamp_fff(sym, ns, rrc, nr, 5, 1, shaped);                              /* _first_resampler */
+    const unsigned delay = (unsigned)((nr - 1) / 2);                              /* first_resampler_delay, gr_mod_dmr.cpp:57 */
+    free(rrc); free(sym);
+    const float sc = (float)0.66666666;
+    for (size_t i = 0; i < n24; i++) shaped[i] = shaped[i] * sc;                 /* _scale_pulses */
+    cf32* fmv = NEW(cf32, n24 + 1);
+    fm_mod(shaped, n24, (float)((M_PI * 4800.0 * 0.85) / 24000.0), fmv);         /* _fm_modulator (float sensitivity) */
+    free(shaped);
+    cf32* g = NEW(cf32, n24 + 1);
+    orc_zero_idle_bursts_delay(fmv, n24, delay, zero_runs, nruns, g);            /* _zero_idle */
+    free(fmv);
+    for (size_t i = 0; i < n24; i++) { g[i].re *= 0.9f; g[i].im *= 0.9f; g[i].re *= bb_gain; g[i].im *= bb_gain; }   /* _amplify, _bb_gain */
+    int nt = orc_low_pass_2(sps, (double)samp_rate * 3, filter_width, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    float* lp = NEW(float, nt);
+    orc_low_pass_2(sps, (double)samp_rate * 3, filter_width, 2000, 60, ORC_WIN_BLACKMAN_HARRIS, lp);
+    const size_t m = orc_resamp_ccf(g, n24, lp, nt, sps, 3, out);                /* _resampler (125, 3) */
+    free(lp); free(g);
+    return m;
+}
+
 /* gr_mod_dsss (reference src/gr/gr_mod_dsss.cpp:27-92, instance make_gr_mod_dsss(25, 1000000, 1700, 150) gr_mod_base.cpp:170;
  * dsss_encoder_bb src/gr/dsss_encoder_bb_impl.cc:66-98): bytes -> bits -> scrambler -> K = 7 encoder -> every coded bit spread by the
  * Barker-13 code (bit 0: the code, bit 1: its complement) -> {-1, +1} -> rational_resampler_ccf(25, 1, RRC(25, 25, 1, 0.35, 275)) ->

@@ -102,6 +102,21 @@ void ref_zero_idle_bursts(const float* in /* 2 n */, size_t n, size_t chunk, con
     }
 }
 
+// gr_zero_idle_bursts(delay > 0) in ONE work() call over the whole stream: the block asked for a history of 2 * SAMPLES_PER_SLOT items, so the
+// scheduler hands it a window that starts 2 * 720 - 1 items (zeros at the start of a stream) in front of the first new item
+void ref_zero_idle_bursts_delay(const float* in /* 2 n */, size_t n, unsigned delay, const uint64_t* offsets, const uint64_t* counts, size_t ntags, float* out)
+{
+    gr_zero_idle_bursts_sptr z = make_gr_zero_idle_bursts(delay);
+    for (size_t i = 0; i < ntags; ++i) z->stub_in_tags.push_back(gr::tag_t{offsets[i], pmt::string_to_symbol("zero_samples"), pmt::from_uint64(counts[i])});
+    const size_t H1 = delay > 0 ? 2 * 720 - 1 : 0;
+    std::vector<gr_complex> buf(H1 + n, gr_complex(0, 0));
+    std::memcpy(buf.data() + H1, in, n * sizeof(gr_complex));
+    gr_vector_const_void_star ins(1, buf.data());
+    gr_vector_void_star outs(1, out);
+    z->stub_written = 0; z->stub_read = 0;
+    z->work((int)n, ins, outs);
+}
+
 // gr::dsss::dsss_decoder_cc(Barker 13, sps): in = the whole stream; the block sees it with its history (set_history(13 sps): 13 sps - 1
 // zeros in front of the first item) and is asked for every output whose input exists.  Returns the outputs; taps optional.
 size_t ref_dsss_decoder(const float* in /* 2 n */, size_t n, int sps, size_t per_call, float* out /* 2 per output */, float* taps_out /* nt or NULL */)

@@ -188,6 +188,7 @@ def load_library():
     lib.qrl_synth_reset.argtypes = [vp]
     lib.qrl_synth_set_bb_gain.argtypes = [vp, C.c_float]
     lib.qrl_synth_add_zero_runs.argtypes = [vp, vp, sz]
+    lib.qrl_mod_add_zero_runs.argtypes = [vp, vp, sz]
     lib.qrl_synth_out_cap.restype = sz
     lib.qrl_synth_out_cap.argtypes = [vp, sz]
     lib.qrl_synth_process.argtypes = [vp, vp, sz, sz, vp, sz, C.POINTER(sz)]
@@ -223,7 +224,7 @@ EXPORTED_SYMBOLS = [
     "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_internal_streams", "qrl_chan_internal_streams", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
-    "qrl_mod_samples_per_byte", "qrl_mod_samples_per_block", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_set_option", "qrl_chan_channelize", "qrl_chan_process_channels", "qrl_chan_wait_for", "qrl_chan_stream_wait", "qrl_chan_stream", "qrl_chan_profile", "qrl_chan_profile_read", "qrl_chan_profile_read_kernels", "qrl_debug_decim_prof", "qrl_debug_decim_prof_enable", "qrl_chan_create",
+    "qrl_mod_samples_per_byte", "qrl_mod_samples_per_block", "qrl_mod_add_zero_runs", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_set_option", "qrl_chan_channelize", "qrl_chan_process_channels", "qrl_chan_wait_for", "qrl_chan_stream_wait", "qrl_chan_stream", "qrl_chan_profile", "qrl_chan_profile_read", "qrl_chan_profile_read_kernels", "qrl_debug_decim_prof", "qrl_debug_decim_prof_enable", "qrl_chan_create",
     "qrl_chan_destroy", "qrl_chan_reset", "qrl_chan_set_level", "qrl_chan_calibrate_rssi", "qrl_chan_set_rssi_output", "qrl_chan_set_4fsk_output", "qrl_chan_out_cap", "qrl_chan_process", "qrl_chan_sync",
     "qrl_synth_create", "qrl_synth_destroy", "qrl_synth_reset", "qrl_synth_set_bb_gain", "qrl_synth_add_zero_runs", "qrl_synth_out_cap", "qrl_synth_process",
     "qrl_synth_sync",
@@ -833,6 +834,12 @@ class Mod:
 
     def set_carrier_offset(self, hz):
         _check(self.lib.qrl_mod_set_carrier_offset(self.h, float(hz)), "qrl_mod_set_carrier_offset")
+
+    def add_zero_runs(self, runs):
+        """QRL_MODEM_DMR: the "zero_samples" tags of gr_zero_idle_bursts, runs = [(stream, T, count), ...] with T in the block's 24 ksps input
+        coordinates (qrl_mod_add_zero_runs)"""
+        arr = (_ZeroRun * len(runs))(*[_ZeroRun(s_, 0, t, c) for s_, t, c in runs])
+        _check(self.lib.qrl_mod_add_zero_runs(self.h, arr, len(runs)), "qrl_mod_add_zero_runs")
 
     def close(self):
         if self.h:

@@ -30,6 +30,10 @@ struct qrl_mod {
     bool bpsk = false, fsk4 = false; float shape_scale = 0.0f;
     // gr_mod_m17: raw dibits -> RRC x5 -> FM -> channel filter -> gains -> 125 / 3 (2500 samples per 3 bytes)
     bool m17 = false; float* m17_filt = nullptr; int m17_nf = 0; float2* m17_flt = nullptr;
+    // gr_mod_dmr (src/gr/gr_mod_dmr.cpp:26-90): the m17 path with the DMR pulse and deviation; gr_zero_idle_bursts(62) in the place of the channel
+    // filter = the stream 2 x 720 - 1 items late (the block's history, gr_zero_idle_bursts.cpp:34-37,76) + the tagged runs zeroed `delay` items early
+    bool dmr = false; std::vector<ZeroRun> zero_runs; ZeroRun* zero_dev = nullptr; size_t zero_dev_cap = 0;
+    static constexpr uint32_t kDmrHist = 2 * 720 - 1, kDmrTagDelay = 62;
     // gr_mod_dsss: coded bits -> Barker-13 chips -> RRC x25 (5200 sps) -> gains -> 50 / 13 (20 ksps) -> 1:50; 1 000 000 samples per byte
     bool dsss = false; uint8_t* ds_chips = nullptr; uint32_t ds_chip_mask = 0; float* ds_shaped = nullptr; float2 *ds_c52 = nullptr, *ds_c20 = nullptr;
     uint32_t ds_m52 = 0, ds_m20 = 0; float* ds_if_taps = nullptr; int ds_if_Jp = 0;
@@ -55,7 +59,7 @@ struct qrl_mod {
     }
     ~qrl_mod() {
         if (taps) (void)hipFree(taps);
-        for (void* p : {(void*)shape_taps, (void*)shaped, (void*)fmv, (void*)phase, (void*)m17_filt, (void*)m17_flt, (void*)ds_chips, (void*)ds_shaped, (void*)ds_c52, (void*)ds_c20, (void*)ds_if_taps}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)zero_dev, (void*)shape_taps, (void*)shaped, (void*)fmv, (void*)phase, (void*)m17_filt, (void*)m17_flt, (void*)ds_chips, (void*)ds_shaped, (void*)ds_c52, (void*)ds_c20, (void*)ds_if_taps}) if (p) (void)hipFree(p);
         if (st) (void)hipFree(st);
         for (void* p : {(void*)be_taps, (void*)bb, (void*)be_ring, (void*)rot_lo}) if (p) (void)hipFree(p);
         if (sym) (void)hipFree(sym);
@@ -80,6 +84,7 @@ struct qrl_mod {
         }
         if (be_ring && hipMemset(be_ring, 0, (size_t)cfg.batch * (be_mask + 1) * sizeof(float2)) != hipSuccess) return QRL_ERR_HIP;
         nsym = 0; n_bb = 0; rot_acc = 0; rot_nbase = 0;
+        zero_runs.clear();
         return QRL_OK;
     }
 };
@@ -137,6 +142,7 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
         case QRL_MODEM_BPSK1K:    c.sps = 500; c.filter_width = 1500;  break;             // :168
         case QRL_MODEM_BPSK2K:    c.sps = 250; c.filter_width = 2800;  break;             // :169
         case QRL_MODEM_M17:       c.sps = 125; c.filter_width = 9000;  break;             // make_gr_mod_m17() :206, defaults gr_mod_m17.h:43-44
+        case QRL_MODEM_DMR:       c.sps = 125; c.filter_width = 5000;  break;             // make_gr_mod_dmr() :207, defaults of make_gr_mod_dmr gr_mod_dmr.h:38-39
         case QRL_MODEM_BPSK8:     c.sps = 25;  c.filter_width = 150;   break;             // make_gr_mod_dsss(25, 1000000, 1700, 150) :170
         default: return qrl_set_error(QRL_ERR_ARG, "modulator: modem_type not supported by this build");
         }
@@ -148,11 +154,12 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
     case QRL_MODEM_4FSK2K: case QRL_MODEM_4FSK2KFM: case QRL_MODEM_4FSK1KFM: case QRL_MODEM_4FSK10KFM: case QRL_MODEM_4FSK100K: fsk = fsk4 = true; break;
     case QRL_MODEM_BPSK1K: case QRL_MODEM_BPSK2K: bpsk = true; break;
     case QRL_MODEM_M17: fsk = true; m->m17 = true; break;
+    case QRL_MODEM_DMR: fsk = true; m->m17 = true; m->dmr = true; break;
     case QRL_MODEM_BPSK8: m->dsss = true; break;
     default: return qrl_set_error(QRL_ERR_ARG, "modulator: modem_type not supported by this build");
     }
     m->bpsk = bpsk; m->fsk4 = fsk4;
-    if (m->m17 && c.sps != 125) return qrl_set_error(QRL_ERR_ARG, "modulator: m17 sps must be 125 (rational_resampler_ccf(sps, 3), gr_mod_m17.cpp:64-66)");
+    if (m->m17 && c.sps != 125) return qrl_set_error(QRL_ERR_ARG, "modulator: m17 / dmr sps must be 125 (rational_resampler_ccf(sps, 3), gr_mod_m17.cpp:64-66)");
     if ((m->m17 || m->dsss) && ((c.device_samp_rate != 0 && c.device_samp_rate != 1000000) || c.carrier_offset_hz != 0.0))
         return qrl_set_error(QRL_ERR_ARG, "modulator: the gr_mod_base back end is not built for m17 / dsss");
     if (m->dsss && c.sps != 25) return qrl_set_error(QRL_ERR_ARG, "modulator: dsss sps must be 25");
@@ -208,10 +215,10 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
         m->fam = qrl_mod::F_FSK;
         int sps = c.sps, nfilts;
         std::vector<float> shape;
-        if (m->m17) {   // gr_mod_m17.cpp:39-70: five samples per symbol at 24 ksps
+        if (m->m17) {   // gr_mod_m17.cpp:39-70 / gr_mod_dmr.cpp:36-62: five samples per symbol at 24 ksps
             sps = 5; m->interp2 = 1; m->amplif = 1.0f;
-            shape = root_raised_cosine(5, 5, 1, 0.5, 250); m->shape_scale = (float)0.66666666;
-            m->fm_k = (float)(M_PI / 5);
+            shape = m->dmr ? root_raised_cosine(5, 24000, 4800, 0.2, 125) : root_raised_cosine(5, 5, 1, 0.5, 250); m->shape_scale = (float)0.66666666;
+            m->fm_k = m->dmr ? (float)((M_PI * 4800.0 * 0.85) / 24000.0) : (float)(M_PI / 5);   // frequency_modulator_fc takes a float
             m->fsk4 = true;      // four levels per ring item
         } else if (gmsk) {   // gr_mod_gmsk.cpp:40-70
             nfilts = 35; m->interp2 = 5; m->amplif = 0.9f;
@@ -239,20 +246,24 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
         if (m->nt_shape > 1536) return qrl_set_error(QRL_ERR_ARG, "modulator: shaping filter too long");
         int r0 = upload(shape, &m->shape_taps);
         if (r0) return r0;
-        const std::vector<float> lp = m->m17 ? low_pass(125, (double)c.samp_rate * 3, 12000, 12000, WIN_BLACKMAN_HARRIS)   // _resampler (125, 3), gr_mod_m17.cpp:64-66
+        const std::vector<float> lp = m->dmr ? low_pass_2(125, (double)c.samp_rate * 3, c.filter_width, 2000, 60, WIN_BLACKMAN_HARRIS)   // gr_mod_dmr.cpp:65-68
+                                    : m->m17 ? low_pass(125, (double)c.samp_rate * 3, 12000, 12000, WIN_BLACKMAN_HARRIS)   // _resampler (125, 3), gr_mod_m17.cpp:64-66
                                              : low_pass(m->interp2, c.samp_rate, c.filter_width, c.filter_width, WIN_HAMMING);
         m->nt = (int)lp.size();
-        if (m->nt > 2048) return qrl_set_error(QRL_ERR_ARG, "modulator: interpolator filter too long");
+        if (m->nt > (m->dmr ? 8192 : 2048)) return qrl_set_error(QRL_ERR_ARG, "modulator: interpolator filter too long");   // (gr_mod_dmr: 4091 taps; k_tx_interp_c reads taps beyond 2048 through the caches)
         if ((r0 = upload(lp, &m->taps))) return r0;
         ring_items = c.max_bytes * 16 + 256;
         uint32_t cap1 = 1024;
-        while (cap1 < c.max_bytes * 16 * (size_t)sps + (size_t)m->nt + 256) cap1 <<= 1;
+        while (cap1 < c.max_bytes * 16 * (size_t)sps + (size_t)m->nt + 256 + (m->dmr ? qrl_mod::kDmrHist + 64 : 0)) cap1 <<= 1;
         m->r1_mask = cap1 - 1;
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->shaped), (size_t)c.batch * cap1 * sizeof(float)));
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->fmv), (size_t)c.batch * cap1 * sizeof(float2)));
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->phase), (size_t)c.batch * sizeof(float)));
         if (m->m17) {
-            const std::vector<float> ft = low_pass(1, 24000, c.filter_width, c.filter_width, WIN_BLACKMAN_HARRIS);   // _filter, gr_mod_m17.cpp:69-70
+            // _filter, gr_mod_m17.cpp:69-70.  gr_mod_dmr: one tap 1.0 at lag 2 x 720 - 1 -- the delay of gr_zero_idle_bursts' history read
+            // through the same FIR kernel (fmaf(1, x, +0) = x; the zero taps leave the chain untouched)
+            std::vector<float> ft = low_pass(1, 24000, c.filter_width, c.filter_width, WIN_BLACKMAN_HARRIS);
+            if (m->dmr) { ft.assign(qrl_mod::kDmrHist + 1, 0.0f); ft.back() = 1.0f; }
             m->m17_nf = (int)ft.size();
             if ((r0 = upload(ft, &m->m17_filt))) return r0;
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->m17_flt), (size_t)c.batch * cap1 * sizeof(float2)));
@@ -307,6 +318,24 @@ int qrl_mod_set_carrier_offset(qrl_mod* m, double hz)
     return m->set_rot(hz);
 }
 int qrl_mod_set_bb_gain(qrl_mod* m, float g) { if (!m) return QRL_ERR_ARG; m->bb_gain = g; return QRL_OK; }
+int qrl_mod_add_zero_runs(qrl_mod* m, const qrl_zero_run* runs, size_t n)
+{
+    if (!m || (!runs && n)) return QRL_ERR_ARG;
+    if (!m->dmr) return qrl_set_error(QRL_ERR_ARG, "qrl_mod_add_zero_runs: QRL_MODEM_DMR handles only (gr_mod_dmr is the one modulator with a gr_zero_idle_bursts)");
+    for (size_t i = 0; i < n; ++i) {
+        if (runs[i].stream < 0 || runs[i].stream >= m->cfg.batch) return qrl_set_error(QRL_ERR_ARG, "zero run: stream out of range");
+        if (runs[i].start < qrl_mod::kDmrTagDelay) continue;                            // `tag.offset == nitems + i + _delay` has no item to match (gr_zero_idle_bursts.cpp:64)
+        // the counter is loaded at OUTPUT item T - delay; one counter per stream, a later tag overwrites it (as qrl_synth_add_zero_runs)
+        ZeroRun z{(uint32_t)runs[i].stream, 0u, runs[i].start - qrl_mod::kDmrTagDelay, runs[i].count};
+        for (ZeroRun& o : m->zero_runs) {
+            if (o.row != z.row) continue;
+            if (o.start < z.start && o.start + o.count > z.start) o.count = z.start - o.start;
+            else if (z.start < o.start && z.start + z.count > o.start) z.count = o.start - z.start;
+        }
+        m->zero_runs.push_back(z);
+    }
+    return QRL_OK;
+}
 size_t qrl_mod_samples_per_block(const qrl_mod* m, size_t* bytes_per_block)
 {
     if (!m) return 0;
@@ -363,7 +392,28 @@ int qrl_mod_process(qrl_mod* m, const uint8_t* bytes, size_t stride, size_t nbyt
         launch_tx_fm(fp, B, m->stream);                                                 // _fm_modulator
         RingC flt{m->m17_flt, m->r1_mask};
         FirCcfParams cf{}; cf.in = fp.out; cf.out = flt; cf.q0 = n24; cf.count = c24; cf.taps = m->m17_filt; cf.nt = m->m17_nf;
-        launch_fir_ccf(cf, B, m->stream);                                               // _filter
+        launch_fir_ccf(cf, B, m->stream);                                               // _filter (gr_mod_dmr: the history delay of _zero_idle)
+        if (m->dmr && !m->zero_runs.empty()) {                                          // _zero_idle: the tagged runs of this call's items
+            const uint64_t lo = n24, hi = n24 + c24;
+            std::vector<ZeroRun> live, keep;
+            for (const ZeroRun& z : m->zero_runs) {
+                if (z.start < hi && z.start + z.count > lo) live.push_back(z);
+                if (z.start + z.count > hi) keep.push_back(z);
+            }
+            if (!live.empty()) {
+                if (live.size() > m->zero_dev_cap) {
+                    HIPCHK(hipStreamSynchronize(m->stream));
+                    if (m->zero_dev) (void)hipFree(m->zero_dev);
+                    m->zero_dev = nullptr; m->zero_dev_cap = 0;
+                    HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->zero_dev), live.size() * 2 * sizeof(ZeroRun)));
+                    m->zero_dev_cap = live.size() * 2;
+                }
+                HIPCHK(hipMemcpyAsync(m->zero_dev, live.data(), live.size() * sizeof(ZeroRun), hipMemcpyHostToDevice, m->stream));
+                HIPCHK(hipStreamSynchronize(m->stream));                                // (`live` is pageable host memory: the copy has left it)
+                launch_zero_runs(flt, m->zero_dev, (uint32_t)live.size(), lo, hi, m->stream);
+            }
+            m->zero_runs.swap(keep);
+        }
         launch_scale_c(flt, n24, c24, 0.9f, B, m->stream);                              // _amplify
         launch_scale_c(flt, n24, c24, m->bb_gain, B, m->stream);                        // _bb_gain
         TxInterpCParams ip{}; ip.in = flt; ip.n0 = n24 / 3 * 125; ip.count = cout; ip.taps = m->taps; ip.nt = m->nt; ip.interp = 125; ip.decim = 3;

@@ -239,12 +239,15 @@ void gr_demod_base_hip::work(const gr_complex* const* iq, size_t n)
     // slot `cur` was last used by call k - 2, which work(k - 1) has harvested: its buffers are free
     for (int s = 0; s < d_n; ++s) std::memcpy(sl.h_iq + (size_t)s * d_chunk, iq[s], n * sizeof(gr_complex));
     hipStream_t hs = static_cast<hipStream_t>(qrl_demod_stream(d_h)), cs = static_cast<hipStream_t>(d_copy);
-    hchk(hipMemcpyAsync(sl.d_iq, sl.h_iq, (size_t)d_n * d_chunk * sizeof(gr_complex), hipMemcpyHostToDevice, hs), "H2D");
     if (!d_demod_on) {                                           // _demod_valve closed (gr_demod_base.cpp:1150-1153): only the spectrum tap, which sits in front of it
+        // everything of this call on the spectrum block's own stream (d_copy): the upload, the FFT fill behind it, and the host waits for THAT
+        // stream before the slot is reused (the upload used to go on the demodulator's stream, which nothing ordered the FFT behind)
+        hchk(hipMemcpyAsync(sl.d_iq, sl.h_iq, (size_t)d_n * d_chunk * sizeof(gr_complex), hipMemcpyHostToDevice, cs), "H2D");
         chk(qrl_fft_process(d_fft, sl.d_iq, d_chunk, n), "qrl_fft_process");
-        hchk(hipStreamSynchronize(hs), "hipStreamSynchronize");  // (the slot's host buffer is reused by the call after next; no harvest belongs to this call)
+        hchk(hipStreamSynchronize(cs), "hipStreamSynchronize");  // (d_calls does not advance: the next call takes the same slot; no harvest belongs to this call)
         return;
     }
+    hchk(hipMemcpyAsync(sl.d_iq, sl.h_iq, (size_t)d_n * d_chunk * sizeof(gr_complex), hipMemcpyHostToDevice, hs), "H2D");
     if (d_mode == QRL_MODEM_DMR) chk(qrl_demod_set_dmo_output(d_h, sl.d_dmo, kDmoCap, sl.d_dmocnt), "qrl_demod_set_dmo_output");
     sl.scoped = d_scope_on;
     chk(qrl_demod_set_time_domain_output(d_h, d_scope_on ? sl.d_scope : nullptr, d_scap, d_scope_on ? sl.d_scnt : nullptr), "qrl_demod_set_time_domain_output");

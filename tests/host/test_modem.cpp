@@ -157,6 +157,44 @@ int main(int argc, char** argv)
             return res[0][2] == res[1][2] && res[0][2] > 0 ? 0 : 3;
         } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
     }
+    if (argc == 3 && !strcmp(argv[1], "valveoff")) {
+        // test_modem valveoff <streams>: enable_demodulator(false) + enable_gui_fft(true) -- only the spectrum tap listens (gr_demod_base.cpp:1150-1153).
+        // Every call carries a tone at a DIFFERENT frequency; the spectrum polled after a call must peak at THAT call's tone (a spectrum of stale
+        // or half-uploaded samples peaks at the previous call's).  Prints one line per call: expected bin, peak bin.
+        const int N = atoi(argv[2]);
+        try {
+            qrl_runtime rt(0);
+            const size_t chunk = 1 << 15;
+            gr_demod_base_hip demod(rt, N, 1000000, 0.0, chunk);
+            demod.set_mode(QRL_MODEM_2FSK1K);
+            demod.set_fft_size(4096);
+            demod.enable_gui_fft(true);
+            demod.enable_demodulator(false);
+            std::vector<std::vector<gr_complex>> x(N, std::vector<gr_complex>(chunk));
+            std::vector<float> spectrum(4096);
+            int bad = 0;
+            for (int k = 0; k < 12; ++k) {
+                const int bin = 300 + 290 * k;                       // cycles per 4096 samples
+                for (int s = 0; s < N; ++s)
+                    for (size_t i = 0; i < chunk; ++i) { const double ph = 2 * M_PI * (double)((long)((bin + s) * i) % 4096) / 4096.0; x[s][i] = gr_complex(0.1f * (float)std::cos(ph), 0.1f * (float)std::sin(ph)); }
+                std::vector<const gr_complex*> in(N);
+                for (int s = 0; s < N; ++s) in[s] = x[s].data();
+                demod.work(in.data(), chunk);
+                for (int s = 0; s < N; ++s) {
+                    unsigned got = 4096;
+                    if (s == 0) demod.get_FFT_data(spectrum.data(), got, 0);          // fetches the frame of every stream ...
+                    else if (const float* p = demod.last_FFT_data(s)) std::copy(p, p + 4096, spectrum.begin());   // ... the others read it from there
+                    else got = 0;
+                    if (got != 4096) { std::printf("call %d stream %d: no spectrum\n", k, s); ++bad; continue; }
+                    int pk = 0; for (int i = 1; i < 4096; ++i) if (spectrum[i] > spectrum[pk]) pk = i;
+                    const int want = (bin + s + 2048) % 4096;        // half swap: DC in the middle
+                    std::printf("call %d stream %d: want %d peak %d (%.1f dB)\n", k, s, want, pk, spectrum[pk]);
+                    if (std::abs(pk - want) > 1) ++bad;
+                }
+            }
+            return bad ? 3 : 0;
+        } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+    }
     if (argc != 6 || strcmp(argv[1], "loopback")) { std::fprintf(stderr, "usage: test_modem loopback modem_type streams frames out.txt\n"); return 2; }
     const int mode = atoi(argv[2]), N = atoi(argv[3]), nframes = atoi(argv[4]);
     try {

@@ -789,6 +789,18 @@ def mod_m17(data, sps=125, samp_rate=1000000, filter_width=9000, bb_gain=1.0):
     return y[:m]
 
 
+def mod_dmr(data, sps=125, samp_rate=1000000, filter_width=5000, bb_gain=1.0, zero_runs=None):
+    """gr_mod_dmr; zero_runs = [(T, count), ...] tags at the zero-idle block's 24 ksps input"""
+    data = np.ascontiguousarray(data, np.uint8)
+    lib.orc_mod_dmr.restype = C.c_size_t
+    zr = np.zeros((0, 3), np.uint64) if not zero_runs else np.ascontiguousarray([[0, t, c] for t, c in zero_runs], np.uint64)
+    args = (_ptr(data), C.c_size_t(data.size), sps, samp_rate, filter_width, C.c_float(bb_gain), _ptr(zr) if zr.size else None, C.c_size_t(zr.shape[0]))
+    n = lib.orc_mod_dmr(*args, None)
+    y = np.zeros(max(n, 1), cf32)
+    m = lib.orc_mod_dmr(*args, _ptr(y))
+    return y[:m]
+
+
 def mod_ssb(audio, sb=0, sps=125, samp_rate=1000000, filter_width=2700, bb_gain=1.0):
     audio = np.ascontiguousarray(audio, np.float32)
     lib.orc_mod_ssb.restype = C.c_size_t

@@ -268,3 +268,12 @@ def test_facade_rx_events_equal_the_reference_gr_modem(tmp_path, mode, streams, 
     for s in range(streams):
         assert facade[s] == reference[s], s
     assert sum(len(f) for f in facade) >= streams      # something was received (the loopback tests say what)
+
+
+def test_facade_spectrum_with_the_demodulator_valve_closed():
+    """enable_demodulator(false) + enable_gui_fft(true): only the spectrum tap listens (gr_demod_base.cpp:1150-1153).  Twelve calls, each a tone
+    at a different frequency per stream: the spectrum polled after a call must peak at THAT call's tone -- the upload, the FFT and the
+    host's wait are on one stream (the FFT used to run on a stream nothing ordered behind the upload)."""
+    r = subprocess.run([EXE, "valveoff", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("want") == 36

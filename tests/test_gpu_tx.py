@@ -452,3 +452,52 @@ def test_dsss_tx_rx_loopback_on_gpu(qrl_ctx):
     dem.close()
     want = "".join(map(str, np.unpackbits(data)[20:100]))
     assert any(want in "".join(map(str, out[p][0])) for p in ("bits_a", "bits_b"))
+
+
+# ---- DMR modulator (gr_mod_dmr): raw dibits, 2500 samples per 3 bytes, gr_zero_idle_bursts(62) in the chain
+@pytest.mark.parametrize("chunk", [264, 33, 3])
+def test_dmr_modulator_bit_exact(qrl_ctx, chunk):
+    """QRL_MODEM_DMR TX against the oracle's gr_mod_dmr chain (src/gr/gr_mod_dmr.cpp:26-90), in one call and in ragged calls, without and with
+    "zero_samples" tags -- runs that straddle call boundaries, overlap (the later tag ends the earlier run), lie in the first 62 items (no
+    item to match) or reach past the end"""
+    import torch
+    import qradiolink_amd as q
+    rng = np.random.default_rng(16)
+    nb = 264                                          # 8 DMR bursts of 33 bytes: 5280 items at 24 ksps
+    data = rng.integers(0, 256, (2, nb), dtype=np.uint8)
+    tags = {0: [(30, 100), (1500, 720), (2000, 50), (2635, 12), (5200, 400)], 1: [(1439 + 62, 1320)]}
+    for with_tags in (False, True):
+        mod = q.Mod(qrl_ctx, q.MODEM_DMR, batch=2, max_bytes=nb, bb_gain=0.9)
+        assert mod.spb == 0 and mod.spblock == 2500 and mod.bytes_per_block == 3
+        if with_tags:
+            mod.add_zero_runs([(s, t, c) for s, l in tags.items() for t, c in l])
+        parts = [mod.process(torch.from_numpy(np.ascontiguousarray(data[:, s:s + chunk])).cuda()).cpu().numpy() for s in range(0, nb, chunk)]
+        got = np.concatenate(parts, axis=1)
+        mod.close()
+        assert got.shape == (2, nb // 3 * 2500)
+        for b in range(2):
+            want = orc.mod_dmr(data[b], bb_gain=0.9, zero_runs=tags[b] if with_tags else None)
+            g, w = got[b].view(np.float32) + np.float32(0), want.view(np.float32) + np.float32(0)
+            assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), "stream %d differs (tags %s)" % (b, with_tags)
+    # the tagged stretch is silence at the output: the tag at 1500 zeroes items 1438 ... until the tag at 2000 reloads the counter with 50 (item
+    # 1938): the signal is back from item 1988 on (x 125 / 3 at 1 Msps; 60 items of margin for the interpolator's span)
+    w = orc.mod_dmr(data[0], bb_gain=0.9, zero_runs=tags[0])
+    lo, hi = (1438 + 60) * 125 // 3, (1988 - 60) * 125 // 3
+    assert np.abs(w[lo:hi]).max() < 1e-3 and np.abs(w[hi + 6000:hi + 12000]).mean() > 0.3
+
+
+def test_dmr_tx_rx_dibit_loopback_on_gpu(qrl_ctx):
+    """bytes -> gr_mod_dmr -> gr_demod_dmr: the dibits that went in come out of the receiver's symbol port (device TX, device RX)"""
+    import torch
+    import qradiolink_amd as q
+    rng = np.random.default_rng(17)
+    data = rng.integers(0, 256, 330, dtype=np.uint8)
+    mod = q.Mod(qrl_ctx, q.MODEM_DMR, batch=1, max_bytes=330)
+    iq = (mod.process(torch.from_numpy(data[None, :]).cuda()) * 0.05).contiguous()
+    mod.close()
+    dem = q.Demod(qrl_ctx, q.MODEM_DMR, batch=1, max_chunk=iq.shape[1])
+    out = q.collect(dem, iq, iq.shape[1])
+    dem.close()
+    got = "".join(map(str, out["bits_a"][0]))
+    want = "".join(map(str, np.unpackbits(data)[1200:1900]))   # (the chain is ~ 320 symbols late: gr_zero_idle_bursts alone 1439 items = 288 symbols)
+    assert want in got

@@ -137,6 +137,26 @@ def test_zero_idle_bursts_oracle_equals_the_reference_block(ref):
     assert np.count_nonzero(want == 0) == 720 + (100 + 50) + 10 + (720 + 720) + 1 + 10   # [100,820) [900,1000)->[1000,1050) [5000,5010) ... [19990,20000)
 
 
+def test_zero_idle_bursts_with_delay_oracle_equals_the_reference_block(ref):
+    """gr_zero_idle_bursts(delay = 62), the form gr_mod_dmr builds (src/gr/gr_mod_dmr.cpp:57,63): the history of 2 x 720 items delays the stream
+    by 1439 items, a tag at offset T zeroes the OUTPUT items T - 62 ...; a tag in the first 62 items has no item to match.  One work() call over
+    the whole stream (across calls the reference misses tags within the first `delay` items of a call's window: not restated)."""
+    rng = np.random.default_rng(7)
+    n = 12000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    offs = np.array([30, 62, 500, 1200, 1230, 4000, 11990], np.uint64)
+    cnts = np.array([10, 5, 720, 100, 3, 1320, 500], np.uint64)
+    runs = np.stack([np.zeros_like(offs), offs, cnts], axis=1).astype(np.uint64)
+    for delay in (62, 0):
+        want, got = np.zeros_like(x), np.zeros_like(x)
+        orc.lib.orc_zero_idle_bursts_delay(P(x), C.c_size_t(n), C.c_uint(delay), P(np.ascontiguousarray(runs)), C.c_size_t(offs.size), P(want))
+        ref.ref_zero_idle_bursts_delay(P(x), C.c_size_t(n), C.c_uint(delay), P(offs), P(cnts), C.c_size_t(offs.size), P(got))
+        assert np.array_equal(got, want), delay
+    # delay 62: the stream itself is 1439 items late; the tag at 62 zeroes items 0..4 (already zero), the one at 4000 items 3938..5257
+    orc.lib.orc_zero_idle_bursts_delay(P(x), C.c_size_t(n), C.c_uint(62), P(np.ascontiguousarray(runs)), C.c_size_t(offs.size), P(want))
+    assert np.array_equal(want[5258:5300], x[5258 - 1439:5300 - 1439]) and not want[3938:5258].any() and want[3937] == x[3937 - 1439]
+
+
 def test_dsss_decoder_oracle_equals_the_reference_block(ref):
     """gr::dsss::dsss_decoder_cc_impl.cc itself (FIR kernel and RRC design supplied by gr_stub with the oracle's summation order):
     matched-filter taps, window positions (set_history(325): the windows of output I start at 325 (I - 2) + 1 + j), first-maximum

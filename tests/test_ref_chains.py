@@ -445,6 +445,16 @@ def test_mod_m17():
             x=np.arange(48, dtype=np.uint8))
 
 
+def test_mod_dmr():
+    """gr_mod_dmr (src/gr/gr_mod_dmr.cpp:26-90, instance make_gr_mod_dmr() gr_mod_base.cpp:207): the M17 modulator's shape with the DMR pulse
+    (RRC(5, 24000, 4800, 0.2, 125)), deviation pi 4800 0.85 / 24000, gr_zero_idle_bursts in the place of the channel filter (the fft_filter_ccf
+    the constructor creates is not connected) and the low_pass_2 125 / 3 interpolator at the make() default width 5000"""
+    compare("mod_dmr", (), orc.mod_dmr, dict(),
+            [UNPACK, "blocks::pack_k_bits_bb(2)", "digital::map_bb([2,3,1,0])", "digital::chunks_to_symbols_bf([-1.5,-0.5,0.5,1.5])",
+             "blocks::multiply_const_ff(0.66666665999999997,1)", "custom::gr_zero_idle_bursts()", "blocks::multiply_const_cc(0.90000000000000002,1)", BB1],
+            x=np.arange(48, dtype=np.uint8))
+
+
 @pytest.mark.parametrize("fw", [2500, 5000])
 def test_mod_nbfm(fw):
     rng = np.random.default_rng(2)
