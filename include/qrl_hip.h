@@ -463,7 +463,7 @@ uint64_t qrl_phase_inc_to_turn(double radians_per_sample);
  * src/gr/gr_mod_nbfm.cpp:19-77, instances gr_mod_base.cpp:171-172) for `batch` independent radios.  audio: device f32 at 8 ksps,
  * stream b at audio + b * stride, n samples per call (a multiple of 4, <= max_samples); iq: device cf32 at 1 Msps, stream b at
  * iq + 2 * b * out_stride floats, n * qrl_amod_samples_per_sample() (= 125 n) samples.  Asynchronous on the handle's stream;
- * results are independent of how the audio is cut into calls.  (AM modulator, CTCSS: not built.) */
+ * results are independent of how the audio is cut into calls.   */
 typedef struct qrl_amod qrl_amod;
 typedef struct qrl_amod_config {
     int modem_type;        /* QRL_MODEM_NBFM2500 | QRL_MODEM_NBFM5000 | QRL_MODEM_USB2500 | QRL_MODEM_LSB2500 */
@@ -476,6 +476,12 @@ int qrl_amod_create(qrl_ctx* ctx, const qrl_amod_config* cfg, qrl_amod** out);
 void qrl_amod_destroy(qrl_amod* m);
 int qrl_amod_reset(qrl_amod* m);
 int qrl_amod_set_bb_gain(qrl_amod* m, float value);
+/* replaces gr_mod_nbfm::set_ctcss(value) (src/gr/gr_mod_nbfm.cpp:101-140; gr_mod_base::set_ctcss :872-877 forwards to both NBFM instances):
+ * tone_hz != 0: _audio_amplify 0.85, the audio filter becomes band_pass_2(1, 8000, 300, 3500, 200, 35, BH) and analog::sig_source_f(8000,
+ * GR_COS_WAVE, tone, 0.15) is added to the audio in front of the pre-emphasis; 0: the low-pass again and _audio_amplify 0.98 (sic: the
+ * constructor's 0.99 does not come back).  Takes effect with the next qrl_amod_process call; the tone's phase runs over the samples produced
+ * while it is on.  NBFM handles only.  [The tone source is GNU Radio's fixed-point NCO with its 1024-row sine table, restated from memory.] */
+int qrl_amod_set_ctcss(qrl_amod* m, float tone_hz);
 size_t qrl_amod_samples_per_sample(const qrl_amod* m);
 /* SSB (replaces make_gr_mod_ssb(125, 1000000, 1700, 2700, sb), reference src/gr/gr_mod_ssb.cpp:19-82, gr_mod_base.cpp:178-179): the
  * cessb stretcher emits whole chunks of 1024 audio-rate items and looks two items ahead, so a call returns 125 x (chunks completed

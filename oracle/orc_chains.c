@@ -294,13 +294,59 @@ void orc_preemph_taps(int sample_rate, double tau, double a[2], double b[2])
     b[0] = g * b0 * 1.0; b[1] = g * b0 * -z1;
     a[0] = 1.0;          a[1] = -p1;
 }
+/* analog::sig_source_f(fs, GR_COS_WAVE, freq, ampl) [GR-MEM: gr-analog/lib/sig_source_impl.cc, gnuradio-runtime fxpt_nco.h / fxpt.h /
+ * sine_table.h -- restated from memory, the least certain entry of the appendix]: a 32-bit fixed-point phase accumulator,
+ *   inc = (int32)(x 2^31 / pi) with x = (float)(2 pi freq / fs) (float arithmetic, truncated),  out[k] = (float)(cos_fx(k inc) * ampl),
+ *   cos_fx(p): u = p + 0x40000000; row = u >> 22; table[row][0] * (float)(u >> 1) + table[row][1]   (two float roundings),
+ * a 1024-row table of float (slope, intercept) pairs of the piecewise-linear sine over x' = u >> 1 in [0, 2^31): slope the secant's,
+ * intercept the mean of the secant's and the one through the segment's midpoint (gen_sine_table.py).  k0 = index of the first sample. */
+void orc_fxpt_sine_table(float* tab /* 1024 x 2 */)
+{
+    for (int i = 0; i < 1024; i++) {
+        const double a = (double)i * 2097152.0, b = (double)(i + 1) * 2097152.0, w = M_PI / 1073741824.0;
+        const double fa = sin(a * w), fb = sin(b * w), fm = sin((a + b) / 2 * w);
+        const double m = (fb - fa) / (b - a);
+        const double c = (3 * a + b) * (fa - fb) / (4 * (b - a)) + (fm + fa) / 2;
+        tab[2 * i] = (float)m; tab[2 * i + 1] = (float)c;
+    }
+}
+uint32_t orc_fxpt_phase_inc(double fs, double freq)
+{
+    float x = (float)(2 * M_PI * freq / fs);                                      /* set_freq(float angle_rate) */
+    const float PI_F = (float)M_PI;
+    const int d = (int)floorf(x / 2 / PI_F + 0.5f);
+    x -= d * 2 * PI_F;
+    return (uint32_t)(int32_t)(x * 2147483648.0f / PI_F);
+}
+void orc_sig_source_cos(double fs, double freq, double ampl, uint64_t k0, size_t n, float* out)
+{
+    static float tab[2048]; static int have = 0;
+    if (!have) { orc_fxpt_sine_table(tab); have = 1; }
+    const uint32_t inc = orc_fxpt_phase_inc(fs, freq);
+    for (size_t k = 0; k < n; k++) {
+        const uint32_t u = (uint32_t)((k0 + k) * (uint64_t)inc) + 0x40000000u;
+        const float v = tab[2 * (u >> 22)] * (float)(u >> 1) + tab[2 * (u >> 22) + 1];
+        out[k] = (float)((double)v * ampl);
+    }
+}
+/* gr_mod_nbfm::set_ctcss(value) (src/gr/gr_mod_nbfm.cpp:101-140) for the NEXT orc_mod_nbfm calls: tone > 0: _audio_amplify 0.85, the audio
+ * filter a band-pass band_pass_2(1, 8000, 300, 3500, 200, 35, BH), sig_source_f(8000, GR_COS_WAVE, tone, 0.15) added in front of the
+ * pre-emphasis; tone < 0: set_ctcss(0) after it had been on -- the low-pass again, but _audio_amplify 0.98 (:106; the constructor's is 0.99);
+ * 0: the constructor's graph. */
+static float g_tx_ctcss = 0.0f;
+void orc_set_tx_ctcss(float tone_hz) { g_tx_ctcss = tone_hz; }
 size_t orc_mod_nbfm(const float* audio, size_t n, int sps, int samp_rate, int filter_width, float bb_gain, cf32* out)
 {
     const size_t n50 = orc_decim_count(n, 25, 4);
     if (!out) return n50 * (size_t)sps;
-    int na = orc_low_pass_2(1, 8000, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    const int tone_on = g_tx_ctcss > 0.0f;
+    const float k_audio = tone_on ? 0.85f : (g_tx_ctcss < 0.0f ? 0.98f : 0.99f);
+    int na = tone_on ? orc_band_pass_2(1, 8000, 300, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, NULL) : orc_low_pass_2(1, 8000, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, NULL);
     float* at = NEW(float, na);
-    orc_low_pass_2(1, 8000, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, at);
+    if (tone_on) orc_band_pass_2(1, 8000, 300, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, at);
+    else orc_low_pass_2(1, 8000, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, at);
+    float* tone = NEW(float, n + 1);
+    if (tone_on) orc_sig_source_cos(8000, (double)g_tx_ctcss, 0.15, 0, n, tone);
     float* a1 = NEW(float, n);
     orc_fir_fff(audio, n, at, na, a1);                                           /* _audio_filter */
     free(at);
@@ -310,7 +356,8 @@ size_t orc_mod_nbfm(const float* audio, size_t n, int sps, int samp_rate, int fi
     {   /* _audio_amplify, _pre_emph_filter: acc = b0 x + b1 x[-1] - a1 y[-1] in double, y kept in double */
         float xp = 0.0f; double yp = 0.0;
         for (size_t i = 0; i < n; i++) {
-            const float x = a1[i] * 0.99f;
+            float x = a1[i] * k_audio;
+            if (tone_on) x = x + tone[i];                                         /* _add (add_ff) */
             double acc = tb[0] * (double)x;
             acc += tb[1] * (double)xp;
             acc += -ta[1] * yp;
@@ -323,7 +370,7 @@ size_t orc_mod_nbfm(const float* audio, size_t n, int sps, int samp_rate, int fi
     orc_low_pass_2(25, 50000.0 * 4, filter_width, 3500, 60, ORC_WIN_BLACKMAN_HARRIS, it);
     float* r = NEW(float, n50);
     orc_resamp_fff(a1, n, it, ni, 25, 4, r);                                     /* _if_resampler */
-    free(it); free(a1);
+    free(it); free(a1); free(tone);
     cf32* fmv = NEW(cf32, n50);
     fm_mod(r, n50, (float)(4 * M_PI * filter_width / 50000.0f), fmv);            /* _fm_modulator */
     free(r);

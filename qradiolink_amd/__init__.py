@@ -107,6 +107,7 @@ def load_library():
     lib.qrl_amod_destroy.restype = None
     lib.qrl_amod_reset.argtypes = [vp]
     lib.qrl_amod_set_bb_gain.argtypes = [vp, C.c_float]
+    lib.qrl_amod_set_ctcss.argtypes = [vp, C.c_float]
     lib.qrl_amod_samples_per_sample.argtypes = [vp]
     lib.qrl_amod_samples_per_sample.restype = sz
     lib.qrl_amod_last_count.argtypes = [vp]
@@ -221,7 +222,7 @@ EXPORTED_SYMBOLS = [
     "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_set_option", "qrl_demod_set_dmo_output", "qrl_demod_stream_wait", "qrl_demod_out_caps",
     "qrl_demod_audio_cap", "qrl_demod_set_squelch", "qrl_demod_set_agc", "qrl_demod_set_ctcss", "qrl_demod_time_domain_cap", "qrl_demod_set_time_domain_output",
     "qrl_bptc19696_decode", "qrl_bptc19696_encode", "qrl_m17_decode_frames", "qrl_m17_encode_frames",
-    "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
+    "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_set_ctcss", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_internal_streams", "qrl_chan_internal_streams", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
     "qrl_mod_samples_per_byte", "qrl_mod_samples_per_block", "qrl_mod_add_zero_runs", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_set_option", "qrl_chan_channelize", "qrl_chan_process_channels", "qrl_chan_wait_for", "qrl_chan_stream_wait", "qrl_chan_stream", "qrl_chan_profile", "qrl_chan_profile_read", "qrl_chan_profile_read_kernels", "qrl_debug_decim_prof", "qrl_debug_decim_prof_enable", "qrl_chan_create",
@@ -872,6 +873,10 @@ class AMod:
 
     def set_bb_gain(self, g):
         _check(self.lib.qrl_amod_set_bb_gain(self.h, C.c_float(g)), "qrl_amod_set_bb_gain")
+
+    def set_ctcss(self, tone_hz):
+        """gr_mod_nbfm::set_ctcss: tone (Hz) added to the audio, band-pass audio filter; 0 switches it off again (qrl_amod_set_ctcss)"""
+        _check(self.lib.qrl_amod_set_ctcss(self.h, C.c_float(tone_hz)), "qrl_amod_set_ctcss")
 
     def reset(self):
         _check(self.lib.qrl_amod_reset(self.h), "qrl_amod_reset")

@@ -48,6 +48,8 @@ struct qrl_amod {
     Dev<float2> t_side, c1, c2, c3; int n_side = 0; Dev<float> atan_tab; uint64_t ns = 0; size_t last = 0;   // SSB
     float bb_gain = 1.0f, fm_k = 0.f;
     Dev<float> t_audio, t_if, t_filt, t_interp; int n_audio = 0, n_if = 0, n_filt = 0, n_interp = 0;
+    // gr_mod_nbfm::set_ctcss (src/gr/gr_mod_nbfm.cpp:101-140): band-pass audio filter, _audio_amplify 0.85 / 0.98, tone source + add_ff
+    Dev<float> t_audio_bp, tone_tab; int n_audio_bp = 0; float k_audio = 0.99f; float tone_hz = 0.0f; uint32_t tone_inc = 0; uint64_t tone_k = 0;
     Dev<float> a0, a1, a2, r50; uint32_t m8 = 0, m50 = 0;       // rings: audio in, filtered, pre-emphasised (8 ksps); 50 ksps
     Dev<float2> fmv, flt;                                        // 50 ksps complex: modulator out, channel filter out
     Dev<AmIirState> iir; Dev<float> phase;
@@ -66,7 +68,7 @@ struct qrl_amod {
             if (hipMemcpy(am_gain.p, one.data(), one.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
             n1m = 0;
         }
-        n8 = n50 = ns = 0; last = 0;
+        n8 = n50 = ns = 0; last = 0; tone_k = 0;
         return QRL_OK;
     }
 };
@@ -141,6 +143,18 @@ int qrl_amod_create(qrl_ctx* ctx, const qrl_amod_config* cfg, qrl_amod** outp)
     if (m->n_interp > 2048) return qrl_set_error(QRL_ERR_ARG, "amod: interpolator filter too long");
     int r;
     if ((r = m->t_audio.upload(ta)) || (r = m->t_if.upload(ti)) || (r = m->t_filt.upload(tf)) || (r = m->t_interp.upload(tr))) return r;
+    {   // set_ctcss(tone): the band-pass and the sine table of the tone source (oracle orc_fxpt_sine_table), ready for qrl_amod_set_ctcss
+        const std::vector<float> tb = band_pass_2(1, 8000, 300, 3500, 200, 35, WIN_BLACKMAN_HARRIS);        // gr_mod_nbfm.cpp:124-125
+        m->n_audio_bp = (int)tb.size();
+        std::vector<float> tab(2048);
+        for (int i = 0; i < 1024; ++i) {
+            const double a = (double)i * 2097152.0, b = (double)(i + 1) * 2097152.0, w = M_PI / 1073741824.0;
+            const double fa = std::sin(a * w), fb = std::sin(b * w), fm = std::sin((a + b) / 2 * w);
+            tab[2 * i] = (float)((fb - fa) / (b - a));
+            tab[2 * i + 1] = (float)((3 * a + b) * (fa - fb) / (4 * (b - a)) + (fm + fa) / 2);
+        }
+        if ((r = m->t_audio_bp.upload(tb)) || (r = m->tone_tab.upload(tab))) return r;
+    }
     m->fm_k = (float)(4 * M_PI * fw / 50000.0f);                                                          // frequency_modulator_fc, :41
     preemph_taps(8000, 50e-6, m->pa, m->pb);                                                              // :39
     const size_t max50 = cfg->max_samples * 25 / 4 + 32;
@@ -161,6 +175,21 @@ int qrl_amod_reset(qrl_amod* m)
     return m->init_state();
 }
 int qrl_amod_set_bb_gain(qrl_amod* m, float g) { if (!m) return QRL_ERR_ARG; m->bb_gain = g; return QRL_OK; }
+int qrl_amod_set_ctcss(qrl_amod* m, float tone_hz)
+{
+    if (!m) return QRL_ERR_ARG;
+    if (m->ssb || m->am) return qrl_set_error(QRL_ERR_ARG, "qrl_amod_set_ctcss: NBFM modulators only (gr_mod_base::set_ctcss forwards to the two gr_mod_nbfm instances)");
+    if (tone_hz < 0.0f || tone_hz > 300.0f) return qrl_set_error(QRL_ERR_ARG, "qrl_amod_set_ctcss: tone out of range");
+    if (tone_hz == 0.0f) { m->k_audio = 0.98f; m->tone_hz = 0.0f; return QRL_OK; }      // gr_mod_nbfm.cpp:104-108 (0.98, not the constructor's 0.99)
+    m->k_audio = 0.85f; m->tone_hz = tone_hz;                                             // :122-126
+    // sig_source_f::set_frequency -> fxpt_nco::set_freq((float)(2 pi f / fs)) -> float_to_fixed (oracle orc_fxpt_phase_inc)
+    float x = (float)(2 * M_PI * (double)tone_hz / 8000.0);
+    const float PI_F = (float)M_PI;
+    const int d = (int)std::floor(x / 2 / PI_F + 0.5f);
+    x -= d * 2 * PI_F;
+    m->tone_inc = (uint32_t)(int32_t)(x * 2147483648.0f / PI_F);
+    return QRL_OK;
+}
 size_t qrl_amod_samples_per_sample(const qrl_amod* m) { return m ? ((m->ssb || m->am) ? (size_t)m->sps : (size_t)25 * m->sps / 4) : 0; }
 size_t qrl_amod_last_count(const qrl_amod* m) { return m ? m->last : 0; }
 size_t qrl_amod_out_cap(const qrl_amod* m, size_t n) { return m ? (m->am ? n * (size_t)m->sps : m->ssb ? (n + 1024) * (size_t)m->sps : n * 25 / 4 * (size_t)m->sps) : 0; }
@@ -236,9 +265,11 @@ int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, f
     const uint32_t c8 = (uint32_t)n, c50 = (uint32_t)(n * 25 / 4);
     AmLoadParams lp{}; lp.in = audio; lp.in_stride = stride; lp.out = a0; lp.n0 = m->n8; lp.count = c8;
     launch_am_load(lp, B, s);
-    FirFffParams af{}; af.in = a0; af.out = a1; af.q0 = m->n8; af.count = c8; af.taps = m->t_audio.p; af.nt = m->n_audio;
-    launch_fir_fff(af, B, s);                                                       // _audio_filter
-    AmIirParams ip{}; ip.in = a1; ip.out = a2; ip.n0 = m->n8; ip.count = c8; ip.gain = 0.99f;   // _audio_amplify, _pre_emph_filter
+    const bool tone_on = m->tone_hz > 0.0f;
+    FirFffParams af{}; af.in = a0; af.out = a1; af.q0 = m->n8; af.count = c8; af.taps = tone_on ? m->t_audio_bp.p : m->t_audio.p; af.nt = tone_on ? m->n_audio_bp : m->n_audio;
+    launch_fir_fff(af, B, s);                                                       // _audio_filter (set_ctcss(tone): the band-pass)
+    AmIirParams ip{}; ip.in = a1; ip.out = a2; ip.n0 = m->n8; ip.count = c8; ip.gain = m->k_audio;   // _audio_amplify, [_add tone], _pre_emph_filter
+    if (tone_on) { ip.tone_tab = m->tone_tab.p; ip.tone_inc = m->tone_inc; ip.tone_k0 = m->tone_k; ip.tone_ampl = 0.15; m->tone_k += c8; }
     ip.ff0 = m->pb[0]; ip.ff1 = m->pb[1]; ip.fb1 = -m->pa[1]; ip.st = m->iir.p;
     launch_am_iir(ip, B, s);
     AnResampParams rp{}; rp.in = a2; rp.out = r50; rp.st = nullptr; rp.taps = m->t_if.p; rp.nt = m->n_if; rp.I = 25; rp.D = 4;

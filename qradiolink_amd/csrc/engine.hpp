@@ -337,7 +337,10 @@ void launch_am_carrier(RingF in, RingC out, uint64_t n0, uint32_t count, float c
 struct AmLoadParams { const float* in; size_t in_stride; RingF out; uint64_t n0; uint32_t count; };
 void launch_am_load(const AmLoadParams& p, int batch, hipStream_t s);
 struct AmIirState { double y1; float x1, pad; };
-struct AmIirParams { RingF in, out; uint64_t n0; uint32_t count; float gain; double ff0, ff1, fb1; AmIirState* st; };
+struct AmIirParams { RingF in, out; uint64_t n0; uint32_t count; float gain; double ff0, ff1, fb1; AmIirState* st;
+                     // gr_mod_nbfm::set_ctcss: add_ff(audio, sig_source_f(8000, GR_COS_WAVE, tone, 0.15)) in front of the filter -- the fixed-point NCO of
+                     // oracle/orc_chains.c orc_sig_source_cos: sample k (tone_k0 + t) = (float)(cos_fx(k * tone_inc) * tone_ampl); tone_tab == nullptr: no tone
+                     const float* tone_tab; uint32_t tone_inc; uint64_t tone_k0; double tone_ampl; };
 void launch_am_iir(const AmIirParams& p, int batch, hipStream_t s);
 // gr_mod_ssb: float_to_complex + cessb clipper (f32 ring -> complex ring), cessb stretcher with complex output over [q0, q0 + count)
 struct AmClipParams { RingF in; RingC out; uint64_t n0; uint32_t count; float clip; const float* atan_tab; };

@@ -354,7 +354,13 @@ __global__ __launch_bounds__(64) void k_am_iir(const AmIirParams P, int batch)
     float* out = P.out.p + (size_t)b * (P.out.mask + 1u);
     for (uint32_t t = 0; t < P.count; ++t) {
         const uint32_t n = (uint32_t)(P.n0 + t);
-        const float x = in[n & P.in.mask] * P.gain;
+        float x = in[n & P.in.mask] * P.gain;
+        if (P.tone_tab) {                                                         // _add: the CTCSS tone (sig_source_f, fixed-point NCO + 1024-row sine table)
+            const uint32_t u = (uint32_t)((P.tone_k0 + t) * (uint64_t)P.tone_inc) + 0x40000000u;
+            float v = P.tone_tab[2 * (u >> 22)] * (float)(u >> 1);
+            v = v + P.tone_tab[2 * (u >> 22) + 1];
+            x = x + (float)((double)v * P.tone_ampl);
+        }
         double acc = P.ff0 * (double)x;
         acc += P.ff1 * (double)st.x1;
         acc += P.fb1 * st.y1;

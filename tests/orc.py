@@ -759,14 +759,25 @@ def demod_analog(x, kind, samp_rate=1000000, filter_width=5000, ctcss=0.0):
     return dict(filtered=filt, audio=aud)
 
 
-def mod_nbfm(audio, sps=20, samp_rate=1000000, filter_width=5000, bb_gain=1.0):
+def mod_nbfm(audio, sps=20, samp_rate=1000000, filter_width=5000, bb_gain=1.0, ctcss=0.0):
+    """ctcss > 0: gr_mod_nbfm::set_ctcss(tone) was called; < 0: set_ctcss(0) after it had been on (x0.98); 0: the constructor's graph"""
     audio = np.ascontiguousarray(audio, np.float32)
     lib.orc_mod_nbfm.restype = C.c_size_t
     args = (_ptr(audio), C.c_size_t(audio.size), sps, samp_rate, filter_width, C.c_float(bb_gain))
-    n = lib.orc_mod_nbfm(*args, None)
-    y = np.zeros(n, cf32)
-    m = lib.orc_mod_nbfm(*args, _ptr(y))
+    lib.orc_set_tx_ctcss(C.c_float(ctcss))
+    try:
+        n = lib.orc_mod_nbfm(*args, None)
+        y = np.zeros(n, cf32)
+        m = lib.orc_mod_nbfm(*args, _ptr(y))
+    finally:
+        lib.orc_set_tx_ctcss(C.c_float(0.0))
     return y[:m]
+
+
+def sig_source_cos(fs, freq, ampl, n, k0=0):
+    out = np.zeros(n, np.float32)
+    lib.orc_sig_source_cos(C.c_double(fs), C.c_double(freq), C.c_double(ampl), C.c_uint64(k0), C.c_size_t(n), _ptr(out))
+    return out
 
 
 def mod_dsss(data, sps=25, samp_rate=1000000, filter_width=150, bb_gain=1.0):

@@ -501,3 +501,59 @@ def test_dmr_tx_rx_dibit_loopback_on_gpu(qrl_ctx):
     got = "".join(map(str, out["bits_a"][0]))
     want = "".join(map(str, np.unpackbits(data)[1200:1900]))   # (the chain is ~ 320 symbols late: gr_zero_idle_bursts alone 1439 items = 288 symbols)
     assert want in got
+
+
+# ---- TX-side CTCSS of gr_mod_nbfm (set_ctcss: tone source + add_ff, band-pass audio filter, x0.85)
+@pytest.mark.parametrize("chunk", [8000, 1000, 324])
+def test_nbfm_modulator_ctcss_bit_exact(qrl_ctx, chunk):
+    """qrl_amod_set_ctcss against the oracle's gr_mod_nbfm with set_ctcss(tone) (src/gr/gr_mod_nbfm.cpp:101-140): 88.5 Hz and the off-table
+    tone 81.5 Hz of the reference's tone list (src/ext/utils.h:17), in one call and in ragged calls; then set_ctcss(0) after it had been on:
+    the low-pass again, but _audio_amplify 0.98"""
+    import torch
+    import qradiolink_amd as q
+    n = 8000
+    audio = np.stack([0.5 * np.sin(2 * np.pi * 700 * np.arange(n) / 8000.0), np.random.default_rng(31).uniform(-0.7, 0.7, n)]).astype(np.float32)
+    for tone, oracle_arg in ((88.5, 88.5), (81.5, 81.5), (0.0, -1.0)):
+        mod = q.AMod(qrl_ctx, q.MODEM_NBFM5000, batch=2, max_samples=chunk, bb_gain=0.75)
+        mod.set_ctcss(88.5)
+        mod.set_ctcss(tone)
+        parts = [mod.process(torch.from_numpy(np.ascontiguousarray(audio[:, s:s + chunk])).cuda()).cpu().numpy() for s in range(0, n, chunk)]
+        mod.close()
+        got = np.concatenate(parts, axis=1)
+        for b in range(2):
+            want = orc.mod_nbfm(audio[b], filter_width=5000, bb_gain=0.75, ctcss=oracle_arg)
+            g, w = got[b].view(np.float32) + np.float32(0), want.view(np.float32) + np.float32(0)
+            assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), "tone %s stream %d differs" % (tone, b)
+    with pytest.raises(q.QrlError):
+        m = q.AMod(qrl_ctx, q.MODEM_USB2500, batch=1, max_samples=2048)
+        try:
+            m.set_ctcss(88.5)
+        finally:
+            m.close()
+
+
+def test_nbfm_ctcss_tx_opens_the_ctcss_squelch_of_the_receiver_on_gpu(qrl_ctx):
+    """gr_mod_nbfm with set_ctcss(88.5) -> gr_demod_nbfm with set_ctcss(88.5), both on the device: the receiver's tone squelch opens and the voice
+    tone comes out; the same transmission WITHOUT the sub-tone (or with another one, 123.0 Hz) keeps the audio path shut"""
+    import torch
+    import qradiolink_amd as q
+    n = 24000
+    audio = (0.5 * np.sin(2 * np.pi * 700 * np.arange(n) / 8000.0)).astype(np.float32)
+    rms = {}
+    for tx_tone in (88.5, 0.0, 123.0):
+        mod = q.AMod(qrl_ctx, q.MODEM_NBFM5000, batch=1, max_samples=n)
+        if tx_tone:
+            mod.set_ctcss(tx_tone)
+        iq = (mod.process(torch.from_numpy(audio[None, :]).cuda()) * 0.05).contiguous()
+        mod.close()
+        dem = q.Demod(qrl_ctx, q.MODEM_NBFM5000, batch=1, max_chunk=iq.shape[1])
+        dem.set_ctcss(88.5)
+        out = q.collect(dem, iq, iq.shape[1])
+        dem.close()
+        a = out["audio"][0].astype(np.float64)
+        rms[tx_tone] = float(np.sqrt(np.mean(a[-8000:] ** 2))) if a.size >= 8000 else 0.0
+        if tx_tone == 88.5:
+            seg = a[-8000:]
+            spec = np.abs(np.fft.rfft(seg * np.hanning(seg.size)))
+            assert abs(np.argmax(spec) * 8000.0 / seg.size - 700.0) < 3.0
+    assert rms[88.5] > 0.2 and rms[0.0] < 1e-3 and rms[123.0] < 1e-3, rms

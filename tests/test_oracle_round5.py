@@ -1,0 +1,54 @@
+"""Round 5 oracle additions on CPU: analog::sig_source_f as restated for the TX-side CTCSS of gr_mod_nbfm ([GR-MEM]: fixed-point NCO + 1024-row
+sine table), the NBFM modulator with set_ctcss, gr_mod_dmr with its zero-idle block."""
+import ctypes as C
+
+import numpy as np
+
+import orc
+
+
+def test_sig_source_cos_is_a_cosine_to_the_table_accuracy():
+    for fs, f, amp in ((8000.0, 88.5, 0.15), (8000.0, 81.5, 0.15), (8000.0, 250.3, 1.0)):
+        y = orc.sig_source_cos(fs, f, amp, 16000)
+        inc = orc.lib.orc_fxpt_phase_inc(C.c_double(fs), C.c_double(f))
+        # the NCO's own frequency: inc / 2^32 cycles per sample (the float conversion of 2 pi f / fs is truncated to the fixed-point grid)
+        k = np.arange(y.size, dtype=np.float64)
+        ref = amp * np.cos(2 * np.pi * ((k * inc) % 2 ** 32) / 2 ** 32)
+        assert np.max(np.abs(y - ref)) < 3e-6 * max(amp, 1.0) + 2e-7          # piecewise-linear table, 1024 rows: ~ (pi / 1024)^2 / 8 / 2 of the amplitude
+        assert abs(inc / 2 ** 32 * fs - f) < 1e-4                             # within the float grid of the angle rate
+        assert y[0] == np.float32(np.float64(np.float32(y[0] / amp)) * amp) or abs(y[0] - amp) < 1e-6
+
+
+def test_sig_source_cos_is_index_addressed():
+    a = orc.sig_source_cos(8000, 88.5, 0.15, 5000)
+    b = orc.sig_source_cos(8000, 88.5, 0.15, 3000, k0=2000)
+    assert np.array_equal(a[2000:], b)
+
+
+def test_nbfm_modulator_ctcss_variants():
+    n = 8000
+    audio = (0.5 * np.sin(2 * np.pi * 700 * np.arange(n) / 8000.0)).astype(np.float32)
+    plain = orc.mod_nbfm(audio)
+    tone = orc.mod_nbfm(audio, ctcss=88.5)
+    off = orc.mod_nbfm(audio, ctcss=-1.0)
+    assert plain.size == tone.size == off.size == 125 * n
+    assert not np.array_equal(plain, tone) and not np.array_equal(plain, off)
+    # the sub-tone is in the instantaneous frequency of the tone variant only: an 88.5 Hz line
+    def line(x, f):
+        ph = np.unwrap(np.angle(x[100000:900000:25].astype(np.complex128)))       # 40 ksps
+        d = np.diff(ph)
+        s = np.abs(np.fft.rfft((d - d.mean()) * np.hanning(d.size)))
+        k = int(round(f * d.size / 40000.0))
+        return s[k - 2:k + 3].max() / np.median(s[5:400])
+    assert line(tone, 88.5) > 50 and line(plain, 88.5) < 10
+
+
+def test_mod_dmr_shape_and_zero_runs():
+    data = (np.arange(198) * 37 % 251).astype(np.uint8)
+    y = orc.mod_dmr(data)
+    assert y.size == 198 // 3 * 2500
+    assert not y[:1439 * 125 // 3 - 2000].any()                                # the zero-idle block's history: 1439 items at 24 ksps of silence first
+    z = orc.mod_dmr(data, zero_runs=[(1439 + 62 + 100, 300)])
+    lo, hi = (1439 + 100 + 60) * 125 // 3, (1439 + 400 - 60) * 125 // 3
+    assert np.abs(z[lo:hi]).max() < 1e-3 and np.abs(y[lo:hi]).min() > 0.3
+    assert np.array_equal(z[:lo - 6000], y[:lo - 6000]) and np.array_equal(z[hi + 6000:], y[hi + 6000:])

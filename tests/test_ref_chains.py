@@ -463,6 +463,29 @@ def test_mod_nbfm(fw):
             x=(rng.standard_normal(800) * 0.1).astype(np.float32))
 
 
+def test_mod_nbfm_ctcss_blocks():
+    """gr_mod_nbfm creates _tone_source = sig_source_f(8000, GR_COS_WAVE, 88.5, 0.15) and _add = add_ff (:53-54) but leaves them unconnected until
+    set_ctcss(tone) (:101-140, not a constructor path): the blocks' constructor parameters are in the construction log, and what set_ctcss does
+    -- x0.85 / x0.98, band_pass_2(1, 8000, 300, 3500, 200, 35, BH), tone -> add -> pre-emphasis -- is checked against the source text and
+    against the oracle's trace of the tone variant."""
+    g = RefGraph(ref_log("mod_nbfm", 20, 1000000, 1700, 5000))
+    src_blk = [(b, a) for b, (k, a) in g.blocks.items() if k == "analog::sig_source_f"]
+    assert len(src_blk) == 1 and src_blk[0][0] not in g.connected
+    assert [norm_value(v) for v in src_blk[0][1][:4]] == [8000.0, norm_value(src_blk[0][1][1]), np.float32(88.5), np.float32(0.15)]
+    rng = np.random.default_rng(2)
+    x = (rng.standard_normal(800) * 0.1).astype(np.float32)
+    tr = [parse_call(l) for l in oracle_trace(lambda v: orc.mod_nbfm(v, filter_width=5000, ctcss=88.5), x)]
+    fir = [a for n_, a in tr if n_ == "fir_fff"]
+    assert any("band_pass_2(1,8000,300,3500,200,35," in a[0] for a in fir)
+    src = "/root/reference/src/gr/gr_mod_nbfm.cpp"
+    if os.path.exists(src):
+        text = open(src).read().replace(" ", "").replace("\n", "")
+        assert "_audio_amplify->set_k(0.85);_audio_filter->set_taps(gr::filter::firdes::band_pass_2(1,target_samp_rate,300,3500,200,35,gr::fft::window::WIN_BLACKMAN_HARRIS));" in text
+        assert "_tone_source->set_frequency(value);" in text and "_audio_amplify->set_k(0.98);" in text
+        assert "connect(_audio_amplify,0,_add,0);connect(_add,0,_pre_emph_filter,0);connect(_tone_source,0,_add,1);" in text
+        assert "sig_source_f::make(target_samp_rate,gr::analog::GR_COS_WAVE,88.5,0.15)" in text
+
+
 def test_mod_am():
     """gr_mod_am (src/gr/gr_mod_am.cpp:26-74, instance gr_mod_base.cpp:167): agc2_ff with set_max_gain(1), rail, audio band-pass, the
     frequency-0 carrier source added to the audio, 1:125 resampler, gains, the 4545-tap complex band-pass; the feedforward_agc_cc the
