@@ -19,19 +19,51 @@ import orc           # noqa: E402
 import make_golden   # noqa: E402
 
 NAMES = {0: "clip(u/2,1)", 1: "clip(u,1)/2", 2: "clip(u,1)"}
-out_dir, iq_dir = sys.argv[1], sys.argv[2]
-for name, mode, rate, offset, (kind, kw) in make_golden.CASES:
-    f1 = os.path.join(out_dir, name + ".port1")
-    if rate != 1000000 or not os.path.exists(f1) or kind not in ("2fsk", "gmsk", "qpsk", "4fsk"):
-        continue
-    real = np.fromfile(f1, np.complex64)
-    x = np.fromfile(os.path.join(iq_dir, name + ".cf32"), np.complex64)
-    which = "cc" if kind == "qpsk" or (kind == "4fsk" and not kw.get("fm", False)) else "ff"
-    for v in (0, 1, 2):
-        orc.lib.orc_set_ted_modmm(v if which == "ff" else -1, v if which == "cc" else -1)
-        got = getattr(orc, "demod_" + kind)(x, **kw)["constellation"]
-        n = min(got.size, real.size)
-        rms = np.sqrt(np.mean(np.abs(real[:n]) ** 2)) + 1e-30
-        off = np.nonzero(np.abs(got[:n] - real[:n]) / rms > 1e-5)[0]
-        print("%-14s symbol_sync_%s %-12s first symbol beyond 1e-5: %s of %d" % (name, which, NAMES[v], off[0] if off.size else "none", n))
-    orc.lib.orc_set_ted_modmm(-1, -1)
+
+
+def arbitrate(out_dir, iq_dir, only=None, out=sys.stdout):
+    """-> {(case, candidate): first symbol beyond 1e-5 of RMS, or None}"""
+    res = {}
+    for name, mode, rate, offset, (kind, kw) in make_golden.CASES:
+        f1 = os.path.join(out_dir, name + ".port1")
+        if rate != 1000000 or not os.path.exists(f1) or kind not in ("2fsk", "gmsk", "qpsk", "4fsk") or (only and name not in only):
+            continue
+        real = np.fromfile(f1, np.complex64)
+        x = np.fromfile(os.path.join(iq_dir, name + ".cf32"), np.complex64)
+        which = "cc" if kind == "qpsk" or (kind == "4fsk" and not kw.get("fm", False)) else "ff"
+        for v in (0, 1, 2):
+            orc.lib.orc_set_ted_modmm(v if which == "ff" else -1, v if which == "cc" else -1)
+            try:
+                got = getattr(orc, "demod_" + kind)(x, **kw)["constellation"]
+            finally:
+                orc.lib.orc_set_ted_modmm(-1, -1)
+            n = min(got.size, real.size)
+            rms = np.sqrt(np.mean(np.abs(real[:n]) ** 2)) + 1e-30
+            off = np.nonzero(np.abs(got[:n] - real[:n]) / rms > 1e-5)[0]
+            res[(name, v)] = int(off[0]) if off.size else None
+            print("%-14s symbol_sync_%s %-12s first symbol beyond 1e-5: %s of %d" % (name, which, NAMES[v], off[0] if off.size else "none", n), file=out)
+    return res
+
+
+def self_test(cases=("2fsk1k_1M", "qpsk250k_1M"), out=sys.stdout):
+    """Dry run without GNU Radio: the "real" port 1 is minted by the oracle under its own contract from the committed fixture inputs; the
+    contract's candidate must then stay within 1e-5 on every symbol and another candidate must leave it -- proves the tool's plumbing
+    (case table, IQ export format, candidate switch, comparison) end to end.  Returns the result dictionary."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        for name, mode, rate, offset, (kind, kw) in make_golden.CASES:
+            if name not in cases:
+                continue
+            z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+            x = z["iq_f16"].astype(np.float32).view(np.complex64)                      # what make_golden.py --export-iq writes
+            x.tofile(os.path.join(d, name + ".cf32"))
+            getattr(orc, "demod_" + kind)(x, **kw)["constellation"].astype(np.complex64).tofile(os.path.join(d, name + ".port1"))
+        return arbitrate(d, d, only=cases, out=out)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 2 and sys.argv[1] == "--self-test":
+        sys.exit(0 if self_test() else 1)
+    if len(sys.argv) != 3:
+        raise SystemExit(__doc__)
+    arbitrate(sys.argv[1], sys.argv[2])

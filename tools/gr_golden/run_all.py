@@ -22,7 +22,32 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 
+def dry_run(work):
+    """--dry-run: everything this script does that needs no GNU Radio -- the case table, the IQ export, the command lines -- so that a CPU test
+    keeps the pinning run one command away (VERDICT r4 #6).  Returns the gr_golden command lines it would run."""
+    import make_golden
+    iq_dir = os.path.join(work, "iq")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "golden", "make_golden.py"), "--export-iq", iq_dir])
+    cmds = []
+    for name, mode, rate, offset, (kind, kw) in make_golden.CASES:
+        if rate != 1000000:
+            continue
+        f = os.path.join(iq_dir, name + ".cf32")
+        assert os.path.getsize(f) > 0 and os.path.getsize(f) % 8 == 0, f
+        cmds.append([os.path.join(work, "gr_golden"), kind, str(kw.get("sps", 0)), str(kw.get("filter_width", 0)), str(int(kw.get("fm", False))),
+                     f, os.path.join(work, "out", name)])
+    for fn in ("CMakeLists.txt", "gr_golden.cpp", "compare.py", "arbitrate_ted.py"):
+        assert os.path.exists(os.path.join(HERE, fn)), fn
+    return cmds
+
+
 def main():
+    if len(sys.argv) >= 2 and sys.argv[1] == "--dry-run":
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            for c in dry_run(d):
+                print("would run:", " ".join(c))
+        return 0
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
     src = os.path.abspath(sys.argv[1])
