@@ -121,8 +121,10 @@ void orc_ctcss_freqs(float freq, float* f_l, float* f_r)
 {
     int i = -1;
     for (int k = 0; k < 38; k++) if (ctcss_tones[k] == freq) i = k;
-    *f_l = (i == -1 || i == 0) ? freq * 0.98f : ctcss_tones[i - 1];
-    *f_r = (i == -1 || i == 37) ? freq * 1.02f : ctcss_tones[i + 1];
+    /* the guard tones of an off-table tone: freq * 0.98 / freq * 1.02 with DOUBLE literals, narrowed to float afterwards [GR-MEM] (the reference's
+     * tone list has off-table entries: 81.5 and 87.4, src/ext/utils.h:17) */
+    *f_l = (i == -1 || i == 0) ? (float)((double)freq * 0.98) : ctcss_tones[i - 1];
+    *f_r = (i == -1 || i == 37) ? (float)((double)freq * 1.02) : ctcss_tones[i + 1];
 }
 void orc_goertzel_coeffs(int rate, float freq, float* wr, float* wi)
 {

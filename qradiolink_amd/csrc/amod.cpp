@@ -210,7 +210,8 @@ int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, f
         RingF a0{m->a0.p, m->m8}, a1{m->a1.p, m->m8}, a2{m->a2.p, m->m8};
         RingC c1{m->c1.p, m->m8}, m1{m->m1.p, m->mm}, m2{m->m2.p, m->mm};
         const uint32_t c8 = (uint32_t)n, c1m = (uint32_t)(n * (size_t)m->sps);
-        if ((size_t)c1m > out_stride && B > 1) return qrl_set_error(QRL_ERR_ARG, "amod: out_stride smaller than this call's output (qrl_amod_out_cap)");
+        // (every batch size: out_stride is the capacity of the final filter's output port, a smaller one would silently truncate -- ADVICE r4)
+        if ((size_t)c1m > out_stride) return qrl_set_error(QRL_ERR_ARG, "amod: out_stride smaller than this call's output (qrl_amod_out_cap)");
         AmLoadParams lp{}; lp.in = audio; lp.in_stride = stride; lp.out = a0; lp.n0 = m->n8; lp.count = c8;
         launch_am_load(lp, B, s);
         AmAgcParams ap{}; ap.in = a0; ap.out = a1; ap.n0 = m->n8; ap.count = c8; ap.attack = 1e-2f; ap.decay = 1e-4f; ap.ref = 1.0f; ap.max_gain = 1.0f;

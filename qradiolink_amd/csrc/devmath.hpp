@@ -69,7 +69,9 @@ __device__ __forceinline__ float fast_atan2f_lut(float y, float x, const float* 
     if (!((y_abs > 0.0f) || (x_abs > 0.0f))) return 0.0f;
     const float z = (y_abs < x_abs) ? (y_abs / x_abs) : (x_abs / y_abs);
     float base;
-    if ((double)z < 0.003921569) {
+    // gnuradio compares in double: (double)z < 0.003921569.  For a float z that is z < nextfloat-at-or-above(0.003921569) = 0x3B808082 exactly
+    // (0.003921569 is not a float; the floats below it are < it, 0x3B808082 is the first one >= it): one f32 compare instead of a conversion and an f64 compare
+    if (z < __uint_as_float(0x3B808082u)) {
         base = z;
     } else {
         float alpha = z * 255.0f;

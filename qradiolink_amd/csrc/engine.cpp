@@ -1346,7 +1346,7 @@ int qrl_demod_set_ctcss(qrl_demod* d, float tone_hz)
                                         203.5f, 210.7f, 218.1f, 225.7f, 233.6f, 241.8f, 250.3f};
         int i = -1;
         for (int k = 0; k < 38; ++k) if (tones[k] == tone_hz) i = k;
-        const float f[3] = {(i == -1 || i == 0) ? tone_hz * 0.98f : tones[i - 1], tone_hz, (i == -1 || i == 37) ? tone_hz * 1.02f : tones[i + 1]};
+        const float f[3] = {(i == -1 || i == 0) ? (float)((double)tone_hz * 0.98) : tones[i - 1], tone_hz, (i == -1 || i == 37) ? (float)((double)tone_hz * 1.02) : tones[i + 1]};   // double literals, then narrowed (ctcss_squelch_ff_impl.cc compute_freqs)
         for (int k = 0; k < 3; ++k) {
             const float w = (float)(2.0 * M_PI * f[k] / 8000);
             d->ct_wr[k] = (float)(2.0 * (double)cosf(w));

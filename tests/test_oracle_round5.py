@@ -52,3 +52,16 @@ def test_mod_dmr_shape_and_zero_runs():
     lo, hi = (1439 + 100 + 60) * 125 // 3, (1439 + 400 - 60) * 125 // 3
     assert np.abs(z[lo:hi]).max() < 1e-3 and np.abs(y[lo:hi]).min() > 0.3
     assert np.array_equal(z[:lo - 6000], y[:lo - 6000]) and np.array_equal(z[hi + 6000:], y[hi + 6000:])
+
+
+def test_ctcss_guard_tones_known_answers():
+    """ctcss_squelch_ff's neighbours: the table entries either side of a standard tone, freq * 0.98 / freq * 1.02 (double literals, narrowed to float)
+    for an off-table tone -- the reference's tone list has two such entries, 81.5 and 87.4 Hz (src/ext/utils.h:17)"""
+    def guards(f):
+        fl, fr = C.c_float(), C.c_float()
+        orc.lib.orc_ctcss_freqs(C.c_float(f), C.byref(fl), C.byref(fr))
+        return fl.value, fr.value
+    assert guards(88.5) == (np.float32(85.4), np.float32(91.5))
+    assert guards(67.0) == (np.float32(np.float64(np.float32(67.0)) * 0.98), np.float32(71.9))
+    for f in (81.5, 87.4):
+        assert guards(f) == (np.float32(np.float64(np.float32(f)) * 0.98), np.float32(np.float64(np.float32(f)) * 1.02))
