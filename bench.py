@@ -267,6 +267,19 @@ def pmc_traffic(name, kernel, default_shape=True):
         return None, None
 
 
+def pmc_chain_traffic(name, default_shape=True):
+    """C4: HBM bytes per step of the WHOLE chain (sum over its kernels) and the per-kernel split, from the same PMC passes; (None, None) when
+    the record is missing or belongs to other kernel sources."""
+    try:
+        allp = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        pmc = allp.get(name)
+        if not pmc or not default_shape or "chain_bytes" not in pmc or allp.get("_source_id") != source_id():
+            return None, None
+        return pmc["chain_bytes"], {k: round(v) for k, v in pmc["chain_by_kernel"].items()}
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def whole_step_obj(bytes_per_step, ms_per_step):
     """The same algorithmic bytes over the WHOLE step (every kernel of the chain, as timed by the bench loop) instead of the dominant
     kernel's own duration: printed beside `frac` on every line (hygiene)."""
@@ -433,10 +446,16 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, c
         abytes = b_kernel * n * C4_BYTES
         ws = whole_step_obj(abytes, ms_step)
         traffic, src = pmc_traffic("c4", dom, not (args.batch or args.nsamp))
+        chain_traffic, chain_by_kernel = pmc_chain_traffic("c4", not (args.batch or args.nsamp))
         flop = (C4_FLOP_PFB + C4_FLOP_TAIL) * b_kernel * n
         line["roofline"] = dict(
             bound="f32 instruction issue (VALU + matrix pipe); hbm figures for reference", achieved=ws["achieved"], peak=HBM_PEAK_GBPS, unit="GB/s", frac=ws["frac"],
-            traffic=traffic, traffic_source=src, kernel=dom, kernel_ms=per_kernel[dom], launches=launches_timed,
+            traffic=chain_traffic if chain_traffic else traffic, traffic_source=src, traffic_kernel=traffic, traffic_by_kernel=chain_by_kernel,
+            traffic_note=("traffic = HBM bytes per step of the WHOLE chain (sum over its kernels, PMC); traffic_kernel = the dominant kernel's own. The chain hands two rings "
+                          "from kernel to kernel -- 1.07 GB of 25 ksps channel samples (written by the channelizer, read with a 20 % halo by the per-channel kernel) and "
+                          "0.5 GB of RRC output (written there, read by the symbol synchroniser) -- which is what separates it from the algorithmic bytes; at the step time "
+                          "it is a quarter of the HBM roof, the chain is bound by f32 instruction issue (flops)") if chain_traffic else None,
+            kernel=dom, kernel_ms=per_kernel[dom], launches=launches_timed,
             algorithmic_bytes_per_launch=abytes, algorithmic_bytes_per_sample=round(C4_BYTES, 3),
             kernels_ms=per_kernel,
             kernel_fracs={k: round(abytes / (v * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) for k, v in per_kernel.items() if v > 0},

@@ -74,6 +74,17 @@ for cfg, rows in sections.items():
                             "factors above" % cfg}
     else:
         print("no PMC rows for", cfg, want)
+    if cfg == "c4" and cfg in out:
+        # C4 is a chain of kernels that hand rings to each other: the whole chain's HBM bytes per step = the sum over its kernels (largest
+        # mean per kernel name = the default shape), next to the dominant kernel's own
+        per = {}
+        for base, targs, cnt, val, n in rows:
+            k = (base + targs).replace("qrl::", "")
+            per.setdefault(k, {})
+            per[k][cnt] = max(per[k].get(cnt, 0.0), val)
+        byk = {k: v.get("FETCH_SIZE", 0.0) * 1024 / f_fetch + v.get("WRITE_SIZE", 0.0) * 1024 / f_write for k, v in per.items() if "decim_mfma" not in k}
+        out[cfg]["chain_bytes"] = sum(byk.values())
+        out[cfg]["chain_by_kernel"] = byk
 # issue side (C3, C5): wave instructions of ONE receiver call = sum over the RX kernels of (mean per launch x launches) / RX calls, where the
 # number of RX calls of the profiled command = launches of the workload's dominant (front-end) kernel
 for cfg, ks in insts.items():
