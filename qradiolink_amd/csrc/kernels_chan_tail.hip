@@ -48,6 +48,13 @@ constexpr int CT_SA = CT_JP + 7, CT_SB = CT_NF + 7;   // window steps of the 8-o
 // of 16 outputs, K: 4 sample offsets d (see the stage).  CT_EM matrix instructions cover d = 15 .. -(CT_NR - 1); the discriminator image is stored
 // item i at (i & 15) CT_DP + (i >> 4) so that "lane (kk, n) reads item 16 n + c - kk" spreads over the banks (CT_DP = 17 mod 32).
 constexpr int CT_EM = (CT_NR + 15 + 3) / 4;            // 35
+// stage B on the matrix pipe as well (round 5): rows = 16 consecutive filter outputs, columns = 8 blocks of 16 outputs x (re, im), K = 4 sample offsets;
+// CT_BM matrix instructions cover d = 15 .. -(CT_NF - 1); the padded tap table of the stage has 15 zeros in front (tB[j] = ft[j - 15])
+#ifndef QRL_CT_B_MFMA
+#define QRL_CT_B_MFMA 1
+#endif
+constexpr int CT_BM = (CT_NF + 15 + 3) / 4;            // 12
+constexpr int CT_HBT = 64;                             // >= 15 + 3 + 4 CT_BM
 constexpr int CT_DP = 113;                             // >= (139 + 16 * 79 + 15) / 16 + 1 = 89 columns
 constexpr int CT_HE = 160;                             // padded tap table: hpad[j] = rrc[j - 15], j < 15 + 3 + 4 CT_EM
 typedef float f32x4_ct __attribute__((ext_vector_type(4)));
@@ -114,7 +121,11 @@ __global__ __launch_bounds__(256, QRL_CT_WPE) void k_chan_tail(const ChanTailPar
     if (tt) __syncthreads();                                                      // the previous tile's readers of xf / av / dv are through
     // step-major tap tables, laid out by the host (chan_tail_tables): straight 16-byte copies (per tile: stage D overwrites them)
     for (int k = tid; k < 3 * CT_SA * 2; k += 256) reinterpret_cast<float4*>(tA)[k] = reinterpret_cast<const float4*>(P.tab_a)[k];
+#if QRL_CT_B_MFMA
+    if (tid < CT_HBT) tB[tid] = P.tab_b[tid];
+#else
     if (tid < CT_SB * 2) reinterpret_cast<float4*>(tB)[tid] = reinterpret_cast<const float4*>(P.tab_b)[tid];
+#endif
     CT_STAMP(0);
     const int64_t ua = ct_floordiv(Q0 - CT_HA, 24), qa = ua * 24;                 // first resampler output of the tile (multiple of 24)
     const int NU = (int)((Q0 + CT_T - qa + 23) / 24);                             // groups of 24 outputs: <= 59
@@ -178,6 +189,10 @@ __global__ __launch_bounds__(256, QRL_CT_WPE) void k_chan_tail(const ChanTailPar
 #pragma unroll
         for (int r = 0; r < 8; ++r) av[r * CT_W + 3 * lane + wv] = make_float2(acc[r].x, acc[r].y);   // item i = 24 lane + 8 w + r
     }
+    // the matrix forms of stages B and E multiply ZERO taps with up to 15 items BEHIND an output, and a zero tap leaves the chain untouched only if
+    // the sample is finite (0 x NaN = NaN): the items behind the last resampler output must not be whatever the LDS held before (found by
+    // tests/test_gpu_sharding.py: the last outputs of a tile differed when the memory behind the image happened to hold a NaN pattern)
+    if (tid < 32) av[ct_pos(24 * NU + tid)] = make_float2(0.f, 0.f);
     CT_STAMP(4);
     __syncthreads();
     CT_STAMP(5);
@@ -186,6 +201,43 @@ __global__ __launch_bounds__(256, QRL_CT_WPE) void k_chan_tail(const ChanTailPar
     // changed nothing), and this stage is the largest: here the 33 taps live in REGISTERS (17 pairs, read once per tile out of rows
     // 7, 15, 23, 31, 39 of the step-major table: row 8 i + 7 holds h[8 i .. 8 i + 7]), the 40 steps are unrolled with compile-time
     // tap indices -- one LDS read (the sample) per step, and the taps that are zero padding are not multiplied at all.
+#if QRL_CT_B_MFMA
+    {
+        // Round 5: the same Toeplitz form as stage E.  Output i' = 16 n + i (relative to qb), component c:  F[i][(n, c)] = sum_d A[i][d] B[d][(n, c)],
+        // A[i][d] = ft[i - d] (0 outside the filter), B[d][(n, c)] = component c of a[ib0 + 16 n + d], d = 15 .. -32 in DESCENDING order, four per
+        // v_mfma_f32_16x16x4_f32 (slot kk of instruction m: d = 15 - 4 m - kk, tap index i - 15 + 4 m + kk): per component the oracle's chain
+        // fmaf(ft[k], a[q - k], acc), k ascending from +0 (orc_fir_ccf), bit for bit.  16 columns = 8 blocks x (re, im): a chain = 128 complex outputs in
+        // CT_BM = 12 instructions; 11 chains cover the NB <= 1339 outputs of a tile (3 + 3 + 3 + 2 over the four waves).  The resampler image `av`
+        // keeps its layout (item at (item & 7) W + (item >> 3)): the item walks down by 4 per instruction = the other row of its pair, one column
+        // every second step -- two base addresses and immediate offsets; results go to the f image in the layout stage D reads.  (The 40 tap
+        // registers of the packed-fma form were the kernel's register peak: 128 -> 103 VGPRs.)
+        const int col = lane & 15, kk = lane >> 4, cmp = col & 1, nl = col >> 1;
+        const float* avf = reinterpret_cast<const float*>(av);
+        float* xff = reinterpret_cast<float*>(xf);
+        const float* hp = tB + col + kk;                                          // A operand: row i = lane & 15, slot kk: tB[i + kk + 4 m]
+#pragma unroll 1
+        for (int cg = wv; cg < (NB + 127) / 128; cg += 4) {
+            const int n = 8 * cg + nl;
+            const int it0 = ib0 + 16 * n + 15 - kk;
+            int ob[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ob[j] = 2 * (ct_pos(it0 - 4 * j) - 6) + cmp;
+            f32x4_ct acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < CT_BM; ++m) {
+                const float a_ = hp[4 * m];
+                const float b_ = avf[ob[m & 1] + 2 * (6 - (m >> 1))];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, acc, 0, 0, 0);
+            }
+            // lane holds outputs i' = 16 n + 4 kk + r, r = 0..3, of component cmp
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i2 = 16 * n + 4 * kk + r;
+                xff[2 * ct_pos(i2) + cmp] = acc[r];
+            }
+        }
+    }
+#else
     if (tid < (NB + 7) / 8) {
         const float4* tp = reinterpret_cast<const float4*>(tB);
         v2f_ct hb[20];
@@ -212,6 +264,7 @@ __global__ __launch_bounds__(256, QRL_CT_WPE) void k_chan_tail(const ChanTailPar
 #pragma unroll
         for (int r = 0; r < 8; ++r) xf[r * CT_W + tid] = make_float2(acc[r].x, acc[r].y);   // f item i' = 8 g + r (relative to qb)
     }
+#endif
     CT_STAMP(6);
     __syncthreads();
     CT_STAMP(7);
@@ -235,6 +288,7 @@ __global__ __launch_bounds__(256, QRL_CT_WPE) void k_chan_tail(const ChanTailPar
             const float im = a.y * p.x - a.x * p.y;
             const float ang = fast_atan2f_lut(im, re, T);
             if (i < NB) dv[ct_dpos(i)] = P.gain2 * ang;
+            if (j == 0 && tid < 16) dv[ct_dpos(NB + tid)] = 0.0f;                 // (stage E: finite items behind the last one, as for stage B)
             if (i < NB && i >= e0) {   // |f|^4 of the tile's own items for the serial RSSI sums below, in item order (the resampler output `av` is dead since stage B: its memory holds them)
                 const float pwr = a.x * a.x + a.y * a.y;
                 pv[i - e0] = pwr * pwr;
@@ -372,6 +426,13 @@ std::vector<float> chan_tail_tables(int which, const float* taps)
         for (int k = 0; k < CT_NR; ++k) t[15 + k] = taps[k];
         return t;
     }
+#if QRL_CT_B_MFMA
+    if (which == 1) {   // stage B (matrix pipe): tB[j] = ft[j - 15]
+        std::vector<float> t((size_t)CT_HBT, 0.0f);
+        for (int k = 0; k < CT_NF; ++k) t[15 + k] = taps[k];
+        return t;
+    }
+#endif
     const int nt = CT_NF, ns = CT_SB;
     std::vector<float> t((size_t)ns * 8, 0.0f);
     for (int st = 0; st < ns; ++st)

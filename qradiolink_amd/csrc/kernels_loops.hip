@@ -384,9 +384,9 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
 size_t symsync_lds_bytes() { return SsGeo<32, 192>::lds_bytes(); }
 
 #ifndef QRL_CHAN_SS_NS
-#define QRL_CHAN_SS_NS 16
-#define QRL_CHAN_SS_W 96
-#endif
+#define QRL_CHAN_SS_NS 32    // round 5: <32 streams, 96 samples> = 128 workgroups of 45 KB for the 4096 channel streams of C4 instead of 256 of 25 KB: the recursion is as
+#define QRL_CHAN_SS_W 96     // fast alone (1.75 against 1.68 ms) and costs the per-channel kernel beside it less: 2.82 - 2.83 against 2.86 - 2.94 ms per step, four
+#endif                       // alternating passes (profiles/r05_c4_experiments.log); 64 streams per wave make the recursion 1.8 x slower (bank conflicts)
 void launch_symsync_ff(const SymSyncParams& p, int batch, hipStream_t s)
 {
     if (p.slim == 2 && (QRL_CHAN_SS_NS != 16 || QRL_CHAN_SS_W != 96)) {   // the multi-carrier receiver's own geometry (QRL_CHAN_SS_NS streams per workgroup, QRL_CHAN_SS_W samples per window)
