@@ -440,18 +440,21 @@ static int chan_process_impl(qrl_chan* h, const float* iq, size_t stride, size_t
         if (h->fsk_bits) tp.out_sym = RingF{h->r6.p, h->m6};
         if (h->rssi_out) { tp.rssi = h->rssi_out; tp.rssi_cap = h->rssi_cap; tp.rssi_counts = h->rssi_counts; tp.rssi_cal = h->rssi_cal;
                            tp.tag0 = h->n2 / 300; tp.ntags = (uint32_t)(n2_1 / 300 - h->n2 / 300); }
-        if (h->tail_only) {   // the last hist_len channel samples of every row for the next call (k_hist, as for the wideband input of the other forms);
-                              // IN FRONT of the per-channel kernel (it writes the other history buffer), so that nothing sits between two of those
-            HistParams th{};
-            th.in = in; th.in_stride = stride; th.n0 = h->n1; th.n = (uint32_t)n;
-            th.hist_old = hist_old; th.hist_new = hist_new; th.hist_len = h->hist_len; th.rot_enable = 0;
-            launch_hist_save(th, S, h->stream); h->flip = !h->flip;
-        }
         hipEvent_t et0 = nullptr, et1 = nullptr;
         if (h->profiling) { HIPCHK(hipEventCreate(&et0)); HIPCHK(hipEventCreate(&et1)); HIPCHK(hipEventRecord(et0, ts)); }
         launch_chan_tail(tp, S, ts);
         if (et1) { HIPCHK(hipEventRecord(et1, ts)); h->prof_tail.emplace_back(et0, et1); }
         if (use_mid) { HIPCHK(hipEventRecord(h->ev_mid[slotr], ts)); h->mid_valid[slotr] = true; }
+        if (h->tail_only) {   // the last hist_len channel samples of every row for the next call (k_hist, as for the wideband input of the other forms).
+                              // BEHIND the per-channel kernel: the cluster records "this buffer has been read" behind it, so the channelizer that waits for that
+                              // record cannot grab the chip between two per-channel kernels (in front of the kernel, this small launch and the persistent
+                              // channelizer workgroups became ready together and it waited ~ 0.6 ms for a place: profiles/r05_c4_cluster_one_rank.log)
+            HistParams th{};
+            th.in = in; th.in_stride = stride; th.n0 = h->n1; th.n = (uint32_t)n;
+            th.hist_old = hist_old; th.hist_new = hist_new; th.hist_len = h->hist_len; th.rot_enable = 0;
+            launch_hist_save(th, S, h->stream); h->flip = !h->flip;
+        }
+
 
     } else {
         FirCcfParams fp{};

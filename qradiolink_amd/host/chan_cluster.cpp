@@ -72,8 +72,17 @@ chan_cluster::chan_cluster(qrl_ctx* ctx, chan_exchange& ex, int num_channels, in
     const char* keep = std::getenv("QRL_CLUSTER_COPY_AT_ONE_RANK");
     d_inplace = W == 1 && !(keep && keep[0] == '1');
     try {
+        // Priorities, and not only for the hardware queues (streams of one priority share a few of them): when a per-channel kernel ends, the next one
+        // on its stream and a channelizer two steps ahead become ready together, and whichever is dispatched first fills the CUs -- the persistent
+        // channelizer workgroups must NOT be that one (the per-channel kernels are the step's critical path; the channelizer has two steps of slack).
+        // Channelizer: lowest priority; exchange and per-channel handle: normal (they are serial anyway); the handle's symbol synchroniser: highest.
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        hipStream_t fs;
+        hchk(hipStreamCreateWithPriority(&fs, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
+        d_fs = fs;
         qrl_chan_config c{};
-        c.num_channels = num_channels; c.batch = streams_local; c.max_chunk = max_chunk; c.form = 0;
+        c.num_channels = num_channels; c.batch = streams_local; c.max_chunk = max_chunk; c.form = 0; c.hip_stream = d_fs;
         chk(qrl_chan_create(ctx, &c, &d_front), "qrl_chan_create (channelizer)");
         qrl_chan_config t{};
         t.num_channels = 1; t.batch = streams_local * W * d_per; t.max_chunk = d_n1max; t.form = 3;
@@ -84,11 +93,7 @@ chan_cluster::chan_cluster(qrl_ctx* ctx, chan_exchange& ex, int num_channels, in
             if (!d_inplace) hchk(hipMalloc(reinterpret_cast<void**>(&d_recv[k]), items * 2 * sizeof(float)), "hipMalloc");
         }
         hipStream_t xs;
-        // lowest priority -- not for the scheduling: streams of one priority share a few hardware queues, and a wait queued on this
-        // stream would otherwise hold back the kernels of a handle stream that happens to sit on the same queue (csrc/engine.cpp, stream creation)
-        int prio_lo = 0, prio_hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        hchk(hipStreamCreateWithPriority(&xs, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
+        hchk(hipStreamCreateWithFlags(&xs, hipStreamNonBlocking), "hipStreamCreate");   // normal priority: shares queues with the per-channel handle's stream at worst, and the exchange of a step and its per-channel kernels are serial
         d_xs = xs;
         for (int k = 0; k < kSlots; ++k) {
             hipEvent_t e;
@@ -106,6 +111,7 @@ void chan_cluster::release()
     if (d_tail) qrl_chan_destroy(d_tail);
     d_front = d_tail = nullptr;
     if (d_xs) { (void)hipStreamSynchronize(static_cast<hipStream_t>(d_xs)); (void)hipStreamDestroy(static_cast<hipStream_t>(d_xs)); d_xs = nullptr; }
+    if (d_fs) { (void)hipStreamSynchronize(static_cast<hipStream_t>(d_fs)); (void)hipStreamDestroy(static_cast<hipStream_t>(d_fs)); d_fs = nullptr; }
     for (int k = 0; k < kSlots; ++k) {
         if (d_ev_sent[k]) (void)hipEventDestroy(static_cast<hipEvent_t>(d_ev_sent[k]));
         if (d_ev_read[k]) (void)hipEventDestroy(static_cast<hipEvent_t>(d_ev_read[k]));

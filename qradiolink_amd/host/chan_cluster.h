@@ -93,6 +93,7 @@ private:
     static constexpr int kSlots = 3;                // buffer sets: the channelizer may run two steps ahead of the per-channel kernels
     float *d_send[kSlots] = {nullptr, nullptr, nullptr}, *d_recv[kSlots] = {nullptr, nullptr, nullptr};
     void* d_xs = nullptr;                           // hipStream_t of the exchange
+    void* d_fs = nullptr;                           // hipStream_t of the channelizer handle (lowest priority)
     // hipEvent_t per buffer slot: exchange k done (send[slot] read, recv[slot] written); the per-channel kernels of step k queued so far done (recv[slot] read)
     void* d_ev_sent[kSlots] = {nullptr, nullptr, nullptr}; void* d_ev_read[kSlots] = {nullptr, nullptr, nullptr};
     bool d_sent_valid[kSlots] = {false, false, false}, d_read_valid[kSlots] = {false, false, false};
