@@ -476,7 +476,7 @@ int qrl_amod_create(qrl_ctx* ctx, const qrl_amod_config* cfg, qrl_amod** out);
 void qrl_amod_destroy(qrl_amod* m);
 int qrl_amod_reset(qrl_amod* m);
 int qrl_amod_set_bb_gain(qrl_amod* m, float value);
-/* replaces gr_mod_nbfm::set_ctcss(value) (src/gr/gr_mod_nbfm.cpp:101-140; gr_mod_base::set_ctcss :872-877 forwards to both NBFM instances):
+/* replaces gr_mod_nbfm::set_ctcss(value) (src/gr/gr_mod_nbfm.cpp:101-135; gr_mod_base::set_ctcss :872-877 forwards to both NBFM instances):
  * tone_hz != 0: _audio_amplify 0.85, the audio filter becomes band_pass_2(1, 8000, 300, 3500, 200, 35, BH) and analog::sig_source_f(8000,
  * GR_COS_WAVE, tone, 0.15) is added to the audio in front of the pre-emphasis; 0: the low-pass again and _audio_amplify 0.98 (sic: the
  * constructor's 0.99 does not come back).  Takes effect with the next qrl_amod_process call; the tone's phase runs over the samples produced

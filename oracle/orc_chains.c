@@ -329,7 +329,7 @@ void orc_sig_source_cos(double fs, double freq, double ampl, uint64_t k0, size_t
         out[k] = (float)((double)v * ampl);
     }
 }
-/* gr_mod_nbfm::set_ctcss(value) (src/gr/gr_mod_nbfm.cpp:101-140) for the NEXT orc_mod_nbfm calls: tone > 0: _audio_amplify 0.85, the audio
+/* gr_mod_nbfm::set_ctcss(value) (src/gr/gr_mod_nbfm.cpp:101-135) for the NEXT orc_mod_nbfm calls: tone > 0: _audio_amplify 0.85, the audio
  * filter a band-pass band_pass_2(1, 8000, 300, 3500, 200, 35, BH), sig_source_f(8000, GR_COS_WAVE, tone, 0.15) added in front of the
  * pre-emphasis; tone < 0: set_ctcss(0) after it had been on -- the low-pass again, but _audio_amplify 0.98 (:106; the constructor's is 0.99);
  * 0: the constructor's graph. */

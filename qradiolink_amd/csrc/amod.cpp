@@ -48,7 +48,7 @@ struct qrl_amod {
     Dev<float2> t_side, c1, c2, c3; int n_side = 0; Dev<float> atan_tab; uint64_t ns = 0; size_t last = 0;   // SSB
     float bb_gain = 1.0f, fm_k = 0.f;
     Dev<float> t_audio, t_if, t_filt, t_interp; int n_audio = 0, n_if = 0, n_filt = 0, n_interp = 0;
-    // gr_mod_nbfm::set_ctcss (src/gr/gr_mod_nbfm.cpp:101-140): band-pass audio filter, _audio_amplify 0.85 / 0.98, tone source + add_ff
+    // gr_mod_nbfm::set_ctcss (src/gr/gr_mod_nbfm.cpp:101-135): band-pass audio filter, _audio_amplify 0.85 / 0.98, tone source + add_ff
     Dev<float> t_audio_bp, tone_tab; int n_audio_bp = 0; float k_audio = 0.99f; float tone_hz = 0.0f; uint32_t tone_inc = 0; uint64_t tone_k = 0;
     Dev<float> a0, a1, a2, r50; uint32_t m8 = 0, m50 = 0;       // rings: audio in, filtered, pre-emphasised (8 ksps); 50 ksps
     Dev<float2> fmv, flt;                                        // 50 ksps complex: modulator out, channel filter out

@@ -59,10 +59,11 @@ struct qrl_chan {
     // channelizer and the fused per-channel kernel of the NEXT call; ring r6 holds two calls, ev_tail[slot] guards its reuse
     hipStream_t tail = nullptr; hipEvent_t ev_ff = nullptr, ev_tail[2] = {nullptr, nullptr}; bool tail_valid[2] = {false, false}; uint64_t call_no = 0;
     uint32_t m6 = 0;
-    // round 5: the fused per-channel kernel of call k runs on its own stream (`mid`) BESIDE the channelizer of call k + 1 (the PFB form on a
-    // handle-owned stream only: with a caller's stream the int16 / RSSI outputs stay ordered on that stream).  The channel ring r1 holds two
-    // calls + the tail's look-back; ev_pfb orders the tail behind its channelizer, ev_mid[slot] the channelizer of call k + 2 behind the tail
-    // of call k (the last reader of the ring items it overwrites).
+    // round 5: the fused per-channel kernel of call k runs on its own stream (`mid`) BESIDE the channelizers of the calls after it (the PFB form on a
+    // handle-owned stream only: with a caller's stream the int16 / RSSI outputs stay ordered on that stream).  The channel ring r1 holds ring_calls = 3
+    // calls + the tail's look-back: ev_pfb orders the per-channel kernel behind its channelizer, ev_mid[slot] the channelizer of call k + 3 behind the
+    // per-channel kernel of call k (the last reader of the ring items it overwrites).  With TWO calls the channelizer of call k + 2 and the per-channel
+    // kernel of call k + 1 became ready at the same instant and the step was bimodal (docs/KERNELS.md 10).
     hipStream_t mid = nullptr; hipEvent_t ev_pfb = nullptr, ev_mid[3] = {nullptr, nullptr, nullptr}, ev_user3 = nullptr; bool mid_valid[3] = {false, false, false};
     int ring_calls = 3;   // calls the channel ring holds: the channelizer may run this many calls minus one ahead of the per-channel kernel
     bool opt_serial_tail = false;

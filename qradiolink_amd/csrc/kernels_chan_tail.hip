@@ -22,6 +22,9 @@
 // spreads over all banks.  The resampler (24 phases) maps lane = group of 24 outputs, wave = which 8 of them: the phase of an output
 // is then wave-uniform and c(q) = floor(25 q / 24) has no carry inside the 8 (x index 25 u + 8 w + r - j, lane stride 25 samples:
 // conflict free for ds_read_b64).
+// Round 5: stages B (33-tap channel filter) and E (125-tap RRC) run on the f32 MATRIX pipe as Toeplitz products (v_mfma_f32_16x16x4_f32: rows = 16
+// consecutive outputs, columns = blocks of 16 outputs, K = four sample offsets in descending order = tap index ascending): see the two stages.  The
+// register-blocked packed-fma form described above is what stage A (the resampler) still uses; QRL_CT_B_MFMA = 0 keeps it for stage B (A/B builds).
 // Every chain is the oracle's: one fmaf chain per output, tap index ascending, first term fmaf(h, x, +0) (orc_resamp_ccf,
 // orc_fir_ccf, orc_fir_fff); discriminator, quantiser and RSSI sums as in k_quad_demod / k_rssi_tag.
 #include <cstring>

@@ -165,6 +165,10 @@ public:
     gr_modem_hip(gr_demod_base_hip* demod, gr_mod_base_hip* mod, gr_modem_events events);
     void toggleRxMode(int modem_type);
     void toggleTxMode(int modem_type);
+    // Return value: with the frame synchroniser on the device (the default) true = a complete frame of `stream` was delivered by this call.  The
+    // reference's synchronize() returns data_to_process = true for ANY bits consumed while a sync is held, also while a frame is only partly
+    // collected (src/gr_modem.cpp:1121-1175): a caller that reads the value as "RX active" sees the difference between two frames; the host-loop
+    // path (set_device_framing(false)) keeps the reference's meaning.  The events (callbacks) are the same either way.  
     bool demodulate(int stream = 0);
     bool demodulateAnalog(int stream = 0);                      // gr_modem::demodulateAnalog, src/gr_modem.cpp:996-1017
     // TX (bytes are queued on the modulator; its work() turns them into samples)

@@ -506,7 +506,7 @@ def test_dmr_tx_rx_dibit_loopback_on_gpu(qrl_ctx):
 # ---- TX-side CTCSS of gr_mod_nbfm (set_ctcss: tone source + add_ff, band-pass audio filter, x0.85)
 @pytest.mark.parametrize("chunk", [8000, 1000, 324])
 def test_nbfm_modulator_ctcss_bit_exact(qrl_ctx, chunk):
-    """qrl_amod_set_ctcss against the oracle's gr_mod_nbfm with set_ctcss(tone) (src/gr/gr_mod_nbfm.cpp:101-140): 88.5 Hz and the off-table
+    """qrl_amod_set_ctcss against the oracle's gr_mod_nbfm with set_ctcss(tone) (src/gr/gr_mod_nbfm.cpp:101-135): 88.5 Hz and the off-table
     tone 81.5 Hz of the reference's tone list (src/ext/utils.h:17), in one call and in ragged calls; then set_ctcss(0) after it had been on:
     the low-pass again, but _audio_amplify 0.98"""
     import torch
