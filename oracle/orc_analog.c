@@ -217,6 +217,17 @@ static void scale_f(float* x, size_t n, float k) { for (size_t i = 0; i < n; i++
 /* gr_demod_nbfm::set_ctcss(value) for the NEXT orc_demod_analog(kind 0) calls: 0 = off (the constructor's graph) */
 static float g_ctcss_tone = 0.0f;
 void orc_set_ctcss(float tone_hz) { g_ctcss_tone = tone_hz; }
+/* gr_demod_nbfm / _am / _wbfm / _ssb::set_filter_width(width) (what gr_demod_base::set_filter_width(width, mode) forwards, src/gr/gr_demod_base.cpp:1155-1185) for
+ * the NEXT orc_demod_analog / orc_demod_ssb calls; 0 = the constructor's graph.  The setters do not repeat the constructors' designs:
+ *   gr_demod_nbfm.cpp:82-90   _filter low_pass(1, 20000, w, 1200, BH), _fm_demod gain 20000 / (4 pi w)          (constructor: low_pass_2(.., 3500, 60))
+ *   gr_demod_am.cpp:84-91     _filter complex_band_pass(1, 20000, -w, w, 1200, BH)                              (constructor: complex_band_pass_2(.., 200, 90))
+ *   gr_demod_wbfm.cpp:76-84   _filter low_pass(1, 200000, w, 1200, BH), _fm_demod gain 200000 / (2 pi w)        (constructor: low_pass_2(.., 600, 90))
+ *   gr_demod_ssb.cpp:89-101   both band-pass filters as constructed with w, the audio filter band_pass_2(2, 8000, 200, w, 200, 90, BH): GAIN 2 (constructor: 1)
+ * orc_set_rx_gain: gr_demod_ssb::set_gain(value) = _if_gain->set_k(value) (:118-121; gr_demod_base::set_gain, gr_demod_base.cpp:1206-1210); < 0 = the constructor's 0.9 */
+static int g_rx_fw_set = 0;
+static float g_rx_gain = -1.0f;
+void orc_set_rx_filter_width(int width) { g_rx_fw_set = width; }
+void orc_set_rx_gain(float k) { g_rx_gain = k; }
 /* kind: 0 NBFM, 1 AM, 2 WBFM.  filtered = port 0 (before the squelch), audio = port 1 (8 kHz). */
 void orc_demod_analog(const cf32* in, size_t n, int kind, int samp_rate, int filter_width,
                       cf32** filtered, size_t* n_filtered, float** audio, size_t* n_audio)
@@ -230,7 +241,21 @@ void orc_demod_analog(const cf32* in, size_t n, int kind, int samp_rate, int fil
     orc_decim_auto(in, n, taps, nt, decim, s1);                                     /* _resampler */
     free(taps);
     cf32* f = NEW(cf32, n1);
-    if (kind == 1) {                                                                /* _filter: fft_filter_ccc */
+    const int wset = g_rx_fw_set > 0;
+    if (wset) filter_width = g_rx_fw_set;
+    if (wset && kind == 1) {
+        int nf = orc_complex_band_pass(1, target, -filter_width, filter_width, 1200, ORC_WIN_BLACKMAN_HARRIS, NULL);
+        cf32* ft = NEW(cf32, nf);
+        orc_complex_band_pass(1, target, -filter_width, filter_width, 1200, ORC_WIN_BLACKMAN_HARRIS, ft);
+        orc_fir_ccc(s1, n1, ft, nf, f);
+        free(ft);
+    } else if (wset) {
+        int nf = orc_low_pass(1, target, filter_width, 1200, ORC_WIN_BLACKMAN_HARRIS, NULL);
+        float* ft = NEW(float, nf);
+        orc_low_pass(1, target, filter_width, 1200, ORC_WIN_BLACKMAN_HARRIS, ft);
+        orc_fir_ccf(s1, n1, ft, nf, f);
+        free(ft);
+    } else if (kind == 1) {                                                         /* _filter: fft_filter_ccc */
         int nf = orc_complex_band_pass_2(1, target, -filter_width, filter_width, 200, 90, ORC_WIN_BLACKMAN_HARRIS, NULL);
         cf32* ft = NEW(cf32, nf);
         orc_complex_band_pass_2(1, target, -filter_width, filter_width, 200, 90, ORC_WIN_BLACKMAN_HARRIS, ft);
@@ -358,7 +383,10 @@ void orc_demod_ssb(const cf32* in, size_t n, int samp_rate, int filter_width, in
     cf32* s1 = NEW(cf32, n1);
     orc_decim_auto(in, n, taps, nt, decim, s1);                                                 /* _resampler */
     free(taps);
-    for (size_t i = 0; i < n1; i++) { s1[i].re = s1[i].re * 0.9f; s1[i].im = s1[i].im * 0.9f; } /* _if_gain */
+    const float ifg = g_rx_gain >= 0.0f ? g_rx_gain : 0.9f;
+    for (size_t i = 0; i < n1; i++) { s1[i].re = s1[i].re * ifg; s1[i].im = s1[i].im * ifg; }   /* _if_gain */
+    const double ag = g_rx_fw_set > 0 ? 2 : 1;                                                  /* set_filter_width's audio filter has gain 2 */
+    if (g_rx_fw_set > 0) filter_width = g_rx_fw_set;
     const double lo = sb ? -filter_width : 200, hi = sb ? -200 : filter_width;
     int nf = orc_complex_band_pass_2(1, target, lo, hi, 200, 90, ORC_WIN_BLACKMAN_HARRIS, NULL);
     cf32* ft = NEW(cf32, nf);
@@ -376,9 +404,9 @@ void orc_demod_ssb(const cf32* in, size_t n, int samp_rate, int filter_width, in
     float* r = NEW(float, ns);
     for (size_t i = 0; i < ns; i++) r[i] = a[i].re * 1.333f;                                    /* _complex_to_real, _level_control */
     free(g); free(a);
-    int na = orc_band_pass_2(1, target, 200, filter_width, 200, 90, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    int na = orc_band_pass_2(ag, target, 200, filter_width, 200, 90, ORC_WIN_BLACKMAN_HARRIS, NULL);
     float* at = NEW(float, na);
-    orc_band_pass_2(1, target, 200, filter_width, 200, 90, ORC_WIN_BLACKMAN_HARRIS, at);
+    orc_band_pass_2(ag, target, 200, filter_width, 200, 90, ORC_WIN_BLACKMAN_HARRIS, at);
     float* out = NEW(float, ns);
     orc_fir_fff(r, ns, at, na, out);                                                            /* _audio_filter -> port 1 */
     free(at); free(r);
@@ -406,10 +434,14 @@ size_t orc_mod_ssb(const float* audio, size_t n, int sps, int samp_rate, int fil
     cf32* d = NEW(cf32, n);
     orc_cessb_clipper(c, n, 0.95f, d);                                       /* _clipper */
     orc_cessb_stretcher(d, n, c);                                            /* _stretcher: ns items */
-    const double lo = sb ? -filter_width : 200, hi = sb ? -200 : filter_width;
-    int nf = orc_complex_band_pass_2(1, 8000, lo, hi, 200, 90, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    extern int g_tx_fw_set;                                                  /* orc_set_tx_filter_width (orc_chains.c): the audio filter above keeps the constructor's width */
+    const int wset = g_tx_fw_set > 0;
+    if (wset) filter_width = g_tx_fw_set;
+    const double e0 = wset ? 300 : 200, tw = wset ? 250 : 200;
+    const double lo = sb ? -filter_width : e0, hi = sb ? -e0 : filter_width;
+    int nf = orc_complex_band_pass_2(1, 8000, lo, hi, tw, 90, ORC_WIN_BLACKMAN_HARRIS, NULL);
     cf32* ft = NEW(cf32, nf);
-    orc_complex_band_pass_2(1, 8000, lo, hi, 200, 90, ORC_WIN_BLACKMAN_HARRIS, ft);
+    orc_complex_band_pass_2(1, 8000, lo, hi, tw, 90, ORC_WIN_BLACKMAN_HARRIS, ft);
     orc_fir_ccc(c, ns, ft, nf, d);                                           /* _filter_usb / _filter_lsb */
     free(ft); free(c);
     for (size_t i = 0; i < ns; i++) { d[i].re *= 0.9f; d[i].im *= 0.9f; d[i].re *= bb_gain; d[i].im *= bb_gain; }   /* _amplify, _bb_gain */
@@ -453,6 +485,7 @@ size_t orc_mod_am(const float* audio, size_t n, int sps, int samp_rate, int filt
     cf32* c = NEW(cf32, n ? n : 1);
     for (size_t i = 0; i < n; i++) { c[i].re = a1[i] + 0.5f; c[i].im = 0.0f; }    /* _add (+ _signal_source), _float_to_complex */
     free(a1);
+    { extern int g_tx_fw_set; if (g_tx_fw_set > 0) filter_width = g_tx_fw_set; }   /* orc_set_tx_filter_width: the constructor's designs with the new width */
     int ni = orc_low_pass(sps, samp_rate, filter_width, filter_width, ORC_WIN_HAMMING, NULL);
     float* it = NEW(float, ni);
     orc_low_pass(sps, samp_rate, filter_width, filter_width, ORC_WIN_HAMMING, it);

@@ -335,11 +335,23 @@ void orc_sig_source_cos(double fs, double freq, double ampl, uint64_t k0, size_t
  * 0: the constructor's graph. */
 static float g_tx_ctcss = 0.0f;
 void orc_set_tx_ctcss(float tone_hz) { g_tx_ctcss = tone_hz; }
+/* gr_mod_nbfm / gr_mod_am / gr_mod_ssb::set_filter_width(width) (what gr_mod_base::set_filter_width(width, mode) forwards, src/gr/gr_mod_base.cpp:878-905) for
+ * the NEXT orc_mod_nbfm / orc_mod_am / orc_mod_ssb calls; 0 = the constructor's graph.  The setters do not repeat the constructors' designs:
+ *   gr_mod_nbfm.cpp:78-93   _if_resampler low_pass_2(25, 200000, w, w, 60, BH), _filter low_pass_2(1, 50000, w, 1200, 60, BH), _resampler low_pass_2(sps, fs, w, w, 60, BH),
+ *                           sensitivity 4 pi w / 50000  (constructor: transition 3500 everywhere)
+ *   gr_mod_am.cpp:75-85     the constructor's two designs with w
+ *   gr_mod_ssb.cpp:85-100   _resampler as constructed with w, _filter_usb / _lsb complex_band_pass_2(1, 8000, 300, w | -w, -300, 250, 90, BH) (constructor: 200 .. w, 200);
+ *                           the AUDIO filter keeps the constructor's width */
+int g_tx_fw_set = 0;
+void orc_set_tx_filter_width(int width) { g_tx_fw_set = width; }
 size_t orc_mod_nbfm(const float* audio, size_t n, int sps, int samp_rate, int filter_width, float bb_gain, cf32* out)
 {
     const size_t n50 = orc_decim_count(n, 25, 4);
     if (!out) return n50 * (size_t)sps;
     const int tone_on = g_tx_ctcss > 0.0f;
+    const int wset = g_tx_fw_set > 0;
+    if (wset) filter_width = g_tx_fw_set;
+    const double tw_if = wset ? filter_width : 3500, tw_f = wset ? 1200 : 3500;
     const float k_audio = tone_on ? 0.85f : (g_tx_ctcss < 0.0f ? 0.98f : 0.99f);
     int na = tone_on ? orc_band_pass_2(1, 8000, 300, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, NULL) : orc_low_pass_2(1, 8000, 3500, 200, 35, ORC_WIN_BLACKMAN_HARRIS, NULL);
     float* at = NEW(float, na);
@@ -365,25 +377,25 @@ size_t orc_mod_nbfm(const float* audio, size_t n, int sps, int samp_rate, int fi
             a1[i] = (float)acc;
         }
     }
-    int ni = orc_low_pass_2(25, 50000.0 * 4, filter_width, 3500, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    int ni = orc_low_pass_2(25, 50000.0 * 4, filter_width, tw_if, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
     float* it = NEW(float, ni);
-    orc_low_pass_2(25, 50000.0 * 4, filter_width, 3500, 60, ORC_WIN_BLACKMAN_HARRIS, it);
+    orc_low_pass_2(25, 50000.0 * 4, filter_width, tw_if, 60, ORC_WIN_BLACKMAN_HARRIS, it);
     float* r = NEW(float, n50);
     orc_resamp_fff(a1, n, it, ni, 25, 4, r);                                     /* _if_resampler */
     free(it); free(a1); free(tone);
     cf32* fmv = NEW(cf32, n50);
     fm_mod(r, n50, (float)(4 * M_PI * filter_width / 50000.0f), fmv);            /* _fm_modulator */
     free(r);
-    int nf = orc_low_pass_2(1, 50000, filter_width, 3500, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    int nf = orc_low_pass_2(1, 50000, filter_width, tw_f, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
     float* ft = NEW(float, nf);
-    orc_low_pass_2(1, 50000, filter_width, 3500, 60, ORC_WIN_BLACKMAN_HARRIS, ft);
+    orc_low_pass_2(1, 50000, filter_width, tw_f, 60, ORC_WIN_BLACKMAN_HARRIS, ft);
     cf32* g = NEW(cf32, n50);
     orc_fir_ccf(fmv, n50, ft, nf, g);                                            /* _filter */
     free(ft); free(fmv);
     for (size_t i = 0; i < n50; i++) { g[i].re *= 0.8f; g[i].im *= 0.8f; g[i].re *= bb_gain; g[i].im *= bb_gain; }   /* _amplify, _bb_gain */
-    int nt = orc_low_pass_2(sps, samp_rate, filter_width, 3500, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
+    int nt = orc_low_pass_2(sps, samp_rate, filter_width, tw_if, 60, ORC_WIN_BLACKMAN_HARRIS, NULL);
     float* lp = NEW(float, nt);
-    orc_low_pass_2(sps, samp_rate, filter_width, 3500, 60, ORC_WIN_BLACKMAN_HARRIS, lp);
+    orc_low_pass_2(sps, samp_rate, filter_width, tw_if, 60, ORC_WIN_BLACKMAN_HARRIS, lp);
     const size_t m = orc_resamp_ccf(g, n50, lp, nt, sps, 1, out);                /* _resampler */
     free(lp); free(g);
     return m;

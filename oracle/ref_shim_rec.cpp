@@ -88,6 +88,19 @@ const char* rr_construct(const char* kind, int sps, int samp_rate, int carrier_f
     else if (k == "mod_mmdvm_multi") { static BurstTimer bt; auto p = make_gr_mod_mmdvm_multi(&bt, sps, samp_rate, carrier_freq != 0); }
     else if (k == "mod_mmdvm_multi2") { static BurstTimer bt; auto p = make_gr_mod_mmdvm_multi2(&bt, sps, samp_rate, carrier_freq != 0); }
     else if (k == "mod_am") { auto p = make_gr_mod_am(sps, samp_rate, carrier_freq, filter_width); }
+    // "<kind>.set_filter_width" / ".set_gain": construct with the instance's arguments of gr_demod_base.cpp / gr_mod_base.cpp, then call the setter the
+    // facade forwards (gr_demod_base::set_filter_width / set_gain, gr_mod_base::set_filter_width) with the value in the LAST argument slot
+    // (a gain travels in thousandths); the log continues with the setter's own set_taps / set_gain / set_sensitivity / set_k events behind a marker line
+    else if (k == "demod_nbfm.set_filter_width") { auto p = make_gr_demod_nbfm(sps, samp_rate, carrier_freq, filter_width); s.lines.push_back("== set_filter_width"); p->set_filter_width(fm); }
+    else if (k == "demod_am.set_filter_width") { auto p = make_gr_demod_am(sps, samp_rate, carrier_freq, filter_width); s.lines.push_back("== set_filter_width"); p->set_filter_width(fm); }
+    else if (k == "demod_wbfm.set_filter_width") { auto p = make_gr_demod_wbfm(sps, samp_rate, carrier_freq, filter_width); s.lines.push_back("== set_filter_width"); p->set_filter_width(fm); }
+    else if (k == "demod_usb.set_filter_width") { auto p = make_gr_demod_ssb(sps, samp_rate, carrier_freq, filter_width, 0); s.lines.push_back("== set_filter_width"); p->set_filter_width(fm); }
+    else if (k == "demod_lsb.set_filter_width") { auto p = make_gr_demod_ssb(sps, samp_rate, carrier_freq, filter_width, 1); s.lines.push_back("== set_filter_width"); p->set_filter_width(fm); }
+    else if (k == "demod_usb.set_gain") { auto p = make_gr_demod_ssb(sps, samp_rate, carrier_freq, filter_width, 0); s.lines.push_back("== set_gain"); p->set_gain((float)fm / 1000.0f); }
+    else if (k == "mod_nbfm.set_filter_width") { auto p = make_gr_mod_nbfm(sps, samp_rate, carrier_freq, filter_width); s.lines.push_back("== set_filter_width"); p->set_filter_width(fm); }
+    else if (k == "mod_am.set_filter_width") { auto p = make_gr_mod_am(sps, samp_rate, carrier_freq, filter_width); s.lines.push_back("== set_filter_width"); p->set_filter_width(fm); }
+    else if (k == "mod_usb.set_filter_width") { auto p = make_gr_mod_ssb(sps, samp_rate, carrier_freq, filter_width, 0); s.lines.push_back("== set_filter_width"); p->set_filter_width(fm); }
+    else if (k == "mod_lsb.set_filter_width") { auto p = make_gr_mod_ssb(sps, samp_rate, carrier_freq, filter_width, 1); s.lines.push_back("== set_filter_width"); p->set_filter_width(fm); }
     else ok = false;
     if (!ok) return nullptr;
     g_text.clear();

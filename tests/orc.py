@@ -744,10 +744,12 @@ def ctcss_squelch_ff(x, rate=8000, freq=88.5, level=0.01, length=8000, ramp=160,
     return out[:n].copy()
 
 
-def demod_analog(x, kind, samp_rate=1000000, filter_width=5000, ctcss=0.0):
-    """-> dict(filtered=cf32 port 0, audio=f32 port 1); ctcss != 0 (NBFM): gr_demod_nbfm::set_ctcss(tone) was called"""
+def demod_analog(x, kind, samp_rate=1000000, filter_width=5000, ctcss=0.0, set_width=0):
+    """-> dict(filtered=cf32 port 0, audio=f32 port 1); ctcss != 0 (NBFM): gr_demod_nbfm::set_ctcss(tone) was called;
+    set_width != 0: gr_demod_X::set_filter_width(set_width) was called on the block constructed with filter_width"""
     x = np.ascontiguousarray(x, cf32)
     lib.orc_set_ctcss(C.c_float(ctcss))
+    lib.orc_set_rx_filter_width(int(set_width))
     f, a = C.c_void_p(), C.c_void_p()
     nf, na = C.c_size_t(), C.c_size_t()
     lib.orc_demod_analog(_ptr(x), C.c_size_t(x.size), ANALOG_KINDS[kind], samp_rate, filter_width,
@@ -756,21 +758,25 @@ def demod_analog(x, kind, samp_rate=1000000, filter_width=5000, ctcss=0.0):
     aud = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_float)), (na.value,)).copy() if na.value else np.zeros(0, np.float32)
     lib.orc_free(f); lib.orc_free(a)
     lib.orc_set_ctcss(C.c_float(0.0))
+    lib.orc_set_rx_filter_width(0)
     return dict(filtered=filt, audio=aud)
 
 
-def mod_nbfm(audio, sps=20, samp_rate=1000000, filter_width=5000, bb_gain=1.0, ctcss=0.0):
-    """ctcss > 0: gr_mod_nbfm::set_ctcss(tone) was called; < 0: set_ctcss(0) after it had been on (x0.98); 0: the constructor's graph"""
+def mod_nbfm(audio, sps=20, samp_rate=1000000, filter_width=5000, bb_gain=1.0, ctcss=0.0, set_width=0):
+    """ctcss > 0: gr_mod_nbfm::set_ctcss(tone) was called; < 0: set_ctcss(0) after it had been on (x0.98); 0: the constructor's graph;
+    set_width != 0: gr_mod_nbfm::set_filter_width(set_width) was called"""
     audio = np.ascontiguousarray(audio, np.float32)
     lib.orc_mod_nbfm.restype = C.c_size_t
     args = (_ptr(audio), C.c_size_t(audio.size), sps, samp_rate, filter_width, C.c_float(bb_gain))
     lib.orc_set_tx_ctcss(C.c_float(ctcss))
+    lib.orc_set_tx_filter_width(int(set_width))
     try:
         n = lib.orc_mod_nbfm(*args, None)
         y = np.zeros(n, cf32)
         m = lib.orc_mod_nbfm(*args, _ptr(y))
     finally:
         lib.orc_set_tx_ctcss(C.c_float(0.0))
+        lib.orc_set_tx_filter_width(0)
     return y[:m]
 
 
@@ -812,23 +818,31 @@ def mod_dmr(data, sps=125, samp_rate=1000000, filter_width=5000, bb_gain=1.0, ze
     return y[:m]
 
 
-def mod_ssb(audio, sb=0, sps=125, samp_rate=1000000, filter_width=2700, bb_gain=1.0):
+def mod_ssb(audio, sb=0, sps=125, samp_rate=1000000, filter_width=2700, bb_gain=1.0, set_width=0):
     audio = np.ascontiguousarray(audio, np.float32)
     lib.orc_mod_ssb.restype = C.c_size_t
     args = (_ptr(audio), C.c_size_t(audio.size), sps, samp_rate, filter_width, sb, C.c_float(bb_gain))
-    n = lib.orc_mod_ssb(*args, None)
-    y = np.zeros(max(n, 1), cf32)
-    m = lib.orc_mod_ssb(*args, _ptr(y)) if n else 0
+    lib.orc_set_tx_filter_width(int(set_width))
+    try:
+        n = lib.orc_mod_ssb(*args, None)
+        y = np.zeros(max(n, 1), cf32)
+        m = lib.orc_mod_ssb(*args, _ptr(y)) if n else 0
+    finally:
+        lib.orc_set_tx_filter_width(0)
     return y[:m]
 
 
-def mod_am(audio, sps=125, samp_rate=1000000, filter_width=5000, bb_gain=1.0):
+def mod_am(audio, sps=125, samp_rate=1000000, filter_width=5000, bb_gain=1.0, set_width=0):
     audio = np.ascontiguousarray(audio, np.float32)
     lib.orc_mod_am.restype = C.c_size_t
     args = (_ptr(audio), C.c_size_t(audio.size), sps, samp_rate, filter_width, C.c_float(bb_gain))
-    n = lib.orc_mod_am(*args, None)
-    y = np.zeros(max(n, 1), cf32)
-    m = lib.orc_mod_am(*args, _ptr(y)) if n else 0
+    lib.orc_set_tx_filter_width(int(set_width))
+    try:
+        n = lib.orc_mod_am(*args, None)
+        y = np.zeros(max(n, 1), cf32)
+        m = lib.orc_mod_am(*args, _ptr(y)) if n else 0
+    finally:
+        lib.orc_set_tx_filter_width(0)
     return y[:m]
 
 
@@ -838,11 +852,18 @@ def preemph_taps(sample_rate, tau=50e-6):
     return list(a), list(b)
 
 
-def demod_ssb(x, sb=0, samp_rate=1000000, filter_width=2700):
+def demod_ssb(x, sb=0, samp_rate=1000000, filter_width=2700, set_width=0, gain=None):
+    """set_width != 0: gr_demod_ssb::set_filter_width(set_width) was called; gain: gr_demod_ssb::set_gain(gain) (None = the constructor's 0.9)"""
     x = np.ascontiguousarray(x, cf32)
     f, a = C.c_void_p(), C.c_void_p()
     nf, na = C.c_size_t(), C.c_size_t()
-    lib.orc_demod_ssb(_ptr(x), C.c_size_t(x.size), samp_rate, filter_width, sb, C.byref(f), C.byref(nf), C.byref(a), C.byref(na))
+    lib.orc_set_rx_filter_width(int(set_width))
+    lib.orc_set_rx_gain(C.c_float(-1.0 if gain is None else gain))
+    try:
+        lib.orc_demod_ssb(_ptr(x), C.c_size_t(x.size), samp_rate, filter_width, sb, C.byref(f), C.byref(nf), C.byref(a), C.byref(na))
+    finally:
+        lib.orc_set_rx_filter_width(0)
+        lib.orc_set_rx_gain(C.c_float(-1.0))
     filt = np.ctypeslib.as_array(C.cast(f, C.POINTER(C.c_float)), (2 * nf.value,)).copy().view(cf32) if nf.value else np.zeros(0, cf32)
     aud = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_float)), (na.value,)).copy() if na.value else np.zeros(0, np.float32)
     lib.orc_free(f); lib.orc_free(a)

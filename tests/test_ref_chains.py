@@ -110,16 +110,18 @@ def parse_call(text):
 
 class RefGraph:
     def __init__(self, log):
-        self.blocks, self.edges, self.calls = {}, [], []
+        self.blocks, self.edges, self.calls, self.setter_calls = {}, [], [], None
         for line in log.splitlines():
             if line.startswith("hier "):
                 self.name = line[5:]
+            elif line.startswith("== "):                      # "<kind>.set_x" logs: what follows is what the setter did
+                self.setter_calls = []
             elif "->" in line:
                 a, b = line.split(" -> ")
                 pa, pb = (int(x) for x in a[1:].split(":")), (int(x) for x in b[1:].split(":"))
                 self.edges.append((tuple(pa), tuple(pb)))
             elif re.match(r"^#\d+\.", line):
-                self.calls.append(line)
+                (self.calls if self.setter_calls is None else self.setter_calls).append(line)
             else:
                 m = re.match(r"^#(\d+) (.*)$", line)
                 self.blocks[int(m.group(1))] = parse_call(m.group(2))
@@ -593,6 +595,87 @@ def test_demod_mmdvm_multi(N):
     compare("demod_mmdvm_multi", (N, 25000, 1), lambda x: orc.demod_mmdvm_xlating(x, N), dict(),
             ["custom::gr_mmdvm_sink()"] + ["custom::rssi_tag_block()", "blocks::multiply_const_ff(1)", "blocks::float_to_short(1,32767)"] * N,
             n=30000)
+
+
+SETTER_CASES = [
+    # kind, constructor arguments + the setter's value, the oracle call with the same setter applied, its input ("iq" / "audio")
+    ("demod_nbfm.set_filter_width", (125, 1000000, 1700, 5000, 4000), lambda v: orc.demod_analog(v, "nbfm", filter_width=5000, set_width=4000), "iq"),
+    ("demod_nbfm.set_filter_width", (125, 1000000, 1700, 2500, 3000), lambda v: orc.demod_analog(v, "nbfm", filter_width=2500, set_width=3000), "iq"),
+    ("demod_am.set_filter_width", (125, 1000000, 1700, 5000, 4000), lambda v: orc.demod_analog(v, "am", filter_width=5000, set_width=4000), "iq"),
+    ("demod_wbfm.set_filter_width", (125, 1000000, 1700, 75000, 60000), lambda v: orc.demod_analog(v, "wbfm", filter_width=75000, set_width=60000), "iq"),
+    ("demod_usb.set_filter_width", (125, 1000000, 1700, 2700, 2400), lambda v: orc.demod_ssb(v, sb=0, set_width=2400), "iq"),
+    ("demod_lsb.set_filter_width", (125, 1000000, 1700, 2700, 2400), lambda v: orc.demod_ssb(v, sb=1, set_width=2400), "iq"),
+    ("mod_nbfm.set_filter_width", (20, 1000000, 1700, 5000, 4000), lambda v: orc.mod_nbfm(v, filter_width=5000, set_width=4000), "audio"),
+    ("mod_am.set_filter_width", (125, 1000000, 1700, 5000, 4000), lambda v: orc.mod_am(v, filter_width=5000, set_width=4000), "audio"),
+    ("mod_usb.set_filter_width", (125, 1000000, 1700, 2700, 2400), lambda v: orc.mod_ssb(v, sb=0, set_width=2400), "audio"),
+    ("mod_lsb.set_filter_width", (125, 1000000, 1700, 2700, 2400), lambda v: orc.mod_ssb(v, sb=1, set_width=2400), "audio"),
+]
+
+
+@pytest.mark.parametrize("kind,args,fn,what", SETTER_CASES, ids=[c[0] + "_%d" % c[1][4] for c in SETTER_CASES])
+def test_set_filter_width_of_the_analogue_blocks(kind, args, fn, what):
+    """gr_demod_base::set_filter_width(width, mode) / gr_mod_base::set_filter_width (src/gr/gr_demod_base.cpp:1155-1185, gr_mod_base.cpp:878-905) forward to
+    the blocks' own set_filter_width, which do NOT repeat the constructors' designs (other transition widths, other design functions, a gain of 2 in the SSB
+    receiver's audio filter).  The reference's setters run here against the recording stand-ins: every set_taps design they issue must be the design the oracle
+    uses for that filter when the same setter is applied, every design of the oracle's chain must come from the constructor or from the setter, and the
+    discriminator gain / modulator sensitivity the setter sets must be the oracle's."""
+    g = RefGraph(ref_log(kind, *args))
+    assert g.setter_calls, "the setter did nothing?"
+    rng = np.random.default_rng(5)
+    if what == "iq":
+        x = ((rng.standard_normal(20000) + 1j * rng.standard_normal(20000)) * 0.3).astype(np.complex64)
+    else:
+        x = (rng.standard_normal(3000) * 0.1).astype(np.float32)
+    tr = [parse_call(l) for l in oracle_trace(fn, x)]
+    designs = lambda calls: {norm_value(a, None, True) for _, aa in calls for a in aa if re.match(r"^[a-z_0-9]+\(.*\)$", a.strip())}
+    oracle_designs = designs(tr)
+    ctor_designs = designs(list(g.blocks.values()))
+    set_designs, numbers = set(), []
+    for line in g.setter_calls:
+        m = re.match(r"^#(\d+)\.(\w+)\((.*)\)$", line)
+        assert m, line
+        blk, call, arg = int(m.group(1)), m.group(2), m.group(3)
+        if call == "set_taps":
+            d = norm_value(arg, None, True)
+            set_designs.add(d)
+            if blk in g.connected:                                   # the SSB blocks set both sideband filters; one of them is in the graph
+                assert d in oracle_designs, (line, sorted(oracle_designs))
+        else:
+            numbers.append((call, float(np.float32(float(arg)))))
+    assert oracle_designs <= ctor_designs | set_designs, sorted(oracle_designs - ctor_designs - set_designs)
+    # the filters the setter re-designed are no longer the constructor's in the oracle either
+    for blk, (k, a) in g.blocks.items():
+        replaced = [l for l in g.setter_calls if l.startswith("#%d.set_taps(" % blk)]
+        if replaced and blk in g.connected:
+            old = designs([(k, a)])
+            new = {norm_value(re.match(r"^#\d+\.set_taps\((.*)\)$", replaced[-1]).group(1), None, True)}
+            if old != new:
+                assert not (old & oracle_designs), (k, a)
+    for call, v in numbers:
+        name = {"set_gain": "quad_demod", "set_sensitivity": "freq_mod"}[call]
+        got = [float(np.float32(float(a[0]))) for n_, a in tr if n_ == name]
+        assert got == [v], (call, v, got)
+
+
+def test_set_gain_of_the_ssb_receiver():
+    """gr_demod_base::set_gain (src/gr/gr_demod_base.cpp:1206-1210) -> gr_demod_ssb::set_gain = _if_gain->set_k(value) (gr_demod_ssb.cpp:118-121): the block the
+    setter touches is the constructor's multiply_const_cc(0.9) between the resampler and the sideband filter, which is where the oracle applies the new gain"""
+    g = RefGraph(ref_log("demod_usb.set_gain", 125, 1000000, 1700, 2700, 500))
+    assert len(g.setter_calls) == 1
+    m = re.match(r"^#(\d+)\.set_k\((.*)\)$", g.setter_calls[0])
+    blk = int(m.group(1))
+    assert float(m.group(2)) == 0.5
+    k, a = g.blocks[blk]
+    assert k == "blocks::multiply_const_cc" and float(np.float32(float(a[0]))) == float(np.float32(0.9))
+    src = {s_[0] for s_, d in g.edges if d[0] == blk}
+    dst = {d[0] for s_, d in g.edges if s_[0] == blk}
+    assert {g.blocks[b][0] for b in src} == {"filter::rational_resampler_ccf"} and {g.blocks[b][0] for b in dst} == {"filter::fft_filter_ccc"}
+    rng = np.random.default_rng(6)
+    x = ((rng.standard_normal(300000) + 1j * rng.standard_normal(300000)) * 0.3).astype(np.complex64)
+    a1, a2 = orc.demod_ssb(x, sb=0), orc.demod_ssb(x, sb=0, gain=0.9)
+    assert np.array_equal(a1["filtered"], a2["filtered"]) and np.array_equal(a1["audio"], a2["audio"])
+    half = orc.demod_ssb(x, sb=0, gain=0.5)
+    assert np.allclose(half["filtered"], a1["filtered"] * np.float32(0.5 / 0.9), rtol=1e-5, atol=1e-7) and not np.array_equal(half["filtered"], a1["filtered"])
 
 
 @pytest.mark.skipif(not os.path.exists(REC), reason="needs the live library")
