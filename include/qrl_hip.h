@@ -144,6 +144,16 @@ int qrl_demod_set_time_domain_output(qrl_demod* d, float* samples, size_t cap, u
 int qrl_demod_set_ctcss(qrl_demod* d, float tone_hz);
 /* replaces gr_demod_am / gr_demod_ssb::set_agc_attack / set_agc_decay (gr_demod_am.cpp:90-98, gr_demod_ssb.cpp:104-112) */
 int qrl_demod_set_agc(qrl_demod* d, float attack, float decay);
+/* replaces gr_demod_base::set_filter_width(filter_width, mode) (src/gr/gr_demod_base.cpp:1155-1185), which forwards to the analogue receiver of
+ * `mode`: gr_demod_nbfm::set_filter_width (gr_demod_nbfm.cpp:82-90), gr_demod_am (gr_demod_am.cpp:84-91), gr_demod_wbfm (gr_demod_wbfm.cpp:76-84),
+ * gr_demod_ssb (gr_demod_ssb.cpp:89-101).  The setters do NOT repeat the constructors' designs: NBFM / WBFM low_pass(1, fs, w, 1200, BH) and the
+ * discriminator gain fs / (4 pi w) resp. fs / (2 pi w); AM complex_band_pass(1, fs, -w, w, 1200, BH); SSB the constructor's band-pass with w and the
+ * audio filter band_pass_2(2, 8000, 200, w, 200, 90, BH) -- gain 2.  The reference swaps the taps of a running graph at a sample its scheduler decides;
+ * here the chain restarts from a fresh state (like qrl_demod_reset; squelch / CTCSS / AGC settings are kept).  Analogue receivers only. */
+int qrl_demod_set_filter_width(qrl_demod* d, int filter_width);
+/* replaces gr_demod_base::set_gain(value) (src/gr/gr_demod_base.cpp:1206-1210) -> gr_demod_ssb::set_gain = _if_gain->set_k(value) (gr_demod_ssb.cpp:118-121;
+ * constructor: 0.9).  Takes effect with the next qrl_demod_process call.  SSB receivers only. */
+int qrl_demod_set_gain(qrl_demod* d, float value);
 
 /* replaces: one scheduler pass of the "demodulator" top_block over n new samples per stream:
  * (the serial tail of a call runs on an internal second HIP stream and overlaps the next call; only
@@ -482,6 +492,13 @@ int qrl_amod_set_bb_gain(qrl_amod* m, float value);
  * constructor's 0.99 does not come back).  Takes effect with the next qrl_amod_process call; the tone's phase runs over the samples produced
  * while it is on.  NBFM handles only.  [The tone source is GNU Radio's fixed-point NCO with its 1024-row sine table, restated from memory.] */
 int qrl_amod_set_ctcss(qrl_amod* m, float tone_hz);
+/* replaces gr_mod_base::set_filter_width(filter_width, mode) (src/gr/gr_mod_base.cpp:878-905) -> gr_mod_nbfm::set_filter_width (gr_mod_nbfm.cpp:78-93:
+ * _if_resampler low_pass_2(25, 200000, w, w, 60, BH), _filter low_pass_2(1, 50000, w, 1200, 60, BH), _resampler low_pass_2(sps, 1e6, w, w, 60, BH),
+ * sensitivity 4 pi w / 50000 -- the constructor uses a 3500 Hz transition everywhere), gr_mod_am (gr_mod_am.cpp:75-85: the constructor's designs with w),
+ * gr_mod_ssb (gr_mod_ssb.cpp:85-100: _resampler as constructed with w, the sideband filter complex_band_pass_2(1, 8000, 300, w | -w, -300, 250, 90, BH);
+ * the audio filter keeps the constructor's width).  The chain restarts from a fresh state (see qrl_demod_set_filter_width); bb_gain and the CTCSS
+ * switch are kept.  Widths whose filters do not fit the kernels' tables are refused (NBFM < 1340, SSB < 1780, AM < 1180 Hz). */
+int qrl_amod_set_filter_width(qrl_amod* m, int filter_width);
 size_t qrl_amod_samples_per_sample(const qrl_amod* m);
 /* SSB (replaces make_gr_mod_ssb(125, 1000000, 1700, 2700, sb), reference src/gr/gr_mod_ssb.cpp:19-82, gr_mod_base.cpp:178-179): the
  * cessb stretcher emits whole chunks of 1024 audio-rate items and looks two items ahead, so a call returns 125 x (chunks completed

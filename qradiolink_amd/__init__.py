@@ -122,6 +122,9 @@ def load_library():
         getattr(lib, name).argtypes = [vp, vp, vp, sz, vp]
     lib.qrl_demod_set_squelch.argtypes = [vp, C.c_double]
     lib.qrl_demod_set_agc.argtypes = [vp, C.c_float, C.c_float]
+    lib.qrl_demod_set_filter_width.argtypes = [vp, C.c_int]
+    lib.qrl_demod_set_gain.argtypes = [vp, C.c_float]
+    lib.qrl_amod_set_filter_width.argtypes = [vp, C.c_int]
     lib.qrl_demod_process.argtypes = [vp, vp, sz, sz, C.POINTER(_Out)]
     lib.qrl_demod_sync.argtypes = [vp]
     lib.qrl_rssi_create.argtypes = [vp, C.c_int, C.c_float, vp, C.POINTER(vp)]
@@ -220,9 +223,9 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "qrl_init", "qrl_shutdown", "qrl_strerror", "qrl_last_error", "qrl_version", "qrl_demod_create",
     "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_set_option", "qrl_demod_set_dmo_output", "qrl_demod_stream_wait", "qrl_demod_out_caps",
-    "qrl_demod_audio_cap", "qrl_demod_set_squelch", "qrl_demod_set_agc", "qrl_demod_set_ctcss", "qrl_demod_time_domain_cap", "qrl_demod_set_time_domain_output",
+    "qrl_demod_audio_cap", "qrl_demod_set_squelch", "qrl_demod_set_agc", "qrl_demod_set_filter_width", "qrl_demod_set_gain", "qrl_demod_set_ctcss", "qrl_demod_time_domain_cap", "qrl_demod_set_time_domain_output",
     "qrl_bptc19696_decode", "qrl_bptc19696_encode", "qrl_m17_decode_frames", "qrl_m17_encode_frames",
-    "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_set_ctcss", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
+    "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_set_ctcss", "qrl_amod_set_filter_width", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_internal_streams", "qrl_chan_internal_streams", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
     "qrl_mod_samples_per_byte", "qrl_mod_samples_per_block", "qrl_mod_add_zero_runs", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_set_option", "qrl_chan_channelize", "qrl_chan_process_channels", "qrl_chan_wait_for", "qrl_chan_stream_wait", "qrl_chan_stream", "qrl_chan_profile", "qrl_chan_profile_read", "qrl_chan_profile_read_kernels", "qrl_debug_decim_prof", "qrl_debug_decim_prof_enable", "qrl_chan_create",
@@ -401,6 +404,14 @@ class Demod:
 
     def set_agc(self, attack, decay):
         _check(self.lib.qrl_demod_set_agc(self.h, C.c_float(attack), C.c_float(decay)), "qrl_demod_set_agc")
+
+    def set_filter_width(self, width):
+        """gr_demod_base::set_filter_width for this handle's analogue mode: the setter's own filter designs, the chain restarts (qrl_demod_set_filter_width)"""
+        _check(self.lib.qrl_demod_set_filter_width(self.h, int(width)), "qrl_demod_set_filter_width")
+
+    def set_gain(self, value):
+        """gr_demod_base::set_gain: the SSB receivers' IF gain (qrl_demod_set_gain)"""
+        _check(self.lib.qrl_demod_set_gain(self.h, C.c_float(value)), "qrl_demod_set_gain")
 
     def stream_wait(self, hip_stream):
         """the given HIP stream (int handle) waits, on the device, for everything this handle has queued so far (qrl_demod_stream_wait)"""
@@ -877,6 +888,10 @@ class AMod:
     def set_ctcss(self, tone_hz):
         """gr_mod_nbfm::set_ctcss: tone (Hz) added to the audio, band-pass audio filter; 0 switches it off again (qrl_amod_set_ctcss)"""
         _check(self.lib.qrl_amod_set_ctcss(self.h, C.c_float(tone_hz)), "qrl_amod_set_ctcss")
+
+    def set_filter_width(self, width):
+        """gr_mod_base::set_filter_width for this handle's mode: the setter's own filter designs, the chain restarts (qrl_amod_set_filter_width)"""
+        _check(self.lib.qrl_amod_set_filter_width(self.h, int(width)), "qrl_amod_set_filter_width")
 
     def reset(self):
         _check(self.lib.qrl_amod_reset(self.h), "qrl_amod_reset")

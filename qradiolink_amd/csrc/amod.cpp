@@ -32,7 +32,7 @@ namespace {
 template <class T> struct Dev {
     T* p = nullptr; size_t n = 0;
     ~Dev() { if (p) (void)hipFree(p); }
-    int alloc(size_t count) { n = count; return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)) == hipSuccess ? QRL_OK : QRL_ERR_HIP; }
+    int alloc(size_t count) { if (p) { (void)hipFree(p); p = nullptr; } n = count; return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)) == hipSuccess ? QRL_OK : QRL_ERR_HIP; }
     int upload(const std::vector<T>& v) { if (int r = alloc(v.size())) return r; return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess ? QRL_OK : QRL_ERR_HIP; }
     int zero() { return hipMemset(p, 0, n * sizeof(T)) == hipSuccess ? QRL_OK : QRL_ERR_HIP; }
 };
@@ -189,6 +189,44 @@ int qrl_amod_set_ctcss(qrl_amod* m, float tone_hz)
     x -= d * 2 * PI_F;
     m->tone_inc = (uint32_t)(int32_t)(x * 2147483648.0f / PI_F);
     return QRL_OK;
+}
+int qrl_amod_set_filter_width(qrl_amod* m, int width)
+{
+    if (!m) return QRL_ERR_ARG;
+    // the setters' own designs (they do not repeat the constructors'): gr_mod_nbfm.cpp:78-93, gr_mod_am.cpp:75-85, gr_mod_ssb.cpp:85-100
+    const double w = width;
+    if (width <= 0 || (m->ssb ? (width <= 300 || width > 4000) : m->am ? 2 * width > 1000000 : width > 25000))
+        return qrl_set_error(QRL_ERR_ARG, "qrl_amod_set_filter_width: width out of range");
+    HIPCHK(hipSetDevice(m->ctx->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    auto to2 = [](const std::vector<std::complex<float>>& t) { std::vector<float2> o(t.size()); for (size_t i = 0; i < t.size(); ++i) o[i] = make_float2(t[i].real(), t[i].imag()); return o; };
+    int r;
+    if (m->am) {
+        const std::vector<float> tr = low_pass(m->sps, 1000000, w, w, WIN_HAMMING);
+        const auto tc = complex_band_pass_2(1, 1000000, -w, w, 1200, 120, WIN_BLACKMAN_HARRIS);
+        if (tr.size() > 2048 || tc.size() != (size_t)m->n_chan) return qrl_set_error(QRL_ERR_ARG, "qrl_amod_set_filter_width: AM interpolator too long for the kernel's LDS table (width >= 1180)");
+        if ((r = m->t_interp.upload(tr)) || (r = m->t_chan.upload(to2(tc)))) return r;
+        m->n_interp = (int)tr.size();
+    } else if (m->ssb) {
+        // (the audio filter keeps the constructor's width)
+        const std::vector<float> tr = low_pass_2(m->sps, 1000000, w, w, 90, WIN_BLACKMAN_HARRIS);
+        const auto ts = m->lsb ? complex_band_pass_2(1, 8000, -w, -300, 250, 90, WIN_BLACKMAN_HARRIS) : complex_band_pass_2(1, 8000, 300, w, 250, 90, WIN_BLACKMAN_HARRIS);
+        if (tr.size() > 2048 || ts.size() > 1024) return qrl_set_error(QRL_ERR_ARG, "qrl_amod_set_filter_width: filter too long (width >= 1780)");
+        if ((r = m->t_interp.upload(tr)) || (r = m->t_side.upload(to2(ts)))) return r;
+        m->n_interp = (int)tr.size(); m->n_side = (int)ts.size();
+    } else {
+        const std::vector<float> ti = low_pass_2(25, 50000.0 * 4, w, w, 60, WIN_BLACKMAN_HARRIS);
+        const std::vector<float> tf = low_pass_2(1, 50000, w, 1200, 60, WIN_BLACKMAN_HARRIS);
+        const std::vector<float> tr = low_pass_2(m->sps, 1000000, w, w, 60, WIN_BLACKMAN_HARRIS);
+        if (tr.size() > 2048 || ti.size() > 1024 || tf.size() > 1024) return qrl_set_error(QRL_ERR_ARG, "qrl_amod_set_filter_width: filter too long (width >= 1340)");
+        if ((r = m->t_if.upload(ti)) || (r = m->t_filt.upload(tf)) || (r = m->t_interp.upload(tr))) return r;
+        m->n_if = (int)ti.size(); m->n_filt = (int)tf.size(); m->n_interp = (int)tr.size();
+        m->fm_k = (float)(4 * M_PI * width / 50000.0f);
+    }
+    m->fw = width;
+    // The reference swaps the taps of a running graph under lock() / unlock(), at a sample position its scheduler decides; here the chain restarts
+    // from a fresh state (like qrl_amod_reset; the set_ctcss switch and bb_gain are kept) -- what the tests compare is the chain built with the setter's designs.
+    return m->init_state();
 }
 size_t qrl_amod_samples_per_sample(const qrl_amod* m) { return m ? ((m->ssb || m->am) ? (size_t)m->sps : (size_t)25 * m->sps / 4) : 0; }
 size_t qrl_amod_last_count(const qrl_amod* m) { return m ? m->last : 0; }

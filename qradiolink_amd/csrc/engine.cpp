@@ -65,6 +65,7 @@ template <class T> struct DevBuf {
     T* p = nullptr; size_t n = 0;
     ~DevBuf() { if (p) (void)hipFree(p); }
     int alloc(size_t count) {
+        if (p) { (void)hipFree(p); p = nullptr; }   // re-designed filters (qrl_demod_set_filter_width) replace their tables
         n = count;
         if (hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return QRL_ERR_NOMEM;
         if (hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return QRL_ERR_HIP;
@@ -249,6 +250,7 @@ struct qrl_demod {
     double an_threshold = 1e-14, an_ff[2] = {0, 0}, an_fb1 = 0, an_de_ff[2] = {0, 0}, an_de_fb1 = 0;
     float an_gain = 1.f, an_attack = 0.1f, an_decay = 0.1f;
     int analog_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* out, uint32_t* counts, bool side);
+    float an_if_gain = 0.9f;
     uint64_t n_in = 0, n1 = 0, n2 = 0;  // items so far: device rate, 1 Msps, target rate
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -1007,7 +1009,7 @@ int qrl_demod::analog_stages(uint64_t n2_0, uint64_t n2_1, const qrl_demod_out* 
     const uint32_t c2 = (uint32_t)(n2_1 - n2_0);
     float2* fport = side && out->filtered ? reinterpret_cast<float2*>(out->filtered) : nullptr;
     const size_t fcap = side ? out->filtered_cap : 0;
-    if (an_kind == 3) launch_scale_c(r2, n2_0, c2, 0.9f, B, stream);   // _if_gain, gr_demod_ssb.cpp:45
+    if (an_kind == 3) launch_scale_c(r2, n2_0, c2, an_if_gain, B, stream);   // _if_gain, gr_demod_ssb.cpp:45 (0.9 until gr_demod_ssb::set_gain)
     if (an_kind == 1 || an_kind == 3) {   // _filter -> port 0
         FirCccParams f{}; f.in = r2; f.out = r2f; f.q0 = n2_0; f.count = c2; f.taps = an_filt_c.p; f.nt = an_nfc;
         f.port = fport; f.port_cap = fcap; f.counts = counts;
@@ -1363,6 +1365,44 @@ int qrl_demod_set_ctcss(qrl_demod* d, float tone_hz)
         for (auto& x : cs) { for (int k = 0; k < 3; ++k) x.d1[k] = x.d2[k] = 0.0f; x.processed = 0; }
         if (hipMemcpy(d->an_cs.p, cs.data(), cs.size() * sizeof(CtcssState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
     }
+    return QRL_OK;
+}
+int qrl_demod_set_filter_width(qrl_demod* d, int width)
+{
+    if (!d || d->fam != qrl_demod::F_ANALOG)
+        return qrl_set_error(QRL_ERR_ARG, "qrl_demod_set_filter_width: analogue receivers only (gr_demod_base::set_filter_width forwards to WBFM, AM, NBFM, USB, LSB)");
+    // firdes' sanity checks: 0 < cutoff <= fs / 2; the SSB band starts at 200 Hz
+    if (width <= 0 || 2 * width > d->target || (d->an_kind == 3 && width <= 200)) return qrl_set_error(QRL_ERR_ARG, "qrl_demod_set_filter_width: width out of range");
+    HIPCHK(hipSetDevice(d->ctx->device));
+    if (int rs = d->sync_all()) return rs;
+    const double fs = d->target, w = width;
+    int r = QRL_OK;
+    // the setters do not repeat the constructors' designs (transition widths, design functions, the SSB audio filter's gain of 2)
+    if (d->an_kind == 0 || d->an_kind == 2) {   // gr_demod_nbfm.cpp:82-90, gr_demod_wbfm.cpp:76-84
+        const std::vector<float> f = low_pass(1, fs, w, 1200, WIN_BLACKMAN_HARRIS);
+        d->filt_nt = (int)f.size();
+        r = d->filt_taps.upload(f);
+        d->an_gain = (float)(d->target / ((d->an_kind == 0 ? 4 : 2) * M_PI * width));
+    } else if (d->an_kind == 1) {               // gr_demod_am.cpp:84-91
+        const auto fc = complex_band_pass(1, fs, -w, w, 1200, WIN_BLACKMAN_HARRIS);
+        d->an_nfc = (int)fc.size();
+        r = d->an_filt_c.upload(to_f2(fc));
+    } else {                                    // gr_demod_ssb.cpp:89-101
+        const auto fc = d->an_lsb ? complex_band_pass_2(1, fs, -w, -200, 200, 90, WIN_BLACKMAN_HARRIS) : complex_band_pass_2(1, fs, 200, w, 200, 90, WIN_BLACKMAN_HARRIS);
+        const std::vector<float> ft = band_pass_2(2, fs, 200, w, 200, 90, WIN_BLACKMAN_HARRIS);
+        d->an_nfc = (int)fc.size(); d->an_nf = (int)ft.size();
+        if (!(r = d->an_filt_c.upload(to_f2(fc)))) r = d->an_ftaps.upload(ft);
+    }
+    if (r) return qrl_set_error(r, "qrl_demod_set_filter_width: filter tables");
+    d->cfg.filter_width = width;
+    // The reference swaps the taps of a running graph under lock() / unlock(), at a sample position its scheduler decides; here the chain restarts
+    // from a fresh state (like qrl_demod_reset; squelch, CTCSS and AGC settings are kept) -- what the tests compare is the chain built with the setter's designs.
+    return d->init_state();
+}
+int qrl_demod_set_gain(qrl_demod* d, float value)
+{
+    if (!d || d->fam != qrl_demod::F_ANALOG || d->an_kind != 3) return qrl_set_error(QRL_ERR_ARG, "qrl_demod_set_gain: SSB receivers only (gr_demod_base::set_gain)");
+    d->an_if_gain = value;   // multiply_const_cc::set_k: from the next call on, nothing restarts
     return QRL_OK;
 }
 int qrl_demod_set_agc(qrl_demod* d, float attack, float decay)

@@ -140,6 +140,8 @@ void gr_demod_base_hip::open()
     if (d_acap) chk(qrl_demod_set_squelch(d_h, (double)d_squelch), "qrl_demod_set_squelch");
     if (d_acap && d_mode == QRL_MODEM_AM5000) chk(qrl_demod_set_agc(d_h, d_agc_attack, d_agc_decay), "qrl_demod_set_agc");
     if (d_acap && d_ctcss != 0.0f && (d_mode == QRL_MODEM_NBFM2500 || d_mode == QRL_MODEM_NBFM5000)) chk(qrl_demod_set_ctcss(d_h, d_ctcss), "qrl_demod_set_ctcss");   // the reference's instances keep their tone across mode changes
+    if (d_acap && d_width.count(d_mode)) chk(qrl_demod_set_filter_width(d_h, d_width[d_mode]), "qrl_demod_set_filter_width");   // ... and their set_filter_width designs
+    if (d_acap && d_if_gain >= 0.0f && (d_mode == QRL_MODEM_USB2500 || d_mode == QRL_MODEM_LSB2500)) chk(qrl_demod_set_gain(d_h, d_if_gain), "qrl_demod_set_gain");
     const size_t N = (size_t)d_n;
     // side outputs on the copy stream: rssi_block behind port 0, rx_fft_c on the device-rate IQ (gr_demod_base.cpp:166,185,199-200)
     chk(qrl_rssi_create(d_rt.ctx(), d_n, d_rssi_cal, d_copy, &d_rssi), "qrl_rssi_create");
@@ -385,6 +387,25 @@ void gr_demod_base_hip::set_ctcss(float value)   // gr_demod_base.cpp:1212-1218 
     d_ctcss = value;
     if (d_h && d_acap && (d_mode == QRL_MODEM_NBFM2500 || d_mode == QRL_MODEM_NBFM5000)) chk(qrl_demod_set_ctcss(d_h, value), "qrl_demod_set_ctcss");
 }
+void gr_demod_base_hip::set_filter_width(int filter_width, int mode)   // gr_demod_base.cpp:1155-1185
+{
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
+    switch (mode) {
+    case QRL_MODEM_WBFM: case QRL_MODEM_AM5000: case QRL_MODEM_NBFM2500: case QRL_MODEM_NBFM5000: case QRL_MODEM_USB2500: case QRL_MODEM_LSB2500: break;
+    default: return;   // the reference's default branch
+    }
+    if (d_h && d_acap && d_mode == mode) {
+        flush();   // the chain restarts: what the running call produced belongs to the old filters (recursive lock)
+        chk(qrl_demod_set_filter_width(d_h, filter_width), "qrl_demod_set_filter_width");
+    }
+    d_width[mode] = filter_width;
+}
+void gr_demod_base_hip::set_gain(float value)   // gr_demod_base.cpp:1206-1210 -> gr_demod_ssb::set_gain on both SSB instances
+{
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
+    d_if_gain = value;
+    if (d_h && d_acap && (d_mode == QRL_MODEM_USB2500 || d_mode == QRL_MODEM_LSB2500)) chk(qrl_demod_set_gain(d_h, value), "qrl_demod_set_gain");
+}
 void gr_demod_base_hip::set_agc_attack(float value)   // :1428-1448
 {
     std::lock_guard<std::recursive_mutex> hg(d_hmutex);
@@ -481,20 +502,41 @@ std::vector<std::vector<unsigned char>> gr_demod_base_hip::getDMRData(int stream
 
 // ================================================================================================ gr_mod_base_hip
 gr_mod_base_hip::gr_mod_base_hip(qrl_runtime& rt, int streams, int device_samp_rate, double carrier_offset_hz, size_t max_bytes)
-    : d_rt(rt), d_n(streams), d_rate(device_samp_rate), d_offset(carrier_offset_hz), d_max(max_bytes), d_queue(streams)
+    : d_rt(rt), d_n(streams), d_rate(device_samp_rate), d_offset(carrier_offset_hz), d_max(max_bytes), d_queue(streams), d_aqueue(streams)
 {
 }
 gr_mod_base_hip::~gr_mod_base_hip()
 {
     if (d_h) qrl_mod_destroy(d_h);
+    if (d_ah) qrl_amod_destroy(d_ah);
     if (d_bytes) (void)hipFree(d_bytes);
+    if (d_audio) (void)hipFree(d_audio);
     if (d_iq) (void)hipFree(d_iq);
+}
+static bool analog_tx_mode(int mode)
+{
+    return mode == QRL_MODEM_NBFM2500 || mode == QRL_MODEM_NBFM5000 || mode == QRL_MODEM_AM5000 || mode == QRL_MODEM_USB2500 || mode == QRL_MODEM_LSB2500;
 }
 void gr_mod_base_hip::open()
 {
     if (d_h) { qrl_mod_destroy(d_h); d_h = nullptr; }
+    if (d_ah) { qrl_amod_destroy(d_ah); d_ah = nullptr; }
     if (d_bytes) { (void)hipFree(d_bytes); d_bytes = nullptr; }
+    if (d_audio) { (void)hipFree(d_audio); d_audio = nullptr; }
     if (d_iq) { (void)hipFree(d_iq); d_iq = nullptr; }
+    if (analog_tx_mode(d_mode)) {
+        if (d_rate != 1000000 || d_offset != 0.0)
+            throw std::runtime_error("gr_mod_base_hip: the analogue modulators run at the 1 Msps device rate with zero carrier offset (the back end is built behind the digital modulators)");
+        qrl_amod_config c{};
+        c.modem_type = d_mode; c.batch = d_n; c.max_samples = d_max; c.bb_gain = d_gain;
+        chk(qrl_amod_create(d_rt.ctx(), &c, &d_ah), "qrl_amod_create");
+        // the reference's instances keep what their setters did across mode changes
+        if (d_ctcss_touched && (d_mode == QRL_MODEM_NBFM2500 || d_mode == QRL_MODEM_NBFM5000)) chk(qrl_amod_set_ctcss(d_ah, d_ctcss), "qrl_amod_set_ctcss");
+        if (d_width.count(d_mode)) chk(qrl_amod_set_filter_width(d_ah, d_width[d_mode]), "qrl_amod_set_filter_width");
+        hchk(hipMalloc(reinterpret_cast<void**>(&d_audio), (size_t)d_n * d_max * sizeof(float)), "hipMalloc");
+        hchk(hipMalloc(reinterpret_cast<void**>(&d_iq), (size_t)d_n * qrl_amod_out_cap(d_ah, d_max) * sizeof(gr_complex)), "hipMalloc");
+        return;
+    }
     qrl_mod_config c{};
     c.modem_type = d_mode; c.use_mode_defaults = 1; c.batch = d_n; c.max_bytes = d_max; c.bb_gain = d_gain;
     c.device_samp_rate = d_rate; c.carrier_offset_hz = d_offset;
@@ -509,6 +551,25 @@ void gr_mod_base_hip::set_mode(int mode)   // gr_mod_base::set_mode (src/gr/gr_m
     open();
     std::lock_guard<std::mutex> g(d_mutex);
     for (auto& q : d_queue) q.clear();
+    for (auto& q : d_aqueue) q.clear();
+}
+int gr_mod_base_hip::set_audio(std::vector<float>* data, int stream)   // gr_mod_base.cpp:793-797 -> gr_audio_source::set_data (gr_audio_source.cpp:55-66)
+{
+    std::lock_guard<std::mutex> g(d_mutex);
+    d_aqueue[stream].insert(d_aqueue[stream].end(), data->begin(), data->end());
+    delete data;
+    return 0;
+}
+void gr_mod_base_hip::set_ctcss(float value)   // gr_mod_base.cpp:872-877
+{
+    d_ctcss = value; d_ctcss_touched = true;
+    if (d_ah && (d_mode == QRL_MODEM_NBFM2500 || d_mode == QRL_MODEM_NBFM5000)) chk(qrl_amod_set_ctcss(d_ah, value), "qrl_amod_set_ctcss");
+}
+void gr_mod_base_hip::set_filter_width(int filter_width, int mode)   // gr_mod_base.cpp:878-905 (CW600USB: not built)
+{
+    if (!analog_tx_mode(mode)) return;   // the reference's default branch
+    if (d_ah && d_mode == mode) chk(qrl_amod_set_filter_width(d_ah, filter_width), "qrl_amod_set_filter_width");
+    d_width[mode] = filter_width;
 }
 int gr_mod_base_hip::set_data(std::vector<uint8_t>* data, int stream)   // gr_mod_base.cpp:783-786 -> gr_byte_source::set_data (:54-62)
 {
@@ -517,11 +578,45 @@ int gr_mod_base_hip::set_data(std::vector<uint8_t>* data, int stream)   // gr_mo
     delete data;
     return 1;
 }
-void gr_mod_base_hip::set_bb_gain(float v) { d_gain = v; if (d_h) chk(qrl_mod_set_bb_gain(d_h, v), "qrl_mod_set_bb_gain"); }
-void gr_mod_base_hip::set_carrier_offset(double hz) { d_offset = hz; if (d_h) chk(qrl_mod_set_carrier_offset(d_h, hz), "qrl_mod_set_carrier_offset"); }
+void gr_mod_base_hip::set_bb_gain(float v)
+{
+    d_gain = v;
+    if (d_h) chk(qrl_mod_set_bb_gain(d_h, v), "qrl_mod_set_bb_gain");
+    if (d_ah) chk(qrl_amod_set_bb_gain(d_ah, v), "qrl_amod_set_bb_gain");
+}
+void gr_mod_base_hip::set_carrier_offset(double hz)
+{
+    if (d_ah && hz != 0.0) throw std::runtime_error("gr_mod_base_hip: the analogue modulators run with zero carrier offset");
+    d_offset = hz;
+    if (d_h) chk(qrl_mod_set_carrier_offset(d_h, hz), "qrl_mod_set_carrier_offset");
+}
 size_t gr_mod_base_hip::samples_per_byte() const { return d_h ? qrl_mod_samples_per_byte(d_h) : 0; }
 size_t gr_mod_base_hip::work(gr_complex* const* out)
 {
+    if (d_ah) {
+        size_t na = 0;
+        std::vector<float> host((size_t)d_n * d_max, 0.0f);
+        {
+            std::lock_guard<std::mutex> g(d_mutex);
+            for (auto& q : d_aqueue) na = std::max(na, std::min(q.size(), d_max));
+            if (d_mode == QRL_MODEM_NBFM2500 || d_mode == QRL_MODEM_NBFM5000) na -= na % 4;   // the 25:4 resampler; the rest waits for the next call
+            if (na == 0) return 0;
+            for (int s = 0; s < d_n; ++s) {   // a stream with fewer samples queued sends silence
+                const size_t k = std::min(d_aqueue[s].size(), na);
+                std::memcpy(host.data() + (size_t)s * d_max, d_aqueue[s].data(), k * sizeof(float));
+                d_aqueue[s].erase(d_aqueue[s].begin(), d_aqueue[s].begin() + k);
+            }
+        }
+        hipStream_t ms = static_cast<hipStream_t>(qrl_amod_stream(d_ah));
+        hchk(hipMemcpyAsync(d_audio, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, ms), "H2D");
+        const size_t stride = qrl_amod_out_cap(d_ah, d_max);
+        chk(qrl_amod_process(d_ah, d_audio, d_max, na, d_iq, stride), "qrl_amod_process");
+        chk(qrl_amod_sync(d_ah), "qrl_amod_sync");
+        const size_t ns = qrl_amod_last_count(d_ah);
+        for (int s = 0; s < d_n && ns; ++s)
+            hchk(hipMemcpy(out[s], d_iq + 2 * (size_t)s * stride, ns * sizeof(gr_complex), hipMemcpyDeviceToHost), "D2H");
+        return ns;
+    }
     if (!d_h) throw std::runtime_error("gr_mod_base_hip::work before set_mode");
     size_t nb = 0;
     std::vector<uint8_t> host((size_t)d_n * d_max, 0);

@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -75,6 +76,10 @@ public:
     void set_ctcss(float value);                               // gr_demod_base::set_ctcss (src/gr/gr_demod_base.cpp:1212-1218): the NBFM chains' tone squelch, 0 = off
     void set_agc_attack(float value);                          // gr_demod_base::set_agc_attack / set_agc_decay (AM)
     void set_agc_decay(float value);
+    // gr_demod_base::set_filter_width(filter_width, mode) (src/gr/gr_demod_base.cpp:1155-1185): forwarded to the analogue receiver of `mode` (WBFM, AM5000,
+    // NBFM2500 / 5000, USB2500 / LSB2500; other modes: ignored, like the reference's default branch); the instance keeps it across mode changes
+    void set_filter_width(int filter_width, int mode);
+    void set_gain(float value);                                // gr_demod_base::set_gain (:1206-1210): the IF gain of both SSB receivers
     // side outputs (gr_demod_base.cpp:199-200, 185; :978-986, 1105-1113, 1227-1237, 1413-1418)
     void enable_rssi(bool value) { d_rssi_on = value; }
     float get_rssi(int stream = 0);                            // probe_signal_f::level() of the rssi_block behind port 0
@@ -111,6 +116,7 @@ private:
     int d_inflight = -1; uint64_t d_calls = 0;
     size_t d_fcap = 0, d_ccap = 0, d_bcap = 0, d_acap = 0;
     int d_squelch = -140; float d_agc_attack = 0.1f, d_agc_decay = 0.1f;
+    std::map<int, int> d_width; float d_if_gain = -1.0f;     // per-mode set_filter_width values; set_gain (< 0: the constructor's)
     std::mutex d_mutex;                                       // the mailboxes (harvest vs the getters)
     // the C-ABI handles (qrl_demod / qrl_rssi / qrl_fft) are single-threaded objects: work() and every setter / GUI getter that
     // touches them takes this lock, as rx_fft_c guards work(), get_fft_data() and set_fft_size() with its own mutex
@@ -136,15 +142,28 @@ public:
     size_t work(gr_complex* const* out);
     size_t samples_per_byte() const;
     int streams() const { return d_n; }
+    // analogue voice modes (NBFM2500 / NBFM5000 / AM5000 / USB2500 / LSB2500; gr_mod_base.cpp:167-179): audio at 8 ksps in, 125 IQ samples per audio
+    // sample out.  set_audio = gr_mod_base::set_audio -> gr_audio_source::set_data (src/gr/gr_mod_base.cpp:793-797, gr_audio_source.cpp:55-66; takes ownership);
+    // work() then consumes up to max_audio() queued samples of every stream (a stream with fewer queued sends silence) -- NBFM in multiples of 4
+    // (the 25:4 resampler), SSB returns whole chunks of 1024 audio items (the cessb stretcher).  The analogue chains run at the 1 Msps device rate
+    // with zero carrier offset only (the rotator / device-rate interpolator of the back end is built behind the digital modulators).
+    int set_audio(std::vector<float>* data, int stream = 0);
+    size_t max_audio() const { return d_max; }
+    size_t samples_per_audio_sample() const { return 125; }
+    bool analog() const { return d_ah != nullptr; }
+    void set_ctcss(float value);                               // gr_mod_base::set_ctcss (:872-877): both NBFM instances, kept across mode changes
+    void set_filter_width(int filter_width, int mode);         // gr_mod_base::set_filter_width (:878-905): the instance of `mode`, kept across mode changes
 
 private:
     void open();
     qrl_runtime& d_rt;
     int d_n, d_rate, d_mode = -1; double d_offset; size_t d_max; float d_gain = 1.0f;
     qrl_mod* d_h = nullptr; uint8_t* d_bytes = nullptr; float* d_iq = nullptr;
+    qrl_amod* d_ah = nullptr; float* d_audio = nullptr; float d_ctcss = 0.0f; bool d_ctcss_touched = false; std::map<int, int> d_width;
     size_t d_spblock = 0, d_bpb = 1;
     std::mutex d_mutex;
     std::vector<std::vector<uint8_t>> d_queue;
+    std::vector<std::vector<float>> d_aqueue;
 };
 
 // the Qt signals of gr_modem that the RX / TX paths emit (src/gr_modem.h:118-139); unset callbacks are skipped.  Buffers are only

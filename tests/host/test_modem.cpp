@@ -61,7 +61,51 @@ int main(int argc, char** argv)
             return 0;
         } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
     }
-    if (argc == 6 && !strcmp(argv[1], "analog")) {
+    if (argc == 8 && !strcmp(argv[1], "analogtx")) {
+        // test_modem analogtx <modem_type> <streams> <audio.bin: [streams][n] f32> <iq prefix> <set_filter_width value or 0> <ctcss tone or 0>:
+        // the TX facade's analogue path -- set_mode, the setters (before AND, for the width, once more after a detour through another mode: the
+        // reference's instances keep them), set_audio in ragged pieces, work() until the queues are empty
+        const int mode = atoi(argv[2]), N = atoi(argv[3]), width = atoi(argv[6]);
+        const float tone = (float)atof(argv[7]);
+        try {
+            qrl_runtime rt(0);
+            gr_mod_base_hip mod(rt, N, 1000000, 0.0, 4096);
+            if (width) mod.set_filter_width(width, mode);            // before the mode exists: remembered for its instance
+            if (tone != 0.0f) mod.set_ctcss(tone);
+            mod.set_mode(QRL_MODEM_QPSK2K);                          // a detour through a digital mode
+            mod.set_mode(mode);
+            if (!mod.analog()) throw std::runtime_error("not an analogue mode");
+            mod.set_bb_gain(0.75f);
+            std::ifstream f(argv[4], std::ios::binary);
+            std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+            const size_t n = raw.size() / sizeof(float) / (size_t)N;
+            const float* a = reinterpret_cast<const float*>(raw.data());
+            std::vector<std::vector<gr_complex>> iq(N);
+            std::vector<std::vector<gr_complex>> buf(N, std::vector<gr_complex>((4096 + 1024) * 125));
+            std::vector<gr_complex*> ptr(N);
+            for (int s = 0; s < N; ++s) ptr[s] = buf[s].data();
+            static const size_t sizes[] = {640, 4096, 3, 1000, 2049};
+            size_t pos = 0; unsigned k = 0;
+            while (pos < n) {
+                const size_t take = std::min(n - pos, sizes[k++ % 5]);
+                for (int s = 0; s < N; ++s) mod.set_audio(new std::vector<float>(a + (size_t)s * n + pos, a + (size_t)s * n + pos + take), s);
+                pos += take;
+                size_t got;
+                while ((got = mod.work(ptr.data())) != 0)
+                    for (int s = 0; s < N; ++s) iq[s].insert(iq[s].end(), buf[s].begin(), buf[s].begin() + got);
+            }
+            for (int s = 0; s < N; ++s) {
+                std::ofstream o(std::string(argv[5]) + std::to_string(s) + ".bin", std::ios::binary);
+                o.write(reinterpret_cast<const char*>(iq[s].data()), (std::streamsize)(iq[s].size() * sizeof(gr_complex)));
+            }
+            bool refused = false;
+            try { gr_mod_base_hip m2(rt, 1, 2000000, 0.0, 4096); m2.set_mode(mode); } catch (const std::exception&) { refused = true; }
+            if (!refused) throw std::runtime_error("a 2 Msps analogue modulator was not refused");
+            std::printf("analogtx ok\n");
+            return 0;
+        } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+    }
+    if ((argc == 6 || argc == 8) && !strcmp(argv[1], "analog")) {
         // test_modem analog <modem_type> <streams> <iq.bin: [streams][n] cf32> <audio prefix>: the facade's analogue path the way
         // radiocontroller polls it (gr_modem::demodulateAnalog -> pcmAudio); stream s's audio goes to <prefix><s>.bin
         const int mode = atoi(argv[2]), N = atoi(argv[3]);
@@ -73,6 +117,11 @@ int main(int argc, char** argv)
             const size_t chunk = 1 << 16;
             gr_demod_base_hip demod(rt, N, 1000000, 0.0, chunk);
             gr_modem_hip modem(&demod, nullptr, ev);
+            if (argc == 8) {   // ... <set_filter_width value or 0> <set_gain value in thousandths or 0>: before the mode exists, remembered for its instance
+                if (atoi(argv[6])) demod.set_filter_width(atoi(argv[6]), mode);
+                if (atoi(argv[7])) demod.set_gain((float)atoi(argv[7]) / 1000.0f);
+                demod.set_filter_width(1234, QRL_MODEM_QPSK2K);   // the reference's default branch: ignored
+            }
             modem.toggleRxMode(mode);
             std::ifstream f(argv[4], std::ios::binary);
             std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());

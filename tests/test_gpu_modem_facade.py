@@ -277,3 +277,64 @@ def test_facade_spectrum_with_the_demodulator_valve_closed():
     r = subprocess.run([EXE, "valveoff", "3"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("want") == 36
+
+
+@pytest.mark.parametrize("mode,kind,fw,w,gain", [(9, "nbfm", 5000, 4000, 0), (14, "am", 5000, 4000, 0), (11, "usb", 2700, 2400, 500)])
+def test_facade_rx_set_filter_width_and_set_gain(tmp_path, mode, kind, fw, w, gain):
+    """gr_demod_base::set_filter_width(width, mode) / set_gain on the facade (called before the mode exists: its instance keeps them; a digital mode is
+    ignored like the reference's default branch): the audio equals the oracle's chain with the reference setters' designs"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import orc
+    import sig
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qradiolink_amd", "csrc"), "adaptor"])
+    if kind == "usb":
+        n = 900000
+        xs = [sig.make_ssb(n=n, seed=7, lsb=False), sig.make_ssb(n=n, seed=8, lsb=False)]
+    else:
+        n = 300000
+        xs = [sig.make_analog(kind, n=n, seed=7)[0], sig.make_analog(kind, n=n, seed=8, gap=(40000, 240000))[0]]
+    (tmp_path / "iq.bin").write_bytes(np.stack(xs).tobytes())
+    r = subprocess.run([EXE, "analog", str(mode), "2", str(tmp_path / "iq.bin"), str(tmp_path / "a"), str(w), str(gain)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for s in range(2):
+        got = np.fromfile(tmp_path / ("a%d.bin" % s), np.float32) + np.float32(0)
+        if kind == "usb":
+            want = orc.demod_ssb(xs[s], sb=0, filter_width=fw, set_width=w, gain=gain / 1000.0)["audio"] + np.float32(0)
+        else:
+            want = orc.demod_analog(xs[s], kind, filter_width=fw, set_width=w)["audio"] + np.float32(0)
+        assert got.size == want.size // 640 * 640 and got.size >= 640
+        assert np.array_equal(got.view(np.uint32), want[:got.size].view(np.uint32))
+
+
+@pytest.mark.parametrize("mode,kind,fw,w,tone", [(9, "nbfm", 5000, 0, 0.0), (9, "nbfm", 5000, 4000, 88.5), (14, "am", 5000, 4000, 0.0), (12, "lsb", 2700, 2400, 0.0)])
+def test_facade_tx_analog_set_audio(tmp_path, mode, kind, fw, w, tone):
+    """gr_mod_base::set_audio / set_ctcss / set_filter_width on the TX facade (src/gr/gr_mod_base.cpp:793-797, 872-905): audio queued in ragged pieces on two
+    radios, work() until the queues are empty; the IQ equals the oracle's modulator with the same setters applied, the setters survive a mode change, and a
+    2 Msps analogue modulator is refused (no back end behind the analogue chains)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import orc
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qradiolink_amd", "csrc"), "adaptor"])
+    n = 6 * 1024 + 700
+    t = np.arange(n) / 8000.0
+    audio = np.stack([0.6 * np.sin(2 * np.pi * 700 * t) + 0.3 * np.sin(2 * np.pi * 1500 * t), np.random.default_rng(51).uniform(-0.8, 0.8, n)]).astype(np.float32)
+    (tmp_path / "audio.bin").write_bytes(audio.tobytes())
+    r = subprocess.run([EXE, "analogtx", str(mode), "2", str(tmp_path / "audio.bin"), str(tmp_path / "iq"), str(w), str(tone)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for s in range(2):
+        got = np.fromfile(tmp_path / ("iq%d.bin" % s), np.complex64)
+        a = audio[s]
+        if kind == "nbfm":
+            a = a[:n // 4 * 4]                                   # the last n % 4 samples wait in the queue for a fourth one
+            want = orc.mod_nbfm(a, filter_width=fw, bb_gain=0.75, set_width=w, ctcss=tone)
+        elif kind == "am":
+            want = orc.mod_am(a, filter_width=fw, bb_gain=0.75, set_width=w)
+        else:
+            want = orc.mod_ssb(a, sb=1, filter_width=fw, bb_gain=0.75, set_width=w)
+        assert got.size == want.size and got.size > 0
+        assert np.array_equal((got.view(np.float32) + np.float32(0)).view(np.uint32), (want.view(np.float32) + np.float32(0)).view(np.uint32))

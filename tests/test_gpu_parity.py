@@ -708,3 +708,69 @@ def test_unfused_option_is_refused_mid_stream_and_on_other_chains(qrl_ctx):
     with pytest.raises(q.QrlError):
         dem.set_option(q.OPT_UNFUSED_DEC2, 1)
     dem.close()
+
+
+# ---- gr_demod_base::set_filter_width / set_gain (src/gr/gr_demod_base.cpp:1155-1185, 1206-1210): the analogue receivers' own setters
+@pytest.mark.parametrize("kind,modem,fw,w", [("nbfm", 9, 5000, 4000), ("nbfm", 8, 2500, 3000), ("am", 14, 5000, 4000), ("wbfm", 10, 75000, 60000)])
+@pytest.mark.parametrize("chunk", [1 << 20, 33334])
+def test_analog_set_filter_width_bit_exact(qrl_ctx, kind, modem, fw, w, chunk):
+    """qrl_demod_set_filter_width against the oracle's chain with the reference setter's designs (pinned by tests/test_ref_chains.py::
+    test_set_filter_width_of_the_analogue_blocks): low_pass(1, fs, w, 1200, BH) + new discriminator gain (NBFM, WBFM), complex_band_pass (AM)"""
+    import torch
+    import qradiolink_amd as q
+    n = 400000
+    xs = [sig.make_analog(kind, n=n, seed=1, gap=(100000, 300000))[0], sig.make_analog(kind, n=n, seed=2)[0]]
+    iq = np.stack(xs)
+    dem = q.Demod(qrl_ctx, modem, batch=2, max_chunk=min(chunk, n))
+    q.collect(dem, torch.from_numpy(iq[:, :50000].copy()).cuda(), min(chunk, 50000))        # something in flight: the setter restarts the chain
+    dem.set_filter_width(w)
+    out = q.collect(dem, torch.from_numpy(iq).cuda(), min(chunk, n))
+    with pytest.raises(q.QrlError):
+        dem.set_filter_width(0)
+    dem.close()
+    for b in range(2):
+        ref = orc.demod_analog(iq[b], kind, filter_width=fw, set_width=w)
+        assert ref["audio"].size > 1500
+        got, want = out["filtered"][b].view(np.float32) + np.float32(0), ref["filtered"].view(np.float32) + np.float32(0)
+        assert got.size == want.size and np.array_equal(got.view(np.uint32), want.view(np.uint32)), "filtered"
+        got, want = out["audio"][b] + np.float32(0), ref["audio"] + np.float32(0)
+        assert got.size == want.size and np.array_equal(got.view(np.uint32), want.view(np.uint32)), "audio"
+        ctor = orc.demod_analog(iq[b], kind, filter_width=w)                                  # not the constructor's chain with that width
+        assert not np.array_equal(ctor["filtered"], ref["filtered"])
+
+
+@pytest.mark.parametrize("lsb,modem", [(False, 11), (True, 12)])
+def test_ssb_set_filter_width_and_set_gain_bit_exact(qrl_ctx, lsb, modem):
+    """gr_demod_ssb::set_filter_width (the band-pass with the new edge, audio filter with GAIN 2) and set_gain (_if_gain) against the oracle"""
+    import torch
+    import qradiolink_amd as q
+    n = 1200000
+    iq = np.stack([sig.make_ssb(n=n, seed=1, lsb=lsb, gap=(300000, 900000)), sig.make_ssb(n=n, seed=2, lsb=lsb)])
+    dem = q.Demod(qrl_ctx, modem, batch=2, max_chunk=150000)
+    dem.set_filter_width(2400)
+    dem.set_gain(0.5)
+    out = q.collect(dem, torch.from_numpy(iq).cuda(), 150000)
+    for b in range(2):
+        ref = orc.demod_ssb(iq[b], sb=int(lsb), set_width=2400, gain=0.5)
+        assert ref["audio"].size >= 4096
+        got, want = out["filtered"][b].view(np.float32) + np.float32(0), ref["filtered"].view(np.float32) + np.float32(0)
+        assert got.size == want.size and np.array_equal(got.view(np.uint32), want.view(np.uint32)), "filtered"
+        got, want = out["audio"][b] + np.float32(0), ref["audio"] + np.float32(0)
+        assert got.size == want.size and np.array_equal(got.view(np.uint32), want.view(np.uint32)), "audio"
+    # set_gain alone is live (no restart): the next call's port 0 scales, the stream position runs on
+    dem.reset()
+    dem.set_gain(0.9)
+    a = q.collect(dem, torch.from_numpy(iq[:, :300000].copy()).cuda(), 150000)
+    ref = orc.demod_ssb(iq[0][:300000], sb=int(lsb), set_width=2400)
+    assert np.array_equal(a["filtered"][0], ref["filtered"])
+    with pytest.raises(q.QrlError):
+        dem.set_filter_width(150)                                                           # below the 200 Hz band edge
+    dem.close()
+    d2 = q.Demod(qrl_ctx, q.MODEM_NBFM5000, batch=1, max_chunk=1000)
+    with pytest.raises(q.QrlError):
+        d2.set_gain(0.5)                                                                    # SSB receivers only
+    d2.close()
+    d3 = q.Demod(qrl_ctx, 0, batch=1, max_chunk=1000)
+    with pytest.raises(q.QrlError):
+        d3.set_filter_width(3000)                                                           # analogue receivers only
+    d3.close()

@@ -557,3 +557,43 @@ def test_nbfm_ctcss_tx_opens_the_ctcss_squelch_of_the_receiver_on_gpu(qrl_ctx):
             spec = np.abs(np.fft.rfft(seg * np.hanning(seg.size)))
             assert abs(np.argmax(spec) * 8000.0 / seg.size - 700.0) < 3.0
     assert rms[88.5] > 0.2 and rms[0.0] < 1e-3 and rms[123.0] < 1e-3, rms
+
+
+# ---- gr_mod_base::set_filter_width (src/gr/gr_mod_base.cpp:878-905): the analogue modulators' own set_filter_width designs
+@pytest.mark.parametrize("modem,kind,fw,w", [(9, "nbfm", 5000, 4000), (8, "nbfm", 2500, 3000), (14, "am", 5000, 4000), (11, "usb", 2700, 2400), (12, "lsb", 2700, 2400)])
+@pytest.mark.parametrize("chunk", [1 << 14, 1000])
+def test_analog_modulator_set_filter_width_bit_exact(qrl_ctx, modem, kind, fw, w, chunk):
+    """qrl_amod_set_filter_width against the oracle's chain with the reference setter's designs (pinned by tests/test_ref_chains.py::
+    test_set_filter_width_of_the_analogue_blocks): called after some audio has gone through (the chain restarts), one call and ragged calls"""
+    import torch
+    import qradiolink_amd as q
+    n = (5 * 1024 + 700) if kind in ("usb", "lsb") else 2000
+    t = np.arange(n) / 8000.0
+    audio = np.stack([0.6 * np.sin(2 * np.pi * 700 * t) + 0.3 * np.sin(2 * np.pi * 1500 * t), np.random.default_rng(41).uniform(-0.8, 0.8, n)]).astype(np.float32)
+    c = min(chunk, n) // 4 * 4
+    mod = q.AMod(qrl_ctx, modem, batch=2, max_samples=c, bb_gain=0.75)
+    mod.process(torch.from_numpy(np.ascontiguousarray(audio[:, :c])).cuda())                 # something in flight: the setter restarts the chain
+    mod.set_filter_width(w)
+    parts = []
+    for s in range(0, n, c):
+        blk = audio[:, s:s + c]
+        if kind == "nbfm" and blk.shape[1] % 4:
+            blk = blk[:, :blk.shape[1] // 4 * 4]
+        parts.append(mod.process(torch.from_numpy(np.ascontiguousarray(blk)).cuda()).cpu().numpy())
+    got = np.concatenate(parts, axis=1)
+    for b in range(2):
+        a = audio[b] if kind != "nbfm" else audio[b][:n // 4 * 4]
+        want = {"nbfm": lambda: orc.mod_nbfm(a, filter_width=fw, bb_gain=0.75, set_width=w),
+                "am": lambda: orc.mod_am(a, filter_width=fw, bb_gain=0.75, set_width=w),
+                "usb": lambda: orc.mod_ssb(a, sb=0, filter_width=fw, bb_gain=0.75, set_width=w),
+                "lsb": lambda: orc.mod_ssb(a, sb=1, filter_width=fw, bb_gain=0.75, set_width=w)}[kind]()
+        g = got[b][:want.size].view(np.float32) + np.float32(0)
+        assert got.shape[1] >= want.size and want.size > 0
+        assert np.array_equal(g.view(np.uint32), (want.view(np.float32) + np.float32(0)).view(np.uint32)), "stream %d differs" % b
+        # and it is not the constructor's chain with that width (the setter's transition widths differ), except for AM where the setter repeats the constructor
+        ctor = {"nbfm": lambda: orc.mod_nbfm(a, filter_width=w, bb_gain=0.75), "am": lambda: orc.mod_am(a, filter_width=w, bb_gain=0.75),
+                "usb": lambda: orc.mod_ssb(a, sb=0, filter_width=w, bb_gain=0.75), "lsb": lambda: orc.mod_ssb(a, sb=1, filter_width=w, bb_gain=0.75)}[kind]()
+        assert (kind == "am") == (ctor.size == want.size and np.array_equal(ctor, want))
+    with pytest.raises(q.QrlError):
+        mod.set_filter_width(100)                                                             # filters would not fit / below the SSB band edge
+    mod.close()
