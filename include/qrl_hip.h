@@ -481,11 +481,18 @@ typedef struct qrl_amod_config {
     size_t max_samples;    /* audio samples per stream and call */
     void* hip_stream;      /* hipStream_t or NULL (own stream) */
     float bb_gain;         /* gr_mod_nbfm::set_bb_gain; 0 = 1.0 */
+    /* gr_mod_base back end (src/gr/gr_mod_base.cpp:38,215-258), as in qrl_mod_config: 0 / 1000000 = none; >= 2e6 (a multiple of 1e6): the chain's 1 Msps
+     * output goes through rotator_cc(2 pi offset / 1e6) and rational_resampler_ccf(rate / 1e6, 1, low_pass(interp, rate, 480000, 20000, BH)); a non-zero
+     * initial offset alone gives the rotator only.  All sample counts (samples_per_sample, out_cap, last_count) then count device-rate samples. */
+    int device_samp_rate;
+    double carrier_offset_hz;
 } qrl_amod_config;
 int qrl_amod_create(qrl_ctx* ctx, const qrl_amod_config* cfg, qrl_amod** out);
 void qrl_amod_destroy(qrl_amod* m);
 int qrl_amod_reset(qrl_amod* m);
 int qrl_amod_set_bb_gain(qrl_amod* m, float value);
+/* replaces gr_mod_base::set_carrier_offset (src/gr/gr_mod_base.cpp:799-805) for handles created with the back end; phase-continuous like rotator_cc::set_phase_inc */
+int qrl_amod_set_carrier_offset(qrl_amod* m, double carrier_offset_hz);
 /* replaces gr_mod_nbfm::set_ctcss(value) (src/gr/gr_mod_nbfm.cpp:101-135; gr_mod_base::set_ctcss :872-877 forwards to both NBFM instances):
  * tone_hz != 0: _audio_amplify 0.85, the audio filter becomes band_pass_2(1, 8000, 300, 3500, 200, 35, BH) and analog::sig_source_f(8000,
  * GR_COS_WAVE, tone, 0.15) is added to the audio in front of the pre-emphasis; 0: the low-pass again and _audio_amplify 0.98 (sic: the

@@ -64,7 +64,8 @@ class _ZeroRun(C.Structure):
 
 
 class _AModConfig(C.Structure):
-    _fields_ = [("modem_type", C.c_int), ("batch", C.c_int), ("max_samples", C.c_size_t), ("hip_stream", C.c_void_p), ("bb_gain", C.c_float)]
+    _fields_ = [("modem_type", C.c_int), ("batch", C.c_int), ("max_samples", C.c_size_t), ("hip_stream", C.c_void_p), ("bb_gain", C.c_float),
+                ("device_samp_rate", C.c_int), ("carrier_offset_hz", C.c_double)]
 
 
 class _Out(C.Structure):
@@ -125,6 +126,7 @@ def load_library():
     lib.qrl_demod_set_filter_width.argtypes = [vp, C.c_int]
     lib.qrl_demod_set_gain.argtypes = [vp, C.c_float]
     lib.qrl_amod_set_filter_width.argtypes = [vp, C.c_int]
+    lib.qrl_amod_set_carrier_offset.argtypes = [vp, C.c_double]
     lib.qrl_demod_process.argtypes = [vp, vp, sz, sz, C.POINTER(_Out)]
     lib.qrl_demod_sync.argtypes = [vp]
     lib.qrl_rssi_create.argtypes = [vp, C.c_int, C.c_float, vp, C.POINTER(vp)]
@@ -225,7 +227,7 @@ EXPORTED_SYMBOLS = [
     "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_set_option", "qrl_demod_set_dmo_output", "qrl_demod_stream_wait", "qrl_demod_out_caps",
     "qrl_demod_audio_cap", "qrl_demod_set_squelch", "qrl_demod_set_agc", "qrl_demod_set_filter_width", "qrl_demod_set_gain", "qrl_demod_set_ctcss", "qrl_demod_time_domain_cap", "qrl_demod_set_time_domain_output",
     "qrl_bptc19696_decode", "qrl_bptc19696_encode", "qrl_m17_decode_frames", "qrl_m17_encode_frames",
-    "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_set_ctcss", "qrl_amod_set_filter_width", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
+    "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_set_ctcss", "qrl_amod_set_filter_width", "qrl_amod_set_carrier_offset", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_internal_streams", "qrl_chan_internal_streams", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
     "qrl_mod_samples_per_byte", "qrl_mod_samples_per_block", "qrl_mod_add_zero_runs", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_set_option", "qrl_chan_channelize", "qrl_chan_process_channels", "qrl_chan_wait_for", "qrl_chan_stream_wait", "qrl_chan_stream", "qrl_chan_profile", "qrl_chan_profile_read", "qrl_chan_profile_read_kernels", "qrl_debug_decim_prof", "qrl_debug_decim_prof_enable", "qrl_chan_create",
@@ -864,10 +866,10 @@ class AMod:
     process(audio) takes a float32 cuda tensor [batch, n] at 8 ksps (NBFM: n a multiple of 4) and returns complex64 at 1 Msps:
     [batch, 125 n] for NBFM, 125 x the audio items of the 1024-chunks the call completed for SSB."""
 
-    def __init__(self, ctx, modem_type, batch, max_samples, bb_gain=1.0):
+    def __init__(self, ctx, modem_type, batch, max_samples, bb_gain=1.0, device_samp_rate=0, carrier_offset_hz=0.0):
         import torch
         self.torch, self.ctx, self.lib = torch, ctx, ctx.lib
-        cfg = _AModConfig(modem_type, batch, max_samples, None, bb_gain)
+        cfg = _AModConfig(modem_type, batch, max_samples, None, bb_gain, device_samp_rate, carrier_offset_hz)
         self.h = C.c_void_p()
         _check(self.lib.qrl_amod_create(ctx.h, C.byref(cfg), C.byref(self.h)), "qrl_amod_create")
         self.batch, self.spa = batch, self.lib.qrl_amod_samples_per_sample(self.h)
@@ -884,6 +886,9 @@ class AMod:
 
     def set_bb_gain(self, g):
         _check(self.lib.qrl_amod_set_bb_gain(self.h, C.c_float(g)), "qrl_amod_set_bb_gain")
+
+    def set_carrier_offset(self, hz):
+        _check(self.lib.qrl_amod_set_carrier_offset(self.h, C.c_double(hz)), "qrl_amod_set_carrier_offset")
 
     def set_ctcss(self, tone_hz):
         """gr_mod_nbfm::set_ctcss: tone (Hz) added to the audio, band-pass audio filter; 0 switches it off again (qrl_amod_set_ctcss)"""

@@ -55,6 +55,38 @@ struct qrl_amod {
     Dev<AmIirState> iir; Dev<float> phase;
     double pb[2] = {0, 0}, pa[2] = {0, 0};
     uint64_t n8 = 0, n50 = 0;
+    // gr_mod_base back end (src/gr/gr_mod_base.cpp:38,215-258), as behind the digital modulators (tx.cpp): rotator at 1 Msps, then the interpolator to the device rate
+    bool backend = false; int be_interp = 1, be_nt = 0; Dev<float> be_taps;
+    Dev<float2> bb, be_ring, rot_lo; size_t bb_stride = 0; uint32_t be_mask = 0;
+    uint64_t rot_inc = 0, rot_acc = 0, rot_nbase = 0, n_bb = 0;
+    int set_rot(double hz)
+    {
+        rot_inc = phase_inc_to_turn(2 * M_PI * hz / 1000000.0);
+        std::vector<float2> lo(512);
+        for (int r = 0; r < 512; ++r) { float sn, cs; sincos_turn_host((uint64_t)r * rot_inc, sn, cs); lo[r] = make_float2(cs, sn); }
+        return hipMemcpy(rot_lo.p, lo.data(), 512 * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess ? QRL_OK : QRL_ERR_HIP;
+    }
+    size_t cap_1msps(size_t n) const { return am ? n * (size_t)sps : ssb ? (n + 1024) * (size_t)sps : n * 25 / 4 * (size_t)sps; }
+    int init_back_end()
+    {
+        const int rate = cfg.device_samp_rate;
+        if (rate != 0 && rate != 1000000 && (rate < 2000000 || rate % 1000000 != 0 || rate > 64000000))
+            return qrl_set_error(QRL_ERR_ARG, "amod: device_samp_rate must be 1e6 or a multiple of 1e6 in [2e6, 64e6]");
+        be_interp = rate >= 2000000 ? rate / 1000000 : 1;
+        backend = be_interp > 1 || cfg.carrier_offset_hz != 0.0;
+        if (!backend) return QRL_OK;
+        int r;
+        bb_stride = cap_1msps(cfg.max_samples);
+        if ((r = bb.alloc((size_t)cfg.batch * bb_stride)) || (r = rot_lo.alloc(512)) || (r = set_rot(cfg.carrier_offset_hz))) return r;
+        if (be_interp > 1) {
+            const std::vector<float> lp = low_pass(be_interp, rate, 480000, 20000, WIN_BLACKMAN_HARRIS);   // gr_mod_base.cpp:215-258
+            be_nt = (int)lp.size();
+            if ((r = be_taps.upload(lp))) return r;
+            be_mask = pow2_at_least(bb_stride + (size_t)be_nt / be_interp + 64) - 1;
+            if ((r = be_ring.alloc((size_t)cfg.batch * (be_mask + 1)))) return r;
+        }
+        return QRL_OK;
+    }
     ~qrl_amod() { if (own_stream && stream) (void)hipStreamDestroy(stream); }
     int init_state()
     {
@@ -69,6 +101,8 @@ struct qrl_amod {
             n1m = 0;
         }
         n8 = n50 = ns = 0; last = 0; tone_k = 0;
+        if (be_ring.p && (r = be_ring.zero())) return r;
+        n_bb = 0; rot_acc = 0; rot_nbase = 0;
         return QRL_OK;
     }
 };
@@ -111,7 +145,7 @@ int qrl_amod_create(qrl_ctx* ctx, const qrl_amod_config* cfg, qrl_amod** outp)
         if ((r = m->a0.alloc(r8)) || (r = m->a1.alloc(r8)) || (r = m->a2.alloc(r8)) || (r = m->c1.alloc(r8)) || (r = m->c2.alloc(1)) || (r = m->c3.alloc(1)) ||
             (r = m->m1.alloc(r1m)) || (r = m->m2.alloc(r1m)) || (r = m->am_gain.alloc(B))) return r;
         if ((r = m->r50.alloc(1)) || (r = m->fmv.alloc(1)) || (r = m->flt.alloc(1)) || (r = m->iir.alloc(1)) || (r = m->phase.alloc(1))) return r;
-        if ((r = m->init_state())) return r;
+        if ((r = m->init_back_end()) || (r = m->init_state())) return r;
         *outp = m.release();
         return QRL_OK;
     }
@@ -131,7 +165,7 @@ int qrl_amod_create(qrl_ctx* ctx, const qrl_amod_config* cfg, qrl_amod** outp)
         if ((r = m->a0.alloc(r8)) || (r = m->a1.alloc(r8)) || (r = m->c1.alloc(r8)) || (r = m->c2.alloc(r8)) || (r = m->c3.alloc(r8))) return r;
         // (members of the FM chain stay empty)
         if ((r = m->a2.alloc(1)) || (r = m->r50.alloc(1)) || (r = m->fmv.alloc(1)) || (r = m->flt.alloc(1)) || (r = m->iir.alloc(1)) || (r = m->phase.alloc(1))) return r;
-        if ((r = m->init_state())) return r;
+        if ((r = m->init_back_end()) || (r = m->init_state())) return r;
         *outp = m.release();
         return QRL_OK;
     }
@@ -163,7 +197,7 @@ int qrl_amod_create(qrl_ctx* ctx, const qrl_amod_config* cfg, qrl_amod** outp)
     const size_t r8 = (size_t)B * (m->m8 + 1), r5 = (size_t)B * (m->m50 + 1);
     if ((r = m->a0.alloc(r8)) || (r = m->a1.alloc(r8)) || (r = m->a2.alloc(r8)) || (r = m->r50.alloc(r5)) || (r = m->fmv.alloc(r5)) ||
         (r = m->flt.alloc(r5)) || (r = m->iir.alloc(B)) || (r = m->phase.alloc(B))) return r;
-    if ((r = m->init_state())) return r;
+    if ((r = m->init_back_end()) || (r = m->init_state())) return r;
     *outp = m.release();
     return QRL_OK;
 }
@@ -228,9 +262,18 @@ int qrl_amod_set_filter_width(qrl_amod* m, int width)
     // from a fresh state (like qrl_amod_reset; the set_ctcss switch and bb_gain are kept) -- what the tests compare is the chain built with the setter's designs.
     return m->init_state();
 }
-size_t qrl_amod_samples_per_sample(const qrl_amod* m) { return m ? ((m->ssb || m->am) ? (size_t)m->sps : (size_t)25 * m->sps / 4) : 0; }
+size_t qrl_amod_samples_per_sample(const qrl_amod* m) { return m ? ((m->ssb || m->am) ? (size_t)m->sps : (size_t)25 * m->sps / 4) * (size_t)m->be_interp : 0; }
 size_t qrl_amod_last_count(const qrl_amod* m) { return m ? m->last : 0; }
-size_t qrl_amod_out_cap(const qrl_amod* m, size_t n) { return m ? (m->am ? n * (size_t)m->sps : m->ssb ? (n + 1024) * (size_t)m->sps : n * 25 / 4 * (size_t)m->sps) : 0; }
+size_t qrl_amod_out_cap(const qrl_amod* m, size_t n) { return m ? m->cap_1msps(n) * (size_t)m->be_interp : 0; }
+int qrl_amod_set_carrier_offset(qrl_amod* m, double hz)
+{
+    if (!m) return QRL_ERR_ARG;
+    if (!m->backend) return qrl_set_error(QRL_ERR_ARG, "analogue modulator was created without the gr_mod_base back end");
+    HIPCHK(hipStreamSynchronize(m->stream));   // rot_lo is rewritten below
+    m->rot_acc += (m->n_bb - m->rot_nbase) * m->rot_inc;   // phase-continuous, like rotator_cc::set_phase_inc
+    m->rot_nbase = m->n_bb;
+    return m->set_rot(hz);
+}
 void* qrl_amod_stream(qrl_amod* m) { return m ? m->stream : nullptr; }
 int qrl_amod_sync(qrl_amod* m) { if (!m) return QRL_ERR_ARG; HIPCHK(hipStreamSynchronize(m->stream)); return QRL_OK; }
 
@@ -244,12 +287,30 @@ int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, f
     HIPCHK(hipSetDevice(m->ctx->device));
     const int B = m->cfg.batch;
     hipStream_t s = m->stream;
+    // with the back end the chain's 1 Msps output goes to the handle's own linear buffer, and from there through the rotator (and the interpolator)
+    float2* const mod_out = m->backend ? m->bb.p : reinterpret_cast<float2*>(iq);
+    const size_t mod_stride = m->backend ? m->bb_stride : out_stride;
+    auto back_end = [&](uint32_t n1) {   // n1 samples per stream at 1 Msps are in bb
+        if (!m->backend || !n1) return;
+        TxRotParams rp{}; rp.in = m->bb.p; rp.in_stride = m->bb_stride; rp.n0 = m->n_bb; rp.count = n1;
+        rp.rot_acc = m->rot_acc; rp.rot_inc = m->rot_inc; rp.rot_nbase = m->rot_nbase; rp.rot_lo = m->rot_lo.p;
+        if (m->be_interp > 1) rp.out_ring = RingC{m->be_ring.p, m->be_mask};
+        else { rp.out = reinterpret_cast<float2*>(iq); rp.out_stride = out_stride; }
+        launch_tx_rot(rp, B, s);
+        if (m->be_interp > 1) {
+            TxInterpCParams bp{}; bp.in = rp.out_ring; bp.n0 = m->n_bb * (uint64_t)m->be_interp; bp.count = n1 * (uint32_t)m->be_interp;
+            bp.taps = m->be_taps.p; bp.nt = m->be_nt; bp.interp = m->be_interp;
+            bp.out = reinterpret_cast<float2*>(iq); bp.out_stride = out_stride;
+            launch_tx_interp_c(bp, B, s);
+        }
+        m->n_bb += n1;
+    };
     if (m->am) {   // gr_mod_am.cpp:66-77 in connection order
         RingF a0{m->a0.p, m->m8}, a1{m->a1.p, m->m8}, a2{m->a2.p, m->m8};
         RingC c1{m->c1.p, m->m8}, m1{m->m1.p, m->mm}, m2{m->m2.p, m->mm};
         const uint32_t c8 = (uint32_t)n, c1m = (uint32_t)(n * (size_t)m->sps);
         // (every batch size: out_stride is the capacity of the final filter's output port, a smaller one would silently truncate -- ADVICE r4)
-        if ((size_t)c1m > out_stride) return qrl_set_error(QRL_ERR_ARG, "amod: out_stride smaller than this call's output (qrl_amod_out_cap)");
+        if ((size_t)c1m * m->be_interp > out_stride) return qrl_set_error(QRL_ERR_ARG, "amod: out_stride smaller than this call's output (qrl_amod_out_cap)");
         AmLoadParams lp{}; lp.in = audio; lp.in_stride = stride; lp.out = a0; lp.n0 = m->n8; lp.count = c8;
         launch_am_load(lp, B, s);
         AmAgcParams ap{}; ap.in = a0; ap.out = a1; ap.n0 = m->n8; ap.count = c8; ap.attack = 1e-2f; ap.decay = 1e-4f; ap.ref = 1.0f; ap.max_gain = 1.0f;
@@ -264,11 +325,12 @@ int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, f
         launch_scale_c(m1, m->n1m, c1m, 0.5f, B, s);                                // _amplify
         launch_scale_c(m1, m->n1m, c1m, m->bb_gain, B, s);                          // _bb_gain
         FirCccParams ff{}; ff.in = m1; ff.out = m2; ff.q0 = m->n1m; ff.count = c1m; ff.taps = m->t_chan.p; ff.nt = m->n_chan;
-        ff.port = reinterpret_cast<float2*>(iq); ff.port_cap = out_stride;
-        launch_an_fir_ccc(ff, B, s);                                                // _filter: straight into the caller's buffer
+        ff.port = mod_out; ff.port_cap = mod_stride;
+        launch_an_fir_ccc(ff, B, s);                                                // _filter: straight into the caller's buffer (or the back end's)
+        back_end(c1m);
         HIPCHK(hipGetLastError());
         if (qrl::take_launch_error()) return QRL_ERR_HIP;
-        m->n8 += c8; m->n1m += c1m; m->last = c1m;
+        m->n8 += c8; m->n1m += c1m; m->last = (size_t)c1m * m->be_interp;
         return QRL_OK;
     }
     if (m->ssb) {
@@ -278,7 +340,7 @@ int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, f
         const uint64_t n8_1 = m->n8 + n;
         const uint64_t ns_1 = n8_1 >= 2 ? 1024 * ((n8_1 - 2) / 1024) : 0;        // stretcher: whole chunks, two items of look-ahead
         const uint32_t cs = (uint32_t)(ns_1 - m->ns);
-        if ((size_t)cs * m->sps > out_stride && B > 1) return qrl_set_error(QRL_ERR_ARG, "amod: out_stride smaller than this call's output (qrl_amod_out_cap)");
+        if ((size_t)cs * m->sps * m->be_interp > out_stride && B > 1) return qrl_set_error(QRL_ERR_ARG, "amod: out_stride smaller than this call's output (qrl_amod_out_cap)");
         AmLoadParams lp{}; lp.in = audio; lp.in_stride = stride; lp.out = a0; lp.n0 = m->n8; lp.count = c8;
         launch_am_load(lp, B, s);
         FirFffParams af{}; af.in = a0; af.out = a1; af.q0 = m->n8; af.count = c8; af.taps = m->t_audio.p; af.nt = m->n_audio;
@@ -292,11 +354,12 @@ int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, f
         launch_scale_c(c3, m->ns, cs, 0.9f, B, s);                                  // _amplify
         launch_scale_c(c3, m->ns, cs, m->bb_gain, B, s);                            // _bb_gain
         TxInterpCParams xp{}; xp.in = c3; xp.n0 = m->ns * (uint64_t)m->sps; xp.count = cs * (uint32_t)m->sps;
-        xp.taps = m->t_interp.p; xp.nt = m->n_interp; xp.interp = m->sps; xp.out = reinterpret_cast<float2*>(iq); xp.out_stride = out_stride;
+        xp.taps = m->t_interp.p; xp.nt = m->n_interp; xp.interp = m->sps; xp.out = mod_out; xp.out_stride = mod_stride;
         if (xp.count) launch_tx_interp_c(xp, B, s);                                 // _resampler
+        back_end(xp.count);
         HIPCHK(hipGetLastError());
         if (qrl::take_launch_error()) return QRL_ERR_HIP;
-        m->n8 = n8_1; m->ns = ns_1; m->last = (size_t)cs * m->sps;
+        m->n8 = n8_1; m->ns = ns_1; m->last = (size_t)cs * m->sps * m->be_interp;
         return QRL_OK;
     }
     RingF a0{m->a0.p, m->m8}, a1{m->a1.p, m->m8}, a2{m->a2.p, m->m8}, r50{m->r50.p, m->m50};
@@ -321,11 +384,12 @@ int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, f
     launch_scale_c(flt, m->n50, c50, 0.8f, B, s);                                   // _amplify
     launch_scale_c(flt, m->n50, c50, m->bb_gain, B, s);                             // _bb_gain
     TxInterpCParams xp{}; xp.in = flt; xp.n0 = m->n50 * (uint64_t)m->sps; xp.count = c50 * (uint32_t)m->sps;
-    xp.taps = m->t_interp.p; xp.nt = m->n_interp; xp.interp = m->sps; xp.out = reinterpret_cast<float2*>(iq); xp.out_stride = out_stride;
+    xp.taps = m->t_interp.p; xp.nt = m->n_interp; xp.interp = m->sps; xp.out = mod_out; xp.out_stride = mod_stride;
     launch_tx_interp_c(xp, B, s);                                                   // _resampler
+    back_end(xp.count);
     HIPCHK(hipGetLastError());
     if (qrl::take_launch_error()) return QRL_ERR_HIP;
-    m->n8 += c8; m->n50 += c50; m->last = (size_t)c50 * m->sps;
+    m->n8 += c8; m->n50 += c50; m->last = (size_t)c50 * m->sps * m->be_interp;
     return QRL_OK;
 }
 

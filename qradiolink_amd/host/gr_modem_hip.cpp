@@ -525,10 +525,9 @@ void gr_mod_base_hip::open()
     if (d_audio) { (void)hipFree(d_audio); d_audio = nullptr; }
     if (d_iq) { (void)hipFree(d_iq); d_iq = nullptr; }
     if (analog_tx_mode(d_mode)) {
-        if (d_rate != 1000000 || d_offset != 0.0)
-            throw std::runtime_error("gr_mod_base_hip: the analogue modulators run at the 1 Msps device rate with zero carrier offset (the back end is built behind the digital modulators)");
         qrl_amod_config c{};
         c.modem_type = d_mode; c.batch = d_n; c.max_samples = d_max; c.bb_gain = d_gain;
+        c.device_samp_rate = d_rate; c.carrier_offset_hz = d_offset;
         chk(qrl_amod_create(d_rt.ctx(), &c, &d_ah), "qrl_amod_create");
         // the reference's instances keep what their setters did across mode changes
         if (d_ctcss_touched && (d_mode == QRL_MODEM_NBFM2500 || d_mode == QRL_MODEM_NBFM5000)) chk(qrl_amod_set_ctcss(d_ah, d_ctcss), "qrl_amod_set_ctcss");
@@ -586,9 +585,9 @@ void gr_mod_base_hip::set_bb_gain(float v)
 }
 void gr_mod_base_hip::set_carrier_offset(double hz)
 {
-    if (d_ah && hz != 0.0) throw std::runtime_error("gr_mod_base_hip: the analogue modulators run with zero carrier offset");
     d_offset = hz;
     if (d_h) chk(qrl_mod_set_carrier_offset(d_h, hz), "qrl_mod_set_carrier_offset");
+    if (d_ah) chk(qrl_amod_set_carrier_offset(d_ah, hz), "qrl_amod_set_carrier_offset");
 }
 size_t gr_mod_base_hip::samples_per_byte() const { return d_h ? qrl_mod_samples_per_byte(d_h) : 0; }
 size_t gr_mod_base_hip::work(gr_complex* const* out)

@@ -145,11 +145,11 @@ public:
     // analogue voice modes (NBFM2500 / NBFM5000 / AM5000 / USB2500 / LSB2500; gr_mod_base.cpp:167-179): audio at 8 ksps in, 125 IQ samples per audio
     // sample out.  set_audio = gr_mod_base::set_audio -> gr_audio_source::set_data (src/gr/gr_mod_base.cpp:793-797, gr_audio_source.cpp:55-66; takes ownership);
     // work() then consumes up to max_audio() queued samples of every stream (a stream with fewer queued sends silence) -- NBFM in multiples of 4
-    // (the 25:4 resampler), SSB returns whole chunks of 1024 audio items (the cessb stretcher).  The analogue chains run at the 1 Msps device rate
-    // with zero carrier offset only (the rotator / device-rate interpolator of the back end is built behind the digital modulators).
+    // (the 25:4 resampler), SSB returns whole chunks of 1024 audio items (the cessb stretcher).  out[s] needs max_audio_out() samples.
     int set_audio(std::vector<float>* data, int stream = 0);
     size_t max_audio() const { return d_max; }
-    size_t samples_per_audio_sample() const { return 125; }
+    size_t max_audio_out() const { return d_ah ? qrl_amod_out_cap(d_ah, d_max) : 0; }
+    size_t samples_per_audio_sample() const { return d_ah ? qrl_amod_samples_per_sample(d_ah) : 0; }   // 125 x device rate / 1e6
     bool analog() const { return d_ah != nullptr; }
     void set_ctcss(float value);                               // gr_mod_base::set_ctcss (:872-877): both NBFM instances, kept across mode changes
     void set_filter_width(int filter_width, int mode);         // gr_mod_base::set_filter_width (:878-905): the instance of `mode`, kept across mode changes

@@ -309,11 +309,13 @@ def test_facade_rx_set_filter_width_and_set_gain(tmp_path, mode, kind, fw, w, ga
         assert np.array_equal(got.view(np.uint32), want[:got.size].view(np.uint32))
 
 
-@pytest.mark.parametrize("mode,kind,fw,w,tone", [(9, "nbfm", 5000, 0, 0.0), (9, "nbfm", 5000, 4000, 88.5), (14, "am", 5000, 4000, 0.0), (12, "lsb", 2700, 2400, 0.0)])
-def test_facade_tx_analog_set_audio(tmp_path, mode, kind, fw, w, tone):
+@pytest.mark.parametrize("mode,kind,fw,w,tone,rate,offset", [(9, "nbfm", 5000, 0, 0.0, 1000000, 0.0), (9, "nbfm", 5000, 4000, 88.5, 1000000, 0.0),
+                                                             (14, "am", 5000, 4000, 0.0, 1000000, 0.0), (12, "lsb", 2700, 2400, 0.0, 1000000, 0.0),
+                                                             (8, "nbfm", 2500, 0, 0.0, 2000000, 12500.0)])
+def test_facade_tx_analog_set_audio(tmp_path, mode, kind, fw, w, tone, rate, offset):
     """gr_mod_base::set_audio / set_ctcss / set_filter_width on the TX facade (src/gr/gr_mod_base.cpp:793-797, 872-905): audio queued in ragged pieces on two
-    radios, work() until the queues are empty; the IQ equals the oracle's modulator with the same setters applied, the setters survive a mode change, and a
-    2 Msps analogue modulator is refused (no back end behind the analogue chains)"""
+    radios, work() until the queues are empty; the IQ equals the oracle's modulator with the same setters applied (+ the back end's rotator and interpolator at
+    a 2 Msps device rate), and the setters survive a mode change"""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
@@ -324,7 +326,8 @@ def test_facade_tx_analog_set_audio(tmp_path, mode, kind, fw, w, tone):
     t = np.arange(n) / 8000.0
     audio = np.stack([0.6 * np.sin(2 * np.pi * 700 * t) + 0.3 * np.sin(2 * np.pi * 1500 * t), np.random.default_rng(51).uniform(-0.8, 0.8, n)]).astype(np.float32)
     (tmp_path / "audio.bin").write_bytes(audio.tobytes())
-    r = subprocess.run([EXE, "analogtx", str(mode), "2", str(tmp_path / "audio.bin"), str(tmp_path / "iq"), str(w), str(tone)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([EXE, "analogtx", str(mode), "2", str(tmp_path / "audio.bin"), str(tmp_path / "iq"), str(w), str(tone), str(rate), str(offset)],
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     for s in range(2):
         got = np.fromfile(tmp_path / ("iq%d.bin" % s), np.complex64)
@@ -336,5 +339,7 @@ def test_facade_tx_analog_set_audio(tmp_path, mode, kind, fw, w, tone):
             want = orc.mod_am(a, filter_width=fw, bb_gain=0.75, set_width=w)
         else:
             want = orc.mod_ssb(a, sb=1, filter_width=fw, bb_gain=0.75, set_width=w)
+        if rate != 1000000 or offset != 0.0:
+            want = orc.tx_interp(orc.rotator(want, orc.phase_inc_to_turn(2 * np.pi * offset / 1000000.0)), rate)
         assert got.size == want.size and got.size > 0
         assert np.array_equal((got.view(np.float32) + np.float32(0)).view(np.uint32), (want.view(np.float32) + np.float32(0)).view(np.uint32))

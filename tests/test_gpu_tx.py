@@ -597,3 +597,44 @@ def test_analog_modulator_set_filter_width_bit_exact(qrl_ctx, modem, kind, fw, w
     with pytest.raises(q.QrlError):
         mod.set_filter_width(100)                                                             # filters would not fit / below the SSB band edge
     mod.close()
+
+
+# ---- the gr_mod_base back end behind the analogue modulators (qrl_amod_config.device_samp_rate / carrier_offset_hz)
+@pytest.mark.parametrize("modem,kind,rate,offset", [(9, "nbfm", 4000000, 25000.0), (14, "am", 1000000, -12500.0), (11, "usb", 2000000, 0.0), (12, "lsb", 10000000, 50000.0)])
+def test_analog_modulator_back_end_bit_exact(qrl_ctx, modem, kind, rate, offset):
+    """rotator at 1 Msps + interpolation to the device rate behind NBFM / AM / SSB, in ragged calls, with a phase-continuous retune in the middle
+    (gr_mod_base.cpp:38,215-258,799-805) -- the same oracle back end as behind the digital modulators"""
+    import torch
+    import qradiolink_amd as q
+    n = (4 * 1024 + 700) if kind in ("usb", "lsb") else 1200
+    t = np.arange(n) / 8000.0
+    audio = np.stack([0.6 * np.sin(2 * np.pi * 700 * t) + 0.3 * np.sin(2 * np.pi * 1500 * t), np.random.default_rng(43).uniform(-0.8, 0.8, n)]).astype(np.float32)
+    cuts = [n] if kind == "lsb" else [400, 4, 796] if kind != "usb" else [1500, 1024, n - 2524]
+    mod = q.AMod(qrl_ctx, modem, batch=2, max_samples=max(cuts), bb_gain=0.75, device_samp_rate=rate, carrier_offset_hz=offset)
+    assert mod.spa == 125 * (rate // 1000000)
+    parts, pos, counts = [], 0, []
+    for i, c in enumerate(cuts):
+        if i == 2 and offset != 0.0:
+            mod.set_carrier_offset(-2 * offset)
+        parts.append(mod.process(torch.from_numpy(np.ascontiguousarray(audio[:, pos:pos + c])).cuda()).cpu().numpy())
+        counts.append(parts[-1].shape[1] // (rate // 1000000))
+        pos += c
+    mod.close()
+    got = np.concatenate(parts, axis=1)
+    for b in range(2):
+        x1 = {"nbfm": lambda: orc.mod_nbfm(audio[b], filter_width=5000, bb_gain=0.75), "am": lambda: orc.mod_am(audio[b], bb_gain=0.75),
+              "usb": lambda: orc.mod_ssb(audio[b], sb=0, bb_gain=0.75), "lsb": lambda: orc.mod_ssb(audio[b], sb=1, bb_gain=0.75)}[kind]()
+        inc0 = orc.phase_inc_to_turn(2 * np.pi * offset / 1e6)
+        if len(cuts) == 3 and offset != 0.0:
+            k = counts[0] + counts[1]                                    # 1 Msps samples produced before the retune
+            inc1 = orc.phase_inc_to_turn(2 * np.pi * -2 * offset / 1e6)
+            rot = np.concatenate([orc.rotator(x1[:k], inc0), orc.rotator(x1[k:], inc1, (k * inc0) & (2 ** 64 - 1))])
+        else:
+            rot = orc.rotator(x1, inc0)
+        ref = orc.tx_interp(rot, rate) if rate != 1000000 else rot
+        assert got[b].size == ref.size, (got[b].size, ref.size)
+        assert np.array_equal((got[b].view(np.float32) + np.float32(0)).view(np.uint32), (ref.view(np.float32) + np.float32(0)).view(np.uint32)), "stream %d differs" % b
+    m1 = q.AMod(qrl_ctx, q.MODEM_NBFM5000, batch=1, max_samples=64)
+    with pytest.raises(q.QrlError):
+        m1.set_carrier_offset(1000.0)                                    # created without the back end
+    m1.close()
