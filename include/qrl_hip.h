@@ -38,7 +38,7 @@ typedef enum {
 /* values of gr_modem_types (reference src/modem_types.h:5-50) accepted by qrl_demod_create */
 enum {
     QRL_MODEM_BPSK2K = 0, QRL_MODEM_QPSK20K = 1, QRL_MODEM_QPSKVIDEO = 2, QRL_MODEM_4FSK2K = 3, QRL_MODEM_4FSK10KFM = 4, QRL_MODEM_4FSK2KFM = 5, QRL_MODEM_4FSK1KFM = 6, QRL_MODEM_QPSK2K = 7,
-    QRL_MODEM_NBFM2500 = 8, QRL_MODEM_NBFM5000 = 9, QRL_MODEM_WBFM = 10, QRL_MODEM_USB2500 = 11, QRL_MODEM_LSB2500 = 12, QRL_MODEM_AM5000 = 14,   /* analogue voice receivers: port 1 = audio */
+    QRL_MODEM_NBFM2500 = 8, QRL_MODEM_NBFM5000 = 9, QRL_MODEM_WBFM = 10, QRL_MODEM_USB2500 = 11, QRL_MODEM_LSB2500 = 12, QRL_MODEM_CW600USB = 13 /* TX only: qrl_amod */, QRL_MODEM_AM5000 = 14,   /* analogue voice receivers: port 1 = audio */
     QRL_MODEM_2FSK2KFM = 15, QRL_MODEM_2FSK1KFM = 16, QRL_MODEM_2FSK2K = 17, QRL_MODEM_2FSK1K = 18,
     QRL_MODEM_2FSK10KFM = 19, QRL_MODEM_GMSK2K = 20, QRL_MODEM_GMSK1K = 21, QRL_MODEM_GMSK10K = 22,
     QRL_MODEM_BPSK1K = 24, QRL_MODEM_BPSK8 = 25 /* DSSS, Barker 13 */, QRL_MODEM_QPSK250K = 26, QRL_MODEM_4FSK100K = 27, QRL_MODEM_M17 = 40, QRL_MODEM_DMR = 41
@@ -476,7 +476,7 @@ uint64_t qrl_phase_inc_to_turn(double radians_per_sample);
  * results are independent of how the audio is cut into calls.   */
 typedef struct qrl_amod qrl_amod;
 typedef struct qrl_amod_config {
-    int modem_type;        /* QRL_MODEM_NBFM2500 | QRL_MODEM_NBFM5000 | QRL_MODEM_USB2500 | QRL_MODEM_LSB2500 */
+    int modem_type;        /* QRL_MODEM_NBFM2500 | QRL_MODEM_NBFM5000 | QRL_MODEM_USB2500 | QRL_MODEM_LSB2500 | QRL_MODEM_CW600USB | QRL_MODEM_AM5000 */
     int batch;
     size_t max_samples;    /* audio samples per stream and call */
     void* hip_stream;      /* hipStream_t or NULL (own stream) */
@@ -504,8 +504,14 @@ int qrl_amod_set_ctcss(qrl_amod* m, float tone_hz);
  * sensitivity 4 pi w / 50000 -- the constructor uses a 3500 Hz transition everywhere), gr_mod_am (gr_mod_am.cpp:75-85: the constructor's designs with w),
  * gr_mod_ssb (gr_mod_ssb.cpp:85-100: _resampler as constructed with w, the sideband filter complex_band_pass_2(1, 8000, 300, w | -w, -300, 250, 90, BH);
  * the audio filter keeps the constructor's width).  The chain restarts from a fresh state (see qrl_demod_set_filter_width); bb_gain and the CTCSS
- * switch are kept.  Widths whose filters do not fit the kernels' tables are refused (NBFM < 1340, SSB < 1780, AM < 1180 Hz). */
+ * switch are kept.  Widths whose filters do not fit the kernels' tables are refused (NBFM < 540, SSB < 500, AM < 295 Hz). */
 int qrl_amod_set_filter_width(qrl_amod* m, int filter_width);
+/* QRL_MODEM_CW600USB (TX only): replaces the CW branch of gr_mod_base (src/gr/gr_mod_base.cpp:144,180,679-683): _signal_source = analog::sig_source_f(8000,
+ * GR_SIN_WAVE, 600, 0.001, 1) -> _usb_cw = make_gr_mod_ssb(125, 1000000, 1700, 1000, 0).  qrl_amod_process(m, NULL, 0, n, iq, stride) produces what n samples
+ * of the tone source give (whole chunks of 1024 like every SSB handle; an audio pointer is ignored); qrl_amod_set_cw_k replaces gr_mod_base::set_cw_k (:948-956):
+ * key down = amplitude 0.98, up = 0.001, from the next call on, the tone's phase runs on.  qrl_amod_set_filter_width works as for USB.  [The tone source is
+ * GNU Radio's fixed-point NCO with its 1024-row sine table, restated from memory.] */
+int qrl_amod_set_cw_k(qrl_amod* m, int key_down);
 size_t qrl_amod_samples_per_sample(const qrl_amod* m);
 /* SSB (replaces make_gr_mod_ssb(125, 1000000, 1700, 2700, sb), reference src/gr/gr_mod_ssb.cpp:19-82, gr_mod_base.cpp:178-179): the
  * cessb stretcher emits whole chunks of 1024 audio-rate items and looks two items ahead, so a call returns 125 x (chunks completed

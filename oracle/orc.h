@@ -234,6 +234,7 @@ void   orc_agc2_ff(const float* in, size_t n, float attack, float decay, float r
 void   orc_iir_ffd_2(const float* in, size_t n, const double ff[2], const double fb[2], int oldstyle, float* out);
 void   orc_set_tx_ctcss(float tone_hz);   /* gr_mod_nbfm::set_ctcss for the next orc_mod_nbfm calls: > 0 tone on, < 0 switched off again (x0.98), 0 = constructor */
 void   orc_fxpt_sine_table(float* tab /* 1024 x 2 */); uint32_t orc_fxpt_phase_inc(double fs, double freq);
+void   orc_sig_source_sin(double fs, double freq, double ampl, float offset, uint64_t k0, size_t n, float* out);   /* analog::sig_source_f(GR_SIN_WAVE, offset) [GR-MEM]: the CW key's tone */
 void   orc_sig_source_cos(double fs, double freq, double ampl, uint64_t k0, size_t n, float* out);   /* analog::sig_source_f(GR_COS_WAVE) [GR-MEM] */
 void   orc_set_rx_filter_width(int width);   /* gr_demod_nbfm / am / wbfm / ssb::set_filter_width for the next orc_demod_analog / orc_demod_ssb calls; 0 = constructor */
 void   orc_set_rx_gain(float k);             /* gr_demod_ssb::set_gain (_if_gain) for the next orc_demod_ssb calls; < 0 = the constructor's 0.9 */

@@ -318,6 +318,21 @@ uint32_t orc_fxpt_phase_inc(double fs, double freq)
     x -= d * 2 * PI_F;
     return (uint32_t)(int32_t)(x * 2147483648.0f / PI_F);
 }
+/* the GR_SIN_WAVE form with an offset (the CW key's source, gr_mod_base.cpp:144: sig_source_f(8000, GR_SIN_WAVE, 600, 0.001, 1)): sin_fx(p) is cos_fx without the
+ * quarter turn, the offset is added to the float sample afterwards (sig_source_impl::work: d_nco.sin(out, n, ampl); out[i] += offset).  [GR-MEM] */
+void orc_sig_source_sin(double fs, double freq, double ampl, float offset, uint64_t k0, size_t n, float* out)
+{
+    static float tab[2048]; static int have = 0;
+    if (!have) { orc_fxpt_sine_table(tab); have = 1; }
+    const uint32_t inc = orc_fxpt_phase_inc(fs, freq);
+    for (size_t k = 0; k < n; k++) {
+        const uint32_t u = (uint32_t)((k0 + k) * (uint64_t)inc);
+        const float v = tab[2 * (u >> 22)] * (float)(u >> 1) + tab[2 * (u >> 22) + 1];
+        float x = (float)((double)v * ampl);
+        if (offset != 0.0f) x = x + offset;
+        out[k] = x;
+    }
+}
 void orc_sig_source_cos(double fs, double freq, double ampl, uint64_t k0, size_t n, float* out)
 {
     static float tab[2048]; static int have = 0;

@@ -22,7 +22,7 @@ MODEM_BPSK2K, MODEM_BPSK1K = 0, 24
 MODEM_4FSK2K, MODEM_4FSK10KFM, MODEM_4FSK2KFM, MODEM_4FSK1KFM, MODEM_4FSK100K = 3, 4, 5, 6, 27
 MODEM_BPSK8 = 25
 MODEM_NBFM2500, MODEM_NBFM5000, MODEM_WBFM, MODEM_AM5000 = 8, 9, 10, 14
-MODEM_USB2500, MODEM_LSB2500 = 11, 12
+MODEM_USB2500, MODEM_LSB2500, MODEM_CW600USB = 11, 12, 13
 MODEM_M17 = 40
 MODEM_DMR = 41
 OPT_OVERLAP, OPT_UNFUSED_DEC2, OPT_FLL_SLIM, OPT_GROUPED = 1, 2, 3, 4
@@ -127,6 +127,7 @@ def load_library():
     lib.qrl_demod_set_gain.argtypes = [vp, C.c_float]
     lib.qrl_amod_set_filter_width.argtypes = [vp, C.c_int]
     lib.qrl_amod_set_carrier_offset.argtypes = [vp, C.c_double]
+    lib.qrl_amod_set_cw_k.argtypes = [vp, C.c_int]
     lib.qrl_demod_process.argtypes = [vp, vp, sz, sz, C.POINTER(_Out)]
     lib.qrl_demod_sync.argtypes = [vp]
     lib.qrl_rssi_create.argtypes = [vp, C.c_int, C.c_float, vp, C.POINTER(vp)]
@@ -227,7 +228,7 @@ EXPORTED_SYMBOLS = [
     "qrl_demod_destroy", "qrl_demod_reset", "qrl_demod_set_carrier_offset", "qrl_demod_set_option", "qrl_demod_set_dmo_output", "qrl_demod_stream_wait", "qrl_demod_out_caps",
     "qrl_demod_audio_cap", "qrl_demod_set_squelch", "qrl_demod_set_agc", "qrl_demod_set_filter_width", "qrl_demod_set_gain", "qrl_demod_set_ctcss", "qrl_demod_time_domain_cap", "qrl_demod_set_time_domain_output",
     "qrl_bptc19696_decode", "qrl_bptc19696_encode", "qrl_m17_decode_frames", "qrl_m17_encode_frames",
-    "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_set_ctcss", "qrl_amod_set_filter_width", "qrl_amod_set_carrier_offset", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
+    "qrl_amod_create", "qrl_amod_destroy", "qrl_amod_reset", "qrl_amod_set_bb_gain", "qrl_amod_set_ctcss", "qrl_amod_set_filter_width", "qrl_amod_set_carrier_offset", "qrl_amod_set_cw_k", "qrl_amod_samples_per_sample", "qrl_amod_last_count", "qrl_amod_out_cap", "qrl_amod_process", "qrl_amod_sync", "qrl_amod_stream",
     "qrl_demod_process", "qrl_demod_sync", "qrl_demod_stream", "qrl_demod_internal_streams", "qrl_chan_internal_streams", "qrl_demod_process_host", "qrl_demod_profile",
     "qrl_demod_profile_read", "qrl_mod_create", "qrl_mod_destroy", "qrl_mod_reset", "qrl_mod_set_bb_gain", "qrl_mod_set_carrier_offset",
     "qrl_mod_samples_per_byte", "qrl_mod_samples_per_block", "qrl_mod_add_zero_runs", "qrl_mod_process", "qrl_mod_sync", "qrl_mod_stream", "qrl_chan_set_option", "qrl_chan_channelize", "qrl_chan_process_channels", "qrl_chan_wait_for", "qrl_chan_stream_wait", "qrl_chan_stream", "qrl_chan_profile", "qrl_chan_profile_read", "qrl_chan_profile_read_kernels", "qrl_debug_decim_prof", "qrl_debug_decim_prof_enable", "qrl_chan_create",
@@ -889,6 +890,19 @@ class AMod:
 
     def set_carrier_offset(self, hz):
         _check(self.lib.qrl_amod_set_carrier_offset(self.h, C.c_double(hz)), "qrl_amod_set_carrier_offset")
+
+    def set_cw_k(self, key_down):
+        """gr_mod_base::set_cw_k: amplitude of the CW tone source, 0.98 (key down) / 0.001 (qrl_amod_set_cw_k; QRL_MODEM_CW600USB handles)"""
+        _check(self.lib.qrl_amod_set_cw_k(self.h, int(bool(key_down))), "qrl_amod_set_cw_k")
+
+    def process_cw(self, n):
+        """QRL_MODEM_CW600USB: what n samples of the key's tone source give (whole chunks of 1024 like every SSB handle)"""
+        t = self.torch
+        out = t.zeros((self.batch, max(self.lib.qrl_amod_out_cap(self.h, n), 1)), dtype=t.complex64, device="cuda")
+        t.cuda.current_stream().synchronize()
+        _check(self.lib.qrl_amod_process(self.h, None, 0, n, out.data_ptr(), out.stride(0)), "qrl_amod_process")
+        _check(self.lib.qrl_amod_sync(self.h), "qrl_amod_sync")
+        return out[:, :self.lib.qrl_amod_last_count(self.h)]
 
     def set_ctcss(self, tone_hz):
         """gr_mod_nbfm::set_ctcss: tone (Hz) added to the audio, band-pass audio filter; 0 switches it off again (qrl_amod_set_ctcss)"""

@@ -37,6 +37,27 @@ template <class T> struct Dev {
     int zero() { return hipMemset(p, 0, n * sizeof(T)) == hipSuccess ? QRL_OK : QRL_ERR_HIP; }
 };
 uint32_t pow2_at_least(size_t v) { uint32_t c = 1024; while (c < v) c <<= 1; return c; }
+// gr::fxpt's 1024-row interpolated sine table {slope, intercept} (oracle orc_fxpt_sine_table)
+std::vector<float> fxpt_sine_table()
+{
+    std::vector<float> tab(2048);
+    for (int i = 0; i < 1024; ++i) {
+        const double a = (double)i * 2097152.0, b = (double)(i + 1) * 2097152.0, w = M_PI / 1073741824.0;
+        const double fa = std::sin(a * w), fb = std::sin(b * w), fm = std::sin((a + b) / 2 * w);
+        tab[2 * i] = (float)((fb - fa) / (b - a));
+        tab[2 * i + 1] = (float)((3 * a + b) * (fa - fb) / (4 * (b - a)) + (fm + fa) / 2);
+    }
+    return tab;
+}
+// sig_source_f::set_frequency -> fxpt_nco::set_freq((float)(2 pi f / fs)) -> float_to_fixed (oracle orc_fxpt_phase_inc)
+uint32_t fxpt_phase_inc(double fs, double freq)
+{
+    float x = (float)(2 * M_PI * freq / fs);
+    const float PI_F = (float)M_PI;
+    const int d = (int)std::floor(x / 2 / PI_F + 0.5f);
+    x -= d * 2 * PI_F;
+    return (uint32_t)(int32_t)(x * 2147483648.0f / PI_F);
+}
 }  // namespace
 
 struct qrl_amod {
@@ -44,6 +65,7 @@ struct qrl_amod {
     qrl_amod_config cfg{};
     hipStream_t stream = nullptr; bool own_stream = false;
     int sps = 20, fw = 5000; bool ssb = false, lsb = false, am = false;
+    bool cw = false; double cw_ampl = 0.001;   // QRL_MODEM_CW600USB: the SSB chain fed by sig_source_f(8000, GR_SIN_WAVE, 600, 0.001, 1) (gr_mod_base.cpp:144,180,679-683)
     Dev<float> am_gain; Dev<float2> t_chan, m1, m2; int n_chan = 0; uint32_t mm = 0; uint64_t n1m = 0;   // AM: agc gain per stream, 1 Msps rings, channel filter
     Dev<float2> t_side, c1, c2, c3; int n_side = 0; Dev<float> atan_tab; uint64_t ns = 0; size_t last = 0;   // SSB
     float bb_gain = 1.0f, fm_k = 0.f;
@@ -122,7 +144,8 @@ int qrl_amod_create(qrl_ctx* ctx, const qrl_amod_config* cfg, qrl_amod** outp)
     case QRL_MODEM_USB2500: m->ssb = true; m->fw = 2700; m->sps = 125; break;              // make_gr_mod_ssb(125, 1000000, 1700, 2700, 0) :178
     case QRL_MODEM_LSB2500: m->ssb = m->lsb = true; m->fw = 2700; m->sps = 125; break;     // :179
     case QRL_MODEM_AM5000: m->am = true; m->fw = 5000; m->sps = 125; break;                 // make_gr_mod_am(125, 1000000, 1700, 5000) gr_mod_base.cpp:167
-    default: return qrl_set_error(QRL_ERR_ARG, "amod: modem_type must be QRL_MODEM_NBFM2500 / NBFM5000 / USB2500 / LSB2500 / AM5000");
+    case QRL_MODEM_CW600USB: m->ssb = m->cw = true; m->fw = 1000; m->sps = 125; break;     // _usb_cw = make_gr_mod_ssb(125, 1000000, 1700, 1000, 0) :180
+    default: return qrl_set_error(QRL_ERR_ARG, "amod: modem_type must be QRL_MODEM_NBFM2500 / NBFM5000 / USB2500 / LSB2500 / CW600USB / AM5000");
     }
     HIPCHK(hipSetDevice(ctx->device));
     if (cfg->hip_stream) m->stream = static_cast<hipStream_t>(cfg->hip_stream);
@@ -134,7 +157,7 @@ int qrl_amod_create(qrl_ctx* ctx, const qrl_amod_config* cfg, qrl_amod** outp)
         const std::vector<float> tr = low_pass(m->sps, 1000000, fw, fw, WIN_HAMMING);
         const auto tc = complex_band_pass_2(1, 1000000, -fw, fw, 1200, 120, WIN_BLACKMAN_HARRIS);
         m->n_audio = (int)ta.size(); m->n_interp = (int)tr.size(); m->n_chan = (int)tc.size();
-        if (m->n_interp > 2048 || (size_t)m->n_chan * sizeof(float2) > 60 * 1024) return qrl_set_error(QRL_ERR_ARG, "amod: AM filters too long for the kernels' LDS tables");
+        if (m->n_interp > 8192 || (size_t)m->n_chan * sizeof(float2) > 60 * 1024) return qrl_set_error(QRL_ERR_ARG, "amod: AM filters too long for the kernels' tables");
         std::vector<float2> tc2(tc.size());
         for (size_t i = 0; i < tc.size(); ++i) tc2[i] = make_float2(tc[i].real(), tc[i].imag());
         int r;
@@ -155,11 +178,12 @@ int qrl_amod_create(qrl_ctx* ctx, const qrl_amod_config* cfg, qrl_amod** outp)
                                : complex_band_pass_2(1, 8000, 200, fw, 200, 90, WIN_BLACKMAN_HARRIS);            // _filter_usb, :54-55
         const std::vector<float> tr = low_pass_2(m->sps, 1000000, fw, fw, 90, WIN_BLACKMAN_HARRIS);            // _resampler (125, 1), :47-50
         m->n_audio = (int)ta.size(); m->n_side = (int)ts.size(); m->n_interp = (int)tr.size();
-        if (m->n_interp > 2048) return qrl_set_error(QRL_ERR_ARG, "amod: interpolator filter too long");
+        if (m->n_interp > 8192) return qrl_set_error(QRL_ERR_ARG, "amod: interpolator filter too long");   // (beyond 2048 taps k_tx_interp_c reads them through L1 / L2: the 4091 taps of the CW chain)
         std::vector<float2> ts2(ts.size());
         for (size_t i = 0; i < ts.size(); ++i) ts2[i] = make_float2(ts[i].real(), ts[i].imag());
         int r;
         if ((r = m->t_audio.upload(ta)) || (r = m->t_side.upload(ts2)) || (r = m->t_interp.upload(tr)) || (r = m->atan_tab.upload(atan_table()))) return r;
+        if (m->cw) { if ((r = m->tone_tab.upload(fxpt_sine_table()))) return r; m->tone_inc = fxpt_phase_inc(8000.0, 600.0); }
         m->m8 = pow2_at_least(cfg->max_samples + 2048) - 1;        // the stretcher holds back up to 1025 items
         const size_t r8 = (size_t)B * (m->m8 + 1);
         if ((r = m->a0.alloc(r8)) || (r = m->a1.alloc(r8)) || (r = m->c1.alloc(r8)) || (r = m->c2.alloc(r8)) || (r = m->c3.alloc(r8))) return r;
@@ -174,20 +198,13 @@ int qrl_amod_create(qrl_ctx* ctx, const qrl_amod_config* cfg, qrl_amod** outp)
     const std::vector<float> tf = low_pass_2(1, 50000, fw, 3500, 60, WIN_BLACKMAN_HARRIS);                 // _filter, :61-62
     const std::vector<float> tr = low_pass_2(m->sps, 1000000, fw, 3500, 60, WIN_BLACKMAN_HARRIS);          // _resampler (sps, 1), :56-58
     m->n_audio = (int)ta.size(); m->n_if = (int)ti.size(); m->n_filt = (int)tf.size(); m->n_interp = (int)tr.size();
-    if (m->n_interp > 2048) return qrl_set_error(QRL_ERR_ARG, "amod: interpolator filter too long");
+    if (m->n_interp > 8192) return qrl_set_error(QRL_ERR_ARG, "amod: interpolator filter too long");   // (beyond 2048 taps k_tx_interp_c reads them through L1 / L2: the 4091 taps of the CW chain)
     int r;
     if ((r = m->t_audio.upload(ta)) || (r = m->t_if.upload(ti)) || (r = m->t_filt.upload(tf)) || (r = m->t_interp.upload(tr))) return r;
     {   // set_ctcss(tone): the band-pass and the sine table of the tone source (oracle orc_fxpt_sine_table), ready for qrl_amod_set_ctcss
         const std::vector<float> tb = band_pass_2(1, 8000, 300, 3500, 200, 35, WIN_BLACKMAN_HARRIS);        // gr_mod_nbfm.cpp:124-125
         m->n_audio_bp = (int)tb.size();
-        std::vector<float> tab(2048);
-        for (int i = 0; i < 1024; ++i) {
-            const double a = (double)i * 2097152.0, b = (double)(i + 1) * 2097152.0, w = M_PI / 1073741824.0;
-            const double fa = std::sin(a * w), fb = std::sin(b * w), fm = std::sin((a + b) / 2 * w);
-            tab[2 * i] = (float)((fb - fa) / (b - a));
-            tab[2 * i + 1] = (float)((3 * a + b) * (fa - fb) / (4 * (b - a)) + (fm + fa) / 2);
-        }
-        if ((r = m->t_audio_bp.upload(tb)) || (r = m->tone_tab.upload(tab))) return r;
+        if ((r = m->t_audio_bp.upload(tb)) || (r = m->tone_tab.upload(fxpt_sine_table()))) return r;
     }
     m->fm_k = (float)(4 * M_PI * fw / 50000.0f);                                                          // frequency_modulator_fc, :41
     preemph_taps(8000, 50e-6, m->pa, m->pb);                                                              // :39
@@ -216,12 +233,13 @@ int qrl_amod_set_ctcss(qrl_amod* m, float tone_hz)
     if (tone_hz < 0.0f || tone_hz > 300.0f) return qrl_set_error(QRL_ERR_ARG, "qrl_amod_set_ctcss: tone out of range");
     if (tone_hz == 0.0f) { m->k_audio = 0.98f; m->tone_hz = 0.0f; return QRL_OK; }      // gr_mod_nbfm.cpp:104-108 (0.98, not the constructor's 0.99)
     m->k_audio = 0.85f; m->tone_hz = tone_hz;                                             // :122-126
-    // sig_source_f::set_frequency -> fxpt_nco::set_freq((float)(2 pi f / fs)) -> float_to_fixed (oracle orc_fxpt_phase_inc)
-    float x = (float)(2 * M_PI * (double)tone_hz / 8000.0);
-    const float PI_F = (float)M_PI;
-    const int d = (int)std::floor(x / 2 / PI_F + 0.5f);
-    x -= d * 2 * PI_F;
-    m->tone_inc = (uint32_t)(int32_t)(x * 2147483648.0f / PI_F);
+    m->tone_inc = fxpt_phase_inc(8000.0, (double)tone_hz);
+    return QRL_OK;
+}
+int qrl_amod_set_cw_k(qrl_amod* m, int key_down)
+{
+    if (!m || !m->cw) return qrl_set_error(QRL_ERR_ARG, "qrl_amod_set_cw_k: QRL_MODEM_CW600USB handles only");
+    m->cw_ampl = key_down ? 0.98 : 0.001;   // gr_mod_base::set_cw_k -> sig_source_f::set_amplitude (gr_mod_base.cpp:948-956): from the next call on, the phase runs on
     return QRL_OK;
 }
 int qrl_amod_set_filter_width(qrl_amod* m, int width)
@@ -238,21 +256,21 @@ int qrl_amod_set_filter_width(qrl_amod* m, int width)
     if (m->am) {
         const std::vector<float> tr = low_pass(m->sps, 1000000, w, w, WIN_HAMMING);
         const auto tc = complex_band_pass_2(1, 1000000, -w, w, 1200, 120, WIN_BLACKMAN_HARRIS);
-        if (tr.size() > 2048 || tc.size() != (size_t)m->n_chan) return qrl_set_error(QRL_ERR_ARG, "qrl_amod_set_filter_width: AM interpolator too long for the kernel's LDS table (width >= 1180)");
+        if (tr.size() > 8192 || tc.size() != (size_t)m->n_chan) return qrl_set_error(QRL_ERR_ARG, "qrl_amod_set_filter_width: AM interpolator too long (width >= 295)");
         if ((r = m->t_interp.upload(tr)) || (r = m->t_chan.upload(to2(tc)))) return r;
         m->n_interp = (int)tr.size();
     } else if (m->ssb) {
         // (the audio filter keeps the constructor's width)
         const std::vector<float> tr = low_pass_2(m->sps, 1000000, w, w, 90, WIN_BLACKMAN_HARRIS);
         const auto ts = m->lsb ? complex_band_pass_2(1, 8000, -w, -300, 250, 90, WIN_BLACKMAN_HARRIS) : complex_band_pass_2(1, 8000, 300, w, 250, 90, WIN_BLACKMAN_HARRIS);
-        if (tr.size() > 2048 || ts.size() > 1024) return qrl_set_error(QRL_ERR_ARG, "qrl_amod_set_filter_width: filter too long (width >= 1780)");
+        if (tr.size() > 8192 || ts.size() > 1024) return qrl_set_error(QRL_ERR_ARG, "qrl_amod_set_filter_width: filter too long (width >= 500)");
         if ((r = m->t_interp.upload(tr)) || (r = m->t_side.upload(to2(ts)))) return r;
         m->n_interp = (int)tr.size(); m->n_side = (int)ts.size();
     } else {
         const std::vector<float> ti = low_pass_2(25, 50000.0 * 4, w, w, 60, WIN_BLACKMAN_HARRIS);
         const std::vector<float> tf = low_pass_2(1, 50000, w, 1200, 60, WIN_BLACKMAN_HARRIS);
         const std::vector<float> tr = low_pass_2(m->sps, 1000000, w, w, 60, WIN_BLACKMAN_HARRIS);
-        if (tr.size() > 2048 || ti.size() > 1024 || tf.size() > 1024) return qrl_set_error(QRL_ERR_ARG, "qrl_amod_set_filter_width: filter too long (width >= 1340)");
+        if (tr.size() > 8192 || ti.size() > 1024 || tf.size() > 1024) return qrl_set_error(QRL_ERR_ARG, "qrl_amod_set_filter_width: filter too long (width >= 540)");
         if ((r = m->t_if.upload(ti)) || (r = m->t_filt.upload(tf)) || (r = m->t_interp.upload(tr))) return r;
         m->n_if = (int)ti.size(); m->n_filt = (int)tf.size(); m->n_interp = (int)tr.size();
         m->fm_k = (float)(4 * M_PI * width / 50000.0f);
@@ -279,7 +297,7 @@ int qrl_amod_sync(qrl_amod* m) { if (!m) return QRL_ERR_ARG; HIPCHK(hipStreamSyn
 
 int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, float* iq, size_t out_stride)
 {
-    if (!m || (!audio && n) || (!iq && n)) return QRL_ERR_ARG;
+    if (!m || (!audio && n && !m->cw) || (!iq && n)) return QRL_ERR_ARG;
     if (n > m->cfg.max_samples) return qrl_set_error(QRL_ERR_TOO_BIG, "n exceeds max_samples");
     if (!m->ssb && !m->am && n % 4) return qrl_set_error(QRL_ERR_ARG, "amod: audio samples per call must be a multiple of 4 (25:4 resampler)");
     m->last = 0;
@@ -341,8 +359,13 @@ int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, f
         const uint64_t ns_1 = n8_1 >= 2 ? 1024 * ((n8_1 - 2) / 1024) : 0;        // stretcher: whole chunks, two items of look-ahead
         const uint32_t cs = (uint32_t)(ns_1 - m->ns);
         if ((size_t)cs * m->sps * m->be_interp > out_stride && B > 1) return qrl_set_error(QRL_ERR_ARG, "amod: out_stride smaller than this call's output (qrl_amod_out_cap)");
-        AmLoadParams lp{}; lp.in = audio; lp.in_stride = stride; lp.out = a0; lp.n0 = m->n8; lp.count = c8;
-        launch_am_load(lp, B, s);
+        if (m->cw) {   // the key's tone source instead of the caller's audio (which is ignored): amplitude 0.001 / 0.98 by qrl_amod_set_cw_k, offset 1
+            AmToneParams tp{}; tp.out = a0; tp.n0 = m->n8; tp.count = c8; tp.tab = m->tone_tab.p; tp.inc = m->tone_inc; tp.k0 = m->n8; tp.ampl = m->cw_ampl; tp.offset = 1.0f;
+            launch_am_tone(tp, B, s);
+        } else {
+            AmLoadParams lp{}; lp.in = audio; lp.in_stride = stride; lp.out = a0; lp.n0 = m->n8; lp.count = c8;
+            launch_am_load(lp, B, s);
+        }
         FirFffParams af{}; af.in = a0; af.out = a1; af.q0 = m->n8; af.count = c8; af.taps = m->t_audio.p; af.nt = m->n_audio;
         launch_fir_fff(af, B, s);                                                   // _audio_filter
         AmClipParams cp{}; cp.in = a1; cp.out = c1; cp.n0 = m->n8; cp.count = c8; cp.clip = 0.95f; cp.atan_tab = m->atan_tab.p;

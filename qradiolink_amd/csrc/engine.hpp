@@ -336,6 +336,8 @@ void launch_am_agc_rail(const AmAgcParams& p, int batch, hipStream_t s);
 void launch_am_carrier(RingF in, RingC out, uint64_t n0, uint32_t count, float carrier, int batch, hipStream_t s);
 struct AmLoadParams { const float* in; size_t in_stride; RingF out; uint64_t n0; uint32_t count; };
 void launch_am_load(const AmLoadParams& p, int batch, hipStream_t s);
+struct AmToneParams { RingF out; uint64_t n0; uint32_t count; const float* tab; uint32_t inc; uint64_t k0; double ampl; float offset; };
+void launch_am_tone(const AmToneParams& p, int batch, hipStream_t s);
 struct AmIirState { double y1; float x1, pad; };
 struct AmIirParams { RingF in, out; uint64_t n0; uint32_t count; float gain; double ff0, ff1, fb1; AmIirState* st;
                      // gr_mod_nbfm::set_ctcss: add_ff(audio, sig_source_f(8000, GR_COS_WAVE, tone, 0.15)) in front of the filter -- the fixed-point NCO of

@@ -344,6 +344,25 @@ void launch_am_load(const AmLoadParams& p, int batch, hipStream_t s)
     if (!p.count) return;
     hipLaunchKernelGGL(k_am_load, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
 }
+// analog::sig_source_f(fs, GR_SIN_WAVE, f, ampl, offset) into an audio ring (the CW key's tone source, gr_mod_base.cpp:144): GNU Radio's fixed-point NCO
+// with its 1024-row sine table (oracle orc_sig_source_f): sample k = (float)(sin_fx(k inc) * ampl) + offset, the phase runs over all samples produced
+__global__ __launch_bounds__(256) void k_am_tone(const AmToneParams P)
+{
+    const int b = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= P.count) return;
+    const uint32_t u = (uint32_t)((P.k0 + t) * (uint64_t)P.inc);
+    float v = P.tab[2 * (u >> 22)] * (float)(u >> 1);
+    v = v + P.tab[2 * (u >> 22) + 1];
+    float x = (float)((double)v * P.ampl);
+    x = x + P.offset;
+    P.out.p[(size_t)b * (P.out.mask + 1u) + ((uint32_t)(P.n0 + t) & P.out.mask)] = x;
+}
+void launch_am_tone(const AmToneParams& p, int batch, hipStream_t s)
+{
+    if (!p.count) return;
+    hipLaunchKernelGGL(k_am_tone, dim3((p.count + 255) / 256, batch), dim3(256), 0, s, p);
+}
 // multiply_const_ff(gain) -> iir_filter_ffd(btaps, ataps, false): acc = b0 x + b1 x[-1] + fb1 y[-1] in double (fb1 = -a1)
 __global__ __launch_bounds__(64) void k_am_iir(const AmIirParams P, int batch)
 {

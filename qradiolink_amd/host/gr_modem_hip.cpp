@@ -515,7 +515,8 @@ gr_mod_base_hip::~gr_mod_base_hip()
 }
 static bool analog_tx_mode(int mode)
 {
-    return mode == QRL_MODEM_NBFM2500 || mode == QRL_MODEM_NBFM5000 || mode == QRL_MODEM_AM5000 || mode == QRL_MODEM_USB2500 || mode == QRL_MODEM_LSB2500;
+    return mode == QRL_MODEM_NBFM2500 || mode == QRL_MODEM_NBFM5000 || mode == QRL_MODEM_AM5000 || mode == QRL_MODEM_USB2500 || mode == QRL_MODEM_LSB2500 ||
+           mode == QRL_MODEM_CW600USB;
 }
 void gr_mod_base_hip::open()
 {
@@ -532,6 +533,7 @@ void gr_mod_base_hip::open()
         // the reference's instances keep what their setters did across mode changes
         if (d_ctcss_touched && (d_mode == QRL_MODEM_NBFM2500 || d_mode == QRL_MODEM_NBFM5000)) chk(qrl_amod_set_ctcss(d_ah, d_ctcss), "qrl_amod_set_ctcss");
         if (d_width.count(d_mode)) chk(qrl_amod_set_filter_width(d_ah, d_width[d_mode]), "qrl_amod_set_filter_width");
+        if (d_mode == QRL_MODEM_CW600USB && d_cw_key) chk(qrl_amod_set_cw_k(d_ah, 1), "qrl_amod_set_cw_k");
         hchk(hipMalloc(reinterpret_cast<void**>(&d_audio), (size_t)d_n * d_max * sizeof(float)), "hipMalloc");
         hchk(hipMalloc(reinterpret_cast<void**>(&d_iq), (size_t)d_n * qrl_amod_out_cap(d_ah, d_max) * sizeof(gr_complex)), "hipMalloc");
         return;
@@ -558,6 +560,11 @@ int gr_mod_base_hip::set_audio(std::vector<float>* data, int stream)   // gr_mod
     d_aqueue[stream].insert(d_aqueue[stream].end(), data->begin(), data->end());
     delete data;
     return 0;
+}
+void gr_mod_base_hip::set_cw_k(bool value)   // gr_mod_base.cpp:948-956
+{
+    d_cw_key = value;
+    if (d_ah && d_mode == QRL_MODEM_CW600USB) chk(qrl_amod_set_cw_k(d_ah, value ? 1 : 0), "qrl_amod_set_cw_k");
 }
 void gr_mod_base_hip::set_ctcss(float value)   // gr_mod_base.cpp:872-877
 {
@@ -592,6 +599,15 @@ void gr_mod_base_hip::set_carrier_offset(double hz)
 size_t gr_mod_base_hip::samples_per_byte() const { return d_h ? qrl_mod_samples_per_byte(d_h) : 0; }
 size_t gr_mod_base_hip::work(gr_complex* const* out)
 {
+    if (d_ah && d_mode == QRL_MODEM_CW600USB) {   // the tone source lives on the device: nothing to upload
+        const size_t stride = qrl_amod_out_cap(d_ah, d_max);
+        chk(qrl_amod_process(d_ah, nullptr, 0, d_cw_n, d_iq, stride), "qrl_amod_process");
+        chk(qrl_amod_sync(d_ah), "qrl_amod_sync");
+        const size_t ns = qrl_amod_last_count(d_ah);
+        for (int s = 0; s < d_n && ns; ++s)
+            hchk(hipMemcpy(out[s], d_iq + 2 * (size_t)s * stride, ns * sizeof(gr_complex), hipMemcpyDeviceToHost), "D2H");
+        return ns;
+    }
     if (d_ah) {
         size_t na = 0;
         std::vector<float> host((size_t)d_n * d_max, 0.0f);

@@ -151,6 +151,11 @@ public:
     size_t max_audio_out() const { return d_ah ? qrl_amod_out_cap(d_ah, d_max) : 0; }
     size_t samples_per_audio_sample() const { return d_ah ? qrl_amod_samples_per_sample(d_ah) : 0; }   // 125 x device rate / 1e6
     bool analog() const { return d_ah != nullptr; }
+    // CW600USB (gr_mod_base.cpp:144,180,679-683): the SSB chain fed by the key's tone source; work() produces what cw_samples_per_call() samples of the
+    // source give (the reference's source free-runs, paced by the device sink).  set_cw_k = gr_mod_base::set_cw_k (:948-956); the key is kept across mode changes.
+    void set_cw_k(bool value);
+    void set_cw_samples_per_call(size_t n) { d_cw_n = std::min(n, d_max); }
+    size_t cw_samples_per_call() const { return d_cw_n; }
     void set_ctcss(float value);                               // gr_mod_base::set_ctcss (:872-877): both NBFM instances, kept across mode changes
     void set_filter_width(int filter_width, int mode);         // gr_mod_base::set_filter_width (:878-905): the instance of `mode`, kept across mode changes
 
@@ -160,6 +165,7 @@ private:
     int d_n, d_rate, d_mode = -1; double d_offset; size_t d_max; float d_gain = 1.0f;
     qrl_mod* d_h = nullptr; uint8_t* d_bytes = nullptr; float* d_iq = nullptr;
     qrl_amod* d_ah = nullptr; float* d_audio = nullptr; float d_ctcss = 0.0f; bool d_ctcss_touched = false; std::map<int, int> d_width;
+    bool d_cw_key = false; size_t d_cw_n = 1024;
     size_t d_spblock = 0, d_bpb = 1;
     std::mutex d_mutex;
     std::vector<std::vector<uint8_t>> d_queue;

@@ -61,6 +61,37 @@ int main(int argc, char** argv)
             return 0;
         } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
     }
+    if (argc == 4 && !strcmp(argv[1], "cw")) {
+        // test_modem cw <streams> <iq prefix>: the CW branch of the TX facade: key up for 3 calls of 1024 tone samples, down for 4 (the key set in another
+        // mode: kept), up again for 3
+        const int N = atoi(argv[2]);
+        try {
+            qrl_runtime rt(0);
+            gr_mod_base_hip mod(rt, N, 1000000, 0.0, 4096);
+            mod.set_mode(QRL_MODEM_CW600USB);
+            mod.set_cw_samples_per_call(1024);
+            std::vector<std::vector<gr_complex>> iq(N), buf(N, std::vector<gr_complex>(mod.max_audio_out()));
+            std::vector<gr_complex*> ptr(N);
+            for (int s = 0; s < N; ++s) ptr[s] = buf[s].data();
+            auto run = [&](int calls) {
+                for (int c = 0; c < calls; ++c) {
+                    const size_t got = mod.work(ptr.data());
+                    for (int s = 0; s < N; ++s) iq[s].insert(iq[s].end(), buf[s].begin(), buf[s].begin() + got);
+                }
+            };
+            run(3);
+            mod.set_cw_k(true);
+            run(4);
+            mod.set_cw_k(false);
+            run(3);
+            for (int s = 0; s < N; ++s) {
+                std::ofstream o(std::string(argv[3]) + std::to_string(s) + ".bin", std::ios::binary);
+                o.write(reinterpret_cast<const char*>(iq[s].data()), (std::streamsize)(iq[s].size() * sizeof(gr_complex)));
+            }
+            std::printf("cw ok\n");
+            return 0;
+        } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+    }
     if ((argc == 8 || argc == 10) && !strcmp(argv[1], "analogtx")) {
         // test_modem analogtx <modem_type> <streams> <audio.bin: [streams][n] f32> <iq prefix> <set_filter_width value or 0> <ctcss tone or 0> [<device rate> <offset Hz>]:
         // the TX facade's analogue path -- set_mode, the setters (before AND, for the width, once more after a detour through another mode: the

@@ -780,6 +780,12 @@ def mod_nbfm(audio, sps=20, samp_rate=1000000, filter_width=5000, bb_gain=1.0, c
     return y[:m]
 
 
+def sig_source_sin(fs, freq, ampl, n, k0=0, offset=0.0):
+    out = np.zeros(n, np.float32)
+    lib.orc_sig_source_sin(C.c_double(fs), C.c_double(freq), C.c_double(ampl), C.c_float(offset), C.c_uint64(k0), C.c_size_t(n), _ptr(out))
+    return out
+
+
 def sig_source_cos(fs, freq, ampl, n, k0=0):
     out = np.zeros(n, np.float32)
     lib.orc_sig_source_cos(C.c_double(fs), C.c_double(freq), C.c_double(ampl), C.c_uint64(k0), C.c_size_t(n), _ptr(out))

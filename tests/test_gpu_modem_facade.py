@@ -343,3 +343,23 @@ def test_facade_tx_analog_set_audio(tmp_path, mode, kind, fw, w, tone, rate, off
             want = orc.tx_interp(orc.rotator(want, orc.phase_inc_to_turn(2 * np.pi * offset / 1000000.0)), rate)
         assert got.size == want.size and got.size > 0
         assert np.array_equal((got.view(np.float32) + np.float32(0)).view(np.uint32), (want.view(np.float32) + np.float32(0)).view(np.uint32))
+
+
+def test_facade_tx_cw_key(tmp_path):
+    """gr_mod_base::set_cw_k on the TX facade in CW600USB mode (src/gr/gr_mod_base.cpp:144,180,679-683,948-956): 3 calls key up, 4 down, 3 up of 1024 tone
+    samples each -- the IQ equals the oracle's SSB chain over the keyed tone source"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import orc
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qradiolink_amd", "csrc"), "adaptor"])
+    r = subprocess.run([EXE, "cw", "2", str(tmp_path / "iq")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    tone = np.concatenate([orc.sig_source_sin(8000, 600, 0.001, 3072, k0=0, offset=1.0), orc.sig_source_sin(8000, 600, 0.98, 4096, k0=3072, offset=1.0),
+                           orc.sig_source_sin(8000, 600, 0.001, 3072, k0=7168, offset=1.0)])
+    want = orc.mod_ssb(tone, sb=0, filter_width=1000)
+    for s in range(2):
+        got = np.fromfile(tmp_path / ("iq%d.bin" % s), np.complex64)
+        assert got.size == want.size == 125 * 9 * 1024
+        assert np.array_equal((got.view(np.float32) + np.float32(0)).view(np.uint32), (want.view(np.float32) + np.float32(0)).view(np.uint32))

@@ -638,3 +638,45 @@ def test_analog_modulator_back_end_bit_exact(qrl_ctx, modem, kind, rate, offset)
     with pytest.raises(q.QrlError):
         m1.set_carrier_offset(1000.0)                                    # created without the back end
     m1.close()
+
+
+# ---- CW600USB: the SSB chain fed by the key's tone source (gr_mod_base.cpp:144,180,679-683,948-956)
+def _cw_reference(segments, set_width=0):
+    """segments: [(n samples, key down)] -> the oracle's gr_mod_ssb(125, 1e6, ., 1000, 0) over sig_source_f(8000, GR_SIN_WAVE, 600, 0.001 | 0.98, 1)"""
+    tone, k0 = [], 0
+    for n, down in segments:
+        tone.append(orc.sig_source_sin(8000, 600, 0.98 if down else 0.001, n, k0=k0, offset=1.0))
+        k0 += n
+    return orc.mod_ssb(np.concatenate(tone), sb=0, filter_width=1000, set_width=set_width)
+
+
+def test_cw_modulator_bit_exact(qrl_ctx):
+    """qrl_amod QRL_MODEM_CW600USB + qrl_amod_set_cw_k against the oracle: keyed in the middle of the stream (the amplitude changes with the next call, the
+    tone's phase runs on), ragged calls; then the same through qrl_amod_set_filter_width(800)"""
+    import qradiolink_amd as q
+    segs = [(1500, False), (2500, True), (1024, True), (3000, False), (168, True)]
+    for width in (0, 800):
+        mod = q.AMod(qrl_ctx, q.MODEM_CW600USB, batch=2, max_samples=3000)
+        if width:
+            mod.set_filter_width(width)
+        parts = []
+        for n, down in segs:
+            mod.set_cw_k(down)
+            parts.append(mod.process_cw(n).cpu().numpy())
+        got = np.concatenate(parts, axis=1)
+        want = _cw_reference(segs, set_width=width)
+        assert got.shape[1] == want.size == 125 * 1024 * ((sum(n for n, _ in segs) - 2) // 1024)
+        for b in range(2):
+            assert np.array_equal((got[b].view(np.float32) + np.float32(0)).view(np.uint32), (want.view(np.float32) + np.float32(0)).view(np.uint32)), (width, b)
+        mod.close()
+    # key down: a carrier 600 Hz above the suppressed carrier (the cessb stretcher holds a full-scale tone at ~ 0.09); key up: the 0.001 tone at the chain's
+    # small-signal gain 0.42, > 40 dB below
+    x = _cw_reference([(8192, True)])
+    y = _cw_reference([(8192, False)])
+    assert 0.05 < np.abs(x[400000:800000]).mean() < 0.2 and np.abs(y[400000:800000]).mean() < 1e-3
+    spec = np.abs(np.fft.fft(x[400000:800000] * np.hanning(400000)))
+    assert abs(np.fft.fftfreq(400000, 1e-6)[np.argmax(spec)] - 600.0) < 5.0
+    m = q.AMod(qrl_ctx, q.MODEM_USB2500, batch=1, max_samples=2048)
+    with pytest.raises(q.QrlError):
+        m.set_cw_k(True)
+    m.close()

@@ -65,3 +65,29 @@ def test_ctcss_guard_tones_known_answers():
     assert guards(67.0) == (np.float32(np.float64(np.float32(67.0)) * 0.98), np.float32(71.9))
     for f in (81.5, 87.4):
         assert guards(f) == (np.float32(np.float64(np.float32(f)) * 0.98), np.float32(np.float64(np.float32(f)) * 1.02))
+
+
+def test_sig_source_sin_with_offset_and_the_cw_branch_of_the_reference():
+    """the CW key's tone source: sig_source_f(8000, GR_SIN_WAVE, 600, 0.001, 1) into gr_mod_ssb(125, 1000000, 1700, 1000, 0); set_cw_k switches the amplitude
+    between 0.98 and 0.001 (src/gr/gr_mod_base.cpp:144,180,679-683,948-956 -- checked against the source text where the reference is present)"""
+    import os
+    for amp in (0.98, 0.001):
+        y = orc.sig_source_sin(8000, 600, amp, 16000, offset=1.0)
+        inc = orc.lib.orc_fxpt_phase_inc(C.c_double(8000.0), C.c_double(600.0))
+        k = np.arange(y.size, dtype=np.float64)
+        ref = amp * np.sin(2 * np.pi * ((k * inc) % 2 ** 32) / 2 ** 32) + 1.0
+        assert np.max(np.abs(y - ref)) < 3e-6 + 2e-7
+    a = orc.sig_source_sin(8000, 600, 0.98, 5000, offset=1.0)
+    b = orc.sig_source_sin(8000, 600, 0.98, 3000, k0=2000, offset=1.0)
+    assert np.array_equal(a[2000:], b) and a[0] == 1.0
+    # the quarter turn between the two waveforms of the source
+    c = orc.sig_source_cos(8000, 1000, 1.0, 64)
+    s = orc.sig_source_sin(8000, 1000, 1.0, 64, k0=2)                  # 1000 Hz at 8 ksps: two samples = a quarter turn
+    assert np.max(np.abs(c[:62] - s[:62])) < 1e-5
+    src = "/root/reference/src/gr/gr_mod_base.cpp"
+    if os.path.exists(src):
+        text = open(src).read().replace(" ", "").replace("\n", "")
+        assert "_signal_source=gr::analog::sig_source_f::make(8000,gr::analog::GR_SIN_WAVE,600,0.001,1);" in text
+        assert "_usb_cw=make_gr_mod_ssb(125,1000000,1700,1000,0);" in text
+        assert "_top_block->connect(_signal_source,0,_usb_cw,0);_top_block->connect(_usb_cw,0,_rotator,0);" in text
+        assert "if(value)a=0.98;elsea=0.001;_signal_source->set_amplitude(a);" in text
