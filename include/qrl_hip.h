@@ -76,6 +76,14 @@ typedef struct {
     size_t max_chunk;        /* largest n (samples per stream) of any process call */
     void* hip_stream;        /* hipStream_t to run on, NULL = the library creates one */
     int enable_side_outputs; /* 1: also produce port 0 (filtered) and port 1 (constellation) */
+    /* the time-domain scope tap's resampler (qrl_demod_set_time_domain_output), 0 = the constructor's 1:10 with low_pass(1, 1e6, 50000, 25000, HAMMING):
+     * time_domain_samp_rate replaces gr_demod_base::set_time_sink_samp_rate(samp_rate) (src/gr/gr_demod_base.cpp:1249-1290): decimation 1e6 / samp_rate
+     * (integer), taps low_pass(1, 1e6, samp_rate / 2 - samp_rate / 8, samp_rate / 4, HAMMING) (integer divisions as in the reference);
+     * time_domain_filter_width > 0 replaces gr_demod_base::set_time_domain_filter_width(width) (:1292-1301) called after it: taps low_pass(1, 1e6, width, width,
+     * HAMMING), same decimation.  Create-time values: the history a handle keeps depends on the filter (the host facade re-opens its handle, the reference
+     * re-creates the block under lock()). */
+    int time_domain_samp_rate;
+    double time_domain_filter_width;
 } qrl_demod_config;
 
 /* per-call outputs, all caller-allocated DEVICE buffers laid out [batch][cap];

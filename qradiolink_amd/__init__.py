@@ -38,7 +38,7 @@ class _Config(C.Structure):
     _fields_ = [("modem_type", C.c_int), ("use_mode_defaults", C.c_int), ("sps", C.c_int), ("samp_rate", C.c_int),
                 ("carrier_freq", C.c_int), ("filter_width", C.c_int), ("fm", C.c_int), ("device_samp_rate", C.c_int),
                 ("carrier_offset_hz", C.c_double), ("batch", C.c_int), ("max_chunk", C.c_size_t),
-                ("hip_stream", C.c_void_p), ("enable_side_outputs", C.c_int)]
+                ("hip_stream", C.c_void_p), ("enable_side_outputs", C.c_int), ("time_domain_samp_rate", C.c_int), ("time_domain_filter_width", C.c_double)]
 
 
 class _ModConfig(C.Structure):
@@ -310,7 +310,7 @@ class Demod:
     (gr_demod_2fsk.cpp:19-37)."""
 
     def __init__(self, ctx, modem_type, batch, max_chunk, device_samp_rate=1000000, carrier_offset_hz=0.0,
-                 side_outputs=True, stream=None, **explicit):
+                 side_outputs=True, stream=None, time_domain_samp_rate=0, time_domain_filter_width=0.0, **explicit):
         import torch
         self.torch = torch
         self.ctx, self.lib = ctx, ctx.lib
@@ -329,6 +329,8 @@ class Demod:
         cfg.max_chunk = max_chunk
         cfg.hip_stream = stream
         cfg.enable_side_outputs = int(side_outputs)
+        cfg.time_domain_samp_rate = time_domain_samp_rate       # gr_demod_base::set_time_sink_samp_rate / set_time_domain_filter_width (0: the constructor's 1:10)
+        cfg.time_domain_filter_width = time_domain_filter_width
         self.batch, self.max_chunk, self.side = batch, max_chunk, side_outputs
         self.h = C.c_void_p()
         _check(self.lib.qrl_demod_create(ctx.h, C.byref(cfg), C.byref(self.h)), "qrl_demod_create")

@@ -202,7 +202,7 @@ struct qrl_demod {
     DecimStage first;   // per-mode _resampler when interp == 1
     // time-domain scope tap (gr_demod_base.cpp:62-63, 1115-1147, 988-1018): _demod_valve -> rational_resampler_ccf(1, 10, low_pass(1, 1e6,
     // 50000, 25000, HAMMING)) -> gr_sample_sink; off until qrl_demod_set_time_domain_output gives it a buffer
-    DecimStage scope; DevBuf<float2> s_scope; uint32_t scope_mask = 0; uint64_t n_scope = 0;
+    DecimStage scope; DevBuf<float2> s_scope; uint32_t scope_mask = 0; uint64_t n_scope = 0; int scope_D = 10;
     float2* scope_out = nullptr; size_t scope_cap = 0; uint32_t* scope_counts = nullptr;
     DevBuf<float> rs_taps; int rs_Jp = 0;  // per-mode _resampler when interp > 1
     DevBuf<float> filt_taps; int filt_nt = 0;
@@ -442,7 +442,17 @@ int qrl_demod::build()
     }
     const uint32_t first_look = interp == 1 ? std::max<uint32_t>(first.lookback(), d2f ? dec2_fir_lookback() : 0u) : 0u;
     // --- the scope tap's 1:10 decimator on the 1 Msps signal (planned here so that the history below covers it; its ring is allocated on first use)
-    if ((r = scope.plan(low_pass(1, 1000000, 50000, 25000, WIN_HAMMING), 10))) return fail(r, "scope plan");
+    {
+        const int sr = cfg.time_domain_samp_rate;
+        if (sr < 0 || sr > 500000 || cfg.time_domain_filter_width < 0 || cfg.time_domain_filter_width > 500000) return fail(QRL_ERR_ARG, "time_domain_samp_rate / filter_width out of range");
+        scope_D = sr > 0 ? 1000000 / sr : 10;
+        if (sr > 0 && sr / 2 - sr / 8 <= 0) return fail(QRL_ERR_ARG, "time_domain_samp_rate too small");
+        const std::vector<float> h = cfg.time_domain_filter_width > 0 ? low_pass(1, 1000000, cfg.time_domain_filter_width, cfg.time_domain_filter_width, WIN_HAMMING)   // gr_demod_base.cpp:1292-1301
+                                   : sr > 0 ? low_pass(1, 1000000, sr / 2 - sr / 8, sr / 4, WIN_HAMMING)                                                                  // :1249-1290
+                                            : low_pass(1, 1000000, 50000, 25000, WIN_HAMMING);                                                                            // :62-63
+        if (h.size() > 4096) return fail(QRL_ERR_ARG, "time-domain filter too long (> 4096 taps)");
+        if ((r = scope.plan(h, scope_D))) return fail(r, "scope plan");
+    }
     if (!fe.used && (r = scope.alloc_edge(cfg.batch))) return fail(r, "scope edge scratch");
     // --- history of the caller's IQ kept by whichever stage reads it
     if (fe.used) hist_len = fe.lookback();
@@ -755,7 +765,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
     if (profiling && !fe.used) { HIPCHK(hipEventRecord(ev1, stream)); prof_events.emplace_back(ev0, ev1); }
     // ---- time-domain scope tap: the 1 Msps signal behind the front end (the caller's rotated IQ when the device runs at 1 Msps) -> 1:10
     if (scope_out) {
-        const uint64_t ns_1 = decim_count(src1, 1, 10);
+        const uint64_t ns_1 = decim_count(src1, 1, scope_D);
         DecimParams p{};
         if (fe.used) { p.in = nullptr; p.in_ring = r1; }
         else { p.in = in; p.in_stride = stride; p.hist = hist_old; p.hist_len = hist_len;
@@ -1306,7 +1316,7 @@ int qrl_demod_time_domain_cap(const qrl_demod* d, size_t n, size_t* cap)
 {
     if (!d || !cap) return QRL_ERR_ARG;
     const size_t n1 = d->fe.used ? n / d->fe_decim + 2 : n;
-    *cap = n1 / 10 + 2;
+    *cap = n1 / (size_t)d->scope_D + 2;
     return QRL_OK;
 }
 int qrl_demod_set_time_domain_output(qrl_demod* d, float* samples, size_t cap, uint32_t* counts)
@@ -1317,12 +1327,12 @@ int qrl_demod_set_time_domain_output(qrl_demod* d, float* samples, size_t cap, u
     if (samples && !d->s_scope.p) {   // first use: the ring of the 100 ksps scope signal (one call + the stages' block granularity)
         if (int rs = d->sync_all()) return rs;
         const size_t max1 = d->fe.used ? d->cfg.max_chunk / d->fe_decim + 2 : d->cfg.max_chunk;
-        d->scope_mask = pow2_at_least(max1 / 10 + 256) - 1;
+        d->scope_mask = pow2_at_least(max1 / (size_t)d->scope_D + 256) - 1;
         if (int r = d->s_scope.alloc((size_t)d->cfg.batch * (d->scope_mask + 1))) return qrl_set_error(r, "scope ring");
         // the tap starts with the samples of the next call: outputs are indexed from the stream's 1 Msps position
-        d->n_scope = decim_count(d->fe.used ? d->n1 : d->n_in, 1, 10);
+        d->n_scope = decim_count(d->fe.used ? d->n1 : d->n_in, 1, d->scope_D);
     }
-    if (samples && !d->scope_out) d->n_scope = decim_count(d->fe.used ? d->n1 : d->n_in, 1, 10);   // (re-)enabled: skip what was not tapped
+    if (samples && !d->scope_out) d->n_scope = decim_count(d->fe.used ? d->n1 : d->n_in, 1, d->scope_D);   // (re-)enabled: skip what was not tapped
     d->scope_out = reinterpret_cast<float2*>(samples); d->scope_cap = cap; d->scope_counts = counts;
     return QRL_OK;
 }

@@ -134,6 +134,7 @@ void gr_demod_base_hip::open()
     qrl_demod_config c{};
     c.modem_type = d_mode; c.use_mode_defaults = 1; c.device_samp_rate = d_rate; c.carrier_offset_hz = d_offset;
     c.batch = d_n; c.max_chunk = d_chunk; c.enable_side_outputs = 1;
+    c.time_domain_samp_rate = d_scope_rate; c.time_domain_filter_width = d_scope_fw;
     chk(qrl_demod_create(d_rt.ctx(), &c, &d_h), "qrl_demod_create");
     chk(qrl_demod_out_caps(d_h, d_chunk, &d_fcap, &d_ccap, &d_bcap), "qrl_demod_out_caps");
     chk(qrl_demod_audio_cap(d_h, d_chunk, &d_acap), "qrl_demod_audio_cap");
@@ -441,6 +442,19 @@ void gr_demod_base_hip::enable_time_domain(bool value)   // gr_demod_base.cpp:11
 {
     std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     d_scope_on = value;
+}
+void gr_demod_base_hip::set_time_sink_samp_rate(int samp_rate)   // gr_demod_base.cpp:1249-1290: a new resampler (decimation 1e6 / samp_rate, its own low-pass) under lock()
+{
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
+    if ((unsigned)samp_rate > 1000000u) return;   // :1251-1252
+    d_scope_rate = samp_rate; d_scope_fw = 0.0;
+    if (d_mode >= 0) { flush(); open(); std::lock_guard<std::mutex> g(d_mutex); for (auto& b : d_boxs) b.clear(); }   // the handle keeps history for the filter it was created with
+}
+void gr_demod_base_hip::set_time_domain_filter_width(double filter_width)   // :1292-1301: set_taps(low_pass(1, 1e6, width, width, HAMMING)) on the current resampler
+{
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
+    d_scope_fw = filter_width;
+    if (d_mode >= 0) { flush(); open(); std::lock_guard<std::mutex> g(d_mutex); for (auto& b : d_boxs) b.clear(); }
 }
 void gr_demod_base_hip::set_sample_window(unsigned int size)   // gr_sample_sink::set_sample_window (:35-41): odd sizes go up by one
 {

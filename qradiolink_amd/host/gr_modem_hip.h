@@ -89,6 +89,10 @@ public:
     // 1115-1147) with gr_sample_sink's mailbox rules (src/gr/gr_sample_sink.cpp:28-89): window 8096 items (made even), nothing is
     // taken while more than 524288 items wait, get_data hands out min(waiting, window) items (an even count) or nothing below 2
     void enable_time_domain(bool value);
+    // gr_demod_base::set_time_sink_samp_rate / set_time_domain_filter_width (:1249-1301): the scope tap's decimation and low-pass.  The device handle is
+    // re-created with the new filter (qrl_demod_config.time_domain_*): the demodulator restarts, like the reference's graph under lock() / unlock().
+    void set_time_sink_samp_rate(int samp_rate);
+    void set_time_domain_filter_width(double filter_width);
     void set_sample_window(unsigned int size);
     void get_sample_data(float* sample_data, unsigned int& size, int stream = 0);   // reals, then imaginaries from index n + 1 on, size = 2 n (:1001-1010)
     void set_fft_size(int size);
@@ -107,6 +111,7 @@ private:
     qrl_demod* d_h = nullptr;
     qrl_rssi* d_rssi = nullptr; qrl_fft* d_fft = nullptr; bool d_rssi_on = false, d_fft_on = false; float d_rssi_cal = 0.0f; unsigned d_fftsize = 32768;
     float d_ctcss = 0.0f; bool d_const_on = true, d_demod_on = true;
+    int d_scope_rate = 0; double d_scope_fw = 0.0;   // set_time_sink_samp_rate / set_time_domain_filter_width (0: the constructor's 1:10)
     bool d_scope_on = false; size_t d_scap = 0; unsigned d_window = 8096; std::vector<std::vector<gr_complex>> d_boxs;   // scope tap mailboxes
     qrl_framesync* d_fs[2] = {nullptr, nullptr}; bool d_want_fs = false, d_keep_bits = false; size_t d_frcap = 0;   // device frame synchronisers of bits A / B
     std::vector<std::vector<frame_record>> d_boxf[2];

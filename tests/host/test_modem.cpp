@@ -61,6 +61,47 @@ int main(int argc, char** argv)
             return 0;
         } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
     }
+    if (argc == 6 && !strcmp(argv[1], "scoperate")) {
+        // test_modem scoperate <iq.bin: [1][n] cf32 at 1 Msps> <out.bin> <time sink samp rate or 0> <time domain filter width or 0>: the facade's scope tap after
+        // set_time_sink_samp_rate / set_time_domain_filter_width, drained through get_sample_data; the complex items go to out.bin
+        try {
+            qrl_runtime rt(0);
+            gr_demod_base_hip demod(rt, 1, 1000000, 0.0, 1 << 16);
+            demod.set_mode(QRL_MODEM_2FSK1K);
+            demod.enable_time_domain(true);
+            demod.set_sample_window(8096);
+            if (atoi(argv[4])) demod.set_time_sink_samp_rate(atoi(argv[4]));
+            if (atof(argv[5]) > 0) demod.set_time_domain_filter_width(atof(argv[5]));
+            demod.set_time_sink_samp_rate(2000000);   // > 1 Msps: ignored (gr_demod_base.cpp:1251-1252)
+            std::ifstream f(argv[2], std::ios::binary);
+            std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+            const size_t n = raw.size() / sizeof(gr_complex);
+            const gr_complex* x = reinterpret_cast<const gr_complex*>(raw.data());
+            std::vector<gr_complex> items;
+            std::vector<float> buf(2 * 8096 + 2);
+            auto drain = [&]() {
+                for (;;) {
+                    unsigned ns = 0;
+                    demod.get_sample_data(buf.data(), ns, 0);
+                    if (!ns) break;
+                    for (unsigned i = 0; i < ns / 2; ++i) items.emplace_back(buf[i], buf[ns / 2 + i + 1]);   // reals, then imaginaries from index n + 1 on
+                }
+            };
+            for (size_t pos = 0; pos < n; pos += 50000) {
+                const size_t take = std::min<size_t>(n - pos, 50000) & ~(size_t)1;
+                if (!take) break;
+                const gr_complex* ptr = x + pos;
+                demod.work(&ptr, take);
+                drain();
+            }
+            demod.flush();
+            drain();
+            std::ofstream o(argv[3], std::ios::binary);
+            o.write(reinterpret_cast<const char*>(items.data()), (std::streamsize)(items.size() * sizeof(gr_complex)));
+            std::printf("scoperate ok: %zu items\n", items.size());
+            return 0;
+        } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+    }
     if (argc == 4 && !strcmp(argv[1], "cw")) {
         // test_modem cw <streams> <iq prefix>: the CW branch of the TX facade: key up for 3 calls of 1024 tone samples, down for 4 (the key set in another
         // mode: kept), up again for 3

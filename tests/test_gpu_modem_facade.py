@@ -363,3 +363,28 @@ def test_facade_tx_cw_key(tmp_path):
         got = np.fromfile(tmp_path / ("iq%d.bin" % s), np.complex64)
         assert got.size == want.size == 125 * 9 * 1024
         assert np.array_equal((got.view(np.float32) + np.float32(0)).view(np.uint32), (want.view(np.float32) + np.float32(0)).view(np.uint32))
+
+
+@pytest.mark.parametrize("sr,fw", [(50000, 0.0), (0, 30000.0), (200000, 40000.0)])
+def test_facade_scope_rate_and_filter_width(tmp_path, sr, fw):
+    """gr_demod_base::set_time_sink_samp_rate / set_time_domain_filter_width on the facade (src/gr/gr_demod_base.cpp:1249-1301): what get_sample_data hands out
+    equals the oracle's decimator with the reference's design for that setter sequence (a rate above 1 Msps is ignored)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import orc
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qradiolink_amd", "csrc"), "adaptor"])
+    rng = np.random.default_rng(61)
+    n = 400000
+    x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.05 + 0.2 * np.exp(2j * np.pi * 3000.0 * np.arange(n) / 1e6)).astype(np.complex64)
+    (tmp_path / "iq.bin").write_bytes(x.tobytes())
+    r = subprocess.run([EXE, "scoperate", str(tmp_path / "iq.bin"), str(tmp_path / "s.bin"), str(sr), str(fw)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(tmp_path / "s.bin", np.complex64)
+    D = 1000000 // sr if sr else 10
+    taps = orc.low_pass(1, 1000000, fw, fw) if fw > 0 else orc.low_pass(1, 1000000, sr // 2 - sr // 8, sr // 4)
+    want = orc.decim_auto(orc.frontend(x, 1000000, 0.0), taps, D)
+    # the sink hands out even counts; at most one item stays behind
+    assert want.size - 1 <= got.size <= want.size and got.size > 1000
+    assert np.array_equal((got.view(np.float32) + np.float32(0)).view(np.uint32), (want[:got.size].view(np.float32) + np.float32(0)).view(np.uint32))

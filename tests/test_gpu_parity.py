@@ -140,6 +140,44 @@ def test_time_domain_scope_tap_bit_exact(qrl_ctx, mode_name, modem, rate, chunk)
         assert np.array_equal(np.concatenate(bits[b]), _oracle(mode_name, iq[b, :used], rate, offset)["bits_a"])
 
 
+@pytest.mark.parametrize("rate,sr,fw", [(1000000, 50000, 0.0), (1000000, 200000, 0.0), (1000000, 0, 30000.0), (4000000, 50000, 10000.0), (1000000, 8000, 0.0)])
+def test_time_domain_scope_tap_rate_and_filter_width(qrl_ctx, rate, sr, fw):
+    """gr_demod_base::set_time_sink_samp_rate / set_time_domain_filter_width (src/gr/gr_demod_base.cpp:1249-1301) as qrl_demod_config.time_domain_samp_rate /
+    time_domain_filter_width: decimation 1e6 / samp_rate with low_pass(1, 1e6, sr / 2 - sr / 8, sr / 4, HAMMING) (integer divisions), or low_pass(1, 1e6, w, w,
+    HAMMING) after set_time_domain_filter_width -- bit-exact against the oracle's decimator on the oracle's 1 Msps front-end signal, cut into calls"""
+    import torch
+    import qradiolink_amd as q
+    offset = 25000.0 if rate >= 2000000 else 1200.0
+    iq = sig.make_batch("2fsk1k", 2, nframes=1, device_rate=rate, rx_offset_hz=offset, seed=43)
+    n = iq.shape[1] & ~1
+    chunk = 100002
+    dem = q.Demod(qrl_ctx, 18, batch=2, max_chunk=chunk, device_samp_rate=rate, carrier_offset_hz=offset, time_domain_samp_rate=sr, time_domain_filter_width=fw)
+    dem.enable_time_domain()
+    d = torch.from_numpy(iq).cuda()
+    parts = [[], []]
+    used = 0
+    for s0 in range(0, n, chunk):
+        part = d[:, s0:min(s0 + chunk, n)]
+        if part.shape[1] & 1:
+            part = part[:, :-1]
+        used += part.shape[1]
+        dem.process(part.contiguous())
+        cnt, sc = dem.scope_counts.cpu().numpy(), dem.scope.cpu().numpy()
+        for b in range(2):
+            parts[b].append(sc[b, :cnt[b]].copy())
+    dem.close()
+    D = 1000000 // sr if sr else 10
+    taps = orc.low_pass(1, 1000000, fw, fw) if fw > 0 else orc.low_pass(1, 1000000, sr // 2 - sr // 8, sr // 4) if sr else orc.low_pass(1, 1000000, 50000, 25000)
+    for b in range(2):
+        fe = orc.frontend(iq[b, :used], rate, offset)
+        want = orc.decim_auto(fe, taps, D).view(np.float32) + np.float32(0)
+        got = np.concatenate(parts[b]).view(np.float32) + np.float32(0)
+        assert got.size == want.size and got.size > 100, (got.size, want.size)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "stream %d" % b
+    with pytest.raises(q.QrlError):
+        q.Demod(qrl_ctx, 18, batch=1, max_chunk=1000, time_domain_samp_rate=600000)
+
+
 def _nbfm_with_tone(n, seed, tone, fs=1000000.0, gap=None):
     """NBFM carrier whose audio is a voice-band tone plus a sub-audible CTCSS tone (deviation ~ 15 %)"""
     rng = np.random.default_rng(seed)

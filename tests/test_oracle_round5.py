@@ -91,3 +91,22 @@ def test_sig_source_sin_with_offset_and_the_cw_branch_of_the_reference():
         assert "_usb_cw=make_gr_mod_ssb(125,1000000,1700,1000,0);" in text
         assert "_top_block->connect(_signal_source,0,_usb_cw,0);_top_block->connect(_usb_cw,0,_rotator,0);" in text
         assert "if(value)a=0.98;elsea=0.001;_signal_source->set_amplitude(a);" in text
+
+
+def test_scope_tap_setters_of_the_reference_source_text():
+    """what qrl_demod_config.time_domain_samp_rate / time_domain_filter_width restate (src/gr/gr_demod_base.cpp:1249-1301), checked against the source text where
+    the reference is present: integer decimation 1e6 / samp_rate, low_pass(1, 1e6, samp_rate/2 - samp_rate/8, samp_rate/4, HAMMING), and the width setter's
+    low_pass(1, 1e6, width, width, HAMMING); rates above 1 Msps are ignored"""
+    import os
+    src = "/root/reference/src/gr/gr_demod_base.cpp"
+    if not os.path.exists(src):
+        return
+    text = open(src).read().replace(" ", "").replace("\n", "")
+    assert "if((uint)samp_rate>INTERNAL_DEFAULT_SAMPLE_RATE)return;" in text
+    assert "intdecimation=INTERNAL_DEFAULT_SAMPLE_RATE/samp_rate;" in text
+    assert "firdes::low_pass(1,INTERNAL_DEFAULT_SAMPLE_RATE,samp_rate/2-samp_rate/8,samp_rate/4,gr::fft::window::WIN_HAMMING);" in text
+    assert "_resampler_time_domain=gr::filter::rational_resampler_ccf::make(1,decimation,taps);" in text
+    assert "firdes::low_pass(1,INTERNAL_DEFAULT_SAMPLE_RATE,filter_width,filter_width,gr::fft::window::WIN_HAMMING);_resampler_time_domain->set_taps(taps);" in text
+    # the integer divisions matter: 50 ksps -> cutoff 18750, transition 12500
+    t = orc.low_pass(1, 1000000, 50000 // 2 - 50000 // 8, 50000 // 4)
+    assert t.size % 2 == 1 and abs(float(t.sum()) - 1.0) < 1e-5
