@@ -516,7 +516,7 @@ std::vector<std::vector<unsigned char>> gr_demod_base_hip::getDMRData(int stream
 
 // ================================================================================================ gr_mod_base_hip
 gr_mod_base_hip::gr_mod_base_hip(qrl_runtime& rt, int streams, int device_samp_rate, double carrier_offset_hz, size_t max_bytes)
-    : d_rt(rt), d_n(streams), d_rate(device_samp_rate), d_offset(carrier_offset_hz), d_max(max_bytes), d_queue(streams), d_aqueue(streams)
+    : d_rt(rt), d_n(streams), d_rate(device_samp_rate), d_offset(carrier_offset_hz), d_max(max_bytes), d_queue(streams), d_aqueue(streams), d_sent(streams, 0)
 {
 }
 gr_mod_base_hip::~gr_mod_base_hip()
@@ -567,6 +567,27 @@ void gr_mod_base_hip::set_mode(int mode)   // gr_mod_base::set_mode (src/gr/gr_m
     std::lock_guard<std::mutex> g(d_mutex);
     for (auto& q : d_queue) q.clear();
     for (auto& q : d_aqueue) q.clear();
+    for (auto& v : d_sent) v = 0;
+}
+int gr_mod_base_hip::setDMRData(const std::vector<std::vector<uint8_t>>& frames, int stream)   // gr_mod_base.cpp:788-791 -> gr_dmr_source.cpp:56-73
+{
+    if (d_mode != QRL_MODEM_DMR || !d_h) throw std::runtime_error("gr_mod_base_hip::setDMRData outside DMR mode");
+    constexpr size_t kZeroBytes = 33 + 2 * 3;            // DMR_ZERO_TX_LENGTH_BYTES = FRAME_LENGTH_BYTES + 2 CACH_LENGTH_BYTES (gr_dmr_source.cpp:24)
+    std::vector<qrl_zero_run> runs;
+    {
+        std::lock_guard<std::mutex> g(d_mutex);
+        for (const auto& f : frames) {
+            auto& q = d_queue[stream];
+            q.insert(q.end(), f.begin(), f.end());
+            const uint64_t first_zero = d_sent[stream] + q.size();   // byte index of the tag (gr_dmr_source.cpp:118-121)
+            q.insert(q.end(), kZeroBytes, (uint8_t)0);
+            qrl_zero_run z{};
+            z.stream = stream; z.channel = 0; z.start = first_zero * 20u; z.count = kZeroBytes * 4u * 5u;   // DMR_ZERO_TX_LENGTH_SAMPLES (:25)
+            runs.push_back(z);
+        }
+    }
+    if (!runs.empty()) chk(qrl_mod_add_zero_runs(d_h, runs.data(), runs.size()), "qrl_mod_add_zero_runs");
+    return 0;
 }
 int gr_mod_base_hip::set_audio(std::vector<float>* data, int stream)   // gr_mod_base.cpp:793-797 -> gr_audio_source::set_data (gr_audio_source.cpp:55-66)
 {
@@ -658,6 +679,7 @@ size_t gr_mod_base_hip::work(gr_complex* const* out)
             const size_t k = std::min(d_queue[s].size(), nb);
             std::memcpy(host.data() + (size_t)s * d_max, d_queue[s].data(), k);
             d_queue[s].erase(d_queue[s].begin(), d_queue[s].begin() + k);
+            d_sent[s] += nb;
         }
     }
     hipStream_t ms = static_cast<hipStream_t>(qrl_mod_stream(d_h));

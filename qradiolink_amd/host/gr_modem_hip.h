@@ -140,6 +140,11 @@ public:
     virtual ~gr_mod_base_hip();
     void set_mode(int mode);
     virtual int set_data(std::vector<uint8_t>* data, int stream = 0);  // takes ownership (gr_byte_source::set_data); 1 = queued (virtual: tests tap the bytes)
+    // gr_mod_base::setDMRData -> gr_dmr_source::set_data (src/gr/gr_mod_base.cpp:788-791, src/gr/gr_dmr_source.cpp:56-73,100-127): every frame (the 33 bytes of
+    // DMRFrame::toByteVector(); the frame classes of src/DMR are protocol code above this layer) is followed by 39 zero bytes, and a "zero_samples" tag of
+    // 39 x 4 x 5 = 780 items sits on the first of them -- here a zero run of the DMR modulator (qrl_mod_add_zero_runs) at 20 items per byte (4 symbols x 5
+    // samples at the zero-idle block's 24 ksps input).  The source's tx_time tags belong to the SDR sink and are not produced.  QRL_MODEM_DMR mode only.
+    int setDMRData(const std::vector<std::vector<uint8_t>>& frames, int stream = 0);
     void set_bb_gain(float value);
     void set_carrier_offset(double hz);
     // one scheduler pass: consumes up to max_bytes queued bytes of every stream (zero padded to the longest) and returns the
@@ -175,6 +180,7 @@ private:
     std::mutex d_mutex;
     std::vector<std::vector<uint8_t>> d_queue;
     std::vector<std::vector<float>> d_aqueue;
+    std::vector<uint64_t> d_sent;   // bytes per stream handed to the modulator since set_mode (with the zero padding of short queues): positions of the zero runs
 };
 
 // the Qt signals of gr_modem that the RX / TX paths emit (src/gr_modem.h:118-139); unset callbacks are skipped.  Buffers are only

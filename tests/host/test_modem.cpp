@@ -61,6 +61,38 @@ int main(int argc, char** argv)
             return 0;
         } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
     }
+    if (argc == 4 && !strcmp(argv[1], "dmrtx")) {
+        // test_modem dmrtx <frames.bin: 5 x 33 bytes> <iq prefix>: gr_mod_base::setDMRData on the TX facade, two radios -- stream 0 sends frames 0..2 (the
+        // third one queued after the first work()), stream 1 frames 3..4
+        try {
+            qrl_runtime rt(0);
+            gr_mod_base_hip mod(rt, 2, 1000000, 0.0, 144);
+            mod.set_mode(QRL_MODEM_DMR);
+            std::ifstream f(argv[2], std::ios::binary);
+            std::vector<uint8_t> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+            if (raw.size() != 5 * 33) throw std::runtime_error("frames.bin: 165 bytes expected");
+            auto fr = [&](int i) { return std::vector<uint8_t>(raw.begin() + 33 * i, raw.begin() + 33 * (i + 1)); };
+            std::vector<std::vector<gr_complex>> iq(2), buf(2, std::vector<gr_complex>(144 / 3 * 2500 + 2500));
+            std::vector<gr_complex*> ptr{buf[0].data(), buf[1].data()};
+            auto run = [&]() {
+                size_t got;
+                while ((got = mod.work(ptr.data())) != 0)
+                    for (int s = 0; s < 2; ++s) iq[s].insert(iq[s].end(), buf[s].begin(), buf[s].begin() + got);
+            };
+            mod.setDMRData({fr(0), fr(1)}, 0);
+            mod.setDMRData({fr(3)}, 1);
+            run();
+            mod.setDMRData({fr(2)}, 0);
+            mod.setDMRData({fr(4)}, 1);
+            run();
+            for (int s = 0; s < 2; ++s) {
+                std::ofstream o(std::string(argv[3]) + std::to_string(s) + ".bin", std::ios::binary);
+                o.write(reinterpret_cast<const char*>(iq[s].data()), (std::streamsize)(iq[s].size() * sizeof(gr_complex)));
+            }
+            std::printf("dmrtx ok\n");
+            return 0;
+        } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+    }
     if (argc == 6 && !strcmp(argv[1], "scoperate")) {
         // test_modem scoperate <iq.bin: [1][n] cf32 at 1 Msps> <out.bin> <time sink samp rate or 0> <time domain filter width or 0>: the facade's scope tap after
         // set_time_sink_samp_rate / set_time_domain_filter_width, drained through get_sample_data; the complex items go to out.bin

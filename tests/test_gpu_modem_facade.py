@@ -388,3 +388,34 @@ def test_facade_scope_rate_and_filter_width(tmp_path, sr, fw):
     # the sink hands out even counts; at most one item stays behind
     assert want.size - 1 <= got.size <= want.size and got.size > 1000
     assert np.array_equal((got.view(np.float32) + np.float32(0)).view(np.uint32), (want[:got.size].view(np.float32) + np.float32(0)).view(np.uint32))
+
+
+def test_facade_tx_setDMRData(tmp_path):
+    """gr_mod_base::setDMRData on the TX facade (src/gr/gr_mod_base.cpp:788-791 -> gr_dmr_source.cpp:56-73,100-127): every 33-byte frame is followed by 39 zero
+    bytes with a "zero_samples" tag of 780 items on the first of them; two radios with different numbers of frames per call (the shorter queue is padded with
+    zero bytes).  The IQ equals the oracle's gr_mod_dmr over the same bytes and tags (20 items of the zero-idle block's input per byte)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import orc
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qradiolink_amd", "csrc"), "adaptor"])
+    frames = np.random.default_rng(71).integers(0, 256, (5, 33), dtype=np.uint8)
+    (tmp_path / "frames.bin").write_bytes(frames.tobytes())
+    r = subprocess.run([EXE, "dmrtx", str(tmp_path / "frames.bin"), str(tmp_path / "iq")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    z = np.zeros(39, np.uint8)
+    # first run: stream 0 sends 144 bytes (two frames), stream 1 one frame + 72 bytes of padding; second run: one frame each
+    s0 = np.concatenate([frames[0], z, frames[1], z, frames[2], z])
+    s1 = np.concatenate([frames[3], z, np.zeros(72, np.uint8), frames[4], z])
+    tags0 = [(20 * 33, 780), (20 * (72 + 33), 780), (20 * (144 + 33), 780)]
+    tags1 = [(20 * 33, 780), (20 * (144 + 33), 780)]
+    for s, (data, tags) in enumerate(((s0, tags0), (s1, tags1))):
+        got = np.fromfile(tmp_path / ("iq%d.bin" % s), np.complex64)
+        want = orc.mod_dmr(data, zero_runs=tags)
+        assert got.size == want.size == 216 // 3 * 2500
+        assert np.array_equal((got.view(np.float32) + np.float32(0)).view(np.uint32), (want.view(np.float32) + np.float32(0)).view(np.uint32)), "stream %d" % s
+    # the tagged stretches are silence: the 39 zero bytes behind a frame (delayed by the block's 1439-item history), not the frame itself
+    w = orc.mod_dmr(s0, zero_runs=tags0)
+    lo, hi = (20 * 33 + 1439 - 62 + 60) * 125 // 3, (20 * 33 + 1439 - 62 + 780 - 60) * 125 // 3
+    assert np.abs(w[lo:hi]).max() < 1e-3
