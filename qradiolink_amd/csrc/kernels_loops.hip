@@ -203,8 +203,8 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
     return v;
 }
 
-template <int SS_NS, int SS_W>
-__global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int batch)
+template <int SS_NS, int SS_W, bool VEC = false, int SS_TH = 256>
+__global__ __launch_bounds__(SS_TH) void k_symsync_ff(const SymSyncParams P, int batch)
 {
     using G = SsGeo<SS_NS, SS_W>;
     constexpr int SS_BACK = G::BACK, SS_COLS = G::COLS, SS_PITCH = G::PITCH, SS_OMAX = G::OMAX, SS_OPITCH = G::OPITCH;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
     const int wv = tid >> 6, lane = tid & 63;
     const int b0 = blockIdx.x * SS_NS;
     const int nstreams = min(SS_NS, batch - b0);
-    for (int k = tid; k < 129 * 8; k += 256) mm[k] = P.mmse[k];
+    for (int k = tid; k < 129 * 8; k += SS_TH) mm[k] = P.mmse[k];
 
     SymSyncState st;
     bool active = false;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
     const long long k_first = kfl[0], k_last = kfl[1];
 
     // loader: window k of all streams -> win[k & 1]
-    auto load_window = [&](long long k, int t, int nthreads) {
+    auto load_window_scalar = [&](long long k, int t, int nthreads) {
         float* wbuf = win + (size_t)(k & 1) * SS_NS * SS_PITCH;
         const long long i0 = k * SS_W - SS_BACK;
         constexpr int BATCH = 12;
@@ -267,6 +267,49 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
             }
         }
     };
+    // the same with four consecutive samples per load (VEC; the multi-carrier receiver's geometry, round 5): the window starts at a multiple of 16 samples and the ring rows are powers of
+    // two, so a group of four never wraps and is 16-byte aligned (a quarter of the load instructions of the scalar form, whose serialised round trips -- not the
+    // bytes -- were what a loader wave spent its time on); groups that touch the stream's start or its end take the checked scalar path.
+    auto load_window_vec = [&](long long k, int t, int nthreads) {
+        float* wbuf = win + (size_t)(k & 1) * SS_NS * SS_PITCH;
+        const long long i0 = k * SS_W - SS_BACK;
+        static_assert(SS_COLS % 4 == 0 && SS_W % 16 == 0 && SS_BACK % 16 == 0, "window geometry: groups of four");
+        constexpr int C4 = SS_COLS / 4;
+        // all of a helper thread's groups in flight at once (one round trip per window instead of several), 16 at most
+        constexpr int PER = (SS_NS * C4 + (SS_TH - 64) - 1) / (SS_TH - 64);
+        constexpr int BATCH = PER < 16 ? PER : 16;
+        const int total = nstreams * C4;
+        for (int base = t; base < total; base += nthreads * BATCH) {
+            float4 v[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int idx = base + u * nthreads;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < total) {
+                    const int s = idx / C4, c = (idx - s * C4) * 4;
+                    const long long i = i0 + c;
+                    const float* row = P.in.p + (size_t)(b0 + s) * (P.in.mask + 1u);
+                    if (i >= 0 && (uint64_t)(i + 3) < P.avail) v[u] = *reinterpret_cast<const float4*>(row + ((uint32_t)i & P.in.mask));
+                    else {
+                        if (i >= 0 && (uint64_t)i < P.avail) v[u].x = row[(uint32_t)i & P.in.mask];
+                        if (i + 1 >= 0 && (uint64_t)(i + 1) < P.avail) v[u].y = row[(uint32_t)(i + 1) & P.in.mask];
+                        if (i + 2 >= 0 && (uint64_t)(i + 2) < P.avail) v[u].z = row[(uint32_t)(i + 2) & P.in.mask];
+                        if (i + 3 >= 0 && (uint64_t)(i + 3) < P.avail) v[u].w = row[(uint32_t)(i + 3) & P.in.mask];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int idx = base + u * nthreads;
+                if (idx < total) {
+                    const int s = idx / C4, c = (idx - s * C4) * 4;
+                    float* w = wbuf + s * SS_PITCH + c;
+                    w[0] = v[u].x; w[1] = v[u].y; w[2] = v[u].z; w[3] = v[u].w;
+                }
+            }
+        }
+    };
+    auto load_window = [&](long long k, int t, int nthreads) { if constexpr (VEC) load_window_vec(k, t, nthreads); else load_window_scalar(k, t, nthreads); };
     // flusher: symbols of window k -> soft-symbol ring (multiply_const -> add_const -> float_to_uchar) and port 1
     auto flush_window = [&](long long k, int t, int nthreads) {
         const int pb = (int)(k & 1);
@@ -316,7 +359,7 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
         }
     };
 
-    if (k_first <= k_last) load_window(k_first, tid, 256);
+    if (k_first <= k_last) load_window(k_first, tid, SS_TH);
     __syncthreads();
     for (long long k = k_first; k <= k_last; ++k) {
         if (wv == 0) {
@@ -368,12 +411,12 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
             if (active) { st.ii = (uint64_t)(i0 + off); st.oo += (uint64_t)nsym; }
             if (lane < SS_NS) { ocnt[pb * 64 + lane] = nsym; obase[pb * 64 + lane] = oo_w; }
         } else {
-            if (k + 1 <= k_last) load_window(k + 1, tid - 64, 192);
-            if (k > k_first) flush_window(k - 1, tid - 64, 192);
+            if (k + 1 <= k_last) load_window(k + 1, tid - 64, SS_TH - 64);
+            if (k > k_first) flush_window(k - 1, tid - 64, SS_TH - 64);
         }
         __syncthreads();
     }
-    if (k_first <= k_last) flush_window(k_last, tid, 256);
+    if (k_first <= k_last) flush_window(k_last, tid, SS_TH);
     if (wv == 0 && active) {
         P.st[b0 + lane] = st;
         P.counts[(b0 + lane) * 4 + 1] = (uint32_t)(st.oo - oo0[lane]);
@@ -383,6 +426,9 @@ __global__ __launch_bounds__(256) void k_symsync_ff(const SymSyncParams P, int b
 
 size_t symsync_lds_bytes() { return SsGeo<32, 192>::lds_bytes(); }
 
+#ifndef QRL_CHAN_SS_TH
+#define QRL_CHAN_SS_TH 256   // threads per workgroup of the multi-carrier receiver's geometry: one recursion wave + (QRL_CHAN_SS_TH / 64 - 1) loader / flusher waves
+#endif
 #ifndef QRL_CHAN_SS_NS
 #define QRL_CHAN_SS_NS 32    // round 5: <32 streams, 96 samples> = 128 workgroups of 45 KB for the 4096 channel streams of C4 instead of 256 of 25 KB: the recursion is as
 #define QRL_CHAN_SS_W 96     // fast alone (1.75 against 1.68 ms) and costs the per-channel kernel beside it less: 2.82 - 2.83 against 2.86 - 2.94 ms per step, four
@@ -390,10 +436,10 @@ size_t symsync_lds_bytes() { return SsGeo<32, 192>::lds_bytes(); }
 void launch_symsync_ff(const SymSyncParams& p, int batch, hipStream_t s)
 {
     if (p.slim == 2 && (QRL_CHAN_SS_NS != 16 || QRL_CHAN_SS_W != 96)) {   // the multi-carrier receiver's own geometry (QRL_CHAN_SS_NS streams per workgroup, QRL_CHAN_SS_W samples per window)
-        const auto k = k_symsync_ff<QRL_CHAN_SS_NS, QRL_CHAN_SS_W>;
+        const auto k = k_symsync_ff<QRL_CHAN_SS_NS, QRL_CHAN_SS_W, true, QRL_CHAN_SS_TH>;
         const size_t lds = SsGeo<QRL_CHAN_SS_NS, QRL_CHAN_SS_W>::lds_bytes();
         if (dyn_lds_limit(reinterpret_cast<const void*>(k), (int)lds) != hipSuccess) return;
-        hipLaunchKernelGGL(k, dim3((batch + QRL_CHAN_SS_NS - 1) / QRL_CHAN_SS_NS), dim3(256), lds, s, p, batch);
+        hipLaunchKernelGGL(k, dim3((batch + QRL_CHAN_SS_NS - 1) / QRL_CHAN_SS_NS), dim3(QRL_CHAN_SS_TH), lds, s, p, batch);
         return;
     }
     if (p.slim) {   // the multi-carrier receiver's geometry (see SsGeo)
