@@ -140,6 +140,15 @@ def complex_band_pass(gain, fs, lo, hi, tw, win=WIN_HAMMING):
     return t
 
 
+def complex_band_pass_2(gain, fs, lo, hi, tw, att, win=WIN_HAMMING):
+    lib.orc_complex_band_pass_2.restype = C.c_int
+    args = (C.c_double(gain), C.c_double(fs), C.c_double(lo), C.c_double(hi), C.c_double(tw), C.c_double(att), win)
+    n = lib.orc_complex_band_pass_2(*args, None)
+    t = np.zeros(n, cf32)
+    lib.orc_complex_band_pass_2(*args, _ptr(t))
+    return t
+
+
 def root_raised_cosine(gain, fs, sr, alpha, ntaps):
     n = lib.orc_root_raised_cosine(gain, fs, sr, alpha, ntaps, None)
     t = np.zeros(n, np.float32)

@@ -34,3 +34,23 @@ def test_arbitrate_ted_self_test():
     assert r[("2fsk1k_1M", 2)] is not None or r[("2fsk1k_1M", 1)] is not None
     assert r[("qpsk250k_1M", 0)] is not None
     assert "first symbol beyond 1e-5" in out.getvalue()
+
+
+def test_stock_blocks_dry_run_and_compare():
+    """tools/gr_golden/stock_blocks.py: the block-level pins of the [GR-MEM] designers and of analog::sig_source_f -- the oracle side of every case runs here, and the
+    comparison reports a one-bit difference where there is one"""
+    import numpy as np
+    m = _load("stock_blocks")
+    out = io.StringIO()
+    res = m.dry_run(out=out)
+    assert len(res) >= 16 and out.getvalue().count("would run:") == len(res)
+    assert res["low_pass_2_dmr_interp"].size == 4091 and res["rrc_dmr"].size == 125 and res["complex_band_pass_am_setter"].dtype == np.complex64
+    a = res["sig_source_sin_600_key_down"]
+    assert m.compare("x", a, a.copy()) is None
+    b = a.copy()
+    b[7] = np.nextafter(b[7], np.float32(2.0))
+    msg = m.compare("x", b, a)
+    assert msg is not None and "1 of 16000 floats differ, first at 7" in msg
+    assert "items from GNU Radio" in m.compare("x", a[:-1], a)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gr_golden", "stock_blocks.py")], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "GNU Radio 3.10 Python modules are required" in (r.stderr + r.stdout)      # this image has no GNU Radio: it says so instead of guessing
