@@ -227,6 +227,7 @@ def timed_loop(fn, sync, args, torch, dev, world, marks=None):
     return dt
 
 
+FRONT_END_FLOP = {"c1": 4.0 * 419 / 50 + 6.0, "c2": 4.0 * 1045 / 25 + 6.0, "c3": 4.0 * 4181 / 100 + 6.0}   # tap counts: docs/PATH_AND_BOUNDARY.md (low_pass of the 1:D stages)
 C4_BYTES = 8.0 + 64 * 24000 * 2 / 1.6e6 + 64 * 4800 * 2 / 1.6e6   # input cf32 + int16 FM samples + unpacked dibits, per wideband sample
 F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector (packed) = f32 matrix peak
 # algorithmic flop of the C4 contract per WIDEBAND sample (a real x complex MAC = 4 flop, a real MAC = 2):
@@ -340,7 +341,7 @@ def promote_issue(roof, issue, dominant, why):
         roof["dominant_kernel_note"] = why
         return roof
     hbm = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernel_ms", "launches",
-                                "algorithmic_bytes_per_launch", "algorithmic_bytes_per_sample", "whole_step", "note") if k in roof}
+                                "algorithmic_bytes_per_launch", "algorithmic_bytes_per_sample", "whole_step", "flops", "note") if k in roof}
     out = {k: issue[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
     out.update(kernel=dominant, kernel_note=why, issue=issue, hbm=hbm)
     return out
@@ -827,6 +828,16 @@ def main():
                      kernel_ms=round(r["kernel_ms"], 4), launches=r["launches"],
                      algorithmic_bytes_per_launch=r["bytes_per_launch"], algorithmic_bytes_per_sample=r["bytes_per_sample"],
                      whole_step=whole_step_obj(r["bytes_per_launch"], r["ms_per_step"]))
+            # the compute roof of the same kernel: contract flop of the front end per input sample (real tap x complex sample = 4 flop per tap and output -> 4 nt / D
+            # per input sample, + the rotator's complex product) over the kernel's duration against the f32 peak (matrix = packed vector rate: the two share the FMA
+            # lanes, profiles/r05_sq_front_end_counters.txt: matrix pipe + other VALU = 98 % of C2's kernel cycles, 85 % of C3's -- busy cycles that add, padding included)
+            fl = FRONT_END_FLOP.get(r["name"])
+            if fl and r["kernel_ms"] > 0:
+                ach_f = fl * r["batch"] * r["nsamp"] / (r["kernel_ms"] * 1e-3) / 1e12
+                d["flops"] = dict(bound="f32", achieved=round(ach_f, 2), peak=F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach_f / F32_PEAK_TFLOPS, 4),
+                                  algorithmic_flop_per_sample=round(fl, 1),
+                                  note="contract flop (4 x taps / decimation + 6 for the rotator, per input sample) / kernel time; the kernel also executes the zero "
+                                       "padding of its tiles (C2 / C3: 42 lags as 48, 25 phases as 28) and the exact-NCO table arithmetic, which are not counted here")
             if ovl and r["name"] == "c1":
                 d["serial_mode"] = dict(kernel_ms=round(ovl["kernel_ms"], 4), achieved=round(ovl["achieved_gbps"], 1),
                                         frac=round(ovl["achieved_gbps"] / HBM_PEAK_GBPS, 4), ms_per_step=round(ovl["ms_per_step"], 3),
