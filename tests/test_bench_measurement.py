@@ -96,3 +96,19 @@ def test_source_id_changes_with_the_kernel_sources(tmp_path, monkeypatch):
         f.write("\n")
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     assert bench.source_id() != a
+
+
+def test_front_end_flop_roofline_on_the_committed_default_line():
+    """c1 / c2 / c3 carry the f32 flop roofline of their front-end kernel beside the HBM one (C2 / C3 are compute bound: profiles/r05_sq_front_end_counters.txt);
+    on c3 it sits with the HBM figures under roofline.hbm (the issue roofline is that line's headline)"""
+    import json
+    import os
+    import bench
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_bench_default_with_traffic.json")
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    f1, f2, f3 = d["roofline"]["flops"], d["c2"]["roofline"]["flops"], d["c3"]["roofline"]["hbm"]["flops"]
+    for f, name in ((f1, "c1"), (f2, "c2"), (f3, "c3")):
+        assert f["bound"] == "f32" and f["peak"] == bench.F32_PEAK_TFLOPS and abs(f["algorithmic_flop_per_sample"] - bench.FRONT_END_FLOP[name]) < 0.06
+        assert abs(f["frac"] - f["achieved"] / f["peak"]) < 1e-3
+    assert 0.35 < f2["frac"] < 0.55 and 0.33 < f3["frac"] < 0.55 and f1["frac"] < 0.2
+    assert abs(bench.FRONT_END_FLOP["c2"] - (4 * 1045 / 25 + 6)) < 1e-9
