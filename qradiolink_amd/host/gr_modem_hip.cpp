@@ -539,6 +539,7 @@ void gr_mod_base_hip::open()
     if (d_bytes) { (void)hipFree(d_bytes); d_bytes = nullptr; }
     if (d_audio) { (void)hipFree(d_audio); d_audio = nullptr; }
     if (d_iq) { (void)hipFree(d_iq); d_iq = nullptr; }
+    d_backend = d_rate >= 2000000 || d_offset != 0.0;
     if (analog_tx_mode(d_mode)) {
         qrl_amod_config c{};
         c.modem_type = d_mode; c.batch = d_n; c.max_samples = d_max; c.bb_gain = d_gain;
@@ -606,7 +607,7 @@ void gr_mod_base_hip::set_ctcss(float value)   // gr_mod_base.cpp:872-877
     d_ctcss = value; d_ctcss_touched = true;
     if (d_ah && (d_mode == QRL_MODEM_NBFM2500 || d_mode == QRL_MODEM_NBFM5000)) chk(qrl_amod_set_ctcss(d_ah, value), "qrl_amod_set_ctcss");
 }
-void gr_mod_base_hip::set_filter_width(int filter_width, int mode)   // gr_mod_base.cpp:878-905 (CW600USB: not built)
+void gr_mod_base_hip::set_filter_width(int filter_width, int mode)   // gr_mod_base.cpp:878-905
 {
     if (!analog_tx_mode(mode)) return;   // the reference's default branch
     if (d_ah && d_mode == mode) chk(qrl_amod_set_filter_width(d_ah, filter_width), "qrl_amod_set_filter_width");
@@ -627,6 +628,14 @@ void gr_mod_base_hip::set_bb_gain(float v)
 }
 void gr_mod_base_hip::set_carrier_offset(double hz)
 {
+    // a handle opened at 1 Msps with zero offset has no back end (no rotator to retune): zero stays a no-op, the first non-zero offset re-opens the handle with one
+    // (the modulator restarts; the reference's rotator is always in the graph, gr_mod_base.cpp:38)
+    if (!d_backend) {
+        if (hz == d_offset) return;
+        d_offset = hz;
+        if (d_mode >= 0) open();
+        return;
+    }
     d_offset = hz;
     if (d_h) chk(qrl_mod_set_carrier_offset(d_h, hz), "qrl_mod_set_carrier_offset");
     if (d_ah) chk(qrl_amod_set_carrier_offset(d_ah, hz), "qrl_amod_set_carrier_offset");

@@ -176,6 +176,7 @@ private:
     qrl_mod* d_h = nullptr; uint8_t* d_bytes = nullptr; float* d_iq = nullptr;
     qrl_amod* d_ah = nullptr; float* d_audio = nullptr; float d_ctcss = 0.0f; bool d_ctcss_touched = false; std::map<int, int> d_width;
     bool d_cw_key = false; size_t d_cw_n = 1024;
+    bool d_backend = false;   // the open handle has the gr_mod_base back end (device rate >= 2 Msps or a non-zero offset at open)
     size_t d_spblock = 0, d_bpb = 1;
     std::mutex d_mutex;
     std::vector<std::vector<uint8_t>> d_queue;

@@ -205,6 +205,14 @@ int main(int argc, char** argv)
                 std::ofstream o(std::string(argv[5]) + std::to_string(s) + ".bin", std::ios::binary);
                 o.write(reinterpret_cast<const char*>(iq[s].data()), (std::streamsize)(iq[s].size() * sizeof(gr_complex)));
             }
+            // set_carrier_offset on a handle without the back end: zero is a no-op, a non-zero offset re-opens the handle with the rotator
+            if (rate == 1000000 && offset == 0.0) {
+                mod.set_carrier_offset(0.0);
+                mod.set_carrier_offset(12500.0);
+                for (int s = 0; s < N; ++s) mod.set_audio(new std::vector<float>(2048 + 4, 0.25f), s);
+                if (mod.work(ptr.data()) == 0) throw std::runtime_error("no output after the retune");
+                mod.set_carrier_offset(-2500.0);                         // now a phase-continuous retune of the open handle
+            }
             std::printf("analogtx ok\n");
             return 0;
         } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
