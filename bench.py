@@ -37,6 +37,10 @@ PARITY_AGAINST = ("oracle/ (C restatement of the GNU Radio 3.10 block semantics;
                   "each with a float64 definition test); the arithmetic of the stock GNU Radio / VOLK blocks is unpinned (no GNU Radio in this image), and the rotator "
                   "is an exact 2^-64-turn NCO that leaves VOLK's phase recursion by up to 4.5e-4 on the float ports at a 25 kHz offset (hard bits unaffected)")
 
+# the channel every synth() stream of C1 / C2 / C3 / C5 goes through (VERDICT r5 "next" #1: parity_check names it)
+SYNTH_CHANNEL = ("SURVEY 8(d) (tests/sig.py SPEC): fractional delay 0.37 sample + clock error +20 ppm (32-tap windowed-sinc resampling of the modulator output), "
+                 "CFO, AWGN at Es/N0 12 dB per channel symbol; then per stream a circular shift, a CFO of -50 .. +50 Hz and AWGN of 0.002 rms per component")
+
 WORKLOADS = {
     # name: (label, sig mode, modem type, device rate, rx offset, default batch, default samples/stream, oracle mode,
     #        algorithmic bytes per input sample: SURVEY.md 8(d))
@@ -54,7 +58,8 @@ def synth(mode, device_rate, offset, batch, nsamp, seed, torch, dev, pad=0):
     shift + CFO + AWGN applied on the GPU (torch is plumbing here, not the product)."""
     import sig
     nframes = {"gmsk10k": 6, "2fsk1k": 6, "qpsk250k": 4}[mode]
-    base, _ = sig.make_stream(mode, nframes=nframes, device_rate=device_rate, rx_offset_hz=offset, seed=seed, amp=0.05)
+    # the base stream goes through SURVEY 8(d)'s channel (tests/sig.py SPEC: 0.37-sample fractional delay, +20 ppm clock error, Es/N0 12 dB)
+    base, _ = sig.make_stream(mode, nframes=nframes, device_rate=device_rate, rx_offset_hz=offset, seed=seed, amp=0.05, impair=sig.SPEC)
     reps = -(-nsamp // base.size)
     base = np.tile(base, reps)[:nsamp]
     g = torch.Generator(device=dev)
@@ -107,7 +112,7 @@ def parity_check(dem, iq, mode, rate, offset, torch, nstreams=4, seed=5):
         ok = ok and got_f.size == want_f.size and np.array_equal(got_f.view(np.uint32), want_f.view(np.uint32))
         if not ok:
             return dict(status="FAILED", stream=b, streams=picks)
-    return dict(status="bit-exact", streams=picks, compared="bits A/B and port 0 (filtered) of one call from a fresh state", against=PARITY_AGAINST,
+    return dict(status="bit-exact", streams=picks, compared="bits A/B and port 0 (filtered) of one call from a fresh state", channel=SYNTH_CHANNEL, against=PARITY_AGAINST,
                 bits_per_stream=int(cnt[picks[0], 2]))
 
 
@@ -542,7 +547,8 @@ def parity_check_c5(dem, mod, iq, data, tx_out, torch, nstreams=3, seed=8):
         ok = ok and g.size == w.size and np.array_equal(g.view(np.uint32), w.view(np.uint32))
         if not ok:
             return dict(status="FAILED", stream=b, streams=picks)
-    return dict(status="bit-exact", streams=picks, compared="RX: bits and port 0 (filtered); TX: every 1 Msps sample; one call each from a fresh state", against=PARITY_AGAINST,
+    return dict(status="bit-exact", streams=picks, compared="RX: bits and port 0 (filtered); TX: every 1 Msps sample; one call each from a fresh state",
+                channel="SURVEY 8(d) (tests/sig.py SPEC): fractional delay 0.37 sample, clock error +20 ppm, CFO, AWGN at Es/N0 12 dB; every stream the same waveform", against=PARITY_AGAINST,
                 bits_per_stream=int(cnt[picks[0], 2]), tx_samples_per_stream=int(tx_out.shape[1]))
 
 
@@ -555,7 +561,7 @@ def run_c5(args, torch, q, ctx, dev, rank, world, steps=None, check=False):
     B = args.batch or 16384
     n = (args.nsamp or (1 << 14)) & ~1
     nbytes = n // 32                                  # the TX produces as many 1 Msps samples as the RX consumes
-    base, _ = sig.make_stream("qpsk250k", nframes=3, device_rate=1000000, seed=3 + rank, amp=0.05)
+    base, _ = sig.make_stream("qpsk250k", nframes=3, device_rate=1000000, seed=3 + rank, amp=0.05, impair=sig.SPEC)   # SURVEY 8(d)'s channel
     base = np.tile(base, -(-n // base.size))[:n]
     iq = torch.from_numpy(base).to(dev).repeat(B, 1).contiguous()
     g = torch.Generator(device=dev)

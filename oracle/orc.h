@@ -114,6 +114,7 @@ enum { ORC_TED_MM = 0, ORC_TED_MOD_MM = 1 };
 void orc_set_ted_modmm(int ff_variant, int cc_variant);
 void orc_get_ted_modmm(int* ff_variant, int* cc_variant);
 enum { ORC_CONST_BPSK = 0, ORC_CONST_DQPSK = 1, ORC_CONST_4LEVEL = 2 };
+size_t orc_loop_clamp_hits(int reset);   /* test statistic: limiter hits of the timing loops since the last reset */
 size_t orc_symbol_sync_ff(const float* in, size_t n, int ted, float sps, float loop_bw, float damping,
                           float ted_gain, float max_dev, int constellation, float* out);
 size_t orc_symbol_sync_cc(const cf32* in, size_t n, int ted, float sps, float loop_bw, float damping,

@@ -609,11 +609,17 @@ static inline float slice_real(int constellation, float x)
     return (float)sector - 1.5f;
 }
 
+/* how often a timing loop sat in its limiter since the last reset (tests only: tests/test_channel_8d.py shows that the clock-error
+ * cases of the parity lists really drive symbol_sync's max_dev clamp / clock_recovery_mm's omega limit; not thread safe, read it
+ * around single-threaded chain calls) */
+static size_t g_clamp_hits = 0;
+size_t orc_loop_clamp_hits(int reset) { size_t v = g_clamp_hits; if (reset) g_clamp_hits = 0; return v; }
+
 typedef struct { float avg, inst, alpha, beta, maxp, minp; } clock_loop;
 static inline void clock_advance(clock_loop* c, float e)
 {
     c->avg = c->avg + c->beta * e;
-    if (c->avg > c->maxp) c->avg = c->maxp; else if (c->avg < c->minp) c->avg = c->minp;
+    if (c->avg > c->maxp) { c->avg = c->maxp; g_clamp_hits++; } else if (c->avg < c->minp) { c->avg = c->minp; g_clamp_hits++; }
     c->inst = c->avg + c->alpha * e;
     if (c->inst <= 0.f) c->inst = c->avg;
 }
@@ -851,6 +857,7 @@ size_t orc_clock_recovery_mm_cc(const cf32* in, size_t n, float omega, float gai
         float mm = branchless_clip(yr - xr, 1.0f);
         out[oo++] = y;
         omega = omega + gain_omega * mm;
+        if (fabsf(omega - omega_mid) > omega_lim) g_clamp_hits++;
         omega = omega_mid + branchless_clip(omega - omega_mid, omega_lim);
         mu = mu + omega + gain_mu * mm;
         const float fl = floorf(mu);

@@ -71,7 +71,7 @@ struct qrl_amod {
     float bb_gain = 1.0f, fm_k = 0.f;
     Dev<float> t_audio, t_if, t_filt, t_interp; int n_audio = 0, n_if = 0, n_filt = 0, n_interp = 0;
     // gr_mod_nbfm::set_ctcss (src/gr/gr_mod_nbfm.cpp:101-135): band-pass audio filter, _audio_amplify 0.85 / 0.98, tone source + add_ff
-    Dev<float> t_audio_bp, tone_tab; int n_audio_bp = 0; float k_audio = 0.99f; float tone_hz = 0.0f; uint32_t tone_inc = 0; uint64_t tone_k = 0;
+    Dev<float> t_audio_bp, tone_tab; int n_audio_bp = 0; float k_audio = 0.99f; float tone_hz = 0.0f; uint32_t tone_inc = 0; uint64_t tone_k = 0, cw_k = 0;   // sample counters of the CTCSS tone and of the CW key's tone source (sig_source_f free-runs: a filter change does not reset them)
     Dev<float> a0, a1, a2, r50; uint32_t m8 = 0, m50 = 0;       // rings: audio in, filtered, pre-emphasised (8 ksps); 50 ksps
     Dev<float2> fmv, flt;                                        // 50 ksps complex: modulator out, channel filter out
     Dev<AmIirState> iir; Dev<float> phase;
@@ -110,7 +110,7 @@ struct qrl_amod {
         return QRL_OK;
     }
     ~qrl_amod() { if (own_stream && stream) (void)hipStreamDestroy(stream); }
-    int init_state()
+    int init_state(bool keep_tone_phase = false)
     {
         int r;
         for (auto* b : {&a0, &a1, &a2, &r50, &phase}) if ((r = b->zero())) return r;
@@ -122,7 +122,8 @@ struct qrl_amod {
             if (hipMemcpy(am_gain.p, one.data(), one.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
             n1m = 0;
         }
-        n8 = n50 = ns = 0; last = 0; tone_k = 0;
+        n8 = n50 = ns = 0; last = 0;
+        if (!keep_tone_phase) tone_k = cw_k = 0;   // qrl_amod_set_filter_width restarts the chain but the reference's sig_source_f keeps running
         if (be_ring.p && (r = be_ring.zero())) return r;
         n_bb = 0; rot_acc = 0; rot_nbase = 0;
         return QRL_OK;
@@ -277,8 +278,9 @@ int qrl_amod_set_filter_width(qrl_amod* m, int width)
     }
     m->fw = width;
     // The reference swaps the taps of a running graph under lock() / unlock(), at a sample position its scheduler decides; here the chain restarts
-    // from a fresh state (like qrl_amod_reset; the set_ctcss switch and bb_gain are kept) -- what the tests compare is the chain built with the setter's designs.
-    return m->init_state();
+    // from a fresh state (like qrl_amod_reset; the set_ctcss switch, bb_gain and the PHASE of the tone sources are kept) -- what the tests compare is the chain
+    // built with the setter's designs.
+    return m->init_state(true);
 }
 size_t qrl_amod_samples_per_sample(const qrl_amod* m) { return m ? ((m->ssb || m->am) ? (size_t)m->sps : (size_t)25 * m->sps / 4) * (size_t)m->be_interp : 0; }
 size_t qrl_amod_last_count(const qrl_amod* m) { return m ? m->last : 0; }
@@ -358,9 +360,9 @@ int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, f
         const uint64_t n8_1 = m->n8 + n;
         const uint64_t ns_1 = n8_1 >= 2 ? 1024 * ((n8_1 - 2) / 1024) : 0;        // stretcher: whole chunks, two items of look-ahead
         const uint32_t cs = (uint32_t)(ns_1 - m->ns);
-        if ((size_t)cs * m->sps * m->be_interp > out_stride && B > 1) return qrl_set_error(QRL_ERR_ARG, "amod: out_stride smaller than this call's output (qrl_amod_out_cap)");
+        if ((size_t)cs * m->sps * m->be_interp > out_stride) return qrl_set_error(QRL_ERR_ARG, "amod: out_stride smaller than this call's output (qrl_amod_out_cap)");
         if (m->cw) {   // the key's tone source instead of the caller's audio (which is ignored): amplitude 0.001 / 0.98 by qrl_amod_set_cw_k, offset 1
-            AmToneParams tp{}; tp.out = a0; tp.n0 = m->n8; tp.count = c8; tp.tab = m->tone_tab.p; tp.inc = m->tone_inc; tp.k0 = m->n8; tp.ampl = m->cw_ampl; tp.offset = 1.0f;
+            AmToneParams tp{}; tp.out = a0; tp.n0 = m->n8; tp.count = c8; tp.tab = m->tone_tab.p; tp.inc = m->tone_inc; tp.k0 = m->cw_k; tp.ampl = m->cw_ampl; tp.offset = 1.0f;
             launch_am_tone(tp, B, s);
         } else {
             AmLoadParams lp{}; lp.in = audio; lp.in_stride = stride; lp.out = a0; lp.n0 = m->n8; lp.count = c8;
@@ -383,11 +385,13 @@ int qrl_amod_process(qrl_amod* m, const float* audio, size_t stride, size_t n, f
         HIPCHK(hipGetLastError());
         if (qrl::take_launch_error()) return QRL_ERR_HIP;
         m->n8 = n8_1; m->ns = ns_1; m->last = (size_t)cs * m->sps * m->be_interp;
+        if (m->cw) m->cw_k += c8;
         return QRL_OK;
     }
     RingF a0{m->a0.p, m->m8}, a1{m->a1.p, m->m8}, a2{m->a2.p, m->m8}, r50{m->r50.p, m->m50};
     RingC fmv{m->fmv.p, m->m50}, flt{m->flt.p, m->m50};
     const uint32_t c8 = (uint32_t)n, c50 = (uint32_t)(n * 25 / 4);
+    if ((size_t)c50 * m->sps * m->be_interp > out_stride) return qrl_set_error(QRL_ERR_ARG, "amod: out_stride smaller than this call's output (qrl_amod_out_cap)");
     AmLoadParams lp{}; lp.in = audio; lp.in_stride = stride; lp.out = a0; lp.n0 = m->n8; lp.count = c8;
     launch_am_load(lp, B, s);
     const bool tone_on = m->tone_hz > 0.0f;

@@ -201,7 +201,13 @@ void gr_demod_base_hip::set_mode(int mode)   // gr_demod_base::set_mode (src/gr/
     std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     flush();
     d_mode = mode;
-    open();
+    try { open(); }
+    catch (const std::exception& e) {
+        if (d_scope_rate == 0 && d_scope_fw == 0.0) throw;
+        d_scope_rate = 0; d_scope_fw = 0.0;   // set before a handle existed and only rejected now: back to the constructor's 1:10 tap
+        open();
+        throw std::invalid_argument(std::string("gr_demod_base_hip::set_mode: time-domain settings rejected and reset to the defaults (the mode is open): ") + e.what());
+    }
     std::lock_guard<std::mutex> g(d_mutex);
     for (int s = 0; s < d_n; ++s) { d_box1[s].clear(); d_box2[s].clear(); d_boxc[s].clear(); d_boxd[s].clear(); d_boxa[s].clear(); d_boxf[0][s].clear(); d_boxf[1][s].clear(); d_boxs[s].clear(); }
 }
@@ -443,18 +449,36 @@ void gr_demod_base_hip::enable_time_domain(bool value)   // gr_demod_base.cpp:11
     std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     d_scope_on = value;
 }
+void gr_demod_base_hip::reconfigure_scope(int samp_rate, double filter_width)
+{
+    // The engine plans the scope decimator at create time and is stricter than the reference's setters (rates above 500 ksps, widths above 500 kHz and
+    // filters of more than 4096 taps -- rates below ~2.4 ksps, widths below ~590 Hz -- are rejected).  A rejected value must not cost the caller the
+    // demodulator: the old settings come back, the handle is re-opened with them, and the call throws std::invalid_argument.
+    const int old_rate = d_scope_rate; const double old_fw = d_scope_fw;
+    if (samp_rate > 500000 || filter_width < 0.0 || filter_width > 500000.0 || (samp_rate > 0 && samp_rate / 2 - samp_rate / 8 <= 0))
+        throw std::invalid_argument("gr_demod_base_hip: time-domain sample rate / filter width outside what the engine plans (rate <= 500000, width <= 500000)");
+    d_scope_rate = samp_rate; d_scope_fw = filter_width;
+    if (d_mode < 0) return;
+    flush();
+    try { open(); }
+    catch (const std::exception& e) {
+        d_scope_rate = old_rate; d_scope_fw = old_fw;
+        open();   // the settings the handle had before: this worked when it was created
+        throw std::invalid_argument(std::string("gr_demod_base_hip: time-domain settings rejected, previous ones restored: ") + e.what());
+    }
+    std::lock_guard<std::mutex> g(d_mutex);
+    for (auto& b : d_boxs) b.clear();   // the handle keeps history for the filter it was created with
+}
 void gr_demod_base_hip::set_time_sink_samp_rate(int samp_rate)   // gr_demod_base.cpp:1249-1290: a new resampler (decimation 1e6 / samp_rate, its own low-pass) under lock()
 {
     std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     if ((unsigned)samp_rate > 1000000u) return;   // :1251-1252
-    d_scope_rate = samp_rate; d_scope_fw = 0.0;
-    if (d_mode >= 0) { flush(); open(); std::lock_guard<std::mutex> g(d_mutex); for (auto& b : d_boxs) b.clear(); }   // the handle keeps history for the filter it was created with
+    reconfigure_scope(samp_rate, 0.0);
 }
 void gr_demod_base_hip::set_time_domain_filter_width(double filter_width)   // :1292-1301: set_taps(low_pass(1, 1e6, width, width, HAMMING)) on the current resampler
 {
     std::lock_guard<std::recursive_mutex> hg(d_hmutex);
-    d_scope_fw = filter_width;
-    if (d_mode >= 0) { flush(); open(); std::lock_guard<std::mutex> g(d_mutex); for (auto& b : d_boxs) b.clear(); }
+    reconfigure_scope(d_scope_rate, filter_width);
 }
 void gr_demod_base_hip::set_sample_window(unsigned int size)   // gr_sample_sink::set_sample_window (:35-41): odd sizes go up by one
 {
@@ -518,6 +542,7 @@ std::vector<std::vector<unsigned char>> gr_demod_base_hip::getDMRData(int stream
 gr_mod_base_hip::gr_mod_base_hip(qrl_runtime& rt, int streams, int device_samp_rate, double carrier_offset_hz, size_t max_bytes)
     : d_rt(rt), d_n(streams), d_rate(device_samp_rate), d_offset(carrier_offset_hz), d_max(max_bytes), d_queue(streams), d_aqueue(streams), d_sent(streams, 0)
 {
+    d_cw_n = std::min<size_t>(1024, d_max);   // a facade built for fewer than 1024 items per call must still key CW
 }
 gr_mod_base_hip::~gr_mod_base_hip()
 {
@@ -534,60 +559,84 @@ static bool analog_tx_mode(int mode)
 }
 void gr_mod_base_hip::open()
 {
-    if (d_h) { qrl_mod_destroy(d_h); d_h = nullptr; }
-    if (d_ah) { qrl_amod_destroy(d_ah); d_ah = nullptr; }
-    if (d_bytes) { (void)hipFree(d_bytes); d_bytes = nullptr; }
-    if (d_audio) { (void)hipFree(d_audio); d_audio = nullptr; }
-    if (d_iq) { (void)hipFree(d_iq); d_iq = nullptr; }
-    d_backend = d_rate >= 2000000 || d_offset != 0.0;
-    if (analog_tx_mode(d_mode)) {
-        qrl_amod_config c{};
-        c.modem_type = d_mode; c.batch = d_n; c.max_samples = d_max; c.bb_gain = d_gain;
-        c.device_samp_rate = d_rate; c.carrier_offset_hz = d_offset;
-        chk(qrl_amod_create(d_rt.ctx(), &c, &d_ah), "qrl_amod_create");
-        // the reference's instances keep what their setters did across mode changes
-        if (d_ctcss_touched && (d_mode == QRL_MODEM_NBFM2500 || d_mode == QRL_MODEM_NBFM5000)) chk(qrl_amod_set_ctcss(d_ah, d_ctcss), "qrl_amod_set_ctcss");
-        if (d_width.count(d_mode)) chk(qrl_amod_set_filter_width(d_ah, d_width[d_mode]), "qrl_amod_set_filter_width");
-        if (d_mode == QRL_MODEM_CW600USB && d_cw_key) chk(qrl_amod_set_cw_k(d_ah, 1), "qrl_amod_set_cw_k");
-        hchk(hipMalloc(reinterpret_cast<void**>(&d_audio), (size_t)d_n * d_max * sizeof(float)), "hipMalloc");
-        hchk(hipMalloc(reinterpret_cast<void**>(&d_iq), (size_t)d_n * qrl_amod_out_cap(d_ah, d_max) * sizeof(gr_complex)), "hipMalloc");
-        return;
+    // create first, swap in on success: a mode / offset the engine rejects leaves the running modulator intact
+    const bool backend = d_rate >= 2000000 || d_offset != 0.0;
+    qrl_mod* nh = nullptr; qrl_amod* nah = nullptr; uint8_t* nbytes = nullptr; float* naudio = nullptr; float* niq = nullptr;
+    size_t spblock = 0, bpb = 1;
+    try {
+        if (analog_tx_mode(d_mode)) {
+            qrl_amod_config c{};
+            c.modem_type = d_mode; c.batch = d_n; c.max_samples = d_max; c.bb_gain = d_gain;
+            c.device_samp_rate = d_rate; c.carrier_offset_hz = d_offset;
+            chk(qrl_amod_create(d_rt.ctx(), &c, &nah), "qrl_amod_create");
+            // the reference's instances keep what their setters did across mode changes
+            if (d_ctcss_touched && (d_mode == QRL_MODEM_NBFM2500 || d_mode == QRL_MODEM_NBFM5000)) chk(qrl_amod_set_ctcss(nah, d_ctcss), "qrl_amod_set_ctcss");
+            if (d_width.count(d_mode)) chk(qrl_amod_set_filter_width(nah, d_width[d_mode]), "qrl_amod_set_filter_width");
+            if (d_mode == QRL_MODEM_CW600USB && d_cw_key) chk(qrl_amod_set_cw_k(nah, 1), "qrl_amod_set_cw_k");
+            hchk(hipMalloc(reinterpret_cast<void**>(&naudio), (size_t)d_n * d_max * sizeof(float)), "hipMalloc");
+            hchk(hipMalloc(reinterpret_cast<void**>(&niq), (size_t)d_n * qrl_amod_out_cap(nah, d_max) * sizeof(gr_complex)), "hipMalloc");
+        } else {
+            qrl_mod_config c{};
+            c.modem_type = d_mode; c.use_mode_defaults = 1; c.batch = d_n; c.max_bytes = d_max; c.bb_gain = d_gain;
+            c.device_samp_rate = d_rate; c.carrier_offset_hz = d_offset;
+            chk(qrl_mod_create(d_rt.ctx(), &c, &nh), "qrl_mod_create");
+            hchk(hipMalloc(reinterpret_cast<void**>(&nbytes), (size_t)d_n * d_max), "hipMalloc");
+            spblock = qrl_mod_samples_per_block(nh, &bpb);     // M17: 2500 samples per 3 bytes; every other mode: samples per byte, 1
+            hchk(hipMalloc(reinterpret_cast<void**>(&niq), (size_t)d_n * (d_max / bpb + 1) * spblock * sizeof(gr_complex)), "hipMalloc");
+        }
+    } catch (...) {
+        if (nh) qrl_mod_destroy(nh);
+        if (nah) qrl_amod_destroy(nah);
+        if (nbytes) (void)hipFree(nbytes);
+        if (naudio) (void)hipFree(naudio);
+        if (niq) (void)hipFree(niq);
+        throw;
     }
-    qrl_mod_config c{};
-    c.modem_type = d_mode; c.use_mode_defaults = 1; c.batch = d_n; c.max_bytes = d_max; c.bb_gain = d_gain;
-    c.device_samp_rate = d_rate; c.carrier_offset_hz = d_offset;
-    chk(qrl_mod_create(d_rt.ctx(), &c, &d_h), "qrl_mod_create");
-    hchk(hipMalloc(reinterpret_cast<void**>(&d_bytes), (size_t)d_n * d_max), "hipMalloc");
-    d_spblock = qrl_mod_samples_per_block(d_h, &d_bpb);     // M17: 2500 samples per 3 bytes; every other mode: samples per byte, 1
-    hchk(hipMalloc(reinterpret_cast<void**>(&d_iq), (size_t)d_n * (d_max / d_bpb + 1) * d_spblock * sizeof(gr_complex)), "hipMalloc");
-}
-void gr_mod_base_hip::set_mode(int mode)   // gr_mod_base::set_mode (src/gr/gr_mod_base.cpp:354-763): new graph, queued bytes dropped
-{
-    d_mode = mode;
-    open();
+    if (d_h) qrl_mod_destroy(d_h);
+    if (d_ah) qrl_amod_destroy(d_ah);
+    if (d_bytes) (void)hipFree(d_bytes);
+    if (d_audio) (void)hipFree(d_audio);
+    if (d_iq) (void)hipFree(d_iq);
+    d_h = nh; d_ah = nah; d_bytes = nbytes; d_audio = naudio; d_iq = niq; d_backend = backend;
+    if (nh) { d_spblock = spblock; d_bpb = bpb; }
+    d_cw_n = std::min(d_cw_n, d_max);
+    // a new handle counts its items from zero: whatever was queued for the old one (and the byte positions of its zero runs) goes with it
     std::lock_guard<std::mutex> g(d_mutex);
     for (auto& q : d_queue) q.clear();
     for (auto& q : d_aqueue) q.clear();
     for (auto& v : d_sent) v = 0;
 }
+void gr_mod_base_hip::set_mode(int mode)   // gr_mod_base::set_mode (src/gr/gr_mod_base.cpp:354-763): new graph, queued bytes dropped
+{
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
+    const int old = d_mode;
+    d_mode = mode;
+    try { open(); }
+    catch (...) { d_mode = old; throw; }   // the previous modulator is still open
+}
 int gr_mod_base_hip::setDMRData(const std::vector<std::vector<uint8_t>>& frames, int stream)   // gr_mod_base.cpp:788-791 -> gr_dmr_source.cpp:56-73
 {
+    // d_hmutex is held by work() across qrl_mod_process: the bytes and the zero runs that belong to them become visible to a pass together
+    // (gr_dmr_source::set_data takes the source's mutex for the same reason, gr_dmr_source.cpp:56-73)
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     if (d_mode != QRL_MODEM_DMR || !d_h) throw std::runtime_error("gr_mod_base_hip::setDMRData outside DMR mode");
     constexpr size_t kZeroBytes = 33 + 2 * 3;            // DMR_ZERO_TX_LENGTH_BYTES = FRAME_LENGTH_BYTES + 2 CACH_LENGTH_BYTES (gr_dmr_source.cpp:24)
     std::vector<qrl_zero_run> runs;
-    {
-        std::lock_guard<std::mutex> g(d_mutex);
-        for (const auto& f : frames) {
-            auto& q = d_queue[stream];
-            q.insert(q.end(), f.begin(), f.end());
-            const uint64_t first_zero = d_sent[stream] + q.size();   // byte index of the tag (gr_dmr_source.cpp:118-121)
-            q.insert(q.end(), kZeroBytes, (uint8_t)0);
-            qrl_zero_run z{};
-            z.stream = stream; z.channel = 0; z.start = first_zero * 20u; z.count = kZeroBytes * 4u * 5u;   // DMR_ZERO_TX_LENGTH_SAMPLES (:25)
-            runs.push_back(z);
-        }
+    std::lock_guard<std::mutex> g(d_mutex);
+    auto& q = d_queue[stream];
+    const size_t q0 = q.size();
+    for (const auto& f : frames) {
+        q.insert(q.end(), f.begin(), f.end());
+        const uint64_t first_zero = d_sent[stream] + q.size();   // byte index of the tag (gr_dmr_source.cpp:118-121)
+        q.insert(q.end(), kZeroBytes, (uint8_t)0);
+        qrl_zero_run z{};
+        z.stream = stream; z.channel = 0; z.start = first_zero * 20u; z.count = kZeroBytes * 4u * 5u;   // DMR_ZERO_TX_LENGTH_SAMPLES (:25)
+        runs.push_back(z);
     }
-    if (!runs.empty()) chk(qrl_mod_add_zero_runs(d_h, runs.data(), runs.size()), "qrl_mod_add_zero_runs");
+    if (!runs.empty() && qrl_mod_add_zero_runs(d_h, runs.data(), runs.size()) != QRL_OK) {
+        q.resize(q0);   // bytes without their idle zeros would be a different waveform: all or nothing
+        throw std::runtime_error(std::string("qrl_mod_add_zero_runs: ") + qrl_last_error());
+    }
     return 0;
 }
 int gr_mod_base_hip::set_audio(std::vector<float>* data, int stream)   // gr_mod_base.cpp:793-797 -> gr_audio_source::set_data (gr_audio_source.cpp:55-66)
@@ -599,17 +648,20 @@ int gr_mod_base_hip::set_audio(std::vector<float>* data, int stream)   // gr_mod
 }
 void gr_mod_base_hip::set_cw_k(bool value)   // gr_mod_base.cpp:948-956
 {
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     d_cw_key = value;
     if (d_ah && d_mode == QRL_MODEM_CW600USB) chk(qrl_amod_set_cw_k(d_ah, value ? 1 : 0), "qrl_amod_set_cw_k");
 }
 void gr_mod_base_hip::set_ctcss(float value)   // gr_mod_base.cpp:872-877
 {
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     d_ctcss = value; d_ctcss_touched = true;
     if (d_ah && (d_mode == QRL_MODEM_NBFM2500 || d_mode == QRL_MODEM_NBFM5000)) chk(qrl_amod_set_ctcss(d_ah, value), "qrl_amod_set_ctcss");
 }
 void gr_mod_base_hip::set_filter_width(int filter_width, int mode)   // gr_mod_base.cpp:878-905
 {
     if (!analog_tx_mode(mode)) return;   // the reference's default branch
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     if (d_ah && d_mode == mode) chk(qrl_amod_set_filter_width(d_ah, filter_width), "qrl_amod_set_filter_width");
     d_width[mode] = filter_width;
 }
@@ -622,27 +674,41 @@ int gr_mod_base_hip::set_data(std::vector<uint8_t>* data, int stream)   // gr_mo
 }
 void gr_mod_base_hip::set_bb_gain(float v)
 {
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     d_gain = v;
     if (d_h) chk(qrl_mod_set_bb_gain(d_h, v), "qrl_mod_set_bb_gain");
     if (d_ah) chk(qrl_amod_set_bb_gain(d_ah, v), "qrl_amod_set_bb_gain");
 }
+static bool tx_mode_has_back_end(int mode)   // qrl_mod_create builds the gr_mod_base back end (rotator + interpolator) for every family but these (tx.cpp)
+{
+    return !(mode == QRL_MODEM_M17 || mode == QRL_MODEM_BPSK8);
+}
 void gr_mod_base_hip::set_carrier_offset(double hz)
 {
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     // a handle opened at 1 Msps with zero offset has no back end (no rotator to retune): zero stays a no-op, the first non-zero offset re-opens the handle with one
-    // (the modulator restarts; the reference's rotator is always in the graph, gr_mod_base.cpp:38)
+    // (the modulator restarts and what was queued is dropped; the reference's rotator is always in the graph, gr_mod_base.cpp:38).  The new handle is created
+    // BEFORE the old one goes (open()), so a mode whose back end is not built (M17, DSSS) keeps its modulator and its offset, and the call throws.
     if (!d_backend) {
         if (hz == d_offset) return;
+        if (d_mode >= 0 && !tx_mode_has_back_end(d_mode))
+            throw std::invalid_argument("gr_mod_base_hip::set_carrier_offset: this mode's modulator has no rotator (M17 / DSSS back end not built); offset unchanged");
+        const double old = d_offset;
         d_offset = hz;
-        if (d_mode >= 0) open();
+        if (d_mode >= 0) {
+            try { open(); }
+            catch (...) { d_offset = old; throw; }
+        }
         return;
     }
-    d_offset = hz;
     if (d_h) chk(qrl_mod_set_carrier_offset(d_h, hz), "qrl_mod_set_carrier_offset");
     if (d_ah) chk(qrl_amod_set_carrier_offset(d_ah, hz), "qrl_amod_set_carrier_offset");
+    d_offset = hz;
 }
 size_t gr_mod_base_hip::samples_per_byte() const { return d_h ? qrl_mod_samples_per_byte(d_h) : 0; }
 size_t gr_mod_base_hip::work(gr_complex* const* out)
 {
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);   // the handle and its zero-run list for the whole pass; the byte / audio queues stay under d_mutex
     if (d_ah && d_mode == QRL_MODEM_CW600USB) {   // the tone source lives on the device: nothing to upload
         const size_t stride = qrl_amod_out_cap(d_ah, d_max);
         chk(qrl_amod_process(d_ah, nullptr, 0, d_cw_n, d_iq, stride), "qrl_amod_process");

@@ -111,6 +111,7 @@ private:
     qrl_demod* d_h = nullptr;
     qrl_rssi* d_rssi = nullptr; qrl_fft* d_fft = nullptr; bool d_rssi_on = false, d_fft_on = false; float d_rssi_cal = 0.0f; unsigned d_fftsize = 32768;
     float d_ctcss = 0.0f; bool d_const_on = true, d_demod_on = true;
+    void reconfigure_scope(int samp_rate, double filter_width);   // re-open with new scope settings; the old ones come back when the engine rejects them
     int d_scope_rate = 0; double d_scope_fw = 0.0;   // set_time_sink_samp_rate / set_time_domain_filter_width (0: the constructor's 1:10)
     bool d_scope_on = false; size_t d_scap = 0; unsigned d_window = 8096; std::vector<std::vector<gr_complex>> d_boxs;   // scope tap mailboxes
     qrl_framesync* d_fs[2] = {nullptr, nullptr}; bool d_want_fs = false, d_keep_bits = false; size_t d_frcap = 0;   // device frame synchronisers of bits A / B
@@ -175,10 +176,11 @@ private:
     int d_n, d_rate, d_mode = -1; double d_offset; size_t d_max; float d_gain = 1.0f;
     qrl_mod* d_h = nullptr; uint8_t* d_bytes = nullptr; float* d_iq = nullptr;
     qrl_amod* d_ah = nullptr; float* d_audio = nullptr; float d_ctcss = 0.0f; bool d_ctcss_touched = false; std::map<int, int> d_width;
-    bool d_cw_key = false; size_t d_cw_n = 1024;
+    bool d_cw_key = false; size_t d_cw_n = 1024;   // clamped to max_bytes by the constructor and by open()
     bool d_backend = false;   // the open handle has the gr_mod_base back end (device rate >= 2 Msps or a non-zero offset at open)
     size_t d_spblock = 0, d_bpb = 1;
-    std::mutex d_mutex;
+    std::recursive_mutex d_hmutex;   // the handle: work() holds it across a pass, every setter that touches the handle takes it.  Lock order: d_hmutex, then d_mutex
+    std::mutex d_mutex;              // the byte / audio queues and d_sent
     std::vector<std::vector<uint8_t>> d_queue;
     std::vector<std::vector<float>> d_aqueue;
     std::vector<uint64_t> d_sent;   // bytes per stream handed to the modulator since set_mode (with the zero padding of short queues): positions of the zero runs

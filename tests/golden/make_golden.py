@@ -29,6 +29,16 @@ CASES = [
     ("4fsk100k_1M", "4fsk100k", 1000000, 0.0, ("4fsk", dict(sps=2, filter_width=125000, fm=True))),
     ("bpsk2k_1M", "bpsk2k", 1000000, 0.0, ("bpsk", dict(sps=5))),
 ]
+# round 6: the same chains behind SURVEY.md 8(d)'s channel (sig.SPEC: 0.37-sample fractional delay, +20 ppm clock error, Es/N0 12 dB) --
+# the inputs under which the timing loops' acquisition matters most, so the first GNU Radio run (tools/gr_golden/run_all.py) pins them too
+CASES_8D = [
+    ("2fsk1k_1M_8d", "2fsk1k", 1000000, 0.0, ("2fsk", dict(sps=10, filter_width=2000, fm=False))),
+    ("gmsk10k_1M_8d", "gmsk10k", 1000000, 0.0, ("gmsk", dict(sps=1, filter_width=20000))),
+    ("qpsk250k_1M_8d", "qpsk250k", 1000000, 0.0, ("qpsk", dict(sps=2, filter_width=160000))),
+    ("4fsk2kfm_1M_8d", "4fsk2kfm", 1000000, 0.0, ("4fsk", dict(sps=5, filter_width=3000, fm=True))),
+    ("bpsk2k_1M_8d", "bpsk2k", 1000000, 0.0, ("bpsk", dict(sps=5))),
+]
+CASES = CASES + CASES_8D
 
 
 def quantise(x):
@@ -58,7 +68,8 @@ def main():
         if only and name not in only:
             continue
         nframes = 1 if rate > 1000000 else (3 if mode.startswith("2fsk") else 4 if mode.startswith("bpsk") else 2)
-        y, payloads = sig.make_stream(mode, nframes=nframes, device_rate=rate, rx_offset_hz=offset, seed=77, amp=0.25)
+        y, payloads = sig.make_stream(mode, nframes=nframes, device_rate=rate, rx_offset_hz=offset, seed=77, amp=0.25,
+                                      impair=sig.SPEC if name.endswith("_8d") else None)
         if mode.startswith(("4fsk", "bpsk")):
             y = np.concatenate([y, np.zeros(20000, np.complex64)])   # flush the long RRC filters / Viterbi frames
         y = quantise(y[: y.size & ~1])

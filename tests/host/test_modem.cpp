@@ -4,6 +4,8 @@
 // the modulator's samples (+ a little silence and a per-stream delay) go into the demodulator in ragged work() calls;
 // demodulate() is polled like the radio loop does.  Every callback is logged to <out.txt> as one line per event.
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -58,6 +60,99 @@ int main(int argc, char** argv)
             std::ofstream o(argv[3], std::ios::binary);
             o.write(reinterpret_cast<const char*>(mod.sent.data()), (std::streamsize)mod.sent.size());
             std::printf("txpin ok: %zu bytes\n", mod.sent.size());
+            return 0;
+        } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+    }
+    if (argc == 3 && !strcmp(argv[1], "robust")) {
+        // test_modem robust <dmr iq out.bin>: a rejected setting must not cost the caller the handle it had, and the TX setters serialise with work()
+        try {
+            qrl_runtime rt(0);
+            auto expect_throw = [](const char* what, auto&& fn) {
+                try { fn(); } catch (const std::exception& e) { std::printf("  %s: rejected (%s)\n", what, e.what()); return; }
+                throw std::runtime_error(std::string(what) + ": expected an exception");
+            };
+            {   // TX: set_carrier_offset on modes without the back end keeps the modulator and its offset
+                gr_mod_base_hip mod(rt, 1, 1000000, 0.0, 96);
+                std::vector<gr_complex> buf(96 * 2500 + 2500); gr_complex* ptr[1] = {buf.data()};
+                for (int mode : {QRL_MODEM_M17, QRL_MODEM_BPSK8}) {
+                    mod.set_mode(mode);
+                    expect_throw("tx offset without back end", [&] { mod.set_carrier_offset(12500.0); });
+                    mod.set_data(new std::vector<uint8_t>(48, 0x5A));
+                    if (mod.work(ptr) == 0) throw std::runtime_error("modulator lost after a rejected set_carrier_offset");
+                    mod.set_mode(mode);   // and set_mode still works (the offset did not stick)
+                }
+                // a mode WITH the back end: the first non-zero offset re-opens the handle with the rotator; queued bytes of the old handle are dropped
+                mod.set_mode(QRL_MODEM_GMSK10K);
+                mod.set_data(new std::vector<uint8_t>(10, 0x33));
+                mod.set_carrier_offset(5000.0);
+                if (mod.work(ptr) != 0) throw std::runtime_error("bytes queued for the old handle survived the re-open");
+                mod.set_data(new std::vector<uint8_t>(10, 0x33));
+                if (mod.work(ptr) != 10 * mod.samples_per_byte()) throw std::runtime_error("modulator with back end produced nothing");
+                mod.set_carrier_offset(0.0);   // has a back end now: plain retune
+                expect_throw("tx unknown mode", [&] { mod.set_mode(9999); });
+                mod.set_data(new std::vector<uint8_t>(10, 0x33));
+                if (mod.work(ptr) == 0) throw std::runtime_error("modulator lost after a rejected set_mode");
+            }
+            {   // TX: a facade built for fewer than 1024 items per call keys CW
+                gr_mod_base_hip mod(rt, 1, 1000000, 0.0, 1023);
+                mod.set_mode(QRL_MODEM_CW600USB);
+                mod.set_cw_k(true);
+                std::vector<gr_complex> buf(mod.max_audio_out() + 16); gr_complex* ptr[1] = {buf.data()};
+                mod.work(ptr); mod.work(ptr);
+                if (mod.cw_samples_per_call() != 1023) throw std::runtime_error("cw_samples_per_call not clamped to max");
+            }
+            {   // TX: setDMRData from another thread while work() runs -- every frame's idle zeros must be applied (frame + 39 zero bytes = 72 bytes = 60000 samples,
+                // of which the zero run silences 780 x 20... checked as: the number of EXACT zero samples equals frames x run length)
+                gr_mod_base_hip mod(rt, 1, 1000000, 0.0, 144);
+                mod.set_mode(QRL_MODEM_DMR);
+                std::vector<gr_complex> buf(144 / 3 * 2500 + 2500), all; gr_complex* ptr[1] = {buf.data()};
+                const int frames = 24;
+                std::atomic<bool> done{false};
+                std::thread feeder([&] {
+                    for (int f = 0; f < frames; ++f) {
+                        std::vector<uint8_t> fr(33);
+                        for (int i = 0; i < 33; ++i) fr[i] = (uint8_t)(0x1B + 7 * i + f);
+                        mod.setDMRData({fr}, 0);
+                        std::this_thread::sleep_for(std::chrono::microseconds(200 * (f % 5)));
+                    }
+                    done = true;
+                });
+                for (;;) {
+                    const bool fin = done.load();
+                    const size_t got = mod.work(ptr);
+                    all.insert(all.end(), buf.begin(), buf.begin() + got);
+                    if (fin && got == 0) break;
+                }
+                feeder.join();
+                // one stream, whole 3-byte blocks per pass: whatever the interleaving of the two threads, the byte stream is frame | 39 zeros | frame ... and
+                // every zero run must be known to the pass that reaches its bytes -- the IQ is compared with the oracle's gr_mod_dmr by the Python test
+                std::printf("  dmr concurrent: %zu samples from %d frames\n", all.size(), frames);
+                if (all.size() != (size_t)frames * 72 / 3 * 2500) throw std::runtime_error("DMR sample count");
+                std::ofstream o(argv[2], std::ios::binary);
+                o.write(reinterpret_cast<const char*>(all.data()), (std::streamsize)(all.size() * sizeof(gr_complex)));
+            }
+            // RX: scope settings the engine rejects restore the previous ones; the demodulator keeps running
+            gr_demod_base_hip demod(rt, 1, 1000000, 0.0, 1 << 15);
+            expect_throw("rx scope rate without a handle", [&] { demod.set_time_sink_samp_rate(800000); });   // no handle yet: range-checked
+            demod.set_mode(QRL_MODEM_2FSK1K);
+            demod.enable_time_domain(true);
+            demod.set_time_sink_samp_rate(50000);
+            int thrown = 0;
+            try { demod.set_time_sink_samp_rate(1000); } catch (const std::invalid_argument&) { ++thrown; }        // low_pass of > 4096 taps
+            try { demod.set_time_domain_filter_width(100.0); } catch (const std::invalid_argument&) { ++thrown; }   // same
+            try { demod.set_time_sink_samp_rate(700000); } catch (const std::invalid_argument&) { ++thrown; }      // above the engine's range
+            if (thrown != 3) throw std::runtime_error("rejected scope settings did not throw");
+            std::vector<gr_complex> x(1 << 15, gr_complex(0.01f, 0.0f));
+            const gr_complex* in[1] = {x.data()};
+            demod.work(in, x.size());
+            demod.work(in, x.size());
+            demod.flush();
+            std::vector<float> buf(2 * 8096 + 2); unsigned ns = 0; size_t items = 0;
+            for (;;) { demod.get_sample_data(buf.data(), ns, 0); if (!ns) break; items += ns / 2; }
+            std::printf("  rx scope after rejected settings: %zu items at the restored 50 ksps\n", items);
+            if (items < 2 * x.size() / 20 - 600 || items > 2 * x.size() / 20) throw std::runtime_error("scope tap not running at the restored rate");
+            demod.set_mode(QRL_MODEM_GMSK10K);   // later mode changes still work
+            std::printf("robust ok\n");
             return 0;
         } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
     }

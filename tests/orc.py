@@ -583,6 +583,14 @@ def agc2(x, attack, decay, ref, gain, max_gain=65536.0):
     return y
 
 
+_sig("orc_loop_clamp_hits", _sz, C.c_int)
+
+
+def loop_clamp_hits(reset=True):
+    """limiter hits of the oracle's timing loops since the last reset (single-threaded test statistic)"""
+    return int(lib.orc_loop_clamp_hits(1 if reset else 0))
+
+
 def symbol_sync_ff(x, ted, sps, loop_bw, damping, ted_gain, max_dev, constellation):
     x = np.ascontiguousarray(x, np.float32)
     y = np.empty(x.size, np.float32)

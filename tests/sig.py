@@ -1,8 +1,19 @@
 """Synthetic IQ for tests and bench (TEST INFRASTRUCTURE): frames built like gr_modem::frame()
 (reference src/gr_modem.cpp:904-961), modulated by the oracle's restatement of the reference
-modulators, passed through a seeded channel (CFO, fractional delay by resampling phase, AWGN) and
-optionally interpolated to the SDR rate like gr_mod_base (gr_mod_base.cpp:249-250) with the RX
-tuning offset applied, so the demodulator's rotator has work to do."""
+modulators, passed through a seeded channel and optionally interpolated to the SDR rate like
+gr_mod_base (gr_mod_base.cpp:249-250) with the RX tuning offset applied, so the demodulator's
+rotator has work to do.
+
+Two channels:
+* the DEFAULT one (what the golden fixtures were made with): CFO + AWGN + an INTEGER lead of zeros;
+* SURVEY 8(d)'s channel, `impair=SPEC` (or any `Impair(...)`): the modulator output is RESAMPLED
+  first -- a fractional delay (0.37 sample) and a clock error (+20 ppm: the transmitter's sample
+  clock runs fast, so the receiver sees a slowly sliding symbol phase) by a 32-tap Kaiser-windowed
+  sinc evaluated per output sample in float64 -- then CFO, then AWGN at a stated Es/N0 (12 dB;
+  Es = signal power x samples per channel symbol, N0 = complex noise variance per sample).
+  This is what exercises the timing loops' stuff / skip and clamp branches (symbol_sync_ff max_dev
+  0.1 gr_demod_2fsk.cpp:106-110, symbol_sync_cc max_dev 8e-4 gr_demod_qpsk.cpp:105-109,
+  clock_recovery_mm_cc gr_demod_bpsk.cpp:51-103) systematically, also across call cuts."""
 import numpy as np
 
 import orc
@@ -34,7 +45,65 @@ def frames(mode, nframes, rng):
     return np.frombuffer(data, np.uint8), payloads
 
 
-def channel(x, fs, cfo, snr_db, amp, rng, lead=0):
+class Impair:
+    """channel impairments beyond CFO / AWGN: fractional delay in samples, clock error in ppm (positive: the transmitter's clock is
+    fast, the received waveform is compressed), Es/N0 in dB (None: the mode's per-sample SNR of MODES)"""
+
+    def __init__(self, frac_delay=0.0, clock_ppm=0.0, esn0_db=None, name=None):
+        self.frac_delay, self.clock_ppm, self.esn0_db = float(frac_delay), float(clock_ppm), esn0_db
+        self.name = name or "delay%.2f_ppm%g_esn0%s" % (frac_delay, clock_ppm, "mode" if esn0_db is None else "%g" % esn0_db)
+
+    def __repr__(self):
+        return self.name
+
+
+SPEC = Impair(0.37, 20.0, 12.0, name="survey8d")            # SURVEY.md 8(d): 0.37 sample, +20 ppm, Es/N0 12 dB
+SPEC_CLEAN = Impair(0.37, 20.0, None, name="survey8d_modesnr")   # same timing, the mode's own SNR
+# Clock errors large enough to drive the timing loops into their limiters -- each one MEASURED with the oracle's limiter-hit counter
+# (orc.loop_clamp_hits, tests/test_channel_8d.py): whether a loop reaches its clamp depends on its bandwidth and on the stream's length
+# (symbol_sync_cc of QPSK-250k: max_dev 8e-4 sample behind a loop bandwidth of 2 pi / 25000 needs > 1e5 symbols; clock_recovery_mm_cc of the
+# BPSK chains: gain_omega 2.5e-5 against a limit of 1e-3 omega needs thousands), so the table carries the frame count too.
+# (sig mode, clock error in ppm, frames per stream, minimum limiter hits of one stream in the oracle)
+CLAMP_CASES = {
+    "2fsk1k": (15000.0, 2, 100), "gmsk10k": (-15000.0, 2, 300), "4fsk2kfm": (-5000.0, 2, 5), "4fsk100k": (-15000.0, 2, 10000),
+    "4fsk2k": (5000.0, 2, 10), "qpsk20k": (15000.0, 2, 30), "qpsk250k": (1000.0, 12, 50000), "bpsk2k": (3000.0, 30, 500),
+    "bpsk1k": (3000.0, 30, 200),
+}
+
+
+def clamp_impair(mode):
+    ppm, nframes, _ = CLAMP_CASES[mode]
+    return Impair(0.37, ppm, None, name="drift%+gppm" % ppm), nframes
+
+
+def resample_clock(x, frac_delay, clock_ppm, half=16, beta=8.0):
+    """y[k] = x((k - frac_delay) * (1 + clock_ppm * 1e-6)): band-limited interpolation with a Kaiser-windowed sinc of 2 * half taps,
+    float64, evaluated per output sample (the test signals occupy a small part of the band, so 32 taps are far below the noise)"""
+    if frac_delay == 0.0 and clock_ppm == 0.0:
+        return np.asarray(x, np.complex128)
+    x = np.asarray(x, np.complex128)
+    r = 1.0 + clock_ppm * 1e-6
+    nout = int(np.floor((x.size - 1) / r + frac_delay))
+    t = (np.arange(nout, dtype=np.float64) - frac_delay) * r
+    i0 = np.floor(t).astype(np.int64)
+    mu = t - i0
+    xp = np.concatenate([np.zeros(half, np.complex128), x, np.zeros(half + 1, np.complex128)])
+    y = np.zeros(nout, np.complex128)
+    wsum = np.zeros(nout, np.float64)
+    from scipy.special import i0 as bessel_i0
+    for k in range(-half + 1, half + 1):
+        d = k - mu                                        # distance of tap k from the interpolation point, in samples
+        w = np.sinc(d) * bessel_i0(beta * np.sqrt(np.clip(1.0 - (d / half) ** 2, 0.0, 1.0)))
+        wsum = wsum + w
+        y += w * xp[i0 + k + half]
+    return y / wsum                                       # unit gain at DC for every fractional offset
+
+
+def channel(x, fs, cfo, snr_db, amp, rng, lead=0, impair=None, samples_per_symbol=None):
+    if impair is not None:
+        x = resample_clock(x, impair.frac_delay, impair.clock_ppm)
+        if impair.esn0_db is not None:
+            snr_db = impair.esn0_db - 10.0 * np.log10(samples_per_symbol)
     n = np.arange(x.size + lead)
     y = np.zeros(x.size + lead, np.complex128)
     y[lead:] = amp * x
@@ -45,13 +114,20 @@ def channel(x, fs, cfo, snr_db, amp, rng, lead=0):
     return y.astype(np.complex64)
 
 
-def make_stream(mode, nframes=4, device_rate=1000000, rx_offset_hz=25000.0, seed=1, amp=0.05, lead=0):
-    """One stream at device_rate.  Returns (iq complex64, payload list)."""
+def samples_per_symbol(mode, nsamples, nbytes):
+    """samples per CHANNEL symbol at 1 Msps: every chain is K = 7 rate 1/2 coded; QPSK and 4FSK carry two coded bits per symbol"""
+    bps = 2 if (mode.startswith("qpsk") or mode.startswith("4fsk")) else 1
+    return nsamples / (8.0 * nbytes) * bps / 2.0
+
+
+def make_stream(mode, nframes=4, device_rate=1000000, rx_offset_hz=25000.0, seed=1, amp=0.05, lead=0, impair=None):
+    """One stream at device_rate.  Returns (iq complex64, payload list).  impair: None = the default channel, or an Impair."""
     rng = np.random.default_rng(seed)
     mod, kw, _, _, cfo, snr = MODES[mode]
     data, payloads = frames(mode, nframes, rng)
     x = mod(data, **kw)
-    y = channel(x, 1e6, cfo + 13.0 * (seed % 7), snr, amp, rng, lead=lead)
+    y = channel(x, 1e6, cfo + 13.0 * (seed % 7), snr, amp, rng, lead=lead, impair=impair,
+                samples_per_symbol=samples_per_symbol(mode, x.size, data.size))
     if device_rate >= 2000000:
         y = orc.tx_interp(y, device_rate)
         n = np.arange(y.size)
@@ -60,8 +136,8 @@ def make_stream(mode, nframes=4, device_rate=1000000, rx_offset_hz=25000.0, seed
     return y, payloads
 
 
-def make_batch(mode, batch, nframes=4, device_rate=1000000, rx_offset_hz=25000.0, seed=1, amp=0.05):
-    streams = [make_stream(mode, nframes, device_rate, rx_offset_hz, seed + 101 * b, amp, lead=37 * b)[0] for b in range(batch)]
+def make_batch(mode, batch, nframes=4, device_rate=1000000, rx_offset_hz=25000.0, seed=1, amp=0.05, impair=None):
+    streams = [make_stream(mode, nframes, device_rate, rx_offset_hz, seed + 101 * b, amp, lead=37 * b, impair=impair)[0] for b in range(batch)]
     n = min(s.size for s in streams) & ~1
     return np.stack([s[:n] for s in streams]).astype(np.complex64)
 

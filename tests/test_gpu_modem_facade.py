@@ -419,3 +419,25 @@ def test_facade_tx_setDMRData(tmp_path):
     w = orc.mod_dmr(s0, zero_runs=tags0)
     lo, hi = (20 * 33 + 1439 - 62 + 60) * 125 // 3, (20 * 33 + 1439 - 62 + 780 - 60) * 125 // 3
     assert np.abs(w[lo:hi]).max() < 1e-3
+
+
+def test_facade_rejected_settings_keep_the_handle_and_tx_setters_serialise(tmp_path):
+    """(1) set_carrier_offset on a TX mode without the back end (M17, DSSS) throws and the modulator keeps running, a rejected set_mode keeps
+    the previous modulator, the re-open of a mode with the back end drops what was queued for the old handle; (2) setDMRData from a second thread while
+    work() runs: every frame's idle zeros are applied (the IQ of 24 frames equals the oracle's gr_mod_dmr with all 24 tags); (3) scope settings the engine
+    rejects restore the previous ones and the demodulator keeps running; (4) a facade built for fewer than 1024 items per call keys CW."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import orc
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qradiolink_amd", "csrc"), "adaptor"])
+    r = subprocess.run([EXE, "robust", str(tmp_path / "dmr.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "robust ok" in r.stdout, r.stdout + r.stderr
+    frames = np.array([[(0x1B + 7 * i + f) & 255 for i in range(33)] for f in range(24)], np.uint8)
+    data = np.concatenate([np.concatenate([fr, np.zeros(39, np.uint8)]) for fr in frames])
+    tags = [(20 * (72 * f + 33), 780) for f in range(24)]
+    got = np.fromfile(tmp_path / "dmr.bin", np.complex64)
+    want = orc.mod_dmr(data, zero_runs=tags)
+    assert got.size == want.size
+    assert np.array_equal((got.view(np.float32) + np.float32(0)).view(np.uint32), (want.view(np.float32) + np.float32(0)).view(np.uint32))

@@ -10,10 +10,10 @@ import sig
 pytestmark = pytest.mark.gpu
 
 
-def _run(qrl_ctx, mode_name, modem, device_rate, offset, B, chunk, nframes=3, seed=3, options=()):
+def _run(qrl_ctx, mode_name, modem, device_rate, offset, B, chunk, nframes=3, seed=3, options=(), impair=None):
     import torch
     import qradiolink_amd as q
-    iq = sig.make_batch(mode_name, B, nframes=nframes, device_rate=device_rate, rx_offset_hz=offset, seed=seed)
+    iq = sig.make_batch(mode_name, B, nframes=nframes, device_rate=device_rate, rx_offset_hz=offset, seed=seed, impair=impair)
     dem = q.Demod(qrl_ctx, modem, batch=B, max_chunk=chunk, device_samp_rate=device_rate, carrier_offset_hz=offset)
     for opt, val in options:
         dem.set_option(opt, val)
@@ -63,7 +63,8 @@ def _compare(iq, out, mode_name, device_rate, offset):
         assert ref["bits_a"].size > 0
 
 
-@pytest.mark.parametrize("mode_name,modem,rate,chunk", [
+# the parity list: every chain family behind every front-end geometry (mode, modem type, device rate, samples per call)
+PARITY_LIST = [
     ("gmsk10k", 22, 1000000, 1 << 20),
     ("gmsk10k", 22, 4000000, 1 << 22),
     ("2fsk1k", 18, 1000000, 1 << 21),
@@ -85,13 +86,56 @@ def _compare(iq, out, mode_name, device_rate, offset):
     ("4fsk100k", 27, 1000000, 1 << 20),     # 1:2 decimation to 500 ksps, 5 samples per symbol
     ("bpsk1k", 24, 1000000, 1 << 21),       # gr_demod_bpsk: FLL(32 taps) -> RRC -> agc2 -> clock_recovery_mm_cc -> costas(2)
     ("bpsk2k", 0, 2000000, 1 << 22),
-])
+]
+
+
+@pytest.mark.parametrize("mode_name,modem,rate,chunk", PARITY_LIST)
 def test_chain_bit_exact_single_call(qrl_ctx, mode_name, modem, rate, chunk):
     offset = 25000.0 if rate >= 2000000 else 1200.0
     iq, out = _run(qrl_ctx, mode_name, modem, rate, offset, B=3, chunk=chunk, nframes=2)
     _compare(iq, out, mode_name, rate, offset)
 
 
+@pytest.mark.parametrize("mode_name,modem,rate,chunk", PARITY_LIST)
+def test_chain_bit_exact_survey_8d_channel(qrl_ctx, mode_name, modem, rate, chunk):
+    """The whole parity list behind SURVEY.md 8(d)'s channel (sig.SPEC: fractional delay 0.37 sample, clock error +20 ppm, Es/N0 12 dB per
+    channel symbol) -- VERDICT r5 "missing" #3: a sliding symbol phase and marginal decisions through symbol_sync_ff (gr_demod_2fsk.cpp:106-110),
+    symbol_sync_cc (gr_demod_qpsk.cpp:105-109) and clock_recovery_mm_cc (gr_demod_bpsk.cpp:51-103).  One call per stream."""
+    offset = 25000.0 if rate >= 2000000 else 1200.0
+    iq, out = _run(qrl_ctx, mode_name, modem, rate, offset, B=3, chunk=chunk, nframes=2, seed=5, impair=sig.SPEC)
+    _compare(iq, out, mode_name, rate, offset)
+
+
+# call cuts under the drifting clock: the recursions carry mu / omega / the interpolator window across calls while the symbol phase slides
+@pytest.mark.parametrize("mode_name,modem,rate,chunk", [
+    ("2fsk1k", 18, 1000000, 50000), ("2fsk1kfm", 16, 1000000, 33334), ("gmsk10k", 22, 1000000, 30000), ("gmsk10k", 22, 25000000, 750000),
+    ("gmsk1k", 21, 2000000, 100002), ("qpsk250k", 26, 1000000, 33334), ("qpsk250k", 26, 100000000, 3000000), ("qpsk2k", 7, 1000000, 60000),
+    ("qpsk20k", 1, 2000000, 100002), ("4fsk2k", 3, 1000000, 50000), ("4fsk2kfm", 5, 1000000, 50000), ("4fsk10kfm", 4, 4000000, 200000),
+    ("4fsk100k", 27, 1000000, 30000), ("bpsk1k", 24, 1000000, 65536), ("bpsk2k", 0, 2000000, 100002),
+])
+def test_chain_bit_exact_survey_8d_channel_cut_into_calls(qrl_ctx, mode_name, modem, rate, chunk):
+    offset = 25000.0 if rate >= 2000000 else 1200.0
+    iq, out = _run(qrl_ctx, mode_name, modem, rate, offset, B=2, chunk=chunk, nframes=2, seed=6, impair=sig.SPEC)
+    _compare(iq, out, mode_name, rate, offset)
+
+
+# clock errors past the loops' clamps (sig.CLAMP_CASES, each measured with the oracle's limiter-hit counter in tests/test_channel_8d.py):
+# symbol_sync_cc max_dev 8e-4 of 2 samples per symbol (QPSK-250k: 400 ppm; the narrow loop needs 1e5 symbols to get there, hence 12 frames),
+# symbol_sync_ff max_dev 0.1 sample of 10 (1 %), clock_recovery_mm_cc's omega limit 1e-3 relative (30 frames); the loop sits in its limiter
+# and the interpolator slips symbols -- same bits, same floats as the oracle, in one call and cut into calls
+@pytest.mark.parametrize("mode_name,modem,rate,chunk", [
+    ("qpsk250k", 26, 1000000, 1 << 20), ("qpsk250k", 26, 1000000, 33334), ("qpsk250k", 26, 10000000, 333340),
+    ("qpsk20k", 1, 1000000, 60000), ("4fsk2k", 3, 1000000, 50000),
+    ("2fsk1k", 18, 1000000, 1 << 21), ("2fsk1k", 18, 1000000, 50000),
+    ("gmsk10k", 22, 1000000, 30000), ("gmsk10k", 22, 25000000, 750000),
+    ("4fsk2kfm", 5, 1000000, 50000), ("4fsk100k", 27, 1000000, 30000),
+    ("bpsk1k", 24, 1000000, 1 << 21), ("bpsk2k", 0, 1000000, 200000),
+])
+def test_chain_bit_exact_clock_error_past_the_loop_clamp(qrl_ctx, mode_name, modem, rate, chunk):
+    offset = 25000.0 if rate >= 2000000 else 1200.0
+    impair, nframes = sig.clamp_impair(mode_name)
+    iq, out = _run(qrl_ctx, mode_name, modem, rate, offset, B=2, chunk=chunk, nframes=nframes, seed=8, impair=impair)
+    _compare(iq, out, mode_name, rate, offset)
 @pytest.mark.parametrize("mode_name,modem,chunk", [("2fsk1k", 18, 1 << 21), ("2fsk1k", 18, 50000), ("bpsk1k", 24, 1 << 21), ("bpsk1k", 24, 65536),
                                                    ("qpsk2k", 7, 60000)])
 def test_fll_slim_geometry_bit_exact(qrl_ctx, mode_name, modem, chunk):

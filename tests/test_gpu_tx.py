@@ -669,6 +669,18 @@ def test_cw_modulator_bit_exact(qrl_ctx):
         for b in range(2):
             assert np.array_equal((got[b].view(np.float32) + np.float32(0)).view(np.uint32), (want.view(np.float32) + np.float32(0)).view(np.uint32)), (width, b)
         mod.close()
+    # qrl_amod_set_filter_width in the MIDDLE of a transmission: the chain restarts, the key's sig_source_f keeps running -- what follows
+    # equals the oracle's chain (setter designs) over the tone from sample 1500 on
+    mod = q.AMod(qrl_ctx, q.MODEM_CW600USB, batch=2, max_samples=3000)
+    mod.set_cw_k(True)
+    mod.process_cw(1500)
+    mod.set_filter_width(800)
+    got = np.concatenate([mod.process_cw(n).cpu().numpy() for n in (2500, 1024, 168)], axis=1)
+    want = orc.mod_ssb(orc.sig_source_sin(8000, 600, 0.98, 2500 + 1024 + 168, k0=1500, offset=1.0), sb=0, filter_width=1000, set_width=800)
+    assert got.shape[1] == want.size > 0
+    for b in range(2):
+        assert np.array_equal((got[b].view(np.float32) + np.float32(0)).view(np.uint32), (want.view(np.float32) + np.float32(0)).view(np.uint32)), b
+    mod.close()
     # key down: a carrier 600 Hz above the suppressed carrier (the cessb stretcher holds a full-scale tone at ~ 0.09); key up: the 0.001 tone at the chain's
     # small-signal gain 0.42, > 40 dB below
     x = _cw_reference([(8192, True)])
