@@ -421,6 +421,10 @@ int qrl_framesync_reset(qrl_framesync* f);
 int qrl_framesync_frame_bytes(const qrl_framesync* f);   /* _rx_frame_length of the mode */
 int qrl_framesync_process(qrl_framesync* f, const uint8_t* bits, size_t stride, size_t n, const uint32_t* counts, size_t count_stride,
                           uint8_t* out, size_t out_cap, uint32_t* out_counts);
+/* Optional: activity[b] (device, [batch]) receives with every qrl_framesync_process call the number of bits of stream b that were collected into a
+ * frame while a sync was held -- non-zero exactly when gr_modem::synchronize would return data_to_process = true for the bits of this call
+ * (src/gr_modem.cpp:1121-1175: "RX active", what radiocontroller.cpp:1298 polls through gr_modem::demodulate()).  NULL switches it off. */
+int qrl_framesync_set_activity_output(qrl_framesync* f, uint32_t* activity);
 int qrl_framesync_sync(qrl_framesync* f);
 
 /* ---- RSSI side output (reference src/gr/rssi_block.cpp:25-50; wired src/gr/gr_demod_base.cpp:199-200: port 0 of the current

@@ -165,6 +165,7 @@ size_t orc_mod_bpsk(const uint8_t* bytes, size_t nbytes, int sps, int samp_rate,
 size_t orc_clock_recovery_mm_cc(const cf32* in, size_t n, float omega, float gain_omega, float mu, float gain_mu,
                                 float omega_relative_limit, cf32* out);
 int orc_modem_sync_geometry(int modem_type, int* bit_buf_len, int* frame_length);
+size_t orc_modem_sync_collected(void);   /* of the last orc_modem_sync call on this thread's library state (tests are single threaded) */
 size_t orc_modem_sync(int modem_type, const uint8_t* bits, size_t n, uint32_t st[5], uint8_t* bitbuf, uint8_t* out);
 size_t orc_deframer(int type, const uint8_t* bits, size_t n, uint32_t st[3], uint8_t* out);
 size_t orc_rssi_tag(const cf32* in, size_t n, float calibration, float* db);

@@ -970,9 +970,14 @@ static uint32_t modem_find_sync(int cls, uint32_t reg)
     if (t24 == 0xDE98AA || t24 == 0x98DEAA || t24 == 0x4C8A2B) return t24;                        /* IP, Video, End */
     return 0;
 }
+/* bits the last orc_modem_sync call collected into a frame while a sync was held: > 0 <=> gr_modem::synchronize returned data_to_process = true
+ * (src/gr_modem.cpp:1121-1175); pinned against the reference's own gr_modem::demodulate() return value in tests/test_ref_modem.py */
+static size_t g_modem_sync_collected = 0;
+size_t orc_modem_sync_collected(void) { return g_modem_sync_collected; }
 size_t orc_modem_sync(int modem_type, const uint8_t* bits, size_t n, uint32_t st[5], uint8_t* bitbuf, uint8_t* out)
 {
     int bit_buf_len0, frame_length0;
+    g_modem_sync_collected = 0;
     const int cls = orc_modem_sync_geometry(modem_type, &bit_buf_len0, &frame_length0);
     size_t no = 0;
     for (size_t i = 0; i < n; i++) {
@@ -988,6 +993,7 @@ size_t orc_modem_sync(int modem_type, const uint8_t* bits, size_t n, uint32_t st
         }
         if (st[1]) {
             bitbuf[st[2]++] = bits[i] & 1u;
+            g_modem_sync_collected++;
             int frame_length = frame_length0, bit_buf_len = bit_buf_len0;
             if ((cls == 1 || cls == 2) && st[3] == 0xED89) frame_length++;          /* reserved byte of voice frames */
             else if (cls == 1 || cls == 2) bit_buf_len = bit_buf_len0 - 8;

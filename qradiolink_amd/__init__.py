@@ -211,6 +211,7 @@ def load_library():
     lib.qrl_framesync_frame_bytes.argtypes = [vp]
     lib.qrl_framesync_process.argtypes = [vp, vp, sz, sz, vp, sz, vp, sz, vp]
     lib.qrl_framesync_sync.argtypes = [vp]
+    lib.qrl_framesync_set_activity_output.argtypes = [vp, vp]
     lib.qrl_firdes_low_pass.argtypes = [C.c_double] * 4 + [C.c_int, vp]
     lib.qrl_firdes_low_pass_2.argtypes = [C.c_double] * 5 + [C.c_int, vp]
     lib.qrl_firdes_complex_band_pass.argtypes = [C.c_double] * 5 + [C.c_int, vp]
@@ -240,7 +241,7 @@ EXPORTED_SYMBOLS = [
     "qrl_fft_get_window_type", "qrl_fft_process", "qrl_fft_get_fft_data", "qrl_fft_sync", "qrl_fft_stream",
     "qrl_deframer_create", "qrl_deframer_destroy", "qrl_deframer_reset", "qrl_deframer_process", "qrl_deframer_sync",
     "qrl_framesync_create", "qrl_framesync_destroy", "qrl_framesync_reset", "qrl_framesync_frame_bytes", "qrl_framesync_process",
-    "qrl_framesync_sync",
+    "qrl_framesync_sync", "qrl_framesync_set_activity_output",
     "qrl_firdes_low_pass",
     "qrl_firdes_low_pass_2", "qrl_firdes_complex_band_pass", "qrl_firdes_root_raised_cosine", "qrl_table_mmse",
     "qrl_table_atan", "qrl_table_tanh", "qrl_phase_inc_to_turn",
@@ -772,6 +773,9 @@ class FrameSync:
         self.frame_bytes = self.lib.qrl_framesync_frame_bytes(self.h)
         self.out = None
         self.out_counts = torch.zeros((batch, 2), dtype=torch.int32, device="cuda:%d" % ctx.device)
+        # bits collected into a frame while a sync was held, per call: > 0 <=> gr_modem::synchronize's data_to_process (src/gr_modem.cpp:1121-1175)
+        self.activity = torch.zeros((batch,), dtype=torch.int32, device="cuda:%d" % ctx.device)
+        _check(self.lib.qrl_framesync_set_activity_output(self.h, self.activity.data_ptr()), "qrl_framesync_set_activity_output")
 
     def process(self, bits, counts=None, count_stride=1, n=None):
         t = self.torch

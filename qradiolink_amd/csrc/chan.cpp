@@ -137,7 +137,12 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     const int M = h->M = (h->xlat || h->xlat2) ? 1 : c.num_channels;   // M = samples consumed per channel-rate instant of the PFB form
     HIPCHK(hipSetDevice(ctx->device));
     if (c.hip_stream) h->stream = static_cast<hipStream_t>(c.hip_stream);
-    else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    else {
+        int r0;
+        if (std::getenv("QRL_CU_CHAN_MAIN")) { if ((r0 = qrl::create_role_stream(&h->stream, 0, "CHAN_MAIN"))) return r0; }
+        else HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
     int r;
     // prototype: low_pass_2(1, fs, 5000, 2000, 60, BH), fs = 25 kHz * M (gr_demod_mmdvm_multi2.cpp:58-60; 250 ksps for M = 10)
     // _filter_width of the reference factories (gr_demod_mmdvm_multi2.cpp:47,58-63; gr_demod_mmdvm.cpp:40-52); 0 = their default call site value
@@ -242,7 +247,7 @@ int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** outp)
     if (can_overlap) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        HIPCHK(hipStreamCreateWithPriority(&h->mid, hipStreamNonBlocking, lo));   // a priority of its own (never the hardware queue of the main or the symbol-sync stream), and BELOW the channelizer's:
+        { int r0; if ((r0 = qrl::create_role_stream(&h->mid, lo, "CHAN_MID"))) return r0; }   // a priority of its own (never the hardware queue of the main or the symbol-sync stream), and BELOW the channelizer's:
                                                                                   // the persistent channelizer workgroups of call k + 1 are placed as the tail of call k drains
         HIPCHK(hipEventCreateWithFlags(&h->ev_pfb, hipEventDisableTiming));
         for (auto& e : h->ev_mid) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -308,7 +313,7 @@ int qrl_chan_set_4fsk_output(qrl_chan* h, uint8_t* bits, size_t bits_cap, float*
         if (!h->tail) {
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            HIPCHK(hipStreamCreateWithPriority(&h->tail, hipStreamNonBlocking, hi));   // a priority of its own: never the hardware queue of the main stream (engine.cpp, stream creation)
+            { int r0; if ((r0 = qrl::create_role_stream(&h->tail, hi, "CHAN_TAIL"))) return r0; }   // a priority of its own: never the hardware queue of the main stream (engine.cpp, stream creation)
             HIPCHK(hipEventCreateWithFlags(&h->ev_ff, hipEventDisableTiming));
             for (auto& e : h->ev_tail) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }

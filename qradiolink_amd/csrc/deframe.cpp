@@ -79,7 +79,7 @@ int qrl_deframer_sync(qrl_deframer* h)
 struct qrl_framesync {
     qrl_ctx* ctx = nullptr; int batch = 1, cls = 2; uint32_t bit_buf_len = 64, frame_length = 7;
     hipStream_t stream = nullptr; bool own_stream = false;
-    FrameSyncState* st = nullptr; uint8_t* bitbuf = nullptr; size_t bitbuf_stride = 0;
+    FrameSyncState* st = nullptr; uint8_t* bitbuf = nullptr; size_t bitbuf_stride = 0; uint32_t* activity = nullptr;
     ~qrl_framesync() {
         if (st) (void)hipFree(st);
         if (bitbuf) (void)hipFree(bitbuf);
@@ -140,9 +140,15 @@ int qrl_framesync_process(qrl_framesync* h, const uint8_t* bits, size_t stride, 
     p.bits = bits; p.stride = stride; p.n = (uint32_t)n; p.counts = counts; p.count_stride = count_stride;
     p.cls = h->cls; p.bit_buf_len = h->bit_buf_len; p.frame_length = h->frame_length;
     p.st = h->st; p.bitbuf = h->bitbuf; p.bitbuf_stride = h->bitbuf_stride;
-    p.out = out; p.out_cap = out_cap; p.out_counts = out_counts;
+    p.out = out; p.out_cap = out_cap; p.out_counts = out_counts; p.activity = h->activity;
     launch_framesync(p, h->batch, h->stream);
     HIPCHK(hipGetLastError());
+    return QRL_OK;
+}
+int qrl_framesync_set_activity_output(qrl_framesync* h, uint32_t* activity)
+{
+    if (!h) return QRL_ERR_ARG;
+    h->activity = activity;
     return QRL_OK;
 }
 int qrl_framesync_sync(qrl_framesync* h)

@@ -42,6 +42,21 @@ hipError_t dyn_lds_limit(const void* kernel, int bytes)
     return e;
 }
 bool take_launch_error() { const bool r = t_launch_error; t_launch_error = false; return r; }
+int create_role_stream(hipStream_t* s, int priority, const char* role)
+{
+    const char* e = role ? std::getenv((std::string("QRL_CU_") + role).c_str()) : nullptr;
+    int first = 0, count = 0;
+    hipError_t err;
+    if (e && std::sscanf(e, "%d:%d", &first, &count) == 2 && first >= 0 && count > 0 && first + count <= 32) {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 256 CUs
+        for (int b = 8 * first; b < 8 * (first + count); ++b) mask[b >> 5] |= 1u << (b & 31);
+        err = hipExtStreamCreateWithCUMask(s, 8, mask);
+    } else {
+        err = hipStreamCreateWithPriority(s, hipStreamNonBlocking, priority);
+    }
+    if (err != hipSuccess) { qrl_set_error(QRL_ERR_HIP, std::string("stream creation: ") + hipGetErrorString(err)); return QRL_ERR_HIP; }
+    return QRL_OK;
+}
 }  // namespace qrl
 
 #define HIPCHK(expr)                                                                              \
@@ -1187,7 +1202,12 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
     // retiring front-end workgroup.  (Reserving CUs for it with a CU mask was measured: it costs the front end ~18 %.)
     {
         if (c.hip_stream) d->stream = static_cast<hipStream_t>(c.hip_stream);
-        else { HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)); d->own_stream = true; }
+        else {
+            int r0;
+            if (std::getenv("QRL_CU_MAIN")) { if ((r0 = create_role_stream(&d->stream, 0, "MAIN"))) return r0; }
+            else HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+            d->own_stream = true;
+        }
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         // THREE DIFFERENT PRIORITIES, and not for the scheduling: the runtime multiplexes the streams of one priority onto a few hardware
@@ -1195,8 +1215,8 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         // the overlapped and grouped orders then silently degrade to the serial one (seen as C4 4.5 instead of 3.05 ms and C2 2.2 instead
         // of 1.78 ms per step in the sub-lines of a long bench process, depending on how many streams the process had created and
         // destroyed before: tools/experiments/r04_subline_order*.py).  Queues of different priorities are never shared.
-        HIPCHK(hipStreamCreateWithPriority(&d->tail, hipStreamNonBlocking, hi));
-        HIPCHK(hipStreamCreateWithPriority(&d->fecs, hipStreamNonBlocking, lo));
+        int r1;
+        if ((r1 = create_role_stream(&d->tail, hi, "TAIL")) || (r1 = create_role_stream(&d->fecs, lo, "FEC"))) return r1;
     }
     HIPCHK(hipEventCreateWithFlags(&d->ev_ff, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&d->ev_tail, hipEventDisableTiming));

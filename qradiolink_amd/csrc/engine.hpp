@@ -16,6 +16,13 @@ hipError_t dyn_lds_limit(const void* kernel, int bytes);
 // ends with take_launch_error() and turns it into QRL_ERR_HIP.
 bool take_launch_error();
 
+// A handle-internal stream, optionally confined to a set of compute units (round 6, VERDICT r5 #4: partition the chip in SPACE).
+// QRL_CU_<ROLE>="first:count" (CUs PER XCD, 32 each on MI355X) turns the stream of that role into a CU-masked one
+// (hipExtStreamCreateWithCUMask); unset = hipStreamCreateWithPriority as before.  Mask bit i = CU (i / 8) of XCD (i % 8): the driver
+// deals the bits of a queue's mask round-robin over the XCDs, so a per-XCD range [first, first + count) is bits 8 * first ... 8 * (first + count) - 1.
+// A masked stream has a hardware queue of its own (the mask is a queue property), so it cannot share one with another stream of the handle.
+int create_role_stream(hipStream_t* s, int priority, const char* role);
+
 struct RingC { float2* p; uint32_t mask; };   // complex ring, stream stride = mask+1 items
 struct RingF { float* p; uint32_t mask; };
 struct RingB { uint8_t* p; uint32_t mask; };
@@ -204,6 +211,7 @@ struct FrameSyncParams {
     int cls; uint32_t bit_buf_len, frame_length;           // sync-word class (0: 1k modes, 1: fast modes, 2: rest), mode table
     FrameSyncState* st; uint8_t* bitbuf; size_t bitbuf_stride;
     uint8_t* out; size_t out_cap; uint32_t* out_counts;    // records; out_counts[2b] = bytes, [2b + 1] = frames
+    uint32_t* activity;                                    // optional [batch]: bits collected into a frame while a sync was held, this call
 };
 void launch_framesync(const FrameSyncParams& p, int batch, hipStream_t s);
 

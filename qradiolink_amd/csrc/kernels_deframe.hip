@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void k_framesync(const FrameSyncParams P)
     uint8_t* out = P.out + (size_t)b * P.out_cap;
     uint8_t* bitbuf = P.bitbuf + (size_t)b * P.bitbuf_stride;
     FrameSyncState st = P.st[b];
-    uint32_t i = 0, no = 0, nframes = 0;
+    uint32_t i = 0, no = 0, nframes = 0, collected = 0;
     // bits of the open frame: [0, carry) sit in bitbuf (written by EARLIER launches), the rest is in[fstart ...] of this call;
     // nothing written in this launch is read back in it (no reliance on L1 coherence between lanes)
     uint32_t carry = st.found ? st.idx : 0u, fstart = 0u;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64) void k_framesync(const FrameSyncParams P)
             const uint32_t need = (adj && !voice) ? P.bit_buf_len - 8u : P.bit_buf_len;
             const uint32_t flen = voice ? P.frame_length + 1u : P.frame_length;
             const uint32_t take = min(n - i, need - st.idx);
-            i += take; st.idx += take;
+            i += take; st.idx += take; collected += take;
             if (st.idx >= need) {
                 const uint32_t padded = (flen + 3u) & ~3u;
                 if (no + 8u + padded <= P.out_cap) {
@@ -158,6 +158,7 @@ __global__ __launch_bounds__(64) void k_framesync(const FrameSyncParams P)
         P.st[b] = st;
         P.out_counts[2 * b] = no;
         P.out_counts[2 * b + 1] = nframes;
+        if (P.activity) P.activity[b] = collected;   // > 0 <=> gr_modem::synchronize returns data_to_process = true for these bits (src/gr_modem.cpp:1121-1175)
     }
 }
 void launch_framesync(const FrameSyncParams& p, int batch, hipStream_t s)

@@ -170,7 +170,12 @@ int qrl_mod_create(qrl_ctx* ctx, const qrl_mod_config* cfg, qrl_mod** outp)
     m->bb_gain = c.bb_gain == 0.0f ? 1.0f : c.bb_gain;
     HIPCHK(hipSetDevice(ctx->device));
     if (c.hip_stream) m->stream = static_cast<hipStream_t>(c.hip_stream);
-    else { HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
+    else {
+        int r0;
+        if (std::getenv("QRL_CU_TX")) { if ((r0 = qrl::create_role_stream(&m->stream, 0, "TX"))) return r0; }
+        else HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+        m->own_stream = true;
+    }
     auto upload = [](const std::vector<float>& v, float** dst) -> int {   // followed by 64 zeros: k_tx_interp_sym reads its I x J = 64 taps unguarded
         const size_t bytes = (v.size() + 64) * sizeof(float);
         if (hipMalloc(reinterpret_cast<void**>(dst), bytes) != hipSuccess) return QRL_ERR_NOMEM;

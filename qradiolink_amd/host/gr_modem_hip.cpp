@@ -80,6 +80,7 @@ gr_demod_base_hip::gr_demod_base_hip(qrl_runtime& rt, int streams, int device_sa
       d_boxa(streams), d_box1(streams), d_box2(streams), d_boxc(streams), d_boxd(streams)
 {
     d_boxf[0].resize(streams); d_boxf[1].resize(streams); d_boxs.resize(streams);
+    for (int k = 0; k < 2; ++k) { d_fbits[k].assign(streams, 0); d_fact[k].assign(streams, 0); }
     if (streams < 1 || d_chunk < 2) throw std::invalid_argument("gr_demod_base_hip: streams >= 1, max_chunk >= 2");
     hipStream_t s;
     // lowest priority -- not for the scheduling: streams of one priority share a few hardware queues, and a wait queued on this
@@ -165,9 +166,9 @@ void gr_demod_base_hip::open()
         hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_scnt), N * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
         if (fs_on) for (int k = 0; k < 2; ++k) {
             hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_fr[k]), N * d_frcap), "hipMalloc");
-            hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_frcnt[k]), N * 2 * sizeof(uint32_t)), "hipMalloc");
+            hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_frcnt[k]), N * 3 * sizeof(uint32_t)), "hipMalloc");   // [2 N]: bytes, frames; [N]: bits collected under a sync
             hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_fr[k]), N * d_frcap, hipHostMallocDefault), "hipHostMalloc");
-            hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_frcnt[k]), N * 2 * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
+            hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_frcnt[k]), N * 3 * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
         }
         hchk(hipMalloc(reinterpret_cast<void**>(&sp->d_rssi), N * sizeof(float)), "hipMalloc");
         hchk(hipHostMalloc(reinterpret_cast<void**>(&sp->h_rssi), N * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
@@ -209,12 +210,28 @@ void gr_demod_base_hip::set_mode(int mode)   // gr_demod_base::set_mode (src/gr/
         throw std::invalid_argument(std::string("gr_demod_base_hip::set_mode: time-domain settings rejected and reset to the defaults (the mode is open): ") + e.what());
     }
     std::lock_guard<std::mutex> g(d_mutex);
-    for (int s = 0; s < d_n; ++s) { d_box1[s].clear(); d_box2[s].clear(); d_boxc[s].clear(); d_boxd[s].clear(); d_boxa[s].clear(); d_boxf[0][s].clear(); d_boxf[1][s].clear(); d_boxs[s].clear(); }
+    for (int s = 0; s < d_n; ++s) { d_box1[s].clear(); d_box2[s].clear(); d_boxc[s].clear(); d_boxd[s].clear(); d_boxa[s].clear(); d_boxf[0][s].clear(); d_boxf[1][s].clear(); d_boxs[s].clear(); d_fbits[0][s] = d_fbits[1][s] = d_fact[0][s] = d_fact[1][s] = 0; }
 }
 void gr_demod_base_hip::enable_device_framing(bool value)
 {
     std::lock_guard<std::recursive_mutex> hg(d_hmutex);
     d_want_fs = value;
+}
+bool gr_demod_base_hip::takeFrames(int nr, int stream, std::vector<frame_record>& frames, size_t& bits, size_t& collected)
+{
+    std::lock_guard<std::mutex> g(d_mutex);
+    const int k = nr == 2 ? 1 : 0;
+    bits = d_fbits[k][stream]; collected = d_fact[k][stream];
+    if (bits < 32) return false;   // gr_bit_sink::get_data (src/gr/gr_bit_sink.cpp:45-59): nothing below 32 bits, and nothing is consumed
+    frames.clear();
+    frames.swap(d_boxf[k][stream]);
+    d_fbits[k][stream] = 0; d_fact[k][stream] = 0;
+    return true;
+}
+size_t gr_demod_base_hip::peekFrameBits(int nr, int stream)
+{
+    std::lock_guard<std::mutex> g(d_mutex);
+    return d_fbits[nr == 2 ? 1 : 0][stream];
 }
 std::vector<gr_demod_base_hip::frame_record> gr_demod_base_hip::getFrames(int nr, int stream)
 {
@@ -278,10 +295,11 @@ void gr_demod_base_hip::work(const gr_complex* const* iq, size_t n)
     if (sl.framed) {
         // the frame synchronisers run on the copy stream behind the demodulator (no host synchronisation in between): bits A / B of
         // this call -> records { type, nbytes | _modem_sync << 16, payload }; only those travel to the host
+        for (int k = 0; k < 2; ++k) chk(qrl_framesync_set_activity_output(d_fs[k], sl.d_frcnt[k] + 2 * N), "qrl_framesync_set_activity_output");
         chk(qrl_framesync_process(d_fs[0], sl.d_a, d_bcap, d_bcap, sl.d_cnt + 2, 4, sl.d_fr[0], d_frcap, sl.d_frcnt[0]), "qrl_framesync_process");
         chk(qrl_framesync_process(d_fs[1], sl.d_b, d_bcap, d_bcap, sl.d_cnt + 3, 4, sl.d_fr[1], d_frcap, sl.d_frcnt[1]), "qrl_framesync_process");
         for (int k = 0; k < 2; ++k) {
-            hchk(hipMemcpyAsync(sl.h_frcnt[k], sl.d_frcnt[k], N * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, cs), "D2H");
+            hchk(hipMemcpyAsync(sl.h_frcnt[k], sl.d_frcnt[k], N * 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, cs), "D2H");
             hchk(hipMemcpyAsync(sl.h_fr[k], sl.d_fr[k], N * d_frcap, hipMemcpyDeviceToHost, cs), "D2H");
         }
     }
@@ -333,6 +351,8 @@ void gr_demod_base_hip::harvest(int which)
             if (d_box2[s].size() <= 1048576) d_box2[s].insert(d_box2[s].end(), sl.h_b + (size_t)s * d_bcap, sl.h_b + (size_t)s * d_bcap + c[3]);
         }
         if (sl.framed) for (int k = 0; k < 2; ++k) {   // the records of this call, in order
+            d_fbits[k][s] += c[2 + k];
+            d_fact[k][s] += sl.h_frcnt[k][2 * (size_t)d_n + s];
             const uint8_t* p = sl.h_fr[k] + (size_t)s * d_frcap;
             const uint32_t nbytes = std::min<uint32_t>(sl.h_frcnt[k][2 * s], (uint32_t)d_frcap);
             for (uint32_t pos = 0; pos + 8 <= nbytes;) {
@@ -816,19 +836,25 @@ bool gr_modem_hip::demodulate(int stream)   // gr_modem.cpp:1019-1117
         // gr_modem::synchronize would have cut out of the bit stream, with _modem_sync as it stood when each frame completed.
         // Same dispatch as the host loop (processReceivedData, :1285-1441); two-branch modes: branch A's frames, then branch B's
         // (BranchRuleReference: branch A only -- the `>=` rule of :1080-1090 with equal counts).
-        bool any = false;
-        for (int k = 0; k < ((two && _branch_rule == BranchRuleBoth) ? 2 : 1); ++k) {
-            std::vector<gr_demod_base_hip::frame_record> recs = _gr_demod_base->getFrames(k + 1, stream);
+        // Return value = the reference's: getData() hands out nothing below 32 bits -- then demodulate() returns false and consumes
+        // nothing (:1057-1071; two-branch modes need both vectors) -- else synchronize()'s data_to_process: true iff a bit of this batch was collected
+        // while a sync was held (:1121-1175), which k_framesync counts per call (qrl_framesync_set_activity_output).
+        if (_gr_demod_base->peekFrameBits(1, stream) < 32 || (two && _gr_demod_base->peekFrameBits(2, stream) < 32)) return false;
+        bool data_to_process = false;
+        for (int k = 0; k < (two ? 2 : 1); ++k) {
+            std::vector<gr_demod_base_hip::frame_record> recs;
+            size_t bits = 0, collected = 0;
+            if (!_gr_demod_base->takeFrames(k + 1, stream, recs, bits, collected)) continue;
+            if (k == 1 && _branch_rule != BranchRuleBoth) continue;   // BranchRuleReference: branch B's vector is fetched and dropped
             rx_state& r = _rx[2 * (size_t)stream + (size_t)k];
+            data_to_process = data_to_process || collected > 0;
             for (auto& f : recs) {
-                any = true;
                 r.modem_sync = (int)f.modem_sync;
                 r.current_frame_type = f.type;
                 processReceivedData(f.payload.data(), f.type, r, stream);
             }
         }
-        if (two && _branch_rule != BranchRuleBoth) (void)_gr_demod_base->getFrames(2, stream);
-        return any;
+        return data_to_process;
     }
     std::vector<unsigned char>*demod_data = nullptr, *demod_data2 = nullptr;
     if (two) {

@@ -72,15 +72,18 @@ int main(int argc, char** argv)
                 throw std::runtime_error(std::string(what) + ": expected an exception");
             };
             {   // TX: set_carrier_offset on modes without the back end keeps the modulator and its offset
+                for (int mode : {QRL_MODEM_M17, QRL_MODEM_BPSK8}) {
+                    const size_t maxb = mode == QRL_MODEM_M17 ? 96 : 3;   // (DSSS makes 1 000 000 samples per byte)
+                    gr_mod_base_hip m2(rt, 1, 1000000, 0.0, maxb);
+                    std::vector<gr_complex> b2(mode == QRL_MODEM_M17 ? 96 / 3 * 2500 + 2500 : 4 * 1000000); gr_complex* p2[1] = {b2.data()};
+                    m2.set_mode(mode);
+                    expect_throw("tx offset without back end", [&] { m2.set_carrier_offset(12500.0); });
+                    m2.set_data(new std::vector<uint8_t>(maxb == 96 ? 48 : 3, 0x5A));
+                    if (m2.work(p2) == 0) throw std::runtime_error("modulator lost after a rejected set_carrier_offset");
+                    m2.set_mode(mode);   // and set_mode still works (the offset did not stick)
+                }
                 gr_mod_base_hip mod(rt, 1, 1000000, 0.0, 96);
                 std::vector<gr_complex> buf(96 * 2500 + 2500); gr_complex* ptr[1] = {buf.data()};
-                for (int mode : {QRL_MODEM_M17, QRL_MODEM_BPSK8}) {
-                    mod.set_mode(mode);
-                    expect_throw("tx offset without back end", [&] { mod.set_carrier_offset(12500.0); });
-                    mod.set_data(new std::vector<uint8_t>(48, 0x5A));
-                    if (mod.work(ptr) == 0) throw std::runtime_error("modulator lost after a rejected set_carrier_offset");
-                    mod.set_mode(mode);   // and set_mode still works (the offset did not stick)
-                }
                 // a mode WITH the back end: the first non-zero offset re-opens the handle with the rotator; queued bytes of the old handle are dropped
                 mod.set_mode(QRL_MODEM_GMSK10K);
                 mod.set_data(new std::vector<uint8_t>(10, 0x33));
@@ -506,7 +509,9 @@ int main(int argc, char** argv)
             for (;;) {
                 if (tap) std::fprintf(tap, "D %d\n", s);
                 if (tap && !host_loop) { delete demod.getData(1, s); if (two) delete demod.getData(2, s); }   // logs the "B" lines of this poll
-                if (!modem.demodulate(s)) break;
+                const bool active = modem.demodulate(s);
+                if (tap) std::fprintf(tap, "R %d %d\n", s, active ? 1 : 0);   // the return value radiocontroller.cpp:1298 polls
+                if (!active) break;
             }
         };
         modem.toggleTxMode(mode);

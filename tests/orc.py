@@ -105,6 +105,7 @@ _sig("orc_mod_bpsk", _sz, _p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, _p)
 _sig("orc_clock_recovery_mm_cc", _sz, _p, _sz, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p)
 _sig("orc_modem_sync", _sz, C.c_int, _p, _sz, _p, _p, _p)
 _sig("orc_modem_sync_geometry", C.c_int, C.c_int, _p, _p)
+_sig("orc_modem_sync_collected", _sz)
 _sig("orc_deframer", _sz, C.c_int, _p, _sz, _p, _p)
 _sig("orc_rssi_tag", _sz, _p, _sz, C.c_float, _p)
 _sig("orc_demod_mmdvm", _sz, _p, _sz, C.c_int, C.c_int, _p, _sz, _p, C.c_float, _p)
@@ -389,6 +390,7 @@ class ModemSync:
         bits = np.ascontiguousarray(bits, np.uint8)
         out = np.zeros(2 * bits.size + 4096, np.uint8)
         n = lib.orc_modem_sync(self.modem_type, _ptr(bits), bits.size, _ptr(self.st), _ptr(self.bitbuf), _ptr(out))
+        self.collected = int(lib.orc_modem_sync_collected())   # > 0 <=> gr_modem::synchronize's data_to_process for these bits
         return out[:n].copy()
 
     def feed(self, bits):

@@ -128,10 +128,12 @@ def test_framesync_bit_exact(qrl_ctx, modem, ncuts):
     want = [[] for _ in range(B)]
     for a, e in zip(edges[:-1], edges[1:]):
         out, oc = fs.process(d[:, a:e].contiguous())
-        out, oc = out.cpu().numpy(), oc.cpu().numpy()
+        out, oc, act = out.cpu().numpy(), oc.cpu().numpy(), fs.activity.cpu().numpy()
         for b in range(B):
             got[b].append(out[b, :oc[b, 0]].copy())
             want[b].append(refs[b].feed_raw(data[b, a:e]))
+            # qrl_framesync_set_activity_output: the bits collected while a sync was held in THIS call (gr_modem::synchronize's return value)
+            assert int(act[b]) == refs[b].collected, (b, a, e)
     fs.close()
     total = 0
     for b in range(B):

@@ -231,15 +231,19 @@ def test_facade_rx_events_equal_the_reference_gr_modem(tmp_path, mode, streams, 
     buf = C.create_string_buffer(1 << 22)
     state = {"pending": None}        # (stream, {nr: bits}) of the demodulate() call being replayed
 
+    returns = {"facade": [], "reference": []}
+
     def run(m, s):
-        L.ref_modem_demodulate(m)
+        r = L.ref_modem_demodulate(m)
         n = L.ref_modem_events(m, buf, len(buf))
         reference[s] += buf.raw[:n].decode("latin-1").splitlines()
+        state["ret"] = state.get("ret", 0) | (1 if r else 0)
 
     def flush():
         if state["pending"] is None:
             return
         s, vec = state["pending"]
+        state["pending"] = None
         if two and len(vec) == 2:
             for k, nr in enumerate((1, 2)):
                 raw = bytes(int(c) for c in vec[nr])
@@ -257,6 +261,13 @@ def test_facade_rx_events_equal_the_reference_gr_modem(tmp_path, mode, streams, 
         if kind == "D":
             flush()
             state["pending"] = (s, {})
+            state["ret"] = 0
+        elif kind == "R":
+            # demodulate()'s return value: the reference's gr_modem::demodulate() on the same vectors -- false when getData() had
+            # nothing (no vector was handed out), else synchronize()'s data_to_process; two-branch modes: either branch's synchroniser
+            flush()
+            returns["facade"].append(int(parts[2]))
+            returns["reference"].append(state.get("ret", 0))
         elif kind == "B":
             state["pending"][1][int(parts[2])] = parts[3] if len(parts) > 3 else ""
         else:
@@ -268,6 +279,7 @@ def test_facade_rx_events_equal_the_reference_gr_modem(tmp_path, mode, streams, 
     for s in range(streams):
         assert facade[s] == reference[s], s
     assert sum(len(f) for f in facade) >= streams      # something was received (the loopback tests say what)
+    assert returns["facade"] == returns["reference"] and 0 < sum(returns["facade"]) < len(returns["facade"])
 
 
 def test_facade_spectrum_with_the_demodulator_valve_closed():

@@ -185,3 +185,35 @@ def test_m17_frames_through_the_reference_gr_modem(ref):
     assert [e for e in got if e.startswith("audio ")] == audio and len(audio) >= 12
     assert audio[:12] == ["audio " + bytes(p).hex() for p in pl]
     assert sum(e.startswith("m17info ") for e in got) == 1
+
+
+@pytest.mark.parametrize("mt", [26, 22, 3, 18, 24])
+def test_demodulate_return_value_equals_the_reference_class(ref, mt):
+    """gr_modem::demodulate() returns synchronize()'s data_to_process: true iff a bit of the call was collected while a sync was held (src/gr_modem.cpp:1121-1175),
+    also while a frame is only partly there.  The oracle's orc_modem_sync_collected() (what qrl_framesync_set_activity_output exports from k_framesync,
+    tests/test_gpu_deframe.py) must say the same, call by call, for ragged calls over a stream with damaged sync words and frames cut short."""
+    rng = np.random.default_rng(300 + mt)
+    bits, _ = _stream(rng, mt, 40 if mt not in (26, 27) else 10)
+    m = ref.ref_modem_new()
+    ref.ref_modem_init_rx(m, mt)
+    ms = orc.ModemSync(mt)
+    pos, calls, trues = 0, 0, 0
+    while pos < bits.size:
+        n = int(rng.integers(32, max(40, bits.size // 60)))
+        part = np.ascontiguousarray(bits[pos:pos + n])
+        if part.size < 32:
+            break   # gr_bit_sink::get_data hands out nothing below 32 bits (src/gr/gr_bit_sink.cpp:45-59): demodulate() returns false without consuming
+        if mt in TWO_BRANCH:
+            ref.ref_modem_push(m, 1, part.ctypes.data, part.size)
+            other = np.ascontiguousarray(rng.integers(0, 2, max(part.size - 1, 1), dtype=np.uint8))
+            ref.ref_modem_push(m, 2, other.ctypes.data, other.size)
+        else:
+            ref.ref_modem_push(m, 0, part.ctypes.data, part.size)
+        want = bool(ref.ref_modem_demodulate(m))
+        _events(ref, m)
+        ms.feed_raw(part)
+        assert (ms.collected > 0) == want, (calls, pos, n, ms.collected, want)
+        calls += 1; trues += want
+        pos += n
+    ref.ref_modem_free(m)
+    assert calls > 20 and 0 < trues < calls
