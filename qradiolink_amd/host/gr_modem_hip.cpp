@@ -725,6 +725,25 @@ void gr_mod_base_hip::set_carrier_offset(double hz)
     if (d_ah) chk(qrl_amod_set_carrier_offset(d_ah, hz), "qrl_amod_set_carrier_offset");
     d_offset = hz;
 }
+void gr_mod_base_hip::set_samp_rate(int device_samp_rate)
+{
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
+    if (device_samp_rate == d_rate) return;
+    const int old = d_rate;
+    d_rate = device_samp_rate;
+    if (d_mode >= 0) {
+        try { open(); }
+        catch (...) { d_rate = old; throw; }   // the previous modulator is still open
+    }
+}
+void gr_mod_base_hip::flush_sources()
+{
+    std::lock_guard<std::recursive_mutex> hg(d_hmutex);
+    std::lock_guard<std::mutex> g(d_mutex);
+    // (bytes already counted into d_sent stay counted: the positions of later zero runs are stream positions of the modulator)
+    for (auto& q : d_queue) q.clear();
+    for (auto& q : d_aqueue) q.clear();
+}
 size_t gr_mod_base_hip::samples_per_byte() const { return d_h ? qrl_mod_samples_per_byte(d_h) : 0; }
 size_t gr_mod_base_hip::work(gr_complex* const* out)
 {

@@ -155,6 +155,10 @@ public:
     int setDMRData(const std::vector<std::vector<uint8_t>>& frames, int stream = 0);
     void set_bb_gain(float value);
     void set_carrier_offset(double hz);
+    double carrier_offset() const { return d_offset; }
+    void set_samp_rate(int device_samp_rate);                  // gr_mod_base::set_samp_rate (src/gr/gr_mod_base.cpp:211-262): the output interpolator is rebuilt (the modulator restarts)
+    void flush_sources();                                      // gr_mod_base::flush_sources (:959-965): what is queued in the byte and audio sources is dropped
+    int mode() const { return d_mode; }
     // one scheduler pass: consumes up to max_bytes queued bytes of every stream (zero padded to the longest) and returns the
     // samples per stream it produced; out[s] receives them (host, capacity >= samples_per_byte() * max_bytes)
     size_t work(gr_complex* const* out);

@@ -1,0 +1,61 @@
+"""VERDICT r5 #6 -- the boundary made literal.  `class gr_modem` of qradiolink_amd/host/qt/gr_modem.* carries the reference's public interface
+(/root/reference/src/gr_modem.h:55-139: the slots radiocontroller.cpp calls at src/radiocontroller.cpp:1298, 1302, 1969-2078 and the signals it connects at
+:121-152).  ONE driver source, tests/host/gr_modem_script.h, written against that interface only, drives
+  * the HIP path's class on the GPU (tests/host/test_gr_modem_literal: TX script -> txSamples -> loop-back channel -> rxSamples -> demodulate() polls), and
+  * the REFERENCE's own class (src/gr_modem.cpp compiled where it lies: oracle/_ref/gr_modem_script_ref), replaying the bit vectors the HIP demodulator handed
+    to its gr_modem, poll by poll;
+the two logs -- every signal with its arguments, and the return value of every demodulate() call -- must be equal line by line, and so must the bytes the two
+classes hand to their modulators."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIP = os.path.join(ROOT, "tests", "host", "test_gr_modem_literal")
+REF = os.path.join(ROOT, "oracle", "_ref", "gr_modem_script_ref")
+
+
+def _run(tmp_path, mode, frames, both=False):
+    if not os.path.exists(HIP):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qradiolink_amd", "csrc"), "adaptor"])
+    env = dict(os.environ)
+    env.pop("QRL_TEST_BOTH_BRANCHES", None)
+    if both:
+        env["QRL_TEST_BOTH_BRANCHES"] = "1"
+    tag = "both" if both else "lit"
+    r = subprocess.run([HIP, str(mode), str(frames), str(tmp_path / ("hip_%s.txt" % tag)), str(tmp_path / ("tap_%s.txt" % tag)), str(tmp_path / ("tx_hip_%s.bin" % tag))],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return (tmp_path / ("hip_%s.txt" % tag)).read_text().splitlines()
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/gr_modem_script_ref not built (make -C oracle ref, needs /root/reference)")
+@pytest.mark.parametrize("mode,frames", [(26, 3), (22, 8), (18, 20), (7, 8), (5, 8)])
+def test_same_driver_same_signal_log(tmp_path, mode, frames):
+    hip = _run(tmp_path, mode, frames)
+    r = subprocess.run([REF, str(mode), str(frames), str(tmp_path / "tap_lit.txt"), str(tmp_path / "ref.txt"), str(tmp_path / "tx_ref.bin")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = (tmp_path / "ref.txt").read_text().splitlines()
+    # TX: the byte stream handed to the modulator (framing, preambles, callsign and end frames)
+    assert (tmp_path / "tx_hip_lit.bin").read_bytes() == (tmp_path / "tx_ref.bin").read_bytes()
+    assert len((tmp_path / "tx_ref.bin").read_bytes()) > 50
+    # RX: signals and demodulate() return values, in order
+    assert hip == ref, "first difference at line %d" % next((i for i, (a, b) in enumerate(zip(hip, ref)) if a != b), min(len(hip), len(ref)))
+    signals = [l for l in hip if l.startswith("S ")]
+    rets = [l for l in hip if l.startswith("R ")]
+    assert any(l.startswith("S digitalAudio") for l in signals), "no voice frame came through the loop"
+    assert "S endAudioTransmission" in signals and "S receiveEnd" in signals
+    assert "R 1" in rets and "R 0" in rets
+
+
+def test_both_branches_deliver_at_least_the_reference_rule(tmp_path):
+    """two-branch mode: the class's default (each Viterbi alignment keeps its own frame synchroniser) delivers every signal the reference's literal `>=` rule
+    delivers -- the transmission is sent twice, one channel bit apart, so one copy sits on either alignment -- and more"""
+    lit = [l for l in _run(tmp_path, 22, 6) if l.startswith("S ")]
+    both = [l for l in _run(tmp_path, 22, 6, both=True) if l.startswith("S ")]
+    it = iter(both)
+    assert all(any(x == l for x in it) for l in lit), "the reference rule's signals are not a subsequence of the default's"
+    assert len(both) > len(lit)
