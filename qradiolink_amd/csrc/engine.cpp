@@ -1205,6 +1205,11 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         else {
             int r0;
             if (std::getenv("QRL_CU_MAIN")) { if ((r0 = create_role_stream(&d->stream, 0, "MAIN"))) return r0; }
+            else if (std::getenv("QRL_MAIN_PRIO_LOW")) {   // experiment: a CU-masked stream has no priority argument (it is a NORMAL stream), so the masked tail only outranks the
+                int plo = 0, phi = 0;                      // front end when the front end's stream is created BELOW normal
+                (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+                HIPCHK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, plo));
+            }
             else HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
             d->own_stream = true;
         }

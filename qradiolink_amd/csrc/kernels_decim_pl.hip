@@ -217,7 +217,14 @@ __device__ unsigned long long g_pm_prof[8];
 // 4.1 - 4.4 TB/s of input (tools/ubench/stream_lds.hip W4), against 2.5 - 2.7 TB/s for the banded-Toeplitz form of rounds 1-2 (26 % of
 // its matrix work multiplied zero taps, every tile went through LDS twice) and for the VALU phase-lane kernel at 100:1.
 constexpr int PM_NHI = 64;   // coarse rotator entries per wave (64 x 512 samples): the wave re-bases and refills its own table as it walks
-template <int J, int NS, int RP, int NW>
+// K1 (round 6): D = 4 (NS - 1) + 1 -- the block's last step holds ONE phase (D = 25: 25 phases in 7 steps of 4).  The step then runs as
+// v_mfma_f32_4x4x1_16B_f32 (K = 1, 8 cycles) instead of v_mfma_f32_16x16x4_f32 (K = 4, 32 cycles, three of its four products 0 x 0):
+// 36 x 32 + 6 x 8 = 1200 instead of 42 x 32 = 1344 matrix-pipe cycles per group at D = 25.  Sixteen 4 x 4 outer products per instruction:
+// batch (lanes 4 b .. 4 b + 3), A[b][i] x B[b][j] -> register i of lane 4 b + j.  With batch b = 4 q + (n >> 2) that IS the accumulator
+// layout of the 16x16x4 instructions (lane (q, n) register r = Z[block n][lag 4 q + r]): A = tap H[D - 1][16 t + 4 q + (n & 3)],
+// B = the rotated last sample of block n in EVERY lane row (row 0 broadcast with two lane-row swaps).  One product added with one
+// rounding: the same link of the pm chain (the three links it drops added 0 x 0).
+template <int J, int NS, int RP, int NW, bool K1 = false>
 __global__ __launch_bounds__(NW * 64)
 void k_decim_pm(const DecimParams P_)
 {
@@ -277,6 +284,9 @@ void k_decim_pm(const DecimParams P_)
 #pragma unroll
         for (int s = 0; s < NS; ++s) a[t][s] = P.pl_taps[(t * NS + s) * 64 + lane];
     const int q = lane >> 4, nn = lane & 15;
+    float a1[NT];                                                    // K1: taps of the block's last phase in the 4x4x1 layout (see above)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a1[t] = K1 ? __shfl(a[t][NS - 1], 4 * q + (nn & 3), 64) : 0.f;   // held by lane (row 0, column 4 q + (n & 3)) of the K = 4 layout
     // the wave's byte stream: row = the stream's buffer (or its edge scratch), first byte of block 16 G0 at row + off0
     const unsigned char* rowp = reinterpret_cast<const unsigned char*>(edge ? P.pl_edge + (size_t)b * P.pl_edge_stride : P.in + (size_t)b * P.in_stride);
     const uint64_t off0 = edge ? 0ull : (uint64_t)(i_first - P.n0) * 8ull;
@@ -378,6 +388,19 @@ void k_decim_pm(const DecimParams P_)
 #endif
             if (s + 1 < NS) xn = rot(s + 1, pn);
             pn = pnn;
+            if (K1 && s == NS - 1) {
+                // the block's last sample, row 0 of the rotated operand, into every lane row: (r0, r1, r2, r3) -> (r0, r1, r0, r1) -> (r0, r0, r0, r0)
+                const auto h32r = __builtin_amdgcn_permlane32_swap(__float_as_uint(xs.x), __float_as_uint(xs.x), false, false);
+                const auto h32i = __builtin_amdgcn_permlane32_swap(__float_as_uint(xs.y), __float_as_uint(xs.y), false, false);
+                const auto h16r = __builtin_amdgcn_permlane16_swap(h32r[0], h32r[0], false, false);
+                const auto h16i = __builtin_amdgcn_permlane16_swap(h32i[0], h32i[0], false, false);
+                const float bx = __uint_as_float(h16r[0]), by = __uint_as_float(h16i[0]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    zr[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[t], bx, zr[t], 0, 0, 0);
+                    zi[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[t], by, zi[t], 0, 0, 0);
+                }
+            } else
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
 #if QRL_PM_ABL & 4
@@ -952,14 +975,14 @@ static uint32_t pm_pick_segment(uint64_t M, uint32_t batch, uint32_t cap, uint32
     }
     return best_S;
 }
-template <int J, int NS, int RP = QRL_PM_RP>
+template <int J, int NS, int RP = QRL_PM_RP, bool K1 = false>
 static int pm_launch_main(DecimParams& q, uint64_t M, uint32_t batch, bool edge_unit, hipStream_t s)
 {
     // RP = ring pieces per wave (a power of two: one 16-block group -- 128 D bytes -- + what is in flight).
     // 4 waves per workgroup; at D = 50 four workgroups per CU (156 KB of LDS).  8-wave workgroups (two per CU, 144 KB: room for slim
     // recursion kernels of the previous call beside them) were measured: 7.24 ms against 6.57 ms alone, and no gain in the overlapped mode.
     constexpr int NW = QRL_PM_NW;
-    const auto kern = k_decim_pm<J, NS, RP, NW>;
+    const auto kern = k_decim_pm<J, NS, RP, NW, K1>;
     const size_t lds = (size_t)NW * RP * 1024 + 512 * sizeof(float2) + NW * PM_NHI * sizeof(float2);
     // occupancy and CU count per (instantiation, device): a second device in the process gets its own LDS attribute (dyn_lds_limit
     // de-duplicates per kernel and device) and its own geometry; first calls may race, hence the lock
@@ -1032,6 +1055,11 @@ int launch_decim_pm(const DecimParams& p, int batch, hipStream_t s)
     const uint32_t Bn = (uint32_t)batch;
     if (J == 9) return pm_launch_main<9, 13>(q, M, Bn, edge_unit, s);   // the 1:50, 419-tap stage
     if (J > 16) {   // device-rate front ends: 42 block lags (the table is zero beyond J; J <= 48 runs the same code)
+#ifndef QRL_PM_NO_K1
+        // D = 25 (C2: the 25 Msps front end): the 25th phase as a K = 1 matrix instruction
+        if (D == 25 && J == 42) return pm_launch_main<42, 7, QRL_PM_RP_SMALL, true>(q, M, Bn, edge_unit, s);
+        if (D == 25) return pm_launch_main<48, 7, QRL_PM_RP_SMALL, true>(q, M, Bn, edge_unit, s);
+#endif
         if (J == 42) switch (NS) {
             case 3: return pm_launch_main<42, 3, QRL_PM_RP_SMALL>(q, M, Bn, edge_unit, s);   case 5: return pm_launch_main<42, 5, QRL_PM_RP_SMALL>(q, M, Bn, edge_unit, s);
             case 7: return pm_launch_main<42, 7, QRL_PM_RP_SMALL>(q, M, Bn, edge_unit, s);   case 13: return pm_launch_main<42, 13, 8>(q, M, Bn, edge_unit, s);

@@ -71,12 +71,15 @@ static void script_transmit(gr_modem& m, int mode, int nframes, const char* call
 {
     const int L = script_frame_length(mode);
     m.startTransmission(QString(callsign));
+    const bool fast = mode == 26 || mode == 27;   // QPSK250K / 4FSK100K: the IP / video modes -- their receivers know the IP, video and end sync words only (src/gr_modem.cpp:1211-1237)
     for (int f = 0; f < nframes; ++f) {
         unsigned char* d = new unsigned char[L];
         for (int i = 0; i < L; ++i) d[i] = (unsigned char)(31 * f + 7 * i + 1);
-        m.transmitDigitalAudio(d, L);          // takes ownership
+        if (!fast) m.transmitDigitalAudio(d, L);          // takes ownership
+        else if (f & 1) m.transmitNetData(d, L);
+        else m.transmitVideoData(d, L);
     }
-    if (L >= 7) {
+    if (L >= 7 && !fast) {
         m.transmitTextData(QString("literal boundary: the quick brown fox"));
         std::vector<char> bin((size_t)L + 3);
         for (size_t i = 0; i < bin.size(); ++i) bin[i] = (char)(200 - i);
