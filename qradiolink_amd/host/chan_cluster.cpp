@@ -63,6 +63,56 @@ void callback_exchange::all_to_all(const void* send, void* recv, size_t bytes_pe
     if (!d_fn || d_fn(d_user, send, recv, bytes_per_peer, stream) != 0) throw std::runtime_error("callback_exchange: the transport callback failed");
 }
 
+local_group::local_group(int world) : d_world(world), d_m(nullptr)
+{
+    if (world < 1) throw std::invalid_argument("local_group: world must be >= 1");
+    d_m = new member[world];
+    for (int r = 0; r < world; ++r) {
+        hipEvent_t e;
+        hchk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); d_m[r].ev_ready = e;
+        hchk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); d_m[r].ev_done = e;
+    }
+}
+local_group::~local_group()
+{
+    for (int r = 0; r < d_world; ++r) {
+        if (d_m[r].ev_ready) (void)hipEventDestroy(static_cast<hipEvent_t>(d_m[r].ev_ready));
+        if (d_m[r].ev_done) (void)hipEventDestroy(static_cast<hipEvent_t>(d_m[r].ev_done));
+    }
+    delete[] d_m;
+}
+void local_group::post(int rank, const void* send, void* recv, size_t bytes_per_peer, void* stream)
+{
+    if (rank < 0 || rank >= d_world) throw std::invalid_argument("local_group: bad rank");
+    member& me = d_m[rank];
+    if (me.posted) throw std::logic_error("local_group: a member posted twice in one round");
+    if (d_posted && bytes_per_peer != d_nbytes) throw std::invalid_argument("local_group: the members of a round must post equal block sizes");
+    d_nbytes = bytes_per_peer;
+    me.send = send; me.recv = recv; me.stream = stream; me.posted = true;
+    hchk(hipEventRecord(static_cast<hipEvent_t>(me.ev_ready), static_cast<hipStream_t>(stream)), "hipEventRecord");   // send_rank is ready (its stream waited for the channelizer)
+    if (++d_posted < d_world) return;
+    // the round is complete: every member's receive side on its own stream
+    for (int r = 0; r < d_world; ++r) {
+        hipStream_t sr = static_cast<hipStream_t>(d_m[r].stream);
+        for (int s = 0; s < d_world; ++s)
+            if (s != r) hchk(hipStreamWaitEvent(sr, static_cast<hipEvent_t>(d_m[s].ev_ready), 0), "hipStreamWaitEvent");
+        if (!d_skip)
+            for (int s = 0; s < d_world; ++s)
+                hchk(hipMemcpyAsync(static_cast<char*>(d_m[r].recv) + (size_t)s * d_nbytes, static_cast<const char*>(d_m[s].send) + (size_t)r * d_nbytes, d_nbytes,
+                                    hipMemcpyDeviceToDevice, sr), "local_group: hipMemcpyAsync");
+        hchk(hipEventRecord(static_cast<hipEvent_t>(d_m[r].ev_done), sr), "hipEventRecord");
+        d_bytes += (uint64_t)d_world * d_nbytes;
+    }
+    // ... and every member's send side: its buffer is free when every rank has copied its block out of it
+    for (int s = 0; s < d_world; ++s) {
+        hipStream_t ss = static_cast<hipStream_t>(d_m[s].stream);
+        for (int r = 0; r < d_world; ++r)
+            if (r != s) hchk(hipStreamWaitEvent(ss, static_cast<hipEvent_t>(d_m[r].ev_done), 0), "hipStreamWaitEvent");
+        d_m[s].posted = false;
+    }
+    d_posted = 0;
+}
+
 chan_cluster::chan_cluster(qrl_ctx* ctx, chan_exchange& ex, int num_channels, int streams_local, size_t max_chunk)
     : d_ex(ex), d_M(num_channels), d_bl(streams_local), d_per(num_channels / (ex.world() > 0 ? ex.world() : 1)), d_n1max(max_chunk / (size_t)num_channels)
 {
@@ -139,7 +189,7 @@ void chan_cluster::channelize(const float* iq, size_t stride, size_t n)
         hchk(hipStreamWaitEvent(static_cast<hipStream_t>(qrl_chan_stream(d_front)), static_cast<hipEvent_t>(d_ev_sent[d_cur]), 0), "hipStreamWaitEvent");
     chk(qrl_chan_channelize(d_front, iq, stride, n, d_send[d_cur], d_n1max, d_ex.world()), "qrl_chan_channelize");
 }
-void chan_cluster::exchange()
+void chan_cluster::exchange_begin()
 {
     // ONE RANK: every channel is this rank's own, the by-destination layout the channelizer wrote IS what the per-channel handle reads -- the
     // all-to-all of one rank would be a 1 GB device copy per step (0.96 ms as rcclGenericKernel at the bench shape) that moves nothing anywhere.
@@ -149,6 +199,10 @@ void chan_cluster::exchange()
     if (d_read_valid[d_cur])                                              // ... and behind the last readers of recv[cur]
         hchk(hipStreamWaitEvent(static_cast<hipStream_t>(d_xs), static_cast<hipEvent_t>(d_ev_read[d_cur]), 0), "hipStreamWaitEvent");
     d_ex.all_to_all(d_send[d_cur], d_recv[d_cur], (size_t)d_bl * d_per * d_n1max * 2 * sizeof(float), d_xs);
+}
+void chan_cluster::exchange_end()
+{
+    if (d_inplace) return;
     hchk(hipEventRecord(static_cast<hipEvent_t>(d_ev_sent[d_cur]), static_cast<hipStream_t>(d_xs)), "hipEventRecord");
     d_sent_valid[d_cur] = true;
 }
@@ -179,6 +233,7 @@ void chan_cluster::sync()
 // ---- C ABI ------------------------------------------------------------------------------------------------------------------------
 struct qrl_exchange { qrl_host::chan_exchange* ex; };
 struct qrl_cluster { qrl_host::chan_cluster* cl; };
+struct qrl_exchange_group { qrl_host::local_group* g; };
 static thread_local std::string g_cluster_error;
 template <class F> static int guarded(F&& f)
 {
@@ -221,6 +276,17 @@ int qrl_cluster_step(qrl_cluster* c, const float* iq, size_t stride, size_t n, i
 }
 int qrl_cluster_channelize(qrl_cluster* c, const float* iq, size_t stride, size_t n) { return c ? guarded([&] { c->cl->channelize(iq, stride, n); }) : QRL_ERR_ARG; }
 int qrl_cluster_exchange(qrl_cluster* c) { return c ? guarded([&] { c->cl->exchange(); }) : QRL_ERR_ARG; }
+int qrl_cluster_exchange_begin(qrl_cluster* c) { return c ? guarded([&] { c->cl->exchange_begin(); }) : QRL_ERR_ARG; }
+int qrl_cluster_exchange_end(qrl_cluster* c) { return c ? guarded([&] { c->cl->exchange_end(); }) : QRL_ERR_ARG; }
+int qrl_exchange_group_create(int world, qrl_exchange_group** out) { return out ? guarded([&] { *out = new qrl_exchange_group{new qrl_host::local_group(world)}; }) : QRL_ERR_ARG; }
+int qrl_exchange_group_member(qrl_exchange_group* g, int rank, qrl_exchange** out)
+{
+    if (!g || !out || rank < 0 || rank >= g->g->world()) return QRL_ERR_ARG;
+    return guarded([&] { *out = new qrl_exchange{new qrl_host::local_group_exchange(*g->g, rank)}; });
+}
+unsigned long long qrl_exchange_group_bytes_moved(const qrl_exchange_group* g) { return g ? (unsigned long long)g->g->bytes_moved() : 0ull; }
+int qrl_exchange_group_skip_copies(qrl_exchange_group* g, int skip) { if (!g) return QRL_ERR_ARG; g->g->skip_copies(skip != 0); return QRL_OK; }
+void qrl_exchange_group_destroy(qrl_exchange_group* g) { if (g) { delete g->g; delete g; } }
 int qrl_cluster_process_channels(qrl_cluster* c, int16_t* out, size_t out_cap, uint32_t* counts)
 {
     return c ? guarded([&] { c->cl->process_channels(out, out_cap, counts); }) : QRL_ERR_ARG;

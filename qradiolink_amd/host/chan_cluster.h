@@ -67,6 +67,35 @@ private:
     int d_world, d_rank; chan_exchange_fn d_fn; void* d_user;
 };
 
+// N ranks of ONE process on ONE device (round 6: the 8-rank SHAPE on a one-GPU box, tools/c4_emulated_ranks.py and tests/test_gpu_sharding.py): a real
+// all-to-all among the members' buffers with an all-to-all's dependency structure, device copies instead of xGMI.  Every member's all_to_all() records
+// "my send buffer is ready" on its stream and registers its buffers; the LAST member of a round then enqueues, on every member r's stream: wait for every
+// source's send buffer, copy block r of every rank's send buffer into block s of recv_r, record "recv_r written"; and on every member s's stream a wait for
+// all of those -- the last readers of send_s.  Members must call in rounds (each member once per round, any order): the emulation's host loop does
+// exchange_begin() for every rank and only then exchange_end() (chan_cluster), so that a rank's "exchange done" event is recorded behind the copies.
+class local_group {
+public:
+    explicit local_group(int world);
+    ~local_group();
+    int world() const { return d_world; }
+    uint64_t bytes_moved() const { return d_bytes; }    // device-to-device bytes enqueued so far (world^2 x bytes_per_peer per round)
+    void skip_copies(bool v) { d_skip = v; }            // timing experiment: the dependency structure without the data movement
+private:
+    friend class local_group_exchange;
+    void post(int rank, const void* send, void* recv, size_t bytes_per_peer, void* stream);
+    struct member { const void* send = nullptr; void* recv = nullptr; void* stream = nullptr; void* ev_ready = nullptr; void* ev_done = nullptr; bool posted = false; };
+    int d_world; member* d_m; int d_posted = 0; size_t d_nbytes = 0; uint64_t d_bytes = 0; bool d_skip = false;
+};
+class local_group_exchange : public chan_exchange {
+public:
+    local_group_exchange(local_group& g, int rank) : d_g(g), d_rank(rank) {}
+    int world() const override { return d_g.world(); }
+    int rank() const override { return d_rank; }
+    void all_to_all(const void* send, void* recv, size_t bytes_per_peer, void* stream) override { d_g.post(d_rank, send, recv, bytes_per_peer, stream); }
+private:
+    local_group& d_g; int d_rank;
+};
+
 // One rank of the channel-sharded receiver: `streams_local` wideband streams in, the rank's 64 / world channels of ALL
 // streams_local * world streams out (row = (source rank * streams_local + stream) * channels_per_rank + local channel).
 class chan_cluster {
@@ -78,7 +107,12 @@ public:
     void step(const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts);
     // the three phases of step() on their own (a single-process emulation of N ranks runs every rank's phase before the next)
     void channelize(const float* iq, size_t stride, size_t n);
-    void exchange();
+    void exchange() { exchange_begin(); exchange_end(); }
+    // the two halves of exchange(): begin = order the exchange stream behind the channelizer and the last readers of the receive buffer, hand the buffers to
+    // the transport; end = record "exchange done" on the exchange stream.  One process that emulates several ranks (local_group) calls begin for every
+    // rank before the first end: the group's copies are enqueued by the last begin.
+    void exchange_begin();
+    void exchange_end();
     void process_channels(int16_t* out, size_t out_cap, uint32_t* counts);
     void sync();
     qrl_chan* front() const { return d_front; }     // the PFB handle (form 0): options, profiling
@@ -122,6 +156,14 @@ int qrl_cluster_rows(qrl_cluster* c);
 int qrl_cluster_step(qrl_cluster* c, const float* iq, size_t stride, size_t n, int16_t* out, size_t out_cap, uint32_t* counts);
 int qrl_cluster_channelize(qrl_cluster* c, const float* iq, size_t stride, size_t n);
 int qrl_cluster_exchange(qrl_cluster* c);
+int qrl_cluster_exchange_begin(qrl_cluster* c);
+int qrl_cluster_exchange_end(qrl_cluster* c);
+typedef struct qrl_exchange_group qrl_exchange_group;
+int qrl_exchange_group_create(int world, qrl_exchange_group** out);                               /* qrl_host::local_group */
+int qrl_exchange_group_member(qrl_exchange_group* g, int rank, qrl_exchange** out);              /* a local_group_exchange of that group */
+unsigned long long qrl_exchange_group_bytes_moved(const qrl_exchange_group* g);
+int qrl_exchange_group_skip_copies(qrl_exchange_group* g, int skip);
+void qrl_exchange_group_destroy(qrl_exchange_group* g);
 int qrl_cluster_process_channels(qrl_cluster* c, int16_t* out, size_t out_cap, uint32_t* counts);
 int qrl_cluster_sync(qrl_cluster* c);
 const char* qrl_cluster_last_error(void);

@@ -95,6 +95,14 @@ def cluster_library():
         L.qrl_cluster_step.argtypes = [vp, vp, sz, sz, vp, sz, vp]
         L.qrl_cluster_channelize.argtypes = [vp, vp, sz, sz]
         L.qrl_cluster_exchange.argtypes = [vp]
+        L.qrl_cluster_exchange_begin.argtypes = [vp]
+        L.qrl_cluster_exchange_end.argtypes = [vp]
+        L.qrl_exchange_group_create.argtypes = [_C.c_int, _C.POINTER(vp)]
+        L.qrl_exchange_group_member.argtypes = [vp, _C.c_int, _C.POINTER(vp)]
+        L.qrl_exchange_group_bytes_moved.argtypes = [vp]
+        L.qrl_exchange_group_bytes_moved.restype = _C.c_ulonglong
+        L.qrl_exchange_group_skip_copies.argtypes = [vp, _C.c_int]
+        L.qrl_exchange_group_destroy.argtypes = [vp]
         L.qrl_cluster_process_channels.argtypes = [vp, vp, sz, vp]
         L.qrl_cluster_sync.argtypes = [vp]
         _cluster_lib = L
@@ -188,6 +196,66 @@ class Exchange:
             self.h = _C.c_void_p()
 
 
+class LocalGroup:
+    """qrl_host::local_group: N ranks of THIS process on one device -- a real all-to-all among the members' buffers (device copies, an all-to-all's
+    dependency structure).  .member(rank) is that rank's Exchange.  The emulation loop: every rank channelize(), every rank exchange_begin(), every rank
+    exchange_end(), every rank process_channels() (EmulatedRanks.step does it)."""
+
+    def __init__(self, world):
+        self.L, self.world = cluster_library(), world
+        self.h = _C.c_void_p()
+        _ck(self.L.qrl_exchange_group_create(world, _C.byref(self.h)), "qrl_exchange_group_create")
+
+    def member(self, rank):
+        h = _C.c_void_p()
+        _ck(self.L.qrl_exchange_group_member(self.h, rank, _C.byref(h)), "qrl_exchange_group_member")
+        return Exchange(h, self.world, rank)
+
+    def bytes_moved(self):
+        return int(self.L.qrl_exchange_group_bytes_moved(self.h))
+
+    def skip_copies(self, skip):
+        _ck(self.L.qrl_exchange_group_skip_copies(self.h, 1 if skip else 0), "qrl_exchange_group_skip_copies")
+
+    def close(self):
+        if self.h:
+            self.L.qrl_exchange_group_destroy(self.h)
+            self.h = _C.c_void_p()
+
+
+class EmulatedRanks:
+    """`world` chan_cluster objects of one process on one device behind a LocalGroup: the multi-GPU step of C4 at the N-rank SHAPE (streams_local
+    wideband streams and num_channels / world channels per rank) on a one-GPU box.  step(iq): iq [world * streams_local, n] (rank r takes rows
+    r * streams_local ...); nothing synchronises with the host."""
+
+    def __init__(self, ctx, world, num_channels, streams_local, max_chunk):
+        self.world, self.bl = world, streams_local
+        self.group = LocalGroup(world)
+        self.exs = [self.group.member(r) for r in range(world)]
+        self.cls = [Cluster(ctx, self.exs[r], num_channels, streams_local, max_chunk) for r in range(world)]
+
+    def step(self, iq):
+        for r, c in enumerate(self.cls):
+            c.channelize(iq[r * self.bl:(r + 1) * self.bl])
+        for c in self.cls:
+            c.exchange_begin()
+        for c in self.cls:
+            c.exchange_end()
+        for c in self.cls:
+            c.process_channels()
+
+    def sync(self):
+        for c in self.cls:
+            c.sync()
+
+    def close(self):
+        for c in self.cls:
+            c.close()
+        for e in self.exs:
+            e.close()
+        self.group.close()
+
+
 class Cluster:
     """qrl_host::chan_cluster: one rank of the channel-sharded C4 receiver (channelize own streams -> one all-to-all -> per-channel
     chains of the owned channels).  .front / .tail are Channelizer views of its two handles (profiling on .front; the int16 / RSSI /
@@ -212,6 +280,12 @@ class Cluster:
 
     def exchange(self):
         _ck(self.L.qrl_cluster_exchange(self.h), "qrl_cluster_exchange")
+
+    def exchange_begin(self):
+        _ck(self.L.qrl_cluster_exchange_begin(self.h), "qrl_cluster_exchange_begin")
+
+    def exchange_end(self):
+        _ck(self.L.qrl_cluster_exchange_end(self.h), "qrl_cluster_exchange_end")
 
     def process_channels(self):
         t = self.tail

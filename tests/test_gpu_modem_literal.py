@@ -50,7 +50,8 @@ def test_same_driver_same_signal_log(tmp_path, mode, frames):
         assert any(l.startswith("S videoData") for l in signals) and any(l.startswith("S netData") for l in signals), "no video / IP frame came through the loop"
     else:
         assert any(l.startswith("S digitalAudio") for l in signals), "no voice frame came through the loop"
-    assert "S endAudioTransmission" in signals and "S receiveEnd" in signals
+    if mode not in (6, 16, 18, 21, 24):   # the 1k modes know the one-byte voice sync word only (src/gr_modem.cpp:1239-1250): no callsign, text or end frames
+        assert "S endAudioTransmission" in signals and "S receiveEnd" in signals
     assert "R 1" in rets and "R 0" in rets
 
 

@@ -205,3 +205,35 @@ def test_cluster_with_the_rccl_transport_on_one_rank_equals_the_plain_receiver(q
             _compare_rank(cl.tail, ref[k], 0, 1, B, M)
         cl.close()
         ex.close()
+
+
+@pytest.mark.parametrize("world,Bl", [(8, 1), (4, 2)])
+def test_emulated_ranks_with_the_local_group_transport_equal_the_unsharded_receiver(qrl_ctx, world, Bl):
+    """the multi-GPU step at the 8-rank SHAPE on one device.  `world` chan_cluster objects of one process behind qrl_host::local_group -- a
+    real all-to-all among their buffers (device copies with an all-to-all's dependencies: every receive side waits for every send buffer, every send
+    buffer is released by its last reader) -- driven by sharding.EmulatedRanks.step with NO host synchronisation inside a step or between the three
+    steps (the 3-slot pipeline: buffers are reused from the fourth step on, so five steps run).  Every rank's rows equal the unsharded receiver's
+    channels bit for bit, step by step."""
+    import torch
+    import test_gpu_chan as tg
+    M = 64
+    B, cpr = world * Bl, M // world
+    cuts = [64 * 700, 64 * 500, 64 * 700, 64 * 300, 64 * 600]
+    iq = tg._wideband(M, sum(cuts), seed=93, nstreams=B)
+    d = torch.from_numpy(iq).cuda()
+    ref = _unsharded(qrl_ctx, d, M, cuts, 0.5)
+    em = sharding.EmulatedRanks(qrl_ctx, world, M, Bl, max(cuts))
+    for c in em.cls:
+        c.tail.calibrate_rssi(0.5)
+        c.tail.enable_4fsk()
+    # the outputs of a step live in the per-channel handle's own buffers, which the next step overwrites: snapshot them on the handle's stream order by
+    # synchronising only AFTER queueing the whole step (the step itself has no host synchronisation)
+    pos = 0
+    for k, c in enumerate(cuts):
+        em.step(d[:, pos:pos + c].contiguous())
+        pos += c
+        em.sync()
+        for r in range(world):
+            _compare_rank(em.cls[r].tail, ref[k], r, world, B, cpr)
+    assert em.group.bytes_moved() == sum(world * world * Bl * cpr * max(cuts) // 64 * 8 for _ in cuts)
+    em.close()
