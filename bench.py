@@ -460,6 +460,12 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, c
                        "bytes_per_link_per_step": link_bytes},
             "step_spread_ms": marks.spread()}
     ms_step = dt / args.steps * 1e3
+    if link_bytes and world > 1:
+        # how to read a SCALE point of this line: xGMI is point to point -- the world - 1 blocks of a rank leave on world - 1 links at once, so one
+        # all-to-all takes ONE block's time; it hides under the 3-slot pipeline only while it is shorter than a rank's compute (= this line's single-GPU step / world
+        # if the kernels scale).  profiles/r06_c4_emulated_ranks.jsonl has the same figures for 2 / 4 / 8 ranks from the one-device emulation.
+        line["config"]["expected_exchange_ms"] = {"at_45_GBps_per_link": round(link_bytes / 45e9 * 1e3, 3), "at_64_GBps_per_link": round(link_bytes / 64e9 * 1e3, 3),
+                                                  "note": "one block per link and step; compare with ms_per_step: a step cannot be shorter than the slower of compute and exchange"}
     if per_kernel:
         # the dominant kernel = the longest of the call (k_chan_tail since round 4); `frac` = the WHOLE chain's algorithmic bytes over the whole step
         # (VERDICT r4 #1a), the per-kernel figures beside it; C4 is bound by f32 instructions, not by HBM: the flop roofline says how far from THAT roof
