@@ -762,7 +762,7 @@ def main():
     ap.add_argument("--cluster-copy", action="store_true", help="c4 --cluster at N = 1: keep the one-rank ncclAllToAll (a 1 GB device copy per step that moves nothing; by default one rank reads the channelizer's output in place)")
     ap.add_argument("--no-marks", action="store_true", help="no per-step completion events (step_spread_ms = null)")
     ap.add_argument("--check", action="store_true", help="with --no-extra: still run the parity check against the oracle at the bench shape")
-    ap.add_argument("--legacy-pfb", type=int, default=0, help="A/B, c4: QRL_CHAN_OPT_LEGACY_PFB (1 = general-M channelizer kernel, 2 = the tiled 64-channel kernel of round 3)")
+    ap.add_argument("--legacy-pfb", type=int, default=0, help="c4: QRL_CHAN_OPT_LEGACY_PFB = 1 (the general-M channelizer kernel at the 64-channel shape)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

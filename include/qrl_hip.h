@@ -286,10 +286,10 @@ typedef struct {
 int qrl_chan_create(qrl_ctx* ctx, const qrl_chan_config* cfg, qrl_chan** out);
 void qrl_chan_destroy(qrl_chan* c);
 int qrl_chan_reset(qrl_chan* c);
-/* kernel selection for A/B measurements and tests (results are identical): QRL_CHAN_OPT_LEGACY_PFB = 1 runs the general-M
- * channelizer kernel also for the 64-channel geometry, = 2 the tiled 64-channel kernel of round 3 (0, the default: the streaming
- * kernel k_pfb_stream64 when the rows are 16-byte aligned); QRL_CHAN_OPT_LEGACY_TAIL = 1 runs the per-channel chain as separate kernels
- * instead of the fused feed-forward kernel -- only before the first samples of a stream or after qrl_chan_reset (QRL_ERR_STATE
+/* path selection for tests (results are identical): the 64-channel geometry runs on k_pfb_stream64 + the fused per-channel kernel; every other
+ * shape (other channel counts, unaligned rows, the single-carrier and frequency-translating forms) on the general-M channelizer and the separate
+ * per-channel kernels.  QRL_CHAN_OPT_LEGACY_PFB = 1 / QRL_CHAN_OPT_LEGACY_TAIL = 1 send the 64-channel geometry down those general paths so that
+ * the parity tests cover them at the bench shape too (round 6 deleted the third channelizer, round 3's tiled k_pfb_chan64).  LEGACY_TAIL only before the first samples of a stream or after qrl_chan_reset (QRL_ERR_STATE
  * otherwise: the fused kernel does not fill the intermediate rings the separate kernels take their history from).
  * QRL_CHAN_OPT_SERIAL_TAIL = 1 keeps the per-channel kernel of a call on the handle's stream, behind its channelizer and in front of the
  * next one (rounds 1-4); 0, the default for a PFB-form handle that owns its stream: it runs on an internal stream BESIDE the channelizer

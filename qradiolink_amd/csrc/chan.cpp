@@ -269,7 +269,7 @@ int qrl_chan_reset(qrl_chan* h)
 int qrl_chan_set_option(qrl_chan* h, int option, int value)
 {
     if (!h) return QRL_ERR_ARG;
-    if (option == QRL_CHAN_OPT_LEGACY_PFB) h->opt_legacy_pfb = value < 0 || value > 2 ? 0 : value;
+    if (option == QRL_CHAN_OPT_LEGACY_PFB) h->opt_legacy_pfb = value == 1 ? 1 : 0;
     else if (option == QRL_CHAN_OPT_LEGACY_TAIL) {
         // the fused per-channel kernel does not fill the intermediate rings the separate kernels read their history from: only before the first samples
         if (h->n_in != 0 || h->n2 != 0) return qrl_set_error(QRL_ERR_STATE, "QRL_CHAN_OPT_LEGACY_TAIL: only before the first call (or after qrl_chan_reset)");
@@ -556,7 +556,7 @@ int qrl_chan_profile_read(qrl_chan* h, double* kernel_ms, uint64_t* launches, co
     }
     if (kernel_ms) *kernel_ms = total;
     if (launches) *launches = h->prof_events.size();
-    if (kernel_name) *kernel_name = (h->xlat || h->xlat2) ? "k_decim_mfma (one launch per channel, summed)" : h->single ? "k_resamp" : (h->opt_legacy_pfb == 0 && h->M == 64) ? "k_pfb_stream64" : h->opt_legacy_pfb == 2 ? "k_pfb_chan64" : "k_pfb_chan";
+    if (kernel_name) *kernel_name = (h->xlat || h->xlat2) ? "k_decim_mfma (one launch per channel, summed)" : h->single ? "k_resamp" : (h->opt_legacy_pfb == 0 && h->M == 64) ? "k_pfb_stream64" : "k_pfb_chan";
     h->prof_events.clear();
     for (auto* v : {&h->prof_tail, &h->prof_ss}) { for (auto& e : *v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } v->clear(); }
     return QRL_OK;

@@ -222,7 +222,7 @@ struct ChanParams {
     RingC out; uint64_t m0; uint32_t m_count;                      // channel rings [batch * c_count], output instants
     const float* taps; const float2* twiddle;                      // taps[p + M k] zero padded to J*M; W[q] = e^{+j 2 pi q / M}
     int M, J, c_first, c_count;
-    int legacy;                 // qrl_chan_set_option(QRL_CHAN_OPT_LEGACY_PFB), A/B and tests: 1 = the general-M kernel also for M = 64, 2 = the tiled k_pfb_chan64 of round 3
+    int legacy;                 // qrl_chan_set_option(QRL_CHAN_OPT_LEGACY_PFB), tests: 1 = the general-M kernel also for M = 64
     // row_cpd > 0: output rows grouped by destination rank -- row = ((cc / row_cpd) * batch + b) * row_cpd + cc % row_cpd
     // (the send layout of an all-to-all that gives rank r the channels [r row_cpd, (r + 1) row_cpd) of every stream);
     // out_pitch > 0: linear rows of out_pitch items, item m - m0 (a caller buffer instead of an engine ring)

@@ -133,114 +133,6 @@ __global__ __launch_bounds__(256) void k_pfb_chan(const ChanParams P)
     }
 }
 
-// ---- k_pfb_chan64: the M = 64 geometry of BASELINE config 4 (64 x 25 kHz out of 1.6 Msps), same contract as k_pfb_chan ----------
-// Phase 1 was LDS-issue bound in k_pfb_chan (one ds_read of a tap and one of a sample per FMA pair).  Here lane = branch p, a
-// wave owns R = 8 consecutive output instants: the branch's J taps h[p + 64 k] live in REGISTERS, the R + J - 1 samples the 8 windows
-// share are read from LDS ONCE each (ds_read_b64, lane stride 8 bytes: conflict free) and every sample feeds up to 8 FMA pairs:
-// 42 LDS reads for 280 FMA pairs.  Per output the chain runs k ascending as the contract says (d = r - k descending in the code).
-// Phase 2 is the f32-MFMA DFT of k_pfb_chan (rows = bins, columns = instants, K = branches, four accumulators per block), reading
-// branch outputs through a pitch of 66 float2 so that the 32 lanes of a ds_read_b64 group (16 instants x 2 k-quarters) hit 32 bank pairs.
-// A workgroup = 32 output instants: 49 KB of LDS, three workgroups per CU, so that one workgroup's matrix phase runs beside the
-// load / VALU phases of the others (the matrix pipe and the VALU are separate units: MI355X_MICROARCH.md "Wave scheduling").
-// The input tile is fetched with 16-byte loads when it lies inside the call's buffer; the first tiles of a call (history) and a
-// ragged last tile go through the checked element loop.
-constexpr int C64_TI = 32, C64_R = 8, C64_VP = 66;
-template <int J>
-__global__ __launch_bounds__(256, 3) void k_pfb_chan64(const ChanParams P)
-{
-    constexpr int M = 64;
-    constexpr int NS = (C64_TI + J - 1) * M;                      // samples a tile reads: x[first .. first + NS)
-    extern __shared__ __align__(16) unsigned char ch_smem[];
-    float2* xa = reinterpret_cast<float2*>(ch_smem);              // xa[j] = x[first - 1 + j], j < NS + 2 (16-byte aligned image)
-    float2* vs = xa + NS + 2;                                     // [TI][VP] branch outputs
-    float2* W = vs + C64_TI * C64_VP;                             // 64 twiddles
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint64_t m_t = P.m0 + (uint64_t)blockIdx.x * C64_TI;    // first output instant of this tile (absolute)
-    const int64_t first = (int64_t)m_t * M - (int64_t)(J * M - 1);// oldest sample any branch of the tile reads (odd)
-    // taps of this lane's branch: registers (issued first, they land while the tile is staged)
-    float h[J];
-#pragma unroll
-    for (int k = 0; k < J; ++k) h[k] = P.taps[lane + M * k];
-    if (tid < M) W[tid] = P.twiddle[tid];
-    const float2* row = P.in + (size_t)b * P.in_stride;
-    const bool inside = first - 1 >= (int64_t)P.n0 && (uint64_t)(first + NS + 1) <= P.n0 + P.n &&
-                        ((reinterpret_cast<uintptr_t>(row) & 15u) == 0) && (((uint64_t)(first - 1) - P.n0) & 1u) == 0;
-    if (inside) {
-        const float4* src = reinterpret_cast<const float4*>(row + ((uint64_t)(first - 1) - P.n0));
-        float4* dst = reinterpret_cast<float4*>(xa);
-        for (int i = tid; i < (NS + 2) / 2; i += 256) dst[i] = src[i];
-    } else {
-        for (int i = tid; i < NS + 1; i += 256) {
-            const int64_t a = first - 1 + i;
-            float2 x = make_float2(0.f, 0.f);
-            if (a >= 0 && (uint64_t)a < P.n0 + P.n) {
-                if ((uint64_t)a >= P.n0) x = row[(size_t)((uint64_t)a - P.n0)];
-                else {
-                    const uint64_t d = P.n0 - (uint64_t)a;
-                    if (d <= P.hist_len) x = P.hist[(size_t)b * P.hist_len + (P.hist_len - (uint32_t)d)];
-                }
-            }
-            xa[i] = x;
-        }
-    }
-    __syncthreads();
-    // phase 1: v_p[i] = sum_k h[p + 64 k] x[64 (m_t + i) - p - 64 k], i = 8 wv + r.  x[first + j] = xa[j + 1];
-    // sample of (r, k): j = (J 64 - 1) + 64 (8 wv + r) - p - 64 k = jb + 64 (r - k + J - 1),  jb = 64 (8 wv) + 63 - p
-    {
-        const float2* xb = xa + 1 + 64 * (8 * wv) + 63 - lane;
-        float ar[C64_R], ai[C64_R];
-#pragma unroll
-        for (int r = 0; r < C64_R; ++r) ar[r] = ai[r] = 0.f;
-#pragma unroll
-        for (int d = C64_R - 1; d >= -(J - 1); --d) {
-            const float2 x = xb[64 * (d + J - 1)];
-#pragma unroll
-            for (int r = 0; r < C64_R; ++r) {
-                const int k = r - d;
-                if (k >= 0 && k < J) { ar[r] = fmaf(h[k], x.x, ar[r]); ai[r] = fmaf(h[k], x.y, ai[r]); }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < C64_R; ++r) vs[(8 * wv + r) * C64_VP + lane] = make_float2(ar[r], ai[r]);
-    }
-    __syncthreads();
-    // phase 2: DFT bins of the owned channels on the f32 matrix pipe (contract: four real fmaf chains over the branches, p ascending)
-    const uint32_t count = P.m_count;
-    const int qb0 = P.c_first >> 4, qb1 = (P.c_first + P.c_count - 1) >> 4;
-    const int k4 = lane >> 4;
-    for (int qb = qb0 + wv; qb <= qb1; qb += 4) {
-        const int bin_a = 16 * qb + (lane & 15);
-        float are[16], aim[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float2 w2 = W[(bin_a * (4 * s + k4)) & 63];
-            are[s] = w2.x; aim[s] = w2.y;
-        }
-#pragma unroll
-        for (int ib = 0; ib < C64_TI / 16; ++ib) {
-            const float2* vb = vs + (16 * ib + (lane & 15)) * C64_VP + k4;
-            f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, sb = sa, sc = sa, sd = sa;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float2 v = vb[4 * s];
-                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(are[s], v.x, sa, 0, 0, 0);
-                sb = __builtin_amdgcn_mfma_f32_16x16x4f32(aim[s], v.y, sb, 0, 0, 0);
-                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(aim[s], v.x, sc, 0, 0, 0);
-                sd = __builtin_amdgcn_mfma_f32_16x16x4f32(are[s], v.y, sd, 0, 0, 0);
-            }
-            const int i = 16 * ib + (lane & 15);
-            if (blockIdx.x * (uint32_t)C64_TI + i < count) {
-                const uint64_t m = m_t + i;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int bin = 16 * qb + 4 * k4 + r, cc = bin - P.c_first;
-                    if (cc >= 0 && cc < P.c_count) *chan_out_addr(P, b, gridDim.y, cc, m) = make_float2(sa[r] - sb[r], sc[r] + sd[r]);
-                }
-            }
-        }
-    }
-}
 // ---- k_pfb_stream64: the production channelizer of BASELINE config 4 since round 4 -- same contract as k_pfb_chan ---------------
 // Round 3's k_pfb_chan64 cut a stream into 32-instant tiles, one workgroup each: every tile re-read a 34-instant halo (PMC: 2.07 x the
 // input bytes), re-loaded the 35 taps of its branch and the twiddles, and spent as much matrix-pipe time on bins 33..63 as on their
@@ -551,8 +443,6 @@ void launch_ring_load(const float2* in, size_t pitch, RingC out, uint64_t q0, ui
     if (!count) return;
     hipLaunchKernelGGL(k_ring_load, dim3((count + 255) / 256, rows), dim3(256), 0, s, in, pitch, out, q0, count);
 }
-size_t chan64_lds_bytes(int J) { return (size_t)((C64_TI + J - 1) * 64 + 2 + C64_TI * C64_VP + 64) * sizeof(float2); }
-
 size_t chan_lds_bytes(int M, int J)
 {
     return (size_t)((CH_TI + J) * M + CH_TI * (M + 1) + M) * sizeof(float2) + (size_t)J * M * sizeof(float);
@@ -563,8 +453,9 @@ void launch_pfb_chan(const ChanParams& p, int batch, hipStream_t s)
     for (const void* k : {reinterpret_cast<const void*>(k_pfb_chan<0>), reinterpret_cast<const void*>(k_pfb_chan<4>), reinterpret_cast<const void*>(k_pfb_chan<8>),
                           reinterpret_cast<const void*>(k_pfb_chan<12>), reinterpret_cast<const void*>(k_pfb_chan<16>)})
         if (dyn_lds_limit(k, 160 * 1024) != hipSuccess) return;
-    // M = 64: the streaming kernel (rows 16-byte aligned, as qrl_chan_process demands of device buffers in practice); legacy = 2 keeps the
-    // tiled kernel of round 3 reachable, legacy = 1 the general-M kernel
+    // M = 64: the streaming kernel (rows 16-byte aligned, as qrl_chan_process demands of device buffers in practice); everything else -- other channel counts,
+    // unaligned rows, ragged sample counts, and QRL_CHAN_OPT_LEGACY_PFB = 1 for the parity test of that path -- the general-M kernel.  (Round 3's tiled
+    // 64-channel kernel k_pfb_chan64 was deleted in round 6: superseded, its A/B is on record in docs/KERNELS.md 5.)
     const bool aligned = (reinterpret_cast<uintptr_t>(p.in) & 15u) == 0 && (p.in_stride & 1u) == 0 && (p.n0 & 63u) == 0 && (p.n & 63u) == 0;
     if (p.M == 64 && p.J == 35 && p.legacy == 0 && aligned) {
         const auto kern = k_pfb_stream64<35>;
@@ -589,11 +480,6 @@ void launch_pfb_chan(const ChanParams& p, int batch, hipStream_t s)
         const uint32_t seg_len = ((p.m_count + nseg - 1) / nseg + S64_T - 1) / S64_T * S64_T;
         nseg = (p.m_count + seg_len - 1) / seg_len;
         hipLaunchKernelGGL(kern, dim3(nseg, batch), dim3(256), stream64_lds_bytes(), s, p, seg_len);
-        return;
-    }
-    if (p.M == 64 && p.J == 35 && p.legacy != 1) {
-        if (dyn_lds_limit(reinterpret_cast<const void*>(k_pfb_chan64<35>), 160 * 1024) != hipSuccess) return;
-        hipLaunchKernelGGL(k_pfb_chan64<35>, dim3((p.m_count + C64_TI - 1) / C64_TI, batch), dim3(256), chan64_lds_bytes(35), s, p);
         return;
     }
     const dim3 grid((p.m_count + CH_TI - 1) / CH_TI, batch);

@@ -24,7 +24,7 @@
 // conflict free for ds_read_b64).
 // Round 5: stages B (33-tap channel filter) and E (125-tap RRC) run on the f32 MATRIX pipe as Toeplitz products (v_mfma_f32_16x16x4_f32: rows = 16
 // consecutive outputs, columns = blocks of 16 outputs, K = four sample offsets in descending order = tap index ascending): see the two stages.  The
-// register-blocked packed-fma form described above is what stage A (the resampler) still uses; QRL_CT_B_MFMA = 0 keeps it for stage B (A/B builds).
+// register-blocked packed-fma form described above is what stage A (the resampler) still uses.
 // Every chain is the oracle's: one fmaf chain per output, tap index ascending, first term fmaf(h, x, +0) (orc_resamp_ccf,
 // orc_fir_ccf, orc_fir_fff); discriminator, quantiser and RSSI sums as in k_quad_demod / k_rssi_tag.
 #include <cstring>
@@ -53,9 +53,6 @@ constexpr int CT_SA = CT_JP + 7, CT_SB = CT_NF + 7;   // window steps of the 8-o
 constexpr int CT_EM = (CT_NR + 15 + 3) / 4;            // 35
 // stage B on the matrix pipe as well (round 5): rows = 16 consecutive filter outputs, columns = 8 blocks of 16 outputs x (re, im), K = 4 sample offsets;
 // CT_BM matrix instructions cover d = 15 .. -(CT_NF - 1); the padded tap table of the stage has 15 zeros in front (tB[j] = ft[j - 15])
-#ifndef QRL_CT_B_MFMA
-#define QRL_CT_B_MFMA 1
-#endif
 constexpr int CT_BM = (CT_NF + 15 + 3) / 4;            // 12
 constexpr int CT_HBT = 64;                             // >= 15 + 3 + 4 CT_BM
 constexpr int CT_DP = 113;                             // >= (139 + 16 * 79 + 15) / 16 + 1 = 89 columns
@@ -101,13 +98,7 @@ __global__ __launch_bounds__(256, QRL_CT_WPE) void k_chan_tail(const ChanTailPar
     // workgroup, so that FIVE workgroups' worth of LDS is there: four of this kernel + the symbol synchroniser of the previous call)
     float* const tA = dv; float* const tB = dv + 3 * CT_SA * 8;
     static_assert(3 * CT_SA * 8 + CT_SB * 8 <= 16 * CT_DP, "tap tables do not fit the discriminator image");
-#ifdef QRL_CT_ROT
-    // wave ROLES rotate with the workgroup: stages A / B / E leave the last wave idle (and give it the RSSI sums) -- if wave i of every workgroup
-    // sits on SIMD i, a fixed role assignment idles one SIMD of the CU during those stages
-    const int tid = (int)((((threadIdx.x >> 6) + blockIdx.x + blockIdx.y) & 3u) << 6 | (threadIdx.x & 63u)), lane = tid & 63;
-#else
     const int tid = threadIdx.x, lane = tid & 63;
-#endif
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = blockIdx.y;
 #ifdef QRL_CT_PROF
@@ -124,11 +115,7 @@ __global__ __launch_bounds__(256, QRL_CT_WPE) void k_chan_tail(const ChanTailPar
     if (tt) __syncthreads();                                                      // the previous tile's readers of xf / av / dv are through
     // step-major tap tables, laid out by the host (chan_tail_tables): straight 16-byte copies (per tile: stage D overwrites them)
     for (int k = tid; k < 3 * CT_SA * 2; k += 256) reinterpret_cast<float4*>(tA)[k] = reinterpret_cast<const float4*>(P.tab_a)[k];
-#if QRL_CT_B_MFMA
     if (tid < CT_HBT) tB[tid] = P.tab_b[tid];
-#else
-    if (tid < CT_SB * 2) reinterpret_cast<float4*>(tB)[tid] = reinterpret_cast<const float4*>(P.tab_b)[tid];
-#endif
     CT_STAMP(0);
     const int64_t ua = ct_floordiv(Q0 - CT_HA, 24), qa = ua * 24;                 // first resampler output of the tile (multiple of 24)
     const int NU = (int)((Q0 + CT_T - qa + 23) / 24);                             // groups of 24 outputs: <= 59
@@ -204,7 +191,6 @@ __global__ __launch_bounds__(256, QRL_CT_WPE) void k_chan_tail(const ChanTailPar
     // changed nothing), and this stage is the largest: here the 33 taps live in REGISTERS (17 pairs, read once per tile out of rows
     // 7, 15, 23, 31, 39 of the step-major table: row 8 i + 7 holds h[8 i .. 8 i + 7]), the 40 steps are unrolled with compile-time
     // tap indices -- one LDS read (the sample) per step, and the taps that are zero padding are not multiplied at all.
-#if QRL_CT_B_MFMA
     {
         // Round 5: the same Toeplitz form as stage E.  Output i' = 16 n + i (relative to qb), component c:  F[i][(n, c)] = sum_d A[i][d] B[d][(n, c)],
         // A[i][d] = ft[i - d] (0 outside the filter), B[d][(n, c)] = component c of a[ib0 + 16 n + d], d = 15 .. -32 in DESCENDING order, four per
@@ -240,34 +226,6 @@ __global__ __launch_bounds__(256, QRL_CT_WPE) void k_chan_tail(const ChanTailPar
             }
         }
     }
-#else
-    if (tid < (NB + 7) / 8) {
-        const float4* tp = reinterpret_cast<const float4*>(tB);
-        v2f_ct hb[20];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const float4 h0 = tp[2 * (8 * i + 7)], h1 = tp[2 * (8 * i + 7) + 1];
-            hb[4 * i] = v2f_ct{h0.x, h0.y}; hb[4 * i + 1] = v2f_ct{h0.z, h0.w}; hb[4 * i + 2] = v2f_ct{h1.x, h1.y}; hb[4 * i + 3] = v2f_ct{h1.z, h1.w};
-        }
-        const float2* ab = av + (ib0 >> 3) + tid;                                  // item ib0 + 8 g + d at ab[(d & 7) W + (d >> 3)]
-        v2f_ct acc[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) acc[r] = v2f_ct{0.f, 0.f};
-#pragma unroll
-        for (int st = 0; st < CT_SB; ++st) {
-            const int d = 7 - st;                                                  // compile time
-            const float2 xs = ab[(d & 7) * CT_W + (d >> 3)];
-            const v2f_ct x = {xs.x, xs.y};
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int t = st - 7 + r;                                          // tap index of output r at this step (ascending with the steps)
-                if (t >= 0 && t < CT_NF) { if (t & 1) ct_fma_hi(acc[r], hb[t >> 1], x); else ct_fma_lo(acc[r], hb[t >> 1], x); }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) xf[r * CT_W + tid] = make_float2(acc[r].x, acc[r].y);   // f item i' = 8 g + r (relative to qb)
-    }
-#endif
     CT_STAMP(6);
     __syncthreads();
     CT_STAMP(7);
@@ -429,20 +387,9 @@ std::vector<float> chan_tail_tables(int which, const float* taps)
         for (int k = 0; k < CT_NR; ++k) t[15 + k] = taps[k];
         return t;
     }
-#if QRL_CT_B_MFMA
-    if (which == 1) {   // stage B (matrix pipe): tB[j] = ft[j - 15]
-        std::vector<float> t((size_t)CT_HBT, 0.0f);
-        for (int k = 0; k < CT_NF; ++k) t[15 + k] = taps[k];
-        return t;
-    }
-#endif
-    const int nt = CT_NF, ns = CT_SB;
-    std::vector<float> t((size_t)ns * 8, 0.0f);
-    for (int st = 0; st < ns; ++st)
-        for (int r = 0; r < 8; ++r) {
-            const int j = r - (7 - st);
-            if (j >= 0 && j < nt) t[(size_t)st * 8 + r] = taps[j];
-        }
+    // which == 1: stage B (matrix pipe): tB[j] = ft[j - 15]
+    std::vector<float> t((size_t)CT_HBT, 0.0f);
+    for (int k = 0; k < CT_NF; ++k) t[15 + k] = taps[k];
     return t;
 }
 bool chan_tail_supported(int rs_I, int rs_D, int rs_Jp, int filt_nt, int rrc_nt)

@@ -193,12 +193,6 @@ __device__ __forceinline__ void pm_wait_vm_dyn(uint32_t allowed)   // wave unifo
     }
 }
 
-#ifndef QRL_PM_PRIO
-#define QRL_PM_PRIO 0   // experiment: distinct s_setprio per resident workgroup
-#endif
-#ifndef QRL_PM_SWP
-#define QRL_PM_SWP 0   // experiment: interleave the rotation of the next step with the matrix instructions (sched_barrier regions + sched_group_barrier); measured: no gain
-#endif
 #ifndef QRL_PM_ABL
 #define QRL_PM_ABL 0   // developer builds only (tools/pl_variants.sh): bit 0 no output store, bit 1 no rotator, bit 2 no MFMA, bit 3 no diagonal sums (wrong results; timing ablations)
 #endif
@@ -240,19 +234,6 @@ void k_decim_pm(const DecimParams P_)
     float2 (*t_hi_all)[NHI] = reinterpret_cast<float2 (*)[NHI]>(t_lo + 512);      // coarse rotator table of each wave's segment (NHI x 512 samples)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#if QRL_PM_PRIO
-    // The waves that share a SIMD (one per resident workgroup) all walk fetch -> LDS -> matrix pipe -> store; with equal priority they
-    // fall into step (everybody fetches, then everybody queues for the matrix pipe) and the pipe idles a third of the time.  Distinct
-    // issue priorities turn the sharing into a pipeline: the highest wave computes at full rate and goes to fetch while the others compute.
-#if QRL_PM_PRIO == 2
-    __builtin_amdgcn_s_setprio(3);   // every front-end wave above the waves of other kernels that share its SIMD
-#else
-    switch (((blockIdx.x >> 8) + blockIdx.x) & 3u) {
-    case 0: __builtin_amdgcn_s_setprio(0); break;  case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;  default: __builtin_amdgcn_s_setprio(3); break;
-    }
-#endif
-#endif
     for (int k = tid; k < 512; k += NW * 64) t_lo[k] = P.rot_lo[k];
 
     // unit = (stream, segment); behind the regular units one EDGE unit per stream (outputs pl_edge_ms .. pl_edge_me out of the staged,
@@ -356,10 +337,9 @@ void k_decim_pm(const DecimParams P_)
         f32x4_pm zr[NT], zi[NT];                                     // [t]: gets tile t now; [0] is complete after this group
         zr[NT - 1] = f32x4_pm{0.f, 0.f, 0.f, 0.f}; zi[NT - 1] = zr[NT - 1];
         if constexpr (NT == 3) { zr[0] = nr1; zi[0] = ni1; zr[1] = nr2; zi[1] = ni2; }
-        // rotator: phasor of sample k = T_hi[k >> 9] (x) T_lo[k & 511], byte addressed.  Software pipelined by one step: the rotation of
-        // step s + 1 is issued between the matrix instructions of step s (a 16x16x4 f32 MFMA holds the pipe for 32 cycles -- room for
-        // three VALU instructions of the same wave), (QRL_PM_SWP = 1; measured without effect: the other waves of the SIMD already fill those gaps)
-        // (the table reads run two steps ahead, so the rotation never waits for the LDS)
+        // rotator: phasor of sample k = T_hi[k >> 9] (x) T_lo[k & 511], byte addressed; the table reads run two steps ahead, so the rotation never
+        // waits for the LDS.  (Pinning the rotation of step s + 1 between the matrix instructions of step s with sched_group_barrier, and distinct
+        // s_setprio per resident workgroup, were measured without effect -- docs/KERNELS.md 1 -- and deleted in round 6.)
         struct Ph { float2 lo, hi; };
         auto tab = [&](int s_) -> Ph {
             const uint32_t kk = kb8 + 32u * (uint32_t)s_;
@@ -383,9 +363,6 @@ void k_decim_pm(const DecimParams P_)
             // (scheduling barriers pin the order: the reads for the step after next are issued HERE, a whole step before their use --
             // otherwise the scheduler sinks every read down to its use and the rotation waits for the LDS)
             if (s + 2 < NS) pnn = tab(s + 2);
-#if QRL_PM_SWP
-            if constexpr (NT == 3) __builtin_amdgcn_sched_barrier(0);
-#endif
             if (s + 1 < NS) xn = rot(s + 1, pn);
             pn = pnn;
             if (K1 && s == NS - 1) {
@@ -410,16 +387,6 @@ void k_decim_pm(const DecimParams P_)
                 zi[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], xs.y, zi[t], 0, 0, 0);
 #endif
             }
-#if QRL_PM_SWP
-            if constexpr (NT == 3) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one matrix instruction
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // three VALU in its shadow
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#endif
             xs = xn;
         }
         PM_STAMP(3);

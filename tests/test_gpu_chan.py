@@ -480,7 +480,7 @@ def test_channelizer_64_legacy_kernel_and_ragged_calls(qrl_ctx, chunk):
     M, n = 64, 64 * 2500
     iq = _wideband(M, n, seed=77, nstreams=2)
     ref = [orc.demod_mmdvm_multi(iq[b], M) for b in range(2)]
-    for legacy in (0, 1, 2):
+    for legacy in (0, 1):
         ch = q.Channelizer(qrl_ctx, M, batch=2, max_chunk=chunk)
         ch.set_option(q.CHAN_OPT_LEGACY_PFB, legacy)
         d = torch.from_numpy(iq).cuda()
