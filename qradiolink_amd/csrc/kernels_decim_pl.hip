@@ -950,7 +950,11 @@ static int pm_launch_main(DecimParams& q, uint64_t M, uint32_t batch, bool edge_
     // recursion kernels of the previous call beside them) were measured: 7.24 ms against 6.57 ms alone, and no gain in the overlapped mode.
     constexpr int NW = QRL_PM_NW;
     const auto kern = k_decim_pm<J, NS, RP, NW, K1>;
-    const size_t lds = (size_t)NW * RP * 1024 + 512 * sizeof(float2) + NW * PM_NHI * sizeof(float2);
+    size_t lds = (size_t)NW * RP * 1024 + 512 * sizeof(float2) + NW * PM_NHI * sizeof(float2);
+    // experiment (VERDICT r5 #4a): pad the dynamic LDS so that fewer front-end workgroups share a CU and a tail-chain workgroup of the previous call always
+    // finds room beside them (QRL_PM_LDS_KB = total KB per workgroup; 45 -> three per CU with 25 KB to spare)
+    static const size_t lds_min = [] { const char* e = std::getenv("QRL_PM_LDS_KB"); return e ? (size_t)std::atoi(e) * 1024 : (size_t)0; }();
+    if (lds_min > lds && lds_min <= 160 * 1024) lds = lds_min;
     // occupancy and CU count per (instantiation, device): a second device in the process gets its own LDS attribute (dyn_lds_limit
     // de-duplicates per kernel and device) and its own geometry; first calls may race, hence the lock
     static std::mutex mu; static int wg_cache[16], cu_cache[16];
