@@ -298,7 +298,8 @@ def roofline_obj(kernel, kms, launches, bytes_per_launch, bytes_per_sample, note
     ach = bytes_per_launch / (kms / max(launches, 1) * 1e-3) / 1e9 if kms > 0 else 0.0
     traffic, src = pmc_traffic(name, kernel, default_shape) if name else (None, None)
     d = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic,
-             traffic_source=src, kernel=kernel, kernel_ms=round(kms / max(launches, 1), 4), launches=launches,
+             traffic_source=src, traffic_from="a separate rocprofv3 --pmc pass on these kernel sources (source id %s), committed under profiles/; NOT collected in this run" % source_id() if traffic else None,
+             kernel=kernel, kernel_ms=round(kms / max(launches, 1), 4), launches=launches,
              algorithmic_bytes_per_launch=bytes_per_launch, algorithmic_bytes_per_sample=bytes_per_sample)
     if ms_per_step:
         d["whole_step"] = whole_step_obj(bytes_per_launch, ms_per_step)
@@ -329,10 +330,11 @@ def issue_roofline(name, rx_seconds_per_call, default_shape=True):
         ach = valu / rx_seconds_per_call / 1e9
         return dict(bound="issue", achieved=round(ach, 1), peak=VALU_ISSUE_PEAK_G, unit="G wave-instr/s", frac=round(ach / VALU_ISSUE_PEAK_G, 4),
                     valu_wave_instr_per_rx_call=valu, all_wave_instr_per_rx_call=every, waves_per_rx_call=pc.get("SQ_WAVES"),
-                    all_classes_frac=round(every / rx_seconds_per_call / 1e9 / VALU_ISSUE_PEAK_G, 4),
                     by_kernel={k: round(v.get("SQ_INSTS_VALU", 0.0)) for k, v in rec["by_kernel"].items()}, source=rec.get("source"),
-                    note="VALU wave instructions of one receiver call (PMC) / RX-alone time of a call (measured here); all_classes_frac "
-                         "adds SALU, LDS, VMEM, SMEM and branch instructions, which issue from other ports in the same cycle")
+                    note="VALU wave instructions of one receiver call (PMC) / RX-alone time of a call (measured here) against the VALU issue port of 1024 SIMDs: a "
+                         "UTILISATION of that port, <= 1 by construction (round 5 also printed every instruction class against the same peak, which exceeded 1 because "
+                         "SALU / LDS / VMEM / branch instructions issue from other ports in the same cycle: removed).  The decoder's other limit, the LDS pipe, and the "
+                         "recursion's, dependent-chain latency, are in docs/KERNELS.md 7 and 9")
     except (OSError, ValueError, KeyError):
         return None
 

@@ -50,7 +50,7 @@ python bench.py --config c1 --no-overlap --no-extra > $O/bench_c1_serial.json 2>
 : > $O/sweep.jsonl
 for b in 1 64 4096 16384; do python bench.py --config c1 --batch $b --no-extra 2>/dev/null | tail -1 >> $O/sweep.jsonl; done
 for b in 1 16 256 384; do python bench.py --config c2 --batch $b --no-extra 2>/dev/null | tail -1 >> $O/sweep.jsonl; done
-for b in 1 4 64 384; do python bench.py --config c3 --batch $b --no-extra 2>/dev/null | tail -1 >> $O/sweep.jsonl; done
+for b in 1 4 64 384 1536; do python bench.py --config c3 --batch $b --no-extra 2>/dev/null | tail -1 >> $O/sweep.jsonl; done
 # the whole GPU suite and the smoke entry on the final build
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc $?" >> $O/smoke.log
