@@ -35,7 +35,9 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 # what "bit-exact" in every parity_check of this file means: the checker is oracle/, not GNU Radio
 PARITY_AGAINST = ("oracle/ (C restatement of the GNU Radio 3.10 block semantics; its FIR / DFT summation orders are contracts shared with the kernels, "
                   "each with a float64 definition test); the arithmetic of the stock GNU Radio / VOLK blocks is unpinned (no GNU Radio in this image), and the rotator "
-                  "is an exact 2^-64-turn NCO that leaves VOLK's phase recursion by up to 4.5e-4 on the float ports at a 25 kHz offset (hard bits unaffected)")
+                  "is an exact 2^-64-turn NCO that leaves VOLK's phase recursion by up to 4.5e-4 on the float ports at a 25 kHz offset (hard bits unaffected); "
+                  "[GR-MEM] the fast_atan2f, tanhf_lut and MMSE-interpolator tables are regenerated from their formulas and rounded to float -- the literal upstream tables "
+                  "are not available here")
 
 # the channel every synth() stream of C1 / C2 / C3 / C5 goes through (VERDICT r5 "next" #1: parity_check names it)
 SYNTH_CHANNEL = ("SURVEY 8(d) (tests/sig.py SPEC): fractional delay 0.37 sample + clock error +20 ppm (32-tap windowed-sinc resampling of the modulator output), "
