@@ -288,6 +288,10 @@ def pmc_chain_traffic(name, default_shape=True):
         return None, None
 
 
+# `traffic` is not measured by the run that prints it
+TRAFFIC_FROM = "a separate rocprofv3 --pmc pass on these kernel sources (source id %s), committed under profiles/; NOT collected in this run"
+
+
 def whole_step_obj(bytes_per_step, ms_per_step):
     """The same algorithmic bytes over the WHOLE step (every kernel of the chain, as timed by the bench loop) instead of the dominant
     kernel's own duration: printed beside `frac` on every line (hygiene)."""
@@ -300,7 +304,7 @@ def roofline_obj(kernel, kms, launches, bytes_per_launch, bytes_per_sample, note
     ach = bytes_per_launch / (kms / max(launches, 1) * 1e-3) / 1e9 if kms > 0 else 0.0
     traffic, src = pmc_traffic(name, kernel, default_shape) if name else (None, None)
     d = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic,
-             traffic_source=src, traffic_from="a separate rocprofv3 --pmc pass on these kernel sources (source id %s), committed under profiles/; NOT collected in this run" % source_id() if traffic else None,
+             traffic_source=src, traffic_from=TRAFFIC_FROM % source_id() if traffic else None,
              kernel=kernel, kernel_ms=round(kms / max(launches, 1), 4), launches=launches,
              algorithmic_bytes_per_launch=bytes_per_launch, algorithmic_bytes_per_sample=bytes_per_sample)
     if ms_per_step:
@@ -481,7 +485,8 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, c
         flop = (C4_FLOP_PFB + C4_FLOP_TAIL) * b_kernel * n
         line["roofline"] = dict(
             bound="f32 instruction issue (VALU + matrix pipe); hbm figures for reference", achieved=ws["achieved"], peak=HBM_PEAK_GBPS, unit="GB/s", frac=ws["frac"],
-            traffic=chain_traffic if chain_traffic else traffic, traffic_source=src, traffic_kernel=traffic, traffic_by_kernel=chain_by_kernel,
+            traffic=chain_traffic if chain_traffic else traffic, traffic_source=src, traffic_from=TRAFFIC_FROM % source_id() if (chain_traffic or traffic) else None,
+            traffic_kernel=traffic, traffic_by_kernel=chain_by_kernel,
             traffic_note=("traffic = HBM bytes per step of the WHOLE chain (sum over its kernels, PMC); traffic_kernel = the dominant kernel's own. The chain hands two rings "
                           "from kernel to kernel -- 1.07 GB of 25 ksps channel samples (written by the channelizer, read with a 20 % halo by the per-channel kernel) and "
                           "0.5 GB of RRC output (written there, read by the symbol synchroniser) -- which is what separates it from the algorithmic bytes; at the step time "
@@ -840,7 +845,8 @@ def main():
             # HBM traffic per launch of the dominant kernel: pmc_traffic() above
             traffic, src = pmc_traffic(r["name"], r["kernel"], r["default_shape"])
             d = dict(bound="hbm", achieved=round(r["achieved_gbps"], 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                     frac=round(r["achieved_gbps"] / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=src, kernel=r["kernel"],
+                     frac=round(r["achieved_gbps"] / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=src,
+                     traffic_from=TRAFFIC_FROM % source_id() if traffic else None, kernel=r["kernel"],
                      kernel_ms=round(r["kernel_ms"], 4), launches=r["launches"],
                      algorithmic_bytes_per_launch=r["bytes_per_launch"], algorithmic_bytes_per_sample=r["bytes_per_sample"],
                      whole_step=whole_step_obj(r["bytes_per_launch"], r["ms_per_step"]))

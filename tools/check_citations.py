@@ -9,8 +9,9 @@ import sys
 
 ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-files = [f for pat in ("*.md", "include/*.h", "oracle/*.c", "oracle/*.h", "qradiolink_amd/csrc/*", "qradiolink_amd/host/*",
+files = [f for pat in ("*.md", "include/*.h", "oracle/*.c", "oracle/*.h", "qradiolink_amd/csrc/*", "qradiolink_amd/host/*", "qradiolink_amd/host/qt/*", "tests/host/*.cpp", "tests/host/*.h", "docs/*.md",
                        "qradiolink_amd/*.py", "tests/*.py", "bench.py") for f in glob.glob(os.path.join(root, pat))]
+files = [f for f in files if os.path.isfile(f) and not f.endswith((".o", ".so", ".a")) and os.access(f, os.R_OK) and not (os.access(f, os.X_OK) and "." not in os.path.basename(f))]
 files = [f for f in files if os.path.basename(f) not in ("SURVEY.md", "PAPERS.md", "SNIPPETS.md", "BASELINE.md")]
 pat = re.compile(r"(?<![\w/])((?:src/)?(?:gr/|DMR/|MMDVM/|M17/)?[A-Za-z_0-9]+\.(?:cpp|h|cc|hpp|pro)):(\d+)(?:-(\d+))?")
 lens, bad, n = {}, 0, 0
