@@ -360,6 +360,31 @@ def promote_issue(roof, issue, dominant, why):
     return out
 
 
+C4_CHANNEL = ("wideband noise (0.05 rms per component) + DMR-like 4FSK on channels 2, 17, 31, 45, 60 of every stream with SURVEY 8(d)'s timing: symbol clocks +-20 ppm, first symbol "
+              "0.37 .. 0.81 symbol late (tests/sig.py make_4fsk clock_ppm / frac_delay); per stream a circular shift")
+
+
+def c4_add_4fsk(iq, torch, seed):
+    """DMR-like 4FSK carriers on five of the 64 channels of every wideband stream (the input of the C4 line: its parity_check then compares the dibits of real symbols
+    under a sliding symbol phase, not only of noise); built once, untimed"""
+    import sig
+    B, n = iq.shape
+    fs = 1.6e6
+    t = torch.arange(n, device=iq.device, dtype=torch.float64)
+    for k, c in enumerate((2, 17, 31, 45, 60)):
+        x, _ = sig.make_4fsk(nsym=int(n / fs * 4800) - 8, seed=seed + k, amp=0.3, noise=0.0, fs=fs, clock_ppm=20.0 * (1 if k % 2 == 0 else -1), frac_delay=0.37 + 0.11 * k)
+        base = np.zeros(n, np.complex64)
+        base[:min(n, x.size)] = x[:n]
+        f0 = c * 25000.0 if c <= 32 else (c - 64) * 25000.0
+        ph = (f0 / fs) * t
+        ph = (ph - torch.floor(ph)) * (2 * np.pi)
+        carrier = torch.polar(torch.ones_like(ph, dtype=torch.float32), ph.to(torch.float32))
+        xb = torch.from_numpy(base).to(iq.device)
+        for b in range(B):
+            iq[b] += torch.roll(xb, 7919 * b + 131 * k) * carrier
+    return iq
+
+
 def parity_check_c4(ch, iq, torch, nstreams=2, seed=6):
     """One call from a fresh state at the bench shape: every channel of `nstreams` random wideband streams against the oracle --
     int16 FM samples and 4FSK dibits bit for bit, rssi_tag_block values to 1e-4 dB (log10f) -- untimed."""
@@ -380,7 +405,7 @@ def parity_check_c4(ch, iq, torch, nstreams=2, seed=6):
             ok = ok and dc[k, 2] == dref[k].size and np.array_equal(d[k, :dc[k, 2]], dref[k])
             if not ok:
                 return dict(status="FAILED", stream=b, channel=k, streams=picks)
-    return dict(status="bit-exact", streams=picks, compared="int16 FM samples and 4FSK dibits of all %d channels (bit for bit), RSSI tags (1e-4 dB), one call from a fresh state" % M, against=PARITY_AGAINST,
+    return dict(status="bit-exact", streams=picks, compared="int16 FM samples and 4FSK dibits of all %d channels (bit for bit), RSSI tags (1e-4 dB), one call from a fresh state" % M, channel=C4_CHANNEL, against=PARITY_AGAINST,
                 int16_per_channel=int(ref.shape[1]), dibit_bytes_per_channel=int(dref[0].size))
 
 
@@ -404,7 +429,7 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, c
     from qradiolink_amd import sharding
     link_bytes = None
     if world == 1 and not args.cluster:
-        iq = torch.view_as_complex(torch.randn((B, n, 2), generator=g, device=dev, dtype=torch.float32) * 0.05)
+        iq = c4_add_4fsk(torch.view_as_complex(torch.randn((B, n, 2), generator=g, device=dev, dtype=torch.float32) * 0.05), torch, 40 + rank)
         ch = q.Channelizer(ctx, M, batch=B, max_chunk=n)
         ch.enable_4fsk()
         if args.legacy_pfb:
@@ -421,7 +446,7 @@ def run_c4(args, torch, q, ctx, dev, rank, world, steps=None, with_form2=True, c
         if getattr(args, "cluster_copy", False):
             os.environ["QRL_CLUSTER_COPY_AT_ONE_RANK"] = "1"
         Bl, n1 = B // world, n // M
-        iq = torch.view_as_complex(torch.randn((Bl, n, 2), generator=g, device=dev, dtype=torch.float32) * 0.05)   # this rank's own inputs
+        iq = c4_add_4fsk(torch.view_as_complex(torch.randn((Bl, n, 2), generator=g, device=dev, dtype=torch.float32) * 0.05), torch, 40 + rank)   # this rank's own inputs
         ex = sharding.Exchange.rccl(torch.distributed if world > 1 else None)
         cl = sharding.Cluster(ctx, ex, M, Bl, n)
         cl.tail.enable_4fsk()

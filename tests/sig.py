@@ -160,20 +160,23 @@ def find_frames(bits, sync, nbits):
     return out
 
 
-def make_4fsk(nsym=400, seed=1, amp=0.3, noise=0.002, cfo=0.0, fs=1000000.0, levels=None, alpha=0.2, dev=1944.0):
+def make_4fsk(nsym=400, seed=1, amp=0.3, noise=0.002, cfo=0.0, fs=1000000.0, levels=None, alpha=0.2, dev=1944.0, clock_ppm=0.0, frac_delay=0.0):
     """DMR-like 4FSK at 4800 sym/s on 1 Msps IQ (RRC alpha 0.2, deviation +-1944 / +-648 Hz; dibit map of the DMR air
     interface: 01 -> +3, 00 -> +1, 10 -> -1, 11 -> -3).  Returns (iq complex64, dibits).  levels: explicit symbol levels in
-    units of the outer deviation (+-1, +-1/3, 0 = unmodulated carrier) instead of random dibits.  M17: alpha=0.5, dev=2400."""
+    units of the outer deviation (+-1, +-1/3, 0 = unmodulated carrier) instead of random dibits.  M17: alpha=0.5, dev=2400.
+    clock_ppm: the transmitter's symbol clock runs fast by that much (symbol rate 4800 (1 + ppm 1e-6)); frac_delay: the first symbol sits that many
+    SYMBOL periods late (SURVEY 8(d)'s timing impairments for the 4FSK tails, where the signal is synthesised at the sample rate directly)."""
     rng = np.random.default_rng(seed)
     dib = rng.integers(0, 4, nsym)
     lev = np.array([+1, +3, -1, -3])[dib] / 3.0
     if levels is not None:
         lev = np.asarray(levels, float)
         nsym, dib = lev.size, None
-    sps = fs / 4800.0
-    n = int(nsym * sps) & ~1
+    sps = fs / (4800.0 * (1.0 + clock_ppm * 1e-6))
+    n = int((nsym + frac_delay) * sps) & ~1
     up = np.zeros(n)
-    up[(np.arange(nsym) * sps).astype(int)] = lev
+    pos = ((np.arange(nsym) + frac_delay) * sps).astype(int)
+    up[pos[pos < n]] = lev[:np.count_nonzero(pos < n)]
     L = int(8 * sps)
     tt = np.arange(-L, L + 1) / sps
     a = alpha
@@ -181,7 +184,11 @@ def make_4fsk(nsym=400, seed=1, amp=0.3, noise=0.002, cfo=0.0, fs=1000000.0, lev
         h = (np.sin(np.pi * tt * (1 - a)) + 4 * a * tt * np.cos(np.pi * tt * (1 + a))) / (np.pi * tt * (1 - (4 * a * tt) ** 2))
     h[np.isnan(h)] = 1 - a + 4 * a / np.pi
     h[np.isinf(h)] = 0
-    f = np.convolve(up, h, mode="same")
+    if float(n) * h.size > 2e8:     # long streams at a high sample rate (bench.py's C4 input): the same pulse shaping through an FFT
+        from scipy.signal import fftconvolve
+        f = fftconvolve(up, h, mode="same")
+    else:
+        f = np.convolve(up, h, mode="same")
     ph = 2 * np.pi * np.cumsum(f * dev + cfo) / fs
     x = amp * np.exp(1j * ph) + noise * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
     return x.astype(np.complex64), dib

@@ -77,3 +77,15 @@ def test_survey_channel_moves_the_decisions(mode, demod, kw):
     ra, rb = demod(orc.frontend(a, 1000000, 0.0), **kw), demod(orc.frontend(b, 1000000, 0.0), **kw)
     n = min(ra["filtered"].size, rb["filtered"].size)
     assert n > 100 and not np.array_equal(ra["filtered"][:n], rb["filtered"][:n])
+
+
+@pytest.mark.parametrize("ppm,expect_hits", [(20.0, False), (-14000.0, True), (14000.0, True)])
+def test_4fsk_symbol_clock_error_reaches_the_dmr_tails_limiter(ppm, expect_hits):
+    """the inputs of test_gpu_chan.py::test_channelizer_64_4fsk_channels_with_symbol_clock_error: at 20 ppm the DMR tail's symbol_sync_ff (max_dev 0.06 of 5
+    samples) tracks without touching its limiter, at -14000 / +14000 ppm it sits in it (orc.loop_clamp_hits), and the symbol count moves with the clock"""
+    x, _ = sig.make_4fsk(nsym=600, seed=50, amp=0.3, noise=0.0, fs=1000000.0, clock_ppm=ppm, frac_delay=0.37)
+    orc.loop_clamp_hits()
+    r = orc.demod_dmr(x)
+    hits = orc.loop_clamp_hits()
+    assert r["bits_a"].size > 800
+    assert (hits > 50) == expect_hits, (ppm, hits)
