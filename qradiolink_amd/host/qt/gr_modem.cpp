@@ -19,11 +19,13 @@ gr_modem::gr_modem(const Settings *settings, Logger *logger, DMRControl *dmrcont
 {
 }
 
-gr_modem::~gr_modem()   // :49-59
+gr_modem::~gr_modem()   // :49-59 (deinitRX / deinitTX without rebuilding the facade object in between)
 {
-    if (_gr_demod_base) deinitRX(_modem_type_rx);
-    if (_gr_mod_base) deinitTX(_modem_type_tx);
     delete _modem;
+    _modem = nullptr;
+    if (_gr_demod_base) { _gr_demod_base->stop(); delete _gr_demod_base; _gr_demod_base = nullptr; }
+    delete _gr_mod_base;
+    _gr_mod_base = nullptr;
 }
 
 void gr_modem::setDevice(int device, size_t rx_max_samples, size_t tx_max_bytes)
