@@ -24,7 +24,7 @@ for _ in range(2): dem.process_async(iq); dem.sync()
 lib.qrl_fec_prof_read(out)
 for _ in range(4): dem.process_async(iq); dem.sync()
 lib.qrl_fec_prof_read(out)
-names = ["symbol load + setup", "metric table pre-pass (2 x)", "forward (2 x 43 steps)", "end state (2 wave minima)", "chainback (scalar, 80 steps x 2)", "descrambler + stores"]
+names = ["symbol selects + setup", "(unused)", "forward (86 steps, table pre-passes included)", "history complement", "end state + chainback (scalar, 80 steps x 2)", "descrambler + stores"]
 nb = out[7]
 tot = sum(out[k] for k in range(6))
 for k in range(6):
