@@ -262,10 +262,10 @@ __global__ __launch_bounds__(256) void k_qpsk_loops(const QpskParams P, int batc
 // The chain is a serial recurrence per stream; with one lane per stream the time of a call is (samples per stream) x (instructions
 // the slowest wave issues per sample), whatever the batch.  So every recurrence gets its own wave (its own SIMD) and nothing but the
 // recurrence runs on it:
-//   wave 0  agc2_cc                          window t      (in place in the LDS ring)
-//   wave 1  costas_loop_cc #1                window t - 1  (in place)
-//   wave 2  symbol_sync_cc (MMSE + M&M TED)  window t - 2  -> interpolated symbols Y
-//   wave 3  costas_loop_cc #2, diff_phasor, rotate         window t - 3  Y -> osym
+//   stage 0 agc2_cc                          window t      (in place in the LDS ring)
+//   stage 1 costas_loop_cc #1                window t - 1  (in place)
+//   stage 2 symbol_sync_cc (MMSE + M&M TED)  window t - 2  -> interpolated symbols Y
+//   stage 3 costas_loop_cc #2, diff_phasor, rotate         window t - 3  Y -> osym
 //   waves 4-5  load window t + 1 from the RRC ring, flush the symbols of window t - 4 (soft symbols + constellation port)
 // one barrier per window.  The samples live in one LDS ring per stream (5 windows of 32 columns + an 8-column mirror of the first
 // columns so that the 8-tap interpolator never wraps); the loops are straight-line code (selects instead of branches, inputs of four
@@ -328,7 +328,11 @@ __global__ __launch_bounds__(384) void k_qpsk_pipe4(const QpskParams P, int batc
     uint64_t* obase = reinterpret_cast<uint64_t*>(ocnt + 2 * 64);        // [2][64]
     uint64_t* oo0 = obase + 2 * 64;                                      // [64]
 
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, hwv = tid >> 6, lane = tid & 63;
+    // stage of this wave.  Consecutive waves of a workgroup go to consecutive SIMDs, so the two loader waves (4, 5) share theirs with waves
+    // 0 and 1: those are the AGC and the symbol synchroniser (45 % / 56 % busy), the two Costas loops -- the first one sets the pace of the
+    // walk -- have a SIMD each (wave 1 <-> wave 2: k_qpsk_pipe4 2 020-2 050 -> 1 970-1 980 us on C3, profiles/r06_c5_experiments.log)
+    const int wv = hwv == 1 ? 2 : hwv == 2 ? 1 : hwv;
     const int b0 = blockIdx.x * 64;
     const int nstreams = min(64, batch - b0);
 #ifndef QRL_Q4_NOPRIO
@@ -390,14 +394,14 @@ __global__ __launch_bounds__(384) void k_qpsk_pipe4(const QpskParams P, int batc
                 const int idx = base + u * nthreads;
                 v[u] = make_float2(0.f, 0.f);
                 if (idx < total) {
-                    const int s = idx / cnt, c = idx - s * cnt;
+                    const int s = cnt == Q4_W ? idx / Q4_W : idx / cnt, c = idx - s * cnt;
                     v[u] = P.in.p[(size_t)(b0 + s) * (P.in.mask + 1u) + ((uint32_t)(ia + c) & P.in.mask)];
                 }
             }
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
                 const int idx = base + u * nthreads;
-                if (idx < total) { const int s = idx / cnt, c = idx - s * cnt; ring[s * Q4_PITCH + c0 + c] = v[u]; }
+                if (idx < total) { const int s = cnt == Q4_W ? idx / Q4_W : idx / cnt, c = idx - s * cnt; ring[s * Q4_PITCH + c0 + c] = v[u]; }
             }
         }
     };
