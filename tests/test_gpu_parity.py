@@ -600,6 +600,29 @@ def test_dsss_info_bits_recovered(qrl_ctx):
     assert any(want in "".join(map(str, out[p][0])) for p in ("bits_a", "bits_b"))
 
 
+# the Viterbi decoder away from a clean signal (round 6: k_fec rebuilt with a rotating state -> lane layout): noise only -- every path metric close
+# to every other, ties at every step -- and inputs so strong or so weak that the soft symbols sit at 0 / 255 or at 128 (saturated adds,
+# renormalisation at almost every step, or never); cc_decoder's block chaining (the start state is the state six steps before the end of
+# the block before) across call cuts that do not line up with the 80-bit blocks
+@pytest.mark.parametrize("mode_name,modem,rate", [("2fsk1k", 18, 1000000), ("gmsk10k", 22, 1000000), ("qpsk250k", 26, 1000000), ("bpsk2k", 0, 1000000),
+                                                   ("4fsk100k", 27, 1000000)])
+@pytest.mark.parametrize("amp", [1e-4, 0.05, 40.0])
+def test_decoder_on_noise_and_saturating_inputs(qrl_ctx, mode_name, modem, rate, amp):
+    import torch
+    import qradiolink_amd as q
+    rng = np.random.default_rng(int(amp * 1e4) + modem)
+    n = 300000 if mode_name in ("qpsk250k", "4fsk100k", "gmsk10k") else 1200000
+    noise = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))).astype(np.complex64) * np.float32(amp)
+    sigl = sig.make_batch(mode_name, 1, nframes=1, device_rate=rate, rx_offset_hz=1200.0, seed=9)[0]
+    iq = noise.copy()
+    m = min(n, sigl.size)
+    iq[1, :m] += sigl[:m] * np.float32(amp / 0.05)          # stream 1: the frame under the same noise level (about 0 dB)
+    dem = q.Demod(qrl_ctx, modem, batch=2, max_chunk=77777, device_samp_rate=rate, carrier_offset_hz=1200.0)
+    out = q.collect(dem, torch.from_numpy(iq).cuda(), 77777)
+    dem.close()
+    _compare(iq, out, mode_name, rate, 1200.0)
+
+
 @pytest.mark.parametrize("mode_name,modem", [("2fsk1k", 18), ("2fsk1kfm", 16), ("gmsk10k", 22), ("qpsk250k", 26), ("bpsk2k", 0)])
 def test_pipelined_calls_without_sync(qrl_ctx, mode_name, modem):
     """Back-to-back qrl_demod_process calls with NO sync in between (how bench.py drives the handle; the 2FSK family then runs
