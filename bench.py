@@ -663,7 +663,7 @@ def run_c5(args, torch, q, ctx, dev, rank, world, steps=None, check=False):
     line["roofline"]["whole_step"] = whole_step_obj(tot / args.steps * (C5_RX_BYTES + 8.0), dt / args.steps * 1e3)
     line["roofline"] = promote_issue(line["roofline"], issue, "k_fec, k_qpsk_pipe4",
                                      "a receiver call is k_dec2_fir -> k_qpsk_pipe4 (the serial QPSK recursion) || k_fec (Viterbi decoder of the call before): the two "
-                                     "longest kernels of the trace, both bound by instruction issue / LDS latency; the HBM-facing front end k_dec2_fir is in `hbm`")
+                                     "longest kernels of the trace -- the recursion bound by the latency of its dependent chain, the decoder by the VALU port; the HBM-facing front end k_dec2_fir is in `hbm`")
     if parity:
         line["parity_check"] = parity
     return line
