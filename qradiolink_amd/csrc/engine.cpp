@@ -122,11 +122,13 @@ struct DecimStage {
     bool used = false, mfma = false, pl = false, pm = false;
     int D = 1, Jpad = 0, variant = DECIM_R4_J12, nt = 0, S = 0;
     DevBuf<float> taps;
-    DevBuf<float2> edge; uint32_t edge_len = 0;   // phase-lane kernels: per-stream scratch for the call's edge outputs
-    int alloc_edge(int B) {
+    DevBuf<float2> edge, edge_b; uint32_t edge_len = 0;   // phase-lane kernels: per-stream scratch for the call's edge outputs (two: staged a call ahead)
+    int alloc_edge(int B, bool two = false) {
         if (!pl && !pm) return QRL_OK;
         edge_len = (uint32_t)(pm ? decim_pm_edge_len(nt, D) : decim_pl_edge_len(nt, D));
-        return edge_len ? edge.alloc((size_t)B * edge_len) : QRL_OK;
+        if (!edge_len) return QRL_OK;
+        if (int r = edge.alloc((size_t)B * edge_len)) return r;
+        return two ? edge_b.alloc((size_t)B * edge_len) : QRL_OK;
     }
     int plan(const std::vector<float>& h, int D_) {
         used = true; D = D_; nt = (int)h.size();
@@ -159,10 +161,11 @@ struct DecimStage {
         return taps.upload(decim_layout(h, D, Jpad));
     }
     uint32_t lookback() const { return pm ? decim_pm_lookback(nt, D) : pl ? (uint32_t)(((nt + D - 1) / D + 1) * D) : mfma ? (uint32_t)(nt + D) : (uint32_t)(Jpad * D); }
-    int launch(DecimParams& p, int B, hipStream_t s) const {
+    int launch(DecimParams& p, int B, hipStream_t s, int parity = 0) const {
         p.nt = nt;
-        if (pm) { p.pl_taps = taps.p; p.pl_edge = edge.p; p.pl_edge_stride = edge_len; p.pl_edge_cap = edge_len; return launch_decim_pm(p, B, s); }
-        if (pl) { p.pl_taps = taps.p; p.pl_edge = edge.p; p.pl_edge_stride = edge_len; p.pl_edge_cap = edge_len; return launch_decim_pl(p, B, s); }
+        float2* e = parity && edge_b.p ? edge_b.p : edge.p;
+        if (pm) { p.pl_taps = taps.p; p.pl_edge = e; p.pl_edge_stride = edge_len; p.pl_edge_cap = edge_len; return launch_decim_pm(p, B, s); }
+        if (pl) { p.pl_taps = taps.p; p.pl_edge = e; p.pl_edge_stride = edge_len; p.pl_edge_cap = edge_len; return launch_decim_pl(p, B, s); }
         if (mfma) { p.gtab = taps.p; p.S = S; return launch_decim_mfma(p, B, s); }
         launch_decim(p, B, variant, s);
         return 0;
@@ -195,7 +198,13 @@ struct qrl_demod {
     bool grouped = false, grouped_capable = false, fec_deferred = false; FecParams fec_pending{}; int fec_pending_slot = 0;
     DevBuf<uint64_t> qp_snap;   // [2][B] symbols produced up to the end of call k (slot k & 1): what that call's decoder may read
     hipEvent_t ev_ff = nullptr, ev_tail = nullptr;
-    hipEvent_t ev_user[3] = {nullptr, nullptr, nullptr};   // qrl_demod_stream_wait
+    // HELPER STREAM of the front end (round 6): k_hist (the rotated tail of this call's IQ, kept for the next call) and k_pl_edge_stage (the
+    // next call's edge scratch: that history + the head of the next buffer) read the caller's buffers only, yet they sat between two front-end
+    // launches on the handle's stream -- 0.2 - 0.29 ms of C1's 8 ms step (profiles/r06_c1_helper_stream.log).  On `pre` they run BESIDE the
+    // front end: edge(k) behind hist(k - 1); hist(k) behind the front end of call k - 1 (the last reader of the history buffer it overwrites);
+    // the front end of call k waits for ev_pre.  The history and the edge scratch are double buffers.
+    hipStream_t pre = nullptr; hipEvent_t ev_pre = nullptr, ev_fe[2] = {nullptr, nullptr}; bool fe_valid[2] = {false, false}; bool pre_pending = false;
+    hipEvent_t ev_user[4] = {nullptr, nullptr, nullptr, nullptr};   // qrl_demod_stream_wait
     bool tail_pending = false;
     // overlapped mode (2FSK / GMSK / 4FSK families): everything behind the first decimated ring runs on the tail stream while
     // the front end of the NEXT call already runs on the main stream; ring s2 holds two calls, ev_tail2 guards its reuse
@@ -278,6 +287,9 @@ struct qrl_demod {
         for (auto e : ev_tail2) if (e) (void)hipEventDestroy(e);
         for (auto e : ev_q) if (e) (void)hipEventDestroy(e);
         for (auto e : ev_fec) if (e) (void)hipEventDestroy(e);
+        if (ev_pre) (void)hipEventDestroy(ev_pre);
+        for (auto e : ev_fe) if (e) (void)hipEventDestroy(e);
+        if (pre) (void)hipStreamDestroy(pre);
         if (fecs) (void)hipStreamDestroy(fecs);
         if (tail) (void)hipStreamDestroy(tail);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -306,6 +318,7 @@ struct qrl_demod {
         HIPCHK(hipStreamSynchronize(stream));
         HIPCHK(hipStreamSynchronize(tail));
         HIPCHK(hipStreamSynchronize(fecs));
+        if (pre) HIPCHK(hipStreamSynchronize(pre));
         return QRL_OK;
     }
     bool loops_family() const { return fam == F_QPSK || fam == F_BPSK || fsk4_disc; }
@@ -364,6 +377,7 @@ int qrl_demod::init_state()
         if (hipMemcpy(an_st.p, as.data(), as.size() * sizeof(AnState), hipMemcpyHostToDevice) != hipSuccess) return QRL_ERR_HIP;
     }
     q_valid[0] = q_valid[1] = false; tail2_valid[0] = tail2_valid[1] = false; tail_pending = false; call_no = 0;
+    fe_valid[0] = fe_valid[1] = false; pre_pending = false;
     fec_deferred = false;
     n_in = n1 = n2 = 0;
     rot_acc = 0; rot_nbase = 0; hist_flip = false;
@@ -429,7 +443,7 @@ int qrl_demod::build()
     if (cfg.device_samp_rate >= 2000000) {
         fe_decim = cfg.device_samp_rate / 1000000;
         if ((r = fe.plan(low_pass(1, cfg.device_samp_rate, 480000, 100000, WIN_BLACKMAN_HARRIS), fe_decim))) return fail(r, "front-end plan");
-        if ((r = fe.alloc_edge(cfg.batch))) return fail(r, "front-end edge scratch");
+        if ((r = fe.alloc_edge(cfg.batch, pre != nullptr))) return fail(r, "front-end edge scratch");
     }
     rot_inc = phase_inc_to_turn(2 * M_PI * -cfg.carrier_offset_hz / cfg.device_samp_rate);
     if ((r = upload_rot_table())) return r;
@@ -442,7 +456,7 @@ int qrl_demod::build()
         : fam == F_QPSK
         ? low_pass_2(interp, (double)interp * samp_rate, target / 2, target / 10, 60, WIN_BLACKMAN_HARRIS)   // gr_demod_qpsk.cpp:92-96
         : low_pass(interp, (double)interp * samp_rate, target / 2, target / 2, WIN_BLACKMAN_HARRIS);
-    if (interp == 1) { if ((r = first.plan(rtaps, decim))) return fail(r, "resampler plan"); if (!fe.used && (r = first.alloc_edge(cfg.batch))) return fail(r, "resampler edge scratch"); }
+    if (interp == 1) { if ((r = first.plan(rtaps, decim))) return fail(r, "resampler plan"); if (!fe.used && (r = first.alloc_edge(cfg.batch, pre != nullptr))) return fail(r, "resampler edge scratch"); }
     else {
         rs_Jp = ((int)rtaps.size() + interp - 1) / interp;
         if ((r = rs_taps.upload(resamp_layout(rtaps, interp, rs_Jp)))) return r;
@@ -714,6 +728,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
     // loops families: the rings the recursion reads hold two calls; call k - 2's recursion must be through before they are rewritten
     if (loops_family() && q_valid[slot]) HIPCHK(hipStreamWaitEvent(stream, ev_q[slot], 0));
     if (grouped && q_valid[slot ^ 1]) HIPCHK(hipStreamWaitEvent(stream, ev_q[slot ^ 1], 0));   // grouped order: this front end behind the recursion of the call before
+    if (pre_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_pre, 0)); pre_pending = false; }   // k_hist of the call before (helper stream)
     const float2* in = reinterpret_cast<const float2*>(iq);
     const float2* hist_old = hist_flip ? hist_b.p : hist_a.p;
     float2* hist_new = hist_flip ? hist_a.p : hist_b.p;
@@ -738,7 +753,8 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         p.out = r1; p.m0 = n1_0; p.m_count = (uint32_t)(n1_1 - n1_0);
         p.taps = fe.taps.p; p.D = fe.D; p.Jpad = fe.Jpad;
         p.rot_enable = 1; p.rot_acc = rot_acc; p.rot_inc = rot_inc; p.rot_nbase = rot_nbase; p.rot_lo = rot_lo.p;
-        if (fe.launch(p, B, stream)) return fail(QRL_ERR_HIP, "front-end launch: hipFuncSetAttribute failed");
+        if (pre) { p.pre_stream = pre; p.pre_event = ev_pre; }
+        if (fe.launch(p, B, stream, slot)) return fail(QRL_ERR_HIP, "front-end launch: hipFuncSetAttribute failed");
     }
     if (profiling && fe.used) { HIPCHK(hipEventRecord(ev1, stream)); prof_events.emplace_back(ev0, ev1); }
     // ---- stage B: per-mode resampler
@@ -760,7 +776,10 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
             f.port_cap = sd ? out->filtered_cap : 0;
             f.counts = counts;
             launch_dec2_fir(f, B, stream);
-        } else if (first.launch(p, B, stream)) return fail(QRL_ERR_HIP, "first-stage launch: hipFuncSetAttribute failed");
+        } else {
+            if (pre && !fe.used) { p.pre_stream = pre; p.pre_event = ev_pre; }   // (device rate 1 Msps: this stage is the one that reads the caller's IQ)
+            if (first.launch(p, B, stream, fe.used ? 0 : slot)) return fail(QRL_ERR_HIP, "first-stage launch: hipFuncSetAttribute failed");
+        }
     } else {
         ResampParams p{};
         if (fe.used) { p.in = nullptr; p.in_ring = r1; }
@@ -798,7 +817,14 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         h.in = in; h.in_stride = stride; h.n0 = n_in0; h.n = (uint32_t)n;
         h.hist_old = hist_old; h.hist_new = hist_new; h.hist_len = hist_len;
         h.rot_enable = 1; h.rot_acc = rot_acc; h.rot_inc = rot_inc; h.rot_nbase = rot_nbase; h.rot_lo = rot_lo.p;
-        launch_hist_save(h, B, stream);
+        if (pre) {
+            // everything of this call that reads the history on the handle's stream has been launched: the call after next overwrites it
+            HIPCHK(hipEventRecord(ev_fe[slot], stream)); fe_valid[slot] = true;
+            if (fe_valid[slot ^ 1]) HIPCHK(hipStreamWaitEvent(pre, ev_fe[slot ^ 1], 0));   // hist_new was the history of the call before
+            launch_hist_save(h, B, pre);
+            HIPCHK(hipEventRecord(ev_pre, pre));
+            pre_pending = true;
+        } else launch_hist_save(h, B, stream);
         hist_flip = !hist_flip;
     }
     if (overlap) {
@@ -1222,8 +1248,12 @@ int qrl_demod_create(qrl_ctx* ctx, const qrl_demod_config* cfg, qrl_demod** outp
         // destroyed before: tools/experiments/r04_subline_order*.py).  Queues of different priorities are never shared.
         int r1;
         if ((r1 = create_role_stream(&d->tail, hi, "TAIL")) || (r1 = create_role_stream(&d->fecs, lo, "FEC"))) return r1;
+        // the front end's helper stream: the handle's own stream only (a caller's stream may share its hardware queue with anything), normal priority
+        if (d->own_stream && !std::getenv("QRL_NO_PRE")) { if ((r1 = create_role_stream(&d->pre, 0, "PRE"))) return r1; }
     }
     HIPCHK(hipEventCreateWithFlags(&d->ev_ff, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&d->ev_pre, hipEventDisableTiming));
+    for (auto& e : d->ev_fe) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&d->ev_tail, hipEventDisableTiming));
     for (auto& e : d->ev_tail2) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : d->ev_q) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1260,6 +1290,7 @@ int qrl_demod_stream_wait(qrl_demod* d, void* hip_stream)
     HIPCHK(hipEventRecord(d->ev_user[0], d->stream));
     HIPCHK(hipEventRecord(d->ev_user[1], d->tail));
     HIPCHK(hipEventRecord(d->ev_user[2], d->fecs));
+    HIPCHK(hipEventRecord(d->ev_user[3], d->pre ? d->pre : d->stream));   // k_hist reads the caller's IQ on the helper stream
     for (auto e : d->ev_user) HIPCHK(hipStreamWaitEvent(user, e, 0));
     return QRL_OK;
 }

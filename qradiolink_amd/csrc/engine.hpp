@@ -51,6 +51,9 @@ struct DecimParams {
     // edge segment (outputs whose window starts in front of this call's buffer): per-stream scratch of ROTATED samples (carried
     // history + head of the buffer), one extra unit per stream behind the regular ones reads it with identity phasors
     float2* pl_edge; uint32_t pl_edge_stride, pl_edge_cap; uint64_t pl_edge_ms, pl_edge_me;
+    // host side only: when set, the edge scratch is staged on THIS stream (k_pl_edge_stage reads the caller's buffer and the carried history,
+    // nothing the call before produces on the launch stream), `pre_event` is recorded behind it and the launch stream waits for that
+    hipStream_t pre_stream; hipEvent_t pre_event;
 };
 struct HistParams {
     const float2* in; size_t in_stride; uint64_t n0; uint32_t n;

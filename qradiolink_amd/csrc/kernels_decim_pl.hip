@@ -836,7 +836,8 @@ int launch_decim_pl(const DecimParams& p, int batch, hipStream_t s)
         const int64_t i_last = (int64_t)(m_main - 1) * g.Dp;                   // last sample of the last edge block
         if (p.pl_edge && g.R == 1 && i_last - i0 + 1 <= (int64_t)p.pl_edge_cap) {
             const uint32_t len = (uint32_t)(i_last - i0 + 1);
-            hipLaunchKernelGGL(k_pl_edge_stage, dim3((len + 255) / 256, batch), dim3(256), 0, s, q, i0, len);
+            hipLaunchKernelGGL(k_pl_edge_stage, dim3((len + 255) / 256, batch), dim3(256), 0, p.pre_stream ? p.pre_stream : s, q, i0, len);
+            if (p.pre_stream) { (void)hipEventRecord(p.pre_event, p.pre_stream); (void)hipStreamWaitEvent(s, p.pre_event, 0); }
             q.pl_edge_ms = p.m0; q.pl_edge_me = m_main;
             edge_unit = true;
         } else {
@@ -1013,7 +1014,8 @@ int launch_decim_pm(const DecimParams& p, int batch, hipStream_t s)
         const int64_t i_last = (int64_t)(m_main - 1) * D;                  // last sample of the last edge output's newest block
         const int64_t len = ((i_last - i0 + 1) + 1) & ~(int64_t)1;
         if (len <= (int64_t)p.pl_edge_cap) {
-            hipLaunchKernelGGL(k_pl_edge_stage, dim3((uint32_t)((len + 255) / 256), batch), dim3(256), 0, s, q, i0, (uint32_t)len);
+            hipLaunchKernelGGL(k_pl_edge_stage, dim3((uint32_t)((len + 255) / 256), batch), dim3(256), 0, p.pre_stream ? p.pre_stream : s, q, i0, (uint32_t)len);
+            if (p.pre_stream) { (void)hipEventRecord(p.pre_event, p.pre_stream); (void)hipStreamWaitEvent(s, p.pre_event, 0); }
             q.pl_edge_ms = p.m0; q.pl_edge_me = m_main;
             edge_unit = true;
         } else gen(p.m0, m_main);

@@ -623,6 +623,41 @@ def test_decoder_on_noise_and_saturating_inputs(qrl_ctx, mode_name, modem, rate,
     _compare(iq, out, mode_name, rate, 1200.0)
 
 
+@pytest.mark.parametrize("mode_name,modem,rate", [("2fsk1k", 18, 1000000), ("gmsk10k", 22, 4000000), ("qpsk250k", 26, 10000000), ("gmsk10k", 22, 25000000)])
+def test_front_end_helper_stream_and_input_buffer_reuse(qrl_ctx, mode_name, modem, rate):
+    """Round 6: k_hist (the tail of a call's IQ kept for the next call) and k_pl_edge_stage (the next call's edge scratch) run on a helper
+    stream beside the front end when the handle owns its streams; a handle on a CALLER's stream keeps them in line.  Both orders give the
+    oracle's bits -- with every call's input in ONE device buffer that is overwritten as soon as qrl_demod_stream_wait lets the copy stream
+    go on (the helper kernels read the caller's buffer: the wait has to cover them), and no qrl_demod_sync between the calls."""
+    import torch
+    import qradiolink_amd as q
+    B = 6
+    offset = 25000.0 if rate >= 2000000 else 1200.0
+    iq = sig.make_batch(mode_name, B, nframes=2, device_rate=rate, rx_offset_hz=offset, seed=12)
+    chunk = 50000 * (rate // 1000000)
+    ncalls = iq.shape[1] // chunk
+    host = torch.from_numpy(iq[:, :ncalls * chunk].copy()).pin_memory()
+    refs = [_oracle(mode_name, iq[b, :ncalls * chunk], rate, offset)["bits_a"] for b in range(B)]
+    for own in (True, False):
+        user, copy = torch.cuda.Stream(), torch.cuda.Stream()
+        dem = q.Demod(qrl_ctx, modem, batch=B, max_chunk=chunk, device_samp_rate=rate, carrier_offset_hz=offset,
+                      stream=None if own else user.cuda_stream)
+        buf = torch.zeros((B, chunk), dtype=torch.complex64, device="cuda")
+        for k in range(ncalls):
+            with torch.cuda.stream(copy):
+                buf.copy_(host[:, k * chunk:(k + 1) * chunk], non_blocking=True)     # overwrites what call k - 1 read: behind its stream_wait
+            copy.synchronize()                     # (the host waits for the COPY only; the copy waited on the device for the handle's reads)
+            dem.process_async(buf)
+            dem.stream_wait(copy.cuda_stream)
+        dem.sync()
+        cnt, a = dem.counts.cpu().numpy(), dem.bits_a.cpu().numpy()
+        dem.close()
+        for b in range(B):
+            n_last = int(cnt[b, 2])
+            assert refs[b].size > 0 and n_last > 0
+            assert np.array_equal(a[b, :n_last], refs[b][-n_last:]), "own streams %s, stream %d" % (own, b)
+
+
 @pytest.mark.parametrize("mode_name,modem", [("2fsk1k", 18), ("2fsk1kfm", 16), ("gmsk10k", 22), ("qpsk250k", 26), ("bpsk2k", 0)])
 def test_pipelined_calls_without_sync(qrl_ctx, mode_name, modem):
     """Back-to-back qrl_demod_process calls with NO sync in between (how bench.py drives the handle; the 2FSK family then runs
