@@ -123,8 +123,13 @@ int qrl_demod_set_dmo_output(qrl_demod* d, uint8_t* frames, size_t cap_frames, u
  * only before the first sample of a stream.  QRL_OPT_GROUPED (gr_demod_qpsk chain; default: 1 when the batch gives the recursion kernel a
  * workgroup for at least every second CU, else 0): the order in which a call's three kernels are put on the device -- value 1: front
  * end of call k + 1 behind the recursion of call k, the decoder of call k - 1 launched with the recursion of call k (flushed by every
- * function that waits for results); value 0: three free-running streams. */
-enum { QRL_OPT_OVERLAP = 1, QRL_OPT_UNFUSED_DEC2 = 2, QRL_OPT_FLL_SLIM = 3 /* tuning: single-wave FLL workgroups */, QRL_OPT_GROUPED = 4 };
+ * function that waits for results); value 0: three free-running streams.  QRL_OPT_INPUT_RESIDENT (default 0; a handle that owns its
+ * streams): value 1 is the caller's promise that the IQ of every call is COMPLETE in device memory when qrl_demod_process is called -- not
+ * the product of work the caller has queued on qrl_demod_stream() and not yet waited for.  The two helper kernels of the front end
+ * (the history kept for the next call, the edge scratch of this one) then read it on a fourth internal stream beside the front end of the
+ * call before instead of in line with it; qrl_demod_sync / qrl_demod_stream_wait cover that stream too.  With value 0 everything that reads
+ * the caller's buffer is ordered behind the handle's stream, as qrl_demod_process documents. */
+enum { QRL_OPT_OVERLAP = 1, QRL_OPT_UNFUSED_DEC2 = 2, QRL_OPT_FLL_SLIM = 3 /* tuning: single-wave FLL workgroups */, QRL_OPT_GROUPED = 4, QRL_OPT_INPUT_RESIDENT = 5 };
 int qrl_demod_set_option(qrl_demod* d, int option, int value);
 int qrl_demod_out_caps(const qrl_demod* d, size_t n, size_t* filtered_cap, size_t* constellation_cap, size_t* bits_cap);
 /* analogue voice receivers (QRL_MODEM_NBFM2500 / NBFM5000 / AM5000 / WBFM / USB2500 / LSB2500; replace make_gr_demod_nbfm / _am /

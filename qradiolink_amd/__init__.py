@@ -25,7 +25,7 @@ MODEM_NBFM2500, MODEM_NBFM5000, MODEM_WBFM, MODEM_AM5000 = 8, 9, 10, 14
 MODEM_USB2500, MODEM_LSB2500, MODEM_CW600USB = 11, 12, 13
 MODEM_M17 = 40
 MODEM_DMR = 41
-OPT_OVERLAP, OPT_UNFUSED_DEC2, OPT_FLL_SLIM, OPT_GROUPED = 1, 2, 3, 4
+OPT_OVERLAP, OPT_UNFUSED_DEC2, OPT_FLL_SLIM, OPT_GROUPED, OPT_INPUT_RESIDENT = 1, 2, 3, 4, 5
 CHAN_OPT_LEGACY_PFB, CHAN_OPT_LEGACY_TAIL, CHAN_OPT_SERIAL_TAIL = 1, 2, 3
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECTANGULAR, WIN_BLACKMAN_HARRIS = 0, 1, 2, 3, 5
 
@@ -311,7 +311,7 @@ class Demod:
     (gr_demod_2fsk.cpp:19-37)."""
 
     def __init__(self, ctx, modem_type, batch, max_chunk, device_samp_rate=1000000, carrier_offset_hz=0.0,
-                 side_outputs=True, stream=None, time_domain_samp_rate=0, time_domain_filter_width=0.0, **explicit):
+                 side_outputs=True, stream=None, time_domain_samp_rate=0, time_domain_filter_width=0.0, input_resident=True, **explicit):
         import torch
         self.torch = torch
         self.ctx, self.lib = ctx, ctx.lib
@@ -341,6 +341,10 @@ class Demod:
         a = C.c_size_t()
         _check(self.lib.qrl_demod_audio_cap(self.h, max_chunk, C.byref(a)), "qrl_demod_audio_cap")
         self.audio_cap = a.value      # > 0 for the analogue voice receivers (port 1 = audio)
+        # process / process_async wait for the producer of iq on the host before they call the library, so the IQ of a call IS complete in
+        # device memory: QRL_OPT_INPUT_RESIDENT (the front end's helper kernels on their own stream) is on unless the caller says otherwise
+        if input_resident and stream is None:
+            _check(self.lib.qrl_demod_set_option(self.h, OPT_INPUT_RESIDENT, 1), "qrl_demod_set_option")
         self.new_outputs()
 
     def new_outputs(self):

@@ -203,7 +203,9 @@ struct qrl_demod {
     // launches on the handle's stream -- 0.2 - 0.29 ms of C1's 8 ms step (profiles/r06_c1_helper_stream.log).  On `pre` they run BESIDE the
     // front end: edge(k) behind hist(k - 1); hist(k) behind the front end of call k - 1 (the last reader of the history buffer it overwrites);
     // the front end of call k waits for ev_pre.  The history and the edge scratch are double buffers.
+    // Only with QRL_OPT_INPUT_RESIDENT: the helpers then read a call's IQ WITHOUT waiting for what the caller queued on the handle's stream before the call.
     hipStream_t pre = nullptr; hipEvent_t ev_pre = nullptr, ev_fe[2] = {nullptr, nullptr}; bool fe_valid[2] = {false, false}; bool pre_pending = false;
+    bool input_resident = false;
     hipEvent_t ev_user[4] = {nullptr, nullptr, nullptr, nullptr};   // qrl_demod_stream_wait
     bool tail_pending = false;
     // overlapped mode (2FSK / GMSK / 4FSK families): everything behind the first decimated ring runs on the tail stream while
@@ -443,7 +445,7 @@ int qrl_demod::build()
     if (cfg.device_samp_rate >= 2000000) {
         fe_decim = cfg.device_samp_rate / 1000000;
         if ((r = fe.plan(low_pass(1, cfg.device_samp_rate, 480000, 100000, WIN_BLACKMAN_HARRIS), fe_decim))) return fail(r, "front-end plan");
-        if ((r = fe.alloc_edge(cfg.batch, pre != nullptr))) return fail(r, "front-end edge scratch");
+        if ((r = fe.alloc_edge(cfg.batch))) return fail(r, "front-end edge scratch");
     }
     rot_inc = phase_inc_to_turn(2 * M_PI * -cfg.carrier_offset_hz / cfg.device_samp_rate);
     if ((r = upload_rot_table())) return r;
@@ -456,7 +458,7 @@ int qrl_demod::build()
         : fam == F_QPSK
         ? low_pass_2(interp, (double)interp * samp_rate, target / 2, target / 10, 60, WIN_BLACKMAN_HARRIS)   // gr_demod_qpsk.cpp:92-96
         : low_pass(interp, (double)interp * samp_rate, target / 2, target / 2, WIN_BLACKMAN_HARRIS);
-    if (interp == 1) { if ((r = first.plan(rtaps, decim))) return fail(r, "resampler plan"); if (!fe.used && (r = first.alloc_edge(cfg.batch, pre != nullptr))) return fail(r, "resampler edge scratch"); }
+    if (interp == 1) { if ((r = first.plan(rtaps, decim))) return fail(r, "resampler plan"); if (!fe.used && (r = first.alloc_edge(cfg.batch))) return fail(r, "resampler edge scratch"); }
     else {
         rs_Jp = ((int)rtaps.size() + interp - 1) / interp;
         if ((r = rs_taps.upload(resamp_layout(rtaps, interp, rs_Jp)))) return r;
@@ -729,6 +731,7 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
     if (loops_family() && q_valid[slot]) HIPCHK(hipStreamWaitEvent(stream, ev_q[slot], 0));
     if (grouped && q_valid[slot ^ 1]) HIPCHK(hipStreamWaitEvent(stream, ev_q[slot ^ 1], 0));   // grouped order: this front end behind the recursion of the call before
     if (pre_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_pre, 0)); pre_pending = false; }   // k_hist of the call before (helper stream)
+    const bool use_pre = pre && input_resident;
     const float2* in = reinterpret_cast<const float2*>(iq);
     const float2* hist_old = hist_flip ? hist_b.p : hist_a.p;
     float2* hist_new = hist_flip ? hist_a.p : hist_b.p;
@@ -753,8 +756,8 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         p.out = r1; p.m0 = n1_0; p.m_count = (uint32_t)(n1_1 - n1_0);
         p.taps = fe.taps.p; p.D = fe.D; p.Jpad = fe.Jpad;
         p.rot_enable = 1; p.rot_acc = rot_acc; p.rot_inc = rot_inc; p.rot_nbase = rot_nbase; p.rot_lo = rot_lo.p;
-        if (pre) { p.pre_stream = pre; p.pre_event = ev_pre; }
-        if (fe.launch(p, B, stream, slot)) return fail(QRL_ERR_HIP, "front-end launch: hipFuncSetAttribute failed");
+        if (use_pre) { p.pre_stream = pre; p.pre_event = ev_pre; }
+        if (fe.launch(p, B, stream, use_pre ? slot : 0)) return fail(QRL_ERR_HIP, "front-end launch: hipFuncSetAttribute failed");
     }
     if (profiling && fe.used) { HIPCHK(hipEventRecord(ev1, stream)); prof_events.emplace_back(ev0, ev1); }
     // ---- stage B: per-mode resampler
@@ -777,8 +780,8 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
             f.counts = counts;
             launch_dec2_fir(f, B, stream);
         } else {
-            if (pre && !fe.used) { p.pre_stream = pre; p.pre_event = ev_pre; }   // (device rate 1 Msps: this stage is the one that reads the caller's IQ)
-            if (first.launch(p, B, stream, fe.used ? 0 : slot)) return fail(QRL_ERR_HIP, "first-stage launch: hipFuncSetAttribute failed");
+            if (use_pre && !fe.used) { p.pre_stream = pre; p.pre_event = ev_pre; }   // (device rate 1 Msps: this stage is the one that reads the caller's IQ)
+            if (first.launch(p, B, stream, use_pre && !fe.used ? slot : 0)) return fail(QRL_ERR_HIP, "first-stage launch: hipFuncSetAttribute failed");
         }
     } else {
         ResampParams p{};
@@ -817,9 +820,8 @@ int qrl_demod::process(const float* iq, size_t stride, size_t n, const qrl_demod
         h.in = in; h.in_stride = stride; h.n0 = n_in0; h.n = (uint32_t)n;
         h.hist_old = hist_old; h.hist_new = hist_new; h.hist_len = hist_len;
         h.rot_enable = 1; h.rot_acc = rot_acc; h.rot_inc = rot_inc; h.rot_nbase = rot_nbase; h.rot_lo = rot_lo.p;
-        if (pre) {
-            // everything of this call that reads the history on the handle's stream has been launched: the call after next overwrites it
-            HIPCHK(hipEventRecord(ev_fe[slot], stream)); fe_valid[slot] = true;
+        if (pre) { HIPCHK(hipEventRecord(ev_fe[slot], stream)); fe_valid[slot] = true; }   // everything of this call that reads the history on the handle's stream has been launched
+        if (use_pre) {
             if (fe_valid[slot ^ 1]) HIPCHK(hipStreamWaitEvent(pre, ev_fe[slot ^ 1], 0));   // hist_new was the history of the call before
             launch_hist_save(h, B, pre);
             HIPCHK(hipEventRecord(ev_pre, pre));
@@ -1333,6 +1335,15 @@ int qrl_demod_set_option(qrl_demod* d, int option, int value)
         if (int rs = d->sync_all()) return rs;
         d->grouped = value != 0;
         return QRL_OK;
+    case QRL_OPT_INPUT_RESIDENT: {
+        if (int rs = d->sync_all()) return rs;
+        if (value != 0 && d->pre) {   // the second edge scratch of the stage that reads the caller's IQ (the helper stages a call ahead)
+            DecimStage& st = d->fe.used ? d->fe : d->first;
+            if (st.edge_len && !st.edge_b.p && st.edge_b.alloc((size_t)d->cfg.batch * st.edge_len)) return qrl_set_error(QRL_ERR_HIP, "edge scratch");
+        }
+        d->input_resident = value != 0;
+        return QRL_OK;
+    }
     case QRL_OPT_UNFUSED_DEC2:
         if (!d->d2f_capable) return qrl_set_error(QRL_ERR_ARG, "this chain has no fused 1:2 decimator + shaping filter");
         if (d->n_in != 0) return qrl_set_error(QRL_ERR_STATE, "QRL_OPT_UNFUSED_DEC2 can only be set before the first sample (the two forms carry different state)");

@@ -638,24 +638,39 @@ def test_front_end_helper_stream_and_input_buffer_reuse(qrl_ctx, mode_name, mode
     ncalls = iq.shape[1] // chunk
     host = torch.from_numpy(iq[:, :ncalls * chunk].copy()).pin_memory()
     refs = [_oracle(mode_name, iq[b, :ncalls * chunk], rate, offset)["bits_a"] for b in range(B)]
-    for own in (True, False):
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    for order in ("resident", "inline", "caller"):
+        # resident: QRL_OPT_INPUT_RESIDENT = 1, the copy is complete before the call.  inline: the option off and the upload QUEUED ON THE
+        # HANDLE'S STREAM right before the call, not waited for (qrl_host::gr_demod_base_hip::work does that) -- everything that reads the
+        # buffer has to sit behind the handle's stream.  caller: the handle on a stream of the caller's.
         user, copy = torch.cuda.Stream(), torch.cuda.Stream()
         dem = q.Demod(qrl_ctx, modem, batch=B, max_chunk=chunk, device_samp_rate=rate, carrier_offset_hz=offset,
-                      stream=None if own else user.cuda_stream)
+                      stream=user.cuda_stream if order == "caller" else None, input_resident=order == "resident")
         buf = torch.zeros((B, chunk), dtype=torch.complex64, device="cuda")
+        nbytes = B * chunk * 8
         for k in range(ncalls):
-            with torch.cuda.stream(copy):
-                buf.copy_(host[:, k * chunk:(k + 1) * chunk], non_blocking=True)     # overwrites what call k - 1 read: behind its stream_wait
-            copy.synchronize()                     # (the host waits for the COPY only; the copy waited on the device for the handle's reads)
+            src = host[:, k * chunk:(k + 1) * chunk].contiguous().pin_memory()
+            if order == "inline":
+                # behind the reads of call k - 1 (the handle's stream waits for the copy stream, which waited for the handle), then the upload on the handle's stream
+                ev = torch.cuda.Event(); ev.record(copy)
+                assert hip.hipStreamWaitEvent(ctypes.c_void_p(dem.stream), ctypes.c_void_p(ev.cuda_event), 0) == 0
+                assert hip.hipMemcpyAsync(ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(src.data_ptr()), ctypes.c_size_t(nbytes), 1, ctypes.c_void_p(dem.stream)) == 0
+            else:
+                with torch.cuda.stream(copy):
+                    buf.copy_(src, non_blocking=True)          # overwrites what call k - 1 read: behind its stream_wait
+                copy.synchronize()                             # (the host waits for the COPY only; the copy waited on the device for the handle's reads)
             dem.process_async(buf)
             dem.stream_wait(copy.cuda_stream)
+            if order == "inline":
+                torch.cuda.synchronize()                       # `src` (a fresh pinned staging tensor per call) must outlive the upload
         dem.sync()
         cnt, a = dem.counts.cpu().numpy(), dem.bits_a.cpu().numpy()
         dem.close()
         for b in range(B):
             n_last = int(cnt[b, 2])
             assert refs[b].size > 0 and n_last > 0
-            assert np.array_equal(a[b, :n_last], refs[b][-n_last:]), "own streams %s, stream %d" % (own, b)
+            assert np.array_equal(a[b, :n_last], refs[b][-n_last:]), "order %s, stream %d" % (order, b)
 
 
 @pytest.mark.parametrize("mode_name,modem", [("2fsk1k", 18), ("2fsk1kfm", 16), ("gmsk10k", 22), ("qpsk250k", 26), ("bpsk2k", 0)])
