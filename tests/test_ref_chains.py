@@ -683,6 +683,8 @@ def test_fixture_is_fresh():
     import json
     with open(FIXTURE) as f:
         fx = json.load(f)
+    if os.environ.get("PYTEST_XDIST_WORKER") and len(_seen) < 50:
+        pytest.skip("pytest-xdist spread this file's tests over several workers: the freshness check needs them all in one process")
     for key, (kind, args) in sorted(_seen.items()):
         assert fx.get(key) == ref_log(kind, *args), "stale tests/golden/ref/chains.json (%s): run tools/make_chain_golden.py" % key
     assert len(_seen) >= 50
