@@ -708,8 +708,21 @@ def cpu_baseline(name, cores, budget_s=8.0):
                slowest_block_share=round(slow[1] / sum(t for _, t in bt), 3),
                note="one stream, thread-per-block pipeline bound = samples / run time of the slowest block (measured per block, "
                     "single thread each); x streams when cores >= blocks x streams")
+    # ... and EMULATED (round 6; C1's chain at 1 Msps only): one thread per block of the 2FSK receiver, bounded queues in between, whole
+    # streams as the items that flow (oracle/orc_pipeline.c).  Its checksum has to equal the plain chain's.
+    tpe = None
+    if name == "c1":
+        ns = max(12, min(64, int(budget_s / 4 * tpb["value"] * 1e6 / per)))
+        iq = np.stack([np.roll(base, 977 * b) for b in range(ns)]).astype(np.complex64)
+        orc.lib.orc_set_decim_impl(1)
+        secs, chk, busy = orc.pipeline_rx_2fsk1k(iq, offset)
+        _, chk_ref = orc.batch_rx(omode, iq, rate, offset, cores)
+        orc.lib.orc_set_decim_impl(0)
+        tpe = dict(value=round(ns * per / secs / 1e6, 3), unit="MS/s", threads=len(busy) + 2, streams=ns, checksum_equals_chain=bool(chk == chk_ref),
+                   busiest_stage_share=round(max(busy) / secs, 3),
+                   note="%d streams of %d samples through 11 block threads + source + sink (%.1f s): one flowgraph's rate; a host runs cores / threads of them side by side" % (ns, per, secs))
     return dict(value=round(v_all, 3), unit="MS/s", cores=cores, kind="port",
-                single_thread=round(v_one, 3), scalar_port=round(v_port, 3), thread_per_block_model=tpb,
+                single_thread=round(v_one, 3), scalar_port=round(v_port, 3), thread_per_block_model=tpb, thread_per_block_emulated=tpe,
                 sample="%d passes over %d streams x %d samples of the %s workload (%.1f s of CPU wall time); oracle/liborc.so "
                        "(C, -O3 -mavx2 -mfma, OpenMP over streams) with the decimating FIRs as AVX2 dot products "
                        "(orc_decim_fir_ccf_simd); GNU Radio / VOLK itself is not installable here"

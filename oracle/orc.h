@@ -276,4 +276,8 @@ void orc_trace_event(const char* fmt, ...);
 void orc_trace_taps(const void* taps, size_t bytes, const char* fmt, ...);
 const char* orc_trace_name(const void* taps, size_t bytes);
 
+/* orc_pipeline.c: SURVEY 8(d) CPU baseline variant (ii), the thread-per-block scheduler EMULATED -- one thread per block of the 2FSK-1k
+ * receiver at 1 Msps, bounded queues in between; returns wall seconds, the checksum orc_batch_rx gives for the same input, busy[11] */
+double orc_pipeline_rx_2fsk1k(const cf32* iq, int batch, size_t n, double carrier_offset_hz, uint64_t* bit_checksum, double* busy, int* nstages);
+
 #endif

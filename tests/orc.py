@@ -721,6 +721,20 @@ def batch_rx(mode, iq, samp_rate, carrier_offset_hz=0.0, threads=0):
     return t, chk.value
 
 
+_sig("orc_pipeline_rx_2fsk1k", C.c_double, _p, C.c_int, C.c_size_t, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_int))
+
+
+def pipeline_rx_2fsk1k(iq, carrier_offset_hz=0.0):
+    """SURVEY 8(d) CPU baseline (ii) emulated: [batch, n] streams at 1 Msps through a thread-per-block pipeline of the 2FSK-1k receiver
+    (oracle/orc_pipeline.c).  Returns (wall seconds, checksum as batch_rx gives it, [seconds every stage worked])."""
+    iq = np.ascontiguousarray(iq, cf32)
+    batch, n = iq.shape
+    chk, ns = C.c_uint64(), C.c_int()
+    busy = (C.c_double * 16)()
+    t = lib.orc_pipeline_rx_2fsk1k(_ptr(iq), batch, n, float(carrier_offset_hz), C.byref(chk), busy, C.byref(ns))
+    return t, chk.value, [busy[k] for k in range(ns.value)]
+
+
 _sig("orc_block_timing_enable", None, C.c_int)
 _sig("orc_block_timing_count", C.c_int)
 _sig("orc_block_timing_get", C.c_double, C.c_int, C.c_char_p, C.c_size_t)
