@@ -7,6 +7,7 @@
 //   k_disc_2fsk  2x fft_filter_ccc + complex_to_mag + divide + rail(0,2) + add(-1) (gr_demod_2fsk.cpp:94-102,140-149)
 #include "devmath.hpp"
 #include "engine.hpp"
+#include <cstdlib>
 
 namespace qrl {
 
@@ -245,13 +246,17 @@ void launch_disc_2fsk(const Disc2fskParams& p, int batch, hipStream_t s)
 constexpr int FF_PL = 280, FF_PF = 264, FF_PD = 264;   // row pitches (words); 8-byte rows: pitch = 8 or 24 (mod 32)
 
 // acc[r] += sum_k taps[k] * tile[4 t + r + 4 A - k], k = 0 .. 4 nq - 1, fmaf chain k ascending (CPLX: complex taps)
-template <int PITCH, typename TapT, typename ItemT, typename Fma>
-__device__ __forceinline__ void ff_window4(const ItemT* __restrict__ tile, int w, int nq, const TapT* __restrict__ taps, Fma&& fma4)
+// NQ > 0: the number of tap quads is a compile-time constant and the loop is unrolled by four -- the (wave-uniform, scalar) tap loads of four
+// quads are issued together, one wait per sixteen taps; NQ = 0: run-time count, one scalar load and one wait per quad.  The scalar loads share
+// their counter with the LDS reads, so they cannot be prefetched across a quad's LDS wait: at C1's geometry (41 + 41 + 25 taps) the per-quad
+// form waits 29 times per thread, 1 011 us alone against 855 (a complete unroll: 914 us and 105 VGPRs).  profiles/r06_c1_helper_stream.log
+template <int PITCH, int NQ, typename TapT, typename ItemT, typename Fma>
+__device__ __forceinline__ void ff_window4(const ItemT* __restrict__ tile, int w, int nq_rt, const TapT* __restrict__ taps, Fma&& fma4)
 {
     ItemT cur[4], nxt[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) cur[s] = tile[s * PITCH + w];
-    for (int q = 0; q < nq; ++q) {
+    auto quad = [&](int q) {
         --w;
 #pragma unroll
         for (int s = 0; s < 4; ++s) nxt[s] = tile[s * PITCH + w];   // word w - 1: subs 1..3 are this step's u < 0 samples
@@ -262,9 +267,16 @@ __device__ __forceinline__ void ff_window4(const ItemT* __restrict__ tile, int w
         fma4(h3, nxt[1], nxt[2], nxt[3], cur[0]);     // e = 3: u = r - 3
 #pragma unroll
         for (int s = 0; s < 4; ++s) cur[s] = nxt[s];
+    };
+    if constexpr (NQ > 0) {
+#pragma unroll 4
+        for (int q = 0; q < NQ; ++q) quad(q);
+    } else {
+        for (int q = 0; q < nq_rt; ++q) quad(q);
     }
 }
 
+template <int NQF, int NQB, int NQS>   // tap quads of the three filters ((padded taps - 1) / 4 + 1), or 0, 0, 0 = run-time counts
 __global__ __launch_bounds__(256) void k_2fsk_ff(const Fsk2FfParams P)
 {
     __shared__ float2 lt[4 * FF_PL];   // FLL output, item i <-> abs n0t - (hf + hb + hs) + i
@@ -293,7 +305,7 @@ __global__ __launch_bounds__(256) void k_2fsk_ff(const Fsk2FfParams P)
     __syncthreads();
     {   // stage 1: f[j] = sum tf[k] l[j + hf - k], j = 4 tid + r
         float2 a[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-        ff_window4<FF_PL>(lt, tid + (hf >> 2) + 1, (hf >> 2) + 1, P.tf,
+        ff_window4<FF_PL, NQF>(lt, tid + (hf >> 2) + 1, (hf >> 2) + 1, P.tf,
                           [&](float h, const float2& x0, const float2& x1, const float2& x2, const float2& x3) {
                               a[0].x = fmaf(h, x0.x, a[0].x); a[0].y = fmaf(h, x0.y, a[0].y);
                               a[1].x = fmaf(h, x1.x, a[1].x); a[1].y = fmaf(h, x1.y, a[1].y);
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(256) void k_2fsk_ff(const Fsk2FfParams P)
     if (4 * tid < nd) {   // stage 2: u/l[j] = sum up/lo[k] f[j + hb - k]; d = rail(|u| / |l|) - 1
         // conjugate tap pair (see k_disc_2fsk): A = sum a x, B = sum b x with the real and imaginary parts of the UPPER filter's taps
         float ar[4] = {0.f, 0.f, 0.f, 0.f}, ai[4] = {0.f, 0.f, 0.f, 0.f}, br[4] = {0.f, 0.f, 0.f, 0.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
-        const int nq = (hb >> 2) + 1;
+        const int nq = NQB > 0 ? NQB : (hb >> 2) + 1;
         int w = tid + (hb >> 2) + 1;
         float2 cur[4], nxt[4];
 #pragma unroll
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(256) void k_2fsk_ff(const Fsk2FfParams P)
                 br[r] = fmaf(h.y, xs[r].x, br[r]); bi[r] = fmaf(h.y, xs[r].y, bi[r]);
             }
         };
-        for (int q = 0; q < nq; ++q) {
+        auto quad = [&](int q) {
             --w;
 #pragma unroll
             for (int s = 0; s < 4; ++s) nxt[s] = ft[s * FF_PF + w];
@@ -333,6 +345,12 @@ __global__ __launch_bounds__(256) void k_2fsk_ff(const Fsk2FfParams P)
             step(P.up[4 * q + 3], nxt[1], nxt[2], nxt[3], cur[0]);
 #pragma unroll
             for (int s = 0; s < 4; ++s) cur[s] = nxt[s];
+        };
+        if constexpr (NQB > 0) {
+#pragma unroll 4
+            for (int q = 0; q < NQB; ++q) quad(q);
+        } else {
+            for (int q = 0; q < nq; ++q) quad(q);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -348,7 +366,7 @@ __global__ __launch_bounds__(256) void k_2fsk_ff(const Fsk2FfParams P)
     __syncthreads();
     if (4 * tid < T) {   // stage 3: y[o] = sum ts[k] d[o + hs - k]
         float a[4] = {0.f, 0.f, 0.f, 0.f};
-        ff_window4<FF_PD>(dt, tid + (hs >> 2) + 1, (hs >> 2) + 1, P.ts,
+        ff_window4<FF_PD, NQS>(dt, tid + (hs >> 2) + 1, (hs >> 2) + 1, P.ts,
                           [&](float h, float x0, float x1, float x2, float x3) {
                               a[0] = fmaf(h, x0, a[0]); a[1] = fmaf(h, x1, a[1]); a[2] = fmaf(h, x2, a[2]); a[3] = fmaf(h, x3, a[3]);
                           });
@@ -372,7 +390,12 @@ void launch_2fsk_ff(const Fsk2FfParams& p, int batch, hipStream_t s)
 {
     if (!p.count) return;
     const int T = 1024 - (p.nb - 1) - (p.ns - 1);
-    hipLaunchKernelGGL(k_2fsk_ff, dim3((p.count + T - 1) / T, batch), dim3(256), 0, s, p);
+    const dim3 grid((p.count + T - 1) / T, batch);
+    // gr_demod_2fsk's designs at sps = 10 / 5 (2FSK-1k, -2k: 41 + 41 + 25 taps at 20 / 40 ksps) and at sps = 1 (10k: 80 ksps) are the instantiations
+    static const bool rt = [] { const char* e = getenv("QRL_FF_RUNTIME_TAPS"); return e && atoi(e) != 0; }();
+    const int qf = (p.nf - 1) / 4 + 1, qb = (p.nb - 1) / 4 + 1, qs = (p.ns - 1) / 4 + 1;
+    if (!rt && qf == 11 && qb == 11 && qs == 7) hipLaunchKernelGGL((k_2fsk_ff<11, 11, 7>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_2fsk_ff<0, 0, 0>), grid, dim3(256), 0, s, p);
 }
 
 }  // namespace qrl
