@@ -623,6 +623,28 @@ def test_decoder_on_noise_and_saturating_inputs(qrl_ctx, mode_name, modem, rate,
     _compare(iq, out, mode_name, rate, 1200.0)
 
 
+@pytest.mark.parametrize("fw", [3000, 1500])
+@pytest.mark.parametrize("chunk", [1 << 21, 70000])
+def test_2fsk_explicit_filter_width_runs_the_run_time_tap_loop(qrl_ctx, fw, chunk):
+    """gr_demod_2fsk with a filter width other than the modes' own (explicit configuration: qrl_demod_config.use_mode_defaults = 0): other tap
+    counts than 41 + 41 + 25, so k_2fsk_ff takes its run-time tap loop instead of the <11, 11, 7> instantiation (3000 Hz: shorter filters;
+    1500 Hz: 53-tap filters, the unfused kernels) -- bit-exact against the oracle chain with the same width."""
+    import torch
+    import qradiolink_amd as q
+    iq = sig.make_batch("2fsk1k", 3, nframes=2, device_rate=1000000, rx_offset_hz=1200.0, seed=17, impair=sig.SPEC)
+    dem = q.Demod(qrl_ctx, 18, batch=3, max_chunk=chunk, device_samp_rate=1000000, carrier_offset_hz=1200.0, sps=10, filter_width=fw)
+    out = q.collect(dem, torch.from_numpy(iq).cuda(), chunk)
+    dem.close()
+    for b in range(3):
+        ref = orc.demod_2fsk(orc.frontend(iq[b], 1000000, 1200.0), sps=10, filter_width=fw, fm=False)
+        assert ref["bits_a"].size > 0
+        for port in ("bits_a", "bits_b"):
+            assert np.array_equal(out[port][b], ref[port]), (port, b)
+        for port in ("filtered", "constellation"):
+            got, want = out[port][b].view(np.float32) + np.float32(0), ref[port].view(np.float32) + np.float32(0)
+            assert got.size == want.size and np.array_equal(got.view(np.uint32), want.view(np.uint32)), (port, b)
+
+
 @pytest.mark.parametrize("mode_name,modem,rate", [("2fsk1k", 18, 1000000), ("gmsk10k", 22, 4000000), ("qpsk250k", 26, 10000000), ("gmsk10k", 22, 25000000)])
 def test_front_end_helper_stream_and_input_buffer_reuse(qrl_ctx, mode_name, modem, rate):
     """Round 6: k_hist (the tail of a call's IQ kept for the next call) and k_pl_edge_stage (the next call's edge scratch) run on a helper
